@@ -1,0 +1,106 @@
+"""Test-infrastructure helpers (oracle side only; never imported by the product).
+
+* synth_image(seed): the SURVEY.md section 8d integer generator ("smooth+noise" class), numpy/pure-Python.
+* RefEncoder: ctypes binding of oracle/_ref/libnhwref_enc.so = the UNMODIFIED reference encoder
+  (/root/reference/encoder/*.c) linked with oracle/ref/ref_shim.c (canonical zero-guard allocator +
+  --wrap checkpoints).  Built by `make -C oracle/ref`; prebuilt .so travels to the GPU box.
+"""
+import ctypes
+import os
+import struct
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SO = os.path.join(HERE, "_ref", "libnhwref_enc.so")
+IMG_BYTES = 512 * 512 * 3
+
+
+def synth_image(seed: int) -> np.ndarray:
+    """SURVEY.md section 8d generator. Returns uint8[512,512,3] in BMP file order (rows as stored, B,G,R)."""
+    x = (0x9E3779B9 * (seed + 1)) & 0xFFFFFFFF
+    if x == 0:
+        x = 1
+    n = 17 * 17 * 3 + IMG_BYTES
+    out = np.empty(n, dtype=np.uint32)
+    # xorshift32 is strictly sequential; plain loop (about 1 s / image). Tests cache results.
+    for i in range(n):
+        x ^= (x << 13) & 0xFFFFFFFF
+        x ^= x >> 17
+        x ^= (x << 5) & 0xFFFFFFFF
+        out[i] = x
+    lat = (out[: 17 * 17 * 3] >> 24).astype(np.int64).reshape(17, 17, 3)
+    noise = (out[17 * 17 * 3 :] % 13).astype(np.int64).reshape(512, 512, 3) - 6
+    ys = np.arange(512)
+    gy = ys >> 5
+    wy = ((ys & 31) << 3)[:, None, None]
+    gx = ys >> 5
+    wx = ((ys & 31) << 3)[None, :, None]
+    l00 = lat[gy][:, gx]
+    l01 = lat[gy][:, gx + 1]
+    l10 = lat[gy + 1][:, gx]
+    l11 = lat[gy + 1][:, gx + 1]
+    v = ((l00 * (256 - wx) + l01 * wx) * (256 - wy) + (l10 * (256 - wx) + l11 * wx) * wy + 32768) >> 16
+    return np.clip(v + noise, 0, 255).astype(np.uint8)
+
+
+def bmp_bytes(img: np.ndarray) -> bytes:
+    """54-byte BITMAPINFOHEADER + pixel rows in file order, height +512."""
+    hdr = struct.pack("<2sIHHIIiiHHIIiiII", b"BM", 54 + IMG_BYTES, 0, 0, 54, 40, 512, 512, 1, 24, 0, IMG_BYTES, 0, 0, 0, 0)
+    return hdr + img.tobytes()
+
+
+def parse_trace(buf: bytes, count: int):
+    """-> list of (name, [blob bytes, ...]) in call order."""
+    out, off = [], 0
+    for _ in range(count):
+        name = buf[off : off + 32].split(b"\0", 1)[0].decode()
+        nblobs, *lens = struct.unpack_from("<6I", buf, off + 32)
+        off += 32 + 24
+        blobs = []
+        for i in range(nblobs):
+            blobs.append(bytes(buf[off : off + lens[i]]))
+            off += lens[i]
+        out.append((name, blobs))
+    return out
+
+
+class RefEncoder:
+    def __init__(self, so_path: str = REF_SO):
+        self.lib = ctypes.CDLL(so_path)
+        self.lib.nhwref_encode.restype = ctypes.c_int
+        self.lib.nhwref_encode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        self.lib.nhwref_trace_begin.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        self.lib.nhwref_trace_end.restype = ctypes.c_size_t
+        self.lib.nhwref_trace_end.argtypes = [ctypes.POINTER(ctypes.c_int)]
+        self.lib.nhwref_encode_file.restype = ctypes.c_int
+        self.lib.nhwref_encode_file.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+        fd, self.tmp = tempfile.mkstemp(suffix=".nhw")
+        os.close(fd)
+        self._out = ctypes.create_string_buffer(1 << 20)
+
+    def __del__(self):
+        try:
+            os.unlink(self.tmp)
+        except OSError:
+            pass
+
+    def encode(self, img: np.ndarray, quality: int, trace: bool = False):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        assert img.size == IMG_BYTES
+        tbuf = None
+        if trace:
+            tbuf = ctypes.create_string_buffer(96 << 20)
+            self.lib.nhwref_trace_begin(tbuf, len(tbuf))
+        n = ctypes.c_size_t(0)
+        rc = self.lib.nhwref_encode(img.ctypes.data, quality, self.tmp.encode(), self._out, len(self._out), ctypes.byref(n))
+        tr = None
+        if trace:
+            cnt = ctypes.c_int(0)
+            tl = self.lib.nhwref_trace_end(ctypes.byref(cnt))
+            tr = parse_trace(tbuf.raw[:tl], cnt.value)
+        if rc != 0:
+            raise RuntimeError(f"reference encoder failed rc={rc}")
+        data = self._out.raw[: n.value]
+        return (data, tr) if trace else data

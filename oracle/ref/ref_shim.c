@@ -1,0 +1,307 @@
+/*
+ * ref_shim.c -- TEST INFRASTRUCTURE ONLY (oracle/_ref).
+ *
+ * Links against the UNMODIFIED reference encoder sources where they lie under
+ * /root/reference/encoder (never copied into this repo) and gives them
+ *   1. the "canonical" allocation model of SURVEY.md section 0 fact 4 / App. F:
+ *      every malloc/calloc is zero-filled and sits between two 4 KiB zero guards, so
+ *      every out-of-bounds or never-written read of the reference returns 0
+ *      (deterministic output; this is the parity target "OOB = ZERO");
+ *   2. an in-memory entry point (BGR24 buffer in, .nhw bytes out) that mirrors
+ *      read_image_bmp (nhw_encoder.c:3047-3098) + main (nhw_encoder_cli.c:175-183);
+ *   3. link-time --wrap checkpoints around every cross-TU call made by encode_image
+ *      (SURVEY.md section 3.2), dumping im_jpeg / im_process so a mismatch in a restatement
+ *      can be localised to one stage without editing the reference;
+ *   4. exit() interception (compress_pixel.c:234,270,271) -> status code.
+ *
+ * Nothing in the product (nhwcodec_amd/, include/) may link or load this.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <setjmp.h>
+#include "codec.h" /* the reference's own header, via -I/root/reference/encoder */
+
+/* ---------------------------------------------------------------- guard allocator */
+#define GUARD 4096
+#define MAX_LIVE 8192
+extern void *__real_calloc(size_t, size_t);
+extern void __real_free(void *);
+static void *g_live[MAX_LIVE];
+static int g_nlive = 0;
+static int g_track = 0;
+
+static void *guard_alloc(size_t n)
+{
+	unsigned char *p = (unsigned char *)__real_calloc(1, n + 2 * GUARD);
+	if (!p) return NULL;
+	p += GUARD;
+	if (g_track && g_nlive < MAX_LIVE) g_live[g_nlive++] = p;
+	return p;
+}
+void *__wrap_malloc(size_t n) { return guard_alloc(n); }
+void *__wrap_calloc(size_t a, size_t b) { return guard_alloc(a * b); }
+void __wrap_free(void *p)
+{
+	int i;
+	if (!p) return;
+	for (i = g_nlive - 1; i >= 0; i--)
+		if (g_live[i] == p) { g_live[i] = g_live[--g_nlive]; break; }
+	__real_free((unsigned char *)p - GUARD);
+}
+static void release_leftovers(void)
+{
+	while (g_nlive > 0) __real_free((unsigned char *)g_live[--g_nlive] - GUARD);
+}
+
+/* ---------------------------------------------------------------- exit() capture */
+static jmp_buf g_jmp;
+static int g_in_call = 0;
+extern void __real_exit(int);
+void __wrap_exit(int code)
+{
+	if (g_in_call) longjmp(g_jmp, code ? code : 1000);
+	__real_exit(code);
+}
+
+/* ---------------------------------------------------------------- trace arena */
+typedef struct {
+	char name[32];
+	uint32_t nblobs;
+	uint32_t len[5]; /* bytes */
+} trace_hdr;
+static uint8_t *g_tbuf = NULL;
+static size_t g_tcap = 0, g_tlen = 0;
+static int g_tcount = 0;
+
+void nhwref_trace_begin(uint8_t *buf, size_t cap) { g_tbuf = buf; g_tcap = cap; g_tlen = 0; g_tcount = 0; }
+size_t nhwref_trace_end(int *count) { if (count) *count = g_tcount; g_tbuf = NULL; return g_tlen; }
+
+static void trace_put(const char *name, int nblobs, const void **blobs, const uint32_t *lens)
+{
+	trace_hdr h;
+	size_t need = sizeof h;
+	int i;
+	if (!g_tbuf) return;
+	memset(&h, 0, sizeof h);
+	strncpy(h.name, name, sizeof h.name - 1);
+	h.nblobs = nblobs;
+	for (i = 0; i < nblobs; i++) { h.len[i] = lens[i]; need += lens[i]; }
+	if (g_tlen + need > g_tcap) return;
+	memcpy(g_tbuf + g_tlen, &h, sizeof h); g_tlen += sizeof h;
+	for (i = 0; i < nblobs; i++) { memcpy(g_tbuf + g_tlen, blobs[i], lens[i]); g_tlen += lens[i]; }
+	g_tcount++;
+}
+static void trace2(const char *name, const void *a, uint32_t la, const void *b, uint32_t lb)
+{
+	const void *bl[2]; uint32_t ln[2]; int n = 0;
+	if (a) { bl[n] = a; ln[n++] = la; }
+	if (b) { bl[n] = b; ln[n++] = lb; }
+	trace_put(name, n, bl, ln);
+}
+
+/* phase tracking: which planes are live and how large they are */
+static int g_chroma = 0;     /* 0 = luma phase (planes 4*IM_SIZE shorts), 1 = chroma (IM_SIZE shorts) */
+static int g_jpeg_live = 1;  /* im_jpeg is freed in the middle of encode_image */
+#define PLANE_BYTES() ((uint32_t)((g_chroma ? IM_SIZE : 4 * IM_SIZE) * sizeof(short)))
+
+/* ---------------------------------------------------------------- --wrap checkpoints */
+extern void __real_downsample_YUV420(image_buffer *, int);
+void __wrap_downsample_YUV420(image_buffer *im, int rate)
+{
+	const void *bl[3]; uint32_t ln[3];
+	__real_downsample_YUV420(im, rate);
+	bl[0] = im->im_jpeg; ln[0] = 4 * IM_SIZE * sizeof(short);
+	bl[1] = im->im_bufferU; ln[1] = IM_SIZE;
+	bl[2] = im->im_bufferV; ln[2] = IM_SIZE;
+	trace_put("downsample_YUV420", 3, bl, ln);
+}
+extern void __real_pre_processing(image_buffer *);
+void __wrap_pre_processing(image_buffer *im)
+{
+	__real_pre_processing(im);
+	trace2("pre_processing", im->im_jpeg, PLANE_BYTES(), NULL, 0);
+}
+extern void __real_pre_processing_UV(image_buffer *);
+void __wrap_pre_processing_UV(image_buffer *im)
+{
+	g_chroma = 1; g_jpeg_live = 1;
+	__real_pre_processing_UV(im);
+	trace2("pre_processing_UV", im->im_jpeg, PLANE_BYTES(), NULL, 0);
+}
+extern void __real_wavelet_analysis(image_buffer *, int, int, int);
+void __wrap_wavelet_analysis(image_buffer *im, int norder, int last_stage, int Y)
+{
+	char nm[32];
+	g_chroma = !Y; g_jpeg_live = 1;
+	__real_wavelet_analysis(im, norder, last_stage, Y);
+	snprintf(nm, sizeof nm, "wavelet_analysis_%d", norder);
+	trace2(nm, im->im_jpeg, PLANE_BYTES(), im->im_process, PLANE_BYTES());
+}
+extern void __real_wavelet_synthesis(image_buffer *, int, int, int);
+void __wrap_wavelet_synthesis(image_buffer *im, int norder, int last_stage, int Y)
+{
+	char nm[32];
+	__real_wavelet_synthesis(im, norder, last_stage, Y);
+	snprintf(nm, sizeof nm, "wavelet_synthesis_%d", norder);
+	trace2(nm, im->im_jpeg, PLANE_BYTES(), im->im_process, PLANE_BYTES());
+}
+extern void __real_offsetY_recons256(image_buffer *, encode_state *, int, int);
+void __wrap_offsetY_recons256(image_buffer *im, encode_state *enc, int m1, int part)
+{
+	__real_offsetY_recons256(im, enc, m1, part);
+	trace2(part ? "offsetY_recons256_p1" : "offsetY_recons256_p0", im->im_jpeg, PLANE_BYTES(), im->im_process, PLANE_BYTES());
+}
+extern void __real_offsetUV_recons256(image_buffer *, int, int);
+void __wrap_offsetUV_recons256(image_buffer *im, int m1, int comp)
+{
+	__real_offsetUV_recons256(im, m1, comp);
+	trace2(comp ? "offsetUV_recons256_c1" : "offsetUV_recons256_c0", im->im_jpeg, PLANE_BYTES(), im->im_process, PLANE_BYTES());
+}
+extern void __real_Y_highres_compression(image_buffer *, encode_state *);
+void __wrap_Y_highres_compression(image_buffer *im, encode_state *enc)
+{
+	const void *bl[5]; uint32_t ln[5]; unsigned char rl;
+	/* inputs of the LL coder = outputs of the inline LL2 emission pass (nhw_encoder.c:661-741) */
+	bl[0] = enc->tree1; ln[0] = IM_SIZE >> 2;
+	bl[1] = enc->ch_res; ln[1] = IM_SIZE >> 2;
+	bl[2] = enc->exw_Y; ln[2] = enc->exw_Y_end;
+	trace_put("LL2_emit_Y", 3, bl, ln);
+	__real_Y_highres_compression(im, enc);
+	rl = im->setup->RES_LOW;
+	bl[0] = enc->highres_comp; ln[0] = enc->Y_res_comp;
+	bl[1] = enc->highres_word; ln[1] = enc->highres_comp_len;
+	bl[2] = enc->highres_mem; ln[2] = enc->highres_mem_len * sizeof(short);
+	bl[3] = &rl; ln[3] = 1;
+	trace_put("Y_highres_compression", 4, bl, ln);
+}
+extern void __real_offsetY(image_buffer *, int);
+void __wrap_offsetY(image_buffer *im, int m1)
+{
+	g_jpeg_live = 0; /* im_jpeg was freed at nhw_encoder.c:780 */
+	trace2("pre_offsetY", NULL, 0, im->im_process, PLANE_BYTES());
+	__real_offsetY(im, m1);
+	trace2("offsetY", NULL, 0, im->im_process, PLANE_BYTES());
+}
+extern void __real_offsetUV(image_buffer *, int);
+void __wrap_offsetUV(image_buffer *im, int m2)
+{
+	trace2("pre_offsetUV", NULL, 0, im->im_process, PLANE_BYTES());
+	__real_offsetUV(im, m2);
+	trace2("offsetUV", NULL, 0, im->im_process, PLANE_BYTES());
+}
+extern void __real_im_recons_wavelet_band(image_buffer *);
+void __wrap_im_recons_wavelet_band(image_buffer *im)
+{
+	__real_im_recons_wavelet_band(im);
+	trace2("im_recons_wavelet_band", im->im_wavelet_band, IM_SIZE * sizeof(short), NULL, 0);
+}
+extern void __real_wavelet_synthesis_high_quality_settings(image_buffer *, encode_state *);
+void __wrap_wavelet_synthesis_high_quality_settings(image_buffer *im, encode_state *enc)
+{
+	const void *bl[5]; uint32_t ln[5];
+	trace2("first_order", im->im_wavelet_first_order, IM_SIZE * sizeof(short), im->im_quality_setting, 2 * IM_SIZE * sizeof(short));
+	__real_wavelet_synthesis_high_quality_settings(im, enc);
+	bl[0] = enc->nhw_res6; ln[0] = enc->nhw_res6_len;
+	bl[1] = enc->nhw_res6_bit; ln[1] = enc->nhw_res6_bit_len;
+	bl[2] = enc->nhw_res6_word; ln[2] = enc->nhw_res6_word_len;
+	bl[3] = enc->nhw_char_res1; ln[3] = enc->nhw_char_res1_len * 2;
+	bl[4] = enc->high_qsetting3; ln[4] = (im->setup->quality_setting > HIGH2) ? enc->qsetting3_len * 4 : 0;
+	trace_put("hq_settings", 5, bl, ln);
+}
+extern void __real_highres_compression(image_buffer *, encode_state *);
+void __wrap_highres_compression(image_buffer *im, encode_state *enc)
+{
+	const void *bl[2]; uint32_t ln[2];
+	bl[0] = enc->tree1; ln[0] = (IM_SIZE >> 2) + (IM_SIZE >> 3) + 1;
+	bl[1] = im->im_nhw; ln[1] = 6 * IM_SIZE;
+	trace_put("pre_highres_compression", 2, bl, ln);
+	__real_highres_compression(im, enc);
+	trace2("highres_compression", enc->ch_res, enc->end_ch_res, NULL, 0);
+}
+extern int __real_wavlts2packet(image_buffer *, encode_state *);
+int __wrap_wavlts2packet(image_buffer *im, encode_state *enc)
+{
+	const void *bl[4]; uint32_t ln[4];
+	int r = __real_wavlts2packet(im, enc);
+	bl[0] = enc->encode; ln[0] = enc->size_data2 * 4;
+	bl[1] = enc->tree1; ln[1] = enc->size_tree1;
+	bl[2] = enc->tree2; ln[2] = enc->size_tree2;
+	trace_put("wavlts2packet", 3, bl, ln);
+	return r;
+}
+
+/* ---------------------------------------------------------------- entry points */
+static int slurp(const char *path, uint8_t *out, size_t cap, size_t *len)
+{
+	FILE *f = fopen(path, "rb");
+	size_t n;
+	if (!f) return -3;
+	n = fread(out, 1, cap, f);
+	if (n == cap && fgetc(f) != EOF) { fclose(f); return -4; }
+	fclose(f);
+	*len = n;
+	return 0;
+}
+
+/* bgr: 512*512*3 bytes in BMP file order (as fread at nhw_encoder.c:3086 would deliver them).
+ * tmp_path: scratch file the reference's write_compressed_file writes to. */
+int nhwref_encode(const uint8_t *bgr, int quality, const char *tmp_path, uint8_t *out, size_t cap, size_t *out_len)
+{
+	image_buffer im;
+	encode_state enc;
+	codec_setup setup;
+	int rc;
+
+	memset(&im, 0, sizeof im);
+	memset(&enc, 0, sizeof enc);
+	memset(&setup, 0, sizeof setup);
+	g_chroma = 0; g_jpeg_live = 1;
+	g_track = 1; g_in_call = 1;
+	rc = setjmp(g_jmp);
+	if (rc == 0) {
+		im.setup = &setup;
+		setup.quality_setting = (unsigned char)quality;
+		/* read_image_bmp, nhw_encoder.c:3055-3060 */
+		setup.colorspace = YUV;
+		setup.wavelet_type = WVLTS_53;
+		setup.RES_HIGH = 0;
+		setup.RES_LOW = 3;
+		setup.wvlts_order = 2;
+		im.im_buffer4 = (unsigned char *)calloc(4 * 3 * IM_SIZE, sizeof(char));
+		memcpy(im.im_buffer4, bgr, 4 * 3 * IM_SIZE);
+		downsample_YUV420(&im, 8);
+		encode_image(&im, &enc, 8);
+		rc = write_compressed_file(&im, &enc, (char *)tmp_path);
+	}
+	g_in_call = 0; g_track = 0;
+	release_leftovers();
+	if (rc) return rc;
+	return slurp(tmp_path, out, cap, out_len);
+}
+
+/* whole-file path through the reference's own BMP reader (header checks, flip, short reads) */
+int nhwref_encode_file(const char *bmp_path, const char *nhw_path, int quality)
+{
+	image_buffer im;
+	encode_state enc;
+	codec_setup setup;
+	int rc;
+	memset(&im, 0, sizeof im);
+	memset(&enc, 0, sizeof enc);
+	memset(&setup, 0, sizeof setup);
+	g_chroma = 0; g_jpeg_live = 1;
+	g_track = 1; g_in_call = 1;
+	rc = setjmp(g_jmp);
+	if (rc == 0) {
+		im.setup = &setup;
+		setup.quality_setting = (unsigned char)quality;
+		read_image_bmp((char *)bmp_path, &enc, &im, 8);
+		encode_image(&im, &enc, 8);
+		rc = write_compressed_file(&im, &enc, (char *)nhw_path);
+	}
+	g_in_call = 0; g_track = 0;
+	release_leftovers();
+	return rc;
+}
