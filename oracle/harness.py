@@ -104,3 +104,40 @@ class RefEncoder:
             raise RuntimeError(f"reference encoder failed rc={rc}")
         data = self._out.raw[: n.value]
         return (data, tr) if trace else data
+
+
+# ---------------------------------------------------------------- deterministic robustness classes
+def _hash_u32(idx: np.ndarray, seed: int) -> np.ndarray:
+    """Stateless integer hash (vectorised, identical on every numpy): used for robustness inputs."""
+    h = (idx.astype(np.uint64) * np.uint64(0x9E3779B1) + np.uint64((seed * 0x85EBCA77 + 0x1234567) & 0xFFFFFFFF)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x2C1B3C6D)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(12)
+    h = (h * np.uint64(0x297A2D39)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    return h.astype(np.uint32)
+
+
+def class_image(kind: str, seed: int = 0) -> np.ndarray:
+    """Secondary input classes of SURVEY.md section 8d: 'noise', 'blocks', 'flat', 'gradient', 'black', 'white'."""
+    idx = np.arange(IMG_BYTES, dtype=np.uint64)
+    if kind == "noise":
+        return (_hash_u32(idx, seed) >> 24).astype(np.uint8).reshape(512, 512, 3)
+    if kind == "flat":
+        return np.full((512, 512, 3), 77, np.uint8)
+    if kind == "black":
+        return np.zeros((512, 512, 3), np.uint8)
+    if kind == "white":
+        return np.full((512, 512, 3), 255, np.uint8)
+    if kind == "gradient":
+        return np.broadcast_to((np.arange(512) // 2).astype(np.uint8)[None, :, None], (512, 512, 3)).copy()
+    if kind == "blocks":
+        h = _hash_u32(np.arange(40 * 7 + 3, dtype=np.uint64), seed + 99)
+        img = np.empty((512, 512, 3), np.uint8)
+        img[:] = (h[-3:] >> 24).astype(np.uint8)
+        for k in range(40):
+            y0, x0 = int(h[7 * k] % 480), int(h[7 * k + 1] % 480)
+            hh, ww = 8 + int(h[7 * k + 2] % 192), 8 + int(h[7 * k + 3] % 192)
+            img[y0 : y0 + hh, x0 : x0 + ww] = (h[7 * k + 4 : 7 * k + 7] >> 24).astype(np.uint8)
+        return img
+    raise ValueError(kind)

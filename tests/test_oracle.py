@@ -1,0 +1,106 @@
+"""CPU tests: the oracle restatement is pinned to the reference's outputs.
+
+1. against the committed golden vectors (tests/golden/, generated from the canonical reference build by
+   tests/golden/make_golden.py) -- complete .nhw files, sha256 of more files, per-checkpoint hashes;
+2. against the real reference itself (oracle/_ref) when that build is present, checkpoint by checkpoint.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle.harness import class_image, synth_image
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _image(oracle, kind, seed):
+    return oracle.synth(seed) if kind == "synth" else class_image(kind, seed)
+
+
+def _parse(key):
+    kind, s, q = key.rsplit("_", 2)
+    return kind, int(s[1:]), int(q[1:])
+
+
+def test_generator_matches_python_definition(oracle):
+    # SURVEY 8d generator: C restatement == numpy/pure-python definition
+    assert np.array_equal(oracle.synth(3), synth_image(3))
+
+
+def test_supported_range(oracle):
+    assert [q for q in range(0, 25) if oracle.supported(q)] == list(range(17, 24))
+
+
+def test_golden_files_bit_exact(oracle, manifest):
+    for key, size in manifest["files"].items():
+        kind, seed, q = _parse(key)
+        with open(os.path.join(GOLD, "nhw", key + ".nhw"), "rb") as f:
+            want = f.read()
+        assert len(want) == size
+        got = oracle.encode(_image(oracle, kind, seed), q)
+        assert got == want, f"{key}: oracle output differs from the reference's .nhw"
+
+
+def test_golden_hashes(oracle, manifest):
+    for key, h in manifest["hashes"].items():
+        kind, seed, q = _parse(key)
+        got = oracle.encode(_image(oracle, kind, seed), q)
+        assert hashlib.sha256(got).hexdigest() == h, key
+
+
+def test_golden_checkpoints(oracle, manifest):
+    # every intermediate plane / stream the reference hands between its translation units
+    for key, cps in manifest["checkpoints"].items():
+        kind, seed, q = _parse(key)
+        _, tr = oracle.encode(_image(oracle, kind, seed), q, trace=True)
+        got = [[n, [hashlib.sha1(b).hexdigest()[:16] for b in blobs]] for n, blobs in tr]
+        assert [g[0] for g in got] == [c[0] for c in cps], key
+        for g, c in zip(got, cps):
+            assert g == c, f"{key}: checkpoint {g[0]} differs"
+
+
+def test_stage_entry_points_consistent(oracle):
+    # the stage-level entry points used by the kernel parity tests reproduce the whole-encoder trace
+    img = oracle.synth(5)
+    _, tr = oracle.encode(img, 20, trace=True)
+    t = {}
+    for n, b in tr:
+        t.setdefault(n, b)
+    y, u, v = oracle.color(img, 20)
+    assert y.tobytes() == t["downsample_YUV420"][0] and u.tobytes() == t["downsample_YUV420"][1] and v.tobytes() == t["downsample_YUV420"][2]
+    y = oracle.prefilter(y, 20)
+    assert y.tobytes() == t["pre_processing"][0]
+    j, p = oracle.analysis(y, 512, 512, 0)
+    assert j.tobytes() == t["wavelet_analysis_512"][0] and p.tobytes() == t["wavelet_analysis_512"][1]
+
+
+def test_unsupported_quality_is_loud(oracle):
+    with pytest.raises(RuntimeError):
+        oracle.encode(oracle.synth(0), 10)
+
+
+@pytest.mark.parametrize("q", [17, 20, 23])
+def test_against_real_reference_trace(oracle, ref, q):
+    img = oracle.synth(12)
+    d_ref, t_ref = ref.encode(img, q, trace=True)
+    d_or, t_or = oracle.encode(img, q, trace=True)
+    assert [n for n, _ in t_ref] == [n for n, _ in t_or]
+    for (n, a), (_, b) in zip(t_ref, t_or):
+        assert a == b, f"q{q}: checkpoint {n}"
+    assert d_ref == d_or
+
+
+def test_reference_decoder_accepts_oracle_output(oracle, tmp_path):
+    dec = os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "nhw-dec")
+    if not os.path.exists(dec):
+        pytest.skip("oracle/_ref/nhw-dec not built")
+    import subprocess
+    img = oracle.synth(4)
+    p = tmp_path / "a.nhw"
+    p.write_bytes(oracle.encode(img, 20))
+    subprocess.check_call([dec, str(p), str(tmp_path / "a.bmp")], stdout=subprocess.DEVNULL)
+    out = np.frombuffer((tmp_path / "a.bmp").read_bytes()[54:], np.uint8).reshape(512, 512, 3).astype(int)
+    mse = ((out - img.astype(int)) ** 2).mean()
+    assert 10 * np.log10(255 ** 2 / mse) > 30  # a q20 decode is a faithful picture of the input
