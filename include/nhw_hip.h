@@ -1,0 +1,91 @@
+/*
+ * nhw_hip.h -- C ABI of libnhwhip.so: the MI355X (gfx950) NHW encoder hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI; its de-facto C API
+ * is encoder/codec.h:184-219 (`read_image_bmp` / `encode_image` / `write_compressed_file`, one
+ * 512x512 image per call, errors by exit()).  The entry points below replace that trio for whole
+ * batches of images:
+ *
+ *   reference                                            this library
+ *   ---------------------------------------------------  ------------------------------------------
+ *   im.setup->quality_setting (nhw_encoder_cli.c:175)     `quality` argument (17..23 in this revision)
+ *   read_image_bmp  -> im_buffer4 (nhw_encoder.c:3047)    caller passes n x 786432 BGR24 bytes in BMP
+ *                                                         file order (what fread at :3086 delivers)
+ *   downsample_YUV420 + encode_image (codec.h:184,189)    nhw_enc_batch / nhw_enc_batch_device
+ *   write_compressed_file (nhw_encoder.c:3100)            the .nhw bytes land in the output arena
+ *   exit(-1) on code-book overflow (compress_pixel.c:234) per-image status NHW_E_CODEBOOK
+ *
+ * Plain C types only; device pointers are passed as void*; `stream` is a hipStream_t passed as
+ * void* (NULL = the library's own stream).  One nhw_enc handle drives one GPU and is not
+ * re-entrant; use one handle per host thread / process (one process per GPU under torchrun).
+ */
+#ifndef NHW_HIP_H
+#define NHW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NHW_IMG_BYTES   786432u      /* 512*512*3, encoder/codec.h:58-61 */
+#define NHW_OUT_STRIDE  (512u << 10) /* bytes reserved per image in the device output arena */
+
+enum {
+	NHW_OK = 0,
+	NHW_E_QUALITY = -1,   /* quality outside the supported set */
+	NHW_E_CODEBOOK = -2,  /* reference would exit(-1): compress_pixel.c:234,270,271 */
+	NHW_E_SPACE = -3,     /* output arena too small */
+	NHW_E_ARG = -4,
+	NHW_E_HIP = -5        /* a HIP call failed; see nhw_last_error() */
+};
+
+typedef struct nhw_enc nhw_enc;
+
+/* stage timings of the last nhw_enc_batch_device call, measured with hipEvents on the launch stream */
+typedef struct {
+	float total_ms;
+	float front_ms;       /* colour + pre-filter + level-1 analysis (the HBM-roofline kernels) */
+	float color_dwt_ms;   /* the fused colour + level-1 analysis kernel alone (0 when q<=21 splits it) */
+	float luma_ms, chroma_ms, entropy_ms;
+} nhw_timing;
+
+/* lifecycle: replaces `im.setup=malloc(..)` + per-image mallocs of encode_image (nhw_encoder.c:108-...) */
+int  nhw_enc_create(int device, int max_batch, nhw_enc **out);
+void nhw_enc_destroy(nhw_enc *e);
+const char *nhw_last_error(void);
+int  nhw_quality_supported(int quality);
+
+/* Encode n images already resident in HBM.  d_bgr: n*NHW_IMG_BYTES.  d_out: n*NHW_OUT_STRIDE, image i's
+ * .nhw starts at i*NHW_OUT_STRIDE.  d_sizes[i] = byte length, d_status[i] = NHW_OK / NHW_E_CODEBOOK.
+ * Asynchronous on `stream`. */
+int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_out, uint32_t *d_sizes,
+                         int32_t *d_status, void *stream);
+
+/* Host convenience: H2D, encode, compact, D2H.  out_off has n+1 entries; image i is
+ * out_arena[out_off[i] .. out_off[i+1]).  status has n entries.  Synchronous. */
+int nhw_enc_batch(nhw_enc *e, const uint8_t *bgr, int n, int quality, uint8_t *out_arena, size_t arena_cap,
+                  uint64_t *out_off, int32_t *status);
+
+/* SURVEY.md section 8d synthetic inputs generated on the device (image i gets seed seed_base+i). */
+int nhw_synth_batch_device(nhw_enc *e, void *d_bgr, int n, uint32_t seed_base, void *stream);
+
+int nhw_enc_last_timing(nhw_enc *e, nhw_timing *t);
+
+/* ---- stage-level entry points (kernel parity tests; same stream rules) ----
+ * colour + 4:2:0 (colorspace.c:55-260): d_y n*262144 int16, d_u/d_v n*65536 uint8 */
+int nhw_stage_color(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_y, void *d_u, void *d_v, void *stream);
+/* luma pre-filter (image_processing.c:558-2426, q17..21), in place on d_y */
+int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, void *stream);
+/* one analysis level (wavelet_filterbank.c:52-302) on planes of `stride` shorts per row, n_img images
+ * spaced plane_stride shorts apart; size = transform size; final_level as in the oracle */
+int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size,
+                       int final_level, void *stream);
+int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size,
+                        void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

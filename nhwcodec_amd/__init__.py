@@ -1,0 +1,117 @@
+"""nhwcodec_amd -- MI355X-native NHW encoder hot path.
+
+Host-side mirror of the reference's C interface (rcanut/nhwcodec encoder/codec.h:184-219: quality setting in,
+512x512 BGR24 image in, .nhw bytes out) over the C ABI of libnhwhip.so (include/nhw_hip.h).  PyTorch is
+used only as plumbing: device buffers, streams, torch.distributed.  There is no CPU path: if the HIP
+library is missing or no GPU is visible, construction fails.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnhwhip.so")
+IMG_BYTES = 786432
+OUT_STRIDE = 512 << 10
+QUALITY_DEFAULT = 20          # reference nhw_encoder_cli.c:95 (NORM)
+
+P = ctypes.c_void_p
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "front_ms", "color_dwt_ms", "luma_ms", "chroma_ms", "entropy_ms")]
+
+
+class NhwError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise NhwError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no CPU fallback")
+    L = ctypes.CDLL(path)
+    L.nhw_last_error.restype = ctypes.c_char_p
+    L.nhw_enc_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)]
+    L.nhw_enc_destroy.argtypes = [P]
+    L.nhw_quality_supported.argtypes = [ctypes.c_int]
+    L.nhw_enc_batch_device.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, P, P, P]
+    L.nhw_enc_batch.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, ctypes.c_size_t, P, P]
+    L.nhw_synth_batch_device.argtypes = [P, P, ctypes.c_int, ctypes.c_uint32, P]
+    L.nhw_enc_last_timing.argtypes = [P, ctypes.POINTER(Timing)]
+    L.nhw_stage_color.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, P, P, P]
+    L.nhw_stage_prefilter.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P]
+    L.nhw_stage_analysis.argtypes = [P, P, P, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
+    L.nhw_stage_synthesis.argtypes = [P, P, P, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, P]
+    return L
+
+
+class Encoder:
+    """One encoder handle on one GPU.  encode_device() works on torch CUDA tensors already in HBM."""
+
+    def __init__(self, device: int = 0, max_batch: int = 64):
+        import torch
+        if not torch.cuda.is_available():
+            raise NhwError("no GPU visible: nhwcodec_amd has no CPU path")
+        self.torch = torch
+        self.lib = load_library()
+        self.device = device
+        self.max_batch = max_batch
+        h = P()
+        self._chk(self.lib.nhw_enc_create(device, max_batch, ctypes.byref(h)))
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NhwError(f"libnhwhip rc={rc}: {self.lib.nhw_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nhw_enc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def synth_device(self, n: int, seed_base: int = 0):
+        t = self.torch.empty((n, 512, 512, 3), dtype=self.torch.uint8, device=f"cuda:{self.device}")
+        self._chk(self.lib.nhw_synth_batch_device(self.h, t.data_ptr(), n, seed_base, self._stream()))
+        return t
+
+    def alloc_out(self, n: int):
+        dev = f"cuda:{self.device}"
+        return (self.torch.empty((n, OUT_STRIDE), dtype=self.torch.uint8, device=dev),
+                self.torch.empty(n, dtype=self.torch.int32, device=dev),
+                self.torch.empty(n, dtype=self.torch.int32, device=dev))
+
+    def encode_device(self, bgr, quality: int = QUALITY_DEFAULT, out=None):
+        """bgr: uint8 CUDA tensor [n,512,512,3] (BMP file order).  Returns (out[n,OUT_STRIDE], sizes[n], status[n]) on device."""
+        n = bgr.shape[0]
+        assert bgr.is_cuda and bgr.dtype == self.torch.uint8 and bgr.is_contiguous() and bgr.numel() == n * IMG_BYTES
+        if out is None:
+            out = self.alloc_out(n)
+        o, sizes, status = out
+        self._chk(self.lib.nhw_enc_batch_device(self.h, bgr.data_ptr(), n, quality, o.data_ptr(), sizes.data_ptr(), status.data_ptr(), self._stream()))
+        return o, sizes, status
+
+    def encode(self, images, quality: int = QUALITY_DEFAULT):
+        """images: numpy uint8 [n,512,512,3] on the host -> list of .nhw byte strings (raises on a per-image failure)."""
+        import numpy as np
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        n = images.shape[0]
+        arena = np.empty(n * OUT_STRIDE, np.uint8)
+        offs = np.empty(n + 1, np.uint64)
+        status = np.empty(n, np.int32)
+        self._chk(self.lib.nhw_enc_batch(self.h, images.ctypes.data, n, quality, arena.ctypes.data, arena.size, offs.ctypes.data, status.ctypes.data))
+        if (status != 0).any():
+            raise NhwError(f"per-image status {status.tolist()}")
+        return [arena[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)]
+
+    def timing(self) -> Timing:
+        t = Timing()
+        self._chk(self.lib.nhw_enc_last_timing(self.h, ctypes.byref(t)))
+        return t

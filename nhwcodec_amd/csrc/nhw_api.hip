@@ -1,0 +1,310 @@
+/*
+ * nhw_api.hip -- the C ABI of libnhwhip.so (include/nhw_hip.h): workspace, batch driver, host
+ * convenience path, stage entry points, hipEvent timing.  gfx950 / ROCm only.
+ *
+ * Batch driver = encode_image (rcanut/nhwcodec encoder/nhw_encoder.c:103-2878) re-cut as a sequence of
+ * batch-wide kernel launches: every launch processes the same stage of all n images.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/nhw_hip.h"
+#include "nhw_ws.h"
+
+/* launchers (nhw_front.hip, nhw_tail.hip) */
+void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_stride, uint8_t *u, uint8_t *v, size_t c_stride, hipStream_t s);
+void nhw_launch_prefilter(int16_t *y, size_t y_stride, int16_t *kmap, size_t k_stride, uint64_t *maps, size_t m_stride, uint8_t *st, size_t s_stride, int n, hipStream_t s);
+void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, int16_t *keep, size_t keep_stride, hipStream_t s);
+void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s);
+void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
+void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s);
+void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
+enum { PH_L1, PH_L2, PH_L3, PH_L4, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL };
+
+static thread_local std::string g_err;
+extern "C" const char *nhw_last_error(void) { return g_err.c_str(); }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { char b_[256]; snprintf(b_, sizeof b_, "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); g_err = b_; return NHW_E_HIP; } } while (0)
+
+struct nhw_enc {
+	int device, max_batch;
+	NhwWs ws;
+	size_t slab_bytes;
+	hipStream_t own_stream;
+	hipEvent_t ev[6];
+	bool timed;
+	/* host convenience path */
+	uint8_t *d_in, *d_out, *d_compact;
+	uint32_t *d_sizes; int32_t *d_status; uint64_t *d_offs;
+	int conv_cap;
+	int stop_after;   /* debug: leave the batch driver after this many stages (0 = run everything) */
+};
+
+static const size_t k_buf_bytes[B_COUNT] = {
+	/* JPEG   */ 8 * Q, /* PROC */ 8 * Q, /* PU */ Q, /* PV */ Q, /* CJPEG */ 2 * Q, /* CPROC */ 2 * Q,
+	/* LL1    */ 2 * Q, /* L2SAVE */ 2 * Q, /* CLL1 */ Q / 2, /* CL2SAVE */ Q / 2, /* KEEP */ 4 * Q, /* FIRST */ 2 * Q,
+	/* BAND   */ 2 * Q, /* HS */ 4 * Q + 256, /* KMAP */ 8 * Q, /* ROWMAP */ 512 * 16, /* ROWSTATE */ 512, /* SCAN */ 6 * Q,
+	/* LLBYTES*/ 24832, /* LLFULL */ 16384, /* EXW */ 16384 + 256, /* LLCOMP */ 32768, /* LLWORD */ 16384, /* LLMEM */ 32768,
+	/* RES4   */ 8192, /* RAW */ 2 * Q + 1024, /* PAY */ 2 * Q + 256, /* CC */ 2 * Q + 1024, /* HALF */ 2 * Q + 1024, /* TMP16 */ Q / 2,
+	/* R1     */ Q + 64, 8192 + 64, 16384 + 64, /* R3 */ Q + 64, 8192 + 64, 16384 + 64, /* R5 */ Q + 64, 8192 + 64, 16384 + 64,
+	/* R6     */ 2 * Q + 1024, 16384 + 64, 16384 + 64, /* CHARRES */ 2048 + 64, /* QSET3 */ 8 * Q + 64,
+	/* RESU64 */ 512, /* RESV64 */ 512, /* PACKET */ 320000, /* BOOK1 */ 768, /* BOOK2 */ 768, /* SEL1 */ 16384 + 64, /* SEL2 */ 16384 + 64,
+	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256
+};
+
+static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int nhw_quality_supported(int quality) { return quality >= 17 && quality <= 23; }
+
+extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
+{
+	if (!out || max_batch < 1 || max_batch > 65535) { g_err = "bad argument"; return NHW_E_ARG; }
+	HIPCHK(hipSetDevice(device));
+	nhw_enc *e = new nhw_enc();
+	memset(e, 0, sizeof *e);
+	e->device = device; e->max_batch = max_batch;
+	size_t total = 0;
+	for (int b = 0; b < B_COUNT; b++) {
+		e->ws.stride[b] = round_up(k_buf_bytes[b] + GUARD, 256);
+		e->ws.off[b] = total + GUARD;
+		total += GUARD + e->ws.stride[b] * (size_t)max_batch;
+	}
+	e->slab_bytes = total;
+	HIPCHK(hipMalloc((void **)&e->ws.base, total));
+	HIPCHK(hipMemset(e->ws.base, 0, total));       /* guards must be zero; they are never written afterwards */
+	HIPCHK(hipStreamCreate(&e->own_stream));
+	for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&e->ev[i]));
+	*out = e;
+	return NHW_OK;
+}
+
+extern "C" void nhw_enc_destroy(nhw_enc *e)
+{
+	if (!e) return;
+	(void)hipSetDevice(e->device);
+	(void)hipDeviceSynchronize();
+	if (e->ws.base) (void)hipFree(e->ws.base);
+	if (e->d_in) (void)hipFree(e->d_in);
+	if (e->d_out) (void)hipFree(e->d_out);
+	if (e->d_compact) (void)hipFree(e->d_compact);
+	if (e->d_sizes) (void)hipFree(e->d_sizes);
+	if (e->d_status) (void)hipFree(e->d_status);
+	if (e->d_offs) (void)hipFree(e->d_offs);
+	for (int i = 0; i < 6; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+	if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+	delete e;
+}
+
+static inline int16_t *plane16(const NhwWs &ws, int b) { return (int16_t *)(ws.base + ws.off[b]); }
+static inline uint8_t *plane8(const NhwWs &ws, int b) { return ws.base + ws.off[b]; }
+
+extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_out, uint32_t *d_sizes,
+                                    int32_t *d_status, void *stream)
+{
+	if (!e || !d_bgr || !d_out || !d_sizes || !d_status || n < 1 || n > e->max_batch) { g_err = "bad argument"; return NHW_E_ARG; }
+	if (!nhw_quality_supported(quality)) { g_err = "quality outside 17..23 is not implemented in this revision"; return NHW_E_QUALITY; }
+	HIPCHK(hipSetDevice(e->device));
+	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+	NhwWs ws = e->ws;
+	ws.n = n; ws.q = quality;
+	const int q = quality;
+	int16_t *jpeg = plane16(ws, B_JPEG), *proc = plane16(ws, B_PROC);
+	int16_t *cjpeg = plane16(ws, B_CJPEG), *cproc = plane16(ws, B_CPROC);
+	const size_t ps = ws.stride[B_JPEG] / 2, cps = ws.stride[B_CJPEG] / 2;
+	uint8_t *out = (uint8_t *)d_out;
+
+	int stage = 0;
+#define STAGE_DONE() do { if (e->stop_after && ++stage == e->stop_after) { HIPCHK(hipGetLastError()); return NHW_OK; } } while (0)
+	HIPCHK(hipEventRecord(e->ev[0], s));
+	/* a1: colour + 4:2:0 */
+	nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
+	STAGE_DONE();
+	/* a2: pre-filter (q<=21, nhw_encoder.c:116-119) */
+	if (q < 22) {
+		nhw_launch_prefilter(jpeg, ws.stride[B_JPEG], plane16(ws, B_KMAP), ws.stride[B_KMAP], (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP],
+		                     plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], n, s);
+		STAGE_DONE();
+	}
+	/* Y2: level-1 analysis (:125) */
+	nhw_launch_analysis(jpeg, proc, n, ps, W, W, 0, q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, s);
+	STAGE_DONE();
+	HIPCHK(hipEventRecord(e->ev[1], s));
+	/* Y3: LL1 copy (:127-135); Y4: level-2 analysis (:139) */
+	nhw_launch_copy_block(jpeg, ps, W, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, H, H, H, n, s);
+	STAGE_DONE();
+	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
+	STAGE_DONE();
+	nhw_launch_phase(PH_L1, ws, 0, out, d_sizes, d_status, s);
+	STAGE_DONE();
+	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s);
+	STAGE_DONE();
+	nhw_launch_phase(PH_L2, ws, 0, out, d_sizes, d_status, s);
+	STAGE_DONE();
+	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
+	STAGE_DONE();
+	nhw_launch_copy_block(proc, ps, W, plane16(ws, B_L2SAVE), ws.stride[B_L2SAVE] / 2, H, H, H, n, s);   /* Y13 (:623-631) */
+	STAGE_DONE();
+	nhw_launch_phase(PH_L3, ws, 0, out, d_sizes, d_status, s);
+	STAGE_DONE();
+	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s);
+	STAGE_DONE();
+	nhw_launch_phase(PH_L4, ws, 0, out, d_sizes, d_status, s);
+	STAGE_DONE();
+	HIPCHK(hipEventRecord(e->ev[2], s));
+
+	for (int comp = 0; comp < 2; comp++) {           /* U then V (:2255-2570, :2572-2868) */
+		nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, s);
+		STAGE_DONE();
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, nullptr, 0, s);
+		STAGE_DONE();
+		nhw_launch_copy_block(cjpeg, cps, H, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, H / 2, H / 2, n, s);
+		STAGE_DONE();
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, s);
+		STAGE_DONE();
+		nhw_launch_phase(PH_C2, ws, comp, out, d_sizes, d_status, s);
+		STAGE_DONE();
+		nhw_launch_synthesis(cjpeg, cproc, n, cps, H, H / 2, s);
+		STAGE_DONE();
+		nhw_launch_phase(PH_C3, ws, comp, out, d_sizes, d_status, s);
+		STAGE_DONE();
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, s);
+		STAGE_DONE();
+		nhw_launch_copy_block(cproc, cps, H, plane16(ws, B_CL2SAVE), ws.stride[B_CL2SAVE] / 2, H / 2, H / 2, H / 2, n, s);
+		STAGE_DONE();
+		nhw_launch_phase(PH_C4, ws, comp, out, d_sizes, d_status, s);
+		STAGE_DONE();
+		nhw_launch_synthesis(cjpeg, cproc, n, cps, H, H / 2, s);
+		STAGE_DONE();
+		nhw_launch_phase(PH_C5, ws, comp, out, d_sizes, d_status, s);
+		STAGE_DONE();
+	}
+	HIPCHK(hipEventRecord(e->ev[3], s));
+	nhw_launch_phase(PH_FINAL, ws, 0, out, d_sizes, d_status, s);   /* Z1, Z2, container */
+	HIPCHK(hipEventRecord(e->ev[4], s));
+	HIPCHK(hipGetLastError());
+	e->timed = true;
+	return NHW_OK;
+}
+
+extern "C" int nhw_enc_last_timing(nhw_enc *e, nhw_timing *t)
+{
+	if (!e || !t || !e->timed) { g_err = "no timed batch"; return NHW_E_ARG; }
+	HIPCHK(hipEventSynchronize(e->ev[4]));
+	memset(t, 0, sizeof *t);
+	HIPCHK(hipEventElapsedTime(&t->total_ms, e->ev[0], e->ev[4]));
+	HIPCHK(hipEventElapsedTime(&t->front_ms, e->ev[0], e->ev[1]));
+	HIPCHK(hipEventElapsedTime(&t->luma_ms, e->ev[1], e->ev[2]));
+	HIPCHK(hipEventElapsedTime(&t->chroma_ms, e->ev[2], e->ev[3]));
+	HIPCHK(hipEventElapsedTime(&t->entropy_ms, e->ev[3], e->ev[4]));
+	t->color_dwt_ms = 0.f;
+	return NHW_OK;
+}
+
+extern "C" int nhw_synth_batch_device(nhw_enc *e, void *d_bgr, int n, uint32_t seed_base, void *stream)
+{
+	if (!e || !d_bgr || n < 1) { g_err = "bad argument"; return NHW_E_ARG; }
+	HIPCHK(hipSetDevice(e->device));
+	nhw_launch_synth((uint8_t *)d_bgr, n, seed_base, stream ? (hipStream_t)stream : e->own_stream);
+	HIPCHK(hipGetLastError());
+	return NHW_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ host path */
+__global__ void k_offsets(const uint32_t *sizes, uint64_t *offs, int n)
+{
+	if (blockIdx.x || threadIdx.x) return;
+	uint64_t acc = 0;
+	for (int i = 0; i < n; i++) { offs[i] = acc; acc += sizes[i]; }
+	offs[n] = acc;
+}
+__global__ __launch_bounds__(256) void k_compact(const uint8_t *out, const uint32_t *sizes, const uint64_t *offs, uint8_t *dst)
+{
+	const int img = blockIdx.x;
+	const uint8_t *s = out + (size_t)img * NHW_OUT_STRIDE;
+	uint8_t *d = dst + offs[img];
+	for (uint32_t i = threadIdx.x; i < sizes[img]; i += 256) d[i] = s[i];
+}
+
+extern "C" int nhw_enc_batch(nhw_enc *e, const uint8_t *bgr, int n, int quality, uint8_t *out_arena, size_t arena_cap,
+                             uint64_t *out_off, int32_t *status)
+{
+	if (!e || !bgr || !out_arena || !out_off || !status || n < 1 || n > e->max_batch) { g_err = "bad argument"; return NHW_E_ARG; }
+	HIPCHK(hipSetDevice(e->device));
+	if (e->conv_cap < n) {
+		if (e->d_in) { (void)hipFree(e->d_in); (void)hipFree(e->d_out); (void)hipFree(e->d_compact); (void)hipFree(e->d_sizes); (void)hipFree(e->d_status); (void)hipFree(e->d_offs); }
+		HIPCHK(hipMalloc((void **)&e->d_in, (size_t)n * NHW_IMG_BYTES));
+		HIPCHK(hipMalloc((void **)&e->d_out, (size_t)n * NHW_OUT_STRIDE));
+		HIPCHK(hipMalloc((void **)&e->d_compact, (size_t)n * NHW_OUT_STRIDE));
+		HIPCHK(hipMalloc((void **)&e->d_sizes, sizeof(uint32_t) * n));
+		HIPCHK(hipMalloc((void **)&e->d_status, sizeof(int32_t) * n));
+		HIPCHK(hipMalloc((void **)&e->d_offs, sizeof(uint64_t) * (n + 1)));
+		e->conv_cap = n;
+	}
+	hipStream_t s = e->own_stream;
+	HIPCHK(hipMemcpyAsync(e->d_in, bgr, (size_t)n * NHW_IMG_BYTES, hipMemcpyHostToDevice, s));
+	int rc = nhw_enc_batch_device(e, e->d_in, n, quality, e->d_out, e->d_sizes, e->d_status, s);
+	if (rc) return rc;
+	k_offsets<<<1, 1, 0, s>>>(e->d_sizes, e->d_offs, n);
+	k_compact<<<n, 256, 0, s>>>(e->d_out, e->d_sizes, e->d_offs, e->d_compact);
+	HIPCHK(hipMemcpyAsync(out_off, e->d_offs, sizeof(uint64_t) * (n + 1), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(status, e->d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	if (out_off[n] > arena_cap) { g_err = "output arena too small"; return NHW_E_SPACE; }
+	HIPCHK(hipMemcpy(out_arena, e->d_compact, out_off[n], hipMemcpyDeviceToHost));
+	return NHW_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ stage entry points */
+extern "C" int nhw_stage_color(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_y, void *d_u, void *d_v, void *stream)
+{
+	if (!e || n < 1) return NHW_E_ARG;
+	if (!nhw_quality_supported(quality)) return NHW_E_QUALITY;
+	HIPCHK(hipSetDevice(e->device));
+	nhw_launch_color((const uint8_t *)d_bgr, n, quality, (int16_t *)d_y, 8 * Q, (uint8_t *)d_u, (uint8_t *)d_v, Q, stream ? (hipStream_t)stream : e->own_stream);
+	HIPCHK(hipGetLastError());
+	return NHW_OK;
+}
+
+extern "C" int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, void *stream)
+{
+	if (!e || n < 1 || n > e->max_batch) return NHW_E_ARG;
+	if (quality < 17 || quality > 21) return NHW_E_QUALITY;
+	HIPCHK(hipSetDevice(e->device));
+	const NhwWs &ws = e->ws;
+	nhw_launch_prefilter((int16_t *)d_y, 8 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP], (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP],
+	                     plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], n, stream ? (hipStream_t)stream : e->own_stream);
+	HIPCHK(hipGetLastError());
+	return NHW_OK;
+}
+
+extern "C" int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size,
+                                  int final_level, void *stream)
+{
+	if (!e || n_img < 1) return NHW_E_ARG;
+	HIPCHK(hipSetDevice(e->device));
+	nhw_launch_analysis((int16_t *)d_jpeg, (int16_t *)d_proc, n_img, plane_stride, stride, size, final_level, nullptr, 0, stream ? (hipStream_t)stream : e->own_stream);
+	HIPCHK(hipGetLastError());
+	return NHW_OK;
+}
+
+extern "C" int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size, void *stream)
+{
+	if (!e || n_img < 1) return NHW_E_ARG;
+	HIPCHK(hipSetDevice(e->device));
+	nhw_launch_synthesis((int16_t *)d_jpeg, (int16_t *)d_proc, n_img, plane_stride, stride, size, stream ? (hipStream_t)stream : e->own_stream);
+	HIPCHK(hipGetLastError());
+	return NHW_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ debug hooks (tests only) */
+extern "C" int nhw_debug_stop_after(nhw_enc *e, int stage) { if (!e) return NHW_E_ARG; e->stop_after = stage; return NHW_OK; }
+extern "C" int nhw_debug_read(nhw_enc *e, int buf, int img, void *dst, size_t bytes)
+{
+	if (!e || buf < 0 || buf >= B_COUNT || img < 0 || img >= e->max_batch || bytes > e->ws.stride[buf]) return NHW_E_ARG;
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(dst, e->ws.base + e->ws.off[buf] + (size_t)img * e->ws.stride[buf], bytes, hipMemcpyDeviceToHost));
+	return NHW_OK;
+}

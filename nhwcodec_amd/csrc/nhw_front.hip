@@ -1,0 +1,439 @@
+/*
+ * nhw_front.hip -- data-parallel front of the NHW encode path for gfx950 (MI355X):
+ * colour conversion + 4:2:0, luma pre-filter, separable integer 5/3 filterbank (analysis + synthesis).
+ *
+ * Algorithm sources (behaviour only; nothing here is derived from the reference's code structure):
+ *   colour        rcanut/nhwcodec encoder/colorspace.c:55-260
+ *   pre-filter    encoder/image_processing.c:558-837, 1927-1990 (quality 17..21 branch)
+ *   filterbank    encoder/wavelet_filterbank.c:52-496, encoder/filters.c:55-114, 203-287, 346-386, 521-572
+ *
+ * No MFMA: there is no dense contraction on this path; every kernel is integer/byte streaming work
+ * bounded by HBM.  Built with -ffp-contract=off: the luma weights are double products summed left to
+ * right and a fused multiply-add changes 300+ of the 2^24 colour triples.
+ */
+#include "nhw_ws.h"
+
+#pragma clang fp contract(off)
+
+namespace nhw {
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+
+/* ------------------------------------------------------------------------------------------------
+ * colour + 4:2:0.  One workgroup per pair of luma rows (2r, 2r+1) = one chroma row r.
+ * The three BGR rows 2r-1..2r+1 are staged in LDS with coalesced 16-byte loads.
+ * ------------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ uint8_t clip_u8(int v) { return (v >> 8) != 0 ? (v < 0 ? 0 : 255) : (uint8_t)v; }
+__device__ __forceinline__ int chroma_round(float cb) { return cb >= 0 ? (int)(cb + 128.5f) : (int)(cb + 128.4f); }
+
+template <int FAMILY> /* 0: q>=20, 1: q 18/19, 2: q17 */
+__device__ __forceinline__ void convert_uv(const uint8_t *px, float yq, int &U, int &V)
+{
+	const int b0 = px[0], b1 = px[1], b2 = px[2];
+	double lu = -0.1687 * b0 - 0.3313 * b1 + 0.5 * b2;
+	double lv = 0.5 * b0 - 0.4187 * b1 - 0.0813 * b2;
+	if (FAMILY == 2) { lu = lu * 0.94; lv = lv * 0.94; }
+	U = clip_u8(chroma_round((float)lu));
+	V = clip_u8(chroma_round((float)lv));
+}
+template <int FAMILY>
+__device__ __forceinline__ int convert_y(const uint8_t *px, float yq)
+{
+	const int b0 = px[0], b1 = px[1], b2 = px[2];
+	const double ly = 0.299 * b0 + 0.587 * b1 + 0.114 * b2;
+	if (FAMILY == 0) return (int)(ly + 0.5f);
+	if (FAMILY == 1) return (int)(ly * yq + 0.5f);
+	return (int)(ly * 0.94 + 0.5f);
+}
+
+template <int FAMILY>
+__global__ __launch_bounds__(256) void k_color(const uint8_t *__restrict__ bgr, int16_t *__restrict__ yb, size_t y_stride,
+                                               uint8_t *__restrict__ ub, uint8_t *__restrict__ vb, size_t c_stride, float yq)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t rows[3][W * 3];
+	const int r = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
+	const uint8_t *src = bgr + (size_t)img * (W * W * 3);
+	const int r0 = r ? 2 * r - 1 : 0; /* row above (unused for r = 0) */
+
+	for (int k = t; k < 3 * (W * 3 / 16); k += 256) {
+		const int which = k / (W * 3 / 16), o = k % (W * 3 / 16);
+		const int row = which == 0 ? r0 : (2 * r + which - 1);
+		reinterpret_cast<uint4 *>(rows[which])[o] = reinterpret_cast<const uint4 *>(src + (size_t)row * (W * 3))[o];
+	}
+	__syncthreads();
+
+	/* luma: pixels 2t, 2t+1 of rows 2r and 2r+1 (Y is not clipped, colorspace.c:80) */
+	int16_t *yrow = (int16_t *)((uint8_t *)yb + (size_t)img * y_stride) + (size_t)(2 * r) * W;
+	for (int k = 1; k <= 2; k++) {
+		const int y0 = convert_y<FAMILY>(&rows[k][6 * t], yq), y1 = convert_y<FAMILY>(&rows[k][6 * t + 3], yq);
+		reinterpret_cast<uint32_t *>(yrow + (k - 1) * W)[t] = (uint32_t)(uint16_t)y0 | ((uint32_t)(uint16_t)y1 << 16);
+	}
+
+	/* chroma: horizontal [1 2 1]/4 at even pixel 2t (first column: (c0+c1+1)>>1), then vertical
+	 * [1 2 1]/4 over rows 2r-1, 2r, 2r+1 (first row: (r0+r1+1)>>1) */
+	int hu[3], hv[3];
+	for (int k = 0; k < 3; k++) {
+		int uc, vc, ur, vr;
+		convert_uv<FAMILY>(&rows[k][6 * t], yq, uc, vc);
+		convert_uv<FAMILY>(&rows[k][6 * t + 3], yq, ur, vr);
+		if (t == 0) { hu[k] = (uc + ur + 1) >> 1; hv[k] = (vc + vr + 1) >> 1; }
+		else {
+			int ul, vl;
+			convert_uv<FAMILY>(&rows[k][6 * t - 3], yq, ul, vl);
+			hu[k] = (ul + 2 * uc + ur + 2) >> 2; hv[k] = (vl + 2 * vc + vr + 2) >> 2;
+		}
+	}
+	int U, V;
+	if (r == 0) { U = (hu[1] + hu[2] + 1) >> 1; V = (hv[1] + hv[2] + 1) >> 1; }
+	else { U = (hu[0] + 2 * hu[1] + hu[2] + 2) >> 2; V = (hv[0] + 2 * hv[1] + hv[2] + 2) >> 2; }
+	(ub + (size_t)img * c_stride)[r * H + t] = (uint8_t)U;
+	(vb + (size_t)img * c_stride)[r * H + t] = (uint8_t)V;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * luma pre-filter.  Pass A is a 3x3 contrast measure pushed through a 4-bit error-diffusion carry that
+ * runs in raster order over the whole interior.  The carry is a 16-state machine; it is parallelised
+ * by composing, per row, the state transfer map (16 states tracked at once, one byte each, SWAR on two
+ * 64-bit words), chaining the 510 row maps, then replaying every row from its now-known start state.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* vb[r][c] = sign(sum) * (15*|sum| + mag), 0 when sum == 0 (carry reset); interior pixels only */
+__global__ __launch_bounds__(256) void k_pre_contrast(const int16_t *__restrict__ yb, size_t y_stride, int16_t *__restrict__ kb, size_t k_stride)
+{
+	const int r = blockIdx.x + 1, img = blockIdx.y, t = threadIdx.x;
+	const int16_t *y = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
+	int16_t *km = (int16_t *)((uint8_t *)kb + (size_t)img * k_stride);
+	for (int c = 2 * t; c <= 2 * t + 1; c++) {
+		if (c < 1 || c > W - 2) continue;
+		const int16_t *p = y + r * W + c;
+		const int ctr = p[0];
+		int sum = 0, mag = 0;
+#pragma unroll
+		for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+			for (int dx = -1; dx <= 1; dx++) {
+				if (!dy && !dx) continue;
+				const int d = ctr - p[dy * W + dx];
+				sum += d; mag += iabs(d);
+			}
+		const int base = 15 * iabs(sum) + mag;
+		km[r * W + c] = (int16_t)(sum == 0 ? 0 : (sum < 0 ? -base : base));
+	}
+}
+
+__device__ __forceinline__ void fsm_step16(uint64_t &m0, uint64_t &m1, int vb)
+{
+	if (vb == 0) { m0 = 0; m1 = 0; return; }
+	const uint64_t add = (uint64_t)(iabs(vb) & 15) * 0x0101010101010101ull;
+	m0 = ((((m0 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
+	m1 = ((((m1 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
+}
+
+/* one lane per (image, row): transfer map of the row */
+__global__ __launch_bounds__(256) void k_pre_rowmap(const int16_t *__restrict__ kb, size_t k_stride, uint64_t *__restrict__ maps, size_t m_stride, int n)
+{
+	const int id = blockIdx.x * 256 + threadIdx.x;
+	if (id >= n * (W - 2)) return;
+	const int img = id / (W - 2), r = id % (W - 2) + 1;
+	const int16_t *km = (const int16_t *)((const uint8_t *)kb + (size_t)img * k_stride) + r * W;
+	uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
+	for (int c8 = 0; c8 < W; c8 += 8) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(km + c8);
+		const int16_t *s = reinterpret_cast<const int16_t *>(&v);
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const int c = c8 + k;
+			if (c >= 1 && c <= W - 2) fsm_step16(m0, m1, s[k]);
+		}
+	}
+	uint64_t *o = (uint64_t *)((uint8_t *)maps + (size_t)img * m_stride) + 2 * r;
+	o[0] = m0; o[1] = m1;
+}
+
+/* one lane per image: chain the row maps -> start state of every row */
+__global__ void k_pre_chain(const uint64_t *__restrict__ maps, size_t m_stride, uint8_t *__restrict__ st, size_t s_stride, int n)
+{
+	const int img = blockIdx.x * blockDim.x + threadIdx.x;
+	if (img >= n) return;
+	const uint64_t *m = (const uint64_t *)((const uint8_t *)maps + (size_t)img * m_stride);
+	uint8_t *s = st + (size_t)img * s_stride;
+	int state = 0;
+	for (int r = 1; r <= W - 2; r++) {
+		s[r] = (uint8_t)state;
+		const uint64_t w = m[2 * r + (state >> 3)];
+		state = (int)((w >> (8 * (state & 7))) & 15);
+	}
+}
+
+/* one lane per (image, row): replay the carry from the known start state; kmap replaces vb in place */
+__global__ __launch_bounds__(256) void k_pre_kmap(int16_t *__restrict__ kb, size_t k_stride, const uint8_t *__restrict__ st, size_t s_stride, int n)
+{
+	const int id = blockIdx.x * 256 + threadIdx.x;
+	if (id >= n * (W - 2)) return;
+	const int img = id / (W - 2), r = id % (W - 2) + 1;
+	int16_t *km = (int16_t *)((uint8_t *)kb + (size_t)img * k_stride) + r * W;
+	int carry = (st + (size_t)img * s_stride)[r];
+	for (int c8 = 0; c8 < W; c8 += 8) {
+		uint4 v = *reinterpret_cast<const uint4 *>(km + c8);
+		int16_t *s = reinterpret_cast<int16_t *>(&v);
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const int c = c8 + k;
+			if (c < 1 || c > W - 2) continue;
+			const int vb = s[k];
+			if (vb == 0) { carry = 0; }
+			else {
+				const int acc = iabs(vb) + ((carry + 2) >> 2);
+				s[k] = (int16_t)(vb < 0 ? -(acc >> 4) : (acc >> 4));
+				carry = acc & 15;
+			}
+		}
+		*reinterpret_cast<uint4 *>(km + c8) = v;
+	}
+}
+
+/* flag handed from one pixel pair to the next in raster order (image_processing.c:1927-1990, `a`) */
+__device__ __forceinline__ int pair_big_flag(int k0, int k1)
+{
+	if (((k0 < 32 && k0 > 10) || (k0 > -32 && k0 < -10)) && iabs(k1) >= 23) return 0;
+	if (k1 < 32 && k1 >= 16) return iabs(k0) >= 23;
+	if (k1 > -32 && k1 <= -16) return iabs(k0) >= 23;
+	return 0;
+}
+
+/* one lane per pixel pair (c, c+1), c odd */
+__global__ __launch_bounds__(256) void k_pre_pairs(int16_t *__restrict__ yb, size_t y_stride, const int16_t *__restrict__ kb, size_t k_stride)
+{
+	const int r = blockIdx.x + 1, img = blockIdx.y, t = threadIdx.x;
+	if (t >= (W - 2) / 2) return;
+	const int c = 1 + 2 * t;
+	int16_t *o = (int16_t *)((uint8_t *)yb + (size_t)img * y_stride) + r * W + c;
+	const int16_t *km = (const int16_t *)((const uint8_t *)kb + (size_t)img * k_stride);
+	const int k0 = km[r * W + c], k1 = km[r * W + c + 1];
+	int prev_big = 0;
+	if (t > 0) prev_big = pair_big_flag(km[r * W + c - 2], km[r * W + c - 1]);
+	else if (r > 1) prev_big = pair_big_flag(km[(r - 1) * W + W - 3], km[(r - 1) * W + W - 2]);
+	int o0 = o[0], o1 = o[1], tag;
+
+	if (k0 > 201) { o0 -= 2; tag = 4; }
+	else if (k0 < -201) { o0 += 2; tag = 3; }
+	else if (k0 > 176) { o0--; tag = 2; }
+	else if (k0 < -176) { o0++; tag = 1; }
+	else tag = 0;
+	if (k1 > 201) { if (!tag || tag == 3) o1 -= 2; else if (tag != 4) o1--; }
+	else if (k1 < -201) { if (!tag || tag == 4) o1 += 2; else if (tag != 3) o1++; }
+	else if (k1 > 176) { if (tag != 4) o1--; }
+	else if (k1 < -176) { if (tag != 3) o1++; }
+
+	bool done = false;
+	if (k0 < 32 && k0 > 10) {
+		if (iabs(k1) >= 23) {
+			if (k0 < 16) { if (k1 > 0 && k1 < 32 && k0 > 11) o1++; o0++; }
+			else o0 += prev_big ? 1 : 2;
+			done = true;
+		}
+	} else if (k0 > -32 && k0 < -10) {
+		if (iabs(k1) >= 23) {
+			if (k0 > -16) { if (k1 < 0 && k1 > -32 && k0 < -11) o1--; o0--; }
+			else o0 -= prev_big ? 1 : 2;
+			done = true;
+		}
+	}
+	if (!done) {
+		if (k1 < 32 && k1 > 10) {
+			if (iabs(k0) >= 23) {
+				if (k1 < 16) { if (k0 > 0 && k0 < 32 && k1 > 11) o0++; o1++; }
+				else o1 += 2;
+			}
+		} else if (k1 > -32 && k1 < -10) {
+			if (iabs(k0) >= 23) {
+				if (k1 > -16) { if (k0 < 0 && k0 > -32 && k1 < -11) o0--; o1--; }
+				else o1 -= 2;
+			}
+		}
+	}
+	o[0] = (int16_t)o0; o[1] = (int16_t)o1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 5/3 filterbank
+ * ------------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ int tap5(const int16_t *x, int n, int k)
+{
+	const int c = 2 * k;
+	const int l1 = c >= 1 ? x[c - 1] : x[1], l2 = c >= 2 ? x[c - 2] : x[2];
+	const int r1 = x[c + 1], r2 = (c + 2 < n) ? x[c + 2] : x[n - 2];
+	return 6 * x[c] + 2 * (l1 + r1) - (l2 + r2);
+}
+__device__ __forceinline__ int pair_predict(const int16_t *x, int k)
+{
+	int a = x[2 * k] + x[2 * k + 2];
+	if ((k & 1) && (a & 1) && ((x[2 * k - 2] + x[2 * k]) & 1)) a++;
+	return x[2 * k + 1] - (a >> 1);
+}
+__device__ __forceinline__ int rnd_half_away(int v, int shift)
+{
+	const int half = 1 << (shift - 1);
+	return v >= 0 ? (v + half) >> shift : -((-v + half) >> shift);
+}
+__device__ __forceinline__ int diffuse(int r)
+{
+	if (r >= 0) { const int m = r & 63; return m < 32 ? (m >> 2) : -((64 - m) >> 2); }
+	const int m = (-r) & 63;
+	return m < 32 ? -(m >> 2) : ((64 - m) >> 2);
+}
+
+/* analysis of rows [0, rows) of a size x size block: one lane per output pair (lo[k], hi[k]).
+ * PASS 1: un-normalised taps (first direction).  PASS 2: second direction; rows below size/2 are
+ * low-pass in the first direction and get the /64 low-pass with the one-tap error diffusion and the /8
+ * high-pass, rows from size/2 on get /16 and /2. */
+template <int PASS>
+__global__ __launch_bounds__(256) void k_ana_rows(const int16_t *__restrict__ src, int16_t *__restrict__ dst, size_t plane_stride, int stride, int size)
+{
+	const int hlf = size >> 1;
+	const int k = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, img = blockIdx.z;
+	if (k >= hlf) return;
+	const int16_t *x = src + (size_t)img * plane_stride + (size_t)row * stride;
+	int16_t *o = dst + (size_t)img * plane_stride + (size_t)row * stride;
+	int lo, hi;
+	if (PASS == 1) {
+		lo = tap5(x, size, k);
+		hi = k < hlf - 1 ? (x[2 * k + 1] << 1) - (x[2 * k] + x[2 * k + 2]) : ((x[size - 1] - x[size - 2]) << 1);
+	} else if (row < hlf) {
+		const int r = tap5(x, size, k);
+		const int carry = k > 0 ? diffuse(tap5(x, size, k - 1)) : 0;
+		lo = rnd_half_away((int16_t)(r + carry), 6);
+		hi = k < hlf - 1 ? rnd_half_away(pair_predict(x, k), 3) : ((x[size - 1] - x[size - 2]) >> 3);
+	} else {
+		lo = rnd_half_away(tap5(x, size, k), 4);
+		if (k < hlf - 1) { const int r = pair_predict(x, k); hi = r > 0 ? (r + 1) >> 1 : r >> 1; }
+		else hi = ((x[size - 1] - x[size - 2]) + 1) >> 1;
+	}
+	o[k] = (int16_t)lo;
+	o[hlf + k] = (int16_t)hi;
+}
+
+/* dst[i][j] = src[j][i] for i, j < size; 64x64 tiles through LDS */
+__global__ __launch_bounds__(256) void k_transpose(const int16_t *__restrict__ src, int16_t *__restrict__ dst, size_t plane_stride, int stride, int size)
+{
+	__shared__ int16_t tile[64][65];
+	const int img = blockIdx.z, bx = blockIdx.x * 64, by = blockIdx.y * 64;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	const int16_t *s = src + (size_t)img * plane_stride;
+	int16_t *d = dst + (size_t)img * plane_stride;
+	for (int j = ty; j < 64; j += 4)
+		if (by + j < size && bx + tx < size) tile[j][tx] = s[(size_t)(by + j) * stride + bx + tx];
+	__syncthreads();
+	for (int j = ty; j < 64; j += 4)
+		if (bx + j < size && by + tx < size) d[(size_t)(bx + j) * stride + by + tx] = tile[tx][j];
+}
+
+/* synthesis of one direction: out[2k], out[2k+1] from lo[k..k+1], hi[k-1..k+1] */
+template <int NORMALISE>
+__global__ __launch_bounds__(256) void k_syn_rows(const int16_t *__restrict__ src, int16_t *__restrict__ dst, size_t plane_stride, int stride, int size)
+{
+	const int m = size >> 1;
+	const int k = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, img = blockIdx.z;
+	if (k >= m) return;
+	const int16_t *lo = src + (size_t)img * plane_stride + (size_t)row * stride, *hi = lo + m;
+	int16_t *out = dst + (size_t)img * plane_stride + (size_t)row * stride;
+	const int ln = (k + 1 < m) ? lo[k + 1] : lo[k];
+	const int hp = k > 0 ? hi[k - 1] : hi[0];
+	const int hn = (k + 1 < m) ? hi[k + 1] : hi[k];
+	int16_t e = (int16_t)(lo[k] << 3);
+	int16_t o = (int16_t)((lo[k] + ln) << 2);
+	e = (int16_t)(e - ((hi[k] + hp) << 1));
+	o = (int16_t)(o + (6 * hi[k] - hp - hn));
+	if (NORMALISE) {
+		if (e > 0) e = (int16_t)(e + 32);
+		e >>= 6;
+		if (o > 0) o = (int16_t)(o + 32);
+		o >>= 6;
+	}
+	reinterpret_cast<uint32_t *>(out)[k] = (uint32_t)(uint16_t)e | ((uint32_t)(uint16_t)o << 16);
+}
+
+/* SURVEY.md section 8d generator, one lane per image (setup only, never timed) */
+__global__ void k_synth(uint8_t *__restrict__ bgr, int n, uint32_t seed_base)
+{
+	const int img = blockIdx.x * blockDim.x + threadIdx.x;
+	if (img >= n) return;
+	uint32_t x = 0x9E3779B9u * (seed_base + (uint32_t)img + 1u);
+	if (!x) x = 1;
+	uint8_t lat[17 * 17 * 3];
+	for (int i = 0; i < 17 * 17 * 3; i++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; lat[i] = (uint8_t)(x >> 24); }
+	uint32_t *out = reinterpret_cast<uint32_t *>(bgr + (size_t)img * (W * W * 3));
+	uint32_t word = 0; int nb = 0;
+	for (int yy = 0; yy < W; yy++) {
+		const int cy = yy >> 5, wy = (yy & 31) << 3;
+		for (int xx = 0; xx < W; xx++) {
+			const int cx = xx >> 5, wx = (xx & 31) << 3;
+			for (int c = 0; c < 3; c++) {
+				const int l00 = lat[(cy * 17 + cx) * 3 + c], l01 = lat[(cy * 17 + cx + 1) * 3 + c];
+				const int l10 = lat[((cy + 1) * 17 + cx) * 3 + c], l11 = lat[((cy + 1) * 17 + cx + 1) * 3 + c];
+				const int v = ((l00 * (256 - wx) + l01 * wx) * (256 - wy) + (l10 * (256 - wx) + l11 * wx) * wy + 32768) >> 16;
+				x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+				int b = v + (int)(x % 13u) - 6;
+				b = b < 0 ? 0 : (b > 255 ? 255 : b);
+				word |= (uint32_t)b << (8 * nb);
+				if (++nb == 4) { *out++ = word; word = 0; nb = 0; }
+			}
+		}
+	}
+}
+
+} // namespace nhw
+
+/* ------------------------------------------------------------------------------------------------ launchers */
+using namespace nhw;
+
+void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_stride, uint8_t *u, uint8_t *v, size_t c_stride, hipStream_t s)
+{
+	const dim3 grid(H, n);
+	if (q >= 20) k_color<0><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, 0.f);
+	else if (q >= 18) k_color<1><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, q == 19 ? 0.975f : 0.93f);
+	else k_color<2><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, 0.f);
+}
+
+void nhw_launch_prefilter(int16_t *y, size_t y_stride, int16_t *kmap, size_t k_stride, uint64_t *maps, size_t m_stride,
+                          uint8_t *st, size_t s_stride, int n, hipStream_t s)
+{
+	const int rows = n * (W - 2);
+	k_pre_contrast<<<dim3(W - 2, n), 256, 0, s>>>(y, y_stride, kmap, k_stride);
+	k_pre_rowmap<<<(rows + 255) / 256, 256, 0, s>>>(kmap, k_stride, maps, m_stride, n);
+	k_pre_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, st, s_stride, n);
+	k_pre_kmap<<<(rows + 255) / 256, 256, 0, s>>>(kmap, k_stride, st, s_stride, n);
+	k_pre_pairs<<<dim3(W - 2, n), 256, 0, s>>>(y, y_stride, kmap, k_stride);
+}
+
+/* keep != nullptr: copy of the first 256 rows x 512 of the transposed pass-1 plane (q>=22, level 0) */
+void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level,
+                         int16_t *keep, size_t keep_stride, hipStream_t s)
+{
+	const int hlf = size >> 1;
+	const dim3 rg((hlf + 255) / 256, size, n), tg((size + 63) / 64, (size + 63) / 64, n);
+	k_ana_rows<1><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
+	k_transpose<<<tg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, size);
+	if (keep)
+		hipMemcpy2DAsync(keep, keep_stride * sizeof(int16_t), jpeg, plane_stride * sizeof(int16_t), 2 * Q * sizeof(int16_t), n, hipMemcpyDeviceToDevice, s);
+	k_ana_rows<2><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
+	if (!final_level) {
+		const dim3 lg((hlf + 63) / 64, (hlf + 63) / 64, n);
+		k_transpose<<<lg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, hlf);
+	}
+}
+
+void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s)
+{
+	const int hlf = size >> 1;
+	const dim3 rg((hlf + 255) / 256, size, n), tg((size + 63) / 64, (size + 63) / 64, n);
+	k_syn_rows<0><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
+	k_transpose<<<tg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, size);
+	k_syn_rows<1><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
+	k_transpose<<<tg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, size);
+}
+
+void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s)
+{
+	k_synth<<<(n + 63) / 64, 64, 0, s>>>(bgr, n, seed_base);
+}

@@ -1,0 +1,65 @@
+/*
+ * nhw_tail.hip -- kernels that run the order-dependent phases of the NHW encoder, one wavefront per
+ * image (see nhw_tail_dev.h), plus the small block-copy kernel used between them.
+ */
+#include "nhw_tail_dev.h"
+
+using namespace nhw;
+
+enum { PH_L1, PH_L2, PH_L3, PH_L4, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL };
+
+template <int PH>
+__global__ __launch_bounds__(64) void k_phase(NhwWs ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status)
+{
+	const int img = blockIdx.x;
+	if (threadIdx.x != 0) return;
+	Ctx c;
+	ctx_load(&c, ws, img);
+	if (PH == PH_L1) luma_p1(&c);
+	else if (PH == PH_L2) luma_p2(&c);
+	else if (PH == PH_L3) luma_p3(&c);
+	else if (PH == PH_L4) luma_p4(&c);
+	else if (PH == PH_C0) chroma_p0(&c, comp);
+	else if (PH == PH_C2) chroma_p2(&c, comp);
+	else if (PH == PH_C3) chroma_p3(&c, comp);
+	else if (PH == PH_C4) chroma_p4(&c, comp);
+	else if (PH == PH_C5) chroma_p5(&c, comp);
+	else if (PH == PH_FINAL) {
+		uint32_t sz = 0;
+		const int rc = final_phase(&c, out + (size_t)img * (512u << 10), 512u << 10, &sz);
+		sizes[img] = sz;
+		status[img] = rc;
+	}
+	ctx_store(&c, ws, img);
+}
+
+/* rows x cols block of shorts between two strided planes, every image of the batch */
+__global__ __launch_bounds__(256) void k_copy_block(const int16_t *__restrict__ src, size_t src_plane, int src_row,
+                                                    int16_t *__restrict__ dst, size_t dst_plane, int dst_row, int rows, int cols)
+{
+	const int img = blockIdx.z, r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+	if (c < cols) dst[(size_t)img * dst_plane + (size_t)r * dst_row + c] = src[(size_t)img * src_plane + (size_t)r * src_row + c];
+}
+
+void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s)
+{
+	const dim3 g(ws.n), b(64);
+	switch (ph) {
+	case PH_L1: k_phase<PH_L1><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L2: k_phase<PH_L2><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L3: k_phase<PH_L3><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L4: k_phase<PH_L4><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	case PH_C0: k_phase<PH_C0><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	case PH_C2: k_phase<PH_C2><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	case PH_C3: k_phase<PH_C3><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	case PH_C4: k_phase<PH_C4><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	case PH_C5: k_phase<PH_C5><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	case PH_FINAL: k_phase<PH_FINAL><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	}
+}
+
+void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row,
+                           int rows, int cols, int n, hipStream_t s)
+{
+	k_copy_block<<<dim3((cols + 255) / 256, rows, n), 256, 0, s>>>(src, src_plane, src_row, dst, dst_plane, dst_row, rows, cols);
+}

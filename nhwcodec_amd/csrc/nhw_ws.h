@@ -1,0 +1,53 @@
+/* nhw_ws.h -- device workspace layout shared by the kernels of libnhwhip.so (gfx950 only). */
+#ifndef NHW_WS_H
+#define NHW_WS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define W  512      /* luma row stride  (reference 2*IM_DIM) */
+#define H  256      /* chroma row stride (reference IM_DIM) */
+#define Q  65536    /* reference IM_SIZE */
+#define DEADZONE 8  /* reference `ratio`: nhw_encoder_cli.c:177 */
+#define GUARD 4096  /* zero bytes kept behind every logical buffer: the reference's out-of-bounds reads
+                        land here and return 0, the canonical-oracle semantics */
+
+/* Per-image buffers are laid out structure-of-arrays over the batch: buffer b of image i lives at
+ * base + off[b] + i * stride[b], stride[b] = size + GUARD rounded to 256 B, and GUARD zero bytes precede
+ * image 0.  The guards are never written, so they stay zero between batches. */
+enum {
+	B_JPEG, B_PROC, B_PU, B_PV, B_CJPEG, B_CPROC, B_LL1, B_L2SAVE, B_CLL1, B_CL2SAVE, B_KEEP, B_FIRST, B_BAND,
+	B_HS, B_KMAP, B_ROWMAP, B_ROWSTATE, B_SCAN, B_LLBYTES, B_LLFULL, B_EXW, B_LLCOMP, B_LLWORD, B_LLMEM, B_RES4,
+	B_RAW, B_PAY, B_CC, B_HALF, B_TMP16,
+	B_R1LIST, B_R1BITS, B_R1WORD, B_R3LIST, B_R3BITS, B_R3WORD, B_R5LIST, B_R5BITS, B_R5WORD,
+	B_R6LIST, B_R6BITS, B_R6WORD, B_CHARRES, B_QSET3,
+	B_RESU64, B_RESV64, B_PACKET, B_BOOK1, B_BOOK2, B_SEL1, B_SEL2, B_S1, B_S2, B_HIST, B_META,
+	B_COUNT
+};
+
+/* scalar per-image state (reference encode_state / codec_setup scalars), one struct per image in B_META */
+struct NhwMeta {
+	int exw_len, res4_len;
+	int r1_list, r1_bits, r1_word;
+	int r3_list, r3_bits, r3_word;
+	int r5_list, r5_bits, r5_word;
+	int r6_list, r6_bits, r6_word;
+	int char_res1_len, qsetting3_len;
+	int ll_comp_y_len, ll_word_len, ll_mem_len, ch_res_len;
+	int res_low, res_high, wavelet_type;
+	int select1, select2;
+	int size_data1, size_data2, size_book1, size_book2, tree_end;
+	int status;
+	int pad;
+};
+
+struct NhwWs {
+	uint8_t *base;
+	size_t off[B_COUNT];
+	size_t stride[B_COUNT];
+	int n;
+	int q;
+	template <typename T> __host__ __device__ T *buf(int b, int img) const { return (T *)(base + off[b] + (size_t)img * stride[b]); }
+};
+
+#endif
