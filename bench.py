@@ -90,11 +90,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import nhwcodec_amd
+    from nhwcodec_amd.dist import broadcast_descriptor, gather_summaries, max_over_ranks
     # work descriptor {base, count, quality, seed}: rank 0 decides, everyone receives
-    desc = torch.tensor([0, args.batch, args.quality, 1234], dtype=torch.int64, device=dev)
-    if dist:
-        dist.broadcast(desc, 0)
-    _, batch, q, seed = (int(v) for v in desc.tolist())
+    _, batch, q, seed = broadcast_descriptor(dist, dev, 0, args.batch, args.quality, 1234)
 
     enc = nhwcodec_amd.Encoder(local_rank, max_batch=batch)
     bgr = enc.synth_device(batch, seed_base=seed + rank * batch)     # inputs resident in HBM before timing
@@ -119,20 +117,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = max_over_ranks(dist, dev, dt)
 
     _, sizes, status = out
     ok = int((status == 0).sum().item())
     nbytes = int(sizes.to(torch.int64).sum().item())
     chk = int((sizes.to(torch.int64) * torch.arange(1, batch + 1, device=dev)).sum().item() % (1 << 61))
-    summary = torch.tensor([nbytes, chk, ok], dtype=torch.int64, device=dev)
-    gathered = [summary]
-    if dist:
-        gathered = [torch.zeros_like(summary) for _ in range(world)]
-        dist.all_gather(gathered, summary)
+    gathered = gather_summaries(dist, dev, nbytes, chk, ok)
 
     if rank == 0:
         total_images = batch * world * args.steps

@@ -18,6 +18,13 @@
 #define NHW_OK 0
 #define NHW_E_CODEBOOK (-2)
 #define S_CAP 131072   /* capacity of the sign-bit scratch lists */
+#ifdef NHW_PROFILE
+#define PROF_BEGIN() unsigned long long t0_ = wall_clock64()
+#define PROF(c, slot) do { unsigned long long t1_ = wall_clock64(); ((unsigned long long *)((c)->prof))[slot] += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define PROF_BEGIN() do {} while (0)
+#define PROF(c, slot) do {} while (0)
+#endif
 
 namespace nhw {
 
@@ -34,6 +41,7 @@ struct Ctx {
 	uint16_t *ll_mem, *char_res1;
 	uint32_t *qsetting3, *packet;
 	int *hist;
+	void *prof;
 	PosList res1, res3, res5, res6;
 	int exw_len, res4_len, char_res1_len, qsetting3_len, ll_comp_y_len, ll_word_len, ll_mem_len, ch_res_len;
 	int res_low, res_high, wavelet_type, select1, select2, size_data1, size_data2, size_book1, size_book2, tree_end;
@@ -65,6 +73,7 @@ DEV void ctx_load(Ctx *c, const NhwWs &ws, int img)
 	c->ll_mem = ws.buf<uint16_t>(B_LLMEM, img); c->char_res1 = ws.buf<uint16_t>(B_CHARRES, img);
 	c->qsetting3 = ws.buf<uint32_t>(B_QSET3, img); c->packet = ws.buf<uint32_t>(B_PACKET, img);
 	c->hist = ws.buf<int>(B_HIST, img);
+	c->prof = ws.buf<uint8_t>(B_PROF, img);
 	c->res1.list = ws.buf<uint8_t>(B_R1LIST, img); c->res1.bits = ws.buf<uint8_t>(B_R1BITS, img); c->res1.word = ws.buf<uint8_t>(B_R1WORD, img);
 	c->res3.list = ws.buf<uint8_t>(B_R3LIST, img); c->res3.bits = ws.buf<uint8_t>(B_R3BITS, img); c->res3.word = ws.buf<uint8_t>(B_R3WORD, img);
 	c->res5.list = ws.buf<uint8_t>(B_R5LIST, img); c->res5.bits = ws.buf<uint8_t>(B_R5BITS, img); c->res5.word = ws.buf<uint8_t>(B_R5WORD, img);
@@ -1621,21 +1630,26 @@ DEV size_t container(Ctx *c, uint8_t *out, size_t cap)
  * ------------------------------------------------------------------------------------------------ */
 
 /* after the first L2 analysis: Y5 + Y6 (nhw_encoder.c:141-179) */
-DEV void luma_p1(Ctx *c) { tag_l2_details(c); dequant_sim_luma(c, 1); }
+DEV void luma_p1(Ctx *c) { PROF_BEGIN(); tag_l2_details(c); PROF(c, 0); dequant_sim_luma(c, 1); PROF(c, 1); }
 
 /* after the first L2 synthesis: Y8 + Y9 (:183-279) */
-DEV void luma_p2(Ctx *c) { apply_tags(c); precompensate_ll1(c); }
+DEV void luma_p2(Ctx *c) { PROF_BEGIN(); apply_tags(c); PROF(c, 2); precompensate_ll1(c); PROF(c, 3); }
 
 /* after the second L2 analysis (l2save already holds the L2 plane, Y13): Y14..Y18a (:636-762) */
 DEV void luma_p3(Ctx *c)
 {
 	int r, i;
 	for (i = Q >> 2; i < (Q >> 2) + (Q >> 3) + 64; i++) c->ll_bytes[i] = 0;  /* the LL coder reads zeros behind the luma samples */
+	PROF_BEGIN();
 	if (c->q > 17) tag_res4(c);
 	emit_ll2(c);
+	PROF(c, 4);
 	ll_code_luma(c);
+	PROF(c, 5);
 	for (r = 0; r < H; r++) memcpy(c->proc + r * W, c->l2save + r * H, sizeof(int16_t) * H);   /* Y17 :749-755 */
+	PROF(c, 6);
 	dequant_sim_luma(c, 0);
+	PROF(c, 7);
 }
 
 /* after the second L2 synthesis: Y19..Y31 (:766-2252) */
@@ -1643,6 +1657,7 @@ DEV void luma_p4(Ctx *c)
 {
 	const int q = c->q;
 	int r, j, res_setting;
+	PROF_BEGIN();
 	if (q > 21) for (r = 0; r < H; r++) memcpy(c->first_order + r * H, c->jpeg + r * W, sizeof(int16_t) * H);   /* Y19 :766-777 */
 	if (q < 20) {                                                                                               /* Y20 (:783-801) */
 		int16_t *p = c->proc;
@@ -1651,12 +1666,17 @@ DEV void luma_p4(Ctx *c)
 			for (j = H; j < W; j++) { int16_t *v = p + r * W + j; if (iabs(*v) >= DEADZONE && iabs(*v) <= 14) *v = (int16_t)(*v > 0 ? 7 : -7); }
 		}
 	}
+	PROF(c, 8);
 	tag_small_runs(c);                                           /* Y21 */
+	PROF(c, 9);
 	res_setting = q >= 20 ? 3 : (q >= 18 ? 4 : 6);               /* :1075-1078 */
 	classify_residuals(c, res_setting);                          /* Y22 */
+	PROF(c, 10);
 	code_residuals(c, res_setting);                              /* Y23 */
+	PROF(c, 11);
 	if (q > 21) adjust_first_order(c);                           /* Y24 */
 	build_poslists(c);                                           /* Y25 */
+	PROF(c, 12);
 	{                                                            /* Y26 :1893-1910 */
 		int16_t *p = c->proc;
 		for (r = 0; r < H; r++)
@@ -1665,11 +1685,16 @@ DEV void luma_p4(Ctx *c)
 				p[r * W + j] = (r < H / 2 && j < H / 2 && v <= 8000) ? 0 : v;
 			}
 	}
+	PROF(c, 13);
 	clean_details(c);                                            /* Y27 */
+	PROF(c, 14);
 	quantise_luma(c);                                            /* Y28 :2100 */
+	PROF(c, 15);
 	if (q > 21) { band_recons(c); hq_settings(c); }              /* Y29 :2102-2106 */
+	PROF(c, 16);
 	for (j = 0; j < 16; j++) c->scan[4 * Q + j] = 0;             /* im_nhw is calloc'ed: the rewrite pass peeks one byte past the luma part */
 	scan_and_rewrite(c);                                         /* Y30, Y31 */
+	PROF(c, 17);
 }
 
 /* chroma (nhw_encoder.c:2255-2868); comp 0 = U, 1 = V */
@@ -1701,6 +1726,7 @@ DEV void chroma_p5(Ctx *c, int comp)
 	const int q = c->q;
 	const int res_uv = q > 17 ? 4 : 5;                            /* :2370 */
 	int r, j, i, a;
+	PROF_BEGIN();
 	if (q >= 18) {                                                /* :2372-2427; the reference's LL1 index runs on across rows */
 		int k = 0;
 		for (r = 0; r < H / 2; r++)
@@ -1750,7 +1776,9 @@ DEV void chroma_p5(Ctx *c, int comp)
 			dst[i] = (uint8_t)v;
 		}
 	}
+	PROF(c, 21);
 	quantise_chroma(c);
+	PROF(c, 22);
 	{                                                             /* serpentine, 32 strips of 8 columns, U even / V odd bytes (:2553-2570) */
 		uint8_t *s = c->scan + 4 * Q + comp;
 		int strip, t = 0;
@@ -1768,10 +1796,14 @@ DEV int final_phase(Ctx *c, uint8_t *out, size_t cap, uint32_t *size)
 {
 	int rc;
 	size_t n;
+	PROF_BEGIN();
 	ll_code_chroma(c);
+	PROF(c, 18);
 	rc = packetise(c);
+	PROF(c, 19);
 	if (rc) { *size = 0; return rc; }
 	n = container(c, out, cap);
+	PROF(c, 20);
 	*size = (uint32_t)n;
 	return n ? NHW_OK : -3;
 }

@@ -1,0 +1,131 @@
+"""CPU tests: multi-process sharding logic over gloo (world_size 2), and the nhw-enc command line contract."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_ranges_partition_the_batch():
+    from nhwcodec_amd.dist import shard_range
+    for count in (1, 7, 8, 4096, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            rs = [shard_range(5, count, r, world) for r in range(world)]
+            assert rs[0][0] == 5 and rs[-1][1] == 5 + count
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nhwcodec_amd.dist import broadcast_descriptor, gather_summaries, max_over_ranks, shard_range
+    dev = torch.device("cpu")
+    # only rank 0 knows the job; everyone must end up with it
+    desc = broadcast_descriptor(dist, dev, *( (100, 4097, 20, 77) if rank == 0 else (0, 0, 0, 0)))
+    lo, hi = shard_range(desc[0], desc[1], rank, world)
+    summ = gather_summaries(dist, dev, bytes_out=(hi - lo) * 10, checksum=lo, images_ok=hi - lo)
+    tmax = max_over_ranks(dist, dev, 1.0 + rank)
+    q.put((rank, desc, (lo, hi), summ, tmax))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_descriptor_broadcast_and_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, d0, s0, g0, t0), (r1, d1, s1, g1, t1) = res
+    assert d0 == d1 == (100, 4097, 20, 77)
+    assert s0 == (100, 2149) and s1 == (2149, 4197)
+    assert g0 == g1 == [(20490, 100, 2049), (20480, 2149, 2048)]
+    assert t0 == t1 == 2.0
+
+
+# ---------------------------------------------------------------- CLI contract (no GPU needed for argument handling)
+CLI = os.path.join(ROOT, "tools", "nhw-enc")
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "nhw-enc")
+
+
+def _run(exe, *a):
+    p = subprocess.run([exe, *a], capture_output=True, text=True)
+    return p.returncode, p.stdout, p.stderr
+
+
+@pytest.fixture(scope="module")
+def cli():
+    if not os.path.exists(CLI):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools")])
+    return CLI
+
+
+@pytest.mark.parametrize("args", [["-q99", "a.bmp", "b.nhw"], ["-qx", "a.bmp", "b.nhw"], ["-z", "a", "b"], ["only_one"], ["same", "same"], ["-h"]])
+def test_cli_argument_handling_matches_reference_binary(cli, args):
+    if not os.path.exists(REF_CLI):
+        pytest.skip("reference binary not built")
+    rc, out, err = _run(cli, *args)
+    rrc, rout, rerr = _run(REF_CLI, *args)
+    assert rc == rrc
+    assert out.splitlines()[:1] == rout.splitlines()[:1] and err == rerr
+
+
+def test_cli_rejects_unimplemented_quality_loudly(cli):
+    rc, out, err = _run(cli, "-q5", "a.bmp", "b.nhw")
+    assert rc == 3 and "not implemented" in err
+
+
+def test_cli_bad_bmp_exit_codes_match_reference(cli, tmp_path):
+    if not os.path.exists(REF_CLI):
+        pytest.skip("reference binary not built")
+    cases = {"nosig.bmp": b"XX" + bytes(60), "short.bmp": b"BM" + bytes(10),
+             "wrongsize.bmp": b"BM" + bytes(8) + (54).to_bytes(4, "little") + (40).to_bytes(4, "little") + (256).to_bytes(4, "little") + (256).to_bytes(4, "little") + (1).to_bytes(2, "little") + (24).to_bytes(2, "little") + bytes(4)}
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        rc, out, _ = _run(cli, str(p), str(tmp_path / "o.nhw"))
+        rrc, rout, _ = _run(REF_CLI, str(p), str(tmp_path / "r.nhw"))
+        assert (rc, out) == (rrc, rout), name
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_files(cli, oracle, tmp_path):
+    """nhw-enc file in -> file out equals the oracle, incl. a top-down (negative height) BMP and a 108-byte V4 header."""
+    import struct
+    from oracle.harness import bmp_bytes
+    img = oracle.synth(21)
+    (tmp_path / "a.bmp").write_bytes(bmp_bytes(img))
+    assert _run(cli, "-q20", str(tmp_path / "a.bmp"), str(tmp_path / "a.nhw"))[0] == 0
+    assert (tmp_path / "a.nhw").read_bytes() == oracle.encode(img, 20)
+    # negative height: rows stored top-down -> the reader flips them
+    hdr = struct.pack("<2sIHHIIiiHHIIiiII", b"BM", 54 + img.size, 0, 0, 54, 40, 512, -512, 1, 24, 0, img.size, 0, 0, 0, 0)
+    (tmp_path / "b.bmp").write_bytes(hdr + img.tobytes())
+    assert _run(cli, "-q23", str(tmp_path / "b.bmp"), str(tmp_path / "b.nhw"))[0] == 0
+    assert (tmp_path / "b.nhw").read_bytes() == oracle.encode(img[::-1], 23)
+    # V4 header (108 bytes) with a larger data offset, truncated pixel data (short read -> zero tail)
+    off = 14 + 108 + 20
+    hdr = struct.pack("<2sIHHI", b"BM", off + img.size, 0, 0, off) + struct.pack("<IiiHHI", 108, 512, 512, 1, 24, 0) + bytes(108 - 20) + bytes(20)
+    cut = img.copy(); cut.reshape(-1)[-30000:] = 0
+    (tmp_path / "c.bmp").write_bytes(hdr + img.tobytes()[:-30000])
+    assert _run(cli, str(tmp_path / "c.bmp"), str(tmp_path / "c.nhw"))[0] == 0
+    assert (tmp_path / "c.nhw").read_bytes() == oracle.encode(cut, 20)
+    # batch directory mode
+    d = tmp_path / "dir"; d.mkdir()
+    for s in (1, 2, 3):
+        (d / f"i{s}.bmp").write_bytes(bmp_bytes(oracle.synth(s)))
+    assert _run(cli, "-q21", "--batch", str(d))[0] == 0
+    for s in (1, 2, 3):
+        assert (d / f"i{s}.nhw").read_bytes() == oracle.encode(oracle.synth(s), 21)
