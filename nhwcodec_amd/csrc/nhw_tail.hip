@@ -1,36 +1,37 @@
 /*
- * nhw_tail.hip -- kernels that run the order-dependent phases of the NHW encoder, one wavefront per
- * image (see nhw_tail_dev.h), plus the small block-copy kernel used between them.
+ * nhw_tail.hip -- kernels that run the order-dependent phases of the NHW encoder, one 256-thread workgroup
+ * per image (see nhw_tail_par.h / nhw_tail_dev.h), plus the small block-copy kernel used between them.
  */
-#include "nhw_tail_dev.h"
+#include "nhw_tail_par.h"
 
 using namespace nhw;
 
 enum { PH_L1, PH_L2, PH_L3, PH_L4, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL };
 
 template <int PH>
-__global__ __launch_bounds__(64) void k_phase(NhwWs ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status)
+__global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status)
 {
-	const int img = blockIdx.x;
-	if (threadIdx.x != 0) return;
+	__shared__ int sh_counts[2];
+	const int img = blockIdx.x, tid = threadIdx.x;
 	Ctx c;
 	ctx_load(&c, ws, img);
-	if (PH == PH_L1) luma_p1(&c);
-	else if (PH == PH_L2) luma_p2(&c);
-	else if (PH == PH_L3) luma_p3(&c);
-	else if (PH == PH_L4) luma_p4(&c);
-	else if (PH == PH_C0) chroma_p0(&c, comp);
-	else if (PH == PH_C2) chroma_p2(&c, comp);
-	else if (PH == PH_C3) chroma_p3(&c, comp);
-	else if (PH == PH_C4) chroma_p4(&c, comp);
-	else if (PH == PH_C5) chroma_p5(&c, comp);
+	if (PH == PH_L1) luma_p1_par(&c, tid);
+	else if (PH == PH_L2) luma_p2_par(&c, tid);
+	else if (PH == PH_L3) luma_p3_par(&c, tid);
+	else if (PH == PH_L4) luma_p4_par(&c, tid, sh_counts);
+	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
+	else if (PH == PH_C2) dequant_sim_chroma_par(&c, 1, tid);
+	else if (PH == PH_C3) chroma_p3_par(&c, comp, tid);
+	else if (PH == PH_C4) dequant_sim_chroma_par(&c, 0, tid);
+	else if (PH == PH_C5) chroma_p5_par(&c, comp, tid);
 	else if (PH == PH_FINAL) {
-		uint32_t sz = 0;
-		const int rc = final_phase(&c, out + (size_t)img * (512u << 10), 512u << 10, &sz);
-		sizes[img] = sz;
-		status[img] = rc;
+		if (tid == 0) {
+			uint32_t sz = 0;
+			const int rc = final_phase(&c, out + (size_t)img * (512u << 10), 512u << 10, &sz);
+			sizes[img] = sz;
+			status[img] = rc;
+		}
 	}
-	ctx_store(&c, ws, img);
 }
 
 /* rows x cols block of shorts between two strided planes, every image of the batch */
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void k_copy_block(const int16_t *__restrict__ 
 
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s)
 {
-	const dim3 g(ws.n), b(64);
+	const dim3 g(ws.n), b(256);
 	switch (ph) {
 	case PH_L1: k_phase<PH_L1><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L2: k_phase<PH_L2><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;

@@ -30,9 +30,10 @@ namespace nhw {
 
 DEV inline int iabs(int v) { return v < 0 ? -v : v; }
 
-struct PosList { uint8_t *list; int list_len; uint8_t *bits; int bits_len; uint8_t *word; int word_len; };
+struct PosList { uint8_t *list, *bits, *word; NhwPosLens *len; };
 
-/* per-image view of the workspace + the scalar encoder state (reference encode_state, codec.h:125-181) */
+/* per-image view of the workspace; the scalar encoder state (reference encode_state, codec.h:125-181) lives in
+ * NhwMeta in global memory so that every thread of the workgroup sees one copy */
 struct Ctx {
 	int q;
 	int16_t *jpeg, *proc, *cjpeg, *cproc, *ll1, *l2save, *cll1, *cl2save, *keep, *first_order, *band, *hs, *tmp16;
@@ -42,16 +43,16 @@ struct Ctx {
 	uint32_t *qsetting3, *packet;
 	int *hist;
 	void *prof;
+	NhwMeta *m;
 	PosList res1, res3, res5, res6;
-	int exw_len, res4_len, char_res1_len, qsetting3_len, ll_comp_y_len, ll_word_len, ll_mem_len, ch_res_len;
-	int res_low, res_high, wavelet_type, select1, select2, size_data1, size_data2, size_book1, size_book2, tree_end;
 };
 
 DEV void poslist_finish(Ctx *c, PosList *pl, uint8_t *raw, int raw_len, const uint8_t *payload, int payload_len, int word_mode);
 
 DEV void ctx_load(Ctx *c, const NhwWs &ws, int img)
 {
-	const NhwMeta *m = ws.buf<NhwMeta>(B_META, img);
+	NhwMeta *m = ws.buf<NhwMeta>(B_META, img);
+	c->m = m;
 	c->q = ws.q;
 	c->jpeg = ws.buf<int16_t>(B_JPEG, img); c->proc = ws.buf<int16_t>(B_PROC, img);
 	c->cjpeg = ws.buf<int16_t>(B_CJPEG, img); c->cproc = ws.buf<int16_t>(B_CPROC, img);
@@ -74,43 +75,12 @@ DEV void ctx_load(Ctx *c, const NhwWs &ws, int img)
 	c->qsetting3 = ws.buf<uint32_t>(B_QSET3, img); c->packet = ws.buf<uint32_t>(B_PACKET, img);
 	c->hist = ws.buf<int>(B_HIST, img);
 	c->prof = ws.buf<uint8_t>(B_PROF, img);
-	c->res1.list = ws.buf<uint8_t>(B_R1LIST, img); c->res1.bits = ws.buf<uint8_t>(B_R1BITS, img); c->res1.word = ws.buf<uint8_t>(B_R1WORD, img);
-	c->res3.list = ws.buf<uint8_t>(B_R3LIST, img); c->res3.bits = ws.buf<uint8_t>(B_R3BITS, img); c->res3.word = ws.buf<uint8_t>(B_R3WORD, img);
-	c->res5.list = ws.buf<uint8_t>(B_R5LIST, img); c->res5.bits = ws.buf<uint8_t>(B_R5BITS, img); c->res5.word = ws.buf<uint8_t>(B_R5WORD, img);
-	c->res6.list = ws.buf<uint8_t>(B_R6LIST, img); c->res6.bits = ws.buf<uint8_t>(B_R6BITS, img); c->res6.word = ws.buf<uint8_t>(B_R6WORD, img);
-	c->exw_len = m->exw_len; c->res4_len = m->res4_len;
-	c->res1.list_len = m->r1_list; c->res1.bits_len = m->r1_bits; c->res1.word_len = m->r1_word;
-	c->res3.list_len = m->r3_list; c->res3.bits_len = m->r3_bits; c->res3.word_len = m->r3_word;
-	c->res5.list_len = m->r5_list; c->res5.bits_len = m->r5_bits; c->res5.word_len = m->r5_word;
-	c->res6.list_len = m->r6_list; c->res6.bits_len = m->r6_bits; c->res6.word_len = m->r6_word;
-	c->char_res1_len = m->char_res1_len; c->qsetting3_len = m->qsetting3_len;
-	c->ll_comp_y_len = m->ll_comp_y_len; c->ll_word_len = m->ll_word_len; c->ll_mem_len = m->ll_mem_len; c->ch_res_len = m->ch_res_len;
-	c->res_low = m->res_low; c->res_high = m->res_high; c->wavelet_type = m->wavelet_type;
-	c->select1 = m->select1; c->select2 = m->select2;
-	c->size_data1 = m->size_data1; c->size_data2 = m->size_data2; c->size_book1 = m->size_book1; c->size_book2 = m->size_book2;
-	c->tree_end = m->tree_end;
+	c->res1.list = ws.buf<uint8_t>(B_R1LIST, img); c->res1.bits = ws.buf<uint8_t>(B_R1BITS, img); c->res1.word = ws.buf<uint8_t>(B_R1WORD, img); c->res1.len = &m->r1;
+	c->res3.list = ws.buf<uint8_t>(B_R3LIST, img); c->res3.bits = ws.buf<uint8_t>(B_R3BITS, img); c->res3.word = ws.buf<uint8_t>(B_R3WORD, img); c->res3.len = &m->r3;
+	c->res5.list = ws.buf<uint8_t>(B_R5LIST, img); c->res5.bits = ws.buf<uint8_t>(B_R5BITS, img); c->res5.word = ws.buf<uint8_t>(B_R5WORD, img); c->res5.len = &m->r5;
+	c->res6.list = ws.buf<uint8_t>(B_R6LIST, img); c->res6.bits = ws.buf<uint8_t>(B_R6BITS, img); c->res6.word = ws.buf<uint8_t>(B_R6WORD, img); c->res6.len = &m->r6;
 }
 
-DEV void ctx_store(const Ctx *c, const NhwWs &ws, int img)
-{
-	NhwMeta *m = ws.buf<NhwMeta>(B_META, img);
-	m->exw_len = c->exw_len; m->res4_len = c->res4_len;
-	m->r1_list = c->res1.list_len; m->r1_bits = c->res1.bits_len; m->r1_word = c->res1.word_len;
-	m->r3_list = c->res3.list_len; m->r3_bits = c->res3.bits_len; m->r3_word = c->res3.word_len;
-	m->r5_list = c->res5.list_len; m->r5_bits = c->res5.bits_len; m->r5_word = c->res5.word_len;
-	m->r6_list = c->res6.list_len; m->r6_bits = c->res6.bits_len; m->r6_word = c->res6.word_len;
-	m->char_res1_len = c->char_res1_len; m->qsetting3_len = c->qsetting3_len;
-	m->ll_comp_y_len = c->ll_comp_y_len; m->ll_word_len = c->ll_word_len; m->ll_mem_len = c->ll_mem_len; m->ch_res_len = c->ch_res_len;
-	m->res_low = c->res_low; m->res_high = c->res_high; m->wavelet_type = c->wavelet_type;
-	m->select1 = c->select1; m->select2 = c->select2;
-	m->size_data1 = c->size_data1; m->size_data2 = c->size_data2; m->size_book1 = c->size_book1; m->size_book2 = c->size_book2;
-	m->tree_end = c->tree_end;
-}
-
-
-
-
-/* escape codes for |coefficient| > 127 (tree.h:54-55): 10+{0,2,4}+8k and 60+{0,2,6}... as published */
 __device__ static const uint8_t k_big_pos[19] = { 10, 12, 14, 18, 20, 22, 26, 28, 30, 34, 36, 38, 42, 44, 46, 50, 52, 54, 58 };
 __device__ static const uint8_t k_big_neg[19] = { 60, 62, 66, 68, 70, 74, 76, 78, 82, 84, 86, 90, 92, 94, 98, 100, 102, 106, 108 };
 
@@ -258,7 +228,7 @@ DEV void dequant_sim_luma(Ctx *c, int part)
 				}
 			}
 		/* samples the LL coder sent verbatim keep their exact value (q>15) */
-		for (i = 0; i < c->ll_mem_len; i++) {
+		for (i = 0; i < c->m->ll_mem_len; i++) {
 			const int idx = c->ll_mem[i];
 			jp[((idx >> 7) << 9) + (idx & 127)] = tmp[idx];
 		}
@@ -548,7 +518,7 @@ DEV void tag_res4(Ctx *c)
 		}
 		if (!hit) n++;
 	}
-	c->res4_len = n;
+	c->m->res4_len = n;
 }
 
 /* Y15: LL2 emission (:661-741) */
@@ -595,7 +565,7 @@ DEV void emit_ll2(Ctx *c)
 			if (!hit) c->res4[n4++] = 128; else c->res4[n4 - 1] += 128;
 		}
 	}
-	c->exw_len = e;
+	c->m->exw_len = e;
 }
 
 /* Y21: +-5..7 run tagging (:970-1073) */
@@ -945,18 +915,18 @@ DEV void scan_and_rewrite(Ctx *c)
 	}
 
 	for (i = 0; i < 4; i++) { s[i] = 128; s[n - 4 + i] = 128; }
-	c->select1 = 0; c->select2 = 0;
+	c->m->select1 = 0; c->m->select2 = 0;
 	for (i = 4; i < n - 4; i++) {                         /* :2166-2219 */
 		if (s[i] == 136 || s[i] == 120) {
 			const int before4 = s[i - 1] == 128 && s[i - 2] == 128 && s[i - 3] == 128 && s[i - 4] == 128;
 			const int pair = (s[i + 1] == 120 || s[i + 1] == 136);
-			if (s[i + 2] == 128 && pair && before4) { s[i + 1] = (uint8_t)(s[i + 1] == 120 ? 157 : 159); c->select2++; }
+			if (s[i + 2] == 128 && pair && before4) { s[i + 1] = (uint8_t)(s[i + 1] == 120 ? 157 : 159); c->m->select2++; }
 			else if (s[i - 1] == 128 && pair && s[i + 2] == 128 && s[i + 3] == 128 && s[i + 4] == 128 && s[i + 5] == 128) {
-				s[i + 1] = (uint8_t)(s[i + 1] == 120 ? 157 : 159); c->select2++;
+				s[i + 1] = (uint8_t)(s[i + 1] == 120 ? 157 : 159); c->m->select2++;
 			}
-			else if (before4 && s[i + 1] == 128) { s[i] = (uint8_t)(s[i] == 136 ? 153 : 155); c->select1++; }
+			else if (before4 && s[i + 1] == 128) { s[i] = (uint8_t)(s[i] == 136 ? 153 : 155); c->m->select1++; }
 			else if (s[i - 1] == 128 && s[i + 1] == 128 && s[i + 2] == 128 && s[i + 3] == 128 && s[i + 4] == 128) {
-				s[i] = (uint8_t)(s[i] == 136 ? 153 : 155); c->select1++;
+				s[i] = (uint8_t)(s[i] == 136 ? 153 : 155); c->m->select1++;
 			}
 		}
 	}
@@ -996,7 +966,7 @@ DEV int ll_verbatim(llc *k, int i)
 	k->o[k->j++] = (uint8_t)(128 + (k->s[i] >> 1));
 	k->o[k->j++] = (uint8_t)(128 + (k->s[i + 1] >> 1));
 	k->c->ll_word[k->mem++] = k->c->ll_full[i];
-	k->c->ll_mem[k->c->ll_mem_len++] = (uint16_t)i;
+	k->c->ll_mem[k->c->m->ll_mem_len++] = (uint16_t)i;
 	return i + 1;
 }
 
@@ -1031,8 +1001,8 @@ DEV void ll_code_luma(Ctx *c)
 	}
 	runs8 += runs16;
 	mode = runs16 > 299 ? 2 : (runs8 > 179 ? 1 : 0);   /* :506-508 */
-	c->res_low = mode;
-	c->ll_mem_len = 0;
+	c->m->res_low = mode;
+	c->m->ll_mem_len = 0;
 
 	k.c = c; k.s = s; k.o = o; k.j = 1; k.mem = 0;
 	o[0] = s[0];
@@ -1107,9 +1077,9 @@ DEV void ll_code_luma(Ctx *c)
 			else o[w++] = tmp[i];
 		}
 		if (i < j) o[w++] = tmp[j - 1];
-		c->ll_comp_y_len = w;
+		c->m->ll_comp_y_len = w;
 	}
-	c->ll_word_len = k.mem;
+	c->m->ll_word_len = k.mem;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1123,8 +1093,8 @@ DEV void ll_code_chroma(Ctx *c)
 	int i, j, a = 0, wide = 0;
 
 	for (i = lo; i < hi; i++) s[i] &= 252;           /* compress_pixel.c:886 */
-	c->res_high = c->res_low;                         /* :887 */
-	j = c->ll_comp_y_len;
+	c->m->res_high = c->m->res_low;                         /* :887 */
+	j = c->m->ll_comp_y_len;
 	o[j++] = s[lo];
 
 	for (i = lo + 1; i < hi; i++) {
@@ -1177,8 +1147,7 @@ DEV void ll_code_chroma(Ctx *c)
 		}
 		else o[j++] = (uint8_t)(128 + (s[i] >> 2));    /* :1004-1010 */
 	}
-	c->ch_res = o;          /* the reference copies highres_comp into a fresh ch_res (:1015-1017) */
-	c->ch_res_len = j;
+	c->m->ch_res_len = j;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1217,7 +1186,7 @@ DEV void poslist_finish(Ctx *c, PosList *pl, uint8_t *raw, int raw_len, const ui
 		}
 		else pl->list[packed++] = half[i];
 	}
-	pl->list_len = packed;
+	pl->len->list_len = packed;
 
 	/* plane of the dropped low bits, markers excluded (nhw_encoder.c:1594-1615) */
 	for (i = 0, nb = 0; i < n; i++) if (cc[i] != H - 2) half[nb++] = cc[i];
@@ -1228,21 +1197,21 @@ DEV void poslist_finish(Ctx *c, PosList *pl, uint8_t *raw, int raw_len, const ui
 		for (b = 0; b < 8; b++) v = (v << 1) | (half[8 * i + b] & 1);
 		pl->bits[i] = (uint8_t)v;
 	}
-	pl->bits_len = groups;
+	pl->len->bits_len = groups;
 
 	/* payload symbols (nhw_encoder.c:1620-1631, 1751-1763); symbols behind payload_len read as 0 */
 	groups = (payload_len >> 3) + 1;
-	pl->word_len = 0;
+	pl->len->word_len = 0;
 	for (i = 0; i < groups; i++) {
 		int b, sym[8];
 		for (b = 0; b < 8; b++) sym[b] = (8 * i + b < payload_len) ? payload[8 * i + b] : 0;
 		if (word_mode == 2) {
-			pl->word[pl->word_len++] = (uint8_t)(((sym[0] & 3) << 6) | ((sym[1] & 3) << 4) | ((sym[2] & 3) << 2) | (sym[3] & 3));
-			pl->word[pl->word_len++] = (uint8_t)(((sym[4] & 3) << 6) | ((sym[5] & 3) << 4) | ((sym[6] & 3) << 2) | (sym[7] & 3));
+			pl->word[pl->len->word_len++] = (uint8_t)(((sym[0] & 3) << 6) | ((sym[1] & 3) << 4) | ((sym[2] & 3) << 2) | (sym[3] & 3));
+			pl->word[pl->len->word_len++] = (uint8_t)(((sym[4] & 3) << 6) | ((sym[5] & 3) << 4) | ((sym[6] & 3) << 2) | (sym[7] & 3));
 		} else {
 			int v = 0;
 			for (b = 0; b < 8; b++) v = (v << 1) | (sym[b] & 1);
-			pl->word[pl->word_len++] = (uint8_t)v;
+			pl->word[pl->len->word_len++] = (uint8_t)v;
 		}
 	}
 }
@@ -1415,15 +1384,15 @@ again:
 
 	if (part == 0) {
 		int b, w;
-		c->size_data1 = bs->a + 1;
-		c->wavelet_type = (select > 4 || !top_is_zero) ? 4 : 0;            /* :367-368 */
+		c->m->size_data1 = bs->a + 1;
+		c->m->wavelet_type = (select > 4 || !top_is_zero) ? 4 : 0;            /* :367-368 */
 		/* sign bits of the isolated +-8 symbols and of the +-8 pairs (:370-398) */
 		b = (n1 >> 3) + 1;
 		for (i = 0; i < b; i++) { int t, v = 0; for (t = 0; t < 8; t++) v = (v << 1) | ((8 * i + t < n1 ? s1[8 * i + t] : 0) & 1); c->sel_word1[i] = (uint8_t)v; }
-		c->select1 = b;
+		c->m->select1 = b;
 		b = (n2 >> 3) + 1;
 		for (i = 0; i < b; i++) { int t, v = 0; for (t = 0; t < 8; t++) v = (v << 1) | ((8 * i + t < n2 ? s2[8 * i + t] : 0) & 1); c->sel_word2[i] = (uint8_t)v; }
-		c->select2 = b;
+		c->m->select2 = b;
 
 		/* code book 1: symbols, a run entry is (3, length); de-interleave even/odd positions and
 		 * collapse consecutive 3s into (3, count) (:400-424) */
@@ -1439,15 +1408,15 @@ again:
 			if (b > 0) { c->book1[w++] = 3; c->book1[w++] = (uint8_t)b; b = 0; i--; }
 			else c->book1[w++] = tmp_book[i];
 		}
-		c->size_book1 = w;
+		c->m->size_book1 = w;
 	} else {
 		int b, w;
-		c->size_data2 = bs->a + 1;
+		c->m->size_data2 = bs->a + 1;
 		for (i = 0, e = 0; i < k; i++) {                                   /* :431-459 */
 			if ((entry[i] >> 8) == 1) c->book2[e++] = (uint8_t)((entry[i] & 0xFF) | 1);
 			else { c->book2[e++] = (uint8_t)(entry[i] & 0xFF); c->book2[e++] = (uint8_t)(entry[i] >> 8); }
 		}
-		c->tree_end = e;
+		c->m->tree_end = e;
 		for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = c->book2[i];
 		for (i = 1; i < e; i += 2) tmp_book[b++] = c->book2[i];
 		tmp_book[e] = 0;
@@ -1456,7 +1425,7 @@ again:
 			if (b > 0) { c->book2[w++] = 128; c->book2[w++] = (uint8_t)b; b = 0; i--; }
 			else c->book2[w++] = tmp_book[i];
 		}
-		c->size_book2 = w;
+		c->m->size_book2 = w;
 	}
 	return NHW_OK;
 }
@@ -1546,7 +1515,7 @@ DEV void hq_settings(Ctx *c)
 			else if (hs[i] == 32500) c->qsetting3[nq++] = (uint32_t)(i << 1) + 1;
 		}
 	}
-	c->qsetting3_len = nq;
+	c->m->qsetting3_len = nq;
 	for (r = 0; r < H; r++)                                    /* :571-610 */
 		for (j = 0; j < W; j++) {
 			const int at = r * W + j;
@@ -1563,7 +1532,7 @@ DEV void hq_settings(Ctx *c)
 			else if (hs[at] == 30000) { raw[n++] = (uint8_t)(j & 255); pay[e++] = 0; }
 			else if (hs[at] == 31000) { raw[n++] = (uint8_t)(j & 255); pay[e++] = 1; }
 		}
-	c->char_res1_len = nc;
+	c->m->char_res1_len = nc;
 	poslist_finish(c, &c->res6, raw, n, pay, e, 1);
 }
 
@@ -1589,37 +1558,37 @@ DEV size_t container(Ctx *c, uint8_t *out, size_t cap)
 	const int q = c->q;
 	uint8_t b;
 	int i;
-	b = (uint8_t)(c->res_high + c->wavelet_type); put(&s, &b, 1);
+	b = (uint8_t)(c->m->res_high + c->m->wavelet_type); put(&s, &b, 1);
 	b = (uint8_t)q; put(&s, &b, 1);
-	put16(&s, (unsigned)c->size_book1); put16(&s, (unsigned)c->size_book2);
-	put32(&s, (uint32_t)c->size_data1); put32(&s, (uint32_t)c->size_data2);
-	put16(&s, (unsigned)c->tree_end); put16(&s, (unsigned)c->exw_len);
-	if (q > 12) put16(&s, (unsigned)c->res1.list_len);
-	if (q >= 19) { put16(&s, (unsigned)c->res3.list_len); put16(&s, (unsigned)c->res3.bits_len); }
-	if (q > 17) put16(&s, (unsigned)c->res4_len);
-	if (q > 12) put16(&s, (unsigned)c->res1.bits_len);
-	if (q >= 21) { put16(&s, (unsigned)c->res5.list_len); put16(&s, (unsigned)c->res5.bits_len); }
-	if (q > 21) { put32(&s, (uint32_t)c->res6.list_len); put16(&s, (unsigned)c->res6.bits_len); put16(&s, (unsigned)c->char_res1_len); }
-	if (q > 22) put16(&s, (unsigned)c->qsetting3_len);
-	put16(&s, (unsigned)c->select1); put16(&s, (unsigned)c->select2);
-	if (q > 15) put16(&s, (unsigned)c->ll_word_len);
-	put16(&s, (unsigned)c->ch_res_len);
+	put16(&s, (unsigned)c->m->size_book1); put16(&s, (unsigned)c->m->size_book2);
+	put32(&s, (uint32_t)c->m->size_data1); put32(&s, (uint32_t)c->m->size_data2);
+	put16(&s, (unsigned)c->m->tree_end); put16(&s, (unsigned)c->m->exw_len);
+	if (q > 12) put16(&s, (unsigned)c->res1.len->list_len);
+	if (q >= 19) { put16(&s, (unsigned)c->res3.len->list_len); put16(&s, (unsigned)c->res3.len->bits_len); }
+	if (q > 17) put16(&s, (unsigned)c->m->res4_len);
+	if (q > 12) put16(&s, (unsigned)c->res1.len->bits_len);
+	if (q >= 21) { put16(&s, (unsigned)c->res5.len->list_len); put16(&s, (unsigned)c->res5.len->bits_len); }
+	if (q > 21) { put32(&s, (uint32_t)c->res6.len->list_len); put16(&s, (unsigned)c->res6.len->bits_len); put16(&s, (unsigned)c->m->char_res1_len); }
+	if (q > 22) put16(&s, (unsigned)c->m->qsetting3_len);
+	put16(&s, (unsigned)c->m->select1); put16(&s, (unsigned)c->m->select2);
+	if (q > 15) put16(&s, (unsigned)c->m->ll_word_len);
+	put16(&s, (unsigned)c->m->ch_res_len);
 
-	put(&s, c->book1, (size_t)c->size_book1); put(&s, c->book2, (size_t)c->size_book2);
-	put(&s, c->exw, (size_t)c->exw_len);
-	if (q > 12) { put(&s, c->res1.list, (size_t)c->res1.list_len); put(&s, c->res1.bits, (size_t)c->res1.bits_len); put(&s, c->res1.word, (size_t)c->res1.word_len); }
-	if (q > 17) put(&s, c->res4, (size_t)c->res4_len);
-	if (q >= 19) { put(&s, c->res3.list, (size_t)c->res3.list_len); put(&s, c->res3.bits, (size_t)c->res3.bits_len); put(&s, c->res3.word, (size_t)c->res3.word_len); }
-	if (q >= 21) { put(&s, c->res5.list, (size_t)c->res5.list_len); put(&s, c->res5.bits, (size_t)c->res5.bits_len); put(&s, c->res5.word, (size_t)c->res5.word_len); }
+	put(&s, c->book1, (size_t)c->m->size_book1); put(&s, c->book2, (size_t)c->m->size_book2);
+	put(&s, c->exw, (size_t)c->m->exw_len);
+	if (q > 12) { put(&s, c->res1.list, (size_t)c->res1.len->list_len); put(&s, c->res1.bits, (size_t)c->res1.len->bits_len); put(&s, c->res1.word, (size_t)c->res1.len->word_len); }
+	if (q > 17) put(&s, c->res4, (size_t)c->m->res4_len);
+	if (q >= 19) { put(&s, c->res3.list, (size_t)c->res3.len->list_len); put(&s, c->res3.bits, (size_t)c->res3.len->bits_len); put(&s, c->res3.word, (size_t)c->res3.len->word_len); }
+	if (q >= 21) { put(&s, c->res5.list, (size_t)c->res5.len->list_len); put(&s, c->res5.bits, (size_t)c->res5.len->bits_len); put(&s, c->res5.word, (size_t)c->res5.len->word_len); }
 	if (q > 21) {
-		put(&s, c->res6.list, (size_t)c->res6.list_len); put(&s, c->res6.bits, (size_t)c->res6.bits_len); put(&s, c->res6.word, (size_t)c->res6.word_len);
-		for (i = 0; i < c->char_res1_len; i++) put16(&s, c->char_res1[i]);
+		put(&s, c->res6.list, (size_t)c->res6.len->list_len); put(&s, c->res6.bits, (size_t)c->res6.len->bits_len); put(&s, c->res6.word, (size_t)c->res6.len->word_len);
+		for (i = 0; i < c->m->char_res1_len; i++) put16(&s, c->char_res1[i]);
 	}
-	if (q > 22) for (i = 0; i < c->qsetting3_len; i++) put32(&s, c->qsetting3[i]);
-	put(&s, c->sel_word1, (size_t)c->select1); put(&s, c->sel_word2, (size_t)c->select2);
-	if (q > 15) { put(&s, c->res_u64, 2 * H); put(&s, c->res_v64, 2 * H); put(&s, c->ll_word, (size_t)c->ll_word_len); }
-	put(&s, c->ch_res, (size_t)c->ch_res_len);
-	for (i = 0; i < c->size_data2; i++) put32(&s, c->packet[i]);
+	if (q > 22) for (i = 0; i < c->m->qsetting3_len; i++) put32(&s, c->qsetting3[i]);
+	put(&s, c->sel_word1, (size_t)c->m->select1); put(&s, c->sel_word2, (size_t)c->m->select2);
+	if (q > 15) { put(&s, c->res_u64, 2 * H); put(&s, c->res_v64, 2 * H); put(&s, c->ll_word, (size_t)c->m->ll_word_len); }
+	put(&s, c->ch_res, (size_t)c->m->ch_res_len);
+	for (i = 0; i < c->m->size_data2; i++) put32(&s, c->packet[i]);
 	return s.ovf ? 0 : s.n;
 }
 
@@ -1749,17 +1718,17 @@ DEV void chroma_p5(Ctx *c, int comp)
 	}
 	for (r = 0; r < H / 2; r++) memcpy(p + r * H, c->cl2save + r * (H / 2), sizeof(int16_t) * (H / 2));  /* :2431-2439 */
 
-	c->exw[c->exw_len++] = 0; c->exw[c->exw_len++] = 0;          /* :2489 (U), :2770 (V) */
+	c->exw[c->m->exw_len++] = 0; c->exw[c->m->exw_len++] = 0;          /* :2489 (U), :2770 (V) */
 	a = comp ? (Q >> 2) + (Q >> 4) : (Q >> 2);
 	for (r = 0; r < H / 4; r++)                                   /* :2491-2525 LL2 emission */
 		for (j = 0; j < H / 4; j++) {
 			int s = p[r * H + j];
 			if ((s > 255 || s < 0) && (j > 0 || r > 0)) {
 				int mag;
-				c->exw[c->exw_len++] = (uint8_t)r;
-				if (s > 255) { c->exw[c->exw_len++] = (uint8_t)(j + 128); mag = s - 255; }
-				else { c->exw[c->exw_len++] = (uint8_t)j; mag = -s; }
-				c->exw[c->exw_len++] = (uint8_t)(mag > 255 ? 255 : mag);
+				c->exw[c->m->exw_len++] = (uint8_t)r;
+				if (s > 255) { c->exw[c->m->exw_len++] = (uint8_t)(j + 128); mag = s - 255; }
+				else { c->exw[c->m->exw_len++] = (uint8_t)j; mag = -s; }
+				c->exw[c->m->exw_len++] = (uint8_t)(mag > 255 ? 255 : mag);
 				c->ll_bytes[a] = c->ll_bytes[a - 1]; a++;
 			} else {
 				if (s > 255) s = 255; else if (s < 0) s = 0;

@@ -26,12 +26,10 @@ enum {
 };
 
 /* scalar per-image state (reference encode_state / codec_setup scalars), one struct per image in B_META */
+struct NhwPosLens { int list_len, bits_len, word_len; };
 struct NhwMeta {
 	int exw_len, res4_len;
-	int r1_list, r1_bits, r1_word;
-	int r3_list, r3_bits, r3_word;
-	int r5_list, r5_bits, r5_word;
-	int r6_list, r6_bits, r6_word;
+	NhwPosLens r1, r3, r5, r6;
 	int char_res1_len, qsetting3_len;
 	int ll_comp_y_len, ll_word_len, ll_mem_len, ch_res_len;
 	int res_low, res_high, wavelet_type;
