@@ -12,25 +12,22 @@ template <int PH>
 __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status)
 {
 	__shared__ int sh_counts[2];
+	__shared__ int sh_pos[2 * NT + 2];
+	__shared__ PackShared sh_pack;
 	const int img = blockIdx.x, tid = threadIdx.x;
 	Ctx c;
 	ctx_load(&c, ws, img);
-	if (PH == PH_L1) luma_p1_par(&c, tid);
+	if (PH == PH_L1) luma_p1_par(&c, tid, sh_pos);
 	else if (PH == PH_L2) luma_p2_par(&c, tid);
-	else if (PH == PH_L3) luma_p3_par(&c, tid);
-	else if (PH == PH_L4) luma_p4_par(&c, tid, sh_counts);
+	else if (PH == PH_L3) luma_p3_par(&c, tid, sh_pos, sh_counts);
+	else if (PH == PH_L4) luma_p4_par(&c, tid, sh_counts, sh_pos);
 	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
 	else if (PH == PH_C2) dequant_sim_chroma_par(&c, 1, tid);
 	else if (PH == PH_C3) chroma_p3_par(&c, comp, tid);
 	else if (PH == PH_C4) dequant_sim_chroma_par(&c, 0, tid);
 	else if (PH == PH_C5) chroma_p5_par(&c, comp, tid);
 	else if (PH == PH_FINAL) {
-		if (tid == 0) {
-			uint32_t sz = 0;
-			const int rc = final_phase(&c, out + (size_t)img * (512u << 10), 512u << 10, &sz);
-			sizes[img] = sz;
-			status[img] = rc;
-		}
+		final_phase_par(&c, out + (size_t)img * (512u << 10), 512u << 10, &sizes[img], &status[img], &sh_pack, tid);
 	}
 }
 

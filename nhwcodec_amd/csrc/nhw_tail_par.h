@@ -138,12 +138,125 @@ DEV void dequant_row(int16_t *p, int16_t *jp, int r, int col0, int part)
 	}
 }
 
+/* ---------------------------------------------------------------- skewed row wavefront for the raster-serial passes */
+/* Three passes write into the row below while they walk a row (triple / vertical-pair marking in the dequantiser
+ * simulation and in the quantiser, the LL2 walks that bump the sample below).  In raster order row r+1 starts
+ * after row r has finished; all that row r+1 needs at column j, though, is that row r is done with columns
+ * <= j+2 (row r writes (r+1, x-1), (r+1, x) at column x, resp. (r+1, x)), and row r at column x only reads row
+ * r+1 at columns >= x-1, which a row lagging >= 3 columns has not touched yet.  So one thread per row, each row
+ * keeps >= 3 columns behind the row above, all rows advance together: ~(columns + 3 x rows) steps instead of
+ * rows x columns.  Steps are separated by workgroup barriers (global writes of a step are visible to the
+ * other rows in the next one). */
+#define WF_INF 0x3fffffff
+template <typename Step>
+DEV void wavefront_rows(int nrows, int tid, int *pos /* shared [NT + 1] */, Step step)
+{
+	const int r = tid;
+	int j = r < nrows ? step.first(r) : WF_INF;
+	const int jend = r < nrows ? step.last(r) : 0;
+	if (j >= jend) j = WF_INF;
+	if (tid == 0) pos[0] = WF_INF;
+	pos[r + 1] = j;
+	BARRIER();
+	for (;;) {
+		if (j != WF_INF && pos[r] >= j + 3) { j = step.run(r, j); if (j >= jend) j = WF_INF; }
+		BARRIER();
+		pos[r + 1] = j;
+		if (!__syncthreads_or(j != WF_INF)) break;
+	}
+}
+
+/* dequantiser simulation: triple / vertical pair marking (image_processing.c:2759-2853), rows 0..254 */
+struct MarkRunsStep {
+	int16_t *p, *jp;
+	__device__ int first(int r) const { return r < H / 2 ? H / 2 + 1 : 1; }
+	__device__ int last(int) const { return H - 1; }
+	__device__ int run(int r, int j) const
+	{
+		const int a = r * W + j;
+		if (p[a] > 3 && p[a] < 8) {
+			if (in_4_7(p[a - 1])) {
+				if (in_4_7(p[a + 1])) { p[a - 1] = 15300; p[a] = 0; jp[a] = 5; jp[a + 1] = 5; j++; }
+				else if (in_4_7(p[a + W - 1]) && in_4_7(p[a + W])) { p[a - 1] = 15500; jp[a] = 5; p[a + W - 1] = 15500; jp[a + W] = 5; p[a + W] = 0; j++; }
+			}
+		} else if (p[a] < -3 && p[a] > -8) {
+			if (in_m7_m4(p[a - 1])) {
+				if (in_m7_m4(p[a + 1])) { p[a - 1] = 15400; p[a] = 0; jp[a] = -6; jp[a + 1] = -5; j++; }
+				else if (in_m7_m4(p[a + W - 1]) && in_m7_m4(p[a + W])) { p[a - 1] = 15600; jp[a] = -5; p[a + W - 1] = 15600; jp[a + W] = -5; p[a + W] = 0; j++; }
+			}
+		}
+		return j + 1;
+	}
+};
+
+/* quantiser: the same marking with the quantiser's codes (image_processing.c:241-284), rows 0..255 */
+struct QuantMarkStep {
+	int16_t *p;
+	__device__ int first(int) const { return 1; }
+	__device__ int last(int) const { return H - 1; }
+	__device__ int run(int r, int j) const
+	{
+		const int a = r * W + j;
+		if (p[a] > 3 && p[a] < 8) {
+			if (in_4_7(p[a - 1])) {
+				if (in_4_7(p[a + 1])) { p[a] = 12700; p[a - 1] = 10100; j++; }
+				else if (in_4_7(p[a + W - 1]) && in_4_7(p[a + W])) { p[a - 1] = 12100; p[a] = 10100; p[a + W - 1] = 10100; p[a + W] = 10100; j++; }
+			}
+		} else if (p[a] < -3 && p[a] > -8) {
+			if (in_m7_m4(p[a - 1])) {
+				if (in_m7_m4(p[a + 1])) { p[a] = 12900; p[a - 1] = 10100; j++; }
+				else if (in_m7_m4(p[a + W - 1]) && in_m7_m4(p[a + W])) { p[a - 1] = 12200; p[a] = 10100; p[a + W - 1] = 10100; p[a + W] = 10100; j++; }
+			}
+		}
+		return j + 1;
+	}
+};
+
+/* the LL2 walk shared by the dequantiser simulation (image_processing.c:2642-2695) and the LL2 emission
+ * (nhw_encoder.c:661-741): three odd samples in a row bump the middle one, an odd L-shaped group bumps the
+ * sample below.  EMIT: also park the sample value for the output pass and clear the cell. */
+template <int EMIT>
+struct LL2Step {
+	int16_t *p, *jp, *park;
+	int q, part;
+	__device__ int first(int) const { return 0; }
+	__device__ int last(int) const { return H / 2; }
+	__device__ int run(int r, int j) const
+	{
+		const int a = r * W + j;
+		const int s = p[a];
+		bool tagged = false;
+		if (EMIT) tagged = q > 17 && s > 10000;
+		else if (s > 10000) {
+			if (!part) jp[a] = p[a];
+			else {
+				p[a] -= 16000; jp[a] = p[a];
+				jp[a + 1] = (p[a + 1] > 0 && p[a + 1] < 256) ? clear_bit0(p[a + 1]) : p[a + 1];
+				j++;
+			}
+			return j + 1;
+		}
+		if (!tagged) {
+			if (odd(s) && j > 0 && odd(p[a + 1])) {
+				if (j < H / 2 - 2 && odd(p[a + 2])) { if (iabs(s - p[a + 2]) > 1 && q > 17) p[a + 1]++; }
+				else if (r * W < Q - W - 2 && odd(p[a + W]) && odd(p[a + W + 1]) && !(p[a + W + 2] & 1)) { if (p[a + W] < 10000 && q > 17) p[a + W]++; }
+			}
+			else if (odd(s) && r >= 1 && r * W < Q - 3 * W) {
+				if (odd(p[a + W]) && odd(p[a + W + 1]) && odd(p[a + 2 * W]) && !(p[a + 3 * W] & 1)) { if (p[a + W] < 10000 && q > 17) p[a + W]++; }
+			}
+		}
+		if (EMIT) { park[r * (H / 2) + j] = (int16_t)s; p[a] = 0; }
+		else if (part) jp[a] = (p[a] > 0 && p[a] < 256) ? clear_bit0(p[a]) : p[a];
+		return j + 1;
+	}
+};
+
 /* offsetY_recons256 (image_processing.c:2600-3190).  Raster-serial pieces (the LL2 walk that bumps the sample
  * below, the triple / vertical-pair marking that writes into the next row) stay on thread 0; everything whose
  * reach is one row runs one row per thread; the isolated-coefficient shrink is pointwise: a coefficient >= 8
  * next to another one >= 8 keeps both from shrinking, so decisions taken on the untouched plane equal the
  * reference's raster-order decisions. */
-DEV void dequant_sim_luma_par(Ctx *c, int part, int tid)
+DEV void dequant_sim_luma_par(Ctx *c, int part, int tid, int *pos)
 {
 	int16_t *p = c->proc, *jp = c->jpeg;
 	const int q = c->q;
@@ -160,32 +273,9 @@ DEV void dequant_sim_luma_par(Ctx *c, int part, int tid)
 		}
 	}
 	BARRIER();
-	if (tid == 0) {                                    /* :2642-2695 (G: writes the sample below) */
-		for (int r = 0; r < H / 2; r++)
-			for (int j = 0; j < H / 2; j++) {
-				int a = r * W + j;
-				if (p[a] > 10000) {
-					if (!part) jp[a] = p[a];
-					else {
-						p[a] -= 16000; jp[a] = p[a];
-						jp[a + 1] = (p[a + 1] > 0 && p[a + 1] < 256) ? clear_bit0(p[a + 1]) : p[a + 1];
-						j++;
-					}
-					continue;
-				}
-				else if (odd(p[a]) && j > 0 && odd(p[a + 1])) {
-					if (j < H / 2 - 2 && odd(p[a + 2])) { if (iabs(p[a] - p[a + 2]) > 1 && q > 17) p[a + 1]++; }
-					else if (r * W < Q - W - 2 && odd(p[a + W]) && odd(p[a + W + 1]) && !(p[a + W + 2] & 1)) {
-						if (p[a + W] < 10000 && q > 17) p[a + W]++;
-					}
-				}
-				else if (odd(p[a]) && r >= 1 && r * W < Q - 3 * W) {
-					if (odd(p[a + W]) && odd(p[a + W + 1]) && odd(p[a + 2 * W]) && !(p[a + 3 * W] & 1)) {
-						if (p[a + W] < 10000 && q > 17) p[a + W]++;
-					}
-				}
-				if (part) jp[a] = (p[a] > 0 && p[a] < 256) ? clear_bit0(p[a]) : p[a];
-			}
+	{                                                  /* :2642-2695 (wavefront) */
+		LL2Step<0> st = { p, jp, nullptr, q, part };
+		wavefront_rows(H / 2, tid, pos, st);
 	}
 	BARRIER();
 	if (!part) {                                       /* :2697-2735 (P) */
@@ -203,9 +293,9 @@ DEV void dequant_sim_luma_par(Ctx *c, int part, int tid)
 		}
 		BARRIER();
 	}
-	if (tid == 0) {                                    /* :2759-2853 (G: marks cells of the next row) */
-		mark_small_runs(p, jp, 0, H / 2, H / 2 + 1);
-		mark_small_runs(p, jp, H / 2, H - 1, 1);
+	{                                                  /* :2759-2853 (wavefront) */
+		MarkRunsStep st = { p, jp };
+		wavefront_rows(H - 1, tid, pos, st);
 	}
 	BARRIER();
 	{
@@ -541,27 +631,14 @@ DEV void quant_code_row(int16_t *p, int r, int next_first)   /* image_processing
 /* offsetY.  Loops 1, 3, 4 reach at most two cells ahead in their own row (the one unguarded look at the first
  * cell of the next row, :389, is served from a value read before any row is rewritten); loop 2 marks cells of
  * the next row and stays serial for now. */
-DEV void quantise_luma_par(Ctx *c, int tid)
+DEV void quantise_luma_par(Ctx *c, int tid, int *pos)
 {
 	int16_t *p = c->proc;
 	quant_pairs_row(p, tid); quant_pairs_row(p, tid + H);
 	BARRIER();
-	if (tid == 0) {
-		for (int r = 0; r < H; r++)                    /* :241-284 (G) */
-			for (int j = 1; j < H - 1; j++) {
-				const int a = r * W + j;
-				if (p[a] > 3 && p[a] < 8) {
-					if (in_4_7(p[a - 1])) {
-						if (in_4_7(p[a + 1])) { p[a] = 12700; p[a - 1] = 10100; j++; }
-						else if (in_4_7(p[a + W - 1]) && in_4_7(p[a + W])) { p[a - 1] = 12100; p[a] = 10100; p[a + W - 1] = 10100; p[a + W] = 10100; j++; }
-					}
-				} else if (p[a] < -3 && p[a] > -8) {
-					if (in_m7_m4(p[a - 1])) {
-						if (in_m7_m4(p[a + 1])) { p[a] = 12900; p[a - 1] = 10100; j++; }
-						else if (in_m7_m4(p[a + W - 1]) && in_m7_m4(p[a + W])) { p[a - 1] = 12200; p[a] = 10100; p[a + W - 1] = 10100; p[a + W] = 10100; j++; }
-					}
-				}
-			}
+	{                                                  /* :241-284 (wavefront) */
+		QuantMarkStep st = { p };
+		wavefront_rows(H, tid, pos, st);
 	}
 	BARRIER();
 	{                                                  /* :286-311 (R) */
@@ -646,24 +723,17 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts)
 	if (tid == 0) { sh_counts[0] = 0; sh_counts[1] = 0; }
 	BARRIER();
 
-	const int per = n / NT, lo = tid * per, hi = lo + per;         /* 1024 stream positions per thread */
-	{
-		bool sel[4];
-		for (int k = 0; k < 4; k++) {                              /* selected(lo-4+k) by walking its chain back */
-			int cpos = lo - 4 + k, m = 0;
-			while (pair_cand(s, cpos, n)) { m++; cpos -= 4; }
-			sel[(lo + k) & 3] = (m & 1) != 0;
-		}
-		uint32_t word = 0;
-		for (int cpos = lo; cpos < hi; cpos++) {
-			const bool take = pair_cand(s, cpos, n) && !sel[cpos & 3];
-			sel[cpos & 3] = take;
-			if (take) word |= 1u << (cpos & 31);
-			if ((cpos & 31) == 31) { bits[cpos >> 5] = word; word = 0; }
-		}
+	/* every loop below strides over stream positions thread-by-thread, so a wavefront reads consecutive bytes */
+	for (int w = tid; w < n / 32; w += NT) bits[w] = 0;
+	BARRIER();
+	for (int cpos = tid; cpos <= n - 5; cpos += NT) {              /* rewrite 1, selection */
+		if (!is_pm8(s[cpos]) || !pair_cand(s, cpos, n)) continue;
+		int m = 1, back = cpos - 4;
+		while (pair_cand(s, back, n)) { m++; back -= 4; }
+		if (m & 1) atomicOr(&bits[cpos >> 5], 1u << (cpos & 31));
 	}
 	BARRIER();
-	for (int w = lo >> 5; w < (hi >> 5); w++) {
+	for (int w = tid; w < n / 32; w += NT) {                       /* rewrite 1, application */
 		uint32_t word = bits[w];
 		while (word) {
 			const int cpos = (w << 5) + __ffs((int)word) - 1;
@@ -679,7 +749,7 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts)
 
 	{                                                              /* rewrite 2 */
 		int n1 = 0, n2 = 0;
-		for (int i = (lo < 4 ? 4 : lo); i < (hi > n - 4 ? n - 4 : hi); i++) {
+		for (int i = 4 + tid; i < n - 4; i += NT) {
 			if (!is_pm8(s[i])) continue;
 			const bool before4 = s[i - 1] == 128 && s[i - 2] == 128 && s[i - 3] == 128 && s[i - 4] == 128;
 			if (i > 4 && is_pm8(s[i - 1])) {                       /* did the left neighbour take me as the second of a pair? */
@@ -701,13 +771,9 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts)
 	BARRIER();
 	if (tid == 0) { c->m->select1 = sh_counts[0]; c->m->select2 = sh_counts[1]; }
 
-	for (int i = lo; i < hi; i++) {                                /* rewrite 3 */
-		if (s[i] != 128 || s[i + 1] != 128) continue;
-		if (i > 0 && s[i - 1] == 128) {                            /* inside a run that started earlier: its owner handles it */
-			if (i == lo) { while (i < n && s[i] == 128) i++; i--; }
-			continue;
-		}
-		int b = i;
+	for (int i = tid; i < n; i += NT) {                            /* rewrite 3: owners of run starts */
+		if (s[i] != 128 || s[i + 1] != 128 || (i > 0 && s[i - 1] == 128)) continue;
+		int b = i + 1;
 		while (s[b + 1] == 128) b++;                               /* run [i, b]; s[n] is 0 */
 		if (b - i >= 252) {                                        /* replay the reference's walk over this run */
 			int k = i, run = 0;
@@ -718,10 +784,10 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts)
 			}
 			if (run >= 252) fix_sign_code(s, k + 1);
 		}
-		i = b;
 	}
 	BARRIER();
 }
+
 
 
 /* ---------------------------------------------------------------- chroma pieces */
@@ -757,14 +823,140 @@ DEV void dequant_sim_chroma_par(Ctx *c, int comp, int tid)
 	if (tid < H / 2) dequant_row_chroma(p, jp, tid, tid < H / 4 ? H / 4 : 0, comp);
 }
 
+/* Y14 + Y15 (nhw_encoder.c:636-741): tag rows of four odd samples (R), walk the LL2 band (wavefront), then turn
+ * the parked samples into the byte plane, the res4 lists (per row, prefix-summed) and the escape triples.
+ * Escapes (samples outside 0..255) make a byte repeat its predecessor, which is a serial chain: they are rare,
+ * thread 0 replays the band only if one occurred. */
+DEV void emit_ll2_par(Ctx *c, int tid, int *pos, int *sh_misc)
+{
+	int16_t *p = c->proc;
+	const int q = c->q;
+	int my_n = 0;
+	if (q > 17 && tid < H / 2) {                                  /* tag_res4, one row per thread */
+		const int r = tid;
+		int hit = 0;
+		for (int j = 0; j < H / 2 - 3; j++) {
+			const int a = r * W + j;
+			if (odd(p[a]) && odd(p[a + 1]) && odd(p[a + 2]) && odd(p[a + 3]) && iabs(p[a] - p[a + 3]) > 1) {
+				p[a] += 24000; p[a + 1] += 16000; p[a + 2] += 16000; p[a + 3] += 16000;
+				hit++; j += 3;
+			}
+		}
+		my_n = hit ? hit : 1;
+	}
+	if (tid == 0) sh_misc[0] = 0;
+	BARRIER();
+	LL2Step<1> st = { p, c->jpeg, c->tmp16, q, 0 };
+	wavefront_rows(H / 2, tid, pos, st);
+	BARRIER();
+	pos[tid] = my_n;                                             /* res4 offsets: exclusive scan of the per-row counts */
+	BARRIER();
+	if (tid == 0) { int acc = 0; for (int t = 0; t < H / 2; t++) { const int v = pos[t]; pos[t] = acc; acc += v; } c->m->res4_len = q > 17 ? acc : 0; }
+	BARRIER();
+	if (tid < H / 2) {
+		const int r = tid;
+		int o4 = pos[r], hit = 0, esc = 0;
+		for (int j = 0; j < H / 2; j++) {
+			int s = c->tmp16[r * (H / 2) + j];
+			const int a = r * (H / 2) + j;
+			if (q > 17 && s > 10000) {
+				if (s > 20000) { s -= 24000; c->res4[o4++] = (uint8_t)(j + 1); hit++; }
+				else s -= 16000;
+				c->tmp16[a] = (int16_t)s;                         /* the replay below wants the plain value */
+			}
+			if ((s > 255 || s < 0) && (j > 0 || r > 0)) esc++;
+			else { if (s > 255) s = 255; else if (s < 0) s = 0; c->ll_full[a] = (uint8_t)s; c->ll_bytes[a] = (uint8_t)(s & 254); }
+		}
+		if (q > 17) { if (!hit) c->res4[o4] = 128; else c->res4[o4 - 1] += 128; }
+		if (esc) atomicAdd(&sh_misc[0], esc);
+	}
+	BARRIER();
+	if (tid == 0) {
+		int e = 0;
+		if (sh_misc[0]) {
+			for (int a = 1; a < Q / 4; a++) {
+				const int s = c->tmp16[a];
+				if (s > 255 || s < 0) {
+					int mag;
+					c->exw[e++] = (uint8_t)(a >> 7);
+					if (s > 255) { c->exw[e++] = (uint8_t)((a & 127) + 128); mag = s - 255; }
+					else { c->exw[e++] = (uint8_t)(a & 127); mag = -s; }
+					c->exw[e++] = (uint8_t)(mag > 255 ? 255 : mag);
+					c->ll_bytes[a] = c->ll_bytes[a - 1]; c->ll_full[a] = c->ll_bytes[a - 1];
+				}
+			}
+		}
+		c->m->exw_len = e;
+	}
+	BARRIER();
+}
+
+/* Y25 (nhw_encoder.c:1498-1887): the three compaction sweeps over the code plane run one row per thread (count,
+ * prefix, write); packing the (short) lists stays on thread 0 */
+DEV void build_poslists_par(Ctx *c, int tid, int *pos)
+{
+	int16_t *o = c->ll1;
+	uint8_t *raw = c->raw, *pay = c->pay;
+	int *off_raw = pos, *off_pay = pos + NT + 1;                  /* shared [2 * NT + 2] */
+	for (int pass = 0; pass < 3; pass++) {
+		if ((pass == 1 && c->q < 19) || (pass == 2 && c->q < 21)) continue;
+		const int r = tid;
+		int nr = 1, np = 0;                                       /* the row marker at column 254 */
+		for (int j = 0; j < H - 2; j++) {
+			const int v = o[r * H + j];
+			const bool take = pass == 0 ? (v == 141 || v == 140 || v == 126 || v == 125 || v == 148 || v == 149)
+			                : pass == 1 ? (v >= 121 && v <= 124) : (v == 144 || v == 145);
+			if (take) { nr++; np++; }
+		}
+		off_raw[tid] = nr; off_pay[tid] = np;
+		BARRIER();
+		if (tid == 0) {
+			int a = 0, b = 0;
+			for (int t = 0; t < NT; t++) { const int x = off_raw[t], y = off_pay[t]; off_raw[t] = a; off_pay[t] = b; a += x; b += y; }
+			off_raw[NT] = a; off_pay[NT] = b;
+		}
+		BARRIER();
+		int n = off_raw[tid], e = off_pay[tid];
+		for (int j = 0; j < H - 2; j++) {
+			int16_t *cell = o + r * H + j;
+			if (pass == 0) {
+				switch (*cell) {
+				case 141: raw[n++] = (uint8_t)j; *cell = 0;   pay[e++] = 1; break;
+				case 140: raw[n++] = (uint8_t)j; *cell = 0;   pay[e++] = 0; break;
+				case 126: raw[n++] = (uint8_t)j; *cell = 122; pay[e++] = 0; break;
+				case 125: raw[n++] = (uint8_t)j; *cell = 121; pay[e++] = 1; break;
+				case 148: raw[n++] = (uint8_t)j; *cell = 144; pay[e++] = 1; break;
+				case 149: raw[n++] = (uint8_t)j; *cell = 145; pay[e++] = 0; break;
+				default: break;
+				}
+			} else if (pass == 1) {
+				switch (*cell) {
+				case 121: raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 1; break;
+				case 122: raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 0; break;
+				case 123: raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 2; break;
+				case 124: raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 3; break;
+				default: break;
+				}
+			} else {
+				if (*cell == 144) { raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 1; }
+				else if (*cell == 145) { raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 0; }
+			}
+		}
+		o[r * H + H - 2] = 0; o[r * H + H - 1] = 0; raw[n++] = H - 2;
+		BARRIER();
+		if (tid == 0) poslist_finish(c, pass == 0 ? &c->res1 : pass == 1 ? &c->res3 : &c->res5, raw, off_raw[NT], pay, off_pay[NT], pass == 1 ? 2 : 1);
+		BARRIER();
+	}
+}
+
 /* ---------------------------------------------------------------- phases (256 threads per image) */
-DEV void luma_p1_par(Ctx *c, int tid)
+DEV void luma_p1_par(Ctx *c, int tid, int *pos)
 {
 	PROF_BEGIN();
 	tag_l2_details_par(c, tid);
 	BARRIER();
 	if (!tid) PROF(c, 0);
-	dequant_sim_luma_par(c, 1, tid);
+	dequant_sim_luma_par(c, 1, tid, pos);
 	if (!tid) PROF(c, 1);
 }
 DEV void luma_p2_par(Ctx *c, int tid)
@@ -776,26 +968,22 @@ DEV void luma_p2_par(Ctx *c, int tid)
 	precompensate_ll1_par(c, tid);
 	if (!tid) PROF(c, 3);
 }
-DEV void luma_p3_par(Ctx *c, int tid)
+DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc)
 {
 	PROF_BEGIN();
 	for (int i = (Q >> 2) + tid; i < (Q >> 2) + (Q >> 3) + 64; i += NT) c->ll_bytes[i] = 0;
 	BARRIER();
-	if (tid == 0) {
-		if (c->q > 17) tag_res4(c);
-		emit_ll2(c);
-		PROF(c, 4);
-		ll_code_luma(c);
-		PROF(c, 5);
-	}
+	emit_ll2_par(c, tid, pos, sh_misc);
+	if (!tid) PROF(c, 4);
+	if (tid == 0) { ll_code_luma(c); PROF(c, 5); }
 	BARRIER();
 	copy_block_par(c->l2save, H, c->proc, W, H, H, tid);          /* Y17 :749-755 */
 	BARRIER();
 	if (!tid) PROF(c, 6);
-	dequant_sim_luma_par(c, 0, tid);
+	dequant_sim_luma_par(c, 0, tid, pos);
 	if (!tid) PROF(c, 7);
 }
-DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts)
+DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos)
 {
 	const int q = c->q;
 	PROF_BEGIN();
@@ -820,8 +1008,7 @@ DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts)
 	BARRIER();
 	if (!tid) PROF(c, 11);
 	if (q > 21) adjust_first_order_par(c, tid);                             /* Y24 */
-	if (tid == 0) build_poslists(c);                                        /* Y25 */
-	BARRIER();
+	build_poslists_par(c, tid, pos);                                        /* Y25 */
 	if (!tid) PROF(c, 12);
 	for (int idx = tid; idx < Q; idx += NT) {                               /* Y26 :1893-1910 */
 		const int r = idx >> 8, j = idx & 255;
@@ -832,7 +1019,7 @@ DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts)
 	if (!tid) PROF(c, 13);
 	clean_details_par(c, tid);                                              /* Y27 */
 	if (!tid) PROF(c, 14);
-	quantise_luma_par(c, tid);                                              /* Y28 */
+	quantise_luma_par(c, tid, pos);                                         /* Y28 */
 	if (!tid) PROF(c, 15);
 	if (q > 21 && tid == 0) { band_recons(c); hq_settings(c); }             /* Y29 */
 	BARRIER();
@@ -938,6 +1125,325 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid)
 			s[2 * (strip * (8 * H) + 8 * r + ((r & 1) ? 7 - k : k))] = (uint8_t)p[idx];
 		}
 	}
+}
+
+
+/* ---------------------------------------------------------------- Z2: RLE + VLC packetiser, workgroup-parallel */
+/* (compress_pixel.c:53-469).  The reference's walk turns the symbol stream into tokens: a non-zero symbol, a lone
+ * zero, or a zero run that is cut into pieces of 254 while more than 255 remain.  Every token boundary is a
+ * pure function of the maximal zero run a position sits in, so the stream is cut into 256 slices, each thread
+ * tokenises the slice it owns (tokens belong to the slice their first symbol is in), the code lengths are
+ * prefix-summed and every thread then drops its bits at its own offset (atomicOr into zeroed words; the
+ * reference ORs MSB-first into 32-bit words the same way, :334-345). */
+#define PK_SLICE 64
+#define PK_CHUNK (PK_SLICE * NT)
+struct PackShared {
+	int hist[256], runs[256];
+	unsigned weight[360];
+	uint16_t entry[600];
+	uint16_t rank_sym[256], rank_run[256];
+	unsigned bits[NT], n1[NT], n2[NT];
+	int k, select, zone, top_is_zero, rc;
+	unsigned total_bits, total_n1, total_n2;
+};
+
+DEV bool book_ok(int v) { return v < 109 ? !(v & 1) : (v == 112 || (v >= 120 && v < 141) || (v >= 144 && !(v & 3))); }
+
+/* tokens whose first symbol lies in [lo, hi); N = stream length (the last symbol can only be swallowed by a run).
+ * MODE 0: histogram (every symbol counts, nothing is skipped); MODE 1: count code bits; MODE 2: write code bits */
+template <int MODE>
+DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint32_t *words, unsigned bit0, uint8_t *s1, unsigned i1, uint8_t *s2, unsigned i2,
+                   unsigned *out_bits, unsigned *out_n1, unsigned *out_n2, const int *prevnz, const int *nextnz, int slice)
+{
+	unsigned bits = 0, n1 = 0, n2 = 0;
+	uint32_t cur = 0; int w = (int)(bit0 >> 5), fill = (int)(bit0 & 31);
+	const int select = sh->select, zone = sh->zone;
+#define EMIT(posv) do { int pos_ = (posv), len_; uint32_t code_; \
+		if (pos_ >= 110 && pos_ < 174 && zone) { code_ = (uint32_t)((1 << 6) | (pos_ - 110)); len_ = 15; } \
+		else { if (pos_ >= 174 && zone) pos_ -= 64; code_ = k_vlc[pos_] & 0xFFFFFF; len_ = (int)(k_vlc[pos_] >> 24); } \
+		if (MODE == 1) bits += (unsigned)len_; \
+		else { fill += len_; if (fill <= 32) cur |= code_ << (32 - fill); \
+			else { const int sp_ = fill - 32; atomicOr(&words[w], cur | (code_ >> sp_)); w++; cur = (code_ & ((1u << sp_) - 1)) << (32 - sp_); fill = sp_; } } } while (0)
+	int i = lo;
+	if (MODE != 0)                                   /* am I inside the 4 symbols that follow a 132..135 code? */
+		for (int k = 1; k <= 4; k++) if (lo - k >= 0 && d[lo - k] >= 132 && d[lo - k] <= 135) { i = lo - k + 5; break; }
+	while (i < hi) {
+		const int px = d[i];
+		if (px != 128) {
+			if (MODE == 0) { atomicAdd(&sh->hist[px], 1); i++; continue; }
+			if (px == 153 || px == 155) { if (MODE == 2 && i1 + n1 < S_CAP) s1[i1 + n1] = (uint8_t)(px == 155); n1++; i++; continue; }
+			if (px == 157 || px == 159) { if (MODE == 2 && i2 + n2 < S_CAP) s2[i2 + n2] = (uint8_t)(px == 159); n2++; i++; continue; }
+			EMIT(sh->rank_sym[px]);
+			i += (px > 131 && px < 136) ? 5 : 1;
+			continue;
+		}
+		int a = i, b = i;                            /* maximal zero run [a, b] around i: inside the slice by looking, outside from the tables */
+		if (i == lo && i > 0 && d[i - 1] == 128) a = prevnz[slice] + 1;
+		const int send = (slice + 1) * PK_SLICE < N ? (slice + 1) * PK_SLICE : N;
+		while (b < send - 1 && d[b + 1] == 128) b++;
+		if (b == send - 1 && send < N) b = nextnz[slice + 1] - 1;
+		const int L = b - a + 1;
+		if (L == 1) {
+			if (MODE == 0) atomicAdd(&sh->hist[128], 1); else EMIT(sh->rank_sym[128]);
+		} else {
+			const int m = L > 255 ? (L - 255 + 253) / 254 : 0;       /* pieces of exactly 254 */
+			for (int k = 0; k <= m; k++) {
+				const int t = a + 254 * k;
+				if (t < i || t >= hi) continue;
+				const int len = k < m ? 254 : L - 254 * m;
+				if (MODE == 0) atomicAdd(&sh->runs[len], 1);
+				else if (len < select) { for (int z = 0; z < len; z++) EMIT(sh->rank_sym[128]); }
+				else EMIT(sh->rank_run[len]);
+			}
+		}
+		i = b + 1;
+	}
+	if (MODE == 2 && fill > 0) atomicOr(&words[w], cur);
+	if (MODE == 1) { *out_bits = bits; *out_n1 = n1; *out_n2 = n2; }
+#undef EMIT
+}
+
+/* Slices are 64 consecutive symbols and a workgroup sweeps the stream in chunks of 256 slices (16 KiB), so the
+ * lanes of a wavefront read adjacent cache lines (a thread-per-kilobyte split makes every lane stream its own
+ * line and thrashes L1: measured 5 us per symbol). */
+DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0)
+{
+	const uint8_t *d = c->scan + (part ? 4 * Q : 0);
+	const int N = part ? 2 * Q : 4 * Q;
+	const int S = N - 1, nchunks = (S + PK_CHUNK - 1) / PK_CHUNK;
+	unsigned *cnt = reinterpret_cast<unsigned *>(c->pay);       /* [3][nchunks * NT] per-slice bit / sign-bit counts */
+	const int nsl = nchunks * NT;
+
+	int *prevnz = reinterpret_cast<int *>(c->raw), *nextnz = prevnz + nsl + 8;   /* last non-zero symbol before / first at-or-after a slice */
+
+	PROF_BEGIN();
+	sh->hist[tid] = 0; sh->runs[tid] = 0;
+	if (tid == 0) { sh->select = part ? 3 : 4; sh->zone = 0; sh->rc = NHW_OK; }
+	for (int ch = 0; ch < nchunks; ch++) {                       /* per slice: last / first symbol that is not 128 */
+		const int g = ch * NT + tid, lo = g * PK_SLICE, hi = lo + PK_SLICE < N ? lo + PK_SLICE : N;
+		int last = -1, first = N;
+		for (int i = lo; i < hi; i++) if (d[i] != 128) { last = i; if (first == N) first = i; }
+		prevnz[g] = last; nextnz[g] = first;
+	}
+	BARRIER();
+	{                                                            /* exclusive prefix max / inclusive suffix min over the slices */
+		int *shm = reinterpret_cast<int *>(sh->bits), *shn = reinterpret_cast<int *>(sh->n1);
+		int mx = -1, mn = N;
+		for (int k = 0; k < nchunks; k++) { const int g = tid * nchunks + k; mx = prevnz[g] > mx ? prevnz[g] : mx; mn = nextnz[g] < mn ? nextnz[g] : mn; }
+		shm[tid] = mx; shn[tid] = mn;
+		BARRIER();
+		if (tid == 0) {
+			int run = -1;
+			for (int t = 0; t < NT; t++) { const int v = shm[t]; shm[t] = run; run = v > run ? v : run; }
+			run = N;
+			for (int t = NT - 1; t >= 0; t--) { const int v = shn[t]; shn[t] = run; run = v < run ? v : run; }   /* exclusive of the own block */
+		}
+		BARRIER();
+		int run = shm[tid];
+		for (int k = 0; k < nchunks; k++) { const int g = tid * nchunks + k; const int v = prevnz[g]; prevnz[g] = run; run = v > run ? v : run; }
+		run = shn[tid];
+		for (int k = nchunks - 1; k >= 0; k--) { const int g = tid * nchunks + k; const int v = nextnz[g]; run = v < run ? v : run; nextnz[g] = run; }
+		if (tid == 0) nextnz[nsl] = N;
+	}
+	BARRIER();
+	for (int ch = 0; ch < nchunks; ch++) {
+		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
+		if (lo < S) pack_walk<0>(d, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
+	}
+	BARRIER();
+	if (!tid) PROF(c, 23);
+	if (tid == 0) {                                              /* L_RATIO (:128-236) */
+		int select = sh->select, k;
+		for (;;) {
+			unsigned zeros = sh->hist[128] > 0 ? (unsigned)sh->hist[128] : 0;
+			for (int j = 2; j < 256; j++) if (sh->runs[j] > 0) zeros += (unsigned)(j * sh->runs[j]);
+			for (int j = 2; j < select; j++) sh->runs[j] = 0;
+			for (int j = select; j < 256; j++) if (sh->runs[j] > 0) zeros -= (unsigned)(j * sh->runs[j]);
+			sh->hist[128] = (int)zeros;
+			k = 0;
+			for (int j = select; j < 256; j++) if (sh->runs[j] > 0) { sh->entry[k] = (uint16_t)((j << 8) | 128); sh->weight[k++] = (unsigned)sh->runs[j]; }
+			for (int v = 0; v < 256; v++) if (book_ok(v) && sh->hist[v] > 0) { sh->entry[k] = (uint16_t)((1 << 8) | v); sh->weight[k++] = (unsigned)sh->hist[v]; }
+			if (k <= 354) break;
+			if (++select >= 100) { sh->rc = NHW_E_CODEBOOK; break; }
+		}
+		sh->k = k; sh->select = select;
+	}
+	BARRIER();
+	if (sh->rc) return;
+	{                                                            /* stable descending rank == the reference's bubble sort (:238-252) */
+		const int k = sh->k;
+		for (int e = tid; e < k; e += NT) {
+			const unsigned w = sh->weight[e];
+			int rank = 0;
+			for (int j = 0; j < k; j++) rank += (sh->weight[j] > w) || (sh->weight[j] == w && j < e);
+			const uint16_t en = sh->entry[e];
+			if ((en >> 8) == 1) sh->rank_sym[en & 0xFF] = (uint16_t)rank; else sh->rank_run[en >> 8] = (uint16_t)rank;
+			reinterpret_cast<uint16_t *>(c->hist)[rank] = en;    /* sorted code book entries (global scratch) */
+		}
+	}
+	BARRIER();
+	if (tid == 0) {
+		const uint16_t *sorted = reinterpret_cast<const uint16_t *>(c->hist);
+		const int k = sh->k, select = sh->select;
+		sh->top_is_zero = (sorted[0] == ((1 << 8) | 128));
+		if (part == 0 && !sh->top_is_zero && k > 290) sh->rc = NHW_E_CODEBOOK;      /* :269-271 */
+		if (part == 1 && select != 4 && k > 290) sh->rc = NHW_E_CODEBOOK;
+		sh->zone = (part == 0 && select == 4 && sh->top_is_zero);
+	}
+	BARRIER();
+	if (sh->rc) return;
+	if (!tid) PROF(c, 24);
+	for (int ch = 0; ch < nchunks; ch++) {
+		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
+		unsigned b = 0, x1 = 0, x2 = 0;
+		if (lo < S) pack_walk<1>(d, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &b, &x1, &x2, prevnz, nextnz, ch * NT + tid);
+		cnt[ch * NT + tid] = b; cnt[nsl + ch * NT + tid] = x1; cnt[2 * nsl + ch * NT + tid] = x2;
+	}
+	BARRIER();
+	{                                                            /* exclusive prefix sums over the slices in stream order */
+		/* level 1: thread t owns slices [t*nchunks, (t+1)*nchunks) of the flattened order */
+		unsigned sum[3] = { 0, 0, 0 };
+		for (int v = 0; v < 3; v++) for (int k = 0; k < nchunks; k++) sum[v] += cnt[v * nsl + tid * nchunks + k];
+		sh->bits[tid] = sum[0]; sh->n1[tid] = sum[1]; sh->n2[tid] = sum[2];
+		BARRIER();
+		if (tid == 0) {
+			unsigned b = 0, x1 = 0, x2 = 0;
+			for (int t = 0; t < NT; t++) { const unsigned vb = sh->bits[t], v1 = sh->n1[t], v2 = sh->n2[t]; sh->bits[t] = b; sh->n1[t] = x1; sh->n2[t] = x2; b += vb; x1 += v1; x2 += v2; }
+			sh->total_bits = b; sh->total_n1 = x1; sh->total_n2 = x2;
+		}
+		BARRIER();
+		unsigned run[3] = { sh->bits[tid], sh->n1[tid], sh->n2[tid] };
+		for (int k = 0; k < nchunks; k++)
+			for (int v = 0; v < 3; v++) { const unsigned x = cnt[v * nsl + tid * nchunks + k]; cnt[v * nsl + tid * nchunks + k] = run[v]; run[v] += x; }
+	}
+	BARRIER();
+	if (!tid) PROF(c, 25);
+	const int nwords = sh->total_bits ? (int)((sh->total_bits - 1) >> 5) + 1 : 1;
+	uint32_t *words = c->packet + word0;
+	for (int t = tid; t < nwords; t += NT) words[t] = 0;
+	BARRIER();
+	for (int ch = 0; ch < nchunks; ch++) {
+		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
+		if (lo < S) pack_walk<2>(d, N, lo, hi, sh, words, cnt[ch * NT + tid], c->s1, cnt[nsl + ch * NT + tid], c->s2, cnt[2 * nsl + ch * NT + tid], nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
+	}
+	BARRIER();
+	if (!tid) PROF(c, 26);
+
+	const uint16_t *sorted = reinterpret_cast<const uint16_t *>(c->hist);
+	uint8_t *tmp_book = reinterpret_cast<uint8_t *>(c->hist) + 1024;
+	if (part == 0) {
+		const int n1 = (int)sh->total_n1, n2 = (int)sh->total_n2;
+		const int b1 = (n1 >> 3) + 1, b2 = (n2 >> 3) + 1;        /* sign bits, 8 per byte (:370-398) */
+		for (int t = tid; t < b1; t += NT) { int v = 0; for (int u = 0; u < 8; u++) v = (v << 1) | ((8 * t + u < n1 && 8 * t + u < S_CAP ? c->s1[8 * t + u] : 0) & 1); c->sel_word1[t] = (uint8_t)v; }
+		for (int t = tid; t < b2; t += NT) { int v = 0; for (int u = 0; u < 8; u++) v = (v << 1) | ((8 * t + u < n2 && 8 * t + u < S_CAP ? c->s2[8 * t + u] : 0) & 1); c->sel_word2[t] = (uint8_t)v; }
+		if (tid == 0) {
+			const int k = sh->k;
+			int e = 0, b, w, i;
+			c->m->size_data1 = nwords;
+			c->m->wavelet_type = (sh->select > 4 || !sh->top_is_zero) ? 4 : 0;       /* :367-368 */
+			c->m->select1 = b1; c->m->select2 = b2;
+			for (i = 0; i < k; i++) {                                                 /* code book 1 (:400-424) */
+				if ((sorted[i] >> 8) == 1) c->book1[e++] = (uint8_t)(sorted[i] & 0xFF);
+				else { c->book1[e++] = 3; c->book1[e++] = (uint8_t)(sorted[i] >> 8); }
+			}
+			for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = c->book1[i];
+			for (i = 1; i < e; i += 2) tmp_book[b++] = c->book1[i];
+			tmp_book[e] = 0;
+			for (i = 0, w = 0, b = 0; i < e; i++) {
+				while (tmp_book[i] == 3) { b++; i++; }
+				if (b > 0) { c->book1[w++] = 3; c->book1[w++] = (uint8_t)b; b = 0; i--; }
+				else c->book1[w++] = tmp_book[i];
+			}
+			c->m->size_book1 = w;
+		}
+	} else if (tid == 0) {
+		const int k = sh->k;
+		int e = 0, b, w, i;
+		c->m->size_data2 = word0 + nwords;
+		for (i = 0; i < k; i++) {                                                     /* code book 2 (:431-459) */
+			if ((sorted[i] >> 8) == 1) c->book2[e++] = (uint8_t)((sorted[i] & 0xFF) | 1);
+			else { c->book2[e++] = (uint8_t)(sorted[i] & 0xFF); c->book2[e++] = (uint8_t)(sorted[i] >> 8); }
+		}
+		c->m->tree_end = e;
+		for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = c->book2[i];
+		for (i = 1; i < e; i += 2) tmp_book[b++] = c->book2[i];
+		tmp_book[e] = 0;
+		for (i = 0, w = 0, b = 0; i < e; i++) {
+			while (tmp_book[i] == 128) { b++; i++; }
+			if (b > 0) { c->book2[w++] = 128; c->book2[w++] = (uint8_t)b; b = 0; i--; }
+			else c->book2[w++] = tmp_book[i];
+		}
+		c->m->size_book2 = w;
+	}
+	BARRIER();
+}
+
+/* container (nhw_encoder.c:3112-3218): every thread walks the same field list, the byte copies are shared */
+struct ParSink { uint8_t *p; size_t cap, n; int tid; };
+DEV void pput(ParSink *s, const void *d, size_t n) { if (s->n + n <= s->cap) for (size_t i = s->tid; i < n; i += NT) s->p[s->n + i] = ((const uint8_t *)d)[i]; s->n += n; }
+DEV void pput16(ParSink *s, unsigned v) { if (s->tid == 0 && s->n + 2 <= s->cap) { s->p[s->n] = (uint8_t)v; s->p[s->n + 1] = (uint8_t)(v >> 8); } s->n += 2; }
+DEV void pput32(ParSink *s, uint32_t v) { if (s->tid == 0 && s->n + 4 <= s->cap) { for (int k = 0; k < 4; k++) s->p[s->n + k] = (uint8_t)(v >> (8 * k)); } s->n += 4; }
+
+DEV size_t container_par(Ctx *c, uint8_t *out, size_t cap, int tid)
+{
+	ParSink s = { out, cap, 0, tid };
+	const int q = c->q;
+	const NhwMeta *m = c->m;
+	if (tid == 0) { out[0] = (uint8_t)(m->res_high + m->wavelet_type); out[1] = (uint8_t)q; }
+	s.n = 2;
+	pput16(&s, (unsigned)m->size_book1); pput16(&s, (unsigned)m->size_book2);
+	pput32(&s, (uint32_t)m->size_data1); pput32(&s, (uint32_t)m->size_data2);
+	pput16(&s, (unsigned)m->tree_end); pput16(&s, (unsigned)m->exw_len);
+	if (q > 12) pput16(&s, (unsigned)m->r1.list_len);
+	if (q >= 19) { pput16(&s, (unsigned)m->r3.list_len); pput16(&s, (unsigned)m->r3.bits_len); }
+	if (q > 17) pput16(&s, (unsigned)m->res4_len);
+	if (q > 12) pput16(&s, (unsigned)m->r1.bits_len);
+	if (q >= 21) { pput16(&s, (unsigned)m->r5.list_len); pput16(&s, (unsigned)m->r5.bits_len); }
+	if (q > 21) { pput32(&s, (uint32_t)m->r6.list_len); pput16(&s, (unsigned)m->r6.bits_len); pput16(&s, (unsigned)m->char_res1_len); }
+	if (q > 22) pput16(&s, (unsigned)m->qsetting3_len);
+	pput16(&s, (unsigned)m->select1); pput16(&s, (unsigned)m->select2);
+	if (q > 15) pput16(&s, (unsigned)m->ll_word_len);
+	pput16(&s, (unsigned)m->ch_res_len);
+
+	pput(&s, c->book1, (size_t)m->size_book1); pput(&s, c->book2, (size_t)m->size_book2);
+	pput(&s, c->exw, (size_t)m->exw_len);
+	if (q > 12) { pput(&s, c->res1.list, (size_t)m->r1.list_len); pput(&s, c->res1.bits, (size_t)m->r1.bits_len); pput(&s, c->res1.word, (size_t)m->r1.word_len); }
+	if (q > 17) pput(&s, c->res4, (size_t)m->res4_len);
+	if (q >= 19) { pput(&s, c->res3.list, (size_t)m->r3.list_len); pput(&s, c->res3.bits, (size_t)m->r3.bits_len); pput(&s, c->res3.word, (size_t)m->r3.word_len); }
+	if (q >= 21) { pput(&s, c->res5.list, (size_t)m->r5.list_len); pput(&s, c->res5.bits, (size_t)m->r5.bits_len); pput(&s, c->res5.word, (size_t)m->r5.word_len); }
+	if (q > 21) {
+		pput(&s, c->res6.list, (size_t)m->r6.list_len); pput(&s, c->res6.bits, (size_t)m->r6.bits_len); pput(&s, c->res6.word, (size_t)m->r6.word_len);
+		pput(&s, c->char_res1, (size_t)m->char_res1_len * 2);            /* little-endian u16, as the reference's fwrite */
+	}
+	if (q > 22) pput(&s, c->qsetting3, (size_t)m->qsetting3_len * 4);
+	pput(&s, c->sel_word1, (size_t)m->select1); pput(&s, c->sel_word2, (size_t)m->select2);
+	if (q > 15) { pput(&s, c->res_u64, 2 * H); pput(&s, c->res_v64, 2 * H); pput(&s, c->ll_word, (size_t)m->ll_word_len); }
+	pput(&s, c->ch_res, (size_t)m->ch_res_len);
+	pput(&s, c->packet, (size_t)m->size_data2 * 4);
+	return s.n <= cap ? s.n : 0;
+}
+
+/* Z1, Z2 and the container */
+DEV void final_phase_par(Ctx *c, uint8_t *out, size_t cap, uint32_t *size, int32_t *status, PackShared *sh, int tid)
+{
+	PROF_BEGIN();
+	if (tid == 0) ll_code_chroma(c);
+	BARRIER();
+	if (!tid) PROF(c, 18);
+	uint8_t saved = c->scan[4 * Q];
+	BARRIER();
+	if (tid == 0) c->scan[4 * Q] = 3;                            /* sentinel behind the luma part (compress_pixel.c:66) */
+	BARRIER();
+	pack_part_par(c, 0, sh, tid, 0);
+	if (sh->rc) { if (tid == 0) { *size = 0; *status = sh->rc; } return; }
+	if (tid == 0) { c->scan[4 * Q] = saved; c->scan[6 * Q - 1] = c->scan[6 * Q - 2]; }   /* :464-465 */
+	BARRIER();
+	pack_part_par(c, 1, sh, tid, c->m->size_data1);
+	if (sh->rc) { if (tid == 0) { *size = 0; *status = sh->rc; } return; }
+	if (!tid) PROF(c, 19);
+	const size_t n = container_par(c, out, cap, tid);
+	if (tid == 0) { *size = (uint32_t)n; *status = n ? NHW_OK : -3; }
+	if (!tid) PROF(c, 20);
 }
 
 } // namespace nhw
