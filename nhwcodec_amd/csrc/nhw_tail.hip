@@ -13,6 +13,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 {
 	__shared__ int sh_counts[2];
 	__shared__ int sh_pos[2 * NT + 2];
+	__shared__ uint32_t sh_z[4 * Q / 16 / 32 + 4];
 	__shared__ PackShared sh_pack;
 	const int img = blockIdx.x, tid = threadIdx.x;
 	Ctx c;
@@ -20,7 +21,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	if (PH == PH_L1) luma_p1_par(&c, tid, sh_pos);
 	else if (PH == PH_L2) luma_p2_par(&c, tid);
 	else if (PH == PH_L3) luma_p3_par(&c, tid, sh_pos, sh_counts);
-	else if (PH == PH_L4) luma_p4_par(&c, tid, sh_counts, sh_pos);
+	else if (PH == PH_L4) luma_p4_par(&c, tid, sh_counts, sh_pos, sh_z);
 	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
 	else if (PH == PH_C2) dequant_sim_chroma_par(&c, 1, tid);
 	else if (PH == PH_C3) chroma_p3_par(&c, comp, tid);

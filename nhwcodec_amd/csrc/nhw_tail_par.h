@@ -705,7 +705,7 @@ DEV void fix_sign_code(uint8_t *s, int at) { if (s[at] == 153) s[at] = 124; else
  * pair rule (two adjacent positions cannot both match it), every other test compares against 128, which is
  * never written.  Rewrite 3 touches only sign codes next to zero runs of >= 252: each thread scans the runs
  * that start in its slice and replays the rare long ones. */
-DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts)
+DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /* shared [n/16/32 + 2] */)
 {
 	const int16_t *p = c->proc;
 	uint8_t *s = c->scan;
@@ -723,14 +723,31 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts)
 	if (tid == 0) { sh_counts[0] = 0; sh_counts[1] = 0; }
 	BARRIER();
 
-	/* every loop below strides over stream positions thread-by-thread, so a wavefront reads consecutive bytes */
+	/* The three rewrites read 16 stream bytes per thread and step (48-byte register window: 16 before, 16 own,
+	 * 16 after), so a wavefront touches 1 KiB of consecutive memory per load instruction. */
+#define WIN_LOAD(w, base) do { const uint4 a_ = *reinterpret_cast<const uint4 *>(s + (base) - 16), b_ = *reinterpret_cast<const uint4 *>(s + (base)), \
+		c_ = *reinterpret_cast<const uint4 *>(s + (base) + 16); \
+		w[0] = a_.x; w[1] = a_.y; w[2] = a_.z; w[3] = a_.w; w[4] = b_.x; w[5] = b_.y; w[6] = b_.z; w[7] = b_.w; w[8] = c_.x; w[9] = c_.y; w[10] = c_.z; w[11] = c_.w; } while (0)
+#define WB(w, k) ((int)(((w)[((k) + 16) >> 2] >> (8 * (((k) + 16) & 3))) & 0xFF))      /* byte at base + k, -16 <= k < 32 */
+#define PM8(v) ((v) == 136 || (v) == 120)
 	for (int w = tid; w < n / 32; w += NT) bits[w] = 0;
+	if (tid < 4) sh_z[n / 16 / 32 + tid] = 0;
 	BARRIER();
-	for (int cpos = tid; cpos <= n - 5; cpos += NT) {              /* rewrite 1, selection */
-		if (!is_pm8(s[cpos]) || !pair_cand(s, cpos, n)) continue;
-		int m = 1, back = cpos - 4;
-		while (pair_cand(s, back, n)) { m++; back -= 4; }
-		if (m & 1) atomicOr(&bits[cpos >> 5], 1u << (cpos & 31));
+	for (int base = 16 * tid; base < n; base += 16 * NT) {         /* rewrite 1, selection */
+		uint32_t w[12];
+		WIN_LOAD(w, base);
+		{                                                          /* bitmap of all-zero 16-byte groups (never changes: rewrites only touch non-zero symbols) */
+			const unsigned long long mask = __ballot(w[4] == 0x80808080u && w[5] == 0x80808080u && w[6] == 0x80808080u && w[7] == 0x80808080u);
+			if ((tid & 63) == 0) { sh_z[base >> 9] = (uint32_t)mask; sh_z[(base >> 9) + 1] = (uint32_t)(mask >> 32); }
+		}
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const int cpos = base + k;
+			if (!(PM8(WB(w, k)) && WB(w, k + 1) == 128 && WB(w, k + 2) == 128 && WB(w, k + 3) == 128 && PM8(WB(w, k + 4))) || cpos > n - 5) continue;
+			int m = 1, back = cpos - 4;
+			while (pair_cand(s, back, n)) { m++; back -= 4; }
+			if (m & 1) atomicOr(&bits[cpos >> 5], 1u << (cpos & 31));
+		}
 	}
 	BARRIER();
 	for (int w = tid; w < n / 32; w += NT) {                       /* rewrite 1, application */
@@ -747,22 +764,29 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts)
 	if (tid < 4) { s[tid] = 128; s[n - 4 + tid] = 128; }
 	BARRIER();
 
-	{                                                              /* rewrite 2 */
+	{                                                              /* rewrite 2 (tests on the window; writes are byte stores) */
 		int n1 = 0, n2 = 0;
-		for (int i = 4 + tid; i < n - 4; i += NT) {
-			if (!is_pm8(s[i])) continue;
-			const bool before4 = s[i - 1] == 128 && s[i - 2] == 128 && s[i - 3] == 128 && s[i - 4] == 128;
-			if (i > 4 && is_pm8(s[i - 1])) {                       /* did the left neighbour take me as the second of a pair? */
-				const bool b4l = s[i - 2] == 128 && s[i - 3] == 128 && s[i - 4] == 128 && s[i - 5] == 128;
-				if (s[i + 1] == 128 && (b4l || (s[i - 2] == 128 && s[i + 2] == 128 && s[i + 3] == 128 && s[i + 4] == 128))) continue;
-			}
-			const bool pair = is_pm8(s[i + 1]);
-			if ((s[i + 2] == 128 && pair && before4) ||
-			    (s[i - 1] == 128 && pair && s[i + 2] == 128 && s[i + 3] == 128 && s[i + 4] == 128 && s[i + 5] == 128)) {
-				s[i + 1] = (uint8_t)(s[i + 1] == 120 ? 157 : 159); n2++;
-			}
-			else if ((before4 && s[i + 1] == 128) || (s[i - 1] == 128 && s[i + 1] == 128 && s[i + 2] == 128 && s[i + 3] == 128 && s[i + 4] == 128)) {
-				s[i] = (uint8_t)(s[i] == 136 ? 153 : 155); n1++;
+		for (int base = 16 * tid; base < n; base += 16 * NT) {
+			uint32_t w[12];
+			WIN_LOAD(w, base);
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const int i = base + k, v = WB(w, k);
+				if (!PM8(v) || i < 4 || i >= n - 4) continue;
+				const bool before4 = WB(w, k - 1) == 128 && WB(w, k - 2) == 128 && WB(w, k - 3) == 128 && WB(w, k - 4) == 128;
+				if (i > 4 && PM8(WB(w, k - 1))) {                  /* did the left neighbour take me as the second of a pair? */
+					const bool b4l = WB(w, k - 2) == 128 && WB(w, k - 3) == 128 && WB(w, k - 4) == 128 && WB(w, k - 5) == 128;
+					if (WB(w, k + 1) == 128 && (b4l || (WB(w, k - 2) == 128 && WB(w, k + 2) == 128 && WB(w, k + 3) == 128 && WB(w, k + 4) == 128))) continue;
+				}
+				const int nx = WB(w, k + 1);
+				const bool pair = PM8(nx);
+				if ((WB(w, k + 2) == 128 && pair && before4) ||
+				    (WB(w, k - 1) == 128 && pair && WB(w, k + 2) == 128 && WB(w, k + 3) == 128 && WB(w, k + 4) == 128 && WB(w, k + 5) == 128)) {
+					s[i + 1] = (uint8_t)(nx == 120 ? 157 : 159); n2++;
+				}
+				else if ((before4 && nx == 128) || (WB(w, k - 1) == 128 && nx == 128 && WB(w, k + 2) == 128 && WB(w, k + 3) == 128 && WB(w, k + 4) == 128)) {
+					s[i] = (uint8_t)(v == 136 ? 153 : 155); n1++;
+				}
 			}
 		}
 		if (n1) atomicAdd(&sh_counts[0], n1);
@@ -771,23 +795,36 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts)
 	BARRIER();
 	if (tid == 0) { c->m->select1 = sh_counts[0]; c->m->select2 = sh_counts[1]; }
 
-	for (int i = tid; i < n; i += NT) {                            /* rewrite 3: owners of run starts */
-		if (s[i] != 128 || s[i + 1] != 128 || (i > 0 && s[i - 1] == 128)) continue;
-		int b = i + 1;
-		while (s[b + 1] == 128) b++;                               /* run [i, b]; s[n] is 0 */
-		if (b - i >= 252) {                                        /* replay the reference's walk over this run */
-			int k = i, run = 0;
-			while (s[k] == 128 && s[k + 1] == 128) {
-				run++;
-				if (run > 255) { for (int t = 0; t < 4; t++) fix_sign_code(s, k + t); k--; run = 0; }
-				else k++;
+	for (int base = 16 * tid; base < n; base += 16 * NT) {         /* rewrite 3: owners of run starts */
+		uint32_t w[12];
+		WIN_LOAD(w, base);
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const int i = base + k;
+			if (WB(w, k) != 128 || WB(w, k + 1) != 128 || (i > 0 && WB(w, k - 1) == 128)) continue;
+			{                                                      /* a run of >= 253 covers the 14 groups that follow: cheap reject */
+				const int g = (base >> 4) + 1;
+				const unsigned long long z = ((unsigned long long)sh_z[(g >> 5) + 1] << 32 | sh_z[g >> 5]) >> (g & 31);
+				if ((z & 0x3FFF) != 0x3FFF) continue;
 			}
-			if (run >= 252) fix_sign_code(s, k + 1);
+			int b = i + 1;
+			while (s[b + 1] == 128) b++;                           /* run [i, b]; s[n] is 0 */
+			if (b - i >= 252) {                                    /* replay the reference's walk over this run */
+				int kk = i, run = 0;
+				while (s[kk] == 128 && s[kk + 1] == 128) {
+					run++;
+					if (run > 255) { for (int t = 0; t < 4; t++) fix_sign_code(s, kk + t); kk--; run = 0; }
+					else kk++;
+				}
+				if (run >= 252) fix_sign_code(s, kk + 1);
+			}
 		}
 	}
 	BARRIER();
+#undef WIN_LOAD
+#undef WB
+#undef PM8
 }
-
 
 
 /* ---------------------------------------------------------------- chroma pieces */
@@ -983,7 +1020,7 @@ DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc)
 	dequant_sim_luma_par(c, 0, tid, pos);
 	if (!tid) PROF(c, 7);
 }
-DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos)
+DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos, uint32_t *sh_z)
 {
 	const int q = c->q;
 	PROF_BEGIN();
@@ -1024,7 +1061,7 @@ DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos)
 	if (q > 21 && tid == 0) { band_recons(c); hq_settings(c); }             /* Y29 */
 	BARRIER();
 	if (!tid) PROF(c, 16);
-	scan_and_rewrite_par(c, tid, sh_counts);                                /* Y30, Y31 */
+	scan_and_rewrite_par(c, tid, sh_counts, sh_z);                          /* Y30, Y31 */
 	if (!tid) PROF(c, 17);
 }
 
