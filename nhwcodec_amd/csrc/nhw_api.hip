@@ -20,6 +20,9 @@ void nhw_launch_prefilter(int16_t *y, size_t y_stride, int16_t *kmap, size_t k_s
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, int16_t *keep, size_t keep_stride, hipStream_t s);
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s);
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
+void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilter, uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
+                            uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
+                            int16_t *keep, size_t keep_stride, int n, hipStream_t s);
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s);
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
 enum { PH_L1, PH_L2, PH_L3, PH_L4, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL };
@@ -39,6 +42,7 @@ struct nhw_enc {
 	uint8_t *d_in, *d_out, *d_compact;
 	uint32_t *d_sizes; int32_t *d_status; uint64_t *d_offs;
 	int conv_cap;
+	int legacy_front; /* debug: separate pre-filter / analysis kernels instead of the fused band kernel */
 	int stop_after;   /* debug: leave the batch driver after this many stages (0 = run everything) */
 };
 
@@ -51,7 +55,7 @@ static const size_t k_buf_bytes[B_COUNT] = {
 	/* R1     */ Q + 64, 8192 + 64, 16384 + 64, /* R3 */ Q + 64, 8192 + 64, 16384 + 64, /* R5 */ Q + 64, 8192 + 64, 16384 + 64,
 	/* R6     */ 2 * Q + 1024, 16384 + 64, 16384 + 64, /* CHARRES */ 2048 + 64, /* QSET3 */ 8 * Q + 64,
 	/* RESU64 */ 512, /* RESV64 */ 512, /* PACKET */ 320000, /* BOOK1 */ 768, /* BOOK2 */ 768, /* SEL1 */ 16384 + 64, /* SEL2 */ 16384 + 64,
-	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512
+	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512, /* ROWFLAG */ 1024
 };
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -121,19 +125,27 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	/* a1: colour + 4:2:0 */
 	nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
 	STAGE_DONE();
-	/* a2: pre-filter (q<=21, nhw_encoder.c:116-119) */
-	if (q < 22) {
-		nhw_launch_prefilter(jpeg, ws.stride[B_JPEG], plane16(ws, B_KMAP), ws.stride[B_KMAP], (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP],
-		                     plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], n, s);
+	/* a2 + Y2 + Y3: pre-filter (q<=21, nhw_encoder.c:116-119), level-1 analysis (:125), LL1 copy (:127-135), fused */
+	if (e->legacy_front) {
+		if (q < 22) {
+			nhw_launch_prefilter(jpeg, ws.stride[B_JPEG], plane16(ws, B_KMAP), ws.stride[B_KMAP], (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP],
+			                     plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], n, s);
+			STAGE_DONE();
+		}
+		nhw_launch_analysis(jpeg, proc, n, ps, W, W, 0, q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, s);
+		STAGE_DONE();
+		nhw_launch_copy_block(jpeg, ps, W, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, H, H, H, n, s);
+		STAGE_DONE();
+	} else {
+		nhw_launch_front_fused(jpeg, ws.stride[B_JPEG], q < 22, (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
+		                       plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2,
+		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s);
+		if (q < 22) STAGE_DONE();
+		STAGE_DONE();
 		STAGE_DONE();
 	}
-	/* Y2: level-1 analysis (:125) */
-	nhw_launch_analysis(jpeg, proc, n, ps, W, W, 0, q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, s);
-	STAGE_DONE();
 	HIPCHK(hipEventRecord(e->ev[1], s));
-	/* Y3: LL1 copy (:127-135); Y4: level-2 analysis (:139) */
-	nhw_launch_copy_block(jpeg, ps, W, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, H, H, H, n, s);
-	STAGE_DONE();
+	/* Y4: level-2 analysis (:139) */
 	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
 	STAGE_DONE();
 	nhw_launch_phase(PH_L1, ws, 0, out, d_sizes, d_status, s);
@@ -299,6 +311,7 @@ extern "C" int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n
 }
 
 /* ------------------------------------------------------------------------------------------------ debug hooks (tests only) */
+extern "C" int nhw_debug_legacy_front(nhw_enc *e, int on) { if (!e) return NHW_E_ARG; e->legacy_front = on; return NHW_OK; }
 extern "C" int nhw_debug_stop_after(nhw_enc *e, int stage) { if (!e) return NHW_E_ARG; e->stop_after = stage; return NHW_OK; }
 extern "C" int nhw_debug_read(nhw_enc *e, int buf, int img, void *dst, size_t bytes)
 {

@@ -97,6 +97,53 @@ __global__ __launch_bounds__(256) void k_color(const uint8_t *__restrict__ bgr, 
  * 64-bit words), chaining the 510 row maps, then replaying every row from its now-known start state.
  * ------------------------------------------------------------------------------------------------ */
 
+/* flag handed from one pixel pair to the next in raster order (image_processing.c:1927-1990, `a`) */
+__device__ __forceinline__ int pair_big_flag_fwd(int k0, int k1)
+{
+	if (((k0 < 32 && k0 > 10) || (k0 > -32 && k0 < -10)) && iabs(k1) >= 23) return 0;
+	if (k1 < 32 && k1 >= 16) return iabs(k0) >= 23;
+	if (k1 > -32 && k1 <= -16) return iabs(k0) >= 23;
+	return 0;
+}
+/* the pair rules of the pre-filter (image_processing.c:810-837, 1927-1990) on one pixel pair */
+__device__ __forceinline__ void prefilter_pair(int k0, int k1, int prev_big, int &o0, int &o1)
+{
+	int tag;
+	if (k0 > 201) { o0 -= 2; tag = 4; }
+	else if (k0 < -201) { o0 += 2; tag = 3; }
+	else if (k0 > 176) { o0--; tag = 2; }
+	else if (k0 < -176) { o0++; tag = 1; }
+	else tag = 0;
+	if (k1 > 201) { if (!tag || tag == 3) o1 -= 2; else if (tag != 4) o1--; }
+	else if (k1 < -201) { if (!tag || tag == 4) o1 += 2; else if (tag != 3) o1++; }
+	else if (k1 > 176) { if (tag != 4) o1--; }
+	else if (k1 < -176) { if (tag != 3) o1++; }
+	if (k0 < 32 && k0 > 10) {
+		if (iabs(k1) >= 23) {
+			if (k0 < 16) { if (k1 > 0 && k1 < 32 && k0 > 11) o1++; o0++; }
+			else o0 += prev_big ? 1 : 2;
+			return;
+		}
+	} else if (k0 > -32 && k0 < -10) {
+		if (iabs(k1) >= 23) {
+			if (k0 > -16) { if (k1 < 0 && k1 > -32 && k0 < -11) o1--; o0--; }
+			else o0 -= prev_big ? 1 : 2;
+			return;
+		}
+	}
+	if (k1 < 32 && k1 > 10) {
+		if (iabs(k0) >= 23) {
+			if (k1 < 16) { if (k0 > 0 && k0 < 32 && k1 > 11) o0++; o1++; }
+			else o1 += 2;
+		}
+	} else if (k1 > -32 && k1 < -10) {
+		if (iabs(k0) >= 23) {
+			if (k1 > -16) { if (k0 < 0 && k0 > -32 && k1 < -11) o0--; o1--; }
+			else o1 -= 2;
+		}
+	}
+}
+
 /* vb[r][c] = sign(sum) * (15*|sum| + mag), 0 when sum == 0 (carry reset); interior pixels only */
 __global__ __launch_bounds__(256) void k_pre_contrast(const int16_t *__restrict__ yb, size_t y_stride, int16_t *__restrict__ kb, size_t k_stride)
 {
@@ -353,6 +400,256 @@ __global__ __launch_bounds__(256) void k_syn_rows(const int16_t *__restrict__ sr
 	reinterpret_cast<uint32_t *>(out)[k] = (uint32_t)(uint16_t)e | ((uint32_t)(uint16_t)o << 16);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused front: pre-filter + level-1 analysis in one band kernel (+ a small pre-pass that only emits 18 bytes
+ * per row).  One workgroup owns 16 output rows ky of the level-1 plane for all 512 columns:
+ *   LDS ybuf: the 39 luma rows 32b-5 .. 32b+33 (original values; the pre-filter needs a 3x3 neighbourhood)
+ *   LDS kbuf: contrast -> kernel map of the 37 rows 32b-4 .. 32b+32, later the horizontal pass output
+ * The carry of the pre-filter enters every row with the state the pre-pass + chain computed, so rows replay
+ * independently; the first pixel pair of a row gets the hand-over flag of the previous row from the chain.
+ * Vertical pass: one thread per column, 16 low + 16 high outputs each (the /64 low-pass error diffusion is a
+ * depth-1 recurrence on the raw taps, so nothing is carried between bands).  Rows are padded to 514 shorts:
+ * a lane that walks a row serially hits bank (row + k) mod 64.
+ * ------------------------------------------------------------------------------------------------ */
+#define FB_KB 16                    /* output rows per band */
+#define FB_TROWS (2 * FB_KB + 5)    /* horizontal-pass rows a band needs: 2k0-4 .. 2k0+32 */
+#define FB_YROWS (FB_TROWS + 2)
+#define FB_RS 514                   /* padded LDS row stride (shorts) */
+
+__device__ __forceinline__ int contrast_at(const int16_t *p /* LDS, row stride FB_RS */)
+{
+	const int ctr = p[0];
+	int sum = 0, mag = 0;
+#pragma unroll
+	for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+		for (int dx = -1; dx <= 1; dx++) {
+			if (!dy && !dx) continue;
+			const int d = ctr - p[dy * FB_RS + dx];
+			sum += d; mag += iabs(d);
+		}
+	const int base = 15 * iabs(sum) + mag;
+	return sum == 0 ? 0 : (sum < 0 ? -base : base);
+}
+
+/* pre-pass: per row the 16-state transfer map of the carry and, for each of the 16 entry states, the hand-over
+ * flag of the row's last pixel pair (509, 510).  One workgroup = 32 rows, 8 segments of 64 pixels per row. */
+__global__ __launch_bounds__(256) void k_front_rowmaps(const int16_t *__restrict__ yb, size_t y_stride, uint64_t *__restrict__ maps, size_t m_stride,
+                                                       uint16_t *__restrict__ flags, size_t f_stride)
+{
+	__shared__ int16_t ybuf[34 * FB_RS];
+	__shared__ uint64_t seg[32 * 8 * 2];
+	__shared__ uint16_t segflag[32];
+	const int band = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
+	const int16_t *y = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
+	const int y0 = 32 * band - 1;                                  /* first staged row */
+	for (int k = t; k < 34 * (W / 8); k += 256) {
+		const int ry = k / (W / 8), o = k % (W / 8), row = y0 + ry;
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (row >= 0 && row < W) v = reinterpret_cast<const uint4 *>(y + (size_t)row * W)[o];
+		uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 8 * o);
+		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+	}
+	__syncthreads();
+	{
+		const int rl = t >> 3, sg = t & 7, row = 32 * band + rl;    /* row-local index, segment */
+		uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
+		uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0; int v509 = 0, v510 = 0;
+		if (row >= 1 && row <= W - 2) {
+			const int c0 = 1 + 64 * sg, c1 = sg == 7 ? W - 2 : c0 + 63;
+			const int16_t *p = ybuf + (rl + 1) * FB_RS;
+			for (int c = c0; c <= c1; c++) {
+				const int vb = contrast_at(p + c);
+				if (c == W - 3) { a0 = m0; a1 = m1; v509 = vb; }
+				if (c == W - 2) { b0 = m0; b1 = m1; v510 = vb; }
+				fsm_step16(m0, m1, vb);
+			}
+		}
+		seg[2 * t] = m0; seg[2 * t + 1] = m1;
+		if (sg == 7) {                                              /* flags per entry state of the last segment */
+			unsigned f = 0;
+			for (int e = 0; e < 16; e++) {
+				const int s509 = (int)(((e < 8 ? a0 : a1) >> (8 * (e & 7))) & 15), s510 = (int)(((e < 8 ? b0 : b1) >> (8 * (e & 7))) & 15);
+				const int k0 = v509 == 0 ? 0 : (v509 < 0 ? -((iabs(v509) + ((s509 + 2) >> 2)) >> 4) : ((iabs(v509) + ((s509 + 2) >> 2)) >> 4));
+				const int k1 = v510 == 0 ? 0 : (v510 < 0 ? -((iabs(v510) + ((s510 + 2) >> 2)) >> 4) : ((iabs(v510) + ((s510 + 2) >> 2)) >> 4));
+				f |= (unsigned)pair_big_flag_fwd(k0, k1) << e;
+			}
+			segflag[rl] = (uint16_t)f;
+		}
+	}
+	__syncthreads();
+	if (t < 32) {                                                   /* compose the 8 segment maps of a row */
+		const int row = 32 * band + t;
+		if (row >= 1 && row <= W - 2) {
+			uint8_t st[16], pre[16];
+			for (int e = 0; e < 16; e++) st[e] = (uint8_t)e;
+			for (int sg = 0; sg < 8; sg++) {
+				if (sg == 7) for (int e = 0; e < 16; e++) pre[e] = st[e];
+				const uint64_t m0 = seg[2 * (8 * t + sg)], m1 = seg[2 * (8 * t + sg) + 1];
+				for (int e = 0; e < 16; e++) { const int s = st[e]; st[e] = (uint8_t)(((s < 8 ? m0 : m1) >> (8 * (s & 7))) & 15); }
+			}
+			uint64_t o0 = 0, o1 = 0; unsigned f = 0;
+			for (int e = 0; e < 8; e++) { o0 |= (uint64_t)st[e] << (8 * e); o1 |= (uint64_t)st[8 + e] << (8 * e); }
+			for (int e = 0; e < 16; e++) f |= ((segflag[t] >> pre[e]) & 1u) << e;
+			uint64_t *mo = (uint64_t *)((uint8_t *)maps + (size_t)img * m_stride) + 2 * row;
+			mo[0] = o0; mo[1] = o1;
+			((uint16_t *)((uint8_t *)flags + (size_t)img * f_stride))[row] = (uint16_t)f;
+		}
+	}
+}
+
+/* one lane per image: entry state of the carry and hand-over flag for every row */
+__global__ void k_front_chain(const uint64_t *__restrict__ maps, size_t m_stride, const uint16_t *__restrict__ flags, size_t f_stride,
+                              uint8_t *__restrict__ st, size_t s_stride, int n)
+{
+	const int img = blockIdx.x * blockDim.x + threadIdx.x;
+	if (img >= n) return;
+	const uint64_t *m = (const uint64_t *)((const uint8_t *)maps + (size_t)img * m_stride);
+	const uint16_t *fl = (const uint16_t *)((const uint8_t *)flags + (size_t)img * f_stride);
+	uint8_t *s = st + (size_t)img * s_stride;
+	int state = 0, hand = 0;
+	for (int r = 1; r <= W - 2; r++) {
+		s[r] = (uint8_t)(state | (hand << 4));
+		hand = (fl[r] >> state) & 1;
+		const uint64_t w = m[2 * r + (state >> 3)];
+		state = (int)((w >> (8 * (state & 7))) & 15);
+	}
+}
+
+template <int PRE>
+__global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ yb, size_t y_stride, const uint8_t *__restrict__ st, size_t s_stride,
+                                                    int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
+                                                    int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
+	int16_t *ybuf = smem;                                          /* FB_YROWS rows */
+	int16_t *kbuf = smem + FB_YROWS * FB_RS;                       /* FB_TROWS rows */
+	const int band = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
+	const int k0 = FB_KB * band, t0 = 2 * k0 - 4;                  /* first horizontal-pass row (may be negative) */
+	const int16_t *y = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
+
+	for (int k = t; k < FB_YROWS * (W / 8); k += 256) {            /* stage rows t0-1 .. t0+37 */
+		const int ry = k / (W / 8), o = k % (W / 8), row = t0 - 1 + ry;
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (row >= 0 && row < W) v = reinterpret_cast<const uint4 *>(y + (size_t)row * W)[o];
+		uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 8 * o);
+		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+	}
+	__syncthreads();
+
+	if (PRE) {
+		for (int k = t; k < FB_TROWS * (W / 2); k += 256) {        /* contrast of the interior pixels */
+			const int rt = k / (W / 2), c = 2 * (k % (W / 2)), row = t0 + rt;
+			if (row < 1 || row > W - 2) continue;
+			const int16_t *p = ybuf + (rt + 1) * FB_RS;
+			if (c >= 1) kbuf[rt * FB_RS + c] = (int16_t)contrast_at(p + c);
+			if (c + 1 <= W - 2) kbuf[rt * FB_RS + c + 1] = (int16_t)contrast_at(p + c + 1);
+		}
+		__syncthreads();
+		if (t < FB_TROWS) {                                        /* replay the carry along each row */
+			const int row = t0 + t;
+			if (row >= 1 && row <= W - 2) {
+				int16_t *km = kbuf + t * FB_RS;
+				int carry = (st + (size_t)img * s_stride)[row] & 15;
+				for (int c = 1; c <= W - 2; c++) {
+					const int vb = km[c];
+					if (vb == 0) carry = 0;
+					else {
+						const int acc = iabs(vb) + ((carry + 2) >> 2);
+						km[c] = (int16_t)(vb < 0 ? -(acc >> 4) : (acc >> 4));
+						carry = acc & 15;
+					}
+				}
+			}
+		}
+		__syncthreads();
+		for (int k = t; k < FB_TROWS * 255; k += 256) {            /* pixel pairs (c, c+1), c odd */
+			const int rt = k / 255, pr = k % 255, row = t0 + rt, c = 1 + 2 * pr;
+			if (row < 1 || row > W - 2) continue;
+			const int16_t *km = kbuf + rt * FB_RS;
+			int16_t *o = ybuf + (rt + 1) * FB_RS + c;
+			const int kk0 = km[c], kk1 = km[c + 1];
+			const int prev_big = pr > 0 ? pair_big_flag_fwd(km[c - 2], km[c - 1]) : (((st + (size_t)img * s_stride)[row] >> 4) & 1);
+			int o0 = o[0], o1 = o[1];
+			prefilter_pair(kk0, kk1, prev_big, o0, o1);
+			o[0] = (int16_t)o0; o[1] = (int16_t)o1;
+		}
+		__syncthreads();
+	}
+
+	for (int k = t; k < FB_TROWS * (W / 2); k += 256) {            /* horizontal pass (filters.c:346-386) into kbuf */
+		const int rt = k >> 8, kx = k & 255, row = t0 + rt;
+		if (row < 0 || row >= W) continue;
+		const int16_t *x = ybuf + (rt + 1) * FB_RS;
+		kbuf[rt * FB_RS + kx] = (int16_t)tap5(x, W, kx);
+		kbuf[rt * FB_RS + H + kx] = (int16_t)(kx < H - 1 ? (x[2 * kx + 1] << 1) - (x[2 * kx] + x[2 * kx + 2]) : ((x[W - 1] - x[W - 2]) << 1));
+	}
+	__syncthreads();
+
+	int16_t *proc = procb + (size_t)img * plane_stride, *jpeg = jpegb + (size_t)img * plane_stride;
+	int16_t *ll1 = ll1b + (size_t)img * ll1_stride;
+	if (keepb) {                                                   /* q>=22: transposed horizontal-pass plane, rows kx < 256 (wavelet_filterbank.c:107-112) */
+		int16_t *keep = keepb + (size_t)img * keep_stride;
+		for (int k = t; k < H * 4; k += 256) {
+			const int kx = k >> 2, part = k & 3;                   /* 8 of this band's 32 own rows */
+			uint32_t v[4];
+			for (int e = 0; e < 4; e++) {
+				const int rt = 4 + 8 * part + 2 * e;                /* rows 2k0 + 8*part + 2e, +1 */
+				v[e] = (uint16_t)kbuf[rt * FB_RS + kx] | ((uint32_t)(uint16_t)kbuf[(rt + 1) * FB_RS + kx] << 16);
+			}
+			*reinterpret_cast<uint4 *>(keep + (size_t)kx * W + 2 * k0 + 8 * part) = make_uint4(v[0], v[1], v[2], v[3]);
+		}
+	}
+	for (int cc = 0; cc < 2; cc++) {                               /* vertical pass: column c, outputs ky = k0 .. k0+15 */
+		const int c = t + 256 * cc;
+		int16_t col[FB_TROWS];                                     /* col[i] = pass-1 row t0+i, symmetric extension x[-j]=x[j], x[511+j]=x[511-j] */
+#pragma unroll
+		for (int rt = 0; rt < FB_TROWS; rt++) {
+			int row = t0 + rt;
+			row = row < 0 ? -row : (row > W - 1 ? 2 * (W - 1) - row : row);
+			col[rt] = kbuf[(row - t0) * FB_RS + c];
+		}
+		uint32_t lo[FB_KB / 2], hi[FB_KB / 2];
+#pragma unroll
+		for (int kk = 0; kk < FB_KB; kk++) {
+			const int ky = k0 + kk;
+#define XS(d) ((int)col[2 * kk + 4 + (d)])                         /* x[2ky + d], -4 <= d <= 2 */
+			const int r = 6 * XS(0) + 2 * (XS(-1) + XS(1)) - (XS(-2) + XS(2));
+			int l, h;
+			if (c < H) {                                           /* filters.c:203-287 */
+				int carry = 0;
+				if (ky > 0) carry = diffuse(6 * XS(-2) + 2 * (XS(-3) + XS(-1)) - (XS(-4) + XS(0)));
+				l = rnd_half_away((int16_t)(r + carry), 6);
+			} else l = rnd_half_away(r, 4);                        /* filters.c:88-113 */
+			if (ky < H - 1) {
+				int a = XS(0) + XS(2);
+				if ((ky & 1) && (a & 1) && ((XS(-2) + XS(0)) & 1)) a++;
+				const int pr = XS(1) - (a >> 1);
+				h = c < H ? rnd_half_away(pr, 3) : (pr > 0 ? (pr + 1) >> 1 : pr >> 1);
+			} else h = c < H ? ((XS(1) - XS(0)) >> 3) : (((XS(1) - XS(0)) + 1) >> 1);
+#undef XS
+			if (kk & 1) { lo[kk >> 1] |= (uint32_t)(uint16_t)l << 16; hi[kk >> 1] |= (uint32_t)(uint16_t)h << 16; }
+			else { lo[kk >> 1] = (uint16_t)l; hi[kk >> 1] = (uint16_t)h; }
+		}
+		int16_t *orow = proc + (size_t)c * W;
+		reinterpret_cast<uint4 *>(orow + k0)[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+		reinterpret_cast<uint4 *>(orow + k0)[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+		reinterpret_cast<uint4 *>(orow + H + k0)[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+		reinterpret_cast<uint4 *>(orow + H + k0)[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+		if (c < H) {                                               /* LL, natural orientation, through LDS for coalesced rows */
+#pragma unroll
+			for (int kk = 0; kk < FB_KB; kk++) ybuf[kk * FB_RS + c] = (int16_t)((kk & 1) ? (lo[kk >> 1] >> 16) : (lo[kk >> 1] & 0xFFFF));
+		}
+	}
+	__syncthreads();
+	for (int k = t; k < FB_KB * (H / 2); k += 256) {               /* jpeg[ky][kx] and ll1[ky][kx], kx < 256 (wavelet_filterbank.c:172-184, nhw_encoder.c:127-135) */
+		const int kk = k >> 7, o = k & 127;
+		const uint32_t v = (uint16_t)ybuf[kk * FB_RS + 2 * o] | ((uint32_t)(uint16_t)ybuf[kk * FB_RS + 2 * o + 1] << 16);
+		reinterpret_cast<uint32_t *>(jpeg + (size_t)(k0 + kk) * W)[o] = v;
+		reinterpret_cast<uint32_t *>(ll1 + (size_t)(k0 + kk) * H)[o] = v;
+	}
+}
+
 /* SURVEY.md section 8d generator, one lane per image (setup only, never timed) */
 __global__ void k_synth(uint8_t *__restrict__ bgr, int n, uint32_t seed_base)
 {
@@ -431,6 +728,28 @@ void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stri
 	k_transpose<<<tg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, size);
 	k_syn_rows<1><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
 	k_transpose<<<tg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, size);
+}
+
+/* fused pre-filter + level-1 analysis (+ LL copy-back, ll1, keep): replaces nhw_launch_prefilter + the size-512 nhw_launch_analysis
+ * + the ll1 block copy of the batch driver */
+void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilter, uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
+                            uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
+                            int16_t *keep, size_t keep_stride, int n, hipStream_t s)
+{
+	const size_t lds = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
+	static bool attr_set = false;
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		attr_set = true;
+	}
+	const dim3 grid(H / FB_KB, n);
+	if (with_prefilter) {
+		k_front_rowmaps<<<grid, 256, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride);
+		k_front_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, flags, f_stride, st, s_stride, n);
+		k_front_band<1><<<grid, 256, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
+	} else
+		k_front_band<0><<<grid, 256, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
 }
 
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s)

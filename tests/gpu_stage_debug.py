@@ -39,8 +39,7 @@ def main(qs, seeds=(0, 1)):
         shift = 0 if q < 22 else -1
         # (stage, trace-record index among same-named records, name, [(buffer, blob index, bytes)])
         plan = [(1, 0, "downsample_YUV420", [("JPEG", 0, 8 * 65536), ("PU", 1, 65536), ("PV", 2, 65536)])]
-        if q < 22:
-            plan.append((2, 0, "pre_processing", [("JPEG", 0, 8 * 65536)]))
+        # (stage 2, the pre-filtered luma plane, never reaches HBM with the fused front kernel)
         L = [(3, 0, "wavelet_analysis_512"), (5, 0, "wavelet_analysis_256"), (6, 0, "offsetY_recons256_p1"), (7, 0, "wavelet_synthesis_256"),
              (9, 1, "wavelet_analysis_256"), (11, 0, "offsetY_recons256_p0"), (12, 1, "wavelet_synthesis_256")]
         for st, k, nm in L:
@@ -65,6 +64,9 @@ def main(qs, seeds=(0, 1)):
                 for bname, bi, nbytes in bufs:
                     got = read(enc, B[bname], i, nbytes)
                     want = recs[k][bi]
+                    if bname == "JPEG" and st > 1:      # only the 256x256 corner of the luma jpeg plane is live after level 1
+                        got = np.frombuffer(got, np.int16).reshape(512, 512)[:256, :256].tobytes()
+                        want = np.frombuffer(want, np.int16).reshape(512, 512)[:256, :256].tobytes()
                     if got != want:
                         ok = False
                         dt = np.uint8 if bname in ("PU", "PV") else np.int16

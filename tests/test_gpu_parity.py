@@ -125,6 +125,37 @@ def test_filterbank_matches_oracle(enc, oracle, stride, size, final):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("q", [17, 20, 21, 22, 23])
+def test_fused_front_matches_oracle(oracle, q):
+    """Fused pre-filter + level-1 analysis band kernel: coefficient plane, LL copy-back, ll1 and (q>=22) the kept
+    transposed horizontal-pass plane, against the oracle's stage functions, on smooth, noisy and blocky inputs."""
+    import ctypes
+    import torch
+    import nhwcodec_amd
+    imgs = [oracle.synth(9), class_image("noise", 3), class_image("blocks", 4), class_image("gradient")]
+    e = nhwcodec_amd.Encoder(0, max_batch=len(imgs))
+    e.lib.nhw_debug_stop_after(e.h, 4 if q < 22 else 3)      # colour, (pre-filter), analysis, ll1 copy
+    e.encode_device(_cuda(np.stack(imgs)), q)
+    torch.cuda.synchronize()
+
+    def rd(buf, i, nbytes):
+        out = np.empty(nbytes, np.uint8)
+        assert e.lib.nhw_debug_read(e.h, buf, i, ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(nbytes)) == 0
+        return out.view(np.int16)
+    for i, im in enumerate(imgs):
+        y = oracle.color(im, q)[0]
+        if q < 22:
+            y = oracle.prefilter(y, q)
+        oj, op, ok = oracle.analysis(y, 512, 512, 0, keep=True)
+        assert np.array_equal(rd(1, i, 8 * 65536), op), f"image {i}: level-1 coefficients"
+        assert np.array_equal(rd(0, i, 8 * 65536).reshape(512, 512)[:256, :256], oj.reshape(512, 512)[:256, :256]), f"image {i}: LL copy-back"
+        assert np.array_equal(rd(6, i, 2 * 65536), oj.reshape(512, 512)[:256, :256].ravel()), f"image {i}: ll1"
+        if q >= 22:
+            assert np.array_equal(rd(10, i, 4 * 65536), ok), f"image {i}: kept horizontal-pass plane"
+    e.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("q", [17, 18, 19, 20, 21, 22, 23])
 def test_whole_encoder_bit_exact_vs_oracle(enc, oracle, q):
     """The .nhw bytes of a mixed batch (synthetic seeds + every robustness class) equal the oracle's."""
