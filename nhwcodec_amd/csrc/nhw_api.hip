@@ -21,7 +21,7 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s);
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
 void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilter, uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
-                            uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
+                            uint64_t *segmaps, size_t g_stride, uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
                             int16_t *keep, size_t keep_stride, int n, hipStream_t s);
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s);
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
@@ -55,7 +55,7 @@ static const size_t k_buf_bytes[B_COUNT] = {
 	/* R1     */ Q + 64, 8192 + 64, 16384 + 64, /* R3 */ Q + 64, 8192 + 64, 16384 + 64, /* R5 */ Q + 64, 8192 + 64, 16384 + 64,
 	/* R6     */ 2 * Q + 1024, 16384 + 64, 16384 + 64, /* CHARRES */ 2048 + 64, /* QSET3 */ 8 * Q + 64,
 	/* RESU64 */ 512, /* RESV64 */ 512, /* PACKET */ 320000, /* BOOK1 */ 768, /* BOOK2 */ 768, /* SEL1 */ 16384 + 64, /* SEL2 */ 16384 + 64,
-	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512, /* ROWFLAG */ 1024
+	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512, /* ROWFLAG */ 1024, /* SEGMAP */ 512 * 8 * 16
 };
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -138,7 +138,7 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 		STAGE_DONE();
 	} else {
 		nhw_launch_front_fused(jpeg, ws.stride[B_JPEG], q < 22, (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
-		                       plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2,
+		                       (uint64_t *)plane8(ws, B_SEGMAP), ws.stride[B_SEGMAP], plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2,
 		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s);
 		if (q < 22) STAGE_DONE();
 		STAGE_DONE();
@@ -311,6 +311,8 @@ extern "C" int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n
 }
 
 /* ------------------------------------------------------------------------------------------------ debug hooks (tests only) */
+void nhw_debug_band_stamps(unsigned long long *out);
+extern "C" int nhw_debug_stamps(unsigned long long *out) { (void)hipDeviceSynchronize(); nhw_debug_band_stamps(out); return NHW_OK; }
 extern "C" int nhw_debug_legacy_front(nhw_enc *e, int on) { if (!e) return NHW_E_ARG; e->legacy_front = on; return NHW_OK; }
 extern "C" int nhw_debug_stop_after(nhw_enc *e, int stage) { if (!e) return NHW_E_ARG; e->stop_after = stage; return NHW_OK; }
 extern "C" int nhw_debug_read(nhw_enc *e, int buf, int img, void *dst, size_t bytes)

@@ -97,51 +97,39 @@ __global__ __launch_bounds__(256) void k_color(const uint8_t *__restrict__ bgr, 
  * 64-bit words), chaining the 510 row maps, then replaying every row from its now-known start state.
  * ------------------------------------------------------------------------------------------------ */
 
-/* flag handed from one pixel pair to the next in raster order (image_processing.c:1927-1990, `a`) */
+/* the pair rules of the pre-filter (image_processing.c:810-837, 1927-1990) on one pixel pair, as sign-normalised
+ * predicate arithmetic (no divergent branches): returns the two luma deltas packed as (d0 & 0xFFFF) | (d1 << 16) */
+__device__ __forceinline__ uint32_t prefilter_pair_delta(int k0, int k1, int prev_big)
+{
+	const int s0 = k0 < 0 ? -1 : 1, s1 = k1 < 0 ? -1 : 1, a0 = iabs(k0), a1 = iabs(k1);
+	const bool same = (k0 < 0) == (k1 < 0);
+	/* :810-837 -- |k| above 176 / 201 pulls the pixel by 1 / 2 against the sign; the second pixel is damped when the first one moved */
+	const int t0 = (a0 > 176) + (a0 > 201), t1 = (a1 > 176) + (a1 > 201);
+	int d0 = -s0 * t0;
+	const int m1 = t1 == 2 ? (t0 == 0 ? 2 : (t0 == 2 ? (same ? 0 : 2) : 1)) : (t1 == 1 ? !(t0 == 2 && same) : 0);
+	int d1 = -s1 * m1;
+	/* :1927-1990 -- a moderate kernel value next to a large one pushes the pixel the other way */
+	const bool mod0 = a0 > 10 && a0 < 32, mod1 = a1 > 10 && a1 < 32;
+	const bool first = mod0 && a1 >= 23;
+	const bool second = !first && mod1 && a0 >= 23;
+	const int k1n = s0 * k1, k0n = s1 * k0;                       /* neighbour value seen from the sign of the moderate one */
+	const int f0 = a0 < 16 ? 1 : (prev_big ? 1 : 2), f1 = (a0 < 16) && k1n > 0 && k1n < 32 && a0 > 11;
+	const int g1 = a1 < 16 ? 1 : 2, g0 = (a1 < 16) && k0n > 0 && k0n < 32 && a1 > 11;
+	d0 += first ? s0 * f0 : (second ? s1 * g0 : 0);
+	d1 += first ? s0 * f1 : (second ? s1 * g1 : 0);
+	return (uint32_t)(uint16_t)d0 | ((uint32_t)(uint16_t)d1 << 16);
+}
+/* hand-over flag to the next pair: set when the second pixel took the "+-2" branch above */
 __device__ __forceinline__ int pair_big_flag_fwd(int k0, int k1)
 {
-	if (((k0 < 32 && k0 > 10) || (k0 > -32 && k0 < -10)) && iabs(k1) >= 23) return 0;
-	if (k1 < 32 && k1 >= 16) return iabs(k0) >= 23;
-	if (k1 > -32 && k1 <= -16) return iabs(k0) >= 23;
-	return 0;
+	const int a0 = iabs(k0), a1 = iabs(k1);
+	const bool first = a0 > 10 && a0 < 32 && a1 >= 23;
+	return !first && a1 >= 16 && a1 < 32 && a0 >= 23;
 }
-/* the pair rules of the pre-filter (image_processing.c:810-837, 1927-1990) on one pixel pair */
 __device__ __forceinline__ void prefilter_pair(int k0, int k1, int prev_big, int &o0, int &o1)
 {
-	int tag;
-	if (k0 > 201) { o0 -= 2; tag = 4; }
-	else if (k0 < -201) { o0 += 2; tag = 3; }
-	else if (k0 > 176) { o0--; tag = 2; }
-	else if (k0 < -176) { o0++; tag = 1; }
-	else tag = 0;
-	if (k1 > 201) { if (!tag || tag == 3) o1 -= 2; else if (tag != 4) o1--; }
-	else if (k1 < -201) { if (!tag || tag == 4) o1 += 2; else if (tag != 3) o1++; }
-	else if (k1 > 176) { if (tag != 4) o1--; }
-	else if (k1 < -176) { if (tag != 3) o1++; }
-	if (k0 < 32 && k0 > 10) {
-		if (iabs(k1) >= 23) {
-			if (k0 < 16) { if (k1 > 0 && k1 < 32 && k0 > 11) o1++; o0++; }
-			else o0 += prev_big ? 1 : 2;
-			return;
-		}
-	} else if (k0 > -32 && k0 < -10) {
-		if (iabs(k1) >= 23) {
-			if (k0 > -16) { if (k1 < 0 && k1 > -32 && k0 < -11) o1--; o0--; }
-			else o0 -= prev_big ? 1 : 2;
-			return;
-		}
-	}
-	if (k1 < 32 && k1 > 10) {
-		if (iabs(k0) >= 23) {
-			if (k1 < 16) { if (k0 > 0 && k0 < 32 && k1 > 11) o0++; o1++; }
-			else o1 += 2;
-		}
-	} else if (k1 > -32 && k1 < -10) {
-		if (iabs(k0) >= 23) {
-			if (k1 > -16) { if (k0 < 0 && k0 > -32 && k1 < -11) o0--; o1--; }
-			else o1 -= 2;
-		}
-	}
+	const uint32_t d = prefilter_pair_delta(k0, k1, prev_big);
+	o0 += (int16_t)(d & 0xFFFF); o1 += (int16_t)(d >> 16);
 }
 
 /* vb[r][c] = sign(sum) * (15*|sum| + mag), 0 when sum == 0 (carry reset); interior pixels only */
@@ -435,7 +423,7 @@ __device__ __forceinline__ int contrast_at(const int16_t *p /* LDS, row stride F
 /* pre-pass: per row the 16-state transfer map of the carry and, for each of the 16 entry states, the hand-over
  * flag of the row's last pixel pair (509, 510).  One workgroup = 32 rows, 8 segments of 64 pixels per row. */
 __global__ __launch_bounds__(256) void k_front_rowmaps(const int16_t *__restrict__ yb, size_t y_stride, uint64_t *__restrict__ maps, size_t m_stride,
-                                                       uint16_t *__restrict__ flags, size_t f_stride)
+                                                       uint16_t *__restrict__ flags, size_t f_stride, uint64_t *__restrict__ segmaps, size_t g_stride)
 {
 	__shared__ int16_t ybuf[34 * FB_RS];
 	__shared__ uint64_t seg[32 * 8 * 2];
@@ -458,14 +446,23 @@ __global__ __launch_bounds__(256) void k_front_rowmaps(const int16_t *__restrict
 		if (row >= 1 && row <= W - 2) {
 			const int c0 = 1 + 64 * sg, c1 = sg == 7 ? W - 2 : c0 + 63;
 			const int16_t *p = ybuf + (rl + 1) * FB_RS;
+			/* 3x3 window slides along the row: three new LDS reads per pixel */
+			int u0 = p[-FB_RS + c0 - 1], u1 = p[-FB_RS + c0], m_0 = p[c0 - 1], m_1 = p[c0], d0 = p[FB_RS + c0 - 1], d1 = p[FB_RS + c0];
 			for (int c = c0; c <= c1; c++) {
-				const int vb = contrast_at(p + c);
+				const int u2 = p[-FB_RS + c + 1], m_2 = p[c + 1], d2 = p[FB_RS + c + 1];
+				const int e0 = m_1 - u0, e1 = m_1 - u1, e2 = m_1 - u2, e3 = m_1 - m_0, e4 = m_1 - m_2, e5 = m_1 - d0, e6 = m_1 - d1, e7 = m_1 - d2;
+				const int sum = e0 + e1 + e2 + e3 + e4 + e5 + e6 + e7;
+				const int mag = iabs(e0) + iabs(e1) + iabs(e2) + iabs(e3) + iabs(e4) + iabs(e5) + iabs(e6) + iabs(e7);
+				const int base = 15 * iabs(sum) + mag;
+				const int vb = sum == 0 ? 0 : (sum < 0 ? -base : base);
 				if (c == W - 3) { a0 = m0; a1 = m1; v509 = vb; }
 				if (c == W - 2) { b0 = m0; b1 = m1; v510 = vb; }
 				fsm_step16(m0, m1, vb);
+				u0 = u1; u1 = u2; m_0 = m_1; m_1 = m_2; d0 = d1; d1 = d2;
 			}
 		}
 		seg[2 * t] = m0; seg[2 * t + 1] = m1;
+		{ uint64_t *go = (uint64_t *)((uint8_t *)segmaps + (size_t)img * g_stride) + 2 * (8 * (size_t)(32 * band + rl) + sg); go[0] = m0; go[1] = m1; }
 		if (sg == 7) {                                              /* flags per entry state of the last segment */
 			unsigned f = 0;
 			for (int e = 0; e < 16; e++) {
@@ -516,18 +513,37 @@ __global__ void k_front_chain(const uint64_t *__restrict__ maps, size_t m_stride
 	}
 }
 
+/* ten luma values x[c0-2 .. c0+9] of one LDS row as six dwords (c0 even) */
+__device__ __forceinline__ void row_window(const int16_t *row, int c0, int v[12])
+{
+	const uint32_t *d = reinterpret_cast<const uint32_t *>(row) + (c0 >> 1) - 1;
+#pragma unroll
+	for (int k = 0; k < 6; k++) {
+		const uint32_t w = (k == 0 && c0 == 0) ? 0u : d[k];
+		v[2 * k] = (int16_t)(w & 0xFFFF); v[2 * k + 1] = (int16_t)(w >> 16);
+	}
+}
+
+__device__ unsigned long long g_band_stamp[16];
+#define STAMP(i) do { if (t == 0 && blockIdx.x == 7 && blockIdx.y == 100) g_band_stamp[i] = wall_clock64(); } while (0)
+
 template <int PRE>
 __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ yb, size_t y_stride, const uint8_t *__restrict__ st, size_t s_stride,
+                                                    const uint64_t *__restrict__ segmaps, size_t g_stride,
                                                     int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
                                                     int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
+	__shared__ uint8_t entry[FB_TROWS * 8];
+	__shared__ uint64_t segl[FB_TROWS * 16];
+	__shared__ uint8_t stl[FB_TROWS];
 	int16_t *ybuf = smem;                                          /* FB_YROWS rows */
 	int16_t *kbuf = smem + FB_YROWS * FB_RS;                       /* FB_TROWS rows */
 	const int band = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
 	const int k0 = FB_KB * band, t0 = 2 * k0 - 4;                  /* first horizontal-pass row (may be negative) */
 	const int16_t *y = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
 
+	STAMP(0);
 	for (int k = t; k < FB_YROWS * (W / 8); k += 256) {            /* stage rows t0-1 .. t0+37 */
 		const int ry = k / (W / 8), o = k % (W / 8), row = t0 - 1 + ry;
 		uint4 v = make_uint4(0, 0, 0, 0);
@@ -535,56 +551,131 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 		uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 8 * o);
 		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 	}
+	if (PRE) {                                                     /* the rows' segment maps and entry states ride along with the luma rows */
+		for (int k = t; k < FB_TROWS * 16; k += 256) {
+			const int row = t0 + (k >> 4);
+			if (row >= 1 && row <= W - 2) segl[k] = ((const uint64_t *)((const uint8_t *)segmaps + (size_t)img * g_stride))[16 * (size_t)row + (k & 15)];
+		}
+		if (t < FB_TROWS && t0 + t >= 1 && t0 + t <= W - 2) stl[t] = (st + (size_t)img * s_stride)[t0 + t];
+	}
 	__syncthreads();
+	STAMP(1);
 
 	if (PRE) {
-		for (int k = t; k < FB_TROWS * (W / 2); k += 256) {        /* contrast of the interior pixels */
-			const int rt = k / (W / 2), c = 2 * (k % (W / 2)), row = t0 + rt;
-			if (row < 1 || row > W - 2) continue;
-			const int16_t *p = ybuf + (rt + 1) * FB_RS;
-			if (c >= 1) kbuf[rt * FB_RS + c] = (int16_t)contrast_at(p + c);
-			if (c + 1 <= W - 2) kbuf[rt * FB_RS + c + 1] = (int16_t)contrast_at(p + c + 1);
+		/* items are (row, 8-pixel group) with the row index fastest: consecutive lanes sit one padded row (257
+		 * dwords) apart, i.e. on consecutive LDS banks */
+		for (int k = t; k < FB_TROWS * (W / 8); k += 256) {        /* contrast, 8 pixels per item */
+			const int rt = k % FB_TROWS, c0 = 8 * (k / FB_TROWS), row = t0 + rt;
+			uint32_t out[4] = { 0, 0, 0, 0 };
+			if (row >= 1 && row <= W - 2) {
+				int up[12], md[12], dn[12];
+				row_window(ybuf + rt * FB_RS, c0, up); row_window(ybuf + (rt + 1) * FB_RS, c0, md); row_window(ybuf + (rt + 2) * FB_RS, c0, dn);
+#pragma unroll
+				for (int e = 0; e < 8; e++) {                      /* pixel c0+e sits at window index e+2 */
+					const int c = c0 + e, ctr = md[e + 2];
+					const int e0 = ctr - up[e + 1], e1 = ctr - up[e + 2], e2 = ctr - up[e + 3], e3 = ctr - md[e + 1], e4 = ctr - md[e + 3],
+					          e5 = ctr - dn[e + 1], e6 = ctr - dn[e + 2], e7 = ctr - dn[e + 3];
+					const int sum = e0 + e1 + e2 + e3 + e4 + e5 + e6 + e7;
+					const int mag = iabs(e0) + iabs(e1) + iabs(e2) + iabs(e3) + iabs(e4) + iabs(e5) + iabs(e6) + iabs(e7);
+					const int base = 15 * iabs(sum) + mag;
+					const int vb = (sum == 0 || c < 1 || c > W - 2) ? 0 : (sum < 0 ? -base : base);
+					out[e >> 1] |= (uint32_t)(uint16_t)vb << (16 * (e & 1));
+				}
+			}
+			uint32_t *d = reinterpret_cast<uint32_t *>(kbuf + rt * FB_RS + c0);
+			d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3];
 		}
-		__syncthreads();
-		if (t < FB_TROWS) {                                        /* replay the carry along each row */
+		if (t < FB_TROWS) {                                        /* carry state at the start of every 64-pixel segment */
 			const int row = t0 + t;
 			if (row >= 1 && row <= W - 2) {
-				int16_t *km = kbuf + t * FB_RS;
-				int carry = (st + (size_t)img * s_stride)[row] & 15;
-				for (int c = 1; c <= W - 2; c++) {
-					const int vb = km[c];
-					if (vb == 0) carry = 0;
-					else {
-						const int acc = iabs(vb) + ((carry + 2) >> 2);
-						km[c] = (int16_t)(vb < 0 ? -(acc >> 4) : (acc >> 4));
-						carry = acc & 15;
-					}
+				const uint64_t *gm = segl + 16 * t;
+				int sv = stl[t] & 15;
+				for (int sg = 0; sg < 8; sg++) {
+					entry[t * 8 + sg] = (uint8_t)sv;
+					const uint64_t w = gm[2 * sg + (sv >> 3)];
+					sv = (int)((w >> (8 * (sv & 7))) & 15);
 				}
 			}
 		}
 		__syncthreads();
-		for (int k = t; k < FB_TROWS * 255; k += 256) {            /* pixel pairs (c, c+1), c odd */
-			const int rt = k / 255, pr = k % 255, row = t0 + rt, c = 1 + 2 * pr;
-			if (row < 1 || row > W - 2) continue;
-			const int16_t *km = kbuf + rt * FB_RS;
-			int16_t *o = ybuf + (rt + 1) * FB_RS + c;
-			const int kk0 = km[c], kk1 = km[c + 1];
-			const int prev_big = pr > 0 ? pair_big_flag_fwd(km[c - 2], km[c - 1]) : (((st + (size_t)img * s_stride)[row] >> 4) & 1);
-			int o0 = o[0], o1 = o[1];
-			prefilter_pair(kk0, kk1, prev_big, o0, o1);
-			o[0] = (int16_t)o0; o[1] = (int16_t)o1;
+		STAMP(2);
+		/* one lane per (row, 64-pixel segment), eight pixels at a time through registers (small loop bodies: a
+		 * fully unrolled 64-step version overflows the instruction cache and runs 10x slower) */
+		for (int it = 0; it < 2; it++) {                           /* replay the carry */
+			const int k = t + 256 * it;
+			const int rt = k % FB_TROWS, sg = k / FB_TROWS, row = t0 + rt;
+			if (k >= FB_TROWS * 8 || row < 1 || row > W - 2) continue;
+			int16_t *km = kbuf + rt * FB_RS + 1 + 64 * sg;         /* segment pixel 0 = column 1 + 64 sg */
+			const int npx = sg == 7 ? 62 : 64;
+			int carry = entry[rt * 8 + sg];
+			for (int ch = 0; ch < 8; ch++) {
+				int16_t v[8];
+#pragma unroll
+				for (int e = 0; e < 8; e++) v[e] = km[8 * ch + e];
+#pragma unroll
+				for (int e = 0; e < 8; e++) {
+					if (8 * ch + e < npx) {
+						const int vb = v[e];
+						if (vb == 0) carry = 0;
+						else {
+							const int acc = iabs(vb) + ((carry + 2) >> 2);
+							v[e] = (int16_t)(vb < 0 ? -(acc >> 4) : (acc >> 4));
+							carry = acc & 15;
+						}
+					}
+				}
+#pragma unroll
+				for (int e = 0; e < 8; e++) if (8 * ch + e < npx) km[8 * ch + e] = v[e];
+			}
 		}
 		__syncthreads();
+		STAMP(3);
+		for (int k = t; k < FB_TROWS * 64; k += 256) {             /* pair rules: four pairs (8 pixels) per item, no serial dependence left */
+			const int rt = k % FB_TROWS, g = k / FB_TROWS, row = t0 + rt;
+			if (row < 1 || row > W - 2) continue;
+			const int16_t *km = kbuf + rt * FB_RS + 8 * g;         /* pairs (8g+1, 8g+2) .. (8g+7, 8g+8) */
+			int16_t *yo = ybuf + (rt + 1) * FB_RS + 8 * g;
+			int16_t v[10];
+#pragma unroll
+			for (int e = 0; e < 10; e++) v[e] = (g == 0 && e == 0) ? (int16_t)0 : km[e - 1];   /* columns 8g-1 .. 8g+8 */
+			int prev_big = g ? pair_big_flag_fwd(v[0], v[1]) : ((stl[rt] >> 4) & 1);
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const int c = 8 * g + 1 + 2 * e;
+				if (c <= W - 3) {
+					const uint32_t dd = prefilter_pair_delta(v[2 * e + 2], v[2 * e + 3], prev_big);
+					if (dd & 0xFFFF) yo[1 + 2 * e] = (int16_t)(yo[1 + 2 * e] + (int16_t)(dd & 0xFFFF));
+					if (dd >> 16) yo[2 + 2 * e] = (int16_t)(yo[2 + 2 * e] + (int16_t)(dd >> 16));
+					prev_big = pair_big_flag_fwd(v[2 * e + 2], v[2 * e + 3]);
+				}
+			}
+		}
+		__syncthreads();
+		STAMP(4);
 	}
 
-	for (int k = t; k < FB_TROWS * (W / 2); k += 256) {            /* horizontal pass (filters.c:346-386) into kbuf */
-		const int rt = k >> 8, kx = k & 255, row = t0 + rt;
+	for (int k = t; k < FB_TROWS * 64; k += 256) {                 /* horizontal pass (filters.c:346-386) into kbuf, four kx per item */
+		const int rt = k % FB_TROWS, g = k / FB_TROWS, row = t0 + rt;
 		if (row < 0 || row >= W) continue;
-		const int16_t *x = ybuf + (rt + 1) * FB_RS;
-		kbuf[rt * FB_RS + kx] = (int16_t)tap5(x, W, kx);
-		kbuf[rt * FB_RS + H + kx] = (int16_t)(kx < H - 1 ? (x[2 * kx + 1] << 1) - (x[2 * kx] + x[2 * kx + 2]) : ((x[W - 1] - x[W - 2]) << 1));
+		int x[12];
+		row_window(ybuf + (rt + 1) * FB_RS, 8 * g, x);             /* x[i] = luma[8g - 2 + i] */
+		if (g == 0) { x[0] = x[4]; x[1] = x[3]; }                  /* x[-2] = x[2], x[-1] = x[1] */
+		if (g == 63) x[10] = x[8];                                 /* x[512] = x[510] */
+		uint32_t lo[2], hi[2];
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			const int i = 2 * e + 2;                               /* x[2kx] */
+			const int l = 6 * x[i] + 2 * (x[i - 1] + x[i + 1]) - (x[i - 2] + x[i + 2]);
+			int h = (x[i + 1] << 1) - (x[i] + x[i + 2]);
+			if (g == 63 && e == 3) h = (x[i + 1] - x[i]) << 1;
+			if (e & 1) { lo[e >> 1] |= (uint32_t)(uint16_t)l << 16; hi[e >> 1] |= (uint32_t)(uint16_t)h << 16; }
+			else { lo[e >> 1] = (uint16_t)l; hi[e >> 1] = (uint16_t)h; }
+		}
+		uint32_t *dl = reinterpret_cast<uint32_t *>(kbuf + rt * FB_RS + 4 * g), *dh = reinterpret_cast<uint32_t *>(kbuf + rt * FB_RS + H + 4 * g);
+		dl[0] = lo[0]; dl[1] = lo[1]; dh[0] = hi[0]; dh[1] = hi[1];
 	}
 	__syncthreads();
+	STAMP(5);
 
 	int16_t *proc = procb + (size_t)img * plane_stride, *jpeg = jpegb + (size_t)img * plane_stride;
 	int16_t *ll1 = ll1b + (size_t)img * ll1_stride;
@@ -642,12 +733,14 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 		}
 	}
 	__syncthreads();
+	STAMP(6);
 	for (int k = t; k < FB_KB * (H / 2); k += 256) {               /* jpeg[ky][kx] and ll1[ky][kx], kx < 256 (wavelet_filterbank.c:172-184, nhw_encoder.c:127-135) */
 		const int kk = k >> 7, o = k & 127;
 		const uint32_t v = (uint16_t)ybuf[kk * FB_RS + 2 * o] | ((uint32_t)(uint16_t)ybuf[kk * FB_RS + 2 * o + 1] << 16);
 		reinterpret_cast<uint32_t *>(jpeg + (size_t)(k0 + kk) * W)[o] = v;
 		reinterpret_cast<uint32_t *>(ll1 + (size_t)(k0 + kk) * H)[o] = v;
 	}
+	STAMP(7);
 }
 
 /* SURVEY.md section 8d generator, one lane per image (setup only, never timed) */
@@ -733,7 +826,7 @@ void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stri
 /* fused pre-filter + level-1 analysis (+ LL copy-back, ll1, keep): replaces nhw_launch_prefilter + the size-512 nhw_launch_analysis
  * + the ll1 block copy of the batch driver */
 void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilter, uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
-                            uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
+                            uint64_t *segmaps, size_t g_stride, uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
                             int16_t *keep, size_t keep_stride, int n, hipStream_t s)
 {
 	const size_t lds = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
@@ -745,12 +838,14 @@ void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilte
 	}
 	const dim3 grid(H / FB_KB, n);
 	if (with_prefilter) {
-		k_front_rowmaps<<<grid, 256, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride);
+		k_front_rowmaps<<<grid, 256, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride, segmaps, g_stride);
 		k_front_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, flags, f_stride, st, s_stride, n);
-		k_front_band<1><<<grid, 256, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
+		k_front_band<1><<<grid, 256, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
 	} else
-		k_front_band<0><<<grid, 256, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
+		k_front_band<0><<<grid, 256, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
 }
+
+void nhw_debug_band_stamps(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(nhw::g_band_stamp), sizeof(unsigned long long) * 16); }
 
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s)
 {
