@@ -535,7 +535,6 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	__shared__ uint8_t entry[FB_TROWS * 8];
-	__shared__ uint64_t segl[FB_TROWS * 16];
 	__shared__ uint8_t stl[FB_TROWS];
 	int16_t *ybuf = smem;                                          /* FB_YROWS rows */
 	int16_t *kbuf = smem + FB_YROWS * FB_RS;                       /* FB_TROWS rows */
@@ -551,6 +550,7 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 		uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 8 * o);
 		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 	}
+	uint64_t *segl = reinterpret_cast<uint64_t *>(kbuf);           /* kbuf is free until the contrast pass: it hosts the segment maps first */
 	if (PRE) {                                                     /* the rows' segment maps and entry states ride along with the luma rows */
 		for (int k = t; k < FB_TROWS * 16; k += 256) {
 			const int row = t0 + (k >> 4);
@@ -562,6 +562,19 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 	STAMP(1);
 
 	if (PRE) {
+		if (t < FB_TROWS) {                                        /* carry state at the start of every 64-pixel segment */
+			const int row = t0 + t;
+			if (row >= 1 && row <= W - 2) {
+				const uint64_t *gm = segl + 16 * t;
+				int sv = stl[t] & 15;
+				for (int sg = 0; sg < 8; sg++) {
+					entry[t * 8 + sg] = (uint8_t)sv;
+					const uint64_t w = gm[2 * sg + (sv >> 3)];
+					sv = (int)((w >> (8 * (sv & 7))) & 15);
+				}
+			}
+		}
+		__syncthreads();
 		/* items are (row, 8-pixel group) with the row index fastest: consecutive lanes sit one padded row (257
 		 * dwords) apart, i.e. on consecutive LDS banks */
 		for (int k = t; k < FB_TROWS * (W / 8); k += 256) {        /* contrast, 8 pixels per item */
@@ -584,18 +597,6 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 			}
 			uint32_t *d = reinterpret_cast<uint32_t *>(kbuf + rt * FB_RS + c0);
 			d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3];
-		}
-		if (t < FB_TROWS) {                                        /* carry state at the start of every 64-pixel segment */
-			const int row = t0 + t;
-			if (row >= 1 && row <= W - 2) {
-				const uint64_t *gm = segl + 16 * t;
-				int sv = stl[t] & 15;
-				for (int sg = 0; sg < 8; sg++) {
-					entry[t * 8 + sg] = (uint8_t)sv;
-					const uint64_t w = gm[2 * sg + (sv >> 3)];
-					sv = (int)((w >> (8 * (sv & 7))) & 15);
-				}
-			}
 		}
 		__syncthreads();
 		STAMP(2);
