@@ -136,7 +136,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": f"batch of {batch} synthetic 512x512 BGR24 images per GPU, -q{q}, whole encoder (BGR in HBM -> .nhw bytes in HBM)",
                        "images_per_gpu": batch, "quality": q, "parallelism": f"dp{world} (independent images, no data-path collective)"},
-            "roofline": {"bound": "hbm", "kernel": "front = k_color + k_pre_* (q<=21) + level-1 analysis (k_ana_rows<1>, k_transpose, k_ana_rows<2>, k_transpose)",
+            "roofline": {"bound": "hbm", "kernel": "front = k_color + k_front_rowmaps + k_front_chain + k_front_band (colour, pre-filter and level-1 analysis; the band kernel fuses pre-filter + both filter directions)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None, "algorithmic_bytes_per_image": FRONT_BYTES_PER_IMAGE, "ms_per_launch_group": round(front_s * 1e3, 3)},
             "stage_ms": {"front": round(tim.front_ms, 3), "luma_tail": round(tim.luma_ms, 3), "chroma": round(tim.chroma_ms, 3),
