@@ -14,12 +14,13 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	__shared__ int sh_counts[2];
 	__shared__ int sh_pos[2 * NT + 2];
 	__shared__ uint32_t sh_z[4 * Q / 16 / 32 + 4];
+	extern __shared__ __attribute__((aligned(16))) int16_t dyn_lds[];   /* LDS tiles of the row-serial passes (size chosen per phase at launch) */
 	__shared__ PackShared sh_pack;
 	const int img = blockIdx.x, tid = threadIdx.x;
 	Ctx c;
 	ctx_load(&c, ws, img);
 	if (PH == PH_L1) luma_p1_par(&c, tid, sh_pos);
-	else if (PH == PH_L2) luma_p2_par(&c, tid);
+	else if (PH == PH_L2) luma_p2_par(&c, tid, dyn_lds);
 	else if (PH == PH_L3) luma_p3_par(&c, tid, sh_pos, sh_counts);
 	else if (PH == PH_L4) luma_p4_par(&c, tid, sh_counts, sh_pos, sh_z);
 	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
@@ -40,20 +41,40 @@ __global__ __launch_bounds__(256) void k_copy_block(const int16_t *__restrict__ 
 	if (c < cols) dst[(size_t)img * dst_plane + (size_t)r * dst_row + c] = src[(size_t)img * src_plane + (size_t)r * src_row + c];
 }
 
+/* dynamic LDS per phase: number of 256-row column tiles (TLS shorts per row) the phase stages at once */
+static size_t phase_lds(int ph)
+{
+	const size_t tile = (size_t)NT * TLS * sizeof(int16_t);
+	switch (ph) {
+	case PH_L2: return 2 * tile;
+	default: return 0;
+	}
+}
+
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s)
 {
 	const dim3 g(ws.n), b(256);
+	static bool attr_set = false;
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L4>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_C5>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
+		attr_set = true;
+	}
+	const size_t lds = phase_lds(ph);
 	switch (ph) {
-	case PH_L1: k_phase<PH_L1><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
-	case PH_L2: k_phase<PH_L2><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
-	case PH_L3: k_phase<PH_L3><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
-	case PH_L4: k_phase<PH_L4><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
-	case PH_C0: k_phase<PH_C0><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
-	case PH_C2: k_phase<PH_C2><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
-	case PH_C3: k_phase<PH_C3><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
-	case PH_C4: k_phase<PH_C4><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
-	case PH_C5: k_phase<PH_C5><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
-	case PH_FINAL: k_phase<PH_FINAL><<<g, b, 0, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L1: k_phase<PH_L1><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L2: k_phase<PH_L2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L3: k_phase<PH_L3><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L4: k_phase<PH_L4><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_C0: k_phase<PH_C0><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_C2: k_phase<PH_C2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_C3: k_phase<PH_C3><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_C4: k_phase<PH_C4><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_C5: k_phase<PH_C5><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_FINAL: k_phase<PH_FINAL><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	}
 }
 

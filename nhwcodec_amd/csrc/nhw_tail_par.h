@@ -42,20 +42,41 @@ DEV void tag_l2_details_par(Ctx *c, int tid)
 	}
 }
 
-/* Y8 (:183-216): every tagged coefficient owns a distinct target sample */
-DEV void apply_tags_par(Ctx *c, int tid)
+/* Y8 (:183-216): every tagged L2 coefficient (r, j) of the transposed coefficient plane nudges the recon sample
+ * that sits under it in the natural-orientation plane: (2(j-128)+1, 2r), (2j, 2(r-128)+1) or (2(j-128)+1,
+ * 2(r-128)+1).  That is a transposition; done naively it is 49k scattered 2-byte read-modify-writes per image
+ * (measured: 133 GB fetched per batch).  Here it goes through LDS in 64x64 target tiles: the three 32x32 blocks
+ * of tags that land in a tile are read (and cleaned) row-wise, their +-1 steps are parked in LDS, and the
+ * target rows are updated with coalesced dword read-modify-writes. */
+DEV void apply_tags_par(Ctx *c, int tid, int16_t *lds)
 {
-	int16_t *p = c->proc;
-	for (int idx = tid; idx < Q; idx += NT) {
-		const int r = idx >> 8, j = idx & 255;
-		int16_t *cell = c->ll1 + idx;
-		int step;
-		if (*cell > 14000) { *cell -= 16000; step = 1; }
-		else if (*cell > 10000) { *cell -= 12000; step = -1; }
-		else continue;
-		if (r < H / 2 && j >= H / 2) p[(2 * (j - H / 2) + 1) * W + 2 * r] += step;
-		else if (r >= H / 2 && j < H / 2) p[2 * j * W + 2 * (r - H / 2) + 1] += step;
-		else if (r >= H / 2 && j >= H / 2) p[(2 * (j - H / 2) + 1) * W + 2 * (r - H / 2) + 1] += step;
+	int8_t *steps = reinterpret_cast<int8_t *>(lds);              /* [3][32][33] */
+	int16_t *p = c->proc, *o = c->ll1;
+	for (int tile = 0; tile < 16; tile++) {
+		const int ty = tile >> 2, tx = tile & 3;                  /* target rows 64ty.., cols 64tx.. */
+		for (int k = tid; k < 3 * 1024; k += NT) {
+			const int type = k >> 10, rl = (k >> 5) & 31, jl = k & 31;
+			const int r = 32 * tx + rl + (type >= 1 ? H / 2 : 0), j = 32 * ty + jl + (type != 1 ? H / 2 : 0);   /* 0: (r<128, j>=128), 1: (r>=128, j<128), 2: both >= 128 */
+			int16_t *cell = o + r * H + j;
+			int step = 0;
+			if (*cell > 14000) { *cell -= 16000; step = 1; }
+			else if (*cell > 10000) { *cell -= 12000; step = -1; }
+			steps[(type * 32 + rl) * 33 + jl] = (int8_t)step;
+		}
+		BARRIER();
+		for (int k = tid; k < 64 * 32; k += NT) {                 /* one dword = target cells (yy, xx), (yy, xx+1), xx even */
+			const int yl = k >> 5, xl = 2 * (k & 31), yy = 64 * ty + yl, xx = 64 * tx + xl;
+			const int rl = xl >> 1, jl = yl >> 1;
+			int s0 = 0, s1 = 0;
+			if (yy & 1) { s0 = steps[(0 * 32 + rl) * 33 + jl]; s1 = steps[(2 * 32 + rl) * 33 + jl]; }   /* odd row: even col <- type 0, odd col <- type 2 */
+			else s1 = steps[(1 * 32 + rl) * 33 + jl];                                                      /* even row: odd col <- type 1 */
+			if (s0 | s1) {
+				uint32_t *w = reinterpret_cast<uint32_t *>(p + yy * W + xx);
+				const uint32_t v = *w;
+				*w = (uint32_t)(uint16_t)((int16_t)(v & 0xFFFF) + s0) | ((uint32_t)(uint16_t)((int16_t)(v >> 16) + s1) << 16);
+			}
+		}
+		BARRIER();
 	}
 }
 
@@ -69,36 +90,98 @@ DEV void copy_block_par(const int16_t *src, int src_row, int16_t *dst, int dst_r
 	}
 }
 
+/* ---------------------------------------------------------------- LDS column tiles for the row-serial passes */
+/* A thread that walks "its" row of a plane touches one 2-byte cell of a different cache line than its
+ * neighbours at every step: measured 10-30x HBM read amplification (profiles/round1_pmc_front.json).  The
+ * row-serial passes therefore run on tiles: 64 columns (+2 halo columns on each side) of all the rows of the
+ * pass are staged in LDS with row-contiguous (coalesced) dword loads, every thread walks its row inside LDS,
+ * and the tile goes back with coalesced stores.  Tile rows are TLS shorts apart (34 dwords: two rows share a
+ * bank only 32 rows apart).  Halo columns are addressed linearly, so "one cell past the end of the row" is the
+ * first cell of the next row, exactly as in the reference's linear indexing. */
+#define TLC 64
+#define TLS 68
+DEV void tile_load(int16_t *lds, const int16_t *plane, int rs, int nrows, int c0, int tid)
+{
+	for (int idx = tid; idx < nrows * (TLS / 2); idx += NT) {
+		const int r = idx / (TLS / 2), d = idx % (TLS / 2);
+		reinterpret_cast<uint32_t *>(lds + r * TLS)[d] = reinterpret_cast<const uint32_t *>(plane + (size_t)r * rs + c0 - 2)[d];
+	}
+}
+DEV void tile_store(const int16_t *lds, int16_t *plane, int rs, int nrows, int c0, int ncols /* even, <= TLC + 2 */, int tid)
+{
+	const int nd = ncols >> 1;
+	for (int idx = tid; idx < nrows * nd; idx += NT) {
+		const int r = idx / nd, d = idx % nd + 1;
+		reinterpret_cast<uint32_t *>(plane + (size_t)r * rs + c0 - 2)[d] = reinterpret_cast<const uint32_t *>(lds + r * TLS)[d];
+	}
+}
+
+/* run(row, r, j, j1, state): process columns [j, j1) of row r (row[jj] is the cell of absolute column jj, valid for
+ * c0-2 <= jj < c0+66), return the next column to visit (>= j1; skips may overshoot into the next tile) */
+template <class F>
+DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int jb, int je, int16_t *lds, int tid, F f)
+{
+	int jnext = jb;
+	typename F::State st = f.init(tid);
+	for (int c0 = (jb / TLC) * TLC; c0 < je; c0 += TLC) {
+		tile_load(lds, plane, rs, nrows, c0, tid);
+		BARRIER();
+		if (tid < nrows) {
+			const int j1 = c0 + TLC < je ? c0 + TLC : je;
+			if (jnext < j1) jnext = f.run(lds + tid * TLS + 2 - c0, tid, jnext, j1, st);
+		}
+		BARRIER();
+		int nst = TLC + 2;
+		if (row_end - c0 < nst) nst = row_end - c0;
+		if (je + 2 - c0 < nst) nst = (je + 2 - c0 + 1) & ~1;
+		tile_store(lds, plane, rs, nrows, c0, nst, tid);
+		BARRIER();
+	}
+}
+
 /* ---------------------------------------------------------------- Y9 (R) */
 /* (:218-279) left neighbour is read after its own update, right neighbour before: serial along a row; rows do
  * not interact (column 0 reads proc[r][-1] = the LH1 cell (r-1, 511), which this pass never writes). */
-DEV void precompensate_ll1_par(Ctx *c, int tid)
+DEV void precompensate_ll1_par(Ctx *c, int tid, int16_t *lds /* two tiles */)
 {
-	int16_t *p = c->proc, *jp = c->jpeg;
-	const int16_t *o = c->ll1;
+	int16_t *tp = lds, *to = lds + NT * TLS;                     /* recon tile (read/write), ll1 tile (read; receives the jpeg values) */
 	const int r = tid;
-	for (int j = 0; j < H; j++) {
-		const int e = r * W + j, k = r * H + j, d = p[e] - o[k];
-		int step = big_step(d);
-		if (!step && iabs(d) > 1) {
-			int a = p[e + 1] - o[k + 1];
-			if (iabs(a) > 4) a += big_step(a);
-			a += p[e - 1] - o[k - 1];
-			if (d >= 4 && a >= 1) step = -1;
-			else if (d <= -4 && a <= -1) step = 1;
-			else if (d == 3 && a >= 0) step = -1;
-			else if (d == -3 && a <= 0) step = 1;
-			else if (iabs(a) >= 3) {
-				if (d > 0 && a > 0) step = -1;
-				else if (d < 0 && a < 0) step = 1;
-				else if (a >= 5) step = -2;
-				else if (a <= -5) step = 2;
-				else if (a >= 4) step = -1;
-				else if (a <= -4) step = 1;
+	for (int c0 = 0; c0 < H; c0 += TLC) {
+		tile_load(tp, c->proc, W, H, c0, tid);
+		tile_load(to, c->ll1, H, H, c0, tid);
+		BARRIER();
+		{
+			int16_t *p = tp + r * TLS + 2 - c0, *o = to + r * TLS + 2 - c0;
+			int prev = p[c0 - 1] - o[c0 - 1];                    /* left neighbour after its own update */
+			for (int j = c0; j < c0 + TLC; j++) {
+				const int ov = o[j], d = p[j] - ov;
+				int step = big_step(d);
+				if (!step && iabs(d) > 1) {
+					int a = p[j + 1] - o[j + 1];
+					if (iabs(a) > 4) a += big_step(a);
+					a += prev;
+					if (d >= 4 && a >= 1) step = -1;
+					else if (d <= -4 && a <= -1) step = 1;
+					else if (d == 3 && a >= 0) step = -1;
+					else if (d == -3 && a <= 0) step = 1;
+					else if (iabs(a) >= 3) {
+						if (d > 0 && a > 0) step = -1;
+						else if (d < 0 && a < 0) step = 1;
+						else if (a >= 5) step = -2;
+						else if (a <= -5) step = 2;
+						else if (a >= 4) step = -1;
+						else if (a <= -4) step = 1;
+					}
+				}
+				p[j] = (int16_t)(p[j] + step);
+				prev = d + step;
+				o[j] = (int16_t)(ov + step);                     /* the jpeg value; o[j] itself is not needed again (prev carries the difference) */
 			}
 		}
-		jp[e] = (int16_t)(o[k] + step);
-		p[e] = (int16_t)(p[e] + step);
+		BARRIER();
+		tile_store(tp, c->proc, W, H, c0, TLC, tid);
+		tile_store(to, c->jpeg, W, H, c0, TLC, tid);
+		BARRIER();
 	}
 }
 
@@ -996,13 +1079,13 @@ DEV void luma_p1_par(Ctx *c, int tid, int *pos)
 	dequant_sim_luma_par(c, 1, tid, pos);
 	if (!tid) PROF(c, 1);
 }
-DEV void luma_p2_par(Ctx *c, int tid)
+DEV void luma_p2_par(Ctx *c, int tid, int16_t *lds)
 {
 	PROF_BEGIN();
-	apply_tags_par(c, tid);
+	apply_tags_par(c, tid, lds);
 	BARRIER();
 	if (!tid) PROF(c, 2);
-	precompensate_ll1_par(c, tid);
+	precompensate_ll1_par(c, tid, lds);
 	if (!tid) PROF(c, 3);
 }
 DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc)
