@@ -107,34 +107,35 @@ DEV void tile_load(int16_t *lds, const int16_t *plane, int rs, int nrows, int c0
 		reinterpret_cast<uint32_t *>(lds + r * TLS)[d] = reinterpret_cast<const uint32_t *>(plane + (size_t)r * rs + c0 - 2)[d];
 	}
 }
-DEV void tile_store(const int16_t *lds, int16_t *plane, int rs, int nrows, int c0, int ncols /* even, <= TLC + 2 */, int tid)
+DEV void tile_store(const int16_t *lds, int16_t *plane, int rs, int nrows, int c0, int ncols /* even, <= TLC + 2 */, int tid, int first = 2 /* 2: from column c0, 0: from c0-2 */)
 {
-	const int nd = ncols >> 1;
+	const int d0 = first >> 1, nd = (ncols + (2 - first)) >> 1;
 	for (int idx = tid; idx < nrows * nd; idx += NT) {
-		const int r = idx / nd, d = idx % nd + 1;
+		const int r = idx / nd, d = idx % nd + d0;
 		reinterpret_cast<uint32_t *>(plane + (size_t)r * rs + c0 - 2)[d] = reinterpret_cast<const uint32_t *>(lds + r * TLS)[d];
 	}
 }
 
-/* run(row, r, j, j1, state): process columns [j, j1) of row r (row[jj] is the cell of absolute column jj, valid for
- * c0-2 <= jj < c0+66), return the next column to visit (>= j1; skips may overshoot into the next tile) */
+/* run(row, r, j, j1, state): process columns [j, j1) of processing row r (row[jj] is the cell of absolute column jj,
+ * valid for c0-2 <= jj < c0+66; row[jj +- TLS] are the plane rows below / above), return the next column to visit
+ * (>= j1; skips may overshoot into the next tile).  The tile holds `nrows` plane rows starting at `plane`; thread t
+ * (t < nproc) owns tile row t + roff.  Cells the pass may write: own row, columns c0-2 .. c0+65. */
 template <class F>
-DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int jb, int je, int16_t *lds, int tid, F f)
+DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff, int nproc, int jb, int je, int16_t *lds, int tid, F f)
 {
 	int jnext = jb;
 	typename F::State st = f.init(tid);
 	for (int c0 = (jb / TLC) * TLC; c0 < je; c0 += TLC) {
 		tile_load(lds, plane, rs, nrows, c0, tid);
 		BARRIER();
-		if (tid < nrows) {
+		if (tid < nproc) {
 			const int j1 = c0 + TLC < je ? c0 + TLC : je;
-			if (jnext < j1) jnext = f.run(lds + tid * TLS + 2 - c0, tid, jnext, j1, st);
+			if (jnext < j1) jnext = f.run(lds + (tid + roff) * TLS + 2 - c0, tid, jnext, j1, st);
 		}
 		BARRIER();
 		int nst = TLC + 2;
 		if (row_end - c0 < nst) nst = row_end - c0;
-		if (je + 2 - c0 < nst) nst = (je + 2 - c0 + 1) & ~1;
-		tile_store(lds, plane, rs, nrows, c0, nst, tid);
+		tile_store(lds + roff * TLS, plane + (size_t)roff * rs, rs, nproc, c0, nst, tid, c0 > 0 ? 0 : 2);
 		BARRIER();
 	}
 }
@@ -409,15 +410,14 @@ DEV void dequant_sim_luma_par(Ctx *c, int part, int tid, int *pos)
 
 /* ---------------------------------------------------------------- Y21 (R) */
 /* (:970-1073) only same-row neighbours are read or written (the vertical branches are unreachable) */
-DEV void tag_small_runs_par(Ctx *c, int tid)
-{
-	int16_t *p = c->proc;
-	for (int pass = 0; pass < 2; pass++) {
-		const int r = pass ? H + 1 + tid : 1 + tid;
-		const int j0 = pass ? 1 : H + 1, j1 = pass ? H - 1 : W - 1;
-		if (tid >= H - 2) continue;
-		for (int j = j0; j < j1; j++) {
-			int16_t *v = p + r * W + j;
+struct TagRunsF {
+	int pass;
+	struct State { int unused; };
+	__device__ State init(int) const { return State{0}; }
+	__device__ int run(int16_t *row, int, int j, int j1, State &) const
+	{
+		for (; j < j1; j++) {
+			int16_t *v = row + j;
 			if (v[0] > 4 && v[0] < 8) { if (in_4_7(v[-1]) && in_4_7(v[1])) { v[0] = 12700; v[-1] = 10100; v[1] = 10100; } }
 			else if (v[0] < -4 && v[0] > -8) { if (in_m7_m4(v[-1]) && in_m7_m4(v[1])) { v[0] = 12900; v[-1] = 10100; v[1] = 10100; } }
 			else if (v[0] == 8) {
@@ -429,7 +429,14 @@ DEV void tag_small_runs_par(Ctx *c, int tid)
 				else if (!pass && v[1] == -8) { v[0] = -9; v[1] = -9; }
 			}
 		}
+		return j;
 	}
+};
+DEV void tag_small_runs_par(Ctx *c, int tid, int16_t *lds)
+{
+	TagRunsF f0 = { 0 }, f1 = { 1 };
+	row_pass_tiled(c->proc + 1 * W, W, W, H - 2, 0, H - 2, H + 1, W - 1, lds, tid, f0);          /* rows 1..254, LH1 columns */
+	row_pass_tiled(c->proc + (H + 1) * W, W, W, H - 2, 0, H - 2, 1, H - 1, lds, tid, f1);        /* rows 257..510, HL1 columns */
 }
 
 /* ---------------------------------------------------------------- Y22 / Y23 (C) */
@@ -627,150 +634,176 @@ DEV void adjust_first_order_par(Ctx *c, int tid)
  * neighbours are taken from a snapshot of the band, ">= 7" for the row above, ">= 6" for the row below (a cell
  * is >= 7 after its visit exactly when it was >= 7 before).  HH1 also reads column 256, which HL1's ripple may
  * have written, hence the barrier between them. */
-DEV void clean_row(int16_t *p, int r, int j0, int j1, int thresh, int lim, int lim2, int mode, int last_look, const int16_t *snap)
-{
-	for (int j = j0; j < j1; j++) {
-		int16_t *v = p + r * W + j;
-		if (iabs(v[0]) >= thresh) {
-			if (iabs(v[0]) < lim2) {
-				int n;
-				if (mode == 2) {
-					const int16_t *sv = snap + (r - H) * H + (j - H);
-					n = (iabs(v[-1]) >= 6) + (iabs(v[1]) >= 6) + (r == H ? iabs(v[-W]) >= 6 : iabs(sv[-H]) >= 7) + (r == W - 1 ? 0 : (iabs(sv[H]) >= 6));
-				} else n = loud_neighbours(v);
-				if (mode == 0) { if (n < 3 && v[0] < lim && v[0] > -lim) { if (v[0] < -6) v[0] = -7; else if (v[0] > 6) v[0] = 7; } }
-				else if (mode == 1) { if ((n < 3 && v[0] < lim && v[0] > -lim) || !n) v[0] = (int16_t)(v[0] < 0 ? -7 : 7); }
-				else { if (n < 3) v[0] = (int16_t)(v[0] < 0 ? -7 : 7); }
-			}
-		} else v[0] = 0;
-		ripple(v, j < last_look);
+struct CleanF {
+	int thresh, lim, lim2, mode, last_look, row0;
+	const int16_t *snap;
+	struct State { int unused; };
+	__device__ State init(int) const { return State{0}; }
+	__device__ int run(int16_t *row, int t, int j, int j1, State &) const
+	{
+		const int r = row0 + t;
+		for (; j < j1; j++) {
+			int16_t *v = row + j;
+			if (iabs(v[0]) >= thresh) {
+				if (iabs(v[0]) < lim2) {
+					int n;
+					if (mode == 2) {
+						const int16_t *sv = snap + (r - H) * H + (j - H);
+						n = (iabs(v[-1]) >= 6) + (iabs(v[1]) >= 6) + (r == H ? iabs(v[-TLS]) >= 6 : iabs(sv[-H]) >= 7) + (iabs(sv[H]) >= 6);
+					} else n = (iabs(v[-1]) >= 6) + (iabs(v[1]) >= 6) + (iabs(v[-TLS]) >= 6) + (iabs(v[TLS]) >= 6);
+					if (mode == 0) { if (n < 3 && v[0] < lim && v[0] > -lim) { if (v[0] < -6) v[0] = -7; else if (v[0] > 6) v[0] = 7; } }
+					else if (mode == 1) { if ((n < 3 && v[0] < lim && v[0] > -lim) || !n) v[0] = (int16_t)(v[0] < 0 ? -7 : 7); }
+					else { if (n < 3) v[0] = (int16_t)(v[0] < 0 ? -7 : 7); }
+				}
+			} else v[0] = 0;
+			ripple(v, j < last_look);
+		}
+		return j;
 	}
-}
-DEV void clean_details_par(Ctx *c, int tid)
+};
+DEV void clean_details_par(Ctx *c, int tid, int16_t *lds)
 {
 	int16_t *p = c->proc;
 	const int q = c->q;
-	if (tid < H - 2) clean_row(p, 1 + tid, H + 1, W - 1, DEADZONE - 2, q > 22 ? 8 : 9, q > 22 ? 4 : 9, 0, W - 2, nullptr);
-	if (tid < H - 1) clean_row(p, H + tid, 1, H, DEADZONE - 2, q > 17 ? 8 : 9, q > 22 ? 4 : 9, 1, H - 2, nullptr);
-	BARRIER();
+	/* LH1: rows 1..254 (tile rows 0..255 so that the rows above / below are at hand); HL1: rows 256..510 (tile rows 255..511) */
+	CleanF fa = { DEADZONE - 2, q > 22 ? 8 : 9, q > 22 ? 4 : 9, 0, W - 2, 1, nullptr };
+	row_pass_tiled(p, W, W, H, 1, H - 2, H + 1, W - 1, lds, tid, fa);
+	CleanF fb = { DEADZONE - 2, q > 17 ? 8 : 9, q > 22 ? 4 : 9, 1, H - 2, H, nullptr };
+	row_pass_tiled(p + (H - 1) * W, W, W, H + 1, 1, H - 1, 1, H, lds, tid, fb);
 	copy_block_par(p + H * W + H, W, c->hs, H, H, H, tid);           /* HH1 band (rows 256..511, cols 256..511) before its pass */
 	BARRIER();
-	if (tid < H - 1) { const int lim = q > 22 ? 8 : 11; clean_row(p, H + tid, H + 1, W - 1, DEADZONE - 1, lim, lim, 2, W - 2, c->hs); }
-	BARRIER();
+	const int lim = q > 22 ? 8 : 11;
+	CleanF fc = { DEADZONE - 1, lim, lim, 2, W - 2, H, c->hs };
+	row_pass_tiled(p + (H - 1) * W, W, W, H + 1, 1, H - 1, H + 1, W - 1, lds, tid, fc);
 }
 
 /* ---------------------------------------------------------------- a10 quantiser */
-DEV void quant_pairs_row(int16_t *p, int r)              /* image_processing.c:195-238, one row */
-{
-	for (int col = (r < H ? H : 0); col < W; col++) {
-		const int i = r * W + col;
-		if (p[i] > 7 && p[i + 1] > 7 && col < W - 1) {
-			const int a = p[i];
-			if (!(a & 7) && !(p[i + 1] & 7)) {
-				if (a > 15) {
-					if (i > 0) {
-						if (p[i - 1] <= 0) p[i]--;
-						else if (p[i + 1] > 15) { if (col < W - 2 && p[i + 2] <= 0) p[i + 1]--; }
+struct QuantPairsF {                                          /* image_processing.c:195-238 */
+	struct State { int unused; };
+	__device__ State init(int) const { return State{0}; }
+	__device__ int run(int16_t *row, int, int j, int j1, State &) const
+	{
+		for (; j < j1; j++) {
+			int16_t *v = row + j;
+			if (v[0] > 7 && v[1] > 7 && j < W - 1) {
+				const int a = v[0];
+				if (!(a & 7) && !(v[1] & 7)) {
+					if (a > 15) {
+						if (v[-1] <= 0) v[0]--;
+						else if (v[1] > 15) { if (j < W - 2 && v[2] <= 0) v[1]--; }
 					}
+					else if (v[1] > 15) { if (j < W - 2 && v[2] <= 0) v[1]--; }
 				}
-				else if (p[i + 1] > 15) { if (col < W - 2 && p[i + 2] <= 0) p[i + 1]--; }
 			}
 		}
+		return j;
 	}
-}
-DEV void quant_code_row(int16_t *p, int r, int next_first)   /* image_processing.c:314-519, one row */
-{
-	for (int col = 0; col < W; col++) {
-		const int i = r * W + col;
-		int a = p[i];
-		const int nx = col < W - 1 ? p[i + 1] : next_first;
-		if (a > 10000) {
-			if (a == 10100) { p[i] = 128; continue; }
-			else if (a == 12700) { p[i] = 127; continue; }
-			else if (a == 12900) { p[i] = 129; continue; }
-			else if (a == 10204) { p[i] = 125; continue; }
-			else if (a == 10300) { p[i] = 126; continue; }
-			else if (a == 12100) { p[i] = 121; continue; }
-			else if (a == 12200) { p[i] = 122; continue; }
+};
+struct QuantPair567F {                                        /* image_processing.c:286-311 */
+	struct State { int unused; };
+	__device__ State init(int) const { return State{0}; }
+	__device__ int run(int16_t *row, int, int j, int j1, State &) const
+	{
+		for (; j < j1; j++) {
+			if (is_567(row[j])) { if (is_567(row[j + 1])) { row[j] = 10300; j++; } }
+			else if (is_m567(row[j])) { if (is_m567(row[j + 1])) { row[j] = 10204; j++; } }
 		}
-		if (a > 127) { p[i] = (int16_t)big_code(a, k_big_pos); continue; }
-		else if (a < -127) { p[i] = (int16_t)big_code(-a, k_big_neg); continue; }
-
-		if (a < -12 && ((-a) & 7) == 6) { if (col < W - 1 && nx == -7) p[i + 1] = -9; }
-		if (a < 0) {
-			if (a == -7 && nx == 8 && col < W - 1) { p[i] = -8; a = -8; }
-			a = -a;
-			if (a > 14 && (a & 7) == 7 && nx > 0 && nx < 8) a -= 2;
-			if ((a & 7) < 7) a &= 504;
-			a = -a;
-		}
-		else if (a == 8 && nx == -7 && col < W - 1) p[i + 1] = -8;
-		else if (a > 12 && (a & 7) >= 6) { if (col < W - 1 && nx == 7) p[i + 1] = 9; }
-
-		if (a < DEADZONE && a > -DEADZONE) p[i] = 128;
-		else p[i] = (int16_t)((a + 128) & 248);
+		return j;
 	}
-}
-/* offsetY.  Loops 1, 3, 4 reach at most two cells ahead in their own row (the one unguarded look at the first
- * cell of the next row, :389, is served from a value read before any row is rewritten); loop 2 marks cells of
- * the next row and stays serial for now. */
-DEV void quantise_luma_par(Ctx *c, int tid, int *pos)
+};
+struct QuantCodeF {                                           /* image_processing.c:314-519 */
+	const int16_t *plane; int rs;
+	struct State { int next_first; };
+	__device__ State init(int t) const { return State{ plane[(size_t)(t + 1) * rs] }; }   /* first cell of the next row, before anybody rewrites it (:389 looks at it unguarded) */
+	__device__ int run(int16_t *row, int, int j, int j1, State &st) const
+	{
+		for (; j < j1; j++) {
+			int a = row[j];
+			const int nx = j < W - 1 ? row[j + 1] : st.next_first;
+			if (a > 10000) {
+				if (a == 10100) { row[j] = 128; continue; }
+				else if (a == 12700) { row[j] = 127; continue; }
+				else if (a == 12900) { row[j] = 129; continue; }
+				else if (a == 10204) { row[j] = 125; continue; }
+				else if (a == 10300) { row[j] = 126; continue; }
+				else if (a == 12100) { row[j] = 121; continue; }
+				else if (a == 12200) { row[j] = 122; continue; }
+			}
+			if (a > 127) { row[j] = (int16_t)big_code(a, k_big_pos); continue; }
+			else if (a < -127) { row[j] = (int16_t)big_code(-a, k_big_neg); continue; }
+			if (a < -12 && ((-a) & 7) == 6) { if (j < W - 1 && nx == -7) row[j + 1] = -9; }
+			if (a < 0) {
+				if (a == -7 && nx == 8 && j < W - 1) { row[j] = -8; a = -8; }
+				a = -a;
+				if (a > 14 && (a & 7) == 7 && nx > 0 && nx < 8) a -= 2;
+				if ((a & 7) < 7) a &= 504;
+				a = -a;
+			}
+			else if (a == 8 && nx == -7 && j < W - 1) row[j + 1] = -8;
+			else if (a > 12 && (a & 7) >= 6) { if (j < W - 1 && nx == 7) row[j + 1] = 9; }
+			if (a < DEADZONE && a > -DEADZONE) row[j] = 128;
+			else row[j] = (int16_t)((a + 128) & 248);
+		}
+		return j;
+	}
+};
+/* offsetY.  Loops 1, 3, 4 reach at most two cells ahead in their own row: tiled row passes.  Loop 2 marks cells of
+ * the next row: skewed wavefront. */
+DEV void quantise_luma_par(Ctx *c, int tid, int *pos, int16_t *lds)
 {
 	int16_t *p = c->proc;
-	quant_pairs_row(p, tid); quant_pairs_row(p, tid + H);
-	BARRIER();
+	row_pass_tiled(p, W, W, H, 0, H, H, W, lds, tid, QuantPairsF{});               /* rows 0..255: detail columns only */
+	row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, QuantPairsF{});       /* rows 256..511 */
 	{                                                  /* :241-284 (wavefront) */
 		QuantMarkStep st = { p };
 		wavefront_rows(H, tid, pos, st);
 	}
 	BARRIER();
-	{                                                  /* :286-311 (R) */
-		const int r = tid;
-		for (int j = 0; j < H - 1; j++) {
-			const int a = r * W + j;
-			if (is_567(p[a])) { if (is_567(p[a + 1])) { p[a] = 10300; j++; } }
-			else if (is_m567(p[a])) { if (is_m567(p[a + 1])) { p[a] = 10204; j++; } }
-		}
+	row_pass_tiled(p, W, W, H, 0, H, 0, H - 1, lds, tid, QuantPair567F{});
+	{
+		QuantCodeF f0 = { p, W }, f1 = { p + H * W, W };
+		row_pass_tiled(p, W, W, H, 0, H, 0, W, lds, tid, f0);
+		row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, f1);
 	}
-	BARRIER();
-	const int nf0 = p[(tid + 1) * W], nf1 = p[(tid + H + 1) * W];   /* row 511's successor is the zero guard */
-	BARRIER();
-	quant_code_row(p, tid, nf0); quant_code_row(p, tid + H, nf1);
-	BARRIER();
 }
 
 /* offsetUV (image_processing.c:108-183): pairs never span rows; the look at the next cell is unguarded at the
  * end of a row, so the first cell of the next row is read before any row is rewritten */
-DEV void quantise_chroma_par(Ctx *c, int tid)
-{
-	int16_t *p = c->cproc;
-	const int r = tid;
-	const int next_first = p[(r + 1) * H];
-	BARRIER();
-	for (int col = 0; col < H; col++) {
-		const int i = r * H + col;
-		int a = p[i];
-		const int nx = col < H - 1 ? p[i + 1] : next_first;
-		if (a > 10000) {
-			if (a == 12400) { p[i] = 124; continue; }
-			else if (a == 12600) { p[i] = 126; continue; }
-			else if (a == 12900) { p[i] = 122; continue; }
-			else if (a == 13000) { p[i] = 130; continue; }
+struct QuantChromaF {
+	const int16_t *plane;
+	struct State { int next_first; };
+	__device__ State init(int t) const { return State{ plane[(t + 1) * H] }; }
+	__device__ int run(int16_t *row, int, int j, int j1, State &st) const
+	{
+		for (; j < j1; j++) {
+			int a = row[j];
+			const int nx = j < H - 1 ? row[j + 1] : st.next_first;
+			if (a > 10000) {
+				if (a == 12400) { row[j] = 124; continue; }
+				else if (a == 12600) { row[j] = 126; continue; }
+				else if (a == 12900) { row[j] = 122; continue; }
+				else if (a == 13000) { row[j] = 130; continue; }
+			}
+			if (a > 127) { row[j] = (int16_t)big_code(a, k_big_pos); continue; }
+			else if (a < -127) { row[j] = (int16_t)big_code(-a, k_big_neg); continue; }
+			if ((a == -7 || a == -8) && j < H - 1 && (nx == -7 || nx == -8)) { row[j] = 120; row[j + 1] = 120; j++; continue; }
+			if (a < 0) {
+				a = -a;
+				if (nx < 0 && nx > -8) { if ((a & 7) < 6) a &= 504; }
+				else { if ((a & 7) < 7) a &= 504; }
+				a = -a;
+			}
+			else if (a > 6 && (a & 7) >= 6) { if (j < H - 1 && nx == 7) row[j + 1] = 8; }
+			if (a < DEADZONE && a > -DEADZONE) row[j] = 128;
+			else row[j] = (int16_t)((a + 128) & 248);
 		}
-		if (a > 127) { p[i] = (int16_t)big_code(a, k_big_pos); continue; }
-		else if (a < -127) { p[i] = (int16_t)big_code(-a, k_big_neg); continue; }
-		if ((a == -7 || a == -8) && col < H - 1 && (nx == -7 || nx == -8)) { p[i] = 120; p[i + 1] = 120; col++; continue; }
-		if (a < 0) {
-			a = -a;
-			if (nx < 0 && nx > -8) { if ((a & 7) < 6) a &= 504; }
-			else { if ((a & 7) < 7) a &= 504; }
-			a = -a;
-		}
-		else if (a > 6 && (a & 7) >= 6) { if (col < H - 1 && nx == 7) p[i + 1] = 8; }
-		if (a < DEADZONE && a > -DEADZONE) p[i] = 128;
-		else p[i] = (int16_t)((a + 128) & 248);
+		return j;
 	}
-	BARRIER();
+};
+DEV void quantise_chroma_par(Ctx *c, int tid, int16_t *lds)
+{
+	QuantChromaF f = { c->cproc };
+	row_pass_tiled(c->cproc, H, H, H, 0, H, 0, H, lds, tid, f);
 }
 
 /* ---------------------------------------------------------------- Y30 + Y31 */
@@ -1103,7 +1136,7 @@ DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc)
 	dequant_sim_luma_par(c, 0, tid, pos);
 	if (!tid) PROF(c, 7);
 }
-DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos, uint32_t *sh_z)
+DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos, uint32_t *sh_z, int16_t *lds)
 {
 	const int q = c->q;
 	PROF_BEGIN();
@@ -1118,7 +1151,7 @@ DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos, uint32_t *sh_z)
 	}
 	BARRIER();
 	if (!tid) PROF(c, 8);
-	tag_small_runs_par(c, tid);                                             /* Y21 */
+	tag_small_runs_par(c, tid, lds);                                        /* Y21 */
 	BARRIER();
 	if (!tid) PROF(c, 9);
 	const int res_setting = q >= 20 ? 3 : (q >= 18 ? 4 : 6);
@@ -1137,9 +1170,9 @@ DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos, uint32_t *sh_z)
 	}
 	BARRIER();
 	if (!tid) PROF(c, 13);
-	clean_details_par(c, tid);                                              /* Y27 */
+	clean_details_par(c, tid, lds);                                         /* Y27 */
 	if (!tid) PROF(c, 14);
-	quantise_luma_par(c, tid, pos);                                         /* Y28 */
+	quantise_luma_par(c, tid, pos, lds);                                    /* Y28 */
 	if (!tid) PROF(c, 15);
 	if (q > 21 && tid == 0) { band_recons(c); hq_settings(c); }             /* Y29 */
 	BARRIER();
@@ -1174,7 +1207,7 @@ DEV void chroma_p3_par(Ctx *c, int comp, int tid)                     /* :2316-2
 		jp[e] = (int16_t)(o[k] + step);
 	}
 }
-DEV void chroma_p5_par(Ctx *c, int comp, int tid)
+DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds)
 {
 	int16_t *p = c->cproc, *o = c->cll1;
 	const int q = c->q;
@@ -1236,7 +1269,7 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid)
 		}
 	}
 	if (!tid) PROF(c, 21);
-	quantise_chroma_par(c, tid);
+	quantise_chroma_par(c, tid, lds);
 	if (!tid) PROF(c, 22);
 	{                                                              /* serpentine, 32 strips of 8 columns, U even / V odd bytes (:2553-2570) */
 		uint8_t *s = c->scan + 4 * Q + comp;
