@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	ctx_load(&c, ws, img);
 	if (PH == PH_L1) luma_p1_par(&c, tid, sh_pos);
 	else if (PH == PH_L2) luma_p2_par(&c, tid, dyn_lds);
-	else if (PH == PH_L3) luma_p3_par(&c, tid, sh_pos, sh_counts);
+	else if (PH == PH_L3) luma_p3_par(&c, tid, sh_pos, sh_counts, dyn_lds);
 	else if (PH == PH_L4) luma_p4_par(&c, tid, sh_counts, sh_pos, sh_z, dyn_lds);
 	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
 	else if (PH == PH_C2) dequant_sim_chroma_par(&c, 1, tid);
@@ -47,8 +47,9 @@ static size_t phase_lds(int ph)
 	const size_t tile = (size_t)NT * TLS * sizeof(int16_t);
 	switch (ph) {
 	case PH_L2: return 2 * tile;
+	case PH_L3: return 16640;
 	case PH_L4: return (size_t)(NT + 2) * TLS * sizeof(int16_t);
-	case PH_C5: return tile;
+	case PH_C5: return 32 * 130 * 2 + (32 * 128 + 258) * 2 > tile ? 32 * 130 * 2 + (32 * 128 + 258) * 2 : tile;
 	default: return 0;
 	}
 }

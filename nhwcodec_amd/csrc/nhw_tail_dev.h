@@ -954,6 +954,7 @@ DEV void scan_and_rewrite(Ctx *c)
 typedef struct {
 	Ctx *c;
 	const uint8_t *s;  /* LL2 samples (even values), followed by zeros */
+	const uint8_t *full; /* the same samples with bit 0 */
 	uint8_t *o;        /* staging output */
 	int j, mem;
 } llc;
@@ -965,7 +966,7 @@ DEV int ll_verbatim(llc *k, int i)
 	k->o[k->j++] = 128;
 	k->o[k->j++] = (uint8_t)(128 + (k->s[i] >> 1));
 	k->o[k->j++] = (uint8_t)(128 + (k->s[i + 1] >> 1));
-	k->c->ll_word[k->mem++] = k->c->ll_full[i];
+	k->c->ll_word[k->mem++] = k->full[i];
 	k->c->ll_mem[k->c->m->ll_mem_len++] = (uint16_t)i;
 	return i + 1;
 }
@@ -981,11 +982,11 @@ DEV int ll_triple(llc *k, int i, int d0, int d1, int d2)
 	return i + 2;
 }
 
-DEV void ll_code_luma(Ctx *c)
+/* s, full, o may live in LDS (the coder is one serial walk; staging its 16 KiB input and its output in LDS takes it off
+ * the global-memory latency chain) */
+DEV void ll_code_luma(Ctx *c, const uint8_t *s, const uint8_t *full, uint8_t *o)
 {
-	const uint8_t *s = c->ll_bytes;
 	const int n = Q >> 2;
-	uint8_t *o = c->ll_comp;
 	llc k;
 	int i, e, runs8 = 0, runs16 = 0, mode;
 
@@ -1004,7 +1005,7 @@ DEV void ll_code_luma(Ctx *c)
 	c->m->res_low = mode;
 	c->m->ll_mem_len = 0;
 
-	k.c = c; k.s = s; k.o = o; k.j = 1; k.mem = 0;
+	k.c = c; k.s = s; k.full = full; k.o = o; k.j = 1; k.mem = 0;
 	o[0] = s[0];
 
 	for (i = 1; i < n; i++) {
@@ -1067,9 +1068,8 @@ DEV void ll_code_luma(Ctx *c)
 	/* strip the 64 / 128 markers (and the first halved sample of a verbatim record): :828-866 */
 	{
 		const int j = k.j;
-		uint8_t *tmp = c->cc; /* scratch; the bytes behind j must read 0 */
+		uint8_t *tmp = o;     /* in place: the write index never passes the read index; the bytes behind j must read 0 */
 		int w = 1;
-		memcpy(tmp, o, (size_t)j);
 		for (i = j; i < j + 8; i++) tmp[i] = 0;
 		for (i = 1; i < j - 1; i++) {
 			if (tmp[i] == 64) { o[w++] = tmp[i + 1]; o[w++] = tmp[i + 2]; i += 2; }
@@ -1613,7 +1613,7 @@ DEV void luma_p3(Ctx *c)
 	if (c->q > 17) tag_res4(c);
 	emit_ll2(c);
 	PROF(c, 4);
-	ll_code_luma(c);
+	ll_code_luma(c, c->ll_bytes, c->ll_full, c->ll_comp);
 	PROF(c, 5);
 	for (r = 0; r < H; r++) memcpy(c->proc + r * W, c->l2save + r * H, sizeof(int16_t) * H);   /* Y17 :749-755 */
 	PROF(c, 6);

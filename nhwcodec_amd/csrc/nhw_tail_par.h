@@ -95,11 +95,10 @@ DEV void copy_block_par(const int16_t *src, int src_row, int16_t *dst, int dst_r
  * neighbours at every step: measured 10-30x HBM read amplification (profiles/round1_pmc_front.json).  The
  * row-serial passes therefore run on tiles: 64 columns (+2 halo columns on each side) of all the rows of the
  * pass are staged in LDS with row-contiguous (coalesced) dword loads, every thread walks its row inside LDS,
- * and the tile goes back with coalesced stores.  Tile rows are TLS shorts apart (34 dwords: two rows share a
- * bank only 32 rows apart).  Halo columns are addressed linearly, so "one cell past the end of the row" is the
+ * and the tile goes back with coalesced stores.  Tile rows are TLS shorts apart.  Halo columns are addressed linearly, so "one cell past the end of the row" is the
  * first cell of the next row, exactly as in the reference's linear indexing. */
-#define TLC 64
-#define TLS 68
+#define TLC 32      /* columns per tile: 258 rows x 36 shorts = 18.6 KB keeps 6+ workgroups on a CU (a 64-column tile halves that and is slower overall) */
+#define TLS 36
 DEV void tile_load(int16_t *lds, const int16_t *plane, int rs, int nrows, int c0, int tid)
 {
 	for (int idx = tid; idx < nrows * (TLS / 2); idx += NT) {
@@ -1121,14 +1120,19 @@ DEV void luma_p2_par(Ctx *c, int tid, int16_t *lds)
 	precompensate_ll1_par(c, tid, lds);
 	if (!tid) PROF(c, 3);
 }
-DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc)
+DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc, int16_t *lds)
 {
 	PROF_BEGIN();
 	for (int i = (Q >> 2) + tid; i < (Q >> 2) + (Q >> 3) + 64; i += NT) c->ll_bytes[i] = 0;
 	BARRIER();
 	emit_ll2_par(c, tid, pos, sh_misc);
 	if (!tid) PROF(c, 4);
-	if (tid == 0) { ll_code_luma(c); PROF(c, 5); }
+	{                                                             /* Y16: the LL2 byte coder reads an LDS copy of its 16 KiB input (its writes do not stall it) */
+		uint8_t *ls = reinterpret_cast<uint8_t *>(lds);
+		for (int i = tid; i < 16640 / 16; i += NT) reinterpret_cast<uint4 *>(ls)[i] = reinterpret_cast<const uint4 *>(c->ll_bytes)[i];
+		BARRIER();
+		if (tid == 0) { ll_code_luma(c, ls, c->ll_full, c->ll_comp); PROF(c, 5); }
+	}
 	BARRIER();
 	copy_block_par(c->l2save, H, c->proc, W, H, H, tid);          /* Y17 :749-755 */
 	BARRIER();
@@ -1212,29 +1216,39 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds)
 	int16_t *p = c->cproc, *o = c->cll1;
 	const int q = c->q;
 	PROF_BEGIN();
-	if (tid == 0 && q >= 18) {                                   /* :2372-2427 (serial: running index, skip-ahead) */
+	if (q >= 18) {                                                 /* :2372-2427 (serial: running index, skip-ahead); recon and cll1 rows come through LDS, 32 rows at a time */
+		int16_t *lp = lds, *lo = lds + 32 * 130;                   /* 32 rows x 129 recon samples (row stride 130); 32*128 + 258 ll1 samples */
 		const int res_uv = q > 17 ? 4 : 5;
-		int k = 0;
-		for (int r = 0; r < H / 2; r++)
-			for (int j = 0; j < H / 2; j++, k++) {
-				const int at = r * H + j, d = p[at] - o[k];
-				if (d > 3 && d < 7) {
-					const int d1 = p[at + 1] - o[k + 1];
-					if (d1 > 2 && d1 < 7 && mark_free_detail(p, at, 12400)) { j++; k++; continue; }
-				}
-				else if (d < -3 && d > -7) {
-					const int d1 = p[at + 1] - o[k + 1];
-					if (d1 < -2 && d1 > -8 && mark_free_detail(p, at, 12600)) { j++; k++; continue; }
-				}
-				if (iabs(d) > res_uv) {
-					if (d > 0) mark_free_detail(p, at, 12900);
-					else if (d == -5) { if ((p[at + 1] - o[k + 1]) < 0) mark_free_detail(p, at, 13000); }
-					else mark_free_detail(p, at, 13000);
-				}
+		int k = 0;                                                 /* only thread 0's copy is used */
+		for (int rb = 0; rb < H / 2; rb += 32) {
+			for (int idx = tid; idx < 32 * 129; idx += NT) { const int r = idx / 129, j = idx % 129; lp[r * 130 + j] = p[(rb + r) * H + j]; }
+			for (int idx = tid; idx < 32 * (H / 2) + 258; idx += NT) lo[idx] = o[rb * (H / 2) + idx];
+			BARRIER();
+			if (tid == 0) {
+				const int kb = rb * (H / 2);                       /* lo[i] = cll1[kb + i]; the running index can be up to 128 cells ahead of the row it belongs to */
+				for (int r = rb; r < rb + 32; r++)
+					for (int j = 0; j < H / 2; j++, k++) {
+						const int at = r * H + j, d = lp[(r - rb) * 130 + j] - lo[k - kb];
+						if (d > 3 && d < 7) {
+							const int d1 = lp[(r - rb) * 130 + j + 1] - lo[k + 1 - kb];
+							if (d1 > 2 && d1 < 7 && mark_free_detail(p, at, 12400)) { j++; k++; continue; }
+						}
+						else if (d < -3 && d > -7) {
+							const int d1 = lp[(r - rb) * 130 + j + 1] - lo[k + 1 - kb];
+							if (d1 < -2 && d1 > -8 && mark_free_detail(p, at, 12600)) { j++; k++; continue; }
+						}
+						if (iabs(d) > res_uv) {
+							if (d > 0) mark_free_detail(p, at, 12900);
+							else if (d == -5) { if ((lp[(r - rb) * 130 + j + 1] - lo[k + 1 - kb]) < 0) mark_free_detail(p, at, 13000); }
+							else mark_free_detail(p, at, 13000);
+						}
+					}
 			}
+			BARRIER();
+		}
 	}
-	BARRIER();
 	copy_block_par(c->cl2save, H / 2, p, H, H / 2, H / 2, tid);    /* :2431-2439 */
+	for (int idx = tid; idx < (H / 4) * (H / 4); idx += NT) lds[idx] = c->cl2save[(idx >> 6) * (H / 2) + (idx & 63)];   /* the LL2 band for the emission below */
 	BARRIER();
 	if (tid == 0) {
 		int e = c->m->exw_len;
@@ -1242,7 +1256,7 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds)
 		c->exw[e++] = 0; c->exw[e++] = 0;                          /* :2489 (U), :2770 (V) */
 		for (int r = 0; r < H / 4; r++)                            /* :2491-2525 LL2 emission */
 			for (int j = 0; j < H / 4; j++) {
-				int s = p[r * H + j];
+				int s = lds[r * (H / 4) + j];
 				if ((s > 255 || s < 0) && (j > 0 || r > 0)) {
 					int mag;
 					c->exw[e++] = (uint8_t)r;
@@ -1254,10 +1268,10 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds)
 					if (s > 255) s = 255; else if (s < 0) s = 0;
 					c->ll_bytes[a++] = (uint8_t)(s & 254);
 				}
-				p[r * H + j] = 0;
 			}
 		c->m->exw_len = e;
 	}
+	for (int idx = tid; idx < (H / 4) * (H / 4); idx += NT) p[(idx >> 6) * H + (idx & 63)] = 0;   /* the emission clears the band */
 	BARRIER();
 	{                                                              /* bit 1 of every LL2 sample (:2527-2548) */
 		uint8_t *dst = comp ? c->res_v64 : c->res_u64;
