@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_C2) dequant_sim_chroma_par(&c, 1, tid);
 	else if (PH == PH_C3) chroma_p3_par(&c, comp, tid);
 	else if (PH == PH_C4) dequant_sim_chroma_par(&c, 0, tid);
-	else if (PH == PH_C5) chroma_p5_par(&c, comp, tid, dyn_lds);
+	else if (PH == PH_C5) chroma_p5_par(&c, comp, tid, dyn_lds, sh_counts);
 	else if (PH == PH_FINAL) {
 		final_phase_par(&c, out + (size_t)img * (512u << 10), 512u << 10, &sizes[img], &status[img], &sh_pack, tid);
 	}

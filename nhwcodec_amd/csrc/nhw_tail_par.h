@@ -120,7 +120,7 @@ DEV void tile_store(const int16_t *lds, int16_t *plane, int rs, int nrows, int c
  * (>= j1; skips may overshoot into the next tile).  The tile holds `nrows` plane rows starting at `plane`; thread t
  * (t < nproc) owns tile row t + roff.  Cells the pass may write: own row, columns c0-2 .. c0+65. */
 template <class F>
-DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff, int nproc, int jb, int je, int16_t *lds, int tid, F f)
+DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff, int nproc, int jb, int je, int16_t *lds, int tid, F f, typename F::State *out = nullptr)
 {
 	int jnext = jb;
 	typename F::State st = f.init(tid);
@@ -137,6 +137,7 @@ DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff
 		tile_store(lds + roff * TLS, plane + (size_t)roff * rs, rs, nproc, c0, nst, tid, c0 > 0 ? 0 : 2);
 		BARRIER();
 	}
+	if (out) *out = st;
 }
 
 /* ---------------------------------------------------------------- Y9 (R) */
@@ -820,19 +821,34 @@ DEV void fix_sign_code(uint8_t *s, int at) { if (s[at] == 153) s[at] = 124; else
  * pair rule (two adjacent positions cannot both match it), every other test compares against 128, which is
  * never written.  Rewrite 3 touches only sign codes next to zero runs of >= 252: each thread scans the runs
  * that start in its slice and replays the rare long ones. */
-DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /* shared [n/16/32 + 2] */)
+DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /* shared [n/16/32 + 2] */, int16_t *lds /* 16 x 520 shorts */)
 {
 	const int16_t *p = c->proc;
 	uint8_t *s = c->scan;
 	const int n = 4 * Q;
 	uint32_t *bits = reinterpret_cast<uint32_t *>(c->half);      /* n bits of selection flags */
 
-	for (int idx = tid; idx < Q; idx += NT) {                    /* 4 columns of one row -> 4 stream bytes */
-		const int r = idx >> 7, strip = idx & 127;
-		const uint2 v = *reinterpret_cast<const uint2 *>(p + r * W + 4 * strip);
-		const uint32_t b0 = v.x & 0xFF, b1 = (v.x >> 16) & 0xFF, b2 = v.y & 0xFF, b3 = (v.y >> 16) & 0xFF;
-		const uint32_t w = (r & 1) ? (b3 | (b2 << 8) | (b1 << 16) | (b0 << 24)) : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
-		*reinterpret_cast<uint32_t *>(s + strip * (4 * W) + 4 * r) = w;
+	/* serpentine gather (:2108-2132) through LDS: 16 plane rows (coalesced 1 KiB rows) -> per 4-column strip a run of
+	 * 64 consecutive stream bytes, written 16 bytes per thread */
+	for (int rb = 0; rb < W; rb += 16) {
+		for (int idx = tid; idx < 16 * (W / 8); idx += NT) {
+			const int r = idx >> 6, o = idx & 63;
+			reinterpret_cast<uint4 *>(lds + r * (W + 8))[o] = reinterpret_cast<const uint4 *>(p + (rb + r) * W)[o];
+		}
+		BARRIER();
+		for (int idx = tid; idx < 128 * 4; idx += NT) {
+			const int strip = idx >> 2, qd = idx & 3;
+			uint32_t w[4];
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const int r = 4 * qd + e;
+				const uint2 v = *reinterpret_cast<const uint2 *>(lds + r * (W + 8) + 4 * strip);
+				const uint32_t b0 = v.x & 0xFF, b1 = (v.x >> 16) & 0xFF, b2 = v.y & 0xFF, b3 = (v.y >> 16) & 0xFF;
+				w[e] = ((rb + r) & 1) ? (b3 | (b2 << 8) | (b1 << 16) | (b0 << 24)) : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+			}
+			*reinterpret_cast<uint4 *>(s + strip * (4 * W) + 4 * (rb + 4 * qd)) = make_uint4(w[0], w[1], w[2], w[3]);
+		}
+		BARRIER();
 	}
 	if (tid < 4) reinterpret_cast<uint32_t *>(s + n)[tid] = 0;     /* im_nhw is calloc'ed: bytes behind the luma part read 0 here */
 	if (tid == 0) { sh_counts[0] = 0; sh_counts[1] = 0; }
@@ -922,16 +938,28 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 				const unsigned long long z = ((unsigned long long)sh_z[(g >> 5) + 1] << 32 | sh_z[g >> 5]) >> (g & 31);
 				if ((z & 0x3FFF) != 0x3FFF) continue;
 			}
+			/* run [i, b]: walk to the end of the 16-byte group, hop over all-zero groups with the bitmap, finish bytewise */
 			int b = i + 1;
-			while (s[b + 1] == 128) b++;                           /* run [i, b]; s[n] is 0 */
-			if (b - i >= 252) {                                    /* replay the reference's walk over this run */
-				int kk = i, run = 0;
-				while (s[kk] == 128 && s[kk + 1] == 128) {
-					run++;
-					if (run > 255) { for (int t = 0; t < 4; t++) fix_sign_code(s, kk + t); kk--; run = 0; }
-					else kk++;
+			while (((b + 1) & 15) && s[b + 1] == 128) b++;
+			if (!((b + 1) & 15) && s[b + 1] == 128) {
+				int g2 = (b + 1) >> 4;                             /* first group not yet examined */
+				for (;;) {
+					const uint32_t inv = ~(sh_z[g2 >> 5] >> (g2 & 31));
+					const int room = 32 - (g2 & 31);
+					const int z = inv ? __ffs((int)inv) - 1 : 32;
+					if (z >= room) { g2 += room; if (g2 >= n / 16) break; continue; }
+					g2 += z; break;
 				}
-				if (run >= 252) fix_sign_code(s, kk + 1);
+				b = 16 * g2 - 1;                                   /* last byte of the last all-zero group */
+				while (b + 1 < n && s[b + 1] == 128) b++;
+			}
+			/* the reference's walk (:2222-2252) fires every 254 cells from i+255 on, then once at the end: closed form */
+			if (b - i >= 256)
+				for (int kk = i + 255; kk + 1 <= b; kk += 254) for (int u = 0; u < 4; u++) fix_sign_code(s, kk + u);
+			{
+				const int fired = b - i >= 256 ? (b - i - 256) / 254 + 1 : 0;
+				const int tail_run = fired ? b - (i + 255 + 254 * (fired - 1)) + 1 : b - i;
+				if (tail_run >= 252) fix_sign_code(s, b + 1);
 			}
 		}
 	}
@@ -1045,22 +1073,43 @@ DEV void emit_ll2_par(Ctx *c, int tid, int *pos, int *sh_misc)
 
 /* Y25 (nhw_encoder.c:1498-1887): the three compaction sweeps over the code plane run one row per thread (count,
  * prefix, write); packing the (short) lists stays on thread 0 */
-DEV void build_poslists_par(Ctx *c, int tid, int *pos)
+struct PosListF {
+	int pass, write;
+	uint8_t *raw, *pay;
+	const int *off_raw, *off_pay;
+	struct State { int n, e; };
+	__device__ State init(int t) const { return write ? State{ off_raw[t], off_pay[t] } : State{ 0, 0 }; }
+	__device__ int run(int16_t *row, int, int j, int j1, State &st) const
+	{
+		for (; j < j1; j++) {
+			const int v = row[j];
+			int payload = -1, keep = 0;
+			if (pass == 0) {
+				if (v == 141) payload = 1; else if (v == 140) payload = 0;
+				else if (v == 126) { payload = 0; keep = 122; } else if (v == 125) { payload = 1; keep = 121; }
+				else if (v == 148) { payload = 1; keep = 144; } else if (v == 149) { payload = 0; keep = 145; }
+			} else if (pass == 1) {
+				if (v == 121) payload = 1; else if (v == 122) payload = 0; else if (v == 123) payload = 2; else if (v == 124) payload = 3;
+			} else { if (v == 144) payload = 1; else if (v == 145) payload = 0; }
+			if (payload >= 0) {
+				if (write) { raw[st.n] = (uint8_t)j; pay[st.e] = (uint8_t)payload; row[j] = (int16_t)keep; }
+				st.n++; st.e++;
+			}
+		}
+		return j;
+	}
+};
+DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 {
 	int16_t *o = c->ll1;
 	uint8_t *raw = c->raw, *pay = c->pay;
 	int *off_raw = pos, *off_pay = pos + NT + 1;                  /* shared [2 * NT + 2] */
 	for (int pass = 0; pass < 3; pass++) {
 		if ((pass == 1 && c->q < 19) || (pass == 2 && c->q < 21)) continue;
-		const int r = tid;
-		int nr = 1, np = 0;                                       /* the row marker at column 254 */
-		for (int j = 0; j < H - 2; j++) {
-			const int v = o[r * H + j];
-			const bool take = pass == 0 ? (v == 141 || v == 140 || v == 126 || v == 125 || v == 148 || v == 149)
-			                : pass == 1 ? (v >= 121 && v <= 124) : (v == 144 || v == 145);
-			if (take) { nr++; np++; }
-		}
-		off_raw[tid] = nr; off_pay[tid] = np;
+		PosListF fc = { pass, 0, raw, pay, off_raw, off_pay };
+		PosListF::State cnt;
+		row_pass_tiled(o, H, H, H, 0, H, 0, H - 2, lds, tid, fc, &cnt);
+		off_raw[tid] = cnt.n + 1; off_pay[tid] = cnt.e;          /* + the row marker at column 254 */
 		BARRIER();
 		if (tid == 0) {
 			int a = 0, b = 0;
@@ -1068,35 +1117,23 @@ DEV void build_poslists_par(Ctx *c, int tid, int *pos)
 			off_raw[NT] = a; off_pay[NT] = b;
 		}
 		BARRIER();
-		int n = off_raw[tid], e = off_pay[tid];
-		for (int j = 0; j < H - 2; j++) {
-			int16_t *cell = o + r * H + j;
-			if (pass == 0) {
-				switch (*cell) {
-				case 141: raw[n++] = (uint8_t)j; *cell = 0;   pay[e++] = 1; break;
-				case 140: raw[n++] = (uint8_t)j; *cell = 0;   pay[e++] = 0; break;
-				case 126: raw[n++] = (uint8_t)j; *cell = 122; pay[e++] = 0; break;
-				case 125: raw[n++] = (uint8_t)j; *cell = 121; pay[e++] = 1; break;
-				case 148: raw[n++] = (uint8_t)j; *cell = 144; pay[e++] = 1; break;
-				case 149: raw[n++] = (uint8_t)j; *cell = 145; pay[e++] = 0; break;
-				default: break;
-				}
-			} else if (pass == 1) {
-				switch (*cell) {
-				case 121: raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 1; break;
-				case 122: raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 0; break;
-				case 123: raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 2; break;
-				case 124: raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 3; break;
-				default: break;
-				}
-			} else {
-				if (*cell == 144) { raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 1; }
-				else if (*cell == 145) { raw[n++] = (uint8_t)j; *cell = 0; pay[e++] = 0; }
+		PosListF fw = { pass, 1, raw, pay, off_raw, off_pay };
+		PosListF::State end;
+		row_pass_tiled(o, H, H, H, 0, H, 0, H - 2, lds, tid, fw, &end);
+		o[tid * H + H - 2] = 0; o[tid * H + H - 1] = 0; raw[end.n] = H - 2;
+		BARRIER();
+		{                                                         /* packing the list is one serial walk: short lists are walked in LDS */
+			const int nraw = off_raw[NT];
+			uint8_t *l8 = reinterpret_cast<uint8_t *>(lds);
+			const bool small = nraw <= 4000;
+			if (small) for (int i = tid; i < nraw; i += NT) l8[i] = raw[i];
+			BARRIER();
+			if (tid == 0) {
+				Ctx c2 = *c;
+				if (small) { c2.cc = l8 + 4096; c2.half = l8 + 8192; }
+				poslist_finish(&c2, pass == 0 ? &c->res1 : pass == 1 ? &c->res3 : &c->res5, small ? l8 : raw, nraw, pay, off_pay[NT], pass == 1 ? 2 : 1);
 			}
 		}
-		o[r * H + H - 2] = 0; o[r * H + H - 1] = 0; raw[n++] = H - 2;
-		BARRIER();
-		if (tid == 0) poslist_finish(c, pass == 0 ? &c->res1 : pass == 1 ? &c->res3 : &c->res5, raw, off_raw[NT], pay, off_pay[NT], pass == 1 ? 2 : 1);
 		BARRIER();
 	}
 }
@@ -1165,7 +1202,7 @@ DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos, uint32_t *sh_z, 
 	BARRIER();
 	if (!tid) PROF(c, 11);
 	if (q > 21) adjust_first_order_par(c, tid);                             /* Y24 */
-	build_poslists_par(c, tid, pos);                                        /* Y25 */
+	build_poslists_par(c, tid, pos, lds);                                   /* Y25 */
 	if (!tid) PROF(c, 12);
 	for (int idx = tid; idx < Q; idx += NT) {                               /* Y26 :1893-1910 */
 		const int r = idx >> 8, j = idx & 255;
@@ -1181,7 +1218,7 @@ DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos, uint32_t *sh_z, 
 	if (q > 21 && tid == 0) { band_recons(c); hq_settings(c); }             /* Y29 */
 	BARRIER();
 	if (!tid) PROF(c, 16);
-	scan_and_rewrite_par(c, tid, sh_counts, sh_z);                          /* Y30, Y31 */
+	scan_and_rewrite_par(c, tid, sh_counts, sh_z, lds);                     /* Y30, Y31 */
 	if (!tid) PROF(c, 17);
 }
 
@@ -1211,42 +1248,66 @@ DEV void chroma_p3_par(Ctx *c, int comp, int tid)                     /* :2316-2
 		jp[e] = (int16_t)(o[k] + step);
 	}
 }
-DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds)
+DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 {
 	int16_t *p = c->cproc, *o = c->cll1;
 	const int q = c->q;
 	PROF_BEGIN();
-	if (q >= 18) {                                                 /* :2372-2427 (serial: running index, skip-ahead); recon and cll1 rows come through LDS, 32 rows at a time */
-		int16_t *lp = lds, *lo = lds + 32 * 130;                   /* 32 rows x 129 recon samples (row stride 130); 32*128 + 258 ll1 samples */
+	if (q >= 18) {
+		/* :2372-2427.  The reference walks the LL1 band with an index into cll1 that is NOT reset per row; it runs
+		 * ahead of the row only when a pair mark is taken at the last column of a row.  Every cell owns the three
+		 * detail cells it may mark, so rows are independent as long as that never happens: a dry run (no writes)
+		 * checks it, then the rows run in parallel; otherwise thread 0 replays the band serially. */
 		const int res_uv = q > 17 ? 4 : 5;
-		int k = 0;                                                 /* only thread 0's copy is used */
-		for (int rb = 0; rb < H / 2; rb += 32) {
-			for (int idx = tid; idx < 32 * 129; idx += NT) { const int r = idx / 129, j = idx % 129; lp[r * 130 + j] = p[(rb + r) * H + j]; }
-			for (int idx = tid; idx < 32 * (H / 2) + 258; idx += NT) lo[idx] = o[rb * (H / 2) + idx];
+		for (int dry = 1; dry >= 0; dry--) {
+			if (dry && tid == 0) sh_misc[0] = 0;
 			BARRIER();
-			if (tid == 0) {
-				const int kb = rb * (H / 2);                       /* lo[i] = cll1[kb + i]; the running index can be up to 128 cells ahead of the row it belongs to */
-				for (int r = rb; r < rb + 32; r++)
-					for (int j = 0; j < H / 2; j++, k++) {
-						const int at = r * H + j, d = lp[(r - rb) * 130 + j] - lo[k - kb];
-						if (d > 3 && d < 7) {
-							const int d1 = lp[(r - rb) * 130 + j + 1] - lo[k + 1 - kb];
-							if (d1 > 2 && d1 < 7 && mark_free_detail(p, at, 12400)) { j++; k++; continue; }
-						}
-						else if (d < -3 && d > -7) {
-							const int d1 = lp[(r - rb) * 130 + j + 1] - lo[k + 1 - kb];
-							if (d1 < -2 && d1 > -8 && mark_free_detail(p, at, 12600)) { j++; k++; continue; }
-						}
-						if (iabs(d) > res_uv) {
-							if (d > 0) mark_free_detail(p, at, 12900);
-							else if (d == -5) { if ((lp[(r - rb) * 130 + j + 1] - lo[k + 1 - kb]) < 0) mark_free_detail(p, at, 13000); }
-							else mark_free_detail(p, at, 13000);
+			if (tid < H / 2 && (dry || !sh_misc[0])) {
+				const int r = tid;
+				for (int j = 0; j < H / 2; j++) {
+					const int at = r * H + j, k = r * (H / 2) + j, d = p[at] - o[k];
+					int16_t code = 0; bool pair = false;
+					if (d > 3 && d < 7) { const int d1 = p[at + 1] - o[k + 1]; if (d1 > 2 && d1 < 7) { code = 12400; pair = true; } }
+					else if (d < -3 && d > -7) { const int d1 = p[at + 1] - o[k + 1]; if (d1 < -2 && d1 > -8) { code = 12600; pair = true; } }
+					if (pair) {
+						const bool free_cell = iabs(p[at + H / 2]) < 8 || iabs(p[at + Q / 2]) < 8 || iabs(p[at + Q / 2 + H / 2]) < 8;
+						if (free_cell) {
+							if (dry) { if (j == H / 2 - 1) sh_misc[0] = 1; }
+							else mark_free_detail(p, at, code);
+							j++; continue;
 						}
 					}
+					if (!dry && iabs(d) > res_uv) {
+						if (d > 0) mark_free_detail(p, at, 12900);
+						else if (d == -5) { if ((p[at + 1] - o[k + 1]) < 0) mark_free_detail(p, at, 13000); }
+						else mark_free_detail(p, at, 13000);
+					}
+				}
 			}
 			BARRIER();
 		}
+		if (tid == 0 && sh_misc[0]) {                              /* rare: literal serial walk */
+			int k = 0;
+			for (int r = 0; r < H / 2; r++)
+				for (int j = 0; j < H / 2; j++, k++) {
+					const int at = r * H + j, d = p[at] - o[k];
+					if (d > 3 && d < 7) {
+						const int d1 = p[at + 1] - o[k + 1];
+						if (d1 > 2 && d1 < 7 && mark_free_detail(p, at, 12400)) { j++; k++; continue; }
+					}
+					else if (d < -3 && d > -7) {
+						const int d1 = p[at + 1] - o[k + 1];
+						if (d1 < -2 && d1 > -8 && mark_free_detail(p, at, 12600)) { j++; k++; continue; }
+					}
+					if (iabs(d) > res_uv) {
+						if (d > 0) mark_free_detail(p, at, 12900);
+						else if (d == -5) { if ((p[at + 1] - o[k + 1]) < 0) mark_free_detail(p, at, 13000); }
+						else mark_free_detail(p, at, 13000);
+					}
+				}
+		}
 	}
+	BARRIER();
 	copy_block_par(c->cl2save, H / 2, p, H, H / 2, H / 2, tid);    /* :2431-2439 */
 	for (int idx = tid; idx < (H / 4) * (H / 4); idx += NT) lds[idx] = c->cl2save[(idx >> 6) * (H / 2) + (idx & 63)];   /* the LL2 band for the emission below */
 	BARRIER();
