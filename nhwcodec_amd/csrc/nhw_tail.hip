@@ -3,10 +3,11 @@
  * per image (see nhw_tail_par.h / nhw_tail_dev.h), plus the small block-copy kernel used between them.
  */
 #include "nhw_tail_par.h"
+#include "nhw_tail_wave.h"
 
 using namespace nhw;
 
-enum { PH_L1, PH_L2, PH_L3, PH_L4, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL };
+enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D };
 
 template <int PH>
 __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status)
@@ -22,7 +23,10 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	if (PH == PH_L1) luma_p1_par(&c, tid, sh_pos);
 	else if (PH == PH_L2) luma_p2_par(&c, tid, dyn_lds);
 	else if (PH == PH_L3) luma_p3_par(&c, tid, sh_pos, sh_counts, dyn_lds);
-	else if (PH == PH_L4) luma_p4_par(&c, tid, sh_counts, sh_pos, sh_z, dyn_lds);
+	else if (PH == PH_L4A) luma_p4a_par(&c, tid, dyn_lds);
+	else if (PH == PH_L4B) luma_p4b_par(&c, tid, sh_pos, dyn_lds);
+	else if (PH == PH_L4C) luma_p4c_par(&c, tid, sh_pos, dyn_lds);
+	else if (PH == PH_L4D) luma_p4d_par(&c, tid, sh_counts, sh_z, dyn_lds);
 	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
 	else if (PH == PH_C2) dequant_sim_chroma_par(&c, 1, tid);
 	else if (PH == PH_C3) chroma_p3_par(&c, comp, tid);
@@ -30,6 +34,27 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_C5) chroma_p5_par(&c, comp, tid, dyn_lds, sh_counts);
 	else if (PH == PH_FINAL) {
 		final_phase_par(&c, out + (size_t)img * (512u << 10), 512u << 10, &sizes[img], &status[img], &sh_pack, tid);
+	}
+}
+
+/* passes that run one wavefront per image (nhw_tail_wave.h): four images per workgroup, no workgroup barriers */
+enum { WV_DQ1, WV_DQ0 };
+template <int PH>
+__global__ __launch_bounds__(256) void k_wave(NhwWs ws)
+{
+	const int img = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (img >= ws.n) return;
+	Ctx c;
+	ctx_load(&c, ws, img);
+	if (PH == WV_DQ1) wave_dequant_sim_luma(&c, 1, lane);
+	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane);
+}
+void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s)
+{
+	const dim3 g((ws.n + 3) / 4), b(256);
+	switch (ph) {
+	case WV_DQ1: k_wave<WV_DQ1><<<g, b, 0, s>>>(ws); break;
+	case WV_DQ0: k_wave<WV_DQ0><<<g, b, 0, s>>>(ws); break;
 	}
 }
 
@@ -48,7 +73,7 @@ static size_t phase_lds(int ph)
 	switch (ph) {
 	case PH_L2: return 2 * tile;
 	case PH_L3: return 16640;
-	case PH_L4: return (size_t)(NT + 2) * TLS * sizeof(int16_t);
+	case PH_L4A: case PH_L4B: case PH_L4C: case PH_L4D: return (size_t)(NT + 2) * TLS * sizeof(int16_t);
 	case PH_C5: return 32 * 130 * 2 + (32 * 128 + 258) * 2 > tile ? 32 * 130 * 2 + (32 * 128 + 258) * 2 : tile;
 	default: return 0;
 	}
@@ -62,7 +87,6 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L4>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_C5>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
 		attr_set = true;
 	}
@@ -71,7 +95,10 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 	case PH_L1: k_phase<PH_L1><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L2: k_phase<PH_L2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L3: k_phase<PH_L3><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
-	case PH_L4: k_phase<PH_L4><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L4A: k_phase<PH_L4A><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L4B: k_phase<PH_L4B><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L4C: k_phase<PH_L4C><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L4D: k_phase<PH_L4D><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C0: k_phase<PH_C0><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C2: k_phase<PH_C2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C3: k_phase<PH_C3><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;

@@ -1145,8 +1145,6 @@ DEV void luma_p1_par(Ctx *c, int tid, int *pos)
 	tag_l2_details_par(c, tid);
 	BARRIER();
 	if (!tid) PROF(c, 0);
-	dequant_sim_luma_par(c, 1, tid, pos);
-	if (!tid) PROF(c, 1);
 }
 DEV void luma_p2_par(Ctx *c, int tid, int16_t *lds)
 {
@@ -1174,10 +1172,10 @@ DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc, int16_t *lds)
 	copy_block_par(c->l2save, H, c->proc, W, H, H, tid);          /* Y17 :749-755 */
 	BARRIER();
 	if (!tid) PROF(c, 6);
-	dequant_sim_luma_par(c, 0, tid, pos);
-	if (!tid) PROF(c, 7);
 }
-DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos, uint32_t *sh_z, int16_t *lds)
+/* Y19..Y31 run as four kernels (a: Y19-Y23, b: Y24-Y25, c: Y26-Y29, d: Y30-Y31) so that each gets the register
+ * and LDS budget of its own passes: one kernel for all of them ran at 4 waves/SIMD. */
+DEV void luma_p4a_par(Ctx *c, int tid, int16_t *lds)
 {
 	const int q = c->q;
 	PROF_BEGIN();
@@ -1201,9 +1199,18 @@ DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos, uint32_t *sh_z, 
 	code_residuals_par(c, res_setting, tid);                                /* Y23 */
 	BARRIER();
 	if (!tid) PROF(c, 11);
-	if (q > 21) adjust_first_order_par(c, tid);                             /* Y24 */
+}
+DEV void luma_p4b_par(Ctx *c, int tid, int *pos, int16_t *lds)
+{
+	PROF_BEGIN();
+	if (c->q > 21) adjust_first_order_par(c, tid);                          /* Y24 */
 	build_poslists_par(c, tid, pos, lds);                                   /* Y25 */
 	if (!tid) PROF(c, 12);
+}
+DEV void luma_p4c_par(Ctx *c, int tid, int *pos, int16_t *lds)
+{
+	const int q = c->q;
+	PROF_BEGIN();
 	for (int idx = tid; idx < Q; idx += NT) {                               /* Y26 :1893-1910 */
 		const int r = idx >> 8, j = idx & 255;
 		const int16_t v = c->l2save[idx];
@@ -1218,6 +1225,10 @@ DEV void luma_p4_par(Ctx *c, int tid, int *sh_counts, int *pos, uint32_t *sh_z, 
 	if (q > 21 && tid == 0) { band_recons(c); hq_settings(c); }             /* Y29 */
 	BARRIER();
 	if (!tid) PROF(c, 16);
+}
+DEV void luma_p4d_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z, int16_t *lds)
+{
+	PROF_BEGIN();
 	scan_and_rewrite_par(c, tid, sh_counts, sh_z, lds);                     /* Y30, Y31 */
 	if (!tid) PROF(c, 17);
 }

@@ -1,0 +1,344 @@
+/*
+ * nhw_tail_wave.h -- one wavefront per image: the raster-serial passes as row-sequential, column-parallel walks.
+ *
+ * The reference walks these bands cell by cell in raster order, and a cell's action depends on what the walk
+ * did just before it (skip the partner of a marked pair, a sample bumped by its left neighbour, ...) and on what
+ * the row above wrote into this row.  Two observations make them data-parallel along a row:
+ *   * within a row the walk's memory is tiny (skip the next cell / this cell was bumped) and the marks it leaves
+ *     never overlap the cells a later step of the same row reads, so "would fire if visited" is a pure function
+ *     of the row's values before the walk: one bit per cell, gathered with __ballot into a 256-bit row mask;
+ *   * "visited" then follows from the fire bits alone: in a run of consecutive fire bits every second cell is
+ *     visited (the closed form alt_runs(), an add-with-carry over the mask), or, for mixed skip lengths, a
+ *     scalar loop over the set bits.
+ * The row masks are wave-uniform, so all of that is scalar-unit work; the lanes only classify their own cells
+ * (lane l owns columns l, l+64, l+128, l+192 of the row: bit l of mask word k) and apply the marks.  Rows stay
+ * sequential -- a row writes into the next one -- but a step is a few hundred instructions on registers, with
+ * the next rows already in flight, instead of one memory round trip per cell.  Four images share a 256-thread
+ * workgroup, one per wavefront; there are no workgroup barriers in here.
+ */
+#ifndef NHW_TAIL_WAVE_H
+#define NHW_TAIL_WAVE_H
+
+#include "nhw_tail_dev.h"
+
+namespace nhw {
+
+struct M4 { uint64_t w[4]; };
+DEV M4 operator&(M4 a, M4 b) { return M4{ { a.w[0] & b.w[0], a.w[1] & b.w[1], a.w[2] & b.w[2], a.w[3] & b.w[3] } }; }
+DEV M4 operator|(M4 a, M4 b) { return M4{ { a.w[0] | b.w[0], a.w[1] | b.w[1], a.w[2] | b.w[2], a.w[3] | b.w[3] } }; }
+DEV M4 operator~(M4 a) { return M4{ { ~a.w[0], ~a.w[1], ~a.w[2], ~a.w[3] } }; }
+DEV M4 m4_zero() { return M4{ { 0, 0, 0, 0 } }; }
+/* up(m)[j] = m[j-1] (the bit moves to the next column), dn(m)[j] = m[j+1] */
+DEV M4 up1(M4 a) { return M4{ { a.w[0] << 1, (a.w[1] << 1) | (a.w[0] >> 63), (a.w[2] << 1) | (a.w[1] >> 63), (a.w[3] << 1) | (a.w[2] >> 63) } }; }
+DEV M4 dn1(M4 a) { return M4{ { (a.w[0] >> 1) | (a.w[1] << 63), (a.w[1] >> 1) | (a.w[2] << 63), (a.w[2] >> 1) | (a.w[3] << 63), a.w[3] >> 1 } }; }
+DEV M4 dn2(M4 a) { return M4{ { (a.w[0] >> 2) | (a.w[1] << 62), (a.w[1] >> 2) | (a.w[2] << 62), (a.w[2] >> 2) | (a.w[3] << 62), a.w[3] >> 2 } }; }
+DEV M4 dn3(M4 a) { return M4{ { (a.w[0] >> 3) | (a.w[1] << 61), (a.w[1] >> 3) | (a.w[2] << 61), (a.w[2] >> 3) | (a.w[3] << 61), a.w[3] >> 3 } }; }
+DEV uint64_t low_bits(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1)); }
+DEV M4 col_range(int lo, int hi)                                /* columns lo..hi inclusive */
+{
+	M4 r;
+	r.w[0] = low_bits(hi + 1) & ~low_bits(lo);
+	r.w[1] = low_bits(hi + 1 - 64) & ~low_bits(lo - 64);
+	r.w[2] = low_bits(hi + 1 - 128) & ~low_bits(lo - 128);
+	r.w[3] = low_bits(hi + 1 - 192) & ~low_bits(lo - 192);
+	return r;
+}
+#define TB(m, k) ((int)(((m).w[k] >> lane) & 1))
+#define BALLOT4(m, arr, expr) do { { const int x = arr[0]; (m).w[0] = __ballot(expr); } { const int x = arr[1]; (m).w[1] = __ballot(expr); } \
+	{ const int x = arr[2]; (m).w[2] = __ballot(expr); } { const int x = arr[3]; (m).w[3] = __ballot(expr); } } while (0)
+
+/* A walk that skips the cell after every cell where it fires: given "fires if visited" per cell, the cells where
+ * it does fire.  Inside a run of consecutive fire bits those are the cells at even distance from the run's
+ * first cell.  Adding a 1 at every run start that sits on an even column ripples through exactly those runs. */
+DEV M4 alt_runs(M4 f)
+{
+	const uint64_t even = 0x5555555555555555ull;
+	const M4 pf = up1(f);
+	uint64_t sum[4];
+	unsigned carry = 0;
+	for (int k = 0; k < 4; k++) {
+		const uint64_t se = f.w[k] & ~pf.w[k] & even;
+		const uint64_t t = f.w[k] + se;
+		const unsigned c1 = t < se;
+		sum[k] = t + carry;
+		carry = c1 | (sum[k] < t);
+	}
+	M4 r;
+	for (int k = 0; k < 4; k++) {
+		const uint64_t re = f.w[k] & ~sum[k];                       /* cells of runs that start on an even column */
+		r.w[k] = (re & even) | (f.w[k] & ~re & ~even);
+	}
+	return r;
+}
+
+/* value of the cell d columns to the right (d = 1..3) for every cell of a row held as v[k] = column lane + 64k */
+DEV int right_of(const int *v, int k, int nk, int d, int lane)
+{
+	const int a = __shfl(v[k], (lane + d) & 63);
+	const int b = k + 1 < nk ? __shfl(v[k + 1], (lane + d) & 63) : 0;
+	return lane + d < 64 ? a : b;
+}
+
+DEV int ll2_round(int v) { return (v > 0 && v < 256) ? (v & 0xFFFE) : v; }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * LL2 part of offsetY_recons256 (image_processing.c:2609-2735): tag runs of four odd samples, the walk that
+ * bumps the next sample / the sample below, and the rounded copy into the reconstruction plane.
+ *
+ * The +16000 tags are kept as masks (values stay untagged in registers): a tag matters only as "tagged cells do
+ * not fire, and in the first loop skip their right neighbour", in the |s - s2| > 1 test (true against a tagged
+ * partner) and in the "< 10000" test of the sample below.  A row's final value is known when its own step
+ * ends (the row above has bumped it, its own walk has bumped it), so the untagging / rounding pass (:2697-2735)
+ * is folded into the step: p = value, jp = tagged ? value : rounded value, in both loops.
+ * ------------------------------------------------------------------------------------------------------------ */
+DEV void ll2_load_row(const int16_t *p, int r, int lane, int *v, M4 *tag, int q, int part)
+{
+	if (r >= H / 2) { v[0] = v[1] = v[2] = 0; *tag = m4_zero(); return; }
+	for (int k = 0; k < 3; k++) v[k] = p[r * W + lane + 64 * k];
+	M4 t = m4_zero();
+	if (q > 17) {                                                  /* :2609-2640 */
+		int v4[4] = { v[0], v[1], v[2], 0 };
+		M4 o, d3;
+		BALLOT4(o, v4, x & 1);
+		int far[4];
+		for (int k = 0; k < 2; k++) far[k] = right_of(v, k, 3, 3, lane);
+		d3.w[0] = __ballot(iabs(v[0] - far[0]) > 1); d3.w[1] = __ballot(iabs(v[1] - far[1]) > 1); d3.w[2] = d3.w[3] = 0;
+		const M4 f = o & dn1(o) & dn2(o) & dn3(o) & d3 & col_range(0, H / 2 - 4);
+		unsigned __int128 m = ((unsigned __int128)f.w[1] << 64) | f.w[0], tg = 0;
+		const unsigned __int128 pat = part ? 5 : 15;
+		while (m) {
+			const uint64_t lo = (uint64_t)m;
+			const int j = lo ? __builtin_ctzll(lo) : 64 + __builtin_ctzll((uint64_t)(m >> 64));
+			tg |= pat << j;
+			m &= ~((unsigned __int128)15 << j);
+		}
+		t.w[0] = (uint64_t)tg; t.w[1] = (uint64_t)(tg >> 64);
+	}
+	*tag = t;
+}
+
+DEV void wave_ll2(Ctx *c, int part, int lane)
+{
+	int16_t *p = c->proc, *jp = c->jpeg;
+	const int q = c->q;
+	int v0[3], v1[3], v2[3], v3[3];
+	M4 t0, t1, t2, t3;
+	ll2_load_row(p, 0, lane, v0, &t0, q, part);
+	ll2_load_row(p, 1, lane, v1, &t1, q, part);
+	ll2_load_row(p, 2, lane, v2, &t2, q, part);
+	ll2_load_row(p, 3, lane, v3, &t3, q, part);
+	const M4 ll = col_range(0, H / 2 - 1);
+	for (int r = 0; r < H / 2; r++) {
+		int vn[3]; M4 tn;
+		ll2_load_row(p, r + 4, lane, vn, &tn, q, part);
+		if (q > 17) {
+			int a0[4] = { v0[0], v0[1], v0[2], 0 }, a1[4] = { v1[0], v1[1], v1[2], 0 }, a2[4] = { v2[0], v2[1], 0, 0 }, a3[4] = { v3[0], v3[1], 0, 0 };
+			M4 o, o1, o2, o3, d2;
+			BALLOT4(o, a0, x & 1); BALLOT4(o1, a1, x & 1); BALLOT4(o2, a2, x & 1); BALLOT4(o3, a3, x & 1);
+			const int f0 = right_of(v0, 0, 3, 2, lane), f1 = right_of(v0, 1, 3, 2, lane);
+			d2.w[0] = __ballot(iabs(v0[0] - f0) > 1); d2.w[1] = __ballot(iabs(v0[1] - f1) > 1); d2.w[2] = d2.w[3] = 0;
+			d2 = d2 | dn2(t0);                                         /* a tagged partner is 16000 away */
+			const M4 cond1 = o & dn1(o) & col_range(1, H / 2 - 1);
+			const M4 hbr = cond1 & dn2(o) & col_range(0, H / 2 - 3);
+			const M4 skip = part ? up1(t0) : m4_zero();
+			const M4 act = ll & ~t0 & ~skip;
+			const M4 fired = alt_runs(hbr & d2 & act);                 /* bumps the next sample */
+			const M4 bumped = up1(fired);
+			M4 vf = m4_zero();
+			if (r <= H / 2 - 2) vf = cond1 & ~hbr & o1 & dn1(o1) & ~dn2(o1);
+			if (r >= 1 && r <= H / 2 - 4) vf = vf | (~cond1 & o & o1 & dn1(o1) & o2 & ~o3);
+			vf = vf & act & ~bumped & ~t1;                             /* bumps the sample below (if it is not tagged) */
+			for (int k = 0; k < 2; k++) { v0[k] += TB(bumped, k); v1[k] += TB(vf, k); }
+		}
+		for (int k = 0; k < 2; k++) {
+			const int at = r * W + lane + 64 * k;
+			p[at] = (int16_t)v0[k];
+			jp[at] = (int16_t)(TB(t0, k) ? v0[k] : ll2_round(v0[k]));
+		}
+		for (int k = 0; k < 3; k++) { v0[k] = v1[k]; v1[k] = v2[k]; v2[k] = v3[k]; v3[k] = vn[k]; }
+		t0 = t1; t1 = t2; t2 = t3; t3 = tn;
+	}
+	if (!part) {                                                   /* samples the LL coder sent verbatim keep their exact value (:2728-2735) */
+		__threadfence_block();
+		const int nm = c->m->ll_mem_len;
+		for (int i = lane; i < nm; i += 64) {
+			const int idx = c->ll_mem[i], pos = ((idx >> 7) << 9) + (idx & 127);
+			jp[pos] = p[pos];
+		}
+	}
+	__threadfence_block();
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * detail bands of offsetY_recons256 (image_processing.c:2759-3124): triple / vertical-pair marking (writes into
+ * the next row), equal-sign 5..7 pairs, and the per-row dequantiser with its next-cell fix-ups.
+ * ------------------------------------------------------------------------------------------------------------ */
+DEV void det_load_row(const int16_t *p, int r, int lane, int *v)
+{
+	if (r >= H) { v[0] = v[1] = v[2] = v[3] = 0; return; }
+	const bool top = r < H / 2;                                    /* rows of the LL2 | HL2 half: only HL2 (columns >= 128) belongs to this pass */
+	v[0] = top ? 0 : p[r * W + lane];
+	v[1] = top ? 0 : p[r * W + lane + 64];
+	v[2] = p[r * W + lane + 128];
+	v[3] = p[r * W + lane + 192];
+}
+
+DEV void wave_dequant_details(Ctx *c, int part, int lane)
+{
+	int16_t *p = c->proc, *jp = c->jpeg;
+	int cur[4], nxt[4], pend_v[4] = { 0, 0, 0, 0 };
+	M4 pend = m4_zero();                                           /* jp cells of the current row the row above has set */
+	det_load_row(p, 0, lane, cur);
+	det_load_row(p, 1, lane, nxt);
+	for (int r = 0; r < H; r++) {
+		int far[4];
+		det_load_row(p, r + 2, lane, far);
+		const bool top = r < H / 2;
+		const int col0 = top ? H / 2 : 0;
+		int jv[4] = { pend_v[0], pend_v[1], pend_v[2], pend_v[3] };
+		M4 je = pend;
+		pend = m4_zero();
+		if (r < H - 1) {                                           /* :2759-2853 */
+			M4 P, N, PN, NN;
+			BALLOT4(P, cur, x > 3 && x < 8); BALLOT4(N, cur, x < -3 && x > -8);
+			BALLOT4(PN, nxt, x > 3 && x < 8); BALLOT4(NN, nxt, x < -3 && x > -8);
+			const M4 rg = col_range(col0 + 1, H - 2);
+			const M4 pp = P & up1(P), nn = N & up1(N);
+			const M4 tp = pp & dn1(P), tn = nn & dn1(N);
+			const M4 vp = pp & ~dn1(P) & up1(PN) & PN, vn = nn & ~dn1(N) & up1(NN) & NN;
+			const M4 fired = alt_runs((tp | vp | tn | vn) & rg);
+			const M4 ftp = fired & tp, ftn = fired & tn, fvp = fired & vp, fvn = fired & vn;
+			const M4 ft = ftp | ftn, fv = fvp | fvn;
+			const M4 ftp_l = dn1(ftp), ftn_l = dn1(ftn), fvp_l = dn1(fvp), fvn_l = dn1(fvn);   /* the cell left of a firing cell */
+			const M4 ftp_r = up1(ftp), ftn_r = up1(ftn);
+			for (int k = 0; k < 4; k++) {
+				if (TB(ft, k)) cur[k] = 0;
+				if (TB(ftp_l, k)) cur[k] = 15300; if (TB(ftn_l, k)) cur[k] = 15400;
+				if (TB(fvp_l, k)) { cur[k] = 15500; nxt[k] = 15500; }
+				if (TB(fvn_l, k)) { cur[k] = 15600; nxt[k] = 15600; }
+				if (TB(fv, k)) nxt[k] = 0;
+				if (TB(ftp, k) || TB(fvp, k) || TB(ftp_r, k)) jv[k] = 5;
+				if (TB(ftn, k)) jv[k] = -6;
+				if (TB(fvn, k) || TB(ftn_r, k)) jv[k] = -5;
+				pend_v[k] = TB(fvp, k) ? 5 : -5;
+			}
+			je = je | fired | ftp_r | ftn_r;
+			pend = fv;
+		}
+		if (!part) {                                               /* :2857-2905 */
+			M4 A, B;
+			BALLOT4(A, cur, x >= 5 && x <= 7); BALLOT4(B, cur, x <= -5 && x >= -7);
+			const M4 fired = alt_runs(((A & dn1(A)) | (B & dn1(B))) & col_range(col0, H - 2));
+			const M4 fa = fired & A, fb = fired & B;
+			for (int k = 0; k < 4; k++) { if (TB(fa, k)) cur[k] = 15700; if (TB(fb, k)) cur[k] = 15800; }
+		}
+		{                                                          /* :2909-3124 */
+			M4 code, k1, k2;
+			BALLOT4(code, cur, x > 15000);
+			BALLOT4(k2, cur, x == 15300 || x == 15400);
+			BALLOT4(k1, cur, x == 15500 || x == 15600 || x == 15700 || x == 15800);
+			const M4 rd = col_range(col0, H - 1);
+			M4 skipped;
+			{                                                      /* which cells the walk steps over: a visited code cell hides the next one (two for a triple) */
+				uint64_t carry = 0;
+				for (int k = 0; k < 4; k++) {
+					uint64_t sk = carry, m = (k1.w[k] | k2.w[k]) & rd.w[k];
+					carry = 0;
+					while (m) {
+						const int j = __builtin_ctzll(m);
+						m &= m - 1;
+						if (!((sk >> j) & 1)) {
+							const uint64_t pat = ((k2.w[k] >> j) & 1) ? 6 : 2;
+							sk |= pat << j;
+							if (j > 60) carry |= pat >> (64 - j);
+						}
+					}
+					skipped.w[k] = sk;
+				}
+			}
+			const M4 vis = rd & ~skipped, vc = vis & code, vnc = vis & ~code;
+			const M4 ml = col_range(0, H - 2);
+			M4 e8, e7, em7, dc, ac;
+			BALLOT4(e8, cur, x == 8); BALLOT4(e7, cur, x == 7); BALLOT4(em7, cur, x == -7);
+			BALLOT4(dc, cur, x > 12 && x < 15000 && (x & 7) >= 6); BALLOT4(ac, cur, x < -12 && ((-x) & 7) == 6);
+			const M4 dm = part ? m4_zero() : (vnc & ml & dc);
+			const M4 is8 = vnc & (e8 | (e7 & up1(dm)));               /* the walk sees an 8 here (a 7 the cell before has raised counts) */
+			const M4 to_m8 = em7 & up1((vnc & ml & ac) | (is8 & ml));
+			const M4 to_8 = e7 & up1(dm);
+			const M4 self_m8 = vnc & ml & em7 & ~to_m8 & dn1(e8);
+			const M4 m8 = to_m8 | self_m8;
+			M4 pr_p, pr_n;                                            /* visited 15700 / 15800: the partner takes the same +-6 */
+			BALLOT4(pr_p, cur, x == 15700); BALLOT4(pr_n, cur, x == 15800);
+			const M4 part_p = up1(pr_p & vc), part_n = up1(pr_n & vc);
+			for (int k = 0; k < 4; k++) {
+				if (TB(m8, k)) cur[k] = -8;
+				if (TB(to_8, k)) cur[k] = 8;
+				if (TB(part_p, k)) jv[k] = 6;
+				if (TB(part_n, k)) jv[k] = -6;
+				if (TB(vc, k)) {
+					const int a = cur[k];
+					if (a == 15300 || a == 15500) jv[k] = 5;
+					else if (a == 15400 || a == 15600) jv[k] = -5;
+					else if (a == 15700) jv[k] = 6;
+					else if (a == 15800) jv[k] = -6;
+				}
+				if (TB(vnc, k)) {
+					int a = cur[k];
+					if (a < 0) { a = -a; if ((a & 7) < 7) a &= 0xFFF8; a = -a; }
+					jv[k] = dequant_value(a);
+				}
+			}
+			M4 wr;                                                    /* code cells with another value (none are produced) write nothing */
+			BALLOT4(wr, cur, x > 15000 && !(x == 15300 || x == 15400 || x == 15500 || x == 15600 || x == 15700 || x == 15800));
+			je = je | part_p | part_n | (vis & ~wr);
+		}
+		for (int k = 0; k < 4; k++) {
+			if (top && k < 2) continue;
+			const int at = r * W + lane + 64 * k;
+			p[at] = (int16_t)cur[k];
+			if (TB(je, k)) jp[at] = (int16_t)jv[k];
+		}
+		for (int k = 0; k < 4; k++) { cur[k] = nxt[k]; nxt[k] = far[k]; }
+	}
+	__threadfence_block();
+}
+
+/* isolated coefficient shrink (image_processing.c:3154-3188): a reconstructed detail >= 8 in magnitude with no
+ * such neighbour moves one step towards zero.  Only isolated cells move, and a cell next to one is small, so the
+ * decisions are those of the untouched plane; a three-row window of ">= 8" masks carries them. */
+DEV void wave_shrink(Ctx *c, int lane)
+{
+	int16_t *jp = c->jpeg;
+	int jc[4], jn[4];
+	M4 bp, bc, bn;
+	for (int k = 0; k < 4; k++) { jn[k] = jp[lane + 64 * k]; jc[k] = jp[W + lane + 64 * k]; }
+	BALLOT4(bp, jn, iabs(x) >= 8);
+	BALLOT4(bc, jc, iabs(x) >= 8);
+	for (int k = 0; k < 4; k++) jn[k] = jp[2 * W + lane + 64 * k];
+	BALLOT4(bn, jn, iabs(x) >= 8);
+	const M4 inner = col_range(1, H - 2), right = col_range(H / 2, H - 2);
+	for (int r = 1; r < H - 1; r++) {
+		int jf[4] = { 0, 0, 0, 0 };
+		if (r + 2 < H) for (int k = 0; k < 4; k++) jf[k] = jp[(r + 2) * W + lane + 64 * k];
+		const M4 near = up1(bp) | bp | dn1(bp) | up1(bc) | dn1(bc) | up1(bn) | bn | dn1(bn);
+		const M4 hit = bc & ~near & (r >= H / 2 ? inner : right);
+		for (int k = 0; k < 4; k++)
+			if (TB(hit, k)) jp[r * W + lane + 64 * k] = (int16_t)(jc[k] > 0 ? jc[k] - 1 : jc[k] + 1);
+		bp = bc; bc = bn;
+		for (int k = 0; k < 4; k++) { jc[k] = jn[k]; jn[k] = jf[k]; }
+		BALLOT4(bn, jn, iabs(x) >= 8);
+	}
+}
+
+/* offsetY_recons256 (image_processing.c:2600-3190), one wavefront per image */
+DEV void wave_dequant_sim_luma(Ctx *c, int part, int lane)
+{
+	PROF_BEGIN();
+	wave_ll2(c, part, lane);
+	wave_dequant_details(c, part, lane);
+	if (!part) wave_shrink(c, lane);
+	if (!lane) PROF(c, part ? 1 : 7);
+}
+
+}  /* namespace nhw */
+#endif
