@@ -72,7 +72,7 @@ static size_t phase_lds(int ph)
 	const size_t tile = (size_t)NT * TLS * sizeof(int16_t);
 	switch (ph) {
 	case PH_L2: return 2 * tile;
-	case PH_L3: return 16640;
+	case PH_L3: return LL_LDS_BYTES;
 	case PH_L4A: case PH_L4B: case PH_L4C: case PH_L4D: return (size_t)(NT + 2) * TLS * sizeof(int16_t);
 	case PH_C5: return 32 * 130 * 2 + (32 * 128 + 258) * 2 > tile ? 32 * 130 * 2 + (32 * 128 + 258) * 2 : tile;
 	default: return 0;

@@ -1139,6 +1139,172 @@ DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 }
 
 /* ---------------------------------------------------------------- phases (256 threads per image) */
+/* ---------------------------------------------------------------- Y16: the LL2 byte coder, workgroup-parallel */
+/* exclusive prefix sum of one 32-bit value per thread over the workgroup (wave shuffles + one LDS hop) */
+DEV unsigned block_exscan(unsigned v, int tid, unsigned *shm /* [NT / 64 + 1] */, unsigned *total)
+{
+	const int lane = tid & 63, wv = tid >> 6;
+	unsigned x = v;
+	for (int d = 1; d < 64; d <<= 1) { const unsigned y = __shfl_up(x, d); if (lane >= d) x += y; }
+	BARRIER();
+	if (lane == 63) shm[wv] = x;
+	BARRIER();
+	unsigned base = 0, sum = 0;
+	for (int k = 0; k < NT / 64; k++) { if (k < wv) base += shm[k]; sum += shm[k]; }
+	*total = sum;
+	return base + x - v;
+}
+
+/* one token of Y_highres_compression (compress_pixel.c:510-790) as if the walk stood at sample i: returns the
+ * sample the walk visits next; OUT: the token's bytes after the marker strip of :828-866 (a single stays, a
+ * (64, x, y) triple keeps x y, a (128, a, b) verbatim record keeps b), and whether it is a verbatim record */
+template <bool OUT>
+DEV int ll_luma_token(const uint8_t *s, int i, int n, int mode, int *nb, int *b0, int *b1, int *verb)
+{
+	const int d0 = s[i] - s[i - 1], d1 = s[i + 1] - s[i];
+	int kind = 2, byte = 0, t0 = 0, t1 = 0, t2 = 0, next;           /* kind 0: one byte, 1: triple, 2: verbatim */
+	if (d0 == 0 && d1 == 0) {
+		int a = 0, ii, d;
+		if (mode == 0) {                                            /* :515-553 */
+			if (s[i + 2] == s[i + 1]) a = 1;
+			ii = i + a + 2; byte = a << 3;
+			d = s[ii] - s[ii - 1];
+			if (d == 2) { const int f = s[ii + 1] - s[ii]; if (f == -2) { byte += 2; ii++; } else if (f == 0) { byte += 3; ii++; } else byte += 1; }
+			else if (d == -2) { const int f = s[ii + 1] - s[ii]; if (f == 2) { byte += 4; ii++; } else if (f == 0) { byte += 5; ii++; } else byte += 6; }
+			else if (d == 4) byte += 7;
+			else ii--;
+		} else if (mode == 1) {                                     /* :652-673 */
+			while (a < 7 && s[i + a + 2] == s[i + a + 1]) a++;
+			ii = i + a + 2; byte = a << 2;
+			d = s[ii] - s[ii - 1];
+			if (d == 2) byte += 1; else if (d == -2) byte += 2; else if (d == 0) byte += 3; else ii--;
+		} else {                                                    /* :762-775 */
+			while (a < 63 && s[i + a + 2] == s[i + a + 1]) a++;
+			ii = i + a + 1; byte = a;
+		}
+		kind = 0; next = ii + 1;
+	} else {
+		const int d2 = s[i + 2] - s[i + 1];
+		const bool d2ok = iabs(d2) <= 32 && i < n - 2;
+		if (mode == 0 && iabs(d0) <= 6 && iabs(d1) <= 8) {          /* :554-599 */
+			const int e0 = d0 + 6, e1 = d1 + 8;
+			if (e0 == 12 || e1 == 16) { if (d2ok) { kind = 1; t0 = e0 + 26; t1 = e1 + 8; t2 = d2 + 32; } }
+			else { kind = 0; byte = e0 < 8 ? 32 + (e0 << 2) + (e1 >> 1) : (e0 == 8 ? 16 + (e1 >> 1) : 24 + (e1 >> 1)); }
+		}
+		else if (mode == 1 && iabs(d0) <= 4 && iabs(d1) <= 8) {     /* :674-706 */
+			const int e0 = d0 + 4, e1 = d1 + 8;
+			if (e0 == 8 || e1 == 16) { if (d2ok) { kind = 1; t0 = e0 + 28; t1 = e1 + 8; t2 = d2 + 32; } }
+			else { kind = 0; byte = 32 + (e0 << 2) + (e1 >> 1); }
+		}
+		else if (iabs(d0) <= 32 && iabs(d1) <= 16 && d2ok) { kind = 1; t0 = d0 + 32; t1 = d1 + 16; t2 = d2 + 32; }   /* :600-630 */
+		if (kind == 1 && (t0 == 64 || t1 == 32 || t2 == 64)) kind = 2;
+		next = kind == 1 ? i + 3 : i + 2;
+	}
+	if (OUT) {
+		*verb = kind == 2;
+		if (kind == 0) { *nb = 1; *b0 = byte; }
+		else if (kind == 1) { t1 >>= 1; *nb = 2; *b0 = 64 + t0 + (t1 >> 3); *b1 = ((t1 & 7) << 5) + (t2 >> 1); }
+		else { *nb = 1; *b0 = 128 + (s[i + 1] >> 1); }
+	}
+	return next;
+}
+
+/* The coder is a parse: the token at sample i decides which sample is looked at next (1 to 66 further).  What a
+ * token would be at i depends only on the samples, so every thread first works out the stride at its samples;
+ * which samples the walk really visits is then a pointer chase, done in three short hops instead of one long
+ * one: (1) per 64-sample block, backwards: from each sample, where does the walk leave the block; (2) one thread
+ * hops block to block (<= 256 hops) and notes where each block is entered; (3) every thread re-walks its block
+ * from its entry, twice: to count its output bytes / verbatim records, and, after a prefix sum, to write them.
+ * LDS: the samples (+ zero padding the reference also reads) and one byte per sample for strides / exits, the
+ * latter padded 4 bytes per block so that one block per lane is bank-conflict free. */
+#define LLX(i) ((i) + (((i) >> 6) << 2))
+#define LL_LDS_BYTES (16640 + 16384 + 1024 + 512 + 64)
+DEV void ll_code_luma_par(Ctx *c, int tid, uint8_t *lds /* LL_LDS_BYTES, the samples already in the first 16640 */)
+{
+	const int n = Q >> 2, lane = tid & 63, wv = tid >> 6;
+	const uint8_t *s = lds;
+	uint8_t *X = lds + 16640;
+	int16_t *entry = reinterpret_cast<int16_t *>(lds + 16640 + 16384 + 1024);
+	unsigned *shm = reinterpret_cast<unsigned *>(lds + 16640 + 16384 + 1024 + 512);   /* [16] */
+
+	/* statistics (compress_pixel.c:482-497): in every run of equal neighbours, cut into pieces of 16 matches, count the
+	 * pieces that reach 8 and 16 matches.  A piece must start before n; its matches may lie in the padding. */
+	const int words = (n + 16 + 63) / 64, wpw = (words + 3) / 4;
+	int last_mis = -1;                                           /* last sample of this wave's range that differs from its left neighbour */
+	for (int k = 0; k < wpw; k++) {
+		const int i = (wv * wpw + k) * 64 + lane;
+		const bool mis = i == 0 || (i < n + 16 && s[i] != s[i - 1]);
+		const uint64_t mm = __ballot(mis);
+		if (mm) last_mis = (wv * wpw + k) * 64 + 63 - __builtin_clzll(mm);
+	}
+	if (lane == 0) reinterpret_cast<int *>(shm)[wv] = last_mis;
+	BARRIER();
+	int carry = 0;
+	for (int k = 0; k < wv; k++) { const int v = reinterpret_cast<int *>(shm)[k]; carry = v > carry ? v : carry; }
+	int r8 = 0, r16 = 0;
+	for (int k = 0; k < wpw; k++) {
+		const int base = (wv * wpw + k) * 64, i = base + lane;
+		const bool in = i >= 1 && i < n + 16;
+		const bool mis = i == 0 || (i < n + 16 && s[i] != s[i - 1]);
+		const uint64_t mm = __ballot(mis);
+		const uint64_t below = mm & ((2ull << lane) - 1);
+		const int lm = below ? base + 63 - __builtin_clzll(below) : carry;
+		const int off = i - lm - 1;                              /* this sample is match number off + 1 of its run */
+		r8 += __popcll(__ballot(in && !mis && (off & 15) == 7 && i - 7 < n));
+		r16 += __popcll(__ballot(in && !mis && (off & 15) == 15 && i - 15 < n));
+		if (mm) carry = base + 63 - __builtin_clzll(mm);
+	}
+	BARRIER();
+	if (lane == 0) { shm[wv] = (unsigned)r8; shm[4 + wv] = (unsigned)r16; }
+	BARRIER();
+	const int runs16 = (int)(shm[4] + shm[5] + shm[6] + shm[7]), runs8 = (int)(shm[0] + shm[1] + shm[2] + shm[3]) + runs16;
+	const int mode = runs16 > 299 ? 2 : (runs8 > 179 ? 1 : 0);       /* :506-508 */
+	BARRIER();
+
+	for (int i = tid; i < n; i += NT) X[LLX(i)] = i ? (uint8_t)(ll_luma_token<false>(s, i, n, mode, nullptr, nullptr, nullptr, nullptr) - i) : 1;
+	entry[tid] = -1;
+	BARRIER();
+	{                                                            /* (1) where the walk leaves my block, from each of its samples */
+		const int b0 = tid * 64, end = b0 + 64;
+		for (int e = end - 1; e >= b0; e--) {
+			const int nx = e + X[LLX(e)];
+			X[LLX(e)] = (uint8_t)(nx >= end ? nx - end : X[LLX(nx)]);
+		}
+	}
+	BARRIER();
+	if (tid == 0) { int pos = 1; while (pos < n) { const int b = pos >> 6; entry[b] = (int16_t)pos; pos = (b + 1) * 64 + X[LLX(pos)]; } }   /* (2) */
+	BARRIER();
+	const int e0 = entry[tid], end = tid * 64 + 64;
+	unsigned cnt = 0;
+	if (e0 >= 0)
+		for (int i = e0; i < end;) {
+			int nb, b0, b1, verb;
+			i = ll_luma_token<true>(s, i, n, mode, &nb, &b0, &b1, &verb);
+			cnt += (unsigned)nb + ((unsigned)verb << 16);
+		}
+	unsigned total;
+	const unsigned off = block_exscan(cnt, tid, shm, &total);
+	if (e0 >= 0) {
+		uint8_t *o = c->ll_comp + 1 + (off & 0xFFFF);
+		int m = (int)(off >> 16);
+		for (int i = e0; i < end;) {
+			int nb, b0, b1, verb;
+			const int at = i;
+			i = ll_luma_token<true>(s, i, n, mode, &nb, &b0, &b1, &verb);
+			*o++ = (uint8_t)b0;
+			if (nb == 2) *o++ = (uint8_t)b1;
+			if (verb) { c->ll_word[m] = c->ll_full[at]; c->ll_mem[m] = (uint16_t)at; m++; }
+		}
+	}
+	if (tid == 0) {
+		c->ll_comp[0] = s[0];
+		c->m->res_low = mode;
+		c->m->ll_comp_y_len = 1 + (int)(total & 0xFFFF);
+		c->m->ll_word_len = (int)(total >> 16);
+		c->m->ll_mem_len = (int)(total >> 16);
+	}
+}
+
 DEV void luma_p1_par(Ctx *c, int tid, int *pos)
 {
 	PROF_BEGIN();
@@ -1162,11 +1328,12 @@ DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc, int16_t *lds)
 	BARRIER();
 	emit_ll2_par(c, tid, pos, sh_misc);
 	if (!tid) PROF(c, 4);
-	{                                                             /* Y16: the LL2 byte coder reads an LDS copy of its 16 KiB input (its writes do not stall it) */
+	{                                                             /* Y16 */
 		uint8_t *ls = reinterpret_cast<uint8_t *>(lds);
 		for (int i = tid; i < 16640 / 16; i += NT) reinterpret_cast<uint4 *>(ls)[i] = reinterpret_cast<const uint4 *>(c->ll_bytes)[i];
 		BARRIER();
-		if (tid == 0) { ll_code_luma(c, ls, c->ll_full, c->ll_comp); PROF(c, 5); }
+		ll_code_luma_par(c, tid, ls);
+		if (!tid) PROF(c, 5);
 	}
 	BARRIER();
 	copy_block_par(c->l2save, H, c->proc, W, H, H, tid);          /* Y17 :749-755 */
