@@ -27,7 +27,7 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s);
 enum { WV_DQ1, WV_DQ0 };
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
-enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D };
+enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC };
 
 static thread_local std::string g_err;
 extern "C" const char *nhw_last_error(void) { return g_err.c_str(); }
@@ -197,7 +197,9 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 		STAGE_DONE();
 	}
 	HIPCHK(hipEventRecord(e->ev[3], s));
-	nhw_launch_phase(PH_FINAL, ws, 0, out, d_sizes, d_status, s);   /* Z1, Z2, container */
+	nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, s);     /* Z1 */
+	nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, s);     /* Z1 */
+	nhw_launch_phase(PH_FINAL, ws, 0, out, d_sizes, d_status, s);   /* Z2, container */
 	HIPCHK(hipEventRecord(e->ev[4], s));
 	HIPCHK(hipGetLastError());
 	e->timed = true;

@@ -1305,6 +1305,95 @@ DEV void ll_code_luma_par(Ctx *c, int tid, uint8_t *lds /* LL_LDS_BYTES, the sam
 	}
 }
 
+/* ---------------------------------------------------------------- Z1: the chroma LL2 byte coder, same scheme */
+/* one token of highres_compression (compress_pixel.c:890-1010) at sample i: always one byte; returns the next sample */
+DEV int ll_chroma_token(const uint8_t *s, int i, int *byte)
+{
+	const int d0 = s[i] - s[i - 1], d1 = s[i + 1] - s[i];
+	if (d0 == 0 && d1 == 0) {                                       /* :898-945 run of equal samples, up to 14 */
+		int a = 0;
+		while (a < 14 && s[i + a + 2] == s[i + a + 1]) a++;
+		int ii = i + a + 1;
+		if (a >= 7) { *byte = 64 + (7 << 3) + a - 7; return ii + 1; }
+		ii++;
+		int b = 64 + (a << 3);
+		const int d = s[ii] - s[ii - 1];
+		if (d == 4) {
+			if (s[ii + 1] - s[ii] == -4) { if (s[ii + 2] - s[ii + 1] == 0) { b += 3; ii += 2; } else { b += 2; ii++; } }
+			else b += 1;
+		} else if (d == -4) {
+			if (s[ii + 1] - s[ii] == 4) { if (s[ii + 2] - s[ii + 1] == 0) { b += 4; ii += 2; } else { b += 5; ii++; } }
+			else b += 6;
+		} else if (d == 8) b += 7;
+		else ii--;
+		*byte = b;
+		return ii + 1;
+	}
+	if (iabs(d0) <= 4 && iabs(d1) <= 4) {                           /* :946-984 steps of 0/+-4 */
+		int code = 0;
+		if (!d0 && d1 == 4) code = 0; else if (!d0 && d1 == -4) code = 1;
+		else if (d0 == 4 && !d1) code = 2; else if (d0 == -4 && !d1) code = 3;
+		else if (d0 == 4 && d1 == 4) code = 4; else if (d0 == 4 && d1 == -4) code = 5;
+		else if (d0 == -4 && d1 == 4) code = 6; else if (d0 == -4 && d1 == -4) code = 7;
+		const int d2 = s[i + 2] - s[i + 1];
+		if (d2 == 0) { *byte = 128 + 64 + (code << 2); return i + 3; }
+		if (d2 == 4) { *byte = 128 + 64 + (code << 2) + 1; return i + 3; }
+		if (d2 == -4) { *byte = 128 + 64 + (code << 2) + 2; return i + 3; }
+		if (d2 == 8) { *byte = 128 + 64 + (code << 2) + 3; return i + 3; }
+		*byte = ((d0 + 16) << 1) + ((d1 + 16) >> 2);
+		return i + 2;
+	}
+	if (iabs(d0) <= 16 && iabs(d1) <= 16) {                         /* :985-1003 */
+		const int e0 = d0 + 16, e1 = d1 + 16;
+		if (e0 == 32 || e1 == 32) { *byte = 128 + (s[i] >> 2); return i + 1; }
+		*byte = (e0 << 1) + (e1 >> 2);
+		return i + 2;
+	}
+	*byte = 128 + (s[i] >> 2);                                      /* :1004-1010 */
+	return i + 1;
+}
+
+#define LCX(i) ((i) + (((i) >> 5) << 2))
+#define LLC_LDS_BYTES (8192 + 128 + 8192 + 1024 + 512 + 64)
+DEV void ll_code_chroma_par(Ctx *c, int tid, uint8_t *lds /* LLC_LDS_BYTES */)
+{
+	const int n = Q >> 3, lo = Q >> 2;
+	uint8_t *s = lds, *X = lds + 8192 + 128;
+	int16_t *entry = reinterpret_cast<int16_t *>(lds + 8192 + 128 + 8192 + 1024);
+	unsigned *shm = reinterpret_cast<unsigned *>(lds + 8192 + 128 + 8192 + 1024 + 512);
+	for (int i = tid; i < (n + 128) / 4; i += NT) {                 /* :886 the samples lose their two low bits (the padding behind them is zero) */
+		uint32_t v = reinterpret_cast<const uint32_t *>(c->ll_bytes + lo)[i];
+		if (4 * i < n) { v &= 0xFCFCFCFCu; reinterpret_cast<uint32_t *>(c->ll_bytes + lo)[i] = v; }
+		reinterpret_cast<uint32_t *>(s)[i] = v;
+	}
+	BARRIER();
+	for (int i = tid; i < n; i += NT) { int byte; X[LCX(i)] = i ? (uint8_t)(ll_chroma_token(s, i, &byte) - i) : 1; }
+	BARRIER();
+	{
+		const int b0 = tid * 32, end = b0 + 32;
+		for (int e = end - 1; e >= b0; e--) {
+			const int nx = e + X[LCX(e)];
+			X[LCX(e)] = (uint8_t)(nx >= end ? nx - end : X[LCX(nx)]);
+		}
+	}
+	BARRIER();
+	if (tid == 0) { int pos = 1; while (pos < n) { const int b = pos >> 5; entry[b] = (int16_t)pos; pos = (b + 1) * 32 + X[LCX(pos)]; } }   /* strides are <= 16: every block is entered */
+	BARRIER();
+	const int e0 = entry[tid], end = tid * 32 + 32;
+	unsigned cnt = 0;
+	for (int i = e0; i < end;) { int byte; i = ll_chroma_token(s, i, &byte); cnt++; }
+	unsigned total;
+	const unsigned off = block_exscan(cnt, tid, shm, &total);
+	const int j = c->m->ll_comp_y_len;
+	uint8_t *o = c->ll_comp + j + 1 + off;
+	for (int i = e0; i < end;) { int byte; i = ll_chroma_token(s, i, &byte); *o++ = (uint8_t)byte; }
+	if (tid == 0) {
+		c->ll_comp[j] = s[0];
+		c->m->res_high = c->m->res_low;                              /* :887 */
+		c->m->ch_res_len = j + 1 + (int)total;
+	}
+}
+
 DEV void luma_p1_par(Ctx *c, int tid, int *pos)
 {
 	PROF_BEGIN();
@@ -1833,9 +1922,6 @@ DEV size_t container_par(Ctx *c, uint8_t *out, size_t cap, int tid)
 DEV void final_phase_par(Ctx *c, uint8_t *out, size_t cap, uint32_t *size, int32_t *status, PackShared *sh, int tid)
 {
 	PROF_BEGIN();
-	if (tid == 0) ll_code_chroma(c);
-	BARRIER();
-	if (!tid) PROF(c, 18);
 	uint8_t saved = c->scan[4 * Q];
 	BARRIER();
 	if (tid == 0) c->scan[4 * Q] = 3;                            /* sentinel behind the luma part (compress_pixel.c:66) */
