@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_C4) dequant_sim_chroma_par(&c, 0, tid);
 	else if (PH == PH_C5) chroma_p5_par(&c, comp, tid, dyn_lds, sh_counts);
 	else if (PH == PH_FINAL) {
-		final_phase_par(&c, out + (size_t)img * (512u << 10), 512u << 10, &sizes[img], &status[img], &sh_pack, tid);
+		final_phase_par(&c, out + (size_t)img * (512u << 10), 512u << 10, &sizes[img], &status[img], &sh_pack, tid, reinterpret_cast<uint32_t *>(dyn_lds));
 	}
 }
 
@@ -75,6 +75,7 @@ static size_t phase_lds(int ph)
 	case PH_L2: return 2 * tile;
 	case PH_L3: return LL_LDS_BYTES;
 	case PH_LLC: return LLC_LDS_BYTES;
+	case PH_FINAL: return PK_LDS_BYTES;
 	case PH_L4A: case PH_L4B: case PH_L4C: case PH_L4D: return (size_t)(NT + 2) * TLS * sizeof(int16_t);
 	case PH_C5: return 32 * 130 * 2 + (32 * 128 + 258) * 2 > tile ? 32 * 130 * 2 + (32 * 128 + 258) * 2 : tile;
 	default: return 0;

@@ -1698,10 +1698,32 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 #undef EMIT
 }
 
+/* One 16 KiB chunk of the symbol stream in LDS, one 64-symbol slice per thread: 17 words per slice, the first holds
+ * the 4 symbols before the slice (the walk looks back that far), so that the slices of a wavefront start in 64
+ * different banks.  Returns the thread's view: dl[x] is stream symbol x for x in [lo - 4, lo + 64). */
+#define PK_LDS_BYTES ((17 * NT + 1) * 4)
+DEV const uint8_t *pack_stage(const uint8_t *d, int N, int ch, int tid, uint32_t *lw)
+{
+	const int clo = ch * PK_CHUNK;
+	BARRIER();
+	for (int g = tid; g < PK_CHUNK / 16; g += NT) {
+		const int at = clo + 16 * g;
+		uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+		if (at < N) v = *reinterpret_cast<const uint4 *>(d + at);
+		const int t = g >> 2, j = (g & 3) * 4;
+		uint32_t *w = lw + 17 * t + 1 + j;
+		w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+		if (j == 12) lw[17 * (t + 1)] = v.w;
+	}
+	if (tid == 0) lw[0] = clo ? *reinterpret_cast<const uint32_t *>(d + clo - 4) : 0x80808080u;
+	BARRIER();
+	return reinterpret_cast<const uint8_t *>(lw + 17 * tid + 1) - (clo + tid * PK_SLICE);
+}
+
 /* Slices are 64 consecutive symbols and a workgroup sweeps the stream in chunks of 256 slices (16 KiB), so the
  * lanes of a wavefront read adjacent cache lines (a thread-per-kilobyte split makes every lane stream its own
  * line and thrashes L1: measured 5 us per symbol). */
-DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0)
+DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uint32_t *lw /* PK_LDS_BYTES */)
 {
 	const uint8_t *d = c->scan + (part ? 4 * Q : 0);
 	const int N = part ? 2 * Q : 4 * Q;
@@ -1715,10 +1737,21 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0)
 	sh->hist[tid] = 0; sh->runs[tid] = 0;
 	if (tid == 0) { sh->select = part ? 3 : 4; sh->zone = 0; sh->rc = NHW_OK; }
 	for (int ch = 0; ch < nchunks; ch++) {                       /* per slice: last / first symbol that is not 128 */
-		const int g = ch * NT + tid, lo = g * PK_SLICE, hi = lo + PK_SLICE < N ? lo + PK_SLICE : N;
-		int last = -1, first = N;
-		for (int i = lo; i < hi; i++) if (d[i] != 128) { last = i; if (first == N) first = i; }
-		prevnz[g] = last; nextnz[g] = first;
+		const int g = ch * NT + tid, lo = g * PK_SLICE;
+		uint64_t nz = 0;                                         /* bit k: symbol lo + k is not 128 */
+		if (lo < N)
+			for (int k = 0; k < 4; k++) {
+				const uint4 v = reinterpret_cast<const uint4 *>(d + lo)[k];
+				const uint32_t w[4] = { v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u };
+				for (int u = 0; u < 4; u++) {
+					uint32_t x = w[u];
+					x = (x | (x >> 4)) & 0x0F0F0F0Fu; x = (x | (x >> 2)) & 0x03030303u; x = (x | (x >> 1)) & 0x01010101u;   /* one bit per non-zero byte */
+					const uint32_t m4 = (x | (x >> 7) | (x >> 14) | (x >> 21)) & 15;
+					nz |= (uint64_t)m4 << (16 * k + 4 * u);
+				}
+			}
+		prevnz[g] = nz ? lo + 63 - __builtin_clzll(nz) : -1;
+		nextnz[g] = nz ? lo + __builtin_ctzll(nz) : N;
 	}
 	BARRIER();
 	{                                                            /* exclusive prefix max / inclusive suffix min over the slices */
@@ -1743,7 +1776,8 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0)
 	BARRIER();
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
-		if (lo < S) pack_walk<0>(d, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
+		const uint8_t *dl = pack_stage(d, N, ch, tid, lw);
+		if (lo < S) pack_walk<0>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
 	}
 	BARRIER();
 	if (!tid) PROF(c, 23);
@@ -1791,7 +1825,8 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0)
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
 		unsigned b = 0, x1 = 0, x2 = 0;
-		if (lo < S) pack_walk<1>(d, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &b, &x1, &x2, prevnz, nextnz, ch * NT + tid);
+		const uint8_t *dl = pack_stage(d, N, ch, tid, lw);
+		if (lo < S) pack_walk<1>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &b, &x1, &x2, prevnz, nextnz, ch * NT + tid);
 		cnt[ch * NT + tid] = b; cnt[nsl + ch * NT + tid] = x1; cnt[2 * nsl + ch * NT + tid] = x2;
 	}
 	BARRIER();
@@ -1819,7 +1854,8 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0)
 	BARRIER();
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
-		if (lo < S) pack_walk<2>(d, N, lo, hi, sh, words, cnt[ch * NT + tid], c->s1, cnt[nsl + ch * NT + tid], c->s2, cnt[2 * nsl + ch * NT + tid], nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
+		const uint8_t *dl = pack_stage(d, N, ch, tid, lw);
+		if (lo < S) pack_walk<2>(dl, N, lo, hi, sh, words, cnt[ch * NT + tid], c->s1, cnt[nsl + ch * NT + tid], c->s2, cnt[2 * nsl + ch * NT + tid], nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
 	}
 	BARRIER();
 	if (!tid) PROF(c, 26);
@@ -1919,18 +1955,18 @@ DEV size_t container_par(Ctx *c, uint8_t *out, size_t cap, int tid)
 }
 
 /* Z1, Z2 and the container */
-DEV void final_phase_par(Ctx *c, uint8_t *out, size_t cap, uint32_t *size, int32_t *status, PackShared *sh, int tid)
+DEV void final_phase_par(Ctx *c, uint8_t *out, size_t cap, uint32_t *size, int32_t *status, PackShared *sh, int tid, uint32_t *lw)
 {
 	PROF_BEGIN();
 	uint8_t saved = c->scan[4 * Q];
 	BARRIER();
 	if (tid == 0) c->scan[4 * Q] = 3;                            /* sentinel behind the luma part (compress_pixel.c:66) */
 	BARRIER();
-	pack_part_par(c, 0, sh, tid, 0);
+	pack_part_par(c, 0, sh, tid, 0, lw);
 	if (sh->rc) { if (tid == 0) { *size = 0; *status = sh->rc; } return; }
 	if (tid == 0) { c->scan[4 * Q] = saved; c->scan[6 * Q - 1] = c->scan[6 * Q - 2]; }   /* :464-465 */
 	BARRIER();
-	pack_part_par(c, 1, sh, tid, c->m->size_data1);
+	pack_part_par(c, 1, sh, tid, c->m->size_data1, lw);
 	if (sh->rc) { if (tid == 0) { *size = 0; *status = sh->rc; } return; }
 	if (!tid) PROF(c, 19);
 	const size_t n = container_par(c, out, cap, tid);
