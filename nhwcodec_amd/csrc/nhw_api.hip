@@ -198,7 +198,6 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	}
 	HIPCHK(hipEventRecord(e->ev[3], s));
 	nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, s);     /* Z1 */
-	nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, s);     /* Z1 */
 	nhw_launch_phase(PH_FINAL, ws, 0, out, d_sizes, d_status, s);   /* Z2, container */
 	HIPCHK(hipEventRecord(e->ev[4], s));
 	HIPCHK(hipGetLastError());

@@ -1637,6 +1637,7 @@ struct PackShared {
 	unsigned weight[360];
 	uint16_t entry[600];
 	uint16_t rank_sym[256], rank_run[256];
+	uint32_t code_sym[256], code_run[256];
 	unsigned bits[NT], n1[NT], n2[NT];
 	int k, select, zone, top_is_zero, rc;
 	unsigned total_bits, total_n1, total_n2;
@@ -1652,43 +1653,52 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 {
 	unsigned bits = 0, n1 = 0, n2 = 0;
 	uint32_t cur = 0; int w = (int)(bit0 >> 5), fill = (int)(bit0 & 31);
-	const int select = sh->select, zone = sh->zone;
-#define EMIT(posv) do { int pos_ = (posv), len_; uint32_t code_; \
-		if (pos_ >= 110 && pos_ < 174 && zone) { code_ = (uint32_t)((1 << 6) | (pos_ - 110)); len_ = 15; } \
-		else { if (pos_ >= 174 && zone) pos_ -= 64; code_ = k_vlc[pos_] & 0xFFFFFF; len_ = (int)(k_vlc[pos_] >> 24); } \
+	const int select = sh->select;
+	/* code tables built after the ranking: (length << 24) | code word of a symbol / of a zero run of a given length */
+#define EMIT(entry) do { const uint32_t e_ = (entry), code_ = e_ & 0xFFFFFF; const int len_ = (int)(e_ >> 24); \
 		if (MODE == 1) bits += (unsigned)len_; \
 		else { fill += len_; if (fill <= 32) cur |= code_ << (32 - fill); \
 			else { const int sp_ = fill - 32; atomicOr(&words[w], cur | (code_ >> sp_)); w++; cur = (code_ & ((1u << sp_) - 1)) << (32 - sp_); fill = sp_; } } } while (0)
+	const int send = (slice + 1) * PK_SLICE < N ? (slice + 1) * PK_SLICE : N;
+	uint64_t nz = 0;                                 /* bit k: symbol lo + k is not 128 (symbols behind the stream read as 128) */
+	{
+		const uint32_t *sw = reinterpret_cast<const uint32_t *>(d + lo);
+		for (int k = 0; k < 16; k++) {
+			uint32_t x = sw[k] ^ 0x80808080u;
+			x = (x | (x >> 4)) & 0x0F0F0F0Fu; x = (x | (x >> 2)) & 0x03030303u; x = (x | (x >> 1)) & 0x01010101u;
+			nz |= (uint64_t)((x | (x >> 7) | (x >> 14) | (x >> 21)) & 15) << (4 * k);
+		}
+	}
 	int i = lo;
 	if (MODE != 0)                                   /* am I inside the 4 symbols that follow a 132..135 code? */
 		for (int k = 1; k <= 4; k++) if (lo - k >= 0 && d[lo - k] >= 132 && d[lo - k] <= 135) { i = lo - k + 5; break; }
 	while (i < hi) {
-		const int px = d[i];
-		if (px != 128) {
+		if ((nz >> (i - lo)) & 1) {
+			const int px = d[i];
 			if (MODE == 0) { atomicAdd(&sh->hist[px], 1); i++; continue; }
 			if (px == 153 || px == 155) { if (MODE == 2 && i1 + n1 < S_CAP) s1[i1 + n1] = (uint8_t)(px == 155); n1++; i++; continue; }
 			if (px == 157 || px == 159) { if (MODE == 2 && i2 + n2 < S_CAP) s2[i2 + n2] = (uint8_t)(px == 159); n2++; i++; continue; }
-			EMIT(sh->rank_sym[px]);
+			EMIT(sh->code_sym[px]);
 			i += (px > 131 && px < 136) ? 5 : 1;
 			continue;
 		}
-		int a = i, b = i;                            /* maximal zero run [a, b] around i: inside the slice by looking, outside from the tables */
+		int a = i, b;                                /* maximal zero run [a, b] around i: inside the slice from the mask, outside from the tables */
 		if (i == lo && i > 0 && d[i - 1] == 128) a = prevnz[slice] + 1;
-		const int send = (slice + 1) * PK_SLICE < N ? (slice + 1) * PK_SLICE : N;
-		while (b < send - 1 && d[b + 1] == 128) b++;
-		if (b == send - 1 && send < N) b = nextnz[slice + 1] - 1;
+		const uint64_t rest = nz >> (i - lo);
+		if (rest) b = i + __builtin_ctzll(rest) - 1;
+		else b = send < N ? nextnz[slice + 1] - 1 : send - 1;
 		const int L = b - a + 1;
 		if (L == 1) {
-			if (MODE == 0) atomicAdd(&sh->hist[128], 1); else EMIT(sh->rank_sym[128]);
+			if (MODE == 0) atomicAdd(&sh->hist[128], 1); else EMIT(sh->code_sym[128]);
 		} else {
-			const int m = L > 255 ? (L - 255 + 253) / 254 : 0;       /* pieces of exactly 254 */
-			for (int k = 0; k <= m; k++) {
-				const int t = a + 254 * k;
-				if (t < i || t >= hi) continue;
+			const int m = L > 255 ? (L - 255 + 253) / 254 : 0;       /* pieces of exactly 254, then the rest; mine are those that start in [i, hi) */
+			int k1 = (hi - 1 - a) / 254;
+			if (k1 > m) k1 = m;
+			for (int k = (i - a + 253) / 254; k <= k1; k++) {
 				const int len = k < m ? 254 : L - 254 * m;
 				if (MODE == 0) atomicAdd(&sh->runs[len], 1);
-				else if (len < select) { for (int z = 0; z < len; z++) EMIT(sh->rank_sym[128]); }
-				else EMIT(sh->rank_run[len]);
+				else if (len < select) { for (int z = 0; z < len; z++) EMIT(sh->code_sym[128]); }
+				else EMIT(sh->code_run[len]);
 			}
 		}
 		i = b + 1;
@@ -1821,6 +1831,14 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	}
 	BARRIER();
 	if (sh->rc) return;
+	for (int v = 0; v < 2; v++) {                                /* rank -> code word (the 64 ranks from 110 use the short escape when the zone is on, :300-330) */
+		int pos = v ? sh->rank_run[tid] : sh->rank_sym[tid];
+		uint32_t e;
+		if (pos >= 110 && pos < 174 && sh->zone) e = (15u << 24) | (uint32_t)((1 << 6) | (pos - 110));
+		else { if (pos >= 174 && sh->zone) pos -= 64; e = k_vlc[pos < 290 ? pos : 0]; }
+		if (v) sh->code_run[tid] = e; else sh->code_sym[tid] = e;
+	}
+	BARRIER();
 	if (!tid) PROF(c, 24);
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
