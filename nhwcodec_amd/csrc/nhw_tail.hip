@@ -3,7 +3,6 @@
  * per image (see nhw_tail_par.h / nhw_tail_dev.h), plus the small block-copy kernel used between them.
  */
 #include "nhw_tail_par.h"
-#include "nhw_tail_wave.h"
 
 using namespace nhw;
 

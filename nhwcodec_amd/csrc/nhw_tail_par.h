@@ -12,6 +12,7 @@
 #define NHW_TAIL_PAR_H
 
 #include "nhw_tail_dev.h"
+#include "nhw_tail_wave.h"
 
 namespace nhw {
 
@@ -1155,6 +1156,22 @@ DEV unsigned block_exscan(unsigned v, int tid, unsigned *shm /* [NT / 64 + 1] */
 	return base + x - v;
 }
 
+/* exclusive prefix maximum (0 for the first thread) */
+DEV unsigned block_exscan_max(unsigned v, int tid, unsigned *shm /* [NT / 64 + 1] */)
+{
+	const int lane = tid & 63, wv = tid >> 6;
+	unsigned x = v;
+	for (int d = 1; d < 64; d <<= 1) { const unsigned y = __shfl_up(x, d); if (lane >= d && y > x) x = y; }
+	BARRIER();
+	if (lane == 63) shm[wv] = x;
+	BARRIER();
+	unsigned base = 0;
+	for (int k = 0; k < wv; k++) base = shm[k] > base ? shm[k] : base;
+	const unsigned prev = __shfl_up(x, 1);
+	const unsigned mine = lane ? prev : 0;
+	return mine > base ? mine : base;
+}
+
 /* one token of Y_highres_compression (compress_pixel.c:510-790) as if the walk stood at sample i: returns the
  * sample the walk visits next; OUT: the token's bytes after the marker strip of :828-866 (a single stays, a
  * (64, x, y) triple keeps x y, a (128, a, b) verbatim record keeps b), and whether it is a verbatim record */
@@ -1526,33 +1543,58 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 		 * detail cells it may mark, so rows are independent as long as that never happens: a dry run (no writes)
 		 * checks it, then the rows run in parallel; otherwise thread 0 replays the band serially. */
 		const int res_uv = q > 17 ? 4 : 5;
-		for (int dry = 1; dry >= 0; dry--) {
-			if (dry && tid == 0) sh_misc[0] = 0;
+		const int lane = tid & 63, wv = tid >> 6;
+		/* One wavefront per row, lane l owns columns l and l + 64 of the 128-wide band; the pair marks are a walk that
+		 * skips the partner, resolved on the row's "pair here and a free detail cell" mask (alt_runs).  Cell (r, 127)
+		 * reads column 128 of its row as its right neighbour: that is the HL detail cell of (r, 0), which (r, 0)
+		 * may just have marked -- then neither a pair nor the d == -5 rule can hold at (r, 127). */
+		for (int pass = 0; pass < 2; pass++) {                     /* 0: does a pair mark fall on the last column of a row? 1: mark */
+			if (pass == 0 && tid == 0) sh_misc[0] = 0;
 			BARRIER();
-			if (tid < H / 2 && (dry || !sh_misc[0])) {
-				const int r = tid;
-				for (int j = 0; j < H / 2; j++) {
-					const int at = r * H + j, k = r * (H / 2) + j, d = p[at] - o[k];
-					int16_t code = 0; bool pair = false;
-					if (d > 3 && d < 7) { const int d1 = p[at + 1] - o[k + 1]; if (d1 > 2 && d1 < 7) { code = 12400; pair = true; } }
-					else if (d < -3 && d > -7) { const int d1 = p[at + 1] - o[k + 1]; if (d1 < -2 && d1 > -8) { code = 12600; pair = true; } }
-					if (pair) {
-						const bool free_cell = iabs(p[at + H / 2]) < 8 || iabs(p[at + Q / 2]) < 8 || iabs(p[at + Q / 2 + H / 2]) < 8;
-						if (free_cell) {
-							if (dry) { if (j == H / 2 - 1) sh_misc[0] = 1; }
-							else mark_free_detail(p, at, code);
-							j++; continue;
-						}
-					}
-					if (!dry && iabs(d) > res_uv) {
-						if (d > 0) mark_free_detail(p, at, 12900);
-						else if (d == -5) { if ((p[at + 1] - o[k + 1]) < 0) mark_free_detail(p, at, 13000); }
-						else mark_free_detail(p, at, 13000);
-					}
+			if (pass == 1 && sh_misc[0]) break;
+			for (int r = wv; r < H / 2; r += 4) {
+				int pl[2], hl[2], lh[2], hh[2], ov[2], d[2], d1[2];
+				for (int k = 0; k < 2; k++) {
+					const int at = r * H + lane + 64 * k;
+					pl[k] = p[at]; hl[k] = p[at + H / 2]; lh[k] = p[at + Q / 2]; hh[k] = p[at + Q / 2 + H / 2];
+					ov[k] = o[r * (H / 2) + lane + 64 * k];
+				}
+				const int o_next = o[(r + 1) * (H / 2)], hl_first = __shfl(hl[0], 0);
+				for (int k = 0; k < 2; k++) {
+					int pn = right_of(pl, k, 2, 1, lane), on = right_of(ov, k, 2, 1, lane);
+					if (k == 1 && lane == 63) { pn = hl_first; on = o_next; }
+					d[k] = pl[k] - ov[k]; d1[k] = pn - on;
+				}
+				uint64_t pp[2], pn_[2], fr[2], sg[2], fhl[2], flh[2], m5[2];
+				for (int k = 0; k < 2; k++) {
+					pp[k] = __ballot(d[k] > 3 && d[k] < 7 && d1[k] > 2 && d1[k] < 7);
+					pn_[k] = __ballot(d[k] < -3 && d[k] > -7 && d1[k] < -2 && d1[k] > -8);
+					fhl[k] = __ballot(iabs(hl[k]) < 8); flh[k] = __ballot(iabs(lh[k]) < 8);
+					fr[k] = fhl[k] | flh[k] | __ballot(iabs(hh[k]) < 8);
+					sg[k] = __ballot(iabs(d[k]) > res_uv && (d[k] > 0 || d[k] != -5 || d1[k] < 0));
+					m5[k] = __ballot(d[k] == -5);
+				}
+				uint64_t f[2] = { (pp[0] | pn_[0]) & fr[0], (pp[1] | pn_[1]) & fr[1] };
+				if ((fhl[0] & 1) && ((f[0] | sg[0]) & 1)) {              /* (r, 0) marks its HL cell */
+					f[1] &= ~(1ull << 63);
+					if (m5[1] >> 63) sg[1] &= ~(1ull << 63);
+				}
+				const M4 fired = alt_runs(M4{ { f[0], f[1], 0, 0 } });
+				if (pass == 0) { if (lane == 0 && (fired.w[1] >> 63)) sh_misc[0] = 1; continue; }
+				const M4 vis = ~up1(fired);
+				for (int k = 0; k < 2; k++) {
+					const bool pair = (fired.w[k] >> lane) & 1;
+					const bool single = !pair && ((vis.w[k] >> lane) & 1) && ((sg[k] >> lane) & 1);
+					if (!pair && !single) continue;
+					const int16_t code = pair ? (((pp[k] >> lane) & 1) ? 12400 : 12600) : (d[k] > 0 ? 12900 : 13000);
+					const int at = r * H + lane + 64 * k;
+					if (iabs(hl[k]) < 8) p[at + H / 2] = code;
+					else if (iabs(lh[k]) < 8) p[at + Q / 2] = code;
+					else if (iabs(hh[k]) < 8) p[at + Q / 2 + H / 2] = code;
 				}
 			}
-			BARRIER();
 		}
+		BARRIER();
 		if (tid == 0 && sh_misc[0]) {                              /* rare: literal serial walk */
 			int k = 0;
 			for (int r = 0; r < H / 2; r++)
@@ -1578,26 +1620,36 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 	copy_block_par(c->cl2save, H / 2, p, H, H / 2, H / 2, tid);    /* :2431-2439 */
 	for (int idx = tid; idx < (H / 4) * (H / 4); idx += NT) lds[idx] = c->cl2save[(idx >> 6) * (H / 2) + (idx & 63)];   /* the LL2 band for the emission below */
 	BARRIER();
-	if (tid == 0) {
-		int e = c->m->exw_len;
-		int a = comp ? (Q >> 2) + (Q >> 4) : (Q >> 2);
-		c->exw[e++] = 0; c->exw[e++] = 0;                          /* :2489 (U), :2770 (V) */
-		for (int r = 0; r < H / 4; r++)                            /* :2491-2525 LL2 emission */
-			for (int j = 0; j < H / 4; j++) {
-				int s = lds[r * (H / 4) + j];
-				if ((s > 255 || s < 0) && (j > 0 || r > 0)) {
-					int mag;
-					c->exw[e++] = (uint8_t)r;
-					if (s > 255) { c->exw[e++] = (uint8_t)(j + 128); mag = s - 255; }
-					else { c->exw[e++] = (uint8_t)j; mag = -s; }
-					c->exw[e++] = (uint8_t)(mag > 255 ? 255 : mag);
-					c->ll_bytes[a] = c->ll_bytes[a - 1]; a++;
-				} else {
-					if (s > 255) s = 255; else if (s < 0) s = 0;
-					c->ll_bytes[a++] = (uint8_t)(s & 254);
-				}
-			}
-		c->m->exw_len = e;
+	{                                                              /* :2489-2525 LL2 emission, 16 consecutive samples per thread */
+		/* a sample outside 0..255 goes to the exception list (row, column | sign, magnitude) and repeats the byte
+		 * before it in the stream, i.e. the byte of the nearest earlier sample that was in range (sample 0 always is) */
+		unsigned *shm = reinterpret_cast<unsigned *>(lds + 4096);
+		const int e0 = c->m->exw_len, base = comp ? (Q >> 2) + (Q >> 4) : (Q >> 2);
+		int nexc = 0, lastgood = -1;
+		for (int u = 0; u < 16; u++) {
+			const int idx = tid * 16 + u, s = lds[idx];
+			if ((s > 255 || s < 0) && idx > 0) nexc++; else lastgood = idx;
+		}
+		unsigned total;
+		const unsigned eoff = block_exscan((unsigned)nexc, tid, shm, &total);
+		int lg = (int)block_exscan_max((unsigned)(lastgood + 1), tid, shm) - 1;
+		uint32_t w[4] = { 0, 0, 0, 0 };
+		uint8_t *ex = c->exw + e0 + 2 + 3 * eoff;
+		for (int u = 0; u < 16; u++) {
+			const int idx = tid * 16 + u, s = lds[idx];
+			if ((s > 255 || s < 0) && idx > 0) {
+				const int mag = s > 255 ? s - 255 : -s;
+				*ex++ = (uint8_t)(idx >> 6);
+				*ex++ = (uint8_t)((idx & 63) + (s > 255 ? 128 : 0));
+				*ex++ = (uint8_t)(mag > 255 ? 255 : mag);
+			} else lg = idx;
+			int v = lds[lg];
+			v = v > 255 ? 255 : (v < 0 ? 0 : v);
+			w[u >> 2] |= (uint32_t)(v & 254) << (8 * (u & 3));
+		}
+		*reinterpret_cast<uint4 *>(c->ll_bytes + base + tid * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+		BARRIER();
+		if (tid == 0) { c->exw[e0] = 0; c->exw[e0 + 1] = 0; c->m->exw_len = e0 + 2 + 3 * (int)total; }   /* :2489 (U), :2770 (V) */
 	}
 	for (int idx = tid; idx < (H / 4) * (H / 4); idx += NT) p[(idx >> 6) * H + (idx & 63)] = 0;   /* the emission clears the band */
 	BARRIER();
