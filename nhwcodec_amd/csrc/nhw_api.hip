@@ -125,7 +125,12 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 #define STAGE_DONE() do { if (e->stop_after && ++stage == e->stop_after) { HIPCHK(hipGetLastError()); return NHW_OK; } } while (0)
 	HIPCHK(hipEventRecord(e->ev[0], s));
 	/* a1: colour + 4:2:0 */
-	nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
+	/* The fused front reads luma rows that belong to other workgroups' output rows of the same plane (band b writes LL rows
+	 * 16b.. into jpeg, band b/2 reads them as input), so its input lives in a plane of its own: the otherwise unused
+	 * contrast-map plane of the unfused path. */
+	int16_t *yin = e->legacy_front ? jpeg : plane16(ws, B_KMAP);
+	const size_t yin_stride = e->legacy_front ? ws.stride[B_JPEG] : ws.stride[B_KMAP];
+	nhw_launch_color((const uint8_t *)d_bgr, n, q, yin, yin_stride, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
 	STAGE_DONE();
 	/* a2 + Y2 + Y3: pre-filter (q<=21, nhw_encoder.c:116-119), level-1 analysis (:125), LL1 copy (:127-135), fused */
 	if (e->legacy_front) {
@@ -139,7 +144,7 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 		nhw_launch_copy_block(jpeg, ps, W, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, H, H, H, n, s);
 		STAGE_DONE();
 	} else {
-		nhw_launch_front_fused(jpeg, ws.stride[B_JPEG], q < 22, (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
+		nhw_launch_front_fused(yin, yin_stride, q < 22, (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
 		                       (uint64_t *)plane8(ws, B_SEGMAP), ws.stride[B_SEGMAP], plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2,
 		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s);
 		if (q < 22) STAGE_DONE();
@@ -320,6 +325,28 @@ void nhw_debug_band_stamps(unsigned long long *out);
 extern "C" int nhw_debug_stamps(unsigned long long *out) { (void)hipDeviceSynchronize(); nhw_debug_band_stamps(out); return NHW_OK; }
 extern "C" int nhw_debug_legacy_front(nhw_enc *e, int on) { if (!e) return NHW_E_ARG; e->legacy_front = on; return NHW_OK; }
 extern "C" int nhw_debug_stop_after(nhw_enc *e, int stage) { if (!e) return NHW_E_ARG; e->stop_after = stage; return NHW_OK; }
+/* developer hook: order-independent 64-bit digest of the first `bytes` bytes of workspace buffer `buf`, one per image, into device memory */
+__global__ __launch_bounds__(256) void k_debug_hash(const uint8_t *base, size_t stride, size_t words, unsigned long long *out)
+{
+	const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (size_t)blockIdx.x * stride);
+	unsigned long long h = 0;
+	for (size_t i = threadIdx.x; i < words; i += 256) {
+		unsigned long long x = ((unsigned long long)p[i] + 0x9E3779B97F4A7C15ull) * (2 * i + 1);
+		x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+		h += x;
+	}
+	if (threadIdx.x == 0) out[blockIdx.x] = 0;
+	__syncthreads();
+	atomicAdd(&out[blockIdx.x], h);
+}
+extern "C" int nhw_debug_hash(nhw_enc *e, int buf, size_t bytes, int n, void *d_out, void *stream)
+{
+	if (!e || buf < 0 || buf >= B_COUNT || n < 1 || n > e->max_batch || bytes > e->ws.stride[buf]) return NHW_E_ARG;
+	HIPCHK(hipSetDevice(e->device));
+	k_debug_hash<<<n, 256, 0, stream ? (hipStream_t)stream : e->own_stream>>>(e->ws.base + e->ws.off[buf], e->ws.stride[buf], bytes / 4, (unsigned long long *)d_out);
+	HIPCHK(hipGetLastError());
+	return NHW_OK;
+}
 extern "C" int nhw_debug_read(nhw_enc *e, int buf, int img, void *dst, size_t bytes)
 {
 	if (!e || buf < 0 || buf >= B_COUNT || img < 0 || img >= e->max_batch || bytes > e->ws.stride[buf]) return NHW_E_ARG;

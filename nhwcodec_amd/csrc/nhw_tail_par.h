@@ -444,20 +444,19 @@ DEV void tag_small_runs_par(Ctx *c, int tid, int16_t *lds)
 /* one column of Y22 (:1084-1325).  sp/so: where the reads of column j+1 (and of the recon sample (j,255) that
  * serves as lh[-1] at r = 0) are taken from: a snapshot for columns 0..254, the live planes for column 255,
  * which the reference visits last. */
-DEV void classify_column(Ctx *c, int j, int res_setting, const int16_t *sp, int sp_row, const int16_t *so, int so_rows)
+/* One step of the Y22 column walk (nhw_encoder.c:1077-1325) at row r of column j.  pr / orow point at the column's
+ * recon sample / LL1 cell of row r (row strides ps / os: the planes themselves, an LDS tile, or a packed copy of
+ * the column), lh at the LH1 coefficient the step may nudge, lhm1 is the one before it (as this walk left it).
+ * sp / so: where the right-hand neighbour column is read (the values from before the pass). */
+DEV void classify_step(int q, int res_setting, int r, int j, int16_t *pr, int ps, int16_t *orow, int os, int16_t *lh, int lhm1,
+                       const int16_t *sp, int sp_row, const int16_t *so, int so_rows)
 {
-	int16_t *p = c->proc, *o = c->ll1;
-	const int q = c->q;
-	for (int r = 0; r < H - 1; r++) {
-		const int s = r * W + j, k = r * H + j;
-		int16_t *cell = o + k;
-		int16_t *lh = p + j * W + H + r;
-		const int lhm1 = r ? lh[-1] : sp[j * sp_row + H - 1];
-		const int res = p[s] - o[k], a = p[s + W] - o[k + H];
-		const int d2 = p[s + 2 * W] - o[k + 2 * H];
+	int16_t *cell = orow;
+	const int res = pr[0] - orow[0], a = pr[ps] - orow[os];
+	const int d2 = pr[2 * ps] - orow[2 * os];
 #define NB(dr) (sp[(r + (dr)) * sp_row + j + 1] - ((r + (dr)) < so_rows ? so[(r + (dr)) * H + j + 1] : 0))
-#define MARK(code, step) do { *cell = (code); p[s + W] += (step); p[s + 2 * W] += (step); } while (0)
-#define SNAP(code) do { *cell = (code); p[s + W] = o[k + H]; } while (0)
+#define MARK(code, step) do { *cell = (code); pr[ps] += (step); pr[2 * ps] += (step); } while (0)
+#define SNAP(code) do { *cell = (code); pr[ps] = orow[os]; } while (0)
 #define NUDGE_UP() do { if (lh[0] == 7) { if (lhm1 >= 0 && lhm1 < 8) lh[0] += 2; } else if (lh[0] == 8) { if (lhm1 >= -2 && lhm1 < 8) lh[0] += 2; } } while (0)
 #define NUDGE_M2() do { if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; } else if (lh[0] == 7 || (lh[0] & 0xFFFE) == 8) { if (lhm1 >= -2) lh[0] += 3; } } while (0)
 #define NUDGE_M3() do { if (q >= 21) *cell = 14500; else if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; } \
@@ -472,19 +471,19 @@ DEV void classify_column(Ctx *c, int j, int res_setting, const int16_t *sp, int 
 			else if (q >= 19) SNAP(12100);
 		}
 		else if (a == -4 && (res == 2 || res == 3) && (d2 == 2 || d2 == 3)) {
-			if (res == 2 && d2 == 2) p[s + W]++; else MARK(12400, -2);
+			if (res == 2 && d2 == 2) pr[ps]++; else MARK(12400, -2);
 		}
 		else if (res == 1 && a == 3 && d2 == 2) {
-			if (r > 0 && (p[s - W] - o[k - H]) >= 0) MARK(12400, -2);
+			if (r > 0 && (pr[-ps] - orow[-os]) >= 0) MARK(12400, -2);
 		}
 		else if ((res == 3 || res == 4 || res == 5 || res > 6) && (a == 3 || (a & 0xFFFE) == 4)) {
 			if (res > 6) SNAP(12500);
 			else if (q >= 19) SNAP(12100);
 			else if (q == 18) {
-				if (res < 5 && a == 5) o[k + H] = 14100;
+				if (res < 5 && a == 5) orow[os] = 14100;
 				else if (res >= 5) *cell = 14100;
-				else if (res == 3 && a >= 4) o[k + H] = 14100;
-				p[s + W] = o[k + H];
+				else if (res == 3 && a >= 4) orow[os] = 14100;
+				pr[ps] = orow[os];
 			}
 		}
 		else if ((res == 2 || res == 3) && (a == 2 || a == 3)) {
@@ -494,16 +493,16 @@ DEV void classify_column(Ctx *c, int j, int res_setting, const int16_t *sp, int 
 			}
 		}
 		else if (a == 4 && (res == -2 || res == -3) && (d2 == -2 || d2 == -3)) {
-			if (res == -2 && d2 == -2) p[s + W]--; else MARK(12300, 2);
+			if (res == -2 && d2 == -2) pr[ps]--; else MARK(12300, 2);
 		}
 		else if ((res == -3 || res == -4 || res == -5 || res < -7) && (a == -3 || a == -4 || a == -5)) {
 			if (res < -7) SNAP(12600);
 			else if (q >= 19) SNAP(12200);
 			else if (q == 18) {
-				if (res > -5 && a == -5) o[k + H] = 14000;
+				if (res > -5 && a == -5) orow[os] = 14000;
 				else if (res <= -5) *cell = 14000;
-				else if (res == -3 && a <= -4) o[k + H] = 14000;
-				p[s + W] = o[k + H];
+				else if (res == -3 && a <= -4) orow[os] = 14000;
+				pr[ps] = orow[os];
 			}
 		}
 		else if (a == -2 || a == -3) {
@@ -518,7 +517,7 @@ DEV void classify_column(Ctx *c, int j, int res_setting, const int16_t *sp, int 
 				else NUDGE_M3();
 			}
 			else if (res == -1 && a == -3 && d2 == -2) {
-				if (r > 0 && (p[s - W] - o[k - H]) <= 0) MARK(12300, 2);
+				if (r > 0 && (pr[-ps] - orow[-os]) <= 0) MARK(12300, 2);
 			}
 			else if (res == -1) { if (d2 == -3) MARK(12300, 2); else NUDGE_UP(); }
 			else if (res == -4) { if (d2 < -1 && d2 > -4) MARK(12300, 2); else MARK_LARGE(); }
@@ -534,70 +533,131 @@ DEV void classify_column(Ctx *c, int j, int res_setting, const int16_t *sp, int 
 #undef NUDGE_M2
 #undef NUDGE_M3
 #undef MARK_LARGE
-	}
 }
 
 /* Y22.  The reference walks column after column; column j only reads column j+1 (not yet visited, i.e. its
- * original values) and the recon sample (j,255) of the last column.  Columns 0..254 therefore run in parallel
- * against a snapshot of the recon plane (rows 0..256) and of ll1; column 255 runs afterwards on the live
- * planes (its "column 256" is the LH1 column written by the other columns, its ll1 neighbour is column 0). */
-DEV void classify_residuals_par(Ctx *c, int res_setting, int tid)
+ * original values) and the recon sample (j,255) of the last column.  Columns 0..254 therefore run in parallel,
+ * one thread each, against a snapshot of the recon plane (rows 0..256) and of ll1 for the neighbour reads.
+ * A column's walk is a chain (a step rewrites the two samples below it and reads what the step before left),
+ * so it runs on LDS: per chunk of CR rows every thread copies its own column's samples and LL1 cells into a
+ * tile (coalesced, no barrier needed for those), the LH1 coefficients -- row j of the plane for column j --
+ * come through a transposing tile.  Column 255 runs afterwards on a packed LDS copy of its column: its "column
+ * 256" is the LH1 column written by the other columns, its ll1 neighbour is column 0, both read live. */
+#define CR 16
+#define CR_LDS_BYTES (((CR + 3) * 2 * H + H * (CR + 2)) * 2)
+DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 {
+	int16_t *p = c->proc, *o = c->ll1;
 	int16_t *snap_p = c->hs, *snap_o = c->band;
+	const int q = c->q;
 	for (int idx = tid; idx < (H + 1) * (H / 4); idx += NT) {       /* rows 0..256 x cols 0..255 of proc */
 		const int r = idx / (H / 4), k = idx % (H / 4);
-		reinterpret_cast<uint2 *>(snap_p + r * H)[k] = reinterpret_cast<const uint2 *>(c->proc + r * W)[k];
+		reinterpret_cast<uint2 *>(snap_p + r * H)[k] = reinterpret_cast<const uint2 *>(p + r * W)[k];
 	}
-	for (int idx = tid; idx < Q / 4; idx += NT) reinterpret_cast<uint2 *>(snap_o)[idx] = reinterpret_cast<const uint2 *>(c->ll1)[idx];
+	for (int idx = tid; idx < Q / 4; idx += NT) reinterpret_cast<uint2 *>(snap_o)[idx] = reinterpret_cast<const uint2 *>(o)[idx];
+	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *lt = lds + 2 * (CR + 3) * H;   /* pt/ot: rows r0-1 .. r0+CR+1; lt: [column][CR + 2] */
+	const int j = tid;
+	int lhm1 = p[j * W + H - 1];                                    /* (j, 255): nothing has touched it yet */
 	BARRIER();
-	if (tid < H - 1) classify_column(c, tid, res_setting, snap_p, H, snap_o, H);
-	BARRIER();
-	if (tid == 0) classify_column(c, H - 1, res_setting, c->proc, W, c->ll1, 1 << 30);
+	for (int r0 = 0; r0 < H - 1; r0 += CR) {
+		for (int i = 0; i < CR + 3; i++) {
+			const int row = r0 - 1 + i;
+			pt[i * H + j] = row >= 0 ? p[row * W + j] : 0;
+			ot[i * H + j] = row >= 0 ? o[row * H + j] : 0;            /* rows 256, 257 of ll1 lie in its zero guard */
+		}
+		for (int idx = tid; idx < H * CR; idx += NT) lt[(idx / CR) * (CR + 2) + idx % CR] = p[(idx / CR) * W + H + r0 + idx % CR];
+		BARRIER();
+		if (j < H - 1)
+			for (int i = 0; i < CR && r0 + i < H - 1; i++) {
+				int16_t *lh = lt + j * (CR + 2) + i;
+				classify_step(q, res_setting, r0 + i, j, pt + (i + 1) * H + j, H, ot + (i + 1) * H + j, H, lh, lhm1, snap_p, H, snap_o, H);
+				lhm1 = lh[0];
+			}
+		BARRIER();
+		if (j < H - 1)
+			for (int i = 1; i < CR + 3; i++) {
+				const int row = r0 - 1 + i;
+				p[row * W + j] = pt[i * H + j];
+				if (row < H) o[row * H + j] = ot[i * H + j];
+			}
+		for (int idx = tid; idx < H * CR; idx += NT) p[(idx / CR) * W + H + r0 + idx % CR] = lt[(idx / CR) * (CR + 2) + idx % CR];
+		BARRIER();
+	}
+	{                                                              /* column 255 */
+		int16_t *pc = lds, *oc = lds + H + 8, *lc = lds + 2 * (H + 8);
+		for (int t = tid; t < H + 2; t += NT) { pc[t] = p[t * W + H - 1]; oc[t] = t < H ? o[t * H + H - 1] : 0; }
+		lc[tid] = p[(H - 1) * W + H + tid];
+		BARRIER();
+		if (tid == 0) {
+			int prev = p[(H - 1) * W + H - 1];
+			for (int r = 0; r < H - 1; r++) {
+				classify_step(q, res_setting, r, H - 1, pc + r, 1, oc + r, 1, lc + r, prev, p, W, o, 1 << 30);
+				if (r == 0) p[(H - 1) * W + H] = lc[0];                /* (255, 256) is also this column's "column 256" neighbour of row 255 */
+				prev = lc[r];
+			}
+		}
+		BARRIER();
+		for (int t = tid; t < H + 2; t += NT) { p[t * W + H - 1] = pc[t]; if (t < H) o[t * H + H - 1] = oc[t]; }
+		p[(H - 1) * W + H + tid] = lc[tid];
+	}
 	BARRIER();
 }
 
 /* Y23 (:1329-1420): cell (r,j) touches its own ll1 cell and the LH1 coefficient (j, 256+r), and reads
- * (j, 256+r-1), which the same column wrote one step earlier: one thread per column, serial in r. */
-DEV void code_residuals_par(Ctx *c, int res_setting, int tid)
+ * (j, 256+r-1), which the same column wrote one step earlier: one thread per column, serial in r, on the same
+ * LDS tiles as Y22. */
+DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 {
 	int16_t *p = c->proc, *o = c->ll1;
 	const int q = c->q, j = tid;
-	for (int r = 0; r < H; r++) {
-		int16_t *cell = o + r * H + j;
-		int16_t *v = p + j * W + H + r;
-		if (*cell < 12000) {
-			const int res = p[r * W + j] - *cell;
-			*cell = 0;
-			if (!res || res == 1) { if (v[0] == -7 || v[0] == -8) { if (v[-1] < 2 && v[-1] > -8) v[0] = -9; } }
-			else if (res == 2) {
-				if (v[0] > 15 && !(v[0] & 7)) v[0]--;
-				else if (v[0] == -7 || v[0] == -8) { if (v[-1] <= 1) v[0] = -9; }
-				else if (v[0] == -6) { if (v[-1] <= -1 && v[-1] > -8) v[0] = -9; }
-			}
-			else if (res == 3) {
-				if (q >= 21) *cell = 144;
-				else if (v[0] > 15 && !(v[0] & 7)) v[0]--;
-				else if (v[0] <= 0 && (((-v[0]) + 2) & 0xFFFC) == 8) { if (v[-1] <= 2) v[0] = -10; }
-			}
-			else if (res > res_setting) {
-				*cell = 141;
-				if (res == 4) { if (v[0] == 7 || (v[0] & 0xFFFE) == 8) { if (v[-1] >= 0 && v[-1] < 8) v[0] += 2; } }
-				else if (res > 6) {
-					if (res > 7 && q >= 21) *cell = 148;
+	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *lt = lds + 2 * (CR + 3) * H;
+	int vm1 = p[j * W + H - 1];
+	for (int r0 = 0; r0 < H; r0 += CR) {
+		for (int i = 0; i < CR; i++) { pt[i * H + j] = p[(r0 + i) * W + j]; ot[i * H + j] = o[(r0 + i) * H + j]; }
+		for (int idx = tid; idx < H * CR; idx += NT) lt[(idx / CR) * (CR + 2) + idx % CR] = p[(idx / CR) * W + H + r0 + idx % CR];
+		BARRIER();
+		for (int i = 0; i < CR; i++) {
+			int16_t *cell = ot + i * H + j;
+			int16_t *v = lt + j * (CR + 2) + i;
+			if (*cell < 12000) {
+				const int res = pt[i * H + j] - *cell;
+				*cell = 0;
+				if (!res || res == 1) { if (v[0] == -7 || v[0] == -8) { if (vm1 < 2 && vm1 > -8) v[0] = -9; } }
+				else if (res == 2) {
+					if (v[0] > 15 && !(v[0] & 7)) v[0]--;
+					else if (v[0] == -7 || v[0] == -8) { if (vm1 <= 1) v[0] = -9; }
+					else if (v[0] == -6) { if (vm1 <= -1 && vm1 > -8) v[0] = -9; }
+				}
+				else if (res == 3) {
+					if (q >= 21) *cell = 144;
 					else if (v[0] > 15 && !(v[0] & 7)) v[0]--;
-					else if (v[0] == -6 || v[0] == -7 || v[0] == -8) { if (v[-1] < 0 && v[-1] > -8) v[0] = -9; }
+					else if (v[0] <= 0 && (((-v[0]) + 2) & 0xFFFC) == 8) { if (vm1 <= 2) v[0] = -10; }
+				}
+				else if (res > res_setting) {
+					*cell = 141;
+					if (res == 4) { if (v[0] == 7 || (v[0] & 0xFFFE) == 8) { if (vm1 >= 0 && vm1 < 8) v[0] += 2; } }
+					else if (res > 6) {
+						if (res > 7 && q >= 21) *cell = 148;
+						else if (v[0] > 15 && !(v[0] & 7)) v[0]--;
+						else if (v[0] == -6 || v[0] == -7 || v[0] == -8) { if (vm1 < 0 && vm1 > -8) v[0] = -9; }
+					}
+				}
+			} else {
+				switch (*cell) {
+				case 14000: *cell = 140; break; case 14500: *cell = 145; break;
+				case 12200: *cell = 122; break; case 12100: *cell = 121; break;
+				case 12300: *cell = 123; break; case 12400: *cell = 124; break;
+				case 14100: *cell = 141; break; case 12500: *cell = 125; break;
+				case 12600: *cell = 126; break; case 14900: *cell = 149; break;
+				default: break;
 				}
 			}
-		} else {
-			switch (*cell) {
-			case 14000: *cell = 140; break; case 14500: *cell = 145; break;
-			case 12200: *cell = 122; break; case 12100: *cell = 121; break;
-			case 12300: *cell = 123; break; case 12400: *cell = 124; break;
-			case 14100: *cell = 141; break; case 12500: *cell = 125; break;
-			case 12600: *cell = 126; break; case 14900: *cell = 149; break;
-			default: break;
-			}
+			vm1 = v[0];
 		}
+		BARRIER();
+		for (int i = 0; i < CR; i++) o[(r0 + i) * H + j] = ot[i * H + j];
+		for (int idx = tid; idx < H * CR; idx += NT) p[(idx / CR) * W + H + r0 + idx % CR] = lt[(idx / CR) * (CR + 2) + idx % CR];
+		BARRIER();
 	}
 }
 
@@ -1467,9 +1527,9 @@ DEV void luma_p4a_par(Ctx *c, int tid, int16_t *lds)
 	BARRIER();
 	if (!tid) PROF(c, 9);
 	const int res_setting = q >= 20 ? 3 : (q >= 18 ? 4 : 6);
-	classify_residuals_par(c, res_setting, tid);                            /* Y22 */
+	classify_residuals_par(c, res_setting, tid, lds);                       /* Y22 */
 	if (!tid) PROF(c, 10);
-	code_residuals_par(c, res_setting, tid);                                /* Y23 */
+	code_residuals_par(c, res_setting, tid, lds);                           /* Y23 */
 	BARRIER();
 	if (!tid) PROF(c, 11);
 }

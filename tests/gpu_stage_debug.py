@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import nhwcodec_amd  # noqa: E402
 from oracle.oraclepy import Oracle  # noqa: E402
 
-B = dict(JPEG=0, PROC=1, PU=2, PV=3, CJPEG=4, CPROC=5, LL1=6, SCAN=17)
+B = dict(JPEG=0, PROC=1, PU=2, PV=3, CJPEG=4, CPROC=5, LL1=6, YIN=14, SCAN=17)   # YIN: the fused front's luma input plane (B_KMAP)
 
 
 def read(enc, buf, img, nbytes):
@@ -38,7 +38,7 @@ def main(qs, seeds=(0, 1)):
         traces = [orc.encode(imgs[i], q, trace=True) for i in range(len(seeds))]
         shift = 0 if q < 22 else -1
         # (stage, trace-record index among same-named records, name, [(buffer, blob index, bytes)])
-        plan = [(1, 0, "downsample_YUV420", [("JPEG", 0, 8 * 65536), ("PU", 1, 65536), ("PV", 2, 65536)])]
+        plan = [(1, 0, "downsample_YUV420", [("YIN", 0, 8 * 65536), ("PU", 1, 65536), ("PV", 2, 65536)])]
         # (stage 2, the pre-filtered luma plane, never reaches HBM with the fused front kernel)
         L = [(3, 0, "wavelet_analysis_512"), (5, 0, "wavelet_analysis_256"), (6, 0, "offsetY_recons256_p1"), (7, 0, "wavelet_synthesis_256"),
              (9, 1, "wavelet_analysis_256"), (11, 0, "offsetY_recons256_p0"), (12, 1, "wavelet_synthesis_256")]

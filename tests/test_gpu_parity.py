@@ -255,3 +255,34 @@ def test_full_batch_4096_properties(oracle):
             mse = ((px - oracle.synth(1000 + pick[0]).astype(int)) ** 2).mean()
             assert 10 * np.log10(255 ** 2 / mse) > 30
     e.close()
+
+
+@pytest.mark.gpu
+def test_repeated_batches_are_identical():
+    """Race detector: 25 encodes of one resident 4096-image batch must give 25 identical outputs.  (The fused front
+    kernel once read luma rows from the plane other workgroups of the same image write their LL rows into: about one
+    run in thirty differed in a handful of images, depending on how far apart the XCDs' dispatchers had drifted.)"""
+    import torch
+    import nhwcodec_amd
+    n = 4096
+    e = nhwcodec_amd.Encoder(0, max_batch=n)
+    bgr = e.synth_device(n, seed_base=777)
+    out = e.alloc_out(n)
+    idx = torch.arange(nhwcodec_amd.OUT_STRIDE, device="cuda")[None, :]
+    w = (idx % 251 + 1).to(torch.int64)
+
+    def digests():
+        e.encode_device(bgr, 20, out)
+        torch.cuda.synchronize()
+        o, sizes, status = out
+        assert int((status != 0).sum()) == 0
+        per = torch.empty(n, dtype=torch.int64, device="cuda")
+        for a in range(0, n, 512):
+            m = torch.where(idx < sizes[a:a + 512, None].to(torch.int64), o[a:a + 512], torch.zeros_like(o[a:a + 512])).to(torch.int64)
+            per[a:a + 512] = (m * w).sum(1) + sizes[a:a + 512].to(torch.int64) * 1000003
+        return per.clone()
+    ref = digests()
+    for k in range(24):
+        bad = torch.nonzero(digests() != ref).flatten().tolist()
+        assert not bad, f"run {k + 1}: images {bad[:8]} differ from the first run"
+    e.close()
