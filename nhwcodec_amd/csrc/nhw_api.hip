@@ -25,7 +25,7 @@ void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilte
                             int16_t *keep, size_t keep_stride, int n, hipStream_t s);
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s);
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s);
-enum { WV_DQ1, WV_DQ0 };
+enum { WV_DQ1, WV_DQ0, WV_EMIT };
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
 enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC };
 
@@ -166,6 +166,7 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	STAGE_DONE();
 	nhw_launch_copy_block(proc, ps, W, plane16(ws, B_L2SAVE), ws.stride[B_L2SAVE] / 2, H, H, H, n, s);   /* Y13 (:623-631) */
 	STAGE_DONE();
+	nhw_launch_wave(WV_EMIT, ws, s);                                 /* Y14, Y15 */
 	nhw_launch_phase(PH_L3, ws, 0, out, d_sizes, d_status, s);
 	nhw_launch_wave(WV_DQ0, ws, s);
 	STAGE_DONE();

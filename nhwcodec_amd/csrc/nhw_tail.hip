@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 }
 
 /* passes that run one wavefront per image (nhw_tail_wave.h): four images per workgroup, no workgroup barriers */
-enum { WV_DQ1, WV_DQ0 };
+enum { WV_DQ1, WV_DQ0, WV_EMIT };
 template <int PH>
 __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 {
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 	ctx_load(&c, ws, img);
 	if (PH == WV_DQ1) wave_dequant_sim_luma(&c, 1, lane);
 	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane);
+	else if (PH == WV_EMIT) { PROF_BEGIN(); wave_emit_ll2(&c, lane); if (!lane) PROF(&c, 4); }
 }
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s)
 {
@@ -55,6 +56,7 @@ void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s)
 	switch (ph) {
 	case WV_DQ1: k_wave<WV_DQ1><<<g, b, 0, s>>>(ws); break;
 	case WV_DQ0: k_wave<WV_DQ0><<<g, b, 0, s>>>(ws); break;
+	case WV_EMIT: k_wave<WV_EMIT><<<g, b, 0, s>>>(ws); break;
 	}
 }
 

@@ -1492,8 +1492,6 @@ DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc, int16_t *lds)
 	PROF_BEGIN();
 	for (int i = (Q >> 2) + tid; i < (Q >> 2) + (Q >> 3) + 64; i += NT) c->ll_bytes[i] = 0;
 	BARRIER();
-	emit_ll2_par(c, tid, pos, sh_misc);
-	if (!tid) PROF(c, 4);
 	{                                                             /* Y16 */
 		uint8_t *ls = reinterpret_cast<uint8_t *>(lds);
 		for (int i = tid; i < 16640 / 16; i += NT) reinterpret_cast<uint4 *>(ls)[i] = reinterpret_cast<const uint4 *>(c->ll_bytes)[i];

@@ -91,8 +91,9 @@ DEV int ll2_round(int v) { return (v > 0 && v < 256) ? (v & 0xFFFE) : v; }
  * ends (the row above has bumped it, its own walk has bumped it), so the untagging / rounding pass (:2697-2735)
  * is folded into the step: p = value, jp = tagged ? value : rounded value, in both loops.
  * ------------------------------------------------------------------------------------------------------------ */
-DEV void ll2_load_row(const int16_t *p, int r, int lane, int *v, M4 *tag, int q, int part)
+DEV void ll2_load_row(const int16_t *p, int r, int lane, int *v, M4 *tag, int q, int part, M4 *starts = nullptr)
 {
+	if (starts) *starts = m4_zero();
 	if (r >= H / 2) { v[0] = v[1] = v[2] = 0; *tag = m4_zero(); return; }
 	for (int k = 0; k < 3; k++) v[k] = p[r * W + lane + 64 * k];
 	M4 t = m4_zero();
@@ -106,13 +107,15 @@ DEV void ll2_load_row(const int16_t *p, int r, int lane, int *v, M4 *tag, int q,
 		const M4 f = o & dn1(o) & dn2(o) & dn3(o) & d3 & col_range(0, H / 2 - 4);
 		unsigned __int128 m = ((unsigned __int128)f.w[1] << 64) | f.w[0], tg = 0;
 		const unsigned __int128 pat = part ? 5 : 15;
+		unsigned __int128 st = 0;
 		while (m) {
 			const uint64_t lo = (uint64_t)m;
 			const int j = lo ? __builtin_ctzll(lo) : 64 + __builtin_ctzll((uint64_t)(m >> 64));
-			tg |= pat << j;
+			tg |= pat << j; st |= (unsigned __int128)1 << j;
 			m &= ~((unsigned __int128)15 << j);
 		}
 		t.w[0] = (uint64_t)tg; t.w[1] = (uint64_t)(tg >> 64);
+		if (starts) { starts->w[0] = (uint64_t)st; starts->w[1] = (uint64_t)(st >> 64); }
 	}
 	*tag = t;
 }
@@ -167,6 +170,90 @@ DEV void wave_ll2(Ctx *c, int part, int lane)
 		}
 	}
 	__threadfence_block();
+}
+
+/* Y14 + Y15 (nhw_encoder.c:640-741): tag the runs of four odd LL2 samples (their first columns go to the res4 list),
+ * the same bump walk as above, and the emission of the samples as bytes: a sample outside 0..255 goes to the
+ * exception list and repeats the byte before it in the stream.  The band is left zero. */
+DEV void wave_emit_ll2(Ctx *c, int lane)
+{
+	int16_t *p = c->proc;
+	const int q = c->q;
+	int v0[3], v1[3], v2[3], v3[3];
+	M4 t0, t1, t2, t3, s0, s1, s2, s3;
+	ll2_load_row(p, 0, lane, v0, &t0, q, 0, &s0);
+	ll2_load_row(p, 1, lane, v1, &t1, q, 0, &s1);
+	ll2_load_row(p, 2, lane, v2, &t2, q, 0, &s2);
+	ll2_load_row(p, 3, lane, v3, &t3, q, 0, &s3);
+	const M4 ll = col_range(0, H / 2 - 1);
+	int n4 = 0, e = 0, carry = 0;
+	for (int r = 0; r < H / 2; r++) {
+		int vn[3]; M4 tn, sn;
+		ll2_load_row(p, r + 4, lane, vn, &tn, q, 0, &sn);
+		if (q > 17) {
+			int a0[4] = { v0[0], v0[1], v0[2], 0 }, a1[4] = { v1[0], v1[1], v1[2], 0 }, a2[4] = { v2[0], v2[1], 0, 0 }, a3[4] = { v3[0], v3[1], 0, 0 };
+			M4 o, o1, o2, o3, d2;
+			BALLOT4(o, a0, x & 1); BALLOT4(o1, a1, x & 1); BALLOT4(o2, a2, x & 1); BALLOT4(o3, a3, x & 1);
+			const int f0 = right_of(v0, 0, 3, 2, lane), f1 = right_of(v0, 1, 3, 2, lane);
+			d2.w[0] = __ballot(iabs(v0[0] - f0) > 1); d2.w[1] = __ballot(iabs(v0[1] - f1) > 1); d2.w[2] = d2.w[3] = 0;
+			d2 = d2 | dn2(t0);
+			const M4 cond1 = o & dn1(o) & col_range(1, H / 2 - 1);
+			const M4 hbr = cond1 & dn2(o) & col_range(0, H / 2 - 3);
+			const M4 act = ll & ~t0;
+			const M4 bumped = up1(alt_runs(hbr & d2 & act));
+			M4 vf = m4_zero();
+			if (r <= H / 2 - 2) vf = cond1 & ~hbr & o1 & dn1(o1) & ~dn2(o1);
+			if (r >= 1 && r <= H / 2 - 4) vf = vf | (~cond1 & o & o1 & dn1(o1) & o2 & ~o3);
+			vf = vf & act & ~bumped & ~t1;
+			/* the emitted value of a cell is the one the walk finds there: bumps by its left neighbour / the row above are in, its own firing is not */
+			for (int k = 0; k < 2; k++) v1[k] += TB(vf, k);
+			for (int k = 0; k < 2; k++) v0[k] += TB(bumped, k);
+		}
+		uint64_t x[2], g[2];
+		int byte[2];
+		for (int k = 0; k < 2; k++) {
+			const int s = v0[k];
+			x[k] = __ballot(s > 255 || s < 0);
+			byte[k] = s > 255 ? 255 : (s < 0 ? 0 : s);
+		}
+		if (r == 0) x[0] &= ~1ull;
+		g[0] = ~x[0]; g[1] = ~x[1];
+		for (int k = 0; k < 2; k++) {
+			const int col = lane + 64 * k, a = r * (H / 2) + col;
+			const bool exc = (x[k] >> lane) & 1;
+			const uint64_t hi = k ? (g[1] & low_bits(lane)) : 0, lo = k ? g[0] : (g[0] & low_bits(lane));
+			const int src = hi ? 64 + 63 - __builtin_clzll(hi) : (lo ? 63 - __builtin_clzll(lo) : -1);   /* nearest in-range sample before me in this row */
+			const int b0 = __shfl(byte[0], src & 63), b1 = __shfl(byte[1], src & 63);
+			const int prev = src < 0 ? carry : (((src >> 6) ? b1 : b0) & 254);
+			if (exc) {
+				const int s = v0[k], mag = s > 255 ? s - 255 : -s;
+				const int rank = __popcll(x[0] & (k ? ~0ull : low_bits(lane))) + (k ? __popcll(x[1] & low_bits(lane)) : 0);
+				uint8_t *ex = c->exw + e + 3 * rank;
+				ex[0] = (uint8_t)r; ex[1] = (uint8_t)(col + (s > 255 ? 128 : 0)); ex[2] = (uint8_t)(mag > 255 ? 255 : mag);
+				c->ll_bytes[a] = (uint8_t)prev; c->ll_full[a] = (uint8_t)prev;
+			} else { c->ll_full[a] = (uint8_t)byte[k]; c->ll_bytes[a] = (uint8_t)(byte[k] & 254); }
+			p[r * W + col] = 0;
+		}
+		e += 3 * (__popcll(x[0]) + __popcll(x[1]));
+		if (g[1]) carry = __shfl(byte[1], 63 - __builtin_clzll(g[1])) & 254;
+		else if (g[0]) carry = __shfl(byte[0], 63 - __builtin_clzll(g[0])) & 254;
+		if (q > 17) {                                              /* res4: first column + 1 of every tagged run, the row's last entry flagged (a lone flag if the row has none) */
+			const int cnt = __popcll(s0.w[0]) + __popcll(s0.w[1]);
+			if (!cnt) { if (lane == 0) c->res4[n4] = 128; n4++; }
+			else {
+				for (int k = 0; k < 2; k++)
+					if ((s0.w[k] >> lane) & 1) {
+						const int rank = __popcll(s0.w[0] & (k ? ~0ull : low_bits(lane))) + (k ? __popcll(s0.w[1] & low_bits(lane)) : 0);
+						c->res4[n4 + rank] = (uint8_t)(lane + 64 * k + 1 + (rank == cnt - 1 ? 128 : 0));
+					}
+				n4 += cnt;
+			}
+		}
+		for (int k = 0; k < 3; k++) { v0[k] = v1[k]; v1[k] = v2[k]; v2[k] = v3[k]; v3[k] = vn[k]; }
+		t0 = t1; t1 = t2; t2 = t3; t3 = tn;
+		s0 = s1; s1 = s2; s2 = s3; s3 = sn;
+	}
+	if (lane == 0) { c->m->res4_len = q > 17 ? n4 : 0; c->m->exw_len = e; }
 }
 
 /* ------------------------------------------------------------------------------------------------------------
