@@ -1134,6 +1134,95 @@ DEV void emit_ll2_par(Ctx *c, int tid, int *pos, int *sh_misc)
 
 /* Y25 (nhw_encoder.c:1498-1887): the three compaction sweeps over the code plane run one row per thread (count,
  * prefix, write); packing the (short) lists stays on thread 0 */
+DEV unsigned block_exscan(unsigned v, int tid, unsigned *shm, unsigned *total);
+DEV unsigned block_exscan_max(unsigned v, int tid, unsigned *shm);
+
+/* The position lists' packing (nhw_encoder.c:1546-1631, 1751-1763), workgroup-parallel.  Every step of the
+ * reference's walk over the list is a filter or a skip-the-partner walk on values the step does not change:
+ *   prune  -- drop a row marker whose neighbours say the column index fell across it: a pure stencil on the raw list;
+ *   fuse   -- two small steps in a row share a byte and the walk jumps over the second: "fires if visited" is a
+ *             stencil on the halved list, the visited cells follow from the parity inside each run of fire bits;
+ *   bits   -- the low bits of the non-marker entries, 8 per byte: a compaction;
+ *   words  -- the payload symbols, 8 (or 4) per byte.
+ * Each thread owns a contiguous chunk of the list; counts go through workgroup prefix sums. */
+DEV void poslist_finish_par(Ctx *c, PosList *pl, const uint8_t *raw, int n, const uint8_t *payload, int payload_len, int word_mode, int tid, unsigned *shm)
+{
+	uint8_t *P = c->cc, *F = c->half;                            /* pruned list; per-entry flags / compacted low bits */
+	unsigned total;
+	{                                                            /* prune (:1546-1561) */
+		const int L = (n + NT - 1) / NT, i0 = tid * L, i1 = i0 + L < n ? i0 + L : n;
+		unsigned cnt = 0;
+		for (int i = i0; i < i1; i++) {
+			const bool drop = i >= 1 && i < n - 1 && raw[i] == H - 2 && raw[i - 1] != H - 2 && raw[i + 1] != H - 2 && raw[i - 1] > raw[i + 1];
+			cnt += !drop;
+		}
+		unsigned at = block_exscan(cnt, tid, shm, &total);
+		for (int i = i0; i < i1; i++) {
+			const bool drop = i >= 1 && i < n - 1 && raw[i] == H - 2 && raw[i - 1] != H - 2 && raw[i + 1] != H - 2 && raw[i - 1] > raw[i + 1];
+			if (!drop) P[at++] = raw[i];
+		}
+	}
+	const int m = (int)total;
+	BARRIER();
+	const int L = (m + NT - 1) / NT, i0 = tid * L, i1 = i0 + L < m ? i0 + L : m;
+#define PL_FIRE(i) ((i) >= 1 && (i) <= m - 2 && (unsigned)((P[i] >> 1) - (P[(i) - 1] >> 1)) < 8u && (unsigned)((P[(i) + 1] >> 1) - (P[i] >> 1)) < 16u)
+	{                                                            /* fuse (:1569-1592): which entries the walk fuses with their successor */
+		int lastnf = 0;                                          /* index + 1 of my last entry that cannot fire */
+		for (int i = i0; i < i1; i++) if (!PL_FIRE(i)) lastnf = i + 1;
+		int rs = (int)block_exscan_max((unsigned)lastnf, tid, shm);   /* first entry of the run of fire bits reaching into my chunk */
+		for (int i = i0; i < i1; i++) {
+			const bool f = PL_FIRE(i);
+			F[i] = f && !((i - rs) & 1);
+			if (!f) rs = i + 1;
+		}
+	}
+	BARRIER();
+	{
+		unsigned cnt = 0;
+		for (int i = i0; i < i1; i++) cnt += i >= 1 && i <= m - 2 && !F[i - 1];
+		unsigned at = 1 + block_exscan(cnt, tid, shm, &total);
+		for (int i = i0; i < i1; i++) {
+			if (!(i >= 1 && i <= m - 2 && !F[i - 1])) continue;
+			const int h = P[i] >> 1;
+			pl->list[at++] = (uint8_t)(F[i] ? 128 + ((h - (P[i - 1] >> 1)) << 4) + ((P[i + 1] >> 1) - h) : h);
+		}
+		if (tid == 0) { pl->list[0] = P[0] >> 1; pl->len->list_len = 1 + (int)total; }
+	}
+#undef PL_FIRE
+	BARRIER();
+	{                                                            /* plane of the dropped low bits, markers excluded (:1594-1615) */
+		unsigned cnt = 0;
+		for (int i = i0; i < i1; i++) cnt += P[i] != H - 2;
+		unsigned at = block_exscan(cnt, tid, shm, &total);
+		for (int i = i0; i < i1; i++) if (P[i] != H - 2) F[at++] = P[i] & 1;
+		BARRIER();
+		const int nb = (int)total, groups = (nb >> 3) + 1;
+		for (int g = tid; g < groups; g += NT) {
+			int v = 0;
+			for (int b = 0; b < 8; b++) v = (v << 1) | (8 * g + b < nb ? F[8 * g + b] : 0);
+			pl->bits[g] = (uint8_t)v;
+		}
+		if (tid == 0) pl->len->bits_len = groups;
+	}
+	{                                                            /* payload symbols (:1620-1631, 1751-1763); symbols behind payload_len read as 0 */
+		const int groups = (payload_len >> 3) + 1;
+		for (int g = tid; g < groups; g += NT) {
+			int sym[8];
+			for (int b = 0; b < 8; b++) sym[b] = (8 * g + b < payload_len) ? payload[8 * g + b] : 0;
+			if (word_mode == 2) {
+				pl->word[2 * g] = (uint8_t)(((sym[0] & 3) << 6) | ((sym[1] & 3) << 4) | ((sym[2] & 3) << 2) | (sym[3] & 3));
+				pl->word[2 * g + 1] = (uint8_t)(((sym[4] & 3) << 6) | ((sym[5] & 3) << 4) | ((sym[6] & 3) << 2) | (sym[7] & 3));
+			} else {
+				int v = 0;
+				for (int b = 0; b < 8; b++) v = (v << 1) | (sym[b] & 1);
+				pl->word[g] = (uint8_t)v;
+			}
+		}
+		if (tid == 0) pl->len->word_len = word_mode == 2 ? 2 * groups : groups;
+	}
+	BARRIER();
+}
+
 struct PosListF {
 	int pass, write;
 	uint8_t *raw, *pay;
@@ -1183,19 +1272,8 @@ DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 		row_pass_tiled(o, H, H, H, 0, H, 0, H - 2, lds, tid, fw, &end);
 		o[tid * H + H - 2] = 0; o[tid * H + H - 1] = 0; raw[end.n] = H - 2;
 		BARRIER();
-		{                                                         /* packing the list is one serial walk: short lists are walked in LDS */
-			const int nraw = off_raw[NT];
-			uint8_t *l8 = reinterpret_cast<uint8_t *>(lds);
-			const bool small = nraw <= 4000;
-			if (small) for (int i = tid; i < nraw; i += NT) l8[i] = raw[i];
-			BARRIER();
-			if (tid == 0) {
-				Ctx c2 = *c;
-				if (small) { c2.cc = l8 + 4096; c2.half = l8 + 8192; }
-				poslist_finish(&c2, pass == 0 ? &c->res1 : pass == 1 ? &c->res3 : &c->res5, small ? l8 : raw, nraw, pay, off_pay[NT], pass == 1 ? 2 : 1);
-			}
-		}
-		BARRIER();
+		poslist_finish_par(c, pass == 0 ? &c->res1 : pass == 1 ? &c->res3 : &c->res5, raw, off_raw[NT], pay, off_pay[NT], pass == 1 ? 2 : 1, tid,
+		                   reinterpret_cast<unsigned *>(lds));
 	}
 }
 
