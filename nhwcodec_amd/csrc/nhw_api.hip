@@ -25,9 +25,9 @@ void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilte
                             int16_t *keep, size_t keep_stride, int n, hipStream_t s);
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s);
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s);
-enum { WV_DQ1, WV_DQ0, WV_EMIT };
+enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
-enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC };
+enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2 };
 
 static thread_local std::string g_err;
 extern "C" const char *nhw_last_error(void) { return g_err.c_str(); }
@@ -172,7 +172,12 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	STAGE_DONE();
 	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s);
 	STAGE_DONE();
-	for (int ph : { PH_L4A, PH_L4B, PH_L4C, PH_L4D }) nhw_launch_phase(ph, ws, 0, out, d_sizes, d_status, s);
+	nhw_launch_phase(PH_L4A, ws, 0, out, d_sizes, d_status, s);      /* Y19-Y23 */
+	nhw_launch_phase(PH_L4B, ws, 0, out, d_sizes, d_status, s);      /* Y24, Y25 */
+	nhw_launch_phase(PH_L4C, ws, 0, out, d_sizes, d_status, s);      /* Y26, Y27 */
+	nhw_launch_wave(WV_QUANT, ws, s);                                /* Y28 */
+	if (q > 21) nhw_launch_phase(PH_L4C2, ws, 0, out, d_sizes, d_status, s);   /* Y29 */
+	nhw_launch_phase(PH_L4D, ws, 0, out, d_sizes, d_status, s);      /* Y30, Y31 */
 	STAGE_DONE();
 	HIPCHK(hipEventRecord(e->ev[2], s));
 

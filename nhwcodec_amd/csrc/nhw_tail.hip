@@ -6,7 +6,7 @@
 
 using namespace nhw;
 
-enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC };
+enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2 };
 
 template <int PH>
 __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status)
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_L4B) luma_p4b_par(&c, tid, sh_pos, dyn_lds);
 	else if (PH == PH_L4C) luma_p4c_par(&c, tid, sh_pos, dyn_lds);
 	else if (PH == PH_L4D) luma_p4d_par(&c, tid, sh_counts, sh_z, dyn_lds);
+	else if (PH == PH_L4C2) luma_p4c2_par(&c, tid);
 	else if (PH == PH_LLC) { PROF_BEGIN(); ll_code_chroma_par(&c, tid, reinterpret_cast<uint8_t *>(dyn_lds)); if (!tid) PROF(&c, 18); }
 	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
 	else if (PH == PH_C2) dequant_sim_chroma_par(&c, 1, tid);
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 }
 
 /* passes that run one wavefront per image (nhw_tail_wave.h): four images per workgroup, no workgroup barriers */
-enum { WV_DQ1, WV_DQ0, WV_EMIT };
+enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
 template <int PH>
 __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 {
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 	ctx_load(&c, ws, img);
 	if (PH == WV_DQ1) wave_dequant_sim_luma(&c, 1, lane);
 	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane);
+	else if (PH == WV_QUANT) { PROF_BEGIN(); wave_quantise_luma(&c, lane); if (!lane) PROF(&c, 15); }
 	else if (PH == WV_EMIT) { PROF_BEGIN(); wave_emit_ll2(&c, lane); if (!lane) PROF(&c, 4); }
 }
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s)
@@ -57,6 +59,7 @@ void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s)
 	case WV_DQ1: k_wave<WV_DQ1><<<g, b, 0, s>>>(ws); break;
 	case WV_DQ0: k_wave<WV_DQ0><<<g, b, 0, s>>>(ws); break;
 	case WV_EMIT: k_wave<WV_EMIT><<<g, b, 0, s>>>(ws); break;
+	case WV_QUANT: k_wave<WV_QUANT><<<g, b, 0, s>>>(ws); break;
 	}
 }
 
@@ -105,6 +108,7 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 	case PH_L4C: k_phase<PH_L4C><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4D: k_phase<PH_L4D><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_LLC: k_phase<PH_LLC><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L4C2: k_phase<PH_L4C2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C0: k_phase<PH_C0><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C2: k_phase<PH_C2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C3: k_phase<PH_C3><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;

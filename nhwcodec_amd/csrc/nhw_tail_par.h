@@ -1618,7 +1618,6 @@ DEV void luma_p4b_par(Ctx *c, int tid, int *pos, int16_t *lds)
 }
 DEV void luma_p4c_par(Ctx *c, int tid, int *pos, int16_t *lds)
 {
-	const int q = c->q;
 	PROF_BEGIN();
 	for (int idx = tid; idx < Q; idx += NT) {                               /* Y26 :1893-1910 */
 		const int r = idx >> 8, j = idx & 255;
@@ -1629,9 +1628,11 @@ DEV void luma_p4c_par(Ctx *c, int tid, int *pos, int16_t *lds)
 	if (!tid) PROF(c, 13);
 	clean_details_par(c, tid, lds);                                         /* Y27 */
 	if (!tid) PROF(c, 14);
-	quantise_luma_par(c, tid, pos, lds);                                    /* Y28 */
-	if (!tid) PROF(c, 15);
-	if (q > 21 && tid == 0) { band_recons(c); hq_settings(c); }             /* Y29 */
+}
+DEV void luma_p4c2_par(Ctx *c, int tid)                                     /* Y29 (q > 21 only; Y28 runs between the two as a wave kernel) */
+{
+	PROF_BEGIN();
+	if (c->q > 21 && tid == 0) { band_recons(c); hq_settings(c); }
 	BARRIER();
 	if (!tid) PROF(c, 16);
 }

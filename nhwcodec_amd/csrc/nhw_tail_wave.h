@@ -417,6 +417,146 @@ DEV void wave_shrink(Ctx *c, int lane)
 	}
 }
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Y28, the quantiser offsetY (image_processing.c:185-521, q>16 branches), on whole 512-column rows: 8 mask words,
+ * lane l owns columns l + 64k.
+ *   loop 1 (:195-238)  paired multiples of 8 in the level-1 detail bands: a cell may decrement itself or its right
+ *                      neighbour, a decremented cell stops being a multiple of 8 and does nothing -> skip walk
+ *   loop 2 (:241-284)  triples / vertical pairs of 4..7 in rows 0..255, columns 1..254 (writes the next row)
+ *   loop 3 (:286-311)  equal-sign 5..7 pairs, rows 0..255
+ *   loop 4 (:314-519)  the symbol of every cell; a cell may rewrite its right neighbour's +-7 first, which only
+ *                      depends on the cell's own value: a stencil.  Its one unguarded look at the next cell at
+ *                      column 511 sees the next row's first cell after loops 1-3, so a row is coded one step late.
+ * ------------------------------------------------------------------------------------------------------------ */
+struct M8 { uint64_t w[8]; };
+DEV M8 operator&(M8 a, M8 b) { M8 r; for (int k = 0; k < 8; k++) r.w[k] = a.w[k] & b.w[k]; return r; }
+DEV M8 operator|(M8 a, M8 b) { M8 r; for (int k = 0; k < 8; k++) r.w[k] = a.w[k] | b.w[k]; return r; }
+DEV M8 operator~(M8 a) { M8 r; for (int k = 0; k < 8; k++) r.w[k] = ~a.w[k]; return r; }
+DEV M8 m8_zero() { M8 r; for (int k = 0; k < 8; k++) r.w[k] = 0; return r; }
+DEV M8 up1(M8 a, unsigned in = 0) { M8 r; r.w[0] = (a.w[0] << 1) | in; for (int k = 1; k < 8; k++) r.w[k] = (a.w[k] << 1) | (a.w[k - 1] >> 63); return r; }
+DEV M8 dn1(M8 a) { M8 r; for (int k = 0; k < 7; k++) r.w[k] = (a.w[k] >> 1) | (a.w[k + 1] << 63); r.w[7] = a.w[7] >> 1; return r; }
+DEV M8 dn2(M8 a) { M8 r; for (int k = 0; k < 7; k++) r.w[k] = (a.w[k] >> 2) | (a.w[k + 1] << 62); r.w[7] = a.w[7] >> 2; return r; }
+DEV M8 col_range8(int lo, int hi) { M8 r; for (int k = 0; k < 8; k++) r.w[k] = low_bits(hi + 1 - 64 * k) & ~low_bits(lo - 64 * k); return r; }
+DEV M8 alt_runs(M8 f)
+{
+	const uint64_t even = 0x5555555555555555ull;
+	const M8 pf = up1(f);
+	M8 r;
+	unsigned carry = 0;
+	for (int k = 0; k < 8; k++) {
+		const uint64_t se = f.w[k] & ~pf.w[k] & even;
+		const uint64_t t = f.w[k] + se;
+		const unsigned c1 = t < se;
+		const uint64_t sum = t + carry;
+		carry = c1 | (sum < t);
+		const uint64_t re = f.w[k] & ~sum;
+		r.w[k] = (re & even) | (f.w[k] & ~re & ~even);
+	}
+	return r;
+}
+#define BALLOT8(m, arr, expr) do { for (int k_ = 0; k_ < 8; k_++) { const int x = arr[k_]; (m).w[k_] = __ballot(expr); } } while (0)
+
+DEV void quant_load_row(const int16_t *p, int r, int lane, int *v)
+{
+	for (int k = 0; k < 8; k++) v[k] = r < W ? p[r * W + lane + 64 * k] : 0;       /* the cell behind the plane reads as 0 (zero guard) */
+}
+
+DEV int quant_symbol(int a, int nx)                               /* :375-396 + :515-518 for a cell that is no code and no big value */
+{
+	if (a < 0) {
+		a = -a;
+		if (a > 14 && (a & 7) == 7 && nx > 0 && nx < 8) a -= 2;
+		if ((a & 7) < 7) a &= 504;
+		a = -a;
+	}
+	return (a < DEADZONE && a > -DEADZONE) ? 128 : ((a + 128) & 248);
+}
+
+DEV void wave_quantise_luma(Ctx *c, int lane)
+{
+	int16_t *p = c->proc;
+	int prev[8], cur[8], nxt[8];
+	quant_load_row(p, 0, lane, cur);
+	quant_load_row(p, 1, lane, nxt);
+	for (int k = 0; k < 8; k++) prev[k] = 0;
+	unsigned last_le0 = 0;                                         /* the last cell of the row above is <= 0 (loop 1 looks at it from column 0) */
+	for (int r = 0; r <= W; r++) {                                 /* step r: loops 1-3 on row r, loop 4 on row r - 1 */
+		int far[8];
+		quant_load_row(p, r + 2, lane, far);
+		if (r < W) {
+			{                                                      /* loop 1 */
+				const M8 region = r < H ? col_range8(H, W - 1) : col_range8(0, W - 1);
+				M8 g8, g16, le0;
+				BALLOT8(g8, cur, x > 7 && !(x & 7)); BALLOT8(g16, cur, x > 15 && !(x & 7)); BALLOT8(le0, cur, x <= 0);
+				const M8 ple = up1(le0, last_le0);
+				const M8 both = g8 & dn1(g8) & col_range8(0, W - 2);
+				const M8 cself = both & g16 & ple;
+				const M8 cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & dn1(g16) & dn2(le0) & col_range8(0, W - 3);
+				const M8 hit = up1(alt_runs(cnext & region));          /* cells decremented by their left neighbour */
+				const M8 dec = hit | (cself & region & ~hit);
+				last_le0 = (unsigned)(le0.w[7] >> 63);
+				for (int k = 0; k < 8; k++) cur[k] -= TB(dec, k);
+			}
+			if (r < H) {
+				{                                                  /* loop 2 */
+					int c4[4] = { cur[0], cur[1], cur[2], cur[3] }, n4[4] = { nxt[0], nxt[1], nxt[2], nxt[3] };
+					M4 P, N, PN, NN;
+					BALLOT4(P, c4, x > 3 && x < 8); BALLOT4(N, c4, x < -3 && x > -8);
+					BALLOT4(PN, n4, x > 3 && x < 8); BALLOT4(NN, n4, x < -3 && x > -8);
+					const M4 rg = col_range(1, H - 2);
+					const M4 pp = P & up1(P), nn = N & up1(N);
+					const M4 tp = pp & dn1(P), tn = nn & dn1(N);
+					const M4 vp = pp & ~dn1(P) & up1(PN) & PN, vn = nn & ~dn1(N) & up1(NN) & NN;
+					const M4 fired = alt_runs((tp | vp | tn | vn) & rg);
+					const M4 ftp = fired & tp, ftn = fired & tn, fvp = fired & vp, fvn = fired & vn;
+					const M4 fv = fvp | fvn, ft_l = dn1(ftp | ftn), fvp_l = dn1(fvp), fvn_l = dn1(fvn), fv_l = dn1(fv);
+					for (int k = 0; k < 4; k++) {
+						if (TB(ftp, k)) cur[k] = 12700; if (TB(ftn, k)) cur[k] = 12900;
+						if (TB(ft_l, k)) cur[k] = 10100;
+						if (TB(fv, k)) { cur[k] = 10100; nxt[k] = 10100; }
+						if (TB(fvp_l, k)) cur[k] = 12100; if (TB(fvn_l, k)) cur[k] = 12200;
+						if (TB(fv_l, k)) nxt[k] = 10100;
+					}
+				}
+				{                                                  /* loop 3 */
+					int c4[4] = { cur[0], cur[1], cur[2], cur[3] };
+					M4 A, B;
+					BALLOT4(A, c4, x >= 5 && x <= 7); BALLOT4(B, c4, x <= -5 && x >= -7);
+					const M4 fired = alt_runs(((A & dn1(A)) | (B & dn1(B))) & col_range(0, H - 2));
+					const M4 fa = fired & A, fb = fired & B;
+					for (int k = 0; k < 4; k++) { if (TB(fa, k)) cur[k] = 10300; if (TB(fb, k)) cur[k] = 10204; }
+				}
+			}
+		}
+		if (r >= 1) {                                              /* loop 4 on row r - 1 */
+			M8 e8, e7, em7, ac, dc;
+			BALLOT8(e8, prev, x == 8); BALLOT8(e7, prev, x == 7); BALLOT8(em7, prev, x == -7);
+			BALLOT8(ac, prev, x < -12 && x >= -127 && ((-x) & 7) == 6); BALLOT8(dc, prev, x > 12 && x <= 127 && (x & 7) >= 6);
+			const M8 ml = col_range8(0, W - 2);
+			const M8 to_m9 = em7 & up1(ac & ml), to_m8 = em7 & up1(e8 & ml), to_9 = e7 & up1(dc & ml);
+			const M8 self_m8 = em7 & ~to_m9 & ~to_m8 & dn1(e8) & ml;
+			const int first_next = __shfl(cur[0], 0);              /* the row below, already through loops 1-3 */
+			for (int k = 0; k < 8; k++) {
+				int a = prev[k], sym;
+				int nx = right_of(prev, k, 8, 1, lane);
+				if (k == 7 && lane == 63) nx = first_next;
+				if (a > 10000 && (a == 10100 || a == 12700 || a == 12900 || a == 10204 || a == 10300 || a == 12100 || a == 12200))
+					sym = a == 10100 ? 128 : a == 12700 ? 127 : a == 12900 ? 129 : a == 10204 ? 125 : a == 10300 ? 126 : a == 12100 ? 121 : 122;
+				else if (a > 127) sym = big_code(a, k_big_pos);
+				else if (a < -127) sym = big_code(-a, k_big_neg);
+				else {
+					if (TB(to_m9, k)) a = -9;
+					if (TB(to_m8, k) || TB(self_m8, k)) a = -8;
+					if (TB(to_9, k)) a = 9;
+					sym = quant_symbol(a, nx);
+				}
+				p[(r - 1) * W + lane + 64 * k] = (int16_t)sym;
+			}
+		}
+		for (int k = 0; k < 8; k++) { prev[k] = cur[k]; cur[k] = nxt[k]; nxt[k] = far[k]; }
+	}
+}
+
 /* offsetY_recons256 (image_processing.c:2600-3190), one wavefront per image */
 DEV void wave_dequant_sim_luma(Ctx *c, int part, int lane)
 {
