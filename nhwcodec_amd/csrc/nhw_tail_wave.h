@@ -43,7 +43,8 @@ DEV M4 col_range(int lo, int hi)                                /* columns lo..h
 	r.w[3] = low_bits(hi + 1 - 192) & ~low_bits(lo - 192);
 	return r;
 }
-#define TB(m, k) ((int)(((m).w[k] >> lane) & 1))
+/* bit `lane` of a wave-uniform mask word as a per-lane condition: the mask itself becomes the select operand (v_cndmask with an SGPR pair) */
+#define TB(m, k) ((int)__builtin_amdgcn_inverse_ballot_w64((m).w[k]))
 #define BALLOT4(m, arr, expr) do { { const int x = arr[0]; (m).w[0] = __ballot(expr); } { const int x = arr[1]; (m).w[1] = __ballot(expr); } \
 	{ const int x = arr[2]; (m).w[2] = __ballot(expr); } { const int x = arr[3]; (m).w[3] = __ballot(expr); } } while (0)
 
@@ -540,15 +541,16 @@ DEV void wave_quantise_luma(Ctx *c, int lane)
 				int a = prev[k], sym;
 				int nx = right_of(prev, k, 8, 1, lane);
 				if (k == 7 && lane == 63) nx = first_next;
-				if (a > 10000 && (a == 10100 || a == 12700 || a == 12900 || a == 10204 || a == 10300 || a == 12100 || a == 12200))
-					sym = a == 10100 ? 128 : a == 12700 ? 127 : a == 12900 ? 129 : a == 10204 ? 125 : a == 10300 ? 126 : a == 12100 ? 121 : 122;
-				else if (a > 127) sym = big_code(a, k_big_pos);
-				else if (a < -127) sym = big_code(-a, k_big_neg);
-				else {
-					if (TB(to_m9, k)) a = -9;
-					if (TB(to_m8, k) || TB(self_m8, k)) a = -8;
-					if (TB(to_9, k)) a = 9;
-					sym = quant_symbol(a, nx);
+				const int raw = a;
+				if (TB(to_m9, k)) a = -9;
+				if (TB(to_m8, k) || TB(self_m8, k)) a = -8;
+				if (TB(to_9, k)) a = 9;
+				sym = quant_symbol(a, nx);
+				if (__ballot(raw > 127 || raw < -127)) {                /* marks of loops 2-3 and values beyond +-127: rare, whole words skip this */
+					if (raw > 10000 && (raw == 10100 || raw == 12700 || raw == 12900 || raw == 10204 || raw == 10300 || raw == 12100 || raw == 12200))
+						sym = raw == 10100 ? 128 : raw == 12700 ? 127 : raw == 12900 ? 129 : raw == 10204 ? 125 : raw == 10300 ? 126 : raw == 12100 ? 121 : 122;
+					else if (raw > 127) sym = big_code(raw, k_big_pos);
+					else if (raw < -127) sym = big_code(-raw, k_big_neg);
 				}
 				p[(r - 1) * W + lane + 64 * k] = (int16_t)sym;
 			}
