@@ -798,9 +798,179 @@ void nhw_launch_prefilter(int16_t *y, size_t y_stride, int16_t *kmap, size_t k_s
 }
 
 /* keep != nullptr: copy of the first 256 rows x 512 of the transposed pass-1 plane (q>=22, level 0) */
+/* ------------------------------------------------------------------------------------------------
+ * Whole-block filterbank kernels for the 256- and 128-sized levels: one workgroup keeps the S x S block in
+ * LDS (row stride S + 2 shorts: column walks hit 64 different banks), runs both directions there and writes
+ * every plane the four-kernel sequence (rows, transpose, rows, transpose) leaves behind -- the coefficient
+ * plane, the transposed first-direction plane in the source plane and, on a non-final level, the LL quadrant
+ * copied back in natural orientation -- with one read and one write of each.  A wavefront owns a row (then a
+ * column): it reads all its taps before it writes its outputs over them, so both directions run in place.
+ * ------------------------------------------------------------------------------------------------ */
+template <int S>
+__device__ __forceinline__ int tap5s(const int16_t *x, int st, int k)
+{
+	const int c = 2 * k;
+	const int l1 = c >= 1 ? x[(c - 1) * st] : x[st], l2 = c >= 2 ? x[(c - 2) * st] : x[2 * st];
+	const int r1 = x[(c + 1) * st], r2 = (c + 2 < S) ? x[(c + 2) * st] : x[(S - 2) * st];
+	return 6 * x[c * st] + 2 * (l1 + r1) - (l2 + r2);
+}
+__device__ __forceinline__ int pair_predict_s(const int16_t *x, int st, int k)
+{
+	int a = x[2 * k * st] + x[(2 * k + 2) * st];
+	if ((k & 1) && (a & 1) && ((x[(2 * k - 2) * st] + x[2 * k * st]) & 1)) a++;
+	return x[(2 * k + 1) * st] - (a >> 1);
+}
+
+template <int S>
+__global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int final_level)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
+	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4;
+	const int img = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	int16_t *jpeg = jpegb + (size_t)img * plane_stride, *proc = procb + (size_t)img * plane_stride;
+	int16_t *A = smem;
+	for (int v = t; v < S * (S / 8); v += NT_) {
+		const int row = v / (S / 8), o = v % (S / 8);
+		const uint4 x = *reinterpret_cast<const uint4 *>(jpeg + (size_t)row * stride + 8 * o);
+		uint32_t *d = reinterpret_cast<uint32_t *>(A + row * LS + 8 * o);
+		d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+	}
+	__syncthreads();
+	for (int i = 0; i < 16; i++) {                                 /* first direction (filters.c:40-86): un-normalised taps */
+		int16_t *x = A + (wv * 16 + i) * LS;
+		int lo[PPL], hi[PPL];
+#pragma unroll
+		for (int u = 0; u < PPL; u++) {
+			const int k = lane + 64 * u;
+			lo[u] = tap5s<S>(x, 1, k);
+			hi[u] = k < HLF - 1 ? (x[2 * k + 1] << 1) - (x[2 * k] + x[2 * k + 2]) : ((x[S - 1] - x[S - 2]) << 1);
+		}
+#pragma unroll
+		for (int u = 0; u < PPL; u++) { x[lane + 64 * u] = (int16_t)lo[u]; x[HLF + lane + 64 * u] = (int16_t)hi[u]; }
+	}
+	__syncthreads();
+	for (int v = t; v < S * HLF; v += NT_) {                       /* the source plane keeps the transposed first-direction plane */
+		const int i = v / HLF, j = 2 * (v % HLF);
+		if (!final_level && i < HLF && j < HLF) continue;           /* (its LL quadrant is overwritten below) */
+		*reinterpret_cast<uint32_t *>(jpeg + (size_t)i * stride + j) = (uint16_t)A[j * LS + i] | ((uint32_t)(uint16_t)A[(j + 1) * LS + i] << 16);
+	}
+	__syncthreads();
+	for (int i = 0; i < 16; i++) {                                 /* second direction along the columns (filters.c:88-287) */
+		const int c = wv * 16 + i;
+		int16_t *x = A + c;
+		int lo[PPL], hi[PPL];
+#pragma unroll
+		for (int u = 0; u < PPL; u++) {
+			const int k = lane + 64 * u;
+			if (c < HLF) {
+				const int r = tap5s<S>(x, LS, k);
+				const int carry = k > 0 ? diffuse(tap5s<S>(x, LS, k - 1)) : 0;
+				lo[u] = rnd_half_away((int16_t)(r + carry), 6);
+				hi[u] = k < HLF - 1 ? rnd_half_away(pair_predict_s(x, LS, k), 3) : ((x[(S - 1) * LS] - x[(S - 2) * LS]) >> 3);
+			} else {
+				lo[u] = rnd_half_away(tap5s<S>(x, LS, k), 4);
+				if (k < HLF - 1) { const int r = pair_predict_s(x, LS, k); hi[u] = r > 0 ? (r + 1) >> 1 : r >> 1; }
+				else hi[u] = ((x[(S - 1) * LS] - x[(S - 2) * LS]) + 1) >> 1;
+			}
+		}
+		int16_t *o = proc + (size_t)c * stride;
+#pragma unroll
+		for (int u = 0; u < PPL; u++) {
+			const int k = lane + 64 * u;
+			o[k] = (int16_t)lo[u]; o[HLF + k] = (int16_t)hi[u];
+			if (!final_level && c < HLF) x[k * LS] = (int16_t)lo[u];  /* LL, parked in the column's own cells */
+		}
+	}
+	if (final_level) return;
+	__syncthreads();
+	for (int v = t; v < HLF * (HLF / 2); v += NT_) {               /* LL copied back in natural orientation (wavelet_filterbank.c:172-184) */
+		const int k = v / (HLF / 2), c = 2 * (v % (HLF / 2));
+		*reinterpret_cast<uint32_t *>(jpeg + (size_t)k * stride + c) = (uint16_t)A[k * LS + c] | ((uint32_t)(uint16_t)A[k * LS + c + 1] << 16);
+	}
+}
+
+template <int S>
+__device__ __forceinline__ void syn_pair(const int16_t *x, int st, int k, bool normalise, int *e_out, int *o_out)
+{
+	constexpr int M = S / 2;
+	const int16_t *lo = x, *hi = x + M * st;
+	const int l0 = lo[k * st], ln = (k + 1 < M) ? lo[(k + 1) * st] : l0;
+	const int h0 = hi[k * st], hp = k > 0 ? hi[(k - 1) * st] : hi[0], hn = (k + 1 < M) ? hi[(k + 1) * st] : h0;
+	int16_t e = (int16_t)(l0 << 3);
+	int16_t o = (int16_t)((l0 + ln) << 2);
+	e = (int16_t)(e - ((h0 + hp) << 1));
+	o = (int16_t)(o + (6 * h0 - hp - hn));
+	if (normalise) {
+		if (e > 0) e = (int16_t)(e + 32);
+		e >>= 6;
+		if (o > 0) o = (int16_t)(o + 32);
+		o >>= 6;
+	}
+	*e_out = e; *o_out = o;
+}
+
+template <int S>
+__global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
+	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4;
+	const int img = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	int16_t *jpeg = jpegb + (size_t)img * plane_stride, *proc = procb + (size_t)img * plane_stride;
+	int16_t *A = smem;
+	for (int v = t; v < S * (S / 8); v += NT_) {
+		const int row = v / (S / 8), o = v % (S / 8);
+		const uint4 x = *reinterpret_cast<const uint4 *>(jpeg + (size_t)row * stride + 8 * o);
+		uint32_t *d = reinterpret_cast<uint32_t *>(A + row * LS + 8 * o);
+		d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+	}
+	__syncthreads();
+	for (int i = 0; i < 16; i++) {                                 /* first direction, un-normalised */
+		int16_t *x = A + (wv * 16 + i) * LS;
+		int e[PPL], o[PPL];
+#pragma unroll
+		for (int u = 0; u < PPL; u++) syn_pair<S>(x, 1, lane + 64 * u, false, &e[u], &o[u]);
+#pragma unroll
+		for (int u = 0; u < PPL; u++) reinterpret_cast<uint32_t *>(x)[lane + 64 * u] = (uint32_t)(uint16_t)e[u] | ((uint32_t)(uint16_t)o[u] << 16);
+	}
+	__syncthreads();
+	for (int i = 0; i < 16; i++) {                                 /* second direction along the columns, normalised: row c of the work plane */
+		const int c = wv * 16 + i;
+		int16_t *x = A + c;
+		int e[PPL], o[PPL];
+#pragma unroll
+		for (int u = 0; u < PPL; u++) syn_pair<S>(x, LS, lane + 64 * u, true, &e[u], &o[u]);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(proc + (size_t)c * stride);
+#pragma unroll
+		for (int u = 0; u < PPL; u++) {
+			const int k = lane + 64 * u;
+			dst[k] = (uint32_t)(uint16_t)e[u] | ((uint32_t)(uint16_t)o[u] << 16);
+			x[(2 * k) * LS] = (int16_t)e[u]; x[(2 * k + 1) * LS] = (int16_t)o[u];
+		}
+	}
+	__syncthreads();
+	for (int v = t; v < S * (S / 8); v += NT_) {                   /* and its transpose, the reconstruction in natural orientation */
+		const int row = v / (S / 8), o = v % (S / 8);
+		const uint32_t *d = reinterpret_cast<const uint32_t *>(A + row * LS + 8 * o);
+		*reinterpret_cast<uint4 *>(jpeg + (size_t)row * stride + 8 * o) = make_uint4(d[0], d[1], d[2], d[3]);
+	}
+}
+
+template <int S>
+static void dwt_lds_attr()
+{
+	static bool done = false;
+	if (done) return;
+	const int lds = S * (S + 2) * (int)sizeof(int16_t);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dwt_ana<S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dwt_syn<S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	done = true;
+}
+
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level,
                          int16_t *keep, size_t keep_stride, hipStream_t s)
 {
+	if (size == 256 && !keep) { dwt_lds_attr<256>(); k_dwt_ana<256><<<n, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level); return; }
+	if (size == 128 && !keep) { dwt_lds_attr<128>(); k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level); return; }
 	const int hlf = size >> 1;
 	const dim3 rg((hlf + 255) / 256, size, n), tg((size + 63) / 64, (size + 63) / 64, n);
 	k_ana_rows<1><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
@@ -816,6 +986,8 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
 
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s)
 {
+	if (size == 256) { dwt_lds_attr<256>(); k_dwt_syn<256><<<n, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride); return; }
+	if (size == 128) { dwt_lds_attr<128>(); k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride); return; }
 	const int hlf = size >> 1;
 	const dim3 rg((hlf + 255) / 256, size, n), tg((size + 63) / 64, (size + 63) / 64, n);
 	k_syn_rows<0><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
