@@ -861,10 +861,42 @@ struct QuantChromaF {
 		return j;
 	}
 };
-DEV void quantise_chroma_par(Ctx *c, int tid, int16_t *lds)
+/* The quantised plane only feeds the symbol stream, in serpentine order: 32 strips of 8 columns, within a strip
+ * row after row, odd rows right to left, U in the even and V in the odd bytes (nhw_encoder.c:2553-2570).  A tile of
+ * the row pass holds 4 whole strips, i.e. 4 runs of 2048 consecutive stream positions, so the stream is written
+ * from the tile while it is in LDS: U parks its bytes in a plane of their own, V merges them and writes whole
+ * 16-bit pairs (byte-interleaved scattered stores cost more than the quantiser). */
+DEV void quantise_chroma_par(Ctx *c, int comp, int tid, int16_t *lds)
 {
-	QuantChromaF f = { c->cproc };
-	row_pass_tiled(c->cproc, H, H, H, 0, H, 0, H, lds, tid, f);
+	int16_t *plane = c->cproc;
+	uint8_t *ubytes = reinterpret_cast<uint8_t *>(c->band);       /* Q bytes, free during the chroma phases */
+	uint8_t *scan = c->scan + 4 * Q;
+	QuantChromaF f = { plane };
+	int jnext = 0;
+	QuantChromaF::State st = f.init(tid);
+	for (int c0 = 0; c0 < H; c0 += TLC) {
+		tile_load(lds, plane, H, H, c0, tid);
+		BARRIER();
+		if (jnext < c0 + TLC) jnext = f.run(lds + tid * TLS + 2 - c0, tid, jnext, c0 + TLC, st);
+		BARRIER();
+		tile_store(lds, plane, H, H, c0, H - c0 < TLC + 2 ? H - c0 : TLC + 2, tid, c0 > 0 ? 0 : 2);   /* the cell a row pushed into the next tile travels through the plane */
+		for (int idx = tid; idx < (TLC / 8) * 512; idx += NT) {    /* 4 stream positions per thread */
+			const int sl = idx >> 9, rem = idx & 511, r = rem >> 1, k0 = (rem & 1) * 4;
+			const int16_t *row = lds + r * TLS + 2 + 8 * sl;
+			uint32_t w = 0;
+			for (int k = 0; k < 4; k++) w |= (uint32_t)(uint8_t)row[(r & 1) ? 7 - (k0 + k) : k0 + k] << (8 * k);
+			const int pos = (c0 / 8 + sl) * (8 * H) + 4 * rem;
+			if (!comp) *reinterpret_cast<uint32_t *>(ubytes + pos) = w;
+			else {
+				const uint32_t u = *reinterpret_cast<const uint32_t *>(ubytes + pos);
+				uint2 o;
+				o.x = (u & 0xFF) | ((w & 0xFF) << 8) | ((u & 0xFF00) << 8) | ((w & 0xFF00) << 16);
+				o.y = ((u >> 16) & 0xFF) | (((w >> 16) & 0xFF) << 8) | ((u >> 24) << 16) | ((w >> 24) << 24);
+				*reinterpret_cast<uint2 *>(scan + 2 * pos) = o;
+			}
+		}
+		BARRIER();
+	}
 }
 
 /* ---------------------------------------------------------------- Y30 + Y31 */
@@ -1675,32 +1707,46 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 	const int q = c->q;
 	PROF_BEGIN();
 	if (q >= 18) {
-		/* :2372-2427.  The reference walks the LL1 band with an index into cll1 that is NOT reset per row; it runs
-		 * ahead of the row only when a pair mark is taken at the last column of a row.  Every cell owns the three
-		 * detail cells it may mark, so rows are independent as long as that never happens: a dry run (no writes)
-		 * checks it, then the rows run in parallel; otherwise thread 0 replays the band serially. */
-		const int res_uv = q > 17 ? 4 : 5;
-		const int lane = tid & 63, wv = tid >> 6;
-		/* One wavefront per row, lane l owns columns l and l + 64 of the 128-wide band; the pair marks are a walk that
+		/* :2372-2427.  The reference walks the LL1 band with an index into cll1 that is NOT reset per row: it runs one
+		 * further ahead of the position each time a pair mark is taken at the last column of a row (the skip of the
+		 * partner then eats the first increment of the next row).  So row r compares against cll1 shifted by the
+		 * number of such events in the rows above it.  Whether a row ends in one depends only on its own shift, so
+		 * the shifts are found by iterating "evaluate every row with its current shift, re-count" to a fixed point
+		 * (one round when there is no event, which is the rule), then the rows are marked, all in parallel.
+		 *
+		 * One wavefront per row, lane l owns columns l and l + 64 of the 128-wide band; the pair marks are a walk that
 		 * skips the partner, resolved on the row's "pair here and a free detail cell" mask (alt_runs).  Cell (r, 127)
 		 * reads column 128 of its row as its right neighbour: that is the HL detail cell of (r, 0), which (r, 0)
 		 * may just have marked -- then neither a pair nor the d == -5 rule can hold at (r, 127). */
-		for (int pass = 0; pass < 2; pass++) {                     /* 0: does a pair mark fall on the last column of a row? 1: mark */
-			if (pass == 0 && tid == 0) sh_misc[0] = 0;
-			BARRIER();
-			if (pass == 1 && sh_misc[0]) break;
+		const int res_uv = q > 17 ? 4 : 5;
+		const int lane = tid & 63, wv = tid >> 6;
+		int *shift = reinterpret_cast<int *>(lds), *haz = shift + H / 2;
+		if (tid < H / 2) shift[tid] = 0;
+		BARRIER();
+		for (int pass = 0;; pass++) {                              /* pass >= 1 with stable shifts: mark */
+			bool mark = false;
+			if (pass > 0) {
+				int ns = 0;
+				if (tid < H / 2) for (int r = 0; r < tid; r++) ns += haz[r];
+				const int changed = __syncthreads_or(tid < H / 2 && ns != shift[tid]);
+				if (tid < H / 2) shift[tid] = ns;
+				BARRIER();
+				mark = !changed;
+			}
 			for (int r = wv; r < H / 2; r += 4) {
-				int pl[2], hl[2], lh[2], hh[2], ov[2], d[2], d1[2];
+				const int sh = shift[r];
+				int pl[2], hl[2], lh[2], hh[2], d[2], d1[2];
 				for (int k = 0; k < 2; k++) {
-					const int at = r * H + lane + 64 * k;
+					const int at = r * H + lane + 64 * k, ko = r * (H / 2) + sh + lane + 64 * k;
 					pl[k] = p[at]; hl[k] = p[at + H / 2]; lh[k] = p[at + Q / 2]; hh[k] = p[at + Q / 2 + H / 2];
-					ov[k] = o[r * (H / 2) + lane + 64 * k];
+					d[k] = pl[k] - o[ko];
+					d1[k] = o[ko + 1];                                  /* the reference cell of the right neighbour */
 				}
-				const int o_next = o[(r + 1) * (H / 2)], hl_first = __shfl(hl[0], 0);
+				const int hl_first = __shfl(hl[0], 0);
 				for (int k = 0; k < 2; k++) {
-					int pn = right_of(pl, k, 2, 1, lane), on = right_of(ov, k, 2, 1, lane);
-					if (k == 1 && lane == 63) { pn = hl_first; on = o_next; }
-					d[k] = pl[k] - ov[k]; d1[k] = pn - on;
+					int pn = right_of(pl, k, 2, 1, lane);
+					if (k == 1 && lane == 63) pn = hl_first;
+					d1[k] = pn - d1[k];
 				}
 				uint64_t pp[2], pn_[2], fr[2], sg[2], fhl[2], flh[2], m5[2];
 				for (int k = 0; k < 2; k++) {
@@ -1717,7 +1763,7 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 					if (m5[1] >> 63) sg[1] &= ~(1ull << 63);
 				}
 				const M4 fired = alt_runs(M4{ { f[0], f[1], 0, 0 } });
-				if (pass == 0) { if (lane == 0 && (fired.w[1] >> 63)) sh_misc[0] = 1; continue; }
+				if (!mark) { if (lane == 0) haz[r] = (int)(fired.w[1] >> 63); continue; }
 				const M4 vis = ~up1(fired);
 				for (int k = 0; k < 2; k++) {
 					const bool pair = (fired.w[k] >> lane) & 1;
@@ -1730,33 +1776,17 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 					else if (iabs(hh[k]) < 8) p[at + Q / 2 + H / 2] = code;
 				}
 			}
+			BARRIER();
+			if (mark) break;
 		}
-		BARRIER();
-		if (tid == 0 && sh_misc[0]) {                              /* rare: literal serial walk */
-			int k = 0;
-			for (int r = 0; r < H / 2; r++)
-				for (int j = 0; j < H / 2; j++, k++) {
-					const int at = r * H + j, d = p[at] - o[k];
-					if (d > 3 && d < 7) {
-						const int d1 = p[at + 1] - o[k + 1];
-						if (d1 > 2 && d1 < 7 && mark_free_detail(p, at, 12400)) { j++; k++; continue; }
-					}
-					else if (d < -3 && d > -7) {
-						const int d1 = p[at + 1] - o[k + 1];
-						if (d1 < -2 && d1 > -8 && mark_free_detail(p, at, 12600)) { j++; k++; continue; }
-					}
-					if (iabs(d) > res_uv) {
-						if (d > 0) mark_free_detail(p, at, 12900);
-						else if (d == -5) { if ((p[at + 1] - o[k + 1]) < 0) mark_free_detail(p, at, 13000); }
-						else mark_free_detail(p, at, 13000);
-					}
-				}
-		}
+		if (tid == 0) { int ev = 0; for (int r = 0; r < H / 2; r++) ev += haz[r]; c->m->pad = comp ? c->m->pad + (ev << 8) : ev; }   /* diagnostics: rows that ended in a pair mark */
 	}
 	BARRIER();
+	if (!tid) PROF(c, 27);
 	copy_block_par(c->cl2save, H / 2, p, H, H / 2, H / 2, tid);    /* :2431-2439 */
 	for (int idx = tid; idx < (H / 4) * (H / 4); idx += NT) lds[idx] = c->cl2save[(idx >> 6) * (H / 2) + (idx & 63)];   /* the LL2 band for the emission below */
 	BARRIER();
+	if (!tid) PROF(c, 28);
 	{                                                              /* :2489-2525 LL2 emission, 16 consecutive samples per thread */
 		/* a sample outside 0..255 goes to the exception list (row, column | sign, magnitude) and repeats the byte
 		 * before it in the stream, i.e. the byte of the nearest earlier sample that was in range (sample 0 always is) */
@@ -1800,15 +1830,8 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 		}
 	}
 	if (!tid) PROF(c, 21);
-	quantise_chroma_par(c, tid, lds);
+	quantise_chroma_par(c, comp, tid, lds);
 	if (!tid) PROF(c, 22);
-	{                                                              /* serpentine, 32 strips of 8 columns, U even / V odd bytes (:2553-2570) */
-		uint8_t *s = c->scan + 4 * Q + comp;
-		for (int idx = tid; idx < Q; idx += NT) {
-			const int r = idx >> 8, col = idx & 255, strip = col >> 3, k = col & 7;
-			s[2 * (strip * (8 * H) + 8 * r + ((r & 1) ? 7 - k : k))] = (uint8_t)p[idx];
-		}
-	}
 }
 
 

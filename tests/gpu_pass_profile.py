@@ -9,7 +9,7 @@ import torch
 
 NAMES = ["tag_l2", "dequant_sim p1", "apply_tags", "precompensate", "res4+emit_ll2", "ll_code_luma", "restore", "dequant_sim p0",
          "Y19/Y20", "tag_small_runs", "Y22 classify", "Y23 code", "Y24+Y25 poslists", "Y26", "Y27 clean", "Y28 quantise", "Y29 hq", "Y30/31 scan+rewrite",
-         "ll_code_chroma", "packetise", "container", "chroma marks+emit", "quantise_chroma", "pack: hist", "pack: ratio+rank", "pack: count", "pack: write"]
+         "ll_code_chroma", "packetise", "container", "chroma marks+emit", "quantise_chroma", "pack: hist", "pack: ratio+rank", "pack: count", "pack: write", "chroma marks only", "chroma copy+stage"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 q = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 enc = nhwcodec_amd.Encoder(0, max_batch=n)
@@ -17,7 +17,7 @@ bgr = enc.synth_device(n, 1234)
 enc.encode_device(bgr, q)
 torch.cuda.synchronize()
 acc = np.zeros(64, np.float64)
-pick = list(range(0, n, max(1, n // 16)))
+pick = [(i * 251 + 17) % n for i in range(32)]
 for i in pick:
     buf = np.zeros(64, np.uint64)
     assert enc.lib.nhw_debug_read(enc.h, 55, i, ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(512)) == 0

@@ -286,3 +286,12 @@ def test_repeated_batches_are_identical():
         bad = torch.nonzero(digests() != ref).flatten().tolist()
         assert not bad, f"run {k + 1}: images {bad[:8]} differ from the first run"
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,q", [(2429, 20), (2928, 20), (3254, 20), (9205, 23), (9787, 23), (5862, 18)])
+def test_chroma_rows_that_end_in_a_pair_mark(enc, oracle, seed, q):
+    """Images (found with tests/gpu_hazard_check.py) whose chroma mark walk takes a pair mark in the last column of a
+    row: from there on the reference compares against cll1 one cell further on (nhw_encoder.c:2372-2427)."""
+    im = oracle.synth(seed)
+    assert enc.encode(im[None], q)[0] == oracle.encode(im, q)
