@@ -448,13 +448,15 @@ DEV void tag_small_runs_par(Ctx *c, int tid, int16_t *lds)
  * recon sample / LL1 cell of row r (row strides ps / os: the planes themselves, an LDS tile, or a packed copy of
  * the column), lh at the LH1 coefficient the step may nudge, lhm1 is the one before it (as this walk left it).
  * sp / so: where the right-hand neighbour column is read (the values from before the pass). */
+template <bool NB_TILE>
 DEV void classify_step(int q, int res_setting, int r, int j, int16_t *pr, int ps, int16_t *orow, int os, int16_t *lh, int lhm1,
                        const int16_t *sp, int sp_row, const int16_t *so, int so_rows)
 {
 	int16_t *cell = orow;
 	const int res = pr[0] - orow[0], a = pr[ps] - orow[os];
 	const int d2 = pr[2 * ps] - orow[2 * os];
-#define NB(dr) (sp[(r + (dr)) * sp_row + j + 1] - ((r + (dr)) < so_rows ? so[(r + (dr)) * H + j + 1] : 0))
+	/* NB_TILE: sp points at the neighbour's (recon - ll1) difference of row r, as it was before the pass, row stride sp_row */
+#define NB(dr) (NB_TILE ? (int)sp[(dr) * sp_row] : (sp[(r + (dr)) * sp_row + j + 1] - ((r + (dr)) < so_rows ? so[(r + (dr)) * H + j + 1] : 0)))
 #define MARK(code, step) do { *cell = (code); pr[ps] += (step); pr[2 * ps] += (step); } while (0)
 #define SNAP(code) do { *cell = (code); pr[ps] = orow[os]; } while (0)
 #define NUDGE_UP() do { if (lh[0] == 7) { if (lhm1 >= 0 && lhm1 < 8) lh[0] += 2; } else if (lh[0] == 8) { if (lhm1 >= -2 && lhm1 < 8) lh[0] += 2; } } while (0)
@@ -537,40 +539,37 @@ DEV void classify_step(int q, int res_setting, int r, int j, int16_t *pr, int ps
 
 /* Y22.  The reference walks column after column; column j only reads column j+1 (not yet visited, i.e. its
  * original values) and the recon sample (j,255) of the last column.  Columns 0..254 therefore run in parallel,
- * one thread each, against a snapshot of the recon plane (rows 0..256) and of ll1 for the neighbour reads.
- * A column's walk is a chain (a step rewrites the two samples below it and reads what the step before left),
- * so it runs on LDS: per chunk of CR rows every thread copies its own column's samples and LL1 cells into a
- * tile (coalesced, no barrier needed for those), the LH1 coefficients -- row j of the plane for column j --
- * come through a transposing tile.  Column 255 runs afterwards on a packed LDS copy of its column: its "column
- * 256" is the LH1 column written by the other columns, its ll1 neighbour is column 0, both read live. */
+ * one thread each.  A column's walk is a chain (a step rewrites the two samples below it and reads what the
+ * step before left), so it runs on LDS: per chunk of CR rows every thread copies its own column's samples and
+ * LL1 cells into a tile (coalesced, no barrier needed for those), the LH1 coefficients -- row j of the plane for
+ * column j -- come through a transposing tile.  What a column reads of its right-hand neighbour is the
+ * difference recon - ll1 from before the pass: a third tile, filled from the values as loaded (a chunk's rows
+ * from the third on are still untouched; the first three are carried over from the chunk before).  Column 255
+ * runs afterwards on a packed LDS copy of its column: its "column 256" is the LH1 column written by the other
+ * columns, its ll1 neighbour is column 0, both read live. */
 #define CR 16
-#define CR_LDS_BYTES (((CR + 3) * 2 * H + H * (CR + 2)) * 2)
+#define CR_LDS_BYTES (((CR + 3) * 3 * H + H * (CR + 2)) * 2)
 DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 {
 	int16_t *p = c->proc, *o = c->ll1;
-	int16_t *snap_p = c->hs, *snap_o = c->band;
 	const int q = c->q;
-	for (int idx = tid; idx < (H + 1) * (H / 4); idx += NT) {       /* rows 0..256 x cols 0..255 of proc */
-		const int r = idx / (H / 4), k = idx % (H / 4);
-		reinterpret_cast<uint2 *>(snap_p + r * H)[k] = reinterpret_cast<const uint2 *>(p + r * W)[k];
-	}
-	for (int idx = tid; idx < Q / 4; idx += NT) reinterpret_cast<uint2 *>(snap_o)[idx] = reinterpret_cast<const uint2 *>(o)[idx];
-	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *lt = lds + 2 * (CR + 3) * H;   /* pt/ot: rows r0-1 .. r0+CR+1; lt: [column][CR + 2] */
+	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *dt = lds + 2 * (CR + 3) * H, *lt = lds + 3 * (CR + 3) * H;   /* pt/ot/dt: rows r0-1 .. r0+CR+1; lt: [column][CR + 2] */
 	const int j = tid;
 	int lhm1 = p[j * W + H - 1];                                    /* (j, 255): nothing has touched it yet */
-	BARRIER();
 	for (int r0 = 0; r0 < H - 1; r0 += CR) {
+		if (r0) for (int i = 0; i < 3; i++) dt[i * H + j] = dt[(i + CR) * H + j];
 		for (int i = 0; i < CR + 3; i++) {
 			const int row = r0 - 1 + i;
-			pt[i * H + j] = row >= 0 ? p[row * W + j] : 0;
-			ot[i * H + j] = row >= 0 ? o[row * H + j] : 0;            /* rows 256, 257 of ll1 lie in its zero guard */
+			const int16_t pv = row >= 0 ? p[row * W + j] : 0, ov = row >= 0 ? o[row * H + j] : 0;   /* rows 256, 257 of ll1 lie in its zero guard */
+			pt[i * H + j] = pv; ot[i * H + j] = ov;
+			if (!r0 || i >= 3) dt[i * H + j] = (int16_t)(pv - ov);
 		}
 		for (int idx = tid; idx < H * CR; idx += NT) lt[(idx / CR) * (CR + 2) + idx % CR] = p[(idx / CR) * W + H + r0 + idx % CR];
 		BARRIER();
 		if (j < H - 1)
 			for (int i = 0; i < CR && r0 + i < H - 1; i++) {
 				int16_t *lh = lt + j * (CR + 2) + i;
-				classify_step(q, res_setting, r0 + i, j, pt + (i + 1) * H + j, H, ot + (i + 1) * H + j, H, lh, lhm1, snap_p, H, snap_o, H);
+				classify_step<true>(q, res_setting, r0 + i, j, pt + (i + 1) * H + j, H, ot + (i + 1) * H + j, H, lh, lhm1, dt + (i + 1) * H + j + 1, H, nullptr, 0);
 				lhm1 = lh[0];
 			}
 		BARRIER();
@@ -591,7 +590,7 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 		if (tid == 0) {
 			int prev = p[(H - 1) * W + H - 1];
 			for (int r = 0; r < H - 1; r++) {
-				classify_step(q, res_setting, r, H - 1, pc + r, 1, oc + r, 1, lc + r, prev, p, W, o, 1 << 30);
+				classify_step<false>(q, res_setting, r, H - 1, pc + r, 1, oc + r, 1, lc + r, prev, p, W, o, 1 << 30);
 				if (r == 0) p[(H - 1) * W + H] = lc[0];                /* (255, 256) is also this column's "column 256" neighbour of row 255 */
 				prev = lc[r];
 			}
@@ -610,7 +609,7 @@ DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 {
 	int16_t *p = c->proc, *o = c->ll1;
 	const int q = c->q, j = tid;
-	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *lt = lds + 2 * (CR + 3) * H;
+	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *lt = lds + 3 * (CR + 3) * H;
 	int vm1 = p[j * W + H - 1];
 	for (int r0 = 0; r0 < H; r0 += CR) {
 		for (int i = 0; i < CR; i++) { pt[i * H + j] = p[(r0 + i) * W + j]; ot[i * H + j] = o[(r0 + i) * H + j]; }
