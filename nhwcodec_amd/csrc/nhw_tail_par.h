@@ -557,14 +557,31 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 	const int j = tid;
 	int lhm1 = p[j * W + H - 1];                                    /* (j, 255): nothing has touched it yet */
 	for (int r0 = 0; r0 < H - 1; r0 += CR) {
-		if (r0) for (int i = 0; i < 3; i++) dt[i * H + j] = dt[(i + CR) * H + j];
-		for (int i = 0; i < CR + 3; i++) {
-			const int row = r0 - 1 + i;
-			const int16_t pv = row >= 0 ? p[row * W + j] : 0, ov = row >= 0 ? o[row * H + j] : 0;   /* rows 256, 257 of ll1 lie in its zero guard */
-			pt[i * H + j] = pv; ot[i * H + j] = ov;
-			if (!r0 || i >= 3) dt[i * H + j] = (int16_t)(pv - ov);
+		if (r0) {                                                   /* the first three rows' differences are the last three of the chunk before */
+			uint4 keep = make_uint4(0, 0, 0, 0);
+			if (tid < 3 * (H / 8)) keep = reinterpret_cast<const uint4 *>(dt + CR * H)[tid];
+			BARRIER();
+			if (tid < 3 * (H / 8)) reinterpret_cast<uint4 *>(dt)[tid] = keep;
 		}
-		for (int idx = tid; idx < H * CR; idx += NT) lt[(idx / CR) * (CR + 2) + idx % CR] = p[(idx / CR) * W + H + r0 + idx % CR];
+		for (int v = tid; v < (CR + 3) * (H / 8); v += NT) {          /* 8 columns of one row per access */
+			const int i = v / (H / 8), c8 = 8 * (v % (H / 8)), row = r0 - 1 + i;
+			uint4 pv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+			if (row >= 0) { pv = *reinterpret_cast<const uint4 *>(p + row * W + c8); ov = *reinterpret_cast<const uint4 *>(o + row * H + c8); }   /* rows 256, 257 of ll1 lie in its zero guard */
+			*reinterpret_cast<uint4 *>(pt + i * H + c8) = pv;
+			*reinterpret_cast<uint4 *>(ot + i * H + c8) = ov;
+			if (!r0 || i >= 3) {
+				const uint32_t a[4] = { pv.x, pv.y, pv.z, pv.w }, b[4] = { ov.x, ov.y, ov.z, ov.w };
+				uint32_t d[4];
+				for (int e = 0; e < 4; e++) d[e] = ((a[e] - b[e]) & 0xFFFF) | (((a[e] >> 16) - (b[e] >> 16)) << 16);
+				*reinterpret_cast<uint4 *>(dt + i * H + c8) = make_uint4(d[0], d[1], d[2], d[3]);
+			}
+		}
+		for (int v = tid; v < H * (CR / 8); v += NT) {
+			const int jj = v / (CR / 8), h = v % (CR / 8);
+			const uint4 x = *reinterpret_cast<const uint4 *>(p + jj * W + H + r0 + 8 * h);
+			uint32_t *d = reinterpret_cast<uint32_t *>(lt + jj * (CR + 2) + 8 * h);
+			d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+		}
 		BARRIER();
 		if (j < H - 1)
 			for (int i = 0; i < CR && r0 + i < H - 1; i++) {
@@ -573,13 +590,16 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 				lhm1 = lh[0];
 			}
 		BARRIER();
-		if (j < H - 1)
-			for (int i = 1; i < CR + 3; i++) {
-				const int row = r0 - 1 + i;
-				p[row * W + j] = pt[i * H + j];
-				if (row < H) o[row * H + j] = ot[i * H + j];
-			}
-		for (int idx = tid; idx < H * CR; idx += NT) p[(idx / CR) * W + H + r0 + idx % CR] = lt[(idx / CR) * (CR + 2) + idx % CR];
+		for (int v = tid; v < (CR + 2) * (H / 8); v += NT) {          /* column 255 travels too, unchanged */
+			const int i = 1 + v / (H / 8), c8 = 8 * (v % (H / 8)), row = r0 - 1 + i;
+			*reinterpret_cast<uint4 *>(p + row * W + c8) = *reinterpret_cast<const uint4 *>(pt + i * H + c8);
+			if (row < H) *reinterpret_cast<uint4 *>(o + row * H + c8) = *reinterpret_cast<const uint4 *>(ot + i * H + c8);
+		}
+		for (int v = tid; v < H * (CR / 8); v += NT) {
+			const int jj = v / (CR / 8), h = v % (CR / 8);
+			const uint32_t *d = reinterpret_cast<const uint32_t *>(lt + jj * (CR + 2) + 8 * h);
+			*reinterpret_cast<uint4 *>(p + jj * W + H + r0 + 8 * h) = make_uint4(d[0], d[1], d[2], d[3]);
+		}
 		BARRIER();
 	}
 	{                                                              /* column 255 */
@@ -612,8 +632,17 @@ DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *lt = lds + 3 * (CR + 3) * H;
 	int vm1 = p[j * W + H - 1];
 	for (int r0 = 0; r0 < H; r0 += CR) {
-		for (int i = 0; i < CR; i++) { pt[i * H + j] = p[(r0 + i) * W + j]; ot[i * H + j] = o[(r0 + i) * H + j]; }
-		for (int idx = tid; idx < H * CR; idx += NT) lt[(idx / CR) * (CR + 2) + idx % CR] = p[(idx / CR) * W + H + r0 + idx % CR];
+		for (int v = tid; v < CR * (H / 8); v += NT) {
+			const int i = v / (H / 8), c8 = 8 * (v % (H / 8));
+			*reinterpret_cast<uint4 *>(pt + i * H + c8) = *reinterpret_cast<const uint4 *>(p + (r0 + i) * W + c8);
+			*reinterpret_cast<uint4 *>(ot + i * H + c8) = *reinterpret_cast<const uint4 *>(o + (r0 + i) * H + c8);
+		}
+		for (int v = tid; v < H * (CR / 8); v += NT) {
+			const int jj = v / (CR / 8), h = v % (CR / 8);
+			const uint4 x = *reinterpret_cast<const uint4 *>(p + jj * W + H + r0 + 8 * h);
+			uint32_t *d = reinterpret_cast<uint32_t *>(lt + jj * (CR + 2) + 8 * h);
+			d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+		}
 		BARRIER();
 		for (int i = 0; i < CR; i++) {
 			int16_t *cell = ot + i * H + j;
@@ -654,8 +683,15 @@ DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 			vm1 = v[0];
 		}
 		BARRIER();
-		for (int i = 0; i < CR; i++) o[(r0 + i) * H + j] = ot[i * H + j];
-		for (int idx = tid; idx < H * CR; idx += NT) p[(idx / CR) * W + H + r0 + idx % CR] = lt[(idx / CR) * (CR + 2) + idx % CR];
+		for (int v = tid; v < CR * (H / 8); v += NT) {
+			const int i = v / (H / 8), c8 = 8 * (v % (H / 8));
+			*reinterpret_cast<uint4 *>(o + (r0 + i) * H + c8) = *reinterpret_cast<const uint4 *>(ot + i * H + c8);
+		}
+		for (int v = tid; v < H * (CR / 8); v += NT) {
+			const int jj = v / (CR / 8), h = v % (CR / 8);
+			const uint32_t *d = reinterpret_cast<const uint32_t *>(lt + jj * (CR + 2) + 8 * h);
+			*reinterpret_cast<uint4 *>(p + jj * W + H + r0 + 8 * h) = make_uint4(d[0], d[1], d[2], d[3]);
+		}
 		BARRIER();
 	}
 }
