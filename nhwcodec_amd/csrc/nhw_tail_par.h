@@ -1128,7 +1128,33 @@ DEV void dequant_sim_chroma_par(Ctx *c, int comp, int tid)
 			else { jp[i] = clear_bit0(p[i]); jp[i + 1] = p[i + 1]; }
 		} else jp[i] = (p[i] > 0 && p[i] < 256) ? clear_bit0(p[i]) : p[i];
 	}
-	if (tid < H / 2) dequant_row_chroma(p, jp, tid, tid < H / 4 ? H / 4 : 0, comp);
+	/* detail rows: one wavefront per row, lane l owns columns l and l + 64; the -7/-8 pairs of the second loop are a
+	 * walk that skips the partner (alt_runs on "pair starts here"), everything else is a stencil on the untouched plane */
+	const int lane = tid & 63, wv = tid >> 6;
+	for (int r = wv; r < H / 2; r += 4) {
+		const int col0 = r < H / 4 ? H / 4 : 0;
+		int v[3];
+		v[0] = col0 ? 0 : p[r * H + lane]; v[1] = p[r * H + 64 + lane]; v[2] = p[r * H + 128 + lane];   /* the last cell looks at column 128 */
+		uint64_t pair[2] = { 0, 0 };
+		if (!comp) {
+			const uint64_t m0 = __ballot(v[0] == -7 || v[0] == -8), m1 = __ballot(v[1] == -7 || v[1] == -8);
+			const M4 m = M4{ { col0 ? 0 : m0, m1, 0, 0 } };
+			const M4 fired = alt_runs(m & dn1(m) & col_range(col0, H / 2 - 2));
+			const M4 both = fired | up1(fired);
+			pair[0] = both.w[0]; pair[1] = both.w[1];
+		}
+		for (int k = col0 ? 1 : 0; k < 2; k++) {
+			int a = v[k];
+			const int nx = right_of(v, k, 3, 1, lane);
+			if (a < 0) {
+				a = -a;
+				if (nx < 0 && nx > -8) { if ((a & 7) < 6) a &= 0xFFF8; }
+				else { if ((a & 7) < 7) a &= 0xFFF8; }
+				a = -a;
+			}
+			jp[r * H + lane + 64 * k] = (int16_t)(((pair[k] >> lane) & 1) ? -11 : dequant_value(a));
+		}
+	}
 }
 
 /* Y14 + Y15 (nhw_encoder.c:636-741): tag rows of four odd samples (R), walk the LL2 band (wavefront), then turn
