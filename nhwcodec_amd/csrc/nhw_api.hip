@@ -17,7 +17,8 @@
 /* launchers (nhw_front.hip, nhw_tail.hip) */
 void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_stride, uint8_t *u, uint8_t *v, size_t c_stride, hipStream_t s);
 void nhw_launch_prefilter(int16_t *y, size_t y_stride, int16_t *kmap, size_t k_stride, uint64_t *maps, size_t m_stride, uint8_t *st, size_t s_stride, int n, hipStream_t s);
-void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, int16_t *keep, size_t keep_stride, hipStream_t s);
+void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, int16_t *keep, size_t keep_stride, hipStream_t s,
+                         int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0);
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s);
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
 void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilter, uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
@@ -162,9 +163,8 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	STAGE_DONE();
 	nhw_launch_phase(PH_L2, ws, 0, out, d_sizes, d_status, s);
 	STAGE_DONE();
-	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
+	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s, plane16(ws, B_L2SAVE), ws.stride[B_L2SAVE] / 2, H, 1);   /* + Y13 (:623-631): copy of the coefficient block */
 	STAGE_DONE();
-	nhw_launch_copy_block(proc, ps, W, plane16(ws, B_L2SAVE), ws.stride[B_L2SAVE] / 2, H, H, H, n, s);   /* Y13 (:623-631) */
 	STAGE_DONE();
 	nhw_launch_wave(WV_EMIT, ws, s);                                 /* Y14, Y15 */
 	nhw_launch_phase(PH_L3, ws, 0, out, d_sizes, d_status, s);
@@ -184,9 +184,8 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	for (int comp = 0; comp < 2; comp++) {           /* U then V (:2255-2570, :2572-2868) */
 		nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, s);
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, nullptr, 0, s);
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, nullptr, 0, s, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2);   /* + the copy of LL1 */
 		STAGE_DONE();
-		nhw_launch_copy_block(cjpeg, cps, H, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, H / 2, H / 2, n, s);
 		STAGE_DONE();
 		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, s);
 		STAGE_DONE();
@@ -196,9 +195,8 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 		STAGE_DONE();
 		nhw_launch_phase(PH_C3, ws, comp, out, d_sizes, d_status, s);
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, s);
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, s, plane16(ws, B_CL2SAVE), ws.stride[B_CL2SAVE] / 2, H / 2, 1);   /* + the copy of the level-2 block */
 		STAGE_DONE();
-		nhw_launch_copy_block(cproc, cps, H, plane16(ws, B_CL2SAVE), ws.stride[B_CL2SAVE] / 2, H / 2, H / 2, H / 2, n, s);
 		STAGE_DONE();
 		nhw_launch_phase(PH_C4, ws, comp, out, d_sizes, d_status, s);
 		STAGE_DONE();

@@ -822,13 +822,15 @@ __device__ __forceinline__ int pair_predict_s(const int16_t *x, int st, int k)
 }
 
 template <int S>
-__global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int final_level)
+__global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int final_level,
+                                                   int16_t *__restrict__ saveb, size_t save_plane, int save_row, int save_kind /* 1: copy of the S x S coefficient block, 2: of the LL quadrant copied back */)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4;
 	const int img = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	int16_t *jpeg = jpegb + (size_t)img * plane_stride, *proc = procb + (size_t)img * plane_stride;
 	int16_t *A = smem;
+	int16_t *save = saveb ? saveb + (size_t)img * save_plane : nullptr;
 	for (int v = t; v < S * (S / 8); v += NT_) {
 		const int row = v / (S / 8), o = v % (S / 8);
 		const uint4 x = *reinterpret_cast<const uint4 *>(jpeg + (size_t)row * stride + 8 * o);
@@ -878,6 +880,7 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 		for (int u = 0; u < PPL; u++) {
 			const int k = lane + 64 * u;
 			o[k] = (int16_t)lo[u]; o[HLF + k] = (int16_t)hi[u];
+			if (save_kind == 1) { save[(size_t)c * save_row + k] = (int16_t)lo[u]; save[(size_t)c * save_row + HLF + k] = (int16_t)hi[u]; }
 			if (!final_level && c < HLF) x[k * LS] = (int16_t)lo[u];  /* LL, parked in the column's own cells */
 		}
 	}
@@ -885,7 +888,9 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 	__syncthreads();
 	for (int v = t; v < HLF * (HLF / 2); v += NT_) {               /* LL copied back in natural orientation (wavelet_filterbank.c:172-184) */
 		const int k = v / (HLF / 2), c = 2 * (v % (HLF / 2));
-		*reinterpret_cast<uint32_t *>(jpeg + (size_t)k * stride + c) = (uint16_t)A[k * LS + c] | ((uint32_t)(uint16_t)A[k * LS + c + 1] << 16);
+		const uint32_t w = (uint16_t)A[k * LS + c] | ((uint32_t)(uint16_t)A[k * LS + c + 1] << 16);
+		*reinterpret_cast<uint32_t *>(jpeg + (size_t)k * stride + c) = w;
+		if (save_kind == 2) *reinterpret_cast<uint32_t *>(save + (size_t)k * save_row + c) = w;
 	}
 }
 
@@ -966,11 +971,16 @@ static void dwt_lds_attr()
 	done = true;
 }
 
+void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
+
+/* save (optional): a second destination for the block the reference copies right after the transform -- the S x S coefficient block
+ * (save_kind 1) or the LL quadrant in natural orientation (save_kind 2) -- written by the fused kernels, by a block copy otherwise */
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level,
-                         int16_t *keep, size_t keep_stride, hipStream_t s)
+                         int16_t *keep, size_t keep_stride, hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind)
 {
-	if (size == 256 && !keep) { dwt_lds_attr<256>(); k_dwt_ana<256><<<n, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level); return; }
-	if (size == 128 && !keep) { dwt_lds_attr<128>(); k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level); return; }
+	if (!save) save_kind = 0;
+	if (size == 256 && !keep) { dwt_lds_attr<256>(); k_dwt_ana<256><<<n, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind); return; }
+	if (size == 128 && !keep) { dwt_lds_attr<128>(); k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind); return; }
 	const int hlf = size >> 1;
 	const dim3 rg((hlf + 255) / 256, size, n), tg((size + 63) / 64, (size + 63) / 64, n);
 	k_ana_rows<1><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
@@ -982,6 +992,8 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
 		const dim3 lg((hlf + 63) / 64, (hlf + 63) / 64, n);
 		k_transpose<<<lg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, hlf);
 	}
+	if (save_kind == 1) nhw_launch_copy_block(proc, plane_stride, stride, save, save_plane, save_row, size, size, n, s);
+	else if (save_kind == 2) nhw_launch_copy_block(jpeg, plane_stride, stride, save, save_plane, save_row, hlf, hlf, n, s);
 }
 
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s)
