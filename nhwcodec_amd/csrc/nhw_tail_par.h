@@ -1316,58 +1316,71 @@ DEV void poslist_finish_par(Ctx *c, PosList *pl, const uint8_t *raw, int n, cons
 	BARRIER();
 }
 
-struct PosListF {
-	int pass, write;
-	uint8_t *raw, *pay;
-	const int *off_raw, *off_pay;
-	struct State { int n, e; };
-	__device__ State init(int t) const { return write ? State{ off_raw[t], off_pay[t] } : State{ 0, 0 }; }
-	__device__ int run(int16_t *row, int, int j, int j1, State &st) const
-	{
-		for (; j < j1; j++) {
-			const int v = row[j];
-			int payload = -1, keep = 0;
-			if (pass == 0) {
-				if (v == 141) payload = 1; else if (v == 140) payload = 0;
-				else if (v == 126) { payload = 0; keep = 122; } else if (v == 125) { payload = 1; keep = 121; }
-				else if (v == 148) { payload = 1; keep = 144; } else if (v == 149) { payload = 0; keep = 145; }
-			} else if (pass == 1) {
-				if (v == 121) payload = 1; else if (v == 122) payload = 0; else if (v == 123) payload = 2; else if (v == 124) payload = 3;
-			} else { if (v == 144) payload = 1; else if (v == 145) payload = 0; }
-			if (payload >= 0) {
-				if (write) { raw[st.n] = (uint8_t)j; pay[st.e] = (uint8_t)payload; row[j] = (int16_t)keep; }
-				st.n++; st.e++;
-			}
-		}
-		return j;
-	}
-};
+/* Y25 (nhw_encoder.c:1498-1763): three filters over the LL1 tag plane, each collecting (column, payload) of its
+ * codes row by row behind a row marker, and leaving a follow-up code for the next filter in some cells.  A cell's
+ * fate through the three filters depends on the cell alone, so one sweep evaluates all three: one wavefront per
+ * row (lane l owns columns l + 64k), match masks by ballot, a count sweep, prefix sums over the rows, a write sweep. */
+DEV int poslist_match(int pass, int v, int *payload, int *keep)
+{
+	*keep = 0;
+	if (pass == 0) {
+		if (v == 141) { *payload = 1; return 1; } if (v == 140) { *payload = 0; return 1; }
+		if (v == 126) { *payload = 0; *keep = 122; return 1; } if (v == 125) { *payload = 1; *keep = 121; return 1; }
+		if (v == 148) { *payload = 1; *keep = 144; return 1; } if (v == 149) { *payload = 0; *keep = 145; return 1; }
+	} else if (pass == 1) {
+		if (v >= 121 && v <= 124) { *payload = v == 121 ? 1 : v == 122 ? 0 : v == 123 ? 2 : 3; return 1; }
+	} else { if (v == 144) { *payload = 1; return 1; } if (v == 145) { *payload = 0; return 1; } }
+	return 0;
+}
 DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 {
 	int16_t *o = c->ll1;
-	uint8_t *raw = c->raw, *pay = c->pay;
-	int *off_raw = pos, *off_pay = pos + NT + 1;                  /* shared [2 * NT + 2] */
-	for (int pass = 0; pass < 3; pass++) {
-		if ((pass == 1 && c->q < 19) || (pass == 2 && c->q < 21)) continue;
-		PosListF fc = { pass, 0, raw, pay, off_raw, off_pay };
-		PosListF::State cnt;
-		row_pass_tiled(o, H, H, H, 0, H, 0, H - 2, lds, tid, fc, &cnt);
-		off_raw[tid] = cnt.n + 1; off_pay[tid] = cnt.e;          /* + the row marker at column 254 */
-		BARRIER();
-		if (tid == 0) {
-			int a = 0, b = 0;
-			for (int t = 0; t < NT; t++) { const int x = off_raw[t], y = off_pay[t]; off_raw[t] = a; off_pay[t] = b; a += x; b += y; }
-			off_raw[NT] = a; off_pay[NT] = b;
+	const int q = c->q, lane = tid & 63, wv = tid >> 6;
+	const int npass = q >= 21 ? 3 : (q >= 19 ? 2 : 1);
+	uint8_t *raw[3] = { c->raw, c->raw + Q + 512, reinterpret_cast<uint8_t *>(c->hs) };
+	uint8_t *pay[3] = { c->pay, c->pay + Q, reinterpret_cast<uint8_t *>(c->hs) + Q + 512 };
+	int *cnt = reinterpret_cast<int *>(lds);                      /* [3][H] matches per row, then their exclusive prefix */
+	unsigned *shm = reinterpret_cast<unsigned *>(lds) + 3 * H;
+	unsigned total[3] = { 0, 0, 0 };
+	for (int sweep = 0; sweep < 2; sweep++) {
+		for (int r = wv; r < H; r += 4) {
+			int v[4];
+			for (int k = 0; k < 4; k++) v[k] = o[r * H + lane + 64 * k];
+			if (lane >= 62) v[3] = 0;                               /* columns 254, 255 take no part and are cleared */
+			for (int pass = 0; pass < npass; pass++) {
+				int pl[4], kp[4];
+				uint64_t m[4];
+				for (int k = 0; k < 4; k++) m[k] = __ballot(poslist_match(pass, v[k], &pl[k], &kp[k]));
+				const int n = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+				if (!sweep) { if (lane == 0) cnt[pass * H + r] = n; }
+				else {
+					const int base = cnt[pass * H + r];               /* matches in the rows above */
+					int before = 0;
+					for (int k = 0; k < 4; k++) {
+						if ((m[k] >> lane) & 1) {
+							const int at = base + before + __popcll(m[k] & low_bits(lane));
+							raw[pass][at + r] = (uint8_t)(lane + 64 * k); pay[pass][at] = (uint8_t)pl[k];     /* r markers precede this row's entries */
+						}
+						before += __popcll(m[k]);
+					}
+					if (lane == 0) raw[pass][base + n + r] = H - 2;
+				}
+				for (int k = 0; k < 4; k++) if ((m[k] >> lane) & 1) v[k] = kp[k];
+			}
+			if (sweep) for (int k = 0; k < 4; k++) o[r * H + lane + 64 * k] = (int16_t)v[k];
 		}
 		BARRIER();
-		PosListF fw = { pass, 1, raw, pay, off_raw, off_pay };
-		PosListF::State end;
-		row_pass_tiled(o, H, H, H, 0, H, 0, H - 2, lds, tid, fw, &end);
-		o[tid * H + H - 2] = 0; o[tid * H + H - 1] = 0; raw[end.n] = H - 2;
-		BARRIER();
-		poslist_finish_par(c, pass == 0 ? &c->res1 : pass == 1 ? &c->res3 : &c->res5, raw, off_raw[NT], pay, off_pay[NT], pass == 1 ? 2 : 1, tid,
-		                   reinterpret_cast<unsigned *>(lds));
+		if (!sweep) {
+			for (int pass = 0; pass < npass; pass++) {
+				const unsigned ex = block_exscan((unsigned)cnt[pass * H + tid], tid, shm, &total[pass]);
+				BARRIER();
+				cnt[pass * H + tid] = (int)ex;
+			}
+			BARRIER();
+		}
 	}
+	for (int pass = 0; pass < npass; pass++)
+		poslist_finish_par(c, pass == 0 ? &c->res1 : pass == 1 ? &c->res3 : &c->res5, raw[pass], (int)total[pass] + H, pay[pass], (int)total[pass], pass == 1 ? 2 : 1, tid, shm);
 }
 
 /* ---------------------------------------------------------------- phases (256 threads per image) */
