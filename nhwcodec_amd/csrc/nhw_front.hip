@@ -403,6 +403,7 @@ __global__ __launch_bounds__(256) void k_syn_rows(const int16_t *__restrict__ sr
 #define FB_TROWS (2 * FB_KB + 5)    /* horizontal-pass rows a band needs: 2k0-4 .. 2k0+32 */
 #define FB_YROWS (FB_TROWS + 2)
 #define FB_RS 514                   /* padded LDS row stride (shorts) */
+#define FB_NT 512                   /* threads per band: the 78 KB of LDS allow two bands per CU, eight wavefronts each keep the SIMDs fed */
 
 __device__ __forceinline__ int contrast_at(const int16_t *p /* LDS, row stride FB_RS */)
 {
@@ -528,7 +529,7 @@ __device__ unsigned long long g_band_stamp[16];
 #define STAMP(i) do { if (t == 0 && blockIdx.x == 7 && blockIdx.y == 100) g_band_stamp[i] = wall_clock64(); } while (0)
 
 template <int PRE>
-__global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ yb, size_t y_stride, const uint8_t *__restrict__ st, size_t s_stride,
+__global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict__ yb, size_t y_stride, const uint8_t *__restrict__ st, size_t s_stride,
                                                     const uint64_t *__restrict__ segmaps, size_t g_stride,
                                                     int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
                                                     int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride)
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 	const int16_t *y = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
 
 	STAMP(0);
-	for (int k = t; k < FB_YROWS * (W / 8); k += 256) {            /* stage rows t0-1 .. t0+37 */
+	for (int k = t; k < FB_YROWS * (W / 8); k += FB_NT) {            /* stage rows t0-1 .. t0+37 */
 		const int ry = k / (W / 8), o = k % (W / 8), row = t0 - 1 + ry;
 		uint4 v = make_uint4(0, 0, 0, 0);
 		if (row >= 0 && row < W) v = reinterpret_cast<const uint4 *>(y + (size_t)row * W)[o];
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 	}
 	uint64_t *segl = reinterpret_cast<uint64_t *>(kbuf);           /* kbuf is free until the contrast pass: it hosts the segment maps first */
 	if (PRE) {                                                     /* the rows' segment maps and entry states ride along with the luma rows */
-		for (int k = t; k < FB_TROWS * 16; k += 256) {
+		for (int k = t; k < FB_TROWS * 16; k += FB_NT) {
 			const int row = t0 + (k >> 4);
 			if (row >= 1 && row <= W - 2) segl[k] = ((const uint64_t *)((const uint8_t *)segmaps + (size_t)img * g_stride))[16 * (size_t)row + (k & 15)];
 		}
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 		__syncthreads();
 		/* items are (row, 8-pixel group) with the row index fastest: consecutive lanes sit one padded row (257
 		 * dwords) apart, i.e. on consecutive LDS banks */
-		for (int k = t; k < FB_TROWS * (W / 8); k += 256) {        /* contrast, 8 pixels per item */
+		for (int k = t; k < FB_TROWS * (W / 8); k += FB_NT) {        /* contrast, 8 pixels per item */
 			const int rt = k % FB_TROWS, c0 = 8 * (k / FB_TROWS), row = t0 + rt;
 			uint32_t out[4] = { 0, 0, 0, 0 };
 			if (row >= 1 && row <= W - 2) {
@@ -602,8 +603,8 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 		STAMP(2);
 		/* one lane per (row, 64-pixel segment), eight pixels at a time through registers (small loop bodies: a
 		 * fully unrolled 64-step version overflows the instruction cache and runs 10x slower) */
-		for (int it = 0; it < 2; it++) {                           /* replay the carry */
-			const int k = t + 256 * it;
+		for (int it = 0; it < (FB_TROWS * 8 + FB_NT - 1) / FB_NT; it++) {   /* replay the carry */
+			const int k = t + FB_NT * it;
 			const int rt = k % FB_TROWS, sg = k / FB_TROWS, row = t0 + rt;
 			if (k >= FB_TROWS * 8 || row < 1 || row > W - 2) continue;
 			int16_t *km = kbuf + rt * FB_RS + 1 + 64 * sg;         /* segment pixel 0 = column 1 + 64 sg */
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 		}
 		__syncthreads();
 		STAMP(3);
-		for (int k = t; k < FB_TROWS * 64; k += 256) {             /* pair rules: four pairs (8 pixels) per item, no serial dependence left */
+		for (int k = t; k < FB_TROWS * 64; k += FB_NT) {             /* pair rules: four pairs (8 pixels) per item, no serial dependence left */
 			const int rt = k % FB_TROWS, g = k / FB_TROWS, row = t0 + rt;
 			if (row < 1 || row > W - 2) continue;
 			const int16_t *km = kbuf + rt * FB_RS + 8 * g;         /* pairs (8g+1, 8g+2) .. (8g+7, 8g+8) */
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 		STAMP(4);
 	}
 
-	for (int k = t; k < FB_TROWS * 64; k += 256) {                 /* horizontal pass (filters.c:346-386) into kbuf, four kx per item */
+	for (int k = t; k < FB_TROWS * 64; k += FB_NT) {                 /* horizontal pass (filters.c:346-386) into kbuf, four kx per item */
 		const int rt = k % FB_TROWS, g = k / FB_TROWS, row = t0 + rt;
 		if (row < 0 || row >= W) continue;
 		int x[12];
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 	int16_t *ll1 = ll1b + (size_t)img * ll1_stride;
 	if (keepb) {                                                   /* q>=22: transposed horizontal-pass plane, rows kx < 256 (wavelet_filterbank.c:107-112) */
 		int16_t *keep = keepb + (size_t)img * keep_stride;
-		for (int k = t; k < H * 4; k += 256) {
+		for (int k = t; k < H * 4; k += FB_NT) {
 			const int kx = k >> 2, part = k & 3;                   /* 8 of this band's 32 own rows */
 			uint32_t v[4];
 			for (int e = 0; e < 4; e++) {
@@ -692,8 +693,8 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 			*reinterpret_cast<uint4 *>(keep + (size_t)kx * W + 2 * k0 + 8 * part) = make_uint4(v[0], v[1], v[2], v[3]);
 		}
 	}
-	for (int cc = 0; cc < 2; cc++) {                               /* vertical pass: column c, outputs ky = k0 .. k0+15 */
-		const int c = t + 256 * cc;
+	for (int cc = 0; cc < W / FB_NT; cc++) {                       /* vertical pass: column c, outputs ky = k0 .. k0+15 */
+		const int c = t + FB_NT * cc;
 		int16_t col[FB_TROWS];                                     /* col[i] = pass-1 row t0+i, symmetric extension x[-j]=x[j], x[511+j]=x[511-j] */
 #pragma unroll
 		for (int rt = 0; rt < FB_TROWS; rt++) {
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(256) void k_front_band(const int16_t *__restrict__ 
 	}
 	__syncthreads();
 	STAMP(6);
-	for (int k = t; k < FB_KB * (H / 2); k += 256) {               /* jpeg[ky][kx] and ll1[ky][kx], kx < 256 (wavelet_filterbank.c:172-184, nhw_encoder.c:127-135) */
+	for (int k = t; k < FB_KB * (H / 2); k += FB_NT) {               /* jpeg[ky][kx] and ll1[ky][kx], kx < 256 (wavelet_filterbank.c:172-184, nhw_encoder.c:127-135) */
 		const int kk = k >> 7, o = k & 127;
 		const uint32_t v = (uint16_t)ybuf[kk * FB_RS + 2 * o] | ((uint32_t)(uint16_t)ybuf[kk * FB_RS + 2 * o + 1] << 16);
 		reinterpret_cast<uint32_t *>(jpeg + (size_t)(k0 + kk) * W)[o] = v;
@@ -1025,9 +1026,9 @@ void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilte
 	if (with_prefilter) {
 		k_front_rowmaps<<<grid, 256, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride, segmaps, g_stride);
 		k_front_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, flags, f_stride, st, s_stride, n);
-		k_front_band<1><<<grid, 256, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
+		k_front_band<1><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
 	} else
-		k_front_band<0><<<grid, 256, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
+		k_front_band<0><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
 }
 
 void nhw_debug_band_stamps(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(nhw::g_band_stamp), sizeof(unsigned long long) * 16); }
