@@ -451,9 +451,9 @@ __global__ __launch_bounds__(256) void k_front_rowmaps(const int16_t *__restrict
 			int u0 = p[-FB_RS + c0 - 1], u1 = p[-FB_RS + c0], m_0 = p[c0 - 1], m_1 = p[c0], d0 = p[FB_RS + c0 - 1], d1 = p[FB_RS + c0];
 			for (int c = c0; c <= c1; c++) {
 				const int u2 = p[-FB_RS + c + 1], m_2 = p[c + 1], d2 = p[FB_RS + c + 1];
-				const int e0 = m_1 - u0, e1 = m_1 - u1, e2 = m_1 - u2, e3 = m_1 - m_0, e4 = m_1 - m_2, e5 = m_1 - d0, e6 = m_1 - d1, e7 = m_1 - d2;
-				const int sum = e0 + e1 + e2 + e3 + e4 + e5 + e6 + e7;
-				const int mag = iabs(e0) + iabs(e1) + iabs(e2) + iabs(e3) + iabs(e4) + iabs(e5) + iabs(e6) + iabs(e7);
+				/* sum of the eight differences = 9 x centre - the 3x3 total; their magnitudes with the sum-of-absolute-differences instruction (luma is 0..255 here) */
+				const int sum = 9 * m_1 - (u0 + u1 + u2 + m_0 + m_1 + m_2 + d0 + d1 + d2);
+				const int mag = (int)__usad(m_1, u0, __usad(m_1, u1, __usad(m_1, u2, __usad(m_1, m_0, __usad(m_1, m_2, __usad(m_1, d0, __usad(m_1, d1, __usad(m_1, d2, 0u))))))));
 				const int base = 15 * iabs(sum) + mag;
 				const int vb = sum == 0 ? 0 : (sum < 0 ? -base : base);
 				if (c == W - 3) { a0 = m0; a1 = m1; v509 = vb; }
@@ -584,13 +584,15 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict_
 			if (row >= 1 && row <= W - 2) {
 				int up[12], md[12], dn[12];
 				row_window(ybuf + rt * FB_RS, c0, up); row_window(ybuf + (rt + 1) * FB_RS, c0, md); row_window(ybuf + (rt + 2) * FB_RS, c0, dn);
+				int s3[12];                                        /* column sums of the three rows, shared by the three windows a column is in */
+#pragma unroll
+				for (int i = 1; i < 11; i++) s3[i] = up[i] + md[i] + dn[i];
 #pragma unroll
 				for (int e = 0; e < 8; e++) {                      /* pixel c0+e sits at window index e+2 */
 					const int c = c0 + e, ctr = md[e + 2];
-					const int e0 = ctr - up[e + 1], e1 = ctr - up[e + 2], e2 = ctr - up[e + 3], e3 = ctr - md[e + 1], e4 = ctr - md[e + 3],
-					          e5 = ctr - dn[e + 1], e6 = ctr - dn[e + 2], e7 = ctr - dn[e + 3];
-					const int sum = e0 + e1 + e2 + e3 + e4 + e5 + e6 + e7;
-					const int mag = iabs(e0) + iabs(e1) + iabs(e2) + iabs(e3) + iabs(e4) + iabs(e5) + iabs(e6) + iabs(e7);
+					const int sum = 9 * ctr - (s3[e + 1] + s3[e + 2] + s3[e + 3]);   /* sum of the eight differences */
+					const int mag = (int)__usad(ctr, up[e + 1], __usad(ctr, up[e + 2], __usad(ctr, up[e + 3], __usad(ctr, md[e + 1], __usad(ctr, md[e + 3],
+					                __usad(ctr, dn[e + 1], __usad(ctr, dn[e + 2], __usad(ctr, dn[e + 3], 0u))))))));
 					const int base = 15 * iabs(sum) + mag;
 					const int vb = (sum == 0 || c < 1 || c > W - 2) ? 0 : (sum < 0 ? -base : base);
 					out[e >> 1] |= (uint32_t)(uint16_t)vb << (16 * (e & 1));
@@ -640,6 +642,10 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict_
 			int16_t v[10];
 #pragma unroll
 			for (int e = 0; e < 10; e++) v[e] = (g == 0 && e == 0) ? (int16_t)0 : km[e - 1];   /* columns 8g-1 .. 8g+8 */
+			int big = 0;                                            /* every rule needs a kernel value beyond +-10 */
+#pragma unroll
+			for (int e = 2; e < 10; e++) big |= iabs(v[e]) > 10;
+			if (!big) continue;
 			int prev_big = g ? pair_big_flag_fwd(v[0], v[1]) : ((stl[rt] >> 4) & 1);
 #pragma unroll
 			for (int e = 0; e < 4; e++) {
