@@ -276,11 +276,13 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 	int16_t *p = c->proc, *jp = c->jpeg;
 	int cur[4], nxt[4], pend_v[4] = { 0, 0, 0, 0 };
 	M4 pend = m4_zero();                                           /* jp cells of the current row the row above has set */
+	int q0[4], q1[4], q2[4];                                       /* rows r+2 .. r+4, already on their way (a row step is shorter than a memory round trip) */
 	det_load_row(p, 0, lane, cur);
 	det_load_row(p, 1, lane, nxt);
+	det_load_row(p, 2, lane, q0); det_load_row(p, 3, lane, q1); det_load_row(p, 4, lane, q2);
 	for (int r = 0; r < H; r++) {
 		int far[4];
-		det_load_row(p, r + 2, lane, far);
+		det_load_row(p, r + 5, lane, far);
 		const bool top = r < H / 2;
 		const int col0 = top ? H / 2 : 0;
 		int jv[4] = { pend_v[0], pend_v[1], pend_v[2], pend_v[3] };
@@ -386,7 +388,7 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 			p[at] = (int16_t)cur[k];
 			if (TB(je, k)) jp[at] = (int16_t)jv[k];
 		}
-		for (int k = 0; k < 4; k++) { cur[k] = nxt[k]; nxt[k] = far[k]; }
+		for (int k = 0; k < 4; k++) { cur[k] = nxt[k]; nxt[k] = q0[k]; q0[k] = q1[k]; q1[k] = q2[k]; q2[k] = far[k]; }
 	}
 	__threadfence_block();
 }
@@ -405,15 +407,17 @@ DEV void wave_shrink(Ctx *c, int lane)
 	for (int k = 0; k < 4; k++) jn[k] = jp[2 * W + lane + 64 * k];
 	BALLOT4(bn, jn, iabs(x) >= 8);
 	const M4 inner = col_range(1, H - 2), right = col_range(H / 2, H - 2);
+	int g0[4], g1[4];                                              /* rows r+2, r+3 in flight */
+	for (int k = 0; k < 4; k++) { g0[k] = jp[3 * W + lane + 64 * k]; g1[k] = jp[4 * W + lane + 64 * k]; }
 	for (int r = 1; r < H - 1; r++) {
 		int jf[4] = { 0, 0, 0, 0 };
-		if (r + 2 < H) for (int k = 0; k < 4; k++) jf[k] = jp[(r + 2) * W + lane + 64 * k];
+		if (r + 4 < H) for (int k = 0; k < 4; k++) jf[k] = jp[(r + 4) * W + lane + 64 * k];
 		const M4 near = up1(bp) | bp | dn1(bp) | up1(bc) | dn1(bc) | up1(bn) | bn | dn1(bn);
 		const M4 hit = bc & ~near & (r >= H / 2 ? inner : right);
 		for (int k = 0; k < 4; k++)
 			if (TB(hit, k)) jp[r * W + lane + 64 * k] = (int16_t)(jc[k] > 0 ? jc[k] - 1 : jc[k] + 1);
 		bp = bc; bc = bn;
-		for (int k = 0; k < 4; k++) { jc[k] = jn[k]; jn[k] = jf[k]; }
+		for (int k = 0; k < 4; k++) { jc[k] = jn[k]; jn[k] = g0[k]; g0[k] = g1[k]; g1[k] = jf[k]; }
 		BALLOT4(bn, jn, iabs(x) >= 8);
 	}
 }
@@ -477,13 +481,15 @@ DEV void wave_quantise_luma(Ctx *c, int lane)
 {
 	int16_t *p = c->proc;
 	int prev[8], cur[8], nxt[8];
+	int q0[8], q1[8];                                              /* rows r+2, r+3 in flight */
 	quant_load_row(p, 0, lane, cur);
 	quant_load_row(p, 1, lane, nxt);
+	quant_load_row(p, 2, lane, q0); quant_load_row(p, 3, lane, q1);
 	for (int k = 0; k < 8; k++) prev[k] = 0;
 	unsigned last_le0 = 0;                                         /* the last cell of the row above is <= 0 (loop 1 looks at it from column 0) */
 	for (int r = 0; r <= W; r++) {                                 /* step r: loops 1-3 on row r, loop 4 on row r - 1 */
 		int far[8];
-		quant_load_row(p, r + 2, lane, far);
+		quant_load_row(p, r + 4, lane, far);
 		if (r < W) {
 			{                                                      /* loop 1 */
 				const M8 region = r < H ? col_range8(H, W - 1) : col_range8(0, W - 1);
@@ -555,7 +561,7 @@ DEV void wave_quantise_luma(Ctx *c, int lane)
 				p[(r - 1) * W + lane + 64 * k] = (int16_t)sym;
 			}
 		}
-		for (int k = 0; k < 8; k++) { prev[k] = cur[k]; cur[k] = nxt[k]; nxt[k] = far[k]; }
+		for (int k = 0; k < 8; k++) { prev[k] = cur[k]; cur[k] = nxt[k]; nxt[k] = q0[k]; q0[k] = q1[k]; q1[k] = far[k]; }
 	}
 }
 
