@@ -461,6 +461,21 @@ DEV M8 alt_runs(M8 f)
 }
 #define BALLOT8(m, arr, expr) do { for (int k_ = 0; k_ < 8; k_++) { const int x = arr[k_]; (m).w[k_] = __ballot(expr); } } while (0)
 
+/* the value one column to the left / right of every cell of a row held as v[k] = column lane + 64k (wave-wide DPP shift, the
+ * word seam through a readlane); `edge` stands in where the row ends */
+DEV int left_of_dpp(const int *v, int k, int lane, int edge)
+{
+	const int seam = k ? __builtin_amdgcn_readlane(v[k - 1], 63) : edge;
+	const int x = __builtin_amdgcn_update_dpp(0, v[k], 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+	return lane ? x : seam;
+}
+DEV int right_of_dpp(const int *v, int k, int nk, int lane, int edge)
+{
+	const int seam = k + 1 < nk ? __builtin_amdgcn_readlane(v[k + 1], 0) : edge;
+	const int x = __builtin_amdgcn_update_dpp(0, v[k], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+	return lane < 63 ? x : seam;
+}
+
 DEV void quant_load_row(const int16_t *p, int r, int lane, int *v)
 {
 	for (int k = 0; k < 8; k++) v[k] = r < W ? p[r * W + lane + 64 * k] : 0;       /* the cell behind the plane reads as 0 (zero guard) */
@@ -491,8 +506,21 @@ DEV void wave_quantise_luma(Ctx *c, int lane)
 		int far[8];
 		quant_load_row(p, r + 4, lane, far);
 		if (r < W) {
-			{                                                      /* loop 1 */
-				const M8 region = r < H ? col_range8(H, W - 1) : col_range8(0, W - 1);
+			if (r < H) {                                           /* loop 1, upper half: only columns 256..511 (mask words 4..7) take part */
+				int c4[4] = { cur[4], cur[5], cur[6], cur[7] };
+				M4 g8, g16, le0;
+				BALLOT4(g8, c4, x > 7 && !(x & 7)); BALLOT4(g16, c4, x > 15 && !(x & 7)); BALLOT4(le0, c4, x <= 0);
+				M4 ple = up1(le0);
+				ple.w[0] |= (uint64_t)(__builtin_amdgcn_readlane(cur[3], 63) <= 0);
+				const M4 both = g8 & dn1(g8) & col_range(0, H - 2);
+				const M4 cself = both & g16 & ple;
+				const M4 cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & dn1(g16) & dn2(le0) & col_range(0, H - 3);
+				const M4 hit = up1(alt_runs(cnext));                  /* cells decremented by their left neighbour */
+				const M4 dec = hit | (cself & ~hit);
+				last_le0 = (unsigned)(le0.w[3] >> 63);
+				for (int k = 0; k < 4; k++) cur[4 + k] -= TB(dec, k);
+			} else {                                               /* loop 1, lower half: whole rows */
+				const M8 region = col_range8(0, W - 1);
 				M8 g8, g16, le0;
 				BALLOT8(g8, cur, x > 7 && !(x & 7)); BALLOT8(g16, cur, x > 15 && !(x & 7)); BALLOT8(le0, cur, x <= 0);
 				const M8 ple = up1(le0, last_le0);
@@ -535,23 +563,18 @@ DEV void wave_quantise_luma(Ctx *c, int lane)
 				}
 			}
 		}
-		if (r >= 1) {                                              /* loop 4 on row r - 1 */
-			M8 e8, e7, em7, ac, dc;
-			BALLOT8(e8, prev, x == 8); BALLOT8(e7, prev, x == 7); BALLOT8(em7, prev, x == -7);
-			BALLOT8(ac, prev, x < -12 && x >= -127 && ((-x) & 7) == 6); BALLOT8(dc, prev, x > 12 && x <= 127 && (x & 7) >= 6);
-			const M8 ml = col_range8(0, W - 2);
-			const M8 to_m9 = em7 & up1(ac & ml), to_m8 = em7 & up1(e8 & ml), to_9 = e7 & up1(dc & ml);
-			const M8 self_m8 = em7 & ~to_m9 & ~to_m8 & dn1(e8) & ml;
-			const int first_next = __shfl(cur[0], 0);              /* the row below, already through loops 1-3 */
+		if (r >= 1) {                                              /* loop 4 on row r - 1: a stencil on (left, cell, right) */
+			const int first_next = __builtin_amdgcn_readlane(cur[0], 0);   /* the row below, already through loops 1-3 */
 			for (int k = 0; k < 8; k++) {
-				int a = prev[k], sym;
-				int nx = right_of(prev, k, 8, 1, lane);
-				if (k == 7 && lane == 63) nx = first_next;
-				const int raw = a;
-				if (TB(to_m9, k)) a = -9;
-				if (TB(to_m8, k) || TB(self_m8, k)) a = -8;
-				if (TB(to_9, k)) a = 9;
-				sym = quant_symbol(a, nx);
+				const int raw = prev[k];
+				const int lf = left_of_dpp(prev, k, lane, 0), rt = right_of_dpp(prev, k, 8, lane, first_next);
+				const bool last = k == 7 && lane == 63;             /* column 511: the fix-ups do not reach across the row end, the look at the next cell does */
+				int a = raw;
+				if (a == -7) {
+					if (lf < -12 && lf >= -127 && ((-lf) & 7) == 6) a = -9;       /* :375 */
+					else if (lf == 8 || (rt == 8 && !last)) a = -8;              /* :389, :378 */
+				} else if (a == 7 && lf > 12 && lf <= 127 && (lf & 7) >= 6) a = 9;   /* :390 */
+				int sym = quant_symbol(a, rt);
 				if (__ballot(raw > 127 || raw < -127)) {                /* marks of loops 2-3 and values beyond +-127: rare, whole words skip this */
 					if (raw > 10000 && (raw == 10100 || raw == 12700 || raw == 12900 || raw == 10204 || raw == 10300 || raw == 12100 || raw == 12200))
 						sym = raw == 10100 ? 128 : raw == 12700 ? 127 : raw == 12900 ? 129 : raw == 10204 ? 125 : raw == 10300 ? 126 : raw == 12100 ? 121 : 122;
