@@ -49,6 +49,8 @@ typedef struct {
 	float front_ms;       /* colour + pre-filter + level-1 analysis (the HBM-roofline kernels) */
 	float color_dwt_ms;   /* the fused colour + level-1 analysis kernel alone (0 when q<=21 splits it) */
 	float luma_ms, chroma_ms, entropy_ms;
+	int parts;            /* sub-batches the stages behind the front ran as (each on a stream of its own); with more than one, luma/chroma/entropy_ms are those of the first */
+	int front_images;     /* images covered by front_ms */
 } nhw_timing;
 
 /* lifecycle: replaces `im.setup=malloc(..)` + per-image mallocs of encode_image (nhw_encoder.c:108-...) */

@@ -18,7 +18,7 @@ P = ctypes.c_void_p
 
 
 class Timing(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "front_ms", "color_dwt_ms", "luma_ms", "chroma_ms", "entropy_ms")]
+    _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "front_ms", "color_dwt_ms", "luma_ms", "chroma_ms", "entropy_ms")] + [("parts", ctypes.c_int), ("front_images", ctypes.c_int)]
 
 
 class NhwError(RuntimeError):

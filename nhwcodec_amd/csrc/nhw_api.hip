@@ -39,8 +39,12 @@ struct nhw_enc {
 	NhwWs ws;
 	size_t slab_bytes;
 	hipStream_t own_stream;
+	hipStream_t part_stream[4];   /* a large batch runs as up to four sub-batches on streams of their own (see nhw_enc_batch_device) */
+	hipEvent_t part_ev[5];
+	int parts;
 	hipEvent_t ev[6];
 	bool timed;
+	int timed_parts, timed_front_images;
 	/* host convenience path */
 	uint8_t *d_in, *d_out, *d_compact;
 	uint32_t *d_sizes; int32_t *d_status; uint64_t *d_offs;
@@ -83,6 +87,10 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 	HIPCHK(hipMemset(e->ws.base, 0, total));       /* guards must be zero; they are never written afterwards */
 	HIPCHK(hipStreamCreate(&e->own_stream));
 	for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&e->ev[i]));
+	for (int i = 0; i < 4; i++) HIPCHK(hipStreamCreateWithFlags(&e->part_stream[i], hipStreamNonBlocking));
+	for (int i = 0; i < 5; i++) HIPCHK(hipEventCreateWithFlags(&e->part_ev[i], hipEventDisableTiming));
+	e->parts = 2;
+	if (const char *p = getenv("NHW_PARTS")) { const int k = atoi(p); if (k >= 1 && k <= 4) e->parts = k; }
 	*out = e;
 	return NHW_OK;
 }
@@ -101,21 +109,19 @@ extern "C" void nhw_enc_destroy(nhw_enc *e)
 	if (e->d_offs) (void)hipFree(e->d_offs);
 	for (int i = 0; i < 6; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
 	if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+	for (int i = 0; i < 4; i++) if (e->part_stream[i]) (void)hipStreamDestroy(e->part_stream[i]);
+	for (int i = 0; i < 5; i++) if (e->part_ev[i]) (void)hipEventDestroy(e->part_ev[i]);
 	delete e;
 }
 
 static inline int16_t *plane16(const NhwWs &ws, int b) { return (int16_t *)(ws.base + ws.off[b]); }
 static inline uint8_t *plane8(const NhwWs &ws, int b) { return ws.base + ws.off[b]; }
 
-extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_out, uint32_t *d_sizes,
-                                    int32_t *d_status, void *stream)
+/* the whole launch sequence for the images of one workspace view on one stream; `timed`: record the stage events of nhw_timing */
+static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int quality, void *d_out, uint32_t *d_sizes, int32_t *d_status, hipStream_t s,
+                     int timed /* 0: no events, 1: ev[0..4] (whole batch), 2: ev[2], ev[3] (tail of the first sub-batch; the caller closes with ev[4]) */,
+                     int what = 3 /* bit 0: the front launch group (colour, pre-filter, level-1 analysis), bit 1: everything behind it */)
 {
-	if (!e || !d_bgr || !d_out || !d_sizes || !d_status || n < 1 || n > e->max_batch) { g_err = "bad argument"; return NHW_E_ARG; }
-	if (!nhw_quality_supported(quality)) { g_err = "quality outside 17..23 is not implemented in this revision"; return NHW_E_QUALITY; }
-	HIPCHK(hipSetDevice(e->device));
-	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
-	NhwWs ws = e->ws;
-	ws.n = n; ws.q = quality;
 	const int q = quality;
 	int16_t *jpeg = plane16(ws, B_JPEG), *proc = plane16(ws, B_PROC);
 	int16_t *cjpeg = plane16(ws, B_CJPEG), *cproc = plane16(ws, B_CPROC);
@@ -124,7 +130,9 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 
 	int stage = 0;
 #define STAGE_DONE() do { if (e->stop_after && ++stage == e->stop_after) { HIPCHK(hipGetLastError()); return NHW_OK; } } while (0)
-	HIPCHK(hipEventRecord(e->ev[0], s));
+	(void)n;
+	if (what & 1) {
+	if (timed == 1) HIPCHK(hipEventRecord(e->ev[0], s));
 	/* a1: colour + 4:2:0 */
 	/* The fused front reads luma rows that belong to other workgroups' output rows of the same plane (band b writes LL rows
 	 * 16b.. into jpeg, band b/2 reads them as input), so its input lives in a plane of its own: the otherwise unused
@@ -152,7 +160,9 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 		STAGE_DONE();
 		STAGE_DONE();
 	}
-	HIPCHK(hipEventRecord(e->ev[1], s));
+	if (timed == 1) HIPCHK(hipEventRecord(e->ev[1], s));
+	if (!(what & 2)) { HIPCHK(hipGetLastError()); return NHW_OK; }
+	}
 	/* Y4: level-2 analysis (:139) */
 	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
 	STAGE_DONE();
@@ -179,7 +189,7 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	if (q > 21) nhw_launch_phase(PH_L4C2, ws, 0, out, d_sizes, d_status, s);   /* Y29 */
 	nhw_launch_phase(PH_L4D, ws, 0, out, d_sizes, d_status, s);      /* Y30, Y31 */
 	STAGE_DONE();
-	HIPCHK(hipEventRecord(e->ev[2], s));
+	if (timed) HIPCHK(hipEventRecord(e->ev[2], s));
 
 	for (int comp = 0; comp < 2; comp++) {           /* U then V (:2255-2570, :2572-2868) */
 		nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, s);
@@ -205,12 +215,53 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 		nhw_launch_phase(PH_C5, ws, comp, out, d_sizes, d_status, s);
 		STAGE_DONE();
 	}
-	HIPCHK(hipEventRecord(e->ev[3], s));
+	if (timed) HIPCHK(hipEventRecord(e->ev[3], s));
 	nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, s);     /* Z1 */
 	nhw_launch_phase(PH_FINAL, ws, 0, out, d_sizes, d_status, s);   /* Z2, container */
-	HIPCHK(hipEventRecord(e->ev[4], s));
+	if (timed == 1) HIPCHK(hipEventRecord(e->ev[4], s));
 	HIPCHK(hipGetLastError());
-	e->timed = true;
+	return NHW_OK;
+}
+
+/* Most kernels of the sequence are bound by latency at the occupancy their LDS footprint allows, not by HBM or the ALUs, so a
+ * large batch is cut into sub-batches whose sequences run on streams of their own: kernels of different stages overlap on the
+ * CUs.  Images are independent and the workspace is indexed per image, so a sub-batch is just a shifted view of it. */
+extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_out, uint32_t *d_sizes,
+                                    int32_t *d_status, void *stream)
+{
+	if (!e || !d_bgr || !d_out || !d_sizes || !d_status || n < 1 || n > e->max_batch) { g_err = "bad argument"; return NHW_E_ARG; }
+	if (!nhw_quality_supported(quality)) { g_err = "quality outside 17..23 is not implemented in this revision"; return NHW_E_QUALITY; }
+	HIPCHK(hipSetDevice(e->device));
+	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+	NhwWs ws = e->ws;
+	ws.n = n; ws.q = quality;
+	const int parts = (e->stop_after || e->legacy_front || n < 512) ? 1 : e->parts;
+	if (parts == 1) {
+		const int rc = run_batch(e, ws, d_bgr, n, quality, d_out, d_sizes, d_status, s, 1);
+		if (rc == NHW_OK && !e->stop_after) { e->timed = true; e->timed_parts = 1; e->timed_front_images = n; }
+		return rc;
+	}
+	/* the front launch group is the part that is bound by the memory system and the ALUs: it runs once for the whole batch */
+	HIPCHK(hipEventRecord(e->ev[0], s));
+	{ const int rc = run_batch(e, ws, d_bgr, n, quality, d_out, d_sizes, d_status, s, 0, 1); if (rc != NHW_OK) return rc; }
+	HIPCHK(hipEventRecord(e->ev[1], s));
+	HIPCHK(hipEventRecord(e->part_ev[4], s));
+	e->timed_front_images = n;
+	for (int k = 0; k < parts; k++) {
+		const int i0 = (int)((long long)n * k / parts), i1 = (int)((long long)n * (k + 1) / parts);
+		NhwWs view = ws;
+		view.n = i1 - i0;
+		for (int b = 0; b < B_COUNT; b++) view.off[b] += (size_t)i0 * ws.stride[b];
+		hipStream_t ps_ = e->part_stream[k];
+		HIPCHK(hipStreamWaitEvent(ps_, e->part_ev[4], 0));
+		const int rc = run_batch(e, view, (const uint8_t *)d_bgr + (size_t)i0 * (W * W * 3), i1 - i0, quality, (uint8_t *)d_out + (size_t)i0 * NHW_OUT_STRIDE,
+		                         d_sizes + i0, d_status + i0, ps_, k == 0 ? 2 : 0, 2);
+		if (rc != NHW_OK) return rc;
+		HIPCHK(hipEventRecord(e->part_ev[k], ps_));
+		HIPCHK(hipStreamWaitEvent(s, e->part_ev[k], 0));
+	}
+	HIPCHK(hipEventRecord(e->ev[4], s));
+	e->timed = true; e->timed_parts = parts;
 	return NHW_OK;
 }
 
@@ -220,11 +271,12 @@ extern "C" int nhw_enc_last_timing(nhw_enc *e, nhw_timing *t)
 	HIPCHK(hipEventSynchronize(e->ev[4]));
 	memset(t, 0, sizeof *t);
 	HIPCHK(hipEventElapsedTime(&t->total_ms, e->ev[0], e->ev[4]));
-	HIPCHK(hipEventElapsedTime(&t->front_ms, e->ev[0], e->ev[1]));
+	HIPCHK(hipEventElapsedTime(&t->front_ms, e->ev[0], e->ev[1]));   /* several parts: the later stage times are those of the first sub-batch, on its stream */
 	HIPCHK(hipEventElapsedTime(&t->luma_ms, e->ev[1], e->ev[2]));
 	HIPCHK(hipEventElapsedTime(&t->chroma_ms, e->ev[2], e->ev[3]));
 	HIPCHK(hipEventElapsedTime(&t->entropy_ms, e->ev[3], e->ev[4]));
 	t->color_dwt_ms = 0.f;
+	t->parts = e->timed_parts; t->front_images = e->timed_front_images;
 	return NHW_OK;
 }
 
