@@ -466,7 +466,8 @@ DEV void classify_step(int q, int res_setting, int r, int j, int16_t *pr, int ps
 #define MARK_LARGE() do { *cell = 14000; if (res == -4) { if (lh[0] == -7 || lh[0] == -8) { if (lhm1 < 2 && lhm1 > -8) lh[0] = -9; } } \
 		else if (res < -6) { if (res < -7 && q >= 21) *cell = 14900; else if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; } \
 		else if (lh[0] == 7 || lh[0] == 8) { if (lhm1 >= -1 && lhm1 < 8) lh[0] += 3; } } } while (0)
-		if (res == 2 && a == 2 && d2 >= 2) { if (d2 < 5 || d2 > 6) MARK(12400, -2); }
+		if (res == 0) { if (a != -2 && a != -3) NUDGE_UP(); }       /* the common case, ahead of the chain it falls through (only the a == -2/-3 branch would swallow it) */
+		else if (res == 2 && a == 2 && d2 >= 2) { if (d2 < 5 || d2 > 6) MARK(12400, -2); }
 		else if (((res == 2 && a == 3) || (res == 3 && a == 2)) && d2 > 1 && d2 < 6) MARK(12400, -2);
 		else if (res == 3 && a == 3) {
 			if (d2 > 0 && d2 < 6) MARK(12400, -2);
