@@ -46,48 +46,53 @@ __device__ __forceinline__ int convert_y(const uint8_t *px, float yq)
 	return (int)(ly * 0.94 + 0.5f);
 }
 
+/* One workgroup per 8 luma rows = 4 chroma rows: the 9 BGR rows 8b-1 .. 8b+7 are staged in LDS with 16-byte loads
+ * (the row above is the only one read twice), every pixel is converted once (Y straight to HBM, U and V as bytes to
+ * LDS), then the [1 2 1] x [1 2 1] chroma filter runs on the LDS bytes. */
 template <int FAMILY>
 __global__ __launch_bounds__(256) void k_color(const uint8_t *__restrict__ bgr, int16_t *__restrict__ yb, size_t y_stride,
                                                uint8_t *__restrict__ ub, uint8_t *__restrict__ vb, size_t c_stride, float yq)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t rows[3][W * 3];
-	const int r = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
+	__shared__ __attribute__((aligned(16))) uint8_t rows[9][W * 3];
+	__shared__ __attribute__((aligned(4))) uint8_t uu[9][W], vv[9][W];
+	const int b = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
 	const uint8_t *src = bgr + (size_t)img * (W * W * 3);
-	const int r0 = r ? 2 * r - 1 : 0; /* row above (unused for r = 0) */
-
-	for (int k = t; k < 3 * (W * 3 / 16); k += 256) {
-		const int which = k / (W * 3 / 16), o = k % (W * 3 / 16);
-		const int row = which == 0 ? r0 : (2 * r + which - 1);
-		reinterpret_cast<uint4 *>(rows[which])[o] = reinterpret_cast<const uint4 *>(src + (size_t)row * (W * 3))[o];
+	for (int k = t; k < 9 * (W * 3 / 16); k += 256) {
+		const int which = k / (W * 3 / 16), o = k % (W * 3 / 16), row = 8 * b - 1 + which;
+		if (row >= 0) reinterpret_cast<uint4 *>(rows[which])[o] = reinterpret_cast<const uint4 *>(src + (size_t)row * (W * 3))[o];
 	}
 	__syncthreads();
-
-	/* luma: pixels 2t, 2t+1 of rows 2r and 2r+1 (Y is not clipped, colorspace.c:80) */
-	int16_t *yrow = (int16_t *)((uint8_t *)yb + (size_t)img * y_stride) + (size_t)(2 * r) * W;
-	for (int k = 1; k <= 2; k++) {
-		const int y0 = convert_y<FAMILY>(&rows[k][6 * t], yq), y1 = convert_y<FAMILY>(&rows[k][6 * t + 3], yq);
-		reinterpret_cast<uint32_t *>(yrow + (k - 1) * W)[t] = (uint32_t)(uint16_t)y0 | ((uint32_t)(uint16_t)y1 << 16);
-	}
-
-	/* chroma: horizontal [1 2 1]/4 at even pixel 2t (first column: (c0+c1+1)>>1), then vertical
-	 * [1 2 1]/4 over rows 2r-1, 2r, 2r+1 (first row: (r0+r1+1)>>1) */
-	int hu[3], hv[3];
-	for (int k = 0; k < 3; k++) {
-		int uc, vc, ur, vr;
-		convert_uv<FAMILY>(&rows[k][6 * t], yq, uc, vc);
-		convert_uv<FAMILY>(&rows[k][6 * t + 3], yq, ur, vr);
-		if (t == 0) { hu[k] = (uc + ur + 1) >> 1; hv[k] = (vc + vr + 1) >> 1; }
-		else {
-			int ul, vl;
-			convert_uv<FAMILY>(&rows[k][6 * t - 3], yq, ul, vl);
-			hu[k] = (ul + 2 * uc + ur + 2) >> 2; hv[k] = (vl + 2 * vc + vr + 2) >> 2;
+	int16_t *yplane = (int16_t *)((uint8_t *)yb + (size_t)img * y_stride);
+	for (int k = t; k < 9 * (W / 2); k += 256) {                   /* two pixels per item */
+		const int which = k / (W / 2), px = 2 * (k % (W / 2)), row = 8 * b - 1 + which;
+		if (row < 0) continue;
+		int u0, v0, u1, v1;
+		convert_uv<FAMILY>(&rows[which][3 * px], yq, u0, v0);
+		convert_uv<FAMILY>(&rows[which][3 * px + 3], yq, u1, v1);
+		*reinterpret_cast<uint16_t *>(&uu[which][px]) = (uint16_t)(u0 | (u1 << 8));
+		*reinterpret_cast<uint16_t *>(&vv[which][px]) = (uint16_t)(v0 | (v1 << 8));
+		if (which) {                                               /* luma is not clipped (colorspace.c:80) */
+			const int y0 = convert_y<FAMILY>(&rows[which][3 * px], yq), y1 = convert_y<FAMILY>(&rows[which][3 * px + 3], yq);
+			*reinterpret_cast<uint32_t *>(yplane + (size_t)row * W + px) = (uint32_t)(uint16_t)y0 | ((uint32_t)(uint16_t)y1 << 16);
 		}
 	}
-	int U, V;
-	if (r == 0) { U = (hu[1] + hu[2] + 1) >> 1; V = (hv[1] + hv[2] + 1) >> 1; }
-	else { U = (hu[0] + 2 * hu[1] + hu[2] + 2) >> 2; V = (hv[0] + 2 * hv[1] + hv[2] + 2) >> 2; }
-	(ub + (size_t)img * c_stride)[r * H + t] = (uint8_t)U;
-	(vb + (size_t)img * c_stride)[r * H + t] = (uint8_t)V;
+	__syncthreads();
+	/* chroma: horizontal [1 2 1]/4 at even pixel 2c (first column: (c0+c1+1)>>1), then vertical [1 2 1]/4 over rows
+	 * 2r-1, 2r, 2r+1 (first row: (r0+r1+1)>>1) */
+	for (int k = t; k < 4 * H; k += 256) {
+		const int rr = k / H, c = k % H, r = 4 * b + rr;
+		int hu[3], hv[3];
+		for (int j = 0; j < 3; j++) {
+			const uint8_t *pu = uu[2 * rr + j] + 2 * c, *pv = vv[2 * rr + j] + 2 * c;
+			if (c == 0) { hu[j] = (pu[0] + pu[1] + 1) >> 1; hv[j] = (pv[0] + pv[1] + 1) >> 1; }
+			else { hu[j] = (pu[-1] + 2 * pu[0] + pu[1] + 2) >> 2; hv[j] = (pv[-1] + 2 * pv[0] + pv[1] + 2) >> 2; }
+		}
+		int U, V;
+		if (r == 0) { U = (hu[1] + hu[2] + 1) >> 1; V = (hv[1] + hv[2] + 1) >> 1; }
+		else { U = (hu[0] + 2 * hu[1] + hu[2] + 2) >> 2; V = (hv[0] + 2 * hv[1] + hv[2] + 2) >> 2; }
+		(ub + (size_t)img * c_stride)[r * H + c] = (uint8_t)U;
+		(vb + (size_t)img * c_stride)[r * H + c] = (uint8_t)V;
+	}
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -787,7 +792,7 @@ using namespace nhw;
 
 void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_stride, uint8_t *u, uint8_t *v, size_t c_stride, hipStream_t s)
 {
-	const dim3 grid(H, n);
+	const dim3 grid(H / 4, n);
 	if (q >= 20) k_color<0><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, 0.f);
 	else if (q >= 18) k_color<1><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, q == 19 ? 0.975f : 0.93f);
 	else k_color<2><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, 0.f);
