@@ -295,3 +295,22 @@ def test_chroma_rows_that_end_in_a_pair_mark(enc, oracle, seed, q):
     row: from there on the reference compares against cll1 one cell further on (nhw_encoder.c:2372-2427)."""
     im = oracle.synth(seed)
     assert enc.encode(im[None], q)[0] == oracle.encode(im, q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,q", [(1001, 23), (517, 18)])
+def test_sub_batches_on_streams_match_oracle(oracle, n, q):
+    """Batches of 512 images or more run their stages behind the front as two sub-batches on streams of their own
+    (odd split here): images around the seam and at both ends must equal the oracle's."""
+    import torch
+    import nhwcodec_amd
+    e = nhwcodec_amd.Encoder(0, max_batch=n)
+    bgr = e.synth_device(n, seed_base=4000)
+    o, sizes, status = e.encode_device(bgr, q)
+    torch.cuda.synchronize()
+    assert e.timing().parts == 2
+    assert int((status != 0).sum()) == 0
+    sz = sizes.cpu().numpy()
+    for i in (0, 1, n // 2 - 1, n // 2, n // 2 + 1, n - 2, n - 1):
+        assert o[i, : sz[i]].cpu().numpy().tobytes() == oracle.encode(oracle.synth(4000 + i), q), f"image {i}"
+    e.close()
