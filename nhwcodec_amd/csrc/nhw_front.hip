@@ -18,6 +18,13 @@
 namespace nhw {
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+/* |a - b| + acc on unsigned operands in one instruction (the compiler does not form it from the C expression) */
+__device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned acc)
+{
+	unsigned d;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+	return d;
+}
 
 /* ------------------------------------------------------------------------------------------------
  * colour + 4:2:0.  One workgroup per pair of luma rows (2r, 2r+1) = one chroma row r.
@@ -454,17 +461,19 @@ __global__ __launch_bounds__(256) void k_front_rowmaps(const int16_t *__restrict
 			const int16_t *p = ybuf + (rl + 1) * FB_RS;
 			/* 3x3 window slides along the row: three new LDS reads per pixel */
 			int u0 = p[-FB_RS + c0 - 1], u1 = p[-FB_RS + c0], m_0 = p[c0 - 1], m_1 = p[c0], d0 = p[FB_RS + c0 - 1], d1 = p[FB_RS + c0];
+			int cs0 = u0 + m_0 + d0, cs1 = u1 + m_1 + d1;
 			for (int c = c0; c <= c1; c++) {
 				const int u2 = p[-FB_RS + c + 1], m_2 = p[c + 1], d2 = p[FB_RS + c + 1];
 				/* sum of the eight differences = 9 x centre - the 3x3 total; their magnitudes with the sum-of-absolute-differences instruction (luma is 0..255 here) */
-				const int sum = 9 * m_1 - (u0 + u1 + u2 + m_0 + m_1 + m_2 + d0 + d1 + d2);
-				const int mag = (int)__usad(m_1, u0, __usad(m_1, u1, __usad(m_1, u2, __usad(m_1, m_0, __usad(m_1, m_2, __usad(m_1, d0, __usad(m_1, d1, __usad(m_1, d2, 0u))))))));
+				const int cs2 = u2 + m_2 + d2;                        /* column sums slide along with the window */
+				const int sum = 9 * m_1 - (cs0 + cs1 + cs2);
+				const int mag = (int)sad_u32(m_1, u0, sad_u32(m_1, u1, sad_u32(m_1, u2, sad_u32(m_1, m_0, sad_u32(m_1, m_2, sad_u32(m_1, d0, sad_u32(m_1, d1, sad_u32(m_1, d2, 0u))))))));
 				const int base = 15 * iabs(sum) + mag;
 				const int vb = sum == 0 ? 0 : (sum < 0 ? -base : base);
 				if (c == W - 3) { a0 = m0; a1 = m1; v509 = vb; }
 				if (c == W - 2) { b0 = m0; b1 = m1; v510 = vb; }
 				fsm_step16(m0, m1, vb);
-				u0 = u1; u1 = u2; m_0 = m_1; m_1 = m_2; d0 = d1; d1 = d2;
+				u0 = u1; u1 = u2; m_0 = m_1; m_1 = m_2; d0 = d1; d1 = d2; cs0 = cs1; cs1 = cs2;
 			}
 		}
 		seg[2 * t] = m0; seg[2 * t + 1] = m1;
@@ -596,8 +605,8 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict_
 				for (int e = 0; e < 8; e++) {                      /* pixel c0+e sits at window index e+2 */
 					const int c = c0 + e, ctr = md[e + 2];
 					const int sum = 9 * ctr - (s3[e + 1] + s3[e + 2] + s3[e + 3]);   /* sum of the eight differences */
-					const int mag = (int)__usad(ctr, up[e + 1], __usad(ctr, up[e + 2], __usad(ctr, up[e + 3], __usad(ctr, md[e + 1], __usad(ctr, md[e + 3],
-					                __usad(ctr, dn[e + 1], __usad(ctr, dn[e + 2], __usad(ctr, dn[e + 3], 0u))))))));
+					const int mag = (int)sad_u32(ctr, up[e + 1], sad_u32(ctr, up[e + 2], sad_u32(ctr, up[e + 3], sad_u32(ctr, md[e + 1], sad_u32(ctr, md[e + 3],
+					                sad_u32(ctr, dn[e + 1], sad_u32(ctr, dn[e + 2], sad_u32(ctr, dn[e + 3], 0u))))))));
 					const int base = 15 * iabs(sum) + mag;
 					const int vb = (sum == 0 || c < 1 || c > W - 2) ? 0 : (sum < 0 ? -base : base);
 					out[e >> 1] |= (uint32_t)(uint16_t)vb << (16 * (e & 1));
