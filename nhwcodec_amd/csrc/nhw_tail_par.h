@@ -448,8 +448,75 @@ DEV void tag_small_runs_par(Ctx *c, int tid, int16_t *lds)
  * recon sample / LL1 cell of row r (row strides ps / os: the planes themselves, an LDS tile, or a packed copy of
  * the column), lh at the LH1 coefficient the step may nudge, lhm1 is the one before it (as this walk left it).
  * sp / so: where the right-hand neighbour column is read (the values from before the pass). */
+/* One step of the Y22 column walk (nhw_encoder.c:1077-1325) decides on three small differences -- this row's residual,
+ * the next row's, the one after -- through a chain of some forty comparisons.  Every comparison only asks which of
+ * 16 x 9 x 12 value classes the triple is in, so the chain is evaluated once per class (classify_kind, by the threads
+ * of the workgroup, into an LDS table) and a step is a table lookup plus a short switch: with 64 columns in a
+ * wavefront the chain itself was most of the divergent instruction stream. */
+enum { CK_NONE, CK_MARKP, CK_MARKN, CK_S12100, CK_S12500, CK_S12200, CK_S12600, CK_INC, CK_DEC, CK_Q18P_NEXT, CK_Q18P_CELL, CK_Q18P_COPY,
+       CK_Q18N_NEXT, CK_Q18N_CELL, CK_Q18N_COPY, CK_NBP, CK_NBN, CK_PREVGE0, CK_PREVLE0, CK_C14500, CK_NUP, CK_NM2, CK_NM3, CK_LARGE };
+#define CK_TABLE_BYTES (16 * 9 * 12)
+DEV int classify_kind(int q, int res_setting, int res, int a, int d2)
+{
+	if (res == 2 && a == 2 && d2 >= 2) return (d2 < 5 || d2 > 6) ? CK_MARKP : CK_NONE;
+	if (((res == 2 && a == 3) || (res == 3 && a == 2)) && d2 > 1 && d2 < 6) return CK_MARKP;
+	if (res == 3 && a == 3) return (d2 > 0 && d2 < 6) ? CK_MARKP : (q >= 19 ? CK_S12100 : CK_NONE);
+	if (a == -4 && (res == 2 || res == 3) && (d2 == 2 || d2 == 3)) return (res == 2 && d2 == 2) ? CK_INC : CK_MARKP;
+	if (res == 1 && a == 3 && d2 == 2) return CK_PREVGE0;
+	if ((res == 3 || res == 4 || res == 5 || res > 6) && (a == 3 || (a & 0xFFFE) == 4)) {
+		if (res > 6) return CK_S12500;
+		if (q >= 19) return CK_S12100;
+		if (q == 18) return (res < 5 && a == 5) ? CK_Q18P_NEXT : (res >= 5 ? CK_Q18P_CELL : ((res == 3 && a >= 4) ? CK_Q18P_NEXT : CK_Q18P_COPY));
+		return CK_NONE;
+	}
+	if ((res == 2 || res == 3) && (a == 2 || a == 3)) return (d2 == 0 || d2 == 1) ? CK_NBP : CK_NONE;
+	if (a == 4 && (res == -2 || res == -3) && (d2 == -2 || d2 == -3)) return (res == -2 && d2 == -2) ? CK_DEC : CK_MARKN;
+	if ((res == -3 || res == -4 || res == -5 || res < -7) && (a == -3 || a == -4 || a == -5)) {
+		if (res < -7) return CK_S12600;
+		if (q >= 19) return CK_S12200;
+		if (q == 18) return (res > -5 && a == -5) ? CK_Q18N_NEXT : (res <= -5 ? CK_Q18N_CELL : ((res == -3 && a <= -4) ? CK_Q18N_NEXT : CK_Q18N_COPY));
+		return CK_NONE;
+	}
+	if (a == -2 || a == -3) {
+		if (res == -2 || res == -3) {
+			if (d2 < 0) return CK_MARKN;
+			if (res == -3 && q >= 21) return CK_C14500;
+			if (d2 == 0) return CK_NBN;
+			return res == -2 ? CK_NM2 : CK_NM3;
+		}
+		if (res == -1 && a == -3 && d2 == -2) return CK_PREVLE0;
+		if (res == -1) return d2 == -3 ? CK_MARKN : CK_NUP;
+		if (res == -4) return (d2 < -1 && d2 > -4) ? CK_MARKN : CK_LARGE;
+		return CK_NONE;
+	}
+	if (!res || res == -1) return CK_NUP;
+	if (res == -2) return CK_NM2;
+	if (res == -3) return CK_NM3;
+	if (res < -res_setting) return CK_LARGE;
+	return CK_NONE;
+}
+/* value classes: residual <= -8, -7 .. 6, >= 7; next residual -5 .. -2, 2 .. 5, anything else; third <= -4, -3 .. 6, >= 7 */
+DEV void classify_table_fill(uint8_t *tab, int q, int res_setting, int tid)
+{
+	for (int idx = tid; idx < CK_TABLE_BYTES; idx += NT) {
+		const int rc = idx / (9 * 12), ac = (idx / 12) % 9, dc = idx % 12;
+		const int a = ac < 4 ? ac - 5 : (ac < 8 ? ac - 2 : 0);
+		tab[idx] = (uint8_t)classify_kind(q, res_setting, rc - 8, a, dc - 4);
+	}
+}
+DEV int classify_lookup(const uint8_t *tab, int res, int a, int d2)
+{
+	const int rc = (res < -8 ? -8 : (res > 7 ? 7 : res)) + 8, dc = (d2 < -4 ? -4 : (d2 > 7 ? 7 : d2)) + 4;
+	const int ac = (a >= -5 && a <= 5) ? (int)((0x76548883210ull >> (4 * (a + 5))) & 15) : 8;
+	return tab[(rc * 9 + ac) * 12 + dc];
+}
+
+/* the step itself.  pr / orow point at the column's recon sample / LL1 cell of row r (row strides ps / os: the planes
+ * themselves, an LDS tile, or a packed copy of the column), lh at the LH1 coefficient the step may nudge, lhm1 is the
+ * one before it (as this walk left it).  sp / so: where the right-hand neighbour column is read (the values from
+ * before the pass). */
 template <bool NB_TILE>
-DEV void classify_step(int q, int res_setting, int r, int j, int16_t *pr, int ps, int16_t *orow, int os, int16_t *lh, int lhm1,
+DEV void classify_step(const uint8_t *tab, int q, int r, int j, int16_t *pr, int ps, int16_t *orow, int os, int16_t *lh, int lhm1,
                        const int16_t *sp, int sp_row, const int16_t *so, int so_rows)
 {
 	int16_t *cell = orow;
@@ -459,83 +526,54 @@ DEV void classify_step(int q, int res_setting, int r, int j, int16_t *pr, int ps
 #define NB(dr) (NB_TILE ? (int)sp[(dr) * sp_row] : (sp[(r + (dr)) * sp_row + j + 1] - ((r + (dr)) < so_rows ? so[(r + (dr)) * H + j + 1] : 0)))
 #define MARK(code, step) do { *cell = (code); pr[ps] += (step); pr[2 * ps] += (step); } while (0)
 #define SNAP(code) do { *cell = (code); pr[ps] = orow[os]; } while (0)
-#define NUDGE_UP() do { if (lh[0] == 7) { if (lhm1 >= 0 && lhm1 < 8) lh[0] += 2; } else if (lh[0] == 8) { if (lhm1 >= -2 && lhm1 < 8) lh[0] += 2; } } while (0)
-#define NUDGE_M2() do { if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; } else if (lh[0] == 7 || (lh[0] & 0xFFFE) == 8) { if (lhm1 >= -2) lh[0] += 3; } } while (0)
-#define NUDGE_M3() do { if (q >= 21) *cell = 14500; else if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; } \
-		else if (lh[0] >= 0 && ((lh[0] + 2) & 0xFFFC) == 8) { if (lhm1 >= -2) lh[0] = 10; } else if (lh[0] > 14 && (lh[0] & 7) == 7) lh[0]++; } while (0)
-#define MARK_LARGE() do { *cell = 14000; if (res == -4) { if (lh[0] == -7 || lh[0] == -8) { if (lhm1 < 2 && lhm1 > -8) lh[0] = -9; } } \
-		else if (res < -6) { if (res < -7 && q >= 21) *cell = 14900; else if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; } \
-		else if (lh[0] == 7 || lh[0] == 8) { if (lhm1 >= -1 && lhm1 < 8) lh[0] += 3; } } } while (0)
-		if (res == 0) { if (a != -2 && a != -3) NUDGE_UP(); }       /* the common case, ahead of the chain it falls through (only the a == -2/-3 branch would swallow it) */
-		else if (res == 2 && a == 2 && d2 >= 2) { if (d2 < 5 || d2 > 6) MARK(12400, -2); }
-		else if (((res == 2 && a == 3) || (res == 3 && a == 2)) && d2 > 1 && d2 < 6) MARK(12400, -2);
-		else if (res == 3 && a == 3) {
-			if (d2 > 0 && d2 < 6) MARK(12400, -2);
-			else if (q >= 19) SNAP(12100);
+	int kind = classify_lookup(tab, res, a, d2);
+	if (kind == CK_NONE) return;
+	if (kind == CK_NBP) { const int x0 = NB(0), x1 = NB(1); kind = ((x0 == 2 || x0 == 3) && (x1 == 2 || x1 == 3) && NB(2) > 0) ? CK_MARKP : CK_NONE; }
+	else if (kind == CK_NBN) { const int x0 = NB(0), x1 = NB(1); kind = ((x0 == -2 || x0 == -3) && (x1 == -2 || x1 == -3) && NB(2) < 0) ? CK_MARKN : CK_NONE; }
+	else if (kind == CK_PREVGE0) kind = (r > 0 && (pr[-ps] - orow[-os]) >= 0) ? CK_MARKP : CK_NONE;
+	else if (kind == CK_PREVLE0) kind = (r > 0 && (pr[-ps] - orow[-os]) <= 0) ? CK_MARKN : CK_NONE;
+	switch (kind) {
+	case CK_MARKP: MARK(12400, -2); break;
+	case CK_MARKN: MARK(12300, 2); break;
+	case CK_S12100: SNAP(12100); break;
+	case CK_S12500: SNAP(12500); break;
+	case CK_S12200: SNAP(12200); break;
+	case CK_S12600: SNAP(12600); break;
+	case CK_INC: pr[ps]++; break;
+	case CK_DEC: pr[ps]--; break;
+	case CK_Q18P_NEXT: orow[os] = 14100; pr[ps] = orow[os]; break;
+	case CK_Q18P_CELL: *cell = 14100; pr[ps] = orow[os]; break;
+	case CK_Q18P_COPY: pr[ps] = orow[os]; break;
+	case CK_Q18N_NEXT: orow[os] = 14000; pr[ps] = orow[os]; break;
+	case CK_Q18N_CELL: *cell = 14000; pr[ps] = orow[os]; break;
+	case CK_Q18N_COPY: pr[ps] = orow[os]; break;
+	case CK_C14500: *cell = 14500; break;
+	case CK_NUP:
+		if (lh[0] == 7) { if (lhm1 >= 0 && lhm1 < 8) lh[0] += 2; } else if (lh[0] == 8) { if (lhm1 >= -2 && lhm1 < 8) lh[0] += 2; }
+		break;
+	case CK_NM2:
+		if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; } else if (lh[0] == 7 || (lh[0] & 0xFFFE) == 8) { if (lhm1 >= -2) lh[0] += 3; }
+		break;
+	case CK_NM3:
+		if (q >= 21) *cell = 14500;
+		else if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; }
+		else if (lh[0] >= 0 && ((lh[0] + 2) & 0xFFFC) == 8) { if (lhm1 >= -2) lh[0] = 10; }
+		else if (lh[0] > 14 && (lh[0] & 7) == 7) lh[0]++;
+		break;
+	case CK_LARGE:
+		*cell = 14000;
+		if (res == -4) { if (lh[0] == -7 || lh[0] == -8) { if (lhm1 < 2 && lhm1 > -8) lh[0] = -9; } }
+		else if (res < -6) {
+			if (res < -7 && q >= 21) *cell = 14900;
+			else if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; }
+			else if (lh[0] == 7 || lh[0] == 8) { if (lhm1 >= -1 && lhm1 < 8) lh[0] += 3; }
 		}
-		else if (a == -4 && (res == 2 || res == 3) && (d2 == 2 || d2 == 3)) {
-			if (res == 2 && d2 == 2) pr[ps]++; else MARK(12400, -2);
-		}
-		else if (res == 1 && a == 3 && d2 == 2) {
-			if (r > 0 && (pr[-ps] - orow[-os]) >= 0) MARK(12400, -2);
-		}
-		else if ((res == 3 || res == 4 || res == 5 || res > 6) && (a == 3 || (a & 0xFFFE) == 4)) {
-			if (res > 6) SNAP(12500);
-			else if (q >= 19) SNAP(12100);
-			else if (q == 18) {
-				if (res < 5 && a == 5) orow[os] = 14100;
-				else if (res >= 5) *cell = 14100;
-				else if (res == 3 && a >= 4) orow[os] = 14100;
-				pr[ps] = orow[os];
-			}
-		}
-		else if ((res == 2 || res == 3) && (a == 2 || a == 3)) {
-			if (d2 == 0 || d2 == 1) {
-				const int x0 = NB(0), x1 = NB(1);
-				if ((x0 == 2 || x0 == 3) && (x1 == 2 || x1 == 3) && NB(2) > 0) MARK(12400, -2);
-			}
-		}
-		else if (a == 4 && (res == -2 || res == -3) && (d2 == -2 || d2 == -3)) {
-			if (res == -2 && d2 == -2) pr[ps]--; else MARK(12300, 2);
-		}
-		else if ((res == -3 || res == -4 || res == -5 || res < -7) && (a == -3 || a == -4 || a == -5)) {
-			if (res < -7) SNAP(12600);
-			else if (q >= 19) SNAP(12200);
-			else if (q == 18) {
-				if (res > -5 && a == -5) orow[os] = 14000;
-				else if (res <= -5) *cell = 14000;
-				else if (res == -3 && a <= -4) orow[os] = 14000;
-				pr[ps] = orow[os];
-			}
-		}
-		else if (a == -2 || a == -3) {
-			if (res == -2 || res == -3) {
-				if (d2 < 0) MARK(12300, 2);
-				else if (res == -3 && q >= 21) *cell = 14500;
-				else if (d2 == 0) {
-					const int x0 = NB(0), x1 = NB(1);
-					if ((x0 == -2 || x0 == -3) && (x1 == -2 || x1 == -3) && NB(2) < 0) MARK(12300, 2);
-				}
-				else if (res == -2) NUDGE_M2();
-				else NUDGE_M3();
-			}
-			else if (res == -1 && a == -3 && d2 == -2) {
-				if (r > 0 && (pr[-ps] - orow[-os]) <= 0) MARK(12300, 2);
-			}
-			else if (res == -1) { if (d2 == -3) MARK(12300, 2); else NUDGE_UP(); }
-			else if (res == -4) { if (d2 < -1 && d2 > -4) MARK(12300, 2); else MARK_LARGE(); }
-		}
-		else if (!res || res == -1) NUDGE_UP();
-		else if (res == -2) NUDGE_M2();
-		else if (res == -3) NUDGE_M3();
-		else if (res < -res_setting) MARK_LARGE();
+		break;
+	default: break;
+	}
 #undef NB
 #undef MARK
 #undef SNAP
-#undef NUDGE_UP
-#undef NUDGE_M2
-#undef NUDGE_M3
-#undef MARK_LARGE
 }
 
 /* Y22.  The reference walks column after column; column j only reads column j+1 (not yet visited, i.e. its
@@ -549,12 +587,14 @@ DEV void classify_step(int q, int res_setting, int r, int j, int16_t *pr, int ps
  * runs afterwards on a packed LDS copy of its column: its "column 256" is the LH1 column written by the other
  * columns, its ll1 neighbour is column 0, both read live. */
 #define CR 16
-#define CR_LDS_BYTES (((CR + 3) * 3 * H + H * (CR + 2)) * 2)
+#define CR_LDS_BYTES (((CR + 3) * 3 * H + H * (CR + 2)) * 2 + CK_TABLE_BYTES)
 DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 {
 	int16_t *p = c->proc, *o = c->ll1;
 	const int q = c->q;
 	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *dt = lds + 2 * (CR + 3) * H, *lt = lds + 3 * (CR + 3) * H;   /* pt/ot/dt: rows r0-1 .. r0+CR+1; lt: [column][CR + 2] */
+	uint8_t *ktab = reinterpret_cast<uint8_t *>(lds + 3 * (CR + 3) * H + H * (CR + 2));
+	classify_table_fill(ktab, q, res_setting, tid);
 	const int j = tid;
 	int lhm1 = p[j * W + H - 1];                                    /* (j, 255): nothing has touched it yet */
 	for (int r0 = 0; r0 < H - 1; r0 += CR) {
@@ -587,7 +627,7 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 		if (j < H - 1)
 			for (int i = 0; i < CR && r0 + i < H - 1; i++) {
 				int16_t *lh = lt + j * (CR + 2) + i;
-				classify_step<true>(q, res_setting, r0 + i, j, pt + (i + 1) * H + j, H, ot + (i + 1) * H + j, H, lh, lhm1, dt + (i + 1) * H + j + 1, H, nullptr, 0);
+				classify_step<true>(ktab, q, r0 + i, j, pt + (i + 1) * H + j, H, ot + (i + 1) * H + j, H, lh, lhm1, dt + (i + 1) * H + j + 1, H, nullptr, 0);
 				lhm1 = lh[0];
 			}
 		BARRIER();
@@ -611,7 +651,7 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 		if (tid == 0) {
 			int prev = p[(H - 1) * W + H - 1];
 			for (int r = 0; r < H - 1; r++) {
-				classify_step<false>(q, res_setting, r, H - 1, pc + r, 1, oc + r, 1, lc + r, prev, p, W, o, 1 << 30);
+				classify_step<false>(ktab, q, r, H - 1, pc + r, 1, oc + r, 1, lc + r, prev, p, W, o, 1 << 30);
 				if (r == 0) p[(H - 1) * W + H] = lc[0];                /* (255, 256) is also this column's "column 256" neighbour of row 255 */
 				prev = lc[r];
 			}
