@@ -2065,7 +2065,6 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	const uint8_t *d = c->scan + (part ? 4 * Q : 0);
 	const int N = part ? 2 * Q : 4 * Q;
 	const int S = N - 1, nchunks = (S + PK_CHUNK - 1) / PK_CHUNK;
-	unsigned *cnt = reinterpret_cast<unsigned *>(c->pay);       /* [3][nchunks * NT] per-slice bit / sign-bit counts */
 	const int nsl = nchunks * NT;
 
 	int *prevnz = reinterpret_cast<int *>(c->raw), *nextnz = prevnz + nsl + 8;   /* last non-zero symbol before / first at-or-after a slice */
@@ -2167,42 +2166,29 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	}
 	BARRIER();
 	if (!tid) PROF(c, 24);
-	for (int ch = 0; ch < nchunks; ch++) {
-		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
-		unsigned b = 0, x1 = 0, x2 = 0;
-		const uint8_t *dl = pack_stage(d, N, ch, tid, lw);
-		if (lo < S) pack_walk<1>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &b, &x1, &x2, prevnz, nextnz, ch * NT + tid);
-		cnt[ch * NT + tid] = b; cnt[nsl + ch * NT + tid] = x1; cnt[2 * nsl + ch * NT + tid] = x2;
-	}
-	BARRIER();
-	{                                                            /* exclusive prefix sums over the slices in stream order */
-		/* level 1: thread t owns slices [t*nchunks, (t+1)*nchunks) of the flattened order */
-		unsigned sum[3] = { 0, 0, 0 };
-		for (int v = 0; v < 3; v++) for (int k = 0; k < nchunks; k++) sum[v] += cnt[v * nsl + tid * nchunks + k];
-		sh->bits[tid] = sum[0]; sh->n1[tid] = sum[1]; sh->n2[tid] = sum[2];
-		BARRIER();
-		if (tid == 0) {
-			unsigned b = 0, x1 = 0, x2 = 0;
-			for (int t = 0; t < NT; t++) { const unsigned vb = sh->bits[t], v1 = sh->n1[t], v2 = sh->n2[t]; sh->bits[t] = b; sh->n1[t] = x1; sh->n2[t] = x2; b += vb; x1 += v1; x2 += v2; }
-			sh->total_bits = b; sh->total_n1 = x1; sh->total_n2 = x2;
-		}
-		BARRIER();
-		unsigned run[3] = { sh->bits[tid], sh->n1[tid], sh->n2[tid] };
-		for (int k = 0; k < nchunks; k++)
-			for (int v = 0; v < 3; v++) { const unsigned x = cnt[v * nsl + tid * nchunks + k]; cnt[v * nsl + tid * nchunks + k] = run[v]; run[v] += x; }
-	}
-	BARRIER();
-	if (!tid) PROF(c, 25);
-	const int nwords = sh->total_bits ? (int)((sh->total_bits - 1) >> 5) + 1 : 1;
+	/* bit counts and bits in one sweep: while a chunk is in LDS every slice is walked twice -- once to count its code bits
+	 * and sign symbols, and, after a workgroup prefix sum on top of the running totals, once to drop its bits at their
+	 * offset.  The words a chunk will touch are zeroed just ahead of it (the chunk before may share its first word). */
 	uint32_t *words = c->packet + word0;
-	for (int t = tid; t < nwords; t += NT) words[t] = 0;
-	BARRIER();
+	unsigned base_bits = 0, base_n1 = 0, base_n2 = 0;
+	int zeroed = 0;                                              /* words [0, zeroed) are cleared or already carry bits */
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
+		unsigned bb = 0, x1 = 0, x2 = 0, tb, tn;
 		const uint8_t *dl = pack_stage(d, N, ch, tid, lw);
-		if (lo < S) pack_walk<2>(dl, N, lo, hi, sh, words, cnt[ch * NT + tid], c->s1, cnt[nsl + ch * NT + tid], c->s2, cnt[2 * nsl + ch * NT + tid], nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
+		if (lo < S) pack_walk<1>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, prevnz, nextnz, ch * NT + tid);
+		const unsigned ob = block_exscan(bb, tid, sh->bits, &tb);
+		const unsigned on = block_exscan(x1 | (x2 << 16), tid, sh->bits, &tn);
+		const int last = tb ? (int)((base_bits + tb - 1) >> 5) : zeroed - 1;
+		for (int w = zeroed + tid; w <= last; w += NT) words[w] = 0;
+		BARRIER();
+		if (lo < S) pack_walk<2>(dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
+		base_bits += tb; base_n1 += tn & 0xFFFF; base_n2 += tn >> 16;
+		if (last + 1 > zeroed) zeroed = last + 1;
 	}
+	if (tid == 0) { if (!zeroed) words[0] = 0; sh->total_bits = base_bits; sh->total_n1 = base_n1; sh->total_n2 = base_n2; }
 	BARRIER();
+	const int nwords = sh->total_bits ? (int)((sh->total_bits - 1) >> 5) + 1 : 1;
 	if (!tid) PROF(c, 26);
 
 	const uint16_t *sorted = reinterpret_cast<const uint16_t *>(c->hist);
