@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 	ctx_load(&c, ws, img);
 	if (PH == WV_DQ1) wave_dequant_sim_luma(&c, 1, lane);
 	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane);
-	else if (PH == WV_QUANT) { PROF_BEGIN(); wave_quantise_luma(&c, lane); if (!lane) PROF(&c, 15); }
+	else if (PH == WV_QUANT) {
+		__shared__ __attribute__((aligned(16))) uint8_t park[4][16 * QROW];
+		PROF_BEGIN(); wave_quantise_luma(&c, lane, park[threadIdx.x >> 6], ws.q > 21); if (!lane) PROF(&c, 15);
+	}
 	else if (PH == WV_EMIT) { PROF_BEGIN(); wave_emit_ll2(&c, lane); if (!lane) PROF(&c, 4); }
 }
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s)

@@ -990,16 +990,16 @@ DEV void fix_sign_code(uint8_t *s, int at) { if (s[at] == 153) s[at] = 124; else
  * pair rule (two adjacent positions cannot both match it), every other test compares against 128, which is
  * never written.  Rewrite 3 touches only sign codes next to zero runs of >= 252: each thread scans the runs
  * that start in its slice and replays the rare long ones. */
-DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /* shared [n/16/32 + 2] */, int16_t *lds /* 16 x 520 shorts */)
+DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /* shared [n/16/32 + 2] */, int16_t *lds /* 16 x 520 shorts */, bool stream_written = false)
 {
 	const int16_t *p = c->proc;
 	uint8_t *s = c->scan;
 	const int n = 4 * Q;
 	uint32_t *bits = reinterpret_cast<uint32_t *>(c->half);      /* n bits of selection flags */
 
-	/* serpentine gather (:2108-2132) through LDS: 16 plane rows (coalesced 1 KiB rows) -> per 4-column strip a run of
+	/* serpentine gather (:2108-2132) through LDS (the quantiser kernel writes the stream itself, this is the stand-alone form): 16 plane rows (coalesced 1 KiB rows) -> per 4-column strip a run of
 	 * 64 consecutive stream bytes, written 16 bytes per thread */
-	for (int rb = 0; rb < W; rb += 16) {
+	for (int rb = 0; rb < W && !stream_written; rb += 16) {
 		for (int idx = tid; idx < 16 * (W / 8); idx += NT) {
 			const int r = idx >> 6, o = idx & 63;
 			reinterpret_cast<uint4 *>(lds + r * (W + 8))[o] = reinterpret_cast<const uint4 *>(p + (rb + r) * W)[o];
@@ -1786,7 +1786,7 @@ DEV void luma_p4c2_par(Ctx *c, int tid)                                     /* Y
 DEV void luma_p4d_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z, int16_t *lds)
 {
 	PROF_BEGIN();
-	scan_and_rewrite_par(c, tid, sh_counts, sh_z, lds);                     /* Y30, Y31 */
+	scan_and_rewrite_par(c, tid, sh_counts, sh_z, lds, true);               /* Y31 (Y30: the quantiser wrote the stream) */
 	if (!tid) PROF(c, 17);
 }
 

@@ -492,9 +492,14 @@ DEV int quant_symbol(int a, int nx)                               /* :375-396 + 
 	return (a < DEADZONE && a > -DEADZONE) ? 128 : ((a + 128) & 248);
 }
 
-DEV void wave_quantise_luma(Ctx *c, int lane)
+/* The symbols go straight into the stream in its serpentine order (Y30, nhw_encoder.c:2108-2132: 128 strips of 4 columns,
+ * within a strip row after row, odd rows right to left): 16 rows are parked as bytes in a wave-private LDS block and
+ * leave as one 64-byte run per strip.  The int16 plane is only written when Y29 needs it (q > 21). */
+#define QROW 516
+DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes of this wavefront */, bool write_plane)
 {
 	int16_t *p = c->proc;
+	uint8_t *stream = c->scan;
 	int prev[8], cur[8], nxt[8];
 	int q0[8], q1[8];                                              /* rows r+2, r+3 in flight */
 	quant_load_row(p, 0, lane, cur);
@@ -581,7 +586,23 @@ DEV void wave_quantise_luma(Ctx *c, int lane)
 					else if (raw > 127) sym = big_code(raw, k_big_pos);
 					else if (raw < -127) sym = big_code(-raw, k_big_neg);
 				}
-				p[(r - 1) * W + lane + 64 * k] = (int16_t)sym;
+				if (write_plane) p[(r - 1) * W + lane + 64 * k] = (int16_t)sym;
+				park[((r - 1) & 15) * QROW + lane + 64 * k] = (uint8_t)sym;
+			}
+			if (((r - 1) & 15) == 15) {                                /* 16 rows complete: strips lane and lane + 64 */
+				__threadfence_block();
+				const int rb = r - 16;
+				for (int h = 0; h < 2; h++) {
+					const int strip = lane + 64 * h;
+					uint32_t w[16];
+					for (int i = 0; i < 16; i++) {
+						const uint32_t x = *reinterpret_cast<const uint32_t *>(park + i * QROW + 4 * strip);
+						w[i] = ((rb + i) & 1) ? __builtin_bswap32(x) : x;
+					}
+					uint4 *dst = reinterpret_cast<uint4 *>(stream + strip * (4 * W) + 4 * rb);
+					for (int i = 0; i < 4; i++) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+				}
+				__threadfence_block();
 			}
 		}
 		for (int k = 0; k < 8; k++) { prev[k] = cur[k]; cur[k] = nxt[k]; nxt[k] = q0[k]; q0[k] = q1[k]; q1[k] = far[k]; }

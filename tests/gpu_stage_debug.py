@@ -44,7 +44,8 @@ def main(qs, seeds=(0, 1)):
              (9, 1, "wavelet_analysis_256"), (11, 0, "offsetY_recons256_p0"), (12, 1, "wavelet_synthesis_256")]
         for st, k, nm in L:
             plan.append((st + shift, k, nm, [("JPEG", 0, 8 * 65536), ("PROC", 1, 8 * 65536)]))
-        plan.append((13 + shift, 0, "offsetY", [("PROC", 0, 8 * 65536)]))
+        if q >= 22:   # below that the quantiser writes the symbol stream directly and leaves the plane alone
+            plan.append((13 + shift, 0, "offsetY", [("PROC", 0, 8 * 65536)]))
         for comp in (0, 1):
             base = 13 + shift + 12 * comp
             # the chroma records named wavelet_analysis_256 come after the two luma ones
