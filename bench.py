@@ -23,9 +23,9 @@ sys.path.insert(0, ROOT)
 MPIX_PER_IMAGE = 0.262144
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 FRONT_BYTES_PER_IMAGE = 786432 + 786432   # 3 B/px read + 3 B/px written (Y coeffs + 2 x chroma)
-# HBM bytes of the front launch group per image from the PMC counters (profiles/round1_v12_pmc.json, batch 4096, -q20: FETCH_SIZE x 2 per
-# the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc passes): k_color 4.83+2.68 GB, k_front_rowmaps 2.27+0.31, k_front_chain 0.04, k_front_band 2.91+3.22
-FRONT_PMC_BYTES_PER_IMAGE = (4.826e9 + 2.684e9 + 2.273e9 + 0.306e9 + 0.040e9 + 2.907e9 + 3.221e9) / 4096
+# HBM bytes of the front launch group per image from the PMC counters (profiles/round1_final_pmc.json, batch 4096, -q20: FETCH_SIZE x 2 per
+# the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc passes): k_color 3.62+2.68 GB, k_front_rowmaps 2.27+0.31, k_front_chain 0.04, k_front_band 2.91+3.22
+FRONT_PMC_BYTES_PER_IMAGE = (3.618e9 + 2.684e9 + 2.273e9 + 0.306e9 + 0.040e9 + 2.907e9 + 3.222e9) / 4096
 
 
 def _cpu_worker(args):
@@ -142,7 +142,7 @@ def main():
                        "images_per_gpu": batch, "quality": q, "parallelism": f"dp{world} (independent images, no data-path collective)"},
             "roofline": {"bound": "hbm", "kernel": "front = k_color + k_front_rowmaps + k_front_chain + k_front_band (colour, pre-filter and level-1 analysis; the band kernel fuses pre-filter + both filter directions)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": int(front_images * FRONT_PMC_BYTES_PER_IMAGE) if q == 20 else None, "traffic_unit": "bytes per launch group (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1_v12_pmc.json, scaled from batch 4096)",
+                         "traffic": int(front_images * FRONT_PMC_BYTES_PER_IMAGE) if q == 20 else None, "traffic_unit": "bytes per launch group (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1_final_pmc.json, scaled from batch 4096)",
                          "algorithmic_bytes_per_launch": front_images * FRONT_BYTES_PER_IMAGE, "images_per_launch": front_images, "sub_batches": tim.parts, "algorithmic_bytes_per_image": FRONT_BYTES_PER_IMAGE, "ms_per_launch_group": round(front_s * 1e3, 3)},
             "stage_ms": {"front": round(tim.front_ms, 3), "luma_tail": round(tim.luma_ms, 3), "chroma": round(tim.chroma_ms, 3),
                          "entropy+container": round(tim.entropy_ms, 3), "total": round(tim.total_ms, 3)},
