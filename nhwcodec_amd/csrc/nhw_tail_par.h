@@ -1965,6 +1965,7 @@ struct PackShared {
 	uint16_t entry[600];
 	uint16_t rank_sym[256], rank_run[256];
 	uint32_t code_sym[256], code_run[256];
+	uint16_t sorted[360];                                         /* code book entries by rank */
 	unsigned bits[NT], n1[NT], n2[NT];
 	int k, select, zone, top_is_zero, rc;
 	unsigned total_bits, total_n1, total_n2;
@@ -2143,14 +2144,13 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 			for (int j = 0; j < k; j++) rank += (sh->weight[j] > w) || (sh->weight[j] == w && j < e);
 			const uint16_t en = sh->entry[e];
 			if ((en >> 8) == 1) sh->rank_sym[en & 0xFF] = (uint16_t)rank; else sh->rank_run[en >> 8] = (uint16_t)rank;
-			reinterpret_cast<uint16_t *>(c->hist)[rank] = en;    /* sorted code book entries (global scratch) */
+			sh->sorted[rank] = en;
 		}
 	}
 	BARRIER();
 	if (tid == 0) {
-		const uint16_t *sorted = reinterpret_cast<const uint16_t *>(c->hist);
 		const int k = sh->k, select = sh->select;
-		sh->top_is_zero = (sorted[0] == ((1 << 8) | 128));
+		sh->top_is_zero = (sh->sorted[0] == ((1 << 8) | 128));
 		if (part == 0 && !sh->top_is_zero && k > 290) sh->rc = NHW_E_CODEBOOK;      /* :269-271 */
 		if (part == 1 && select != 4 && k > 290) sh->rc = NHW_E_CODEBOOK;
 		sh->zone = (part == 0 && select == 4 && sh->top_is_zero);
@@ -2191,8 +2191,10 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	const int nwords = sh->total_bits ? (int)((sh->total_bits - 1) >> 5) + 1 : 1;
 	if (!tid) PROF(c, 26);
 
-	const uint16_t *sorted = reinterpret_cast<const uint16_t *>(c->hist);
-	uint8_t *tmp_book = reinterpret_cast<uint8_t *>(c->hist) + 1024;
+	/* the code book (:400-459) is one short serial walk: on LDS, then copied out by everybody */
+	const uint16_t *sorted = sh->sorted;
+	uint8_t *book = reinterpret_cast<uint8_t *>(lw), *tmp_book = book + 1024;
+	int *book_len = reinterpret_cast<int *>(book + 2048);
 	if (part == 0) {
 		const int n1 = (int)sh->total_n1, n2 = (int)sh->total_n2;
 		const int b1 = (n1 >> 3) + 1, b2 = (n2 >> 3) + 1;        /* sign bits, 8 per byte (:370-398) */
@@ -2205,37 +2207,42 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 			c->m->wavelet_type = (sh->select > 4 || !sh->top_is_zero) ? 4 : 0;       /* :367-368 */
 			c->m->select1 = b1; c->m->select2 = b2;
 			for (i = 0; i < k; i++) {                                                 /* code book 1 (:400-424) */
-				if ((sorted[i] >> 8) == 1) c->book1[e++] = (uint8_t)(sorted[i] & 0xFF);
-				else { c->book1[e++] = 3; c->book1[e++] = (uint8_t)(sorted[i] >> 8); }
+				if ((sorted[i] >> 8) == 1) book[e++] = (uint8_t)(sorted[i] & 0xFF);
+				else { book[e++] = 3; book[e++] = (uint8_t)(sorted[i] >> 8); }
 			}
-			for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = c->book1[i];
-			for (i = 1; i < e; i += 2) tmp_book[b++] = c->book1[i];
+			for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = book[i];
+			for (i = 1; i < e; i += 2) tmp_book[b++] = book[i];
 			tmp_book[e] = 0;
 			for (i = 0, w = 0, b = 0; i < e; i++) {
 				while (tmp_book[i] == 3) { b++; i++; }
-				if (b > 0) { c->book1[w++] = 3; c->book1[w++] = (uint8_t)b; b = 0; i--; }
-				else c->book1[w++] = tmp_book[i];
+				if (b > 0) { book[w++] = 3; book[w++] = (uint8_t)b; b = 0; i--; }
+				else book[w++] = tmp_book[i];
 			}
-			c->m->size_book1 = w;
+			c->m->size_book1 = w; *book_len = w;
 		}
 	} else if (tid == 0) {
 		const int k = sh->k;
 		int e = 0, b, w, i;
 		c->m->size_data2 = word0 + nwords;
 		for (i = 0; i < k; i++) {                                                     /* code book 2 (:431-459) */
-			if ((sorted[i] >> 8) == 1) c->book2[e++] = (uint8_t)((sorted[i] & 0xFF) | 1);
-			else { c->book2[e++] = (uint8_t)(sorted[i] & 0xFF); c->book2[e++] = (uint8_t)(sorted[i] >> 8); }
+			if ((sorted[i] >> 8) == 1) book[e++] = (uint8_t)((sorted[i] & 0xFF) | 1);
+			else { book[e++] = (uint8_t)(sorted[i] & 0xFF); book[e++] = (uint8_t)(sorted[i] >> 8); }
 		}
 		c->m->tree_end = e;
-		for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = c->book2[i];
-		for (i = 1; i < e; i += 2) tmp_book[b++] = c->book2[i];
+		for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = book[i];
+		for (i = 1; i < e; i += 2) tmp_book[b++] = book[i];
 		tmp_book[e] = 0;
 		for (i = 0, w = 0, b = 0; i < e; i++) {
 			while (tmp_book[i] == 128) { b++; i++; }
-			if (b > 0) { c->book2[w++] = 128; c->book2[w++] = (uint8_t)b; b = 0; i--; }
-			else c->book2[w++] = tmp_book[i];
+			if (b > 0) { book[w++] = 128; book[w++] = (uint8_t)b; b = 0; i--; }
+			else book[w++] = tmp_book[i];
 		}
-		c->m->size_book2 = w;
+		c->m->size_book2 = w; *book_len = w;
+	}
+	BARRIER();
+	{
+		uint8_t *dst = part ? c->book2 : c->book1;
+		for (int i = tid; i < *book_len; i += NT) dst[i] = book[i];
 	}
 	BARRIER();
 }
