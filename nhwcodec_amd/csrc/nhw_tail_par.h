@@ -2097,11 +2097,11 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 		for (int k = 0; k < nchunks; k++) { const int g = tid * nchunks + k; mx = prevnz[g] > mx ? prevnz[g] : mx; mn = nextnz[g] < mn ? nextnz[g] : mn; }
 		shm[tid] = mx; shn[tid] = mn;
 		BARRIER();
-		if (tid == 0) {
-			int run = -1;
-			for (int t = 0; t < NT; t++) { const int v = shm[t]; shm[t] = run; run = v > run ? v : run; }
-			run = N;
-			for (int t = NT - 1; t >= 0; t--) { const int v = shn[t]; shn[t] = run; run = v < run ? v : run; }   /* exclusive of the own block */
+		{                                                        /* exclusive prefix max of mx, exclusive suffix min of mn over the threads (wave scans) */
+			const int a = (int)block_exscan_max((unsigned)(mx + 1), tid, sh->n2) - 1;
+			const int b = N - (int)block_exscan_max((unsigned)(N - shn[NT - 1 - tid]), tid, sh->n2);
+			BARRIER();
+			shm[tid] = a; shn[NT - 1 - tid] = b;
 		}
 		BARRIER();
 		int run = shm[tid];
@@ -2118,21 +2118,25 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	}
 	BARRIER();
 	if (!tid) PROF(c, 23);
-	if (tid == 0) {                                              /* L_RATIO (:128-236) */
-		int select = sh->select, k;
-		for (;;) {
-			unsigned zeros = sh->hist[128] > 0 ? (unsigned)sh->hist[128] : 0;
-			for (int j = 2; j < 256; j++) if (sh->runs[j] > 0) zeros += (unsigned)(j * sh->runs[j]);
-			for (int j = 2; j < select; j++) sh->runs[j] = 0;
-			for (int j = select; j < 256; j++) if (sh->runs[j] > 0) zeros -= (unsigned)(j * sh->runs[j]);
-			sh->hist[128] = (int)zeros;
-			k = 0;
-			for (int j = select; j < 256; j++) if (sh->runs[j] > 0) { sh->entry[k] = (uint16_t)((j << 8) | 128); sh->weight[k++] = (unsigned)sh->runs[j]; }
-			for (int v = 0; v < 256; v++) if (book_ok(v) && sh->hist[v] > 0) { sh->entry[k] = (uint16_t)((1 << 8) | v); sh->weight[k++] = (unsigned)sh->hist[v]; }
-			if (k <= 354) break;
-			if (++select >= 100) { sh->rc = NHW_E_CODEBOOK; break; }
-		}
-		sh->k = k; sh->select = select;
+	for (;;) {                                                   /* L_RATIO (:128-236): short runs become plain zeros until the book fits */
+		const int select = sh->select, j = tid;
+		unsigned tot, totr, tots;
+		(void)block_exscan((j >= 2 && j < select && sh->runs[j] > 0) ? (unsigned)(j * sh->runs[j]) : 0u, tid, sh->n2, &tot);
+		BARRIER();
+		if (j >= 2 && j < select) sh->runs[j] = 0;
+		if (tid == 0) sh->hist[128] = (int)((sh->hist[128] > 0 ? (unsigned)sh->hist[128] : 0u) + tot);
+		BARRIER();
+		const bool fr = j >= select && sh->runs[j] > 0, fs = book_ok(j) && sh->hist[j] > 0;
+		const unsigned orr = block_exscan(fr, tid, sh->n2, &totr);
+		const unsigned os = block_exscan(fs, tid, sh->n2, &tots);
+		if (fr) { sh->entry[orr] = (uint16_t)((j << 8) | 128); sh->weight[orr] = (unsigned)sh->runs[j]; }
+		if (fs && totr + os < 600) { sh->entry[totr + os] = (uint16_t)((1 << 8) | j); sh->weight[totr + os < 360 ? totr + os : 359] = (unsigned)sh->hist[j]; }
+		const int k = (int)(totr + tots);
+		BARRIER();
+		if (k <= 354) { if (tid == 0) sh->k = k; break; }
+		if (tid == 0) { sh->select = select + 1; if (select + 1 >= 100) sh->rc = NHW_E_CODEBOOK; }
+		BARRIER();
+		if (sh->rc) break;
 	}
 	BARRIER();
 	if (sh->rc) return;
