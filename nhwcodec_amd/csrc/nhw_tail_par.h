@@ -25,21 +25,33 @@ namespace nhw {
 DEV void tag_l2_details_par(Ctx *c, int tid)
 {
 	const int16_t *p = c->proc;
-	for (int idx = tid; idx < Q; idx += NT) {
-		const int r = idx >> 8, j = idx & 255;
-		if (r < H / 2 && j < H / 2) continue;
-		const int at = r * W + j, s = p[at];
-		int16_t *cell = c->ll1 + idx;
-		if (s < -7) { if (mult8_or_7(-s)) *cell += 16000; }
-		else if (s < -4) *cell += 12000;
-		else if (s >= 0) {
-			if (s >= 2 && s < 5) {
-				if (at >= W + 1 && at < 2 * Q - W - 1 && (p[at - (W + 1)] != 0 || p[at + (W + 1)] != 0)) *cell += 12000;
+	for (int g = tid; g < Q / 8; g += NT) {                        /* 8 cells of one row per item, 16-byte loads */
+		const int r = g >> 5, j0 = (g & 31) * 8;
+		if (r < H / 2 && j0 < H / 2) continue;
+		const int at0 = r * W + j0;
+		const uint4 pv = *reinterpret_cast<const uint4 *>(p + at0);
+		uint4 cv = *reinterpret_cast<const uint4 *>(c->ll1 + r * H + j0);
+		uint32_t pw[4] = { pv.x, pv.y, pv.z, pv.w }, cw[4] = { cv.x, cv.y, cv.z, cv.w };
+#pragma unroll
+		for (int e = 0; e < 8; e++) {
+			const int s = (int16_t)(pw[e >> 1] >> (16 * (e & 1))), at = at0 + e;
+			int add = 0;
+			if (s < -7) { if (mult8_or_7(-s)) add = 16000; }
+			else if (s < -4) add = 12000;
+			else if (s >= 0) {
+				if (s >= 2 && s < 5) {
+					if (at >= W + 1 && at < 2 * Q - W - 1 && (p[at - (W + 1)] != 0 || p[at + (W + 1)] != 0)) add = 12000;
+				}
+				else if (!(s & 7)) add = 12000;
+				else if ((s & 7) == 1) add = 12000;
+				else if (s > 4 && s <= 7) add = 16000;
 			}
-			else if (!(s & 7)) *cell += 12000;
-			else if ((s & 7) == 1) *cell += 12000;
-			else if (s > 4 && s <= 7) *cell += 16000;
+			if (add) {
+				const int cell = (int16_t)(cw[e >> 1] >> (16 * (e & 1))) + add;
+				cw[e >> 1] = (cw[e >> 1] & ~(0xFFFFu << (16 * (e & 1)))) | ((uint32_t)(uint16_t)cell << (16 * (e & 1)));
+			}
 		}
+		*reinterpret_cast<uint4 *>(c->ll1 + r * H + j0) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
 	}
 }
 
@@ -1766,10 +1778,18 @@ DEV void luma_p4b_par(Ctx *c, int tid, int *pos, int16_t *lds)
 DEV void luma_p4c_par(Ctx *c, int tid, int *pos, int16_t *lds)
 {
 	PROF_BEGIN();
-	for (int idx = tid; idx < Q; idx += NT) {                               /* Y26 :1893-1910 */
-		const int r = idx >> 8, j = idx & 255;
-		const int16_t v = c->l2save[idx];
-		c->proc[r * W + j] = (r < H / 2 && j < H / 2 && v <= 8000) ? 0 : v;
+	for (int g = tid; g < Q / 8; g += NT) {                                  /* Y26 :1893-1910, 8 cells per item */
+		const int r = g >> 5, j0 = (g & 31) * 8;
+		uint4 v = *reinterpret_cast<const uint4 *>(c->l2save + r * H + j0);
+		if (r < H / 2 && j0 < H / 2) {
+			uint32_t w[4] = { v.x, v.y, v.z, v.w };
+			for (int e = 0; e < 4; e++) {
+				if ((int16_t)(w[e] & 0xFFFF) <= 8000) w[e] &= 0xFFFF0000u;
+				if ((int16_t)(w[e] >> 16) <= 8000) w[e] &= 0x0000FFFFu;
+			}
+			v = make_uint4(w[0], w[1], w[2], w[3]);
+		}
+		*reinterpret_cast<uint4 *>(c->proc + r * W + j0) = v;
 	}
 	BARRIER();
 	if (!tid) PROF(c, 13);
