@@ -47,7 +47,7 @@ typedef struct nhw_enc nhw_enc;
 typedef struct {
 	float total_ms;
 	float front_ms;       /* colour + pre-filter + level-1 analysis (the HBM-roofline kernels) */
-	float color_dwt_ms;   /* the fused colour + level-1 analysis kernel alone (0 when q<=21 splits it) */
+	float color_dwt_ms;   /* the colour + 4:2:0 kernel alone, the first kernel of the front group */
 	float luma_ms, chroma_ms, entropy_ms;
 	int parts;            /* sub-batches the stages behind the front ran as (each on a stream of its own); with more than one, luma/chroma/entropy_ms are those of the first */
 	int front_images;     /* images covered by front_ms */

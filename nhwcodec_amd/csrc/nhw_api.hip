@@ -140,6 +140,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	int16_t *yin = e->legacy_front ? jpeg : plane16(ws, B_KMAP);
 	const size_t yin_stride = e->legacy_front ? ws.stride[B_JPEG] : ws.stride[B_KMAP];
 	nhw_launch_color((const uint8_t *)d_bgr, n, q, yin, yin_stride, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
+	HIPCHK(hipEventRecord(e->ev[5], s));                          /* end of the colour kernel (the front runs once per batch, on the caller's stream) */
 	STAGE_DONE();
 	/* a2 + Y2 + Y3: pre-filter (q<=21, nhw_encoder.c:116-119), level-1 analysis (:125), LL1 copy (:127-135), fused */
 	if (e->legacy_front) {
@@ -275,7 +276,7 @@ extern "C" int nhw_enc_last_timing(nhw_enc *e, nhw_timing *t)
 	HIPCHK(hipEventElapsedTime(&t->luma_ms, e->ev[1], e->ev[2]));
 	HIPCHK(hipEventElapsedTime(&t->chroma_ms, e->ev[2], e->ev[3]));
 	HIPCHK(hipEventElapsedTime(&t->entropy_ms, e->ev[3], e->ev[4]));
-	t->color_dwt_ms = 0.f;
+	HIPCHK(hipEventElapsedTime(&t->color_dwt_ms, e->ev[0], e->ev[5]));
 	t->parts = e->timed_parts; t->front_images = e->timed_front_images;
 	return NHW_OK;
 }

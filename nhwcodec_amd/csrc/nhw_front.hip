@@ -33,10 +33,22 @@ __device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned acc
 __device__ __forceinline__ uint8_t clip_u8(int v) { return (v >> 8) != 0 ? (v < 0 ? 0 : 255) : (uint8_t)v; }
 __device__ __forceinline__ int chroma_round(float cb) { return cb >= 0 ? (int)(cb + 128.5f) : (int)(cb + 128.4f); }
 
+/* For q >= 20 the conversion is exact integer arithmetic (checked against the double/float form on all 2^24 triples):
+ *   chroma: cb = (-1687 b0 - 3313 b1 + 5000 b2) / 10000 lies at least 1e-4 away from every rounding boundary the float
+ *           form can hit, so (int)(cb + 128.5f) (cb >= 0) / (int)(cb + 128.4f) (cb < 0) are floors of the exact value;
+ *   luma:   (int)(0.299 b0 + 0.587 b1 + 0.114 b2 + 0.5f) is floor((299 b0 + 587 b1 + 114 b2 + 500) / 1000) except when that
+ *           division is exact (one triple in a thousand): there the double rounding of the three products decides, and
+ *           the lane takes the double path. */
 template <int FAMILY> /* 0: q>=20, 1: q 18/19, 2: q17 */
 __device__ __forceinline__ void convert_uv(const uint8_t *px, float yq, int &U, int &V)
 {
 	const int b0 = px[0], b1 = px[1], b2 = px[2];
+	if (FAMILY == 0) {
+		const int su = -1687 * b0 - 3313 * b1 + 5000 * b2, sv = 5000 * b0 - 4187 * b1 - 813 * b2;
+		U = clip_u8((int)((unsigned)(su + (su >= 0 ? 1285000 : 1284000)) / 10000u));
+		V = clip_u8((int)((unsigned)(sv + (sv >= 0 ? 1285000 : 1284000)) / 10000u));
+		return;
+	}
 	double lu = -0.1687 * b0 - 0.3313 * b1 + 0.5 * b2;
 	double lv = 0.5 * b0 - 0.4187 * b1 - 0.0813 * b2;
 	if (FAMILY == 2) { lu = lu * 0.94; lv = lv * 0.94; }
@@ -47,6 +59,10 @@ template <int FAMILY>
 __device__ __forceinline__ int convert_y(const uint8_t *px, float yq)
 {
 	const int b0 = px[0], b1 = px[1], b2 = px[2];
+	if (FAMILY == 0) {
+		const unsigned s = (unsigned)(299 * b0 + 587 * b1 + 114 * b2 + 500), y = s / 1000u;
+		if (s - 1000u * y != 0u) return (int)y;
+	}
 	const double ly = 0.299 * b0 + 0.587 * b1 + 0.114 * b2;
 	if (FAMILY == 0) return (int)(ly + 0.5f);
 	if (FAMILY == 1) return (int)(ly * yq + 0.5f);
