@@ -314,3 +314,31 @@ def test_sub_batches_on_streams_match_oracle(oracle, n, q):
     for i in (0, 1, n // 2 - 1, n // 2, n // 2 + 1, n - 2, n - 1):
         assert o[i, : sz[i]].cpu().numpy().tobytes() == oracle.encode(oracle.synth(4000 + i), q), f"image {i}"
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [17, 18, 19, 20, 21, 22, 23])
+def test_many_seeds_bit_exact(oracle, q):
+    """40 more synthetic images per quality (seeds far from the ones used elsewhere), bit-exact against the oracle."""
+    import torch
+    import nhwcodec_amd
+    n, base = 40, 70000 + 1000 * q
+    e = nhwcodec_amd.Encoder(0, max_batch=n)
+    o, sizes, status = e.encode_device(e.synth_device(n, seed_base=base), q)
+    torch.cuda.synchronize()
+    assert int((status != 0).sum()) == 0
+    sz = sizes.cpu().numpy()
+    host = o.cpu().numpy()
+    bad = [i for i in range(n) if host[i, : sz[i]].tobytes() != oracle.encode(oracle.synth(base + i), q)]
+    assert not bad, f"q{q}: images {bad} differ from the oracle"
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [17, 19, 20, 22, 23])
+def test_robustness_classes_more_seeds(enc, oracle, q):
+    """White noise and hard-edge rectangles (the worst cases for the order-dependent passes and the packetiser), six seeds each."""
+    imgs = [class_image(k, s) for k in ("noise", "blocks") for s in range(1, 7)]
+    got = enc.encode(np.stack(imgs), q)
+    bad = [i for i, im in enumerate(imgs) if got[i] != oracle.encode(im, q)]
+    assert not bad, f"q{q}: images {bad} differ from the oracle"
