@@ -321,10 +321,21 @@ extern "C" int nhw_enc_batch(nhw_enc *e, const uint8_t *bgr, int n, int quality,
 		HIPCHK(hipMalloc((void **)&e->d_offs, sizeof(uint64_t) * (n + 1)));
 		e->conv_cap = n;
 	}
-	hipStream_t s = e->own_stream;
-	HIPCHK(hipMemcpyAsync(e->d_in, bgr, (size_t)n * NHW_IMG_BYTES, hipMemcpyHostToDevice, s));
-	int rc = nhw_enc_batch_device(e, e->d_in, n, quality, e->d_out, e->d_sizes, e->d_status, s);
-	if (rc) return rc;
+	hipStream_t s = e->own_stream, cs = e->part_stream[3];
+	/* chunks of 1024 images: the upload of a chunk (its own stream) overlaps the encode of the one before; every chunk is
+	 * encoded in the first workspace slots, one after the other on `s` */
+	const int chunk = 1024;
+	for (int i0 = 0; i0 < n; i0 += chunk) {
+		const int m = n - i0 < chunk ? n - i0 : chunk;
+		hipEvent_t up;
+		HIPCHK(hipEventCreateWithFlags(&up, hipEventDisableTiming));
+		HIPCHK(hipMemcpyAsync(e->d_in + (size_t)i0 * NHW_IMG_BYTES, bgr + (size_t)i0 * NHW_IMG_BYTES, (size_t)m * NHW_IMG_BYTES, hipMemcpyHostToDevice, cs));
+		HIPCHK(hipEventRecord(up, cs));
+		HIPCHK(hipStreamWaitEvent(s, up, 0));
+		HIPCHK(hipEventDestroy(up));
+		const int rc = nhw_enc_batch_device(e, e->d_in + (size_t)i0 * NHW_IMG_BYTES, m, quality, e->d_out + (size_t)i0 * NHW_OUT_STRIDE, e->d_sizes + i0, e->d_status + i0, s);
+		if (rc) return rc;
+	}
 	k_offsets<<<1, 1, 0, s>>>(e->d_sizes, e->d_offs, n);
 	k_compact<<<n, 256, 0, s>>>(e->d_out, e->d_sizes, e->d_offs, e->d_compact);
 	HIPCHK(hipMemcpyAsync(out_off, e->d_offs, sizeof(uint64_t) * (n + 1), hipMemcpyDeviceToHost, s));
