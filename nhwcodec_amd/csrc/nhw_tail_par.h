@@ -1042,6 +1042,10 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 		w[0] = a_.x; w[1] = a_.y; w[2] = a_.z; w[3] = a_.w; w[4] = b_.x; w[5] = b_.y; w[6] = b_.z; w[7] = b_.w; w[8] = c_.x; w[9] = c_.y; w[10] = c_.z; w[11] = c_.w; } while (0)
 #define WB(w, k) ((int)(((w)[((k) + 16) >> 2] >> (8 * (((k) + 16) & 3))) & 0xFF))      /* byte at base + k, -16 <= k < 32 */
 #define PM8(v) ((v) == 136 || (v) == 120)
+	/* any +-8 symbol (136 / 120) among the 16 own bytes of a window?  (zero-byte test on the words xor-ed with the symbol) */
+#define HASZ(x) ((((x) - 0x01010101u) & ~(x)) & 0x80808080u)
+#define ANY_PM8(w) ((HASZ((w)[4] ^ 0x88888888u) | HASZ((w)[5] ^ 0x88888888u) | HASZ((w)[6] ^ 0x88888888u) | HASZ((w)[7] ^ 0x88888888u) | \
+                     HASZ((w)[4] ^ 0x78787878u) | HASZ((w)[5] ^ 0x78787878u) | HASZ((w)[6] ^ 0x78787878u) | HASZ((w)[7] ^ 0x78787878u)) != 0)
 	for (int w = tid; w < n / 32; w += NT) bits[w] = 0;
 	if (tid < 4) sh_z[n / 16 / 32 + tid] = 0;
 	BARRIER();
@@ -1052,6 +1056,7 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 			const unsigned long long mask = __ballot(w[4] == 0x80808080u && w[5] == 0x80808080u && w[6] == 0x80808080u && w[7] == 0x80808080u);
 			if ((tid & 63) == 0) { sh_z[base >> 9] = (uint32_t)mask; sh_z[(base >> 9) + 1] = (uint32_t)(mask >> 32); }
 		}
+		if (!ANY_PM8(w)) continue;
 #pragma unroll
 		for (int k = 0; k < 16; k++) {
 			const int cpos = base + k;
@@ -1081,6 +1086,7 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 		for (int base = 16 * tid; base < n; base += 16 * NT) {
 			uint32_t w[12];
 			WIN_LOAD(w, base);
+			if (!ANY_PM8(w)) continue;
 #pragma unroll
 			for (int k = 0; k < 16; k++) {
 				const int i = base + k, v = WB(w, k);
@@ -1108,17 +1114,17 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 	if (tid == 0) { c->m->select1 = sh_counts[0]; c->m->select2 = sh_counts[1]; }
 
 	for (int base = 16 * tid; base < n; base += 16 * NT) {         /* rewrite 3: owners of run starts */
+		{                                                          /* a run of >= 253 that starts in this group covers the 14 groups that follow: cheap reject before anything is loaded */
+			const int g = (base >> 4) + 1;
+			const unsigned long long z = ((unsigned long long)sh_z[(g >> 5) + 1] << 32 | sh_z[g >> 5]) >> (g & 31);
+			if ((z & 0x3FFF) != 0x3FFF) continue;
+		}
 		uint32_t w[12];
 		WIN_LOAD(w, base);
 #pragma unroll
 		for (int k = 0; k < 16; k++) {
 			const int i = base + k;
 			if (WB(w, k) != 128 || WB(w, k + 1) != 128 || (i > 0 && WB(w, k - 1) == 128)) continue;
-			{                                                      /* a run of >= 253 covers the 14 groups that follow: cheap reject */
-				const int g = (base >> 4) + 1;
-				const unsigned long long z = ((unsigned long long)sh_z[(g >> 5) + 1] << 32 | sh_z[g >> 5]) >> (g & 31);
-				if ((z & 0x3FFF) != 0x3FFF) continue;
-			}
 			/* run [i, b]: walk to the end of the 16-byte group, hop over all-zero groups with the bitmap, finish bytewise */
 			int b = i + 1;
 			while (((b + 1) & 15) && s[b + 1] == 128) b++;
@@ -1148,6 +1154,8 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 #undef WIN_LOAD
 #undef WB
 #undef PM8
+#undef HASZ
+#undef ANY_PM8
 }
 
 
