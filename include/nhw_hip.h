@@ -76,7 +76,7 @@ int nhw_synth_batch_device(nhw_enc *e, void *d_bgr, int n, uint32_t seed_base, v
 int nhw_enc_last_timing(nhw_enc *e, nhw_timing *t);
 
 /* ---- stage-level entry points (kernel parity tests; same stream rules) ----
- * colour + 4:2:0 (colorspace.c:55-260): d_y n*262144 int16, d_u/d_v n*65536 uint8 */
+ * colour + 4:2:0 (colorspace.c:55-260), any quality 1..23: d_y n*262144 int16, d_u/d_v n*65536 uint8 */
 int nhw_stage_color(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_y, void *d_u, void *d_v, void *stream);
 /* luma pre-filter (image_processing.c:558-2426, q17..21), in place on d_y */
 int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, void *stream);

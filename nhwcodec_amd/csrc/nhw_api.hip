@@ -350,7 +350,7 @@ extern "C" int nhw_enc_batch(nhw_enc *e, const uint8_t *bgr, int n, int quality,
 extern "C" int nhw_stage_color(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_y, void *d_u, void *d_v, void *stream)
 {
 	if (!e || n < 1) return NHW_E_ARG;
-	if (!nhw_quality_supported(quality)) return NHW_E_QUALITY;
+	if (quality < 1 || quality > 23) return NHW_E_QUALITY;          /* this stage covers every quality (the whole encoder: 17..23) */
 	HIPCHK(hipSetDevice(e->device));
 	nhw_launch_color((const uint8_t *)d_bgr, n, quality, (int16_t *)d_y, 8 * Q, (uint8_t *)d_u, (uint8_t *)d_v, Q, stream ? (hipStream_t)stream : e->own_stream);
 	HIPCHK(hipGetLastError());

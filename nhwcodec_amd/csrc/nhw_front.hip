@@ -39,10 +39,16 @@ __device__ __forceinline__ int chroma_round(float cb) { return cb >= 0 ? (int)(c
  *   luma:   (int)(0.299 b0 + 0.587 b1 + 0.114 b2 + 0.5f) is floor((299 b0 + 587 b1 + 114 b2 + 500) / 1000) except when that
  *           division is exact (one triple in a thousand): there the double rounding of the three products decides, and
  *           the lane takes the double path. */
-template <int FAMILY> /* 0: q>=20, 1: q 18/19, 2: q17 */
+template <int FAMILY> /* 0: q>=20, 1: q 18/19, 2: q17, 3: q<=16 (integer BT.601 scaled by the quality table; yq carries the table entry's bits) */
 __device__ __forceinline__ void convert_uv(const uint8_t *px, float yq, int &U, int &V)
 {
 	const int b0 = px[0], b1 = px[1], b2 = px[2];
+	if (FAMILY == 3) {                                             /* colorspace.c:172-214 */
+		const int qz = __float_as_int(yq);
+		U = clip_u8((((-38 * b0 - 74 * b1 + 112 * b2) * qz + 4194304) >> 23) + 128);
+		V = clip_u8((((112 * b0 - 94 * b1 - 18 * b2) * qz + 4194304) >> 23) + 128);
+		return;
+	}
 	if (FAMILY == 0) {
 		const int su = -1687 * b0 - 3313 * b1 + 5000 * b2, sv = 5000 * b0 - 4187 * b1 - 813 * b2;
 		U = clip_u8((int)((unsigned)(su + (su >= 0 ? 1285000 : 1284000)) / 10000u));
@@ -59,6 +65,7 @@ template <int FAMILY>
 __device__ __forceinline__ int convert_y(const uint8_t *px, float yq)
 {
 	const int b0 = px[0], b1 = px[1], b2 = px[2];
+	if (FAMILY == 3) return (((66 * b0 + 129 * b1 + 25 * b2) * __float_as_int(yq) + 4194304) >> 23) + 16;
 	if (FAMILY == 0) {
 		const unsigned s = (unsigned)(299 * b0 + 587 * b1 + 114 * b2 + 500), y = s / 1000u;
 		if (s - 1000u * y != 0u) return (int)y;
@@ -820,7 +827,11 @@ void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_str
 	const dim3 grid(H / 4, n);
 	if (q >= 20) k_color<0><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, 0.f);
 	else if (q >= 18) k_color<1><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, q == 19 ? 0.975f : 0.93f);
-	else k_color<2><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, 0.f);
+	else if (q == 17) k_color<2><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, 0.f);
+	else {                                                         /* quality table of colorspace.c:174-189 (format constants) */
+		static const int k_qtz[17] = { 0, 15900, 16500, 17100, 18000, 18820, 19670, 20640, 21540, 23540, 25570, 27522, 27830, 27607, 28786, 31262, 32375 };
+		k_color<3><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, __builtin_bit_cast(float, k_qtz[q < 1 ? 1 : q]));
+	}
 }
 
 void nhw_launch_prefilter(int16_t *y, size_t y_stride, int16_t *kmap, size_t k_stride, uint64_t *maps, size_t m_stride,

@@ -61,9 +61,10 @@ def _cuda(a):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [17, 18, 19, 20])
+@pytest.mark.parametrize("q", [1, 9, 16, 17, 18, 19, 20])
 def test_colour_exhaustive_all_2_24_triples(enc, oracle, q):
-    """a1: every (b0,b1,b2) triple once (64 images x 262144 pixels): Y in double, chroma through float."""
+    """a1: every (b0,b1,b2) triple once (64 images x 262144 pixels): Y in double, chroma through float (q >= 17; exact integer form
+    for q >= 20), integer BT.601 scaled by the quality table below (the colour stage covers every quality)."""
     import torch
     idx = np.arange(1 << 24, dtype=np.uint32)
     imgs = np.stack([(idx >> 16).astype(np.uint8), (idx >> 8).astype(np.uint8), idx.astype(np.uint8)], axis=1).reshape(64, 512, 512, 3)

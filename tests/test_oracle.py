@@ -104,3 +104,16 @@ def test_reference_decoder_accepts_oracle_output(oracle, tmp_path):
     out = np.frombuffer((tmp_path / "a.bmp").read_bytes()[54:], np.uint8).reshape(512, 512, 3).astype(int)
     mse = ((out - img.astype(int)) ** 2).mean()
     assert 10 * np.log10(255 ** 2 / mse) > 30  # a q20 decode is a faithful picture of the input
+
+
+@pytest.mark.parametrize("q", [1, 4, 8, 12, 16])
+def test_colour_below_q17_against_reference(oracle, ref, q):
+    """Row a1 below q17 (integer BT.601 scaled by the quality table, colorspace.c:172-214): the oracle's colour stage against the
+    reference's first checkpoint (the rest of the q <= 16 path is not restated yet, so only this stage is pinned)."""
+    from oracle.harness import class_image
+    for img in (oracle.synth(12), class_image("noise", 2)):
+        _, tr = ref.encode(img, q, trace=True)
+        name, blobs = tr[0]
+        assert name == "downsample_YUV420"
+        y, u, v = oracle.color(img, q)
+        assert blobs[0] == y.tobytes() and blobs[1] == u.tobytes() and blobs[2] == v.tobytes()
