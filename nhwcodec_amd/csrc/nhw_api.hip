@@ -89,7 +89,7 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 	for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&e->ev[i]));
 	for (int i = 0; i < 4; i++) HIPCHK(hipStreamCreateWithFlags(&e->part_stream[i], hipStreamNonBlocking));
 	for (int i = 0; i < 5; i++) HIPCHK(hipEventCreateWithFlags(&e->part_ev[i], hipEventDisableTiming));
-	e->parts = 2;
+	e->parts = 1;   /* sub-batches on streams of their own (NHW_PARTS=2..4) bought 4 % while the tail kernels were latency-bound; they no longer do */
 	if (const char *p = getenv("NHW_PARTS")) { const int k = atoi(p); if (k >= 1 && k <= 4) e->parts = k; }
 	*out = e;
 	return NHW_OK;

@@ -301,11 +301,15 @@ def test_chroma_rows_that_end_in_a_pair_mark(enc, oracle, seed, q):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,q", [(1001, 23), (517, 18)])
 def test_sub_batches_on_streams_match_oracle(oracle, n, q):
-    """Batches of 512 images or more run their stages behind the front as two sub-batches on streams of their own
-    (odd split here): images around the seam and at both ends must equal the oracle's."""
+    """With NHW_PARTS=2, batches of 512 images or more run their stages behind the front as two sub-batches on streams of
+    their own (odd split here): images around the seam and at both ends must equal the oracle's."""
     import torch
     import nhwcodec_amd
-    e = nhwcodec_amd.Encoder(0, max_batch=n)
+    os.environ["NHW_PARTS"] = "2"
+    try:
+        e = nhwcodec_amd.Encoder(0, max_batch=n)
+    finally:
+        del os.environ["NHW_PARTS"]
     bgr = e.synth_device(n, seed_base=4000)
     o, sizes, status = e.encode_device(bgr, q)
     torch.cuda.synchronize()
