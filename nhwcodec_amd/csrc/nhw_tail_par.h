@@ -598,7 +598,7 @@ DEV void classify_step(const uint8_t *tab, int q, int r, int j, int16_t *pr, int
  * from the third on are still untouched; the first three are carried over from the chunk before).  Column 255
  * runs afterwards on a packed LDS copy of its column: its "column 256" is the LH1 column written by the other
  * columns, its ll1 neighbour is column 0, both read live. */
-#define CR 16
+#define CR 8
 #define CR_LDS_BYTES (((CR + 3) * 3 * H + H * (CR + 2)) * 2 + CK_TABLE_BYTES)
 DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 {
