@@ -156,22 +156,29 @@ DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff
 /* ---------------------------------------------------------------- Y9 (R) */
 /* (:218-279) left neighbour is read after its own update, right neighbour before: serial along a row; rows do
  * not interact (column 0 reads proc[r][-1] = the LH1 cell (r-1, 511), which this pass never writes). */
-DEV void precompensate_ll1_par(Ctx *c, int tid, int16_t *lds /* two tiles */)
+DEV void precompensate_ll1_par(Ctx *c, int tid, int16_t *lds /* one tile */)
 {
-	int16_t *tp = lds, *to = lds + NT * TLS;                     /* recon tile (read/write), ll1 tile (read; receives the jpeg values) */
+	/* The walk only looks at differences d = recon - ll1 (its own, its right neighbour's original one, its left neighbour's
+	 * updated one) and moves recon and the jpeg copy of ll1 by the same step: the tile holds the differences, each row's
+	 * thread replaces them by the steps, and the planes are updated from the steps with coalesced pair accesses. */
+	int16_t *p = c->proc, *o = c->ll1, *jp = c->jpeg;
 	const int r = tid;
+	int prev = 0;
 	for (int c0 = 0; c0 < H; c0 += TLC) {
-		tile_load(tp, c->proc, W, H, c0, tid);
-		tile_load(to, c->ll1, H, H, c0, tid);
+		for (int idx = tid; idx < H * (TLS / 2); idx += NT) {
+			const int rr = idx / (TLS / 2), d = idx % (TLS / 2);
+			const uint32_t a = reinterpret_cast<const uint32_t *>(p + (size_t)rr * W + c0 - 2)[d], b2 = reinterpret_cast<const uint32_t *>(o + (size_t)rr * H + c0 - 2)[d];
+			reinterpret_cast<uint32_t *>(lds + rr * TLS)[d] = ((a - b2) & 0xFFFF) | (((a >> 16) - (b2 >> 16)) << 16);
+		}
 		BARRIER();
 		{
-			int16_t *p = tp + r * TLS + 2 - c0, *o = to + r * TLS + 2 - c0;
-			int prev = p[c0 - 1] - o[c0 - 1];                    /* left neighbour after its own update */
+			int16_t *dv = lds + r * TLS + 2 - c0;
+			if (c0 == 0) prev = dv[-1];                             /* left neighbour of column 0 (the cells before the row in memory; never updated) */
 			for (int j = c0; j < c0 + TLC; j++) {
-				const int ov = o[j], d = p[j] - ov;
+				const int d = dv[j];
 				int step = big_step(d);
 				if (!step && iabs(d) > 1) {
-					int a = p[j + 1] - o[j + 1];
+					int a = dv[j + 1];
 					if (iabs(a) > 4) a += big_step(a);
 					a += prev;
 					if (d >= 4 && a >= 1) step = -1;
@@ -187,14 +194,19 @@ DEV void precompensate_ll1_par(Ctx *c, int tid, int16_t *lds /* two tiles */)
 						else if (a <= -4) step = 1;
 					}
 				}
-				p[j] = (int16_t)(p[j] + step);
 				prev = d + step;
-				o[j] = (int16_t)(ov + step);                     /* the jpeg value; o[j] itself is not needed again (prev carries the difference) */
+				dv[j] = (int16_t)step;
 			}
 		}
 		BARRIER();
-		tile_store(tp, c->proc, W, H, c0, TLC, tid);
-		tile_store(to, c->jpeg, W, H, c0, TLC, tid);
+		for (int idx = tid; idx < H * (TLC / 2); idx += NT) {        /* recon += step, jpeg = ll1 + step */
+			const int rr = idx / (TLC / 2), d = idx % (TLC / 2);
+			const uint32_t st = reinterpret_cast<const uint32_t *>(lds + rr * TLS + 2)[d];
+			uint32_t *pp = reinterpret_cast<uint32_t *>(p + (size_t)rr * W + c0) + d;
+			const uint32_t a = *pp, b2 = reinterpret_cast<const uint32_t *>(o + (size_t)rr * H + c0)[d];
+			*pp = ((a + st) & 0xFFFF) | (((a >> 16) + (st >> 16)) << 16);
+			reinterpret_cast<uint32_t *>(jp + (size_t)rr * W + c0)[d] = ((b2 + st) & 0xFFFF) | (((b2 >> 16) + (st >> 16)) << 16);
+		}
 		BARRIER();
 	}
 }
