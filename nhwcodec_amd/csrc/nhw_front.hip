@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_syn_rows(const int16_t *__restrict__ sr
  * depth-1 recurrence on the raw taps, so nothing is carried between bands).  Rows are padded to 514 shorts:
  * a lane that walks a row serially hits bank (row + k) mod 64.
  * ------------------------------------------------------------------------------------------------ */
-#define FB_KB 16                    /* output rows per band */
+#define FB_KB 16                    /* output rows per band (8 gives three bands per CU but a third more halo work: measured equal) */
 #define FB_TROWS (2 * FB_KB + 5)    /* horizontal-pass rows a band needs: 2k0-4 .. 2k0+32 */
 #define FB_YROWS (FB_TROWS + 2)
 #define FB_RS 514                   /* padded LDS row stride (shorts) */
@@ -726,8 +726,8 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict_
 	int16_t *ll1 = ll1b + (size_t)img * ll1_stride;
 	if (keepb) {                                                   /* q>=22: transposed horizontal-pass plane, rows kx < 256 (wavelet_filterbank.c:107-112) */
 		int16_t *keep = keepb + (size_t)img * keep_stride;
-		for (int k = t; k < H * 4; k += FB_NT) {
-			const int kx = k >> 2, part = k & 3;                   /* 8 of this band's 32 own rows */
+		for (int k = t; k < H * (FB_KB / 4); k += FB_NT) {
+			const int kx = k / (FB_KB / 4), part = k % (FB_KB / 4);   /* 8 of this band's 2 FB_KB own rows */
 			uint32_t v[4];
 			for (int e = 0; e < 4; e++) {
 				const int rt = 4 + 8 * part + 2 * e;                /* rows 2k0 + 8*part + 2e, +1 */
@@ -768,10 +768,11 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict_
 			else { lo[kk >> 1] = (uint16_t)l; hi[kk >> 1] = (uint16_t)h; }
 		}
 		int16_t *orow = proc + (size_t)c * W;
-		reinterpret_cast<uint4 *>(orow + k0)[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-		reinterpret_cast<uint4 *>(orow + k0)[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
-		reinterpret_cast<uint4 *>(orow + H + k0)[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-		reinterpret_cast<uint4 *>(orow + H + k0)[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+#pragma unroll
+		for (int i = 0; i < FB_KB / 8; i++) {
+			reinterpret_cast<uint4 *>(orow + k0)[i] = make_uint4(lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]);
+			reinterpret_cast<uint4 *>(orow + H + k0)[i] = make_uint4(hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]);
+		}
 		if (c < H) {                                               /* LL, natural orientation, through LDS for coalesced rows */
 #pragma unroll
 			for (int kk = 0; kk < FB_KB; kk++) ybuf[kk * FB_RS + c] = (int16_t)((kk & 1) ? (lo[kk >> 1] >> 16) : (lo[kk >> 1] & 0xFFFF));
@@ -1069,9 +1070,9 @@ void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilte
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		attr_set = true;
 	}
-	const dim3 grid(H / FB_KB, n);
+	const dim3 grid(H / FB_KB, n), rgrid(W / 32, n);               /* the row-map pass owns 32 rows per workgroup */
 	if (with_prefilter) {
-		k_front_rowmaps<<<grid, 256, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride, segmaps, g_stride);
+		k_front_rowmaps<<<rgrid, 256, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride, segmaps, g_stride);
 		k_front_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, flags, f_stride, st, s_stride, n);
 		k_front_band<1><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
 	} else
