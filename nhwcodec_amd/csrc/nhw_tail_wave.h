@@ -572,6 +572,11 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 			const int first_next = __builtin_amdgcn_readlane(cur[0], 0);   /* the row below, already through loops 1-3 */
 			for (int k = 0; k < 8; k++) {
 				const int raw = prev[k];
+				if (!__ballot(iabs(raw) >= 7)) {                        /* 64 quiet cells: every one is inside the dead zone whatever its neighbours do (the fix-ups only touch +-7) */
+					if (write_plane) p[(r - 1) * W + lane + 64 * k] = 128;
+					park[((r - 1) & 15) * QROW + lane + 64 * k] = 128;
+					continue;
+				}
 				const int lf = left_of_dpp(prev, k, lane, 0), rt = right_of_dpp(prev, k, 8, lane, first_next);
 				const bool last = k == 7 && lane == 63;             /* column 511: the fix-ups do not reach across the row end, the look at the next cell does */
 				int a = raw;
