@@ -48,6 +48,26 @@ DEV M4 col_range(int lo, int hi)                                /* columns lo..h
 #define BALLOT4(m, arr, expr) do { { const int x = arr[0]; (m).w[0] = __ballot(expr); } { const int x = arr[1]; (m).w[1] = __ballot(expr); } \
 	{ const int x = arr[2]; (m).w[2] = __ballot(expr); } { const int x = arr[3]; (m).w[3] = __ballot(expr); } } while (0)
 
+/* Bit-sliced rows.  The scalar unit is one per CU: a row mask algebra of a few hundred scalar instructions per step, times 16 resident
+ * wavefronts, is what bounded these kernels.  So a lane also keeps its cells' booleans as a small bit field (bit k = cell lane + 64k):
+ * one vector instruction combines a whole row, a shift by one column is a wave-wide DPP move plus the word seam, and the scalar unit only
+ * sees the ballots that feed a run resolution (alt_runs) and what comes back from it. */
+template <int N> DEV unsigned bs_up(unsigned b, int lane, unsigned in0 = 0)          /* cell j takes the bit of cell j - 1 (in0: the bit left of column 0) */
+{
+	const unsigned seam = (((unsigned)__builtin_amdgcn_readlane((int)b, 63) << 1) | in0) & ((1u << N) - 1);
+	const unsigned x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+	return lane ? x : seam;
+}
+DEV unsigned bs_dn(unsigned b, int lane)                                             /* cell j takes the bit of cell j + 1 (0 behind the last column) */
+{
+	const unsigned seam = (unsigned)__builtin_amdgcn_readlane((int)b, 0) >> 1;
+	const unsigned x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+	return lane < 63 ? x : seam;
+}
+#define BS_PRED(b, arr, n, expr) do { (b) = 0; for (int k_ = 0; k_ < (n); k_++) { const int x = (arr)[k_]; (b) |= ((expr) ? 1u : 0u) << k_; } } while (0)
+DEV M4 bs_ballot4(unsigned b) { return M4{ { __ballot(b & 1), __ballot(b & 2), __ballot(b & 4), __ballot(b & 8) } }; }
+DEV unsigned bs_from4(M4 m) { unsigned b = 0; for (int k = 0; k < 4; k++) b |= (unsigned)__builtin_amdgcn_inverse_ballot_w64(m.w[k]) << k; return b; }
+
 /* A walk that skips the cell after every cell where it fires: given "fires if visited" per cell, the cells where
  * it does fire.  Inside a run of consecutive fire bits those are the cells at even distance from the run's
  * first cell.  Adding a 1 at every run start that sits on an even column ripples through exactly those runs. */
@@ -461,6 +481,11 @@ DEV M8 alt_runs(M8 f)
 }
 #define BALLOT8(m, arr, expr) do { for (int k_ = 0; k_ < 8; k_++) { const int x = arr[k_]; (m).w[k_] = __ballot(expr); } } while (0)
 
+DEV M8 bs_ballot8(unsigned b) { M8 m; for (int k = 0; k < 8; k++) m.w[k] = __ballot(b & (1u << k)); return m; }
+DEV unsigned bs_from8(M8 m) { unsigned b = 0; for (int k = 0; k < 8; k++) b |= (unsigned)__builtin_amdgcn_inverse_ballot_w64(m.w[k]) << k; return b; }
+/* multiples of 8 from `from` on (x = from, from + 8, ...) with one comparison */
+DEV bool mult8_from(int x, int from) { return ((unsigned)(x - from) & 0x80000007u) == 0; }
+
 /* the value one column to the left / right of every cell of a row held as v[k] = column lane + 64k (wave-wide DPP shift, the
  * word seam through a readlane); `edge` stands in where the row ends */
 DEV int left_of_dpp(const int *v, int k, int lane, int edge)
@@ -511,60 +536,57 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 		int far[8];
 		quant_load_row(p, r + 4, lane, far);
 		if (r < W) {
-			if (r < H) {                                           /* loop 1, upper half: only columns 256..511 (mask words 4..7) take part */
-				int c4[4] = { cur[4], cur[5], cur[6], cur[7] };
-				M4 g8, g16, le0;
-				BALLOT4(g8, c4, x > 7 && !(x & 7)); BALLOT4(g16, c4, x > 15 && !(x & 7)); BALLOT4(le0, c4, x <= 0);
-				M4 ple = up1(le0);
-				ple.w[0] |= (uint64_t)(__builtin_amdgcn_readlane(cur[3], 63) <= 0);
-				const M4 both = g8 & dn1(g8) & col_range(0, H - 2);
-				const M4 cself = both & g16 & ple;
-				const M4 cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & dn1(g16) & dn2(le0) & col_range(0, H - 3);
-				const M4 hit = up1(alt_runs(cnext));                  /* cells decremented by their left neighbour */
-				const M4 dec = hit | (cself & ~hit);
-				last_le0 = (unsigned)(le0.w[3] >> 63);
-				for (int k = 0; k < 4; k++) cur[4 + k] -= TB(dec, k);
+			if (r < H) {                                           /* loop 1, upper half: only columns 256..511 (words 4..7) take part */
+				const int *c4 = cur + 4;
+				unsigned g8, g16, le0;
+				BS_PRED(g8, c4, 4, mult8_from(x, 8)); BS_PRED(g16, c4, 4, mult8_from(x, 16)); BS_PRED(le0, c4, 4, x <= 0);
+				const unsigned ple = bs_up<4>(le0, lane, __builtin_amdgcn_readlane(cur[3], 63) <= 0);
+				const unsigned both = g8 & bs_dn(g8, lane) & (lane == 63 ? 0x7u : 0xFu);                       /* columns <= 510 */
+				const unsigned cself = both & g16 & ple;
+				const unsigned cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & bs_dn(g16, lane) & bs_dn(bs_dn(le0, lane), lane) & (lane >= 62 ? 0x7u : 0xFu);   /* columns <= 509 */
+				const unsigned hit = bs_from4(up1(alt_runs(bs_ballot4(cnext))));                               /* cells decremented by their left neighbour */
+				const unsigned dec = hit | (cself & ~hit);
+				last_le0 = (unsigned)__builtin_amdgcn_readlane((int)le0, 63) >> 3;
+				for (int k = 0; k < 4; k++) cur[4 + k] -= (dec >> k) & 1;
 			} else {                                               /* loop 1, lower half: whole rows */
-				const M8 region = col_range8(0, W - 1);
-				M8 g8, g16, le0;
-				BALLOT8(g8, cur, x > 7 && !(x & 7)); BALLOT8(g16, cur, x > 15 && !(x & 7)); BALLOT8(le0, cur, x <= 0);
-				const M8 ple = up1(le0, last_le0);
-				const M8 both = g8 & dn1(g8) & col_range8(0, W - 2);
-				const M8 cself = both & g16 & ple;
-				const M8 cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & dn1(g16) & dn2(le0) & col_range8(0, W - 3);
-				const M8 hit = up1(alt_runs(cnext & region));          /* cells decremented by their left neighbour */
-				const M8 dec = hit | (cself & region & ~hit);
-				last_le0 = (unsigned)(le0.w[7] >> 63);
-				for (int k = 0; k < 8; k++) cur[k] -= TB(dec, k);
+				unsigned g8, g16, le0;
+				BS_PRED(g8, cur, 8, mult8_from(x, 8)); BS_PRED(g16, cur, 8, mult8_from(x, 16)); BS_PRED(le0, cur, 8, x <= 0);
+				const unsigned ple = bs_up<8>(le0, lane, last_le0);
+				const unsigned both = g8 & bs_dn(g8, lane) & (lane == 63 ? 0x7Fu : 0xFFu);
+				const unsigned cself = both & g16 & ple;
+				const unsigned cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & bs_dn(g16, lane) & bs_dn(bs_dn(le0, lane), lane) & (lane >= 62 ? 0x7Fu : 0xFFu);
+				const unsigned hit = bs_from8(up1(alt_runs(bs_ballot8(cnext))));
+				const unsigned dec = hit | (cself & ~hit);
+				last_le0 = (unsigned)__builtin_amdgcn_readlane((int)le0, 63) >> 7;
+				for (int k = 0; k < 8; k++) cur[k] -= (dec >> k) & 1;
 			}
 			if (r < H) {
 				{                                                  /* loop 2 */
-					int c4[4] = { cur[0], cur[1], cur[2], cur[3] }, n4[4] = { nxt[0], nxt[1], nxt[2], nxt[3] };
-					M4 P, N, PN, NN;
-					BALLOT4(P, c4, x > 3 && x < 8); BALLOT4(N, c4, x < -3 && x > -8);
-					BALLOT4(PN, n4, x > 3 && x < 8); BALLOT4(NN, n4, x < -3 && x > -8);
-					const M4 rg = col_range(1, H - 2);
-					const M4 pp = P & up1(P), nn = N & up1(N);
-					const M4 tp = pp & dn1(P), tn = nn & dn1(N);
-					const M4 vp = pp & ~dn1(P) & up1(PN) & PN, vn = nn & ~dn1(N) & up1(NN) & NN;
-					const M4 fired = alt_runs((tp | vp | tn | vn) & rg);
-					const M4 ftp = fired & tp, ftn = fired & tn, fvp = fired & vp, fvn = fired & vn;
-					const M4 fv = fvp | fvn, ft_l = dn1(ftp | ftn), fvp_l = dn1(fvp), fvn_l = dn1(fvn), fv_l = dn1(fv);
+					unsigned P, N, PN, NN;
+					BS_PRED(P, cur, 4, (unsigned)(x - 4) < 4u); BS_PRED(N, cur, 4, (unsigned)(x + 7) < 4u);
+					BS_PRED(PN, nxt, 4, (unsigned)(x - 4) < 4u); BS_PRED(NN, nxt, 4, (unsigned)(x + 7) < 4u);
+					const unsigned rg = (lane == 0 ? 0xEu : 0xFu) & (lane == 63 ? 0x7u : 0xFu);              /* columns 1..254 */
+					const unsigned pdn = bs_dn(P, lane), ndn = bs_dn(N, lane);
+					const unsigned pp = P & bs_up<4>(P, lane), nn = N & bs_up<4>(N, lane);
+					const unsigned tp = pp & pdn, tn = nn & ndn;
+					const unsigned vp = pp & ~pdn & bs_up<4>(PN, lane) & PN, vn = nn & ~ndn & bs_up<4>(NN, lane) & NN;
+					const unsigned fired = bs_from4(alt_runs(bs_ballot4((tp | vp | tn | vn) & rg)));
+					const unsigned ftp = fired & tp, ftn = fired & tn, fvp = fired & vp, fvn = fired & vn, fv = fvp | fvn;
+					const unsigned ft_l = bs_dn(ftp | ftn, lane), fvp_l = bs_dn(fvp, lane), fvn_l = bs_dn(fvn, lane), fv_l = fvp_l | fvn_l;
 					for (int k = 0; k < 4; k++) {
-						if (TB(ftp, k)) cur[k] = 12700; if (TB(ftn, k)) cur[k] = 12900;
-						if (TB(ft_l, k)) cur[k] = 10100;
-						if (TB(fv, k)) { cur[k] = 10100; nxt[k] = 10100; }
-						if (TB(fvp_l, k)) cur[k] = 12100; if (TB(fvn_l, k)) cur[k] = 12200;
-						if (TB(fv_l, k)) nxt[k] = 10100;
+						if ((ftp >> k) & 1) cur[k] = 12700; if ((ftn >> k) & 1) cur[k] = 12900;
+						if ((ft_l >> k) & 1) cur[k] = 10100;
+						if ((fv >> k) & 1) { cur[k] = 10100; nxt[k] = 10100; }
+						if ((fvp_l >> k) & 1) cur[k] = 12100; if ((fvn_l >> k) & 1) cur[k] = 12200;
+						if ((fv_l >> k) & 1) nxt[k] = 10100;
 					}
 				}
 				{                                                  /* loop 3 */
-					int c4[4] = { cur[0], cur[1], cur[2], cur[3] };
-					M4 A, B;
-					BALLOT4(A, c4, x >= 5 && x <= 7); BALLOT4(B, c4, x <= -5 && x >= -7);
-					const M4 fired = alt_runs(((A & dn1(A)) | (B & dn1(B))) & col_range(0, H - 2));
-					const M4 fa = fired & A, fb = fired & B;
-					for (int k = 0; k < 4; k++) { if (TB(fa, k)) cur[k] = 10300; if (TB(fb, k)) cur[k] = 10204; }
+					unsigned A, B;
+					BS_PRED(A, cur, 4, (unsigned)(x - 5) < 3u); BS_PRED(B, cur, 4, (unsigned)(x + 7) < 3u);
+					const unsigned fired = bs_from4(alt_runs(bs_ballot4(((A & bs_dn(A, lane)) | (B & bs_dn(B, lane))) & (lane == 63 ? 0x7u : 0xFu))));   /* columns 0..254 */
+					const unsigned fa = fired & A, fb = fired & B;
+					for (int k = 0; k < 4; k++) { if ((fa >> k) & 1) cur[k] = 10300; if ((fb >> k) & 1) cur[k] = 10204; }
 				}
 			}
 		}
