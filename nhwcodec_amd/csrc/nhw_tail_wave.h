@@ -601,12 +601,21 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				}
 				const int lf = left_of_dpp(prev, k, lane, 0), rt = right_of_dpp(prev, k, 8, lane, first_next);
 				const bool last = k == 7 && lane == 63;             /* column 511: the fix-ups do not reach across the row end, the look at the next cell does */
+				/* straight-line selects (a divergent branch costs scalar exec-mask work in every wavefront of the CU) */
+				const bool m7 = raw == -7;
+				const bool ac = (unsigned)(-lf - 13) < 115u && ((-lf) & 7) == 6;     /* -127 <= lf < -12, residue 6: rewrites a -7 behind it to -9 (:375) */
+				const bool to8 = lf == 8 || (rt == 8 && !last);                      /* :389, :378 */
+				const bool dc = (unsigned)(lf - 13) < 115u && (lf & 7) >= 6;         /* 12 < lf <= 127, residue 6/7: raises a 7 behind it to 9 (:390) */
 				int a = raw;
-				if (a == -7) {
-					if (lf < -12 && lf >= -127 && ((-lf) & 7) == 6) a = -9;       /* :375 */
-					else if (lf == 8 || (rt == 8 && !last)) a = -8;              /* :389, :378 */
-				} else if (a == 7 && lf > 12 && lf <= 127 && (lf & 7) >= 6) a = 9;   /* :390 */
-				int sym = quant_symbol(a, rt);
+				a = (m7 && ac) ? -9 : a;
+				a = (m7 && !ac && to8) ? -8 : a;
+				a = (raw == 7 && dc) ? 9 : a;
+				const bool neg = a < 0;
+				int m = neg ? -a : a;
+				m = (neg && m > 14 && (m & 7) == 7 && (unsigned)(rt - 1) < 7u) ? m - 2 : m;     /* :381 */
+				m = (neg && (m & 7) < 7) ? (m & 504) : m;
+				const int v = neg ? -m : m;
+				int sym = (unsigned)(v + 7) < 15u ? 128 : ((v + 128) & 248);
 				if (__ballot(raw > 127 || raw < -127)) {                /* marks of loops 2-3 and values beyond +-127: rare, whole words skip this */
 					if (raw > 10000 && (raw == 10100 || raw == 12700 || raw == 12900 || raw == 10204 || raw == 10300 || raw == 12100 || raw == 12200))
 						sym = raw == 10100 ? 128 : raw == 12700 ? 127 : raw == 12900 ? 129 : raw == 10204 ? 125 : raw == 10300 ? 126 : raw == 12100 ? 121 : 122;

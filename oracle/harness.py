@@ -106,6 +106,48 @@ class RefEncoder:
         return (data, tr) if trace else data
 
 
+REF_DEC_SO = os.path.join(HERE, "_ref", "libnhwref_dec.so")
+
+
+class RefDecoder:
+    """ctypes binding of oracle/_ref/libnhwref_dec.so = the UNMODIFIED reference decoder (/root/reference/decoder/*.c)
+    linked with oracle/ref/ref_dec_shim.c (zero-guard allocator)."""
+
+    def __init__(self, so_path: str = REF_DEC_SO):
+        self.lib = ctypes.CDLL(so_path)
+        self.lib.nhwref_decode_planes.restype = ctypes.c_int
+        self.lib.nhwref_decode_planes.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        self.lib.nhwref_decode_bmp.restype = ctypes.c_int
+        self.lib.nhwref_decode_bmp.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        self.dir = tempfile.mkdtemp(prefix="nhwrefdec")
+
+    def __del__(self):
+        import shutil
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+    def _file(self, nhw: bytes) -> str:
+        p = os.path.join(self.dir, "in.nhw")
+        with open(p, "wb") as fh:
+            fh.write(nhw)
+        return p
+
+    def planes(self, nhw: bytes):
+        out = np.empty((3, 512, 512), np.uint8)
+        q = ctypes.c_int(0)
+        rc = self.lib.nhwref_decode_planes(self._file(nhw).encode(), out.ctypes.data, ctypes.byref(q))
+        if rc != 0:
+            raise RuntimeError(f"reference decoder failed rc={rc}")
+        return out, q.value
+
+    def bmp(self, nhw: bytes) -> bytes:
+        o = os.path.join(self.dir, "out.bmp")
+        rc = self.lib.nhwref_decode_bmp(self._file(nhw).encode(), o.encode())
+        if rc != 0:
+            raise RuntimeError(f"reference decoder failed rc={rc}")
+        with open(o, "rb") as fh:
+            return fh.read()
+
+
 # ---------------------------------------------------------------- deterministic robustness classes
 def _hash_u32(idx: np.ndarray, seed: int) -> np.ndarray:
     """Stateless integer hash (vectorised, identical on every numpy): used for robustness inputs."""

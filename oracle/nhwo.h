@@ -71,6 +71,14 @@ void nhwo_analysis(int16_t *jpeg, int16_t *proc, int stride, int n, int final_le
 /* a7: wavelet_filterbank.c:305-496. */
 void nhwo_synthesis(int16_t *jpeg, int16_t *proc, int stride, int n);
 
+/* ---- decoder (BASELINE config 5; nhwo_dec.c) ---- */
+/* .nhw bytes -> 786432 bytes in the order the reference's nhw-dec writes them behind its 54-byte BMP header */
+int nhwo_decode(const uint8_t *nhw, size_t len, uint8_t *bgr, int *quality);
+/* checkpoint before the colour matrix: planes = Y, U, V, 262144 bytes each (decode_image's im_bufferY/U/V) */
+int nhwo_decode_planes(const uint8_t *nhw, size_t len, uint8_t *planes, int *quality);
+void nhwo_dec_color(const uint8_t *y, const uint8_t *u, const uint8_t *v, int q, uint8_t *out);
+void nhwo_dec_bmp_header(uint8_t h[54]);
+
 #ifdef __cplusplus
 }
 #endif

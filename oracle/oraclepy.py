@@ -24,7 +24,28 @@ class Oracle:
         L.nhwo_quality_supported.argtypes = [ctypes.c_int]
         L.nhwo_encode.restype = ctypes.c_int
         L.nhwo_encode.argtypes = [P, ctypes.c_int, P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(_Trace)]
+        L.nhwo_decode.restype = ctypes.c_int
+        L.nhwo_decode.argtypes = [P, ctypes.c_size_t, P, ctypes.POINTER(ctypes.c_int)]
+        L.nhwo_decode_planes.restype = ctypes.c_int
+        L.nhwo_decode_planes.argtypes = [P, ctypes.c_size_t, P, ctypes.POINTER(ctypes.c_int)]
+        L.nhwo_dec_bmp_header.argtypes = [P]
         self._out = ctypes.create_string_buffer(1 << 20)
+
+    def decode(self, nhw: bytes, planes: bool = False):
+        """.nhw bytes -> uint8[512,512,3] in nhw-dec's output byte order (planes=True: uint8[3,512,512] Y,U,V before the colour matrix)"""
+        out = np.empty((3, 512, 512) if planes else (512, 512, 3), np.uint8)
+        q = ctypes.c_int(0)
+        buf = ctypes.create_string_buffer(bytes(nhw), len(nhw))
+        fn = self.lib.nhwo_decode_planes if planes else self.lib.nhwo_decode
+        rc = fn(ctypes.cast(buf, P), len(nhw), out.ctypes.data, ctypes.byref(q))
+        if rc != 0:
+            raise RuntimeError(f"oracle decode failed rc={rc}")
+        return out, q.value
+
+    def bmp_header(self) -> bytes:
+        h = ctypes.create_string_buffer(54)
+        self.lib.nhwo_dec_bmp_header(ctypes.cast(h, P))
+        return h.raw
 
     def synth(self, seed: int) -> np.ndarray:
         b = np.empty((512, 512, 3), np.uint8)
