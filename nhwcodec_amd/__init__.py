@@ -115,3 +115,77 @@ class Encoder:
         t = Timing()
         self._chk(self.lib.nhw_enc_last_timing(self.h, ctypes.byref(t)))
         return t
+
+
+class Decoder:
+    """One decoder handle on one GPU: mirror of the reference's decode_image + write_image_bmp
+    (decoder/nhw_decoder.c:54, decoder/nhw_decoder_cli.c:108) for batches of .nhw files."""
+
+    def __init__(self, device: int = 0, max_batch: int = 64):
+        import torch
+        if not torch.cuda.is_available():
+            raise NhwError("no GPU visible: nhwcodec_amd has no CPU path")
+        self.torch = torch
+        self.lib = L = load_library()
+        L.nhw_dec_last_error.restype = ctypes.c_char_p
+        L.nhw_dec_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)]
+        L.nhw_dec_destroy.argtypes = [P]
+        L.nhw_dec_batch_device.argtypes = [P, P, P, ctypes.c_int, P, P, P, P]
+        L.nhw_dec_batch.argtypes = [P, P, P, ctypes.c_int, P, P, P]
+        L.nhw_dec_bmp_header.argtypes = [P]
+        L.nhw_dec_debug_stop_after.argtypes = [P, ctypes.c_int]
+        L.nhw_dec_debug_read.argtypes = [P, ctypes.c_int, ctypes.c_int, P, ctypes.c_size_t]
+        self.device = device
+        self.max_batch = max_batch
+        h = P()
+        self._chk(L.nhw_dec_create(device, max_batch, ctypes.byref(h)))
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NhwError(f"libnhwhip rc={rc}: {self.lib.nhw_dec_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nhw_dec_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bmp_header(self) -> bytes:
+        h = ctypes.create_string_buffer(54)
+        self.lib.nhw_dec_bmp_header(ctypes.cast(h, P))
+        return h.raw
+
+    def decode_device(self, blob, offsets, out=None):
+        """blob: uint8 CUDA tensor holding the files back to back; offsets: int64/uint64 CUDA tensor [n+1].
+        Returns (pixels[n,512,512,3], status[n], quality[n]) on the device."""
+        t = self.torch
+        n = offsets.numel() - 1
+        dev = f"cuda:{self.device}"
+        if out is None:
+            out = t.empty((n, 512, 512, 3), dtype=t.uint8, device=dev)
+        status = t.empty(n, dtype=t.int32, device=dev)
+        quality = t.empty(n, dtype=t.int32, device=dev)
+        self._chk(self.lib.nhw_dec_batch_device(self.h, blob.data_ptr(), offsets.data_ptr(), n, out.data_ptr(), status.data_ptr(), quality.data_ptr(),
+                                                t.cuda.current_stream(self.device).cuda_stream))
+        return out, status, quality
+
+    def decode(self, files):
+        """files: list of .nhw byte strings -> (uint8 [n,512,512,3] in nhw-dec's output byte order, quality list)."""
+        import numpy as np
+        n = len(files)
+        offs = np.zeros(n + 1, np.uint64)
+        offs[1:] = np.cumsum([len(f) for f in files])
+        blob = np.frombuffer(b"".join(files), np.uint8)
+        out = np.empty((n, 512, 512, 3), np.uint8)
+        status = np.empty(n, np.int32)
+        quality = np.empty(n, np.int32)
+        self._chk(self.lib.nhw_dec_batch(self.h, blob.ctypes.data, offs.ctypes.data, n, out.ctypes.data, status.ctypes.data, quality.ctypes.data))
+        if (status != 0).any():
+            raise NhwError(f"per-file status {status.tolist()}")
+        return out, quality.tolist()

@@ -1,0 +1,1240 @@
+/*
+ * nhw_dec.hip -- the NHW decoder (BASELINE config 5) for gfx950: kernels, workspace
+ * and the decode half of the C ABI (include/nhw_hip.h).
+ *
+ * What the reference does per file (decoder/nhw_decoder.c:54 decode_image, :1478 parse_file,
+ * decoder/compress_pixel.c:49,446, decoder/wavelet_filterbank.c:52,237, decoder/nhw_decoder_cli.c:108) is re-cut
+ * into batch-wide launches, every launch running one stage of all n files:
+ *
+ *   k_dec_parse    header + section table, packets copied to aligned words; the four byte-serial side streams
+ *                  (LL2 DPCM bytes, the three/four position lists) are walked by one lane each, side by side
+ *   k_dec_vlc      the prefix-code walk, one wavefront per stream (luma, chroma), written straight to its
+ *                  place in the coefficient plane (the reference's un-zig-zag pass disappears)
+ *   k_dec_expand   pattern symbols -> coefficients, the +-1 nudge of the HH band, LL2 samples, odd-LL tags,
+ *                  exception samples: one wavefront per image, rows in order, a row with no pattern symbol
+ *                  is one load and a ballot
+ *   k_dec_shrink, k_dec_synth (x4 luma, x4 per chroma plane), k_dec_resid, k_dec_marks, k_dec_corr,
+ *   k_dec_smooth, k_dec_cpairs, k_dec_sharpen, k_dec_color
+ *
+ * Everything is int16/uint8 arithmetic; the only floating point is the colour matrix (compiled with
+ * -ffp-contract=off like the rest of the library).  No stage falls back to the host.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/nhw_hip.h"
+
+#define DW 512
+#define DH 256
+#define DQ 65536
+#define DEV __device__ __forceinline__
+
+namespace {
+
+/* ---------------------------------------------------------------------------------------------- workspace
+ * structure of arrays over the batch: buffer b of image i at base + off[b] + i * size[b] */
+enum {
+	D_META, D_LL, D_PK, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_YB, D_CU, D_COUNT
+};
+enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304 };
+const size_t k_dec_bytes[D_COUNT] = {
+	/* META */ 512, /* LL */ 24832, /* PK */ (size_t)PK_WORDS * 4, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
+	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 8 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 2 * (2 * DQ + 4096), /* YB */ 4 * DQ, /* CU */ 2 * DQ
+};
+
+struct DecMeta {
+	int status, q, res_high;
+	int book1_len, book2_len, data1, data2, tree_end, exw_len;
+	int res1_len, res1_bits, res3_len, res3_bits, res4_len, res5_len, res5_bits, res6_len, res6_bits, char_res1_len, qs3_len;
+	int select1, select2, ll_word_len, ch_res_len;
+	uint32_t o_book1, o_book2, o_exw, o_res1, o_res1_bit, o_res1_word, o_res4, o_res3, o_res3_bit, o_res3_word;
+	uint32_t o_res5, o_res5_bit, o_res5_word, o_res6, o_res6_bit, o_res6_word, o_char, o_qs3;
+	uint32_t o_sel1, o_sel2, o_u64, o_v64, o_llword, o_chres, o_packet1, o_packet2;
+	int carry;          /* the left-over `count` that reaches nhw_decoder.c:571 */
+	int nmarks;
+	int size;
+};
+
+struct DecWs {
+	uint8_t *base;
+	size_t off[D_COUNT];
+	int n;
+	const uint8_t *blob;       /* device arena holding the .nhw files */
+	const uint64_t *blob_off;  /* n + 1 offsets into it */
+	template <typename T> __host__ __device__ T *buf(int b, int img) const { return (T *)(base + off[b] + (size_t)img * k_dec_bytes_dev(b)); }
+	__host__ __device__ static size_t k_dec_bytes_dev(int b)
+	{
+		switch (b) {
+		case D_META: return 512; case D_LL: return 24832; case D_PK: return (size_t)PK_WORDS * 4;
+		case D_P1: case D_P3: case D_P5: return P16_CAP * 2; case D_P6: return (size_t)P6_CAP * 4;
+		case D_MARKS: return 2 * DQ; case D_A: case D_B: return 8 * DQ + 8192;
+		case D_CA: case D_CB: return 2 * (2 * DQ + 4096); case D_YB: return 4 * DQ; default: return 2 * DQ;
+		}
+	}
+};
+
+/* planes: A and B start 4096 bytes into their buffers (the reference writes one cell in front of a plane in a corner case) */
+DEV int16_t *plane_a(const DecWs &ws, int img) { return ws.buf<int16_t>(D_A, img) + 2048; }
+DEV int16_t *plane_b(const DecWs &ws, int img) { return ws.buf<int16_t>(D_B, img) + 2048; }
+DEV int16_t *plane_ca(const DecWs &ws, int img, int comp) { return ws.buf<int16_t>(D_CA, img) + 1024 + (size_t)comp * (DQ + 2048); }
+DEV int16_t *plane_cb(const DecWs &ws, int img, int comp) { return ws.buf<int16_t>(D_CB, img) + 1024 + (size_t)comp * (DQ + 2048); }
+
+DEV int iabs(int v) { return v < 0 ? -v : v; }
+DEV int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+DEV int bit_of(const uint8_t *bytes, int nbytes, int k) { return (k >> 3) < nbytes ? (bytes[k >> 3] >> (7 - (k & 7))) & 1 : 0; }
+
+/* add to one int16 cell when other threads may be adding to it or to its neighbour in the same 32-bit word */
+DEV void add_i16(int16_t *p, int delta)
+{
+	unsigned *w = (unsigned *)((uintptr_t)p & ~(uintptr_t)3);
+	const int sh = ((uintptr_t)p & 2) ? 16 : 0;
+	unsigned old = *w, seen;
+	do {
+		seen = old;
+		const unsigned v = ((((seen >> sh) & 0xFFFFu) + (unsigned)delta) & 0xFFFFu) << sh;
+		old = atomicCAS(w, seen, (seen & ~(0xFFFFu << sh)) | v);
+	} while (old != seen);
+}
+
+/* ---------------------------------------------------------------------------------------------- parse (d1)
+ * parse_file, nhw_decoder.c:1497-1659 */
+struct Rd { const uint8_t *p; uint32_t n, at; int bad; };
+DEV unsigned rd8(Rd &s) { if (s.at + 1 > s.n) { s.bad = 1; return 0; } return s.p[s.at++]; }
+DEV unsigned rd16(Rd &s) { const unsigned a = rd8(s); return a | (rd8(s) << 8); }
+DEV unsigned rd32(Rd &s) { const unsigned a = rd16(s); return a | (rd16(s) << 16); }
+DEV uint32_t take(Rd &s, uint32_t n) { const uint32_t r = s.at; if (s.at + n > s.n || s.at + n < s.at) { s.bad = 1; return 0; } s.at += n; return r; }
+
+DEV void parse_header(const uint8_t *d, uint32_t len, DecMeta *m)
+{
+	Rd s = { d, len, 0, 0 };
+	m->res_high = (int)rd8(s);
+	const int q = m->q = (int)rd8(s);
+	if (s.bad || m->res_high > 6 || q < 1 || q > 23) { m->status = NHW_E_FORMAT; return; }
+	m->book1_len = (int)rd16(s); m->book2_len = (int)rd16(s);
+	m->data1 = (int)rd32(s); m->data2 = (int)rd32(s);
+	m->tree_end = (int)rd16(s); m->exw_len = (int)rd16(s);
+	if (q > 12) m->res1_len = (int)rd16(s);
+	if (q >= 19) { m->res3_len = (int)rd16(s); m->res3_bits = (int)rd16(s); }
+	if (q > 17) m->res4_len = (int)rd16(s);
+	if (q > 12) m->res1_bits = (int)rd16(s);
+	if (q >= 21) { m->res5_len = (int)rd16(s); m->res5_bits = (int)rd16(s); }
+	if (q > 21) { m->res6_len = (int)rd32(s); m->res6_bits = (int)rd16(s); m->char_res1_len = (int)rd16(s); }
+	if (q > 22) m->qs3_len = (int)rd16(s);
+	m->select1 = (int)rd16(s); m->select2 = (int)rd16(s);
+	if (q > 15) m->ll_word_len = (int)rd16(s);
+	m->ch_res_len = (int)rd16(s);
+	if (s.bad || m->data1 < 0 || m->data2 < m->data1 || m->data2 > PK_WORDS - 8 || m->res6_len < 0) { m->status = NHW_E_FORMAT; return; }
+	m->o_book1 = take(s, (uint32_t)m->book1_len); m->o_book2 = take(s, (uint32_t)m->book2_len);
+	m->o_exw = take(s, (uint32_t)m->exw_len);
+	if (q > 12) { m->o_res1 = take(s, (uint32_t)m->res1_len); m->o_res1_bit = take(s, (uint32_t)m->res1_bits); m->o_res1_word = take(s, (uint32_t)m->res1_bits); }
+	if (q > 17) m->o_res4 = take(s, (uint32_t)m->res4_len);
+	if (q >= 19) { m->o_res3 = take(s, (uint32_t)m->res3_len); m->o_res3_bit = take(s, (uint32_t)m->res3_bits); m->o_res3_word = take(s, (uint32_t)m->res3_bits * 2); }
+	if (q >= 21) { m->o_res5 = take(s, (uint32_t)m->res5_len); m->o_res5_bit = take(s, (uint32_t)m->res5_bits); m->o_res5_word = take(s, (uint32_t)m->res5_bits); }
+	if (q > 21) {
+		m->o_res6 = take(s, (uint32_t)m->res6_len); m->o_res6_bit = take(s, (uint32_t)m->res6_bits); m->o_res6_word = take(s, (uint32_t)m->res6_bits);
+		m->o_char = take(s, (uint32_t)m->char_res1_len * 2);
+	}
+	if (q > 22) m->o_qs3 = take(s, (uint32_t)m->qs3_len * 4);
+	m->o_sel1 = take(s, (uint32_t)m->select1); m->o_sel2 = take(s, (uint32_t)m->select2);
+	if (q > 15) { m->o_u64 = take(s, 2 * DH); m->o_v64 = take(s, 2 * DH); m->o_llword = take(s, (uint32_t)m->ll_word_len); }
+	m->o_chres = take(s, (uint32_t)m->ch_res_len);
+	m->o_packet1 = take(s, (uint32_t)m->data1 * 4);
+	m->o_packet2 = take(s, (uint32_t)(m->data2 - m->data1) * 4);
+	if (s.bad || m->res1_bits * 8 > P16_CAP - 64 || m->res3_bits * 8 > P16_CAP - 64 || m->res5_bits * 8 > P16_CAP - 64 || m->res6_bits * 8 > P6_CAP - 64)
+		m->status = NHW_E_FORMAT;
+}
+
+/* LL2 samples (res_comp), nhw_decoder.c:1661-2026; unsigned char arithmetic. One lane. */
+DEV void ll_expand(const uint8_t *f, const DecMeta *m, uint8_t *ll)
+{
+	const uint8_t *code = f + m->o_chres, *fine = f + m->o_llword;
+	const int mode = m->res_high & 3, q = m->q, ncode = m->ch_res_len;
+	int i = 1, j = 1, a = 0;
+#define CODE(k) ((k) < ncode ? (int)code[k] : 0)
+#define PUSH(v) do { ll[j] = (uint8_t)(v); j++; } while (0)
+#define PREV ((int)ll[j - 1])
+	ll[0] = (uint8_t)CODE(0);
+	while (j < DQ / 4) {
+		const int b = CODE(i);
+		if (b >= 128) {
+			if (q > 15) { PUSH(a < m->ll_word_len ? fine[a] : 0); a++; }
+			PUSH((b - 128) << 1);
+		}
+		else if (b >= 64) {                                    /* three differences in two bytes: 5 + 4 + 5 bits (all modes) */
+			const int c = b - 64; i++;
+			const int d = CODE(i);
+			PUSH((((c >> 1) & 31) << 1) - 32 + PREV);
+			PUSH(((((c & 1) << 3) | (d >> 5)) << 1) - 16 + PREV);
+			PUSH(((d & 31) << 1) - 32 + PREV);
+		}
+		else if (mode == 1) {
+			if (b < 32) {
+				const int run = ((b >> 2) & 7) + 2, v = PREV;
+				for (int e = 0; e < run; e++) PUSH(v);
+				const int t = b & 3;
+				if (t == 1) PUSH(PREV + 2); else if (t == 2) PUSH(PREV - 2); else if (t == 3) PUSH(PREV);
+			}
+			else { const int c = b - 32; PUSH(((c >> 3) << 1) - 4 + PREV); PUSH(((c & 7) << 1) - 8 + PREV); }
+		}
+		else if (mode == 2) { const int run = (b & 63) + 2, v = PREV; for (int e = 0; e < run; e++) PUSH(v); }
+		else {
+			if (b < 16) {
+				const int run = ((b >> 3) & 1) + 2, v = PREV;
+				for (int e = 0; e < run; e++) PUSH(v);
+				switch (b & 7) {
+				case 1: PUSH(PREV + 2); break;
+				case 2: PUSH(PREV + 2); PUSH(PREV - 2); break;
+				case 3: PUSH(PREV + 2); PUSH(PREV); break;
+				case 4: PUSH(PREV - 2); PUSH(PREV + 2); break;
+				case 5: PUSH(PREV - 2); PUSH(PREV); break;
+				case 6: PUSH(PREV - 2); break;
+				case 7: PUSH(PREV + 4); break;
+				default: break;
+				}
+			}
+			else if (b < 32) { PUSH(PREV + (b >= 24 ? 4 : 2)); PUSH(((b & 7) << 1) - 8 + PREV); }
+			else { const int c = b - 32; PUSH(((c >> 3) << 1) - 6 + PREV); PUSH(((c & 7) << 1) - 8 + PREV); }
+		}
+		i++;
+	}
+	ll[DQ / 4] = (uint8_t)CODE(i); i++;
+	j = DQ / 4 + 1;
+	while (j < DQ / 4 + DQ / 8) {
+		const int b = CODE(i);
+		if (b >= 192) {
+			const int c = b - 192, pr = c >> 2;
+			const int d0 = pr == 2 || pr == 4 || pr == 5 ? 4 : pr == 3 || pr == 6 || pr == 7 ? -4 : 0;
+			const int d1 = pr == 0 || pr == 4 || pr == 6 ? 4 : pr == 1 || pr == 5 || pr == 7 ? -4 : 0;
+			PUSH(d0 + PREV); PUSH(d1 + PREV);
+			const int t = c & 3;
+			PUSH(PREV + (t == 0 ? 0 : t == 1 ? 4 : t == 2 ? -4 : 8));
+		}
+		else if (b >= 128) PUSH((b - 128) << 2);
+		else if (b >= 64) {
+			int run = (b >> 3) & 7;
+			const int v = PREV;
+			if (run == 7) { run = (b & 7) + 7; for (int e = 0; e < run + 2; e++) PUSH(v); }
+			else {
+				for (int e = 0; e < run + 2; e++) PUSH(v);
+				switch (b & 7) {
+				case 1: PUSH(PREV + 4); break;
+				case 2: PUSH(PREV + 4); PUSH(PREV - 4); break;
+				case 3: PUSH(PREV + 4); PUSH(PREV - 4); PUSH(PREV); break;
+				case 4: PUSH(PREV - 4); PUSH(PREV + 4); PUSH(PREV); break;
+				case 5: PUSH(PREV - 4); PUSH(PREV + 4); break;
+				case 6: PUSH(PREV - 4); break;
+				case 7: PUSH(PREV + 8); break;
+				default: break;
+				}
+			}
+		}
+		else { PUSH(((b >> 3) << 2) - 16 + PREV); PUSH(((b & 7) << 2) - 16 + PREV); }
+		i++;
+	}
+#undef CODE
+#undef PUSH
+#undef PREV
+}
+
+/* position list walk (nhw_decoder.c:93-137 and its three copies): list bytes -> (row | column) entries; one lane.
+ * The reference patches list bytes to 127 as it goes; only the next step's look at the previous byte sees that. */
+template <typename T>
+DEV int poslist_walk(const uint8_t *b, int len, T *pos, int cap, int row_step, bool mask16)
+{
+	int n = 0, row = 0, last = 0;          /* last = low byte of the entry written last (0 before the first: out-of-range read) */
+	if (len <= 0) return 0;
+#define EMIT(v) do { const unsigned v_ = (unsigned)(v); if (n < cap) pos[n] = (T)(mask16 ? (v_ & 0xFFFFu) : v_); last = (int)(v_ & 255u); n++; } while (0)
+	bool prev127 = b[0] == 127;
+	if (prev127) row = row_step; else EMIT(b[0] << 1);
+	for (int i = 1; i < len; i++) {
+		const int v = b[i];
+		bool now127 = v == 127;
+		if (v >= 128) {
+			if (prev127) { row += 2 * row_step; now127 = true; }
+			else {
+				int col = last + (((v - 128) >> 4) << 1);
+				if (col >= 254) { row += row_step; now127 = true; } else EMIT(col + row);
+				col += (v & 15) << 1;
+				if (col >= 254) { row += row_step; now127 = true; } else EMIT(col + row);
+			}
+		}
+		else if (v == 127) row += row_step;
+		else {
+			if ((v << 1) < last && !prev127) row += row_step;
+			EMIT((v << 1) + row);
+		}
+		prev127 = now127;
+	}
+#undef EMIT
+	return n;
+}
+
+__global__ __launch_bounds__(256) void k_dec_parse(DecWs ws)
+{
+	__shared__ DecMeta sm;
+	__shared__ int counts[4];
+	const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint8_t *f = ws.blob + ws.blob_off[img];
+	const uint64_t flen = ws.blob_off[img + 1] - ws.blob_off[img];
+	if (!tid) {
+		memset(&sm, 0, sizeof sm);
+		sm.size = (int)flen;
+		if (flen > (1u << 24)) sm.status = NHW_E_FORMAT; else parse_header(f, (uint32_t)flen, &sm);
+	}
+	__syncthreads();
+	DecMeta *gm = ws.buf<DecMeta>(D_META, img);
+	if (sm.status) { if (!tid) *gm = sm; return; }
+	const int q = sm.q;
+
+	/* packets -> aligned little-endian words, two zero words behind each part */
+	uint32_t *pk = ws.buf<uint32_t>(D_PK, img);
+	for (int w = tid; w < sm.data2 + 8; w += 256) {
+		uint32_t v = 0;
+		if (w < sm.data2) { const uint8_t *p = f + sm.o_packet1 + 4u * (uint32_t)w; v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+		pk[w] = v;
+	}
+
+	/* the byte-serial side streams, one lane each */
+	uint16_t *p1 = ws.buf<uint16_t>(D_P1, img), *p3 = ws.buf<uint16_t>(D_P3, img), *p5 = ws.buf<uint16_t>(D_P5, img);
+	uint32_t *p6 = ws.buf<uint32_t>(D_P6, img);
+	if (!lane) {
+		if (wv == 0) ll_expand(f, &sm, ws.buf<uint8_t>(D_LL, img));
+		else if (wv == 1) counts[1] = q > 12 ? poslist_walk(f + sm.o_res1, sm.res1_len, p1, sm.res1_bits * 8, 256, true) : 0;
+		else if (wv == 2) counts[2] = q >= 19 ? poslist_walk(f + sm.o_res3, sm.res3_len, p3, sm.res3_bits * 8, 256, true) : 0;
+		else { counts[3] = q >= 21 ? poslist_walk(f + sm.o_res5, sm.res5_len, p5, sm.res5_bits * 8, 256, true) : 0;
+		       counts[0] = q > 21 ? poslist_walk(f + sm.o_res6, sm.res6_len, p6, sm.res6_bits * 8, 256, false) : 0; }
+	}
+	__syncthreads();
+	/* low bits from the bit planes; entries the list did not reach are 0 + their bit (the reference's calloc) */
+	if (q > 12) for (int k = tid; k < sm.res1_bits * 8; k += 256) p1[k] = (uint16_t)((k < counts[1] ? p1[k] : 0) + bit_of(f + sm.o_res1_bit, sm.res1_bits, k));
+	if (q >= 19) for (int k = tid; k < sm.res3_bits * 8; k += 256) p3[k] = (uint16_t)((k < counts[2] ? p3[k] : 0) + bit_of(f + sm.o_res3_bit, sm.res3_bits, k));
+	if (q >= 21) for (int k = tid; k < sm.res5_bits * 8; k += 256) p5[k] = (uint16_t)((k < counts[3] ? p5[k] : 0) + bit_of(f + sm.o_res5_bit, sm.res5_bits, k));
+	if (q > 21) for (int k = tid; k < sm.res6_bits * 8; k += 256) p6[k] = (k < counts[0] ? p6[k] : 0u) + (uint32_t)bit_of(f + sm.o_res6_bit, sm.res6_bits, k);
+	/* bit-1 planes of the chroma LL2 samples (:1983-2026) */
+	if (q > 15) {
+		uint8_t *ll = ws.buf<uint8_t>(D_LL, img);
+		for (int k = tid; k < 2 * DH * 8; k += 256) {
+			ll[DQ / 4 + k] = (uint8_t)(ll[DQ / 4 + k] + (bit_of(f + sm.o_u64, 2 * DH, k) << 1));
+			ll[DQ / 4 + DQ / 16 + k] = (uint8_t)(ll[DQ / 4 + DQ / 16 + k] + (bit_of(f + sm.o_v64, 2 * DH, k) << 1));
+		}
+	}
+	if (!tid) {
+		/* the reference's `count` as decode_image reaches :571 (see oracle/nhwo_dec.c) */
+		int carry = 4 * DQ;
+		if (q > 12) carry = sm.res1_bits > 0 ? (sm.res1_bits - 1) * 8 : 0;
+		if (q >= 21) carry = sm.res5_bits > 0 ? (sm.res5_bits - 1) * 8 : 0;
+		if (q > 21) carry = sm.res6_bits > 0 ? (sm.res6_bits - 1) * 8 : 0;
+		if (q >= 19) carry = sm.res3_bits > 0 ? (sm.res3_bits * 2 - 2) * 4 : 0;
+		sm.carry = carry;
+		*gm = sm;
+	}
+}
+
+/* ---------------------------------------------------------------------------------------------- VLC (d2)
+ * the 290-word prefix code (encoder/tree.h:58-140; decoder/tables.h:59,125 hold it as two lookup tables) */
+struct VlcRun { uint32_t first; uint8_t len; uint16_t count; };
+__constant__ VlcRun k_runs[26] = {
+	{0x0000,2,1},{0x0002,3,1},{0x0004,3,1},{0x000a,4,2},{0x0006,4,2},{0x0018,5,3},{0x0036,6,2},{0x0070,7,2},
+	{0x00e8,8,12},{0x01c8,9,8},{0x01e8,9,8},{0x03e8,10,8},{0x03e4,10,4},{0x07c0,11,2},{0x07e0,11,2},
+	{0x07f0,11,16},{0x07e8,11,8},{0x0f88,12,8},{0x0fc8,12,8},{0x1f08,13,4},{0x3f10,14,8},
+	{0x1f0c0,17,64},{0x1f8c0,17,46},{0x3f1dc,18,12},{0x7e3d0,19,38},{0xfc7ec,20,20}
+};
+
+struct Bits {
+	const uint32_t *w; int nwords; int at;     /* next word to load */
+	uint64_t buf; int fill;                    /* `fill` valid bits at the top of buf */
+	DEV void init(const uint32_t *p, int n) { w = p; nwords = n; at = 0; buf = 0; fill = 0; }
+	DEV void need32() { if (fill <= 32) { const uint32_t v = at < nwords ? w[at] : 0u; at++; buf |= (uint64_t)v << (32 - fill); fill += 32; } }
+	DEV unsigned peek(int n) { return (unsigned)(buf >> (64 - n)); }
+	DEV void skip(int n) { buf <<= n; fill -= n; }
+	DEV bool spent() const { return at > nwords + 3; }
+};
+
+/* lut[v] for the top 8 bits: (len << 8) | rank for code words of up to 8 bits, 0 otherwise */
+DEV void vlc_fill_lut(uint16_t *lut, int lane)
+{
+	for (int v = lane; v < 256; v += 64) {
+		unsigned e = 0; int rank = 0;
+		for (int r = 0; r < 9; r++) {
+			const unsigned c = (unsigned)v >> (8 - k_runs[r].len);
+			if (c >= k_runs[r].first && c < k_runs[r].first + k_runs[r].count) { e = ((unsigned)k_runs[r].len << 8) | (unsigned)(rank + (int)(c - k_runs[r].first)); break; }
+			rank += k_runs[r].count;
+		}
+		lut[v] = (uint16_t)e;
+	}
+}
+DEV int vlc_next(Bits &b, const uint16_t *lut)
+{
+	b.need32();
+	const unsigned look = b.peek(20);
+	const unsigned e = lut[look >> 12];
+	if (e) { b.skip((int)(e >> 8)); return (int)(e & 255u); }
+	int rank = 26;
+	for (int r = 9; r < 26; r++) {
+		const unsigned c = look >> (20 - k_runs[r].len);
+		if (c >= k_runs[r].first && c < k_runs[r].first + k_runs[r].count) { b.skip(k_runs[r].len); return rank + (int)(c - k_runs[r].first); }
+		rank += k_runs[r].count;
+	}
+	return -1;
+}
+
+/* books, compress_pixel.c:86-117 / :456-478: entry = (run length << 8) | symbol; one lane, LDS scratch */
+DEV int build_book(const uint8_t *raw, int raw_len, bool chroma, int tree_end, uint16_t *book, uint8_t *flat, uint8_t *inter)
+{
+	const int rep = chroma ? 128 : 3;
+	int e = 0, n = 0;
+	for (int i = 0; i < 720; i++) { flat[i] = 0; inter[i] = 0; }
+	for (int i = 0; i < raw_len; i++) {
+		if (raw[i] == rep) { const int cnt = i + 1 < raw_len ? raw[i + 1] : 0; for (int j = 0; j < cnt && e < 708; j++) flat[e++] = (uint8_t)rep; i++; }
+		else if (e < 708) flat[e++] = raw[i];
+	}
+	if (chroma) e = tree_end;
+	if (e > 708) e = 708;
+	int j = 0;
+	for (int i = 0; i < e; i += 2) inter[i] = flat[j++];
+	for (int i = 1; i < e; i += 2) inter[i] = flat[j++];
+	for (int i = 0; i < e; i++) {
+		if (!chroma) {
+			if (inter[i] == 3) { book[n++] = (uint16_t)((inter[i + 1] << 8) | 128); i++; }
+			else book[n++] = (uint16_t)(256 | inter[i]);
+		} else {
+			if (!(inter[i] & 1)) { book[n++] = (uint16_t)((inter[i + 1] << 8) | inter[i]); i++; }
+			else book[n++] = (uint16_t)(256 | (inter[i] & 0xfe));
+		}
+	}
+	for (int i = n; i < 720; i++) book[i] = 0;
+	return n;
+}
+
+DEV int extra_level(int word)          /* decoder/tables.h:51 */
+{
+	const int off = word & 7;
+	if (word < 10 || word > 108 || (off != 2 && off != 4 && off != 6)) return 0;
+	const int n = ((word >> 3) - 1) * 3 + (off >> 1);
+	return n <= 19 ? n : -(n - 19);
+}
+DEV int plain_level(int word)
+{
+	const int x = word < 110 ? extra_level(word) : 0;
+	if (x > 0) return 123 + (x << 3);
+	if (x < 0) return (x << 3) - 123;
+	return word > 128 ? word - 125 : word - 131;
+}
+
+/* where stream position e of the luma scan lives in the plane (strips of 4 columns, serpentine; nhw_decoder.c:71-91) */
+DEV int luma_cell(int e)
+{
+	const int k = e >> 11, within = e & 2047, rp = within >> 3, idx = within & 7;
+	return (2 * rp + (idx >> 2)) * DW + 4 * k + ((idx & 4) ? 7 - idx : idx);
+}
+/* chroma: position m of one component's half of the interleaved scan (strips of 8 columns; :904-932) */
+DEV int chroma_cell(int m)
+{
+	const int k = m >> 11, within = m & 2047, rp = within >> 4, idx = within & 15;
+	return (2 * rp + (idx >> 3)) * DH + 8 * k + ((idx & 8) ? 15 - idx : (idx & 7));
+}
+
+struct Hist {                      /* the five stream values before position e (zero before the start) */
+	int h1, h2, h3, h4, h5;
+	DEV void push(int v) { h5 = h4; h4 = h3; h3 = h2; h2 = h1; h1 = v; }
+	DEV void zeros(int n) { if (n >= 5) { h1 = h2 = h3 = h4 = h5 = 0; } else for (int i = 0; i < n; i++) push(0); }
+};
+
+__global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
+{
+	__shared__ uint16_t lut[2][256];
+	__shared__ uint16_t book[2][720];
+	__shared__ uint8_t scratch[2][1440];
+	const int img = blockIdx.x, part = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status) return;
+	const uint8_t *f = ws.blob + ws.blob_off[img];
+	vlc_fill_lut(lut[part], lane);
+	if (lane) return;
+	int bad = 0;
+	if (!part) {
+		/* retrieve_pixel_Y_comp, compress_pixel.c:49-444 */
+		build_book(f + m->o_book1, m->book1_len, false, 0, book[0], scratch[0], scratch[0] + 720);
+		int16_t *a = plane_a(ws, img);
+		const uint8_t *s1 = f + m->o_sel1, *s2 = f + m->o_sel2;
+		Bits b; b.init(ws.buf<uint32_t>(D_PK, img), m->data1);
+		const bool zoned = m->res_high < 4;
+		const int limit = 4 * DQ - 1;
+		int e = 0, mem = 0, mem2 = 0, ac1 = 0, run_over = -257, t = 0, t2 = 0;
+		Hist h = { 0, 0, 0, 0, 0 };
+#define PUT(v) do { const int v_ = (v); if (e < 4 * DQ) a[luma_cell(e)] = (int16_t)v_; h.push(v_); e++; } while (0)
+		while (e < limit) {
+			int rank;
+			if (b.spent()) { bad = 1; break; }
+			b.need32();
+			if (zoned && b.peek(9) == 1) { b.skip(9); b.need32(); rank = 110 + (int)b.peek(6); b.skip(6); }
+			else {
+				rank = vlc_next(b, lut[0]);
+				if (rank < 0) { bad = 1; break; }
+				if (zoned && rank >= 110) rank += 64;
+			}
+			const int word = book[0][rank] & 255, rle = book[0][rank] >> 8;
+			if (word == 128) {
+				int put = 0, neg = 0;
+				mem++;
+				if (mem2 == 1) {
+					if ((e >= 5 && !h.h2 && !h.h3 && !h.h4 && !h.h5) || (rle >= 4 && !h.h2)) { put = 1; neg = !bit_of(s2, m->select2, t2++); }
+					mem2 = 0;
+				}
+				else {
+					const bool room = rle >= 4 && e > 0 && !h.h1 && !ac1 && (e + rle - 257) >= run_over;
+					if (mem == 2 && !ac1) {
+						if ((e >= 4 && !h.h1 && !h.h2 && !h.h3 && !h.h4 && (e + rle - 257) >= run_over) || room) { put = 1; neg = bit_of(s1, m->select1, t++); mem = 1; }
+					}
+					else if (room) { put = 1; neg = bit_of(s1, m->select1, t++); mem = 1; }
+				}
+				if (put) PUT(neg ? -11 : 11);
+				if (rle == 254) { ac1 = 1; mem = 0; run_over = e; } else ac1 = 0;
+				e += rle; h.zeros(rle);
+			}
+			else {
+				mem = 0; mem2 = 0; ac1 = 0;
+				switch (word) {
+				case 136: PUT(11); mem2 = 1; break;
+				case 120: PUT(-11); mem2 = 1; break;
+				case 132: PUT(11); e += 3; h.zeros(3); PUT(11); break;
+				case 133: PUT(11); e += 3; h.zeros(3); PUT(-11); break;
+				case 134: PUT(-11); e += 3; h.zeros(3); PUT(11); break;
+				case 135: PUT(-11); e += 3; h.zeros(3); PUT(-11); break;
+				case 127: PUT(1008); break;
+				case 129: PUT(1009); break;
+				case 125: PUT(1006); break;
+				case 126: PUT(1007); break;
+				case 121: PUT(1010); break;
+				case 122: PUT(1011); break;
+				case 124: PUT(11); break;
+				case 123: PUT(-11); break;
+				default: PUT(plain_level(word)); break;
+				}
+			}
+		}
+#undef PUT
+	}
+	else {
+		/* retrieve_pixel_UV_comp, :446-640: U on even, V on odd stream positions */
+		build_book(f + m->o_book2, m->book2_len, true, m->tree_end, book[1], scratch[1], scratch[1] + 720);
+		int16_t *cu = plane_ca(ws, img, 0), *cv = plane_ca(ws, img, 1);
+		Bits b; b.init(ws.buf<uint32_t>(D_PK, img) + m->data1, m->data2 - m->data1);
+		const int limit = 2 * DQ - 2;
+		int e = 0;
+		while (e < limit) {
+			if (b.spent()) { bad = 1; break; }
+			const int rank = vlc_next(b, lut[1]);
+			if (rank < 0) { bad = 1; break; }
+			const int word = book[1][rank] & 255;
+			if (word == 128) { e += book[1][rank] >> 8; continue; }
+			int v;
+			if (word == 124) v = 5005; else if (word == 126) v = 5006; else if (word == 122) v = 5003; else if (word == 130) v = 5004;
+			else v = plain_level(word);
+			if (e < 2 * DQ) ((e & 1) ? cv : cu)[chroma_cell(e >> 1)] = (int16_t)v;
+			e++;
+		}
+	}
+	if (bad) atomicExch(&ws.buf<DecMeta>(D_META, img)->status, (int)NHW_E_FORMAT);
+}
+
+/* ---------------------------------------------------------------------------------------------- expand (d3)
+ * nhw_decoder.c:493-668 (luma) and the chroma LL2 / exception samples (:943-981, :1231-1267): one wavefront per image.
+ * Rows run in order.  A row is loaded by the whole wavefront (cell = lane + 64k); if it holds no pattern symbol there is
+ * nothing to do for loops 1-2 and the HH nudge of loop 3 is a per-cell function of loaded values.  A row with pattern
+ * symbols is replayed by lane 0 on an LDS copy, cell by cell in the reference's order. */
+DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_wave_barrier(); }
+
+__global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
+{
+	__shared__ int16_t stage[4][3 * DW + 8];
+	const int img = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (img >= ws.n) return;
+	DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status) return;
+	const int q = m->q;
+	int16_t *a = plane_a(ws, img);
+	int16_t *st = stage[threadIdx.x >> 6];
+	const uint8_t *f = ws.blob + ws.blob_off[img];
+
+	/* loop 1: rows 0..255, all columns (:493-527) */
+	for (int i = 0; i < DH; i++) {
+		int16_t *row = a + (size_t)i * DW;
+		int v[8]; bool any = false;
+		for (int k = 0; k < 8; k++) { v[k] = row[lane + 64 * k]; any |= v[k] > 1000; }
+		if (!__any(any)) continue;
+		for (int k = 0; k < 8; k++) { st[lane + 64 * k] = (int16_t)v[k]; st[DW + lane + 64 * k] = row[DW + lane + 64 * k]; }
+		__builtin_amdgcn_wave_barrier();
+		if (!lane) {
+			for (int j = 0; j < DW; j++) {
+				int16_t *p = st + j;
+				const int s = *p;
+				if (s <= 1000) continue;
+				int lft = 0x7fff;                                   /* value written to p[-1], if any */
+				switch (s) {
+				case 1008: lft = 5; p[1] = 5; p[0] = (int16_t)(j < DH ? 5 : 6); break;
+				case 1009: lft = -5; p[1] = -5; p[0] = (int16_t)(j < DH ? -6 : -7); break;
+				case 1010: p[0] = 5; p[1] = 5; p[DW] = 5; if (j < DW - 1) p[DW + 1] = 5; else row[2 * DW] = 5; break;
+				case 1011: p[0] = -5; p[1] = -5; p[DW] = -5; if (j < DW - 1) p[DW + 1] = -5; else row[2 * DW] = -5; break;
+				case 1006: p[0] = -6; p[1] = -6; break;
+				case 1007: p[0] = 6; p[1] = 6; break;
+				default: break;
+				}
+				if (lft != 0x7fff) { if (j > 0) p[-1] = (int16_t)lft; else row[-1] = (int16_t)lft; }
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+		for (int k = 0; k < 8; k++) { row[lane + 64 * k] = st[lane + 64 * k]; row[DW + lane + 64 * k] = st[DW + lane + 64 * k]; }
+		wave_sync();
+	}
+
+	/* loops 2 and 3, row by row: the left half's pattern symbols (:529-560), then the HH half (:562-616) */
+	int carry = m->carry;
+	for (int i = DH; i < DW; i++) {
+		int16_t *row = a + (size_t)i * DW;
+		{
+			int v[4]; bool any = false;
+			for (int k = 0; k < 4; k++) { v[k] = row[lane + 64 * k]; any |= v[k] > 1000; }
+			if (__any(any)) {
+				for (int k = 0; k < 4; k++) st[lane + 64 * k] = (int16_t)v[k];
+				if (!lane) st[DH] = row[DH];
+				__builtin_amdgcn_wave_barrier();
+				if (!lane) {
+					for (int j = 0; j < DH; j++) {
+						int16_t *p = st + j;
+						const int s = *p;
+						int lft = 0x7fff;
+						if (s == 1008) { lft = 5; p[0] = 6; p[1] = 5; }
+						else if (s == 1009) { lft = -5; p[0] = -7; p[1] = -5; }
+						else if (s == 1006) { p[0] = -7; p[1] = -7; }
+						else if (s == 1007) { p[0] = 7; p[1] = 7; }
+						if (lft != 0x7fff) { if (j > 0) p[-1] = (int16_t)lft; else row[-1] = (int16_t)lft; }
+					}
+					row[DH] = st[DH];
+				}
+				__builtin_amdgcn_wave_barrier();
+				for (int k = 0; k < 4; k++) row[lane + 64 * k] = st[lane + 64 * k];
+				wave_sync();
+			}
+		}
+		/* HH half of the row: columns 256..511 */
+		int cur[4], up[4], dn[4]; bool any = false;
+		for (int k = 0; k < 4; k++) {
+			const int c = DH + lane + 64 * k;
+			cur[k] = row[c]; up[k] = row[c - DW]; dn[k] = i + 1 < DW ? row[c + DW] : 0;
+			any |= cur[k] > 1000;
+		}
+		if (!__any(any)) {
+			if (q >= 23) continue;
+			/* no pattern symbol in this row: left / right neighbours are the loaded values */
+			unsigned cand = 0, hit[4];
+			for (int k = 0; k < 4; k++) {
+				const int c = DH + lane + 64 * k;
+				const int l = __shfl(cur[k], (lane + 63) & 63), lw = k ? __shfl(cur[k - 1], 63) : 0;
+				const int r = __shfl(cur[k], (lane + 1) & 63), rw = k < 3 ? __shfl(cur[k + 1], 0) : 0;
+				const int lv = lane ? l : lw, rv = lane < 63 ? r : rw;
+				const bool cd = iabs(cur[k]) > 8 && iabs(cur[k]) < 16 && c > DH && c < DW - 1;
+				hit[k] = (unsigned)((iabs(lv) < 8) + (iabs(rv) < 8) + (iabs(up[k]) < 8) + (iabs(dn[k]) < 8));
+				cand |= cd ? 1u << k : 0u;
+			}
+			if (carry) {                                          /* the very first candidate of the walk also gets the left-over count */
+				for (int k = 0; k < 4 && carry; k++) {
+					const uint64_t bm = __ballot((cand >> k) & 1);
+					if (bm) { if (lane == __builtin_ctzll(bm)) hit[k] += (unsigned)carry; carry = 0; }
+				}
+			}
+			for (int k = 0; k < 4; k++)
+				if (((cand >> k) & 1) && hit[k] >= 2) row[DH + lane + 64 * k] = (int16_t)(cur[k] > 0 ? cur[k] + 1 : cur[k] - 1);
+			continue;
+		}
+		/* replay on an LDS copy: rows i-1, i, i+1 of the HH half at st[0], st[DW], st[2*DW] (+1: one cell of margin on the left) */
+		for (int k = 0; k < 4; k++) { st[1 + lane + 64 * k] = (int16_t)up[k]; st[DW + 1 + lane + 64 * k] = (int16_t)cur[k]; st[2 * DW + 1 + lane + 64 * k] = (int16_t)dn[k]; }
+		__builtin_amdgcn_wave_barrier();
+		if (!lane) {
+			for (int j = DH; j < DW; j++) {
+				int16_t *p = st + DW + 1 + (j - DH);
+				const int s = *p;
+				if (s > 1000) {
+					if (s == 1008 || s == 1009) {
+						const int sg = s == 1008 ? 1 : -1;
+						if (j > DH) p[-1] = (int16_t)(5 * sg); else row[DH - 1] = (int16_t)(5 * sg);
+						p[0] = (int16_t)(s == 1008 ? 6 : -7);
+						if (j < DW - 1) p[1] = (int16_t)(5 * sg); else row[DW] = (int16_t)(5 * sg);
+					}
+					else if (s == 1006 || s == 1007) {
+						const int16_t val = (int16_t)(s == 1006 ? -7 : 7);
+						row[j - DH] = val; row[j - 3 * DH] = val; p[0] = 0;
+					}
+				}
+				else if (iabs(s) > 8 && iabs(s) < 16 && q < 23 && j > DH && j < DW - 1) {
+					carry += (iabs(p[-1]) < 8) + (iabs(p[1]) < 8) + (iabs(p[-DW]) < 8) + (iabs(p[DW]) < 8);
+					if (carry >= 2) *p = (int16_t)(s > 0 ? s + 1 : s - 1);
+					carry = 0;
+				}
+			}
+		}
+		carry = __shfl(carry, 0);
+		__builtin_amdgcn_wave_barrier();
+		for (int k = 0; k < 4; k++) row[DH + lane + 64 * k] = st[DW + 1 + lane + 64 * k];
+		wave_sync();
+	}
+	wave_sync();
+
+	/* LL2 samples (:618-625) */
+	const uint8_t *ll = ws.buf<uint8_t>(D_LL, img);
+	for (int k = lane; k < DQ / 4; k += 64) a[(size_t)(k >> 7) * DW + (k & 127)] = ll[k];
+	for (int c = 0; c < 2; c++) {
+		int16_t *ca = plane_ca(ws, img, c);
+		const uint8_t *l = ll + DQ / 4 + (c ? DQ / 16 : 0);
+		for (int k = lane; k < DQ / 16; k += 64) ca[(size_t)(k >> 6) * DH + (k & 63)] = (int16_t)(l[k] + (q > 15 ? 0 : 1));
+	}
+	wave_sync();
+	if (!lane) {
+		if (q > 17) {                                              /* odd-LL tags (:627-654) */
+			const uint8_t *r4 = f + m->o_res4;
+			int rowi = 0;
+			for (int i = 0; i < m->res4_len; i++) {
+				const int v = r4[i];
+				if (v == 128) { rowi++; continue; }
+				const int at = (rowi << 9) + (v > 128 ? v - 129 : v - 1);
+				if (at >= 0 && at + 3 < 4 * DQ) for (int k = 0; k < 4; k++) if (!(a[at + k] & 1)) a[at + k]++;
+				if (v > 128) rowi++;
+			}
+		}
+		/* exception samples: luma, then U, then V share one cursor (:656-668, :965-981, :1255-1267) */
+		const uint8_t *x = f + m->o_exw;
+		const int n = m->exw_len;
+#define XB(k) ((k) < n ? (int)x[k] : 0)
+		int i = 0;
+		for (; i < n; i += 3) {
+			if (!XB(i) && !XB(i + 1)) break;
+			const int hi = XB(i + 1) >= 128, lo = XB(i + 1) & 127;
+			a[(XB(i) << 9) + lo] = (int16_t)(hi ? XB(i + 2) + 255 : -XB(i + 2));
+		}
+		int16_t *cu = plane_ca(ws, img, 0), *cv = plane_ca(ws, img, 1);
+		i += 2;
+		for (; i < n; i += 3) {
+			if (!XB(i) && !XB(i + 1)) break;
+			const int hi = XB(i + 1) >= 128, lo = XB(i + 1) & 127;
+			cu[(XB(i) << 8) + lo] = (int16_t)(hi ? XB(i + 2) + 255 : -XB(i + 2));
+		}
+		i += 2;
+		for (; i < n; i += 3) {
+			const int hi = XB(i + 1) >= 128, lo = XB(i + 1) & 127;
+			cv[(XB(i) << 8) + lo] = (int16_t)(hi ? XB(i + 2) + 255 : -XB(i + 2));
+		}
+#undef XB
+	}
+}
+
+/* isolated level-2 coefficients shrink by one (:670-721); a pure stencil (a cell that shrinks has no neighbour that can) */
+__global__ __launch_bounds__(256) void k_dec_shrink(DecWs ws)
+{
+	const int img = blockIdx.y, i = 1 + blockIdx.x, j = threadIdx.x;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status || j < 1 || j > DH - 2) return;
+	int16_t *p = plane_a(ws, img) + (size_t)i * DW + j;
+	const int diag = m->q <= 16 ? 16 : 8, v = *p;
+	if (iabs(v) <= 8 || (i < DH / 2 && j < DH / 2)) return;
+	if (iabs(p[-DW - 1]) > diag || iabs(p[-DW]) > 8 || iabs(p[-DW + 1]) > diag || iabs(p[-1]) > 8 || iabs(p[1]) > 8 ||
+	    iabs(p[DW - 1]) > diag || iabs(p[DW]) > 8 || iabs(p[DW + 1]) > diag) return;
+	*p = (int16_t)(v > 0 ? v - 1 : v + 1);
+}
+
+/* ---------------------------------------------------------------------------------------------- synthesis (d4)
+ * One pass of the 5/3 synthesis over rows of [low half | high half] (decoder/filters.c:143-194, driven as in
+ * decoder/wavelet_filterbank.c:52-357).  The reference transposes between passes; here a pass reads its input
+ * transposed instead (rows below `lo_t` take their low half from columns, `hi_t` likewise for the high half).
+ * A workgroup stages 16 rows in LDS and writes 16 output rows. */
+struct SynthArgs {
+	int src, dst;            /* D_A / D_B / D_CA / D_CB (+ component for chroma), dst -1: clipped bytes to D_YB */
+	int comp;
+	int st, rows, n;         /* row stride of both planes, rows to produce, samples per output row */
+	int lo_t, hi_t, norm;
+};
+DEV int16_t *synth_plane(const DecWs &ws, int kind, int img, int comp)
+{
+	switch (kind) { case D_A: return plane_a(ws, img); case D_B: return plane_b(ws, img); case D_CA: return plane_ca(ws, img, comp); default: return plane_cb(ws, img, comp); }
+}
+__global__ __launch_bounds__(256) void k_dec_synth(DecWs ws, SynthArgs g)
+{
+	__shared__ int16_t t[16][DW + 2];
+	const int img = blockIdx.y, comp = g.comp < 0 ? (int)blockIdx.z : g.comp, r0 = blockIdx.x * 16, tid = threadIdx.x;
+	if (ws.buf<DecMeta>(D_META, img)->status) return;
+	const int16_t *src = synth_plane(ws, g.src, img, comp);
+	const int M = g.n / 2;
+	/* low halves */
+	if (r0 < g.lo_t) for (int idx = tid; idx < 16 * M; idx += 256) { const int k = idx >> 4, rr = idx & 15; t[rr][k] = src[(size_t)k * g.st + r0 + rr]; }
+	else for (int idx = tid; idx < 16 * M; idx += 256) { const int rr = idx / M, k = idx - rr * M; t[rr][k] = src[(size_t)(r0 + rr) * g.st + k]; }
+	if (g.hi_t) for (int idx = tid; idx < 16 * M; idx += 256) { const int k = idx >> 4, rr = idx & 15; t[rr][M + k] = src[(size_t)(M + k) * g.st + r0 + rr]; }
+	else for (int idx = tid; idx < 16 * M; idx += 256) { const int rr = idx / M, k = idx - rr * M; t[rr][M + k] = src[(size_t)(r0 + rr) * g.st + M + k]; }
+	__syncthreads();
+	for (int idx = tid; idx < 16 * M; idx += 256) {
+		const int rr = idx / M, k = idx - rr * M;
+		const int16_t *lo = t[rr], *hi = t[rr] + M;
+		int ev = (int16_t)(lo[k] << 3), od = k < M - 1 ? (int16_t)((lo[k + 1] + lo[k]) << 2) : (int16_t)(lo[M - 1] << 3);
+		if (k == 0) { ev -= hi[0] << 2; od += 5 * hi[0] - hi[1]; }
+		else if (k < M - 1) { ev -= (hi[k] + hi[k - 1]) << 1; od += 6 * hi[k] - hi[k + 1] - hi[k - 1]; }
+		else { ev -= (hi[M - 1] + hi[M - 2]) << 1; od += 5 * hi[M - 1] - hi[M - 2]; }
+		ev = (int16_t)ev; od = (int16_t)od;
+		if (g.norm) { if (ev > 0) ev = (int16_t)(ev + 32); ev >>= 6; if (od > 0) od = (int16_t)(od + 32); od >>= 6; }
+		if (g.dst < 0) {
+			uint8_t *y = ws.buf<uint8_t>(D_YB, img) + (size_t)(r0 + rr) * g.n + 2 * k;
+			*(uchar2 *)y = make_uchar2((unsigned char)clip8(ev), (unsigned char)clip8(od));
+		} else {
+			int16_t *d = synth_plane(ws, g.dst, img, comp) + (size_t)(r0 + rr) * g.st + 2 * k;
+			*(short2 *)d = make_short2((short)ev, (short)od);
+		}
+	}
+}
+
+/* ---------------------------------------------------------------------------------------------- residual lists (:731-787)
+ * onto the level-1 LL (kept in the top-left quarter of plane A); positions may repeat, hence add_i16 */
+__global__ __launch_bounds__(256) void k_dec_resid(DecWs ws)
+{
+	const int img = blockIdx.x, tid = threadIdx.x;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status) return;
+	const int q = m->q;
+	const uint8_t *f = ws.blob + ws.blob_off[img];
+	int16_t *c = plane_a(ws, img);
+#define AT(p) ((((int)(p) & 65280) << 1) + ((int)(p) & 255))
+	if (q >= 21) {
+		const uint16_t *p5 = ws.buf<uint16_t>(D_P5, img);
+		const int cnt = (m->res5_bits - 1) * 8;
+		for (int k = tid; k < cnt; k += 256) add_i16(c + AT(p5[k]), bit_of(f + m->o_res5_word, m->res5_bits, k) ? -3 : 3);
+	}
+	if (q > 12) {
+		const uint16_t *p1 = ws.buf<uint16_t>(D_P1, img);
+		const int amp = q >= 18 ? 5 : q >= 15 ? 7 : 9, cnt = (m->res1_bits - 1) * 8;
+		for (int k = tid; k < cnt; k += 256) add_i16(c + AT(p1[k]), bit_of(f + m->o_res1_word, m->res1_bits, k) ? -amp : amp);
+	}
+	if (q >= 19) {
+		const uint16_t *p3 = ws.buf<uint16_t>(D_P3, img);
+		const uint8_t *w = f + m->o_res3_word;
+		const int cnt = (m->res3_bits * 2 - 2) * 4;
+		for (int k = tid; k < cnt; k += 256) {
+			const int sel = (w[k >> 2] >> (6 - 2 * (k & 3))) & 3;
+			/* rows 254/255 reach below the level-1 LL: in the reference those cells are scratch that the next pass overwrites; here they are
+			 * the level-1 detail bands, so those adds are dropped */
+			const int at = AT(p3[k]);
+			int16_t *t = c + at;
+			const bool r1 = at + DW < DH * DW, r2 = at + 2 * DW < DH * DW;
+			if (sel == 1) { add_i16(t, -4); if (r1) add_i16(t + DW, -3); }
+			else if (sel == 0) { add_i16(t, 4); if (r1) add_i16(t + DW, 3); }
+			else if (sel == 2) { add_i16(t, 2); if (r1) add_i16(t + DW, 2); if (r2) add_i16(t + 2 * DW, 2); }
+			else { add_i16(t, -2); if (r1) add_i16(t + DW, -2); if (r2) add_i16(t + 2 * DW, -2); }
+		}
+	}
+#undef AT
+}
+
+/* ---------------------------------------------------------------------------------------------- smooth-edge marks (:789-848)
+ * The reference marks a sample by adding 16000 to it in place while it walks the level-1 LL in raster order, so a
+ * mark shows up (as -16000) in the Laplacians of the pairs visited after it: the row above (three cells) and the
+ * cell to the left.  One wavefront per image walks the rows in order; a lane owns two pairs (cells 4l+1 .. 4l+4),
+ * evaluates them for both states of the cell on its left, and the chain of "my last cell is marked" along the row
+ * is settled on the ballots.  Output: the marked positions in raster order. */
+DEV int lap_at(const int16_t *p)
+{
+	return (p[0] << 3) - p[-1] - p[1] - p[-DW] - p[DW] - p[-DW - 1] - p[DW - 1] - p[-DW + 1] - p[DW + 1];
+}
+DEV void pair_decide(int r0, int r1, int &m0, int &m1)
+{
+	m0 = m1 = 0;
+	if (r0 > 41 && r0 < 108 && r1 < 16) m0 = 1;
+	else if (r0 < -41 && r0 > -108 && r1 > -16) m0 = 1;
+	else if (r1 > 41 && r1 < 108 && r0 < 16) m1 = 1;
+	else if (r1 < -41 && r1 > -108 && r0 > -16) m1 = 1;
+}
+__global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
+{
+	const int img = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (img >= ws.n) return;
+	DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status) return;
+	const int16_t *c = plane_a(ws, img);
+	uint16_t *marks = ws.buf<uint16_t>(D_MARKS, img);
+	int total = 0;
+	unsigned above = 0;                                             /* marks of the row above on my cells 4l+1..4l+4 (bits 0..3) */
+	for (int i = 1; i < DH - 1; i++) {
+		const int16_t *p = c + (size_t)i * DW + 4 * lane + 1;
+		int base[4];
+		for (int k = 0; k < 4; k++) base[k] = (lane < 63 || k < 2) ? lap_at(p + k) : 0;
+		/* marks above cells 4l .. 4l+5 as bits 0..5 */
+		const unsigned fromL = (unsigned)__shfl((int)above, (lane + 63) & 63), fromR = (unsigned)__shfl((int)above, (lane + 1) & 63);
+		const unsigned ab = (lane ? (fromL >> 3) & 1u : 0u) | (above << 1) | (lane < 63 ? (fromR & 1u) << 5 : 0u);
+		int cont[4];
+		for (int k = 0; k < 4; k++) cont[k] = (int)((ab >> k) & 1u) + (int)((ab >> (k + 1)) & 1u) + (int)((ab >> (k + 2)) & 1u);
+		int res[2][4];                                               /* [left cell marked][m0A, m1A, m0B, m1B] */
+		for (int ml = 0; ml < 2; ml++) {
+			int a0, a1, b0, b1;
+			pair_decide(base[0] - 16000 * (cont[0] + ml), base[1] - 16000 * cont[1], a0, a1);
+			pair_decide(base[2] - 16000 * (cont[2] + a1), base[3] - 16000 * cont[3], b0, b1);
+			if (lane == 63) { b0 = 0; b1 = 0; }                       /* pair 127 (cells 255, 256) does not exist */
+			res[ml][0] = a0; res[ml][1] = a1; res[ml][2] = b0; res[ml][3] = b1;
+		}
+		const uint64_t o0 = __ballot(res[0][3]), o1 = __ballot(res[1][3]);
+		uint64_t x = o0;
+		for (;;) { const uint64_t need = x << 1, xn = (o0 & ~need) | (o1 & need); if (xn == x) break; x = xn; }
+		const int ml = lane ? (int)((x >> (lane - 1)) & 1ull) : 0;
+		const unsigned mine = (unsigned)res[ml][0] | ((unsigned)res[ml][1] << 1) | ((unsigned)res[ml][2] << 2) | ((unsigned)res[ml][3] << 3);
+		/* ordered output */
+		const int cnt = __popc(mine);
+		int pre = cnt;
+		for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(pre, d); if (lane >= d) pre += o; }
+		int at = total + pre - cnt;
+		for (int k = 0; k < 4; k++) if ((mine >> k) & 1u) marks[at++] = (uint16_t)(i * DH + 4 * lane + 1 + k);
+		total += __shfl(pre, 63);
+		above = mine;
+	}
+	if (!lane) m->nmarks = total;
+}
+
+/* q>21 corrections on the first-direction output of level 1 (wavelet_filterbank.c:301-347) */
+__global__ __launch_bounds__(256) void k_dec_corr(DecWs ws)
+{
+	const int img = blockIdx.x, tid = threadIdx.x;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status || m->q <= 21) return;
+	const uint8_t *f = ws.blob + ws.blob_off[img];
+	int16_t *b = plane_b(ws, img);
+	const uint32_t *p6 = ws.buf<uint32_t>(D_P6, img);
+	const int cnt = (m->res6_bits - 1) * 8;
+	for (int k = tid; k < cnt; k += 256) if (p6[k] < 4u * DQ) add_i16(b + p6[k], bit_of(f + m->o_res6_word, m->res6_bits, k) ? -32 : 32);
+	const uint8_t *cr = f + m->o_char;
+	for (int k = tid; k < m->char_res1_len; k += 256) {
+		const int v = cr[2 * k] | (cr[2 * k + 1] << 8);
+		const int t = v & 3;
+		const int at = t == 0 ? (v << 1) + DH - 2 : t == 1 ? ((v - 1) << 1) + DH - 2 : t == 2 ? ((v - 2) << 1) + DH - 1 : ((v - 3) << 1) + DH - 1;
+		if (at >= 0 && at < 4 * DQ) add_i16(b + at, (t & 1) ? -32 : 32);
+	}
+	if (m->q > 22) {
+		const uint8_t *qs = f + m->o_qs3;
+		for (int k = tid; k < m->qs3_len; k += 256) {
+			const uint32_t v = (uint32_t)qs[4 * k] | ((uint32_t)qs[4 * k + 1] << 8) | ((uint32_t)qs[4 * k + 2] << 16) | ((uint32_t)qs[4 * k + 3] << 24);
+			if ((v >> 1) < 4u * DQ) add_i16(b + (v >> 1), (v & 1) ? -56 : 56);
+		}
+	}
+}
+
+/* 5-tap smoothing at the marked samples (:859-876), on plane B read transposed (the reference transposes first).
+ * List order matters only inside a run of horizontally adjacent marks: the head of a run walks it. */
+__global__ __launch_bounds__(256) void k_dec_smooth(DecWs ws)
+{
+	const int img = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status || k >= m->nmarks) return;
+	const uint16_t *marks = ws.buf<uint16_t>(D_MARKS, img);
+	int16_t *b = plane_b(ws, img);
+	if (k > 0 && marks[k - 1] + 1 == marks[k]) return;
+	for (int t = k; t < m->nmarks && (t == k || marks[t - 1] + 1 == marks[t]); t++) {
+		const int row = (marks[t] >> 8) << 1, col = marks[t] & 255;     /* cell (row, col) of the transposed plane = b[col][row] */
+#define TP(dr, dc) ((int)b[(size_t)(col + (dc)) * DW + row + (dr)])
+		const int ctr = TP(0, 0);
+		const int lap = (ctr << 3) - TP(0, -1) - TP(0, 1) - TP(-1, 0) - TP(1, 0) - TP(-1, -1) - TP(1, -1) - TP(-1, 1) - TP(1, 1);
+		if (iabs(lap) < 116) b[(size_t)col * DW + row] = (int16_t)(((ctr << 2) + TP(0, -1) + TP(0, 1) + TP(-1, 0) + TP(1, 0) + 4) >> 3);
+#undef TP
+	}
+}
+
+/* ---------------------------------------------------------------------------------------------- chroma
+ * pair / single corrections carried as symbols in the level-1 detail bands (:992-1083) */
+__global__ __launch_bounds__(256) void k_dec_cpairs(DecWs ws)
+{
+	const int img = blockIdx.y, comp = blockIdx.z, i = blockIdx.x, j = threadIdx.x;
+	if (ws.buf<DecMeta>(D_META, img)->status) return;
+	if (i < DH / 2 && j < DH / 2) return;
+	int16_t *a = plane_ca(ws, img, comp);
+	int16_t *p = a + (size_t)i * DH + j;
+	const int s = *p;
+	if (s < 5003 || s > 5006) return;
+	int16_t *t = a + (size_t)(i < DH / 2 ? i : i - DH / 2) * DH + (j < DH / 2 ? j : j - DH / 2);   /* level-1 LL lives in the top-left quarter of the same plane */
+	const bool two = (j < DH / 2 ? j : j - DH / 2) < DH / 2 - 1;      /* the second cell of a pair at the last LL column is scratch in the reference */
+	if (s == 5005) { add_i16(t, -4); if (two) add_i16(t + 1, -4); }
+	else if (s == 5006) { add_i16(t, 4); if (two) add_i16(t + 1, 4); }
+	else if (s == 5003) add_i16(t, -6);
+	else add_i16(t, 6);
+	*p = 0;
+}
+
+/* sharpen (:1097-1121): in place and in raster order -- a cell sees the new values of its left and upper neighbours.
+ * One wavefront per plane, rows in order, a lane owns four consecutive cells; along a row the only thing that travels is
+ * the change (0, +-2, +-3) of the cell on the left, settled by re-evaluating until no lane's outgoing change moves. */
+__global__ __launch_bounds__(256) void k_dec_sharpen(DecWs ws)
+{
+	const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const int img = wv >> 1, comp = wv & 1;
+	if (img >= ws.n) return;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status) return;
+	const int thr = m->q <= 14 ? 35 : 60;
+	int16_t *b = plane_ca(ws, img, comp);
+	uint8_t *out = ws.buf<uint8_t>(D_CU, img) + (size_t)comp * DQ;
+	int up[6], cur[6], dn[6];                                       /* cells 4l-1 .. 4l+4 of rows i-1 (already sharpened), i, i+1 */
+#define LOADROW(dst, r) do { const int16_t *p_ = b + (size_t)(r) * DH + 4 * lane; for (int k_ = 0; k_ < 6; k_++) { const int c_ = 4 * lane - 1 + k_; dst[k_] = (c_ >= 0 && c_ < DH) ? p_[k_ - 1] : 0; } } while (0)
+	LOADROW(up, 0); LOADROW(cur, 1);
+	for (int k = 0; k < 4; k++) out[4 * lane + k] = (uint8_t)clip8(up[k + 1]);
+	for (int i = 1; i < DH - 1; i++) {
+		LOADROW(dn, i + 1);
+		int nw[4], din = 0;
+		for (;;) {
+			int left = cur[0] + din;
+			for (int k = 0; k < 4; k++) {
+				const int c = 4 * lane + k;
+				const int x = cur[k + 1];
+				int v = x;
+				if (c >= 1 && c <= DH - 2) {
+					const int r = (x << 3) - left - cur[k + 2] - up[k + 1] - dn[k + 1] - up[k] - dn[k] - up[k + 2] - dn[k + 2];
+					if (r > thr) v = x + (r > 160 ? 3 : 2); else if (r < -thr) v = x - (r < -160 ? 3 : 2);
+				}
+				nw[k] = v; left = v;
+			}
+			const int fromL = __shfl(nw[3] - cur[4], (lane + 63) & 63);
+			const int ndin = lane ? fromL : 0;
+			if (!__any(ndin != din)) break;
+			din = ndin;
+		}
+		/* the sharpened row becomes `up`: own cells, plus the edge cells of the neighbours */
+		const int l = __shfl(nw[3], (lane + 63) & 63), r = __shfl(nw[0], (lane + 1) & 63);
+		up[0] = lane ? l : 0; up[5] = lane < 63 ? r : 0;
+		for (int k = 0; k < 4; k++) { up[k + 1] = nw[k]; out[(size_t)i * DH + 4 * lane + k] = (uint8_t)clip8(nw[k]); }
+		for (int k = 0; k < 6; k++) cur[k] = dn[k];
+	}
+	for (int k = 0; k < 4; k++) out[(size_t)(DH - 1) * DH + 4 * lane + k] = (uint8_t)clip8(cur[k + 1]);
+#undef LOADROW
+}
+
+/* ---------------------------------------------------------------------------------------------- colour (d5 tail + d6)
+ * x2 bilinear chroma (:1150-1196: columns of rows first, each rounded to a byte, then along the rows) and the colour
+ * matrix of write_image_bmp (nhw_decoder_cli.c:135-286); output bytes in the order the reference writes them */
+DEV int chroma_tall(const uint8_t *c, int r, int j)          /* row r (0..511) of the vertically doubled plane */
+{
+	const int i = r >> 1;
+	if (r >= 2 * DH - 2) return c[(DH - 1) * DH + j];
+	return (r & 1) ? (c[i * DH + j] + c[(i + 1) * DH + j] + 1) >> 1 : c[i * DH + j];
+}
+DEV int chroma_full(const uint8_t *c, int r, int x)
+{
+	const int j = x >> 1;
+	if (x >= DW - 2) return chroma_tall(c, r, DH - 1);
+	return (x & 1) ? (chroma_tall(c, r, j) + chroma_tall(c, r, j + 1) + 1) >> 1 : chroma_tall(c, r, j);
+}
+__constant__ float k_inv_low[17] = { 0.0f, 2.060881f, 1.985939f, 1.916257f, 1.820444f, 1.741126f, 1.665887f, 1.587597f, 1.521263f,
+	1.392014f, 1.281502f, 1.190611f, 1.177434f, 1.186945f, 1.138331f, 1.048174f, 1.012139f };
+__global__ __launch_bounds__(256) void k_dec_color(DecWs ws, uint8_t *out)
+{
+	const int img = blockIdx.y, r = blockIdx.x;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status) return;
+	const int q = m->q;
+	const uint8_t *yb = ws.buf<uint8_t>(D_YB, img), *cu = ws.buf<uint8_t>(D_CU, img), *cv = cu + DQ;
+	uint8_t *o = out + (size_t)img * NHW_IMG_BYTES + (size_t)r * DW * 3;
+	for (int x = threadIdx.x; x < DW; x += 256) {
+		const int yv = yb[(size_t)r * DW + x], uv = chroma_full(cu, r, x), vv = chroma_full(cv, r, x);
+		int R, G, B;
+		if (q >= 20) {
+			const int Y = yv, U = uv - 128, V = vv - 128;
+			R = (int)(Y + 1.402 * V + 0.5f); G = (int)(Y - 0.34414 * U - 0.71414 * V + 0.5f); B = (int)(Y + 1.772 * U + 0.5f);
+		}
+		else if (q >= 18) {
+			const float yinv = q == 19 ? 1.025641f : 1.075269f;
+			const float Yq = (float)(yv * yinv);
+			const int U = uv - 128, V = vv - 128;
+			R = (int)(Yq + 1.402 * V + 0.5f); G = (int)(Yq - 0.34414 * U - 0.71414 * V + 0.5f); B = (int)(Yq + 1.772 * U + 0.5f);
+		}
+		else if (q == 17) {
+			const float yinv = 1.063830f;
+			const int Y = yv, U = uv - 128, V = vv - 128;
+			R = (int)((Y + 1.402 * V) * yinv + 0.5f); G = (int)((Y - 0.34414 * U - 0.71414 * V) * yinv + 0.5f); B = (int)((Y + 1.772 * U) * yinv + 0.5f);
+		}
+		else {
+			const float yinv = k_inv_low[q];
+			const int Y = yv * 298, U = uv, V = vv;
+			R = ((int)((Y + 409 * V + (-56992 - 128)) * yinv + 128.5f)) >> 8;
+			G = ((int)((Y - 100 * U - 208 * V + (34784 - 128)) * yinv + 128.5f)) >> 8;
+			B = ((int)((Y + 516 * U + (-70688 - 128)) * yinv + 128.5f)) >> 8;
+		}
+		o[3 * x] = (uint8_t)clip8(R); o[3 * x + 1] = (uint8_t)clip8(G); o[3 * x + 2] = (uint8_t)clip8(B);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_dec_status(DecWs ws, int32_t *status, int32_t *quality)
+{
+	const int img = blockIdx.x * 256 + threadIdx.x;
+	if (img >= ws.n) return;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	status[img] = m->status;
+	if (quality) quality[img] = m->q;
+}
+
+} /* namespace */
+
+/* ---------------------------------------------------------------------------------------------- host side */
+static thread_local std::string g_derr;
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { char b_[256]; snprintf(b_, sizeof b_, "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); g_derr = b_; return NHW_E_HIP; } } while (0)
+extern "C" const char *nhw_dec_last_error(void) { return g_derr.c_str(); }
+
+struct nhw_dec {
+	int device, max_batch;
+	DecWs ws;
+	size_t slab_bytes;
+	hipStream_t own_stream;
+	int stop_after;
+	/* host convenience path */
+	uint8_t *d_blob; size_t blob_cap;
+	uint64_t *d_off; uint8_t *d_out; int32_t *d_status; int32_t *d_quality;
+};
+
+extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
+{
+	if (!out || max_batch < 1) return NHW_E_ARG;
+	HIPCHK(hipSetDevice(device));
+	nhw_dec *d = new nhw_dec();
+	memset(d, 0, sizeof *d);
+	d->device = device; d->max_batch = max_batch;
+	size_t at = 0;
+	for (int b = 0; b < D_COUNT; b++) { d->ws.off[b] = at; at += k_dec_bytes[b] * (size_t)max_batch; at = (at + 255) & ~(size_t)255; }
+	d->slab_bytes = at;
+	HIPCHK(hipMalloc(&d->ws.base, at));
+	HIPCHK(hipMemset(d->ws.base, 0, at));
+	HIPCHK(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
+	*out = d;
+	return NHW_OK;
+}
+
+extern "C" void nhw_dec_destroy(nhw_dec *d)
+{
+	if (!d) return;
+	(void)hipSetDevice(d->device);
+	if (d->ws.base) (void)hipFree(d->ws.base);
+	if (d->d_blob) (void)hipFree(d->d_blob);
+	if (d->d_off) (void)hipFree(d->d_off);
+	if (d->d_out) (void)hipFree(d->d_out);
+	if (d->d_status) (void)hipFree(d->d_status);
+	if (d->d_quality) (void)hipFree(d->d_quality);
+	if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
+	delete d;
+}
+
+extern "C" void nhw_dec_debug_stop_after(nhw_dec *d, int stage) { if (d) d->stop_after = stage; }
+
+/* debug: copy a workspace buffer of one image to the host (what = D_* index) */
+extern "C" int nhw_dec_debug_read(nhw_dec *d, int what, int img, void *dst, size_t bytes)
+{
+	if (!d || what < 0 || what >= D_COUNT || img < 0 || img >= d->max_batch || bytes > k_dec_bytes[what]) return NHW_E_ARG;
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(dst, d->ws.base + d->ws.off[what] + (size_t)img * k_dec_bytes[what], bytes, hipMemcpyDeviceToHost));
+	return NHW_OK;
+}
+
+extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_t *d_off, int n, void *d_bgr, int32_t *d_status,
+                                    int32_t *d_quality, void *stream)
+{
+	if (!d || !d_nhw || !d_off || !d_bgr || !d_status || n < 1 || n > d->max_batch) return NHW_E_ARG;
+	hipStream_t s = stream ? (hipStream_t)stream : d->own_stream;
+	DecWs ws = d->ws;
+	ws.n = n; ws.blob = (const uint8_t *)d_nhw; ws.blob_off = d_off;
+	int stage = 0;
+#define STAGE_END() do { if (d->stop_after && ++stage >= d->stop_after) goto done; } while (0)
+	/* coefficient planes start from zero (the reference's calloc, nhw_decoder.c:2029, :894) */
+	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_A], 0, k_dec_bytes[D_A] * (size_t)n, s));
+	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_CA], 0, k_dec_bytes[D_CA] * (size_t)n, s));
+	k_dec_parse<<<n, 256, 0, s>>>(ws);
+	STAGE_END();                                                                  /* 1 */
+	k_dec_vlc<<<n, 128, 0, s>>>(ws);
+	STAGE_END();                                                                  /* 2 */
+	k_dec_expand<<<(n + 3) / 4, 256, 0, s>>>(ws);
+	STAGE_END();                                                                  /* 3 */
+	k_dec_shrink<<<dim3(DH - 2, n), 256, 0, s>>>(ws);
+	STAGE_END();                                                                  /* 4 */
+	{
+		/* level 2 luma: A (top-left 256x256) -> B -> level-1 LL back in A's top-left quarter */
+		SynthArgs p1 = { D_A, D_B, 0, DW, DH, DH, 0, 0, 0 }, p2 = { D_B, D_A, 0, DW, DH, DH, DH, 1, 1 };
+		k_dec_synth<<<dim3(DH / 16, n), 256, 0, s>>>(ws, p1);
+		k_dec_synth<<<dim3(DH / 16, n), 256, 0, s>>>(ws, p2);
+	}
+	STAGE_END();                                                                  /* 5 */
+	k_dec_resid<<<n, 256, 0, s>>>(ws);
+	STAGE_END();                                                                  /* 6 */
+	k_dec_marks<<<(n + 3) / 4, 256, 0, s>>>(ws);
+	STAGE_END();                                                                  /* 7 */
+	{
+		SynthArgs p1 = { D_A, D_B, 0, DW, DW, DW, DH, 0, 0 };
+		k_dec_synth<<<dim3(DW / 16, n), 256, 0, s>>>(ws, p1);
+	}
+	k_dec_corr<<<n, 256, 0, s>>>(ws);
+	STAGE_END();                                                                  /* 8 */
+	k_dec_smooth<<<dim3(DQ / 256, n), 256, 0, s>>>(ws);
+	STAGE_END();                                                                  /* 9 */
+	{
+		SynthArgs p2 = { D_B, -1, 0, DW, DW, DW, DW, 1, 1 };
+		k_dec_synth<<<dim3(DW / 16, n), 256, 0, s>>>(ws, p2);
+	}
+	STAGE_END();                                                                  /* 10 */
+	{
+		/* chroma, both planes per launch (blockIdx.z) */
+		SynthArgs a1 = { D_CA, D_CB, -1, DH, DH / 2, DH / 2, 0, 0, 0 }, a2 = { D_CB, D_CA, -1, DH, DH / 2, DH / 2, DH / 2, 1, 1 };
+		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, s>>>(ws, a1);
+		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, s>>>(ws, a2);
+		STAGE_END();                                                              /* 11 */
+		k_dec_cpairs<<<dim3(DH, n, 2), 256, 0, s>>>(ws);
+		STAGE_END();                                                              /* 12 */
+		SynthArgs b1 = { D_CA, D_CB, -1, DH, DH, DH, DH / 2, 0, 0 }, b2 = { D_CB, D_CA, -1, DH, DH, DH, DH, 1, 1 };
+		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, s>>>(ws, b1);
+		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, s>>>(ws, b2);
+		STAGE_END();                                                              /* 13 */
+		k_dec_sharpen<<<(2 * n + 3) / 4, 256, 0, s>>>(ws);
+		STAGE_END();                                                              /* 14 */
+	}
+	k_dec_color<<<dim3(DW, n), 256, 0, s>>>(ws, (uint8_t *)d_bgr);
+done:
+	k_dec_status<<<(n + 255) / 256, 256, 0, s>>>(ws, d_status, d_quality);
+	HIPCHK(hipGetLastError());
+	return NHW_OK;
+#undef STAGE_END
+}
+
+/* host convenience: H2D of the files, decode, D2H of the pixels.  nhw: the files back to back, off[n+1]. */
+extern "C" int nhw_dec_batch(nhw_dec *d, const uint8_t *nhw, const uint64_t *off, int n, uint8_t *bgr, int32_t *status, int32_t *quality)
+{
+	if (!d || !nhw || !off || !bgr || !status || n < 1 || n > d->max_batch) return NHW_E_ARG;
+	HIPCHK(hipSetDevice(d->device));
+	const size_t total = (size_t)(off[n] - off[0]);
+	if (total + 64 > d->blob_cap) {
+		if (d->d_blob) (void)hipFree(d->d_blob);
+		d->blob_cap = total + (total >> 2) + (1u << 20);
+		HIPCHK(hipMalloc(&d->d_blob, d->blob_cap));
+	}
+	if (!d->d_off) {
+		HIPCHK(hipMalloc(&d->d_off, ((size_t)d->max_batch + 1) * 8));
+		HIPCHK(hipMalloc(&d->d_out, (size_t)d->max_batch * NHW_IMG_BYTES));
+		HIPCHK(hipMalloc(&d->d_status, (size_t)d->max_batch * 4));
+		HIPCHK(hipMalloc(&d->d_quality, (size_t)d->max_batch * 4));
+	}
+	uint64_t *rel = (uint64_t *)malloc(((size_t)n + 1) * 8);
+	if (!rel) return NHW_E_ARG;
+	for (int i = 0; i <= n; i++) rel[i] = off[i] - off[0];
+	hipError_t e1 = hipMemcpyAsync(d->d_blob, nhw + off[0], total, hipMemcpyHostToDevice, d->own_stream);
+	hipError_t e2 = hipMemcpyAsync(d->d_off, rel, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, d->own_stream);
+	hipError_t e3 = hipStreamSynchronize(d->own_stream);
+	free(rel);
+	HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
+	const int rc = nhw_dec_batch_device(d, d->d_blob, d->d_off, n, d->d_out, d->d_status, d->d_quality, d->own_stream);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(bgr, d->d_out, (size_t)n * NHW_IMG_BYTES, hipMemcpyDeviceToHost, d->own_stream));
+	HIPCHK(hipMemcpyAsync(status, d->d_status, (size_t)n * 4, hipMemcpyDeviceToHost, d->own_stream));
+	if (quality) HIPCHK(hipMemcpyAsync(quality, d->d_quality, (size_t)n * 4, hipMemcpyDeviceToHost, d->own_stream));
+	HIPCHK(hipStreamSynchronize(d->own_stream));
+	return NHW_OK;
+}
+
+/* the 54-byte header nhw-dec writes in front of the pixels (nhw_decoder_cli.c:61-65, :293-312) */
+extern "C" void nhw_dec_bmp_header(uint8_t h[54])
+{
+	static const uint8_t base[54] = { 66,77,54,0,12,0,0,0,0,0, 54,0,0,0,40,0,0,0,0,2, 0,0,0,2,0,0,1,0,24,0, 0,0,0,0,0,0,12,0,0,0 };
+	memcpy(h, base, 54);
+}

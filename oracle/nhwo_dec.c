@@ -23,6 +23,17 @@
 
 static inline int iabs(int v) { return v < 0 ? -v : v; }
 
+/* checkpoint probe (tests/gpu_dec_debug.py): copy one intermediate buffer out of the next decode */
+static struct { int id; void *dst; size_t cap, got; } g_probe;
+void nhwo_dec_probe(int id, void *dst, size_t cap) { g_probe.id = id; g_probe.dst = dst; g_probe.cap = cap; g_probe.got = 0; }
+size_t nhwo_dec_probe_len(void) { return g_probe.got; }
+static void probe(int id, const void *p, size_t n)
+{
+	if (id != g_probe.id || !g_probe.dst) return;
+	if (n > g_probe.cap) n = g_probe.cap;
+	memcpy(g_probe.dst, p, n); g_probe.got = n;
+}
+
 /* ------------------------------------------------------------------------------------------ container */
 typedef struct {
 	const uint8_t *p; size_t n, at; int bad;
@@ -475,6 +486,7 @@ static int decode_luma(dctx *d, uint8_t *ybytes)
 			r0[0] = stream[carry]; r0[1] = stream[carry + 1]; r0[2] = stream[carry + 2]; r0[3] = stream[carry + 3];
 			r1[3] = stream[carry + 4]; r1[2] = stream[carry + 5]; r1[1] = stream[carry + 6]; r1[0] = stream[carry + 7];
 		}
+	probe(2, a, 4 * Q * 2);
 	/* `carry` now stands for the reference's `count`, whose left-over value reaches the loop at :571 */
 
 	if (q > 12) { n1 = f->res1_bits * 8; p1 = (uint32_t *)grab(d->mem, (size_t)n1 * 4 + 64); poslist_decode(f->res1, f->res1_len, f->res1_bit, f->res1_bits, p1, 256, 1, tmp); carry = (f->res1_bits - 1) * 8; if (carry < 0) carry = 0; }
@@ -547,6 +559,7 @@ static int decode_luma(dctx *d, uint8_t *ybytes)
 		a[(d->exw[i] << 9) + d->exw[i + 1]] = (int16_t)v;
 	}
 
+	probe(3, a, 4 * Q * 2);
 	{                                                             /* isolated level-2 coefficients shrink by one (:670-721) */
 		const int diag = q <= 16 ? 16 : 8;
 		for (i = 1; i < H - 1; i++) for (j = 1; j < H - 1; j++) {
@@ -558,11 +571,13 @@ static int decode_luma(dctx *d, uint8_t *ybytes)
 		}
 	}
 
+	probe(4, a, 4 * Q * 2);
 	/* level 2 synthesis: rows, transpose, rows with normalisation (wavelet_filterbank.c:52-141) */
 	synth_rows(a, b, W, H, H, 0);
 	transpose(b, a, W, H);
 	synth_rows(a, b, W, H, H, 1);
 
+	probe(5, b, 4 * Q * 2);
 #define AT(p) (((int)((p) & 65280u) << 1) + (int)((p) & 255u))
 	/* residual lists onto the level-1 LL (:731-787).  Selector bits/pairs: nhw_res*_word */
 	if (q >= 21) {
@@ -594,6 +609,7 @@ static int decode_luma(dctx *d, uint8_t *ybytes)
 	}
 #undef AT
 
+	probe(6, b, 4 * Q * 2);
 	/* mark smooth-edge samples of the level-1 LL, in place, raster order (:789-836) */
 	for (i = 1; i < H - 1; i++) for (j = 1; j < H - 2; j += 2) {
 		int16_t *p = b + (size_t)i * W + j;
@@ -610,6 +626,7 @@ static int decode_luma(dctx *d, uint8_t *ybytes)
 		if (*p > 10000) { marks[nmarks++] = (uint16_t)(i * H + j); *p = (int16_t)(*p - 16000); }
 	}
 
+	probe(7, marks, (size_t)nmarks * 2);
 	for (i = 0; i < H; i++) for (j = 0; j < H; j++) a[(size_t)i * W + j] = b[(size_t)j * W + i];            /* :850-853 */
 
 	/* level 1, first direction (wavelet_synthesis2, wavelet_filterbank.c:237-357) */
@@ -634,6 +651,7 @@ static int decode_luma(dctx *d, uint8_t *ybytes)
 			if (!(v & 1)) b[v >> 1] += 56; else b[v >> 1] -= 56;
 		}
 	}
+	probe(8, b, 4 * Q * 2);
 	transpose(b, a, W, W);
 
 	for (k = 0; k < nmarks; k++) {                                /* 5-tap smoothing at the marked samples, list order (:859-876) */
@@ -641,6 +659,7 @@ static int decode_luma(dctx *d, uint8_t *ybytes)
 		if (iabs(lap8(p, W)) < 116) *p = (int16_t)(((p[0] << 2) + p[-1] + p[1] + p[-W] + p[W] + 4) >> 3);
 	}
 
+	probe(9, a, 4 * Q * 2);
 	synth_rows(a, b, W, W, W, 1);                                 /* second direction (Y==3) */
 	for (i = 0; i < 4 * Q; i++) ybytes[i] = clip8(b[i]);
 	return NHWO_OK;
@@ -673,6 +692,7 @@ static int decode_chroma(dctx *d, int comp, uint8_t *full)
 		a[(d->exw[i] << 8) + d->exw[i + 1]] = (int16_t)v;
 	}
 
+	probe(30 + comp, a, Q * 2);
 	/* level 2: rows, transpose, rows normalised (wavelet_filterbank.c:143-213) */
 	synth_rows(a, b, H, H / 2, H / 2, 0);
 	transpose(b, a, H, H / 2);
@@ -680,6 +700,7 @@ static int decode_chroma(dctx *d, int comp, uint8_t *full)
 	/* (a still holds the level-1 detail bands outside its top-left quarter: the transpose above only
 	 * rewrote that quarter) */
 
+	probe(40 + comp, b, Q * 2);
 	/* pair / single corrections carried as symbols in the level-1 detail bands (:992-1083) */
 	for (i = 0; i < H / 2; i++) for (j = H / 2; j < H; j++) {
 		int16_t *p = a + (size_t)i * H + j, *t = b + (size_t)i * H + j - H / 2;
@@ -701,6 +722,7 @@ static int decode_chroma(dctx *d, int comp, uint8_t *full)
 		default: break;
 		}
 	}
+	probe(42 + comp, b, Q * 2);
 	for (i = 0; i < H / 2; i++) for (j = 0; j < H / 2; j++) a[(size_t)i * H + j] = b[(size_t)j * H + i];  /* :1085-1088 */
 
 	/* level 1 */
@@ -708,6 +730,7 @@ static int decode_chroma(dctx *d, int comp, uint8_t *full)
 	transpose(b, a, H, H);
 	synth_rows(a, b, H, H, H, 1);
 
+	probe(44 + comp, b, Q * 2);
 	for (i = 1; i < H - 1; i++) for (j = 1; j < H - 1; j++) {     /* sharpen, in place, raster order (:1097-1121) */
 		int16_t *p = b + (size_t)i * H + j;
 		const int r = lap8(p, H);
@@ -715,6 +738,7 @@ static int decode_chroma(dctx *d, int comp, uint8_t *full)
 		else if (r < -thr) *p = (int16_t)(*p - (r < -160 ? 3 : 2));
 	}
 	for (i = 0; i < Q; i++) b[i] = clip8(b[i]);
+	probe(46 + comp, b, Q * 2);
 
 	/* x2 bilinear: rows first (:1150-1163), then columns (:1181-1196) */
 	for (j = 0; j < H; j++) {

@@ -42,6 +42,19 @@ class Oracle:
             raise RuntimeError(f"oracle decode failed rc={rc}")
         return out, q.value
 
+    def decode_probe(self, nhw: bytes, probe_id: int, cap: int = 1 << 20) -> bytes:
+        """one intermediate buffer of the decode of `nhw` (ids: see probe() calls in nhwo_dec.c)"""
+        buf = ctypes.create_string_buffer(cap)
+        self.lib.nhwo_dec_probe.argtypes = [ctypes.c_int, P, ctypes.c_size_t]
+        self.lib.nhwo_dec_probe_len.restype = ctypes.c_size_t
+        self.lib.nhwo_dec_probe(probe_id, ctypes.cast(buf, P), cap)
+        try:
+            self.decode(nhw, planes=True)
+            n = self.lib.nhwo_dec_probe_len()
+        finally:
+            self.lib.nhwo_dec_probe(0, None, 0)
+        return buf.raw[:n]
+
     def bmp_header(self) -> bytes:
         h = ctypes.create_string_buffer(54)
         self.lib.nhwo_dec_bmp_header(ctypes.cast(h, P))
