@@ -90,14 +90,15 @@ int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_
 
 /* ---- decoder (BASELINE config 5): replaces decode_image + write_image_bmp (decoder/codec.h:184-186,
  * decoder/nhw_decoder.c:54, decoder/nhw_decoder_cli.c:108), one launch sequence per batch of files ----
- * d_nhw: the .nhw files back to back in HBM, d_off[n+1] their byte offsets (device memory).  d_bgr: n*NHW_IMG_BYTES,
+ * d_nhw: an arena in HBM holding the .nhw files, file i at d_off[i] with d_len[i] bytes (device arrays; the encoder's output
+ * arena is such an arena with d_off[i] = i*NHW_OUT_STRIDE and d_len = d_sizes).  d_bgr: n*NHW_IMG_BYTES,
  * the pixel bytes in the order nhw-dec writes them behind its 54-byte header (nhw_dec_bmp_header).  d_status[i] =
  * NHW_OK / NHW_E_FORMAT, d_quality[i] (may be NULL) = the quality setting stored in file i.  Asynchronous on `stream`. */
 typedef struct nhw_dec nhw_dec;
 int  nhw_dec_create(int device, int max_batch, nhw_dec **out);
 void nhw_dec_destroy(nhw_dec *d);
 const char *nhw_dec_last_error(void);
-int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_t *d_off, int n, void *d_bgr, int32_t *d_status,
+int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_t *d_off, const uint32_t *d_len, int n, void *d_bgr, int32_t *d_status,
                          int32_t *d_quality, void *stream);
 /* host convenience: H2D of the files (nhw[off[i]..off[i+1])), decode, D2H.  Synchronous. */
 int nhw_dec_batch(nhw_dec *d, const uint8_t *nhw, const uint64_t *off, int n, uint8_t *bgr, int32_t *status, int32_t *quality);

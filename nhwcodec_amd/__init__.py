@@ -130,7 +130,7 @@ class Decoder:
         L.nhw_dec_last_error.restype = ctypes.c_char_p
         L.nhw_dec_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)]
         L.nhw_dec_destroy.argtypes = [P]
-        L.nhw_dec_batch_device.argtypes = [P, P, P, ctypes.c_int, P, P, P, P]
+        L.nhw_dec_batch_device.argtypes = [P, P, P, P, ctypes.c_int, P, P, P, P]
         L.nhw_dec_batch.argtypes = [P, P, P, ctypes.c_int, P, P, P]
         L.nhw_dec_bmp_header.argtypes = [P]
         L.nhw_dec_debug_stop_after.argtypes = [P, ctypes.c_int]
@@ -161,18 +161,20 @@ class Decoder:
         self.lib.nhw_dec_bmp_header(ctypes.cast(h, P))
         return h.raw
 
-    def decode_device(self, blob, offsets, out=None):
-        """blob: uint8 CUDA tensor holding the files back to back; offsets: int64/uint64 CUDA tensor [n+1].
+    def decode_device(self, arena, offsets, lengths, out=None):
+        """arena: uint8 CUDA tensor holding the files; offsets: int64 CUDA tensor [n]; lengths: int32 CUDA tensor [n]
+        (the encoder's output arena with offsets i*OUT_STRIDE and its sizes tensor fits as is).
         Returns (pixels[n,512,512,3], status[n], quality[n]) on the device."""
         t = self.torch
-        n = offsets.numel() - 1
+        n = offsets.numel()
         dev = f"cuda:{self.device}"
+        assert offsets.dtype == t.int64 and lengths.dtype == t.int32 and lengths.numel() == n and offsets.is_cuda and lengths.is_cuda
         if out is None:
             out = t.empty((n, 512, 512, 3), dtype=t.uint8, device=dev)
         status = t.empty(n, dtype=t.int32, device=dev)
         quality = t.empty(n, dtype=t.int32, device=dev)
-        self._chk(self.lib.nhw_dec_batch_device(self.h, blob.data_ptr(), offsets.data_ptr(), n, out.data_ptr(), status.data_ptr(), quality.data_ptr(),
-                                                t.cuda.current_stream(self.device).cuda_stream))
+        self._chk(self.lib.nhw_dec_batch_device(self.h, arena.data_ptr(), offsets.data_ptr(), lengths.data_ptr(), n, out.data_ptr(), status.data_ptr(),
+                                                quality.data_ptr(), t.cuda.current_stream(self.device).cuda_stream))
         return out, status, quality
 
     def decode(self, files):

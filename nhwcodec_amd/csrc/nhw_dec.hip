@@ -63,7 +63,8 @@ struct DecWs {
 	size_t off[D_COUNT];
 	int n;
 	const uint8_t *blob;       /* device arena holding the .nhw files */
-	const uint64_t *blob_off;  /* n + 1 offsets into it */
+	const uint64_t *blob_off;  /* n offsets into it */
+	const uint32_t *blob_len;  /* n lengths */
 	template <typename T> __host__ __device__ T *buf(int b, int img) const { return (T *)(base + off[b] + (size_t)img * k_dec_bytes_dev(b)); }
 	__host__ __device__ static size_t k_dec_bytes_dev(int b)
 	{
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void k_dec_parse(DecWs ws)
 	__shared__ int counts[4];
 	const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint8_t *f = ws.blob + ws.blob_off[img];
-	const uint64_t flen = ws.blob_off[img + 1] - ws.blob_off[img];
+	const uint64_t flen = ws.blob_len[img];
 	if (!tid) {
 		memset(&sm, 0, sizeof sm);
 		sm.size = (int)flen;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void k_dec_parse(DecWs ws)
 		}
 	}
 	if (!tid) {
-		/* the reference's `count` as decode_image reaches :571 (see oracle/nhwo_dec.c) */
+		/* the reference's `count` as decode_image reaches :571 */
 		int carry = 4 * DQ;
 		if (q > 12) carry = sm.res1_bits > 0 ? (sm.res1_bits - 1) * 8 : 0;
 		if (q >= 21) carry = sm.res5_bits > 0 ? (sm.res5_bits - 1) * 8 : 0;
@@ -543,14 +544,60 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 
 /* ---------------------------------------------------------------------------------------------- expand (d3)
  * nhw_decoder.c:493-668 (luma) and the chroma LL2 / exception samples (:943-981, :1231-1267): one wavefront per image.
- * Rows run in order.  A row is loaded by the whole wavefront (cell = lane + 64k); if it holds no pattern symbol there is
- * nothing to do for loops 1-2 and the HH nudge of loop 3 is a per-cell function of loaded values.  A row with pattern
- * symbols is replayed by lane 0 on an LDS copy, cell by cell in the reference's order. */
+ *
+ * The reference walks the plane in raster order and lets a pattern symbol write constants over its neighbours, so
+ * whether a symbol is still there when the walk reaches it depends on the symbols before it.  Rows run in order here; a
+ * row is loaded by the whole wavefront (cell = lane + 64k) and its symbols gathered with ballots.
+ *   loops 1-2 (rows 0..255, and the left half of rows 256..511): symbols are sparse, so a row with none is one load and a
+ *     ballot; a row with some is replayed on an LDS copy, symbol by symbol in column order (not cell by cell).
+ *   loop 3 (HH quadrant): besides its symbols every 9..15 coefficient is nudged by what its four neighbours hold at the
+ *     moment of the visit.  Which symbols are live comes from the same sparse replay (only 1008/1009 kill their right
+ *     neighbour); everything else is a per-cell function of the loaded row, the live masks, the finished row above and
+ *     the untouched row below, evaluated by all lanes at once. */
 DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_wave_barrier(); }
+
+struct Mask4 { uint64_t w[4]; };
+DEV Mask4 m4_prev(const Mask4 &a) { return Mask4{ { a.w[0] << 1, (a.w[1] << 1) | (a.w[0] >> 63), (a.w[2] << 1) | (a.w[1] >> 63), (a.w[3] << 1) | (a.w[2] >> 63) } }; }   /* bit of column j-1 at j */
+DEV Mask4 m4_next(const Mask4 &a) { return Mask4{ { (a.w[0] >> 1) | (a.w[1] << 63), (a.w[1] >> 1) | (a.w[2] << 63), (a.w[2] >> 1) | (a.w[3] << 63), a.w[3] >> 1 } }; }   /* bit of column j+1 at j */
+DEV Mask4 m4_and(const Mask4 &a, const Mask4 &b) { return Mask4{ { a.w[0] & b.w[0], a.w[1] & b.w[1], a.w[2] & b.w[2], a.w[3] & b.w[3] } }; }
+DEV int m4_bit(const Mask4 &a, int k, int lane) { return (int)((a.w[k] >> lane) & 1ull); }
+
+/* replay the pattern symbols of one row (columns 0..ncols-1, staged at st[0..], the row below at st[DW..]) in column order.
+ * `upper`: loop 1 (all six symbols, rows 0..255); otherwise loop 2 (left half of rows 256..511).  Lane 0 only. */
+DEV void replay_symbols(int16_t *st, int16_t *row, const uint64_t *mk, int nwords, bool upper)
+{
+	for (int k = 0; k < nwords; k++) {
+		uint64_t m = mk[k];
+		while (m) {
+			const int j = 64 * k + __builtin_ctzll(m);
+			m &= m - 1;
+			int16_t *p = st + j;
+			const int s = *p;
+			int lft = 0x7fff;
+			if (upper) {
+				switch (s) {
+				case 1008: lft = 5; p[1] = 5; p[0] = (int16_t)(j < DH ? 5 : 6); break;
+				case 1009: lft = -5; p[1] = -5; p[0] = (int16_t)(j < DH ? -6 : -7); break;
+				case 1010: p[0] = 5; p[1] = 5; p[DW] = 5; if (j < DW - 1) p[DW + 1] = 5; else row[2 * DW] = 5; break;
+				case 1011: p[0] = -5; p[1] = -5; p[DW] = -5; if (j < DW - 1) p[DW + 1] = -5; else row[2 * DW] = -5; break;
+				case 1006: p[0] = -6; p[1] = -6; break;
+				case 1007: p[0] = 6; p[1] = 6; break;
+				default: break;
+				}
+			} else {
+				if (s == 1008) { lft = 5; p[0] = 6; p[1] = 5; }
+				else if (s == 1009) { lft = -5; p[0] = -7; p[1] = -5; }
+				else if (s == 1006) { p[0] = -7; p[1] = -7; }
+				else if (s == 1007) { p[0] = 7; p[1] = 7; }
+			}
+			if (lft != 0x7fff) { if (j > 0) p[-1] = (int16_t)lft; else row[-1] = (int16_t)lft; }
+		}
+	}
+}
 
 __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 {
-	__shared__ int16_t stage[4][3 * DW + 8];
+	__shared__ int16_t stage[4][2 * DW + 8];
 	const int img = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (img >= ws.n) return;
 	DecMeta *m = ws.buf<DecMeta>(D_META, img);
@@ -563,29 +610,13 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 	/* loop 1: rows 0..255, all columns (:493-527) */
 	for (int i = 0; i < DH; i++) {
 		int16_t *row = a + (size_t)i * DW;
-		int v[8]; bool any = false;
-		for (int k = 0; k < 8; k++) { v[k] = row[lane + 64 * k]; any |= v[k] > 1000; }
-		if (!__any(any)) continue;
+		int v[8]; uint64_t mk[8]; uint64_t any = 0;
+		for (int k = 0; k < 8; k++) v[k] = row[lane + 64 * k];
+		for (int k = 0; k < 8; k++) { mk[k] = __ballot(v[k] > 1000); any |= mk[k]; }
+		if (!any) continue;
 		for (int k = 0; k < 8; k++) { st[lane + 64 * k] = (int16_t)v[k]; st[DW + lane + 64 * k] = row[DW + lane + 64 * k]; }
 		__builtin_amdgcn_wave_barrier();
-		if (!lane) {
-			for (int j = 0; j < DW; j++) {
-				int16_t *p = st + j;
-				const int s = *p;
-				if (s <= 1000) continue;
-				int lft = 0x7fff;                                   /* value written to p[-1], if any */
-				switch (s) {
-				case 1008: lft = 5; p[1] = 5; p[0] = (int16_t)(j < DH ? 5 : 6); break;
-				case 1009: lft = -5; p[1] = -5; p[0] = (int16_t)(j < DH ? -6 : -7); break;
-				case 1010: p[0] = 5; p[1] = 5; p[DW] = 5; if (j < DW - 1) p[DW + 1] = 5; else row[2 * DW] = 5; break;
-				case 1011: p[0] = -5; p[1] = -5; p[DW] = -5; if (j < DW - 1) p[DW + 1] = -5; else row[2 * DW] = -5; break;
-				case 1006: p[0] = -6; p[1] = -6; break;
-				case 1007: p[0] = 6; p[1] = 6; break;
-				default: break;
-				}
-				if (lft != 0x7fff) { if (j > 0) p[-1] = (int16_t)lft; else row[-1] = (int16_t)lft; }
-			}
-		}
+		if (!lane) replay_symbols(st, row, mk, 8, true);
 		__builtin_amdgcn_wave_barrier();
 		for (int k = 0; k < 8; k++) { row[lane + 64 * k] = st[lane + 64 * k]; row[DW + lane + 64 * k] = st[DW + lane + 64 * k]; }
 		wave_sync();
@@ -593,93 +624,92 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 
 	/* loops 2 and 3, row by row: the left half's pattern symbols (:529-560), then the HH half (:562-616) */
 	int carry = m->carry;
+	int upf[4];
+	for (int k = 0; k < 4; k++) upf[k] = a[(size_t)(DH - 1) * DW + DH + lane + 64 * k];
 	for (int i = DH; i < DW; i++) {
 		int16_t *row = a + (size_t)i * DW;
 		{
-			int v[4]; bool any = false;
-			for (int k = 0; k < 4; k++) { v[k] = row[lane + 64 * k]; any |= v[k] > 1000; }
-			if (__any(any)) {
+			int v[4]; uint64_t mk[4]; uint64_t any = 0;
+			for (int k = 0; k < 4; k++) v[k] = row[lane + 64 * k];
+			for (int k = 0; k < 4; k++) { mk[k] = __ballot(v[k] > 1000); any |= mk[k]; }
+			if (any) {
 				for (int k = 0; k < 4; k++) st[lane + 64 * k] = (int16_t)v[k];
 				if (!lane) st[DH] = row[DH];
 				__builtin_amdgcn_wave_barrier();
-				if (!lane) {
-					for (int j = 0; j < DH; j++) {
-						int16_t *p = st + j;
-						const int s = *p;
-						int lft = 0x7fff;
-						if (s == 1008) { lft = 5; p[0] = 6; p[1] = 5; }
-						else if (s == 1009) { lft = -5; p[0] = -7; p[1] = -5; }
-						else if (s == 1006) { p[0] = -7; p[1] = -7; }
-						else if (s == 1007) { p[0] = 7; p[1] = 7; }
-						if (lft != 0x7fff) { if (j > 0) p[-1] = (int16_t)lft; else row[-1] = (int16_t)lft; }
-					}
-					row[DH] = st[DH];
-				}
+				if (!lane) { replay_symbols(st, row, mk, 4, false); row[DH] = st[DH]; }
 				__builtin_amdgcn_wave_barrier();
 				for (int k = 0; k < 4; k++) row[lane + 64 * k] = st[lane + 64 * k];
 				wave_sync();
 			}
 		}
 		/* HH half of the row: columns 256..511 */
-		int cur[4], up[4], dn[4]; bool any = false;
+		int cur[4], dn[4];
+		for (int k = 0; k < 4; k++) { const int c = DH + lane + 64 * k; cur[k] = row[c]; dn[k] = i + 1 < DW ? row[c + DW] : 0; }
+		Mask4 k8, k9, s67, liveK = { { 0, 0, 0, 0 } }, live67 = { { 0, 0, 0, 0 } };
+		uint64_t any = 0;
+		for (int k = 0; k < 4; k++) {
+			k8.w[k] = __ballot(cur[k] == 1008); k9.w[k] = __ballot(cur[k] == 1009); s67.w[k] = __ballot(cur[k] == 1006 || cur[k] == 1007);
+			any |= k8.w[k] | k9.w[k] | s67.w[k];
+		}
+		if (!any && q >= 23) { for (int k = 0; k < 4; k++) upf[k] = cur[k]; continue; }
+		if (any) {                                                 /* which symbols are still there when the walk reaches them */
+			int dead_at = -1;
+			for (int k = 0; k < 4; k++) {
+				uint64_t mm = k8.w[k] | k9.w[k] | s67.w[k];
+				while (mm) {
+					const int b = __builtin_ctzll(mm), col = 64 * k + b;
+					mm &= mm - 1;
+					if (col == dead_at) continue;
+					if ((s67.w[k] >> b) & 1ull) live67.w[k] |= 1ull << b;
+					else { liveK.w[k] |= 1ull << b; dead_at = col + 1; }
+				}
+			}
+		}
+		const Mask4 live8 = m4_and(liveK, k8);
+		const Mask4 kL = m4_prev(liveK), kL2 = m4_prev(kL), kR = m4_next(liveK), p8L = m4_prev(live8), p8R = m4_next(live8), s67L = m4_prev(live67);
+		unsigned cand = 0, hit[4];
+		int fin[4];
 		for (int k = 0; k < 4; k++) {
 			const int c = DH + lane + 64 * k;
-			cur[k] = row[c]; up[k] = row[c - DW]; dn[k] = i + 1 < DW ? row[c + DW] : 0;
-			any |= cur[k] > 1000;
+			const int l = __shfl(cur[k], (lane + 63) & 63), lw = k ? __shfl(cur[k - 1], 63) : 0;
+			const int r = __shfl(cur[k], (lane + 1) & 63), rw = k < 3 ? __shfl(cur[k + 1], 0) : 0;
+			const int lv = lane ? l : lw, rv = lane < 63 ? r : rw;
+			const int lk = m4_bit(liveK, k, lane), l67 = m4_bit(live67, k, lane), lkL = m4_bit(kL, k, lane), lkR = m4_bit(kR, k, lane);
+			const bool cd = !lkL && !lk && !l67 && cur[k] <= 1000 && iabs(cur[k]) > 8 && iabs(cur[k]) < 16 && c > DH && c < DW - 1 && q < 23;
+			const bool lsmall = m4_bit(kL2, k, lane) || m4_bit(s67L, k, lane) || iabs(lv) < 8;
+			hit[k] = (unsigned)((lsmall ? 1 : 0) + (iabs(rv) < 8) + (iabs(upf[k]) < 8) + (iabs(dn[k]) < 8));
+			cand |= cd ? 1u << k : 0u;
+			int v = cur[k];
+			if (lkR) v = m4_bit(p8R, k, lane) ? 5 : -5;
+			else if (lk) v = cur[k] == 1008 ? 6 : -7;
+			else if (l67) v = 0;
+			else if (lkL) v = m4_bit(p8L, k, lane) ? 5 : -5;
+			fin[k] = v;
 		}
-		if (!__any(any)) {
-			if (q >= 23) continue;
-			/* no pattern symbol in this row: left / right neighbours are the loaded values */
-			unsigned cand = 0, hit[4];
+		if (carry) {                                              /* the very first candidate of the walk also gets the left-over count */
+			for (int k = 0; k < 4 && carry; k++) {
+				const uint64_t bm = __ballot((cand >> k) & 1);
+				if (bm) { if (lane == __builtin_ctzll(bm)) hit[k] += (unsigned)carry; carry = 0; }
+			}
+		}
+		for (int k = 0; k < 4; k++) {
+			const int lkR = m4_bit(kR, k, lane);
+			if (((cand >> k) & 1) && hit[k] >= 2 && !lkR) fin[k] = cur[k] > 0 ? cur[k] + 1 : cur[k] - 1;
+			if (fin[k] != cur[k]) row[DH + lane + 64 * k] = (int16_t)fin[k];
+			upf[k] = fin[k];
+		}
+		if (any) {                                                 /* what the symbols write outside the HH half of this row */
 			for (int k = 0; k < 4; k++) {
 				const int c = DH + lane + 64 * k;
-				const int l = __shfl(cur[k], (lane + 63) & 63), lw = k ? __shfl(cur[k - 1], 63) : 0;
-				const int r = __shfl(cur[k], (lane + 1) & 63), rw = k < 3 ? __shfl(cur[k + 1], 0) : 0;
-				const int lv = lane ? l : lw, rv = lane < 63 ? r : rw;
-				const bool cd = iabs(cur[k]) > 8 && iabs(cur[k]) < 16 && c > DH && c < DW - 1;
-				hit[k] = (unsigned)((iabs(lv) < 8) + (iabs(rv) < 8) + (iabs(up[k]) < 8) + (iabs(dn[k]) < 8));
-				cand |= cd ? 1u << k : 0u;
-			}
-			if (carry) {                                          /* the very first candidate of the walk also gets the left-over count */
-				for (int k = 0; k < 4 && carry; k++) {
-					const uint64_t bm = __ballot((cand >> k) & 1);
-					if (bm) { if (lane == __builtin_ctzll(bm)) hit[k] += (unsigned)carry; carry = 0; }
+				if (m4_bit(live67, k, lane)) { const int16_t val = (int16_t)(cur[k] == 1006 ? -7 : 7); row[c - DH] = val; row[c - 3 * DH] = val; }
+				if (m4_bit(liveK, k, lane)) {
+					const int16_t val = (int16_t)(cur[k] == 1008 ? 5 : -5);
+					if (c == DH) row[DH - 1] = val;
+					if (c == DW - 1) row[DW] = val;
 				}
 			}
-			for (int k = 0; k < 4; k++)
-				if (((cand >> k) & 1) && hit[k] >= 2) row[DH + lane + 64 * k] = (int16_t)(cur[k] > 0 ? cur[k] + 1 : cur[k] - 1);
-			continue;
+			wave_sync();
 		}
-		/* replay on an LDS copy: rows i-1, i, i+1 of the HH half at st[0], st[DW], st[2*DW] (+1: one cell of margin on the left) */
-		for (int k = 0; k < 4; k++) { st[1 + lane + 64 * k] = (int16_t)up[k]; st[DW + 1 + lane + 64 * k] = (int16_t)cur[k]; st[2 * DW + 1 + lane + 64 * k] = (int16_t)dn[k]; }
-		__builtin_amdgcn_wave_barrier();
-		if (!lane) {
-			for (int j = DH; j < DW; j++) {
-				int16_t *p = st + DW + 1 + (j - DH);
-				const int s = *p;
-				if (s > 1000) {
-					if (s == 1008 || s == 1009) {
-						const int sg = s == 1008 ? 1 : -1;
-						if (j > DH) p[-1] = (int16_t)(5 * sg); else row[DH - 1] = (int16_t)(5 * sg);
-						p[0] = (int16_t)(s == 1008 ? 6 : -7);
-						if (j < DW - 1) p[1] = (int16_t)(5 * sg); else row[DW] = (int16_t)(5 * sg);
-					}
-					else if (s == 1006 || s == 1007) {
-						const int16_t val = (int16_t)(s == 1006 ? -7 : 7);
-						row[j - DH] = val; row[j - 3 * DH] = val; p[0] = 0;
-					}
-				}
-				else if (iabs(s) > 8 && iabs(s) < 16 && q < 23 && j > DH && j < DW - 1) {
-					carry += (iabs(p[-1]) < 8) + (iabs(p[1]) < 8) + (iabs(p[-DW]) < 8) + (iabs(p[DW]) < 8);
-					if (carry >= 2) *p = (int16_t)(s > 0 ? s + 1 : s - 1);
-					carry = 0;
-				}
-			}
-		}
-		carry = __shfl(carry, 0);
-		__builtin_amdgcn_wave_barrier();
-		for (int k = 0; k < 4; k++) row[DH + lane + 64 * k] = st[DW + 1 + lane + 64 * k];
-		wave_sync();
 	}
 	wave_sync();
 
@@ -1086,7 +1116,7 @@ struct nhw_dec {
 	int stop_after;
 	/* host convenience path */
 	uint8_t *d_blob; size_t blob_cap;
-	uint64_t *d_off; uint8_t *d_out; int32_t *d_status; int32_t *d_quality;
+	uint64_t *d_off; uint32_t *d_len; uint8_t *d_out; int32_t *d_status; int32_t *d_quality;
 };
 
 extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
@@ -1113,6 +1143,7 @@ extern "C" void nhw_dec_destroy(nhw_dec *d)
 	if (d->ws.base) (void)hipFree(d->ws.base);
 	if (d->d_blob) (void)hipFree(d->d_blob);
 	if (d->d_off) (void)hipFree(d->d_off);
+	if (d->d_len) (void)hipFree(d->d_len);
 	if (d->d_out) (void)hipFree(d->d_out);
 	if (d->d_status) (void)hipFree(d->d_status);
 	if (d->d_quality) (void)hipFree(d->d_quality);
@@ -1131,13 +1162,13 @@ extern "C" int nhw_dec_debug_read(nhw_dec *d, int what, int img, void *dst, size
 	return NHW_OK;
 }
 
-extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_t *d_off, int n, void *d_bgr, int32_t *d_status,
+extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_t *d_off, const uint32_t *d_len, int n, void *d_bgr, int32_t *d_status,
                                     int32_t *d_quality, void *stream)
 {
-	if (!d || !d_nhw || !d_off || !d_bgr || !d_status || n < 1 || n > d->max_batch) return NHW_E_ARG;
+	if (!d || !d_nhw || !d_off || !d_len || !d_bgr || !d_status || n < 1 || n > d->max_batch) return NHW_E_ARG;
 	hipStream_t s = stream ? (hipStream_t)stream : d->own_stream;
 	DecWs ws = d->ws;
-	ws.n = n; ws.blob = (const uint8_t *)d_nhw; ws.blob_off = d_off;
+	ws.n = n; ws.blob = (const uint8_t *)d_nhw; ws.blob_off = d_off; ws.blob_len = d_len;
 	int stage = 0;
 #define STAGE_END() do { if (d->stop_after && ++stage >= d->stop_after) goto done; } while (0)
 	/* coefficient planes start from zero (the reference's calloc, nhw_decoder.c:2029, :894) */
@@ -1211,19 +1242,26 @@ extern "C" int nhw_dec_batch(nhw_dec *d, const uint8_t *nhw, const uint64_t *off
 	}
 	if (!d->d_off) {
 		HIPCHK(hipMalloc(&d->d_off, ((size_t)d->max_batch + 1) * 8));
+		HIPCHK(hipMalloc(&d->d_len, ((size_t)d->max_batch + 1) * 4));
 		HIPCHK(hipMalloc(&d->d_out, (size_t)d->max_batch * NHW_IMG_BYTES));
 		HIPCHK(hipMalloc(&d->d_status, (size_t)d->max_batch * 4));
 		HIPCHK(hipMalloc(&d->d_quality, (size_t)d->max_batch * 4));
 	}
-	uint64_t *rel = (uint64_t *)malloc(((size_t)n + 1) * 8);
+	uint64_t *rel = (uint64_t *)malloc(((size_t)n + 1) * 12);
 	if (!rel) return NHW_E_ARG;
-	for (int i = 0; i <= n; i++) rel[i] = off[i] - off[0];
+	uint32_t *len = (uint32_t *)(rel + n + 1);
+	for (int i = 0; i < n; i++) {
+		rel[i] = off[i] - off[0];
+		const uint64_t l = off[i + 1] - off[i];
+		len[i] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+	}
 	hipError_t e1 = hipMemcpyAsync(d->d_blob, nhw + off[0], total, hipMemcpyHostToDevice, d->own_stream);
-	hipError_t e2 = hipMemcpyAsync(d->d_off, rel, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, d->own_stream);
+	hipError_t e2 = hipMemcpyAsync(d->d_off, rel, (size_t)n * 8, hipMemcpyHostToDevice, d->own_stream);
+	hipError_t e4 = hipMemcpyAsync(d->d_len, len, (size_t)n * 4, hipMemcpyHostToDevice, d->own_stream);
 	hipError_t e3 = hipStreamSynchronize(d->own_stream);
 	free(rel);
-	HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
-	const int rc = nhw_dec_batch_device(d, d->d_blob, d->d_off, n, d->d_out, d->d_status, d->d_quality, d->own_stream);
+	HIPCHK(e1); HIPCHK(e2); HIPCHK(e4); HIPCHK(e3);
+	const int rc = nhw_dec_batch_device(d, d->d_blob, d->d_off, d->d_len, n, d->d_out, d->d_status, d->d_quality, d->own_stream);
 	if (rc) return rc;
 	HIPCHK(hipMemcpyAsync(bgr, d->d_out, (size_t)n * NHW_IMG_BYTES, hipMemcpyDeviceToHost, d->own_stream));
 	HIPCHK(hipMemcpyAsync(status, d->d_status, (size_t)n * 4, hipMemcpyDeviceToHost, d->own_stream));
