@@ -554,7 +554,8 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
  *     moment of the visit.  Which symbols are live comes from the same sparse replay (only 1008/1009 kill their right
  *     neighbour); everything else is a per-cell function of the loaded row, the live masks, the finished row above and
  *     the untouched row below, evaluated by all lanes at once. */
-DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_wave_barrier(); }
+/* stores of this wavefront visible to its own later loads (one CU, one L1): a workgroup-scope fence; an agent-scope one would write the L2 back */
+DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 struct Mask4 { uint64_t w[4]; };
 DEV Mask4 m4_prev(const Mask4 &a) { return Mask4{ { a.w[0] << 1, (a.w[1] << 1) | (a.w[0] >> 63), (a.w[2] << 1) | (a.w[1] >> 63), (a.w[3] << 1) | (a.w[2] >> 63) } }; }   /* bit of column j-1 at j */
@@ -590,7 +591,7 @@ DEV void replay_symbols(int16_t *st, int16_t *row, const uint64_t *mk, int nword
 				else if (s == 1006) { p[0] = -7; p[1] = -7; }
 				else if (s == 1007) { p[0] = 7; p[1] = 7; }
 			}
-			if (lft != 0x7fff) { if (j > 0) p[-1] = (int16_t)lft; else row[-1] = (int16_t)lft; }
+			if (lft != 0x7fff) { if (j > 0) p[-1] = (int16_t)lft; else if (upper) row[-1] = (int16_t)lft; }   /* loop 2, column 0: done up front, see the caller */
 		}
 	}
 }
@@ -622,8 +623,18 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 		wave_sync();
 	}
 
-	/* loops 2 and 3, row by row: the left half's pattern symbols (:529-560), then the HH half (:562-616) */
+	/* loops 2 and 3, row by row: the left half's pattern symbols (:529-560), then the HH half (:562-616).  The reference finishes
+	 * loop 2 before loop 3 starts; going row by row instead only differs where the two loops touch each other's cells across a row
+	 * end: a 1008/1009 in column 0 (loop 2) writes the last HH cell of the row above -- applied here before anything else -- and a
+	 * 1008/1009 in column 511 (loop 3) writes column 0 of the next row -- held back until that row's loop-2 part is done. */
+	wave_sync();
+	for (int i = DH + lane; i < DW; i += 64) {
+		const int s = a[(size_t)i * DW];
+		if (s == 1008 || s == 1009) a[(size_t)i * DW - 1] = (int16_t)(s == 1008 ? 5 : -5);
+	}
+	wave_sync();
 	int carry = m->carry;
+	int pend0 = 0x7fff;                                           /* value a column-511 symbol of the previous row writes to column 0 of this one */
 	int upf[4];
 	for (int k = 0; k < 4; k++) upf[k] = a[(size_t)(DH - 1) * DW + DH + lane + 64 * k];
 	for (int i = DH; i < DW; i++) {
@@ -642,6 +653,7 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 				wave_sync();
 			}
 		}
+		if (pend0 != 0x7fff) { if (!lane) row[0] = (int16_t)pend0; pend0 = 0x7fff; }
 		/* HH half of the row: columns 256..511 */
 		int cur[4], dn[4];
 		for (int k = 0; k < 4; k++) { const int c = DH + lane + 64 * k; cur[k] = row[c]; dn[k] = i + 1 < DW ? row[c + DW] : 0; }
@@ -705,10 +717,9 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 				if (m4_bit(liveK, k, lane)) {
 					const int16_t val = (int16_t)(cur[k] == 1008 ? 5 : -5);
 					if (c == DH) row[DH - 1] = val;
-					if (c == DW - 1) row[DW] = val;
 				}
 			}
-			wave_sync();
+			if ((liveK.w[3] >> 63) & 1ull) pend0 = ((k8.w[3] >> 63) & 1ull) ? 5 : -5;
 		}
 	}
 	wave_sync();
@@ -1041,55 +1052,68 @@ __global__ __launch_bounds__(256) void k_dec_sharpen(DecWs ws)
 /* ---------------------------------------------------------------------------------------------- colour (d5 tail + d6)
  * x2 bilinear chroma (:1150-1196: columns of rows first, each rounded to a byte, then along the rows) and the colour
  * matrix of write_image_bmp (nhw_decoder_cli.c:135-286); output bytes in the order the reference writes them */
-DEV int chroma_tall(const uint8_t *c, int r, int j)          /* row r (0..511) of the vertically doubled plane */
-{
-	const int i = r >> 1;
-	if (r >= 2 * DH - 2) return c[(DH - 1) * DH + j];
-	return (r & 1) ? (c[i * DH + j] + c[(i + 1) * DH + j] + 1) >> 1 : c[i * DH + j];
-}
-DEV int chroma_full(const uint8_t *c, int r, int x)
-{
-	const int j = x >> 1;
-	if (x >= DW - 2) return chroma_tall(c, r, DH - 1);
-	return (x & 1) ? (chroma_tall(c, r, j) + chroma_tall(c, r, j + 1) + 1) >> 1 : chroma_tall(c, r, j);
-}
 __constant__ float k_inv_low[17] = { 0.0f, 2.060881f, 1.985939f, 1.916257f, 1.820444f, 1.741126f, 1.665887f, 1.587597f, 1.521263f,
 	1.392014f, 1.281502f, 1.190611f, 1.177434f, 1.186945f, 1.138331f, 1.048174f, 1.012139f };
+DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
+{
+	if (q >= 20) {
+		const int Y = yv, U = uv - 128, V = vv - 128;
+		R = (int)(Y + 1.402 * V + 0.5f); G = (int)(Y - 0.34414 * U - 0.71414 * V + 0.5f); B = (int)(Y + 1.772 * U + 0.5f);
+	}
+	else if (q >= 18) {
+		const float yinv = q == 19 ? 1.025641f : 1.075269f;
+		const float Yq = (float)(yv * yinv);
+		const int U = uv - 128, V = vv - 128;
+		R = (int)(Yq + 1.402 * V + 0.5f); G = (int)(Yq - 0.34414 * U - 0.71414 * V + 0.5f); B = (int)(Yq + 1.772 * U + 0.5f);
+	}
+	else if (q == 17) {
+		const float yinv = 1.063830f;
+		const int Y = yv, U = uv - 128, V = vv - 128;
+		R = (int)((Y + 1.402 * V) * yinv + 0.5f); G = (int)((Y - 0.34414 * U - 0.71414 * V) * yinv + 0.5f); B = (int)((Y + 1.772 * U) * yinv + 0.5f);
+	}
+	else {
+		const float yinv = k_inv_low[q];
+		const int Y = yv * 298, U = uv, V = vv;
+		R = ((int)((Y + 409 * V + (-56992 - 128)) * yinv + 128.5f)) >> 8;
+		G = ((int)((Y - 100 * U - 208 * V + (34784 - 128)) * yinv + 128.5f)) >> 8;
+		B = ((int)((Y + 516 * U + (-70688 - 128)) * yinv + 128.5f)) >> 8;
+	}
+	R = clip8(R); G = clip8(G); B = clip8(B);
+}
+/* one workgroup = two output rows (2i, 2i+1); a thread = four pixels of one of them: one 32-bit load of Y, three chroma
+ * columns of the two source rows, 12 output bytes as three 32-bit stores */
 __global__ __launch_bounds__(256) void k_dec_color(DecWs ws, uint8_t *out)
 {
-	const int img = blockIdx.y, r = blockIdx.x;
+	const int img = blockIdx.y, r = 2 * blockIdx.x + (threadIdx.x >> 7), t = threadIdx.x & 127;
 	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
 	if (m->status) return;
 	const int q = m->q;
 	const uint8_t *yb = ws.buf<uint8_t>(D_YB, img), *cu = ws.buf<uint8_t>(D_CU, img), *cv = cu + DQ;
-	uint8_t *o = out + (size_t)img * NHW_IMG_BYTES + (size_t)r * DW * 3;
-	for (int x = threadIdx.x; x < DW; x += 256) {
-		const int yv = yb[(size_t)r * DW + x], uv = chroma_full(cu, r, x), vv = chroma_full(cv, r, x);
-		int R, G, B;
-		if (q >= 20) {
-			const int Y = yv, U = uv - 128, V = vv - 128;
-			R = (int)(Y + 1.402 * V + 0.5f); G = (int)(Y - 0.34414 * U - 0.71414 * V + 0.5f); B = (int)(Y + 1.772 * U + 0.5f);
-		}
-		else if (q >= 18) {
-			const float yinv = q == 19 ? 1.025641f : 1.075269f;
-			const float Yq = (float)(yv * yinv);
-			const int U = uv - 128, V = vv - 128;
-			R = (int)(Yq + 1.402 * V + 0.5f); G = (int)(Yq - 0.34414 * U - 0.71414 * V + 0.5f); B = (int)(Yq + 1.772 * U + 0.5f);
-		}
-		else if (q == 17) {
-			const float yinv = 1.063830f;
-			const int Y = yv, U = uv - 128, V = vv - 128;
-			R = (int)((Y + 1.402 * V) * yinv + 0.5f); G = (int)((Y - 0.34414 * U - 0.71414 * V) * yinv + 0.5f); B = (int)((Y + 1.772 * U) * yinv + 0.5f);
-		}
-		else {
-			const float yinv = k_inv_low[q];
-			const int Y = yv * 298, U = uv, V = vv;
-			R = ((int)((Y + 409 * V + (-56992 - 128)) * yinv + 128.5f)) >> 8;
-			G = ((int)((Y - 100 * U - 208 * V + (34784 - 128)) * yinv + 128.5f)) >> 8;
-			B = ((int)((Y + 516 * U + (-70688 - 128)) * yinv + 128.5f)) >> 8;
-		}
-		o[3 * x] = (uint8_t)clip8(R); o[3 * x + 1] = (uint8_t)clip8(G); o[3 * x + 2] = (uint8_t)clip8(B);
+	const uint32_t y4 = *(const uint32_t *)(yb + (size_t)r * DW + 4 * t);
+	const int i = r >> 1, j = 2 * t;
+	int tu[3], tv[3];                                             /* the vertically doubled chroma rows at columns j, j+1, j+2 */
+	for (int c = 0; c < 3; c++) {
+		const int jj = j + c < DH ? j + c : DH - 1;
+		if (r >= 2 * DH - 2) { tu[c] = cu[(DH - 1) * DH + jj]; tv[c] = cv[(DH - 1) * DH + jj]; }
+		else if (r & 1) { tu[c] = (cu[i * DH + jj] + cu[(i + 1) * DH + jj] + 1) >> 1; tv[c] = (cv[i * DH + jj] + cv[(i + 1) * DH + jj] + 1) >> 1; }
+		else { tu[c] = cu[i * DH + jj]; tv[c] = cv[i * DH + jj]; }
 	}
+	uint32_t w[3] = { 0, 0, 0 };
+	for (int px = 0; px < 4; px++) {
+		const int x = 4 * t + px;
+		int uv, vv;
+		if (x >= DW - 2) { uv = tu[DH - 1 - j]; vv = tv[DH - 1 - j]; }          /* last two columns repeat column 255 (j = 254 here) */
+		else if (x & 1) { uv = (tu[px >> 1] + tu[(px >> 1) + 1] + 1) >> 1; vv = (tv[px >> 1] + tv[(px >> 1) + 1] + 1) >> 1; }
+		else { uv = tu[px >> 1]; vv = tv[px >> 1]; }
+		int R, G, B;
+		yuv_to_bytes(q, (int)((y4 >> (8 * px)) & 255u), uv, vv, R, G, B);
+		const int b0 = 3 * px;
+		w[b0 >> 2] |= (uint32_t)R << (8 * (b0 & 3));
+		w[(b0 + 1) >> 2] |= (uint32_t)G << (8 * ((b0 + 1) & 3));
+		w[(b0 + 2) >> 2] |= (uint32_t)B << (8 * ((b0 + 2) & 3));
+	}
+	uint32_t *o = (uint32_t *)(out + (size_t)img * NHW_IMG_BYTES + (size_t)r * DW * 3 + 12 * t);
+	o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
 }
 
 __global__ __launch_bounds__(256) void k_dec_status(DecWs ws, int32_t *status, int32_t *quality)
@@ -1221,7 +1245,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 		k_dec_sharpen<<<(2 * n + 3) / 4, 256, 0, s>>>(ws);
 		STAGE_END();                                                              /* 14 */
 	}
-	k_dec_color<<<dim3(DW, n), 256, 0, s>>>(ws, (uint8_t *)d_bgr);
+	k_dec_color<<<dim3(DW / 2, n), 256, 0, s>>>(ws, (uint8_t *)d_bgr);
 done:
 	k_dec_status<<<(n + 255) / 256, 256, 0, s>>>(ws, d_status, d_quality);
 	HIPCHK(hipGetLastError());

@@ -19,6 +19,8 @@ def main():
     enc.close(); del img
     torch.cuda.empty_cache()
     dec = na.Decoder(0, n)
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
     pix = torch.empty((n, 512, 512, 3), dtype=torch.uint8, device="cuda")
     dec.decode_device(blob, offs, sizes, pix)
     torch.cuda.synchronize()
