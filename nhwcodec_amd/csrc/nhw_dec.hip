@@ -39,7 +39,7 @@ namespace {
 enum {
 	D_META, D_LL, D_PK, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_YB, D_CU, D_COUNT
 };
-enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304 };
+enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304, WIN_BYTES = 4096, LL_WIN_BYTES = 26624 };
 const size_t k_dec_bytes[D_COUNT] = {
 	/* META */ 512, /* LL */ 24832, /* PK */ (size_t)PK_WORDS * 4, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
 	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 8 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 2 * (2 * DQ + 4096), /* YB */ 4 * DQ, /* CU */ 2 * DQ
@@ -148,110 +148,200 @@ DEV void parse_header(const uint8_t *d, uint32_t len, DecMeta *m)
 		m->status = NHW_E_FORMAT;
 }
 
-/* LL2 samples (res_comp), nhw_decoder.c:1661-2026; unsigned char arithmetic. One lane. */
-DEV void ll_expand(const uint8_t *f, const DecMeta *m, uint8_t *ll)
+/* A serial walker's view of its input bytes: the first `win` of them staged in LDS (read four at a time), the rest -- if a
+ * stream is longer than its window -- from the file itself.  Reads behind the end return 0. */
+struct ByteWin {
+	const uint8_t *g; const uint32_t *lds; int len, win;
+	int have; uint32_t word;
+	DEV void init(const uint8_t *g_, const uint32_t *lds_, int len_, int win_) { g = g_; lds = lds_; len = len_; win = win_ < len_ ? win_ : len_; have = -1; word = 0; }
+	DEV int at(int i)
+	{
+		if (i >= len) return 0;
+		if (i >= win) return g[i];
+		if ((i >> 2) != have) { have = i >> 2; word = lds[have]; }
+		return (int)((word >> (8 * (i & 3))) & 255u);
+	}
+};
+/* all lanes of a wavefront: stage the first bytes of a stream (byte loads: a file section has no alignment) */
+DEV void stage_bytes(const uint8_t *g, int len, int win, uint8_t *lds, int lane)
 {
-	const uint8_t *code = f + m->o_chres, *fine = f + m->o_llword;
-	const int mode = m->res_high & 3, q = m->q, ncode = m->ch_res_len;
-	int i = 1, j = 1, a = 0;
-#define CODE(k) ((k) < ncode ? (int)code[k] : 0)
-#define PUSH(v) do { ll[j] = (uint8_t)(v); j++; } while (0)
-#define PREV ((int)ll[j - 1])
-	ll[0] = (uint8_t)CODE(0);
-	while (j < DQ / 4) {
-		const int b = CODE(i);
-		if (b >= 128) {
-			if (q > 15) { PUSH(a < m->ll_word_len ? fine[a] : 0); a++; }
-			PUSH((b - 128) << 1);
-		}
-		else if (b >= 64) {                                    /* three differences in two bytes: 5 + 4 + 5 bits (all modes) */
-			const int c = b - 64; i++;
-			const int d = CODE(i);
-			PUSH((((c >> 1) & 31) << 1) - 32 + PREV);
-			PUSH(((((c & 1) << 3) | (d >> 5)) << 1) - 16 + PREV);
-			PUSH(((d & 31) << 1) - 32 + PREV);
-		}
-		else if (mode == 1) {
-			if (b < 32) {
-				const int run = ((b >> 2) & 7) + 2, v = PREV;
-				for (int e = 0; e < run; e++) PUSH(v);
-				const int t = b & 3;
-				if (t == 1) PUSH(PREV + 2); else if (t == 2) PUSH(PREV - 2); else if (t == 3) PUSH(PREV);
+	const int n = len < win ? len : win;
+	for (int i = lane; i < n; i += 64) lds[i] = g[i];
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+}
+
+/* LL2 samples (res_comp), nhw_decoder.c:1661-2026; unsigned char arithmetic.
+ *
+ * The reference expands the DPCM bytes one at a time, each sample relative to the one before.  The dependence has two parts,
+ * and both are scans: (1) which bytes start a token -- every byte does, except the one after a 64..127 byte that itself
+ * starts a token (its payload), an alternation inside runs of such bytes; (2) the sample values -- a token either sets an
+ * absolute value or adds a few differences, so the value after each token is a segmented sum (mod 256).  One wavefront takes
+ * 64 bytes per step: token starts from a ballot, sample offsets from a prefix sum of the tokens' lengths, values from a
+ * segmented scan; then every lane writes its own token's samples.  The luma part ends at the first token that would start at
+ * sample 16384; that byte is the first chroma sample, verbatim, and the chroma bytes (one-byte tokens) follow. */
+struct LlTok { int copies, n, d0, d1, d2, abs_n, a0, a1; };   /* `copies` repeats of the value before, then n differences; or abs_n absolute samples */
+
+DEV LlTok ll_token_luma(int b, int d, int mode, bool fine_on, int fine)
+{
+	LlTok t = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	if (b >= 128) { if (fine_on) { t.abs_n = 2; t.a0 = fine; t.a1 = (b - 128) << 1; } else { t.abs_n = 1; t.a0 = (b - 128) << 1; } }
+	else if (b >= 64) { const int c = b - 64; t.n = 3; t.d0 = (((c >> 1) & 31) << 1) - 32; t.d1 = ((((c & 1) << 3) | (d >> 5)) << 1) - 16; t.d2 = ((d & 31) << 1) - 32; }
+	else if (mode == 1) {
+		if (b < 32) { t.copies = ((b >> 2) & 7) + 2; const int k = b & 3; if (k) { t.n = 1; t.d0 = k == 1 ? 2 : k == 2 ? -2 : 0; } }
+		else { const int c = b - 32; t.n = 2; t.d0 = ((c >> 3) << 1) - 4; t.d1 = ((c & 7) << 1) - 8; }
+	}
+	else if (mode == 2) t.copies = (b & 63) + 2;
+	else {
+		if (b < 16) {
+			t.copies = ((b >> 3) & 1) + 2;
+			switch (b & 7) {
+			case 1: t.n = 1; t.d0 = 2; break;
+			case 2: t.n = 2; t.d0 = 2; t.d1 = -2; break;
+			case 3: t.n = 2; t.d0 = 2; t.d1 = 0; break;
+			case 4: t.n = 2; t.d0 = -2; t.d1 = 2; break;
+			case 5: t.n = 2; t.d0 = -2; t.d1 = 0; break;
+			case 6: t.n = 1; t.d0 = -2; break;
+			case 7: t.n = 1; t.d0 = 4; break;
+			default: break;
 			}
-			else { const int c = b - 32; PUSH(((c >> 3) << 1) - 4 + PREV); PUSH(((c & 7) << 1) - 8 + PREV); }
 		}
-		else if (mode == 2) { const int run = (b & 63) + 2, v = PREV; for (int e = 0; e < run; e++) PUSH(v); }
+		else if (b < 32) { t.n = 2; t.d0 = b >= 24 ? 4 : 2; t.d1 = ((b & 7) << 1) - 8; }
+		else { const int c = b - 32; t.n = 2; t.d0 = ((c >> 3) << 1) - 6; t.d1 = ((c & 7) << 1) - 8; }
+	}
+	return t;
+}
+DEV LlTok ll_token_chroma(int b)
+{
+	LlTok t = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	if (b >= 192) {
+		const int c = b - 192, pr = c >> 2, k = c & 3;
+		t.n = 3;
+		t.d0 = pr == 2 || pr == 4 || pr == 5 ? 4 : pr == 3 || pr == 6 || pr == 7 ? -4 : 0;
+		t.d1 = pr == 0 || pr == 4 || pr == 6 ? 4 : pr == 1 || pr == 5 || pr == 7 ? -4 : 0;
+		t.d2 = k == 0 ? 0 : k == 1 ? 4 : k == 2 ? -4 : 8;
+	}
+	else if (b >= 128) { t.abs_n = 1; t.a0 = (b - 128) << 2; }
+	else if (b >= 64) {
+		const int run = (b >> 3) & 7;
+		if (run == 7) t.copies = (b & 7) + 7 + 2;
 		else {
-			if (b < 16) {
-				const int run = ((b >> 3) & 1) + 2, v = PREV;
-				for (int e = 0; e < run; e++) PUSH(v);
-				switch (b & 7) {
-				case 1: PUSH(PREV + 2); break;
-				case 2: PUSH(PREV + 2); PUSH(PREV - 2); break;
-				case 3: PUSH(PREV + 2); PUSH(PREV); break;
-				case 4: PUSH(PREV - 2); PUSH(PREV + 2); break;
-				case 5: PUSH(PREV - 2); PUSH(PREV); break;
-				case 6: PUSH(PREV - 2); break;
-				case 7: PUSH(PREV + 4); break;
-				default: break;
-				}
+			t.copies = run + 2;
+			switch (b & 7) {
+			case 1: t.n = 1; t.d0 = 4; break;
+			case 2: t.n = 2; t.d0 = 4; t.d1 = -4; break;
+			case 3: t.n = 3; t.d0 = 4; t.d1 = -4; t.d2 = 0; break;
+			case 4: t.n = 3; t.d0 = -4; t.d1 = 4; t.d2 = 0; break;
+			case 5: t.n = 2; t.d0 = -4; t.d1 = 4; break;
+			case 6: t.n = 1; t.d0 = -4; break;
+			case 7: t.n = 1; t.d0 = 8; break;
+			default: break;
 			}
-			else if (b < 32) { PUSH(PREV + (b >= 24 ? 4 : 2)); PUSH(((b & 7) << 1) - 8 + PREV); }
-			else { const int c = b - 32; PUSH(((c >> 3) << 1) - 6 + PREV); PUSH(((c & 7) << 1) - 8 + PREV); }
 		}
-		i++;
 	}
-	ll[DQ / 4] = (uint8_t)CODE(i); i++;
-	j = DQ / 4 + 1;
+	else { t.n = 2; t.d0 = ((b >> 3) << 2) - 16; t.d1 = ((b & 7) << 2) - 16; }
+	return t;
+}
+
+/* one 64-byte step: lanes that start a token carry `t`; returns through j / prev the running sample offset and value */
+DEV void ll_emit_block(const LlTok &t, bool is_tok, int lane, int &j, int &prev, int limit, uint8_t *ll)
+{
+	const int cnt = is_tok ? (t.abs_n ? t.abs_n : t.copies + t.n) : 0;
+	int off = cnt;                                                  /* inclusive prefix of the sample counts */
+	for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(off, d); if (lane >= d) off += o; }
+	/* value after each token: (absolute?, value) pairs under "a later absolute token wins, otherwise differences add up" */
+	int isabs = is_tok && t.abs_n ? 1 : 0;
+	int val = !is_tok ? 0 : t.abs_n ? (t.abs_n == 2 ? t.a1 : t.a0) : (t.d0 + t.d1 + t.d2);
+	for (int d = 1; d < 64; d <<= 1) {
+		const int oa = __shfl_up(isabs, d), ov = __shfl_up(val, d);
+		if (lane >= d && !isabs) { val += ov; isabs = oa; }
+	}
+	const int after = (isabs ? val : prev + val) & 255;             /* value after my token */
+	int before = __shfl_up(after, 1);
+	if (!lane) before = prev;
+	if (is_tok) {
+		int at = j + off - cnt;
+		if (t.abs_n) { if (at < limit) ll[at] = (uint8_t)t.a0; if (t.abs_n == 2 && at + 1 < limit) ll[at + 1] = (uint8_t)t.a1; }
+		else {
+			for (int k = 0; k < t.copies; k++, at++) if (at < limit) ll[at] = (uint8_t)before;
+			int v = before;
+			if (t.n > 0) { v += t.d0; if (at < limit) ll[at] = (uint8_t)v; at++; }
+			if (t.n > 1) { v += t.d1; if (at < limit) ll[at] = (uint8_t)v; at++; }
+			if (t.n > 2) { v += t.d2; if (at < limit) ll[at] = (uint8_t)v; at++; }
+		}
+	}
+	j += __shfl(off, 63);
+	prev = __shfl(after, 63);
+}
+
+/* whole wavefront */
+DEV void ll_expand_wave(ByteWin &code, const uint8_t *fine, const DecMeta *m, uint8_t *ll, int lane)
+{
+	const int mode = (m->res_high & 3) == 3 ? 0 : (m->res_high & 3), q = m->q;
+	int prev = code.at(0), j = 1, a = 0, i0 = 1;
+	bool pending = false;                                           /* byte i0 is the payload of a token that started in the block before */
+	if (!lane) ll[0] = (uint8_t)prev;
+	int split = -1;                                                 /* index of the byte that is sample 16384 */
+	while (split < 0) {
+		const int b = code.at(i0 + lane), d = code.at(i0 + lane + 1);
+		const uint64_t T = __ballot(b >= 64 && b < 128);
+		uint64_t pay = pending ? 1ull : 0ull, m_ = T;
+		bool pend_out = false;
+		while (m_) {                                                /* a 64..127 byte that is not itself a payload starts a two-byte token */
+			const int l = __builtin_ctzll(m_);
+			m_ &= m_ - 1;
+			if ((pay >> l) & 1ull) continue;
+			if (l == 63) pend_out = true; else pay |= 1ull << (l + 1);
+		}
+		const bool start = !((pay >> lane) & 1ull);
+		const bool verb = start && b >= 128;
+		/* fine bytes: one per verbatim token, in order */
+		int vpre = verb ? 1 : 0;
+		for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(vpre, dd); if (lane >= dd) vpre += o; }
+		const int fidx = a + vpre - 1;
+		const int fv = (verb && q > 15 && fidx < m->ll_word_len) ? fine[fidx] : 0;
+		LlTok t = ll_token_luma(b, d, mode, q > 15, fv);
+		/* where would my token start? the first token at or past sample 16384 is not a token but the chroma seed */
+		const int cnt = start ? (t.abs_n ? t.abs_n : t.copies + t.n) : 0;
+		int off = cnt;
+		for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(off, dd); if (lane >= dd) off += o; }
+		const uint64_t over = __ballot(start && j + off - cnt >= DQ / 4);
+		bool live = start;
+		if (over) { const int ls = __builtin_ctzll(over); split = i0 + ls; live = start && lane < ls; }
+		ll_emit_block(t, live, lane, j, prev, DQ / 4, ll);
+		a += __shfl(vpre, 63);                                     /* (past the split this is no longer used) */
+		pending = pend_out;
+		i0 += 64;
+	}
+	/* chroma: sample 16384 verbatim (:1878), then one-byte tokens (:1882-1979) */
+	prev = code.at(split); j = DQ / 4 + 1;
+	if (!lane) ll[DQ / 4] = (uint8_t)prev;
+	i0 = split + 1;
 	while (j < DQ / 4 + DQ / 8) {
-		const int b = CODE(i);
-		if (b >= 192) {
-			const int c = b - 192, pr = c >> 2;
-			const int d0 = pr == 2 || pr == 4 || pr == 5 ? 4 : pr == 3 || pr == 6 || pr == 7 ? -4 : 0;
-			const int d1 = pr == 0 || pr == 4 || pr == 6 ? 4 : pr == 1 || pr == 5 || pr == 7 ? -4 : 0;
-			PUSH(d0 + PREV); PUSH(d1 + PREV);
-			const int t = c & 3;
-			PUSH(PREV + (t == 0 ? 0 : t == 1 ? 4 : t == 2 ? -4 : 8));
-		}
-		else if (b >= 128) PUSH((b - 128) << 2);
-		else if (b >= 64) {
-			int run = (b >> 3) & 7;
-			const int v = PREV;
-			if (run == 7) { run = (b & 7) + 7; for (int e = 0; e < run + 2; e++) PUSH(v); }
-			else {
-				for (int e = 0; e < run + 2; e++) PUSH(v);
-				switch (b & 7) {
-				case 1: PUSH(PREV + 4); break;
-				case 2: PUSH(PREV + 4); PUSH(PREV - 4); break;
-				case 3: PUSH(PREV + 4); PUSH(PREV - 4); PUSH(PREV); break;
-				case 4: PUSH(PREV - 4); PUSH(PREV + 4); PUSH(PREV); break;
-				case 5: PUSH(PREV - 4); PUSH(PREV + 4); break;
-				case 6: PUSH(PREV - 4); break;
-				case 7: PUSH(PREV + 8); break;
-				default: break;
-				}
-			}
-		}
-		else { PUSH(((b >> 3) << 2) - 16 + PREV); PUSH(((b & 7) << 2) - 16 + PREV); }
-		i++;
+		const int b = code.at(i0 + lane);
+		LlTok t = ll_token_chroma(b);
+		const int cnt = t.abs_n ? t.abs_n : t.copies + t.n;
+		int off = cnt;
+		for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(off, dd); if (lane >= dd) off += o; }
+		const bool live = j + off - cnt < DQ / 4 + DQ / 8;         /* the walk stops at the first token that would start past the end */
+		ll_emit_block(t, live, lane, j, prev, DQ / 4 + DQ / 8, ll);
+		i0 += 64;
 	}
-#undef CODE
-#undef PUSH
-#undef PREV
 }
 
 /* position list walk (nhw_decoder.c:93-137 and its three copies): list bytes -> (row | column) entries; one lane.
  * The reference patches list bytes to 127 as it goes; only the next step's look at the previous byte sees that. */
 template <typename T>
-DEV int poslist_walk(const uint8_t *b, int len, T *pos, int cap, int row_step, bool mask16)
+DEV int poslist_walk(ByteWin &b, int len, T *pos, int cap, int row_step, bool mask16)
 {
 	int n = 0, row = 0, last = 0;          /* last = low byte of the entry written last (0 before the first: out-of-range read) */
 	if (len <= 0) return 0;
 #define EMIT(v) do { const unsigned v_ = (unsigned)(v); if (n < cap) pos[n] = (T)(mask16 ? (v_ & 0xFFFFu) : v_); last = (int)(v_ & 255u); n++; } while (0)
-	bool prev127 = b[0] == 127;
-	if (prev127) row = row_step; else EMIT(b[0] << 1);
+	const int b0 = b.at(0);
+	bool prev127 = b0 == 127;
+	if (prev127) row = row_step; else EMIT(b0 << 1);
 	for (int i = 1; i < len; i++) {
-		const int v = b[i];
+		const int v = b.at(i);
 		bool now127 = v == 127;
 		if (v >= 128) {
 			if (prev127) { row += 2 * row_step; now127 = true; }
@@ -298,15 +388,49 @@ __global__ __launch_bounds__(256) void k_dec_parse(DecWs ws)
 		pk[w] = v;
 	}
 
-	/* the byte-serial side streams, one lane each */
+	/* the byte-serial side streams: each wavefront stages its stream in LDS, then one lane walks it */
 	uint16_t *p1 = ws.buf<uint16_t>(D_P1, img), *p3 = ws.buf<uint16_t>(D_P3, img), *p5 = ws.buf<uint16_t>(D_P5, img);
 	uint32_t *p6 = ws.buf<uint32_t>(D_P6, img);
-	if (!lane) {
-		if (wv == 0) ll_expand(f, &sm, ws.buf<uint8_t>(D_LL, img));
-		else if (wv == 1) counts[1] = q > 12 ? poslist_walk(f + sm.o_res1, sm.res1_len, p1, sm.res1_bits * 8, 256, true) : 0;
-		else if (wv == 2) counts[2] = q >= 19 ? poslist_walk(f + sm.o_res3, sm.res3_len, p3, sm.res3_bits * 8, 256, true) : 0;
-		else { counts[3] = q >= 21 ? poslist_walk(f + sm.o_res5, sm.res5_len, p5, sm.res5_bits * 8, 256, true) : 0;
-		       counts[0] = q > 21 ? poslist_walk(f + sm.o_res6, sm.res6_len, p6, sm.res6_bits * 8, 256, false) : 0; }
+	__shared__ __attribute__((aligned(16))) uint8_t win_ll[LL_WIN_BYTES];
+	__shared__ __attribute__((aligned(16))) uint8_t win[4][WIN_BYTES];
+	ByteWin bw;
+	if (wv == 0) {
+		stage_bytes(f + sm.o_chres, sm.ch_res_len, LL_WIN_BYTES, win_ll, lane);
+		bw.init(f + sm.o_chres, (const uint32_t *)win_ll, sm.ch_res_len, LL_WIN_BYTES);
+		ll_expand_wave(bw, f + sm.o_llword, &sm, ws.buf<uint8_t>(D_LL, img), lane);
+	}
+	else if (wv == 1) {
+		int c = 0;
+		if (q > 12) {
+			stage_bytes(f + sm.o_res1, sm.res1_len, WIN_BYTES, win[1], lane);
+			bw.init(f + sm.o_res1, (const uint32_t *)win[1], sm.res1_len, WIN_BYTES);
+			if (!lane) c = poslist_walk(bw, sm.res1_len, p1, sm.res1_bits * 8, 256, true);
+		}
+		if (!lane) counts[1] = c;
+	}
+	else if (wv == 2) {
+		int c = 0;
+		if (q >= 19) {
+			stage_bytes(f + sm.o_res3, sm.res3_len, WIN_BYTES, win[2], lane);
+			bw.init(f + sm.o_res3, (const uint32_t *)win[2], sm.res3_len, WIN_BYTES);
+			if (!lane) c = poslist_walk(bw, sm.res3_len, p3, sm.res3_bits * 8, 256, true);
+		}
+		if (!lane) counts[2] = c;
+	}
+	else {
+		int c5 = 0, c6 = 0;
+		if (q >= 21) {
+			stage_bytes(f + sm.o_res5, sm.res5_len, WIN_BYTES, win[3], lane);
+			bw.init(f + sm.o_res5, (const uint32_t *)win[3], sm.res5_len, WIN_BYTES);
+			if (!lane) c5 = poslist_walk(bw, sm.res5_len, p5, sm.res5_bits * 8, 256, true);
+			__builtin_amdgcn_wave_barrier();
+		}
+		if (q > 21) {
+			stage_bytes(f + sm.o_res6, sm.res6_len, WIN_BYTES, win[3], lane);
+			bw.init(f + sm.o_res6, (const uint32_t *)win[3], sm.res6_len, WIN_BYTES);
+			if (!lane) c6 = poslist_walk(bw, sm.res6_len, p6, sm.res6_bits * 8, 256, false);
+		}
+		if (!lane) { counts[3] = c5; counts[0] = c6; }
 	}
 	__syncthreads();
 	/* low bits from the bit planes; entries the list did not reach are 0 + their bit (the reference's calloc) */
