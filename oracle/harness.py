@@ -161,7 +161,7 @@ def _hash_u32(idx: np.ndarray, seed: int) -> np.ndarray:
 
 
 def class_image(kind: str, seed: int = 0) -> np.ndarray:
-    """Secondary input classes of SURVEY.md section 8d: 'noise', 'blocks', 'flat', 'gradient', 'black', 'white'."""
+    """Secondary input classes of SURVEY.md section 8d: 'noise', 'blocks', 'flat', 'gradient', 'black', 'white', 'tiles'."""
     idx = np.arange(IMG_BYTES, dtype=np.uint64)
     if kind == "noise":
         return (_hash_u32(idx, seed) >> 24).astype(np.uint8).reshape(512, 512, 3)
@@ -182,4 +182,9 @@ def class_image(kind: str, seed: int = 0) -> np.ndarray:
             hh, ww = 8 + int(h[7 * k + 2] % 192), 8 + int(h[7 * k + 3] % 192)
             img[y0 : y0 + hh, x0 : x0 + ww] = (h[7 * k + 4 : 7 * k + 7] >> 24).astype(np.uint8)
         return img
+    if kind == "tiles":                                   # flat 48x48 tiles: LL2 runs of 12 equal samples -> the LL2 coder's mode 1
+        h = _hash_u32(np.arange(11 * 11 * 3, dtype=np.uint64), seed + 7).reshape(11, 11, 3)
+        t = (64 + (h >> 25)).astype(np.uint8)
+        ys = np.arange(512) // 48
+        return t[ys][:, ys].copy()
     raise ValueError(kind)

@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "dec")
 def main():
     O, RE, RD = Oracle(), RefEncoder(), RefDecoder()
     man = {}
-    cases = [(q, 0) for q in range(1, 24)] + [(1, 1), (10, 1), (6, 2), (14, 3), (16, 4), (20, "blocks"), (10, "gradient"), (3, "blocks")]
+    cases = [(q, 0) for q in range(1, 24)] + [(1, 1), (10, 1), (6, 2), (14, 3), (16, 4), (20, "blocks"), (10, "gradient"), (3, "blocks"), (10, "tiles"), (20, "tiles"), (23, "tiles")]
     for q, s in cases:
         img = O.synth(s) if isinstance(s, int) else class_image(s, 0)
         nhw = RE.encode(img, q)

@@ -343,7 +343,7 @@ def test_many_seeds_bit_exact(oracle, q):
 @pytest.mark.parametrize("q", [17, 19, 20, 22, 23])
 def test_robustness_classes_more_seeds(enc, oracle, q):
     """White noise and hard-edge rectangles (the worst cases for the order-dependent passes and the packetiser), six seeds each."""
-    imgs = [class_image(k, s) for k in ("noise", "blocks") for s in range(1, 7)]
+    imgs = [class_image(k, s) for k in ("noise", "blocks") for s in range(1, 7)] + [class_image("tiles", s) for s in range(3)]   # tiles: the LL2 coder's mode 1
     got = enc.encode(np.stack(imgs), q)
     bad = [i for i, im in enumerate(imgs) if got[i] != oracle.encode(im, q)]
     assert not bad, f"q{q}: images {bad} differ from the oracle"
