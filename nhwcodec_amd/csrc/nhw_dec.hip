@@ -39,9 +39,9 @@ namespace {
 enum {
 	D_META, D_LL, D_PK, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_YB, D_CU, D_COUNT
 };
-enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304, WIN_BYTES = 4096, LL_WIN_BYTES = 26624 };
+enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304, WIN_BYTES = 4096, LL_WIN_BYTES = 26624, VLC_WIN0 = 1280, VLC_WIN1 = 360, VLC_K = 4, SEL1_WIN = 512, SEL2_WIN = 64 };
 const size_t k_dec_bytes[D_COUNT] = {
-	/* META */ 512, /* LL */ 24832, /* PK */ (size_t)PK_WORDS * 4, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
+	/* META */ 512, /* LL */ 24832, /* PK (unused) */ 256, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
 	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 8 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 2 * (2 * DQ + 4096), /* YB */ 4 * DQ, /* CU */ 2 * DQ
 };
 
@@ -69,7 +69,7 @@ struct DecWs {
 	__host__ __device__ static size_t k_dec_bytes_dev(int b)
 	{
 		switch (b) {
-		case D_META: return 512; case D_LL: return 24832; case D_PK: return (size_t)PK_WORDS * 4;
+		case D_META: return 512; case D_LL: return 24832; case D_PK: return 256;
 		case D_P1: case D_P3: case D_P5: return P16_CAP * 2; case D_P6: return (size_t)P6_CAP * 4;
 		case D_MARKS: return 2 * DQ; case D_A: case D_B: return 8 * DQ + 8192;
 		case D_CA: case D_CB: return 2 * (2 * DQ + 4096); case D_YB: return 4 * DQ; default: return 2 * DQ;
@@ -380,14 +380,6 @@ __global__ __launch_bounds__(256) void k_dec_parse(DecWs ws)
 	if (sm.status) { if (!tid) *gm = sm; return; }
 	const int q = sm.q;
 
-	/* packets -> aligned little-endian words, two zero words behind each part */
-	uint32_t *pk = ws.buf<uint32_t>(D_PK, img);
-	for (int w = tid; w < sm.data2 + 8; w += 256) {
-		uint32_t v = 0;
-		if (w < sm.data2) { const uint8_t *p = f + sm.o_packet1 + 4u * (uint32_t)w; v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-		pk[w] = v;
-	}
-
 	/* the byte-serial side streams: each wavefront stages its stream in LDS, then one lane walks it */
 	uint16_t *p1 = ws.buf<uint16_t>(D_P1, img), *p3 = ws.buf<uint16_t>(D_P3, img), *p5 = ws.buf<uint16_t>(D_P5, img);
 	uint32_t *p6 = ws.buf<uint32_t>(D_P6, img);
@@ -469,17 +461,46 @@ __constant__ VlcRun k_runs[26] = {
 };
 
 struct Bits {
-	const uint32_t *w; int nwords; int at;     /* next word to load */
-	uint64_t buf; int fill;                    /* `fill` valid bits at the top of buf */
-	DEV void init(const uint32_t *p, int n) { w = p; nwords = n; at = 0; buf = 0; fill = 0; }
-	DEV void need32() { if (fill <= 32) { const uint32_t v = at < nwords ? w[at] : 0u; at++; buf |= (uint64_t)v << (32 - fill); fill += 32; } }
+	uint32_t *lds; const uint8_t *g; int nwords, win, base; int at;   /* packet words [base, base + win) sit in LDS */
+	uint64_t buf; int fill;                                          /* `fill` valid bits at the top of buf */
+	DEV void init(uint32_t *l, const uint8_t *bytes, int n, int w) { lds = l; g = bytes; nwords = n; win = w; base = 0; at = 0; buf = 0; fill = 0; }
+	/* the walking lane moves the window on by itself (a stream longer than the window: noise-like images).  The common path must
+	 * not share a register with a global load: on gfx9 stores count in vmcnt, and a wait for such a load is a wait for every symbol
+	 * store still in flight (a memory round trip per refill). */
+	DEV void slide()
+	{
+		base += win;
+		for (int k = 0; k < win; k++) {
+			uint32_t v = 0;
+			if (base + k < nwords) { const uint8_t *p = g + 4 * (size_t)(base + k); v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+			lds[k] = v;
+		}
+	}
+	DEV void need32()
+	{
+		if (fill <= 32) {
+			if (at >= base + win) slide();
+			const uint32_t v = at < nwords ? lds[at - base] : 0u;
+			at++; buf |= (uint64_t)v << (32 - fill); fill += 32;
+		}
+	}
 	DEV unsigned peek(int n) { return (unsigned)(buf >> (64 - n)); }
 	DEV void skip(int n) { buf <<= n; fill -= n; }
 	DEV bool spent() const { return at > nwords + 3; }
 };
+/* all lanes: stage the first packet words of a stream (little-endian words at an unaligned file offset) */
+DEV void stage_words(const uint8_t *g, int nwords, int win, uint32_t *lds, int lane)
+{
+	const int n = nwords < win ? nwords : win;
+	for (int k = lane; k < n; k += 64) { const uint8_t *p = g + 4 * (size_t)k; lds[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+}
 
-/* lut[v] for the top 8 bits: (len << 8) | rank for code words of up to 8 bits, 0 otherwise */
-DEV void vlc_fill_lut(uint16_t *lut, int lane)
+/* Two-level code table.  lut[v], v = the next 8 bits: (len << 8) | rank for code words of up to 8 bits; 0x8000 | s when v is one of
+ * the sixteen 8-bit prefixes of longer words, s selecting a 64-entry sub-table indexed by the following 6 bits: (len << 10) | rank for
+ * words of 9..14 bits, 0 for the 17..20-bit tail (ranks >= 110), which is searched by its {first, length, count} runs. */
+DEV void vlc_fill_lut(uint16_t *lut, uint16_t *lut2, int lane)
 {
 	for (int v = lane; v < 256; v += 64) {
 		unsigned e = 0; int rank = 0;
@@ -488,27 +509,48 @@ DEV void vlc_fill_lut(uint16_t *lut, int lane)
 			if (c >= k_runs[r].first && c < k_runs[r].first + k_runs[r].count) { e = ((unsigned)k_runs[r].len << 8) | (unsigned)(rank + (int)(c - k_runs[r].first)); break; }
 			rank += k_runs[r].count;
 		}
+		if (!e) e = 0x8000u | (unsigned)(v < 0xe8 ? v - 0xe4 : v < 0xf8 ? 4 + v - 0xf4 : 8 + v - 0xf8);   /* the 16 prefixes no short word covers: e4-e7, f4-f7, f8-ff */
 		lut[v] = (uint16_t)e;
 	}
+	for (int idx = lane; idx < 16 * 64; idx += 64) {
+		const int s = idx >> 6;
+		const unsigned pre = (unsigned)(s < 4 ? 0xe4 + s : s < 8 ? 0xf4 + s - 4 : 0xf8 + s - 8);
+		const unsigned v14 = (pre << 6) | (unsigned)(idx & 63);
+		unsigned e = 0; int rank = 26;
+		for (int r = 9; r < 21; r++) {
+			const unsigned c = v14 >> (14 - k_runs[r].len);
+			if (c >= k_runs[r].first && c < k_runs[r].first + k_runs[r].count) { e = ((unsigned)k_runs[r].len << 10) | (unsigned)(rank + (int)(c - k_runs[r].first)); break; }
+			rank += k_runs[r].count;
+		}
+		lut2[idx] = (uint16_t)e;
+	}
 }
-DEV int vlc_next(Bits &b, const uint16_t *lut)
+/* next code word -> rank */
+DEV int vlc_next(Bits &b, const uint16_t *lut, const uint16_t *lut2)
 {
 	b.need32();
 	const unsigned look = b.peek(20);
 	const unsigned e = lut[look >> 12];
-	if (e) { b.skip((int)(e >> 8)); return (int)(e & 255u); }
-	int rank = 26;
-	for (int r = 9; r < 26; r++) {
-		const unsigned c = look >> (20 - k_runs[r].len);
-		if (c >= k_runs[r].first && c < k_runs[r].first + k_runs[r].count) { b.skip(k_runs[r].len); return rank + (int)(c - k_runs[r].first); }
-		rank += k_runs[r].count;
+	if (!(e & 0x8000u)) { b.skip((int)(e >> 8)); return (int)(e & 255u); }
+	{
+		const unsigned e2 = lut2[(e & 15u) * 64 + ((look >> 6) & 63u)];
+		if (e2) { b.skip((int)(e2 >> 10)); return (int)(e2 & 1023u); }
+		/* the 17..20-bit tail, ranks 110..289: five runs of consecutive words, compared as immediates (a table in constant memory costs a
+		 * memory round trip per probe on the one lane that walks) */
+		unsigned d;
+		if ((d = (look >> 3) - 0x1f0c0u) < 64u) { b.skip(17); return 110 + (int)d; }
+		if ((d = (look >> 3) - 0x1f8c0u) < 46u) { b.skip(17); return 174 + (int)d; }
+		if ((d = (look >> 2) - 0x3f1dcu) < 12u) { b.skip(18); return 220 + (int)d; }
+		if ((d = (look >> 1) - 0x7e3d0u) < 38u) { b.skip(19); return 232 + (int)d; }
+		if ((d = look - 0xfc7ecu) < 20u) { b.skip(20); return 270 + (int)d; }
 	}
 	return -1;
 }
 
-/* books, compress_pixel.c:86-117 / :456-478: entry = (run length << 8) | symbol; one lane, LDS scratch */
-DEV int build_book(const uint8_t *raw, int raw_len, bool chroma, int tree_end, uint16_t *book, uint8_t *flat, uint8_t *inter)
+/* books, compress_pixel.c:86-117 / :456-478: entry = (run length << 8) | symbol, 354 entries (ranks 0..353); one lane, scr = 1440 bytes of LDS scratch */
+DEV int build_book_small(const uint8_t *raw, int raw_len, bool chroma, int tree_end, uint16_t *book, uint8_t *scr)
 {
+	uint8_t *flat = scr, *inter = scr + 720;
 	const int rep = chroma ? 128 : 3;
 	int e = 0, n = 0;
 	for (int i = 0; i < 720; i++) { flat[i] = 0; inter[i] = 0; }
@@ -522,15 +564,18 @@ DEV int build_book(const uint8_t *raw, int raw_len, bool chroma, int tree_end, u
 	for (int i = 0; i < e; i += 2) inter[i] = flat[j++];
 	for (int i = 1; i < e; i += 2) inter[i] = flat[j++];
 	for (int i = 0; i < e; i++) {
+		uint16_t v;
 		if (!chroma) {
-			if (inter[i] == 3) { book[n++] = (uint16_t)((inter[i + 1] << 8) | 128); i++; }
-			else book[n++] = (uint16_t)(256 | inter[i]);
+			if (inter[i] == 3) { v = (uint16_t)((inter[i + 1] << 8) | 128); i++; }
+			else v = (uint16_t)(256 | inter[i]);
 		} else {
-			if (!(inter[i] & 1)) { book[n++] = (uint16_t)((inter[i + 1] << 8) | inter[i]); i++; }
-			else book[n++] = (uint16_t)(256 | (inter[i] & 0xfe));
+			if (!(inter[i] & 1)) { v = (uint16_t)((inter[i + 1] << 8) | inter[i]); i++; }
+			else v = (uint16_t)(256 | (inter[i] & 0xfe));
 		}
+		if (n < 354) book[n] = v;
+		n++;
 	}
-	for (int i = n; i < 720; i++) book[i] = 0;
+	for (int i = n; i < 354; i++) book[i] = 0;
 	return n;
 }
 
@@ -549,72 +594,103 @@ DEV int plain_level(int word)
 	return word > 128 ? word - 125 : word - 131;
 }
 
-/* where stream position e of the luma scan lives in the plane (strips of 4 columns, serpentine; nhw_decoder.c:71-91) */
-DEV int luma_cell(int e)
-{
-	const int k = e >> 11, within = e & 2047, rp = within >> 3, idx = within & 7;
-	return (2 * rp + (idx >> 2)) * DW + 4 * k + ((idx & 4) ? 7 - idx : idx);
-}
-/* chroma: position m of one component's half of the interleaved scan (strips of 8 columns; :904-932) */
-DEV int chroma_cell(int m)
-{
-	const int k = m >> 11, within = m & 2047, rp = within >> 4, idx = within & 15;
-	return (2 * rp + (idx >> 3)) * DH + 8 * k + ((idx & 8) ? 15 - idx : (idx & 7));
-}
-
-struct Hist {                      /* the five stream values before position e (zero before the start) */
-	int h1, h2, h3, h4, h5;
-	DEV void push(int v) { h5 = h4; h4 = h3; h3 = h2; h2 = h1; h1 = v; }
-	DEV void zeros(int n) { if (n >= 5) { h1 = h2 = h3 = h4 = h5 = 0; } else for (int i = 0; i < n; i++) push(0); }
+struct SelBits {                       /* bit k of a byte string, bytes [base, base + nwin) in LDS; reads go forward only */
+	uint8_t *win; const uint8_t *g; int nwin, nbytes, base;
+	DEV void slide(int at) { base = at; for (int k = 0; k < nwin; k++) win[k] = base + k < nbytes ? g[base + k] : 0; }
+	DEV int bit(int k)
+	{
+		const int at = k >> 3;
+		if (at >= nbytes) return 0;
+		if (at >= base + nwin) slide(at);
+		return (win[at - base] >> (7 - (k & 7))) & 1;
+	}
 };
 
+struct Hist {                      /* which of the five stream values before position e are non-zero (bit k-1: e-k); zero before the start */
+	unsigned nz;
+	DEV void push(int v) { nz = ((nz << 1) | (v != 0 ? 1u : 0u)) & 31u; }
+	DEV void zeros(int n) { nz = n >= 5 ? 0u : (nz << n) & 31u; }
+	DEV bool z(int k) const { return !((nz >> (k - 1)) & 1u); }
+};
+
+/* The walk over a prefix-coded stream is serial, and a wavefront that runs one walk on one lane still pays for 64.  So a
+ * wavefront runs VLC_K walks side by side, one image per group of 64 / VLC_K lanes: the group stages its packet words and fills
+ * its tables together, then its first lane walks.  Wave 0 of a workgroup: the luma streams of VLC_K images; wave 1: their
+ * chroma streams. */
 __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 {
-	__shared__ uint16_t lut[2][256];
-	__shared__ uint16_t book[2][720];
-	__shared__ uint8_t scratch[2][1440];
-	const int img = blockIdx.x, part = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
-	if (m->status) return;
-	const uint8_t *f = ws.blob + ws.blob_off[img];
-	vlc_fill_lut(lut[part], lane);
-	if (lane) return;
+	__shared__ uint16_t lut[256], lut2[16 * 64];
+	__shared__ uint16_t book[2][VLC_K][354];
+	__shared__ int16_t level[VLC_K][354];                           /* luma only: the value of an ordinary symbol, per rank */
+	__shared__ __attribute__((aligned(16))) uint32_t pkw0[VLC_K][VLC_WIN0], pkw1[VLC_K][VLC_WIN1];
+	__shared__ uint8_t selw[VLC_K][SEL1_WIN + SEL2_WIN];            /* the sign bits of the folded +-8 symbols (nhw_select_word1/2), luma only */
+	const int part = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int GL = 64 / VLC_K, slot = lane / GL, gl = lane % GL;       /* lanes per image, my image, my lane within its group */
+	const int img = blockIdx.x * VLC_K + slot;
+	if (!part) vlc_fill_lut(lut, lut2, lane);
+	const bool have = img < ws.n;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, have ? img : 0);
+	const bool on = have && !m->status;
+	const uint8_t *f = ws.blob + ws.blob_off[have ? img : 0];
+	uint32_t *pk = part ? pkw1[slot] : pkw0[slot];
+	const int nwords = !on ? 0 : part ? m->data2 - m->data1 : m->data1, win = part ? VLC_WIN1 : VLC_WIN0;
+	if (on && !gl) {
+		/* the code book first, with the packet window as scratch space */
+		uint8_t *scr = (uint8_t *)pk;                          /* 1440 bytes: both windows are at least that large */
+		uint16_t *bk = book[part][slot];
+		build_book_small(part ? f + m->o_book2 : f + m->o_book1, part ? m->book2_len : m->book1_len, part != 0, m->tree_end, bk, scr);
+	}
+	__syncthreads();
+	if (on) {
+		if (!part) for (int r = gl; r < 354; r += GL) level[slot][r] = (int16_t)plain_level(book[0][slot][r] & 255);
+		const uint8_t *g = f + (part ? m->o_packet2 : m->o_packet1);
+		const int nst = nwords < win ? nwords : win;
+		for (int k = gl; k < nst; k += GL) { const uint8_t *p = g + 4 * (size_t)k; pk[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+		if (!part) {
+			for (int k = gl; k < SEL1_WIN && k < m->select1; k += GL) selw[slot][k] = f[m->o_sel1 + k];
+			for (int k = gl; k < SEL2_WIN && k < m->select2; k += GL) selw[slot][SEL1_WIN + k] = f[m->o_sel2 + k];
+		}
+	}
+	__syncthreads();
+	if (!on || gl) return;
+	const uint16_t *bk = book[part][slot];
+	const int16_t *lv = level[slot];
 	int bad = 0;
 	if (!part) {
 		/* retrieve_pixel_Y_comp, compress_pixel.c:49-444 */
-		build_book(f + m->o_book1, m->book1_len, false, 0, book[0], scratch[0], scratch[0] + 720);
-		int16_t *a = plane_a(ws, img);
+		int16_t *a = plane_b(ws, img);                          /* the symbols in stream order; k_dec_unzig puts them in place */
 		const uint8_t *s1 = f + m->o_sel1, *s2 = f + m->o_sel2;
-		Bits b; b.init(ws.buf<uint32_t>(D_PK, img), m->data1);
+		Bits b; b.init(pk, f + m->o_packet1, m->data1, VLC_WIN0);
 		const bool zoned = m->res_high < 4;
+		SelBits sb1 = { selw[slot], s1, SEL1_WIN, m->select1, 0 }, sb2 = { selw[slot] + SEL1_WIN, s2, SEL2_WIN, m->select2, 0 };
 		const int limit = 4 * DQ - 1;
 		int e = 0, mem = 0, mem2 = 0, ac1 = 0, run_over = -257, t = 0, t2 = 0;
-		Hist h = { 0, 0, 0, 0, 0 };
-#define PUT(v) do { const int v_ = (v); if (e < 4 * DQ) a[luma_cell(e)] = (int16_t)v_; h.push(v_); e++; } while (0)
+		Hist h = { 0u };
+#define PUT(v) do { const int v_ = (v); if (e < 4 * DQ) a[e] = (int16_t)v_; h.push(v_); e++; } while (0)
 		while (e < limit) {
 			int rank;
 			if (b.spent()) { bad = 1; break; }
 			b.need32();
 			if (zoned && b.peek(9) == 1) { b.skip(9); b.need32(); rank = 110 + (int)b.peek(6); b.skip(6); }
 			else {
-				rank = vlc_next(b, lut[0]);
+				rank = vlc_next(b, lut, lut2);
 				if (rank < 0) { bad = 1; break; }
 				if (zoned && rank >= 110) rank += 64;
 			}
-			const int word = book[0][rank] & 255, rle = book[0][rank] >> 8;
+			const int word = bk[rank] & 255, rle = bk[rank] >> 8;
 			if (word == 128) {
 				int put = 0, neg = 0;
 				mem++;
 				if (mem2 == 1) {
-					if ((e >= 5 && !h.h2 && !h.h3 && !h.h4 && !h.h5) || (rle >= 4 && !h.h2)) { put = 1; neg = !bit_of(s2, m->select2, t2++); }
+					if ((e >= 5 && h.z(2) && h.z(3) && h.z(4) && h.z(5)) || (rle >= 4 && h.z(2))) { put = 1; neg = !sb2.bit(t2++); }
 					mem2 = 0;
 				}
 				else {
-					const bool room = rle >= 4 && e > 0 && !h.h1 && !ac1 && (e + rle - 257) >= run_over;
+					const bool room = rle >= 4 && e > 0 && h.z(1) && !ac1 && (e + rle - 257) >= run_over;
 					if (mem == 2 && !ac1) {
-						if ((e >= 4 && !h.h1 && !h.h2 && !h.h3 && !h.h4 && (e + rle - 257) >= run_over) || room) { put = 1; neg = bit_of(s1, m->select1, t++); mem = 1; }
+						if ((e >= 4 && h.z(1) && h.z(2) && h.z(3) && h.z(4) && (e + rle - 257) >= run_over) || room) { put = 1; neg = sb1.bit(t++); mem = 1; }
 					}
-					else if (room) { put = 1; neg = bit_of(s1, m->select1, t++); mem = 1; }
+					else if (room) { put = 1; neg = sb1.bit(t++); mem = 1; }
 				}
 				if (put) PUT(neg ? -11 : 11);
 				if (rle == 254) { ac1 = 1; mem = 0; run_over = e; } else ac1 = 0;
@@ -622,7 +698,8 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 			}
 			else {
 				mem = 0; mem2 = 0; ac1 = 0;
-				switch (word) {
+				if (word < 120 || word > 136) PUT(lv[rank]);
+				else switch (word) {
 				case 136: PUT(11); mem2 = 1; break;
 				case 120: PUT(-11); mem2 = 1; break;
 				case 132: PUT(11); e += 3; h.zeros(3); PUT(11); break;
@@ -637,7 +714,7 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 				case 122: PUT(1011); break;
 				case 124: PUT(11); break;
 				case 123: PUT(-11); break;
-				default: PUT(plain_level(word)); break;
+				default: PUT(lv[rank]); break;
 				}
 			}
 		}
@@ -645,25 +722,67 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 	}
 	else {
 		/* retrieve_pixel_UV_comp, :446-640: U on even, V on odd stream positions */
-		build_book(f + m->o_book2, m->book2_len, true, m->tree_end, book[1], scratch[1], scratch[1] + 720);
-		int16_t *cu = plane_ca(ws, img, 0), *cv = plane_ca(ws, img, 1);
-		Bits b; b.init(ws.buf<uint32_t>(D_PK, img) + m->data1, m->data2 - m->data1);
+		int16_t *cs = plane_cb(ws, img, 0);                     /* U and V interleaved, stream order (the two chroma planes of D_CB are one buffer) */
+		Bits b; b.init(pk, f + m->o_packet2, m->data2 - m->data1, VLC_WIN1);
 		const int limit = 2 * DQ - 2;
 		int e = 0;
 		while (e < limit) {
 			if (b.spent()) { bad = 1; break; }
-			const int rank = vlc_next(b, lut[1]);
+			const int rank = vlc_next(b, lut, lut2);
 			if (rank < 0) { bad = 1; break; }
-			const int word = book[1][rank] & 255;
-			if (word == 128) { e += book[1][rank] >> 8; continue; }
+			const int word = bk[rank] & 255;
+			if (word == 128) { e += bk[rank] >> 8; continue; }
 			int v;
 			if (word == 124) v = 5005; else if (word == 126) v = 5006; else if (word == 122) v = 5003; else if (word == 130) v = 5004;
 			else v = plain_level(word);
-			if (e < 2 * DQ) ((e & 1) ? cv : cu)[chroma_cell(e >> 1)] = (int16_t)v;
+			if (e < 2 * DQ) cs[e] = (int16_t)v;
 			e++;
 		}
 	}
 	if (bad) atomicExch(&ws.buf<DecMeta>(D_META, img)->status, (int)NHW_E_FORMAT);
+}
+
+/* ---------------------------------------------------------------------------------------------- un-zig-zag
+ * nhw_decoder.c:71-91 (luma: strips of 4 columns, serpentine down the rows) and :904-932 / :1192-1220 (chroma: strips of 8
+ * columns, U on even and V on odd stream positions).  The walk above stores in stream order, where neighbouring stores share
+ * a cache line; putting a symbol straight into its cell instead would touch a different row for every fourth symbol, and a row's
+ * line would be fetched and written back once per strip.  Here a workgroup moves a 64 x 64 tile through LDS: contiguous runs of
+ * the stream in, whole rows out.  blockIdx.x < 64: luma tiles; then 16 tiles that each do U and V. */
+__global__ __launch_bounds__(256) void k_dec_unzig(DecWs ws)
+{
+	__shared__ int16_t tile[2][64][66];
+	const int img = blockIdx.y, tid = threadIdx.x;
+	if (ws.buf<DecMeta>(D_META, img)->status) return;
+	if (blockIdx.x < 64) {
+		const int cg = blockIdx.x & 7, rg = blockIdx.x >> 3;
+		const int16_t *sb = plane_b(ws, img);
+		int16_t *a = plane_a(ws, img);
+		const int s = tid >> 4, j = tid & 15;                       /* strip within the tile, 16 symbols of its 256 */
+		const int16_t *src = sb + (size_t)(cg * 16 + s) * 2048 + rg * 256 + 16 * j;
+		for (int k = 0; k < 16; k++) {
+			const int w = 16 * j + k, rp = w >> 3, idx = w & 7;
+			tile[0][2 * rp + (idx >> 2)][4 * s + ((idx & 4) ? 7 - idx : idx)] = src[k];
+		}
+		__syncthreads();
+		const int row = tid >> 2, c0 = (tid & 3) * 16;
+		int16_t *dst = a + (size_t)(rg * 64 + row) * DW + cg * 64 + c0;
+		for (int k = 0; k < 16; k++) dst[k] = tile[0][row][c0 + k];
+	} else {
+		const int b = blockIdx.x - 64, cg = b & 3, rg = b >> 2;
+		const int16_t *cs = plane_cb(ws, img, 0);
+		const int s = tid >> 5, j = tid & 31;                       /* strip within the tile (8 of 8 columns), 32 of its 1024 interleaved symbols */
+		const int16_t *src = cs + 2 * ((size_t)(cg * 8 + s) * 2048 + rg * 512) + 32 * j;
+		for (int k = 0; k < 32; k++) {
+			const int w = (32 * j + k) >> 1, comp = k & 1, rp = w >> 4, idx = w & 15;
+			tile[comp][2 * rp + (idx >> 3)][8 * s + ((idx & 8) ? 15 - idx : (idx & 7))] = src[k];
+		}
+		__syncthreads();
+		const int row = tid >> 2, c0 = (tid & 3) * 16;
+		for (int comp = 0; comp < 2; comp++) {
+			int16_t *dst = plane_ca(ws, img, comp) + (size_t)(rg * 64 + row) * DH + cg * 64 + c0;
+			for (int k = 0; k < 16; k++) dst[k] = tile[comp][row][c0 + k];
+		}
+	}
 }
 
 /* ---------------------------------------------------------------------------------------------- expand (d3)
@@ -1319,12 +1438,13 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	ws.n = n; ws.blob = (const uint8_t *)d_nhw; ws.blob_off = d_off; ws.blob_len = d_len;
 	int stage = 0;
 #define STAGE_END() do { if (d->stop_after && ++stage >= d->stop_after) goto done; } while (0)
-	/* coefficient planes start from zero (the reference's calloc, nhw_decoder.c:2029, :894) */
-	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_A], 0, k_dec_bytes[D_A] * (size_t)n, s));
-	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_CA], 0, k_dec_bytes[D_CA] * (size_t)n, s));
+	/* the symbol streams start from zero (the reference's calloc, nhw_decoder.c:2029, :894): a zero run is a skip */
+	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_B], 0, k_dec_bytes[D_B] * (size_t)n, s));
+	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_CB], 0, k_dec_bytes[D_CB] * (size_t)n, s));
 	k_dec_parse<<<n, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 1 */
-	k_dec_vlc<<<n, 128, 0, s>>>(ws);
+	k_dec_vlc<<<(n + VLC_K - 1) / VLC_K, 128, 0, s>>>(ws);
+	k_dec_unzig<<<dim3(80, n), 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 2 */
 	k_dec_expand<<<(n + 3) / 4, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 3 */

@@ -302,8 +302,10 @@ static int vlc_luma(const nhw_file *f, int16_t *out)
 	memset(book, 0, sizeof book);
 	nbook = build_book(f->book1, f->book1_len, 0, 0, book);
 	(void)nbook;
+	int nsym = 0, nrun = 0, nput = 0;
 	while (e < limit) {
 		int rank, word, rle;
+		nsym++;
 		if (b.bit >= ((size_t)f->data1 + 2) * 32) return -1;
 		if (zoned && peek_bits(&b, 9) == 1) { b.bit += 9; rank = 110 + (int)peek_bits(&b, 6); b.bit += 6; }     /* :127-142 */
 		else {
@@ -327,6 +329,7 @@ static int vlc_luma(const nhw_file *f, int16_t *out)
 				}
 				else if (room) { put = 1; neg = bit_of(f->sel1, f->select1, t++); mem = 1; }
 			}
+			nrun++; nput += put;
 			if (put) out[e++] = (int16_t)(neg ? -11 : 11);
 			if (rle == 254) { ac1 = 1; mem = 0; run_over = e; } else ac1 = 0;
 			e += rle;
@@ -352,6 +355,7 @@ static int vlc_luma(const nhw_file *f, int16_t *out)
 			}
 		}
 	}
+	{ int stats[4] = { nsym, nrun, nput, (int)b.bit }; probe(90, stats, sizeof stats); }
 	return 0;
 }
 
