@@ -12,6 +12,7 @@ region; `cpu_baseline` times the reference encoder (oracle/_ref, kind "reference
 absent, the plain-C port (oracle/, kind "port") on the host cores over a bounded sample.
 """
 import argparse
+import math
 import json
 import os
 import sys
@@ -77,6 +78,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="images per GPU per step")
     ap.add_argument("--quality", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (BASELINE config 5) reported next to the encode metric")
     args = ap.parse_args()
 
     import torch
@@ -130,6 +132,37 @@ def main():
     chk = int((sizes.to(torch.int64) * torch.arange(1, batch + 1, device=dev)).sum().item() % (1 << 61))
     gathered = gather_summaries(dist, dev, nbytes, chk, ok)
 
+    # BASELINE config 5 beside the headline metric: the batch just encoded goes back through the decoder, HBM to HBM
+    # (the encoder's output arena is the decoder's input arena).  Timed after, and apart from, the encode region.
+    dec_line = None
+    if not args.no_decode:
+        dec = nhwcodec_amd.Decoder(local_rank, max_batch=batch)
+        offs = torch.arange(batch, dtype=torch.int64, device=dev) * nhwcodec_amd.OUT_STRIDE
+        pix = torch.empty((batch, 512, 512, 3), dtype=torch.uint8, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            for _ in range(max(1, args.warmup)):
+                dec.decode_device(out[0], offs, sizes, pix)
+            torch.cuda.synchronize()
+            if dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                _, dst, dq = dec.decode_device(out[0], offs, sizes, pix)
+            torch.cuda.synchronize()
+            if dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ddt = max_over_ranks(dist, dev, time.perf_counter() - t1)
+        dec_ok = int((dst == 0).sum().item())
+        err = (pix[:64].float() - bgr[:64].float()).pow(2).mean().item()
+        dec_line = {"metric": "decode Mpixels/s (512x512 .nhw batch -> BGR24, BASELINE config 5)", "value": round(batch * world * args.steps * MPIX_PER_IMAGE / ddt, 2),
+                    "unit": "Mpixels/s", "ms_per_step": round(ddt / args.steps * 1e3, 3), "files_ok_rank0": dec_ok,
+                    "psnr_db_first_64": round(10 * math.log10(255.0 ** 2 / max(err, 1e-9)), 2),
+                    "workload": f"the {batch} .nhw files per GPU this run just encoded (-q{q}), decoder arena = encoder arena in HBM"}
+        dec.close()
+
     if rank == 0:
         total_images = batch * world * args.steps
         value = total_images * MPIX_PER_IMAGE / dt
@@ -155,6 +188,8 @@ def main():
                          "entropy+container": round(tim.entropy_ms, 3), "total": round(tim.total_ms, 3)},
             "images_ok": [int(g[2]) for g in gathered], "bytes_out": [int(g[0]) for g in gathered],
         }
+        if dec_line:
+            line["decode"] = dec_line
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(q)
         print(json.dumps(line), flush=True)

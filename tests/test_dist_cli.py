@@ -129,3 +129,49 @@ def test_cli_end_to_end_files(cli, oracle, tmp_path):
     assert _run(cli, "-q21", "--batch", str(d))[0] == 0
     for s in (1, 2, 3):
         assert (d / f"i{s}.nhw").read_bytes() == oracle.encode(oracle.synth(s), 21)
+
+
+# ---------------------------------------------------------------- nhw-dec
+DEC_CLI = os.path.join(ROOT, "tools", "nhw-dec")
+REF_DEC_CLI = os.path.join(ROOT, "oracle", "_ref", "nhw-dec")
+
+
+@pytest.fixture(scope="module")
+def dec_cli():
+    if not os.path.exists(DEC_CLI):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools")])
+    return DEC_CLI
+
+
+def test_dec_cli_usage_matches_reference_binary(dec_cli):
+    if not os.path.exists(REF_DEC_CLI):
+        pytest.skip("reference binary not built")
+    for args in ([], ["only_one.nhw"]):
+        rc, out, err = _run(dec_cli, *args)
+        rrc, rout, rerr = _run(REF_DEC_CLI, *args)
+        assert rc == rrc == 0
+        assert out.splitlines()[:5] == rout.splitlines()[:5] and err == rerr
+
+
+@pytest.mark.gpu
+def test_dec_cli_end_to_end_files(dec_cli, oracle, tmp_path):
+    """nhw-dec file in -> BMP out equals the oracle's BMP (= the reference decoder's, by the golden digests); batch mode; a foreign file"""
+    import hashlib
+    import json
+    import shutil
+    gold = os.path.join(ROOT, "tests", "golden", "dec")
+    man = json.load(open(os.path.join(gold, "manifest.json")))
+    for name in ("q20_0.nhw", "q07_0.nhw", "q23_0.nhw"):
+        shutil.copy(os.path.join(gold, name), tmp_path / name)
+        assert _run(dec_cli, str(tmp_path / name), str(tmp_path / (name + ".bmp")))[0] == 0
+        assert hashlib.sha256((tmp_path / (name + ".bmp")).read_bytes()).hexdigest() == man[name]["bmp_sha256"]
+    d = tmp_path / "dir"; d.mkdir()
+    names = ["q01_0.nhw", "q10_0.nhw", "q16_4.nhw", "q20_blocks.nhw"]
+    for n in names:
+        shutil.copy(os.path.join(gold, n), d / n)
+    assert _run(dec_cli, "--batch", str(d))[0] == 0
+    for n in names:
+        assert hashlib.sha256((d / (n[:-4] + ".bmp")).read_bytes()).hexdigest() == man[n]["bmp_sha256"]
+    (tmp_path / "junk.nhw").write_bytes(b"BM" + bytes(500))
+    rc, out, _ = _run(dec_cli, str(tmp_path / "junk.nhw"), str(tmp_path / "junk.bmp"))
+    assert rc == 3 and "Not an .nhw file" in out and not (tmp_path / "junk.bmp").exists()

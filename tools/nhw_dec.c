@@ -1,0 +1,113 @@
+/*
+ * nhw-dec -- command-line decoder over libnhwhip.so (include/nhw_hip.h).
+ *
+ * Same interface as the reference CLI (rcanut/nhwcodec decoder/nhw_decoder_cli.c:70-118):
+ *     nhw-dec image.nhw image.bmp          (with fewer arguments: the usage text, exit 0)
+ * The BMP is the 54-byte header of decoder/nhw_decoder_cli.c:61-65,293-312 followed by the pixel bytes in the order
+ * write_image_bmp (:108-291) writes them.  Exit codes: 0 ok, 1 cannot read / write a file (the reference prints and
+ * carries on into undefined behaviour), 3 not an .nhw file (reference: "Not an .nhw file", exit(-1)).
+ * Extension: --batch <dir> decodes every *.nhw of a directory to <name>.bmp in one GPU batch.
+ */
+#include <dirent.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/nhw_hip.h"
+
+#define PROGRAM "nhw-dec"
+
+static void show_usage(void)
+{
+	fprintf(stdout,
+	"Usage: %s <image.nhw> <image.bmp>\n"
+	"Convert image: nwh to bmp\n"
+	" (with a bitmap color 512x512 image)\n"
+	"\n"
+	"  example: nhw-dec image.nhw image.bmp\n"
+	"  batch:   nhw-dec --batch <directory of .nhw files>\n",
+	PROGRAM);
+}
+
+static int read_file(const char *path, uint8_t **buf, size_t *len)
+{
+	FILE *f = fopen(path, "rb");
+	long n;
+	if (!f) { printf("\nCould not open file\n"); return 1; }
+	fseek(f, 0, SEEK_END); n = ftell(f); fseek(f, 0, SEEK_SET);
+	*buf = (uint8_t *)malloc((size_t)n + 1);
+	if (!*buf || fread(*buf, 1, (size_t)n, f) != (size_t)n) { fclose(f); return 1; }
+	fclose(f);
+	*len = (size_t)n;
+	return 0;
+}
+
+static int write_bmp(const char *path, const uint8_t *pixels)
+{
+	uint8_t hdr[54];
+	FILE *f = fopen(path, "wb");
+	if (!f) { printf("Failed to open output decompressed .bmp file %s\n", path); return 1; }
+	nhw_dec_bmp_header(hdr);
+	fwrite(hdr, 54, 1, f);
+	fwrite(pixels, NHW_IMG_BYTES, 1, f);
+	fclose(f);
+	return 0;
+}
+
+static int decode_files(char **in, char **out, int n)
+{
+	nhw_dec *d = NULL;
+	uint8_t *blob = NULL, *pix;
+	uint64_t *off = (uint64_t *)calloc((size_t)n + 1, sizeof *off);
+	int32_t *status = (int32_t *)calloc((size_t)n, sizeof *status);
+	size_t total = 0;
+	int i, rc = 0;
+	for (i = 0; i < n; i++) {
+		uint8_t *b; size_t len;
+		if (read_file(in[i], &b, &len)) return 1;
+		blob = (uint8_t *)realloc(blob, total + len + 16);
+		memcpy(blob + total, b, len); free(b);
+		off[i] = total; total += len;
+	}
+	off[n] = total;
+	pix = (uint8_t *)malloc((size_t)n * NHW_IMG_BYTES);
+	if (nhw_dec_create(0, n, &d) || nhw_dec_batch(d, blob, off, n, pix, status, NULL)) {
+		fprintf(stderr, "%s: GPU decoder unavailable: %s\n", PROGRAM, nhw_dec_last_error());
+		return 2;
+	}
+	for (i = 0; i < n; i++) {
+		if (status[i]) { printf("\nNot an .nhw file"); if (n > 1) printf(": %s", in[i]); printf("\n"); rc = 3; continue; }
+		if (write_bmp(out[i], pix + (size_t)i * NHW_IMG_BYTES)) rc = rc ? rc : 1;
+	}
+	nhw_dec_destroy(d);
+	free(blob); free(pix); free(off); free(status);
+	return rc;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 3) { show_usage(); return 0; }
+	if (!strcmp(argv[1], "--batch")) {
+		DIR *dir = opendir(argv[2]);
+		struct dirent *e;
+		char **in = NULL, **out = NULL;
+		int n = 0, rc;
+		if (!dir) { printf("\nCould not open file\n"); return 1; }
+		while ((e = readdir(dir))) {
+			const size_t l = strlen(e->d_name);
+			if (l < 5 || strcmp(e->d_name + l - 4, ".nhw")) continue;
+			in = (char **)realloc(in, (size_t)(n + 1) * sizeof *in); out = (char **)realloc(out, (size_t)(n + 1) * sizeof *out);
+			in[n] = (char *)malloc(strlen(argv[2]) + l + 2); out[n] = (char *)malloc(strlen(argv[2]) + l + 2);
+			sprintf(in[n], "%s/%s", argv[2], e->d_name);
+			sprintf(out[n], "%s/%.*s.bmp", argv[2], (int)(l - 4), e->d_name);
+			n++;
+		}
+		closedir(dir);
+		if (!n) return 0;
+		rc = decode_files(in, out, n);
+		printf("%d file(s) decoded\n", n);
+		return rc;
+	}
+	return decode_files(&argv[1], &argv[2], 1);
+}
