@@ -613,133 +613,256 @@ struct Hist {                      /* which of the five stream values before pos
 	DEV bool z(int k) const { return !((nz >> (k - 1)) & 1u); }
 };
 
-/* The walk over a prefix-coded stream is serial, and a wavefront that runs one walk on one lane still pays for 64.  So a
- * wavefront runs VLC_K walks side by side, one image per group of 64 / VLC_K lanes: the group stages its packet words and fills
- * its tables together, then its first lane walks.  Wave 0 of a workgroup: the luma streams of VLC_K images; wave 1: their
- * chroma streams. */
+/* The prefix-code walk, in parallel (compress_pixel.c:49-444 luma, :446-640 chroma).
+ *
+ * Read serially, a stream costs about a microsecond per symbol on this machine: a lone lane of a lone wavefront, some 120
+ * dependent instructions per symbol.  Both halves of the walk are really short-memory chains:
+ *
+ *  A. Parsing.  Where a code word starts depends on all words before it -- but a prefix code re-synchronises within a few
+ *     words.  A chunk of 4096 bits is cut into 64 spans of 64 bits, one per lane.  Every lane parses its span from a guessed
+ *     start and reports where it left the span; that is the next lane's true start, so lanes whose start moved parse again,
+ *     until nothing moves (lane 0's start is known; in practice two or three rounds).  A last pass stores the ranks of the
+ *     chunk in order (prefix sum of the per-span counts).
+ *  B. Placing.  Luma only: the encoder folded isolated +-8 values into the zero runs around them, and the decoder re-inserts one
+ *     in front of a run when a handful of conditions on the recent past hold (mem, mem2, nhw_ac1, the five values before, the
+ *     distance to the last 254-run: compress_pixel.c:280-320).  That past is a 14-bit state; a lane takes one symbol, computes
+ *     its transition from a guessed entry state, passes the exit state to the right, and the chain is iterated to its fixed
+ *     point as in A.  Stream positions and the indices into the two sign-bit strings are then prefix sums.
+ *
+ * One workgroup per image: wave 0 the luma stream, wave 1 the chroma stream.  Symbols are stored in stream order (k_dec_unzig
+ * puts them in place). */
+enum { VCH_WORDS = 128, VCH_SYMS = 2048 + 64 };
+
+DEV unsigned peek20(const uint32_t *cw, int rel)
+{
+	const int w = rel >> 5, sh = rel & 31;
+	const uint64_t v = ((uint64_t)cw[w] << 32) | cw[w + 1];
+	return (unsigned)((v << sh) >> 44);
+}
+/* the code word at bit `rel` of the chunk: its length, and through `rank` its rank (after the zone shift), -1 if no word matches */
+DEV int code_at(const uint32_t *cw, int rel, bool zoned, const uint16_t *lut, const uint16_t *lut2, int &rank)
+{
+	const unsigned look = peek20(cw, rel);
+	if (zoned && (look >> 11) == 1u) { rank = 110 + (int)((look >> 5) & 63u); return 15; }      /* 000000001 + 6 bits (:127-142) */
+	int len, r;
+	const unsigned e = lut[look >> 12];
+	if (!(e & 0x8000u)) { len = (int)(e >> 8); r = (int)(e & 255u); }
+	else {
+		const unsigned e2 = lut2[(e & 15u) * 64 + ((look >> 6) & 63u)];
+		unsigned d;
+		if (e2) { len = (int)(e2 >> 10); r = (int)(e2 & 1023u); }
+		else if ((d = (look >> 3) - 0x1f0c0u) < 64u) { len = 17; r = 110 + (int)d; }
+		else if ((d = (look >> 3) - 0x1f8c0u) < 46u) { len = 17; r = 174 + (int)d; }
+		else if ((d = (look >> 2) - 0x3f1dcu) < 12u) { len = 18; r = 220 + (int)d; }
+		else if ((d = (look >> 1) - 0x7e3d0u) < 38u) { len = 19; r = 232 + (int)d; }
+		else if ((d = look - 0xfc7ecu) < 20u) { len = 20; r = 270 + (int)d; }
+		else { len = 20; r = -1; }
+	}
+	if (zoned && r >= 110) r += 64;                                  /* :277 */
+	rank = r;
+	return len;
+}
+
+/* A: ranks of the code words that start in chunk `c` of the stream, in order, into syms[]; returns their number.
+ * start0: bit offset (relative to the chunk) of the first word, updated to the one of the next chunk. */
+DEV int vlc_parse_chunk(const uint8_t *g, int nwords, int c, int &start0, bool zoned, const uint16_t *lut, const uint16_t *lut2,
+                        uint32_t *cw, uint16_t *syms, int lane, int &bad)
+{
+	for (int k = lane; k < VCH_WORDS + 2; k += 64) {
+		const int w = c * VCH_WORDS + k;
+		uint32_t v = 0;
+		if (w < nwords) { const uint8_t *p = g + 4 * (size_t)w; v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+		cw[k] = v;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	const int total_bits = (nwords - c * VCH_WORDS) * 32;           /* bits of the stream from the start of this chunk */
+	const int lo = 64 * lane, hi = min(64 * (lane + 1), total_bits);
+	int start = lane ? lo : start0, exitp = 0, cnt = 0;
+	for (;;) {
+		int pos = start, n = 0, rk;
+		while (pos < hi) { pos += code_at(cw, pos, zoned, lut, lut2, rk); n++; }
+		exitp = pos; cnt = n;
+		int nxt = __shfl_up(exitp, 1);
+		if (!lane) nxt = start0;
+		if (nxt < lo) nxt = lo;                                        /* (a span past the end of the stream: nothing starts in it) */
+		if (!__any(nxt != start)) break;
+		start = nxt;
+	}
+	int off = cnt;
+	for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(off, d); if (lane >= d) off += o; }
+	{
+		int pos = start, at = off - cnt, rk;
+		while (pos < hi) { pos += code_at(cw, pos, zoned, lut, lut2, rk); if (rk < 0) { bad = 1; rk = 0; } syms[at++] = (uint16_t)rk; }
+	}
+	start0 = __shfl(exitp, 63) - 64 * 64;
+	if (start0 < 0) start0 = 0;
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	return __shfl(off, 63);
+}
+
+/* B: the luma placement state.  bits 0-1 mem (3 = three or more), 2 mem2, 3 nhw_ac1, 4-8 which of the five values before are
+ * non-zero (bit 4: the last one), 9-10 values written since the last 254-run (3 = three or more, or no such run yet), 11-13 min(e, 5) */
+#define ST_NEUTRAL ((3u << 9) | (5u << 11) | (31u << 4))
+DEV unsigned luma_step(unsigned s, bool is_run, int rle, bool lit5, bool mark, int &put, int &which)
+{
+	unsigned mem = s & 3u, mem2 = (s >> 2) & 1u, ac1 = (s >> 3) & 1u, hist = (s >> 4) & 31u, btw = (s >> 9) & 3u, e5 = (s >> 11) & 7u;
+	put = 0; which = 0;
+	int adv;
+	if (is_run) {
+		const bool z1 = !(hist & 1u), z2 = !(hist & 2u), z3 = !(hist & 4u), z4 = !(hist & 8u), z5 = !(hist & 16u);
+		const bool far = (int)btw + rle >= 3;
+		mem = mem < 3u ? mem + 1u : 3u;
+		if (mem2) {
+			if ((e5 >= 5u && z2 && z3 && z4 && z5) || (rle >= 4 && z2)) { put = 1; which = 2; }
+			mem2 = 0;
+		} else {
+			const bool room = rle >= 4 && e5 > 0u && z1 && !ac1 && far;
+			if (mem == 2u && !ac1) { if ((e5 >= 4u && z1 && z2 && z3 && z4 && far) || room) { put = 1; which = 1; mem = 1; } }
+			else if (room) { put = 1; which = 1; mem = 1; }
+		}
+		if (put) hist = ((hist << 1) | 1u) & 31u;
+		adv = put + rle;
+		if (rle == 254) { ac1 = 1; mem = 0; btw = 0; } else { ac1 = 0; btw = min(3u, btw + (unsigned)adv); }
+		hist = rle >= 5 ? 0u : (hist << rle) & 31u;
+	} else {
+		mem = 0; mem2 = mark ? 1u : 0u; ac1 = 0;
+		adv = lit5 ? 5 : 1;
+		hist = lit5 ? 17u : ((hist << 1) | 1u) & 31u;
+		btw = min(3u, btw + (unsigned)adv);
+	}
+	e5 = min(5u, e5 + (unsigned)adv);
+	return mem | (mem2 << 2) | (ac1 << 3) | (hist << 4) | (btw << 9) | (e5 << 11);
+}
+DEV int luma_literal(int word, int lvl, int &second)                /* value of a non-run symbol (:324-386); `second`: the value four cells on, for 132..135 */
+{
+	second = 0;
+	switch (word) {
+	case 136: return 11;   case 120: return -11;
+	case 132: second = 11; return 11;   case 133: second = -11; return 11;
+	case 134: second = 11; return -11;  case 135: second = -11; return -11;
+	case 127: return 1008; case 129: return 1009; case 125: return 1006; case 126: return 1007;
+	case 121: return 1010; case 122: return 1011; case 124: return 11;   case 123: return -11;
+	default: return lvl;
+	}
+}
+
 __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 {
 	__shared__ uint16_t lut[256], lut2[16 * 64];
-	__shared__ uint16_t book[2][VLC_K][354];
-	__shared__ int16_t level[VLC_K][354];                           /* luma only: the value of an ordinary symbol, per rank */
-	__shared__ __attribute__((aligned(16))) uint32_t pkw0[VLC_K][VLC_WIN0], pkw1[VLC_K][VLC_WIN1];
-	__shared__ uint8_t selw[VLC_K][SEL1_WIN + SEL2_WIN];            /* the sign bits of the folded +-8 symbols (nhw_select_word1/2), luma only */
-	const int part = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int GL = 64 / VLC_K, slot = lane / GL, gl = lane % GL;       /* lanes per image, my image, my lane within its group */
-	const int img = blockIdx.x * VLC_K + slot;
+	__shared__ uint16_t book[2][354];
+	__shared__ int16_t level[2][354];
+	__shared__ __attribute__((aligned(16))) uint32_t cw[2][VCH_WORDS + 4];
+	__shared__ uint16_t syms[2][VCH_SYMS];
+	__shared__ __attribute__((aligned(16))) uint8_t scr[2][1440];
+	const int img = blockIdx.x, part = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status) return;
+	const uint8_t *f = ws.blob + ws.blob_off[img];
 	if (!part) vlc_fill_lut(lut, lut2, lane);
-	const bool have = img < ws.n;
-	const DecMeta *m = ws.buf<DecMeta>(D_META, have ? img : 0);
-	const bool on = have && !m->status;
-	const uint8_t *f = ws.blob + ws.blob_off[have ? img : 0];
-	uint32_t *pk = part ? pkw1[slot] : pkw0[slot];
-	const int nwords = !on ? 0 : part ? m->data2 - m->data1 : m->data1, win = part ? VLC_WIN1 : VLC_WIN0;
-	if (on && !gl) {
-		/* the code book first, with the packet window as scratch space */
-		uint8_t *scr = (uint8_t *)pk;                          /* 1440 bytes: both windows are at least that large */
-		uint16_t *bk = book[part][slot];
-		build_book_small(part ? f + m->o_book2 : f + m->o_book1, part ? m->book2_len : m->book1_len, part != 0, m->tree_end, bk, scr);
-	}
+	if (!lane) build_book_small(part ? f + m->o_book2 : f + m->o_book1, part ? m->book2_len : m->book1_len, part != 0, m->tree_end, book[part], scr[part]);
 	__syncthreads();
-	if (on) {
-		if (!part) for (int r = gl; r < 354; r += GL) level[slot][r] = (int16_t)plain_level(book[0][slot][r] & 255);
-		const uint8_t *g = f + (part ? m->o_packet2 : m->o_packet1);
-		const int nst = nwords < win ? nwords : win;
-		for (int k = gl; k < nst; k += GL) { const uint8_t *p = g + 4 * (size_t)k; pk[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-		if (!part) {
-			for (int k = gl; k < SEL1_WIN && k < m->select1; k += GL) selw[slot][k] = f[m->o_sel1 + k];
-			for (int k = gl; k < SEL2_WIN && k < m->select2; k += GL) selw[slot][SEL1_WIN + k] = f[m->o_sel2 + k];
-		}
-	}
-	__syncthreads();
-	if (!on || gl) return;
-	const uint16_t *bk = book[part][slot];
-	const int16_t *lv = level[slot];
-	int bad = 0;
+	for (int r = lane; r < 354; r += 64) level[part][r] = (int16_t)plain_level(book[part][r] & 255);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	const uint16_t *bk = book[part];
+	const int16_t *lv = level[part];
+	const uint8_t *g = f + (part ? m->o_packet2 : m->o_packet1);
+	const int nwords = part ? m->data2 - m->data1 : m->data1;
+	const int nchunks = (nwords + VCH_WORDS - 1) / VCH_WORDS + 1;       /* one more: zero bits behind the stream decode as words too, as in the reference */
+	int bad = 0, start0 = 0;
 	if (!part) {
-		/* retrieve_pixel_Y_comp, compress_pixel.c:49-444 */
-		int16_t *a = plane_b(ws, img);                          /* the symbols in stream order; k_dec_unzig puts them in place */
+		int16_t *a = plane_b(ws, img);                                /* stream order */
 		const uint8_t *s1 = f + m->o_sel1, *s2 = f + m->o_sel2;
-		Bits b; b.init(pk, f + m->o_packet1, m->data1, VLC_WIN0);
+		const int n1 = m->select1, n2 = m->select2;
 		const bool zoned = m->res_high < 4;
-		SelBits sb1 = { selw[slot], s1, SEL1_WIN, m->select1, 0 }, sb2 = { selw[slot] + SEL1_WIN, s2, SEL2_WIN, m->select2, 0 };
 		const int limit = 4 * DQ - 1;
-		int e = 0, mem = 0, mem2 = 0, ac1 = 0, run_over = -257, t = 0, t2 = 0;
-		Hist h = { 0u };
-#define PUT(v) do { const int v_ = (v); if (e < 4 * DQ) a[e] = (int16_t)v_; h.push(v_); e++; } while (0)
-		while (e < limit) {
-			int rank;
-			if (b.spent()) { bad = 1; break; }
-			b.need32();
-			if (zoned && b.peek(9) == 1) { b.skip(9); b.need32(); rank = 110 + (int)b.peek(6); b.skip(6); }
-			else {
-				rank = vlc_next(b, lut, lut2);
-				if (rank < 0) { bad = 1; break; }
-				if (zoned && rank >= 110) rank += 64;
-			}
-			const int word = bk[rank] & 255, rle = bk[rank] >> 8;
-			if (word == 128) {
-				int put = 0, neg = 0;
-				mem++;
-				if (mem2 == 1) {
-					if ((e >= 5 && h.z(2) && h.z(3) && h.z(4) && h.z(5)) || (rle >= 4 && h.z(2))) { put = 1; neg = !sb2.bit(t2++); }
-					mem2 = 0;
+		int e = 0, t1 = 0, t2 = 0;
+		unsigned carry = (0u) | (3u << 9);                            /* nothing before the start: mem 0, no 254-run yet, e = 0, history zero */
+		bool done = false;
+		for (int c = 0; c < nchunks + 64 && !done; c++) {
+			const int nsym = vlc_parse_chunk(g, nwords, c, start0, zoned, lut, lut2, cw[0], syms[0], lane, bad);
+			for (int base = 0; base < nsym && !done; base += 64) {
+				const bool have = base + lane < nsym;
+				const int rank = have ? syms[0][base + lane] : 0;
+				const int bkv = bk[rank], word = bkv & 255, rle = bkv >> 8;
+				const bool is_run = word == 128, lit5 = word >= 132 && word <= 135, mark = word == 136 || word == 120;
+				unsigned sin = lane ? ST_NEUTRAL : carry, sout;
+				int put, which;
+				for (;;) {
+					sout = luma_step(sin, is_run, rle, lit5, mark, put, which);
+					unsigned nxt = (unsigned)__shfl_up((int)sout, 1);
+					if (!lane) nxt = carry;
+					if (!__any(have && nxt != sin)) break;
+					sin = nxt;
 				}
-				else {
-					const bool room = rle >= 4 && e > 0 && h.z(1) && !ac1 && (e + rle - 257) >= run_over;
-					if (mem == 2 && !ac1) {
-						if ((e >= 4 && h.z(1) && h.z(2) && h.z(3) && h.z(4) && (e + rle - 257) >= run_over) || room) { put = 1; neg = sb1.bit(t++); mem = 1; }
+				const int adv = have ? put + (is_run ? rle : (lit5 ? 5 : 1)) : 0;
+				int pe = adv, p1 = have && put && which == 1 ? 1 : 0, p2 = have && put && which == 2 ? 1 : 0;
+				const int q1 = p1, q2 = p2;
+				for (int d = 1; d < 64; d <<= 1) {
+					const int oe = __shfl_up(pe, d), o1 = __shfl_up(p1, d), o2 = __shfl_up(p2, d);
+					if (lane >= d) { pe += oe; p1 += o1; p2 += o2; }
+				}
+				const int at = e + pe - adv;
+				const bool live = have && at < limit;                       /* the reference's loop test: a symbol is taken while e < limit */
+				if (live) {
+					int pos = at;
+					if (put) {
+						int neg;
+						if (which == 1) { const int k = t1 + p1 - q1; neg = (k >> 3) < n1 ? (s1[k >> 3] >> (7 - (k & 7))) & 1 : 0; }
+						else { const int k = t2 + p2 - q2; neg = !((k >> 3) < n2 ? (s2[k >> 3] >> (7 - (k & 7))) & 1 : 0); }
+						if (pos < 4 * DQ) a[pos] = (int16_t)(neg ? -11 : 11);
+						pos++;
 					}
-					else if (room) { put = 1; neg = sb1.bit(t++); mem = 1; }
+					if (!is_run) {
+						int second;
+						const int v = luma_literal(word, lv[rank], second);
+						if (pos < 4 * DQ) a[pos] = (int16_t)v;
+						if (lit5 && pos + 4 < 4 * DQ) a[pos + 4] = (int16_t)second;
+					}
 				}
-				if (put) PUT(neg ? -11 : 11);
-				if (rle == 254) { ac1 = 1; mem = 0; run_over = e; } else ac1 = 0;
-				e += rle; h.zeros(rle);
-			}
-			else {
-				mem = 0; mem2 = 0; ac1 = 0;
-				if (word < 120 || word > 136) PUT(lv[rank]);
-				else switch (word) {
-				case 136: PUT(11); mem2 = 1; break;
-				case 120: PUT(-11); mem2 = 1; break;
-				case 132: PUT(11); e += 3; h.zeros(3); PUT(11); break;
-				case 133: PUT(11); e += 3; h.zeros(3); PUT(-11); break;
-				case 134: PUT(-11); e += 3; h.zeros(3); PUT(11); break;
-				case 135: PUT(-11); e += 3; h.zeros(3); PUT(-11); break;
-				case 127: PUT(1008); break;
-				case 129: PUT(1009); break;
-				case 125: PUT(1006); break;
-				case 126: PUT(1007); break;
-				case 121: PUT(1010); break;
-				case 122: PUT(1011); break;
-				case 124: PUT(11); break;
-				case 123: PUT(-11); break;
-				default: PUT(lv[rank]); break;
+				const uint64_t lm = __ballot(live);
+				if (lm != __ballot(have)) done = true;
+				if (lm) {
+					const int last = 63 - __builtin_clzll(lm);
+					e += __shfl(pe, last); t1 += __shfl(p1, last); t2 += __shfl(p2, last);
+					carry = (unsigned)__shfl((int)sout, last);
 				}
+				if (e >= limit) done = true;
 			}
+			if (c >= nchunks - 1 && !done && (c + 1) * VCH_WORDS > nwords + 8) { bad = 1; break; }   /* ran out of stream before the last cell */
 		}
-#undef PUT
-	}
-	else {
-		/* retrieve_pixel_UV_comp, :446-640: U on even, V on odd stream positions */
-		int16_t *cs = plane_cb(ws, img, 0);                     /* U and V interleaved, stream order (the two chroma planes of D_CB are one buffer) */
-		Bits b; b.init(pk, f + m->o_packet2, m->data2 - m->data1, VLC_WIN1);
+	} else {
+		int16_t *cs = plane_cb(ws, img, 0);                           /* U and V interleaved, stream order */
 		const int limit = 2 * DQ - 2;
 		int e = 0;
-		while (e < limit) {
-			if (b.spent()) { bad = 1; break; }
-			const int rank = vlc_next(b, lut, lut2);
-			if (rank < 0) { bad = 1; break; }
-			const int word = bk[rank] & 255;
-			if (word == 128) { e += bk[rank] >> 8; continue; }
-			int v;
-			if (word == 124) v = 5005; else if (word == 126) v = 5006; else if (word == 122) v = 5003; else if (word == 130) v = 5004;
-			else v = plain_level(word);
-			if (e < 2 * DQ) cs[e] = (int16_t)v;
-			e++;
+		bool done = false;
+		for (int c = 0; c < nchunks + 64 && !done; c++) {
+			const int nsym = vlc_parse_chunk(g, nwords, c, start0, false, lut, lut2, cw[1], syms[1], lane, bad);
+			for (int base = 0; base < nsym && !done; base += 64) {
+				const bool have = base + lane < nsym;
+				const int rank = have ? syms[1][base + lane] : 0;
+				const int bkv = bk[rank], word = bkv & 255;
+				const bool is_run = word == 128;
+				const int adv = have ? (is_run ? bkv >> 8 : 1) : 0;
+				int pe = adv;
+				for (int d = 1; d < 64; d <<= 1) { const int oe = __shfl_up(pe, d); if (lane >= d) pe += oe; }
+				const int at = e + pe - adv;
+				const bool live = have && at < limit;
+				if (live && !is_run) {
+					const int v = word == 124 ? 5005 : word == 126 ? 5006 : word == 122 ? 5003 : word == 130 ? 5004 : lv[rank];
+					if (at < 2 * DQ) cs[at] = (int16_t)v;
+				}
+				const uint64_t lm = __ballot(live);
+				if (lm != __ballot(have)) done = true;
+				if (lm) e += __shfl(pe, 63 - __builtin_clzll(lm));
+				if (e >= limit) done = true;
+			}
+			if (c >= nchunks - 1 && !done && (c + 1) * VCH_WORDS > nwords + 8) { bad = 1; break; }
 		}
 	}
-	if (bad) atomicExch(&ws.buf<DecMeta>(D_META, img)->status, (int)NHW_E_FORMAT);
+	if (__any(bad) && !lane) atomicExch(&m->status, (int)NHW_E_FORMAT);
 }
 
 /* ---------------------------------------------------------------------------------------------- un-zig-zag
@@ -1443,7 +1566,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_CB], 0, k_dec_bytes[D_CB] * (size_t)n, s));
 	k_dec_parse<<<n, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 1 */
-	k_dec_vlc<<<(n + VLC_K - 1) / VLC_K, 128, 0, s>>>(ws);
+	k_dec_vlc<<<n, 128, 0, s>>>(ws);
 	k_dec_unzig<<<dim3(80, n), 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 2 */
 	k_dec_expand<<<(n + 3) / 4, 256, 0, s>>>(ws);
