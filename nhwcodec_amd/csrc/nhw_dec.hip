@@ -8,8 +8,8 @@
  *
  *   k_dec_parse    header + section table, packets copied to aligned words; the four byte-serial side streams
  *                  (LL2 DPCM bytes, the three/four position lists) are walked by one lane each, side by side
- *   k_dec_vlc      the prefix-code walk, one wavefront per stream (luma, chroma), written straight to its
- *                  place in the coefficient plane (the reference's un-zig-zag pass disappears)
+ *   k_dec_vlc      the prefix-code walk, one wavefront per stream (luma, chroma): a speculative parallel parse and a
+ *                  short-state chain for the placement rules; k_dec_unzig then moves the symbols to their cells
  *   k_dec_expand   pattern symbols -> coefficients, the +-1 nudge of the HH band, LL2 samples, odd-LL tags,
  *                  exception samples: one wavefront per image, rows in order, a row with no pattern symbol
  *                  is one load and a ballot
@@ -39,7 +39,7 @@ namespace {
 enum {
 	D_META, D_LL, D_PK, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_YB, D_CU, D_COUNT
 };
-enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304, WIN_BYTES = 4096, LL_WIN_BYTES = 26624, VLC_WIN0 = 1280, VLC_WIN1 = 360, VLC_K = 4, SEL1_WIN = 512, SEL2_WIN = 64 };
+enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304, WIN_BYTES = 4096, LL_WIN_BYTES = 26624 };
 const size_t k_dec_bytes[D_COUNT] = {
 	/* META */ 512, /* LL */ 24832, /* PK (unused) */ 256, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
 	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 8 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 2 * (2 * DQ + 4096), /* YB */ 4 * DQ, /* CU */ 2 * DQ
@@ -460,43 +460,6 @@ __constant__ VlcRun k_runs[26] = {
 	{0x1f0c0,17,64},{0x1f8c0,17,46},{0x3f1dc,18,12},{0x7e3d0,19,38},{0xfc7ec,20,20}
 };
 
-struct Bits {
-	uint32_t *lds; const uint8_t *g; int nwords, win, base; int at;   /* packet words [base, base + win) sit in LDS */
-	uint64_t buf; int fill;                                          /* `fill` valid bits at the top of buf */
-	DEV void init(uint32_t *l, const uint8_t *bytes, int n, int w) { lds = l; g = bytes; nwords = n; win = w; base = 0; at = 0; buf = 0; fill = 0; }
-	/* the walking lane moves the window on by itself (a stream longer than the window: noise-like images).  The common path must
-	 * not share a register with a global load: on gfx9 stores count in vmcnt, and a wait for such a load is a wait for every symbol
-	 * store still in flight (a memory round trip per refill). */
-	DEV void slide()
-	{
-		base += win;
-		for (int k = 0; k < win; k++) {
-			uint32_t v = 0;
-			if (base + k < nwords) { const uint8_t *p = g + 4 * (size_t)(base + k); v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-			lds[k] = v;
-		}
-	}
-	DEV void need32()
-	{
-		if (fill <= 32) {
-			if (at >= base + win) slide();
-			const uint32_t v = at < nwords ? lds[at - base] : 0u;
-			at++; buf |= (uint64_t)v << (32 - fill); fill += 32;
-		}
-	}
-	DEV unsigned peek(int n) { return (unsigned)(buf >> (64 - n)); }
-	DEV void skip(int n) { buf <<= n; fill -= n; }
-	DEV bool spent() const { return at > nwords + 3; }
-};
-/* all lanes: stage the first packet words of a stream (little-endian words at an unaligned file offset) */
-DEV void stage_words(const uint8_t *g, int nwords, int win, uint32_t *lds, int lane)
-{
-	const int n = nwords < win ? nwords : win;
-	for (int k = lane; k < n; k += 64) { const uint8_t *p = g + 4 * (size_t)k; lds[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	__builtin_amdgcn_wave_barrier();
-}
-
 /* Two-level code table.  lut[v], v = the next 8 bits: (len << 8) | rank for code words of up to 8 bits; 0x8000 | s when v is one of
  * the sixteen 8-bit prefixes of longer words, s selecting a 64-entry sub-table indexed by the following 6 bits: (len << 10) | rank for
  * words of 9..14 bits, 0 for the 17..20-bit tail (ranks >= 110), which is searched by its {first, length, count} runs. */
@@ -525,28 +488,6 @@ DEV void vlc_fill_lut(uint16_t *lut, uint16_t *lut2, int lane)
 		lut2[idx] = (uint16_t)e;
 	}
 }
-/* next code word -> rank */
-DEV int vlc_next(Bits &b, const uint16_t *lut, const uint16_t *lut2)
-{
-	b.need32();
-	const unsigned look = b.peek(20);
-	const unsigned e = lut[look >> 12];
-	if (!(e & 0x8000u)) { b.skip((int)(e >> 8)); return (int)(e & 255u); }
-	{
-		const unsigned e2 = lut2[(e & 15u) * 64 + ((look >> 6) & 63u)];
-		if (e2) { b.skip((int)(e2 >> 10)); return (int)(e2 & 1023u); }
-		/* the 17..20-bit tail, ranks 110..289: five runs of consecutive words, compared as immediates (a table in constant memory costs a
-		 * memory round trip per probe on the one lane that walks) */
-		unsigned d;
-		if ((d = (look >> 3) - 0x1f0c0u) < 64u) { b.skip(17); return 110 + (int)d; }
-		if ((d = (look >> 3) - 0x1f8c0u) < 46u) { b.skip(17); return 174 + (int)d; }
-		if ((d = (look >> 2) - 0x3f1dcu) < 12u) { b.skip(18); return 220 + (int)d; }
-		if ((d = (look >> 1) - 0x7e3d0u) < 38u) { b.skip(19); return 232 + (int)d; }
-		if ((d = look - 0xfc7ecu) < 20u) { b.skip(20); return 270 + (int)d; }
-	}
-	return -1;
-}
-
 /* books, compress_pixel.c:86-117 / :456-478: entry = (run length << 8) | symbol, 354 entries (ranks 0..353); one lane, scr = 1440 bytes of LDS scratch */
 DEV int build_book_small(const uint8_t *raw, int raw_len, bool chroma, int tree_end, uint16_t *book, uint8_t *scr)
 {
@@ -593,25 +534,6 @@ DEV int plain_level(int word)
 	if (x < 0) return (x << 3) - 123;
 	return word > 128 ? word - 125 : word - 131;
 }
-
-struct SelBits {                       /* bit k of a byte string, bytes [base, base + nwin) in LDS; reads go forward only */
-	uint8_t *win; const uint8_t *g; int nwin, nbytes, base;
-	DEV void slide(int at) { base = at; for (int k = 0; k < nwin; k++) win[k] = base + k < nbytes ? g[base + k] : 0; }
-	DEV int bit(int k)
-	{
-		const int at = k >> 3;
-		if (at >= nbytes) return 0;
-		if (at >= base + nwin) slide(at);
-		return (win[at - base] >> (7 - (k & 7))) & 1;
-	}
-};
-
-struct Hist {                      /* which of the five stream values before position e are non-zero (bit k-1: e-k); zero before the start */
-	unsigned nz;
-	DEV void push(int v) { nz = ((nz << 1) | (v != 0 ? 1u : 0u)) & 31u; }
-	DEV void zeros(int n) { nz = n >= 5 ? 0u : (nz << n) & 31u; }
-	DEV bool z(int k) const { return !((nz >> (k - 1)) & 1u); }
-};
 
 /* The prefix-code walk, in parallel (compress_pixel.c:49-444 luma, :446-640 chroma).
  *
