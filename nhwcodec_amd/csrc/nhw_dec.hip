@@ -39,7 +39,7 @@ namespace {
 enum {
 	D_META, D_LL, D_PK, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_YB, D_CU, D_COUNT
 };
-enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304, WIN_BYTES = 4096, LL_WIN_BYTES = 26624 };
+enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304 };
 const size_t k_dec_bytes[D_COUNT] = {
 	/* META */ 512, /* LL */ 24832, /* PK (unused) */ 256, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
 	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 8 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 2 * (2 * DQ + 4096), /* YB */ 4 * DQ, /* CU */ 2 * DQ
@@ -148,28 +148,15 @@ DEV void parse_header(const uint8_t *d, uint32_t len, DecMeta *m)
 		m->status = NHW_E_FORMAT;
 }
 
-/* A serial walker's view of its input bytes: the first `win` of them staged in LDS (read four at a time), the rest -- if a
- * stream is longer than its window -- from the file itself.  Reads behind the end return 0. */
-struct ByteWin {
-	const uint8_t *g; const uint32_t *lds; int len, win;
-	int have; uint32_t word;
-	DEV void init(const uint8_t *g_, const uint32_t *lds_, int len_, int win_) { g = g_; lds = lds_; len = len_; win = win_ < len_ ? win_ : len_; have = -1; word = 0; }
-	DEV int at(int i)
-	{
-		if (i >= len) return 0;
-		if (i >= win) return g[i];
-		if ((i >> 2) != have) { have = i >> 2; word = lds[have]; }
-		return (int)((word >> (8 * (i & 3))) & 255u);
-	}
+/* A wavefront's view of a byte string, 64 bytes at a time (lane l holds byte i0 + l): the block in hand, and the next one already
+ * on its way from memory while this one is being worked on.  Bytes behind the end read 0. */
+struct BlockReader {
+	const uint8_t *g; int len, i0, cur, nxt;
+	DEV int ld(int i) const { return i < len ? (int)g[i] : 0; }
+	DEV void init(const uint8_t *g_, int len_, int start, int lane) { g = g_; len = len_; i0 = start; cur = ld(i0 + lane); nxt = ld(i0 + 64 + lane); }
+	DEV void advance(int lane) { i0 += 64; cur = nxt; nxt = ld(i0 + 64 + lane); }
+	DEV int after(int lane) const { const int a = __shfl(cur, (lane + 1) & 63), b = __shfl(nxt, 0); return lane < 63 ? a : b; }   /* byte i0 + l + 1 */
 };
-/* all lanes of a wavefront: stage the first bytes of a stream (byte loads: a file section has no alignment) */
-DEV void stage_bytes(const uint8_t *g, int len, int win, uint8_t *lds, int lane)
-{
-	const int n = len < win ? len : win;
-	for (int i = lane; i < n; i += 64) lds[i] = g[i];
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	__builtin_amdgcn_wave_barrier();
-}
 
 /* LL2 samples (res_comp), nhw_decoder.c:1661-2026; unsigned char arithmetic.
  *
@@ -275,15 +262,17 @@ DEV void ll_emit_block(const LlTok &t, bool is_tok, int lane, int &j, int &prev,
 }
 
 /* whole wavefront */
-DEV void ll_expand_wave(ByteWin &code, const uint8_t *fine, const DecMeta *m, uint8_t *ll, int lane)
+DEV void ll_expand_wave(const uint8_t *code_g, int code_len, const uint8_t *fine, const DecMeta *m, uint8_t *ll, int lane)
 {
+	BlockReader code;
 	const int mode = (m->res_high & 3) == 3 ? 0 : (m->res_high & 3), q = m->q;
-	int prev = code.at(0), j = 1, a = 0, i0 = 1;
+	int prev = code_len > 0 ? code_g[0] : 0, j = 1, a = 0;
+	code.init(code_g, code_len, 1, lane);
 	bool pending = false;                                           /* byte i0 is the payload of a token that started in the block before */
 	if (!lane) ll[0] = (uint8_t)prev;
 	int split = -1;                                                 /* index of the byte that is sample 16384 */
 	while (split < 0) {
-		const int b = code.at(i0 + lane), d = code.at(i0 + lane + 1);
+		const int b = code.cur, d = code.after(lane), i0 = code.i0;
 		const uint64_t T = __ballot(b >= 64 && b < 128);
 		uint64_t pay = pending ? 1ull : 0ull, m_ = T;
 		bool pend_out = false;
@@ -311,56 +300,90 @@ DEV void ll_expand_wave(ByteWin &code, const uint8_t *fine, const DecMeta *m, ui
 		ll_emit_block(t, live, lane, j, prev, DQ / 4, ll);
 		a += __shfl(vpre, 63);                                     /* (past the split this is no longer used) */
 		pending = pend_out;
-		i0 += 64;
+		code.advance(lane);
 	}
 	/* chroma: sample 16384 verbatim (:1878), then one-byte tokens (:1882-1979) */
-	prev = code.at(split); j = DQ / 4 + 1;
+	prev = split < code_len ? code_g[split] : 0; j = DQ / 4 + 1;
 	if (!lane) ll[DQ / 4] = (uint8_t)prev;
-	i0 = split + 1;
+	code.init(code_g, code_len, split + 1, lane);
 	while (j < DQ / 4 + DQ / 8) {
-		const int b = code.at(i0 + lane);
+		const int b = code.cur;
 		LlTok t = ll_token_chroma(b);
 		const int cnt = t.abs_n ? t.abs_n : t.copies + t.n;
 		int off = cnt;
 		for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(off, dd); if (lane >= dd) off += o; }
 		const bool live = j + off - cnt < DQ / 4 + DQ / 8;         /* the walk stops at the first token that would start past the end */
 		ll_emit_block(t, live, lane, j, prev, DQ / 4 + DQ / 8, ll);
-		i0 += 64;
+		code.advance(lane);
 	}
 }
 
-/* position list walk (nhw_decoder.c:93-137 and its three copies): list bytes -> (row | column) entries; one lane.
- * The reference patches list bytes to 127 as it goes; only the next step's look at the previous byte sees that. */
-template <typename T>
-DEV int poslist_walk(ByteWin &b, int len, T *pos, int cap, int row_step, bool mask16)
+/* Position lists (nhw_decoder.c:93-137 and its three copies): list bytes -> (row | column) entries.
+ *
+ * Byte by byte the reference keeps a row counter, the column of the entry it wrote last and "the byte before was a row mark".
+ * A byte below 127 is a column (absolute: it starts a segment; the row advances if the column went backwards); 127 is a row
+ * mark; a byte from 128 carries two column steps from the entry before, and a step that would pass column 253 ends the row
+ * instead -- after that, and after a row mark, further step bytes only advance the row, until the next absolute column.  (The
+ * reference does that by patching list bytes to 127 as it goes.)
+ * Per segment that is a running sum with one cut-off point, so a wavefront takes 64 bytes per step: columns from a segmented
+ * sum, the cut-off from a "last non-neutral wins" scan of {column byte: alive, mark / overflow: dead}, the column written last
+ * from another such scan, rows and entry offsets from prefix sums. */
+struct PlCarry { int last, p127, row, n; };
+DEV int scan_add(int v, int lane) { for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; } return v; }
+/* inclusive "the last lane at or before me that has one" scan: has/val in, the winning val (or `none` if no lane has one) out */
+DEV int scan_last(bool has, int val, int none, int lane)
 {
-	int n = 0, row = 0, last = 0;          /* last = low byte of the entry written last (0 before the first: out-of-range read) */
-	if (len <= 0) return 0;
-#define EMIT(v) do { const unsigned v_ = (unsigned)(v); if (n < cap) pos[n] = (T)(mask16 ? (v_ & 0xFFFFu) : v_); last = (int)(v_ & 255u); n++; } while (0)
-	const int b0 = b.at(0);
-	bool prev127 = b0 == 127;
-	if (prev127) row = row_step; else EMIT(b0 << 1);
-	for (int i = 1; i < len; i++) {
-		const int v = b.at(i);
-		bool now127 = v == 127;
-		if (v >= 128) {
-			if (prev127) { row += 2 * row_step; now127 = true; }
-			else {
-				int col = last + (((v - 128) >> 4) << 1);
-				if (col >= 254) { row += row_step; now127 = true; } else EMIT(col + row);
-				col += (v & 15) << 1;
-				if (col >= 254) { row += row_step; now127 = true; } else EMIT(col + row);
-			}
+	int h = has ? 1 : 0, v = val;
+	for (int d = 1; d < 64; d <<= 1) { const int oh = __shfl_up(h, d), ov = __shfl_up(v, d); if (lane >= d && !h) { h = oh; v = ov; } }
+	return h ? v : none;
+}
+template <typename T>
+DEV int poslist_wave(const uint8_t *list, int len, T *pos, int cap, int row_step, bool mask16, int lane)
+{
+	PlCarry c = { 0, 0, 0, 0 };
+	BlockReader b;
+	b.init(list, len, 0, lane);
+	for (int i0 = 0; i0 < len; i0 += 64, b.advance(lane)) {
+		const int i = i0 + lane;
+		const bool valid = i < len;
+		const int v = b.cur;
+		const bool isM = valid && v == 127, isA = valid && !isM && (v < 127 || i == 0), isR = valid && !isM && !isA;
+		const int d1 = ((v - 128) >> 4) << 1, d2 = (v & 15) << 1, D = isR ? d1 + d2 : 0;
+		const int anew = (v << 1) & 255;
+		/* running column assuming no cut-off: segmented sum, a column byte restarts it */
+		int flag = isA ? 1 : 0, sum = isA ? anew : D;
+		for (int d = 1; d < 64; d <<= 1) { const int of = __shfl_up(flag, d), os = __shfl_up(sum, d); if (lane >= d && !flag) { sum += os; flag = of; } }
+		const int run = flag ? sum : c.last + sum;
+		const int c1 = run - D + d1, c2 = run;
+		const bool ovf = isR && c2 >= 254;
+		/* "the byte before was a row mark" after each byte: column byte -> 0, mark or overflow -> 1, otherwise unchanged */
+		const int st_after = scan_last(isA || isM || ovf, isA ? 0 : 1, c.p127, lane);
+		int p127b = __shfl_up(st_after, 1);
+		if (!lane) p127b = c.p127;
+		const bool alive = isR && !p127b;
+		const int nemit = isA ? 1 : alive ? (ovf ? (c1 < 254 ? 1 : 0) : 2) : 0;
+		/* column of the entry written last, after each byte */
+		const bool writes = isA || (alive && nemit > 0);
+		const int last_after = scan_last(writes, isA ? anew : (ovf ? c1 : c2), c.last, lane);
+		int lastb = __shfl_up(last_after, 1);
+		if (!lane) lastb = c.last;
+		int inc = 0;
+		if (isA) inc = (i != 0 && (v << 1) < lastb && !p127b) ? row_step : 0;
+		else if (isM) inc = row_step;
+		else if (isR) inc = !alive ? 2 * row_step : ovf ? (c1 >= 254 ? 2 * row_step : row_step) : 0;
+		const int rsum = scan_add(inc, lane), esum = scan_add(nemit, lane);
+		const int row_before = c.row + rsum - inc;
+		int at = c.n + esum - nemit;
+		if (isA) { const unsigned val = (unsigned)((v << 1) + row_before + inc); if (at < cap) pos[at] = (T)(mask16 ? (val & 0xFFFFu) : val); }
+		else if (nemit > 0) {
+			const unsigned v1 = (unsigned)(c1 + row_before), v2 = (unsigned)(c2 + row_before);
+			if (at < cap) pos[at] = (T)(mask16 ? (v1 & 0xFFFFu) : v1);
+			if (nemit > 1 && at + 1 < cap) pos[at + 1] = (T)(mask16 ? (v2 & 0xFFFFu) : v2);
 		}
-		else if (v == 127) row += row_step;
-		else {
-			if ((v << 1) < last && !prev127) row += row_step;
-			EMIT((v << 1) + row);
-		}
-		prev127 = now127;
+		c.last = __shfl(last_after, 63); c.p127 = __shfl(st_after, 63);
+		c.row += __shfl(rsum, 63); c.n += __shfl(esum, 63);
 	}
-#undef EMIT
-	return n;
+	return c.n;
 }
 
 __global__ __launch_bounds__(256) void k_dec_parse(DecWs ws)
@@ -380,48 +403,15 @@ __global__ __launch_bounds__(256) void k_dec_parse(DecWs ws)
 	if (sm.status) { if (!tid) *gm = sm; return; }
 	const int q = sm.q;
 
-	/* the byte-serial side streams: each wavefront stages its stream in LDS, then one lane walks it */
+	/* the side streams, one wavefront each: LL2 DPCM bytes and the position lists, all as 64-byte scans */
 	uint16_t *p1 = ws.buf<uint16_t>(D_P1, img), *p3 = ws.buf<uint16_t>(D_P3, img), *p5 = ws.buf<uint16_t>(D_P5, img);
 	uint32_t *p6 = ws.buf<uint32_t>(D_P6, img);
-	__shared__ __attribute__((aligned(16))) uint8_t win_ll[LL_WIN_BYTES];
-	__shared__ __attribute__((aligned(16))) uint8_t win[4][WIN_BYTES];
-	ByteWin bw;
-	if (wv == 0) {
-		stage_bytes(f + sm.o_chres, sm.ch_res_len, LL_WIN_BYTES, win_ll, lane);
-		bw.init(f + sm.o_chres, (const uint32_t *)win_ll, sm.ch_res_len, LL_WIN_BYTES);
-		ll_expand_wave(bw, f + sm.o_llword, &sm, ws.buf<uint8_t>(D_LL, img), lane);
-	}
-	else if (wv == 1) {
-		int c = 0;
-		if (q > 12) {
-			stage_bytes(f + sm.o_res1, sm.res1_len, WIN_BYTES, win[1], lane);
-			bw.init(f + sm.o_res1, (const uint32_t *)win[1], sm.res1_len, WIN_BYTES);
-			if (!lane) c = poslist_walk(bw, sm.res1_len, p1, sm.res1_bits * 8, 256, true);
-		}
-		if (!lane) counts[1] = c;
-	}
-	else if (wv == 2) {
-		int c = 0;
-		if (q >= 19) {
-			stage_bytes(f + sm.o_res3, sm.res3_len, WIN_BYTES, win[2], lane);
-			bw.init(f + sm.o_res3, (const uint32_t *)win[2], sm.res3_len, WIN_BYTES);
-			if (!lane) c = poslist_walk(bw, sm.res3_len, p3, sm.res3_bits * 8, 256, true);
-		}
-		if (!lane) counts[2] = c;
-	}
+	if (wv == 0) ll_expand_wave(f + sm.o_chres, sm.ch_res_len, f + sm.o_llword, &sm, ws.buf<uint8_t>(D_LL, img), lane);
+	else if (wv == 1) { const int c = q > 12 ? poslist_wave(f + sm.o_res1, sm.res1_len, p1, sm.res1_bits * 8, 256, true, lane) : 0; if (!lane) counts[1] = c; }
+	else if (wv == 2) { const int c = q >= 19 ? poslist_wave(f + sm.o_res3, sm.res3_len, p3, sm.res3_bits * 8, 256, true, lane) : 0; if (!lane) counts[2] = c; }
 	else {
-		int c5 = 0, c6 = 0;
-		if (q >= 21) {
-			stage_bytes(f + sm.o_res5, sm.res5_len, WIN_BYTES, win[3], lane);
-			bw.init(f + sm.o_res5, (const uint32_t *)win[3], sm.res5_len, WIN_BYTES);
-			if (!lane) c5 = poslist_walk(bw, sm.res5_len, p5, sm.res5_bits * 8, 256, true);
-			__builtin_amdgcn_wave_barrier();
-		}
-		if (q > 21) {
-			stage_bytes(f + sm.o_res6, sm.res6_len, WIN_BYTES, win[3], lane);
-			bw.init(f + sm.o_res6, (const uint32_t *)win[3], sm.res6_len, WIN_BYTES);
-			if (!lane) c6 = poslist_walk(bw, sm.res6_len, p6, sm.res6_bits * 8, 256, false);
-		}
+		const int c5 = q >= 21 ? poslist_wave(f + sm.o_res5, sm.res5_len, p5, sm.res5_bits * 8, 256, true, lane) : 0;
+		const int c6 = q > 21 ? poslist_wave(f + sm.o_res6, sm.res6_len, p6, sm.res6_bits * 8, 256, false, lane) : 0;
 		if (!lane) { counts[3] = c5; counts[0] = c6; }
 	}
 	__syncthreads();
