@@ -48,6 +48,28 @@ def _cpu_worker(args):
     return len(imgs), time.perf_counter() - t0
 
 
+def valu_evidence():
+    """VALU issue statistics of the front kernels from the committed PMC pass (profiles/round1_pmc_valu.json, batch 4096, -q20):
+    wave-instructions issued / (CUs x kernel cycles) -- why these kernels sit where they do against the HBM roofline."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc_valu.json")) as fh:
+            d = json.load(fh)
+    except OSError:
+        return None
+    out = {}
+    for k, v in d.items():
+        if "SQ_INSTS_VALU" not in v or "GRBM_GUI_ACTIVE" not in v:
+            continue
+        name = k.split("::")[-1].split("<")[0].replace("void ", "")
+        if name not in ("k_color", "k_front_rowmaps", "k_front_band"):
+            continue
+        cyc = v["GRBM_GUI_ACTIVE"]["per_launch"] / 8.0          # summed over the 8 XCDs
+        valu = v["SQ_INSTS_VALU"]["per_launch"]
+        out[name] = {"valu_wave_instructions": int(valu), "lane_ops_per_pixel": round(valu * 64 / (4096 * 262144), 1),
+                     "issue_frac_of_1_per_cu_cycle": round(valu / (256 * cyc), 3)}
+    return out or None
+
+
 def cpu_baseline(q, budget_s=12.0):
     """Reference encoder on the host cores, bounded sample (about `budget_s` seconds of wall time)."""
     import multiprocessing as mp
@@ -188,6 +210,9 @@ def main():
                          "entropy+container": round(tim.entropy_ms, 3), "total": round(tim.total_ms, 3)},
             "images_ok": [int(g[2]) for g in gathered], "bytes_out": [int(g[0]) for g in gathered],
         }
+        ev = valu_evidence()
+        if ev:
+            line["roofline"]["valu_pmc"] = ev
         if dec_line:
             line["decode"] = dec_line
         if not args.no_cpu_baseline and world == 1:
