@@ -347,3 +347,12 @@ def test_robustness_classes_more_seeds(enc, oracle, q):
     got = enc.encode(np.stack(imgs), q)
     bad = [i for i, im in enumerate(imgs) if got[i] != oracle.encode(im, q)]
     assert not bad, f"q{q}: images {bad} differ from the oracle"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [20, 23])
+def test_full_batch_4096_every_image_bit_exact(q):
+    """BASELINE config 2 at its full size, every one of the 4096 outputs against the oracle (oracle side spread over the host cores)"""
+    from tests.gpu_enc_fullcheck import full_encode_check
+    bad = full_encode_check(4096, q, 900000 + q)
+    assert not bad, f"q{q}: images {bad[:16]} differ from the oracle"
