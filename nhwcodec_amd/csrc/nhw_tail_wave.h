@@ -291,125 +291,151 @@ DEV void det_load_row(const int16_t *p, int r, int lane, int *v)
 	v[3] = p[r * W + lane + 192];
 }
 
+/* columns lo..hi of a 256-column row as a lane's bit field (bit k = column lane + 64k) */
+DEV unsigned bs_range(int lo, int hi, int lane)
+{
+	unsigned b = 0;
+	for (int k = 0; k < 4; k++) { const int col = lane + 64 * k; b |= (col >= lo && col <= hi ? 1u : 0u) << k; }
+	return b;
+}
+
 DEV void wave_dequant_details(Ctx *c, int part, int lane)
 {
 	int16_t *p = c->proc, *jp = c->jpeg;
 	int cur[4], nxt[4], pend_v[4] = { 0, 0, 0, 0 };
-	M4 pend = m4_zero();                                           /* jp cells of the current row the row above has set */
+	unsigned pend = 0;                                             /* jp cells of the current row the row above has set (bit-sliced, like every row mask in here) */
 	int q0[4], q1[4], q2[4];                                       /* rows r+2 .. r+4, already on their way (a row step is shorter than a memory round trip) */
 	det_load_row(p, 0, lane, cur);
 	det_load_row(p, 1, lane, nxt);
 	det_load_row(p, 2, lane, q0); det_load_row(p, 3, lane, q1); det_load_row(p, 4, lane, q2);
+#define UP(b) bs_up<4>((b), lane)
+#define DN(b) bs_dn((b), lane)
+#define BIT(b, k) (((b) >> (k)) & 1u)
 	for (int r = 0; r < H; r++) {
 		int far[4];
 		det_load_row(p, r + 5, lane, far);
 		const bool top = r < H / 2;
 		const int col0 = top ? H / 2 : 0;
 		int jv[4] = { pend_v[0], pend_v[1], pend_v[2], pend_v[3] };
-		M4 je = pend;
-		pend = m4_zero();
+		unsigned je = pend;
+		pend = 0;
 		if (r < H - 1) {                                           /* :2759-2853 */
-			M4 P, N, PN, NN;
-			BALLOT4(P, cur, x > 3 && x < 8); BALLOT4(N, cur, x < -3 && x > -8);
-			BALLOT4(PN, nxt, x > 3 && x < 8); BALLOT4(NN, nxt, x < -3 && x > -8);
-			const M4 rg = col_range(col0 + 1, H - 2);
-			const M4 pp = P & up1(P), nn = N & up1(N);
-			const M4 tp = pp & dn1(P), tn = nn & dn1(N);
-			const M4 vp = pp & ~dn1(P) & up1(PN) & PN, vn = nn & ~dn1(N) & up1(NN) & NN;
-			const M4 fired = alt_runs((tp | vp | tn | vn) & rg);
-			const M4 ftp = fired & tp, ftn = fired & tn, fvp = fired & vp, fvn = fired & vn;
-			const M4 ft = ftp | ftn, fv = fvp | fvn;
-			const M4 ftp_l = dn1(ftp), ftn_l = dn1(ftn), fvp_l = dn1(fvp), fvn_l = dn1(fvn);   /* the cell left of a firing cell */
-			const M4 ftp_r = up1(ftp), ftn_r = up1(ftn);
-			for (int k = 0; k < 4; k++) {
-				if (TB(ft, k)) cur[k] = 0;
-				if (TB(ftp_l, k)) cur[k] = 15300; if (TB(ftn_l, k)) cur[k] = 15400;
-				if (TB(fvp_l, k)) { cur[k] = 15500; nxt[k] = 15500; }
-				if (TB(fvn_l, k)) { cur[k] = 15600; nxt[k] = 15600; }
-				if (TB(fv, k)) nxt[k] = 0;
-				if (TB(ftp, k) || TB(fvp, k) || TB(ftp_r, k)) jv[k] = 5;
-				if (TB(ftn, k)) jv[k] = -6;
-				if (TB(fvn, k) || TB(ftn_r, k)) jv[k] = -5;
-				pend_v[k] = TB(fvp, k) ? 5 : -5;
+			unsigned P, N, PN, NN;
+			BS_PRED(P, cur, 4, x > 3 && x < 8); BS_PRED(N, cur, 4, x < -3 && x > -8);
+			BS_PRED(PN, nxt, 4, x > 3 && x < 8); BS_PRED(NN, nxt, 4, x < -3 && x > -8);
+			const unsigned rg = bs_range(col0 + 1, H - 2, lane);
+			const unsigned dP = DN(P), dN = DN(N);
+			const unsigned pp = P & UP(P), nn = N & UP(N);
+			const unsigned tp = pp & dP, tn = nn & dN;
+			const unsigned vp = pp & ~dP & UP(PN) & PN, vn = nn & ~dN & UP(NN) & NN;
+			const unsigned cand = (tp | vp | tn | vn) & rg;
+			unsigned fired = 0;
+			if (__any(cand != 0)) fired = bs_from4(alt_runs(bs_ballot4(cand)));
+			if (__any(fired != 0)) {
+				const unsigned ftp = fired & tp, ftn = fired & tn, fvp = fired & vp, fvn = fired & vn;
+				const unsigned ft = ftp | ftn, fv = fvp | fvn;
+				const unsigned ftp_l = DN(ftp), ftn_l = DN(ftn), fvp_l = DN(fvp), fvn_l = DN(fvn);   /* the cell left of a firing cell */
+				const unsigned ftp_r = UP(ftp), ftn_r = UP(ftn);
+				for (int k = 0; k < 4; k++) {
+					if (BIT(ft, k)) cur[k] = 0;
+					if (BIT(ftp_l, k)) cur[k] = 15300; if (BIT(ftn_l, k)) cur[k] = 15400;
+					if (BIT(fvp_l, k)) { cur[k] = 15500; nxt[k] = 15500; }
+					if (BIT(fvn_l, k)) { cur[k] = 15600; nxt[k] = 15600; }
+					if (BIT(fv, k)) nxt[k] = 0;
+					if (BIT(ftp, k) || BIT(fvp, k) || BIT(ftp_r, k)) jv[k] = 5;
+					if (BIT(ftn, k)) jv[k] = -6;
+					if (BIT(fvn, k) || BIT(ftn_r, k)) jv[k] = -5;
+					pend_v[k] = BIT(fvp, k) ? 5 : -5;
+				}
+				je |= fired | ftp_r | ftn_r;
+				pend = fv;
 			}
-			je = je | fired | ftp_r | ftn_r;
-			pend = fv;
 		}
 		if (!part) {                                               /* :2857-2905 */
-			M4 A, B;
-			BALLOT4(A, cur, x >= 5 && x <= 7); BALLOT4(B, cur, x <= -5 && x >= -7);
-			const M4 fired = alt_runs(((A & dn1(A)) | (B & dn1(B))) & col_range(col0, H - 2));
-			const M4 fa = fired & A, fb = fired & B;
-			for (int k = 0; k < 4; k++) { if (TB(fa, k)) cur[k] = 15700; if (TB(fb, k)) cur[k] = 15800; }
+			unsigned A, B;
+			BS_PRED(A, cur, 4, x >= 5 && x <= 7); BS_PRED(B, cur, 4, x <= -5 && x >= -7);
+			const unsigned cand = ((A & DN(A)) | (B & DN(B))) & bs_range(col0, H - 2, lane);
+			if (__any(cand != 0)) {
+				const unsigned fired = bs_from4(alt_runs(bs_ballot4(cand)));
+				const unsigned fa = fired & A, fb = fired & B;
+				for (int k = 0; k < 4; k++) { if (BIT(fa, k)) cur[k] = 15700; if (BIT(fb, k)) cur[k] = 15800; }
+			}
 		}
 		{                                                          /* :2909-3124 */
-			M4 code, k1, k2;
-			BALLOT4(code, cur, x > 15000);
-			BALLOT4(k2, cur, x == 15300 || x == 15400);
-			BALLOT4(k1, cur, x == 15500 || x == 15600 || x == 15700 || x == 15800);
-			const M4 rd = col_range(col0, H - 1);
-			M4 skipped;
-			{                                                      /* which cells the walk steps over: a visited code cell hides the next one (two for a triple) */
+			unsigned code, k1, k2;
+			BS_PRED(code, cur, 4, x > 15000);
+			BS_PRED(k2, cur, 4, x == 15300 || x == 15400);
+			BS_PRED(k1, cur, 4, x == 15500 || x == 15600 || x == 15700 || x == 15800);
+			const unsigned rd = bs_range(col0, H - 1, lane);
+			unsigned skipped = 0;
+			if (__any(((k1 | k2) & rd) != 0)) {                    /* which cells the walk steps over: a visited code cell hides the next one (two for a triple) */
+				const M4 k12 = bs_ballot4((k1 | k2) & rd), k2m = bs_ballot4(k2);
+				M4 sk4;
 				uint64_t carry = 0;
 				for (int k = 0; k < 4; k++) {
-					uint64_t sk = carry, m = (k1.w[k] | k2.w[k]) & rd.w[k];
+					uint64_t sk = carry, m = k12.w[k];
 					carry = 0;
 					while (m) {
 						const int j = __builtin_ctzll(m);
 						m &= m - 1;
 						if (!((sk >> j) & 1)) {
-							const uint64_t pat = ((k2.w[k] >> j) & 1) ? 6 : 2;
+							const uint64_t pat = ((k2m.w[k] >> j) & 1) ? 6 : 2;
 							sk |= pat << j;
 							if (j > 60) carry |= pat >> (64 - j);
 						}
 					}
-					skipped.w[k] = sk;
+					sk4.w[k] = sk;
 				}
+				skipped = bs_from4(sk4);
 			}
-			const M4 vis = rd & ~skipped, vc = vis & code, vnc = vis & ~code;
-			const M4 ml = col_range(0, H - 2);
-			M4 e8, e7, em7, dc, ac;
-			BALLOT4(e8, cur, x == 8); BALLOT4(e7, cur, x == 7); BALLOT4(em7, cur, x == -7);
-			BALLOT4(dc, cur, x > 12 && x < 15000 && (x & 7) >= 6); BALLOT4(ac, cur, x < -12 && ((-x) & 7) == 6);
-			const M4 dm = part ? m4_zero() : (vnc & ml & dc);
-			const M4 is8 = vnc & (e8 | (e7 & up1(dm)));               /* the walk sees an 8 here (a 7 the cell before has raised counts) */
-			const M4 to_m8 = em7 & up1((vnc & ml & ac) | (is8 & ml));
-			const M4 to_8 = e7 & up1(dm);
-			const M4 self_m8 = vnc & ml & em7 & ~to_m8 & dn1(e8);
-			const M4 m8 = to_m8 | self_m8;
-			M4 pr_p, pr_n;                                            /* visited 15700 / 15800: the partner takes the same +-6 */
-			BALLOT4(pr_p, cur, x == 15700); BALLOT4(pr_n, cur, x == 15800);
-			const M4 part_p = up1(pr_p & vc), part_n = up1(pr_n & vc);
+			const unsigned vis = rd & ~skipped, vc = vis & code, vnc = vis & ~code;
+			const unsigned ml = bs_range(0, H - 2, lane);
+			unsigned e8, e7, em7, dc, ac;
+			BS_PRED(e8, cur, 4, x == 8); BS_PRED(e7, cur, 4, x == 7); BS_PRED(em7, cur, 4, x == -7);
+			BS_PRED(dc, cur, 4, x > 12 && x < 15000 && (x & 7) >= 6); BS_PRED(ac, cur, 4, x < -12 && ((-x) & 7) == 6);
+			const unsigned dm = part ? 0u : (vnc & ml & dc);
+			const unsigned udm = UP(dm);
+			const unsigned is8 = vnc & (e8 | (e7 & udm));           /* the walk sees an 8 here (a 7 the cell before has raised counts) */
+			const unsigned to_m8 = em7 & UP((vnc & ml & ac) | (is8 & ml));
+			const unsigned to_8 = e7 & udm;
+			const unsigned self_m8 = vnc & ml & em7 & ~to_m8 & DN(e8);
+			const unsigned m8 = to_m8 | self_m8;
+			unsigned pr_p, pr_n;                                    /* visited 15700 / 15800: the partner takes the same +-6 */
+			BS_PRED(pr_p, cur, 4, x == 15700); BS_PRED(pr_n, cur, 4, x == 15800);
+			const unsigned part_p = UP(pr_p & vc), part_n = UP(pr_n & vc);
 			for (int k = 0; k < 4; k++) {
-				if (TB(m8, k)) cur[k] = -8;
-				if (TB(to_8, k)) cur[k] = 8;
-				if (TB(part_p, k)) jv[k] = 6;
-				if (TB(part_n, k)) jv[k] = -6;
-				if (TB(vc, k)) {
+				if (BIT(m8, k)) cur[k] = -8;
+				if (BIT(to_8, k)) cur[k] = 8;
+				if (BIT(part_p, k)) jv[k] = 6;
+				if (BIT(part_n, k)) jv[k] = -6;
+				if (BIT(vc, k)) {
 					const int a = cur[k];
 					if (a == 15300 || a == 15500) jv[k] = 5;
 					else if (a == 15400 || a == 15600) jv[k] = -5;
 					else if (a == 15700) jv[k] = 6;
 					else if (a == 15800) jv[k] = -6;
 				}
-				if (TB(vnc, k)) {
+				if (BIT(vnc, k)) {
 					int a = cur[k];
 					if (a < 0) { a = -a; if ((a & 7) < 7) a &= 0xFFF8; a = -a; }
 					jv[k] = dequant_value(a);
 				}
 			}
-			M4 wr;                                                    /* code cells with another value (none are produced) write nothing */
-			BALLOT4(wr, cur, x > 15000 && !(x == 15300 || x == 15400 || x == 15500 || x == 15600 || x == 15700 || x == 15800));
-			je = je | part_p | part_n | (vis & ~wr);
+			unsigned wr;                                            /* code cells with another value (none are produced) write nothing */
+			BS_PRED(wr, cur, 4, x > 15000 && !(x == 15300 || x == 15400 || x == 15500 || x == 15600 || x == 15700 || x == 15800));
+			je |= part_p | part_n | (vis & ~wr);
 		}
 		for (int k = 0; k < 4; k++) {
 			if (top && k < 2) continue;
 			const int at = r * W + lane + 64 * k;
 			p[at] = (int16_t)cur[k];
-			if (TB(je, k)) jp[at] = (int16_t)jv[k];
+			if (BIT(je, k)) jp[at] = (int16_t)jv[k];
 		}
 		for (int k = 0; k < 4; k++) { cur[k] = nxt[k]; nxt[k] = q0[k]; q0[k] = q1[k]; q1[k] = q2[k]; q2[k] = far[k]; }
 	}
+#undef UP
+#undef DN
+#undef BIT
 	__threadfence_block();
 }
 
