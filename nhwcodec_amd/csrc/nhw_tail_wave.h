@@ -446,25 +446,26 @@ DEV void wave_shrink(Ctx *c, int lane)
 {
 	int16_t *jp = c->jpeg;
 	int jc[4], jn[4];
-	M4 bp, bc, bn;
+	unsigned bp, bc, bn;                                           /* ">= 8" of rows r-1, r, r+1, bit-sliced (bit k = column lane + 64k) */
 	for (int k = 0; k < 4; k++) { jn[k] = jp[lane + 64 * k]; jc[k] = jp[W + lane + 64 * k]; }
-	BALLOT4(bp, jn, iabs(x) >= 8);
-	BALLOT4(bc, jc, iabs(x) >= 8);
+	BS_PRED(bp, jn, 4, iabs(x) >= 8);
+	BS_PRED(bc, jc, 4, iabs(x) >= 8);
 	for (int k = 0; k < 4; k++) jn[k] = jp[2 * W + lane + 64 * k];
-	BALLOT4(bn, jn, iabs(x) >= 8);
-	const M4 inner = col_range(1, H - 2), right = col_range(H / 2, H - 2);
+	BS_PRED(bn, jn, 4, iabs(x) >= 8);
+	const unsigned inner = bs_range(1, H - 2, lane), right = bs_range(H / 2, H - 2, lane);
 	int g0[4], g1[4];                                              /* rows r+2, r+3 in flight */
 	for (int k = 0; k < 4; k++) { g0[k] = jp[3 * W + lane + 64 * k]; g1[k] = jp[4 * W + lane + 64 * k]; }
 	for (int r = 1; r < H - 1; r++) {
 		int jf[4] = { 0, 0, 0, 0 };
 		if (r + 4 < H) for (int k = 0; k < 4; k++) jf[k] = jp[(r + 4) * W + lane + 64 * k];
-		const M4 near = up1(bp) | bp | dn1(bp) | up1(bc) | dn1(bc) | up1(bn) | bn | dn1(bn);
-		const M4 hit = bc & ~near & (r >= H / 2 ? inner : right);
+		const unsigned side = bp | bc | bn;                           /* a neighbour column with any of its three rows set */
+		const unsigned near = bs_up<4>(side, lane) | bs_dn(side, lane) | bp | bn;
+		const unsigned hit = bc & ~near & (r >= H / 2 ? inner : right);
 		for (int k = 0; k < 4; k++)
-			if (TB(hit, k)) jp[r * W + lane + 64 * k] = (int16_t)(jc[k] > 0 ? jc[k] - 1 : jc[k] + 1);
+			if ((hit >> k) & 1u) jp[r * W + lane + 64 * k] = (int16_t)(jc[k] > 0 ? jc[k] - 1 : jc[k] + 1);
 		bp = bc; bc = bn;
 		for (int k = 0; k < 4; k++) { jc[k] = jn[k]; jn[k] = g0[k]; g0[k] = g1[k]; g1[k] = jf[k]; }
-		BALLOT4(bn, jn, iabs(x) >= 8);
+		BS_PRED(bn, jn, 4, iabs(x) >= 8);
 	}
 }
 
