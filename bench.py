@@ -48,6 +48,40 @@ def _cpu_worker(args):
     return len(imgs), time.perf_counter() - t0
 
 
+def _cpu_dec_worker(args):
+    kind, files, reps = args
+    from oracle.oraclepy import Oracle
+    if kind == "reference":
+        from oracle.harness import RefDecoder
+        rd = RefDecoder()
+        f = rd.bmp                      # the unmodified reference decoder incl. its BMP writer (a tmpfs file per call)
+    else:
+        orc = Oracle()
+        f = lambda b: orc.decode(b)
+    f(files[0])
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for b in files:
+            f(b)
+    return reps * len(files), time.perf_counter() - t0
+
+
+def cpu_decode_baseline(files, budget_s=6.0):
+    """Reference decoder on the host cores over a sample of the files the GPU just decoded."""
+    import multiprocessing as mp
+    kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libnhwref_dec.so")) else "port"
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    reps = max(1, int(budget_s / (0.012 * 4)))
+    jobs = [(kind, files[(4 * w) % len(files):(4 * w) % len(files) + 4] or files[:4], reps) for w in range(cores)]
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_cpu_dec_worker, jobs)
+    n = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    return {"value": round(n * MPIX_PER_IMAGE / busy, 2), "unit": "Mpixels/s", "cores": cores, "kind": kind,
+            "sample": f"{n} decodes of {min(len(files), 4 * cores)} of this run's .nhw files, one in-process decoder per core, {busy:.1f} s; "
+                      f"{'unmodified reference sources + zero-guard allocator, BMP written to a temporary file' if kind == 'reference' else 'plain-C restatement'}"}
+
+
 def valu_evidence():
     """VALU issue statistics of the front kernels from the committed PMC pass (profiles/round1_pmc_valu.json, batch 4096, -q20):
     wave-instructions issued / (CUs x kernel cycles) -- why these kernels sit where they do against the HBM roofline."""
@@ -183,6 +217,9 @@ def main():
                     "unit": "Mpixels/s", "ms_per_step": round(ddt / args.steps * 1e3, 3), "files_ok_rank0": dec_ok,
                     "psnr_db_first_64": round(10 * math.log10(255.0 ** 2 / max(err, 1e-9)), 2),
                     "workload": f"the {batch} .nhw files per GPU this run just encoded (-q{q}), decoder arena = encoder arena in HBM"}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            szh = sizes[:256].cpu().numpy(); ar = out[0][:256].cpu().numpy()
+            dec_line["cpu_baseline"] = cpu_decode_baseline([ar[i, : int(szh[i])].tobytes() for i in range(min(256, batch))])
         dec.close()
 
     if rank == 0:
