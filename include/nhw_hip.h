@@ -60,6 +60,13 @@ void nhw_enc_destroy(nhw_enc *e);
 const char *nhw_last_error(void);
 int  nhw_quality_supported(int quality);
 
+/* What the reference's out-of-bounds reads return.  NHW_COMPAT_CANONICAL (default, normative): zeros -- the output equals the reference
+ * sources built with a zero-filling guard allocator.  NHW_COMPAT_GLIBC_ONESHOT: the heap neighbours of the stock `gcc -O3` nhw-enc run on
+ * one image per process -- the output equals that binary's, except for the bytes it leaves un-initialised itself (the
+ * last byte of the res1/res5/res6 word sections and of the two select-word and code-book sections, the last two of res3's). */
+enum { NHW_COMPAT_CANONICAL = 0, NHW_COMPAT_GLIBC_ONESHOT = 1 };
+int  nhw_enc_set_compat(nhw_enc *e, int mode);
+
 /* Encode n images already resident in HBM.  d_bgr: n*NHW_IMG_BYTES.  d_out: n*NHW_OUT_STRIDE, image i's
  * .nhw starts at i*NHW_OUT_STRIDE.  d_sizes[i] = byte length, d_status[i] = NHW_OK / NHW_E_CODEBOOK.
  * Asynchronous on `stream`. */

@@ -33,6 +33,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.nhw_enc_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)]
     L.nhw_enc_destroy.argtypes = [P]
     L.nhw_quality_supported.argtypes = [ctypes.c_int]
+    L.nhw_enc_set_compat.argtypes = [P, ctypes.c_int]
     L.nhw_enc_batch_device.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, P, P, P]
     L.nhw_enc_batch.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, ctypes.c_size_t, P, P]
     L.nhw_synth_batch_device.argtypes = [P, P, ctypes.c_int, ctypes.c_uint32, P]
@@ -73,6 +74,10 @@ class Encoder:
             self.close()
         except Exception:
             pass
+
+    def set_compat(self, glibc_oneshot: bool):
+        """False: canonical output (default).  True: reproduce the stock one-image-per-process binary (include/nhw_hip.h)."""
+        self._chk(self.lib.nhw_enc_set_compat(self.h, 1 if glibc_oneshot else 0))
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream

@@ -1079,6 +1079,42 @@ void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilte
 		k_front_band<0><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
 }
 
+/* Compatibility mode (NHW_COMPAT_GLIBC_ONESHOT) only: the kernel-map cells whose memory the stock binary's malloc hands out again as
+ * res256's slack (row 128, columns 0..3) and as tree1 (from byte 262176 of the map on: rows 272..280 cover what is read before it is
+ * written).  A lane replays one row from the row's entry state; out: [0..3] row 128, then 9 rows of 512. */
+__global__ void k_front_stale(const int16_t *__restrict__ yb, size_t y_stride, const uint8_t *__restrict__ st, size_t s_stride, int16_t *__restrict__ stale, size_t stale_stride)
+{
+	const int img = blockIdx.x, lane = threadIdx.x;
+	if (lane >= 10) return;
+	const int16_t *y = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
+	int16_t *out = (int16_t *)((uint8_t *)stale + (size_t)img * stale_stride);
+	const int row = lane ? 271 + lane : 128, ncols = lane ? W : 4;
+	int16_t *dst = lane ? out + 4 + (lane - 1) * W : out;
+	int carry = st[(size_t)img * s_stride + row] & 15;
+	dst[0] = 0;                                                     /* column 0 (and 511) of the map are never written */
+	for (int c = 1; c < ncols; c++) {
+		int k = 0;
+		if (c <= W - 2) {
+			const int16_t *p = y + (size_t)row * W + c;
+			const int ctr = p[0];
+			int sum = 0, mag = 0;
+			for (int dy = -1; dy <= 1; dy++)
+				for (int dx = -1; dx <= 1; dx++) {
+					if (!dy && !dx) continue;
+					const int d = ctr - p[dy * W + dx];
+					sum += d; mag += iabs(d);
+				}
+			if (sum == 0) carry = 0;
+			else { const int acc = 15 * iabs(sum) + mag + ((carry + 2) >> 2); k = sum < 0 ? -(acc >> 4) : (acc >> 4); carry = acc & 15; }
+		}
+		dst[c] = (int16_t)k;
+	}
+}
+void nhw_launch_front_stale(const int16_t *y, size_t y_stride, const uint8_t *st, size_t s_stride, int16_t *stale, size_t stale_stride, int n, hipStream_t s)
+{
+	k_front_stale<<<n, 64, 0, s>>>(y, y_stride, st, s_stride, stale, stale_stride);
+}
+
 void nhw_debug_band_stamps(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(nhw::g_band_stamp), sizeof(unsigned long long) * 16); }
 
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s)

@@ -669,7 +669,7 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 	}
 	{                                                              /* column 255 */
 		int16_t *pc = lds, *oc = lds + H + 8, *lc = lds + 2 * (H + 8);
-		for (int t = tid; t < H + 2; t += NT) { pc[t] = p[t * W + H - 1]; oc[t] = t < H ? o[t * H + H - 1] : 0; }
+		for (int t = tid; t < H + 2; t += NT) { pc[t] = p[t * W + H - 1]; oc[t] = o[t * H + H - 1];   /* rows 256, 257: the guard behind ll1 */ }
 		lc[tid] = p[(H - 1) * W + H + tid];
 		BARRIER();
 		if (tid == 0) {
@@ -1731,6 +1731,7 @@ DEV void ll_code_chroma_par(Ctx *c, int tid, uint8_t *lds /* LLC_LDS_BYTES */)
 DEV void luma_p1_par(Ctx *c, int tid, int *pos)
 {
 	PROF_BEGIN();
+	if (c->compat) for (int k = tid; k < 512; k += NT) c->ll1[Q + k] = 0;   /* the passes before the LL2 emission see nothing behind res256 (nhw_tail_par.h, luma_p3_par) */
 	tag_l2_details_par(c, tid);
 	BARRIER();
 	if (!tid) PROF(c, 0);
@@ -1747,7 +1748,22 @@ DEV void luma_p2_par(Ctx *c, int tid, int16_t *lds)
 DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc, int16_t *lds)
 {
 	PROF_BEGIN();
-	for (int i = (Q >> 2) + tid; i < (Q >> 2) + (Q >> 3) + 64; i += NT) c->ll_bytes[i] = 0;
+	if (c->compat) {
+		/* the stock binary's heap: tree1 is carved out of the freed kernel map (q<=21), so what the LL2 coder reads behind the luma
+		 * samples is map bytes; and res256 is followed by 8 bytes of map, the next chunk's size word and resIII */
+		for (int i = (Q >> 2) + tid; i < (Q >> 2) + (Q >> 3) + 64; i += NT) {
+			int b = 0;
+			if (c->q < 22) {
+				const int s = 131088 + (i >> 1), v = (uint16_t)c->stale[4 + ((s >> 9) - 272) * W + (s & 511)];
+				b = (i & 1) ? v >> 8 : v & 255;
+			}
+			c->ll_bytes[i] = (uint8_t)b;
+		}
+		int16_t *tail = c->ll1 + Q;
+		for (int k = tid; k < 512; k += NT)
+			tail[k] = (int16_t)(k < 4 ? (c->q < 22 ? c->stale[k] : 0) : k == 4 ? 0x0011 : k == 5 ? 0x0002 : k < 8 ? 0 : c->l2save[k - 8]);
+	}
+	else for (int i = (Q >> 2) + tid; i < (Q >> 2) + (Q >> 3) + 64; i += NT) c->ll_bytes[i] = 0;
 	BARRIER();
 	{                                                             /* Y16 */
 		uint8_t *ls = reinterpret_cast<uint8_t *>(lds);

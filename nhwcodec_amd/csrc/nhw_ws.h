@@ -21,7 +21,7 @@ enum {
 	B_RAW, B_PAY, B_CC, B_HALF, B_TMP16,
 	B_R1LIST, B_R1BITS, B_R1WORD, B_R3LIST, B_R3BITS, B_R3WORD, B_R5LIST, B_R5BITS, B_R5WORD,
 	B_R6LIST, B_R6BITS, B_R6WORD, B_CHARRES, B_QSET3,
-	B_RESU64, B_RESV64, B_PACKET, B_BOOK1, B_BOOK2, B_SEL1, B_SEL2, B_S1, B_S2, B_HIST, B_META, B_PROF, B_ROWFLAG, B_SEGMAP,
+	B_RESU64, B_RESV64, B_PACKET, B_BOOK1, B_BOOK2, B_SEL1, B_SEL2, B_S1, B_S2, B_HIST, B_META, B_PROF, B_ROWFLAG, B_SEGMAP, B_STALE,
 	B_COUNT
 };
 
@@ -45,6 +45,7 @@ struct NhwWs {
 	size_t stride[B_COUNT];
 	int n;
 	int q;
+	int compat;   /* 0: canonical (out-of-bounds reads see zeros); 1: the heap neighbours of the stock one-image-per-process binary (nhw_hip.h) */
 	template <typename T> __host__ __device__ T *buf(int b, int img) const { return (T *)(base + off[b] + (size_t)img * stride[b]); }
 };
 

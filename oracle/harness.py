@@ -107,6 +107,60 @@ class RefEncoder:
 
 
 REF_DEC_SO = os.path.join(HERE, "_ref", "libnhwref_dec.so")
+STOCK_ENC = os.path.join(HERE, "_ref", "nhw-enc")      # the reference encoder exactly as its README builds it (gcc *.c -O3), no shim
+
+
+def stock_encode(img: np.ndarray, quality: int) -> bytes:
+    """Run the stock reference binary on one image (one process per image: the heap layout SURVEY.md App. D describes)."""
+    import subprocess
+    d = tempfile.mkdtemp(prefix="nhwstock")
+    try:
+        with open(os.path.join(d, "a.bmp"), "wb") as fh:
+            fh.write(bmp_bytes(img))
+        subprocess.run([STOCK_ENC, f"-q{quality}", os.path.join(d, "a.bmp"), os.path.join(d, "a.nhw")], capture_output=True, check=True)
+        with open(os.path.join(d, "a.nhw"), "rb") as fh:
+            return fh.read()
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def uninitialised_positions(nhw: bytes) -> set:
+    """Byte offsets of a .nhw file whose value the stock encoder itself leaves to un-initialised memory (located from
+    the header): the last byte of the res1 / res5 / res6 word sections, the last two of res3's, the last byte of the two select-word
+    sections, and the last byte of the two code books (the collapse loop at compress_pixel.c:410-421 looks one stack byte past them)."""
+    q = nhw[1]
+    o = 2
+    f = {}
+
+    def g(n, name):
+        nonlocal o
+        f[name] = int.from_bytes(nhw[o:o + n], "little")
+        o += n
+    g(2, "book1"); g(2, "book2"); g(4, "data1"); g(4, "data2"); g(2, "tree_end"); g(2, "exw")
+    if q > 12: g(2, "res1")
+    if q >= 19: g(2, "res3"); g(2, "res3b")
+    if q > 17: g(2, "res4")
+    if q > 12: g(2, "res1b")
+    if q >= 21: g(2, "res5"); g(2, "res5b")
+    if q > 21: g(4, "res6"); g(2, "res6b"); g(2, "char")
+    if q > 22: g(2, "qs3")
+    g(2, "sel1"); g(2, "sel2")
+    if q > 15: g(2, "llword")
+    g(2, "chres")
+    pad = set()
+    o += f["book1"]; pad.add(o - 1)
+    o += f["book2"]; pad.add(o - 1)
+    o += f["exw"]
+    if q > 12: o += f["res1"] + 2 * f["res1b"]; pad.add(o - 1)
+    if q > 17: o += f["res4"]
+    if q >= 19: o += f["res3"] + 3 * f["res3b"]; pad.update((o - 1, o - 2))
+    if q >= 21: o += f["res5"] + 2 * f["res5b"]; pad.add(o - 1)
+    if q > 21: o += f["res6"] + 2 * f["res6b"]; pad.add(o - 1); o += 2 * f["char"]
+    if q > 22: o += 4 * f["qs3"]
+    o += f["sel1"]; pad.add(o - 1)
+    o += f["sel2"]; pad.add(o - 1)
+    return pad
 
 
 class RefDecoder:

@@ -52,6 +52,13 @@ typedef struct {
 
 int nhwo_quality_supported(int quality);
 
+/* What out-of-bounds reads of the reference return.  NHWO_OOB_ZERO (default) is the canonical, normative model (every such read
+ * is 0).  NHWO_OOB_GLIBC_ONESHOT reproduces the heap adjacency of the stock `gcc -O3` nhw-enc run on one image per process
+ * (SURVEY.md App. D): a compatibility mode for comparing against that binary; its output equals the binary's except for the
+ * un-initialised padding bytes at the end of the res*_word / select_word sections. */
+enum { NHWO_OOB_ZERO = 0, NHWO_OOB_GLIBC_ONESHOT = 1 };
+extern int nhwo_oob_mode;
+
 /* Whole encoder: BGR24 (BMP file order, 786432 bytes) -> .nhw bytes.  trace may be NULL. */
 int nhwo_encode(const uint8_t *bgr, int quality, uint8_t *out, size_t cap, size_t *out_len, nhwo_trace *trace);
 

@@ -97,6 +97,9 @@ void nhwo_color(const uint8_t *bgr, int quality, int16_t *y, uint8_t *u, uint8_t
  *     pass A (:601-764): 8-neighbour contrast map with a 4-bit error carry that runs through the
  *     whole interior in raster order; pass B (:770-837 q>16 branch, :1927-1990): pixel pairs.
  * ------------------------------------------------------------------------------------------ */
+int16_t nhwo_kernel_row128[4];   /* the four kernel-map values that sit behind res256 in the stock binary's heap (GLIBC_ONESHOT mode, nhwo_luma.c) */
+int16_t nhwo_kernel_stale[16384]; /* kernel map from byte 262176 on: what the stock binary's malloc hands out as tree1 (same mode) */
+
 void nhwo_prefilter(int16_t *y, int quality)
 {
 	const int S = NHWO_DIM;
@@ -126,6 +129,9 @@ void nhwo_prefilter(int16_t *y, int quality)
 				carry = acc & 15;
 			}
 		}
+
+	for (c = 0; c < 4; c++) nhwo_kernel_row128[c] = kmap[128 * S + c];
+	memcpy(nhwo_kernel_stale, kmap + 262176 / 2, sizeof nhwo_kernel_stale);
 
 	for (r = 1; r < S - 1; r++)
 		for (c = 1; c < S - 2; c += 2) {            /* pairs (1,2) (3,4) ... (509,510), :772-778 */

@@ -559,6 +559,21 @@ int nhwo_luma(nhwo_ctx *c)
 	trace_planes(c, "wavelet_analysis_256", c->jpeg, 8 * Q, c->proc, 8 * Q);
 
 	for (r = 0; r < H; r++) memcpy(c->l2save + r * H, c->proc + r * W, sizeof(int16_t) * H);                    /* Y13 :623-631 */
+	if (nhwo_oob_mode) {                                          /* (values 2 and 3 switch on one half only: debugging aid) */
+		/* in the stock one-image-per-process binary res256 is followed by 8 bytes of stale nhw_kernel (q<=21; a fresh
+		 * heap, i.e. zeros, above), the size word of the next chunk (0x20011) and resIII itself; the residual passes read up to 430
+		 * bytes past res256 */
+		extern int16_t nhwo_kernel_row128[4];
+		int16_t *tail = c->ll1 + Q;
+		int k;
+		if (nhwo_oob_mode != 3) {
+		for (k = 0; k < 4; k++) tail[k] = q < 22 ? nhwo_kernel_row128[k] : 0;
+		tail[4] = 0x0011; tail[5] = 0x0002; tail[6] = 0; tail[7] = 0;
+		for (k = 0; k < 504; k++) tail[8 + k] = c->l2save[k];
+		}
+		/* tree1 is carved out of the freed nhw_kernel block as well (q<=21): what it has not written yet is stale kernel map */
+		if (q < 22 && nhwo_oob_mode != 2) { extern int16_t nhwo_kernel_stale[16384]; memcpy(c->ll_bytes, nhwo_kernel_stale, 96 * H + 1); }
+	}
 	if (q > 17) tag_res4(c);
 	emit_ll2(c);
 	if (c->trace) {

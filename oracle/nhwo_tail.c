@@ -294,6 +294,7 @@ size_t nhwo_container(nhwo_ctx *c, uint8_t *out, size_t cap)
 
 /* ---------------------------------------------------------------- public entry point */
 int nhwo_quality_supported(int quality) { return quality >= 17 && quality <= 23; }
+int nhwo_oob_mode = NHWO_OOB_ZERO;
 
 int nhwo_encode(const uint8_t *bgr, int quality, uint8_t *out, size_t cap, size_t *out_len, nhwo_trace *trace)
 {

@@ -60,6 +60,10 @@ class Oracle:
         self.lib.nhwo_dec_bmp_header(ctypes.cast(h, P))
         return h.raw
 
+    def set_oob_mode(self, glibc_oneshot: bool):
+        """False: canonical (out-of-bounds reads see zeros).  True: NHWO_OOB_GLIBC_ONESHOT, the stock binary's heap neighbours (nhwo.h)."""
+        ctypes.c_int.in_dll(self.lib, "nhwo_oob_mode").value = 1 if glibc_oneshot else 0
+
     def synth(self, seed: int) -> np.ndarray:
         b = np.empty((512, 512, 3), np.uint8)
         self.lib.nhwo_synth_image(seed, b.ctypes.data)

@@ -356,3 +356,35 @@ def test_full_batch_4096_every_image_bit_exact(q):
     from tests.gpu_enc_fullcheck import full_encode_check
     bad = full_encode_check(4096, q, 900000 + q)
     assert not bad, f"q{q}: images {bad[:16]} differ from the oracle"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [17, 18, 19, 20, 21, 22, 23])
+def test_compat_mode_matches_oracle_and_stock_binary(oracle, q):
+    """NHW_COMPAT_GLIBC_ONESHOT: bit-exact against the oracle in its GLIBC_ONESHOT mode, equal to the stock reference binary outside the
+    positions that binary leaves un-initialised (on images where the luma heap neighbours are the only live out-of-bounds reads: DESIGN.md
+    section 2); switching back gives the canonical output again (the guard behind ll1 is clean)."""
+    import nhwcodec_amd
+    from oracle.harness import STOCK_ENC, stock_encode, uninitialised_positions
+    enc = nhwcodec_amd.Encoder(0, 16)
+    imgs = np.stack([oracle.synth(i) for i in range(10)] + [class_image(k, q) for k in ("blocks", "noise", "tiles")])
+    enc.set_compat(True)
+    got = enc.encode(imgs, q)
+    got2 = enc.encode(imgs, q)                      # a second batch over the same workspace
+    enc.set_compat(False)
+    canon = enc.encode(imgs, q)
+    enc.close()
+    oracle.set_oob_mode(True)
+    try:
+        want = [oracle.encode(im, q) for im in imgs]
+    finally:
+        oracle.set_oob_mode(False)
+    assert [i for i in range(len(imgs)) if got[i] != want[i]] == []
+    assert got2 == got
+    assert [i for i in range(len(imgs)) if canon[i] != oracle.encode(imgs[i], q)] == []
+    if os.path.exists(STOCK_ENC):
+        for i in range(6):
+            stock = stock_encode(imgs[i], q)
+            assert len(stock) == len(got[i])
+            pad = uninitialised_positions(stock)
+            assert [k for k in range(len(stock)) if stock[k] != got[i][k] and k not in pad] == [], f"image {i}"

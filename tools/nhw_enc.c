@@ -10,6 +10,7 @@
  * Batch extensions (not in the reference):
  *   nhw-enc [-q N] --batch <dir>                 every <dir>/x.bmp  -> <dir>/x.nhw, one GPU batch per 1024 files
  *   nhw-enc [-q N] --synthetic <count> [--seed S] --outdir <dir>   SURVEY 8d generator on the device
+ *   --stock-compat   reproduce the stock one-image-per-process binary instead of the canonical output (include/nhw_hip.h)
  */
 #include <dirent.h>
 #include <stdint.h>
@@ -136,6 +137,7 @@ int main(int argc, char **argv)
 	int quality = QUALITY_DEFAULT, overwrite = 0, synthetic = 0, i;
 	uint32_t seed = 0;
 	const char *batch_dir = NULL, *outdir = NULL;
+	int stock_compat = 0;   /* --stock-compat: NHW_COMPAT_GLIBC_ONESHOT, the stock binary's out-of-bounds reads (include/nhw_hip.h) */
 	nhw_enc *enc = NULL;
 	int rc;
 
@@ -144,6 +146,7 @@ int main(int argc, char **argv)
 		if (!strcmp(argv[1], "--synthetic") && argc > 2) { synthetic = atoi(argv[2]); argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--seed") && argc > 2) { seed = (uint32_t)strtoul(argv[2], NULL, 10); argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--outdir") && argc > 2) { outdir = argv[2]; argc -= 2; argv += 2; continue; }
+		if (!strcmp(argv[1], "--stock-compat")) { stock_compat = 1; argc -= 1; argv += 1; continue; }
 		for (i = 1; argv[1][i] != '\0'; i++) {
 			const char ch = argv[1][i];
 			if (ch >= '0' && ch <= '9') continue;
@@ -193,6 +196,7 @@ int main(int argc, char **argv)
 		closedir(d);
 		if (!n) { printf("Not enough arguments. Check help.\n"); return 0; }
 		if ((rc = nhw_enc_create(0, n < 1024 ? n : 1024, &enc))) die_lib("nhw_enc_create", rc);
+		if (stock_compat) nhw_enc_set_compat(enc, NHW_COMPAT_GLIBC_ONESHOT);
 		imgs = (uint8_t *)malloc((size_t)(n < 1024 ? n : 1024) * NHW_IMG_BYTES);
 		for (base = 0; base < n; base += 1024) {
 			const int m = n - base < 1024 ? n - base : 1024;
@@ -211,6 +215,7 @@ int main(int argc, char **argv)
 		int bad;
 		load_bmp(argv[1], img);
 		if ((rc = nhw_enc_create(0, 1, &enc))) die_lib("nhw_enc_create", rc);
+		if (stock_compat) nhw_enc_set_compat(enc, NHW_COMPAT_GLIBC_ONESHOT);
 		names[0] = argv[2];
 		bad = encode_host_batch(enc, img, 1, quality, names);
 		nhw_enc_destroy(enc);
