@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_L4C2) luma_p4c2_par(&c, tid);
 	else if (PH == PH_LLC) { PROF_BEGIN(); ll_code_chroma_par(&c, tid, reinterpret_cast<uint8_t *>(dyn_lds)); if (!tid) PROF(&c, 18); }
 	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
-	else if (PH == PH_C2) dequant_sim_chroma_par(&c, 1, tid);
+	else if (PH == PH_C2) { chroma_ll1_neighbour(&c, tid); dequant_sim_chroma_par(&c, 1, tid); }
 	else if (PH == PH_C3) chroma_p3_par(&c, comp, tid);
 	else if (PH == PH_C4) dequant_sim_chroma_par(&c, 0, tid);
 	else if (PH == PH_C5) chroma_p5_par(&c, comp, tid, dyn_lds, sh_counts);

@@ -1857,6 +1857,13 @@ DEV void chroma_p0_par(Ctx *c, int comp, int tid)
 		reinterpret_cast<uint2 *>(c->cjpeg)[idx] = o;
 	}
 }
+/* the one cell the chroma passes read behind cll1 (res256): zero, or in the compatibility mode what the stock binary finds there -- both
+ * chroma res256 blocks are carved out of the freed 4:2:0 U plane, whose bytes 32768, 32769 follow them.  Written
+ * by the phase before the first reader (after the analysis kernel that fills cll1). */
+DEV void chroma_ll1_neighbour(Ctx *c, int tid)
+{
+	if (!tid) c->cll1[Q >> 2] = (int16_t)(c->compat ? (c->pu[32768] | (c->pu[32769] << 8)) : 0);
+}
 DEV void chroma_p3_par(Ctx *c, int comp, int tid)                     /* :2316-2336 (U), :2629-2648 (V): pointwise */
 {
 	int16_t *jp = c->cjpeg, *p = c->cproc, *o = c->cll1;

@@ -147,6 +147,10 @@ int nhwo_chroma(nhwo_ctx *c, int comp)
 	const int res_uv = q > 17 ? 4 : 5;                          /* :2370 */
 	int r, j, i, a;
 
+	if (nhwo_oob_mode == NHWO_OOB_GLIBC_ONESHOT)
+		/* the chroma res256 (both planes) is carved out of the freed im_bufferU: the one short the passes below read behind it is that
+		 * plane's bytes 32768, 32769 (SURVEY App. D method: malloc trace of the stock binary) */
+		o[Q >> 2] = (int16_t)(c->pu[32768] | (c->pu[32769] << 8));
 	for (i = 0; i < Q; i++) jp[i] = src[i];                     /* :2256 / :2573 */
 	memset(p, 0, sizeof(int16_t) * Q);                          /* U: fresh zero plane; V re-uses it, every cell read later is rewritten first */
 

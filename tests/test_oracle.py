@@ -129,7 +129,7 @@ def test_glibc_oneshot_mode_reproduces_the_stock_binary(oracle, q):
         pytest.skip("oracle/_ref/nhw-enc not built (needs /root/reference)")
     oracle.set_oob_mode(True)
     try:
-        for seed in (0, 1, 2, 4):
+        for seed in (0, 1, 110, 117, 925):
             img = oracle.synth(seed)
             stock = stock_encode(img, q)
             got = oracle.encode(img, q)
