@@ -37,11 +37,11 @@ namespace {
 /* ---------------------------------------------------------------------------------------------- workspace
  * structure of arrays over the batch: buffer b of image i at base + off[b] + i * size[b] */
 enum {
-	D_META, D_LL, D_PK, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_YB, D_CU, D_COUNT
+	D_META, D_LL, D_SPARE, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_YB, D_CU, D_COUNT
 };
-enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304 };
+enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304 /* sanity bound on the packet words of a file (the encoder's buffer holds 80000) */ };
 const size_t k_dec_bytes[D_COUNT] = {
-	/* META */ 512, /* LL */ 24832, /* PK (unused) */ 256, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
+	/* META */ 512, /* LL */ 24832, /* SPARE */ 256, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
 	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 8 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 2 * (2 * DQ + 4096), /* YB */ 4 * DQ, /* CU */ 2 * DQ
 };
 
@@ -69,7 +69,7 @@ struct DecWs {
 	__host__ __device__ static size_t k_dec_bytes_dev(int b)
 	{
 		switch (b) {
-		case D_META: return 512; case D_LL: return 24832; case D_PK: return 256;
+		case D_META: return 512; case D_LL: return 24832; case D_SPARE: return 256;
 		case D_P1: case D_P3: case D_P5: return P16_CAP * 2; case D_P6: return (size_t)P6_CAP * 4;
 		case D_MARKS: return 2 * DQ; case D_A: case D_B: return 8 * DQ + 8192;
 		case D_CA: case D_CB: return 2 * (2 * DQ + 4096); case D_YB: return 4 * DQ; default: return 2 * DQ;
