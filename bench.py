@@ -204,8 +204,11 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
+            s1 = s2 = sc = 0.0
             for _ in range(args.steps):
                 _, dst, dq = dec.decode_device(out[0], offs, sizes, pix)
+                dtm = dec.timing()
+                s1 += dtm.synth1_ms; s2 += dtm.synth2_ms; sc += dtm.color_ms
             torch.cuda.synchronize()
             if dist:
                 dist.barrier()
@@ -216,7 +219,20 @@ def main():
         dec_line = {"metric": "decode Mpixels/s (512x512 .nhw batch -> BGR24, BASELINE config 5)", "value": round(batch * world * args.steps * MPIX_PER_IMAGE / ddt, 2),
                     "unit": "Mpixels/s", "ms_per_step": round(ddt / args.steps * 1e3, 3), "files_ok_rank0": dec_ok,
                     "psnr_db_first_64": round(10 * math.log10(255.0 ** 2 / max(err, 1e-9)), 2),
-                    "workload": f"the {batch} .nhw files per GPU this run just encoded (-q{q}), decoder arena = encoder arena in HBM"}
+                    "workload": f"the {batch} .nhw files per GPU this run just encoded (-q{q}), decoder arena = encoder arena in HBM",
+                    "stage_ms": {"entropy": round(dtm.entropy_ms, 3), "total": round(dtm.total_ms, 3)},
+                    # SURVEY 8(d) for config 5: the final reconstruction (level-1 synthesis, both directions, + colour) has 3 B/px of coefficients in and 3 B/px of
+                    # BGR out as its algorithmic traffic; here it is three kernels, each listed with its own bytes (hipEvents on the launch stream)
+                    "roofline": {"bound": "hbm", "kernel": "k_dec_synth (level 1, first direction) + k_dec_synth (level 1, second direction, -> bytes) + k_dec_color",
+                                 "achieved": round(batch * 1572864 / ((s1 + s2 + sc) / 1e3 / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(batch * 1572864 / ((s1 + s2 + sc) / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                 "algorithmic_bytes_per_image": 1572864,
+                                 "kernels": [{"kernel": "level-1 synthesis, rows (int16 in, int16 out)", "ms": round(s1 / args.steps, 3), "algorithmic_bytes": batch * 1048576,
+                                              "achieved": round(batch * 1048576 / (s1 / 1e3 / args.steps) / 1e9, 1)},
+                                             {"kernel": "level-1 synthesis, columns (int16 in, clipped bytes out)", "ms": round(s2 / args.steps, 3), "algorithmic_bytes": batch * 786432,
+                                              "achieved": round(batch * 786432 / (s2 / 1e3 / args.steps) / 1e9, 1)},
+                                             {"kernel": "x2 chroma + colour matrix (Y + 4:2:0 U,V bytes in, BGR24 out)", "ms": round(sc / args.steps, 3), "algorithmic_bytes": batch * (262144 + 131072 + 786432),
+                                              "achieved": round(batch * (262144 + 131072 + 786432) / (sc / 1e3 / args.steps) / 1e9, 1)}]}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             szh = sizes[:256].cpu().numpy(); ar = out[0][:256].cpu().numpy()
             dec_line["cpu_baseline"] = cpu_decode_baseline([ar[i, : int(szh[i])].tobytes() for i in range(min(256, batch))])

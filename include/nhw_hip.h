@@ -110,6 +110,11 @@ int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_t *d_off, c
 /* host convenience: H2D of the files (nhw[off[i]..off[i+1])), decode, D2H.  Synchronous. */
 int nhw_dec_batch(nhw_dec *d, const uint8_t *nhw, const uint64_t *off, int n, uint8_t *bgr, int32_t *status, int32_t *quality);
 void nhw_dec_bmp_header(uint8_t h[54]);
+/* hipEvent timings of the last nhw_dec_batch_device call (events on its launch stream): the whole sequence, the entropy stages
+ * (parse, prefix-code walk, un-zig-zag), the two level-1 luma synthesis passes and the colour kernel -- the last three are the kernels
+ * SURVEY.md 8(d) prices against the HBM roofline for the decode path */
+typedef struct { float total_ms, entropy_ms, synth1_ms, synth2_ms, color_ms; } nhw_dec_timing;
+int nhw_dec_last_timing(nhw_dec *d, nhw_dec_timing *t);
 
 #ifdef __cplusplus
 }

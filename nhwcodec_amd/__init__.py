@@ -122,6 +122,10 @@ class Encoder:
         return t
 
 
+class DecTiming(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "entropy_ms", "synth1_ms", "synth2_ms", "color_ms")]
+
+
 class Decoder:
     """One decoder handle on one GPU: mirror of the reference's decode_image + write_image_bmp
     (decoder/nhw_decoder.c:54, decoder/nhw_decoder_cli.c:108) for batches of .nhw files."""
@@ -138,6 +142,7 @@ class Decoder:
         L.nhw_dec_batch_device.argtypes = [P, P, P, P, ctypes.c_int, P, P, P, P]
         L.nhw_dec_batch.argtypes = [P, P, P, ctypes.c_int, P, P, P]
         L.nhw_dec_bmp_header.argtypes = [P]
+        L.nhw_dec_last_timing.argtypes = [P, ctypes.POINTER(DecTiming)]
         L.nhw_dec_debug_stop_after.argtypes = [P, ctypes.c_int]
         L.nhw_dec_debug_read.argtypes = [P, ctypes.c_int, ctypes.c_int, P, ctypes.c_size_t]
         self.device = device
@@ -165,6 +170,11 @@ class Decoder:
         h = ctypes.create_string_buffer(54)
         self.lib.nhw_dec_bmp_header(ctypes.cast(h, P))
         return h.raw
+
+    def timing(self) -> DecTiming:
+        t = DecTiming()
+        self._chk(self.lib.nhw_dec_last_timing(self.h, ctypes.byref(t)))
+        return t
 
     def decode_device(self, arena, offsets, lengths, out=None):
         """arena: uint8 CUDA tensor holding the files; offsets: int64 CUDA tensor [n]; lengths: int32 CUDA tensor [n]

@@ -1416,6 +1416,8 @@ struct nhw_dec {
 	size_t slab_bytes;
 	hipStream_t own_stream;
 	int stop_after;
+	hipEvent_t ev[8];         /* start, after the entropy stages, around the two level-1 luma synthesis passes, around the colour kernel, end */
+	bool timed;
 	/* host convenience path */
 	uint8_t *d_blob; size_t blob_cap;
 	uint64_t *d_off; uint32_t *d_len; uint8_t *d_out; int32_t *d_status; int32_t *d_quality;
@@ -1434,6 +1436,7 @@ extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
 	HIPCHK(hipMalloc(&d->ws.base, at));
 	HIPCHK(hipMemset(d->ws.base, 0, at));
 	HIPCHK(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
+	for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&d->ev[i]));
 	*out = d;
 	return NHW_OK;
 }
@@ -1450,6 +1453,7 @@ extern "C" void nhw_dec_destroy(nhw_dec *d)
 	if (d->d_status) (void)hipFree(d->d_status);
 	if (d->d_quality) (void)hipFree(d->d_quality);
 	if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
+	for (int i = 0; i < 8; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
 	delete d;
 }
 
@@ -1472,7 +1476,10 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	DecWs ws = d->ws;
 	ws.n = n; ws.blob = (const uint8_t *)d_nhw; ws.blob_off = d_off; ws.blob_len = d_len;
 	int stage = 0;
+	d->timed = false;
 #define STAGE_END() do { if (d->stop_after && ++stage >= d->stop_after) goto done; } while (0)
+#define EV(i) HIPCHK(hipEventRecord(d->ev[i], s))
+	EV(0);
 	/* the symbol streams start from zero (the reference's calloc, nhw_decoder.c:2029, :894): a zero run is a skip */
 	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_B], 0, k_dec_bytes[D_B] * (size_t)n, s));
 	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_CB], 0, k_dec_bytes[D_CB] * (size_t)n, s));
@@ -1480,6 +1487,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	STAGE_END();                                                                  /* 1 */
 	k_dec_vlc<<<n, 128, 0, s>>>(ws);
 	k_dec_unzig<<<dim3(80, n), 256, 0, s>>>(ws);
+	EV(1);
 	STAGE_END();                                                                  /* 2 */
 	k_dec_expand<<<(n + 3) / 4, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 3 */
@@ -1498,7 +1506,9 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	STAGE_END();                                                                  /* 7 */
 	{
 		SynthArgs p1 = { D_A, D_B, 0, DW, DW, DW, DH, 0, 0 };
+		EV(2);
 		k_dec_synth<<<dim3(DW / 16, n), 256, 0, s>>>(ws, p1);
+		EV(3);
 	}
 	k_dec_corr<<<n, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 8 */
@@ -1506,7 +1516,9 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	STAGE_END();                                                                  /* 9 */
 	{
 		SynthArgs p2 = { D_B, -1, 0, DW, DW, DW, DW, 1, 1 };
+		EV(4);
 		k_dec_synth<<<dim3(DW / 16, n), 256, 0, s>>>(ws, p2);
+		EV(5);
 	}
 	STAGE_END();                                                                  /* 10 */
 	{
@@ -1524,12 +1536,28 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 		k_dec_sharpen<<<(2 * n + 3) / 4, 256, 0, s>>>(ws);
 		STAGE_END();                                                              /* 14 */
 	}
+	EV(6);
 	k_dec_color<<<dim3(DW / 2, n), 256, 0, s>>>(ws, (uint8_t *)d_bgr);
+	EV(7);
+	d->timed = true;
 done:
 	k_dec_status<<<(n + 255) / 256, 256, 0, s>>>(ws, d_status, d_quality);
 	HIPCHK(hipGetLastError());
 	return NHW_OK;
 #undef STAGE_END
+#undef EV
+}
+
+extern "C" int nhw_dec_last_timing(nhw_dec *d, nhw_dec_timing *t)
+{
+	if (!d || !t || !d->timed) return NHW_E_ARG;
+	HIPCHK(hipEventSynchronize(d->ev[7]));
+	HIPCHK(hipEventElapsedTime(&t->total_ms, d->ev[0], d->ev[7]));
+	HIPCHK(hipEventElapsedTime(&t->entropy_ms, d->ev[0], d->ev[1]));
+	HIPCHK(hipEventElapsedTime(&t->synth1_ms, d->ev[2], d->ev[3]));
+	HIPCHK(hipEventElapsedTime(&t->synth2_ms, d->ev[4], d->ev[5]));
+	HIPCHK(hipEventElapsedTime(&t->color_ms, d->ev[6], d->ev[7]));
+	return NHW_OK;
 }
 
 /* host convenience: H2D of the files, decode, D2H of the pixels.  nhw: the files back to back, off[n+1]. */
