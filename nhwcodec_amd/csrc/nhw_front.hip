@@ -438,6 +438,7 @@ __global__ __launch_bounds__(256) void k_syn_rows(const int16_t *__restrict__ sr
 #define FB_TROWS (2 * FB_KB + 5)    /* horizontal-pass rows a band needs: 2k0-4 .. 2k0+32 */
 #define FB_YROWS (FB_TROWS + 2)
 #define FB_RS 514                   /* padded LDS row stride (shorts) */
+#define FB_LOOK 12                  /* pixels of look-back for a segment's entry state (all 16 states have merged within 8 for 99.9 % of the segments) */
 #define FB_NT 512                   /* threads per band: the 78 KB of LDS allow two bands per CU, eight wavefronts each keep the SIMDs fed */
 
 __device__ __forceinline__ int contrast_at(const int16_t *p /* LDS, row stride FB_RS */)
@@ -456,81 +457,63 @@ __device__ __forceinline__ int contrast_at(const int16_t *p /* LDS, row stride F
 	return sum == 0 ? 0 : (sum < 0 ? -base : base);
 }
 
-/* pre-pass: per row the 16-state transfer map of the carry and, for each of the 16 entry states, the hand-over
- * flag of the row's last pixel pair (509, 510).  One workgroup = 32 rows, 8 segments of 64 pixels per row. */
-__global__ __launch_bounds__(256) void k_front_rowmaps(const int16_t *__restrict__ yb, size_t y_stride, uint64_t *__restrict__ maps, size_t m_stride,
-                                                       uint16_t *__restrict__ flags, size_t f_stride, uint64_t *__restrict__ segmaps, size_t g_stride)
+/* pre-pass: per row the 16-state transfer map of the carry across the row and, for each of the 16 entry states, the hand-over
+ * flag of the row's last pixel pair (509, 510) -- what k_front_chain needs to walk down the rows.  The carry forgets its past
+ * within a few pixels (see k_front_band: measured, all 16 states merge within 16 pixels, 99.9 % within 8), so the RT_LOOK pixels
+ * before pixel 509 decide both: if the states have merged by then, map and flags are the same for every entry state.  Otherwise
+ * (rare) the lane walks the whole row.  One lane per row. */
+#define RT_LOOK 24
+__global__ __launch_bounds__(64) void k_front_rowtail(const int16_t *__restrict__ yb, size_t y_stride, uint64_t *__restrict__ maps, size_t m_stride,
+                                                      uint16_t *__restrict__ flags, size_t f_stride)
 {
-	__shared__ int16_t ybuf[34 * FB_RS];
-	__shared__ uint64_t seg[32 * 8 * 2];
-	__shared__ uint16_t segflag[32];
-	const int band = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
-	const int16_t *y = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
-	const int y0 = 32 * band - 1;                                  /* first staged row */
-	for (int k = t; k < 34 * (W / 8); k += 256) {
-		const int ry = k / (W / 8), o = k % (W / 8), row = y0 + ry;
+	__shared__ __attribute__((aligned(16))) int16_t tail[66][40];      /* rows r0-1 .. r0+64, columns 480..511 (+ padding: 80-byte rows) */
+	const int img = blockIdx.y, r0 = 1 + blockIdx.x * 64, row = r0 + threadIdx.x;
+	const int16_t *yi = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
+	for (int k = threadIdx.x; k < 66 * 4; k += 64) {
+		const int rr = k >> 2, o = k & 3, gr = r0 - 1 + rr;
 		uint4 v = make_uint4(0, 0, 0, 0);
-		if (row >= 0 && row < W) v = reinterpret_cast<const uint4 *>(y + (size_t)row * W)[o];
-		uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 8 * o);
-		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+		if (gr >= 0 && gr < W) v = *reinterpret_cast<const uint4 *>(yi + (size_t)gr * W + 480 + 8 * o);
+		*reinterpret_cast<uint4 *>(&tail[rr][8 * o]) = v;
 	}
 	__syncthreads();
-	{
-		const int rl = t >> 3, sg = t & 7, row = 32 * band + rl;    /* row-local index, segment */
-		uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
-		uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0; int v509 = 0, v510 = 0;
-		if (row >= 1 && row <= W - 2) {
-			const int c0 = 1 + 64 * sg, c1 = sg == 7 ? W - 2 : c0 + 63;
-			const int16_t *p = ybuf + (rl + 1) * FB_RS;
-			/* 3x3 window slides along the row: three new LDS reads per pixel */
-			int u0 = p[-FB_RS + c0 - 1], u1 = p[-FB_RS + c0], m_0 = p[c0 - 1], m_1 = p[c0], d0 = p[FB_RS + c0 - 1], d1 = p[FB_RS + c0];
-			int cs0 = u0 + m_0 + d0, cs1 = u1 + m_1 + d1;
-			for (int c = c0; c <= c1; c++) {
-				const int u2 = p[-FB_RS + c + 1], m_2 = p[c + 1], d2 = p[FB_RS + c + 1];
-				/* sum of the eight differences = 9 x centre - the 3x3 total; their magnitudes with the sum-of-absolute-differences instruction (luma is 0..255 here) */
-				const int cs2 = u2 + m_2 + d2;                        /* column sums slide along with the window */
-				const int sum = 9 * m_1 - (cs0 + cs1 + cs2);
-				const int mag = (int)sad_u32(m_1, u0, sad_u32(m_1, u1, sad_u32(m_1, u2, sad_u32(m_1, m_0, sad_u32(m_1, m_2, sad_u32(m_1, d0, sad_u32(m_1, d1, sad_u32(m_1, d2, 0u))))))));
-				const int base = 15 * iabs(sum) + mag;
-				const int vb = sum == 0 ? 0 : (sum < 0 ? -base : base);
-				if (c == W - 3) { a0 = m0; a1 = m1; v509 = vb; }
-				if (c == W - 2) { b0 = m0; b1 = m1; v510 = vb; }
-				fsm_step16(m0, m1, vb);
-				u0 = u1; u1 = u2; m_0 = m_1; m_1 = m_2; d0 = d1; d1 = d2; cs0 = cs1; cs1 = cs2;
-			}
+	if (row > W - 2) return;
+	const int16_t *y = yi + (size_t)row * W;
+	uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+	int v509 = 0, v510 = 0;
+	for (int pass = 0; pass < 2; pass++) {
+		m0 = 0x0706050403020100ull; m1 = 0x0F0E0D0C0B0A0908ull;
+		int c = pass ? 1 : W - 3 - RT_LOOK;
+		/* pass 0 reads the staged tail (LDS column = c - 480), the rare pass 1 the row itself; stride and base differ, the walk does not */
+		const int16_t *p = pass ? y : &tail[threadIdx.x + 1][0] - 480;
+		const int rs = pass ? W : 40;
+		/* 3x3 window slides along the row: three new reads per pixel */
+		int u0 = p[-rs + c - 1], u1 = p[-rs + c], m_0 = p[c - 1], m_1 = p[c], d0 = p[rs + c - 1], d1 = p[rs + c];
+		int cs0 = u0 + m_0 + d0, cs1 = u1 + m_1 + d1;
+		for (; c <= W - 2; c++) {
+			const int u2 = p[-rs + c + 1], m_2 = p[c + 1], d2 = p[rs + c + 1];
+			const int cs2 = u2 + m_2 + d2;
+			const int sum = 9 * m_1 - (cs0 + cs1 + cs2);
+			const int mag = (int)sad_u32(m_1, u0, sad_u32(m_1, u1, sad_u32(m_1, u2, sad_u32(m_1, m_0, sad_u32(m_1, m_2, sad_u32(m_1, d0, sad_u32(m_1, d1, sad_u32(m_1, d2, 0u))))))));
+			const int base = 15 * iabs(sum) + mag;
+			const int vb = sum == 0 ? 0 : (sum < 0 ? -base : base);
+			if (c == W - 3) { a0 = m0; a1 = m1; v509 = vb; }
+			if (c == W - 2) { b0 = m0; b1 = m1; v510 = vb; }
+			fsm_step16(m0, m1, vb);
+			u0 = u1; u1 = u2; m_0 = m_1; m_1 = m_2; d0 = d1; d1 = d2; cs0 = cs1; cs1 = cs2;
 		}
-		seg[2 * t] = m0; seg[2 * t + 1] = m1;
-		{ uint64_t *go = (uint64_t *)((uint8_t *)segmaps + (size_t)img * g_stride) + 2 * (8 * (size_t)(32 * band + rl) + sg); go[0] = m0; go[1] = m1; }
-		if (sg == 7) {                                              /* flags per entry state of the last segment */
-			unsigned f = 0;
-			for (int e = 0; e < 16; e++) {
-				const int s509 = (int)(((e < 8 ? a0 : a1) >> (8 * (e & 7))) & 15), s510 = (int)(((e < 8 ? b0 : b1) >> (8 * (e & 7))) & 15);
-				const int k0 = v509 == 0 ? 0 : (v509 < 0 ? -((iabs(v509) + ((s509 + 2) >> 2)) >> 4) : ((iabs(v509) + ((s509 + 2) >> 2)) >> 4));
-				const int k1 = v510 == 0 ? 0 : (v510 < 0 ? -((iabs(v510) + ((s510 + 2) >> 2)) >> 4) : ((iabs(v510) + ((s510 + 2) >> 2)) >> 4));
-				f |= (unsigned)pair_big_flag_fwd(k0, k1) << e;
-			}
-			segflag[rl] = (uint16_t)f;
-		}
+		const uint64_t b = (a0 & 0xFF) * 0x0101010101010101ull;
+		if (a0 == b && a1 == b) break;                                /* merged before pixel 509: the rest of the row does not matter */
 	}
-	__syncthreads();
-	if (t < 32) {                                                   /* compose the 8 segment maps of a row */
-		const int row = 32 * band + t;
-		if (row >= 1 && row <= W - 2) {
-			uint8_t st[16], pre[16];
-			for (int e = 0; e < 16; e++) st[e] = (uint8_t)e;
-			for (int sg = 0; sg < 8; sg++) {
-				if (sg == 7) for (int e = 0; e < 16; e++) pre[e] = st[e];
-				const uint64_t m0 = seg[2 * (8 * t + sg)], m1 = seg[2 * (8 * t + sg) + 1];
-				for (int e = 0; e < 16; e++) { const int s = st[e]; st[e] = (uint8_t)(((s < 8 ? m0 : m1) >> (8 * (s & 7))) & 15); }
-			}
-			uint64_t o0 = 0, o1 = 0; unsigned f = 0;
-			for (int e = 0; e < 8; e++) { o0 |= (uint64_t)st[e] << (8 * e); o1 |= (uint64_t)st[8 + e] << (8 * e); }
-			for (int e = 0; e < 16; e++) f |= ((segflag[t] >> pre[e]) & 1u) << e;
-			uint64_t *mo = (uint64_t *)((uint8_t *)maps + (size_t)img * m_stride) + 2 * row;
-			mo[0] = o0; mo[1] = o1;
-			((uint16_t *)((uint8_t *)flags + (size_t)img * f_stride))[row] = (uint16_t)f;
-		}
+	unsigned f = 0;
+	for (int e = 0; e < 16; e++) {
+		const int s509 = (int)(((e < 8 ? a0 : a1) >> (8 * (e & 7))) & 15), s510 = (int)(((e < 8 ? b0 : b1) >> (8 * (e & 7))) & 15);
+		const int k0 = v509 == 0 ? 0 : (v509 < 0 ? -((iabs(v509) + ((s509 + 2) >> 2)) >> 4) : ((iabs(v509) + ((s509 + 2) >> 2)) >> 4));
+		const int k1 = v510 == 0 ? 0 : (v510 < 0 ? -((iabs(v510) + ((s510 + 2) >> 2)) >> 4) : ((iabs(v510) + ((s510 + 2) >> 2)) >> 4));
+		f |= (unsigned)pair_big_flag_fwd(k0, k1) << e;
 	}
+	uint64_t *mo = (uint64_t *)((uint8_t *)maps + (size_t)img * m_stride) + 2 * row;
+	mo[0] = m0; mo[1] = m1;
+	((uint16_t *)((uint8_t *)flags + (size_t)img * f_stride))[row] = (uint16_t)f;
 }
 
 /* one lane per image: entry state of the carry and hand-over flag for every row */
@@ -588,31 +571,13 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict_
 		uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 8 * o);
 		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 	}
-	uint64_t *segl = reinterpret_cast<uint64_t *>(kbuf);           /* kbuf is free until the contrast pass: it hosts the segment maps first */
-	if (PRE) {                                                     /* the rows' segment maps and entry states ride along with the luma rows */
-		for (int k = t; k < FB_TROWS * 16; k += FB_NT) {
-			const int row = t0 + (k >> 4);
-			if (row >= 1 && row <= W - 2) segl[k] = ((const uint64_t *)((const uint8_t *)segmaps + (size_t)img * g_stride))[16 * (size_t)row + (k & 15)];
-		}
+	if (PRE) {                                                     /* the rows' entry states ride along with the luma rows */
 		if (t < FB_TROWS && t0 + t >= 1 && t0 + t <= W - 2) stl[t] = (st + (size_t)img * s_stride)[t0 + t];
 	}
 	__syncthreads();
 	STAMP(1);
 
 	if (PRE) {
-		if (t < FB_TROWS) {                                        /* carry state at the start of every 64-pixel segment */
-			const int row = t0 + t;
-			if (row >= 1 && row <= W - 2) {
-				const uint64_t *gm = segl + 16 * t;
-				int sv = stl[t] & 15;
-				for (int sg = 0; sg < 8; sg++) {
-					entry[t * 8 + sg] = (uint8_t)sv;
-					const uint64_t w = gm[2 * sg + (sv >> 3)];
-					sv = (int)((w >> (8 * (sv & 7))) & 15);
-				}
-			}
-		}
-		__syncthreads();
 		/* items are (row, 8-pixel group) with the row index fastest: consecutive lanes sit one padded row (257
 		 * dwords) apart, i.e. on consecutive LDS banks */
 		for (int k = t; k < FB_TROWS * (W / 8); k += FB_NT) {        /* contrast, 8 pixels per item */
@@ -637,6 +602,34 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict_
 			}
 			uint32_t *d = reinterpret_cast<uint32_t *>(kbuf + rt * FB_RS + c0);
 			d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3];
+		}
+		__syncthreads();
+		/* Carry state at the start of every 64-pixel segment.  The 16-state carry forgets its past quickly (a step maps the 16 states
+		 * onto at most five neighbouring ones, a zero sum resets it): run all 16 states through the FB_LOOK pixels in front of the segment;
+		 * if they end in one state, that is the entry state whatever came before.  Where they do not (rare), the segment before is
+		 * replayed from its own entry state -- by then known -- so the result is exact in every case. */
+		for (int k = t; k < FB_TROWS * 8; k += FB_NT) {
+			const int rt = k % FB_TROWS, sg = k / FB_TROWS, row = t0 + rt;
+			if (row < 1 || row > W - 2) continue;
+			int e = stl[rt] & 15;
+			if (sg > 0) {
+				const int16_t *km = kbuf + rt * FB_RS + 1 + 64 * sg - FB_LOOK;
+				uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
+				for (int i = 0; i < FB_LOOK; i++) fsm_step16(m0, m1, km[i]);
+				const uint64_t b = (m0 & 0xFF) * 0x0101010101010101ull;
+				e = (m0 == b && m1 == b) ? (int)(m0 & 15) : 0xFF;
+			}
+			entry[rt * 8 + sg] = (uint8_t)e;
+		}
+		__syncthreads();
+		if (t < FB_TROWS && t0 + t >= 1 && t0 + t <= W - 2) {
+			for (int sg = 1; sg < 8; sg++) {
+				if (entry[t * 8 + sg] != 0xFF) continue;
+				const int16_t *km = kbuf + t * FB_RS + 1 + 64 * (sg - 1);
+				int carry = entry[t * 8 + sg - 1];
+				for (int i = 0; i < 64; i++) { const int vb = km[i]; carry = vb == 0 ? 0 : ((iabs(vb) + ((carry + 2) >> 2)) & 15); }
+				entry[t * 8 + sg] = (uint8_t)carry;
+			}
 		}
 		__syncthreads();
 		STAMP(2);
@@ -1072,7 +1065,7 @@ void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilte
 	}
 	const dim3 grid(H / FB_KB, n), rgrid(W / 32, n);               /* the row-map pass owns 32 rows per workgroup */
 	if (with_prefilter) {
-		k_front_rowmaps<<<rgrid, 256, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride, segmaps, g_stride);
+		k_front_rowtail<<<dim3((W - 2 + 63) / 64, n), 64, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride);
 		k_front_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, flags, f_stride, st, s_stride, n);
 		k_front_band<1><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
 	} else
