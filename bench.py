@@ -25,8 +25,8 @@ MPIX_PER_IMAGE = 0.262144
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 FRONT_BYTES_PER_IMAGE = 786432 + 786432   # 3 B/px read + 3 B/px written (Y coeffs + 2 x chroma)
 # HBM bytes of the front launch group per image from the PMC counters (profiles/round1_final_pmc.json, batch 4096, -q20: FETCH_SIZE x 2 per
-# the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc passes): k_color 3.62+2.68 GB, k_front_rowmaps 2.27+0.31, k_front_chain 0.04, k_front_band 2.91+3.22
-FRONT_PMC_BYTES_PER_IMAGE = (3.618e9 + 2.684e9 + 2.273e9 + 0.306e9 + 0.040e9 + 2.907e9 + 3.222e9) / 4096
+# the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc passes): k_color 3.62+2.68 GB, k_front_rowtail 0.28+0.04, k_front_chain 0.04, k_front_band 2.60+3.22
+FRONT_PMC_BYTES_PER_IMAGE = (3.618e9 + 2.684e9 + 0.276e9 + 0.040e9 + 0.040e9 + 2.600e9 + 3.224e9) / 4096
 
 
 def _cpu_worker(args):
@@ -95,7 +95,7 @@ def valu_evidence():
         if "SQ_INSTS_VALU" not in v or "GRBM_GUI_ACTIVE" not in v:
             continue
         name = k.split("::")[-1].split("<")[0].replace("void ", "")
-        if name not in ("k_color", "k_front_rowmaps", "k_front_band"):
+        if name not in ("k_color", "k_front_rowtail", "k_front_band"):
             continue
         cyc = v["GRBM_GUI_ACTIVE"]["per_launch"] / 8.0          # summed over the 8 XCDs
         valu = v["SQ_INSTS_VALU"]["per_launch"]
@@ -250,13 +250,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": f"batch of {batch} synthetic 512x512 BGR24 images per GPU, -q{q}, whole encoder (BGR in HBM -> .nhw bytes in HBM)",
                        "images_per_gpu": batch, "quality": q, "parallelism": f"dp{world} (independent images, no data-path collective)"},
-            "roofline": {"bound": "hbm", "kernel": "front = k_color + k_front_rowmaps + k_front_chain + k_front_band (colour, pre-filter and level-1 analysis; the band kernel fuses pre-filter + both filter directions)",
+            "roofline": {"bound": "hbm", "kernel": "front = k_color + k_front_rowtail + k_front_chain + k_front_band (colour, pre-filter and level-1 analysis; the band kernel fuses pre-filter + both filter directions)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": int(front_images * FRONT_PMC_BYTES_PER_IMAGE) if q == 20 else None, "traffic_unit": "bytes per launch group (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1_final_pmc.json, scaled from batch 4096)",
                          "kernels": [   # the members of the group, each with its own algorithmic bytes and live hipEvent time
                              {"kernel": "k_color (BGR24 -> Y int16 + 4:2:0 U,V)", "ms": round(color_ms / args.steps, 3), "algorithmic_bytes": front_images * (786432 + 524288 + 131072),
                               "achieved": round(front_images * (786432 + 524288 + 131072) / (color_ms / 1e3 / args.steps) / 1e9, 1), "frac": round(front_images * (786432 + 524288 + 131072) / (color_ms / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
-                             {"kernel": "k_front_rowmaps + k_front_chain + k_front_band (pre-filter + level-1 analysis)", "ms": round((front_ms - color_ms) / args.steps, 3), "algorithmic_bytes": front_images * (524288 + 786432),
+                             {"kernel": "k_front_rowtail + k_front_chain + k_front_band (pre-filter + level-1 analysis)", "ms": round((front_ms - color_ms) / args.steps, 3), "algorithmic_bytes": front_images * (524288 + 786432),
                               "achieved": round(front_images * (524288 + 786432) / ((front_ms - color_ms) / 1e3 / args.steps) / 1e9, 1), "frac": round(front_images * (524288 + 786432) / ((front_ms - color_ms) / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}],
                          "algorithmic_bytes_per_launch": front_images * FRONT_BYTES_PER_IMAGE, "images_per_launch": front_images, "sub_batches": tim.parts, "algorithmic_bytes_per_image": FRONT_BYTES_PER_IMAGE, "ms_per_launch_group": round(front_s * 1e3, 3)},
             "stage_ms": {"front": round(tim.front_ms, 3), "luma_tail": round(tim.luma_ms, 3), "chroma": round(tim.chroma_ms, 3),

@@ -550,7 +550,6 @@ __device__ unsigned long long g_band_stamp[16];
 
 template <int PRE>
 __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict__ yb, size_t y_stride, const uint8_t *__restrict__ st, size_t s_stride,
-                                                    const uint64_t *__restrict__ segmaps, size_t g_stride,
                                                     int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
                                                     int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride)
 {
@@ -1053,7 +1052,7 @@ void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stri
 /* fused pre-filter + level-1 analysis (+ LL copy-back, ll1, keep): replaces nhw_launch_prefilter + the size-512 nhw_launch_analysis
  * + the ll1 block copy of the batch driver */
 void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilter, uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
-                            uint64_t *segmaps, size_t g_stride, uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
+                            uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
                             int16_t *keep, size_t keep_stride, int n, hipStream_t s)
 {
 	const size_t lds = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
@@ -1063,13 +1062,13 @@ void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilte
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		attr_set = true;
 	}
-	const dim3 grid(H / FB_KB, n), rgrid(W / 32, n);               /* the row-map pass owns 32 rows per workgroup */
+	const dim3 grid(H / FB_KB, n);
 	if (with_prefilter) {
 		k_front_rowtail<<<dim3((W - 2 + 63) / 64, n), 64, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride);
 		k_front_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, flags, f_stride, st, s_stride, n);
-		k_front_band<1><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
+		k_front_band<1><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
 	} else
-		k_front_band<0><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, segmaps, g_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
+		k_front_band<0><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
 }
 
 /* Compatibility mode (NHW_COMPAT_GLIBC_ONESHOT) only: the kernel-map cells whose memory the stock binary's malloc hands out again as
