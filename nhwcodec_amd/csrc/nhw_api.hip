@@ -23,7 +23,7 @@ void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stri
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
 void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilter, uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
                             uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
-                            int16_t *keep, size_t keep_stride, int n, hipStream_t s);
+                            int16_t *keep, size_t keep_stride, int n, hipStream_t s, int force_fallback);
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s);
 void nhw_launch_front_stale(const int16_t *y, size_t y_stride, const uint8_t *st, size_t s_stride, int16_t *stale, size_t stale_stride, int n, hipStream_t s);
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s);
@@ -50,6 +50,7 @@ struct nhw_enc {
 	uint8_t *d_in, *d_out, *d_compact;
 	uint32_t *d_sizes; int32_t *d_status; uint64_t *d_offs;
 	int conv_cap;
+	int front_fallback; /* debug: every row / segment of the pre-filter carry takes its exact fallback path (tests) */
 	int legacy_front; /* debug: separate pre-filter / analysis kernels instead of the fused band kernel */
 	int stop_after;   /* debug: leave the batch driver after this many stages (0 = run everything) */
 };
@@ -169,7 +170,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	} else {
 		nhw_launch_front_fused(yin, yin_stride, q < 22, (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
 		                       plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2,
-		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s);
+		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s, e->front_fallback);
 		if (ws.compat && q < 22)   /* the kernel-map cells the stock binary's heap re-uses (compatibility mode only) */
 			nhw_launch_front_stale(yin, yin_stride, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], plane16(ws, B_STALE), ws.stride[B_STALE], n, s);
 		if (q < 22) STAGE_DONE();
@@ -406,6 +407,7 @@ extern "C" int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n
 /* ------------------------------------------------------------------------------------------------ debug hooks (tests only) */
 void nhw_debug_band_stamps(unsigned long long *out);
 extern "C" int nhw_debug_stamps(unsigned long long *out) { (void)hipDeviceSynchronize(); nhw_debug_band_stamps(out); return NHW_OK; }
+extern "C" int nhw_debug_front_fallback(nhw_enc *e, int on) { if (!e) return NHW_E_ARG; e->front_fallback = on; return NHW_OK; }
 extern "C" int nhw_debug_legacy_front(nhw_enc *e, int on) { if (!e) return NHW_E_ARG; e->legacy_front = on; return NHW_OK; }
 extern "C" int nhw_debug_stop_after(nhw_enc *e, int stage) { if (!e) return NHW_E_ARG; e->stop_after = stage; return NHW_OK; }
 /* developer hook: order-independent 64-bit digest of the first `bytes` bytes of workspace buffer `buf`, one per image, into device memory */

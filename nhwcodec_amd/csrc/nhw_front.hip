@@ -464,7 +464,7 @@ __device__ __forceinline__ int contrast_at(const int16_t *p /* LDS, row stride F
  * (rare) the lane walks the whole row.  One lane per row. */
 #define RT_LOOK 24
 __global__ __launch_bounds__(64) void k_front_rowtail(const int16_t *__restrict__ yb, size_t y_stride, uint64_t *__restrict__ maps, size_t m_stride,
-                                                      uint16_t *__restrict__ flags, size_t f_stride)
+                                                      uint16_t *__restrict__ flags, size_t f_stride, int force_full)
 {
 	__shared__ __attribute__((aligned(16))) int16_t tail[66][40];      /* rows r0-1 .. r0+64, columns 480..511 (+ padding: 80-byte rows) */
 	const int img = blockIdx.y, r0 = 1 + blockIdx.x * 64, row = r0 + threadIdx.x;
@@ -480,17 +480,15 @@ __global__ __launch_bounds__(64) void k_front_rowtail(const int16_t *__restrict_
 	const int16_t *y = yi + (size_t)row * W;
 	uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
 	int v509 = 0, v510 = 0;
-	for (int pass = 0; pass < 2; pass++) {
+	/* the walk over columns c .. W-2 of one row; p[0] is column `co` of that row, rs the row stride of the buffer p points into */
+	auto walk = [&](const int16_t *p, const int rs, int c, const int co) {
 		m0 = 0x0706050403020100ull; m1 = 0x0F0E0D0C0B0A0908ull;
-		int c = pass ? 1 : W - 3 - RT_LOOK;
-		/* pass 0 reads the staged tail (LDS column = c - 480), the rare pass 1 the row itself; stride and base differ, the walk does not */
-		const int16_t *p = pass ? y : &tail[threadIdx.x + 1][0] - 480;
-		const int rs = pass ? W : 40;
+		int i = c - co;
 		/* 3x3 window slides along the row: three new reads per pixel */
-		int u0 = p[-rs + c - 1], u1 = p[-rs + c], m_0 = p[c - 1], m_1 = p[c], d0 = p[rs + c - 1], d1 = p[rs + c];
+		int u0 = p[-rs + i - 1], u1 = p[-rs + i], m_0 = p[i - 1], m_1 = p[i], d0 = p[rs + i - 1], d1 = p[rs + i];
 		int cs0 = u0 + m_0 + d0, cs1 = u1 + m_1 + d1;
-		for (; c <= W - 2; c++) {
-			const int u2 = p[-rs + c + 1], m_2 = p[c + 1], d2 = p[rs + c + 1];
+		for (; c <= W - 2; c++, i++) {
+			const int u2 = p[-rs + i + 1], m_2 = p[i + 1], d2 = p[rs + i + 1];
 			const int cs2 = u2 + m_2 + d2;
 			const int sum = 9 * m_1 - (cs0 + cs1 + cs2);
 			const int mag = (int)sad_u32(m_1, u0, sad_u32(m_1, u1, sad_u32(m_1, u2, sad_u32(m_1, m_0, sad_u32(m_1, m_2, sad_u32(m_1, d0, sad_u32(m_1, d1, sad_u32(m_1, d2, 0u))))))));
@@ -502,8 +500,13 @@ __global__ __launch_bounds__(64) void k_front_rowtail(const int16_t *__restrict_
 			u0 = u1; u1 = u2; m_0 = m_1; m_1 = m_2; d0 = d1; d1 = d2; cs0 = cs1; cs1 = cs2;
 		}
 		const uint64_t b = (a0 & 0xFF) * 0x0101010101010101ull;
-		if (a0 == b && a1 == b) break;                                /* merged before pixel 509: the rest of the row does not matter */
-	}
+		return a0 == b && a1 == b;                                    /* merged before pixel 509: the rest of the row does not matter */
+	};
+	/* first the staged tail (LDS, columns 480..511); the rare row whose carry has not merged by pixel 509 walks the whole row in HBM.
+	 * force_full is a test switch that sends every row down that fallback.  Two call sites so that each keeps its own address space. */
+	bool merged = false;
+	if (!force_full) merged = walk(&tail[threadIdx.x + 1][4], 40, W - 3 - RT_LOOK, 484);
+	if (!merged) walk(y + 1, W, 1, 1);
 	unsigned f = 0;
 	for (int e = 0; e < 16; e++) {
 		const int s509 = (int)(((e < 8 ? a0 : a1) >> (8 * (e & 7))) & 15), s510 = (int)(((e < 8 ? b0 : b1) >> (8 * (e & 7))) & 15);
@@ -551,7 +554,7 @@ __device__ unsigned long long g_band_stamp[16];
 template <int PRE>
 __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict__ yb, size_t y_stride, const uint8_t *__restrict__ st, size_t s_stride,
                                                     int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
-                                                    int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride)
+                                                    int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride, int force_fixup)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	__shared__ uint8_t entry[FB_TROWS * 8];
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict_
 				uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
 				for (int i = 0; i < FB_LOOK; i++) fsm_step16(m0, m1, km[i]);
 				const uint64_t b = (m0 & 0xFF) * 0x0101010101010101ull;
-				e = (m0 == b && m1 == b) ? (int)(m0 & 15) : 0xFF;
+				e = (m0 == b && m1 == b && !force_fixup) ? (int)(m0 & 15) : 0xFF;   /* force_fixup: test switch, every segment takes the exact replay */
 			}
 			entry[rt * 8 + sg] = (uint8_t)e;
 		}
@@ -1053,7 +1056,7 @@ void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stri
  * + the ll1 block copy of the batch driver */
 void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilter, uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
                             uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
-                            int16_t *keep, size_t keep_stride, int n, hipStream_t s)
+                            int16_t *keep, size_t keep_stride, int n, hipStream_t s, int force_fallback)
 {
 	const size_t lds = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
 	static bool attr_set = false;
@@ -1064,11 +1067,11 @@ void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilte
 	}
 	const dim3 grid(H / FB_KB, n);
 	if (with_prefilter) {
-		k_front_rowtail<<<dim3((W - 2 + 63) / 64, n), 64, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride);
+		k_front_rowtail<<<dim3((W - 2 + 63) / 64, n), 64, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride, force_fallback);
 		k_front_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, flags, f_stride, st, s_stride, n);
-		k_front_band<1><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
+		k_front_band<1><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback);
 	} else
-		k_front_band<0><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride);
+		k_front_band<0><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, 0);
 }
 
 /* Compatibility mode (NHW_COMPAT_GLIBC_ONESHOT) only: the kernel-map cells whose memory the stock binary's malloc hands out again as

@@ -388,3 +388,23 @@ def test_compat_mode_matches_oracle_and_stock_binary(oracle, q):
             assert len(stock) == len(got[i])
             pad = uninitialised_positions(stock)
             assert [k for k in range(len(stock)) if stock[k] != got[i][k] and k not in pad] == [], f"image {i}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [17, 20, 21])
+def test_front_fallback_paths_are_exact(oracle, q):
+    """The pre-filter's carry normally comes from a short look-back (its 16 states merge within a dozen pixels); where they have not merged, a
+    row is walked in full (k_front_rowtail) and a segment is replayed from the one before (k_front_band).  Those paths are rare on real
+    content, so a debug switch sends every row and every segment down them: the output must not change."""
+    import nhwcodec_amd
+    enc = nhwcodec_amd.Encoder(0, 32)
+    imgs = np.stack([oracle.synth(40 + i) for i in range(20)] + [class_image(k, s) for k in ("noise", "blocks", "tiles", "gradient") for s in (1, 2)])
+    enc.lib.nhw_debug_front_fallback.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert enc.lib.nhw_debug_front_fallback(enc.h, 1) == 0
+    forced = enc.encode(imgs, q)
+    assert enc.lib.nhw_debug_front_fallback(enc.h, 0) == 0
+    normal = enc.encode(imgs, q)
+    enc.close()
+    assert forced == normal
+    bad = [i for i in range(len(imgs)) if forced[i] != oracle.encode(imgs[i], q)]
+    assert not bad, f"q{q}: images {bad} differ from the oracle on the fallback paths"
