@@ -49,7 +49,9 @@ typedef struct {
 	float total_ms;
 	float front_ms;       /* colour + pre-filter + level-1 analysis (the HBM-roofline kernels) */
 	float color_dwt_ms;   /* the colour + 4:2:0 kernel alone, the first kernel of the front group */
-	float luma_ms, chroma_ms, entropy_ms;
+	float luma_ms;        /* luma tail; the chroma sequence runs next to it on a stream of its own (NHW_CHROMA_FORK=0: behind it) */
+	float chroma_ms;      /* what is left of the chroma sequence once the luma tail is done (about 0 when it is hidden; its full time with NHW_CHROMA_FORK=0) */
+	float entropy_ms;
 	int parts;            /* sub-batches the stages behind the front ran as (each on a stream of its own); with more than one, luma/chroma/entropy_ms are those of the first */
 	int front_images;     /* images covered by front_ms */
 } nhw_timing;

@@ -50,6 +50,7 @@ struct nhw_enc {
 	uint8_t *d_in, *d_out, *d_compact;
 	uint32_t *d_sizes; int32_t *d_status; uint64_t *d_offs;
 	int conv_cap;
+	int chroma_fork;  /* the chroma sequence on a stream of its own next to the luma tail (NHW_CHROMA_FORK=0 turns it off) */
 	int front_fallback; /* debug: every row / segment of the pre-filter carry takes its exact fallback path (tests) */
 	int legacy_front; /* debug: separate pre-filter / analysis kernels instead of the fused band kernel */
 	int stop_after;   /* debug: leave the batch driver after this many stages (0 = run everything) */
@@ -104,6 +105,8 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 	for (int i = 0; i < 4; i++) HIPCHK(hipStreamCreateWithFlags(&e->part_stream[i], hipStreamNonBlocking));
 	for (int i = 0; i < 5; i++) HIPCHK(hipEventCreateWithFlags(&e->part_ev[i], hipEventDisableTiming));
 	e->parts = 1;   /* sub-batches on streams of their own (NHW_PARTS=2..4) bought 4 % while the tail kernels were latency-bound; they no longer do */
+	e->chroma_fork = 1;
+	if (const char *p = getenv("NHW_CHROMA_FORK")) e->chroma_fork = atoi(p) != 0;
 	if (const char *p = getenv("NHW_PARTS")) { const int k = atoi(p); if (k >= 1 && k <= 4) e->parts = k; }
 	*out = e;
 	return NHW_OK;
@@ -143,7 +146,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	uint8_t *out = (uint8_t *)d_out;
 
 	int stage = 0;
-#define STAGE_DONE() do { if (e->stop_after && ++stage == e->stop_after) { HIPCHK(hipGetLastError()); return NHW_OK; } } while (0)
+#define STAGE_DONE() do { if (e->stop_after && ++stage == e->stop_after) { HIPCHK(hipGetLastError()); return NHW_OK; } } while (0)   
 	(void)n;
 	if (what & 1) {
 	if (timed == 1) HIPCHK(hipEventRecord(e->ev[0], s));
@@ -180,6 +183,44 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	if (timed == 1) HIPCHK(hipEventRecord(e->ev[1], s));
 	if (!(what & 2)) { HIPCHK(hipGetLastError()); return NHW_OK; }
 	}
+	/* The chroma sequence needs nothing of the luma tail except the length of the exception list (its own entries go behind the
+	 * luma ones, Y15) and, for q > 21, the band plane that Y29 is done with: it runs on a stream of its own next to the luma tail
+	 * and fills the issue slots the latency-bound luma kernels leave.  U and V share their planes, so they stay in sequence. */
+	const bool fork = timed == 1 && what == 3 && !e->stop_after && e->chroma_fork;
+	hipStream_t cs = fork ? e->part_stream[0] : s;
+	auto chroma_head = [&](int comp) -> int {                        /* everything up to the second dequantiser simulation */
+		nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, cs);
+		STAGE_DONE();
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, nullptr, 0, cs, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2);   /* + the copy of LL1 */
+		STAGE_DONE();
+		STAGE_DONE();
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, cs);
+		STAGE_DONE();
+		nhw_launch_phase(PH_C2, ws, comp, out, d_sizes, d_status, cs);
+		STAGE_DONE();
+		nhw_launch_synthesis(cjpeg, cproc, n, cps, H, H / 2, cs);
+		STAGE_DONE();
+		nhw_launch_phase(PH_C3, ws, comp, out, d_sizes, d_status, cs);
+		STAGE_DONE();
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, cs, plane16(ws, B_CL2SAVE), ws.stride[B_CL2SAVE] / 2, H / 2, 1);   /* + the copy of the level-2 block */
+		STAGE_DONE();
+		STAGE_DONE();
+		nhw_launch_phase(PH_C4, ws, comp, out, d_sizes, d_status, cs);
+		STAGE_DONE();
+		nhw_launch_synthesis(cjpeg, cproc, n, cps, H, H / 2, cs);
+		STAGE_DONE();
+		return 1;
+	};
+	auto chroma_tail = [&](int comp) -> int {                        /* marks, LL2 emission (appends to the exception list), quantiser, stream bytes */
+		nhw_launch_phase(PH_C5, ws, comp, out, d_sizes, d_status, cs);
+		STAGE_DONE();
+		return 1;
+	};
+#define CHROMA(call) do { const int rc_ = (call); if (rc_ != 1) return rc_; } while (0)   /* 1 = carry on; NHW_OK (debug stop) or an error leaves */
+	if (fork) {
+		HIPCHK(hipStreamWaitEvent(cs, e->ev[1], 0));                 /* behind the front launch group: that one is bound by vector issue and has nothing to give (and its time is the roofline figure) */
+		CHROMA(chroma_head(0));
+	}
 	/* Y4: level-2 analysis (:139) */
 	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
 	STAGE_DONE();
@@ -195,6 +236,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	STAGE_DONE();
 	nhw_launch_wave(WV_EMIT, ws, s);                                 /* Y14, Y15 */
 	nhw_launch_phase(PH_L3, ws, 0, out, d_sizes, d_status, s);
+	if (fork && q <= 21) HIPCHK(hipEventRecord(e->part_ev[0], s));   /* exception list of the luma plane complete */
 	nhw_launch_wave(WV_DQ0, ws, s);
 	STAGE_DONE();
 	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s);
@@ -204,34 +246,25 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	nhw_launch_phase(PH_L4C, ws, 0, out, d_sizes, d_status, s);      /* Y26, Y27 */
 	nhw_launch_wave(WV_QUANT, ws, s);                                /* Y28 */
 	if (q > 21) nhw_launch_phase(PH_L4C2, ws, 0, out, d_sizes, d_status, s);   /* Y29 */
+	if (fork && q > 21) HIPCHK(hipEventRecord(e->part_ev[0], s));    /* ... and the band plane free */
+	if (fork) {                                                      /* queued here so that the wait finds its event recorded */
+		HIPCHK(hipStreamWaitEvent(cs, e->part_ev[0], 0));
+		CHROMA(chroma_tail(0));
+		CHROMA(chroma_head(1));
+		CHROMA(chroma_tail(1));
+		HIPCHK(hipEventRecord(e->part_ev[1], cs));
+	}
 	nhw_launch_phase(PH_L4D, ws, 0, out, d_sizes, d_status, s);      /* Y30, Y31 */
 	STAGE_DONE();
 	if (timed) HIPCHK(hipEventRecord(e->ev[2], s));
 
-	for (int comp = 0; comp < 2; comp++) {           /* U then V (:2255-2570, :2572-2868) */
-		nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, s);
-		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, nullptr, 0, s, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2);   /* + the copy of LL1 */
-		STAGE_DONE();
-		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, s);
-		STAGE_DONE();
-		nhw_launch_phase(PH_C2, ws, comp, out, d_sizes, d_status, s);
-		STAGE_DONE();
-		nhw_launch_synthesis(cjpeg, cproc, n, cps, H, H / 2, s);
-		STAGE_DONE();
-		nhw_launch_phase(PH_C3, ws, comp, out, d_sizes, d_status, s);
-		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, s, plane16(ws, B_CL2SAVE), ws.stride[B_CL2SAVE] / 2, H / 2, 1);   /* + the copy of the level-2 block */
-		STAGE_DONE();
-		STAGE_DONE();
-		nhw_launch_phase(PH_C4, ws, comp, out, d_sizes, d_status, s);
-		STAGE_DONE();
-		nhw_launch_synthesis(cjpeg, cproc, n, cps, H, H / 2, s);
-		STAGE_DONE();
-		nhw_launch_phase(PH_C5, ws, comp, out, d_sizes, d_status, s);
-		STAGE_DONE();
-	}
+	if (fork) HIPCHK(hipStreamWaitEvent(s, e->part_ev[1], 0));
+	else
+		for (int comp = 0; comp < 2; comp++) {       /* U then V (:2255-2570, :2572-2868) */
+			CHROMA(chroma_head(comp));
+			CHROMA(chroma_tail(comp));
+		}
+#undef CHROMA
 	if (timed) HIPCHK(hipEventRecord(e->ev[3], s));
 	nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, s);     /* Z1 */
 	nhw_launch_phase(PH_FINAL, ws, 0, out, d_sizes, d_status, s);   /* Z2, container */

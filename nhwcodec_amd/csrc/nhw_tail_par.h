@@ -1043,14 +1043,13 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 		}
 		BARRIER();
 	}
-	if (tid < 4) reinterpret_cast<uint32_t *>(s + n)[tid] = 0;     /* im_nhw is calloc'ed: bytes behind the luma part read 0 here */
 	if (tid == 0) { sh_counts[0] = 0; sh_counts[1] = 0; }
 	BARRIER();
 
 	/* The three rewrites read 16 stream bytes per thread and step (48-byte register window: 16 before, 16 own,
 	 * 16 after), so a wavefront touches 1 KiB of consecutive memory per load instruction. */
 #define WIN_LOAD(w, base) do { const uint4 a_ = *reinterpret_cast<const uint4 *>(s + (base) - 16), b_ = *reinterpret_cast<const uint4 *>(s + (base)), \
-		c_ = *reinterpret_cast<const uint4 *>(s + (base) + 16); \
+		c_ = (base) + 16 < n ? *reinterpret_cast<const uint4 *>(s + (base) + 16) : make_uint4(0, 0, 0, 0);   /* im_nhw is calloc'ed and the chroma part not yet written when the reference is here: bytes behind the luma part read 0 (the chroma sequence may be writing them on its own stream) */ \
 		w[0] = a_.x; w[1] = a_.y; w[2] = a_.z; w[3] = a_.w; w[4] = b_.x; w[5] = b_.y; w[6] = b_.z; w[7] = b_.w; w[8] = c_.x; w[9] = c_.y; w[10] = c_.z; w[11] = c_.w; } while (0)
 #define WB(w, k) ((int)(((w)[((k) + 16) >> 2] >> (8 * (((k) + 16) & 3))) & 0xFF))      /* byte at base + k, -16 <= k < 32 */
 #define PM8(v) ((v) == 136 || (v) == 120)
@@ -1140,7 +1139,7 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 			/* run [i, b]: walk to the end of the 16-byte group, hop over all-zero groups with the bitmap, finish bytewise */
 			int b = i + 1;
 			while (((b + 1) & 15) && s[b + 1] == 128) b++;
-			if (!((b + 1) & 15) && s[b + 1] == 128) {
+			if (!((b + 1) & 15) && b + 1 < n && s[b + 1] == 128) {
 				int g2 = (b + 1) >> 4;                             /* first group not yet examined */
 				for (;;) {
 					const uint32_t inv = ~(sh_z[g2 >> 5] >> (g2 & 31));
@@ -1154,11 +1153,11 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 			}
 			/* the reference's walk (:2222-2252) fires every 254 cells from i+255 on, then once at the end: closed form */
 			if (b - i >= 256)
-				for (int kk = i + 255; kk + 1 <= b; kk += 254) for (int u = 0; u < 4; u++) fix_sign_code(s, kk + u);
+				for (int kk = i + 255; kk + 1 <= b; kk += 254) for (int u = 0; u < 4; u++) if (kk + u < n) fix_sign_code(s, kk + u);
 			{
 				const int fired = b - i >= 256 ? (b - i - 256) / 254 + 1 : 0;
 				const int tail_run = fired ? b - (i + 255 + 254 * (fired - 1)) + 1 : b - i;
-				if (tail_run >= 252) fix_sign_code(s, b + 1);
+				if (tail_run >= 252 && b + 1 < n) fix_sign_code(s, b + 1);
 			}
 		}
 	}
