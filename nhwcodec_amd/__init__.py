@@ -84,7 +84,8 @@ class Encoder:
 
     def synth_device(self, n: int, seed_base: int = 0):
         t = self.torch.empty((n, 512, 512, 3), dtype=self.torch.uint8, device=f"cuda:{self.device}")
-        self._chk(self.lib.nhw_synth_batch_device(self.h, t.data_ptr(), n, seed_base, self._stream()))
+        with _OnTorchStream(self) as st:
+            self._chk(self.lib.nhw_synth_batch_device(self.h, t.data_ptr(), n, seed_base, st))
         return t
 
     def alloc_out(self, n: int):
@@ -100,7 +101,8 @@ class Encoder:
         if out is None:
             out = self.alloc_out(n)
         o, sizes, status = out
-        self._chk(self.lib.nhw_enc_batch_device(self.h, bgr.data_ptr(), n, quality, o.data_ptr(), sizes.data_ptr(), status.data_ptr(), self._stream()))
+        with _OnTorchStream(self) as st:
+            self._chk(self.lib.nhw_enc_batch_device(self.h, bgr.data_ptr(), n, quality, o.data_ptr(), sizes.data_ptr(), status.data_ptr(), st))
         return o, sizes, status
 
     def encode(self, images, quality: int = QUALITY_DEFAULT):
@@ -120,6 +122,32 @@ class Encoder:
         t = Timing()
         self._chk(self.lib.nhw_enc_last_timing(self.h, ctypes.byref(t)))
         return t
+
+
+class _OnTorchStream:
+    """Stream-ordered launch next to torch: the C ABI takes a hipStream_t and reads NULL as "the handle's own stream", which torch's
+    default stream (handle 0) would select by accident.  On the default stream the work goes to a side stream that waits for it
+    and that it waits for afterwards, so callers see ordinary stream semantics either way."""
+
+    def __init__(self, owner):
+        self.o = owner
+
+    def __enter__(self):
+        t, o = self.o.torch, self.o
+        self.cur = t.cuda.current_stream(o.device)
+        if self.cur.cuda_stream != 0:
+            self.side = None
+            return self.cur.cuda_stream
+        if getattr(o, "_side", None) is None:
+            o._side = t.cuda.Stream(o.device)
+        self.side = o._side
+        self.side.wait_stream(self.cur)
+        return self.side.cuda_stream
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.cur.wait_stream(self.side)
+        return False
 
 
 class DecTiming(ctypes.Structure):
@@ -188,8 +216,9 @@ class Decoder:
             out = t.empty((n, 512, 512, 3), dtype=t.uint8, device=dev)
         status = t.empty(n, dtype=t.int32, device=dev)
         quality = t.empty(n, dtype=t.int32, device=dev)
-        self._chk(self.lib.nhw_dec_batch_device(self.h, arena.data_ptr(), offsets.data_ptr(), lengths.data_ptr(), n, out.data_ptr(), status.data_ptr(),
-                                                quality.data_ptr(), t.cuda.current_stream(self.device).cuda_stream))
+        with _OnTorchStream(self) as st:
+            self._chk(self.lib.nhw_dec_batch_device(self.h, arena.data_ptr(), offsets.data_ptr(), lengths.data_ptr(), n, out.data_ptr(), status.data_ptr(),
+                                                    quality.data_ptr(), st))
         return out, status, quality
 
     def decode(self, files):

@@ -1005,11 +1005,6 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 	/* LL2 samples (:618-625) */
 	const uint8_t *ll = ws.buf<uint8_t>(D_LL, img);
 	for (int k = lane; k < DQ / 4; k += 64) a[(size_t)(k >> 7) * DW + (k & 127)] = ll[k];
-	for (int c = 0; c < 2; c++) {
-		int16_t *ca = plane_ca(ws, img, c);
-		const uint8_t *l = ll + DQ / 4 + (c ? DQ / 16 : 0);
-		for (int k = lane; k < DQ / 16; k += 64) ca[(size_t)(k >> 6) * DH + (k & 63)] = (int16_t)(l[k] + (q > 15 ? 0 : 1));
-	}
 	wave_sync();
 	if (!lane) {
 		if (q > 17) {                                              /* odd-LL tags (:627-654) */
@@ -1023,16 +1018,43 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 				if (v > 128) rowi++;
 			}
 		}
-		/* exception samples: luma, then U, then V share one cursor (:656-668, :965-981, :1255-1267) */
+		/* exception samples of the luma plane (:656-668); U and V follow on the same cursor (k_dec_expand_chroma) */
 		const uint8_t *x = f + m->o_exw;
 		const int n = m->exw_len;
 #define XB(k) ((k) < n ? (int)x[k] : 0)
-		int i = 0;
-		for (; i < n; i += 3) {
+		for (int i = 0; i < n; i += 3) {
 			if (!XB(i) && !XB(i + 1)) break;
 			const int hi = XB(i + 1) >= 128, lo = XB(i + 1) & 127;
 			a[(XB(i) << 9) + lo] = (int16_t)(hi ? XB(i + 2) + 255 : -XB(i + 2));
 		}
+#undef XB
+	}
+}
+
+/* The chroma side of the expansion: LL2 samples (:943-963, :1231-1253) and exception samples (:965-981, :1255-1267) of U and V.  A kernel of
+ * its own so that the chroma sequence can run next to the luma one: it touches nothing the luma kernels write.  One wavefront per image. */
+__global__ __launch_bounds__(256) void k_dec_expand_chroma(DecWs ws)
+{
+	const int img = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (img >= ws.n) return;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status) return;
+	const int q = m->q;
+	const uint8_t *f = ws.blob + ws.blob_off[img];
+	const uint8_t *ll = ws.buf<uint8_t>(D_LL, img);
+	for (int c = 0; c < 2; c++) {
+		int16_t *ca = plane_ca(ws, img, c);
+		const uint8_t *l = ll + DQ / 4 + (c ? DQ / 16 : 0);
+		for (int k = lane; k < DQ / 16; k += 64) ca[(size_t)(k >> 6) * DH + (k & 63)] = (int16_t)(l[k] + (q > 15 ? 0 : 1));
+	}
+	wave_sync();
+	if (!lane) {
+		/* luma, then U, then V share one cursor: skip the luma entries up to their terminator */
+		const uint8_t *x = f + m->o_exw;
+		const int n = m->exw_len;
+#define XB(k) ((k) < n ? (int)x[k] : 0)
+		int i = 0;
+		for (; i < n; i += 3) if (!XB(i) && !XB(i + 1)) break;
 		int16_t *cu = plane_ca(ws, img, 0), *cv = plane_ca(ws, img, 1);
 		i += 2;
 		for (; i < n; i += 3) {
@@ -1415,6 +1437,9 @@ struct nhw_dec {
 	DecWs ws;
 	size_t slab_bytes;
 	hipStream_t own_stream;
+	hipStream_t chroma_stream;   /* the chroma sequence runs here, next to the luma one (NHW_CHROMA_FORK=0: behind it, on the caller's stream) */
+	hipEvent_t fork_ev, join_ev;
+	int chroma_fork;
 	int stop_after;
 	hipEvent_t ev[8];         /* start, after the entropy stages, around the two level-1 luma synthesis passes, around the colour kernel, end */
 	bool timed;
@@ -1436,6 +1461,11 @@ extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
 	HIPCHK(hipMalloc(&d->ws.base, at));
 	HIPCHK(hipMemset(d->ws.base, 0, at));
 	HIPCHK(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&d->chroma_stream, hipStreamNonBlocking));
+	HIPCHK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&d->join_ev, hipEventDisableTiming));
+	d->chroma_fork = 1;
+	if (const char *p = getenv("NHW_CHROMA_FORK")) d->chroma_fork = atoi(p) != 0;
 	for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&d->ev[i]));
 	*out = d;
 	return NHW_OK;
@@ -1453,6 +1483,9 @@ extern "C" void nhw_dec_destroy(nhw_dec *d)
 	if (d->d_status) (void)hipFree(d->d_status);
 	if (d->d_quality) (void)hipFree(d->d_quality);
 	if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
+	if (d->chroma_stream) (void)hipStreamDestroy(d->chroma_stream);
+	if (d->fork_ev) (void)hipEventDestroy(d->fork_ev);
+	if (d->join_ev) (void)hipEventDestroy(d->join_ev);
 	for (int i = 0; i < 8; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
 	delete d;
 }
@@ -1477,6 +1510,8 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	ws.n = n; ws.blob = (const uint8_t *)d_nhw; ws.blob_off = d_off; ws.blob_len = d_len;
 	int stage = 0;
 	d->timed = false;
+	const bool fork = d->chroma_fork && !d->stop_after;
+	hipStream_t cs = fork ? d->chroma_stream : s;
 #define STAGE_END() do { if (d->stop_after && ++stage >= d->stop_after) goto done; } while (0)
 #define EV(i) HIPCHK(hipEventRecord(d->ev[i], s))
 	EV(0);
@@ -1489,7 +1524,23 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	k_dec_unzig<<<dim3(80, n), 256, 0, s>>>(ws);
 	EV(1);
 	STAGE_END();                                                                  /* 2 */
+	/* From here the luma and the chroma sequences share nothing until the colour kernel: chroma goes to a stream of its own, where its
+	 * bandwidth-bound kernels run under the latency-bound luma ones (the expansion walk, the marks chain).  With the debug stop it stays in line. */
+	if (fork) { HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0)); }
 	k_dec_expand<<<(n + 3) / 4, 256, 0, s>>>(ws);
+	k_dec_expand_chroma<<<(n + 3) / 4, 256, 0, cs>>>(ws);
+	if (fork) {
+		/* chroma, both planes per launch (blockIdx.z) */
+		SynthArgs a1 = { D_CA, D_CB, -1, DH, DH / 2, DH / 2, 0, 0, 0 }, a2 = { D_CB, D_CA, -1, DH, DH / 2, DH / 2, DH / 2, 1, 1 };
+		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, cs>>>(ws, a1);
+		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, cs>>>(ws, a2);
+		k_dec_cpairs<<<dim3(DH, n, 2), 256, 0, cs>>>(ws);
+		SynthArgs b1 = { D_CA, D_CB, -1, DH, DH, DH, DH / 2, 0, 0 }, b2 = { D_CB, D_CA, -1, DH, DH, DH, DH, 1, 1 };
+		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, cs>>>(ws, b1);
+		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, cs>>>(ws, b2);
+		k_dec_sharpen<<<(2 * n + 3) / 4, 256, 0, cs>>>(ws);
+		HIPCHK(hipEventRecord(d->join_ev, cs));
+	}
 	STAGE_END();                                                                  /* 3 */
 	k_dec_shrink<<<dim3(DH - 2, n), 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 4 */
@@ -1521,7 +1572,8 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 		EV(5);
 	}
 	STAGE_END();                                                                  /* 10 */
-	{
+	if (fork) HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
+	else {
 		/* chroma, both planes per launch (blockIdx.z) */
 		SynthArgs a1 = { D_CA, D_CB, -1, DH, DH / 2, DH / 2, 0, 0, 0 }, a2 = { D_CB, D_CA, -1, DH, DH / 2, DH / 2, DH / 2, 1, 1 };
 		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, s>>>(ws, a1);
