@@ -668,10 +668,21 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 	__shared__ __attribute__((aligned(16))) uint32_t cw[2][VCH_WORDS + 4];
 	__shared__ uint16_t syms[2][VCH_SYMS];
 	__shared__ __attribute__((aligned(16))) uint8_t scr[2][1440];
+	/* The kernel runs next to k_dec_parse on a stream of its own, so it reads the file header itself (a few dozen bytes) instead of the
+	 * workspace copy, and reports into a word of its own (D_SPARE[0]) that k_dec_verdict folds into the file's status. */
+	__shared__ DecMeta hm;
 	const int img = blockIdx.x, part = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	DecMeta *m = ws.buf<DecMeta>(D_META, img);
-	if (m->status) return;
 	const uint8_t *f = ws.blob + ws.blob_off[img];
+	int *verdict = ws.buf<int>(D_SPARE, img);
+	if (!threadIdx.x) {
+		const uint64_t flen = ws.blob_len[img];
+		memset(&hm, 0, sizeof hm);
+		if (flen > (1u << 24)) hm.status = NHW_E_FORMAT; else parse_header(f, (uint32_t)flen, &hm);
+		*verdict = hm.status;
+	}
+	__syncthreads();
+	const DecMeta *m = &hm;
+	if (m->status) return;
 	if (!part) vlc_fill_lut(lut, lut2, lane);
 	if (!lane) build_book_small(part ? f + m->o_book2 : f + m->o_book1, part ? m->book2_len : m->book1_len, part != 0, m->tree_end, book[part], scr[part]);
 	__syncthreads();
@@ -774,7 +785,7 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 			if (c >= nchunks - 1 && !done && (c + 1) * VCH_WORDS > nwords + 8) { bad = 1; break; }
 		}
 	}
-	if (__any(bad) && !lane) atomicExch(&m->status, (int)NHW_E_FORMAT);
+	if (__any(bad) && !lane) atomicExch(verdict, (int)NHW_E_FORMAT);
 }
 
 /* ---------------------------------------------------------------------------------------------- un-zig-zag
@@ -787,7 +798,7 @@ __global__ __launch_bounds__(256) void k_dec_unzig(DecWs ws)
 {
 	__shared__ int16_t tile[2][64][66];
 	const int img = blockIdx.y, tid = threadIdx.x;
-	if (ws.buf<DecMeta>(D_META, img)->status) return;
+	if (*ws.buf<int>(D_SPARE, img)) return;                        /* the walk's verdict (header included): the workspace header may still be in the making */
 	if (blockIdx.x < 64) {
 		const int cg = blockIdx.x & 7, rg = blockIdx.x >> 3;
 		const int16_t *sb = plane_b(ws, img);
@@ -872,6 +883,16 @@ DEV void replay_symbols(int16_t *st, int16_t *row, const uint64_t *mk, int nword
 			if (lft != 0x7fff) { if (j > 0) p[-1] = (int16_t)lft; else if (upper) row[-1] = (int16_t)lft; }   /* loop 2, column 0: done up front, see the caller */
 		}
 	}
+}
+
+/* the two entropy branches meet: a file the prefix-code walk gave up on is skipped by everything that follows */
+__global__ __launch_bounds__(256) void k_dec_verdict(DecWs ws)
+{
+	const int img = blockIdx.x * 256 + threadIdx.x;
+	if (img >= ws.n) return;
+	const int v = *ws.buf<int>(D_SPARE, img);
+	DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (v && !m->status) m->status = v;
 }
 
 __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
@@ -1518,15 +1539,22 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	/* the symbol streams start from zero (the reference's calloc, nhw_decoder.c:2029, :894): a zero run is a skip */
 	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_B], 0, k_dec_bytes[D_B] * (size_t)n, s));
 	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_CB], 0, k_dec_bytes[D_CB] * (size_t)n, s));
+	/* Two entropy branches that only meet at the expansion: the side streams (LL2 DPCM, position lists; latency-bound scans) on the caller's
+	 * stream, the prefix-code walk and the un-zig-zag on the second one. */
+	if (fork) { HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0)); }
 	k_dec_parse<<<n, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 1 */
-	k_dec_vlc<<<n, 128, 0, s>>>(ws);
-	k_dec_unzig<<<dim3(80, n), 256, 0, s>>>(ws);
+	k_dec_vlc<<<n, 128, 0, cs>>>(ws);
+	k_dec_unzig<<<dim3(80, n), 256, 0, cs>>>(ws);
+	if (fork) {
+		HIPCHK(hipEventRecord(d->join_ev, cs)); HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
+		HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0));   /* chroma goes on once both branches are in */
+	}
+	k_dec_verdict<<<(n + 255) / 256, 256, 0, s>>>(ws);
 	EV(1);
 	STAGE_END();                                                                  /* 2 */
 	/* From here the luma and the chroma sequences share nothing until the colour kernel: chroma goes to a stream of its own, where its
 	 * bandwidth-bound kernels run under the latency-bound luma ones (the expansion walk, the marks chain).  With the debug stop it stays in line. */
-	if (fork) { HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0)); }
 	k_dec_expand<<<(n + 3) / 4, 256, 0, s>>>(ws);
 	k_dec_expand_chroma<<<(n + 3) / 4, 256, 0, cs>>>(ws);
 	if (fork) {
