@@ -252,6 +252,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		CHROMA(chroma_tail(0));
 		CHROMA(chroma_head(1));
 		CHROMA(chroma_tail(1));
+		nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, cs);   /* Z1: the chroma LL2 coder appends to the luma one's output (Y16, long done) */
 		HIPCHK(hipEventRecord(e->part_ev[1], cs));
 	}
 	nhw_launch_phase(PH_L4D, ws, 0, out, d_sizes, d_status, s);      /* Y30, Y31 */
@@ -266,7 +267,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		}
 #undef CHROMA
 	if (timed) HIPCHK(hipEventRecord(e->ev[3], s));
-	nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, s);     /* Z1 */
+	if (!fork) nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, s);     /* Z1 */
 	nhw_launch_phase(PH_FINAL, ws, 0, out, d_sizes, d_status, s);   /* Z2, container */
 	if (timed == 1) HIPCHK(hipEventRecord(e->ev[4], s));
 	HIPCHK(hipGetLastError());

@@ -1093,17 +1093,23 @@ __global__ __launch_bounds__(256) void k_dec_expand_chroma(DecWs ws)
 }
 
 /* isolated level-2 coefficients shrink by one (:670-721); a pure stencil (a cell that shrinks has no neighbour that can) */
+#define SHRINK_ROWS 8                /* rows per workgroup: one row each made a million tiny workgroups per batch, and their dispatch was the kernel's time */
 __global__ __launch_bounds__(256) void k_dec_shrink(DecWs ws)
 {
-	const int img = blockIdx.y, i = 1 + blockIdx.x, j = threadIdx.x;
+	const int img = blockIdx.y, i0 = 1 + SHRINK_ROWS * blockIdx.x, j = threadIdx.x;
 	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
 	if (m->status || j < 1 || j > DH - 2) return;
-	int16_t *p = plane_a(ws, img) + (size_t)i * DW + j;
-	const int diag = m->q <= 16 ? 16 : 8, v = *p;
-	if (iabs(v) <= 8 || (i < DH / 2 && j < DH / 2)) return;
-	if (iabs(p[-DW - 1]) > diag || iabs(p[-DW]) > 8 || iabs(p[-DW + 1]) > diag || iabs(p[-1]) > 8 || iabs(p[1]) > 8 ||
-	    iabs(p[DW - 1]) > diag || iabs(p[DW]) > 8 || iabs(p[DW + 1]) > diag) return;
-	*p = (int16_t)(v > 0 ? v - 1 : v + 1);
+	const int diag = m->q <= 16 ? 16 : 8;
+	int16_t *p = plane_a(ws, img) + (size_t)i0 * DW + j;
+	/* a 3x3 window slides down the column on the values as they were: a cell that shrinks has no neighbour that can */
+	int u0 = p[-DW - 1], u1 = p[-DW], u2 = p[-DW + 1], c0 = p[-1], c1 = p[0], c2 = p[1];
+	for (int i = i0; i < i0 + SHRINK_ROWS && i <= DH - 2; i++, p += DW) {
+		const int d0 = p[DW - 1], d1 = p[DW], d2 = p[DW + 1];
+		if (iabs(c1) > 8 && !(i < DH / 2 && j < DH / 2) &&
+		    !(iabs(u0) > diag || iabs(u1) > 8 || iabs(u2) > diag || iabs(c0) > 8 || iabs(c2) > 8 || iabs(d0) > diag || iabs(d1) > 8 || iabs(d2) > diag))
+			*p = (int16_t)(c1 > 0 ? c1 - 1 : c1 + 1);
+		u0 = c0; u1 = c1; u2 = c2; c0 = d0; c1 = d1; c2 = d2;
+	}
 }
 
 /* ---------------------------------------------------------------------------------------------- synthesis (d4)
@@ -1285,21 +1291,25 @@ __global__ __launch_bounds__(256) void k_dec_corr(DecWs ws)
 
 /* 5-tap smoothing at the marked samples (:859-876), on plane B read transposed (the reference transposes first).
  * List order matters only inside a run of horizontally adjacent marks: the head of a run walks it. */
+#define SMOOTH_WGS 16
 __global__ __launch_bounds__(256) void k_dec_smooth(DecWs ws)
 {
-	const int img = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+	const int img = blockIdx.y;
 	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
-	if (m->status || k >= m->nmarks) return;
+	if (m->status) return;
+	const int nmarks = m->nmarks;
 	const uint16_t *marks = ws.buf<uint16_t>(D_MARKS, img);
 	int16_t *b = plane_b(ws, img);
-	if (k > 0 && marks[k - 1] + 1 == marks[k]) return;
-	for (int t = k; t < m->nmarks && (t == k || marks[t - 1] + 1 == marks[t]); t++) {
+	for (int k = blockIdx.x * 256 + threadIdx.x; k < nmarks; k += 256 * SMOOTH_WGS) {   /* a workgroup per 256 possible marks was a million workgroups, most of them empty */
+	if (k > 0 && marks[k - 1] + 1 == marks[k]) continue;
+	for (int t = k; t < nmarks && (t == k || marks[t - 1] + 1 == marks[t]); t++) {
 		const int row = (marks[t] >> 8) << 1, col = marks[t] & 255;     /* cell (row, col) of the transposed plane = b[col][row] */
 #define TP(dr, dc) ((int)b[(size_t)(col + (dc)) * DW + row + (dr)])
 		const int ctr = TP(0, 0);
 		const int lap = (ctr << 3) - TP(0, -1) - TP(0, 1) - TP(-1, 0) - TP(1, 0) - TP(-1, -1) - TP(1, -1) - TP(-1, 1) - TP(1, 1);
 		if (iabs(lap) < 116) b[(size_t)col * DW + row] = (int16_t)(((ctr << 2) + TP(0, -1) + TP(0, 1) + TP(-1, 0) + TP(1, 0) + 4) >> 3);
 #undef TP
+	}
 	}
 }
 
@@ -1401,15 +1411,18 @@ DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
 	}
 	R = clip8(R); G = clip8(G); B = clip8(B);
 }
-/* one workgroup = two output rows (2i, 2i+1); a thread = four pixels of one of them: one 32-bit load of Y, three chroma
+#define COLOR_PAIRS 4                /* row pairs per workgroup */
+/* one workgroup = COLOR_PAIRS x two output rows (2i, 2i+1); a thread = four pixels of one of them: one 32-bit load of Y, three chroma
  * columns of the two source rows, 12 output bytes as three 32-bit stores */
 __global__ __launch_bounds__(256) void k_dec_color(DecWs ws, uint8_t *out)
 {
-	const int img = blockIdx.y, r = 2 * blockIdx.x + (threadIdx.x >> 7), t = threadIdx.x & 127;
+	const int img = blockIdx.y, t = threadIdx.x & 127;
 	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
 	if (m->status) return;
 	const int q = m->q;
 	const uint8_t *yb = ws.buf<uint8_t>(D_YB, img), *cu = ws.buf<uint8_t>(D_CU, img), *cv = cu + DQ;
+	for (int it = 0; it < COLOR_PAIRS; it++) {
+	const int r = 2 * (COLOR_PAIRS * blockIdx.x + it) + (threadIdx.x >> 7);
 	const uint32_t y4 = *(const uint32_t *)(yb + (size_t)r * DW + 4 * t);
 	const int i = r >> 1, j = 2 * t;
 	int tu[3], tv[3];                                             /* the vertically doubled chroma rows at columns j, j+1, j+2 */
@@ -1435,6 +1448,7 @@ __global__ __launch_bounds__(256) void k_dec_color(DecWs ws, uint8_t *out)
 	}
 	uint32_t *o = (uint32_t *)(out + (size_t)img * NHW_IMG_BYTES + (size_t)r * DW * 3 + 12 * t);
 	o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+	}
 }
 
 __global__ __launch_bounds__(256) void k_dec_status(DecWs ws, int32_t *status, int32_t *quality)
@@ -1570,7 +1584,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 		HIPCHK(hipEventRecord(d->join_ev, cs));
 	}
 	STAGE_END();                                                                  /* 3 */
-	k_dec_shrink<<<dim3(DH - 2, n), 256, 0, s>>>(ws);
+	k_dec_shrink<<<dim3((DH - 2 + SHRINK_ROWS - 1) / SHRINK_ROWS, n), 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 4 */
 	{
 		/* level 2 luma: A (top-left 256x256) -> B -> level-1 LL back in A's top-left quarter */
@@ -1591,7 +1605,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	}
 	k_dec_corr<<<n, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 8 */
-	k_dec_smooth<<<dim3(DQ / 256, n), 256, 0, s>>>(ws);
+	k_dec_smooth<<<dim3(SMOOTH_WGS, n), 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 9 */
 	{
 		SynthArgs p2 = { D_B, -1, 0, DW, DW, DW, DW, 1, 1 };
@@ -1617,7 +1631,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 		STAGE_END();                                                              /* 14 */
 	}
 	EV(6);
-	k_dec_color<<<dim3(DW / 2, n), 256, 0, s>>>(ws, (uint8_t *)d_bgr);
+	k_dec_color<<<dim3(DW / 2 / COLOR_PAIRS, n), 256, 0, s>>>(ws, (uint8_t *)d_bgr);
 	EV(7);
 	d->timed = true;
 done:
