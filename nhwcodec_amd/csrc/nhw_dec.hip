@@ -1413,42 +1413,56 @@ DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
 }
 #define COLOR_PAIRS 4                /* row pairs per workgroup */
 /* one workgroup = COLOR_PAIRS x two output rows (2i, 2i+1); a thread = four pixels of one of them: one 32-bit load of Y, three chroma
- * columns of the two source rows, 12 output bytes as three 32-bit stores */
+ * columns of the two source rows (staged in LDS: five chroma rows of each plane serve the eight output rows), 12 output bytes.  The
+ * output rows go through LDS as well so that they leave as 16-byte stores of consecutive lanes (12-byte pieces per lane made every
+ * store instruction touch every line of the row). */
 __global__ __launch_bounds__(256) void k_dec_color(DecWs ws, uint8_t *out)
 {
-	const int img = blockIdx.y, t = threadIdx.x & 127;
+	__shared__ __attribute__((aligned(16))) uint8_t crow[2][COLOR_PAIRS + 1][DH];
+	__shared__ __attribute__((aligned(16))) uint32_t orow[2 * COLOR_PAIRS][DW * 3 / 4];
+	const int img = blockIdx.y, t = threadIdx.x & 127, tid = threadIdx.x;
 	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
 	if (m->status) return;
 	const int q = m->q;
 	const uint8_t *yb = ws.buf<uint8_t>(D_YB, img), *cu = ws.buf<uint8_t>(D_CU, img), *cv = cu + DQ;
+	const int i0 = COLOR_PAIRS * blockIdx.x;
+	for (int k = tid; k < 2 * (COLOR_PAIRS + 1) * (DH / 16); k += 256) {
+		const int pl = k / ((COLOR_PAIRS + 1) * (DH / 16)), rem = k % ((COLOR_PAIRS + 1) * (DH / 16)), rr = rem / (DH / 16), o = rem % (DH / 16);
+		const int src = i0 + rr < DH ? i0 + rr : DH - 1;
+		reinterpret_cast<uint4 *>(crow[pl][rr])[o] = reinterpret_cast<const uint4 *>((pl ? cv : cu) + (size_t)src * DH)[o];
+	}
+	__syncthreads();
 	for (int it = 0; it < COLOR_PAIRS; it++) {
-	const int r = 2 * (COLOR_PAIRS * blockIdx.x + it) + (threadIdx.x >> 7);
-	const uint32_t y4 = *(const uint32_t *)(yb + (size_t)r * DW + 4 * t);
-	const int i = r >> 1, j = 2 * t;
-	int tu[3], tv[3];                                             /* the vertically doubled chroma rows at columns j, j+1, j+2 */
-	for (int c = 0; c < 3; c++) {
-		const int jj = j + c < DH ? j + c : DH - 1;
-		if (r >= 2 * DH - 2) { tu[c] = cu[(DH - 1) * DH + jj]; tv[c] = cv[(DH - 1) * DH + jj]; }
-		else if (r & 1) { tu[c] = (cu[i * DH + jj] + cu[(i + 1) * DH + jj] + 1) >> 1; tv[c] = (cv[i * DH + jj] + cv[(i + 1) * DH + jj] + 1) >> 1; }
-		else { tu[c] = cu[i * DH + jj]; tv[c] = cv[i * DH + jj]; }
+		const int r = 2 * (i0 + it) + (tid >> 7);
+		const uint32_t y4 = *(const uint32_t *)(yb + (size_t)r * DW + 4 * t);
+		const int j = 2 * t;
+		int tu[3], tv[3];                                         /* the vertically doubled chroma rows at columns j, j+1, j+2 */
+		for (int c = 0; c < 3; c++) {
+			const int jj = j + c < DH ? j + c : DH - 1;
+			if (r >= 2 * DH - 2) { tu[c] = crow[0][it][jj]; tv[c] = crow[1][it][jj]; }              /* rows 510, 511: chroma row 255 */
+			else if (r & 1) { tu[c] = (crow[0][it][jj] + crow[0][it + 1][jj] + 1) >> 1; tv[c] = (crow[1][it][jj] + crow[1][it + 1][jj] + 1) >> 1; }
+			else { tu[c] = crow[0][it][jj]; tv[c] = crow[1][it][jj]; }
+		}
+		uint32_t w[3] = { 0, 0, 0 };
+		for (int px = 0; px < 4; px++) {
+			const int x = 4 * t + px;
+			int uv, vv;
+			if (x >= DW - 2) { uv = tu[DH - 1 - j]; vv = tv[DH - 1 - j]; }      /* last two columns repeat column 255 (j = 254 here) */
+			else if (x & 1) { uv = (tu[px >> 1] + tu[(px >> 1) + 1] + 1) >> 1; vv = (tv[px >> 1] + tv[(px >> 1) + 1] + 1) >> 1; }
+			else { uv = tu[px >> 1]; vv = tv[px >> 1]; }
+			int R, G, B;
+			yuv_to_bytes(q, (int)((y4 >> (8 * px)) & 255u), uv, vv, R, G, B);
+			const int b0 = 3 * px;
+			w[b0 >> 2] |= (uint32_t)R << (8 * (b0 & 3));
+			w[(b0 + 1) >> 2] |= (uint32_t)G << (8 * ((b0 + 1) & 3));
+			w[(b0 + 2) >> 2] |= (uint32_t)B << (8 * ((b0 + 2) & 3));
+		}
+		uint32_t *o = orow[2 * it + (tid >> 7)] + 3 * t;
+		o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
 	}
-	uint32_t w[3] = { 0, 0, 0 };
-	for (int px = 0; px < 4; px++) {
-		const int x = 4 * t + px;
-		int uv, vv;
-		if (x >= DW - 2) { uv = tu[DH - 1 - j]; vv = tv[DH - 1 - j]; }          /* last two columns repeat column 255 (j = 254 here) */
-		else if (x & 1) { uv = (tu[px >> 1] + tu[(px >> 1) + 1] + 1) >> 1; vv = (tv[px >> 1] + tv[(px >> 1) + 1] + 1) >> 1; }
-		else { uv = tu[px >> 1]; vv = tv[px >> 1]; }
-		int R, G, B;
-		yuv_to_bytes(q, (int)((y4 >> (8 * px)) & 255u), uv, vv, R, G, B);
-		const int b0 = 3 * px;
-		w[b0 >> 2] |= (uint32_t)R << (8 * (b0 & 3));
-		w[(b0 + 1) >> 2] |= (uint32_t)G << (8 * ((b0 + 1) & 3));
-		w[(b0 + 2) >> 2] |= (uint32_t)B << (8 * ((b0 + 2) & 3));
-	}
-	uint32_t *o = (uint32_t *)(out + (size_t)img * NHW_IMG_BYTES + (size_t)r * DW * 3 + 12 * t);
-	o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
-	}
+	__syncthreads();
+	uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)img * NHW_IMG_BYTES + (size_t)(2 * i0) * DW * 3);   /* 2 COLOR_PAIRS consecutive rows */
+	for (int k = tid; k < 2 * COLOR_PAIRS * (DW * 3 / 16); k += 256) dst[k] = reinterpret_cast<const uint4 *>(&orow[0][0])[k];
 }
 
 __global__ __launch_bounds__(256) void k_dec_status(DecWs ws, int32_t *status, int32_t *quality)
