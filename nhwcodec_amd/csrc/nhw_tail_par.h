@@ -1019,6 +1019,7 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 	const int16_t *p = c->proc;
 	uint8_t *s = c->scan;
 	const int n = 4 * Q;
+	PROF_BEGIN();
 	uint32_t *bits = reinterpret_cast<uint32_t *>(c->half);      /* n bits of selection flags */
 
 	/* serpentine gather (:2108-2132) through LDS (the quantiser kernel writes the stream itself, this is the stand-alone form): 16 plane rows (coalesced 1 KiB rows) -> per 4-column strip a run of
@@ -1048,11 +1049,17 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 
 	/* The three rewrites read 16 stream bytes per thread and step (48-byte register window: 16 before, 16 own,
 	 * 16 after), so a wavefront touches 1 KiB of consecutive memory per load instruction. */
-#define WIN_LOAD(w, base) do { const uint4 a_ = *reinterpret_cast<const uint4 *>(s + (base) - 16), b_ = *reinterpret_cast<const uint4 *>(s + (base)), \
+#define WIN_LOAD(dst_, base) do { const uint4 a_ = *reinterpret_cast<const uint4 *>(s + (base) - 16), b_ = *reinterpret_cast<const uint4 *>(s + (base)), \
 		c_ = (base) + 16 < n ? *reinterpret_cast<const uint4 *>(s + (base) + 16) : make_uint4(0, 0, 0, 0);   /* im_nhw is calloc'ed and the chroma part not yet written when the reference is here: bytes behind the luma part read 0 (the chroma sequence may be writing them on its own stream) */ \
-		w[0] = a_.x; w[1] = a_.y; w[2] = a_.z; w[3] = a_.w; w[4] = b_.x; w[5] = b_.y; w[6] = b_.z; w[7] = b_.w; w[8] = c_.x; w[9] = c_.y; w[10] = c_.z; w[11] = c_.w; } while (0)
+		dst_[0] = a_.x; dst_[1] = a_.y; dst_[2] = a_.z; dst_[3] = a_.w; dst_[4] = b_.x; dst_[5] = b_.y; dst_[6] = b_.z; dst_[7] = b_.w; dst_[8] = c_.x; dst_[9] = c_.y; dst_[10] = c_.z; dst_[11] = c_.w; } while (0)
 #define WB(w, k) ((int)(((w)[((k) + 16) >> 2] >> (8 * (((k) + 16) & 3))) & 0xFF))      /* byte at base + k, -16 <= k < 32 */
 #define PM8(v) ((v) == 136 || (v) == 120)
+	/* one bit per window byte 8 .. 39 (bit j = byte base - 16 + j) that equals the byte replicated in `pat`: all a test on an own byte looks at */
+#define EQ4(x, pat) ((((~(((((x) ^ (pat)) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | ((x) ^ (pat)) | 0x7F7F7F7Fu)) >> 7) * 0x00204081u) >> 21 & 15u)
+#define WIN_MASK(w, pat) ((unsigned long long)(EQ4((w)[2], pat) | EQ4((w)[3], pat) << 4 | EQ4((w)[4], pat) << 8 | EQ4((w)[5], pat) << 12 | \
+                                               EQ4((w)[6], pat) << 16 | EQ4((w)[7], pat) << 20 | EQ4((w)[8], pat) << 24 | EQ4((w)[9], pat) << 28) << 8)
+	/* 4-bit mask of the bytes of a word that are the zero symbol 128 (exact per byte, then the four flags gathered by a multiply) */
+#define Z4(x) ((((~((((x) ^ 0x80808080u) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu | ((x) ^ 0x80808080u) | 0x7F7F7F7Fu)) >> 7) * 0x00204081u) >> 21 & 15u)
 	/* any +-8 symbol (136 / 120) among the 16 own bytes of a window?  (zero-byte test on the words xor-ed with the symbol) */
 #define HASZ(x) ((((x) - 0x01010101u) & ~(x)) & 0x80808080u)
 #define ANY_PM8(w) ((HASZ((w)[4] ^ 0x88888888u) | HASZ((w)[5] ^ 0x88888888u) | HASZ((w)[6] ^ 0x88888888u) | HASZ((w)[7] ^ 0x88888888u) | \
@@ -1060,6 +1067,7 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 	for (int w = tid; w < n / 32; w += NT) bits[w] = 0;
 	if (tid < 4) sh_z[n / 16 / 32 + tid] = 0;
 	BARRIER();
+	if (!tid) PROF(c, 40);
 	for (int base = 16 * tid; base < n; base += 16 * NT) {         /* rewrite 1, selection */
 		uint32_t w[12];
 		WIN_LOAD(w, base);
@@ -1068,16 +1076,25 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 			if ((tid & 63) == 0) { sh_z[base >> 9] = (uint32_t)mask; sh_z[(base >> 9) + 1] = (uint32_t)(mask >> 32); }
 		}
 		if (!ANY_PM8(w)) continue;
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			const int cpos = base + k;
-			if (!(PM8(WB(w, k)) && WB(w, k + 1) == 128 && WB(w, k + 2) == 128 && WB(w, k + 3) == 128 && PM8(WB(w, k + 4))) || cpos > n - 5) continue;
+		/* The tests on the 16 own symbols are done on all of them at once: one bit per window byte (bit j = byte base - 16 + j) for "is the
+		 * zero symbol" and "is +-8", the patterns as shifted ANDs; only the hits are visited one by one. */
+		const unsigned long long Zm = WIN_MASK(w, 0x80808080u), P = WIN_MASK(w, 0x88888888u) | WIN_MASK(w, 0x78787878u);
+		unsigned long long hit = P & (Zm >> 1) & (Zm >> 2) & (Zm >> 3) & (P >> 4) & 0xFFFF0000ull;       /* (+-8, 0, 0, 0, +-8) starting at an own byte */
+		if (base > n - 5 - 15) hit &= (1ull << (n - 4 - base + 16)) - 1;                                /* cpos <= n - 5 */
+		const unsigned long long prev = (P << 4) & (Zm << 3) & (Zm << 2) & (Zm << 1);                   /* the same pattern one step back */
+		while (hit) {
+			const int j = __ffsll((long long)hit) - 1, cpos = base + j - 16;
+			hit &= hit - 1;
 			int m = 1, back = cpos - 4;
-			while (pair_cand(s, back, n)) { m++; back -= 4; }
+			if (back >= 0 && ((prev >> j) & 1)) {                  /* only a chain of them goes on through memory */
+				m++; back -= 4;
+				while (pair_cand(s, back, n)) { m++; back -= 4; }
+			}
 			if (m & 1) atomicOr(&bits[cpos >> 5], 1u << (cpos & 31));
 		}
 	}
 	BARRIER();
+	if (!tid) PROF(c, 41);
 	for (int w = tid; w < n / 32; w += NT) {                       /* rewrite 1, application */
 		uint32_t word = bits[w];
 		while (word) {
@@ -1092,31 +1109,34 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 	if (tid < 4) { s[tid] = 128; s[n - 4 + tid] = 128; }
 	BARRIER();
 
+	if (!tid) PROF(c, 42);
 	{                                                              /* rewrite 2 (tests on the window; writes are byte stores) */
 		int n1 = 0, n2 = 0;
 		for (int base = 16 * tid; base < n; base += 16 * NT) {
 			uint32_t w[12];
 			WIN_LOAD(w, base);
 			if (!ANY_PM8(w)) continue;
-#pragma unroll
-			for (int k = 0; k < 16; k++) {
-				const int i = base + k, v = WB(w, k);
-				if (!PM8(v) || i < 4 || i >= n - 4) continue;
-				const bool before4 = WB(w, k - 1) == 128 && WB(w, k - 2) == 128 && WB(w, k - 3) == 128 && WB(w, k - 4) == 128;
-				if (i > 4 && PM8(WB(w, k - 1))) {                  /* did the left neighbour take me as the second of a pair? */
-					const bool b4l = WB(w, k - 2) == 128 && WB(w, k - 3) == 128 && WB(w, k - 4) == 128 && WB(w, k - 5) == 128;
-					if (WB(w, k + 1) == 128 && (b4l || (WB(w, k - 2) == 128 && WB(w, k + 2) == 128 && WB(w, k + 3) == 128 && WB(w, k + 4) == 128))) continue;
-				}
-				const int nx = WB(w, k + 1);
-				const bool pair = PM8(nx);
-				if ((WB(w, k + 2) == 128 && pair && before4) ||
-				    (WB(w, k - 1) == 128 && pair && WB(w, k + 2) == 128 && WB(w, k + 3) == 128 && WB(w, k + 4) == 128 && WB(w, k + 5) == 128)) {
-					s[i + 1] = (uint8_t)(nx == 120 ? 157 : 159); n2++;
-				}
-				else if ((before4 && nx == 128) || (WB(w, k - 1) == 128 && nx == 128 && WB(w, k + 2) == 128 && WB(w, k + 3) == 128 && WB(w, k + 4) == 128)) {
-					s[i] = (uint8_t)(v == 136 ? 153 : 155); n1++;
-				}
+			const unsigned long long Zm = WIN_MASK(w, 0x80808080u), P6 = WIN_MASK(w, 0x88888888u), P0 = WIN_MASK(w, 0x78787878u), P = P6 | P0;
+			unsigned long long act = P & 0xFFFF0000ull;            /* own +-8 symbols at 4 <= i < n - 4 */
+			unsigned long long left = P << 1;                      /* the left neighbour is +-8 (asked only for i > 4) */
+			if (base == 0) { act &= ~0xFull << 16; left &= ~0x1Full << 16; }
+			if (base == n - 16) act &= (1ull << 28) - 1;
+			const unsigned long long before4 = (Zm << 1) & (Zm << 2) & (Zm << 3) & (Zm << 4);
+			const unsigned long long after3 = (Zm >> 2) & (Zm >> 3) & (Zm >> 4);                        /* bytes +2 .. +4 */
+			/* did the left neighbour take me as the second of a pair? */
+			const unsigned long long taken = left & (Zm >> 1) & (((Zm << 2) & (Zm << 3) & (Zm << 4) & (Zm << 5)) | ((Zm << 2) & after3));
+			act &= ~taken;
+			const unsigned long long pairA = act & (P >> 1) & (Zm >> 2) & (before4 | ((Zm << 1) & (Zm >> 3) & (Zm >> 4) & (Zm >> 5)));
+			const unsigned long long lone = act & ~pairA & (Zm >> 1) & (before4 | ((Zm << 1) & after3));
+			for (unsigned long long h = pairA; h; h &= h - 1) {
+				const int j = __ffsll((long long)h) - 1;
+				s[base + j - 15] = (uint8_t)(((P0 >> (j + 1)) & 1) ? 157 : 159);
 			}
+			for (unsigned long long h = lone; h; h &= h - 1) {
+				const int j = __ffsll((long long)h) - 1;
+				s[base + j - 16] = (uint8_t)(((P6 >> j) & 1) ? 153 : 155);
+			}
+			n2 += __popcll(pairA); n1 += __popcll(lone);
 		}
 		if (n1) atomicAdd(&sh_counts[0], n1);
 		if (n2) atomicAdd(&sh_counts[1], n2);
@@ -1124,23 +1144,44 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 	BARRIER();
 	if (tid == 0) { c->m->select1 = sh_counts[0]; c->m->select2 = sh_counts[1]; }
 
-	for (int base = 16 * tid; base < n; base += 16 * NT) {         /* rewrite 3: owners of run starts */
-		{                                                          /* a run of >= 253 that starts in this group covers the 14 groups that follow: cheap reject before anything is loaded */
-			const int g = (base >> 4) + 1;
-			const unsigned long long z = ((unsigned long long)sh_z[(g >> 5) + 1] << 32 | sh_z[g >> 5]) >> (g & 31);
-			if ((z & 0x3FFF) != 0x3FFF) continue;
+	if (!tid) PROF(c, 43);
+	/* rewrite 3: runs of zero symbols.  Only a run of 252 or more does anything, and one that long covers the rest of the group it starts
+	 * in and the 14 groups behind it, so a group holds at most one such start: the first of its trailing zero symbols.  Pass one finds the
+	 * starts (from the bitmap of all-zero groups alone inside a zero region: nothing is loaded there) and lists them; pass two deals them out
+	 * to the threads, so that the dependent loads of a run (its end, the symbols behind it) are a chain of two or three per thread and not
+	 * one in every step of a 64-step sweep. */
+	int *cand = reinterpret_cast<int *>(lds);                      /* [0]: count, then the start positions (at most one per 15 groups) */
+	if (!tid) cand[0] = 0;
+	BARRIER();
+	for (int base = 16 * tid; base < n; base += 16 * NT) {
+		const int gi = base >> 4;
+		unsigned long long zz;                                     /* bit 0: the group before is all zero symbols, bit 1: this one, bits 2..15: the 14 behind it */
+		if (gi) { const int g = gi - 1; zz = ((unsigned long long)sh_z[(g >> 5) + 1] << 32 | sh_z[g >> 5]) >> (g & 31); }
+		else zz = ((unsigned long long)sh_z[1] << 32 | sh_z[0]) << 1;
+		if (((zz >> 2) & 0x3FFF) != 0x3FFF) continue;
+		int i;
+		if ((zz >> 1) & 1) {                                       /* all zero: a start only if the run does not come from the group before */
+			if (zz & 1) continue;
+			if (base > 0 && s[base - 1] == 128) continue;
+			i = base;
+		} else {
+			const uint4 o = *reinterpret_cast<const uint4 *>(s + base);
+			const unsigned own = Z4(o.x) | (Z4(o.y) << 4) | (Z4(o.z) << 8) | (Z4(o.w) << 12);   /* bit k: byte base + k is the zero symbol */
+			const int tz = __clz((int)~(own << 16));               /* trailing zero symbols of the group */
+			if (tz == 0) continue;
+			i = base + 16 - tz;
 		}
-		uint32_t w[12];
-		WIN_LOAD(w, base);
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			const int i = base + k;
-			if (WB(w, k) != 128 || WB(w, k + 1) != 128 || (i > 0 && WB(w, k - 1) == 128)) continue;
-			/* run [i, b]: walk to the end of the 16-byte group, hop over all-zero groups with the bitmap, finish bytewise */
-			int b = i + 1;
-			while (((b + 1) & 15) && s[b + 1] == 128) b++;
-			if (!((b + 1) & 15) && b + 1 < n && s[b + 1] == 128) {
-				int g2 = (b + 1) >> 4;                             /* first group not yet examined */
+		cand[1 + atomicAdd(&cand[0], 1)] = i;
+	}
+	BARRIER();
+	const int ncand = cand[0];
+	for (int ci = tid; ci < ncand; ci += NT) {
+		const int i = cand[1 + ci];
+		{
+			/* run [i, b]: hop over the all-zero groups with the bitmap, finish on one 16-byte load of the group the run ends in */
+			int b;
+			{
+				int g2 = (i >> 4) + 1;                             /* first group not yet examined (all zero, like the thirteen behind it) */
 				for (;;) {
 					const uint32_t inv = ~(sh_z[g2 >> 5] >> (g2 & 31));
 					const int room = 32 - (g2 & 31);
@@ -1149,7 +1190,11 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 					g2 += z; break;
 				}
 				b = 16 * g2 - 1;                                   /* last byte of the last all-zero group */
-				while (b + 1 < n && s[b + 1] == 128) b++;
+				if (b + 1 < n) {
+					const uint4 e = *reinterpret_cast<const uint4 *>(s + b + 1);
+					const unsigned lead = Z4(e.x) | (Z4(e.y) << 4) | (Z4(e.z) << 8) | (Z4(e.w) << 12);
+					b += __ffs((int)~lead) - 1;                    /* not all sixteen: the bitmap said so */
+				}
 			}
 			/* the reference's walk (:2222-2252) fires every 254 cells from i+255 on, then once at the end: closed form */
 			if (b - i >= 256)
@@ -1162,9 +1207,13 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 		}
 	}
 	BARRIER();
+	if (!tid) PROF(c, 44);
 #undef WIN_LOAD
 #undef WB
 #undef PM8
+#undef Z4
+#undef EQ4
+#undef WIN_MASK
 #undef HASZ
 #undef ANY_PM8
 }
