@@ -865,23 +865,41 @@ __device__ __forceinline__ int pair_predict_s(const int16_t *x, int st, int k)
 	return x[(2 * k + 1) * st] - (a >> 1);
 }
 
+/* workgroup barrier that orders LDS traffic only: global loads stay in flight across it */
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int S>
 __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int final_level,
-                                                   int16_t *__restrict__ saveb, size_t save_plane, int save_row, int save_kind /* 1: copy of the S x S coefficient block, 2: of the LL quadrant copied back */)
+                                                   int16_t *__restrict__ saveb, size_t save_plane, int save_row, int save_kind /* 1: copy of the S x S coefficient block, 2: of the LL quadrant copied back */, int n)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
-	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4;
-	const int img = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-	int16_t *jpeg = jpegb + (size_t)img * plane_stride, *proc = procb + (size_t)img * plane_stride;
+	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4, NPRE = S * (S / 8) / NT_;
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	int16_t *A = smem;
-	int16_t *save = saveb ? saveb + (size_t)img * save_plane : nullptr;
-	for (int v = t; v < S * (S / 8); v += NT_) {
-		const int row = v / (S / 8), o = v % (S / 8);
-		const uint4 x = *reinterpret_cast<const uint4 *>(jpeg + (size_t)row * stride + 8 * o);
-		uint32_t *d = reinterpret_cast<uint32_t *>(A + row * LS + 8 * o);
-		d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+	/* The block fills the LDS a CU has (S = 256), so a CU holds one workgroup and its load, filter and store phases would follow one another with
+	 * the memory system idle in between.  A workgroup therefore works through several images and has the next block on its way, in registers,
+	 * while it filters the present one.  The barriers order LDS traffic only (no thread reads global memory another one wrote). */
+	uint4 pre[NPRE];
+	if ((int)blockIdx.x < n) {
+		const int16_t *src = jpegb + (size_t)blockIdx.x * plane_stride;
+#pragma unroll
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * stride + 8 * (v % (S / 8))); }
 	}
-	__syncthreads();
+	for (int img = blockIdx.x; img < n; img += gridDim.x) {
+	int16_t *jpeg = jpegb + (size_t)img * plane_stride, *proc = procb + (size_t)img * plane_stride;
+	int16_t *save = saveb ? saveb + (size_t)img * save_plane : nullptr;
+#pragma unroll
+	for (int u = 0; u < NPRE; u++) {
+		const int v = t + u * NT_, row = v / (S / 8), o = v % (S / 8);
+		uint32_t *d = reinterpret_cast<uint32_t *>(A + row * LS + 8 * o);
+		d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
+	}
+	lds_barrier();
+	if (img + (int)gridDim.x < n) {
+		const int16_t *src = jpegb + (size_t)(img + gridDim.x) * plane_stride;
+#pragma unroll
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * stride + 8 * (v % (S / 8))); }
+	}
 	for (int i = 0; i < 16; i++) {                                 /* first direction (filters.c:40-86): un-normalised taps */
 		int16_t *x = A + (wv * 16 + i) * LS;
 		int lo[PPL], hi[PPL];
@@ -894,13 +912,13 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 #pragma unroll
 		for (int u = 0; u < PPL; u++) { x[lane + 64 * u] = (int16_t)lo[u]; x[HLF + lane + 64 * u] = (int16_t)hi[u]; }
 	}
-	__syncthreads();
+	lds_barrier();
 	for (int v = t; v < S * HLF; v += NT_) {                       /* the source plane keeps the transposed first-direction plane */
 		const int i = v / HLF, j = 2 * (v % HLF);
 		if (!final_level && i < HLF && j < HLF) continue;           /* (its LL quadrant is overwritten below) */
 		*reinterpret_cast<uint32_t *>(jpeg + (size_t)i * stride + j) = (uint16_t)A[j * LS + i] | ((uint32_t)(uint16_t)A[(j + 1) * LS + i] << 16);
 	}
-	__syncthreads();
+	lds_barrier();
 	for (int i = 0; i < 16; i++) {                                 /* second direction along the columns (filters.c:88-287) */
 		const int c = wv * 16 + i;
 		int16_t *x = A + c;
@@ -928,13 +946,16 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 			if (!final_level && c < HLF) x[k * LS] = (int16_t)lo[u];  /* LL, parked in the column's own cells */
 		}
 	}
-	if (final_level) return;
-	__syncthreads();
+	if (!final_level) {
+	lds_barrier();
 	for (int v = t; v < HLF * (HLF / 2); v += NT_) {               /* LL copied back in natural orientation (wavelet_filterbank.c:172-184) */
 		const int k = v / (HLF / 2), c = 2 * (v % (HLF / 2));
 		const uint32_t w = (uint16_t)A[k * LS + c] | ((uint32_t)(uint16_t)A[k * LS + c + 1] << 16);
 		*reinterpret_cast<uint32_t *>(jpeg + (size_t)k * stride + c) = w;
 		if (save_kind == 2) *reinterpret_cast<uint32_t *>(save + (size_t)k * save_row + c) = w;
+	}
+	}
+	lds_barrier();                                                 /* the block is done with before the next one moves in */
 	}
 }
 
@@ -959,20 +980,32 @@ __device__ __forceinline__ void syn_pair(const int16_t *x, int st, int k, bool n
 }
 
 template <int S>
-__global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride)
+__global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int n)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
-	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4;
-	const int img = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-	int16_t *jpeg = jpegb + (size_t)img * plane_stride, *proc = procb + (size_t)img * plane_stride;
+	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4, NPRE = S * (S / 8) / NT_;
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	int16_t *A = smem;
-	for (int v = t; v < S * (S / 8); v += NT_) {
-		const int row = v / (S / 8), o = v % (S / 8);
-		const uint4 x = *reinterpret_cast<const uint4 *>(jpeg + (size_t)row * stride + 8 * o);
-		uint32_t *d = reinterpret_cast<uint32_t *>(A + row * LS + 8 * o);
-		d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+	uint4 pre[NPRE];                                               /* several images per workgroup, the next block on its way while this one is filtered (see k_dwt_ana) */
+	if ((int)blockIdx.x < n) {
+		const int16_t *src = jpegb + (size_t)blockIdx.x * plane_stride;
+#pragma unroll
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * stride + 8 * (v % (S / 8))); }
 	}
-	__syncthreads();
+	for (int img = blockIdx.x; img < n; img += gridDim.x) {
+	int16_t *jpeg = jpegb + (size_t)img * plane_stride, *proc = procb + (size_t)img * plane_stride;
+#pragma unroll
+	for (int u = 0; u < NPRE; u++) {
+		const int v = t + u * NT_, row = v / (S / 8), o = v % (S / 8);
+		uint32_t *d = reinterpret_cast<uint32_t *>(A + row * LS + 8 * o);
+		d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
+	}
+	lds_barrier();
+	if (img + (int)gridDim.x < n) {
+		const int16_t *src = jpegb + (size_t)(img + gridDim.x) * plane_stride;
+#pragma unroll
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * stride + 8 * (v % (S / 8))); }
+	}
 	for (int i = 0; i < 16; i++) {                                 /* first direction, un-normalised */
 		int16_t *x = A + (wv * 16 + i) * LS;
 		int e[PPL], o[PPL];
@@ -981,7 +1014,7 @@ __global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, 
 #pragma unroll
 		for (int u = 0; u < PPL; u++) reinterpret_cast<uint32_t *>(x)[lane + 64 * u] = (uint32_t)(uint16_t)e[u] | ((uint32_t)(uint16_t)o[u] << 16);
 	}
-	__syncthreads();
+	lds_barrier();
 	for (int i = 0; i < 16; i++) {                                 /* second direction along the columns, normalised: row c of the work plane */
 		const int c = wv * 16 + i;
 		int16_t *x = A + c;
@@ -996,14 +1029,17 @@ __global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, 
 			x[(2 * k) * LS] = (int16_t)e[u]; x[(2 * k + 1) * LS] = (int16_t)o[u];
 		}
 	}
-	__syncthreads();
+	lds_barrier();
 	for (int v = t; v < S * (S / 8); v += NT_) {                   /* and its transpose, the reconstruction in natural orientation */
 		const int row = v / (S / 8), o = v % (S / 8);
 		const uint32_t *d = reinterpret_cast<const uint32_t *>(A + row * LS + 8 * o);
 		*reinterpret_cast<uint4 *>(jpeg + (size_t)row * stride + 8 * o) = make_uint4(d[0], d[1], d[2], d[3]);
 	}
+	lds_barrier();
+	}
 }
 
+#define DWT_WGS 256                  /* one resident workgroup per CU for the 256 x 256 blocks */
 template <int S>
 static void dwt_lds_attr()
 {
@@ -1023,8 +1059,8 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
                          int16_t *keep, size_t keep_stride, hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind)
 {
 	if (!save) save_kind = 0;
-	if (size == 256 && !keep) { dwt_lds_attr<256>(); k_dwt_ana<256><<<n, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind); return; }
-	if (size == 128 && !keep) { dwt_lds_attr<128>(); k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind); return; }
+	if (size == 256 && !keep) { dwt_lds_attr<256>(); k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n); return; }
+	if (size == 128 && !keep) { dwt_lds_attr<128>(); k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n); return; }
 	const int hlf = size >> 1;
 	const dim3 rg((hlf + 255) / 256, size, n), tg((size + 63) / 64, (size + 63) / 64, n);
 	k_ana_rows<1><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
@@ -1042,8 +1078,8 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
 
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s)
 {
-	if (size == 256) { dwt_lds_attr<256>(); k_dwt_syn<256><<<n, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride); return; }
-	if (size == 128) { dwt_lds_attr<128>(); k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride); return; }
+	if (size == 256) { dwt_lds_attr<256>(); k_dwt_syn<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n); return; }
+	if (size == 128) { dwt_lds_attr<128>(); k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n); return; }
 	const int hlf = size >> 1;
 	const dim3 rg((hlf + 255) / 256, size, n), tg((size + 63) / 64, (size + 63) / 64, n);
 	k_syn_rows<0><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
