@@ -84,7 +84,8 @@ static size_t phase_lds(int ph)
 	case PH_LLC: return LLC_LDS_BYTES;
 	case PH_FINAL: return PK_LDS_BYTES;
 	case PH_L4A: return CR_LDS_BYTES > (NT + 2) * TLS * sizeof(int16_t) ? CR_LDS_BYTES : (size_t)(NT + 2) * TLS * sizeof(int16_t);
-	case PH_L4B: case PH_L4C: return (size_t)(NT + 2) * TLS * sizeof(int16_t);
+	case PH_L4B: return (size_t)(NT + 2) * TLS * sizeof(int16_t);
+	case PH_L4C: return 0;                                         /* Y26 is pointwise, Y27 a wavefront per row straight on the plane */
 	case PH_L4D: return 4608;                                      /* the list of run starts (at most one per 15 groups of the stream); the stream itself is written by the quantiser kernel */
 	case PH_C5: return 32 * 130 * 2 + (32 * 128 + 258) * 2 > tile ? 32 * 130 * 2 + (32 * 128 + 258) * 2 : tile;
 	default: return 0;

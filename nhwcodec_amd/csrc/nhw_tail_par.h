@@ -795,47 +795,116 @@ DEV void adjust_first_order_par(Ctx *c, int tid)
  * neighbours are taken from a snapshot of the band, ">= 7" for the row above, ">= 6" for the row below (a cell
  * is >= 7 after its visit exactly when it was >= 7 before).  HH1 also reads column 256, which HL1's ripple may
  * have written, hence the barrier between them. */
-struct CleanF {
-	int thresh, lim, lim2, mode, last_look, row0;
-	const int16_t *snap;
-	struct State { int unused; };
-	__device__ State init(int) const { return State{0}; }
-	__device__ int run(int16_t *row, int t, int j, int j1, State &) const
-	{
-		const int r = row0 + t;
-		for (; j < j1; j++) {
-			int16_t *v = row + j;
-			if (iabs(v[0]) >= thresh) {
-				if (iabs(v[0]) < lim2) {
-					int n;
-					if (mode == 2) {
-						const int16_t *sv = snap + (r - H) * H + (j - H);
-						n = (iabs(v[-1]) >= 6) + (iabs(v[1]) >= 6) + (r == H ? iabs(v[-TLS]) >= 6 : iabs(sv[-H]) >= 7) + (iabs(sv[H]) >= 6);
-					} else n = (iabs(v[-1]) >= 6) + (iabs(v[1]) >= 6) + (iabs(v[-TLS]) >= 6) + (iabs(v[TLS]) >= 6);
-					if (mode == 0) { if (n < 3 && v[0] < lim && v[0] > -lim) { if (v[0] < -6) v[0] = -7; else if (v[0] > 6) v[0] = 7; } }
-					else if (mode == 1) { if ((n < 3 && v[0] < lim && v[0] > -lim) || !n) v[0] = (int16_t)(v[0] < 0 ? -7 : 7); }
-					else { if (n < 3) v[0] = (int16_t)(v[0] < 0 ? -7 : 7); }
-				}
-			} else v[0] = 0;
-			ripple(v, j < last_look);
+/* What travels along a row is only what a cell's ripple did to the cell on its right -- nothing, -1 or +1 (the fourth case of the
+ * reference's ripple, "8 next to -7", is dead code behind the first) -- and the ripple moves only values beyond +-7, so every loudness test
+ * can be made on the values as they were.  A wavefront takes a row, a lane four cells of it: the lanes evaluate their cells for a guessed
+ * incoming step (none), hand the step they produce to the lane on their right and repeat until no lane's input moves (one extra round as
+ * a rule).  Rows are independent, the next one is on its way while this one is evaluated. */
+struct CleanP { int thresh, lim, lim2, last_look; };
+template <int MODE>
+DEV int clean_cell(const CleanP &f, int x, int n, int v1, int v2, bool look2, int &dout)
+{
+	int e = 0;
+	const int ax = iabs(x);
+	if (ax >= f.thresh) {
+		e = x;
+		if (ax < f.lim2) {
+			if (MODE == 0) { if (n < 3 && x < f.lim && x > -f.lim) { if (x < -6) e = -7; else if (x > 6) e = 7; } }
+			else if (MODE == 1) { if ((n < 3 && x < f.lim && x > -f.lim) || !n) e = x < 0 ? -7 : 7; }
+			else { if (n < 3) e = x < 0 ? -7 : 7; }
 		}
-		return j;
 	}
-};
+	dout = 0;                                                      /* the ripple (:1957-1976 etc.) */
+	if (iabs(e) > 6) {
+		if (e >= 8 && (e & 7) < 2) { if (v1 > 7 && v1 < 10000) dout = -1; }
+		else if (e == -7 && v1 == 8) e = -8;
+		else if (e < -7 && ((-e) & 7) < 2) {
+			if (v1 < -14) { if (((-v1) & 7) == 7) dout = 1; else if (((-v1) & 7) < 2 && look2 && v2 <= 0) dout = 1; }
+		}
+	}
+	return e;
+}
+DEV void unpack4(uint2 w, int v[4]) { v[0] = (int16_t)(w.x & 0xFFFF); v[1] = (int16_t)(w.x >> 16); v[2] = (int16_t)(w.y & 0xFFFF); v[3] = (int16_t)(w.y >> 16); }
+/* rows r_first .. r_last of the plane, columns jb .. je-1 processed; the lanes span the 256 columns from c_base (the band's half of the row).
+ * snap (mode 2): the band as it was before the pass, H wide, its row 0 = plane row H, its column 0 = plane column H. */
+template <int MODE>
+DEV void clean_rows_wave(int16_t *p, const CleanP f, int r_first, int r_last, int c_base, int jb, int je, const int16_t *snap, int tid)
+{
+	const int lane = tid & 63, wv = tid >> 6, c0 = c_base + 4 * lane;
+	const bool outer = je > c_base + H - 1;                        /* HL1: the cell behind the last processed one (column 256) is outside the span */
+	uint2 cur = make_uint2(0, 0), up = cur, dn = cur; int far = 0;
+#define CLEAN_LOAD(r) do { \
+		cur = *reinterpret_cast<const uint2 *>(p + (size_t)(r) * W + c0); \
+		if (MODE == 2 && (r) > H) up = *reinterpret_cast<const uint2 *>(snap + (size_t)((r) - H - 1) * H + c0 - H); \
+		else up = *reinterpret_cast<const uint2 *>(p + (size_t)((r) - 1) * W + c0); \
+		if (MODE == 2) dn = *reinterpret_cast<const uint2 *>(snap + (size_t)((r) - H + 1) * H + c0 - H); \
+		else dn = *reinterpret_cast<const uint2 *>(p + (size_t)((r) + 1) * W + c0); \
+		if (outer && lane == 63) far = p[(size_t)(r) * W + c_base + H]; } while (0)
+	int r = r_first + wv;
+	if (r <= r_last) CLEAN_LOAD(r);
+	for (; r <= r_last; r += NT / 64) {
+		int o[4], u[4], d[4];
+		unpack4(cur, o); unpack4(up, u); unpack4(dn, d);
+		const int my_far = far, upt = (MODE == 2 && r > H) ? 7 : 6;
+		const int row = r;
+		if (r + NT / 64 <= r_last) CLEAN_LOAD(r + NT / 64);
+		/* neighbours across the lanes: the cell on the left of my first one, the two on the right of my last one */
+		const int left = __shfl_up(o[3], 1), sd0 = __shfl_down(o[0], 1), r2 = __shfl_down(o[1], 1);   /* every lane takes part in a shuffle: lane 62 reads lane 63 */
+		const int r1 = lane < 63 ? sd0 : my_far;
+		int n[4]; bool proc[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int j = c0 + k;
+			proc[k] = j >= jb && j < je;
+			const int lv = k ? o[k - 1] : left, rv = k < 3 ? o[k + 1] : r1;
+			/* the left neighbour has been visited (HH1 zeroes below 7 there) unless it is the cell in front of the range */
+			const int lt = (MODE == 2 && j - 1 >= jb) ? 7 : 6;
+			n[k] = (iabs(lv) >= lt) + (iabs(rv) >= 6) + (iabs(u[k]) >= upt) + (iabs(d[k]) >= 6);
+		}
+		int din = 0, e[4], dout;
+		for (;;) {
+			int dd = din;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const int j = c0 + k, x = o[k] + dd;
+				if (proc[k]) {
+					const int v1 = k < 3 ? o[k + 1] : r1, v2 = k < 2 ? o[k + 2] : (k == 2 ? r1 : r2);
+					e[k] = clean_cell<MODE>(f, x, n[k], v1, v2, j < f.last_look, dd);
+				} else { e[k] = x; dd = 0; }
+			}
+			dout = dd;
+			int nd = __shfl_up(dout, 1);
+			if (!lane) nd = 0;
+			if (!__any(nd != din)) break;
+			din = nd;
+		}
+		uint2 w;
+		w.x = (uint32_t)(uint16_t)e[0] | ((uint32_t)(uint16_t)e[1] << 16); w.y = (uint32_t)(uint16_t)e[2] | ((uint32_t)(uint16_t)e[3] << 16);
+		*reinterpret_cast<uint2 *>(p + (size_t)row * W + c0) = w;
+		if (outer && lane == 63 && dout) p[(size_t)row * W + c_base + H] = (int16_t)(my_far + dout);
+	}
+#undef CLEAN_LOAD
+}
 DEV void clean_details_par(Ctx *c, int tid, int16_t *lds)
 {
 	int16_t *p = c->proc;
 	const int q = c->q;
-	/* LH1: rows 1..254 (tile rows 0..255 so that the rows above / below are at hand); HL1: rows 256..510 (tile rows 255..511) */
-	CleanF fa = { DEADZONE - 2, q > 22 ? 8 : 9, q > 22 ? 4 : 9, 0, W - 2, 1, nullptr };
-	row_pass_tiled(p, W, W, H, 1, H - 2, H + 1, W - 1, lds, tid, fa);
-	CleanF fb = { DEADZONE - 2, q > 17 ? 8 : 9, q > 22 ? 4 : 9, 1, H - 2, H, nullptr };
-	row_pass_tiled(p + (H - 1) * W, W, W, H + 1, 1, H - 1, 1, H, lds, tid, fb);
+	(void)lds;
+	/* (:1912-2098).  LH1 and HL1 zero everything below 6 and never move a value across 6, so "loud" (|v| >= 6) of any cell is the same
+	 * before, during and after these two passes: the vertical neighbour test does not care which row went first.  HH1 zeroes below 7, so
+	 * a 6 above (already visited in raster order) reads as quiet while a 6 below (not yet visited) reads as loud: the vertical neighbours
+	 * are taken from a snapshot of the band, ">= 7" for the row above, ">= 6" for the row below (a cell is >= 7 after its visit exactly
+	 * when it was >= 7 before).  HH1 also reads column 256, which HL1's ripple may have written, hence the barrier between them. */
+	const CleanP fa = { DEADZONE - 2, q > 22 ? 8 : 9, q > 22 ? 4 : 9, W - 2 };
+	clean_rows_wave<0>(p, fa, 1, H - 2, H, H + 1, W - 1, nullptr, tid);             /* LH1: rows 1..254, columns 257..510 */
+	const CleanP fb = { DEADZONE - 2, q > 17 ? 8 : 9, q > 22 ? 4 : 9, H - 2 };
+	clean_rows_wave<1>(p, fb, H, W - 2, 0, 1, H, nullptr, tid);                     /* HL1: rows 256..510, columns 1..255 */
+	BARRIER();
 	copy_block_par(p + H * W + H, W, c->hs, H, H, H, tid);           /* HH1 band (rows 256..511, cols 256..511) before its pass */
 	BARRIER();
 	const int lim = q > 22 ? 8 : 11;
-	CleanF fc = { DEADZONE - 1, lim, lim, 2, W - 2, H, c->hs };
-	row_pass_tiled(p + (H - 1) * W, W, W, H + 1, 1, H - 1, H + 1, W - 1, lds, tid, fc);
+	const CleanP fc = { DEADZONE - 1, lim, lim, W - 2 };
+	clean_rows_wave<2>(p, fc, H, W - 2, H, H + 1, W - 1, c->hs, tid);               /* HH1: rows 256..510, columns 257..510 */
 }
 
 /* ---------------------------------------------------------------- a10 quantiser */
