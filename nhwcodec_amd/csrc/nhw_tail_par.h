@@ -435,33 +435,71 @@ DEV void dequant_sim_luma_par(Ctx *c, int part, int tid, int *pos)
 
 /* ---------------------------------------------------------------- Y21 (R) */
 /* (:970-1073) only same-row neighbours are read or written (the vertical branches are unreachable) */
-struct TagRunsF {
-	int pass;
-	struct State { int unused; };
-	__device__ State init(int) const { return State{0}; }
-	__device__ int run(int16_t *row, int, int j, int j1, State &) const
-	{
-		for (; j < j1; j++) {
-			int16_t *v = row + j;
-			if (v[0] > 4 && v[0] < 8) { if (in_4_7(v[-1]) && in_4_7(v[1])) { v[0] = 12700; v[-1] = 10100; v[1] = 10100; } }
-			else if (v[0] < -4 && v[0] > -8) { if (in_m7_m4(v[-1]) && in_m7_m4(v[1])) { v[0] = 12900; v[-1] = 10100; v[1] = 10100; } }
-			else if (v[0] == 8) {
-				if ((v[-1] & 0xFFFE) == 6 || (v[1] & 0xFFFE) == 6) v[0] = 10;
-				else if (!pass && v[1] == 8) { v[0] = 9; v[1] = 9; }
-			}
-			else if (v[0] == -8) {
-				if (((-v[-1]) & 0xFFFE) == 6 || ((-v[1]) & 0xFFFE) == 6) v[0] = -9;
-				else if (!pass && v[1] == -8) { v[0] = -9; v[1] = -9; }
-			}
-		}
-		return j;
+/* A cell may overwrite its two neighbours: the one on the left has been visited (nobody looks at it again: that is just its final value),
+ * the one on the right has not, so what travels along the row is (value of the cell as its visit left it, value forced on the next cell).
+ * A wavefront takes a row, a lane four cells; the lanes start from "nothing forced, left neighbour as it was" and hand their results to
+ * the right until nothing moves.  (Every value a cell can be set to fails all of the tests, so the chain dies out after a cell or two.) */
+DEV void unpack4(uint2 w, int v[4]) { v[0] = (int16_t)(w.x & 0xFFFF); v[1] = (int16_t)(w.x >> 16); v[2] = (int16_t)(w.y & 0xFFFF); v[3] = (int16_t)(w.y >> 16); }
+template <int PASS>
+DEV void tag_cell(int x, int lv, int rv, int &own, int &force_next, int &triple)
+{
+	own = x; force_next = 0; triple = 0;
+	if (x > 4 && x < 8) { if (in_4_7(lv) && in_4_7(rv)) { own = 12700; force_next = 10100; triple = 1; } }
+	else if (x < -4 && x > -8) { if (in_m7_m4(lv) && in_m7_m4(rv)) { own = 12900; force_next = 10100; triple = 1; } }
+	else if (x == 8) {
+		if ((lv & 0xFFFE) == 6 || (rv & 0xFFFE) == 6) own = 10;
+		else if (!PASS && rv == 8) { own = 9; force_next = 9; }
 	}
-};
+	else if (x == -8) {
+		if (((-lv) & 0xFFFE) == 6 || ((-rv) & 0xFFFE) == 6) own = -9;
+		else if (!PASS && rv == -8) { own = -9; force_next = -9; }
+	}
+}
+template <int PASS>
+DEV void tag_rows_wave(int16_t *p, int r_first, int r_last, int c_base, int jb, int je, int tid)
+{
+	const int lane = tid & 63, wv = tid >> 6, c0 = c_base + 4 * lane;
+	int r = r_first + wv;
+	uint2 cur = make_uint2(0, 0);
+	if (r <= r_last) cur = *reinterpret_cast<const uint2 *>(p + (size_t)r * W + c0);
+	for (; r <= r_last; r += NT / 64) {
+		int o[4];
+		unpack4(cur, o);
+		const int row = r;
+		if (r + NT / 64 <= r_last) cur = *reinterpret_cast<const uint2 *>(p + (size_t)(r + NT / 64) * W + c0);
+		const int sd0 = __shfl_down(o[0], 1);                      /* the cell on the right of my last one, as it was */
+		const int left0 = __shfl_up(o[3], 1);
+		int lv_in = left0, force_in = 0, own[4], trip[4], lv_out, force_out;
+		for (;;) {
+			int lv = lv_in, force = force_in;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const int j = c0 + k, x = force ? force : o[k];
+				if (j >= jb && j < je) tag_cell<PASS>(x, lv, k < 3 ? o[k + 1] : sd0, own[k], force, trip[k]);
+				else { own[k] = x; force = 0; trip[k] = 0; }
+				lv = own[k];
+			}
+			lv_out = lv; force_out = force;
+			int nl = __shfl_up(lv_out, 1), nf = __shfl_up(force_out, 1);
+			if (!lane) { nl = left0; nf = 0; }
+			if (!__any(nl != lv_in || nf != force_in)) break;
+			lv_in = nl; force_in = nf;
+		}
+		const int tnext = __shfl_down(trip[0], 1);                 /* a triple marks the cell before it as well */
+		int fin[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) fin[k] = (k < 3 ? trip[k + 1] : (lane < 63 ? tnext : 0)) ? 10100 : own[k];
+		uint2 w;
+		w.x = (uint32_t)(uint16_t)fin[0] | ((uint32_t)(uint16_t)fin[1] << 16); w.y = (uint32_t)(uint16_t)fin[2] | ((uint32_t)(uint16_t)fin[3] << 16);
+		*reinterpret_cast<uint2 *>(p + (size_t)row * W + c0) = w;
+	}
+}
 DEV void tag_small_runs_par(Ctx *c, int tid, int16_t *lds)
 {
-	TagRunsF f0 = { 0 }, f1 = { 1 };
-	row_pass_tiled(c->proc + 1 * W, W, W, H - 2, 0, H - 2, H + 1, W - 1, lds, tid, f0);          /* rows 1..254, LH1 columns */
-	row_pass_tiled(c->proc + (H + 1) * W, W, W, H - 2, 0, H - 2, 1, H - 1, lds, tid, f1);        /* rows 257..510, HL1 columns */
+	(void)lds;
+	tag_rows_wave<0>(c->proc, 1, H - 2, H, H + 1, W - 1, tid);                   /* rows 1..254, LH1 columns 257..510 */
+	tag_rows_wave<1>(c->proc, H + 1, W - 2, 0, 1, H - 1, tid);                   /* rows 257..510, HL1 columns 1..254 */
+	BARRIER();
 }
 
 /* ---------------------------------------------------------------- Y22 / Y23 (C) */
@@ -824,7 +862,6 @@ DEV int clean_cell(const CleanP &f, int x, int n, int v1, int v2, bool look2, in
 	}
 	return e;
 }
-DEV void unpack4(uint2 w, int v[4]) { v[0] = (int16_t)(w.x & 0xFFFF); v[1] = (int16_t)(w.x >> 16); v[2] = (int16_t)(w.y & 0xFFFF); v[3] = (int16_t)(w.y >> 16); }
 /* rows r_first .. r_last of the plane, columns jb .. je-1 processed; the lanes span the 256 columns from c_base (the band's half of the row).
  * snap (mode 2): the band as it was before the pass, H wide, its row 0 = plane row H, its column 0 = plane column H. */
 template <int MODE>
