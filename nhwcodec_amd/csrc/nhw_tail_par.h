@@ -156,59 +156,73 @@ DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff
 /* ---------------------------------------------------------------- Y9 (R) */
 /* (:218-279) left neighbour is read after its own update, right neighbour before: serial along a row; rows do
  * not interact (column 0 reads proc[r][-1] = the LH1 cell (r-1, 511), which this pass never writes). */
-DEV void precompensate_ll1_par(Ctx *c, int tid, int16_t *lds /* one tile */)
+DEV void unpack4(uint2 w, int v[4]) { v[0] = (int16_t)(w.x & 0xFFFF); v[1] = (int16_t)(w.x >> 16); v[2] = (int16_t)(w.y & 0xFFFF); v[3] = (int16_t)(w.y >> 16); }
+DEV int precomp_step(int d, int dnext, int prev)
+{
+	int step = big_step(d);
+	if (!step && iabs(d) > 1) {
+		int a = dnext;
+		if (iabs(a) > 4) a += big_step(a);
+		a += prev;
+		if (d >= 4 && a >= 1) step = -1;
+		else if (d <= -4 && a <= -1) step = 1;
+		else if (d == 3 && a >= 0) step = -1;
+		else if (d == -3 && a <= 0) step = 1;
+		else if (iabs(a) >= 3) {
+			if (d > 0 && a > 0) step = -1;
+			else if (d < 0 && a < 0) step = 1;
+			else if (a >= 5) step = -2;
+			else if (a <= -5) step = 2;
+			else if (a >= 4) step = -1;
+			else if (a <= -4) step = 1;
+		}
+	}
+	return step;
+}
+DEV void precompensate_ll1_par(Ctx *c, int tid, int16_t *lds)
 {
 	/* The walk only looks at differences d = recon - ll1 (its own, its right neighbour's original one, its left neighbour's
-	 * updated one) and moves recon and the jpeg copy of ll1 by the same step: the tile holds the differences, each row's
-	 * thread replaces them by the steps, and the planes are updated from the steps with coalesced pair accesses. */
+	 * updated one) and moves recon and the jpeg copy of ll1 by the same step.  A wavefront takes a row, a lane four cells: what travels
+	 * along the row is the updated difference of the cell on the left; the lanes start from the original one and hand theirs on until
+	 * nothing moves.  The next row is on its way meanwhile. */
 	int16_t *p = c->proc, *o = c->ll1, *jp = c->jpeg;
-	const int r = tid;
-	int prev = 0;
-	for (int c0 = 0; c0 < H; c0 += TLC) {
-		for (int idx = tid; idx < H * (TLS / 2); idx += NT) {
-			const int rr = idx / (TLS / 2), d = idx % (TLS / 2);
-			const uint32_t a = reinterpret_cast<const uint32_t *>(p + (size_t)rr * W + c0 - 2)[d], b2 = reinterpret_cast<const uint32_t *>(o + (size_t)rr * H + c0 - 2)[d];
-			reinterpret_cast<uint32_t *>(lds + rr * TLS)[d] = ((a - b2) & 0xFFFF) | (((a >> 16) - (b2 >> 16)) << 16);
+	const int lane = tid & 63, wv = tid >> 6, c0 = 4 * lane;
+	(void)lds;
+	uint2 pc = make_uint2(0, 0), oc = pc; int edge = 0;
+#define PRE_LOAD(r) do { pc = *reinterpret_cast<const uint2 *>(p + (size_t)(r) * W + c0); oc = *reinterpret_cast<const uint2 *>(o + (size_t)(r) * H + c0); \
+		if (lane == 0) edge = p[(size_t)(r) * W - 1] - o[(size_t)(r) * H - 1];       /* left neighbour of column 0: the cells before the row in memory, never updated */ \
+		if (lane == 63) edge = p[(size_t)(r) * W + H] - o[(size_t)(r) * H + H]; } while (0)
+	int r = wv;
+	PRE_LOAD(r);
+	for (; r < H; r += NT / 64) {
+		int pv[4], ov[4], d[4], st[4];
+		unpack4(pc, pv); unpack4(oc, ov);
+		const int my_edge = edge, row = r;
+#pragma unroll
+		for (int k = 0; k < 4; k++) d[k] = (int16_t)(pv[k] - ov[k]);
+		if (r + NT / 64 < H) PRE_LOAD(r + NT / 64);
+		const int sd = __shfl_down(d[0], 1), su = __shfl_up(d[3], 1);
+		const int dn4 = lane < 63 ? sd : my_edge;                  /* the difference on the right of my last cell, as it was */
+		const int first = lane ? su : my_edge;
+		int prev_in = first, prev_out;
+		for (;;) {
+			int prev = prev_in;
+#pragma unroll
+			for (int k = 0; k < 4; k++) { st[k] = precomp_step(d[k], k < 3 ? d[k + 1] : dn4, prev); prev = d[k] + st[k]; }
+			prev_out = prev;
+			int np = __shfl_up(prev_out, 1);
+			if (!lane) np = first;
+			if (!__any(np != prev_in)) break;
+			prev_in = np;
 		}
-		BARRIER();
-		{
-			int16_t *dv = lds + r * TLS + 2 - c0;
-			if (c0 == 0) prev = dv[-1];                             /* left neighbour of column 0 (the cells before the row in memory; never updated) */
-			for (int j = c0; j < c0 + TLC; j++) {
-				const int d = dv[j];
-				int step = big_step(d);
-				if (!step && iabs(d) > 1) {
-					int a = dv[j + 1];
-					if (iabs(a) > 4) a += big_step(a);
-					a += prev;
-					if (d >= 4 && a >= 1) step = -1;
-					else if (d <= -4 && a <= -1) step = 1;
-					else if (d == 3 && a >= 0) step = -1;
-					else if (d == -3 && a <= 0) step = 1;
-					else if (iabs(a) >= 3) {
-						if (d > 0 && a > 0) step = -1;
-						else if (d < 0 && a < 0) step = 1;
-						else if (a >= 5) step = -2;
-						else if (a <= -5) step = 2;
-						else if (a >= 4) step = -1;
-						else if (a <= -4) step = 1;
-					}
-				}
-				prev = d + step;
-				dv[j] = (int16_t)step;
-			}
-		}
-		BARRIER();
-		for (int idx = tid; idx < H * (TLC / 2); idx += NT) {        /* recon += step, jpeg = ll1 + step */
-			const int rr = idx / (TLC / 2), d = idx % (TLC / 2);
-			const uint32_t st = reinterpret_cast<const uint32_t *>(lds + rr * TLS + 2)[d];
-			uint32_t *pp = reinterpret_cast<uint32_t *>(p + (size_t)rr * W + c0) + d;
-			const uint32_t a = *pp, b2 = reinterpret_cast<const uint32_t *>(o + (size_t)rr * H + c0)[d];
-			*pp = ((a + st) & 0xFFFF) | (((a >> 16) + (st >> 16)) << 16);
-			reinterpret_cast<uint32_t *>(jp + (size_t)rr * W + c0)[d] = ((b2 + st) & 0xFFFF) | (((b2 >> 16) + (st >> 16)) << 16);
-		}
-		BARRIER();
+		uint2 w;
+		w.x = (uint32_t)(uint16_t)(pv[0] + st[0]) | ((uint32_t)(uint16_t)(pv[1] + st[1]) << 16); w.y = (uint32_t)(uint16_t)(pv[2] + st[2]) | ((uint32_t)(uint16_t)(pv[3] + st[3]) << 16);
+		*reinterpret_cast<uint2 *>(p + (size_t)row * W + c0) = w;
+		w.x = (uint32_t)(uint16_t)(ov[0] + st[0]) | ((uint32_t)(uint16_t)(ov[1] + st[1]) << 16); w.y = (uint32_t)(uint16_t)(ov[2] + st[2]) | ((uint32_t)(uint16_t)(ov[3] + st[3]) << 16);
+		*reinterpret_cast<uint2 *>(jp + (size_t)row * W + c0) = w;
 	}
+#undef PRE_LOAD
+	BARRIER();
 }
 
 /* ---------------------------------------------------------------- a8 dequantisation simulation */
@@ -439,7 +453,6 @@ DEV void dequant_sim_luma_par(Ctx *c, int part, int tid, int *pos)
  * the one on the right has not, so what travels along the row is (value of the cell as its visit left it, value forced on the next cell).
  * A wavefront takes a row, a lane four cells; the lanes start from "nothing forced, left neighbour as it was" and hand their results to
  * the right until nothing moves.  (Every value a cell can be set to fails all of the tests, so the chain dies out after a cell or two.) */
-DEV void unpack4(uint2 w, int v[4]) { v[0] = (int16_t)(w.x & 0xFFFF); v[1] = (int16_t)(w.x >> 16); v[2] = (int16_t)(w.y & 0xFFFF); v[3] = (int16_t)(w.y >> 16); }
 template <int PASS>
 DEV void tag_cell(int x, int lv, int rv, int &own, int &force_next, int &triple)
 {
