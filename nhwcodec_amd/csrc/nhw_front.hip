@@ -674,9 +674,9 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict_
 			int16_t v[10];
 #pragma unroll
 			for (int e = 0; e < 10; e++) v[e] = (g == 0 && e == 0) ? (int16_t)0 : km[e - 1];   /* columns 8g-1 .. 8g+8 */
-			int big = 0;                                            /* every rule needs a kernel value beyond +-10 */
+			int big = 0;                                            /* every rule needs a kernel value of at least 23 in its pair: |k| > 176, or a moderate one (11..31) next to one >= 23 */
 #pragma unroll
-			for (int e = 2; e < 10; e++) big |= iabs(v[e]) > 10;
+			for (int e = 2; e < 10; e++) big |= iabs(v[e]) > 22;
 			if (!big) continue;
 			int prev_big = g ? pair_big_flag_fwd(v[0], v[1]) : ((stl[rt] >> 4) & 1);
 #pragma unroll
