@@ -242,7 +242,17 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s);
 	STAGE_DONE();
 	nhw_launch_phase(PH_L4A, ws, 0, out, d_sizes, d_status, s);      /* Y19-Y23 */
-	nhw_launch_phase(PH_L4B, ws, 0, out, d_sizes, d_status, s);      /* Y24, Y25 */
+	/* Y24, Y25: the position lists are read by nothing before the packetiser, and what the pass leaves in the residual-code plane by nobody
+	 * at all; below q21 it shares no scratch with the passes behind it either (from q21 on its third list and Y27's snapshot both live in
+	 * the hs plane, and Y29 needs Y24), so there it runs beside them on a stream of its own */
+	const bool fork_lists = fork && q <= 20;
+	if (fork_lists) {
+		HIPCHK(hipEventRecord(e->part_ev[2], s));
+		HIPCHK(hipStreamWaitEvent(e->part_stream[1], e->part_ev[2], 0));
+		nhw_launch_phase(PH_L4B, ws, 0, out, d_sizes, d_status, e->part_stream[1]);
+		HIPCHK(hipEventRecord(e->part_ev[3], e->part_stream[1]));
+	} else
+		nhw_launch_phase(PH_L4B, ws, 0, out, d_sizes, d_status, s);  /* Y24, Y25 */
 	nhw_launch_phase(PH_L4C, ws, 0, out, d_sizes, d_status, s);      /* Y26, Y27 */
 	nhw_launch_wave(WV_QUANT, ws, s);                                /* Y28 */
 	if (q > 21) nhw_launch_phase(PH_L4C2, ws, 0, out, d_sizes, d_status, s);   /* Y29 */
@@ -259,6 +269,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	STAGE_DONE();
 	if (timed) HIPCHK(hipEventRecord(e->ev[2], s));
 
+	if (fork_lists) HIPCHK(hipStreamWaitEvent(s, e->part_ev[3], 0));
 	if (fork) HIPCHK(hipStreamWaitEvent(s, e->part_ev[1], 0));
 	else
 		for (int comp = 0; comp < 2; comp++) {       /* U then V (:2255-2570, :2572-2868) */
