@@ -25,6 +25,20 @@ __device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned acc
 	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
 	return d;
 }
+/* |a.lo - b.lo| + |a.hi - b.hi| + acc on the two unsigned 16-bit halves of a dword */
+__device__ __forceinline__ unsigned sad_u16(unsigned a, unsigned b, unsigned acc)
+{
+	unsigned d;
+	asm("v_sad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+	return d;
+}
+/* two 16-bit sums in a dword (no carry between the halves) */
+__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b)
+{
+	unsigned d;
+	asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
 
 /* ------------------------------------------------------------------------------------------------
  * colour + 4:2:0.  One workgroup per pair of luma rows (2r, 2r+1) = one chroma row r.
@@ -586,20 +600,38 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict_
 			const int rt = k % FB_TROWS, c0 = 8 * (k / FB_TROWS), row = t0 + rt;
 			uint32_t out[4] = { 0, 0, 0, 0 };
 			if (row >= 1 && row <= W - 2) {
-				int up[12], md[12], dn[12];
-				row_window(ybuf + rt * FB_RS, c0, up); row_window(ybuf + (rt + 1) * FB_RS, c0, md); row_window(ybuf + (rt + 2) * FB_RS, c0, dn);
-				int s3[12];                                        /* column sums of the three rows, shared by the three windows a column is in */
+				/* The rows stay packed, two pixels to a dword (luma is never negative here): a pixel's eight absolute differences are four
+				 * v_sad_u16 against dwords that hold two neighbours each -- the two pixels above and below that share its dword, and two
+				 * dwords put together from the neighbouring ones -- and the column sums of the three rows are packed adds. */
+				uint32_t U[6], M[6], D[6], S[6];
+				const uint32_t *ru = reinterpret_cast<const uint32_t *>(ybuf + rt * FB_RS) + (c0 >> 1) - 1;
+				const uint32_t *rm = reinterpret_cast<const uint32_t *>(ybuf + (rt + 1) * FB_RS) + (c0 >> 1) - 1;
+				const uint32_t *rd = reinterpret_cast<const uint32_t *>(ybuf + (rt + 2) * FB_RS) + (c0 >> 1) - 1;
 #pragma unroll
-				for (int i = 1; i < 11; i++) s3[i] = up[i] + md[i] + dn[i];
+				for (int j = 0; j < 6; j++) {
+					const bool skip = j == 0 && c0 == 0;               /* the two pixels before the row: no neighbours of anything that counts */
+					U[j] = skip ? 0u : ru[j]; M[j] = skip ? 0u : rm[j]; D[j] = skip ? 0u : rd[j];
+					S[j] = pk_add16(pk_add16(U[j], M[j]), D[j]);
+				}
 #pragma unroll
-				for (int e = 0; e < 8; e++) {                      /* pixel c0+e sits at window index e+2 */
-					const int c = c0 + e, ctr = md[e + 2];
-					const int sum = 9 * ctr - (s3[e + 1] + s3[e + 2] + s3[e + 3]);   /* sum of the eight differences */
-					const int mag = (int)sad_u32(ctr, up[e + 1], sad_u32(ctr, up[e + 2], sad_u32(ctr, up[e + 3], sad_u32(ctr, md[e + 1], sad_u32(ctr, md[e + 3],
-					                sad_u32(ctr, dn[e + 1], sad_u32(ctr, dn[e + 2], sad_u32(ctr, dn[e + 3], 0u))))))));
-					const int base = 15 * iabs(sum) + mag;
-					const int vb = (sum == 0 || c < 1 || c > W - 2) ? 0 : (sum < 0 ? -base : base);
-					out[e >> 1] |= (uint32_t)(uint16_t)vb << (16 * (e & 1));
+				for (int pr = 0; pr < 4; pr++) {                     /* pixels c0 + 2 pr (low half of dword K) and c0 + 2 pr + 1 (high half) */
+					const int K = pr + 1;
+					const int T = (int)(S[K] & 0xFFFFu) + (int)(S[K] >> 16);
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						const int c = c0 + 2 * pr + h;
+						const int ctr = h ? (int)(M[K] >> 16) : (int)(M[K] & 0xFFFFu);
+						const uint32_t cc = __builtin_amdgcn_perm(M[K], M[K], h ? 0x03020302u : 0x01000100u);
+						/* the column beside the dword: the one on the left for the low pixel, on the right for the high one */
+						const uint32_t side = h ? __builtin_amdgcn_perm(D[K + 1], U[K + 1], 0x05040100u) : __builtin_amdgcn_perm(D[K - 1], U[K - 1], 0x07060302u);
+						const uint32_t mids = h ? __builtin_amdgcn_perm(M[K + 1], M[K], 0x05040100u) : __builtin_amdgcn_perm(M[K], M[K - 1], 0x07060302u);
+						const int mag = (int)sad_u16(cc, U[K], sad_u16(cc, D[K], sad_u16(cc, side, sad_u16(cc, mids, 0u))));
+						const int wsum = T + (h ? (int)(S[K + 1] & 0xFFFFu) : (int)(S[K - 1] >> 16));
+						const int sum = 9 * ctr - wsum;
+						const int base = 15 * iabs(sum) + mag;
+						const int vb = (sum == 0 || c < 1 || c > W - 2) ? 0 : (sum < 0 ? -base : base);
+						out[pr] |= (uint32_t)(uint16_t)vb << (16 * h);
+					}
 				}
 			}
 			uint32_t *d = reinterpret_cast<uint32_t *>(kbuf + rt * FB_RS + c0);
