@@ -79,7 +79,7 @@ static size_t phase_lds(int ph)
 {
 	const size_t tile = (size_t)NT * TLS * sizeof(int16_t);
 	switch (ph) {
-	case PH_L2: return tile;
+	case PH_L2: return 3 * 32 * 33 + 32;                          /* the three 32 x 32 blocks of steps of Y8 (Y9 works on the plane itself) */
 	case PH_L3: return LL_LDS_BYTES;
 	case PH_LLC: return LLC_LDS_BYTES;
 	case PH_FINAL: return PK_LDS_BYTES;
