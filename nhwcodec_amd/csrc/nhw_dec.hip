@@ -1338,15 +1338,17 @@ __global__ __launch_bounds__(256) void k_dec_smooth(DecWs ws)
 
 /* ---------------------------------------------------------------------------------------------- chroma
  * pair / single corrections carried as symbols in the level-1 detail bands (:992-1083) */
+#define CPAIR_ROWS 16
 __global__ __launch_bounds__(256) void k_dec_cpairs(DecWs ws)
 {
-	const int img = blockIdx.y, comp = blockIdx.z, i = blockIdx.x, j = threadIdx.x;
+	const int img = blockIdx.y, comp = blockIdx.z, j = threadIdx.x;
 	if (ws.buf<DecMeta>(D_META, img)->status) return;
-	if (i < DH / 2 && j < DH / 2) return;
 	int16_t *a = plane_ca(ws, img, comp);
+	for (int i = CPAIR_ROWS * blockIdx.x; i < CPAIR_ROWS * (blockIdx.x + 1); i++) {   /* a workgroup per row was two million workgroups of a few instructions */
+	if (i < DH / 2 && j < DH / 2) continue;
 	int16_t *p = a + (size_t)i * DH + j;
 	const int s = *p;
-	if (s < 5003 || s > 5006) return;
+	if (s < 5003 || s > 5006) continue;
 	int16_t *t = a + (size_t)(i < DH / 2 ? i : i - DH / 2) * DH + (j < DH / 2 ? j : j - DH / 2);   /* level-1 LL lives in the top-left quarter of the same plane */
 	const bool two = (j < DH / 2 ? j : j - DH / 2) < DH / 2 - 1;      /* the second cell of a pair at the last LL column is scratch in the reference */
 	if (s == 5005) { add_i16(t, -4); if (two) add_i16(t + 1, -4); }
@@ -1354,6 +1356,7 @@ __global__ __launch_bounds__(256) void k_dec_cpairs(DecWs ws)
 	else if (s == 5003) add_i16(t, -6);
 	else add_i16(t, 6);
 	*p = 0;
+	}
 }
 
 /* sharpen (:1097-1121): in place and in raster order -- a cell sees the new values of its left and upper neighbours.
@@ -1613,7 +1616,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 		SynthArgs a1 = { D_CA, D_CB, -1, DH, DH / 2, DH / 2, 0, 0, 0 }, a2 = { D_CB, D_CA, -1, DH, DH / 2, DH / 2, DH / 2, 1, 1 };
 		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, cs>>>(ws, a1);
 		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, cs>>>(ws, a2);
-		k_dec_cpairs<<<dim3(DH, n, 2), 256, 0, cs>>>(ws);
+		k_dec_cpairs<<<dim3(DH / CPAIR_ROWS, n, 2), 256, 0, cs>>>(ws);
 		SynthArgs b1 = { D_CA, D_CB, -1, DH, DH, DH, DH / 2, 0, 0 }, b2 = { D_CB, D_CA, -1, DH, DH, DH, DH, 1, 1 };
 		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, cs>>>(ws, b1);
 		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, cs>>>(ws, b2);
@@ -1658,7 +1661,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, s>>>(ws, a1);
 		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, s>>>(ws, a2);
 		STAGE_END();                                                              /* 11 */
-		k_dec_cpairs<<<dim3(DH, n, 2), 256, 0, s>>>(ws);
+		k_dec_cpairs<<<dim3(DH / CPAIR_ROWS, n, 2), 256, 0, s>>>(ws);
 		STAGE_END();                                                              /* 12 */
 		SynthArgs b1 = { D_CA, D_CB, -1, DH, DH, DH, DH / 2, 0, 0 }, b2 = { D_CB, D_CA, -1, DH, DH, DH, DH, 1, 1 };
 		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, s>>>(ws, b1);
