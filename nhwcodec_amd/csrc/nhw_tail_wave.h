@@ -1,3 +1,4 @@
+#include <type_traits>
 /*
  * nhw_tail_wave.h -- one wavefront per image: the raster-serial passes as row-sequential, column-parallel walks.
  *
@@ -64,6 +65,7 @@ DEV unsigned bs_dn(unsigned b, int lane)                                        
 	const unsigned x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
 	return lane < 63 ? x : seam;
 }
+#define BS_PREDK(b, arr, k0, expr) do { (b) = 0; for (int k_ = (k0); k_ < 4; k_++) { const int x = (arr)[k_]; (b) |= ((expr) ? 1u : 0u) << k_; } } while (0)
 #define BS_PRED(b, arr, n, expr) do { (b) = 0; for (int k_ = 0; k_ < (n); k_++) { const int x = (arr)[k_]; (b) |= ((expr) ? 1u : 0u) << k_; } } while (0)
 DEV M4 bs_ballot4(unsigned b) { return M4{ { __ballot(b & 1), __ballot(b & 2), __ballot(b & 4), __ballot(b & 8) } }; }
 DEV unsigned bs_from4(M4 m) { unsigned b = 0; for (int k = 0; k < 4; k++) b |= (unsigned)__builtin_amdgcn_inverse_ballot_w64(m.w[k]) << k; return b; }
@@ -311,7 +313,10 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 #define UP(b) bs_up<4>((b), lane)
 #define DN(b) bs_dn((b), lane)
 #define BIT(b, k) (((b) >> (k)) & 1u)
-	for (int r = 0; r < H; r++) {
+	/* one row; K0 = 2 in the upper half, where the first two words of a row (columns 0..127: they read as zero, det_load_row) take no part:
+	 * their predicates and updates are not evaluated at all (the kernel is bound by vector work) */
+	auto row_step = [&](auto k0c, const int r) {
+		constexpr int K0 = decltype(k0c)::value;
 		int far[4];
 		det_load_row(p, r + 5, lane, far);
 		const bool top = r < H / 2;
@@ -321,8 +326,8 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 		pend = 0;
 		if (r < H - 1) {                                           /* :2759-2853 */
 			unsigned P, N, PN, NN;
-			BS_PRED(P, cur, 4, x > 3 && x < 8); BS_PRED(N, cur, 4, x < -3 && x > -8);
-			BS_PRED(PN, nxt, 4, x > 3 && x < 8); BS_PRED(NN, nxt, 4, x < -3 && x > -8);
+			BS_PREDK(P, cur, K0, x > 3 && x < 8); BS_PREDK(N, cur, K0, x < -3 && x > -8);
+			BS_PREDK(PN, nxt, K0, x > 3 && x < 8); BS_PREDK(NN, nxt, K0, x < -3 && x > -8);
 			const unsigned rg = bs_range(col0 + 1, H - 2, lane);
 			const unsigned dP = DN(P), dN = DN(N);
 			const unsigned pp = P & UP(P), nn = N & UP(N);
@@ -336,7 +341,7 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 				const unsigned ft = ftp | ftn, fv = fvp | fvn;
 				const unsigned ftp_l = DN(ftp), ftn_l = DN(ftn), fvp_l = DN(fvp), fvn_l = DN(fvn);   /* the cell left of a firing cell */
 				const unsigned ftp_r = UP(ftp), ftn_r = UP(ftn);
-				for (int k = 0; k < 4; k++) {
+				for (int k = K0; k < 4; k++) {
 					if (BIT(ft, k)) cur[k] = 0;
 					if (BIT(ftp_l, k)) cur[k] = 15300; if (BIT(ftn_l, k)) cur[k] = 15400;
 					if (BIT(fvp_l, k)) { cur[k] = 15500; nxt[k] = 15500; }
@@ -353,19 +358,19 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 		}
 		if (!part) {                                               /* :2857-2905 */
 			unsigned A, B;
-			BS_PRED(A, cur, 4, x >= 5 && x <= 7); BS_PRED(B, cur, 4, x <= -5 && x >= -7);
+			BS_PREDK(A, cur, K0, x >= 5 && x <= 7); BS_PREDK(B, cur, K0, x <= -5 && x >= -7);
 			const unsigned cand = ((A & DN(A)) | (B & DN(B))) & bs_range(col0, H - 2, lane);
 			if (__any(cand != 0)) {
 				const unsigned fired = bs_from4(alt_runs(bs_ballot4(cand)));
 				const unsigned fa = fired & A, fb = fired & B;
-				for (int k = 0; k < 4; k++) { if (BIT(fa, k)) cur[k] = 15700; if (BIT(fb, k)) cur[k] = 15800; }
+				for (int k = K0; k < 4; k++) { if (BIT(fa, k)) cur[k] = 15700; if (BIT(fb, k)) cur[k] = 15800; }
 			}
 		}
 		{                                                          /* :2909-3124 */
 			unsigned code, k1, k2;
-			BS_PRED(code, cur, 4, x > 15000);
-			BS_PRED(k2, cur, 4, x == 15300 || x == 15400);
-			BS_PRED(k1, cur, 4, x == 15500 || x == 15600 || x == 15700 || x == 15800);
+			BS_PREDK(code, cur, K0, x > 15000);
+			BS_PREDK(k2, cur, K0, x == 15300 || x == 15400);
+			BS_PREDK(k1, cur, K0, x == 15500 || x == 15600 || x == 15700 || x == 15800);
 			const unsigned rd = bs_range(col0, H - 1, lane);
 			unsigned skipped = 0;
 			if (__any(((k1 | k2) & rd) != 0)) {                    /* which cells the walk steps over: a visited code cell hides the next one (two for a triple) */
@@ -391,8 +396,8 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 			const unsigned vis = rd & ~skipped, vc = vis & code, vnc = vis & ~code;
 			const unsigned ml = bs_range(0, H - 2, lane);
 			unsigned e8, e7, em7, dc, ac;
-			BS_PRED(e8, cur, 4, x == 8); BS_PRED(e7, cur, 4, x == 7); BS_PRED(em7, cur, 4, x == -7);
-			BS_PRED(dc, cur, 4, x > 12 && x < 15000 && (x & 7) >= 6); BS_PRED(ac, cur, 4, x < -12 && ((-x) & 7) == 6);
+			BS_PREDK(e8, cur, K0, x == 8); BS_PREDK(e7, cur, K0, x == 7); BS_PREDK(em7, cur, K0, x == -7);
+			BS_PREDK(dc, cur, K0, x > 12 && x < 15000 && (x & 7) >= 6); BS_PREDK(ac, cur, K0, x < -12 && ((-x) & 7) == 6);
 			const unsigned dm = part ? 0u : (vnc & ml & dc);
 			const unsigned udm = UP(dm);
 			const unsigned is8 = vnc & (e8 | (e7 & udm));           /* the walk sees an 8 here (a 7 the cell before has raised counts) */
@@ -401,9 +406,9 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 			const unsigned self_m8 = vnc & ml & em7 & ~to_m8 & DN(e8);
 			const unsigned m8 = to_m8 | self_m8;
 			unsigned pr_p, pr_n;                                    /* visited 15700 / 15800: the partner takes the same +-6 */
-			BS_PRED(pr_p, cur, 4, x == 15700); BS_PRED(pr_n, cur, 4, x == 15800);
+			BS_PREDK(pr_p, cur, K0, x == 15700); BS_PREDK(pr_n, cur, K0, x == 15800);
 			const unsigned part_p = UP(pr_p & vc), part_n = UP(pr_n & vc);
-			for (int k = 0; k < 4; k++) {
+			for (int k = K0; k < 4; k++) {
 				if (BIT(m8, k)) cur[k] = -8;
 				if (BIT(to_8, k)) cur[k] = 8;
 				if (BIT(part_p, k)) jv[k] = 6;
@@ -422,17 +427,18 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 				}
 			}
 			unsigned wr;                                            /* code cells with another value (none are produced) write nothing */
-			BS_PRED(wr, cur, 4, x > 15000 && !(x == 15300 || x == 15400 || x == 15500 || x == 15600 || x == 15700 || x == 15800));
+			BS_PREDK(wr, cur, K0, x > 15000 && !(x == 15300 || x == 15400 || x == 15500 || x == 15600 || x == 15700 || x == 15800));
 			je |= part_p | part_n | (vis & ~wr);
 		}
-		for (int k = 0; k < 4; k++) {
-			if (top && k < 2) continue;
+		for (int k = K0; k < 4; k++) {
 			const int at = r * W + lane + 64 * k;
 			p[at] = (int16_t)cur[k];
 			if (BIT(je, k)) jp[at] = (int16_t)jv[k];
 		}
 		for (int k = 0; k < 4; k++) { cur[k] = nxt[k]; nxt[k] = q0[k]; q0[k] = q1[k]; q1[k] = q2[k]; q2[k] = far[k]; }
-	}
+	};
+	for (int r = 0; r < H / 2; r++) row_step(std::integral_constant<int, 2>{}, r);
+	for (int r = H / 2; r < H; r++) row_step(std::integral_constant<int, 0>{}, r);
 #undef UP
 #undef DN
 #undef BIT
