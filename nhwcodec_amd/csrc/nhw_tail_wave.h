@@ -367,10 +367,13 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 			}
 		}
 		{                                                          /* :2909-3124 */
-			unsigned code, k1, k2;
+			unsigned code, k1 = 0, k2 = 0;
 			BS_PREDK(code, cur, K0, x > 15000);
-			BS_PREDK(k2, cur, K0, x == 15300 || x == 15400);
-			BS_PREDK(k1, cur, K0, x == 15500 || x == 15600 || x == 15700 || x == 15800);
+			const bool any_code = __any(code != 0);                 /* most rows carry no mark at all: the tests that tell the marks apart are skipped then */
+			if (any_code) {
+				BS_PREDK(k2, cur, K0, x == 15300 || x == 15400);
+				BS_PREDK(k1, cur, K0, x == 15500 || x == 15600 || x == 15700 || x == 15800);
+			}
 			const unsigned rd = bs_range(col0, H - 1, lane);
 			unsigned skipped = 0;
 			if (__any(((k1 | k2) & rd) != 0)) {                    /* which cells the walk steps over: a visited code cell hides the next one (two for a triple) */
@@ -405,8 +408,8 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 			const unsigned to_8 = e7 & udm;
 			const unsigned self_m8 = vnc & ml & em7 & ~to_m8 & DN(e8);
 			const unsigned m8 = to_m8 | self_m8;
-			unsigned pr_p, pr_n;                                    /* visited 15700 / 15800: the partner takes the same +-6 */
-			BS_PREDK(pr_p, cur, K0, x == 15700); BS_PREDK(pr_n, cur, K0, x == 15800);
+			unsigned pr_p = 0, pr_n = 0;                            /* visited 15700 / 15800: the partner takes the same +-6 */
+			if (any_code) { BS_PREDK(pr_p, cur, K0, x == 15700); BS_PREDK(pr_n, cur, K0, x == 15800); }
 			const unsigned part_p = UP(pr_p & vc), part_n = UP(pr_n & vc);
 			for (int k = K0; k < 4; k++) {
 				if (BIT(m8, k)) cur[k] = -8;
@@ -426,8 +429,8 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 					jv[k] = dequant_value(a);
 				}
 			}
-			unsigned wr;                                            /* code cells with another value (none are produced) write nothing */
-			BS_PREDK(wr, cur, K0, x > 15000 && !(x == 15300 || x == 15400 || x == 15500 || x == 15600 || x == 15700 || x == 15800));
+			unsigned wr = 0;                                        /* code cells with another value (none are produced) write nothing */
+			if (any_code) BS_PREDK(wr, cur, K0, x > 15000 && !(x == 15300 || x == 15400 || x == 15500 || x == 15600 || x == 15700 || x == 15800));
 			je |= part_p | part_n | (vis & ~wr);
 		}
 		for (int k = K0; k < 4; k++) {
