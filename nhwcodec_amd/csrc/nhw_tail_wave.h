@@ -580,7 +580,7 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				const unsigned both = g8 & bs_dn(g8, lane) & (lane == 63 ? 0x7u : 0xFu);                       /* columns <= 510 */
 				const unsigned cself = both & g16 & ple;
 				const unsigned cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & bs_dn(g16, lane) & bs_dn(bs_dn(le0, lane), lane) & (lane >= 62 ? 0x7u : 0xFu);   /* columns <= 509 */
-				const unsigned hit = bs_from4(up1(alt_runs(bs_ballot4(cnext))));                               /* cells decremented by their left neighbour */
+				const unsigned hit = __any(cnext != 0) ? bs_from4(up1(alt_runs(bs_ballot4(cnext)))) : 0u;      /* cells decremented by their left neighbour (a row with no such pair skips the run resolution) */
 				const unsigned dec = hit | (cself & ~hit);
 				last_le0 = (unsigned)__builtin_amdgcn_readlane((int)le0, 63) >> 3;
 				for (int k = 0; k < 4; k++) cur[4 + k] -= (dec >> k) & 1;
@@ -591,7 +591,7 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				const unsigned both = g8 & bs_dn(g8, lane) & (lane == 63 ? 0x7Fu : 0xFFu);
 				const unsigned cself = both & g16 & ple;
 				const unsigned cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & bs_dn(g16, lane) & bs_dn(bs_dn(le0, lane), lane) & (lane >= 62 ? 0x7Fu : 0xFFu);
-				const unsigned hit = bs_from8(up1(alt_runs(bs_ballot8(cnext))));
+				const unsigned hit = __any(cnext != 0) ? bs_from8(up1(alt_runs(bs_ballot8(cnext)))) : 0u;
 				const unsigned dec = hit | (cself & ~hit);
 				last_le0 = (unsigned)__builtin_amdgcn_readlane((int)le0, 63) >> 7;
 				for (int k = 0; k < 8; k++) cur[k] -= (dec >> k) & 1;
@@ -606,7 +606,8 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 					const unsigned pp = P & bs_up<4>(P, lane), nn = N & bs_up<4>(N, lane);
 					const unsigned tp = pp & pdn, tn = nn & ndn;
 					const unsigned vp = pp & ~pdn & bs_up<4>(PN, lane) & PN, vn = nn & ~ndn & bs_up<4>(NN, lane) & NN;
-					const unsigned fired = bs_from4(alt_runs(bs_ballot4((tp | vp | tn | vn) & rg)));
+					const unsigned cand2 = (tp | vp | tn | vn) & rg;
+					const unsigned fired = __any(cand2 != 0) ? bs_from4(alt_runs(bs_ballot4(cand2))) : 0u;
 					const unsigned ftp = fired & tp, ftn = fired & tn, fvp = fired & vp, fvn = fired & vn, fv = fvp | fvn;
 					const unsigned ft_l = bs_dn(ftp | ftn, lane), fvp_l = bs_dn(fvp, lane), fvn_l = bs_dn(fvn, lane), fv_l = fvp_l | fvn_l;
 					for (int k = 0; k < 4; k++) {
@@ -620,7 +621,8 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				{                                                  /* loop 3 */
 					unsigned A, B;
 					BS_PRED(A, cur, 4, (unsigned)(x - 5) < 3u); BS_PRED(B, cur, 4, (unsigned)(x + 7) < 3u);
-					const unsigned fired = bs_from4(alt_runs(bs_ballot4(((A & bs_dn(A, lane)) | (B & bs_dn(B, lane))) & (lane == 63 ? 0x7u : 0xFu))));   /* columns 0..254 */
+					const unsigned cand3 = ((A & bs_dn(A, lane)) | (B & bs_dn(B, lane))) & (lane == 63 ? 0x7u : 0xFu);   /* columns 0..254 */
+					const unsigned fired = __any(cand3 != 0) ? bs_from4(alt_runs(bs_ballot4(cand3))) : 0u;
 					const unsigned fa = fired & A, fb = fired & B;
 					for (int k = 0; k < 4; k++) { if ((fa >> k) & 1) cur[k] = 10300; if ((fb >> k) & 1) cur[k] = 10204; }
 				}
