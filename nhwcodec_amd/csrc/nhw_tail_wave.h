@@ -610,6 +610,7 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 					const unsigned fired = __any(cand2 != 0) ? bs_from4(alt_runs(bs_ballot4(cand2))) : 0u;
 					const unsigned ftp = fired & tp, ftn = fired & tn, fvp = fired & vp, fvn = fired & vn, fv = fvp | fvn;
 					const unsigned ft_l = bs_dn(ftp | ftn, lane), fvp_l = bs_dn(fvp, lane), fvn_l = bs_dn(fvn, lane), fv_l = fvp_l | fvn_l;
+					if (__any(fired != 0))
 					for (int k = 0; k < 4; k++) {
 						if ((ftp >> k) & 1) cur[k] = 12700; if ((ftn >> k) & 1) cur[k] = 12900;
 						if ((ft_l >> k) & 1) cur[k] = 10100;
