@@ -23,6 +23,7 @@ static int ll_verbatim(llc *k, int i)
 {
 	k->o[k->j++] = 128;
 	k->o[k->j++] = (uint8_t)(128 + (k->s[i] >> 1));
+	if (k->c->q <= 15) return i;                       /* one halved sample, nothing verbatim (:573-577) */
 	k->o[k->j++] = (uint8_t)(128 + (k->s[i + 1] >> 1));
 	k->c->ll_word[k->mem++] = k->c->ll_full[i];
 	k->c->ll_mem[k->c->ll_mem_len++] = (uint16_t)i;
@@ -131,7 +132,7 @@ void nhwo_ll_code_luma(nhwo_ctx *c)
 		memcpy(tmp, o, (size_t)j);
 		for (i = 1; i < j - 1; i++) {
 			if (tmp[i] == 64) { o[w++] = tmp[i + 1]; o[w++] = tmp[i + 2]; i += 2; }
-			else if (tmp[i] == 128) { o[w++] = tmp[i + 2]; i += 2; }
+			else if (tmp[i] == 128) { if (c->q > 15) { o[w++] = tmp[i + 2]; i += 2; } else { o[w++] = tmp[i + 1]; i++; } }
 			else o[w++] = tmp[i];
 		}
 		if (i < j) o[w++] = tmp[j - 1];
@@ -338,7 +339,10 @@ static int pack_part(nhwo_ctx *c, int part, bitsink *bs)
 	int hist[256], runs[256];
 	unsigned weight[354];
 	uint16_t entry[580];
-	uint8_t tmp_book[580];
+	/* the reference's `codebook[580]` is one stack array for both parts and is never cleared: when the second part's table ends in
+	 * a run of 128s, the collapse below reads on into what the first part left there (its de-interleaved table; behind that, 0 in
+	 * the canonical build's stack) */
+	uint8_t *tmp_book = c->book_tmp;
 	int select = part ? 3 : 4, i, j, k, e, zone, top_is_zero;
 	uint8_t *s1, *s2;
 	int n1 = 0, n2 = 0;
@@ -452,7 +456,7 @@ again:
 		}
 		for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = c->book1[i];
 		for (i = 1; i < e; i += 2) tmp_book[b++] = c->book1[i];
-		tmp_book[e] = 0;
+		memset(tmp_book + e, 0, 600 - (size_t)e);
 		for (i = 0, w = 0, b = 0; i < e; i++) {
 			while (tmp_book[i] == 3) { b++; i++; }
 			if (b > 0) { c->book1[w++] = 3; c->book1[w++] = (uint8_t)b; b = 0; i--; }
@@ -469,7 +473,6 @@ again:
 		c->tree_end = e;
 		for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = c->book2[i];
 		for (i = 1; i < e; i += 2) tmp_book[b++] = c->book2[i];
-		tmp_book[e] = 0;
 		for (i = 0, w = 0, b = 0; i < e; i++) {
 			while (tmp_book[i] == 128) { b++; i++; }
 			if (b > 0) { c->book2[w++] = 128; c->book2[w++] = (uint8_t)b; b = 0; i--; }

@@ -100,6 +100,8 @@ void nhwo_color(const uint8_t *bgr, int quality, int16_t *y, uint8_t *u, uint8_t
 int16_t nhwo_kernel_row128[4];   /* the four kernel-map values that sit behind res256 in the stock binary's heap (GLIBC_ONESHOT mode, nhwo_luma.c) */
 int16_t nhwo_kernel_stale[16384]; /* kernel map from byte 262176 on: what the stock binary's malloc hands out as tree1 (same mode) */
 
+void nhwo_prefilter_low(int16_t *y, int quality);   /* nhwo_prelow.c */
+
 void nhwo_prefilter(int16_t *y, int quality)
 {
 	const int S = NHWO_DIM;
@@ -107,6 +109,7 @@ void nhwo_prefilter(int16_t *y, int quality)
 	int16_t *kmap = (int16_t *)calloc(S * S, sizeof(int16_t)); /* borders never written: read as 0 */
 	int r, c, carry = 0, prev_big = 0;
 
+	if (quality <= 16) { free(kmap); free(src); nhwo_prefilter_low(y, quality); return; }
 	memcpy(src, y, sizeof(int16_t) * S * S); /* image_processing.c:566 */
 
 	for (r = 1; r < S - 1; r++)

@@ -75,6 +75,7 @@ typedef struct {
 	int size_data1, size_data2;
 	uint8_t *book1, *book2;         /* second life of tree1 / tree2: 708 bytes each */
 	int size_book1, size_book2, tree_end;
+	uint8_t book_tmp[600];          /* wavlts2packet's `codebook` scratch, shared by both parts */
 	int res1_count, res3_count, res5_count; /* running nhw_resN_word_len counters of Y22/Y23 */
 } nhwo_ctx;
 
@@ -90,6 +91,7 @@ static inline void trace_planes(nhwo_ctx *c, const char *name, const void *a, ui
 }
 
 /* stages */
+void nhwo_prefilter_chroma(int16_t *plane, int quality);        /* pre_processing_UV */
 void nhwo_dequant_sim_luma(nhwo_ctx *c, int part);              /* offsetY_recons256 */
 void nhwo_dequant_sim_chroma(nhwo_ctx *c, int comp);            /* offsetUV_recons256 */
 void nhwo_quantise_luma(nhwo_ctx *c);                           /* offsetY */

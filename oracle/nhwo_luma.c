@@ -1,5 +1,5 @@
 /*
- * nhwo_luma.c -- oracle: the luma half of encode_image for quality 17..23.
+ * nhwo_luma.c -- oracle: the luma half of encode_image, quality 1..23.
  * TEST INFRASTRUCTURE ONLY (see nhwo.h).  Reference: encoder/nhw_encoder.c:103-2252.
  * Pass ids (Y2..Y31) are those of SURVEY.md Appendix A.
  */
@@ -534,6 +534,204 @@ static void scan_and_rewrite(nhwo_ctx *c)
 	}
 }
 
+/* Y11: isolated just-above-dead-zone coefficients of the level-2 bands of rows 128..255 (:285-309), q<=11 */
+static void kill_isolated_l2(nhwo_ctx *c)
+{
+	int16_t *p = c->proc;
+	const int lim = c->q > 6 ? 10 : 11;
+	int r, j;
+	for (r = H / 2; r < H; r++)
+		for (j = 0; j < H; j++) {
+			int16_t *v = p + r * W + j;
+			const int m = iabs(v[0]);
+			if (m >= DEADZONE && m < lim) {
+				const int ql = iabs(v[-1]) < DEADZONE, qr = iabs(v[1]) < DEADZONE;
+				if (ql && qr) v[0] = 0;
+				else if (m == DEADZONE && (ql || qr)) v[0] = 0;
+			}
+		}
+}
+
+static inline void zero_if_below(int16_t *v, int lim) { if (iabs(*v) < lim) *v = 0; }
+
+/* the 2x2 level-1 coefficients of all three level-1 bands that sit under the LL2 cell with flat index `cell` */
+static void clear_l1_children(int16_t *p, int cell, int lim_a, int lim_b, int lim_c)
+{
+	const int base = cell << 1;
+	const int band[3] = { H, 2 * Q, 2 * Q + H };
+	const int lim[3] = { lim_a, lim_b, lim_c };
+	int b;
+	for (b = 0; b < 3; b++) {
+		int16_t *v = p + base + band[b];
+		zero_if_below(v, lim[b]); zero_if_below(v + 1, lim[b]); zero_if_below(v + W, lim[b]); zero_if_below(v + W + 1, lim[b]);
+	}
+}
+/* the level-2 detail coefficients at the position of the LL2 cell (q<=11) */
+static void clear_l2_siblings(int16_t *p, int cell)
+{
+	zero_if_below(p + cell + H / 2, 11); zero_if_below(p + cell + Q, 12); zero_if_below(p + cell + Q + H / 2, 13);
+}
+
+/* Y12: LL2 smoothing with zeroing of the coefficients under smoothed cells, q<=12 (:311-621) */
+static void smooth_ll2(nhwo_ctx *c)
+{
+	/* wvlt_thrx1..7 by quality (:313-381) */
+	static const uint8_t thr_by_q[13][7] = {
+		{ 0 }, { 11, 15, 10, 15, 36, 20, 21 }, { 11, 15, 10, 15, 36, 19, 20 }, { 11, 15, 10, 15, 36, 18, 18 },
+		{ 11, 15, 10, 15, 36, 17, 17 }, { 11, 15, 10, 15, 36, 17, 17 }, { 11, 15, 10, 15, 36, 17, 17 },
+		{ 10, 15, 9, 14, 36, 17, 17 }, { 8, 13, 6, 11, 34, 15, 15 }, { 8, 13, 6, 11, 34, 15, 15 },
+		{ 8, 13, 6, 11, 34, 15, 15 }, { 8, 13, 6, 11, 34, 15, 15 }, { 8, 13, 6, 11, 34, 14, 0 } };
+	int16_t *p = c->proc;
+	const int q = c->q, deep = q <= 11;
+	const uint8_t *t = thr_by_q[q];
+	const int t1 = t[0], t2 = t[1], t3 = t[2], t4 = t[3], t5 = t[4], t6 = t[5], t7 = t[6];
+	/* the reference's `count` variable: loop counter of the inner loops of the first walk, cell index in the others;
+	 * the third walk uses it without having set it when its innermost test fails (:571-579).  It enters this pass as
+	 * IM_SIZE, left there by the copy loops above (:129-135, :218). */
+	int last = Q;
+	int r, j, k;
+
+	for (r = 0; r < H / 2; r++)                                  /* five cells in a row (:383-486) */
+		for (j = 0; j < H / 2 - 4; j++) {
+			int16_t *v = p + r * W + j;
+			int hit = 0;
+			if (iabs(v[4] - v[0]) < t1 && iabs(v[4] - v[3]) < t1 && iabs(v[1] - v[0]) < t1 &&
+			    iabs(v[3] - v[1]) < t1 && iabs(v[3] - v[2]) < t2 - 2) {
+				if ((v[3] - v[1]) > 5 && (v[2] - v[3]) >= 0) v[2] = v[3];
+				else if ((v[1] - v[3]) > 5 && (v[2] - v[3]) <= 0) v[2] = v[3];
+				else if ((v[1] - v[3]) > 5 && (v[2] - v[1]) >= 0) v[2] = v[1];
+				else if ((v[3] - v[1]) > 5 && (v[2] - v[1]) <= 0) v[2] = v[1];
+				else if ((v[3] - v[2]) > 0 && (v[2] - v[1]) > 0) { }
+				else if ((v[1] - v[2]) > 0 && (v[2] - v[3]) > 0) { }
+				else v[2] = (int16_t)((v[3] + v[1]) >> 1);
+				hit = 1;
+			}
+			else if (iabs(v[4] - v[0]) < t2 + 1 && iabs(v[4] - v[3]) < t2 + 1 && iabs(v[1] - v[0]) < t2 + 1) {
+				if (iabs(v[3] - v[1]) < t2 + 6 && iabs(v[3] - v[2]) < t2 + 6) {
+					const int up = v[3] - v[2], dn = v[2] - v[1];
+					if ((up >= 0 && dn >= 0) || (up <= 0 && dn <= 0)) hit = 1;
+				}
+			}
+			if (hit) {
+				for (k = 1; k < 4; k++) clear_l1_children(p, r * W + j + k, t6, t6 + 6, t5);
+				if (deep) for (k = 1; k < 4; k++) clear_l2_siblings(p, r * W + j + k);
+				last = 4;
+			}
+		}
+
+	for (r = 0; r < H / 2 - 2; r++)                              /* centre of a plus shape, rounding +2 (:488-533) */
+		for (j = 0; j < H / 2 - 2; j++) {
+			int16_t *v = p + r * W + j;
+			if (iabs(v[1] - v[2 * W + 1]) < t3 && iabs(v[W] - v[W + 2]) < t3 &&
+			    iabs(v[W + 1] - v[W]) < t4 - 1 && iabs(v[1] - v[W + 1]) < t4) {
+				const int e = (v[1] + v[2 * W + 1] + v[W] + v[W + 2] + 2) >> 2;
+				if (iabs(e - v[W]) < 5 || iabs(e - v[W + 2]) < 5) v[W + 1] = (int16_t)e;
+				last = r * W + j + W + 1;
+				clear_l1_children(p, last, t6, t6 + 6, 32);
+				if (deep) for (k = 0; k < 3; k++) clear_l2_siblings(p, last + k - 1);
+			}
+		}
+
+	for (r = 0; r < H / 2 - 2; r++)                              /* flat corner, rounding +1 (:535-583) */
+		for (j = 0; j < H / 2 - 2; j++) {
+			int16_t *v = p + r * W + j;
+			if (iabs(v[2] - v[1]) < t3 && iabs(v[1] - v[0]) < t3 && iabs(v[0] - v[W]) < t3 && iabs(v[2] - v[W + 2]) < t3) {
+				if (iabs(v[2 * W + 1] - v[W]) < t3 && iabs(v[W] - v[W + 1]) < t4) {
+					const int e = (v[1] + v[2 * W + 1] + v[W] + v[W + 2] + 1) >> 2;
+					if (iabs(e - v[W]) < 5 || iabs(e - v[W + 2]) < 5) v[W + 1] = (int16_t)e;
+					last = r * W + j + W + 1;
+					clear_l1_children(p, last, t6, t6 + 6, 32);
+				}
+				if (deep) for (k = 0; k < 3; k++) clear_l2_siblings(p, last + k - 1);
+			}
+		}
+
+	if (deep)                                                    /* three flat cells in a row (:585-620) */
+		for (r = 0; r < H / 2; r++)
+			for (j = 0; j < H / 2 - 2; j++) {
+				const int16_t *v = p + r * W + j;
+				if (iabs(v[2] - v[1]) < t7 && iabs(v[2] - v[0]) < t7 && iabs(v[1] - v[0]) < t7) {
+					clear_l1_children(p, r * W + j + 1, t6, t6 + 6, 34);
+					clear_l2_siblings(p, r * W + j + 1);
+				}
+			}
+}
+
+/* zeroing rule shared by the three bands of Y20 at q<=13: a small coefficient goes when its level-2 parent is small,
+ * or together with a neighbour when the pair nearly cancels (:875-886 etc.) */
+static inline void thin_by_parent(int16_t *v, int parent, int lim_parent, int lim_pair)
+{
+	if (iabs(parent) < lim_parent) v[0] = 0;
+	else if (iabs(v[0] + v[-1]) < lim_pair && iabs(v[1]) < lim_pair) { v[0] = 0; v[-1] = 0; }
+	else if (iabs(v[0] + v[1]) < lim_pair && iabs(v[-1]) < lim_pair) { v[0] = 0; v[1] = 0; }
+}
+static inline int16_t keep_loud(int v, int q) /* :947-953 */
+{
+	if (q > 10) return (int16_t)(v >= 16 ? 7 : v <= -16 ? -7 : 0);
+	return 0;
+}
+
+/* Y20 for q<=15: thresholding of the level-1 bands (:804-968) */
+static void thin_l1_low(nhwo_ctx *c)
+{
+	int16_t *p = c->proc;
+	const int16_t *par = c->l2save;
+	const int q = c->q;
+	int r, j, t1, t2, t3, t4, t5;
+
+	if (q >= 14) {                                               /* :804-832 */
+		t1 = 11; t2 = (q == 15) ? 19 : 20;
+		for (r = H; r < W; r++) {
+			for (j = 0; j < H; j++) { int16_t *v = p + r * W + j; if (iabs(*v) >= DEADZONE && iabs(*v) < t1) *v = 0; }
+			for (j = H; j < W; j++) {
+				int16_t *v = p + r * W + j;
+				if (iabs(*v) >= DEADZONE && iabs(*v) < t2) *v = (int16_t)(*v >= 14 ? 7 : *v <= -14 ? -7 : 0);
+			}
+		}
+		return;
+	}
+	if (q == 13) { t1 = 15; t2 = 27; t3 = 10; t4 = 6; t5 = 3; }
+	else {                                                       /* thresholds follow the number of loud coefficients (:836-868) */
+		int loud = 0, i;
+		t1 = 16; t2 = 28; t3 = 11; t4 = 8; t5 = 5;
+		for (i = 2 * Q; i < 4 * Q; i++) if (iabs(p[i]) >= 12) loud++;
+		if (loud > 12500) { t1 = 19; t2 = 31; t3 = 13; t4 = 9; t5 = 6; }
+		else if (loud > 10000) { t1 = 18; t2 = 30; t3 = 12; t4 = 8; t5 = 6; }
+		else if (loud >= 7000) { t1 = 17; t2 = 29; t3 = 11; t4 = 8; t5 = 5; }
+		if (q == 11) { if (loud > 12500) { t1++; t2++; t3++; t4++; t5++; } else t1++; }
+		else if (q <= 10) {
+			if (loud > 12500) { t1 += 3; t2 += 3; t3 += 2; t4 += 3; t5 += 3; }
+			else { t1 += 3; t2 += 2; t3 += 2; t4 += 2; t5 += 2; }
+		}
+	}
+
+	for (r = 0; r < H; r++)                                      /* rows 0..255, columns 256..511 (:871-896) */
+		for (j = H; j < W; j++) {
+			int16_t *v = p + r * W + j;
+			if (iabs(*v) >= DEADZONE && iabs(*v) < t3 + 2) thin_by_parent(v, par[((r * H + (j - H)) >> 1) + H / 2], t4, t5);
+			if (iabs(*v) >= DEADZONE && iabs(*v) < t3) { if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = 0; }
+		}
+	for (r = H; r < W; r++) {                                    /* rows 256..511 (:898-967) */
+		for (j = 0; j < H; j++) {
+			int16_t *v = p + r * W + j;
+			if (iabs(*v) >= DEADZONE && iabs(*v) < t1 + 2) thin_by_parent(v, par[(((r - H) * H + j) >> 1) + Q / 2], t4, t5);
+			if (iabs(*v) >= DEADZONE && iabs(*v) < t1) {
+				if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = 0;
+				else if (iabs(*v) < t1 - 4) *v = 0;
+			}
+		}
+		for (j = H; j < W - 1; j++) {
+			int16_t *v = p + r * W + j;
+			if (iabs(*v) >= DEADZONE && iabs(*v) < t2 + 1)
+				thin_by_parent(v, par[(((r - H) * H + (j - H)) >> 1) + Q / 2 + H / 2], t4 + 1, t5);
+			if (iabs(*v) >= DEADZONE && iabs(*v) < t2) {
+				if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = keep_loud(*v, q);
+				else if (iabs(*v) < t2 - 5) *v = keep_loud(*v, q);
+			}
+		}
+	}
+}
+
 int nhwo_luma(nhwo_ctx *c)
 {
 	const int q = c->q;
@@ -547,7 +745,7 @@ int nhwo_luma(nhwo_ctx *c)
 	nhwo_analysis(c->jpeg, c->proc, W, H, 1, NULL);                                                             /* Y4 :139 */
 	trace_planes(c, "wavelet_analysis_256", c->jpeg, 8 * Q, c->proc, 8 * Q);
 
-	/* first closed loop (q>6) */
+	if (q > 6) {                                                                                                /* first closed loop (:141-283) */
 	tag_l2_details(c);
 	nhwo_dequant_sim_luma(c, 1);
 	trace_planes(c, "offsetY_recons256_p1", c->jpeg, 8 * Q, c->proc, 8 * Q);
@@ -557,6 +755,9 @@ int nhwo_luma(nhwo_ctx *c)
 	precompensate_ll1(c);
 	nhwo_analysis(c->jpeg, c->proc, W, H, 1, NULL);                                                             /* Y10 :281 */
 	trace_planes(c, "wavelet_analysis_256", c->jpeg, 8 * Q, c->proc, 8 * Q);
+	}
+	if (q <= 11) kill_isolated_l2(c);                                                                           /* Y11 */
+	if (q <= 12) smooth_ll2(c);                                                                                 /* Y12 */
 
 	for (r = 0; r < H; r++) memcpy(c->l2save + r * H, c->proc + r * W, sizeof(int16_t) * H);                    /* Y13 :623-631 */
 	if (nhwo_oob_mode) {                                          /* (values 2 and 3 switch on one half only: debugging aid) */
@@ -590,27 +791,31 @@ int nhwo_luma(nhwo_ctx *c)
 	}
 	for (r = 0; r < H; r++) memcpy(c->proc + r * W, c->l2save + r * H, sizeof(int16_t) * H);                    /* Y17 :749-755 */
 
-	/* second closed loop (q>12) */
+	if (q > 12) {                                                                                               /* second closed loop (:759-779) */
 	nhwo_dequant_sim_luma(c, 0);
 	trace_planes(c, "offsetY_recons256_p0", c->jpeg, 8 * Q, c->proc, 8 * Q);
 	nhwo_synthesis(c->jpeg, c->proc, W, H);
 	trace_planes(c, "wavelet_synthesis_256", c->jpeg, 8 * Q, c->proc, 8 * Q);
 	if (q > 21) for (r = 0; r < H; r++) memcpy(c->first_order + r * H, c->jpeg + r * W, sizeof(int16_t) * H);   /* Y19 :766-777 */
+	}
 
-	if (q < 20) {                                                                                               /* Y20, 16<=q<=19 (:783-801) */
+	if (q <= 15) thin_l1_low(c);                                                                                /* Y20, q<=15 (:804-968) */
+	else if (q < 20) {                                                                                               /* Y20, 16<=q<=19 (:783-801) */
 		int16_t *p = c->proc;
 		for (r = H; r < W; r++) {
 			for (j = 0; j < H; j++) { int16_t *v = p + r * W + j; if (iabs(*v) >= DEADZONE && iabs(*v) < 9) *v = (int16_t)(*v > 0 ? 7 : -7); }
 			for (j = H; j < W; j++) { int16_t *v = p + r * W + j; if (iabs(*v) >= DEADZONE && iabs(*v) <= 14) *v = (int16_t)(*v > 0 ? 7 : -7); }
 		}
 	}
-	tag_small_runs(c);                                                                                          /* Y21 (q>16) */
+	if (q > 16) tag_small_runs(c);                                                                              /* Y21 (:970) */
 
-	res_setting = q >= 20 ? 3 : (q >= 18 ? 4 : 6);                                                              /* :1075-1078 */
+	res_setting = q >= 20 ? 3 : q >= 18 ? 4 : q >= 15 ? 6 : 8;                                                  /* :1075-1079 */
+	if (q > 12) {                                                                                               /* :1081, :1498 */
 	classify_residuals(c, res_setting);                                                                         /* Y22 */
 	code_residuals(c, res_setting);                                                                             /* Y23 */
 	if (q > 21) adjust_first_order(c);                                                                          /* Y24 */
 	build_poslists(c);                                                                                          /* Y25 */
+	}
 
 	{                                                                                                           /* Y26 :1893-1910 */
 		int16_t *p = c->proc;

@@ -1,7 +1,7 @@
 /*
  * nhwo_quant.c -- oracle: the quantiser (offsetY / offsetUV) and the decoder-simulating
  * dequantisers used by the encoder's closed loop (offsetY_recons256 / offsetUV_recons256).
- * TEST INFRASTRUCTURE ONLY (see nhwo.h).  Quality 17..23 branches only.
+ * TEST INFRASTRUCTURE ONLY (see nhwo.h).  Quality 1..23.
  * Reference: encoder/image_processing.c:108-521, 2600-3353; tables encoder/tree.h:54-55.
  */
 #include "nhwo_internal.h"
@@ -66,10 +66,21 @@ static void mark_pairs(int16_t *p, int row0, int row1, int col0)
 }
 
 /* per-row dequantisation of detail bands: image_processing.c:2909-3015 and 3018-3124 */
-static void dequant_rows(int16_t *p, int16_t *jp, int row0, int row1, int col0, int part)
+/* q<=16: negative magnitudes keep their low bits only on a ration: of the 15s in a row every sixth is floored to 8, of the
+ * x7 above 22 every fourth (:2938-2989, :357-410); everything else is floored.  Returns the magnitude to carry on with. */
+static inline int ration_low_bits(int a, int *n15, int *nx7, int mask)
+{
+	if (a == 15) { if (!*n15) a &= mask; *n15 = (*n15 + 1) % 6; }
+	else if (a > 22 && (a & 7) == 7) { if (!*nx7) a &= mask; *nx7 = (*nx7 + 1) % 4; }
+	else a &= mask;
+	return a;
+}
+
+static void dequant_rows(int16_t *p, int16_t *jp, int row0, int row1, int col0, int part, int q)
 {
 	int r, j;
-	for (r = row0; r < row1; r++)
+	for (r = row0; r < row1; r++) {
+		int n15 = 0, nx7 = 0;
 		for (j = col0; j < H; j++) {
 			const int at = r * W + j;
 			int a = p[at];
@@ -86,13 +97,15 @@ static void dequant_rows(int16_t *p, int16_t *jp, int row0, int row1, int col0, 
 			if (a < 0) {
 				if (a == -7 && j < H - 1 && p[at + 1] == 8) { p[at] = -8; a = -8; }
 				a = -a;
-				if ((a & 7) < 7) a &= 0xFFF8;
+				if (q <= 16) a = ration_low_bits(a, &n15, &nx7, 0xFFF8);
+				else if ((a & 7) < 7) a &= 0xFFF8;
 				a = -a;
 			}
 			else if (a == 8 && j < H - 1 && p[at + 1] == -7) p[at + 1] = -8;
 			else if (a > 12 && !part && (a & 7) >= 6) { if (j < H - 1 && p[at + 1] == 7) p[at + 1] = 8; }
 			jp[at] = (int16_t)dequant_value(a);
 		}
+	}
 }
 
 /* a8: offsetY_recons256, image_processing.c:2600-3190.  `part` 1 = first closed loop, 0 = second. */
@@ -161,24 +174,26 @@ void nhwo_dequant_sim_luma(nhwo_ctx *c, int part)
 		free(tmp);
 	}
 
-	/* q>16 from here (:2757) */
-	mark_small_runs(p, jp, 0, H / 2, H / 2 + 1);
-	mark_small_runs(p, jp, H / 2, H - 1, 1);
-	if (!part) {
-		mark_pairs(p, 0, H / 2, H / 2);
-		mark_pairs(p, H / 2, H, 0);
+	if (q > 16) {                                    /* :2759-2907 */
+		mark_small_runs(p, jp, 0, H / 2, H / 2 + 1);
+		mark_small_runs(p, jp, H / 2, H - 1, 1);
+		if (!part) {
+			mark_pairs(p, 0, H / 2, H / 2);
+			mark_pairs(p, H / 2, H, 0);
+		}
 	}
-	dequant_rows(p, jp, 0, H / 2, H / 2, part);
-	dequant_rows(p, jp, H / 2, H, 0, part);
+	dequant_rows(p, jp, 0, H / 2, H / 2, part, q);
+	dequant_rows(p, jp, H / 2, H, 0, part, q);
 
-	if (!part) {                                     /* :3154-3188 isolated coefficient shrink (q>16 form) */
+	if (!part) {                                     /* :3135-3188 isolated coefficient shrink; q<=16 lets diagonal neighbours up to 15 pass */
+		const int diag = q <= 16 ? 16 : 8;
 		for (r = 1; r < H - 1; r++)
 			for (j = 1; j < H - 1; j++) {
 				const int e = r * W + j;
 				if (iabs(jp[e]) >= 8) {
-					if (iabs(jp[e - W - 1]) >= 8 || iabs(jp[e - W]) >= 8 || iabs(jp[e - W + 1]) >= 8 ||
+					if (iabs(jp[e - W - 1]) >= diag || iabs(jp[e - W]) >= 8 || iabs(jp[e - W + 1]) >= diag ||
 					    iabs(jp[e - 1]) >= 8 || iabs(jp[e + 1]) >= 8 ||
-					    iabs(jp[e + W - 1]) >= 8 || iabs(jp[e + W]) >= 8 || iabs(jp[e + W + 1]) >= 8) continue;
+					    iabs(jp[e + W - 1]) >= diag || iabs(jp[e + W]) >= 8 || iabs(jp[e + W + 1]) >= diag) continue;
 					if (r >= H / 2 || j >= H / 2) { if (jp[e] > 0) jp[e]--; else jp[e]++; }
 				}
 			}
@@ -213,7 +228,8 @@ void nhwo_dequant_sim_chroma(nhwo_ctx *c, int comp)
 	for (r = 0; r < H / 4; r++)
 		for (j = 0; j < H / 4; j++) {
 			const int i = r * H + j;
-			if (comp) {                              /* :3198-3219 alternate which sample of a pair keeps bit 0 */
+			if (comp && c->q <= 15) jp[i] = (int16_t)((p[i] & 0xFFFC) + 1);   /* :3221-3230 two low bits dropped, midpoint */
+			else if (comp) {                         /* :3198-3219 alternate which sample of a pair keeps bit 0 */
 				if (r == 0) { jp[i] = p[i]; jp[i + 1] = clear_bit0(p[i + 1]); }
 				else { jp[i] = clear_bit0(p[i]); jp[i + 1] = p[i + 1]; }
 				j++;
@@ -235,7 +251,10 @@ static inline int big_code(int a, const uint8_t *tab)
 void nhwo_quantise_luma(nhwo_ctx *c)
 {
 	int16_t *p = c->proc;
+	const int low = c->q <= 16;
 	int i, r, j;
+	int n15 = 0, nx7 = 0;        /* quant, quant6: per row */
+	int pair_turn = 0;           /* quant4: runs through the whole plane */
 
 	for (i = 0; i < 4 * Q; i++) {                    /* :195-238 paired multiples of 8 in detail bands */
 		const int col = i & (W - 1);
@@ -254,7 +273,7 @@ void nhwo_quantise_luma(nhwo_ctx *c)
 		}
 	}
 
-	for (r = 0; r < H; r++)                          /* :241-284 */
+	for (r = 0; r < (low ? 0 : H); r++)              /* :241-284 (q>16) */
 		for (j = 1; j < H - 1; j++) {
 			const int a = r * W + j;
 			if (p[a] > 3 && p[a] < 8) {
@@ -273,7 +292,7 @@ void nhwo_quantise_luma(nhwo_ctx *c)
 				}
 			}
 		}
-	for (r = 0; r < H; r++)                          /* :286-311 */
+	for (r = 0; r < (low ? 0 : H); r++)              /* :286-311 (q>16) */
 		for (j = 0; j < H - 1; j++) {
 			const int a = r * W + j;
 			if (is_567(p[a])) { if (is_567(p[a + 1])) { p[a] = 10300; j++; } }
@@ -283,6 +302,7 @@ void nhwo_quantise_luma(nhwo_ctx *c)
 	for (i = 0; i < 4 * Q; i++) {                    /* :314-519 */
 		const int col = i & (W - 1);
 		int a = p[i];
+		if (!col) { n15 = 0; nx7 = 0; }
 		if (a > 10000) {
 			if (a == 10100) { p[i] = 128; continue; }
 			else if (a == 12700) { p[i] = 127; continue; }
@@ -300,11 +320,33 @@ void nhwo_quantise_luma(nhwo_ctx *c)
 			if (a == -7 && p[i + 1] == 8 && col < W - 1) { p[i] = -8; a = -8; }
 			a = -a;
 			if (a > 14 && (a & 7) == 7 && p[i + 1] > 0 && p[i + 1] < 8) a -= 2;
-			if ((a & 7) < 7) a &= 504;
+			if (low) a = ration_low_bits(a, &n15, &nx7, 504);
+			else if ((a & 7) < 7) a &= 504;
 			a = -a;
 		}
 		else if (a == 8 && p[i + 1] == -7 && col < W - 1) p[i + 1] = -8;
 		else if (a > 12 && (a & 7) >= 6) { if (col < W - 1 && p[i + 1] == 7) p[i + 1] = 9; }
+
+		/* q<=16: two neighbours that both sit on x6/x7 in a detail band: every third such pair is pushed apart by 2 so
+		 * that one of them reaches the next quantisation step, unless a negative neighbour on that side forbids it (:427-510) */
+		if (low && a >= 14 && p[i + 1] >= 14 && (i >= 2 * Q || col >= H)) {
+			const int nx = p[i + 1];
+			if (((a & 510) & 7) == 6 && ((nx & 510) & 7) == 6 && ((a & 1) || (nx & 1))) {
+				int veto_l = 0, veto_r = 0;
+				if (col > 0 && col < W - 2) {
+					const int l = p[i - 1], rr = p[i + 2];
+					veto_l = (l < -2 && l > -8) || (l < -7 && ((-l) & 7) >= 6);
+					veto_r = (rr < -2 && rr > -8) || (rr < -7 && ((-rr) & 7) >= 6);
+				}
+				if (!pair_turn) {
+					int push_left;
+					if ((a & 504) == (nx & 504)) push_left = a >= nx; else push_left = a <= nx;
+					if (push_left) { if (!veto_l) { a += 2; p[i + 1] -= 2; } }
+					else { if (!veto_r) p[i + 1] += 2; }
+				}
+				pair_turn = (pair_turn + 1) % 3;
+			}
+		}
 
 		if (a < DEADZONE && a > -DEADZONE) p[i] = 128;
 		else p[i] = (int16_t)((a + 128) & 248);

@@ -154,9 +154,18 @@ int nhwo_chroma(nhwo_ctx *c, int comp)
 	for (i = 0; i < Q; i++) jp[i] = src[i];                     /* :2256 / :2573 */
 	memset(p, 0, sizeof(int16_t) * Q);                          /* U: fresh zero plane; V re-uses it, every cell read later is rewritten first */
 
+	if (q <= 14) { nhwo_prefilter_chroma(jp, q); trace_planes(c, "pre_processing_UV", jp, 2 * Q, NULL, 0); }   /* :2263 / :2579 */
 	nhwo_analysis(jp, p, H, H, 0, NULL);
 	trace_planes(c, "wavelet_analysis_256", jp, 2 * Q, p, 2 * Q);
 	for (r = 0; r < H / 2; r++) memcpy(o + r * (H / 2), jp + r * H, sizeof(int16_t) * (H / 2));   /* :2271-2276 */
+	if (q <= 16) {                                              /* level-1 chroma detail below 24 / 32 / 48 goes (:2277-2308, :2590-2621) */
+		for (r = 0; r < H; r++)
+			for (j = 0; j < H; j++) {
+				int16_t *v = p + r * H + j;
+				const int lim = r < H / 2 ? (j < H / 2 ? 0 : 24) : (j < H / 2 ? 32 : 48);
+				if (iabs(*v) >= DEADZONE && iabs(*v) < lim) *v = 0;
+			}
+	}
 	nhwo_analysis(jp, p, H, H / 2, 1, NULL);
 	trace_planes(c, "wavelet_analysis_128", jp, 2 * Q, p, 2 * Q);
 	nhwo_dequant_sim_chroma(c, 1);
@@ -206,6 +215,23 @@ int nhwo_chroma(nhwo_ctx *c, int comp)
 	}
 	for (r = 0; r < H / 2; r++) memcpy(p + r * H, c->cl2save + r * (H / 2), sizeof(int16_t) * (H / 2));  /* :2431-2439 */
 
+	if (q <= 11) {                                              /* chroma LL2 smoothing, in place in raster order (:2438-2478, :2739-2779) */
+		int pass;
+		for (pass = 0; pass < 2; pass++)
+			for (r = 0; r < H / 4 - 2; r++)
+				for (j = 0; j < H / 4 - 2; j++) {
+					int16_t *v = p + r * H + j;
+					if (!pass) {
+						if (iabs(v[1] - v[2 * H + 1]) < 5 && iabs(v[H] - v[H + 2]) < 5 && iabs(v[H + 1] - v[H]) < 7 && iabs(v[1] - v[H + 1]) < 8)
+							v[H + 1] = (int16_t)((v[1] + v[2 * H + 1] + v[H] + v[H + 2] + 2) >> 2);
+					} else {
+						if (iabs(v[2] - v[1]) < 5 && iabs(v[1] - v[0]) < 5 && iabs(v[0] - v[H]) < 5 && iabs(v[2] - v[H + 2]) < 5 &&
+						    iabs(v[2 * H + 1] - v[H]) < 5 && iabs(v[H] - v[H + 1]) < 8)
+							v[H + 1] = (int16_t)((v[1] + v[2 * H + 1] + v[H] + v[H + 2] + 1) >> 2);
+					}
+				}
+	}
+
 	c->exw[c->exw_len++] = 0; c->exw[c->exw_len++] = 0;                  /* :2489 (U), :2770 (V) */
 	a = comp ? (Q >> 2) + (Q >> 4) : (Q >> 2);
 	for (r = 0; r < H / 4; r++)                                  /* :2491-2525 LL2 emission */
@@ -224,7 +250,7 @@ int nhwo_chroma(nhwo_ctx *c, int comp)
 			}
 			p[r * H + j] = 0;
 		}
-	{                                                            /* bit 1 of every LL2 sample, q>15 (:2527-2548) */
+	if (q > 15) {                                                /* bit 1 of every LL2 sample (:2517-2537, :2815-2836) */
 		uint8_t *dst = comp ? c->res_v64 : c->res_u64;
 		const uint8_t *sb = c->ll_bytes + (comp ? 20480 : 16384);
 		for (i = 0; i < 16 * H / 8; i++) {
@@ -297,7 +323,7 @@ size_t nhwo_container(nhwo_ctx *c, uint8_t *out, size_t cap)
 }
 
 /* ---------------------------------------------------------------- public entry point */
-int nhwo_quality_supported(int quality) { return quality >= 17 && quality <= 23; }
+int nhwo_quality_supported(int quality) { return quality >= 1 && quality <= 23; }
 int nhwo_oob_mode = NHWO_OOB_ZERO;
 
 int nhwo_encode(const uint8_t *bgr, int quality, uint8_t *out, size_t cap, size_t *out_len, nhwo_trace *trace)

@@ -221,10 +221,21 @@ void __wrap_highres_compression(image_buffer *im, encode_state *enc)
 	trace2("highres_compression", enc->ch_res, enc->end_ch_res, NULL, 0);
 }
 extern int __real_wavlts2packet(image_buffer *, encode_state *);
+/* wavlts2packet collapses the trailing run of its code-book scratch (`unsigned char codebook[580]`, a stack array it never clears:
+ * compress_pixel.c:58, :411-421, :442-456) by reading one byte past what it wrote.  The canonical model says a never-written read
+ * returns 0; for heap blocks the allocator above sees to that, for this one stack array the frame is handed a zeroed stack. */
+static void __attribute__((noinline)) scrub_stack_below(void)
+{
+	volatile unsigned char pad[32768];
+	memset((void *)pad, 0, sizeof pad);
+	__asm__ volatile("" : : "r"(pad) : "memory");
+}
 int __wrap_wavlts2packet(image_buffer *im, encode_state *enc)
 {
 	const void *bl[4]; uint32_t ln[4];
-	int r = __real_wavlts2packet(im, enc);
+	int r;
+	scrub_stack_below();
+	r = __real_wavlts2packet(im, enc);
 	bl[0] = enc->encode; ln[0] = enc->size_data2 * 4;
 	bl[1] = enc->tree1; ln[1] = enc->size_tree1;
 	bl[2] = enc->tree2; ln[2] = enc->size_tree2;

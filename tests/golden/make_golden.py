@@ -28,12 +28,22 @@ def main():
     man = {"files": {}, "hashes": {}, "checkpoints": {}}
     full = [("synth", s, q) for s in (0, 1) for q in (17, 18, 19, 20, 21, 22, 23)]
     full += [("noise", 0, 20), ("blocks", 0, 20), ("flat", 0, 20), ("gradient", 0, 23)]
+    traced = list(full[:14])
+    # quality 1..16 (integer colour, the rationed pre-filter, LL2 smoothing, no closed loops at the bottom): complete files for
+    # seed 0 at every setting and for BASELINE config 3's q1 / q10 on a second seed and on the hard classes; checkpoints for the
+    # settings where the gate structure changes
+    low_full = [("synth", 0, q) for q in range(1, 17)] + [("synth", 1, 1), ("synth", 1, 10), ("noise", 0, 1), ("noise", 0, 10),
+                                                          ("blocks", 0, 10), ("tiles", 0, 1)]
+    full += low_full
+    traced += [("synth", 0, q) for q in (1, 6, 7, 10, 11, 12, 13, 14, 15, 16)]
     hashed = [("synth", s, q) for s in range(2, 8) for q in (17, 20, 23)]
     hashed += [(k, 0, q) for k in ("noise", "blocks", "flat", "black", "white", "gradient") for q in (17, 19, 21, 22, 23)]
+    hashed += [("synth", s, q) for s in range(2, 6) for q in range(1, 17)]
+    hashed += [(k, 0, q) for k in ("noise", "blocks", "flat", "black", "white", "gradient", "tiles") for q in (1, 3, 5, 7, 8, 9, 10, 12, 13, 15, 16)]
     for kind, seed, q in full + hashed:
         img = synth_image(seed) if kind == "synth" else class_image(kind, seed)
         key = f"{kind}_s{seed}_q{q}"
-        want_trace = (kind, seed, q) in full[:14]
+        want_trace = (kind, seed, q) in traced
         if want_trace:
             data, tr = ref.encode(img, q, trace=True)
             man["checkpoints"][key] = [[n, [fnv64(b) for b in blobs]] for n, blobs in tr]

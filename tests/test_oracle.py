@@ -30,7 +30,7 @@ def test_generator_matches_python_definition(oracle):
 
 
 def test_supported_range(oracle):
-    assert [q for q in range(0, 25) if oracle.supported(q)] == list(range(17, 24))
+    assert [q for q in range(0, 25) if oracle.supported(q)] == list(range(1, 24))
 
 
 def test_golden_files_bit_exact(oracle, manifest):
@@ -77,11 +77,12 @@ def test_stage_entry_points_consistent(oracle):
 
 
 def test_unsupported_quality_is_loud(oracle):
-    with pytest.raises(RuntimeError):
-        oracle.encode(oracle.synth(0), 10)
+    for q in (0, 24):      # -q0 is accepted by the reference CLI but has no tables downstream
+        with pytest.raises(RuntimeError):
+            oracle.encode(oracle.synth(0), q)
 
 
-@pytest.mark.parametrize("q", [17, 20, 23])
+@pytest.mark.parametrize("q", [1, 3, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 23])
 def test_against_real_reference_trace(oracle, ref, q):
     img = oracle.synth(12)
     d_ref, t_ref = ref.encode(img, q, trace=True)
@@ -109,7 +110,7 @@ def test_reference_decoder_accepts_oracle_output(oracle, tmp_path):
 @pytest.mark.parametrize("q", [1, 4, 8, 12, 16])
 def test_colour_below_q17_against_reference(oracle, ref, q):
     """Row a1 below q17 (integer BT.601 scaled by the quality table, colorspace.c:172-214): the oracle's colour stage against the
-    reference's first checkpoint (the rest of the q <= 16 path is not restated yet, so only this stage is pinned)."""
+    reference's first checkpoint."""
     from oracle.harness import class_image
     for img in (oracle.synth(12), class_image("noise", 2)):
         _, tr = ref.encode(img, q, trace=True)
@@ -139,3 +140,18 @@ def test_glibc_oneshot_mode_reproduces_the_stock_binary(oracle, q):
             assert not bad, f"q{q} seed {seed}: bytes {bad[:8]} differ outside the un-initialised positions"
     finally:
         oracle.set_oob_mode(False)
+
+
+@pytest.mark.parametrize("kind", ["noise", "blocks", "tiles", "gradient"])
+def test_low_quality_hard_classes_against_real_reference(oracle, ref, kind):
+    """Quality 1..16 on the input classes that drive the rationed pre-filter, the LL2 smoothing and the coders through their rare
+    branches; every checkpoint and the file."""
+    from oracle.harness import class_image
+    img = class_image(kind, 3)
+    for q in (1, 5, 8, 10, 13, 16):
+        d_ref, t_ref = ref.encode(img, q, trace=True)
+        d_or, t_or = oracle.encode(img, q, trace=True)
+        assert [n for n, _ in t_ref] == [n for n, _ in t_or]
+        for (n, a), (_, b) in zip(t_ref, t_or):
+            assert a == b, f"{kind} q{q}: checkpoint {n}"
+        assert d_ref == d_or
