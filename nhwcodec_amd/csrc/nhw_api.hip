@@ -29,7 +29,12 @@ void nhw_launch_front_stale(const int16_t *y, size_t y_stride, const uint8_t *st
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s);
 enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
-enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2 };
+enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2, PH_DQ1L, PH_DQ0L, PH_QL, PH_L4DL };
+/* quality 1..16 only (nhw_low.hip) */
+void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int q, int n, hipStream_t s);
+void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s);
+void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipStream_t s);
+void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s);
 
 static thread_local std::string g_err;
 extern "C" const char *nhw_last_error(void) { return g_err.c_str(); }
@@ -70,7 +75,7 @@ static const size_t k_buf_bytes[B_COUNT] = {
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-extern "C" int nhw_quality_supported(int quality) { return quality >= 17 && quality <= 23; }
+extern "C" int nhw_quality_supported(int quality) { return quality >= 1 && quality <= 23; }
 
 extern "C" int nhw_enc_set_compat(nhw_enc *e, int mode)
 {
@@ -140,6 +145,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
                      int what = 3 /* bit 0: the front launch group (colour, pre-filter, level-1 analysis), bit 1: everything behind it */)
 {
 	const int q = quality;
+	const bool low = q <= 16;      /* integer colour, the rationed pre-filter of image_processing.c:838-2423 and the other quality 1..16 forms (nhw_low.hip) */
 	int16_t *jpeg = plane16(ws, B_JPEG), *proc = plane16(ws, B_PROC);
 	int16_t *cjpeg = plane16(ws, B_CJPEG), *cproc = plane16(ws, B_CPROC);
 	const size_t ps = ws.stride[B_JPEG] / 2, cps = ws.stride[B_CJPEG] / 2;
@@ -156,9 +162,18 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	 * contrast-map plane of the unfused path. */
 	int16_t *yin = e->legacy_front ? jpeg : plane16(ws, B_KMAP);
 	const size_t yin_stride = e->legacy_front ? ws.stride[B_JPEG] : ws.stride[B_KMAP];
+	if (low && !e->legacy_front) {
+		/* colour -> jpeg plane (free until the band kernel writes it), pre-filter: jpeg plane -> the band kernel's input plane */
+		nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
+		HIPCHK(hipEventRecord(e->ev[5], s));
+		STAGE_DONE();
+		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, q, n, s);
+		STAGE_DONE();
+	} else {
 	nhw_launch_color((const uint8_t *)d_bgr, n, q, yin, yin_stride, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
 	HIPCHK(hipEventRecord(e->ev[5], s));                          /* end of the colour kernel (the front runs once per batch, on the caller's stream) */
 	STAGE_DONE();
+	}
 	/* a2 + Y2 + Y3: pre-filter (q<=21, nhw_encoder.c:116-119), level-1 analysis (:125), LL1 copy (:127-135), fused */
 	if (e->legacy_front) {
 		if (q < 22) {
@@ -171,12 +186,12 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		nhw_launch_copy_block(jpeg, ps, W, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, H, H, H, n, s);
 		STAGE_DONE();
 	} else {
-		nhw_launch_front_fused(yin, yin_stride, q < 22, (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
+		nhw_launch_front_fused(yin, yin_stride, q < 22 && !low, (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
 		                       plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2,
 		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s, e->front_fallback);
-		if (ws.compat && q < 22)   /* the kernel-map cells the stock binary's heap re-uses (compatibility mode only) */
+		if (ws.compat && q < 22 && !low)   /* the kernel-map cells the stock binary's heap re-uses (compatibility mode only) */
 			nhw_launch_front_stale(yin, yin_stride, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], plane16(ws, B_STALE), ws.stride[B_STALE], n, s);
-		if (q < 22) STAGE_DONE();
+		if (q < 22 && !low) STAGE_DONE();
 		STAGE_DONE();
 		STAGE_DONE();
 	}
@@ -189,9 +204,11 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	const bool fork = timed == 1 && what == 3 && !e->stop_after && e->chroma_fork;
 	hipStream_t cs = fork ? e->part_stream[0] : s;
 	auto chroma_head = [&](int comp) -> int {                        /* everything up to the second dequantiser simulation */
-		nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, cs);
+		if (q <= 14) nhw_launch_low_prefilter_chroma(comp ? plane8(ws, B_PV) : plane8(ws, B_PU), ws.stride[B_PU], cjpeg, cps, q, n, cs);   /* :2263 / :2579 */
+		else nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
 		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, nullptr, 0, cs, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2);   /* + the copy of LL1 */
+		if (low) nhw_launch_low_chroma_thin(cproc, cps, n, cs);      /* :2277-2308 / :2590-2621 */
 		STAGE_DONE();
 		STAGE_DONE();
 		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, cs);
@@ -224,37 +241,47 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	/* Y4: level-2 analysis (:139) */
 	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
 	STAGE_DONE();
+	if (q > 6) {                                                     /* first closed loop (:141-283) */
 	nhw_launch_phase(PH_L1, ws, 0, out, d_sizes, d_status, s);
-	nhw_launch_wave(WV_DQ1, ws, s);
+	if (low) nhw_launch_phase(PH_DQ1L, ws, 0, out, d_sizes, d_status, s); else nhw_launch_wave(WV_DQ1, ws, s);
 	STAGE_DONE();
 	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s);
 	STAGE_DONE();
 	nhw_launch_phase(PH_L2, ws, 0, out, d_sizes, d_status, s);
 	STAGE_DONE();
-	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s, plane16(ws, B_L2SAVE), ws.stride[B_L2SAVE] / 2, H, 1);   /* + Y13 (:623-631): copy of the coefficient block */
+	if (q > 12) nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s, plane16(ws, B_L2SAVE), ws.stride[B_L2SAVE] / 2, H, 1);   /* + Y13 (:623-631): copy of the coefficient block */
+	else nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
 	STAGE_DONE();
+	}
+	if (q <= 12) {                                                   /* Y11 (q <= 11), Y12, then Y13 */
+		nhw_launch_low_ll2(proc, ps, q, n, s);
+		nhw_launch_copy_block(proc, ps, W, plane16(ws, B_L2SAVE), ws.stride[B_L2SAVE] / 2, H, H, H, n, s);
+	}
 	STAGE_DONE();
 	nhw_launch_wave(WV_EMIT, ws, s);                                 /* Y14, Y15 */
 	nhw_launch_phase(PH_L3, ws, 0, out, d_sizes, d_status, s);
 	if (fork && q <= 21) HIPCHK(hipEventRecord(e->part_ev[0], s));   /* exception list of the luma plane complete */
-	nhw_launch_wave(WV_DQ0, ws, s);
+	if (q > 12) {                                                    /* second closed loop (:759-779) */
+	if (low) nhw_launch_phase(PH_DQ0L, ws, 0, out, d_sizes, d_status, s); else nhw_launch_wave(WV_DQ0, ws, s);
 	STAGE_DONE();
 	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s);
 	STAGE_DONE();
+	}
 	nhw_launch_phase(PH_L4A, ws, 0, out, d_sizes, d_status, s);      /* Y19-Y23 */
 	/* Y24, Y25: the position lists are read by nothing before the packetiser, and what the pass leaves in the residual-code plane by nobody
 	 * at all; below q21 it shares no scratch with the passes behind it either (from q21 on its third list and Y27's snapshot both live in
 	 * the hs plane, and Y29 needs Y24), so there it runs beside them on a stream of its own */
-	const bool fork_lists = fork && q <= 20;
+	const bool fork_lists = fork && q <= 20 && q > 12;
 	if (fork_lists) {
 		HIPCHK(hipEventRecord(e->part_ev[2], s));
 		HIPCHK(hipStreamWaitEvent(e->part_stream[1], e->part_ev[2], 0));
 		nhw_launch_phase(PH_L4B, ws, 0, out, d_sizes, d_status, e->part_stream[1]);
 		HIPCHK(hipEventRecord(e->part_ev[3], e->part_stream[1]));
-	} else
-		nhw_launch_phase(PH_L4B, ws, 0, out, d_sizes, d_status, s);  /* Y24, Y25 */
+	} else if (q > 12)
+		nhw_launch_phase(PH_L4B, ws, 0, out, d_sizes, d_status, s);  /* Y24, Y25 (:1498) */
 	nhw_launch_phase(PH_L4C, ws, 0, out, d_sizes, d_status, s);      /* Y26, Y27 */
-	nhw_launch_wave(WV_QUANT, ws, s);                                /* Y28 */
+	if (low) nhw_launch_phase(PH_QL, ws, 0, out, d_sizes, d_status, s);   /* Y28, quality 1..16 form */
+	else nhw_launch_wave(WV_QUANT, ws, s);                           /* Y28 */
 	if (q > 21) nhw_launch_phase(PH_L4C2, ws, 0, out, d_sizes, d_status, s);   /* Y29 */
 	if (fork && q > 21) HIPCHK(hipEventRecord(e->part_ev[0], s));    /* ... and the band plane free */
 	if (fork) {                                                      /* queued here so that the wait finds its event recorded */
@@ -265,7 +292,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, cs);   /* Z1: the chroma LL2 coder appends to the luma one's output (Y16, long done) */
 		HIPCHK(hipEventRecord(e->part_ev[1], cs));
 	}
-	nhw_launch_phase(PH_L4D, ws, 0, out, d_sizes, d_status, s);      /* Y30, Y31 */
+	nhw_launch_phase(low ? PH_L4DL : PH_L4D, ws, 0, out, d_sizes, d_status, s);      /* Y30, Y31 */
 	STAGE_DONE();
 	if (timed) HIPCHK(hipEventRecord(e->ev[2], s));
 
@@ -292,7 +319,7 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
                                     int32_t *d_status, void *stream)
 {
 	if (!e || !d_bgr || !d_out || !d_sizes || !d_status || n < 1 || n > e->max_batch) { g_err = "bad argument"; return NHW_E_ARG; }
-	if (!nhw_quality_supported(quality)) { g_err = "quality outside 17..23 is not implemented in this revision"; return NHW_E_QUALITY; }
+	if (!nhw_quality_supported(quality)) { g_err = "quality outside 1..23"; return NHW_E_QUALITY; }
 	HIPCHK(hipSetDevice(e->device));
 	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
 	NhwWs ws = e->ws;

@@ -1,0 +1,854 @@
+/*
+ * nhw_low.hip -- kernels that exist only for quality 1..16 of the NHW encoder (gfx950).
+ *
+ *   k_low_prefilter   the luma pre-filter of those settings (rcanut/nhwcodec encoder/image_processing.c:558-2426, the
+ *                     `quality_setting<=LOW4` branches) and k_low_prefilter_chroma (pre_processing_UV, :2428-2464, q <= 14)
+ *   k_low_ll2         Y11 + Y12 of SURVEY.md App. A (encoder/nhw_encoder.c:285-621): isolated level-2 coefficients, LL2 smoothing
+ *
+ * Why these are serial walks here.  Below quality 17 the reference rations its sharpening with about sixty integer counters that
+ * live across the whole picture (bursts of pixel pairs whose lengths, pauses and strengths follow fixed schedules, :838-1925), resolves
+ * markers with every-third-one counters (:1994-2127) and moves its pair cursor backwards (:2279-2308).  A pair's action depends on the
+ * counters as the raster walk left them, and the counters on every pair before: there is no bounded-state summary of a row to compose
+ * (the counters reach into the millions).  So the dependency chain is walked by ONE lane per image, and everything that is not on the
+ * chain is taken off it:
+ *   * one wavefront per image; the 64 lanes load the three source rows of a step with 16-byte loads into LDS, compute the 8-neighbour
+ *     sums of the row in parallel, apply the q <= 14 smoothing in parallel and store finished rows;
+ *   * the four raster passes of the reference (contrast map, pair machine, marker pass, final pair pass) run as ONE sweep over the rows:
+ *     pass C of row r touches rows r and r-1 only and pass D of row r-1 nothing that a later row changes, so A(r) B(r) C(r) D(r-1) keep
+ *     two rows of every plane in LDS and the contrast map never travels to HBM at all;
+ *   * 4096 images = 4096 independent chains = 16 wavefronts per CU; the chain lane's instructions interleave with those of the other
+ *     fifteen wavefronts of its CU.
+ * Traffic per image: 512 KiB read, 512 KiB written (the reference makes four passes over three planes).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nhw_ws.h"
+
+#define DEVI __device__ static __forceinline__
+
+namespace {
+
+DEVI int iabs_(int v) { return v < 0 ? -v : v; }
+
+/* ------------------------------------------------------------------------------------------------ parameters (:570-598) */
+struct PfP { int sharp, s2, half, smooth_hi, smooth, tail_rules; };
+__device__ static const uint8_t k_sharp_by_q[17] = { 0, 48, 45, 36, 24, 24, 0, 0, 0, 1, 17, 35, 41, 44, 49, 54, 59 };
+DEVI PfP pf_params(int q)
+{
+	PfP p;
+	p.sharp = k_sharp_by_q[q];
+	p.s2 = p.sharp < 10 ? 10 : p.sharp;
+	p.half = p.sharp >> 1;
+	p.smooth_hi = q > 9 ? 36 : q == 9 ? 24 : q == 8 ? 10 : q == 7 ? 6 : q >= 3 ? 36 : q == 2 ? 56 : 60;
+	p.smooth = q <= 14;
+	p.tail_rules = q > 14 || (q <= 10 && q > 7);
+	return p;
+}
+
+/* ------------------------------------------------------------------------------------------------ pass A: contrast map (:601-764) */
+struct MapState { int carry, neg_run, neg_cycle, pos_run, pos_cycle, pos_alt, pos_neg_alt, exact_count, bump_count; };
+
+/* one row; sum/mag: the 8-neighbour sum and sum of magnitudes of every interior pixel (computed by all lanes), k: the map row */
+DEVI void map_row(MapState &s, const PfP &pp, const int16_t *sum, const int16_t *mag, int16_t *k)
+{
+	const int s2 = pp.s2;
+	for (int c = 1; c < W - 1; c++) {
+		const int sm = sum[c];
+		if (sm == 0) { k[c] = 0; s.carry = 0; continue; }
+		const int acc = 15 * iabs_(sm) + mag[c] + ((s.carry + 2) >> 2);
+		int val = acc >> 4;
+		s.carry = acc & 15;
+		if (sm < 0) {
+			val = -val;
+			if (val == -s2 && s.bump_count < 3) { val = -s2 - 1; s.bump_count++; }
+			if (-sm <= s2 && -val > s2 && -val <= s2 + 20) {          /* borderline: the plain sum is not above the threshold, the contrast is */
+				if (c > 1 && iabs_(k[c - 1]) <= pp.half) s.neg_run = 0;
+				if (!s.neg_run) { k[c] = -20000; s.neg_run = 1; }
+				else {
+					k[c] = (int16_t)val;
+					if (!s.neg_cycle) { s.neg_run = 0; s.neg_cycle = 1; }
+					else if (s.neg_run == 1) s.neg_run = 2;
+					else { s.neg_run = 0; s.neg_cycle = s.neg_cycle == 1 ? 2 : s.neg_cycle == 2 ? 3 : 0; }
+				}
+			}
+			else k[c] = (int16_t)val;
+		} else {
+			if (sm <= s2 && val > s2 && val <= s2 + 20) {
+				if (c > 1) {
+					const int left = k[c - 1];
+					if (iabs_(left) <= pp.half) s.pos_run = 0;
+					else if (iabs_(left) > 10000 || left == s2 + 21) {
+						if (!s.pos_alt) { s.pos_run = 0; if (!s.pos_cycle) s.pos_cycle = 1; s.pos_alt = 1; }
+						else s.pos_alt = 0;
+					}
+					else if (left == -(s2 + 21)) {
+						if (!s.pos_neg_alt) s.pos_neg_alt = 1;
+						else {
+							if (!s.pos_alt) { s.pos_run = 0; if (!s.pos_cycle) s.pos_cycle = 1; s.pos_alt = 1; }
+							else s.pos_alt = 0;
+							s.pos_neg_alt = s.pos_neg_alt == 1 ? 2 : 0;
+						}
+					}
+					else if (left == s2 + 22) k[c - 1] = 7000;
+				}
+				if (!s.pos_run) { k[c] = 20000; s.pos_run = 1; }
+				else {
+					k[c] = (int16_t)val;
+					if (!s.pos_cycle) { s.pos_run = 0; s.pos_cycle = 1; }
+					else if (s.pos_run == 1) s.pos_run = 2;
+					else { s.pos_run = 0; s.pos_cycle = s.pos_cycle == 1 ? 2 : s.pos_cycle == 2 ? 3 : 0; }
+				}
+			}
+			else if (val == s2 + 21) { k[c] = (int16_t)(s.exact_count ? val : 7000); s.exact_count++; }
+			else k[c] = (int16_t)val;
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------ pass B: the pair machine (:770-1992) */
+/* The counters are numbered as the reference numbers its variables (t1..t44, w1..w8): they have no documented meaning, and a reader
+ * can put the two side by side.  Constant indices only, so the arrays live in registers. */
+struct PfM { int t[45], w[9]; };
+#define T(n) (m.t[n])
+#define Wv(n) (m.w[n])
+
+DEVI void machine_reset(PfM &m)
+{
+	for (int i = 0; i < 45; i++) m.t[i] = 0;
+	for (int i = 0; i < 9; i++) m.w[i] = 0;
+	T(6) = 8; T(10) = 10; T(11) = 15; T(18) = 8; T(44) = 2; Wv(3) = 20;
+}
+DEVI void set_window(PfM &m, int wide) { if (wide) { T(10) = 10; T(11) = 15; } else { T(10) = 8; T(11) = 12; } }
+
+/* schedule walked once the burst counter t7 has reached 4 (:1203-1448) */
+__device__ static void long_schedule(PfM &m)
+{
+	switch (T(16)) {
+	case 0:
+		set_window(m, 1); T(16) = 1;
+		if ((Wv(7) == 2 || Wv(7) == 4) && T(24) == 14) { if (Wv(7) == 2) T(1) = 2000005; }
+		else { T(4) = 1000000; T(1) = 9; }
+		break;
+	case 1:
+		set_window(m, 0); T(16) = 2; Wv(5)++;
+		if (Wv(5) == 3 && T(1) > 0 && T(1) < 30) T(1) = (-T(1)) >> 2;
+		else { T(4) = 10; T(1) += 2; }
+		break;
+	case 2:
+		set_window(m, 1); T(16) = 3; T(4) = 1000000; Wv(6)++;
+		if (Wv(6) == 6 || Wv(6) == 10) T(1) = 10;
+		break;
+	case 3: set_window(m, 0); T(16) = 4; T(4) = 8; T(1) -= 4; break;
+	case 4: set_window(m, 1); T(16) = 5; break;
+	case 5: set_window(m, 1); T(16) = 6; T(4) = 10; T(1) = 2000000; break;
+	case 6: set_window(m, 0); T(16) = 7; T(4) = 8; T(1) = 3000000; break;
+	case 7: set_window(m, 0); T(16) = 8; T(4) = 1000000; break;
+	case 8: {
+		set_window(m, 0);
+		const int s = T(24);
+		if (s >= 0 && s < 14) {
+			/* sub-position -> next position; the t4 / t1 presets are sparse: written out */
+			int n16 = 1;
+			switch (s) {
+			case 0: n16 = 1; T(4) = 1000000; break;
+			case 1: n16 = 2; break;
+			case 2: n16 = 1; T(4) = 1000000; break;
+			case 3: n16 = 2; break;
+			case 4: n16 = 1; T(1) = 2999998; break;
+			case 5: n16 = 0; break;
+			case 6: n16 = 3; break;
+			case 7: n16 = 3; T(1) = 7; break;
+			case 8: n16 = 1; break;
+			case 9: n16 = 8; T(4) = 1000000; break;
+			case 10: n16 = 1; T(4) = 8; T(1) = 11; break;
+			case 11: n16 = 0; break;
+			case 12: n16 = 1; break;
+			default: n16 = 0; break;     /* 13 */
+			}
+			T(16) = n16; T(24) = s + 1;
+		}
+		else if (s == 14) { T(16) = 1; T(24) = 15; Wv(7)++; T(1) = Wv(2) == 0 ? 1999978 : Wv(2) == 1 ? 1999982 : 1999993; }
+		else if (s == 15) { T(16) = 0; T(24) = 12; T(1) = (Wv(2) == 1 || Wv(2) == 3) ? -5 : 2000005; Wv(2)++; }
+		break;
+	}
+	default: break;
+	}
+}
+
+/* end of a burst (:1053-1456) */
+__device__ static void burst_end(PfM &m)
+{
+	if (!T(6)) {
+		T(6) = 1; T(14) = 0;
+		if (!T(22)) T(7)++;
+		if (T(22) == 1) T(22) = 0;
+	} else {
+		T(6)++; T(1)++;
+		if (T(4) > 900000 && T(1) == 12) T(4) = 8;
+		if (T(1) > 3000000) { T(1) = 12; T(4) = 8; }
+		else if (T(1) > 2000006 && T(1) < 2500000) { T(1) = 14; T(4) = 10; }
+		if (!T(15)) { T(14) = 1; T(15) = 1; }
+		else { T(14) = 0; T(15)++; if (T(15) > 9) T(15) = 0; }
+		if (T(6) > 15 && T(7) < 4) { T(6) = 0; if (T(19) > 0) T(20)++; }
+	}
+	if (T(4) == 8 || (T(4) == 10 && Wv(3) > 16)) {
+		if (Wv(3) < 21) { T(4) = 0; Wv(3)++; }
+		else if (T(4) == 8) Wv(3) = 0;
+		else if (Wv(4) < 2) { T(4) = 8; T(1) = 12; Wv(4)++; }
+		else { T(4) = 0; Wv(4) = 0; }
+	}
+	else T(4) = 0;
+	T(8) = 0; T(5) = 0; T(12) = 0;
+	if (T(7) == 3) set_window(m, !T(6));
+	else if (T(7) == 1) {
+		set_window(m, T(9) < 2);
+		T(9)++;
+		if (T(9) >= 3 && T(10) == 8) T(9) = 0;
+	}
+	else if (T(7) == 2) set_window(m, 0);
+	else if ((T(6) == 10 || T(6) == 11) && !T(7)) { T(10) = 6; T(11) = 9; }
+	else if (T(7) >= 4) long_schedule(m);
+	else { T(10) = T(10) == 8 ? 10 : 8; T(11) = T(11) == 12 ? 15 : 12; }
+}
+
+/* a pair inside a burst that neither ends it nor sits at its cap (:1504-1873) */
+__device__ static void burst_idle(PfM &m)
+{
+	if (T(1) == 6 && !Wv(8)) { T(1)++; Wv(8)++; T(44) = -100000; }
+	else if (T(44) < -90000) { T(1)++; Wv(8)++; T(44) = 0; }
+	else if (T(44) < 3) T(44)++;
+	else { T(1) += 3; T(44) = 0; }
+
+	if (!(T(29) > 0 && (T(14) == 4 || T(14) == 5 || T(39) == 2 || T(41) > 0))) return;
+
+	if (T(4) < 2 && T(1) == 15 && (T(14) == 4 || (T(14) == 5 && T(32) > 2))) {
+		if (T(32) == 0 || T(32) == 2 || T(32) == 3 || (T(32) > 7 && T(32) < 500000)) {
+			if (T(32) > 7 && T(14) == 5) { T(14) = 1; T(32) = 1000000; }
+			else if (!T(34)) T(34) = 1;
+			else { T(14) = 5; T(34) = 0; }
+		}
+		if (!T(32)) T(14) = 5;
+		T(32)++;
+	}
+	else if (T(32) == 4 || T(32) == 5 || T(32) == 7) {
+		if (T(37) == 4) T(14) = 3;
+		else if (T(37) == 15) { T(14) = 3; T(32)++; }
+		else if (T(32) == 7 && T(37) > -345000) {
+			if (T(14) == 4) {
+				if (!T(42)) T(37) -= 10000;
+				if (T(38) > 0) {
+					T(42)++;
+					if (T(42) > 0 || (!T(42) && T(43) > 3)) {
+						if (!T(42)) T(14) = T(43) == 14 ? 3 : T(43) == 24 ? 4 : 1;
+						else T(14) = 1;
+						T(39) = 0;
+						if (T(42) > 5) { T(42) = -1; T(43)++; }
+					}
+					else if (T(42) == -1) { T(14) = 3; T(39) = 2; T(40) = -2; T(42) = 0; }
+					else T(39) = 0;
+				}
+				else { T(14) = 5; T(39) = 1; T(42) = 0; }
+			}
+			else if (T(39) >= 1) {
+				T(38)++;
+				if (T(39) < 2) T(39) = (T(38) == 2 || T(38) == 4 || T(38) == 6 || T(38) == 9) ? 2 : 0;
+				else {
+					T(40)++;
+					if (T(38) == 8) { T(39) = 0; T(40) = 0; }
+					if (T(40) > 2) { T(40) = 0; T(39) = 0; }
+				}
+				if (T(38) >= 1 && T(38) <= 10) T(14) = 4;
+			}
+			else { T(40) = 1; if (T(38) == 1) T(39) = 2; }
+		}
+		if (T(37) >= 0) T(37)++;
+	}
+	else if (T(32) == 6 && T(36) < 118) {
+		if (T(14) == 4 || T(14) == 5 || T(41) == 0 || T(41) > 3) T(36)++;
+		if (T(41) > 3 && T(36) < 8) T(41) = 0;
+		switch (T(36)) {                 /* t36 -> t14; t41 is reset, counted up or set to 4 */
+		case 1: T(14) = 1; T(41) = 0; break;   case 2: T(14) = 2; T(41) = 0; break;   case 3: T(14) = 1; T(41) = 0; break;
+		case 4: T(14) = 3; T(41) = 0; break;   case 5: T(14) = 3; T(41)++; break;     case 6: T(14) = 0; T(41) = 0; break;
+		case 7: T(14) = 2; T(41) = 0; break;   case 8: T(14) = 2; T(41) = 4; break;   case 15: T(14) = 1; T(41) = 0; break;
+		case 31: T(14) = 3; T(41)++; break;    case 47: T(14) = 2; T(41) = 0; break;  case 100: T(14) = 0; T(41)++; break;
+		case 116: T(14) = 2; T(41) = 0; break;
+		default: break;
+		}
+	}
+
+	if (T(28) < 14 && T(1) > 7) {                        /* :1711-1871 */
+		const int st = T(28);
+		if (T(14) == 5 && !st && !T(33) && T(1) > 13 && T(31) > 0) { T(30) = 1; T(33) = 2; }
+		else T(30)++;
+		const int ahead = T(30) - T(33);
+		int late_d = 0x7fffffff, l14 = 0, l15 = 0, l1 = 0, l4 = 0;   /* stages 6..12 fire once t30 has run far enough past t33 */
+		switch (st) {
+		case 6: late_d = 54; l14 = 2; l15 = 3; l1 = 3; break;    case 7: late_d = 57; l14 = 2; l15 = 8; l1 = 8; break;
+		case 8: late_d = 84; l14 = 2; l15 = 7; l1 = 7; break;    case 9: late_d = 111; l14 = 2; l15 = 3; l1 = 7; break;
+		case 10: late_d = 116; l14 = 1; l15 = 0; l1 = 1; l4 = 8; break;
+		case 11: late_d = 185; l14 = 0; l15 = 4; l1 = -17; break; case 12: late_d = 187; l14 = 3; l15 = 3; l1 = -19; break;
+		default: break;
+		}
+		if (!st && ahead > 10 && T(33) > 0 && T(14) == 4) { T(14) = 3; T(15) += 6; T(28)++; }
+		else if (st == 1 && ahead > 70 && T(14) == 4 && T(1) == 11) { T(15) = 1; T(1) = 13; T(28)++; }
+		else if (st == 2 && T(31) > 2 && T(1) == 15 && T(15) > 1) { T(15) = 15; T(33) = T(30); T(1) = 6; T(28)++; }
+		else if (st == 3 && ahead > 3 && T(31) > 2) { T(15) = 0; T(28)++; }
+		else if (st == 5 && ahead > 22 && T(31) > 2 && T(1) == 12) { T(15) = 3; T(1) = 9; T(28)++; }
+		else if (st == 4 && ahead > 6 && T(1) == 15) { T(14) = 1; T(15) += 6; T(1)++; T(28)++; }
+		else if (st >= 6 && st <= 12 && ahead > late_d) { T(14) = l14; T(15) = l15; T(1) = l1; if (l4) T(4) = l4; T(28)++; }
+		else if (ahead == 9) { T(1) += (12 - T(4)) >> 2; T(4) = 10; }
+		else if (st > 0 && T(1) == 15 && Wv(1) < 11) { if (T(4) != 10) { if (Wv(1) == 4 || Wv(1) == 10) T(4) = 10; Wv(1)++; } }
+		else if (st == 13 && ahead > 188) { T(14) = 0; T(15) = 3; T(1) = -30; T(28)++; }
+	}
+}
+
+/* one pixel pair (:838-1925).  km: the pair's map cells, o: the pair in the output row, so: the pair's flags */
+DEVI void machine_pair(PfM &m, const PfP &pp, int row, int &k0, int &k1, int16_t *km, int16_t *o, uint8_t *so)
+{
+	const int sharp = pp.sharp, s2 = pp.s2;
+	if (!T(1)) {                                     /* first pair of a burst (:840-994) */
+		T(2) = 0;
+		if (iabs_(k0) > sharp) {
+			o[0] += k0 > 0 ? 2 : -2;
+			if (iabs_(k1) > s2 || T(8) == 1) {
+				km[0] = 0;
+				if ((T(19) < 4 * Q || (T(20) >= 3 && T(20) < 4 * Q)) && iabs_(k0) > sharp + 96 && T(6) > 0 && row > 2) {
+					if (T(20) >= 3 && T(19) >= 8 * Q) { T(6) = 7000000; T(20) = 8 * Q; }
+					if (T(19) > 0 && T(19) < 4 * Q) {
+						if (T(20) > 2 || (T(20) == 2 && T(6) > 3 && !T(23)) || (T(20) == 2 && T(6) > 14 && T(23) > 0)) {
+							if (T(23) == 1) T(6) = 5000000;
+							T(23)++; T(21)++;
+							if (T(21) >= 2) T(19) = 8 * Q;
+						}
+					}
+					if (!T(19)) { T(6)++; T(20) = 1; }
+					T(19)++;
+				}
+			}
+			T(2) = 1;
+		}
+		if (iabs_(k1) > sharp) {
+			if ((T(2) == 1 || T(12) == 1) && (!T(14) || T(14) == 4 || T(14) == 5)) {
+				if (!T(3) && T(2) == 1) {
+					if (iabs_(k0) > 3000) k0 = k0 > 0 ? s2 + 5 : -s2 - 5;          /* a marker counts as just above the threshold */
+					if (iabs_(k1) > 3000) k1 = k1 > 0 ? s2 + 22 : -s2 - 22;
+					if (iabs_(k0) < (iabs_(k1) >> 2)) {
+						o[0] += k0 > 0 ? -1 : 1;
+						km[0] = (int16_t)k0;
+						o[1] += k1 > 0 ? 2 : -2;
+						if (iabs_(k0) > s2) km[1] = 0;
+					}
+					else o[1] += k1 > 0 ? 1 : -1;
+					T(3) = 1;
+				} else {
+					o[1] += k1 > 0 ? 2 : -2;
+					if (iabs_(k0) > s2) km[1] = 0;
+					T(3) = T(3) == 1 ? 2 : T(3) == 2 ? 3 : 0;
+				}
+			} else {
+				o[1] += k1 > 0 ? 2 : -2;
+				if (iabs_(k0) > s2) km[1] = 0;
+			}
+			if (T(14) == 2) { T(14) = 1; T(26) = 3; if (T(25) > 0) T(25)++; }
+			if (T(14) == 1) { if (T(26) < 4) T(26)++; else { T(14) = 2; T(26) = 0; } }
+		}
+		if (iabs_(k0) > sharp || iabs_(k1) > sharp) T(13) = 1;
+		if (T(14) == 1 || T(14) == 2) T(27)++; else T(27) = 0;
+		if (T(27) > 2) T(14) = 1;
+		if (T(14) == 1) {
+			T(14) = 4;
+			if (!T(25)) { T(15)++; T(25) = 1; }
+			else { T(25)++; if (T(25) > 3) T(25) = 0; }
+		}
+		T(1) = 1;
+	} else {                                         /* inside a burst (:995-1910) */
+		if (iabs_(k0) > sharp) { o[0] += k0 > 0 ? 1 : -1; T(1)++; T(4)++; }
+		if (iabs_(k1) > sharp) { o[1] += k1 > 0 ? 1 : -1; T(1)++; T(4)++; }
+
+		if (T(4) < 10) T(17) = (T(4) == T(10) && T(1) == T(11));
+		else if (T(4) > 10 || T(1) != 15) {
+			if (!T(18)) { T(17) = 1; T(18) = 1; }
+			else { T(17) = 0; T(18)++; if (T(18) > 15) T(18) = 0; }
+		}
+		else T(17) = (T(4) == T(10) && T(1) == T(11));
+
+		if (T(6) > 6000000) { T(6) = 0; T(22) = 0; }
+		else if (T(6) > 4000000) { T(6) = 0; T(22) = (T(21) == 1); }
+
+		if (T(17) == 1 || T(1) > 2000003) burst_end(m);
+		else if (T(1) >= 15) {                       /* :1457-1503 */
+			if (!T(4)) T(8)++; else { T(8) = 0; T(5) = 0; T(12) = 0; }
+			T(1)++;
+			if (T(4) < 2 && T(29) > 0 && T(14) == 4) {
+				if (T(31) == 0 || T(31) == 1) { T(14) = 3; T(31)++; }
+				else if (T(31) == 2) { T(14) = 0; T(15) = 0; T(31)++; }
+			}
+			if (T(14) == 5 && !T(35) && T(32) > 4 && T(32) < 8) { T(14) = 1; T(32)--; T(35)++; }
+		}
+		else burst_idle(m);
+
+		if (T(8) > 6 && !T(4) && T(1) > 1 && T(1) < 15) {  /* :1875-1900 */
+			T(5)++;
+			if (T(5) < 35) {
+				T(1) = 0;
+				if (!T(13)) { T(12) = 1; T(13) = 1; }
+				else { T(12) = 0; T(13)++; if (T(13) > 3) T(13) = 0; }
+			}
+			else T(12) = 0;
+		}
+		if (T(1) > 15 && T(1) < 1000000) { T(1) = 0; T(4) = 0; T(29)++; }
+	}
+	/* opposite signs, both just above the threshold (:1912-1924) */
+	if (iabs_(k0) > sharp && iabs_(k0) <= sharp + 20 && iabs_(k1) > sharp && iabs_(k1) <= sharp + 20) {
+		if (k0 > 0 && k1 < 0) { o[0]++; o[1]--; so[0] = 2; so[1] = 3; }
+		else if (k0 < 0 && k1 > 0) { o[0]--; o[1]++; so[0] = 3; so[1] = 2; }
+	}
+}
+#undef T
+#undef Wv
+
+/* pass B over one row */
+DEVI void pair_row(PfM &m, int &prev_big, const PfP &pp, int r, int16_t *km, int16_t *y, uint8_t *so)
+{
+	for (int c = 1; c < W - 2; c += 2) {
+		int16_t *o = y + c;
+		int k0 = km[c], k1 = km[c + 1];
+		machine_pair(m, pp, r, k0, k1, km + c, o, so + c);
+		if (!pp.tail_rules) continue;
+		/* :1927-1990, on the (possibly rewritten) pair values */
+		if (k0 < 32 && k0 > 10) {
+			if (iabs_(k1) >= 23) {
+				if (k0 < 16) { if (k1 > 0 && k1 < 32 && k0 > 11) o[1]++; o[0]++; }
+				else o[0] += prev_big ? 1 : 2;
+				prev_big = 0;
+				continue;
+			}
+		} else if (k0 > -32 && k0 < -10) {
+			if (iabs_(k1) >= 23) {
+				if (k0 > -16) { if (k1 < 0 && k1 > -32 && k0 < -11) o[1]--; o[0]--; }
+				else o[0] -= prev_big ? 1 : 2;
+				prev_big = 0;
+				continue;
+			}
+		}
+		prev_big = 0;
+		if (k1 < 32 && k1 > 10) {
+			if (iabs_(k0) >= 23) {
+				if (k1 < 16) { if (k0 > 0 && k0 < 32 && k1 > 11) o[0]++; o[1]++; }
+				else { o[1] += 2; prev_big = 1; }
+			}
+		} else if (k1 > -32 && k1 < -10) {
+			if (iabs_(k0) >= 23) {
+				if (k1 > -16) { if (k0 < 0 && k0 > -32 && k1 < -11) o[0]--; o[1]--; }
+				else { o[1] -= 2; prev_big = 1; }
+			}
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------ pass C: markers, weak partners (:1994-2310) */
+struct MarkState { int skip_toggle, second_toggle, pos0, neg0, pos1, neg1; };
+
+DEVI void resolve_marker(int16_t *cell, int v, int &pos_cnt, int &neg_cnt, int s2)
+{
+	if (v == 20000) { if (!pos_cnt) { *cell = 0; pos_cnt = 1; } else { *cell = 5000; pos_cnt = pos_cnt == 1 ? 2 : 0; } }
+	else if (v == -20000) { if (!neg_cnt) { *cell = 0; neg_cnt = 1; } else { *cell = -5000; neg_cnt = neg_cnt == 1 ? 2 : 0; } }
+	else if (v == 7000) *cell = (int16_t)(s2 + 22);
+}
+/* strong pixel with a weak partner: nudge the strong one, the partner if it agrees in sign, and the two pixels above the pair */
+DEVI void sharpen_weak_partner(int strong, int weak, int16_t *ys, int16_t *yw, uint8_t *ss, uint8_t *sw,
+                               const int16_t *kup, int16_t *yup, uint8_t *sup, bool have_up, bool no_retry)
+{
+	const int sg = strong > 0 ? 1 : -1;
+	*ys += sg; *ss = 1;
+	if ((sg > 0 && weak > 0) || (sg < 0 && weak < 0)) { *yw += 2 * sg; *sw = 1; }
+	if (have_up) {
+		const int a = kup[0] * sg, b = kup[-1] * sg;
+		if (a > 4) { yup[0] += sg; sup[0] = 1; }
+		if (b > 4) { yup[-1] += sg; sup[-1] = 1; }
+		if (a < -24 && no_retry) { yup[0] -= sg; sup[0] = 1; }
+		if (b < -24 && no_retry) { yup[-1] -= sg; sup[-1] = 1; }
+	}
+}
+/* one row: km / y / so of the row, kmu / yu / sou of the row above */
+DEVI void marker_row(MarkState &s, const PfP &pp, int r, int16_t *km, int16_t *y, uint8_t *so, const int16_t *kmu, int16_t *yu, uint8_t *sou)
+{
+	const int sharp = pp.sharp, s2 = pp.s2, half = pp.half;
+	int idle = 0, retry = 0, idle_fresh = 0;
+	for (int c = 1; c < W - 3; c++) {
+		c++;
+		const int k0 = km[c - 1], k1 = km[c];
+		if (iabs_(k0) > 6000) {
+			resolve_marker(km + c - 1, k0, s.pos0, s.neg0, s2);
+			if (!s.second_toggle) { resolve_marker(km + c, k1, s.pos1, s.neg1, s2); s.second_toggle = 1; }
+			else s.second_toggle = 0;
+			if (!s.skip_toggle) { s.skip_toggle = 1; continue; }
+			s.skip_toggle = 0;
+		}
+		else if (iabs_(k1) > 6000) { resolve_marker(km + c, k1, s.pos1, s.neg1, s2); continue; }
+
+		const bool have_up = r > 2 || (r == 2 && c >= 2);
+		if (iabs_(k0) > sharp + 20 && iabs_(k1) > half && iabs_(k1) <= s2) {
+			sharpen_weak_partner(k0, k1, y + c - 1, y + c, so + c - 1, so + c, kmu + c, yu + c, sou + c, have_up, !retry);
+			idle = 0; idle_fresh = 0;
+			if (retry == 1) { c++; retry = 0; } else if (retry == 2) { c += 3; retry = 0; }
+		}
+		else if (iabs_(k1) > sharp + 20 && iabs_(k0) > half && iabs_(k0) <= s2) {
+			sharpen_weak_partner(k1, k0, y + c, y + c - 1, so + c, so + c - 1, kmu + c, yu + c, sou + c, have_up, !retry);
+			idle = 0; idle_fresh = 0;
+			if (retry == 1) { c++; retry = 0; } else if (retry == 2) { c += 3; retry = 0; }
+		}
+		else {                                       /* the cursor goes back and tries the other pairing */
+			idle++;
+			if (!retry) idle_fresh++;
+			if (idle == 2) { c -= 3; idle = 0; retry = 1; }
+			else if (retry == 1) {
+				c++; retry = 0; idle = 0;
+				if (idle_fresh == 4) {
+					if (iabs_(km[c - 5]) <= s2 || iabs_(km[c - 2]) <= s2) { c -= 5; retry = 2; }
+					idle_fresh = 0;
+				}
+			}
+			else if (retry == 2) { c += 3; retry = 0; idle = 0; idle_fresh = 0; }
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------ pass D (:2312-2420) */
+DEVI void final_row(const PfP &pp, const int16_t *km, int16_t *y, const uint8_t *so)
+{
+	const int sharp = pp.sharp, s2 = pp.s2;
+#define JUST_ABOVE(v, base) (iabs_(v) > (base) && iabs_(v) <= (base) + 20)
+	for (int c = 1; c < W - 2; c++) {
+		c++;
+		const int k0 = km[c - 1], k1 = km[c];
+		int16_t *o = y + c - 1;
+		const uint8_t *f = so + c - 1;
+		bool slide = false;
+		if (iabs_(k0) > 4000 || iabs_(k1) > 4000) continue;
+		if (JUST_ABOVE(k0, sharp) && JUST_ABOVE(k1, sharp)) {
+			const int k2 = km[c + 1];
+			const bool next_same = c < W - 4 && JUST_ABOVE(k2, sharp) && ((k1 > 0 && k2 > 0) || (k1 < 0 && k2 < 0));
+			if (f[0] != 1 && f[1] != 1) {
+				if (k0 > 0 && k1 > 0) {
+					if (k0 >= k1) { if (f[0] != 2) o[0]++; else if (f[1] != 2) o[1]++; }
+					else { if (f[1] != 2) o[1]++; else if (f[0] != 2) o[0]++; }
+				}
+				else if (k0 < 0 && k1 < 0) {
+					if (k0 <= k1) { if (f[0] != 3) o[0]--; else if (f[1] != 3) o[1]--; }
+					else { if (f[1] != 3) o[1]--; else if (f[0] != 3) o[0]--; }
+				}
+				else slide = next_same;
+			}
+			else slide = next_same;
+		}
+		else if (iabs_(k0) > sharp + 56 && iabs_(k1) > sharp + 56) {
+			if (!f[0] && !f[1]) {
+				if (k0 > 0 && k1 < 0) { o[0]++; o[1]--; }
+				else if (k0 < 0 && k1 > 0) { o[0]--; o[1]++; }
+				else if (iabs_(k0) > sharp + 96 && iabs_(k1) > sharp + 96) {
+					if (k0 > 0 && k1 > 0) { if (k0 > k1) o[0]++; else o[1]++; }
+					else if (k0 < 0 && k1 < 0) { if (k0 < k1) o[0]--; else o[1]--; }
+				}
+			}
+		}
+		else if (iabs_(k0) > sharp + 160 && JUST_ABOVE(k1, s2)) {
+			if (!f[0] && !f[1]) {
+				if (k0 > 0 && k1 > 0) o[1]--;
+				else if (k0 < 0 && k1 < 0) o[1]++;
+				else slide = c < W - 6 && iabs_(km[c + 1]) > sharp + 160 && iabs_(km[c + 2]) <= s2;
+			}
+			else slide = c < W - 6 && iabs_(km[c + 1]) > sharp + 160 && iabs_(km[c + 2]) > s2 + 20;
+		}
+		else if (iabs_(k1) > sharp + 160 && JUST_ABOVE(k0, s2)) {
+			if (!f[0] && !f[1]) {
+				if (k0 > 0 && k1 > 0) o[0]--;
+				else if (k0 < 0 && k1 < 0) o[0]++;
+				else slide = c < W - 4 && JUST_ABOVE(km[c + 1], s2);
+			}
+			else slide = true;
+		}
+		else slide = true;
+		if (slide) c--;
+	}
+#undef JUST_ABOVE
+}
+
+} // namespace
+
+/* src: the luma plane as the colour kernel wrote it (read only); y: the filtered plane (every row is written) */
+__global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride, int q)
+{
+	__shared__ __attribute__((aligned(16))) int16_t s_src[3][W];
+	__shared__ __attribute__((aligned(16))) int16_t s_km[2][W + 8];
+	__shared__ __attribute__((aligned(16))) int16_t s_y[2][W];
+	__shared__ __attribute__((aligned(16))) uint8_t s_so[2][W];
+	__shared__ int16_t s_sum[W], s_mag[W];
+	const int lane = threadIdx.x;
+	const int16_t *src = srcb + (size_t)blockIdx.x * src_stride;
+	int16_t *yo = yb + (size_t)blockIdx.x * y_stride;
+	const PfP pp = pf_params(q);
+
+	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	MarkState ks = { 0, 0, 0, 0, 0, 0 };
+	PfM mach;
+	int prev_big = 0;
+	machine_reset(mach);
+
+	const int c0 = lane * 8;
+	auto load_row = [&](int r) { *reinterpret_cast<uint4 *>(&s_src[r % 3][c0]) = *reinterpret_cast<const uint4 *>(src + (size_t)r * W + c0); };
+	load_row(0); load_row(1);
+	for (int k = lane; k < 2 * (W + 8); k += 64) (&s_km[0][0])[k] = 0;
+	__syncthreads();
+	*reinterpret_cast<uint4 *>(yo + c0) = *reinterpret_cast<const uint4 *>(&s_src[0][c0]);      /* row 0 is not touched by any pass */
+
+	for (int r = 1; r < W - 1; r++) {
+		load_row(r + 1);
+		__syncthreads();
+		const int16_t *up = s_src[(r - 1) % 3], *mid = s_src[r % 3], *dn = s_src[(r + 1) % 3];
+		int16_t *km = s_km[r & 1], *kmu = s_km[(r - 1) & 1];
+		int16_t *y = s_y[r & 1], *yu = s_y[(r - 1) & 1];
+		uint8_t *so = s_so[r & 1], *sou = s_so[(r - 1) & 1];
+		/* every lane: 8-neighbour sum and magnitude sum of its 8 pixels (:605-618) */
+		for (int e = 0; e < 8; e++) {
+			const int c = c0 + e;
+			if (c < 1 || c > W - 2) continue;
+			const int ctr = mid[c];
+			int sm = 0, mg = 0;
+#define NB(v) do { const int d_ = ctr - (v); sm += d_; mg += iabs_(d_); } while (0)
+			NB(mid[c - 1]); NB(mid[c + 1]); NB(up[c]); NB(dn[c]); NB(up[c + 1]); NB(up[c - 1]); NB(dn[c - 1]); NB(dn[c + 1]);
+#undef NB
+			s_sum[c] = (int16_t)sm; s_mag[c] = (int16_t)mg;
+		}
+		*reinterpret_cast<uint4 *>(&y[c0]) = *reinterpret_cast<const uint4 *>(&mid[c0]);        /* :566: the passes work on a copy */
+		*reinterpret_cast<uint2 *>(&so[c0]) = make_uint2(0, 0);
+		__syncthreads();
+		if (lane == 0) { km[0] = 0; km[W - 1] = 0; map_row(ms, pp, s_sum, s_mag, km); }
+		__syncthreads();
+		if (pp.smooth) {                                          /* :780-807, reads the source copy only: off the chain */
+			for (int e = 0; e < 8; e++) {
+				const int c = c0 + e;
+				if (c < 1 || c > W - 2) continue;
+				const int k = km[c];
+				if (iabs_(k) > 4 && iabs_(k) < pp.smooth_hi &&
+				    iabs_(up[c] - mid[c - 1]) < 4 && iabs_(mid[c - 1] - dn[c]) < 4 && iabs_(dn[c] - mid[c + 1]) < 4 && iabs_(mid[c + 1] - up[c]) < 4)
+					y[c] = (int16_t)(((mid[c] << 2) + mid[c - 1] + mid[c + 1] + up[c] + dn[c] + 4) >> 3);
+			}
+			__syncthreads();
+		}
+		if (lane == 0) {
+			pair_row(mach, prev_big, pp, r, km, y, so);
+			marker_row(ks, pp, r, km, y, so, kmu, yu, sou);
+			if (r > 1) final_row(pp, kmu, yu, sou);
+		}
+		__syncthreads();
+		if (r > 1) *reinterpret_cast<uint4 *>(yo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&yu[c0]);
+	}
+	{
+		const int r = W - 2;
+		if (lane == 0) final_row(pp, s_km[r & 1], s_y[r & 1], s_so[r & 1]);
+		__syncthreads();
+		*reinterpret_cast<uint4 *>(yo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[r & 1][c0]);
+		*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
+	}
+}
+
+/* pre_processing_UV (:2428-2464), pointwise on a copy: 8-neighbour Laplacian of the 256 x 256 chroma plane, one or two steps back.
+ * src: the 4:2:0 byte plane; dst: the int16 plane the filterbank starts from. */
+__global__ __launch_bounds__(256) void k_low_prefilter_chroma(const uint8_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ dstb, size_t dst_stride, int q)
+{
+	const uint8_t *s = srcb + (size_t)blockIdx.y * src_stride;
+	int16_t *d = dstb + (size_t)blockIdx.y * dst_stride;
+	const int idx = blockIdx.x * 256 + threadIdx.x, r = idx >> 8, c = idx & 255;
+	int v = s[idx];
+	if (r >= 1 && r < H - 1 && c >= 1 && c < H - 1) {
+		const int lap = (v << 3) - s[idx - 1] - s[idx + 1] - s[idx - H] - s[idx + H] - s[idx - H - 1] - s[idx + H - 1] - s[idx - H + 1] - s[idx + H + 1];
+		if (q < 14) {
+			if (iabs_(lap) >= 14) v += lap > 0 ? -2 : 2;
+			else if (iabs_(lap) > 5) v += lap > 0 ? -1 : 1;
+		} else {
+			if (lap > 5) v--; else if (lap < -5) v++;
+		}
+	}
+	d[idx] = (int16_t)v;
+}
+
+/* ------------------------------------------------------------------------------------------------ Y11 + Y12 (nhw_encoder.c:285-621) */
+namespace {
+__device__ static const uint8_t k_ll2_thr[13][7] = {          /* wvlt_thrx1..7 by quality (:313-381) */
+	{ 0 }, { 11, 15, 10, 15, 36, 20, 21 }, { 11, 15, 10, 15, 36, 19, 20 }, { 11, 15, 10, 15, 36, 18, 18 },
+	{ 11, 15, 10, 15, 36, 17, 17 }, { 11, 15, 10, 15, 36, 17, 17 }, { 11, 15, 10, 15, 36, 17, 17 },
+	{ 10, 15, 9, 14, 36, 17, 17 }, { 8, 13, 6, 11, 34, 15, 15 }, { 8, 13, 6, 11, 34, 15, 15 },
+	{ 8, 13, 6, 11, 34, 15, 15 }, { 8, 13, 6, 11, 34, 15, 15 }, { 8, 13, 6, 11, 34, 14, 0 } };
+DEVI void zero_below(int16_t *v, int lim) { if (iabs_(*v) < lim) *v = 0; }
+}
+#define LS (H / 2)          /* LL2 is 128 x 128 */
+/* Hit byte of an LL2 cell: bits 0..1 = the largest limit its level-1 children under HH1 get (0 none, 1 = 32, 2 = 34, 3 = 36; thrx5 is 34
+ * or 36; the other two bands always get thrx6 and thrx6 + 6), bit 2 = its level-2 siblings go too (q <= 11).  Zeroing below a limit is idempotent and
+ * monotone, and the walks never read what they zero, so the walk (one lane, on the LDS copy of LL2) only records hits and all lanes
+ * clear the children afterwards. */
+__global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, size_t plane_stride, int q)
+{
+	__shared__ __attribute__((aligned(16))) int16_t ll[LS * LS + 8];
+	__shared__ __attribute__((aligned(16))) uint8_t hit[LS * LS];
+	__shared__ int stale_hits;
+	int16_t *p = procb + (size_t)blockIdx.x * plane_stride;
+	const int lane = threadIdx.x;
+
+	if (q <= 11) {                                                 /* Y11 (:285-309): rows are independent, a lane walks two of them */
+		const int lim = q > 6 ? 10 : 11;
+		for (int r = H / 2 + lane; r < H; r += 64) {
+			int16_t *row = p + (size_t)r * W;
+			int left = row[-1];                                    /* the cell before the row in memory (never written by this pass) */
+			int cur = row[0];
+			for (int j = 0; j < H; j++) {
+				const int nxt = row[j + 1];
+				const int m = iabs_(cur);
+				int out = cur;
+				if (m >= DEADZONE && m < lim) {
+					const bool ql = iabs_(left) < DEADZONE, qr = iabs_(nxt) < DEADZONE;
+					if ((ql && qr) || (m == DEADZONE && (ql || qr))) out = 0;
+				}
+				if (out != cur) row[j] = (int16_t)out;
+				left = out; cur = nxt;
+			}
+		}
+	}
+	if (q > 12) return;
+	for (int k = lane; k < LS * LS / 8; k += 64) {
+		const int r = k >> 4, c8 = (k & 15) * 8;
+		*reinterpret_cast<uint4 *>(&ll[r * LS + c8]) = *reinterpret_cast<const uint4 *>(p + (size_t)r * W + c8);
+	}
+	for (int k = lane; k < LS * LS / 4; k += 64) reinterpret_cast<uint32_t *>(hit)[k] = 0;
+	if (lane == 0) stale_hits = 0;
+	__syncthreads();
+
+	const uint8_t *t = k_ll2_thr[q];
+	const int t1 = t[0], t2 = t[1], t3 = t[2], t4 = t[3], t5 = t[4], t6 = t[5], t7 = t[6];
+	const bool deep = q <= 11;
+	const int c5 = t5 == 36 ? 3 : 2;                              /* limit classes by value: 32 < 34 < 36 */
+	if (lane == 0) {
+#define HIT(cell, cls) do { const int c_ = (cell); const int old_ = hit[c_]; const int lv_ = (old_ & 3) > (cls) ? (old_ & 3) : (cls); hit[c_] = (uint8_t)((old_ & 4) | lv_); } while (0)
+#define SIB(cell) do { hit[(cell)] |= 4; } while (0)
+		/* `last`: the reference's `count` variable as the third walk finds it (:571-579 use it without having set it when the inner test
+		 * fails): -1 = still IM_SIZE (no hit so far), otherwise an LL2 cell index in this 128-stride layout */
+		int last = -1;
+		for (int r = 0; r < LS; r++)                              /* five cells in a row (:383-486) */
+			for (int j = 0; j < LS - 4; j++) {
+				int16_t *v = ll + r * LS + j;
+				bool h = false;
+				if (iabs_(v[4] - v[0]) < t1 && iabs_(v[4] - v[3]) < t1 && iabs_(v[1] - v[0]) < t1 &&
+				    iabs_(v[3] - v[1]) < t1 && iabs_(v[3] - v[2]) < t2 - 2) {
+					if ((v[3] - v[1]) > 5 && (v[2] - v[3]) >= 0) v[2] = v[3];
+					else if ((v[1] - v[3]) > 5 && (v[2] - v[3]) <= 0) v[2] = v[3];
+					else if ((v[1] - v[3]) > 5 && (v[2] - v[1]) >= 0) v[2] = v[1];
+					else if ((v[3] - v[1]) > 5 && (v[2] - v[1]) <= 0) v[2] = v[1];
+					else if ((v[3] - v[2]) > 0 && (v[2] - v[1]) > 0) { }
+					else if ((v[1] - v[2]) > 0 && (v[2] - v[3]) > 0) { }
+					else v[2] = (int16_t)((v[3] + v[1]) >> 1);
+					h = true;
+				}
+				else if (iabs_(v[4] - v[0]) < t2 + 1 && iabs_(v[4] - v[3]) < t2 + 1 && iabs_(v[1] - v[0]) < t2 + 1) {
+					if (iabs_(v[3] - v[1]) < t2 + 6 && iabs_(v[3] - v[2]) < t2 + 6) {
+						const int a = v[3] - v[2], b = v[2] - v[1];
+						if ((a >= 0 && b >= 0) || (a <= 0 && b <= 0)) h = true;
+					}
+				}
+				if (h) {
+					for (int k = 1; k < 4; k++) { HIT(r * LS + j + k, c5); if (deep) SIB(r * LS + j + k); }
+					last = 4;                                     /* the inner loop counter's exit value: row 0, column 4 */
+				}
+			}
+		for (int pass = 0; pass < 2; pass++)                      /* plus shape (+2, :488-533), then flat corner (+1, :535-583) */
+			for (int r = 0; r < LS - 2; r++)
+				for (int j = 0; j < LS - 2; j++) {
+					int16_t *v = ll + r * LS + j;
+					if (!pass) {
+						if (iabs_(v[1] - v[2 * LS + 1]) < t3 && iabs_(v[LS] - v[LS + 2]) < t3 &&
+						    iabs_(v[LS + 1] - v[LS]) < t4 - 1 && iabs_(v[1] - v[LS + 1]) < t4) {
+							const int e = (v[1] + v[2 * LS + 1] + v[LS] + v[LS + 2] + 2) >> 2;
+							if (iabs_(e - v[LS]) < 5 || iabs_(e - v[LS + 2]) < 5) v[LS + 1] = (int16_t)e;
+							last = (r + 1) * LS + j + 1;
+							HIT(last, 1);
+							if (deep) for (int k = -1; k < 2; k++) SIB(last + k);
+						}
+					} else if (iabs_(v[2] - v[1]) < t3 && iabs_(v[1] - v[0]) < t3 && iabs_(v[0] - v[LS]) < t3 && iabs_(v[2] - v[LS + 2]) < t3) {
+						if (iabs_(v[2 * LS + 1] - v[LS]) < t3 && iabs_(v[LS] - v[LS + 1]) < t4) {
+							const int e = (v[1] + v[2 * LS + 1] + v[LS] + v[LS + 2] + 1) >> 2;
+							if (iabs_(e - v[LS]) < 5 || iabs_(e - v[LS + 2]) < 5) v[LS + 1] = (int16_t)e;
+							last = (r + 1) * LS + j + 1;
+							HIT(last, 1);
+						}
+						if (deep) { if (last < 0) stale_hits = 1; else for (int k = -1; k < 2; k++) SIB(last + k); }
+					}
+				}
+		if (deep)
+			for (int r = 0; r < LS; r++)                          /* three flat cells in a row (:585-620) */
+				for (int j = 0; j < LS - 2; j++) {
+					const int16_t *v = ll + r * LS + j;
+					if (iabs_(v[2] - v[1]) < t7 && iabs_(v[2] - v[0]) < t7 && iabs_(v[1] - v[0]) < t7) { HIT(r * LS + j + 1, 2); SIB(r * LS + j + 1); }
+				}
+#undef HIT
+#undef SIB
+	}
+	__syncthreads();
+	for (int k = lane; k < LS * LS / 8; k += 64) {                /* the smoothed LL2 band goes back */
+		const int r = k >> 4, c8 = (k & 15) * 8;
+		*reinterpret_cast<uint4 *>(p + (size_t)r * W + c8) = *reinterpret_cast<const uint4 *>(&ll[r * LS + c8]);
+	}
+	for (int cell = lane; cell < LS * LS; cell += 64) {
+		const int hb = hit[cell];
+		if (!hb) continue;
+		const int r = cell >> 7, j = cell & 127, flat = r * W + j;
+		if (hb & 3) {
+			const int limc = (hb & 3) == 1 ? 32 : (hb & 3) == 2 ? 34 : 36;
+			const int base = flat << 1;
+			const int band[3] = { H, 2 * Q, 2 * Q + H }, lim[3] = { t6, t6 + 6, limc };
+			for (int b = 0; b < 3; b++) {
+				int16_t *v = p + base + band[b];
+				zero_below(v, lim[b]); zero_below(v + 1, lim[b]); zero_below(v + W, lim[b]); zero_below(v + W + 1, lim[b]);
+			}
+		}
+		if (hb & 4) { zero_below(p + flat + H / 2, 11); zero_below(p + flat + Q, 12); zero_below(p + flat + Q + H / 2, 13); }
+	}
+	if (stale_hits && lane < 3) {                                  /* `count` still IM_SIZE: the "siblings" of plane cells 65535..65537 */
+		const int flat = Q - 1 + lane;
+		zero_below(p + flat + H / 2, 11); zero_below(p + flat + Q, 12); zero_below(p + flat + Q + H / 2, 13);
+	}
+}
+#undef LS
+
+/* level-1 chroma detail below 24 / 32 / 48 goes (nhw_encoder.c:2277-2308, :2590-2621; q <= 16), pointwise on the 256 x 256 coefficient plane */
+__global__ __launch_bounds__(256) void k_low_chroma_thin(int16_t *__restrict__ planeb, size_t plane_stride)
+{
+	int16_t *p = planeb + (size_t)blockIdx.y * plane_stride;
+	const int g = blockIdx.x * 256 + threadIdx.x;                  /* 8 cells */
+	const int r = g >> 5, c0 = (g & 31) * 8;
+	if (r < H / 2 && c0 < H / 2) return;
+	const int lim = r < H / 2 ? 24 : (c0 < H / 2 ? 32 : 48);
+	uint4 w = *reinterpret_cast<uint4 *>(p + r * H + c0);
+	uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+	for (int e = 0; e < 4; e++) {
+		const int lo = (int16_t)(ww[e] & 0xFFFF), hi = (int16_t)(ww[e] >> 16);
+		if (iabs_(lo) >= DEADZONE && iabs_(lo) < lim) ww[e] &= 0xFFFF0000u;
+		if (iabs_(hi) >= DEADZONE && iabs_(hi) < lim) ww[e] &= 0x0000FFFFu;
+	}
+	*reinterpret_cast<uint4 *>(p + r * H + c0) = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+}
+void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipStream_t s)
+{
+	k_low_chroma_thin<<<dim3(Q / 8 / 256, n), 256, 0, s>>>(plane, plane_stride);
+}
+
+void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s)
+{
+	k_low_ll2<<<n, 64, 0, s>>>(proc, plane_stride, q);
+}
+void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int q, int n, hipStream_t s)
+{
+	k_low_prefilter<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, q);
+}
+void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s)
+{
+	k_low_prefilter_chroma<<<dim3(Q / 256, n), 256, 0, s>>>(src, src_stride, dst, dst_stride, q);
+}

@@ -234,8 +234,18 @@ DEV void mark_pairs_row(int16_t *p, int r, int col0)
 		else if (is_m567(p[a])) { if (is_m567(p[a + 1])) { p[a] = 15800; j++; } }
 	}
 }
-DEV void dequant_row(int16_t *p, int16_t *jp, int r, int col0, int part)
+/* q<=16: negative magnitudes keep their low bits only on a ration: of the 15s in a row every sixth is floored to 8, of the
+ * x7 above 22 every fourth (image_processing.c:2938-2989, :357-410); everything else is floored */
+DEV int ration_low_bits(int a, int &n15, int &nx7, int mask)
 {
+	if (a == 15) { if (!n15) a &= mask; n15 = n15 == 5 ? 0 : n15 + 1; }
+	else if (a > 22 && (a & 7) == 7) { if (!nx7) a &= mask; nx7 = (nx7 + 1) & 3; }
+	else a &= mask;
+	return a;
+}
+DEV void dequant_row(int16_t *p, int16_t *jp, int r, int col0, int part, int q)
+{
+	int n15 = 0, nx7 = 0;
 	for (int j = col0; j < H; j++) {
 		const int at = r * W + j;
 		int a = p[at];
@@ -252,7 +262,8 @@ DEV void dequant_row(int16_t *p, int16_t *jp, int r, int col0, int part)
 		if (a < 0) {
 			if (a == -7 && j < H - 1 && p[at + 1] == 8) { p[at] = -8; a = -8; }
 			a = -a;
-			if ((a & 7) < 7) a &= 0xFFF8;
+			if (q <= 16) a = ration_low_bits(a, n15, nx7, 0xFFF8);
+			else if ((a & 7) < 7) a &= 0xFFF8;
 			a = -a;
 		}
 		else if (a == 8 && j < H - 1 && p[at + 1] == -7) p[at + 1] = -8;
@@ -416,27 +427,27 @@ DEV void dequant_sim_luma_par(Ctx *c, int part, int tid, int *pos)
 		}
 		BARRIER();
 	}
-	{                                                  /* :2759-2853 (wavefront) */
+	if (q > 16) {                                      /* :2759-2853 (wavefront) */
 		MarkRunsStep st = { p, jp };
 		wavefront_rows(H - 1, tid, pos, st);
 	}
 	BARRIER();
 	{
 		const int r = tid, col0 = r < H / 2 ? H / 2 : 0;
-		if (!part) mark_pairs_row(p, r, col0);           /* :2857-2905 (R) */
-		dequant_row(p, jp, r, col0, part);               /* :2909-3124 (R) */
+		if (!part && q > 16) mark_pairs_row(p, r, col0); /* :2857-2905 (R) */
+		dequant_row(p, jp, r, col0, part, q);            /* :2909-3124 (R) */
 	}
 	BARRIER();
-	if (!part) {                                       /* :3154-3188 */
-		const int r = tid;
+	if (!part) {                                       /* :3135-3188; q<=16 lets diagonal neighbours up to 15 pass */
+		const int r = tid, diag = q <= 16 ? 16 : 8;
 		uint32_t hit[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 		if (r >= 1 && r < H - 1)
 			for (int j = 1; j < H - 1; j++) {
 				const int e = r * W + j;
 				if (iabs(jp[e]) >= 8 && (r >= H / 2 || j >= H / 2)) {
-					if (iabs(jp[e - W - 1]) >= 8 || iabs(jp[e - W]) >= 8 || iabs(jp[e - W + 1]) >= 8 ||
+					if (iabs(jp[e - W - 1]) >= diag || iabs(jp[e - W]) >= 8 || iabs(jp[e - W + 1]) >= diag ||
 					    iabs(jp[e - 1]) >= 8 || iabs(jp[e + 1]) >= 8 ||
-					    iabs(jp[e + W - 1]) >= 8 || iabs(jp[e + W]) >= 8 || iabs(jp[e + W + 1]) >= 8) continue;
+					    iabs(jp[e + W - 1]) >= diag || iabs(jp[e + W]) >= 8 || iabs(jp[e + W + 1]) >= diag) continue;
 					hit[j >> 5] |= 1u << (j & 31);
 				}
 			}
@@ -530,7 +541,7 @@ DEV void tag_small_runs_par(Ctx *c, int tid, int16_t *lds)
  * wavefront the chain itself was most of the divergent instruction stream. */
 enum { CK_NONE, CK_MARKP, CK_MARKN, CK_S12100, CK_S12500, CK_S12200, CK_S12600, CK_INC, CK_DEC, CK_Q18P_NEXT, CK_Q18P_CELL, CK_Q18P_COPY,
        CK_Q18N_NEXT, CK_Q18N_CELL, CK_Q18N_COPY, CK_NBP, CK_NBN, CK_PREVGE0, CK_PREVLE0, CK_C14500, CK_NUP, CK_NM2, CK_NM3, CK_LARGE };
-#define CK_TABLE_BYTES (16 * 9 * 12)
+#define CK_TABLE_BYTES (17 * 9 * 12)
 DEV int classify_kind(int q, int res_setting, int res, int a, int d2)
 {
 	if (res == 2 && a == 2 && d2 >= 2) return (d2 < 5 || d2 > 6) ? CK_MARKP : CK_NONE;
@@ -570,18 +581,18 @@ DEV int classify_kind(int q, int res_setting, int res, int a, int d2)
 	if (res < -res_setting) return CK_LARGE;
 	return CK_NONE;
 }
-/* value classes: residual <= -8, -7 .. 6, >= 7; next residual -5 .. -2, 2 .. 5, anything else; third <= -4, -3 .. 6, >= 7 */
+/* value classes: residual <= -9, -8 .. 6, >= 7 (the chain compares it with -7 and with -res_setting >= -8); next residual -5 .. -2, 2 .. 5, anything else; third <= -4, -3 .. 6, >= 7 */
 DEV void classify_table_fill(uint8_t *tab, int q, int res_setting, int tid)
 {
 	for (int idx = tid; idx < CK_TABLE_BYTES; idx += NT) {
 		const int rc = idx / (9 * 12), ac = (idx / 12) % 9, dc = idx % 12;
 		const int a = ac < 4 ? ac - 5 : (ac < 8 ? ac - 2 : 0);
-		tab[idx] = (uint8_t)classify_kind(q, res_setting, rc - 8, a, dc - 4);
+		tab[idx] = (uint8_t)classify_kind(q, res_setting, rc - 9, a, dc - 4);
 	}
 }
 DEV int classify_lookup(const uint8_t *tab, int res, int a, int d2)
 {
-	const int rc = (res < -8 ? -8 : (res > 7 ? 7 : res)) + 8, dc = (d2 < -4 ? -4 : (d2 > 7 ? 7 : d2)) + 4;
+	const int rc = (res < -9 ? -9 : (res > 7 ? 7 : res)) + 9, dc = (d2 < -4 ? -4 : (d2 > 7 ? 7 : d2)) + 4;
 	const int ac = (a >= -5 && a <= 5) ? (int)((0x76548883210ull >> (4 * (a + 5))) & 15) : 8;
 	return tab[(rc * 9 + ac) * 12 + dc];
 }
@@ -1027,6 +1038,130 @@ struct QuantCodeF {                                           /* image_processin
 		return j;
 	}
 };
+/* ---- quality 1..16 (image_processing.c:357-410, :427-510) ----
+ * Two things change in the main loop.  (1) The low bits of negative magnitudes are rationed per row (ration_low_bits): local to a row.
+ * (2) `quant4`: of the pairs of neighbours that both sit on x6/x7 (>= 14) in a detail band, every third one -- counted through the WHOLE
+ * plane in raster order -- is pushed apart by 2 so that one of them reaches the next step.  A push changes the right-hand cell, which
+ * thereby stops being a candidate itself, so how many candidates a row counts depends on the counter it is entered with; and the
+ * right-hand cell of a pair that starts in column 511 is the first cell of the next row.  A row is therefore summarised by a map
+ * (counter, "my first cell was pushed") -> (counter, push handed to the next row): six entries, found by a dry walk that only reads;
+ * the 512 maps are chained by one thread, and the real walk starts every row from its true entry state.  (The veto by a negative left
+ * neighbour, :438-447, can never hold: the left neighbour has already been replaced by its code, which is >= 0.) */
+DEV bool q4_cand(int a, int nx) { return a >= 14 && nx >= 14 && (a & 6) == 6 && (nx & 6) == 6 && ((a | nx) & 1); }
+DEV bool q4_veto(int v) { return (v < -2 && v > -8) || (v < -7 && ((-v) & 7) >= 6); }
+/* what the pair (a, nx) does when its turn has come: 0 nothing, -2 / +2 = the change of nx (a -2 comes with a += 2) */
+DEV int q4_push(int a, int nx, int col, int right2)
+{
+	const bool left = (a & 504) == (nx & 504) ? a >= nx : a <= nx;
+	if (left) return -2;
+	const bool veto_r = col > 0 && col < W - 2 && q4_veto(right2);
+	return veto_r ? 0 : 2;
+}
+struct QuantTurnDryF {
+	const int16_t *plane; int rs, row0; uint32_t *maps;         /* maps[row]: 4 bits per entry state e = turn * 2 + pushed (packed at the end of run) */
+	struct State { int next_first; uint8_t turn[6], kill[6]; int8_t carry[6]; };
+	__device__ State init(int t) const
+	{
+		State st;
+		st.next_first = plane[(size_t)(t + 1) * rs];
+		for (int e = 0; e < 6; e++) { st.turn[e] = (uint8_t)(e >> 1); st.kill[e] = (uint8_t)(e & 1); st.carry[e] = 0; }
+		return st;
+	}
+	__device__ int run(int16_t *row, int t, int j, int j1, State &st) const
+	{
+		const int r = row0 + t;
+		for (; j < j1; j++) {
+			const bool detail = r >= H || j >= H;
+			const int a = row[j], nx = j < W - 1 ? row[j + 1] : st.next_first;
+			const bool cand = detail && a <= 127 && q4_cand(a, nx);
+			if (!cand) { for (int e = 0; e < 6; e++) st.kill[e] = 0; continue; }
+			const int push = q4_push(a, nx, j, row[j + 2]);
+			for (int e = 0; e < 6; e++) {
+				int k = 0;
+				if (!st.kill[e]) {
+					if (!st.turn[e]) { k = push != 0; if (j == W - 1) st.carry[e] = (int8_t)push; }
+					st.turn[e] = st.turn[e] == 2 ? 0 : st.turn[e] + 1;
+				}
+				st.kill[e] = (uint8_t)k;
+			}
+		}
+		if (j1 == W) {                                          /* row finished: file the map (4 bits per entry: exit turn, carry code 0 / 1 = -2 / 2 = +2) */
+			uint32_t mword = 0;
+			for (int e = 0; e < 6; e++) mword |= (uint32_t)(st.turn[e] | ((st.carry[e] < 0 ? 1 : st.carry[e] > 0 ? 2 : 0) << 2)) << (4 * e);
+			maps[r] = mword;
+		}
+		return j;
+	}
+};
+struct QuantCodeLowF {                                        /* image_processing.c:314-519, q <= 16 */
+	const int16_t *plane; int rs, row0; const uint8_t *entry;    /* entry[row] = turn | carry code << 2 */
+	struct State { int next_first, n15, nx7, turn, delta; };
+	__device__ State init(int t) const
+	{
+		const int e = entry[row0 + t];
+		return State{ plane[(size_t)(t + 1) * rs], 0, 0, e & 3, (e >> 2) == 1 ? -2 : (e >> 2) == 2 ? 2 : 0 };
+	}
+	__device__ int run(int16_t *row, int t, int j, int j1, State &st) const
+	{
+		const int r = row0 + t;
+		if (j == 0 && st.delta) row[0] = (int16_t)(row[0] + st.delta);   /* the push the row above handed down */
+		for (; j < j1; j++) {
+			int a = row[j];
+			const int nx = j < W - 1 ? row[j + 1] : st.next_first;
+			if (a > 127) { row[j] = (int16_t)big_code(a, k_big_pos); continue; }
+			else if (a < -127) { row[j] = (int16_t)big_code(-a, k_big_neg); continue; }
+			if (a < -12 && ((-a) & 7) == 6) { if (j < W - 1 && nx == -7) row[j + 1] = -9; }
+			if (a < 0) {
+				if (a == -7 && nx == 8 && j < W - 1) { row[j] = -8; a = -8; }
+				a = -a;
+				if (a > 14 && (a & 7) == 7 && nx > 0 && nx < 8) a -= 2;
+				a = ration_low_bits(a, st.n15, st.nx7, 504);
+				a = -a;
+			}
+			else if (a == 8 && nx == -7 && j < W - 1) row[j + 1] = -8;
+			else if (a > 12 && (a & 7) >= 6) { if (j < W - 1 && nx == 7) row[j + 1] = 9; }
+			if ((r >= H || j >= H) && q4_cand(a, nx)) {
+				if (!st.turn) {
+					const int push = q4_push(a, nx, j, row[j + 2]);
+					if (push < 0) a += 2;
+					if (push && j < W - 1) row[j + 1] = (int16_t)(nx + push);   /* column 511: the next row applies it (its entry state) */
+				}
+				st.turn = st.turn == 2 ? 0 : st.turn + 1;
+			}
+			if (a < DEADZONE && a > -DEADZONE) row[j] = 128;
+			else row[j] = (int16_t)((a + 128) & 248);
+		}
+		return j;
+	}
+};
+DEV void quantise_luma_low_par(Ctx *c, int tid, uint32_t *maps /* shared, 512 words */, uint8_t *entry /* shared, 512 bytes */, int16_t *lds)
+{
+	int16_t *p = c->proc;
+	row_pass_tiled(p, W, W, H, 0, H, H, W, lds, tid, QuantPairsF{});               /* :195-238, rows 0..255: detail columns only */
+	row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, QuantPairsF{});       /* rows 256..511 */
+	{
+		QuantTurnDryF d0 = { p, W, 0, maps }, d1 = { p + H * W, W, H, maps };
+		row_pass_tiled(p, W, W, H, 0, H, 0, W, lds, tid, d0);
+		row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, d1);
+	}
+	BARRIER();
+	if (tid == 0) {
+		int turn = 0, carry = 0;
+		for (int r = 0; r < W; r++) {
+			entry[r] = (uint8_t)(turn | (carry << 2));
+			const uint32_t mword = maps[r];
+			const int e = (int)(mword >> (4 * (turn * 2 + (carry != 0)))) & 15;
+			turn = e & 3; carry = e >> 2;
+		}
+	}
+	BARRIER();
+	{
+		QuantCodeLowF f0 = { p, W, 0, entry }, f1 = { p + H * W, W, H, entry };
+		row_pass_tiled(p, W, W, H, 0, H, 0, W, lds, tid, f0);
+		row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, f1);
+	}
+}
+
 /* offsetY.  Loops 1, 3, 4 reach at most two cells ahead in their own row: tiled row passes.  Loop 2 marks cells of
  * the next row: skewed wavefront. */
 DEV void quantise_luma_par(Ctx *c, int tid, int *pos, int16_t *lds)
@@ -1362,7 +1497,8 @@ DEV void dequant_sim_chroma_par(Ctx *c, int comp, int tid)
 	int16_t *p = c->cproc, *jp = c->cjpeg;
 	for (int idx = tid; idx < (H / 4) * (H / 4); idx += NT) {
 		const int r = idx >> 6, j = idx & 63, i = r * H + j;
-		if (comp) {
+		if (comp && c->q <= 15) jp[i] = (int16_t)((p[i] & 0xFFFC) + 1);   /* :3221-3230: two low bits dropped, midpoint */
+		else if (comp) {
 			if (j & 1) continue;
 			if (r == 0) { jp[i] = p[i]; jp[i + 1] = clear_bit0(p[i + 1]); }
 			else { jp[i] = clear_bit0(p[i]); jp[i + 1] = p[i + 1]; }
@@ -1660,7 +1796,7 @@ DEV unsigned block_exscan_max(unsigned v, int tid, unsigned *shm /* [NT / 64 + 1
  * sample the walk visits next; OUT: the token's bytes after the marker strip of :828-866 (a single stays, a
  * (64, x, y) triple keeps x y, a (128, a, b) verbatim record keeps b), and whether it is a verbatim record */
 template <bool OUT>
-DEV int ll_luma_token(const uint8_t *s, int i, int n, int mode, int *nb, int *b0, int *b1, int *verb)
+DEV int ll_luma_token(const uint8_t *s, int i, int n, int mode, int *nb, int *b0, int *b1, int *verb, bool low /* q <= 15: an escape is (128, halved sample i), nothing verbatim, and the walk moves one sample (:573-577, :857-861) */)
 {
 	const int d0 = s[i] - s[i - 1], d1 = s[i + 1] - s[i];
 	int kind = 2, byte = 0, t0 = 0, t1 = 0, t2 = 0, next;           /* kind 0: one byte, 1: triple, 2: verbatim */
@@ -1699,13 +1835,13 @@ DEV int ll_luma_token(const uint8_t *s, int i, int n, int mode, int *nb, int *b0
 		}
 		else if (iabs(d0) <= 32 && iabs(d1) <= 16 && d2ok) { kind = 1; t0 = d0 + 32; t1 = d1 + 16; t2 = d2 + 32; }   /* :600-630 */
 		if (kind == 1 && (t0 == 64 || t1 == 32 || t2 == 64)) kind = 2;
-		next = kind == 1 ? i + 3 : i + 2;
+		next = kind == 1 ? i + 3 : (kind == 2 && low ? i + 1 : i + 2);
 	}
 	if (OUT) {
-		*verb = kind == 2;
+		*verb = kind == 2 && !low;
 		if (kind == 0) { *nb = 1; *b0 = byte; }
 		else if (kind == 1) { t1 >>= 1; *nb = 2; *b0 = 64 + t0 + (t1 >> 3); *b1 = ((t1 & 7) << 5) + (t2 >> 1); }
-		else { *nb = 1; *b0 = 128 + (s[i + 1] >> 1); }
+		else { *nb = 1; *b0 = 128 + (s[low ? i : i + 1] >> 1); }
 	}
 	return next;
 }
@@ -1762,7 +1898,8 @@ DEV void ll_code_luma_par(Ctx *c, int tid, uint8_t *lds /* LL_LDS_BYTES, the sam
 	const int mode = runs16 > 299 ? 2 : (runs8 > 179 ? 1 : 0);       /* :506-508 */
 	BARRIER();
 
-	for (int i = tid; i < n; i += NT) X[LLX(i)] = i ? (uint8_t)(ll_luma_token<false>(s, i, n, mode, nullptr, nullptr, nullptr, nullptr) - i) : 1;
+	const bool low = c->q <= 15;
+	for (int i = tid; i < n; i += NT) X[LLX(i)] = i ? (uint8_t)(ll_luma_token<false>(s, i, n, mode, nullptr, nullptr, nullptr, nullptr, low) - i) : 1;
 	entry[tid] = -1;
 	BARRIER();
 	{                                                            /* (1) where the walk leaves my block, from each of its samples */
@@ -1780,7 +1917,7 @@ DEV void ll_code_luma_par(Ctx *c, int tid, uint8_t *lds /* LL_LDS_BYTES, the sam
 	if (e0 >= 0)
 		for (int i = e0; i < end;) {
 			int nb, b0, b1, verb;
-			i = ll_luma_token<true>(s, i, n, mode, &nb, &b0, &b1, &verb);
+			i = ll_luma_token<true>(s, i, n, mode, &nb, &b0, &b1, &verb, low);
 			cnt += (unsigned)nb + ((unsigned)verb << 16);
 		}
 	unsigned total;
@@ -1791,7 +1928,7 @@ DEV void ll_code_luma_par(Ctx *c, int tid, uint8_t *lds /* LL_LDS_BYTES, the sam
 		for (int i = e0; i < end;) {
 			int nb, b0, b1, verb;
 			const int at = i;
-			i = ll_luma_token<true>(s, i, n, mode, &nb, &b0, &b1, &verb);
+			i = ll_luma_token<true>(s, i, n, mode, &nb, &b0, &b1, &verb, low);
 			*o++ = (uint8_t)b0;
 			if (nb == 2) *o++ = (uint8_t)b1;
 			if (verb) { c->ll_word[m] = c->ll_full[at]; c->ll_mem[m] = (uint16_t)at; m++; }
@@ -1944,6 +2081,126 @@ DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc, int16_t *lds)
 	BARRIER();
 	if (!tid) PROF(c, 6);
 }
+/* ---------------------------------------------------------------- Y20 for q <= 15 (nhw_encoder.c:804-968) */
+/* zeroing rule shared by the three bands at q <= 13: a small coefficient goes when its level-2 parent is small, or together with a
+ * neighbour when the pair nearly cancels (:875-886 etc.).  lv: the value the walk finds on the left (for the first cell of a row of the
+ * lower bands that is the last cell of the row above, which belongs to another thread: handed in, and a write to it handed back) */
+DEV void thin_by_parent(int16_t *v, int lv, int parent, int lim_parent, int lim_pair, bool *zero_left)
+{
+	if (iabs(parent) < lim_parent) v[0] = 0;
+	else if (iabs(v[0] + lv) < lim_pair && iabs(v[1]) < lim_pair) { v[0] = 0; *zero_left = true; }
+	else if (iabs(v[0] + v[1]) < lim_pair && iabs(lv) < lim_pair) { v[0] = 0; v[1] = 0; }
+}
+DEV int16_t keep_loud(int v, int q) { return q > 10 ? (int16_t)(v >= 16 ? 7 : v <= -16 ? -7 : 0) : (int16_t)0; }   /* :947-953 */
+struct ThinT { int t1, t2, t3, t4, t5; };
+/* one row of the lower bands (rows 256..511): columns 0..255, then 256..510 (:898-967).  left0: value of the cell before the row. */
+DEV bool thin_lower_row(int16_t *row, int rr /* row - 256 */, const int16_t *par, const ThinT &t, int q, int left0)
+{
+	bool zl0 = false;
+	for (int j = 0; j < H; j++) {
+		int16_t *v = row + j;
+		int lv = j ? v[-1] : left0;
+		bool zl = false;
+		if (iabs(*v) >= DEADZONE && iabs(*v) < t.t1 + 2) thin_by_parent(v, lv, par[((rr * H + j) >> 1) + Q / 2], t.t4, t.t5, &zl);
+		if (zl) { if (j) v[-1] = 0; else zl0 = true; lv = 0; }
+		if (iabs(*v) >= DEADZONE && iabs(*v) < t.t1) {
+			if (iabs(lv) < DEADZONE && iabs(v[1]) < DEADZONE) *v = 0;
+			else if (iabs(*v) < t.t1 - 4) *v = 0;
+		}
+	}
+	for (int j = H; j < W - 1; j++) {
+		int16_t *v = row + j;
+		bool zl = false;
+		if (iabs(*v) >= DEADZONE && iabs(*v) < t.t2 + 1) thin_by_parent(v, v[-1], par[((rr * H + (j - H)) >> 1) + Q / 2 + H / 2], t.t4 + 1, t.t5, &zl);
+		if (zl) v[-1] = 0;
+		if (iabs(*v) >= DEADZONE && iabs(*v) < t.t2) {
+			if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = keep_loud(*v, q);
+			else if (iabs(*v) < t.t2 - 5) *v = keep_loud(*v, q);
+		}
+	}
+	return zl0;
+}
+DEV void thin_l1_low_par(Ctx *c, int tid, int *sh /* shared, >= 2 * NT + 2 ints */)
+{
+	int16_t *p = c->proc;
+	const int16_t *par = c->l2save;
+	const int q = c->q;
+	if (q >= 14) {                                               /* :804-832, pointwise */
+		const int t2 = q == 15 ? 19 : 20;
+		for (int idx = tid; idx < 2 * Q; idx += NT) {
+			int16_t *v = p + 2 * Q + idx;
+			const int col = idx & (W - 1), m = iabs(*v);
+			if (m < DEADZONE) continue;
+			if (col < H) { if (m < 11) *v = 0; }
+			else if (m < t2) *v = (int16_t)(*v >= 14 ? 7 : *v <= -14 ? -7 : 0);
+		}
+		BARRIER();
+		return;
+	}
+	ThinT t;
+	if (q == 13) t = ThinT{ 15, 27, 10, 6, 3 };
+	else {                                                       /* thresholds follow the number of loud coefficients of the lower bands (:836-868) */
+		unsigned loud = 0;
+		for (int idx = tid; idx < 2 * Q / 8; idx += NT) {
+			const uint4 w = reinterpret_cast<const uint4 *>(p + 2 * Q)[idx];
+			const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+			for (int e = 0; e < 4; e++) { loud += iabs((int16_t)(ww[e] & 0xFFFF)) >= 12; loud += iabs((int16_t)(ww[e] >> 16)) >= 12; }
+		}
+		{ unsigned total; block_exscan(loud, tid, reinterpret_cast<unsigned *>(sh), &total); loud = total; BARRIER(); }
+		t = ThinT{ 16, 28, 11, 8, 5 };
+		if (loud > 12500) t = ThinT{ 19, 31, 13, 9, 6 };
+		else if (loud > 10000) t = ThinT{ 18, 30, 12, 8, 6 };
+		else if (loud >= 7000) t = ThinT{ 17, 29, 11, 8, 5 };
+		if (q == 11) { if (loud > 12500) { t.t1++; t.t2++; t.t3++; t.t4++; t.t5++; } else t.t1++; }
+		else if (q <= 10) {
+			if (loud > 12500) { t.t1 += 3; t.t2 += 3; t.t3 += 2; t.t4 += 3; t.t5 += 3; }
+			else { t.t1 += 3; t.t2 += 2; t.t3 += 2; t.t4 += 2; t.t5 += 2; }
+		}
+	}
+	{                                                            /* rows 0..255, columns 256..511 (:871-896): a thread per row; the cell a row reaches in the next
+		                                                            row (column 0) is read or written by no other row of this walk */
+		const int r = tid;
+		int16_t *row = p + (size_t)r * W;
+		for (int j = H; j < W; j++) {
+			int16_t *v = row + j;
+			bool zl = false;
+			if (iabs(*v) >= DEADZONE && iabs(*v) < t.t3 + 2) thin_by_parent(v, v[-1], par[((r * H + (j - H)) >> 1) + H / 2], t.t4, t.t5, &zl);
+			if (zl) v[-1] = 0;
+			if (iabs(*v) >= DEADZONE && iabs(*v) < t.t3) { if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = 0; }
+		}
+	}
+	BARRIER();
+	/* rows 256..511: the first cell of a row looks at (and may zero) the last cell of the row above, which that row may have zeroed in
+	 * its own last step: the only link between rows.  Every row is walked at once on the assumption that the cell above kept its value;
+	 * a row whose assumption turns out wrong is restored from a copy and walked again, until nothing changes (usually no second round).
+	 * The zeroing of the cell above is applied at the end: the row above reads that cell before this row would have written it. */
+	int16_t *copy = c->jpeg;                                     /* free here: the reference has released im_jpeg (:781) */
+	for (int idx = tid; idx < 2 * Q / 8; idx += NT) reinterpret_cast<uint4 *>(copy + 2 * Q)[idx] = reinterpret_cast<const uint4 *>(p + 2 * Q)[idx];
+	int *zl_flag = sh;                                           /* [NT] */
+	BARRIER();
+	{
+		const int r = H + tid;
+		int16_t *row = p + (size_t)r * W;
+		const int above_orig = tid ? copy[(size_t)r * W - 1] : p[(size_t)r * W - 1];
+		int used = above_orig;
+		zl_flag[tid] = thin_lower_row(row, tid, par, t, q, used);
+		for (;;) {
+			BARRIER();
+			const int now = tid ? p[(size_t)r * W - 1] : above_orig;       /* what the row above left in its last cell */
+			const bool redo = now != used;
+			if (!__syncthreads_or(redo)) break;
+			if (redo) {
+				for (int j = 0; j < W; j += 8) *reinterpret_cast<uint4 *>(row + j) = *reinterpret_cast<const uint4 *>(copy + (size_t)r * W + j);
+				used = now;
+				zl_flag[tid] = thin_lower_row(row, tid, par, t, q, used);
+			}
+		}
+		BARRIER();
+		if (zl_flag[tid]) p[(size_t)r * W - 1] = 0;
+	}
+	BARRIER();
+}
+
 /* Y19..Y31 run as four kernels (a: Y19-Y23, b: Y24-Y25, c: Y26-Y29, d: Y30-Y31) so that each gets the register
  * and LDS budget of its own passes: one kernel for all of them ran at 4 waves/SIMD. */
 DEV void luma_p4a_par(Ctx *c, int tid, int16_t *lds)
@@ -1951,7 +2208,8 @@ DEV void luma_p4a_par(Ctx *c, int tid, int16_t *lds)
 	const int q = c->q;
 	PROF_BEGIN();
 	if (q > 21) copy_block_par(c->jpeg, W, c->first_order, H, H, H, tid);   /* Y19 :766-777 */
-	if (q < 20) {                                                           /* Y20 (:783-801) */
+	if (q <= 15) thin_l1_low_par(c, tid, reinterpret_cast<int *>(lds));     /* Y20 (:804-968) */
+	else if (q < 20) {                                                      /* Y20 (:783-801) */
 		int16_t *p = c->proc;
 		for (int idx = tid; idx < 2 * Q; idx += NT) {
 			int16_t *v = p + 2 * Q + idx;
@@ -1961,10 +2219,11 @@ DEV void luma_p4a_par(Ctx *c, int tid, int16_t *lds)
 	}
 	BARRIER();
 	if (!tid) PROF(c, 8);
-	tag_small_runs_par(c, tid, lds);                                        /* Y21 */
+	if (q > 16) tag_small_runs_par(c, tid, lds);                            /* Y21 (:970) */
 	BARRIER();
 	if (!tid) PROF(c, 9);
-	const int res_setting = q >= 20 ? 3 : (q >= 18 ? 4 : 6);
+	if (q <= 12) return;                                                    /* no second closed loop, no residual lists (:1081, :1498) */
+	const int res_setting = q >= 20 ? 3 : q >= 18 ? 4 : q >= 15 ? 6 : 8;    /* :1075-1079 */
 	classify_residuals_par(c, res_setting, tid, lds);                       /* Y22 */
 	if (!tid) PROF(c, 10);
 	code_residuals_par(c, res_setting, tid, lds);                           /* Y23 */
@@ -2131,6 +2390,25 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 	copy_block_par(c->cl2save, H / 2, p, H, H / 2, H / 2, tid);    /* :2431-2439 */
 	for (int idx = tid; idx < (H / 4) * (H / 4); idx += NT) lds[idx] = c->cl2save[(idx >> 6) * (H / 2) + (idx & 63)];   /* the LL2 band for the emission below */
 	BARRIER();
+	if (q <= 11 && tid == 0) {
+		/* chroma LL2 smoothing (:2438-2478, :2739-2779): two raster walks that write the cell diagonally below and read it again; 64 x 64
+		 * cells.  Only the emission reads the band afterwards (it clears it), so the walks run on the LDS copy. */
+		const int L = H / 4;
+		for (int pass = 0; pass < 2; pass++)
+			for (int r = 0; r < L - 2; r++)
+				for (int j = 0; j < L - 2; j++) {
+					int16_t *v = lds + r * L + j;
+					if (!pass) {
+						if (iabs(v[1] - v[2 * L + 1]) < 5 && iabs(v[L] - v[L + 2]) < 5 && iabs(v[L + 1] - v[L]) < 7 && iabs(v[1] - v[L + 1]) < 8)
+							v[L + 1] = (int16_t)((v[1] + v[2 * L + 1] + v[L] + v[L + 2] + 2) >> 2);
+					} else {
+						if (iabs(v[2] - v[1]) < 5 && iabs(v[1] - v[0]) < 5 && iabs(v[0] - v[L]) < 5 && iabs(v[2] - v[L + 2]) < 5 &&
+						    iabs(v[2 * L + 1] - v[L]) < 5 && iabs(v[L] - v[L + 1]) < 8)
+							v[L + 1] = (int16_t)((v[1] + v[2 * L + 1] + v[L] + v[L + 2] + 1) >> 2);
+					}
+				}
+	}
+	BARRIER();
 	if (!tid) PROF(c, 28);
 	{                                                              /* :2489-2525 LL2 emission, 16 consecutive samples per thread */
 		/* a sample outside 0..255 goes to the exception list (row, column | sign, magnitude) and repeats the byte
@@ -2199,6 +2477,11 @@ struct PackShared {
 	unsigned bits[NT], n1[NT], n2[NT];
 	int k, select, zone, top_is_zero, rc;
 	unsigned total_bits, total_n1, total_n2;
+	/* the reference's `codebook[580]` scratch is ONE stack array for both parts and is never cleared (compress_pixel.c:58): when the
+	 * chroma table ends in a run of 128s the collapse at :442-456 reads on into what the luma part left there (its de-interleaved
+	 * table; behind that, zeros in the canonical model) */
+	uint8_t stale_book[720];
+	int stale_len;
 };
 
 DEV bool book_ok(int v) { return v < 109 ? !(v & 1) : (v == 112 || (v >= 120 && v < 141) || (v >= 144 && !(v & 3))); }
@@ -2447,6 +2730,8 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 			for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = book[i];
 			for (i = 1; i < e; i += 2) tmp_book[b++] = book[i];
 			tmp_book[e] = 0;
+			for (i = 0; i < e; i++) sh->stale_book[i] = tmp_book[i];
+			sh->stale_len = e;
 			for (i = 0, w = 0, b = 0; i < e; i++) {
 				while (tmp_book[i] == 3) { b++; i++; }
 				if (b > 0) { book[w++] = 3; book[w++] = (uint8_t)b; b = 0; i--; }
@@ -2465,7 +2750,8 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 		c->m->tree_end = e;
 		for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = book[i];
 		for (i = 1; i < e; i += 2) tmp_book[b++] = book[i];
-		tmp_book[e] = 0;
+		for (i = e; i < sh->stale_len; i++) tmp_book[i] = sh->stale_book[i];
+		tmp_book[e > sh->stale_len ? e : sh->stale_len] = 0;
 		for (i = 0, w = 0, b = 0; i < e; i++) {
 			while (tmp_book[i] == 128) { b++; i++; }
 			if (b > 0) { book[w++] = 128; book[w++] = (uint8_t)b; b = 0; i--; }

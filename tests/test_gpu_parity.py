@@ -157,7 +157,7 @@ def test_fused_front_matches_oracle(oracle, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [17, 18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("q", list(range(1, 24)))
 def test_whole_encoder_bit_exact_vs_oracle(enc, oracle, q):
     """The .nhw bytes of a mixed batch (synthetic seeds + every robustness class) equal the oracle's."""
     imgs = [oracle.synth(s) for s in (0, 7, 31)] + [class_image(k, 0) for k in ("noise", "blocks", "flat", "gradient", "black", "white")]
@@ -207,8 +207,9 @@ def test_device_generator_matches_definition(enc, oracle):
 @pytest.mark.gpu
 def test_unsupported_quality_fails_loudly(enc, oracle):
     import nhwcodec_amd
-    with pytest.raises(nhwcodec_amd.NhwError):
-        enc.encode(np.stack([oracle.synth(0)]), 10)
+    for q in (0, 24, -1):     # -q0 is accepted by the reference CLI but has no tables downstream
+        with pytest.raises(nhwcodec_amd.NhwError):
+            enc.encode(np.stack([oracle.synth(0)]), q)
 
 
 @pytest.mark.gpu
@@ -322,7 +323,7 @@ def test_sub_batches_on_streams_match_oracle(oracle, n, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [17, 18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("q", list(range(1, 24)))
 def test_many_seeds_bit_exact(oracle, q):
     """40 more synthetic images per quality (seeds far from the ones used elsewhere), bit-exact against the oracle."""
     import torch
@@ -340,7 +341,7 @@ def test_many_seeds_bit_exact(oracle, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [17, 19, 20, 22, 23])
+@pytest.mark.parametrize("q", [1, 4, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 20, 22, 23])
 def test_robustness_classes_more_seeds(enc, oracle, q):
     """White noise and hard-edge rectangles (the worst cases for the order-dependent passes and the packetiser), six seeds each."""
     imgs = [class_image(k, s) for k in ("noise", "blocks") for s in range(1, 7)] + [class_image("tiles", s) for s in range(3)]   # tiles: the LL2 coder's mode 1
@@ -350,9 +351,10 @@ def test_robustness_classes_more_seeds(enc, oracle, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [20, 23])
+@pytest.mark.parametrize("q", [1, 10, 20, 23])
 def test_full_batch_4096_every_image_bit_exact(q):
-    """BASELINE config 2 at its full size, every one of the 4096 outputs against the oracle (oracle side spread over the host cores)"""
+    """BASELINE configs 2 and 3 (-q20; -q1 / -q10 / -q23) at their full size, every one of the 4096 outputs against the oracle (oracle
+    side spread over the host cores)"""
     from tests.gpu_enc_fullcheck import full_encode_check
     bad = full_encode_check(4096, q, 900000 + q)
     assert not bad, f"q{q}: images {bad[:16]} differ from the oracle"
