@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- encode Mpixels/s of the MI355X NHW encoder on batches of synthetic 512x512 RGB images.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
-torch.distributed.run, one rank per GPU.  A "step" = one pass of the whole encode hot path (BGR24 in HBM ->
-.nhw bytes in HBM) over one batch of `--batch` synthetic images per GPU (BASELINE.json configs[1]: 4096 images,
--q20).  Images are independent, so ranks shard the work with no data-path collective (weak scaling); the only
-collectives are the 32-byte work descriptor broadcast and the all-gather of per-rank {bytes, checksum}.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N>1 the driver launches it under
+torch.distributed.run, one rank per GPU; started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) it
+re-executes itself under torch.distributed.run with N ranks, so the documented command works either way and the line always
+says n_gpus = N.  A "step" = one pass of the whole encode hot path (BGR24 in HBM -> .nhw bytes in HBM) over one batch of
+`--batch` synthetic images per GPU (BASELINE.json configs[1]: 4096 images, -q20).  Images are independent, so ranks shard the
+work with no data-path collective; the only collectives are the 32-byte work descriptor broadcast and the all-gather of
+per-rank {bytes, checksum, images ok}.  Default: weak scaling (`--batch` images per GPU).  `--total-images T` (BASELINE
+configs[3]: 65536 over 8 GPUs) cuts ONE job of T images into contiguous per-rank ranges instead (strong scaling).
+`--dry` runs the multi-process plumbing alone on CPU over gloo (tests).
 
 Rank 0 prints ONE JSON line.  `roofline` is measured with HIP events on the launch stream inside the timed
 region; `cpu_baseline` times the reference encoder (oracle/_ref, kind "reference") or, if that build is
@@ -24,9 +28,34 @@ sys.path.insert(0, ROOT)
 MPIX_PER_IMAGE = 0.262144
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 FRONT_BYTES_PER_IMAGE = 786432 + 786432   # 3 B/px read + 3 B/px written (Y coeffs + 2 x chroma)
-# HBM bytes of the front launch group per image from the PMC counters (profiles/round1_final_pmc.json, batch 4096, -q20: FETCH_SIZE x 2 per
-# the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc passes): k_color 3.62+2.68 GB, k_front_rowtail 0.28+0.04, k_front_chain 0.04, k_front_band 2.60+3.22
-FRONT_PMC_BYTES_PER_IMAGE = (3.618e9 + 2.684e9 + 0.276e9 + 0.040e9 + 0.040e9 + 2.600e9 + 3.224e9) / 4096
+FRONT_KERNEL_NAME = "front = k_color + k_front_rowtail + k_front_chain + k_front_band (colour, pre-filter and level-1 analysis; the band kernel fuses pre-filter + both filter directions)"
+PMC_FILE = os.path.join(ROOT, "profiles", "front_pmc.json")     # written by profiles/pmc_summarise.py from separate rocprofv3 --pmc passes
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: ties a committed PMC profile to the code it was taken from"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "nhwcodec_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def front_traffic(q, images):
+    """HBM bytes of the front launch group from the committed PMC file (2 x FETCH_SIZE per the gfx950 note + WRITE_SIZE, per image, batch
+    4096), scaled to this launch -- or None when the file was taken from other kernel sources, another quality, or is absent."""
+    try:
+        with open(PMC_FILE) as fh:
+            d = json.load(fh)
+    except OSError:
+        return None, "no committed PMC file"
+    if d.get("source_hash") != kernel_source_hash():
+        return None, f"profiles/front_pmc.json was taken from other kernel sources ({d.get('source_hash')}, commit {d.get('commit')}); not reused"
+    if d.get("quality") != q:
+        return None, "PMC file is for another quality"
+    return int(d["front_bytes_per_image"] * images), f"PMC: 2 x FETCH_SIZE + WRITE_SIZE over the group's kernels, {d.get('file')}, commit {d.get('commit')}, batch {d.get('batch')}"
 
 
 def _cpu_worker(args):
@@ -104,6 +133,54 @@ def valu_evidence():
     return out or None
 
 
+def physical_cores():
+    """physical cores of the box (distinct (package, core id) pairs of /proc/cpuinfo), or None"""
+    try:
+        seen, pkg, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pkg = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if core is not None:
+                    seen.add((pkg, core))
+                pkg = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def vanilla_xargs_baseline(q, cores, budget_s=8.0):
+    """the reference exactly as its README builds it (`gcc *.c -O3`, oracle/_ref/nhw-enc, no shim), one process per
+    image under `xargs -P cores`, BMPs on tmpfs."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "nhw-enc")
+    if not os.path.exists(exe) or not shutil.which("xargs"):
+        return None
+    from oracle.harness import bmp_bytes
+    from oracle.oraclepy import Oracle
+    orc = Oracle()
+    n = max(cores, min(cores * 6, int(budget_s * cores / 0.035)))
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=base) as td:
+        for i in range(n):
+            with open(os.path.join(td, f"{i}.bmp"), "wb") as fh:
+                fh.write(bmp_bytes(orc.synth(i)))
+        names = "\n".join(str(i) for i in range(n))
+        t0 = time.perf_counter()
+        subprocess.run(["xargs", "-P", str(cores), "-I", "{}", exe, f"-q{q}", os.path.join(td, "{}.bmp"), os.path.join(td, "{}.nhw")],
+                       input=names.encode(), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+        wall = time.perf_counter() - t0
+        done = sum(os.path.exists(os.path.join(td, f"{i}.nhw")) for i in range(n))
+    if not done:
+        return None
+    return {"value": round(done * MPIX_PER_IMAGE / wall, 2), "unit": "Mpixels/s", "images": done, "wall_s": round(wall, 2),
+            "how": f"stock `gcc -O3` nhw-enc -q{q}, one process per image, xargs -P {cores}, BMP files on tmpfs (process start and file I/O included)"}
+
+
 def cpu_baseline(q, budget_s=12.0):
     """Reference encoder on the host cores, bounded sample (about `budget_s` seconds of wall time)."""
     import multiprocessing as mp
@@ -111,7 +188,9 @@ def cpu_baseline(q, budget_s=12.0):
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         import subprocess
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    logical = os.cpu_count() or 1
+    phys = physical_cores()
+    cores = max(1, min(phys or logical, 64))        # one worker per PHYSICAL core: SMT siblings would flatter nothing and slow every worker
     per = max(4, int(budget_s / 0.03))          # ~30 ms per image per core
     per = min(per, 400)
     jobs = [(kind, list(range(w * per, (w + 1) * per)), q) for w in range(cores)]
@@ -121,56 +200,48 @@ def cpu_baseline(q, budget_s=12.0):
     wall = time.perf_counter() - t0
     n = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
-    return {"value": round(n * MPIX_PER_IMAGE / busy, 2), "unit": "Mpixels/s", "cores": cores, "kind": kind,
-            "sample": f"{n} synthetic 512x512 images (SURVEY 8d generator, seeds 0..{n - 1}), -q{q}, one in-process encoder per core, "
-                      f"{busy:.1f} s encode time ({wall:.1f} s incl. process start); {'unmodified reference sources + zero-guard allocator' if kind == 'reference' else 'plain-C restatement'}"}
+    one = _cpu_worker((kind, list(range(40)), q))       # the same encoder alone on one core (BASELINE.md's single-core figure)
+    out = {"value": round(n * MPIX_PER_IMAGE / busy, 2), "unit": "Mpixels/s", "cores": cores, "kind": kind,
+           "physical_cores": phys, "logical_cpus": logical,
+           "one_core": {"value": round(one[0] * MPIX_PER_IMAGE / one[1], 2), "unit": "Mpixels/s", "ms_per_image": round(one[1] / one[0] * 1e3, 2)},
+           "sample": f"{n} synthetic 512x512 images (SURVEY 8d generator, seeds 0..{n - 1}), -q{q}, one in-process encoder per physical core, "
+                     f"{busy:.1f} s encode time ({wall:.1f} s incl. process start); {'unmodified reference sources + zero-guard allocator' if kind == 'reference' else 'plain-C restatement'}"}
+    try:
+        v = vanilla_xargs_baseline(q, cores)
+        if v:
+            out["vanilla_xargs"] = v
+    except Exception as ex:     # the baseline is a courtesy figure: never let it take the bench line down
+        out["vanilla_xargs"] = {"error": str(ex)[:200]}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096, help="images per GPU per step")
-    ap.add_argument("--quality", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (BASELINE config 5) reported next to the encode metric")
-    args = ap.parse_args()
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
+
+def timed_steps(enc, bgr, q, out, steps, warmup, dist, dev, max_over_ranks):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; returns (seconds, max over ranks; stage sums)"""
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    import nhwcodec_amd
-    from nhwcodec_amd.dist import broadcast_descriptor, gather_summaries, max_over_ranks
-    # work descriptor {base, count, quality, seed}: rank 0 decides, everyone receives (SURVEY 8e)
-    _, batch, q, seed = broadcast_descriptor(dist, dev, 0, args.batch, args.quality, 1234)
-
-    enc = nhwcodec_amd.Encoder(local_rank, max_batch=batch)
-    bgr = enc.synth_device(batch, seed_base=seed + rank * batch)     # inputs resident in HBM before timing
-    out = enc.alloc_out(batch)
-    torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         enc.encode_device(bgr, q, out)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    front_ms = 0.0
-    color_ms = 0.0
+    front_ms = color_ms = 0.0
     tim = None
-    for _ in range(args.steps):
+    for _ in range(steps):
         enc.encode_device(bgr, q, out)
         tim = enc.timing()          # hipEvents recorded on the launch stream; waits for this step's last event
         front_ms += tim.front_ms
@@ -179,14 +250,100 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = max_over_ranks(dist, dev, dt)
+    dt = max_over_ranks(dist, dev, time.perf_counter() - t0)
+    return dt, front_ms, color_ms, tim
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="images per GPU per step (weak scaling)")
+    ap.add_argument("--total-images", type=int, default=0, help="strong scaling: ONE job of this many images per step, cut into contiguous per-rank ranges (BASELINE configs[3]: 65536 over 8 GPUs)")
+    ap.add_argument("--quality", type=int, default=20)
+    ap.add_argument("--sweep", type=str, default="1,10,23", help="BASELINE configs[2]: quality settings timed after the headline measurement (N=1 only); '' = none")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (BASELINE config 5) reported next to the encode metric")
+    ap.add_argument("--dry", action="store_true", help="CPU only: rendezvous over gloo, descriptor broadcast, sharding, gather -- no encode (tests of the N>1 plumbing)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"launched with {world} ranks but --gpus {args.gpus}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dry:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        assert dist.get_world_size() == args.gpus
+    dev = torch.device("cpu") if args.dry else torch.device("cuda", local_rank)
+    if not args.dry:
+        torch.cuda.set_device(local_rank)
+
+    from nhwcodec_amd.dist import broadcast_descriptor, gather_summaries, max_over_ranks, shard_range
+    # work descriptor {base, count, quality, seed}: rank 0 decides, everyone receives (SURVEY 8e)
+    strong = args.total_images > 0
+    _, count, q, seed = broadcast_descriptor(dist, dev, 0, args.total_images if strong else args.batch, args.quality, 1234)
+    if strong:
+        lo, hi = shard_range(0, count, rank, world)       # this rank's contiguous range of the one job
+        batch, first_seed = hi - lo, seed + lo
+    else:
+        batch, first_seed = count, seed + rank * count
+
+    if args.dry:
+        # the plumbing alone: every rank reports its range; no encode, no timing claim
+        gathered = gather_summaries(dist, dev, batch, first_seed, batch)
+        if dist:
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "encode Mpixels/s (512x512 RGB batch)", "value": None, "unit": "Mpixels/s", "n_gpus": world, "dry": True,
+                              "scaling": "strong" if strong else "weak", "images_per_rank": [int(g[0]) for g in gathered],
+                              "first_seed_per_rank": [int(g[1]) for g in gathered]}), flush=True)
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    import nhwcodec_amd
+    enc = nhwcodec_amd.Encoder(local_rank, max_batch=batch)
+    bgr = enc.synth_device(batch, seed_base=first_seed)              # inputs resident in HBM before timing
+    out = enc.alloc_out(batch)
+    torch.cuda.synchronize()
+
+    dt, front_ms, color_ms, tim = timed_steps(enc, bgr, q, out, args.steps, args.warmup, dist, dev, max_over_ranks)
 
     _, sizes, status = out
     ok = int((status == 0).sum().item())
     nbytes = int(sizes.to(torch.int64).sum().item())
     chk = int((sizes.to(torch.int64) * torch.arange(1, batch + 1, device=dev)).sum().item() % (1 << 61))
     gathered = gather_summaries(dist, dev, nbytes, chk, ok)
+    total_per_step = sum(shard_range(0, count, r, world)[1] - shard_range(0, count, r, world)[0] for r in range(world)) if strong else batch * world
+
+    # BASELINE config 2/3: the other quality settings, each under the same timed contract (barrier + synchronize on both sides), on the
+    # same resident batch.  The rationed settings (q <= 16) take much longer per step, so they get fewer steps; the count is reported.
+    sweep = []
+    if world == 1 and args.sweep:
+        for sq in [int(v) for v in args.sweep.split(",") if v.strip()]:
+            if sq == q:
+                continue
+            k = args.steps if sq > 16 else max(2, args.steps // 5)
+            sdt, _, _, stim = timed_steps(enc, bgr, sq, out, k, 1, None, dev, max_over_ranks)
+            sok = int((out[2] == 0).sum().item())
+            sweep.append({"quality": sq, "steps": k, "warmup": 1, "ms_per_step": round(sdt / k * 1e3, 3), "value": round(batch * k * MPIX_PER_IMAGE / sdt, 2), "unit": "Mpixels/s",
+                          "images_ok": sok, "bytes_out": int(out[1].to(torch.int64).sum().item()),
+                          "stage_ms": {"front": round(stim.front_ms, 3), "luma_tail": round(stim.luma_ms, 3), "entropy+container": round(stim.entropy_ms, 3)}})
+        enc.encode_device(bgr, q, out)      # leave the headline quality's files in the arena for the decode leg
+        torch.cuda.synchronize()
+        sizes, status = out[1], out[2]
 
     # BASELINE config 5 beside the headline metric: the batch just encoded goes back through the decoder, HBM to HBM
     # (the encoder's output arena is the decoder's input arena).  Timed after, and apart from, the encode region.
@@ -216,7 +373,7 @@ def main():
             ddt = max_over_ranks(dist, dev, time.perf_counter() - t1)
         dec_ok = int((dst == 0).sum().item())
         err = (pix[:64].float() - bgr[:64].float()).pow(2).mean().item()
-        dec_line = {"metric": "decode Mpixels/s (512x512 .nhw batch -> BGR24, BASELINE config 5)", "value": round(batch * world * args.steps * MPIX_PER_IMAGE / ddt, 2),
+        dec_line = {"metric": "decode Mpixels/s (512x512 .nhw batch -> BGR24, BASELINE config 5)", "value": round(total_per_step * args.steps * MPIX_PER_IMAGE / ddt, 2),
                     "unit": "Mpixels/s", "ms_per_step": round(ddt / args.steps * 1e3, 3), "files_ok_rank0": dec_ok,
                     "psnr_db_first_64": round(10 * math.log10(255.0 ** 2 / max(err, 1e-9)), 2),
                     "workload": f"the {batch} .nhw files per GPU this run just encoded (-q{q}), decoder arena = encoder arena in HBM",
@@ -239,30 +396,33 @@ def main():
         dec.close()
 
     if rank == 0:
-        total_images = batch * world * args.steps
+        total_images = total_per_step * args.steps
         value = total_images * MPIX_PER_IMAGE / dt
         front_s = front_ms / 1e3 / args.steps
         front_images = tim.front_images or batch      # the batch runs as `parts` sub-batches on their own streams; the events bracket the first one's launch group
         achieved = front_images * FRONT_BYTES_PER_IMAGE / front_s / 1e9
+        traffic, traffic_note = front_traffic(q, front_images)
         line = {
             "metric": "encode Mpixels/s (512x512 RGB batch)", "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": f"batch of {batch} synthetic 512x512 BGR24 images per GPU, -q{q}, whole encoder (BGR in HBM -> .nhw bytes in HBM)",
-                       "images_per_gpu": batch, "quality": q, "parallelism": f"dp{world} (independent images, no data-path collective)"},
-            "roofline": {"bound": "hbm", "kernel": "front = k_color + k_front_rowtail + k_front_chain + k_front_band (colour, pre-filter and level-1 analysis; the band kernel fuses pre-filter + both filter directions)",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "config": {"workload": (f"one job of {count} synthetic 512x512 BGR24 images cut into contiguous ranges over {world} GPU(s)" if strong else
+                                    f"batch of {batch} synthetic 512x512 BGR24 images per GPU") + f", -q{q}, whole encoder (BGR in HBM -> .nhw bytes in HBM)",
+                       "images_per_gpu": batch if not strong else [shard_range(0, count, r, world)[1] - shard_range(0, count, r, world)[0] for r in range(world)],
+                       "images_per_step": total_per_step, "quality": q, "parallelism": f"dp{world} (independent images, no data-path collective)"},
+            "roofline": {"bound": "hbm", "kernel": FRONT_KERNEL_NAME,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": int(front_images * FRONT_PMC_BYTES_PER_IMAGE) if q == 20 else None, "traffic_unit": "bytes per launch group (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1_final_pmc.json, scaled from batch 4096)",
+                         "traffic": traffic, "traffic_unit": "bytes per launch group; " + traffic_note,
                          "kernels": [   # the members of the group, each with its own algorithmic bytes and live hipEvent time
-                             {"kernel": "k_color (BGR24 -> Y int16 + 4:2:0 U,V)", "ms": round(color_ms / args.steps, 3), "algorithmic_bytes": front_images * (786432 + 524288 + 131072),
-                              "achieved": round(front_images * (786432 + 524288 + 131072) / (color_ms / 1e3 / args.steps) / 1e9, 1), "frac": round(front_images * (786432 + 524288 + 131072) / (color_ms / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
-                             {"kernel": "k_front_rowtail + k_front_chain + k_front_band (pre-filter + level-1 analysis)", "ms": round((front_ms - color_ms) / args.steps, 3), "algorithmic_bytes": front_images * (524288 + 786432),
-                              "achieved": round(front_images * (524288 + 786432) / ((front_ms - color_ms) / 1e3 / args.steps) / 1e9, 1), "frac": round(front_images * (524288 + 786432) / ((front_ms - color_ms) / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}],
+                             {"kernel": "first kernel of the group (see `kernel`)", "ms": round(color_ms / args.steps, 3)},
+                             {"kernel": "rest of the group", "ms": round((front_ms - color_ms) / args.steps, 3)}],
                          "algorithmic_bytes_per_launch": front_images * FRONT_BYTES_PER_IMAGE, "images_per_launch": front_images, "sub_batches": tim.parts, "algorithmic_bytes_per_image": FRONT_BYTES_PER_IMAGE, "ms_per_launch_group": round(front_s * 1e3, 3)},
             "stage_ms": {"front": round(tim.front_ms, 3), "luma_tail (chroma sequence alongside, on its own stream)": round(tim.luma_ms, 3), "chroma left over": round(tim.chroma_ms, 3),
                          "entropy+container": round(tim.entropy_ms, 3), "total": round(tim.total_ms, 3)},
             "images_ok": [int(g[2]) for g in gathered], "bytes_out": [int(g[0]) for g in gathered],
         }
+        if sweep:
+            line["sweep"] = sweep
         ev = valu_evidence()
         if ev:
             line["roofline"]["valu_pmc"] = ev

@@ -82,6 +82,14 @@ int nhw_enc_batch(nhw_enc *e, const uint8_t *bgr, int n, int quality, uint8_t *o
 
 /* SURVEY.md section 8d synthetic inputs generated on the device (image i gets seed seed_base+i). */
 int nhw_synth_batch_device(nhw_enc *e, void *d_bgr, int n, uint32_t seed_base, void *stream);
+/* the same images generated on the device, encoded, and the .nhw files brought to the host like nhw_enc_batch does (`nhw-enc --synthetic`) */
+int nhw_enc_synth_batch(nhw_enc *e, int n, uint32_t seed_base, int quality, uint8_t *out_arena, size_t arena_cap, uint64_t *out_off, int32_t *status);
+
+/* page-locked host memory for nhw_enc_batch's input (DMA at PCIe speed, overlapped with the encode of the chunk before), and the number
+ * of GPUs this process sees (one encoder handle per device, e.g. one host thread each: tools/nhw_enc.c --gpus) */
+void *nhw_host_alloc(size_t bytes);
+void  nhw_host_free(void *p);
+int   nhw_device_count(void);
 
 int nhw_enc_last_timing(nhw_enc *e, nhw_timing *t);
 

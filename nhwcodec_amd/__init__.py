@@ -38,6 +38,11 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.nhw_enc_batch.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, ctypes.c_size_t, P, P]
     L.nhw_synth_batch_device.argtypes = [P, P, ctypes.c_int, ctypes.c_uint32, P]
     L.nhw_enc_last_timing.argtypes = [P, ctypes.POINTER(Timing)]
+    L.nhw_enc_synth_batch.argtypes = [P, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, P, ctypes.c_size_t, P, P]
+    L.nhw_host_alloc.restype = P
+    L.nhw_host_alloc.argtypes = [ctypes.c_size_t]
+    L.nhw_host_free.argtypes = [P]
+    L.nhw_device_count.restype = ctypes.c_int
     L.nhw_stage_color.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, P, P, P]
     L.nhw_stage_prefilter.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P]
     L.nhw_stage_analysis.argtypes = [P, P, P, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
@@ -96,11 +101,17 @@ class Encoder:
 
     def encode_device(self, bgr, quality: int = QUALITY_DEFAULT, out=None):
         """bgr: uint8 CUDA tensor [n,512,512,3] (BMP file order).  Returns (out[n,OUT_STRIDE], sizes[n], status[n]) on device."""
+        if not (bgr.is_cuda and bgr.dtype == self.torch.uint8 and bgr.is_contiguous() and bgr.dim() == 4 and tuple(bgr.shape[1:]) == (512, 512, 3)):
+            raise NhwError("encode_device wants a contiguous uint8 CUDA tensor of shape [n, 512, 512, 3]")
+        if bgr.device.index != self.device:
+            raise NhwError(f"the batch is on cuda:{bgr.device.index}, this encoder on cuda:{self.device}")
         n = bgr.shape[0]
-        assert bgr.is_cuda and bgr.dtype == self.torch.uint8 and bgr.is_contiguous() and bgr.numel() == n * IMG_BYTES
         if out is None:
             out = self.alloc_out(n)
         o, sizes, status = out
+        for t_, dt_, cnt_ in ((o, self.torch.uint8, n * OUT_STRIDE), (sizes, self.torch.int32, n), (status, self.torch.int32, n)):
+            if not (t_.is_cuda and t_.device.index == self.device and t_.dtype == dt_ and t_.is_contiguous() and t_.numel() >= cnt_):
+                raise NhwError("encode_device: output tensors must be contiguous, on this encoder's device, uint8 [n, OUT_STRIDE] / int32 [n] / int32 [n]")
         with _OnTorchStream(self) as st:
             self._chk(self.lib.nhw_enc_batch_device(self.h, bgr.data_ptr(), n, quality, o.data_ptr(), sizes.data_ptr(), status.data_ptr(), st))
         return o, sizes, status
@@ -108,7 +119,10 @@ class Encoder:
     def encode(self, images, quality: int = QUALITY_DEFAULT):
         """images: numpy uint8 [n,512,512,3] on the host -> list of .nhw byte strings (raises on a per-image failure)."""
         import numpy as np
-        images = np.ascontiguousarray(images, dtype=np.uint8)
+        images = np.asarray(images)
+        if images.dtype != np.uint8 or images.ndim != 4 or images.shape[1:] != (512, 512, 3):
+            raise NhwError(f"encode wants uint8 [n, 512, 512, 3] (BMP file order), got {images.dtype} {images.shape}")
+        images = np.ascontiguousarray(images)
         n = images.shape[0]
         arena = np.empty(n * OUT_STRIDE, np.uint8)
         offs = np.empty(n + 1, np.uint64)
@@ -122,6 +136,34 @@ class Encoder:
         t = Timing()
         self._chk(self.lib.nhw_enc_last_timing(self.h, ctypes.byref(t)))
         return t
+
+    def encode_synthetic(self, n: int, seed_base: int, quality: int = QUALITY_DEFAULT):
+        """SURVEY 8(d) images seed_base.. generated on the device, encoded, files brought to the host (`nhw-enc --synthetic`)."""
+        import numpy as np
+        arena = np.empty(n * OUT_STRIDE, np.uint8)
+        offs = np.empty(n + 1, np.uint64)
+        status = np.empty(n, np.int32)
+        self._chk(self.lib.nhw_enc_synth_batch(self.h, n, seed_base, quality, arena.ctypes.data, arena.size, offs.ctypes.data, status.ctypes.data))
+        if (status != 0).any():
+            raise NhwError(f"per-image status {status.tolist()}")
+        return [arena[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)]
+
+    def pinned_images(self, n: int):
+        """uint8 [n,512,512,3] in page-locked host memory (nhw_host_alloc): encode() uploads such a batch by DMA at PCIe speed while the
+        chunk before is being encoded.  Keep the returned array alive only as long as this encoder; free with free_pinned()."""
+        import numpy as np
+        p = self.lib.nhw_host_alloc(n * IMG_BYTES)
+        if not p:
+            raise NhwError("nhw_host_alloc failed")
+        buf = (ctypes.c_uint8 * (n * IMG_BYTES)).from_address(p)
+        a = np.frombuffer(buf, np.uint8).reshape(n, 512, 512, 3)
+        self._pinned = getattr(self, "_pinned", []) + [p]
+        return a
+
+    def free_pinned(self):
+        for p in getattr(self, "_pinned", []):
+            self.lib.nhw_host_free(p)
+        self._pinned = []
 
 
 class _OnTorchStream:
@@ -211,9 +253,15 @@ class Decoder:
         t = self.torch
         n = offsets.numel()
         dev = f"cuda:{self.device}"
-        assert offsets.dtype == t.int64 and lengths.dtype == t.int32 and lengths.numel() == n and offsets.is_cuda and lengths.is_cuda
+        for name, x, dt in (("arena", arena, t.uint8), ("offsets", offsets, t.int64), ("lengths", lengths, t.int32)):
+            if not (x.is_cuda and x.device.index == self.device and x.dtype == dt and x.is_contiguous()):
+                raise NhwError(f"decode_device: `{name}` must be a contiguous {dt} tensor on cuda:{self.device}")
+        if lengths.numel() != n or n < 1:
+            raise NhwError("decode_device: offsets and lengths must have one entry per file")
         if out is None:
             out = t.empty((n, 512, 512, 3), dtype=t.uint8, device=dev)
+        elif not (out.is_cuda and out.device.index == self.device and out.dtype == t.uint8 and out.is_contiguous() and out.numel() >= n * IMG_BYTES):
+            raise NhwError("decode_device: `out` must be a contiguous uint8 tensor of n*786432 bytes on this decoder's device")
         status = t.empty(n, dtype=t.int32, device=dev)
         quality = t.empty(n, dtype=t.int32, device=dev)
         with _OnTorchStream(self) as st:

@@ -36,6 +36,8 @@ void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int1
 void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipStream_t s);
 void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s);
 
+int nhw_attr_status = 0;
+const char *nhw_attr_where = "";
 static thread_local std::string g_err;
 extern "C" const char *nhw_last_error(void) { return g_err.c_str(); }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { char b_[256]; snprintf(b_, sizeof b_, "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); g_err = b_; return NHW_E_HIP; } } while (0)
@@ -89,6 +91,7 @@ extern "C" int nhw_enc_set_compat(nhw_enc *e, int mode)
 	return NHW_OK;
 }
 
+extern "C" void nhw_enc_destroy(nhw_enc *e);
 extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 {
 	if (!out || max_batch < 1 || max_batch > 65535) { g_err = "bad argument"; return NHW_E_ARG; }
@@ -103,12 +106,24 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 		total += GUARD + e->ws.stride[b] * (size_t)max_batch;
 	}
 	e->slab_bytes = total;
-	HIPCHK(hipMalloc((void **)&e->ws.base, total));
-	HIPCHK(hipMemset(e->ws.base, 0, total));       /* guards must be zero; they are never written afterwards */
-	HIPCHK(hipStreamCreate(&e->own_stream));
-	for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&e->ev[i]));
-	for (int i = 0; i < 4; i++) HIPCHK(hipStreamCreateWithFlags(&e->part_stream[i], hipStreamNonBlocking));
-	for (int i = 0; i < 5; i++) HIPCHK(hipEventCreateWithFlags(&e->part_ev[i], hipEventDisableTiming));
+	const int rc = [&]() -> int {                                  /* a failure half-way leaves nothing behind: the handle is destroyed below */
+		size_t free_b = 0, total_b = 0;
+		HIPCHK(hipMemGetInfo(&free_b, &total_b));
+		if (total > free_b) {                                      /* 5.6 MB of workspace per image: say so instead of failing inside hipMalloc */
+			char b[200];
+			snprintf(b, sizeof b, "encoder workspace for max_batch %d needs %zu MiB (%.1f MiB per image), %zu MiB of HBM are free", max_batch, total >> 20, (double)total / max_batch / 1048576.0, free_b >> 20);
+			g_err = b;
+			return NHW_E_ARG;
+		}
+		HIPCHK(hipMalloc((void **)&e->ws.base, total));
+		HIPCHK(hipMemset(e->ws.base, 0, total));       /* guards must be zero; they are never written afterwards */
+		HIPCHK(hipStreamCreate(&e->own_stream));
+		for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&e->ev[i]));
+		for (int i = 0; i < 4; i++) HIPCHK(hipStreamCreateWithFlags(&e->part_stream[i], hipStreamNonBlocking));
+		for (int i = 0; i < 5; i++) HIPCHK(hipEventCreateWithFlags(&e->part_ev[i], hipEventDisableTiming));
+		return NHW_OK;
+	}();
+	if (rc != NHW_OK) { nhw_enc_destroy(e); return rc; }
 	e->parts = 1;   /* sub-batches on streams of their own (NHW_PARTS=2..4) bought 4 % while the tail kernels were latency-bound; they no longer do */
 	e->chroma_fork = 1;
 	if (const char *p = getenv("NHW_CHROMA_FORK")) e->chroma_fork = atoi(p) != 0;
@@ -309,6 +324,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	nhw_launch_phase(PH_FINAL, ws, 0, out, d_sizes, d_status, s);   /* Z2, container */
 	if (timed == 1) HIPCHK(hipEventRecord(e->ev[4], s));
 	HIPCHK(hipGetLastError());
+	if (nhw_attr_status) { g_err = std::string(nhw_attr_where) + " -> " + hipGetErrorString((hipError_t)nhw_attr_status); return NHW_E_HIP; }
 	return NHW_OK;
 }
 
@@ -394,21 +410,49 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *out, const uint3
 	for (uint32_t i = threadIdx.x; i < sizes[img]; i += 256) d[i] = s[i];
 }
 
+/* buffers of the host path for up to n images; on a failed allocation nothing dangles and the capacity stays what really exists */
+static int host_buffers(nhw_enc *e, int n)
+{
+	if (e->conv_cap >= n) return NHW_OK;
+	void **ptrs[6] = { (void **)&e->d_in, (void **)&e->d_out, (void **)&e->d_compact, (void **)&e->d_sizes, (void **)&e->d_status, (void **)&e->d_offs };
+	for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
+	e->conv_cap = 0;
+	HIPCHK(hipMalloc((void **)&e->d_in, (size_t)n * NHW_IMG_BYTES));
+	HIPCHK(hipMalloc((void **)&e->d_out, (size_t)n * NHW_OUT_STRIDE));
+	HIPCHK(hipMalloc((void **)&e->d_compact, (size_t)n * NHW_OUT_STRIDE));
+	HIPCHK(hipMalloc((void **)&e->d_sizes, sizeof(uint32_t) * n));
+	HIPCHK(hipMalloc((void **)&e->d_status, sizeof(int32_t) * n));
+	HIPCHK(hipMalloc((void **)&e->d_offs, sizeof(uint64_t) * (n + 1)));
+	e->conv_cap = n;
+	return NHW_OK;
+}
+
+/* compact the per-image output slots and bring them to the host */
+static int host_download(nhw_enc *e, int n, uint8_t *out_arena, size_t arena_cap, uint64_t *out_off, int32_t *status)
+{
+	hipStream_t s = e->own_stream;
+	k_offsets<<<1, 1, 0, s>>>(e->d_sizes, e->d_offs, n);
+	k_compact<<<n, 256, 0, s>>>(e->d_out, e->d_sizes, e->d_offs, e->d_compact);
+	HIPCHK(hipMemcpyAsync(out_off, e->d_offs, sizeof(uint64_t) * (n + 1), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(status, e->d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	if (out_off[n] > arena_cap) { g_err = "output arena too small"; return NHW_E_SPACE; }
+	HIPCHK(hipMemcpy(out_arena, e->d_compact, out_off[n], hipMemcpyDeviceToHost));
+	return NHW_OK;
+}
+
+/* page-locked host memory: buffers handed to nhw_enc_batch that come from here travel by DMA at PCIe speed while the previous chunk
+ * is being encoded (pageable memory is staged by the runtime and moves at about half of that) */
+extern "C" void *nhw_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+extern "C" void nhw_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int nhw_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
 extern "C" int nhw_enc_batch(nhw_enc *e, const uint8_t *bgr, int n, int quality, uint8_t *out_arena, size_t arena_cap,
                              uint64_t *out_off, int32_t *status)
 {
 	if (!e || !bgr || !out_arena || !out_off || !status || n < 1 || n > e->max_batch) { g_err = "bad argument"; return NHW_E_ARG; }
 	HIPCHK(hipSetDevice(e->device));
-	if (e->conv_cap < n) {
-		if (e->d_in) { (void)hipFree(e->d_in); (void)hipFree(e->d_out); (void)hipFree(e->d_compact); (void)hipFree(e->d_sizes); (void)hipFree(e->d_status); (void)hipFree(e->d_offs); }
-		HIPCHK(hipMalloc((void **)&e->d_in, (size_t)n * NHW_IMG_BYTES));
-		HIPCHK(hipMalloc((void **)&e->d_out, (size_t)n * NHW_OUT_STRIDE));
-		HIPCHK(hipMalloc((void **)&e->d_compact, (size_t)n * NHW_OUT_STRIDE));
-		HIPCHK(hipMalloc((void **)&e->d_sizes, sizeof(uint32_t) * n));
-		HIPCHK(hipMalloc((void **)&e->d_status, sizeof(int32_t) * n));
-		HIPCHK(hipMalloc((void **)&e->d_offs, sizeof(uint64_t) * (n + 1)));
-		e->conv_cap = n;
-	}
+	{ const int rc = host_buffers(e, n); if (rc) return rc; }
 	hipStream_t s = e->own_stream, cs = e->part_stream[3];
 	/* chunks of 1024 images: the upload of a chunk (its own stream) overlaps the encode of the one before; every chunk is
 	 * encoded in the first workspace slots, one after the other on `s` */
@@ -424,14 +468,20 @@ extern "C" int nhw_enc_batch(nhw_enc *e, const uint8_t *bgr, int n, int quality,
 		const int rc = nhw_enc_batch_device(e, e->d_in + (size_t)i0 * NHW_IMG_BYTES, m, quality, e->d_out + (size_t)i0 * NHW_OUT_STRIDE, e->d_sizes + i0, e->d_status + i0, s);
 		if (rc) return rc;
 	}
-	k_offsets<<<1, 1, 0, s>>>(e->d_sizes, e->d_offs, n);
-	k_compact<<<n, 256, 0, s>>>(e->d_out, e->d_sizes, e->d_offs, e->d_compact);
-	HIPCHK(hipMemcpyAsync(out_off, e->d_offs, sizeof(uint64_t) * (n + 1), hipMemcpyDeviceToHost, s));
-	HIPCHK(hipMemcpyAsync(status, e->d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
-	if (out_off[n] > arena_cap) { g_err = "output arena too small"; return NHW_E_SPACE; }
-	HIPCHK(hipMemcpy(out_arena, e->d_compact, out_off[n], hipMemcpyDeviceToHost));
-	return NHW_OK;
+	return host_download(e, n, out_arena, arena_cap, out_off, status);
+}
+
+/* SURVEY.md 8(d) synthetic images seed_base .. seed_base+n-1, generated on the device, encoded, and the files brought to the host:
+ * `nhw-enc --synthetic` (tools/nhw_enc.c) */
+extern "C" int nhw_enc_synth_batch(nhw_enc *e, int n, uint32_t seed_base, int quality, uint8_t *out_arena, size_t arena_cap, uint64_t *out_off, int32_t *status)
+{
+	if (!e || !out_arena || !out_off || !status || n < 1 || n > e->max_batch) { g_err = "bad argument"; return NHW_E_ARG; }
+	HIPCHK(hipSetDevice(e->device));
+	{ const int rc = host_buffers(e, n); if (rc) return rc; }
+	nhw_launch_synth(e->d_in, n, seed_base, e->own_stream);
+	HIPCHK(hipGetLastError());
+	{ const int rc = nhw_enc_batch_device(e, e->d_in, n, quality, e->d_out, e->d_sizes, e->d_status, e->own_stream); if (rc) return rc; }
+	return host_download(e, n, out_arena, arena_cap, out_off, status);
 }
 
 /* ------------------------------------------------------------------------------------------------ stage entry points */

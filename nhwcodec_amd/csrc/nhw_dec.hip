@@ -1523,9 +1523,10 @@ struct nhw_dec {
 	uint64_t *d_off; uint32_t *d_len; uint8_t *d_out; int32_t *d_status; int32_t *d_quality;
 };
 
+extern "C" void nhw_dec_destroy(nhw_dec *d);
 extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
 {
-	if (!out || max_batch < 1) return NHW_E_ARG;
+	if (!out || max_batch < 1) { g_derr = "bad argument"; return NHW_E_ARG; }
 	HIPCHK(hipSetDevice(device));
 	nhw_dec *d = new nhw_dec();
 	memset(d, 0, sizeof *d);
@@ -1533,15 +1534,22 @@ extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
 	size_t at = 0;
 	for (int b = 0; b < D_COUNT; b++) { d->ws.off[b] = at; at += k_dec_bytes[b] * (size_t)max_batch; at = (at + 255) & ~(size_t)255; }
 	d->slab_bytes = at;
-	HIPCHK(hipMalloc(&d->ws.base, at));
-	HIPCHK(hipMemset(d->ws.base, 0, at));
-	HIPCHK(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
-	HIPCHK(hipStreamCreateWithFlags(&d->chroma_stream, hipStreamNonBlocking));
-	HIPCHK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
-	HIPCHK(hipEventCreateWithFlags(&d->join_ev, hipEventDisableTiming));
+	const int rc = [&]() -> int {                                  /* a failure half-way leaves nothing behind: the handle is destroyed below */
+		size_t free_b = 0, total_b = 0;
+		HIPCHK(hipMemGetInfo(&free_b, &total_b));
+		if (at > free_b) { char b[160]; snprintf(b, sizeof b, "decoder workspace for max_batch %d needs %zu MiB, %zu MiB of HBM are free", max_batch, at >> 20, free_b >> 20); g_derr = b; return NHW_E_ARG; }
+		HIPCHK(hipMalloc(&d->ws.base, at));
+		HIPCHK(hipMemset(d->ws.base, 0, at));
+		HIPCHK(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
+		HIPCHK(hipStreamCreateWithFlags(&d->chroma_stream, hipStreamNonBlocking));
+		HIPCHK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&d->join_ev, hipEventDisableTiming));
+		for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&d->ev[i]));
+		return NHW_OK;
+	}();
+	if (rc != NHW_OK) { nhw_dec_destroy(d); return rc; }
 	d->chroma_fork = 1;
 	if (const char *p = getenv("NHW_CHROMA_FORK")) d->chroma_fork = atoi(p) != 0;
-	for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&d->ev[i]));
 	*out = d;
 	return NHW_OK;
 }
@@ -1570,7 +1578,8 @@ extern "C" void nhw_dec_debug_stop_after(nhw_dec *d, int stage) { if (d) d->stop
 /* debug: copy a workspace buffer of one image to the host (what = D_* index) */
 extern "C" int nhw_dec_debug_read(nhw_dec *d, int what, int img, void *dst, size_t bytes)
 {
-	if (!d || what < 0 || what >= D_COUNT || img < 0 || img >= d->max_batch || bytes > k_dec_bytes[what]) return NHW_E_ARG;
+	if (!d || what < 0 || what >= D_COUNT || img < 0 || img >= d->max_batch || bytes > k_dec_bytes[what]) { g_derr = "bad argument"; return NHW_E_ARG; }
+	HIPCHK(hipSetDevice(d->device));
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(dst, d->ws.base + d->ws.off[what] + (size_t)img * k_dec_bytes[what], bytes, hipMemcpyDeviceToHost));
 	return NHW_OK;
@@ -1579,7 +1588,8 @@ extern "C" int nhw_dec_debug_read(nhw_dec *d, int what, int img, void *dst, size
 extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_t *d_off, const uint32_t *d_len, int n, void *d_bgr, int32_t *d_status,
                                     int32_t *d_quality, void *stream)
 {
-	if (!d || !d_nhw || !d_off || !d_len || !d_bgr || !d_status || n < 1 || n > d->max_batch) return NHW_E_ARG;
+	if (!d || !d_nhw || !d_off || !d_len || !d_bgr || !d_status || n < 1 || n > d->max_batch) { g_derr = "bad argument"; return NHW_E_ARG; }
+	HIPCHK(hipSetDevice(d->device));                              /* the handle's device, whatever the calling thread had current */
 	hipStream_t s = stream ? (hipStream_t)stream : d->own_stream;
 	DecWs ws = d->ws;
 	ws.n = n; ws.blob = (const uint8_t *)d_nhw; ws.blob_off = d_off; ws.blob_len = d_len;
@@ -1697,13 +1707,15 @@ extern "C" int nhw_dec_last_timing(nhw_dec *d, nhw_dec_timing *t)
 /* host convenience: H2D of the files, decode, D2H of the pixels.  nhw: the files back to back, off[n+1]. */
 extern "C" int nhw_dec_batch(nhw_dec *d, const uint8_t *nhw, const uint64_t *off, int n, uint8_t *bgr, int32_t *status, int32_t *quality)
 {
-	if (!d || !nhw || !off || !bgr || !status || n < 1 || n > d->max_batch) return NHW_E_ARG;
+	if (!d || !nhw || !off || !bgr || !status || n < 1 || n > d->max_batch) { g_derr = "bad argument"; return NHW_E_ARG; }
 	HIPCHK(hipSetDevice(d->device));
 	const size_t total = (size_t)(off[n] - off[0]);
 	if (total + 64 > d->blob_cap) {
 		if (d->d_blob) (void)hipFree(d->d_blob);
-		d->blob_cap = total + (total >> 2) + (1u << 20);
-		HIPCHK(hipMalloc(&d->d_blob, d->blob_cap));
+		d->d_blob = nullptr; d->blob_cap = 0;                      /* nothing dangling if the allocation below fails */
+		const size_t want = total + (total >> 2) + (1u << 20);
+		HIPCHK(hipMalloc(&d->d_blob, want));
+		d->blob_cap = want;
 	}
 	if (!d->d_off) {
 		HIPCHK(hipMalloc(&d->d_off, ((size_t)d->max_batch + 1) * 8));

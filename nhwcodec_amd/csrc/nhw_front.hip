@@ -1078,8 +1078,8 @@ static void dwt_lds_attr()
 	static bool done = false;
 	if (done) return;
 	const int lds = S * (S + 2) * (int)sizeof(int16_t);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dwt_ana<S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dwt_syn<S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+	NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dwt_ana<S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+	NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dwt_syn<S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 	done = true;
 }
 
@@ -1129,8 +1129,8 @@ void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilte
 	const size_t lds = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
 	static bool attr_set = false;
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		attr_set = true;
 	}
 	const dim3 grid(H / FB_KB, n);

@@ -104,10 +104,10 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 	const dim3 g(ws.n), b(256);
 	static bool attr_set = false;
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_C5>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10));
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10));
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10));
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_C5>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10));
 		attr_set = true;
 	}
 	const size_t lds = phase_lds(ph);

@@ -17,6 +17,7 @@
 #define DEV __device__ static
 #define NHW_OK 0
 #define NHW_E_CODEBOOK (-2)
+#define NHW_E_SPACE (-3)
 #define S_CAP 131072   /* capacity of the sign-bit scratch lists */
 #ifdef NHW_PROFILE
 #define PROF_BEGIN() unsigned long long t0_ = wall_clock64()

@@ -2697,6 +2697,9 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 		const unsigned ob = block_exscan(bb, tid, sh->bits, &tb);
 		const unsigned on = block_exscan(x1 | (x2 << 16), tid, sh->bits, &tn);
 		const int last = tb ? (int)((base_bits + tb - 1) >> 5) : zeroed - 1;
+		/* the packet holds 80000 words per image, like the reference's calloc(80000) (compress_pixel.c:64), which never checks: a
+		 * stream that would not fit ends THIS image with a status instead of running into its neighbours' words */
+		if (word0 + last >= 80000) { if (tid == 0) sh->rc = NHW_E_SPACE; BARRIER(); return; }
 		for (int w = zeroed + tid; w <= last; w += NT) words[w] = 0;
 		BARRIER();
 		if (lo < S) pack_walk<2>(dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);

@@ -56,6 +56,35 @@ def test_gloo_world2_descriptor_broadcast_and_gather():
     assert t0 == t1 == 2.0
 
 
+def _bench_dry(*extra):
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry", *extra], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout       # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_spawns_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher in the environment re-executes itself under torch.distributed.run: two ranks meet
+    (gloo in this CPU test), the line says n_gpus 2 and every rank reports its share."""
+    d = _bench_dry("--gpus", "2")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["images_per_rank"] == [4096, 4096]
+    assert d["first_seed_per_rank"][1] - d["first_seed_per_rank"][0] == 4096      # disjoint seed ranges
+
+
+def test_bench_strong_split_is_baseline_config_4():
+    """--total-images 65536 over 8 ranks = 8192 contiguous images per rank (BASELINE configs[3]); here 3 ranks to keep the CPU test light"""
+    d = _bench_dry("--gpus", "3", "--total-images", "65536")
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and sum(d["images_per_rank"]) == 65536
+    assert max(d["images_per_rank"]) - min(d["images_per_rank"]) <= 1
+    seeds = d["first_seed_per_rank"]
+    assert [seeds[i + 1] - seeds[i] for i in range(2)] == d["images_per_rank"][:2]
+
+
 # ---------------------------------------------------------------- CLI contract (no GPU needed for argument handling)
 CLI = os.path.join(ROOT, "tools", "nhw-enc")
 REF_CLI = os.path.join(ROOT, "oracle", "_ref", "nhw-enc")
@@ -84,7 +113,7 @@ def test_cli_argument_handling_matches_reference_binary(cli, args):
 
 
 def test_cli_rejects_unimplemented_quality_loudly(cli):
-    rc, out, err = _run(cli, "-q5", "a.bmp", "b.nhw")
+    rc, out, err = _run(cli, "-q0", "a.bmp", "b.nhw")       # accepted by the reference's argument loop, but it has no tables for it
     assert rc == 3 and "not implemented" in err
 
 
@@ -129,6 +158,13 @@ def test_cli_end_to_end_files(cli, oracle, tmp_path):
     assert _run(cli, "-q21", "--batch", str(d))[0] == 0
     for s in (1, 2, 3):
         assert (d / f"i{s}.nhw").read_bytes() == oracle.encode(oracle.synth(s), 21)
+    # synthetic mode: SURVEY 8d images generated on the device, one file per seed; --gpus 1 = one worker thread on device 0
+    o = tmp_path / "syn"; o.mkdir()
+    assert _run(cli, "-q10", "--gpus", "1", "--synthetic", "5", "--seed", "40", "--outdir", str(o))[0] == 0
+    for s in range(40, 45):
+        assert (o / f"synth_{s}.nhw").read_bytes() == oracle.encode(oracle.synth(s), 10)
+    rc, _, err = _run(cli, "--gpus", "99", "--synthetic", "2", "--outdir", str(o))
+    assert rc == 1 and "device(s) visible" in err
 
 
 # ---------------------------------------------------------------- nhw-dec

@@ -410,3 +410,28 @@ def test_front_fallback_paths_are_exact(oracle, q):
     assert forced == normal
     bad = [i for i in range(len(imgs)) if forced[i] != oracle.encode(imgs[i], q)]
     assert not bad, f"q{q}: images {bad} differ from the oracle on the fallback paths"
+
+
+@pytest.mark.gpu
+def test_host_path_pcie_inclusive(oracle):
+    """nhw_enc_batch from page-locked host memory (nhw_host_alloc): 2048 images uploaded in chunks next to the encode of the chunk before,
+    files compacted on the device and downloaded.  Bit-exact on a sample, and the PCIe-inclusive rate stays above what a pageable copy
+    alone used to allow (the figure itself goes to bench.py's `host_path` field, never to `value`)."""
+    import time
+    import nhwcodec_amd
+    n = 2048
+    e = nhwcodec_amd.Encoder(0, max_batch=1024)
+    a = e.pinned_images(n)
+    base = e.synth_device(1024, seed_base=300).cpu().numpy()
+    a[:1024] = base; a[1024:] = base[::-1]
+    e2 = nhwcodec_amd.Encoder(0, max_batch=n)
+    e2.encode(a[:64], 20)                      # warm
+    t0 = time.perf_counter()
+    got = e2.encode(a, 20)
+    dt = time.perf_counter() - t0
+    for i in (0, 1, 1023, 1024, 2047):
+        assert got[i] == oracle.encode(a[i], 20)
+    rate = n * 0.262144 / dt / 1e3
+    print(f"host path: {n} images in {dt * 1e3:.1f} ms = {rate:.1f} Gpixel/s incl. PCIe both ways")
+    assert rate > 5.0
+    e.free_pinned(); e.close(); e2.close()

@@ -8,11 +8,17 @@
  * library through its C ABI (include/nhw_hip.h); this file is host plumbing only.
  *
  * Batch extensions (not in the reference):
- *   nhw-enc [-q N] --batch <dir>                 every <dir>/x.bmp  -> <dir>/x.nhw, one GPU batch per 1024 files
- *   nhw-enc [-q N] --synthetic <count> [--seed S] --outdir <dir>   SURVEY 8d generator on the device
+ *   nhw-enc [-q N] [--gpus G] --batch <dir>      every <dir>/x.bmp  -> <dir>/x.nhw, GPU batches of up to 1024 files
+ *   nhw-enc [-q N] [--gpus G] --synthetic <count> [--seed S] --outdir <dir>
+ *                                                SURVEY 8d generator on the device -> <dir>/synth_<seed>.nhw
  *   --stock-compat   reproduce the stock one-image-per-process binary instead of the canonical output (include/nhw_hip.h)
+ * --gpus G: images are independent (encoder/nhw_encoder_cli.c:175-183 is a per-image sequence), so the job is a queue of chunks of up
+ * to 1024 images; one host thread per GPU, each with its own encoder handle, takes the next chunk until the queue is empty.  The work
+ * descriptor {first image, count, quality, seed} lives in this process; between processes (one per GPU under torchrun) it travels by
+ * RCCL broadcast: nhwcodec_amd/dist.py, bench.py.
  */
 #include <dirent.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -40,7 +46,7 @@ static void usage(void)
 	        "  -h        print this help\n"
 	        "  -V        show version and legal information\n\n"
 	        "  example: nhw-enc -q15 image.bmp image.nhw\n"
-	        "Batch (MI355X build): %s [-q#] --batch <dir> | --synthetic <n> [--seed s] --outdir <dir>\n",
+	        "Batch (MI355X build): %s [-q#] [--gpus g] --batch <dir> | --synthetic <n> [--seed s] --outdir <dir>\n",
 	        PROGRAM, PROGRAM);
 }
 
@@ -132,9 +138,64 @@ static int ends_with(const char *s, const char *suf)
 	return a >= b && strcmp(s + a - b, suf) == 0;
 }
 
+/* the job queue of the batch modes: chunks of up to 1024 images, taken in order by one host thread per GPU */
+#define CHUNK 1024
+struct job {
+	int n, next;                   /* images in the job, first image nobody has taken yet */
+	int quality, stock_compat;
+	uint32_t seed;                 /* --synthetic: image i is generator seed `seed + i` */
+	char **in, **out;              /* --batch: file names */
+	const char *outdir;            /* --synthetic */
+	pthread_mutex_t lock;
+};
+struct worker { struct job *jb; int device, bad; };
+
+static void *worker_main(void *arg)
+{
+	struct worker *w = (struct worker *)arg;
+	struct job *jb = w->jb;
+	nhw_enc *enc = NULL;
+	uint8_t *imgs = NULL, *arena = NULL;
+	uint64_t *off = (uint64_t *)malloc(sizeof(uint64_t) * (CHUNK + 1));
+	int32_t *st = (int32_t *)malloc(sizeof(int32_t) * CHUNK);
+	const int cap = jb->n < CHUNK ? jb->n : CHUNK;
+	int rc, i;
+	if ((rc = nhw_enc_create(w->device, cap, &enc))) die_lib("nhw_enc_create", rc);
+	if (jb->stock_compat) nhw_enc_set_compat(enc, NHW_COMPAT_GLIBC_ONESHOT);
+	arena = (uint8_t *)malloc((size_t)cap * NHW_OUT_STRIDE);
+	if (!jb->outdir) {                                 /* page-locked input buffer: the upload runs at PCIe speed next to the encode */
+		imgs = (uint8_t *)nhw_host_alloc((size_t)cap * NHW_IMG_BYTES);
+		if (!imgs) imgs = (uint8_t *)malloc((size_t)cap * NHW_IMG_BYTES);
+	}
+	for (;;) {
+		int base, m;
+		pthread_mutex_lock(&jb->lock);
+		base = jb->next; m = jb->n - base < CHUNK ? jb->n - base : CHUNK; jb->next += m > 0 ? m : 0;
+		pthread_mutex_unlock(&jb->lock);
+		if (m <= 0) break;
+		if (jb->outdir) rc = nhw_enc_synth_batch(enc, m, jb->seed + (uint32_t)base, jb->quality, arena, (size_t)cap * NHW_OUT_STRIDE, off, st);
+		else {
+			for (i = 0; i < m; i++) load_bmp(jb->in[base + i], imgs + (size_t)i * NHW_IMG_BYTES);
+			rc = nhw_enc_batch(enc, imgs, m, jb->quality, arena, (size_t)cap * NHW_OUT_STRIDE, off, st);
+		}
+		if (rc) die_lib("encode", rc);
+		for (i = 0; i < m; i++) {
+			char name[4096];
+			const char *path = name;
+			if (jb->outdir) snprintf(name, sizeof name, "%s/synth_%u.nhw", jb->outdir, (unsigned)(jb->seed + (uint32_t)(base + i)));
+			else path = jb->out[base + i];
+			if (st[i]) { fprintf(stderr, "%s: %s: encoder status %d (code book overflow)\n", PROGRAM, path, st[i]); w->bad++; continue; }
+			if (write_file(path, arena + off[i], (size_t)(off[i + 1] - off[i]))) w->bad++;
+		}
+	}
+	nhw_enc_destroy(enc);
+	free(st); free(off); free(arena);
+	return NULL;
+}
+
 int main(int argc, char **argv)
 {
-	int quality = QUALITY_DEFAULT, overwrite = 0, synthetic = 0, i;
+	int quality = QUALITY_DEFAULT, overwrite = 0, synthetic = 0, gpus = 1, i;
 	uint32_t seed = 0;
 	const char *batch_dir = NULL, *outdir = NULL;
 	int stock_compat = 0;   /* --stock-compat: NHW_COMPAT_GLIBC_ONESHOT, the stock binary's out-of-bounds reads (include/nhw_hip.h) */
@@ -146,6 +207,7 @@ int main(int argc, char **argv)
 		if (!strcmp(argv[1], "--synthetic") && argc > 2) { synthetic = atoi(argv[2]); argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--seed") && argc > 2) { seed = (uint32_t)strtoul(argv[2], NULL, 10); argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--outdir") && argc > 2) { outdir = argv[2]; argc -= 2; argv += 2; continue; }
+		if (!strcmp(argv[1], "--gpus") && argc > 2) { gpus = atoi(argv[2]); argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--stock-compat")) { stock_compat = 1; argc -= 1; argv += 1; continue; }
 		for (i = 1; argv[1][i] != '\0'; i++) {
 			const char ch = argv[1][i];
@@ -167,43 +229,44 @@ int main(int argc, char **argv)
 	(void)overwrite; /* the reference's overwrite check is effectively off (its flag is never initialised, nhw_encoder_cli.c:93,164) */
 
 	if (!nhw_quality_supported(quality)) {
-		fprintf(stderr, "%s: quality %d is not implemented by the MI355X path in this revision (supported: 17..23)\n", PROGRAM, quality);
+		fprintf(stderr, "%s: quality %d is not implemented (supported: 1..23; the reference accepts -q0 but has no tables for it)\n", PROGRAM, quality);
 		return 3;
 	}
 
-	if (synthetic > 0) {
-		fprintf(stderr, "%s: --synthetic is served by bench.py / the Python binding (device-resident generator)\n", PROGRAM);
-		(void)seed; (void)outdir;
-		return 3;
-	}
-
-	if (batch_dir) {
-		DIR *d = opendir(batch_dir);
-		struct dirent *de;
-		char **in = NULL, **out = NULL;
-		int n = 0, cap = 0, bad = 0, base;
-		uint8_t *imgs;
-		if (!d) { printf("menu(): Could not open file: %s\n", batch_dir); exit(-1); }
-		while ((de = readdir(d))) {
-			if (!ends_with(de->d_name, ".bmp")) continue;
-			if (n == cap) { cap = cap ? cap * 2 : 256; in = (char **)realloc(in, sizeof(char *) * cap); out = (char **)realloc(out, sizeof(char *) * cap); }
-			in[n] = (char *)malloc(strlen(batch_dir) + strlen(de->d_name) + 2);
-			sprintf(in[n], "%s/%s", batch_dir, de->d_name);
-			out[n] = strdup(in[n]);
-			strcpy(out[n] + strlen(out[n]) - 4, ".nhw");
-			n++;
+	if (synthetic > 0 || batch_dir) {
+		struct job jb;
+		pthread_t th[16];
+		struct worker wk[16];
+		int ndev = nhw_device_count(), g, bad = 0;
+		memset(&jb, 0, sizeof jb);
+		jb.quality = quality; jb.stock_compat = stock_compat; jb.seed = seed;
+		pthread_mutex_init(&jb.lock, NULL);
+		if (synthetic > 0) {
+			if (!outdir) { fprintf(stderr, "%s: --synthetic needs --outdir <dir>\n", PROGRAM); return 1; }
+			jb.n = synthetic; jb.outdir = outdir;
+		} else {
+			DIR *d = opendir(batch_dir);
+			struct dirent *de;
+			int cap = 0;
+			if (!d) { printf("menu(): Could not open file: %s\n", batch_dir); exit(-1); }
+			while ((de = readdir(d))) {
+				if (!ends_with(de->d_name, ".bmp")) continue;
+				if (jb.n == cap) { cap = cap ? cap * 2 : 256; jb.in = (char **)realloc(jb.in, sizeof(char *) * cap); jb.out = (char **)realloc(jb.out, sizeof(char *) * cap); }
+				jb.in[jb.n] = (char *)malloc(strlen(batch_dir) + strlen(de->d_name) + 2);
+				sprintf(jb.in[jb.n], "%s/%s", batch_dir, de->d_name);
+				jb.out[jb.n] = strdup(jb.in[jb.n]);
+				strcpy(jb.out[jb.n] + strlen(jb.out[jb.n]) - 4, ".nhw");
+				jb.n++;
+			}
+			closedir(d);
+			if (!jb.n) { printf("Not enough arguments. Check help.\n"); return 0; }
 		}
-		closedir(d);
-		if (!n) { printf("Not enough arguments. Check help.\n"); return 0; }
-		if ((rc = nhw_enc_create(0, n < 1024 ? n : 1024, &enc))) die_lib("nhw_enc_create", rc);
-		if (stock_compat) nhw_enc_set_compat(enc, NHW_COMPAT_GLIBC_ONESHOT);
-		imgs = (uint8_t *)malloc((size_t)(n < 1024 ? n : 1024) * NHW_IMG_BYTES);
-		for (base = 0; base < n; base += 1024) {
-			const int m = n - base < 1024 ? n - base : 1024;
-			for (i = 0; i < m; i++) load_bmp(in[base + i], imgs + (size_t)i * NHW_IMG_BYTES);
-			bad += encode_host_batch(enc, imgs, m, quality, out + base);
-		}
-		nhw_enc_destroy(enc);
+		if (ndev < 1) { fprintf(stderr, "%s: no GPU visible\n", PROGRAM); return 2; }
+		if (gpus < 1) gpus = 1;
+		if (gpus > ndev) { fprintf(stderr, "%s: --gpus %d but %d device(s) visible\n", PROGRAM, gpus, ndev); return 1; }
+		if (gpus > 16) gpus = 16;
+		for (g = 0; g < gpus; g++) { wk[g].jb = &jb; wk[g].device = g; wk[g].bad = 0; pthread_create(&th[g], NULL, worker_main, &wk[g]); }
+		for (g = 0; g < gpus; g++) { pthread_join(th[g], NULL); bad += wk[g].bad; }
 		return bad ? 1 : 0;
 	}
 
