@@ -16,12 +16,12 @@
 
 /* launchers (nhw_front.hip, nhw_tail.hip) */
 void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_stride, uint8_t *u, uint8_t *v, size_t c_stride, hipStream_t s);
-void nhw_launch_prefilter(int16_t *y, size_t y_stride, int16_t *kmap, size_t k_stride, uint64_t *maps, size_t m_stride, uint8_t *st, size_t s_stride, int n, hipStream_t s);
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, int16_t *keep, size_t keep_stride, hipStream_t s,
                          int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0);
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s);
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
-void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilter, uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
+void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv, size_t c_stride, const int16_t *y, size_t y_stride, int with_prefilter,
+                            uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
                             uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
                             int16_t *keep, size_t keep_stride, int n, hipStream_t s, int force_fallback);
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s);
@@ -59,7 +59,6 @@ struct nhw_enc {
 	int conv_cap;
 	int chroma_fork;  /* the chroma sequence on a stream of its own next to the luma tail (NHW_CHROMA_FORK=0 turns it off) */
 	int front_fallback; /* debug: every row / segment of the pre-filter carry takes its exact fallback path (tests) */
-	int legacy_front; /* debug: separate pre-filter / analysis kernels instead of the fused band kernel */
 	int stop_after;   /* debug: leave the batch driver after this many stages (0 = run everything) */
 };
 
@@ -171,45 +170,33 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	(void)n;
 	if (what & 1) {
 	if (timed == 1) HIPCHK(hipEventRecord(e->ev[0], s));
-	/* a1: colour + 4:2:0 */
-	/* The fused front reads luma rows that belong to other workgroups' output rows of the same plane (band b writes LL rows
-	 * 16b.. into jpeg, band b/2 reads them as input), so its input lives in a plane of its own: the otherwise unused
-	 * contrast-map plane of the unfused path. */
-	int16_t *yin = e->legacy_front ? jpeg : plane16(ws, B_KMAP);
-	const size_t yin_stride = e->legacy_front ? ws.stride[B_JPEG] : ws.stride[B_KMAP];
-	if (low && !e->legacy_front) {
-		/* colour -> jpeg plane (free until the band kernel writes it), pre-filter: jpeg plane -> the band kernel's input plane */
+	HIPCHK(hipEventRecord(e->ev[5], s));                          /* (the colour conversion used to be a kernel of its own that ended here) */
+	/* a1 + a2 + Y2 + Y3: colour + 4:2:0, pre-filter (q<=21, nhw_encoder.c:116-119), level-1 analysis (:125), LL1 copy (:127-135): ONE kernel
+	 * for quality 17..23 (k_front_band; for q 17..21 behind the two small kernels that hand every row its carry state).  The luma plane
+	 * never reaches HBM.  Quality 1..16: colour kernel -> luma plane, the rationed pre-filter (nhw_low.hip) -> the band kernel's input plane. */
+	int16_t *yin = plane16(ws, B_KMAP);
+	const size_t yin_stride = ws.stride[B_KMAP];
+	if (low) {
 		nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
-		HIPCHK(hipEventRecord(e->ev[5], s));
 		STAGE_DONE();
 		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, q, n, s);
 		STAGE_DONE();
+		nhw_launch_front_fused(nullptr, q, nullptr, nullptr, 0, yin, yin_stride, 0, nullptr, 0, nullptr, 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
+		                       proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n, s, 0);
 	} else {
-	nhw_launch_color((const uint8_t *)d_bgr, n, q, yin, yin_stride, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
-	HIPCHK(hipEventRecord(e->ev[5], s));                          /* end of the colour kernel (the front runs once per batch, on the caller's stream) */
-	STAGE_DONE();
-	}
-	/* a2 + Y2 + Y3: pre-filter (q<=21, nhw_encoder.c:116-119), level-1 analysis (:125), LL1 copy (:127-135), fused */
-	if (e->legacy_front) {
-		if (q < 22) {
-			nhw_launch_prefilter(jpeg, ws.stride[B_JPEG], plane16(ws, B_KMAP), ws.stride[B_KMAP], (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP],
-			                     plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], n, s);
-			STAGE_DONE();
-		}
-		nhw_launch_analysis(jpeg, proc, n, ps, W, W, 0, q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, s);
 		STAGE_DONE();
-		nhw_launch_copy_block(jpeg, ps, W, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, H, H, H, n, s);
-		STAGE_DONE();
-	} else {
-		nhw_launch_front_fused(yin, yin_stride, q < 22 && !low, (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
+		if (q < 22) STAGE_DONE();
+		nhw_launch_front_fused((const uint8_t *)d_bgr, q, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], nullptr, 0, q < 22,
+		                       (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
 		                       plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2,
 		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s, e->front_fallback);
-		if (ws.compat && q < 22 && !low)   /* the kernel-map cells the stock binary's heap re-uses (compatibility mode only) */
+		if (ws.compat && q < 22) {   /* compatibility mode only: the kernel-map cells the stock binary's heap re-uses are replayed from a luma plane */
+			nhw_launch_color((const uint8_t *)d_bgr, n, q, yin, yin_stride, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
 			nhw_launch_front_stale(yin, yin_stride, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], plane16(ws, B_STALE), ws.stride[B_STALE], n, s);
-		if (q < 22 && !low) STAGE_DONE();
-		STAGE_DONE();
-		STAGE_DONE();
+		}
 	}
+	STAGE_DONE();
+	STAGE_DONE();
 	if (timed == 1) HIPCHK(hipEventRecord(e->ev[1], s));
 	if (!(what & 2)) { HIPCHK(hipGetLastError()); return NHW_OK; }
 	}
@@ -340,7 +327,7 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
 	NhwWs ws = e->ws;
 	ws.n = n; ws.q = quality;
-	const int parts = (e->stop_after || e->legacy_front || n < 512) ? 1 : e->parts;
+	const int parts = (e->stop_after || n < 512) ? 1 : e->parts;
 	if (parts == 1) {
 		const int rc = run_batch(e, ws, d_bgr, n, quality, d_out, d_sizes, d_status, s, 1);
 		if (rc == NHW_OK && !e->stop_after) { e->timed = true; e->timed_parts = 1; e->timed_front_images = n; }
@@ -495,24 +482,40 @@ extern "C" int nhw_stage_color(nhw_enc *e, const void *d_bgr, int n, int quality
 	return NHW_OK;
 }
 
+/* the luma pre-filter as a stage exists for quality 1..16 only (k_low_prefilter, the kernel the encoder runs); for 17..21 it is a step
+ * inside the fused front kernel and has no output of its own: nhw_debug_stop_after + nhw_debug_read see the planes behind it */
 extern "C" int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, void *stream)
 {
-	if (!e || n < 1 || n > e->max_batch) return NHW_E_ARG;
-	if (quality < 17 || quality > 21) return NHW_E_QUALITY;
+	if (!e || !d_y || n < 1 || n > e->max_batch) { g_err = "bad argument"; return NHW_E_ARG; }
+	if (quality < 1 || quality > 16) { g_err = "the pre-filter is a stage of its own only for quality 1..16"; return NHW_E_QUALITY; }
 	HIPCHK(hipSetDevice(e->device));
 	const NhwWs &ws = e->ws;
-	nhw_launch_prefilter((int16_t *)d_y, 8 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP], (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP],
-	                     plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], n, stream ? (hipStream_t)stream : e->own_stream);
+	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+	/* in place for the caller: filter into the workspace plane the encoder uses, copy back */
+	nhw_launch_low_prefilter((const int16_t *)d_y, 4 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP] / 2, quality, n, s);
+	HIPCHK(hipMemcpy2DAsync(d_y, 8 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP], 8 * Q, (size_t)n, hipMemcpyDeviceToDevice, s));
 	HIPCHK(hipGetLastError());
 	return NHW_OK;
 }
 
+/* one analysis level with the kernels the encoder runs: size 512 = the band kernel on a luma plane (its LL copy goes to the jpeg plane,
+ * the second copy it makes to the workspace's ll1), 256 / 128 = the whole-block kernels */
 extern "C" int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size,
                                   int final_level, void *stream)
 {
-	if (!e || n_img < 1) return NHW_E_ARG;
+	if (!e || n_img < 1) { g_err = "bad argument"; return NHW_E_ARG; }
 	HIPCHK(hipSetDevice(e->device));
-	nhw_launch_analysis((int16_t *)d_jpeg, (int16_t *)d_proc, n_img, plane_stride, stride, size, final_level, nullptr, 0, stream ? (hipStream_t)stream : e->own_stream);
+	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+	if (size == 512) {
+		if (stride != W || final_level || n_img > e->max_batch) { g_err = "size 512: stride 512, not the final level, n <= max_batch"; return NHW_E_ARG; }
+		const NhwWs &ws = e->ws;
+		/* the band kernel reads rows that other bands of the same image overwrite with LL rows: its input is a plane of its own */
+		HIPCHK(hipMemcpy2DAsync(plane16(ws, B_KMAP), ws.stride[B_KMAP], d_jpeg, plane_stride * 2, 8 * Q, (size_t)n_img, hipMemcpyDeviceToDevice, s));
+		nhw_launch_front_fused(nullptr, 20, nullptr, nullptr, 0, plane16(ws, B_KMAP), ws.stride[B_KMAP], 0, nullptr, 0, nullptr, 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
+		                       (int16_t *)d_proc, (int16_t *)d_jpeg, plane_stride, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n_img, s, 0);
+	} else if (size == 256 || size == 128)
+		nhw_launch_analysis((int16_t *)d_jpeg, (int16_t *)d_proc, n_img, plane_stride, stride, size, final_level, nullptr, 0, s);
+	else { g_err = "transform size must be 512, 256 or 128"; return NHW_E_ARG; }
 	HIPCHK(hipGetLastError());
 	return NHW_OK;
 }
@@ -530,7 +533,6 @@ extern "C" int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n
 void nhw_debug_band_stamps(unsigned long long *out);
 extern "C" int nhw_debug_stamps(unsigned long long *out) { (void)hipDeviceSynchronize(); nhw_debug_band_stamps(out); return NHW_OK; }
 extern "C" int nhw_debug_front_fallback(nhw_enc *e, int on) { if (!e) return NHW_E_ARG; e->front_fallback = on; return NHW_OK; }
-extern "C" int nhw_debug_legacy_front(nhw_enc *e, int on) { if (!e) return NHW_E_ARG; e->legacy_front = on; return NHW_OK; }
 extern "C" int nhw_debug_stop_after(nhw_enc *e, int stage) { if (!e) return NHW_E_ARG; e->stop_after = stage; return NHW_OK; }
 /* developer hook: order-independent 64-bit digest of the first `bytes` bytes of workspace buffer `buf`, one per image, into device memory */
 __global__ __launch_bounds__(256) void k_debug_hash(const uint8_t *base, size_t stride, size_t words, unsigned long long *out)

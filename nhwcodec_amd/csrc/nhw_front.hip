@@ -175,36 +175,6 @@ __device__ __forceinline__ int pair_big_flag_fwd(int k0, int k1)
 	const bool first = a0 > 10 && a0 < 32 && a1 >= 23;
 	return !first && a1 >= 16 && a1 < 32 && a0 >= 23;
 }
-__device__ __forceinline__ void prefilter_pair(int k0, int k1, int prev_big, int &o0, int &o1)
-{
-	const uint32_t d = prefilter_pair_delta(k0, k1, prev_big);
-	o0 += (int16_t)(d & 0xFFFF); o1 += (int16_t)(d >> 16);
-}
-
-/* vb[r][c] = sign(sum) * (15*|sum| + mag), 0 when sum == 0 (carry reset); interior pixels only */
-__global__ __launch_bounds__(256) void k_pre_contrast(const int16_t *__restrict__ yb, size_t y_stride, int16_t *__restrict__ kb, size_t k_stride)
-{
-	const int r = blockIdx.x + 1, img = blockIdx.y, t = threadIdx.x;
-	const int16_t *y = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
-	int16_t *km = (int16_t *)((uint8_t *)kb + (size_t)img * k_stride);
-	for (int c = 2 * t; c <= 2 * t + 1; c++) {
-		if (c < 1 || c > W - 2) continue;
-		const int16_t *p = y + r * W + c;
-		const int ctr = p[0];
-		int sum = 0, mag = 0;
-#pragma unroll
-		for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-			for (int dx = -1; dx <= 1; dx++) {
-				if (!dy && !dx) continue;
-				const int d = ctr - p[dy * W + dx];
-				sum += d; mag += iabs(d);
-			}
-		const int base = 15 * iabs(sum) + mag;
-		km[r * W + c] = (int16_t)(sum == 0 ? 0 : (sum < 0 ? -base : base));
-	}
-}
-
 __device__ __forceinline__ void fsm_step16(uint64_t &m0, uint64_t &m1, int vb)
 {
 	if (vb == 0) { m0 = 0; m1 = 0; return; }
@@ -213,148 +183,6 @@ __device__ __forceinline__ void fsm_step16(uint64_t &m0, uint64_t &m1, int vb)
 	m1 = ((((m1 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
 }
 
-/* one lane per (image, row): transfer map of the row */
-__global__ __launch_bounds__(256) void k_pre_rowmap(const int16_t *__restrict__ kb, size_t k_stride, uint64_t *__restrict__ maps, size_t m_stride, int n)
-{
-	const int id = blockIdx.x * 256 + threadIdx.x;
-	if (id >= n * (W - 2)) return;
-	const int img = id / (W - 2), r = id % (W - 2) + 1;
-	const int16_t *km = (const int16_t *)((const uint8_t *)kb + (size_t)img * k_stride) + r * W;
-	uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
-	for (int c8 = 0; c8 < W; c8 += 8) {
-		const uint4 v = *reinterpret_cast<const uint4 *>(km + c8);
-		const int16_t *s = reinterpret_cast<const int16_t *>(&v);
-#pragma unroll
-		for (int k = 0; k < 8; k++) {
-			const int c = c8 + k;
-			if (c >= 1 && c <= W - 2) fsm_step16(m0, m1, s[k]);
-		}
-	}
-	uint64_t *o = (uint64_t *)((uint8_t *)maps + (size_t)img * m_stride) + 2 * r;
-	o[0] = m0; o[1] = m1;
-}
-
-/* one lane per image: chain the row maps -> start state of every row */
-__global__ void k_pre_chain(const uint64_t *__restrict__ maps, size_t m_stride, uint8_t *__restrict__ st, size_t s_stride, int n)
-{
-	const int img = blockIdx.x * blockDim.x + threadIdx.x;
-	if (img >= n) return;
-	const uint64_t *m = (const uint64_t *)((const uint8_t *)maps + (size_t)img * m_stride);
-	uint8_t *s = st + (size_t)img * s_stride;
-	int state = 0;
-	for (int r = 1; r <= W - 2; r++) {
-		s[r] = (uint8_t)state;
-		const uint64_t w = m[2 * r + (state >> 3)];
-		state = (int)((w >> (8 * (state & 7))) & 15);
-	}
-}
-
-/* one lane per (image, row): replay the carry from the known start state; kmap replaces vb in place */
-__global__ __launch_bounds__(256) void k_pre_kmap(int16_t *__restrict__ kb, size_t k_stride, const uint8_t *__restrict__ st, size_t s_stride, int n)
-{
-	const int id = blockIdx.x * 256 + threadIdx.x;
-	if (id >= n * (W - 2)) return;
-	const int img = id / (W - 2), r = id % (W - 2) + 1;
-	int16_t *km = (int16_t *)((uint8_t *)kb + (size_t)img * k_stride) + r * W;
-	int carry = (st + (size_t)img * s_stride)[r];
-	for (int c8 = 0; c8 < W; c8 += 8) {
-		uint4 v = *reinterpret_cast<const uint4 *>(km + c8);
-		int16_t *s = reinterpret_cast<int16_t *>(&v);
-#pragma unroll
-		for (int k = 0; k < 8; k++) {
-			const int c = c8 + k;
-			if (c < 1 || c > W - 2) continue;
-			const int vb = s[k];
-			if (vb == 0) { carry = 0; }
-			else {
-				const int acc = iabs(vb) + ((carry + 2) >> 2);
-				s[k] = (int16_t)(vb < 0 ? -(acc >> 4) : (acc >> 4));
-				carry = acc & 15;
-			}
-		}
-		*reinterpret_cast<uint4 *>(km + c8) = v;
-	}
-}
-
-/* flag handed from one pixel pair to the next in raster order (image_processing.c:1927-1990, `a`) */
-__device__ __forceinline__ int pair_big_flag(int k0, int k1)
-{
-	if (((k0 < 32 && k0 > 10) || (k0 > -32 && k0 < -10)) && iabs(k1) >= 23) return 0;
-	if (k1 < 32 && k1 >= 16) return iabs(k0) >= 23;
-	if (k1 > -32 && k1 <= -16) return iabs(k0) >= 23;
-	return 0;
-}
-
-/* one lane per pixel pair (c, c+1), c odd */
-__global__ __launch_bounds__(256) void k_pre_pairs(int16_t *__restrict__ yb, size_t y_stride, const int16_t *__restrict__ kb, size_t k_stride)
-{
-	const int r = blockIdx.x + 1, img = blockIdx.y, t = threadIdx.x;
-	if (t >= (W - 2) / 2) return;
-	const int c = 1 + 2 * t;
-	int16_t *o = (int16_t *)((uint8_t *)yb + (size_t)img * y_stride) + r * W + c;
-	const int16_t *km = (const int16_t *)((const uint8_t *)kb + (size_t)img * k_stride);
-	const int k0 = km[r * W + c], k1 = km[r * W + c + 1];
-	int prev_big = 0;
-	if (t > 0) prev_big = pair_big_flag(km[r * W + c - 2], km[r * W + c - 1]);
-	else if (r > 1) prev_big = pair_big_flag(km[(r - 1) * W + W - 3], km[(r - 1) * W + W - 2]);
-	int o0 = o[0], o1 = o[1], tag;
-
-	if (k0 > 201) { o0 -= 2; tag = 4; }
-	else if (k0 < -201) { o0 += 2; tag = 3; }
-	else if (k0 > 176) { o0--; tag = 2; }
-	else if (k0 < -176) { o0++; tag = 1; }
-	else tag = 0;
-	if (k1 > 201) { if (!tag || tag == 3) o1 -= 2; else if (tag != 4) o1--; }
-	else if (k1 < -201) { if (!tag || tag == 4) o1 += 2; else if (tag != 3) o1++; }
-	else if (k1 > 176) { if (tag != 4) o1--; }
-	else if (k1 < -176) { if (tag != 3) o1++; }
-
-	bool done = false;
-	if (k0 < 32 && k0 > 10) {
-		if (iabs(k1) >= 23) {
-			if (k0 < 16) { if (k1 > 0 && k1 < 32 && k0 > 11) o1++; o0++; }
-			else o0 += prev_big ? 1 : 2;
-			done = true;
-		}
-	} else if (k0 > -32 && k0 < -10) {
-		if (iabs(k1) >= 23) {
-			if (k0 > -16) { if (k1 < 0 && k1 > -32 && k0 < -11) o1--; o0--; }
-			else o0 -= prev_big ? 1 : 2;
-			done = true;
-		}
-	}
-	if (!done) {
-		if (k1 < 32 && k1 > 10) {
-			if (iabs(k0) >= 23) {
-				if (k1 < 16) { if (k0 > 0 && k0 < 32 && k1 > 11) o0++; o1++; }
-				else o1 += 2;
-			}
-		} else if (k1 > -32 && k1 < -10) {
-			if (iabs(k0) >= 23) {
-				if (k1 > -16) { if (k0 < 0 && k0 > -32 && k1 < -11) o0--; o1--; }
-				else o1 -= 2;
-			}
-		}
-	}
-	o[0] = (int16_t)o0; o[1] = (int16_t)o1;
-}
-
-/* ------------------------------------------------------------------------------------------------
- * 5/3 filterbank
- * ------------------------------------------------------------------------------------------------ */
-__device__ __forceinline__ int tap5(const int16_t *x, int n, int k)
-{
-	const int c = 2 * k;
-	const int l1 = c >= 1 ? x[c - 1] : x[1], l2 = c >= 2 ? x[c - 2] : x[2];
-	const int r1 = x[c + 1], r2 = (c + 2 < n) ? x[c + 2] : x[n - 2];
-	return 6 * x[c] + 2 * (l1 + r1) - (l2 + r2);
-}
-__device__ __forceinline__ int pair_predict(const int16_t *x, int k)
-{
-	int a = x[2 * k] + x[2 * k + 2];
-	if ((k & 1) && (a & 1) && ((x[2 * k - 2] + x[2 * k]) & 1)) a++;
-	return x[2 * k + 1] - (a >> 1);
-}
 __device__ __forceinline__ int rnd_half_away(int v, int shift)
 {
 	const int half = 1 << (shift - 1);
@@ -365,76 +193,6 @@ __device__ __forceinline__ int diffuse(int r)
 	if (r >= 0) { const int m = r & 63; return m < 32 ? (m >> 2) : -((64 - m) >> 2); }
 	const int m = (-r) & 63;
 	return m < 32 ? -(m >> 2) : ((64 - m) >> 2);
-}
-
-/* analysis of rows [0, rows) of a size x size block: one lane per output pair (lo[k], hi[k]).
- * PASS 1: un-normalised taps (first direction).  PASS 2: second direction; rows below size/2 are
- * low-pass in the first direction and get the /64 low-pass with the one-tap error diffusion and the /8
- * high-pass, rows from size/2 on get /16 and /2. */
-template <int PASS>
-__global__ __launch_bounds__(256) void k_ana_rows(const int16_t *__restrict__ src, int16_t *__restrict__ dst, size_t plane_stride, int stride, int size)
-{
-	const int hlf = size >> 1;
-	const int k = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, img = blockIdx.z;
-	if (k >= hlf) return;
-	const int16_t *x = src + (size_t)img * plane_stride + (size_t)row * stride;
-	int16_t *o = dst + (size_t)img * plane_stride + (size_t)row * stride;
-	int lo, hi;
-	if (PASS == 1) {
-		lo = tap5(x, size, k);
-		hi = k < hlf - 1 ? (x[2 * k + 1] << 1) - (x[2 * k] + x[2 * k + 2]) : ((x[size - 1] - x[size - 2]) << 1);
-	} else if (row < hlf) {
-		const int r = tap5(x, size, k);
-		const int carry = k > 0 ? diffuse(tap5(x, size, k - 1)) : 0;
-		lo = rnd_half_away((int16_t)(r + carry), 6);
-		hi = k < hlf - 1 ? rnd_half_away(pair_predict(x, k), 3) : ((x[size - 1] - x[size - 2]) >> 3);
-	} else {
-		lo = rnd_half_away(tap5(x, size, k), 4);
-		if (k < hlf - 1) { const int r = pair_predict(x, k); hi = r > 0 ? (r + 1) >> 1 : r >> 1; }
-		else hi = ((x[size - 1] - x[size - 2]) + 1) >> 1;
-	}
-	o[k] = (int16_t)lo;
-	o[hlf + k] = (int16_t)hi;
-}
-
-/* dst[i][j] = src[j][i] for i, j < size; 64x64 tiles through LDS */
-__global__ __launch_bounds__(256) void k_transpose(const int16_t *__restrict__ src, int16_t *__restrict__ dst, size_t plane_stride, int stride, int size)
-{
-	__shared__ int16_t tile[64][65];
-	const int img = blockIdx.z, bx = blockIdx.x * 64, by = blockIdx.y * 64;
-	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-	const int16_t *s = src + (size_t)img * plane_stride;
-	int16_t *d = dst + (size_t)img * plane_stride;
-	for (int j = ty; j < 64; j += 4)
-		if (by + j < size && bx + tx < size) tile[j][tx] = s[(size_t)(by + j) * stride + bx + tx];
-	__syncthreads();
-	for (int j = ty; j < 64; j += 4)
-		if (bx + j < size && by + tx < size) d[(size_t)(bx + j) * stride + by + tx] = tile[tx][j];
-}
-
-/* synthesis of one direction: out[2k], out[2k+1] from lo[k..k+1], hi[k-1..k+1] */
-template <int NORMALISE>
-__global__ __launch_bounds__(256) void k_syn_rows(const int16_t *__restrict__ src, int16_t *__restrict__ dst, size_t plane_stride, int stride, int size)
-{
-	const int m = size >> 1;
-	const int k = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, img = blockIdx.z;
-	if (k >= m) return;
-	const int16_t *lo = src + (size_t)img * plane_stride + (size_t)row * stride, *hi = lo + m;
-	int16_t *out = dst + (size_t)img * plane_stride + (size_t)row * stride;
-	const int ln = (k + 1 < m) ? lo[k + 1] : lo[k];
-	const int hp = k > 0 ? hi[k - 1] : hi[0];
-	const int hn = (k + 1 < m) ? hi[k + 1] : hi[k];
-	int16_t e = (int16_t)(lo[k] << 3);
-	int16_t o = (int16_t)((lo[k] + ln) << 2);
-	e = (int16_t)(e - ((hi[k] + hp) << 1));
-	o = (int16_t)(o + (6 * hi[k] - hp - hn));
-	if (NORMALISE) {
-		if (e > 0) e = (int16_t)(e + 32);
-		e >>= 6;
-		if (o > 0) o = (int16_t)(o + 32);
-		o >>= 6;
-	}
-	reinterpret_cast<uint32_t *>(out)[k] = (uint32_t)(uint16_t)e | ((uint32_t)(uint16_t)o << 16);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -455,54 +213,46 @@ __global__ __launch_bounds__(256) void k_syn_rows(const int16_t *__restrict__ sr
 #define FB_LOOK 12                  /* pixels of look-back for a segment's entry state (all 16 states have merged within 8 for 99.9 % of the segments) */
 #define FB_NT 512                   /* threads per band: the 78 KB of LDS allow two bands per CU, eight wavefronts each keep the SIMDs fed */
 
-__device__ __forceinline__ int contrast_at(const int16_t *p /* LDS, row stride FB_RS */)
-{
-	const int ctr = p[0];
-	int sum = 0, mag = 0;
-#pragma unroll
-	for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-		for (int dx = -1; dx <= 1; dx++) {
-			if (!dy && !dx) continue;
-			const int d = ctr - p[dy * FB_RS + dx];
-			sum += d; mag += iabs(d);
-		}
-	const int base = 15 * iabs(sum) + mag;
-	return sum == 0 ? 0 : (sum < 0 ? -base : base);
-}
-
 /* pre-pass: per row the 16-state transfer map of the carry across the row and, for each of the 16 entry states, the hand-over
  * flag of the row's last pixel pair (509, 510) -- what k_front_chain needs to walk down the rows.  The carry forgets its past
  * within a few pixels (see k_front_band: measured, all 16 states merge within 16 pixels, 99.9 % within 8), so the RT_LOOK pixels
  * before pixel 509 decide both: if the states have merged by then, map and flags are the same for every entry state.  Otherwise
  * (rare) the lane walks the whole row.  One lane per row. */
 #define RT_LOOK 24
-__global__ __launch_bounds__(64) void k_front_rowtail(const int16_t *__restrict__ yb, size_t y_stride, uint64_t *__restrict__ maps, size_t m_stride,
+/* The luma plane does not exist in HBM any more (the band kernel converts its rows itself): this pre-pass converts the last 32 pixels of
+ * every row from the BGR bytes (and, on the rare full-row fallback, every pixel it walks over). */
+template <int FAMILY>
+__global__ __launch_bounds__(64) void k_front_rowtail(const uint8_t *__restrict__ bgr, float yq, uint64_t *__restrict__ maps, size_t m_stride,
                                                       uint16_t *__restrict__ flags, size_t f_stride, int force_full)
 {
 	__shared__ __attribute__((aligned(16))) int16_t tail[66][40];      /* rows r0-1 .. r0+64, columns 480..511 (+ padding: 80-byte rows) */
 	const int img = blockIdx.y, r0 = 1 + blockIdx.x * 64, row = r0 + threadIdx.x;
-	const int16_t *yi = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
+	const uint8_t *src = bgr + (size_t)img * (W * W * 3);
 	for (int k = threadIdx.x; k < 66 * 4; k += 64) {
 		const int rr = k >> 2, o = k & 3, gr = r0 - 1 + rr;
-		uint4 v = make_uint4(0, 0, 0, 0);
-		if (gr >= 0 && gr < W) v = *reinterpret_cast<const uint4 *>(yi + (size_t)gr * W + 480 + 8 * o);
-		*reinterpret_cast<uint4 *>(&tail[rr][8 * o]) = v;
+		uint32_t y4[4] = { 0, 0, 0, 0 };
+		if (gr >= 0 && gr < W) {
+			uint8_t px[24];
+			const uint2 *q8 = reinterpret_cast<const uint2 *>(src + (size_t)gr * (W * 3) + (480 + 8 * o) * 3);
+#pragma unroll
+			for (int j = 0; j < 3; j++) { const uint2 w = q8[j]; for (int b = 0; b < 4; b++) { px[8 * j + b] = (uint8_t)(w.x >> (8 * b)); px[8 * j + 4 + b] = (uint8_t)(w.y >> (8 * b)); } }
+#pragma unroll
+			for (int e = 0; e < 8; e++) y4[e >> 1] |= (uint32_t)(uint16_t)convert_y<FAMILY>(px + 3 * e, yq) << (16 * (e & 1));
+		}
+		*reinterpret_cast<uint4 *>(&tail[rr][8 * o]) = make_uint4(y4[0], y4[1], y4[2], y4[3]);
 	}
 	__syncthreads();
 	if (row > W - 2) return;
-	const int16_t *y = yi + (size_t)row * W;
 	uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
 	int v509 = 0, v510 = 0;
-	/* the walk over columns c .. W-2 of one row; p[0] is column `co` of that row, rs the row stride of the buffer p points into */
-	auto walk = [&](const int16_t *p, const int rs, int c, const int co) {
+	/* the walk over columns c .. W-2 of one row; px(dr, col) = luma of row `row + dr`, column col */
+	auto walk = [&](auto px, int c) {
 		m0 = 0x0706050403020100ull; m1 = 0x0F0E0D0C0B0A0908ull;
-		int i = c - co;
 		/* 3x3 window slides along the row: three new reads per pixel */
-		int u0 = p[-rs + i - 1], u1 = p[-rs + i], m_0 = p[i - 1], m_1 = p[i], d0 = p[rs + i - 1], d1 = p[rs + i];
+		int u0 = px(-1, c - 1), u1 = px(-1, c), m_0 = px(0, c - 1), m_1 = px(0, c), d0 = px(1, c - 1), d1 = px(1, c);
 		int cs0 = u0 + m_0 + d0, cs1 = u1 + m_1 + d1;
-		for (; c <= W - 2; c++, i++) {
-			const int u2 = p[-rs + i + 1], m_2 = p[i + 1], d2 = p[rs + i + 1];
+		for (; c <= W - 2; c++) {
+			const int u2 = px(-1, c + 1), m_2 = px(0, c + 1), d2 = px(1, c + 1);
 			const int cs2 = u2 + m_2 + d2;
 			const int sum = 9 * m_1 - (cs0 + cs1 + cs2);
 			const int mag = (int)sad_u32(m_1, u0, sad_u32(m_1, u1, sad_u32(m_1, u2, sad_u32(m_1, m_0, sad_u32(m_1, m_2, sad_u32(m_1, d0, sad_u32(m_1, d1, sad_u32(m_1, d2, 0u))))))));
@@ -519,8 +269,9 @@ __global__ __launch_bounds__(64) void k_front_rowtail(const int16_t *__restrict_
 	/* first the staged tail (LDS, columns 480..511); the rare row whose carry has not merged by pixel 509 walks the whole row in HBM.
 	 * force_full is a test switch that sends every row down that fallback.  Two call sites so that each keeps its own address space. */
 	bool merged = false;
-	if (!force_full) merged = walk(&tail[threadIdx.x + 1][4], 40, W - 3 - RT_LOOK, 484);
-	if (!merged) walk(y + 1, W, 1, 1);
+	const int tl = threadIdx.x + 1;
+	if (!force_full) merged = walk([&](int dr, int col) { return (int)tail[tl + dr][col - 480]; }, W - 3 - RT_LOOK);
+	if (!merged) walk([&](int dr, int col) { return convert_y<FAMILY>(src + (size_t)(row + dr) * (W * 3) + 3 * col, yq); }, 1);
 	unsigned f = 0;
 	for (int e = 0; e < 16; e++) {
 		const int s509 = (int)(((e < 8 ? a0 : a1) >> (8 * (e & 7))) & 15), s510 = (int)(((e < 8 ? b0 : b1) >> (8 * (e & 7))) & 15);
@@ -563,29 +314,105 @@ __device__ __forceinline__ void row_window(const int16_t *row, int c0, int v[12]
 }
 
 __device__ unsigned long long g_band_stamp[16];
-#define STAMP(i) do { if (t == 0 && blockIdx.x == 7 && blockIdx.y == 100) g_band_stamp[i] = wall_clock64(); } while (0)
+#define STAMP(i) do { if (t == 0 && blockIdx.x == 3207) g_band_stamp[i] = wall_clock64(); } while (0)
 
-template <int PRE>
-__global__ __launch_bounds__(FB_NT) void k_front_band(const int16_t *__restrict__ yb, size_t y_stride, const uint8_t *__restrict__ st, size_t s_stride,
+/* THE fused front kernel: colour conversion + 4:2:0 + (q <= 21) pre-filter + both directions of the level-1 analysis in one launch
+ * (colorspace.c:55-260 + image_processing.c:558-837, 1927-1990 + wavelet_filterbank.c:52-184): the BGR bytes of the 39 rows a band
+ * of 16 output rows needs come in with 16-byte loads (48 bytes = 16 pixels per lane and step), are converted in registers, and the
+ * luma lands in LDS where the old kernel used to stage it from HBM -- the luma plane never travels.  The same lane filters the chroma
+ * of its 16 pixels horizontally ([1 2 1]/4 at the even pixels; the pixel on its left is converted once more for that) and parks the
+ * bytes in the LDS rows the contrast values will occupy later; a second step filters them vertically and writes the band's 16 rows
+ * of the two 4:2:0 planes.  SRC 0: the luma comes from a plane in HBM instead (quality 1..16: its pre-filter is a walk of its own,
+ * nhw_low.hip).
+ * The workgroup -> (image, band) mapping keeps the bands of an image on one XCD: hardware deals consecutive workgroup ids round-robin
+ * over the 8 XCDs, each with an L2 of its own, and a band shares 7 of its 39 input rows with its neighbours. */
+template <int PRE, int SRC, int FAMILY>
+__global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ srcb, size_t src_stride, float yq, uint8_t *__restrict__ pub, uint8_t *__restrict__ pvb, size_t c_stride,
+                                                    const uint8_t *__restrict__ st, size_t s_stride,
                                                     int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
-                                                    int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride, int force_fixup)
+                                                    int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride, int force_fixup, int n_img)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	__shared__ uint8_t entry[FB_TROWS * 8];
 	__shared__ uint8_t stl[FB_TROWS];
 	int16_t *ybuf = smem;                                          /* FB_YROWS rows */
 	int16_t *kbuf = smem + FB_YROWS * FB_RS;                       /* FB_TROWS rows */
-	const int band = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
+	const int t = threadIdx.x;
+	/* XCD-aware order: workgroup w runs on XCD w % 8; the w / 8-th workgroup of XCD x takes work item x * (total / 8) + w / 8, so that the
+	 * items of one XCD are consecutive (image-major, band-minor) */
+	int band, img;
+	{
+		const int nb = H / FB_KB, total = nb * n_img, w = blockIdx.x;
+		const int per = total >> 3;                                 /* total is a multiple of 32 */
+		const int item = (total & 7) ? w : (w & 7) * per + (w >> 3);
+		img = item / nb; band = item % nb;
+	}
 	const int k0 = FB_KB * band, t0 = 2 * k0 - 4;                  /* first horizontal-pass row (may be negative) */
-	const int16_t *y = (const int16_t *)((const uint8_t *)yb + (size_t)img * y_stride);
 
 	STAMP(0);
-	for (int k = t; k < FB_YROWS * (W / 8); k += FB_NT) {            /* stage rows t0-1 .. t0+37 */
-		const int ry = k / (W / 8), o = k % (W / 8), row = t0 - 1 + ry;
-		uint4 v = make_uint4(0, 0, 0, 0);
-		if (row >= 0 && row < W) v = reinterpret_cast<const uint4 *>(y + (size_t)row * W)[o];
-		uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 8 * o);
-		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+	if (SRC == 0) {
+		const int16_t *y = (const int16_t *)((const uint8_t *)srcb + (size_t)img * src_stride);
+		for (int k = t; k < FB_YROWS * (W / 8); k += FB_NT) {        /* stage rows t0-1 .. t0+37 */
+			const int ry = k / (W / 8), o = k % (W / 8), row = t0 - 1 + ry;
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (row >= 0 && row < W) v = reinterpret_cast<const uint4 *>(y + (size_t)row * W)[o];
+			uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 8 * o);
+			d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+		}
+	} else {
+		const uint8_t *src = (const uint8_t *)srcb + (size_t)img * (W * W * 3);
+		uint8_t *hu = reinterpret_cast<uint8_t *>(kbuf) + 4, *hv = hu + (2 * FB_KB + 1) * H;   /* 33 rows x 256 bytes each: full-resolution rows 2k0-1 .. 2k0+31 (+4: kbuf starts 12 bytes behind a 16-byte boundary) */
+		for (int k = t; k < FB_YROWS * (W / 16); k += FB_NT) {       /* rows t0-1 .. t0+37, 16 pixels per item */
+			const int ry = k / (W / 16), g = k % (W / 16), row = t0 - 1 + ry;
+			uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 16 * g);
+			if (row < 0 || row >= W) { for (int e = 0; e < 8; e++) d[e] = 0; continue; }
+			const uint8_t *rp = src + (size_t)row * (W * 3) + 48 * g;
+			const uint4 q0 = reinterpret_cast<const uint4 *>(rp)[0], q1 = reinterpret_cast<const uint4 *>(rp)[1], q2 = reinterpret_cast<const uint4 *>(rp)[2];
+			const uint32_t wv[12] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w };
+			uint8_t px[48];
+#pragma unroll
+			for (int b = 0; b < 48; b++) px[b] = (uint8_t)(wv[b >> 2] >> (8 * (b & 3)));
+			uint32_t yw[8];
+#pragma unroll
+			for (int e = 0; e < 16; e++) {
+				const uint32_t yv = (uint32_t)(uint16_t)convert_y<FAMILY>(px + 3 * e, yq);
+				if (e & 1) yw[e >> 1] |= yv << 16; else yw[e >> 1] = yv;
+			}
+#pragma unroll
+			for (int e = 0; e < 8; e++) d[e] = yw[e];
+			const int cr = row - (2 * k0 - 1);                         /* row of the chroma staging area */
+			if (cr >= 0 && cr <= 2 * FB_KB) {
+				int U[17], V[17];                                       /* pixel 16g - 1 (for the filter's left tap), then the 16 own ones */
+				if (g) convert_uv<FAMILY>(rp - 3, yq, U[0], V[0]); else { U[0] = 0; V[0] = 0; }
+#pragma unroll
+				for (int e = 0; e < 16; e++) convert_uv<FAMILY>(px + 3 * e, yq, U[e + 1], V[e + 1]);
+				uint32_t hu2[2] = { 0, 0 }, hv2[2] = { 0, 0 };
+#pragma unroll
+				for (int j = 0; j < 8; j++) {                           /* output column 8g + j = even pixel 16g + 2j (colorspace.c:220-234) */
+					int fu, fv;
+					if (g == 0 && j == 0) { fu = (U[1] + U[2] + 1) >> 1; fv = (V[1] + V[2] + 1) >> 1; }
+					else { fu = (U[2 * j] + 2 * U[2 * j + 1] + U[2 * j + 2] + 2) >> 2; fv = (V[2 * j] + 2 * V[2 * j + 1] + V[2 * j + 2] + 2) >> 2; }
+					hu2[j >> 2] |= (uint32_t)fu << (8 * (j & 3)); hv2[j >> 2] |= (uint32_t)fv << (8 * (j & 3));
+				}
+				*reinterpret_cast<uint2 *>(hu + cr * H + 8 * g) = make_uint2(hu2[0], hu2[1]);
+				*reinterpret_cast<uint2 *>(hv + cr * H + 8 * g) = make_uint2(hv2[0], hv2[1]);
+			}
+		}
+		__syncthreads();
+		/* vertical [1 2 1]/4 over full-resolution rows 2r-1, 2r, 2r+1 (colorspace.c:241-256; row 0: (r0 + r1 + 1) >> 1), four columns per item */
+		uint8_t *pu = pub + (size_t)img * c_stride, *pv = pvb + (size_t)img * c_stride;
+		for (int k = t; k < 2 * FB_KB * (H / 4); k += FB_NT) {
+			const int pl = k / (FB_KB * (H / 4)), rem = k % (FB_KB * (H / 4)), rr = rem / (H / 4), c4 = rem % (H / 4), r = k0 + rr;
+			const uint8_t *hb = (pl ? hv : hu) + 2 * rr * H + 4 * c4;
+			const uint32_t a = *reinterpret_cast<const uint32_t *>(hb), b = *reinterpret_cast<const uint32_t *>(hb + H), c = *reinterpret_cast<const uint32_t *>(hb + 2 * H);
+			uint32_t o = 0;
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const int x0 = (a >> (8 * e)) & 255, x1 = (b >> (8 * e)) & 255, x2 = (c >> (8 * e)) & 255;
+				o |= (uint32_t)(r == 0 ? (x1 + x2 + 1) >> 1 : (x0 + 2 * x1 + x2 + 2) >> 2) << (8 * e);
+			}
+			*reinterpret_cast<uint32_t *>((pl ? pv : pu) + r * H + 4 * c4) = o;
+		}
 	}
 	if (PRE) {                                                     /* the rows' entry states ride along with the luma rows */
 		if (t < FB_TROWS && t0 + t >= 1 && t0 + t <= W - 2) stl[t] = (st + (size_t)img * s_stride)[t0 + t];
@@ -850,27 +677,16 @@ __global__ void k_synth(uint8_t *__restrict__ bgr, int n, uint32_t seed_base)
 /* ------------------------------------------------------------------------------------------------ launchers */
 using namespace nhw;
 
+static float color_yq(int q, int *family);
 void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_stride, uint8_t *u, uint8_t *v, size_t c_stride, hipStream_t s)
 {
 	const dim3 grid(H / 4, n);
-	if (q >= 20) k_color<0><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, 0.f);
-	else if (q >= 18) k_color<1><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, q == 19 ? 0.975f : 0.93f);
-	else if (q == 17) k_color<2><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, 0.f);
-	else {                                                         /* quality table of colorspace.c:174-189 (format constants) */
-		static const int k_qtz[17] = { 0, 15900, 16500, 17100, 18000, 18820, 19670, 20640, 21540, 23540, 25570, 27522, 27830, 27607, 28786, 31262, 32375 };
-		k_color<3><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, __builtin_bit_cast(float, k_qtz[q < 1 ? 1 : q]));
-	}
-}
-
-void nhw_launch_prefilter(int16_t *y, size_t y_stride, int16_t *kmap, size_t k_stride, uint64_t *maps, size_t m_stride,
-                          uint8_t *st, size_t s_stride, int n, hipStream_t s)
-{
-	const int rows = n * (W - 2);
-	k_pre_contrast<<<dim3(W - 2, n), 256, 0, s>>>(y, y_stride, kmap, k_stride);
-	k_pre_rowmap<<<(rows + 255) / 256, 256, 0, s>>>(kmap, k_stride, maps, m_stride, n);
-	k_pre_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, st, s_stride, n);
-	k_pre_kmap<<<(rows + 255) / 256, 256, 0, s>>>(kmap, k_stride, st, s_stride, n);
-	k_pre_pairs<<<dim3(W - 2, n), 256, 0, s>>>(y, y_stride, kmap, k_stride);
+	int fam = 0;
+	const float yq = color_yq(q, &fam);
+	if (fam == 0) k_color<0><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, yq);
+	else if (fam == 1) k_color<1><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, yq);
+	else if (fam == 2) k_color<2><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, yq);
+	else k_color<3><<<grid, 256, 0, s>>>(bgr, y, y_stride, u, v, c_stride, yq);         /* quality table of colorspace.c:174-189 (format constants) */
 }
 
 /* keep != nullptr: copy of the first 256 rows x 512 of the transposed pass-1 plane (q>=22, level 0) */
@@ -1093,53 +909,60 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
 	if (!save) save_kind = 0;
 	if (size == 256 && !keep) { dwt_lds_attr<256>(); k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n); return; }
 	if (size == 128 && !keep) { dwt_lds_attr<128>(); k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n); return; }
-	const int hlf = size >> 1;
-	const dim3 rg((hlf + 255) / 256, size, n), tg((size + 63) / 64, (size + 63) / 64, n);
-	k_ana_rows<1><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
-	k_transpose<<<tg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, size);
-	if (keep)
-		hipMemcpy2DAsync(keep, keep_stride * sizeof(int16_t), jpeg, plane_stride * sizeof(int16_t), 2 * Q * sizeof(int16_t), n, hipMemcpyDeviceToDevice, s);
-	k_ana_rows<2><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
-	if (!final_level) {
-		const dim3 lg((hlf + 63) / 64, (hlf + 63) / 64, n);
-		k_transpose<<<lg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, hlf);
-	}
-	if (save_kind == 1) nhw_launch_copy_block(proc, plane_stride, stride, save, save_plane, save_row, size, size, n, s);
-	else if (save_kind == 2) nhw_launch_copy_block(jpeg, plane_stride, stride, save, save_plane, save_row, hlf, hlf, n, s);
+	(void)keep; (void)keep_stride;       /* size 512 is the band kernel's (nhw_launch_front_fused); nothing else is called with another size */
 }
 
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s)
 {
 	if (size == 256) { dwt_lds_attr<256>(); k_dwt_syn<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n); return; }
 	if (size == 128) { dwt_lds_attr<128>(); k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n); return; }
-	const int hlf = size >> 1;
-	const dim3 rg((hlf + 255) / 256, size, n), tg((size + 63) / 64, (size + 63) / 64, n);
-	k_syn_rows<0><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
-	k_transpose<<<tg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, size);
-	k_syn_rows<1><<<rg, 256, 0, s>>>(jpeg, proc, plane_stride, stride, size);
-	k_transpose<<<tg, 256, 0, s>>>(proc, jpeg, plane_stride, stride, size);
 }
 
-/* fused pre-filter + level-1 analysis (+ LL copy-back, ll1, keep): replaces nhw_launch_prefilter + the size-512 nhw_launch_analysis
- * + the ll1 block copy of the batch driver */
-void nhw_launch_front_fused(const int16_t *y, size_t y_stride, int with_prefilter, uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
+/* the front launch group: [k_front_rowtail + k_front_chain for q 17..21] + k_front_band.
+ * bgr != nullptr: quality 17..23, everything from the BGR bytes (colour, 4:2:0 planes pu / pv, pre-filter, level-1 analysis);
+ * bgr == nullptr: the luma plane y is the input (quality 1..16 behind their own pre-filter; the stage entry point) */
+static float color_yq(int q, int *family)
+{
+	static const int k_qtz[17] = { 0, 15900, 16500, 17100, 18000, 18820, 19670, 20640, 21540, 23540, 25570, 27522, 27830, 27607, 28786, 31262, 32375 };
+	if (q >= 20) { *family = 0; return 0.f; }
+	if (q >= 18) { *family = 1; return q == 19 ? 0.975f : 0.93f; }
+	if (q == 17) { *family = 2; return 0.f; }
+	*family = 3;
+	return __builtin_bit_cast(float, k_qtz[q < 1 ? 1 : q]);
+}
+void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv, size_t c_stride, const int16_t *y, size_t y_stride, int with_prefilter,
+                            uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
                             uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
                             int16_t *keep, size_t keep_stride, int n, hipStream_t s, int force_fallback)
 {
 	const size_t lds = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
 	static bool attr_set = false;
 	if (!attr_set) {
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<0, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		attr_set = true;
 	}
-	const dim3 grid(H / FB_KB, n);
+	const dim3 grid((H / FB_KB) * n);
+	if (!bgr) {
+		k_front_band<0, 0, 0><<<grid, FB_NT, lds, s>>>(y, y_stride, 0.f, nullptr, nullptr, 0, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, 0, n);
+		return;
+	}
+	int fam = 0;
+	const float yq = color_yq(q, &fam);
 	if (with_prefilter) {
-		k_front_rowtail<<<dim3((W - 2 + 63) / 64, n), 64, 0, s>>>(y, y_stride, maps, m_stride, flags, f_stride, force_fallback);
+		const dim3 rg((W - 2 + 63) / 64, n);
+		if (fam == 0) k_front_rowtail<0><<<rg, 64, 0, s>>>(bgr, yq, maps, m_stride, flags, f_stride, force_fallback);
+		else if (fam == 1) k_front_rowtail<1><<<rg, 64, 0, s>>>(bgr, yq, maps, m_stride, flags, f_stride, force_fallback);
+		else k_front_rowtail<2><<<rg, 64, 0, s>>>(bgr, yq, maps, m_stride, flags, f_stride, force_fallback);
 		k_front_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, flags, f_stride, st, s_stride, n);
-		k_front_band<1><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback);
+		if (fam == 0) k_front_band<1, 1, 0><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback, n);
+		else if (fam == 1) k_front_band<1, 1, 1><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback, n);
+		else k_front_band<1, 1, 2><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback, n);
 	} else
-		k_front_band<0><<<grid, FB_NT, lds, s>>>(y, y_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, 0);
+		k_front_band<0, 1, 0><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, 0, n);
 }
 
 /* Compatibility mode (NHW_COMPAT_GLIBC_ONESHOT) only: the kernel-map cells whose memory the stock binary's malloc hands out again as

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_L4B) luma_p4b_par(&c, tid, sh_pos, dyn_lds);
 	else if (PH == PH_L4C) luma_p4c_par(&c, tid, sh_pos, dyn_lds);
 	else if (PH == PH_L4D) luma_p4d_par(&c, tid, sh_counts, sh_z, dyn_lds);
-	else if (PH == PH_L4C2) luma_p4c2_par(&c, tid);
+	else if (PH == PH_L4C2) luma_p4c2_par(&c, tid, reinterpret_cast<unsigned *>(sh_z), sh_pos);
 	else if (PH == PH_DQ1L) dequant_sim_luma_par(&c, 1, tid, sh_pos);
 	else if (PH == PH_DQ0L) dequant_sim_luma_par(&c, 0, tid, sh_pos);
 	else if (PH == PH_QL) { PROF_BEGIN(); quantise_luma_low_par(&c, tid, sh_z, reinterpret_cast<uint8_t *>(sh_pos), dyn_lds); if (!tid) PROF(&c, 15); }

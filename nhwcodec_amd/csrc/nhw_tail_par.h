@@ -323,28 +323,6 @@ struct MarkRunsStep {
 	}
 };
 
-/* quantiser: the same marking with the quantiser's codes (image_processing.c:241-284), rows 0..255 */
-struct QuantMarkStep {
-	int16_t *p;
-	__device__ int first(int) const { return 1; }
-	__device__ int last(int) const { return H - 1; }
-	__device__ int run(int r, int j) const
-	{
-		const int a = r * W + j;
-		if (p[a] > 3 && p[a] < 8) {
-			if (in_4_7(p[a - 1])) {
-				if (in_4_7(p[a + 1])) { p[a] = 12700; p[a - 1] = 10100; j++; }
-				else if (in_4_7(p[a + W - 1]) && in_4_7(p[a + W])) { p[a - 1] = 12100; p[a] = 10100; p[a + W - 1] = 10100; p[a + W] = 10100; j++; }
-			}
-		} else if (p[a] < -3 && p[a] > -8) {
-			if (in_m7_m4(p[a - 1])) {
-				if (in_m7_m4(p[a + 1])) { p[a] = 12900; p[a - 1] = 10100; j++; }
-				else if (in_m7_m4(p[a + W - 1]) && in_m7_m4(p[a + W])) { p[a - 1] = 12200; p[a] = 10100; p[a + W - 1] = 10100; p[a + W] = 10100; j++; }
-			}
-		}
-		return j + 1;
-	}
-};
 
 /* the LL2 walk shared by the dequantiser simulation (image_processing.c:2642-2695) and the LL2 emission
  * (nhw_encoder.c:661-741): three odd samples in a row bump the middle one, an odd L-shaped group bumps the
@@ -990,54 +968,6 @@ struct QuantPairsF {                                          /* image_processin
 		return j;
 	}
 };
-struct QuantPair567F {                                        /* image_processing.c:286-311 */
-	struct State { int unused; };
-	__device__ State init(int) const { return State{0}; }
-	__device__ int run(int16_t *row, int, int j, int j1, State &) const
-	{
-		for (; j < j1; j++) {
-			if (is_567(row[j])) { if (is_567(row[j + 1])) { row[j] = 10300; j++; } }
-			else if (is_m567(row[j])) { if (is_m567(row[j + 1])) { row[j] = 10204; j++; } }
-		}
-		return j;
-	}
-};
-struct QuantCodeF {                                           /* image_processing.c:314-519 */
-	const int16_t *plane; int rs;
-	struct State { int next_first; };
-	__device__ State init(int t) const { return State{ plane[(size_t)(t + 1) * rs] }; }   /* first cell of the next row, before anybody rewrites it (:389 looks at it unguarded) */
-	__device__ int run(int16_t *row, int, int j, int j1, State &st) const
-	{
-		for (; j < j1; j++) {
-			int a = row[j];
-			const int nx = j < W - 1 ? row[j + 1] : st.next_first;
-			if (a > 10000) {
-				if (a == 10100) { row[j] = 128; continue; }
-				else if (a == 12700) { row[j] = 127; continue; }
-				else if (a == 12900) { row[j] = 129; continue; }
-				else if (a == 10204) { row[j] = 125; continue; }
-				else if (a == 10300) { row[j] = 126; continue; }
-				else if (a == 12100) { row[j] = 121; continue; }
-				else if (a == 12200) { row[j] = 122; continue; }
-			}
-			if (a > 127) { row[j] = (int16_t)big_code(a, k_big_pos); continue; }
-			else if (a < -127) { row[j] = (int16_t)big_code(-a, k_big_neg); continue; }
-			if (a < -12 && ((-a) & 7) == 6) { if (j < W - 1 && nx == -7) row[j + 1] = -9; }
-			if (a < 0) {
-				if (a == -7 && nx == 8 && j < W - 1) { row[j] = -8; a = -8; }
-				a = -a;
-				if (a > 14 && (a & 7) == 7 && nx > 0 && nx < 8) a -= 2;
-				if ((a & 7) < 7) a &= 504;
-				a = -a;
-			}
-			else if (a == 8 && nx == -7 && j < W - 1) row[j + 1] = -8;
-			else if (a > 12 && (a & 7) >= 6) { if (j < W - 1 && nx == 7) row[j + 1] = 9; }
-			if (a < DEADZONE && a > -DEADZONE) row[j] = 128;
-			else row[j] = (int16_t)((a + 128) & 248);
-		}
-		return j;
-	}
-};
 /* ---- quality 1..16 (image_processing.c:357-410, :427-510) ----
  * Two things change in the main loop.  (1) The low bits of negative magnitudes are rationed per row (ration_low_bits): local to a row.
  * (2) `quant4`: of the pairs of neighbours that both sit on x6/x7 (>= 14) in a detail band, every third one -- counted through the WHOLE
@@ -1162,25 +1092,6 @@ DEV void quantise_luma_low_par(Ctx *c, int tid, uint32_t *maps /* shared, 512 wo
 	}
 }
 
-/* offsetY.  Loops 1, 3, 4 reach at most two cells ahead in their own row: tiled row passes.  Loop 2 marks cells of
- * the next row: skewed wavefront. */
-DEV void quantise_luma_par(Ctx *c, int tid, int *pos, int16_t *lds)
-{
-	int16_t *p = c->proc;
-	row_pass_tiled(p, W, W, H, 0, H, H, W, lds, tid, QuantPairsF{});               /* rows 0..255: detail columns only */
-	row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, QuantPairsF{});       /* rows 256..511 */
-	{                                                  /* :241-284 (wavefront) */
-		QuantMarkStep st = { p };
-		wavefront_rows(H, tid, pos, st);
-	}
-	BARRIER();
-	row_pass_tiled(p, W, W, H, 0, H, 0, H - 1, lds, tid, QuantPair567F{});
-	{
-		QuantCodeF f0 = { p, W }, f1 = { p + H * W, W };
-		row_pass_tiled(p, W, W, H, 0, H, 0, W, lds, tid, f0);
-		row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, f1);
-	}
-}
 
 /* offsetUV (image_processing.c:108-183): pairs never span rows; the look at the next cell is unguarded at the
  * end of a row, so the first cell of the next row is read before any row is rewritten */
@@ -1473,24 +1384,6 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 }
 
 
-/* ---------------------------------------------------------------- chroma pieces */
-DEV void dequant_row_chroma(int16_t *p, int16_t *jp, int r, int col0, int comp)
-{
-	for (int j = col0; j < H / 2; j++) {
-		const int at = r * H + j;
-		int a = p[at];
-		if ((a == -7 || a == -8) && !comp) {
-			if (j < H / 2 - 1 && (p[at + 1] == -7 || p[at + 1] == -8)) { jp[at] = -11; jp[at + 1] = -11; j++; continue; }
-		}
-		if (a < 0) {
-			a = -a;
-			if (p[at + 1] < 0 && p[at + 1] > -8) { if ((a & 7) < 6) a &= 0xFFF8; }
-			else { if ((a & 7) < 7) a &= 0xFFF8; }
-			a = -a;
-		}
-		jp[at] = (int16_t)dequant_value(a);
-	}
-}
 /* offsetUV_recons256 (image_processing.c:3192-3353): p is only read, every row writes its own jp cells */
 DEV void dequant_sim_chroma_par(Ctx *c, int comp, int tid)
 {
@@ -1533,73 +1426,6 @@ DEV void dequant_sim_chroma_par(Ctx *c, int comp, int tid)
 	}
 }
 
-/* Y14 + Y15 (nhw_encoder.c:636-741): tag rows of four odd samples (R), walk the LL2 band (wavefront), then turn
- * the parked samples into the byte plane, the res4 lists (per row, prefix-summed) and the escape triples.
- * Escapes (samples outside 0..255) make a byte repeat its predecessor, which is a serial chain: they are rare,
- * thread 0 replays the band only if one occurred. */
-DEV void emit_ll2_par(Ctx *c, int tid, int *pos, int *sh_misc)
-{
-	int16_t *p = c->proc;
-	const int q = c->q;
-	int my_n = 0;
-	if (q > 17 && tid < H / 2) {                                  /* tag_res4, one row per thread */
-		const int r = tid;
-		int hit = 0;
-		for (int j = 0; j < H / 2 - 3; j++) {
-			const int a = r * W + j;
-			if (odd(p[a]) && odd(p[a + 1]) && odd(p[a + 2]) && odd(p[a + 3]) && iabs(p[a] - p[a + 3]) > 1) {
-				p[a] += 24000; p[a + 1] += 16000; p[a + 2] += 16000; p[a + 3] += 16000;
-				hit++; j += 3;
-			}
-		}
-		my_n = hit ? hit : 1;
-	}
-	if (tid == 0) sh_misc[0] = 0;
-	BARRIER();
-	LL2Step<1> st = { p, c->jpeg, c->tmp16, q, 0 };
-	wavefront_rows(H / 2, tid, pos, st);
-	BARRIER();
-	pos[tid] = my_n;                                             /* res4 offsets: exclusive scan of the per-row counts */
-	BARRIER();
-	if (tid == 0) { int acc = 0; for (int t = 0; t < H / 2; t++) { const int v = pos[t]; pos[t] = acc; acc += v; } c->m->res4_len = q > 17 ? acc : 0; }
-	BARRIER();
-	if (tid < H / 2) {
-		const int r = tid;
-		int o4 = pos[r], hit = 0, esc = 0;
-		for (int j = 0; j < H / 2; j++) {
-			int s = c->tmp16[r * (H / 2) + j];
-			const int a = r * (H / 2) + j;
-			if (q > 17 && s > 10000) {
-				if (s > 20000) { s -= 24000; c->res4[o4++] = (uint8_t)(j + 1); hit++; }
-				else s -= 16000;
-				c->tmp16[a] = (int16_t)s;                         /* the replay below wants the plain value */
-			}
-			if ((s > 255 || s < 0) && (j > 0 || r > 0)) esc++;
-			else { if (s > 255) s = 255; else if (s < 0) s = 0; c->ll_full[a] = (uint8_t)s; c->ll_bytes[a] = (uint8_t)(s & 254); }
-		}
-		if (q > 17) { if (!hit) c->res4[o4] = 128; else c->res4[o4 - 1] += 128; }
-		if (esc) atomicAdd(&sh_misc[0], esc);
-	}
-	BARRIER();
-	if (tid == 0) {
-		int e = 0;
-		if (sh_misc[0]) {
-			for (int a = 1; a < Q / 4; a++) {
-				const int s = c->tmp16[a];
-				if (s > 255 || s < 0) {
-					int mag;
-					c->exw[e++] = (uint8_t)(a >> 7);
-					if (s > 255) { c->exw[e++] = (uint8_t)((a & 127) + 128); mag = s - 255; }
-					else { c->exw[e++] = (uint8_t)(a & 127); mag = -s; }
-					c->exw[e++] = (uint8_t)(mag > 255 ? 255 : mag);
-					c->ll_bytes[a] = c->ll_bytes[a - 1]; c->ll_full[a] = c->ll_bytes[a - 1];
-				}
-			}
-		}
-		c->m->exw_len = e;
-	}
-	BARRIER();
-}
 
 /* Y25 (nhw_encoder.c:1498-1887): the three compaction sweeps over the code plane run one row per thread (count,
  * prefix, write); packing the (short) lists stays on thread 0 */
@@ -2258,10 +2084,132 @@ DEV void luma_p4c_par(Ctx *c, int tid, int *pos, int16_t *lds)
 	clean_details_par(c, tid, lds);                                         /* Y27 */
 	if (!tid) PROF(c, 14);
 }
-DEV void luma_p4c2_par(Ctx *c, int tid)                                     /* Y29 (q > 21 only; Y28 runs between the two as a wave kernel) */
+/* Y29 (q > 21): im_recons_wavelet_band (image_processing.c:523-556) + wavelet_synthesis_high_quality_settings
+ * (wavelet_filterbank.c:498-707), workgroup-parallel.
+ *
+ * band_recons walks the quantised LH1 band (rows < 256, columns 256..511) in raster order and writes the decoder's value of every cell
+ * into a compact 256 x 256 plane through a running index t: a zero code advances t, a plain code writes b[t++], a triple mark (127 /
+ * 129) writes b[t-1], b[t], b[t+1], advances t by TWO and skips the next cell.  A skipped cell is exactly the second step of the
+ * mark, so t stays the cell's linear index -- except behind a mark in the LAST column of a row, whose skip has no cell to eat: from
+ * there on everything sits one slot further.  A thread takes a row: the cells a walk visits are every second one of each run of marks
+ * (serial along the row), the row's base index is 256 r + the number of such row-end marks above it (prefix sum), and the three
+ * writes that cross a row boundary are ordered by hand: (r, 255)'s b[t+1] before row r+1 writes, (r, 0)'s b[t-1] after row r-1 has. */
+DEV int band_value(int a)
+{
+	if ((a & 7) != 0) { const int k = (a >= 0 && a < 109) ? big_index(a) : 0; return k > 0 ? 123 + (k << 3) : (k << 3) - 123; }
+	return a > 128 ? a - 125 : a - 131;
+}
+DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *sh /* [2 * NT + 2] */)
 {
 	PROF_BEGIN();
-	if (c->q > 21 && tid == 0) { band_recons(c); hq_settings(c); }
+	const int q = c->q;
+	if (q <= 21) return;
+	const int16_t *p = c->proc;
+	int16_t *b = c->band;
+	for (int i = tid; i < Q / 8; i += NT) reinterpret_cast<uint4 *>(b)[i] = make_uint4(0, 0, 0, 0);
+	const int r = tid;
+	const int16_t *row = p + (size_t)r * W + H;
+	/* does the walk of my row end in a mark on its last cell?  (visited cells: every second one of a run of marks) */
+	int end_mark = 0;
+	{
+		bool skip = false;
+		for (int j = 0; j < H; j++) {
+			const int a = row[j];
+			const bool mark = !skip && (a == 127 || a == 129);
+			if (mark && j == H - 1) end_mark = 1;
+			skip = mark;
+		}
+	}
+	unsigned tot;
+	const int base = r * H + (int)block_exscan((unsigned)end_mark, tid, shm, &tot);
+	BARRIER();
+	if (end_mark) b[base + H] = (int16_t)(row[H - 1] == 127 ? 5 : -5);        /* b[t+1] of a mark in column 255: the first slot of the next row, which may still overwrite it */
+	BARRIER();
+	int back = 0;                                                              /* b[t-1] of a mark in column 0: the slot before my row */
+	{
+		bool skip = false;
+		for (int j = 0; j < H; j++) {
+			const int a = row[j], t = base + j;
+			if (skip) { skip = false; continue; }
+			if (a == 128) continue;
+			if (a == 127 || a == 129) {
+				const int16_t e = (int16_t)(a == 127 ? 5 : -5);
+				if (j) b[t - 1] = e; else back = e;
+				b[t] = (int16_t)(a == 127 ? 6 : -7);
+				if (j < H - 1) b[t + 1] = e;
+				skip = true;
+			}
+			else b[t] = (int16_t)band_value(a);
+		}
+	}
+	BARRIER();
+	if (back && base > 0) b[base - 1] = (int16_t)back;
+	BARRIER();
+
+	/* half synthesis of the kept first-order LL + that band against the original pass-1 plane (:509-541): pointwise */
+	int16_t *hs = c->hs;
+	const int thr = q > 22 ? 30 : 34;
+	for (int idx = tid; idx < Q; idx += NT) {
+		const int rr = idx >> 8, k = idx & 255;
+		const int16_t *lo = c->first_order + rr * H, *hi = b + rr * H;
+		const int ln = k + 1 < H ? lo[k + 1] : lo[k];
+		const int hp = k > 0 ? hi[k - 1] : hi[0], hn = k + 1 < H ? hi[k + 1] : hi[k];
+		int16_t o[2];
+		o[0] = (int16_t)((int16_t)(lo[k] << 3) - ((hi[k] + hp) << 1));
+		o[1] = (int16_t)((int16_t)((lo[k] + ln) << 2) + (6 * hi[k] - hp - hn));
+		for (int e = 0; e < 2; e++) {
+			const int i = rr * W + 2 * k + e, d = c->keep[i] - o[e];
+			if (iabs(d) > thr) o[e] = (int16_t)((q > 22 && iabs(d) > 56) ? (d > 0 ? 32000 : 32500) : (d > 0 ? 30000 : 31000));
+		}
+		*reinterpret_cast<uint32_t *>(hs + rr * W + 2 * k) = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+	}
+	BARRIER();
+	if (q > 22) {                                                              /* :547-564, 512 consecutive cells per thread */
+		unsigned cnt = 0;
+		const int i0 = tid * (2 * Q / NT);
+		for (int i = i0; i < i0 + 2 * Q / NT; i++) cnt += hs[i] == 32000 || hs[i] == 32500;
+		unsigned at = block_exscan(cnt, tid, shm, &tot);
+		for (int i = i0; i < i0 + 2 * Q / NT; i++) {
+			if (hs[i] == 32000) c->qsetting3[at++] = (uint32_t)(i << 1);
+			else if (hs[i] == 32500) c->qsetting3[at++] = (uint32_t)(i << 1) + 1;
+		}
+		if (tid == 0) c->m->qsetting3_len = (int)tot;
+		BARRIER();
+	}
+	else if (tid == 0) c->m->qsetting3_len = 0;
+	/* the position list of the 30000 / 31000 cells (:571-610): a row per thread; columns 254, 255 and 510, 511 are a row mark each, the
+	 * first pair reported through char_res1 instead */
+	uint8_t *raw = c->raw, *pay = c->pay;
+	{
+		const int16_t *hr = hs + (size_t)r * W;
+		unsigned n = 2, e = 0, nc = 0;
+		for (int j = 0; j < W; j++) {
+			if (j == H - 2 || j == W - 2) {
+				if (j == H - 2) { nc += (hr[j] == 30000 || hr[j] == 31000); nc += (hr[j + 1] == 30000 || hr[j + 1] == 31000); }
+				j++;
+			}
+			else if (hr[j] == 30000 || hr[j] == 31000) { n++; e++; }
+		}
+		unsigned tn, te, tc;
+		unsigned an = block_exscan(n, tid, shm, &tn);
+		unsigned ae = block_exscan(e, tid, shm, &te);
+		unsigned ac = block_exscan(nc, tid, shm, &tc);
+		for (int j = 0; j < W; j++) {
+			if (j == H - 2 || j == W - 2) {
+				raw[an++] = H - 2;
+				if (j == H - 2) {
+					if (hr[j] == 30000) c->char_res1[ac++] = (uint16_t)(r * H); else if (hr[j] == 31000) c->char_res1[ac++] = (uint16_t)(r * H + 1);
+					if (hr[j + 1] == 30000) c->char_res1[ac++] = (uint16_t)(r * H + 2); else if (hr[j + 1] == 31000) c->char_res1[ac++] = (uint16_t)(r * H + 3);
+				}
+				j++;
+			}
+			else if (hr[j] == 30000) { raw[an++] = (uint8_t)(j & 255); pay[ae++] = 0; }
+			else if (hr[j] == 31000) { raw[an++] = (uint8_t)(j & 255); pay[ae++] = 1; }
+		}
+		if (tid == 0) { c->m->char_res1_len = (int)tc; sh[0] = (int)tn; sh[1] = (int)te; }
+		BARRIER();
+	}
+	poslist_finish_par(c, &c->res6, raw, sh[0], pay, sh[1], 1, tid, shm);
 	BARRIER();
 	if (!tid) PROF(c, 16);
 }

@@ -493,11 +493,9 @@ struct M8 { uint64_t w[8]; };
 DEV M8 operator&(M8 a, M8 b) { M8 r; for (int k = 0; k < 8; k++) r.w[k] = a.w[k] & b.w[k]; return r; }
 DEV M8 operator|(M8 a, M8 b) { M8 r; for (int k = 0; k < 8; k++) r.w[k] = a.w[k] | b.w[k]; return r; }
 DEV M8 operator~(M8 a) { M8 r; for (int k = 0; k < 8; k++) r.w[k] = ~a.w[k]; return r; }
-DEV M8 m8_zero() { M8 r; for (int k = 0; k < 8; k++) r.w[k] = 0; return r; }
 DEV M8 up1(M8 a, unsigned in = 0) { M8 r; r.w[0] = (a.w[0] << 1) | in; for (int k = 1; k < 8; k++) r.w[k] = (a.w[k] << 1) | (a.w[k - 1] >> 63); return r; }
 DEV M8 dn1(M8 a) { M8 r; for (int k = 0; k < 7; k++) r.w[k] = (a.w[k] >> 1) | (a.w[k + 1] << 63); r.w[7] = a.w[7] >> 1; return r; }
 DEV M8 dn2(M8 a) { M8 r; for (int k = 0; k < 7; k++) r.w[k] = (a.w[k] >> 2) | (a.w[k + 1] << 62); r.w[7] = a.w[7] >> 2; return r; }
-DEV M8 col_range8(int lo, int hi) { M8 r; for (int k = 0; k < 8; k++) r.w[k] = low_bits(hi + 1 - 64 * k) & ~low_bits(lo - 64 * k); return r; }
 DEV M8 alt_runs(M8 f)
 {
 	const uint64_t even = 0x5555555555555555ull;
@@ -542,16 +540,6 @@ DEV void quant_load_row(const int16_t *p, int r, int lane, int *v)
 	for (int k = 0; k < 8; k++) v[k] = r < W ? p[r * W + lane + 64 * k] : 0;       /* the cell behind the plane reads as 0 (zero guard) */
 }
 
-DEV int quant_symbol(int a, int nx)                               /* :375-396 + :515-518 for a cell that is no code and no big value */
-{
-	if (a < 0) {
-		a = -a;
-		if (a > 14 && (a & 7) == 7 && nx > 0 && nx < 8) a -= 2;
-		if ((a & 7) < 7) a &= 504;
-		a = -a;
-	}
-	return (a < DEADZONE && a > -DEADZONE) ? 128 : ((a + 128) & 248);
-}
 
 /* The symbols go straight into the stream in its serpentine order (Y30, nhw_encoder.c:2108-2132: 128 strips of 4 columns,
  * within a strip row after row, odd rows right to left): 16 rows are parked as bytes in a wave-private LDS block and

@@ -82,8 +82,10 @@ def test_colour_exhaustive_all_2_24_triples(enc, oracle, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [17, 20, 21])
+@pytest.mark.parametrize("q", [1, 6, 9, 10, 14, 16])
 def test_prefilter_matches_oracle(enc, oracle, q):
+    """The pre-filter is a stage of its own for quality 1..16 (k_low_prefilter, the kernel the encoder runs); for 17..21 it lives inside
+    the fused front kernel (test_fused_front_matches_oracle)."""
     import torch
     imgs = [oracle.synth(3), class_image("noise", 1), class_image("blocks", 2), class_image("flat")]
     ys = np.stack([oracle.color(im, q)[0] for im in imgs])
@@ -111,7 +113,11 @@ def test_filterbank_matches_oracle(enc, oracle, stride, size, final):
         oj, op = oracle.analysis(planes[i], stride, size, final)
         m = np.zeros((stride, stride), bool); m[:size, :size] = True
         assert np.array_equal(gp[i].reshape(stride, stride)[m], op.reshape(stride, stride)[m]), "coefficients"
+        if size == 512:     # the band kernel (the product's level-1 kernel) leaves only what is read afterwards: the LL quadrant
+            m[:] = False; m[:256, :256] = True
         assert np.array_equal(gj[i].reshape(stride, stride)[m], oj.reshape(stride, stride)[m]), "transposed plane / LL copy-back"
+    if size == 512:
+        return              # the encoder has no synthesis of that size
     # synthesis of small coefficients (decoder-simulation path of the encoder)
     coef = rng.integers(-40, 300, (2, stride * stride)).astype(np.int16)
     j, p = _cuda(coef), _cuda(np.zeros_like(coef))
@@ -126,10 +132,11 @@ def test_filterbank_matches_oracle(enc, oracle, stride, size, final):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [17, 20, 21, 22, 23])
+@pytest.mark.parametrize("q", [17, 18, 19, 20, 21, 22, 23])
 def test_fused_front_matches_oracle(oracle, q):
-    """Fused pre-filter + level-1 analysis band kernel: coefficient plane, LL copy-back, ll1 and (q>=22) the kept
-    transposed horizontal-pass plane, against the oracle's stage functions, on smooth, noisy and blocky inputs."""
+    """The fused front kernel (colour + 4:2:0 + pre-filter + level-1 analysis from the BGR bytes): coefficient plane, LL copy-back, ll1, the two
+    4:2:0 chroma planes and (q>=22) the kept transposed horizontal-pass plane, against the oracle's stage functions, on smooth, noisy
+    and blocky inputs."""
     import ctypes
     import torch
     import nhwcodec_amd
@@ -144,7 +151,8 @@ def test_fused_front_matches_oracle(oracle, q):
         assert e.lib.nhw_debug_read(e.h, buf, i, ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(nbytes)) == 0
         return out.view(np.int16)
     for i, im in enumerate(imgs):
-        y = oracle.color(im, q)[0]
+        y, u, v = oracle.color(im, q)
+        assert np.array_equal(rd(2, i, 65536).view(np.uint8), u.ravel()) and np.array_equal(rd(3, i, 65536).view(np.uint8), v.ravel()), f"image {i}: 4:2:0 planes"
         if q < 22:
             y = oracle.prefilter(y, q)
         oj, op, ok = oracle.analysis(y, 512, 512, 0, keep=True)
