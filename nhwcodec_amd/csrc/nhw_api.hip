@@ -31,7 +31,8 @@ enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
 enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2, PH_DQ1L, PH_DQ0L, PH_QL, PH_L4DL };
 /* quality 1..16 only (nhw_low.hip) */
-void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int q, int n, hipStream_t s);
+void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
+                              int q, int n, hipStream_t s);
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s);
 void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipStream_t s);
 void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s);
@@ -179,7 +180,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	if (low) {
 		nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
 		STAGE_DONE();
-		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, q, n, s);
+		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], q, n, s);   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser */
 		STAGE_DONE();
 		nhw_launch_front_fused(nullptr, q, nullptr, nullptr, 0, yin, yin_stride, 0, nullptr, 0, nullptr, 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
 		                       proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n, s, 0);
@@ -492,7 +493,7 @@ extern "C" int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, vo
 	const NhwWs &ws = e->ws;
 	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
 	/* in place for the caller: filter into the workspace plane the encoder uses, copy back */
-	nhw_launch_low_prefilter((const int16_t *)d_y, 4 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP] / 2, quality, n, s);
+	nhw_launch_low_prefilter((const int16_t *)d_y, 4 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP] / 2, plane16(ws, B_PROC), ws.stride[B_PROC] / 2, plane8(ws, B_SCAN), ws.stride[B_SCAN], quality, n, s);
 	HIPCHK(hipMemcpy2DAsync(d_y, 8 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP], 8 * Q, (size_t)n, hipMemcpyDeviceToDevice, s));
 	HIPCHK(hipGetLastError());
 	return NHW_OK;

@@ -22,13 +22,21 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "nhw_ws.h"
 
 #define DEVI __device__ static __forceinline__
+#define PF_LOOK 16         /* pixels of look-back for a lane's entry state of the carry (the 16 states have merged within 16 for everything measured; a row where they have not is replayed serially) */
 
 namespace {
 
 DEVI int iabs_(int v) { return v < 0 ? -v : v; }
+
+/* The chain walks below are executed by the whole wavefront on wave-uniform values: what comes out of LDS goes through
+ * v_readfirstlane, so counters and cursors live in scalar registers and every branch is a scalar branch (a lone lane inside a
+ * divergent region pays an exec-mask save / restore and a vector compare per branch: measured 4x slower); stores are issued by lane 0. */
+#define LDK(p) __builtin_amdgcn_readfirstlane((int)*(p))
+#define STK(p, v) do { if (threadIdx.x == 0) *(p) = (v); } while (0)
 
 /* ------------------------------------------------------------------------------------------------ parameters (:570-598) */
 struct PfP { int sharp, s2, half, smooth_hi, smooth, tail_rules; };
@@ -48,61 +56,73 @@ DEVI PfP pf_params(int q)
 /* ------------------------------------------------------------------------------------------------ pass A: contrast map (:601-764) */
 struct MapState { int carry, neg_run, neg_cycle, pos_run, pos_cycle, pos_alt, pos_neg_alt, exact_count, bump_count; };
 
-/* one row; sum/mag: the 8-neighbour sum and sum of magnitudes of every interior pixel (computed by all lanes), k: the map row */
-DEVI void map_row(MapState &s, const PfP &pp, const int16_t *sum, const int16_t *mag, int16_t *k)
+/* The carry itself (4 bits, reset where the sum is zero) is the machine the quality 17..21 pre-filter has too: its past is forgotten within
+ * a dozen pixels, so every lane finds the entry state of its 8 pixels by running all 16 states through the 12 pixels before them (one
+ * SWAR step per pixel on two 64-bit words) and replays its own 8 -- no walk along the row.  What IS order-dependent below quality 17 is
+ * the marker rule: it fires only on borderline pixels (sum not above the threshold, carried value above it), on the first three values
+ * that hit the threshold from below and on the first value of threshold + 21; those few pixels are visited in raster order by one lane,
+ * everything else is written by the lanes that computed it. */
+DEVI void fsm_step16(uint64_t &m0, uint64_t &m1, int vb)
+{
+	if (vb == 0) { m0 = 0; m1 = 0; return; }
+	const uint64_t add = (uint64_t)(iabs_(vb) & 15) * 0x0101010101010101ull;
+	m0 = ((((m0 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
+	m1 = ((((m1 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
+}
+/* one pixel of pass A behind the carry: sm = its 8-neighbour sum (non-zero), val = the signed carried value; k = the map row, c its column */
+DEVI void map_cell(MapState &s, const PfP &pp, int c, int sm, int val, int16_t *k)
 {
 	const int s2 = pp.s2;
-	for (int c = 1; c < W - 1; c++) {
-		const int sm = sum[c];
-		if (sm == 0) { k[c] = 0; s.carry = 0; continue; }
-		const int acc = 15 * iabs_(sm) + mag[c] + ((s.carry + 2) >> 2);
-		int val = acc >> 4;
-		s.carry = acc & 15;
-		if (sm < 0) {
-			val = -val;
-			if (val == -s2 && s.bump_count < 3) { val = -s2 - 1; s.bump_count++; }
-			if (-sm <= s2 && -val > s2 && -val <= s2 + 20) {          /* borderline: the plain sum is not above the threshold, the contrast is */
-				if (c > 1 && iabs_(k[c - 1]) <= pp.half) s.neg_run = 0;
-				if (!s.neg_run) { k[c] = -20000; s.neg_run = 1; }
-				else {
-					k[c] = (int16_t)val;
-					if (!s.neg_cycle) { s.neg_run = 0; s.neg_cycle = 1; }
-					else if (s.neg_run == 1) s.neg_run = 2;
-					else { s.neg_run = 0; s.neg_cycle = s.neg_cycle == 1 ? 2 : s.neg_cycle == 2 ? 3 : 0; }
-				}
+	if (sm < 0) {
+		if (val == -s2 && s.bump_count < 3) { val = -s2 - 1; s.bump_count++; }
+		if (-sm <= s2 && -val > s2 && -val <= s2 + 20) {          /* borderline: the plain sum is not above the threshold, the contrast is */
+			if (c > 1 && iabs_(LDK(k + c - 1)) <= pp.half) s.neg_run = 0;
+			if (!s.neg_run) { STK(k + c, (int16_t)(-20000)); s.neg_run = 1; }
+			else {
+				STK(k + c, (int16_t)((int16_t)val));
+				if (!s.neg_cycle) { s.neg_run = 0; s.neg_cycle = 1; }
+				else if (s.neg_run == 1) s.neg_run = 2;
+				else { s.neg_run = 0; s.neg_cycle = s.neg_cycle == 1 ? 2 : s.neg_cycle == 2 ? 3 : 0; }
 			}
-			else k[c] = (int16_t)val;
-		} else {
-			if (sm <= s2 && val > s2 && val <= s2 + 20) {
-				if (c > 1) {
-					const int left = k[c - 1];
-					if (iabs_(left) <= pp.half) s.pos_run = 0;
-					else if (iabs_(left) > 10000 || left == s2 + 21) {
+		}
+		else STK(k + c, (int16_t)((int16_t)val));
+	} else {
+		if (sm <= s2 && val > s2 && val <= s2 + 20) {
+			if (c > 1) {
+				const int left = LDK(k + c - 1);
+				if (iabs_(left) <= pp.half) s.pos_run = 0;
+				else if (iabs_(left) > 10000 || left == s2 + 21) {
+					if (!s.pos_alt) { s.pos_run = 0; if (!s.pos_cycle) s.pos_cycle = 1; s.pos_alt = 1; }
+					else s.pos_alt = 0;
+				}
+				else if (left == -(s2 + 21)) {
+					if (!s.pos_neg_alt) s.pos_neg_alt = 1;
+					else {
 						if (!s.pos_alt) { s.pos_run = 0; if (!s.pos_cycle) s.pos_cycle = 1; s.pos_alt = 1; }
 						else s.pos_alt = 0;
+						s.pos_neg_alt = s.pos_neg_alt == 1 ? 2 : 0;
 					}
-					else if (left == -(s2 + 21)) {
-						if (!s.pos_neg_alt) s.pos_neg_alt = 1;
-						else {
-							if (!s.pos_alt) { s.pos_run = 0; if (!s.pos_cycle) s.pos_cycle = 1; s.pos_alt = 1; }
-							else s.pos_alt = 0;
-							s.pos_neg_alt = s.pos_neg_alt == 1 ? 2 : 0;
-						}
-					}
-					else if (left == s2 + 22) k[c - 1] = 7000;
 				}
-				if (!s.pos_run) { k[c] = 20000; s.pos_run = 1; }
-				else {
-					k[c] = (int16_t)val;
-					if (!s.pos_cycle) { s.pos_run = 0; s.pos_cycle = 1; }
-					else if (s.pos_run == 1) s.pos_run = 2;
-					else { s.pos_run = 0; s.pos_cycle = s.pos_cycle == 1 ? 2 : s.pos_cycle == 2 ? 3 : 0; }
-				}
+				else if (left == s2 + 22) STK(k + c - 1, (int16_t)7000);
 			}
-			else if (val == s2 + 21) { k[c] = (int16_t)(s.exact_count ? val : 7000); s.exact_count++; }
-			else k[c] = (int16_t)val;
+			if (!s.pos_run) { STK(k + c, (int16_t)(20000)); s.pos_run = 1; }
+			else {
+				STK(k + c, (int16_t)((int16_t)val));
+				if (!s.pos_cycle) { s.pos_run = 0; s.pos_cycle = 1; }
+				else if (s.pos_run == 1) s.pos_run = 2;
+				else { s.pos_run = 0; s.pos_cycle = s.pos_cycle == 1 ? 2 : s.pos_cycle == 2 ? 3 : 0; }
+			}
 		}
+		else if (val == s2 + 21) { STK(k + c, (int16_t)((int16_t)(s.exact_count ? val : 7000))); s.exact_count++; }
+		else STK(k + c, (int16_t)((int16_t)val));
 	}
+}
+/* does pixel (sm, val) need the serial visit? */
+DEVI bool map_candidate(const PfP &pp, int sm, int val)
+{
+	const int s2 = pp.s2;
+	if (sm < 0) return val == -s2 || (-sm <= s2 && -val > s2 && -val <= s2 + 20);
+	return sm > 0 && ((sm <= s2 && val > s2 && val <= s2 + 20) || val == s2 + 21);
 }
 
 /* ------------------------------------------------------------------------------------------------ pass B: the pair machine (:770-1992) */
@@ -303,15 +323,15 @@ __device__ static void burst_idle(PfM &m)
 }
 
 /* one pixel pair (:838-1925).  km: the pair's map cells, o: the pair in the output row, so: the pair's flags */
-DEVI void machine_pair(PfM &m, const PfP &pp, int row, int &k0, int &k1, int16_t *km, int16_t *o, uint8_t *so)
+DEVI void machine_pair(PfM &m, const PfP &pp, int row, int &k0, int &k1, int16_t *km, int &d0, int &d1, uint8_t *so)
 {
 	const int sharp = pp.sharp, s2 = pp.s2;
 	if (!T(1)) {                                     /* first pair of a burst (:840-994) */
 		T(2) = 0;
 		if (iabs_(k0) > sharp) {
-			o[0] += k0 > 0 ? 2 : -2;
+			d0 += k0 > 0 ? 2 : -2;
 			if (iabs_(k1) > s2 || T(8) == 1) {
-				km[0] = 0;
+				STK(km, (int16_t)0);
 				if ((T(19) < 4 * Q || (T(20) >= 3 && T(20) < 4 * Q)) && iabs_(k0) > sharp + 96 && T(6) > 0 && row > 2) {
 					if (T(20) >= 3 && T(19) >= 8 * Q) { T(6) = 7000000; T(20) = 8 * Q; }
 					if (T(19) > 0 && T(19) < 4 * Q) {
@@ -333,21 +353,21 @@ DEVI void machine_pair(PfM &m, const PfP &pp, int row, int &k0, int &k1, int16_t
 					if (iabs_(k0) > 3000) k0 = k0 > 0 ? s2 + 5 : -s2 - 5;          /* a marker counts as just above the threshold */
 					if (iabs_(k1) > 3000) k1 = k1 > 0 ? s2 + 22 : -s2 - 22;
 					if (iabs_(k0) < (iabs_(k1) >> 2)) {
-						o[0] += k0 > 0 ? -1 : 1;
-						km[0] = (int16_t)k0;
-						o[1] += k1 > 0 ? 2 : -2;
-						if (iabs_(k0) > s2) km[1] = 0;
+						d0 += k0 > 0 ? -1 : 1;
+						STK(km, (int16_t)k0);
+						d1 += k1 > 0 ? 2 : -2;
+						if (iabs_(k0) > s2) STK(km + 1, (int16_t)0);
 					}
-					else o[1] += k1 > 0 ? 1 : -1;
+					else d1 += k1 > 0 ? 1 : -1;
 					T(3) = 1;
 				} else {
-					o[1] += k1 > 0 ? 2 : -2;
-					if (iabs_(k0) > s2) km[1] = 0;
+					d1 += k1 > 0 ? 2 : -2;
+					if (iabs_(k0) > s2) STK(km + 1, (int16_t)0);
 					T(3) = T(3) == 1 ? 2 : T(3) == 2 ? 3 : 0;
 				}
 			} else {
-				o[1] += k1 > 0 ? 2 : -2;
-				if (iabs_(k0) > s2) km[1] = 0;
+				d1 += k1 > 0 ? 2 : -2;
+				if (iabs_(k0) > s2) STK(km + 1, (int16_t)0);
 			}
 			if (T(14) == 2) { T(14) = 1; T(26) = 3; if (T(25) > 0) T(25)++; }
 			if (T(14) == 1) { if (T(26) < 4) T(26)++; else { T(14) = 2; T(26) = 0; } }
@@ -362,8 +382,8 @@ DEVI void machine_pair(PfM &m, const PfP &pp, int row, int &k0, int &k1, int16_t
 		}
 		T(1) = 1;
 	} else {                                         /* inside a burst (:995-1910) */
-		if (iabs_(k0) > sharp) { o[0] += k0 > 0 ? 1 : -1; T(1)++; T(4)++; }
-		if (iabs_(k1) > sharp) { o[1] += k1 > 0 ? 1 : -1; T(1)++; T(4)++; }
+		if (iabs_(k0) > sharp) { d0 += k0 > 0 ? 1 : -1; T(1)++; T(4)++; }
+		if (iabs_(k1) > sharp) { d1 += k1 > 0 ? 1 : -1; T(1)++; T(4)++; }
 
 		if (T(4) < 10) T(17) = (T(4) == T(10) && T(1) == T(11));
 		else if (T(4) > 10 || T(1) != 15) {
@@ -400,49 +420,58 @@ DEVI void machine_pair(PfM &m, const PfP &pp, int row, int &k0, int &k1, int16_t
 	}
 	/* opposite signs, both just above the threshold (:1912-1924) */
 	if (iabs_(k0) > sharp && iabs_(k0) <= sharp + 20 && iabs_(k1) > sharp && iabs_(k1) <= sharp + 20) {
-		if (k0 > 0 && k1 < 0) { o[0]++; o[1]--; so[0] = 2; so[1] = 3; }
-		else if (k0 < 0 && k1 > 0) { o[0]--; o[1]++; so[0] = 3; so[1] = 2; }
+		if (k0 > 0 && k1 < 0) { d0++; d1--; STK(so, (uint8_t)2); STK(so + 1, (uint8_t)3); }
+		else if (k0 < 0 && k1 > 0) { d0--; d1++; STK(so, (uint8_t)3); STK(so + 1, (uint8_t)2); }
 	}
 }
 #undef T
 #undef Wv
 
 /* pass B over one row */
+DEVI void tail_rules(int k0, int k1, int &prev_big, int &d0, int &d1)      /* :1927-1990, on the (possibly rewritten) pair values */
+{
+	if (k0 < 32 && k0 > 10) {
+		if (iabs_(k1) >= 23) {
+			if (k0 < 16) { if (k1 > 0 && k1 < 32 && k0 > 11) d1++; d0++; }
+			else d0 += prev_big ? 1 : 2;
+			prev_big = 0;
+			return;
+		}
+	} else if (k0 > -32 && k0 < -10) {
+		if (iabs_(k1) >= 23) {
+			if (k0 > -16) { if (k1 < 0 && k1 > -32 && k0 < -11) d1--; d0--; }
+			else d0 -= prev_big ? 1 : 2;
+			prev_big = 0;
+			return;
+		}
+	}
+	prev_big = 0;
+	if (k1 < 32 && k1 > 10) {
+		if (iabs_(k0) >= 23) {
+			if (k1 < 16) { if (k0 > 0 && k0 < 32 && k1 > 11) d0++; d1++; }
+			else { d1 += 2; prev_big = 1; }
+		}
+	} else if (k1 > -32 && k1 < -10) {
+		if (iabs_(k0) >= 23) {
+			if (k1 > -16) { if (k0 < 0 && k0 > -32 && k1 < -11) d0--; d1--; }
+			else { d1 -= 2; prev_big = 1; }
+		}
+	}
+}
+/* Runs on lane 0 alone, on the vector unit (plain loads: the counters stay in vector registers), while the marker walk below runs on the
+ * scalar unit: a CU has one of each, both issue one instruction per cycle, and its sixteen images are at different rows at any moment, so
+ * the two walks of different images overlap instead of queueing for one unit (both on the scalar unit: 471 ms per batch; split: see
+ * DESIGN.md). */
 DEVI void pair_row(PfM &m, int &prev_big, const PfP &pp, int r, int16_t *km, int16_t *y, uint8_t *so)
 {
+	int n0 = km[1], n1 = km[2];                                   /* the next pair's values are on their way while this one is worked on (a pair only ever rewrites its own two cells) */
 	for (int c = 1; c < W - 2; c += 2) {
-		int16_t *o = y + c;
-		int k0 = km[c], k1 = km[c + 1];
-		machine_pair(m, pp, r, k0, k1, km + c, o, so + c);
-		if (!pp.tail_rules) continue;
-		/* :1927-1990, on the (possibly rewritten) pair values */
-		if (k0 < 32 && k0 > 10) {
-			if (iabs_(k1) >= 23) {
-				if (k0 < 16) { if (k1 > 0 && k1 < 32 && k0 > 11) o[1]++; o[0]++; }
-				else o[0] += prev_big ? 1 : 2;
-				prev_big = 0;
-				continue;
-			}
-		} else if (k0 > -32 && k0 < -10) {
-			if (iabs_(k1) >= 23) {
-				if (k0 > -16) { if (k1 < 0 && k1 > -32 && k0 < -11) o[1]--; o[0]--; }
-				else o[0] -= prev_big ? 1 : 2;
-				prev_big = 0;
-				continue;
-			}
-		}
-		prev_big = 0;
-		if (k1 < 32 && k1 > 10) {
-			if (iabs_(k0) >= 23) {
-				if (k1 < 16) { if (k0 > 0 && k0 < 32 && k1 > 11) o[0]++; o[1]++; }
-				else { o[1] += 2; prev_big = 1; }
-			}
-		} else if (k1 > -32 && k1 < -10) {
-			if (iabs_(k0) >= 23) {
-				if (k1 > -16) { if (k0 < 0 && k0 > -32 && k1 < -11) o[0]--; o[1]--; }
-				else { o[1] -= 2; prev_big = 1; }
-			}
-		}
+		int k0 = n0, k1 = n1, d0 = 0, d1 = 0;
+		if (c + 2 < W - 2) { n0 = km[c + 2]; n1 = km[c + 3]; }
+		machine_pair(m, pp, r, k0, k1, km + c, d0, d1, so + c);
+		if (pp.tail_rules) tail_rules(k0, k1, prev_big, d0, d1);
+		if (d0) y[c] = (int16_t)(y[c] + d0);
+		if (d1) y[c + 1] = (int16_t)(y[c + 1] + d1);
 	}
 }
 
@@ -451,23 +480,27 @@ struct MarkState { int skip_toggle, second_toggle, pos0, neg0, pos1, neg1; };
 
 DEVI void resolve_marker(int16_t *cell, int v, int &pos_cnt, int &neg_cnt, int s2)
 {
-	if (v == 20000) { if (!pos_cnt) { *cell = 0; pos_cnt = 1; } else { *cell = 5000; pos_cnt = pos_cnt == 1 ? 2 : 0; } }
-	else if (v == -20000) { if (!neg_cnt) { *cell = 0; neg_cnt = 1; } else { *cell = -5000; neg_cnt = neg_cnt == 1 ? 2 : 0; } }
-	else if (v == 7000) *cell = (int16_t)(s2 + 22);
+	if (v == 20000) { if (!pos_cnt) { STK(cell, (int16_t)0); pos_cnt = 1; } else { STK(cell, (int16_t)5000); pos_cnt = pos_cnt == 1 ? 2 : 0; } }
+	else if (v == -20000) { if (!neg_cnt) { STK(cell, (int16_t)0); neg_cnt = 1; } else { STK(cell, (int16_t)-5000); neg_cnt = neg_cnt == 1 ? 2 : 0; } }
+	else if (v == 7000) STK(cell, (int16_t)(s2 + 22));
 }
+DEVI void bump(int16_t *yc, uint8_t *sc, int d) { STK(yc, (int16_t)(LDK(yc) + d)); STK(sc, (uint8_t)1); }
 /* strong pixel with a weak partner: nudge the strong one, the partner if it agrees in sign, and the two pixels above the pair */
 DEVI void sharpen_weak_partner(int strong, int weak, int16_t *ys, int16_t *yw, uint8_t *ss, uint8_t *sw,
                                const int16_t *kup, int16_t *yup, uint8_t *sup, bool have_up, bool no_retry)
 {
 	const int sg = strong > 0 ? 1 : -1;
-	*ys += sg; *ss = 1;
-	if ((sg > 0 && weak > 0) || (sg < 0 && weak < 0)) { *yw += 2 * sg; *sw = 1; }
+	bump(ys, ss, sg);
+	if ((sg > 0 && weak > 0) || (sg < 0 && weak < 0)) bump(yw, sw, 2 * sg);
 	if (have_up) {
-		const int a = kup[0] * sg, b = kup[-1] * sg;
-		if (a > 4) { yup[0] += sg; sup[0] = 1; }
-		if (b > 4) { yup[-1] += sg; sup[-1] = 1; }
-		if (a < -24 && no_retry) { yup[0] -= sg; sup[0] = 1; }
-		if (b < -24 && no_retry) { yup[-1] -= sg; sup[-1] = 1; }
+		const int a = LDK(kup) * sg, b = LDK(kup - 1) * sg;
+		int da = 0, db = 0;
+		if (a > 4) da += sg;
+		if (b > 4) db += sg;
+		if (a < -24 && no_retry) da -= sg;
+		if (b < -24 && no_retry) db -= sg;
+		if (da) bump(yup, sup, da);
+		if (db) bump(yup - 1, sup - 1, db);
 	}
 }
 /* one row: km / y / so of the row, kmu / yu / sou of the row above */
@@ -477,7 +510,7 @@ DEVI void marker_row(MarkState &s, const PfP &pp, int r, int16_t *km, int16_t *y
 	int idle = 0, retry = 0, idle_fresh = 0;
 	for (int c = 1; c < W - 3; c++) {
 		c++;
-		const int k0 = km[c - 1], k1 = km[c];
+		const int k0 = LDK(km + c - 1), k1 = LDK(km + c);
 		if (iabs_(k0) > 6000) {
 			resolve_marker(km + c - 1, k0, s.pos0, s.neg0, s2);
 			if (!s.second_toggle) { resolve_marker(km + c, k1, s.pos1, s.neg1, s2); s.second_toggle = 1; }
@@ -505,7 +538,7 @@ DEVI void marker_row(MarkState &s, const PfP &pp, int r, int16_t *km, int16_t *y
 			else if (retry == 1) {
 				c++; retry = 0; idle = 0;
 				if (idle_fresh == 4) {
-					if (iabs_(km[c - 5]) <= s2 || iabs_(km[c - 2]) <= s2) { c -= 5; retry = 2; }
+					if (iabs_(LDK(km + c - 5)) <= s2 || iabs_(LDK(km + c - 2)) <= s2) { c -= 5; retry = 2; }
 					idle_fresh = 0;
 				}
 			}
@@ -577,22 +610,26 @@ DEVI void final_row(const PfP &pp, const int16_t *km, int16_t *y, const uint8_t 
 } // namespace
 
 /* src: the luma plane as the colour kernel wrote it (read only); y: the filtered plane (every row is written) */
-__global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride, int q)
+__global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
+                                                      int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q, int dbg)
 {
 	__shared__ __attribute__((aligned(16))) int16_t s_src[3][W];
 	__shared__ __attribute__((aligned(16))) int16_t s_km[2][W + 8];
 	__shared__ __attribute__((aligned(16))) int16_t s_y[2][W];
 	__shared__ __attribute__((aligned(16))) uint8_t s_so[2][W];
-	__shared__ int16_t s_sum[W], s_mag[W];
+	__shared__ __attribute__((aligned(16))) int16_t s_sum[W], s_vb[W];
+	__shared__ int s_misc[4];
 	const int lane = threadIdx.x;
 	const int16_t *src = srcb + (size_t)blockIdx.x * src_stride;
 	int16_t *yo = yb + (size_t)blockIdx.x * y_stride;
+	int16_t *kmo = kmb + (size_t)blockIdx.x * km_stride;         /* contrast map and flags as passes A..C leave them: pass D is a kernel of its own */
+	uint8_t *soo = sob + (size_t)blockIdx.x * so_stride;
 	const PfP pp = pf_params(q);
 
 	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	MarkState ks = { 0, 0, 0, 0, 0, 0 };
 	PfM mach;
-	int prev_big = 0;
+	int prev_big = 0, row_carry = 0;
 	machine_reset(mach);
 
 	const int c0 = lane * 8;
@@ -609,21 +646,89 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 		int16_t *km = s_km[r & 1], *kmu = s_km[(r - 1) & 1];
 		int16_t *y = s_y[r & 1], *yu = s_y[(r - 1) & 1];
 		uint8_t *so = s_so[r & 1], *sou = s_so[(r - 1) & 1];
-		/* every lane: 8-neighbour sum and magnitude sum of its 8 pixels (:605-618) */
+		/* every lane: 8-neighbour sum and magnitude sum of its 8 pixels (:605-618), as the signed base value 15 |sum| + mag of the carry */
+		int smv[8], vbv[8];
 		for (int e = 0; e < 8; e++) {
 			const int c = c0 + e;
+			smv[e] = 0; vbv[e] = 0;
 			if (c < 1 || c > W - 2) continue;
 			const int ctr = mid[c];
 			int sm = 0, mg = 0;
 #define NB(v) do { const int d_ = ctr - (v); sm += d_; mg += iabs_(d_); } while (0)
 			NB(mid[c - 1]); NB(mid[c + 1]); NB(up[c]); NB(dn[c]); NB(up[c + 1]); NB(up[c - 1]); NB(dn[c - 1]); NB(dn[c + 1]);
 #undef NB
-			s_sum[c] = (int16_t)sm; s_mag[c] = (int16_t)mg;
+			smv[e] = sm;
+			vbv[e] = sm == 0 ? 0 : (sm < 0 ? -(15 * -sm + mg) : 15 * sm + mg);
 		}
+		{ uint32_t w4[4], z4[4];
+		  for (int e = 0; e < 4; e++) { w4[e] = (uint32_t)(uint16_t)vbv[2 * e] | ((uint32_t)(uint16_t)vbv[2 * e + 1] << 16); z4[e] = (uint32_t)(uint16_t)smv[2 * e] | ((uint32_t)(uint16_t)smv[2 * e + 1] << 16); }
+		  *reinterpret_cast<uint4 *>(&s_vb[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+		  *reinterpret_cast<uint4 *>(&s_sum[c0]) = make_uint4(z4[0], z4[1], z4[2], z4[3]); }
 		*reinterpret_cast<uint4 *>(&y[c0]) = *reinterpret_cast<const uint4 *>(&mid[c0]);        /* :566: the passes work on a copy */
 		*reinterpret_cast<uint2 *>(&so[c0]) = make_uint2(0, 0);
 		__syncthreads();
-		if (lane == 0) { km[0] = 0; km[W - 1] = 0; map_row(ms, pp, s_sum, s_mag, km); }
+		unsigned cand = 0;
+		if (!(dbg & 1)) {
+			/* entry state of my 8 pixels */
+			int carry;
+			bool merged = true;
+			if (c0 <= PF_LOOK) {                                   /* the row's own entry state reaches me */
+				carry = row_carry;
+				for (int c = 1; c < c0; c++) { const int vb = s_vb[c]; carry = vb == 0 ? 0 : ((iabs_(vb) + ((carry + 2) >> 2)) & 15); }
+			} else {
+				uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
+				for (int c = c0 - PF_LOOK; c < c0; c++) fsm_step16(m0, m1, s_vb[c]);
+				const uint64_t bb = (m0 & 0xFF) * 0x0101010101010101ull;
+				merged = m0 == bb && m1 == bb;
+				carry = (int)(m0 & 15);
+			}
+			int valv[8];
+			for (int e = 0; e < 8; e++) {
+				const int vb = vbv[e];
+				valv[e] = 0;
+				if (c0 + e < 1 || c0 + e > W - 2) continue;
+				if (vb == 0) carry = 0;
+				else {
+					const int acc = iabs_(vb) + ((carry + 2) >> 2);
+					valv[e] = vb < 0 ? -(acc >> 4) : (acc >> 4);
+					carry = acc & 15;
+				}
+			}
+			if (__any(!merged)) {
+				/* rare: some lane's 16 states had not merged within the look-back -- the row is replayed by one lane */
+				if (lane == 0) {
+					int cr = row_carry;
+					for (int c = 1; c < W - 1; c++) {
+						const int vb = s_vb[c];
+						int val = 0;
+						if (vb == 0) cr = 0; else { const int acc = iabs_(vb) + ((cr + 2) >> 2); val = vb < 0 ? -(acc >> 4) : (acc >> 4); cr = acc & 15; }
+						km[c] = (int16_t)val;
+					}
+					s_misc[0] = cr;
+				}
+				__syncthreads();
+				for (int e = 0; e < 8; e++) valv[e] = (c0 + e >= 1 && c0 + e <= W - 2) ? (int)km[c0 + e] : 0;
+				row_carry = s_misc[0];
+			} else {
+				row_carry = __builtin_amdgcn_readlane(carry, 63);
+			}
+			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)valv[2 * e] | ((uint32_t)(uint16_t)valv[2 * e + 1] << 16);
+			  *reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
+			for (int e = 0; e < 8; e++) if (smv[e] != 0 && map_candidate(pp, smv[e], valv[e])) cand |= 1u << e;
+			/* the few order-dependent pixels, in raster order: lanes ascending, pixels ascending inside a lane */
+			uint64_t lanes = __ballot(cand != 0);
+			__syncthreads();
+			while (lanes) {
+				const int l = __builtin_ctzll(lanes);
+				lanes &= lanes - 1;
+				unsigned cm = (unsigned)__builtin_amdgcn_readlane((int)cand, l);
+				while (cm) {
+					const int e = __builtin_ctz(cm);
+					cm &= cm - 1;
+					map_cell(ms, pp, 8 * l + e, LDK(s_sum + 8 * l + e), LDK(km + 8 * l + e), km);
+				}
+			}
+		}
 		__syncthreads();
 		if (pp.smooth) {                                          /* :780-807, reads the source copy only: off the chain */
 			for (int e = 0; e < 8; e++) {
@@ -636,21 +741,33 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 			}
 			__syncthreads();
 		}
-		if (lane == 0) {
-			pair_row(mach, prev_big, pp, r, km, y, so);
-			marker_row(ks, pp, r, km, y, so, kmu, yu, sou);
-			if (r > 1) final_row(pp, kmu, yu, sou);
-		}
+		if (!(dbg & 2) && lane == 0) pair_row(mach, prev_big, pp, r, km, y, so);
 		__syncthreads();
-		if (r > 1) *reinterpret_cast<uint4 *>(yo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&yu[c0]);
+		if (!(dbg & 4)) marker_row(ks, pp, r, km, y, so, kmu, yu, sou);
+		__syncthreads();
+		if (r > 1) {                                              /* row r-1 is through passes A..C: nothing of a later row touches it */
+			*reinterpret_cast<uint4 *>(yo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&yu[c0]);
+			*reinterpret_cast<uint4 *>(kmo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&kmu[c0]);
+			*reinterpret_cast<uint2 *>(soo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint2 *>(&sou[c0]);
+		}
 	}
 	{
 		const int r = W - 2;
-		if (lane == 0) final_row(pp, s_km[r & 1], s_y[r & 1], s_so[r & 1]);
-		__syncthreads();
 		*reinterpret_cast<uint4 *>(yo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[r & 1][c0]);
+		*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[r & 1][c0]);
+		*reinterpret_cast<uint2 *>(soo + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[r & 1][c0]);
 		*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
 	}
+}
+
+/* pass D (:2312-2420) has no memory beyond its cursor inside a row: a lane per row, all rows of the batch at once */
+__global__ __launch_bounds__(256) void k_low_final(int16_t *__restrict__ yb, size_t y_stride, const int16_t *__restrict__ kmb, size_t km_stride,
+                                                   const uint8_t *__restrict__ sob, size_t so_stride, int q)
+{
+	const int r = 1 + blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+	if (r > W - 2) return;
+	const PfP pp = pf_params(q);
+	final_row(pp, kmb + (size_t)img * km_stride + (size_t)r * W, yb + (size_t)img * y_stride + (size_t)r * W, sob + (size_t)img * so_stride + (size_t)r * W);
 }
 
 /* pre_processing_UV (:2428-2464), pointwise on a copy: 8-neighbour Laplacian of the 256 x 256 chroma plane, one or two steps back.
@@ -844,9 +961,13 @@ void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStr
 {
 	k_low_ll2<<<n, 64, 0, s>>>(proc, plane_stride, q);
 }
-void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int q, int n, hipStream_t s)
+void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
+                              int q, int n, hipStream_t s)
 {
-	k_low_prefilter<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, q);
+	static int dbg = -1;
+	if (dbg < 0) { const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
+	k_low_prefilter<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, dbg);
+	if (!(dbg & 8)) k_low_final<<<dim3(2, n), 256, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q);
 }
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s)
 {
