@@ -776,18 +776,29 @@ __global__ __launch_bounds__(256) void k_low_prefilter_chroma(const uint8_t *__r
 {
 	const uint8_t *s = srcb + (size_t)blockIdx.y * src_stride;
 	int16_t *d = dstb + (size_t)blockIdx.y * dst_stride;
-	const int idx = blockIdx.x * 256 + threadIdx.x, r = idx >> 8, c = idx & 255;
-	int v = s[idx];
-	if (r >= 1 && r < H - 1 && c >= 1 && c < H - 1) {
-		const int lap = (v << 3) - s[idx - 1] - s[idx + 1] - s[idx - H] - s[idx + H] - s[idx - H - 1] - s[idx + H - 1] - s[idx - H + 1] - s[idx + H + 1];
-		if (q < 14) {
-			if (iabs_(lap) >= 14) v += lap > 0 ? -2 : 2;
-			else if (iabs_(lap) > 5) v += lap > 0 ? -1 : 1;
-		} else {
-			if (lap > 5) v--; else if (lap < -5) v++;
+	const int g = blockIdx.x * 256 + threadIdx.x, r = g >> 6, c4 = (g & 63) * 4;        /* four pixels of one row */
+	const uint8_t *m = s + r * H + c4;
+	const uint32_t wm = *reinterpret_cast<const uint32_t *>(m);
+	int o[4] = { (int)(wm & 255), (int)((wm >> 8) & 255), (int)((wm >> 16) & 255), (int)(wm >> 24) };
+	if (r >= 1 && r < H - 1) {
+		int U[6], M[6], D[6];                                      /* columns c4-1 .. c4+4 of the rows above, at and below */
+		const uint32_t wu = *reinterpret_cast<const uint32_t *>(m - H), wd = *reinterpret_cast<const uint32_t *>(m + H);
+		for (int e = 0; e < 4; e++) { U[e + 1] = (wu >> (8 * e)) & 255; M[e + 1] = o[e]; D[e + 1] = (wd >> (8 * e)) & 255; }
+		U[0] = c4 ? m[-H - 1] : 0; M[0] = c4 ? m[-1] : 0; D[0] = c4 ? m[H - 1] : 0;
+		U[5] = c4 < H - 4 ? m[-H + 4] : 0; M[5] = c4 < H - 4 ? m[4] : 0; D[5] = c4 < H - 4 ? m[H + 4] : 0;
+		for (int e = 0; e < 4; e++) {
+			const int c = c4 + e;
+			if (c < 1 || c > H - 2) continue;
+			const int lap = (M[e + 1] << 3) - M[e] - M[e + 2] - U[e] - U[e + 1] - U[e + 2] - D[e] - D[e + 1] - D[e + 2];
+			if (q < 14) {
+				if (iabs_(lap) >= 14) o[e] += lap > 0 ? -2 : 2;
+				else if (iabs_(lap) > 5) o[e] += lap > 0 ? -1 : 1;
+			} else {
+				if (lap > 5) o[e]--; else if (lap < -5) o[e]++;
+			}
 		}
 	}
-	d[idx] = (int16_t)v;
+	*reinterpret_cast<uint2 *>(d + r * H + c4) = make_uint2((uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16), (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16));
 }
 
 /* ------------------------------------------------------------------------------------------------ Y11 + Y12 (nhw_encoder.c:285-621) */
@@ -800,14 +811,19 @@ __device__ static const uint8_t k_ll2_thr[13][7] = {          /* wvlt_thrx1..7 b
 DEVI void zero_below(int16_t *v, int lim) { if (iabs_(*v) < lim) *v = 0; }
 }
 #define LS (H / 2)          /* LL2 is 128 x 128 */
-/* Hit byte of an LL2 cell: bits 0..1 = the largest limit its level-1 children under HH1 get (0 none, 1 = 32, 2 = 34, 3 = 36; thrx5 is 34
- * or 36; the other two bands always get thrx6 and thrx6 + 6), bit 2 = its level-2 siblings go too (q <= 11).  Zeroing below a limit is idempotent and
- * monotone, and the walks never read what they zero, so the walk (one lane, on the LDS copy of LL2) only records hits and all lanes
- * clear the children afterwards. */
+#define LP (LS + 2)         /* LDS row pitch in shorts: a lane per row then walks 64 different banks */
+/* Hits are kept as four bitmaps over the LL2 cells: the level-1 children under HH1 get the largest of the limits 32 / 34 / 36 that hit the
+ * cell (thrx5 is 34 or 36; the other two bands always get thrx6 and thrx6 + 6), and -- q <= 11 -- its level-2 siblings go too.  Zeroing
+ * below a limit is idempotent and monotone, and the walks never read what they zero, so the walks only record hits and all lanes clear
+ * the children afterwards.
+ * The first walk (five cells in a row, :383-486) and the last (three flat cells, :585-620) stay inside a row: a lane per row.  The two in
+ * between (:488-583) write the cell diagonally below and read it back in the next row: one raster walk each, on the scalar unit, every
+ * cell's eight samples fetched in one go. */
+#define HITBIT(map, cell) atomicOr(&(map)[(cell) >> 5], 1u << ((cell) & 31))
 __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, size_t plane_stride, int q)
 {
-	__shared__ __attribute__((aligned(16))) int16_t ll[LS * LS + 8];
-	__shared__ __attribute__((aligned(16))) uint8_t hit[LS * LS];
+	__shared__ __attribute__((aligned(16))) int16_t ll[LS * LP + 8];
+	__shared__ uint32_t h32[LS * LS / 32], h34[LS * LS / 32], h36[LS * LS / 32], hsib[LS * LS / 32];
 	__shared__ int stale_hits;
 	int16_t *p = procb + (size_t)blockIdx.x * plane_stride;
 	const int lane = threadIdx.x;
@@ -832,107 +848,114 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 		}
 	}
 	if (q > 12) return;
-	for (int k = lane; k < LS * LS / 8; k += 64) {
-		const int r = k >> 4, c8 = (k & 15) * 8;
-		*reinterpret_cast<uint4 *>(&ll[r * LS + c8]) = *reinterpret_cast<const uint4 *>(p + (size_t)r * W + c8);
+	for (int k = lane; k < LS * LS / 2; k += 64) {
+		const int r = k >> 6, c2 = (k & 63) * 2;
+		*reinterpret_cast<uint32_t *>(&ll[r * LP + c2]) = *reinterpret_cast<const uint32_t *>(p + (size_t)r * W + c2);
 	}
-	for (int k = lane; k < LS * LS / 4; k += 64) reinterpret_cast<uint32_t *>(hit)[k] = 0;
+	for (int k = lane; k < LS * LS / 32; k += 64) { h32[k] = 0; h34[k] = 0; h36[k] = 0; hsib[k] = 0; }
 	if (lane == 0) stale_hits = 0;
 	__syncthreads();
 
 	const uint8_t *t = k_ll2_thr[q];
 	const int t1 = t[0], t2 = t[1], t3 = t[2], t4 = t[3], t5 = t[4], t6 = t[5], t7 = t[6];
 	const bool deep = q <= 11;
-	const int c5 = t5 == 36 ? 3 : 2;                              /* limit classes by value: 32 < 34 < 36 */
-	if (lane == 0) {
-#define HIT(cell, cls) do { const int c_ = (cell); const int old_ = hit[c_]; const int lv_ = (old_ & 3) > (cls) ? (old_ & 3) : (cls); hit[c_] = (uint8_t)((old_ & 4) | lv_); } while (0)
-#define SIB(cell) do { hit[(cell)] |= 4; } while (0)
-		/* `last`: the reference's `count` variable as the third walk finds it (:571-579 use it without having set it when the inner test
-		 * fails): -1 = still IM_SIZE (no hit so far), otherwise an LL2 cell index in this 128-stride layout */
-		int last = -1;
-		for (int r = 0; r < LS; r++)                              /* five cells in a row (:383-486) */
-			for (int j = 0; j < LS - 4; j++) {
-				int16_t *v = ll + r * LS + j;
-				bool h = false;
-				if (iabs_(v[4] - v[0]) < t1 && iabs_(v[4] - v[3]) < t1 && iabs_(v[1] - v[0]) < t1 &&
-				    iabs_(v[3] - v[1]) < t1 && iabs_(v[3] - v[2]) < t2 - 2) {
-					if ((v[3] - v[1]) > 5 && (v[2] - v[3]) >= 0) v[2] = v[3];
-					else if ((v[1] - v[3]) > 5 && (v[2] - v[3]) <= 0) v[2] = v[3];
-					else if ((v[1] - v[3]) > 5 && (v[2] - v[1]) >= 0) v[2] = v[1];
-					else if ((v[3] - v[1]) > 5 && (v[2] - v[1]) <= 0) v[2] = v[1];
-					else if ((v[3] - v[2]) > 0 && (v[2] - v[1]) > 0) { }
-					else if ((v[1] - v[2]) > 0 && (v[2] - v[3]) > 0) { }
-					else v[2] = (int16_t)((v[3] + v[1]) >> 1);
-					h = true;
-				}
-				else if (iabs_(v[4] - v[0]) < t2 + 1 && iabs_(v[4] - v[3]) < t2 + 1 && iabs_(v[1] - v[0]) < t2 + 1) {
-					if (iabs_(v[3] - v[1]) < t2 + 6 && iabs_(v[3] - v[2]) < t2 + 6) {
-						const int a = v[3] - v[2], b = v[2] - v[1];
-						if ((a >= 0 && b >= 0) || (a <= 0 && b <= 0)) h = true;
-					}
-				}
-				if (h) {
-					for (int k = 1; k < 4; k++) { HIT(r * LS + j + k, c5); if (deep) SIB(r * LS + j + k); }
-					last = 4;                                     /* the inner loop counter's exit value: row 0, column 4 */
+	uint32_t *h5 = t5 == 36 ? h36 : h34;
+	/* `last`: the reference's `count` variable as the third walk finds it (:571-579 use it without having set it when the inner test fails):
+	 * -1 = still IM_SIZE (no hit so far), otherwise an LL2 cell index */
+	int any1 = 0;
+	for (int r = lane; r < LS; r += 64) {                          /* five cells in a row (:383-486), in place along the row */
+		int16_t *row = ll + r * LP;
+		int v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+		for (int j = 0; j < LS - 4; j++) {
+			const int v4 = row[j + 4];
+			bool h = false;
+			if (iabs_(v4 - v0) < t1 && iabs_(v4 - v3) < t1 && iabs_(v1 - v0) < t1 && iabs_(v3 - v1) < t1 && iabs_(v3 - v2) < t2 - 2) {
+				int n2;
+				if ((v3 - v1) > 5 && (v2 - v3) >= 0) n2 = v3;
+				else if ((v1 - v3) > 5 && (v2 - v3) <= 0) n2 = v3;
+				else if ((v1 - v3) > 5 && (v2 - v1) >= 0) n2 = v1;
+				else if ((v3 - v1) > 5 && (v2 - v1) <= 0) n2 = v1;
+				else if ((v3 - v2) > 0 && (v2 - v1) > 0) n2 = v2;
+				else if ((v1 - v2) > 0 && (v2 - v3) > 0) n2 = v2;
+				else n2 = (v3 + v1) >> 1;
+				if (n2 != v2) { v2 = n2; row[j + 2] = (int16_t)n2; }
+				h = true;
+			}
+			else if (iabs_(v4 - v0) < t2 + 1 && iabs_(v4 - v3) < t2 + 1 && iabs_(v1 - v0) < t2 + 1) {
+				if (iabs_(v3 - v1) < t2 + 6 && iabs_(v3 - v2) < t2 + 6) {
+					const int a = v3 - v2, bq = v2 - v1;
+					if ((a >= 0 && bq >= 0) || (a <= 0 && bq <= 0)) h = true;
 				}
 			}
-		for (int pass = 0; pass < 2; pass++)                      /* plus shape (+2, :488-533), then flat corner (+1, :535-583) */
-			for (int r = 0; r < LS - 2; r++)
-				for (int j = 0; j < LS - 2; j++) {
-					int16_t *v = ll + r * LS + j;
-					if (!pass) {
-						if (iabs_(v[1] - v[2 * LS + 1]) < t3 && iabs_(v[LS] - v[LS + 2]) < t3 &&
-						    iabs_(v[LS + 1] - v[LS]) < t4 - 1 && iabs_(v[1] - v[LS + 1]) < t4) {
-							const int e = (v[1] + v[2 * LS + 1] + v[LS] + v[LS + 2] + 2) >> 2;
-							if (iabs_(e - v[LS]) < 5 || iabs_(e - v[LS + 2]) < 5) v[LS + 1] = (int16_t)e;
-							last = (r + 1) * LS + j + 1;
-							HIT(last, 1);
-							if (deep) for (int k = -1; k < 2; k++) SIB(last + k);
-						}
-					} else if (iabs_(v[2] - v[1]) < t3 && iabs_(v[1] - v[0]) < t3 && iabs_(v[0] - v[LS]) < t3 && iabs_(v[2] - v[LS + 2]) < t3) {
-						if (iabs_(v[2 * LS + 1] - v[LS]) < t3 && iabs_(v[LS] - v[LS + 1]) < t4) {
-							const int e = (v[1] + v[2 * LS + 1] + v[LS] + v[LS + 2] + 1) >> 2;
-							if (iabs_(e - v[LS]) < 5 || iabs_(e - v[LS + 2]) < 5) v[LS + 1] = (int16_t)e;
-							last = (r + 1) * LS + j + 1;
-							HIT(last, 1);
-						}
-						if (deep) { if (last < 0) stale_hits = 1; else for (int k = -1; k < 2; k++) SIB(last + k); }
-					}
-				}
-		if (deep)
-			for (int r = 0; r < LS; r++)                          /* three flat cells in a row (:585-620) */
-				for (int j = 0; j < LS - 2; j++) {
-					const int16_t *v = ll + r * LS + j;
-					if (iabs_(v[2] - v[1]) < t7 && iabs_(v[2] - v[0]) < t7 && iabs_(v[1] - v[0]) < t7) { HIT(r * LS + j + 1, 2); SIB(r * LS + j + 1); }
-				}
-#undef HIT
-#undef SIB
+			if (h) {
+				for (int k = 1; k < 4; k++) { HITBIT(h5, r * LS + j + k); if (deep) HITBIT(hsib, r * LS + j + k); }
+				any1 = 1;
+			}
+			v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+		}
 	}
+	int last = __any(any1) ? 4 : -1;                              /* the inner loop counter's exit value: row 0, column 4 */
 	__syncthreads();
-	for (int k = lane; k < LS * LS / 8; k += 64) {                /* the smoothed LL2 band goes back */
-		const int r = k >> 4, c8 = (k & 15) * 8;
-		*reinterpret_cast<uint4 *>(p + (size_t)r * W + c8) = *reinterpret_cast<const uint4 *>(&ll[r * LS + c8]);
-	}
-	for (int cell = lane; cell < LS * LS; cell += 64) {
-		const int hb = hit[cell];
-		if (!hb) continue;
-		const int r = cell >> 7, j = cell & 127, flat = r * W + j;
-		if (hb & 3) {
-			const int limc = (hb & 3) == 1 ? 32 : (hb & 3) == 2 ? 34 : 36;
-			const int base = flat << 1;
-			const int band[3] = { H, 2 * Q, 2 * Q + H }, lim[3] = { t6, t6 + 6, limc };
-			for (int b = 0; b < 3; b++) {
-				int16_t *v = p + base + band[b];
-				zero_below(v, lim[b]); zero_below(v + 1, lim[b]); zero_below(v + W, lim[b]); zero_below(v + W + 1, lim[b]);
+	for (int pass = 0; pass < 2; pass++)                          /* plus shape (+2, :488-533), then flat corner (+1, :535-583) */
+		for (int r = 0; r < LS - 2; r++) {
+			const int16_t *row = ll + r * LP;
+			for (int j = 0; j < LS - 2; j++) {
+				const int16_t *v = row + j;
+				const int a0 = LDK(v), a1 = LDK(v + 1), a2 = LDK(v + 2), b0 = LDK(v + LP), b1 = LDK(v + LP + 1), b2 = LDK(v + LP + 2), c1 = LDK(v + 2 * LP + 1);
+				if (!pass) {
+					if (iabs_(a1 - c1) < t3 && iabs_(b0 - b2) < t3 && iabs_(b1 - b0) < t4 - 1 && iabs_(a1 - b1) < t4) {
+						const int e = (a1 + c1 + b0 + b2 + 2) >> 2;
+						if (iabs_(e - b0) < 5 || iabs_(e - b2) < 5) STK(ll + (r + 1) * LP + j + 1, (int16_t)e);
+						last = (r + 1) * LS + j + 1;
+						if (lane == 0) { HITBIT(h32, last); if (deep) for (int k = -1; k < 2; k++) HITBIT(hsib, last + k); }
+					}
+				} else if (iabs_(a2 - a1) < t3 && iabs_(a1 - a0) < t3 && iabs_(a0 - b0) < t3 && iabs_(a2 - b2) < t3) {
+					if (iabs_(c1 - b0) < t3 && iabs_(b0 - b1) < t4) {
+						const int e = (a1 + c1 + b0 + b2 + 1) >> 2;
+						if (iabs_(e - b0) < 5 || iabs_(e - b2) < 5) STK(ll + (r + 1) * LP + j + 1, (int16_t)e);
+						last = (r + 1) * LS + j + 1;
+						if (lane == 0) HITBIT(h32, last);
+					}
+					if (deep && lane == 0) { if (last < 0) stale_hits = 1; else for (int k = -1; k < 2; k++) HITBIT(hsib, last + k); }
+				}
 			}
 		}
-		if (hb & 4) { zero_below(p + flat + H / 2, 11); zero_below(p + flat + Q, 12); zero_below(p + flat + Q + H / 2, 13); }
+	__syncthreads();
+	if (deep)
+		for (int r = lane; r < LS; r += 64) {                      /* three flat cells in a row (:585-620): reads only */
+			const int16_t *row = ll + r * LP;
+			for (int j = 0; j < LS - 2; j++)
+				if (iabs_(row[j + 2] - row[j + 1]) < t7 && iabs_(row[j + 2] - row[j]) < t7 && iabs_(row[j + 1] - row[j]) < t7) { HITBIT(h34, r * LS + j + 1); HITBIT(hsib, r * LS + j + 1); }
+		}
+	__syncthreads();
+	for (int k = lane; k < LS * LS / 2; k += 64) {                /* the smoothed LL2 band goes back */
+		const int r = k >> 6, c2 = (k & 63) * 2;
+		*reinterpret_cast<uint32_t *>(p + (size_t)r * W + c2) = *reinterpret_cast<const uint32_t *>(&ll[r * LP + c2]);
+	}
+	for (int cell = lane; cell < LS * LS; cell += 64) {
+		const int w = cell >> 5;
+		const uint32_t bit = 1u << (cell & 31);
+		const int limc = (h36[w] & bit) ? 36 : (h34[w] & bit) ? 34 : (h32[w] & bit) ? 32 : 0;
+		const bool sib = hsib[w] & bit;
+		if (!limc && !sib) continue;
+		const int r = cell >> 7, j = cell & 127, flat = r * W + j;
+		if (limc) {
+			const int base = flat << 1;
+			const int band[3] = { H, 2 * Q, 2 * Q + H }, lim[3] = { t6, t6 + 6, limc };
+			for (int bnd = 0; bnd < 3; bnd++) {
+				int16_t *v = p + base + band[bnd];
+				zero_below(v, lim[bnd]); zero_below(v + 1, lim[bnd]); zero_below(v + W, lim[bnd]); zero_below(v + W + 1, lim[bnd]);
+			}
+		}
+		if (sib) { zero_below(p + flat + H / 2, 11); zero_below(p + flat + Q, 12); zero_below(p + flat + Q + H / 2, 13); }
 	}
 	if (stale_hits && lane < 3) {                                  /* `count` still IM_SIZE: the "siblings" of plane cells 65535..65537 */
 		const int flat = Q - 1 + lane;
 		zero_below(p + flat + H / 2, 11); zero_below(p + flat + Q, 12); zero_below(p + flat + Q + H / 2, 13);
 	}
 }
+#undef HITBIT
+#undef LP
 #undef LS
 
 /* level-1 chroma detail below 24 / 32 / 48 goes (nhw_encoder.c:2277-2308, :2590-2621; q <= 16), pointwise on the 256 x 256 coefficient plane */
@@ -971,5 +994,5 @@ void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y,
 }
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s)
 {
-	k_low_prefilter_chroma<<<dim3(Q / 256, n), 256, 0, s>>>(src, src_stride, dst, dst_stride, q);
+	k_low_prefilter_chroma<<<dim3(Q / 4 / 256, n), 256, 0, s>>>(src, src_stride, dst, dst_stride, q);
 }
