@@ -313,6 +313,27 @@ __device__ __forceinline__ void row_window(const int16_t *row, int c0, int v[12]
 	}
 }
 
+/* The pair rules only ask which of eight magnitude classes the two contrast values are in -- up to 10, 11, 12..15, 16..22, 23..31,
+ * 32..176, 177..201, above (the constants of image_processing.c:810-837, :1927-1990) -- and their signs: 15 signed classes, so the ~60
+ * predicate operations per pair become two class look-ups and one table entry.  The table is filled at kernel start by evaluating the
+ * rules themselves on one representative per class: entry = (d0 + 8) | (d1 + 8) << 4 | hand-over flag << 8. */
+#define PCLS 15
+__device__ __forceinline__ int pair_class_rep(int cls)          /* a value of signed class cls (0: |k| <= 10; 1..7 positive, 8..14 negative) */
+{
+	const int m = cls == 0 ? 0 : (cls - 1) % 7 + 1;
+	const int mag = m == 0 ? 5 : m == 1 ? 11 : m == 2 ? 13 : m == 3 ? 18 : m == 4 ? 27 : m == 5 ? 100 : m == 6 ? 190 : 300;
+	return cls >= 8 ? -mag : mag;
+}
+__device__ __forceinline__ int pair_mag_class(int a)             /* a = |k| */
+{
+	return (a > 10) + (a > 11) + (a > 15) + (a > 22) + (a > 31) + (a > 176) + (a > 201);
+}
+__device__ __forceinline__ int pair_class(int k, const uint8_t *mcls /* LDS: class of min(|k|, 202) */)
+{
+	const int a = iabs(k), m = mcls[a > 202 ? 202 : a];
+	return (k < 0 && m) ? m + 7 : m;
+}
+
 __device__ unsigned long long g_band_stamp[16];
 #define STAMP(i) do { if (t == 0 && blockIdx.x == 3207) g_band_stamp[i] = wall_clock64(); } while (0)
 
@@ -335,6 +356,8 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	__shared__ uint8_t entry[FB_TROWS * 8];
 	__shared__ uint8_t stl[FB_TROWS];
+	__shared__ uint16_t ptab[2 * PCLS * PCLS];
+	__shared__ uint8_t mcls[204];
 	int16_t *ybuf = smem;                                          /* FB_YROWS rows */
 	int16_t *kbuf = smem + FB_YROWS * FB_RS;                       /* FB_TROWS rows */
 	const int t = threadIdx.x;
@@ -350,6 +373,15 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 	const int k0 = FB_KB * band, t0 = 2 * k0 - 4;                  /* first horizontal-pass row (may be negative) */
 
 	STAMP(0);
+	if (PRE) {
+		if (t < 2 * PCLS * PCLS) {
+			const int pb = t / (PCLS * PCLS), c0 = (t / PCLS) % PCLS, c1 = t % PCLS;
+			const int r0 = pair_class_rep(c0), r1 = pair_class_rep(c1);
+			const uint32_t dd = prefilter_pair_delta(r0, r1, pb);
+			ptab[t] = (uint16_t)(((int16_t)(dd & 0xFFFF) + 8) | (((int16_t)(dd >> 16) + 8) << 4) | (pair_big_flag_fwd(r0, r1) << 8));
+		}
+		if (t < 203) mcls[t] = (uint8_t)pair_mag_class(t);
+	}
 	if (SRC == 0) {
 		const int16_t *y = (const int16_t *)((const uint8_t *)srcb + (size_t)img * src_stride);
 		for (int k = t; k < FB_YROWS * (W / 8); k += FB_NT) {        /* stage rows t0-1 .. t0+37 */
@@ -537,15 +569,19 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 #pragma unroll
 			for (int e = 2; e < 10; e++) big |= iabs(v[e]) > 22;
 			if (!big) continue;
-			int prev_big = g ? pair_big_flag_fwd(v[0], v[1]) : ((stl[rt] >> 4) & 1);
+			int cl[10];
+#pragma unroll
+			for (int e = 0; e < 10; e++) cl[e] = pair_class(v[e], mcls);
+			int prev_big = g ? ((ptab[cl[0] * PCLS + cl[1]] >> 8) & 1) : ((stl[rt] >> 4) & 1);
 #pragma unroll
 			for (int e = 0; e < 4; e++) {
 				const int c = 8 * g + 1 + 2 * e;
 				if (c <= W - 3) {
-					const uint32_t dd = prefilter_pair_delta(v[2 * e + 2], v[2 * e + 3], prev_big);
-					if (dd & 0xFFFF) yo[1 + 2 * e] = (int16_t)(yo[1 + 2 * e] + (int16_t)(dd & 0xFFFF));
-					if (dd >> 16) yo[2 + 2 * e] = (int16_t)(yo[2 + 2 * e] + (int16_t)(dd >> 16));
-					prev_big = pair_big_flag_fwd(v[2 * e + 2], v[2 * e + 3]);
+					const int en = ptab[(prev_big * PCLS + cl[2 * e + 2]) * PCLS + cl[2 * e + 3]];
+					const int d0 = (en & 15) - 8, d1 = ((en >> 4) & 15) - 8;
+					if (d0) yo[1 + 2 * e] = (int16_t)(yo[1 + 2 * e] + d0);
+					if (d1) yo[2 + 2 * e] = (int16_t)(yo[2 + 2 * e] + d1);
+					prev_big = (en >> 8) & 1;
 				}
 			}
 		}
