@@ -11,6 +11,8 @@
  * bounded by HBM.  Built with -ffp-contract=off: the luma weights are double products summed left to
  * right and a fused multiply-add changes 300+ of the 2^24 colour triples.
  */
+#include <type_traits>
+#include <cstdlib>
 #include "nhw_ws.h"
 
 #pragma clang fp contract(off)
@@ -53,6 +55,9 @@ __device__ __forceinline__ int chroma_round(float cb) { return cb >= 0 ? (int)(c
  *   luma:   (int)(0.299 b0 + 0.587 b1 + 0.114 b2 + 0.5f) is floor((299 b0 + 587 b1 + 114 b2 + 500) / 1000) except when that
  *           division is exact (one triple in a thousand): there the double rounding of the three products decides, and
  *           the lane takes the double path. */
+/* the full-rate 24 x 24 bit multiplier: low 32 bits and bits 32..47 of the product (operands must fit 24 bits) */
+__device__ __forceinline__ unsigned mulhi_u24(unsigned a, unsigned b) { unsigned r; asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned mul_u24(unsigned a, unsigned b) { unsigned r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <int FAMILY> /* 0: q>=20, 1: q 18/19, 2: q17, 3: q<=16 (integer BT.601 scaled by the quality table; yq carries the table entry's bits) */
 __device__ __forceinline__ void convert_uv(const uint8_t *px, float yq, int &U, int &V)
 {
@@ -64,9 +69,11 @@ __device__ __forceinline__ void convert_uv(const uint8_t *px, float yq, int &U, 
 		return;
 	}
 	if (FAMILY == 0) {
+		/* the biased sums are 9000 .. 2560000 (22 bits): x / 10000 = (x * 13743896) >> 37 exactly over that range, and both factors fit the
+		 * full-rate 24-bit multiplier (a 32-bit v_mul_hi runs at a quarter of the rate); the quotient is 0 .. 256, so one min() clips it */
 		const int su = -1687 * b0 - 3313 * b1 + 5000 * b2, sv = 5000 * b0 - 4187 * b1 - 813 * b2;
-		U = clip_u8((int)((unsigned)(su + (su >= 0 ? 1285000 : 1284000)) / 10000u));
-		V = clip_u8((int)((unsigned)(sv + (sv >= 0 ? 1285000 : 1284000)) / 10000u));
+		U = (int)min(mulhi_u24((unsigned)(su + (su >= 0 ? 1285000 : 1284000)), 13743896u) >> 5, 255u);
+		V = (int)min(mulhi_u24((unsigned)(sv + (sv >= 0 ? 1285000 : 1284000)), 13743896u) >> 5, 255u);
 		return;
 	}
 	double lu = -0.1687 * b0 - 0.3313 * b1 + 0.5 * b2;
@@ -81,8 +88,9 @@ __device__ __forceinline__ int convert_y(const uint8_t *px, float yq)
 	const int b0 = px[0], b1 = px[1], b2 = px[2];
 	if (FAMILY == 3) return (((66 * b0 + 129 * b1 + 25 * b2) * __float_as_int(yq) + 4194304) >> 23) + 16;
 	if (FAMILY == 0) {
-		const unsigned s = (unsigned)(299 * b0 + 587 * b1 + 114 * b2 + 500), y = s / 1000u;
-		if (s - 1000u * y != 0u) return (int)y;
+		/* s <= 255500 (18 bits): s / 1000 = (s * 8589935) >> 33 exactly, again on the 24-bit multiplier */
+		const unsigned s = (unsigned)(299 * b0 + 587 * b1 + 114 * b2 + 500), y = mulhi_u24(s, 8589935u) >> 1;
+		if (s != mul_u24(y, 1000u)) return (int)y;
 	}
 	const double ly = 0.299 * b0 + 0.587 * b1 + 0.114 * b2;
 	if (FAMILY == 0) return (int)(ly + 0.5f);
@@ -185,14 +193,16 @@ __device__ __forceinline__ void fsm_step16(uint64_t &m0, uint64_t &m1, int vb)
 
 __device__ __forceinline__ int rnd_half_away(int v, int shift)
 {
-	const int half = 1 << (shift - 1);
-	return v >= 0 ? (v + half) >> shift : -((-v + half) >> shift);
+	/* v < 0: -((-v + half) >> shift) = ceil((v - half) / 2^shift) = (v + half - 1) >> shift -- no branch either way */
+	return (v + (1 << (shift - 1)) + (v >> 31)) >> shift;
 }
 __device__ __forceinline__ int diffuse(int r)
 {
-	if (r >= 0) { const int m = r & 63; return m < 32 ? (m >> 2) : -((64 - m) >> 2); }
-	const int m = (-r) & 63;
-	return m < 32 ? -(m >> 2) : ((64 - m) >> 2);
+	/* an odd function of r: |r| mod 64 read as a signed 6-bit number, divided by 4 towards zero, with the sign of r */
+	const int s = r >> 31, a = (r ^ s) - s;
+	const int t = (int)((unsigned)a << 26) >> 26;
+	const int d = (t + ((t >> 31) & 3)) >> 2;
+	return (d ^ s) - s;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -211,6 +221,8 @@ __device__ __forceinline__ int diffuse(int r)
 #define FB_YROWS (FB_TROWS + 2)
 #define FB_RS 514                   /* padded LDS row stride (shorts) */
 #define FB_LOOK 12                  /* pixels of look-back for a segment's entry state (all 16 states have merged within 8 for 99.9 % of the segments) */
+#define FB_SEG 32                   /* pixels per carry segment; FB_NSEG segments per row, replayed two to a lane */
+#define FB_NSEG (W / FB_SEG)
 #define FB_NT 512                   /* threads per band: the 78 KB of LDS allow two bands per CU, eight wavefronts each keep the SIMDs fed */
 
 /* pre-pass: per row the 16-state transfer map of the carry across the row and, for each of the 16 entry states, the hand-over
@@ -316,26 +328,29 @@ __device__ __forceinline__ void row_window(const int16_t *row, int c0, int v[12]
 /* The pair rules only ask which of eight magnitude classes the two contrast values are in -- up to 10, 11, 12..15, 16..22, 23..31,
  * 32..176, 177..201, above (the constants of image_processing.c:810-837, :1927-1990) -- and their signs: 15 signed classes, so the ~60
  * predicate operations per pair become two class look-ups and one table entry.  The table is filled at kernel start by evaluating the
- * rules themselves on one representative per class: entry = (d0 + 8) | (d1 + 8) << 4 | hand-over flag << 8. */
+ * rules themselves on one representative per class: entry = (d0 + 8) | (d1 + 8) << 4 | hand-over flag << 8.
+ * (Leaving the classes in place of the values in the carry replay, which has them in registers, was tried: the replay is the serial
+ * phase of the band and every instruction added there costs more than the look-ups it saves here.) */
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 #define PCLS 15
-__device__ __forceinline__ int pair_class_rep(int cls)          /* a value of signed class cls (0: |k| <= 10; 1..7 positive, 8..14 negative) */
+__device__ __forceinline__ int pair_class_rep(int sc)           /* a value of signed class sc = -7 .. 7 (0: |k| <= 10) */
 {
-	const int m = cls == 0 ? 0 : (cls - 1) % 7 + 1;
+	const int m = iabs(sc);
 	const int mag = m == 0 ? 5 : m == 1 ? 11 : m == 2 ? 13 : m == 3 ? 18 : m == 4 ? 27 : m == 5 ? 100 : m == 6 ? 190 : 300;
-	return cls >= 8 ? -mag : mag;
+	return sc < 0 ? -mag : mag;
 }
 __device__ __forceinline__ int pair_mag_class(int a)             /* a = |k| */
 {
 	return (a > 10) + (a > 11) + (a > 15) + (a > 22) + (a > 31) + (a > 176) + (a > 201);
 }
-__device__ __forceinline__ int pair_class(int k, const uint8_t *mcls /* LDS: class of min(|k|, 202) */)
-{
-	const int a = iabs(k), m = mcls[a > 202 ? 202 : a];
-	return (k < 0 && m) ? m + 7 : m;
-}
 
 __device__ unsigned long long g_band_stamp[16];
-#define STAMP(i) do { if (t == 0 && blockIdx.x == 3207) g_band_stamp[i] = wall_clock64(); } while (0)
+#ifdef NHW_DEV   /* developer builds: phase time stamps of one band in steady state, and a switch that ends every band after phase i */
+#define STAMP(i) do { if (t == 0 && blockIdx.x == 70001) g_band_stamp[i] = wall_clock64(); if ((force_fixup >> 8) == (i) && (i)) return; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 /* THE fused front kernel: colour conversion + 4:2:0 + (q <= 21) pre-filter + both directions of the level-1 analysis in one launch
  * (colorspace.c:55-260 + image_processing.c:558-837, 1927-1990 + wavelet_filterbank.c:52-184): the BGR bytes of the 39 rows a band
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
                                                     int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride, int force_fixup, int n_img)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
-	__shared__ uint8_t entry[FB_TROWS * 8];
+	__shared__ uint8_t entry[FB_TROWS * FB_NSEG];
 	__shared__ uint8_t stl[FB_TROWS];
 	__shared__ uint16_t ptab[2 * PCLS * PCLS];
 	__shared__ uint8_t mcls[204];
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 	if (PRE) {
 		if (t < 2 * PCLS * PCLS) {
 			const int pb = t / (PCLS * PCLS), c0 = (t / PCLS) % PCLS, c1 = t % PCLS;
-			const int r0 = pair_class_rep(c0), r1 = pair_class_rep(c1);
+			const int r0 = pair_class_rep(c0 - 7), r1 = pair_class_rep(c1 - 7);
 			const uint32_t dd = prefilter_pair_delta(r0, r1, pb);
 			ptab[t] = (uint16_t)(((int16_t)(dd & 0xFFFF) + 8) | (((int16_t)(dd >> 16) + 8) << 4) | (pair_big_flag_fwd(r0, r1) << 8));
 		}
@@ -497,62 +512,67 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 			d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3];
 		}
 		__syncthreads();
-		/* Carry state at the start of every 64-pixel segment.  The 16-state carry forgets its past quickly (a step maps the 16 states
+		/* Carry state at the start of every FB_SEG-pixel segment.  The 16-state carry forgets its past quickly (a step maps the 16 states
 		 * onto at most five neighbouring ones, a zero sum resets it): run all 16 states through the FB_LOOK pixels in front of the segment;
 		 * if they end in one state, that is the entry state whatever came before.  Where they do not (rare), the segment before is
 		 * replayed from its own entry state -- by then known -- so the result is exact in every case. */
-		for (int k = t; k < FB_TROWS * 8; k += FB_NT) {
+		for (int k = t; k < FB_TROWS * FB_NSEG; k += FB_NT) {
 			const int rt = k % FB_TROWS, sg = k / FB_TROWS, row = t0 + rt;
 			if (row < 1 || row > W - 2) continue;
 			int e = stl[rt] & 15;
 			if (sg > 0) {
-				const int16_t *km = kbuf + rt * FB_RS + 1 + 64 * sg - FB_LOOK;
-				uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
-				for (int i = 0; i < FB_LOOK; i++) fsm_step16(m0, m1, km[i]);
-				const uint64_t b = (m0 & 0xFF) * 0x0101010101010101ull;
-				e = (m0 == b && m1 == b && !force_fixup) ? (int)(m0 & 15) : 0xFF;   /* force_fixup: test switch, every segment takes the exact replay */
+				/* one step maps all 16 states onto the five (|v| + 0..4) & 15, so five candidates are all there is to follow: 5-bit fields of one
+				 * dword (c + 2 and |v| + 4 stay below 32), every step a handful of whole-dword operations */
+				const int16_t *km = kbuf + rt * FB_RS + 1 + FB_SEG * sg - FB_LOOK;
+				const uint32_t R = 0x108421u;                          /* 1 in each field */
+				uint32_t x = km[0] == 0 ? 0u : ((((uint32_t)iabs(km[0]) & 15u) * R + 0x418820u) & (15u * R));
+				for (int i = 1; i < FB_LOOK; i++) {
+					const int vb = km[i];
+					const uint32_t nx = (((uint32_t)iabs(vb) & 15u) * R + (((x + 2u * R) >> 2) & (7u * R))) & (15u * R);
+					x = vb == 0 ? 0u : nx;
+				}
+				e = (x == (x & 31u) * R && !(force_fixup & 1)) ? (int)(x & 15u) : 0xFF;   /* force_fixup: test switch, every segment takes the exact replay */
 			}
-			entry[rt * 8 + sg] = (uint8_t)e;
+			entry[rt * FB_NSEG + sg] = (uint8_t)e;
 		}
 		__syncthreads();
 		if (t < FB_TROWS && t0 + t >= 1 && t0 + t <= W - 2) {
-			for (int sg = 1; sg < 8; sg++) {
-				if (entry[t * 8 + sg] != 0xFF) continue;
-				const int16_t *km = kbuf + t * FB_RS + 1 + 64 * (sg - 1);
-				int carry = entry[t * 8 + sg - 1];
-				for (int i = 0; i < 64; i++) { const int vb = km[i]; carry = vb == 0 ? 0 : ((iabs(vb) + ((carry + 2) >> 2)) & 15); }
-				entry[t * 8 + sg] = (uint8_t)carry;
+			for (int sg = 1; sg < FB_NSEG; sg++) {
+				if (entry[t * FB_NSEG + sg] != 0xFF) continue;
+				const int16_t *km = kbuf + t * FB_RS + 1 + FB_SEG * (sg - 1);
+				int carry = entry[t * FB_NSEG + sg - 1];
+				for (int i = 0; i < FB_SEG; i++) { const int vb = km[i]; carry = vb == 0 ? 0 : ((iabs(vb) + ((carry + 2) >> 2)) & 15); }
+				entry[t * FB_NSEG + sg] = (uint8_t)carry;
 			}
 		}
 		__syncthreads();
 		STAMP(2);
-		/* one lane per (row, 64-pixel segment), eight pixels at a time through registers (small loop bodies: a
-		 * fully unrolled 64-step version overflows the instruction cache and runs 10x slower) */
-		for (int it = 0; it < (FB_TROWS * 8 + FB_NT - 1) / FB_NT; it++) {   /* replay the carry */
-			const int k = t + FB_NT * it;
-			const int rt = k % FB_TROWS, sg = k / FB_TROWS, row = t0 + rt;
-			if (k >= FB_TROWS * 8 || row < 1 || row > W - 2) continue;
-			int16_t *km = kbuf + rt * FB_RS + 1 + 64 * sg;         /* segment pixel 0 = column 1 + 64 sg */
-			const int npx = sg == 7 ? 62 : 64;
-			int carry = entry[rt * 8 + sg];
-			for (int ch = 0; ch < 8; ch++) {
-				int16_t v[8];
+		/* replay the carry: one lane per row and PAIR of segments (sp, sp + FB_NSEG / 2), the two values side by side in the halves of a
+		 * dword so that every step is packed 16-bit arithmetic -- half the instructions of a lane per segment.  Eight pixels at a time
+		 * through registers (small loop bodies: a fully unrolled version overflows the instruction cache and runs 10x slower). */
+		if (t < FB_TROWS * (FB_NSEG / 2)) {
+			const int rt = t % FB_TROWS, sp = t / FB_TROWS, row = t0 + rt;
+			if (row >= 1 && row <= W - 2) {
+				int16_t *ka = kbuf + rt * FB_RS + 1 + FB_SEG * sp, *kb = ka + 256;   /* segment pixel 0 = column 1 + FB_SEG sg */
+				const int nb = sp == FB_NSEG / 2 - 1 ? FB_SEG - 2 : FB_SEG;   /* the last segment ends at column 510 */
+				u16x2 carry = { entry[rt * FB_NSEG + sp], entry[rt * FB_NSEG + sp + FB_NSEG / 2] };
+#pragma unroll 1
+				for (int ch = 0; ch < FB_SEG / 8; ch++) {
+					s16x2 v[8];
 #pragma unroll
-				for (int e = 0; e < 8; e++) v[e] = km[8 * ch + e];
+					for (int e = 0; e < 8; e++) { v[e].x = ka[8 * ch + e]; v[e].y = kb[8 * ch + e]; }
 #pragma unroll
-				for (int e = 0; e < 8; e++) {
-					if (8 * ch + e < npx) {
-						const int vb = v[e];
-						if (vb == 0) carry = 0;
-						else {
-							const int acc = iabs(vb) + ((carry + 2) >> 2);
-							v[e] = (int16_t)(vb < 0 ? -(acc >> 4) : (acc >> 4));
-							carry = acc & 15;
-						}
+					for (int e = 0; e < 8; e++) {                        /* v == 0: |v| + f(carry) <= 4 gives output 0 by itself; only the carry needs the reset */
+						const s16x2 sgn = v[e] >> 15;
+						const u16x2 a = __builtin_bit_cast(u16x2, (s16x2)((v[e] ^ sgn) - sgn));
+						const u16x2 acc = a + ((carry + (u16x2)(2)) >> 2);
+						const s16x2 o = __builtin_bit_cast(s16x2, (u16x2)(acc >> 4));
+						v[e] = (o ^ sgn) - sgn;
+						carry = (acc & (u16x2)(15)) * __builtin_elementwise_min(a, (u16x2)(1));
 					}
-				}
 #pragma unroll
-				for (int e = 0; e < 8; e++) if (8 * ch + e < npx) km[8 * ch + e] = v[e];
+					for (int e = 0; e < 8; e++) { ka[8 * ch + e] = v[e].x; if (8 * ch + e < nb) kb[8 * ch + e] = v[e].y; }
+				}
 			}
 		}
 		__syncthreads();
@@ -565,19 +585,19 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 			int16_t v[10];
 #pragma unroll
 			for (int e = 0; e < 10; e++) v[e] = (g == 0 && e == 0) ? (int16_t)0 : km[e - 1];   /* columns 8g-1 .. 8g+8 */
-			int big = 0;                                            /* every rule needs a kernel value of at least 23 in its pair: |k| > 176, or a moderate one (11..31) next to one >= 23 */
+			int big = 0;                                            /* every rule needs a kernel value of at least 23 (class 4 and up) in its pair: |k| > 176, or a moderate one (11..31) next to one >= 23 */
 #pragma unroll
 			for (int e = 2; e < 10; e++) big |= iabs(v[e]) > 22;
 			if (!big) continue;
-			int cl[10];
+			int cl[10];                                             /* signed class + 7 */
 #pragma unroll
-			for (int e = 0; e < 10; e++) cl[e] = pair_class(v[e], mcls);
+			for (int e = 0; e < 10; e++) { const int a = iabs(v[e]), m = mcls[a > 202 ? 202 : a]; cl[e] = v[e] < 0 ? 7 - m : 7 + m; }
 			int prev_big = g ? ((ptab[cl[0] * PCLS + cl[1]] >> 8) & 1) : ((stl[rt] >> 4) & 1);
 #pragma unroll
 			for (int e = 0; e < 4; e++) {
 				const int c = 8 * g + 1 + 2 * e;
 				if (c <= W - 3) {
-					const int en = ptab[(prev_big * PCLS + cl[2 * e + 2]) * PCLS + cl[2 * e + 3]];
+					const int en = ptab[prev_big * (PCLS * PCLS) + cl[2 * e + 2] * PCLS + cl[2 * e + 3]];
 					const int d0 = (en & 15) - 8, d1 = ((en >> 4) & 15) - 8;
 					if (d0) yo[1 + 2 * e] = (int16_t)(yo[1 + 2 * e] + d0);
 					if (d1) yo[2 + 2 * e] = (int16_t)(yo[2 + 2 * e] + d1);
@@ -626,8 +646,13 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 			*reinterpret_cast<uint4 *>(keep + (size_t)kx * W + 2 * k0 + 8 * part) = make_uint4(v[0], v[1], v[2], v[3]);
 		}
 	}
-	for (int cc = 0; cc < W / FB_NT; cc++) {                       /* vertical pass: column c, outputs ky = k0 .. k0+15 */
-		const int c = t + FB_NT * cc;
+	/* vertical pass: column c = t, outputs ky = k0 .. k0+15.  Columns below 256 (the low band of pass 1) and the others take different
+	 * rounding rules; a wavefront lies wholly on one side, so the side is a compile-time constant of two instances of the body and the
+	 * choice a scalar branch. */
+	static_assert(FB_NT == W, "one column per thread");
+	auto vertical = [&](auto side) {
+		constexpr bool LEFT = decltype(side)::value;
+		const int c = t;
 		int16_t col[FB_TROWS];                                     /* col[i] = pass-1 row t0+i, symmetric extension x[-j]=x[j], x[511+j]=x[511-j] */
 #pragma unroll
 		for (int rt = 0; rt < FB_TROWS; rt++) {
@@ -642,7 +667,7 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 #define XS(d) ((int)col[2 * kk + 4 + (d)])                         /* x[2ky + d], -4 <= d <= 2 */
 			const int r = 6 * XS(0) + 2 * (XS(-1) + XS(1)) - (XS(-2) + XS(2));
 			int l, h;
-			if (c < H) {                                           /* filters.c:203-287 */
+			if (LEFT) {                                            /* filters.c:203-287 */
 				int carry = 0;
 				if (ky > 0) carry = diffuse(6 * XS(-2) + 2 * (XS(-3) + XS(-1)) - (XS(-4) + XS(0)));
 				l = rnd_half_away((int16_t)(r + carry), 6);
@@ -651,8 +676,8 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 				int a = XS(0) + XS(2);
 				if ((ky & 1) && (a & 1) && ((XS(-2) + XS(0)) & 1)) a++;
 				const int pr = XS(1) - (a >> 1);
-				h = c < H ? rnd_half_away(pr, 3) : (pr > 0 ? (pr + 1) >> 1 : pr >> 1);
-			} else h = c < H ? ((XS(1) - XS(0)) >> 3) : (((XS(1) - XS(0)) + 1) >> 1);
+				h = LEFT ? rnd_half_away(pr, 3) : (pr > 0 ? (pr + 1) >> 1 : pr >> 1);
+			} else h = LEFT ? ((XS(1) - XS(0)) >> 3) : (((XS(1) - XS(0)) + 1) >> 1);
 #undef XS
 			if (kk & 1) { lo[kk >> 1] |= (uint32_t)(uint16_t)l << 16; hi[kk >> 1] |= (uint32_t)(uint16_t)h << 16; }
 			else { lo[kk >> 1] = (uint16_t)l; hi[kk >> 1] = (uint16_t)h; }
@@ -663,11 +688,12 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 			reinterpret_cast<uint4 *>(orow + k0)[i] = make_uint4(lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]);
 			reinterpret_cast<uint4 *>(orow + H + k0)[i] = make_uint4(hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]);
 		}
-		if (c < H) {                                               /* LL, natural orientation, through LDS for coalesced rows */
+		if (LEFT) {                                                /* LL, natural orientation, through LDS for coalesced rows */
 #pragma unroll
 			for (int kk = 0; kk < FB_KB; kk++) ybuf[kk * FB_RS + c] = (int16_t)((kk & 1) ? (lo[kk >> 1] >> 16) : (lo[kk >> 1] & 0xFFFF));
 		}
-	}
+	};
+	if (__builtin_amdgcn_readfirstlane(t) < H) vertical(std::true_type{}); else vertical(std::false_type{});
 	__syncthreads();
 	STAMP(6);
 	for (int k = t; k < FB_KB * (H / 2); k += FB_NT) {               /* jpeg[ky][kx] and ll1[ky][kx], kx < 256 (wavelet_filterbank.c:172-184, nhw_encoder.c:127-135) */
@@ -994,6 +1020,9 @@ void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv,
 		else if (fam == 1) k_front_rowtail<1><<<rg, 64, 0, s>>>(bgr, yq, maps, m_stride, flags, f_stride, force_fallback);
 		else k_front_rowtail<2><<<rg, 64, 0, s>>>(bgr, yq, maps, m_stride, flags, f_stride, force_fallback);
 		k_front_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, flags, f_stride, st, s_stride, n);
+#ifdef NHW_DEV
+		{ const char *e = getenv("NHW_BAND_STOP"); if (e) force_fallback |= atoi(e) << 8; }
+#endif
 		if (fam == 0) k_front_band<1, 1, 0><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback, n);
 		else if (fam == 1) k_front_band<1, 1, 1><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback, n);
 		else k_front_band<1, 1, 2><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback, n);

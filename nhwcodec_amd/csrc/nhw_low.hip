@@ -987,8 +987,10 @@ void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStr
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
                               int q, int n, hipStream_t s)
 {
-	static int dbg = -1;
-	if (dbg < 0) { const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
+	static int dbg = 0;
+#ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing */
+	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
+#endif
 	k_low_prefilter<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, dbg);
 	if (!(dbg & 8)) k_low_final<<<dim3(2, n), 256, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q);
 }

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Run on the GPU box: issue/stall counters of the encode kernels (one --pmc pass per counter group).  usage: bash profiles/collect_valu.sh <tag>
+set -u
+TAG=${1:-r2v}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/$TAG; mkdir -p $OUT/pmc
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --sweep="
+i=0
+for grp in "SQ_INSTS_VALU GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS" "SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM"; do
+	i=$((i+1))
+	rocprofv3 --pmc $grp --kernel-trace -d $OUT/pmc/g$i -o p --output-format csv -- $CMD > $OUT/pmc_g$i.log 2>&1
+done
+python profiles/pmc_summarise.py $OUT/pmc > $OUT/pmc_valu.json 2>$OUT/pmc.err
+rm -rf $OUT/pmc

@@ -11,3 +11,4 @@ st=np.zeros(16,np.uint64); e.lib.nhw_debug_stamps(ctypes.c_void_p(st.ctypes.data
 names=['load','contrast+entry','replay','pairs','pass1','vertical','LL store']
 for i,nm in enumerate(names): print(f"{nm:16s} {(int(st[i+1])-int(st[i]))/100.0:8.2f} us")
 print('total', (int(st[7])-int(st[0]))/100.0)
+print('big pair groups per image', int(st[15]) / (2.0 * n), 'of', 510 * 64)
