@@ -651,13 +651,35 @@ DEV void classify_step(const uint8_t *tab, int q, int r, int j, int16_t *pr, int
  * runs afterwards on a packed LDS copy of its column: its "column 256" is the LH1 column written by the other
  * columns, its ll1 neighbour is column 0, both read live. */
 #define CR 8
-#define CR_LDS_BYTES (((CR + 3) * 3 * H + H * (CR + 2)) * 2 + CK_TABLE_BYTES)
+/* The LH1 coefficients of column j are row j of the plane, LW of them at a time for all 256 rows: whole 64-byte pieces of every row
+ * (a piece per chunk of CR rows is 16 bytes of a line that has left the L2 again when the next chunk asks for its neighbour -- measured
+ * 4x the band's bytes in either direction).  LP: LDS pitch of a column's piece, an odd number of dwords. */
+#define LW 16
+#define LP (LW + 2)
+#define CR_LDS_BYTES (((CR + 3) * 3 * H + H * LP) * 2 + CK_TABLE_BYTES)
+DEV void lh_tile_load(int16_t *lt, const int16_t *p, int r0, int tid)
+{
+	for (int v = tid; v < H * (LW / 8); v += NT) {
+		const int jj = v / (LW / 8), h = v % (LW / 8);
+		const uint4 x = *reinterpret_cast<const uint4 *>(p + jj * W + H + r0 + 8 * h);
+		uint32_t *d = reinterpret_cast<uint32_t *>(lt + jj * LP + 8 * h);
+		d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+	}
+}
+DEV void lh_tile_store(const int16_t *lt, int16_t *p, int r0, int tid)
+{
+	for (int v = tid; v < H * (LW / 8); v += NT) {
+		const int jj = v / (LW / 8), h = v % (LW / 8);
+		const uint32_t *d = reinterpret_cast<const uint32_t *>(lt + jj * LP + 8 * h);
+		*reinterpret_cast<uint4 *>(p + jj * W + H + r0 + 8 * h) = make_uint4(d[0], d[1], d[2], d[3]);
+	}
+}
 DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 {
 	int16_t *p = c->proc, *o = c->ll1;
 	const int q = c->q;
-	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *dt = lds + 2 * (CR + 3) * H, *lt = lds + 3 * (CR + 3) * H;   /* pt/ot/dt: rows r0-1 .. r0+CR+1; lt: [column][CR + 2] */
-	uint8_t *ktab = reinterpret_cast<uint8_t *>(lds + 3 * (CR + 3) * H + H * (CR + 2));
+	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *dt = lds + 2 * (CR + 3) * H, *lt = lds + 3 * (CR + 3) * H;   /* pt/ot/dt: rows r0-1 .. r0+CR+1; lt: [column][LP] */
+	uint8_t *ktab = reinterpret_cast<uint8_t *>(lds + 3 * (CR + 3) * H + H * LP);
 	classify_table_fill(ktab, q, res_setting, tid);
 	const int j = tid;
 	int lhm1 = p[j * W + H - 1];                                    /* (j, 255): nothing has touched it yet */
@@ -681,16 +703,11 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 				*reinterpret_cast<uint4 *>(dt + i * H + c8) = make_uint4(d[0], d[1], d[2], d[3]);
 			}
 		}
-		for (int v = tid; v < H * (CR / 8); v += NT) {
-			const int jj = v / (CR / 8), h = v % (CR / 8);
-			const uint4 x = *reinterpret_cast<const uint4 *>(p + jj * W + H + r0 + 8 * h);
-			uint32_t *d = reinterpret_cast<uint32_t *>(lt + jj * (CR + 2) + 8 * h);
-			d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-		}
+		if (r0 % LW == 0) lh_tile_load(lt, p, r0, tid);
 		BARRIER();
 		if (j < H - 1)
 			for (int i = 0; i < CR && r0 + i < H - 1; i++) {
-				int16_t *lh = lt + j * (CR + 2) + i;
+				int16_t *lh = lt + j * LP + r0 % LW + i;
 				classify_step<true>(ktab, q, r0 + i, j, pt + (i + 1) * H + j, H, ot + (i + 1) * H + j, H, lh, lhm1, dt + (i + 1) * H + j + 1, H, nullptr, 0);
 				lhm1 = lh[0];
 			}
@@ -700,11 +717,7 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 			*reinterpret_cast<uint4 *>(p + row * W + c8) = *reinterpret_cast<const uint4 *>(pt + i * H + c8);
 			if (row < H) *reinterpret_cast<uint4 *>(o + row * H + c8) = *reinterpret_cast<const uint4 *>(ot + i * H + c8);
 		}
-		for (int v = tid; v < H * (CR / 8); v += NT) {
-			const int jj = v / (CR / 8), h = v % (CR / 8);
-			const uint32_t *d = reinterpret_cast<const uint32_t *>(lt + jj * (CR + 2) + 8 * h);
-			*reinterpret_cast<uint4 *>(p + jj * W + H + r0 + 8 * h) = make_uint4(d[0], d[1], d[2], d[3]);
-		}
+		if ((r0 + CR) % LW == 0) lh_tile_store(lt, p, r0 + CR - LW, tid);
 		BARRIER();
 	}
 	{                                                              /* column 255 */
@@ -742,16 +755,11 @@ DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 			*reinterpret_cast<uint4 *>(pt + i * H + c8) = *reinterpret_cast<const uint4 *>(p + (r0 + i) * W + c8);
 			*reinterpret_cast<uint4 *>(ot + i * H + c8) = *reinterpret_cast<const uint4 *>(o + (r0 + i) * H + c8);
 		}
-		for (int v = tid; v < H * (CR / 8); v += NT) {
-			const int jj = v / (CR / 8), h = v % (CR / 8);
-			const uint4 x = *reinterpret_cast<const uint4 *>(p + jj * W + H + r0 + 8 * h);
-			uint32_t *d = reinterpret_cast<uint32_t *>(lt + jj * (CR + 2) + 8 * h);
-			d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-		}
+		if (r0 % LW == 0) lh_tile_load(lt, p, r0, tid);
 		BARRIER();
 		for (int i = 0; i < CR; i++) {
 			int16_t *cell = ot + i * H + j;
-			int16_t *v = lt + j * (CR + 2) + i;
+			int16_t *v = lt + j * LP + r0 % LW + i;
 			if (*cell < 12000) {
 				const int res = pt[i * H + j] - *cell;
 				*cell = 0;
@@ -792,11 +800,7 @@ DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 			const int i = v / (H / 8), c8 = 8 * (v % (H / 8));
 			*reinterpret_cast<uint4 *>(o + (r0 + i) * H + c8) = *reinterpret_cast<const uint4 *>(ot + i * H + c8);
 		}
-		for (int v = tid; v < H * (CR / 8); v += NT) {
-			const int jj = v / (CR / 8), h = v % (CR / 8);
-			const uint32_t *d = reinterpret_cast<const uint32_t *>(lt + jj * (CR + 2) + 8 * h);
-			*reinterpret_cast<uint4 *>(p + jj * W + H + r0 + 8 * h) = make_uint4(d[0], d[1], d[2], d[3]);
-		}
+		if ((r0 + CR) % LW == 0) lh_tile_store(lt, p, r0 + CR - LW, tid);
 		BARRIER();
 	}
 }
