@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 MPIX_PER_IMAGE = 0.262144
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 FRONT_BYTES_PER_IMAGE = 786432 + 786432   # 3 B/px read + 3 B/px written (Y coeffs + 2 x chroma)
-FRONT_KERNEL_NAME = "front = k_color + k_front_rowtail + k_front_chain + k_front_band (colour, pre-filter and level-1 analysis; the band kernel fuses pre-filter + both filter directions)"
+FRONT_KERNEL_NAME = ("front = k_front_band, ONE fused kernel: BGR24 -> Y + 4:2:0 chroma planes, luma pre-filter, both directions of the level-1 analysis (the luma plane never "
+                     "travels) -- preceded by its two small pre-passes k_front_rowtail + k_front_chain (18 bytes of carry state per image row), all inside the timed group")
 PMC_FILE = os.path.join(ROOT, "profiles", "front_pmc.json")     # written by profiles/pmc_summarise.py from separate rocprofv3 --pmc passes
 
 
@@ -112,10 +113,10 @@ def cpu_decode_baseline(files, budget_s=6.0):
 
 
 def valu_evidence():
-    """VALU issue statistics of the front kernels from the committed PMC pass (profiles/round1_pmc_valu.json, batch 4096, -q20):
+    """VALU issue statistics of the front kernels from the committed PMC pass (profiles/round2_pmc_valu.json, batch 4096, -q20):
     wave-instructions issued / (CUs x kernel cycles) -- why these kernels sit where they do against the HBM roofline."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc_valu.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "round2_pmc_valu.json")) as fh:
             d = json.load(fh)
     except OSError:
         return None
@@ -124,7 +125,7 @@ def valu_evidence():
         if "SQ_INSTS_VALU" not in v or "GRBM_GUI_ACTIVE" not in v:
             continue
         name = k.split("::")[-1].split("<")[0].replace("void ", "")
-        if name not in ("k_color", "k_front_rowtail", "k_front_band"):
+        if name not in ("k_front_rowtail", "k_front_band"):
             continue
         cyc = v["GRBM_GUI_ACTIVE"]["per_launch"] / 8.0          # summed over the 8 XCDs
         valu = v["SQ_INSTS_VALU"]["per_launch"]
@@ -264,6 +265,7 @@ def main():
     ap.add_argument("--quality", type=int, default=20)
     ap.add_argument("--sweep", type=str, default="1,10,23", help="BASELINE configs[2]: quality settings timed after the headline measurement (N=1 only); '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive leg (host buffers through nhw_enc_batch) reported next to the metric")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (BASELINE config 5) reported next to the encode metric")
     ap.add_argument("--dry", action="store_true", help="CPU only: rendezvous over gloo, descriptor broadcast, sharding, gather -- no encode (tests of the N>1 plumbing)")
     args = ap.parse_args()
@@ -361,11 +363,11 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            s1 = s2 = sc = 0.0
+            rec = 0.0
             for _ in range(args.steps):
                 _, dst, dq = dec.decode_device(out[0], offs, sizes, pix)
                 dtm = dec.timing()
-                s1 += dtm.synth1_ms; s2 += dtm.synth2_ms; sc += dtm.color_ms
+                rec += dtm.recon_ms
             torch.cuda.synchronize()
             if dist:
                 dist.barrier()
@@ -379,21 +381,32 @@ def main():
                     "workload": f"the {batch} .nhw files per GPU this run just encoded (-q{q}), decoder arena = encoder arena in HBM",
                     "stage_ms": {"entropy": round(dtm.entropy_ms, 3), "total": round(dtm.total_ms, 3)},
                     # SURVEY 8(d) for config 5: the final reconstruction (level-1 synthesis, both directions, + colour) has 3 B/px of coefficients in and 3 B/px of
-                    # BGR out as its algorithmic traffic; here it is three kernels, each listed with its own bytes (hipEvents on the launch stream)
-                    "roofline": {"bound": "hbm", "kernel": "k_dec_synth (level 1, first direction) + k_dec_synth (level 1, second direction, -> bytes) + k_dec_color",
-                                 "achieved": round(batch * 1572864 / ((s1 + s2 + sc) / 1e3 / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(batch * 1572864 / ((s1 + s2 + sc) / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                                 "algorithmic_bytes_per_image": 1572864,
-                                 "kernels": [{"kernel": "level-1 synthesis, rows (int16 in, int16 out)", "ms": round(s1 / args.steps, 3), "algorithmic_bytes": batch * 1048576,
-                                              "achieved": round(batch * 1048576 / (s1 / 1e3 / args.steps) / 1e9, 1)},
-                                             {"kernel": "level-1 synthesis, columns (int16 in, clipped bytes out)", "ms": round(s2 / args.steps, 3), "algorithmic_bytes": batch * 786432,
-                                              "achieved": round(batch * 786432 / (s2 / 1e3 / args.steps) / 1e9, 1)},
-                                             {"kernel": "x2 chroma + colour matrix (Y + 4:2:0 U,V bytes in, BGR24 out)", "ms": round(sc / args.steps, 3), "algorithmic_bytes": batch * (262144 + 131072 + 786432),
-                                              "achieved": round(batch * (262144 + 131072 + 786432) / (sc / 1e3 / args.steps) / 1e9, 1)}]}}
+                    # BGR out as its algorithmic traffic; it is ONE kernel (k_dec_final: the intermediate plane and the luma bytes stay in LDS), hipEvents on the launch stream
+                    "roofline": {"bound": "hbm", "kernel": "k_dec_final (level-1 synthesis in both directions + q>21 corrections + smoothing at the marks + x2 chroma + colour matrix)",
+                                 "achieved": round(batch * 1572864 / (rec / 1e3 / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(batch * 1572864 / (rec / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                 "algorithmic_bytes_per_image": 1572864, "ms_per_launch": round(rec / args.steps, 3)}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             szh = sizes[:256].cpu().numpy(); ar = out[0][:256].cpu().numpy()
             dec_line["cpu_baseline"] = cpu_decode_baseline([ar[i, : int(szh[i])].tobytes() for i in range(min(256, batch))])
         dec.close()
+
+    # the same encoder behind the host-buffer entry point (page-locked BGR in host memory -> chunked H2D on a copy stream next
+    # to the encode of the chunk before -> files compacted on the device -> D2H).  PCIe-inclusive, reported apart; never `value`.
+    host_line = None
+    if world == 1 and not args.no_host_path:
+        import numpy as np
+        hn = min(batch, 2048)
+        pinned = enc.pinned_images(hn)
+        pinned[:] = bgr[:hn].cpu().numpy()
+        enc.encode(pinned[:64], q)
+        th = time.perf_counter()
+        files = enc.encode(pinned, q)
+        hdt = time.perf_counter() - th
+        host_line = {"metric": "encode Mpixels/s incl. PCIe both ways (page-locked host BGR in, .nhw bytes on the host out)", "value": round(hn * MPIX_PER_IMAGE / hdt, 2),
+                     "unit": "Mpixels/s", "images": hn, "ms": round(hdt * 1e3, 2), "bytes_in": hn * 786432, "bytes_out": int(sum(len(f) for f in files)),
+                     "same_files_as_resident_run": bool(all(files[i] == bytes(out[0][i, : int(sizes[i])].cpu().numpy().tobytes()) for i in (0, hn // 2, hn - 1)))}
+        enc.free_pinned()
 
     if rank == 0:
         total_images = total_per_step * args.steps
@@ -413,9 +426,6 @@ def main():
             "roofline": {"bound": "hbm", "kernel": FRONT_KERNEL_NAME,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_unit": "bytes per launch group; " + traffic_note,
-                         "kernels": [   # the members of the group, each with its own algorithmic bytes and live hipEvent time
-                             {"kernel": "first kernel of the group (see `kernel`)", "ms": round(color_ms / args.steps, 3)},
-                             {"kernel": "rest of the group", "ms": round((front_ms - color_ms) / args.steps, 3)}],
                          "algorithmic_bytes_per_launch": front_images * FRONT_BYTES_PER_IMAGE, "images_per_launch": front_images, "sub_batches": tim.parts, "algorithmic_bytes_per_image": FRONT_BYTES_PER_IMAGE, "ms_per_launch_group": round(front_s * 1e3, 3)},
             "stage_ms": {"front": round(tim.front_ms, 3), "luma_tail (chroma sequence alongside, on its own stream)": round(tim.luma_ms, 3), "chroma left over": round(tim.chroma_ms, 3),
                          "entropy+container": round(tim.entropy_ms, 3), "total": round(tim.total_ms, 3)},
@@ -426,6 +436,8 @@ def main():
         ev = valu_evidence()
         if ev:
             line["roofline"]["valu_pmc"] = ev
+        if host_line:
+            line["host_path"] = host_line
         if dec_line:
             line["decode"] = dec_line
         if not args.no_cpu_baseline and world == 1:

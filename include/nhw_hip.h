@@ -123,7 +123,7 @@ void nhw_dec_bmp_header(uint8_t h[54]);
 /* hipEvent timings of the last nhw_dec_batch_device call (events on its launch stream): the whole sequence, the entropy stages
  * (parse, prefix-code walk, un-zig-zag), the two level-1 luma synthesis passes and the colour kernel -- the last three are the kernels
  * SURVEY.md 8(d) prices against the HBM roofline for the decode path */
-typedef struct { float total_ms, entropy_ms, synth1_ms, synth2_ms, color_ms; } nhw_dec_timing;
+typedef struct { float total_ms, entropy_ms, recon_ms; } nhw_dec_timing;   /* recon_ms: the final reconstruction kernel (level-1 synthesis both ways + colour) */
 int nhw_dec_last_timing(nhw_dec *d, nhw_dec_timing *t);
 
 #ifdef __cplusplus

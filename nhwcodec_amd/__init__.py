@@ -193,7 +193,7 @@ class _OnTorchStream:
 
 
 class DecTiming(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "entropy_ms", "synth1_ms", "synth2_ms", "color_ms")]
+    _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "entropy_ms", "recon_ms")]
 
 
 class Decoder:

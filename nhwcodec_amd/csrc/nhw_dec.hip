@@ -37,12 +37,12 @@ namespace {
 /* ---------------------------------------------------------------------------------------------- workspace
  * structure of arrays over the batch: buffer b of image i at base + off[b] + i * size[b] */
 enum {
-	D_META, D_LL, D_SPARE, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_YB, D_CU, D_COUNT
+	D_META, D_LL, D_SPARE, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_CU, D_COUNT
 };
 enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304 /* sanity bound on the packet words of a file (the encoder's buffer holds 80000) */ };
 const size_t k_dec_bytes[D_COUNT] = {
-	/* META */ 512, /* LL */ 24832, /* SPARE */ 256, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
-	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 8 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 2 * (2 * DQ + 4096), /* YB */ 4 * DQ, /* CU */ 2 * DQ
+	/* META */ 512, /* LL */ 24832, /* SPARE */ 1024, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
+	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 8 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 2 * (2 * DQ + 4096), /* CU */ 2 * DQ
 };
 
 struct DecMeta {
@@ -69,10 +69,10 @@ struct DecWs {
 	__host__ __device__ static size_t k_dec_bytes_dev(int b)
 	{
 		switch (b) {
-		case D_META: return 512; case D_LL: return 24832; case D_SPARE: return 256;
+		case D_META: return 512; case D_LL: return 24832; case D_SPARE: return 1024;
 		case D_P1: case D_P3: case D_P5: return P16_CAP * 2; case D_P6: return (size_t)P6_CAP * 4;
 		case D_MARKS: return 2 * DQ; case D_A: case D_B: return 8 * DQ + 8192;
-		case D_CA: case D_CB: return 2 * (2 * DQ + 4096); case D_YB: return 4 * DQ; default: return 2 * DQ;
+		case D_CA: case D_CB: return 2 * (2 * DQ + 4096); default: return 2 * DQ;
 		}
 	}
 };
@@ -80,6 +80,7 @@ struct DecWs {
 /* planes: A and B start 4096 bytes into their buffers (the reference writes one cell in front of a plane in a corner case) */
 DEV int16_t *plane_a(const DecWs &ws, int img) { return ws.buf<int16_t>(D_A, img) + 2048; }
 DEV int16_t *plane_b(const DecWs &ws, int img) { return ws.buf<int16_t>(D_B, img) + 2048; }
+DEV uint16_t *mark_rows(const DecWs &ws, int img) { return ws.buf<uint16_t>(D_SPARE, img) + 8; }   /* behind the verdict word */
 DEV int16_t *plane_ca(const DecWs &ws, int img, int comp) { return ws.buf<int16_t>(D_CA, img) + 1024 + (size_t)comp * (DQ + 2048); }
 DEV int16_t *plane_cb(const DecWs &ws, int img, int comp) { return ws.buf<int16_t>(D_CB, img) + 1024 + (size_t)comp * (DQ + 2048); }
 
@@ -1118,7 +1119,7 @@ __global__ __launch_bounds__(256) void k_dec_shrink(DecWs ws)
  * transposed instead (rows below `lo_t` take their low half from columns, `hi_t` likewise for the high half).
  * A workgroup stages 16 rows in LDS and writes 16 output rows. */
 struct SynthArgs {
-	int src, dst;            /* D_A / D_B / D_CA / D_CB (+ component for chroma), dst -1: clipped bytes to D_YB */
+	int src, dst;            /* D_A / D_B / D_CA / D_CB (+ component for chroma) */
 	int comp;
 	int st, rows, n;         /* row stride of both planes, rows to produce, samples per output row */
 	int lo_t, hi_t, norm;
@@ -1149,13 +1150,8 @@ __global__ __launch_bounds__(256) void k_dec_synth(DecWs ws, SynthArgs g)
 		else { ev -= (hi[M - 1] + hi[M - 2]) << 1; od += 5 * hi[M - 1] - hi[M - 2]; }
 		ev = (int16_t)ev; od = (int16_t)od;
 		if (g.norm) { if (ev > 0) ev = (int16_t)(ev + 32); ev >>= 6; if (od > 0) od = (int16_t)(od + 32); od >>= 6; }
-		if (g.dst < 0) {
-			uint8_t *y = ws.buf<uint8_t>(D_YB, img) + (size_t)(r0 + rr) * g.n + 2 * k;
-			*(uchar2 *)y = make_uchar2((unsigned char)clip8(ev), (unsigned char)clip8(od));
-		} else {
-			int16_t *d = synth_plane(ws, g.dst, img, comp) + (size_t)(r0 + rr) * g.st + 2 * k;
-			*(short2 *)d = make_short2((short)ev, (short)od);
-		}
+		int16_t *d = synth_plane(ws, g.dst, img, comp) + (size_t)(r0 + rr) * g.st + 2 * k;
+		*(short2 *)d = make_short2((short)ev, (short)od);
 	}
 }
 
@@ -1249,7 +1245,9 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 	if (m->status) return;
 	const int16_t *c = plane_a(ws, img);
 	uint16_t *marks = ws.buf<uint16_t>(D_MARKS, img);
+	uint16_t *rowstart = mark_rows(ws, img);                        /* [257]: index of the first mark of row i (the list is in row order) */
 	int total = 0;
+	if (lane < 2) rowstart[lane] = 0;
 	unsigned above = 0;                                             /* marks of the row above on my cells 4l+1..4l+4 (bits 0..3) */
 	for (int i = 1; i < DH - 1; i++) {
 		const int16_t *p = c + (size_t)i * DW + 4 * lane + 1;
@@ -1281,59 +1279,9 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 		for (int k = 0; k < 4; k++) if ((mine >> k) & 1u) marks[at++] = (uint16_t)(i * DH + 4 * lane + 1 + k);
 		total += __shfl(pre, 63);
 		above = mine;
+		if (!lane) rowstart[i + 1] = (uint16_t)total;
 	}
-	if (!lane) m->nmarks = total;
-}
-
-/* q>21 corrections on the first-direction output of level 1 (wavelet_filterbank.c:301-347) */
-__global__ __launch_bounds__(256) void k_dec_corr(DecWs ws)
-{
-	const int img = blockIdx.x, tid = threadIdx.x;
-	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
-	if (m->status || m->q <= 21) return;
-	const uint8_t *f = ws.blob + ws.blob_off[img];
-	int16_t *b = plane_b(ws, img);
-	const uint32_t *p6 = ws.buf<uint32_t>(D_P6, img);
-	const int cnt = (m->res6_bits - 1) * 8;
-	for (int k = tid; k < cnt; k += 256) if (p6[k] < 4u * DQ) add_i16(b + p6[k], bit_of(f + m->o_res6_word, m->res6_bits, k) ? -32 : 32);
-	const uint8_t *cr = f + m->o_char;
-	for (int k = tid; k < m->char_res1_len; k += 256) {
-		const int v = cr[2 * k] | (cr[2 * k + 1] << 8);
-		const int t = v & 3;
-		const int at = t == 0 ? (v << 1) + DH - 2 : t == 1 ? ((v - 1) << 1) + DH - 2 : t == 2 ? ((v - 2) << 1) + DH - 1 : ((v - 3) << 1) + DH - 1;
-		if (at >= 0 && at < 4 * DQ) add_i16(b + at, (t & 1) ? -32 : 32);
-	}
-	if (m->q > 22) {
-		const uint8_t *qs = f + m->o_qs3;
-		for (int k = tid; k < m->qs3_len; k += 256) {
-			const uint32_t v = (uint32_t)qs[4 * k] | ((uint32_t)qs[4 * k + 1] << 8) | ((uint32_t)qs[4 * k + 2] << 16) | ((uint32_t)qs[4 * k + 3] << 24);
-			if ((v >> 1) < 4u * DQ) add_i16(b + (v >> 1), (v & 1) ? -56 : 56);
-		}
-	}
-}
-
-/* 5-tap smoothing at the marked samples (:859-876), on plane B read transposed (the reference transposes first).
- * List order matters only inside a run of horizontally adjacent marks: the head of a run walks it. */
-#define SMOOTH_WGS 16
-__global__ __launch_bounds__(256) void k_dec_smooth(DecWs ws)
-{
-	const int img = blockIdx.y;
-	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
-	if (m->status) return;
-	const int nmarks = m->nmarks;
-	const uint16_t *marks = ws.buf<uint16_t>(D_MARKS, img);
-	int16_t *b = plane_b(ws, img);
-	for (int k = blockIdx.x * 256 + threadIdx.x; k < nmarks; k += 256 * SMOOTH_WGS) {   /* a workgroup per 256 possible marks was a million workgroups, most of them empty */
-	if (k > 0 && marks[k - 1] + 1 == marks[k]) continue;
-	for (int t = k; t < nmarks && (t == k || marks[t - 1] + 1 == marks[t]); t++) {
-		const int row = (marks[t] >> 8) << 1, col = marks[t] & 255;     /* cell (row, col) of the transposed plane = b[col][row] */
-#define TP(dr, dc) ((int)b[(size_t)(col + (dc)) * DW + row + (dr)])
-		const int ctr = TP(0, 0);
-		const int lap = (ctr << 3) - TP(0, -1) - TP(0, 1) - TP(-1, 0) - TP(1, 0) - TP(-1, -1) - TP(1, -1) - TP(-1, 1) - TP(1, 1);
-		if (iabs(lap) < 116) b[(size_t)col * DW + row] = (int16_t)(((ctr << 2) + TP(0, -1) + TP(0, 1) + TP(-1, 0) + TP(1, 0) + 4) >> 3);
-#undef TP
-	}
-	}
+	if (!lane) { m->nmarks = total; rowstart[DH] = (uint16_t)total; }
 }
 
 /* ---------------------------------------------------------------------------------------------- chroma
@@ -1411,11 +1359,26 @@ __global__ __launch_bounds__(256) void k_dec_sharpen(DecWs ws)
  * matrix of write_image_bmp (nhw_decoder_cli.c:135-286); output bytes in the order the reference writes them */
 __constant__ float k_inv_low[17] = { 0.0f, 2.060881f, 1.985939f, 1.916257f, 1.820444f, 1.741126f, 1.665887f, 1.587597f, 1.521263f,
 	1.392014f, 1.281502f, 1.190611f, 1.177434f, 1.186945f, 1.138331f, 1.048174f, 1.012139f };
+/* bits 32..47 of a 24 x 24 bit product on the full-rate multiplier (operands must fit 24 bits) */
+DEV unsigned mulhi_u24(unsigned a, unsigned b) { unsigned r; asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
 {
 	if (q >= 20) {
+		/* The reference evaluates Y + 1.402 V + 0.5 and its two sisters in double and truncates.  The exact values are multiples of 1/1000
+		 * (1/100000 for G) and the rounding errors are some 1e-13, so the truncation can only differ from the integer quotient below where
+		 * the exact value IS an integer: never for R, harmlessly for B, and for G at 493 of the 2^24 triples -- those take the double path
+		 * (checked against the double evaluation over all 2^24 triples).  Negative values and values from 256 clip either way. */
 		const int Y = yv, U = uv - 128, V = vv - 128;
-		R = (int)(Y + 1.402 * V + 0.5f); G = (int)(Y - 0.34414 * U - 0.71414 * V + 0.5f); B = (int)(Y + 1.772 * U + 0.5f);
+		/* every product fits the full-rate 24-bit multiplier; n / 1000 = (n * 8589935) >> 33 for n < 2^19, and
+		 * n / 100000 = ((n >> 5) * 10995117) >> 35 for n < 2^26 (floor(floor(n / 32) / 3125)) */
+		const int base = __mul24(Y, 1000) + 500;
+		const int nR = base + __mul24(V, 1402), nB = base + __mul24(U, 1772);
+		const int nG = __mul24(Y, 100000) - __mul24(U, 34414) - __mul24(V, 71414) + 50000;
+		R = (int)min(mulhi_u24((unsigned)max(nR, 0), 8589935u) >> 1, 255u);
+		B = (int)min(mulhi_u24((unsigned)max(nB, 0), 8589935u) >> 1, 255u);
+		const unsigned gq = mulhi_u24((unsigned)max(nG, 0) >> 5, 10995117u) >> 3;
+		G = (int)min(gq, 255u);
+		if (nG > 0 && (unsigned)__mul24((int)gq, 100000) == (unsigned)nG) G = (int)(Y - 0.34414 * U - 0.71414 * V + 0.5f);
 	}
 	else if (q >= 18) {
 		const float yinv = q == 19 ? 1.025641f : 1.075269f;
@@ -1437,58 +1400,217 @@ DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
 	}
 	R = clip8(R); G = clip8(G); B = clip8(B);
 }
-#define COLOR_PAIRS 4                /* row pairs per workgroup */
-/* one workgroup = COLOR_PAIRS x two output rows (2i, 2i+1); a thread = four pixels of one of them: one 32-bit load of Y, three chroma
- * columns of the two source rows (staged in LDS: five chroma rows of each plane serve the eight output rows), 12 output bytes.  The
- * output rows go through LDS as well so that they leave as 16-byte stores of consecutive lanes (12-byte pieces per lane made every
- * store instruction touch every line of the row). */
-__global__ __launch_bounds__(256) void k_dec_color(DecWs ws, uint8_t *out)
+/* ---------------------------------------------------------------------------------------------- final reconstruction, one kernel
+ * Level-1 synthesis in both directions (decoder/wavelet_filterbank.c:52-357 as driven by nhw_decoder.c), the q > 21 corrections on the
+ * plane between them (wavelet_filterbank.c:301-347), the 5-tap smoothing at the marked samples (nhw_decoder.c:859-876), the doubling of
+ * the chroma planes and the colour matrix (nhw_decoder_cli.c:133-283) for a band of FR output rows: the intermediate plane and the luma
+ * bytes never travel.
+ *
+ * The second direction is pointwise in the output row r': Y[r'][2j], Y[r'][2j+1] come from T[j][r'], T[256+j][r'] and their neighbours in j,
+ * where T is the first direction's output (the reference's transposed plane).  T[k][2m], T[k][2m+1] in turn come from line k of plane A:
+ * its low half (for k < 256 the level-1 LL, kept transposed: A[m][k]) and high half around m.  So a band needs, of every one of the 512
+ * lines of A, the dozen coefficients around m = r0/2 -- 24-byte pieces; the four bands that share a 64-byte sector run next to each other
+ * on one XCD (same workgroup order as the encoder's front kernel), so the sector is fetched from HBM once.
+ * The smoothing reads the rows above and below a mark; marks sit in even rows only (k_dec_marks), and the rows next to them are never
+ * marked, so a band needs one extra row (r0 - 1) and sees it as the corrections left it.  The list is in row order and k_dec_marks
+ * leaves the index of every row's first mark, so a band knows its share. */
+#define FR 16                        /* output rows per workgroup */
+#define FBP (FR + 2)                 /* LDS pitch (shorts) of a line of T: local index l <-> row r0 - 2 + l (l = 0 unused); 9 dwords: no bank conflicts across lines */
+#define FM (FR / 2 + 1)              /* values of m a band computes: r0/2 - 1 .. r0/2 + FR/2 - 1 */
+#define F_T_BYTES (2 * DH * FBP * 2)
+#define F_HI_P 12                    /* staged coefficients per line: high half m - 1 .. m + FM (11 used), low half m .. m + FM (10 used) */
+#define F_LDS_BYTES (F_T_BYTES + 24576 + 2 * (FR / 2 + 1) * DH)
+/* add to element idx of an int16 array in LDS (dword-aligned base): compare-and-swap on the dword, the pointer stays a typed offset of
+ * the base so that it compiles to the LDS instruction */
+DEV void add_i16_at(int16_t *base, int idx, int delta)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t crow[2][COLOR_PAIRS + 1][DH];
-	__shared__ __attribute__((aligned(16))) uint32_t orow[2 * COLOR_PAIRS][DW * 3 / 4];
-	const int img = blockIdx.y, t = threadIdx.x & 127, tid = threadIdx.x;
+	unsigned *w = reinterpret_cast<unsigned *>(base) + (idx >> 1);
+	const int sh = (idx & 1) << 4;
+	unsigned old = *w, seen;
+	do {
+		seen = old;
+		const unsigned v = ((((seen >> sh) & 0xFFFFu) + (unsigned)delta) & 0xFFFFu) << sh;
+		old = atomicCAS(w, seen, (seen & ~(0xFFFFu << sh)) | v);
+	} while (old != seen);
+}
+__global__ __launch_bounds__(256) void k_dec_final(DecWs ws, uint8_t *out, int dev_stop /* developer builds: end every band after phase dev_stop (0: run it all) */)
+{
+#ifdef NHW_DEV
+#define F_STOP(i) do { if (dev_stop == (i)) return; } while (0)
+#else
+#define F_STOP(i) do { } while (0)
+#endif
+	extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
+	int16_t *T = reinterpret_cast<int16_t *>(fl);                               /* [512][FBP] */
+	uint8_t *X = fl + F_T_BYTES;                                                /* 24 KB: the staged pieces of A, later the luma bytes (at its end) */
+	int16_t *hiA = reinterpret_cast<int16_t *>(X);                              /* [512][F_HI_P]: A[k][256 + r0/2 - 2 + e] */
+	int16_t *loB = hiA + 2 * DH * F_HI_P;                                       /* [256][F_HI_P]: A[256 + k][r0/2 - 2 + e] */
+	int16_t *loT = loB + DH * F_HI_P;                                           /* [10][256]: A[r0/2 - 1 + e][k] */
+	uint8_t *ybuf = X + 24576 - FR * DW;                                        /* [FR][512] */
+	uint32_t *orow = reinterpret_cast<uint32_t *>(fl);                          /* [FR][384 dwords]: the output rows, over T and the head of X once both are done with */
+	uint8_t *crow = X + 24576;                                                  /* [2][FR / 2 + 1][256] */
+	const int tid = threadIdx.x;
+	int band, img;
+	{
+		const int nb = DW / FR, total = nb * ws.n, w = blockIdx.x, per = total >> 3;
+		const int item = (total & 7) ? w : (w & 7) * per + (w >> 3);            /* workgroup w runs on XCD w % 8: consecutive items stay on one XCD */
+		img = item / nb; band = item % nb;
+	}
 	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
 	if (m->status) return;
-	const int q = m->q;
-	const uint8_t *yb = ws.buf<uint8_t>(D_YB, img), *cu = ws.buf<uint8_t>(D_CU, img), *cv = cu + DQ;
-	const int i0 = COLOR_PAIRS * blockIdx.x;
-	for (int k = tid; k < 2 * (COLOR_PAIRS + 1) * (DH / 16); k += 256) {
-		const int pl = k / ((COLOR_PAIRS + 1) * (DH / 16)), rem = k % ((COLOR_PAIRS + 1) * (DH / 16)), rr = rem / (DH / 16), o = rem % (DH / 16);
-		const int src = i0 + rr < DH ? i0 + rr : DH - 1;
-		reinterpret_cast<uint4 *>(crow[pl][rr])[o] = reinterpret_cast<const uint4 *>((pl ? cv : cu) + (size_t)src * DH)[o];
+	const int q = m->q, r0 = FR * band, m0 = r0 / 2 - 1;                       /* m0: first m of the band (-1 in band 0: skipped) */
+	const int16_t *A = plane_a(ws, img);
+
+	/* stage the pieces of A: of each of the 768 lines (high halves of all 512, low halves of lines 256..511) the twelve coefficients
+	 * r0/2 - 2 .. r0/2 + 9 -- one 16-byte load at r0/2 (16-byte aligned) and a dword on either side; the few coefficients outside a
+	 * line's half that this touches at the first and the last band are never used */
+	for (int ln = tid; ln < 3 * DH; ln += 256) {
+		const int16_t *src = ln < 2 * DH ? A + (size_t)ln * DW + DH + r0 / 2 : A + (size_t)(ln - DH) * DW + r0 / 2;
+		const uint32_t w0 = *reinterpret_cast<const uint32_t *>(src - 2), w5 = *reinterpret_cast<const uint32_t *>(src + 8);
+		const uint4 wm = *reinterpret_cast<const uint4 *>(src);
+		uint32_t *d = reinterpret_cast<uint32_t *>(hiA + ln * F_HI_P);          /* loB follows hiA: line 512 + k is loB[k] */
+		d[0] = w0; d[1] = wm.x; d[2] = wm.y; d[3] = wm.z; d[4] = wm.w; d[5] = w5;
+	}
+	for (int idx = tid; idx < (FM + 1) * (DH / 8); idx += 256) {
+		const int e = idx / (DH / 8), o = idx % (DH / 8);
+		reinterpret_cast<uint4 *>(loT + e * DH)[o] = reinterpret_cast<const uint4 *>(A + (ptrdiff_t)(m0 + e) * DW)[o];   /* row -1 (band 0) lies in the pad in front of the plane */
+	}
+	for (int k = tid; k < 2 * (FR / 2 + 1) * (DH / 16); k += 256) {
+		const int pl = k / ((FR / 2 + 1) * (DH / 16)), rem = k % ((FR / 2 + 1) * (DH / 16)), rr = rem / (DH / 16), o = rem % (DH / 16);
+		const int src = r0 / 2 + rr < DH ? r0 / 2 + rr : DH - 1;
+		reinterpret_cast<uint4 *>(crow + (pl * (FR / 2 + 1) + rr) * DH)[o] = reinterpret_cast<const uint4 *>(ws.buf<uint8_t>(D_CU, img) + (size_t)pl * DQ + (size_t)src * DH)[o];
 	}
 	__syncthreads();
-	for (int it = 0; it < COLOR_PAIRS; it++) {
-		const int r = 2 * (i0 + it) + (tid >> 7);
-		const uint32_t y4 = *(const uint32_t *)(yb + (size_t)r * DW + 4 * t);
-		const int j = 2 * t;
-		int tu[3], tv[3];                                         /* the vertically doubled chroma rows at columns j, j+1, j+2 */
-		for (int c = 0; c < 3; c++) {
-			const int jj = j + c < DH ? j + c : DH - 1;
-			if (r >= 2 * DH - 2) { tu[c] = crow[0][it][jj]; tv[c] = crow[1][it][jj]; }              /* rows 510, 511: chroma row 255 */
-			else if (r & 1) { tu[c] = (crow[0][it][jj] + crow[0][it + 1][jj] + 1) >> 1; tv[c] = (crow[1][it][jj] + crow[1][it + 1][jj] + 1) >> 1; }
-			else { tu[c] = crow[0][it][jj]; tv[c] = crow[1][it][jj]; }
-		}
-		uint32_t w[3] = { 0, 0, 0 };
-		for (int px = 0; px < 4; px++) {
-			const int x = 4 * t + px;
-			int uv, vv;
-			if (x >= DW - 2) { uv = tu[DH - 1 - j]; vv = tv[DH - 1 - j]; }      /* last two columns repeat column 255 (j = 254 here) */
-			else if (x & 1) { uv = (tu[px >> 1] + tu[(px >> 1) + 1] + 1) >> 1; vv = (tv[px >> 1] + tv[(px >> 1) + 1] + 1) >> 1; }
-			else { uv = tu[px >> 1]; vv = tv[px >> 1]; }
-			int R, G, B;
-			yuv_to_bytes(q, (int)((y4 >> (8 * px)) & 255u), uv, vv, R, G, B);
-			const int b0 = 3 * px;
-			w[b0 >> 2] |= (uint32_t)R << (8 * (b0 & 3));
-			w[(b0 + 1) >> 2] |= (uint32_t)G << (8 * ((b0 + 1) & 3));
-			w[(b0 + 2) >> 2] |= (uint32_t)B << (8 * ((b0 + 2) & 3));
-		}
-		uint32_t *o = orow[2 * it + (tid >> 7)] + 3 * t;
-		o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+	F_STOP(1);
+
+	/* first direction (decoder/filters.c:143-194 on line k): T[k][2m], T[k][2m + 1] */
+	for (int idx = tid; idx < 2 * DH * FM; idx += 256) {
+		const int k = idx % (2 * DH), mi = idx / (2 * DH), j = m0 + mi;
+		if (j < 0) continue;
+		const int M = DH;
+		const int16_t *hi = hiA + k * F_HI_P + 1 + mi;                           /* hi[0] = high-half coefficient j */
+		int l0, l1;
+		if (k < DH) { l0 = loT[mi * DH + k]; l1 = loT[(mi + 1) * DH + k]; }
+		else { const int16_t *lo = loB + (k - DH) * F_HI_P + 1 + mi; l0 = lo[0]; l1 = lo[1]; }
+		int ev = (int16_t)(l0 << 3), od = j < M - 1 ? (int16_t)((l1 + l0) << 2) : (int16_t)(l0 << 3);
+		if (j == 0) { ev -= hi[0] << 2; od += 5 * hi[0] - hi[1]; }
+		else if (j < M - 1) { ev -= (hi[0] + hi[-1]) << 1; od += 6 * hi[0] - hi[1] - hi[-1]; }
+		else { ev -= (hi[0] + hi[-1]) << 1; od += 5 * hi[0] - hi[-1]; }
+		*reinterpret_cast<uint32_t *>(T + k * FBP + 2 * mi) = (uint32_t)(uint16_t)ev | ((uint32_t)(uint16_t)od << 16);
 	}
 	__syncthreads();
-	uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)img * NHW_IMG_BYTES + (size_t)(2 * i0) * DW * 3);   /* 2 COLOR_PAIRS consecutive rows */
-	for (int k = tid; k < 2 * COLOR_PAIRS * (DW * 3 / 16); k += 256) dst[k] = reinterpret_cast<const uint4 *>(&orow[0][0])[k];
+	F_STOP(2);
+
+	/* q > 21: the corrections that land in rows r0 - 1 .. r0 + FR - 1 (wavelet_filterbank.c:301-347); positions may repeat */
+	if (q > 21) {
+		const uint8_t *f = ws.blob + ws.blob_off[img];
+		const uint32_t *p6 = ws.buf<uint32_t>(D_P6, img);
+		const int cnt = (m->res6_bits - 1) * 8;
+#define F_ADD(at, delta) do { const int rr_ = (int)((at) & (DW - 1)) - (r0 - 2); if (rr_ >= 1 && rr_ <= FR + 1) add_i16_at(T, (int)((at) >> 9) * FBP + rr_, (delta)); } while (0)
+		for (int k = tid; k < cnt; k += 256) if (p6[k] < 4u * DQ) F_ADD(p6[k], bit_of(f + m->o_res6_word, m->res6_bits, k) ? -32 : 32);
+		const uint8_t *cr = f + m->o_char;
+		for (int k = tid; k < m->char_res1_len; k += 256) {
+			const int v = cr[2 * k] | (cr[2 * k + 1] << 8);
+			const int t = v & 3;
+			const int at = t == 0 ? (v << 1) + DH - 2 : t == 1 ? ((v - 1) << 1) + DH - 2 : t == 2 ? ((v - 2) << 1) + DH - 1 : ((v - 3) << 1) + DH - 1;
+			if (at >= 0 && at < 4 * DQ) F_ADD(at, (t & 1) ? -32 : 32);
+		}
+		if (q > 22) {
+			const uint8_t *qs = f + m->o_qs3;
+			for (int k = tid; k < m->qs3_len; k += 256) {
+				const uint32_t v = (uint32_t)qs[4 * k] | ((uint32_t)qs[4 * k + 1] << 8) | ((uint32_t)qs[4 * k + 2] << 16) | ((uint32_t)qs[4 * k + 3] << 24);
+				if ((v >> 1) < 4u * DQ) F_ADD(v >> 1, (v & 1) ? -56 : 56);
+			}
+		}
+#undef F_ADD
+		__syncthreads();
+	}
+
+	/* 5-tap smoothing at the marked samples of my rows (:859-876).  List order matters only inside a run of adjacent marks: the head of a run walks it. */
+	{
+		const int nmarks = m->nmarks;
+		const uint16_t *marks = ws.buf<uint16_t>(D_MARKS, img);
+		const uint16_t *rows = mark_rows(ws, img);
+		const int k_lo = rows[r0 / 2], k_hi = rows[r0 / 2 + FR / 2];
+		for (int k = k_lo + tid; k < k_hi; k += 256) {
+			if (k > 0 && marks[k - 1] + 1 == marks[k]) continue;
+			for (int t = k; t < nmarks && (t == k || marks[t - 1] + 1 == marks[t]); t++) {
+				const int l = ((marks[t] >> 8) << 1) - (r0 - 2), col = marks[t] & 255;   /* cell (row, col) of the transposed plane = T[col][row] */
+#define TP(dr, dc) ((int)T[(col + (dc)) * FBP + l + (dr)])
+				const int ctr = TP(0, 0);
+				const int lap = (ctr << 3) - TP(0, -1) - TP(0, 1) - TP(-1, 0) - TP(1, 0) - TP(-1, -1) - TP(1, -1) - TP(-1, 1) - TP(1, 1);
+				if (iabs(lap) < 116) T[col * FBP + l] = (int16_t)(((ctr << 2) + TP(0, -1) + TP(0, 1) + TP(-1, 0) + TP(1, 0) + 4) >> 3);
+#undef TP
+			}
+		}
+	}
+	__syncthreads();
+	F_STOP(3);
+
+	/* second direction: two output rows (one dword of every line of T) per step, a thread per j */
+	for (int lp = 1; lp <= FR / 2; lp++) {                                       /* local rows 2 lp, 2 lp + 1 <-> r0 + 2 (lp - 1), + 1 */
+		const int j = tid, M = DH;
+#define TW(k) (*reinterpret_cast<const uint32_t *>(T + (k) * FBP + 2 * lp))
+		const uint32_t lo0 = TW(j), lo1 = j < M - 1 ? TW(j + 1) : 0u, h0 = TW(M + j), hm = j ? TW(M + j - 1) : 0u, hp = j < M - 1 ? TW(M + j + 1) : 0u;
+#undef TW
+		uint32_t yy[2];
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int l0 = (int16_t)(h ? lo0 >> 16 : lo0 & 0xFFFF), l1 = (int16_t)(h ? lo1 >> 16 : lo1 & 0xFFFF);
+			const int c0 = (int16_t)(h ? h0 >> 16 : h0 & 0xFFFF), cm = (int16_t)(h ? hm >> 16 : hm & 0xFFFF), cp = (int16_t)(h ? hp >> 16 : hp & 0xFFFF);
+			int ev = (int16_t)(l0 << 3), od = j < M - 1 ? (int16_t)((l1 + l0) << 2) : (int16_t)(l0 << 3);
+			if (j == 0) { ev -= c0 << 2; od += 5 * c0 - cp; }
+			else if (j < M - 1) { ev -= (c0 + cm) << 1; od += 6 * c0 - cp - cm; }
+			else { ev -= (c0 + cm) << 1; od += 5 * c0 - cm; }
+			ev = (int16_t)ev; od = (int16_t)od;
+			if (ev > 0) ev = (int16_t)(ev + 32); ev >>= 6; if (od > 0) od = (int16_t)(od + 32); od >>= 6;
+			yy[h] = (uint32_t)clip8(ev) | ((uint32_t)clip8(od) << 8);
+		}
+		*reinterpret_cast<uint16_t *>(ybuf + (2 * lp - 2) * DW + 2 * j) = (uint16_t)yy[0];
+		*reinterpret_cast<uint16_t *>(ybuf + (2 * lp - 1) * DW + 2 * j) = (uint16_t)yy[1];
+	}
+	__syncthreads();
+	F_STOP(4);
+
+	/* colour (nhw_decoder_cli.c:133-283): a thread = four pixels of one row; chroma doubled on the fly from the staged rows */
+	{
+		const int t = tid & 127;
+		const uint8_t *cU = crow, *cV = crow + (FR / 2 + 1) * DH;
+		for (int it = 0; it < FR / 2; it++) {
+			const int lr = 2 * it + (tid >> 7), r = r0 + lr;
+			const uint32_t y4 = *reinterpret_cast<const uint32_t *>(ybuf + lr * DW + 4 * t);
+			const int j = 2 * t;
+			int tu[3], tv[3];                                         /* the vertically doubled chroma rows at columns j, j+1, j+2 */
+#pragma unroll
+			for (int c = 0; c < 3; c++) {
+				const int jj = j + c < DH ? j + c : DH - 1;
+				const int u0 = cU[it * DH + jj], u1 = cU[(it + 1) * DH + jj], v0 = cV[it * DH + jj], v1 = cV[(it + 1) * DH + jj];
+				if (r >= 2 * DH - 2 || !(r & 1)) { tu[c] = u0; tv[c] = v0; }       /* rows 510, 511: chroma row 255 */
+				else { tu[c] = (u0 + u1 + 1) >> 1; tv[c] = (v0 + v1 + 1) >> 1; }
+			}
+			uint32_t w[3] = { 0, 0, 0 };
+#pragma unroll
+			for (int px = 0; px < 4; px++) {
+				const int x = 4 * t + px;
+				int uv, vv;
+				if (x >= DW - 2) { uv = tu[DH - 1 - j]; vv = tv[DH - 1 - j]; }      /* last two columns repeat column 255 (j = 254 here) */
+				else if (x & 1) { uv = (tu[px >> 1] + tu[(px >> 1) + 1] + 1) >> 1; vv = (tv[px >> 1] + tv[(px >> 1) + 1] + 1) >> 1; }
+				else { uv = tu[px >> 1]; vv = tv[px >> 1]; }
+				int R, G, B;
+				yuv_to_bytes(q, (int)((y4 >> (8 * px)) & 255u), uv, vv, R, G, B);
+				const int b0 = 3 * px;
+				w[b0 >> 2] |= (uint32_t)R << (8 * (b0 & 3));
+				w[(b0 + 1) >> 2] |= (uint32_t)G << (8 * ((b0 + 1) & 3));
+				w[(b0 + 2) >> 2] |= (uint32_t)B << (8 * ((b0 + 2) & 3));
+			}
+			uint32_t *o = orow + lr * (DW * 3 / 4) + 3 * t;
+			o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+		}
+	}
+	__syncthreads();
+	F_STOP(5);
+	uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)img * NHW_IMG_BYTES + (size_t)r0 * DW * 3);   /* FR consecutive rows */
+	for (int k = tid; k < FR * (DW * 3 / 16); k += 256) dst[k] = reinterpret_cast<const uint4 *>(orow)[k];
 }
 
 __global__ __launch_bounds__(256) void k_dec_status(DecWs ws, int32_t *status, int32_t *quality)
@@ -1516,7 +1638,7 @@ struct nhw_dec {
 	hipEvent_t fork_ev, join_ev;
 	int chroma_fork;
 	int stop_after;
-	hipEvent_t ev[8];         /* start, after the entropy stages, around the two level-1 luma synthesis passes, around the colour kernel, end */
+	hipEvent_t ev[4];         /* start, after the entropy stages, around the final reconstruction kernel (= end) */
 	bool timed;
 	/* host convenience path */
 	uint8_t *d_blob; size_t blob_cap;
@@ -1544,7 +1666,7 @@ extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
 		HIPCHK(hipStreamCreateWithFlags(&d->chroma_stream, hipStreamNonBlocking));
 		HIPCHK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&d->join_ev, hipEventDisableTiming));
-		for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&d->ev[i]));
+		for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&d->ev[i]));
 		return NHW_OK;
 	}();
 	if (rc != NHW_OK) { nhw_dec_destroy(d); return rc; }
@@ -1569,7 +1691,7 @@ extern "C" void nhw_dec_destroy(nhw_dec *d)
 	if (d->chroma_stream) (void)hipStreamDestroy(d->chroma_stream);
 	if (d->fork_ev) (void)hipEventDestroy(d->fork_ev);
 	if (d->join_ev) (void)hipEventDestroy(d->join_ev);
-	for (int i = 0; i < 8; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
+	for (int i = 0; i < 4; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
 	delete d;
 }
 
@@ -1647,42 +1769,32 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	STAGE_END();                                                                  /* 6 */
 	k_dec_marks<<<(n + 3) / 4, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 7 */
-	{
-		SynthArgs p1 = { D_A, D_B, 0, DW, DW, DW, DH, 0, 0 };
-		EV(2);
-		k_dec_synth<<<dim3(DW / 16, n), 256, 0, s>>>(ws, p1);
-		EV(3);
-	}
-	k_dec_corr<<<n, 256, 0, s>>>(ws);
-	STAGE_END();                                                                  /* 8 */
-	k_dec_smooth<<<dim3(SMOOTH_WGS, n), 256, 0, s>>>(ws);
-	STAGE_END();                                                                  /* 9 */
-	{
-		SynthArgs p2 = { D_B, -1, 0, DW, DW, DW, DW, 1, 1 };
-		EV(4);
-		k_dec_synth<<<dim3(DW / 16, n), 256, 0, s>>>(ws, p2);
-		EV(5);
-	}
-	STAGE_END();                                                                  /* 10 */
 	if (fork) HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
 	else {
 		/* chroma, both planes per launch (blockIdx.z) */
 		SynthArgs a1 = { D_CA, D_CB, -1, DH, DH / 2, DH / 2, 0, 0, 0 }, a2 = { D_CB, D_CA, -1, DH, DH / 2, DH / 2, DH / 2, 1, 1 };
 		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, s>>>(ws, a1);
 		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, s>>>(ws, a2);
-		STAGE_END();                                                              /* 11 */
+		STAGE_END();                                                              /* 8 */
 		k_dec_cpairs<<<dim3(DH / CPAIR_ROWS, n, 2), 256, 0, s>>>(ws);
-		STAGE_END();                                                              /* 12 */
+		STAGE_END();                                                              /* 9 */
 		SynthArgs b1 = { D_CA, D_CB, -1, DH, DH, DH, DH / 2, 0, 0 }, b2 = { D_CB, D_CA, -1, DH, DH, DH, DH, 1, 1 };
 		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, s>>>(ws, b1);
 		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, s>>>(ws, b2);
-		STAGE_END();                                                              /* 13 */
+		STAGE_END();                                                              /* 10 */
 		k_dec_sharpen<<<(2 * n + 3) / 4, 256, 0, s>>>(ws);
-		STAGE_END();                                                              /* 14 */
+		STAGE_END();                                                              /* 11 */
 	}
-	EV(6);
-	k_dec_color<<<dim3(DW / 2 / COLOR_PAIRS, n), 256, 0, s>>>(ws, (uint8_t *)d_bgr);
-	EV(7);
+	/* level-1 synthesis both ways + corrections + smoothing + colour: one kernel, one band of FR output rows per workgroup */
+	EV(2);
+	{
+		int dev_stop = 0;
+#ifdef NHW_DEV
+		if (const char *e = getenv("NHW_FINAL_STOP")) dev_stop = atoi(e);
+#endif
+		k_dec_final<<<(DW / FR) * n, 256, F_LDS_BYTES, s>>>(ws, (uint8_t *)d_bgr, dev_stop);
+	}
+	EV(3);
 	d->timed = true;
 done:
 	k_dec_status<<<(n + 255) / 256, 256, 0, s>>>(ws, d_status, d_quality);
@@ -1695,12 +1807,10 @@ done:
 extern "C" int nhw_dec_last_timing(nhw_dec *d, nhw_dec_timing *t)
 {
 	if (!d || !t || !d->timed) return NHW_E_ARG;
-	HIPCHK(hipEventSynchronize(d->ev[7]));
-	HIPCHK(hipEventElapsedTime(&t->total_ms, d->ev[0], d->ev[7]));
+	HIPCHK(hipEventSynchronize(d->ev[3]));
+	HIPCHK(hipEventElapsedTime(&t->total_ms, d->ev[0], d->ev[3]));
 	HIPCHK(hipEventElapsedTime(&t->entropy_ms, d->ev[0], d->ev[1]));
-	HIPCHK(hipEventElapsedTime(&t->synth1_ms, d->ev[2], d->ev[3]));
-	HIPCHK(hipEventElapsedTime(&t->synth2_ms, d->ev[4], d->ev[5]));
-	HIPCHK(hipEventElapsedTime(&t->color_ms, d->ev[6], d->ev[7]));
+	HIPCHK(hipEventElapsedTime(&t->recon_ms, d->ev[2], d->ev[3]));
 	return NHW_OK;
 }
 

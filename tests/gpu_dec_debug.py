@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import nhwcodec_amd as na
 from oracle.oraclepy import Oracle
 
-D = dict(META=0, LL=1, PK=2, P1=3, P3=4, P5=5, P6=6, MARKS=7, A=8, B=9, CA=10, CB=11, YB=12, CU=13)
+D = dict(META=0, LL=1, PK=2, P1=3, P3=4, P5=5, P6=6, MARKS=7, A=8, B=9, CA=10, CB=11, CU=12)
 O = Oracle()
 
 def files(args):
@@ -64,17 +64,14 @@ def main():
         (5, "C after L2", lambda i, nhw: (plane(dec, "A", i)[:256, :256], pr(nhw, 5).reshape(512, 512)[:256, :256])),
         (6, "C after residuals", lambda i, nhw: (plane(dec, "A", i)[:256, :256], pr(nhw, 6).reshape(512, 512)[:256, :256])),
         (7, "marks", lambda i, nhw: (rd(dec, "MARKS", i, 2 * 65536, np.uint16)[:len(pr(nhw, 7, np.uint16))], pr(nhw, 7, np.uint16))),
-        (8, "B after L1 pass 1", lambda i, nhw: (plane(dec, "B", i), pr(nhw, 8).reshape(512, 512))),
-        (9, "B after smoothing", lambda i, nhw: (plane(dec, "B", i).T, pr(nhw, 9).reshape(512, 512))),
-        (10, "Y bytes", lambda i, nhw: (rd(dec, "YB", i, 262144, np.uint8).reshape(512, 512), O.decode(nhw, planes=True)[0][0])),
-        (11, "Cc0 after L2", lambda i, nhw: (plane(dec, "CA", i, 0)[:128, :128], pr(nhw, 40).reshape(256, 256)[:128, :128])),
-        (11, "Cc1 after L2", lambda i, nhw: (plane(dec, "CA", i, 1)[:128, :128], pr(nhw, 41).reshape(256, 256)[:128, :128])),
-        (12, "Cc0 after pairs", lambda i, nhw: (plane(dec, "CA", i, 0)[:128, :128], pr(nhw, 42).reshape(256, 256)[:128, :128])),
-        (12, "Cc1 after pairs", lambda i, nhw: (plane(dec, "CA", i, 1)[:128, :128], pr(nhw, 43).reshape(256, 256)[:128, :128])),
-        (13, "chroma0 before sharpen", lambda i, nhw: (plane(dec, "CA", i, 0), pr(nhw, 44).reshape(256, 256))),
-        (13, "chroma1 before sharpen", lambda i, nhw: (plane(dec, "CA", i, 1), pr(nhw, 45).reshape(256, 256))),
-        (14, "chroma0 sharpened", lambda i, nhw: (rd(dec, "CU", i, 131072, np.uint8)[:65536].reshape(256, 256), pr(nhw, 46).reshape(256, 256).astype(np.uint8))),
-        (14, "chroma1 sharpened", lambda i, nhw: (rd(dec, "CU", i, 131072, np.uint8)[65536:].reshape(256, 256), pr(nhw, 47).reshape(256, 256).astype(np.uint8))),
+        (8, "Cc0 after L2", lambda i, nhw: (plane(dec, "CA", i, 0)[:128, :128], pr(nhw, 40).reshape(256, 256)[:128, :128])),
+        (8, "Cc1 after L2", lambda i, nhw: (plane(dec, "CA", i, 1)[:128, :128], pr(nhw, 41).reshape(256, 256)[:128, :128])),
+        (9, "Cc0 after pairs", lambda i, nhw: (plane(dec, "CA", i, 0)[:128, :128], pr(nhw, 42).reshape(256, 256)[:128, :128])),
+        (9, "Cc1 after pairs", lambda i, nhw: (plane(dec, "CA", i, 1)[:128, :128], pr(nhw, 43).reshape(256, 256)[:128, :128])),
+        (10, "chroma0 before sharpen", lambda i, nhw: (plane(dec, "CA", i, 0), pr(nhw, 44).reshape(256, 256))),
+        (10, "chroma1 before sharpen", lambda i, nhw: (plane(dec, "CA", i, 1), pr(nhw, 45).reshape(256, 256))),
+        (11, "chroma0 sharpened", lambda i, nhw: (rd(dec, "CU", i, 131072, np.uint8)[:65536].reshape(256, 256), pr(nhw, 46).reshape(256, 256).astype(np.uint8))),
+        (11, "chroma1 sharpened", lambda i, nhw: (rd(dec, "CU", i, 131072, np.uint8)[65536:].reshape(256, 256), pr(nhw, 47).reshape(256, 256).astype(np.uint8))),
     ]
     last = None
     for stage, tag, fn in checks:
