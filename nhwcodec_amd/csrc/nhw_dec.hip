@@ -1409,8 +1409,9 @@ DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
  * The second direction is pointwise in the output row r': Y[r'][2j], Y[r'][2j+1] come from T[j][r'], T[256+j][r'] and their neighbours in j,
  * where T is the first direction's output (the reference's transposed plane).  T[k][2m], T[k][2m+1] in turn come from line k of plane A:
  * its low half (for k < 256 the level-1 LL, kept transposed: A[m][k]) and high half around m.  So a band needs, of every one of the 512
- * lines of A, the dozen coefficients around m = r0/2 -- 24-byte pieces; the four bands that share a 64-byte sector run next to each other
- * on one XCD (same workgroup order as the encoder's front kernel), so the sector is fetched from HBM once.
+ * lines of A, the dozen coefficients around m = r0/2 -- 24-byte pieces, loaded straight into the registers of the thread that owns the
+ * line; the four bands that share a 64-byte sector run next to each other on one XCD (same workgroup order as the encoder's front
+ * kernel), so the sector is fetched from HBM once.  Only T (18 KB), the band's luma bytes and nine rows of either chroma plane live in LDS.
  * The smoothing reads the rows above and below a mark; marks sit in even rows only (k_dec_marks), and the rows next to them are never
  * marked, so a band needs one extra row (r0 - 1) and sees it as the corrections left it.  The list is in row order and k_dec_marks
  * leaves the index of every row's first mark, so a band knows its share. */
@@ -1418,8 +1419,7 @@ DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
 #define FBP (FR + 2)                 /* LDS pitch (shorts) of a line of T: local index l <-> row r0 - 2 + l (l = 0 unused); 9 dwords: no bank conflicts across lines */
 #define FM (FR / 2 + 1)              /* values of m a band computes: r0/2 - 1 .. r0/2 + FR/2 - 1 */
 #define F_T_BYTES (2 * DH * FBP * 2)
-#define F_HI_P 12                    /* staged coefficients per line: high half m - 1 .. m + FM (11 used), low half m .. m + FM (10 used) */
-#define F_LDS_BYTES (F_T_BYTES + 24576 + 2 * (FR / 2 + 1) * DH)
+#define F_LDS_BYTES (F_T_BYTES + FR * DW + 2 * (FR / 2 + 1) * DH)   /* T, the luma bytes, the chroma rows: 31 KB, five bands to a CU */
 /* add to element idx of an int16 array in LDS (dword-aligned base): compare-and-swap on the dword, the pointer stays a typed offset of
  * the base so that it compiles to the LDS instruction */
 DEV void add_i16_at(int16_t *base, int idx, int delta)
@@ -1442,13 +1442,8 @@ __global__ __launch_bounds__(256) void k_dec_final(DecWs ws, uint8_t *out, int d
 #endif
 	extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
 	int16_t *T = reinterpret_cast<int16_t *>(fl);                               /* [512][FBP] */
-	uint8_t *X = fl + F_T_BYTES;                                                /* 24 KB: the staged pieces of A, later the luma bytes (at its end) */
-	int16_t *hiA = reinterpret_cast<int16_t *>(X);                              /* [512][F_HI_P]: A[k][256 + r0/2 - 2 + e] */
-	int16_t *loB = hiA + 2 * DH * F_HI_P;                                       /* [256][F_HI_P]: A[256 + k][r0/2 - 2 + e] */
-	int16_t *loT = loB + DH * F_HI_P;                                           /* [10][256]: A[r0/2 - 1 + e][k] */
-	uint8_t *ybuf = X + 24576 - FR * DW;                                        /* [FR][512] */
-	uint32_t *orow = reinterpret_cast<uint32_t *>(fl);                          /* [FR][384 dwords]: the output rows, over T and the head of X once both are done with */
-	uint8_t *crow = X + 24576;                                                  /* [2][FR / 2 + 1][256] */
+	uint8_t *ybuf = fl + F_T_BYTES;                                             /* [FR][512] */
+	uint8_t *crow = ybuf + FR * DW;                                             /* [2][FR / 2 + 1][256] */
 	const int tid = threadIdx.x;
 	int band, img;
 	{
@@ -1461,42 +1456,51 @@ __global__ __launch_bounds__(256) void k_dec_final(DecWs ws, uint8_t *out, int d
 	const int q = m->q, r0 = FR * band, m0 = r0 / 2 - 1;                       /* m0: first m of the band (-1 in band 0: skipped) */
 	const int16_t *A = plane_a(ws, img);
 
-	/* stage the pieces of A: of each of the 768 lines (high halves of all 512, low halves of lines 256..511) the twelve coefficients
-	 * r0/2 - 2 .. r0/2 + 9 -- one 16-byte load at r0/2 (16-byte aligned) and a dword on either side; the few coefficients outside a
-	 * line's half that this touches at the first and the last band are never used */
-	for (int ln = tid; ln < 3 * DH; ln += 256) {
-		const int16_t *src = ln < 2 * DH ? A + (size_t)ln * DW + DH + r0 / 2 : A + (size_t)(ln - DH) * DW + r0 / 2;
-		const uint32_t w0 = *reinterpret_cast<const uint32_t *>(src - 2), w5 = *reinterpret_cast<const uint32_t *>(src + 8);
-		const uint4 wm = *reinterpret_cast<const uint4 *>(src);
-		uint32_t *d = reinterpret_cast<uint32_t *>(hiA + ln * F_HI_P);          /* loB follows hiA: line 512 + k is loB[k] */
-		d[0] = w0; d[1] = wm.x; d[2] = wm.y; d[3] = wm.z; d[4] = wm.w; d[5] = w5;
-	}
-	for (int idx = tid; idx < (FM + 1) * (DH / 8); idx += 256) {
-		const int e = idx / (DH / 8), o = idx % (DH / 8);
-		reinterpret_cast<uint4 *>(loT + e * DH)[o] = reinterpret_cast<const uint4 *>(A + (ptrdiff_t)(m0 + e) * DW)[o];   /* row -1 (band 0) lies in the pad in front of the plane */
-	}
 	for (int k = tid; k < 2 * (FR / 2 + 1) * (DH / 16); k += 256) {
 		const int pl = k / ((FR / 2 + 1) * (DH / 16)), rem = k % ((FR / 2 + 1) * (DH / 16)), rr = rem / (DH / 16), o = rem % (DH / 16);
 		const int src = r0 / 2 + rr < DH ? r0 / 2 + rr : DH - 1;
 		reinterpret_cast<uint4 *>(crow + (pl * (FR / 2 + 1) + rr) * DH)[o] = reinterpret_cast<const uint4 *>(ws.buf<uint8_t>(D_CU, img) + (size_t)pl * DQ + (size_t)src * DH)[o];
 	}
-	__syncthreads();
-	F_STOP(1);
-
-	/* first direction (decoder/filters.c:143-194 on line k): T[k][2m], T[k][2m + 1] */
-	for (int idx = tid; idx < 2 * DH * FM; idx += 256) {
-		const int k = idx % (2 * DH), mi = idx / (2 * DH), j = m0 + mi;
-		if (j < 0) continue;
-		const int M = DH;
-		const int16_t *hi = hiA + k * F_HI_P + 1 + mi;                           /* hi[0] = high-half coefficient j */
-		int l0, l1;
-		if (k < DH) { l0 = loT[mi * DH + k]; l1 = loT[(mi + 1) * DH + k]; }
-		else { const int16_t *lo = loB + (k - DH) * F_HI_P + 1 + mi; l0 = lo[0]; l1 = lo[1]; }
-		int ev = (int16_t)(l0 << 3), od = j < M - 1 ? (int16_t)((l1 + l0) << 2) : (int16_t)(l0 << 3);
-		if (j == 0) { ev -= hi[0] << 2; od += 5 * hi[0] - hi[1]; }
-		else if (j < M - 1) { ev -= (hi[0] + hi[-1]) << 1; od += 6 * hi[0] - hi[1] - hi[-1]; }
-		else { ev -= (hi[0] + hi[-1]) << 1; od += 5 * hi[0] - hi[-1]; }
-		*reinterpret_cast<uint32_t *>(T + k * FBP + 2 * mi) = (uint32_t)(uint16_t)ev | ((uint32_t)(uint16_t)od << 16);
+	/* first direction (decoder/filters.c:143-194 on line k): T[k][2m], T[k][2m + 1].  A thread takes lines tid and tid + 256 and loads what
+	 * they need of A straight into registers: of a line's high half (and of the low half of the lines from 256) the twelve coefficients
+	 * r0/2 - 2 .. r0/2 + 9 -- one 16-byte load at r0/2 (16-byte aligned) and a dword on either side; the low half of line k < 256 is column
+	 * k of rows r0/2 - 1 .. of the level-1 LL, consecutive lanes on consecutive columns.  The few coefficients outside a line's half that
+	 * this touches at the first and the last band are never used (row -1 lies in the pad in front of the plane). */
+#pragma unroll
+	for (int half = 0; half < 2; half++) {
+		const int k = tid + DH * half;
+		int hi[12], lo[12];                                                     /* hi[e], lo[e]: coefficient m0 - 1 + e */
+		{
+			const int16_t *src = A + (size_t)k * DW + DH + r0 / 2;
+			const uint32_t w0 = *reinterpret_cast<const uint32_t *>(src - 2), w5 = *reinterpret_cast<const uint32_t *>(src + 8);
+			const uint4 wm = *reinterpret_cast<const uint4 *>(src);
+			const uint32_t w[6] = { w0, wm.x, wm.y, wm.z, wm.w, w5 };
+#pragma unroll
+			for (int e = 0; e < 6; e++) { hi[2 * e] = (int16_t)(w[e] & 0xFFFF); hi[2 * e + 1] = (int16_t)(w[e] >> 16); }
+		}
+		if (half) {
+			const int16_t *src = A + (size_t)k * DW + r0 / 2;
+			const uint32_t w0 = *reinterpret_cast<const uint32_t *>(src - 2), w5 = *reinterpret_cast<const uint32_t *>(src + 8);
+			const uint4 wm = *reinterpret_cast<const uint4 *>(src);
+			const uint32_t w[6] = { w0, wm.x, wm.y, wm.z, wm.w, w5 };
+#pragma unroll
+			for (int e = 0; e < 6; e++) { lo[2 * e] = (int16_t)(w[e] & 0xFFFF); lo[2 * e + 1] = (int16_t)(w[e] >> 16); }
+		} else {
+			lo[0] = 0; lo[11] = 0;
+#pragma unroll
+			for (int e = 0; e <= FM; e++) lo[1 + e] = A[(ptrdiff_t)(m0 + e) * DW + k];
+		}
+#pragma unroll
+		for (int mi = 0; mi < FM; mi++) {
+			const int j = m0 + mi, M = DH;
+			if (j < 0) continue;
+			const int l0 = lo[1 + mi], l1 = lo[2 + mi], h0 = hi[1 + mi], hm = hi[mi], hp = hi[2 + mi];
+			int ev = (int16_t)(l0 << 3), od = j < M - 1 ? (int16_t)((l1 + l0) << 2) : (int16_t)(l0 << 3);
+			if (j == 0) { ev -= h0 << 2; od += 5 * h0 - hp; }
+			else if (j < M - 1) { ev -= (h0 + hm) << 1; od += 6 * h0 - hp - hm; }
+			else { ev -= (h0 + hm) << 1; od += 5 * h0 - hm; }
+			*reinterpret_cast<uint32_t *>(T + k * FBP + 2 * mi) = (uint32_t)(uint16_t)ev | ((uint32_t)(uint16_t)od << 16);
+		}
 	}
 	__syncthreads();
 	F_STOP(2);
@@ -1603,14 +1607,10 @@ __global__ __launch_bounds__(256) void k_dec_final(DecWs ws, uint8_t *out, int d
 				w[(b0 + 1) >> 2] |= (uint32_t)G << (8 * ((b0 + 1) & 3));
 				w[(b0 + 2) >> 2] |= (uint32_t)B << (8 * ((b0 + 2) & 3));
 			}
-			uint32_t *o = orow + lr * (DW * 3 / 4) + 3 * t;
-			o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+			/* consecutive lanes, consecutive 12-byte pieces: one store instruction writes 768 contiguous bytes of the row */
+			*reinterpret_cast<uint3 *>(out + (size_t)img * NHW_IMG_BYTES + (size_t)r * DW * 3 + 12 * t) = make_uint3(w[0], w[1], w[2]);
 		}
 	}
-	__syncthreads();
-	F_STOP(5);
-	uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)img * NHW_IMG_BYTES + (size_t)r0 * DW * 3);   /* FR consecutive rows */
-	for (int k = tid; k < FR * (DW * 3 / 16); k += 256) dst[k] = reinterpret_cast<const uint4 *>(orow)[k];
 }
 
 __global__ __launch_bounds__(256) void k_dec_status(DecWs ws, int32_t *status, int32_t *quality)
