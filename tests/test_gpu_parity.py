@@ -443,3 +443,53 @@ def test_host_path_pcie_inclusive(oracle):
     print(f"host path: {n} images in {dt * 1e3:.1f} ms = {rate:.1f} Gpixel/s incl. PCIe both ways")
     assert rate > 5.0
     e.free_pinned(); e.close(); e2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [17, 20, 23])
+def test_tail_stages_match_the_oracle_trace(oracle, q):
+    """Rows a8-a16 stage by stage: the batch driver is stopped after every launch group of the luma tail and of both chroma sequences
+    (nhw_debug_stop_after) and the live planes are compared with the oracle's checkpoint of the same point of encode_image -- both filter
+    banks of both closed loops, both dequantiser simulations, the quantisers.  A regression in one pass is reported at that pass."""
+    import torch
+    import nhwcodec_amd
+    B = dict(JPEG=0, PROC=1, PU=2, PV=3, CJPEG=4, CPROC=5)
+    seeds = (0, 1)
+    e = nhwcodec_amd.Encoder(0, max_batch=len(seeds))
+    imgs = np.stack([oracle.synth(s) for s in seeds])
+    d_in = torch.from_numpy(imgs).cuda()
+    traces = [oracle.encode(imgs[i], q, trace=True) for i in range(len(seeds))]
+    shift = 0 if q < 22 else -1                                 # no pre-filter stage from q22
+    plan = []                                                   # (stage, index among same-named trace records, record name, [(buffer, blob of the record, bytes)])
+    for st, k, nm in [(3, 0, "wavelet_analysis_512"), (5, 0, "wavelet_analysis_256"), (6, 0, "offsetY_recons256_p1"), (7, 0, "wavelet_synthesis_256"),
+                      (9, 1, "wavelet_analysis_256"), (11, 0, "offsetY_recons256_p0"), (12, 1, "wavelet_synthesis_256")]:
+        plan.append((st + shift, k, nm, [("JPEG", 0, 8 * 65536), ("PROC", 1, 8 * 65536)]))
+    if q >= 22:                                                 # below that the quantiser writes the symbol stream directly and leaves the plane alone
+        plan.append((13 + shift, 0, "offsetY", [("PROC", 0, 8 * 65536)]))
+    for comp in (0, 1):
+        base = 13 + shift + 12 * comp
+        for st, k, nm in [(2, 2 + comp, "wavelet_analysis_256"), (4, 2 * comp, "wavelet_analysis_128"), (5, comp, "offsetUV_recons256_c1"),
+                          (6, 2 * comp, "wavelet_synthesis_128"), (8, 2 * comp + 1, "wavelet_analysis_128"), (10, comp, "offsetUV_recons256_c0"),
+                          (11, 2 * comp + 1, "wavelet_synthesis_128")]:
+            plan.append((base + st, k, nm, [("CJPEG", 0, 2 * 65536), ("CPROC", 1, 2 * 65536)]))
+        plan.append((base + 12, comp, "offsetUV", [("CPROC", 0, 2 * 65536)]))
+    try:
+        for st, k, nm, bufs in plan:
+            e.lib.nhw_debug_stop_after(e.h, st)
+            e.encode_device(d_in, q)
+            torch.cuda.synchronize()
+            for i in range(len(seeds)):
+                recs = [b for n, b in traces[i][1] if n == nm]
+                for bname, bi, nbytes in bufs:
+                    out = np.empty(nbytes, np.uint8)
+                    assert e.lib.nhw_debug_read(e.h, B[bname], i, ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(nbytes)) == 0
+                    got, want = out.view(np.int16), np.frombuffer(recs[k][bi], np.int16)
+                    if bname == "JPEG":                         # only the 256x256 corner of the luma jpeg plane is live after level 1
+                        got, want = got.reshape(512, 512)[:256, :256], want.reshape(512, 512)[:256, :256]
+                    bad = np.argwhere(got != want)
+                    assert bad.size == 0, f"q{q} stage {st} ({nm} #{k}) image {i} plane {bname}: {len(bad)} cells differ, first {bad[0].tolist()}"
+    finally:
+        e.lib.nhw_debug_stop_after(e.h, 0)
+    got = e.encode(imgs, q)
+    assert [g == t[0] for g, t in zip(got, traces)] == [True] * len(seeds)
+    e.close()
