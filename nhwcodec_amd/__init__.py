@@ -132,6 +132,11 @@ class Encoder:
             raise NhwError(f"per-image status {status.tolist()}")
         return [arena[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)]
 
+    def encode_tiled(self, big, quality: int = QUALITY_DEFAULT):
+        """a picture whose sides are multiples of 512 -> (list of .nhw byte strings, one per tile, row-major, (ny, nx)); `nhw-enc --tiles`"""
+        tiles, shape = tile_images(big)
+        return self.encode(tiles, quality), shape
+
     def timing(self) -> Timing:
         t = Timing()
         self._chk(self.lib.nhw_enc_last_timing(self.h, ctypes.byref(t)))
@@ -164,6 +169,26 @@ class Encoder:
         for p in getattr(self, "_pinned", []):
             self.lib.nhw_host_free(p)
         self._pinned = []
+
+
+def tile_images(big):
+    """a uint8 [512*ny, 512*nx, 3] picture (BMP file row order) -> ([ny*nx, 512, 512, 3] independent tiles, row-major, (ny, nx)).
+    Every tile is a picture of its own to the codec: no state crosses a tile edge, in either direction."""
+    import numpy as np
+    big = np.asarray(big)
+    if big.dtype != np.uint8 or big.ndim != 3 or big.shape[2] != 3 or big.shape[0] < 512 or big.shape[1] < 512 or big.shape[0] % 512 or big.shape[1] % 512:
+        raise NhwError(f"tiling wants uint8 [512*ny, 512*nx, 3], got {big.dtype} {big.shape}")
+    ny, nx = big.shape[0] // 512, big.shape[1] // 512
+    return np.ascontiguousarray(big.reshape(ny, 512, nx, 512, 3).transpose(0, 2, 1, 3, 4)).reshape(ny * nx, 512, 512, 3), (ny, nx)
+
+
+def untile_images(tiles, ny: int, nx: int):
+    """the inverse of tile_images"""
+    import numpy as np
+    tiles = np.asarray(tiles)
+    if tiles.shape != (ny * nx, 512, 512, 3):
+        raise NhwError(f"untile wants [{ny * nx}, 512, 512, 3], got {tiles.shape}")
+    return np.ascontiguousarray(tiles.reshape(ny, nx, 512, 512, 3).transpose(0, 2, 1, 3, 4)).reshape(ny * 512, nx * 512, 3)
 
 
 class _OnTorchStream:
@@ -240,6 +265,13 @@ class Decoder:
         h = ctypes.create_string_buffer(54)
         self.lib.nhw_dec_bmp_header(ctypes.cast(h, P))
         return h.raw
+
+    def decode_tiled(self, files, ny: int, nx: int):
+        """the tiles written by encode_tiled -> uint8 [512*ny, 512*nx, 3]; `nhw-dec --tiles`"""
+        if len(files) != ny * nx:
+            raise NhwError(f"{len(files)} files for {ny} x {nx} tiles")
+        px, _ = self.decode(files)
+        return untile_images(px, ny, nx)
 
     def timing(self) -> DecTiming:
         t = DecTiming()

@@ -211,3 +211,63 @@ def test_dec_cli_end_to_end_files(dec_cli, oracle, tmp_path):
     (tmp_path / "junk.nhw").write_bytes(b"BM" + bytes(500))
     rc, out, _ = _run(dec_cli, str(tmp_path / "junk.nhw"), str(tmp_path / "junk.bmp"))
     assert rc == 3 and "Not an .nhw file" in out and not (tmp_path / "junk.bmp").exists()
+
+
+# ---------------------------------------------------------------- pictures larger than 512x512 as independent tiles
+def _big_bmp(img, negative_height=False):
+    import struct
+    h, w = img.shape[:2]
+    return struct.pack("<2sIHHIIiiHHIIiiII", b"BM", 54 + img.size, 0, 0, 54, 40, w, -h if negative_height else h, 1, 24, 0, img.size, 0, 0, 0, 0) + img.tobytes()
+
+
+def test_tile_helpers_round_trip_and_reject_odd_sizes():
+    import nhwcodec_amd as na
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 256, (1024, 1536, 3), dtype=np.uint8)
+    tiles, (ny, nx) = na.tile_images(big)
+    assert (ny, nx) == (2, 3) and tiles.shape == (6, 512, 512, 3)
+    assert np.array_equal(tiles[4], big[512:, 512:1024])            # tile (1, 1)
+    assert np.array_equal(na.untile_images(tiles, ny, nx), big)
+    for shape in [(512, 700, 3), (300, 512, 3), (1024, 1024, 4)]:
+        with pytest.raises(na.NhwError):
+            na.tile_images(np.zeros(shape, np.uint8))
+
+
+def test_cli_tiles_rejects_sizes_that_are_not_multiples_of_512(cli, tmp_path):
+    """the size check comes before any GPU work: same "invalid image file." line and exit code as a wrong-size BMP in the one-tile path"""
+    (tmp_path / "odd.bmp").write_bytes(_big_bmp(np.zeros((512, 600, 3), np.uint8)))
+    rc, out, err = _run(cli, "--tiles", str(tmp_path / "odd.bmp"), str(tmp_path / "odd"))
+    assert rc == (-16) % 256 and "invalid image file." in out and "multiples of 512" in err
+
+
+@pytest.mark.gpu
+def test_cli_tiles_encode_and_join(cli, dec_cli, oracle, tmp_path):
+    """nhw-enc --tiles: every tile of a 1024x1536 picture is the file the oracle writes for that crop; nhw-dec --tiles puts the oracle's
+    decodes of the tiles side by side; a top-down file is flipped as a whole first.  The python helpers give the same files."""
+    import nhwcodec_amd as na
+    big = na.untile_images(np.stack([oracle.synth(700 + t) for t in range(6)]), 2, 3)
+    (tmp_path / "big.bmp").write_bytes(_big_bmp(big))
+    rc, out, _ = _run(cli, "-q20", "--tiles", str(tmp_path / "big.bmp"), str(tmp_path / "t"))
+    assert rc == 0 and "2 x 3 tiles" in out
+    files = []
+    for r in range(2):
+        for c in range(3):
+            f = (tmp_path / f"t_y{r}_x{c}.nhw").read_bytes()
+            assert f == oracle.encode(big[512 * r:512 * r + 512, 512 * c:512 * c + 512], 20), (r, c)
+            files.append(f)
+    assert _run(dec_cli, "--tiles", "2", "3", str(tmp_path / "t"), str(tmp_path / "joined.bmp"))[0] == 0
+    joined = (tmp_path / "joined.bmp").read_bytes()
+    want = na.untile_images(np.stack([oracle.decode(f)[0] for f in files]), 2, 3)
+    assert len(joined) == 54 + want.size and joined[54:] == want.tobytes()
+    assert int.from_bytes(joined[18:22], "little") == 1536 and int.from_bytes(joined[22:26], "little") == 1024
+    # top-down file
+    (tmp_path / "neg.bmp").write_bytes(_big_bmp(big, negative_height=True))
+    assert _run(cli, "-q23", "--tiles", str(tmp_path / "neg.bmp"), str(tmp_path / "n"))[0] == 0
+    assert (tmp_path / "n_y0_x2.nhw").read_bytes() == oracle.encode(big[::-1][:512, 1024:], 23)
+    # python
+    e = na.Encoder(0, 6)
+    got, shape = e.encode_tiled(big, 20)
+    assert shape == (2, 3) and got == files
+    d = na.Decoder(0, 6)
+    assert np.array_equal(d.decode_tiled(got, 2, 3), want)
+    e.close(); d.close()

@@ -26,7 +26,8 @@ static void show_usage(void)
 	" (with a bitmap color 512x512 image)\n"
 	"\n"
 	"  example: nhw-dec image.nhw image.bmp\n"
-	"  batch:   nhw-dec --batch <directory of .nhw files>\n",
+	"  batch:   nhw-dec --batch <directory of .nhw files>\n"
+	"  tiles:   nhw-dec --tiles <rows> <columns> <stem> <image.bmp>   (joins <stem>_y<r>_x<c>.nhw, as written by nhw-enc --tiles)\n",
 	PROGRAM);
 }
 
@@ -85,9 +86,61 @@ static int decode_files(char **in, char **out, int n)
 	return rc;
 }
 
+/* --tiles: the inverse of nhw-enc --tiles.  Every tile is a file of its own and decodes on its own; the tiles are put side by side in file
+ * row order under one bottom-up BMP header of the whole size. */
+static int decode_tiles(int ny, int nx, const char *stem, const char *out_path)
+{
+	const int n = ny * nx;
+	nhw_dec *d = NULL;
+	uint8_t *blob = NULL, *pix, hdr[54];
+	uint64_t *off = (uint64_t *)calloc((size_t)n + 1, sizeof *off);
+	int32_t *status = (int32_t *)calloc((size_t)n, sizeof *status);
+	size_t total = 0;
+	const uint32_t width = 512u * (uint32_t)nx, height = 512u * (uint32_t)ny, bytes = width * height * 3u;
+	FILE *f;
+	int t, r;
+	for (t = 0; t < n; t++) {
+		char name[4096];
+		uint8_t *b; size_t len;
+		snprintf(name, sizeof name, "%s_y%d_x%d.nhw", stem, t / nx, t % nx);
+		if (read_file(name, &b, &len)) return 1;
+		blob = (uint8_t *)realloc(blob, total + len + 16);
+		memcpy(blob + total, b, len); free(b);
+		off[t] = total; total += len;
+	}
+	off[n] = total;
+	pix = (uint8_t *)malloc((size_t)n * NHW_IMG_BYTES);
+	if (nhw_dec_create(0, n, &d) || nhw_dec_batch(d, blob, off, n, pix, status, NULL)) {
+		fprintf(stderr, "%s: GPU decoder unavailable: %s\n", PROGRAM, nhw_dec_last_error());
+		return 2;
+	}
+	for (t = 0; t < n; t++) if (status[t]) { printf("\nNot an .nhw file: %s_y%d_x%d.nhw\n", stem, t / nx, t % nx); return 3; }
+	nhw_dec_bmp_header(hdr);                                          /* the reference's 54 bytes, with the size fields of the whole picture */
+	hdr[2] = (uint8_t)(bytes + 54); hdr[3] = (uint8_t)((bytes + 54) >> 8); hdr[4] = (uint8_t)((bytes + 54) >> 16); hdr[5] = (uint8_t)((bytes + 54) >> 24);
+	hdr[18] = (uint8_t)width; hdr[19] = (uint8_t)(width >> 8); hdr[20] = (uint8_t)(width >> 16); hdr[21] = (uint8_t)(width >> 24);
+	hdr[22] = (uint8_t)height; hdr[23] = (uint8_t)(height >> 8); hdr[24] = (uint8_t)(height >> 16); hdr[25] = (uint8_t)(height >> 24);
+	hdr[34] = (uint8_t)bytes; hdr[35] = (uint8_t)(bytes >> 8); hdr[36] = (uint8_t)(bytes >> 16); hdr[37] = (uint8_t)(bytes >> 24);
+	f = fopen(out_path, "wb");
+	if (!f) { printf("Failed to open output decompressed .bmp file %s\n", out_path); return 1; }
+	fwrite(hdr, 54, 1, f);
+	for (r = 0; r < (int)height; r++)
+		for (t = 0; t < nx; t++)
+			fwrite(pix + ((size_t)(r / 512) * nx + t) * NHW_IMG_BYTES + (size_t)(r % 512) * 1536, 1536, 1, f);
+	fclose(f);
+	nhw_dec_destroy(d);
+	free(blob); free(pix); free(off); free(status);
+	printf("%d x %d tiles\n", ny, nx);
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc < 3) { show_usage(); return 0; }
+	if (!strcmp(argv[1], "--tiles")) {
+		int ny, nx;
+		if (argc < 6 || (ny = atoi(argv[2])) < 1 || (nx = atoi(argv[3])) < 1 || ny * nx > 65535) { show_usage(); return 1; }
+		return decode_tiles(ny, nx, argv[4], argv[5]);
+	}
 	if (!strcmp(argv[1], "--batch")) {
 		DIR *dir = opendir(argv[2]);
 		struct dirent *e;

@@ -46,8 +46,9 @@ static void usage(void)
 	        "  -h        print this help\n"
 	        "  -V        show version and legal information\n\n"
 	        "  example: nhw-enc -q15 image.bmp image.nhw\n"
-	        "Batch (MI355X build): %s [-q#] [--gpus g] --batch <dir> | --synthetic <n> [--seed s] --outdir <dir>\n",
-	        PROGRAM, PROGRAM);
+	        "Batch (MI355X build): %s [-q#] [--gpus g] --batch <dir> | --synthetic <n> [--seed s] --outdir <dir>\n"
+	        "Tiles (MI355X build): %s [-q#] --tiles <big.bmp> <stem>   (width, height multiples of 512: one <stem>_y<r>_x<c>.nhw per 512x512 tile)\n",
+	        PROGRAM, PROGRAM, PROGRAM);
 }
 
 static void version(void)
@@ -114,6 +115,45 @@ static void die_lib(const char *what, int rc)
 {
 	fprintf(stderr, "%s: %s failed (%d): %s\n", PROGRAM, what, rc, nhw_last_error());
 	exit(2);
+}
+
+/* --tiles: a 24-bit BMP whose sides are multiples of 512 is cut into independent 512x512 tiles, every tile encoded exactly as
+ * the reference would encode that crop saved as a BMP of its own (file row order kept; a top-down file is flipped as a whole first, as
+ * the reference does with a single tile).  Returns the tiles (malloc), tile (r, c) at index r * nx + c. */
+static uint8_t *load_bmp_tiles(const char *path, int *ny, int *nx)
+{
+	FILE *f = fopen(path, "rb");
+	uint8_t h[34], *row, *tiles;
+	int bih, width, height, planes, bpp, compr, flipped, r, c;
+	long off;
+	if (!f) { printf("menu(): Could not open file: %s\n", path); exit(-1); }
+	if (fread(h, 1, sizeof h, f) < sizeof h) { printf("invalid image file.\n"); exit(HDR_NO_DATA); }
+	if (h[0] != 'B' || h[1] != 'M') { printf("invalid image file.\n"); exit(HDR_NO_SIG); }
+	off = (long)(int)le32(h + 10);
+	bih = (int)le32(h + 14);
+	if (bih != 40 && bih != 52 && bih != 56 && bih != 108 && bih != 124) { printf("invalid image file.\n"); exit(HDR_BIH); }
+	width = (int)le32(h + 18); height = (int)le32(h + 22); planes = (short)le16(h + 26); bpp = (short)le16(h + 28); compr = (int)le32(h + 30);
+	if (planes != 1) { printf("invalid image file.\n"); exit(HDR_PLANES); }
+	flipped = height < 0;
+	if (flipped) height = -height;
+	if (width < 512 || height < 512 || width % 512 || height % 512 || bpp != 24 || compr != 0) {
+		printf("invalid image file.\n");
+		fprintf(stderr, "%s: --tiles wants a 24-bit uncompressed BMP whose width and height are multiples of 512 (got %dx%d, %d bpp)\n", PROGRAM, width, height, bpp);
+		exit(HDR_FORMAT);
+	}
+	if (fseek(f, off, SEEK_SET) != 0) { printf("unable to seek to actual data.\n"); exit(-2); }
+	*nx = width / 512; *ny = height / 512;
+	tiles = (uint8_t *)calloc((size_t)*nx * *ny, NHW_IMG_BYTES);
+	row = (uint8_t *)malloc((size_t)width * 3);
+	for (r = 0; r < height; r++) {
+		const int fr = flipped ? height - 1 - r : r;                  /* row of the picture as the encoder sees it */
+		if (fread(row, 1, (size_t)width * 3, f) < (size_t)width * 3) break;   /* short file: the rest stays zero, like the reference's read */
+		for (c = 0; c < *nx; c++)
+			memcpy(tiles + ((size_t)(fr / 512) * *nx + c) * NHW_IMG_BYTES + (size_t)(fr % 512) * 1536, row + (size_t)c * 1536, 1536);
+	}
+	free(row);
+	fclose(f);
+	return tiles;
 }
 
 static int encode_host_batch(nhw_enc *enc, const uint8_t *imgs, int n, int quality, char **out_names)
@@ -198,6 +238,7 @@ int main(int argc, char **argv)
 	int quality = QUALITY_DEFAULT, overwrite = 0, synthetic = 0, gpus = 1, i;
 	uint32_t seed = 0;
 	const char *batch_dir = NULL, *outdir = NULL;
+	int tiles = 0;
 	int stock_compat = 0;   /* --stock-compat: NHW_COMPAT_GLIBC_ONESHOT, the stock binary's out-of-bounds reads (include/nhw_hip.h) */
 	nhw_enc *enc = NULL;
 	int rc;
@@ -209,6 +250,7 @@ int main(int argc, char **argv)
 		if (!strcmp(argv[1], "--outdir") && argc > 2) { outdir = argv[2]; argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--gpus") && argc > 2) { gpus = atoi(argv[2]); argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--stock-compat")) { stock_compat = 1; argc -= 1; argv += 1; continue; }
+		if (!strcmp(argv[1], "--tiles")) { tiles = 1; argc -= 1; argv += 1; continue; }
 		for (i = 1; argv[1][i] != '\0'; i++) {
 			const char ch = argv[1][i];
 			if (ch >= '0' && ch <= '9') continue;
@@ -271,6 +313,24 @@ int main(int argc, char **argv)
 	}
 
 	if (argc < 3) { printf("Not enough arguments. Check help.\n"); usage(); return 0; }
+	if (tiles) {
+		int ny = 0, nx = 0, n, bad, t;
+		uint8_t *imgs = load_bmp_tiles(argv[1], &ny, &nx);
+		char **names;
+		n = ny * nx;
+		names = (char **)malloc(sizeof(char *) * (size_t)n);
+		for (t = 0; t < n; t++) {
+			names[t] = (char *)malloc(strlen(argv[2]) + 48);
+			sprintf(names[t], "%s_y%d_x%d.nhw", argv[2], t / nx, t % nx);
+		}
+		if ((rc = nhw_enc_create(0, n, &enc))) die_lib("nhw_enc_create", rc);
+		if (stock_compat) nhw_enc_set_compat(enc, NHW_COMPAT_GLIBC_ONESHOT);
+		bad = encode_host_batch(enc, imgs, n, quality, names);
+		nhw_enc_destroy(enc);
+		printf("%d x %d tiles\n", ny, nx);
+		free(imgs);
+		return bad ? 1 : 0;
+	}
 	if (strcmp(argv[1], argv[2]) == 0) { fprintf(stdout, "Input and output are the same file: '%s'.\n", argv[1]); return 1; }
 	{
 		uint8_t *img = (uint8_t *)malloc(NHW_IMG_BYTES);
