@@ -2111,43 +2111,55 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 	const int16_t *p = c->proc;
 	int16_t *b = c->band;
 	for (int i = tid; i < Q / 8; i += NT) reinterpret_cast<uint4 *>(b)[i] = make_uint4(0, 0, 0, 0);
-	const int r = tid;
-	const int16_t *row = p + (size_t)r * W + H;
-	/* does the walk of my row end in a mark on its last cell?  (visited cells: every second one of a run of marks) */
-	int end_mark = 0;
-	{
-		bool skip = false;
-		for (int j = 0; j < H; j++) {
-			const int a = row[j];
-			const bool mark = !skip && (a == 127 || a == 129);
-			if (mark && j == H - 1) end_mark = 1;
-			skip = mark;
-		}
+	const int r = tid, lane = tid & 63, wv = tid >> 6;
+	/* A wavefront takes a row, lane l its cells l, l + 64, l + 128, l + 192 (coalesced loads; a thread walking "its" row reads one cell of a
+	 * different line at every step -- 148 GB per batch that way).  The cells a walk visits are every second one of each run of marks:
+	 * alt_runs on the ballots.  First the rows' end marks (does the walk end in a mark on the last cell?) ... */
+	for (int row = wv; row < H; row += NT / 64) {
+		int a[4];
+		for (int k = 0; k < 4; k++) a[k] = p[(size_t)row * W + H + lane + 64 * k];
+		M4 cand;
+		BALLOT4(cand, a, x == 127 || x == 129);
+		const M4 fired = alt_runs(cand);
+		if (!lane) sh[row] = (int)(fired.w[3] >> 63);
 	}
+	BARRIER();
 	unsigned tot;
-	const int base = r * H + (int)block_exscan((unsigned)end_mark, tid, shm, &tot);
+	const int end_mark = sh[r];
+	const int base_r = r * H + (int)block_exscan((unsigned)end_mark, tid, shm, &tot);
+	sh[H + r] = base_r;
 	BARRIER();
-	if (end_mark) b[base + H] = (int16_t)(row[H - 1] == 127 ? 5 : -5);        /* b[t+1] of a mark in column 255: the first slot of the next row, which may still overwrite it */
-	BARRIER();
-	int back = 0;                                                              /* b[t-1] of a mark in column 0: the slot before my row */
-	{
-		bool skip = false;
-		for (int j = 0; j < H; j++) {
-			const int a = row[j], t = base + j;
-			if (skip) { skip = false; continue; }
-			if (a == 128) continue;
-			if (a == 127 || a == 129) {
-				const int16_t e = (int16_t)(a == 127 ? 5 : -5);
-				if (j) b[t - 1] = e; else back = e;
-				b[t] = (int16_t)(a == 127 ? 6 : -7);
-				if (j < H - 1) b[t + 1] = e;
-				skip = true;
-			}
-			else b[t] = (int16_t)band_value(a);
+	/* ... then every slot of the compact plane from the one cell whose write is the last to land there: the mark on its right (b[t-1]),
+	 * the cell itself (a mark's centre or a plain code), the mark on its left (b[t+1]) -- in that order of precedence, which is the
+	 * raster order of the writes.  Across a row boundary: the last slot of a row that does not end in a mark takes the b[t-1] of a mark
+	 * in column 0 of the next row; behind a row that does end in one, the extra slot (where everything moves one further) holds that
+	 * mark's b[t+1] unless the next row's column 0 is a mark as well. */
+	for (int row = wv; row < H; row += NT / 64) {
+		int a[4];
+		for (int k = 0; k < 4; k++) a[k] = p[(size_t)row * W + H + lane + 64 * k];
+		const int nxt = row + 1 < H ? (int)p[(size_t)(row + 1) * W + H] : 0;   /* column 0 of the next row is always visited */
+		const bool next_mark0 = nxt == 127 || nxt == 129;
+		M4 cand;
+		BALLOT4(cand, a, x == 127 || x == 129);
+		const M4 fired = alt_runs(cand), fnext = dn1(fired), fprev = up1(fired);
+		const int base = sh[H + row], ends = sh[row];
+		for (int k = 0; k < 4; k++) {
+			const int j = lane + 64 * k, x = a[k];
+			const int xr = right_of(a, k, 4, 1, lane);                            /* cell j + 1 */
+			const int seam = k ? __shfl(a[k - 1], 63) : 0;
+			const int from_left = __shfl(a[k], (lane + 63) & 63);                 /* (every lane takes part: a lane that sits out answers 0) */
+			const int xl = lane ? from_left : seam;                               /* cell j - 1 */
+			int val = 0; bool wr = true;
+			if (TB(fnext, k)) val = xr == 127 ? 5 : -5;
+			else if (TB(fired, k)) val = x == 127 ? 6 : -7;
+			else if (TB(fprev, k)) val = xl == 127 ? 5 : -5;
+			else if (x != 128) val = band_value(x);
+			else wr = false;
+			if (j == H - 1 && !ends && next_mark0) { val = nxt == 127 ? 5 : -5; wr = true; }
+			if (wr) b[base + j] = (int16_t)val;
+			if (j == H - 1 && ends) b[base + H] = (int16_t)(next_mark0 ? (nxt == 127 ? 5 : -5) : (x == 127 ? 5 : -5));
 		}
 	}
-	BARRIER();
-	if (back && base > 0) b[base - 1] = (int16_t)back;
 	BARRIER();
 
 	/* half synthesis of the kept first-order LL + that band against the original pass-1 plane (:509-541): pointwise */
@@ -2168,49 +2180,94 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 		*reinterpret_cast<uint32_t *>(hs + rr * W + 2 * k) = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
 	}
 	BARRIER();
-	if (q > 22) {                                                              /* :547-564, 512 consecutive cells per thread */
-		unsigned cnt = 0;
-		const int i0 = tid * (2 * Q / NT);
-		for (int i = i0; i < i0 + 2 * Q / NT; i++) cnt += hs[i] == 32000 || hs[i] == 32500;
-		unsigned at = block_exscan(cnt, tid, shm, &tot);
-		for (int i = i0; i < i0 + 2 * Q / NT; i++) {
-			if (hs[i] == 32000) c->qsetting3[at++] = (uint32_t)(i << 1);
-			else if (hs[i] == 32500) c->qsetting3[at++] = (uint32_t)(i << 1) + 1;
+	/* The two list passes below visit the cells of hs in raster order; a wavefront takes a row (512 cells, lane l the eight from 8 l on:
+	 * 16-byte loads), counts first, the rows' offsets from a prefix sum over the rows, then the entries at offset + (entries of the lanes
+	 * before mine). */
+	auto load8 = [&](const int16_t *rowp, int v[8]) {
+		const uint4 w = reinterpret_cast<const uint4 *>(rowp)[lane];
+		const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+		for (int e = 0; e < 4; e++) { v[2 * e] = (int16_t)(ww[e] & 0xFFFF); v[2 * e + 1] = (int16_t)(ww[e] >> 16); }
+	};
+	auto wave_exscan = [&](int v, int &total) {
+		int x = v;
+		for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+		total = __shfl(x, 63);
+		return x - v;
+	};
+	if (q > 22) {                                                              /* :547-564 */
+		for (int row = wv; row < H; row += NT / 64) {
+			int v[8], cnt = 0, total;
+			load8(hs + (size_t)row * W, v);
+			for (int e = 0; e < 8; e++) cnt += v[e] == 32000 || v[e] == 32500;
+			(void)wave_exscan(cnt, total);
+			if (!lane) sh[row] = total;
+		}
+		BARRIER();
+		const unsigned at_r = block_exscan((unsigned)sh[r], tid, shm, &tot);
+		sh[H + r] = (int)at_r;
+		BARRIER();
+		for (int row = wv; row < H; row += NT / 64) {
+			int v[8], cnt = 0, total;
+			load8(hs + (size_t)row * W, v);
+			for (int e = 0; e < 8; e++) cnt += v[e] == 32000 || v[e] == 32500;
+			int at = sh[H + row] + wave_exscan(cnt, total);
+			for (int e = 0; e < 8; e++) {
+				const int i = row * W + 8 * lane + e;
+				if (v[e] == 32000) c->qsetting3[at++] = (uint32_t)(i << 1);
+				else if (v[e] == 32500) c->qsetting3[at++] = (uint32_t)(i << 1) + 1;
+			}
 		}
 		if (tid == 0) c->m->qsetting3_len = (int)tot;
 		BARRIER();
 	}
 	else if (tid == 0) c->m->qsetting3_len = 0;
-	/* the position list of the 30000 / 31000 cells (:571-610): a row per thread; columns 254, 255 and 510, 511 are a row mark each, the
-	 * first pair reported through char_res1 instead */
+	/* the position list of the 30000 / 31000 cells (:571-610): columns 254, 255 and 510, 511 are a row mark each (raw value 254, behind the
+	 * entries of the columns before them), the first pair reported through char_res1 instead */
 	uint8_t *raw = c->raw, *pay = c->pay;
 	{
-		const int16_t *hr = hs + (size_t)r * W;
-		unsigned n = 2, e = 0, nc = 0;
-		for (int j = 0; j < W; j++) {
-			if (j == H - 2 || j == W - 2) {
-				if (j == H - 2) { nc += (hr[j] == 30000 || hr[j] == 31000); nc += (hr[j + 1] == 30000 || hr[j + 1] == 31000); }
-				j++;
+		for (int row = wv; row < H; row += NT / 64) {
+			int v[8], cnt = 0, nc = 0, total;
+			load8(hs + (size_t)row * W, v);
+			for (int e = 0; e < 8; e++) {
+				const bool hit = v[e] == 30000 || v[e] == 31000;
+				if ((lane == 31 || lane == 63) && e >= 6) { if (lane == 31) nc += hit; }
+				else cnt += hit;
 			}
-			else if (hr[j] == 30000 || hr[j] == 31000) { n++; e++; }
+			(void)wave_exscan(cnt, total);
+			const int ncr = __shfl(nc, 31);
+			if (!lane) { sh[row] = total; sh[H + row] = ncr; }
 		}
-		unsigned tn, te, tc;
-		unsigned an = block_exscan(n, tid, shm, &tn);
-		unsigned ae = block_exscan(e, tid, shm, &te);
-		unsigned ac = block_exscan(nc, tid, shm, &tc);
-		for (int j = 0; j < W; j++) {
-			if (j == H - 2 || j == W - 2) {
-				raw[an++] = H - 2;
-				if (j == H - 2) {
-					if (hr[j] == 30000) c->char_res1[ac++] = (uint16_t)(r * H); else if (hr[j] == 31000) c->char_res1[ac++] = (uint16_t)(r * H + 1);
-					if (hr[j + 1] == 30000) c->char_res1[ac++] = (uint16_t)(r * H + 2); else if (hr[j + 1] == 31000) c->char_res1[ac++] = (uint16_t)(r * H + 3);
-				}
-				j++;
+		BARRIER();
+		const unsigned e_r = (unsigned)sh[r], nc_r = (unsigned)sh[H + r];
+		BARRIER();
+		unsigned te, tc;
+		const unsigned ae_r = block_exscan(e_r, tid, shm, &te);
+		const unsigned ac_r = block_exscan(nc_r, tid, shm, &tc);
+		sh[r] = (int)ae_r; sh[H + r] = (int)ac_r;
+		BARRIER();
+		for (int row = wv; row < H; row += NT / 64) {
+			int v[8], cnt = 0, total;
+			load8(hs + (size_t)row * W, v);
+			const bool special = lane == 31 || lane == 63;
+			for (int e = 0; e < (special ? 6 : 8); e++) cnt += v[e] == 30000 || v[e] == 31000;
+			const int off = wave_exscan(cnt, total);
+			const int first_half = __shfl(off, 32);                              /* entries of columns 0..253 */
+			int ae = sh[row] + off;                                              /* payload index; the raw list has two marks per row before this row's, one more from column 256 on */
+			int an = ae + 2 * row + (lane >= 32);
+			for (int e = 0; e < (special ? 6 : 8); e++) {
+				if (v[e] == 30000) { raw[an++] = (uint8_t)((8 * lane + e) & 255); pay[ae++] = 0; }
+				else if (v[e] == 31000) { raw[an++] = (uint8_t)((8 * lane + e) & 255); pay[ae++] = 1; }
 			}
-			else if (hr[j] == 30000) { raw[an++] = (uint8_t)(j & 255); pay[ae++] = 0; }
-			else if (hr[j] == 31000) { raw[an++] = (uint8_t)(j & 255); pay[ae++] = 1; }
+			if (lane == 31) {
+				raw[sh[row] + 2 * row + first_half] = H - 2;
+				int ac = sh[H + row];
+				if (v[6] == 30000) c->char_res1[ac++] = (uint16_t)(row * H); else if (v[6] == 31000) c->char_res1[ac++] = (uint16_t)(row * H + 1);
+				if (v[7] == 30000) c->char_res1[ac++] = (uint16_t)(row * H + 2); else if (v[7] == 31000) c->char_res1[ac++] = (uint16_t)(row * H + 3);
+			}
+			if (lane == 63) raw[sh[row] + 2 * row + total + 1] = H - 2;
 		}
-		if (tid == 0) { c->m->char_res1_len = (int)tc; sh[0] = (int)tn; sh[1] = (int)te; }
+		BARRIER();
+		if (tid == 0) { c->m->char_res1_len = (int)tc; sh[0] = (int)(te + 2 * H); sh[1] = (int)te; }
 		BARRIER();
 	}
 	poslist_finish_par(c, &c->res6, raw, sh[0], pay, sh[1], 1, tid, shm);
