@@ -807,28 +807,47 @@ DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 
 /* Y24 (:1426-1496): commutative adds; thread j owns row j of the first-order plane, the two cells that spill
  * into row j+1 (r = 254, 255) are added in a second step */
-DEV void adjust_first_order_par(Ctx *c, int tid)
+DEV void first_order_step(int code, int16_t *t)
+{
+	switch (code) {
+	case 141: t[0] -= 5; break;            case 140: t[0] += 5; break;
+	case 144: t[0] -= 3; break;            case 145: t[0] += 3; break;
+	case 121: t[0] -= 4; t[1] -= 3; break; case 122: t[0] += 4; t[1] += 3; break;
+	case 123: t[0] += 2; t[1] += 2; t[2] += 2; break;
+	case 124: t[0] -= 2; t[1] -= 2; t[2] -= 2; break;
+	case 126: t[0] += 9; t[1] += 3; break; case 125: t[0] -= 9; t[1] -= 3; break;
+	case 148: t[0] -= 8; break;            case 149: t[0] += 8; break;
+	default: break;
+	}
+}
+/* Thread j reads column j of the code plane (consecutive threads, consecutive cells) but owns ROW j of the first-order plane: its cells
+ * go through LDS, 32 columns (+ the two a step may spill into) of all 256 rows at a time, loaded and stored as row pieces. */
+#define FO_C 32
+#define FO_P (FO_C + 2)                                           /* 17 dwords: a thread per row walks conflict-free */
+DEV void adjust_first_order_par(Ctx *c, int tid, int16_t *lds /* [H][FO_P] */)
 {
 	int16_t *f = c->first_order;
 	const int j = tid;
-	for (int step = 0; step < 2; step++) {
-		if (j < H - 2)
-			for (int r = step ? H - 2 : 0; r < (step ? H : H - 2); r++) {
-				const int code = c->ll1[r * H + j];
-				int16_t *t = f + j * H + r;
-				switch (code) {
-				case 141: t[0] -= 5; break;            case 140: t[0] += 5; break;
-				case 144: t[0] -= 3; break;            case 145: t[0] += 3; break;
-				case 121: t[0] -= 4; t[1] -= 3; break; case 122: t[0] += 4; t[1] += 3; break;
-				case 123: t[0] += 2; t[1] += 2; t[2] += 2; break;
-				case 124: t[0] -= 2; t[1] -= 2; t[2] -= 2; break;
-				case 126: t[0] += 9; t[1] += 3; break; case 125: t[0] -= 9; t[1] -= 3; break;
-				case 148: t[0] -= 8; break;            case 149: t[0] += 8; break;
-				default: break;
-				}
-			}
+	for (int r0 = 0; r0 < H - 2; r0 += FO_C) {
+		const int nd = (H - r0 < FO_P ? H - r0 : FO_P) / 2;        /* dwords of a row piece: columns r0 .. r0 + 2 nd - 1 */
+		for (int idx = tid; idx < H * (FO_P / 2); idx += NT) {
+			const int row = idx / (FO_P / 2), d = idx % (FO_P / 2);
+			if (d < nd) reinterpret_cast<uint32_t *>(lds + row * FO_P)[d] = reinterpret_cast<const uint32_t *>(f + row * H + r0)[d];
+		}
+		BARRIER();
+		if (j < H - 2) {
+			const int r1 = r0 + FO_C < H - 2 ? r0 + FO_C : H - 2;
+			for (int r = r0; r < r1; r++) first_order_step(c->ll1[r * H + j], lds + j * FO_P + (r - r0));
+		}
+		BARRIER();
+		for (int idx = tid; idx < H * (FO_P / 2); idx += NT) {
+			const int row = idx / (FO_P / 2), d = idx % (FO_P / 2);
+			if (d < nd) reinterpret_cast<uint32_t *>(f + row * H + r0)[d] = reinterpret_cast<const uint32_t *>(lds + row * FO_P)[d];
+		}
 		BARRIER();
 	}
+	if (j < H - 2) for (int r = H - 2; r < H; r++) first_order_step(c->ll1[r * H + j], f + j * H + r);   /* these two spill into row j + 1: after everything else */
+	BARRIER();
 }
 
 /* ---------------------------------------------------------------- Y27 (R) */
@@ -2063,7 +2082,7 @@ DEV void luma_p4a_par(Ctx *c, int tid, int16_t *lds)
 DEV void luma_p4b_par(Ctx *c, int tid, int *pos, int16_t *lds)
 {
 	PROF_BEGIN();
-	if (c->q > 21) adjust_first_order_par(c, tid);                          /* Y24 */
+	if (c->q > 21) adjust_first_order_par(c, tid, lds);                     /* Y24 */
 	build_poslists_par(c, tid, pos, lds);                                   /* Y25 */
 	if (!tid) PROF(c, 12);
 }
