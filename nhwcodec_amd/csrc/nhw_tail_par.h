@@ -650,10 +650,10 @@ DEV void classify_step(const uint8_t *tab, int q, int r, int j, int16_t *pr, int
  * from the third on are still untouched; the first three are carried over from the chunk before).  Column 255
  * runs afterwards on a packed LDS copy of its column: its "column 256" is the LH1 column written by the other
  * columns, its ll1 neighbour is column 0, both read live. */
-#define CR 8
+#define CR 4      /* rows per chunk: 22 KB of LDS, seven workgroups per CU (measured, ms per 4096-image batch: CR 2: 3.78, 4: 3.40, 8: 3.71, 16: 4.00) */
 /* The LH1 coefficients of column j are row j of the plane, LW of them at a time for all 256 rows: whole 64-byte pieces of every row
- * (a piece per chunk of CR rows is 16 bytes of a line that has left the L2 again when the next chunk asks for its neighbour -- measured
- * 4x the band's bytes in either direction).  LP: LDS pitch of a column's piece, an odd number of dwords. */
+ * (a piece per chunk of rows is a few bytes of a line that has left the L2 again when the next chunk asks for its neighbour -- measured
+ * 4x the band's bytes in either direction with 16-byte pieces).  LP: LDS pitch of a column's piece, an odd number of dwords. */
 #define LW 16
 #define LP (LW + 2)
 #define CR_LDS_BYTES (((CR + 3) * 3 * H + H * LP) * 2 + CK_TABLE_BYTES)
