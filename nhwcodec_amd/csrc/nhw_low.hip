@@ -37,6 +37,9 @@ DEVI int iabs_(int v) { return v < 0 ? -v : v; }
  * divergent region pays an exec-mask save / restore and a vector compare per branch: measured 4x slower); stores are issued by lane 0. */
 #define LDK(p) __builtin_amdgcn_readfirstlane((int)*(p))
 #define STK(p, v) do { if (threadIdx.x == 0) *(p) = (v); } while (0)
+/* passes B and C run one image per LANE (the first PG lanes of the wavefront, PG images to a wavefront): plain per-lane accesses */
+#define LDL(p) ((int)*(p))
+#define STL(p, v) (*(p) = (v))
 
 /* ------------------------------------------------------------------------------------------------ parameters (:570-598) */
 struct PfP { int sharp, s2, half, smooth_hi, smooth, tail_rules; };
@@ -331,7 +334,7 @@ DEVI void machine_pair(PfM &m, const PfP &pp, int row, int &k0, int &k1, int16_t
 		if (iabs_(k0) > sharp) {
 			d0 += k0 > 0 ? 2 : -2;
 			if (iabs_(k1) > s2 || T(8) == 1) {
-				STK(km, (int16_t)0);
+				STL(km, (int16_t)0);
 				if ((T(19) < 4 * Q || (T(20) >= 3 && T(20) < 4 * Q)) && iabs_(k0) > sharp + 96 && T(6) > 0 && row > 2) {
 					if (T(20) >= 3 && T(19) >= 8 * Q) { T(6) = 7000000; T(20) = 8 * Q; }
 					if (T(19) > 0 && T(19) < 4 * Q) {
@@ -354,20 +357,20 @@ DEVI void machine_pair(PfM &m, const PfP &pp, int row, int &k0, int &k1, int16_t
 					if (iabs_(k1) > 3000) k1 = k1 > 0 ? s2 + 22 : -s2 - 22;
 					if (iabs_(k0) < (iabs_(k1) >> 2)) {
 						d0 += k0 > 0 ? -1 : 1;
-						STK(km, (int16_t)k0);
+						STL(km, (int16_t)k0);
 						d1 += k1 > 0 ? 2 : -2;
-						if (iabs_(k0) > s2) STK(km + 1, (int16_t)0);
+						if (iabs_(k0) > s2) STL(km + 1, (int16_t)0);
 					}
 					else d1 += k1 > 0 ? 1 : -1;
 					T(3) = 1;
 				} else {
 					d1 += k1 > 0 ? 2 : -2;
-					if (iabs_(k0) > s2) STK(km + 1, (int16_t)0);
+					if (iabs_(k0) > s2) STL(km + 1, (int16_t)0);
 					T(3) = T(3) == 1 ? 2 : T(3) == 2 ? 3 : 0;
 				}
 			} else {
 				d1 += k1 > 0 ? 2 : -2;
-				if (iabs_(k0) > s2) STK(km + 1, (int16_t)0);
+				if (iabs_(k0) > s2) STL(km + 1, (int16_t)0);
 			}
 			if (T(14) == 2) { T(14) = 1; T(26) = 3; if (T(25) > 0) T(25)++; }
 			if (T(14) == 1) { if (T(26) < 4) T(26)++; else { T(14) = 2; T(26) = 0; } }
@@ -420,8 +423,8 @@ DEVI void machine_pair(PfM &m, const PfP &pp, int row, int &k0, int &k1, int16_t
 	}
 	/* opposite signs, both just above the threshold (:1912-1924) */
 	if (iabs_(k0) > sharp && iabs_(k0) <= sharp + 20 && iabs_(k1) > sharp && iabs_(k1) <= sharp + 20) {
-		if (k0 > 0 && k1 < 0) { d0++; d1--; STK(so, (uint8_t)2); STK(so + 1, (uint8_t)3); }
-		else if (k0 < 0 && k1 > 0) { d0--; d1++; STK(so, (uint8_t)3); STK(so + 1, (uint8_t)2); }
+		if (k0 > 0 && k1 < 0) { d0++; d1--; STL(so, (uint8_t)2); STL(so + 1, (uint8_t)3); }
+		else if (k0 < 0 && k1 > 0) { d0--; d1++; STL(so, (uint8_t)3); STL(so + 1, (uint8_t)2); }
 	}
 }
 #undef T
@@ -458,10 +461,10 @@ DEVI void tail_rules(int k0, int k1, int &prev_big, int &d0, int &d1)      /* :1
 		}
 	}
 }
-/* Runs on lane 0 alone, on the vector unit (plain loads: the counters stay in vector registers), while the marker walk below runs on the
- * scalar unit: a CU has one of each, both issue one instruction per cycle, and its sixteen images are at different rows at any moment, so
- * the two walks of different images overlap instead of queueing for one unit (both on the scalar unit: 471 ms per batch; split: see
- * DESIGN.md). */
+/* Runs on the vector unit, one image per lane (the first PG lanes of the wavefront): plain per-lane loads and stores, the counters stay in
+ * vector registers.  (History, ms per 4096-image batch for the front of q10: both serial passes on the scalar unit of a wavefront per
+ * image 471; pass B on lane 0 and pass C on the scalar unit 443; both per lane with four images to a wavefront 313 -- what is left is the
+ * length of one machine's dependent instruction chain, one wavefront per SIMD.) */
 DEVI void pair_row(PfM &m, int &prev_big, const PfP &pp, int r, int16_t *km, int16_t *y, uint8_t *so)
 {
 	int n0 = km[1], n1 = km[2];                                   /* the next pair's values are on their way while this one is worked on (a pair only ever rewrites its own two cells) */
@@ -480,11 +483,11 @@ struct MarkState { int skip_toggle, second_toggle, pos0, neg0, pos1, neg1; };
 
 DEVI void resolve_marker(int16_t *cell, int v, int &pos_cnt, int &neg_cnt, int s2)
 {
-	if (v == 20000) { if (!pos_cnt) { STK(cell, (int16_t)0); pos_cnt = 1; } else { STK(cell, (int16_t)5000); pos_cnt = pos_cnt == 1 ? 2 : 0; } }
-	else if (v == -20000) { if (!neg_cnt) { STK(cell, (int16_t)0); neg_cnt = 1; } else { STK(cell, (int16_t)-5000); neg_cnt = neg_cnt == 1 ? 2 : 0; } }
-	else if (v == 7000) STK(cell, (int16_t)(s2 + 22));
+	if (v == 20000) { if (!pos_cnt) { STL(cell, (int16_t)0); pos_cnt = 1; } else { STL(cell, (int16_t)5000); pos_cnt = pos_cnt == 1 ? 2 : 0; } }
+	else if (v == -20000) { if (!neg_cnt) { STL(cell, (int16_t)0); neg_cnt = 1; } else { STL(cell, (int16_t)-5000); neg_cnt = neg_cnt == 1 ? 2 : 0; } }
+	else if (v == 7000) STL(cell, (int16_t)(s2 + 22));
 }
-DEVI void bump(int16_t *yc, uint8_t *sc, int d) { STK(yc, (int16_t)(LDK(yc) + d)); STK(sc, (uint8_t)1); }
+DEVI void bump(int16_t *yc, uint8_t *sc, int d) { STL(yc, (int16_t)(LDL(yc) + d)); STL(sc, (uint8_t)1); }
 /* strong pixel with a weak partner: nudge the strong one, the partner if it agrees in sign, and the two pixels above the pair */
 DEVI void sharpen_weak_partner(int strong, int weak, int16_t *ys, int16_t *yw, uint8_t *ss, uint8_t *sw,
                                const int16_t *kup, int16_t *yup, uint8_t *sup, bool have_up, bool no_retry)
@@ -493,7 +496,7 @@ DEVI void sharpen_weak_partner(int strong, int weak, int16_t *ys, int16_t *yw, u
 	bump(ys, ss, sg);
 	if ((sg > 0 && weak > 0) || (sg < 0 && weak < 0)) bump(yw, sw, 2 * sg);
 	if (have_up) {
-		const int a = LDK(kup) * sg, b = LDK(kup - 1) * sg;
+		const int a = LDL(kup) * sg, b = LDL(kup - 1) * sg;
 		int da = 0, db = 0;
 		if (a > 4) da += sg;
 		if (b > 4) db += sg;
@@ -503,14 +506,14 @@ DEVI void sharpen_weak_partner(int strong, int weak, int16_t *ys, int16_t *yw, u
 		if (db) bump(yup - 1, sup - 1, db);
 	}
 }
-/* one row: km / y / so of the row, kmu / yu / sou of the row above */
+/* one row: km / y / so of the row, kmu / yu / sou of the row above; per lane like pass B */
 DEVI void marker_row(MarkState &s, const PfP &pp, int r, int16_t *km, int16_t *y, uint8_t *so, const int16_t *kmu, int16_t *yu, uint8_t *sou)
 {
 	const int sharp = pp.sharp, s2 = pp.s2, half = pp.half;
 	int idle = 0, retry = 0, idle_fresh = 0;
 	for (int c = 1; c < W - 3; c++) {
 		c++;
-		const int k0 = LDK(km + c - 1), k1 = LDK(km + c);
+		const int k0 = LDL(km + c - 1), k1 = LDL(km + c);
 		if (iabs_(k0) > 6000) {
 			resolve_marker(km + c - 1, k0, s.pos0, s.neg0, s2);
 			if (!s.second_toggle) { resolve_marker(km + c, k1, s.pos1, s.neg1, s2); s.second_toggle = 1; }
@@ -538,7 +541,7 @@ DEVI void marker_row(MarkState &s, const PfP &pp, int r, int16_t *km, int16_t *y
 			else if (retry == 1) {
 				c++; retry = 0; idle = 0;
 				if (idle_fresh == 4) {
-					if (iabs_(LDK(km + c - 5)) <= s2 || iabs_(LDK(km + c - 2)) <= s2) { c -= 5; retry = 2; }
+					if (iabs_(LDL(km + c - 5)) <= s2 || iabs_(LDL(km + c - 2)) <= s2) { c -= 5; retry = 2; }
 					idle_fresh = 0;
 				}
 			}
@@ -609,43 +612,60 @@ DEVI void final_row(const PfP &pp, const int16_t *km, int16_t *y, const uint8_t 
 
 } // namespace
 
-/* src: the luma plane as the colour kernel wrote it (read only); y: the filtered plane (every row is written) */
+/* src: the luma plane as the colour kernel wrote it (read only); y: the filtered plane (every row is written).
+ *
+ * The counters of passes B and C tie every pixel pair of an image to the one before it, so an image is a serial job of ~130 000 steps and
+ * only images run side by side.  A wavefront per image leaves 63 of 64 lanes idle in those passes, and with 4096 images every SIMD holds
+ * four such wavefronts whose one-lane instructions take turns.  So a wavefront takes PG = 4 images: pass A (the part that is parallel
+ * along a row, all 64 lanes) runs image after image, passes B and C run the four images in lanes 0..3 -- one instruction stream, four
+ * machines (their counters are plain per-lane registers) -- at the price of the lanes' divergence. */
+#define PG 4
 __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
-                                                      int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q, int dbg)
+                                                      int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q, int n_img, int dbg)
 {
-	__shared__ __attribute__((aligned(16))) int16_t s_src[3][W];
-	__shared__ __attribute__((aligned(16))) int16_t s_km[2][W + 8];
-	__shared__ __attribute__((aligned(16))) int16_t s_y[2][W];
-	__shared__ __attribute__((aligned(16))) uint8_t s_so[2][W];
-	__shared__ __attribute__((aligned(16))) int16_t s_sum[W], s_vb[W];
+	__shared__ __attribute__((aligned(16))) int16_t s_src[PG][3][W];
+	__shared__ __attribute__((aligned(16))) int16_t s_km[PG][2][W + 8];
+	__shared__ __attribute__((aligned(16))) int16_t s_y[PG][2][W];
+	__shared__ __attribute__((aligned(16))) uint8_t s_so[PG][2][W];
+	__shared__ __attribute__((aligned(16))) int16_t s_sum[W], s_vb[W];   /* of the image pass A is working on */
 	__shared__ int s_misc[4];
-	const int lane = threadIdx.x;
-	const int16_t *src = srcb + (size_t)blockIdx.x * src_stride;
-	int16_t *yo = yb + (size_t)blockIdx.x * y_stride;
-	int16_t *kmo = kmb + (size_t)blockIdx.x * km_stride;         /* contrast map and flags as passes A..C leave them: pass D is a kernel of its own */
-	uint8_t *soo = sob + (size_t)blockIdx.x * so_stride;
+	const int lane = threadIdx.x, img0 = blockIdx.x * PG;
+	const int nimg = n_img - img0 < PG ? n_img - img0 : PG;              /* images of this wavefront */
 	const PfP pp = pf_params(q);
 
-	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	MapState ms[PG];
+	int row_carry[PG];
+	for (int g = 0; g < PG; g++) { ms[g] = MapState{ 0, 0, 0, 0, 0, 0, 0, 0, 0 }; row_carry[g] = 0; }
+	/* per lane: the machine of pass B and the state of pass C of image img0 + lane */
 	MarkState ks = { 0, 0, 0, 0, 0, 0 };
 	PfM mach;
-	int prev_big = 0, row_carry = 0;
+	int prev_big = 0;
 	machine_reset(mach);
 
 	const int c0 = lane * 8;
-	auto load_row = [&](int r) { *reinterpret_cast<uint4 *>(&s_src[r % 3][c0]) = *reinterpret_cast<const uint4 *>(src + (size_t)r * W + c0); };
-	load_row(0); load_row(1);
-	for (int k = lane; k < 2 * (W + 8); k += 64) (&s_km[0][0])[k] = 0;
+#define SRC(g) (srcb + (size_t)(img0 + (g)) * src_stride)
+#define YO(g) (yb + (size_t)(img0 + (g)) * y_stride)
+#define KMO(g) (kmb + (size_t)(img0 + (g)) * km_stride)             /* contrast map and flags as passes A..C leave them: pass D is a kernel of its own */
+#define SOO(g) (sob + (size_t)(img0 + (g)) * so_stride)
+	auto load_row = [&](int g, int r) { *reinterpret_cast<uint4 *>(&s_src[g][r % 3][c0]) = *reinterpret_cast<const uint4 *>(SRC(g) + (size_t)r * W + c0); };
+#pragma unroll
+	for (int g = 0; g < PG; g++) if (g < nimg) { load_row(g, 0); load_row(g, 1); }
+	for (int k = lane; k < PG * 2 * (W + 8); k += 64) (&s_km[0][0][0])[k] = 0;
 	__syncthreads();
-	*reinterpret_cast<uint4 *>(yo + c0) = *reinterpret_cast<const uint4 *>(&s_src[0][c0]);      /* row 0 is not touched by any pass */
+#pragma unroll
+	for (int g = 0; g < PG; g++) if (g < nimg) *reinterpret_cast<uint4 *>(YO(g) + c0) = *reinterpret_cast<const uint4 *>(&s_src[g][0][c0]);      /* row 0 is not touched by any pass */
 
 	for (int r = 1; r < W - 1; r++) {
-		load_row(r + 1);
+#pragma unroll
+		for (int g = 0; g < PG; g++) if (g < nimg) load_row(g, r + 1);
 		__syncthreads();
-		const int16_t *up = s_src[(r - 1) % 3], *mid = s_src[r % 3], *dn = s_src[(r + 1) % 3];
-		int16_t *km = s_km[r & 1], *kmu = s_km[(r - 1) & 1];
-		int16_t *y = s_y[r & 1], *yu = s_y[(r - 1) & 1];
-		uint8_t *so = s_so[r & 1], *sou = s_so[(r - 1) & 1];
+#pragma unroll
+		for (int g = 0; g < PG; g++) {
+		if (g >= nimg) continue;
+		const int16_t *up = s_src[g][(r - 1) % 3], *mid = s_src[g][r % 3], *dn = s_src[g][(r + 1) % 3];
+		int16_t *km = s_km[g][r & 1];
+		int16_t *y = s_y[g][r & 1];
+		uint8_t *so = s_so[g][r & 1];
 		/* every lane: 8-neighbour sum and magnitude sum of its 8 pixels (:605-618), as the signed base value 15 |sum| + mag of the carry */
 		int smv[8], vbv[8];
 		for (int e = 0; e < 8; e++) {
@@ -673,7 +693,7 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 			int carry;
 			bool merged = true;
 			if (c0 <= PF_LOOK) {                                   /* the row's own entry state reaches me */
-				carry = row_carry;
+				carry = row_carry[g];
 				for (int c = 1; c < c0; c++) { const int vb = s_vb[c]; carry = vb == 0 ? 0 : ((iabs_(vb) + ((carry + 2) >> 2)) & 15); }
 			} else {
 				uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
@@ -697,7 +717,7 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 			if (__any(!merged)) {
 				/* rare: some lane's 16 states had not merged within the look-back -- the row is replayed by one lane */
 				if (lane == 0) {
-					int cr = row_carry;
+					int cr = row_carry[g];
 					for (int c = 1; c < W - 1; c++) {
 						const int vb = s_vb[c];
 						int val = 0;
@@ -708,9 +728,9 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 				}
 				__syncthreads();
 				for (int e = 0; e < 8; e++) valv[e] = (c0 + e >= 1 && c0 + e <= W - 2) ? (int)km[c0 + e] : 0;
-				row_carry = s_misc[0];
+				row_carry[g] = s_misc[0];
 			} else {
-				row_carry = __builtin_amdgcn_readlane(carry, 63);
+				row_carry[g] = __builtin_amdgcn_readlane(carry, 63);
 			}
 			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)valv[2 * e] | ((uint32_t)(uint16_t)valv[2 * e + 1] << 16);
 			  *reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
@@ -725,7 +745,7 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 				while (cm) {
 					const int e = __builtin_ctz(cm);
 					cm &= cm - 1;
-					map_cell(ms, pp, 8 * l + e, LDK(s_sum + 8 * l + e), LDK(km + 8 * l + e), km);
+					map_cell(ms[g], pp, 8 * l + e, LDK(s_sum + 8 * l + e), LDK(km + 8 * l + e), km);
 				}
 			}
 		}
@@ -739,25 +759,36 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 				    iabs_(up[c] - mid[c - 1]) < 4 && iabs_(mid[c - 1] - dn[c]) < 4 && iabs_(dn[c] - mid[c + 1]) < 4 && iabs_(mid[c + 1] - up[c]) < 4)
 					y[c] = (int16_t)(((mid[c] << 2) + mid[c - 1] + mid[c + 1] + up[c] + dn[c] + 4) >> 3);
 			}
-			__syncthreads();
 		}
-		if (!(dbg & 2) && lane == 0) pair_row(mach, prev_big, pp, r, km, y, so);
-		__syncthreads();
-		if (!(dbg & 4)) marker_row(ks, pp, r, km, y, so, kmu, yu, sou);
+		__syncthreads();                                           /* s_vb / s_sum are the next image's from here */
+		}
+		/* passes B and C of this row, image img0 + lane on lane `lane` */
+		if (lane < nimg) {
+			if (!(dbg & 2)) pair_row(mach, prev_big, pp, r, s_km[lane][r & 1], s_y[lane][r & 1], s_so[lane][r & 1]);
+			if (!(dbg & 4)) marker_row(ks, pp, r, s_km[lane][r & 1], s_y[lane][r & 1], s_so[lane][r & 1], s_km[lane][(r - 1) & 1], s_y[lane][(r - 1) & 1], s_so[lane][(r - 1) & 1]);
+		}
 		__syncthreads();
 		if (r > 1) {                                              /* row r-1 is through passes A..C: nothing of a later row touches it */
-			*reinterpret_cast<uint4 *>(yo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&yu[c0]);
-			*reinterpret_cast<uint4 *>(kmo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&kmu[c0]);
-			*reinterpret_cast<uint2 *>(soo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint2 *>(&sou[c0]);
+#pragma unroll
+			for (int g = 0; g < PG; g++) if (g < nimg) {
+				*reinterpret_cast<uint4 *>(YO(g) + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[g][(r - 1) & 1][c0]);
+				*reinterpret_cast<uint4 *>(KMO(g) + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[g][(r - 1) & 1][c0]);
+				*reinterpret_cast<uint2 *>(SOO(g) + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[g][(r - 1) & 1][c0]);
+			}
 		}
 	}
-	{
+#pragma unroll
+	for (int g = 0; g < PG; g++) if (g < nimg) {
 		const int r = W - 2;
-		*reinterpret_cast<uint4 *>(yo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[r & 1][c0]);
-		*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[r & 1][c0]);
-		*reinterpret_cast<uint2 *>(soo + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[r & 1][c0]);
-		*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
+		*reinterpret_cast<uint4 *>(YO(g) + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[g][r & 1][c0]);
+		*reinterpret_cast<uint4 *>(KMO(g) + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[g][r & 1][c0]);
+		*reinterpret_cast<uint2 *>(SOO(g) + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[g][r & 1][c0]);
+		*reinterpret_cast<uint4 *>(YO(g) + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[g][(W - 1) % 3][c0]);
 	}
+#undef SRC
+#undef YO
+#undef KMO
+#undef SOO
 }
 
 /* pass D (:2312-2420) has no memory beyond its cursor inside a row: a lane per row, all rows of the batch at once */
@@ -991,7 +1022,7 @@ void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y,
 #ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing */
 	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
-	k_low_prefilter<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, dbg);
+	k_low_prefilter<<<(n + PG - 1) / PG, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, n, dbg);
 	if (!(dbg & 8)) k_low_final<<<dim3(2, n), 256, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q);
 }
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s)
