@@ -63,8 +63,8 @@ struct MapState { int carry, neg_run, neg_cycle, pos_run, pos_cycle, pos_alt, po
  * a dozen pixels, so every lane finds the entry state of its 8 pixels by running all 16 states through the 12 pixels before them (one
  * SWAR step per pixel on two 64-bit words) and replays its own 8 -- no walk along the row.  What IS order-dependent below quality 17 is
  * the marker rule: it fires only on borderline pixels (sum not above the threshold, carried value above it), on the first three values
- * that hit the threshold from below and on the first value of threshold + 21; those few pixels are visited in raster order by one lane,
- * everything else is written by the lanes that computed it. */
+ * that hit the threshold from below and on the first value of threshold + 21; those few pixels are visited in raster order by the lane
+ * that owns the image in the serial phases (map_cell), everything else is written by the lanes that computed it. */
 DEVI void fsm_step16(uint64_t &m0, uint64_t &m1, int vb)
 {
 	if (vb == 0) { m0 = 0; m1 = 0; return; }
@@ -79,20 +79,20 @@ DEVI void map_cell(MapState &s, const PfP &pp, int c, int sm, int val, int16_t *
 	if (sm < 0) {
 		if (val == -s2 && s.bump_count < 3) { val = -s2 - 1; s.bump_count++; }
 		if (-sm <= s2 && -val > s2 && -val <= s2 + 20) {          /* borderline: the plain sum is not above the threshold, the contrast is */
-			if (c > 1 && iabs_(LDK(k + c - 1)) <= pp.half) s.neg_run = 0;
-			if (!s.neg_run) { STK(k + c, (int16_t)(-20000)); s.neg_run = 1; }
+			if (c > 1 && iabs_(LDL(k + c - 1)) <= pp.half) s.neg_run = 0;
+			if (!s.neg_run) { STL(k + c, (int16_t)(-20000)); s.neg_run = 1; }
 			else {
-				STK(k + c, (int16_t)((int16_t)val));
+				STL(k + c, (int16_t)((int16_t)val));
 				if (!s.neg_cycle) { s.neg_run = 0; s.neg_cycle = 1; }
 				else if (s.neg_run == 1) s.neg_run = 2;
 				else { s.neg_run = 0; s.neg_cycle = s.neg_cycle == 1 ? 2 : s.neg_cycle == 2 ? 3 : 0; }
 			}
 		}
-		else STK(k + c, (int16_t)((int16_t)val));
+		else STL(k + c, (int16_t)((int16_t)val));
 	} else {
 		if (sm <= s2 && val > s2 && val <= s2 + 20) {
 			if (c > 1) {
-				const int left = LDK(k + c - 1);
+				const int left = LDL(k + c - 1);
 				if (iabs_(left) <= pp.half) s.pos_run = 0;
 				else if (iabs_(left) > 10000 || left == s2 + 21) {
 					if (!s.pos_alt) { s.pos_run = 0; if (!s.pos_cycle) s.pos_cycle = 1; s.pos_alt = 1; }
@@ -106,18 +106,18 @@ DEVI void map_cell(MapState &s, const PfP &pp, int c, int sm, int val, int16_t *
 						s.pos_neg_alt = s.pos_neg_alt == 1 ? 2 : 0;
 					}
 				}
-				else if (left == s2 + 22) STK(k + c - 1, (int16_t)7000);
+				else if (left == s2 + 22) STL(k + c - 1, (int16_t)7000);
 			}
-			if (!s.pos_run) { STK(k + c, (int16_t)(20000)); s.pos_run = 1; }
+			if (!s.pos_run) { STL(k + c, (int16_t)(20000)); s.pos_run = 1; }
 			else {
-				STK(k + c, (int16_t)((int16_t)val));
+				STL(k + c, (int16_t)((int16_t)val));
 				if (!s.pos_cycle) { s.pos_run = 0; s.pos_cycle = 1; }
 				else if (s.pos_run == 1) s.pos_run = 2;
 				else { s.pos_run = 0; s.pos_cycle = s.pos_cycle == 1 ? 2 : s.pos_cycle == 2 ? 3 : 0; }
 			}
 		}
-		else if (val == s2 + 21) { STK(k + c, (int16_t)((int16_t)(s.exact_count ? val : 7000))); s.exact_count++; }
-		else STK(k + c, (int16_t)((int16_t)val));
+		else if (val == s2 + 21) { STL(k + c, (int16_t)((int16_t)(s.exact_count ? val : 7000))); s.exact_count++; }
+		else STL(k + c, (int16_t)((int16_t)val));
 	}
 }
 /* does pixel (sm, val) need the serial visit? */
@@ -627,16 +627,17 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 	__shared__ __attribute__((aligned(16))) int16_t s_km[PG][2][W + 8];
 	__shared__ __attribute__((aligned(16))) int16_t s_y[PG][2][W];
 	__shared__ __attribute__((aligned(16))) uint8_t s_so[PG][2][W];
-	__shared__ __attribute__((aligned(16))) int16_t s_sum[W], s_vb[W];   /* of the image pass A is working on */
+	__shared__ __attribute__((aligned(16))) int16_t s_sum[PG][W], s_vb[W];   /* s_vb: of the image pass A is working on */
+	__shared__ __attribute__((aligned(8))) uint8_t s_cand[PG][64];        /* per 8-pixel group: the pixels that need the serial visit of pass A */
 	__shared__ int s_misc[4];
 	const int lane = threadIdx.x, img0 = blockIdx.x * PG;
 	const int nimg = n_img - img0 < PG ? n_img - img0 : PG;              /* images of this wavefront */
 	const PfP pp = pf_params(q);
 
-	MapState ms[PG];
 	int row_carry[PG];
-	for (int g = 0; g < PG; g++) { ms[g] = MapState{ 0, 0, 0, 0, 0, 0, 0, 0, 0 }; row_carry[g] = 0; }
-	/* per lane: the machine of pass B and the state of pass C of image img0 + lane */
+	for (int g = 0; g < PG; g++) row_carry[g] = 0;
+	/* per lane: the marker state of pass A, the machine of pass B and the state of pass C of image img0 + lane */
+	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	MarkState ks = { 0, 0, 0, 0, 0, 0 };
 	PfM mach;
 	int prev_big = 0;
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 		{ uint32_t w4[4], z4[4];
 		  for (int e = 0; e < 4; e++) { w4[e] = (uint32_t)(uint16_t)vbv[2 * e] | ((uint32_t)(uint16_t)vbv[2 * e + 1] << 16); z4[e] = (uint32_t)(uint16_t)smv[2 * e] | ((uint32_t)(uint16_t)smv[2 * e + 1] << 16); }
 		  *reinterpret_cast<uint4 *>(&s_vb[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-		  *reinterpret_cast<uint4 *>(&s_sum[c0]) = make_uint4(z4[0], z4[1], z4[2], z4[3]); }
+		  *reinterpret_cast<uint4 *>(&s_sum[g][c0]) = make_uint4(z4[0], z4[1], z4[2], z4[3]); }
 		*reinterpret_cast<uint4 *>(&y[c0]) = *reinterpret_cast<const uint4 *>(&mid[c0]);        /* :566: the passes work on a copy */
 		*reinterpret_cast<uint2 *>(&so[c0]) = make_uint2(0, 0);
 		__syncthreads();
@@ -735,32 +736,41 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)valv[2 * e] | ((uint32_t)(uint16_t)valv[2 * e + 1] << 16);
 			  *reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
 			for (int e = 0; e < 8; e++) if (smv[e] != 0 && map_candidate(pp, smv[e], valv[e])) cand |= 1u << e;
-			/* the few order-dependent pixels, in raster order: lanes ascending, pixels ascending inside a lane */
-			uint64_t lanes = __ballot(cand != 0);
-			__syncthreads();
-			while (lanes) {
-				const int l = __builtin_ctzll(lanes);
-				lanes &= lanes - 1;
-				unsigned cm = (unsigned)__builtin_amdgcn_readlane((int)cand, l);
-				while (cm) {
-					const int e = __builtin_ctz(cm);
-					cm &= cm - 1;
-					map_cell(ms[g], pp, 8 * l + e, LDK(s_sum + 8 * l + e), LDK(km + 8 * l + e), km);
+		}
+		s_cand[g][lane] = (uint8_t)cand;
+		__syncthreads();                                           /* s_vb is the next image's from here */
+		}
+		/* the few order-dependent pixels of pass A, in raster order, image img0 + lane on lane `lane` */
+		if (lane < nimg && !(dbg & 1)) {
+			int16_t *km = s_km[lane][r & 1];
+			for (int l8 = 0; l8 < 8; l8++) {
+				uint64_t m8 = reinterpret_cast<const uint64_t *>(s_cand[lane])[l8];
+				while (m8) {
+					const int bit = __builtin_ctzll(m8);
+					m8 &= m8 - 1;
+					const int c = 64 * l8 + bit;                        /* byte l of the word = group 8 l8 + l, bit e of it = pixel 8 (8 l8 + l) + e */
+					map_cell(ms, pp, c, (int)s_sum[lane][c], (int)km[c], km);
 				}
 			}
 		}
 		__syncthreads();
 		if (pp.smooth) {                                          /* :780-807, reads the source copy only: off the chain */
-			for (int e = 0; e < 8; e++) {
-				const int c = c0 + e;
-				if (c < 1 || c > W - 2) continue;
-				const int k = km[c];
-				if (iabs_(k) > 4 && iabs_(k) < pp.smooth_hi &&
-				    iabs_(up[c] - mid[c - 1]) < 4 && iabs_(mid[c - 1] - dn[c]) < 4 && iabs_(dn[c] - mid[c + 1]) < 4 && iabs_(mid[c + 1] - up[c]) < 4)
-					y[c] = (int16_t)(((mid[c] << 2) + mid[c - 1] + mid[c + 1] + up[c] + dn[c] + 4) >> 3);
+#pragma unroll
+			for (int g = 0; g < PG; g++) {
+				if (g >= nimg) continue;
+				const int16_t *up = s_src[g][(r - 1) % 3], *mid = s_src[g][r % 3], *dn = s_src[g][(r + 1) % 3];
+				const int16_t *km = s_km[g][r & 1];
+				int16_t *y = s_y[g][r & 1];
+				for (int e = 0; e < 8; e++) {
+					const int c = c0 + e;
+					if (c < 1 || c > W - 2) continue;
+					const int k = km[c];
+					if (iabs_(k) > 4 && iabs_(k) < pp.smooth_hi &&
+					    iabs_(up[c] - mid[c - 1]) < 4 && iabs_(mid[c - 1] - dn[c]) < 4 && iabs_(dn[c] - mid[c + 1]) < 4 && iabs_(mid[c + 1] - up[c]) < 4)
+						y[c] = (int16_t)(((mid[c] << 2) + mid[c - 1] + mid[c + 1] + up[c] + dn[c] + 4) >> 3);
+				}
 			}
-		}
-		__syncthreads();                                           /* s_vb / s_sum are the next image's from here */
+			__syncthreads();
 		}
 		/* passes B and C of this row, image img0 + lane on lane `lane` */
 		if (lane < nimg) {
