@@ -34,13 +34,13 @@ PMC_FILE = os.path.join(ROOT, "profiles", "front_pmc.json")     # written by pro
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources: ties a committed PMC profile to the code it was taken from"""
+    """sha256 over the sources of the front kernels (nhw_front.hip and the workspace header it includes): ties the committed PMC profile of
+    the front launch group to the code it was taken from"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "nhwcodec_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("nhw_front.hip", "nhw_ws.h"):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
