@@ -31,6 +31,7 @@
 namespace {
 
 DEVI int iabs_(int v) { return v < 0 ? -v : v; }
+DEVI uint64_t low_bits64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1); }   /* bits 0 .. n-1 */
 
 /* The chain walks below are executed by the whole wavefront on wave-uniform values: what comes out of LDS goes through
  * v_readfirstlane, so counters and cursors live in scalar registers and every branch is a scalar branch (a lone lane inside a
@@ -869,23 +870,42 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 	int16_t *p = procb + (size_t)blockIdx.x * plane_stride;
 	const int lane = threadIdx.x;
 
-	if (q <= 11) {                                                 /* Y11 (:285-309): rows are independent, a lane walks two of them */
+	if (q <= 11) {
+		/* Y11 (:285-309): rows are independent, a lane walks two of them -- through LDS, 64 columns of all 128 rows at a time (a lane on
+		 * "its" row of the plane reads one cell of a different line at every step); what the walk carries from tile to tile is the
+		 * updated left neighbour. */
 		const int lim = q > 6 ? 10 : 11;
-		for (int r = H / 2 + lane; r < H; r += 64) {
-			int16_t *row = p + (size_t)r * W;
-			int left = row[-1];                                    /* the cell before the row in memory (never written by this pass) */
-			int cur = row[0];
-			for (int j = 0; j < H; j++) {
-				const int nxt = row[j + 1];
-				const int m = iabs_(cur);
-				int out = cur;
-				if (m >= DEADZONE && m < lim) {
-					const bool ql = iabs_(left) < DEADZONE, qr = iabs_(nxt) < DEADZONE;
-					if ((ql && qr) || (m == DEADZONE && (ql || qr))) out = 0;
-				}
-				if (out != cur) row[j] = (int16_t)out;
-				left = out; cur = nxt;
+		enum { TP = 68 };                                          /* tile pitch: columns c0-2 .. c0+65 as 34 dwords */
+		int16_t *tile = ll;                                        /* 128 x 68 shorts: the LL2 buffer is not in use yet */
+		int left[2] = { 0, 0 };
+		for (int c0 = 0; c0 < H; c0 += 64) {
+			for (int k = lane; k < (H / 2) * (TP / 2); k += 64) {
+				const int rr = k / (TP / 2), d = k % (TP / 2);
+				reinterpret_cast<uint32_t *>(tile + rr * TP)[d] = reinterpret_cast<const uint32_t *>(p + (size_t)(H / 2 + rr) * W + c0 - 2)[d];
 			}
+			__syncthreads();
+			for (int h = 0; h < 2; h++) {
+				int16_t *row = tile + (lane + 64 * h) * TP + 2 - c0;   /* row[j]: cell of column j */
+				if (!c0) left[h] = row[-1];                        /* the cell before the row in memory (never written by this pass) */
+				int cur = row[c0];
+				for (int j = c0; j < c0 + 64; j++) {
+					const int nxt = row[j + 1];
+					const int m = iabs_(cur);
+					int out = cur;
+					if (m >= DEADZONE && m < lim) {
+						const bool ql = iabs_(left[h]) < DEADZONE, qr = iabs_(nxt) < DEADZONE;
+						if ((ql && qr) || (m == DEADZONE && (ql || qr))) out = 0;
+					}
+					if (out != cur) row[j] = (int16_t)out;
+					left[h] = out; cur = nxt;
+				}
+			}
+			__syncthreads();
+			for (int k = lane; k < (H / 2) * 32; k += 64) {
+				const int rr = k >> 5, d = 1 + (k & 31);
+				reinterpret_cast<uint32_t *>(p + (size_t)(H / 2 + rr) * W + c0 - 2)[d] = reinterpret_cast<const uint32_t *>(tile + rr * TP)[d];
+			}
+			__syncthreads();
 		}
 	}
 	if (q > 12) return;
@@ -937,30 +957,44 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 	}
 	int last = __any(any1) ? 4 : -1;                              /* the inner loop counter's exit value: row 0, column 4 */
 	__syncthreads();
-	for (int pass = 0; pass < 2; pass++)                          /* plus shape (+2, :488-533), then flat corner (+1, :535-583) */
-		for (int r = 0; r < LS - 2; r++) {
-			const int16_t *row = ll + r * LP;
-			for (int j = 0; j < LS - 2; j++) {
-				const int16_t *v = row + j;
-				const int a0 = LDK(v), a1 = LDK(v + 1), a2 = LDK(v + 2), b0 = LDK(v + LP), b1 = LDK(v + LP + 1), b2 = LDK(v + LP + 2), c1 = LDK(v + 2 * LP + 1);
-				if (!pass) {
-					if (iabs_(a1 - c1) < t3 && iabs_(b0 - b2) < t3 && iabs_(b1 - b0) < t4 - 1 && iabs_(a1 - b1) < t4) {
-						const int e = (a1 + c1 + b0 + b2 + 2) >> 2;
-						if (iabs_(e - b0) < 5 || iabs_(e - b2) < 5) STK(ll + (r + 1) * LP + j + 1, (int16_t)e);
-						last = (r + 1) * LS + j + 1;
-						if (lane == 0) { HITBIT(h32, last); if (deep) for (int k = -1; k < 2; k++) HITBIT(hsib, last + k); }
+	/* plus shape (+2, :488-533), then flat corner (+1, :535-583): two raster walks in which a hit rewrites cell (r+1, j+1) -- which only
+	 * the NEXT cell of the row (and the rows below) reads.  So 64 cells of a row are tested at once on the band as it stands; the first
+	 * hit among them is committed, the cells behind it are tested again, and so on: one round per hit instead of one step per cell.
+	 * `last` (the reference's stale `count`) is what the cells between two hits see: the hit before them. */
+	for (int pass = 0; pass < 2; pass++)
+		for (int r = 0; r < LS - 2; r++)
+			for (int j0 = 0; j0 < LS - 2; j0 += 64) {
+				const int j = j0 + lane;
+				const bool valid = j < LS - 2;
+				int start = 0;                                       /* lanes from here on are still to be visited */
+				for (;;) {
+					const int16_t *v = ll + r * LP + (valid ? j : 0);
+					const int a0 = v[0], a1 = v[1], a2 = v[2], b0 = v[LP], b1 = v[LP + 1], b2 = v[LP + 2], c1 = v[2 * LP + 1];
+					bool outer, hit;
+					if (!pass) { outer = false; hit = iabs_(a1 - c1) < t3 && iabs_(b0 - b2) < t3 && iabs_(b1 - b0) < t4 - 1 && iabs_(a1 - b1) < t4; }
+					else {
+						outer = iabs_(a2 - a1) < t3 && iabs_(a1 - a0) < t3 && iabs_(a0 - b0) < t3 && iabs_(a2 - b2) < t3;
+						hit = outer && iabs_(c1 - b0) < t3 && iabs_(b0 - b1) < t4;
 					}
-				} else if (iabs_(a2 - a1) < t3 && iabs_(a1 - a0) < t3 && iabs_(a0 - b0) < t3 && iabs_(a2 - b2) < t3) {
-					if (iabs_(c1 - b0) < t3 && iabs_(b0 - b1) < t4) {
-						const int e = (a1 + c1 + b0 + b2 + 1) >> 2;
-						if (iabs_(e - b0) < 5 || iabs_(e - b2) < 5) STK(ll + (r + 1) * LP + j + 1, (int16_t)e);
-						last = (r + 1) * LS + j + 1;
-						if (lane == 0) HITBIT(h32, last);
+					const bool live = valid && lane >= start;
+					const uint64_t mh = __ballot(live && hit), mo = __ballot(live && outer);
+					const int f = mh ? __builtin_ctzll(mh) : 64;         /* first hit */
+					if (deep && (mo & low_bits64(f))) {                  /* pass 1: cells before the first hit that pass the outer test mark the siblings of the hit before them */
+						if (last < 0) { if (lane == 0) stale_hits = 1; }
+						else if (lane < 3) HITBIT(hsib, last - 1 + lane);
 					}
-					if (deep && lane == 0) { if (last < 0) stale_hits = 1; else for (int k = -1; k < 2; k++) HITBIT(hsib, last + k); }
+					if (f == 64) break;
+					last = (r + 1) * LS + j0 + f + 1;
+					if (lane == f) {
+						const int e = (a1 + c1 + b0 + b2 + (pass ? 1 : 2)) >> 2;
+						if (iabs_(e - b0) < 5 || iabs_(e - b2) < 5) ll[(r + 1) * LP + j + 1] = (int16_t)e;
+						HITBIT(h32, last);
+					}
+					if (deep && lane < 3) HITBIT(hsib, last - 1 + lane);
+					start = f + 1;
+					if (start >= 64) break;
 				}
 			}
-		}
 	__syncthreads();
 	if (deep)
 		for (int r = lane; r < LS; r += 64) {                      /* three flat cells in a row (:585-620): reads only */
