@@ -957,18 +957,25 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 	}
 	int last = __any(any1) ? 4 : -1;                              /* the inner loop counter's exit value: row 0, column 4 */
 	__syncthreads();
-	/* plus shape (+2, :488-533), then flat corner (+1, :535-583): two raster walks in which a hit rewrites cell (r+1, j+1) -- which only
-	 * the NEXT cell of the row (and the rows below) reads.  So 64 cells of a row are tested at once on the band as it stands; the first
-	 * hit among them is committed, the cells behind it are tested again, and so on: one round per hit instead of one step per cell.
-	 * `last` (the reference's stale `count`) is what the cells between two hits see: the hit before them. */
-	for (int pass = 0; pass < 2; pass++)
-		for (int r = 0; r < LS - 2; r++)
-			for (int j0 = 0; j0 < LS - 2; j0 += 64) {
-				const int j = j0 + lane;
-				const bool valid = j < LS - 2;
-				int start = 0;                                       /* lanes from here on are still to be visited */
-				for (;;) {
-					const int16_t *v = ll + r * LP + (valid ? j : 0);
+	/* plus shape (+2, :488-533), then flat corner (+1, :535-583): two raster walks in which a hit at (r, j) rewrites cell (r+1, j+1).
+	 * Cell (r, j) reads rows r .. r+2 at columns j .. j+2: of what the walk has written before it gets there it sees (r+1, j) -- from its
+	 * own left neighbour -- and row r, written by row r-1's cells up to column j+1.  So the rows run as a skewed wavefront: lane l takes
+	 * row r0 + l and is at column t - 2 l in step t (its upper neighbour is two columns ahead, and reads (r+2, j+1) two steps before the
+	 * row below rewrites it); 64 rows per block, 252 steps per block instead of 8000 cells one after the other.
+	 * The reference's stale `count` (`last`): every hit marks the siblings of its own target (the inner test sits inside the outer one);
+	 * a cell that passes only the outer test marks the target of the hit before it -- marked already -- or, before the first hit of the
+	 * second walk, what the first walk left: its last hit's target, else the 4 / IM_SIZE of the row pass above. */
+	int last0 = last;                                              /* `count` as the second walk finds it */
+	for (int pass = 0; pass < 2; pass++) {
+		int hit_max = -1, hit_min = 1 << 30, outer_min = 1 << 30;    /* visiting positions r * LS + j */
+		for (int r0 = 0; r0 < LS - 2; r0 += 64) {
+			const int r = r0 + lane;
+			const bool row_ok = r < LS - 2;
+			const int nrows = LS - 2 - r0 < 64 ? LS - 2 - r0 : 64;
+			for (int t = 0; t < (LS - 2) + 2 * (nrows - 1); t++) {
+				const int j = t - 2 * lane;
+				if (row_ok && j >= 0 && j < LS - 2) {
+					const int16_t *v = ll + r * LP + j;
 					const int a0 = v[0], a1 = v[1], a2 = v[2], b0 = v[LP], b1 = v[LP + 1], b2 = v[LP + 2], c1 = v[2 * LP + 1];
 					bool outer, hit;
 					if (!pass) { outer = false; hit = iabs_(a1 - c1) < t3 && iabs_(b0 - b2) < t3 && iabs_(b1 - b0) < t4 - 1 && iabs_(a1 - b1) < t4; }
@@ -976,25 +983,30 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 						outer = iabs_(a2 - a1) < t3 && iabs_(a1 - a0) < t3 && iabs_(a0 - b0) < t3 && iabs_(a2 - b2) < t3;
 						hit = outer && iabs_(c1 - b0) < t3 && iabs_(b0 - b1) < t4;
 					}
-					const bool live = valid && lane >= start;
-					const uint64_t mh = __ballot(live && hit), mo = __ballot(live && outer);
-					const int f = mh ? __builtin_ctzll(mh) : 64;         /* first hit */
-					if (deep && (mo & low_bits64(f))) {                  /* pass 1: cells before the first hit that pass the outer test mark the siblings of the hit before them */
-						if (last < 0) { if (lane == 0) stale_hits = 1; }
-						else if (lane < 3) HITBIT(hsib, last - 1 + lane);
-					}
-					if (f == 64) break;
-					last = (r + 1) * LS + j0 + f + 1;
-					if (lane == f) {
+					const int pos = r * LS + j;
+					if (outer && pos < outer_min) outer_min = pos;
+					if (hit) {
+						const int target = (r + 1) * LS + j + 1;
 						const int e = (a1 + c1 + b0 + b2 + (pass ? 1 : 2)) >> 2;
 						if (iabs_(e - b0) < 5 || iabs_(e - b2) < 5) ll[(r + 1) * LP + j + 1] = (int16_t)e;
-						HITBIT(h32, last);
+						HITBIT(h32, target);
+						if (deep) for (int k = -1; k < 2; k++) HITBIT(hsib, target + k);
+						if (pos > hit_max) hit_max = pos;
+						if (pos < hit_min) hit_min = pos;
 					}
-					if (deep && lane < 3) HITBIT(hsib, last - 1 + lane);
-					start = f + 1;
-					if (start >= 64) break;
 				}
 			}
+		}
+		for (int d = 32; d; d >>= 1) {                               /* over the rows */
+			const int a = __shfl_xor(hit_max, d), bq = __shfl_xor(hit_min, d), cq = __shfl_xor(outer_min, d);
+			hit_max = a > hit_max ? a : hit_max; hit_min = bq < hit_min ? bq : hit_min; outer_min = cq < outer_min ? cq : outer_min;
+		}
+		if (!pass) { if (hit_max >= 0) last0 = hit_max + LS + 1; }    /* target of the walk's last hit: (r+1) * LS + j + 1 */
+		else if (deep && outer_min < hit_min) {                      /* cells that pass the outer test before any hit of this walk */
+			if (last0 < 0) { if (lane == 0) stale_hits = 1; }
+			else if (lane < 3) HITBIT(hsib, last0 - 1 + lane);
+		}
+	}
 	__syncthreads();
 	if (deep)
 		for (int r = lane; r < LS; r += 64) {                      /* three flat cells in a row (:585-620): reads only */
@@ -1007,6 +1019,8 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 		const int r = k >> 6, c2 = (k & 63) * 2;
 		*reinterpret_cast<uint32_t *>(p + (size_t)r * W + c2) = *reinterpret_cast<const uint32_t *>(&ll[r * LP + c2]);
 	}
+	/* the children / siblings of the cells that were hit are cleared where they are small.  All loads of a cell's up to fifteen targets
+	 * are issued before the first store (one memory round trip per cell instead of fifteen in a row: this loop was most of the kernel). */
 	for (int cell = lane; cell < LS * LS; cell += 64) {
 		const int w = cell >> 5;
 		const uint32_t bit = 1u << (cell & 31);
@@ -1014,15 +1028,28 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 		const bool sib = hsib[w] & bit;
 		if (!limc && !sib) continue;
 		const int r = cell >> 7, j = cell & 127, flat = r * W + j;
-		if (limc) {
-			const int base = flat << 1;
-			const int band[3] = { H, 2 * Q, 2 * Q + H }, lim[3] = { t6, t6 + 6, limc };
+		uint32_t cw[6] = { 0, 0, 0, 0, 0, 0 };
+		int sv[3] = { 0, 0, 0 };
+		int16_t *sp[3] = { p + flat + H / 2, p + flat + Q, p + flat + Q + H / 2 };
+		const int band[3] = { H, 2 * Q, 2 * Q + H };
+		if (limc)
 			for (int bnd = 0; bnd < 3; bnd++) {
-				int16_t *v = p + base + band[bnd];
-				zero_below(v, lim[bnd]); zero_below(v + 1, lim[bnd]); zero_below(v + W, lim[bnd]); zero_below(v + W + 1, lim[bnd]);
+				const uint32_t *v = reinterpret_cast<const uint32_t *>(p + (flat << 1) + band[bnd]);
+				cw[2 * bnd] = v[0]; cw[2 * bnd + 1] = v[W / 2];
 			}
+		if (sib) for (int k = 0; k < 3; k++) sv[k] = *sp[k];
+		if (limc) {
+			const int lim[3] = { t6, t6 + 6, limc };
+			for (int bnd = 0; bnd < 3; bnd++)
+				for (int h = 0; h < 2; h++) {
+					const uint32_t x = cw[2 * bnd + h];
+					uint32_t y = x;
+					if (iabs_((int16_t)(x & 0xFFFF)) < lim[bnd]) y &= 0xFFFF0000u;
+					if (iabs_((int16_t)(x >> 16)) < lim[bnd]) y &= 0x0000FFFFu;
+					if (y != x) reinterpret_cast<uint32_t *>(p + (flat << 1) + band[bnd])[h ? W / 2 : 0] = y;
+				}
 		}
-		if (sib) { zero_below(p + flat + H / 2, 11); zero_below(p + flat + Q, 12); zero_below(p + flat + Q + H / 2, 13); }
+		if (sib) { const int sl[3] = { 11, 12, 13 }; for (int k = 0; k < 3; k++) if (sv[k] && iabs_(sv[k]) < sl[k]) *sp[k] = 0; }
 	}
 	if (stale_hits && lane < 3) {                                  /* `count` still IM_SIZE: the "siblings" of plane cells 65535..65537 */
 		const int flat = Q - 1 + lane;
