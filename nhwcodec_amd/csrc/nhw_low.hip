@@ -552,63 +552,63 @@ DEVI void marker_row(MarkState &s, const PfP &pp, int r, int16_t *km, int16_t *y
 }
 
 /* ------------------------------------------------------------------------------------------------ pass D (:2312-2420) */
-DEVI void final_row(const PfP &pp, const int16_t *km, int16_t *y, const uint8_t *so)
+/* one pair of pass D: km / y / so are row pointers indexed by column, p the pair's first column; returns the next pair's first column
+ * (p + 2, or p + 1 where the walk slides by one) */
+DEVI int final_pair(const PfP &pp, const int16_t *km, int16_t *y, const uint8_t *so, int p)
 {
 	const int sharp = pp.sharp, s2 = pp.s2;
 #define JUST_ABOVE(v, base) (iabs_(v) > (base) && iabs_(v) <= (base) + 20)
-	for (int c = 1; c < W - 2; c++) {
-		c++;
-		const int k0 = km[c - 1], k1 = km[c];
-		int16_t *o = y + c - 1;
-		const uint8_t *f = so + c - 1;
-		bool slide = false;
-		if (iabs_(k0) > 4000 || iabs_(k1) > 4000) continue;
-		if (JUST_ABOVE(k0, sharp) && JUST_ABOVE(k1, sharp)) {
-			const int k2 = km[c + 1];
-			const bool next_same = c < W - 4 && JUST_ABOVE(k2, sharp) && ((k1 > 0 && k2 > 0) || (k1 < 0 && k2 < 0));
-			if (f[0] != 1 && f[1] != 1) {
-				if (k0 > 0 && k1 > 0) {
-					if (k0 >= k1) { if (f[0] != 2) o[0]++; else if (f[1] != 2) o[1]++; }
-					else { if (f[1] != 2) o[1]++; else if (f[0] != 2) o[0]++; }
-				}
-				else if (k0 < 0 && k1 < 0) {
-					if (k0 <= k1) { if (f[0] != 3) o[0]--; else if (f[1] != 3) o[1]--; }
-					else { if (f[1] != 3) o[1]--; else if (f[0] != 3) o[0]--; }
-				}
-				else slide = next_same;
+	const int c = p + 1;
+	const int k0 = km[c - 1], k1 = km[c];
+	int16_t *o = y + c - 1;
+	const uint8_t *f = so + c - 1;
+	bool slide = false;
+	if (iabs_(k0) > 4000 || iabs_(k1) > 4000) return p + 2;
+	if (JUST_ABOVE(k0, sharp) && JUST_ABOVE(k1, sharp)) {
+		const int k2 = km[c + 1];
+		const bool next_same = c < W - 4 && JUST_ABOVE(k2, sharp) && ((k1 > 0 && k2 > 0) || (k1 < 0 && k2 < 0));
+		if (f[0] != 1 && f[1] != 1) {
+			if (k0 > 0 && k1 > 0) {
+				if (k0 >= k1) { if (f[0] != 2) o[0]++; else if (f[1] != 2) o[1]++; }
+				else { if (f[1] != 2) o[1]++; else if (f[0] != 2) o[0]++; }
+			}
+			else if (k0 < 0 && k1 < 0) {
+				if (k0 <= k1) { if (f[0] != 3) o[0]--; else if (f[1] != 3) o[1]--; }
+				else { if (f[1] != 3) o[1]--; else if (f[0] != 3) o[0]--; }
 			}
 			else slide = next_same;
 		}
-		else if (iabs_(k0) > sharp + 56 && iabs_(k1) > sharp + 56) {
-			if (!f[0] && !f[1]) {
-				if (k0 > 0 && k1 < 0) { o[0]++; o[1]--; }
-				else if (k0 < 0 && k1 > 0) { o[0]--; o[1]++; }
-				else if (iabs_(k0) > sharp + 96 && iabs_(k1) > sharp + 96) {
-					if (k0 > 0 && k1 > 0) { if (k0 > k1) o[0]++; else o[1]++; }
-					else if (k0 < 0 && k1 < 0) { if (k0 < k1) o[0]--; else o[1]--; }
-				}
+		else slide = next_same;
+	}
+	else if (iabs_(k0) > sharp + 56 && iabs_(k1) > sharp + 56) {
+		if (!f[0] && !f[1]) {
+			if (k0 > 0 && k1 < 0) { o[0]++; o[1]--; }
+			else if (k0 < 0 && k1 > 0) { o[0]--; o[1]++; }
+			else if (iabs_(k0) > sharp + 96 && iabs_(k1) > sharp + 96) {
+				if (k0 > 0 && k1 > 0) { if (k0 > k1) o[0]++; else o[1]++; }
+				else if (k0 < 0 && k1 < 0) { if (k0 < k1) o[0]--; else o[1]--; }
 			}
 		}
-		else if (iabs_(k0) > sharp + 160 && JUST_ABOVE(k1, s2)) {
-			if (!f[0] && !f[1]) {
-				if (k0 > 0 && k1 > 0) o[1]--;
-				else if (k0 < 0 && k1 < 0) o[1]++;
-				else slide = c < W - 6 && iabs_(km[c + 1]) > sharp + 160 && iabs_(km[c + 2]) <= s2;
-			}
-			else slide = c < W - 6 && iabs_(km[c + 1]) > sharp + 160 && iabs_(km[c + 2]) > s2 + 20;
+	}
+	else if (iabs_(k0) > sharp + 160 && JUST_ABOVE(k1, s2)) {
+		if (!f[0] && !f[1]) {
+			if (k0 > 0 && k1 > 0) o[1]--;
+			else if (k0 < 0 && k1 < 0) o[1]++;
+			else slide = c < W - 6 && iabs_(km[c + 1]) > sharp + 160 && iabs_(km[c + 2]) <= s2;
 		}
-		else if (iabs_(k1) > sharp + 160 && JUST_ABOVE(k0, s2)) {
-			if (!f[0] && !f[1]) {
-				if (k0 > 0 && k1 > 0) o[0]--;
-				else if (k0 < 0 && k1 < 0) o[0]++;
-				else slide = c < W - 4 && JUST_ABOVE(km[c + 1], s2);
-			}
-			else slide = true;
+		else slide = c < W - 6 && iabs_(km[c + 1]) > sharp + 160 && iabs_(km[c + 2]) > s2 + 20;
+	}
+	else if (iabs_(k1) > sharp + 160 && JUST_ABOVE(k0, s2)) {
+		if (!f[0] && !f[1]) {
+			if (k0 > 0 && k1 > 0) o[0]--;
+			else if (k0 < 0 && k1 < 0) o[0]++;
+			else slide = c < W - 4 && JUST_ABOVE(km[c + 1], s2);
 		}
 		else slide = true;
-		if (slide) c--;
 	}
+	else slide = true;
 #undef JUST_ABOVE
+	return slide ? p + 1 : p + 2;
 }
 
 } // namespace
@@ -802,14 +802,45 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 #undef SOO
 }
 
-/* pass D (:2312-2420) has no memory beyond its cursor inside a row: a lane per row, all rows of the batch at once */
+/* pass D (:2312-2420) has no memory beyond its cursor inside a row: a thread per row, 256 rows to a workgroup, through LDS tiles of 32
+ * columns of the three planes (a thread on "its" row of a plane reads one cell of a different line at every step: 130 GB per batch that
+ * way).  A pair that starts in a tile reads three columns past it; the cursor is what a row carries from tile to tile. */
+#define FD_C 32
+#define FD_P 36                                                       /* tile pitch (cells): columns c0 .. c0 + 35 */
 __global__ __launch_bounds__(256) void k_low_final(int16_t *__restrict__ yb, size_t y_stride, const int16_t *__restrict__ kmb, size_t km_stride,
                                                    const uint8_t *__restrict__ sob, size_t so_stride, int q)
 {
-	const int r = 1 + blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
-	if (r > W - 2) return;
+	__shared__ __attribute__((aligned(16))) int16_t kt[256 * FD_P], yt[256 * FD_P];
+	__shared__ __attribute__((aligned(16))) uint8_t st[256 * FD_P];
+	const int tid = threadIdx.x, r0 = 1 + blockIdx.x * 256, img = blockIdx.y;
+	const int nrows = W - 1 - r0 < 256 ? W - 1 - r0 : 256;             /* rows r0 .. r0 + nrows - 1 (<= W - 2) */
 	const PfP pp = pf_params(q);
-	final_row(pp, kmb + (size_t)img * km_stride + (size_t)r * W, yb + (size_t)img * y_stride + (size_t)r * W, sob + (size_t)img * so_stride + (size_t)r * W);
+	const int16_t *km = kmb + (size_t)img * km_stride;
+	int16_t *y = yb + (size_t)img * y_stride;
+	const uint8_t *so = sob + (size_t)img * so_stride;
+	int p = 1;
+	for (int c0 = 0; c0 < W; c0 += FD_C) {
+		for (int k = tid; k < nrows * (FD_P / 2); k += 256) {
+			const int rr = k / (FD_P / 2), d = k % (FD_P / 2);
+			reinterpret_cast<uint32_t *>(kt + rr * FD_P)[d] = reinterpret_cast<const uint32_t *>(km + (size_t)(r0 + rr) * W + c0)[d];
+			reinterpret_cast<uint32_t *>(yt + rr * FD_P)[d] = reinterpret_cast<const uint32_t *>(y + (size_t)(r0 + rr) * W + c0)[d];
+		}
+		for (int k = tid; k < nrows * (FD_P / 4); k += 256) {
+			const int rr = k / (FD_P / 4), d = k % (FD_P / 4);
+			reinterpret_cast<uint32_t *>(st + rr * FD_P)[d] = reinterpret_cast<const uint32_t *>(so + (size_t)(r0 + rr) * W + c0)[d];
+		}
+		__syncthreads();
+		if (tid < nrows) {
+			const int end = c0 + FD_C < W - 2 ? c0 + FD_C : W - 2;
+			while (p < end) p = final_pair(pp, kt + tid * FD_P - c0, yt + tid * FD_P - c0, st + tid * FD_P - c0, p);
+		}
+		__syncthreads();
+		for (int k = tid; k < nrows * (FD_P / 2 - 1); k += 256) {      /* columns c0 .. c0 + 33: a pair that starts in the tile's last column writes one past it */
+			const int rr = k / (FD_P / 2 - 1), d = k % (FD_P / 2 - 1);
+			if (c0 + 2 * d < W) reinterpret_cast<uint32_t *>(y + (size_t)(r0 + rr) * W + c0)[d] = reinterpret_cast<const uint32_t *>(yt + rr * FD_P)[d];
+		}
+		__syncthreads();
+	}
 }
 
 /* pre_processing_UV (:2428-2464), pointwise on a copy: 8-neighbour Laplacian of the 256 x 256 chroma plane, one or two steps back.
