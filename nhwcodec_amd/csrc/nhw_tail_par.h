@@ -1969,6 +1969,54 @@ DEV bool thin_lower_row(int16_t *row, int rr /* row - 256 */, const int16_t *par
 	}
 	return zl0;
 }
+/* the two walks of Y20's low form as row passes on LDS tiles (a thread on "its" row of the plane read one cell of a different line at every
+ * step: 70 GB per batch) */
+struct ThinUpperF {                                             /* rows 0..255, columns 256..511 (:871-896) */
+	const int16_t *par; ThinT t;
+	struct State { int unused; };
+	__device__ State init(int) const { return State{0}; }
+	__device__ int run(int16_t *row, int r, int j, int j1, State &) const
+	{
+		for (; j < j1; j++) {
+			int16_t *v = row + j;
+			bool zl = false;
+			if (iabs(*v) >= DEADZONE && iabs(*v) < t.t3 + 2) thin_by_parent(v, v[-1], par[((r * H + (j - H)) >> 1) + H / 2], t.t4, t.t5, &zl);
+			if (zl) v[-1] = 0;
+			if (iabs(*v) >= DEADZONE && iabs(*v) < t.t3) { if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = 0; }
+		}
+		return j;
+	}
+};
+struct ThinLowerF {                                             /* rows 256..511: columns 0..255, then 256..510 (:898-967); same steps as thin_lower_row */
+	const int16_t *par; ThinT t; int q;
+	struct State { int used, zl0; };                            /* the value the row found in the cell before it, and whether it wants that cell zeroed */
+	__device__ State init(int) const { return State{ 0, 0 }; }
+	__device__ int run(int16_t *row, int rr, int j, int j1, State &st) const
+	{
+		for (; j < j1 && j < W - 1; j++) {
+			int16_t *v = row + j;
+			bool zl = false;
+			if (j < H) {
+				int lv = v[-1];
+				if (!j) st.used = lv;
+				if (iabs(*v) >= DEADZONE && iabs(*v) < t.t1 + 2) thin_by_parent(v, lv, par[((rr * H + j) >> 1) + Q / 2], t.t4, t.t5, &zl);
+				if (zl) { if (j) v[-1] = 0; else st.zl0 = 1; lv = 0; }
+				if (iabs(*v) >= DEADZONE && iabs(*v) < t.t1) {
+					if (iabs(lv) < DEADZONE && iabs(v[1]) < DEADZONE) *v = 0;
+					else if (iabs(*v) < t.t1 - 4) *v = 0;
+				}
+			} else {
+				if (iabs(*v) >= DEADZONE && iabs(*v) < t.t2 + 1) thin_by_parent(v, v[-1], par[((rr * H + (j - H)) >> 1) + Q / 2 + H / 2], t.t4 + 1, t.t5, &zl);
+				if (zl) v[-1] = 0;
+				if (iabs(*v) >= DEADZONE && iabs(*v) < t.t2) {
+					if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = keep_loud(*v, q);
+					else if (iabs(*v) < t.t2 - 5) *v = keep_loud(*v, q);
+				}
+			}
+		}
+		return j1;
+	}
+};
 DEV void thin_l1_low_par(Ctx *c, int tid, int *sh /* shared, >= 2 * NT + 2 ints */)
 {
 	int16_t *p = c->proc;
@@ -2006,18 +2054,10 @@ DEV void thin_l1_low_par(Ctx *c, int tid, int *sh /* shared, >= 2 * NT + 2 ints 
 			else { t.t1 += 3; t.t2 += 2; t.t3 += 2; t.t4 += 2; t.t5 += 2; }
 		}
 	}
-	{                                                            /* rows 0..255, columns 256..511 (:871-896): a thread per row; the cell a row reaches in the next
-		                                                            row (column 0) is read or written by no other row of this walk */
-		const int r = tid;
-		int16_t *row = p + (size_t)r * W;
-		for (int j = H; j < W; j++) {
-			int16_t *v = row + j;
-			bool zl = false;
-			if (iabs(*v) >= DEADZONE && iabs(*v) < t.t3 + 2) thin_by_parent(v, v[-1], par[((r * H + (j - H)) >> 1) + H / 2], t.t4, t.t5, &zl);
-			if (zl) v[-1] = 0;
-			if (iabs(*v) >= DEADZONE && iabs(*v) < t.t3) { if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = 0; }
-		}
-	}
+	int16_t *tiles = reinterpret_cast<int16_t *>(sh + NT);        /* (NT + 2) x TLS shorts behind the flags */
+	/* rows 0..255, columns 256..511: the cell a row reaches in the next row (column 0) is read or written by no other row of this walk; it
+	 * travels with the last tile (row_end = W + 2) */
+	row_pass_tiled(p, W, W + 2, H, 0, H, H, W, tiles, tid, ThinUpperF{ par, t });
 	BARRIER();
 	/* rows 256..511: the first cell of a row looks at (and may zero) the last cell of the row above, which that row may have zeroed in
 	 * its own last step: the only link between rows.  Every row is walked at once on the assumption that the cell above kept its value;
@@ -2031,8 +2071,10 @@ DEV void thin_l1_low_par(Ctx *c, int tid, int *sh /* shared, >= 2 * NT + 2 ints 
 		const int r = H + tid;
 		int16_t *row = p + (size_t)r * W;
 		const int above_orig = tid ? copy[(size_t)r * W - 1] : p[(size_t)r * W - 1];
-		int used = above_orig;
-		zl_flag[tid] = thin_lower_row(row, tid, par, t, q, used);
+		ThinLowerF::State st;
+		row_pass_tiled(p + (size_t)H * W, W, W, H, 0, H, 0, W, tiles, tid, ThinLowerF{ par, t, q }, &st);   /* first round: every row at once, through LDS tiles */
+		int used = st.used;
+		zl_flag[tid] = st.zl0;
 		for (;;) {
 			BARRIER();
 			const int now = tid ? p[(size_t)r * W - 1] : above_orig;       /* what the row above left in its last cell */
