@@ -2536,22 +2536,22 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
  * prefix-summed and every thread then drops its bits at its own offset (atomicOr into zeroed words; the
  * reference ORs MSB-first into 32-bit words the same way, :334-345). */
 #define PK_SLICE 64
+#define PK_SCAN(sh) ((sh)->n2 + 150)                            /* scan scratch that the book entries do not reach (they end at n2[148]) */
 #define PK_CHUNK (PK_SLICE * NT)
 struct PackShared {
-	int hist[256], runs[256];
-	unsigned weight[360];
-	uint16_t entry[600];
-	uint16_t rank_sym[256], rank_run[256];
-	uint32_t code_sym[256], code_run[256];
-	uint16_t sorted[360];                                         /* code book entries by rank */
-	unsigned bits[NT], n1[NT], n2[NT];
+	/* Two pairs of tables are never alive together and share their space (22.5 KB of LDS per workgroup instead of 30: seven packetisers to a
+	 * CU instead of five; with the ranks in the staging area and the stale code book in global memory): the histograms are done with when the code words are made from the ranks; the book entries and their weights
+	 * live between the histogram sweep and the ranking, the per-thread scan words before and after that (the scans inside that span keep
+	 * their scratch behind the part the entries cover: PK_SCAN). */
+	union { struct { int hist[256], runs[256]; }; struct { uint32_t code_sym[256], code_run[256]; }; };
+	union { struct { unsigned bits[NT], n1[NT], n2[160]; }; struct { unsigned weight[360]; uint16_t entry[600]; }; };   /* n2: scan scratch only */
+	uint16_t sorted[360];                                         /* code book entries by rank (the ranks themselves sit in the slice staging area, which is idle between the sweeps) */
 	int k, select, zone, top_is_zero, rc;
 	unsigned total_bits, total_n1, total_n2;
 	/* the reference's `codebook[580]` scratch is ONE stack array for both parts and is never cleared (compress_pixel.c:58): when the
 	 * chroma table ends in a run of 128s the collapse at :442-456 reads on into what the luma part left there (its de-interleaved
 	 * table; behind that, zeros in the canonical model) */
-	uint8_t stale_book[720];
-	int stale_len;
+	int stale_len;                                                /* the bytes themselves: c->cc (written and read by thread 0) */
 };
 
 DEV bool book_ok(int v) { return v < 109 ? !(v & 1) : (v == 112 || (v >= 120 && v < 141) || (v >= 144 && !(v & 3))); }
@@ -2704,14 +2704,14 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	for (;;) {                                                   /* L_RATIO (:128-236): short runs become plain zeros until the book fits */
 		const int select = sh->select, j = tid;
 		unsigned tot, totr, tots;
-		(void)block_exscan((j >= 2 && j < select && sh->runs[j] > 0) ? (unsigned)(j * sh->runs[j]) : 0u, tid, sh->n2, &tot);
+		(void)block_exscan((j >= 2 && j < select && sh->runs[j] > 0) ? (unsigned)(j * sh->runs[j]) : 0u, tid, PK_SCAN(sh), &tot);
 		BARRIER();
 		if (j >= 2 && j < select) sh->runs[j] = 0;
 		if (tid == 0) sh->hist[128] = (int)((sh->hist[128] > 0 ? (unsigned)sh->hist[128] : 0u) + tot);
 		BARRIER();
 		const bool fr = j >= select && sh->runs[j] > 0, fs = book_ok(j) && sh->hist[j] > 0;
-		const unsigned orr = block_exscan(fr, tid, sh->n2, &totr);
-		const unsigned os = block_exscan(fs, tid, sh->n2, &tots);
+		const unsigned orr = block_exscan(fr, tid, PK_SCAN(sh), &totr);
+		const unsigned os = block_exscan(fs, tid, PK_SCAN(sh), &tots);
 		if (fr) { sh->entry[orr] = (uint16_t)((j << 8) | 128); sh->weight[orr] = (unsigned)sh->runs[j]; }
 		if (fs && totr + os < 600) { sh->entry[totr + os] = (uint16_t)((1 << 8) | j); sh->weight[totr + os < 360 ? totr + os : 359] = (unsigned)sh->hist[j]; }
 		const int k = (int)(totr + tots);
@@ -2723,6 +2723,7 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	}
 	BARRIER();
 	if (sh->rc) return;
+	uint16_t *rank_sym = reinterpret_cast<uint16_t *>(lw), *rank_run = rank_sym + 256;
 	{                                                            /* stable descending rank == the reference's bubble sort (:238-252) */
 		const int k = sh->k;
 		for (int e = tid; e < k; e += NT) {
@@ -2730,7 +2731,7 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 			int rank = 0;
 			for (int j = 0; j < k; j++) rank += (sh->weight[j] > w) || (sh->weight[j] == w && j < e);
 			const uint16_t en = sh->entry[e];
-			if ((en >> 8) == 1) sh->rank_sym[en & 0xFF] = (uint16_t)rank; else sh->rank_run[en >> 8] = (uint16_t)rank;
+			if ((en >> 8) == 1) rank_sym[en & 0xFF] = (uint16_t)rank; else rank_run[en >> 8] = (uint16_t)rank;
 			sh->sorted[rank] = en;
 		}
 	}
@@ -2745,7 +2746,7 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	BARRIER();
 	if (sh->rc) return;
 	for (int v = 0; v < 2; v++) {                                /* rank -> code word (the 64 ranks from 110 use the short escape when the zone is on, :300-330) */
-		int pos = v ? sh->rank_run[tid] : sh->rank_sym[tid];
+		int pos = v ? rank_run[tid] : rank_sym[tid];
 		uint32_t e;
 		if (pos >= 110 && pos < 174 && sh->zone) e = (15u << 24) | (uint32_t)((1 << 6) | (pos - 110));
 		else { if (pos >= 174 && sh->zone) pos -= 64; e = k_vlc[pos < 290 ? pos : 0]; }
@@ -2803,7 +2804,7 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 			for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = book[i];
 			for (i = 1; i < e; i += 2) tmp_book[b++] = book[i];
 			tmp_book[e] = 0;
-			for (i = 0; i < e; i++) sh->stale_book[i] = tmp_book[i];
+			for (i = 0; i < e; i++) c->cc[i] = tmp_book[i];
 			sh->stale_len = e;
 			for (i = 0, w = 0, b = 0; i < e; i++) {
 				while (tmp_book[i] == 3) { b++; i++; }
@@ -2823,7 +2824,7 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 		c->m->tree_end = e;
 		for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = book[i];
 		for (i = 1; i < e; i += 2) tmp_book[b++] = book[i];
-		for (i = e; i < sh->stale_len; i++) tmp_book[i] = sh->stale_book[i];
+		for (i = e; i < sh->stale_len; i++) tmp_book[i] = c->cc[i];
 		tmp_book[e > sh->stale_len ? e : sh->stale_len] = 0;
 		for (i = 0, w = 0, b = 0; i < e; i++) {
 			while (tmp_book[i] == 128) { b++; i++; }
