@@ -617,10 +617,12 @@ DEVI int final_pair(const PfP &pp, const int16_t *km, int16_t *y, const uint8_t 
  *
  * The counters of passes B and C tie every pixel pair of an image to the one before it, so an image is a serial job of ~130 000 steps and
  * only images run side by side.  A wavefront per image leaves 63 of 64 lanes idle in those passes, and with 4096 images every SIMD holds
- * four such wavefronts whose one-lane instructions take turns.  So a wavefront takes PG = 4 images: pass A (the part that is parallel
- * along a row, all 64 lanes) runs image after image, passes B and C run the four images in lanes 0..3 -- one instruction stream, four
- * machines (their counters are plain per-lane registers) -- at the price of the lanes' divergence. */
-#define PG 4
+ * four such wavefronts whose one-lane instructions take turns.  So a wavefront takes PG images: pass A (the part that is parallel
+ * along a row, all 64 lanes) runs image after image, the serial phases run the PG images in lanes 0..PG-1 -- one instruction stream, PG
+ * machines (their counters are plain per-lane registers) -- at the price of the lanes' divergence.  Measured (front of q10, ms per
+ * 4096-image batch): PG 1: 443, PG 4: 307, PG 2: 280 -- two wavefronts per SIMD hide each other's dependent-instruction latency and two
+ * machines diverge less than four. */
+#define PG 2
 __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
                                                       int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q, int n_img, int dbg)
 {
@@ -635,8 +637,8 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 	const int nimg = n_img - img0 < PG ? n_img - img0 : PG;              /* images of this wavefront */
 	const PfP pp = pf_params(q);
 
-	int row_carry[PG];
-	for (int g = 0; g < PG; g++) row_carry[g] = 0;
+	__shared__ int row_carry[PG];                                        /* wave-uniform per image; in LDS so that the loop over the images need not be unrolled (code size) */
+	if (threadIdx.x < PG) row_carry[threadIdx.x] = 0;
 	/* per lane: the marker state of pass A, the machine of pass B and the state of pass C of image img0 + lane */
 	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	MarkState ks = { 0, 0, 0, 0, 0, 0 };
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 #pragma unroll
 		for (int g = 0; g < PG; g++) if (g < nimg) load_row(g, r + 1);
 		__syncthreads();
-#pragma unroll
+#pragma unroll 1
 		for (int g = 0; g < PG; g++) {
 		if (g >= nimg) continue;
 		const int16_t *up = s_src[g][(r - 1) % 3], *mid = s_src[g][r % 3], *dn = s_src[g][(r + 1) % 3];
