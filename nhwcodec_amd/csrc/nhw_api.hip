@@ -531,8 +531,6 @@ extern "C" int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n
 }
 
 /* ------------------------------------------------------------------------------------------------ debug hooks (tests only) */
-void nhw_debug_band_stamps(unsigned long long *out);
-extern "C" int nhw_debug_stamps(unsigned long long *out) { (void)hipDeviceSynchronize(); nhw_debug_band_stamps(out); return NHW_OK; }
 extern "C" int nhw_debug_front_fallback(nhw_enc *e, int on) { if (!e) return NHW_E_ARG; e->front_fallback = on; return NHW_OK; }
 extern "C" int nhw_debug_stop_after(nhw_enc *e, int stage) { if (!e) return NHW_E_ARG; e->stop_after = stage; return NHW_OK; }
 /* developer hook: order-independent 64-bit digest of the first `bytes` bytes of workspace buffer `buf`, one per image, into device memory */

@@ -345,9 +345,8 @@ __device__ __forceinline__ int pair_mag_class(int a)             /* a = |k| */
 	return (a > 10) + (a > 11) + (a > 15) + (a > 22) + (a > 31) + (a > 176) + (a > 201);
 }
 
-__device__ unsigned long long g_band_stamp[16];
-#ifdef NHW_DEV   /* developer builds: phase time stamps of one band in steady state, and a switch that ends every band after phase i */
-#define STAMP(i) do { if (t == 0 && blockIdx.x == 70001) g_band_stamp[i] = wall_clock64(); if ((force_fixup >> 8) == (i) && (i)) return; } while (0)
+#ifdef NHW_DEV   /* developer builds: a switch that ends every band after phase i (tests/gpu_band_ablate.py: the cost of the phases under real contention) */
+#define STAMP(i) do { if ((force_fixup >> 8) == (i) && (i)) return; } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -1066,7 +1065,6 @@ void nhw_launch_front_stale(const int16_t *y, size_t y_stride, const uint8_t *st
 	k_front_stale<<<n, 64, 0, s>>>(y, y_stride, st, s_stride, stale, stale_stride);
 }
 
-void nhw_debug_band_stamps(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(nhw::g_band_stamp), sizeof(unsigned long long) * 16); }
 
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s)
 {

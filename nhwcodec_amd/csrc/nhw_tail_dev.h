@@ -1,7 +1,7 @@
 /*
  * nhw_tail_dev.h -- what the tail kernels of the NHW encode path share (gfx950): the per-image view of the workspace (Ctx), the small
  * value predicates of the reference's coefficient heuristics, the format tables (escape codes, the prefix code), the position-list
- * packer and the two q >= 22 passes that still run on one lane (band_recons, hq_settings).
+ * packer.
  *
  * The passes themselves -- everything between the filterbank calls of encode_image (rcanut/nhwcodec encoder/nhw_encoder.c:103-2878,
  * encoder/image_processing.c:108-521, 2600-3353, encoder/compress_pixel.c:53-1022) -- are in nhw_tail_par.h (a 256-thread workgroup
@@ -242,82 +242,6 @@ DEV int big_index(int code)
 	int k;
 	for (k = 0; k < 19; k++) { if (code == pos[k]) return k + 1; if (code == neg[k]) return -(k + 1); }
 	return 0;
-}
-DEV void band_recons(Ctx *c)
-{
-	const int16_t *p = c->proc;
-	int16_t *b = c->band;
-	int r, j, t = 0;
-	memset(b, 0, sizeof(int16_t) * Q);
-	for (r = 0; r < H; r++)
-		for (j = 0; j < H; j++) {
-			const int a = p[r * W + H + j];
-			if (a == 128) { t++; continue; }
-			else if (a == 127) { b[t - 1] = 5; b[t] = 6; b[t + 1] = 5; t += 2; j++; }
-			else if (a == 129) { b[t - 1] = -5; b[t] = -7; b[t + 1] = -5; t += 2; j++; }
-			else if ((a & 7) != 0) {
-				/* extra_table is indexed 0..108; other odd codes (121..126 ...) read past it in the
-				 * reference; those codes do not occur in this band at q>=22 */
-				const int k = (a >= 0 && a < 109) ? big_index(a) : 0;
-				b[t++] = (int16_t)(k > 0 ? 123 + (k << 3) : (k << 3) - 123);
-			}
-			else b[t++] = (int16_t)(a > 128 ? a - 125 : a - 131);
-		}
-}
-
-/* half synthesis of the kept first-order LL + quantised LH vs the original pass-1 plane: res6,
- * char_res1, qsetting3 (wavelet_filterbank.c:498-707) */
-DEV void hq_settings(Ctx *c)
-{
-	const int q = c->q;
-	int16_t *hs = c->hs;
-	uint8_t *raw = c->raw;
-	uint8_t *pay = c->pay;
-	const int thr = q > 22 ? 30 : 34;
-	int i, r, j, n = 0, e = 0, nq = 0, nc = 0;
-	for (r = 0; r < H; r++) {                                  /* upfilter53I + upfilter53III, :509-513 */
-		const int16_t *lo = c->first_order + r * H, *hi = c->band + r * H;
-		int16_t *out = hs + r * W;
-		int k;
-		for (k = 0; k < H; k++) {
-			const int ln = k + 1 < H ? lo[k + 1] : lo[k];
-			const int hp = k > 0 ? hi[k - 1] : hi[0], hn = k + 1 < H ? hi[k + 1] : hi[k];
-			out[2 * k] = (int16_t)((int16_t)(lo[k] << 3) - ((hi[k] + hp) << 1));
-			out[2 * k + 1] = (int16_t)((int16_t)((lo[k] + ln) << 2) + (6 * hi[k] - hp - hn));
-		}
-	}
-	for (i = 0; i < 2 * Q; i++) {                              /* :518-541 */
-		const int d = c->keep[i] - hs[i];
-		if (iabs(d) > thr) {
-			if (q > 22 && iabs(d) > 56) hs[i] = (int16_t)(d > 0 ? 32000 : 32500);
-			else hs[i] = (int16_t)(d > 0 ? 30000 : 31000);
-		}
-	}
-	if (q > 22) {                                              /* :547-564 */
-		for (i = 0; i < 2 * Q; i++) {
-			if (hs[i] == 32000) c->qsetting3[nq++] = (uint32_t)(i << 1);
-			else if (hs[i] == 32500) c->qsetting3[nq++] = (uint32_t)(i << 1) + 1;
-		}
-	}
-	c->m->qsetting3_len = nq;
-	for (r = 0; r < H; r++)                                    /* :571-610 */
-		for (j = 0; j < W; j++) {
-			const int at = r * W + j;
-			if (j == H - 2 || j == W - 2) {
-				raw[n++] = H - 2;
-				if (j == H - 2) {
-					if (hs[at] == 30000) c->char_res1[nc++] = (uint16_t)(r * H);
-					else if (hs[at] == 31000) c->char_res1[nc++] = (uint16_t)(r * H + 1);
-					if (hs[at + 1] == 30000) c->char_res1[nc++] = (uint16_t)(r * H + 2);
-					else if (hs[at + 1] == 31000) c->char_res1[nc++] = (uint16_t)(r * H + 3);
-				}
-				j++;
-			}
-			else if (hs[at] == 30000) { raw[n++] = (uint8_t)(j & 255); pay[e++] = 0; }
-			else if (hs[at] == 31000) { raw[n++] = (uint8_t)(j & 255); pay[e++] = 1; }
-		}
-	c->m->char_res1_len = nc;
-	poslist_finish(c, &c->res6, raw, n, pay, e, 1);
 }
 
 } // namespace nhw
