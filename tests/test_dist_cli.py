@@ -271,3 +271,41 @@ def test_cli_tiles_encode_and_join(cli, dec_cli, oracle, tmp_path):
     d = na.Decoder(0, 6)
     assert np.array_equal(d.decode_tiled(got, 2, 3), want)
     e.close(); d.close()
+
+
+# ---------------------------------------------------------------- a tar archive as the batch container
+def test_cli_tar_missing_archive_fails_before_any_gpu_work(cli, dec_cli, tmp_path):
+    rc, out, _ = _run(cli, "--tar", str(tmp_path / "none.tar"), str(tmp_path / "o.tar"))
+    assert rc == 255 and "Could not open file" in out
+    assert _run(dec_cli, "--tar", str(tmp_path / "none.tar"), str(tmp_path / "o.tar"))[0] == 1
+
+
+@pytest.mark.gpu
+def test_cli_tar_round_trip(cli, dec_cli, oracle, tmp_path):
+    """nhw-enc --tar: the .bmp members of a ustar archive (others are passed over, a broken one is reported and left out) come back as .nhw
+    members that equal the oracle's files, in order; nhw-dec --tar turns them into the BMPs the oracle's decoder gives."""
+    import io, tarfile
+    from oracle.harness import bmp_bytes
+    imgs = {f"dir/img{s}.bmp": oracle.synth(900 + s) for s in range(5)}
+    src = tmp_path / "in.tar"
+    with tarfile.open(src, "w", format=tarfile.USTAR_FORMAT) as tf:
+        def add(name, data):
+            ti = tarfile.TarInfo(name); ti.size = len(data); tf.addfile(ti, io.BytesIO(data))
+        add("readme.txt", b"not an image\n" * 50)
+        for name, im in imgs.items():
+            add(name, bmp_bytes(im))
+        add("broken.bmp", b"BM" + bytes(100))
+    rc, out, err = _run(cli, "-q21", "--tar", str(src), str(tmp_path / "out.tar"))
+    assert rc == 1 and "5 image(s) encoded" in out and "broken.bmp" in err          # the broken member makes the exit code 1, the others are there
+    with tarfile.open(tmp_path / "out.tar") as tf:
+        members = tf.getmembers()
+        assert [m.name for m in members] == [n[:-4] + ".nhw" for n in imgs]
+        files = [tf.extractfile(m).read() for m in members]
+    for f, im in zip(files, imgs.values()):
+        assert f == oracle.encode(im, 21)
+    assert _run(dec_cli, "--tar", str(tmp_path / "out.tar"), str(tmp_path / "back.tar"))[0] == 0
+    with tarfile.open(tmp_path / "back.tar") as tf:
+        members = tf.getmembers()
+        assert [m.name for m in members] == list(imgs)
+        for m, f in zip(members, files):
+            assert tf.extractfile(m).read() == oracle.bmp_header() + oracle.decode(f)[0].tobytes()

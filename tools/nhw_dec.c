@@ -27,7 +27,8 @@ static void show_usage(void)
 	"\n"
 	"  example: nhw-dec image.nhw image.bmp\n"
 	"  batch:   nhw-dec --batch <directory of .nhw files>\n"
-	"  tiles:   nhw-dec --tiles <rows> <columns> <stem> <image.bmp>   (joins <stem>_y<r>_x<c>.nhw, as written by nhw-enc --tiles)\n",
+	"  tiles:   nhw-dec --tiles <rows> <columns> <stem> <image.bmp>   (joins <stem>_y<r>_x<c>.nhw, as written by nhw-enc --tiles)\n"
+	"  tar:     nhw-dec --tar <in.tar> <out.tar>   (every x.nhw member of a ustar archive -> member x.bmp, in order)\n",
 	PROGRAM);
 }
 
@@ -133,9 +134,88 @@ static int decode_tiles(int ny, int nx, const char *stem, const char *out_path)
 	return 0;
 }
 
+/* --tar: the inverse of nhw-enc --tar; members are decoded in batches of up to 1024 */
+static unsigned long tar_octal(const uint8_t *p, int n) { unsigned long v = 0; int i; for (i = 0; i < n && p[i] >= '0' && p[i] <= '7'; i++) v = v * 8 + (unsigned long)(p[i] - '0'); return v; }
+static int tar_write_member(FILE *f, const char *name, const uint8_t *head, size_t head_len, const uint8_t *data, size_t len)
+{
+	uint8_t h[512];
+	unsigned sum = 0;
+	const size_t total = head_len + len, pad = (512 - total % 512) % 512;
+	size_t i;
+	static const uint8_t zeros[512];
+	memset(h, 0, sizeof h);
+	if (strlen(name) > 99) return -1;
+	strcpy((char *)h, name);
+	memcpy(h + 100, "0000644", 8); memcpy(h + 108, "0000000", 8); memcpy(h + 116, "0000000", 8);
+	snprintf((char *)h + 124, 12, "%011lo", (unsigned long)total);
+	memcpy(h + 136, "00000000000", 12);
+	memset(h + 148, ' ', 8);
+	h[156] = '0';
+	memcpy(h + 257, "ustar", 6); memcpy(h + 263, "00", 2);
+	for (i = 0; i < 512; i++) sum += h[i];
+	snprintf((char *)h + 148, 8, "%06o", sum); h[155] = ' ';
+	return (fwrite(h, 1, 512, f) == 512 && fwrite(head, 1, head_len, f) == head_len && fwrite(data, 1, len, f) == len && fwrite(zeros, 1, pad, f) == pad) ? 0 : -1;
+}
+static int decode_tar(const char *in_path, const char *out_path)
+{
+	enum { CH = 1024 };
+	FILE *in = fopen(in_path, "rb"), *out;
+	nhw_dec *d = NULL;
+	uint8_t hdr[512], bmp[54], *blob = NULL, *pix;
+	size_t blob_cap = 0, total_bytes = 0;
+	uint64_t *off = (uint64_t *)calloc(CH + 1, sizeof *off);
+	int32_t *status = (int32_t *)calloc(CH, sizeof *status);
+	char (*names)[104] = (char (*)[104])malloc((size_t)CH * 104);
+	int n = 0, total = 0, bad = 0, eof = 0, i;
+	static const uint8_t zeros[1024];
+	if (!in) { printf("\nCould not open file\n"); return 1; }
+	out = fopen(out_path, "wb");
+	if (!out) { printf("Failed to open output decompressed .bmp file %s\n", out_path); return 1; }
+	pix = (uint8_t *)malloc((size_t)CH * NHW_IMG_BYTES);
+	nhw_dec_bmp_header(bmp);
+	while (!eof) {
+		if (fread(hdr, 1, 512, in) != 512 || hdr[0] == 0) eof = 1;
+		else {
+			const unsigned long size = tar_octal(hdr + 124, 12);
+			size_t nl;
+			hdr[99] = 0;
+			nl = strlen((const char *)hdr);
+			if ((hdr[156] == '0' || hdr[156] == 0) && nl > 4 && !strcmp((const char *)hdr + nl - 4, ".nhw")) {
+				if (total_bytes + size + 16 > blob_cap) { blob_cap = (total_bytes + size + 16) * 2; blob = (uint8_t *)realloc(blob, blob_cap); }
+				if (fread(blob + total_bytes, 1, size, in) != size) { fprintf(stderr, "%s: %s: archive ends inside member %s\n", PROGRAM, in_path, (const char *)hdr); bad++; eof = 1; }
+				else { off[n] = total_bytes; total_bytes += size; snprintf(names[n], 104, "%.*s.bmp", (int)(nl - 4), (const char *)hdr); n++; }
+				if (size % 512) fseek(in, (long)(512 - size % 512), SEEK_CUR);
+			}
+			else fseek(in, (long)((size + 511) / 512 * 512), SEEK_CUR);
+		}
+		if (n == CH || (eof && n > 0)) {
+			off[n] = total_bytes;
+			if ((!d && nhw_dec_create(0, CH, &d)) || nhw_dec_batch(d, blob, off, n, pix, status, NULL)) {
+				fprintf(stderr, "%s: GPU decoder unavailable: %s\n", PROGRAM, nhw_dec_last_error());
+				return 2;
+			}
+			for (i = 0; i < n; i++) {
+				if (status[i]) { printf("\nNot an .nhw file: %s\n", names[i]); bad++; continue; }
+				if (tar_write_member(out, names[i], bmp, 54, pix + (size_t)i * NHW_IMG_BYTES, NHW_IMG_BYTES)) { bad++; break; }
+			}
+			total += n; n = 0; total_bytes = 0;
+		}
+	}
+	fwrite(zeros, 1, 1024, out);
+	fclose(out); fclose(in);
+	if (d) nhw_dec_destroy(d);
+	printf("%d file(s) decoded\n", total);
+	free(blob); free(pix); free(off); free(status); free(names);
+	return bad ? 3 : 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc < 3) { show_usage(); return 0; }
+	if (!strcmp(argv[1], "--tar")) {
+		if (argc < 4) { show_usage(); return 1; }
+		return decode_tar(argv[2], argv[3]);
+	}
 	if (!strcmp(argv[1], "--tiles")) {
 		int ny, nx;
 		if (argc < 6 || (ny = atoi(argv[2])) < 1 || (nx = atoi(argv[3])) < 1 || ny * nx > 65535) { show_usage(); return 1; }

@@ -47,8 +47,9 @@ static void usage(void)
 	        "  -V        show version and legal information\n\n"
 	        "  example: nhw-enc -q15 image.bmp image.nhw\n"
 	        "Batch (MI355X build): %s [-q#] [--gpus g] --batch <dir> | --synthetic <n> [--seed s] --outdir <dir>\n"
-	        "Tiles (MI355X build): %s [-q#] --tiles <big.bmp> <stem>   (width, height multiples of 512: one <stem>_y<r>_x<c>.nhw per 512x512 tile)\n",
-	        PROGRAM, PROGRAM, PROGRAM);
+	        "Tiles (MI355X build): %s [-q#] --tiles <big.bmp> <stem>   (width, height multiples of 512: one <stem>_y<r>_x<c>.nhw per 512x512 tile)\n"
+	        "Tar   (MI355X build): %s [-q#] --tar <in.tar> <out.tar>    (every x.bmp member of a ustar archive -> member x.nhw, in order)\n",
+	        PROGRAM, PROGRAM, PROGRAM, PROGRAM);
 }
 
 static void version(void)
@@ -233,12 +234,120 @@ static void *worker_main(void *arg)
 	return NULL;
 }
 
+/* --tar: a POSIX ustar archive as the batch container.  Members are read in order; every regular member whose name ends in
+ * .bmp goes through the same header checks as a file on its own (a member that fails them is reported and left out), the images are
+ * encoded in chunks of CHUNK, and the .nhw files leave as members of the output archive under the same names with the suffix changed. */
+static unsigned long tar_octal(const uint8_t *p, int n) { unsigned long v = 0; int i; for (i = 0; i < n && p[i] >= '0' && p[i] <= '7'; i++) v = v * 8 + (unsigned long)(p[i] - '0'); return v; }
+static int tar_write_member(FILE *f, const char *name, const uint8_t *data, size_t len)
+{
+	uint8_t h[512];
+	unsigned sum = 0;
+	size_t i, pad = (512 - len % 512) % 512;
+	static const uint8_t zeros[512];
+	memset(h, 0, sizeof h);
+	if (strlen(name) > 99) { fprintf(stderr, "%s: member name too long for the archive: %s\n", PROGRAM, name); return -1; }
+	strcpy((char *)h, name);
+	memcpy(h + 100, "0000644", 8); memcpy(h + 108, "0000000", 8); memcpy(h + 116, "0000000", 8);
+	snprintf((char *)h + 124, 12, "%011lo", (unsigned long)len);
+	memcpy(h + 136, "00000000000", 12);
+	memset(h + 148, ' ', 8);
+	h[156] = '0';
+	memcpy(h + 257, "ustar", 6); memcpy(h + 263, "00", 2);
+	for (i = 0; i < 512; i++) sum += h[i];
+	snprintf((char *)h + 148, 8, "%06o", sum); h[155] = ' ';
+	if (fwrite(h, 1, 512, f) != 512 || fwrite(data, 1, len, f) != len || fwrite(zeros, 1, pad, f) != pad) return -1;
+	return 0;
+}
+/* a BMP held in memory -> dst[786432], the same acceptance rules as check_header + load_bmp; returns HDR_OK or the reference's code */
+static int bmp_from_memory(const uint8_t *b, size_t len, uint8_t *dst)
+{
+	int bih, width, height, planes, bpp, compr, r;
+	long off;
+	if (len < 34) return HDR_NO_DATA;
+	if (b[0] != 'B' || b[1] != 'M') return HDR_NO_SIG;
+	off = (long)(int)le32(b + 10);
+	bih = (int)le32(b + 14);
+	if (bih != 12 && bih != 40 && bih != 52 && bih != 56 && bih != 108 && bih != 124) return HDR_BIH;
+	if (bih == 12) { width = le16(b + 18); height = le16(b + 20); planes = (short)le16(b + 22); bpp = (short)le16(b + 24); compr = 0; }
+	else { width = (int)le32(b + 18); height = (int)le32(b + 22); planes = (short)le16(b + 26); bpp = (short)le16(b + 28); compr = (int)le32(b + 30); }
+	if (planes != 1) return HDR_PLANES;
+	if (width != 512 || (height != 512 && height != -512) || bpp != 24 || compr != 0) return HDR_FORMAT;
+	memset(dst, 0, NHW_IMG_BYTES);
+	if (off >= 0 && (size_t)off < len) memcpy(dst, b + off, len - (size_t)off < NHW_IMG_BYTES ? len - (size_t)off : NHW_IMG_BYTES);   /* short data: the tail stays zero */
+	if (height < 0)
+		for (r = 0; r < 256; r++) {
+			uint8_t tmp[1536];
+			memcpy(tmp, dst + (size_t)r * 1536, 1536);
+			memcpy(dst + (size_t)r * 1536, dst + (size_t)(511 - r) * 1536, 1536);
+			memcpy(dst + (size_t)(511 - r) * 1536, tmp, 1536);
+		}
+	return HDR_OK;
+}
+static int encode_tar(const char *in_path, const char *out_path, int quality, int stock_compat)
+{
+	FILE *in = fopen(in_path, "rb"), *out;
+	nhw_enc *enc = NULL;
+	uint8_t hdr[512], *imgs, *arena, *member = NULL;
+	size_t member_cap = 0;
+	uint64_t *off = (uint64_t *)malloc(sizeof(uint64_t) * (CHUNK + 1));
+	int32_t *st = (int32_t *)malloc(sizeof(int32_t) * CHUNK);
+	char (*names)[104] = (char (*)[104])malloc((size_t)CHUNK * 104);
+	int n = 0, total = 0, bad = 0, rc, i, eof = 0;
+	static const uint8_t zeros[1024];
+	if (!in) { printf("menu(): Could not open file: %s\n", in_path); exit(-1); }
+	out = fopen(out_path, "wb");
+	if (!out) { printf("Failed to create file: %s\n", out_path); return 1; }
+	imgs = (uint8_t *)malloc((size_t)CHUNK * NHW_IMG_BYTES);
+	arena = (uint8_t *)malloc((size_t)CHUNK * NHW_OUT_STRIDE);
+	while (!eof) {
+		unsigned long size = 0;
+		int is_bmp = 0;
+		if (fread(hdr, 1, 512, in) != 512 || hdr[0] == 0) eof = 1;          /* end of archive: a zero block (or the file's end) */
+		else {
+			size_t nl;
+			size = tar_octal(hdr + 124, 12);
+			hdr[99] = 0;
+			nl = strlen((const char *)hdr);
+			is_bmp = (hdr[156] == '0' || hdr[156] == 0) && nl > 4 && !strcmp((const char *)hdr + nl - 4, ".bmp");
+			if (is_bmp) {
+				if (size + 1 > member_cap) { member_cap = size + 1; member = (uint8_t *)realloc(member, member_cap); }
+				if (fread(member, 1, size, in) != size) { fprintf(stderr, "%s: %s: archive ends inside member %s\n", PROGRAM, in_path, (const char *)hdr); bad++; eof = 1; is_bmp = 0; }
+				else {
+					const int hc = bmp_from_memory(member, size, imgs + (size_t)n * NHW_IMG_BYTES);
+					if (hc != HDR_OK) { fprintf(stderr, "%s: %s: invalid image file (%d), left out\n", PROGRAM, (const char *)hdr, hc); bad++; }
+					else { snprintf(names[n], 104, "%.*s.nhw", (int)(nl - 4), (const char *)hdr); n++; }
+				}
+				if (size % 512) fseek(in, (long)(512 - size % 512), SEEK_CUR);
+			}
+			else fseek(in, (long)((size + 511) / 512 * 512), SEEK_CUR);
+		}
+		if (n == CHUNK || (eof && n > 0)) {
+			if (!enc) {
+				if ((rc = nhw_enc_create(0, CHUNK, &enc))) die_lib("nhw_enc_create", rc);
+				if (stock_compat) nhw_enc_set_compat(enc, NHW_COMPAT_GLIBC_ONESHOT);
+			}
+			if ((rc = nhw_enc_batch(enc, imgs, n, quality, arena, (size_t)CHUNK * NHW_OUT_STRIDE, off, st))) die_lib("nhw_enc_batch", rc);
+			for (i = 0; i < n; i++) {
+				if (st[i]) { fprintf(stderr, "%s: %s: encoder status %d (code book overflow)\n", PROGRAM, names[i], st[i]); bad++; continue; }
+				if (tar_write_member(out, names[i], arena + off[i], (size_t)(off[i + 1] - off[i]))) { bad++; break; }
+			}
+			total += n; n = 0;
+		}
+	}
+	fwrite(zeros, 1, 1024, out);
+	fclose(out); fclose(in);
+	if (enc) nhw_enc_destroy(enc);
+	printf("%d image(s) encoded\n", total);
+	free(member); free(names); free(st); free(off); free(arena); free(imgs);
+	return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
 	int quality = QUALITY_DEFAULT, overwrite = 0, synthetic = 0, gpus = 1, i;
 	uint32_t seed = 0;
 	const char *batch_dir = NULL, *outdir = NULL;
-	int tiles = 0;
+	int tiles = 0, tar = 0;
 	int stock_compat = 0;   /* --stock-compat: NHW_COMPAT_GLIBC_ONESHOT, the stock binary's out-of-bounds reads (include/nhw_hip.h) */
 	nhw_enc *enc = NULL;
 	int rc;
@@ -251,6 +360,7 @@ int main(int argc, char **argv)
 		if (!strcmp(argv[1], "--gpus") && argc > 2) { gpus = atoi(argv[2]); argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--stock-compat")) { stock_compat = 1; argc -= 1; argv += 1; continue; }
 		if (!strcmp(argv[1], "--tiles")) { tiles = 1; argc -= 1; argv += 1; continue; }
+		if (!strcmp(argv[1], "--tar")) { tar = 1; argc -= 1; argv += 1; continue; }
 		for (i = 1; argv[1][i] != '\0'; i++) {
 			const char ch = argv[1][i];
 			if (ch >= '0' && ch <= '9') continue;
@@ -313,6 +423,7 @@ int main(int argc, char **argv)
 	}
 
 	if (argc < 3) { printf("Not enough arguments. Check help.\n"); usage(); return 0; }
+	if (tar) return encode_tar(argv[1], argv[2], quality, stock_compat);
 	if (tiles) {
 		int ny = 0, nx = 0, n, bad, t;
 		uint8_t *imgs = load_bmp_tiles(argv[1], &ny, &nx);
