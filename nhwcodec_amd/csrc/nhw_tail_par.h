@@ -2460,13 +2460,17 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 	copy_block_par(c->cl2save, H / 2, p, H, H / 2, H / 2, tid);    /* :2431-2439 */
 	for (int idx = tid; idx < (H / 4) * (H / 4); idx += NT) lds[idx] = c->cl2save[(idx >> 6) * (H / 2) + (idx & 63)];   /* the LL2 band for the emission below */
 	BARRIER();
-	if (q <= 11 && tid == 0) {
-		/* chroma LL2 smoothing (:2438-2478, :2739-2779): two raster walks that write the cell diagonally below and read it again; 64 x 64
-		 * cells.  Only the emission reads the band afterwards (it clears it), so the walks run on the LDS copy. */
-		const int L = H / 4;
+	if (q <= 11 && tid < 64) {
+		/* chroma LL2 smoothing (:2438-2478, :2739-2779): two raster walks over 62 x 62 cells; a cell reads rows r .. r+2 at columns j .. j+2 and
+		 * may rewrite (r+1, j+1), which only the next cell of its row and the rows below read.  One wavefront runs the rows skewed by two
+		 * columns (lane l on row l, at column t - 2 l in step t: its upper neighbour is two columns ahead, and it reads (r+2, j+1) two steps
+		 * before the row below rewrites it) -- 184 steps a walk instead of 3844 cells one after the other on one thread.  Only the emission
+		 * reads the band afterwards (it clears it), so the walks run on the LDS copy. */
+		const int L = H / 4, lane = tid;
 		for (int pass = 0; pass < 2; pass++)
-			for (int r = 0; r < L - 2; r++)
-				for (int j = 0; j < L - 2; j++) {
+			for (int t = 0; t < (L - 2) + 2 * (L - 3); t++) {
+				const int r = lane, j = t - 2 * lane;
+				if (r < L - 2 && j >= 0 && j < L - 2) {
 					int16_t *v = lds + r * L + j;
 					if (!pass) {
 						if (iabs(v[1] - v[2 * L + 1]) < 5 && iabs(v[L] - v[L + 2]) < 5 && iabs(v[L + 1] - v[L]) < 7 && iabs(v[1] - v[L + 1]) < 8)
@@ -2477,6 +2481,7 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 							v[L + 1] = (int16_t)((v[1] + v[2 * L + 1] + v[L] + v[L + 2] + 1) >> 2);
 					}
 				}
+			}
 	}
 	BARRIER();
 	if (!tid) PROF(c, 28);
