@@ -216,7 +216,8 @@ __device__ __forceinline__ int diffuse(int r)
  * depth-1 recurrence on the raw taps, so nothing is carried between bands).  Rows are padded to 514 shorts:
  * a lane that walks a row serially hits bank (row + k) mod 64.
  * ------------------------------------------------------------------------------------------------ */
-#define FB_KB 16                    /* output rows per band (8 gives three bands per CU but a third more halo work: measured equal) */
+#define FB_KB 16                    /* output rows per band.  Measured, ms per 4096-image batch at q20: 8 rows (three bands per CU, a third more halo work): equal; 32 rows with 1024 threads (one band per CU, 11 % halo work instead of 22 %): 5.55 against 5.10 -- sixteen wavefronts wait longer at the barriers than the halo rows cost */
+#define FB_VK 16                    /* of them per thread in the vertical pass */
 #define FB_TROWS (2 * FB_KB + 5)    /* horizontal-pass rows a band needs: 2k0-4 .. 2k0+32 */
 #define FB_YROWS (FB_TROWS + 2)
 #define FB_RS 514                   /* padded LDS row stride (shorts) */
@@ -645,24 +646,24 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 			*reinterpret_cast<uint4 *>(keep + (size_t)kx * W + 2 * k0 + 8 * part) = make_uint4(v[0], v[1], v[2], v[3]);
 		}
 	}
-	/* vertical pass: column c = t, outputs ky = k0 .. k0+15.  Columns below 256 (the low band of pass 1) and the others take different
-	 * rounding rules; a wavefront lies wholly on one side, so the side is a compile-time constant of two instances of the body and the
-	 * choice a scalar branch. */
-	static_assert(FB_NT == W, "one column per thread");
+	/* vertical pass: a thread takes column c and FB_VK of the band's output rows (FB_NT = 512 x FB_KB / FB_VK threads).  Columns below 256 (the
+	 * low band of pass 1) and the others take different rounding rules; a wavefront lies wholly on one side, so the side is a
+	 * compile-time constant of two instances of the body and the choice a scalar branch. */
+	static_assert(FB_NT == W * (FB_KB / FB_VK), "a column and FB_VK output rows per thread");
 	auto vertical = [&](auto side) {
 		constexpr bool LEFT = decltype(side)::value;
-		const int c = t;
-		int16_t col[FB_TROWS];                                     /* col[i] = pass-1 row t0+i, symmetric extension x[-j]=x[j], x[511+j]=x[511-j] */
+		const int c = t % W, kb = FB_VK * (t / W);                  /* output rows k0 + kb .. k0 + kb + FB_VK - 1 */
+		int16_t col[2 * FB_VK + 5];                                /* col[i] = pass-1 row t0 + 2 kb + i, symmetric extension x[-j]=x[j], x[511+j]=x[511-j] */
 #pragma unroll
-		for (int rt = 0; rt < FB_TROWS; rt++) {
-			int row = t0 + rt;
+		for (int rt = 0; rt < 2 * FB_VK + 5; rt++) {
+			int row = t0 + 2 * kb + rt;
 			row = row < 0 ? -row : (row > W - 1 ? 2 * (W - 1) - row : row);
 			col[rt] = kbuf[(row - t0) * FB_RS + c];
 		}
-		uint32_t lo[FB_KB / 2], hi[FB_KB / 2];
+		uint32_t lo[FB_VK / 2], hi[FB_VK / 2];
 #pragma unroll
-		for (int kk = 0; kk < FB_KB; kk++) {
-			const int ky = k0 + kk;
+		for (int kk = 0; kk < FB_VK; kk++) {
+			const int ky = k0 + kb + kk;
 #define XS(d) ((int)col[2 * kk + 4 + (d)])                         /* x[2ky + d], -4 <= d <= 2 */
 			const int r = 6 * XS(0) + 2 * (XS(-1) + XS(1)) - (XS(-2) + XS(2));
 			int l, h;
@@ -683,16 +684,16 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 		}
 		int16_t *orow = proc + (size_t)c * W;
 #pragma unroll
-		for (int i = 0; i < FB_KB / 8; i++) {
-			reinterpret_cast<uint4 *>(orow + k0)[i] = make_uint4(lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]);
-			reinterpret_cast<uint4 *>(orow + H + k0)[i] = make_uint4(hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]);
+		for (int i = 0; i < FB_VK / 8; i++) {
+			reinterpret_cast<uint4 *>(orow + k0 + kb)[i] = make_uint4(lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]);
+			reinterpret_cast<uint4 *>(orow + H + k0 + kb)[i] = make_uint4(hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]);
 		}
 		if (LEFT) {                                                /* LL, natural orientation, through LDS for coalesced rows */
 #pragma unroll
-			for (int kk = 0; kk < FB_KB; kk++) ybuf[kk * FB_RS + c] = (int16_t)((kk & 1) ? (lo[kk >> 1] >> 16) : (lo[kk >> 1] & 0xFFFF));
+			for (int kk = 0; kk < FB_VK; kk++) ybuf[(kb + kk) * FB_RS + c] = (int16_t)((kk & 1) ? (lo[kk >> 1] >> 16) : (lo[kk >> 1] & 0xFFFF));
 		}
 	};
-	if (__builtin_amdgcn_readfirstlane(t) < H) vertical(std::true_type{}); else vertical(std::false_type{});
+	if (__builtin_amdgcn_readfirstlane(t % W) < H) vertical(std::true_type{}); else vertical(std::false_type{});
 	__syncthreads();
 	STAMP(6);
 	for (int k = t; k < FB_KB * (H / 2); k += FB_NT) {               /* jpeg[ky][kx] and ll1[ky][kx], kx < 256 (wavelet_filterbank.c:172-184, nhw_encoder.c:127-135) */
