@@ -493,3 +493,17 @@ def test_tail_stages_match_the_oracle_trace(oracle, q):
     got = e.encode(imgs, q)
     assert [g == t[0] for g, t in zip(got, traces)] == [True] * len(seeds)
     e.close()
+
+
+@pytest.mark.gpu
+def test_synthetic_entry_point_and_device_count(oracle):
+    """nhw_enc_synth_batch (what `nhw-enc --synthetic` calls): generator seeds in, the oracle's files for those seeds out; nhw_device_count
+    sees the GPU the suite runs on."""
+    import nhwcodec_amd
+    e = nhwcodec_amd.Encoder(0, max_batch=8)
+    assert e.lib.nhw_device_count() >= 1
+    got = e.encode_synthetic(5, 4242, 19)
+    assert got == [oracle.encode(oracle.synth(4242 + i), 19) for i in range(5)]
+    with pytest.raises(nhwcodec_amd.NhwError):
+        e.encode_synthetic(2, 0, 24)
+    e.close()
