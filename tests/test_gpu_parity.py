@@ -507,3 +507,18 @@ def test_synthetic_entry_point_and_device_count(oracle):
     with pytest.raises(nhwcodec_amd.NhwError):
         e.encode_synthetic(2, 0, 24)
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [1, 10, 13, 20, 23])
+def test_odd_batch_sizes(oracle, q):
+    """Batches that do not fill the kernels' image groups (four images per workgroup in the wave kernels, two per wavefront in the q <= 16
+    pre-filter, bands of an image spread over the XCDs): 1, 2, 3, 5 and 7 images in a workspace made for 7."""
+    import nhwcodec_amd
+    e = nhwcodec_amd.Encoder(0, max_batch=7)
+    imgs = np.stack([oracle.synth(3100 + i) for i in range(7)])
+    want = [oracle.encode(im, q) for im in imgs]
+    for n in (1, 2, 3, 5, 7):
+        assert e.encode(imgs[:n], q) == want[:n], f"q{q} n={n}"
+    assert e.encode(imgs[4:7], q) == want[4:7]
+    e.close()
