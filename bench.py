@@ -342,7 +342,10 @@ def main():
             sok = int((out[2] == 0).sum().item())
             sweep.append({"quality": sq, "steps": k, "warmup": 1, "ms_per_step": round(sdt / k * 1e3, 3), "value": round(batch * k * MPIX_PER_IMAGE / sdt, 2), "unit": "Mpixels/s",
                           "images_ok": sok, "bytes_out": int(out[1].to(torch.int64).sum().item()),
-                          "stage_ms": {"front": round(stim.front_ms, 3), "luma_tail": round(stim.luma_ms, 3), "entropy+container": round(stim.entropy_ms, 3)}})
+                          "stage_ms": {"front": round(stim.front_ms, 3), "luma_tail": round(stim.luma_ms, 3), "entropy+container": round(stim.entropy_ms, 3)},
+                          # the same roofline figure as the headline's, for this quality's front launch group (q >= 22: no pre-filter in the fused kernel;
+                          # q <= 16: colour kernel + the serial pre-filter + the band kernel)
+                          "front_roofline_frac": round((stim.front_images or batch) * FRONT_BYTES_PER_IMAGE / (stim.front_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)})
         enc.encode_device(bgr, q, out)      # leave the headline quality's files in the arena for the decode leg
         torch.cuda.synchronize()
         sizes, status = out[1], out[2]
