@@ -68,19 +68,23 @@ __device__ __forceinline__ void convert_uv(const uint8_t *px, float yq, int &U, 
 		V = clip_u8((((112 * b0 - 94 * b1 - 18 * b2) * qz + 4194304) >> 23) + 128);
 		return;
 	}
-	if (FAMILY == 0) {
+	const int su = -1687 * b0 - 3313 * b1 + 5000 * b2, sv = 5000 * b0 - 4187 * b1 - 813 * b2;
+	if (FAMILY == 0 || FAMILY == 1) {                              /* q 18/19 scale the luma only: the chroma is that of q >= 20 */
 		/* the biased sums are 9000 .. 2560000 (22 bits): x / 10000 = (x * 13743896) >> 37 exactly over that range, and both factors fit the
 		 * full-rate 24-bit multiplier (a 32-bit v_mul_hi runs at a quarter of the rate); the quotient is 0 .. 256, so one min() clips it */
-		const int su = -1687 * b0 - 3313 * b1 + 5000 * b2, sv = 5000 * b0 - 4187 * b1 - 813 * b2;
 		U = (int)min(mulhi_u24((unsigned)(su + (su >= 0 ? 1285000 : 1284000)), 13743896u) >> 5, 255u);
 		V = (int)min(mulhi_u24((unsigned)(sv + (sv >= 0 ? 1285000 : 1284000)), 13743896u) >> 5, 255u);
 		return;
 	}
-	double lu = -0.1687 * b0 - 0.3313 * b1 + 0.5 * b2;
-	double lv = 0.5 * b0 - 0.4187 * b1 - 0.0813 * b2;
-	if (FAMILY == 2) { lu = lu * 0.94; lv = lv * 0.94; }
-	U = clip_u8(chroma_round((float)lu));
-	V = clip_u8(chroma_round((float)lv));
+	/* q17: 0.94 x the same sums, rounded through a float.  Exactly, the value is N / 10^6 with N = 94 s + 128.5e6 (128.4e6 below zero); the
+	 * float form can only differ from floor(N / 10^6) when N sits within 1e-4 of a multiple of 10^6 (2.5e-4 of the triples): those lanes
+	 * take the reference's own arithmetic.  N / 10^6 = ((N >> 6) * 8796094) >> 37 for N < 2^28 (floor(floor(N / 64) / 15625)). */
+	const unsigned nu = (unsigned)(94 * su + (su >= 0 ? 128500000 : 128400000)), nv = (unsigned)(94 * sv + (sv >= 0 ? 128500000 : 128400000));
+	const unsigned qu = mulhi_u24(nu >> 6, 8796094u) >> 5, qv = mulhi_u24(nv >> 6, 8796094u) >> 5;
+	const unsigned ru = nu - mul_u24(qu, 1000000u), rv = nv - mul_u24(qv, 1000000u);
+	U = (int)min(qu, 255u); V = (int)min(qv, 255u);
+	if (ru - 100u > 999800u) U = clip_u8(chroma_round((float)((-0.1687 * b0 - 0.3313 * b1 + 0.5 * b2) * 0.94)));
+	if (rv - 100u > 999800u) V = clip_u8(chroma_round((float)((0.5 * b0 - 0.4187 * b1 - 0.0813 * b2) * 0.94)));
 }
 template <int FAMILY>
 __device__ __forceinline__ int convert_y(const uint8_t *px, float yq)
@@ -91,6 +95,14 @@ __device__ __forceinline__ int convert_y(const uint8_t *px, float yq)
 		/* s <= 255500 (18 bits): s / 1000 = (s * 8589935) >> 33 exactly, again on the 24-bit multiplier */
 		const unsigned s = (unsigned)(299 * b0 + 587 * b1 + 114 * b2 + 500), y = mulhi_u24(s, 8589935u) >> 1;
 		if (s != mul_u24(y, 1000u)) return (int)y;
+	}
+	if (FAMILY == 1 || FAMILY == 2) {
+		/* q 17..19: (int)(ly x scale + 0.5) in double.  The same product in single precision is off by less than 1e-4, so its floor is the
+		 * answer unless it lands within 2.5e-4 of an integer (5e-4 of the triples): those lanes take the double path below.  Checked, like
+		 * everything here, on all 2^24 triples. */
+		const float c = (FAMILY == 1 ? yq : 0.94f) * 0.001f;
+		const float v = (float)(299 * b0 + 587 * b1 + 114 * b2) * c + 0.5f, fl = floorf(v), fr = v - fl;
+		if (fr > 2.5e-4f && fr < 1.f - 2.5e-4f) return (int)fl;
 	}
 	const double ly = 0.299 * b0 + 0.587 * b1 + 0.114 * b2;
 	if (FAMILY == 0) return (int)(ly + 0.5f);
