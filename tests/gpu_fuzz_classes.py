@@ -41,6 +41,12 @@ def want_chunk(args):
     return [hashlib.sha1(o.encode(make(s), q)).hexdigest() for s in seeds]
 
 
+def dec_chunk(files):
+    from oracle.oraclepy import Oracle
+    o = Oracle()
+    return [hashlib.sha1(o.decode(f)[0].tobytes()).hexdigest() for f in files]
+
+
 def main(n=192, first=0):
     import nhwcodec_amd as na
     seeds = list(range(first, first + n))
@@ -54,7 +60,16 @@ def main(n=192, first=0):
             want = [h for part in ex.map(want_chunk, chunks) for h in part]
         bad = [seeds[i] for i in range(n) if got[i] != want[i]]
         bad_total += len(bad)
-        print(f"q{q}: {len(bad)} of {n} images differ {bad[:8]}", flush=True)
+        # ... and the files back through the GPU decoder against the oracle's decoder
+        files = enc.encode(imgs, q)
+        dec = na.Decoder(0, n)
+        px, qs = dec.decode(files)
+        dec.close()
+        with ProcessPoolExecutor(max_workers=min(48, os.cpu_count() or 8)) as ex:
+            dwant = [h for part in ex.map(dec_chunk, [files[i:i + 8] for i in range(0, n, 8)]) for h in part]
+        dbad = [seeds[i] for i in range(n) if hashlib.sha1(px[i].tobytes()).hexdigest() != dwant[i] or qs[i] != q]
+        bad_total += len(dbad)
+        print(f"q{q}: encode {len(bad)} of {n} images differ {bad[:8]}; decode {len(dbad)} differ {dbad[:8]}", flush=True)
     print("TOTAL differing:", bad_total)
 
 
