@@ -260,7 +260,11 @@ __global__ __launch_bounds__(64) void k_front_rowtail(const uint8_t *__restrict_
 			uint8_t px[24];
 			const uint2 *q8 = reinterpret_cast<const uint2 *>(src + (size_t)gr * (W * 3) + (480 + 8 * o) * 3);
 #pragma unroll
-			for (int j = 0; j < 3; j++) { const uint2 w = q8[j]; for (int b = 0; b < 4; b++) { px[8 * j + b] = (uint8_t)(w.x >> (8 * b)); px[8 * j + 4 + b] = (uint8_t)(w.y >> (8 * b)); } }
+			for (int j = 0; j < 3; j++) {
+				const uint2 w = q8[j];
+#pragma unroll
+				for (int b = 0; b < 4; b++) { px[8 * j + b] = (uint8_t)(w.x >> (8 * b)); px[8 * j + 4 + b] = (uint8_t)(w.y >> (8 * b)); }
+			}
 #pragma unroll
 			for (int e = 0; e < 8; e++) y4[e >> 1] |= (uint32_t)(uint16_t)convert_y<FAMILY>(px + 3 * e, yq) << (16 * (e & 1));
 		}
@@ -271,23 +275,25 @@ __global__ __launch_bounds__(64) void k_front_rowtail(const uint8_t *__restrict_
 	uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
 	int v509 = 0, v510 = 0;
 	/* the walk over columns c .. W-2 of one row; px(dr, col) = luma of row `row + dr`, column col */
-	auto walk = [&](auto px, int c) {
+	auto walk = [&](auto px, int c) __attribute__((always_inline)) {     /* inlined: the maps it updates stay in registers (captured by reference they sat in scratch memory) */
 		m0 = 0x0706050403020100ull; m1 = 0x0F0E0D0C0B0A0908ull;
 		/* 3x3 window slides along the row: three new reads per pixel */
 		int u0 = px(-1, c - 1), u1 = px(-1, c), m_0 = px(0, c - 1), m_1 = px(0, c), d0 = px(1, c - 1), d1 = px(1, c);
 		int cs0 = u0 + m_0 + d0, cs1 = u1 + m_1 + d1;
-		for (; c <= W - 2; c++) {
-			const int u2 = px(-1, c + 1), m_2 = px(0, c + 1), d2 = px(1, c + 1);
+		/* one pixel: its signed base value, the window moved on.  The last two pixels are taken out of the loop: what they record (the maps
+		 * in front of pixels 509 and 510) would otherwise be conditional stores inside it, which the compiler turns into scratch memory. */
+		auto cell = [&](int cc) __attribute__((always_inline)) {
+			const int u2 = px(-1, cc + 1), m_2 = px(0, cc + 1), d2 = px(1, cc + 1);
 			const int cs2 = u2 + m_2 + d2;
 			const int sum = 9 * m_1 - (cs0 + cs1 + cs2);
 			const int mag = (int)sad_u32(m_1, u0, sad_u32(m_1, u1, sad_u32(m_1, u2, sad_u32(m_1, m_0, sad_u32(m_1, m_2, sad_u32(m_1, d0, sad_u32(m_1, d1, sad_u32(m_1, d2, 0u))))))));
 			const int base = 15 * iabs(sum) + mag;
-			const int vb = sum == 0 ? 0 : (sum < 0 ? -base : base);
-			if (c == W - 3) { a0 = m0; a1 = m1; v509 = vb; }
-			if (c == W - 2) { b0 = m0; b1 = m1; v510 = vb; }
-			fsm_step16(m0, m1, vb);
 			u0 = u1; u1 = u2; m_0 = m_1; m_1 = m_2; d0 = d1; d1 = d2; cs0 = cs1; cs1 = cs2;
-		}
+			return sum == 0 ? 0 : (sum < 0 ? -base : base);
+		};
+		for (; c <= W - 4; c++) fsm_step16(m0, m1, cell(c));
+		v509 = cell(W - 3); a0 = m0; a1 = m1; fsm_step16(m0, m1, v509);
+		v510 = cell(W - 2); b0 = m0; b1 = m1; fsm_step16(m0, m1, v510);
 		const uint64_t b = (a0 & 0xFF) * 0x0101010101010101ull;
 		return a0 == b && a1 == b;                                    /* merged before pixel 509: the rest of the row does not matter */
 	};
