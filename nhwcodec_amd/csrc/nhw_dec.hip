@@ -1231,11 +1231,9 @@ DEV int lap_at(const int16_t *p)
 }
 DEV void pair_decide(int r0, int r1, int &m0, int &m1)
 {
-	m0 = m1 = 0;
-	if (r0 > 41 && r0 < 108 && r1 < 16) m0 = 1;
-	else if (r0 < -41 && r0 > -108 && r1 > -16) m0 = 1;
-	else if (r1 > 41 && r1 < 108 && r0 < 16) m1 = 1;
-	else if (r1 < -41 && r1 > -108 && r0 > -16) m1 = 1;
+	/* (as an if / else-if chain that sets one of the two, the compiler made the pair an array in scratch memory) */
+	m0 = (r0 > 41 && r0 < 108 && r1 < 16) || (r0 < -41 && r0 > -108 && r1 > -16);
+	m1 = !m0 && ((r1 > 41 && r1 < 108 && r0 < 16) || (r1 < -41 && r1 > -108 && r0 > -16));
 }
 __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 {
@@ -1252,13 +1250,16 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 	for (int i = 1; i < DH - 1; i++) {
 		const int16_t *p = c + (size_t)i * DW + 4 * lane + 1;
 		int base[4];
+#pragma unroll
 		for (int k = 0; k < 4; k++) base[k] = (lane < 63 || k < 2) ? lap_at(p + k) : 0;
 		/* marks above cells 4l .. 4l+5 as bits 0..5 */
 		const unsigned fromL = (unsigned)__shfl((int)above, (lane + 63) & 63), fromR = (unsigned)__shfl((int)above, (lane + 1) & 63);
 		const unsigned ab = (lane ? (fromL >> 3) & 1u : 0u) | (above << 1) | (lane < 63 ? (fromR & 1u) << 5 : 0u);
 		int cont[4];
+#pragma unroll
 		for (int k = 0; k < 4; k++) cont[k] = (int)((ab >> k) & 1u) + (int)((ab >> (k + 1)) & 1u) + (int)((ab >> (k + 2)) & 1u);
 		int res[2][4];                                               /* [left cell marked][m0A, m1A, m0B, m1B] */
+#pragma unroll
 		for (int ml = 0; ml < 2; ml++) {
 			int a0, a1, b0, b1;
 			pair_decide(base[0] - 16000 * (cont[0] + ml), base[1] - 16000 * cont[1], a0, a1);
@@ -1270,12 +1271,15 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 		uint64_t x = o0;
 		for (;;) { const uint64_t need = x << 1, xn = (o0 & ~need) | (o1 & need); if (xn == x) break; x = xn; }
 		const int ml = lane ? (int)((x >> (lane - 1)) & 1ull) : 0;
-		const unsigned mine = (unsigned)res[ml][0] | ((unsigned)res[ml][1] << 1) | ((unsigned)res[ml][2] << 2) | ((unsigned)res[ml][3] << 3);
+		const unsigned mine0 = (unsigned)res[0][0] | ((unsigned)res[0][1] << 1) | ((unsigned)res[0][2] << 2) | ((unsigned)res[0][3] << 3);
+		const unsigned mine1 = (unsigned)res[1][0] | ((unsigned)res[1][1] << 1) | ((unsigned)res[1][2] << 2) | ((unsigned)res[1][3] << 3);
+		const unsigned mine = ml ? mine1 : mine0;                       /* (indexing res[] with ml put the array in scratch memory) */
 		/* ordered output */
 		const int cnt = __popc(mine);
 		int pre = cnt;
 		for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(pre, d); if (lane >= d) pre += o; }
 		int at = total + pre - cnt;
+#pragma unroll
 		for (int k = 0; k < 4; k++) if ((mine >> k) & 1u) marks[at++] = (uint16_t)(i * DH + 4 * lane + 1 + k);
 		total += __shfl(pre, 63);
 		above = mine;
