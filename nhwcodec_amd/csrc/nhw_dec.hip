@@ -851,37 +851,29 @@ struct Mask4 { uint64_t w[4]; };
 DEV Mask4 m4_prev(const Mask4 &a) { return Mask4{ { a.w[0] << 1, (a.w[1] << 1) | (a.w[0] >> 63), (a.w[2] << 1) | (a.w[1] >> 63), (a.w[3] << 1) | (a.w[2] >> 63) } }; }   /* bit of column j-1 at j */
 DEV Mask4 m4_next(const Mask4 &a) { return Mask4{ { (a.w[0] >> 1) | (a.w[1] << 63), (a.w[1] >> 1) | (a.w[2] << 63), (a.w[2] >> 1) | (a.w[3] << 63), a.w[3] >> 1 } }; }   /* bit of column j+1 at j */
 DEV Mask4 m4_and(const Mask4 &a, const Mask4 &b) { return Mask4{ { a.w[0] & b.w[0], a.w[1] & b.w[1], a.w[2] & b.w[2], a.w[3] & b.w[3] } }; }
-DEV int m4_bit(const Mask4 &a, int k, int lane) { return (int)((a.w[k] >> lane) & 1ull); }
-
-/* replay the pattern symbols of one row (columns 0..ncols-1, staged at st[0..], the row below at st[DW..]) in column order.
- * `upper`: loop 1 (all six symbols, rows 0..255); otherwise loop 2 (left half of rows 256..511).  Lane 0 only. */
-DEV void replay_symbols(int16_t *st, int16_t *row, const uint64_t *mk, int nwords, bool upper)
+/* this lane's bit of a wave-uniform mask: the mask IS a lane-select operand, no 64-bit shift per lane needed */
+DEV int m4_bit(const Mask4 &a, int k, int)
 {
-	for (int k = 0; k < nwords; k++) {
+	int r;
+	asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(a.w[k]));
+	return r;
+}
+
+/* replay the pattern symbols of the left half of one of the rows 256..511 (loop 2, :529-560), staged in LDS with its HH half behind it, in
+ * column order.  Lane 0 only.  A 1008/1009 in column 0 writes the last cell of the row above: done up front, see the caller. */
+DEV void replay_lower(int16_t *st, const uint64_t *mk)
+{
+	for (int k = 0; k < 4; k++) {
 		uint64_t m = mk[k];
 		while (m) {
 			const int j = 64 * k + __builtin_ctzll(m);
 			m &= m - 1;
 			int16_t *p = st + j;
 			const int s = *p;
-			int lft = 0x7fff;
-			if (upper) {
-				switch (s) {
-				case 1008: lft = 5; p[1] = 5; p[0] = (int16_t)(j < DH ? 5 : 6); break;
-				case 1009: lft = -5; p[1] = -5; p[0] = (int16_t)(j < DH ? -6 : -7); break;
-				case 1010: p[0] = 5; p[1] = 5; p[DW] = 5; if (j < DW - 1) p[DW + 1] = 5; else row[2 * DW] = 5; break;
-				case 1011: p[0] = -5; p[1] = -5; p[DW] = -5; if (j < DW - 1) p[DW + 1] = -5; else row[2 * DW] = -5; break;
-				case 1006: p[0] = -6; p[1] = -6; break;
-				case 1007: p[0] = 6; p[1] = 6; break;
-				default: break;
-				}
-			} else {
-				if (s == 1008) { lft = 5; p[0] = 6; p[1] = 5; }
-				else if (s == 1009) { lft = -5; p[0] = -7; p[1] = -5; }
-				else if (s == 1006) { p[0] = -7; p[1] = -7; }
-				else if (s == 1007) { p[0] = 7; p[1] = 7; }
-			}
-			if (lft != 0x7fff) { if (j > 0) p[-1] = (int16_t)lft; else if (upper) row[-1] = (int16_t)lft; }   /* loop 2, column 0: done up front, see the caller */
+			if (s == 1008) { if (j > 0) p[-1] = 5; p[0] = 6; p[1] = 5; }
+			else if (s == 1009) { if (j > 0) p[-1] = -5; p[0] = -7; p[1] = -5; }
+			else if (s == 1006) { p[0] = -7; p[1] = -7; }
+			else if (s == 1007) { p[0] = 7; p[1] = 7; }
 		}
 	}
 }
@@ -896,9 +888,40 @@ __global__ __launch_bounds__(256) void k_dec_verdict(DecWs ws)
 	if (v && !m->status) m->status = v;
 }
 
+/* one pattern symbol of loop 1 (:493-527) at column j of a row staged in LDS; the rows around it are staged contiguously, so the cell in
+ * front of column 0 and the cell behind column 511 of the row below are where the reference's raster arithmetic puts them */
+DEV void replay_upper(int16_t *p, int j)
+{
+	switch (*p) {
+	case 1008: p[-1] = 5; p[1] = 5; p[0] = (int16_t)(j < DH ? 5 : 6); break;
+	case 1009: p[-1] = -5; p[1] = -5; p[0] = (int16_t)(j < DH ? -6 : -7); break;
+	case 1010: p[0] = 5; p[1] = 5; p[DW] = 5; p[DW + 1] = 5; break;
+	case 1011: p[0] = -5; p[1] = -5; p[DW] = -5; p[DW + 1] = -5; break;
+	case 1006: p[0] = -6; p[1] = -6; break;
+	case 1007: p[0] = 6; p[1] = 6; break;
+	default: break;                                               /* a symbol an earlier one wrote over */
+	}
+}
+DEV unsigned symbols_of(const uint4 &r)                          /* which of a lane's eight cells hold a pattern symbol */
+{
+	const unsigned w[4] = { r.x, r.y, r.z, r.w };
+	unsigned sm = 0;
+#pragma unroll
+	for (int e = 0; e < 4; e++) {
+		sm |= ((int)(int16_t)(w[e] & 0xFFFFu) > 1000 ? 1u : 0u) << (2 * e);
+		sm |= ((int)(int16_t)(w[e] >> 16) > 1000 ? 1u : 0u) << (2 * e + 1);
+	}
+	return sm;
+}
+
+#define XC 8                          /* rows per chunk of loop 1 */
+#define XD 4                          /* rows per chunk of loops 2 and 3: their row work needs more registers, the rows in flight fewer */
+#define X_CELLS (8 + (XC + 1) * DW + 8)
+#define X_NONE 0x7fff
 __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 {
-	__shared__ int16_t stage[4][2 * DW + 8];
+	__shared__ __attribute__((aligned(16))) int16_t stage[4][X_CELLS];
+	__shared__ uint8_t symb[4][XC + 1][64];
 	const int img = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (img >= ws.n) return;
 	DecMeta *m = ws.buf<DecMeta>(D_META, img);
@@ -908,138 +931,281 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 	int16_t *st = stage[threadIdx.x >> 6];
 	const uint8_t *f = ws.blob + ws.blob_off[img];
 
-	/* loop 1: rows 0..255, all columns (:493-527) */
-	for (int i = 0; i < DH; i++) {
-		int16_t *row = a + (size_t)i * DW;
-		int v[8]; uint64_t mk[8]; uint64_t any = 0;
-		for (int k = 0; k < 8; k++) v[k] = row[lane + 64 * k];
-		for (int k = 0; k < 8; k++) { mk[k] = __ballot(v[k] > 1000); any |= mk[k]; }
-		if (!any) continue;
-		for (int k = 0; k < 8; k++) { st[lane + 64 * k] = (int16_t)v[k]; st[DW + lane + 64 * k] = row[DW + lane + 64 * k]; }
-		__builtin_amdgcn_wave_barrier();
-		if (!lane) replay_symbols(st, row, mk, 8, true);
-		__builtin_amdgcn_wave_barrier();
-		for (int k = 0; k < 8; k++) { row[lane + 64 * k] = st[lane + 64 * k]; row[DW + lane + 64 * k] = st[DW + lane + 64 * k]; }
-		wave_sync();
+	/* loop 1: rows 0..255, all columns (:493-527).  A symbol writes into its own row, the row below, the last cell of the row above and the
+	 * first cell of the row after next; the walk is serial, but only over the symbols.  Rows pass through LDS XC at a time -- slot s of the
+	 * buffer is row i0+s, slot XC is the row below the chunk (the next chunk's slot 0) -- lane 0 replays the symbols of slots 0..XC-1 in
+	 * raster order while the next XC rows are already on their way from HBM, and the chunk goes back with one 16-byte store per lane and row.
+	 * Which cells are symbols is taken from the rows as loaded: a replay only ever writes small values, it cannot make a new symbol, and a
+	 * symbol that was written over is seen as such when the walk reads it. */
+	{
+		int16_t *buf = st + 8;
+		uint8_t *sm = &symb[threadIdx.x >> 6][0][0];
+		const uint4 *ag = (const uint4 *)a;
+		uint4 nx[XC];
+		uint64_t any_halo;
+		{
+			const uint4 r0 = ag[lane];
+			*(uint4 *)(buf + 8 * lane) = r0;
+			const unsigned s0 = symbols_of(r0);
+			sm[lane] = (uint8_t)s0;
+			any_halo = __ballot(s0 != 0);
+		}
+#pragma unroll
+		for (int g = 0; g < XC; g++) nx[g] = ag[(size_t)(1 + g) * (DW / 8) + lane];
+		int pend = X_NONE;                                        /* what a column-511 symbol of the chunk's last row left for column 0 of the row after next */
+		uint64_t any_m2 = 0, any_m1 = 0;                          /* symbols in the last two rows of the chunk before */
+		for (int i0 = 0; i0 < DH; i0 += XC) {
+			uint64_t anyx[XC + 3]; uint64_t any_all = any_halo;
+			uint64_t *any = anyx + 2;                               /* any[s]: slot s holds a symbol; a symbol reaches from the row above it to the first cell two rows below */
+			any[-2] = any_m2; any[-1] = any_m1; any[0] = any_halo;
+#pragma unroll
+			for (int g = 0; g < XC; g++) {
+				*(uint4 *)(buf + (g + 1) * DW + 8 * lane) = nx[g];
+				const unsigned sg = symbols_of(nx[g]);
+				sm[(g + 1) * 64 + lane] = (uint8_t)sg;
+				any[g + 1] = __ballot(sg != 0);
+				if (g + 1 < XC) any_all |= any[g + 1];
+			}
+			if (!lane) {
+				if (pend != X_NONE) buf[DW] = (int16_t)pend;
+				buf[-1] = X_NONE; buf[(XC + 1) * DW] = X_NONE;
+			}
+			const bool more = i0 + XC < DH;
+			if (more) {
+#pragma unroll
+				for (int g = 0; g < XC; g++) nx[g] = ag[(size_t)(i0 + XC + 1 + g) * (DW / 8) + lane];
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (any_all) {
+				if (!lane) {
+#pragma unroll
+					for (int s = 0; s < XC; s++) {
+						uint64_t mm = any[s];
+						while (mm) {
+							const int l = __builtin_ctzll(mm);
+							mm &= mm - 1;
+							unsigned bits = sm[s * 64 + l];
+							while (bits) {
+								const int e = __builtin_ctz(bits);
+								bits &= bits - 1;
+								replay_upper(buf + s * DW + 8 * l + e, 8 * l + e);
+							}
+						}
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+				const int up = buf[-1];
+				if (up != X_NONE) { wave_sync(); if (!lane) a[(size_t)i0 * DW - 1] = (int16_t)up; }   /* behind the rows the last chunk stored */
+			}
+			pend = buf[(XC + 1) * DW];
+#pragma unroll
+			for (int s = 0; s < XC; s++) {
+				if (any[s - 2] | any[s - 1] | any[s] | any[s + 1]) *(uint4 *)(a + (size_t)(i0 + s) * DW + 8 * lane) = *(const uint4 *)(buf + s * DW + 8 * lane);
+			}
+			{
+				const uint4 h = *(const uint4 *)(buf + XC * DW + 8 * lane);
+				const uint8_t hs = sm[XC * 64 + lane];
+				__builtin_amdgcn_wave_barrier();
+				*(uint4 *)(buf + 8 * lane) = h;
+				sm[lane] = hs;
+				any_halo = any[XC]; any_m1 = any[XC - 1]; any_m2 = any[XC - 2];
+			}
+		}
+		if (any_m2 | any_m1) *(uint4 *)(a + (size_t)DH * DW + 8 * lane) = *(const uint4 *)(buf + 8 * lane);   /* row 256, with what rows 254 and 255 wrote into it */
+		if (pend != X_NONE && !lane) a[(size_t)(DH + 1) * DW] = (int16_t)pend;
 	}
 
 	/* loops 2 and 3, row by row: the left half's pattern symbols (:529-560), then the HH half (:562-616).  The reference finishes
 	 * loop 2 before loop 3 starts; going row by row instead only differs where the two loops touch each other's cells across a row
 	 * end: a 1008/1009 in column 0 (loop 2) writes the last HH cell of the row above -- applied here before anything else -- and a
-	 * 1008/1009 in column 511 (loop 3) writes column 0 of the next row -- held back until that row's loop-2 part is done. */
+	 * 1008/1009 in column 511 (loop 3) writes column 0 of the next row -- held back until that row's loop-2 part is done.
+	 * The rows pass through the same LDS buffer as in loop 1, XD at a time with the next XD on their way: a row reads the untouched HH
+	 * half of the row below (slot s+1), writes itself and one cell class into the left half of the row above (slot s-1; for slot 0 that
+	 * row has left already and is patched in memory), and the finished HH row above stays in registers. */
 	wave_sync();
 	for (int i = DH + lane; i < DW; i += 64) {
 		const int s = a[(size_t)i * DW];
 		if (s == 1008 || s == 1009) a[(size_t)i * DW - 1] = (int16_t)(s == 1008 ? 5 : -5);
 	}
 	wave_sync();
-	int carry = m->carry;
-	int pend0 = 0x7fff;                                           /* value a column-511 symbol of the previous row writes to column 0 of this one */
-	int upf[4];
-	for (int k = 0; k < 4; k++) upf[k] = a[(size_t)(DH - 1) * DW + DH + lane + 64 * k];
-	for (int i = DH; i < DW; i++) {
-		int16_t *row = a + (size_t)i * DW;
-		{
-			int v[4]; uint64_t mk[4]; uint64_t any = 0;
-			for (int k = 0; k < 4; k++) v[k] = row[lane + 64 * k];
-			for (int k = 0; k < 4; k++) { mk[k] = __ballot(v[k] > 1000); any |= mk[k]; }
-			if (any) {
-				for (int k = 0; k < 4; k++) st[lane + 64 * k] = (int16_t)v[k];
-				if (!lane) st[DH] = row[DH];
-				__builtin_amdgcn_wave_barrier();
-				if (!lane) { replay_symbols(st, row, mk, 4, false); row[DH] = st[DH]; }
-				__builtin_amdgcn_wave_barrier();
-				for (int k = 0; k < 4; k++) row[lane + 64 * k] = st[lane + 64 * k];
-				wave_sync();
-			}
-		}
-		if (pend0 != 0x7fff) { if (!lane) row[0] = (int16_t)pend0; pend0 = 0x7fff; }
-		/* HH half of the row: columns 256..511 */
-		int cur[4], dn[4];
-		for (int k = 0; k < 4; k++) { const int c = DH + lane + 64 * k; cur[k] = row[c]; dn[k] = i + 1 < DW ? row[c + DW] : 0; }
-		Mask4 k8, k9, s67, liveK = { { 0, 0, 0, 0 } }, live67 = { { 0, 0, 0, 0 } };
-		uint64_t any = 0;
-		for (int k = 0; k < 4; k++) {
-			k8.w[k] = __ballot(cur[k] == 1008); k9.w[k] = __ballot(cur[k] == 1009); s67.w[k] = __ballot(cur[k] == 1006 || cur[k] == 1007);
-			any |= k8.w[k] | k9.w[k] | s67.w[k];
-		}
-		if (!any && q >= 23) { for (int k = 0; k < 4; k++) upf[k] = cur[k]; continue; }
-		if (any) {                                                 /* which symbols are still there when the walk reaches them */
-			int dead_at = -1;
-			for (int k = 0; k < 4; k++) {
-				uint64_t mm = k8.w[k] | k9.w[k] | s67.w[k];
-				while (mm) {
-					const int b = __builtin_ctzll(mm), col = 64 * k + b;
-					mm &= mm - 1;
-					if (col == dead_at) continue;
-					if ((s67.w[k] >> b) & 1ull) live67.w[k] |= 1ull << b;
-					else { liveK.w[k] |= 1ull << b; dead_at = col + 1; }
+	{
+		int16_t *buf = st + 8;
+		const uint4 *ag = (const uint4 *)a;
+		static_assert(XD == 4, "the rows in flight are four named registers");
+#define X_ROW(r) ag[(size_t)((r) < DW ? (r) : DW - 1) * (DW / 8) + lane]   /* past the last row: loaded, never looked at */
+		*(uint4 *)(buf + 8 * lane) = ag[(size_t)DH * (DW / 8) + lane];
+		uint4 nx0 = X_ROW(DH + 1), nx1 = X_ROW(DH + 2), nx2 = X_ROW(DH + 3), nx3 = X_ROW(DH + 4);
+		int carry = m->carry;
+		int pend0 = X_NONE;                                       /* value a column-511 symbol of the previous row writes to column 0 of this one */
+		int upf[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) upf[k] = a[(size_t)(DH - 1) * DW + DH + lane + 64 * k];
+		for (int i0 = DH; i0 < DW; i0 += XD) {
+			*(uint4 *)(buf + 1 * DW + 8 * lane) = nx0; *(uint4 *)(buf + 2 * DW + 8 * lane) = nx1;
+			*(uint4 *)(buf + 3 * DW + 8 * lane) = nx2; *(uint4 *)(buf + 4 * DW + 8 * lane) = nx3;
+			nx0 = X_ROW(i0 + XD + 1); nx1 = X_ROW(i0 + XD + 2); nx2 = X_ROW(i0 + XD + 3); nx3 = X_ROW(i0 + XD + 4);
+			__builtin_amdgcn_wave_barrier();
+			unsigned wrote = 0;                                     /* slots with a cell that differs from memory */
+#pragma unroll 1
+			for (int s = 0; s < XD; s++) {
+				const int i = i0 + s;
+				int16_t *row = buf + s * DW;
+				{
+					int v[4]; uint64_t mk[4]; uint64_t any = 0;
+#pragma unroll
+					for (int k = 0; k < 4; k++) v[k] = row[lane + 64 * k];
+#pragma unroll
+					for (int k = 0; k < 4; k++) { mk[k] = __ballot(v[k] > 1000); any |= mk[k]; }
+					if (any) {
+						if (!lane) replay_lower(row, mk);
+						__builtin_amdgcn_wave_barrier();
+						wrote |= 1u << s;
+					}
+				}
+				if (pend0 != X_NONE) { if (!lane) row[0] = (int16_t)pend0; pend0 = X_NONE; wrote |= 1u << s; }
+				/* HH half of the row: columns 256..511 */
+				int cur[4], dn[4];
+#pragma unroll
+				for (int k = 0; k < 4; k++) { const int c = DH + lane + 64 * k; cur[k] = row[c]; dn[k] = i + 1 < DW ? row[c + DW] : 0; }
+				Mask4 k8, k9, s67, liveK = { { 0, 0, 0, 0 } }, live67 = { { 0, 0, 0, 0 } };
+				uint64_t any = 0;
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					k8.w[k] = __ballot(cur[k] == 1008); k9.w[k] = __ballot(cur[k] == 1009); s67.w[k] = __ballot(cur[k] == 1006 || cur[k] == 1007);
+					any |= k8.w[k] | k9.w[k] | s67.w[k];
+				}
+				if (!any && q >= 23) {
+#pragma unroll
+					for (int k = 0; k < 4; k++) upf[k] = cur[k];
+					continue;
+				}
+				if (any) {                                           /* which symbols are still there when the walk reaches them */
+					int dead_at = -1;
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						uint64_t mm = k8.w[k] | k9.w[k] | s67.w[k];
+						while (mm) {
+							const int b = __builtin_ctzll(mm), col = 64 * k + b;
+							mm &= mm - 1;
+							if (col == dead_at) continue;
+							if ((s67.w[k] >> b) & 1ull) live67.w[k] |= 1ull << b;
+							else { liveK.w[k] |= 1ull << b; dead_at = col + 1; }
+						}
+					}
+				}
+				const Mask4 live8 = m4_and(liveK, k8);
+				const Mask4 kL = m4_prev(liveK), kL2 = m4_prev(kL), kR = m4_next(liveK), p8L = m4_prev(live8), p8R = m4_next(live8), s67L = m4_prev(live67);
+				unsigned cand = 0, hit[4];
+				int fin[4];
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const int c = DH + lane + 64 * k;
+					const int l = __shfl(cur[k], (lane + 63) & 63), lw = k ? __shfl(cur[k - 1], 63) : 0;
+					const int r = __shfl(cur[k], (lane + 1) & 63), rw = k < 3 ? __shfl(cur[k + 1], 0) : 0;
+					const int lv = lane ? l : lw, rv = lane < 63 ? r : rw;
+					const int lk = m4_bit(liveK, k, lane), l67 = m4_bit(live67, k, lane), lkL = m4_bit(kL, k, lane), lkR = m4_bit(kR, k, lane);
+					const bool cd = !lkL && !lk && !l67 && cur[k] <= 1000 && iabs(cur[k]) > 8 && iabs(cur[k]) < 16 && c > DH && c < DW - 1 && q < 23;
+					const bool lsmall = m4_bit(kL2, k, lane) || m4_bit(s67L, k, lane) || iabs(lv) < 8;
+					hit[k] = (unsigned)((lsmall ? 1 : 0) + (iabs(rv) < 8) + (iabs(upf[k]) < 8) + (iabs(dn[k]) < 8));
+					cand |= cd ? 1u << k : 0u;
+					int v = cur[k];
+					if (lkR) v = m4_bit(p8R, k, lane) ? 5 : -5;
+					else if (lk) v = cur[k] == 1008 ? 6 : -7;
+					else if (l67) v = 0;
+					else if (lkL) v = m4_bit(p8L, k, lane) ? 5 : -5;
+					fin[k] = v;
+				}
+				if (carry) {                                        /* the very first candidate of the walk also gets the left-over count */
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const uint64_t bm = __ballot((cand >> k) & 1);
+						if (bm && carry) { if (lane == __builtin_ctzll(bm)) hit[k] += (unsigned)carry; carry = 0; }
+					}
+				}
+				bool changed = false;
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const int lkR = m4_bit(kR, k, lane);
+					if (((cand >> k) & 1) && hit[k] >= 2 && !lkR) fin[k] = cur[k] > 0 ? cur[k] + 1 : cur[k] - 1;
+					if (fin[k] != cur[k]) { row[DH + lane + 64 * k] = (int16_t)fin[k]; changed = true; }
+					upf[k] = fin[k];
+				}
+				if (__ballot(changed)) wrote |= 1u << s;
+				if (any) {                                           /* what the symbols write outside the HH half of this row */
+					const bool up67 = (live67.w[0] | live67.w[1] | live67.w[2] | live67.w[3]) != 0;
+					if (up67 && s == 0) wave_sync();                   /* the row above went to memory with the chunk before: patch it there, behind those stores */
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const int c = DH + lane + 64 * k;
+						if (m4_bit(live67, k, lane)) {
+							const int16_t val = (int16_t)(cur[k] == 1006 ? -7 : 7);
+							row[c - DH] = val;
+							if (s) row[c - 3 * DH] = val; else a[(size_t)i * DW + c - 3 * DH] = val;
+						}
+						if (m4_bit(liveK, k, lane)) {
+							const int16_t val = (int16_t)(cur[k] == 1008 ? 5 : -5);
+							if (c == DH) row[DH - 1] = val;
+						}
+					}
+					wrote |= 1u << s;
+					if (up67 && s) wrote |= 1u << (s - 1);
+					if ((liveK.w[3] >> 63) & 1ull) pend0 = ((k8.w[3] >> 63) & 1ull) ? 5 : -5;
 				}
 			}
-		}
-		const Mask4 live8 = m4_and(liveK, k8);
-		const Mask4 kL = m4_prev(liveK), kL2 = m4_prev(kL), kR = m4_next(liveK), p8L = m4_prev(live8), p8R = m4_next(live8), s67L = m4_prev(live67);
-		unsigned cand = 0, hit[4];
-		int fin[4];
-		for (int k = 0; k < 4; k++) {
-			const int c = DH + lane + 64 * k;
-			const int l = __shfl(cur[k], (lane + 63) & 63), lw = k ? __shfl(cur[k - 1], 63) : 0;
-			const int r = __shfl(cur[k], (lane + 1) & 63), rw = k < 3 ? __shfl(cur[k + 1], 0) : 0;
-			const int lv = lane ? l : lw, rv = lane < 63 ? r : rw;
-			const int lk = m4_bit(liveK, k, lane), l67 = m4_bit(live67, k, lane), lkL = m4_bit(kL, k, lane), lkR = m4_bit(kR, k, lane);
-			const bool cd = !lkL && !lk && !l67 && cur[k] <= 1000 && iabs(cur[k]) > 8 && iabs(cur[k]) < 16 && c > DH && c < DW - 1 && q < 23;
-			const bool lsmall = m4_bit(kL2, k, lane) || m4_bit(s67L, k, lane) || iabs(lv) < 8;
-			hit[k] = (unsigned)((lsmall ? 1 : 0) + (iabs(rv) < 8) + (iabs(upf[k]) < 8) + (iabs(dn[k]) < 8));
-			cand |= cd ? 1u << k : 0u;
-			int v = cur[k];
-			if (lkR) v = m4_bit(p8R, k, lane) ? 5 : -5;
-			else if (lk) v = cur[k] == 1008 ? 6 : -7;
-			else if (l67) v = 0;
-			else if (lkL) v = m4_bit(p8L, k, lane) ? 5 : -5;
-			fin[k] = v;
-		}
-		if (carry) {                                              /* the very first candidate of the walk also gets the left-over count */
-			for (int k = 0; k < 4 && carry; k++) {
-				const uint64_t bm = __ballot((cand >> k) & 1);
-				if (bm) { if (lane == __builtin_ctzll(bm)) hit[k] += (unsigned)carry; carry = 0; }
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int s = 0; s < XD; s++)
+				if ((wrote >> s) & 1u) *(uint4 *)(a + (size_t)(i0 + s) * DW + 8 * lane) = *(const uint4 *)(buf + s * DW + 8 * lane);
+			{
+				const uint4 h = *(const uint4 *)(buf + XD * DW + 8 * lane);
+				__builtin_amdgcn_wave_barrier();
+				*(uint4 *)(buf + 8 * lane) = h;
 			}
 		}
-		for (int k = 0; k < 4; k++) {
-			const int lkR = m4_bit(kR, k, lane);
-			if (((cand >> k) & 1) && hit[k] >= 2 && !lkR) fin[k] = cur[k] > 0 ? cur[k] + 1 : cur[k] - 1;
-			if (fin[k] != cur[k]) row[DH + lane + 64 * k] = (int16_t)fin[k];
-			upf[k] = fin[k];
-		}
-		if (any) {                                                 /* what the symbols write outside the HH half of this row */
-			for (int k = 0; k < 4; k++) {
-				const int c = DH + lane + 64 * k;
-				if (m4_bit(live67, k, lane)) { const int16_t val = (int16_t)(cur[k] == 1006 ? -7 : 7); row[c - DH] = val; row[c - 3 * DH] = val; }
-				if (m4_bit(liveK, k, lane)) {
-					const int16_t val = (int16_t)(cur[k] == 1008 ? 5 : -5);
-					if (c == DH) row[DH - 1] = val;
-				}
-			}
-			if ((liveK.w[3] >> 63) & 1ull) pend0 = ((k8.w[3] >> 63) & 1ull) ? 5 : -5;
-		}
+#undef X_ROW
 	}
 	wave_sync();
 
-	/* LL2 samples (:618-625) */
-	const uint8_t *ll = ws.buf<uint8_t>(D_LL, img);
-	for (int k = lane; k < DQ / 4; k += 64) a[(size_t)(k >> 7) * DW + (k & 127)] = ll[k];
+	/* LL2 samples (:618-625): 16 of them per lane and step */
+	{
+		const uint4 *l4 = (const uint4 *)ws.buf<uint8_t>(D_LL, img);
+		for (int k = lane; k < DQ / 64; k += 64) {
+			const uint4 b = l4[k];
+			const unsigned w[4] = { b.x, b.y, b.z, b.w };
+			unsigned o[8];
+#pragma unroll
+			for (int e = 0; e < 4; e++) { o[2 * e] = (w[e] & 0xFFu) | ((w[e] & 0xFF00u) << 8); o[2 * e + 1] = ((w[e] >> 16) & 0xFFu) | ((w[e] >> 24) << 16); }
+			uint4 *dst = (uint4 *)(a + (size_t)(k >> 3) * DW + (k & 7) * 16);
+			dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+			dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+		}
+	}
 	wave_sync();
-	if (!lane) {
-		if (q > 17) {                                              /* odd-LL tags (:627-654) */
-			const uint8_t *r4 = f + m->o_res4;
-			int rowi = 0;
-			for (int i = 0; i < m->res4_len; i++) {
-				const int v = r4[i];
-				if (v == 128) { rowi++; continue; }
+	if (q > 17) {                                                  /* odd-LL tags (:627-654): a tag makes four cells odd, which is the same done once or twice, in any order; the row a tag
+	                                                                * is in is the number of row-advancing bytes in front of it */
+		const uint8_t *r4 = f + m->o_res4;
+		const int n = m->res4_len;
+		int rowbase = 0;
+		for (int i0 = 0; i0 < n; i0 += 64) {
+			const bool valid = i0 + lane < n;
+			const int v = valid ? r4[i0 + lane] : 0;
+			const uint64_t adv = __ballot(valid && v >= 128);
+			const int rowi = rowbase + __builtin_popcountll(adv & ((1ull << lane) - 1ull));
+			rowbase += __builtin_popcountll(adv);
+			if (valid && v != 128) {
 				const int at = (rowi << 9) + (v > 128 ? v - 129 : v - 1);
-				if (at >= 0 && at + 3 < 4 * DQ) for (int k = 0; k < 4; k++) if (!(a[at + k] & 1)) a[at + k]++;
-				if (v > 128) rowi++;
+				if (at >= 0 && at + 3 < 4 * DQ) {
+					int c4[4];
+#pragma unroll
+					for (int k = 0; k < 4; k++) c4[k] = a[at + k];
+#pragma unroll
+					for (int k = 0; k < 4; k++) if (!(c4[k] & 1)) a[at + k] = (int16_t)(c4[k] + 1);
+				}
 			}
 		}
+		wave_sync();
+	}
+	if (!lane) {
 		/* exception samples of the luma plane (:656-668); U and V follow on the same cursor (k_dec_expand_chroma) */
 		const uint8_t *x = f + m->o_exw;
 		const int n = m->exw_len;
