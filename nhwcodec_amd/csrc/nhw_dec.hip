@@ -11,10 +11,10 @@
  *   k_dec_vlc      the prefix-code walk, one wavefront per stream (luma, chroma): a speculative parallel parse and a
  *                  short-state chain for the placement rules; k_dec_unzig then moves the symbols to their cells
  *   k_dec_expand   pattern symbols -> coefficients, the +-1 nudge of the HH band, LL2 samples, odd-LL tags,
- *                  exception samples: one wavefront per image, rows in order, a row with no pattern symbol
- *                  is one load and a ballot
- *   k_dec_shrink, k_dec_synth (x4 luma, x4 per chroma plane), k_dec_resid, k_dec_marks, k_dec_corr,
- *   k_dec_smooth, k_dec_cpairs, k_dec_sharpen, k_dec_color
+ *                  exception samples: one wavefront per image, the rows streaming through LDS in order
+ *   k_dec_shrink, k_dec_synth2d (level 2 of the luma, levels 2 and 1 of both chroma planes: both directions of a
+ *                  level on one LDS residency of the block), k_dec_resid, k_dec_marks, k_dec_cpairs, k_dec_sharpen
+ *   k_dec_final    level 1 of the luma both ways, corrections, smoothing, chroma up-sampling, colour matrix -> BGR24
  *
  * Everything is int16/uint8 arithmetic; the only floating point is the colour matrix (compiled with
  * -ffp-contract=off like the rest of the library).  No stage falls back to the host.
@@ -1280,45 +1280,93 @@ __global__ __launch_bounds__(256) void k_dec_shrink(DecWs ws)
 }
 
 /* ---------------------------------------------------------------------------------------------- synthesis (d4)
- * One pass of the 5/3 synthesis over rows of [low half | high half] (decoder/filters.c:143-194, driven as in
- * decoder/wavelet_filterbank.c:52-357).  The reference transposes between passes; here a pass reads its input
- * transposed instead (rows below `lo_t` take their low half from columns, `hi_t` likewise for the high half).
- * A workgroup stages 16 rows in LDS and writes 16 output rows. */
-struct SynthArgs {
-	int src, dst;            /* D_A / D_B / D_CA / D_CB (+ component for chroma) */
-	int comp;
-	int st, rows, n;         /* row stride of both planes, rows to produce, samples per output row */
-	int lo_t, hi_t, norm;
-};
-DEV int16_t *synth_plane(const DecWs &ws, int kind, int img, int comp)
+ * The 5/3 synthesis over rows of [low half | high half] (decoder/filters.c:143-194), driven as in decoder/wavelet_filterbank.c:52-357:
+ * along the rows, transpose, along the rows again (normalised), which leaves every level's result transposed.
+ */
+/* Both directions of one level in one launch: the S x S block (S = 256: 129 KB, the LDS a CU has) is loaded once, filtered along the rows in
+ * place, then along the columns, and column c of the result leaves as row c of the plane -- the transposed orientation the two-pass form
+ * leaves behind and everything downstream expects.  The plane in between never travels.  LLT: the low-low quadrant of the block is itself the
+ * transposed output of the level before (chroma level 1) and is turned while it is written to LDS.  A workgroup works through several
+ * blocks and has the next one on its way, in registers, while it filters the present one (one workgroup fills a CU at S = 256: without that
+ * the memory system would idle during the filter phases).  Items: images (luma, plane A) or image x component (chroma, plane CA). */
+DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   /* orders LDS traffic only: global loads stay in flight across it */
+template <int S>
+DEV void synth_pair(const int16_t *x, int st, int k, bool norm, int &ev, int &od)
 {
-	switch (kind) { case D_A: return plane_a(ws, img); case D_B: return plane_b(ws, img); case D_CA: return plane_ca(ws, img, comp); default: return plane_cb(ws, img, comp); }
+	constexpr int M = S / 2;
+	const int16_t *lo = x, *hi = x + M * st;
+	const int l0 = lo[k * st], ln = k + 1 < M ? lo[(k + 1) * st] : l0;
+	const int h0 = hi[k * st], hp = k > 0 ? hi[(k - 1) * st] : h0, hn = k + 1 < M ? hi[(k + 1) * st] : h0;
+	ev = (int16_t)((int16_t)(l0 << 3) - ((h0 + hp) << 1));
+	od = (int16_t)((int16_t)((l0 + ln) << 2) + (6 * h0 - hp - hn));
+	if (norm) { if (ev > 0) ev = (int16_t)(ev + 32); ev >>= 6; if (od > 0) od = (int16_t)(od + 32); od >>= 6; }
 }
-__global__ __launch_bounds__(256) void k_dec_synth(DecWs ws, SynthArgs g)
+template <int S, bool LLT>
+__global__ __launch_bounds__(S * 4) void k_dec_synth2d(DecWs ws, int chroma, int items)
 {
-	__shared__ int16_t t[16][DW + 2];
-	const int img = blockIdx.y, comp = g.comp < 0 ? (int)blockIdx.z : g.comp, r0 = blockIdx.x * 16, tid = threadIdx.x;
-	if (ws.buf<DecMeta>(D_META, img)->status) return;
-	const int16_t *src = synth_plane(ws, g.src, img, comp);
-	const int M = g.n / 2;
-	/* low halves */
-	if (r0 < g.lo_t) for (int idx = tid; idx < 16 * M; idx += 256) { const int k = idx >> 4, rr = idx & 15; t[rr][k] = src[(size_t)k * g.st + r0 + rr]; }
-	else for (int idx = tid; idx < 16 * M; idx += 256) { const int rr = idx / M, k = idx - rr * M; t[rr][k] = src[(size_t)(r0 + rr) * g.st + k]; }
-	if (g.hi_t) for (int idx = tid; idx < 16 * M; idx += 256) { const int k = idx >> 4, rr = idx & 15; t[rr][M + k] = src[(size_t)(M + k) * g.st + r0 + rr]; }
-	else for (int idx = tid; idx < 16 * M; idx += 256) { const int rr = idx / M, k = idx - rr * M; t[rr][M + k] = src[(size_t)(r0 + rr) * g.st + M + k]; }
-	__syncthreads();
-	for (int idx = tid; idx < 16 * M; idx += 256) {
-		const int rr = idx / M, k = idx - rr * M;
-		const int16_t *lo = t[rr], *hi = t[rr] + M;
-		int ev = (int16_t)(lo[k] << 3), od = k < M - 1 ? (int16_t)((lo[k + 1] + lo[k]) << 2) : (int16_t)(lo[M - 1] << 3);
-		if (k == 0) { ev -= hi[0] << 2; od += 5 * hi[0] - hi[1]; }
-		else if (k < M - 1) { ev -= (hi[k] + hi[k - 1]) << 1; od += 6 * hi[k] - hi[k + 1] - hi[k - 1]; }
-		else { ev -= (hi[M - 1] + hi[M - 2]) << 1; od += 5 * hi[M - 1] - hi[M - 2]; }
-		ev = (int16_t)ev; od = (int16_t)od;
-		if (g.norm) { if (ev > 0) ev = (int16_t)(ev + 32); ev >>= 6; if (od > 0) od = (int16_t)(od + 32); od >>= 6; }
-		int16_t *d = synth_plane(ws, g.dst, img, comp) + (size_t)(r0 + rr) * g.st + 2 * k;
-		*(short2 *)d = make_short2((short)ev, (short)od);
+	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
+	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4, NPRE = S * (S / 8) / NT_;
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const int stride = chroma ? DH : DW;
+	auto block_of = [&](int item) { return chroma ? plane_ca(ws, item >> 1, item & 1) : plane_a(ws, item); };
+	uint4 pre[NPRE];
+	if ((int)blockIdx.x < items) {
+		const int16_t *src = block_of(blockIdx.x);
+#pragma unroll
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * stride + 8 * (v % (S / 8))); }
 	}
+	for (int item = blockIdx.x; item < items; item += gridDim.x) {
+		int16_t *pl = block_of(item);
+		const bool skip = ws.buf<DecMeta>(D_META, chroma ? item >> 1 : item)->status != 0;
+#pragma unroll
+		for (int u = 0; u < NPRE; u++) {
+			const int v = t + u * NT_, row = v / (S / 8), o = v % (S / 8);
+			const uint32_t w[4] = { pre[u].x, pre[u].y, pre[u].z, pre[u].w };
+			if (LLT && row < HLF && o < HLF / 8) {
+#pragma unroll
+				for (int e = 0; e < 4; e++) { smem[(8 * o + 2 * e) * LS + row] = (int16_t)(w[e] & 0xFFFFu); smem[(8 * o + 2 * e + 1) * LS + row] = (int16_t)(w[e] >> 16); }
+			} else {
+				uint32_t *d = reinterpret_cast<uint32_t *>(smem + row * LS + 8 * o);
+				d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+			}
+		}
+		lds_barrier();
+		if (item + (int)gridDim.x < items) {
+			const int16_t *src = block_of(item + gridDim.x);
+#pragma unroll
+			for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * stride + 8 * (v % (S / 8))); }
+		}
+		for (int i = 0; i < 16; i++) {                               /* along the rows, un-normalised (decoder/filters.c:143-194) */
+			int16_t *x = smem + (wv * 16 + i) * LS;
+			int e[PPL], o[PPL];
+#pragma unroll
+			for (int u = 0; u < PPL; u++) synth_pair<S>(x, 1, lane + 64 * u, false, e[u], o[u]);
+#pragma unroll
+			for (int u = 0; u < PPL; u++) reinterpret_cast<uint32_t *>(x)[lane + 64 * u] = (uint32_t)(uint16_t)e[u] | ((uint32_t)(uint16_t)o[u] << 16);
+		}
+		lds_barrier();
+		if (!skip)
+		for (int i = 0; i < 16; i++) {                               /* along the columns, normalised: column c is row c of the plane */
+			const int c = wv * 16 + i;
+			uint32_t *dst = reinterpret_cast<uint32_t *>(pl + (size_t)c * stride);
+#pragma unroll
+			for (int u = 0; u < PPL; u++) {
+				int e, o;
+				synth_pair<S>(smem + c, LS, lane + 64 * u, true, e, o);
+				dst[lane + 64 * u] = (uint32_t)(uint16_t)e | ((uint32_t)(uint16_t)o << 16);
+			}
+		}
+		lds_barrier();                                               /* the block is done with before the next one moves in */
+	}
+}
+#define SYNTH_WGS 256                /* one resident workgroup per CU for the 256 x 256 blocks */
+static int synth2d_attrs()
+{
+	int rc = NHW_OK;                                               /* per device: every handle sets it for its own */
+	const int big = 256 * 258 * (int)sizeof(int16_t);
+	if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_synth2d<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+	    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_synth2d<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) rc = NHW_E_HIP;
+	return rc;
 }
 
 /* ---------------------------------------------------------------------------------------------- residual lists (:731-787)
@@ -1837,6 +1885,7 @@ extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
 		HIPCHK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&d->join_ev, hipEventDisableTiming));
 		for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&d->ev[i]));
+		if (synth2d_attrs() != NHW_OK) { g_derr = "hipFuncSetAttribute(k_dec_synth2d<256>, 129 KB of LDS) failed"; return NHW_E_HIP; }
 		return NHW_OK;
 	}();
 	if (rc != NHW_OK) { nhw_dec_destroy(d); return rc; }
@@ -1915,13 +1964,9 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	k_dec_expand_chroma<<<(n + 3) / 4, 256, 0, cs>>>(ws);
 	if (fork) {
 		/* chroma, both planes per launch (blockIdx.z) */
-		SynthArgs a1 = { D_CA, D_CB, -1, DH, DH / 2, DH / 2, 0, 0, 0 }, a2 = { D_CB, D_CA, -1, DH, DH / 2, DH / 2, DH / 2, 1, 1 };
-		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, cs>>>(ws, a1);
-		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, cs>>>(ws, a2);
+		k_dec_synth2d<128, false><<<2 * n, 512, 128 * 130 * sizeof(int16_t), cs>>>(ws, 1, 2 * n);                                        /* level 2 */
 		k_dec_cpairs<<<dim3(DH / CPAIR_ROWS, n, 2), 256, 0, cs>>>(ws);
-		SynthArgs b1 = { D_CA, D_CB, -1, DH, DH, DH, DH / 2, 0, 0 }, b2 = { D_CB, D_CA, -1, DH, DH, DH, DH, 1, 1 };
-		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, cs>>>(ws, b1);
-		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, cs>>>(ws, b2);
+		k_dec_synth2d<256, true><<<2 * n < SYNTH_WGS ? 2 * n : SYNTH_WGS, 1024, 256 * 258 * sizeof(int16_t), cs>>>(ws, 1, 2 * n);      /* level 1 */
 		k_dec_sharpen<<<(2 * n + 3) / 4, 256, 0, cs>>>(ws);
 		HIPCHK(hipEventRecord(d->join_ev, cs));
 	}
@@ -1929,10 +1974,8 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	k_dec_shrink<<<dim3((DH - 2 + SHRINK_ROWS - 1) / SHRINK_ROWS, n), 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 4 */
 	{
-		/* level 2 luma: A (top-left 256x256) -> B -> level-1 LL back in A's top-left quarter */
-		SynthArgs p1 = { D_A, D_B, 0, DW, DH, DH, 0, 0, 0 }, p2 = { D_B, D_A, 0, DW, DH, DH, DH, 1, 1 };
-		k_dec_synth<<<dim3(DH / 16, n), 256, 0, s>>>(ws, p1);
-		k_dec_synth<<<dim3(DH / 16, n), 256, 0, s>>>(ws, p2);
+		/* level 2 luma: A's top-left 256 x 256 -> the level-1 LL in the same place */
+		k_dec_synth2d<256, false><<<n < SYNTH_WGS ? n : SYNTH_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(ws, 0, n);
 	}
 	STAGE_END();                                                                  /* 5 */
 	k_dec_resid<<<dim3(DH / RESID_ROWS, n), 256, 0, s>>>(ws);
@@ -1942,15 +1985,11 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	if (fork) HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
 	else {
 		/* chroma, both planes per launch (blockIdx.z) */
-		SynthArgs a1 = { D_CA, D_CB, -1, DH, DH / 2, DH / 2, 0, 0, 0 }, a2 = { D_CB, D_CA, -1, DH, DH / 2, DH / 2, DH / 2, 1, 1 };
-		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, s>>>(ws, a1);
-		k_dec_synth<<<dim3(DH / 32, n, 2), 256, 0, s>>>(ws, a2);
+		k_dec_synth2d<128, false><<<2 * n, 512, 128 * 130 * sizeof(int16_t), s>>>(ws, 1, 2 * n);
 		STAGE_END();                                                              /* 8 */
 		k_dec_cpairs<<<dim3(DH / CPAIR_ROWS, n, 2), 256, 0, s>>>(ws);
 		STAGE_END();                                                              /* 9 */
-		SynthArgs b1 = { D_CA, D_CB, -1, DH, DH, DH, DH / 2, 0, 0 }, b2 = { D_CB, D_CA, -1, DH, DH, DH, DH, 1, 1 };
-		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, s>>>(ws, b1);
-		k_dec_synth<<<dim3(DH / 16, n, 2), 256, 0, s>>>(ws, b2);
+		k_dec_synth2d<256, true><<<2 * n < SYNTH_WGS ? 2 * n : SYNTH_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(ws, 1, 2 * n);
 		STAGE_END();                                                              /* 10 */
 		k_dec_sharpen<<<(2 * n + 3) / 4, 256, 0, s>>>(ws);
 		STAGE_END();                                                              /* 11 */
