@@ -12,8 +12,9 @@
  *                  short-state chain for the placement rules; k_dec_unzig then moves the symbols to their cells
  *   k_dec_expand   pattern symbols -> coefficients, the +-1 nudge of the HH band, LL2 samples, odd-LL tags,
  *                  exception samples: one wavefront per image, the rows streaming through LDS in order
- *   k_dec_shrink, k_dec_synth2d (level 2 of the luma, levels 2 and 1 of both chroma planes: both directions of a
- *                  level on one LDS residency of the block), k_dec_resid, k_dec_marks, k_dec_cpairs, k_dec_sharpen
+ *   k_dec_luma_l2  level 2 of the luma on one LDS residency of the block: shrink, synthesis both ways, residual lists
+ *   k_dec_synth2d  levels 2 and 1 of both chroma planes, both directions of a level per launch
+ *   k_dec_marks, k_dec_cpairs, k_dec_sharpen
  *   k_dec_final    level 1 of the luma both ways, corrections, smoothing, chroma up-sampling, colour matrix -> BGR24
  *
  * Everything is int16/uint8 arithmetic; the only floating point is the colour matrix (compiled with
@@ -1259,24 +1260,18 @@ __global__ __launch_bounds__(256) void k_dec_expand_chroma(DecWs ws)
 	}
 }
 
-/* isolated level-2 coefficients shrink by one (:670-721); a pure stencil (a cell that shrinks has no neighbour that can) */
-#define SHRINK_ROWS 8                /* rows per workgroup: one row each made a million tiny workgroups per batch, and their dispatch was the kernel's time */
-__global__ __launch_bounds__(256) void k_dec_shrink(DecWs ws)
+/* add to element idx of an int16 array in LDS (dword-aligned base): compare-and-swap on the dword, the pointer stays a typed offset of
+ * the base so that it compiles to the LDS instruction */
+DEV void add_i16_at(int16_t *base, int idx, int delta)
 {
-	const int img = blockIdx.y, i0 = 1 + SHRINK_ROWS * blockIdx.x, j = threadIdx.x;
-	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
-	if (m->status || j < 1 || j > DH - 2) return;
-	const int diag = m->q <= 16 ? 16 : 8;
-	int16_t *p = plane_a(ws, img) + (size_t)i0 * DW + j;
-	/* a 3x3 window slides down the column on the values as they were: a cell that shrinks has no neighbour that can */
-	int u0 = p[-DW - 1], u1 = p[-DW], u2 = p[-DW + 1], c0 = p[-1], c1 = p[0], c2 = p[1];
-	for (int i = i0; i < i0 + SHRINK_ROWS && i <= DH - 2; i++, p += DW) {
-		const int d0 = p[DW - 1], d1 = p[DW], d2 = p[DW + 1];
-		if (iabs(c1) > 8 && !(i < DH / 2 && j < DH / 2) &&
-		    !(iabs(u0) > diag || iabs(u1) > 8 || iabs(u2) > diag || iabs(c0) > 8 || iabs(c2) > 8 || iabs(d0) > diag || iabs(d1) > 8 || iabs(d2) > diag))
-			*p = (int16_t)(c1 > 0 ? c1 - 1 : c1 + 1);
-		u0 = c0; u1 = c1; u2 = c2; c0 = d0; c1 = d1; c2 = d2;
-	}
+	unsigned *w = reinterpret_cast<unsigned *>(base) + (idx >> 1);
+	const int sh = (idx & 1) << 4;
+	unsigned old = *w, seen;
+	do {
+		seen = old;
+		const unsigned v = ((((seen >> sh) & 0xFFFFu) + (unsigned)delta) & 0xFFFFu) << sh;
+		old = atomicCAS(w, seen, (seen & ~(0xFFFFu << sh)) | v);
+	} while (old != seen);
 }
 
 /* ---------------------------------------------------------------------------------------------- synthesis (d4)
@@ -1359,78 +1354,150 @@ __global__ __launch_bounds__(S * 4) void k_dec_synth2d(DecWs ws, int chroma, int
 		lds_barrier();                                               /* the block is done with before the next one moves in */
 	}
 }
+/* ---------------------------------------------------------------------------------------------- level 2 of the luma (:670-787)
+ * Three passes of the reference on one LDS residency of the 256 x 256 block (plane A's top-left quarter), one launch:
+ *   shrink    isolated level-2 coefficients shrink by one (:670-721): a stencil on the values as they were -- a cell that shrinks cannot
+ *             have a neighbour that does, but its new value would read differently to that neighbour, so all decisions are taken (a
+ *             thread slides a 3 x 3 window down 64 rows of a column, a bit per row) before any is applied;
+ *   synthesis both directions, in place (see k_dec_synth2d): afterwards LDS holds sample (row c, column j) of the level-1 LL, in the
+ *             transposed orientation the plane keeps, at [j][c];
+ *   residuals the three residual lists onto it (:731-787): positions repeat, the steps commute: compare-and-swap adds on the LDS words;
+ * then column c of the LDS block leaves as row c of the plane.  Before: three kernels, each a round trip of the block (and the residual
+ * kernel read every list eight times, once per band of rows).  `upto`: the debug stop (1: write the block back after the shrink, 2: after
+ * the synthesis; 3: everything). */
+__global__ __launch_bounds__(1024) void k_dec_luma_l2(DecWs ws, int items, int upto)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
+	constexpr int S = DH, LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = 1024, NPRE = S * (S / 8) / NT_;
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	uint4 pre[NPRE];
+	if ((int)blockIdx.x < items) {
+		const int16_t *src = plane_a(ws, blockIdx.x);
+#pragma unroll
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * DW + 8 * (v % (S / 8))); }
+	}
+	for (int img = blockIdx.x; img < items; img += gridDim.x) {
+		int16_t *pl = plane_a(ws, img);
+		const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+		const bool skip = m->status != 0;
+		const int q = m->q;
+#pragma unroll
+		for (int u = 0; u < NPRE; u++) {
+			const int v = t + u * NT_, row = v / (S / 8), o = v % (S / 8);
+			uint32_t *d = reinterpret_cast<uint32_t *>(smem + row * LS + 8 * o);
+			d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
+		}
+		lds_barrier();
+		if (img + (int)gridDim.x < items) {
+			const int16_t *src = plane_a(ws, img + gridDim.x);
+#pragma unroll
+			for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * DW + 8 * (v % (S / 8))); }
+		}
+		{                                                            /* shrink: column j, rows 64 seg .. 64 seg + 63 (within 1 .. 254) */
+			const int j = t & (S - 1), seg = t >> 8, i_lo = seg ? 64 * seg : 1, i_hi = seg == 3 ? S - 2 : 64 * seg + 63;
+			const int diag = q <= 16 ? 16 : 8;
+			uint64_t hit = 0;
+			if (j >= 1 && j <= S - 2) {
+				const int16_t *x = smem + j;
+				int u0 = x[(i_lo - 1) * LS - 1], u1 = x[(i_lo - 1) * LS], u2 = x[(i_lo - 1) * LS + 1], c0 = x[i_lo * LS - 1], c1 = x[i_lo * LS], c2 = x[i_lo * LS + 1];
+				for (int i = i_lo; i <= i_hi; i++) {
+					const int d0 = x[(i + 1) * LS - 1], d1 = x[(i + 1) * LS], d2 = x[(i + 1) * LS + 1];
+					if (iabs(c1) > 8 && !(i < HLF && j < HLF) &&
+					    !(iabs(u0) > diag || iabs(u1) > 8 || iabs(u2) > diag || iabs(c0) > 8 || iabs(c2) > 8 || iabs(d0) > diag || iabs(d1) > 8 || iabs(d2) > diag))
+						hit |= 1ull << (i - i_lo);
+					u0 = c0; u1 = c1; u2 = c2; c0 = d0; c1 = d1; c2 = d2;
+				}
+			}
+			lds_barrier();
+			while (hit) {
+				const int i = i_lo + __builtin_ctzll(hit);
+				hit &= hit - 1;
+				int16_t *cell = smem + i * LS + j;
+				*cell = (int16_t)(*cell > 0 ? *cell - 1 : *cell + 1);
+			}
+			lds_barrier();
+		}
+		if (upto == 1) {
+			if (!skip)
+				for (int v = t; v < S * (S / 8); v += NT_) {
+					const int row = v / (S / 8), o = v % (S / 8);
+					const uint32_t *d = reinterpret_cast<const uint32_t *>(smem + row * LS + 8 * o);
+					*reinterpret_cast<uint4 *>(pl + (size_t)row * DW + 8 * o) = make_uint4(d[0], d[1], d[2], d[3]);
+				}
+			lds_barrier();
+			continue;
+		}
+		for (int i = 0; i < 16; i++) {                               /* along the rows, un-normalised */
+			int16_t *x = smem + (wv * 16 + i) * LS;
+			int e[PPL], o[PPL];
+#pragma unroll
+			for (int u = 0; u < PPL; u++) synth_pair<S>(x, 1, lane + 64 * u, false, e[u], o[u]);
+#pragma unroll
+			for (int u = 0; u < PPL; u++) reinterpret_cast<uint32_t *>(x)[lane + 64 * u] = (uint32_t)(uint16_t)e[u] | ((uint32_t)(uint16_t)o[u] << 16);
+		}
+		lds_barrier();
+		for (int i = 0; i < 16; i++) {                               /* along the columns, normalised, in place: sample 2k, 2k+1 of column c */
+			int16_t *x = smem + wv * 16 + i;
+			int e[PPL], o[PPL];
+#pragma unroll
+			for (int u = 0; u < PPL; u++) synth_pair<S>(x, LS, lane + 64 * u, true, e[u], o[u]);
+#pragma unroll
+			for (int u = 0; u < PPL; u++) { const int k = lane + 64 * u; x[(2 * k) * LS] = (int16_t)e[u]; x[(2 * k + 1) * LS] = (int16_t)o[u]; }
+		}
+		lds_barrier();
+		if (upto >= 3 && !skip) {                                    /* residual lists: plane cell (row, col) sits at [col][row] */
+			const uint8_t *f = ws.blob + ws.blob_off[img];
+#define ACC(row, col, d) add_i16_at(smem, (col) * LS + (row), (d))
+			if (q >= 21) {
+				const uint16_t *p5 = ws.buf<uint16_t>(D_P5, img);
+				const int cnt = (m->res5_bits - 1) * 8;
+				for (int k = t; k < cnt; k += NT_) { const int p = p5[k]; ACC(p >> 8, p & 255, bit_of(f + m->o_res5_word, m->res5_bits, k) ? -3 : 3); }
+			}
+			if (q > 12) {
+				const uint16_t *p1 = ws.buf<uint16_t>(D_P1, img);
+				const int amp = q >= 18 ? 5 : q >= 15 ? 7 : 9, cnt = (m->res1_bits - 1) * 8;
+				for (int k = t; k < cnt; k += NT_) { const int p = p1[k]; ACC(p >> 8, p & 255, bit_of(f + m->o_res1_word, m->res1_bits, k) ? -amp : amp); }
+			}
+			if (q >= 19) {
+				const uint16_t *p3 = ws.buf<uint16_t>(D_P3, img);
+				const uint8_t *w = f + m->o_res3_word;
+				const int cnt = (m->res3_bits * 2 - 2) * 4;
+				for (int k = t; k < cnt; k += NT_) {
+					const int p = p3[k], row = p >> 8, col = p & 255;
+					const int sel = (w[k >> 2] >> (6 - 2 * (k & 3))) & 3;
+					/* rows 254/255 reach below the level-1 LL: in the reference those cells are scratch that the next pass overwrites; here they are
+					 * the level-1 detail bands, so those adds are dropped */
+					const int d0 = sel == 1 ? -4 : sel == 0 ? 4 : sel == 2 ? 2 : -2, d1 = sel == 1 ? -3 : sel == 0 ? 3 : sel == 2 ? 2 : -2, d2 = sel == 2 ? 2 : sel == 3 ? -2 : 0;
+					ACC(row, col, d0);
+					if (row + 1 < DH) ACC(row + 1, col, d1);
+					if (d2 && row + 2 < DH) ACC(row + 2, col, d2);
+				}
+			}
+#undef ACC
+		}
+		lds_barrier();
+		if (!skip)
+		for (int i = 0; i < 16; i++) {                               /* column c of the block is row c of the plane */
+			const int c = wv * 16 + i;
+			uint32_t *dst = reinterpret_cast<uint32_t *>(pl + (size_t)c * DW);
+#pragma unroll
+			for (int u = 0; u < PPL; u++) {
+				const int k = lane + 64 * u;
+				dst[k] = (uint32_t)(uint16_t)smem[(2 * k) * LS + c] | ((uint32_t)(uint16_t)smem[(2 * k + 1) * LS + c] << 16);
+			}
+		}
+		lds_barrier();                                               /* the block is done with before the next one moves in */
+	}
+}
+
 #define SYNTH_WGS 256                /* one resident workgroup per CU for the 256 x 256 blocks */
 static int synth2d_attrs()
 {
 	int rc = NHW_OK;                                               /* per device: every handle sets it for its own */
 	const int big = 256 * 258 * (int)sizeof(int16_t);
-	if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_synth2d<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-	    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_synth2d<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) rc = NHW_E_HIP;
+	if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_synth2d<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+	    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_luma_l2), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) rc = NHW_E_HIP;
 	return rc;
-}
-
-/* ---------------------------------------------------------------------------------------------- residual lists (:731-787)
- * onto the level-1 LL (kept in the top-left quarter of plane A); positions may repeat, hence add_i16 */
-/* A workgroup takes a band of 32 rows of the level-1 LL: it reads the lists (they are short), sums the steps that land in its band in LDS
- * (positions repeat, the sums commute) and adds the band to the plane once, coalesced.  One compare-and-swap on the 32-bit word per
- * step in global memory took 0.85 ms per batch. */
-#define RESID_ROWS 32
-__global__ __launch_bounds__(256) void k_dec_resid(DecWs ws)
-{
-	__shared__ int acc[RESID_ROWS * DH];
-	const int img = blockIdx.y, tid = threadIdx.x, row0 = RESID_ROWS * blockIdx.x;
-	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
-	if (m->status) return;
-	const int q = m->q;
-	const uint8_t *f = ws.blob + ws.blob_off[img];
-	for (int k = tid; k < RESID_ROWS * DH; k += 256) acc[k] = 0;
-	__syncthreads();
-#define IN_BAND(row) ((unsigned)((row) - row0) < (unsigned)RESID_ROWS)
-#define ACC(row, col, d) atomicAdd(&acc[((row) - row0) * DH + (col)], (d))
-	if (q >= 21) {
-		const uint16_t *p5 = ws.buf<uint16_t>(D_P5, img);
-		const int cnt = (m->res5_bits - 1) * 8;
-		for (int k = tid; k < cnt; k += 256) {
-			const int p = p5[k], row = p >> 8;
-			if (IN_BAND(row)) ACC(row, p & 255, bit_of(f + m->o_res5_word, m->res5_bits, k) ? -3 : 3);
-		}
-	}
-	if (q > 12) {
-		const uint16_t *p1 = ws.buf<uint16_t>(D_P1, img);
-		const int amp = q >= 18 ? 5 : q >= 15 ? 7 : 9, cnt = (m->res1_bits - 1) * 8;
-		for (int k = tid; k < cnt; k += 256) {
-			const int p = p1[k], row = p >> 8;
-			if (IN_BAND(row)) ACC(row, p & 255, bit_of(f + m->o_res1_word, m->res1_bits, k) ? -amp : amp);
-		}
-	}
-	if (q >= 19) {
-		const uint16_t *p3 = ws.buf<uint16_t>(D_P3, img);
-		const uint8_t *w = f + m->o_res3_word;
-		const int cnt = (m->res3_bits * 2 - 2) * 4;
-		for (int k = tid; k < cnt; k += 256) {
-			const int p = p3[k], row = p >> 8, col = p & 255;
-			if (row + 2 < row0 || row >= row0 + RESID_ROWS) continue;
-			const int sel = (w[k >> 2] >> (6 - 2 * (k & 3))) & 3;
-			/* rows 254/255 reach below the level-1 LL: in the reference those cells are scratch that the next pass overwrites; here they are
-			 * the level-1 detail bands, so those adds are dropped */
-			const int d0 = sel == 1 ? -4 : sel == 0 ? 4 : sel == 2 ? 2 : -2, d1 = sel == 1 ? -3 : sel == 0 ? 3 : sel == 2 ? 2 : -2, d2 = sel == 2 ? 2 : sel == 3 ? -2 : 0;
-			if (IN_BAND(row)) ACC(row, col, d0);
-			if (row + 1 < DH && IN_BAND(row + 1)) ACC(row + 1, col, d1);
-			if (d2 && row + 2 < DH && IN_BAND(row + 2)) ACC(row + 2, col, d2);
-		}
-	}
-#undef IN_BAND
-#undef ACC
-	__syncthreads();
-	int16_t *c = plane_a(ws, img) + (size_t)row0 * DW;
-	for (int k = tid; k < RESID_ROWS * DH / 2; k += 256) {
-		const int r = k / (DH / 2), o = k % (DH / 2);
-		const int a0 = acc[r * DH + 2 * o], a1 = acc[r * DH + 2 * o + 1];
-		if (!(a0 | a1)) continue;
-		uint32_t *wp = reinterpret_cast<uint32_t *>(c + (size_t)r * DW) + o;
-		const uint32_t v = *wp;
-		*wp = ((v + (uint32_t)a0) & 0xFFFFu) | ((((v >> 16) + (uint32_t)a1) & 0xFFFFu) << 16);
-	}
 }
 
 /* ---------------------------------------------------------------------------------------------- smooth-edge marks (:789-848)
@@ -1638,19 +1705,6 @@ DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
 #define FM (FR / 2 + 1)              /* values of m a band computes: r0/2 - 1 .. r0/2 + FR/2 - 1 */
 #define F_T_BYTES (2 * DH * FBP * 2)
 #define F_LDS_BYTES (F_T_BYTES + FR * DW + 2 * (FR / 2 + 1) * DH)   /* T, the luma bytes, the chroma rows: 31 KB, five bands to a CU */
-/* add to element idx of an int16 array in LDS (dword-aligned base): compare-and-swap on the dword, the pointer stays a typed offset of
- * the base so that it compiles to the LDS instruction */
-DEV void add_i16_at(int16_t *base, int idx, int delta)
-{
-	unsigned *w = reinterpret_cast<unsigned *>(base) + (idx >> 1);
-	const int sh = (idx & 1) << 4;
-	unsigned old = *w, seen;
-	do {
-		seen = old;
-		const unsigned v = ((((seen >> sh) & 0xFFFFu) + (unsigned)delta) & 0xFFFFu) << sh;
-		old = atomicCAS(w, seen, (seen & ~(0xFFFFu << sh)) | v);
-	} while (old != seen);
-}
 __global__ __launch_bounds__(256) void k_dec_final(DecWs ws, uint8_t *out, int dev_stop /* developer builds: end every band after phase dev_stop (0: run it all) */)
 {
 #ifdef NHW_DEV
@@ -1885,7 +1939,7 @@ extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
 		HIPCHK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&d->join_ev, hipEventDisableTiming));
 		for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&d->ev[i]));
-		if (synth2d_attrs() != NHW_OK) { g_derr = "hipFuncSetAttribute(k_dec_synth2d<256>, 129 KB of LDS) failed"; return NHW_E_HIP; }
+		if (synth2d_attrs() != NHW_OK) { g_derr = "hipFuncSetAttribute(129 KB of LDS for the block kernels) failed"; return NHW_E_HIP; }
 		return NHW_OK;
 	}();
 	if (rc != NHW_OK) { nhw_dec_destroy(d); return rc; }
@@ -1971,14 +2025,13 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 		HIPCHK(hipEventRecord(d->join_ev, cs));
 	}
 	STAGE_END();                                                                  /* 3 */
-	k_dec_shrink<<<dim3((DH - 2 + SHRINK_ROWS - 1) / SHRINK_ROWS, n), 256, 0, s>>>(ws);
-	STAGE_END();                                                                  /* 4 */
 	{
-		/* level 2 luma: A's top-left 256 x 256 -> the level-1 LL in the same place */
-		k_dec_synth2d<256, false><<<n < SYNTH_WGS ? n : SYNTH_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(ws, 0, n);
+		/* level 2 of the luma: shrink, synthesis, residual lists on A's top-left 256 x 256 -> the level-1 LL in the same place */
+		const int upto = d->stop_after == 4 ? 1 : d->stop_after == 5 ? 2 : 3;
+		k_dec_luma_l2<<<n < SYNTH_WGS ? n : SYNTH_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(ws, n, upto);
 	}
-	STAGE_END();                                                                  /* 5 */
-	k_dec_resid<<<dim3(DH / RESID_ROWS, n), 256, 0, s>>>(ws);
+	STAGE_END();                                                                  /* 4 (the block as the shrink leaves it) */
+	STAGE_END();                                                                  /* 5 (after the synthesis) */
 	STAGE_END();                                                                  /* 6 */
 	k_dec_marks<<<(n + 3) / 4, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 7 */
