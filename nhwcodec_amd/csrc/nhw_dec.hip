@@ -1506,10 +1506,6 @@ static int synth2d_attrs()
  * cell to the left.  One wavefront per image walks the rows in order; a lane owns two pairs (cells 4l+1 .. 4l+4),
  * evaluates them for both states of the cell on its left, and the chain of "my last cell is marked" along the row
  * is settled on the ballots.  Output: the marked positions in raster order. */
-DEV int lap_at(const int16_t *p)
-{
-	return (p[0] << 3) - p[-1] - p[1] - p[-DW] - p[DW] - p[-DW - 1] - p[DW - 1] - p[-DW + 1] - p[DW + 1];
-}
 DEV void pair_decide(int r0, int r1, int &m0, int &m1)
 {
 	/* (as an if / else-if chain that sets one of the two, the compiler made the pair an array in scratch memory) */
@@ -1528,11 +1524,33 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 	int total = 0;
 	if (lane < 2) rowstart[lane] = 0;
 	unsigned above = 0;                                             /* marks of the row above on my cells 4l+1..4l+4 (bits 0..3) */
-	for (int i = 1; i < DH - 1; i++) {
-		const int16_t *p = c + (size_t)i * DW + 4 * lane + 1;
-		int base[4];
+	/* A lane's Laplacians need columns 4l .. 4l+5 of three rows: one 16-byte load per row (4l .. 4l+7), the rows rolling through registers
+	 * and MK_AHEAD more on their way -- the marks chain runs down the rows, the loads do not depend on it.  (Nine 2-byte loads per cell and
+	 * a wait per row were 2 us a row.) */
+	struct __attribute__((aligned(8))) Row8 { uint32_t w[4]; };
+	auto ld = [&](int r) { return *reinterpret_cast<const Row8 *>(c + (size_t)(r < DW ? r : DW - 1) * DW + 4 * lane); };
+	auto cells = [](const Row8 &r, int *v) {
 #pragma unroll
-		for (int k = 0; k < 4; k++) base[k] = (lane < 63 || k < 2) ? lap_at(p + k) : 0;
+		for (int e = 0; e < 3; e++) { v[2 * e] = (int16_t)(r.w[e] & 0xFFFFu); v[2 * e + 1] = (int16_t)(r.w[e] >> 16); }
+	};
+#define MK_AHEAD 4
+	int up[6], mid[6], dn[6];
+	{ const Row8 r0 = ld(0), r1 = ld(1); cells(r0, up); cells(r1, mid); }
+	Row8 fly[MK_AHEAD];
+#pragma unroll
+	for (int g = 0; g < MK_AHEAD; g++) fly[g] = ld(2 + g);
+	for (int i = 1; i < DH - 1; i++) {
+		cells(fly[0], dn);
+#pragma unroll
+		for (int g = 0; g + 1 < MK_AHEAD; g++) fly[g] = fly[g + 1];
+		fly[MK_AHEAD - 1] = ld(i + 1 + MK_AHEAD);
+		int cs[6], base[4];
+#pragma unroll
+		for (int x = 0; x < 6; x++) cs[x] = up[x] + mid[x] + dn[x];
+#pragma unroll
+		for (int k = 0; k < 4; k++) base[k] = (lane < 63 || k < 2) ? 9 * mid[k + 1] - (cs[k] + cs[k + 1] + cs[k + 2]) : 0;
+#pragma unroll
+		for (int x = 0; x < 6; x++) { up[x] = mid[x]; mid[x] = dn[x]; }
 		/* marks above cells 4l .. 4l+5 as bits 0..5 */
 		const unsigned fromL = (unsigned)__shfl((int)above, (lane + 63) & 63), fromR = (unsigned)__shfl((int)above, (lane + 1) & 63);
 		const unsigned ab = (lane ? (fromL >> 3) & 1u : 0u) | (above << 1) | (lane < 63 ? (fromR & 1u) << 5 : 0u);
@@ -1567,6 +1585,7 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 		if (!lane) rowstart[i + 1] = (uint16_t)total;
 	}
 	if (!lane) { m->nmarks = total; rowstart[DH] = (uint16_t)total; }
+#undef MK_AHEAD
 }
 
 /* ---------------------------------------------------------------------------------------------- chroma
