@@ -38,12 +38,13 @@ namespace {
 /* ---------------------------------------------------------------------------------------------- workspace
  * structure of arrays over the batch: buffer b of image i at base + off[b] + i * size[b] */
 enum {
-	D_META, D_LL, D_SPARE, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_CU, D_COUNT
+	D_META, D_LL, D_SPARE, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_CU, D_SEG, D_COUNT
 };
 enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304 /* sanity bound on the packet words of a file (the encoder's buffer holds 80000) */ };
 const size_t k_dec_bytes[D_COUNT] = {
 	/* META */ 512, /* LL */ 24832, /* SPARE */ 1024, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
-	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 8 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 2 * (2 * DQ + 4096), /* CU */ 2 * DQ
+	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 16 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 8 * DQ + 8192, /* CU */ 2 * DQ,
+	/* SEG */ 5120
 };
 
 struct DecMeta {
@@ -72,18 +73,24 @@ struct DecWs {
 		switch (b) {
 		case D_META: return 512; case D_LL: return 24832; case D_SPARE: return 1024;
 		case D_P1: case D_P3: case D_P5: return P16_CAP * 2; case D_P6: return (size_t)P6_CAP * 4;
-		case D_MARKS: return 2 * DQ; case D_A: case D_B: return 8 * DQ + 8192;
-		case D_CA: case D_CB: return 2 * (2 * DQ + 4096); default: return 2 * DQ;
+		case D_MARKS: return 2 * DQ; case D_A: return 8 * DQ + 8192; case D_B: return 16 * DQ + 8192;
+		case D_CA: return 2 * (2 * DQ + 4096); case D_CB: return 8 * DQ + 8192; case D_SEG: return 5120; default: return 2 * DQ;
 		}
 	}
 };
 
-/* planes: A and B start 4096 bytes into their buffers (the reference writes one cell in front of a plane in a corner case) */
+/* plane A starts 4096 bytes into its buffer (the reference writes one cell in front of a plane in a corner case) */
 DEV int16_t *plane_a(const DecWs &ws, int img) { return ws.buf<int16_t>(D_A, img) + 2048; }
-DEV int16_t *plane_b(const DecWs &ws, int img) { return ws.buf<int16_t>(D_B, img) + 2048; }
+/* D_B / D_CB: what the prefix-code walk found, as a list in stream order -- (value << 18) | position in the stream, one word per value that
+ * is not part of a zero run (at most one per cell, plus a few words of slack) -- and D_SEG: the index of the first entry at or behind the
+ * start of every segment of the stream the un-zig-zag takes in one piece (luma: 1024 segments of 256 symbols from word 0, chroma: 128 of
+ * 1024 interleaved symbols from word SEG_CHROMA), with the total behind the last one */
+#define SEG_CHROMA 1040
+#define ENT_POS(e) ((int)((e) & 0x3FFFFu))
+#define ENT_VAL(e) ((int)(e) >> 18)
+#define ENT_MAKE(pos, v) (((uint32_t)(v) << 18) | (uint32_t)(pos))
 DEV uint16_t *mark_rows(const DecWs &ws, int img) { return ws.buf<uint16_t>(D_SPARE, img) + 8; }   /* behind the verdict word */
 DEV int16_t *plane_ca(const DecWs &ws, int img, int comp) { return ws.buf<int16_t>(D_CA, img) + 1024 + (size_t)comp * (DQ + 2048); }
-DEV int16_t *plane_cb(const DecWs &ws, int img, int comp) { return ws.buf<int16_t>(D_CB, img) + 1024 + (size_t)comp * (DQ + 2048); }
 
 DEV int iabs(int v) { return v < 0 ? -v : v; }
 DEV int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
@@ -662,6 +669,20 @@ DEV int luma_literal(int word, int lvl, int &second)                /* value of 
 	}
 }
 
+/* index of the first entry at or behind the start of each of the nseg segments (1 << shift stream positions each) of a list the calling
+ * wavefront has just written, and the total behind them: entry k opens every segment from the one after its predecessor's up to its own */
+DEV void segment_index(const uint32_t *ent, int n, int shift, int nseg, uint32_t *segt, int lane)
+{
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          /* the entries are this wavefront's own stores */
+	__builtin_amdgcn_wave_barrier();
+	for (int k0 = 0; k0 < n + 1; k0 += 64) {
+		const int k = k0 + lane;
+		if (k > n) continue;
+		const int cur = k < n ? ENT_POS(ent[k]) >> shift : nseg, prev = k ? ENT_POS(ent[k - 1]) >> shift : -1;
+		for (int sg = prev + 1; sg <= cur; sg++) segt[sg] = (uint32_t)k;
+	}
+}
+
 __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 {
 	__shared__ uint16_t lut[256], lut2[16 * 64];
@@ -669,7 +690,6 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 	__shared__ int16_t level[2][354];
 	__shared__ __attribute__((aligned(16))) uint32_t cw[2][VCH_WORDS + 4];
 	__shared__ uint16_t syms[2][VCH_SYMS];
-	__shared__ __attribute__((aligned(16))) uint8_t scr[2][1440];
 	/* The kernel runs next to k_dec_parse on a stream of its own, so it reads the file header itself (a few dozen bytes) instead of the
 	 * workspace copy, and reports into a word of its own (D_SPARE[0]) that k_dec_verdict folds into the file's status. */
 	__shared__ DecMeta hm;
@@ -686,7 +706,7 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 	const DecMeta *m = &hm;
 	if (m->status) return;
 	if (!part) vlc_fill_lut(lut, lut2, lane);
-	if (!lane) build_book_small(part ? f + m->o_book2 : f + m->o_book1, part ? m->book2_len : m->book1_len, part != 0, m->tree_end, book[part], scr[part]);
+	if (!lane) build_book_small(part ? f + m->o_book2 : f + m->o_book1, part ? m->book2_len : m->book1_len, part != 0, m->tree_end, book[part], reinterpret_cast<uint8_t *>(syms[part]) /* 1440 bytes of scratch, before the first chunk is parsed */);
 	__syncthreads();
 	for (int r = lane; r < 354; r += 64) level[part][r] = (int16_t)plain_level(book[part][r] & 255);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -698,7 +718,12 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 	const int nchunks = (nwords + VCH_WORDS - 1) / VCH_WORDS + 1;       /* one more: zero bits behind the stream decode as words too, as in the reference */
 	int bad = 0, start0 = 0;
 	if (!part) {
-		int16_t *a = plane_b(ws, img);                                /* stream order */
+		/* The symbols leave as a list of (position in the stream, value) in stream order -- a q20 file has a few thousand values for its
+		 * 262 144 luma cells -- with the index of the first entry of every segment of the stream that the un-zig-zag takes in one piece: it
+		 * clears its tile in LDS and drops the entries of the tile's segments in.  (Before: the stream itself, 512 KB per file, zeroed by a
+		 * fill, written here value by value and read back whole.) */
+		uint32_t *ent = ws.buf<uint32_t>(D_B, img);
+		int nE = 0;
 		const uint8_t *s1 = f + m->o_sel1, *s2 = f + m->o_sel2;
 		const int n1 = m->select1, n2 = m->select2;
 		const bool zoned = m->res_high < 4;
@@ -725,41 +750,51 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 				const int adv = have ? put + (is_run ? rle : (lit5 ? 5 : 1)) : 0;
 				int pe = adv, p1 = have && put && which == 1 ? 1 : 0, p2 = have && put && which == 2 ? 1 : 0;
 				const int q1 = p1, q2 = p2;
-				for (int d = 1; d < 64; d <<= 1) {
-					const int oe = __shfl_up(pe, d), o1 = __shfl_up(p1, d), o2 = __shfl_up(p2, d);
-					if (lane >= d) { pe += oe; p1 += o1; p2 += o2; }
+				const int nw = have ? put + (is_run ? 0 : lit5 ? 2 : 1) : 0;   /* list entries of this symbol */
+				int pw = nw;
+				{                                                           /* four prefix sums as two: a batch advances at most 64 x 255 cells and writes at most 192 entries */
+					int sa = pe | (pw << 16), sb = p1 | (p2 << 16);
+					for (int d = 1; d < 64; d <<= 1) {
+						const int oa = __shfl_up(sa, d), ob = __shfl_up(sb, d);
+						if (lane >= d) { sa += oa; sb += ob; }
+					}
+					pe = sa & 0xFFFF; pw = sa >> 16; p1 = sb & 0xFFFF; p2 = sb >> 16;
 				}
 				const int at = e + pe - adv;
 				const bool live = have && at < limit;                       /* the reference's loop test: a symbol is taken while e < limit */
-				if (live) {
-					int pos = at;
+				if (live) {                                                 /* (at < limit: every position but the last of a 132..135 symbol is inside the stream) */
+					int pos = at, k = nE + pw - nw;
+#define ENTRY(P, V) do { ent[k++] = ENT_MAKE(P, V); } while (0)
 					if (put) {
 						int neg;
-						if (which == 1) { const int k = t1 + p1 - q1; neg = (k >> 3) < n1 ? (s1[k >> 3] >> (7 - (k & 7))) & 1 : 0; }
-						else { const int k = t2 + p2 - q2; neg = !((k >> 3) < n2 ? (s2[k >> 3] >> (7 - (k & 7))) & 1 : 0); }
-						if (pos < 4 * DQ) a[pos] = (int16_t)(neg ? -11 : 11);
+						if (which == 1) { const int kk = t1 + p1 - q1; neg = (kk >> 3) < n1 ? (s1[kk >> 3] >> (7 - (kk & 7))) & 1 : 0; }
+						else { const int kk = t2 + p2 - q2; neg = !((kk >> 3) < n2 ? (s2[kk >> 3] >> (7 - (kk & 7))) & 1 : 0); }
+						ENTRY(pos, neg ? -11 : 11);
 						pos++;
 					}
 					if (!is_run) {
 						int second;
 						const int v = luma_literal(word, lv[rank], second);
-						if (pos < 4 * DQ) a[pos] = (int16_t)v;
-						if (lit5 && pos + 4 < 4 * DQ) a[pos + 4] = (int16_t)second;
+						ENTRY(pos, v);
+						if (lit5) { if (pos + 4 < 4 * DQ) ENTRY(pos + 4, second); else ENTRY(pos, v); }   /* past the end: the slot repeats the value */
 					}
+#undef ENTRY
 				}
 				const uint64_t lm = __ballot(live);
 				if (lm != __ballot(have)) done = true;
 				if (lm) {
 					const int last = 63 - __builtin_clzll(lm);
-					e += __shfl(pe, last); t1 += __shfl(p1, last); t2 += __shfl(p2, last);
+					e += __shfl(pe, last); t1 += __shfl(p1, last); t2 += __shfl(p2, last); nE += __shfl(pw, last);
 					carry = (unsigned)__shfl((int)sout, last);
 				}
 				if (e >= limit) done = true;
 			}
 			if (c >= nchunks - 1 && !done && (c + 1) * VCH_WORDS > nwords + 8) { bad = 1; break; }   /* ran out of stream before the last cell */
 		}
+		segment_index(ent, nE, 8, 1024, ws.buf<uint32_t>(D_SEG, img), lane);
 	} else {
-		int16_t *cs = plane_cb(ws, img, 0);                           /* U and V interleaved, stream order */
+		uint32_t *ent = ws.buf<uint32_t>(D_CB, img);                  /* U on even, V on odd stream positions */
+		int nE = 0;
 		const int limit = 2 * DQ - 2;
 		int e = 0;
 		bool done = false;
@@ -770,66 +805,77 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 				const int rank = have ? syms[1][base + lane] : 0;
 				const int bkv = bk[rank], word = bkv & 255;
 				const bool is_run = word == 128;
-				const int adv = have ? (is_run ? bkv >> 8 : 1) : 0;
-				int pe = adv;
-				for (int d = 1; d < 64; d <<= 1) { const int oe = __shfl_up(pe, d); if (lane >= d) pe += oe; }
+				const int adv = have ? (is_run ? bkv >> 8 : 1) : 0, nw = have && !is_run ? 1 : 0;
+				int sa = adv | (nw << 16);
+				for (int d = 1; d < 64; d <<= 1) { const int oa = __shfl_up(sa, d); if (lane >= d) sa += oa; }
+				const int pe = sa & 0xFFFF, pw = sa >> 16;
 				const int at = e + pe - adv;
 				const bool live = have && at < limit;
 				if (live && !is_run) {
 					const int v = word == 124 ? 5005 : word == 126 ? 5006 : word == 122 ? 5003 : word == 130 ? 5004 : lv[rank];
-					if (at < 2 * DQ) cs[at] = (int16_t)v;
+					ent[nE + pw - 1] = ENT_MAKE(at, v);
 				}
 				const uint64_t lm = __ballot(live);
 				if (lm != __ballot(have)) done = true;
-				if (lm) e += __shfl(pe, 63 - __builtin_clzll(lm));
+				if (lm) { const int last = 63 - __builtin_clzll(lm); e += __shfl(pe, last); nE += __shfl(pw, last); }
 				if (e >= limit) done = true;
 			}
 			if (c >= nchunks - 1 && !done && (c + 1) * VCH_WORDS > nwords + 8) { bad = 1; break; }
 		}
+		segment_index(ent, nE, 10, 128, ws.buf<uint32_t>(D_SEG, img) + SEG_CHROMA, lane);
 	}
 	if (__any(bad) && !lane) atomicExch(verdict, (int)NHW_E_FORMAT);
 }
 
 /* ---------------------------------------------------------------------------------------------- un-zig-zag
  * nhw_decoder.c:71-91 (luma: strips of 4 columns, serpentine down the rows) and :904-932 / :1192-1220 (chroma: strips of 8
- * columns, U on even and V on odd stream positions).  The walk above stores in stream order, where neighbouring stores share
- * a cache line; putting a symbol straight into its cell instead would touch a different row for every fourth symbol, and a row's
- * line would be fetched and written back once per strip.  Here a workgroup moves a 64 x 64 tile through LDS: contiguous runs of
- * the stream in, whole rows out.  blockIdx.x < 64: luma tiles; then 16 tiles that each do U and V. */
+ * columns, U on even and V on odd stream positions).  A workgroup builds a 64 x 64 tile of the plane in LDS -- zeros (the reference's
+ * calloc: a zero run is a skip), then the entries of the tile's pieces of the stream (a strip's 64 rows are one contiguous segment of it:
+ * 256 luma symbols, 1024 interleaved chroma symbols) -- and writes whole rows.  Putting a symbol straight into its cell from the walk
+ * would touch a different row for every fourth symbol, and a row's line would be written back once per strip.
+ * blockIdx.x < 64: luma tiles; then 16 tiles that each do U and V. */
 __global__ __launch_bounds__(256) void k_dec_unzig(DecWs ws)
 {
-	__shared__ int16_t tile[2][64][66];
+	__shared__ __attribute__((aligned(16))) int16_t tile[2][64][66];
 	const int img = blockIdx.y, tid = threadIdx.x;
 	if (*ws.buf<int>(D_SPARE, img)) return;                        /* the walk's verdict (header included): the workspace header may still be in the making */
-	if (blockIdx.x < 64) {
+	const uint32_t *segt = ws.buf<uint32_t>(D_SEG, img);
+	const bool luma = blockIdx.x < 64;
+	for (int k = tid; k < (luma ? 1 : 2) * 64 * 66 / 2; k += 256) reinterpret_cast<uint32_t *>(&tile[0][0][0])[k] = 0;
+	const int row = tid >> 2, c0 = (tid & 3) * 16;
+	auto put_row = [&](int comp, int16_t *dst) {
+		const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile[comp][row][c0]);
+		reinterpret_cast<uint4 *>(dst)[0] = make_uint4(t[0], t[1], t[2], t[3]);
+		reinterpret_cast<uint4 *>(dst)[1] = make_uint4(t[4], t[5], t[6], t[7]);
+	};
+	if (luma) {
 		const int cg = blockIdx.x & 7, rg = blockIdx.x >> 3;
-		const int16_t *sb = plane_b(ws, img);
-		int16_t *a = plane_a(ws, img);
-		const int s = tid >> 4, j = tid & 15;                       /* strip within the tile, 16 symbols of its 256 */
-		const int16_t *src = sb + (size_t)(cg * 16 + s) * 2048 + rg * 256 + 16 * j;
-		for (int k = 0; k < 16; k++) {
-			const int w = 16 * j + k, rp = w >> 3, idx = w & 7;
-			tile[0][2 * rp + (idx >> 2)][4 * s + ((idx & 4) ? 7 - idx : idx)] = src[k];
+		const uint32_t *ent = ws.buf<uint32_t>(D_B, img);
+		const int s = tid >> 4, j = tid & 15;                       /* strip within the tile, every 16th of its entries */
+		const int seg = (cg * 16 + s) * 8 + rg;
+		const int lo = (int)segt[seg], hi = (int)segt[seg + 1];
+		__syncthreads();
+		for (int k = lo + j; k < hi; k += 16) {
+			const uint32_t en = ent[k];
+			const int w = ENT_POS(en) & 255, rp = w >> 3, idx = w & 7;
+			tile[0][2 * rp + (idx >> 2)][4 * s + ((idx & 4) ? 7 - idx : idx)] = (int16_t)ENT_VAL(en);
 		}
 		__syncthreads();
-		const int row = tid >> 2, c0 = (tid & 3) * 16;
-		int16_t *dst = a + (size_t)(rg * 64 + row) * DW + cg * 64 + c0;
-		for (int k = 0; k < 16; k++) dst[k] = tile[0][row][c0 + k];
+		put_row(0, plane_a(ws, img) + (size_t)(rg * 64 + row) * DW + cg * 64 + c0);
 	} else {
 		const int b = blockIdx.x - 64, cg = b & 3, rg = b >> 2;
-		const int16_t *cs = plane_cb(ws, img, 0);
-		const int s = tid >> 5, j = tid & 31;                       /* strip within the tile (8 of 8 columns), 32 of its 1024 interleaved symbols */
-		const int16_t *src = cs + 2 * ((size_t)(cg * 8 + s) * 2048 + rg * 512) + 32 * j;
-		for (int k = 0; k < 32; k++) {
-			const int w = (32 * j + k) >> 1, comp = k & 1, rp = w >> 4, idx = w & 15;
-			tile[comp][2 * rp + (idx >> 3)][8 * s + ((idx & 8) ? 15 - idx : (idx & 7))] = src[k];
+		const uint32_t *ent = ws.buf<uint32_t>(D_CB, img);
+		const int s = tid >> 5, j = tid & 31;                       /* strip within the tile (8 of 8 columns), every 32nd of its entries */
+		const int seg = (cg * 8 + s) * 4 + rg;
+		const int lo = (int)segt[SEG_CHROMA + seg], hi = (int)segt[SEG_CHROMA + seg + 1];
+		__syncthreads();
+		for (int k = lo + j; k < hi; k += 32) {
+			const uint32_t en = ent[k];
+			const int i = ENT_POS(en) & 1023, comp = i & 1, w = i >> 1, rp = w >> 4, idx = w & 15;
+			tile[comp][2 * rp + (idx >> 3)][8 * s + ((idx & 8) ? 15 - idx : (idx & 7))] = (int16_t)ENT_VAL(en);
 		}
 		__syncthreads();
-		const int row = tid >> 2, c0 = (tid & 3) * 16;
-		for (int comp = 0; comp < 2; comp++) {
-			int16_t *dst = plane_ca(ws, img, comp) + (size_t)(rg * 64 + row) * DH + cg * 64 + c0;
-			for (int k = 0; k < 16; k++) dst[k] = tile[comp][row][c0 + k];
-		}
+		for (int comp = 0; comp < 2; comp++) put_row(comp, plane_ca(ws, img, comp) + (size_t)(rg * 64 + row) * DH + cg * 64 + c0);
 	}
 }
 
@@ -2014,9 +2060,6 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 #define STAGE_END() do { if (d->stop_after && ++stage >= d->stop_after) goto done; } while (0)
 #define EV(i) HIPCHK(hipEventRecord(d->ev[i], s))
 	EV(0);
-	/* the symbol streams start from zero (the reference's calloc, nhw_decoder.c:2029, :894): a zero run is a skip */
-	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_B], 0, k_dec_bytes[D_B] * (size_t)n, s));
-	HIPCHK(hipMemsetAsync(ws.base + ws.off[D_CB], 0, k_dec_bytes[D_CB] * (size_t)n, s));
 	/* Two entropy branches that only meet at the expansion: the side streams (LL2 DPCM, position lists; latency-bound scans) on the caller's
 	 * stream, the prefix-code walk and the un-zig-zag on the second one. */
 	if (fork) { HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0)); }
