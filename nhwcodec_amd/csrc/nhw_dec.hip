@@ -1718,17 +1718,18 @@ DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
 		 * (1/100000 for G) and the rounding errors are some 1e-13, so the truncation can only differ from the integer quotient below where
 		 * the exact value IS an integer: never for R, harmlessly for B, and for G at 493 of the 2^24 triples -- those take the double path
 		 * (checked against the double evaluation over all 2^24 triples).  Negative values and values from 256 clip either way. */
-		const int Y = yv, U = uv - 128, V = vv - 128;
-		/* every product fits the full-rate 24-bit multiplier; n / 1000 = (n * 8589935) >> 33 for n < 2^19, and
-		 * n / 100000 = ((n >> 5) * 10995117) >> 35 for n < 2^26 (floor(floor(n / 32) / 3125)) */
-		const int base = __mul24(Y, 1000) + 500;
-		const int nR = base + __mul24(V, 1402), nB = base + __mul24(U, 1772);
-		const int nG = __mul24(Y, 100000) - __mul24(U, 34414) - __mul24(V, 71414) + 50000;
-		R = (int)min(mulhi_u24((unsigned)max(nR, 0), 8589935u) >> 1, 255u);
-		B = (int)min(mulhi_u24((unsigned)max(nB, 0), 8589935u) >> 1, 255u);
-		const unsigned gq = mulhi_u24((unsigned)max(nG, 0) >> 5, 10995117u) >> 3;
-		G = (int)min(gq, 255u);
-		if (nG > 0 && (unsigned)__mul24((int)gq, 100000) == (unsigned)nG) G = (int)(Y - 0.34414 * U - 0.71414 * V + 0.5f);
+		/* every product fits the full-rate 24-bit multiplier; the -128 of U and V sit in the constants; one v_med3 clamps a numerator to the
+		 * range whose quotient is 0 .. 255; n / 1000 = (n * 4294968) >> 32 for n < 256000 and n / 100000 = ((n >> 5) * 1374390) >> 32 for
+		 * n < 25.6e6 (floor(floor(n / 32) / 3125)): the quotient is the multiplier's high half, no shift behind it
+		 * (tests/test_dec_colour_formula.py evaluates exactly this arithmetic against the double form on all 2^24 triples) */
+		const int nR = __mul24(vv, 1402) + (__mul24(yv, 1000) + (500 - 1402 * 128));
+		const int nB = __mul24(uv, 1772) + (__mul24(yv, 1000) + (500 - 1772 * 128));
+		const int nG = __mul24(yv, 100000) - __mul24(uv, 34414) - __mul24(vv, 71414) + (50000 + (34414 + 71414) * 128);
+		R = (int)mulhi_u24((unsigned)min(max(nR, 0), 255999), 4294968u);
+		B = (int)mulhi_u24((unsigned)min(max(nB, 0), 255999), 4294968u);
+		const int gq = (int)mulhi_u24((unsigned)min(max(nG, 0), 25599999) >> 5, 1374390u);
+		G = gq;
+		if (nG > 0 && __mul24(gq, 100000) == nG) G = clip8((int)(yv - 0.34414 * (uv - 128) - 0.71414 * (vv - 128) + 0.5f));
 	}
 	else if (q >= 18) {
 		const float yinv = q == 19 ? 1.025641f : 1.075269f;
@@ -1748,7 +1749,7 @@ DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
 		G = ((int)((Y - 100 * U - 208 * V + (34784 - 128)) * yinv + 128.5f)) >> 8;
 		B = ((int)((Y + 516 * U + (-70688 - 128)) * yinv + 128.5f)) >> 8;
 	}
-	R = clip8(R); G = clip8(G); B = clip8(B);
+	if (q < 20) { R = clip8(R); G = clip8(G); B = clip8(B); }
 }
 /* ---------------------------------------------------------------------------------------------- final reconstruction, one kernel
  * Level-1 synthesis in both directions (decoder/wavelet_filterbank.c:52-357 as driven by nhw_decoder.c), the q > 21 corrections on the
@@ -1934,8 +1935,8 @@ __global__ __launch_bounds__(256) void k_dec_final(DecWs ws, uint8_t *out, int d
 			for (int px = 0; px < 4; px++) {
 				const int x = 4 * t + px;
 				int uv, vv;
-				if (x >= DW - 2) { uv = tu[DH - 1 - j]; vv = tv[DH - 1 - j]; }      /* last two columns repeat column 255 (j = 254 here) */
-				else if (x & 1) { uv = (tu[px >> 1] + tu[(px >> 1) + 1] + 1) >> 1; vv = (tv[px >> 1] + tv[(px >> 1) + 1] + 1) >> 1; }
+				/* (the last two columns repeat column 255: tu[1] = tu[2] = column 255 there, and both rules give it) */
+				if (px & 1) { uv = (tu[px >> 1] + tu[(px >> 1) + 1] + 1) >> 1; vv = (tv[px >> 1] + tv[(px >> 1) + 1] + 1) >> 1; }
 				else { uv = tu[px >> 1]; vv = tv[px >> 1]; }
 				int R, G, B;
 				yuv_to_bytes(q, (int)((y4 >> (8 * px)) & 255u), uv, vv, R, G, B);

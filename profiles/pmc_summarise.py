@@ -5,7 +5,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0]
+        k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[k][row["Counter_Name"]].add(row["Dispatch_Id"])
 out = {}
