@@ -96,6 +96,35 @@ DEV int iabs(int v) { return v < 0 ? -v : v; }
 DEV int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
 DEV int bit_of(const uint8_t *bytes, int nbytes, int k) { return (k >> 3) < nbytes ? (bytes[k >> 3] >> (7 - (k & 7))) & 1 : 0; }
 
+/* Wave-wide scans on the DPP network (an instruction each step; the shuffle forms go through the LDS crossbar: address arithmetic, a
+ * ds_bpermute and its latency per step, and these scans sit on the serial path of every 64-byte step of the entropy kernels).
+ * Inclusive, lane 0 first: four shifts inside the rows of 16 lanes, then the total of the row before into rows 1 and 3 and the total of
+ * the first two rows into rows 2 and 3.  A lane that has no source reads 0, which every operator below takes as "nothing on my left". */
+#define DPP_STEPS(S) S(0x111, 0xF, true) S(0x112, 0xF, true) S(0x114, 0xF, true) S(0x118, 0xF, true) S(0x142, 0xA, false) S(0x143, 0xC, false)
+DEV int wscan_add(int v)
+{
+#define S_(CTRL, RM, BC) v += __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xF, BC);
+	DPP_STEPS(S_)
+#undef S_
+	return v;
+}
+/* segmented sum: a flagged lane starts over; (flag, sum) -> flag: some lane at or before me is flagged, sum: from the nearest one on */
+DEV void wscan_seg(int &flag, int &sum)
+{
+#define S_(CTRL, RM, BC) { const int lf = __builtin_amdgcn_update_dpp(0, flag, CTRL, RM, 0xF, BC), ls = __builtin_amdgcn_update_dpp(0, sum, CTRL, RM, 0xF, BC); if (!flag) { sum += ls; flag = lf; } }
+	DPP_STEPS(S_)
+#undef S_
+}
+/* the value of the last lane at or before me that has one (has = 0: none so far, val undefined) */
+DEV void wscan_last(int &has, int &val)
+{
+#define S_(CTRL, RM, BC) { const int lh = __builtin_amdgcn_update_dpp(0, has, CTRL, RM, 0xF, BC), lv = __builtin_amdgcn_update_dpp(0, val, CTRL, RM, 0xF, BC); if (!has) { has = lh; val = lv; } }
+	DPP_STEPS(S_)
+#undef S_
+}
+DEV int from_left(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false); }   /* lane l: v of lane l - 1; lane 0: `first` */
+DEV int last_lane(int v) { return __builtin_amdgcn_readlane(v, 63); }
+
 /* add to one int16 cell when other threads may be adding to it or to its neighbour in the same 32-bit word */
 DEV void add_i16(int16_t *p, int delta)
 {
@@ -117,6 +146,9 @@ DEV unsigned rd16(Rd &s) { const unsigned a = rd8(s); return a | (rd8(s) << 8); 
 DEV unsigned rd32(Rd &s) { const unsigned a = rd16(s); return a | (rd16(s) << 16); }
 DEV uint32_t take(Rd &s, uint32_t n) { const uint32_t r = s.at; if (s.at + n > s.n || s.at + n < s.at) { s.bad = 1; return 0; } s.at += n; return r; }
 
+#define HDR_STAGE 128                /* bytes of the file brought into LDS for parse_header (it reads fewer than 64) */
+#define BOOK_STAGE 2048              /* bytes of a packed code book staged in LDS; a longer one (no encoder writes that) is read from memory from there on */
+DEV void stage_hdr(uint8_t *dst, const uint8_t *f, uint64_t flen, int t) { dst[t] = (uint64_t)t < flen ? f[t] : 0; }
 DEV void parse_header(const uint8_t *d, uint32_t len, DecMeta *m)
 {
 	Rd s = { d, len, 0, 0 };
@@ -244,17 +276,13 @@ DEV void ll_emit_block(const LlTok &t, bool is_tok, int lane, int &j, int &prev,
 {
 	const int cnt = is_tok ? (t.abs_n ? t.abs_n : t.copies + t.n) : 0;
 	int off = cnt;                                                  /* inclusive prefix of the sample counts */
-	for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(off, d); if (lane >= d) off += o; }
+	off = wscan_add(off);
 	/* value after each token: (absolute?, value) pairs under "a later absolute token wins, otherwise differences add up" */
 	int isabs = is_tok && t.abs_n ? 1 : 0;
 	int val = !is_tok ? 0 : t.abs_n ? (t.abs_n == 2 ? t.a1 : t.a0) : (t.d0 + t.d1 + t.d2);
-	for (int d = 1; d < 64; d <<= 1) {
-		const int oa = __shfl_up(isabs, d), ov = __shfl_up(val, d);
-		if (lane >= d && !isabs) { val += ov; isabs = oa; }
-	}
+	wscan_seg(isabs, val);
 	const int after = (isabs ? val : prev + val) & 255;             /* value after my token */
-	int before = __shfl_up(after, 1);
-	if (!lane) before = prev;
+	const int before = from_left(after, prev);
 	if (is_tok) {
 		int at = j + off - cnt;
 		if (t.abs_n) { if (at < limit) ll[at] = (uint8_t)t.a0; if (t.abs_n == 2 && at + 1 < limit) ll[at + 1] = (uint8_t)t.a1; }
@@ -295,14 +323,14 @@ DEV void ll_expand_wave(const uint8_t *code_g, int code_len, const uint8_t *fine
 		const bool verb = start && b >= 128;
 		/* fine bytes: one per verbatim token, in order */
 		int vpre = verb ? 1 : 0;
-		for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(vpre, dd); if (lane >= dd) vpre += o; }
+		vpre = wscan_add(vpre);
 		const int fidx = a + vpre - 1;
 		const int fv = (verb && q > 15 && fidx < m->ll_word_len) ? fine[fidx] : 0;
 		LlTok t = ll_token_luma(b, d, mode, q > 15, fv);
 		/* where would my token start? the first token at or past sample 16384 is not a token but the chroma seed */
 		const int cnt = start ? (t.abs_n ? t.abs_n : t.copies + t.n) : 0;
 		int off = cnt;
-		for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(off, dd); if (lane >= dd) off += o; }
+		off = wscan_add(off);
 		const uint64_t over = __ballot(start && j + off - cnt >= DQ / 4);
 		bool live = start;
 		if (over) { const int ls = __builtin_ctzll(over); split = i0 + ls; live = start && lane < ls; }
@@ -320,7 +348,7 @@ DEV void ll_expand_wave(const uint8_t *code_g, int code_len, const uint8_t *fine
 		LlTok t = ll_token_chroma(b);
 		const int cnt = t.abs_n ? t.abs_n : t.copies + t.n;
 		int off = cnt;
-		for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(off, dd); if (lane >= dd) off += o; }
+		off = wscan_add(off);
 		const bool live = j + off - cnt < DQ / 4 + DQ / 8;         /* the walk stops at the first token that would start past the end */
 		ll_emit_block(t, live, lane, j, prev, DQ / 4 + DQ / 8, ll);
 		code.advance(lane);
@@ -338,12 +366,12 @@ DEV void ll_expand_wave(const uint8_t *code_g, int code_len, const uint8_t *fine
  * sum, the cut-off from a "last non-neutral wins" scan of {column byte: alive, mark / overflow: dead}, the column written last
  * from another such scan, rows and entry offsets from prefix sums. */
 struct PlCarry { int last, p127, row, n; };
-DEV int scan_add(int v, int lane) { for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; } return v; }
+DEV int scan_add(int v, int) { return wscan_add(v); }
 /* inclusive "the last lane at or before me that has one" scan: has/val in, the winning val (or `none` if no lane has one) out */
 DEV int scan_last(bool has, int val, int none, int lane)
 {
 	int h = has ? 1 : 0, v = val;
-	for (int d = 1; d < 64; d <<= 1) { const int oh = __shfl_up(h, d), ov = __shfl_up(v, d); if (lane >= d && !h) { h = oh; v = ov; } }
+	wscan_last(h, v);
 	return h ? v : none;
 }
 template <typename T>
@@ -361,21 +389,19 @@ DEV int poslist_wave(const uint8_t *list, int len, T *pos, int cap, int row_step
 		const int anew = (v << 1) & 255;
 		/* running column assuming no cut-off: segmented sum, a column byte restarts it */
 		int flag = isA ? 1 : 0, sum = isA ? anew : D;
-		for (int d = 1; d < 64; d <<= 1) { const int of = __shfl_up(flag, d), os = __shfl_up(sum, d); if (lane >= d && !flag) { sum += os; flag = of; } }
+		wscan_seg(flag, sum);
 		const int run = flag ? sum : c.last + sum;
 		const int c1 = run - D + d1, c2 = run;
 		const bool ovf = isR && c2 >= 254;
 		/* "the byte before was a row mark" after each byte: column byte -> 0, mark or overflow -> 1, otherwise unchanged */
 		const int st_after = scan_last(isA || isM || ovf, isA ? 0 : 1, c.p127, lane);
-		int p127b = __shfl_up(st_after, 1);
-		if (!lane) p127b = c.p127;
+		const int p127b = from_left(st_after, c.p127);
 		const bool alive = isR && !p127b;
 		const int nemit = isA ? 1 : alive ? (ovf ? (c1 < 254 ? 1 : 0) : 2) : 0;
 		/* column of the entry written last, after each byte */
 		const bool writes = isA || (alive && nemit > 0);
 		const int last_after = scan_last(writes, isA ? anew : (ovf ? c1 : c2), c.last, lane);
-		int lastb = __shfl_up(last_after, 1);
-		if (!lane) lastb = c.last;
+		const int lastb = from_left(last_after, c.last);
 		int inc = 0;
 		if (isA) inc = (i != 0 && (v << 1) < lastb && !p127b) ? row_step : 0;
 		else if (isM) inc = row_step;
@@ -402,10 +428,13 @@ __global__ __launch_bounds__(256) void k_dec_parse(DecWs ws)
 	const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint8_t *f = ws.blob + ws.blob_off[img];
 	const uint64_t flen = ws.blob_len[img];
+	__shared__ uint8_t hdr[HDR_STAGE];
+	if (tid < HDR_STAGE) stage_hdr(hdr, f, flen, tid);               /* the header's bytes by the workgroup, then one lane reads them from LDS */
+	__syncthreads();
 	if (!tid) {
 		memset(&sm, 0, sizeof sm);
 		sm.size = (int)flen;
-		if (flen > (1u << 24)) sm.status = NHW_E_FORMAT; else parse_header(f, (uint32_t)flen, &sm);
+		if (flen > (1u << 24)) sm.status = NHW_E_FORMAT; else parse_header(hdr, (uint32_t)flen, &sm);
 	}
 	__syncthreads();
 	DecMeta *gm = ws.buf<DecMeta>(D_META, img);
@@ -488,16 +517,19 @@ DEV void vlc_fill_lut(uint16_t *lut, uint16_t *lut2, int lane)
 	}
 }
 /* books, compress_pixel.c:86-117 / :456-478: entry = (run length << 8) | symbol, 354 entries (ranks 0..353); one lane, scr = 1440 bytes of LDS scratch */
-DEV int build_book_small(const uint8_t *raw, int raw_len, bool chroma, int tree_end, uint16_t *book, uint8_t *scr)
+DEV int build_book_small(const uint8_t *raw_g, int raw_len, const uint8_t *raw_s, int staged, bool chroma, int tree_end, uint16_t *book, uint8_t *scr)
 {
 	uint8_t *flat = scr, *inter = scr + 720;
 	const int rep = chroma ? 128 : 3;
 	int e = 0, n = 0;
 	for (int i = 0; i < 720; i++) { flat[i] = 0; inter[i] = 0; }
-	for (int i = 0; i < raw_len; i++) {
-		if (raw[i] == rep) { const int cnt = i + 1 < raw_len ? raw[i + 1] : 0; for (int j = 0; j < cnt && e < 708; j++) flat[e++] = (uint8_t)rep; i++; }
-		else if (e < 708) flat[e++] = raw[i];
+#define RAW(i) ((i) < staged ? raw_s[i] : raw_g[i])
+	for (int i = 0; i < raw_len && e < 708; i++) {                 /* (once 708 bytes are out nothing more is kept) */
+		const int b = RAW(i);
+		if (b == rep) { const int cnt = i + 1 < raw_len ? RAW(i + 1) : 0; for (int j = 0; j < cnt && e < 708; j++) flat[e++] = (uint8_t)rep; i++; }
+		else flat[e++] = (uint8_t)b;
 	}
+#undef RAW
 	if (chroma) e = tree_end;
 	if (e > 708) e = 708;
 	int j = 0;
@@ -604,14 +636,13 @@ DEV int vlc_parse_chunk(const uint8_t *g, int nwords, int c, int &start0, bool z
 		int pos = start, n = 0, rk;
 		while (pos < hi) { pos += code_at(cw, pos, zoned, lut, lut2, rk); n++; }
 		exitp = pos; cnt = n;
-		int nxt = __shfl_up(exitp, 1);
-		if (!lane) nxt = start0;
+		int nxt = from_left(exitp, start0);
 		if (nxt < lo) nxt = lo;                                        /* (a span past the end of the stream: nothing starts in it) */
 		if (!__any(nxt != start)) break;
 		start = nxt;
 	}
 	int off = cnt;
-	for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(off, d); if (lane >= d) off += o; }
+	off = wscan_add(off);
 	{
 		int pos = start, at = off - cnt, rk;
 		while (pos < hi) { pos += code_at(cw, pos, zoned, lut, lut2, rk); if (rk < 0) { bad = 1; rk = 0; } syms[at++] = (uint16_t)rk; }
@@ -696,17 +727,29 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 	const int img = blockIdx.x, part = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint8_t *f = ws.blob + ws.blob_off[img];
 	int *verdict = ws.buf<int>(D_SPARE, img);
+	/* One lane reads the header and one lane per stream unpacks its code book: byte-serial work, so the bytes are brought into LDS by the
+	 * whole workgroup first (a dependent global load per byte was most of this kernel's time per file). */
+	const uint64_t flen = ws.blob_len[img];
+	uint8_t *stage = reinterpret_cast<uint8_t *>(syms[part]);     /* 4224 bytes per stream, free until the first chunk is parsed */
+	if (threadIdx.x < HDR_STAGE) stage_hdr(reinterpret_cast<uint8_t *>(syms[0]), f, flen, threadIdx.x);
+	__syncthreads();
 	if (!threadIdx.x) {
-		const uint64_t flen = ws.blob_len[img];
 		memset(&hm, 0, sizeof hm);
-		if (flen > (1u << 24)) hm.status = NHW_E_FORMAT; else parse_header(f, (uint32_t)flen, &hm);
+		if (flen > (1u << 24)) hm.status = NHW_E_FORMAT; else parse_header(reinterpret_cast<const uint8_t *>(syms[0]), (uint32_t)flen, &hm);
 		*verdict = hm.status;
 	}
 	__syncthreads();
 	const DecMeta *m = &hm;
 	if (m->status) return;
 	if (!part) vlc_fill_lut(lut, lut2, lane);
-	if (!lane) build_book_small(part ? f + m->o_book2 : f + m->o_book1, part ? m->book2_len : m->book1_len, part != 0, m->tree_end, book[part], reinterpret_cast<uint8_t *>(syms[part]) /* 1440 bytes of scratch, before the first chunk is parsed */);
+	{
+		const uint8_t *raw = part ? f + m->o_book2 : f + m->o_book1;
+		const int raw_len = part ? m->book2_len : m->book1_len, staged = min(raw_len, BOOK_STAGE);
+		for (int k = lane; k < staged; k += 64) stage[1440 + k] = raw[k];
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		if (!lane) build_book_small(raw, raw_len, stage + 1440, staged, part != 0, m->tree_end, book[part], stage /* 1440 bytes of scratch */);
+	}
 	__syncthreads();
 	for (int r = lane; r < 354; r += 64) level[part][r] = (int16_t)plain_level(book[part][r] & 255);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -742,8 +785,7 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 				int put, which;
 				for (;;) {
 					sout = luma_step(sin, is_run, rle, lit5, mark, put, which);
-					unsigned nxt = (unsigned)__shfl_up((int)sout, 1);
-					if (!lane) nxt = carry;
+					const unsigned nxt = (unsigned)from_left((int)sout, (int)carry);
 					if (!__any(have && nxt != sin)) break;
 					sin = nxt;
 				}
@@ -754,10 +796,7 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 				int pw = nw;
 				{                                                           /* four prefix sums as two: a batch advances at most 64 x 255 cells and writes at most 192 entries */
 					int sa = pe | (pw << 16), sb = p1 | (p2 << 16);
-					for (int d = 1; d < 64; d <<= 1) {
-						const int oa = __shfl_up(sa, d), ob = __shfl_up(sb, d);
-						if (lane >= d) { sa += oa; sb += ob; }
-					}
+					sa = wscan_add(sa); sb = wscan_add(sb);
 					pe = sa & 0xFFFF; pw = sa >> 16; p1 = sb & 0xFFFF; p2 = sb >> 16;
 				}
 				const int at = e + pe - adv;
@@ -807,7 +846,7 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 				const bool is_run = word == 128;
 				const int adv = have ? (is_run ? bkv >> 8 : 1) : 0, nw = have && !is_run ? 1 : 0;
 				int sa = adv | (nw << 16);
-				for (int d = 1; d < 64; d <<= 1) { const int oa = __shfl_up(sa, d); if (lane >= d) sa += oa; }
+				sa = wscan_add(sa);
 				const int pe = sa & 0xFFFF, pw = sa >> 16;
 				const int at = e + pe - adv;
 				const bool live = have && at < limit;
@@ -1622,7 +1661,7 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 		/* ordered output */
 		const int cnt = __popc(mine);
 		int pre = cnt;
-		for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(pre, d); if (lane >= d) pre += o; }
+		pre = wscan_add(pre);
 		int at = total + pre - cnt;
 #pragma unroll
 		for (int k = 0; k < 4; k++) if ((mine >> k) & 1u) marks[at++] = (uint16_t)(i * DH + 4 * lane + 1 + k);
