@@ -89,7 +89,9 @@ DEV int16_t *plane_a(const DecWs &ws, int img) { return ws.buf<int16_t>(D_A, img
 #define ENT_POS(e) ((int)((e) & 0x3FFFFu))
 #define ENT_VAL(e) ((int)(e) >> 18)
 #define ENT_MAKE(pos, v) (((uint32_t)(v) << 18) | (uint32_t)(pos))
-DEV uint16_t *mark_rows(const DecWs &ws, int img) { return ws.buf<uint16_t>(D_SPARE, img) + 8; }   /* behind the verdict word */
+DEV uint16_t *mark_rows(const DecWs &ws, int img) { return ws.buf<uint16_t>(D_SPARE, img) + 8; }   /* behind the verdict words */
+/* the prefix-code walk's verdict on a file: a word per stream (each written by that stream's workgroup only), 0 = fine */
+DEV int walk_verdict(const DecWs &ws, int img) { const int *v = ws.buf<int>(D_SPARE, img); return v[0] ? v[0] : v[1]; }
 DEV int16_t *plane_ca(const DecWs &ws, int img, int comp) { return ws.buf<int16_t>(D_CA, img) + 1024 + (size_t)comp * (DQ + 2048); }
 
 DEV int iabs(int v) { return v < 0 ? -v : v; }
@@ -714,48 +716,58 @@ DEV void segment_index(const uint32_t *ent, int n, int shift, int nseg, uint32_t
 	}
 }
 
-__global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
+/* the code table is the same for every file: built once per handle into device memory, copied into LDS by every workgroup */
+__global__ __launch_bounds__(64) void k_dec_vlc_table(uint16_t *tab /* [256 + 1024] */)
 {
-	__shared__ uint16_t lut[256], lut2[16 * 64];
-	__shared__ uint16_t book[2][354];
-	__shared__ int16_t level[2][354];
-	__shared__ __attribute__((aligned(16))) uint32_t cw[2][VCH_WORDS + 4];
-	__shared__ uint16_t syms[2][VCH_SYMS];
+	vlc_fill_lut(tab, tab + 256, threadIdx.x);
+}
+
+/* One wavefront per workgroup and stream: the luma streams of the batch first (they are the long ones), then the chroma streams -- as two
+ * wavefronts of one workgroup the short chroma walk kept its half of the workgroup's LDS until the luma walk was through, and LDS is what
+ * bounds the number of resident walks. */
+__global__ __launch_bounds__(64) void k_dec_vlc(DecWs ws, const uint16_t *__restrict__ table)
+{
+	__shared__ uint16_t lut[256 + 16 * 64];
+	__shared__ uint16_t book1[354];
+	__shared__ int16_t level1[354];
+	__shared__ __attribute__((aligned(16))) uint32_t cw1[VCH_WORDS + 4];
+	__shared__ __attribute__((aligned(16))) uint16_t syms1[VCH_SYMS];
 	/* The kernel runs next to k_dec_parse on a stream of its own, so it reads the file header itself (a few dozen bytes) instead of the
-	 * workspace copy, and reports into a word of its own (D_SPARE[0]) that k_dec_verdict folds into the file's status. */
+	 * workspace copy, and reports into a word of its own (D_SPARE[0] / [1]: one per stream) that k_dec_verdict folds into the file's status. */
 	__shared__ DecMeta hm;
-	const int img = blockIdx.x, part = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int part = (int)blockIdx.x >= ws.n ? 1 : 0, img = (int)blockIdx.x - part * ws.n, lane = threadIdx.x;
+	const uint16_t *lut2 = lut + 256;
+	uint16_t *book = book1, *syms = syms1;
+	int16_t *level = level1;
+	uint32_t *cw = cw1;
 	const uint8_t *f = ws.blob + ws.blob_off[img];
-	int *verdict = ws.buf<int>(D_SPARE, img);
-	/* One lane reads the header and one lane per stream unpacks its code book: byte-serial work, so the bytes are brought into LDS by the
-	 * whole workgroup first (a dependent global load per byte was most of this kernel's time per file). */
+	int *verdict = ws.buf<int>(D_SPARE, img) + part;
+	/* One lane reads the header and unpacks the code book: byte-serial work, so the bytes are brought into LDS by the wavefront first */
 	const uint64_t flen = ws.blob_len[img];
-	uint8_t *stage = reinterpret_cast<uint8_t *>(syms[part]);     /* 4224 bytes per stream, free until the first chunk is parsed */
-	if (threadIdx.x < HDR_STAGE) stage_hdr(reinterpret_cast<uint8_t *>(syms[0]), f, flen, threadIdx.x);
+	uint8_t *stage = reinterpret_cast<uint8_t *>(syms);             /* 4224 bytes, free until the first chunk is parsed */
+	for (int k = lane; k < HDR_STAGE; k += 64) stage_hdr(stage, f, flen, k);
+	for (int k = lane; k < (256 + 16 * 64) / 2; k += 64) reinterpret_cast<uint32_t *>(lut)[k] = reinterpret_cast<const uint32_t *>(table)[k];
 	__syncthreads();
-	if (!threadIdx.x) {
+	if (!lane) {
 		memset(&hm, 0, sizeof hm);
-		if (flen > (1u << 24)) hm.status = NHW_E_FORMAT; else parse_header(reinterpret_cast<const uint8_t *>(syms[0]), (uint32_t)flen, &hm);
+		if (flen > (1u << 24)) hm.status = NHW_E_FORMAT; else parse_header(stage, (uint32_t)flen, &hm);
 		*verdict = hm.status;
 	}
 	__syncthreads();
 	const DecMeta *m = &hm;
 	if (m->status) return;
-	if (!part) vlc_fill_lut(lut, lut2, lane);
 	{
 		const uint8_t *raw = part ? f + m->o_book2 : f + m->o_book1;
 		const int raw_len = part ? m->book2_len : m->book1_len, staged = min(raw_len, BOOK_STAGE);
 		for (int k = lane; k < staged; k += 64) stage[1440 + k] = raw[k];
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		__builtin_amdgcn_wave_barrier();
-		if (!lane) build_book_small(raw, raw_len, stage + 1440, staged, part != 0, m->tree_end, book[part], stage /* 1440 bytes of scratch */);
+		__syncthreads();
+		if (!lane) build_book_small(raw, raw_len, stage + 1440, staged, part != 0, m->tree_end, book, stage /* 1440 bytes of scratch */);
 	}
 	__syncthreads();
-	for (int r = lane; r < 354; r += 64) level[part][r] = (int16_t)plain_level(book[part][r] & 255);
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	__builtin_amdgcn_wave_barrier();
-	const uint16_t *bk = book[part];
-	const int16_t *lv = level[part];
+	for (int r = lane; r < 354; r += 64) level[r] = (int16_t)plain_level(book[r] & 255);
+	__syncthreads();
+	const uint16_t *bk = book;
+	const int16_t *lv = level;
 	const uint8_t *g = f + (part ? m->o_packet2 : m->o_packet1);
 	const int nwords = part ? m->data2 - m->data1 : m->data1;
 	const int nchunks = (nwords + VCH_WORDS - 1) / VCH_WORDS + 1;       /* one more: zero bits behind the stream decode as words too, as in the reference */
@@ -775,10 +787,10 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 		unsigned carry = (0u) | (3u << 9);                            /* nothing before the start: mem 0, no 254-run yet, e = 0, history zero */
 		bool done = false;
 		for (int c = 0; c < nchunks + 64 && !done; c++) {
-			const int nsym = vlc_parse_chunk(g, nwords, c, start0, zoned, lut, lut2, cw[0], syms[0], lane, bad);
+			const int nsym = vlc_parse_chunk(g, nwords, c, start0, zoned, lut, lut2, cw, syms, lane, bad);
 			for (int base = 0; base < nsym && !done; base += 64) {
 				const bool have = base + lane < nsym;
-				const int rank = have ? syms[0][base + lane] : 0;
+				const int rank = have ? syms[base + lane] : 0;
 				const int bkv = bk[rank], word = bkv & 255, rle = bkv >> 8;
 				const bool is_run = word == 128, lit5 = word >= 132 && word <= 135, mark = word == 136 || word == 120;
 				unsigned sin = lane ? ST_NEUTRAL : carry, sout;
@@ -838,10 +850,10 @@ __global__ __launch_bounds__(128) void k_dec_vlc(DecWs ws)
 		int e = 0;
 		bool done = false;
 		for (int c = 0; c < nchunks + 64 && !done; c++) {
-			const int nsym = vlc_parse_chunk(g, nwords, c, start0, false, lut, lut2, cw[1], syms[1], lane, bad);
+			const int nsym = vlc_parse_chunk(g, nwords, c, start0, false, lut, lut2, cw, syms, lane, bad);
 			for (int base = 0; base < nsym && !done; base += 64) {
 				const bool have = base + lane < nsym;
-				const int rank = have ? syms[1][base + lane] : 0;
+				const int rank = have ? syms[base + lane] : 0;
 				const int bkv = bk[rank], word = bkv & 255;
 				const bool is_run = word == 128;
 				const int adv = have ? (is_run ? bkv >> 8 : 1) : 0, nw = have && !is_run ? 1 : 0;
@@ -877,7 +889,7 @@ __global__ __launch_bounds__(256) void k_dec_unzig(DecWs ws)
 {
 	__shared__ __attribute__((aligned(16))) int16_t tile[2][64][66];
 	const int img = blockIdx.y, tid = threadIdx.x;
-	if (*ws.buf<int>(D_SPARE, img)) return;                        /* the walk's verdict (header included): the workspace header may still be in the making */
+	if (walk_verdict(ws, img)) return;                             /* the walk's verdict (header included): the workspace header may still be in the making */
 	const uint32_t *segt = ws.buf<uint32_t>(D_SEG, img);
 	const bool luma = blockIdx.x < 64;
 	for (int k = tid; k < (luma ? 1 : 2) * 64 * 66 / 2; k += 256) reinterpret_cast<uint32_t *>(&tile[0][0][0])[k] = 0;
@@ -969,7 +981,7 @@ __global__ __launch_bounds__(256) void k_dec_verdict(DecWs ws)
 {
 	const int img = blockIdx.x * 256 + threadIdx.x;
 	if (img >= ws.n) return;
-	const int v = *ws.buf<int>(D_SPARE, img);
+	const int v = walk_verdict(ws, img);
 	DecMeta *m = ws.buf<DecMeta>(D_META, img);
 	if (v && !m->status) m->status = v;
 }
@@ -2013,6 +2025,7 @@ struct nhw_dec {
 	hipStream_t own_stream;
 	hipStream_t chroma_stream;   /* the chroma sequence runs here, next to the luma one (NHW_CHROMA_FORK=0: behind it, on the caller's stream) */
 	hipEvent_t fork_ev, join_ev;
+	uint16_t *vlc_table;         /* the prefix code's two-level lookup table (k_dec_vlc_table), 2.5 KB */
 	int chroma_fork;
 	int stop_after;
 	hipEvent_t ev[4];         /* start, after the entropy stages, around the final reconstruction kernel (= end) */
@@ -2044,6 +2057,9 @@ extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
 		HIPCHK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&d->join_ev, hipEventDisableTiming));
 		for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&d->ev[i]));
+		HIPCHK(hipMalloc(&d->vlc_table, (256 + 16 * 64) * sizeof(uint16_t)));
+		k_dec_vlc_table<<<1, 64, 0, d->own_stream>>>(d->vlc_table);
+		HIPCHK(hipStreamSynchronize(d->own_stream));
 		if (synth2d_attrs() != NHW_OK) { g_derr = "hipFuncSetAttribute(129 KB of LDS for the block kernels) failed"; return NHW_E_HIP; }
 		return NHW_OK;
 	}();
@@ -2067,6 +2083,7 @@ extern "C" void nhw_dec_destroy(nhw_dec *d)
 	if (d->d_quality) (void)hipFree(d->d_quality);
 	if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
 	if (d->chroma_stream) (void)hipStreamDestroy(d->chroma_stream);
+	if (d->vlc_table) (void)hipFree(d->vlc_table);
 	if (d->fork_ev) (void)hipEventDestroy(d->fork_ev);
 	if (d->join_ev) (void)hipEventDestroy(d->join_ev);
 	for (int i = 0; i < 4; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
@@ -2105,7 +2122,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	if (fork) { HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0)); }
 	k_dec_parse<<<n, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 1 */
-	k_dec_vlc<<<n, 128, 0, cs>>>(ws);
+	k_dec_vlc<<<2 * n, 64, 0, cs>>>(ws, d->vlc_table);
 	k_dec_unzig<<<dim3(80, n), 256, 0, cs>>>(ws);
 	if (fork) {
 		HIPCHK(hipEventRecord(d->join_ev, cs)); HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
