@@ -423,52 +423,59 @@ DEV int poslist_wave(const uint8_t *list, int len, T *pos, int cap, int row_step
 	return c.n;
 }
 
-__global__ __launch_bounds__(256) void k_dec_parse(DecWs ws)
+/* One wavefront per workgroup and side stream -- role 0: the LL2 DPCM bytes (+ the chroma bit planes on top of them, + the file's
+ * header record for the kernels behind); roles 1..3: the position lists res1, res3, res5 + res6 with their bit planes -- the long role
+ * first for the whole batch.  (As four wavefronts of one workgroup the three list walks waited at a barrier for the LL2 walk.) */
+__global__ __launch_bounds__(64) void k_dec_parse(DecWs ws)
 {
 	__shared__ DecMeta sm;
-	__shared__ int counts[4];
-	const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	__shared__ uint8_t hdr[HDR_STAGE];
+	const int role = (int)blockIdx.x / ws.n, img = (int)blockIdx.x - role * ws.n, lane = threadIdx.x;
 	const uint8_t *f = ws.blob + ws.blob_off[img];
 	const uint64_t flen = ws.blob_len[img];
-	__shared__ uint8_t hdr[HDR_STAGE];
-	if (tid < HDR_STAGE) stage_hdr(hdr, f, flen, tid);               /* the header's bytes by the workgroup, then one lane reads them from LDS */
+	for (int k = lane; k < HDR_STAGE; k += 64) stage_hdr(hdr, f, flen, k);   /* the header's bytes by the wavefront, then one lane reads them from LDS */
 	__syncthreads();
-	if (!tid) {
+	if (!lane) {
 		memset(&sm, 0, sizeof sm);
 		sm.size = (int)flen;
 		if (flen > (1u << 24)) sm.status = NHW_E_FORMAT; else parse_header(hdr, (uint32_t)flen, &sm);
 	}
 	__syncthreads();
 	DecMeta *gm = ws.buf<DecMeta>(D_META, img);
-	if (sm.status) { if (!tid) *gm = sm; return; }
+	if (sm.status) { if (!lane && !role) *gm = sm; return; }
 	const int q = sm.q;
 
-	/* the side streams, one wavefront each: LL2 DPCM bytes and the position lists, all as 64-byte scans */
-	uint16_t *p1 = ws.buf<uint16_t>(D_P1, img), *p3 = ws.buf<uint16_t>(D_P3, img), *p5 = ws.buf<uint16_t>(D_P5, img);
-	uint32_t *p6 = ws.buf<uint32_t>(D_P6, img);
-	if (wv == 0) ll_expand_wave(f + sm.o_chres, sm.ch_res_len, f + sm.o_llword, &sm, ws.buf<uint8_t>(D_LL, img), lane);
-	else if (wv == 1) { const int c = q > 12 ? poslist_wave(f + sm.o_res1, sm.res1_len, p1, sm.res1_bits * 8, 256, true, lane) : 0; if (!lane) counts[1] = c; }
-	else if (wv == 2) { const int c = q >= 19 ? poslist_wave(f + sm.o_res3, sm.res3_len, p3, sm.res3_bits * 8, 256, true, lane) : 0; if (!lane) counts[2] = c; }
-	else {
-		const int c5 = q >= 21 ? poslist_wave(f + sm.o_res5, sm.res5_len, p5, sm.res5_bits * 8, 256, true, lane) : 0;
-		const int c6 = q > 21 ? poslist_wave(f + sm.o_res6, sm.res6_len, p6, sm.res6_bits * 8, 256, false, lane) : 0;
-		if (!lane) { counts[3] = c5; counts[0] = c6; }
+	/* a list: (row, col) entries by 64-byte scans, then the low bits from the bit plane; entries the list did not reach are 0 + their bit (the
+	 * reference's calloc) */
+#define LIST16(P, RES_OFF, RES_LEN, BITS, BIT_OFF) do { \
+		const int c_ = poslist_wave(f + (RES_OFF), (RES_LEN), (P), (BITS) * 8, 256, true, lane); \
+		__syncthreads(); \
+		for (int k = lane; k < (BITS) * 8; k += 64) (P)[k] = (uint16_t)((k < c_ ? (P)[k] : 0) + bit_of(f + (BIT_OFF), (BITS), k)); \
+	} while (0)
+	if (role == 1) { if (q > 12) LIST16(ws.buf<uint16_t>(D_P1, img), sm.o_res1, sm.res1_len, sm.res1_bits, sm.o_res1_bit); return; }
+	if (role == 2) { if (q >= 19) LIST16(ws.buf<uint16_t>(D_P3, img), sm.o_res3, sm.res3_len, sm.res3_bits, sm.o_res3_bit); return; }
+	if (role == 3) {
+		if (q >= 21) LIST16(ws.buf<uint16_t>(D_P5, img), sm.o_res5, sm.res5_len, sm.res5_bits, sm.o_res5_bit);
+		if (q > 21) {
+			uint32_t *p6 = ws.buf<uint32_t>(D_P6, img);
+			const int c6 = poslist_wave(f + sm.o_res6, sm.res6_len, p6, sm.res6_bits * 8, 256, false, lane);
+			__syncthreads();
+			for (int k = lane; k < sm.res6_bits * 8; k += 64) p6[k] = (k < c6 ? p6[k] : 0u) + (uint32_t)bit_of(f + sm.o_res6_bit, sm.res6_bits, k);
+		}
+		return;
 	}
+#undef LIST16
+	uint8_t *ll = ws.buf<uint8_t>(D_LL, img);
+	ll_expand_wave(f + sm.o_chres, sm.ch_res_len, f + sm.o_llword, &sm, ll, lane);
 	__syncthreads();
-	/* low bits from the bit planes; entries the list did not reach are 0 + their bit (the reference's calloc) */
-	if (q > 12) for (int k = tid; k < sm.res1_bits * 8; k += 256) p1[k] = (uint16_t)((k < counts[1] ? p1[k] : 0) + bit_of(f + sm.o_res1_bit, sm.res1_bits, k));
-	if (q >= 19) for (int k = tid; k < sm.res3_bits * 8; k += 256) p3[k] = (uint16_t)((k < counts[2] ? p3[k] : 0) + bit_of(f + sm.o_res3_bit, sm.res3_bits, k));
-	if (q >= 21) for (int k = tid; k < sm.res5_bits * 8; k += 256) p5[k] = (uint16_t)((k < counts[3] ? p5[k] : 0) + bit_of(f + sm.o_res5_bit, sm.res5_bits, k));
-	if (q > 21) for (int k = tid; k < sm.res6_bits * 8; k += 256) p6[k] = (k < counts[0] ? p6[k] : 0u) + (uint32_t)bit_of(f + sm.o_res6_bit, sm.res6_bits, k);
 	/* bit-1 planes of the chroma LL2 samples (:1983-2026) */
 	if (q > 15) {
-		uint8_t *ll = ws.buf<uint8_t>(D_LL, img);
-		for (int k = tid; k < 2 * DH * 8; k += 256) {
+		for (int k = lane; k < 2 * DH * 8; k += 64) {
 			ll[DQ / 4 + k] = (uint8_t)(ll[DQ / 4 + k] + (bit_of(f + sm.o_u64, 2 * DH, k) << 1));
 			ll[DQ / 4 + DQ / 16 + k] = (uint8_t)(ll[DQ / 4 + DQ / 16 + k] + (bit_of(f + sm.o_v64, 2 * DH, k) << 1));
 		}
 	}
-	if (!tid) {
+	if (!lane) {
 		/* the reference's `count` as decode_image reaches :571 */
 		int carry = 4 * DQ;
 		if (q > 12) carry = sm.res1_bits > 0 ? (sm.res1_bits - 1) * 8 : 0;
@@ -2120,7 +2127,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	/* Two entropy branches that only meet at the expansion: the side streams (LL2 DPCM, position lists; latency-bound scans) on the caller's
 	 * stream, the prefix-code walk and the un-zig-zag on the second one. */
 	if (fork) { HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0)); }
-	k_dec_parse<<<n, 256, 0, s>>>(ws);
+	k_dec_parse<<<4 * n, 64, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 1 */
 	k_dec_vlc<<<2 * n, 64, 0, cs>>>(ws, d->vlc_table);
 	k_dec_unzig<<<dim3(80, n), 256, 0, cs>>>(ws);
