@@ -83,8 +83,8 @@ struct DecWs {
 DEV int16_t *plane_a(const DecWs &ws, int img) { return ws.buf<int16_t>(D_A, img) + 2048; }
 /* D_B / D_CB: what the prefix-code walk found, as a list in stream order -- (value << 18) | position in the stream, one word per value that
  * is not part of a zero run (at most one per cell, plus a few words of slack) -- and D_SEG: the index of the first entry at or behind the
- * start of every segment of the stream the un-zig-zag takes in one piece (luma: 1024 segments of 256 symbols from word 0, chroma: 128 of
- * 1024 interleaved symbols from word SEG_CHROMA), with the total behind the last one */
+ * start of every piece of the stream its consumer takes in one go (luma: the 128 strips of 2048 symbols, from word 0; chroma: 128
+ * segments of 1024 interleaved symbols, from word SEG_CHROMA), with the total behind the last one */
 #define SEG_CHROMA 1040
 #define ENT_POS(e) ((int)((e) & 0x3FFFFu))
 #define ENT_VAL(e) ((int)(e) >> 18)
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(64) void k_dec_vlc(DecWs ws, const uint16_t *__rest
 			}
 			if (c >= nchunks - 1 && !done && (c + 1) * VCH_WORDS > nwords + 8) { bad = 1; break; }   /* ran out of stream before the last cell */
 		}
-		segment_index(ent, nE, 8, 1024, ws.buf<uint32_t>(D_SEG, img), lane);
+		segment_index(ent, nE, 11, 128, ws.buf<uint32_t>(D_SEG, img), lane);   /* the strips of the luma stream: k_dec_expand follows each with a cursor */
 	} else {
 		uint32_t *ent = ws.buf<uint32_t>(D_CB, img);                  /* U on even, V on odd stream positions */
 		int nE = 0;
@@ -887,53 +887,36 @@ __global__ __launch_bounds__(64) void k_dec_vlc(DecWs ws, const uint16_t *__rest
 
 /* ---------------------------------------------------------------------------------------------- un-zig-zag
  * nhw_decoder.c:71-91 (luma: strips of 4 columns, serpentine down the rows) and :904-932 / :1192-1220 (chroma: strips of 8
- * columns, U on even and V on odd stream positions).  A workgroup builds a 64 x 64 tile of the plane in LDS -- zeros (the reference's
- * calloc: a zero run is a skip), then the entries of the tile's pieces of the stream (a strip's 64 rows are one contiguous segment of it:
- * 256 luma symbols, 1024 interleaved chroma symbols) -- and writes whole rows.  Putting a symbol straight into its cell from the walk
- * would touch a different row for every fourth symbol, and a row's line would be written back once per strip.
- * blockIdx.x < 64: luma tiles; then 16 tiles that each do U and V. */
+ * columns, U on even and V on odd stream positions).  The luma entries go straight into the rows k_dec_expand works on (there is no
+ * luma plane before it).  Chroma: a workgroup builds a 64 x 64 tile of both planes in LDS -- zeros (the reference's calloc: a zero run is
+ * a skip), then the entries of the tile's pieces of the stream (a strip's 64 rows are one contiguous segment of it: 1024 interleaved
+ * symbols) -- and writes whole rows.  Putting a symbol straight into its cell from the walk would touch a different row for every eighth
+ * symbol, and a row's line would be written back once per strip.  16 tiles per file. */
 __global__ __launch_bounds__(256) void k_dec_unzig(DecWs ws)
 {
 	__shared__ __attribute__((aligned(16))) int16_t tile[2][64][66];
 	const int img = blockIdx.y, tid = threadIdx.x;
 	if (walk_verdict(ws, img)) return;                             /* the walk's verdict (header included): the workspace header may still be in the making */
-	const uint32_t *segt = ws.buf<uint32_t>(D_SEG, img);
-	const bool luma = blockIdx.x < 64;
-	for (int k = tid; k < (luma ? 1 : 2) * 64 * 66 / 2; k += 256) reinterpret_cast<uint32_t *>(&tile[0][0][0])[k] = 0;
+	const uint32_t *segt = ws.buf<uint32_t>(D_SEG, img) + SEG_CHROMA;
+	for (int k = tid; k < 2 * 64 * 66 / 2; k += 256) reinterpret_cast<uint32_t *>(&tile[0][0][0])[k] = 0;
 	const int row = tid >> 2, c0 = (tid & 3) * 16;
-	auto put_row = [&](int comp, int16_t *dst) {
+	const int cg = blockIdx.x & 3, rg = blockIdx.x >> 2;
+	const uint32_t *ent = ws.buf<uint32_t>(D_CB, img);
+	const int s = tid >> 5, j = tid & 31;                           /* strip within the tile (8 of 8 columns), every 32nd of its entries */
+	const int seg = (cg * 8 + s) * 4 + rg;
+	const int lo = (int)segt[seg], hi = (int)segt[seg + 1];
+	__syncthreads();
+	for (int k = lo + j; k < hi; k += 32) {
+		const uint32_t en = ent[k];
+		const int i = ENT_POS(en) & 1023, comp = i & 1, w = i >> 1, rp = w >> 4, idx = w & 15;
+		tile[comp][2 * rp + (idx >> 3)][8 * s + ((idx & 8) ? 15 - idx : (idx & 7))] = (int16_t)ENT_VAL(en);
+	}
+	__syncthreads();
+	for (int comp = 0; comp < 2; comp++) {
 		const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile[comp][row][c0]);
-		reinterpret_cast<uint4 *>(dst)[0] = make_uint4(t[0], t[1], t[2], t[3]);
-		reinterpret_cast<uint4 *>(dst)[1] = make_uint4(t[4], t[5], t[6], t[7]);
-	};
-	if (luma) {
-		const int cg = blockIdx.x & 7, rg = blockIdx.x >> 3;
-		const uint32_t *ent = ws.buf<uint32_t>(D_B, img);
-		const int s = tid >> 4, j = tid & 15;                       /* strip within the tile, every 16th of its entries */
-		const int seg = (cg * 16 + s) * 8 + rg;
-		const int lo = (int)segt[seg], hi = (int)segt[seg + 1];
-		__syncthreads();
-		for (int k = lo + j; k < hi; k += 16) {
-			const uint32_t en = ent[k];
-			const int w = ENT_POS(en) & 255, rp = w >> 3, idx = w & 7;
-			tile[0][2 * rp + (idx >> 2)][4 * s + ((idx & 4) ? 7 - idx : idx)] = (int16_t)ENT_VAL(en);
-		}
-		__syncthreads();
-		put_row(0, plane_a(ws, img) + (size_t)(rg * 64 + row) * DW + cg * 64 + c0);
-	} else {
-		const int b = blockIdx.x - 64, cg = b & 3, rg = b >> 2;
-		const uint32_t *ent = ws.buf<uint32_t>(D_CB, img);
-		const int s = tid >> 5, j = tid & 31;                       /* strip within the tile (8 of 8 columns), every 32nd of its entries */
-		const int seg = (cg * 8 + s) * 4 + rg;
-		const int lo = (int)segt[SEG_CHROMA + seg], hi = (int)segt[SEG_CHROMA + seg + 1];
-		__syncthreads();
-		for (int k = lo + j; k < hi; k += 32) {
-			const uint32_t en = ent[k];
-			const int i = ENT_POS(en) & 1023, comp = i & 1, w = i >> 1, rp = w >> 4, idx = w & 15;
-			tile[comp][2 * rp + (idx >> 3)][8 * s + ((idx & 8) ? 15 - idx : (idx & 7))] = (int16_t)ENT_VAL(en);
-		}
-		__syncthreads();
-		for (int comp = 0; comp < 2; comp++) put_row(comp, plane_ca(ws, img, comp) + (size_t)(rg * 64 + row) * DH + cg * 64 + c0);
+		uint4 *dst = reinterpret_cast<uint4 *>(plane_ca(ws, img, comp) + (size_t)(rg * 64 + row) * DH + cg * 64 + c0);
+		dst[0] = make_uint4(t[0], t[1], t[2], t[3]);
+		dst[1] = make_uint4(t[4], t[5], t[6], t[7]);
 	}
 }
 
@@ -1036,6 +1019,47 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 	int16_t *st = stage[threadIdx.x >> 6];
 	const uint8_t *f = ws.blob + ws.blob_off[img];
 
+	/* Where the rows come from: the prefix-code walk left the file's values as a list in stream order -- 128 strips of 4 columns, a strip row
+	 * after row -- so the values of any range of rows are, for every strip, the next few entries of the strip's part of the list.  A lane
+	 * follows two strips (lane, lane + 64) with a cursor and the next four entries of each already in registers: feeding rows into the LDS
+	 * buffer is zeros, then each lane drops the entries of its strips that lie in those rows into their cells and asks for the next four
+	 * (which arrive while the rows are being worked on).  The plane in memory is only ever written here, row by row, finished. */
+	struct __attribute__((aligned(4))) Ent4 { uint32_t w[4]; };
+	const uint32_t *ent = ws.buf<uint32_t>(D_B, img);
+	int ecur0, ecur1, eend0, eend1;
+	Ent4 ewin0, ewin1;
+	{
+		const uint32_t *sidx = ws.buf<uint32_t>(D_SEG, img);
+		ecur0 = (int)sidx[lane]; eend0 = (int)sidx[lane + 1]; ecur1 = (int)sidx[lane + 64]; eend1 = (int)sidx[lane + 65];
+		ewin0 = *reinterpret_cast<const Ent4 *>(ent + ecur0); ewin1 = *reinterpret_cast<const Ent4 *>(ent + ecur1);
+	}
+	auto feed_strip = [&](int strip, int &ecur, int eend, Ent4 &ewin, int hi, int base) {
+		const int limit = strip * 2048 + 4 * (hi + 1);
+		for (;;) {
+			int used = 0;
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const uint32_t en = ewin.w[t];
+				if (ecur + t < eend && ENT_POS(en) < limit) {
+					const int w = ENT_POS(en) - strip * 2048, idx = w & 7;
+					st[8 + (2 * (w >> 3) + (idx >> 2) - base) * DW + 4 * strip + ((idx & 4) ? 7 - idx : idx)] = (int16_t)ENT_VAL(en);
+					used = t + 1;
+				}
+			}
+			if (!used) break;
+			ecur += used;
+			ewin = *reinterpret_cast<const Ent4 *>(ent + ecur);
+			if (used < 4) break;
+		}
+	};
+	auto feed = [&](int lo, int hi, int base) {                   /* rows lo .. hi into slots lo - base .. hi - base */
+		for (int r = lo; r <= hi; r++) *(uint4 *)(st + 8 + (r - base) * DW + 8 * lane) = make_uint4(0, 0, 0, 0);
+		__builtin_amdgcn_wave_barrier();
+		feed_strip(lane, ecur0, eend0, ewin0, hi, base);
+		feed_strip(lane + 64, ecur1, eend1, ewin1, hi, base);
+	};
+	int pend_lower = X_NONE;
+
 	/* loop 1: rows 0..255, all columns (:493-527).  A symbol writes into its own row, the row below, the last cell of the row above and the
 	 * first cell of the row after next; the walk is serial, but only over the symbols.  Rows pass through LDS XC at a time -- slot s of the
 	 * buffer is row i0+s, slot XC is the row below the chunk (the next chunk's slot 0) -- lane 0 replays the symbols of slots 0..XC-1 in
@@ -1045,28 +1069,23 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 	{
 		int16_t *buf = st + 8;
 		uint8_t *sm = &symb[threadIdx.x >> 6][0][0];
-		const uint4 *ag = (const uint4 *)a;
-		uint4 nx[XC];
 		uint64_t any_halo;
+		feed(0, 0, 0);
+		__builtin_amdgcn_wave_barrier();
 		{
-			const uint4 r0 = ag[lane];
-			*(uint4 *)(buf + 8 * lane) = r0;
-			const unsigned s0 = symbols_of(r0);
+			const unsigned s0 = symbols_of(*(const uint4 *)(buf + 8 * lane));
 			sm[lane] = (uint8_t)s0;
 			any_halo = __ballot(s0 != 0);
 		}
-#pragma unroll
-		for (int g = 0; g < XC; g++) nx[g] = ag[(size_t)(1 + g) * (DW / 8) + lane];
 		int pend = X_NONE;                                        /* what a column-511 symbol of the chunk's last row left for column 0 of the row after next */
-		uint64_t any_m2 = 0, any_m1 = 0;                          /* symbols in the last two rows of the chunk before */
 		for (int i0 = 0; i0 < DH; i0 += XC) {
-			uint64_t anyx[XC + 3]; uint64_t any_all = any_halo;
-			uint64_t *any = anyx + 2;                               /* any[s]: slot s holds a symbol; a symbol reaches from the row above it to the first cell two rows below */
-			any[-2] = any_m2; any[-1] = any_m1; any[0] = any_halo;
+			uint64_t any[XC + 1]; uint64_t any_all = any_halo;          /* any[s]: slot s holds a symbol */
+			any[0] = any_halo;
+			feed(i0 + 1, i0 + XC, i0);
+			__builtin_amdgcn_wave_barrier();
 #pragma unroll
 			for (int g = 0; g < XC; g++) {
-				*(uint4 *)(buf + (g + 1) * DW + 8 * lane) = nx[g];
-				const unsigned sg = symbols_of(nx[g]);
+				const unsigned sg = symbols_of(*(const uint4 *)(buf + (g + 1) * DW + 8 * lane));
 				sm[(g + 1) * 64 + lane] = (uint8_t)sg;
 				any[g + 1] = __ballot(sg != 0);
 				if (g + 1 < XC) any_all |= any[g + 1];
@@ -1074,11 +1093,6 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 			if (!lane) {
 				if (pend != X_NONE) buf[DW] = (int16_t)pend;
 				buf[-1] = X_NONE; buf[(XC + 1) * DW] = X_NONE;
-			}
-			const bool more = i0 + XC < DH;
-			if (more) {
-#pragma unroll
-				for (int g = 0; g < XC; g++) nx[g] = ag[(size_t)(i0 + XC + 1 + g) * (DW / 8) + lane];
 			}
 			__builtin_amdgcn_wave_barrier();
 			if (any_all) {
@@ -1104,20 +1118,17 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 			}
 			pend = buf[(XC + 1) * DW];
 #pragma unroll
-			for (int s = 0; s < XC; s++) {
-				if (any[s - 2] | any[s - 1] | any[s] | any[s + 1]) *(uint4 *)(a + (size_t)(i0 + s) * DW + 8 * lane) = *(const uint4 *)(buf + s * DW + 8 * lane);
-			}
+			for (int s = 0; s < XC; s++) *(uint4 *)(a + (size_t)(i0 + s) * DW + 8 * lane) = *(const uint4 *)(buf + s * DW + 8 * lane);
 			{
 				const uint4 h = *(const uint4 *)(buf + XC * DW + 8 * lane);
 				const uint8_t hs = sm[XC * 64 + lane];
 				__builtin_amdgcn_wave_barrier();
 				*(uint4 *)(buf + 8 * lane) = h;
 				sm[lane] = hs;
-				any_halo = any[XC]; any_m1 = any[XC - 1]; any_m2 = any[XC - 2];
+				any_halo = any[XC];
 			}
 		}
-		if (any_m2 | any_m1) *(uint4 *)(a + (size_t)DH * DW + 8 * lane) = *(const uint4 *)(buf + 8 * lane);   /* row 256, with what rows 254 and 255 wrote into it */
-		if (pend != X_NONE && !lane) a[(size_t)(DH + 1) * DW] = (int16_t)pend;
+		pend_lower = pend;                                          /* row 256 stays in slot 0, with what rows 254 and 255 wrote into it */
 	}
 
 	/* loops 2 and 3, row by row: the left half's pattern symbols (:529-560), then the HH half (:562-616).  The reference finishes
@@ -1127,30 +1138,29 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 	 * The rows pass through the same LDS buffer as in loop 1, XD at a time with the next XD on their way: a row reads the untouched HH
 	 * half of the row below (slot s+1), writes itself and one cell class into the left half of the row above (slot s-1; for slot 0 that
 	 * row has left already and is patched in memory), and the finished HH row above stays in registers. */
-	wave_sync();
-	for (int i = DH + lane; i < DW; i += 64) {
-		const int s = a[(size_t)i * DW];
-		if (s == 1008 || s == 1009) a[(size_t)i * DW - 1] = (int16_t)(s == 1008 ? 5 : -5);
-	}
-	wave_sync();
 	{
 		int16_t *buf = st + 8;
-		const uint4 *ag = (const uint4 *)a;
-		static_assert(XD == 4, "the rows in flight are four named registers");
-#define X_ROW(r) ag[(size_t)((r) < DW ? (r) : DW - 1) * (DW / 8) + lane]   /* past the last row: loaded, never looked at */
-		*(uint4 *)(buf + 8 * lane) = ag[(size_t)DH * (DW / 8) + lane];
-		uint4 nx0 = X_ROW(DH + 1), nx1 = X_ROW(DH + 2), nx2 = X_ROW(DH + 3), nx3 = X_ROW(DH + 4);
+		{                                                           /* row 256 is in slot 0: a 1008/1009 in its column 0 writes the last cell of row 255, which has left */
+			const int s256 = buf[0];
+			wave_sync();
+			if ((s256 == 1008 || s256 == 1009) && !lane) a[(size_t)DH * DW - 1] = (int16_t)(s256 == 1008 ? 5 : -5);
+			wave_sync();
+		}
 		int carry = m->carry;
 		int pend0 = X_NONE;                                       /* value a column-511 symbol of the previous row writes to column 0 of this one */
 		int upf[4];
 #pragma unroll
 		for (int k = 0; k < 4; k++) upf[k] = a[(size_t)(DH - 1) * DW + DH + lane + 64 * k];
 		for (int i0 = DH; i0 < DW; i0 += XD) {
-			*(uint4 *)(buf + 1 * DW + 8 * lane) = nx0; *(uint4 *)(buf + 2 * DW + 8 * lane) = nx1;
-			*(uint4 *)(buf + 3 * DW + 8 * lane) = nx2; *(uint4 *)(buf + 4 * DW + 8 * lane) = nx3;
-			nx0 = X_ROW(i0 + XD + 1); nx1 = X_ROW(i0 + XD + 2); nx2 = X_ROW(i0 + XD + 3); nx3 = X_ROW(i0 + XD + 4);
+			if (i0 + 1 < DW) feed(i0 + 1, i0 + XD < DW ? i0 + XD : DW - 1, i0);
 			__builtin_amdgcn_wave_barrier();
-			unsigned wrote = 0;                                     /* slots with a cell that differs from memory */
+			if (i0 == DH && pend_lower != X_NONE && !lane) buf[DW] = (int16_t)pend_lower;   /* what loop 1's last row left for column 0 of row 257 */
+			__builtin_amdgcn_wave_barrier();
+			if (lane < XD && i0 + 1 + lane < DW) {                  /* a 1008/1009 in column 0 of a row writes the last HH cell of the row above: before anything else */
+				const int s0 = buf[(1 + lane) * DW];
+				if (s0 == 1008 || s0 == 1009) buf[lane * DW + DW - 1] = (int16_t)(s0 == 1008 ? 5 : -5);
+			}
+			__builtin_amdgcn_wave_barrier();
 #pragma unroll 1
 			for (int s = 0; s < XD; s++) {
 				const int i = i0 + s;
@@ -1164,10 +1174,9 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 					if (any) {
 						if (!lane) replay_lower(row, mk);
 						__builtin_amdgcn_wave_barrier();
-						wrote |= 1u << s;
 					}
 				}
-				if (pend0 != X_NONE) { if (!lane) row[0] = (int16_t)pend0; pend0 = X_NONE; wrote |= 1u << s; }
+				if (pend0 != X_NONE) { if (!lane) row[0] = (int16_t)pend0; pend0 = X_NONE; }
 				/* HH half of the row: columns 256..511 */
 				int cur[4], dn[4];
 #pragma unroll
@@ -1227,15 +1236,13 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 						if (bm && carry) { if (lane == __builtin_ctzll(bm)) hit[k] += (unsigned)carry; carry = 0; }
 					}
 				}
-				bool changed = false;
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					const int lkR = m4_bit(kR, k, lane);
 					if (((cand >> k) & 1) && hit[k] >= 2 && !lkR) fin[k] = cur[k] > 0 ? cur[k] + 1 : cur[k] - 1;
-					if (fin[k] != cur[k]) { row[DH + lane + 64 * k] = (int16_t)fin[k]; changed = true; }
+					if (fin[k] != cur[k]) row[DH + lane + 64 * k] = (int16_t)fin[k];
 					upf[k] = fin[k];
 				}
-				if (__ballot(changed)) wrote |= 1u << s;
 				if (any) {                                           /* what the symbols write outside the HH half of this row */
 					const bool up67 = (live67.w[0] | live67.w[1] | live67.w[2] | live67.w[3]) != 0;
 					if (up67 && s == 0) wave_sync();                   /* the row above went to memory with the chunk before: patch it there, behind those stores */
@@ -1252,22 +1259,18 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 							if (c == DH) row[DH - 1] = val;
 						}
 					}
-					wrote |= 1u << s;
-					if (up67 && s) wrote |= 1u << (s - 1);
 					if ((liveK.w[3] >> 63) & 1ull) pend0 = ((k8.w[3] >> 63) & 1ull) ? 5 : -5;
 				}
 			}
 			__builtin_amdgcn_wave_barrier();
 #pragma unroll
-			for (int s = 0; s < XD; s++)
-				if ((wrote >> s) & 1u) *(uint4 *)(a + (size_t)(i0 + s) * DW + 8 * lane) = *(const uint4 *)(buf + s * DW + 8 * lane);
+			for (int s = 0; s < XD; s++) *(uint4 *)(a + (size_t)(i0 + s) * DW + 8 * lane) = *(const uint4 *)(buf + s * DW + 8 * lane);
 			{
 				const uint4 h = *(const uint4 *)(buf + XD * DW + 8 * lane);
 				__builtin_amdgcn_wave_barrier();
 				*(uint4 *)(buf + 8 * lane) = h;
 			}
 		}
-#undef X_ROW
 	}
 	wave_sync();
 
@@ -2130,7 +2133,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	k_dec_parse<<<4 * n, 64, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 1 */
 	k_dec_vlc<<<2 * n, 64, 0, cs>>>(ws, d->vlc_table);
-	k_dec_unzig<<<dim3(80, n), 256, 0, cs>>>(ws);
+	k_dec_unzig<<<dim3(16, n), 256, 0, cs>>>(ws);
 	if (fork) {
 		HIPCHK(hipEventRecord(d->join_ev, cs)); HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
 		HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0));   /* chroma goes on once both branches are in */
