@@ -1950,27 +1950,27 @@ __global__ __launch_bounds__(256) void k_dec_final(DecWs ws, uint8_t *out, int d
 	__syncthreads();
 	F_STOP(3);
 
-	/* second direction: two output rows (one dword of every line of T) per step, a thread per j */
+	/* second direction: two output rows (one dword of every line of T) per step, a thread per j.  Both rows at once in packed 16-bit
+	 * arithmetic: the reference's values are int16 with wrap-around at every step, which is what the packed instructions compute; at the two
+	 * ends of a line the missing neighbour is the sample itself (that is what the end rules of filters.c:143-194 amount to). */
 	for (int lp = 1; lp <= FR / 2; lp++) {                                       /* local rows 2 lp, 2 lp + 1 <-> r0 + 2 (lp - 1), + 1 */
+		typedef short s16x2 __attribute__((ext_vector_type(2)));
 		const int j = tid, M = DH;
 #define TW(k) (*reinterpret_cast<const uint32_t *>(T + (k) * FBP + 2 * lp))
-		const uint32_t lo0 = TW(j), lo1 = j < M - 1 ? TW(j + 1) : 0u, h0 = TW(M + j), hm = j ? TW(M + j - 1) : 0u, hp = j < M - 1 ? TW(M + j + 1) : 0u;
+		const uint32_t lo0 = TW(j), h0 = TW(M + j);
+		const uint32_t lo1 = j < M - 1 ? TW(j + 1) : lo0, hm = j ? TW(M + j - 1) : h0, hp = j < M - 1 ? TW(M + j + 1) : h0;
 #undef TW
-		uint32_t yy[2];
-#pragma unroll
-		for (int h = 0; h < 2; h++) {
-			const int l0 = (int16_t)(h ? lo0 >> 16 : lo0 & 0xFFFF), l1 = (int16_t)(h ? lo1 >> 16 : lo1 & 0xFFFF);
-			const int c0 = (int16_t)(h ? h0 >> 16 : h0 & 0xFFFF), cm = (int16_t)(h ? hm >> 16 : hm & 0xFFFF), cp = (int16_t)(h ? hp >> 16 : hp & 0xFFFF);
-			int ev = (int16_t)(l0 << 3), od = j < M - 1 ? (int16_t)((l1 + l0) << 2) : (int16_t)(l0 << 3);
-			if (j == 0) { ev -= c0 << 2; od += 5 * c0 - cp; }
-			else if (j < M - 1) { ev -= (c0 + cm) << 1; od += 6 * c0 - cp - cm; }
-			else { ev -= (c0 + cm) << 1; od += 5 * c0 - cm; }
-			ev = (int16_t)ev; od = (int16_t)od;
-			if (ev > 0) ev = (int16_t)(ev + 32); ev >>= 6; if (od > 0) od = (int16_t)(od + 32); od >>= 6;
-			yy[h] = (uint32_t)clip8(ev) | ((uint32_t)clip8(od) << 8);
-		}
-		*reinterpret_cast<uint16_t *>(ybuf + (2 * lp - 2) * DW + 2 * j) = (uint16_t)yy[0];
-		*reinterpret_cast<uint16_t *>(ybuf + (2 * lp - 1) * DW + 2 * j) = (uint16_t)yy[1];
+		const s16x2 L0 = __builtin_bit_cast(s16x2, lo0), L1 = __builtin_bit_cast(s16x2, lo1);
+		const s16x2 C0 = __builtin_bit_cast(s16x2, h0), CM = __builtin_bit_cast(s16x2, hm), CP = __builtin_bit_cast(s16x2, hp);
+		s16x2 ev = (L0 << 3) - ((C0 + CM) << 1);
+		s16x2 od = ((L1 + L0) << 2) + (C0 * (s16x2)(6) - CP - CM);
+		const s16x2 zero = (s16x2)(0), one = (s16x2)(1), top = (s16x2)(255);
+		ev = (ev + (__builtin_elementwise_min(__builtin_elementwise_max(ev, zero), one) << 5)) >> 6;   /* + 32 where positive, then the arithmetic shift */
+		od = (od + (__builtin_elementwise_min(__builtin_elementwise_max(od, zero), one) << 5)) >> 6;
+		ev = __builtin_elementwise_min(__builtin_elementwise_max(ev, zero), top);
+		od = __builtin_elementwise_min(__builtin_elementwise_max(od, zero), top);
+		*reinterpret_cast<uint16_t *>(ybuf + (2 * lp - 2) * DW + 2 * j) = (uint16_t)((unsigned)ev.x | ((unsigned)od.x << 8));
+		*reinterpret_cast<uint16_t *>(ybuf + (2 * lp - 1) * DW + 2 * j) = (uint16_t)((unsigned)ev.y | ((unsigned)od.y << 8));
 	}
 	__syncthreads();
 	F_STOP(4);
