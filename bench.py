@@ -44,6 +44,32 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+DEC_PMC_FILE = os.path.join(ROOT, "profiles", "dec_pmc.json")       # profiles/collect_dec.sh
+
+
+def decoder_source_hash():
+    """sha256 over nhw_dec.hip: ties the committed PMC profile of the decoder kernels to the code it was taken from"""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(open(os.path.join(ROOT, "nhwcodec_amd", "csrc", "nhw_dec.hip"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def final_traffic(q, files):
+    """HBM bytes of one k_dec_final launch from the committed PMC file, scaled to this batch -- or None (stale file, other quality, absent)"""
+    try:
+        with open(DEC_PMC_FILE) as fh:
+            d = json.load(fh)
+    except OSError:
+        return None, "no committed PMC file"
+    if d.get("source_hash") != decoder_source_hash():
+        return None, f"profiles/dec_pmc.json was taken from other kernel sources (commit {d.get('commit')}); not reused"
+    if d.get("quality") != q:
+        return None, "PMC file is for another quality"
+    return int(d["final_bytes_per_file"] * files), (f"PMC: 2 x FETCH_SIZE + WRITE_SIZE of k_dec_final, profiles/dec_pmc.json, commit {d.get('commit')}, batch {d.get('batch')}; "
+                                                    f"the whole decoder moves {d.get('decoder_bytes_per_file', 0) / 1e6:.2f} MB per file")
+
+
 def front_traffic(q, images):
     """HBM bytes of the front launch group from the committed PMC file (2 x FETCH_SIZE per the gfx950 note + WRITE_SIZE, per image, batch
     4096), scaled to this launch -- or None when the file was taken from other kernel sources, another quality, or is absent."""
@@ -387,7 +413,8 @@ def main():
                     # BGR out as its algorithmic traffic; it is ONE kernel (k_dec_final: the intermediate plane and the luma bytes stay in LDS), hipEvents on the launch stream
                     "roofline": {"bound": "hbm", "kernel": "k_dec_final (level-1 synthesis in both directions + q>21 corrections + smoothing at the marks + x2 chroma + colour matrix)",
                                  "achieved": round(batch * 1572864 / (rec / 1e3 / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(batch * 1572864 / (rec / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                 "frac": round(batch * 1572864 / (rec / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "traffic": final_traffic(q, batch)[0], "traffic_unit": "bytes per launch; " + final_traffic(q, batch)[1],
                                  "algorithmic_bytes_per_image": 1572864, "ms_per_launch": round(rec / args.steps, 3)}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             szh = sizes[:256].cpu().numpy(); ar = out[0][:256].cpu().numpy()
