@@ -939,13 +939,8 @@ struct Mask4 { uint64_t w[4]; };
 DEV Mask4 m4_prev(const Mask4 &a) { return Mask4{ { a.w[0] << 1, (a.w[1] << 1) | (a.w[0] >> 63), (a.w[2] << 1) | (a.w[1] >> 63), (a.w[3] << 1) | (a.w[2] >> 63) } }; }   /* bit of column j-1 at j */
 DEV Mask4 m4_next(const Mask4 &a) { return Mask4{ { (a.w[0] >> 1) | (a.w[1] << 63), (a.w[1] >> 1) | (a.w[2] << 63), (a.w[2] >> 1) | (a.w[3] << 63), a.w[3] >> 1 } }; }   /* bit of column j+1 at j */
 DEV Mask4 m4_and(const Mask4 &a, const Mask4 &b) { return Mask4{ { a.w[0] & b.w[0], a.w[1] & b.w[1], a.w[2] & b.w[2], a.w[3] & b.w[3] } }; }
-/* this lane's bit of a wave-uniform mask: the mask IS a lane-select operand, no 64-bit shift per lane needed */
-DEV int m4_bit(const Mask4 &a, int k, int)
-{
-	int r;
-	asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(a.w[k]));
-	return r;
-}
+/* this lane's bit of a wave-uniform mask: the mask IS a lane-select operand (v_cndmask), no 64-bit shift per lane needed */
+DEV int m4_bit(const Mask4 &a, int k, int) { return (int)__builtin_amdgcn_inverse_ballot_w64(a.w[k]); }
 
 /* replay the pattern symbols of the left half of one of the rows 256..511 (loop 2, :529-560), staged in LDS with its HH half behind it, in
  * column order.  Lane 0 only.  A 1008/1009 in column 0 writes the last cell of the row above: done up front, see the caller. */
@@ -1500,27 +1495,47 @@ __global__ __launch_bounds__(1024) void k_dec_luma_l2(DecWs ws, int items, int u
 #pragma unroll
 			for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * DW + 8 * (v % (S / 8))); }
 		}
-		{                                                            /* shrink: column j, rows 64 seg .. 64 seg + 63 (within 1 .. 254) */
-			const int j = t & (S - 1), seg = t >> 8, i_lo = seg ? 64 * seg : 1, i_hi = seg == 3 ? S - 2 : 64 * seg + 63;
-			const int diag = q <= 16 ? 16 : 8;
-			uint64_t hit = 0;
-			if (j >= 1 && j <= S - 2) {
-				const int16_t *x = smem + j;
-				int u0 = x[(i_lo - 1) * LS - 1], u1 = x[(i_lo - 1) * LS], u2 = x[(i_lo - 1) * LS + 1], c0 = x[i_lo * LS - 1], c1 = x[i_lo * LS], c2 = x[i_lo * LS + 1];
-				for (int i = i_lo; i <= i_hi; i++) {
-					const int d0 = x[(i + 1) * LS - 1], d1 = x[(i + 1) * LS], d2 = x[(i + 1) * LS + 1];
-					if (iabs(c1) > 8 && !(i < HLF && j < HLF) &&
-					    !(iabs(u0) > diag || iabs(u1) > 8 || iabs(u2) > diag || iabs(c0) > 8 || iabs(c2) > 8 || iabs(d0) > diag || iabs(d1) > 8 || iabs(d2) > diag))
-						hit |= 1ull << (i - i_lo);
-					u0 = c0; u1 = c1; u2 = c2; c0 = d0; c1 = d1; c2 = d2;
+		{
+			/* shrink: a wavefront takes 16 rows, its lanes the columns (lane + 64k).  "Loud" (|v| > 8, > diag) is one compare per cell into a
+			 * row mask; the 3 x 3 rule is then mask algebra on the three rows around a cell (the scalar unit's work, 256 columns at a time), and
+			 * a lane only keeps its own 4 x 16 verdicts, as bits, until every wavefront has taken its decisions. */
+			const int diag = q <= 16 ? 16 : 8, i_first = 16 * wv;
+			auto loud = [&](int r, Mask4 &m8, Mask4 &md) {
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const int a = r >= 0 && r < S ? iabs((int)smem[r * LS + lane + 64 * k]) : 0;
+					m8.w[k] = __ballot(a > 8); md.w[k] = __ballot(a > diag);
 				}
+			};
+			Mask4 p8, pd, c8, cd, n8, nd;
+			loud(i_first - 1, p8, pd); loud(i_first, c8, cd);
+			unsigned hb0 = 0, hb1 = 0;                               /* rows 0..7, 8..15 of mine: four bits a row */
+#pragma unroll 1
+			for (int t = 0; t < 16; t++) {
+				const int i = i_first + t;
+				loud(i + 1, n8, nd);
+				Mask4 h;
+				const Mask4 c8l = m4_prev(c8), c8r = m4_next(c8), pdl = m4_prev(pd), pdr = m4_next(pd), ndl = m4_prev(nd), ndr = m4_next(nd);
+#pragma unroll
+				for (int k = 0; k < 4; k++) h.w[k] = c8.w[k] & ~(c8l.w[k] | c8r.w[k] | p8.w[k] | n8.w[k] | pdl.w[k] | pdr.w[k] | ndl.w[k] | ndr.w[k]);
+				h.w[0] &= ~1ull; h.w[3] &= ~(1ull << 63);                 /* columns 1 .. 254 */
+				if (i < HLF) { h.w[0] = 0; h.w[1] = 0; }                  /* not the LL2 quadrant */
+				if (i < 1 || i > S - 2) { h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0; }
+				unsigned nib = 0;
+#pragma unroll
+				for (int k = 0; k < 4; k++) nib |= (unsigned)m4_bit(h, k, lane) << k;
+				if (t < 8) hb0 |= nib << (4 * t); else hb1 |= nib << (4 * t - 32);
+				p8 = c8; pd = cd; c8 = n8; cd = nd;
 			}
 			lds_barrier();
-			while (hit) {
-				const int i = i_lo + __builtin_ctzll(hit);
-				hit &= hit - 1;
-				int16_t *cell = smem + i * LS + j;
-				*cell = (int16_t)(*cell > 0 ? *cell - 1 : *cell + 1);
+			for (int half = 0; half < 2; half++) {
+				unsigned hb = half ? hb1 : hb0;
+				while (hb) {
+					const int b = __builtin_ctz(hb);
+					hb &= hb - 1;
+					int16_t *cell = smem + (i_first + 8 * half + (b >> 2)) * LS + lane + 64 * (b & 3);
+					*cell = (int16_t)(*cell > 0 ? *cell - 1 : *cell + 1);
+				}
 			}
 			lds_barrier();
 		}
