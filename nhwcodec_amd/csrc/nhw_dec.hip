@@ -9,12 +9,13 @@
  *   k_dec_parse    header + section table, packets copied to aligned words; the four byte-serial side streams
  *                  (LL2 DPCM bytes, the three/four position lists) are walked by one lane each, side by side
  *   k_dec_vlc      the prefix-code walk, one wavefront per stream (luma, chroma): a speculative parallel parse and a
- *                  short-state chain for the placement rules; k_dec_unzig then moves the symbols to their cells
+ *                  short-state chain for the placement rules; it leaves lists of (position, value), stream order
  *   k_dec_expand   pattern symbols -> coefficients, the +-1 nudge of the HH band, LL2 samples, odd-LL tags,
  *                  exception samples: one wavefront per image, the rows streaming through LDS in order
  *   k_dec_luma_l2  level 2 of the luma on one LDS residency of the block: shrink, synthesis both ways, residual lists
- *   k_dec_synth2d  levels 2 and 1 of both chroma planes, both directions of a level per launch
- *   k_dec_marks, k_dec_cpairs, k_dec_sharpen
+ *   k_dec_chroma   a chroma plane on one LDS residency: built from the value list, LL2 + exception samples, level 2, pair
+ *                  corrections, level 1
+ *   k_dec_marks, k_dec_sharpen
  *   k_dec_final    level 1 of the luma both ways, corrections, smoothing, chroma up-sampling, colour matrix -> BGR24
  *
  * Everything is int16/uint8 arithmetic; the only floating point is the colour matrix (compiled with
@@ -126,19 +127,6 @@ DEV void wscan_last(int &has, int &val)
 }
 DEV int from_left(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false); }   /* lane l: v of lane l - 1; lane 0: `first` */
 DEV int last_lane(int v) { return __builtin_amdgcn_readlane(v, 63); }
-
-/* add to one int16 cell when other threads may be adding to it or to its neighbour in the same 32-bit word */
-DEV void add_i16(int16_t *p, int delta)
-{
-	unsigned *w = (unsigned *)((uintptr_t)p & ~(uintptr_t)3);
-	const int sh = ((uintptr_t)p & 2) ? 16 : 0;
-	unsigned old = *w, seen;
-	do {
-		seen = old;
-		const unsigned v = ((((seen >> sh) & 0xFFFFu) + (unsigned)delta) & 0xFFFFu) << sh;
-		old = atomicCAS(w, seen, (seen & ~(0xFFFFu << sh)) | v);
-	} while (old != seen);
-}
 
 /* ---------------------------------------------------------------------------------------------- parse (d1)
  * parse_file, nhw_decoder.c:1497-1659 */
@@ -591,7 +579,7 @@ DEV int plain_level(int word)
  *     its transition from a guessed entry state, passes the exit state to the right, and the chain is iterated to its fixed
  *     point as in A.  Stream positions and the indices into the two sign-bit strings are then prefix sums.
  *
- * One workgroup per image: wave 0 the luma stream, wave 1 the chroma stream.  Symbols are stored in stream order (k_dec_unzig
+ * One wavefront (workgroup) per stream.  Values leave as a list in stream order (k_dec_expand / k_dec_chroma
  * puts them in place). */
 enum { VCH_WORDS = 128, VCH_SYMS = 2048 + 64 };
 
@@ -880,44 +868,9 @@ __global__ __launch_bounds__(64) void k_dec_vlc(DecWs ws, const uint16_t *__rest
 			}
 			if (c >= nchunks - 1 && !done && (c + 1) * VCH_WORDS > nwords + 8) { bad = 1; break; }
 		}
-		segment_index(ent, nE, 10, 128, ws.buf<uint32_t>(D_SEG, img) + SEG_CHROMA, lane);
+		if (!lane) ws.buf<uint32_t>(D_SEG, img)[SEG_CHROMA + 128] = (uint32_t)nE;     /* k_dec_chroma takes its component's entries from the whole list */
 	}
 	if (__any(bad) && !lane) atomicExch(verdict, (int)NHW_E_FORMAT);
-}
-
-/* ---------------------------------------------------------------------------------------------- un-zig-zag
- * nhw_decoder.c:71-91 (luma: strips of 4 columns, serpentine down the rows) and :904-932 / :1192-1220 (chroma: strips of 8
- * columns, U on even and V on odd stream positions).  The luma entries go straight into the rows k_dec_expand works on (there is no
- * luma plane before it).  Chroma: a workgroup builds a 64 x 64 tile of both planes in LDS -- zeros (the reference's calloc: a zero run is
- * a skip), then the entries of the tile's pieces of the stream (a strip's 64 rows are one contiguous segment of it: 1024 interleaved
- * symbols) -- and writes whole rows.  Putting a symbol straight into its cell from the walk would touch a different row for every eighth
- * symbol, and a row's line would be written back once per strip.  16 tiles per file. */
-__global__ __launch_bounds__(256) void k_dec_unzig(DecWs ws)
-{
-	__shared__ __attribute__((aligned(16))) int16_t tile[2][64][66];
-	const int img = blockIdx.y, tid = threadIdx.x;
-	if (walk_verdict(ws, img)) return;                             /* the walk's verdict (header included): the workspace header may still be in the making */
-	const uint32_t *segt = ws.buf<uint32_t>(D_SEG, img) + SEG_CHROMA;
-	for (int k = tid; k < 2 * 64 * 66 / 2; k += 256) reinterpret_cast<uint32_t *>(&tile[0][0][0])[k] = 0;
-	const int row = tid >> 2, c0 = (tid & 3) * 16;
-	const int cg = blockIdx.x & 3, rg = blockIdx.x >> 2;
-	const uint32_t *ent = ws.buf<uint32_t>(D_CB, img);
-	const int s = tid >> 5, j = tid & 31;                           /* strip within the tile (8 of 8 columns), every 32nd of its entries */
-	const int seg = (cg * 8 + s) * 4 + rg;
-	const int lo = (int)segt[seg], hi = (int)segt[seg + 1];
-	__syncthreads();
-	for (int k = lo + j; k < hi; k += 32) {
-		const uint32_t en = ent[k];
-		const int i = ENT_POS(en) & 1023, comp = i & 1, w = i >> 1, rp = w >> 4, idx = w & 15;
-		tile[comp][2 * rp + (idx >> 3)][8 * s + ((idx & 8) ? 15 - idx : (idx & 7))] = (int16_t)ENT_VAL(en);
-	}
-	__syncthreads();
-	for (int comp = 0; comp < 2; comp++) {
-		const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile[comp][row][c0]);
-		uint4 *dst = reinterpret_cast<uint4 *>(plane_ca(ws, img, comp) + (size_t)(rg * 64 + row) * DH + cg * 64 + c0);
-		dst[0] = make_uint4(t[0], t[1], t[2], t[3]);
-		dst[1] = make_uint4(t[4], t[5], t[6], t[7]);
-	}
 }
 
 /* ---------------------------------------------------------------------------------------------- expand (d3)
@@ -1309,7 +1262,7 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 		wave_sync();
 	}
 	if (!lane) {
-		/* exception samples of the luma plane (:656-668); U and V follow on the same cursor (k_dec_expand_chroma) */
+		/* exception samples of the luma plane (:656-668); U and V follow on the same cursor (k_dec_chroma) */
 		const uint8_t *x = f + m->o_exw;
 		const int n = m->exw_len;
 #define XB(k) ((k) < n ? (int)x[k] : 0)
@@ -1317,46 +1270,6 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 			if (!XB(i) && !XB(i + 1)) break;
 			const int hi = XB(i + 1) >= 128, lo = XB(i + 1) & 127;
 			a[(XB(i) << 9) + lo] = (int16_t)(hi ? XB(i + 2) + 255 : -XB(i + 2));
-		}
-#undef XB
-	}
-}
-
-/* The chroma side of the expansion: LL2 samples (:943-963, :1231-1253) and exception samples (:965-981, :1255-1267) of U and V.  A kernel of
- * its own so that the chroma sequence can run next to the luma one: it touches nothing the luma kernels write.  One wavefront per image. */
-__global__ __launch_bounds__(256) void k_dec_expand_chroma(DecWs ws)
-{
-	const int img = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-	if (img >= ws.n) return;
-	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
-	if (m->status) return;
-	const int q = m->q;
-	const uint8_t *f = ws.blob + ws.blob_off[img];
-	const uint8_t *ll = ws.buf<uint8_t>(D_LL, img);
-	for (int c = 0; c < 2; c++) {
-		int16_t *ca = plane_ca(ws, img, c);
-		const uint8_t *l = ll + DQ / 4 + (c ? DQ / 16 : 0);
-		for (int k = lane; k < DQ / 16; k += 64) ca[(size_t)(k >> 6) * DH + (k & 63)] = (int16_t)(l[k] + (q > 15 ? 0 : 1));
-	}
-	wave_sync();
-	if (!lane) {
-		/* luma, then U, then V share one cursor: skip the luma entries up to their terminator */
-		const uint8_t *x = f + m->o_exw;
-		const int n = m->exw_len;
-#define XB(k) ((k) < n ? (int)x[k] : 0)
-		int i = 0;
-		for (; i < n; i += 3) if (!XB(i) && !XB(i + 1)) break;
-		int16_t *cu = plane_ca(ws, img, 0), *cv = plane_ca(ws, img, 1);
-		i += 2;
-		for (; i < n; i += 3) {
-			if (!XB(i) && !XB(i + 1)) break;
-			const int hi = XB(i + 1) >= 128, lo = XB(i + 1) & 127;
-			cu[(XB(i) << 8) + lo] = (int16_t)(hi ? XB(i + 2) + 255 : -XB(i + 2));
-		}
-		i += 2;
-		for (; i < n; i += 3) {
-			const int hi = XB(i + 1) >= 128, lo = XB(i + 1) & 127;
-			cv[(XB(i) << 8) + lo] = (int16_t)(hi ? XB(i + 2) + 255 : -XB(i + 2));
 		}
 #undef XB
 	}
@@ -1380,12 +1293,10 @@ DEV void add_i16_at(int16_t *base, int idx, int delta)
  * The 5/3 synthesis over rows of [low half | high half] (decoder/filters.c:143-194), driven as in decoder/wavelet_filterbank.c:52-357:
  * along the rows, transpose, along the rows again (normalised), which leaves every level's result transposed.
  */
-/* Both directions of one level in one launch: the S x S block (S = 256: 129 KB, the LDS a CU has) is loaded once, filtered along the rows in
- * place, then along the columns, and column c of the result leaves as row c of the plane -- the transposed orientation the two-pass form
- * leaves behind and everything downstream expects.  The plane in between never travels.  LLT: the low-low quadrant of the block is itself the
- * transposed output of the level before (chroma level 1) and is turned while it is written to LDS.  A workgroup works through several
- * blocks and has the next one on its way, in registers, while it filters the present one (one workgroup fills a CU at S = 256: without that
- * the memory system would idle during the filter phases).  Items: images (luma, plane A) or image x component (chroma, plane CA). */
+/* Both directions of a level run on one LDS residency of the block: filtered along the rows in place (a wavefront owns a row: it has read
+ * it before it writes it), then along the columns, and column c of the result is row c of the plane -- the transposed orientation the
+ * reference's transposes leave behind and everything downstream expects.  The plane in between never travels.  The block kernels below
+ * (k_dec_luma_l2, k_dec_chroma) fill a CU's LDS with one 1024-thread workgroup, which therefore works through several blocks. */
 DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   /* orders LDS traffic only: global loads stay in flight across it */
 template <int S>
 DEV void synth_pair(const int16_t *x, int st, int k, bool norm, int &ev, int &od)
@@ -1397,64 +1308,6 @@ DEV void synth_pair(const int16_t *x, int st, int k, bool norm, int &ev, int &od
 	ev = (int16_t)((int16_t)(l0 << 3) - ((h0 + hp) << 1));
 	od = (int16_t)((int16_t)((l0 + ln) << 2) + (6 * h0 - hp - hn));
 	if (norm) { if (ev > 0) ev = (int16_t)(ev + 32); ev >>= 6; if (od > 0) od = (int16_t)(od + 32); od >>= 6; }
-}
-template <int S, bool LLT>
-__global__ __launch_bounds__(S * 4) void k_dec_synth2d(DecWs ws, int chroma, int items)
-{
-	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
-	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4, NPRE = S * (S / 8) / NT_;
-	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-	const int stride = chroma ? DH : DW;
-	auto block_of = [&](int item) { return chroma ? plane_ca(ws, item >> 1, item & 1) : plane_a(ws, item); };
-	uint4 pre[NPRE];
-	if ((int)blockIdx.x < items) {
-		const int16_t *src = block_of(blockIdx.x);
-#pragma unroll
-		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * stride + 8 * (v % (S / 8))); }
-	}
-	for (int item = blockIdx.x; item < items; item += gridDim.x) {
-		int16_t *pl = block_of(item);
-		const bool skip = ws.buf<DecMeta>(D_META, chroma ? item >> 1 : item)->status != 0;
-#pragma unroll
-		for (int u = 0; u < NPRE; u++) {
-			const int v = t + u * NT_, row = v / (S / 8), o = v % (S / 8);
-			const uint32_t w[4] = { pre[u].x, pre[u].y, pre[u].z, pre[u].w };
-			if (LLT && row < HLF && o < HLF / 8) {
-#pragma unroll
-				for (int e = 0; e < 4; e++) { smem[(8 * o + 2 * e) * LS + row] = (int16_t)(w[e] & 0xFFFFu); smem[(8 * o + 2 * e + 1) * LS + row] = (int16_t)(w[e] >> 16); }
-			} else {
-				uint32_t *d = reinterpret_cast<uint32_t *>(smem + row * LS + 8 * o);
-				d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
-			}
-		}
-		lds_barrier();
-		if (item + (int)gridDim.x < items) {
-			const int16_t *src = block_of(item + gridDim.x);
-#pragma unroll
-			for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * stride + 8 * (v % (S / 8))); }
-		}
-		for (int i = 0; i < 16; i++) {                               /* along the rows, un-normalised (decoder/filters.c:143-194) */
-			int16_t *x = smem + (wv * 16 + i) * LS;
-			int e[PPL], o[PPL];
-#pragma unroll
-			for (int u = 0; u < PPL; u++) synth_pair<S>(x, 1, lane + 64 * u, false, e[u], o[u]);
-#pragma unroll
-			for (int u = 0; u < PPL; u++) reinterpret_cast<uint32_t *>(x)[lane + 64 * u] = (uint32_t)(uint16_t)e[u] | ((uint32_t)(uint16_t)o[u] << 16);
-		}
-		lds_barrier();
-		if (!skip)
-		for (int i = 0; i < 16; i++) {                               /* along the columns, normalised: column c is row c of the plane */
-			const int c = wv * 16 + i;
-			uint32_t *dst = reinterpret_cast<uint32_t *>(pl + (size_t)c * stride);
-#pragma unroll
-			for (int u = 0; u < PPL; u++) {
-				int e, o;
-				synth_pair<S>(smem + c, LS, lane + 64 * u, true, e, o);
-				dst[lane + 64 * u] = (uint32_t)(uint16_t)e | ((uint32_t)(uint16_t)o << 16);
-			}
-		}
-		lds_barrier();                                               /* the block is done with before the next one moves in */
-	}
 }
 /* ---------------------------------------------------------------------------------------------- level 2 of the luma (:670-787)
  * Three passes of the reference on one LDS residency of the 256 x 256 block (plane A's top-left quarter), one launch:
@@ -1612,12 +1465,136 @@ __global__ __launch_bounds__(1024) void k_dec_luma_l2(DecWs ws, int items, int u
 	}
 }
 
+/* ---------------------------------------------------------------------------------------------- a chroma plane up to its level-1 synthesis
+ * One launch, one LDS residency of the 256 x 256 block per (file, component): the block is BUILT in LDS -- zeros, the component's entries of
+ * the walk's value list (stream order -> cells: strips of 8 columns, serpentine, U on even and V on odd positions, nhw_decoder.c:904-932 /
+ * :1192-1220), the LL2 samples and the exception samples (:943-981, :1231-1267) -- then level 2 of the filterbank on its 128 x 128 corner in
+ * place, the pair / single corrections carried as symbols in the level-1 detail bands (:992-1083) onto the level-1 LL, level 1, and column
+ * c of the result leaves as row c of the plane.  Before: five kernels and four round trips of the plane.  After the in-place level 2 the
+ * corner holds sample (row r, column c) of the level-1 LL at [c][r] -- which is how level 1 wants it (its row pass reads line c of the
+ * transposed LL) and where the corrections, given in plane coordinates, are added.  `upto`: the debug stop (1: the block as built, 2: after
+ * level 2, 3: after the corrections -- written back in the plane's layout; 4: everything). */
+__global__ __launch_bounds__(1024) void k_dec_chroma(DecWs ws, int items, int upto)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
+	constexpr int S = DH, LS = S + 2, HLF = S / 2, NT_ = 1024;
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	for (int item = blockIdx.x; item < items; item += gridDim.x) {
+		const int img = item >> 1, comp = item & 1;
+		const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+		if (m->status) continue;                                     /* (uniform: the whole workgroup skips the file) */
+		const int q = m->q;
+		int16_t *pl = plane_ca(ws, img, comp);
+		const uint8_t *f = ws.blob + ws.blob_off[img];
+#pragma unroll 4
+		for (int k = t; k < S * LS / 2; k += NT_) reinterpret_cast<uint32_t *>(smem)[k] = 0;
+		lds_barrier();
+		{                                                            /* the component's values */
+			const uint32_t *ent = ws.buf<uint32_t>(D_CB, img);
+			const int n_ent = (int)ws.buf<uint32_t>(D_SEG, img)[SEG_CHROMA + 128];
+			for (int k = t; k < n_ent; k += NT_) {
+				const uint32_t en = ent[k];
+				const int pos = ENT_POS(en);
+				if ((pos & 1) != comp) continue;
+				const int w = pos >> 1, strip = w >> 11, rp = (w & 2047) >> 4, idx = w & 15;
+				smem[(2 * rp + (idx >> 3)) * LS + 8 * strip + ((idx & 8) ? 15 - idx : (idx & 7))] = (int16_t)ENT_VAL(en);
+			}
+		}
+		lds_barrier();
+		{                                                            /* LL2 samples (64 x 64) */
+			const uint8_t *l = ws.buf<uint8_t>(D_LL, img) + DQ / 4 + (comp ? DQ / 16 : 0);
+#pragma unroll 1
+			for (int k = t; k < DQ / 16; k += NT_) smem[(k >> 6) * LS + (k & 63)] = (int16_t)(l[k] + (q > 15 ? 0 : 1));
+		}
+		lds_barrier();
+		if (!t) {                                                    /* exception samples: luma, then U, then V share one cursor */
+			const uint8_t *x = f + m->o_exw;
+			const int n = m->exw_len;
+#define XB(k) ((k) < n ? (int)x[k] : 0)
+			int i = 0;
+			for (; i < n; i += 3) if (!XB(i) && !XB(i + 1)) break;
+			i += 2;
+			if (comp) { for (; i < n; i += 3) if (!XB(i) && !XB(i + 1)) break; i += 2; }
+			for (; i < n; i += 3) {
+				if (!comp && !XB(i) && !XB(i + 1)) break;
+				const int hi = XB(i + 1) >= 128, lo = XB(i + 1) & 127;
+				smem[XB(i) * LS + lo] = (int16_t)(hi ? XB(i + 2) + 255 : -XB(i + 2));
+			}
+#undef XB
+		}
+		lds_barrier();
+		/* the block back to the plane for the debug stop; llt: the 128 x 128 corner sits transposed in LDS */
+		auto store_block = [&](bool llt) {
+#pragma unroll 1
+			for (int v = t; v < S * S; v += NT_) {
+				const int r = v >> 8, c = v & 255;
+				pl[(size_t)r * DH + c] = (llt && r < HLF && c < HLF) ? smem[c * LS + r] : smem[r * LS + c];
+			}
+		};
+		if (upto == 1) { store_block(false); lds_barrier(); continue; }
+#pragma unroll 1
+		for (int i = 0; i < 8; i++) {                                /* level 2, along the rows of the corner (un-normalised) */
+			int16_t *x = smem + (wv * 8 + i) * LS;
+			int e, o;
+			synth_pair<HLF>(x, 1, lane, false, e, o);
+			reinterpret_cast<uint32_t *>(x)[lane] = (uint32_t)(uint16_t)e | ((uint32_t)(uint16_t)o << 16);
+		}
+		lds_barrier();
+#pragma unroll 1
+		for (int i = 0; i < 8; i++) {                                /* along its columns, normalised, in place */
+			int16_t *x = smem + wv * 8 + i;
+			int e, o;
+			synth_pair<HLF>(x, LS, lane, true, e, o);
+			x[(2 * lane) * LS] = (int16_t)e; x[(2 * lane + 1) * LS] = (int16_t)o;
+		}
+		lds_barrier();
+		if (upto == 2) { store_block(true); lds_barrier(); continue; }
+#pragma unroll 2
+		for (int v = t; v < S * S; v += NT_) {                       /* the corrections: a symbol in a detail band steps the level-1 LL cell(s) it sits over */
+			const int i = v >> 8, j = v & 255;
+			if (i < HLF && j < HLF) continue;
+			const int sy = smem[i * LS + j];
+			if (sy < 5003 || sy > 5006) continue;
+			const int ti = i < HLF ? i : i - HLF, tj = j < HLF ? j : j - HLF;   /* plane cell (ti, tj) of the LL sits at [tj][ti] */
+			const bool two = tj < HLF - 1;                            /* the second cell of a pair at the last LL column is scratch in the reference */
+			const int d = sy == 5005 ? -4 : sy == 5006 ? 4 : sy == 5003 ? -6 : 6;
+			add_i16_at(smem, tj * LS + ti, d);
+			if (two && (sy == 5005 || sy == 5006)) add_i16_at(smem, (tj + 1) * LS + ti, d);
+			smem[i * LS + j] = 0;
+		}
+		lds_barrier();
+		if (upto == 3) { store_block(true); lds_barrier(); continue; }
+#pragma unroll 1
+		for (int i = 0; i < 16; i++) {                               /* level 1, along the rows */
+			int16_t *x = smem + (wv * 16 + i) * LS;
+			int e[2], o[2];
+#pragma unroll
+			for (int u = 0; u < 2; u++) synth_pair<S>(x, 1, lane + 64 * u, false, e[u], o[u]);
+#pragma unroll
+			for (int u = 0; u < 2; u++) reinterpret_cast<uint32_t *>(x)[lane + 64 * u] = (uint32_t)(uint16_t)e[u] | ((uint32_t)(uint16_t)o[u] << 16);
+		}
+		lds_barrier();
+#pragma unroll 1
+		for (int i = 0; i < 16; i++) {                               /* along the columns, normalised: column c is row c of the plane */
+			const int c = wv * 16 + i;
+			uint32_t *dst = reinterpret_cast<uint32_t *>(pl + (size_t)c * DH);
+#pragma unroll
+			for (int u = 0; u < 2; u++) {
+				int e, o;
+				synth_pair<S>(smem + c, LS, lane + 64 * u, true, e, o);
+				dst[lane + 64 * u] = (uint32_t)(uint16_t)e | ((uint32_t)(uint16_t)o << 16);
+			}
+		}
+		lds_barrier();                                               /* the block is done with before the next one is built */
+	}
+}
+
 #define SYNTH_WGS 256                /* one resident workgroup per CU for the 256 x 256 blocks */
 static int synth2d_attrs()
 {
 	int rc = NHW_OK;                                               /* per device: every handle sets it for its own */
 	const int big = 256 * 258 * (int)sizeof(int16_t);
-	if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_synth2d<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+	if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_chroma), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
 	    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_luma_l2), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) rc = NHW_E_HIP;
 	return rc;
 }
@@ -1711,28 +1688,7 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 }
 
 /* ---------------------------------------------------------------------------------------------- chroma
- * pair / single corrections carried as symbols in the level-1 detail bands (:992-1083) */
-#define CPAIR_ROWS 16
-__global__ __launch_bounds__(256) void k_dec_cpairs(DecWs ws)
-{
-	const int img = blockIdx.y, comp = blockIdx.z, j = threadIdx.x;
-	if (ws.buf<DecMeta>(D_META, img)->status) return;
-	int16_t *a = plane_ca(ws, img, comp);
-	for (int i = CPAIR_ROWS * blockIdx.x; i < CPAIR_ROWS * (blockIdx.x + 1); i++) {   /* a workgroup per row was two million workgroups of a few instructions */
-	if (i < DH / 2 && j < DH / 2) continue;
-	int16_t *p = a + (size_t)i * DH + j;
-	const int s = *p;
-	if (s < 5003 || s > 5006) continue;
-	int16_t *t = a + (size_t)(i < DH / 2 ? i : i - DH / 2) * DH + (j < DH / 2 ? j : j - DH / 2);   /* level-1 LL lives in the top-left quarter of the same plane */
-	const bool two = (j < DH / 2 ? j : j - DH / 2) < DH / 2 - 1;      /* the second cell of a pair at the last LL column is scratch in the reference */
-	if (s == 5005) { add_i16(t, -4); if (two) add_i16(t + 1, -4); }
-	else if (s == 5006) { add_i16(t, 4); if (two) add_i16(t + 1, 4); }
-	else if (s == 5003) add_i16(t, -6);
-	else add_i16(t, 6);
-	*p = 0;
-	}
-}
-
+ */
 /* sharpen (:1097-1121): in place and in raster order -- a cell sees the new values of its left and upper neighbours.
  * One wavefront per plane, rows in order, a lane owns four consecutive cells; along a row the only thing that travels is
  * the change (0, +-2, +-3) of the cell on the left, settled by re-evaluating until no lane's outgoing change moves. */
@@ -2148,7 +2104,6 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	k_dec_parse<<<4 * n, 64, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 1 */
 	k_dec_vlc<<<2 * n, 64, 0, cs>>>(ws, d->vlc_table);
-	k_dec_unzig<<<dim3(16, n), 256, 0, cs>>>(ws);
 	if (fork) {
 		HIPCHK(hipEventRecord(d->join_ev, cs)); HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
 		HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0));   /* chroma goes on once both branches are in */
@@ -2156,18 +2111,16 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	k_dec_verdict<<<(n + 255) / 256, 256, 0, s>>>(ws);
 	EV(1);
 	STAGE_END();                                                                  /* 2 */
-	/* From here the luma and the chroma sequences share nothing until the colour kernel: chroma goes to a stream of its own, where its
-	 * bandwidth-bound kernels run under the latency-bound luma ones (the expansion walk, the marks chain).  With the debug stop it stays in line. */
+	/* From here the luma and the chroma sequences share nothing until the colour kernel: chroma goes to a stream of its own.  With the debug
+	 * stop it stays in line. */
+#define CHROMA(UPTO, STREAM) k_dec_chroma<<<2 * n < SYNTH_WGS ? 2 * n : SYNTH_WGS, 1024, 256 * 258 * sizeof(int16_t), STREAM>>>(ws, 2 * n, UPTO)
 	k_dec_expand<<<(n + 3) / 4, 256, 0, s>>>(ws);
-	k_dec_expand_chroma<<<(n + 3) / 4, 256, 0, cs>>>(ws);
 	if (fork) {
-		/* chroma, both planes per launch (blockIdx.z) */
-		k_dec_synth2d<128, false><<<2 * n, 512, 128 * 130 * sizeof(int16_t), cs>>>(ws, 1, 2 * n);                                        /* level 2 */
-		k_dec_cpairs<<<dim3(DH / CPAIR_ROWS, n, 2), 256, 0, cs>>>(ws);
-		k_dec_synth2d<256, true><<<2 * n < SYNTH_WGS ? 2 * n : SYNTH_WGS, 1024, 256 * 258 * sizeof(int16_t), cs>>>(ws, 1, 2 * n);      /* level 1 */
+		CHROMA(4, cs);
 		k_dec_sharpen<<<(2 * n + 3) / 4, 256, 0, cs>>>(ws);
 		HIPCHK(hipEventRecord(d->join_ev, cs));
 	}
+	else if (d->stop_after == 3) CHROMA(1, s);                                    /* the chroma planes as the expansion leaves them */
 	STAGE_END();                                                                  /* 3 */
 	{
 		/* level 2 of the luma: shrink, synthesis, residual lists on A's top-left 256 x 256 -> the level-1 LL in the same place */
@@ -2181,12 +2134,9 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	STAGE_END();                                                                  /* 7 */
 	if (fork) HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
 	else {
-		/* chroma, both planes per launch (blockIdx.z) */
-		k_dec_synth2d<128, false><<<2 * n, 512, 128 * 130 * sizeof(int16_t), s>>>(ws, 1, 2 * n);
-		STAGE_END();                                                              /* 8 */
-		k_dec_cpairs<<<dim3(DH / CPAIR_ROWS, n, 2), 256, 0, s>>>(ws);
-		STAGE_END();                                                              /* 9 */
-		k_dec_synth2d<256, true><<<2 * n < SYNTH_WGS ? 2 * n : SYNTH_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(ws, 1, 2 * n);
+		CHROMA(d->stop_after == 8 ? 2 : d->stop_after == 9 ? 3 : 4, s);
+		STAGE_END();                                                              /* 8 (after level 2) */
+		STAGE_END();                                                              /* 9 (after the corrections) */
 		STAGE_END();                                                              /* 10 */
 		k_dec_sharpen<<<(2 * n + 3) / 4, 256, 0, s>>>(ws);
 		STAGE_END();                                                              /* 11 */
@@ -2208,6 +2158,7 @@ done:
 	return NHW_OK;
 #undef STAGE_END
 #undef EV
+#undef CHROMA
 }
 
 extern "C" int nhw_dec_last_timing(nhw_dec *d, nhw_dec_timing *t)
