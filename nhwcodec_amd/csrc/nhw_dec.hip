@@ -1703,14 +1703,32 @@ __global__ __launch_bounds__(256) void k_dec_sharpen(DecWs ws)
 	int16_t *b = plane_ca(ws, img, comp);
 	uint8_t *out = ws.buf<uint8_t>(D_CU, img) + (size_t)comp * DQ;
 	int up[6], cur[6], dn[6];                                       /* cells 4l-1 .. 4l+4 of rows i-1 (already sharpened), i, i+1 */
-#define LOADROW(dst, r) do { const int16_t *p_ = b + (size_t)(r) * DH + 4 * lane; for (int k_ = 0; k_ < 6; k_++) { const int c_ = 4 * lane - 1 + k_; dst[k_] = (c_ >= 0 && c_ < DH) ? p_[k_ - 1] : 0; } } while (0)
-	LOADROW(up, 0); LOADROW(cur, 1);
-	for (int k = 0; k < 4; k++) out[4 * lane + k] = (uint8_t)clip8(up[k + 1]);
+	/* a lane loads its own four cells of a row with one 8-byte load, SH_AHEAD rows ahead of the one in work (the walk down the rows is a
+	 * chain, the loads are not part of it), and takes the cell on either side from its neighbours */
+	auto ld = [&](int r) { return *reinterpret_cast<const uint2 *>(b + (size_t)(r < DH ? r : DH - 1) * DH + 4 * lane); };
+	auto spread = [&](const uint2 &w, int *dst) {
+		dst[1] = (int16_t)(w.x & 0xFFFFu); dst[2] = (int16_t)(w.x >> 16); dst[3] = (int16_t)(w.y & 0xFFFFu); dst[4] = (int16_t)(w.y >> 16);
+		const int l = from_left(dst[4], 0), r = __builtin_amdgcn_update_dpp(0, dst[1], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+		dst[0] = lane ? l : 0; dst[5] = lane < 63 ? r : 0;
+	};
+	auto put = [&](int r, const int *v /* [4] */) {
+		*reinterpret_cast<uint32_t *>(out + (size_t)r * DH + 4 * lane) = (uint32_t)clip8(v[0]) | ((uint32_t)clip8(v[1]) << 8) | ((uint32_t)clip8(v[2]) << 16) | ((uint32_t)clip8(v[3]) << 24);
+	};
+#define SH_AHEAD 4
+	{ const uint2 r0 = ld(0), r1 = ld(1); spread(r0, up); spread(r1, cur); }
+	uint2 fly[SH_AHEAD];
+#pragma unroll
+	for (int g = 0; g < SH_AHEAD; g++) fly[g] = ld(2 + g);
+	put(0, up + 1);
 	for (int i = 1; i < DH - 1; i++) {
-		LOADROW(dn, i + 1);
+		spread(fly[0], dn);
+#pragma unroll
+		for (int g = 0; g + 1 < SH_AHEAD; g++) fly[g] = fly[g + 1];
+		fly[SH_AHEAD - 1] = ld(i + 1 + SH_AHEAD);
 		int nw[4], din = 0;
 		for (;;) {
 			int left = cur[0] + din;
+#pragma unroll
 			for (int k = 0; k < 4; k++) {
 				const int c = 4 * lane + k;
 				const int x = cur[k + 1];
@@ -1721,19 +1739,21 @@ __global__ __launch_bounds__(256) void k_dec_sharpen(DecWs ws)
 				}
 				nw[k] = v; left = v;
 			}
-			const int fromL = __shfl(nw[3] - cur[4], (lane + 63) & 63);
-			const int ndin = lane ? fromL : 0;
+			const int ndin = from_left(nw[3] - cur[4], 0);
 			if (!__any(ndin != din)) break;
 			din = ndin;
 		}
 		/* the sharpened row becomes `up`: own cells, plus the edge cells of the neighbours */
-		const int l = __shfl(nw[3], (lane + 63) & 63), r = __shfl(nw[0], (lane + 1) & 63);
+		const int l = from_left(nw[3], 0), r = __builtin_amdgcn_update_dpp(0, nw[0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
 		up[0] = lane ? l : 0; up[5] = lane < 63 ? r : 0;
-		for (int k = 0; k < 4; k++) { up[k + 1] = nw[k]; out[(size_t)i * DH + 4 * lane + k] = (uint8_t)clip8(nw[k]); }
+#pragma unroll
+		for (int k = 0; k < 4; k++) up[k + 1] = nw[k];
+		put(i, nw);
+#pragma unroll
 		for (int k = 0; k < 6; k++) cur[k] = dn[k];
 	}
-	for (int k = 0; k < 4; k++) out[(size_t)(DH - 1) * DH + 4 * lane + k] = (uint8_t)clip8(cur[k + 1]);
-#undef LOADROW
+	put(DH - 1, cur + 1);
+#undef SH_AHEAD
 }
 
 /* ---------------------------------------------------------------------------------------------- colour (d5 tail + d6)
