@@ -182,11 +182,19 @@ DEV void parse_header(const uint8_t *d, uint32_t len, DecMeta *m)
 /* A wavefront's view of a byte string, 64 bytes at a time (lane l holds byte i0 + l): the block in hand, and the next one already
  * on its way from memory while this one is being worked on.  Bytes behind the end read 0. */
 struct BlockReader {
-	const uint8_t *g; int len, i0, cur, nxt;
+	const uint8_t *g; int len, i0, cur, nxt, n2, n3;                /* the block in hand and the three behind it: a 64-byte step is shorter than a memory round trip */
 	DEV int ld(int i) const { return i < len ? (int)g[i] : 0; }
-	DEV void init(const uint8_t *g_, int len_, int start, int lane) { g = g_; len = len_; i0 = start; cur = ld(i0 + lane); nxt = ld(i0 + 64 + lane); }
-	DEV void advance(int lane) { i0 += 64; cur = nxt; nxt = ld(i0 + 64 + lane); }
-	DEV int after(int lane) const { const int a = __shfl(cur, (lane + 1) & 63), b = __shfl(nxt, 0); return lane < 63 ? a : b; }   /* byte i0 + l + 1 */
+	DEV void init(const uint8_t *g_, int len_, int start, int lane) { g = g_; len = len_; i0 = start; cur = ld(i0 + lane); nxt = ld(i0 + 64 + lane); n2 = ld(i0 + 128 + lane); n3 = ld(i0 + 192 + lane); }
+	DEV void advance(int lane) { i0 += 64; cur = nxt; nxt = n2; n2 = n3; n3 = ld(i0 + 192 + lane); }
+	DEV int after(int lane) const { const int a = __builtin_amdgcn_update_dpp(0, cur, 0x130 /* wave_shl:1 */, 0xF, 0xF, false), b = __builtin_amdgcn_readlane(nxt, 0); return lane < 63 ? a : b; }   /* byte i0 + l + 1 */
+};
+/* bytes that a walk consumes a few at a time, at most 64 a step, by index: a 256-byte window in registers that slides 64 at a time */
+struct WindowReader {
+	const uint8_t *g; int len, base, w0, w1, w2, w3;
+	DEV int ld(int i) const { return i < len ? (int)g[i] : 0; }
+	DEV void init(const uint8_t *g_, int len_, int lane) { g = g_; len = len_; base = 0; w0 = ld(lane); w1 = ld(64 + lane); w2 = ld(128 + lane); w3 = ld(192 + lane); }
+	DEV int at(int i) const { const int r = i - base, a = __shfl(w0, r & 63), b = __shfl(w1, r & 63); return r < 64 ? a : b; }   /* base <= i < base + 128 */
+	DEV void consumed_up_to(int a, int lane) { if (a - base >= 64) { base += 64; w0 = w1; w1 = w2; w2 = w3; w3 = ld(base + 192 + lane); } }   /* a: first index still wanted */
 };
 
 /* LL2 samples (res_comp), nhw_decoder.c:1661-2026; unsigned char arithmetic.
@@ -295,27 +303,30 @@ DEV void ll_expand_wave(const uint8_t *code_g, int code_len, const uint8_t *fine
 	const int mode = (m->res_high & 3) == 3 ? 0 : (m->res_high & 3), q = m->q;
 	int prev = code_len > 0 ? code_g[0] : 0, j = 1, a = 0;
 	code.init(code_g, code_len, 1, lane);
+	WindowReader fines;
+	fines.init(fine, q > 15 ? m->ll_word_len : 0, lane);
 	bool pending = false;                                           /* byte i0 is the payload of a token that started in the block before */
 	if (!lane) ll[0] = (uint8_t)prev;
 	int split = -1;                                                 /* index of the byte that is sample 16384 */
 	while (split < 0) {
 		const int b = code.cur, d = code.after(lane), i0 = code.i0;
 		const uint64_t T = __ballot(b >= 64 && b < 128);
-		uint64_t pay = pending ? 1ull : 0ull, m_ = T;
-		bool pend_out = false;
-		while (m_) {                                                /* a 64..127 byte that is not itself a payload starts a two-byte token */
-			const int l = __builtin_ctzll(m_);
-			m_ &= m_ - 1;
-			if ((pay >> l) & 1ull) continue;
-			if (l == 63) pend_out = true; else pay |= 1ull << (l + 1);
-		}
+		/* a 64..127 byte that is not itself a payload starts a two-byte token: inside a run of such bytes every second one does, counted from
+		 * the run's first byte (which starts one unless it is the payload handed over by the block before).  The starters of the runs that
+		 * begin on an even position are the run's bytes on even positions, likewise odd: a carry through the run picks the run out. */
+		const uint64_t Tm = pending ? T & ~1ull : T;                  /* byte 0 is a payload: it starts nothing, whatever it is */
+		const uint64_t rs = Tm & ~(Tm << 1), ev = 0x5555555555555555ull;
+		const uint64_t starters = (Tm & ~(Tm + (rs & ev)) & ev) | (Tm & ~(Tm + (rs & ~ev)) & ~ev);
+		const uint64_t pay = (starters << 1) | (pending ? 1ull : 0ull);
+		const bool pend_out = (starters >> 63) != 0;
 		const bool start = !((pay >> lane) & 1ull);
 		const bool verb = start && b >= 128;
 		/* fine bytes: one per verbatim token, in order */
 		int vpre = verb ? 1 : 0;
 		vpre = wscan_add(vpre);
 		const int fidx = a + vpre - 1;
-		const int fv = (verb && q > 15 && fidx < m->ll_word_len) ? fine[fidx] : 0;
+		const int fw = fines.at(verb ? fidx : a);                   /* (every lane takes part in the shuffle) */
+		const int fv = (verb && q > 15 && fidx < m->ll_word_len) ? fw : 0;
 		LlTok t = ll_token_luma(b, d, mode, q > 15, fv);
 		/* where would my token start? the first token at or past sample 16384 is not a token but the chroma seed */
 		const int cnt = start ? (t.abs_n ? t.abs_n : t.copies + t.n) : 0;
@@ -326,6 +337,7 @@ DEV void ll_expand_wave(const uint8_t *code_g, int code_len, const uint8_t *fine
 		if (over) { const int ls = __builtin_ctzll(over); split = i0 + ls; live = start && lane < ls; }
 		ll_emit_block(t, live, lane, j, prev, DQ / 4, ll);
 		a += __shfl(vpre, 63);                                     /* (past the split this is no longer used) */
+		fines.consumed_up_to(a, lane);
 		pending = pend_out;
 		code.advance(lane);
 	}
