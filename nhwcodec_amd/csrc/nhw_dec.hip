@@ -292,8 +292,8 @@ DEV void ll_emit_block(const LlTok &t, bool is_tok, int lane, int &j, int &prev,
 			if (t.n > 2) { v += t.d2; if (at < limit) ll[at] = (uint8_t)v; at++; }
 		}
 	}
-	j += __shfl(off, 63);
-	prev = __shfl(after, 63);
+	j += last_lane(off);
+	prev = last_lane(after);
 }
 
 /* whole wavefront */
@@ -336,7 +336,7 @@ DEV void ll_expand_wave(const uint8_t *code_g, int code_len, const uint8_t *fine
 		bool live = start;
 		if (over) { const int ls = __builtin_ctzll(over); split = i0 + ls; live = start && lane < ls; }
 		ll_emit_block(t, live, lane, j, prev, DQ / 4, ll);
-		a += __shfl(vpre, 63);                                     /* (past the split this is no longer used) */
+		a += last_lane(vpre);                                     /* (past the split this is no longer used) */
 		fines.consumed_up_to(a, lane);
 		pending = pend_out;
 		code.advance(lane);
@@ -417,8 +417,8 @@ DEV int poslist_wave(const uint8_t *list, int len, T *pos, int cap, int row_step
 			if (at < cap) pos[at] = (T)(mask16 ? (v1 & 0xFFFFu) : v1);
 			if (nemit > 1 && at + 1 < cap) pos[at + 1] = (T)(mask16 ? (v2 & 0xFFFFu) : v2);
 		}
-		c.last = __shfl(last_after, 63); c.p127 = __shfl(st_after, 63);
-		c.row += __shfl(rsum, 63); c.n += __shfl(esum, 63);
+		c.last = last_lane(last_after); c.p127 = last_lane(st_after);
+		c.row += last_lane(rsum); c.n += last_lane(esum);
 	}
 	return c.n;
 }
@@ -656,11 +656,11 @@ DEV int vlc_parse_chunk(const uint8_t *g, int nwords, int c, int &start0, bool z
 		int pos = start, at = off - cnt, rk;
 		while (pos < hi) { pos += code_at(cw, pos, zoned, lut, lut2, rk); if (rk < 0) { bad = 1; rk = 0; } syms[at++] = (uint16_t)rk; }
 	}
-	start0 = __shfl(exitp, 63) - 64 * 64;
+	start0 = last_lane(exitp) - 64 * 64;
 	if (start0 < 0) start0 = 0;
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	__builtin_amdgcn_wave_barrier();
-	return __shfl(off, 63);
+	return last_lane(off);
 }
 
 /* B: the luma placement state.  bits 0-1 mem (3 = three or more), 2 mem2, 3 nhw_ac1, 4-8 which of the five values before are
@@ -842,8 +842,8 @@ __global__ __launch_bounds__(64) void k_dec_vlc(DecWs ws, const uint16_t *__rest
 				if (lm != __ballot(have)) done = true;
 				if (lm) {
 					const int last = 63 - __builtin_clzll(lm);
-					e += __shfl(pe, last); t1 += __shfl(p1, last); t2 += __shfl(p2, last); nE += __shfl(pw, last);
-					carry = (unsigned)__shfl((int)sout, last);
+					e += __builtin_amdgcn_readlane(pe, last); t1 += __builtin_amdgcn_readlane(p1, last); t2 += __builtin_amdgcn_readlane(p2, last); nE += __builtin_amdgcn_readlane(pw, last);
+					carry = (unsigned)__builtin_amdgcn_readlane((int)sout, last);
 				}
 				if (e >= limit) done = true;
 			}
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(64) void k_dec_vlc(DecWs ws, const uint16_t *__rest
 				}
 				const uint64_t lm = __ballot(live);
 				if (lm != __ballot(have)) done = true;
-				if (lm) { const int last = 63 - __builtin_clzll(lm); e += __shfl(pe, last); nE += __shfl(pw, last); }
+				if (lm) { const int last = 63 - __builtin_clzll(lm); e += __builtin_amdgcn_readlane(pe, last); nE += __builtin_amdgcn_readlane(pw, last); }
 				if (e >= limit) done = true;
 			}
 			if (c >= nchunks - 1 && !done && (c + 1) * VCH_WORDS > nwords + 8) { bad = 1; break; }
@@ -1174,9 +1174,10 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					const int c = DH + lane + 64 * k;
-					const int l = __shfl(cur[k], (lane + 63) & 63), lw = k ? __shfl(cur[k - 1], 63) : 0;
-					const int r = __shfl(cur[k], (lane + 1) & 63), rw = k < 3 ? __shfl(cur[k + 1], 0) : 0;
-					const int lv = lane ? l : lw, rv = lane < 63 ? r : rw;
+					const int lw = k ? __builtin_amdgcn_readlane(cur[k - 1], 63) : 0, rw = k < 3 ? __builtin_amdgcn_readlane(cur[k + 1], 0) : 0;
+					const int lv = from_left(cur[k], lw);                   /* lane 0 takes the word seam */
+					const int r = __builtin_amdgcn_update_dpp(0, cur[k], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+					const int rv = lane < 63 ? r : rw;
 					const int lk = m4_bit(liveK, k, lane), l67 = m4_bit(live67, k, lane), lkL = m4_bit(kL, k, lane), lkR = m4_bit(kR, k, lane);
 					const bool cd = !lkL && !lk && !l67 && cur[k] <= 1000 && iabs(cur[k]) > 8 && iabs(cur[k]) < 16 && c > DH && c < DW - 1 && q < 23;
 					const bool lsmall = m4_bit(kL2, k, lane) || m4_bit(s67L, k, lane) || iabs(lv) < 8;
@@ -1663,7 +1664,7 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 #pragma unroll
 		for (int x = 0; x < 6; x++) { up[x] = mid[x]; mid[x] = dn[x]; }
 		/* marks above cells 4l .. 4l+5 as bits 0..5 */
-		const unsigned fromL = (unsigned)__shfl((int)above, (lane + 63) & 63), fromR = (unsigned)__shfl((int)above, (lane + 1) & 63);
+		const unsigned fromL = (unsigned)from_left((int)above, 0), fromR = (unsigned)__builtin_amdgcn_update_dpp(0, (int)above, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
 		const unsigned ab = (lane ? (fromL >> 3) & 1u : 0u) | (above << 1) | (lane < 63 ? (fromR & 1u) << 5 : 0u);
 		int cont[4];
 #pragma unroll
@@ -1691,7 +1692,7 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 		int at = total + pre - cnt;
 #pragma unroll
 		for (int k = 0; k < 4; k++) if ((mine >> k) & 1u) marks[at++] = (uint16_t)(i * DH + 4 * lane + 1 + k);
-		total += __shfl(pre, 63);
+		total += last_lane(pre);
 		above = mine;
 		if (!lane) rowstart[i + 1] = (uint16_t)total;
 	}
