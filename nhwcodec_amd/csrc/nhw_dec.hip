@@ -44,7 +44,7 @@ enum {
 enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304 /* sanity bound on the packet words of a file (the encoder's buffer holds 80000) */ };
 const size_t k_dec_bytes[D_COUNT] = {
 	/* META */ 512, /* LL */ 24832, /* SPARE */ 1024, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
-	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B */ 16 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB */ 8 * DQ + 8192, /* CU */ 2 * DQ,
+	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B: luma value list */ 16 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB: chroma value list */ 8 * DQ + 8192, /* CU */ 2 * DQ,
 	/* SEG */ 5120
 };
 
@@ -84,8 +84,8 @@ struct DecWs {
 DEV int16_t *plane_a(const DecWs &ws, int img) { return ws.buf<int16_t>(D_A, img) + 2048; }
 /* D_B / D_CB: what the prefix-code walk found, as a list in stream order -- (value << 18) | position in the stream, one word per value that
  * is not part of a zero run (at most one per cell, plus a few words of slack) -- and D_SEG: the index of the first entry at or behind the
- * start of every piece of the stream its consumer takes in one go (luma: the 128 strips of 2048 symbols, from word 0; chroma: 128
- * segments of 1024 interleaved symbols, from word SEG_CHROMA), with the total behind the last one */
+ * start of each of the 128 strips (2048 symbols) of the luma stream, the total behind them (k_dec_expand follows every strip with a
+ * cursor); of the chroma list only the total, at word SEG_CHROMA + 128 (k_dec_chroma goes through the whole list) */
 #define SEG_CHROMA 1040
 #define ENT_POS(e) ((int)((e) & 0x3FFFFu))
 #define ENT_VAL(e) ((int)(e) >> 18)
@@ -1998,7 +1998,6 @@ __global__ __launch_bounds__(256) void k_dec_final(DecWs ws, uint8_t *out, int d
 			uint32_t w[3] = { 0, 0, 0 };
 #pragma unroll
 			for (int px = 0; px < 4; px++) {
-				const int x = 4 * t + px;
 				int uv, vv;
 				/* (the last two columns repeat column 255: tu[1] = tu[2] = column 255 there, and both rules give it) */
 				if (px & 1) { uv = (tu[px >> 1] + tu[(px >> 1) + 1] + 1) >> 1; vv = (tv[px >> 1] + tv[(px >> 1) + 1] + 1) >> 1; }
