@@ -125,6 +125,15 @@ DEV void wscan_last(int &has, int &val)
 	DPP_STEPS(S_)
 #undef S_
 }
+/* Markers that take the byte behind them as a payload, whatever that byte is: inside a run of marker bytes every second one is a marker,
+ * counted from the run's first byte (unless that one is the payload handed over by the block before).  T: the marker-valued bytes of a
+ * 64-byte block; returns the real markers.  The markers of the runs that begin on an even position are the run's bytes on even positions,
+ * likewise odd: an addition at the run's first bit carries through the run and picks it out. */
+DEV uint64_t alt_starts(uint64_t T, bool pending)
+{
+	const uint64_t Tm = pending ? T & ~1ull : T, rs = Tm & ~(Tm << 1), ev = 0x5555555555555555ull;
+	return (Tm & ~(Tm + (rs & ev)) & ev) | (Tm & ~(Tm + (rs & ~ev)) & ~ev);
+}
 DEV int from_left(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false); }   /* lane l: v of lane l - 1; lane 0: `first` */
 DEV int last_lane(int v) { return __builtin_amdgcn_readlane(v, 63); }
 
@@ -311,12 +320,8 @@ DEV void ll_expand_wave(const uint8_t *code_g, int code_len, const uint8_t *fine
 	while (split < 0) {
 		const int b = code.cur, d = code.after(lane), i0 = code.i0;
 		const uint64_t T = __ballot(b >= 64 && b < 128);
-		/* a 64..127 byte that is not itself a payload starts a two-byte token: inside a run of such bytes every second one does, counted from
-		 * the run's first byte (which starts one unless it is the payload handed over by the block before).  The starters of the runs that
-		 * begin on an even position are the run's bytes on even positions, likewise odd: a carry through the run picks the run out. */
-		const uint64_t Tm = pending ? T & ~1ull : T;                  /* byte 0 is a payload: it starts nothing, whatever it is */
-		const uint64_t rs = Tm & ~(Tm << 1), ev = 0x5555555555555555ull;
-		const uint64_t starters = (Tm & ~(Tm + (rs & ev)) & ev) | (Tm & ~(Tm + (rs & ~ev)) & ~ev);
+		/* a 64..127 byte that is not itself a payload starts a two-byte token */
+		const uint64_t starters = alt_starts(T, pending);
 		const uint64_t pay = (starters << 1) | (pending ? 1ull : 0ull);
 		const bool pend_out = (starters >> 63) != 0;
 		const bool start = !((pay >> lane) & 1ull);
@@ -560,6 +565,52 @@ DEV int build_book_small(const uint8_t *raw_g, int raw_len, const uint8_t *raw_s
 	return n;
 }
 
+/* the same by a whole wavefront, the packed book in LDS (raw_len <= BOOK_STAGE): both byte-serial parts are "a marker takes the next byte
+ * as its payload" walks (the 3 / 128 repeat marker of the packing, the two-byte entries of the book), 64 bytes a step */
+DEV void build_book_wave(const uint8_t *raw, int raw_len, bool chroma, int tree_end, uint16_t *book, uint8_t *scr, int lane)
+{
+	uint8_t *flat = scr, *inter = scr + 720;
+	const int rep = chroma ? 128 : 3;
+	for (int k = lane; k < 1440; k += 64) scr[k] = 0;
+	__syncthreads();
+	int e = 0;
+	bool pend = false;
+	for (int i0 = 0; i0 < raw_len && e < 708; i0 += 64) {
+		const int i = i0 + lane;
+		const bool valid = i < raw_len;
+		const int b = valid ? raw[i] : -1, cnt = i + 1 < raw_len ? raw[i + 1] : 0;
+		const uint64_t st = alt_starts(__ballot(b == rep), pend), pay = (st << 1) | (pend ? 1ull : 0ull);
+		const bool is_st = (st >> lane) & 1ull, is_pay = (pay >> lane) & 1ull;
+		const int len = !valid || is_pay ? 0 : is_st ? cnt : 1;
+		const int inc = wscan_add(len), at = e + inc - len;
+		if (is_st) { for (int z = 0; z < cnt && at + z < 708; z++) flat[at + z] = (uint8_t)rep; }
+		else if (len && at < 708) flat[at] = (uint8_t)b;
+		e = min(708, e + last_lane(inc));
+		pend = (st >> 63) != 0;
+	}
+	if (chroma) e = tree_end;
+	if (e > 708) e = 708;
+	if (e < 0) e = 0;
+	__syncthreads();
+	for (int k = lane; k < e; k += 64) inter[k] = flat[(k & 1) ? ((e + 1) >> 1) + (k >> 1) : (k >> 1)];
+	__syncthreads();
+	int n = 0;
+	pend = false;
+	for (int i0 = 0; i0 < e; i0 += 64) {
+		const int i = i0 + lane;
+		const bool valid = i < e;
+		const int b = valid ? inter[i] : 1, nx = valid ? inter[i + 1] : 0;      /* (1: a marker of neither kind) */
+		const uint64_t st = alt_starts(__ballot(valid && (chroma ? !(b & 1) : b == 3)), pend), pay = (st << 1) | (pend ? 1ull : 0ull);
+		const bool is_st = (st >> lane) & 1ull, entry = valid && !((pay >> lane) & 1ull);
+		const int v = is_st ? (chroma ? (nx << 8) | b : (nx << 8) | 128) : (chroma ? 256 | (b & 0xfe) : 256 | b);
+		const int inc = wscan_add(entry ? 1 : 0), idx = n + inc - (entry ? 1 : 0);
+		if (entry && idx < 354) book[idx] = (uint16_t)v;
+		n += last_lane(inc);
+		pend = (st >> 63) != 0;
+	}
+	for (int r = (n < 354 ? n : 354) + lane; r < 354; r += 64) book[r] = 0;
+}
+
 DEV int extra_level(int word)          /* decoder/tables.h:51 */
 {
 	const int off = word & 7;
@@ -768,7 +819,8 @@ __global__ __launch_bounds__(64) void k_dec_vlc(DecWs ws, const uint16_t *__rest
 		const int raw_len = part ? m->book2_len : m->book1_len, staged = min(raw_len, BOOK_STAGE);
 		for (int k = lane; k < staged; k += 64) stage[1440 + k] = raw[k];
 		__syncthreads();
-		if (!lane) build_book_small(raw, raw_len, stage + 1440, staged, part != 0, m->tree_end, book, stage /* 1440 bytes of scratch */);
+		if (raw_len <= BOOK_STAGE) build_book_wave(stage + 1440, raw_len, part != 0, m->tree_end, book, stage /* 1440 bytes of scratch */, lane);
+		else if (!lane) build_book_small(raw, raw_len, stage + 1440, staged, part != 0, m->tree_end, book, stage);   /* (no encoder writes a book that long) */
 	}
 	__syncthreads();
 	for (int r = lane; r < 354; r += 64) level[r] = (int16_t)plain_level(book[r] & 255);
