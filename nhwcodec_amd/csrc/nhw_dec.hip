@@ -1614,18 +1614,25 @@ __global__ __launch_bounds__(1024) void k_dec_chroma(DecWs ws, int items, int up
 		}
 		lds_barrier();
 		if (upto == 2) { store_block(true); lds_barrier(); continue; }
-#pragma unroll 2
-		for (int v = t; v < S * S; v += NT_) {                       /* the corrections: a symbol in a detail band steps the level-1 LL cell(s) it sits over */
-			const int i = v >> 8, j = v & 255;
-			if (i < HLF && j < HLF) continue;
-			const int sy = smem[i * LS + j];
-			if (sy < 5003 || sy > 5006) continue;
-			const int ti = i < HLF ? i : i - HLF, tj = j < HLF ? j : j - HLF;   /* plane cell (ti, tj) of the LL sits at [tj][ti] */
-			const bool two = tj < HLF - 1;                            /* the second cell of a pair at the last LL column is scratch in the reference */
-			const int d = sy == 5005 ? -4 : sy == 5006 ? 4 : sy == 5003 ? -6 : 6;
-			add_i16_at(smem, tj * LS + ti, d);
-			if (two && (sy == 5005 || sy == 5006)) add_i16_at(smem, (tj + 1) * LS + ti, d);
-			smem[i * LS + j] = 0;
+		{                                                            /* the corrections: a symbol 5003..5006 in a detail band steps the level-1 LL cell(s) it sits over.  Such a symbol can only
+		                                                              * have come from the value list (LL2 and exception samples are small), so the list is gone through again instead of
+		                                                              * the 49 152 detail cells; a cell an exception sample has overwritten since no longer holds its symbol and is left alone */
+			const uint32_t *ent = ws.buf<uint32_t>(D_CB, img);
+			const int n_ent = (int)ws.buf<uint32_t>(D_SEG, img)[SEG_CHROMA + 128];
+			for (int k = t; k < n_ent; k += NT_) {
+				const uint32_t en = ent[k];
+				const int pos = ENT_POS(en), sy = ENT_VAL(en);
+				if ((pos & 1) != comp || sy < 5003 || sy > 5006) continue;
+				const int w = pos >> 1, strip = w >> 11, rp = (w & 2047) >> 4, idx = w & 15;
+				const int i = 2 * rp + (idx >> 3), j = 8 * strip + ((idx & 8) ? 15 - idx : (idx & 7));
+				if ((i < HLF && j < HLF) || smem[i * LS + j] != sy) continue;
+				const int ti = i < HLF ? i : i - HLF, tj = j < HLF ? j : j - HLF;   /* plane cell (ti, tj) of the LL sits at [tj][ti] */
+				const bool two = tj < HLF - 1;                            /* the second cell of a pair at the last LL column is scratch in the reference */
+				const int d = sy == 5005 ? -4 : sy == 5006 ? 4 : sy == 5003 ? -6 : 6;
+				add_i16_at(smem, tj * LS + ti, d);
+				if (two && (sy == 5005 || sy == 5006)) add_i16_at(smem, (tj + 1) * LS + ti, d);
+				smem[i * LS + j] = 0;
+			}
 		}
 		lds_barrier();
 		if (upto == 3) { store_block(true); lds_barrier(); continue; }
