@@ -2563,16 +2563,29 @@ DEV bool book_ok(int v) { return v < 109 ? !(v & 1) : (v == 112 || (v >= 120 && 
 
 /* tokens whose first symbol lies in [lo, hi); N = stream length (the last symbol can only be swallowed by a run).
  * MODE 0: histogram (every symbol counts, nothing is skipped); MODE 1: count code bits; MODE 2: write code bits */
+/* what a slice's walk leaves for the placement behind the prefix sums: its code bits, MSB first, if they fit 128 (they nearly always do: a
+ * slice holds a handful of tokens), and its sign symbols as bit masks -- so that a slice is walked once per sweep, not twice */
+struct SliceBits { uint32_t b[4]; uint64_t s1m, s2m; };
 template <int MODE>
 DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint32_t *words, unsigned bit0, uint8_t *s1, unsigned i1, uint8_t *s2, unsigned i2,
-                   unsigned *out_bits, unsigned *out_n1, unsigned *out_n2, const int *prevnz, const int *nextnz, int slice)
+                   unsigned *out_bits, unsigned *out_n1, unsigned *out_n2, const int *prevnz, const int *nextnz, int slice, SliceBits *rec = nullptr)
 {
 	unsigned bits = 0, n1 = 0, n2 = 0;
 	uint32_t cur = 0; int w = (int)(bit0 >> 5), fill = (int)(bit0 & 31);
+	uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0; uint64_t s1m = 0, s2m = 0;   /* MODE 1 */
 	const int select = sh->select;
 	/* code tables built after the ranking: (length << 24) | code word of a symbol / of a zero run of a given length */
 #define EMIT(entry) do { const uint32_t e_ = (entry), code_ = e_ & 0xFFFFFF; const int len_ = (int)(e_ >> 24); \
-		if (MODE == 1) bits += (unsigned)len_; \
+		if (MODE == 1) { \
+			if (bits + (unsigned)len_ <= 128u) { \
+				const int f_ = (int)(bits & 31) + len_; \
+				uint32_t a_, b_ = 0; \
+				if (f_ <= 32) a_ = code_ << (32 - f_); else { a_ = code_ >> (f_ - 32); b_ = code_ << (64 - f_); } \
+				const unsigned wi_ = bits >> 5; \
+				r0 |= wi_ == 0 ? a_ : 0u; r1 |= wi_ == 1 ? a_ : wi_ == 0 ? b_ : 0u; r2 |= wi_ == 2 ? a_ : wi_ == 1 ? b_ : 0u; r3 |= wi_ == 3 ? a_ : wi_ == 2 ? b_ : 0u; \
+			} \
+			bits += (unsigned)len_; \
+		} \
 		else { fill += len_; if (fill <= 32) cur |= code_ << (32 - fill); \
 			else { const int sp_ = fill - 32; atomicOr(&words[w], cur | (code_ >> sp_)); w++; cur = (code_ & ((1u << sp_) - 1)) << (32 - sp_); fill = sp_; } } } while (0)
 	const int send = (slice + 1) * PK_SLICE < N ? (slice + 1) * PK_SLICE : N;
@@ -2592,8 +2605,8 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 		if ((nz >> (i - lo)) & 1) {
 			const int px = d[i];
 			if (MODE == 0) { atomicAdd(&sh->hist[px], 1); i++; continue; }
-			if (px == 153 || px == 155) { if (MODE == 2 && i1 + n1 < S_CAP) s1[i1 + n1] = (uint8_t)(px == 155); n1++; i++; continue; }
-			if (px == 157 || px == 159) { if (MODE == 2 && i2 + n2 < S_CAP) s2[i2 + n2] = (uint8_t)(px == 159); n2++; i++; continue; }
+			if (px == 153 || px == 155) { if (MODE == 2 && i1 + n1 < S_CAP) s1[i1 + n1] = (uint8_t)(px == 155); if (MODE == 1 && px == 155) s1m |= 1ull << n1; n1++; i++; continue; }
+			if (px == 157 || px == 159) { if (MODE == 2 && i2 + n2 < S_CAP) s2[i2 + n2] = (uint8_t)(px == 159); if (MODE == 1 && px == 159) s2m |= 1ull << n2; n2++; i++; continue; }
 			EMIT(sh->code_sym[px]);
 			i += (px > 131 && px < 136) ? 5 : 1;
 			continue;
@@ -2620,7 +2633,7 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 		i = b + 1;
 	}
 	if (MODE == 2 && fill > 0) atomicOr(&words[w], cur);
-	if (MODE == 1) { *out_bits = bits; *out_n1 = n1; *out_n2 = n2; }
+	if (MODE == 1) { *out_bits = bits; *out_n1 = n1; *out_n2 = n2; rec->b[0] = r0; rec->b[1] = r1; rec->b[2] = r2; rec->b[3] = r3; rec->s1m = s1m; rec->s2m = s2m; }
 #undef EMIT
 }
 
@@ -2628,20 +2641,32 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
  * the 4 symbols before the slice (the walk looks back that far), so that the slices of a wavefront start in 64
  * different banks.  Returns the thread's view: dl[x] is stream symbol x for x in [lo - 4, lo + 64). */
 #define PK_LDS_BYTES ((17 * NT + 1) * 4)
-DEV const uint8_t *pack_stage(const uint8_t *d, int N, int ch, int tid, uint32_t *lw)
+struct PackPre { uint4 v[PK_CHUNK / 16 / NT]; uint32_t before; };   /* a chunk on its way from memory: the thread's 16-byte pieces, and (thread 0) the four symbols in front of it */
+DEV void pack_fetch(const uint8_t *d, int N, int ch, int tid, PackPre *pre)
+{
+	const int clo = ch * PK_CHUNK;
+#pragma unroll
+	for (int u = 0; u < PK_CHUNK / 16 / NT; u++) {
+		const int at = clo + 16 * (tid + u * NT);
+		pre->v[u] = at < N ? *reinterpret_cast<const uint4 *>(d + at) : make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+	}
+	pre->before = (tid == 0 && clo) ? *reinterpret_cast<const uint32_t *>(d + clo - 4) : 0x80808080u;
+}
+/* ... and into LDS once the chunk before is done with (the loads were issued a chunk's work ago) */
+DEV const uint8_t *pack_stage(const PackPre *pre, int ch, int tid, uint32_t *lw)
 {
 	const int clo = ch * PK_CHUNK;
 	BARRIER();
-	for (int g = tid; g < PK_CHUNK / 16; g += NT) {
-		const int at = clo + 16 * g;
-		uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
-		if (at < N) v = *reinterpret_cast<const uint4 *>(d + at);
+#pragma unroll
+	for (int u = 0; u < PK_CHUNK / 16 / NT; u++) {
+		const int g = tid + u * NT;
+		const uint4 v = pre->v[u];
 		const int t = g >> 2, j = (g & 3) * 4;
 		uint32_t *w = lw + 17 * t + 1 + j;
 		w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 		if (j == 12) lw[17 * (t + 1)] = v.w;
 	}
-	if (tid == 0) lw[0] = clo ? *reinterpret_cast<const uint32_t *>(d + clo - 4) : 0x80808080u;
+	if (tid == 0) lw[0] = pre->before;
 	BARRIER();
 	return reinterpret_cast<const uint8_t *>(lw + 17 * tid + 1) - (clo + tid * PK_SLICE);
 }
@@ -2699,9 +2724,12 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 		if (tid == 0) nextnz[nsl] = N;
 	}
 	BARRIER();
+	PackPre pre;
+	pack_fetch(d, N, 0, tid, &pre);
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
-		const uint8_t *dl = pack_stage(d, N, ch, tid, lw);
+		const uint8_t *dl = pack_stage(&pre, ch, tid, lw);
+		if (ch + 1 < nchunks) pack_fetch(d, N, ch + 1, tid, &pre);
 		if (lo < S) pack_walk<0>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
 	}
 	BARRIER();
@@ -2765,11 +2793,14 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	uint32_t *words = c->packet + word0;
 	unsigned base_bits = 0, base_n1 = 0, base_n2 = 0;
 	int zeroed = 0;                                              /* words [0, zeroed) are cleared or already carry bits */
+	pack_fetch(d, N, 0, tid, &pre);
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
 		unsigned bb = 0, x1 = 0, x2 = 0, tb, tn;
-		const uint8_t *dl = pack_stage(d, N, ch, tid, lw);
-		if (lo < S) pack_walk<1>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, prevnz, nextnz, ch * NT + tid);
+		const uint8_t *dl = pack_stage(&pre, ch, tid, lw);
+		if (ch + 1 < nchunks) pack_fetch(d, N, ch + 1, tid, &pre);
+		SliceBits rec;
+		if (lo < S) pack_walk<1>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, prevnz, nextnz, ch * NT + tid, &rec);
 		const unsigned ob = block_exscan(bb, tid, sh->bits, &tb);
 		const unsigned on = block_exscan(x1 | (x2 << 16), tid, sh->bits, &tn);
 		const int last = tb ? (int)((base_bits + tb - 1) >> 5) : zeroed - 1;
@@ -2778,7 +2809,20 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 		if (word0 + last >= 80000) { if (tid == 0) sh->rc = NHW_E_SPACE; BARRIER(); return; }
 		for (int w = zeroed + tid; w <= last; w += NT) words[w] = 0;
 		BARRIER();
-		if (lo < S) pack_walk<2>(dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
+		if (lo < S) {
+			if (bb <= 128u) {                                        /* the recorded bits, moved to their place (the words were zeroed above; neighbours share words) */
+				const unsigned o = base_bits + ob, r = o & 31;
+				const int w0 = (int)(o >> 5), nw = bb ? (int)((r + bb + 31) >> 5) : 0;
+				const uint32_t v[5] = { rec.b[0] >> r, r ? (rec.b[0] << (32 - r)) | (rec.b[1] >> r) : rec.b[1], r ? (rec.b[1] << (32 - r)) | (rec.b[2] >> r) : rec.b[2],
+				                        r ? (rec.b[2] << (32 - r)) | (rec.b[3] >> r) : rec.b[3], r ? rec.b[3] << (32 - r) : 0u };
+#pragma unroll
+				for (int k = 0; k < 5; k++) if (k < nw && v[k]) atomicOr(&words[w0 + k], v[k]);
+				const unsigned a1 = base_n1 + (on & 0xFFFF), a2 = base_n2 + (on >> 16);
+				for (unsigned z = 0; z < x1; z++) if (a1 + z < S_CAP) c->s1[a1 + z] = (uint8_t)((rec.s1m >> z) & 1);
+				for (unsigned z = 0; z < x2; z++) if (a2 + z < S_CAP) c->s2[a2 + z] = (uint8_t)((rec.s2m >> z) & 1);
+			}
+			else pack_walk<2>(dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
+		}
 		base_bits += tb; base_n1 += tn & 0xFFFF; base_n2 += tn >> 16;
 		if (last + 1 > zeroed) zeroed = last + 1;
 	}
