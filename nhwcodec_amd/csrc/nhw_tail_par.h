@@ -65,28 +65,52 @@ DEV void apply_tags_par(Ctx *c, int tid, int16_t *lds)
 {
 	int8_t *steps = reinterpret_cast<int8_t *>(lds);              /* [3][32][33] */
 	int16_t *p = c->proc, *o = c->ll1;
+	/* A tile is two short phases with a memory round trip in front of each (the tags; the target dwords): both are requested a tile ahead.
+	 * Tiles touch disjoint tags and disjoint target cells, so reading the next tile's before this one's are written back changes nothing. */
+	auto tag_cell = [&](int tile, int k) {
+		const int ty = tile >> 2, tx = tile & 3, type = k >> 10, rl = (k >> 5) & 31, jl = k & 31;
+		const int r = 32 * tx + rl + (type >= 1 ? H / 2 : 0), j = 32 * ty + jl + (type != 1 ? H / 2 : 0);   /* 0: (r<128, j>=128), 1: (r>=128, j<128), 2: both >= 128 */
+		return o + r * H + j;
+	};
+	auto target = [&](int tile, int k) {                            /* one dword = target cells (yy, xx), (yy, xx+1), xx even */
+		const int ty = tile >> 2, tx = tile & 3, yl = k >> 5, xl = 2 * (k & 31);
+		return reinterpret_cast<uint32_t *>(p + (64 * ty + yl) * W + 64 * tx + xl);
+	};
+	int16_t tg[12]; uint32_t tv[8];
+#pragma unroll
+	for (int u = 0; u < 12; u++) tg[u] = *tag_cell(0, tid + u * NT);
+#pragma unroll
+	for (int u = 0; u < 8; u++) tv[u] = *target(0, tid + u * NT);
 	for (int tile = 0; tile < 16; tile++) {
-		const int ty = tile >> 2, tx = tile & 3;                  /* target rows 64ty.., cols 64tx.. */
-		for (int k = tid; k < 3 * 1024; k += NT) {
-			const int type = k >> 10, rl = (k >> 5) & 31, jl = k & 31;
-			const int r = 32 * tx + rl + (type >= 1 ? H / 2 : 0), j = 32 * ty + jl + (type != 1 ? H / 2 : 0);   /* 0: (r<128, j>=128), 1: (r>=128, j<128), 2: both >= 128 */
-			int16_t *cell = o + r * H + j;
+#pragma unroll
+		for (int u = 0; u < 12; u++) {
+			const int k = tid + u * NT, type = k >> 10, rl = (k >> 5) & 31, jl = k & 31;
 			int step = 0;
-			if (*cell > 14000) { *cell -= 16000; step = 1; }
-			else if (*cell > 10000) { *cell -= 12000; step = -1; }
+			if (tg[u] > 14000) { *tag_cell(tile, k) = (int16_t)(tg[u] - 16000); step = 1; }
+			else if (tg[u] > 10000) { *tag_cell(tile, k) = (int16_t)(tg[u] - 12000); step = -1; }
 			steps[(type * 32 + rl) * 33 + jl] = (int8_t)step;
 		}
+		uint32_t cur[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++) cur[u] = tv[u];
+		if (tile + 1 < 16) {
+#pragma unroll
+			for (int u = 0; u < 12; u++) tg[u] = *tag_cell(tile + 1, tid + u * NT);
+#pragma unroll
+			for (int u = 0; u < 8; u++) tv[u] = *target(tile + 1, tid + u * NT);
+		}
 		BARRIER();
-		for (int k = tid; k < 64 * 32; k += NT) {                 /* one dword = target cells (yy, xx), (yy, xx+1), xx even */
-			const int yl = k >> 5, xl = 2 * (k & 31), yy = 64 * ty + yl, xx = 64 * tx + xl;
+		const int ty = tile >> 2;
+#pragma unroll
+		for (int u = 0; u < 8; u++) {
+			const int k = tid + u * NT, yl = k >> 5, xl = 2 * (k & 31), yy = 64 * ty + yl;
 			const int rl = xl >> 1, jl = yl >> 1;
 			int s0 = 0, s1 = 0;
 			if (yy & 1) { s0 = steps[(0 * 32 + rl) * 33 + jl]; s1 = steps[(2 * 32 + rl) * 33 + jl]; }   /* odd row: even col <- type 0, odd col <- type 2 */
 			else s1 = steps[(1 * 32 + rl) * 33 + jl];                                                      /* even row: odd col <- type 1 */
 			if (s0 | s1) {
-				uint32_t *w = reinterpret_cast<uint32_t *>(p + yy * W + xx);
-				const uint32_t v = *w;
-				*w = (uint32_t)(uint16_t)((int16_t)(v & 0xFFFF) + s0) | ((uint32_t)(uint16_t)((int16_t)(v >> 16) + s1) << 16);
+				const uint32_t v = cur[u];
+				*target(tile, k) = (uint32_t)(uint16_t)((int16_t)(v & 0xFFFF) + s0) | ((uint32_t)(uint16_t)((int16_t)(v >> 16) + s1) << 16);
 			}
 		}
 		BARRIER();
