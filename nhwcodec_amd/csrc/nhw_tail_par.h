@@ -31,16 +31,26 @@ DEV void tag_l2_details_par(Ctx *c, int tid)
 		const int at0 = r * W + j0;
 		const uint4 pv = *reinterpret_cast<const uint4 *>(p + at0);
 		uint4 cv = *reinterpret_cast<const uint4 *>(c->ll1 + r * H + j0);
+		/* the two diagonal neighbours a 2..4 sample looks at (linear indexing, as the reference's): cells at0 - W - 1 .. of the row above and
+		 * at0 + W + 1 .. of the row below, requested with the item's own loads instead of one by one when a sample asks (a dependent round
+		 * trip per asking sample was most of this pass's time) */
+		uint4 uv = make_uint4(0, 0, 0, 0), dv = uv;
+		int u0 = 0, d7 = 0;
+		if (r > 0) { uv = *reinterpret_cast<const uint4 *>(p + at0 - W); u0 = p[at0 - W - 1]; }
+		dv = *reinterpret_cast<const uint4 *>(p + at0 + W); d7 = p[at0 + W + 8];
+		const uint32_t uw[4] = { uv.x, uv.y, uv.z, uv.w }, dw[4] = { dv.x, dv.y, dv.z, dv.w };
 		uint32_t pw[4] = { pv.x, pv.y, pv.z, pv.w }, cw[4] = { cv.x, cv.y, cv.z, cv.w };
 #pragma unroll
 		for (int e = 0; e < 8; e++) {
 			const int s = (int16_t)(pw[e >> 1] >> (16 * (e & 1))), at = at0 + e;
+			const int up = e ? (int)(int16_t)(uw[(e - 1) >> 1] >> (16 * ((e - 1) & 1))) : u0;
+			const int dn = e < 7 ? (int)(int16_t)(dw[(e + 1) >> 1] >> (16 * ((e + 1) & 1))) : d7;
 			int add = 0;
 			if (s < -7) { if (mult8_or_7(-s)) add = 16000; }
 			else if (s < -4) add = 12000;
 			else if (s >= 0) {
 				if (s >= 2 && s < 5) {
-					if (at >= W + 1 && at < 2 * Q - W - 1 && (p[at - (W + 1)] != 0 || p[at + (W + 1)] != 0)) add = 12000;
+					if (at >= W + 1 && at < 2 * Q - W - 1 && (up != 0 || dn != 0)) add = 12000;
 				}
 				else if (!(s & 7)) add = 12000;
 				else if ((s & 7) == 1) add = 12000;
