@@ -2441,15 +2441,27 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 				BARRIER();
 				mark = !changed;
 			}
-			for (int r = wv; r < H / 2; r += 4) {
+			/* a row's twelve cells per lane are requested while the row before is evaluated (rows are independent; a row's marks land in its own row) */
+			int16_t nx[12];
+			auto fetch = [&](int r) {
 				const int sh = shift[r];
-				int pl[2], hl[2], lh[2], hh[2], d[2], d1[2];
+#pragma unroll
 				for (int k = 0; k < 2; k++) {
 					const int at = r * H + lane + 64 * k, ko = r * (H / 2) + sh + lane + 64 * k;
-					pl[k] = p[at]; hl[k] = p[at + H / 2]; lh[k] = p[at + Q / 2]; hh[k] = p[at + Q / 2 + H / 2];
-					d[k] = pl[k] - o[ko];
-					d1[k] = o[ko + 1];                                  /* the reference cell of the right neighbour */
+					nx[6 * k] = p[at]; nx[6 * k + 1] = p[at + H / 2]; nx[6 * k + 2] = p[at + Q / 2]; nx[6 * k + 3] = p[at + Q / 2 + H / 2];
+					nx[6 * k + 4] = o[ko]; nx[6 * k + 5] = o[ko + 1];
 				}
+			};
+			fetch(wv);
+			for (int r = wv; r < H / 2; r += 4) {
+				int pl[2], hl[2], lh[2], hh[2], d[2], d1[2];
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					pl[k] = nx[6 * k]; hl[k] = nx[6 * k + 1]; lh[k] = nx[6 * k + 2]; hh[k] = nx[6 * k + 3];
+					d[k] = pl[k] - nx[6 * k + 4];
+					d1[k] = nx[6 * k + 5];                              /* the reference cell of the right neighbour */
+				}
+				if (r + 4 < H / 2) fetch(r + 4);
 				const int hl_first = __shfl(hl[0], 0);
 				for (int k = 0; k < 2; k++) {
 					int pn = right_of(pl, k, 2, 1, lane);
