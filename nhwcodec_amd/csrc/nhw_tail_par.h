@@ -1457,10 +1457,12 @@ DEV void dequant_sim_chroma_par(Ctx *c, int comp, int tid)
 	/* detail rows: one wavefront per row, lane l owns columns l and l + 64; the -7/-8 pairs of the second loop are a
 	 * walk that skips the partner (alt_runs on "pair starts here"), everything else is a stencil on the untouched plane */
 	const int lane = tid & 63, wv = tid >> 6;
+	int nv[3];                                                      /* the next row's cells, requested while this row is worked on (rows are independent) */
+	nv[0] = wv < H / 4 ? 0 : p[wv * H + lane]; nv[1] = p[wv * H + 64 + lane]; nv[2] = p[wv * H + 128 + lane];
 	for (int r = wv; r < H / 2; r += 4) {
 		const int col0 = r < H / 4 ? H / 4 : 0;
-		int v[3];
-		v[0] = col0 ? 0 : p[r * H + lane]; v[1] = p[r * H + 64 + lane]; v[2] = p[r * H + 128 + lane];   /* the last cell looks at column 128 */
+		int v[3] = { nv[0], nv[1], nv[2] };                          /* the last cell looks at column 128 */
+		if (r + 4 < H / 2) { const int rn = r + 4; nv[0] = rn < H / 4 ? 0 : p[rn * H + lane]; nv[1] = p[rn * H + 64 + lane]; nv[2] = p[rn * H + 128 + lane]; }
 		uint64_t pair[2] = { 0, 0 };
 		if (!comp) {
 			const uint64_t m0 = __ballot(v[0] == -7 || v[0] == -8), m1 = __ballot(v[1] == -7 || v[1] == -8);
