@@ -1604,9 +1604,17 @@ DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 	unsigned *shm = reinterpret_cast<unsigned *>(lds) + 3 * H;
 	unsigned total[3] = { 0, 0, 0 };
 	for (int sweep = 0; sweep < 2; sweep++) {
+		int nv[4];                                                  /* the next row of this wavefront, requested while the row is worked on (a row only rewrites itself) */
+#pragma unroll
+		for (int k = 0; k < 4; k++) nv[k] = o[wv * H + lane + 64 * k];
 		for (int r = wv; r < H; r += 4) {
 			int v[4];
-			for (int k = 0; k < 4; k++) v[k] = o[r * H + lane + 64 * k];
+#pragma unroll
+			for (int k = 0; k < 4; k++) v[k] = nv[k];
+			if (r + 4 < H) {
+#pragma unroll
+				for (int k = 0; k < 4; k++) nv[k] = o[(r + 4) * H + lane + 64 * k];
+			}
 			if (lane >= 62) v[3] = 0;                               /* columns 254, 255 take no part and are cleared */
 			for (int pass = 0; pass < npass; pass++) {
 				int pl[4], kp[4];
