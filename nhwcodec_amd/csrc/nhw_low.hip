@@ -26,6 +26,7 @@
 #include "nhw_ws.h"
 
 #define DEVI __device__ static __forceinline__
+#define DEVN __device__ static
 #define PF_LOOK 16         /* pixels of look-back for a lane's entry state of the carry (the 16 states have merged within 16 for everything measured; a row where they have not is replayed serially) */
 
 namespace {
@@ -38,7 +39,7 @@ DEVI uint64_t low_bits64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1); } 
  * divergent region pays an exec-mask save / restore and a vector compare per branch: measured 4x slower); stores are issued by lane 0. */
 #define LDK(p) __builtin_amdgcn_readfirstlane((int)*(p))
 #define STK(p, v) do { if (threadIdx.x == 0) *(p) = (v); } while (0)
-/* passes B and C run one image per LANE (the first PG lanes of the wavefront, PG images to a wavefront): plain per-lane accesses */
+/* the chain phases run one image per LANE (the first lanes of the wavefront): plain per-lane accesses */
 #define LDL(p) ((int)*(p))
 #define STL(p, v) (*(p) = (v))
 
@@ -129,309 +130,9 @@ DEVI bool map_candidate(const PfP &pp, int sm, int val)
 	return sm > 0 && ((sm <= s2 && val > s2 && val <= s2 + 20) || val == s2 + 21);
 }
 
-/* ------------------------------------------------------------------------------------------------ pass B: the pair machine (:770-1992) */
-/* The counters are numbered as the reference numbers its variables (t1..t44, w1..w8): they have no documented meaning, and a reader
- * can put the two side by side.  Constant indices only, so the arrays live in registers. */
-struct PfM { int t[45], w[9]; };
-#define T(n) (m.t[n])
-#define Wv(n) (m.w[n])
+#include "nhw_low_machine.h"
 
-DEVI void machine_reset(PfM &m)
-{
-	for (int i = 0; i < 45; i++) m.t[i] = 0;
-	for (int i = 0; i < 9; i++) m.w[i] = 0;
-	T(6) = 8; T(10) = 10; T(11) = 15; T(18) = 8; T(44) = 2; Wv(3) = 20;
-}
-DEVI void set_window(PfM &m, int wide) { if (wide) { T(10) = 10; T(11) = 15; } else { T(10) = 8; T(11) = 12; } }
 
-/* schedule walked once the burst counter t7 has reached 4 (:1203-1448) */
-__device__ static void long_schedule(PfM &m)
-{
-	switch (T(16)) {
-	case 0:
-		set_window(m, 1); T(16) = 1;
-		if ((Wv(7) == 2 || Wv(7) == 4) && T(24) == 14) { if (Wv(7) == 2) T(1) = 2000005; }
-		else { T(4) = 1000000; T(1) = 9; }
-		break;
-	case 1:
-		set_window(m, 0); T(16) = 2; Wv(5)++;
-		if (Wv(5) == 3 && T(1) > 0 && T(1) < 30) T(1) = (-T(1)) >> 2;
-		else { T(4) = 10; T(1) += 2; }
-		break;
-	case 2:
-		set_window(m, 1); T(16) = 3; T(4) = 1000000; Wv(6)++;
-		if (Wv(6) == 6 || Wv(6) == 10) T(1) = 10;
-		break;
-	case 3: set_window(m, 0); T(16) = 4; T(4) = 8; T(1) -= 4; break;
-	case 4: set_window(m, 1); T(16) = 5; break;
-	case 5: set_window(m, 1); T(16) = 6; T(4) = 10; T(1) = 2000000; break;
-	case 6: set_window(m, 0); T(16) = 7; T(4) = 8; T(1) = 3000000; break;
-	case 7: set_window(m, 0); T(16) = 8; T(4) = 1000000; break;
-	case 8: {
-		set_window(m, 0);
-		const int s = T(24);
-		if (s >= 0 && s < 14) {
-			/* sub-position -> next position; the t4 / t1 presets are sparse: written out */
-			int n16 = 1;
-			switch (s) {
-			case 0: n16 = 1; T(4) = 1000000; break;
-			case 1: n16 = 2; break;
-			case 2: n16 = 1; T(4) = 1000000; break;
-			case 3: n16 = 2; break;
-			case 4: n16 = 1; T(1) = 2999998; break;
-			case 5: n16 = 0; break;
-			case 6: n16 = 3; break;
-			case 7: n16 = 3; T(1) = 7; break;
-			case 8: n16 = 1; break;
-			case 9: n16 = 8; T(4) = 1000000; break;
-			case 10: n16 = 1; T(4) = 8; T(1) = 11; break;
-			case 11: n16 = 0; break;
-			case 12: n16 = 1; break;
-			default: n16 = 0; break;     /* 13 */
-			}
-			T(16) = n16; T(24) = s + 1;
-		}
-		else if (s == 14) { T(16) = 1; T(24) = 15; Wv(7)++; T(1) = Wv(2) == 0 ? 1999978 : Wv(2) == 1 ? 1999982 : 1999993; }
-		else if (s == 15) { T(16) = 0; T(24) = 12; T(1) = (Wv(2) == 1 || Wv(2) == 3) ? -5 : 2000005; Wv(2)++; }
-		break;
-	}
-	default: break;
-	}
-}
-
-/* end of a burst (:1053-1456) */
-__device__ static void burst_end(PfM &m)
-{
-	if (!T(6)) {
-		T(6) = 1; T(14) = 0;
-		if (!T(22)) T(7)++;
-		if (T(22) == 1) T(22) = 0;
-	} else {
-		T(6)++; T(1)++;
-		if (T(4) > 900000 && T(1) == 12) T(4) = 8;
-		if (T(1) > 3000000) { T(1) = 12; T(4) = 8; }
-		else if (T(1) > 2000006 && T(1) < 2500000) { T(1) = 14; T(4) = 10; }
-		if (!T(15)) { T(14) = 1; T(15) = 1; }
-		else { T(14) = 0; T(15)++; if (T(15) > 9) T(15) = 0; }
-		if (T(6) > 15 && T(7) < 4) { T(6) = 0; if (T(19) > 0) T(20)++; }
-	}
-	if (T(4) == 8 || (T(4) == 10 && Wv(3) > 16)) {
-		if (Wv(3) < 21) { T(4) = 0; Wv(3)++; }
-		else if (T(4) == 8) Wv(3) = 0;
-		else if (Wv(4) < 2) { T(4) = 8; T(1) = 12; Wv(4)++; }
-		else { T(4) = 0; Wv(4) = 0; }
-	}
-	else T(4) = 0;
-	T(8) = 0; T(5) = 0; T(12) = 0;
-	if (T(7) == 3) set_window(m, !T(6));
-	else if (T(7) == 1) {
-		set_window(m, T(9) < 2);
-		T(9)++;
-		if (T(9) >= 3 && T(10) == 8) T(9) = 0;
-	}
-	else if (T(7) == 2) set_window(m, 0);
-	else if ((T(6) == 10 || T(6) == 11) && !T(7)) { T(10) = 6; T(11) = 9; }
-	else if (T(7) >= 4) long_schedule(m);
-	else { T(10) = T(10) == 8 ? 10 : 8; T(11) = T(11) == 12 ? 15 : 12; }
-}
-
-/* a pair inside a burst that neither ends it nor sits at its cap (:1504-1873) */
-__device__ static void burst_idle(PfM &m)
-{
-	if (T(1) == 6 && !Wv(8)) { T(1)++; Wv(8)++; T(44) = -100000; }
-	else if (T(44) < -90000) { T(1)++; Wv(8)++; T(44) = 0; }
-	else if (T(44) < 3) T(44)++;
-	else { T(1) += 3; T(44) = 0; }
-
-	if (!(T(29) > 0 && (T(14) == 4 || T(14) == 5 || T(39) == 2 || T(41) > 0))) return;
-
-	if (T(4) < 2 && T(1) == 15 && (T(14) == 4 || (T(14) == 5 && T(32) > 2))) {
-		if (T(32) == 0 || T(32) == 2 || T(32) == 3 || (T(32) > 7 && T(32) < 500000)) {
-			if (T(32) > 7 && T(14) == 5) { T(14) = 1; T(32) = 1000000; }
-			else if (!T(34)) T(34) = 1;
-			else { T(14) = 5; T(34) = 0; }
-		}
-		if (!T(32)) T(14) = 5;
-		T(32)++;
-	}
-	else if (T(32) == 4 || T(32) == 5 || T(32) == 7) {
-		if (T(37) == 4) T(14) = 3;
-		else if (T(37) == 15) { T(14) = 3; T(32)++; }
-		else if (T(32) == 7 && T(37) > -345000) {
-			if (T(14) == 4) {
-				if (!T(42)) T(37) -= 10000;
-				if (T(38) > 0) {
-					T(42)++;
-					if (T(42) > 0 || (!T(42) && T(43) > 3)) {
-						if (!T(42)) T(14) = T(43) == 14 ? 3 : T(43) == 24 ? 4 : 1;
-						else T(14) = 1;
-						T(39) = 0;
-						if (T(42) > 5) { T(42) = -1; T(43)++; }
-					}
-					else if (T(42) == -1) { T(14) = 3; T(39) = 2; T(40) = -2; T(42) = 0; }
-					else T(39) = 0;
-				}
-				else { T(14) = 5; T(39) = 1; T(42) = 0; }
-			}
-			else if (T(39) >= 1) {
-				T(38)++;
-				if (T(39) < 2) T(39) = (T(38) == 2 || T(38) == 4 || T(38) == 6 || T(38) == 9) ? 2 : 0;
-				else {
-					T(40)++;
-					if (T(38) == 8) { T(39) = 0; T(40) = 0; }
-					if (T(40) > 2) { T(40) = 0; T(39) = 0; }
-				}
-				if (T(38) >= 1 && T(38) <= 10) T(14) = 4;
-			}
-			else { T(40) = 1; if (T(38) == 1) T(39) = 2; }
-		}
-		if (T(37) >= 0) T(37)++;
-	}
-	else if (T(32) == 6 && T(36) < 118) {
-		if (T(14) == 4 || T(14) == 5 || T(41) == 0 || T(41) > 3) T(36)++;
-		if (T(41) > 3 && T(36) < 8) T(41) = 0;
-		switch (T(36)) {                 /* t36 -> t14; t41 is reset, counted up or set to 4 */
-		case 1: T(14) = 1; T(41) = 0; break;   case 2: T(14) = 2; T(41) = 0; break;   case 3: T(14) = 1; T(41) = 0; break;
-		case 4: T(14) = 3; T(41) = 0; break;   case 5: T(14) = 3; T(41)++; break;     case 6: T(14) = 0; T(41) = 0; break;
-		case 7: T(14) = 2; T(41) = 0; break;   case 8: T(14) = 2; T(41) = 4; break;   case 15: T(14) = 1; T(41) = 0; break;
-		case 31: T(14) = 3; T(41)++; break;    case 47: T(14) = 2; T(41) = 0; break;  case 100: T(14) = 0; T(41)++; break;
-		case 116: T(14) = 2; T(41) = 0; break;
-		default: break;
-		}
-	}
-
-	if (T(28) < 14 && T(1) > 7) {                        /* :1711-1871 */
-		const int st = T(28);
-		if (T(14) == 5 && !st && !T(33) && T(1) > 13 && T(31) > 0) { T(30) = 1; T(33) = 2; }
-		else T(30)++;
-		const int ahead = T(30) - T(33);
-		int late_d = 0x7fffffff, l14 = 0, l15 = 0, l1 = 0, l4 = 0;   /* stages 6..12 fire once t30 has run far enough past t33 */
-		switch (st) {
-		case 6: late_d = 54; l14 = 2; l15 = 3; l1 = 3; break;    case 7: late_d = 57; l14 = 2; l15 = 8; l1 = 8; break;
-		case 8: late_d = 84; l14 = 2; l15 = 7; l1 = 7; break;    case 9: late_d = 111; l14 = 2; l15 = 3; l1 = 7; break;
-		case 10: late_d = 116; l14 = 1; l15 = 0; l1 = 1; l4 = 8; break;
-		case 11: late_d = 185; l14 = 0; l15 = 4; l1 = -17; break; case 12: late_d = 187; l14 = 3; l15 = 3; l1 = -19; break;
-		default: break;
-		}
-		if (!st && ahead > 10 && T(33) > 0 && T(14) == 4) { T(14) = 3; T(15) += 6; T(28)++; }
-		else if (st == 1 && ahead > 70 && T(14) == 4 && T(1) == 11) { T(15) = 1; T(1) = 13; T(28)++; }
-		else if (st == 2 && T(31) > 2 && T(1) == 15 && T(15) > 1) { T(15) = 15; T(33) = T(30); T(1) = 6; T(28)++; }
-		else if (st == 3 && ahead > 3 && T(31) > 2) { T(15) = 0; T(28)++; }
-		else if (st == 5 && ahead > 22 && T(31) > 2 && T(1) == 12) { T(15) = 3; T(1) = 9; T(28)++; }
-		else if (st == 4 && ahead > 6 && T(1) == 15) { T(14) = 1; T(15) += 6; T(1)++; T(28)++; }
-		else if (st >= 6 && st <= 12 && ahead > late_d) { T(14) = l14; T(15) = l15; T(1) = l1; if (l4) T(4) = l4; T(28)++; }
-		else if (ahead == 9) { T(1) += (12 - T(4)) >> 2; T(4) = 10; }
-		else if (st > 0 && T(1) == 15 && Wv(1) < 11) { if (T(4) != 10) { if (Wv(1) == 4 || Wv(1) == 10) T(4) = 10; Wv(1)++; } }
-		else if (st == 13 && ahead > 188) { T(14) = 0; T(15) = 3; T(1) = -30; T(28)++; }
-	}
-}
-
-/* one pixel pair (:838-1925).  km: the pair's map cells, o: the pair in the output row, so: the pair's flags */
-DEVI void machine_pair(PfM &m, const PfP &pp, int row, int &k0, int &k1, int16_t *km, int &d0, int &d1, uint8_t *so)
-{
-	const int sharp = pp.sharp, s2 = pp.s2;
-	if (!T(1)) {                                     /* first pair of a burst (:840-994) */
-		T(2) = 0;
-		if (iabs_(k0) > sharp) {
-			d0 += k0 > 0 ? 2 : -2;
-			if (iabs_(k1) > s2 || T(8) == 1) {
-				STL(km, (int16_t)0);
-				if ((T(19) < 4 * Q || (T(20) >= 3 && T(20) < 4 * Q)) && iabs_(k0) > sharp + 96 && T(6) > 0 && row > 2) {
-					if (T(20) >= 3 && T(19) >= 8 * Q) { T(6) = 7000000; T(20) = 8 * Q; }
-					if (T(19) > 0 && T(19) < 4 * Q) {
-						if (T(20) > 2 || (T(20) == 2 && T(6) > 3 && !T(23)) || (T(20) == 2 && T(6) > 14 && T(23) > 0)) {
-							if (T(23) == 1) T(6) = 5000000;
-							T(23)++; T(21)++;
-							if (T(21) >= 2) T(19) = 8 * Q;
-						}
-					}
-					if (!T(19)) { T(6)++; T(20) = 1; }
-					T(19)++;
-				}
-			}
-			T(2) = 1;
-		}
-		if (iabs_(k1) > sharp) {
-			if ((T(2) == 1 || T(12) == 1) && (!T(14) || T(14) == 4 || T(14) == 5)) {
-				if (!T(3) && T(2) == 1) {
-					if (iabs_(k0) > 3000) k0 = k0 > 0 ? s2 + 5 : -s2 - 5;          /* a marker counts as just above the threshold */
-					if (iabs_(k1) > 3000) k1 = k1 > 0 ? s2 + 22 : -s2 - 22;
-					if (iabs_(k0) < (iabs_(k1) >> 2)) {
-						d0 += k0 > 0 ? -1 : 1;
-						STL(km, (int16_t)k0);
-						d1 += k1 > 0 ? 2 : -2;
-						if (iabs_(k0) > s2) STL(km + 1, (int16_t)0);
-					}
-					else d1 += k1 > 0 ? 1 : -1;
-					T(3) = 1;
-				} else {
-					d1 += k1 > 0 ? 2 : -2;
-					if (iabs_(k0) > s2) STL(km + 1, (int16_t)0);
-					T(3) = T(3) == 1 ? 2 : T(3) == 2 ? 3 : 0;
-				}
-			} else {
-				d1 += k1 > 0 ? 2 : -2;
-				if (iabs_(k0) > s2) STL(km + 1, (int16_t)0);
-			}
-			if (T(14) == 2) { T(14) = 1; T(26) = 3; if (T(25) > 0) T(25)++; }
-			if (T(14) == 1) { if (T(26) < 4) T(26)++; else { T(14) = 2; T(26) = 0; } }
-		}
-		if (iabs_(k0) > sharp || iabs_(k1) > sharp) T(13) = 1;
-		if (T(14) == 1 || T(14) == 2) T(27)++; else T(27) = 0;
-		if (T(27) > 2) T(14) = 1;
-		if (T(14) == 1) {
-			T(14) = 4;
-			if (!T(25)) { T(15)++; T(25) = 1; }
-			else { T(25)++; if (T(25) > 3) T(25) = 0; }
-		}
-		T(1) = 1;
-	} else {                                         /* inside a burst (:995-1910) */
-		if (iabs_(k0) > sharp) { d0 += k0 > 0 ? 1 : -1; T(1)++; T(4)++; }
-		if (iabs_(k1) > sharp) { d1 += k1 > 0 ? 1 : -1; T(1)++; T(4)++; }
-
-		if (T(4) < 10) T(17) = (T(4) == T(10) && T(1) == T(11));
-		else if (T(4) > 10 || T(1) != 15) {
-			if (!T(18)) { T(17) = 1; T(18) = 1; }
-			else { T(17) = 0; T(18)++; if (T(18) > 15) T(18) = 0; }
-		}
-		else T(17) = (T(4) == T(10) && T(1) == T(11));
-
-		if (T(6) > 6000000) { T(6) = 0; T(22) = 0; }
-		else if (T(6) > 4000000) { T(6) = 0; T(22) = (T(21) == 1); }
-
-		if (T(17) == 1 || T(1) > 2000003) burst_end(m);
-		else if (T(1) >= 15) {                       /* :1457-1503 */
-			if (!T(4)) T(8)++; else { T(8) = 0; T(5) = 0; T(12) = 0; }
-			T(1)++;
-			if (T(4) < 2 && T(29) > 0 && T(14) == 4) {
-				if (T(31) == 0 || T(31) == 1) { T(14) = 3; T(31)++; }
-				else if (T(31) == 2) { T(14) = 0; T(15) = 0; T(31)++; }
-			}
-			if (T(14) == 5 && !T(35) && T(32) > 4 && T(32) < 8) { T(14) = 1; T(32)--; T(35)++; }
-		}
-		else burst_idle(m);
-
-		if (T(8) > 6 && !T(4) && T(1) > 1 && T(1) < 15) {  /* :1875-1900 */
-			T(5)++;
-			if (T(5) < 35) {
-				T(1) = 0;
-				if (!T(13)) { T(12) = 1; T(13) = 1; }
-				else { T(12) = 0; T(13)++; if (T(13) > 3) T(13) = 0; }
-			}
-			else T(12) = 0;
-		}
-		if (T(1) > 15 && T(1) < 1000000) { T(1) = 0; T(4) = 0; T(29)++; }
-	}
-	/* opposite signs, both just above the threshold (:1912-1924) */
-	if (iabs_(k0) > sharp && iabs_(k0) <= sharp + 20 && iabs_(k1) > sharp && iabs_(k1) <= sharp + 20) {
-		if (k0 > 0 && k1 < 0) { d0++; d1--; STL(so, (uint8_t)2); STL(so + 1, (uint8_t)3); }
-		else if (k0 < 0 && k1 > 0) { d0--; d1++; STL(so, (uint8_t)3); STL(so + 1, (uint8_t)2); }
-	}
-}
-#undef T
-#undef Wv
-
-/* pass B over one row */
 DEVI void tail_rules(int k0, int k1, int &prev_big, int &d0, int &d1)      /* :1927-1990, on the (possibly rewritten) pair values */
 {
 	if (k0 < 32 && k0 > 10) {
@@ -462,20 +163,48 @@ DEVI void tail_rules(int k0, int k1, int &prev_big, int &d0, int &d1)      /* :1
 		}
 	}
 }
-/* Runs on the vector unit, one image per lane (the first PG lanes of the wavefront): plain per-lane loads and stores, the counters stay in
- * vector registers.  (History, ms per 4096-image batch for the front of q10: both serial passes on the scalar unit of a wavefront per
- * image 471; pass B on lane 0 and pass C on the scalar unit 443; both per lane with four images to a wavefront 313 -- what is left is the
- * length of one machine's dependent instruction chain, one wavefront per SIMD.) */
-DEVI void pair_row(PfM &m, int &prev_big, const PfP &pp, int r, int16_t *km, int16_t *y, uint8_t *so)
+/* what the tail rules (:1927-1990) leave in `prev_big` behind a pair: every path assigns it, so it is a function of the pair alone */
+DEVI int tail_flag(int k0, int k1)
 {
-	int n0 = km[1], n1 = km[2];                                   /* the next pair's values are on their way while this one is worked on (a pair only ever rewrites its own two cells) */
-	for (int c = 1; c < W - 2; c += 2) {
-		int k0 = n0, k1 = n1, d0 = 0, d1 = 0;
-		if (c + 2 < W - 2) { n0 = km[c + 2]; n1 = km[c + 3]; }
-		machine_pair(m, pp, r, k0, k1, km + c, d0, d1, so + c);
-		if (pp.tail_rules) tail_rules(k0, k1, prev_big, d0, d1);
-		if (d0) y[c] = (int16_t)(y[c] + d0);
-		if (d1) y[c + 1] = (int16_t)(y[c + 1] + d1);
+	if (((k0 < 32 && k0 > 10) || (k0 > -32 && k0 < -10)) && iabs_(k1) >= 23) return 0;
+	if ((k1 < 32 && k1 > 10 && k1 >= 16) || (k1 > -32 && k1 < -10 && k1 <= -16)) return iabs_(k0) >= 23;
+	return 0;
+}
+/* The picture side of one pair of pass B: what machine_step's answer `act` does to the pair's two pixels (d0, d1: additions), its two map
+ * cells (k0, k1 in: values behind pass A; out: what passes C and D find) and its two flags (s0, s1).  e0 / e1: the pair's values as the
+ * rules behind the machine see them (after the marker substitution).  :840-917 (first pair of a burst), :996-1001 (inside one),
+ * :1912-1924 (opposite signs). */
+DEVI void pair_apply(const PfP &pp, int act, int &k0, int &k1, int &e0, int &e1, int &d0, int &d1, int &s0, int &s1)
+{
+	const int sharp = pp.sharp, s2 = pp.s2;
+	const bool f0 = iabs_(k0) > sharp, f1 = iabs_(k1) > sharp;
+	const int c0 = k0, c1 = k1;
+	e0 = k0; e1 = k1;
+	if (act & ACT_FIRST) {
+		if (f0) { d0 += c0 > 0 ? 2 : -2; if (act & ACT_ZERO0) k0 = 0; }
+		if (f1) {
+			if (act & ACT_SUBST) {
+				if (iabs_(e0) > 3000) e0 = e0 > 0 ? s2 + 5 : -s2 - 5;          /* a marker counts as just above the threshold */
+				if (iabs_(e1) > 3000) e1 = e1 > 0 ? s2 + 22 : -s2 - 22;
+				if (iabs_(e0) < (iabs_(e1) >> 2)) {
+					d0 += e0 > 0 ? -1 : 1;
+					k0 = e0;
+					d1 += e1 > 0 ? 2 : -2;
+					if (iabs_(e0) > s2) k1 = 0;
+				}
+				else d1 += e1 > 0 ? 1 : -1;
+			} else {
+				d1 += c1 > 0 ? 2 : -2;
+				if (iabs_(c0) > s2) k1 = 0;
+			}
+		}
+	} else {
+		if (f0) d0 += c0 > 0 ? 1 : -1;
+		if (f1) d1 += c1 > 0 ? 1 : -1;
+	}
+	if (iabs_(e0) > sharp && iabs_(e0) <= sharp + 20 && iabs_(e1) > sharp && iabs_(e1) <= sharp + 20) {
+		if (e0 > 0 && e1 < 0) { d0++; d1--; s0 = 2; s1 = 3; }
+		else if (e0 < 0 && e1 > 0) { d0--; d1++; s0 = 3; s1 = 2; }
 	}
 }
 
@@ -552,56 +281,54 @@ DEVI void marker_row(MarkState &s, const PfP &pp, int r, int16_t *km, int16_t *y
 }
 
 /* ------------------------------------------------------------------------------------------------ pass D (:2312-2420) */
-/* one pair of pass D: km / y / so are row pointers indexed by column, p the pair's first column; returns the next pair's first column
- * (p + 2, or p + 1 where the walk slides by one) */
-DEVI int final_pair(const PfP &pp, const int16_t *km, int16_t *y, const uint8_t *so, int p)
+/* one pair of pass D: km is a row pointer indexed by column, p the pair's first column, f0 / f1 the pair's flags; d0 / d1: what the pair
+ * adds to its two pixels; returns the next pair's first column (p + 2, or p + 1 where the walk slides by one) */
+DEVI int final_pair(const PfP &pp, const int16_t *km, int f0, int f1, int p, int &d0, int &d1)
 {
 	const int sharp = pp.sharp, s2 = pp.s2;
 #define JUST_ABOVE(v, base) (iabs_(v) > (base) && iabs_(v) <= (base) + 20)
 	const int c = p + 1;
 	const int k0 = km[c - 1], k1 = km[c];
-	int16_t *o = y + c - 1;
-	const uint8_t *f = so + c - 1;
 	bool slide = false;
 	if (iabs_(k0) > 4000 || iabs_(k1) > 4000) return p + 2;
 	if (JUST_ABOVE(k0, sharp) && JUST_ABOVE(k1, sharp)) {
 		const int k2 = km[c + 1];
 		const bool next_same = c < W - 4 && JUST_ABOVE(k2, sharp) && ((k1 > 0 && k2 > 0) || (k1 < 0 && k2 < 0));
-		if (f[0] != 1 && f[1] != 1) {
+		if (f0 != 1 && f1 != 1) {
 			if (k0 > 0 && k1 > 0) {
-				if (k0 >= k1) { if (f[0] != 2) o[0]++; else if (f[1] != 2) o[1]++; }
-				else { if (f[1] != 2) o[1]++; else if (f[0] != 2) o[0]++; }
+				if (k0 >= k1) { if (f0 != 2) d0++; else if (f1 != 2) d1++; }
+				else { if (f1 != 2) d1++; else if (f0 != 2) d0++; }
 			}
 			else if (k0 < 0 && k1 < 0) {
-				if (k0 <= k1) { if (f[0] != 3) o[0]--; else if (f[1] != 3) o[1]--; }
-				else { if (f[1] != 3) o[1]--; else if (f[0] != 3) o[0]--; }
+				if (k0 <= k1) { if (f0 != 3) d0--; else if (f1 != 3) d1--; }
+				else { if (f1 != 3) d1--; else if (f0 != 3) d0--; }
 			}
 			else slide = next_same;
 		}
 		else slide = next_same;
 	}
 	else if (iabs_(k0) > sharp + 56 && iabs_(k1) > sharp + 56) {
-		if (!f[0] && !f[1]) {
-			if (k0 > 0 && k1 < 0) { o[0]++; o[1]--; }
-			else if (k0 < 0 && k1 > 0) { o[0]--; o[1]++; }
+		if (!f0 && !f1) {
+			if (k0 > 0 && k1 < 0) { d0++; d1--; }
+			else if (k0 < 0 && k1 > 0) { d0--; d1++; }
 			else if (iabs_(k0) > sharp + 96 && iabs_(k1) > sharp + 96) {
-				if (k0 > 0 && k1 > 0) { if (k0 > k1) o[0]++; else o[1]++; }
-				else if (k0 < 0 && k1 < 0) { if (k0 < k1) o[0]--; else o[1]--; }
+				if (k0 > 0 && k1 > 0) { if (k0 > k1) d0++; else d1++; }
+				else if (k0 < 0 && k1 < 0) { if (k0 < k1) d0--; else d1--; }
 			}
 		}
 	}
 	else if (iabs_(k0) > sharp + 160 && JUST_ABOVE(k1, s2)) {
-		if (!f[0] && !f[1]) {
-			if (k0 > 0 && k1 > 0) o[1]--;
-			else if (k0 < 0 && k1 < 0) o[1]++;
+		if (!f0 && !f1) {
+			if (k0 > 0 && k1 > 0) d1--;
+			else if (k0 < 0 && k1 < 0) d1++;
 			else slide = c < W - 6 && iabs_(km[c + 1]) > sharp + 160 && iabs_(km[c + 2]) <= s2;
 		}
 		else slide = c < W - 6 && iabs_(km[c + 1]) > sharp + 160 && iabs_(km[c + 2]) > s2 + 20;
 	}
 	else if (iabs_(k1) > sharp + 160 && JUST_ABOVE(k0, s2)) {
-		if (!f[0] && !f[1]) {
-			if (k0 > 0 && k1 > 0) o[0]--;
-			else if (k0 < 0 && k1 < 0) o[0]++;
+		if (!f0 && !f1) {
+			if (k0 > 0 && k1 > 0) d0--;
+			else if (k0 < 0 && k1 < 0) d0++;
 			else slide = c < W - 4 && JUST_ABOVE(km[c + 1], s2);
 		}
 		else slide = true;
@@ -615,56 +342,67 @@ DEVI int final_pair(const PfP &pp, const int16_t *km, int16_t *y, const uint8_t 
 
 /* src: the luma plane as the colour kernel wrote it (read only); y: the filtered plane (every row is written).
  *
- * The counters of passes B and C tie every pixel pair of an image to the one before it, so an image is a serial job of ~130 000 steps and
- * only images run side by side.  A wavefront per image leaves 63 of 64 lanes idle in those passes, and with 4096 images every SIMD holds
- * four such wavefronts whose one-lane instructions take turns.  So a wavefront takes PG images: pass A (the part that is parallel
- * along a row, all 64 lanes) runs image after image, the serial phases run the PG images in lanes 0..PG-1 -- one instruction stream, PG
- * machines (their counters are plain per-lane registers) -- at the price of the lanes' divergence.  Measured (front of q10, ms per
- * 4096-image batch): PG 1: 443, PG 4: 307, PG 2: 280 -- two wavefronts per SIMD hide each other's dependent-instruction latency and two
- * machines diverge less than four. */
-#define PG 2
-__global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
-                                                      int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q, int n_img, int dbg)
+ * The counters of pass B tie every pixel pair of an image to the one before it: an image is a serial job of ~130 000 machine steps and only
+ * images run side by side.  What is on that chain is machine_step and nothing else: a wavefront takes LI images, computes for a row of each
+ * (all 64 lanes) pass A, the q <= 14 smoothing and the 255 pair codes, then lanes 0..LI-1 walk their image's codes through their machine
+ * (the counters are plain per-lane registers), then all lanes apply the answers to the row (pair_apply, tail rules).  Pass C (markers,
+ * weak partners) has counters of its own, but they only move where the walk meets a marker: a row without one is independent of every
+ * other row, and k_low_marks does those rows a lane per row.  The rows WITH a marker (a few dozen per image) are walked here, in order, by
+ * the image's chain lane, and are listed in a 512-bit row mask for k_low_marks (kept in the flag plane's row 0, which no pass uses).
+ *
+ * History (front of q10, ms per 4096-image batch): wavefront per image, passes B and C on the scalar unit 471; B on lane 0 443; both
+ * per lane, 2 images per wavefront 280 (round 2); codes / answers + row-parallel pass C, 4 images per wavefront: see DESIGN 4.7. */
+template <int LI>
+__global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
+                                                    int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q, int n_img, int dbg)
 {
-	__shared__ __attribute__((aligned(16))) int16_t s_src[PG][3][W];
-	__shared__ __attribute__((aligned(16))) int16_t s_km[PG][2][W + 8];
-	__shared__ __attribute__((aligned(16))) int16_t s_y[PG][2][W];
-	__shared__ __attribute__((aligned(16))) uint8_t s_so[PG][2][W];
-	__shared__ __attribute__((aligned(16))) int16_t s_sum[PG][W], s_vb[W];   /* s_vb: of the image pass A is working on */
-	__shared__ __attribute__((aligned(8))) uint8_t s_cand[PG][64];        /* per 8-pixel group: the pixels that need the serial visit of pass A */
-	__shared__ int s_misc[4];
-	const int lane = threadIdx.x, img0 = blockIdx.x * PG;
-	const int nimg = n_img - img0 < PG ? n_img - img0 : PG;              /* images of this wavefront */
+	__shared__ __attribute__((aligned(16))) int16_t s_src[LI][3][W];
+	__shared__ __attribute__((aligned(16))) int16_t s_km[LI][2][W + 8];
+	__shared__ __attribute__((aligned(16))) int16_t s_y[LI][2][W];
+	__shared__ __attribute__((aligned(16))) uint8_t s_so[LI][2][W];
+	__shared__ __attribute__((aligned(16))) int16_t s_sum[LI][W];
+	__shared__ __attribute__((aligned(8))) uint8_t s_cand[LI][64];        /* per 8-pixel group: the pixels that need the serial visit of pass A */
+	/* per pair: threshold tests in, the machine's answer out -- in place (the chain lane has read a dword of codes before it stores the
+	 * answers there).  Pass A's base values of the image it is working on (s_vb) are dead before the first code is written: same bytes. */
+	__shared__ __attribute__((aligned(16))) uint8_t s_code[LI < 4 ? 4 : LI][256];
+	uint8_t (*s_act)[256] = s_code;
+	int16_t *s_vb = reinterpret_cast<int16_t *>(&s_code[0][0]);
+	__shared__ uint32_t s_rowmask[LI][16];                                 /* rows whose pass C ran here */
+	__shared__ int s_misc[4], s_mrow[LI], s_pb[LI];
+	const int lane = threadIdx.x, img0 = blockIdx.x * LI;
+	const int nimg = n_img - img0 < LI ? n_img - img0 : LI;              /* images of this wavefront */
 	const PfP pp = pf_params(q);
 
-	__shared__ int row_carry[PG];                                        /* wave-uniform per image; in LDS so that the loop over the images need not be unrolled (code size) */
-	if (threadIdx.x < PG) row_carry[threadIdx.x] = 0;
+	__shared__ int row_carry[LI];                                        /* wave-uniform per image; in LDS so that the loop over the images need not be unrolled (code size) */
+	if (threadIdx.x < LI) { row_carry[threadIdx.x] = 0; s_pb[threadIdx.x] = 0; }
+	for (int k = lane; k < LI * 16; k += 64) (&s_rowmask[0][0])[k] = 0;
 	/* per lane: the marker state of pass A, the machine of pass B and the state of pass C of image img0 + lane */
 	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	MarkState ks = { 0, 0, 0, 0, 0, 0 };
 	PfM mach;
-	int prev_big = 0;
+	PfC mcache;
 	machine_reset(mach);
+	machine_cache(mach, mcache);
 
 	const int c0 = lane * 8;
 #define SRC(g) (srcb + (size_t)(img0 + (g)) * src_stride)
 #define YO(g) (yb + (size_t)(img0 + (g)) * y_stride)
-#define KMO(g) (kmb + (size_t)(img0 + (g)) * km_stride)             /* contrast map and flags as passes A..C leave them: pass D is a kernel of its own */
+#define KMO(g) (kmb + (size_t)(img0 + (g)) * km_stride)             /* contrast map and flags as passes A..C leave them */
 #define SOO(g) (sob + (size_t)(img0 + (g)) * so_stride)
 	auto load_row = [&](int g, int r) { *reinterpret_cast<uint4 *>(&s_src[g][r % 3][c0]) = *reinterpret_cast<const uint4 *>(SRC(g) + (size_t)r * W + c0); };
 #pragma unroll
-	for (int g = 0; g < PG; g++) if (g < nimg) { load_row(g, 0); load_row(g, 1); }
-	for (int k = lane; k < PG * 2 * (W + 8); k += 64) (&s_km[0][0][0])[k] = 0;
+	for (int g = 0; g < LI; g++) if (g < nimg) { load_row(g, 0); load_row(g, 1); }
+	for (int k = lane; k < LI * 2 * (W + 8); k += 64) (&s_km[0][0][0])[k] = 0;
 	__syncthreads();
 #pragma unroll
-	for (int g = 0; g < PG; g++) if (g < nimg) *reinterpret_cast<uint4 *>(YO(g) + c0) = *reinterpret_cast<const uint4 *>(&s_src[g][0][c0]);      /* row 0 is not touched by any pass */
+	for (int g = 0; g < LI; g++) if (g < nimg) *reinterpret_cast<uint4 *>(YO(g) + c0) = *reinterpret_cast<const uint4 *>(&s_src[g][0][c0]);      /* row 0 is not touched by any pass */
 
 	for (int r = 1; r < W - 1; r++) {
 #pragma unroll
-		for (int g = 0; g < PG; g++) if (g < nimg) load_row(g, r + 1);
+		for (int g = 0; g < LI; g++) if (g < nimg) load_row(g, r + 1);
 		__syncthreads();
 #pragma unroll 1
-		for (int g = 0; g < PG; g++) {
+		for (int g = 0; g < LI; g++) {
 		if (g >= nimg) continue;
 		const int16_t *up = s_src[g][(r - 1) % 3], *mid = s_src[g][r % 3], *dn = s_src[g][(r + 1) % 3];
 		int16_t *km = s_km[g][r & 1];
@@ -757,12 +495,14 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 			}
 		}
 		__syncthreads();
-		if (pp.smooth) {                                          /* :780-807, reads the source copy only: off the chain */
+		/* all lanes, image by image: the q <= 14 smoothing (:780-807, reads the source copy only) and the pair codes of the row: lane l has
+		 * pairs 4 l .. 4 l + 3 = cells 8 l + 1 .. 8 l + 8 */
 #pragma unroll
-			for (int g = 0; g < PG; g++) {
-				if (g >= nimg) continue;
+		for (int g = 0; g < LI; g++) {
+			if (g >= nimg) continue;
+			const int16_t *km = s_km[g][r & 1];
+			if (pp.smooth) {
 				const int16_t *up = s_src[g][(r - 1) % 3], *mid = s_src[g][r % 3], *dn = s_src[g][(r + 1) % 3];
-				const int16_t *km = s_km[g][r & 1];
 				int16_t *y = s_y[g][r & 1];
 				for (int e = 0; e < 8; e++) {
 					const int c = c0 + e;
@@ -773,17 +513,91 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 						y[c] = (int16_t)(((mid[c] << 2) + mid[c - 1] + mid[c + 1] + up[c] + dn[c] + 4) >> 3);
 				}
 			}
-			__syncthreads();
-		}
-		/* passes B and C of this row, image img0 + lane on lane `lane` */
-		if (lane < nimg) {
-			if (!(dbg & 2)) pair_row(mach, prev_big, pp, r, s_km[lane][r & 1], s_y[lane][r & 1], s_so[lane][r & 1]);
-			if (!(dbg & 4)) marker_row(ks, pp, r, s_km[lane][r & 1], s_y[lane][r & 1], s_so[lane][r & 1], s_km[lane][(r - 1) & 1], s_y[lane][(r - 1) & 1], s_so[lane][(r - 1) & 1]);
+			uint32_t cw = 0;
+			for (int j = 0; j < 4; j++) {
+				const int k0 = km[c0 + 2 * j + 1], k1 = km[c0 + 2 * j + 2];
+				const uint32_t code = (iabs_(k0) > pp.sharp ? 1u : 0u) | (iabs_(k1) > pp.sharp ? 2u : 0u) | (iabs_(k1) > pp.s2 ? 4u : 0u) | (iabs_(k0) > pp.sharp + 96 ? 8u : 0u);
+				cw |= code << (8 * j);
+			}
+			*reinterpret_cast<uint32_t *>(&s_code[g][4 * lane]) = cw;
 		}
 		__syncthreads();
-		if (r > 1) {                                              /* row r-1 is through passes A..C: nothing of a later row touches it */
+		/* the chain: image img0 + lane on lane `lane`, 255 codes through the machine */
+		if (lane < nimg && !(dbg & 2)) {
+			const uint32_t *cp = reinterpret_cast<const uint32_t *>(s_code[lane]);
+			uint32_t *ap = reinterpret_cast<uint32_t *>(s_act[lane]);
+			uint32_t nxt = cp[0], cw = 0, aw = 0;
+#pragma unroll 1
+			for (int i = 0; i < 255; i++) {
+				if (!(i & 3)) { cw = nxt; nxt = cp[(i >> 2) + 1 < 64 ? (i >> 2) + 1 : 63]; aw = 0; }
+				int a = machine_step_fast(mach, mcache, (int)(cw & 15));
+				if (a < 0) { a = machine_step(mach, (int)(cw & 15), r); machine_cache(mach, mcache); }
+				aw |= (uint32_t)a << (8 * (i & 3));
+				cw >>= 8;
+				if ((i & 3) == 3 || i == 254) ap[i >> 2] = aw;
+			}
+		}
+		__syncthreads();
+		/* all lanes: the answers applied to the row (pass B's picture side), the tail rules, and the test for markers */
+#pragma unroll 1
+		for (int g = 0; g < LI; g++) {
+			if (g >= nimg) continue;
+			int16_t *km = s_km[g][r & 1];
+			int16_t *y = s_y[g][r & 1];
+			uint8_t *so = s_so[g][r & 1];
+			const uint32_t aw = (dbg & 2) ? 0u : *reinterpret_cast<const uint32_t *>(&s_act[g][4 * lane]);
+			int kc[9], dd[9], sv[9], e0[4], e1[4];
+			{ const uint4 kw = *reinterpret_cast<const uint4 *>(&km[c0]);
+			  const uint32_t w4[4] = { kw.x, kw.y, kw.z, kw.w };
+			  for (int e = 0; e < 4; e++) { kc[2 * e] = (int16_t)(w4[e] & 0xFFFF); kc[2 * e + 1] = (int16_t)(w4[e] >> 16); }
+			  kc[8] = km[c0 + 8]; }
+			for (int e = 0; e < 9; e++) { dd[e] = 0; sv[e] = 0; }
+			const int npair = lane == 63 ? 3 : 4;                      /* pair 255 does not exist */
+			for (int j = 0; j < 4; j++) {
+				e0[j] = 0; e1[j] = 0;
+				if (j < npair && !(dbg & 2)) pair_apply(pp, (int)((aw >> (8 * j)) & 7), kc[2 * j + 1], kc[2 * j + 2], e0[j], e1[j], dd[2 * j + 1], dd[2 * j + 2], sv[2 * j + 1], sv[2 * j + 2]);
+			}
+			if (pp.tail_rules && !(dbg & 2)) {
+				int pbo[4];
+				for (int j = 0; j < 4; j++) pbo[j] = tail_flag(e0[j], e1[j]);
+				int pb_in = __shfl_up(pbo[3], 1);
+				if (lane == 0) pb_in = s_pb[g];
+				for (int j = 0; j < 4; j++) {
+					int pb = j ? pbo[j - 1] : pb_in;
+					if (j < npair) tail_rules(e0[j], e1[j], pb, dd[2 * j + 1], dd[2 * j + 2]);
+				}
+				if (lane == 63) s_pb[g] = pbo[2];
+			}
+			/* cell 8 l is the second cell of the previous lane's last pair */
+			{ const int pk = __shfl_up(kc[8], 1), pd = __shfl_up(dd[8], 1), ps = __shfl_up(sv[8], 1);
+			  if (lane) { kc[0] = pk; dd[0] = pd; sv[0] = ps; } }
+			bool mark = false;
+			for (int e = 0; e < 8; e++) mark |= iabs_(kc[e]) > 6000;
+			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)kc[2 * e] | ((uint32_t)(uint16_t)kc[2 * e + 1] << 16);
+			  *reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
+			{ const uint4 yw = *reinterpret_cast<const uint4 *>(&y[c0]);
+			  uint32_t w4[4] = { yw.x, yw.y, yw.z, yw.w };
+			  for (int e = 0; e < 4; e++) {
+				const int lo = (int16_t)(w4[e] & 0xFFFF) + dd[2 * e], hi = (int16_t)(w4[e] >> 16) + dd[2 * e + 1];
+				w4[e] = (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16);
+			  }
+			  *reinterpret_cast<uint4 *>(&y[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
+			{ uint32_t lo = 0, hi = 0;
+			  for (int e = 0; e < 4; e++) { lo |= (uint32_t)sv[e] << (8 * e); hi |= (uint32_t)sv[4 + e] << (8 * e); }
+			  *reinterpret_cast<uint2 *>(&so[c0]) = make_uint2(lo, hi); }
+			const bool any_mark = __any(mark);
+			if (lane == 0) s_mrow[g] = any_mark;
+		}
+		__syncthreads();
+		/* pass C of this row where it holds a marker: the image's chain lane, in row order */
+		if (lane < nimg && s_mrow[lane] && !(dbg & 4)) {
+			marker_row(ks, pp, r, s_km[lane][r & 1], s_y[lane][r & 1], s_so[lane][r & 1], s_km[lane][(r - 1) & 1], s_y[lane][(r - 1) & 1], s_so[lane][(r - 1) & 1]);
+			s_rowmask[lane][r >> 5] |= 1u << (r & 31);
+		}
+		__syncthreads();
+		if (r > 1) {                                              /* row r-1 is through passes A..C as far as they run here */
 #pragma unroll
-			for (int g = 0; g < PG; g++) if (g < nimg) {
+			for (int g = 0; g < LI; g++) if (g < nimg) {
 				*reinterpret_cast<uint4 *>(YO(g) + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[g][(r - 1) & 1][c0]);
 				*reinterpret_cast<uint4 *>(KMO(g) + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[g][(r - 1) & 1][c0]);
 				*reinterpret_cast<uint2 *>(SOO(g) + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[g][(r - 1) & 1][c0]);
@@ -791,12 +605,13 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 		}
 	}
 #pragma unroll
-	for (int g = 0; g < PG; g++) if (g < nimg) {
+	for (int g = 0; g < LI; g++) if (g < nimg) {
 		const int r = W - 2;
 		*reinterpret_cast<uint4 *>(YO(g) + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[g][r & 1][c0]);
 		*reinterpret_cast<uint4 *>(KMO(g) + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[g][r & 1][c0]);
 		*reinterpret_cast<uint2 *>(SOO(g) + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[g][r & 1][c0]);
 		*reinterpret_cast<uint4 *>(YO(g) + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[g][(W - 1) % 3][c0]);
+		if (lane < 16) reinterpret_cast<uint32_t *>(SOO(g))[lane] = s_rowmask[g][lane];      /* flag plane, row 0: the rows k_low_marks must leave alone */
 	}
 #undef SRC
 #undef YO
@@ -804,44 +619,144 @@ __global__ __launch_bounds__(64) void k_low_prefilter(const int16_t *__restrict_
 #undef SOO
 }
 
-/* pass D (:2312-2420) has no memory beyond its cursor inside a row: a thread per row, 256 rows to a workgroup, through LDS tiles of 32
- * columns of the three planes (a thread on "its" row of a plane reads one cell of a different line at every step: 130 GB per batch that
- * way).  A pair that starts in a tile reads three columns past it; the cursor is what a row carries from tile to tile. */
-#define FD_C 32
-#define FD_P 36                                                       /* tile pitch (cells): columns c0 .. c0 + 35 */
-__global__ __launch_bounds__(256) void k_low_final(int16_t *__restrict__ yb, size_t y_stride, const int16_t *__restrict__ kmb, size_t km_stride,
-                                                   const uint8_t *__restrict__ sob, size_t so_stride, int q)
+/* Passes C and D for the rows pass C can take independently of each other -- every row without a marker (k_low_machine lists the others
+ * and has walked their pass C itself) -- a lane per row, 255 rows (+ the one below them) to a workgroup, through LDS tiles of 32 columns.
+ *
+ * Pass C (:1994-2310) without markers keeps nothing from row to row: its cursor dance (pairs at even phase, back by one to try the odd
+ * phase, :2279-2308) starts afresh in every row; it reads the contrast map of its row and of the row above and ADDS to the picture in
+ * both (and sets their flags to 1): additions commute, so rows need no order.  A lane records what it adds to its own row and to the row
+ * above in two planes of its own (low byte: sum, bit 8: flag); nothing else is written during the walk, so lanes never meet.  Pass D
+ * (:2312-2420) of a row reads the row's map and flags as passes B and C leave them -- final a few columns behind the cursor of pass C
+ * of this row and of the row below -- and adds to the picture too: it follows pass C at a distance inside the same tile loop.  Then the
+ * tile's sums go to the picture (and its flags to the flag plane) where there are any: the picture is not read at all elsewhere.
+ * Per image: the map once (+ 8 of 40 columns twice), the flag plane once, some hundred read-modify-writes.
+ * (Round 2 ran pass C on the chain lane of the pre-filter kernel, 30 % of its 271 ms, and pass D as a kernel over the three planes: 21 GB.) */
+#define MK_C 32                                                        /* columns a tile advances */
+#define MK_L 8                                                         /* columns kept to the left: the cursor of pass C goes back by 3, looks 4 further back and bumps one more */
+#define MK_W (MK_C + MK_L)
+#define MK_P 42                                                        /* pitch in cells (21 dwords: a lane per row walks all banks) */
+#define MK_SP 44                                                       /* pitch of the flag tile in bytes */
+__global__ __launch_bounds__(256) void k_low_marks(int16_t *__restrict__ yb, size_t y_stride, const int16_t *__restrict__ kmb, size_t km_stride,
+                                                   uint8_t *__restrict__ sob, size_t so_stride, int q, int dbg)
 {
-	__shared__ __attribute__((aligned(16))) int16_t kt[256 * FD_P], yt[256 * FD_P];
-	__shared__ __attribute__((aligned(16))) uint8_t st[256 * FD_P];
-	const int tid = threadIdx.x, r0 = 1 + blockIdx.x * 256, img = blockIdx.y;
-	const int nrows = W - 1 - r0 < 256 ? W - 1 - r0 : 256;             /* rows r0 .. r0 + nrows - 1 (<= W - 2) */
+	__shared__ __attribute__((aligned(16))) int16_t kt[257 * MK_P];        /* map; tile row 0 = the row above the workgroup's first */
+	__shared__ __attribute__((aligned(16))) uint16_t own[256 * MK_P], upd[256 * MK_P];
+	__shared__ __attribute__((aligned(16))) uint8_t st[256 * MK_SP];
+	__shared__ uint32_t s_mask[16];
+	const int tid = threadIdx.x, img = blockIdx.y;
+	const int R0 = 1 + 255 * blockIdx.x;                               /* rows R0 .. R0 + 254 are this workgroup's; lane 255 walks pass C of the row below them for what it adds to the last one */
+	const int r = R0 + tid;
 	const PfP pp = pf_params(q);
+	const int sharp = pp.sharp, s2 = pp.s2, half = pp.half;
 	const int16_t *km = kmb + (size_t)img * km_stride;
 	int16_t *y = yb + (size_t)img * y_stride;
-	const uint8_t *so = sob + (size_t)img * so_stride;
-	int p = 1;
-	for (int c0 = 0; c0 < W; c0 += FD_C) {
-		for (int k = tid; k < nrows * (FD_P / 2); k += 256) {
-			const int rr = k / (FD_P / 2), d = k % (FD_P / 2);
-			reinterpret_cast<uint32_t *>(kt + rr * FD_P)[d] = reinterpret_cast<const uint32_t *>(km + (size_t)(r0 + rr) * W + c0)[d];
-			reinterpret_cast<uint32_t *>(yt + rr * FD_P)[d] = reinterpret_cast<const uint32_t *>(y + (size_t)(r0 + rr) * W + c0)[d];
+	uint8_t *so = sob + (size_t)img * so_stride;
+	if (tid < 16) s_mask[tid] = reinterpret_cast<const uint32_t *>(so)[tid];
+	__syncthreads();
+	const bool in_pic = r <= W - 2;
+	const bool walk_c = in_pic && !((s_mask[(r >> 5) & 15] >> (r & 31)) & 1) && !(dbg & 4);
+	const bool own_row = tid < 255 && in_pic;
+	const bool have_up = r >= 2;
+	int v = 2, idle = 0, retry = 0, fresh = 0;                         /* pass C: cursor (second pixel of the pair), :1998-2000 */
+	int p = 1;                                                         /* pass D: first pixel of the pair */
+
+	for (int t0 = 0; t0 < W; t0 += MK_C) {
+		const int cb = t0 - MK_L;                                      /* first column of the tile (negative in the first tile: those cells are never touched) */
+		for (int k = tid; k < 257 * (MK_W / 2); k += 256) {
+			const int rr = k / (MK_W / 2), d = k % (MK_W / 2), row = R0 - 1 + rr, col = cb + 2 * d;
+			uint32_t w = 0;
+			if (col >= 0 && row >= 1 && row <= W - 2) w = *reinterpret_cast<const uint32_t *>(km + (size_t)row * W + col);
+			reinterpret_cast<uint32_t *>(kt + rr * MK_P)[d] = w;
 		}
-		for (int k = tid; k < nrows * (FD_P / 4); k += 256) {
-			const int rr = k / (FD_P / 4), d = k % (FD_P / 4);
-			reinterpret_cast<uint32_t *>(st + rr * FD_P)[d] = reinterpret_cast<const uint32_t *>(so + (size_t)(r0 + rr) * W + c0)[d];
+		for (int k = tid; k < 256 * (MK_W / 2); k += 256) {
+			const int rr = k / (MK_W / 2), d = k % (MK_W / 2);
+			reinterpret_cast<uint32_t *>(own + rr * MK_P)[d] = 0;
+			reinterpret_cast<uint32_t *>(upd + rr * MK_P)[d] = 0;
+		}
+		for (int k = tid; k < 255 * (MK_W / 4); k += 256) {
+			const int rr = k / (MK_W / 4), d = k % (MK_W / 4), row = R0 + rr, col = cb + 4 * d;
+			uint32_t w = 0;
+			if (col >= 0 && row <= W - 2) w = *reinterpret_cast<const uint32_t *>(so + (size_t)row * W + col);
+			reinterpret_cast<uint32_t *>(st + rr * MK_SP)[d] = w;
 		}
 		__syncthreads();
-		if (tid < nrows) {
-			const int end = c0 + FD_C < W - 2 ? c0 + FD_C : W - 2;
-			while (p < end) p = final_pair(pp, kt + tid * FD_P - c0, yt + tid * FD_P - c0, st + tid * FD_P - c0, p);
+		const int16_t *kr = kt + (tid + 1) * MK_P - cb, *ku = kt + tid * MK_P - cb;     /* indexed by column */
+		uint16_t *ow = own + tid * MK_P - cb, *uw = upd + tid * MK_P - cb;
+#define MK_ADD(cell, d) do { const uint32_t x_ = (cell); (cell) = (uint16_t)(((x_ + (uint32_t)(d)) & 0xFFu) | 0x100u); } while (0)
+#define MK_ADD_QUIET(cell, d) do { const uint32_t x_ = (cell); (cell) = (uint16_t)(((x_ + (uint32_t)(d)) & 0xFFu) | (x_ & 0x100u)); } while (0)
+		if (walk_c) {
+			const int te = t0 + MK_C < W - 2 ? t0 + MK_C : W - 2;      /* the cursor takes the values 2 .. W - 3 */
+			while (v < te) {
+				const int k0 = kr[v - 1], k1 = kr[v];
+				int dv = 0;
+				const bool first = iabs_(k0) > sharp + 20 && iabs_(k1) > half && iabs_(k1) <= s2;
+				const bool second = !first && iabs_(k1) > sharp + 20 && iabs_(k0) > half && iabs_(k0) <= s2;
+				if (first || second) {                                 /* strong pixel with a weak partner (:2129-2278) */
+					const int strong = first ? k0 : k1, weak = first ? k1 : k0;
+					const int cs = first ? v - 1 : v, cw = first ? v : v - 1;
+					const int sg = strong > 0 ? 1 : -1;
+					MK_ADD(ow[cs], sg);
+					if ((sg > 0 && weak > 0) || (sg < 0 && weak < 0)) MK_ADD(ow[cw], 2 * sg);
+					if (have_up) {
+						const int a = ku[v] * sg, b = ku[v - 1] * sg;
+						int da = 0, db = 0;
+						if (a > 4) da += sg;
+						if (b > 4) db += sg;
+						if (a < -24 && !retry) da -= sg;
+						if (b < -24 && !retry) db -= sg;
+						if (da) MK_ADD(uw[v], da);
+						if (db) MK_ADD(uw[v - 1], db);
+					}
+					idle = 0; fresh = 0;
+					if (retry == 1) dv = 1; else if (retry == 2) dv = 3;
+					retry = 0;
+				} else {                                               /* the cursor goes back and tries the other pairing (:2279-2308) */
+					idle++;
+					if (!retry) fresh++;
+					if (idle == 2) { dv = -3; idle = 0; retry = 1; }
+					else if (retry == 1) {
+						dv = 1; retry = 0; idle = 0;
+						if (fresh == 4) {
+							if (iabs_(kr[v + 1 - 5]) <= s2 || iabs_(kr[v + 1 - 2]) <= s2) { dv = -4; retry = 2; }
+							fresh = 0;
+						}
+					}
+					else if (retry == 2) { dv = 3; retry = 0; idle = 0; fresh = 0; }
+				}
+				v += 2 + dv;
+			}
 		}
 		__syncthreads();
-		for (int k = tid; k < nrows * (FD_P / 2 - 1); k += 256) {      /* columns c0 .. c0 + 33: a pair that starts in the tile's last column writes one past it */
-			const int rr = k / (FD_P / 2 - 1), d = k % (FD_P / 2 - 1);
-			if (c0 + 2 * d < W) reinterpret_cast<uint32_t *>(y + (size_t)(r0 + rr) * W + c0)[d] = reinterpret_cast<const uint32_t *>(yt + rr * FD_P)[d];
+		if (own_row && !(dbg & 8)) {                                   /* pass D behind pass C: cells up to t0 + 27 have their final flags */
+			const int pe = t0 + MK_C >= W ? W - 2 : t0 + MK_C - 5;     /* pairs p < pe */
+			const uint16_t *un = upd + (tid + 1) * MK_P - cb;          /* what the row below adds to this one */
+			const uint8_t *sr = st + tid * MK_SP - cb;
+			while (p < pe) {
+				const int f0 = ((ow[p] | un[p]) & 0x100) ? 1 : sr[p], f1 = ((ow[p + 1] | un[p + 1]) & 0x100) ? 1 : sr[p + 1];
+				const int p0 = p;
+				int d0 = 0, d1 = 0;
+				p = final_pair(pp, kr, f0, f1, p0, d0, d1);
+				if (d0) MK_ADD_QUIET(ow[p0], d0);                      /* pass D does not raise flags */
+				if (d1) MK_ADD_QUIET(ow[p0 + 1], d1);
+			}
 		}
 		__syncthreads();
+		for (int k = tid; k < 255 * (MK_W / 2); k += 256) {            /* the tile's sums and flags go out where there are any */
+			const int rr = k / (MK_W / 2), d = k % (MK_W / 2), row = R0 + rr, col = cb + 2 * d;
+			const uint32_t o2 = reinterpret_cast<const uint32_t *>(own + rr * MK_P)[d] | 0u, u2 = reinterpret_cast<const uint32_t *>(upd + (rr + 1) * MK_P)[d];
+			if (!(o2 | u2) || col < 0 || row > W - 2) continue;
+			for (int h = 0; h < 2; h++) {
+				const uint32_t o = (o2 >> (16 * h)) & 0xFFFF, u = (u2 >> (16 * h)) & 0xFFFF;
+				if (!(o | u)) continue;
+				const int add = (int)(int8_t)(o & 0xFF) + (int)(int8_t)(u & 0xFF);
+				const size_t at = (size_t)row * W + col + h;
+				if (add) y[at] = (int16_t)(y[at] + add);
+				if ((o | u) & 0x100) so[at] = 1;
+			}
+		}
+		__syncthreads();
+#undef MK_ADD
+#undef MK_ADD_QUIET
 	}
 }
 
@@ -1122,12 +1037,14 @@ void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStr
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
                               int q, int n, hipStream_t s)
 {
-	static int dbg = 0;
-#ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing */
-	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
+	static int dbg = 0, li = 4;
+#ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing; images per wavefront */
+	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; e = getenv("NHW_LOW_LI"); li = e ? atoi(e) : 4; }
 #endif
-	k_low_prefilter<<<(n + PG - 1) / PG, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, n, dbg);
-	if (!(dbg & 8)) k_low_final<<<dim3(2, n), 256, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q);
+	if (li == 2) k_low_machine<2><<<(n + 1) / 2, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, n, dbg);
+	else if (li == 8) k_low_machine<8><<<(n + 7) / 8, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, n, dbg);
+	else k_low_machine<4><<<(n + 3) / 4, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, n, dbg);
+	k_low_marks<<<dim3(2, n), 256, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
 }
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s)
 {

@@ -1,0 +1,35 @@
+"""Developer tool (GPU box): the q <= 16 luma pre-filter as a stage on a full batch -- ms per batch and a check of some images against the oracle.
+usage: python tests/gpu_prefilter_time.py [q ...]   (NHW_LOW_LI / NHW_LOW_DBG act on developer builds)"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import nhwcodec_amd as na
+from oracle.oraclepy import Oracle
+
+def main(qs, n=4096, check=6):
+    orc = Oracle()
+    enc = na.Encoder(0, n)
+    img = enc.synth_device(n, 0)
+    y = torch.empty((n, 512 * 512), dtype=torch.int16, device="cuda")
+    u = torch.empty((n, 65536), dtype=torch.uint8, device="cuda"); v = torch.empty_like(u)
+    for q in qs:
+        assert enc.lib.nhw_stage_color(enc.h, img.data_ptr(), n, q, y.data_ptr(), u.data_ptr(), v.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        y0 = y[:check].cpu().numpy()
+        work = y.clone()
+        assert enc.lib.nhw_stage_prefilter(enc.h, work.data_ptr(), n, q, None) == 0
+        torch.cuda.synchronize()
+        got = work[:check].cpu().numpy()
+        bad = [i for i in range(check) if not np.array_equal(got[i], orc.prefilter(y0[i], q))]
+        ts = []
+        for _ in range(3):
+            work.copy_(y); torch.cuda.synchronize()
+            t0 = time.time()
+            enc.lib.nhw_stage_prefilter(enc.h, work.data_ptr(), n, q, None)
+            torch.cuda.synchronize()
+            ts.append((time.time() - t0) * 1e3)
+        print(f"q{q}: prefilter stage {min(ts):.1f} ms / {n} images (runs {', '.join(f'{t:.1f}' for t in ts)}); oracle check of {check}: {'OK' if not bad else 'MISMATCH ' + str(bad)}", flush=True)
+
+if __name__ == "__main__":
+    main([int(a) for a in sys.argv[1:]] or [1, 10, 16])

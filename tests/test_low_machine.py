@@ -1,0 +1,34 @@
+"""The pair machine of the quality 1..16 pre-filter (nhwcodec_amd/csrc/nhw_low_machine.h, the text the HIP kernel k_low_machine runs)
+compiled for the host and walked next to the oracle's machine (oracle/nhwo_prelow.c, reference encoder/image_processing.c:838-1925):
+machine_step must leave the ~50 counters exactly as the oracle's machine_pair does at every pair of every image; machine_step_fast
+must either decline with the counters untouched or agree with machine_step.  No GPU needed."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "low_machine")
+
+
+@pytest.fixture(scope="module")
+def machine_check(tmp_path_factory):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    d = tmp_path_factory.mktemp("low_machine")
+    obj, exe = str(d / "oracle_side.o"), str(d / "machine_check")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-c", os.path.join(SRC, "oracle_side.c"), "-o", obj])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(SRC, "product_side.cpp"), obj,
+                           "-L" + os.path.join(ROOT, "oracle"), "-l:liboracle.so", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    return exe
+
+
+@pytest.mark.parametrize("cls,images", [(0, 2), (1, 1), (2, 2), (3, 1)])
+def test_machine_forms_follow_the_oracle(machine_check, cls, images):
+    """classes: 0 SURVEY 8d synthetic, 1 white noise, 2 synthetic + flat / noisy / dotted patches, 3 stripes; every quality 1..16"""
+    r = subprocess.run([machine_check, "1", "16", str(images), str(cls)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("q")]
+    assert len(lines) == 16 and all("fast mismatches 0, step mismatches 0" in l for l in lines), r.stdout
+    if cls == 0:    # the fast form is what the benchmark images run on
+        pct = {int(l.split()[0][1:]): float(l.split("fast form")[1].split("%")[0]) for l in lines}
+        assert pct[1] > 99.0 and pct[10] > 99.0, pct
