@@ -39,9 +39,6 @@ DEVI uint64_t low_bits64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1); } 
  * divergent region pays an exec-mask save / restore and a vector compare per branch: measured 4x slower); stores are issued by lane 0. */
 #define LDK(p) __builtin_amdgcn_readfirstlane((int)*(p))
 #define STK(p, v) do { if (threadIdx.x == 0) *(p) = (v); } while (0)
-/* the chain phases run one image per LANE (the first lanes of the wavefront): plain per-lane accesses */
-#define LDL(p) ((int)*(p))
-#define STL(p, v) (*(p) = (v))
 
 /* ------------------------------------------------------------------------------------------------ parameters (:570-598) */
 struct PfP { int sharp, s2, half, smooth_hi, smooth, tail_rules; };
@@ -81,20 +78,20 @@ DEVI void map_cell(MapState &s, const PfP &pp, int c, int sm, int val, int16_t *
 	if (sm < 0) {
 		if (val == -s2 && s.bump_count < 3) { val = -s2 - 1; s.bump_count++; }
 		if (-sm <= s2 && -val > s2 && -val <= s2 + 20) {          /* borderline: the plain sum is not above the threshold, the contrast is */
-			if (c > 1 && iabs_(LDL(k + c - 1)) <= pp.half) s.neg_run = 0;
-			if (!s.neg_run) { STL(k + c, (int16_t)(-20000)); s.neg_run = 1; }
+			if (c > 1 && iabs_(LDK(k + c - 1)) <= pp.half) s.neg_run = 0;
+			if (!s.neg_run) { STK(k + c, (int16_t)(-20000)); s.neg_run = 1; }
 			else {
-				STL(k + c, (int16_t)((int16_t)val));
+				STK(k + c, (int16_t)((int16_t)val));
 				if (!s.neg_cycle) { s.neg_run = 0; s.neg_cycle = 1; }
 				else if (s.neg_run == 1) s.neg_run = 2;
 				else { s.neg_run = 0; s.neg_cycle = s.neg_cycle == 1 ? 2 : s.neg_cycle == 2 ? 3 : 0; }
 			}
 		}
-		else STL(k + c, (int16_t)((int16_t)val));
+		else STK(k + c, (int16_t)((int16_t)val));
 	} else {
 		if (sm <= s2 && val > s2 && val <= s2 + 20) {
 			if (c > 1) {
-				const int left = LDL(k + c - 1);
+				const int left = LDK(k + c - 1);
 				if (iabs_(left) <= pp.half) s.pos_run = 0;
 				else if (iabs_(left) > 10000 || left == s2 + 21) {
 					if (!s.pos_alt) { s.pos_run = 0; if (!s.pos_cycle) s.pos_cycle = 1; s.pos_alt = 1; }
@@ -108,18 +105,18 @@ DEVI void map_cell(MapState &s, const PfP &pp, int c, int sm, int val, int16_t *
 						s.pos_neg_alt = s.pos_neg_alt == 1 ? 2 : 0;
 					}
 				}
-				else if (left == s2 + 22) STL(k + c - 1, (int16_t)7000);
+				else if (left == s2 + 22) STK(k + c - 1, (int16_t)7000);
 			}
-			if (!s.pos_run) { STL(k + c, (int16_t)(20000)); s.pos_run = 1; }
+			if (!s.pos_run) { STK(k + c, (int16_t)(20000)); s.pos_run = 1; }
 			else {
-				STL(k + c, (int16_t)((int16_t)val));
+				STK(k + c, (int16_t)((int16_t)val));
 				if (!s.pos_cycle) { s.pos_run = 0; s.pos_cycle = 1; }
 				else if (s.pos_run == 1) s.pos_run = 2;
 				else { s.pos_run = 0; s.pos_cycle = s.pos_cycle == 1 ? 2 : s.pos_cycle == 2 ? 3 : 0; }
 			}
 		}
-		else if (val == s2 + 21) { STL(k + c, (int16_t)((int16_t)(s.exact_count ? val : 7000))); s.exact_count++; }
-		else STL(k + c, (int16_t)((int16_t)val));
+		else if (val == s2 + 21) { STK(k + c, (int16_t)((int16_t)(s.exact_count ? val : 7000))); s.exact_count++; }
+		else STK(k + c, (int16_t)((int16_t)val));
 	}
 }
 /* does pixel (sm, val) need the serial visit? */
@@ -213,11 +210,11 @@ struct MarkState { int skip_toggle, second_toggle, pos0, neg0, pos1, neg1; };
 
 DEVI void resolve_marker(int16_t *cell, int v, int &pos_cnt, int &neg_cnt, int s2)
 {
-	if (v == 20000) { if (!pos_cnt) { STL(cell, (int16_t)0); pos_cnt = 1; } else { STL(cell, (int16_t)5000); pos_cnt = pos_cnt == 1 ? 2 : 0; } }
-	else if (v == -20000) { if (!neg_cnt) { STL(cell, (int16_t)0); neg_cnt = 1; } else { STL(cell, (int16_t)-5000); neg_cnt = neg_cnt == 1 ? 2 : 0; } }
-	else if (v == 7000) STL(cell, (int16_t)(s2 + 22));
+	if (v == 20000) { if (!pos_cnt) { STK(cell, (int16_t)0); pos_cnt = 1; } else { STK(cell, (int16_t)5000); pos_cnt = pos_cnt == 1 ? 2 : 0; } }
+	else if (v == -20000) { if (!neg_cnt) { STK(cell, (int16_t)0); neg_cnt = 1; } else { STK(cell, (int16_t)-5000); neg_cnt = neg_cnt == 1 ? 2 : 0; } }
+	else if (v == 7000) STK(cell, (int16_t)(s2 + 22));
 }
-DEVI void bump(int16_t *yc, uint8_t *sc, int d) { STL(yc, (int16_t)(LDL(yc) + d)); STL(sc, (uint8_t)1); }
+DEVI void bump(int16_t *yc, uint8_t *sc, int d) { STK(yc, (int16_t)(LDK(yc) + d)); STK(sc, (uint8_t)1); }
 /* strong pixel with a weak partner: nudge the strong one, the partner if it agrees in sign, and the two pixels above the pair */
 DEVI void sharpen_weak_partner(int strong, int weak, int16_t *ys, int16_t *yw, uint8_t *ss, uint8_t *sw,
                                const int16_t *kup, int16_t *yup, uint8_t *sup, bool have_up, bool no_retry)
@@ -226,7 +223,7 @@ DEVI void sharpen_weak_partner(int strong, int weak, int16_t *ys, int16_t *yw, u
 	bump(ys, ss, sg);
 	if ((sg > 0 && weak > 0) || (sg < 0 && weak < 0)) bump(yw, sw, 2 * sg);
 	if (have_up) {
-		const int a = LDL(kup) * sg, b = LDL(kup - 1) * sg;
+		const int a = LDK(kup) * sg, b = LDK(kup - 1) * sg;
 		int da = 0, db = 0;
 		if (a > 4) da += sg;
 		if (b > 4) db += sg;
@@ -243,7 +240,7 @@ DEVI void marker_row(MarkState &s, const PfP &pp, int r, int16_t *km, int16_t *y
 	int idle = 0, retry = 0, idle_fresh = 0;
 	for (int c = 1; c < W - 3; c++) {
 		c++;
-		const int k0 = LDL(km + c - 1), k1 = LDL(km + c);
+		const int k0 = LDK(km + c - 1), k1 = LDK(km + c);
 		if (iabs_(k0) > 6000) {
 			resolve_marker(km + c - 1, k0, s.pos0, s.neg0, s2);
 			if (!s.second_toggle) { resolve_marker(km + c, k1, s.pos1, s.neg1, s2); s.second_toggle = 1; }
@@ -271,7 +268,7 @@ DEVI void marker_row(MarkState &s, const PfP &pp, int r, int16_t *km, int16_t *y
 			else if (retry == 1) {
 				c++; retry = 0; idle = 0;
 				if (idle_fresh == 4) {
-					if (iabs_(LDL(km + c - 5)) <= s2 || iabs_(LDL(km + c - 2)) <= s2) { c -= 5; retry = 2; }
+					if (iabs_(LDK(km + c - 5)) <= s2 || iabs_(LDK(km + c - 2)) <= s2) { c -= 5; retry = 2; }
 					idle_fresh = 0;
 				}
 			}
@@ -342,41 +339,41 @@ DEVI int final_pair(const PfP &pp, const int16_t *km, int f0, int f1, int p, int
 
 /* src: the luma plane as the colour kernel wrote it (read only); y: the filtered plane (every row is written).
  *
- * The counters of pass B tie every pixel pair of an image to the one before it: an image is a serial job of ~130 000 machine steps and only
- * images run side by side.  What is on that chain is machine_step and nothing else: a wavefront takes LI images, computes for a row of each
- * (all 64 lanes) pass A, the q <= 14 smoothing and the 255 pair codes, then lanes 0..LI-1 walk their image's codes through their machine
- * (the counters are plain per-lane registers), then all lanes apply the answers to the row (pair_apply, tail rules).  Pass C (markers,
- * weak partners) has counters of its own, but they only move where the walk meets a marker: a row without one is independent of every
- * other row, and k_low_marks does those rows a lane per row.  The rows WITH a marker (a few dozen per image) are walked here, in order, by
- * the image's chain lane, and are listed in a 512-bit row mask for k_low_marks (kept in the flag plane's row 0, which no pass uses).
+ * One wavefront per image, 16 wavefronts per CU.  The counters of pass B tie every pixel pair of an image to the one before it, but what
+ * that chain really costs is small once it is taken apart (nhw_low_machine.h):
+ *   * the machine never looks at the picture, only at four threshold tests per pair (the pair's code); all 64 lanes compute a row's codes
+ *     and the prefix sums of its hits;
+ *   * inside a burst the counters move by closed forms, so the pairs of a burst are evaluated one per lane and a whole burst is one step of
+ *     the chain (burst_lane / burst_commit: ballots and mask arithmetic on the scalar unit);
+ *   * what is left -- a burst's first pair, bursts that wake one of the slow schedules, bursts cut by the end of the row -- goes pair by
+ *     pair through machine_step_fast / machine_step on wave-uniform values, i.e. in scalar registers with scalar branches;
+ *   * the machine's answers (3 bits per pair) are applied to the row by all lanes (pair_apply, tail rules).
+ * Pass A's few order-dependent cells and pass C of the rows that hold a marker (its counters only move at markers: k_low_marks takes all
+ * other rows a lane per row) are walked on the scalar unit too; those rows are listed in a 512-bit mask (flag plane, row 0).
+ * Passes A..C run as ONE sweep over the rows with two rows of every plane in LDS (9.7 KB); the contrast map, the flags and the picture
+ * are written once.
  *
- * History (front of q10, ms per 4096-image batch): wavefront per image, passes B and C on the scalar unit 471; B on lane 0 443; both
- * per lane, 2 images per wavefront 280 (round 2); codes / answers + row-parallel pass C, 4 images per wavefront: see DESIGN 4.7. */
-template <int LI>
+ * History (front of q10 / q1, ms per 4096-image batch): round 2, two images per wavefront with the machines in lanes 0 and 1: 271 / 176;
+ * codes + answers, row-parallel pass C, four images per wavefront, machine_step_fast per pair: 118 / 84; whole bursts: see DESIGN 4.7. */
 __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
-                                                    int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q, int n_img, int dbg)
+                                                    int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q, int dbg)
 {
-	__shared__ __attribute__((aligned(16))) int16_t s_src[LI][3][W];
-	__shared__ __attribute__((aligned(16))) int16_t s_km[LI][2][W + 8];
-	__shared__ __attribute__((aligned(16))) int16_t s_y[LI][2][W];
-	__shared__ __attribute__((aligned(16))) uint8_t s_so[LI][2][W];
-	__shared__ __attribute__((aligned(16))) int16_t s_sum[LI][W];
-	__shared__ __attribute__((aligned(8))) uint8_t s_cand[LI][64];        /* per 8-pixel group: the pixels that need the serial visit of pass A */
-	/* per pair: threshold tests in, the machine's answer out -- in place (the chain lane has read a dword of codes before it stores the
-	 * answers there).  Pass A's base values of the image it is working on (s_vb) are dead before the first code is written: same bytes. */
-	__shared__ __attribute__((aligned(16))) uint8_t s_code[LI < 4 ? 4 : LI][256];
-	uint8_t (*s_act)[256] = s_code;
-	int16_t *s_vb = reinterpret_cast<int16_t *>(&s_code[0][0]);
-	__shared__ uint32_t s_rowmask[LI][16];                                 /* rows whose pass C ran here */
-	__shared__ int s_misc[4], s_mrow[LI], s_pb[LI];
-	const int lane = threadIdx.x, img0 = blockIdx.x * LI;
-	const int nimg = n_img - img0 < LI ? n_img - img0 : LI;              /* images of this wavefront */
+	__shared__ __attribute__((aligned(16))) int16_t s_src[3][W];
+	__shared__ __attribute__((aligned(16))) int16_t s_km[2][W + 8];
+	__shared__ __attribute__((aligned(16))) int16_t s_y[2][W];
+	__shared__ __attribute__((aligned(16))) uint8_t s_so[2][W];
+	__shared__ __attribute__((aligned(16))) int16_t s_sum[W];             /* pass A: the 8-neighbour sums; behind it: the prefix sums of the pairs' hits (s_hits) */
+	__shared__ __attribute__((aligned(8))) uint8_t s_cand[64];            /* per 8-pixel group: the pixels that need the serial visit of pass A */
+	__shared__ __attribute__((aligned(16))) uint8_t s_code[256], s_act[256];   /* per pair: threshold tests in, the machine's answer out */
+	__shared__ uint32_t s_rowmask[16];                                     /* rows whose pass C ran here */
+	__shared__ int s_misc[4];
+	int16_t *s_hits = s_sum;
+	const int lane = threadIdx.x, img = blockIdx.x;
 	const PfP pp = pf_params(q);
 
-	__shared__ int row_carry[LI];                                        /* wave-uniform per image; in LDS so that the loop over the images need not be unrolled (code size) */
-	if (threadIdx.x < LI) { row_carry[threadIdx.x] = 0; s_pb[threadIdx.x] = 0; }
-	for (int k = lane; k < LI * 16; k += 64) (&s_rowmask[0][0])[k] = 0;
-	/* per lane: the marker state of pass A, the machine of pass B and the state of pass C of image img0 + lane */
+	if (lane < 16) s_rowmask[lane] = 0;
+	/* wave-uniform: pass A's entry carry, its marker state, the machine of pass B with its cache, the state of pass C, the tail rules' flag */
+	int row_carry = 0, prev_big = 0;
 	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	MarkState ks = { 0, 0, 0, 0, 0, 0 };
 	PfM mach;
@@ -385,29 +382,24 @@ __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ 
 	machine_cache(mach, mcache);
 
 	const int c0 = lane * 8;
-#define SRC(g) (srcb + (size_t)(img0 + (g)) * src_stride)
-#define YO(g) (yb + (size_t)(img0 + (g)) * y_stride)
-#define KMO(g) (kmb + (size_t)(img0 + (g)) * km_stride)             /* contrast map and flags as passes A..C leave them */
-#define SOO(g) (sob + (size_t)(img0 + (g)) * so_stride)
-	auto load_row = [&](int g, int r) { *reinterpret_cast<uint4 *>(&s_src[g][r % 3][c0]) = *reinterpret_cast<const uint4 *>(SRC(g) + (size_t)r * W + c0); };
-#pragma unroll
-	for (int g = 0; g < LI; g++) if (g < nimg) { load_row(g, 0); load_row(g, 1); }
-	for (int k = lane; k < LI * 2 * (W + 8); k += 64) (&s_km[0][0][0])[k] = 0;
+	const int16_t *src = srcb + (size_t)img * src_stride;
+	int16_t *yo = yb + (size_t)img * y_stride;
+	int16_t *kmo = kmb + (size_t)img * km_stride;                      /* contrast map and flags as passes A..C leave them */
+	uint8_t *soo = sob + (size_t)img * so_stride;
+	auto load_row = [&](int r) { *reinterpret_cast<uint4 *>(&s_src[r % 3][c0]) = *reinterpret_cast<const uint4 *>(src + (size_t)r * W + c0); };
+	load_row(0); load_row(1);
+	for (int k = lane; k < 2 * (W + 8); k += 64) (&s_km[0][0])[k] = 0;
 	__syncthreads();
-#pragma unroll
-	for (int g = 0; g < LI; g++) if (g < nimg) *reinterpret_cast<uint4 *>(YO(g) + c0) = *reinterpret_cast<const uint4 *>(&s_src[g][0][c0]);      /* row 0 is not touched by any pass */
+	*reinterpret_cast<uint4 *>(yo + c0) = *reinterpret_cast<const uint4 *>(&s_src[0][c0]);      /* row 0 is not touched by any pass */
 
 	for (int r = 1; r < W - 1; r++) {
-#pragma unroll
-		for (int g = 0; g < LI; g++) if (g < nimg) load_row(g, r + 1);
+		load_row(r + 1);
 		__syncthreads();
-#pragma unroll 1
-		for (int g = 0; g < LI; g++) {
-		if (g >= nimg) continue;
-		const int16_t *up = s_src[g][(r - 1) % 3], *mid = s_src[g][r % 3], *dn = s_src[g][(r + 1) % 3];
-		int16_t *km = s_km[g][r & 1];
-		int16_t *y = s_y[g][r & 1];
-		uint8_t *so = s_so[g][r & 1];
+		const int16_t *up = s_src[(r - 1) % 3], *mid = s_src[r % 3], *dn = s_src[(r + 1) % 3];
+		int16_t *km = s_km[r & 1];
+		int16_t *y = s_y[r & 1];
+		uint8_t *so = s_so[r & 1];
+		int16_t *s_vb = y;                                           /* pass A's base values: the row's picture copy is made behind it */
 		/* every lane: 8-neighbour sum and magnitude sum of its 8 pixels (:605-618), as the signed base value 15 |sum| + mag of the carry */
 		int smv[8], vbv[8];
 		for (int e = 0; e < 8; e++) {
@@ -425,8 +417,7 @@ __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ 
 		{ uint32_t w4[4], z4[4];
 		  for (int e = 0; e < 4; e++) { w4[e] = (uint32_t)(uint16_t)vbv[2 * e] | ((uint32_t)(uint16_t)vbv[2 * e + 1] << 16); z4[e] = (uint32_t)(uint16_t)smv[2 * e] | ((uint32_t)(uint16_t)smv[2 * e + 1] << 16); }
 		  *reinterpret_cast<uint4 *>(&s_vb[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-		  *reinterpret_cast<uint4 *>(&s_sum[g][c0]) = make_uint4(z4[0], z4[1], z4[2], z4[3]); }
-		*reinterpret_cast<uint4 *>(&y[c0]) = *reinterpret_cast<const uint4 *>(&mid[c0]);        /* :566: the passes work on a copy */
+		  *reinterpret_cast<uint4 *>(&s_sum[c0]) = make_uint4(z4[0], z4[1], z4[2], z4[3]); }
 		*reinterpret_cast<uint2 *>(&so[c0]) = make_uint2(0, 0);
 		__syncthreads();
 		unsigned cand = 0;
@@ -435,7 +426,7 @@ __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ 
 			int carry;
 			bool merged = true;
 			if (c0 <= PF_LOOK) {                                   /* the row's own entry state reaches me */
-				carry = row_carry[g];
+				carry = row_carry;
 				for (int c = 1; c < c0; c++) { const int vb = s_vb[c]; carry = vb == 0 ? 0 : ((iabs_(vb) + ((carry + 2) >> 2)) & 15); }
 			} else {
 				uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
@@ -459,7 +450,7 @@ __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ 
 			if (__any(!merged)) {
 				/* rare: some lane's 16 states had not merged within the look-back -- the row is replayed by one lane */
 				if (lane == 0) {
-					int cr = row_carry[g];
+					int cr = row_carry;
 					for (int c = 1; c < W - 1; c++) {
 						const int vb = s_vb[c];
 						int val = 0;
@@ -470,82 +461,101 @@ __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ 
 				}
 				__syncthreads();
 				for (int e = 0; e < 8; e++) valv[e] = (c0 + e >= 1 && c0 + e <= W - 2) ? (int)km[c0 + e] : 0;
-				row_carry[g] = s_misc[0];
+				row_carry = LDK(&s_misc[0]);
 			} else {
-				row_carry[g] = __builtin_amdgcn_readlane(carry, 63);
+				row_carry = __builtin_amdgcn_readlane(carry, 63);
 			}
 			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)valv[2 * e] | ((uint32_t)(uint16_t)valv[2 * e + 1] << 16);
 			  *reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
 			for (int e = 0; e < 8; e++) if (smv[e] != 0 && map_candidate(pp, smv[e], valv[e])) cand |= 1u << e;
 		}
-		s_cand[g][lane] = (uint8_t)cand;
-		__syncthreads();                                           /* s_vb is the next image's from here */
-		}
-		/* the few order-dependent pixels of pass A, in raster order, image img0 + lane on lane `lane` */
-		if (lane < nimg && !(dbg & 1)) {
-			int16_t *km = s_km[lane][r & 1];
+		s_cand[lane] = (uint8_t)cand;
+		__syncthreads();                                           /* s_vb is dead from here */
+		/* the few order-dependent pixels of pass A, in raster order, on the scalar unit */
+		if (!(dbg & 1)) {
 			for (int l8 = 0; l8 < 8; l8++) {
-				uint64_t m8 = reinterpret_cast<const uint64_t *>(s_cand[lane])[l8];
+				const uint32_t lo = (uint32_t)LDK(reinterpret_cast<const int *>(s_cand) + 2 * l8), hi = (uint32_t)LDK(reinterpret_cast<const int *>(s_cand) + 2 * l8 + 1);
+				uint64_t m8 = (uint64_t)lo | ((uint64_t)hi << 32);
 				while (m8) {
 					const int bit = __builtin_ctzll(m8);
 					m8 &= m8 - 1;
 					const int c = 64 * l8 + bit;                        /* byte l of the word = group 8 l8 + l, bit e of it = pixel 8 (8 l8 + l) + e */
-					map_cell(ms, pp, c, (int)s_sum[lane][c], (int)km[c], km);
+					map_cell(ms, pp, c, LDK(&s_sum[c]), LDK(&km[c]), km);
 				}
 			}
 		}
 		__syncthreads();
-		/* all lanes, image by image: the q <= 14 smoothing (:780-807, reads the source copy only) and the pair codes of the row: lane l has
-		 * pairs 4 l .. 4 l + 3 = cells 8 l + 1 .. 8 l + 8 */
-#pragma unroll
-		for (int g = 0; g < LI; g++) {
-			if (g >= nimg) continue;
-			const int16_t *km = s_km[g][r & 1];
-			if (pp.smooth) {
-				const int16_t *up = s_src[g][(r - 1) % 3], *mid = s_src[g][r % 3], *dn = s_src[g][(r + 1) % 3];
-				int16_t *y = s_y[g][r & 1];
-				for (int e = 0; e < 8; e++) {
-					const int c = c0 + e;
-					if (c < 1 || c > W - 2) continue;
-					const int k = km[c];
-					if (iabs_(k) > 4 && iabs_(k) < pp.smooth_hi &&
-					    iabs_(up[c] - mid[c - 1]) < 4 && iabs_(mid[c - 1] - dn[c]) < 4 && iabs_(dn[c] - mid[c + 1]) < 4 && iabs_(mid[c + 1] - up[c]) < 4)
-						y[c] = (int16_t)(((mid[c] << 2) + mid[c - 1] + mid[c + 1] + up[c] + dn[c] + 4) >> 3);
+		/* all lanes: the row's picture copy (:566) with the q <= 14 smoothing (:780-807, reads the source copy only), the pair codes of the
+		 * row (lane l has pairs 4 l .. 4 l + 3 = cells 8 l + 1 .. 8 l + 8) and the prefix sums of their hits */
+		{
+			uint32_t yw[4];
+			for (int e2 = 0; e2 < 4; e2++) {
+				int v2[2];
+				for (int h = 0; h < 2; h++) {
+					const int c = c0 + 2 * e2 + h;
+					int v = mid[c];
+					if (pp.smooth && c >= 1 && c <= W - 2) {
+						const int k = km[c];
+						if (iabs_(k) > 4 && iabs_(k) < pp.smooth_hi &&
+						    iabs_(up[c] - mid[c - 1]) < 4 && iabs_(mid[c - 1] - dn[c]) < 4 && iabs_(dn[c] - mid[c + 1]) < 4 && iabs_(mid[c + 1] - up[c]) < 4)
+							v = ((mid[c] << 2) + mid[c - 1] + mid[c + 1] + up[c] + dn[c] + 4) >> 3;
+					}
+					v2[h] = v;
 				}
+				yw[e2] = (uint32_t)(uint16_t)v2[0] | ((uint32_t)(uint16_t)v2[1] << 16);
 			}
+			*reinterpret_cast<uint4 *>(&y[c0]) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
 			uint32_t cw = 0;
+			int hp[4], h = 0;
 			for (int j = 0; j < 4; j++) {
 				const int k0 = km[c0 + 2 * j + 1], k1 = km[c0 + 2 * j + 2];
-				const uint32_t code = (iabs_(k0) > pp.sharp ? 1u : 0u) | (iabs_(k1) > pp.sharp ? 2u : 0u) | (iabs_(k1) > pp.s2 ? 4u : 0u) | (iabs_(k0) > pp.sharp + 96 ? 8u : 0u);
+				const int f0 = iabs_(k0) > pp.sharp, f1 = iabs_(k1) > pp.sharp;
+				const uint32_t code = (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (iabs_(k1) > pp.s2 ? 4u : 0u) | (iabs_(k0) > pp.sharp + 96 ? 8u : 0u);
 				cw |= code << (8 * j);
+				h += f0 + f1; hp[j] = h;
 			}
-			*reinterpret_cast<uint32_t *>(&s_code[g][4 * lane]) = cw;
+			*reinterpret_cast<uint32_t *>(&s_code[4 * lane]) = cw;
+			*reinterpret_cast<uint32_t *>(&s_act[4 * lane]) = 0;
+			int incl = h;                                              /* inclusive scan of the lanes' totals */
+			for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+			const int excl = incl - h;
+			*reinterpret_cast<uint2 *>(&s_hits[4 * lane]) = make_uint2((uint32_t)(uint16_t)(excl + hp[0]) | ((uint32_t)(uint16_t)(excl + hp[1]) << 16),
+			                                                           (uint32_t)(uint16_t)(excl + hp[2]) | ((uint32_t)(uint16_t)(excl + hp[3]) << 16));
 		}
 		__syncthreads();
-		/* the chain: image img0 + lane on lane `lane`, 255 codes through the machine */
-		if (lane < nimg && !(dbg & 2)) {
-			const uint32_t *cp = reinterpret_cast<const uint32_t *>(s_code[lane]);
-			uint32_t *ap = reinterpret_cast<uint32_t *>(s_act[lane]);
-			uint32_t nxt = cp[0], cw = 0, aw = 0;
-#pragma unroll 1
-			for (int i = 0; i < 255; i++) {
-				if (!(i & 3)) { cw = nxt; nxt = cp[(i >> 2) + 1 < 64 ? (i >> 2) + 1 : 63]; aw = 0; }
-				int a = machine_step_fast(mach, mcache, (int)(cw & 15));
-				if (a < 0) { a = machine_step(mach, (int)(cw & 15), r); machine_cache(mach, mcache); }
-				aw |= (uint32_t)a << (8 * (i & 3));
-				cw >>= 8;
-				if ((i & 3) == 3 || i == 254) ap[i >> 2] = aw;
+		/* the chain: whole bursts where the counters allow it, single pairs otherwise; everything below is wave-uniform */
+		if (!(dbg & 2)) {
+			int pos = 0;
+			bool give_up = false;                                  /* a burst that was declined is walked pair by pair to its end */
+			while (pos < 255) {
+				if (mach.t[1] == 0) give_up = false;
+				if (!give_up && burst_entry_ok(mach, mcache)) {
+					const int base = pos ? LDK(&s_hits[pos - 1]) : 0;
+					const int i = pos + lane < 255 ? pos + lane : 255;
+					const int hj = (int)s_hits[i] - base;
+					const PfBurstLane b = burst_lane(lane, mach.t[1], mach.t[4], mach.t[44], hj, mach.t[10], mach.t[11], mcache.exT);
+					PfBurstMasks k;
+					k.cap = __ballot(b.cap); k.wrap = __ballot(b.wrap); k.win = __ballot(b.win); k.cyc = __ballot(b.cyc); k.i6 = __ballot(b.i6);
+					k.iS = __ballot(b.iS); k.cnt = __ballot(b.cnt); k.g13 = __ballot(b.g13); k.e15 = __ballot(b.e15); k.eT = __ballot(b.eT);
+					const unsigned long long endm = k.cap | k.wrap;
+					int e = endm ? __builtin_ctzll(endm) : 64;
+					if (e >= 255 - pos) e = 255 - pos - 1;                 /* the row ends first */
+					const int n = burst_commit(mach, mcache, k, 255 - pos, mach.t[4] + __builtin_amdgcn_readlane(hj, e));
+					if (n > 0) { pos += n; continue; }
+					give_up = true;
+				}
+				const int code = LDK(&s_code[pos]);
+				int a = machine_step_fast(mach, mcache, code);
+				if (a < 0) { a = machine_step(mach, code, r); machine_cache(mach, mcache); }
+				STK(&s_act[pos], (uint8_t)a);
+				pos++;
 			}
 		}
 		__syncthreads();
 		/* all lanes: the answers applied to the row (pass B's picture side), the tail rules, and the test for markers */
-#pragma unroll 1
-		for (int g = 0; g < LI; g++) {
-			if (g >= nimg) continue;
-			int16_t *km = s_km[g][r & 1];
-			int16_t *y = s_y[g][r & 1];
-			uint8_t *so = s_so[g][r & 1];
-			const uint32_t aw = (dbg & 2) ? 0u : *reinterpret_cast<const uint32_t *>(&s_act[g][4 * lane]);
+		bool any_mark;
+		{
+			const uint32_t aw = (dbg & 2) ? 0u : *reinterpret_cast<const uint32_t *>(&s_act[4 * lane]);
 			int kc[9], dd[9], sv[9], e0[4], e1[4];
 			{ const uint4 kw = *reinterpret_cast<const uint4 *>(&km[c0]);
 			  const uint32_t w4[4] = { kw.x, kw.y, kw.z, kw.w };
@@ -561,12 +571,12 @@ __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ 
 				int pbo[4];
 				for (int j = 0; j < 4; j++) pbo[j] = tail_flag(e0[j], e1[j]);
 				int pb_in = __shfl_up(pbo[3], 1);
-				if (lane == 0) pb_in = s_pb[g];
+				if (lane == 0) pb_in = prev_big;
 				for (int j = 0; j < 4; j++) {
 					int pb = j ? pbo[j - 1] : pb_in;
 					if (j < npair) tail_rules(e0[j], e1[j], pb, dd[2 * j + 1], dd[2 * j + 2]);
 				}
-				if (lane == 63) s_pb[g] = pbo[2];
+				prev_big = __builtin_amdgcn_readlane(pbo[2], 63);
 			}
 			/* cell 8 l is the second cell of the previous lane's last pair */
 			{ const int pk = __shfl_up(kc[8], 1), pd = __shfl_up(dd[8], 1), ps = __shfl_up(sv[8], 1);
@@ -585,38 +595,30 @@ __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ 
 			{ uint32_t lo = 0, hi = 0;
 			  for (int e = 0; e < 4; e++) { lo |= (uint32_t)sv[e] << (8 * e); hi |= (uint32_t)sv[4 + e] << (8 * e); }
 			  *reinterpret_cast<uint2 *>(&so[c0]) = make_uint2(lo, hi); }
-			const bool any_mark = __any(mark);
-			if (lane == 0) s_mrow[g] = any_mark;
+			any_mark = __any(mark);
 		}
 		__syncthreads();
-		/* pass C of this row where it holds a marker: the image's chain lane, in row order */
-		if (lane < nimg && s_mrow[lane] && !(dbg & 4)) {
-			marker_row(ks, pp, r, s_km[lane][r & 1], s_y[lane][r & 1], s_so[lane][r & 1], s_km[lane][(r - 1) & 1], s_y[lane][(r - 1) & 1], s_so[lane][(r - 1) & 1]);
-			s_rowmask[lane][r >> 5] |= 1u << (r & 31);
+		/* pass C of this row where it holds a marker, in row order, on the scalar unit */
+		if (any_mark && !(dbg & 4)) {
+			marker_row(ks, pp, r, s_km[r & 1], s_y[r & 1], s_so[r & 1], s_km[(r - 1) & 1], s_y[(r - 1) & 1], s_so[(r - 1) & 1]);
+			if (lane == 0) s_rowmask[r >> 5] |= 1u << (r & 31);
+			__syncthreads();
 		}
-		__syncthreads();
 		if (r > 1) {                                              /* row r-1 is through passes A..C as far as they run here */
-#pragma unroll
-			for (int g = 0; g < LI; g++) if (g < nimg) {
-				*reinterpret_cast<uint4 *>(YO(g) + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[g][(r - 1) & 1][c0]);
-				*reinterpret_cast<uint4 *>(KMO(g) + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[g][(r - 1) & 1][c0]);
-				*reinterpret_cast<uint2 *>(SOO(g) + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[g][(r - 1) & 1][c0]);
-			}
+			*reinterpret_cast<uint4 *>(yo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[(r - 1) & 1][c0]);
+			*reinterpret_cast<uint4 *>(kmo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[(r - 1) & 1][c0]);
+			*reinterpret_cast<uint2 *>(soo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[(r - 1) & 1][c0]);
 		}
 	}
-#pragma unroll
-	for (int g = 0; g < LI; g++) if (g < nimg) {
+	__syncthreads();
+	{
 		const int r = W - 2;
-		*reinterpret_cast<uint4 *>(YO(g) + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[g][r & 1][c0]);
-		*reinterpret_cast<uint4 *>(KMO(g) + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[g][r & 1][c0]);
-		*reinterpret_cast<uint2 *>(SOO(g) + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[g][r & 1][c0]);
-		*reinterpret_cast<uint4 *>(YO(g) + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[g][(W - 1) % 3][c0]);
-		if (lane < 16) reinterpret_cast<uint32_t *>(SOO(g))[lane] = s_rowmask[g][lane];      /* flag plane, row 0: the rows k_low_marks must leave alone */
+		*reinterpret_cast<uint4 *>(yo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[r & 1][c0]);
+		*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[r & 1][c0]);
+		*reinterpret_cast<uint2 *>(soo + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[r & 1][c0]);
+		*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
+		if (lane < 16) reinterpret_cast<uint32_t *>(soo)[lane] = s_rowmask[lane];      /* flag plane, row 0: the rows k_low_marks must leave alone */
 	}
-#undef SRC
-#undef YO
-#undef KMO
-#undef SOO
 }
 
 /* Passes C and D for the rows pass C can take independently of each other -- every row without a marker (k_low_machine lists the others
@@ -1037,13 +1039,11 @@ void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStr
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
                               int q, int n, hipStream_t s)
 {
-	static int dbg = 0, li = 4;
-#ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing; images per wavefront */
-	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; e = getenv("NHW_LOW_LI"); li = e ? atoi(e) : 4; }
+	static int dbg = 0;
+#ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing */
+	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
-	if (li == 2) k_low_machine<2><<<(n + 1) / 2, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, n, dbg);
-	else if (li == 8) k_low_machine<8><<<(n + 7) / 8, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, n, dbg);
-	else k_low_machine<4><<<(n + 3) / 4, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, n, dbg);
+	k_low_machine<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, dbg);
 	k_low_marks<<<dim3(2, n), 256, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
 }
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s)

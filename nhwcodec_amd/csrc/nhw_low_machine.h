@@ -337,27 +337,32 @@ DEVI void machine_cache(const PfM &m, PfC &c)
 	c.w8z = Wv(8) == 0;
 }
 
-/* The pairs machine_step spends its time on, as straight-line code (selects, one exit): returns the answer, or -1 (state untouched) where
- * the pair needs machine_step itself.  Covered: a burst's first pair while t14 is not 1 or 2 and the strong-contrast bookkeeping
- * (:850-873) is not due; inside a burst, a pair that neither ends it (t17, :1053) nor makes one of the slow schedules of :1504-1873 move
- * (with their gate open the t28 schedule may count, :1714-1716).  On the synthetic images of the benchmark that is 99.6 % of the pairs at
- * quality 10 and all of them at quality 1; on white noise 80-90 %.  c: machine_cache() of the counters as they are. */
-DEVI int machine_step_fast(PfM &m, const PfC &c, int code)
+/* The pairs machine_step spends its time on, in short forms: each returns the answer, or -1 (counters untouched) where the pair needs
+ * machine_step itself.  The chain runs on wave-uniform values, so these are scalar code with scalar branches.
+ * Covered: a burst's first pair while t14 is not 1 or 2 and the strong-contrast bookkeeping (:850-873) is not due; inside a burst, a pair
+ * that neither ends it (t17, :1053) nor makes one of the slow schedules of :1504-1873 move (with their gate open the t28 schedule may
+ * count, :1714-1716).  On the synthetic images of the benchmark that is 99.6 % of the pairs at quality 10 and all of them at quality 1; on
+ * white noise 80-90 %.  c: machine_cache() of the counters as they are. */
+DEVI int machine_first_fast(PfM &m, const PfC &c, int code)          /* a burst's first pair (:840-994); t1 == 0 */
 {
 	const int f0 = code & 1, f1 = (code >> 1) & 1, g1 = (code >> 2) & 1, h0 = (code >> 3) & 1;
-	const int fires = f0 + f1;
-	const int first = T(1) == 0;
-
-	/* a burst's first pair (:840-994) */
-	const int bad_first = c.fb14 | (f0 & h0);
-	const int o3 = T(3);
-	const int pick = f1 & (f0 | (T(12) == 1)) & c.t14_045;             /* the second pixel goes through the weak-first rule or its rotation (:884-930) */
-	const int subst = pick & (o3 == 0) & f0;
-	const int rot3 = ((o3 == 1) << 1) | ((o3 == 2) * 3);                    /* 1 -> 2 -> 3 -> 0 */
-	const int n3 = subst ? 1 : pick ? rot3 : o3;
-	const int act_first = ACT_FIRST | ((f0 & (g1 | (T(8) == 1))) ? ACT_ZERO0 : 0) | (subst ? ACT_SUBST : 0);
-
-	/* inside a burst (:995-1910) */
+	if (c.fb14 | (f0 & h0)) return -1;
+	int act = ACT_FIRST;
+	if (f0 & (g1 | (T(8) == 1))) act |= ACT_ZERO0;
+	if (f1 & (f0 | (T(12) == 1)) & c.t14_045) {                         /* the second pixel goes through the weak-first rule or its rotation (:884-930) */
+		const int o3 = T(3);
+		if ((o3 == 0) & f0) { act |= ACT_SUBST; T(3) = 1; }
+		else T(3) = ((o3 == 1) << 1) | ((o3 == 2) * 3);                 /* 1 -> 2 -> 3 -> 0 */
+	}
+	T(2) = f0;
+	if (f0 | f1) T(13) = 1;
+	T(27) = 0;
+	T(1) = 1;
+	return act;
+}
+DEVI int machine_burst_fast(PfM &m, const PfC &c, int code)          /* inside a burst (:995-1910); t1 != 0 */
+{
+	const int fires = (code & 1) + ((code >> 1) & 1);
 	int t1 = T(1) + fires, t4 = T(4) + fires, t8 = T(8), t5 = T(5), t12 = T(12), t44 = T(44), t29 = T(29), t30 = T(30);
 	const int t18 = T(18);
 	const int win = (t4 == T(10)) & (t1 == T(11));
@@ -389,24 +394,11 @@ DEVI int machine_step_fast(PfM &m, const PfC &c, int code)
 	bad_burst |= (t8 > 6) & (t4 == 0) & (t1 > 1) & (t1 < 15);         /* the re-arm of :1875-1900 */
 	const int wrap = (t1 > 15) & (t1 < 1000000);
 	t1 = wrap ? 0 : t1; t4 = wrap ? 0 : t4; t29 += wrap;
-
-	if (first ? bad_first : bad_burst) return -1;
-	T(1) = first ? 1 : t1;
-	T(2) = first ? f0 : T(2);
-	T(3) = first ? n3 : o3;
-	T(13) = (first & (fires > 0)) ? 1 : T(13);
-	T(27) = first ? 0 : T(27);
-	T(4) = first ? T(4) : t4;
-	T(5) = first ? T(5) : t5;
-	T(8) = first ? T(8) : t8;
-	T(12) = first ? T(12) : t12;
-	T(17) = first ? T(17) : 0;
-	T(18) = first ? t18 : n18;
-	T(29) = first ? T(29) : t29;
-	T(30) = first ? T(30) : t30;
-	T(44) = first ? T(44) : t44;
-	return first ? act_first : 0;
+	if (bad_burst) return -1;
+	T(1) = t1; T(4) = t4; T(5) = t5; T(8) = t8; T(12) = t12; T(17) = 0; T(18) = n18; T(29) = t29; T(30) = t30; T(44) = t44;
+	return 0;
 }
+DEVI int machine_step_fast(PfM &m, const PfC &c, int code) { return T(1) == 0 ? machine_first_fast(m, c, code) : machine_burst_fast(m, c, code); }
 
 /* ---- a whole burst at a time ------------------------------------------------------------------------------------------------------
  * Inside a burst the fast form above does very little: hits add to t1 and t4, every fourth idle pair adds 3 to t1 (t44 counts them), and
@@ -443,18 +435,20 @@ DEVI int burst_entry_ok(const PfM &m, const PfC &c)
 {
 	return (T(1) >= 1) & (T(1) < 15) & (T(4) >= 0) & (T(4) < 15) & (T(44) >= 0) & (T(44) <= 3) & !c.t6bad & (T(8) <= 6);
 }
-/* masks: of the pairs behind the present one (at least those that exist); avail: how many exist in this row; t4_end(j): t4 behind pair j.
- * Returns the number of pairs the burst took (counters moved), or 0 (counters untouched). */
+/* k: the masks of burst_lane's answers for the pairs from the present one on; avail: how many of them exist in this row;
+ * hits_at_end_plus_t4: t4 behind the last pair taken (the pair that ends the burst, or the row's last).
+ * Returns the number of pairs taken (counters moved), or 0 (counters untouched). */
 DEVI int burst_commit(PfM &m, const PfC &c, const PfBurstMasks &k, int avail, int hits_at_end_plus_t4)
 {
 	const unsigned long long endm = k.cap | k.wrap;
-	if (!endm) return 0;
-	const int e = __builtin_ctzll(endm);
-	if (e >= avail) return 0;                                           /* the burst runs past the row */
+	const int e_ = endm ? __builtin_ctzll(endm) : 64;
+	const int open = e_ >= avail;                                       /* the row ends first: its last pairs are taken, the burst goes on in the next row */
+	if (open && avail > 24) return 0;                                   /* (a burst is over within 21 pairs: not reached) */
+	const int e = open ? avail - 1 : e_;
 	const unsigned long long upto = burst_low_bits(e + 1);
-	const int cap_end = (int)((k.cap >> e) & 1);
+	const int cap_end = open ? 0 : (int)((k.cap >> e) & 1);
 	const unsigned long long idle = cap_end ? burst_low_bits(e) : upto; /* the pairs that take the idle step */
-	const int t4e = hits_at_end_plus_t4;
+	const int t4e = hits_at_end_plus_t4;                                /* t4 behind pair e */
 	const int v = T(44);
 	if (k.win & ~k.cyc & upto) return 0;
 	const int ncyc = burst_popc(k.cyc & upto), t18 = T(18);             /* pairs that rotate t18 (:1006-1037): 1 .. 15 -> 0, and at 0 the burst ends */
@@ -480,12 +474,19 @@ DEVI int burst_commit(PfM &m, const PfC &c, const PfBurstMasks &k, int avail, in
 		}
 	}
 	T(30) += counted;
+	T(18) = (t18 + ncyc) & 15;
+	T(17) = 0;
+	if (open) {                                                         /* e + 1 idle pairs: t1 as burst_lane's t1i of pair e */
+		T(1) += (t4e - T(4)) + 3 * ((v + e + 1) >> 2);
+		T(4) = t4e;
+		T(44) = (v + e + 1) & 3;
+		return e + 1;
+	}
 	if (cap_end) {
 		if (t4e == 0) T(8)++; else { T(8) = 0; T(5) = 0; T(12) = 0; }
 		T(44) = (v + e) & 3;
 	} else T(44) = 0;
-	T(18) = (t18 + ncyc) & 15;
-	T(29)++; T(1) = 0; T(4) = 0; T(17) = 0;
+	T(29)++; T(1) = 0; T(4) = 0;
 	return e + 1;
 }
 

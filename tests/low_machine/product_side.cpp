@@ -69,8 +69,9 @@ static int row_hop(PfM &m, PfC &c, const uint8_t *codes, uint8_t *acts, int row)
 				if (b.iS) k.iS |= bit; if (b.cnt) k.cnt |= bit; if (b.g13) k.g13 |= bit; if (b.e15) k.e15 |= bit; if (b.eT) k.eT |= bit;
 			}
 			const unsigned long long endm = k.cap | k.wrap;
-			const int e = endm ? __builtin_ctzll(endm) : 0;
-			const int ie = pos + e < 255 ? pos + e : 255;
+			int e = endm ? __builtin_ctzll(endm) : 64;
+			if (e >= 255 - pos) e = 255 - pos - 1;                          /* the row ends first */
+			const int ie = pos + e;
 			const int n = burst_commit(m, c, k, 255 - pos, m.t[4] + hits_prefix[ie] - base);
 			if (n > 0) { pos += n; bursted += n; continue; }
 			give_up = true;
