@@ -27,6 +27,7 @@
 
 #define DEVI __device__ static __forceinline__
 #define DEVN __device__ static
+#define DEVM __device__ __forceinline__
 #define PF_LOOK 16         /* pixels of look-back for a lane's entry state of the carry (the 16 states have merged within 16 for everything measured; a row where they have not is replayed serially) */
 
 namespace {
@@ -207,75 +208,132 @@ DEVI void pair_apply(const PfP &pp, int act, int &k0, int &k1, int &e0, int &e1,
 
 /* ------------------------------------------------------------------------------------------------ pass C: markers, weak partners (:1994-2310) */
 struct MarkState { int skip_toggle, second_toggle, pos0, neg0, pos1, neg1; };
-
-DEVI void resolve_marker(int16_t *cell, int v, int &pos_cnt, int &neg_cnt, int s2)
+struct CWalk { int v, idle, retry, fresh; };                        /* the cursor (second pixel of the pair) and the dance's counters (:1998-2000) */
+/* magnitude classes of the 64 map cells of a window, one bit a cell (bit i = column wb + i) */
+struct CMasks { uint64_t strong, weak, small, marker; };             /* |k| > sharp + 20; half < |k| <= sharp2; |k| <= sharp2; |k| > 6000 */
+DEVI void c_classify(const PfP &pp, int k, bool &strong, bool &weak, bool &small, bool &marker)
 {
-	if (v == 20000) { if (!pos_cnt) { STK(cell, (int16_t)0); pos_cnt = 1; } else { STK(cell, (int16_t)5000); pos_cnt = pos_cnt == 1 ? 2 : 0; } }
-	else if (v == -20000) { if (!neg_cnt) { STK(cell, (int16_t)0); neg_cnt = 1; } else { STK(cell, (int16_t)-5000); neg_cnt = neg_cnt == 1 ? 2 : 0; } }
-	else if (v == 7000) STK(cell, (int16_t)(s2 + 22));
+	const int a = iabs_(k);
+	strong = a > pp.sharp + 20; weak = a > pp.half && a <= pp.s2; small = a <= pp.s2; marker = a > 6000;
 }
-DEVI void bump(int16_t *yc, uint8_t *sc, int d) { STK(yc, (int16_t)(LDK(yc) + d)); STK(sc, (uint8_t)1); }
-/* strong pixel with a weak partner: nudge the strong one, the partner if it agrees in sign, and the two pixels above the pair */
-DEVI void sharpen_weak_partner(int strong, int weak, int16_t *ys, int16_t *yw, uint8_t *ss, uint8_t *sw,
-                               const int16_t *kup, int16_t *yup, uint8_t *sup, bool have_up, bool no_retry)
+/* what a marker becomes when the walk meets it: every third +-20000 of its kind 0, the others +-5000; 7000 -> sharp2 + 22 (:2008-2040) */
+DEVI int resolved_marker(int v, int &pos_cnt, int &neg_cnt, int s2)
 {
-	const int sg = strong > 0 ? 1 : -1;
-	bump(ys, ss, sg);
-	if ((sg > 0 && weak > 0) || (sg < 0 && weak < 0)) bump(yw, sw, 2 * sg);
-	if (have_up) {
-		const int a = LDK(kup) * sg, b = LDK(kup - 1) * sg;
-		int da = 0, db = 0;
-		if (a > 4) da += sg;
-		if (b > 4) db += sg;
-		if (a < -24 && no_retry) da -= sg;
-		if (b < -24 && no_retry) db -= sg;
-		if (da) bump(yup, sup, da);
-		if (db) bump(yup - 1, sup - 1, db);
-	}
+	if (v == 20000) { if (!pos_cnt) { pos_cnt = 1; return 0; } pos_cnt = pos_cnt == 1 ? 2 : 0; return 5000; }
+	if (v == -20000) { if (!neg_cnt) { neg_cnt = 1; return 0; } neg_cnt = neg_cnt == 1 ? 2 : 0; return -5000; }
+	if (v == 7000) return s2 + 22;
+	return v;
 }
-/* one row: km / y / so of the row, kmu / yu / sou of the row above; per lane like pass B */
-DEVI void marker_row(MarkState &s, const PfP &pp, int r, int16_t *km, int16_t *y, uint8_t *so, const int16_t *kmu, int16_t *yu, uint8_t *sou)
+/* Pass C of one row over the window of columns wb .. wb + 63, from the cursor in `st` while it is <= vmax (the caller picks vmax so that
+ * the cells a block looks at, up to v + 6, are inside the window; at the row's end W - 3).  The walk only asks which class a cell is in:
+ * it runs on the window's bit masks.  Its dance is periodic while nothing fires: from (idle, retry, fresh) = 0 at cursor v it looks at the
+ * pairs that start at v-1, v+1, v, v+3, v+5, v+4 (and at v+2 if one of the cells v+1, v+4 is small) and is back in that state at v + 8
+ * (:2279-2308) -- a block without a "strong next to weak" pair (or a marker) among those is skipped by one test.
+ * fx: the picture side.  fx.k(col) / fx.kup(col): map cells of the row / the row above; fx.own(col, d) / fx.up(col, d): add d to the
+ * row's / the upper row's pixel and raise its flag; fx.resolve(col, value): a marker cell takes its value.  MARKERS: rows with markers
+ * (their counters `ks` run across the rows of the picture: those rows go in order); without, `ks` is not touched. */
+template <bool MARKERS, class FX>
+DEVI void c_walk_window(CWalk &st, MarkState &ks, const PfP &pp, CMasks &mk, int wb, int vmax, bool have_up, FX &fx)
 {
-	const int sharp = pp.sharp, s2 = pp.s2, half = pp.half;
-	int idle = 0, retry = 0, idle_fresh = 0;
-	for (int c = 1; c < W - 3; c++) {
-		c++;
-		const int k0 = LDK(km + c - 1), k1 = LDK(km + c);
-		if (iabs_(k0) > 6000) {
-			resolve_marker(km + c - 1, k0, s.pos0, s.neg0, s2);
-			if (!s.second_toggle) { resolve_marker(km + c, k1, s.pos1, s.neg1, s2); s.second_toggle = 1; }
-			else s.second_toggle = 0;
-			if (!s.skip_toggle) { s.skip_toggle = 1; continue; }
-			s.skip_toggle = 0;
+	int v = st.v, idle = st.idle, retry = st.retry, fresh = st.fresh;
+	while (v <= vmax) {
+		const int b = v - wb;
+		/* bit i: the pair (wb + i, wb + i + 1) fires one way or the other (:2129, :2203), or holds a marker */
+		uint64_t event = (mk.strong & (mk.weak >> 1)) | ((mk.strong >> 1) & mk.weak);
+		if (MARKERS) event |= mk.marker | (mk.marker >> 1);
+		if (!(idle | retry | fresh) && v + 6 <= W - 3 && !((event >> (b - 1)) & 0x7F)) { v += 8; continue; }
+		const bool s0 = (mk.strong >> (b - 1)) & 1, s1 = (mk.strong >> b) & 1, w0 = (mk.weak >> (b - 1)) & 1, w1 = (mk.weak >> b) & 1;
+		int k0 = 0, k1 = 0;
+		bool have_k = false;
+		if (MARKERS && ((mk.marker >> (b - 1)) & 3)) {                 /* :2006-2127 */
+			const bool m0 = (mk.marker >> (b - 1)) & 1;
+			k0 = fx.k(v - 1); k1 = fx.k(v); have_k = true;
+			int n0 = k0, n1 = k1;
+			bool through = false;
+			if (m0) {
+				n0 = resolved_marker(k0, ks.pos0, ks.neg0, pp.s2);
+				if (!ks.second_toggle) { n1 = resolved_marker(k1, ks.pos1, ks.neg1, pp.s2); ks.second_toggle = 1; }
+				else ks.second_toggle = 0;
+				if (!ks.skip_toggle) ks.skip_toggle = 1; else { ks.skip_toggle = 0; through = true; }
+			}
+			else n1 = resolved_marker(k1, ks.pos1, ks.neg1, pp.s2);
+			for (int h = 0; h < 2; h++) {
+				const int nv = h ? n1 : n0, ov = h ? k1 : k0;
+				if (nv == ov) continue;
+				bool cs, cw, cl, cm;
+				c_classify(pp, nv, cs, cw, cl, cm);
+				const uint64_t bit = 1ull << (b - 1 + h);
+				mk.strong = cs ? mk.strong | bit : mk.strong & ~bit;
+				mk.weak = cw ? mk.weak | bit : mk.weak & ~bit;
+				mk.small = cl ? mk.small | bit : mk.small & ~bit;
+				mk.marker = cm ? mk.marker | bit : mk.marker & ~bit;
+				fx.resolve(v - 1 + h, nv);
+			}
+			if (!through) { v += 2; continue; }                        /* the pair's rules below see the values as they were (s0 .. w1, k0, k1) */
 		}
-		else if (iabs_(k1) > 6000) { resolve_marker(km + c, k1, s.pos1, s.neg1, s2); continue; }
-
-		const bool have_up = r > 2 || (r == 2 && c >= 2);
-		if (iabs_(k0) > sharp + 20 && iabs_(k1) > half && iabs_(k1) <= s2) {
-			sharpen_weak_partner(k0, k1, y + c - 1, y + c, so + c - 1, so + c, kmu + c, yu + c, sou + c, have_up, !retry);
-			idle = 0; idle_fresh = 0;
-			if (retry == 1) { c++; retry = 0; } else if (retry == 2) { c += 3; retry = 0; }
-		}
-		else if (iabs_(k1) > sharp + 20 && iabs_(k0) > half && iabs_(k0) <= s2) {
-			sharpen_weak_partner(k1, k0, y + c, y + c - 1, so + c, so + c - 1, kmu + c, yu + c, sou + c, have_up, !retry);
-			idle = 0; idle_fresh = 0;
-			if (retry == 1) { c++; retry = 0; } else if (retry == 2) { c += 3; retry = 0; }
-		}
-		else {                                       /* the cursor goes back and tries the other pairing */
+		int dv = 0;
+		const bool first = s0 && w1;
+		const bool second = !first && s1 && w0;
+		if (first || second) {                                         /* strong pixel with a weak partner (:2129-2278) */
+			if (!have_k) { k0 = fx.k(v - 1); k1 = fx.k(v); }
+			const int strong = first ? k0 : k1, weak = first ? k1 : k0;
+			const int cs = first ? v - 1 : v, cw = first ? v : v - 1;
+			const int sg = strong > 0 ? 1 : -1;
+			fx.own(cs, sg);
+			if ((sg > 0 && weak > 0) || (sg < 0 && weak < 0)) fx.own(cw, 2 * sg);
+			if (have_up) {
+				const int a = fx.kup(v) * sg, bb = fx.kup(v - 1) * sg;
+				int da = 0, db = 0;
+				if (a > 4) da += sg;
+				if (bb > 4) db += sg;
+				if (a < -24 && !retry) da -= sg;
+				if (bb < -24 && !retry) db -= sg;
+				if (da) fx.up(v, da);
+				if (db) fx.up(v - 1, db);
+			}
+			idle = 0; fresh = 0;
+			if (retry == 1) dv = 1; else if (retry == 2) dv = 3;
+			retry = 0;
+		} else {                                                       /* the cursor goes back and tries the other pairing (:2279-2308) */
 			idle++;
-			if (!retry) idle_fresh++;
-			if (idle == 2) { c -= 3; idle = 0; retry = 1; }
+			if (!retry) fresh++;
+			if (idle == 2) { dv = -3; idle = 0; retry = 1; }
 			else if (retry == 1) {
-				c++; retry = 0; idle = 0;
-				if (idle_fresh == 4) {
-					if (iabs_(LDK(km + c - 5)) <= s2 || iabs_(LDK(km + c - 2)) <= s2) { c -= 5; retry = 2; }
-					idle_fresh = 0;
+				dv = 1; retry = 0; idle = 0;
+				if (fresh == 4) {
+					if (((mk.small >> (b - 4)) | (mk.small >> (b - 1))) & 1) { dv = -4; retry = 2; }
+					fresh = 0;
 				}
 			}
-			else if (retry == 2) { c += 3; retry = 0; idle = 0; idle_fresh = 0; }
+			else if (retry == 2) { dv = 3; retry = 0; idle = 0; fresh = 0; }
 		}
+		v += 2 + dv;
 	}
+	st.v = v; st.idle = idle; st.retry = retry; st.fresh = fresh;
 }
+
+/* 64 cells of a 512-cell bit mask kept as bytes in cell order, from cell wb (a multiple of 32) on */
+DEVI uint64_t window64(const uint8_t *mask, int wb)
+{
+	const uint32_t lo = reinterpret_cast<const uint32_t *>(mask)[wb >> 5];
+	const uint32_t hi = wb + 32 < W ? reinterpret_cast<const uint32_t *>(mask)[(wb >> 5) + 1] : 0u;
+	return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+/* the picture side of pass C in k_low_machine (rows with markers, one lane): the rows in LDS, directly */
+struct MachFx {
+	int16_t *km; const int16_t *kmu; int16_t *y, *yu; uint8_t *so, *sou; uint8_t *cmask; PfP pp;
+	DEVM int k(int col) const { return km[col]; }
+	DEVM int kup(int col) const { return kmu[col]; }
+	DEVM void own(int col, int d) { y[col] = (int16_t)(y[col] + d); so[col] = 1; }
+	DEVM void up(int col, int d) { yu[col] = (int16_t)(yu[col] + d); sou[col] = 1; }
+	DEVM void resolve(int col, int v)
+	{
+		bool c[4];
+		km[col] = (int16_t)v;
+		c_classify(pp, v, c[0], c[1], c[2], c[3]);
+		for (int h = 0; h < 4; h++) { uint8_t &m = cmask[h * 64 + (col >> 3)]; m = c[h] ? (uint8_t)(m | (1u << (col & 7))) : (uint8_t)(m & ~(1u << (col & 7))); }
+	}
+};
 
 /* ------------------------------------------------------------------------------------------------ pass D (:2312-2420) */
 /* one pair of pass D: km is a row pointer indexed by column, p the pair's first column, f0 / f1 the pair's flags; d0 / d1: what the pair
@@ -355,7 +413,7 @@ DEVI int final_pair(const PfP &pp, const int16_t *km, int f0, int f1, int p, int
  *
  * History (front of q10 / q1, ms per 4096-image batch): round 2, two images per wavefront with the machines in lanes 0 and 1: 271 / 176;
  * codes + answers, row-parallel pass C, four images per wavefront, machine_step_fast per pair: 118 / 84; whole bursts: see DESIGN 4.7. */
-__global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_low_machine(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
                                                     int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q, int dbg)
 {
 	__shared__ __attribute__((aligned(16))) int16_t s_src[3][W];
@@ -366,6 +424,7 @@ __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ 
 	__shared__ __attribute__((aligned(8))) uint8_t s_cand[64];            /* per 8-pixel group: the pixels that need the serial visit of pass A */
 	__shared__ __attribute__((aligned(16))) uint8_t s_code[256], s_act[256];   /* per pair: threshold tests in, the machine's answer out */
 	__shared__ uint32_t s_rowmask[16];                                     /* rows whose pass C ran here */
+	__shared__ __attribute__((aligned(8))) uint8_t s_cmask[4][64];          /* a marker row's cells by class (c_classify), a bit a cell */
 	__shared__ int s_misc[4];
 	int16_t *s_hits = s_sum;
 	const int lane = threadIdx.x, img = blockIdx.x;
@@ -596,12 +655,30 @@ __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ 
 			  for (int e = 0; e < 4; e++) { lo |= (uint32_t)sv[e] << (8 * e); hi |= (uint32_t)sv[4 + e] << (8 * e); }
 			  *reinterpret_cast<uint2 *>(&so[c0]) = make_uint2(lo, hi); }
 			any_mark = __any(mark);
+			if (any_mark) {                                           /* the classes pass C asks for, a bit a cell, in cell order */
+				uint32_t cs = 0, cw = 0, cl = 0, cm = 0;
+				for (int e = 0; e < 8; e++) {
+					bool a, b2, c2, d2;
+					c_classify(pp, kc[e], a, b2, c2, d2);
+					cs |= (uint32_t)a << e; cw |= (uint32_t)b2 << e; cl |= (uint32_t)c2 << e; cm |= (uint32_t)d2 << e;
+				}
+				s_cmask[0][lane] = (uint8_t)cs; s_cmask[1][lane] = (uint8_t)cw; s_cmask[2][lane] = (uint8_t)cl; s_cmask[3][lane] = (uint8_t)cm;
+			}
 		}
 		__syncthreads();
-		/* pass C of this row where it holds a marker, in row order, on the scalar unit */
+		/* pass C of this row where it holds a marker, in row order: lane 0 walks it on windows of the row's class masks */
 		if (any_mark && !(dbg & 4)) {
-			marker_row(ks, pp, r, s_km[r & 1], s_y[r & 1], s_so[r & 1], s_km[(r - 1) & 1], s_y[(r - 1) & 1], s_so[(r - 1) & 1]);
-			if (lane == 0) s_rowmask[r >> 5] |= 1u << (r & 31);
+			if (lane == 0) {
+				MachFx fx = { s_km[r & 1], s_km[(r - 1) & 1], s_y[r & 1], s_y[(r - 1) & 1], s_so[r & 1], s_so[(r - 1) & 1], &s_cmask[0][0], pp };
+				CWalk cw = { 2, 0, 0, 0 };
+				while (cw.v <= W - 3) {
+					const int wb = cw.v < 40 ? 0 : ((cw.v - 8) & ~31);
+					CMasks cm;
+					cm.strong = window64(s_cmask[0], wb); cm.weak = window64(s_cmask[1], wb); cm.small = window64(s_cmask[2], wb); cm.marker = window64(s_cmask[3], wb);
+					c_walk_window<true>(cw, ks, pp, cm, wb, wb + 57 < W - 3 ? wb + 57 : W - 3, r >= 2, fx);
+				}
+				s_rowmask[r >> 5] |= 1u << (r & 31);
+			}
 			__syncthreads();
 		}
 		if (r > 1) {                                              /* row r-1 is through passes A..C as far as they run here */
@@ -622,31 +699,51 @@ __global__ __launch_bounds__(64) void k_low_machine(const int16_t *__restrict__ 
 }
 
 /* Passes C and D for the rows pass C can take independently of each other -- every row without a marker (k_low_machine lists the others
- * and has walked their pass C itself) -- a lane per row, 255 rows (+ the one below them) to a workgroup, through LDS tiles of 32 columns.
+ * and has walked their pass C itself) -- a lane per row, 191 rows (+ the one below them) to a workgroup, in windows of 64 columns.
  *
- * Pass C (:1994-2310) without markers keeps nothing from row to row: its cursor dance (pairs at even phase, back by one to try the odd
- * phase, :2279-2308) starts afresh in every row; it reads the contrast map of its row and of the row above and ADDS to the picture in
- * both (and sets their flags to 1): additions commute, so rows need no order.  A lane records what it adds to its own row and to the row
- * above in two planes of its own (low byte: sum, bit 8: flag); nothing else is written during the walk, so lanes never meet.  Pass D
- * (:2312-2420) of a row reads the row's map and flags as passes B and C leave them -- final a few columns behind the cursor of pass C
- * of this row and of the row below -- and adds to the picture too: it follows pass C at a distance inside the same tile loop.  Then the
- * tile's sums go to the picture (and its flags to the flag plane) where there are any: the picture is not read at all elsewhere.
- * Per image: the map once (+ 8 of 40 columns twice), the flag plane once, some hundred read-modify-writes.
- * (Round 2 ran pass C on the chain lane of the pre-filter kernel, 30 % of its 271 ms, and pass D as a kernel over the three planes: 21 GB.) */
-#define MK_C 32                                                        /* columns a tile advances */
-#define MK_L 8                                                         /* columns kept to the left: the cursor of pass C goes back by 3, looks 4 further back and bumps one more */
-#define MK_W (MK_C + MK_L)
-#define MK_P 42                                                        /* pitch in cells (21 dwords: a lane per row walks all banks) */
-#define MK_SP 44                                                       /* pitch of the flag tile in bytes */
-__global__ __launch_bounds__(256) void k_low_marks(int16_t *__restrict__ yb, size_t y_stride, const int16_t *__restrict__ kmb, size_t km_stride,
-                                                   uint8_t *__restrict__ sob, size_t so_stride, int q, int dbg)
+ * Pass C (:1994-2310) without markers keeps nothing from row to row: its cursor dance starts afresh in every row; it reads the contrast
+ * map of its row and of the row above and ADDS to the picture in both (and sets their flags to 1): additions commute, so rows need no
+ * order.  Both walks only ask which of a few magnitude classes a map cell is in, so a lane turns the 64 cells of its row's window into bit
+ * masks once and then walks on registers:
+ *   * pass C's dance is periodic while nothing fires: from (idle, retry, fresh) = 0 at cursor v it looks at the pairs starting at
+ *     v-1, v+1, v, v+3, v+5, v+4 (and v+2 if one of the cells v+1, v+4 is small) and is back in the same state at v+8 (:2279-2308).  A block
+ *     without a "strong next to weak" pair among those is skipped with one mask test; only blocks with one are walked visit by visit;
+ *   * pass D (:2312-2420) slides by one wherever none of its five pair rules applies: the cursor jumps to the next pair where one does.
+ * What the walks add goes to byte planes of the lane's own (own row / the row above), the flags they raise to bit masks; nothing else is
+ * written during the walks, so lanes never meet.  Pass D of a row needs the row's flags as pass C of this row and of the row below leave
+ * them -- final a few columns behind both cursors -- so it follows inside the same window loop.  Then the window's sums go to the picture
+ * (and its flags to the flag plane) where there are any: the picture is not read at all elsewhere.
+ * (Round 2 ran pass C on the chain lane of the pre-filter kernel, 30 % of its 271 ms, and pass D as a kernel over the three planes: 21 GB;
+ * the first row-parallel form -- LDS loads and compares at every visit -- took 15.5 ms per batch at quality 10.) */
+#define MK_R 192                                                       /* lanes: 191 rows + the row below them */
+#define MK_A 48                                                        /* columns a window advances */
+#define MK_P 66                                                        /* pitch of the map tile in cells (33 dwords: a lane per row walks all banks) */
+#define MK_BP 68                                                       /* pitch of the byte planes */
+namespace {
+struct MkMasks { uint64_t strong, weak, small, ja, g56, g160, jas, big; };
+DEVI uint64_t bits_from(uint64_t m, int b) { return b >= 64 ? 0 : b <= 0 ? m : (m >> b); }   /* m >> b with the window's edges */
+/* the picture side of pass C in k_low_marks: the lane's byte planes and bit masks */
+struct MkFx {
+	const int16_t *kr, *ku;
+	int8_t *ow, *uw;
+	int wb;
+	uint64_t own_flag, own_dirty, up_flag, up_dirty;
+	DEVM int k(int col) const { return kr[col]; }
+	DEVM int kup(int col) const { return ku[col]; }
+	DEVM void own(int col, int d) { ow[col] = (int8_t)(ow[col] + d); own_flag |= 1ull << (col - wb); own_dirty |= 1ull << (col - wb); }
+	DEVM void up(int col, int d) { uw[col] = (int8_t)(uw[col] + d); up_flag |= 1ull << (col - wb); up_dirty |= 1ull << (col - wb); }
+	DEVM void resolve(int, int) {}
+};
+}
+__global__ __launch_bounds__(MK_R) void k_low_marks(int16_t *__restrict__ yb, size_t y_stride, const int16_t *__restrict__ kmb, size_t km_stride,
+                                                    uint8_t *__restrict__ sob, size_t so_stride, int q, int dbg)
 {
-	__shared__ __attribute__((aligned(16))) int16_t kt[257 * MK_P];        /* map; tile row 0 = the row above the workgroup's first */
-	__shared__ __attribute__((aligned(16))) uint16_t own[256 * MK_P], upd[256 * MK_P];
-	__shared__ __attribute__((aligned(16))) uint8_t st[256 * MK_SP];
+	__shared__ __attribute__((aligned(16))) int16_t kt[(MK_R + 1) * MK_P];  /* map; tile row 0 = the row above the workgroup's first */
+	__shared__ __attribute__((aligned(16))) int8_t own[MK_R * MK_BP], upd[MK_R * MK_BP];   /* what a lane adds to its row / to the row above */
+	__shared__ uint64_t s_upflag[MK_R + 1], s_updirty[MK_R + 1];          /* of the lane's additions to the row above: flags raised, cells touched */
 	__shared__ uint32_t s_mask[16];
 	const int tid = threadIdx.x, img = blockIdx.y;
-	const int R0 = 1 + 255 * blockIdx.x;                               /* rows R0 .. R0 + 254 are this workgroup's; lane 255 walks pass C of the row below them for what it adds to the last one */
+	const int R0 = 1 + (MK_R - 1) * blockIdx.x;                        /* rows R0 .. R0 + 190 are this workgroup's; the last lane walks pass C of the row below them for what it adds to the last one */
 	const int r = R0 + tid;
 	const PfP pp = pf_params(q);
 	const int sharp = pp.sharp, s2 = pp.s2, half = pp.half;
@@ -654,111 +751,106 @@ __global__ __launch_bounds__(256) void k_low_marks(int16_t *__restrict__ yb, siz
 	int16_t *y = yb + (size_t)img * y_stride;
 	uint8_t *so = sob + (size_t)img * so_stride;
 	if (tid < 16) s_mask[tid] = reinterpret_cast<const uint32_t *>(so)[tid];
+	for (int k = tid; k < MK_R * MK_BP / 4; k += MK_R) { reinterpret_cast<uint32_t *>(own)[k] = 0; reinterpret_cast<uint32_t *>(upd)[k] = 0; }
+	if (tid == 0) { s_upflag[MK_R] = 0; s_updirty[MK_R] = 0; }
 	__syncthreads();
 	const bool in_pic = r <= W - 2;
 	const bool walk_c = in_pic && !((s_mask[(r >> 5) & 15] >> (r & 31)) & 1) && !(dbg & 4);
-	const bool own_row = tid < 255 && in_pic;
+	const bool own_row = tid < MK_R - 1 && in_pic;
 	const bool have_up = r >= 2;
-	int v = 2, idle = 0, retry = 0, fresh = 0;                         /* pass C: cursor (second pixel of the pair), :1998-2000 */
+	CWalk cw = { 2, 0, 0, 0 };                                         /* pass C */
+	MarkState no_marks = { 0, 0, 0, 0, 0, 0 };
 	int p = 1;                                                         /* pass D: first pixel of the pair */
 
-	for (int t0 = 0; t0 < W; t0 += MK_C) {
-		const int cb = t0 - MK_L;                                      /* first column of the tile (negative in the first tile: those cells are never touched) */
-		for (int k = tid; k < 257 * (MK_W / 2); k += 256) {
-			const int rr = k / (MK_W / 2), d = k % (MK_W / 2), row = R0 - 1 + rr, col = cb + 2 * d;
+	for (int wb = 0; wb < W - 16; wb += MK_A) {                        /* windows of columns wb .. wb + 63: 0, 48, .., 480 */
+		const bool last = wb + MK_A >= W - 16;
+		for (int k = tid; k < (MK_R + 1) * 32; k += MK_R) {
+			const int rr = k >> 5, d = k & 31, row = R0 - 1 + rr, col = wb + 2 * d;
 			uint32_t w = 0;
-			if (col >= 0 && row >= 1 && row <= W - 2) w = *reinterpret_cast<const uint32_t *>(km + (size_t)row * W + col);
+			if (col < W && row >= 1 && row <= W - 2) w = *reinterpret_cast<const uint32_t *>(km + (size_t)row * W + col);
 			reinterpret_cast<uint32_t *>(kt + rr * MK_P)[d] = w;
 		}
-		for (int k = tid; k < 256 * (MK_W / 2); k += 256) {
-			const int rr = k / (MK_W / 2), d = k % (MK_W / 2);
-			reinterpret_cast<uint32_t *>(own + rr * MK_P)[d] = 0;
-			reinterpret_cast<uint32_t *>(upd + rr * MK_P)[d] = 0;
-		}
-		for (int k = tid; k < 255 * (MK_W / 4); k += 256) {
-			const int rr = k / (MK_W / 4), d = k % (MK_W / 4), row = R0 + rr, col = cb + 4 * d;
-			uint32_t w = 0;
-			if (col >= 0 && row <= W - 2) w = *reinterpret_cast<const uint32_t *>(so + (size_t)row * W + col);
-			reinterpret_cast<uint32_t *>(st + rr * MK_SP)[d] = w;
-		}
-		__syncthreads();
-		const int16_t *kr = kt + (tid + 1) * MK_P - cb, *ku = kt + tid * MK_P - cb;     /* indexed by column */
-		uint16_t *ow = own + tid * MK_P - cb, *uw = upd + tid * MK_P - cb;
-#define MK_ADD(cell, d) do { const uint32_t x_ = (cell); (cell) = (uint16_t)(((x_ + (uint32_t)(d)) & 0xFFu) | 0x100u); } while (0)
-#define MK_ADD_QUIET(cell, d) do { const uint32_t x_ = (cell); (cell) = (uint16_t)(((x_ + (uint32_t)(d)) & 0xFFu) | (x_ & 0x100u)); } while (0)
-		if (walk_c) {
-			const int te = t0 + MK_C < W - 2 ? t0 + MK_C : W - 2;      /* the cursor takes the values 2 .. W - 3 */
-			while (v < te) {
-				const int k0 = kr[v - 1], k1 = kr[v];
-				int dv = 0;
-				const bool first = iabs_(k0) > sharp + 20 && iabs_(k1) > half && iabs_(k1) <= s2;
-				const bool second = !first && iabs_(k1) > sharp + 20 && iabs_(k0) > half && iabs_(k0) <= s2;
-				if (first || second) {                                 /* strong pixel with a weak partner (:2129-2278) */
-					const int strong = first ? k0 : k1, weak = first ? k1 : k0;
-					const int cs = first ? v - 1 : v, cw = first ? v : v - 1;
-					const int sg = strong > 0 ? 1 : -1;
-					MK_ADD(ow[cs], sg);
-					if ((sg > 0 && weak > 0) || (sg < 0 && weak < 0)) MK_ADD(ow[cw], 2 * sg);
-					if (have_up) {
-						const int a = ku[v] * sg, b = ku[v - 1] * sg;
-						int da = 0, db = 0;
-						if (a > 4) da += sg;
-						if (b > 4) db += sg;
-						if (a < -24 && !retry) da -= sg;
-						if (b < -24 && !retry) db -= sg;
-						if (da) MK_ADD(uw[v], da);
-						if (db) MK_ADD(uw[v - 1], db);
-					}
-					idle = 0; fresh = 0;
-					if (retry == 1) dv = 1; else if (retry == 2) dv = 3;
-					retry = 0;
-				} else {                                               /* the cursor goes back and tries the other pairing (:2279-2308) */
-					idle++;
-					if (!retry) fresh++;
-					if (idle == 2) { dv = -3; idle = 0; retry = 1; }
-					else if (retry == 1) {
-						dv = 1; retry = 0; idle = 0;
-						if (fresh == 4) {
-							if (iabs_(kr[v + 1 - 5]) <= s2 || iabs_(kr[v + 1 - 2]) <= s2) { dv = -4; retry = 2; }
-							fresh = 0;
-						}
-					}
-					else if (retry == 2) { dv = 3; retry = 0; idle = 0; fresh = 0; }
-				}
-				v += 2 + dv;
+		/* the flags of my row as passes B and C have left them so far (2 bits a cell: two masks) */
+		uint64_t f_lo = 0, f_hi = 0;
+		if (own_row)
+			for (int d = 0; d < 16; d++) {
+				const int col = wb + 4 * d;
+				const uint32_t w = col < W ? *reinterpret_cast<const uint32_t *>(so + (size_t)r * W + col) : 0u;
+				for (int e = 0; e < 4; e++) { f_lo |= (uint64_t)((w >> (8 * e)) & 1) << (4 * d + e); f_hi |= (uint64_t)((w >> (8 * e + 1)) & 1) << (4 * d + e); }
 			}
-		}
 		__syncthreads();
-		if (own_row && !(dbg & 8)) {                                   /* pass D behind pass C: cells up to t0 + 27 have their final flags */
-			const int pe = t0 + MK_C >= W ? W - 2 : t0 + MK_C - 5;     /* pairs p < pe */
-			const uint16_t *un = upd + (tid + 1) * MK_P - cb;          /* what the row below adds to this one */
-			const uint8_t *sr = st + tid * MK_SP - cb;
+		const int16_t *kr = kt + (tid + 1) * MK_P - wb, *ku = kt + tid * MK_P - wb;     /* indexed by column */
+		int8_t *ow = own + tid * MK_BP - wb, *uw = upd + tid * MK_BP - wb;
+		MkMasks mk = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		if (in_pic)
+			for (int d = 0; d < 32; d++) {
+				const uint32_t w = reinterpret_cast<const uint32_t *>(kt + (tid + 1) * MK_P)[d];
+				for (int h = 0; h < 2; h++) {
+					const int a = iabs_((int)(int16_t)(h ? w >> 16 : w & 0xFFFF));
+					const uint64_t bit = 1ull << (2 * d + h);
+					if (a > sharp + 20) mk.strong |= bit;
+					if (a > half && a <= s2) mk.weak |= bit;
+					if (a <= s2) mk.small |= bit;
+					if (a > sharp && a <= sharp + 20) mk.ja |= bit;
+					if (a > sharp + 56) mk.g56 |= bit;
+					if (a > sharp + 160) mk.g160 |= bit;
+					if (a > s2 && a <= s2 + 20) mk.jas |= bit;
+					if (a > 4000) mk.big |= bit;
+				}
+			}
+		MkFx fx = { kr, ku, ow, uw, wb, 0, 0, 0, 0 };
+		if (walk_c) {
+			CMasks cm = { mk.strong, mk.weak, mk.small, 0 };
+			c_walk_window<false>(cw, no_marks, pp, cm, wb, last ? W - 3 : wb + 57, have_up, fx);   /* a block that starts at v looks at cells up to v + 6 */
+		}
+		uint64_t own_dirty = fx.own_dirty;
+		const uint64_t own_flag = fx.own_flag, up_flag = fx.up_flag, up_dirty = fx.up_dirty;
+		s_upflag[tid] = up_flag; s_updirty[tid] = up_dirty;
+		__syncthreads();
+		const uint64_t below_flag = s_upflag[tid + 1], below_dirty = s_updirty[tid + 1];   /* what the row below adds to mine */
+		if (own_row && !(dbg & 8)) {                                   /* pass D behind pass C: cells up to wb + 53 have their final flags */
+			const int pe = last ? W - 2 : wb + 53;                     /* pairs p < pe */
+			const uint64_t raised = own_flag | below_flag;
+			const uint64_t is1 = (f_lo & ~f_hi) | raised, is2 = f_hi & ~f_lo & ~raised, is3 = f_hi & f_lo & ~raised;
+			/* bit i: one of the rules of :2322-2414 applies to the pair (wb + i, wb + i + 1); everywhere else the walk slides by one */
+			const uint64_t rule = mk.big | (mk.big >> 1) | (mk.ja & (mk.ja >> 1)) | (mk.g56 & (mk.g56 >> 1)) | (mk.g160 & (mk.jas >> 1)) | ((mk.g160 >> 1) & mk.jas);
+			const int16_t *krr = kr;
 			while (p < pe) {
-				const int f0 = ((ow[p] | un[p]) & 0x100) ? 1 : sr[p], f1 = ((ow[p + 1] | un[p + 1]) & 0x100) ? 1 : sr[p + 1];
+				const uint64_t ahead = bits_from(rule, p - wb);
+				if (!ahead) { p = pe; break; }
+				p += __builtin_ctzll(ahead);
+				if (p >= pe) break;
+				const int b = p - wb;
+				const int f0 = ((is1 >> b) & 1) ? 1 : ((is2 >> b) & 1) ? 2 : ((is3 >> b) & 1) ? 3 : 0;
+				const int f1 = ((is1 >> (b + 1)) & 1) ? 1 : ((is2 >> (b + 1)) & 1) ? 2 : ((is3 >> (b + 1)) & 1) ? 3 : 0;
 				const int p0 = p;
 				int d0 = 0, d1 = 0;
-				p = final_pair(pp, kr, f0, f1, p0, d0, d1);
-				if (d0) MK_ADD_QUIET(ow[p0], d0);                      /* pass D does not raise flags */
-				if (d1) MK_ADD_QUIET(ow[p0 + 1], d1);
+				p = final_pair(pp, krr, f0, f1, p0, d0, d1);
+				if (d0) { ow[p0] = (int8_t)(ow[p0] + d0); own_dirty |= 1ull << b; }            /* pass D does not raise flags */
+				if (d1) { ow[p0 + 1] = (int8_t)(ow[p0 + 1] + d1); own_dirty |= 1ull << (b + 1); }
 			}
+			if (p > pe && !last) { /* a pair that started below pe may end at pe + 1: fine, the cursor is what is carried */ }
 		}
 		__syncthreads();
-		for (int k = tid; k < 255 * (MK_W / 2); k += 256) {            /* the tile's sums and flags go out where there are any */
-			const int rr = k / (MK_W / 2), d = k % (MK_W / 2), row = R0 + rr, col = cb + 2 * d;
-			const uint32_t o2 = reinterpret_cast<const uint32_t *>(own + rr * MK_P)[d] | 0u, u2 = reinterpret_cast<const uint32_t *>(upd + (rr + 1) * MK_P)[d];
-			if (!(o2 | u2) || col < 0 || row > W - 2) continue;
-			for (int h = 0; h < 2; h++) {
-				const uint32_t o = (o2 >> (16 * h)) & 0xFFFF, u = (u2 >> (16 * h)) & 0xFFFF;
-				if (!(o | u)) continue;
-				const int add = (int)(int8_t)(o & 0xFF) + (int)(int8_t)(u & 0xFF);
-				const size_t at = (size_t)row * W + col + h;
+		if (own_row) {                                                 /* the window's sums and flags go out where there are any */
+			uint64_t dirty = own_dirty | below_dirty;
+			const uint64_t raised = own_flag | below_flag;
+			const int8_t *un = upd + (tid + 1) * MK_BP - wb;
+			while (dirty) {
+				const int b = __builtin_ctzll(dirty);
+				dirty &= dirty - 1;
+				const int col = wb + b;
+				const int add = (int)ow[col] + ((below_dirty >> b) & 1 ? (int)un[col] : 0);
+				const size_t at = (size_t)r * W + col;
 				if (add) y[at] = (int16_t)(y[at] + add);
-				if ((o | u) & 0x100) so[at] = 1;
+				ow[col] = 0;
 			}
+			uint64_t rs = raised;
+			while (rs) { const int b = __builtin_ctzll(rs); rs &= rs - 1; so[(size_t)r * W + wb + b] = 1; }
 		}
 		__syncthreads();
-#undef MK_ADD
-#undef MK_ADD_QUIET
+		{ uint64_t ud = up_dirty; while (ud) { const int b = __builtin_ctzll(ud); ud &= ud - 1; uw[wb + b] = 0; } }   /* my additions to the row above have been taken */
+		__syncthreads();
 	}
 }
 
@@ -1044,7 +1136,7 @@ void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y,
 	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
 	k_low_machine<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, dbg);
-	k_low_marks<<<dim3(2, n), 256, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
+	k_low_marks<<<dim3((W - 2 + MK_R - 2) / (MK_R - 1), n), MK_R, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
 }
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s)
 {
