@@ -242,6 +242,47 @@ def cpu_baseline(q, budget_s=12.0):
     return out
 
 
+def cpu_baseline_light(q, budget_s=4.0):
+    """The sweep legs' own baseline: the same reference encoder at that quality, same method as cpu_baseline(), a smaller sample."""
+    import multiprocessing as mp
+    kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libnhwref_enc.so")) else "port"
+    logical = os.cpu_count() or 1
+    phys = physical_cores()
+    cores = max(1, min(phys or logical, 64))
+    per = min(max(4, int(budget_s / 0.03)), 160)
+    jobs = [(kind, list(range(w * per, (w + 1) * per)), q) for w in range(cores)]
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    n = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    one = _cpu_worker((kind, list(range(24)), q))
+    return {"value": round(n * MPIX_PER_IMAGE / busy, 2), "unit": "Mpixels/s", "cores": cores, "kind": kind,
+            "one_core": {"value": round(one[0] * MPIX_PER_IMAGE / one[1], 2), "unit": "Mpixels/s", "ms_per_image": round(one[1] / one[0] * 1e3, 2)},
+            "sample": f"{n} synthetic images (seeds 0..{n - 1}), -q{q}, one in-process encoder per physical core, {busy:.1f} s encode time"}
+
+
+def chroma_l1_ms(enc, n, repeats=3):
+    """SURVEY 8(d) counts the chroma level-1 coefficients among the fused front kernel's 6 B/pixel, but that analysis runs as two launches of
+    the 256 x 256 filterbank kernel on the chroma stream.  Their time for a batch of n images, measured here on its own
+    (hipEvents round the two launches, on the stage entry point's stream), so that the line can carry a roofline figure that includes it."""
+    import torch
+    planes = torch.randint(0, 256, (2, n, 65536), dtype=torch.int16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    best = None
+    for _ in range(repeats + 1):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _comp in range(2):      # U, then V: wavelet_analysis(256, 0, 0) each (nhw_encoder.c:2265, 2576)
+            if enc.lib.nhw_stage_analysis(enc.h, planes[0].data_ptr(), planes[1].data_ptr(), n, 65536, 256, 256, 0, st) != 0:
+                return None
+        b.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b)
+        best = t if best is None else min(best, t)
+    del planes
+    return best
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` with N > 1 and no launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`"""
     import socket
@@ -266,18 +307,21 @@ def timed_steps(enc, bgr, q, out, steps, warmup, dist, dev, max_over_ranks):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    front_ms = color_ms = 0.0
+    front_ms = color_ms = pre_ms = 0.0
     tim = None
     for _ in range(steps):
         enc.encode_device(bgr, q, out)
         tim = enc.timing()          # hipEvents recorded on the launch stream; waits for this step's last event
         front_ms += tim.front_ms
         color_ms += tim.color_dwt_ms
+        pre_ms += tim.prefilter_ms
     torch.cuda.synchronize()
+    local = time.perf_counter() - t0            # this rank's own K steps (reported per rank; the metric uses the max below)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = max_over_ranks(dist, dev, time.perf_counter() - t0)
+    timed_steps.last = {"local_s": local, "color_ms": color_ms, "prefilter_ms": pre_ms}
     return dt, front_ms, color_ms, tim
 
 
@@ -354,6 +398,8 @@ def main():
     nbytes = int(sizes.to(torch.int64).sum().item())
     chk = int((sizes.to(torch.int64) * torch.arange(1, batch + 1, device=dev)).sum().item() % (1 << 61))
     gathered = gather_summaries(dist, dev, nbytes, chk, ok)
+    head_local = timed_steps.last["local_s"]
+    rank_ms = [g[0] / 1e3 for g in gather_summaries(dist, dev, int(head_local / args.steps * 1e6), rank, 0)]      # every rank's own ms per step
     total_per_step = sum(shard_range(0, count, r, world)[1] - shard_range(0, count, r, world)[0] for r in range(world)) if strong else batch * world
 
     # BASELINE config 2/3: the other quality settings, each under the same timed contract (barrier + synchronize on both sides), on the
@@ -363,10 +409,14 @@ def main():
         for sq in [int(v) for v in args.sweep.split(",") if v.strip()]:
             if sq == q:
                 continue
-            k = args.steps if sq > 16 else max(2, args.steps // 5)
-            sdt, _, _, stim = timed_steps(enc, bgr, sq, out, k, 1, None, dev, max_over_ranks)
+            k = args.steps if sq > 16 else max(3, args.steps // 2)
+            sdt, sfront, _, stim = timed_steps(enc, bgr, sq, out, k, 1, None, dev, max_over_ranks)
             sok = int((out[2] == 0).sum().item())
+            split = timed_steps.last
             sweep.append({"quality": sq, "steps": k, "warmup": 1, "ms_per_step": round(sdt / k * 1e3, 3), "value": round(batch * k * MPIX_PER_IMAGE / sdt, 2), "unit": "Mpixels/s",
+                          **({"front_kernels_ms": {"colour + 4:2:0 (k_color)": round(split["color_ms"] / k, 3), "rationed pre-filter (k_low_machine + k_low_marks)": round(split["prefilter_ms"] / k, 3),
+                                                   "level-1 analysis (k_front_band)": round((sfront - split["color_ms"] - split["prefilter_ms"]) / k, 3)}} if sq <= 16 else {}),
+                          **({"cpu_baseline": cpu_baseline_light(sq)} if not args.no_cpu_baseline else {}),
                           "images_ok": sok, "bytes_out": int(out[1].to(torch.int64).sum().item()),
                           "stage_ms": {"front": round(stim.front_ms, 3), "luma_tail": round(stim.luma_ms, 3), "entropy+container": round(stim.entropy_ms, 3)},
                           # the same roofline figure as the headline's, for this quality's front launch group (q >= 22: no pre-filter in the fused kernel;
@@ -445,6 +495,7 @@ def main():
         front_images = tim.front_images or batch      # the batch runs as `parts` sub-batches on their own streams; the events bracket the first one's launch group
         achieved = front_images * FRONT_BYTES_PER_IMAGE / front_s / 1e9
         traffic, traffic_note = front_traffic(q, front_images)
+        cl1 = chroma_l1_ms(enc, front_images) if q >= 17 else None
         line = {
             "metric": "encode Mpixels/s (512x512 RGB batch)", "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -458,10 +509,14 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes per launch group; " + traffic_note,
                          "algorithmic_bytes_per_launch": front_images * FRONT_BYTES_PER_IMAGE, "images_per_launch": front_images,
                          # SURVEY 8(d) also states its >= 0.50 target on the READ side alone (n x 786 432 B of BGR / t): half of `frac`
-                         "frac_on_reads_only": round(front_images * 786432 / front_s / 1e9 / HBM_PEAK_GBS, 4), "sub_batches": tim.parts, "algorithmic_bytes_per_image": FRONT_BYTES_PER_IMAGE, "ms_per_launch_group": round(front_s * 1e3, 3)},
+                         "frac_on_reads_only": round(front_images * 786432 / front_s / 1e9 / HBM_PEAK_GBS, 4),
+                         # the same bytes over the front group PLUS the two chroma level-1 launches whose output the 6 B/pixel include (measured apart, see chroma_l1_ms)
+                         **({"frac_incl_chroma_l1": round(front_images * FRONT_BYTES_PER_IMAGE / ((front_s + cl1 / 1e3)) / 1e9 / HBM_PEAK_GBS, 4), "chroma_l1_ms": round(cl1, 3)} if cl1 else {}), "sub_batches": tim.parts, "algorithmic_bytes_per_image": FRONT_BYTES_PER_IMAGE, "ms_per_launch_group": round(front_s * 1e3, 3)},
             "stage_ms": {"front": round(tim.front_ms, 3), "luma_tail (chroma sequence alongside, on its own stream)": round(tim.luma_ms, 3), "chroma left over": round(tim.chroma_ms, 3),
                          "entropy+container": round(tim.entropy_ms, 3), "total": round(tim.total_ms, 3)},
             "images_ok": [int(g[2]) for g in gathered], "bytes_out": [int(g[0]) for g in gathered],
+            "ms_per_step_per_rank": [round(v, 3) for v in rank_ms],      # each rank's own clock over its K steps; ms_per_step is the max-over-ranks figure with the barriers
+            "world_size_from_collective": len(gathered),                # what the all-gather (RCCL for N > 1) saw, next to n_gpus from the launcher
         }
         if sweep:
             line["sweep"] = sweep

@@ -8,7 +8,7 @@
  *
  *   reference                                            this library
  *   ---------------------------------------------------  ------------------------------------------
- *   im.setup->quality_setting (nhw_encoder_cli.c:175)     `quality` argument (17..23 in this revision)
+ *   im.setup->quality_setting (nhw_encoder_cli.c:175)     `quality` argument (1..23: every setting the reference has tables for)
  *   read_image_bmp  -> im_buffer4 (nhw_encoder.c:3047)    caller passes n x 786432 BGR24 bytes in BMP
  *                                                         file order (what fread at :3086 delivers)
  *   downsample_YUV420 + encode_image (codec.h:184,189)    nhw_enc_batch / nhw_enc_batch_device
@@ -48,12 +48,13 @@ typedef struct nhw_enc nhw_enc;
 typedef struct {
 	float total_ms;
 	float front_ms;       /* colour + pre-filter + level-1 analysis (the HBM-roofline kernels) */
-	float color_dwt_ms;   /* the colour + 4:2:0 kernel alone, the first kernel of the front group */
+	float color_dwt_ms;   /* quality 1..16: the colour + 4:2:0 kernel, the first of the front group; 0 for 17..23 (the conversion is inside the fused front kernel) */
 	float luma_ms;        /* luma tail; the chroma sequence runs next to it on a stream of its own (NHW_CHROMA_FORK=0: behind it) */
 	float chroma_ms;      /* what is left of the chroma sequence once the luma tail is done (about 0 when it is hidden; its full time with NHW_CHROMA_FORK=0) */
 	float entropy_ms;
 	int parts;            /* sub-batches the stages behind the front ran as (each on a stream of its own); with more than one, luma/chroma/entropy_ms are those of the first */
 	int front_images;     /* images covered by front_ms */
+	float prefilter_ms;   /* quality 1..16: the rationed luma pre-filter (k_low_machine + k_low_marks), second of the front group; 0 for 17..23 */
 } nhw_timing;
 
 /* lifecycle: replaces `im.setup=malloc(..)` + per-image mallocs of encode_image (nhw_encoder.c:108-...) */
@@ -96,7 +97,8 @@ int nhw_enc_last_timing(nhw_enc *e, nhw_timing *t);
 /* ---- stage-level entry points (kernel parity tests; same stream rules) ----
  * colour + 4:2:0 (colorspace.c:55-260), any quality 1..23: d_y n*262144 int16, d_u/d_v n*65536 uint8 */
 int nhw_stage_color(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_y, void *d_u, void *d_v, void *stream);
-/* luma pre-filter (image_processing.c:558-2426, q17..21), in place on d_y */
+/* luma pre-filter (image_processing.c:558-2426) as a stage of its own: quality 1..16 (k_low_machine + k_low_marks, the kernels the encoder runs);
+ * for 17..21 it is a step inside the fused front kernel (NHW_E_QUALITY here).  In place on d_y */
 int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, void *stream);
 /* one analysis level (wavelet_filterbank.c:52-302) on planes of `stride` shorts per row, n_img images
  * spaced plane_stride shorts apart; size = transform size; final_level as in the oracle */

@@ -18,7 +18,7 @@ P = ctypes.c_void_p
 
 
 class Timing(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "front_ms", "color_dwt_ms", "luma_ms", "chroma_ms", "entropy_ms")] + [("parts", ctypes.c_int), ("front_images", ctypes.c_int)]
+    _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "front_ms", "color_dwt_ms", "luma_ms", "chroma_ms", "entropy_ms")] + [("parts", ctypes.c_int), ("front_images", ctypes.c_int), ("prefilter_ms", ctypes.c_float)]
 
 
 class NhwError(RuntimeError):
@@ -71,6 +71,7 @@ class Encoder:
 
     def close(self):
         if getattr(self, "h", None):
+            self.free_pinned()        # page-locked buffers handed out by pinned_images() end with the handle
             self.lib.nhw_enc_destroy(self.h)
             self.h = None
 

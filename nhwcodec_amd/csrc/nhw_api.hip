@@ -37,8 +37,8 @@ void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int1
 void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipStream_t s);
 void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s);
 
-int nhw_attr_status = 0;
-const char *nhw_attr_where = "";
+int nhw_front_set_attrs(const char **where);   /* nhw_front.hip, nhw_tail.hip: dynamic-LDS opt-ins of the device the handle lives on */
+int nhw_tail_set_attrs(const char **where);
 static thread_local std::string g_err;
 extern "C" const char *nhw_last_error(void) { return g_err.c_str(); }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { char b_[256]; snprintf(b_, sizeof b_, "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); g_err = b_; return NHW_E_HIP; } } while (0)
@@ -51,7 +51,7 @@ struct nhw_enc {
 	hipStream_t part_stream[4];   /* a large batch runs as up to four sub-batches on streams of their own (see nhw_enc_batch_device) */
 	hipEvent_t part_ev[5];
 	int parts;
-	hipEvent_t ev[6];
+	hipEvent_t ev[7];
 	bool timed;
 	int timed_parts, timed_front_images;
 	/* host convenience path */
@@ -115,10 +115,12 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 			g_err = b;
 			return NHW_E_ARG;
 		}
+		{ const char *where = ""; int rc_ = nhw_front_set_attrs(&where); if (!rc_) rc_ = nhw_tail_set_attrs(&where);   /* before anything is launched on this device */
+		  if (rc_) { g_err = std::string(where) + " -> " + hipGetErrorString((hipError_t)rc_); return NHW_E_HIP; } }
 		HIPCHK(hipMalloc((void **)&e->ws.base, total));
 		HIPCHK(hipMemset(e->ws.base, 0, total));       /* guards must be zero; they are never written afterwards */
 		HIPCHK(hipStreamCreate(&e->own_stream));
-		for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&e->ev[i]));
+		for (int i = 0; i < 7; i++) HIPCHK(hipEventCreate(&e->ev[i]));
 		for (int i = 0; i < 4; i++) HIPCHK(hipStreamCreateWithFlags(&e->part_stream[i], hipStreamNonBlocking));
 		for (int i = 0; i < 5; i++) HIPCHK(hipEventCreateWithFlags(&e->part_ev[i], hipEventDisableTiming));
 		return NHW_OK;
@@ -144,7 +146,7 @@ extern "C" void nhw_enc_destroy(nhw_enc *e)
 	if (e->d_sizes) (void)hipFree(e->d_sizes);
 	if (e->d_status) (void)hipFree(e->d_status);
 	if (e->d_offs) (void)hipFree(e->d_offs);
-	for (int i = 0; i < 6; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+	for (int i = 0; i < 7; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
 	if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
 	for (int i = 0; i < 4; i++) if (e->part_stream[i]) (void)hipStreamDestroy(e->part_stream[i]);
 	for (int i = 0; i < 5; i++) if (e->part_ev[i]) (void)hipEventDestroy(e->part_ev[i]);
@@ -171,7 +173,6 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	(void)n;
 	if (what & 1) {
 	if (timed == 1) HIPCHK(hipEventRecord(e->ev[0], s));
-	HIPCHK(hipEventRecord(e->ev[5], s));                          /* (the colour conversion used to be a kernel of its own that ended here) */
 	/* a1 + a2 + Y2 + Y3: colour + 4:2:0, pre-filter (q<=21, nhw_encoder.c:116-119), level-1 analysis (:125), LL1 copy (:127-135): ONE kernel
 	 * for quality 17..23 (k_front_band; for q 17..21 behind the two small kernels that hand every row its carry state).  The luma plane
 	 * never reaches HBM.  Quality 1..16: colour kernel -> luma plane, the rationed pre-filter (nhw_low.hip) -> the band kernel's input plane. */
@@ -179,12 +180,15 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	const size_t yin_stride = ws.stride[B_KMAP];
 	if (low) {
 		nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
+		HIPCHK(hipEventRecord(e->ev[5], s));                      /* with the front group, whoever brackets it: nhw_timing.color_dwt_ms / prefilter_ms */
 		STAGE_DONE();
 		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], q, n, s);   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser */
+		HIPCHK(hipEventRecord(e->ev[6], s));
 		STAGE_DONE();
 		nhw_launch_front_fused(nullptr, q, nullptr, nullptr, 0, yin, yin_stride, 0, nullptr, 0, nullptr, 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
 		                       proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n, s, 0);
 	} else {
+		HIPCHK(hipEventRecord(e->ev[5], s)); HIPCHK(hipEventRecord(e->ev[6], s));   /* no kernels of their own for colour and pre-filter: both times 0 */
 		STAGE_DONE();
 		if (q < 22) STAGE_DONE();
 		nhw_launch_front_fused((const uint8_t *)d_bgr, q, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], nullptr, 0, q < 22,
@@ -312,7 +316,6 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	nhw_launch_phase(PH_FINAL, ws, 0, out, d_sizes, d_status, s);   /* Z2, container */
 	if (timed == 1) HIPCHK(hipEventRecord(e->ev[4], s));
 	HIPCHK(hipGetLastError());
-	if (nhw_attr_status) { g_err = std::string(nhw_attr_where) + " -> " + hipGetErrorString((hipError_t)nhw_attr_status); return NHW_E_HIP; }
 	return NHW_OK;
 }
 
@@ -369,6 +372,7 @@ extern "C" int nhw_enc_last_timing(nhw_enc *e, nhw_timing *t)
 	HIPCHK(hipEventElapsedTime(&t->chroma_ms, e->ev[2], e->ev[3]));
 	HIPCHK(hipEventElapsedTime(&t->entropy_ms, e->ev[3], e->ev[4]));
 	HIPCHK(hipEventElapsedTime(&t->color_dwt_ms, e->ev[0], e->ev[5]));
+	HIPCHK(hipEventElapsedTime(&t->prefilter_ms, e->ev[5], e->ev[6]));
 	t->parts = e->timed_parts; t->front_images = e->timed_front_images;
 	return NHW_OK;
 }

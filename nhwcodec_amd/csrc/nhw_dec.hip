@@ -2275,12 +2275,14 @@ extern "C" int nhw_dec_batch(nhw_dec *d, const uint8_t *nhw, const uint64_t *off
 		HIPCHK(hipMalloc(&d->d_blob, want));
 		d->blob_cap = want;
 	}
-	if (!d->d_off) {
-		HIPCHK(hipMalloc(&d->d_off, ((size_t)d->max_batch + 1) * 8));
-		HIPCHK(hipMalloc(&d->d_len, ((size_t)d->max_batch + 1) * 4));
-		HIPCHK(hipMalloc(&d->d_out, (size_t)d->max_batch * NHW_IMG_BYTES));
-		HIPCHK(hipMalloc(&d->d_status, (size_t)d->max_batch * 4));
-		HIPCHK(hipMalloc(&d->d_quality, (size_t)d->max_batch * 4));
+	if (!d->d_off) {                                               /* all five or none: a half-made set would hand null pointers to the next call */
+		void *b[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+		const size_t bytes[5] = { ((size_t)d->max_batch + 1) * 8, ((size_t)d->max_batch + 1) * 4, (size_t)d->max_batch * NHW_IMG_BYTES, (size_t)d->max_batch * 4, (size_t)d->max_batch * 4 };
+		hipError_t err = hipSuccess;
+		for (int i = 0; i < 5 && err == hipSuccess; i++) err = hipMalloc(&b[i], bytes[i]);
+		if (err != hipSuccess) { for (int i = 0; i < 5; i++) if (b[i]) (void)hipFree(b[i]); HIPCHK(err); }
+		d->d_off = (decltype(d->d_off))b[0]; d->d_len = (decltype(d->d_len))b[1]; d->d_out = (decltype(d->d_out))b[2];
+		d->d_status = (decltype(d->d_status))b[3]; d->d_quality = (decltype(d->d_quality))b[4];
 	}
 	uint64_t *rel = (uint64_t *)malloc(((size_t)n + 1) * 12);
 	if (!rel) return NHW_E_ARG;

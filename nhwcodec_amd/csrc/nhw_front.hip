@@ -968,15 +968,19 @@ __global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, 
 }
 
 #define DWT_WGS 256                  /* one resident workgroup per CU for the 256 x 256 blocks */
-template <int S>
-static void dwt_lds_attr()
+/* The kernels that need more dynamic LDS than the default limit are opted in PER DEVICE, when a handle is created on it
+ * (nhw_enc_create, after hipSetDevice): the attribute belongs to the device's copy of the function.  Returns the first failing call. */
+int nhw_front_set_attrs(const char **where)
 {
-	static bool done = false;
-	if (done) return;
-	const int lds = S * (S + 2) * (int)sizeof(int16_t);
-	NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dwt_ana<S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-	NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dwt_syn<S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-	done = true;
+#define SETATTR(fn, bytes) do { const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+                                if (e_ != hipSuccess) { *where = "hipFuncSetAttribute(" #fn ", MaxDynamicSharedMemorySize)"; return (int)e_; } } while (0)
+	const size_t band = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
+	SETATTR((k_front_band<0, 0, 0>), band); SETATTR((k_front_band<0, 1, 0>), band); SETATTR((k_front_band<1, 1, 0>), band);
+	SETATTR((k_front_band<1, 1, 1>), band); SETATTR((k_front_band<1, 1, 2>), band);
+	SETATTR(k_dwt_ana<256>, 256 * 258 * sizeof(int16_t)); SETATTR(k_dwt_syn<256>, 256 * 258 * sizeof(int16_t));
+	SETATTR(k_dwt_ana<128>, 128 * 130 * sizeof(int16_t)); SETATTR(k_dwt_syn<128>, 128 * 130 * sizeof(int16_t));
+#undef SETATTR
+	return 0;
 }
 
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
@@ -987,15 +991,15 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
                          int16_t *keep, size_t keep_stride, hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind)
 {
 	if (!save) save_kind = 0;
-	if (size == 256 && !keep) { dwt_lds_attr<256>(); k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n); return; }
-	if (size == 128 && !keep) { dwt_lds_attr<128>(); k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n); return; }
+	if (size == 256 && !keep) { k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n); return; }
+	if (size == 128 && !keep) { k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n); return; }
 	(void)keep; (void)keep_stride;       /* size 512 is the band kernel's (nhw_launch_front_fused); nothing else is called with another size */
 }
 
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s)
 {
-	if (size == 256) { dwt_lds_attr<256>(); k_dwt_syn<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n); return; }
-	if (size == 128) { dwt_lds_attr<128>(); k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n); return; }
+	if (size == 256) { k_dwt_syn<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n); return; }
+	if (size == 128) { k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n); return; }
 }
 
 /* the front launch group: [k_front_rowtail + k_front_chain for q 17..21] + k_front_band.
@@ -1016,15 +1020,6 @@ void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv,
                             int16_t *keep, size_t keep_stride, int n, hipStream_t s, int force_fallback)
 {
 	const size_t lds = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
-	static bool attr_set = false;
-	if (!attr_set) {
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<0, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front_band<1, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		attr_set = true;
-	}
 	const dim3 grid((H / FB_KB) * n);
 	if (!bgr) {
 		k_front_band<0, 0, 0><<<grid, FB_NT, lds, s>>>(y, y_stride, 0.f, nullptr, nullptr, 0, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, 0, n);

@@ -99,17 +99,19 @@ static size_t phase_lds(int ph)
 	}
 }
 
+/* per device, from nhw_enc_create (see nhw_front_set_attrs) */
+int nhw_tail_set_attrs(const char **where)
+{
+#define SETATTR(fn) do { const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10); \
+                         if (e_ != hipSuccess) { *where = "hipFuncSetAttribute(" #fn ", MaxDynamicSharedMemorySize)"; return (int)e_; } } while (0)
+	SETATTR(k_phase<PH_L1>); SETATTR(k_phase<PH_L2>); SETATTR(k_phase<PH_L3>); SETATTR(k_phase<PH_C5>);
+#undef SETATTR
+	return 0;
+}
+
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s)
 {
 	const dim3 g(ws.n), b(256);
-	static bool attr_set = false;
-	if (!attr_set) {
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10));
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10));
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_L3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10));
-		NHW_ATTR(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase<PH_C5>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10));
-		attr_set = true;
-	}
 	const size_t lds = phase_lds(ph);
 	switch (ph) {
 	case PH_L1: k_phase<PH_L1><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;

@@ -50,10 +50,4 @@ struct NhwWs {
 };
 
 
-/* A failed hipFuncSetAttribute (dynamic LDS above the default limit) would otherwise surface as a launch failure far from its cause: the
- * first failure is kept (nhw_api.hip defines the variable) and the batch driver returns it as NHW_E_HIP with this call's name. */
-extern int nhw_attr_status;
-extern const char *nhw_attr_where;
-#define NHW_ATTR(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess && !nhw_attr_status) { nhw_attr_status = (int)e_; nhw_attr_where = #call; } } while (0)
-
 #endif

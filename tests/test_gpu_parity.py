@@ -22,11 +22,23 @@ def test_c_abi_exports_every_declared_symbol():
         import __graft_entry__ as g
         g.build()
     lib = ctypes.CDLL(nhwcodec_amd.LIB_PATH)      # loading needs no GPU
-    hdr = open(os.path.join(ROOT, "include", "nhw_hip.h")).read()
-    names = set(re.findall(r"\b(nhw_[a-z_0-9]+)\s*\(", hdr))
-    assert {"nhw_enc_create", "nhw_enc_batch", "nhw_enc_batch_device", "nhw_enc_destroy"} <= names
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/nhw_hip.h but not exported"
+    for header, must in (("nhw_hip.h", {"nhw_enc_create", "nhw_enc_batch", "nhw_enc_batch_device", "nhw_enc_destroy"}),
+                         ("nhw_hip_debug.h", {"nhw_debug_stop_after", "nhw_debug_read", "nhw_dec_debug_read"})):   # the boundary, and the hooks the tests call
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        names = set(re.findall(r"\b(nhw_[a-z_0-9]+)\s*\(", hdr))
+        assert must <= names
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in include/{header} but not exported"
+    # ... and nothing the tests call is missing from the headers
+    declared = set()
+    for header in ("nhw_hip.h", "nhw_hip_debug.h"):
+        declared |= set(re.findall(r"\b(nhw_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", header)).read()))
+    used = set()
+    for dp, _, fs in os.walk(os.path.join(ROOT, "tests")):
+        for f in fs:
+            if f.endswith(".py"):
+                used |= set(re.findall(r"\.lib\.(nhw_[a-z_0-9]+)", open(os.path.join(dp, f)).read()))
+    assert used <= declared, f"called by the tests but declared in no header: {sorted(used - declared)}"
 
 
 def test_product_never_touches_the_oracle():

@@ -100,12 +100,18 @@ static int decode_tiles(int ny, int nx, const char *stem, const char *out_path)
 	const uint32_t width = 512u * (uint32_t)nx, height = 512u * (uint32_t)ny, bytes = width * height * 3u;
 	FILE *f;
 	int t, r;
+	if ((uint64_t)width * height * 3u + 54u > 0xFFFFFFFFull) {       /* the BMP header's 32-bit size fields */
+		fprintf(stderr, "%s: a %d x %d grid of tiles does not fit a BMP file (4 GiB)\n", PROGRAM, ny, nx);
+		return 1;
+	}
 	for (t = 0; t < n; t++) {
 		char name[4096];
 		uint8_t *b; size_t len;
 		snprintf(name, sizeof name, "%s_y%d_x%d.nhw", stem, t / nx, t % nx);
 		if (read_file(name, &b, &len)) return 1;
-		blob = (uint8_t *)realloc(blob, total + len + 16);
+		{ uint8_t *grown = (uint8_t *)realloc(blob, total + len + 16);
+		  if (!grown) { fprintf(stderr, "%s: out of memory\n", PROGRAM); return 1; }
+		  blob = grown; }
 		memcpy(blob + total, b, len); free(b);
 		off[t] = total; total += len;
 	}
@@ -156,6 +162,16 @@ static int tar_write_member(FILE *f, const char *name, const uint8_t *head, size
 	snprintf((char *)h + 148, 8, "%06o", sum); h[155] = ' ';
 	return (fwrite(h, 1, 512, f) == 512 && fwrite(head, 1, head_len, f) == head_len && fwrite(data, 1, len, f) == len && fwrite(zeros, 1, pad, f) == pad) ? 0 : -1;
 }
+#define TAR_NHW_MAX (1u << 20)      /* largest archive member taken for a .nhw file */
+/* skip n bytes of the archive: by seeking, or by reading where the input cannot seek (a pipe); non-zero at the end of the input */
+static int tar_skip(FILE *in, unsigned long n)
+{
+	uint8_t sink[4096];
+	if (n == 0) return 0;
+	if (fseek(in, (long)n, SEEK_CUR) == 0) return 0;
+	while (n) { const size_t k = n < sizeof sink ? (size_t)n : sizeof sink; if (fread(sink, 1, k, in) != k) return 1; n -= (unsigned long)k; }
+	return 0;
+}
 static int decode_tar(const char *in_path, const char *out_path)
 {
 	enum { CH = 1024 };
@@ -181,12 +197,22 @@ static int decode_tar(const char *in_path, const char *out_path)
 			hdr[99] = 0;
 			nl = strlen((const char *)hdr);
 			if ((hdr[156] == '0' || hdr[156] == 0) && nl > 4 && !strcmp((const char *)hdr + nl - 4, ".nhw")) {
-				if (total_bytes + size + 16 > blob_cap) { blob_cap = (total_bytes + size + 16) * 2; blob = (uint8_t *)realloc(blob, blob_cap); }
+				if (size > TAR_NHW_MAX) {                          /* the encoder never writes more than 512 KiB a file */
+					fprintf(stderr, "%s: %s: member of %lu bytes is no .nhw file, left out\n", PROGRAM, (const char *)hdr, size); bad++;
+					if (tar_skip(in, (size + 511) / 512 * 512)) eof = 1;
+				}
+				else {
+				if (total_bytes + size + 16 > blob_cap) {
+					uint8_t *grown = (uint8_t *)realloc(blob, (total_bytes + size + 16) * 2);
+					if (!grown) { fprintf(stderr, "%s: out of memory\n", PROGRAM); return 1; }
+					blob = grown; blob_cap = (total_bytes + size + 16) * 2;
+				}
 				if (fread(blob + total_bytes, 1, size, in) != size) { fprintf(stderr, "%s: %s: archive ends inside member %s\n", PROGRAM, in_path, (const char *)hdr); bad++; eof = 1; }
 				else { off[n] = total_bytes; total_bytes += size; snprintf(names[n], 104, "%.*s.bmp", (int)(nl - 4), (const char *)hdr); n++; }
-				if (size % 512) fseek(in, (long)(512 - size % 512), SEEK_CUR);
+				if (size % 512 && tar_skip(in, 512 - size % 512)) eof = 1;
+				}
 			}
-			else fseek(in, (long)((size + 511) / 512 * 512), SEEK_CUR);
+			else if (tar_skip(in, (size + 511) / 512 * 512)) eof = 1;
 		}
 		if (n == CH || (eof && n > 0)) {
 			off[n] = total_bytes;

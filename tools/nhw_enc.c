@@ -197,6 +197,7 @@ static void *worker_main(void *arg)
 	struct job *jb = w->jb;
 	nhw_enc *enc = NULL;
 	uint8_t *imgs = NULL, *arena = NULL;
+	int imgs_pinned = 0;
 	uint64_t *off = (uint64_t *)malloc(sizeof(uint64_t) * (CHUNK + 1));
 	int32_t *st = (int32_t *)malloc(sizeof(int32_t) * CHUNK);
 	const int cap = jb->n < CHUNK ? jb->n : CHUNK;
@@ -206,7 +207,9 @@ static void *worker_main(void *arg)
 	arena = (uint8_t *)malloc((size_t)cap * NHW_OUT_STRIDE);
 	if (!jb->outdir) {                                 /* page-locked input buffer: the upload runs at PCIe speed next to the encode */
 		imgs = (uint8_t *)nhw_host_alloc((size_t)cap * NHW_IMG_BYTES);
+		imgs_pinned = imgs != NULL;
 		if (!imgs) imgs = (uint8_t *)malloc((size_t)cap * NHW_IMG_BYTES);
+		if (!imgs) { fprintf(stderr, "%s: out of memory for %d input images\n", PROGRAM, cap); exit(-1); }
 	}
 	for (;;) {
 		int base, m;
@@ -229,6 +232,7 @@ static void *worker_main(void *arg)
 			if (write_file(path, arena + off[i], (size_t)(off[i + 1] - off[i]))) w->bad++;
 		}
 	}
+	if (imgs_pinned) nhw_host_free(imgs); else free(imgs);        /* before the handle goes: page-locked memory belongs to its device context */
 	nhw_enc_destroy(enc);
 	free(st); free(off); free(arena);
 	return NULL;
@@ -283,6 +287,16 @@ static int bmp_from_memory(const uint8_t *b, size_t len, uint8_t *dst)
 		}
 	return HDR_OK;
 }
+#define TAR_BMP_MAX (4u << 20)      /* largest archive member taken for an image */
+/* skip n bytes of the archive: by seeking, or by reading where the input cannot seek (a pipe); non-zero at the end of the input */
+static int tar_skip(FILE *in, unsigned long n)
+{
+	uint8_t sink[4096];
+	if (n == 0) return 0;
+	if (fseek(in, (long)n, SEEK_CUR) == 0) return 0;
+	while (n) { const size_t k = n < sizeof sink ? (size_t)n : sizeof sink; if (fread(sink, 1, k, in) != k) return 1; n -= (unsigned long)k; }
+	return 0;
+}
 static int encode_tar(const char *in_path, const char *out_path, int quality, int stock_compat)
 {
 	FILE *in = fopen(in_path, "rb"), *out;
@@ -310,16 +324,26 @@ static int encode_tar(const char *in_path, const char *out_path, int quality, in
 			nl = strlen((const char *)hdr);
 			is_bmp = (hdr[156] == '0' || hdr[156] == 0) && nl > 4 && !strcmp((const char *)hdr + nl - 4, ".bmp");
 			if (is_bmp) {
-				if (size + 1 > member_cap) { member_cap = size + 1; member = (uint8_t *)realloc(member, member_cap); }
-				if (fread(member, 1, size, in) != size) { fprintf(stderr, "%s: %s: archive ends inside member %s\n", PROGRAM, in_path, (const char *)hdr); bad++; eof = 1; is_bmp = 0; }
+				if (size > TAR_BMP_MAX) {                          /* a 512 x 512 24-bit BMP is 786 486 bytes; a header that claims gigabytes is damage */
+					fprintf(stderr, "%s: %s: member of %lu bytes is no 512 x 512 image, left out\n", PROGRAM, (const char *)hdr, size); bad++;
+					if (tar_skip(in, (size + 511) / 512 * 512)) { fprintf(stderr, "%s: %s: archive ends inside member %s\n", PROGRAM, in_path, (const char *)hdr); eof = 1; }
+					is_bmp = 0;
+				}
+				else if (size + 1 > member_cap) {
+					uint8_t *grown = (uint8_t *)realloc(member, size + 1);
+					if (!grown) { fprintf(stderr, "%s: out of memory for a member of %lu bytes\n", PROGRAM, size); exit(-1); }
+					member = grown; member_cap = size + 1;
+				}
+				if (!is_bmp) { }
+				else if (fread(member, 1, size, in) != size) { fprintf(stderr, "%s: %s: archive ends inside member %s\n", PROGRAM, in_path, (const char *)hdr); bad++; eof = 1; is_bmp = 0; }
 				else {
 					const int hc = bmp_from_memory(member, size, imgs + (size_t)n * NHW_IMG_BYTES);
 					if (hc != HDR_OK) { fprintf(stderr, "%s: %s: invalid image file (%d), left out\n", PROGRAM, (const char *)hdr, hc); bad++; }
 					else { snprintf(names[n], 104, "%.*s.nhw", (int)(nl - 4), (const char *)hdr); n++; }
 				}
-				if (size % 512) fseek(in, (long)(512 - size % 512), SEEK_CUR);
+				if (is_bmp && size % 512 && tar_skip(in, 512 - size % 512)) eof = 1;
 			}
-			else fseek(in, (long)((size + 511) / 512 * 512), SEEK_CUR);
+			else if (tar_skip(in, (size + 511) / 512 * 512)) eof = 1;
 		}
 		if (n == CHUNK || (eof && n > 0)) {
 			if (!enc) {
