@@ -120,12 +120,15 @@ DEVI void map_cell(MapState &s, const PfP &pp, int c, int sm, int val, int16_t *
 		else STK(k + c, (int16_t)((int16_t)val));
 	}
 }
-/* does pixel (sm, val) need the serial visit? */
-DEVI bool map_candidate(const PfP &pp, int sm, int val)
+/* does pixel (sm, val) need the serial visit?  Three kinds of cell do: borderline ones (the marker rule proper, a few dozen per image), the
+ * first three values that hit the threshold from below (bump_count) and the first value of threshold + 21 (exact_count).  The last two
+ * kinds are thousands of cells per image at the busy settings, and all but the first few leave the value as the lanes wrote it: with the
+ * counts as the row finds them they are not candidates at all (a count that fills up inside the row only makes map_cell a no-op). */
+DEVI bool map_candidate(const PfP &pp, int sm, int val, bool bumps_left, bool exact_left)
 {
 	const int s2 = pp.s2;
-	if (sm < 0) return val == -s2 || (-sm <= s2 && -val > s2 && -val <= s2 + 20);
-	return sm > 0 && ((sm <= s2 && val > s2 && val <= s2 + 20) || val == s2 + 21);
+	if (sm < 0) return (bumps_left && val == -s2) || (-sm <= s2 && -val > s2 && -val <= s2 + 20);
+	return sm > 0 && ((sm <= s2 && val > s2 && val <= s2 + 20) || (exact_left && val == s2 + 21));
 }
 
 #include "nhw_low_machine.h"
@@ -422,9 +425,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 	__shared__ __attribute__((aligned(16))) uint8_t s_so[2][W];
 	__shared__ __attribute__((aligned(16))) int16_t s_sum[W];             /* pass A: the 8-neighbour sums; behind it: the prefix sums of the pairs' hits (s_hits) */
 	__shared__ __attribute__((aligned(8))) uint8_t s_cand[64];            /* per 8-pixel group: the pixels that need the serial visit of pass A */
-	__shared__ __attribute__((aligned(16))) uint8_t s_code[256], s_act[256];   /* per pair: threshold tests in, the machine's answer out */
-	__shared__ uint32_t s_rowmask[16];                                     /* rows whose pass C ran here */
 	__shared__ __attribute__((aligned(8))) uint8_t s_cmask[4][64];          /* a marker row's cells by class (c_classify), a bit a cell */
+	__shared__ uint32_t s_rowmask[16];                                     /* rows whose pass C ran here */
 	__shared__ int s_misc[4];
 	int16_t *s_hits = s_sum;
 	const int lane = threadIdx.x, img = blockIdx.x;
@@ -440,6 +442,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 	machine_reset(mach);
 	machine_cache(mach, mcache);
 
+#ifdef NHW_DEV
+	long long pclk[6] = { 0, 0, 0, 0, 0, 0 }, pt0 = 0;
+#define PCLK_BEGIN() (pt0 = (long long)__builtin_readcyclecounter())
+#define PCLK_END(i) (pclk[i] += (long long)__builtin_readcyclecounter() - pt0)
+#else
+#define PCLK_BEGIN() ((void)0)
+#define PCLK_END(i) ((void)0)
+#endif
 	const int c0 = lane * 8;
 	const int16_t *src = srcb + (size_t)img * src_stride;
 	int16_t *yo = yb + (size_t)img * y_stride;
@@ -452,8 +462,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 	*reinterpret_cast<uint4 *>(yo + c0) = *reinterpret_cast<const uint4 *>(&s_src[0][c0]);      /* row 0 is not touched by any pass */
 
 	for (int r = 1; r < W - 1; r++) {
+		PCLK_BEGIN();
 		load_row(r + 1);
 		__syncthreads();
+		PCLK_END(0);
+		PCLK_BEGIN();
 		const int16_t *up = s_src[(r - 1) % 3], *mid = s_src[r % 3], *dn = s_src[(r + 1) % 3];
 		int16_t *km = s_km[r & 1];
 		int16_t *y = s_y[r & 1];
@@ -526,10 +539,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			}
 			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)valv[2 * e] | ((uint32_t)(uint16_t)valv[2 * e + 1] << 16);
 			  *reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
-			for (int e = 0; e < 8; e++) if (smv[e] != 0 && map_candidate(pp, smv[e], valv[e])) cand |= 1u << e;
+			for (int e = 0; e < 8; e++) if (smv[e] != 0 && map_candidate(pp, smv[e], valv[e], ms.bump_count < 3, ms.exact_count == 0)) cand |= 1u << e;
 		}
 		s_cand[lane] = (uint8_t)cand;
 		__syncthreads();                                           /* s_vb is dead from here */
+		PCLK_END(1);
+		PCLK_BEGIN();
 		/* the few order-dependent pixels of pass A, in raster order, on the scalar unit */
 		if (!(dbg & 1)) {
 			for (int l8 = 0; l8 < 8; l8++) {
@@ -544,6 +559,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			}
 		}
 		__syncthreads();
+		PCLK_END(2);
+		PCLK_BEGIN();
+		uint32_t cw = 0;                                             /* the codes of my four pairs */
 		/* all lanes: the row's picture copy (:566) with the q <= 14 smoothing (:780-807, reads the source copy only), the pair codes of the
 		 * row (lane l has pairs 4 l .. 4 l + 3 = cells 8 l + 1 .. 8 l + 8) and the prefix sums of their hits */
 		{
@@ -564,7 +582,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				yw[e2] = (uint32_t)(uint16_t)v2[0] | ((uint32_t)(uint16_t)v2[1] << 16);
 			}
 			*reinterpret_cast<uint4 *>(&y[c0]) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
-			uint32_t cw = 0;
 			int hp[4], h = 0;
 			for (int j = 0; j < 4; j++) {
 				const int k0 = km[c0 + 2 * j + 1], k1 = km[c0 + 2 * j + 2];
@@ -573,8 +590,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				cw |= code << (8 * j);
 				h += f0 + f1; hp[j] = h;
 			}
-			*reinterpret_cast<uint32_t *>(&s_code[4 * lane]) = cw;
-			*reinterpret_cast<uint32_t *>(&s_act[4 * lane]) = 0;
 			int incl = h;                                              /* inclusive scan of the lanes' totals */
 			for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
 			const int excl = incl - h;
@@ -582,39 +597,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			                                                           (uint32_t)(uint16_t)(excl + hp[2]) | ((uint32_t)(uint16_t)(excl + hp[3]) << 16));
 		}
 		__syncthreads();
-		/* the chain: whole bursts where the counters allow it, single pairs otherwise; everything below is wave-uniform */
+		PCLK_END(3);
+		PCLK_BEGIN();
+		/* the chain: whole bursts where the counters allow it, single pairs otherwise; everything below is wave-uniform.  The chain's one
+		 * scarce resource is the CU's scalar unit (16 wavefronts share it), so nothing on it goes through LDS: a pair's code comes out of
+		 * the lane that made it (readlane), the hits before the present pair are a running sum, the answers go into the lanes' registers. */
+		uint32_t aw = 0;                                             /* the answers of my four pairs */
 		if (!(dbg & 2)) {
-			int pos = 0;
-			bool give_up = false;                                  /* a burst that was declined is walked pair by pair to its end */
-			while (pos < 255) {
-				if (mach.t[1] == 0) give_up = false;
-				if (!give_up && burst_entry_ok(mach, mcache)) {
-					const int base = pos ? LDK(&s_hits[pos - 1]) : 0;
-					const int i = pos + lane < 255 ? pos + lane : 255;
-					const int hj = (int)s_hits[i] - base;
-					const PfBurstLane b = burst_lane(lane, mach.t[1], mach.t[4], mach.t[44], hj, mach.t[10], mach.t[11], mcache.exT);
-					PfBurstMasks k;
-					k.cap = __ballot(b.cap); k.wrap = __ballot(b.wrap); k.win = __ballot(b.win); k.cyc = __ballot(b.cyc); k.i6 = __ballot(b.i6);
-					k.iS = __ballot(b.iS); k.cnt = __ballot(b.cnt); k.g13 = __ballot(b.g13); k.e15 = __ballot(b.e15); k.eT = __ballot(b.eT);
-					const unsigned long long endm = k.cap | k.wrap;
-					int e = endm ? __builtin_ctzll(endm) : 64;
-					if (e >= 255 - pos) e = 255 - pos - 1;                 /* the row ends first */
-					const int n = burst_commit(mach, mcache, k, 255 - pos, mach.t[4] + __builtin_amdgcn_readlane(hj, e));
-					if (n > 0) { pos += n; continue; }
-					give_up = true;
-				}
-				const int code = LDK(&s_code[pos]);
+			int pos = 0, hbase = 0;                                  /* hbase: hits of the pairs before pos */
+			bool give_up = false;                                    /* a burst that was declined is walked pair by pair to its end */
+			auto single_pair = [&]() {
+				const int code = (int)(((uint32_t)__builtin_amdgcn_readlane((int)cw, pos >> 2) >> (8 * (pos & 3))) & 15u);
 				int a = machine_step_fast(mach, mcache, code);
 				if (a < 0) { a = machine_step(mach, code, r); machine_cache(mach, mcache); }
-				STK(&s_act[pos], (uint8_t)a);
+				if (a && lane == (pos >> 2)) aw |= (uint32_t)a << (8 * (pos & 3));
+				hbase += (code & 1) + ((code >> 1) & 1);
 				pos++;
+			};
+			while (pos < 255) {
+				if (mach.t[1] == 0) {                                 /* a burst's first pair */
+					give_up = false;
+					single_pair();
+					if (pos >= 255) break;
+				}
+				if (!give_up && burst_entry_ok(mach, mcache)) {
+					const int i = pos + lane < 255 ? pos + lane : 255;
+					const int hj = (int)s_hits[i] - hbase;
+					const PfBurstLane b = burst_lane(lane, mach.t[1], mach.t[4], mach.t[44], hj, mach.t[10], mach.t[11], mcache.exT);
+					auto hits_to = [&](int e) { return __builtin_amdgcn_readlane(hj, e); };
+					int n;
+					if (burst_quiet(mach, mcache))
+						n = burst_commit_quiet(mach, mcache, (unsigned)__ballot(b.cap), (unsigned)__ballot(b.wrap), (unsigned)__ballot(b.win), (unsigned)__ballot(b.cyc),
+						                       mcache.w8z ? (unsigned)__ballot(b.i6) : 0u, 255 - pos, hits_to);
+					else {
+						PfBurstMasks k;
+						k.cap = __ballot(b.cap); k.wrap = __ballot(b.wrap); k.win = __ballot(b.win); k.cyc = __ballot(b.cyc); k.i6 = __ballot(b.i6);
+						k.iS = __ballot(b.iS); k.cnt = __ballot(b.cnt); k.g13 = __ballot(b.g13); k.e15 = __ballot(b.e15); k.eT = __ballot(b.eT);
+						n = burst_commit(mach, mcache, k, 255 - pos, hits_to);
+					}
+					if (n > 0) { hbase += __builtin_amdgcn_readlane(hj, n - 1); pos += n; continue; }
+					give_up = true;
+				}
+				if (mach.t[1] != 0) single_pair();                    /* a pair inside a burst that was declined */
 			}
 		}
 		__syncthreads();
+		PCLK_END(4);
+		PCLK_BEGIN();
 		/* all lanes: the answers applied to the row (pass B's picture side), the tail rules, and the test for markers */
 		bool any_mark;
 		{
-			const uint32_t aw = (dbg & 2) ? 0u : *reinterpret_cast<const uint32_t *>(&s_act[4 * lane]);
 			int kc[9], dd[9], sv[9], e0[4], e1[4];
 			{ const uint4 kw = *reinterpret_cast<const uint4 *>(&km[c0]);
 			  const uint32_t w4[4] = { kw.x, kw.y, kw.z, kw.w };
@@ -656,13 +688,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			  *reinterpret_cast<uint2 *>(&so[c0]) = make_uint2(lo, hi); }
 			any_mark = __any(mark);
 			if (any_mark) {                                           /* the classes pass C asks for, a bit a cell, in cell order */
-				uint32_t cs = 0, cw = 0, cl = 0, cm = 0;
+				uint32_t cs = 0, cwk = 0, cl = 0, cm = 0;
 				for (int e = 0; e < 8; e++) {
 					bool a, b2, c2, d2;
 					c_classify(pp, kc[e], a, b2, c2, d2);
-					cs |= (uint32_t)a << e; cw |= (uint32_t)b2 << e; cl |= (uint32_t)c2 << e; cm |= (uint32_t)d2 << e;
+					cs |= (uint32_t)a << e; cwk |= (uint32_t)b2 << e; cl |= (uint32_t)c2 << e; cm |= (uint32_t)d2 << e;
 				}
-				s_cmask[0][lane] = (uint8_t)cs; s_cmask[1][lane] = (uint8_t)cw; s_cmask[2][lane] = (uint8_t)cl; s_cmask[3][lane] = (uint8_t)cm;
+				s_cmask[0][lane] = (uint8_t)cs; s_cmask[1][lane] = (uint8_t)cwk; s_cmask[2][lane] = (uint8_t)cl; s_cmask[3][lane] = (uint8_t)cm;
 			}
 		}
 		__syncthreads();
@@ -681,6 +713,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			}
 			__syncthreads();
 		}
+		PCLK_END(5);
 		if (r > 1) {                                              /* row r-1 is through passes A..C as far as they run here */
 			*reinterpret_cast<uint4 *>(yo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[(r - 1) & 1][c0]);
 			*reinterpret_cast<uint4 *>(kmo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[(r - 1) & 1][c0]);
@@ -695,6 +728,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		*reinterpret_cast<uint2 *>(soo + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[r & 1][c0]);
 		*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
 		if (lane < 16) reinterpret_cast<uint32_t *>(soo)[lane] = s_rowmask[lane];      /* flag plane, row 0: the rows k_low_marks must leave alone */
+#ifdef NHW_DEV
+		if (lane < 6) reinterpret_cast<long long *>(soo + (size_t)(W - 1) * W)[lane] = pclk[lane];   /* developer builds: cycles per phase, in the flag plane's unused last row */
+#endif
 	}
 }
 

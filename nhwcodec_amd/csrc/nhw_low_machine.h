@@ -435,10 +435,15 @@ DEVI int burst_entry_ok(const PfM &m, const PfC &c)
 {
 	return (T(1) >= 1) & (T(1) < 15) & (T(4) >= 0) & (T(4) < 15) & (T(44) >= 0) & (T(44) <= 3) & !c.t6bad & (T(8) <= 6);
 }
-/* k: the masks of burst_lane's answers for the pairs from the present one on; avail: how many of them exist in this row;
- * hits_at_end_plus_t4: t4 behind the last pair taken (the pair that ends the burst, or the row's last).
+/* is the gate of the slow schedules (:1532) shut?  Then a burst can only be stopped by its window, by the t18 rotation or by the one-time
+ * step of :1506, and burst_commit_quiet decides on five masks instead of ten. */
+DEVI int burst_quiet(const PfM &m, const PfC &c) { return !((T(29) > 0) & c.gate14); }
+
+/* k: the masks of burst_lane's answers for the pairs from the present one on; avail: how many of them exist in this row (1 .. 255);
+ * hits_to(e): the hits of pairs 0 .. e (the caller has them per lane: one readlane).
  * Returns the number of pairs taken (counters moved), or 0 (counters untouched). */
-DEVI int burst_commit(PfM &m, const PfC &c, const PfBurstMasks &k, int avail, int hits_at_end_plus_t4)
+template <class HITS>
+DEVI int burst_commit(PfM &m, const PfC &c, const PfBurstMasks &k, int avail, HITS hits_to)
 {
 	const unsigned long long endm = k.cap | k.wrap;
 	const int e_ = endm ? __builtin_ctzll(endm) : 64;
@@ -448,7 +453,7 @@ DEVI int burst_commit(PfM &m, const PfC &c, const PfBurstMasks &k, int avail, in
 	const unsigned long long upto = burst_low_bits(e + 1);
 	const int cap_end = open ? 0 : (int)((k.cap >> e) & 1);
 	const unsigned long long idle = cap_end ? burst_low_bits(e) : upto; /* the pairs that take the idle step */
-	const int t4e = hits_at_end_plus_t4;                                /* t4 behind pair e */
+	const int t4e = T(4) + hits_to(e);                                  /* t4 behind pair e */
 	const int v = T(44);
 	if (k.win & ~k.cyc & upto) return 0;
 	const int ncyc = burst_popc(k.cyc & upto), t18 = T(18);             /* pairs that rotate t18 (:1006-1037): 1 .. 15 -> 0, and at 0 the burst ends */
@@ -484,6 +489,40 @@ DEVI int burst_commit(PfM &m, const PfC &c, const PfBurstMasks &k, int avail, in
 	}
 	if (cap_end) {
 		if (t4e == 0) T(8)++; else { T(8) = 0; T(5) = 0; T(12) = 0; }
+		T(44) = (v + e) & 3;
+	} else T(44) = 0;
+	T(29)++; T(1) = 0; T(4) = 0;
+	return e + 1;
+}
+/* the same with the gate of the slow schedules shut (burst_quiet): masks of the first 32 pairs (a burst is over within 21) */
+template <class HITS>
+DEVI int burst_commit_quiet(PfM &m, const PfC &c, unsigned cap, unsigned wrap, unsigned win, unsigned cyc, unsigned i6, int avail, HITS hits_to)
+{
+	const unsigned endm = cap | wrap;
+	const int e_ = endm ? __builtin_ctz(endm) : 32;
+	const int open = e_ >= avail;
+	if (open && avail > 24) return 0;
+	const int e = open ? avail - 1 : e_;
+	const unsigned upto = 0xFFFFFFFFu >> (31 - e);                      /* bits 0 .. e */
+	const int cap_end = open ? 0 : (int)((cap >> e) & 1);
+	if (win & ~cyc & upto) return 0;
+	const unsigned cy = cyc & upto;
+	const int t18 = T(18), v = T(44);
+	int n18 = t18;
+	if (cy) { const int ncyc = __builtin_popcount(cy); if (t18 == 0 || ncyc > 16 - t18) return 0; n18 = (t18 + ncyc) & 15; }
+	if (c.w8z && (i6 & (cap_end ? upto >> 1 : upto))) return 0;         /* the idle pairs: all of them, or all but the last */
+	if (cap_end & c.capB) return 0;                                     /* (capA needs t29 > 0 and t14 == 4: the gate would be open) */
+	const int dh = hits_to(e);
+	T(18) = n18;
+	T(17) = 0;
+	if (open) {
+		T(1) += dh + 3 * ((v + e + 1) >> 2);
+		T(4) += dh;
+		T(44) = (v + e + 1) & 3;
+		return e + 1;
+	}
+	if (cap_end) {
+		if (T(4) + dh == 0) T(8)++; else { T(8) = 0; T(5) = 0; T(12) = 0; }
 		T(44) = (v + e) & 3;
 	} else T(44) = 0;
 	T(29)++; T(1) = 0; T(4) = 0;

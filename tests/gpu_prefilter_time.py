@@ -29,6 +29,18 @@ def main(qs, n=4096, check=6):
             enc.lib.nhw_stage_prefilter(enc.h, work.data_ptr(), n, q, None)
             torch.cuda.synchronize()
             ts.append((time.time() - t0) * 1e3)
+        try:
+            import ctypes
+            acc = np.zeros(6)
+            for i in range(0, n, max(1, n // 64)):
+                m = np.zeros(512 * 512, np.uint8)
+                enc.lib.nhw_debug_read(enc.h, 17, i, ctypes.c_void_p(m.ctypes.data), ctypes.c_size_t(512 * 512))
+                acc += m[511 * 512: 511 * 512 + 48].view(np.int64)
+            if acc.sum() > 0:
+                names = ["load+sync", "A parallel", "A serial", "copy/codes/hits", "chain", "apply+marker rows"]
+                print("   phase cycles per row (mean over sampled images):", {k: int(v / (n // max(1, n // 64)) / 510) for k, v in zip(names, acc)})
+        except Exception as ex:
+            print("   (no phase clocks:", ex, ")")
         print(f"q{q}: prefilter stage {min(ts):.1f} ms / {n} images (runs {', '.join(f'{t:.1f}' for t in ts)}); oracle check of {check}: {'OK' if not bad else 'MISMATCH ' + str(bad)}", flush=True)
 
 if __name__ == "__main__":

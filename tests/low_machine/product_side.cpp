@@ -68,11 +68,9 @@ static int row_hop(PfM &m, PfC &c, const uint8_t *codes, uint8_t *acts, int row)
 				if (b.cap) k.cap |= bit; if (b.wrap) k.wrap |= bit; if (b.win) k.win |= bit; if (b.cyc) k.cyc |= bit; if (b.i6) k.i6 |= bit;
 				if (b.iS) k.iS |= bit; if (b.cnt) k.cnt |= bit; if (b.g13) k.g13 |= bit; if (b.e15) k.e15 |= bit; if (b.eT) k.eT |= bit;
 			}
-			const unsigned long long endm = k.cap | k.wrap;
-			int e = endm ? __builtin_ctzll(endm) : 64;
-			if (e >= 255 - pos) e = 255 - pos - 1;                          /* the row ends first */
-			const int ie = pos + e;
-			const int n = burst_commit(m, c, k, 255 - pos, m.t[4] + hits_prefix[ie] - base);
+			auto hits_to = [&](int e) { return hits_prefix[pos + e < 255 ? pos + e : 255] - base; };
+			const int n = burst_quiet(m, c) ? burst_commit_quiet(m, c, (unsigned)k.cap, (unsigned)k.wrap, (unsigned)k.win, (unsigned)k.cyc, c.w8z ? (unsigned)k.i6 : 0u, 255 - pos, hits_to)
+			                                : burst_commit(m, c, k, 255 - pos, hits_to);
 			if (n > 0) { pos += n; bursted += n; continue; }
 			give_up = true;
 		}
