@@ -753,7 +753,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
  * the first row-parallel form -- LDS loads and compares at every visit -- took 15.5 ms per batch at quality 10.) */
 #define MK_R 192                                                       /* lanes: 191 rows + the row below them */
 #define MK_A 48                                                        /* columns a window advances */
-#define MK_P 66                                                        /* pitch of the map tile in cells (33 dwords: a lane per row walks all banks) */
 #define MK_BP 68                                                       /* pitch of the byte planes */
 namespace {
 struct MkMasks { uint64_t strong, weak, small, ja, g56, g160, jas, big; };
@@ -774,7 +773,6 @@ struct MkFx {
 __global__ __launch_bounds__(MK_R) void k_low_marks(int16_t *__restrict__ yb, size_t y_stride, const int16_t *__restrict__ kmb, size_t km_stride,
                                                     uint8_t *__restrict__ sob, size_t so_stride, int q, int dbg)
 {
-	__shared__ __attribute__((aligned(16))) int16_t kt[(MK_R + 1) * MK_P];  /* map; tile row 0 = the row above the workgroup's first */
 	__shared__ __attribute__((aligned(16))) int8_t own[MK_R * MK_BP], upd[MK_R * MK_BP];   /* what a lane adds to its row / to the row above */
 	__shared__ uint64_t s_upflag[MK_R + 1], s_updirty[MK_R + 1];          /* of the lane's additions to the row above: flags raised, cells touched */
 	__shared__ uint32_t s_mask[16];
@@ -800,12 +798,6 @@ __global__ __launch_bounds__(MK_R) void k_low_marks(int16_t *__restrict__ yb, si
 
 	for (int wb = 0; wb < W - 16; wb += MK_A) {                        /* windows of columns wb .. wb + 63: 0, 48, .., 480 */
 		const bool last = wb + MK_A >= W - 16;
-		for (int k = tid; k < (MK_R + 1) * 32; k += MK_R) {
-			const int rr = k >> 5, d = k & 31, row = R0 - 1 + rr, col = wb + 2 * d;
-			uint32_t w = 0;
-			if (col < W && row >= 1 && row <= W - 2) w = *reinterpret_cast<const uint32_t *>(km + (size_t)row * W + col);
-			reinterpret_cast<uint32_t *>(kt + rr * MK_P)[d] = w;
-		}
 		/* the flags of my row as passes B and C have left them so far (2 bits a cell: two masks) */
 		uint64_t f_lo = 0, f_hi = 0;
 		if (own_row)
@@ -814,16 +806,20 @@ __global__ __launch_bounds__(MK_R) void k_low_marks(int16_t *__restrict__ yb, si
 				const uint32_t w = col < W ? *reinterpret_cast<const uint32_t *>(so + (size_t)r * W + col) : 0u;
 				for (int e = 0; e < 4; e++) { f_lo |= (uint64_t)((w >> (8 * e)) & 1) << (4 * d + e); f_hi |= (uint64_t)((w >> (8 * e + 1)) & 1) << (4 * d + e); }
 			}
-		__syncthreads();
-		const int16_t *kr = kt + (tid + 1) * MK_P - wb, *ku = kt + tid * MK_P - wb;     /* indexed by column */
+		const int16_t *kr = km + (size_t)r * W, *ku = km + (size_t)(r - 1) * W;        /* indexed by column: the few cells a fired rule looks at come from the plane */
 		int8_t *ow = own + tid * MK_BP - wb, *uw = upd + tid * MK_BP - wb;
 		MkMasks mk = { 0, 0, 0, 0, 0, 0, 0, 0 };
-		if (in_pic)
-			for (int d = 0; d < 32; d++) {
-				const uint32_t w = reinterpret_cast<const uint32_t *>(kt + (tid + 1) * MK_P)[d];
-				for (int h = 0; h < 2; h++) {
-					const int a = iabs_((int)(int16_t)(h ? w >> 16 : w & 0xFFFF));
-					const uint64_t bit = 1ull << (2 * d + h);
+		if (in_pic) {
+			uint4 nx = *reinterpret_cast<const uint4 *>(kr + wb);                       /* the next eight cells are on their way while these are sorted */
+#pragma unroll 1
+			for (int g = 0; g < 8; g++) {
+				const uint4 q4 = nx;
+				if (g < 7) nx = wb + 8 * (g + 1) < W ? *reinterpret_cast<const uint4 *>(kr + wb + 8 * (g + 1)) : make_uint4(0, 0, 0, 0);
+				const uint32_t w4[4] = { q4.x, q4.y, q4.z, q4.w };
+#pragma unroll
+				for (int e = 0; e < 8; e++) {
+					const int a = iabs_((int)(int16_t)((e & 1) ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xFFFF));
+					const uint64_t bit = 1ull << (8 * g + e);
 					if (a > sharp + 20) mk.strong |= bit;
 					if (a > half && a <= s2) mk.weak |= bit;
 					if (a <= s2) mk.small |= bit;
@@ -834,6 +830,7 @@ __global__ __launch_bounds__(MK_R) void k_low_marks(int16_t *__restrict__ yb, si
 					if (a > 4000) mk.big |= bit;
 				}
 			}
+		}
 		MkFx fx = { kr, ku, ow, uw, wb, 0, 0, 0, 0 };
 		if (walk_c) {
 			CMasks cm = { mk.strong, mk.weak, mk.small, 0 };
