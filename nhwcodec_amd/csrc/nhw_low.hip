@@ -937,46 +937,47 @@ DEVI void zero_below(int16_t *v, int lim) { if (iabs_(*v) < lim) *v = 0; }
  * between (:488-583) write the cell diagonally below and read it back in the next row: one raster walk each, on the scalar unit, every
  * cell's eight samples fetched in one go. */
 #define HITBIT(map, cell) atomicOr(&(map)[(cell) >> 5], 1u << ((cell) & 31))
-__global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, size_t plane_stride, int q)
+#define LL2_NT 256
+__global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb, size_t plane_stride, int q)
 {
 	__shared__ __attribute__((aligned(16))) int16_t ll[LS * LP + 8];
 	__shared__ uint32_t h32[LS * LS / 32], h34[LS * LS / 32], h36[LS * LS / 32], hsib[LS * LS / 32];
 	__shared__ int stale_hits;
 	int16_t *p = procb + (size_t)blockIdx.x * plane_stride;
-	const int lane = threadIdx.x;
+	const int tid = threadIdx.x, lane = tid & 63;                  /* four wavefronts: the row walks take a thread per row (128 rows), the clearing of children all 256; the two skewed raster walks stay one wavefront */
 
 	if (q <= 11) {
-		/* Y11 (:285-309): rows are independent, a lane walks two of them -- through LDS, 64 columns of all 128 rows at a time (a lane on
+		/* Y11 (:285-309): rows are independent, a thread walks one of them -- through LDS, 64 columns of all 128 rows at a time (a lane on
 		 * "its" row of the plane reads one cell of a different line at every step); what the walk carries from tile to tile is the
 		 * updated left neighbour. */
 		const int lim = q > 6 ? 10 : 11;
 		enum { TP = 68 };                                          /* tile pitch: columns c0-2 .. c0+65 as 34 dwords */
 		int16_t *tile = ll;                                        /* 128 x 68 shorts: the LL2 buffer is not in use yet */
-		int left[2] = { 0, 0 };
+		int left = 0;
 		for (int c0 = 0; c0 < H; c0 += 64) {
-			for (int k = lane; k < (H / 2) * (TP / 2); k += 64) {
+			for (int k = tid; k < (H / 2) * (TP / 2); k += LL2_NT) {
 				const int rr = k / (TP / 2), d = k % (TP / 2);
 				reinterpret_cast<uint32_t *>(tile + rr * TP)[d] = reinterpret_cast<const uint32_t *>(p + (size_t)(H / 2 + rr) * W + c0 - 2)[d];
 			}
 			__syncthreads();
-			for (int h = 0; h < 2; h++) {
-				int16_t *row = tile + (lane + 64 * h) * TP + 2 - c0;   /* row[j]: cell of column j */
-				if (!c0) left[h] = row[-1];                        /* the cell before the row in memory (never written by this pass) */
+			if (tid < H / 2) {
+				int16_t *row = tile + tid * TP + 2 - c0;               /* row[j]: cell of column j */
+				if (!c0) left = row[-1];                               /* the cell before the row in memory (never written by this pass) */
 				int cur = row[c0];
 				for (int j = c0; j < c0 + 64; j++) {
 					const int nxt = row[j + 1];
 					const int m = iabs_(cur);
 					int out = cur;
 					if (m >= DEADZONE && m < lim) {
-						const bool ql = iabs_(left[h]) < DEADZONE, qr = iabs_(nxt) < DEADZONE;
+						const bool ql = iabs_(left) < DEADZONE, qr = iabs_(nxt) < DEADZONE;
 						if ((ql && qr) || (m == DEADZONE && (ql || qr))) out = 0;
 					}
 					if (out != cur) row[j] = (int16_t)out;
-					left[h] = out; cur = nxt;
+					left = out; cur = nxt;
 				}
 			}
 			__syncthreads();
-			for (int k = lane; k < (H / 2) * 32; k += 64) {
+			for (int k = tid; k < (H / 2) * 32; k += LL2_NT) {
 				const int rr = k >> 5, d = 1 + (k & 31);
 				reinterpret_cast<uint32_t *>(p + (size_t)(H / 2 + rr) * W + c0 - 2)[d] = reinterpret_cast<const uint32_t *>(tile + rr * TP)[d];
 			}
@@ -984,12 +985,12 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 		}
 	}
 	if (q > 12) return;
-	for (int k = lane; k < LS * LS / 2; k += 64) {
+	for (int k = tid; k < LS * LS / 2; k += LL2_NT) {
 		const int r = k >> 6, c2 = (k & 63) * 2;
 		*reinterpret_cast<uint32_t *>(&ll[r * LP + c2]) = *reinterpret_cast<const uint32_t *>(p + (size_t)r * W + c2);
 	}
-	for (int k = lane; k < LS * LS / 32; k += 64) { h32[k] = 0; h34[k] = 0; h36[k] = 0; hsib[k] = 0; }
-	if (lane == 0) stale_hits = 0;
+	for (int k = tid; k < LS * LS / 32; k += LL2_NT) { h32[k] = 0; h34[k] = 0; h36[k] = 0; hsib[k] = 0; }
+	if (tid == 0) stale_hits = 0;
 	__syncthreads();
 
 	const uint8_t *t = k_ll2_thr[q];
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 	/* `last`: the reference's `count` variable as the third walk finds it (:571-579 use it without having set it when the inner test fails):
 	 * -1 = still IM_SIZE (no hit so far), otherwise an LL2 cell index */
 	int any1 = 0;
-	for (int r = lane; r < LS; r += 64) {                          /* five cells in a row (:383-486), in place along the row */
+	for (int r = tid; r < LS; r += LL2_NT) {                       /* five cells in a row (:383-486), in place along the row */
 		int16_t *row = ll + r * LP;
 		int v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
 		for (int j = 0; j < LS - 4; j++) {
@@ -1030,8 +1031,7 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 			v0 = v1; v1 = v2; v2 = v3; v3 = v4;
 		}
 	}
-	int last = __any(any1) ? 4 : -1;                              /* the inner loop counter's exit value: row 0, column 4 */
-	__syncthreads();
+	int last = __syncthreads_or(any1) ? 4 : -1;                   /* the inner loop counter's exit value: row 0, column 4 */
 	/* plus shape (+2, :488-533), then flat corner (+1, :535-583): two raster walks in which a hit at (r, j) rewrites cell (r+1, j+1).
 	 * Cell (r, j) reads rows r .. r+2 at columns j .. j+2: of what the walk has written before it gets there it sees (r+1, j) -- from its
 	 * own left neighbour -- and row r, written by row r-1's cells up to column j+1.  So the rows run as a skewed wavefront: lane l takes
@@ -1041,6 +1041,7 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 	 * a cell that passes only the outer test marks the target of the hit before it -- marked already -- or, before the first hit of the
 	 * second walk, what the first walk left: its last hit's target, else the 4 / IM_SIZE of the row pass above. */
 	int last0 = last;                                              /* `count` as the second walk finds it */
+	if (tid < 64)
 	for (int pass = 0; pass < 2; pass++) {
 		int hit_max = -1, hit_min = 1 << 30, outer_min = 1 << 30;    /* visiting positions r * LS + j */
 		for (int r0 = 0; r0 < LS - 2; r0 += 64) {
@@ -1084,19 +1085,19 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 	}
 	__syncthreads();
 	if (deep)
-		for (int r = lane; r < LS; r += 64) {                      /* three flat cells in a row (:585-620): reads only */
+		for (int r = tid; r < LS; r += LL2_NT) {                   /* three flat cells in a row (:585-620): reads only */
 			const int16_t *row = ll + r * LP;
 			for (int j = 0; j < LS - 2; j++)
 				if (iabs_(row[j + 2] - row[j + 1]) < t7 && iabs_(row[j + 2] - row[j]) < t7 && iabs_(row[j + 1] - row[j]) < t7) { HITBIT(h34, r * LS + j + 1); HITBIT(hsib, r * LS + j + 1); }
 		}
 	__syncthreads();
-	for (int k = lane; k < LS * LS / 2; k += 64) {                /* the smoothed LL2 band goes back */
+	for (int k = tid; k < LS * LS / 2; k += LL2_NT) {             /* the smoothed LL2 band goes back */
 		const int r = k >> 6, c2 = (k & 63) * 2;
 		*reinterpret_cast<uint32_t *>(p + (size_t)r * W + c2) = *reinterpret_cast<const uint32_t *>(&ll[r * LP + c2]);
 	}
 	/* the children / siblings of the cells that were hit are cleared where they are small.  All loads of a cell's up to fifteen targets
 	 * are issued before the first store (one memory round trip per cell instead of fifteen in a row: this loop was most of the kernel). */
-	for (int cell = lane; cell < LS * LS; cell += 64) {
+	for (int cell = tid; cell < LS * LS; cell += LL2_NT) {
 		const int w = cell >> 5;
 		const uint32_t bit = 1u << (cell & 31);
 		const int limc = (h36[w] & bit) ? 36 : (h34[w] & bit) ? 34 : (h32[w] & bit) ? 32 : 0;
@@ -1126,8 +1127,8 @@ __global__ __launch_bounds__(64) void k_low_ll2(int16_t *__restrict__ procb, siz
 		}
 		if (sib) { const int sl[3] = { 11, 12, 13 }; for (int k = 0; k < 3; k++) if (sv[k] && iabs_(sv[k]) < sl[k]) *sp[k] = 0; }
 	}
-	if (stale_hits && lane < 3) {                                  /* `count` still IM_SIZE: the "siblings" of plane cells 65535..65537 */
-		const int flat = Q - 1 + lane;
+	if (stale_hits && tid < 3) {                                  /* `count` still IM_SIZE: the "siblings" of plane cells 65535..65537 */
+		const int flat = Q - 1 + tid;
 		zero_below(p + flat + H / 2, 11); zero_below(p + flat + Q, 12); zero_below(p + flat + Q + H / 2, 13);
 	}
 }
@@ -1159,7 +1160,7 @@ void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipS
 
 void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s)
 {
-	k_low_ll2<<<n, 64, 0, s>>>(proc, plane_stride, q);
+	k_low_ll2<<<n, LL2_NT, 0, s>>>(proc, plane_stride, q);
 }
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
                               int q, int n, hipStream_t s)
