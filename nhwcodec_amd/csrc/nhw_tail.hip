@@ -7,7 +7,7 @@
 using namespace nhw;
 
 enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2,
-       PH_DQ1L, PH_DQ0L, PH_QL, PH_L4DL };   /* the last four: quality 1..16 forms (thread-per-row dequantiser simulation and quantiser, stand-alone stream gather) */
+       PH_QL, PH_L4DL };   /* the last two: quality 1..16 forms (row-per-thread quantiser, stand-alone stream gather) */
 
 template <int PH>
 __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status)
@@ -28,8 +28,6 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_L4C) luma_p4c_par(&c, tid, sh_pos, dyn_lds);
 	else if (PH == PH_L4D) luma_p4d_par(&c, tid, sh_counts, sh_z, dyn_lds);
 	else if (PH == PH_L4C2) luma_p4c2_par(&c, tid, reinterpret_cast<unsigned *>(sh_z), sh_pos);
-	else if (PH == PH_DQ1L) dequant_sim_luma_par(&c, 1, tid, sh_pos);
-	else if (PH == PH_DQ0L) dequant_sim_luma_par(&c, 0, tid, sh_pos);
 	else if (PH == PH_QL) { PROF_BEGIN(); quantise_luma_low_par(&c, tid, sh_z, reinterpret_cast<uint8_t *>(sh_pos), dyn_lds); if (!tid) PROF(&c, 15); }
 	else if (PH == PH_L4DL) { PROF_BEGIN(); scan_and_rewrite_par(&c, tid, sh_counts, sh_z, dyn_lds, false); if (!tid) PROF(&c, 17); }
 	else if (PH == PH_LLC) { PROF_BEGIN(); ll_code_chroma_par(&c, tid, reinterpret_cast<uint8_t *>(dyn_lds)); if (!tid) PROF(&c, 18); }
@@ -123,8 +121,6 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 	case PH_L4D: k_phase<PH_L4D><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_LLC: k_phase<PH_LLC><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4C2: k_phase<PH_L4C2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
-	case PH_DQ1L: k_phase<PH_DQ1L><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
-	case PH_DQ0L: k_phase<PH_DQ0L><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_QL: k_phase<PH_QL><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4DL: k_phase<PH_L4DL><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C0: k_phase<PH_C0><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;

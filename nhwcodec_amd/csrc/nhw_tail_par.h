@@ -260,14 +260,7 @@ DEV void precompensate_ll1_par(Ctx *c, int tid, int16_t *lds)
 }
 
 /* ---------------------------------------------------------------- a8 dequantisation simulation */
-DEV void mark_pairs_row(int16_t *p, int r, int col0)
-{
-	for (int j = col0; j < H - 1; j++) {
-		const int a = r * W + j;
-		if (is_567(p[a])) { if (is_567(p[a + 1])) { p[a] = 15700; j++; } }
-		else if (is_m567(p[a])) { if (is_m567(p[a + 1])) { p[a] = 15800; j++; } }
-	}
-}
+/* (the dequantiser simulation itself is a wavefront-per-image kernel for every quality: nhw_tail_wave.h) */
 /* q<=16: negative magnitudes keep their low bits only on a ration: of the 15s in a row every sixth is floored to 8, of the
  * x7 above 22 every fourth (image_processing.c:2938-2989, :357-410); everything else is floored */
 DEV int ration_low_bits(int a, int &n15, int &nx7, int mask)
@@ -276,198 +269,6 @@ DEV int ration_low_bits(int a, int &n15, int &nx7, int mask)
 	else if (a > 22 && (a & 7) == 7) { if (!nx7) a &= mask; nx7 = (nx7 + 1) & 3; }
 	else a &= mask;
 	return a;
-}
-DEV void dequant_row(int16_t *p, int16_t *jp, int r, int col0, int part, int q)
-{
-	int n15 = 0, nx7 = 0;
-	for (int j = col0; j < H; j++) {
-		const int at = r * W + j;
-		int a = p[at];
-		if (a > 15000) {
-			if (a == 15300) { jp[at] = 5; j += 2; }
-			else if (a == 15400) { jp[at] = -5; j += 2; }
-			else if (a == 15500) { jp[at] = 5; j++; }
-			else if (a == 15600) { jp[at] = -5; j++; }
-			else if (a == 15700) { jp[at] = 6; jp[at + 1] = 6; j++; }
-			else if (a == 15800) { jp[at] = -6; jp[at + 1] = -6; j++; }
-			continue;
-		}
-		if (a < -12 && ((-a) & 7) == 6) { if (j < H - 1 && p[at + 1] == -7) p[at + 1] = -8; }
-		if (a < 0) {
-			if (a == -7 && j < H - 1 && p[at + 1] == 8) { p[at] = -8; a = -8; }
-			a = -a;
-			if (q <= 16) a = ration_low_bits(a, n15, nx7, 0xFFF8);
-			else if ((a & 7) < 7) a &= 0xFFF8;
-			a = -a;
-		}
-		else if (a == 8 && j < H - 1 && p[at + 1] == -7) p[at + 1] = -8;
-		else if (a > 12 && !part && (a & 7) >= 6) { if (j < H - 1 && p[at + 1] == 7) p[at + 1] = 8; }
-		jp[at] = (int16_t)dequant_value(a);
-	}
-}
-
-/* ---------------------------------------------------------------- skewed row wavefront for the raster-serial passes */
-/* Three passes write into the row below while they walk a row (triple / vertical-pair marking in the dequantiser
- * simulation and in the quantiser, the LL2 walks that bump the sample below).  In raster order row r+1 starts
- * after row r has finished; all that row r+1 needs at column j, though, is that row r is done with columns
- * <= j+2 (row r writes (r+1, x-1), (r+1, x) at column x, resp. (r+1, x)), and row r at column x only reads row
- * r+1 at columns >= x-1, which a row lagging >= 3 columns has not touched yet.  So one thread per row, each row
- * keeps >= 3 columns behind the row above, all rows advance together: ~(columns + 3 x rows) steps instead of
- * rows x columns.  Steps are separated by workgroup barriers (global writes of a step are visible to the
- * other rows in the next one). */
-#define WF_INF 0x3fffffff
-template <typename Step>
-DEV void wavefront_rows(int nrows, int tid, int *pos /* shared [NT + 1] */, Step step)
-{
-	const int r = tid;
-	int j = r < nrows ? step.first(r) : WF_INF;
-	const int jend = r < nrows ? step.last(r) : 0;
-	if (j >= jend) j = WF_INF;
-	if (tid == 0) pos[0] = WF_INF;
-	pos[r + 1] = j;
-	BARRIER();
-	for (;;) {
-		if (j != WF_INF && pos[r] >= j + 3) { j = step.run(r, j); if (j >= jend) j = WF_INF; }
-		BARRIER();
-		pos[r + 1] = j;
-		if (!__syncthreads_or(j != WF_INF)) break;
-	}
-}
-
-/* dequantiser simulation: triple / vertical pair marking (image_processing.c:2759-2853), rows 0..254 */
-struct MarkRunsStep {
-	int16_t *p, *jp;
-	__device__ int first(int r) const { return r < H / 2 ? H / 2 + 1 : 1; }
-	__device__ int last(int) const { return H - 1; }
-	__device__ int run(int r, int j) const
-	{
-		const int a = r * W + j;
-		if (p[a] > 3 && p[a] < 8) {
-			if (in_4_7(p[a - 1])) {
-				if (in_4_7(p[a + 1])) { p[a - 1] = 15300; p[a] = 0; jp[a] = 5; jp[a + 1] = 5; j++; }
-				else if (in_4_7(p[a + W - 1]) && in_4_7(p[a + W])) { p[a - 1] = 15500; jp[a] = 5; p[a + W - 1] = 15500; jp[a + W] = 5; p[a + W] = 0; j++; }
-			}
-		} else if (p[a] < -3 && p[a] > -8) {
-			if (in_m7_m4(p[a - 1])) {
-				if (in_m7_m4(p[a + 1])) { p[a - 1] = 15400; p[a] = 0; jp[a] = -6; jp[a + 1] = -5; j++; }
-				else if (in_m7_m4(p[a + W - 1]) && in_m7_m4(p[a + W])) { p[a - 1] = 15600; jp[a] = -5; p[a + W - 1] = 15600; jp[a + W] = -5; p[a + W] = 0; j++; }
-			}
-		}
-		return j + 1;
-	}
-};
-
-
-/* the LL2 walk shared by the dequantiser simulation (image_processing.c:2642-2695) and the LL2 emission
- * (nhw_encoder.c:661-741): three odd samples in a row bump the middle one, an odd L-shaped group bumps the
- * sample below.  EMIT: also park the sample value for the output pass and clear the cell. */
-template <int EMIT>
-struct LL2Step {
-	int16_t *p, *jp, *park;
-	int q, part;
-	__device__ int first(int) const { return 0; }
-	__device__ int last(int) const { return H / 2; }
-	__device__ int run(int r, int j) const
-	{
-		const int a = r * W + j;
-		const int s = p[a];
-		bool tagged = false;
-		if (EMIT) tagged = q > 17 && s > 10000;
-		else if (s > 10000) {
-			if (!part) jp[a] = p[a];
-			else {
-				p[a] -= 16000; jp[a] = p[a];
-				jp[a + 1] = (p[a + 1] > 0 && p[a + 1] < 256) ? clear_bit0(p[a + 1]) : p[a + 1];
-				j++;
-			}
-			return j + 1;
-		}
-		if (!tagged) {
-			if (odd(s) && j > 0 && odd(p[a + 1])) {
-				if (j < H / 2 - 2 && odd(p[a + 2])) { if (iabs(s - p[a + 2]) > 1 && q > 17) p[a + 1]++; }
-				else if (r * W < Q - W - 2 && odd(p[a + W]) && odd(p[a + W + 1]) && !(p[a + W + 2] & 1)) { if (p[a + W] < 10000 && q > 17) p[a + W]++; }
-			}
-			else if (odd(s) && r >= 1 && r * W < Q - 3 * W) {
-				if (odd(p[a + W]) && odd(p[a + W + 1]) && odd(p[a + 2 * W]) && !(p[a + 3 * W] & 1)) { if (p[a + W] < 10000 && q > 17) p[a + W]++; }
-			}
-		}
-		if (EMIT) { park[r * (H / 2) + j] = (int16_t)s; p[a] = 0; }
-		else if (part) jp[a] = (p[a] > 0 && p[a] < 256) ? clear_bit0(p[a]) : p[a];
-		return j + 1;
-	}
-};
-
-/* offsetY_recons256 (image_processing.c:2600-3190).  Raster-serial pieces (the LL2 walk that bumps the sample
- * below, the triple / vertical-pair marking that writes into the next row) stay on thread 0; everything whose
- * reach is one row runs one row per thread; the isolated-coefficient shrink is pointwise: a coefficient >= 8
- * next to another one >= 8 keeps both from shrinking, so decisions taken on the untouched plane equal the
- * reference's raster-order decisions. */
-DEV void dequant_sim_luma_par(Ctx *c, int part, int tid, int *pos)
-{
-	int16_t *p = c->proc, *jp = c->jpeg;
-	const int q = c->q;
-
-	if (q > 17 && tid < H / 2) {                       /* :2609-2640 four odd LL2 samples in a row (R) */
-		const int r = tid;
-		for (int j = 0; j < H / 2 - 3; j++) {
-			const int a = r * W + j;
-			if (odd(p[a]) && odd(p[a + 1]) && odd(p[a + 2]) && odd(p[a + 3]) && iabs(p[a] - p[a + 3]) > 1) {
-				if (!part) { p[a] += 16000; p[a + 1] += 16000; p[a + 2] += 16000; p[a + 3] += 16000; }
-				else { p[a] += 16000; p[a + 2] += 16000; }
-				j += 3;
-			}
-		}
-	}
-	BARRIER();
-	{                                                  /* :2642-2695 (wavefront) */
-		LL2Step<0> st = { p, jp, nullptr, q, part };
-		wavefront_rows(H / 2, tid, pos, st);
-	}
-	BARRIER();
-	if (!part) {                                       /* :2697-2735 (P) */
-		int16_t *tmp = c->tmp16;
-		for (int idx = tid; idx < Q / 4; idx += NT) {
-			const int a = (idx >> 7) * W + (idx & 127);
-			if (p[a] < 10000) { tmp[idx] = p[a]; jp[a] = (p[a] >= 0 && p[a] < 256) ? clear_bit0(p[a]) : p[a]; }
-			else { p[a] -= 16000; tmp[idx] = p[a]; jp[a] = p[a]; }
-		}
-		BARRIER();
-		const int nm = c->m->ll_mem_len;
-		for (int i = tid; i < nm; i += NT) {
-			const int idx = c->ll_mem[i];
-			jp[((idx >> 7) << 9) + (idx & 127)] = tmp[idx];
-		}
-		BARRIER();
-	}
-	if (q > 16) {                                      /* :2759-2853 (wavefront) */
-		MarkRunsStep st = { p, jp };
-		wavefront_rows(H - 1, tid, pos, st);
-	}
-	BARRIER();
-	{
-		const int r = tid, col0 = r < H / 2 ? H / 2 : 0;
-		if (!part && q > 16) mark_pairs_row(p, r, col0); /* :2857-2905 (R) */
-		dequant_row(p, jp, r, col0, part, q);            /* :2909-3124 (R) */
-	}
-	BARRIER();
-	if (!part) {                                       /* :3135-3188; q<=16 lets diagonal neighbours up to 15 pass */
-		const int r = tid, diag = q <= 16 ? 16 : 8;
-		uint32_t hit[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-		if (r >= 1 && r < H - 1)
-			for (int j = 1; j < H - 1; j++) {
-				const int e = r * W + j;
-				if (iabs(jp[e]) >= 8 && (r >= H / 2 || j >= H / 2)) {
-					if (iabs(jp[e - W - 1]) >= diag || iabs(jp[e - W]) >= 8 || iabs(jp[e - W + 1]) >= diag ||
-					    iabs(jp[e - 1]) >= 8 || iabs(jp[e + 1]) >= 8 ||
-					    iabs(jp[e + W - 1]) >= diag || iabs(jp[e + W]) >= 8 || iabs(jp[e + W + 1]) >= diag) continue;
-					hit[j >> 5] |= 1u << (j & 31);
-				}
-			}
-		BARRIER();
-		for (int j = 1; j < H - 1; j++)
-			if (hit[j >> 5] & (1u << (j & 31))) { const int e = r * W + j; if (jp[e] > 0) jp[e]--; else jp[e]++; }
-	}
-	BARRIER();
 }
 
 /* ---------------------------------------------------------------- Y21 (R) */

@@ -304,6 +304,7 @@ DEV unsigned bs_range(int lo, int hi, int lane)
 DEV void wave_dequant_details(Ctx *c, int part, int lane)
 {
 	int16_t *p = c->proc, *jp = c->jpeg;
+	const bool hq = c->q > 16;                                     /* quality 1..16: no triple / pair marking, and negative magnitudes keep their low bits on a ration (:2938-2989) */
 	int cur[4], nxt[4], pend_v[4] = { 0, 0, 0, 0 };
 	unsigned pend = 0;                                             /* jp cells of the current row the row above has set (bit-sliced, like every row mask in here) */
 	int q0[4], q1[4], q2[4];                                       /* rows r+2 .. r+4, already on their way (a row step is shorter than a memory round trip) */
@@ -324,7 +325,7 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 		int jv[4] = { pend_v[0], pend_v[1], pend_v[2], pend_v[3] };
 		unsigned je = pend;
 		pend = 0;
-		if (r < H - 1) {                                           /* :2759-2853 */
+		if (hq && r < H - 1) {                                     /* :2759-2853 (quality 17 and up) */
 			unsigned P, N, PN, NN;
 			BS_PREDK(P, cur, K0, x > 3 && x < 8); BS_PREDK(N, cur, K0, x < -3 && x > -8);
 			BS_PREDK(PN, nxt, K0, x > 3 && x < 8); BS_PREDK(NN, nxt, K0, x < -3 && x > -8);
@@ -356,7 +357,7 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 				pend = fv;
 			}
 		}
-		if (!part) {                                               /* :2857-2905 */
+		if (!part && hq) {                                         /* :2857-2905 (quality 17 and up) */
 			unsigned A, B;
 			BS_PREDK(A, cur, K0, x >= 5 && x <= 7); BS_PREDK(B, cur, K0, x <= -5 && x >= -7);
 			const unsigned cand = ((A & DN(A)) | (B & DN(B))) & bs_range(col0, H - 2, lane);
@@ -414,6 +415,28 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 			for (int k = K0; k < 4; k++) {
 				if (BIT(m8, k)) cur[k] = -8;
 				if (BIT(to_8, k)) cur[k] = 8;
+			}
+			/* quality 1..16: of the -15 the walk meets in a row every sixth is floored to -8 (the first, the seventh ..), of the -x7 below -22
+			 * every fourth; all other negative values are floored (ration_low_bits in the row-per-thread form: counters that start at 0 in
+			 * every row).  The count a cell finds is its rank among the row's cells of its kind: ballots and popcounts. */
+			unsigned keep_low = 0;                                  /* visited negative cells that keep their low bits */
+			if (!hq) {
+				unsigned b15, bx7;
+				BS_PREDK(b15, cur, K0, x == -15); BS_PREDK(bx7, cur, K0, x < -22 && ((-x) & 7) == 7);
+				b15 &= vnc; bx7 &= vnc;
+				if (__any((b15 | bx7) != 0)) {
+					const M4 m15 = bs_ballot4(b15), mx7 = bs_ballot4(bx7);
+					const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+					int base15 = 0, basex7 = 0;
+					for (int k = 0; k < 4; k++) {
+						const int r15 = base15 + __builtin_popcountll(m15.w[k] & below), rx7 = basex7 + __builtin_popcountll(mx7.w[k] & below);
+						if (BIT(b15, k) && r15 % 6 != 0) keep_low |= 1u << k;
+						if (BIT(bx7, k) && (rx7 & 3) != 0) keep_low |= 1u << k;
+						base15 += __builtin_popcountll(m15.w[k]); basex7 += __builtin_popcountll(mx7.w[k]);
+					}
+				}
+			}
+			for (int k = K0; k < 4; k++) {
 				if (BIT(part_p, k)) jv[k] = 6;
 				if (BIT(part_n, k)) jv[k] = -6;
 				if (BIT(vc, k)) {
@@ -425,7 +448,7 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 				}
 				if (BIT(vnc, k)) {
 					int a = cur[k];
-					if (a < 0) { a = -a; if ((a & 7) < 7) a &= 0xFFF8; a = -a; }
+					if (a < 0) { a = -a; if (hq ? (a & 7) < 7 : !BIT(keep_low, k)) a &= 0xFFF8; a = -a; }
 					jv[k] = dequant_value(a);
 				}
 			}
@@ -454,27 +477,31 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 DEV void wave_shrink(Ctx *c, int lane)
 {
 	int16_t *jp = c->jpeg;
+	const int diag = c->q <= 16 ? 16 : 8;                          /* quality 1..16 lets diagonal neighbours up to 15 pass (:3135-3188) */
 	int jc[4], jn[4];
 	unsigned bp, bc, bn;                                           /* ">= 8" of rows r-1, r, r+1, bit-sliced (bit k = column lane + 64k) */
+	unsigned dp, dn_;                                              /* ">= diag" of rows r-1, r+1 */
 	for (int k = 0; k < 4; k++) { jn[k] = jp[lane + 64 * k]; jc[k] = jp[W + lane + 64 * k]; }
-	BS_PRED(bp, jn, 4, iabs(x) >= 8);
+	BS_PRED(bp, jn, 4, iabs(x) >= 8); BS_PRED(dp, jn, 4, iabs(x) >= diag);
 	BS_PRED(bc, jc, 4, iabs(x) >= 8);
+	unsigned dc_;                                                  /* ">= diag" of row r (becomes dp of the next step) */
+	BS_PRED(dc_, jc, 4, iabs(x) >= diag);
 	for (int k = 0; k < 4; k++) jn[k] = jp[2 * W + lane + 64 * k];
-	BS_PRED(bn, jn, 4, iabs(x) >= 8);
+	BS_PRED(bn, jn, 4, iabs(x) >= 8); BS_PRED(dn_, jn, 4, iabs(x) >= diag);
 	const unsigned inner = bs_range(1, H - 2, lane), right = bs_range(H / 2, H - 2, lane);
 	int g0[4], g1[4];                                              /* rows r+2, r+3 in flight */
 	for (int k = 0; k < 4; k++) { g0[k] = jp[3 * W + lane + 64 * k]; g1[k] = jp[4 * W + lane + 64 * k]; }
 	for (int r = 1; r < H - 1; r++) {
 		int jf[4] = { 0, 0, 0, 0 };
 		if (r + 4 < H) for (int k = 0; k < 4; k++) jf[k] = jp[(r + 4) * W + lane + 64 * k];
-		const unsigned side = bp | bc | bn;                           /* a neighbour column with any of its three rows set */
+		const unsigned side = bc | dp | dn_;                          /* a neighbour column: its cell of this row at 8 or more, or one of its two diagonal cells at `diag` or more */
 		const unsigned near = bs_up<4>(side, lane) | bs_dn(side, lane) | bp | bn;
 		const unsigned hit = bc & ~near & (r >= H / 2 ? inner : right);
 		for (int k = 0; k < 4; k++)
 			if ((hit >> k) & 1u) jp[r * W + lane + 64 * k] = (int16_t)(jc[k] > 0 ? jc[k] - 1 : jc[k] + 1);
-		bp = bc; bc = bn;
+		bp = bc; bc = bn; dp = dc_; dc_ = dn_;
 		for (int k = 0; k < 4; k++) { jc[k] = jn[k]; jn[k] = g0[k]; g0[k] = g1[k]; g1[k] = jf[k]; }
-		BS_PRED(bn, jn, 4, iabs(x) >= 8);
+		BS_PRED(bn, jn, 4, iabs(x) >= 8); BS_PRED(dn_, jn, 4, iabs(x) >= diag);
 	}
 }
 

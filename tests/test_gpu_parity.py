@@ -508,6 +508,43 @@ def test_tail_stages_match_the_oracle_trace(oracle, q):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("q", [1, 10, 13, 16])
+def test_low_quality_stages_match_the_oracle_trace(oracle, q):
+    """The same walk for the quality 1..16 forms: colour, the rationed pre-filter, both filter banks of both closed loops (where the quality
+    has them), both dequantiser simulations (offsetY_recons256 with the rationed low bits), Y11/Y12 (through the analysis that follows
+    them), the quantiser's plane, and both chroma sequences with pre_processing_UV -- stage by stage against the oracle's checkpoints
+    (the stage plan is the developer tool's, tests/gpu_low_debug.py)."""
+    import torch
+    import nhwcodec_amd
+    from tests.gpu_low_debug import B, plan_for, read
+    seeds = (0, 1)
+    e = nhwcodec_amd.Encoder(0, max_batch=len(seeds))
+    imgs = np.stack([oracle.synth(s) for s in seeds])
+    d_in = torch.from_numpy(imgs).cuda()
+    traces = [oracle.encode(imgs[i], q, trace=True) for i in range(len(seeds))]
+    try:
+        for st, nm, k, bufs in plan_for(q):
+            e.lib.nhw_debug_stop_after(e.h, st)
+            e.encode_device(d_in, q)
+            torch.cuda.synchronize()
+            for i in range(len(seeds)):
+                recs = [b for n, b in traces[i][1] if n == nm]
+                for bname, bi, nbytes, corner in bufs:
+                    g, w = read(e, B[bname], i, nbytes), recs[k][bi]
+                    dt = np.uint8 if bname in ("PU", "PV") else np.int16
+                    ga, wa = np.frombuffer(g, dt), np.frombuffer(w, dt)
+                    if corner:
+                        ga, wa = ga.reshape(512, 512)[:corner, :corner], wa.reshape(512, 512)[:corner, :corner]
+                    bad = np.argwhere(ga != wa)
+                    assert bad.size == 0, f"q{q} stage {st} ({nm} #{k}) image {i} plane {bname}: {len(bad)} cells differ, first {bad[0].tolist()}"
+    finally:
+        e.lib.nhw_debug_stop_after(e.h, 0)
+    got = e.encode(imgs, q)
+    assert [g == t[0] for g, t in zip(got, traces)] == [True] * len(seeds)
+    e.close()
+
+
+@pytest.mark.gpu
 def test_synthetic_entry_point_and_device_count(oracle):
     """nhw_enc_synth_batch (what `nhw-enc --synthetic` calls): generator seeds in, the oracle's files for those seeds out; nhw_device_count
     sees the GPU the suite runs on."""
