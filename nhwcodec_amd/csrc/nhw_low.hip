@@ -60,18 +60,11 @@ DEVI PfP pf_params(int q)
 struct MapState { int carry, neg_run, neg_cycle, pos_run, pos_cycle, pos_alt, pos_neg_alt, exact_count, bump_count; };
 
 /* The carry itself (4 bits, reset where the sum is zero) is the machine the quality 17..21 pre-filter has too: its past is forgotten within
- * a dozen pixels, so every lane finds the entry state of its 8 pixels by running all 16 states through the 12 pixels before them (one
- * SWAR step per pixel on two 64-bit words) and replays its own 8 -- no walk along the row.  What IS order-dependent below quality 17 is
- * the marker rule: it fires only on borderline pixels (sum not above the threshold, carried value above it), on the first three values
+ * a dozen pixels, so every lane finds the entry state of its 8 pixels by running the candidate states through the 16 pixels before them
+ * (after one step only five neighbouring states are left: 5-bit fields of one dword) and replays its own 8 -- no walk along the row.
+ * What IS order-dependent below quality 17 is the marker rule: it fires only on borderline pixels (sum not above the threshold, carried value above it), on the first three values
  * that hit the threshold from below and on the first value of threshold + 21; those few pixels are visited in raster order by the lane
  * that owns the image in the serial phases (map_cell), everything else is written by the lanes that computed it. */
-DEVI void fsm_step16(uint64_t &m0, uint64_t &m1, int vb)
-{
-	if (vb == 0) { m0 = 0; m1 = 0; return; }
-	const uint64_t add = (uint64_t)(iabs_(vb) & 15) * 0x0101010101010101ull;
-	m0 = ((((m0 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
-	m1 = ((((m1 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
-}
 /* one pixel of pass A behind the carry: sm = its 8-neighbour sum (non-zero), val = the signed carried value; k = the map row, c its column */
 DEVI void map_cell(MapState &s, const PfP &pp, int c, int sm, int val, int16_t *k)
 {
@@ -501,11 +494,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				carry = row_carry;
 				for (int c = 1; c < c0; c++) { const int vb = s_vb[c]; carry = vb == 0 ? 0 : ((iabs_(vb) + ((carry + 2) >> 2)) & 15); }
 			} else {
-				uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull;
-				for (int c = c0 - PF_LOOK; c < c0; c++) fsm_step16(m0, m1, s_vb[c]);
-				const uint64_t bb = (m0 & 0xFF) * 0x0101010101010101ull;
-				merged = m0 == bb && m1 == bb;
-				carry = (int)(m0 & 15);
+				/* one step maps all 16 states onto the five (|v| + 0..4) & 15, so five candidates are all there is to follow: 5-bit fields of
+				 * one dword (a field's c + 2 and |v| + 4 stay below 32), every step a handful of whole-dword operations */
+				const uint32_t R = 0x108421u;                           /* 1 in each field */
+				const int v0 = s_vb[c0 - PF_LOOK];
+				uint32_t x = v0 == 0 ? 0u : ((((uint32_t)iabs_(v0) & 15u) * R + 0x418820u) & (15u * R));
+				for (int c = c0 - PF_LOOK + 1; c < c0; c++) {
+					const int vb = s_vb[c];
+					const uint32_t nx = (((uint32_t)iabs_(vb) & 15u) * R + (((x + 2u * R) >> 2) & (7u * R))) & (15u * R);
+					x = vb == 0 ? 0u : nx;
+				}
+				merged = x == (x & 31u) * R;
+				carry = (int)(x & 15u);
 			}
 			int valv[8];
 			for (int e = 0; e < 8; e++) {

@@ -498,34 +498,35 @@ DEVI int burst_commit(PfM &m, const PfC &c, const PfBurstMasks &k, int avail, HI
 template <class HITS>
 DEVI int burst_commit_quiet(PfM &m, const PfC &c, unsigned cap, unsigned wrap, unsigned win, unsigned cyc, unsigned i6, int avail, HITS hits_to)
 {
+	/* one decision, one exit: everything that can stop the burst goes into `bad` first (the compiler keeps the counters where they are
+	 * instead of shuffling them at every early return) */
 	const unsigned endm = cap | wrap;
 	const int e_ = endm ? __builtin_ctz(endm) : 32;
 	const int open = e_ >= avail;
-	if (open && avail > 24) return 0;
 	const int e = open ? avail - 1 : e_;
-	const unsigned upto = 0xFFFFFFFFu >> (31 - e);                      /* bits 0 .. e */
-	const int cap_end = open ? 0 : (int)((cap >> e) & 1);
-	if (win & ~cyc & upto) return 0;
+	const unsigned upto = 0xFFFFFFFFu >> ((31 - e) & 31);               /* bits 0 .. e */
+	const int cap_end = open ? 0 : (int)((cap >> (e & 31)) & 1);
 	const unsigned cy = cyc & upto;
-	const int t18 = T(18), v = T(44);
-	int n18 = t18;
-	if (cy) { const int ncyc = __builtin_popcount(cy); if (t18 == 0 || ncyc > 16 - t18) return 0; n18 = (t18 + ncyc) & 15; }
-	if (c.w8z && (i6 & (cap_end ? upto >> 1 : upto))) return 0;         /* the idle pairs: all of them, or all but the last */
-	if (cap_end & c.capB) return 0;                                     /* (capA needs t29 > 0 and t14 == 4: the gate would be open) */
+	const int ncyc = __builtin_popcount(cy), t18 = T(18), v = T(44);
+	int bad = open & (avail > 24);
+	bad |= (win & ~cyc & upto) != 0;
+	bad |= (ncyc != 0) & ((t18 == 0) | (ncyc > 16 - t18));
+	bad |= c.w8z & ((i6 & (cap_end ? upto >> 1 : upto)) != 0);          /* the idle pairs: all of them, or all but the last */
+	bad |= cap_end & c.capB;                                            /* (capA needs t29 > 0 and t14 == 4: the gate would be open) */
+	if (bad) return 0;
 	const int dh = hits_to(e);
-	T(18) = n18;
+	const int t4e = T(4) + dh;
+	const int done = !open;                                             /* the burst ended: its cap or its wrap */
+	const int zero_hit_cap = cap_end & (t4e == 0), hit_cap = cap_end & (t4e != 0);
+	T(18) = (t18 + ncyc) & 15;
 	T(17) = 0;
-	if (open) {
-		T(1) += dh + 3 * ((v + e + 1) >> 2);
-		T(4) += dh;
-		T(44) = (v + e + 1) & 3;
-		return e + 1;
-	}
-	if (cap_end) {
-		if (T(4) + dh == 0) T(8)++; else { T(8) = 0; T(5) = 0; T(12) = 0; }
-		T(44) = (v + e) & 3;
-	} else T(44) = 0;
-	T(29)++; T(1) = 0; T(4) = 0;
+	T(8) = hit_cap ? 0 : T(8) + zero_hit_cap;
+	T(5) = hit_cap ? 0 : T(5);
+	T(12) = hit_cap ? 0 : T(12);
+	T(44) = open ? (v + e + 1) & 3 : (cap_end ? (v + e) & 3 : 0);
+	T(29) += done;
+	T(1) = done ? 0 : T(1) + dh + 3 * ((v + e + 1) >> 2);
+	T(4) = done ? 0 : t4e;
 	return e + 1;
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): kernel stats (two streams and one stream) and the HBM counters of one bench command, summaries under
-# gpurun_out/r2/.  usage: bash profiles/collect.sh <tag> <commit>      (counters in their own passes: FETCH_SIZE and WRITE_SIZE do not fit one)
+# gpurun_out/<tag>/.  usage: bash profiles/collect.sh <tag> <commit>      (counters in their own passes: FETCH_SIZE and WRITE_SIZE do not fit one)
 set -u
 TAG=${1:-r2}; COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -1,13 +1,13 @@
 """Regenerates the kernel table of DESIGN.md (between the KERNEL_TABLE markers) from the committed profile summaries, so that the numbers
 cannot drift from the files they cite.   usage: python profiles/make_design_table.py [--check]
-inputs: profiles/round2_kernel_stats_1stream.txt (rocprofv3 --kernel-trace --stats, one stream), profiles/round2_pmc.json (FETCH_SIZE and
+inputs: profiles/round3_kernel_stats_1stream.txt (rocprofv3 --kernel-trace --stats, one stream), profiles/round3_pmc.json (FETCH_SIZE and
 WRITE_SIZE per kernel from separate --pmc passes; KiB; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STATS = os.path.join(ROOT, "profiles", "round2_kernel_stats_1stream.txt")
-PMC = os.path.join(ROOT, "profiles", "round2_pmc.json")
+STATS = os.path.join(ROOT, "profiles", "round3_kernel_stats_1stream.txt")
+PMC = os.path.join(ROOT, "profiles", "round3_pmc.json")
 BATCHES = 7.0            # bench.py --steps 5 --warmup 2 in profiles/collect.sh
-PH = ["L1", "L2", "L3", "L4A", "C0", "C2", "C3", "C4", "C5", "FINAL", "L4B", "L4C", "L4D", "LLC", "L4C2", "DQ1L", "DQ0L", "QL", "L4DL"]
+PH = ["L1", "L2", "L3", "L4A", "C0", "C2", "C3", "C4", "C5", "FINAL", "L4B", "L4C", "L4D", "LLC", "L4C2", "QL", "L4DL"]
 WV = ["DQ1", "DQ0", "EMIT", "QUANT"]
 WHAT = {
     "k_front_band": "a1 + a2 + Y2 + Y3 fused: BGR24 -> Y, 4:2:0 chroma planes out, pre-filter, both directions of the level-1 analysis, LL copy (16 output rows, 512 threads, 80 KB LDS per workgroup)",
