@@ -337,6 +337,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive leg (host buffers through nhw_enc_batch) reported next to the metric")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (BASELINE config 5) reported next to the encode metric")
+    ap.add_argument("--no-chroma-l1", action="store_true", help="skip the separate timing of the two chroma level-1 launches (roofline.frac_incl_chroma_l1); the profile scripts use it so that kernel tables hold the encoder's own launches only")
     ap.add_argument("--dry", action="store_true", help="CPU only: rendezvous over gloo, descriptor broadcast, sharding, gather -- no encode (tests of the N>1 plumbing)")
     args = ap.parse_args()
 
@@ -495,7 +496,7 @@ def main():
         front_images = tim.front_images or batch      # the batch runs as `parts` sub-batches on their own streams; the events bracket the first one's launch group
         achieved = front_images * FRONT_BYTES_PER_IMAGE / front_s / 1e9
         traffic, traffic_note = front_traffic(q, front_images)
-        cl1 = chroma_l1_ms(enc, front_images) if q >= 17 else None
+        cl1 = chroma_l1_ms(enc, front_images) if (q >= 17 and not args.no_chroma_l1) else None
         line = {
             "metric": "encode Mpixels/s (512x512 RGB batch)", "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),

@@ -29,7 +29,7 @@ void nhw_launch_front_stale(const int16_t *y, size_t y_stride, const uint8_t *st
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s);
 enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
-enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2, PH_QL, PH_L4DL };
+enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2, PH_QL };
 /* quality 1..16 only (nhw_low.hip) */
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
                               int q, int n, hipStream_t s);
@@ -299,7 +299,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, cs);   /* Z1: the chroma LL2 coder appends to the luma one's output (Y16, long done) */
 		HIPCHK(hipEventRecord(e->part_ev[1], cs));
 	}
-	nhw_launch_phase(low ? PH_L4DL : PH_L4D, ws, 0, out, d_sizes, d_status, s);      /* Y30, Y31 */
+	nhw_launch_phase(PH_L4D, ws, 0, out, d_sizes, d_status, s);      /* Y31 (Y30, the stream order, is the quantisers' output order) */
 	STAGE_DONE();
 	if (timed) HIPCHK(hipEventRecord(e->ev[2], s));
 

@@ -7,7 +7,7 @@
 using namespace nhw;
 
 enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2,
-       PH_QL, PH_L4DL };   /* the last two: quality 1..16 forms (row-per-thread quantiser, stand-alone stream gather) */
+       PH_QL };   /* the last: the quantiser of quality 1..16 (row per thread on LDS tiles; writes the symbol stream like the wavefront form of 17..23) */
 
 template <int PH>
 __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status)
@@ -29,7 +29,6 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_L4D) luma_p4d_par(&c, tid, sh_counts, sh_z, dyn_lds);
 	else if (PH == PH_L4C2) luma_p4c2_par(&c, tid, reinterpret_cast<unsigned *>(sh_z), sh_pos);
 	else if (PH == PH_QL) { PROF_BEGIN(); quantise_luma_low_par(&c, tid, sh_z, reinterpret_cast<uint8_t *>(sh_pos), dyn_lds); if (!tid) PROF(&c, 15); }
-	else if (PH == PH_L4DL) { PROF_BEGIN(); scan_and_rewrite_par(&c, tid, sh_counts, sh_z, dyn_lds, false); if (!tid) PROF(&c, 17); }
 	else if (PH == PH_LLC) { PROF_BEGIN(); ll_code_chroma_par(&c, tid, reinterpret_cast<uint8_t *>(dyn_lds)); if (!tid) PROF(&c, 18); }
 	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
 	else if (PH == PH_C2) { chroma_ll1_neighbour(&c, tid); dequant_sim_chroma_par(&c, 1, tid); }
@@ -92,7 +91,6 @@ static size_t phase_lds(int ph)
 	case PH_L4D: return 4608;                                      /* the list of run starts (at most one per 15 groups of the stream); the stream itself is written by the quantiser kernel */
 	case PH_C5: return 32 * 130 * 2 + (32 * 128 + 258) * 2 > tile ? 32 * 130 * 2 + (32 * 128 + 258) * 2 : tile;
 	case PH_QL: return tile;
-	case PH_L4DL: return 16 * (W + 8) * sizeof(int16_t);           /* 16 plane rows of the stream gather */
 	default: return 0;
 	}
 }
@@ -122,7 +120,6 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 	case PH_LLC: k_phase<PH_LLC><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4C2: k_phase<PH_L4C2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_QL: k_phase<PH_QL><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
-	case PH_L4DL: k_phase<PH_L4DL><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C0: k_phase<PH_C0><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C2: k_phase<PH_C2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C3: k_phase<PH_C3><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;

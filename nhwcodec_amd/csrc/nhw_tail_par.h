@@ -166,8 +166,13 @@ DEV void tile_store(const int16_t *lds, int16_t *plane, int rs, int nrows, int c
  * valid for c0-2 <= jj < c0+66; row[jj +- TLS] are the plane rows below / above), return the next column to visit
  * (>= j1; skips may overshoot into the next tile).  The tile holds `nrows` plane rows starting at `plane`; thread t
  * (t < nproc) owns tile row t + roff.  Cells the pass may write: own row, columns c0-2 .. c0+65. */
+/* stream (optional; luma, 256 rows of 512 columns from plane row `stream_row0` on): the pass leaves the symbols of the tile's columns final,
+ * and the symbol stream wants them in its serpentine order (Y30, nhw_encoder.c:2108-2132: 128 strips of 4 columns, within a strip row
+ * after row, odd rows right to left) -- a tile holds 8 whole strips, i.e. per strip a run of 1024 consecutive stream bytes: they leave
+ * from LDS, four bytes (one row of one strip) per thread and step, consecutive threads on consecutive dwords. */
 template <class F>
-DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff, int nproc, int jb, int je, int16_t *lds, int tid, F f, typename F::State *out = nullptr)
+DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff, int nproc, int jb, int je, int16_t *lds, int tid, F f, typename F::State *out = nullptr,
+                        uint8_t *stream = nullptr, int stream_row0 = 0)
 {
 	int jnext = jb;
 	typename F::State st = f.init(tid);
@@ -179,6 +184,13 @@ DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff
 			if (jnext < j1) jnext = f.run(lds + (tid + roff) * TLS + 2 - c0, tid, jnext, j1, st);
 		}
 		BARRIER();
+		if (stream)
+			for (int idx = tid; idx < (TLC / 4) * nproc; idx += NT) {
+				const int sl = idx / nproc, r = idx % nproc, row = stream_row0 + r;
+				const int16_t *cell = lds + (r + roff) * TLS + 2 + 4 * sl;
+				const uint32_t b0 = (uint8_t)cell[0], b1 = (uint8_t)cell[1], b2 = (uint8_t)cell[2], b3 = (uint8_t)cell[3];
+				*reinterpret_cast<uint32_t *>(stream + (size_t)(c0 / 4 + sl) * (4 * W) + 4 * row) = (row & 1) ? (b3 | (b2 << 8) | (b1 << 16) | (b0 << 24)) : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+			}
 		int nst = TLC + 2;
 		if (row_end - c0 < nst) nst = row_end - c0;
 		tile_store(lds + roff * TLS, plane + (size_t)roff * rs, rs, nproc, c0, nst, tid, c0 > 0 ? 0 : 2);
@@ -945,8 +957,8 @@ DEV void quantise_luma_low_par(Ctx *c, int tid, uint32_t *maps /* shared, 512 wo
 	BARRIER();
 	{
 		QuantCodeLowF f0 = { p, W, 0, entry }, f1 = { p + H * W, W, H, entry };
-		row_pass_tiled(p, W, W, H, 0, H, 0, W, lds, tid, f0);
-		row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, f1);
+		row_pass_tiled(p, W, W, H, 0, H, 0, W, lds, tid, f0, nullptr, c->scan, 0);          /* the symbols go straight into the stream (Y30) */
+		row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, f1, nullptr, c->scan, H);
 	}
 }
 
@@ -1037,7 +1049,7 @@ DEV void fix_sign_code(uint8_t *s, int at) { if (s[at] == 153) s[at] = 124; else
  * pair rule (two adjacent positions cannot both match it), every other test compares against 128, which is
  * never written.  Rewrite 3 touches only sign codes next to zero runs of >= 252: each thread scans the runs
  * that start in its slice and replays the rare long ones. */
-DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /* shared [n/16/32 + 2] */, int16_t *lds /* 16 x 520 shorts */, bool stream_written = false)
+DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /* shared [n/16/32 + 2] */, int16_t *lds /* the list of run starts */)
 {
 	const int16_t *p = c->proc;
 	uint8_t *s = c->scan;
@@ -1045,28 +1057,6 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 	PROF_BEGIN();
 	uint32_t *bits = reinterpret_cast<uint32_t *>(c->half);      /* n bits of selection flags */
 
-	/* serpentine gather (:2108-2132) through LDS (the quantiser kernel writes the stream itself, this is the stand-alone form): 16 plane rows (coalesced 1 KiB rows) -> per 4-column strip a run of
-	 * 64 consecutive stream bytes, written 16 bytes per thread */
-	for (int rb = 0; rb < W && !stream_written; rb += 16) {
-		for (int idx = tid; idx < 16 * (W / 8); idx += NT) {
-			const int r = idx >> 6, o = idx & 63;
-			reinterpret_cast<uint4 *>(lds + r * (W + 8))[o] = reinterpret_cast<const uint4 *>(p + (rb + r) * W)[o];
-		}
-		BARRIER();
-		for (int idx = tid; idx < 128 * 4; idx += NT) {
-			const int strip = idx >> 2, qd = idx & 3;
-			uint32_t w[4];
-#pragma unroll
-			for (int e = 0; e < 4; e++) {
-				const int r = 4 * qd + e;
-				const uint2 v = *reinterpret_cast<const uint2 *>(lds + r * (W + 8) + 4 * strip);
-				const uint32_t b0 = v.x & 0xFF, b1 = (v.x >> 16) & 0xFF, b2 = v.y & 0xFF, b3 = (v.y >> 16) & 0xFF;
-				w[e] = ((rb + r) & 1) ? (b3 | (b2 << 8) | (b1 << 16) | (b0 << 24)) : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
-			}
-			*reinterpret_cast<uint4 *>(s + strip * (4 * W) + 4 * (rb + 4 * qd)) = make_uint4(w[0], w[1], w[2], w[3]);
-		}
-		BARRIER();
-	}
 	if (tid == 0) { sh_counts[0] = 0; sh_counts[1] = 0; }
 	BARRIER();
 
@@ -2183,7 +2173,7 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 DEV void luma_p4d_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z, int16_t *lds)
 {
 	PROF_BEGIN();
-	scan_and_rewrite_par(c, tid, sh_counts, sh_z, lds, true);               /* Y31 (Y30: the quantiser wrote the stream) */
+	scan_and_rewrite_par(c, tid, sh_counts, sh_z, lds);                     /* Y31 (Y30: the quantiser wrote the stream) */
 	if (!tid) PROF(c, 17);
 }
 
