@@ -29,7 +29,7 @@ void nhw_launch_front_stale(const int16_t *y, size_t y_stride, const uint8_t *st
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s);
 enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
-enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2, PH_QL };
+enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2 };
 /* quality 1..16 only (nhw_low.hip) */
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
                               int q, int n, hipStream_t s);
@@ -287,8 +287,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	} else if (q > 12)
 		nhw_launch_phase(PH_L4B, ws, 0, out, d_sizes, d_status, s);  /* Y24, Y25 (:1498) */
 	nhw_launch_phase(PH_L4C, ws, 0, out, d_sizes, d_status, s);      /* Y26, Y27 */
-	if (low) nhw_launch_phase(PH_QL, ws, 0, out, d_sizes, d_status, s);   /* Y28, quality 1..16 form */
-	else nhw_launch_wave(WV_QUANT, ws, s);                           /* Y28 */
+	nhw_launch_wave(WV_QUANT, ws, s);                                /* Y28 (+ Y30: the symbols leave in stream order), every quality */
 	if (q > 21) nhw_launch_phase(PH_L4C2, ws, 0, out, d_sizes, d_status, s);   /* Y29 */
 	if (fork && q > 21) HIPCHK(hipEventRecord(e->part_ev[0], s));    /* ... and the band plane free */
 	if (fork) {                                                      /* queued here so that the wait finds its event recorded */
@@ -330,7 +329,7 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	HIPCHK(hipSetDevice(e->device));
 	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
 	NhwWs ws = e->ws;
-	ws.n = n; ws.q = quality;
+	ws.n = n; ws.q = quality; ws.dbg = e->stop_after != 0;
 	const int parts = (e->stop_after || n < 512) ? 1 : e->parts;
 	if (parts == 1) {
 		const int rc = run_batch(e, ws, d_bgr, n, quality, d_out, d_sizes, d_status, s, 1);

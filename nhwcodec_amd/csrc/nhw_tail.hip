@@ -6,8 +6,7 @@
 
 using namespace nhw;
 
-enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2,
-       PH_QL };   /* the last: the quantiser of quality 1..16 (row per thread on LDS tiles; writes the symbol stream like the wavefront form of 17..23) */
+enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2 };
 
 template <int PH>
 __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status)
@@ -28,7 +27,6 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_L4C) luma_p4c_par(&c, tid, sh_pos, dyn_lds);
 	else if (PH == PH_L4D) luma_p4d_par(&c, tid, sh_counts, sh_z, dyn_lds);
 	else if (PH == PH_L4C2) luma_p4c2_par(&c, tid, reinterpret_cast<unsigned *>(sh_z), sh_pos);
-	else if (PH == PH_QL) { PROF_BEGIN(); quantise_luma_low_par(&c, tid, sh_z, reinterpret_cast<uint8_t *>(sh_pos), dyn_lds); if (!tid) PROF(&c, 15); }
 	else if (PH == PH_LLC) { PROF_BEGIN(); ll_code_chroma_par(&c, tid, reinterpret_cast<uint8_t *>(dyn_lds)); if (!tid) PROF(&c, 18); }
 	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
 	else if (PH == PH_C2) { chroma_ll1_neighbour(&c, tid); dequant_sim_chroma_par(&c, 1, tid); }
@@ -53,7 +51,7 @@ __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane);
 	else if (PH == WV_QUANT) {
 		__shared__ __attribute__((aligned(16))) uint8_t park[4][16 * QROW];
-		PROF_BEGIN(); wave_quantise_luma(&c, lane, park[threadIdx.x >> 6], ws.q > 21); if (!lane) PROF(&c, 15);
+		PROF_BEGIN(); wave_quantise_luma(&c, lane, park[threadIdx.x >> 6], ws.q > 21 || ws.dbg); if (!lane) PROF(&c, 15);
 	}
 	else if (PH == WV_EMIT) { PROF_BEGIN(); wave_emit_ll2(&c, lane); if (!lane) PROF(&c, 4); }
 }
@@ -90,7 +88,6 @@ static size_t phase_lds(int ph)
 	case PH_L4C: return 0;                                         /* Y26 is pointwise, Y27 a wavefront per row straight on the plane */
 	case PH_L4D: return 4608;                                      /* the list of run starts (at most one per 15 groups of the stream); the stream itself is written by the quantiser kernel */
 	case PH_C5: return 32 * 130 * 2 + (32 * 128 + 258) * 2 > tile ? 32 * 130 * 2 + (32 * 128 + 258) * 2 : tile;
-	case PH_QL: return tile;
 	default: return 0;
 	}
 }
@@ -119,7 +116,6 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 	case PH_L4D: k_phase<PH_L4D><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_LLC: k_phase<PH_LLC><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4C2: k_phase<PH_L4C2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
-	case PH_QL: k_phase<PH_QL><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C0: k_phase<PH_C0><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C2: k_phase<PH_C2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C3: k_phase<PH_C3><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;

@@ -166,13 +166,8 @@ DEV void tile_store(const int16_t *lds, int16_t *plane, int rs, int nrows, int c
  * valid for c0-2 <= jj < c0+66; row[jj +- TLS] are the plane rows below / above), return the next column to visit
  * (>= j1; skips may overshoot into the next tile).  The tile holds `nrows` plane rows starting at `plane`; thread t
  * (t < nproc) owns tile row t + roff.  Cells the pass may write: own row, columns c0-2 .. c0+65. */
-/* stream (optional; luma, 256 rows of 512 columns from plane row `stream_row0` on): the pass leaves the symbols of the tile's columns final,
- * and the symbol stream wants them in its serpentine order (Y30, nhw_encoder.c:2108-2132: 128 strips of 4 columns, within a strip row
- * after row, odd rows right to left) -- a tile holds 8 whole strips, i.e. per strip a run of 1024 consecutive stream bytes: they leave
- * from LDS, four bytes (one row of one strip) per thread and step, consecutive threads on consecutive dwords. */
 template <class F>
-DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff, int nproc, int jb, int je, int16_t *lds, int tid, F f, typename F::State *out = nullptr,
-                        uint8_t *stream = nullptr, int stream_row0 = 0)
+DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff, int nproc, int jb, int je, int16_t *lds, int tid, F f, typename F::State *out = nullptr)
 {
 	int jnext = jb;
 	typename F::State st = f.init(tid);
@@ -184,13 +179,6 @@ DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff
 			if (jnext < j1) jnext = f.run(lds + (tid + roff) * TLS + 2 - c0, tid, jnext, j1, st);
 		}
 		BARRIER();
-		if (stream)
-			for (int idx = tid; idx < (TLC / 4) * nproc; idx += NT) {
-				const int sl = idx / nproc, r = idx % nproc, row = stream_row0 + r;
-				const int16_t *cell = lds + (r + roff) * TLS + 2 + 4 * sl;
-				const uint32_t b0 = (uint8_t)cell[0], b1 = (uint8_t)cell[1], b2 = (uint8_t)cell[2], b3 = (uint8_t)cell[3];
-				*reinterpret_cast<uint32_t *>(stream + (size_t)(c0 / 4 + sl) * (4 * W) + 4 * row) = (row & 1) ? (b3 | (b2 << 8) | (b1 << 16) | (b0 << 24)) : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
-			}
 		int nst = TLC + 2;
 		if (row_end - c0 < nst) nst = row_end - c0;
 		tile_store(lds + roff * TLS, plane + (size_t)roff * rs, rs, nproc, c0, nst, tid, c0 > 0 ? 0 : 2);
@@ -273,16 +261,6 @@ DEV void precompensate_ll1_par(Ctx *c, int tid, int16_t *lds)
 
 /* ---------------------------------------------------------------- a8 dequantisation simulation */
 /* (the dequantiser simulation itself is a wavefront-per-image kernel for every quality: nhw_tail_wave.h) */
-/* q<=16: negative magnitudes keep their low bits only on a ration: of the 15s in a row every sixth is floored to 8, of the
- * x7 above 22 every fourth (image_processing.c:2938-2989, :357-410); everything else is floored */
-DEV int ration_low_bits(int a, int &n15, int &nx7, int mask)
-{
-	if (a == 15) { if (!n15) a &= mask; n15 = n15 == 5 ? 0 : n15 + 1; }
-	else if (a > 22 && (a & 7) == 7) { if (!nx7) a &= mask; nx7 = (nx7 + 1) & 3; }
-	else a &= mask;
-	return a;
-}
-
 /* ---------------------------------------------------------------- Y21 (R) */
 /* (:970-1073) only same-row neighbours are read or written (the vertical branches are unreachable) */
 /* A cell may overwrite its two neighbours: the one on the left has been visited (nobody looks at it again: that is just its final value),
@@ -817,151 +795,7 @@ DEV void clean_details_par(Ctx *c, int tid, int16_t *lds)
 }
 
 /* ---------------------------------------------------------------- a10 quantiser */
-struct QuantPairsF {                                          /* image_processing.c:195-238 */
-	struct State { int unused; };
-	__device__ State init(int) const { return State{0}; }
-	__device__ int run(int16_t *row, int, int j, int j1, State &) const
-	{
-		for (; j < j1; j++) {
-			int16_t *v = row + j;
-			if (v[0] > 7 && v[1] > 7 && j < W - 1) {
-				const int a = v[0];
-				if (!(a & 7) && !(v[1] & 7)) {
-					if (a > 15) {
-						if (v[-1] <= 0) v[0]--;
-						else if (v[1] > 15) { if (j < W - 2 && v[2] <= 0) v[1]--; }
-					}
-					else if (v[1] > 15) { if (j < W - 2 && v[2] <= 0) v[1]--; }
-				}
-			}
-		}
-		return j;
-	}
-};
-/* ---- quality 1..16 (image_processing.c:357-410, :427-510) ----
- * Two things change in the main loop.  (1) The low bits of negative magnitudes are rationed per row (ration_low_bits): local to a row.
- * (2) `quant4`: of the pairs of neighbours that both sit on x6/x7 (>= 14) in a detail band, every third one -- counted through the WHOLE
- * plane in raster order -- is pushed apart by 2 so that one of them reaches the next step.  A push changes the right-hand cell, which
- * thereby stops being a candidate itself, so how many candidates a row counts depends on the counter it is entered with; and the
- * right-hand cell of a pair that starts in column 511 is the first cell of the next row.  A row is therefore summarised by a map
- * (counter, "my first cell was pushed") -> (counter, push handed to the next row): six entries, found by a dry walk that only reads;
- * the 512 maps are chained by one thread, and the real walk starts every row from its true entry state.  (The veto by a negative left
- * neighbour, :438-447, can never hold: the left neighbour has already been replaced by its code, which is >= 0.) */
-DEV bool q4_cand(int a, int nx) { return a >= 14 && nx >= 14 && (a & 6) == 6 && (nx & 6) == 6 && ((a | nx) & 1); }
-DEV bool q4_veto(int v) { return (v < -2 && v > -8) || (v < -7 && ((-v) & 7) >= 6); }
-/* what the pair (a, nx) does when its turn has come: 0 nothing, -2 / +2 = the change of nx (a -2 comes with a += 2) */
-DEV int q4_push(int a, int nx, int col, int right2)
-{
-	const bool left = (a & 504) == (nx & 504) ? a >= nx : a <= nx;
-	if (left) return -2;
-	const bool veto_r = col > 0 && col < W - 2 && q4_veto(right2);
-	return veto_r ? 0 : 2;
-}
-struct QuantTurnDryF {
-	const int16_t *plane; int rs, row0; uint32_t *maps;         /* maps[row]: 4 bits per entry state e = turn * 2 + pushed (packed at the end of run) */
-	struct State { int next_first; uint8_t turn[6], kill[6]; int8_t carry[6]; };
-	__device__ State init(int t) const
-	{
-		State st;
-		st.next_first = plane[(size_t)(t + 1) * rs];
-		for (int e = 0; e < 6; e++) { st.turn[e] = (uint8_t)(e >> 1); st.kill[e] = (uint8_t)(e & 1); st.carry[e] = 0; }
-		return st;
-	}
-	__device__ int run(int16_t *row, int t, int j, int j1, State &st) const
-	{
-		const int r = row0 + t;
-		for (; j < j1; j++) {
-			const bool detail = r >= H || j >= H;
-			const int a = row[j], nx = j < W - 1 ? row[j + 1] : st.next_first;
-			const bool cand = detail && a <= 127 && q4_cand(a, nx);
-			if (!cand) { for (int e = 0; e < 6; e++) st.kill[e] = 0; continue; }
-			const int push = q4_push(a, nx, j, row[j + 2]);
-			for (int e = 0; e < 6; e++) {
-				int k = 0;
-				if (!st.kill[e]) {
-					if (!st.turn[e]) { k = push != 0; if (j == W - 1) st.carry[e] = (int8_t)push; }
-					st.turn[e] = st.turn[e] == 2 ? 0 : st.turn[e] + 1;
-				}
-				st.kill[e] = (uint8_t)k;
-			}
-		}
-		if (j1 == W) {                                          /* row finished: file the map (4 bits per entry: exit turn, carry code 0 / 1 = -2 / 2 = +2) */
-			uint32_t mword = 0;
-			for (int e = 0; e < 6; e++) mword |= (uint32_t)(st.turn[e] | ((st.carry[e] < 0 ? 1 : st.carry[e] > 0 ? 2 : 0) << 2)) << (4 * e);
-			maps[r] = mword;
-		}
-		return j;
-	}
-};
-struct QuantCodeLowF {                                        /* image_processing.c:314-519, q <= 16 */
-	const int16_t *plane; int rs, row0; const uint8_t *entry;    /* entry[row] = turn | carry code << 2 */
-	struct State { int next_first, n15, nx7, turn, delta; };
-	__device__ State init(int t) const
-	{
-		const int e = entry[row0 + t];
-		return State{ plane[(size_t)(t + 1) * rs], 0, 0, e & 3, (e >> 2) == 1 ? -2 : (e >> 2) == 2 ? 2 : 0 };
-	}
-	__device__ int run(int16_t *row, int t, int j, int j1, State &st) const
-	{
-		const int r = row0 + t;
-		if (j == 0 && st.delta) row[0] = (int16_t)(row[0] + st.delta);   /* the push the row above handed down */
-		for (; j < j1; j++) {
-			int a = row[j];
-			const int nx = j < W - 1 ? row[j + 1] : st.next_first;
-			if (a > 127) { row[j] = (int16_t)big_code(a, k_big_pos); continue; }
-			else if (a < -127) { row[j] = (int16_t)big_code(-a, k_big_neg); continue; }
-			if (a < -12 && ((-a) & 7) == 6) { if (j < W - 1 && nx == -7) row[j + 1] = -9; }
-			if (a < 0) {
-				if (a == -7 && nx == 8 && j < W - 1) { row[j] = -8; a = -8; }
-				a = -a;
-				if (a > 14 && (a & 7) == 7 && nx > 0 && nx < 8) a -= 2;
-				a = ration_low_bits(a, st.n15, st.nx7, 504);
-				a = -a;
-			}
-			else if (a == 8 && nx == -7 && j < W - 1) row[j + 1] = -8;
-			else if (a > 12 && (a & 7) >= 6) { if (j < W - 1 && nx == 7) row[j + 1] = 9; }
-			if ((r >= H || j >= H) && q4_cand(a, nx)) {
-				if (!st.turn) {
-					const int push = q4_push(a, nx, j, row[j + 2]);
-					if (push < 0) a += 2;
-					if (push && j < W - 1) row[j + 1] = (int16_t)(nx + push);   /* column 511: the next row applies it (its entry state) */
-				}
-				st.turn = st.turn == 2 ? 0 : st.turn + 1;
-			}
-			if (a < DEADZONE && a > -DEADZONE) row[j] = 128;
-			else row[j] = (int16_t)((a + 128) & 248);
-		}
-		return j;
-	}
-};
-DEV void quantise_luma_low_par(Ctx *c, int tid, uint32_t *maps /* shared, 512 words */, uint8_t *entry /* shared, 512 bytes */, int16_t *lds)
-{
-	int16_t *p = c->proc;
-	row_pass_tiled(p, W, W, H, 0, H, H, W, lds, tid, QuantPairsF{});               /* :195-238, rows 0..255: detail columns only */
-	row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, QuantPairsF{});       /* rows 256..511 */
-	{
-		QuantTurnDryF d0 = { p, W, 0, maps }, d1 = { p + H * W, W, H, maps };
-		row_pass_tiled(p, W, W, H, 0, H, 0, W, lds, tid, d0);
-		row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, d1);
-	}
-	BARRIER();
-	if (tid == 0) {
-		int turn = 0, carry = 0;
-		for (int r = 0; r < W; r++) {
-			entry[r] = (uint8_t)(turn | (carry << 2));
-			const uint32_t mword = maps[r];
-			const int e = (int)(mword >> (4 * (turn * 2 + (carry != 0)))) & 15;
-			turn = e & 3; carry = e >> 2;
-		}
-	}
-	BARRIER();
-	{
-		QuantCodeLowF f0 = { p, W, 0, entry }, f1 = { p + H * W, W, H, entry };
-		row_pass_tiled(p, W, W, H, 0, H, 0, W, lds, tid, f0, nullptr, c->scan, 0);          /* the symbols go straight into the stream (Y30) */
-		row_pass_tiled(p + H * W, W, W, H, 0, H, 0, W, lds, tid, f1, nullptr, c->scan, H);
-	}
-}
-
+/* (the luma quantiser is a wavefront-per-image kernel for every quality: wave_quantise_luma, nhw_tail_wave.h) */
 
 /* offsetUV (image_processing.c:108-183): pairs never span rows; the look at the next cell is unguarded at the
  * end of a row, so the first cell of the next row is read before any row is rewritten */

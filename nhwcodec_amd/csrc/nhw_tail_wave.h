@@ -417,8 +417,8 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 				if (BIT(to_8, k)) cur[k] = 8;
 			}
 			/* quality 1..16: of the -15 the walk meets in a row every sixth is floored to -8 (the first, the seventh ..), of the -x7 below -22
-			 * every fourth; all other negative values are floored (ration_low_bits in the row-per-thread form: counters that start at 0 in
-			 * every row).  The count a cell finds is its rank among the row's cells of its kind: ballots and popcounts. */
+			 * every fourth; all other negative values are floored (the reference's counters start at 0 in every row).  The count a cell
+			 * finds is its rank among the row's cells of its kind: ballots and popcounts. */
 			unsigned keep_low = 0;                                  /* visited negative cells that keep their low bits */
 			if (!hq) {
 				unsigned b15, bx7;
@@ -582,6 +582,8 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 	quant_load_row(p, 1, lane, nxt);
 	quant_load_row(p, 2, lane, q0); quant_load_row(p, 3, lane, q1);
 	for (int k = 0; k < 8; k++) prev[k] = 0;
+	const bool low = c->q <= 16;                                   /* quality 1..16 (image_processing.c:357-410, :427-510): no loops 2 and 3; rationed low bits; the `quant4` pushes */
+	int q4_turn = 0, q4_carry = 0;                                 /* quant4: its every-third-pair counter runs through the whole plane; a push out of column 511 lands in the next row's first cell */
 	unsigned last_le0 = 0;                                         /* the last cell of the row above is <= 0 (loop 1 looks at it from column 0) */
 	for (int r = 0; r <= W; r++) {                                 /* step r: loops 1-3 on row r, loop 4 on row r - 1 */
 		int far[8];
@@ -611,7 +613,7 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				last_le0 = (unsigned)__builtin_amdgcn_readlane((int)le0, 63) >> 7;
 				for (int k = 0; k < 8; k++) cur[k] -= (dec >> k) & 1;
 			}
-			if (r < H) {
+			if (r < H && !low) {
 				{                                                  /* loop 2 */
 					unsigned P, N, PN, NN;
 					BS_PRED(P, cur, 4, (unsigned)(x - 4) < 4u); BS_PRED(N, cur, 4, (unsigned)(x + 7) < 4u);
@@ -644,7 +646,103 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				}
 			}
 		}
-		if (r >= 1) {                                              /* loop 4 on row r - 1: a stencil on (left, cell, right) */
+		if (r >= 1 && low) {                                       /* loop 4 of quality 1..16 on row r - 1 */
+			const int rr = r - 1;
+			const int first_next = __builtin_amdgcn_readlane(cur[0], 0);   /* the row below, through loop 1, before the push this row may hand it */
+			if (q4_carry) { if (lane == 0) prev[0] += q4_carry; q4_carry = 0; }   /* the push the row above handed down (:427-510 leaves it for the next row's first cell) */
+			unsigned pusher = 0;                                        /* my cells that pushed to the left: their += 2 comes behind the "above 127" test of :314 */
+			/* quant4 (:427-510): of the pairs of neighbours that both sit on x6 / x7 (>= 14) in a detail band every third one -- counted through
+			 * the whole plane -- is pushed apart by 2.  A pushed cell stops being a candidate; candidates are few (two large coefficients of
+			 * the right residues side by side): the walk over them runs on the scalar unit, in column order. */
+			{
+				unsigned cb = 0;
+				for (int k = (rr < H ? 4 : 0); k < 8; k++) {               /* detail cells: rows from 256 on, or columns from 256 on */
+					const int a = prev[k], nx = right_of_dpp(prev, k, 8, lane, first_next);
+					cb |= (a >= 14 && a <= 127 && nx >= 14 && (a & 6) == 6 && (nx & 6) == 6 && ((a | nx) & 1) ? 1u : 0u) << k;   /* q4_cand; a value above 127 has left the walk with its code (:314) */
+				}
+				if (__any(cb != 0)) {
+					const M8 cm = bs_ballot8(cb);
+					int killed = -1;                                    /* the column a push has just changed */
+					int dl[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+					for (int k = 0; k < 8; k++) {
+						uint64_t m = cm.w[k];
+						while (m) {
+							const int bit = __builtin_ctzll(m);
+							m &= m - 1;
+							const int col = 64 * k + bit;
+							if (col == killed) continue;
+							if (!q4_turn) {
+								const int a = __builtin_amdgcn_readlane(prev[k], bit);
+								const int c1 = col + 1, c2 = col + 2;
+								int nx = first_next, r2 = 0;
+								if (c1 < W) { nx = 0; for (int kk = 0; kk < 8; kk++) if (kk == (c1 >> 6)) nx = __builtin_amdgcn_readlane(prev[kk], c1 & 63); }
+								if (c2 < W) for (int kk = 0; kk < 8; kk++) if (kk == (c2 >> 6)) r2 = __builtin_amdgcn_readlane(prev[kk], c2 & 63);
+								const bool left = (a & 504) == (nx & 504) ? a >= nx : a <= nx;
+								const bool veto = col > 0 && col < W - 2 && ((r2 < -2 && r2 > -8) || (r2 < -7 && ((-r2) & 7) >= 6));
+								const int push = left ? -2 : (veto ? 0 : 2);
+								if (push) {
+									for (int kk = 0; kk < 8; kk++) {
+										if (push < 0 && kk == k && lane == bit) { dl[kk] += 2; pusher |= 1u << kk; }
+										if (c1 < W && kk == (c1 >> 6) && lane == (c1 & 63)) dl[kk] += push;
+									}
+									if (c1 >= W) q4_carry = push;
+									killed = c1;
+								}
+							}
+							q4_turn = q4_turn == 2 ? 0 : q4_turn + 1;
+						}
+					}
+					for (int k = 0; k < 8; k++) prev[k] += dl[k];
+				}
+			}
+			/* the symbols: the same stencil on (left, cell, right) as above quality 16; what differs is which negative values keep their low
+			 * bits: of the 15s a row's walk meets every sixth is floored to 8, of the x7 above 22 every fourth, all others are floored */
+			int mv[8];
+			unsigned negm = 0, b15 = 0, bx7 = 0;
+			for (int k = 0; k < 8; k++) {
+				const int raw = prev[k];
+				const int lf = left_of_dpp(prev, k, lane, 0), rt = right_of_dpp(prev, k, 8, lane, first_next);
+				const bool last = k == 7 && lane == 63;
+				const bool m7 = raw == -7;
+				const bool ac = (unsigned)(-lf - 13) < 115u && ((-lf) & 7) == 6;
+				const bool to8 = lf == 8 || (rt == 8 && !last);
+				const bool dc = (unsigned)(lf - 13) < 115u && (lf & 7) >= 6;
+				int a = raw;
+				a = (m7 && ac) ? -9 : a;
+				a = (m7 && !ac && to8) ? -8 : a;
+				a = (raw == 7 && dc) ? 9 : a;
+				const bool neg = a < 0 && a >= -127;
+				int m = a < 0 ? -a : a;
+				m = (neg && m > 14 && (m & 7) == 7 && (unsigned)(rt - 1) < 7u) ? m - 2 : m;
+				mv[k] = a < 0 ? -m : m;
+				negm |= (neg ? 1u : 0u) << k;
+				b15 |= (neg && m == 15 ? 1u : 0u) << k;
+				bx7 |= (neg && m > 22 && (m & 7) == 7 ? 1u : 0u) << k;
+			}
+			unsigned keep_low = 0;
+			if (__any((b15 | bx7) != 0)) {
+				const M8 m15 = bs_ballot8(b15), mx7 = bs_ballot8(bx7);
+				const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+				int base15 = 0, basex7 = 0;
+				for (int k = 0; k < 8; k++) {
+					const int r15 = base15 + __builtin_popcountll(m15.w[k] & below), rx7 = basex7 + __builtin_popcountll(mx7.w[k] & below);
+					if (((b15 >> k) & 1) && r15 % 6 != 0) keep_low |= 1u << k;
+					if (((bx7 >> k) & 1) && (rx7 & 3) != 0) keep_low |= 1u << k;
+					base15 += __builtin_popcountll(m15.w[k]); basex7 += __builtin_popcountll(mx7.w[k]);
+				}
+			}
+			for (int k = 0; k < 8; k++) {
+				int v = mv[k];
+				if (((negm >> k) & 1) && !((keep_low >> k) & 1)) v = -((-v) & 504);
+				int sym = (unsigned)(v + 7) < 15u ? 128 : ((v + 128) & 248);
+				const int raw = prev[k];
+				if (raw > 127 && !((pusher >> k) & 1 && raw <= 129)) sym = big_code(raw, k_big_pos);
+				else if (raw < -127) sym = big_code(-raw, k_big_neg);
+				if (write_plane) p[rr * W + lane + 64 * k] = (int16_t)sym;
+				park[(rr & 15) * QROW + lane + 64 * k] = (uint8_t)sym;
+			}
+		}
+		if (r >= 1 && !low) {                                      /* loop 4 on row r - 1: a stencil on (left, cell, right) */
 			const int first_next = __builtin_amdgcn_readlane(cur[0], 0);   /* the row below, already through loops 1-3 */
 			for (int k = 0; k < 8; k++) {
 				const int raw = prev[k];
@@ -679,6 +777,8 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				if (write_plane) p[(r - 1) * W + lane + 64 * k] = (int16_t)sym;
 				park[((r - 1) & 15) * QROW + lane + 64 * k] = (uint8_t)sym;
 			}
+		}
+		if (r >= 1) {
 			if (((r - 1) & 15) == 15) {                                /* 16 rows complete: strips lane and lane + 64 */
 				__threadfence_block();
 				const int rb = r - 16;

@@ -45,6 +45,7 @@ struct NhwWs {
 	size_t stride[B_COUNT];
 	int n;
 	int q;
+	int dbg;      /* the batch driver is stopped after a stage (tests): kernels also write the planes that nothing but a test reads */
 	int compat;   /* 0: canonical (out-of-bounds reads see zeros); 1: the heap neighbours of the stock one-image-per-process binary (nhw_hip.h) */
 	template <typename T> __host__ __device__ T *buf(int b, int img) const { return (T *)(base + off[b] + (size_t)img * stride[b]); }
 };

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STATS = os.path.join(ROOT, "profiles", "round3_kernel_stats_1stream.txt")
 PMC = os.path.join(ROOT, "profiles", "round3_pmc.json")
 BATCHES = 7.0            # bench.py --steps 5 --warmup 2 in profiles/collect.sh
-PH = ["L1", "L2", "L3", "L4A", "C0", "C2", "C3", "C4", "C5", "FINAL", "L4B", "L4C", "L4D", "LLC", "L4C2", "QL"]
+PH = ["L1", "L2", "L3", "L4A", "C0", "C2", "C3", "C4", "C5", "FINAL", "L4B", "L4C", "L4D", "LLC", "L4C2"]
 WV = ["DQ1", "DQ0", "EMIT", "QUANT"]
 WHAT = {
     "k_front_band": "a1 + a2 + Y2 + Y3 fused: BGR24 -> Y, 4:2:0 chroma planes out, pre-filter, both directions of the level-1 analysis, LL copy (16 output rows, 512 threads, 80 KB LDS per workgroup)",
