@@ -139,10 +139,10 @@ def cpu_decode_baseline(files, budget_s=6.0):
 
 
 def valu_evidence():
-    """VALU issue statistics of the front kernels from the committed PMC pass (profiles/round2_pmc_valu.json, batch 4096, -q20):
+    """VALU issue statistics of the front kernels from the committed PMC pass (profiles/round3_pmc_valu.json, batch 4096, -q20):
     wave-instructions issued / (CUs x kernel cycles) -- why these kernels sit where they do against the HBM roofline."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round2_pmc_valu.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "round3_pmc_valu.json")) as fh:
             d = json.load(fh)
     except OSError:
         return None

@@ -45,6 +45,27 @@ def test_mixed_class_images_encode_and_decode_like_the_oracle(q):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("q", [5, 11, 14])
+def test_noise_and_hard_edges_at_the_rationed_qualities(q):
+    """White noise and hard-edge rectangles at quality 1..16: the images on which the quantisers' rare rules fire (values beyond +-127, the
+    `quant4` pushes out of and into such values, rationed low bits) -- a slice of tests/gpu_fuzz_noise.py, whose full run found a pusher
+    that crossed 127 in round 3."""
+    from concurrent.futures import ProcessPoolExecutor
+    import nhwcodec_amd as na
+    from oracle.harness import class_image
+    from tests.gpu_fuzz_noise import want_chunk as noise_want
+    items = [(k, s) for k in ("noise", "blocks") for s in range(50 + q, 58 + q)]
+    imgs = np.stack([class_image(k, s) for k, s in items])
+    enc = na.Encoder(0, len(items))
+    got = [hashlib.sha1(f).hexdigest() for f in enc.encode(imgs, q)]
+    enc.close()
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
+        want = [h for part in ex.map(noise_want, [(q, items[i:i + 2]) for i in range(0, len(items), 2)]) for h in part]
+    bad = [items[i] for i in range(len(items)) if got[i] != want[i]]
+    assert not bad, f"q{q}: {bad} differ from the oracle"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("q,seed", [(20, 31000), (10, 32000)])
 def test_images_with_shifted_chroma_mark_rows(q, seed):
     """nhw_encoder.c:2372-2427: the index into the chroma LL1 block is not reset per row; a pair mark in a row's last column shifts every
