@@ -26,6 +26,7 @@ void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv,
                             int16_t *keep, size_t keep_stride, int n, hipStream_t s, int force_fallback);
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s);
 void nhw_launch_front_stale(const int16_t *y, size_t y_stride, const uint8_t *st, size_t s_stride, int16_t *stale, size_t stale_stride, int n, hipStream_t s);
+void nhw_launch_low_stale(const int16_t *km, size_t km_stride, int16_t *stale, size_t stale_stride, int n, hipStream_t s);
 void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s);
 enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
@@ -72,7 +73,7 @@ static const size_t k_buf_bytes[B_COUNT] = {
 	/* R1     */ Q + 64, 8192 + 64, 16384 + 64, /* R3 */ Q + 64, 8192 + 64, 16384 + 64, /* R5 */ Q + 64, 8192 + 64, 16384 + 64,
 	/* R6     */ 2 * Q + 1024, 16384 + 64, 16384 + 64, /* CHARRES */ 2048 + 64, /* QSET3 */ 8 * Q + 64,
 	/* RESU64 */ 512, /* RESV64 */ 512, /* PACKET */ 320000, /* BOOK1 */ 768, /* BOOK2 */ 768, /* SEL1 */ 16384 + 64, /* SEL2 */ 16384 + 64,
-	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512, /* ROWFLAG */ 1024, /* SEGMAP (unused) */ 16, /* STALE */ (4 + 9 * 512) * 2
+	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512, /* ROWFLAG */ 1024, /* SEGMAP (unused) */ 16, /* STALE */ (8 + 9 * 512) * 2
 };
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -82,10 +83,11 @@ extern "C" int nhw_quality_supported(int quality) { return quality >= 1 && quali
 extern "C" int nhw_enc_set_compat(nhw_enc *e, int mode)
 {
 	if (!e || (mode != NHW_COMPAT_CANONICAL && mode != NHW_COMPAT_GLIBC_ONESHOT)) return NHW_E_ARG;
-	if (e->ws.compat != mode && mode == NHW_COMPAT_CANONICAL) {      /* the compatibility mode writes behind ll1: give the guard its zeros back */
+	if (e->ws.compat != mode && mode == NHW_COMPAT_CANONICAL) {      /* the compatibility mode writes behind ll1 and the level-2 copy: give the guards their zeros back */
 		HIPCHK(hipSetDevice(e->device));
 		HIPCHK(hipDeviceSynchronize());
 		HIPCHK(hipMemset2D(e->ws.base + e->ws.off[B_LL1] + 2 * Q, e->ws.stride[B_LL1], 0, 1024, (size_t)e->max_batch));
+		HIPCHK(hipMemset2D(e->ws.base + e->ws.off[B_L2SAVE] + 2 * Q, e->ws.stride[B_L2SAVE], 0, 256, (size_t)e->max_batch));
 	}
 	e->ws.compat = mode;
 	return NHW_OK;
@@ -185,6 +187,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], q, n, s);   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser */
 		HIPCHK(hipEventRecord(e->ev[6], s));
 		STAGE_DONE();
+		if (ws.compat) nhw_launch_low_stale(proc, ps, plane16(ws, B_STALE), ws.stride[B_STALE], n, s);   /* compatibility mode only: the map cells the stock binary's heap re-uses */
 		nhw_launch_front_fused(nullptr, q, nullptr, nullptr, 0, yin, yin_stride, 0, nullptr, 0, nullptr, 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
 		                       proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n, s, 0);
 	} else {

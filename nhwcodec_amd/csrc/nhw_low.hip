@@ -1172,6 +1172,22 @@ void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y,
 	k_low_machine<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, dbg);
 	k_low_marks<<<dim3((W - 2 + MK_R - 2) / (MK_R - 1), n), MK_R, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
 }
+/* Compatibility mode (NHW_COMPAT_GLIBC_ONESHOT) only, quality <= 16: the contrast-map cells whose memory the stock binary's malloc hands
+ * out again -- res256's slack (row 128, columns 0..3), tree1 (map bytes from 262176 on: rows 272..280 hold what is read before it is
+ * written) and resIII's slack (row 256, columns 8..11) -- copied out of the map plane before the band kernel takes the plane over.
+ * out: [0..3] row 128, 9 rows of 512, [4 + 9*512 ..+3] row 256 (the first two as k_front_stale lays them out for quality 17..21). */
+__global__ void k_low_stale(const int16_t *__restrict__ kmb, size_t km_stride, int16_t *__restrict__ stale, size_t stale_stride)
+{
+	const int16_t *km = kmb + (size_t)blockIdx.x * km_stride;
+	int16_t *out = (int16_t *)((uint8_t *)stale + (size_t)blockIdx.x * stale_stride);
+	const int t = threadIdx.x;
+	for (int i = t; i < 9 * W / 4; i += 256) reinterpret_cast<uint2 *>(out + 4)[i] = reinterpret_cast<const uint2 *>(km + (size_t)272 * W)[i];
+	if (t < 4) { out[t] = km[(size_t)128 * W + t]; out[4 + 9 * W + t] = km[(size_t)256 * W + 8 + t]; }
+}
+void nhw_launch_low_stale(const int16_t *km, size_t km_stride, int16_t *stale, size_t stale_stride, int n, hipStream_t s)
+{
+	k_low_stale<<<n, 256, 0, s>>>(km, km_stride, stale, stale_stride);
+}
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s)
 {
 	k_low_prefilter_chroma<<<dim3(Q / 4 / 256, n), 256, 0, s>>>(src, src_stride, dst, dst_stride, q);

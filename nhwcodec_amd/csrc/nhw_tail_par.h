@@ -1594,6 +1594,12 @@ DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc, int16_t *lds)
 		ll_code_luma_par(c, tid, ls);
 		if (!tid) PROF(c, 5);
 	}
+	if (c->compat && c->q <= 13 && tid < 128) {
+		/* the same heap once more: Y20 finds its level-2 parents up to 128 entries behind resIII -- 8 bytes of map (row 256, columns 8..11),
+		 * the next chunk's size word (0x6011) and that chunk, tree1 */
+		const int k = tid;
+		c->l2save[Q + k] = (int16_t)(k < 4 ? c->stale[4 + 9 * W + k] : k == 4 ? 0x6011 : k < 8 ? 0 : (c->ll_bytes[2 * (k - 8)] | c->ll_bytes[2 * (k - 8) + 1] << 8));
+	}
 	BARRIER();
 	copy_block_par(c->l2save, H, c->proc, W, H, H, tid);          /* Y17 :749-755 */
 	BARRIER();

@@ -99,6 +99,7 @@ void nhwo_color(const uint8_t *bgr, int quality, int16_t *y, uint8_t *u, uint8_t
  * ------------------------------------------------------------------------------------------ */
 int16_t nhwo_kernel_row128[4];   /* the four kernel-map values that sit behind res256 in the stock binary's heap (GLIBC_ONESHOT mode, nhwo_luma.c) */
 int16_t nhwo_kernel_stale[16384]; /* kernel map from byte 262176 on: what the stock binary's malloc hands out as tree1 (same mode) */
+int16_t nhwo_kernel_row256[4];   /* kernel map bytes 262160..262167 (row 256, columns 8..11): the 8 bytes of slack behind resIII in that heap (same mode, quality <= 13) */
 
 void nhwo_prefilter_low(int16_t *y, int quality);   /* nhwo_prelow.c */
 
@@ -133,7 +134,7 @@ void nhwo_prefilter(int16_t *y, int quality)
 			}
 		}
 
-	for (c = 0; c < 4; c++) nhwo_kernel_row128[c] = kmap[128 * S + c];
+	for (c = 0; c < 4; c++) { nhwo_kernel_row128[c] = kmap[128 * S + c]; nhwo_kernel_row256[c] = kmap[256 * S + 8 + c]; }
 	memcpy(nhwo_kernel_stale, kmap + 262176 / 2, sizeof nhwo_kernel_stale);
 
 	for (r = 1; r < S - 1; r++)

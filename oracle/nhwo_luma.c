@@ -799,6 +799,16 @@ int nhwo_luma(nhwo_ctx *c)
 	if (q > 21) for (r = 0; r < H; r++) memcpy(c->first_order + r * H, c->jpeg + r * W, sizeof(int16_t) * H);   /* Y19 :766-777 */
 	}
 
+	if (nhwo_oob_mode && q <= 13) {
+		/* the same heap once more: Y20 reads its level-2 parents up to 128 entries behind resIII, which is followed by 8 bytes of stale
+		 * kernel map (row 256, columns 8..11), the size word of the next chunk (0x6011) and that chunk, tree1 */
+		extern int16_t nhwo_kernel_row256[4];
+		int16_t *tail = c->l2save + Q;
+		int k;
+		for (k = 0; k < 4; k++) tail[k] = nhwo_kernel_row256[k];
+		tail[4] = 0x6011; tail[5] = 0; tail[6] = 0; tail[7] = 0;
+		for (k = 0; k < 120; k++) tail[8 + k] = (int16_t)(c->ll_bytes[2 * k] | c->ll_bytes[2 * k + 1] << 8);
+	}
 	if (q <= 15) thin_l1_low(c);                                                                                /* Y20, q<=15 (:804-968) */
 	else if (q < 20) {                                                                                               /* Y20, 16<=q<=19 (:783-801) */
 		int16_t *p = c->proc;

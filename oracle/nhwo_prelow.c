@@ -26,6 +26,7 @@
 /* what the stock binary finds behind res256 / in tree1 (GLIBC_ONESHOT mode, nhwo_luma.c); defined in nhwo_front.c */
 extern int16_t nhwo_kernel_row128[4];
 extern int16_t nhwo_kernel_stale[16384];
+extern int16_t nhwo_kernel_row256[4];
 
 typedef struct {
 	int sharp;      /* `sharpness` (:573-587) */
@@ -670,7 +671,7 @@ void nhwo_prefilter_low(int16_t *y, int quality)
 	marker_pass(km, y, so, &pp);
 	final_pair_pass(km, y, so, &pp);
 
-	for (c = 0; c < 4; c++) nhwo_kernel_row128[c] = km[128 * S + c];
+	for (c = 0; c < 4; c++) { nhwo_kernel_row128[c] = km[128 * S + c]; nhwo_kernel_row256[c] = km[256 * S + 8 + c]; }
 	memcpy(nhwo_kernel_stale, km + 262176 / 2, sizeof nhwo_kernel_stale);
 	free(so); free(km); free(src);
 }

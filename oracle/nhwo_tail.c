@@ -341,7 +341,7 @@ int nhwo_encode(const uint8_t *bgr, int quality, uint8_t *out, size_t cap, size_
 	c->jpeg = GET(int16_t, 4 * Q); c->proc = GET(int16_t, 4 * Q);
 	c->cjpeg = GET(int16_t, Q); c->cproc = GET(int16_t, Q);
 	c->pu = GET(uint8_t, Q); c->pv = GET(uint8_t, Q);
-	c->ll1 = GET(int16_t, Q); c->l2save = GET(int16_t, Q);
+	c->ll1 = GET(int16_t, Q); c->l2save = GET(int16_t, Q + 256);   /* + what Y20 reads behind it at quality <= 13 (zeros here) */
 	c->cll1 = GET(int16_t, Q >> 2); c->cl2save = GET(int16_t, Q >> 2);
 	c->keep = GET(int16_t, 2 * Q); c->first_order = GET(int16_t, Q); c->band = GET(int16_t, Q);
 	c->scan = GET(uint8_t, 6 * Q);
