@@ -343,8 +343,16 @@ DEV void tag_small_runs_par(Ctx *c, int tid, int16_t *lds)
  * of the workgroup, into an LDS table) and a step is a table lookup plus a short switch: with 64 columns in a
  * wavefront the chain itself was most of the divergent instruction stream. */
 enum { CK_NONE, CK_MARKP, CK_MARKN, CK_S12100, CK_S12500, CK_S12200, CK_S12600, CK_INC, CK_DEC, CK_Q18P_NEXT, CK_Q18P_CELL, CK_Q18P_COPY,
-       CK_Q18N_NEXT, CK_Q18N_CELL, CK_Q18N_COPY, CK_NBP, CK_NBN, CK_PREVGE0, CK_PREVLE0, CK_C14500, CK_NUP, CK_NM2, CK_NM3, CK_LARGE };
-#define CK_TABLE_BYTES (17 * 9 * 12)
+       CK_Q18N_NEXT, CK_Q18N_CELL, CK_Q18N_COPY, CK_NBP, CK_NBN, CK_PREVGE0, CK_PREVLE0, CK_C14500, CK_NUP, CK_NM2, CK_NM3,
+       CK_LARGE4, CK_LARGE56, CK_LARGE7, CK_LARGE8, CK_KINDS };   /* CK_LARGE*: by the residual (-4; -5, -6; -7; below) */
+#define CK_CLASS_BYTES (17 * 9 * 12)
+/* behind the class table: what a kind does, one word per kind (classify_action), and what its rule does to the LH1 coefficient by the
+ * coefficient's class and the one before it (lh_table_fill) -- so that the 64 columns of a wavefront take ONE path through the step
+ * whatever their kinds (the switch over the kinds was 200 of the step's 230 instructions: every step found most kinds among its lanes) */
+#define CK_ACT_OFF CK_CLASS_BYTES
+#define CK_LHT_OFF (CK_ACT_OFF + 4 * CK_KINDS)
+#define CK_LH_RULES 5
+#define CK_TABLE_BYTES ((CK_LHT_OFF + CK_LH_RULES * 9 * 18 + 3) & ~3)
 DEV int classify_kind(int q, int res_setting, int res, int a, int d2)
 {
 	if (res == 2 && a == 2 && d2 >= 2) return (d2 < 5 || d2 > 6) ? CK_MARKP : CK_NONE;
@@ -375,94 +383,151 @@ DEV int classify_kind(int q, int res_setting, int res, int a, int d2)
 		}
 		if (res == -1 && a == -3 && d2 == -2) return CK_PREVLE0;
 		if (res == -1) return d2 == -3 ? CK_MARKN : CK_NUP;
-		if (res == -4) return (d2 < -1 && d2 > -4) ? CK_MARKN : CK_LARGE;
+		if (res == -4) return (d2 < -1 && d2 > -4) ? CK_MARKN : CK_LARGE4;
 		return CK_NONE;
 	}
 	if (!res || res == -1) return CK_NUP;
 	if (res == -2) return CK_NM2;
 	if (res == -3) return CK_NM3;
-	if (res < -res_setting) return CK_LARGE;
+	if (res < -res_setting) return res == -4 ? CK_LARGE4 : res >= -6 ? CK_LARGE56 : res == -7 ? CK_LARGE7 : CK_LARGE8;
 	return CK_NONE;
+}
+/* what a kind does (:1084-1325), as a word: bits 0..15 the code its LL1 cell takes (0: none), 16..18 / 19..21 what is added to the recon
+ * samples one / two rows down (+2), 22 "the sample one row down becomes its LL1 cell", 23..24 that cell first becomes 14100 (1) / 14000 (2)
+ * (q18 only), 25.. the rule applied to the LH1 coefficient (0: none) */
+enum { LHR_NONE, LHR_NUP, LHR_NM2, LHR_NM3, LHR_L4, LHR_L6 };
+DEV uint32_t ck_word(int code, int d1, int d2, int snap, int next, int rule) { return (uint32_t)code | (uint32_t)(d1 + 2) << 16 | (uint32_t)(d2 + 2) << 19 | (uint32_t)snap << 22 | (uint32_t)next << 23 | (uint32_t)rule << 25; }
+DEV uint32_t classify_action(int kind, int q)
+{
+	switch (kind) {
+	case CK_MARKP: return ck_word(12400, -2, -2, 0, 0, 0);
+	case CK_MARKN: return ck_word(12300, 2, 2, 0, 0, 0);
+	case CK_S12100: return ck_word(12100, 0, 0, 1, 0, 0);
+	case CK_S12500: return ck_word(12500, 0, 0, 1, 0, 0);
+	case CK_S12200: return ck_word(12200, 0, 0, 1, 0, 0);
+	case CK_S12600: return ck_word(12600, 0, 0, 1, 0, 0);
+	case CK_INC: return ck_word(0, 1, 0, 0, 0, 0);
+	case CK_DEC: return ck_word(0, -1, 0, 0, 0, 0);
+	case CK_Q18P_NEXT: return ck_word(0, 0, 0, 1, 1, 0);
+	case CK_Q18P_CELL: return ck_word(14100, 0, 0, 1, 0, 0);
+	case CK_Q18P_COPY: return ck_word(0, 0, 0, 1, 0, 0);
+	case CK_Q18N_NEXT: return ck_word(0, 0, 0, 1, 2, 0);
+	case CK_Q18N_CELL: return ck_word(14000, 0, 0, 1, 0, 0);
+	case CK_Q18N_COPY: return ck_word(0, 0, 0, 1, 0, 0);
+	case CK_C14500: return ck_word(14500, 0, 0, 0, 0, 0);
+	case CK_NUP: return ck_word(0, 0, 0, 0, 0, LHR_NUP);
+	case CK_NM2: return ck_word(0, 0, 0, 0, 0, LHR_NM2);
+	case CK_NM3: return q >= 21 ? ck_word(14500, 0, 0, 0, 0, 0) : ck_word(0, 0, 0, 0, 0, LHR_NM3);
+	case CK_LARGE4: return ck_word(14000, 0, 0, 0, 0, LHR_L4);
+	case CK_LARGE56: return ck_word(14000, 0, 0, 0, 0, 0);
+	case CK_LARGE7: return ck_word(14000, 0, 0, 0, 0, LHR_L6);
+	case CK_LARGE8: return q >= 21 ? ck_word(14900, 0, 0, 0, 0, 0) : ck_word(14000, 0, 0, 0, 0, LHR_L6);
+	default: return ck_word(0, 0, 0, 0, 0, 0);                  /* CK_NONE; the four kinds that look at more cells become one of the above first */
+	}
+}
+/* the rules on the LH1 coefficient v of the cell, given the one before it (as the walk left it) */
+DEV int lh_rule(int rule, int v, int before)
+{
+	switch (rule) {
+	case LHR_NUP:
+		if (v == 7) { if (before >= 0 && before < 8) v += 2; } else if (v == 8) { if (before >= -2 && before < 8) v += 2; }
+		break;
+	case LHR_NM2:
+		if (v < -14) { if (mult8_or_7(-v)) v++; } else if (v == 7 || (v & 0xFFFE) == 8) { if (before >= -2) v += 3; }
+		break;
+	case LHR_NM3:
+		if (v < -14) { if (mult8_or_7(-v)) v++; }
+		else if (v >= 0 && ((v + 2) & 0xFFFC) == 8) { if (before >= -2) v = 10; }
+		else if (v > 14 && (v & 7) == 7) v++;
+		break;
+	case LHR_L4:
+		if (v == -7 || v == -8) { if (before < 2 && before > -8) v = -9; }
+		break;
+	case LHR_L6:
+		if (v < -14) { if (mult8_or_7(-v)) v++; } else if (v == 7 || v == 8) { if (before >= -1 && before < 8) v += 3; }
+		break;
+	default: break;
+	}
+	return v;
+}
+/* the rules only tell these coefficients apart: below -14 on a multiple of 8 or one short of it (1), -8, -7 (2, 3), 6 .. 9 (4 .. 7), above 14
+ * and 7 modulo 8 (8), anything else (0: no rule moves it); and of the coefficient before, where it lies in -9 (or less) .. 8 (or more) */
+DEV int lh_class(int v)
+{
+	const int m = (1 - v) & 7;                                     /* 0 or 1: -v is a multiple of 8 or one short of it */
+	int c = (v < -14 && m < 2) ? 1 : 0;
+	c = (v > 14 && (v & 7) == 7) ? 8 : c;
+	c = (unsigned)(v + 8) <= 1u ? v + 10 : c;
+	c = (unsigned)(v - 6) <= 3u ? v - 2 : c;
+	return c;
 }
 /* value classes: residual <= -9, -8 .. 6, >= 7 (the chain compares it with -7 and with -res_setting >= -8); next residual -5 .. -2, 2 .. 5, anything else; third <= -4, -3 .. 6, >= 7 */
 DEV void classify_table_fill(uint8_t *tab, int q, int res_setting, int tid)
 {
-	for (int idx = tid; idx < CK_TABLE_BYTES; idx += NT) {
+	for (int idx = tid; idx < CK_CLASS_BYTES; idx += NT) {
 		const int rc = idx / (9 * 12), ac = (idx / 12) % 9, dc = idx % 12;
 		const int a = ac < 4 ? ac - 5 : (ac < 8 ? ac - 2 : 0);
 		tab[idx] = (uint8_t)classify_kind(q, res_setting, rc - 9, a, dc - 4);
+	}
+	if (tid < CK_KINDS) reinterpret_cast<uint32_t *>(tab + CK_ACT_OFF)[tid] = classify_action(tid, q);
+	for (int idx = tid; idx < CK_LH_RULES * 9 * 18; idx += NT) {
+		const int rule = idx / (9 * 18) + 1, lc = (idx / 18) % 9, before = idx % 18 - 9;
+		const int v = lc == 0 ? 0 : lc == 1 ? -16 : lc == 8 ? 15 : lc < 4 ? lc - 10 : lc + 2;   /* one coefficient of the class */
+		reinterpret_cast<int8_t *>(tab + CK_LHT_OFF)[idx] = (int8_t)(lh_rule(rule, v, before) - v);
 	}
 }
 DEV int classify_lookup(const uint8_t *tab, int res, int a, int d2)
 {
 	const int rc = (res < -9 ? -9 : (res > 7 ? 7 : res)) + 9, dc = (d2 < -4 ? -4 : (d2 > 7 ? 7 : d2)) + 4;
 	const int ac = (a >= -5 && a <= 5) ? (int)((0x76548883210ull >> (4 * (a + 5))) & 15) : 8;
-	return tab[(rc * 9 + ac) * 12 + dc];
+	return tab[__mul24(__mul24(rc, 9) + ac, 12) + dc];
 }
 
 /* the step itself.  pr / orow point at the column's recon sample / LL1 cell of row r (row strides ps / os: the planes
  * themselves, an LDS tile, or a packed copy of the column), lh at the LH1 coefficient the step may nudge, lhm1 is the
  * one before it (as this walk left it).  sp / so: where the right-hand neighbour column is read (the values from
  * before the pass). */
+/* the column's three cells the step looks at travel in registers from step to step (what a step writes is what the next one would read
+ * back): recon sample and LL1 cell of rows r, r+1 (the step loads those of row r+2) */
+struct ColCells { int v0, o0, v1, o1; };
+DEV ColCells col_cells(const int16_t *pr, int ps, const int16_t *orow, int os) { return ColCells{ pr[0], orow[0], pr[ps], orow[os] }; }
 template <bool NB_TILE>
-DEV void classify_step(const uint8_t *tab, int q, int r, int j, int16_t *pr, int ps, int16_t *orow, int os, int16_t *lh, int lhm1,
-                       const int16_t *sp, int sp_row, const int16_t *so, int so_rows)
+DEV int classify_step(const uint8_t *tab, int q, int r, int j, int16_t *pr, int ps, int16_t *orow, int os, int16_t *lh, int lhm1,
+                      const int16_t *sp, int sp_row, const int16_t *so, int so_rows, ColCells &cc)
 {
-	int16_t *cell = orow;
-	const int res = pr[0] - orow[0], a = pr[ps] - orow[os];
-	const int d2 = pr[2 * ps] - orow[2 * os];
+	const int v2 = pr[2 * ps], o2 = orow[2 * os];
+	int lv = lh[0];                                                /* returned: the coefficient as the step leaves it */
+	const int res = cc.v0 - cc.o0, a = cc.v1 - cc.o1, d2 = v2 - o2;
+	const int v1 = cc.v1, o1 = cc.o1;
+	cc = ColCells{ v1, o1, v2, o2 };                               /* a step that does nothing */
 	/* NB_TILE: sp points at the neighbour's (recon - ll1) difference of row r, as it was before the pass, row stride sp_row */
 #define NB(dr) (NB_TILE ? (int)sp[(dr) * sp_row] : (sp[(r + (dr)) * sp_row + j + 1] - ((r + (dr)) < so_rows ? so[(r + (dr)) * H + j + 1] : 0)))
-#define MARK(code, step) do { *cell = (code); pr[ps] += (step); pr[2 * ps] += (step); } while (0)
-#define SNAP(code) do { *cell = (code); pr[ps] = orow[os]; } while (0)
 	int kind = classify_lookup(tab, res, a, d2);
-	if (kind == CK_NONE) return;
-	if (kind == CK_NBP) { const int x0 = NB(0), x1 = NB(1); kind = ((x0 == 2 || x0 == 3) && (x1 == 2 || x1 == 3) && NB(2) > 0) ? CK_MARKP : CK_NONE; }
-	else if (kind == CK_NBN) { const int x0 = NB(0), x1 = NB(1); kind = ((x0 == -2 || x0 == -3) && (x1 == -2 || x1 == -3) && NB(2) < 0) ? CK_MARKN : CK_NONE; }
-	else if (kind == CK_PREVGE0) kind = (r > 0 && (pr[-ps] - orow[-os]) >= 0) ? CK_MARKP : CK_NONE;
-	else if (kind == CK_PREVLE0) kind = (r > 0 && (pr[-ps] - orow[-os]) <= 0) ? CK_MARKN : CK_NONE;
-	switch (kind) {
-	case CK_MARKP: MARK(12400, -2); break;
-	case CK_MARKN: MARK(12300, 2); break;
-	case CK_S12100: SNAP(12100); break;
-	case CK_S12500: SNAP(12500); break;
-	case CK_S12200: SNAP(12200); break;
-	case CK_S12600: SNAP(12600); break;
-	case CK_INC: pr[ps]++; break;
-	case CK_DEC: pr[ps]--; break;
-	case CK_Q18P_NEXT: orow[os] = 14100; pr[ps] = orow[os]; break;
-	case CK_Q18P_CELL: *cell = 14100; pr[ps] = orow[os]; break;
-	case CK_Q18P_COPY: pr[ps] = orow[os]; break;
-	case CK_Q18N_NEXT: orow[os] = 14000; pr[ps] = orow[os]; break;
-	case CK_Q18N_CELL: *cell = 14000; pr[ps] = orow[os]; break;
-	case CK_Q18N_COPY: pr[ps] = orow[os]; break;
-	case CK_C14500: *cell = 14500; break;
-	case CK_NUP:
-		if (lh[0] == 7) { if (lhm1 >= 0 && lhm1 < 8) lh[0] += 2; } else if (lh[0] == 8) { if (lhm1 >= -2 && lhm1 < 8) lh[0] += 2; }
-		break;
-	case CK_NM2:
-		if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; } else if (lh[0] == 7 || (lh[0] & 0xFFFE) == 8) { if (lhm1 >= -2) lh[0] += 3; }
-		break;
-	case CK_NM3:
-		if (q >= 21) *cell = 14500;
-		else if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; }
-		else if (lh[0] >= 0 && ((lh[0] + 2) & 0xFFFC) == 8) { if (lhm1 >= -2) lh[0] = 10; }
-		else if (lh[0] > 14 && (lh[0] & 7) == 7) lh[0]++;
-		break;
-	case CK_LARGE:
-		*cell = 14000;
-		if (res == -4) { if (lh[0] == -7 || lh[0] == -8) { if (lhm1 < 2 && lhm1 > -8) lh[0] = -9; } }
-		else if (res < -6) {
-			if (res < -7 && q >= 21) *cell = 14900;
-			else if (lh[0] < -14) { if (mult8_or_7(-lh[0])) lh[0]++; }
-			else if (lh[0] == 7 || lh[0] == 8) { if (lhm1 >= -1 && lhm1 < 8) lh[0] += 3; }
-		}
-		break;
-	default: break;
+	if (kind == CK_NONE) return lv;
+	if (kind >= CK_NBP && kind <= CK_PREVLE0) {                    /* the four kinds that look further: two cells of the column on the right and their sign, or the row above */
+		const int sg = (kind == CK_NBP || kind == CK_PREVGE0) ? 1 : -1;
+		bool ok;
+		if (kind <= CK_NBN) { const int x0 = sg * NB(0), x1 = sg * NB(1), x2 = sg * NB(2); ok = (x0 & ~1) == 2 && (x1 & ~1) == 2 && x2 > 0; }
+		else ok = r > 0 && sg * (pr[-ps] - orow[-os]) >= 0;
+		if (!ok) return lv;
+		kind = sg > 0 ? CK_MARKP : CK_MARKN;
 	}
+	const uint32_t aw = reinterpret_cast<const uint32_t *>(tab + CK_ACT_OFF)[kind];
+	const int code = (int)(aw & 0xFFFF);
+	if (code) orow[0] = (int16_t)code;
+	int below = o1;                                                /* the LL1 cell one row down */
+	if (q == 18) { const int nx = (int)(aw >> 23) & 3; if (nx) { below = nx == 1 ? 14100 : 14000; orow[os] = (int16_t)below; } }
+	const int n1 = (int16_t)(((aw >> 22) & 1) ? below : v1 + (int)((aw >> 16) & 7) - 2), n2 = (int16_t)(v2 + (int)((aw >> 19) & 7) - 2);
+	pr[ps] = (int16_t)n1; pr[2 * ps] = (int16_t)n2;
+	cc = ColCells{ n1, below, n2, o2 };
+	const int rule = (int)(aw >> 25);
+	if (rule) {
+		const int bc = (lhm1 < -9 ? -9 : lhm1 > 8 ? 8 : lhm1) + 9;
+		lv = (int16_t)(lv + reinterpret_cast<const int8_t *>(tab + CK_LHT_OFF)[__mul24(__mul24(rule - 1, 9) + lh_class(lv), 18) + bc]);
+		lh[0] = (int16_t)lv;
+	}
+	return lv;
 #undef NB
-#undef MARK
-#undef SNAP
 }
 
 /* Y22.  The reference walks column after column; column j only reads column j+1 (not yet visited, i.e. its
@@ -530,12 +595,11 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 		}
 		if (r0 % LW == 0) lh_tile_load(lt, p, r0, tid);
 		BARRIER();
-		if (j < H - 1)
-			for (int i = 0; i < CR && r0 + i < H - 1; i++) {
-				int16_t *lh = lt + j * LP + r0 % LW + i;
-				classify_step<true>(ktab, q, r0 + i, j, pt + (i + 1) * H + j, H, ot + (i + 1) * H + j, H, lh, lhm1, dt + (i + 1) * H + j + 1, H, nullptr, 0);
-				lhm1 = lh[0];
-			}
+		if (j < H - 1) {
+			ColCells cc = col_cells(pt + H + j, H, ot + H + j, H);
+			for (int i = 0; i < CR && r0 + i < H - 1; i++)
+				lhm1 = classify_step<true>(ktab, q, r0 + i, j, pt + (i + 1) * H + j, H, ot + (i + 1) * H + j, H, lt + j * LP + r0 % LW + i, lhm1, dt + (i + 1) * H + j + 1, H, nullptr, 0, cc);
+		}
 		BARRIER();
 		for (int v = tid; v < (CR + 2) * (H / 8); v += NT) {          /* column 255 travels too, unchanged */
 			const int i = 1 + v / (H / 8), c8 = 8 * (v % (H / 8)), row = r0 - 1 + i;
@@ -552,10 +616,10 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 		BARRIER();
 		if (tid == 0) {
 			int prev = p[(H - 1) * W + H - 1];
+			ColCells cc = col_cells(pc, 1, oc, 1);
 			for (int r = 0; r < H - 1; r++) {
-				classify_step<false>(ktab, q, r, H - 1, pc + r, 1, oc + r, 1, lc + r, prev, p, W, o, 1 << 30);
+				prev = classify_step<false>(ktab, q, r, H - 1, pc + r, 1, oc + r, 1, lc + r, prev, p, W, o, 1 << 30, cc);
 				if (r == 0) p[(H - 1) * W + H] = lc[0];                /* (255, 256) is also this column's "column 256" neighbour of row 255 */
-				prev = lc[r];
 			}
 		}
 		BARRIER();

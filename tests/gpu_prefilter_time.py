@@ -1,5 +1,5 @@
 """Developer tool (GPU box): the q <= 16 luma pre-filter as a stage on a full batch -- ms per batch and a check of some images against the oracle.
-usage: python tests/gpu_prefilter_time.py [q ...]   (NHW_LOW_LI / NHW_LOW_DBG act on developer builds)"""
+usage: python tests/gpu_prefilter_time.py [q ...]   (NHW_N=<images>; NHW_LOW_DBG acts on developer builds)"""
 import os, sys, time
 import numpy as np
 import torch
@@ -44,4 +44,4 @@ def main(qs, n=4096, check=6):
         print(f"q{q}: prefilter stage {min(ts):.1f} ms / {n} images (runs {', '.join(f'{t:.1f}' for t in ts)}); oracle check of {check}: {'OK' if not bad else 'MISMATCH ' + str(bad)}", flush=True)
 
 if __name__ == "__main__":
-    main([int(a) for a in sys.argv[1:]] or [1, 10, 16])
+    main([int(a) for a in sys.argv[1:]] or [1, 10, 16], n=int(os.environ.get("NHW_N", "4096")))
