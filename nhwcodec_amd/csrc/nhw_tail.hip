@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_C2) { chroma_ll1_neighbour(&c, tid); dequant_sim_chroma_par(&c, 1, tid); }
 	else if (PH == PH_C3) chroma_p3_par(&c, comp, tid);
 	else if (PH == PH_C4) dequant_sim_chroma_par(&c, 0, tid);
-	else if (PH == PH_C5) chroma_p5_par(&c, comp, tid, dyn_lds, sh_counts);
+	else if (PH == PH_C5) chroma_p5_par(&c, comp, tid, dyn_lds, sh_counts, ws.dbg != 0);
 	else if (PH == PH_FINAL) {
 		final_phase_par(&c, out + (size_t)img * (512u << 10), 512u << 10, &sizes[img], &status[img], &sh_pack, tid, reinterpret_cast<uint32_t *>(dyn_lds));
 	}
@@ -87,7 +87,7 @@ static size_t phase_lds(int ph)
 	case PH_L4B: return (size_t)(NT + 2) * TLS * sizeof(int16_t);
 	case PH_L4C: return 0;                                         /* Y26 is pointwise, Y27 a wavefront per row straight on the plane */
 	case PH_L4D: return 4608;                                      /* the list of run starts (at most one per 15 groups of the stream); the stream itself is written by the quantiser kernel */
-	case PH_C5: return 32 * 130 * 2 + (32 * 128 + 258) * 2 > tile ? 32 * 130 * 2 + (32 * 128 + 258) * 2 : tile;
+	case PH_C5: return CQ_LDS_BYTES > 32 * 130 * 2 + (32 * 128 + 258) * 2 ? CQ_LDS_BYTES : 32 * 130 * 2 + (32 * 128 + 258) * 2;   /* the quantiser's parked rows; the marks' and the emission's tables */
 	default: return 0;
 	}
 }

@@ -861,74 +861,89 @@ DEV void clean_details_par(Ctx *c, int tid, int16_t *lds)
 /* ---------------------------------------------------------------- a10 quantiser */
 /* (the luma quantiser is a wavefront-per-image kernel for every quality: wave_quantise_luma, nhw_tail_wave.h) */
 
-/* offsetUV (image_processing.c:108-183): pairs never span rows; the look at the next cell is unguarded at the
- * end of a row, so the first cell of the next row is read before any row is rewritten */
-struct QuantChromaF {
-	const int16_t *plane;
-	struct State { int next_first; };
-	__device__ State init(int t) const { return State{ plane[(t + 1) * H] }; }
-	__device__ int run(int16_t *row, int, int j, int j1, State &st) const
-	{
-		for (; j < j1; j++) {
-			int a = row[j];
-			const int nx = j < H - 1 ? row[j + 1] : st.next_first;
-			if (a > 10000) {
-				if (a == 12400) { row[j] = 124; continue; }
-				else if (a == 12600) { row[j] = 126; continue; }
-				else if (a == 12900) { row[j] = 122; continue; }
-				else if (a == 13000) { row[j] = 130; continue; }
-			}
-			if (a > 127) { row[j] = (int16_t)big_code(a, k_big_pos); continue; }
-			else if (a < -127) { row[j] = (int16_t)big_code(-a, k_big_neg); continue; }
-			if ((a == -7 || a == -8) && j < H - 1 && (nx == -7 || nx == -8)) { row[j] = 120; row[j + 1] = 120; j++; continue; }
-			if (a < 0) {
-				a = -a;
-				if (nx < 0 && nx > -8) { if ((a & 7) < 6) a &= 504; }
-				else { if ((a & 7) < 7) a &= 504; }
-				a = -a;
-			}
-			else if (a > 6 && (a & 7) >= 6) { if (j < H - 1 && nx == 7) row[j + 1] = 8; }
-			if (a < DEADZONE && a > -DEADZONE) row[j] = 128;
-			else row[j] = (int16_t)((a + 128) & 248);
-		}
-		return j;
-	}
-};
-/* The quantised plane only feeds the symbol stream, in serpentine order: 32 strips of 8 columns, within a strip
- * row after row, odd rows right to left, U in the even and V in the odd bytes (nhw_encoder.c:2553-2570).  A tile of
- * the row pass holds 4 whole strips, i.e. 4 runs of 2048 consecutive stream positions, so the stream is written
- * from the tile while it is in LDS: U parks its bytes in a plane of their own, V merges them and writes whole
- * 16-bit pairs (byte-interleaved scattered stores cost more than the quantiser). */
-DEV void quantise_chroma_par(Ctx *c, int comp, int tid, int16_t *lds)
+/* offsetUV (image_processing.c:108-183), a wavefront per row (lane l: columns l, l + 64, l + 128, l + 192), 64 consecutive rows per wavefront.
+ * The reference's walk along a row has two ways of reaching into the next cell: a pair of -7 / -8 neighbours becomes two 120s and the walk
+ * skips the second; a cell above 6 on residue 6 / 7 raises a 7 behind it to 8 (which then raises nothing itself).  Both only test values
+ * from before the walk, so each is "fires if visited / if not raised" along runs of candidates: the cells at even distance from the head
+ * of a run (alt_runs); the two never meet (one is about negative cells, the other about positive ones).  Everything else looks at the cell
+ * and at the cell behind it as it was; the look from column 255 goes to the first cell of the next row, unguarded, before any row is
+ * rewritten (nf: those cells, read before the pass).
+ * The quantised plane only feeds the symbol stream, in serpentine order: 32 strips of 8 columns, within a strip row after row, odd rows
+ * right to left, U in the even and V in the odd bytes (nhw_encoder.c:2553-2570): 16 rows are parked as bytes in a wave-private LDS block and
+ * leave as 64-byte runs (8 rows of a strip) per lane -- U into a byte plane of its own, V merged with it into the stream.  The int16
+ * plane is only written for the tests' stage check.
+ * (Until round 3 this was a thread per row on eight 32-column LDS tiles: 72-byte row pieces in and out, 0.93 + 0.39 MB per plane moved
+ * for 128 KB of coefficients and 64 KB of symbols.) */
+#define CQROW 264
+#define CQ_LDS_BYTES (4 * 16 * CQROW + 2 * (H + 2))
+DEV void quantise_chroma_par(Ctx *c, int comp, int tid, int16_t *lds, bool write_plane)
 {
-	int16_t *plane = c->cproc;
+	int16_t *p = c->cproc;
 	uint8_t *ubytes = reinterpret_cast<uint8_t *>(c->band);       /* Q bytes, free during the chroma phases */
 	uint8_t *scan = c->scan + 4 * Q;
-	QuantChromaF f = { plane };
-	int jnext = 0;
-	QuantChromaF::State st = f.init(tid);
-	for (int c0 = 0; c0 < H; c0 += TLC) {
-		tile_load(lds, plane, H, H, c0, tid);
-		BARRIER();
-		if (jnext < c0 + TLC) jnext = f.run(lds + tid * TLS + 2 - c0, tid, jnext, c0 + TLC, st);
-		BARRIER();
-		tile_store(lds, plane, H, H, c0, H - c0 < TLC + 2 ? H - c0 : TLC + 2, tid, c0 > 0 ? 0 : 2);   /* the cell a row pushed into the next tile travels through the plane */
-		for (int idx = tid; idx < (TLC / 8) * 512; idx += NT) {    /* 4 stream positions per thread */
-			const int sl = idx >> 9, rem = idx & 511, r = rem >> 1, k0 = (rem & 1) * 4;
-			const int16_t *row = lds + r * TLS + 2 + 8 * sl;
-			uint32_t w = 0;
-			for (int k = 0; k < 4; k++) w |= (uint32_t)(uint8_t)row[(r & 1) ? 7 - (k0 + k) : k0 + k] << (8 * k);
-			const int pos = (c0 / 8 + sl) * (8 * H) + 4 * rem;
-			if (!comp) *reinterpret_cast<uint32_t *>(ubytes + pos) = w;
-			else {
-				const uint32_t u = *reinterpret_cast<const uint32_t *>(ubytes + pos);
-				uint2 o;
-				o.x = (u & 0xFF) | ((w & 0xFF) << 8) | ((u & 0xFF00) << 8) | ((w & 0xFF00) << 16);
-				o.y = ((u >> 16) & 0xFF) | (((w >> 16) & 0xFF) << 8) | ((u >> 24) << 16) | ((w >> 24) << 24);
-				*reinterpret_cast<uint2 *>(scan + 2 * pos) = o;
+	const int lane = tid & 63, wv = tid >> 6;
+	uint8_t *park = reinterpret_cast<uint8_t *>(lds) + wv * 16 * CQROW;
+	int16_t *nf = lds + 4 * 16 * CQROW / 2;                        /* nf[r]: cell (r, 0) as it was (r = 256: what lies behind the plane) */
+	nf[tid + 1] = p[(tid + 1) * H];
+	BARRIER();
+	int cur[4], nxt[4] = { 0, 0, 0, 0 };
+	const int r0 = 64 * wv;
+	for (int k = 0; k < 4; k++) cur[k] = p[r0 * H + lane + 64 * k];
+	for (int i = 0; i < 64; i++) {
+		const int r = r0 + i;
+		if (i + 1 < 64) for (int k = 0; k < 4; k++) nxt[k] = p[(r + 1) * H + lane + 64 * k];
+		const int first_next = nf[r + 1];
+		unsigned P, S, T;
+		BS_PRED(P, cur, 4, (unsigned)(x + 8) < 2u); BS_PRED(S, cur, 4, x > 6 && x <= 127 && (x & 7) >= 6); BS_PRED(T, cur, 4, x == 7);
+		const unsigned inrow = lane == 63 ? 0x7u : 0xFu;           /* columns 0..254: neither reaches across the row end */
+		const unsigned pc = P & bs_dn(P, lane) & inrow, bc = S & bs_dn(T, lane) & inrow;
+		const unsigned pf = __any(pc != 0) ? bs_from4(alt_runs(bs_ballot4(pc))) : 0u;
+		const unsigned bf = __any(bc != 0) ? bs_from4(alt_runs(bs_ballot4(bc))) : 0u;
+		const unsigned pair = pf | bs_up<4>(pf, lane), raised = bs_up<4>(bf, lane);
+		for (int k = 0; k < 4; k++) {
+			const int x = cur[k], nx = right_of_dpp(cur, k, 4, lane, first_next);
+			int a = (raised >> k) & 1 ? 8 : x;
+			const bool neg = a < 0;
+			int m = neg ? -a : a;
+			const bool keep = (nx < 0 && nx > -8) ? (m & 7) >= 6 : (m & 7) == 7;
+			m = (neg && !keep) ? (m & 504) : m;
+			a = neg ? -m : m;
+			int sym = (unsigned)(a + DEADZONE - 1) < (unsigned)(2 * DEADZONE - 1) ? 128 : ((a + 128) & 248);
+			sym = (pair >> k) & 1 ? 120 : sym;
+			if (__ballot(x > 127 || x < -127)) {                     /* marks of the pass before and values beyond +-127: rare, whole words skip this */
+				if (x == 12400) sym = 124; else if (x == 12600) sym = 126; else if (x == 12900) sym = 122; else if (x == 13000) sym = 130;
+				else if (x > 127) sym = big_code(x, k_big_pos);
+				else if (x < -127) sym = big_code(-x, k_big_neg);
 			}
+			if (write_plane) p[r * H + lane + 64 * k] = (int16_t)sym;
+			park[(i & 15) * CQROW + lane + 64 * k] = (uint8_t)sym;
 		}
-		BARRIER();
+		if ((i & 15) == 15) {                                      /* 16 rows complete: lane l takes rows 8 (l & 1) .. + 7 of strip l >> 1, 64 stream bytes */
+			__threadfence_block();
+			const int strip = lane >> 1, rb = r - 15 + 8 * (lane & 1);
+			uint32_t w[16];
+			for (int j = 0; j < 8; j++) {
+				const uint2 x = *reinterpret_cast<const uint2 *>(park + (8 * (lane & 1) + j) * CQROW + 8 * strip);
+				if ((rb + j) & 1) { w[2 * j] = __builtin_bswap32(x.y); w[2 * j + 1] = __builtin_bswap32(x.x); } else { w[2 * j] = x.x; w[2 * j + 1] = x.y; }
+			}
+			const int pos = strip * (8 * H) + 8 * rb;
+			if (!comp) { for (int j = 0; j < 4; j++) reinterpret_cast<uint4 *>(ubytes + pos)[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]); }
+			else {
+				uint32_t o[32];
+				for (int j = 0; j < 4; j++) {
+					const uint4 u4 = reinterpret_cast<const uint4 *>(ubytes + pos)[j];
+					const uint32_t uu[4] = { u4.x, u4.y, u4.z, u4.w };
+					for (int e = 0; e < 4; e++) {
+						const uint32_t u = uu[e], v = w[4 * j + e];
+						o[8 * j + 2 * e] = (u & 0xFF) | ((v & 0xFF) << 8) | ((u & 0xFF00) << 8) | ((v & 0xFF00) << 16);
+						o[8 * j + 2 * e + 1] = ((u >> 16) & 0xFF) | (((v >> 16) & 0xFF) << 8) | ((u >> 24) << 16) | ((v >> 24) << 24);
+					}
+				}
+				for (int j = 0; j < 8; j++) reinterpret_cast<uint4 *>(scan + 2 * pos)[j] = make_uint4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+			}
+			__threadfence_block();
+		}
+		for (int k = 0; k < 4; k++) cur[k] = nxt[k];
 	}
 }
 
@@ -2125,7 +2140,7 @@ DEV void chroma_p3_par(Ctx *c, int comp, int tid)                     /* :2316-2
 		*reinterpret_cast<uint4 *>(jp + e0) = make_uint4(out[0], out[1], out[2], out[3]);
 	}
 }
-DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
+DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc, bool write_plane)
 {
 	int16_t *p = c->cproc, *o = c->cll1;
 	const int q = c->q;
@@ -2290,7 +2305,8 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc)
 		}
 	}
 	if (!tid) PROF(c, 21);
-	quantise_chroma_par(c, comp, tid, lds);
+	BARRIER();
+	quantise_chroma_par(c, comp, tid, lds, write_plane);
 	if (!tid) PROF(c, 22);
 }
 
