@@ -19,6 +19,7 @@ void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_str
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, int16_t *keep, size_t keep_stride, hipStream_t s,
                          int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0);
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s);
+void nhw_launch_l2_recon(int16_t *jpeg, const int16_t *proc, size_t plane_stride, int16_t *ll1, size_t ll1_stride, int n, hipStream_t s);
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
 void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv, size_t c_stride, const int16_t *y, size_t y_stride, int with_prefilter,
                             uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
@@ -255,10 +256,12 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	nhw_launch_phase(PH_L1, ws, 0, out, d_sizes, d_status, s);
 	nhw_launch_wave(WV_DQ1, ws, s);          /* every quality (1..16: rationed low bits, no marking passes) */
 	STAGE_DONE();
+	if (ws.dbg) {
 	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s);
 	STAGE_DONE();
 	nhw_launch_phase(PH_L2, ws, 0, out, d_sizes, d_status, s);
 	STAGE_DONE();
+	} else nhw_launch_l2_recon(jpeg, proc, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, n, s);   /* synthesis + Y8 + Y9 on one residency of the block; the stage checks take the three kernels */
 	if (q > 12) nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s, plane16(ws, B_L2SAVE), ws.stride[B_L2SAVE] / 2, H, 1);   /* + Y13 (:623-631): copy of the coefficient block */
 	else nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
 	STAGE_DONE();

@@ -755,6 +755,7 @@ __global__ void k_synth(uint8_t *__restrict__ bgr, int n, uint32_t seed_base)
 } // namespace nhw
 
 /* ------------------------------------------------------------------------------------------------ launchers */
+#include "nhw_dwt.h"
 using namespace nhw;
 
 static float color_yq(int q, int *family);
@@ -792,9 +793,6 @@ __device__ __forceinline__ int pair_predict_s(const int16_t *x, int st, int k)
 	if ((k & 1) && (a & 1) && ((x[(2 * k - 2) * st] + x[2 * k * st]) & 1)) a++;
 	return x[(2 * k + 1) * st] - (a >> 1);
 }
-
-/* workgroup barrier that orders LDS traffic only: global loads stay in flight across it */
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int S>
 __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int final_level,
@@ -885,26 +883,6 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 	}
 	lds_barrier();                                                 /* the block is done with before the next one moves in */
 	}
-}
-
-template <int S>
-__device__ __forceinline__ void syn_pair(const int16_t *x, int st, int k, bool normalise, int *e_out, int *o_out)
-{
-	constexpr int M = S / 2;
-	const int16_t *lo = x, *hi = x + M * st;
-	const int l0 = lo[k * st], ln = (k + 1 < M) ? lo[(k + 1) * st] : l0;
-	const int h0 = hi[k * st], hp = k > 0 ? hi[(k - 1) * st] : hi[0], hn = (k + 1 < M) ? hi[(k + 1) * st] : h0;
-	int16_t e = (int16_t)(l0 << 3);
-	int16_t o = (int16_t)((l0 + ln) << 2);
-	e = (int16_t)(e - ((h0 + hp) << 1));
-	o = (int16_t)(o + (6 * h0 - hp - hn));
-	if (normalise) {
-		if (e > 0) e = (int16_t)(e + 32);
-		e >>= 6;
-		if (o > 0) o = (int16_t)(o + 32);
-		o >>= 6;
-	}
-	*e_out = e; *o_out = o;
 }
 
 template <int S>

@@ -3,6 +3,7 @@
  * per image (see nhw_tail_par.h / nhw_tail_dev.h), plus the small block-copy kernel used between them.
  */
 #include "nhw_tail_par.h"
+#include "nhw_dwt.h"
 
 using namespace nhw;
 
@@ -66,6 +67,128 @@ void nhw_launch_wave(int ph, const NhwWs &ws, hipStream_t s)
 	}
 }
 
+/* The middle of the first closed loop on one LDS residency of the 256 x 256 block: level-2 synthesis (wavelet_filterbank.c:305-496), Y8 (the
+ * tags of the level-2 details nudge the reconstruction, nhw_encoder.c:183-216) and Y9 (LL1 pre-compensation, :218-279).  The reconstruction
+ * is only ever read by Y9, and Y9 only hands on `ll1 + step` (the input of the analysis that follows): as three kernels the block went out
+ * twice in two orientations, came back through Y8's tiles and Y9's rows and went out again (6.3 GB per 4096 images); here it never leaves
+ * the LDS (2.2 GB: coefficients and LL1 in, LL1 without its tags and the pre-compensated LL1 out).
+ *   * the synthesis leaves column c of the block as what the plane holds in row c: proc[y][x] = A[x][y];
+ *   * a tag at (r, j) of the LL1 plane nudges proc[2(j-128)+1][2r], proc[2j][2(r-128)+1] or proc[2(j-128)+1][2(r-128)+1] (:205-213), i.e. a
+ *     cell of ROW 2r / 2(r-128)+1 of the block: a wavefront takes an LL1 row, its targets are cells of one row of LDS, no two tags share one;
+ *   * Y9 walks a row of proc = a column of the block (odd dword stride: no bank conflicts), a lane four cells, the step handed from lane to
+ *     lane until nothing moves (precompensate_ll1_par).  Its two outer neighbours are cells of the planes outside the block.
+ * One 1024-thread workgroup per CU works through the batch, the next block on its way in registers (k_dwt_syn).  The tests' stage checks
+ * (nhw_debug_stop_after) run the three kernels instead, which leave every intermediate plane. */
+__global__ __launch_bounds__(1024) void k_l2_recon(int16_t *__restrict__ jpegb, const int16_t *__restrict__ procb, size_t plane_stride, int16_t *__restrict__ ll1b, size_t ll1_stride, int n)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
+	constexpr int S = H, LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = 1024, NPRE = S * (S / 8) / NT_;
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	int16_t *A = smem;
+	uint4 pre[NPRE];
+	if ((int)blockIdx.x < n) {
+		const int16_t *src = jpegb + (size_t)blockIdx.x * plane_stride;
+#pragma unroll
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * W + 8 * (v % (S / 8))); }
+	}
+	for (int img = blockIdx.x; img < n; img += gridDim.x) {
+		int16_t *jp = jpegb + (size_t)img * plane_stride, *o = ll1b + (size_t)img * ll1_stride;
+		const int16_t *p = procb + (size_t)img * plane_stride;
+#pragma unroll
+		for (int u = 0; u < NPRE; u++) {
+			const int v = t + u * NT_, row = v / (S / 8), c8 = v % (S / 8);
+			uint32_t *d = reinterpret_cast<uint32_t *>(A + row * LS + 8 * c8);
+			d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
+		}
+		lds_barrier();
+		if (img + (int)gridDim.x < n) {
+			const int16_t *src = jpegb + (size_t)(img + gridDim.x) * plane_stride;
+#pragma unroll
+			for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * W + 8 * (v % (S / 8))); }
+		}
+		for (int i = 0; i < 16; i++) {                             /* synthesis, first direction, un-normalised */
+			int16_t *x = A + (wv * 16 + i) * LS;
+			int e[PPL], od[PPL];
+#pragma unroll
+			for (int u = 0; u < PPL; u++) syn_pair<S>(x, 1, lane + 64 * u, false, &e[u], &od[u]);
+#pragma unroll
+			for (int u = 0; u < PPL; u++) reinterpret_cast<uint32_t *>(x)[lane + 64 * u] = (uint32_t)(uint16_t)e[u] | ((uint32_t)(uint16_t)od[u] << 16);
+		}
+		lds_barrier();
+		for (int i = 0; i < 16; i++) {                             /* second direction along the columns, normalised, in place */
+			int16_t *x = A + wv * 16 + i;
+			int e[PPL], od[PPL];
+#pragma unroll
+			for (int u = 0; u < PPL; u++) syn_pair<S>(x, LS, lane + 64 * u, true, &e[u], &od[u]);
+#pragma unroll
+			for (int u = 0; u < PPL; u++) { const int k = lane + 64 * u; x[(2 * k) * LS] = (int16_t)e[u]; x[(2 * k + 1) * LS] = (int16_t)od[u]; }
+		}
+		lds_barrier();
+		for (int i = 0; i < 16; i++) {                             /* Y8: LL1 row r, a lane four cells */
+			const int r = wv * 16 + i, j0 = 4 * lane;
+			uint2 w = *reinterpret_cast<const uint2 *>(o + (size_t)r * H + j0);
+			int v[4];
+			unpack4(w, v);
+			bool any = false;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				int step = 0;
+				if (v[k] > 14000) { v[k] -= 16000; step = 1; } else if (v[k] > 10000) { v[k] -= 12000; step = -1; }
+				if (!step) continue;
+				any = true;
+				const int j = j0 + k;
+				if (r < HLF && j >= HLF) A[(2 * r) * LS + 2 * (j - HLF) + 1] += (int16_t)step;
+				else if (r >= HLF && j < HLF) A[(2 * (r - HLF) + 1) * LS + 2 * j] += (int16_t)step;
+				else if (r >= HLF && j >= HLF) A[(2 * (r - HLF) + 1) * LS + 2 * (j - HLF) + 1] += (int16_t)step;
+			}
+			if (any) {
+				w.x = (uint32_t)(uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16); w.y = (uint32_t)(uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
+				*reinterpret_cast<uint2 *>(o + (size_t)r * H + j0) = w;
+			}
+		}
+		__syncthreads();                                           /* the nudged block, and LL1 without its tags (rows of other wavefronts: the cell before and behind a row) */
+		{                                                          /* Y9 */
+			const int c0 = 4 * lane;
+			uint2 oc = make_uint2(0, 0); int edge = 0;
+#define Y9_LOAD(r) do { oc = *reinterpret_cast<const uint2 *>(o + (size_t)(r) * H + c0); \
+		if (lane == 0) edge = p[(size_t)(r) * W - 1] - o[(size_t)(r) * H - 1];      /* left of column 0: the cells before the row in memory, never updated */ \
+		if (lane == 63) edge = p[(size_t)(r) * W + H] - o[(size_t)(r) * H + H]; } while (0)
+			int r = wv * 16;
+			Y9_LOAD(r);
+			for (int i = 0; i < 16; i++, r++) {
+				int pv[4], ov[4], d[4], st[4];
+				unpack4(oc, ov);
+				const int my_edge = edge;
+#pragma unroll
+				for (int k = 0; k < 4; k++) { pv[k] = A[(c0 + k) * LS + r]; d[k] = (int16_t)(pv[k] - ov[k]); }
+				if (i + 1 < 16) Y9_LOAD(r + 1);
+				const int sd = __shfl_down(d[0], 1), su = __shfl_up(d[3], 1);
+				const int dn4 = lane < 63 ? sd : my_edge;             /* the difference on the right of my last cell, as it was */
+				const int first = lane ? su : my_edge;
+				int prev_in = first;
+				for (;;) {
+					int prev = prev_in;
+#pragma unroll
+					for (int k = 0; k < 4; k++) { st[k] = precomp_step(d[k], k < 3 ? d[k + 1] : dn4, prev); prev = d[k] + st[k]; }
+					int np = __shfl_up(prev, 1);
+					if (!lane) np = first;
+					if (!__any(np != prev_in)) break;
+					prev_in = np;
+				}
+				uint2 w;
+				w.x = (uint32_t)(uint16_t)(ov[0] + st[0]) | ((uint32_t)(uint16_t)(ov[1] + st[1]) << 16); w.y = (uint32_t)(uint16_t)(ov[2] + st[2]) | ((uint32_t)(uint16_t)(ov[3] + st[3]) << 16);
+				*reinterpret_cast<uint2 *>(jp + (size_t)r * W + c0) = w;
+			}
+#undef Y9_LOAD
+		}
+		lds_barrier();                                             /* the block is done with before the next one moves in */
+	}
+}
+void nhw_launch_l2_recon(int16_t *jpeg, const int16_t *proc, size_t plane_stride, int16_t *ll1, size_t ll1_stride, int n, hipStream_t s)
+{
+	k_l2_recon<<<n < 256 ? n : 256, 1024, H * (H + 2) * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, ll1, ll1_stride, n);
+}
+
 /* rows x cols block of shorts between two strided planes, every image of the batch */
 __global__ __launch_bounds__(256) void k_copy_block(const int16_t *__restrict__ src, size_t src_plane, int src_row,
                                                     int16_t *__restrict__ dst, size_t dst_plane, int dst_row, int rows, int cols)
@@ -98,6 +221,8 @@ int nhw_tail_set_attrs(const char **where)
 #define SETATTR(fn) do { const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10); \
                          if (e_ != hipSuccess) { *where = "hipFuncSetAttribute(" #fn ", MaxDynamicSharedMemorySize)"; return (int)e_; } } while (0)
 	SETATTR(k_phase<PH_L1>); SETATTR(k_phase<PH_L2>); SETATTR(k_phase<PH_L3>); SETATTR(k_phase<PH_C5>);
+	{ const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_l2_recon), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(H * (H + 2) * sizeof(int16_t)));
+	  if (e_ != hipSuccess) { *where = "hipFuncSetAttribute(k_l2_recon, MaxDynamicSharedMemorySize)"; return (int)e_; } }
 #undef SETATTR
 	return 0;
 }
