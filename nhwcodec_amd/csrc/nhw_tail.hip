@@ -106,6 +106,15 @@ __global__ __launch_bounds__(1024) void k_l2_recon(int16_t *__restrict__ jpegb, 
 #pragma unroll
 			for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * W + 8 * (v % (S / 8))); }
 		}
+		/* the cells of the planes around the block that Y9 looks at, requested now -- lane l < 16: the cell of proc before row l of mine, lanes
+		 * 16 .. 31: the one behind it; lane 32 / 33: the LL1 cell before my first row / behind my last one (rows of my neighbours).  Taking a
+		 * tag off an LL1 cell is a function of the cell, so nobody waits for the wavefront that writes the clean value back. */
+		const int r0 = wv * 16, c0 = 4 * lane;
+		int side = 0;
+		if (lane < 16) side = p[(size_t)(r0 + lane) * W - 1];
+		else if (lane < 32) side = p[(size_t)(r0 + lane - 16) * W + H];
+		else if (lane == 32) { side = o[(size_t)r0 * H - 1]; if (wv > 0) side = side > 14000 ? side - 16000 : side > 10000 ? side - 12000 : side; }   /* (what lies outside the plane is left as it is) */
+		else if (lane == 33) { side = o[(size_t)(r0 + 16) * H]; if (wv < 15) side = side > 14000 ? side - 16000 : side > 10000 ? side - 12000 : side; }
 		for (int i = 0; i < 16; i++) {                             /* synthesis, first direction, un-normalised */
 			int16_t *x = A + (wv * 16 + i) * LS;
 			int e[PPL], od[PPL];
@@ -124,62 +133,67 @@ __global__ __launch_bounds__(1024) void k_l2_recon(int16_t *__restrict__ jpegb, 
 			for (int u = 0; u < PPL; u++) { const int k = lane + 64 * u; x[(2 * k) * LS] = (int16_t)e[u]; x[(2 * k + 1) * LS] = (int16_t)od[u]; }
 		}
 		lds_barrier();
+		auto ll1_row = [&](int i) { return *reinterpret_cast<const uint2 *>(o + (size_t)(r0 + (i < 16 ? i : 15)) * H + c0); };   /* row i of mine */
+		auto untag = [](int v) { return v > 14000 ? v - 16000 : v > 10000 ? v - 12000 : v; };
+		/* both walks keep a window of four rows in registers: the row in hand and the three behind it, requested three rows ahead of their use
+		 * (rolled loops: unrolled, the compiler interleaves the rows and spills) */
+		uint2 w0 = ll1_row(0), w1 = ll1_row(1), w2 = ll1_row(2), w3 = ll1_row(3);
+#pragma unroll 1
 		for (int i = 0; i < 16; i++) {                             /* Y8: LL1 row r, a lane four cells */
-			const int r = wv * 16 + i, j0 = 4 * lane;
-			uint2 w = *reinterpret_cast<const uint2 *>(o + (size_t)r * H + j0);
+			const int r = r0 + i;
 			int v[4];
-			unpack4(w, v);
+			unpack4(w0, v);
+			w0 = w1; w1 = w2; w2 = w3; w3 = ll1_row(i + 4);
 			bool any = false;
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
-				int step = 0;
-				if (v[k] > 14000) { v[k] -= 16000; step = 1; } else if (v[k] > 10000) { v[k] -= 12000; step = -1; }
+				const int step = v[k] > 14000 ? 1 : v[k] > 10000 ? -1 : 0;
 				if (!step) continue;
+				v[k] = untag(v[k]);
 				any = true;
-				const int j = j0 + k;
+				const int j = c0 + k;
 				if (r < HLF && j >= HLF) A[(2 * r) * LS + 2 * (j - HLF) + 1] += (int16_t)step;
 				else if (r >= HLF && j < HLF) A[(2 * (r - HLF) + 1) * LS + 2 * j] += (int16_t)step;
 				else if (r >= HLF && j >= HLF) A[(2 * (r - HLF) + 1) * LS + 2 * (j - HLF) + 1] += (int16_t)step;
 			}
 			if (any) {
+				uint2 w;
 				w.x = (uint32_t)(uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16); w.y = (uint32_t)(uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
-				*reinterpret_cast<uint2 *>(o + (size_t)r * H + j0) = w;
+				*reinterpret_cast<uint2 *>(o + (size_t)r * H + c0) = w;
 			}
 		}
-		__syncthreads();                                           /* the nudged block, and LL1 without its tags (rows of other wavefronts: the cell before and behind a row) */
-		{                                                          /* Y9 */
-			const int c0 = 4 * lane;
-			uint2 oc = make_uint2(0, 0); int edge = 0;
-#define Y9_LOAD(r) do { oc = *reinterpret_cast<const uint2 *>(o + (size_t)(r) * H + c0); \
-		if (lane == 0) edge = p[(size_t)(r) * W - 1] - o[(size_t)(r) * H - 1];      /* left of column 0: the cells before the row in memory, never updated */ \
-		if (lane == 63) edge = p[(size_t)(r) * W + H] - o[(size_t)(r) * H + H]; } while (0)
-			int r = wv * 16;
-			Y9_LOAD(r);
-			for (int i = 0; i < 16; i++, r++) {
-				int pv[4], ov[4], d[4], st[4];
-				unpack4(oc, ov);
-				const int my_edge = edge;
+		w0 = ll1_row(0); w1 = ll1_row(1); w2 = ll1_row(2); w3 = ll1_row(3);   /* (with or without their tags: whichever the memory system hands out) */
+		lds_barrier();                                             /* the nudged block */
+		int o_left = __builtin_amdgcn_readlane(side, 32);          /* the LL1 cell before the row in memory, without its tag */
+#pragma unroll 1
+		for (int i = 0; i < 16; i++) {                             /* Y9 */
+			const int r = r0 + i;
+			int pv[4], ov[4], d[4], st[4];
+			unpack4(w0, ov);
+			/* left of column 0 / right of column 255: the cells before and behind the row in memory, never updated */
+			const int o_right = i == 15 ? __builtin_amdgcn_readlane(side, 33) : untag((int)(int16_t)(__builtin_amdgcn_readlane((int)w1.x, 0) & 0xFFFF));
+			w0 = w1; w1 = w2; w2 = w3; w3 = ll1_row(i + 4);
 #pragma unroll
-				for (int k = 0; k < 4; k++) { pv[k] = A[(c0 + k) * LS + r]; d[k] = (int16_t)(pv[k] - ov[k]); }
-				if (i + 1 < 16) Y9_LOAD(r + 1);
-				const int sd = __shfl_down(d[0], 1), su = __shfl_up(d[3], 1);
-				const int dn4 = lane < 63 ? sd : my_edge;             /* the difference on the right of my last cell, as it was */
-				const int first = lane ? su : my_edge;
-				int prev_in = first;
-				for (;;) {
-					int prev = prev_in;
+			for (int k = 0; k < 4; k++) { ov[k] = untag(ov[k]); pv[k] = A[(c0 + k) * LS + r]; d[k] = (int16_t)(pv[k] - ov[k]); }
+			const int p_left = __shfl(side, i), p_right = __shfl(side, 16 + i);
+			const int my_edge = lane ? p_right - o_right : p_left - o_left;
+			o_left = __builtin_amdgcn_readlane(ov[3], 63);
+			const int sd = __shfl_down(d[0], 1), su = __shfl_up(d[3], 1);
+			const int dn4 = lane < 63 ? sd : my_edge;                 /* the difference on the right of my last cell, as it was */
+			const int first = lane ? su : my_edge;
+			int prev_in = first;
+			for (;;) {
+				int prev = prev_in;
 #pragma unroll
-					for (int k = 0; k < 4; k++) { st[k] = precomp_step(d[k], k < 3 ? d[k + 1] : dn4, prev); prev = d[k] + st[k]; }
-					int np = __shfl_up(prev, 1);
-					if (!lane) np = first;
-					if (!__any(np != prev_in)) break;
-					prev_in = np;
-				}
-				uint2 w;
-				w.x = (uint32_t)(uint16_t)(ov[0] + st[0]) | ((uint32_t)(uint16_t)(ov[1] + st[1]) << 16); w.y = (uint32_t)(uint16_t)(ov[2] + st[2]) | ((uint32_t)(uint16_t)(ov[3] + st[3]) << 16);
-				*reinterpret_cast<uint2 *>(jp + (size_t)r * W + c0) = w;
+				for (int k = 0; k < 4; k++) { st[k] = precomp_step(d[k], k < 3 ? d[k + 1] : dn4, prev); prev = d[k] + st[k]; }
+				int np = __shfl_up(prev, 1);
+				if (!lane) np = first;
+				if (!__any(np != prev_in)) break;
+				prev_in = np;
 			}
-#undef Y9_LOAD
+			uint2 w;
+			w.x = (uint32_t)(uint16_t)(ov[0] + st[0]) | ((uint32_t)(uint16_t)(ov[1] + st[1]) << 16); w.y = (uint32_t)(uint16_t)(ov[2] + st[2]) | ((uint32_t)(uint16_t)(ov[3] + st[3]) << 16);
+			*reinterpret_cast<uint2 *>(jp + (size_t)r * W + c0) = w;
 		}
 		lds_barrier();                                             /* the block is done with before the next one moves in */
 	}
