@@ -574,24 +574,22 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 	const int j = tid;
 	int lhm1 = p[j * W + H - 1];                                    /* (j, 255): nothing has touched it yet */
 	for (int r0 = 0; r0 < H - 1; r0 += CR) {
-		if (r0) {                                                   /* the first three rows' differences are the last three of the chunk before */
-			uint4 keep = make_uint4(0, 0, 0, 0);
-			if (tid < 3 * (H / 8)) keep = reinterpret_cast<const uint4 *>(dt + CR * H)[tid];
+		if (r0) {                                                   /* the first three rows are the last three of the chunk before: samples and cells as its steps left them, differences as loaded */
+			uint4 kd = make_uint4(0, 0, 0, 0), kp = kd, ko = kd;
+			if (tid < 3 * (H / 8)) { kd = reinterpret_cast<const uint4 *>(dt + CR * H)[tid]; kp = reinterpret_cast<const uint4 *>(pt + CR * H)[tid]; ko = reinterpret_cast<const uint4 *>(ot + CR * H)[tid]; }
 			BARRIER();
-			if (tid < 3 * (H / 8)) reinterpret_cast<uint4 *>(dt)[tid] = keep;
+			if (tid < 3 * (H / 8)) { reinterpret_cast<uint4 *>(dt)[tid] = kd; reinterpret_cast<uint4 *>(pt)[tid] = kp; reinterpret_cast<uint4 *>(ot)[tid] = ko; }
 		}
-		for (int v = tid; v < (CR + 3) * (H / 8); v += NT) {          /* 8 columns of one row per access */
+		for (int v = tid + (r0 ? 3 * (H / 8) : 0); v < (CR + 3) * (H / 8); v += NT) {   /* 8 columns of one row per access */
 			const int i = v / (H / 8), c8 = 8 * (v % (H / 8)), row = r0 - 1 + i;
 			uint4 pv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
 			if (row >= 0) { pv = *reinterpret_cast<const uint4 *>(p + row * W + c8); ov = *reinterpret_cast<const uint4 *>(o + row * H + c8); }   /* rows 256, 257 of ll1 lie in its zero guard */
 			*reinterpret_cast<uint4 *>(pt + i * H + c8) = pv;
 			*reinterpret_cast<uint4 *>(ot + i * H + c8) = ov;
-			if (!r0 || i >= 3) {
-				const uint32_t a[4] = { pv.x, pv.y, pv.z, pv.w }, b[4] = { ov.x, ov.y, ov.z, ov.w };
-				uint32_t d[4];
-				for (int e = 0; e < 4; e++) d[e] = ((a[e] - b[e]) & 0xFFFF) | (((a[e] >> 16) - (b[e] >> 16)) << 16);
-				*reinterpret_cast<uint4 *>(dt + i * H + c8) = make_uint4(d[0], d[1], d[2], d[3]);
-			}
+			const uint32_t a[4] = { pv.x, pv.y, pv.z, pv.w }, b[4] = { ov.x, ov.y, ov.z, ov.w };
+			uint32_t d[4];
+			for (int e = 0; e < 4; e++) d[e] = ((a[e] - b[e]) & 0xFFFF) | (((a[e] >> 16) - (b[e] >> 16)) << 16);
+			*reinterpret_cast<uint4 *>(dt + i * H + c8) = make_uint4(d[0], d[1], d[2], d[3]);
 		}
 		if (r0 % LW == 0) lh_tile_load(lt, p, r0, tid);
 		BARRIER();
@@ -601,7 +599,7 @@ DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 				lhm1 = classify_step<true>(ktab, q, r0 + i, j, pt + (i + 1) * H + j, H, ot + (i + 1) * H + j, H, lt + j * LP + r0 % LW + i, lhm1, dt + (i + 1) * H + j + 1, H, nullptr, 0, cc);
 		}
 		BARRIER();
-		for (int v = tid; v < (CR + 2) * (H / 8); v += NT) {          /* column 255 travels too, unchanged */
+		for (int v = tid; v < (r0 + CR < H - 1 ? CR : CR + 2) * (H / 8); v += NT) {   /* the rows this chunk is through with (the last two go on to the next one in LDS); column 255 travels too, unchanged */
 			const int i = 1 + v / (H / 8), c8 = 8 * (v % (H / 8)), row = r0 - 1 + i;
 			*reinterpret_cast<uint4 *>(p + row * W + c8) = *reinterpret_cast<const uint4 *>(pt + i * H + c8);
 			if (row < H) *reinterpret_cast<uint4 *>(o + row * H + c8) = *reinterpret_cast<const uint4 *>(ot + i * H + c8);
