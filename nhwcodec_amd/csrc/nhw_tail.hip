@@ -85,6 +85,8 @@ __global__ __launch_bounds__(1024) void k_l2_recon(int16_t *__restrict__ jpegb, 
 	constexpr int S = H, LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = 1024, NPRE = S * (S / 8) / NT_;
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	int16_t *A = smem;
+	int8_t *ytab = reinterpret_cast<int8_t *>(A + S * LS);         /* Y9's step by (difference, what it sees of its neighbours) */
+	if (t < PRECOMP_TAB) ytab[t] = (int8_t)precomp_pick(t / 11 - 12, t % 11 - 5);
 	uint4 pre[NPRE];
 	if ((int)blockIdx.x < n) {
 		const int16_t *src = jpegb + (size_t)blockIdx.x * plane_stride;
@@ -181,11 +183,12 @@ __global__ __launch_bounds__(1024) void k_l2_recon(int16_t *__restrict__ jpegb, 
 			const int sd = __shfl_down(d[0], 1), su = __shfl_up(d[3], 1);
 			const int dn4 = lane < 63 ? sd : my_edge;                 /* the difference on the right of my last cell, as it was */
 			const int first = lane ? su : my_edge;
+			const int nb[4] = { precomp_right(d[1]), precomp_right(d[2]), precomp_right(d[3]), precomp_right(dn4) };
 			int prev_in = first;
 			for (;;) {
 				int prev = prev_in;
 #pragma unroll
-				for (int k = 0; k < 4; k++) { st[k] = precomp_step(d[k], k < 3 ? d[k + 1] : dn4, prev); prev = d[k] + st[k]; }
+				for (int k = 0; k < 4; k++) { st[k] = ytab[precomp_index(d[k], nb[k] + prev)]; prev = d[k] + st[k]; }
 				int np = __shfl_up(prev, 1);
 				if (!lane) np = first;
 				if (!__any(np != prev_in)) break;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_l2_recon(int16_t *__restrict__ jpegb, 
 }
 void nhw_launch_l2_recon(int16_t *jpeg, const int16_t *proc, size_t plane_stride, int16_t *ll1, size_t ll1_stride, int n, hipStream_t s)
 {
-	k_l2_recon<<<n < 256 ? n : 256, 1024, H * (H + 2) * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, ll1, ll1_stride, n);
+	k_l2_recon<<<n < 256 ? n : 256, 1024, H * (H + 2) * sizeof(int16_t) + 288, s>>>(jpeg, proc, plane_stride, ll1, ll1_stride, n);
 }
 
 /* rows x cols block of shorts between two strided planes, every image of the batch */
@@ -235,7 +238,7 @@ int nhw_tail_set_attrs(const char **where)
 #define SETATTR(fn) do { const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10); \
                          if (e_ != hipSuccess) { *where = "hipFuncSetAttribute(" #fn ", MaxDynamicSharedMemorySize)"; return (int)e_; } } while (0)
 	SETATTR(k_phase<PH_L1>); SETATTR(k_phase<PH_L2>); SETATTR(k_phase<PH_L3>); SETATTR(k_phase<PH_C5>);
-	{ const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_l2_recon), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(H * (H + 2) * sizeof(int16_t)));
+	{ const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_l2_recon), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(H * (H + 2) * sizeof(int16_t) + 288));
 	  if (e_ != hipSuccess) { *where = "hipFuncSetAttribute(k_l2_recon, MaxDynamicSharedMemorySize)"; return (int)e_; } }
 #undef SETATTR
 	return 0;

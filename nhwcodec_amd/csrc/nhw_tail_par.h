@@ -191,13 +191,13 @@ DEV void row_pass_tiled(int16_t *plane, int rs, int row_end, int nrows, int roff
 /* (:218-279) left neighbour is read after its own update, right neighbour before: serial along a row; rows do
  * not interact (column 0 reads proc[r][-1] = the LH1 cell (r-1, 511), which this pass never writes). */
 DEV void unpack4(uint2 w, int v[4]) { v[0] = (int16_t)(w.x & 0xFFFF); v[1] = (int16_t)(w.x >> 16); v[2] = (int16_t)(w.y & 0xFFFF); v[3] = (int16_t)(w.y >> 16); }
-DEV int precomp_step(int d, int dnext, int prev)
+/* the step of a cell with difference d, given the difference on its right as the walk found it and the one on its left as the walk left it
+ * (:225-279): what it sees of the two is their sum a, the right one first pulled in by its own large step */
+DEV int precomp_right(int dnext) { return iabs(dnext) > 4 ? dnext + big_step(dnext) : dnext; }
+DEV int precomp_pick(int d, int a)
 {
 	int step = big_step(d);
 	if (!step && iabs(d) > 1) {
-		int a = dnext;
-		if (iabs(a) > 4) a += big_step(a);
-		a += prev;
 		if (d >= 4 && a >= 1) step = -1;
 		else if (d <= -4 && a <= -1) step = 1;
 		else if (d == 3 && a >= 0) step = -1;
@@ -213,6 +213,10 @@ DEV int precomp_step(int d, int dnext, int prev)
 	}
 	return step;
 }
+DEV int precomp_step(int d, int dnext, int prev) { return precomp_pick(d, precomp_right(dnext) + prev); }
+/* precomp_pick only tells d apart inside -12 .. 12 and a inside -5 .. 5: as a table (k_l2_recon) */
+#define PRECOMP_TAB (25 * 11)
+DEV int precomp_index(int d, int a) { return __mul24((d < -12 ? -12 : d > 12 ? 12 : d) + 12, 11) + (a < -5 ? -5 : a > 5 ? 5 : a) + 5; }
 DEV void precompensate_ll1_par(Ctx *c, int tid, int16_t *lds)
 {
 	/* The walk only looks at differences d = recon - ll1 (its own, its right neighbour's original one, its left neighbour's
