@@ -15,14 +15,15 @@ WHAT = {
     "k_front_chain": "a2: the rows' maps chained down the image: entry state of every row",
     "k_dwt_ana<256>": "level-1 chroma analysis, level-2 luma analysis of both closed loops (whole block in LDS, persistent workgroups)",
     "k_dwt_ana<128>": "level-2 chroma analysis",
-    "k_dwt_syn<256>": "level-2 luma synthesis of both closed loops",
+    "k_dwt_syn<256>": "level-2 luma synthesis of the second closed loop",
     "k_dwt_syn<128>": "level-2 chroma synthesis",
-    "L1": "Y5 tag level-2 details", "L2": "Y8 tags -> recon, Y9 pre-compensation (wavefront per row)", "L3": "Y16 LL2 coder (parse), Y17",
-    "L4A": "Y19-Y23: small runs (wavefront per row), residual classification and coding (column walks on LDS tiles)",
+    "k_l2_recon": "first closed loop: level-2 synthesis + Y8 (tags -> reconstruction) + Y9 (LL1 pre-compensation) on one LDS residency of the block",
+    "L1": "Y5 tag level-2 details", "L2": "Y8, Y9 as a kernel of their own (only the tests' stage checks run it)", "L3": "Y16 LL2 coder (parse), Y17",
+    "L4A": "Y19-Y23: small runs (wavefront per row), residual classification (one table-driven step for every kind) and coding (column walks on LDS tiles)",
     "L4B": "Y24, Y25 position lists + list packing", "L4C": "Y26, Y27 detail clean-up (wavefront per row)", "L4D": "Y31 rewrites of the symbol stream",
     "L4C2": "Y29 (q >= 22): band reconstruction, half synthesis, res6 / char_res1 / qsetting3 lists",
     "C0": "chroma: copy", "C2": "chroma: dequantiser simulation 1", "C3": "chroma: tags", "C4": "chroma: dequantiser simulation 2",
-    "C5": "chroma: marks (running-index fixed point), LL2 emission, quantiser + stream bytes", "LLC": "Z1 chroma LL2 coder", "FINAL": "Z2 packetiser + container",
+    "C5": "chroma: marks (running-index fixed point), LL2 emission, quantiser (wavefront per row) + stream bytes", "LLC": "Z1 chroma LL2 coder", "FINAL": "Z2 packetiser + container",
     "DQ1": "a8 dequantiser simulation, first closed loop (wavefront per image)", "DQ0": "a8 dequantiser simulation, second closed loop",
     "EMIT": "Y14/Y15 LL2 emission", "QUANT": "Y28 luma quantiser + Y30 stream order (wavefront per image)",
 }
