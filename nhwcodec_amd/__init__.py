@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(HERE, "libnhwhip.so")
 IMG_BYTES = 786432
 OUT_STRIDE = 512 << 10
 QUALITY_DEFAULT = 20          # reference nhw_encoder_cli.c:95 (NORM)
+# per-image / call status (include/nhw_hip.h)
+NHW_OK, NHW_E_QUALITY, NHW_E_CODEBOOK, NHW_E_SPACE, NHW_E_ARG, NHW_E_HIP, NHW_E_FORMAT = 0, -1, -2, -3, -4, -5, -6
 
 P = ctypes.c_void_p
 

@@ -31,4 +31,35 @@ __device__ __forceinline__ void syn_pair(const int16_t *x, int st, int k, bool n
 	*e_out = e; *o_out = o;
 }
 
+/* rounding of the analysis' second direction (filters.c:88-287) */
+__device__ __forceinline__ int rnd_half_away(int v, int shift)
+{
+	/* v < 0: -((-v + half) >> shift) = ceil((v - half) / 2^shift) = (v + half - 1) >> shift -- no branch either way */
+	return (v + (1 << (shift - 1)) + (v >> 31)) >> shift;
+}
+__device__ __forceinline__ int diffuse(int r)
+{
+	/* an odd function of r: |r| mod 64 read as a signed 6-bit number, divided by 4 towards zero, with the sign of r */
+	const int s = r >> 31, a = (r ^ s) - s;
+	const int t = (int)((unsigned)a << 26) >> 26;
+	const int d = (t + ((t >> 31) & 3)) >> 2;
+	return (d ^ s) - s;
+}
+
+/* the 5-tap low-pass numerator and the predicted odd sample of the analysis (filters.c:55-114, 203-287, 346-386), on cells st apart */
+template <int S>
+__device__ __forceinline__ int tap5s(const int16_t *x, int st, int k)
+{
+	const int c = 2 * k;
+	const int l1 = c >= 1 ? x[(c - 1) * st] : x[st], l2 = c >= 2 ? x[(c - 2) * st] : x[2 * st];
+	const int r1 = x[(c + 1) * st], r2 = (c + 2 < S) ? x[(c + 2) * st] : x[(S - 2) * st];
+	return 6 * x[c * st] + 2 * (l1 + r1) - (l2 + r2);
+}
+__device__ __forceinline__ int pair_predict_s(const int16_t *x, int st, int k)
+{
+	int a = x[2 * k * st] + x[(2 * k + 2) * st];
+	if ((k & 1) && (a & 1) && ((x[(2 * k - 2) * st] + x[2 * k * st]) & 1)) a++;
+	return x[(2 * k + 1) * st] - (a >> 1);
+}
+
 #endif

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include <cstdlib>
 #include "nhw_ws.h"
+#include "nhw_dwt.h"
 
 #pragma clang fp contract(off)
 
@@ -201,20 +202,6 @@ __device__ __forceinline__ void fsm_step16(uint64_t &m0, uint64_t &m1, int vb)
 	const uint64_t add = (uint64_t)(iabs(vb) & 15) * 0x0101010101010101ull;
 	m0 = ((((m0 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
 	m1 = ((((m1 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
-}
-
-__device__ __forceinline__ int rnd_half_away(int v, int shift)
-{
-	/* v < 0: -((-v + half) >> shift) = ceil((v - half) / 2^shift) = (v + half - 1) >> shift -- no branch either way */
-	return (v + (1 << (shift - 1)) + (v >> 31)) >> shift;
-}
-__device__ __forceinline__ int diffuse(int r)
-{
-	/* an odd function of r: |r| mod 64 read as a signed 6-bit number, divided by 4 towards zero, with the sign of r */
-	const int s = r >> 31, a = (r ^ s) - s;
-	const int t = (int)((unsigned)a << 26) >> 26;
-	const int d = (t + ((t >> 31) & 3)) >> 2;
-	return (d ^ s) - s;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -755,7 +742,6 @@ __global__ void k_synth(uint8_t *__restrict__ bgr, int n, uint32_t seed_base)
 } // namespace nhw
 
 /* ------------------------------------------------------------------------------------------------ launchers */
-#include "nhw_dwt.h"
 using namespace nhw;
 
 static float color_yq(int q, int *family);
@@ -779,21 +765,6 @@ void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_str
  * copied back in natural orientation -- with one read and one write of each.  A wavefront owns a row (then a
  * column): it reads all its taps before it writes its outputs over them, so both directions run in place.
  * ------------------------------------------------------------------------------------------------ */
-template <int S>
-__device__ __forceinline__ int tap5s(const int16_t *x, int st, int k)
-{
-	const int c = 2 * k;
-	const int l1 = c >= 1 ? x[(c - 1) * st] : x[st], l2 = c >= 2 ? x[(c - 2) * st] : x[2 * st];
-	const int r1 = x[(c + 1) * st], r2 = (c + 2 < S) ? x[(c + 2) * st] : x[(S - 2) * st];
-	return 6 * x[c * st] + 2 * (l1 + r1) - (l2 + r2);
-}
-__device__ __forceinline__ int pair_predict_s(const int16_t *x, int st, int k)
-{
-	int a = x[2 * k * st] + x[(2 * k + 2) * st];
-	if ((k & 1) && (a & 1) && ((x[(2 * k - 2) * st] + x[2 * k * st]) & 1)) a++;
-	return x[(2 * k + 1) * st] - (a >> 1);
-}
-
 template <int S>
 __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int final_level,
                                                    int16_t *__restrict__ saveb, size_t save_plane, int save_row, int save_kind /* 1: copy of the S x S coefficient block, 2: of the LL quadrant copied back */, int n)

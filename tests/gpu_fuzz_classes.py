@@ -38,13 +38,28 @@ def want_chunk(args):
     from oracle.oraclepy import Oracle
     q, seeds = args
     o = Oracle()
-    return [hashlib.sha1(o.encode(make(s), q)).hexdigest() for s in seeds]
+    out = []
+    for s in seeds:
+        try:
+            out.append(hashlib.sha1(o.encode(make(s), q)).hexdigest())
+        except RuntimeError as ex:                       # the reference's exit(-1) (code-book overflow): the GPU must report the same status
+            out.append(str(ex).split("rc=")[-1])
+    return out
 
 
 def dec_chunk(files):
     from oracle.oraclepy import Oracle
     o = Oracle()
     return [hashlib.sha1(o.decode(f)[0].tobytes()).hexdigest() for f in files]
+
+
+def encode_with_status(enc, imgs, q):
+    """files (b"" where the encoder reports a per-image status) and the statuses"""
+    import torch
+    o, sizes, status = enc.encode_device(torch.from_numpy(imgs).cuda(), q)
+    torch.cuda.synchronize()
+    o, sizes, status = o.cpu().numpy().reshape(len(imgs), -1), sizes.cpu().numpy(), status.cpu().numpy()
+    return [o[i, :sizes[i]].tobytes() if status[i] == 0 else b"" for i in range(len(imgs))], [int(x) for x in status]
 
 
 def main(n=192, first=0):
@@ -54,20 +69,22 @@ def main(n=192, first=0):
     enc = na.Encoder(0, n)
     bad_total = 0
     for q in range(1, 24):
-        got = [hashlib.sha1(f).hexdigest() for f in enc.encode(imgs, q)]
+        files, status = encode_with_status(enc, imgs, q)
+        got = [hashlib.sha1(f).hexdigest() if st == 0 else str(st) for f, st in zip(files, status)]
         chunks = [(q, seeds[i:i + 8]) for i in range(0, n, 8)]
         with ProcessPoolExecutor(max_workers=min(48, os.cpu_count() or 8)) as ex:
             want = [h for part in ex.map(want_chunk, chunks) for h in part]
         bad = [seeds[i] for i in range(n) if got[i] != want[i]]
         bad_total += len(bad)
         # ... and the files back through the GPU decoder against the oracle's decoder
-        files = enc.encode(imgs, q)
+        ok = [i for i in range(n) if status[i] == 0]
+        okf = [files[i] for i in ok]
         dec = na.Decoder(0, n)
-        px, qs = dec.decode(files)
+        px, qs = dec.decode(okf)
         dec.close()
         with ProcessPoolExecutor(max_workers=min(48, os.cpu_count() or 8)) as ex:
-            dwant = [h for part in ex.map(dec_chunk, [files[i:i + 8] for i in range(0, n, 8)]) for h in part]
-        dbad = [seeds[i] for i in range(n) if hashlib.sha1(px[i].tobytes()).hexdigest() != dwant[i] or qs[i] != q]
+            dwant = [h for part in ex.map(dec_chunk, [okf[i:i + 8] for i in range(0, len(okf), 8)]) for h in part]
+        dbad = [seeds[ok[i]] for i in range(len(ok)) if hashlib.sha1(px[i].tobytes()).hexdigest() != dwant[i] or qs[i] != q]
         bad_total += len(dbad)
         print(f"q{q}: encode {len(bad)} of {n} images differ {bad[:8]}; decode {len(dbad)} differ {dbad[:8]}", flush=True)
     print("TOTAL differing:", bad_total)

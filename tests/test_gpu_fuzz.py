@@ -112,3 +112,29 @@ def test_bench_strong_split_at_config_4_shape():
     assert line["scaling"] == "strong" and line["n_gpus"] == 1 and line["world_size_from_collective"] == 1
     assert line["config"]["images_per_step"] == 8192 and line["images_ok"] == [8192]
     assert line["value"] > 0 and len(line["ms_per_step_per_rank"]) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [16, 17, 20, 23])
+def test_code_book_overflow_status_matches_the_oracle(q):
+    """The reference exits with -1 when the packetiser's code book overflows (compress_pixel.c:234,270,271); the C ABI reports
+    NHW_E_CODEBOOK for THAT image and encodes its neighbours in the batch.  Image: tests/gpu_fuzz_classes.py seed 50431 (overflows from
+    quality 17 on, not at 16); oracle side: test_code_book_overflow_is_the_reference_exit."""
+    import nhwcodec_amd
+    from oracle.oraclepy import Oracle
+    from tests.gpu_fuzz_classes import make, encode_with_status
+    o = Oracle()
+    imgs = np.stack([o.synth(3), make(50431), o.synth(4), make(50430)])
+    enc = nhwcodec_amd.Encoder(0, len(imgs))
+    files, status = encode_with_status(enc, imgs, q)
+    if q > 16:
+        with pytest.raises(nhwcodec_amd.NhwError):                 # the host convenience path refuses the batch
+            enc.encode(imgs, q)
+    enc.close()
+    for i, im in enumerate(imgs):
+        try:
+            want, rc = o.encode(im, q), 0
+        except RuntimeError as ex:
+            want, rc = b"", int(str(ex).split("rc=")[-1])
+        assert status[i] == rc and files[i] == want, f"image {i}: status {status[i]} (oracle {rc})"
+    assert status[1] == (nhwcodec_amd.NHW_E_CODEBOOK if q > 16 else 0)

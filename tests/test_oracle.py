@@ -159,3 +159,26 @@ def test_low_quality_hard_classes_against_real_reference(oracle, ref, kind):
         for (n, a), (_, b) in zip(t_ref, t_or):
             assert a == b, f"{kind} q{q}: checkpoint {n}"
         assert d_ref == d_or
+
+
+def test_code_book_overflow_is_the_reference_exit(oracle, ref):
+    """compress_pixel.c:234,270,271: the reference calls exit(-1) when the packetiser's code book does not fit.  A busy synthetic class image
+    (found by tests/gpu_fuzz_classes.py, seed 50431) does that from quality 17 on and encodes at 16: the oracle reports NHWO_E_CODEBOOK (-2)
+    exactly where the reference exits."""
+    from tests.gpu_fuzz_classes import make
+    img = make(50431)
+    for q in (16, 17, 20, 23):
+        try:
+            want = ref.encode(img, q)
+        except RuntimeError as ex:
+            assert "rc=-1" in str(ex)
+            want = None
+        try:
+            got = oracle.encode(img, q)
+        except RuntimeError as ex:
+            assert "rc=-2" in str(ex)
+            got = None
+        assert (got is None) == (want is None), q
+        if got is not None:
+            assert got == (want[0] if isinstance(want, tuple) else want)
+    assert oracle.encode(img, 16) and got is None
