@@ -699,7 +699,11 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 			 * bits: of the 15s a row's walk meets every sixth is floored to 8, of the x7 above 22 every fourth, all others are floored */
 			int mv[8];
 			unsigned negm = 0, b15 = 0, bx7 = 0;
+			unsigned loud = 0;                                          /* words with a cell at +-7 or beyond: in the others every cell is inside the dead zone whatever its neighbours do (the fix-ups only touch +-7), as above quality 16 */
+			for (int k = 0; k < 8; k++) loud |= (__ballot(iabs(prev[k]) >= 7) ? 1u : 0u) << k;
 			for (int k = 0; k < 8; k++) {
+				mv[k] = 0;
+				if (!((loud >> k) & 1)) continue;
 				const int raw = prev[k];
 				const int lf = left_of_dpp(prev, k, lane, 0), rt = right_of_dpp(prev, k, 8, lane, first_next);
 				const bool last = k == 7 && lane == 63;
@@ -732,6 +736,11 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				}
 			}
 			for (int k = 0; k < 8; k++) {
+				if (!((loud >> k) & 1)) {
+					if (write_plane) p[rr * W + lane + 64 * k] = 128;
+					park[(rr & 15) * QROW + lane + 64 * k] = 128;
+					continue;
+				}
 				int v = mv[k];
 				if (((negm >> k) & 1) && !((keep_low >> k) & 1)) v = -((-v) & 504);
 				int sym = (unsigned)(v + 7) < 15u ? 128 : ((v + 128) & 248);
