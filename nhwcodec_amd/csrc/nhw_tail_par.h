@@ -1700,81 +1700,63 @@ DEV void thin_by_parent(int16_t *v, int lv, int parent, int lim_parent, int lim_
 }
 DEV int16_t keep_loud(int v, int q) { return q > 10 ? (int16_t)(v >= 16 ? 7 : v <= -16 ? -7 : 0) : (int16_t)0; }   /* :947-953 */
 struct ThinT { int t1, t2, t3, t4, t5; };
-/* one row of the lower bands (rows 256..511): columns 0..255, then 256..510 (:898-967).  left0: value of the cell before the row. */
-DEV bool thin_lower_row(int16_t *row, int rr /* row - 256 */, const int16_t *par, const ThinT &t, int q, int left0)
+/* One cell of the walk: x the cell as the walk finds it, lv the cell on its left as its own visit left it, x1 the cell on its right (not yet
+ * visited); the step may zero either of them.  Three sets of limits: rows < 256 (limC 0: no "else"), rows >= 256 left / right half. */
+struct ThinRule { int limA, limB, limC, lim_parent, lim_pair, loud; };
+DEV int thin_cell(int x, int &lv, int &x1, int parent, const ThinRule &R, int q, bool &zl)
 {
-	bool zl0 = false;
-	for (int j = 0; j < H; j++) {
-		int16_t *v = row + j;
-		int lv = j ? v[-1] : left0;
-		bool zl = false;
-		if (iabs(*v) >= DEADZONE && iabs(*v) < t.t1 + 2) thin_by_parent(v, lv, par[((rr * H + j) >> 1) + Q / 2], t.t4, t.t5, &zl);
-		if (zl) { if (j) v[-1] = 0; else zl0 = true; lv = 0; }
-		if (iabs(*v) >= DEADZONE && iabs(*v) < t.t1) {
-			if (iabs(lv) < DEADZONE && iabs(v[1]) < DEADZONE) *v = 0;
-			else if (iabs(*v) < t.t1 - 4) *v = 0;
-		}
+	int v = x;
+	zl = false;
+	if (iabs(v) >= DEADZONE && iabs(v) < R.limA) {
+		if (iabs(parent) < R.lim_parent) v = 0;
+		else if (iabs(v + lv) < R.lim_pair && iabs(x1) < R.lim_pair) { v = 0; zl = true; lv = 0; }
+		else if (iabs(v + x1) < R.lim_pair && iabs(lv) < R.lim_pair) { v = 0; x1 = 0; }
 	}
-	for (int j = H; j < W - 1; j++) {
-		int16_t *v = row + j;
-		bool zl = false;
-		if (iabs(*v) >= DEADZONE && iabs(*v) < t.t2 + 1) thin_by_parent(v, v[-1], par[((rr * H + (j - H)) >> 1) + Q / 2 + H / 2], t.t4 + 1, t.t5, &zl);
-		if (zl) v[-1] = 0;
-		if (iabs(*v) >= DEADZONE && iabs(*v) < t.t2) {
-			if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = keep_loud(*v, q);
-			else if (iabs(*v) < t.t2 - 5) *v = keep_loud(*v, q);
-		}
+	if (iabs(v) >= DEADZONE && iabs(v) < R.limB) {
+		if ((iabs(lv) < DEADZONE && iabs(x1) < DEADZONE) || iabs(v) < R.limC) v = R.loud ? keep_loud(v, q) : 0;
 	}
-	return zl0;
+	return v;
 }
-/* the two walks of Y20's low form as row passes on LDS tiles (a thread on "its" row of the plane read one cell of a different line at every
- * step: 70 GB per batch) */
-struct ThinUpperF {                                             /* rows 0..255, columns 256..511 (:871-896) */
-	const int16_t *par; ThinT t;
-	struct State { int unused; };
-	__device__ State init(int) const { return State{0}; }
-	__device__ int run(int16_t *row, int r, int j, int j1, State &) const
-	{
-		for (; j < j1; j++) {
-			int16_t *v = row + j;
-			bool zl = false;
-			if (iabs(*v) >= DEADZONE && iabs(*v) < t.t3 + 2) thin_by_parent(v, v[-1], par[((r * H + (j - H)) >> 1) + H / 2], t.t4, t.t5, &zl);
-			if (zl) v[-1] = 0;
-			if (iabs(*v) >= DEADZONE && iabs(*v) < t.t3) { if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = 0; }
+/* A row of the walk on a wavefront, a lane NC consecutive cells (the first `nact` of them visited, the rest only looked at): what travels
+ * from cell to cell is the value a visit leaves behind and "your cell has been zeroed"; the lanes start from the cells as they are and hand
+ * theirs on until nothing moves.  o: the lane's cells, o_next: the cell behind them, left_in: the cell in front of lane 0's.
+ * Returns: e = the cells afterwards; zero_left: lane 0's first cell wants the cell in front of the row zeroed; zero_right: lane 63's last
+ * visit zeroed the cell behind the lanes. */
+template <int NC>
+DEV void thin_row_wave(const int *o, int o_next, int left_in, const int *par, int nact, const ThinRule &R, int q, int lane, int *e, bool &zero_left, bool &zero_right)
+{
+	const int left0 = __shfl_up(o[NC - 1], 1);
+	int lv_in = lane ? left0 : left_in, f_in = 0, lv_out, f_out;
+	bool zlf;
+	for (;;) {
+		int cur[NC];
+#pragma unroll
+		for (int k = 0; k < NC; k++) cur[k] = o[k];
+		if (f_in) cur[0] = 0;
+		int lv = lv_in;
+		zlf = false; f_out = 0;
+#pragma unroll
+		for (int k = 0; k < NC; k++) {
+			int x1 = k < NC - 1 ? cur[k < NC - 1 ? k + 1 : k] : o_next;
+			if (k < nact) {
+				bool zl;
+				e[k] = thin_cell(cur[k], lv, x1, par[k], R, q, zl);
+				if (zl) { if (k) e[k - 1] = 0; else zlf = true; }
+			} else e[k] = cur[k];
+			if (k < NC - 1) cur[k < NC - 1 ? k + 1 : k] = x1; else f_out = x1 != o_next;
+			lv = e[k];
 		}
-		return j;
+		lv_out = lv;
+		int nl = __shfl_up(lv_out, 1), nf = __shfl_up(f_out, 1);
+		if (!lane) { nl = left_in; nf = 0; }
+		if (!__any(nl != lv_in || nf != f_in)) break;
+		lv_in = nl; f_in = nf;
 	}
-};
-struct ThinLowerF {                                             /* rows 256..511: columns 0..255, then 256..510 (:898-967); same steps as thin_lower_row */
-	const int16_t *par; ThinT t; int q;
-	struct State { int used, zl0; };                            /* the value the row found in the cell before it, and whether it wants that cell zeroed */
-	__device__ State init(int) const { return State{ 0, 0 }; }
-	__device__ int run(int16_t *row, int rr, int j, int j1, State &st) const
-	{
-		for (; j < j1 && j < W - 1; j++) {
-			int16_t *v = row + j;
-			bool zl = false;
-			if (j < H) {
-				int lv = v[-1];
-				if (!j) st.used = lv;
-				if (iabs(*v) >= DEADZONE && iabs(*v) < t.t1 + 2) thin_by_parent(v, lv, par[((rr * H + j) >> 1) + Q / 2], t.t4, t.t5, &zl);
-				if (zl) { if (j) v[-1] = 0; else st.zl0 = 1; lv = 0; }
-				if (iabs(*v) >= DEADZONE && iabs(*v) < t.t1) {
-					if (iabs(lv) < DEADZONE && iabs(v[1]) < DEADZONE) *v = 0;
-					else if (iabs(*v) < t.t1 - 4) *v = 0;
-				}
-			} else {
-				if (iabs(*v) >= DEADZONE && iabs(*v) < t.t2 + 1) thin_by_parent(v, v[-1], par[((rr * H + (j - H)) >> 1) + Q / 2 + H / 2], t.t4 + 1, t.t5, &zl);
-				if (zl) v[-1] = 0;
-				if (iabs(*v) >= DEADZONE && iabs(*v) < t.t2) {
-					if (iabs(v[-1]) < DEADZONE && iabs(v[1]) < DEADZONE) *v = keep_loud(*v, q);
-					else if (iabs(*v) < t.t2 - 5) *v = keep_loud(*v, q);
-				}
-			}
-		}
-		return j1;
-	}
-};
+	const int zn = __shfl_down((int)zlf, 1);                        /* the lane on my right wants my last cell zeroed (its own visits are over) */
+	if (lane < 63 && zn) e[NC - 1] = 0;
+	zero_left = __shfl((int)zlf, 0) != 0;
+	zero_right = __shfl(f_out, 63) != 0;
+}
 DEV void thin_l1_low_par(Ctx *c, int tid, int *sh /* shared, >= 2 * NT + 2 ints */)
 {
 	int16_t *p = c->proc;
@@ -1812,40 +1794,102 @@ DEV void thin_l1_low_par(Ctx *c, int tid, int *sh /* shared, >= 2 * NT + 2 ints 
 			else { t.t1 += 3; t.t2 += 2; t.t3 += 2; t.t4 += 2; t.t5 += 2; }
 		}
 	}
-	int16_t *tiles = reinterpret_cast<int16_t *>(sh + NT);        /* (NT + 2) x TLS shorts behind the flags */
-	/* rows 0..255, columns 256..511: the cell a row reaches in the next row (column 0) is read or written by no other row of this walk; it
-	 * travels with the last tile (row_end = W + 2) */
-	row_pass_tiled(p, W, W + 2, H, 0, H, H, W, tiles, tid, ThinUpperF{ par, t });
-	BARRIER();
-	/* rows 256..511: the first cell of a row looks at (and may zero) the last cell of the row above, which that row may have zeroed in
-	 * its own last step: the only link between rows.  Every row is walked at once on the assumption that the cell above kept its value;
-	 * a row whose assumption turns out wrong is restored from a copy and walked again, until nothing changes (usually no second round).
-	 * The zeroing of the cell above is applied at the end: the row above reads that cell before this row would have written it. */
-	int16_t *copy = c->jpeg;                                     /* free here: the reference has released im_jpeg (:781) */
-	for (int idx = tid; idx < 2 * Q / 8; idx += NT) reinterpret_cast<uint4 *>(copy + 2 * Q)[idx] = reinterpret_cast<const uint4 *>(p + 2 * Q)[idx];
-	int *zl_flag = sh;                                           /* [NT] */
-	BARRIER();
+	/* Both walks run a wavefront per row (thin_row_wave).  Until round 3 they were a thread per row on 32-column LDS tiles (72-byte row pieces
+	 * in and out of eight tiles, a copy of the lower half for the rows that had to be walked again: 13 GB per batch, 2.3 ms at quality 1). */
+	const int lane = tid & 63, wv = tid >> 6;
+	/* rows 0..255, columns 256..511 (:871-896): the walk reaches one cell over either end of its band -- column 255 of its row and the first
+	 * cell of the next row -- which no other row of this walk reads or writes */
 	{
-		const int r = H + tid;
-		int16_t *row = p + (size_t)r * W;
-		const int above_orig = tid ? copy[(size_t)r * W - 1] : p[(size_t)r * W - 1];
-		ThinLowerF::State st;
-		row_pass_tiled(p + (size_t)H * W, W, W, H, 0, H, 0, W, tiles, tid, ThinLowerF{ par, t, q }, &st);   /* first round: every row at once, through LDS tiles */
-		int used = st.used;
-		zl_flag[tid] = st.zl0;
-		for (;;) {
-			BARRIER();
-			const int now = tid ? p[(size_t)r * W - 1] : above_orig;       /* what the row above left in its last cell */
-			const bool redo = now != used;
-			if (!__syncthreads_or(redo)) break;
-			if (redo) {
-				for (int j = 0; j < W; j += 8) *reinterpret_cast<uint4 *>(row + j) = *reinterpret_cast<const uint4 *>(copy + (size_t)r * W + j);
-				used = now;
-				zl_flag[tid] = thin_lower_row(row, tid, par, t, q, used);
+		const ThinRule R = { t.t3 + 2, t.t3, 0, t.t4, t.t5, 0 };
+		uint2 w = make_uint2(0, 0); uint32_t pw = 0; int edge = 0;
+#define UP_LOAD(r) do { w = *reinterpret_cast<const uint2 *>(p + (size_t)(r) * W + H + 4 * lane); pw = *reinterpret_cast<const uint32_t *>(par + (r) * (H / 2) + H / 2 + 2 * lane); \
+		if (lane == 0) edge = p[(size_t)(r) * W + H - 1]; if (lane == 63) edge = p[(size_t)((r) + 1) * W]; } while (0)
+		int r = wv;
+		UP_LOAD(r);
+		for (; r < H; r += NT / 64) {
+			int o[4], e[4];
+			unpack4(w, o);
+			const int pr[4] = { (int16_t)(pw & 0xFFFF), (int16_t)(pw & 0xFFFF), (int16_t)(pw >> 16), (int16_t)(pw >> 16) };
+			const int my_edge = edge, row = r;
+			if (r + NT / 64 < H) UP_LOAD(r + NT / 64);
+			bool busy = false;                                      /* a row without a cell inside the walk's range stays as it is (most rows of quality 1) */
+#pragma unroll
+			for (int k = 0; k < 4; k++) busy |= iabs(o[k]) >= DEADZONE && iabs(o[k]) < R.limA;
+			if (!__any(busy)) continue;
+			const int sd = __shfl_down(o[0], 1);
+			bool zl, zr;
+			thin_row_wave<4>(o, lane < 63 ? sd : my_edge, __shfl(my_edge, 0), pr, 4, R, q, lane, e, zl, zr);
+			uint2 out;
+			out.x = (uint32_t)(uint16_t)e[0] | ((uint32_t)(uint16_t)e[1] << 16); out.y = (uint32_t)(uint16_t)e[2] | ((uint32_t)(uint16_t)e[3] << 16);
+			*reinterpret_cast<uint2 *>(p + (size_t)row * W + H + 4 * lane) = out;
+			if (lane == 0 && zl) p[(size_t)row * W + H - 1] = 0;
+			if (lane == 63 && zr) p[(size_t)(row + 1) * W] = 0;
+		}
+#undef UP_LOAD
+	}
+	BARRIER();
+	/* rows 256..511, columns 0..510 (:898-967).  The first cell of a row looks at (and may zero) the last cell of the row above, which that
+	 * row may have zeroed in its own last step: the only link between rows.  A row whose cell above is not zero to begin with is therefore
+	 * walked for both cases -- the cell above as it was (result to the plane) and zeroed (result to a scratch row) -- and says for either
+	 * whether it zeroes its own last cell; one thread then follows the chain of choices down the rows, the rows that turn out to have been
+	 * entered on a zeroed cell are copied from the scratch rows, and the zeroings of the cell above are applied last (the row above read
+	 * that cell before this row would have written it). */
+	{
+		int16_t *scratch = c->jpeg;                               /* free here: the reference has released im_jpeg (:781) */
+		int16_t *above = reinterpret_cast<int16_t *>(sh);           /* [H] the cell before every row, as it is now */
+		uint8_t *fl = reinterpret_cast<uint8_t *>(sh) + 2 * H;      /* [H] per row: bit 0 / 1: zeroes its own last cell (entered as is / zeroed), 2 / 3: wants the cell above zeroed, 4: walked twice, 5: the choice */
+		above[tid] = p[(size_t)(H + tid) * W - 1];
+		BARRIER();
+		const ThinRule RA = { t.t1 + 2, t.t1, t.t1 - 4, t.t4, t.t5, 0 }, RB = { t.t2 + 1, t.t2, t.t2 - 5, t.t4 + 1, t.t5, 1 };
+		const ThinRule R = lane < 32 ? RA : RB;
+		uint4 w = make_uint4(0, 0, 0, 0); uint2 pw = make_uint2(0, 0);
+#define LO_LOAD(rr) do { w = *reinterpret_cast<const uint4 *>(p + (size_t)(H + (rr)) * W + 8 * lane); pw = *reinterpret_cast<const uint2 *>(par + (rr) * (H / 2) + Q / 2 + 4 * lane); } while (0)
+		int rr = wv;
+		LO_LOAD(rr);
+		for (; rr < H; rr += NT / 64) {
+			const uint32_t ww[4] = { w.x, w.y, w.z, w.w }, pp[2] = { pw.x, pw.y };
+			int o[8], pr[8], e[8];
+#pragma unroll
+			for (int k = 0; k < 4; k++) { o[2 * k] = (int16_t)(ww[k] & 0xFFFF); o[2 * k + 1] = (int16_t)(ww[k] >> 16); }
+#pragma unroll
+			for (int k = 0; k < 8; k++) pr[k] = (int16_t)(pp[k >> 2] >> (16 * ((k >> 1) & 1)));
+			const int row = rr, left = above[rr];
+			if (rr + NT / 64 < H) LO_LOAD(rr + NT / 64);
+			bool busy = false;
+#pragma unroll
+			for (int k = 0; k < 8; k++) busy |= iabs(o[k]) >= DEADZONE && iabs(o[k]) < R.limA;
+			if (!__any(busy)) { if (lane == 0) fl[row] = 0; continue; }
+			const int sd = __shfl_down(o[0], 1);
+			const int nact = lane < 63 ? 8 : 7;                     /* column 511 is only looked at */
+			unsigned flags = 0;
+			for (int pass = 0; pass < (left != 0 && row > 0 ? 2 : 1); pass++) {   /* (the first row's cell above is what the upper walk left: no second case) */
+				bool zl, zr;
+				thin_row_wave<8>(o, lane < 63 ? sd : 0, pass ? 0 : left, pr, nact, R, q, lane, e, zl, zr);
+				const int last = __shfl(e[7], 63), last0 = __shfl(o[7], 63);
+				flags |= ((last == 0 && last0 != 0) ? 1u : 0u) << pass | (zl ? 4u : 0u) << pass | (pass ? 16u : 0u);
+				int16_t *dst = (pass ? scratch : p) + (size_t)(H + row) * W + 8 * lane;
+				*reinterpret_cast<uint4 *>(dst) = make_uint4((uint32_t)(uint16_t)e[0] | ((uint32_t)(uint16_t)e[1] << 16), (uint32_t)(uint16_t)e[2] | ((uint32_t)(uint16_t)e[3] << 16),
+				                                             (uint32_t)(uint16_t)e[4] | ((uint32_t)(uint16_t)e[5] << 16), (uint32_t)(uint16_t)e[6] | ((uint32_t)(uint16_t)e[7] << 16));
+			}
+			if (!(flags & 16u)) flags |= (flags & 1u) << 1 | (flags & 4u) << 1;   /* one case: both read the same */
+			if (lane == 0) fl[row] = (uint8_t)flags;
+		}
+#undef LO_LOAD
+		BARRIER();
+		if (tid == 0) {
+			bool zeroed = false;                                    /* the row above zeroes its last cell (in the case that applies to it) */
+			for (int r2 = 0; r2 < H; r2++) {
+				const unsigned f = fl[r2];
+				const bool second = zeroed && (f & 16u);
+				if (second) fl[r2] = (uint8_t)(f | 32u);
+				zeroed = (f >> (second ? 1 : 0)) & 1u;
 			}
 		}
 		BARRIER();
-		if (zl_flag[tid]) p[(size_t)r * W - 1] = 0;
+		for (int r2 = wv; r2 < H; r2 += NT / 64)
+			if (fl[r2] & 32u) *reinterpret_cast<uint4 *>(p + (size_t)(H + r2) * W + 8 * lane) = *reinterpret_cast<const uint4 *>(scratch + (size_t)(H + r2) * W + 8 * lane);
+		BARRIER();
+		{ const unsigned f = fl[tid]; if ((f >> ((f & 32u) ? 3 : 2)) & 1u) p[(size_t)(H + tid) * W - 1] = 0; }
 	}
 	BARRIER();
 }
