@@ -17,7 +17,7 @@
 /* launchers (nhw_front.hip, nhw_tail.hip) */
 void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_stride, uint8_t *u, uint8_t *v, size_t c_stride, hipStream_t s);
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, int16_t *keep, size_t keep_stride, hipStream_t s,
-                         int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0);
+                         int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0, const uint8_t *src8 = nullptr, size_t src8_plane = 0);
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s);
 void nhw_launch_l2_recon(int16_t *jpeg, const int16_t *proc, size_t plane_stride, int16_t *ll1, size_t ll1_stride, int n, hipStream_t s);
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
@@ -215,10 +215,12 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	const bool fork = timed == 1 && what == 3 && !e->stop_after && e->chroma_fork;
 	hipStream_t cs = fork ? e->part_stream[0] : s;
 	auto chroma_head = [&](int comp) -> int {                        /* everything up to the second dequantiser simulation */
+		const bool widen_in_analysis = q > 14 && !ws.dbg;              /* the analysis reads the byte plane itself (the stage checks keep the copy as a stage of its own) */
 		if (q <= 14) nhw_launch_low_prefilter_chroma(comp ? plane8(ws, B_PV) : plane8(ws, B_PU), ws.stride[B_PU], cjpeg, cps, q, n, cs);   /* :2263 / :2579 */
-		else nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, cs);
+		else if (!widen_in_analysis) nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, nullptr, 0, cs, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2);   /* + the copy of LL1 */
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, nullptr, 0, cs, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2,   /* + the copy of LL1 */
+		                    widen_in_analysis ? (comp ? plane8(ws, B_PV) : plane8(ws, B_PU)) : nullptr, ws.stride[B_PU]);
 		if (low) nhw_launch_low_chroma_thin(cproc, cps, n, cs);      /* :2277-2308 / :2590-2621 */
 		STAGE_DONE();
 		STAGE_DONE();

@@ -765,9 +765,17 @@ void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_str
  * copied back in natural orientation -- with one read and one write of each.  A wavefront owns a row (then a
  * column): it reads all its taps before it writes its outputs over them, so both directions run in place.
  * ------------------------------------------------------------------------------------------------ */
+/* eight cells of a row of the block: from the int16 plane, or widened from a byte plane */
+__device__ __forceinline__ uint4 ana_piece(const int16_t *src, const uint8_t *src8, int row, int o, int stride, int S)
+{
+	if (!src8) return *reinterpret_cast<const uint4 *>(src + (size_t)row * stride + 8 * o);
+	const uint2 b = *reinterpret_cast<const uint2 *>(src8 + (size_t)row * S + 8 * o);
+	return make_uint4((b.x & 0xFF) | ((b.x >> 8 & 0xFF) << 16), (b.x >> 16 & 0xFF) | ((b.x >> 24) << 16), (b.y & 0xFF) | ((b.y >> 8 & 0xFF) << 16), (b.y >> 16 & 0xFF) | ((b.y >> 24) << 16));
+}
 template <int S>
 __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int final_level,
-                                                   int16_t *__restrict__ saveb, size_t save_plane, int save_row, int save_kind /* 1: copy of the S x S coefficient block, 2: of the LL quadrant copied back */, int n)
+                                                   int16_t *__restrict__ saveb, size_t save_plane, int save_row, int save_kind /* 1: copy of the S x S coefficient block, 2: of the LL quadrant copied back */, int n,
+                                                   const uint8_t *__restrict__ src8b, size_t src8_plane /* the block as S x S bytes (a 4:2:0 chroma plane: nhw_encoder.c:2257-2263 widens it first), or null */)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4, NPRE = S * (S / 8) / NT_;
@@ -780,7 +788,7 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 	if ((int)blockIdx.x < n) {
 		const int16_t *src = jpegb + (size_t)blockIdx.x * plane_stride;
 #pragma unroll
-		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * stride + 8 * (v % (S / 8))); }
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = ana_piece(src, src8b ? src8b + (size_t)blockIdx.x * src8_plane : nullptr, v / (S / 8), v % (S / 8), stride, S); }
 	}
 	for (int img = blockIdx.x; img < n; img += gridDim.x) {
 	int16_t *jpeg = jpegb + (size_t)img * plane_stride, *proc = procb + (size_t)img * plane_stride;
@@ -795,7 +803,7 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 	if (img + (int)gridDim.x < n) {
 		const int16_t *src = jpegb + (size_t)(img + gridDim.x) * plane_stride;
 #pragma unroll
-		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(v / (S / 8)) * stride + 8 * (v % (S / 8))); }
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = ana_piece(src, src8b ? src8b + (size_t)(img + gridDim.x) * src8_plane : nullptr, v / (S / 8), v % (S / 8), stride, S); }
 	}
 	for (int i = 0; i < 16; i++) {                                 /* first direction (filters.c:40-86): un-normalised taps */
 		int16_t *x = A + (wv * 16 + i) * LS;
@@ -937,11 +945,11 @@ void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, in
 /* save (optional): a second destination for the block the reference copies right after the transform -- the S x S coefficient block
  * (save_kind 1) or the LL quadrant in natural orientation (save_kind 2) -- written by the fused kernels, by a block copy otherwise */
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level,
-                         int16_t *keep, size_t keep_stride, hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind)
+                         int16_t *keep, size_t keep_stride, hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind, const uint8_t *src8, size_t src8_plane)
 {
 	if (!save) save_kind = 0;
-	if (size == 256 && !keep) { k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n); return; }
-	if (size == 128 && !keep) { k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n); return; }
+	if (size == 256 && !keep) { k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane); return; }
+	if (size == 128 && !keep) { k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0); return; }
 	(void)keep; (void)keep_stride;       /* size 512 is the band kernel's (nhw_launch_front_fused); nothing else is called with another size */
 }
 
