@@ -17,8 +17,8 @@
 /* launchers (nhw_front.hip, nhw_tail.hip) */
 void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_stride, uint8_t *u, uint8_t *v, size_t c_stride, hipStream_t s);
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, int16_t *keep, size_t keep_stride, hipStream_t s,
-                         int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0, const uint8_t *src8 = nullptr, size_t src8_plane = 0);
-void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s);
+                         int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0, const uint8_t *src8 = nullptr, size_t src8_plane = 0, int drop_t = 0);
+void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s, int drop_nat = 0);
 void nhw_launch_l2_recon(int16_t *jpeg, const int16_t *proc, size_t plane_stride, int16_t *ll1, size_t ll1_stride, int n, hipStream_t s);
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
 void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv, size_t c_stride, const int16_t *y, size_t y_stride, int with_prefilter,
@@ -220,24 +220,24 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		else if (!widen_in_analysis) nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
 		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, nullptr, 0, cs, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2,   /* + the copy of LL1 */
-		                    widen_in_analysis ? (comp ? plane8(ws, B_PV) : plane8(ws, B_PU)) : nullptr, ws.stride[B_PU]);
+		                    widen_in_analysis ? (comp ? plane8(ws, B_PV) : plane8(ws, B_PU)) : nullptr, ws.stride[B_PU], !ws.dbg);
 		if (low) nhw_launch_low_chroma_thin(cproc, cps, n, cs);      /* :2277-2308 / :2590-2621 */
 		STAGE_DONE();
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, cs);
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, cs, nullptr, 0, 0, 0, nullptr, 0, !ws.dbg);
 		STAGE_DONE();
 		nhw_launch_phase(PH_C2, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
-		nhw_launch_synthesis(cjpeg, cproc, n, cps, H, H / 2, cs);
+		nhw_launch_synthesis(cjpeg, cproc, n, cps, H, H / 2, cs, !ws.dbg);
 		STAGE_DONE();
 		nhw_launch_phase(PH_C3, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, cs, plane16(ws, B_CL2SAVE), ws.stride[B_CL2SAVE] / 2, H / 2, 1);   /* + the copy of the level-2 block */
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, cs, plane16(ws, B_CL2SAVE), ws.stride[B_CL2SAVE] / 2, H / 2, 1, nullptr, 0, !ws.dbg);   /* + the copy of the level-2 block */
 		STAGE_DONE();
 		STAGE_DONE();
 		nhw_launch_phase(PH_C4, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
-		nhw_launch_synthesis(cjpeg, cproc, n, cps, H, H / 2, cs);
+		nhw_launch_synthesis(cjpeg, cproc, n, cps, H, H / 2, cs, !ws.dbg);
 		STAGE_DONE();
 		return 1;
 	};
@@ -279,7 +279,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	if (q > 12) {                                                    /* second closed loop (:759-779) */
 	nhw_launch_wave(WV_DQ0, ws, s);
 	STAGE_DONE();
-	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s);
+	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s, q <= 21 && !ws.dbg);   /* its copy in natural orientation is only read by Y19 (q > 21, :766-777) */
 	STAGE_DONE();
 	}
 	nhw_launch_phase(PH_L4A, ws, 0, out, d_sizes, d_status, s);      /* Y19-Y23 */

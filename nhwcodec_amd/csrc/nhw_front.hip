@@ -775,7 +775,8 @@ __device__ __forceinline__ uint4 ana_piece(const int16_t *src, const uint8_t *sr
 template <int S>
 __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int final_level,
                                                    int16_t *__restrict__ saveb, size_t save_plane, int save_row, int save_kind /* 1: copy of the S x S coefficient block, 2: of the LL quadrant copied back */, int n,
-                                                   const uint8_t *__restrict__ src8b, size_t src8_plane /* the block as S x S bytes (a 4:2:0 chroma plane: nhw_encoder.c:2257-2263 widens it first), or null */)
+                                                   const uint8_t *__restrict__ src8b, size_t src8_plane /* the block as S x S bytes (a 4:2:0 chroma plane: nhw_encoder.c:2257-2263 widens it first), or null */,
+                                                   int drop_t /* the transposed first-direction plane is not stored: nothing reads it behind a chroma analysis (the dequantiser simulation rewrites every cell) */)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4, NPRE = S * (S / 8) / NT_;
@@ -818,6 +819,7 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 		for (int u = 0; u < PPL; u++) { x[lane + 64 * u] = (int16_t)lo[u]; x[HLF + lane + 64 * u] = (int16_t)hi[u]; }
 	}
 	lds_barrier();
+	if (!drop_t)
 	for (int v = t; v < S * HLF; v += NT_) {                       /* the source plane keeps the transposed first-direction plane */
 		const int i = v / HLF, j = 2 * (v % HLF);
 		if (!final_level && i < HLF && j < HLF) continue;           /* (its LL quadrant is overwritten below) */
@@ -865,7 +867,8 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 }
 
 template <int S>
-__global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int n)
+__global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int n,
+                                                   int drop_nat /* the reconstruction in natural orientation is not stored (nothing reads it: the chroma loops, the second luma loop below q22) */)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4, NPRE = S * (S / 8) / NT_;
@@ -915,6 +918,7 @@ __global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, 
 		}
 	}
 	lds_barrier();
+	if (!drop_nat)
 	for (int v = t; v < S * (S / 8); v += NT_) {                   /* and its transpose, the reconstruction in natural orientation */
 		const int row = v / (S / 8), o = v % (S / 8);
 		const uint32_t *d = reinterpret_cast<const uint32_t *>(A + row * LS + 8 * o);
@@ -945,18 +949,18 @@ void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, in
 /* save (optional): a second destination for the block the reference copies right after the transform -- the S x S coefficient block
  * (save_kind 1) or the LL quadrant in natural orientation (save_kind 2) -- written by the fused kernels, by a block copy otherwise */
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level,
-                         int16_t *keep, size_t keep_stride, hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind, const uint8_t *src8, size_t src8_plane)
+                         int16_t *keep, size_t keep_stride, hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind, const uint8_t *src8, size_t src8_plane, int drop_t)
 {
 	if (!save) save_kind = 0;
-	if (size == 256 && !keep) { k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane); return; }
-	if (size == 128 && !keep) { k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0); return; }
+	if (size == 256 && !keep) { k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane, drop_t); return; }
+	if (size == 128 && !keep) { k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0, drop_t); return; }
 	(void)keep; (void)keep_stride;       /* size 512 is the band kernel's (nhw_launch_front_fused); nothing else is called with another size */
 }
 
-void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s)
+void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s, int drop_nat)
 {
-	if (size == 256) { k_dwt_syn<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n); return; }
-	if (size == 128) { k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n); return; }
+	if (size == 256) { k_dwt_syn<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat); return; }
+	if (size == 128) { k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat); return; }
 }
 
 /* the front launch group: [k_front_rowtail + k_front_chain for q 17..21] + k_front_band.

@@ -2208,9 +2208,18 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc, bo
 		const int res_uv = q > 17 ? 4 : 5;
 		const int lane = tid & 63, wv = tid >> 6;
 		int *shift = reinterpret_cast<int *>(lds), *haz = shift + H / 2;
-		if (tid < H / 2) shift[tid] = 0;
-		BARRIER();
-		for (int pass = 0;; pass++) {                              /* pass >= 1 with stable shifts: mark */
+		/* a row can only end in a pair mark if its last cell is a pair candidate with a free detail cell: where no row's is (the rule), the
+		 * evaluation pass is not needed -- every shift is 0 -- and the rows are marked at once (they were loaded twice: 1.3 GB per batch) */
+		bool last_cand = false;
+		if (tid < H / 2) {
+			shift[tid] = 0; haz[tid] = 0;
+			const int at = tid * H + H / 2 - 1, ko = tid * (H / 2) + H / 2 - 1;
+			const int d = p[at] - o[ko], d1 = p[tid * H + H / 2] - o[ko + 1];
+			const bool pair = (d > 3 && d < 7 && d1 > 2 && d1 < 7) || (d < -3 && d > -7 && d1 < -2 && d1 > -8);
+			last_cand = pair && (iabs(p[at + H / 2]) < 8 || iabs(p[at + Q / 2]) < 8 || iabs(p[at + Q / 2 + H / 2]) < 8);
+		}
+		const int first_pass = __syncthreads_or(last_cand) ? 0 : 1;
+		for (int pass = first_pass;; pass++) {                     /* pass >= 1 with stable shifts: mark */
 			bool mark = false;
 			if (pass > 0) {
 				int ns = 0;
