@@ -264,7 +264,9 @@ def cpu_baseline_light(q, budget_s=4.0):
 def chroma_l1_ms(enc, n, repeats=3):
     """SURVEY 8(d) counts the chroma level-1 coefficients among the fused front kernel's 6 B/pixel, but that analysis runs as two launches of
     the 256 x 256 filterbank kernel on the chroma stream.  Their time for a batch of n images, measured here on its own
-    (hipEvents round the two launches, on the stage entry point's stream), so that the line can carry a roofline figure that includes it."""
+    (hipEvents round the two launches, on the stage entry point's stream), so that the line can carry a roofline figure that includes it.
+    The stage entry point runs the reference's full form (int16 plane in, every plane out); the encoder's own two launches read the 4:2:0
+    byte plane directly and leave out a store nothing reads, so this is an upper bound of what they cost."""
     import torch
     planes = torch.randint(0, 256, (2, n, 65536), dtype=torch.int16, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
