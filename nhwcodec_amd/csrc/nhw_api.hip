@@ -61,6 +61,7 @@ struct nhw_enc {
 	uint32_t *d_sizes; int32_t *d_status; uint64_t *d_offs;
 	int conv_cap;
 	int chroma_fork;  /* the chroma sequence on a stream of its own next to the luma tail (NHW_CHROMA_FORK=0 turns it off) */
+	int lists_fork;   /* the position lists (Y24/Y25) on a third stream (NHW_LISTS_FORK=0 turns it off: +0.75 ms per q20 batch) */
 	int front_fallback; /* debug: every row / segment of the pre-filter carry takes its exact fallback path (tests) */
 	int stop_after;   /* debug: leave the batch driver after this many stages (0 = run everything) */
 };
@@ -132,6 +133,8 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 	e->parts = 1;   /* sub-batches on streams of their own (NHW_PARTS=2..4) bought 4 % while the tail kernels were latency-bound; they no longer do */
 	e->chroma_fork = 1;
 	if (const char *p = getenv("NHW_CHROMA_FORK")) e->chroma_fork = atoi(p) != 0;
+	e->lists_fork = 1;
+	if (const char *p = getenv("NHW_LISTS_FORK")) e->lists_fork = atoi(p) != 0;
 	if (const char *p = getenv("NHW_PARTS")) { const int k = atoi(p); if (k >= 1 && k <= 4) e->parts = k; }
 	*out = e;
 	return NHW_OK;
@@ -286,7 +289,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	/* Y24, Y25: the position lists are read by nothing before the packetiser, and what the pass leaves in the residual-code plane by nobody
 	 * at all; below q21 it shares no scratch with the passes behind it either (from q21 on its third list and Y27's snapshot both live in
 	 * the hs plane, and Y29 needs Y24), so there it runs beside them on a stream of its own */
-	const bool fork_lists = fork && q <= 20 && q > 12;
+	const bool fork_lists = fork && q <= 20 && q > 12 && e->lists_fork;
 	if (fork_lists) {
 		HIPCHK(hipEventRecord(e->part_ev[2], s));
 		HIPCHK(hipStreamWaitEvent(e->part_stream[1], e->part_ev[2], 0));

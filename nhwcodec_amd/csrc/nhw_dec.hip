@@ -2136,8 +2136,9 @@ extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
 		return NHW_OK;
 	}();
 	if (rc != NHW_OK) { nhw_dec_destroy(d); return rc; }
-	d->chroma_fork = 1;
-	if (const char *p = getenv("NHW_CHROMA_FORK")) d->chroma_fork = atoi(p) != 0;
+	d->chroma_fork = 0;                                              /* bit 0: the entropy branches side by side, bit 1: the chroma sequence beside the luma one.  Both bought 2.2 ms in round 2; with the kernels of round 3 either one only stretches the kernels it overlaps (a 4096-file batch: 7.03 ms with both, 6.66 with neither), so both are off unless asked for */
+	if (const char *p = getenv("NHW_CHROMA_FORK")) d->chroma_fork = atoi(p) != 0 ? 3 : 0;
+	if (const char *p = getenv("NHW_DEC_FORK")) d->chroma_fork = atoi(p) & 3;
 	*out = d;
 	return NHW_OK;
 }
@@ -2184,21 +2185,21 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	ws.n = n; ws.blob = (const uint8_t *)d_nhw; ws.blob_off = d_off; ws.blob_len = d_len;
 	int stage = 0;
 	d->timed = false;
-	const bool fork = d->chroma_fork && !d->stop_after;
+	const bool fork = (d->chroma_fork & 2) && !d->stop_after;          /* the chroma sequence beside the luma one */
+	const bool fork_e = (d->chroma_fork & 1) && !d->stop_after;        /* the two entropy branches side by side */
 	hipStream_t cs = fork ? d->chroma_stream : s;
+	hipStream_t es = fork_e ? d->chroma_stream : s;
 #define STAGE_END() do { if (d->stop_after && ++stage >= d->stop_after) goto done; } while (0)
 #define EV(i) HIPCHK(hipEventRecord(d->ev[i], s))
 	EV(0);
 	/* Two entropy branches that only meet at the expansion: the side streams (LL2 DPCM, position lists; latency-bound scans) on the caller's
 	 * stream, the prefix-code walk and the un-zig-zag on the second one. */
-	if (fork) { HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0)); }
+	if (fork_e) { HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(es, d->fork_ev, 0)); }
 	k_dec_parse<<<4 * n, 64, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 1 */
-	k_dec_vlc<<<2 * n, 64, 0, cs>>>(ws, d->vlc_table);
-	if (fork) {
-		HIPCHK(hipEventRecord(d->join_ev, cs)); HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
-		HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0));   /* chroma goes on once both branches are in */
-	}
+	k_dec_vlc<<<2 * n, 64, 0, es>>>(ws, d->vlc_table);
+	if (fork_e) { HIPCHK(hipEventRecord(d->join_ev, es)); HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0)); }
+	if (fork) { HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(cs, d->fork_ev, 0)); }   /* chroma goes on once both branches are in */
 	k_dec_verdict<<<(n + 255) / 256, 256, 0, s>>>(ws);
 	EV(1);
 	STAGE_END();                                                                  /* 2 */
