@@ -2136,9 +2136,9 @@ extern "C" int nhw_dec_create(int device, int max_batch, nhw_dec **out)
 		return NHW_OK;
 	}();
 	if (rc != NHW_OK) { nhw_dec_destroy(d); return rc; }
-	d->chroma_fork = 0;                                              /* bit 0: the entropy branches side by side, bit 1: the chroma sequence beside the luma one.  Both bought 2.2 ms in round 2; with the kernels of round 3 either one only stretches the kernels it overlaps (a 4096-file batch: 7.03 ms with both, 6.66 with neither), so both are off unless asked for */
+	d->chroma_fork = 4;                                              /* bit 0: the entropy branches side by side, bit 1: the chroma sequence beside the luma one.  Both bought 2.2 ms in round 2; with the kernels of round 3 either one only stretches the kernels it overlaps (a 4096-file batch: 7.03 ms with both, 6.66 with neither), so both are off unless asked for; bit 2: the chroma sequence behind the luma's level 2, beside the smooth-edge marks only (6.51 ms): on */
 	if (const char *p = getenv("NHW_CHROMA_FORK")) d->chroma_fork = atoi(p) != 0 ? 3 : 0;
-	if (const char *p = getenv("NHW_DEC_FORK")) d->chroma_fork = atoi(p) & 3;
+	if (const char *p = getenv("NHW_DEC_FORK")) d->chroma_fork = atoi(p) & 7;
 	*out = d;
 	return NHW_OK;
 }
@@ -2189,6 +2189,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	const bool fork_e = (d->chroma_fork & 1) && !d->stop_after;        /* the two entropy branches side by side */
 	hipStream_t cs = fork ? d->chroma_stream : s;
 	hipStream_t es = fork_e ? d->chroma_stream : s;
+	const bool fork_late = (d->chroma_fork & 4) && !fork && !d->stop_after;   /* the chroma sequence beside the smooth-edge marks only: behind the luma's level 2 */
 #define STAGE_END() do { if (d->stop_after && ++stage >= d->stop_after) goto done; } while (0)
 #define EV(i) HIPCHK(hipEventRecord(d->ev[i], s))
 	EV(0);
@@ -2222,9 +2223,15 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	STAGE_END();                                                                  /* 4 (the block as the shrink leaves it) */
 	STAGE_END();                                                                  /* 5 (after the synthesis) */
 	STAGE_END();                                                                  /* 6 */
+	if (fork_late) {
+		HIPCHK(hipEventRecord(d->fork_ev, s)); HIPCHK(hipStreamWaitEvent(d->chroma_stream, d->fork_ev, 0));
+		CHROMA(4, d->chroma_stream);
+		k_dec_sharpen<<<(2 * n + 3) / 4, 256, 0, d->chroma_stream>>>(ws);
+		HIPCHK(hipEventRecord(d->join_ev, d->chroma_stream));
+	}
 	k_dec_marks<<<(n + 3) / 4, 256, 0, s>>>(ws);
 	STAGE_END();                                                                  /* 7 */
-	if (fork) HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
+	if (fork || fork_late) HIPCHK(hipStreamWaitEvent(s, d->join_ev, 0));
 	else {
 		CHROMA(d->stop_after == 8 ? 2 : d->stop_after == 9 ? 3 : 4, s);
 		STAGE_END();                                                              /* 8 (after level 2) */
