@@ -572,3 +572,32 @@ def test_odd_batch_sizes(oracle, q):
         assert e.encode(imgs[:n], q) == want[:n], f"q{q} n={n}"
     assert e.encode(imgs[4:7], q) == want[4:7]
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"NHW_CHROMA_FORK": "0"}, {"NHW_LISTS_FORK": "0"}])
+def test_encoder_stream_modes_give_the_same_files(oracle, env):
+    """The chroma sequence and the position lists run on streams of their own beside the luma tail; NHW_CHROMA_FORK=0 /
+    NHW_LISTS_FORK=0 put them back in line.  Same arithmetic under another schedule: 512 images at q20 and q23, every file equal to the
+    default schedule's, a sample of them to the oracle's."""
+    import torch
+    import nhwcodec_amd
+    n = 512
+    base = nhwcodec_amd.Encoder(0, n)
+    os.environ.update(env)
+    try:
+        e = nhwcodec_amd.Encoder(0, n)
+    finally:
+        for k in env: del os.environ[k]
+    bgr = base.synth_device(n, seed_base=61000)
+    for q in (20, 23):
+        o0, s0, st0 = base.encode_device(bgr, q)
+        o1, s1, st1 = e.encode_device(bgr, q)
+        torch.cuda.synchronize()
+        assert int(st0.abs().sum()) == 0 and int(st1.abs().sum()) == 0 and torch.equal(s0, s1)
+        sz = s0.cpu().numpy()
+        a0, a1 = o0.cpu().numpy(), o1.cpu().numpy()
+        assert [i for i in range(n) if not np.array_equal(a0[i, : sz[i]], a1[i, : sz[i]])] == []
+        for i in (0, 255, 511):
+            assert a1[i, : sz[i]].tobytes() == oracle.encode(oracle.synth(61000 + i), q), f"q{q} image {i}"
+    e.close(); base.close()
