@@ -2666,7 +2666,10 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	const int nwords = sh->total_bits ? (int)((sh->total_bits - 1) >> 5) + 1 : 1;
 	if (!tid) PROF(c, 26);
 
-	/* the code book (:400-459) is one short serial walk: on LDS, then copied out by everybody */
+	/* the code book (:400-459): the ranked entries as bytes (a run entry takes two), de-interleaved (even positions, then odd ones), runs of
+	 * the marker byte (3 in book 1, 128 in book 2) collapsed into (marker, count).  Until round 3 one thread walked this -- 0.1 of the
+	 * packetiser's 0.58 ms per image with 255 threads waiting; now three prefix sums.  Book 2's collapse reads on behind its table into what
+	 * book 1 left in the reference's one scratch array (c->cc) when the table ends in a run of 128s. */
 	const uint16_t *sorted = sh->sorted;
 	uint8_t *book = reinterpret_cast<uint8_t *>(lw), *tmp_book = book + 1024;
 	int *book_len = reinterpret_cast<int *>(book + 2048);
@@ -2676,46 +2679,58 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 		for (int t = tid; t < b1; t += NT) { int v = 0; for (int u = 0; u < 8; u++) v = (v << 1) | ((8 * t + u < n1 && 8 * t + u < S_CAP ? c->s1[8 * t + u] : 0) & 1); c->sel_word1[t] = (uint8_t)v; }
 		for (int t = tid; t < b2; t += NT) { int v = 0; for (int u = 0; u < 8; u++) v = (v << 1) | ((8 * t + u < n2 && 8 * t + u < S_CAP ? c->s2[8 * t + u] : 0) & 1); c->sel_word2[t] = (uint8_t)v; }
 		if (tid == 0) {
-			const int k = sh->k;
-			int e = 0, b, w, i;
 			c->m->size_data1 = nwords;
 			c->m->wavelet_type = (sh->select > 4 || !sh->top_is_zero) ? 4 : 0;       /* :367-368 */
 			c->m->select1 = b1; c->m->select2 = b2;
-			for (i = 0; i < k; i++) {                                                 /* code book 1 (:400-424) */
-				if ((sorted[i] >> 8) == 1) book[e++] = (uint8_t)(sorted[i] & 0xFF);
-				else { book[e++] = 3; book[e++] = (uint8_t)(sorted[i] >> 8); }
+		}
+	} else if (tid == 0) c->m->size_data2 = word0 + nwords;
+	{
+		const int k = sh->k, marker = part ? 128 : 3;
+		unsigned *scr = sh->bits;                                  /* scan scratch (the write sweep is done with it) */
+		unsigned tot;
+		int e;
+		{                                                          /* entries 2 tid, 2 tid + 1 -> bytes (:400-411, :431-438) */
+			int sz[2];
+			for (int h = 0; h < 2; h++) { const int i = 2 * tid + h; sz[h] = i < k ? ((sorted[i] >> 8) == 1 ? 1 : 2) : 0; }
+			unsigned at = block_exscan((unsigned)(sz[0] + sz[1]), tid, scr, &tot);
+			for (int h = 0; h < 2; h++) {
+				const int i = 2 * tid + h;
+				if (i >= k) break;
+				const int en = sorted[i];
+				if ((en >> 8) == 1) book[at++] = (uint8_t)(part ? ((en & 0xFF) | 1) : (en & 0xFF));
+				else { book[at++] = (uint8_t)(part ? (en & 0xFF) : 3); book[at++] = (uint8_t)(en >> 8); }
 			}
-			for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = book[i];
-			for (i = 1; i < e; i += 2) tmp_book[b++] = book[i];
-			tmp_book[e] = 0;
-			for (i = 0; i < e; i++) c->cc[i] = tmp_book[i];
-			sh->stale_len = e;
-			for (i = 0, w = 0, b = 0; i < e; i++) {
-				while (tmp_book[i] == 3) { b++; i++; }
-				if (b > 0) { book[w++] = 3; book[w++] = (uint8_t)b; b = 0; i--; }
-				else book[w++] = tmp_book[i];
+			e = (int)tot;
+		}
+		BARRIER();
+		const int half = (e + 1) >> 1;
+		for (int j = tid; j < e; j += NT) tmp_book[j] = j < half ? book[2 * j] : book[2 * (j - half) + 1];
+		const int stale = part ? sh->stale_len : 0;
+		if (part) for (int i = e + tid; i < stale; i += NT) tmp_book[i] = c->cc[i];
+		if (tid == 0) tmp_book[e > stale ? e : stale] = 0;
+		BARRIER();
+		if (!part) { for (int j = tid; j < e; j += NT) c->cc[j] = tmp_book[j]; if (tid == 0) sh->stale_len = e; }
+		{                                                          /* the collapse (:413-424, :440-459): bytes 3 tid .. 3 tid + 2 */
+			int osz[3];
+			for (int h = 0; h < 3; h++) {
+				const int j = 3 * tid + h;
+				osz[h] = 0;
+				if (j >= e) continue;
+				const bool is_m = tmp_book[j] == marker;
+				osz[h] = !is_m ? 1 : ((j == 0 || tmp_book[j - 1] != marker) ? 2 : 0);
 			}
-			c->m->size_book1 = w; *book_len = w;
+			unsigned at = block_exscan((unsigned)(osz[0] + osz[1] + osz[2]), tid, scr, &tot);
+			BARRIER();                                             /* (the de-interleave's source is overwritten now) */
+			for (int h = 0; h < 3; h++) {
+				const int j = 3 * tid + h;
+				if (osz[h] == 1) book[at++] = tmp_book[j];
+				else if (osz[h] == 2) { int len = 0; while (tmp_book[j + len] == marker) len++; book[at++] = (uint8_t)marker; book[at++] = (uint8_t)len; }
+			}
+			if (tid == 0) {
+				if (part) { c->m->tree_end = e; c->m->size_book2 = (int)tot; } else c->m->size_book1 = (int)tot;
+				*book_len = (int)tot;
+			}
 		}
-	} else if (tid == 0) {
-		const int k = sh->k;
-		int e = 0, b, w, i;
-		c->m->size_data2 = word0 + nwords;
-		for (i = 0; i < k; i++) {                                                     /* code book 2 (:431-459) */
-			if ((sorted[i] >> 8) == 1) book[e++] = (uint8_t)((sorted[i] & 0xFF) | 1);
-			else { book[e++] = (uint8_t)(sorted[i] & 0xFF); book[e++] = (uint8_t)(sorted[i] >> 8); }
-		}
-		c->m->tree_end = e;
-		for (i = 0, b = 0; i < e; i += 2) tmp_book[b++] = book[i];
-		for (i = 1; i < e; i += 2) tmp_book[b++] = book[i];
-		for (i = e; i < sh->stale_len; i++) tmp_book[i] = c->cc[i];
-		tmp_book[e > sh->stale_len ? e : sh->stale_len] = 0;
-		for (i = 0, w = 0, b = 0; i < e; i++) {
-			while (tmp_book[i] == 128) { b++; i++; }
-			if (b > 0) { book[w++] = 128; book[w++] = (uint8_t)b; b = 0; i--; }
-			else book[w++] = tmp_book[i];
-		}
-		c->m->size_book2 = w; *book_len = w;
 	}
 	BARRIER();
 	{
