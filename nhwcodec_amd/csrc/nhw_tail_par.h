@@ -2411,14 +2411,8 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 	const int select = sh->select;
 	/* code tables built after the ranking: (length << 24) | code word of a symbol / of a zero run of a given length */
 #define EMIT(entry) do { const uint32_t e_ = (entry), code_ = e_ & 0xFFFFFF; const int len_ = (int)(e_ >> 24); \
-		if (MODE == 1) { \
-			if (bits + (unsigned)len_ <= 128u) { \
-				const int f_ = (int)(bits & 31) + len_; \
-				uint32_t a_, b_ = 0; \
-				if (f_ <= 32) a_ = code_ << (32 - f_); else { a_ = code_ >> (f_ - 32); b_ = code_ << (64 - f_); } \
-				const unsigned wi_ = bits >> 5; \
-				r0 |= wi_ == 0 ? a_ : 0u; r1 |= wi_ == 1 ? a_ : wi_ == 0 ? b_ : 0u; r2 |= wi_ == 2 ? a_ : wi_ == 1 ? b_ : 0u; r3 |= wi_ == 3 ? a_ : wi_ == 2 ? b_ : 0u; \
-			} \
+		if (MODE == 1) {   /* the slice's bits in a 128-bit register, the newest at the bottom (left-justified once, at the end: a code is 1 .. 24 bits) */ \
+			r0 = (r0 << len_) | (r1 >> (32 - len_)); r1 = (r1 << len_) | (r2 >> (32 - len_)); r2 = (r2 << len_) | (r3 >> (32 - len_)); r3 = (r3 << len_) | code_; \
 			bits += (unsigned)len_; \
 		} \
 		else { fill += len_; if (fill <= 32) cur |= code_ << (32 - fill); \
@@ -2468,7 +2462,19 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 		i = b + 1;
 	}
 	if (MODE == 2 && fill > 0) atomicOr(&words[w], cur);
-	if (MODE == 1) { *out_bits = bits; *out_n1 = n1; *out_n2 = n2; rec->b[0] = r0; rec->b[1] = r1; rec->b[2] = r2; rec->b[3] = r3; rec->s1m = s1m; rec->s2m = s2m; }
+	if (MODE == 1) {
+		*out_bits = bits; *out_n1 = n1; *out_n2 = n2;
+		if (bits <= 128u) {                                        /* (more than 128: the slice is walked again to place its bits, MODE 2) */
+			const unsigned sh_ = 128u - bits, ws_ = sh_ >> 5, bs_ = sh_ & 31;
+			const uint32_t w_[7] = { r0, r1, r2, r3, 0u, 0u, 0u };
+			uint32_t x_[5];
+#pragma unroll
+			for (int k_ = 0; k_ < 5; k_++) x_[k_] = ws_ == 0 ? w_[k_] : ws_ == 1 ? w_[k_ + 1] : ws_ == 2 ? w_[k_ + 2] : ws_ == 3 ? w_[(k_ + 3) < 7 ? k_ + 3 : 6] : 0u;
+#pragma unroll
+			for (int k_ = 0; k_ < 4; k_++) rec->b[k_] = bs_ ? (x_[k_] << bs_) | (x_[k_ + 1] >> (32 - bs_)) : x_[k_];
+		}
+		rec->s1m = s1m; rec->s2m = s2m;
+	}
 #undef EMIT
 }
 
