@@ -2430,24 +2430,28 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 	int i = lo;
 	if (MODE != 0)                                   /* am I inside the 4 symbols that follow a 132..135 code? */
 		for (int k = 1; k <= 4; k++) if (lo - k >= 0 && d[lo - k] >= 132 && d[lo - k] <= 135) { i = lo - k + 5; break; }
+	uint64_t rest = (i - lo) < 64 ? nz >> (i - lo) : 0;             /* the mask from the walk's position on (bit 0: symbol i) */
 	while (i < hi) {
-		if ((nz >> (i - lo)) & 1) {
+		if (rest & 1) {
 			const int px = d[i];
-			if (MODE == 0) { atomicAdd(&sh->hist[px], 1); i++; continue; }
-			if (px == 153 || px == 155) { if (MODE == 2 && i1 + n1 < S_CAP) s1[i1 + n1] = (uint8_t)(px == 155); if (MODE == 1 && px == 155) s1m |= 1ull << n1; n1++; i++; continue; }
-			if (px == 157 || px == 159) { if (MODE == 2 && i2 + n2 < S_CAP) s2[i2 + n2] = (uint8_t)(px == 159); if (MODE == 1 && px == 159) s2m |= 1ull << n2; n2++; i++; continue; }
+			if (MODE == 0) { atomicAdd(&sh->hist[px], 1); i++; rest >>= 1; continue; }
+			if (px == 153 || px == 155) { if (MODE == 2 && i1 + n1 < S_CAP) s1[i1 + n1] = (uint8_t)(px == 155); if (MODE == 1 && px == 155) s1m |= 1ull << n1; n1++; i++; rest >>= 1; continue; }
+			if (px == 157 || px == 159) { if (MODE == 2 && i2 + n2 < S_CAP) s2[i2 + n2] = (uint8_t)(px == 159); if (MODE == 1 && px == 159) s2m |= 1ull << n2; n2++; i++; rest >>= 1; continue; }
 			EMIT(sh->code_sym[px]);
-			i += (px > 131 && px < 136) ? 5 : 1;
+			if (px > 131 && px < 136) { i += 5; rest >>= 5; } else { i++; rest >>= 1; }
 			continue;
 		}
 		int a = i, b;                                /* maximal zero run [a, b] around i: inside the slice from the mask, outside from the tables */
 		if (i == lo && i > 0 && d[i - 1] == 128) a = prevnz[slice] + 1;
-		const uint64_t rest = nz >> (i - lo);
 		if (rest) b = i + __builtin_ctzll(rest) - 1;
 		else b = send < N ? nextnz[slice + 1] - 1 : send - 1;
 		const int L = b - a + 1;
 		if (L == 1) {
 			if (MODE == 0) atomicAdd(&sh->hist[128], 1); else EMIT(sh->code_sym[128]);
+		} else if (a == i && L < 255) {              /* the usual run: one piece, begun here */
+			if (MODE == 0) atomicAdd(&sh->runs[L], 1);
+			else if (L < select) { for (int z = 0; z < L; z++) EMIT(sh->code_sym[128]); }
+			else EMIT(sh->code_run[L]);
 		} else {
 			const int m = L > 255 ? (L - 255 + 253) / 254 : 0;       /* pieces of exactly 254, then the rest; mine are those that start in [i, hi) */
 			int k1 = (hi - 1 - a) / 254;
@@ -2459,6 +2463,7 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 				else EMIT(sh->code_run[len]);
 			}
 		}
+		rest = (b + 1 - i) < 64 ? rest >> (b + 1 - i) : 0;
 		i = b + 1;
 	}
 	if (MODE == 2 && fill > 0) atomicOr(&words[w], cur);
