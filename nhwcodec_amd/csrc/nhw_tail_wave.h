@@ -590,28 +590,38 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 		quant_load_row(p, r + 4, lane, far);
 		if (r < W) {
 			if (r < H) {                                           /* loop 1, upper half: only columns 256..511 (words 4..7) take part */
+				/* both rules start from two neighbours on multiples of 8 (from 8 up): a row without such a pair -- most rows -- is done after that test */
 				const int *c4 = cur + 4;
-				unsigned g8, g16, le0;
-				BS_PRED(g8, c4, 4, mult8_from(x, 8)); BS_PRED(g16, c4, 4, mult8_from(x, 16)); BS_PRED(le0, c4, 4, x <= 0);
-				const unsigned ple = bs_up<4>(le0, lane, __builtin_amdgcn_readlane(cur[3], 63) <= 0);
+				unsigned g8;
+				BS_PRED(g8, c4, 4, mult8_from(x, 8));
 				const unsigned both = g8 & bs_dn(g8, lane) & (lane == 63 ? 0x7u : 0xFu);                       /* columns <= 510 */
-				const unsigned cself = both & g16 & ple;
-				const unsigned cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & bs_dn(g16, lane) & bs_dn(bs_dn(le0, lane), lane) & (lane >= 62 ? 0x7u : 0xFu);   /* columns <= 509 */
-				const unsigned hit = __any(cnext != 0) ? bs_from4(up1(alt_runs(bs_ballot4(cnext)))) : 0u;      /* cells decremented by their left neighbour (a row with no such pair skips the run resolution) */
-				const unsigned dec = hit | (cself & ~hit);
-				last_le0 = (unsigned)__builtin_amdgcn_readlane((int)le0, 63) >> 3;
-				for (int k = 0; k < 4; k++) cur[4 + k] -= (dec >> k) & 1;
+				last_le0 = __builtin_amdgcn_readlane(cur[7], 63) <= 0;
+				if (__any(both != 0)) {
+					unsigned g16, le0;
+					BS_PRED(g16, c4, 4, mult8_from(x, 16)); BS_PRED(le0, c4, 4, x <= 0);
+					const unsigned ple = bs_up<4>(le0, lane, __builtin_amdgcn_readlane(cur[3], 63) <= 0);
+					const unsigned cself = both & g16 & ple;
+					const unsigned cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & bs_dn(g16, lane) & bs_dn(bs_dn(le0, lane), lane) & (lane >= 62 ? 0x7u : 0xFu);   /* columns <= 509 */
+					const unsigned hit = __any(cnext != 0) ? bs_from4(up1(alt_runs(bs_ballot4(cnext)))) : 0u;      /* cells decremented by their left neighbour (a row with no such pair skips the run resolution) */
+					const unsigned dec = hit | (cself & ~hit);
+					for (int k = 0; k < 4; k++) cur[4 + k] -= (dec >> k) & 1;
+				}
 			} else {                                               /* loop 1, lower half: whole rows */
-				unsigned g8, g16, le0;
-				BS_PRED(g8, cur, 8, mult8_from(x, 8)); BS_PRED(g16, cur, 8, mult8_from(x, 16)); BS_PRED(le0, cur, 8, x <= 0);
-				const unsigned ple = bs_up<8>(le0, lane, last_le0);
+				unsigned g8;
+				BS_PRED(g8, cur, 8, mult8_from(x, 8));
 				const unsigned both = g8 & bs_dn(g8, lane) & (lane == 63 ? 0x7Fu : 0xFFu);
-				const unsigned cself = both & g16 & ple;
-				const unsigned cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & bs_dn(g16, lane) & bs_dn(bs_dn(le0, lane), lane) & (lane >= 62 ? 0x7Fu : 0xFFu);
-				const unsigned hit = __any(cnext != 0) ? bs_from8(up1(alt_runs(bs_ballot8(cnext)))) : 0u;
-				const unsigned dec = hit | (cself & ~hit);
-				last_le0 = (unsigned)__builtin_amdgcn_readlane((int)le0, 63) >> 7;
-				for (int k = 0; k < 8; k++) cur[k] -= (dec >> k) & 1;
+				const unsigned prev_le0 = last_le0;
+				last_le0 = __builtin_amdgcn_readlane(cur[7], 63) <= 0;
+				if (__any(both != 0)) {
+					unsigned g16, le0;
+					BS_PRED(g16, cur, 8, mult8_from(x, 16)); BS_PRED(le0, cur, 8, x <= 0);
+					const unsigned ple = bs_up<8>(le0, lane, prev_le0);
+					const unsigned cself = both & g16 & ple;
+					const unsigned cnext = both & ((g16 & ~ple) | (g8 & ~g16)) & bs_dn(g16, lane) & bs_dn(bs_dn(le0, lane), lane) & (lane >= 62 ? 0x7Fu : 0xFFu);
+					const unsigned hit = __any(cnext != 0) ? bs_from8(up1(alt_runs(bs_ballot8(cnext)))) : 0u;
+					const unsigned dec = hit | (cself & ~hit);
+					for (int k = 0; k < 8; k++) cur[k] -= (dec >> k) & 1;
+				}
 			}
 			if (r < H && !low) {
 				{                                                  /* loop 2 */
