@@ -1303,6 +1303,7 @@ DEV int poslist_match(int pass, int v, int *payload, int *keep)
 }
 DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 {
+	PROF_BEGIN();
 	int16_t *o = c->ll1;
 	const int q = c->q, lane = tid & 63, wv = tid >> 6;
 	const int npass = q >= 21 ? 3 : (q >= 19 ? 2 : 1);
@@ -1325,9 +1326,17 @@ DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 			}
 			if (lane >= 62) v[3] = 0;                               /* columns 254, 255 take no part and are cleared */
 			for (int pass = 0; pass < npass; pass++) {
-				int pl[4], kp[4];
+				/* which codes a pass takes, as a bit a code from 120 on (poslist_match): the match is two instructions, what a match carries is
+				 * only worked out in the lanes that have one (the pass is bound by its instruction count: 300 a row before this) */
+				const uint32_t takes = pass == 0 ? (1u << 21 | 1u << 20 | 1u << 6 | 1u << 5 | 1u << 28 | 1u << 29) : pass == 1 ? (15u << 1) : (3u << 24);
+				int pl[4] = { 0, 0, 0, 0 }, kp[4] = { 0, 0, 0, 0 };
 				uint64_t m[4];
-				for (int k = 0; k < 4; k++) m[k] = __ballot(poslist_match(pass, v[k], &pl[k], &kp[k]));
+				for (int k = 0; k < 4; k++) {
+					const unsigned u = (unsigned)(v[k] - 120);
+					const bool hit = u < 30u && ((takes >> u) & 1u);
+					m[k] = __ballot(hit);
+					if (hit) poslist_match(pass, v[k], &pl[k], &kp[k]);
+				}
 				const int n = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
 				if (!sweep) { if (lane == 0) cnt[pass * H + r] = n; }
 				else {
@@ -1356,8 +1365,11 @@ DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 			BARRIER();
 		}
 	}
-	for (int pass = 0; pass < npass; pass++)
+	if (!tid) PROF(c, 45);
+	for (int pass = 0; pass < npass; pass++) {
 		poslist_finish_par(c, pass == 0 ? &c->res1 : pass == 1 ? &c->res3 : &c->res5, raw[pass], (int)total[pass] + H, pay[pass], (int)total[pass], pass == 1 ? 2 : 1, tid, shm);
+		if (!tid) PROF(c, 46 + pass);
+	}
 }
 
 /* ---------------------------------------------------------------- phases (256 threads per image) */

@@ -26,7 +26,7 @@ acc /= len(pick)
 tot = acc.sum()
 for k, nm in enumerate(NAMES):
     print(f"{nm:24s} {acc[k] / 100e3:9.3f} ms  {100 * acc[k] / tot:5.1f}%")   # wall_clock64: 100 MHz
-for k in range(len(NAMES), 64):                                               # finer stamps inside a pass (Y31: 40 clear, 41 selection, 42 / 43 rewrites 1 / 2, 44 rewrite 3)
+for k in range(len(NAMES), 64):                                               # finer stamps inside a pass (Y31: 40 clear, 41 selection, 42 / 43 rewrites 1 / 2, 44 rewrite 3; Y25: 45 the two sweeps over the tag plane, 46 .. 48 the lists' packing)
     if acc[k]: print(f"stamp {k:2d}                 {acc[k] / 100e3:9.3f} ms")
 t = enc.timing()
 print("timing ms", {f: round(getattr(t, f), 2) for f, _ in t._fields_})
