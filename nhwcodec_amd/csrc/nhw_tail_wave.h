@@ -577,17 +577,17 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 	int16_t *p = c->proc;
 	uint8_t *stream = c->scan;
 	int prev[8], cur[8], nxt[8];
-	int q0[8], q1[8];                                              /* rows r+2, r+3 in flight */
+	int q0[8];                                                     /* row r+2 in flight (and r+3: `far`; a row's step is 3.5 us, a memory round trip shorter) */
 	quant_load_row(p, 0, lane, cur);
 	quant_load_row(p, 1, lane, nxt);
-	quant_load_row(p, 2, lane, q0); quant_load_row(p, 3, lane, q1);
+	quant_load_row(p, 2, lane, q0);
 	for (int k = 0; k < 8; k++) prev[k] = 0;
 	const bool low = c->q <= 16;                                   /* quality 1..16 (image_processing.c:357-410, :427-510): no loops 2 and 3; rationed low bits; the `quant4` pushes */
 	int q4_turn = 0, q4_carry = 0;                                 /* quant4: its every-third-pair counter runs through the whole plane; a push out of column 511 lands in the next row's first cell */
 	unsigned last_le0 = 0;                                         /* the last cell of the row above is <= 0 (loop 1 looks at it from column 0) */
 	for (int r = 0; r <= W; r++) {                                 /* step r: loops 1-3 on row r, loop 4 on row r - 1 */
 		int far[8];
-		quant_load_row(p, r + 4, lane, far);
+		quant_load_row(p, r + 3, lane, far);
 		if (r < W) {
 			if (r < H) {                                           /* loop 1, upper half: only columns 256..511 (words 4..7) take part */
 				/* both rules start from two neighbours on multiples of 8 (from 8 up): a row without such a pair -- most rows -- is done after that test */
@@ -814,7 +814,7 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				__threadfence_block();
 			}
 		}
-		for (int k = 0; k < 8; k++) { prev[k] = cur[k]; cur[k] = nxt[k]; nxt[k] = q0[k]; q0[k] = q1[k]; q1[k] = far[k]; }
+		for (int k = 0; k < 8; k++) { prev[k] = cur[k]; cur[k] = nxt[k]; nxt[k] = q0[k]; q0[k] = far[k]; }
 	}
 }
 
