@@ -696,48 +696,57 @@ DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 	}
 }
 
-/* Y24 (:1426-1496): commutative adds; thread j owns row j of the first-order plane, the two cells that spill
- * into row j+1 (r = 254, 255) are added in a second step */
-DEV void first_order_step(int code, int16_t *t)
-{
-	switch (code) {
-	case 141: t[0] -= 5; break;            case 140: t[0] += 5; break;
-	case 144: t[0] -= 3; break;            case 145: t[0] += 3; break;
-	case 121: t[0] -= 4; t[1] -= 3; break; case 122: t[0] += 4; t[1] += 3; break;
-	case 123: t[0] += 2; t[1] += 2; t[2] += 2; break;
-	case 124: t[0] -= 2; t[1] -= 2; t[2] -= 2; break;
-	case 126: t[0] += 9; t[1] += 3; break; case 125: t[0] -= 9; t[1] -= 3; break;
-	case 148: t[0] -= 8; break;            case 149: t[0] += 8; break;
-	default: break;
-	}
-}
-/* Thread j reads column j of the code plane (consecutive threads, consecutive cells) but owns ROW j of the first-order plane: its cells
- * go through LDS, 32 columns (+ the two a step may spill into) of all 256 rows at a time, loaded and stored as row pieces. */
-#define FO_C 32
-#define FO_P (FO_C + 2)                                           /* 17 dwords: a thread per row walks conflict-free */
-DEV void adjust_first_order_par(Ctx *c, int tid, int16_t *lds /* [H][FO_P] */)
+/* Y24 (nhw_encoder.c:1426-1496): every code of the code plane adds a constant to one, two or three consecutive cells of the first-order
+ * plane, linearly indexed, transposed: code (r, j) to cells j * 256 + r .. */
+/* The adds commute, so the pass is a gather: cell x = j * 256 + c of the first-order plane takes A0(code(c, j)) + A1(code(c - 1, j)) +
+ * A2(code(c - 2, j)), code(r, j) = the code plane's cell (r, j), j < 254 -- and, since the reference indexes linearly, the first two cells
+ * of a row take what codes (254, j - 1) and (255, j - 1) spill over the row end.  Row j of the result needs COLUMN j of the code plane:
+ * 64 columns at a time go through LDS as bytes (a code is 121 .. 149), transposed, with the two spilling codes of the row before in front
+ * of every row; then a wavefront takes a row, a lane four cells and the six bytes they look at -- all zero for nearly every lane, which
+ * then touches nothing.  (Until round 3: a thread per row stepped through 32-column tiles of the plane, 0.36 ms per image at q23.) */
+#define FO_TP 260                                                 /* bytes per transposed row: 2 + 256, a multiple of 4 */
+__device__ static const int8_t k_fo_add[3][32] = {               /* by code - 120 */
+	{ 0, -4, 4, 2, -2, -9, 9, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5, -5, 0, 0, -3, 3, 0, 0, -8, 8, 0, 0 },
+	{ 0, -3, 3, 2, -2, -3, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 },
+	{ 0, 0, 0, 2, -2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 } };
+DEV void adjust_first_order_par(Ctx *c, int tid, int16_t *lds /* 64 * FO_TP + 96 + 4 bytes */)
 {
 	int16_t *f = c->first_order;
-	const int j = tid;
-	for (int r0 = 0; r0 < H - 2; r0 += FO_C) {
-		const int nd = (H - r0 < FO_P ? H - r0 : FO_P) / 2;        /* dwords of a row piece: columns r0 .. r0 + 2 nd - 1 */
-		for (int idx = tid; idx < H * (FO_P / 2); idx += NT) {
-			const int row = idx / (FO_P / 2), d = idx % (FO_P / 2);
-			if (d < nd) reinterpret_cast<uint32_t *>(lds + row * FO_P)[d] = reinterpret_cast<const uint32_t *>(f + row * H + r0)[d];
+	const int16_t *code = c->ll1;
+	uint8_t *T = reinterpret_cast<uint8_t *>(lds);
+	int8_t *add = reinterpret_cast<int8_t *>(T + 64 * FO_TP);      /* the table, in LDS: the lanes of a wavefront index it differently */
+	uint8_t *carry = reinterpret_cast<uint8_t *>(add + 96);         /* codes (254, j), (255, j) of the last column of the band before */
+	const int lane = tid & 63, wv = tid >> 6;
+	if (tid < 96) add[tid] = k_fo_add[tid >> 5][tid & 31];
+	if (tid < 2) carry[tid] = 0;
+	for (int b = 0; b < 4; b++) {
+		BARRIER();
+		for (int idx = tid; idx < H * 64; idx += NT) {             /* 64 columns of every row of the code plane, transposed */
+			const int r = idx >> 6, jl = idx & 63, j = 64 * b + jl;
+			const unsigned u = (unsigned)(code[r * H + j] - 120);
+			T[jl * FO_TP + 2 + r] = (uint8_t)((u < 30u && j < H - 2) ? u : 0u);
 		}
 		BARRIER();
-		if (j < H - 2) {
-			const int r1 = r0 + FO_C < H - 2 ? r0 + FO_C : H - 2;
-			for (int r = r0; r < r1; r++) first_order_step(c->ll1[r * H + j], lds + j * FO_P + (r - r0));
+		if (tid < 64) {                                            /* what the row before spills into a row's first two cells */
+			const uint8_t s0 = tid ? T[(tid - 1) * FO_TP + 2 + H - 2] : carry[0], s1 = tid ? T[(tid - 1) * FO_TP + 2 + H - 1] : carry[1];
+			T[tid * FO_TP] = s0; T[tid * FO_TP + 1] = s1;
 		}
 		BARRIER();
-		for (int idx = tid; idx < H * (FO_P / 2); idx += NT) {
-			const int row = idx / (FO_P / 2), d = idx % (FO_P / 2);
-			if (d < nd) reinterpret_cast<uint32_t *>(f + row * H + r0)[d] = reinterpret_cast<const uint32_t *>(lds + row * FO_P)[d];
+		if (tid < 2) carry[tid] = T[63 * FO_TP + 2 + H - 2 + tid];
+		for (int jl = wv; jl < 64; jl += NT / 64) {
+			const uint32_t *w = reinterpret_cast<const uint32_t *>(T + jl * FO_TP + 4 * lane);   /* bytes 4 l .. 4 l + 5: codes (c - 2 .. c + 3, j) of my cells c = 4 l .. */
+			const uint32_t w0 = w[0], w1 = w[1] & 0xFFFFu;
+			if (!(w0 | w1)) continue;
+			const unsigned by[6] = { w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24, w1 & 255u, w1 >> 8 };
+			uint2 *cell = reinterpret_cast<uint2 *>(f + (size_t)(64 * b + jl) * H + 4 * lane);
+			uint2 v = *cell;
+			int x[4] = { (int16_t)(v.x & 0xFFFF), (int16_t)(v.x >> 16), (int16_t)(v.y & 0xFFFF), (int16_t)(v.y >> 16) };
+#pragma unroll
+			for (int k = 0; k < 4; k++) x[k] += add[by[k + 2]] + add[32 + by[k + 1]] + add[64 + by[k]];
+			v.x = (uint32_t)(uint16_t)x[0] | ((uint32_t)(uint16_t)x[1] << 16); v.y = (uint32_t)(uint16_t)x[2] | ((uint32_t)(uint16_t)x[3] << 16);
+			*cell = v;
 		}
-		BARRIER();
 	}
-	if (j < H - 2) for (int r = H - 2; r < H; r++) first_order_step(c->ll1[r * H + j], f + j * H + r);   /* these two spill into row j + 1: after everything else */
 	BARRIER();
 }
 
