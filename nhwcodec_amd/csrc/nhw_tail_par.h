@@ -2049,19 +2049,33 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 	/* half synthesis of the kept first-order LL + that band against the original pass-1 plane (:509-541): pointwise */
 	int16_t *hs = c->hs;
 	const int thr = q > 22 ? 30 : 34;
-	for (int idx = tid; idx < Q; idx += NT) {
-		const int rr = idx >> 8, k = idx & 255;
+	for (int idx = tid; idx < Q / 4; idx += NT) {                               /* four cells (eight outputs) per item: 8- and 16-byte accesses */
+		const int rr = idx >> 6, k0 = (idx & 63) * 4;
 		const int16_t *lo = c->first_order + rr * H, *hi = b + rr * H;
-		const int ln = k + 1 < H ? lo[k + 1] : lo[k];
-		const int hp = k > 0 ? hi[k - 1] : hi[0], hn = k + 1 < H ? hi[k + 1] : hi[k];
-		int16_t o[2];
-		o[0] = (int16_t)((int16_t)(lo[k] << 3) - ((hi[k] + hp) << 1));
-		o[1] = (int16_t)((int16_t)((lo[k] + ln) << 2) + (6 * hi[k] - hp - hn));
-		for (int e = 0; e < 2; e++) {
-			const int i = rr * W + 2 * k + e, d = c->keep[i] - o[e];
-			if (iabs(d) > thr) o[e] = (int16_t)((q > 22 && iabs(d) > 56) ? (d > 0 ? 32000 : 32500) : (d > 0 ? 30000 : 31000));
+		int l[5], h[6];                                                          /* lo[k0 .. k0 + 4], hi[k0 - 1 .. k0 + 4] */
+		{
+			const uint2 lw = *reinterpret_cast<const uint2 *>(lo + k0), hw = *reinterpret_cast<const uint2 *>(hi + k0);
+			l[0] = (int16_t)(lw.x & 0xFFFF); l[1] = (int16_t)(lw.x >> 16); l[2] = (int16_t)(lw.y & 0xFFFF); l[3] = (int16_t)(lw.y >> 16);
+			h[1] = (int16_t)(hw.x & 0xFFFF); h[2] = (int16_t)(hw.x >> 16); h[3] = (int16_t)(hw.y & 0xFFFF); h[4] = (int16_t)(hw.y >> 16);
+			l[4] = k0 + 4 < H ? lo[k0 + 4] : l[3];
+			h[0] = k0 > 0 ? hi[k0 - 1] : h[1];
+			h[5] = k0 + 4 < H ? hi[k0 + 4] : h[4];
 		}
-		*reinterpret_cast<uint32_t *>(hs + rr * W + 2 * k) = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+		const uint4 kw = *reinterpret_cast<const uint4 *>(c->keep + rr * W + 2 * k0);
+		const uint32_t kk[4] = { kw.x, kw.y, kw.z, kw.w };
+		uint32_t out[4];
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			int16_t o[2];
+			o[0] = (int16_t)((int16_t)(l[t] << 3) - ((h[t + 1] + h[t]) << 1));
+			o[1] = (int16_t)((int16_t)((l[t] + l[t + 1]) << 2) + (6 * h[t + 1] - h[t] - h[t + 2]));
+			for (int e = 0; e < 2; e++) {
+				const int d = (int16_t)(kk[t] >> (16 * e)) - o[e];
+				if (iabs(d) > thr) o[e] = (int16_t)((q > 22 && iabs(d) > 56) ? (d > 0 ? 32000 : 32500) : (d > 0 ? 30000 : 31000));
+			}
+			out[t] = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+		}
+		*reinterpret_cast<uint4 *>(hs + rr * W + 2 * k0) = make_uint4(out[0], out[1], out[2], out[3]);
 	}
 	BARRIER();
 	/* The two list passes below visit the cells of hs in raster order; a wavefront takes a row (512 cells, lane l the eight from 8 l on:
