@@ -2004,6 +2004,7 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 		for (int k = 0; k < 4; k++) a[k] = p[(size_t)row * W + H + lane + 64 * k];
 		M4 cand;
 		BALLOT4(cand, a, x == 127 || x == 129);
+		if (!(cand.w[3] >> 63)) { if (!lane) sh[row] = 0; continue; }        /* the last cell is no mark (the rule): the walk cannot end in one */
 		const M4 fired = alt_runs(cand);
 		if (!lane) sh[row] = (int)(fired.w[3] >> 63);
 	}
@@ -2025,8 +2026,16 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 		const bool next_mark0 = nxt == 127 || nxt == 129;
 		M4 cand;
 		BALLOT4(cand, a, x == 127 || x == 129);
-		const M4 fired = alt_runs(cand), fnext = dn1(fired), fprev = up1(fired);
 		const int base = sh[H + row], ends = sh[row];
+		if (!(cand.w[0] | cand.w[1] | cand.w[2] | cand.w[3])) {                 /* a row without marks (most): every code lands in its own slot */
+			for (int k = 0; k < 4; k++) {
+				const int j = lane + 64 * k, x = a[k];
+				if (j == H - 1 && next_mark0) b[base + j] = (int16_t)(nxt == 127 ? 5 : -5);
+				else if (x != 128) b[base + j] = (int16_t)band_value(x);
+			}
+			continue;
+		}
+		const M4 fired = alt_runs(cand), fnext = dn1(fired), fprev = up1(fired);
 		for (int k = 0; k < 4; k++) {
 			const int j = lane + 64 * k, x = a[k];
 			const int xr = right_of(a, k, 4, 1, lane);                            /* cell j + 1 */
