@@ -2055,11 +2055,21 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 	}
 	BARRIER();
 
+	if (!tid) PROF(c, 50);
 	/* half synthesis of the kept first-order LL + that band against the original pass-1 plane (:509-541): pointwise */
 	int16_t *hs = c->hs;
 	const int thr = q > 22 ? 30 : 34;
+	auto wave_exscan = [&](int v, int &total) {
+		int x = v;
+		for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+		total = __shfl(x, 63);
+		return x - v;
+	};
+	/* (a wavefront per row, a lane the row's eight cells from 8 l on -- the layout of the list passes below, whose counts are taken here, where
+	 * the values are made: sh[row] = the row's 32000 / 32500 cells, sh[H + row] = its 30000 / 31000 cells | those of columns 254, 255 << 16) */
 	for (int idx = tid; idx < Q / 4; idx += NT) {                               /* four cells (eight outputs) per item: 8- and 16-byte accesses */
 		const int rr = idx >> 6, k0 = (idx & 63) * 4;
+		int n_q3 = 0, n_e = 0, n_c = 0;
 		const int16_t *lo = c->first_order + rr * H, *hi = b + rr * H;
 		int l[5], h[6];                                                          /* lo[k0 .. k0 + 4], hi[k0 - 1 .. k0 + 4] */
 		{
@@ -2083,10 +2093,20 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 				if (iabs(d) > thr) o[e] = (int16_t)((q > 22 && iabs(d) > 56) ? (d > 0 ? 32000 : 32500) : (d > 0 ? 30000 : 31000));
 			}
 			out[t] = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+			for (int e = 0; e < 2; e++) {
+				n_q3 += o[e] == 32000 || o[e] == 32500;
+				const bool hit = o[e] == 30000 || o[e] == 31000;
+				if ((lane == 31 || lane == 63) && t == 3) { if (lane == 31) n_c += hit; } else n_e += hit;   /* columns 254, 255 (char_res1) and 510, 511 (nowhere) are no list entries */
+			}
 		}
 		*reinterpret_cast<uint4 *>(hs + rr * W + 2 * k0) = make_uint4(out[0], out[1], out[2], out[3]);
+		int t_q3, t_e;
+		(void)wave_exscan(n_q3, t_q3); (void)wave_exscan(n_e, t_e);
+		const int t_c = __shfl(n_c, 31);
+		if (!lane) { sh[rr] = t_q3; sh[H + rr] = t_e | (t_c << 16); }
 	}
 	BARRIER();
+	if (!tid) PROF(c, 51);
 	/* The two list passes below visit the cells of hs in raster order; a wavefront takes a row (512 cells, lane l the eight from 8 l on:
 	 * 16-byte loads), counts first, the rows' offsets from a prefix sum over the rows, then the entries at offset + (entries of the lanes
 	 * before mine). */
@@ -2095,88 +2115,53 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 		const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
 		for (int e = 0; e < 4; e++) { v[2 * e] = (int16_t)(ww[e] & 0xFFFF); v[2 * e + 1] = (int16_t)(ww[e] >> 16); }
 	};
-	auto wave_exscan = [&](int v, int &total) {
-		int x = v;
-		for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
-		total = __shfl(x, 63);
-		return x - v;
-	};
-	if (q > 22) {                                                              /* :547-564 */
-		for (int row = wv; row < H; row += NT / 64) {
-			int v[8], cnt = 0, total;
-			load8(hs + (size_t)row * W, v);
-			for (int e = 0; e < 8; e++) cnt += v[e] == 32000 || v[e] == 32500;
-			(void)wave_exscan(cnt, total);
-			if (!lane) sh[row] = total;
-		}
-		BARRIER();
-		const unsigned at_r = block_exscan((unsigned)sh[r], tid, shm, &tot);
-		sh[H + r] = (int)at_r;
-		BARRIER();
-		for (int row = wv; row < H; row += NT / 64) {
-			int v[8], cnt = 0, total;
-			load8(hs + (size_t)row * W, v);
-			for (int e = 0; e < 8; e++) cnt += v[e] == 32000 || v[e] == 32500;
-			int at = sh[H + row] + wave_exscan(cnt, total);
+	/* the rows' offsets from prefix sums over the rows' counts; then one pass writes both lists: the entries at offset + (entries of the
+	 * lanes before mine) */
+	const unsigned q3_r = (unsigned)sh[r], e_r = (unsigned)sh[H + r] & 0xFFFFu, nc_r = (unsigned)sh[H + r] >> 16;
+	BARRIER();
+	unsigned te, tc;
+	const unsigned aq_r = block_exscan(q3_r, tid, shm, &tot);
+	const unsigned ae_r = block_exscan(e_r, tid, shm, &te);
+	const unsigned ac_r = block_exscan(nc_r, tid, shm, &tc);
+	sh[r] = (int)aq_r; sh[H + r] = (int)(ae_r | (ac_r << 20));
+	BARRIER();
+	if (!tid) PROF(c, 52);
+	/* qsetting3: the 32000 / 32500 cells (:547-564, q23).  The position list of the 30000 / 31000 cells (:571-610): columns 254, 255 and 510,
+	 * 511 are a row mark each (raw value 254, behind the entries of the columns before them), the first pair reported through char_res1 instead */
+	uint8_t *raw = c->raw, *pay = c->pay;
+	for (int row = wv; row < H; row += NT / 64) {
+		int v[8], cnt = 0, nq = 0, total, tq;
+		load8(hs + (size_t)row * W, v);
+		const bool special = lane == 31 || lane == 63;
+		for (int e = 0; e < 8; e++) { nq += v[e] == 32000 || v[e] == 32500; if (e < (special ? 6 : 8)) cnt += v[e] == 30000 || v[e] == 31000; }
+		if (tot) {
+			int at = sh[row] + wave_exscan(nq, tq);
 			for (int e = 0; e < 8; e++) {
 				const int i = row * W + 8 * lane + e;
 				if (v[e] == 32000) c->qsetting3[at++] = (uint32_t)(i << 1);
 				else if (v[e] == 32500) c->qsetting3[at++] = (uint32_t)(i << 1) + 1;
 			}
 		}
-		if (tid == 0) c->m->qsetting3_len = (int)tot;
-		BARRIER();
-	}
-	else if (tid == 0) c->m->qsetting3_len = 0;
-	/* the position list of the 30000 / 31000 cells (:571-610): columns 254, 255 and 510, 511 are a row mark each (raw value 254, behind the
-	 * entries of the columns before them), the first pair reported through char_res1 instead */
-	uint8_t *raw = c->raw, *pay = c->pay;
-	{
-		for (int row = wv; row < H; row += NT / 64) {
-			int v[8], cnt = 0, nc = 0, total;
-			load8(hs + (size_t)row * W, v);
-			for (int e = 0; e < 8; e++) {
-				const bool hit = v[e] == 30000 || v[e] == 31000;
-				if ((lane == 31 || lane == 63) && e >= 6) { if (lane == 31) nc += hit; }
-				else cnt += hit;
-			}
-			(void)wave_exscan(cnt, total);
-			const int ncr = __shfl(nc, 31);
-			if (!lane) { sh[row] = total; sh[H + row] = ncr; }
+		const int off = wave_exscan(cnt, total);
+		const int first_half = __shfl(off, 32);                                  /* entries of columns 0..253 */
+		const int base_e = sh[H + row] & 0xFFFFF;
+		int ae = base_e + off;                                                   /* payload index; the raw list has two marks per row before this row's, one more from column 256 on */
+		int an = ae + 2 * row + (lane >= 32);
+		for (int e = 0; e < (special ? 6 : 8); e++) {
+			if (v[e] == 30000) { raw[an++] = (uint8_t)((8 * lane + e) & 255); pay[ae++] = 0; }
+			else if (v[e] == 31000) { raw[an++] = (uint8_t)((8 * lane + e) & 255); pay[ae++] = 1; }
 		}
-		BARRIER();
-		const unsigned e_r = (unsigned)sh[r], nc_r = (unsigned)sh[H + r];
-		BARRIER();
-		unsigned te, tc;
-		const unsigned ae_r = block_exscan(e_r, tid, shm, &te);
-		const unsigned ac_r = block_exscan(nc_r, tid, shm, &tc);
-		sh[r] = (int)ae_r; sh[H + r] = (int)ac_r;
-		BARRIER();
-		for (int row = wv; row < H; row += NT / 64) {
-			int v[8], cnt = 0, total;
-			load8(hs + (size_t)row * W, v);
-			const bool special = lane == 31 || lane == 63;
-			for (int e = 0; e < (special ? 6 : 8); e++) cnt += v[e] == 30000 || v[e] == 31000;
-			const int off = wave_exscan(cnt, total);
-			const int first_half = __shfl(off, 32);                              /* entries of columns 0..253 */
-			int ae = sh[row] + off;                                              /* payload index; the raw list has two marks per row before this row's, one more from column 256 on */
-			int an = ae + 2 * row + (lane >= 32);
-			for (int e = 0; e < (special ? 6 : 8); e++) {
-				if (v[e] == 30000) { raw[an++] = (uint8_t)((8 * lane + e) & 255); pay[ae++] = 0; }
-				else if (v[e] == 31000) { raw[an++] = (uint8_t)((8 * lane + e) & 255); pay[ae++] = 1; }
-			}
-			if (lane == 31) {
-				raw[sh[row] + 2 * row + first_half] = H - 2;
-				int ac = sh[H + row];
-				if (v[6] == 30000) c->char_res1[ac++] = (uint16_t)(row * H); else if (v[6] == 31000) c->char_res1[ac++] = (uint16_t)(row * H + 1);
-				if (v[7] == 30000) c->char_res1[ac++] = (uint16_t)(row * H + 2); else if (v[7] == 31000) c->char_res1[ac++] = (uint16_t)(row * H + 3);
-			}
-			if (lane == 63) raw[sh[row] + 2 * row + total + 1] = H - 2;
+		if (lane == 31) {
+			raw[base_e + 2 * row + first_half] = H - 2;
+			int ac = sh[H + row] >> 20;
+			if (v[6] == 30000) c->char_res1[ac++] = (uint16_t)(row * H); else if (v[6] == 31000) c->char_res1[ac++] = (uint16_t)(row * H + 1);
+			if (v[7] == 30000) c->char_res1[ac++] = (uint16_t)(row * H + 2); else if (v[7] == 31000) c->char_res1[ac++] = (uint16_t)(row * H + 3);
 		}
-		BARRIER();
-		if (tid == 0) { c->m->char_res1_len = (int)tc; sh[0] = (int)(te + 2 * H); sh[1] = (int)te; }
-		BARRIER();
+		if (lane == 63) raw[base_e + 2 * row + total + 1] = H - 2;
 	}
+	BARRIER();
+	if (tid == 0) { c->m->qsetting3_len = (int)tot; c->m->char_res1_len = (int)tc; sh[0] = (int)(te + 2 * H); sh[1] = (int)te; }
+	BARRIER();
 	poslist_finish_par(c, &c->res6, raw, sh[0], pay, sh[1], 1, tid, shm);
 	BARRIER();
 	if (!tid) PROF(c, 16);
