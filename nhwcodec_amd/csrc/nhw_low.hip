@@ -940,8 +940,12 @@ DEVI void zero_below(int16_t *v, int lim) { if (iabs_(*v) < lim) *v = 0; }
 #define LL2_NT 256
 __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb, size_t plane_stride, int q)
 {
-	__shared__ __attribute__((aligned(16))) int16_t ll[LS * LP + 8];
-	__shared__ uint32_t h32[LS * LS / 32], h34[LS * LS / 32], h36[LS * LS / 32], hsib[LS * LS / 32];
+	/* LDS sized at launch: the buffer and the hit maps -- three of them where thrx5 is 34 (quality 8 .. 12: the first walk's hits and the last
+	 * walk's share a limit and a map), four where it is 36: 39.4 KB, four workgroups to a CU, instead of 41.5 KB and three */
+	extern __shared__ __attribute__((aligned(16))) int16_t ll2_lds[];
+	int16_t *ll = ll2_lds;
+	uint32_t *h32 = reinterpret_cast<uint32_t *>(ll2_lds + LS * LP + 8), *h34 = h32 + LS * LS / 32, *hsib = h34 + LS * LS / 32;
+	uint32_t *h36 = k_ll2_thr[q <= 12 ? q : 12][4] == 36 ? hsib + LS * LS / 32 : h34;
 	__shared__ int stale_hits;
 	int16_t *p = procb + (size_t)blockIdx.x * plane_stride;
 	const int tid = threadIdx.x, lane = tid & 63;                  /* four wavefronts: the row walks take a thread per row (128 rows), the clearing of children all 256; the two skewed raster walks stay one wavefront */
@@ -1120,7 +1124,7 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 #endif
 		const int w = cell >> 5;
 		const uint32_t bit = 1u << (cell & 31);
-		const int limc = (h36[w] & bit) ? 36 : (h34[w] & bit) ? 34 : (h32[w] & bit) ? 32 : 0;
+		const int limc = (t5 == 36 && (h36[w] & bit)) ? 36 : (h34[w] & bit) ? 34 : (h32[w] & bit) ? 32 : 0;   /* (thrx5 34: h36 is h34) */
 		const bool sib = hsib[w] & bit;
 		if (!limc && !sib) continue;
 		const int r = cell >> 7, j = cell & 127, flat = r * W + j;
@@ -1180,7 +1184,8 @@ void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipS
 
 void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s)
 {
-	k_low_ll2<<<n, LL2_NT, 0, s>>>(proc, plane_stride, q);
+	const int maps = (q <= 7) ? 4 : 3;                               /* k_ll2_thr[q][4] == 36 up to quality 7 */
+	k_low_ll2<<<n, LL2_NT, (size_t)(128 * 130 + 8) * 2 + (size_t)maps * (128 * 128 / 32) * 4, s>>>(proc, plane_stride, q);
 }
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
                               int q, int n, hipStream_t s)
