@@ -335,7 +335,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="images per GPU per step (weak scaling)")
     ap.add_argument("--total-images", type=int, default=0, help="strong scaling: ONE job of this many images per step, cut into contiguous per-rank ranges (BASELINE configs[3]: 65536 over 8 GPUs)")
     ap.add_argument("--quality", type=int, default=20)
-    ap.add_argument("--sweep", type=str, default="1,10,17,23", help="BASELINE configs[2]: quality settings timed after the headline measurement (N=1 only); '' = none")
+    ap.add_argument("--sweep", type=str, default="1,8,10,17,23", help="BASELINE configs[2]: quality settings timed after the headline measurement (N=1 only; 8 stands for the slowest band of qualities, 6 .. 9: DESIGN 4.7); '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive leg (host buffers through nhw_enc_batch) reported next to the metric")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (BASELINE config 5) reported next to the encode metric")
