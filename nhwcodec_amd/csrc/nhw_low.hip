@@ -436,10 +436,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 	machine_cache(mach, mcache);
 
 #ifdef NHW_DEV
-	long long pclk[6] = { 0, 0, 0, 0, 0, 0 }, pt0 = 0;
+	long long pclk[14] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, pt0 = 0, st0 = 0;   /* 6..13: the chain's steps by kind, cycles and count */
 #define PCLK_BEGIN() (pt0 = (long long)__builtin_readcyclecounter())
 #define PCLK_END(i) (pclk[i] += (long long)__builtin_readcyclecounter() - pt0)
+#define SCLK_BEGIN() (st0 = (long long)__builtin_readcyclecounter())
+#define SCLK_END(i) (pclk[i] += (long long)__builtin_readcyclecounter() - st0, pclk[(i) + 1]++)
 #else
+#define SCLK_BEGIN() ((void)0)
+#define SCLK_END(i) ((void)0)
 #define PCLK_BEGIN() ((void)0)
 #define PCLK_END(i) ((void)0)
 #endif
@@ -605,22 +609,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		uint32_t aw = 0;                                             /* the answers of my four pairs */
 		if (!(dbg & 2)) {
 			int pos = 0, hbase = 0;                                  /* hbase: hits of the pairs before pos */
-			bool give_up = false;                                    /* a burst that was declined is walked pair by pair to its end */
+			bool give_up = false;                                    /* a burst that was declined is walked pair by pair: to its end, or to the next pair machine_step takes */
+			int cut_at = 255;                                        /* where a burst's pairs end: the row's end, or the pair that ends the burst through t17 (machine_step's) */
 			auto single_pair = [&]() {
 				const int code = (int)(((uint32_t)__builtin_amdgcn_readlane((int)cw, pos >> 2) >> (8 * (pos & 3))) & 15u);
-				int a = machine_step_fast(mach, mcache, code);
-				if (a < 0) { a = machine_step(mach, code, r); machine_cache(mach, mcache); }
+				SCLK_BEGIN();
+				int a = pos == cut_at ? -1 : machine_step_fast(mach, mcache, code);
+				const bool slow = a < 0;
+				if (slow) { a = machine_step(mach, code, r); machine_cache(mach, mcache); give_up = false; cut_at = 255; }
 				if (a && lane == (pos >> 2)) aw |= (uint32_t)a << (8 * (pos & 3));
 				hbase += (code & 1) + ((code >> 1) & 1);
 				pos++;
+				if (slow) SCLK_END(8); else SCLK_END(6);
 			};
 			while (pos < 255) {
-				if (mach.t[1] == 0) {                                 /* a burst's first pair */
-					give_up = false;
-					single_pair();
-					if (pos >= 255) break;
-				}
-				if (!give_up && burst_entry_ok(mach, mcache)) {
+				if (mach.t[1] == 0) give_up = false;                  /* a burst's first pair comes next */
+				else if (!give_up && pos != cut_at && burst_entry_ok(mach, mcache)) {
+					SCLK_BEGIN();
 					const int i = pos + lane < 255 ? pos + lane : 255;
 					const int hj = (int)s_hits[i] - hbase;
 					const PfBurstLane b = burst_lane(lane, mach.t[1], mach.t[4], mach.t[44], hj, mach.t[10], mach.t[11], mcache.exT);
@@ -628,17 +633,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 					int n;
 					if (burst_quiet(mach, mcache))
 						n = burst_commit_quiet(mach, mcache, (unsigned)__ballot(b.cap), (unsigned)__ballot(b.wrap), (unsigned)__ballot(b.win), (unsigned)__ballot(b.cyc),
-						                       mcache.w8z ? (unsigned)__ballot(b.i6) : 0u, 255 - pos, hits_to);
+						                       mcache.w8z ? (unsigned)__ballot(b.i6) : 0u, cut_at - pos, hits_to);
 					else {
 						PfBurstMasks k;
 						k.cap = __ballot(b.cap); k.wrap = __ballot(b.wrap); k.win = __ballot(b.win); k.cyc = __ballot(b.cyc); k.i6 = __ballot(b.i6);
 						k.iS = __ballot(b.iS); k.cnt = __ballot(b.cnt); k.g13 = __ballot(b.g13); k.e15 = __ballot(b.e15); k.eT = __ballot(b.eT);
-						n = burst_commit(mach, mcache, k, 255 - pos, hits_to);
+						n = burst_commit(mach, mcache, k, cut_at - pos, hits_to);
 					}
-					if (n > 0) { hbase += __builtin_amdgcn_readlane(hj, n - 1); pos += n; continue; }
+					if (n > 0) { hbase += __builtin_amdgcn_readlane(hj, n - 1); pos += n; SCLK_END(10); continue; }
+					/* declined.  If that is because one of its pairs ends it through t17, the burst is taken up to that pair as a burst the row cuts
+					 * (the next turn of the loop, with the masks made again: this path must not cost the bursts that are taken anything); the
+					 * pair itself goes through machine_step, and what follows it is a burst again */
+					if (cut_at == 255) {
+						const int w = burst_t17_pair(mach, __ballot(b.cap), __ballot(b.wrap), __ballot(b.win), __ballot(b.cyc), 255 - pos);
+						if (w >= 1 && w < 255 - pos) { cut_at = pos + w; SCLK_END(12); continue; }
+					}
+					cut_at = 255;
 					give_up = true;
+					SCLK_END(12);
 				}
-				if (mach.t[1] != 0) single_pair();                    /* a pair inside a burst that was declined */
+				single_pair();                                        /* a first pair, or a pair inside a burst that was declined */
 			}
 		}
 		__syncthreads();
@@ -729,7 +743,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
 		if (lane < 16) reinterpret_cast<uint32_t *>(soo)[lane] = s_rowmask[lane];      /* flag plane, row 0: the rows k_low_marks must leave alone */
 #ifdef NHW_DEV
-		if (lane < 6) reinterpret_cast<long long *>(soo + (size_t)(W - 1) * W)[lane] = pclk[lane];   /* developer builds: cycles per phase, in the flag plane's unused last row */
+		if (lane < 14) reinterpret_cast<long long *>(soo + (size_t)(W - 1) * W)[lane] = pclk[lane];   /* developer builds: cycles per phase, in the flag plane's unused last row */
 #endif
 	}
 }

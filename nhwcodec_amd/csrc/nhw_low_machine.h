@@ -494,6 +494,20 @@ DEVI int burst_commit(PfM &m, const PfC &c, const PfBurstMasks &k, int avail, HI
 	T(29)++; T(1) = 0; T(4) = 0;
 	return e + 1;
 }
+/* A burst that was declined: the first of its pairs that ends it through t17 (:1053) -- a pair at the window (:1004 / :1039), or the pair that
+ * finds the t18 rotation at 0 (:1006-1037: 16 - t18 rotating pairs take it there) -- or 64 if there is none before the burst's cap or wrap.
+ * The pairs before that one can still go as an open burst (burst_commit with avail = the answer); the pair itself needs machine_step. */
+DEVI int burst_t17_pair(const PfM &m, unsigned long long cap, unsigned long long wrap, unsigned long long win, unsigned long long cyc, int avail)
+{
+	const unsigned long long endm = cap | wrap;
+	const int e_ = endm ? __builtin_ctzll(endm) : 63;
+	const unsigned long long upto = burst_low_bits((e_ < avail ? e_ : avail - 1) + 1);
+	const unsigned long long wm = win & ~cyc & upto;
+	unsigned long long cy = cyc & upto;
+	for (int skip = T(18) == 0 ? 0 : 16 - T(18); skip > 0 && cy; skip--) cy &= cy - 1;
+	const int w1 = wm ? __builtin_ctzll(wm) : 64, w2 = cy ? __builtin_ctzll(cy) : 64;
+	return w1 < w2 ? w1 : w2;
+}
 /* the same with the gate of the slow schedules shut (burst_quiet): masks of the first 32 pairs (a burst is over within 21) */
 template <class HITS>
 DEVI int burst_commit_quiet(PfM &m, const PfC &c, unsigned cap, unsigned wrap, unsigned win, unsigned cyc, unsigned i6, int avail, HITS hits_to)

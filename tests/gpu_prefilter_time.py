@@ -31,14 +31,17 @@ def main(qs, n=4096, check=6):
             ts.append((time.time() - t0) * 1e3)
         try:
             import ctypes
-            acc = np.zeros(6)
+            acc = np.zeros(14)
             for i in range(0, n, max(1, n // 64)):
                 m = np.zeros(512 * 512, np.uint8)
                 enc.lib.nhw_debug_read(enc.h, 17, i, ctypes.c_void_p(m.ctypes.data), ctypes.c_size_t(512 * 512))
-                acc += m[511 * 512: 511 * 512 + 48].view(np.int64)
+                acc += m[511 * 512: 511 * 512 + 112].view(np.int64)
             if acc.sum() > 0:
                 names = ["load+sync", "A parallel", "A serial", "copy/codes/hits", "chain", "apply+marker rows"]
-                print("   phase cycles per row (mean over sampled images):", {k: int(v / (n // max(1, n // 64)) / 510) for k, v in zip(names, acc)})
+                per_row = (n // max(1, n // 64)) * 510
+                print("   phase cycles per row (mean over sampled images):", {k: int(v / per_row) for k, v in zip(names, acc)})
+                kinds = ["fast single pair", "machine_step + cache", "burst taken", "burst declined"]
+                print("   chain steps per row, cycles a step:", {k: (round(acc[7 + 2 * i] / per_row, 1), int(acc[6 + 2 * i] / max(1, acc[7 + 2 * i]))) for i, k in enumerate(kinds)})
         except Exception as ex:
             print("   (no phase clocks:", ex, ")")
         print(f"q{q}: prefilter stage {min(ts):.1f} ms / {n} images (runs {', '.join(f'{t:.1f}' for t in ts)}); oracle check of {check}: {'OK' if not bad else 'MISMATCH ' + str(bad)}", flush=True)

@@ -55,10 +55,11 @@ static int row_hop(PfM &m, PfC &c, const uint8_t *codes, uint8_t *acts, int row)
 	int hits_prefix[256];                                               /* inclusive prefix sums of the pairs' hits */
 	{ int h = 0; for (int i = 0; i < 255; i++) { h += (codes[i] & 1) + ((codes[i] >> 1) & 1); hits_prefix[i] = h; } hits_prefix[255] = h; }
 	memset(acts, 0, 255);
-	bool give_up = false;                                               /* a burst that was declined is walked pair by pair to its end */
+	bool give_up = false;                                               /* a burst that was declined is walked pair by pair: to its end, or to the next pair machine_step takes */
+	int cut_at = 255;                                                   /* where a burst's pairs end: the row's end, or the pair that ends the burst through t17 */
 	while (pos < 255) {
 		if (m.t[1] == 0) give_up = false;
-		if (!give_up && burst_entry_ok(m, c)) {
+		else if (!give_up && pos != cut_at && burst_entry_ok(m, c)) {
 			PfBurstMasks k = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 			const int base = pos ? hits_prefix[pos - 1] : 0;
 			for (int j = 0; j < 64; j++) {
@@ -69,13 +70,18 @@ static int row_hop(PfM &m, PfC &c, const uint8_t *codes, uint8_t *acts, int row)
 				if (b.iS) k.iS |= bit; if (b.cnt) k.cnt |= bit; if (b.g13) k.g13 |= bit; if (b.e15) k.e15 |= bit; if (b.eT) k.eT |= bit;
 			}
 			auto hits_to = [&](int e) { return hits_prefix[pos + e < 255 ? pos + e : 255] - base; };
-			const int n = burst_quiet(m, c) ? burst_commit_quiet(m, c, (unsigned)k.cap, (unsigned)k.wrap, (unsigned)k.win, (unsigned)k.cyc, c.w8z ? (unsigned)k.i6 : 0u, 255 - pos, hits_to)
-			                                : burst_commit(m, c, k, 255 - pos, hits_to);
+			const int n = burst_quiet(m, c) ? burst_commit_quiet(m, c, (unsigned)k.cap, (unsigned)k.wrap, (unsigned)k.win, (unsigned)k.cyc, c.w8z ? (unsigned)k.i6 : 0u, cut_at - pos, hits_to)
+			                                : burst_commit(m, c, k, cut_at - pos, hits_to);
 			if (n > 0) { pos += n; bursted += n; continue; }
+			if (cut_at == 255) {                                            /* declined for a pair that ends it through t17: taken up to that pair */
+				const int w = burst_t17_pair(m, k.cap, k.wrap, k.win, k.cyc, 255 - pos);
+				if (w >= 1 && w < 255 - pos) { cut_at = pos + w; continue; }
+			}
+			cut_at = 255;
 			give_up = true;
 		}
-		int a = machine_step_fast(m, c, codes[pos]);
-		if (a < 0) { a = machine_step(m, codes[pos], row); machine_cache(m, c); }
+		int a = pos == cut_at ? -1 : machine_step_fast(m, c, codes[pos]);
+		if (a < 0) { a = machine_step(m, codes[pos], row); machine_cache(m, c); give_up = false; cut_at = 255; }
 		acts[pos++] = (uint8_t)a;
 	}
 	return bursted;
