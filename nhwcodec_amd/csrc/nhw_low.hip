@@ -453,6 +453,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 	int16_t *kmo = kmb + (size_t)img * km_stride;                      /* contrast map and flags as passes A..C leave them */
 	uint8_t *soo = sob + (size_t)img * so_stride;
 	auto load_row = [&](int r) { *reinterpret_cast<uint4 *>(&s_src[r % 3][c0]) = *reinterpret_cast<const uint4 *>(src + (size_t)r * W + c0); };
+	/* cells c0 - 1 .. c0 + 8 of a row in LDS (0 outside the row) */
+	auto load10 = [&](const int16_t *row, int *out) {
+		const uint4 q4 = *reinterpret_cast<const uint4 *>(row + c0);
+		const uint32_t w4[4] = { q4.x, q4.y, q4.z, q4.w };
+		for (int e = 0; e < 4; e++) { out[1 + 2 * e] = (int16_t)(w4[e] & 0xFFFF); out[2 + 2 * e] = (int16_t)(w4[e] >> 16); }
+		const int lo = row[lane ? c0 - 1 : 0], hi = row[lane < 63 ? c0 + 8 : W - 1];
+		out[0] = lane ? lo : 0; out[9] = lane < 63 ? hi : 0;
+	};
 	load_row(0); load_row(1);
 	for (int k = lane; k < 2 * (W + 8); k += 64) (&s_km[0][0])[k] = 0;
 	__syncthreads();
@@ -469,19 +477,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		int16_t *y = s_y[r & 1];
 		uint8_t *so = s_so[r & 1];
 		int16_t *s_vb = y;                                           /* pass A's base values: the row's picture copy is made behind it */
-		/* every lane: 8-neighbour sum and magnitude sum of its 8 pixels (:605-618), as the signed base value 15 |sum| + mag of the carry */
+		/* every lane: 8-neighbour sum and magnitude sum of its 8 pixels (:605-618), as the signed base value 15 |sum| + mag of the carry.
+		 * The three rows' cells c0 - 1 .. c0 + 8 come in as one 16-byte read and two cells a row (a read a neighbour was 72 of them) */
 		int smv[8], vbv[8];
-		for (int e = 0; e < 8; e++) {
-			const int c = c0 + e;
-			smv[e] = 0; vbv[e] = 0;
-			if (c < 1 || c > W - 2) continue;
-			const int ctr = mid[c];
-			int sm = 0, mg = 0;
+		{
+			int u10[10], m10[10], d10[10];
+			load10(up, u10); load10(mid, m10); load10(dn, d10);
+			for (int e = 0; e < 8; e++) {
+				const int c = c0 + e;
+				smv[e] = 0; vbv[e] = 0;
+				if (c < 1 || c > W - 2) continue;
+				const int ctr = m10[e + 1];
+				int sm = 0, mg = 0;
 #define NB(v) do { const int d_ = ctr - (v); sm += d_; mg += iabs_(d_); } while (0)
-			NB(mid[c - 1]); NB(mid[c + 1]); NB(up[c]); NB(dn[c]); NB(up[c + 1]); NB(up[c - 1]); NB(dn[c - 1]); NB(dn[c + 1]);
+				NB(m10[e]); NB(m10[e + 2]); NB(u10[e + 1]); NB(d10[e + 1]); NB(u10[e + 2]); NB(u10[e]); NB(d10[e]); NB(d10[e + 2]);
 #undef NB
-			smv[e] = sm;
-			vbv[e] = sm == 0 ? 0 : (sm < 0 ? -(15 * -sm + mg) : 15 * sm + mg);
+				smv[e] = sm;
+				vbv[e] = sm == 0 ? 0 : (sm < 0 ? -(15 * -sm + mg) : 15 * sm + mg);
+			}
 		}
 		{ uint32_t w4[4], z4[4];
 		  for (int e = 0; e < 4; e++) { w4[e] = (uint32_t)(uint16_t)vbv[2 * e] | ((uint32_t)(uint16_t)vbv[2 * e + 1] << 16); z4[e] = (uint32_t)(uint16_t)smv[2 * e] | ((uint32_t)(uint16_t)smv[2 * e + 1] << 16); }
@@ -492,21 +505,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		unsigned cand = 0;
 		if (!(dbg & 1)) {
 			/* entry state of my 8 pixels */
+			/* one step maps all 16 states onto the five (|v| + 0..4) & 15, so five candidates are all there is to follow: 5-bit fields of
+			 * one dword (a field's c + 2 and |v| + 4 stay below 32), every step a handful of whole-dword operations.  The 16 cells before
+			 * mine come in as two 16-byte reads; the lanes the row's own entry state reaches (cells 1 .. c0 - 1 are fewer than 16) start
+			 * from it in all five fields and skip the cells that do not exist */
 			int carry;
-			bool merged = true;
-			if (c0 <= PF_LOOK) {                                   /* the row's own entry state reaches me */
-				carry = row_carry;
-				for (int c = 1; c < c0; c++) { const int vb = s_vb[c]; carry = vb == 0 ? 0 : ((iabs_(vb) + ((carry + 2) >> 2)) & 15); }
-			} else {
-				/* one step maps all 16 states onto the five (|v| + 0..4) & 15, so five candidates are all there is to follow: 5-bit fields of
-				 * one dword (a field's c + 2 and |v| + 4 stay below 32), every step a handful of whole-dword operations */
+			bool merged;
+			{
 				const uint32_t R = 0x108421u;                           /* 1 in each field */
-				const int v0 = s_vb[c0 - PF_LOOK];
-				uint32_t x = v0 == 0 ? 0u : ((((uint32_t)iabs_(v0) & 15u) * R + 0x418820u) & (15u * R));
-				for (int c = c0 - PF_LOOK + 1; c < c0; c++) {
-					const int vb = s_vb[c];
-					const uint32_t nx = (((uint32_t)iabs_(vb) & 15u) * R + (((x + 2u * R) >> 2) & (7u * R))) & (15u * R);
-					x = vb == 0 ? 0u : nx;
+				int lb[16];
+				{ const uint4 a4 = *reinterpret_cast<const uint4 *>(&s_vb[c0 >= 16 ? c0 - 16 : 0]), b4 = *reinterpret_cast<const uint4 *>(&s_vb[c0 >= 8 ? c0 - 8 : 0]);
+				  const uint32_t w8[8] = { a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w };
+				  for (int e = 0; e < 8; e++) { lb[2 * e] = (int16_t)(w8[e] & 0xFFFF); lb[2 * e + 1] = (int16_t)(w8[e] >> 16); } }
+				const bool far = c0 > PF_LOOK;
+				uint32_t x = far ? (lb[0] == 0 ? 0u : ((((uint32_t)iabs_(lb[0]) & 15u) * R + 0x418820u) & (15u * R))) : (uint32_t)row_carry * R;
+				for (int i = 1; i < 16; i++) {
+					const int vb = lb[i];
+					const uint32_t nx = vb == 0 ? 0u : ((((uint32_t)iabs_(vb) & 15u) * R + (((x + 2u * R) >> 2) & (7u * R))) & (15u * R));
+					x = (far || c0 - 16 + i >= 1) ? nx : x;
 				}
 				merged = x == (x & 31u) * R;
 				carry = (int)(x & 15u);
@@ -569,26 +585,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		/* all lanes: the row's picture copy (:566) with the q <= 14 smoothing (:780-807, reads the source copy only), the pair codes of the
 		 * row (lane l has pairs 4 l .. 4 l + 3 = cells 8 l + 1 .. 8 l + 8) and the prefix sums of their hits */
 		{
+			int k9[9];                                                 /* map cells c0 .. c0 + 8 */
+			{ const uint4 kq = *reinterpret_cast<const uint4 *>(&km[c0]);
+			  const uint32_t w4[4] = { kq.x, kq.y, kq.z, kq.w };
+			  for (int e = 0; e < 4; e++) { k9[2 * e] = (int16_t)(w4[e] & 0xFFFF); k9[2 * e + 1] = (int16_t)(w4[e] >> 16); }
+			  k9[8] = km[c0 + 8]; }
 			uint32_t yw[4];
-			for (int e2 = 0; e2 < 4; e2++) {
-				int v2[2];
-				for (int h = 0; h < 2; h++) {
-					const int c = c0 + 2 * e2 + h;
-					int v = mid[c];
-					if (pp.smooth && c >= 1 && c <= W - 2) {
-						const int k = km[c];
-						if (iabs_(k) > 4 && iabs_(k) < pp.smooth_hi &&
-						    iabs_(up[c] - mid[c - 1]) < 4 && iabs_(mid[c - 1] - dn[c]) < 4 && iabs_(dn[c] - mid[c + 1]) < 4 && iabs_(mid[c + 1] - up[c]) < 4)
-							v = ((mid[c] << 2) + mid[c - 1] + mid[c + 1] + up[c] + dn[c] + 4) >> 3;
+			if (pp.smooth) {
+				int u10[10], m10[10], d10[10];
+				load10(up, u10); load10(mid, m10); load10(dn, d10);
+				for (int e2 = 0; e2 < 4; e2++) {
+					int v2[2];
+					for (int h = 0; h < 2; h++) {
+						const int e = 2 * e2 + h, c = c0 + e;
+						const int ctr = m10[e + 1], lf = m10[e], rt = m10[e + 2], ab = u10[e + 1], bl = d10[e + 1];
+						int v = ctr;
+						if (c >= 1 && c <= W - 2) {
+							const int k = k9[e];
+							if (iabs_(k) > 4 && iabs_(k) < pp.smooth_hi && iabs_(ab - lf) < 4 && iabs_(lf - bl) < 4 && iabs_(bl - rt) < 4 && iabs_(rt - ab) < 4)
+								v = ((ctr << 2) + lf + rt + ab + bl + 4) >> 3;
+						}
+						v2[h] = v;
 					}
-					v2[h] = v;
+					yw[e2] = (uint32_t)(uint16_t)v2[0] | ((uint32_t)(uint16_t)v2[1] << 16);
 				}
-				yw[e2] = (uint32_t)(uint16_t)v2[0] | ((uint32_t)(uint16_t)v2[1] << 16);
+			} else {
+				const uint4 mq = *reinterpret_cast<const uint4 *>(&mid[c0]);
+				yw[0] = mq.x; yw[1] = mq.y; yw[2] = mq.z; yw[3] = mq.w;
 			}
 			*reinterpret_cast<uint4 *>(&y[c0]) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
 			int hp[4], h = 0;
 			for (int j = 0; j < 4; j++) {
-				const int k0 = km[c0 + 2 * j + 1], k1 = km[c0 + 2 * j + 2];
+				const int k0 = k9[2 * j + 1], k1 = k9[2 * j + 2];
 				const int f0 = iabs_(k0) > pp.sharp, f1 = iabs_(k1) > pp.sharp;
 				const uint32_t code = (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (iabs_(k1) > pp.s2 ? 4u : 0u) | (iabs_(k0) > pp.sharp + 96 ? 8u : 0u);
 				cw |= code << (8 * j);
