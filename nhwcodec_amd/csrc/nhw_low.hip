@@ -461,6 +461,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		const int lo = row[lane ? c0 - 1 : 0], hi = row[lane < 63 ? c0 + 8 : W - 1];
 		out[0] = lane ? lo : 0; out[9] = lane < 63 ? hi : 0;
 	};
+	auto load10u = [&](const int16_t *row, uint32_t *out) {           /* the same as 16-bit unsigned values, sign bit flipped */
+		const uint4 q4 = *reinterpret_cast<const uint4 *>(row + c0);
+		const uint32_t w4[4] = { q4.x ^ 0x80008000u, q4.y ^ 0x80008000u, q4.z ^ 0x80008000u, q4.w ^ 0x80008000u };
+		for (int e = 0; e < 4; e++) { out[1 + 2 * e] = w4[e] & 0xFFFFu; out[2 + 2 * e] = w4[e] >> 16; }
+		out[0] = (uint32_t)(uint16_t)row[lane ? c0 - 1 : 0] ^ 0x8000u; out[9] = (uint32_t)(uint16_t)row[lane < 63 ? c0 + 8 : W - 1] ^ 0x8000u;
+	};
 	load_row(0); load_row(1);
 	for (int k = lane; k < 2 * (W + 8); k += 64) (&s_km[0][0])[k] = 0;
 	__syncthreads();
@@ -481,19 +487,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		 * The three rows' cells c0 - 1 .. c0 + 8 come in as one 16-byte read and two cells a row (a read a neighbour was 72 of them) */
 		int smv[8], vbv[8];
 		{
-			int u10[10], m10[10], d10[10];
-			load10(up, u10); load10(mid, m10); load10(dn, d10);
+			/* the cells as unsigned values with the sign bit flipped (differences are what counts): the sum of the eight differences is
+			 * 9 centre - the 3 x 3 block's sum, whose column sums the neighbouring pixels share; a magnitude is one v_sad_u16 */
+			uint32_t u10[10], m10[10], d10[10], t10[10];
+			load10u(up, u10); load10u(mid, m10); load10u(dn, d10);
+			for (int i = 0; i < 10; i++) t10[i] = u10[i] + m10[i] + d10[i];
 			for (int e = 0; e < 8; e++) {
 				const int c = c0 + e;
 				smv[e] = 0; vbv[e] = 0;
 				if (c < 1 || c > W - 2) continue;
-				const int ctr = m10[e + 1];
-				int sm = 0, mg = 0;
-#define NB(v) do { const int d_ = ctr - (v); sm += d_; mg += iabs_(d_); } while (0)
-				NB(m10[e]); NB(m10[e + 2]); NB(u10[e + 1]); NB(d10[e + 1]); NB(u10[e + 2]); NB(u10[e]); NB(d10[e]); NB(d10[e + 2]);
-#undef NB
+				const uint32_t ctr = m10[e + 1];
+				const int sm = 9 * (int)ctr - (int)(t10[e] + t10[e + 1] + t10[e + 2]);
+				uint32_t mg = __builtin_amdgcn_sad_u16(ctr, m10[e], 0u);
+				mg = __builtin_amdgcn_sad_u16(ctr, m10[e + 2], mg); mg = __builtin_amdgcn_sad_u16(ctr, u10[e], mg); mg = __builtin_amdgcn_sad_u16(ctr, u10[e + 1], mg);
+				mg = __builtin_amdgcn_sad_u16(ctr, u10[e + 2], mg); mg = __builtin_amdgcn_sad_u16(ctr, d10[e], mg); mg = __builtin_amdgcn_sad_u16(ctr, d10[e + 1], mg);
+				mg = __builtin_amdgcn_sad_u16(ctr, d10[e + 2], mg);
 				smv[e] = sm;
-				vbv[e] = sm == 0 ? 0 : (sm < 0 ? -(15 * -sm + mg) : 15 * sm + mg);
+				vbv[e] = sm == 0 ? 0 : (sm < 0 ? -(15 * -sm + (int)mg) : 15 * sm + (int)mg);
 			}
 		}
 		{ uint32_t w4[4], z4[4];
