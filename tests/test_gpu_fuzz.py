@@ -45,7 +45,7 @@ def test_mixed_class_images_encode_and_decode_like_the_oracle(q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [5, 11, 14])
+@pytest.mark.parametrize("q", [5, 8, 11, 14])
 def test_noise_and_hard_edges_at_the_rationed_qualities(q):
     """White noise and hard-edge rectangles at quality 1..16: the images on which the quantisers' rare rules fire (values beyond +-127, the
     `quant4` pushes out of and into such values, rationed low bits) -- a slice of tests/gpu_fuzz_noise.py, whose full run found a pusher

@@ -94,7 +94,7 @@ def test_colour_exhaustive_all_2_24_triples(enc, oracle, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [1, 6, 9, 10, 14, 16])
+@pytest.mark.parametrize("q", [1, 6, 7, 8, 9, 10, 14, 16])
 def test_prefilter_matches_oracle(enc, oracle, q):
     """The pre-filter is a stage of its own for quality 1..16 (k_low_prefilter, the kernel the encoder runs); for 17..21 it lives inside
     the fused front kernel (test_fused_front_matches_oracle)."""
@@ -371,10 +371,10 @@ def test_robustness_classes_more_seeds(enc, oracle, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [1, 10, 20, 23])
+@pytest.mark.parametrize("q", [1, 8, 10, 20, 23])
 def test_full_batch_4096_every_image_bit_exact(q):
     """BASELINE configs 2 and 3 (-q20; -q1 / -q10 / -q23) at their full size, every one of the 4096 outputs against the oracle (oracle
-    side spread over the host cores)"""
+    side spread over the host cores); -q8 for the band of qualities whose bursts end through t17 (the cut bursts of the chain)"""
     from tests.gpu_enc_fullcheck import full_encode_check
     bad = full_encode_check(4096, q, 900000 + q)
     assert not bad, f"q{q}: images {bad[:16]} differ from the oracle"
