@@ -669,12 +669,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 					const PfBurstLane b = burst_lane(lane, mach.t[1], mach.t[4], mach.t[44], hj, mach.t[10], mach.t[11], mcache.exT);
 					auto hits_to = [&](int e) { return __builtin_amdgcn_readlane(hj, e); };
 					int n;
+					/* the five masks both tiers ask for, taken where the lanes' tests are made (behind a branch each costs a select and a compare more) */
+					const unsigned long long m_cap = __ballot(b.cap), m_wrap = __ballot(b.wrap), m_win = __ballot(b.win), m_cyc = __ballot(b.cyc), m_i6 = __ballot(b.i6);
 					if (burst_quiet(mach, mcache))
-						n = burst_commit_quiet(mach, mcache, (unsigned)__ballot(b.cap), (unsigned)__ballot(b.wrap), (unsigned)__ballot(b.win), (unsigned)__ballot(b.cyc),
-						                       mcache.w8z ? (unsigned)__ballot(b.i6) : 0u, cut_at - pos, hits_to);
+						n = burst_commit_quiet(mach, mcache, (unsigned)m_cap, (unsigned)m_wrap, (unsigned)m_win, (unsigned)m_cyc, mcache.w8z ? (unsigned)m_i6 : 0u, cut_at - pos, hits_to);
 					else {
 						PfBurstMasks k;
-						k.cap = __ballot(b.cap); k.wrap = __ballot(b.wrap); k.win = __ballot(b.win); k.cyc = __ballot(b.cyc); k.i6 = __ballot(b.i6);
+						k.cap = m_cap; k.wrap = m_wrap; k.win = m_win; k.cyc = m_cyc; k.i6 = m_i6;
 						k.iS = __ballot(b.iS); k.cnt = __ballot(b.cnt); k.g13 = __ballot(b.g13); k.e15 = __ballot(b.e15); k.eT = __ballot(b.eT);
 						n = burst_commit(mach, mcache, k, cut_at - pos, hits_to);
 					}
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 					 * (the next turn of the loop, with the masks made again: this path must not cost the bursts that are taken anything); the
 					 * pair itself goes through machine_step, and what follows it is a burst again */
 					if (cut_at == 255) {
-						const int w = burst_t17_pair(mach, __ballot(b.cap), __ballot(b.wrap), __ballot(b.win), __ballot(b.cyc), 255 - pos);
+						const int w = burst_t17_pair(mach, m_cap, m_wrap, m_win, m_cyc, 255 - pos);
 						if (w >= 1 && w < 255 - pos) { cut_at = pos + w; SCLK_END(12); continue; }
 					}
 					cut_at = 255;
