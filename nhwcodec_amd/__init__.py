@@ -30,6 +30,9 @@ class NhwError(RuntimeError):
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     if not os.path.exists(path):
         raise NhwError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no CPU fallback")
+    # torch brings its own HIP runtime; a process must have one.  Loaded after torch, libnhwhip.so binds to the runtime that is there; loaded
+    # before it, the system's runtime comes in first and torch (or this library) then finds no device (`g.build(); g.smoke()` in one process).
+    import torch  # noqa: F401
     L = ctypes.CDLL(path)
     L.nhw_last_error.restype = ctypes.c_char_p
     L.nhw_enc_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)]

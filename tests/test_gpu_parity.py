@@ -601,3 +601,14 @@ def test_encoder_stream_modes_give_the_same_files(oracle, env):
         for i in (0, 255, 511):
             assert a1[i, : sz[i]].tobytes() == oracle.encode(oracle.synth(61000 + i), q), f"q{q} image {i}"
     e.close(); base.close()
+
+
+@pytest.mark.gpu
+def test_build_then_smoke_in_one_process():
+    """The driver's hooks back to back in one interpreter: build() loads the C ABI library, smoke() then brings torch in.  A process must
+    have one HIP runtime -- load_library() imports torch first so that it is torch's (loaded the other way round, neither finds a device)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "smoke OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
