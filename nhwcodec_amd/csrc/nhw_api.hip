@@ -198,7 +198,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		HIPCHK(hipEventRecord(e->ev[5], s)); HIPCHK(hipEventRecord(e->ev[6], s));   /* no kernels of their own for colour and pre-filter: both times 0 */
 		STAGE_DONE();
 		if (q < 22) STAGE_DONE();
-		nhw_launch_front_fused((const uint8_t *)d_bgr, q, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], nullptr, 0, q < 22,
+		nhw_launch_front_fused((const uint8_t *)d_bgr, q, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], yin, yin_stride /* developer builds only: a plane for a dump */, q < 22,
 		                       (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
 		                       plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2,
 		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s, e->front_fallback);

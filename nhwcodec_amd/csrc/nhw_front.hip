@@ -111,6 +111,7 @@ __device__ __forceinline__ int convert_y(const uint8_t *px, float yq)
 	return (int)(ly * 0.94 + 0.5f);
 }
 
+template <int FAMILY> __device__ __forceinline__ void convert16(const uint32_t wv[12], float yq, uint32_t yw[8], uint32_t uw[4], uint32_t vw[4], bool uv);   /* nhw_front_image.h */
 /* One workgroup per 8 luma rows = 4 chroma rows: the 9 BGR rows 8b-1 .. 8b+7 are staged in LDS with 16-byte loads
  * (the row above is the only one read twice), every pixel is converted once (Y straight to HBM, U and V as bytes to
  * LDS), then the [1 2 1] x [1 2 1] chroma filter runs on the LDS bytes. */
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k_color(const uint8_t *__restrict__ bgr, 
                                                uint8_t *__restrict__ ub, uint8_t *__restrict__ vb, size_t c_stride, float yq)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t rows[9][W * 3];
-	__shared__ __attribute__((aligned(4))) uint8_t uu[9][W], vv[9][W];
+	__shared__ __attribute__((aligned(16))) uint8_t uu[9][W], vv[9][W];
 	const int b = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
 	const uint8_t *src = bgr + (size_t)img * (W * W * 3);
 	for (int k = t; k < 9 * (W * 3 / 16); k += 256) {
@@ -128,6 +129,23 @@ __global__ __launch_bounds__(256) void k_color(const uint8_t *__restrict__ bgr, 
 	}
 	__syncthreads();
 	int16_t *yplane = (int16_t *)((uint8_t *)yb + (size_t)img * y_stride);
+	if (FAMILY != 3) {                                             /* quality 17..23: the arithmetic of the fused front kernel (nhw_front_image.h), 16 pixels per item */
+		for (int k = t; k < 9 * (W / 16); k += 256) {
+			const int which = k / (W / 16), g = k % (W / 16), row = 8 * b - 1 + which;
+			if (row < 0) continue;
+			const uint4 *rp = reinterpret_cast<const uint4 *>(&rows[which][48 * g]);
+			const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+			const uint32_t wv[12] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w };
+			uint32_t yw[8], uw[4], vw[4];
+			convert16<FAMILY == 3 ? 0 : FAMILY>(wv, yq, yw, uw, vw, true);
+			*reinterpret_cast<uint4 *>(&uu[which][16 * g]) = make_uint4(uw[0], uw[1], uw[2], uw[3]);
+			*reinterpret_cast<uint4 *>(&vv[which][16 * g]) = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+			if (which) {
+				uint4 *yo = reinterpret_cast<uint4 *>(yplane + (size_t)row * W + 16 * g);
+				yo[0] = make_uint4(yw[0], yw[1], yw[2], yw[3]); yo[1] = make_uint4(yw[4], yw[5], yw[6], yw[7]);
+			}
+		}
+	} else
 	for (int k = t; k < 9 * (W / 2); k += 256) {                   /* two pixels per item */
 		const int which = k / (W / 2), px = 2 * (k % (W / 2)), row = 8 * b - 1 + which;
 		if (row < 0) continue;
@@ -710,6 +728,10 @@ __global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ s
 	STAMP(7);
 }
 
+} // namespace nhw
+#include "nhw_front_image.h"
+namespace nhw {
+
 /* SURVEY.md section 8d generator, one lane per image (setup only, never timed) */
 __global__ void k_synth(uint8_t *__restrict__ bgr, int n, uint32_t seed_base)
 {
@@ -938,6 +960,8 @@ int nhw_front_set_attrs(const char **where)
 	const size_t band = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
 	SETATTR((k_front_band<0, 0, 0>), band); SETATTR((k_front_band<0, 1, 0>), band); SETATTR((k_front_band<1, 1, 0>), band);
 	SETATTR((k_front_band<1, 1, 1>), band); SETATTR((k_front_band<1, 1, 2>), band);
+	SETATTR((k_front_image<0, 0, 0>), FI_LDS_BYTES); SETATTR((k_front_image<0, 1, 0>), FI_LDS_BYTES); SETATTR((k_front_image<1, 1, 0>), FI_LDS_BYTES);
+	SETATTR((k_front_image<1, 1, 1>), FI_LDS_BYTES); SETATTR((k_front_image<1, 1, 2>), FI_LDS_BYTES);
 	SETATTR(k_dwt_ana<256>, 256 * 258 * sizeof(int16_t)); SETATTR(k_dwt_syn<256>, 256 * 258 * sizeof(int16_t));
 	SETATTR(k_dwt_ana<128>, 128 * 130 * sizeof(int16_t)); SETATTR(k_dwt_syn<128>, 128 * 130 * sizeof(int16_t));
 #undef SETATTR
@@ -980,6 +1004,24 @@ void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv,
                             uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
                             int16_t *keep, size_t keep_stride, int n, hipStream_t s, int force_fallback)
 {
+	static const int use_old = getenv("NHW_FRONT_OLD") ? atoi(getenv("NHW_FRONT_OLD")) : 0;   /* TEMP: A/B against the band kernel */
+	if (!use_old) {
+		int fam = 0;
+		const float yq = bgr ? color_yq(q, &fam) : 0.f;
+		int fl = force_fallback & 1;
+#ifdef NHW_DEV
+		{ const char *e = getenv("NHW_BAND_STOP"); if (e) fl |= atoi(e) << 8; }
+		if (getenv("NHW_FRONT_DUMP") && y && bgr && with_prefilter) { fl |= 2 | (atoi(getenv("NHW_FRONT_DUMP")) << 4); keep = const_cast<int16_t *>(y); keep_stride = y_stride / 2; }
+#endif
+#define FI_ARGS(srcp, sstride) srcp, sstride, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, fl
+		if (!bgr) k_front_image<0, 0, 0><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)y, y_stride));
+		else if (!with_prefilter) k_front_image<0, 1, 0><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
+		else if (fam == 0) k_front_image<1, 1, 0><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
+		else if (fam == 1) k_front_image<1, 1, 1><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
+		else k_front_image<1, 1, 2><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
+#undef FI_ARGS
+		return;
+	}
 	const size_t lds = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
 	const dim3 grid((H / FB_KB) * n);
 	if (!bgr) {

@@ -1,0 +1,587 @@
+/*
+ * nhw_front_image.h -- THE fused front kernel of the encode path (included by nhw_front.hip):
+ * colour conversion + 4:2:0 + luma pre-filter (quality 17..21) + both directions of the level-1 analysis,
+ * one workgroup per image, walking the image top to bottom with a rolling window of rows in LDS.
+ *
+ * Algorithm sources (behaviour only):
+ *   colour        rcanut/nhwcodec encoder/colorspace.c:55-260
+ *   pre-filter    encoder/image_processing.c:558-837, 1927-1990 (quality 17..21 branch)
+ *   filterbank    encoder/wavelet_filterbank.c:52-184, encoder/filters.c:55-114, 203-287, 346-386
+ *
+ * Why a walk: a band of 16 output rows needs 37 rows of the horizontal pass, 39 rows of luma; independent bands converted and
+ * contrasted 22 % of their rows twice, and the pre-filter's carry needed two pre-pass kernels to hand every row its entry state.
+ * Here band b keeps what band b+1 shares with it (2 luma rows, 5 horizontal-pass rows, 1 row of filtered chroma, the carry at the
+ * end of its last row): no row is converted, contrasted or filtered twice, the carry simply runs on, and the next band's BGR rows
+ * are in flight (in registers) while this band's vertical pass runs.
+ *
+ * Everything is integer / byte streaming work: no MFMA.  The arithmetic is done two pixels to a dword (packed 16-bit) wherever the
+ * values fit, bytes four to a dword in the chroma filters (v_lerp_u8: the [1 2 1]/4 filter is two byte-wise averages), and the colour
+ * conversion in single precision on v_cvt_f32_ubyteN / v_fma_f32 / v_cvt_pk_u8_f32 -- exact by construction, see convert16().
+ */
+#ifndef NHW_FRONT_IMAGE_H
+#define NHW_FRONT_IMAGE_H
+
+namespace nhw {
+
+#define FI_NT    512                 /* threads of a workgroup: two workgroups share a CU (78 KB of LDS each) */
+#define FI_RS    514                 /* LDS row stride in shorts (257 dwords: a lane per row walks over consecutive banks) */
+#define FI_RD    (FI_RS / 2)         /* the same in dwords */
+#define FI_BR    32                  /* new image rows per band = 16 output rows of every sub-band */
+#define FI_YROWS 35                  /* luma rows 32b .. 32b+33 (index = row - 32b) + one spare row (index 34: row 32b+32 as it was before the pair rules) */
+#define FI_KROWS 37                  /* horizontal-pass rows 32b-4 .. 32b+32 (index = row - 32b + 4); rows 5.. hold the contrast / kernel map before that */
+#define FI_SEG   32                  /* pixels per carry segment */
+#define FI_NSEG  16
+#define FI_LOOK  12                  /* pixels of look-back for a segment's entry state */
+/* byte offsets into the dynamic LDS block */
+#define FI_YB_OFF   16
+#define FI_KB_OFF   (FI_YB_OFF + FI_YROWS * FI_RS * 2)
+#define FI_STG_OFF  (FI_KB_OFF + 5 * FI_RS * 2)             /* chroma staging: 34 rows x (256 U + 256 V) bytes, over the rows the contrast map takes later */
+#define FI_TAB_OFF  (FI_KB_OFF + FI_KROWS * FI_RS * 2)
+#define FI_PT_OFF   FI_TAB_OFF                              /* 225 x 16 B: pair-rule entries */
+#define FI_CA_OFF   (FI_PT_OFF + 3600)                      /* 405 B (+3): class of a kernel value, clamped to -202 .. 202 */
+#define FI_CB_OFF   (FI_CA_OFF + 408)                       /* the same x 16 */
+#define FI_EN_OFF   (FI_CB_OFF + 408)                       /* 512 B: entry state of every carry segment of the band */
+#define FI_CR_OFF   (FI_EN_OFF + 512)                       /* 512 B: the last row of filtered chroma, kept for the next band */
+#define FI_MISC_OFF (FI_CR_OFF + 512)
+#define FI_LDS_BYTES (FI_MISC_OFF + 64)
+static_assert(FI_STG_OFF % 16 == 0 && FI_CR_OFF % 16 == 0 && FI_PT_OFF % 16 == 0, "16-byte pieces");
+static_assert(FI_STG_OFF + 34 * 512 <= FI_TAB_OFF, "the chroma staging fits into the rows of the contrast map");
+static_assert(FI_LDS_BYTES <= 81920, "two workgroups to a CU");
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s(uint32_t x) { return __builtin_bit_cast(s16x2, x); }
+__device__ __forceinline__ u16x2 as_us(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ uint32_t as_w(s16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t as_w(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+/* (lo half of a) | (lo half of b) << 16, and the same of the high halves */
+__device__ __forceinline__ uint32_t pack_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+/* (hi half of a) | (lo half of b) << 16 */
+__device__ __forceinline__ uint32_t pack_hl(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }
+/* byte-wise (a + b) >> 1 and (a + b + 1) >> 1 on four bytes */
+__device__ __forceinline__ uint32_t avg_dn(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0u); }
+__device__ __forceinline__ uint32_t avg_up(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
+/* byte-wise (a + 2 b + c + 2) >> 2 = avg_up(avg_dn(a, c), b): with a + c even the inner average is exact, with a + c odd
+ * a + 2b + c + 2 is odd and losing the half changes nothing under the floor (checked over all byte triples on the device) */
+__device__ __forceinline__ uint32_t tri121(uint32_t a, uint32_t b, uint32_t c) { return avg_up(avg_dn(a, c), b); }
+
+/* ------------------------------------------------------------------------------------------------
+ * 16 pixels (48 BGR bytes in 12 dwords) -> luma, two pixels to a dword, and (uv) the U and V bytes, four pixels to a dword.
+ * colorspace.c:55-214.  FAMILY 0: quality >= 20, 1: 18 / 19 (luma scaled by yq), 2: 17 (everything scaled by 0.94).
+ *
+ * Single precision is exact here because every sum of products is an integer below 2^24:
+ *   luma, q >= 20: the reference's (int)(0.299 b0 + 0.587 b1 + 0.114 b2 + 0.5f) is floor(s / 1000), s = 299 b0 + 587 b1 + 114 b2 + 500,
+ *     except where the division is exact (one triple in a thousand: there the double rounding of the three products decides and the
+ *     lane takes the reference's arithmetic).  floor(s / 1000) comes out of ONE fma: (s + 0.11) * 0.001f + (2^23 - 0.5) is rounded to
+ *     the integer 2^23 + floor(s / 1000) (the fraction of (s + 0.11) / 1000 lies in [1.1e-4, 0.9992], the constant's error is 1.2e-5),
+ *     and the low 16 bits of that float ARE the result; s - 1000 y < 0.5 finds the exact divisions.
+ *   chroma, q >= 18: the reference's (int)(cb + 128.5f) (cb >= 0) / (int)(cb + 128.4f) (cb < 0), cb = su / 10000 through a float, is
+ *     floor((su + 1285000 or 1284000) / 10000) (checked on all 2^24 triples: nhw_front.hip, convert_uv); v_cvt_pk_u8_f32 rounds to
+ *     nearest even and saturates to 0 .. 255 (probed on the device), so the floor is rne(su * 1e-4f + bias - 0.5 + 4.6e-5): the true
+ *     fractions are multiples of 1e-4, the float error is below 1.2e-5.  One instruction converts, clips and packs the byte.
+ * The exhaustive test (all 2^24 triples, tests/test_gpu_parity.py) runs this function through k_color.
+ * ------------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ float ubf(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   /* v_cvt_f32_ubyte<k> */
+template <int FAMILY>
+__device__ __forceinline__ void convert16(const uint32_t wv[12], float yq, uint32_t yw[8], uint32_t uw[4], uint32_t vw[4], bool uv)
+{
+	float f[48];
+#pragma unroll
+	for (int b = 0; b < 48; b++) f[b] = ubf(wv[b >> 2], b & 3);
+	uint32_t ym[16];
+#pragma unroll
+	for (int e = 0; e < 16; e++) {
+		const float b0 = f[3 * e], b1 = f[3 * e + 1], b2 = f[3 * e + 2];
+		if (FAMILY == 0) {
+			const float s = __builtin_fmaf(b2, 114.f, __builtin_fmaf(b1, 587.f, __builtin_fmaf(b0, 299.f, 500.109375f)));
+			const float m = __builtin_fmaf(s, 0.001f, 8388607.5f);
+			const float r = __builtin_fmaf(m - 8388608.f, -1000.f, s);
+			uint32_t bits = __float_as_uint(m);
+			if (r < 0.5f) {                                            /* s is a multiple of 1000: the reference's double arithmetic decides */
+				const double ly = 0.299 * (double)b0 + 0.587 * (double)b1 + 0.114 * (double)b2;
+				bits = (uint32_t)(int)(ly + 0.5f);
+			}
+			ym[e] = bits;
+		} else {
+			/* q 17..19: (int)(ly x scale + 0.5) in double.  The same product in single precision is off by less than 1e-4, so its floor is the
+			 * answer unless it lands within 2.5e-4 of an integer (5e-4 of the triples): those lanes take the double path. */
+			const float s = __builtin_fmaf(b2, 114.f, __builtin_fmaf(b1, 587.f, b0 * 299.f));
+			const float c = (FAMILY == 1 ? yq : 0.94f) * 0.001f;
+			const float v = s * c + 0.5f, fl = floorf(v), fr = v - fl;
+			int y = (int)fl;
+			if (!(fr > 2.5e-4f && fr < 1.f - 2.5e-4f)) {
+				const double ly = 0.299 * (double)b0 + 0.587 * (double)b1 + 0.114 * (double)b2;
+				y = FAMILY == 1 ? (int)(ly * yq + 0.5f) : (int)(ly * 0.94 + 0.5f);
+			}
+			ym[e] = (uint32_t)y;
+		}
+	}
+#pragma unroll
+	for (int e = 0; e < 8; e++) yw[e] = pack_lo(ym[2 * e], ym[2 * e + 1]);
+	if (!uv) return;
+#pragma unroll
+	for (int e = 0; e < 4; e++) { uw[e] = 0; vw[e] = 0; }
+#pragma unroll
+	for (int e = 0; e < 16; e++) {
+		const float b0 = f[3 * e], b1 = f[3 * e + 1], b2 = f[3 * e + 2];
+		if (FAMILY != 2) {
+			const float su = __builtin_fmaf(b2, 5000.f, __builtin_fmaf(b1, -3313.f, b0 * -1687.f));
+			const float sv = __builtin_fmaf(b2, -813.f, __builtin_fmaf(b1, -4187.f, b0 * 5000.f));
+			const float tu = __builtin_fmaf(su, 1e-4f, su >= 0.f ? 128.0000457763671875f : 127.90005f);
+			const float tv = __builtin_fmaf(sv, 1e-4f, sv >= 0.f ? 128.0000457763671875f : 127.90005f);
+			uw[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(tu, e & 3, uw[e >> 2]);
+			vw[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(tv, e & 3, vw[e >> 2]);
+		} else {
+			const uint8_t px[3] = { (uint8_t)(wv[(3 * e) >> 2] >> (8 * ((3 * e) & 3))), (uint8_t)(wv[(3 * e + 1) >> 2] >> (8 * ((3 * e + 1) & 3))), (uint8_t)(wv[(3 * e + 2) >> 2] >> (8 * ((3 * e + 2) & 3))) };
+			int U, V;
+			convert_uv<2>(px, yq, U, V);
+			uw[e >> 2] |= (uint32_t)U << (8 * (e & 3)); vw[e >> 2] |= (uint32_t)V << (8 * (e & 3));
+		}
+	}
+}
+
+/* horizontal [1 2 1]/4 at the even pixels of 16 (colorspace.c:220-234): c[0..3] = the bytes of pixels 0..15, left = a dword whose top byte is
+ * pixel -1 (for the first group of a row: pixel 1, which turns the filter into the reference's (c0 + c1 + 1) >> 1) -> eight bytes */
+__device__ __forceinline__ uint2 chroma_h8(const uint32_t c[4], uint32_t left)
+{
+	const uint32_t e01 = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u), o01 = __builtin_amdgcn_perm(c[1], c[0], 0x07050301u);
+	const uint32_t e23 = __builtin_amdgcn_perm(c[3], c[2], 0x06040200u), o23 = __builtin_amdgcn_perm(c[3], c[2], 0x07050301u);
+	const uint32_t p01 = __builtin_amdgcn_alignbyte(o01, left, 3), p23 = __builtin_amdgcn_alignbyte(o23, o01, 3);   /* the odd pixels one to the left */
+	return make_uint2(tri121(p01, e01, o01), tri121(p23, e23, o23));
+}
+
+/* packed 16-bit helpers of the two filter passes (filters.c:88-287: the values stay inside 16 bits, so two columns share a dword) */
+__device__ __forceinline__ s16x2 pk_rnd_half_away(s16x2 v, int shift) { return (v + (s16x2)(short)(1 << (shift - 1)) + (v >> 15)) >> shift; }
+__device__ __forceinline__ s16x2 pk_diffuse(s16x2 r)
+{
+	const s16x2 s = r >> 15, a = (r ^ s) - s;
+	const s16x2 t = (s16x2)(a << 10) >> 10;                           /* |r| mod 64 read as a signed 6-bit number */
+	const s16x2 d = (t + ((t >> 15) & (s16x2)(short)3)) >> 2;
+	return (d ^ s) - s;
+}
+
+#ifdef NHW_DEV   /* developer builds: 32 rows of a plane in LDS (from row index 1 / 5 on) into a plane in memory, for tests/gpu_front_debug.py */
+#define FI_DUMP(kind, base) do { if ((flags & 2) && ((flags >> 4) & 15) == (kind) && keepb) { \
+	for (int k_ = t; k_ < 32 * 256; k_ += FI_NT) { const int rr_ = 1 + (k_ >> 8), o_ = k_ & 255; \
+		if (r0 + rr_ < W - ((kind) == 2 || (kind) == 3)) reinterpret_cast<uint32_t *>(keepb + (size_t)img * keep_stride + (size_t)(r0 + rr_) * W)[o_] = reinterpret_cast<const uint32_t *>((base) + (rr_ - 1) * FI_RS)[o_]; } \
+	__syncthreads(); } } while (0)
+#else
+#define FI_DUMP(kind, base) do { } while (0)
+#endif
+#ifdef NHW_DEV   /* developer builds: a switch that ends every band after phase i (tests/gpu_band_ablate.py: the cost of the phases under real contention) */
+#define FI_STAMP(i) do { if ((flags >> 8) == (i)) { __syncthreads(); if (b + 1 < W / FI_BR) issue(b + 1); continue; } } while (0)
+#else
+#define FI_STAMP(i) do { } while (0)
+#endif
+
+/* PRE: with the pre-filter (quality 17..21).  SRC 1: from the BGR bytes (quality 17..23).  SRC 0: from a luma plane (quality 1..16
+ * behind their own pre-filter, nhw_low.hip; the analysis stage entry point): no colour, no chroma, PRE = 0.
+ * flags bit 0: test switch, every carry segment takes its exact replay instead of the look-back. */
+template <int PRE, int SRC, int FAMILY>
+__global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_front_image(const void *__restrict__ srcb, size_t src_stride, float yq, uint8_t *__restrict__ pub, uint8_t *__restrict__ pvb, size_t c_stride,
+                                                     uint8_t *__restrict__ stb, size_t s_stride,
+                                                     int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
+                                                     int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride, int flags)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	int16_t *const ybuf = reinterpret_cast<int16_t *>(lds + FI_YB_OFF);
+	int16_t *const kbuf = reinterpret_cast<int16_t *>(lds + FI_KB_OFF);
+	uint8_t *const stg = lds + FI_STG_OFF;                          /* row j + 1 of it: filtered chroma of image row 32b + 1 + j, j = -1 .. 32 */
+	uint32_t *const ptab = reinterpret_cast<uint32_t *>(lds + FI_PT_OFF);
+	uint8_t *const tca = lds + FI_CA_OFF, *const tcb = lds + FI_CB_OFF;
+	uint8_t *const entry = lds + FI_EN_OFF;
+	uint8_t *const crow = lds + FI_CR_OFF;
+	uint8_t *const misc = lds + FI_MISC_OFF;                        /* [0]: carry behind the band's last row, [2 + (b & 1)]: hand-over flag of its last pixel pair */
+	const int t = threadIdx.x, img = blockIdx.x;
+
+	const uint8_t *const src = (const uint8_t *)srcb + (size_t)img * (SRC ? (size_t)(W * W * 3) : src_stride);
+	int16_t *const proc = procb + (size_t)img * plane_stride, *const jpeg = jpegb + (size_t)img * plane_stride;
+	int16_t *const ll1 = ll1b + (size_t)img * ll1_stride;
+
+	/* the next band's rows, on their way while this band is worked on: image rows 32b+2 .. 32b+33 */
+	constexpr int NPF = SRC ? 6 : 4;
+	uint4 pf[NPF];
+	auto issue = [&](int b) {
+		if (SRC) {
+#pragma unroll
+			for (int it = 0; it < 2; it++) {                         /* 16 pixels = 48 bytes an item, two items a thread */
+				const int row = FI_BR * b + 2 + (t >> 5) + 16 * it, g = t & 31;
+				if (row >= 0 && row < W) {
+					const uint4 *rp = reinterpret_cast<const uint4 *>(src + (size_t)row * (W * 3) + 48 * g);
+					pf[3 * it] = rp[0]; pf[3 * it + 1] = rp[1]; pf[3 * it + 2] = rp[2];
+				}
+			}
+		} else {
+#pragma unroll
+			for (int it = 0; it < 4; it++) {                         /* 8 pixels = 16 bytes an item, four items a thread */
+				const int k = t + FI_NT * it, row = FI_BR * b + 2 + (k >> 6);
+				if (row >= 0 && row < W) pf[it] = reinterpret_cast<const uint4 *>(reinterpret_cast<const int16_t *>(src) + (size_t)row * W)[k & 63];
+			}
+		}
+	};
+	issue(-1);
+
+	if (PRE) {
+		/* The pair rules only ask which of eight magnitude classes the two kernel values are in (the constants of image_processing.c:810-837,
+		 * :1927-1990) and their signs: 15 signed classes.  Entry (c0, c1) = 16 bytes: the two luma deltas packed as two 16-bit halves for
+		 * hand-over flag 0 and 1, and the flag the pair hands on; filled by evaluating the rules themselves on one representative per class. */
+		if (t < PCLS * PCLS) {
+			const int c0 = t / PCLS, c1 = t % PCLS;
+			const int r0 = pair_class_rep(c0 - 7), r1 = pair_class_rep(c1 - 7);
+			ptab[4 * t] = prefilter_pair_delta(r0, r1, 0); ptab[4 * t + 1] = prefilter_pair_delta(r0, r1, 1);
+			ptab[4 * t + 2] = (uint32_t)pair_big_flag_fwd(r0, r1); ptab[4 * t + 3] = 0;
+		}
+		if (t < 405) { const int k = t - 202, m = pair_mag_class(iabs(k)), c = k < 0 ? 7 - m : 7 + m; tca[t] = (uint8_t)c; tcb[t] = (uint8_t)(16 * c); }
+		if (t == 0) { misc[0] = 0; misc[2] = 0; misc[3] = 0; }
+	}
+
+#pragma unroll 1
+	for (int b = -1; b < W / FI_BR; b++) {
+		const int r0 = FI_BR * b;                                     /* image row of luma index 0 */
+		/* ---------------------------------------------------------------- phase 0: the prefetched rows -> luma (and filtered chroma) in LDS */
+		if (SRC) {
+#pragma unroll
+			for (int it = 0; it < 2; it++) {
+				const int i = (t >> 5) + 16 * it, g = t & 31, row = r0 + 2 + i;
+				uint32_t yw[8], uw[4], vw[4];
+				const bool live = row >= 0 && row < W;
+				if (live) {
+					const uint32_t wv[12] = { pf[3 * it].x, pf[3 * it].y, pf[3 * it].z, pf[3 * it].w, pf[3 * it + 1].x, pf[3 * it + 1].y, pf[3 * it + 1].z, pf[3 * it + 1].w,
+					                          pf[3 * it + 2].x, pf[3 * it + 2].y, pf[3 * it + 2].z, pf[3 * it + 2].w };
+					convert16<FAMILY>(wv, yq, yw, uw, vw, true);
+				} else {
+#pragma unroll
+					for (int e = 0; e < 8; e++) yw[e] = 0;
+#pragma unroll
+					for (int e = 0; e < 4; e++) { uw[e] = 0; vw[e] = 0; }
+				}
+				uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + (i + 2) * FI_RS + 16 * g);
+#pragma unroll
+				for (int e = 0; e < 8; e++) d[e] = yw[e];
+				/* the pixel on the left of the group comes from the lane on the left (every lane takes part in the shuffle) */
+				uint32_t lu = (uint32_t)__shfl_up((int)uw[3], 1), lv = (uint32_t)__shfl_up((int)vw[3], 1);
+				if (g == 0) { lu = uw[0] << 16; lv = vw[0] << 16; }
+				*reinterpret_cast<uint2 *>(stg + (i + 2) * 512 + 8 * g) = chroma_h8(uw, lu);
+				*reinterpret_cast<uint2 *>(stg + (i + 2) * 512 + 256 + 8 * g) = chroma_h8(vw, lv);
+			}
+			if (t < 32) reinterpret_cast<uint4 *>(stg + 512)[t] = reinterpret_cast<const uint4 *>(crow)[t];   /* image row 32b+1, filtered by the band before */
+		} else {
+#pragma unroll
+			for (int it = 0; it < 4; it++) {
+				const int k = t + FI_NT * it, i = k >> 6, row = r0 + 2 + i;
+				const uint4 v = (row >= 0 && row < W) ? pf[it] : make_uint4(0, 0, 0, 0);
+				uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + (i + 2) * FI_RS + 8 * (k & 63));
+				d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+			}
+		}
+		__syncthreads();
+		FI_STAMP(1);
+		/* ---------------------------------------------------------------- 4:2:0: vertical [1 2 1]/4 over image rows 2r-1, 2r, 2r+1 (colorspace.c:241-256) */
+		if (SRC) {
+			const int pl = t >> 8, rr = (t >> 4) & 15, c16 = t & 15, r = 16 * b + 1 + rr;   /* chroma rows 16b+1 .. 16b+16; the band before the first: row 0 */
+			if (b < 0 ? rr == 15 : r < H) {
+				const uint8_t *sp = stg + (2 * rr + 1) * 512 + pl * 256 + 16 * c16;
+				const uint4 x0 = *reinterpret_cast<const uint4 *>(sp), x1 = *reinterpret_cast<const uint4 *>(sp + 512), x2 = *reinterpret_cast<const uint4 *>(sp + 1024);
+				uint4 o;
+				if (b < 0) o = make_uint4(avg_up(x1.x, x2.x), avg_up(x1.y, x2.y), avg_up(x1.z, x2.z), avg_up(x1.w, x2.w));   /* row 0: (r0 + r1 + 1) >> 1 */
+				else o = make_uint4(tri121(x0.x, x1.x, x2.x), tri121(x0.y, x1.y, x2.y), tri121(x0.z, x1.z, x2.z), tri121(x0.w, x1.w, x2.w));
+				*reinterpret_cast<uint4 *>((pl ? pvb : pub) + (size_t)img * c_stride + (b < 0 ? 0 : r) * H + 16 * c16) = o;
+				if (rr == 15) *reinterpret_cast<uint4 *>(crow + pl * 256 + 16 * c16) = x2;
+			}
+		}
+		if (b < 0) {
+			/* rows 0 and 1 sit at luma index 32 and 33: move them to 0 and 1, ask for the first band's rows */
+			for (int k = t; k < 2 * FI_RD; k += FI_NT) { uint32_t *y = reinterpret_cast<uint32_t *>(ybuf); y[k] = y[32 * FI_RD + k]; }
+			issue(0);
+			__syncthreads();
+			continue;
+		}
+		const int last_row = r0 + FI_BR < W - 2 ? r0 + FI_BR : W - 2; /* last image row of this band with a kernel value */
+		if (PRE) {
+			__syncthreads();                                           /* the staging rows become the contrast map */
+			FI_STAMP(2);
+			/* ------------------------------------------------------------ contrast of image rows 32b+1 .. 32b+32, 8 pixels an item (image_processing.c:568-640).
+			 * The rows stay packed, two pixels to a dword (luma is never negative here).  The signed sum 9 x centre - block sum is packed
+			 * arithmetic on both pixels of a dword; a pixel's eight absolute differences are four v_sad_u16 against dwords that hold two
+			 * neighbours each.  Items are (row, group) with the row fastest: consecutive lanes sit a padded row apart, on consecutive banks. */
+#pragma unroll 1
+			for (int it = 0; it < 4; it++) {
+				const int k = t + FI_NT * it, rr = 1 + (k & 31), g = k >> 5;
+				if (r0 + rr > W - 2) continue;
+				const uint32_t *ru = reinterpret_cast<const uint32_t *>(ybuf + (rr - 1) * FI_RS) + 4 * g - 1, *rm = ru + FI_RD, *rd = rm + FI_RD;
+				uint32_t U[6], M[6], D[6], S[6];
+#pragma unroll
+				for (int j = 0; j < 6; j++) { U[j] = ru[j]; M[j] = rm[j]; D[j] = rd[j]; S[j] = pk_add16(pk_add16(U[j], M[j]), D[j]); }
+				uint32_t out[4];
+#pragma unroll
+				for (int K = 1; K < 5; K++) {
+					const uint32_t T = pk_add16(S[K], __builtin_amdgcn_alignbit(S[K], S[K], 16));   /* both halves: the dword's two column sums */
+					const uint32_t wsum = pk_add16(T, pack_hl(S[K - 1], S[K + 1]));                  /* + the column on the left (low pixel) / right (high pixel) */
+					const s16x2 sum = as_s(as_w(as_us(M[K]) * (u16x2)(unsigned short)9)) - as_s(wsum);
+					const s16x2 sg = sum >> 15;
+					const u16x2 ab = as_us(as_w((s16x2)((sum ^ sg) - sg)));
+					uint32_t mag[2];
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						const uint32_t cc = __builtin_amdgcn_perm(M[K], M[K], h ? 0x03020302u : 0x01000100u);
+						const uint32_t side = h ? __builtin_amdgcn_perm(D[K + 1], U[K + 1], 0x05040100u) : __builtin_amdgcn_perm(D[K - 1], U[K - 1], 0x07060302u);
+						const uint32_t mids = h ? __builtin_amdgcn_perm(M[K + 1], M[K], 0x05040100u) : __builtin_amdgcn_perm(M[K], M[K - 1], 0x07060302u);
+						mag[h] = sad_u16(cc, U[K], sad_u16(cc, D[K], sad_u16(cc, side, sad_u16(cc, mids, 0u))));
+					}
+					if (K == 1 && g == 0) mag[0] = 0;                     /* column 0 has no kernel value, and what lies in front of the row is not luma: its sum must not spill into column 1's half */
+					const u16x2 base = ab * (u16x2)(unsigned short)15 + as_us(mag[0] | (mag[1] << 16));
+					const s16x2 vb = (as_s(as_w(base)) ^ sg) - sg;
+					out[K - 1] = as_w((u16x2)(as_us(as_w(vb)) * __builtin_elementwise_min(ab, (u16x2)(unsigned short)1)));   /* a zero sum gives no kernel value */
+				}
+				if (g == 0) out[0] &= 0xFFFF0000u;                       /* columns 0 and 511 have none */
+				if (g == 63) out[3] &= 0x0000FFFFu;
+				uint32_t *d = reinterpret_cast<uint32_t *>(kbuf + (rr + 4) * FI_RS + 8 * g);
+				d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3];
+			}
+			if (t < FI_RD) reinterpret_cast<uint32_t *>(ybuf + 34 * FI_RS)[t] = reinterpret_cast<const uint32_t *>(ybuf + 32 * FI_RS)[t];   /* the next band's contrast wants row 32b+32 as it is now */
+			__syncthreads();
+			FI_STAMP(3);
+			FI_DUMP(3, kbuf + 5 * FI_RS);
+			FI_DUMP(4, ybuf + FI_RS);
+			FI_DUMP(5, ybuf);
+			FI_DUMP(6, ybuf + 3 * FI_RS);
+			/* ------------------------------------------------------------ carry state at the start of every 32-pixel segment (image_processing.c:641-700).
+			 * The carry is a 16-state machine that runs in raster order over the interior of the whole image.  A step maps the 16 states onto at
+			 * most five neighbouring ones and a zero sum resets it: run five candidates (5-bit fields of one dword) through the 12 pixels in
+			 * front of the segment -- for a row's first segment the end of the row above --; if they end in one state, that is the entry state
+			 * whatever came before.  Where they do not (rare), the segments are replayed in order from the one before.  The band's first
+			 * segment continues from where the band before stopped. */
+			{
+				const int rr = 1 + (t & 31), sg = t >> 5;
+				int e = 0;
+				if (r0 + rr <= W - 2) {
+					if (sg == 0 && rr == 1) e = misc[0];
+					else {
+						const int16_t *km = sg ? kbuf + (rr + 4) * FI_RS + 1 + FI_SEG * sg - FI_LOOK : kbuf + (rr + 3) * FI_RS + (W - 1 - FI_LOOK);
+						const uint32_t R = 0x108421u;                    /* 1 in each field */
+						uint32_t x = km[0] == 0 ? 0u : ((((uint32_t)iabs(km[0]) & 15u) * R + 0x418820u) & (15u * R));
+						for (int i = 1; i < FI_LOOK; i++) {
+							const int vb = km[i];
+							const uint32_t nx = (((uint32_t)iabs(vb) & 15u) * R + (((x + 2u * R) >> 2) & (7u * R))) & (15u * R);
+							x = vb == 0 ? 0u : nx;
+						}
+						e = (x == (x & 31u) * R && !(flags & 1)) ? (int)(x & 15u) : 0xFF;
+					}
+					entry[(rr - 1) * FI_NSEG + sg] = (uint8_t)e;
+				}
+				if (__syncthreads_or(e == 0xFF)) {
+					if (t == 0) {
+						for (int s = 1; s < (last_row - r0) * FI_NSEG; s++) {   /* raster order; segment 0 of the band is never open */
+							if (entry[s] != 0xFF) continue;
+							const int pr = (s - 1) >> 4, ps = (s - 1) & 15, n = ps == FI_NSEG - 1 ? FI_SEG - 2 : FI_SEG;
+							const int16_t *km = kbuf + (pr + 5) * FI_RS + 1 + FI_SEG * ps;
+							int carry = entry[s - 1];
+							for (int i = 0; i < n; i++) { const int vb = km[i]; carry = vb == 0 ? 0 : ((iabs(vb) + ((carry + 2) >> 2)) & 15); }
+							entry[s] = (uint8_t)carry;
+						}
+					}
+					__syncthreads();
+				}
+				if (stb && sg == 0 && r0 + rr <= W - 2) (stb + (size_t)img * s_stride)[r0 + rr] = entry[(rr - 1) * FI_NSEG];   /* compatibility mode replays a few rows from these */
+			}
+			FI_STAMP(4);
+			/* ------------------------------------------------------------ replay the carry: a lane per row and PAIR of segments (sp, sp + 8), side by side in the halves
+			 * of a dword, every step packed 16-bit arithmetic.  Eight pixels at a time through registers. */
+			if (t < 32 * (FI_NSEG / 2)) {
+				const int rr = 1 + (t & 31), sp = t >> 5;
+				if (r0 + rr <= W - 2) {
+					int16_t *ka = kbuf + (rr + 4) * FI_RS + 1 + FI_SEG * sp, *kb = ka + 256;
+					const int nb = sp == FI_NSEG / 2 - 1 ? FI_SEG - 2 : FI_SEG;   /* the last segment ends at column 510 */
+					u16x2 carry = { entry[(rr - 1) * FI_NSEG + sp], entry[(rr - 1) * FI_NSEG + sp + FI_NSEG / 2] }, c29 = carry;
+#pragma unroll 1
+					for (int ch = 0; ch < FI_SEG / 8; ch++) {
+						s16x2 v[8];
+#pragma unroll
+						for (int e = 0; e < 8; e++) { v[e].x = ka[8 * ch + e]; v[e].y = kb[8 * ch + e]; }
+#pragma unroll
+						for (int e = 0; e < 8; e++) {                      /* v == 0: |v| + f(carry) <= 4 gives output 0 by itself; only the carry needs the reset */
+							const s16x2 sgn = v[e] >> 15;
+							const u16x2 a = __builtin_bit_cast(u16x2, (s16x2)((v[e] ^ sgn) - sgn));
+							const u16x2 acc = a + ((carry + (u16x2)(2)) >> 2);
+							const s16x2 o = __builtin_bit_cast(s16x2, (u16x2)(acc >> 4));
+							v[e] = (o ^ sgn) - sgn;
+							carry = (acc & (u16x2)(15)) * __builtin_elementwise_min(a, (u16x2)(1));
+							if (e == 5) c29 = carry;                        /* in the last chunk: the state behind column 510 */
+						}
+#pragma unroll
+						for (int e = 0; e < 8; e++) { ka[8 * ch + e] = v[e].x; if (8 * ch + e < nb) kb[8 * ch + e] = v[e].y; }
+					}
+					if (sp == FI_NSEG / 2 - 1 && r0 + rr == last_row) misc[0] = (uint8_t)c29.y;
+				}
+			}
+			__syncthreads();
+			FI_STAMP(5);
+			FI_DUMP(2, kbuf + 5 * FI_RS);
+			/* ------------------------------------------------------------ pair rules (image_processing.c:810-837, 1927-1990): pixel pairs (1,2), (3,4) .. (509,510) of a row,
+			 * four pairs an item; a pair's deltas depend on its two kernel values and on a flag the pair before hands over -- which depends on
+			 * that pair's values only, so nothing is serial.  Class of a value, entry of a pair: table look-ups (see the fill above). */
+#pragma unroll 1
+			for (int it = 0; it < 4; it++) {
+				const int k = t + FI_NT * it, rr = 1 + (k & 31), g = k >> 5;
+				if (r0 + rr > W - 2) continue;
+				const uint32_t *kr = reinterpret_cast<const uint32_t *>(kbuf + (rr + 4) * FI_RS);
+				/* values of columns 8g-1 .. 8g+8: v0 = high half of P[0], v1 = low half of P[1], v2 = high half of KQ[0], v3 / v4 = KQ[1] .. v9 = low half of KQ[4].
+				 * The first item of a row looks at the last pair (509, 510) of the row above instead of columns -1, 0. */
+				const uint32_t *pp = g ? kr + 4 * g - 1 : kr - FI_RD + 254;
+				uint32_t P[2] = { pp[0], pp[1] }, KQ[5];
+#pragma unroll
+				for (int j = 0; j < 5; j++) KQ[j] = kr[4 * g + j];
+				const s16x2 lim = (s16x2)(short)202;
+				auto clampw = [&](uint32_t w) { return as_w((s16x2)__builtin_elementwise_min(__builtin_elementwise_max(as_s(w), -lim), lim)); };
+				P[0] = clampw(P[0]); P[1] = clampw(P[1]);
+#pragma unroll
+				for (int j = 0; j < 5; j++) KQ[j] = clampw(KQ[j]);
+				auto lo = [](uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); };
+				auto hi = [](uint32_t w) { return (int)w >> 16; };
+				/* byte offset of a pair's entry: 240 x class of the first + 16 x class of the second */
+				int prev = tcb[202 + lo(P[1])] + 240 * tca[202 + hi(P[0])];
+				int flag = (int)*reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(ptab) + prev + 8);
+				if (g == 0 && rr == 1) flag = misc[2 + ((b + 1) & 1)];     /* the band before left it (0 at the top of the image) */
+				uint32_t dl[4];
+				int flag2 = 0;
+#pragma unroll
+				for (int e = 0; e < 4; e++) {
+					const int off = tcb[202 + lo(KQ[e + 1])] + 240 * tca[202 + hi(KQ[e])];
+					const uint8_t *en = reinterpret_cast<const uint8_t *>(ptab) + off;
+					dl[e] = *reinterpret_cast<const uint32_t *>(en + 4 * flag);
+					flag = (int)*reinterpret_cast<const uint32_t *>(en + 8);
+					if (e == 2) flag2 = flag;
+				}
+				if (g == 63) {                                           /* the last item's fourth pair would be (511, 512): no such pair; its third, (509, 510), hands the flag to the next row */
+					dl[3] = 0;
+					if (r0 + rr == last_row) misc[2 + (b & 1)] = (uint8_t)flag2;
+				}
+				/* luma columns 8g+1 .. 8g+8: the high half of dword 4g, dwords 4g+1 .. 4g+3, the low half of dword 4g+4 */
+				uint32_t *yo = reinterpret_cast<uint32_t *>(ybuf + rr * FI_RS) + 4 * g;
+				int16_t *ys = reinterpret_cast<int16_t *>(yo);
+				ys[1] = (int16_t)(ys[1] + (int16_t)(dl[0] & 0xFFFFu));
+#pragma unroll
+				for (int j = 1; j < 4; j++) yo[j] = pk_add16(yo[j], pack_hl(dl[j - 1], dl[j]));
+				ys[8] = (int16_t)(ys[8] + (int16_t)(dl[3] >> 16));
+			}
+			__syncthreads();
+			FI_STAMP(6);
+			FI_DUMP(1, ybuf + FI_RS);
+		}
+		/* ---------------------------------------------------------------- horizontal pass (filters.c:346-386) of image rows 32b+1 .. 32b+32 (and row 0), four kx an item,
+		 * two outputs to a dword: L(k, k+1) = 6 E(k) + 2 (O(k-1) + O(k)) - (E(k-1) + E(k+1)), H(k, k+1) = 2 O(k) - (E(k) + E(k+1)) with
+		 * E(j) = (x[2j], x[2j+2]), O(j) = (x[2j+1], x[2j+3]) put together from the row's dwords (x[2j], x[2j+1]). */
+		{
+			const int top = r0 + FI_BR < W ? FI_BR : W - 1 - r0;       /* luma index of the band's last image row */
+			for (int k = t; k < (b == 0 ? 33 : 32) * 64; k += FI_NT) {
+				int rr, g;
+				if (b == 0) { rr = k % 33; g = k / 33; } else { rr = 1 + (k & 31); g = k >> 5; if (rr > top) continue; }
+				const uint32_t *yr = reinterpret_cast<const uint32_t *>(ybuf + rr * FI_RS) + 4 * g - 1;
+				uint32_t X[6];                                           /* X[j] = (x[8g - 2 + 2j], x[8g - 1 + 2j]) */
+#pragma unroll
+				for (int j = 0; j < 6; j++) X[j] = yr[j];
+				if (g == 0) X[0] = __builtin_amdgcn_perm(X[1], X[2], 0x07060100u);   /* x[-2] = x[2], x[-1] = x[1] */
+				if (g == 63) X[5] = X[4];                               /* x[512] = x[510] */
+				uint32_t E[5], O[4];
+#pragma unroll
+				for (int j = 0; j < 5; j++) E[j] = pack_lo(X[j], X[j + 1]);
+#pragma unroll
+				for (int j = 0; j < 4; j++) O[j] = pack_hi(X[j], X[j + 1]);
+				uint32_t L[2], Hh[2];
+#pragma unroll
+				for (int p = 0; p < 2; p++) {
+					const s16x2 e0 = as_s(E[2 * p]), e1 = as_s(E[2 * p + 1]), e2 = as_s(E[2 * p + 2]), o0 = as_s(O[2 * p]), o1 = as_s(O[2 * p + 1]);
+					L[p] = as_w((s16x2)(e1 * (s16x2)(short)6 + ((o0 + o1) << 1) - (e0 + e2)));
+					Hh[p] = as_w((s16x2)((o1 << 1) - (e1 + e2)));
+				}
+				uint32_t *dlo = reinterpret_cast<uint32_t *>(kbuf + (rr + 4) * FI_RS + 4 * g), *dhi = reinterpret_cast<uint32_t *>(kbuf + (rr + 4) * FI_RS + H + 4 * g);
+				dlo[0] = L[0]; dlo[1] = L[1]; dhi[0] = Hh[0]; dhi[1] = Hh[1];
+			}
+		}
+		__syncthreads();
+		FI_STAMP(7);
+		/* ---------------------------------------------------------------- vertical pass + stores.  First the next band's rows are asked for. */
+		if (b + 1 < W / FI_BR) issue(b + 1);
+		if (keepb && !(flags & 2)) {                                   /* q >= 22: transposed horizontal-pass plane, rows kx < 256 (wavelet_filterbank.c:107-112): image rows 32b .. 32b+31 */
+			int16_t *keep = keepb + (size_t)img * keep_stride;
+			for (int k = t; k < H * 4; k += FI_NT) {
+				const int kx = k >> 2, part = k & 3;
+				uint32_t v[4];
+#pragma unroll
+				for (int e = 0; e < 4; e++) {
+					const int ri = 4 + 8 * part + 2 * e;
+					v[e] = (uint16_t)kbuf[ri * FI_RS + kx] | ((uint32_t)(uint16_t)kbuf[(ri + 1) * FI_RS + kx] << 16);
+				}
+				*reinterpret_cast<uint4 *>(keep + (size_t)kx * W + r0 + 8 * part) = make_uint4(v[0], v[1], v[2], v[3]);
+			}
+		}
+		uint32_t hold[3];                                              /* horizontal-pass rows 32b+28 .. 32b+32: the next band's first five */
+#pragma unroll
+		for (int e = 0; e < 3; e++) { const int k = t + FI_NT * e; if (k < 5 * FI_RD) hold[e] = reinterpret_cast<const uint32_t *>(kbuf + 32 * FI_RS)[k]; }
+		/* luma rows 32b+32 (before the pair rules) and 32b+33 become the next band's rows 0 and 1 */
+		for (int k = t; k < 2 * FI_RD; k += FI_NT) {
+			uint32_t *y = reinterpret_cast<uint32_t *>(ybuf);
+			y[k] = k < FI_RD ? y[(PRE ? 34 : 32) * FI_RD + k] : y[32 * FI_RD + k];   /* k >= FI_RD: row 33, dword k - FI_RD */
+		}
+		{
+			/* a thread takes a PAIR of columns (2cp, 2cp+1) -- the halves of one dword -- and eight of the band's output rows.  Columns below 256
+			 * (the low band of the horizontal pass) and the others take different rounding rules; a wavefront lies wholly on one side. */
+			const int cp = t & 255, kb = 8 * (t >> 8);
+			auto vertical = [&](auto side) {
+				constexpr bool LEFT = decltype(side)::value;
+				uint32_t col[21];                                       /* col[i] = horizontal-pass row 32b - 4 + 2kb + i, symmetric extension x[-j] = x[j], x[511+j] = x[511-j] */
+#pragma unroll
+				for (int i = 0; i < 21; i++) {
+					int ri = 2 * kb + i;
+					if (b == 0 && ri < 4) ri = 8 - ri;
+					if (b == W / FI_BR - 1 && ri == 36) ri = 34;
+					col[i] = reinterpret_cast<const uint32_t *>(kbuf + ri * FI_RS)[cp];
+				}
+				uint32_t lo[8], hi[8];
+				s16x2 rprev = (s16x2)(short)0;
+				if (LEFT) rprev = as_s(col[2]) * (s16x2)(short)6 + ((as_s(col[1]) + as_s(col[3])) << 1) - (as_s(col[0]) + as_s(col[4]));
+#pragma unroll
+				for (int kk = 0; kk < 8; kk++) {
+#define XS(d) as_s(col[2 * kk + 4 + (d)])                            /* x[2ky + d], -4 <= d <= 2 */
+					const s16x2 r = XS(0) * (s16x2)(short)6 + ((XS(-1) + XS(1)) << 1) - (XS(-2) + XS(2));
+					s16x2 l, h;
+					if (LEFT) {                                        /* filters.c:203-287 */
+						s16x2 carry = pk_diffuse(rprev);
+						if (kk == 0 && b == 0 && kb == 0) carry = (s16x2)(short)0;
+						l = pk_rnd_half_away(r + carry, 6);
+						rprev = r;
+					} else l = pk_rnd_half_away(r, 4);                 /* filters.c:88-113 */
+					s16x2 a = XS(0) + XS(2);
+					if (kk & 1) a = a + (a & (XS(-2) + XS(0)) & (s16x2)(short)1);   /* odd ky: both neighbouring sums odd -> the mean is taken one up */
+					const s16x2 pr = XS(1) - (a >> 1);
+					h = pk_rnd_half_away(pr, LEFT ? 3 : 1);            /* right half: pr > 0 ? (pr + 1) >> 1 : pr >> 1, the same thing */
+					if (kk == 7 && b == W / FI_BR - 1 && kb == 8) { const s16x2 dd = XS(1) - XS(0); h = LEFT ? dd >> 3 : (dd + (s16x2)(short)1) >> 1; }   /* ky = 255 */
+#undef XS
+					lo[kk] = as_w(l); hi[kk] = as_w(h);
+				}
+				/* the level-1 plane is kept transposed: column c is row c of it, eight output rows = 16 bytes */
+				int16_t *orow = proc + (size_t)(2 * cp) * W + 16 * b + kb;
+				*reinterpret_cast<uint4 *>(orow) = make_uint4(pack_lo(lo[0], lo[1]), pack_lo(lo[2], lo[3]), pack_lo(lo[4], lo[5]), pack_lo(lo[6], lo[7]));
+				*reinterpret_cast<uint4 *>(orow + W) = make_uint4(pack_hi(lo[0], lo[1]), pack_hi(lo[2], lo[3]), pack_hi(lo[4], lo[5]), pack_hi(lo[6], lo[7]));
+				*reinterpret_cast<uint4 *>(orow + H) = make_uint4(pack_lo(hi[0], hi[1]), pack_lo(hi[2], hi[3]), pack_lo(hi[4], hi[5]), pack_lo(hi[6], hi[7]));
+				*reinterpret_cast<uint4 *>(orow + W + H) = make_uint4(pack_hi(hi[0], hi[1]), pack_hi(hi[2], hi[3]), pack_hi(hi[4], hi[5]), pack_hi(hi[6], hi[7]));
+				if (LEFT) {                                            /* LL in natural orientation: jpeg[ky][kx] and ll1[ky][kx], kx < 256 (wavelet_filterbank.c:172-184, nhw_encoder.c:127-135) */
+#pragma unroll
+					for (int kk = 0; kk < 8; kk++) {
+						const int ky = 16 * b + kb + kk;
+						reinterpret_cast<uint32_t *>(jpeg + (size_t)ky * W)[cp] = lo[kk];
+						reinterpret_cast<uint32_t *>(ll1 + (size_t)ky * H)[cp] = lo[kk];
+					}
+				}
+			};
+			if (__builtin_amdgcn_readfirstlane(cp) < H / 2) vertical(std::true_type{}); else vertical(std::false_type{});
+		}
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < 3; e++) { const int k = t + FI_NT * e; if (k < 5 * FI_RD) reinterpret_cast<uint32_t *>(kbuf)[k] = hold[e]; }
+	}
+}
+
+} // namespace nhw
+#endif

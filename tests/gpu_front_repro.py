@@ -1,0 +1,18 @@
+import ctypes, torch, nhwcodec_amd, os
+n=1024
+e = nhwcodec_amd.Encoder(0, max_batch=n)
+bgr = e.synth_device(n, seed_base=1000)
+out = e.alloc_out(n)
+e.lib.nhw_debug_hash.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+e.lib.nhw_debug_stop_after(e.h, 4)
+def hs(b, nb):
+    h = torch.zeros(n, dtype=torch.int64, device="cuda")
+    assert e.lib.nhw_debug_hash(e.h, b, nb, n, h.data_ptr(), e._stream()) == 0
+    torch.cuda.synchronize(); return h
+e.encode_device(bgr, 20, out); ref = {b: hs(b, 8*65536) for b in (14, 1)}
+tot = {14: 0, 1: 0}
+for k in range(6):
+    e.encode_device(bgr, 20, out)
+    for b in (14, 1):
+        tot[b] += len(torch.nonzero(hs(b, 8*65536) != ref[b]).flatten().tolist())
+print("dump kind", os.environ.get("NHW_FRONT_DUMP"), "irreproducible images over 6 runs: dump", tot[14], "proc", tot[1])
