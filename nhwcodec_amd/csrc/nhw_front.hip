@@ -13,6 +13,8 @@
  */
 #include <type_traits>
 #include <cstdlib>
+#include <cstdio>
+#include <cstring>
 #include "nhw_ws.h"
 #include "nhw_dwt.h"
 
@@ -1011,6 +1013,8 @@ void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv,
 		int fl = force_fallback & 1;
 #ifdef NHW_DEV
 		{ const char *e = getenv("NHW_BAND_STOP"); if (e) fl |= atoi(e) << 8; }
+		if (getenv("NHW_FRONT_PROF")) fl |= 0x10000;
+		{ const char *e = getenv("NHW_FRONT_SKIP"); if (e) fl |= atoi(e) & 12; }     /* 4: no stores of the level-1 plane, 8: none of the LL rows (timing experiments) */
 		if (getenv("NHW_FRONT_DUMP") && y && bgr && with_prefilter) { fl |= 2 | (atoi(getenv("NHW_FRONT_DUMP")) << 4); keep = const_cast<int16_t *>(y); keep_stride = y_stride / 2; }
 #endif
 #define FI_ARGS(srcp, sstride) srcp, sstride, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, fl
@@ -1020,6 +1024,18 @@ void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv,
 		else if (fam == 1) k_front_image<1, 1, 1><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
 		else k_front_image<1, 1, 2><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
 #undef FI_ARGS
+#ifdef NHW_DEV
+		if (getenv("NHW_FRONT_PROF")) {
+			unsigned long long h[16];
+			hipStreamSynchronize(s);
+			hipMemcpyFromSymbol(h, HIP_SYMBOL(nhw::g_fi_prof), sizeof h);
+			static const char *nm[16] = { "loop top (hold rows, last barrier)", "barrier after phase 0 (+ prefetch issue)", "chroma vertical + barrier", "contrast + barrier", "entry states + barrier(s)", "replay + barrier", "pair rules + barrier", "horizontal + barrier", "vertical + barrier", "phase 0 work (wait for rows, colour, LDS stores)", "vertical: keep stores", "vertical: row copies + column loads", "vertical: arithmetic", "vertical: stores issued" };
+			unsigned long long tot = 0; for (int i = 0; i < 14; i++) tot += h[i];
+			fprintf(stderr, "k_front_image q%d: thread-0 clock ticks per image (sum over bands), %d images\n", q, n);
+			for (int i = 0; i < 14; i++) fprintf(stderr, "  %-52s %10.0f  %5.1f %%\n", nm[i], (double)h[i] / n, 100.0 * h[i] / (tot ? tot : 1));
+			memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(nhw::g_fi_prof), h, sizeof h);
+		}
+#endif
 		return;
 	}
 	const size_t lds = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);

@@ -59,6 +59,11 @@ __device__ __forceinline__ uint32_t pack_lo(uint32_t a, uint32_t b) { return __b
 __device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 /* (hi half of a) | (lo half of b) << 16 */
 __device__ __forceinline__ uint32_t pack_hl(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }
+/* packed 16-bit minimum / maximum as ONE instruction each (left to itself the compiler turns them into compares and selects on the halves) */
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 /* byte-wise (a + b) >> 1 and (a + b + 1) >> 1 on four bytes */
 __device__ __forceinline__ uint32_t avg_dn(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0u); }
 __device__ __forceinline__ uint32_t avg_up(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
@@ -83,61 +88,83 @@ __device__ __forceinline__ uint32_t tri121(uint32_t a, uint32_t b, uint32_t c) {
  * The exhaustive test (all 2^24 triples, tests/test_gpu_parity.py) runs this function through k_color.
  * ------------------------------------------------------------------------------------------------ */
 __device__ __forceinline__ float ubf(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   /* v_cvt_f32_ubyte<k> */
+/* four pixels = three dwords at a time (few values alive at once: the kernel has 128 registers a lane).  The sums run as packed single
+ * precision (v_pk_fma_f32: two lanes of arithmetic an instruction): two pixels side by side for the luma, U beside V for the chroma. */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk2(float a, float b) { return (f32x2){ a, b }; }
 template <int FAMILY>
-__device__ __forceinline__ void convert16(const uint32_t wv[12], float yq, uint32_t yw[8], uint32_t uw[4], uint32_t vw[4], bool uv)
+__device__ __forceinline__ void convert4(uint32_t w0, uint32_t w1, uint32_t w2, float yq, uint32_t yw[2], uint32_t &uw, uint32_t &vw, bool uv)
 {
-	float f[48];
+	const uint32_t wv[3] = { w0, w1, w2 };
+	float f[12];
 #pragma unroll
-	for (int b = 0; b < 48; b++) f[b] = ubf(wv[b >> 2], b & 3);
-	uint32_t ym[16];
+	for (int b = 0; b < 12; b++) f[b] = ubf(wv[b >> 2], b & 3);
+	uint32_t ym[4];
 #pragma unroll
-	for (int e = 0; e < 16; e++) {
-		const float b0 = f[3 * e], b1 = f[3 * e + 1], b2 = f[3 * e + 2];
+	for (int p = 0; p < 2; p++) {                                   /* pixels 2p, 2p+1 */
+		const f32x2 B0 = pk2(f[6 * p], f[6 * p + 3]), B1 = pk2(f[6 * p + 1], f[6 * p + 4]), B2 = pk2(f[6 * p + 2], f[6 * p + 5]);
 		if (FAMILY == 0) {
-			const float s = __builtin_fmaf(b2, 114.f, __builtin_fmaf(b1, 587.f, __builtin_fmaf(b0, 299.f, 500.109375f)));
-			const float m = __builtin_fmaf(s, 0.001f, 8388607.5f);
-			const float r = __builtin_fmaf(m - 8388608.f, -1000.f, s);
-			uint32_t bits = __float_as_uint(m);
-			if (r < 0.5f) {                                            /* s is a multiple of 1000: the reference's double arithmetic decides */
-				const double ly = 0.299 * (double)b0 + 0.587 * (double)b1 + 0.114 * (double)b2;
-				bits = (uint32_t)(int)(ly + 0.5f);
+			const f32x2 s = pk_fma(B2, pk2(114.f, 114.f), pk_fma(B1, pk2(587.f, 587.f), pk_fma(B0, pk2(299.f, 299.f), pk2(500.109375f, 500.109375f))));
+			const f32x2 m = pk_fma(s, pk2(0.001f, 0.001f), pk2(8388607.5f, 8388607.5f));
+			const f32x2 r = pk_fma(m - pk2(8388608.f, 8388608.f), pk2(-1000.f, -1000.f), s);
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				uint32_t bits = __float_as_uint(h ? m.y : m.x);
+				if ((h ? r.y : r.x) < 0.5f) {                           /* s is a multiple of 1000: the reference's double arithmetic decides */
+					const double ly = 0.299 * (double)(h ? B0.y : B0.x) + 0.587 * (double)(h ? B1.y : B1.x) + 0.114 * (double)(h ? B2.y : B2.x);
+					bits = (uint32_t)(int)(ly + 0.5f);
+				}
+				ym[2 * p + h] = bits;
 			}
-			ym[e] = bits;
 		} else {
 			/* q 17..19: (int)(ly x scale + 0.5) in double.  The same product in single precision is off by less than 1e-4, so its floor is the
 			 * answer unless it lands within 2.5e-4 of an integer (5e-4 of the triples): those lanes take the double path. */
-			const float s = __builtin_fmaf(b2, 114.f, __builtin_fmaf(b1, 587.f, b0 * 299.f));
+			const f32x2 s = pk_fma(B2, pk2(114.f, 114.f), pk_fma(B1, pk2(587.f, 587.f), B0 * pk2(299.f, 299.f)));
 			const float c = (FAMILY == 1 ? yq : 0.94f) * 0.001f;
-			const float v = s * c + 0.5f, fl = floorf(v), fr = v - fl;
-			int y = (int)fl;
-			if (!(fr > 2.5e-4f && fr < 1.f - 2.5e-4f)) {
-				const double ly = 0.299 * (double)b0 + 0.587 * (double)b1 + 0.114 * (double)b2;
-				y = FAMILY == 1 ? (int)(ly * yq + 0.5f) : (int)(ly * 0.94 + 0.5f);
+			const f32x2 v = s * pk2(c, c) + pk2(0.5f, 0.5f);
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const float vv = h ? v.y : v.x, fl = floorf(vv), fr = vv - fl;
+				int y = (int)fl;
+				if (!(fr > 2.5e-4f && fr < 1.f - 2.5e-4f)) {
+					const double ly = 0.299 * (double)(h ? B0.y : B0.x) + 0.587 * (double)(h ? B1.y : B1.x) + 0.114 * (double)(h ? B2.y : B2.x);
+					y = FAMILY == 1 ? (int)(ly * yq + 0.5f) : (int)(ly * 0.94 + 0.5f);
+				}
+				ym[2 * p + h] = (uint32_t)y;
 			}
-			ym[e] = (uint32_t)y;
 		}
 	}
-#pragma unroll
-	for (int e = 0; e < 8; e++) yw[e] = pack_lo(ym[2 * e], ym[2 * e + 1]);
+	yw[0] = pack_lo(ym[0], ym[1]); yw[1] = pack_lo(ym[2], ym[3]);
 	if (!uv) return;
+	uw = 0; vw = 0;
 #pragma unroll
-	for (int e = 0; e < 4; e++) { uw[e] = 0; vw[e] = 0; }
-#pragma unroll
-	for (int e = 0; e < 16; e++) {
+	for (int e = 0; e < 4; e++) {
 		const float b0 = f[3 * e], b1 = f[3 * e + 1], b2 = f[3 * e + 2];
 		if (FAMILY != 2) {
-			const float su = __builtin_fmaf(b2, 5000.f, __builtin_fmaf(b1, -3313.f, b0 * -1687.f));
-			const float sv = __builtin_fmaf(b2, -813.f, __builtin_fmaf(b1, -4187.f, b0 * 5000.f));
-			const float tu = __builtin_fmaf(su, 1e-4f, su >= 0.f ? 128.0000457763671875f : 127.90005f);
-			const float tv = __builtin_fmaf(sv, 1e-4f, sv >= 0.f ? 128.0000457763671875f : 127.90005f);
-			uw[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(tu, e & 3, uw[e >> 2]);
-			vw[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(tv, e & 3, vw[e >> 2]);
+			const f32x2 suv = pk_fma(pk2(b2, b2), pk2(5000.f, -813.f), pk_fma(pk2(b1, b1), pk2(-3313.f, -4187.f), pk2(b0, b0) * pk2(-1687.f, 5000.f)));
+			/* the bias: 127.90005 below zero, + 0.1 from zero on.  The sums are integers, so clamp(s + 1) to 0 .. 1 is the step (one packed add with the
+			 * clamp modifier for U and V together; a compare and a select each otherwise) */
+			f32x2 step;
+			asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(step) : "v"(suv), "v"(pk2(1.f, 1.f)));
+			const f32x2 t = pk_fma(suv, pk2(1e-4f, 1e-4f), pk_fma(step, pk2(0.1f, 0.1f), pk2(127.90005f, 127.90005f)));
+			uw = __builtin_amdgcn_cvt_pk_u8_f32(t.x, e, uw);
+			vw = __builtin_amdgcn_cvt_pk_u8_f32(t.y, e, vw);
 		} else {
 			const uint8_t px[3] = { (uint8_t)(wv[(3 * e) >> 2] >> (8 * ((3 * e) & 3))), (uint8_t)(wv[(3 * e + 1) >> 2] >> (8 * ((3 * e + 1) & 3))), (uint8_t)(wv[(3 * e + 2) >> 2] >> (8 * ((3 * e + 2) & 3))) };
 			int U, V;
 			convert_uv<2>(px, yq, U, V);
-			uw[e >> 2] |= (uint32_t)U << (8 * (e & 3)); vw[e >> 2] |= (uint32_t)V << (8 * (e & 3));
+			uw |= (uint32_t)U << (8 * e); vw |= (uint32_t)V << (8 * e);
 		}
+	}
+}
+template <int FAMILY>
+__device__ __forceinline__ void convert16(const uint32_t wv[12], float yq, uint32_t yw[8], uint32_t uw[4], uint32_t vw[4], bool uv)
+{
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		convert4<FAMILY>(wv[3 * c], wv[3 * c + 1], wv[3 * c + 2], yq, yw + 2 * c, uw[c], vw[c], uv);
+		__builtin_amdgcn_sched_barrier(0);                             /* one chunk after the other: interleaved, the four of them need more registers than there are */
 	}
 }
 
@@ -161,16 +188,27 @@ __device__ __forceinline__ s16x2 pk_diffuse(s16x2 r)
 	return (d ^ s) - s;
 }
 
+/* The kernel is one long loop over the bands; left alone, the compiler computes every phase's per-thread offsets once in front of the loop and
+ * then has 40 more values alive than there are registers (they went to scratch memory).  A thread index taken through this at the start of
+ * a phase is opaque to it: the few adds and shifts are redone every band, and nothing of one phase is alive in another. */
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+
 #ifdef NHW_DEV   /* developer builds: 32 rows of a plane in LDS (from row index 1 / 5 on) into a plane in memory, for tests/gpu_front_debug.py */
 #define FI_DUMP(kind, base) do { if ((flags & 2) && ((flags >> 4) & 15) == (kind) && keepb) { \
-	for (int k_ = t; k_ < 32 * 256; k_ += FI_NT) { const int rr_ = 1 + (k_ >> 8), o_ = k_ & 255; \
+	for (int k_ = t0; k_ < 32 * 256; k_ += FI_NT) { const int rr_ = 1 + (k_ >> 8), o_ = k_ & 255; \
 		if (r0 + rr_ < W - ((kind) == 2 || (kind) == 3)) reinterpret_cast<uint32_t *>(keepb + (size_t)img * keep_stride + (size_t)(r0 + rr_) * W)[o_] = reinterpret_cast<const uint32_t *>((base) + (rr_ - 1) * FI_RS)[o_]; } \
 	__syncthreads(); } } while (0)
 #else
 #define FI_DUMP(kind, base) do { } while (0)
 #endif
+#ifdef NHW_DEV   /* developer builds: clock ticks of thread 0 between the phase boundaries, summed over all workgroups (NHW_FRONT_PROF=1 prints them) */
+__device__ unsigned long long g_fi_prof[16];
+#define FI_TICK(i) do { if ((flags & 0x10000) && t0 == 0) { const long long now_ = clock64(); acc_[i] += (unsigned)(now_ - tick_); tick_ = now_; } } while (0)
+#else
+#define FI_TICK(i) do { } while (0)
+#endif
 #ifdef NHW_DEV   /* developer builds: a switch that ends every band after phase i (tests/gpu_band_ablate.py: the cost of the phases under real contention) */
-#define FI_STAMP(i) do { if ((flags >> 8) == (i)) { __syncthreads(); if (b + 1 < W / FI_BR) issue(b + 1); continue; } } while (0)
+#define FI_STAMP(i) do { if (((flags >> 8) & 255) == (i)) { __syncthreads(); continue; } } while (0)
 #else
 #define FI_STAMP(i) do { } while (0)
 #endif
@@ -193,7 +231,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 	uint8_t *const entry = lds + FI_EN_OFF;
 	uint8_t *const crow = lds + FI_CR_OFF;
 	uint8_t *const misc = lds + FI_MISC_OFF;                        /* [0]: carry behind the band's last row, [2 + (b & 1)]: hand-over flag of its last pixel pair */
-	const int t = threadIdx.x, img = blockIdx.x;
+	const int t0 = threadIdx.x, img = blockIdx.x;
 
 	const uint8_t *const src = (const uint8_t *)srcb + (size_t)img * (SRC ? (size_t)(W * W * 3) : src_stride);
 	int16_t *const proc = procb + (size_t)img * plane_stride, *const jpeg = jpegb + (size_t)img * plane_stride;
@@ -203,6 +241,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 	constexpr int NPF = SRC ? 6 : 4;
 	uint4 pf[NPF];
 	auto issue = [&](int b) {
+		const int t = opaque(t0);
 		if (SRC) {
 #pragma unroll
 			for (int it = 0; it < 2; it++) {                         /* 16 pixels = 48 bytes an item, two items a thread */
@@ -223,6 +262,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 	issue(-1);
 
 	if (PRE) {
+		const int t = t0;
 		/* The pair rules only ask which of eight magnitude classes the two kernel values are in (the constants of image_processing.c:810-837,
 		 * :1927-1990) and their signs: 15 signed classes.  Entry (c0, c1) = 16 bytes: the two luma deltas packed as two 16-bit halves for
 		 * hand-over flag 0 and 1, and the flag the pair hands on; filled by evaluating the rules themselves on one representative per class. */
@@ -233,14 +273,20 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			ptab[4 * t + 2] = (uint32_t)pair_big_flag_fwd(r0, r1); ptab[4 * t + 3] = 0;
 		}
 		if (t < 405) { const int k = t - 202, m = pair_mag_class(iabs(k)), c = k < 0 ? 7 - m : 7 + m; tca[t] = (uint8_t)c; tcb[t] = (uint8_t)(16 * c); }
-		if (t == 0) { misc[0] = 0; misc[2] = 0; misc[3] = 0; }
+		if (t == 0) { misc[0] = 0; misc[2] = 0; misc[3] = 0; misc[8] = 0; }
 	}
 
+#ifdef NHW_DEV
+	long long tick_ = clock64();
+	unsigned acc_[14] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
 #pragma unroll 1
 	for (int b = -1; b < W / FI_BR; b++) {
-		const int r0 = FI_BR * b;                                     /* image row of luma index 0 */
+		const int r0 = FI_BR * b;
+		FI_TICK(0);                                     /* image row of luma index 0 */
 		/* ---------------------------------------------------------------- phase 0: the prefetched rows -> luma (and filtered chroma) in LDS */
 		if (SRC) {
+			const int t = opaque(t0);
 #pragma unroll
 			for (int it = 0; it < 2; it++) {
 				const int i = (t >> 5) + 16 * it, g = t & 31, row = r0 + 2 + i;
@@ -267,6 +313,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			}
 			if (t < 32) reinterpret_cast<uint4 *>(stg + 512)[t] = reinterpret_cast<const uint4 *>(crow)[t];   /* image row 32b+1, filtered by the band before */
 		} else {
+			const int t = opaque(t0);
 #pragma unroll
 			for (int it = 0; it < 4; it++) {
 				const int k = t + FI_NT * it, i = k >> 6, row = r0 + 2 + i;
@@ -275,10 +322,13 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 			}
 		}
+		FI_TICK(9);
 		__syncthreads();
-		FI_STAMP(1);
+		if (b >= 0 && b + 1 < W / FI_BR) issue(b + 1);                /* the next band's rows are on their way while this band is worked on */
+		FI_TICK(1); FI_STAMP(1);
 		/* ---------------------------------------------------------------- 4:2:0: vertical [1 2 1]/4 over image rows 2r-1, 2r, 2r+1 (colorspace.c:241-256) */
 		if (SRC) {
+			const int t = opaque(t0);
 			const int pl = t >> 8, rr = (t >> 4) & 15, c16 = t & 15, r = 16 * b + 1 + rr;   /* chroma rows 16b+1 .. 16b+16; the band before the first: row 0 */
 			if (b < 0 ? rr == 15 : r < H) {
 				const uint8_t *sp = stg + (2 * rr + 1) * 512 + pl * 256 + 16 * c16;
@@ -292,6 +342,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 		}
 		if (b < 0) {
 			/* rows 0 and 1 sit at luma index 32 and 33: move them to 0 and 1, ask for the first band's rows */
+			const int t = opaque(t0);
 			for (int k = t; k < 2 * FI_RD; k += FI_NT) { uint32_t *y = reinterpret_cast<uint32_t *>(ybuf); y[k] = y[32 * FI_RD + k]; }
 			issue(0);
 			__syncthreads();
@@ -300,11 +351,13 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 		const int last_row = r0 + FI_BR < W - 2 ? r0 + FI_BR : W - 2; /* last image row of this band with a kernel value */
 		if (PRE) {
 			__syncthreads();                                           /* the staging rows become the contrast map */
-			FI_STAMP(2);
+			FI_TICK(2); FI_STAMP(2);
 			/* ------------------------------------------------------------ contrast of image rows 32b+1 .. 32b+32, 8 pixels an item (image_processing.c:568-640).
 			 * The rows stay packed, two pixels to a dword (luma is never negative here).  The signed sum 9 x centre - block sum is packed
 			 * arithmetic on both pixels of a dword; a pixel's eight absolute differences are four v_sad_u16 against dwords that hold two
 			 * neighbours each.  Items are (row, group) with the row fastest: consecutive lanes sit a padded row apart, on consecutive banks. */
+			{
+			const int t = opaque(t0);
 #pragma unroll 1
 			for (int it = 0; it < 4; it++) {
 				const int k = t + FI_NT * it, rr = 1 + (k & 31), g = k >> 5;
@@ -319,8 +372,9 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 					const uint32_t T = pk_add16(S[K], __builtin_amdgcn_alignbit(S[K], S[K], 16));   /* both halves: the dword's two column sums */
 					const uint32_t wsum = pk_add16(T, pack_hl(S[K - 1], S[K + 1]));                  /* + the column on the left (low pixel) / right (high pixel) */
 					const s16x2 sum = as_s(as_w(as_us(M[K]) * (u16x2)(unsigned short)9)) - as_s(wsum);
-					const s16x2 sg = sum >> 15;
-					const u16x2 ab = as_us(as_w((s16x2)((sum ^ sg) - sg)));
+					const uint32_t sgw = pk_max_i16(pk_min_i16(as_w(sum), 0x00010001u), 0xFFFFFFFFu);   /* -1, 0, 1 */
+					const s16x2 sg = as_s(sgw);
+					const u16x2 ab = as_us(pk_mul_u16(as_w(sum), sgw));
 					uint32_t mag[2];
 #pragma unroll
 					for (int h = 0; h < 2; h++) {
@@ -331,8 +385,8 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 					}
 					if (K == 1 && g == 0) mag[0] = 0;                     /* column 0 has no kernel value, and what lies in front of the row is not luma: its sum must not spill into column 1's half */
 					const u16x2 base = ab * (u16x2)(unsigned short)15 + as_us(mag[0] | (mag[1] << 16));
-					const s16x2 vb = (as_s(as_w(base)) ^ sg) - sg;
-					out[K - 1] = as_w((u16x2)(as_us(as_w(vb)) * __builtin_elementwise_min(ab, (u16x2)(unsigned short)1)));   /* a zero sum gives no kernel value */
+					out[K - 1] = pk_mul_u16(as_w(base), sgw);               /* the sign of the sum; a zero sum gives no kernel value */
+					(void)sg;
 				}
 				if (g == 0) out[0] &= 0xFFFF0000u;                       /* columns 0 and 511 have none */
 				if (g == 63) out[3] &= 0x0000FFFFu;
@@ -340,8 +394,9 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3];
 			}
 			if (t < FI_RD) reinterpret_cast<uint32_t *>(ybuf + 34 * FI_RS)[t] = reinterpret_cast<const uint32_t *>(ybuf + 32 * FI_RS)[t];   /* the next band's contrast wants row 32b+32 as it is now */
+			}
 			__syncthreads();
-			FI_STAMP(3);
+			FI_TICK(3); FI_STAMP(3);
 			FI_DUMP(3, kbuf + 5 * FI_RS);
 			FI_DUMP(4, ybuf + FI_RS);
 			FI_DUMP(5, ybuf);
@@ -353,6 +408,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			 * whatever came before.  Where they do not (rare), the segments are replayed in order from the one before.  The band's first
 			 * segment continues from where the band before stopped. */
 			{
+				const int t = opaque(t0);
 				const int rr = 1 + (t & 31), sg = t >> 5;
 				int e = 0;
 				if (r0 + rr <= W - 2) {
@@ -370,7 +426,9 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 					}
 					entry[(rr - 1) * FI_NSEG + sg] = (uint8_t)e;
 				}
-				if (__syncthreads_or(e == 0xFF)) {
+				if (e == 0xFF) misc[8] = 1;                              /* (cleared again in the pair-rule phase) */
+				__syncthreads();
+				if (misc[8]) {
 					if (t == 0) {
 						for (int s = 1; s < (last_row - r0) * FI_NSEG; s++) {   /* raster order; segment 0 of the band is never open */
 							if (entry[s] != 0xFF) continue;
@@ -385,10 +443,11 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				}
 				if (stb && sg == 0 && r0 + rr <= W - 2) (stb + (size_t)img * s_stride)[r0 + rr] = entry[(rr - 1) * FI_NSEG];   /* compatibility mode replays a few rows from these */
 			}
-			FI_STAMP(4);
+			FI_TICK(4); FI_STAMP(4);
 			/* ------------------------------------------------------------ replay the carry: a lane per row and PAIR of segments (sp, sp + 8), side by side in the halves
 			 * of a dword, every step packed 16-bit arithmetic.  Eight pixels at a time through registers. */
-			if (t < 32 * (FI_NSEG / 2)) {
+			if (t0 < 32 * (FI_NSEG / 2)) {
+				const int t = opaque(t0);
 				const int rr = 1 + (t & 31), sp = t >> 5;
 				if (r0 + rr <= W - 2) {
 					int16_t *ka = kbuf + (rr + 4) * FI_RS + 1 + FI_SEG * sp, *kb = ka + 256;
@@ -406,7 +465,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 							const u16x2 acc = a + ((carry + (u16x2)(2)) >> 2);
 							const s16x2 o = __builtin_bit_cast(s16x2, (u16x2)(acc >> 4));
 							v[e] = (o ^ sgn) - sgn;
-							carry = (acc & (u16x2)(15)) * __builtin_elementwise_min(a, (u16x2)(1));
+							carry = as_us(pk_mul_u16(as_w((u16x2)(acc & (u16x2)(15))), pk_min_u16(as_w(a), 0x00010001u)));
 							if (e == 5) c29 = carry;                        /* in the last chunk: the state behind column 510 */
 						}
 #pragma unroll
@@ -416,12 +475,14 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				}
 			}
 			__syncthreads();
-			FI_STAMP(5);
+			FI_TICK(5); FI_STAMP(5);
 			FI_DUMP(2, kbuf + 5 * FI_RS);
 			/* ------------------------------------------------------------ pair rules (image_processing.c:810-837, 1927-1990): pixel pairs (1,2), (3,4) .. (509,510) of a row,
 			 * four pairs an item; a pair's deltas depend on its two kernel values and on a flag the pair before hands over -- which depends on
 			 * that pair's values only, so nothing is serial.  Class of a value, entry of a pair: table look-ups (see the fill above). */
-#pragma unroll 1
+			{
+			const int t = opaque(t0);
+#pragma unroll 2
 			for (int it = 0; it < 4; it++) {
 				const int k = t + FI_NT * it, rr = 1 + (k & 31), g = k >> 5;
 				if (r0 + rr > W - 2) continue;
@@ -453,6 +514,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 					flag = (int)*reinterpret_cast<const uint32_t *>(en + 8);
 					if (e == 2) flag2 = flag;
 				}
+				if (k == 0) misc[8] = 0;
 				if (g == 63) {                                           /* the last item's fourth pair would be (511, 512): no such pair; its third, (509, 510), hands the flag to the next row */
 					dl[3] = 0;
 					if (r0 + rr == last_row) misc[2 + (b & 1)] = (uint8_t)flag2;
@@ -465,14 +527,17 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				for (int j = 1; j < 4; j++) yo[j] = pk_add16(yo[j], pack_hl(dl[j - 1], dl[j]));
 				ys[8] = (int16_t)(ys[8] + (int16_t)(dl[3] >> 16));
 			}
+			}
 			__syncthreads();
-			FI_STAMP(6);
+			FI_TICK(6); FI_STAMP(6);
 			FI_DUMP(1, ybuf + FI_RS);
 		}
+		if (!PRE && SRC) __syncthreads();                              /* the staging rows become rows of the horizontal pass */
 		/* ---------------------------------------------------------------- horizontal pass (filters.c:346-386) of image rows 32b+1 .. 32b+32 (and row 0), four kx an item,
 		 * two outputs to a dword: L(k, k+1) = 6 E(k) + 2 (O(k-1) + O(k)) - (E(k-1) + E(k+1)), H(k, k+1) = 2 O(k) - (E(k) + E(k+1)) with
 		 * E(j) = (x[2j], x[2j+2]), O(j) = (x[2j+1], x[2j+3]) put together from the row's dwords (x[2j], x[2j+1]). */
 		{
+			const int t = opaque(t0);
 			const int top = r0 + FI_BR < W ? FI_BR : W - 1 - r0;       /* luma index of the band's last image row */
 			for (int k = t; k < (b == 0 ? 33 : 32) * 64; k += FI_NT) {
 				int rr, g;
@@ -500,9 +565,9 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			}
 		}
 		__syncthreads();
-		FI_STAMP(7);
-		/* ---------------------------------------------------------------- vertical pass + stores.  First the next band's rows are asked for. */
-		if (b + 1 < W / FI_BR) issue(b + 1);
+		FI_TICK(7); FI_STAMP(7);
+		/* ---------------------------------------------------------------- vertical pass + stores */
+		const int t = opaque(t0);
 		if (keepb && !(flags & 2)) {                                   /* q >= 22: transposed horizontal-pass plane, rows kx < 256 (wavelet_filterbank.c:107-112): image rows 32b .. 32b+31 */
 			int16_t *keep = keepb + (size_t)img * keep_stride;
 			for (int k = t; k < H * 4; k += FI_NT) {
@@ -516,6 +581,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				*reinterpret_cast<uint4 *>(keep + (size_t)kx * W + r0 + 8 * part) = make_uint4(v[0], v[1], v[2], v[3]);
 			}
 		}
+		FI_TICK(10);
 		uint32_t hold[3];                                              /* horizontal-pass rows 32b+28 .. 32b+32: the next band's first five */
 #pragma unroll
 		for (int e = 0; e < 3; e++) { const int k = t + FI_NT * e; if (k < 5 * FI_RD) hold[e] = reinterpret_cast<const uint32_t *>(kbuf + 32 * FI_RS)[k]; }
@@ -527,7 +593,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 		{
 			/* a thread takes a PAIR of columns (2cp, 2cp+1) -- the halves of one dword -- and eight of the band's output rows.  Columns below 256
 			 * (the low band of the horizontal pass) and the others take different rounding rules; a wavefront lies wholly on one side. */
-			const int cp = t & 255, kb = 8 * (t >> 8);
+			const int cp = t >> 1, kb = 8 * (t & 1);                    /* neighbouring lanes: the two halves of a column's 32 bytes */
 			auto vertical = [&](auto side) {
 				constexpr bool LEFT = decltype(side)::value;
 				uint32_t col[21];                                       /* col[i] = horizontal-pass row 32b - 4 + 2kb + i, symmetric extension x[-j] = x[j], x[511+j] = x[511-j] */
@@ -538,6 +604,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 					if (b == W / FI_BR - 1 && ri == 36) ri = 34;
 					col[i] = reinterpret_cast<const uint32_t *>(kbuf + ri * FI_RS)[cp];
 				}
+				FI_TICK(11);
 				uint32_t lo[8], hi[8];
 				s16x2 rprev = (s16x2)(short)0;
 				if (LEFT) rprev = as_s(col[2]) * (s16x2)(short)6 + ((as_s(col[1]) + as_s(col[3])) << 1) - (as_s(col[0]) + as_s(col[4]));
@@ -560,27 +627,38 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #undef XS
 					lo[kk] = as_w(l); hi[kk] = as_w(h);
 				}
+				FI_TICK(12);
 				/* the level-1 plane is kept transposed: column c is row c of it, eight output rows = 16 bytes */
 				int16_t *orow = proc + (size_t)(2 * cp) * W + 16 * b + kb;
+#ifdef NHW_DEV
+				if (!(flags & 4))
+#endif
+				{
 				*reinterpret_cast<uint4 *>(orow) = make_uint4(pack_lo(lo[0], lo[1]), pack_lo(lo[2], lo[3]), pack_lo(lo[4], lo[5]), pack_lo(lo[6], lo[7]));
 				*reinterpret_cast<uint4 *>(orow + W) = make_uint4(pack_hi(lo[0], lo[1]), pack_hi(lo[2], lo[3]), pack_hi(lo[4], lo[5]), pack_hi(lo[6], lo[7]));
 				*reinterpret_cast<uint4 *>(orow + H) = make_uint4(pack_lo(hi[0], hi[1]), pack_lo(hi[2], hi[3]), pack_lo(hi[4], hi[5]), pack_lo(hi[6], hi[7]));
 				*reinterpret_cast<uint4 *>(orow + W + H) = make_uint4(pack_hi(hi[0], hi[1]), pack_hi(hi[2], hi[3]), pack_hi(hi[4], hi[5]), pack_hi(hi[6], hi[7]));
+				}
+#ifdef NHW_DEV
+				if (!(flags & 8))
+#endif
 				if (LEFT) {                                            /* LL in natural orientation: jpeg[ky][kx] and ll1[ky][kx], kx < 256 (wavelet_filterbank.c:172-184, nhw_encoder.c:127-135) */
+					uint32_t *jp = reinterpret_cast<uint32_t *>(jpeg + (size_t)(16 * b + kb) * W) + cp, *lp = reinterpret_cast<uint32_t *>(ll1 + (size_t)(16 * b + kb) * H) + cp;
 #pragma unroll
-					for (int kk = 0; kk < 8; kk++) {
-						const int ky = 16 * b + kb + kk;
-						reinterpret_cast<uint32_t *>(jpeg + (size_t)ky * W)[cp] = lo[kk];
-						reinterpret_cast<uint32_t *>(ll1 + (size_t)ky * H)[cp] = lo[kk];
-					}
+					for (int kk = 0; kk < 8; kk++) { jp[kk * (W / 2)] = lo[kk]; lp[kk * (H / 2)] = lo[kk]; }
 				}
 			};
 			if (__builtin_amdgcn_readfirstlane(cp) < H / 2) vertical(std::true_type{}); else vertical(std::false_type{});
 		}
+		FI_TICK(13);
 		__syncthreads();
+		FI_TICK(8);
 #pragma unroll
 		for (int e = 0; e < 3; e++) { const int k = t + FI_NT * e; if (k < 5 * FI_RD) reinterpret_cast<uint32_t *>(kbuf)[k] = hold[e]; }
 	}
+#ifdef NHW_DEV
+	if ((flags & 0x10000) && t0 == 0) for (int i = 0; i < 14; i++) atomicAdd(&g_fi_prof[i], (unsigned long long)acc_[i]);
+#endif
 }
 
 } // namespace nhw

@@ -7,7 +7,7 @@ import torch
 import nhwcodec_amd
 
 Q = 65536
-BUFS = {"JPEG": (0, 8 * Q), "PROC": (1, 8 * Q), "LL1": (6, 2 * Q), "CJPEG": (4, 2 * Q), "CPROC": (5, 2 * Q)}
+BUFS = {"JPEG": (0, 8 * Q), "PROC": (1, 8 * Q), "LL1": (6, 2 * Q), "CJPEG": (4, 2 * Q), "CPROC": (5, 2 * Q), "PU": (2, Q), "PV": (3, Q)}
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 q = int(sys.argv[3]) if len(sys.argv) > 3 else 20
