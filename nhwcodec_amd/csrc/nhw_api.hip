@@ -193,7 +193,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		STAGE_DONE();
 		if (ws.compat) nhw_launch_low_stale(proc, ps, plane16(ws, B_STALE), ws.stride[B_STALE], n, s);   /* compatibility mode only: the map cells the stock binary's heap re-uses */
 		nhw_launch_front_fused(nullptr, q, nullptr, nullptr, 0, yin, yin_stride, 0, nullptr, 0, nullptr, 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
-		                       proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n, s, 0);
+		                       proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n, s, ws.dbg ? 2 : 0);
 	} else {
 		HIPCHK(hipEventRecord(e->ev[5], s)); HIPCHK(hipEventRecord(e->ev[6], s));   /* no kernels of their own for colour and pre-filter: both times 0 */
 		STAGE_DONE();
@@ -201,7 +201,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		nhw_launch_front_fused((const uint8_t *)d_bgr, q, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], yin, yin_stride /* developer builds only: a plane for a dump */, q < 22,
 		                       (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
 		                       plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2,
-		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s, e->front_fallback);
+		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s, (e->front_fallback & 1) | (ws.dbg ? 2 : 0));
 		if (ws.compat && q < 22) {   /* compatibility mode only: the kernel-map cells the stock binary's heap re-uses are replayed from a luma plane */
 			nhw_launch_color((const uint8_t *)d_bgr, n, q, yin, yin_stride, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
 			nhw_launch_front_stale(yin, yin_stride, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], plane16(ws, B_STALE), ws.stride[B_STALE], n, s);
@@ -341,6 +341,7 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
 	NhwWs ws = e->ws;
 	ws.n = n; ws.q = quality; ws.dbg = e->stop_after != 0;
+	e->timed = false;                                              /* set again only when a whole, un-stopped batch has recorded every event of nhw_timing */
 	const int parts = (e->stop_after || n < 512) ? 1 : e->parts;
 	if (parts == 1) {
 		const int rc = run_batch(e, ws, d_bgr, n, quality, d_out, d_sizes, d_status, s, 1);
@@ -527,7 +528,7 @@ extern "C" int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_
 		/* the band kernel reads rows that other bands of the same image overwrite with LL rows: its input is a plane of its own */
 		HIPCHK(hipMemcpy2DAsync(plane16(ws, B_KMAP), ws.stride[B_KMAP], d_jpeg, plane_stride * 2, 8 * Q, (size_t)n_img, hipMemcpyDeviceToDevice, s));
 		nhw_launch_front_fused(nullptr, 20, nullptr, nullptr, 0, plane16(ws, B_KMAP), ws.stride[B_KMAP], 0, nullptr, 0, nullptr, 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
-		                       (int16_t *)d_proc, (int16_t *)d_jpeg, plane_stride, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n_img, s, 0);
+		                       (int16_t *)d_proc, (int16_t *)d_jpeg, plane_stride, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n_img, s, 2);
 	} else if (size == 256 || size == 128)
 		nhw_launch_analysis((int16_t *)d_jpeg, (int16_t *)d_proc, n_img, plane_stride, stride, size, final_level, nullptr, 0, s);
 	else { g_err = "transform size must be 512, 256 or 128"; return NHW_E_ARG; }

@@ -962,7 +962,7 @@ int nhw_front_set_attrs(const char **where)
 	const size_t band = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
 	SETATTR((k_front_band<0, 0, 0>), band); SETATTR((k_front_band<0, 1, 0>), band); SETATTR((k_front_band<1, 1, 0>), band);
 	SETATTR((k_front_band<1, 1, 1>), band); SETATTR((k_front_band<1, 1, 2>), band);
-	SETATTR((k_front_image<0, 0, 0>), FI_LDS_BYTES); SETATTR((k_front_image<0, 1, 0>), FI_LDS_BYTES); SETATTR((k_front_image<1, 1, 0>), FI_LDS_BYTES);
+	SETATTR((k_front_plain<0, 0>), FP_LDS_BYTES); SETATTR((k_front_plain<1, 0>), FP_LDS_BYTES); SETATTR((k_front_image<1, 1, 0>), FI_LDS_BYTES);
 	SETATTR((k_front_image<1, 1, 1>), FI_LDS_BYTES); SETATTR((k_front_image<1, 1, 2>), FI_LDS_BYTES);
 	SETATTR(k_dwt_ana<256>, 256 * 258 * sizeof(int16_t)); SETATTR(k_dwt_syn<256>, 256 * 258 * sizeof(int16_t));
 	SETATTR(k_dwt_ana<128>, 128 * 130 * sizeof(int16_t)); SETATTR(k_dwt_syn<128>, 128 * 130 * sizeof(int16_t));
@@ -1010,7 +1010,7 @@ void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv,
 	if (!use_old) {
 		int fam = 0;
 		const float yq = bgr ? color_yq(q, &fam) : 0.f;
-		int fl = force_fallback & 1;
+		int fl = (force_fallback & 1) | ((force_fallback & 2) ? 0x100000 : 0);   /* bit 1 of the caller's switches: a stage check reads every plane */
 #ifdef NHW_DEV
 		{ const char *e = getenv("NHW_BAND_STOP"); if (e) fl |= atoi(e) << 8; }
 		if (getenv("NHW_FRONT_PROF")) fl |= 0x10000;
@@ -1018,8 +1018,10 @@ void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv,
 		if (getenv("NHW_FRONT_DUMP") && y && bgr && with_prefilter) { fl |= 2 | (atoi(getenv("NHW_FRONT_DUMP")) << 4); keep = const_cast<int16_t *>(y); keep_stride = y_stride / 2; }
 #endif
 #define FI_ARGS(srcp, sstride) srcp, sstride, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, fl
-		if (!bgr) k_front_image<0, 0, 0><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)y, y_stride));
-		else if (!with_prefilter) k_front_image<0, 1, 0><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
+#define FP_ARGS(srcp, sstride) srcp, sstride, yq, pu, pv, c_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, fl
+		if (!bgr) k_front_plain<0, 0><<<n, FI_NT, FP_LDS_BYTES, s>>>(FP_ARGS((const void *)y, y_stride));
+		else if (!with_prefilter) k_front_plain<1, 0><<<n, FI_NT, FP_LDS_BYTES, s>>>(FP_ARGS((const void *)bgr, (size_t)0));
+#undef FP_ARGS
 		else if (fam == 0) k_front_image<1, 1, 0><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
 		else if (fam == 1) k_front_image<1, 1, 1><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
 		else k_front_image<1, 1, 2><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));

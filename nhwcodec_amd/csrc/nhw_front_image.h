@@ -634,10 +634,13 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				if (!(flags & 4))
 #endif
 				{
-				*reinterpret_cast<uint4 *>(orow) = make_uint4(pack_lo(lo[0], lo[1]), pack_lo(lo[2], lo[3]), pack_lo(lo[4], lo[5]), pack_lo(lo[6], lo[7]));
-				*reinterpret_cast<uint4 *>(orow + W) = make_uint4(pack_hi(lo[0], lo[1]), pack_hi(lo[2], lo[3]), pack_hi(lo[4], lo[5]), pack_hi(lo[6], lo[7]));
-				*reinterpret_cast<uint4 *>(orow + H) = make_uint4(pack_lo(hi[0], hi[1]), pack_lo(hi[2], hi[3]), pack_lo(hi[4], hi[5]), pack_lo(hi[6], hi[7]));
-				*reinterpret_cast<uint4 *>(orow + W + H) = make_uint4(pack_hi(hi[0], hi[1]), pack_hi(hi[2], hi[3]), pack_hi(hi[4], hi[5]), pack_hi(hi[6], hi[7]));
+				auto st16 = [&](int16_t *p, uint32_t a, uint32_t b_, uint32_t c, uint32_t d) { *reinterpret_cast<uint4 *>(p) = make_uint4(a, b_, c, d); };
+				if (!LEFT || (flags & 0x100000)) {                       /* the LL quadrant of the transposed plane: the level-2 analysis writes all of it, nothing reads it before (stored for the stage checks only) */
+					st16(orow, pack_lo(lo[0], lo[1]), pack_lo(lo[2], lo[3]), pack_lo(lo[4], lo[5]), pack_lo(lo[6], lo[7]));
+					st16(orow + W, pack_hi(lo[0], lo[1]), pack_hi(lo[2], lo[3]), pack_hi(lo[4], lo[5]), pack_hi(lo[6], lo[7]));
+				}
+				st16(orow + H, pack_lo(hi[0], hi[1]), pack_lo(hi[2], hi[3]), pack_lo(hi[4], hi[5]), pack_lo(hi[6], hi[7]));
+				st16(orow + W + H, pack_hi(hi[0], hi[1]), pack_hi(hi[2], hi[3]), pack_hi(hi[4], hi[5]), pack_hi(hi[6], hi[7]));
 				}
 #ifdef NHW_DEV
 				if (!(flags & 8))
@@ -659,6 +662,223 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #ifdef NHW_DEV
 	if ((flags & 0x10000) && t0 == 0) for (int i = 0; i < 14; i++) atomicAdd(&g_fi_prof[i], (unsigned long long)acc_[i]);
 #endif
+}
+
+
+/* ------------------------------------------------------------------------------------------------
+ * The front WITHOUT the pre-filter of quality 17..21: quality 22 / 23 from the BGR bytes (SRC 1), quality 1..16 and the analysis stage from a
+ * luma plane (SRC 0).  Nothing needs a row of luma twice then: the horizontal pass runs in phase 0 straight from the registers the colour
+ * conversion left the row in (the two neighbours' edge pixels come over the lanes), so there is no luma buffer and no horizontal phase, and
+ * the LDS that frees holds 64 image rows of the horizontal pass instead of 32: the vertical pass makes 32 output rows a time, a column's
+ * run in the transposed level-1 plane is 64 bytes (two neighbouring lanes) instead of 32, the rows kept for quality >= 22 go out as whole
+ * 128-byte lines, and an image costs 34 barriers instead of 150.
+ * A step takes 32 image rows, 32s+1 .. 32s+32 (row 0 comes with a step of its own before the first: s = -1), a thread two neighbouring rows
+ * of a group of 16 pixels.  4:2:0: chroma row m needs image rows 2m-1, 2m, 2m+1 = a thread's two rows and the first row of the thread below;
+ * the first rows go through LDS, the last thread's pair waits there for the next step.
+ * ------------------------------------------------------------------------------------------------ */
+#define FP_RS     512                 /* LDS row stride in shorts: rows are written 16 bytes a lane, columns read a dword a lane -- no padding needed */
+#define FP_HROWS  69                  /* horizontal-pass rows 64B-4 .. 64B+64 (index = row - 64B + 4) */
+#define FP_STG_OFF (FP_HROWS * FP_RS * 2)
+#define FP_LDS_BYTES (FP_STG_OFF + 19 * 512)   /* filtered chroma of the threads' first rows (slots 0..14: threads 1..15), two pairs of rows of the last thread (slots 15..18) */
+static_assert(FP_LDS_BYTES <= 81920, "two workgroups to a CU");
+
+/* the horizontal pass (filters.c:346-386) of 16 pixels: X[0] = (x[-2], x[-1]), X[1..8] = the row's dwords, X[9] = (x[16], .) -> four dwords of the low band, four of the high */
+__device__ __forceinline__ void hp16(const uint32_t X[10], uint32_t L[4], uint32_t Hh[4])
+{
+	uint32_t E[9], O[8];
+#pragma unroll
+	for (int j = 0; j < 9; j++) E[j] = pack_lo(X[j], X[j + 1]);     /* (x[2j-2], x[2j]) */
+#pragma unroll
+	for (int j = 0; j < 8; j++) O[j] = pack_hi(X[j], X[j + 1]);     /* (x[2j-1], x[2j+1]) */
+#pragma unroll
+	for (int p = 0; p < 4; p++) {                                    /* outputs 2p, 2p+1 */
+		const s16x2 e0 = as_s(E[2 * p]), e1 = as_s(E[2 * p + 1]), e2 = as_s(E[2 * p + 2]), o0 = as_s(O[2 * p]), o1 = as_s(O[2 * p + 1]);
+		L[p] = as_w((s16x2)(e1 * (s16x2)(short)6 + ((o0 + o1) << 1) - (e0 + e2)));
+		Hh[p] = as_w((s16x2)((o1 << 1) - (e1 + e2)));
+	}
+}
+
+template <int SRC, int FAMILY>
+__global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_front_plain(const void *__restrict__ srcb, size_t src_stride, float yq, uint8_t *__restrict__ pub, uint8_t *__restrict__ pvb, size_t c_stride,
+                                                     int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
+                                                     int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride, int flags)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	int16_t *const hbuf = reinterpret_cast<int16_t *>(lds);
+	uint8_t *const stg = lds + FP_STG_OFF;
+	const int t0 = threadIdx.x, img = blockIdx.x;
+	const uint8_t *const src = (const uint8_t *)srcb + (size_t)img * (SRC ? (size_t)(W * W * 3) : src_stride);
+	int16_t *const proc = procb + (size_t)img * plane_stride, *const jpeg = jpegb + (size_t)img * plane_stride;
+	int16_t *const ll1 = ll1b + (size_t)img * ll1_stride;
+
+	constexpr int NPF = SRC ? 6 : 4;
+	uint4 pf[NPF];
+	auto issue = [&](int s) {                                       /* image rows 32s+1+2j, 32s+2+2j of the thread's group of 16 pixels */
+		const int t = opaque(t0), g = t & 31, j = t >> 5;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int row = 32 * s + 1 + 2 * j + h;
+			if (row < 0 || row >= W) continue;
+			if (SRC) {
+				const uint4 *rp = reinterpret_cast<const uint4 *>(src + (size_t)row * (W * 3) + 48 * g);
+				pf[3 * h] = rp[0]; pf[3 * h + 1] = rp[1]; pf[3 * h + 2] = rp[2];
+			} else {
+				const uint4 *rp = reinterpret_cast<const uint4 *>(reinterpret_cast<const int16_t *>(src) + (size_t)row * W + 16 * g);
+				pf[2 * h] = rp[0]; pf[2 * h + 1] = rp[1];
+			}
+		}
+	};
+	issue(-1);
+#pragma unroll 1
+	for (int s = -1; s < W / 32; s++) {
+		const int B = s < 0 ? 0 : s >> 1;                            /* the 64-row band the step belongs to */
+		uint2 cu[2], cv[2];                                          /* the thread's two rows of horizontally filtered chroma */
+		{
+			const int t = opaque(t0), g = t & 31, j = t >> 5;
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const int row = 32 * s + 1 + 2 * j + h;
+				const bool live = row >= 0 && row < W;
+				uint32_t X[10], uw[4] = { 0, 0, 0, 0 }, vw[4] = { 0, 0, 0, 0 };
+				if (live) {
+					if (SRC) {
+						const uint32_t wv[12] = { pf[3 * h].x, pf[3 * h].y, pf[3 * h].z, pf[3 * h].w, pf[3 * h + 1].x, pf[3 * h + 1].y, pf[3 * h + 1].z, pf[3 * h + 1].w,
+						                          pf[3 * h + 2].x, pf[3 * h + 2].y, pf[3 * h + 2].z, pf[3 * h + 2].w };
+						convert16<FAMILY>(wv, yq, X + 1, uw, vw, true);
+					} else {
+						X[1] = pf[2 * h].x; X[2] = pf[2 * h].y; X[3] = pf[2 * h].z; X[4] = pf[2 * h].w; X[5] = pf[2 * h + 1].x; X[6] = pf[2 * h + 1].y; X[7] = pf[2 * h + 1].z; X[8] = pf[2 * h + 1].w;
+					}
+				} else {
+#pragma unroll
+					for (int e = 1; e < 9; e++) X[e] = 0;
+				}
+				/* the neighbours' edge pixels come over the lanes (every lane takes part); the ends of the row are mirrored: x[-2] = x[2], x[-1] = x[1], x[512] = x[510] */
+				X[0] = (uint32_t)__shfl_up((int)X[8], 1);
+				X[9] = (uint32_t)__shfl_down((int)X[1], 1);
+				if (g == 0) X[0] = __builtin_amdgcn_perm(X[1], X[2], 0x07060100u);
+				if (g == 31) X[9] = X[8];
+				if (SRC) {
+					uint32_t lu = (uint32_t)__shfl_up((int)uw[3], 1), lv = (uint32_t)__shfl_up((int)vw[3], 1);
+					if (g == 0) { lu = uw[0] << 16; lv = vw[0] << 16; }
+					cu[h] = chroma_h8(uw, lu); cv[h] = chroma_h8(vw, lv);
+				}
+				if (live) {
+					uint32_t L[4], Hh[4];
+					hp16(X, L, Hh);
+					int16_t *hr = hbuf + (row - 64 * B + 4) * FP_RS + 8 * g;
+					*reinterpret_cast<uint4 *>(hr) = make_uint4(L[0], L[1], L[2], L[3]);
+					*reinterpret_cast<uint4 *>(hr + H) = make_uint4(Hh[0], Hh[1], Hh[2], Hh[3]);
+				}
+			}
+			if (SRC) {
+				/* slot of a first row: thread j - 1 finds it; the last thread leaves both its rows for the next step (two pairs, taken in turns) */
+				if (j) { *reinterpret_cast<uint2 *>(stg + (j - 1) * 512 + 8 * g) = cu[0]; *reinterpret_cast<uint2 *>(stg + (j - 1) * 512 + 256 + 8 * g) = cv[0]; }
+				if (j == 15) {
+					uint8_t *kp = stg + (15 + 2 * (s & 1)) * 512;
+					*reinterpret_cast<uint2 *>(kp + 8 * g) = cu[0]; *reinterpret_cast<uint2 *>(kp + 256 + 8 * g) = cv[0];
+					*reinterpret_cast<uint2 *>(kp + 512 + 8 * g) = cu[1]; *reinterpret_cast<uint2 *>(kp + 768 + 8 * g) = cv[1];
+				}
+			}
+		}
+		if (SRC || (s & 1)) __syncthreads();
+		if (s + 1 < W / 32) issue(s + 1);
+		if (SRC && s >= 0) {
+			/* 4:2:0 (colorspace.c:241-256): chroma row m = 16s+1+j from the thread's rows 2m-1, 2m and the first row of the thread below; the first
+			 * thread also makes row 16s, which waited for its third row (row 0: (r0 + r1 + 1) >> 1 of image rows 0 and 1) */
+			const int t = opaque(t0), g = t & 31, j = t >> 5, m = 16 * s + 1 + j;
+			uint8_t *pu = pub + (size_t)img * c_stride, *pv = pvb + (size_t)img * c_stride;
+			if (j < 15 && m < H) {
+				const uint2 nu = *reinterpret_cast<const uint2 *>(stg + j * 512 + 8 * g), nv = *reinterpret_cast<const uint2 *>(stg + j * 512 + 256 + 8 * g);
+				*reinterpret_cast<uint2 *>(pu + m * H + 8 * g) = make_uint2(tri121(cu[0].x, cu[1].x, nu.x), tri121(cu[0].y, cu[1].y, nu.y));
+				*reinterpret_cast<uint2 *>(pv + m * H + 8 * g) = make_uint2(tri121(cv[0].x, cv[1].x, nv.x), tri121(cv[0].y, cv[1].y, nv.y));
+			}
+			if (j == 0) {
+				const uint8_t *kp = stg + (15 + 2 * ((s + 1) & 1)) * 512;   /* what the step before left */
+				const uint2 au = *reinterpret_cast<const uint2 *>(kp + 8 * g), av = *reinterpret_cast<const uint2 *>(kp + 256 + 8 * g);
+				const uint2 bu = *reinterpret_cast<const uint2 *>(kp + 512 + 8 * g), bv = *reinterpret_cast<const uint2 *>(kp + 768 + 8 * g);
+				uint2 ou, ov;
+				if (s == 0) { ou = make_uint2(avg_up(bu.x, cu[0].x), avg_up(bu.y, cu[0].y)); ov = make_uint2(avg_up(bv.x, cv[0].x), avg_up(bv.y, cv[0].y)); }
+				else { ou = make_uint2(tri121(au.x, bu.x, cu[0].x), tri121(au.y, bu.y, cu[0].y)); ov = make_uint2(tri121(av.x, bv.x, cv[0].x), tri121(av.y, bv.y, cv[0].y)); }
+				*reinterpret_cast<uint2 *>(pu + 16 * s * H + 8 * g) = ou;
+				*reinterpret_cast<uint2 *>(pv + 16 * s * H + 8 * g) = ov;
+			}
+		}
+		if (s > 0 && (s & 1)) {
+			/* ------------------------------------------------------------ vertical pass of the band's 32 output rows: a thread takes a pair of columns and 16 of them */
+			const int t = opaque(t0);
+			if (keepb) {                                               /* q >= 22: transposed horizontal-pass plane, rows kx < 256 (wavelet_filterbank.c:107-112): image rows 64B .. 64B+63, whole lines */
+				int16_t *keep = keepb + (size_t)img * keep_stride;
+				const int kx = t >> 1, part = t & 1;
+				uint32_t v[16];
+#pragma unroll
+				for (int e = 0; e < 16; e++) {
+					const int ri = 4 + 32 * part + 2 * e;
+					v[e] = (uint16_t)hbuf[ri * FP_RS + kx] | ((uint32_t)(uint16_t)hbuf[(ri + 1) * FP_RS + kx] << 16);
+				}
+				uint4 *kd = reinterpret_cast<uint4 *>(keep + (size_t)kx * W + 64 * B + 32 * part);
+#pragma unroll
+				for (int e = 0; e < 4; e++) kd[e] = make_uint4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+			}
+			uint32_t hold[3];                                          /* horizontal-pass rows 64B+60 .. 64B+64: the next band's first five */
+#pragma unroll
+			for (int e = 0; e < 3; e++) { const int k = t + FI_NT * e; if (k < 5 * (FP_RS / 2)) hold[e] = reinterpret_cast<const uint32_t *>(hbuf + 64 * FP_RS)[k]; }
+			const int cp = t >> 1, kb = 16 * (t & 1);
+			auto vertical = [&](auto side) {
+				constexpr bool LEFT = decltype(side)::value;
+				int16_t *orow = proc + (size_t)(2 * cp) * W + 32 * B + kb;
+				uint32_t *jp = reinterpret_cast<uint32_t *>(jpeg + (size_t)(32 * B + kb) * W) + cp, *lp = reinterpret_cast<uint32_t *>(ll1 + (size_t)(32 * B + kb) * H) + cp;
+				s16x2 rprev = (s16x2)(short)0;
+#pragma unroll
+				for (int part = 0; part < 2; part++) {                   /* eight output rows at a time */
+					uint32_t col[21];                                   /* col[i] = horizontal-pass row 64B - 4 + 2 (kb + 8 part) + i, symmetric extension at both ends of the image */
+#pragma unroll
+					for (int i = 0; i < 21; i++) {
+						int ri = 2 * (kb + 8 * part) + i;
+						if (B == 0 && ri < 4) ri = 8 - ri;
+						if (B == W / 64 - 1 && ri == 68) ri = 66;
+						col[i] = reinterpret_cast<const uint32_t *>(hbuf + ri * FP_RS)[cp];
+					}
+					uint32_t lo[8], hi[8];
+					if (LEFT && part == 0) rprev = as_s(col[2]) * (s16x2)(short)6 + ((as_s(col[1]) + as_s(col[3])) << 1) - (as_s(col[0]) + as_s(col[4]));
+#pragma unroll
+					for (int kk = 0; kk < 8; kk++) {
+#define XS(d) as_s(col[2 * kk + 4 + (d)])
+						const s16x2 r = XS(0) * (s16x2)(short)6 + ((XS(-1) + XS(1)) << 1) - (XS(-2) + XS(2));
+						s16x2 l, h;
+						if (LEFT) {                                    /* filters.c:203-287 */
+							s16x2 carry = pk_diffuse(rprev);
+							if (part == 0 && kk == 0 && B == 0 && kb == 0) carry = (s16x2)(short)0;
+							l = pk_rnd_half_away(r + carry, 6);
+							rprev = r;
+						} else l = pk_rnd_half_away(r, 4);             /* filters.c:88-113 */
+						s16x2 a = XS(0) + XS(2);
+						if (kk & 1) a = a + (a & (XS(-2) + XS(0)) & (s16x2)(short)1);
+						const s16x2 pr = XS(1) - (a >> 1);
+						h = pk_rnd_half_away(pr, LEFT ? 3 : 1);
+						if (part == 1 && kk == 7 && B == W / 64 - 1 && kb == 16) { const s16x2 dd = XS(1) - XS(0); h = LEFT ? dd >> 3 : (dd + (s16x2)(short)1) >> 1; }   /* ky = 255 */
+#undef XS
+						lo[kk] = as_w(l); hi[kk] = as_w(h);
+					}
+					auto st16 = [&](int16_t *p, uint32_t a, uint32_t b_, uint32_t c, uint32_t d) { *reinterpret_cast<uint4 *>(p) = make_uint4(a, b_, c, d); };
+					int16_t *op = orow + 8 * part;
+					if (!LEFT || (flags & 0x100000)) {                   /* the LL quadrant of the transposed plane: the level-2 analysis writes all of it, nothing reads it before (stored for the stage checks only) */
+						st16(op, pack_lo(lo[0], lo[1]), pack_lo(lo[2], lo[3]), pack_lo(lo[4], lo[5]), pack_lo(lo[6], lo[7]));
+						st16(op + W, pack_hi(lo[0], lo[1]), pack_hi(lo[2], lo[3]), pack_hi(lo[4], lo[5]), pack_hi(lo[6], lo[7]));
+					}
+					st16(op + H, pack_lo(hi[0], hi[1]), pack_lo(hi[2], hi[3]), pack_lo(hi[4], hi[5]), pack_lo(hi[6], hi[7]));
+					st16(op + W + H, pack_hi(hi[0], hi[1]), pack_hi(hi[2], hi[3]), pack_hi(hi[4], hi[5]), pack_hi(hi[6], hi[7]));
+					if (LEFT) {
+#pragma unroll
+						for (int kk = 0; kk < 8; kk++) { jp[(8 * part + kk) * (W / 2)] = lo[kk]; lp[(8 * part + kk) * (H / 2)] = lo[kk]; }
+					}
+				}
+			};
+			if (__builtin_amdgcn_readfirstlane(cp) < H / 2) vertical(std::true_type{}); else vertical(std::false_type{});
+			__syncthreads();
+#pragma unroll
+			for (int e = 0; e < 3; e++) { const int k = t + FI_NT * e; if (k < 5 * (FP_RS / 2)) reinterpret_cast<uint32_t *>(hbuf)[k] = hold[e]; }
+		} else if (SRC) __syncthreads();                               /* the chroma slots are free for the next step */
+	}
 }
 
 } // namespace nhw

@@ -1003,11 +1003,7 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 	int16_t *p = procb + (size_t)blockIdx.x * plane_stride;
 	const int tid = threadIdx.x, lane = tid & 63;                  /* four wavefronts: the row walks take a thread per row (128 rows), the clearing of children all 256; the two skewed raster walks stay one wavefront */
 
-#ifdef NHW_EXP_LL2_A
-	if (0) {
-#else
 	if (q <= 11) {
-#endif
 		/* Y11 (:285-309): rows are independent, a thread walks one of them -- through LDS, 64 columns of all 128 rows at a time (a lane on
 		 * "its" row of the plane reads one cell of a different line at every step); what the walk carries from tile to tile is the
 		 * updated left neighbour. */
@@ -1061,11 +1057,7 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 	/* `last`: the reference's `count` variable as the third walk finds it (:571-579 use it without having set it when the inner test fails):
 	 * -1 = still IM_SIZE (no hit so far), otherwise an LL2 cell index */
 	int any1 = 0;
-#ifdef NHW_EXP_LL2_B
-	for (int r = LS; r < LS; r += LL2_NT) {
-#else
 	for (int r = tid; r < LS; r += LL2_NT) {                       /* five cells in a row (:383-486), in place along the row */
-#endif
 		int16_t *row = ll + r * LP;
 		int v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
 		for (int j = 0; j < LS - 4; j++) {
@@ -1106,11 +1098,7 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 	 * a cell that passes only the outer test marks the target of the hit before it -- marked already -- or, before the first hit of the
 	 * second walk, what the first walk left: its last hit's target, else the 4 / IM_SIZE of the row pass above. */
 	int last0 = last;                                              /* `count` as the second walk finds it */
-#ifdef NHW_EXP_LL2_C
-	if (0)
-#else
 	if (tid < 64)
-#endif
 	for (int pass = 0; pass < 2; pass++) {
 		int hit_max = -1, hit_min = 1 << 30, outer_min = 1 << 30;    /* visiting positions r * LS + j */
 		for (int r0 = 0; r0 < LS - 2; r0 += 64) {
@@ -1153,11 +1141,7 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 		}
 	}
 	__syncthreads();
-#ifdef NHW_EXP_LL2_D
-	if (0)
-#else
 	if (deep)
-#endif
 		for (int r = tid; r < LS; r += LL2_NT) {                   /* three flat cells in a row (:585-620): reads only */
 			const int16_t *row = ll + r * LP;
 			for (int j = 0; j < LS - 2; j++)
@@ -1170,11 +1154,7 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 	}
 	/* the children / siblings of the cells that were hit are cleared where they are small.  All loads of a cell's up to fifteen targets
 	 * are issued before the first store (one memory round trip per cell instead of fifteen in a row: this loop was most of the kernel). */
-#ifdef NHW_EXP_LL2_E
-	for (int cell = LS * LS; cell < LS * LS; cell += LL2_NT) {
-#else
 	for (int cell = tid; cell < LS * LS; cell += LL2_NT) {
-#endif
 		const int w = cell >> 5;
 		const uint32_t bit = 1u << (cell & 31);
 		const int limc = (t5 == 36 && (h36[w] & bit)) ? 36 : (h34[w] & bit) ? 34 : (h32[w] & bit) ? 32 : 0;   /* (thrx5 34: h36 is h34) */

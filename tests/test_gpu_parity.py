@@ -96,8 +96,8 @@ def test_colour_exhaustive_all_2_24_triples(enc, oracle, q):
 @pytest.mark.gpu
 @pytest.mark.parametrize("q", [1, 6, 7, 8, 9, 10, 14, 16])
 def test_prefilter_matches_oracle(enc, oracle, q):
-    """The pre-filter is a stage of its own for quality 1..16 (k_low_prefilter, the kernel the encoder runs); for 17..21 it lives inside
-    the fused front kernel (test_fused_front_matches_oracle)."""
+    """The pre-filter is a stage of its own for quality 1..16 (k_low_machine + k_low_marks + the chroma pass, the kernels the encoder runs,
+    behind nhw_stage_prefilter); for 17..21 it lives inside the fused front kernel k_front_image (test_fused_front_matches_oracle)."""
     import torch
     imgs = [oracle.synth(3), class_image("noise", 1), class_image("blocks", 2), class_image("flat")]
     ys = np.stack([oracle.color(im, q)[0] for im in imgs])
@@ -422,8 +422,8 @@ def test_compat_mode_matches_oracle_and_stock_binary(oracle, q):
 @pytest.mark.parametrize("q", [17, 20, 21])
 def test_front_fallback_paths_are_exact(oracle, q):
     """The pre-filter's carry normally comes from a short look-back (its 16 states merge within a dozen pixels); where they have not merged, a
-    row is walked in full (k_front_rowtail) and a segment is replayed from the one before (k_front_band).  Those paths are rare on real
-    content, so a debug switch sends every row and every segment down them: the output must not change."""
+    segment is replayed from the one before it, in raster order across the rows of a band (k_front_image).  That path is rare on real
+    content, so a debug switch sends every segment down it: the output must not change."""
     import nhwcodec_amd
     enc = nhwcodec_amd.Encoder(0, 32)
     imgs = np.stack([oracle.synth(40 + i) for i in range(20)] + [class_image(k, s) for k in ("noise", "blocks", "tiles", "gradient") for s in (1, 2)])
