@@ -22,9 +22,8 @@ void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stri
 void nhw_launch_l2_recon(int16_t *jpeg, const int16_t *proc, size_t plane_stride, int16_t *ll1, size_t ll1_stride, int n, hipStream_t s);
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
 void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv, size_t c_stride, const int16_t *y, size_t y_stride, int with_prefilter,
-                            uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
                             uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
-                            int16_t *keep, size_t keep_stride, int n, hipStream_t s, int force_fallback);
+                            int16_t *keep, size_t keep_stride, int n, hipStream_t s, int switches);
 void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t *sizes, int32_t *status, hipStream_t s);
 void nhw_launch_front_stale(const int16_t *y, size_t y_stride, const uint8_t *st, size_t s_stride, int16_t *stale, size_t stale_stride, int n, hipStream_t s);
 void nhw_launch_low_stale(const int16_t *km, size_t km_stride, int16_t *stale, size_t stale_stride, int n, hipStream_t s);
@@ -69,13 +68,13 @@ struct nhw_enc {
 static const size_t k_buf_bytes[B_COUNT] = {
 	/* JPEG   */ 8 * Q, /* PROC */ 8 * Q, /* PU */ Q, /* PV */ Q, /* CJPEG */ 2 * Q, /* CPROC */ 2 * Q,
 	/* LL1    */ 2 * Q, /* L2SAVE */ 2 * Q, /* CLL1 */ Q / 2, /* CL2SAVE */ Q / 2, /* KEEP */ 4 * Q, /* FIRST */ 2 * Q,
-	/* BAND   */ 2 * Q, /* HS */ 4 * Q + 256, /* KMAP */ 8 * Q, /* ROWMAP */ 512 * 16, /* ROWSTATE */ 512, /* SCAN */ 6 * Q,
+	/* BAND   */ 2 * Q, /* HS */ 4 * Q + 256, /* KMAP */ 8 * Q, /* ROWMAP (unused) */ 16, /* ROWSTATE */ 512, /* SCAN */ 6 * Q,
 	/* LLBYTES*/ 24832, /* LLFULL */ 16384, /* EXW */ 16384 + 256, /* LLCOMP */ 32768, /* LLWORD */ 16384, /* LLMEM */ 32768,
 	/* RES4   */ 8192, /* RAW */ 2 * Q + 1024, /* PAY */ 2 * Q + 256, /* CC */ 2 * Q + 1024, /* HALF */ 2 * Q + 1024, /* TMP16 */ Q / 2,
 	/* R1     */ Q + 64, 8192 + 64, 16384 + 64, /* R3 */ Q + 64, 8192 + 64, 16384 + 64, /* R5 */ Q + 64, 8192 + 64, 16384 + 64,
 	/* R6     */ 2 * Q + 1024, 16384 + 64, 16384 + 64, /* CHARRES */ 2048 + 64, /* QSET3 */ 8 * Q + 64,
 	/* RESU64 */ 512, /* RESV64 */ 512, /* PACKET */ 320000, /* BOOK1 */ 768, /* BOOK2 */ 768, /* SEL1 */ 16384 + 64, /* SEL2 */ 16384 + 64,
-	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512, /* ROWFLAG */ 1024, /* SEGMAP (unused) */ 16, /* STALE */ (8 + 9 * 512) * 2
+	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512, /* ROWFLAG (unused) */ 16, /* SEGMAP (unused) */ 16, /* STALE */ (8 + 9 * 512) * 2
 };
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -180,8 +179,8 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	if (what & 1) {
 	if (timed == 1) HIPCHK(hipEventRecord(e->ev[0], s));
 	/* a1 + a2 + Y2 + Y3: colour + 4:2:0, pre-filter (q<=21, nhw_encoder.c:116-119), level-1 analysis (:125), LL1 copy (:127-135): ONE kernel
-	 * for quality 17..23 (k_front_band; for q 17..21 behind the two small kernels that hand every row its carry state).  The luma plane
-	 * never reaches HBM.  Quality 1..16: colour kernel -> luma plane, the rationed pre-filter (nhw_low.hip) -> the band kernel's input plane. */
+	 * for quality 17..23 (k_front_image with the pre-filter, k_front_plain without: a workgroup walks an image top to bottom).  The luma plane
+	 * never reaches HBM.  Quality 1..16: colour kernel -> luma plane, the rationed pre-filter (nhw_low.hip) -> k_front_plain's input plane. */
 	int16_t *yin = plane16(ws, B_KMAP);
 	const size_t yin_stride = ws.stride[B_KMAP];
 	if (low) {
@@ -192,14 +191,13 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		HIPCHK(hipEventRecord(e->ev[6], s));
 		STAGE_DONE();
 		if (ws.compat) nhw_launch_low_stale(proc, ps, plane16(ws, B_STALE), ws.stride[B_STALE], n, s);   /* compatibility mode only: the map cells the stock binary's heap re-uses */
-		nhw_launch_front_fused(nullptr, q, nullptr, nullptr, 0, yin, yin_stride, 0, nullptr, 0, nullptr, 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
+		nhw_launch_front_fused(nullptr, q, nullptr, nullptr, 0, yin, yin_stride, 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
 		                       proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n, s, ws.dbg ? 2 : 0);
 	} else {
 		HIPCHK(hipEventRecord(e->ev[5], s)); HIPCHK(hipEventRecord(e->ev[6], s));   /* no kernels of their own for colour and pre-filter: both times 0 */
 		STAGE_DONE();
 		if (q < 22) STAGE_DONE();
 		nhw_launch_front_fused((const uint8_t *)d_bgr, q, plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], yin, yin_stride /* developer builds only: a plane for a dump */, q < 22,
-		                       (uint64_t *)plane8(ws, B_ROWMAP), ws.stride[B_ROWMAP], (uint16_t *)plane8(ws, B_ROWFLAG), ws.stride[B_ROWFLAG],
 		                       plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE], proc, jpeg, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2,
 		                       q > 21 ? plane16(ws, B_KEEP) : nullptr, ws.stride[B_KEEP] / 2, n, s, (e->front_fallback & 1) | (ws.dbg ? 2 : 0));
 		if (ws.compat && q < 22) {   /* compatibility mode only: the kernel-map cells the stock binary's heap re-uses are replayed from a luma plane */
@@ -525,9 +523,9 @@ extern "C" int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_
 	if (size == 512) {
 		if (stride != W || final_level || n_img > e->max_batch) { g_err = "size 512: stride 512, not the final level, n <= max_batch"; return NHW_E_ARG; }
 		const NhwWs &ws = e->ws;
-		/* the band kernel reads rows that other bands of the same image overwrite with LL rows: its input is a plane of its own */
+		/* the level-1 kernel's input is a plane of its own (the caller's jpeg plane receives the LL rows) */
 		HIPCHK(hipMemcpy2DAsync(plane16(ws, B_KMAP), ws.stride[B_KMAP], d_jpeg, plane_stride * 2, 8 * Q, (size_t)n_img, hipMemcpyDeviceToDevice, s));
-		nhw_launch_front_fused(nullptr, 20, nullptr, nullptr, 0, plane16(ws, B_KMAP), ws.stride[B_KMAP], 0, nullptr, 0, nullptr, 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
+		nhw_launch_front_fused(nullptr, 20, nullptr, nullptr, 0, plane16(ws, B_KMAP), ws.stride[B_KMAP], 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
 		                       (int16_t *)d_proc, (int16_t *)d_jpeg, plane_stride, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n_img, s, 2);
 	} else if (size == 256 || size == 128)
 		nhw_launch_analysis((int16_t *)d_jpeg, (int16_t *)d_proc, n_img, plane_stride, stride, size, final_level, nullptr, 0, s);

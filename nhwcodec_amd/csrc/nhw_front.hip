@@ -216,149 +216,10 @@ __device__ __forceinline__ int pair_big_flag_fwd(int k0, int k1)
 	const bool first = a0 > 10 && a0 < 32 && a1 >= 23;
 	return !first && a1 >= 16 && a1 < 32 && a0 >= 23;
 }
-__device__ __forceinline__ void fsm_step16(uint64_t &m0, uint64_t &m1, int vb)
-{
-	if (vb == 0) { m0 = 0; m1 = 0; return; }
-	const uint64_t add = (uint64_t)(iabs(vb) & 15) * 0x0101010101010101ull;
-	m0 = ((((m0 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
-	m1 = ((((m1 + 0x0202020202020202ull) >> 2) & 0x0707070707070707ull) + add) & 0x0F0F0F0F0F0F0F0Full;
-}
-
-/* ------------------------------------------------------------------------------------------------
- * Fused front: pre-filter + level-1 analysis in one band kernel (+ a small pre-pass that only emits 18 bytes
- * per row).  One workgroup owns 16 output rows ky of the level-1 plane for all 512 columns:
- *   LDS ybuf: the 39 luma rows 32b-5 .. 32b+33 (original values; the pre-filter needs a 3x3 neighbourhood)
- *   LDS kbuf: contrast -> kernel map of the 37 rows 32b-4 .. 32b+32, later the horizontal pass output
- * The carry of the pre-filter enters every row with the state the pre-pass + chain computed, so rows replay
- * independently; the first pixel pair of a row gets the hand-over flag of the previous row from the chain.
- * Vertical pass: one thread per column, 16 low + 16 high outputs each (the /64 low-pass error diffusion is a
- * depth-1 recurrence on the raw taps, so nothing is carried between bands).  Rows are padded to 514 shorts:
- * a lane that walks a row serially hits bank (row + k) mod 64.
- * ------------------------------------------------------------------------------------------------ */
-#define FB_KB 16                    /* output rows per band.  Measured, ms per 4096-image batch at q20: 8 rows (three bands per CU, a third more halo work): equal; 32 rows with 1024 threads (one band per CU, 11 % halo work instead of 22 %): 5.55 against 5.10 -- sixteen wavefronts wait longer at the barriers than the halo rows cost */
-#define FB_VK 16                    /* of them per thread in the vertical pass */
-#define FB_TROWS (2 * FB_KB + 5)    /* horizontal-pass rows a band needs: 2k0-4 .. 2k0+32 */
-#define FB_YROWS (FB_TROWS + 2)
-#define FB_RS 514                   /* padded LDS row stride (shorts) */
-#define FB_LOOK 12                  /* pixels of look-back for a segment's entry state (all 16 states have merged within 8 for 99.9 % of the segments) */
-#define FB_SEG 32                   /* pixels per carry segment; FB_NSEG segments per row, replayed two to a lane */
-#define FB_NSEG (W / FB_SEG)
-#define FB_NT 512                   /* threads per band: the 78 KB of LDS allow two bands per CU, eight wavefronts each keep the SIMDs fed */
-
-/* pre-pass: per row the 16-state transfer map of the carry across the row and, for each of the 16 entry states, the hand-over
- * flag of the row's last pixel pair (509, 510) -- what k_front_chain needs to walk down the rows.  The carry forgets its past
- * within a few pixels (see k_front_band: measured, all 16 states merge within 16 pixels, 99.9 % within 8), so the RT_LOOK pixels
- * before pixel 509 decide both: if the states have merged by then, map and flags are the same for every entry state.  Otherwise
- * (rare) the lane walks the whole row.  One lane per row. */
-#define RT_LOOK 24
-/* The luma plane does not exist in HBM any more (the band kernel converts its rows itself): this pre-pass converts the last 32 pixels of
- * every row from the BGR bytes (and, on the rare full-row fallback, every pixel it walks over). */
-template <int FAMILY>
-__global__ __launch_bounds__(64) void k_front_rowtail(const uint8_t *__restrict__ bgr, float yq, uint64_t *__restrict__ maps, size_t m_stride,
-                                                      uint16_t *__restrict__ flags, size_t f_stride, int force_full)
-{
-	__shared__ __attribute__((aligned(16))) int16_t tail[66][40];      /* rows r0-1 .. r0+64, columns 480..511 (+ padding: 80-byte rows) */
-	const int img = blockIdx.y, r0 = 1 + blockIdx.x * 64, row = r0 + threadIdx.x;
-	const uint8_t *src = bgr + (size_t)img * (W * W * 3);
-	for (int k = threadIdx.x; k < 66 * 4; k += 64) {
-		const int rr = k >> 2, o = k & 3, gr = r0 - 1 + rr;
-		uint32_t y4[4] = { 0, 0, 0, 0 };
-		if (gr >= 0 && gr < W) {
-			uint8_t px[24];
-			const uint2 *q8 = reinterpret_cast<const uint2 *>(src + (size_t)gr * (W * 3) + (480 + 8 * o) * 3);
-#pragma unroll
-			for (int j = 0; j < 3; j++) {
-				const uint2 w = q8[j];
-#pragma unroll
-				for (int b = 0; b < 4; b++) { px[8 * j + b] = (uint8_t)(w.x >> (8 * b)); px[8 * j + 4 + b] = (uint8_t)(w.y >> (8 * b)); }
-			}
-#pragma unroll
-			for (int e = 0; e < 8; e++) y4[e >> 1] |= (uint32_t)(uint16_t)convert_y<FAMILY>(px + 3 * e, yq) << (16 * (e & 1));
-		}
-		*reinterpret_cast<uint4 *>(&tail[rr][8 * o]) = make_uint4(y4[0], y4[1], y4[2], y4[3]);
-	}
-	__syncthreads();
-	if (row > W - 2) return;
-	uint64_t m0 = 0x0706050403020100ull, m1 = 0x0F0E0D0C0B0A0908ull, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-	int v509 = 0, v510 = 0;
-	/* the walk over columns c .. W-2 of one row; px(dr, col) = luma of row `row + dr`, column col */
-	auto walk = [&](auto px, int c) __attribute__((always_inline)) {     /* inlined: the maps it updates stay in registers (captured by reference they sat in scratch memory) */
-		m0 = 0x0706050403020100ull; m1 = 0x0F0E0D0C0B0A0908ull;
-		/* 3x3 window slides along the row: three new reads per pixel */
-		int u0 = px(-1, c - 1), u1 = px(-1, c), m_0 = px(0, c - 1), m_1 = px(0, c), d0 = px(1, c - 1), d1 = px(1, c);
-		int cs0 = u0 + m_0 + d0, cs1 = u1 + m_1 + d1;
-		/* one pixel: its signed base value, the window moved on.  The last two pixels are taken out of the loop: what they record (the maps
-		 * in front of pixels 509 and 510) would otherwise be conditional stores inside it, which the compiler turns into scratch memory. */
-		auto cell = [&](int cc) __attribute__((always_inline)) {
-			const int u2 = px(-1, cc + 1), m_2 = px(0, cc + 1), d2 = px(1, cc + 1);
-			const int cs2 = u2 + m_2 + d2;
-			const int sum = 9 * m_1 - (cs0 + cs1 + cs2);
-			const int mag = (int)sad_u32(m_1, u0, sad_u32(m_1, u1, sad_u32(m_1, u2, sad_u32(m_1, m_0, sad_u32(m_1, m_2, sad_u32(m_1, d0, sad_u32(m_1, d1, sad_u32(m_1, d2, 0u))))))));
-			const int base = 15 * iabs(sum) + mag;
-			u0 = u1; u1 = u2; m_0 = m_1; m_1 = m_2; d0 = d1; d1 = d2; cs0 = cs1; cs1 = cs2;
-			return sum == 0 ? 0 : (sum < 0 ? -base : base);
-		};
-		for (; c <= W - 4; c++) fsm_step16(m0, m1, cell(c));
-		v509 = cell(W - 3); a0 = m0; a1 = m1; fsm_step16(m0, m1, v509);
-		v510 = cell(W - 2); b0 = m0; b1 = m1; fsm_step16(m0, m1, v510);
-		const uint64_t b = (a0 & 0xFF) * 0x0101010101010101ull;
-		return a0 == b && a1 == b;                                    /* merged before pixel 509: the rest of the row does not matter */
-	};
-	/* first the staged tail (LDS, columns 480..511); the rare row whose carry has not merged by pixel 509 walks the whole row in HBM.
-	 * force_full is a test switch that sends every row down that fallback.  Two call sites so that each keeps its own address space. */
-	bool merged = false;
-	const int tl = threadIdx.x + 1;
-	if (!force_full) merged = walk([&](int dr, int col) { return (int)tail[tl + dr][col - 480]; }, W - 3 - RT_LOOK);
-	if (!merged) walk([&](int dr, int col) { return convert_y<FAMILY>(src + (size_t)(row + dr) * (W * 3) + 3 * col, yq); }, 1);
-	unsigned f = 0;
-	for (int e = 0; e < 16; e++) {
-		const int s509 = (int)(((e < 8 ? a0 : a1) >> (8 * (e & 7))) & 15), s510 = (int)(((e < 8 ? b0 : b1) >> (8 * (e & 7))) & 15);
-		const int k0 = v509 == 0 ? 0 : (v509 < 0 ? -((iabs(v509) + ((s509 + 2) >> 2)) >> 4) : ((iabs(v509) + ((s509 + 2) >> 2)) >> 4));
-		const int k1 = v510 == 0 ? 0 : (v510 < 0 ? -((iabs(v510) + ((s510 + 2) >> 2)) >> 4) : ((iabs(v510) + ((s510 + 2) >> 2)) >> 4));
-		f |= (unsigned)pair_big_flag_fwd(k0, k1) << e;
-	}
-	uint64_t *mo = (uint64_t *)((uint8_t *)maps + (size_t)img * m_stride) + 2 * row;
-	mo[0] = m0; mo[1] = m1;
-	((uint16_t *)((uint8_t *)flags + (size_t)img * f_stride))[row] = (uint16_t)f;
-}
-
-/* one lane per image: entry state of the carry and hand-over flag for every row */
-__global__ void k_front_chain(const uint64_t *__restrict__ maps, size_t m_stride, const uint16_t *__restrict__ flags, size_t f_stride,
-                              uint8_t *__restrict__ st, size_t s_stride, int n)
-{
-	const int img = blockIdx.x * blockDim.x + threadIdx.x;
-	if (img >= n) return;
-	const uint64_t *m = (const uint64_t *)((const uint8_t *)maps + (size_t)img * m_stride);
-	const uint16_t *fl = (const uint16_t *)((const uint8_t *)flags + (size_t)img * f_stride);
-	uint8_t *s = st + (size_t)img * s_stride;
-	int state = 0, hand = 0;
-	for (int r = 1; r <= W - 2; r++) {
-		s[r] = (uint8_t)(state | (hand << 4));
-		hand = (fl[r] >> state) & 1;
-		const uint64_t w = m[2 * r + (state >> 3)];
-		state = (int)((w >> (8 * (state & 7))) & 15);
-	}
-}
-
-/* ten luma values x[c0-2 .. c0+9] of one LDS row as six dwords (c0 even) */
-__device__ __forceinline__ void row_window(const int16_t *row, int c0, int v[12])
-{
-	const uint32_t *d = reinterpret_cast<const uint32_t *>(row) + (c0 >> 1) - 1;
-#pragma unroll
-	for (int k = 0; k < 6; k++) {
-		const uint32_t w = (k == 0 && c0 == 0) ? 0u : d[k];
-		v[2 * k] = (int16_t)(w & 0xFFFF); v[2 * k + 1] = (int16_t)(w >> 16);
-	}
-}
-
 /* The pair rules only ask which of eight magnitude classes the two contrast values are in -- up to 10, 11, 12..15, 16..22, 23..31,
  * 32..176, 177..201, above (the constants of image_processing.c:810-837, :1927-1990) -- and their signs: 15 signed classes, so the ~60
  * predicate operations per pair become two class look-ups and one table entry.  The table is filled at kernel start by evaluating the
- * rules themselves on one representative per class: entry = (d0 + 8) | (d1 + 8) << 4 | hand-over flag << 8.
- * (Leaving the classes in place of the values in the carry replay, which has them in registers, was tried: the replay is the serial
- * phase of the band and every instruction added there costs more than the look-ups it saves here.) */
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+ * rules themselves on one representative per class (k_front_image, nhw_front_image.h). */
 #define PCLS 15
 __device__ __forceinline__ int pair_class_rep(int sc)           /* a value of signed class sc = -7 .. 7 (0: |k| <= 10) */
 {
@@ -369,365 +230,6 @@ __device__ __forceinline__ int pair_class_rep(int sc)           /* a value of si
 __device__ __forceinline__ int pair_mag_class(int a)             /* a = |k| */
 {
 	return (a > 10) + (a > 11) + (a > 15) + (a > 22) + (a > 31) + (a > 176) + (a > 201);
-}
-
-#ifdef NHW_DEV   /* developer builds: a switch that ends every band after phase i (tests/gpu_band_ablate.py: the cost of the phases under real contention) */
-#define STAMP(i) do { if ((force_fixup >> 8) == (i) && (i)) return; } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
-
-/* THE fused front kernel: colour conversion + 4:2:0 + (q <= 21) pre-filter + both directions of the level-1 analysis in one launch
- * (colorspace.c:55-260 + image_processing.c:558-837, 1927-1990 + wavelet_filterbank.c:52-184): the BGR bytes of the 39 rows a band
- * of 16 output rows needs come in with 16-byte loads (48 bytes = 16 pixels per lane and step), are converted in registers, and the
- * luma lands in LDS where the old kernel used to stage it from HBM -- the luma plane never travels.  The same lane filters the chroma
- * of its 16 pixels horizontally ([1 2 1]/4 at the even pixels; the pixel on its left is converted once more for that) and parks the
- * bytes in the LDS rows the contrast values will occupy later; a second step filters them vertically and writes the band's 16 rows
- * of the two 4:2:0 planes.  SRC 0: the luma comes from a plane in HBM instead (quality 1..16: its pre-filter is a walk of its own,
- * nhw_low.hip).
- * The workgroup -> (image, band) mapping keeps the bands of an image on one XCD: hardware deals consecutive workgroup ids round-robin
- * over the 8 XCDs, each with an L2 of its own, and a band shares 7 of its 39 input rows with its neighbours. */
-template <int PRE, int SRC, int FAMILY>
-__global__ __launch_bounds__(FB_NT) void k_front_band(const void *__restrict__ srcb, size_t src_stride, float yq, uint8_t *__restrict__ pub, uint8_t *__restrict__ pvb, size_t c_stride,
-                                                    const uint8_t *__restrict__ st, size_t s_stride,
-                                                    int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
-                                                    int16_t *__restrict__ ll1b, size_t ll1_stride, int16_t *__restrict__ keepb, size_t keep_stride, int force_fixup, int n_img)
-{
-	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
-	__shared__ uint8_t entry[FB_TROWS * FB_NSEG];
-	__shared__ uint8_t stl[FB_TROWS];
-	__shared__ uint16_t ptab[2 * PCLS * PCLS];
-	__shared__ uint8_t mcls[204];
-	int16_t *ybuf = smem;                                          /* FB_YROWS rows */
-	int16_t *kbuf = smem + FB_YROWS * FB_RS;                       /* FB_TROWS rows */
-	const int t = threadIdx.x;
-	/* XCD-aware order: workgroup w runs on XCD w % 8; the w / 8-th workgroup of XCD x takes work item x * (total / 8) + w / 8, so that the
-	 * items of one XCD are consecutive (image-major, band-minor) */
-	int band, img;
-	{
-		const int nb = H / FB_KB, total = nb * n_img, w = blockIdx.x;
-		const int per = total >> 3;                                 /* total is a multiple of 32 */
-		const int item = (total & 7) ? w : (w & 7) * per + (w >> 3);
-		img = item / nb; band = item % nb;
-	}
-	const int k0 = FB_KB * band, t0 = 2 * k0 - 4;                  /* first horizontal-pass row (may be negative) */
-
-	STAMP(0);
-	if (PRE) {
-		if (t < 2 * PCLS * PCLS) {
-			const int pb = t / (PCLS * PCLS), c0 = (t / PCLS) % PCLS, c1 = t % PCLS;
-			const int r0 = pair_class_rep(c0 - 7), r1 = pair_class_rep(c1 - 7);
-			const uint32_t dd = prefilter_pair_delta(r0, r1, pb);
-			ptab[t] = (uint16_t)(((int16_t)(dd & 0xFFFF) + 8) | (((int16_t)(dd >> 16) + 8) << 4) | (pair_big_flag_fwd(r0, r1) << 8));
-		}
-		if (t < 203) mcls[t] = (uint8_t)pair_mag_class(t);
-	}
-	if (SRC == 0) {
-		const int16_t *y = (const int16_t *)((const uint8_t *)srcb + (size_t)img * src_stride);
-		for (int k = t; k < FB_YROWS * (W / 8); k += FB_NT) {        /* stage rows t0-1 .. t0+37 */
-			const int ry = k / (W / 8), o = k % (W / 8), row = t0 - 1 + ry;
-			uint4 v = make_uint4(0, 0, 0, 0);
-			if (row >= 0 && row < W) v = reinterpret_cast<const uint4 *>(y + (size_t)row * W)[o];
-			uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 8 * o);
-			d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-		}
-	} else {
-		const uint8_t *src = (const uint8_t *)srcb + (size_t)img * (W * W * 3);
-		uint8_t *hu = reinterpret_cast<uint8_t *>(kbuf) + 4, *hv = hu + (2 * FB_KB + 1) * H;   /* 33 rows x 256 bytes each: full-resolution rows 2k0-1 .. 2k0+31 (+4: kbuf starts 12 bytes behind a 16-byte boundary) */
-		for (int k = t; k < FB_YROWS * (W / 16); k += FB_NT) {       /* rows t0-1 .. t0+37, 16 pixels per item */
-			const int ry = k / (W / 16), g = k % (W / 16), row = t0 - 1 + ry;
-			uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + ry * FB_RS + 16 * g);
-			if (row < 0 || row >= W) { for (int e = 0; e < 8; e++) d[e] = 0; continue; }
-			const uint8_t *rp = src + (size_t)row * (W * 3) + 48 * g;
-			const uint4 q0 = reinterpret_cast<const uint4 *>(rp)[0], q1 = reinterpret_cast<const uint4 *>(rp)[1], q2 = reinterpret_cast<const uint4 *>(rp)[2];
-			const uint32_t wv[12] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w };
-			uint8_t px[48];
-#pragma unroll
-			for (int b = 0; b < 48; b++) px[b] = (uint8_t)(wv[b >> 2] >> (8 * (b & 3)));
-			uint32_t yw[8];
-#pragma unroll
-			for (int e = 0; e < 16; e++) {
-				const uint32_t yv = (uint32_t)(uint16_t)convert_y<FAMILY>(px + 3 * e, yq);
-				if (e & 1) yw[e >> 1] |= yv << 16; else yw[e >> 1] = yv;
-			}
-#pragma unroll
-			for (int e = 0; e < 8; e++) d[e] = yw[e];
-			const int cr = row - (2 * k0 - 1);                         /* row of the chroma staging area */
-			if (cr >= 0 && cr <= 2 * FB_KB) {
-				int U[17], V[17];                                       /* pixel 16g - 1 (for the filter's left tap), then the 16 own ones */
-				if (g) convert_uv<FAMILY>(rp - 3, yq, U[0], V[0]); else { U[0] = 0; V[0] = 0; }
-#pragma unroll
-				for (int e = 0; e < 16; e++) convert_uv<FAMILY>(px + 3 * e, yq, U[e + 1], V[e + 1]);
-				uint32_t hu2[2] = { 0, 0 }, hv2[2] = { 0, 0 };
-#pragma unroll
-				for (int j = 0; j < 8; j++) {                           /* output column 8g + j = even pixel 16g + 2j (colorspace.c:220-234) */
-					int fu, fv;
-					if (g == 0 && j == 0) { fu = (U[1] + U[2] + 1) >> 1; fv = (V[1] + V[2] + 1) >> 1; }
-					else { fu = (U[2 * j] + 2 * U[2 * j + 1] + U[2 * j + 2] + 2) >> 2; fv = (V[2 * j] + 2 * V[2 * j + 1] + V[2 * j + 2] + 2) >> 2; }
-					hu2[j >> 2] |= (uint32_t)fu << (8 * (j & 3)); hv2[j >> 2] |= (uint32_t)fv << (8 * (j & 3));
-				}
-				*reinterpret_cast<uint2 *>(hu + cr * H + 8 * g) = make_uint2(hu2[0], hu2[1]);
-				*reinterpret_cast<uint2 *>(hv + cr * H + 8 * g) = make_uint2(hv2[0], hv2[1]);
-			}
-		}
-		__syncthreads();
-		/* vertical [1 2 1]/4 over full-resolution rows 2r-1, 2r, 2r+1 (colorspace.c:241-256; row 0: (r0 + r1 + 1) >> 1), four columns per item */
-		uint8_t *pu = pub + (size_t)img * c_stride, *pv = pvb + (size_t)img * c_stride;
-		for (int k = t; k < 2 * FB_KB * (H / 4); k += FB_NT) {
-			const int pl = k / (FB_KB * (H / 4)), rem = k % (FB_KB * (H / 4)), rr = rem / (H / 4), c4 = rem % (H / 4), r = k0 + rr;
-			const uint8_t *hb = (pl ? hv : hu) + 2 * rr * H + 4 * c4;
-			const uint32_t a = *reinterpret_cast<const uint32_t *>(hb), b = *reinterpret_cast<const uint32_t *>(hb + H), c = *reinterpret_cast<const uint32_t *>(hb + 2 * H);
-			uint32_t o = 0;
-#pragma unroll
-			for (int e = 0; e < 4; e++) {
-				const int x0 = (a >> (8 * e)) & 255, x1 = (b >> (8 * e)) & 255, x2 = (c >> (8 * e)) & 255;
-				o |= (uint32_t)(r == 0 ? (x1 + x2 + 1) >> 1 : (x0 + 2 * x1 + x2 + 2) >> 2) << (8 * e);
-			}
-			*reinterpret_cast<uint32_t *>((pl ? pv : pu) + r * H + 4 * c4) = o;
-		}
-	}
-	if (PRE) {                                                     /* the rows' entry states ride along with the luma rows */
-		if (t < FB_TROWS && t0 + t >= 1 && t0 + t <= W - 2) stl[t] = (st + (size_t)img * s_stride)[t0 + t];
-	}
-	__syncthreads();
-	STAMP(1);
-
-	if (PRE) {
-		/* items are (row, 8-pixel group) with the row index fastest: consecutive lanes sit one padded row (257
-		 * dwords) apart, i.e. on consecutive LDS banks */
-		for (int k = t; k < FB_TROWS * (W / 8); k += FB_NT) {        /* contrast, 8 pixels per item */
-			const int rt = k % FB_TROWS, c0 = 8 * (k / FB_TROWS), row = t0 + rt;
-			uint32_t out[4] = { 0, 0, 0, 0 };
-			if (row >= 1 && row <= W - 2) {
-				/* The rows stay packed, two pixels to a dword (luma is never negative here): a pixel's eight absolute differences are four
-				 * v_sad_u16 against dwords that hold two neighbours each -- the two pixels above and below that share its dword, and two
-				 * dwords put together from the neighbouring ones -- and the column sums of the three rows are packed adds. */
-				uint32_t U[6], M[6], D[6], S[6];
-				const uint32_t *ru = reinterpret_cast<const uint32_t *>(ybuf + rt * FB_RS) + (c0 >> 1) - 1;
-				const uint32_t *rm = reinterpret_cast<const uint32_t *>(ybuf + (rt + 1) * FB_RS) + (c0 >> 1) - 1;
-				const uint32_t *rd = reinterpret_cast<const uint32_t *>(ybuf + (rt + 2) * FB_RS) + (c0 >> 1) - 1;
-#pragma unroll
-				for (int j = 0; j < 6; j++) {
-					const bool skip = j == 0 && c0 == 0;               /* the two pixels before the row: no neighbours of anything that counts */
-					U[j] = skip ? 0u : ru[j]; M[j] = skip ? 0u : rm[j]; D[j] = skip ? 0u : rd[j];
-					S[j] = pk_add16(pk_add16(U[j], M[j]), D[j]);
-				}
-#pragma unroll
-				for (int pr = 0; pr < 4; pr++) {                     /* pixels c0 + 2 pr (low half of dword K) and c0 + 2 pr + 1 (high half) */
-					const int K = pr + 1;
-					const int T = (int)(S[K] & 0xFFFFu) + (int)(S[K] >> 16);
-#pragma unroll
-					for (int h = 0; h < 2; h++) {
-						const int c = c0 + 2 * pr + h;
-						const int ctr = h ? (int)(M[K] >> 16) : (int)(M[K] & 0xFFFFu);
-						const uint32_t cc = __builtin_amdgcn_perm(M[K], M[K], h ? 0x03020302u : 0x01000100u);
-						/* the column beside the dword: the one on the left for the low pixel, on the right for the high one */
-						const uint32_t side = h ? __builtin_amdgcn_perm(D[K + 1], U[K + 1], 0x05040100u) : __builtin_amdgcn_perm(D[K - 1], U[K - 1], 0x07060302u);
-						const uint32_t mids = h ? __builtin_amdgcn_perm(M[K + 1], M[K], 0x05040100u) : __builtin_amdgcn_perm(M[K], M[K - 1], 0x07060302u);
-						const int mag = (int)sad_u16(cc, U[K], sad_u16(cc, D[K], sad_u16(cc, side, sad_u16(cc, mids, 0u))));
-						const int wsum = T + (h ? (int)(S[K + 1] & 0xFFFFu) : (int)(S[K - 1] >> 16));
-						const int sum = 9 * ctr - wsum;
-						const int base = 15 * iabs(sum) + mag;
-						const int vb = (sum == 0 || c < 1 || c > W - 2) ? 0 : (sum < 0 ? -base : base);
-						out[pr] |= (uint32_t)(uint16_t)vb << (16 * h);
-					}
-				}
-			}
-			uint32_t *d = reinterpret_cast<uint32_t *>(kbuf + rt * FB_RS + c0);
-			d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3];
-		}
-		__syncthreads();
-		/* Carry state at the start of every FB_SEG-pixel segment.  The 16-state carry forgets its past quickly (a step maps the 16 states
-		 * onto at most five neighbouring ones, a zero sum resets it): run all 16 states through the FB_LOOK pixels in front of the segment;
-		 * if they end in one state, that is the entry state whatever came before.  Where they do not (rare), the segment before is
-		 * replayed from its own entry state -- by then known -- so the result is exact in every case. */
-		for (int k = t; k < FB_TROWS * FB_NSEG; k += FB_NT) {
-			const int rt = k % FB_TROWS, sg = k / FB_TROWS, row = t0 + rt;
-			if (row < 1 || row > W - 2) continue;
-			int e = stl[rt] & 15;
-			if (sg > 0) {
-				/* one step maps all 16 states onto the five (|v| + 0..4) & 15, so five candidates are all there is to follow: 5-bit fields of one
-				 * dword (c + 2 and |v| + 4 stay below 32), every step a handful of whole-dword operations */
-				const int16_t *km = kbuf + rt * FB_RS + 1 + FB_SEG * sg - FB_LOOK;
-				const uint32_t R = 0x108421u;                          /* 1 in each field */
-				uint32_t x = km[0] == 0 ? 0u : ((((uint32_t)iabs(km[0]) & 15u) * R + 0x418820u) & (15u * R));
-				for (int i = 1; i < FB_LOOK; i++) {
-					const int vb = km[i];
-					const uint32_t nx = (((uint32_t)iabs(vb) & 15u) * R + (((x + 2u * R) >> 2) & (7u * R))) & (15u * R);
-					x = vb == 0 ? 0u : nx;
-				}
-				e = (x == (x & 31u) * R && !(force_fixup & 1)) ? (int)(x & 15u) : 0xFF;   /* force_fixup: test switch, every segment takes the exact replay */
-			}
-			entry[rt * FB_NSEG + sg] = (uint8_t)e;
-		}
-		__syncthreads();
-		if (t < FB_TROWS && t0 + t >= 1 && t0 + t <= W - 2) {
-			for (int sg = 1; sg < FB_NSEG; sg++) {
-				if (entry[t * FB_NSEG + sg] != 0xFF) continue;
-				const int16_t *km = kbuf + t * FB_RS + 1 + FB_SEG * (sg - 1);
-				int carry = entry[t * FB_NSEG + sg - 1];
-				for (int i = 0; i < FB_SEG; i++) { const int vb = km[i]; carry = vb == 0 ? 0 : ((iabs(vb) + ((carry + 2) >> 2)) & 15); }
-				entry[t * FB_NSEG + sg] = (uint8_t)carry;
-			}
-		}
-		__syncthreads();
-		STAMP(2);
-		/* replay the carry: one lane per row and PAIR of segments (sp, sp + FB_NSEG / 2), the two values side by side in the halves of a
-		 * dword so that every step is packed 16-bit arithmetic -- half the instructions of a lane per segment.  Eight pixels at a time
-		 * through registers (small loop bodies: a fully unrolled version overflows the instruction cache and runs 10x slower). */
-		if (t < FB_TROWS * (FB_NSEG / 2)) {
-			const int rt = t % FB_TROWS, sp = t / FB_TROWS, row = t0 + rt;
-			if (row >= 1 && row <= W - 2) {
-				int16_t *ka = kbuf + rt * FB_RS + 1 + FB_SEG * sp, *kb = ka + 256;   /* segment pixel 0 = column 1 + FB_SEG sg */
-				const int nb = sp == FB_NSEG / 2 - 1 ? FB_SEG - 2 : FB_SEG;   /* the last segment ends at column 510 */
-				u16x2 carry = { entry[rt * FB_NSEG + sp], entry[rt * FB_NSEG + sp + FB_NSEG / 2] };
-#pragma unroll 1
-				for (int ch = 0; ch < FB_SEG / 8; ch++) {
-					s16x2 v[8];
-#pragma unroll
-					for (int e = 0; e < 8; e++) { v[e].x = ka[8 * ch + e]; v[e].y = kb[8 * ch + e]; }
-#pragma unroll
-					for (int e = 0; e < 8; e++) {                        /* v == 0: |v| + f(carry) <= 4 gives output 0 by itself; only the carry needs the reset */
-						const s16x2 sgn = v[e] >> 15;
-						const u16x2 a = __builtin_bit_cast(u16x2, (s16x2)((v[e] ^ sgn) - sgn));
-						const u16x2 acc = a + ((carry + (u16x2)(2)) >> 2);
-						const s16x2 o = __builtin_bit_cast(s16x2, (u16x2)(acc >> 4));
-						v[e] = (o ^ sgn) - sgn;
-						carry = (acc & (u16x2)(15)) * __builtin_elementwise_min(a, (u16x2)(1));
-					}
-#pragma unroll
-					for (int e = 0; e < 8; e++) { ka[8 * ch + e] = v[e].x; if (8 * ch + e < nb) kb[8 * ch + e] = v[e].y; }
-				}
-			}
-		}
-		__syncthreads();
-		STAMP(3);
-		for (int k = t; k < FB_TROWS * 64; k += FB_NT) {             /* pair rules: four pairs (8 pixels) per item, no serial dependence left */
-			const int rt = k % FB_TROWS, g = k / FB_TROWS, row = t0 + rt;
-			if (row < 1 || row > W - 2) continue;
-			const int16_t *km = kbuf + rt * FB_RS + 8 * g;         /* pairs (8g+1, 8g+2) .. (8g+7, 8g+8) */
-			int16_t *yo = ybuf + (rt + 1) * FB_RS + 8 * g;
-			int16_t v[10];
-#pragma unroll
-			for (int e = 0; e < 10; e++) v[e] = (g == 0 && e == 0) ? (int16_t)0 : km[e - 1];   /* columns 8g-1 .. 8g+8 */
-			int big = 0;                                            /* every rule needs a kernel value of at least 23 (class 4 and up) in its pair: |k| > 176, or a moderate one (11..31) next to one >= 23 */
-#pragma unroll
-			for (int e = 2; e < 10; e++) big |= iabs(v[e]) > 22;
-			if (!big) continue;
-			int cl[10];                                             /* signed class + 7 */
-#pragma unroll
-			for (int e = 0; e < 10; e++) { const int a = iabs(v[e]), m = mcls[a > 202 ? 202 : a]; cl[e] = v[e] < 0 ? 7 - m : 7 + m; }
-			int prev_big = g ? ((ptab[cl[0] * PCLS + cl[1]] >> 8) & 1) : ((stl[rt] >> 4) & 1);
-#pragma unroll
-			for (int e = 0; e < 4; e++) {
-				const int c = 8 * g + 1 + 2 * e;
-				if (c <= W - 3) {
-					const int en = ptab[prev_big * (PCLS * PCLS) + cl[2 * e + 2] * PCLS + cl[2 * e + 3]];
-					const int d0 = (en & 15) - 8, d1 = ((en >> 4) & 15) - 8;
-					if (d0) yo[1 + 2 * e] = (int16_t)(yo[1 + 2 * e] + d0);
-					if (d1) yo[2 + 2 * e] = (int16_t)(yo[2 + 2 * e] + d1);
-					prev_big = (en >> 8) & 1;
-				}
-			}
-		}
-		__syncthreads();
-		STAMP(4);
-	}
-
-	for (int k = t; k < FB_TROWS * 64; k += FB_NT) {                 /* horizontal pass (filters.c:346-386) into kbuf, four kx per item */
-		const int rt = k % FB_TROWS, g = k / FB_TROWS, row = t0 + rt;
-		if (row < 0 || row >= W) continue;
-		int x[12];
-		row_window(ybuf + (rt + 1) * FB_RS, 8 * g, x);             /* x[i] = luma[8g - 2 + i] */
-		if (g == 0) { x[0] = x[4]; x[1] = x[3]; }                  /* x[-2] = x[2], x[-1] = x[1] */
-		if (g == 63) x[10] = x[8];                                 /* x[512] = x[510] */
-		uint32_t lo[2], hi[2];
-#pragma unroll
-		for (int e = 0; e < 4; e++) {
-			const int i = 2 * e + 2;                               /* x[2kx] */
-			const int l = 6 * x[i] + 2 * (x[i - 1] + x[i + 1]) - (x[i - 2] + x[i + 2]);
-			int h = (x[i + 1] << 1) - (x[i] + x[i + 2]);
-			if (g == 63 && e == 3) h = (x[i + 1] - x[i]) << 1;
-			if (e & 1) { lo[e >> 1] |= (uint32_t)(uint16_t)l << 16; hi[e >> 1] |= (uint32_t)(uint16_t)h << 16; }
-			else { lo[e >> 1] = (uint16_t)l; hi[e >> 1] = (uint16_t)h; }
-		}
-		uint32_t *dl = reinterpret_cast<uint32_t *>(kbuf + rt * FB_RS + 4 * g), *dh = reinterpret_cast<uint32_t *>(kbuf + rt * FB_RS + H + 4 * g);
-		dl[0] = lo[0]; dl[1] = lo[1]; dh[0] = hi[0]; dh[1] = hi[1];
-	}
-	__syncthreads();
-	STAMP(5);
-
-	int16_t *proc = procb + (size_t)img * plane_stride, *jpeg = jpegb + (size_t)img * plane_stride;
-	int16_t *ll1 = ll1b + (size_t)img * ll1_stride;
-	if (keepb) {                                                   /* q>=22: transposed horizontal-pass plane, rows kx < 256 (wavelet_filterbank.c:107-112) */
-		int16_t *keep = keepb + (size_t)img * keep_stride;
-		for (int k = t; k < H * (FB_KB / 4); k += FB_NT) {
-			const int kx = k / (FB_KB / 4), part = k % (FB_KB / 4);   /* 8 of this band's 2 FB_KB own rows */
-			uint32_t v[4];
-			for (int e = 0; e < 4; e++) {
-				const int rt = 4 + 8 * part + 2 * e;                /* rows 2k0 + 8*part + 2e, +1 */
-				v[e] = (uint16_t)kbuf[rt * FB_RS + kx] | ((uint32_t)(uint16_t)kbuf[(rt + 1) * FB_RS + kx] << 16);
-			}
-			*reinterpret_cast<uint4 *>(keep + (size_t)kx * W + 2 * k0 + 8 * part) = make_uint4(v[0], v[1], v[2], v[3]);
-		}
-	}
-	/* vertical pass: a thread takes column c and FB_VK of the band's output rows (FB_NT = 512 x FB_KB / FB_VK threads).  Columns below 256 (the
-	 * low band of pass 1) and the others take different rounding rules; a wavefront lies wholly on one side, so the side is a
-	 * compile-time constant of two instances of the body and the choice a scalar branch. */
-	static_assert(FB_NT == W * (FB_KB / FB_VK), "a column and FB_VK output rows per thread");
-	auto vertical = [&](auto side) {
-		constexpr bool LEFT = decltype(side)::value;
-		const int c = t % W, kb = FB_VK * (t / W);                  /* output rows k0 + kb .. k0 + kb + FB_VK - 1 */
-		int16_t col[2 * FB_VK + 5];                                /* col[i] = pass-1 row t0 + 2 kb + i, symmetric extension x[-j]=x[j], x[511+j]=x[511-j] */
-#pragma unroll
-		for (int rt = 0; rt < 2 * FB_VK + 5; rt++) {
-			int row = t0 + 2 * kb + rt;
-			row = row < 0 ? -row : (row > W - 1 ? 2 * (W - 1) - row : row);
-			col[rt] = kbuf[(row - t0) * FB_RS + c];
-		}
-		uint32_t lo[FB_VK / 2], hi[FB_VK / 2];
-#pragma unroll
-		for (int kk = 0; kk < FB_VK; kk++) {
-			const int ky = k0 + kb + kk;
-#define XS(d) ((int)col[2 * kk + 4 + (d)])                         /* x[2ky + d], -4 <= d <= 2 */
-			const int r = 6 * XS(0) + 2 * (XS(-1) + XS(1)) - (XS(-2) + XS(2));
-			int l, h;
-			if (LEFT) {                                            /* filters.c:203-287 */
-				int carry = 0;
-				if (ky > 0) carry = diffuse(6 * XS(-2) + 2 * (XS(-3) + XS(-1)) - (XS(-4) + XS(0)));
-				l = rnd_half_away((int16_t)(r + carry), 6);
-			} else l = rnd_half_away(r, 4);                        /* filters.c:88-113 */
-			if (ky < H - 1) {
-				int a = XS(0) + XS(2);
-				if ((ky & 1) && (a & 1) && ((XS(-2) + XS(0)) & 1)) a++;
-				const int pr = XS(1) - (a >> 1);
-				h = LEFT ? rnd_half_away(pr, 3) : (pr > 0 ? (pr + 1) >> 1 : pr >> 1);
-			} else h = LEFT ? ((XS(1) - XS(0)) >> 3) : (((XS(1) - XS(0)) + 1) >> 1);
-#undef XS
-			if (kk & 1) { lo[kk >> 1] |= (uint32_t)(uint16_t)l << 16; hi[kk >> 1] |= (uint32_t)(uint16_t)h << 16; }
-			else { lo[kk >> 1] = (uint16_t)l; hi[kk >> 1] = (uint16_t)h; }
-		}
-		int16_t *orow = proc + (size_t)c * W;
-#pragma unroll
-		for (int i = 0; i < FB_VK / 8; i++) {
-			reinterpret_cast<uint4 *>(orow + k0 + kb)[i] = make_uint4(lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]);
-			reinterpret_cast<uint4 *>(orow + H + k0 + kb)[i] = make_uint4(hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]);
-		}
-		if (LEFT) {                                                /* LL, natural orientation, through LDS for coalesced rows */
-#pragma unroll
-			for (int kk = 0; kk < FB_VK; kk++) ybuf[(kb + kk) * FB_RS + c] = (int16_t)((kk & 1) ? (lo[kk >> 1] >> 16) : (lo[kk >> 1] & 0xFFFF));
-		}
-	};
-	if (__builtin_amdgcn_readfirstlane(t % W) < H) vertical(std::true_type{}); else vertical(std::false_type{});
-	__syncthreads();
-	STAMP(6);
-	for (int k = t; k < FB_KB * (H / 2); k += FB_NT) {               /* jpeg[ky][kx] and ll1[ky][kx], kx < 256 (wavelet_filterbank.c:172-184, nhw_encoder.c:127-135) */
-		const int kk = k >> 7, o = k & 127;
-		const uint32_t v = (uint16_t)ybuf[kk * FB_RS + 2 * o] | ((uint32_t)(uint16_t)ybuf[kk * FB_RS + 2 * o + 1] << 16);
-		reinterpret_cast<uint32_t *>(jpeg + (size_t)(k0 + kk) * W)[o] = v;
-		reinterpret_cast<uint32_t *>(ll1 + (size_t)(k0 + kk) * H)[o] = v;
-	}
-	STAMP(7);
 }
 
 } // namespace nhw
@@ -959,9 +461,6 @@ int nhw_front_set_attrs(const char **where)
 {
 #define SETATTR(fn, bytes) do { const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
                                 if (e_ != hipSuccess) { *where = "hipFuncSetAttribute(" #fn ", MaxDynamicSharedMemorySize)"; return (int)e_; } } while (0)
-	const size_t band = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
-	SETATTR((k_front_band<0, 0, 0>), band); SETATTR((k_front_band<0, 1, 0>), band); SETATTR((k_front_band<1, 1, 0>), band);
-	SETATTR((k_front_band<1, 1, 1>), band); SETATTR((k_front_band<1, 1, 2>), band);
 	SETATTR((k_front_plain<0, 0>), FP_LDS_BYTES); SETATTR((k_front_plain<1, 0>), FP_LDS_BYTES); SETATTR((k_front_image<1, 1, 0>), FI_LDS_BYTES);
 	SETATTR((k_front_image<1, 1, 1>), FI_LDS_BYTES); SETATTR((k_front_image<1, 1, 2>), FI_LDS_BYTES);
 	SETATTR(k_dwt_ana<256>, 256 * 258 * sizeof(int16_t)); SETATTR(k_dwt_syn<256>, 256 * 258 * sizeof(int16_t));
@@ -989,9 +488,12 @@ void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stri
 	if (size == 128) { k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat); return; }
 }
 
-/* the front launch group: [k_front_rowtail + k_front_chain for q 17..21] + k_front_band.
- * bgr != nullptr: quality 17..23, everything from the BGR bytes (colour, 4:2:0 planes pu / pv, pre-filter, level-1 analysis);
- * bgr == nullptr: the luma plane y is the input (quality 1..16 behind their own pre-filter; the stage entry point) */
+/* the front launch group = ONE kernel.
+ * bgr != nullptr: quality 17..23, everything from the BGR bytes (colour, 4:2:0 planes pu / pv, pre-filter for q <= 21, level-1 analysis): k_front_image
+ *                 with the pre-filter, k_front_plain without;
+ * bgr == nullptr: the luma plane y is the input (quality 1..16 behind their own pre-filter; the analysis stage entry point): k_front_plain.
+ * st (optional): the carry at the start of every image row, for the compatibility mode's replay of a few rows (k_front_stale).
+ * switches bit 0: every carry segment takes its exact replay (tests); bit 1: a stage check is going to read every plane (nothing is left out). */
 static float color_yq(int q, int *family)
 {
 	static const int k_qtz[17] = { 0, 15900, 16500, 17100, 18000, 18820, 19670, 20640, 21540, 23540, 25570, 27522, 27830, 27607, 28786, 31262, 32375 };
@@ -1002,66 +504,39 @@ static float color_yq(int q, int *family)
 	return __builtin_bit_cast(float, k_qtz[q < 1 ? 1 : q]);
 }
 void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv, size_t c_stride, const int16_t *y, size_t y_stride, int with_prefilter,
-                            uint64_t *maps, size_t m_stride, uint16_t *flags, size_t f_stride,
                             uint8_t *st, size_t s_stride, int16_t *proc, int16_t *jpeg, size_t plane_stride, int16_t *ll1, size_t ll1_stride,
-                            int16_t *keep, size_t keep_stride, int n, hipStream_t s, int force_fallback)
+                            int16_t *keep, size_t keep_stride, int n, hipStream_t s, int switches)
 {
-	static const int use_old = getenv("NHW_FRONT_OLD") ? atoi(getenv("NHW_FRONT_OLD")) : 0;   /* TEMP: A/B against the band kernel */
-	if (!use_old) {
-		int fam = 0;
-		const float yq = bgr ? color_yq(q, &fam) : 0.f;
-		int fl = (force_fallback & 1) | ((force_fallback & 2) ? 0x100000 : 0);   /* bit 1 of the caller's switches: a stage check reads every plane */
+	int fam = 0;
+	const float yq = bgr ? color_yq(q, &fam) : 0.f;
+	int fl = (switches & 1) | ((switches & 2) ? 0x100000 : 0);
 #ifdef NHW_DEV
-		{ const char *e = getenv("NHW_BAND_STOP"); if (e) fl |= atoi(e) << 8; }
-		if (getenv("NHW_FRONT_PROF")) fl |= 0x10000;
-		{ const char *e = getenv("NHW_FRONT_SKIP"); if (e) fl |= atoi(e) & 12; }     /* 4: no stores of the level-1 plane, 8: none of the LL rows (timing experiments) */
-		if (getenv("NHW_FRONT_DUMP") && y && bgr && with_prefilter) { fl |= 2 | (atoi(getenv("NHW_FRONT_DUMP")) << 4); keep = const_cast<int16_t *>(y); keep_stride = y_stride / 2; }
+	{ const char *e = getenv("NHW_BAND_STOP"); if (e) fl |= atoi(e) << 8; }
+	if (getenv("NHW_FRONT_PROF")) fl |= 0x10000;
+	{ const char *e = getenv("NHW_FRONT_SKIP"); if (e) fl |= atoi(e) & 12; }     /* 4: no stores of the level-1 plane, 8: none of the LL rows (timing experiments) */
+	if (getenv("NHW_FRONT_DUMP") && y && bgr && with_prefilter) { fl |= 2 | (atoi(getenv("NHW_FRONT_DUMP")) << 4); keep = const_cast<int16_t *>(y); keep_stride = y_stride / 2; }
 #endif
 #define FI_ARGS(srcp, sstride) srcp, sstride, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, fl
 #define FP_ARGS(srcp, sstride) srcp, sstride, yq, pu, pv, c_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, fl
-		if (!bgr) k_front_plain<0, 0><<<n, FI_NT, FP_LDS_BYTES, s>>>(FP_ARGS((const void *)y, y_stride));
-		else if (!with_prefilter) k_front_plain<1, 0><<<n, FI_NT, FP_LDS_BYTES, s>>>(FP_ARGS((const void *)bgr, (size_t)0));
+	if (!bgr) k_front_plain<0, 0><<<n, FI_NT, FP_LDS_BYTES, s>>>(FP_ARGS((const void *)y, y_stride));
+	else if (!with_prefilter) k_front_plain<1, 0><<<n, FI_NT, FP_LDS_BYTES, s>>>(FP_ARGS((const void *)bgr, (size_t)0));
+	else if (fam == 0) k_front_image<1, 1, 0><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
+	else if (fam == 1) k_front_image<1, 1, 1><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
+	else k_front_image<1, 1, 2><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
 #undef FP_ARGS
-		else if (fam == 0) k_front_image<1, 1, 0><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
-		else if (fam == 1) k_front_image<1, 1, 1><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
-		else k_front_image<1, 1, 2><<<n, FI_NT, FI_LDS_BYTES, s>>>(FI_ARGS((const void *)bgr, (size_t)0));
 #undef FI_ARGS
 #ifdef NHW_DEV
-		if (getenv("NHW_FRONT_PROF")) {
-			unsigned long long h[16];
-			hipStreamSynchronize(s);
-			hipMemcpyFromSymbol(h, HIP_SYMBOL(nhw::g_fi_prof), sizeof h);
-			static const char *nm[16] = { "loop top (hold rows, last barrier)", "barrier after phase 0 (+ prefetch issue)", "chroma vertical + barrier", "contrast + barrier", "entry states + barrier(s)", "replay + barrier", "pair rules + barrier", "horizontal + barrier", "vertical + barrier", "phase 0 work (wait for rows, colour, LDS stores)", "vertical: keep stores", "vertical: row copies + column loads", "vertical: arithmetic", "vertical: stores issued" };
-			unsigned long long tot = 0; for (int i = 0; i < 14; i++) tot += h[i];
-			fprintf(stderr, "k_front_image q%d: thread-0 clock ticks per image (sum over bands), %d images\n", q, n);
-			for (int i = 0; i < 14; i++) fprintf(stderr, "  %-52s %10.0f  %5.1f %%\n", nm[i], (double)h[i] / n, 100.0 * h[i] / (tot ? tot : 1));
-			memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(nhw::g_fi_prof), h, sizeof h);
-		}
-#endif
-		return;
+	if (getenv("NHW_FRONT_PROF") && bgr && with_prefilter) {
+		unsigned long long h[16];
+		hipStreamSynchronize(s);
+		hipMemcpyFromSymbol(h, HIP_SYMBOL(nhw::g_fi_prof), sizeof h);
+		static const char *nm[16] = { "loop top (hold rows, last barrier)", "barrier after phase 0 (+ prefetch issue)", "chroma vertical + barrier", "contrast + barrier", "entry states + barrier(s)", "replay + barrier", "pair rules + barrier", "horizontal + barrier", "vertical + barrier", "phase 0 work (wait for rows, colour, LDS stores)", "vertical: keep stores", "vertical: row copies + column loads", "vertical: arithmetic", "vertical: stores issued" };
+		unsigned long long tot = 0; for (int i = 0; i < 14; i++) tot += h[i];
+		fprintf(stderr, "k_front_image q%d: thread-0 clock ticks per image (sum over bands), %d images\n", q, n);
+		for (int i = 0; i < 14; i++) fprintf(stderr, "  %-52s %10.0f  %5.1f %%\n", nm[i], (double)h[i] / n, 100.0 * h[i] / (tot ? tot : 1));
+		memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(nhw::g_fi_prof), h, sizeof h);
 	}
-	const size_t lds = (size_t)(FB_YROWS + FB_TROWS) * FB_RS * sizeof(int16_t);
-	const dim3 grid((H / FB_KB) * n);
-	if (!bgr) {
-		k_front_band<0, 0, 0><<<grid, FB_NT, lds, s>>>(y, y_stride, 0.f, nullptr, nullptr, 0, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, 0, n);
-		return;
-	}
-	int fam = 0;
-	const float yq = color_yq(q, &fam);
-	if (with_prefilter) {
-		const dim3 rg((W - 2 + 63) / 64, n);
-		if (fam == 0) k_front_rowtail<0><<<rg, 64, 0, s>>>(bgr, yq, maps, m_stride, flags, f_stride, force_fallback);
-		else if (fam == 1) k_front_rowtail<1><<<rg, 64, 0, s>>>(bgr, yq, maps, m_stride, flags, f_stride, force_fallback);
-		else k_front_rowtail<2><<<rg, 64, 0, s>>>(bgr, yq, maps, m_stride, flags, f_stride, force_fallback);
-		k_front_chain<<<(n + 63) / 64, 64, 0, s>>>(maps, m_stride, flags, f_stride, st, s_stride, n);
-#ifdef NHW_DEV
-		{ const char *e = getenv("NHW_BAND_STOP"); if (e) force_fallback |= atoi(e) << 8; }
 #endif
-		if (fam == 0) k_front_band<1, 1, 0><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback, n);
-		else if (fam == 1) k_front_band<1, 1, 1><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback, n);
-		else k_front_band<1, 1, 2><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, force_fallback, n);
-	} else
-		k_front_band<0, 1, 0><<<grid, FB_NT, lds, s>>>(bgr, 0, yq, pu, pv, c_stride, st, s_stride, proc, jpeg, plane_stride, ll1, ll1_stride, keep, keep_stride, 0, n);
 }
 
 /* Compatibility mode (NHW_COMPAT_GLIBC_ONESHOT) only: the kernel-map cells whose memory the stock binary's malloc hands out again as

@@ -1,18 +1,17 @@
 """Regenerates the kernel table of DESIGN.md (between the KERNEL_TABLE markers) from the committed profile summaries, so that the numbers
 cannot drift from the files they cite.   usage: python profiles/make_design_table.py [--check]
-inputs: profiles/round3_kernel_stats_1stream.txt (rocprofv3 --kernel-trace --stats, one stream), profiles/round3_pmc.json (FETCH_SIZE and
+inputs: profiles/round4_kernel_stats_1stream.txt (rocprofv3 --kernel-trace --stats, one stream), profiles/round4_pmc.json (FETCH_SIZE and
 WRITE_SIZE per kernel from separate --pmc passes; KiB; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STATS = os.path.join(ROOT, "profiles", "round3_kernel_stats_1stream.txt")
-PMC = os.path.join(ROOT, "profiles", "round3_pmc.json")
+STATS = os.path.join(ROOT, "profiles", "round4_kernel_stats_1stream.txt")
+PMC = os.path.join(ROOT, "profiles", "round4_pmc.json")
 BATCHES = 7.0            # bench.py --steps 5 --warmup 2 in profiles/collect.sh
 PH = ["L1", "L2", "L3", "L4A", "C0", "C2", "C3", "C4", "C5", "FINAL", "L4B", "L4C", "L4D", "LLC", "L4C2"]
 WV = ["DQ1", "DQ0", "EMIT", "QUANT"]
 WHAT = {
-    "k_front_band": "a1 + a2 + Y2 + Y3 fused: BGR24 -> Y, 4:2:0 chroma planes out, pre-filter, both directions of the level-1 analysis, LL copy (16 output rows, 512 threads, 80 KB LDS per workgroup)",
-    "k_front_rowtail": "a2: carry transfer map of every image row from its last pixels (reads BGR)",
-    "k_front_chain": "a2: the rows' maps chained down the image: entry state of every row",
+    "k_front_image": "a1 + a2 + Y2 + Y3 fused: BGR24 -> Y, 4:2:0 chroma planes out, pre-filter (carry chained in the kernel), both directions of the level-1 analysis, LL copy; a workgroup walks an image (32 rows a band, 512 threads, 78 KB LDS)",
+    "k_front_plain": "the same without the pre-filter (q >= 22; q <= 16 and the analysis stage from a luma plane): horizontal pass from registers, 64 rows a band",
     "k_dwt_ana<256>": "level-1 chroma analysis, level-2 luma analysis of both closed loops (whole block in LDS, persistent workgroups)",
     "k_dwt_ana<128>": "level-2 chroma analysis",
     "k_dwt_syn<256>": "level-2 luma synthesis of the second closed loop",
