@@ -266,24 +266,20 @@ def cpu_baseline_light(q, budget_s=4.0):
 def chroma_l1_ms(enc, n, repeats=3):
     """SURVEY 8(d) counts the chroma level-1 coefficients among the fused front kernel's 6 B/pixel, but that analysis runs as two launches of
     the 256 x 256 filterbank kernel on the chroma stream.  Their time for a batch of n images, measured here on its own
-    (hipEvents round the two launches, on the stage entry point's stream), so that the line can carry a roofline figure that includes it.
-    The stage entry point runs the reference's full form (int16 plane in, every plane out); the encoder's own two launches read the 4:2:0
-    byte plane directly and leave out a store nothing reads, so this is an upper bound of what they cost."""
+    (hipEvents round the two launches the way the encoder makes them -- from the 4:2:0 byte planes of the batch just encoded, nhw_stage_chroma_l1 --
+    on the current stream), so that the line can carry a roofline figure that includes it."""
     import torch
-    planes = torch.randint(0, 256, (2, n, 65536), dtype=torch.int16, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     best = None
     for _ in range(repeats + 1):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _comp in range(2):      # U, then V: wavelet_analysis(256, 0, 0) each (nhw_encoder.c:2265, 2576)
-            if enc.lib.nhw_stage_analysis(enc.h, planes[0].data_ptr(), planes[1].data_ptr(), n, 65536, 256, 256, 0, st) != 0:
-                return None
+        if enc.lib.nhw_stage_chroma_l1(enc.h, n, st) != 0:
+            return None
         b.record()
         torch.cuda.synchronize()
         t = a.elapsed_time(b)
         best = t if best is None else min(best, t)
-    del planes
     return best
 
 

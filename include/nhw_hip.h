@@ -106,6 +106,9 @@ int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t
                        int final_level, void *stream);
 int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size,
                         void *stream);
+/* the two chroma level-1 analyses (nhw_encoder.c:2265, 2576) as the encoder launches them for quality >= 15, on the 4:2:0 planes of the handle's
+ * last batch (a measurement hook: bench.py adds their time to the fused front kernel's) */
+int nhw_stage_chroma_l1(nhw_enc *e, int n, void *stream);
 
 /* ---- decoder (BASELINE config 5): replaces decode_image + write_image_bmp (decoder/codec.h:184-186,
  * decoder/nhw_decoder.c:54, decoder/nhw_decoder_cli.c:108), one launch sequence per batch of files ----

@@ -50,6 +50,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.nhw_device_count.restype = ctypes.c_int
     L.nhw_stage_color.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, P, P, P]
     L.nhw_stage_prefilter.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P]
+    L.nhw_stage_chroma_l1.argtypes = [P, ctypes.c_int, P]
     L.nhw_stage_analysis.argtypes = [P, P, P, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
     L.nhw_stage_synthesis.argtypes = [P, P, P, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, P]
     return L

@@ -534,6 +534,22 @@ extern "C" int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_
 	return NHW_OK;
 }
 
+/* the two chroma level-1 analyses (wavelet_analysis(256, 0, 0) of U and of V, nhw_encoder.c:2265, 2576) exactly as the encoder launches them for quality >= 15:
+ * from the 4:2:0 byte planes the front left in the workspace, without the store nothing reads.  A measurement hook: bench.py brackets it with
+ * events to add these launches' time to the fused front kernel's (SURVEY 8(d) counts their output among that kernel's bytes). */
+extern "C" int nhw_stage_chroma_l1(nhw_enc *e, int n, void *stream)
+{
+	if (!e || n < 1 || n > e->max_batch) { g_err = "bad argument"; return NHW_E_ARG; }
+	HIPCHK(hipSetDevice(e->device));
+	const NhwWs &ws = e->ws;
+	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+	for (int comp = 0; comp < 2; comp++)
+		nhw_launch_analysis(plane16(ws, B_CJPEG), plane16(ws, B_CPROC), n, ws.stride[B_CJPEG] / 2, H, H, 0, nullptr, 0, s, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2,
+		                    comp ? plane8(ws, B_PV) : plane8(ws, B_PU), ws.stride[B_PU], 1);
+	HIPCHK(hipGetLastError());
+	return NHW_OK;
+}
+
 extern "C" int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size, void *stream)
 {
 	if (!e || n_img < 1) return NHW_E_ARG;

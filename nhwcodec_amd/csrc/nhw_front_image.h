@@ -35,17 +35,17 @@ namespace nhw {
 /* byte offsets into the dynamic LDS block */
 #define FI_YB_OFF   16
 #define FI_KB_OFF   (FI_YB_OFF + FI_YROWS * FI_RS * 2)
-#define FI_STG_OFF  (FI_KB_OFF + 5 * FI_RS * 2)             /* chroma staging: 34 rows x (256 U + 256 V) bytes, over the rows the contrast map takes later */
+#define FI_STG_OFF  (FI_KB_OFF + 5 * FI_RS * 2)             /* chroma staging: 32 rows x (256 U + 256 V) bytes, over rows 5..20: the rows the SECOND half of the contrast pass fills */
 #define FI_TAB_OFF  (FI_KB_OFF + FI_KROWS * FI_RS * 2)
 #define FI_PT_OFF   FI_TAB_OFF                              /* 225 x 16 B: pair-rule entries */
 #define FI_CA_OFF   (FI_PT_OFF + 3600)                      /* 405 B (+3): class of a kernel value, clamped to -202 .. 202 */
 #define FI_CB_OFF   (FI_CA_OFF + 408)                       /* the same x 16 */
 #define FI_EN_OFF   (FI_CB_OFF + 408)                       /* 512 B: entry state of every carry segment of the band */
-#define FI_CR_OFF   (FI_EN_OFF + 512)                       /* 512 B: the last row of filtered chroma, kept for the next band */
-#define FI_MISC_OFF (FI_CR_OFF + 512)
+#define FI_CR_OFF   (FI_EN_OFF + 512)                       /* 2 x 512 B: the last row of filtered chroma, kept for the next band (written by one band while the row of the band before is read) */
+#define FI_MISC_OFF (FI_CR_OFF + 1024)
 #define FI_LDS_BYTES (FI_MISC_OFF + 64)
 static_assert(FI_STG_OFF % 16 == 0 && FI_CR_OFF % 16 == 0 && FI_PT_OFF % 16 == 0, "16-byte pieces");
-static_assert(FI_STG_OFF + 34 * 512 <= FI_TAB_OFF, "the chroma staging fits into the rows of the contrast map");
+static_assert(32 * 512 <= 16 * FI_RS * 2, "the chroma staging fits into rows 5..20 of the contrast map");
 static_assert(FI_LDS_BYTES <= 81920, "two workgroups to a CU");
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	int16_t *const ybuf = reinterpret_cast<int16_t *>(lds + FI_YB_OFF);
 	int16_t *const kbuf = reinterpret_cast<int16_t *>(lds + FI_KB_OFF);
-	uint8_t *const stg = lds + FI_STG_OFF;                          /* row j + 1 of it: filtered chroma of image row 32b + 1 + j, j = -1 .. 32 */
+	uint8_t *const stg = lds + FI_STG_OFF;                          /* row i of it: filtered chroma of image row 32b + 2 + i */
 	uint32_t *const ptab = reinterpret_cast<uint32_t *>(lds + FI_PT_OFF);
 	uint8_t *const tca = lds + FI_CA_OFF, *const tcb = lds + FI_CB_OFF;
 	uint8_t *const entry = lds + FI_EN_OFF;
@@ -308,10 +308,9 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				/* the pixel on the left of the group comes from the lane on the left (every lane takes part in the shuffle) */
 				uint32_t lu = (uint32_t)__shfl_up((int)uw[3], 1), lv = (uint32_t)__shfl_up((int)vw[3], 1);
 				if (g == 0) { lu = uw[0] << 16; lv = vw[0] << 16; }
-				*reinterpret_cast<uint2 *>(stg + (i + 2) * 512 + 8 * g) = chroma_h8(uw, lu);
-				*reinterpret_cast<uint2 *>(stg + (i + 2) * 512 + 256 + 8 * g) = chroma_h8(vw, lv);
+				*reinterpret_cast<uint2 *>(stg + i * 512 + 8 * g) = chroma_h8(uw, lu);
+				*reinterpret_cast<uint2 *>(stg + i * 512 + 256 + 8 * g) = chroma_h8(vw, lv);
 			}
-			if (t < 32) reinterpret_cast<uint4 *>(stg + 512)[t] = reinterpret_cast<const uint4 *>(crow)[t];   /* image row 32b+1, filtered by the band before */
 		} else {
 			const int t = opaque(t0);
 #pragma unroll
@@ -331,13 +330,14 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			const int t = opaque(t0);
 			const int pl = t >> 8, rr = (t >> 4) & 15, c16 = t & 15, r = 16 * b + 1 + rr;   /* chroma rows 16b+1 .. 16b+16; the band before the first: row 0 */
 			if (b < 0 ? rr == 15 : r < H) {
-				const uint8_t *sp = stg + (2 * rr + 1) * 512 + pl * 256 + 16 * c16;
-				const uint4 x0 = *reinterpret_cast<const uint4 *>(sp), x1 = *reinterpret_cast<const uint4 *>(sp + 512), x2 = *reinterpret_cast<const uint4 *>(sp + 1024);
+				/* image rows 32b+1+2rr, +1, +2: for rr = 0 the first of them is the last row of the band before */
+				const uint8_t *sp = stg + 2 * rr * 512 + pl * 256 + 16 * c16;
+				const uint4 x0 = *reinterpret_cast<const uint4 *>(rr ? sp - 512 : crow + ((b + 1) & 1) * 512 + pl * 256 + 16 * c16), x1 = *reinterpret_cast<const uint4 *>(sp), x2 = *reinterpret_cast<const uint4 *>(sp + 512);
 				uint4 o;
 				if (b < 0) o = make_uint4(avg_up(x1.x, x2.x), avg_up(x1.y, x2.y), avg_up(x1.z, x2.z), avg_up(x1.w, x2.w));   /* row 0: (r0 + r1 + 1) >> 1 */
 				else o = make_uint4(tri121(x0.x, x1.x, x2.x), tri121(x0.y, x1.y, x2.y), tri121(x0.z, x1.z, x2.z), tri121(x0.w, x1.w, x2.w));
 				*reinterpret_cast<uint4 *>((pl ? pvb : pub) + (size_t)img * c_stride + (b < 0 ? 0 : r) * H + 16 * c16) = o;
-				if (rr == 15) *reinterpret_cast<uint4 *>(crow + pl * 256 + 16 * c16) = x2;
+				if (rr == 15) *reinterpret_cast<uint4 *>(crow + (b & 1) * 512 + pl * 256 + 16 * c16) = x2;
 			}
 		}
 		if (b < 0) {
@@ -350,17 +350,20 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 		}
 		const int last_row = r0 + FI_BR < W - 2 ? r0 + FI_BR : W - 2; /* last image row of this band with a kernel value */
 		if (PRE) {
-			__syncthreads();                                           /* the staging rows become the contrast map */
-			FI_TICK(2); FI_STAMP(2);
+			FI_TICK(2);
 			/* ------------------------------------------------------------ contrast of image rows 32b+1 .. 32b+32, 8 pixels an item (image_processing.c:568-640).
 			 * The rows stay packed, two pixels to a dword (luma is never negative here).  The signed sum 9 x centre - block sum is packed
 			 * arithmetic on both pixels of a dword; a pixel's eight absolute differences are four v_sad_u16 against dwords that hold two
-			 * neighbours each.  Items are (row, group) with the row fastest: consecutive lanes sit a padded row apart, on consecutive banks. */
+			 * neighbours each.  Items are (row, group) with the row fastest: consecutive lanes sit a padded row apart, on consecutive banks.
+			 * Two halves: rows 17..32 first -- their map rows (21..36) are free, so this half runs beside the 4:2:0 step above, which still reads
+			 * the staging rows --, a barrier, then rows 1..16 over the staging rows. */
 			{
 			const int t = opaque(t0);
 #pragma unroll 1
 			for (int it = 0; it < 4; it++) {
-				const int k = t + FI_NT * it, rr = 1 + (k & 31), g = k >> 5;
+				if (it == 2) __syncthreads();                            /* the staging rows become the contrast map */
+				const int k = t + FI_NT * (it & 1), gh = k >> 4;
+				const int rr = (it < 2 ? 17 : 1) + (k & 15), g = (gh & ~7) | ((gh & 1) << 2) | ((gh >> 1) & 3);   /* 16 lanes a group; the two groups of a half-wavefront 16 banks apart */
 				if (r0 + rr > W - 2) continue;
 				const uint32_t *ru = reinterpret_cast<const uint32_t *>(ybuf + (rr - 1) * FI_RS) + 4 * g - 1, *rm = ru + FI_RD, *rd = rm + FI_RD;
 				uint32_t U[6], M[6], D[6], S[6];
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			if (t < FI_RD) reinterpret_cast<uint32_t *>(ybuf + 34 * FI_RS)[t] = reinterpret_cast<const uint32_t *>(ybuf + 32 * FI_RS)[t];   /* the next band's contrast wants row 32b+32 as it is now */
 			}
 			__syncthreads();
-			FI_TICK(3); FI_STAMP(3);
+			FI_TICK(3); FI_STAMP(2); FI_STAMP(3);
 			FI_DUMP(3, kbuf + 5 * FI_RS);
 			FI_DUMP(4, ybuf + FI_RS);
 			FI_DUMP(5, ybuf);
@@ -447,6 +450,9 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			/* ------------------------------------------------------------ replay the carry: a lane per row and PAIR of segments (sp, sp + 8), side by side in the halves
 			 * of a dword, every step packed 16-bit arithmetic.  Eight pixels at a time through registers. */
 			if (t0 < 32 * (FI_NSEG / 2)) {
+				/* half the workgroup's wavefronts walk the segments, the others wait at the barrier: the walkers are the band's critical path and
+				 * share their SIMDs with the other workgroup's wavefronts -- they go first */
+				__builtin_amdgcn_s_setprio(3);
 				const int t = opaque(t0);
 				const int rr = 1 + (t & 31), sp = t >> 5;
 				if (r0 + rr <= W - 2) {
@@ -473,6 +479,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 					}
 					if (sp == FI_NSEG / 2 - 1 && r0 + rr == last_row) misc[0] = (uint8_t)c29.y;
 				}
+				__builtin_amdgcn_s_setprio(0);
 			}
 			__syncthreads();
 			FI_TICK(5); FI_STAMP(5);
