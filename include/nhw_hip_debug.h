@@ -24,6 +24,10 @@ int nhw_debug_read(nhw_enc *e, int buf, int img, void *dst, size_t bytes);
 /* encoder: an order-independent 64-bit digest of the first `bytes` bytes of buffer `buf`, one per image, into device memory (n x uint64) */
 int nhw_debug_hash(nhw_enc *e, int buf, size_t bytes, int n, void *d_out, void *stream);
 
+/* encoder: the first `bytes` bytes of buffer `buf` of the first n images set to `byte` (the zero guard behind the buffer is not touched): a test
+ * that the production launch sequence -- which leaves out stores nothing reads -- never reads what an earlier batch left in a plane */
+int nhw_debug_fill(nhw_enc *e, int buf, int byte, size_t bytes, int n);
+
 /* decoder: the same two hooks (stage order: decode_image, decoder/nhw_decoder.c:54-1476; `what`: an index of the D_* list in nhw_dec.hip) */
 void nhw_dec_debug_stop_after(nhw_dec *d, int stage);
 int  nhw_dec_debug_read(nhw_dec *d, int what, int img, void *dst, size_t bytes);

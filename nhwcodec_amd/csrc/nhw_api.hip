@@ -584,6 +584,15 @@ extern "C" int nhw_debug_hash(nhw_enc *e, int buf, size_t bytes, int n, void *d_
 	HIPCHK(hipGetLastError());
 	return NHW_OK;
 }
+extern "C" int nhw_debug_fill(nhw_enc *e, int buf, int byte, size_t bytes, int n)
+{
+	if (!e || buf < 0 || buf >= B_COUNT || n < 1 || n > e->max_batch || bytes + GUARD > e->ws.stride[buf]) return NHW_E_ARG;
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemset2D(e->ws.base + e->ws.off[buf], e->ws.stride[buf], byte, bytes, (size_t)n));
+	HIPCHK(hipDeviceSynchronize());
+	return NHW_OK;
+}
 extern "C" int nhw_debug_read(nhw_enc *e, int buf, int img, void *dst, size_t bytes)
 {
 	if (!e || buf < 0 || buf >= B_COUNT || img < 0 || img >= e->max_batch || bytes > e->ws.stride[buf]) return NHW_E_ARG;

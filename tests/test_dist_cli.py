@@ -167,6 +167,25 @@ def test_cli_end_to_end_files(cli, oracle, tmp_path):
     assert rc == 1 and "device(s) visible" in err
 
 
+@pytest.mark.gpu
+def test_cli_two_workers_on_one_device_share_the_queue(cli, oracle, tmp_path):
+    """`--devices 0,0`: two worker threads, two encoder handles on device 0, one queue of chunks behind a mutex (what `--gpus G` runs with G > 1,
+    on the one GPU there is): every file equals the single-worker run's and the oracle's, whichever worker took its chunk -- at a rationed
+    quality and at the headline one, so that both front kernels and their per-handle attributes run twice in one process."""
+    for q, n in ((20, 40), (10, 24)):
+        one = tmp_path / f"one{q}"; two = tmp_path / f"two{q}"; one.mkdir(); two.mkdir()
+        assert _run(cli, f"-q{q}", "--gpus", "1", "--chunk", "7", "--synthetic", str(n), "--seed", "900", "--outdir", str(one))[0] == 0
+        rc, out, err = _run(cli, f"-q{q}", "--devices", "0,0", "--chunk", "7", "--synthetic", str(n), "--seed", "900", "--outdir", str(two))
+        assert rc == 0, err
+        for s in range(900, 900 + n):
+            a, b = (one / f"synth_{s}.nhw").read_bytes(), (two / f"synth_{s}.nhw").read_bytes()
+            assert a == b, f"q{q} seed {s}: the two-worker run differs from the one-worker run"
+        for s in (900, 900 + n // 2, 900 + n - 1):
+            assert (two / f"synth_{s}.nhw").read_bytes() == oracle.encode(oracle.synth(s), q)
+    rc, _, err = _run(cli, "--devices", "0,7", "--synthetic", "2", "--outdir", str(tmp_path))
+    assert rc == 1 and "device(s) visible" in err
+
+
 # ---------------------------------------------------------------- nhw-dec
 DEC_CLI = os.path.join(ROOT, "tools", "nhw-dec")
 REF_DEC_CLI = os.path.join(ROOT, "oracle", "_ref", "nhw-dec")

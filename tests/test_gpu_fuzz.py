@@ -138,3 +138,27 @@ def test_code_book_overflow_status_matches_the_oracle(q):
             want, rc = b"", int(str(ex).split("rc=")[-1])
         assert status[i] == rc and files[i] == want, f"image {i}: status {status[i]} (oracle {rc})"
     assert status[1] == (nhwcodec_amd.NHW_E_CODEBOOK if q > 16 else 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [7, 13, 16, 20, 23])
+def test_production_batches_never_read_stale_planes(q):
+    """The production launch sequence leaves out stores nothing reads (the transposed copy of the LL quadrant, the transposed first-direction
+    planes of the chroma analyses, the natural-orientation copies of the syntheses ...), which the stage checks do not: their kernels write
+    every plane.  So the work planes are filled with 0x7F7F garbage before a production batch: the files must still equal the oracle's --
+    a cell that is read without having been written in THIS batch shows up here."""
+    import nhwcodec_amd as na
+    from oracle.oraclepy import Oracle
+    orc = Oracle()
+    seeds = [3000 + 17 * q + i for i in range(6)]
+    imgs = np.stack([orc.synth(s) for s in seeds[:4]] + [make(seeds[4]), make(seeds[5])])
+    enc = na.Encoder(0, len(imgs))
+    enc.lib.nhw_debug_fill.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int]
+    enc.encode(imgs, q)                                     # a batch before, as in a long-running encoder
+    Q = 65536
+    for buf, nbytes in ((0, 8 * Q), (1, 8 * Q), (4, 2 * Q), (5, 2 * Q)):     # JPEG, PROC, CJPEG, CPROC (nhw_ws.h)
+        assert enc.lib.nhw_debug_fill(enc.h, buf, 0x7F, nbytes, len(imgs)) == 0
+    got = enc.encode(imgs, q)
+    enc.close()
+    for i in range(len(imgs)):
+        assert got[i] == orc.encode(imgs[i], q), f"q{q} image {i}: a production batch read a plane cell it had not written"

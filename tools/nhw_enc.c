@@ -9,7 +9,7 @@
  *
  * Batch extensions (not in the reference):
  *   nhw-enc [-q N] [--gpus G] --batch <dir>      every <dir>/x.bmp  -> <dir>/x.nhw, GPU batches of up to 1024 files
- *   nhw-enc [-q N] [--gpus G] --synthetic <count> [--seed S] --outdir <dir>
+ *   nhw-enc [-q N] [--gpus G | --devices a,b,..] --synthetic <count> [--seed S] --outdir <dir>
  *                                                SURVEY 8d generator on the device -> <dir>/synth_<seed>.nhw
  *   --stock-compat   reproduce the stock one-image-per-process binary instead of the canonical output (include/nhw_hip.h)
  * --gpus G: images are independent (encoder/nhw_encoder_cli.c:175-183 is a per-image sequence), so the job is a queue of chunks of up
@@ -46,7 +46,7 @@ static void usage(void)
 	        "  -h        print this help\n"
 	        "  -V        show version and legal information\n\n"
 	        "  example: nhw-enc -q15 image.bmp image.nhw\n"
-	        "Batch (MI355X build): %s [-q#] [--gpus g] --batch <dir> | --synthetic <n> [--seed s] --outdir <dir>\n"
+	        "Batch (MI355X build): %s [-q#] [--gpus g | --devices a,b,..] --batch <dir> | --synthetic <n> [--seed s] --outdir <dir>\n"
 	        "Tiles (MI355X build): %s [-q#] --tiles <big.bmp> <stem>   (width, height multiples of 512: one <stem>_y<r>_x<c>.nhw per 512x512 tile)\n"
 	        "Tar   (MI355X build): %s [-q#] --tar <in.tar> <out.tar>    (every x.bmp member of a ustar archive -> member x.nhw, in order)\n",
 	        PROGRAM, PROGRAM, PROGRAM, PROGRAM);
@@ -180,7 +180,8 @@ static int ends_with(const char *s, const char *suf)
 }
 
 /* the job queue of the batch modes: chunks of up to 1024 images, taken in order by one host thread per GPU */
-#define CHUNK 1024
+#define CHUNK 1024                 /* images per GPU batch at most */
+static int g_chunk = CHUNK;        /* --chunk N: images a worker takes from the queue at a time (1 .. CHUNK) */
 struct job {
 	int n, next;                   /* images in the job, first image nobody has taken yet */
 	int quality, stock_compat;
@@ -200,7 +201,7 @@ static void *worker_main(void *arg)
 	int imgs_pinned = 0;
 	uint64_t *off = (uint64_t *)malloc(sizeof(uint64_t) * (CHUNK + 1));
 	int32_t *st = (int32_t *)malloc(sizeof(int32_t) * CHUNK);
-	const int cap = jb->n < CHUNK ? jb->n : CHUNK;
+	const int cap = jb->n < g_chunk ? jb->n : g_chunk;
 	int rc, i;
 	if ((rc = nhw_enc_create(w->device, cap, &enc))) die_lib("nhw_enc_create", rc);
 	if (jb->stock_compat) nhw_enc_set_compat(enc, NHW_COMPAT_GLIBC_ONESHOT);
@@ -214,7 +215,7 @@ static void *worker_main(void *arg)
 	for (;;) {
 		int base, m;
 		pthread_mutex_lock(&jb->lock);
-		base = jb->next; m = jb->n - base < CHUNK ? jb->n - base : CHUNK; jb->next += m > 0 ? m : 0;
+		base = jb->next; m = jb->n - base < g_chunk ? jb->n - base : g_chunk; jb->next += m > 0 ? m : 0;
 		pthread_mutex_unlock(&jb->lock);
 		if (m <= 0) break;
 		if (jb->outdir) rc = nhw_enc_synth_batch(enc, m, jb->seed + (uint32_t)base, jb->quality, arena, (size_t)cap * NHW_OUT_STRIDE, off, st);
@@ -369,6 +370,7 @@ static int encode_tar(const char *in_path, const char *out_path, int quality, in
 int main(int argc, char **argv)
 {
 	int quality = QUALITY_DEFAULT, overwrite = 0, synthetic = 0, gpus = 1, i;
+	int devlist[16], ndevlist = 0;
 	uint32_t seed = 0;
 	const char *batch_dir = NULL, *outdir = NULL;
 	int tiles = 0, tar = 0;
@@ -382,6 +384,12 @@ int main(int argc, char **argv)
 		if (!strcmp(argv[1], "--seed") && argc > 2) { seed = (uint32_t)strtoul(argv[2], NULL, 10); argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--outdir") && argc > 2) { outdir = argv[2]; argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--gpus") && argc > 2) { gpus = atoi(argv[2]); argc -= 2; argv += 2; continue; }
+		if (!strcmp(argv[1], "--chunk") && argc > 2) { g_chunk = atoi(argv[2]); if (g_chunk < 1) g_chunk = 1; if (g_chunk > CHUNK) g_chunk = CHUNK; argc -= 2; argv += 2; continue; }
+		if (!strcmp(argv[1], "--devices") && argc > 2) {            /* one worker per entry; a device may be named more than once (two handles, two workers on one GPU) */
+			const char *p = argv[2];
+			while (*p && ndevlist < 16) { devlist[ndevlist++] = (int)strtol(p, (char **)&p, 10); if (*p == ',') p++; else break; }
+			argc -= 2; argv += 2; continue;
+		}
 		if (!strcmp(argv[1], "--stock-compat")) { stock_compat = 1; argc -= 1; argv += 1; continue; }
 		if (!strcmp(argv[1], "--tiles")) { tiles = 1; argc -= 1; argv += 1; continue; }
 		if (!strcmp(argv[1], "--tar")) { tar = 1; argc -= 1; argv += 1; continue; }
@@ -439,9 +447,15 @@ int main(int argc, char **argv)
 		}
 		if (ndev < 1) { fprintf(stderr, "%s: no GPU visible\n", PROGRAM); return 2; }
 		if (gpus < 1) gpus = 1;
-		if (gpus > ndev) { fprintf(stderr, "%s: --gpus %d but %d device(s) visible\n", PROGRAM, gpus, ndev); return 1; }
-		if (gpus > 16) gpus = 16;
-		for (g = 0; g < gpus; g++) { wk[g].jb = &jb; wk[g].device = g; wk[g].bad = 0; pthread_create(&th[g], NULL, worker_main, &wk[g]); }
+		if (ndevlist) {
+			gpus = ndevlist;
+			for (g = 0; g < gpus; g++) if (devlist[g] < 0 || devlist[g] >= ndev) { fprintf(stderr, "%s: --devices names device %d but %d device(s) visible\n", PROGRAM, devlist[g], ndev); return 1; }
+		} else {
+			if (gpus > ndev) { fprintf(stderr, "%s: --gpus %d but %d device(s) visible\n", PROGRAM, gpus, ndev); return 1; }
+			if (gpus > 16) gpus = 16;
+			for (g = 0; g < gpus; g++) devlist[g] = g;
+		}
+		for (g = 0; g < gpus; g++) { wk[g].jb = &jb; wk[g].device = devlist[g]; wk[g].bad = 0; pthread_create(&th[g], NULL, worker_main, &wk[g]); }
 		for (g = 0; g < gpus; g++) { pthread_join(th[g], NULL); bad += wk[g].bad; }
 		return bad ? 1 : 0;
 	}
