@@ -31,6 +31,9 @@ int nhw_debug_fill(nhw_enc *e, int buf, int byte, size_t bytes, int n);
 /* decoder: the same two hooks (stage order: decode_image, decoder/nhw_decoder.c:54-1476; `what`: an index of the D_* list in nhw_dec.hip) */
 void nhw_dec_debug_stop_after(nhw_dec *d, int stage);
 int  nhw_dec_debug_read(nhw_dec *d, int what, int img, void *dst, size_t bytes);
+/* decoder: the colour matrix of write_image_bmp (nhw_decoder_cli.c:133-283) for quality q on n (Y, U, V) byte triples in device memory (n a
+ * multiple of 8) -> n x 3 bytes in the order the reference writes them, through the functions k_dec_final runs: the exhaustive 2^24 test */
+int  nhw_dec_debug_colour(int quality, const void *d_yuv, void *d_rgb, int n);
 
 #ifdef __cplusplus
 }

@@ -1875,6 +1875,72 @@ DEV void yuv_to_bytes(int q, int yv, int uv, int vv, int &R, int &G, int &B)
 	}
 	if (q < 20) { R = clip8(R); G = clip8(G); B = clip8(B); }
 }
+/* Quality >= 20, eight pixels at a time, in single precision -- exact by construction, like the encoder's conversion (nhw_front_image.h):
+ *   R = trunc(Y + 1.402 V' + 0.5) is floor(nR / 1000), nR = 1000 Y + 1402 V + c an integer below 2^24; v_cvt_pk_u8_f32 rounds to nearest even and
+ *   saturates to 0 .. 255, so the floor is rne(nR * 0.001f + (c / 1000 - 0.5 + 5e-4)): the true fractions are multiples of 1e-3, the float error
+ *   stays below 7e-5, a negative numerator clips to 0 either way.  B likewise; R and B run as one packed fma pair.
+ *   G = floor(Y + 0.5 - w / 100000), w = 34414 U' + 71414 V' (|w| < 2^24 with the -128 taken first): its fractions are multiples of 1e-5, less than
+ *   the float error (2.5e-5), so a value that comes out within 1e-4 of an integer boundary is done again in the integer / double form of
+ *   yuv_to_bytes (7 triples in 100 000); everything else is the float's rne(. - 0.5).
+ * One v_cvt_pk_u8_f32 converts, clips and drops a byte into its place of the 24 output bytes.  y: 8 luma bytes; u / v: 8 bytes each (x2 chroma done). */
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+DEV float ubf_(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }            /* v_cvt_f32_ubyte<k> */
+DEV void colour8_q20(uint2 y8, uint2 u8, uint2 v8, uint32_t w[6])
+{
+#pragma unroll
+	for (int e = 0; e < 6; e++) w[e] = 0;
+#pragma unroll
+	for (int px = 0; px < 8; px++) {
+		const uint32_t yw = px < 4 ? y8.x : y8.y, uw = px < 4 ? u8.x : u8.y, vw = px < 4 ? v8.x : v8.y;
+		const float yf = ubf_(yw, px & 3), uf = ubf_(uw, px & 3), vf = ubf_(vw, px & 3);
+		const float t = yf * 1000.f;
+		const f32x2_ nrb = __builtin_elementwise_fma((f32x2_){ vf, uf }, (f32x2_){ 1402.f, 1772.f }, (f32x2_){ t, t });
+		const f32x2_ xrb = __builtin_elementwise_fma(nrb, (f32x2_){ 0.001f, 0.001f }, (f32x2_){ (500.f - 1402.f * 128.f) / 1000.f - 0.4995f, (500.f - 1772.f * 128.f) / 1000.f - 0.4995f });
+		const f32x2_ uvc = (f32x2_){ uf, vf } - (f32x2_){ 128.f, 128.f };
+		const float wg = __builtin_fmaf(uvc.y, 71414.f, uvc.x * 34414.f);
+		const float xg = __builtin_fmaf(wg, -1e-5f, yf);                    /* the value the floor is taken of, minus 0.5 */
+		const int b0 = 3 * px;
+		w[b0 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(xrb.x, b0 & 3, w[b0 >> 2]);
+		w[(b0 + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(xrb.y, (b0 + 2) & 3, w[(b0 + 2) >> 2]);
+		if (__builtin_fabsf(xg - __builtin_rintf(xg)) > 0.5f - 1e-4f) {     /* too close to a boundary for single precision */
+			int R, G, B;
+			yuv_to_bytes(20, (int)yf, (int)uf, (int)vf, R, G, B);
+			w[(b0 + 1) >> 2] |= (uint32_t)G << (8 * ((b0 + 1) & 3));
+		} else w[(b0 + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(xg, (b0 + 1) & 3, w[(b0 + 1) >> 2]);
+	}
+}
+/* byte-wise (a + b + 1) >> 1 on four bytes (v_lerp_u8) */
+DEV uint32_t avg_up4(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
+/* x2 along a row (nhw_decoder.c:1150-1196): four chroma samples c0 (and the one behind them, low byte of c1) -> eight: the sample, then its mean with the next */
+DEV uint2 chroma_x2(uint32_t c0, uint32_t c1)
+{
+	const uint32_t odd = avg_up4(c0, __builtin_amdgcn_alignbyte(c1, c0, 1));
+	return make_uint2(__builtin_amdgcn_perm(odd, c0, 0x05010400u), __builtin_amdgcn_perm(odd, c0, 0x07030602u));
+}
+/* developer / test hook: the colour matrix of quality q on n (Y, U, V) byte triples, eight to a thread, through the functions k_dec_final runs */
+__global__ void k_dec_colour_probe(const uint8_t *__restrict__ yuv, uint8_t *__restrict__ rgb, int n8, int q)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n8) return;
+	const uint8_t *p = yuv + (size_t)i * 24;
+	uint8_t y[8], u[8], v[8];
+	for (int e = 0; e < 8; e++) { y[e] = p[3 * e]; u[e] = p[3 * e + 1]; v[e] = p[3 * e + 2]; }
+	uint32_t w[6];
+	if (q >= 20) {
+		auto pk = [](const uint8_t *b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); };
+		colour8_q20(make_uint2(pk(y), pk(y + 4)), make_uint2(pk(u), pk(u + 4)), make_uint2(pk(v), pk(v + 4)), w);
+	} else {
+		for (int e = 0; e < 6; e++) w[e] = 0;
+		for (int px = 0; px < 8; px++) {
+			int R, G, B;
+			yuv_to_bytes(q, y[px], u[px], v[px], R, G, B);
+			const int b0 = 3 * px;
+			w[b0 >> 2] |= (uint32_t)R << (8 * (b0 & 3)); w[(b0 + 1) >> 2] |= (uint32_t)G << (8 * ((b0 + 1) & 3)); w[(b0 + 2) >> 2] |= (uint32_t)B << (8 * ((b0 + 2) & 3));
+		}
+	}
+	for (int e = 0; e < 6; e++) reinterpret_cast<uint32_t *>(rgb + (size_t)i * 24)[e] = w[e];
+}
+
 /* ---------------------------------------------------------------------------------------------- final reconstruction, one kernel
  * Level-1 synthesis in both directions (decoder/wavelet_filterbank.c:52-357 as driven by nhw_decoder.c), the q > 21 corrections on the
  * plane between them (wavelet_filterbank.c:301-347), the 5-tap smoothing at the marked samples (nhw_decoder.c:859-876), the doubling of
@@ -2038,8 +2104,32 @@ __global__ __launch_bounds__(256) void k_dec_final(DecWs ws, uint8_t *out, int d
 	__syncthreads();
 	F_STOP(4);
 
-	/* colour (nhw_decoder_cli.c:133-283): a thread = four pixels of one row; chroma doubled on the fly from the staged rows */
-	{
+	/* colour (nhw_decoder_cli.c:133-283).  Quality >= 20: a thread = EIGHT pixels of one row, four rows a step; the chroma is doubled four bytes
+	 * at a time (byte-wise means: v_lerp_u8), the matrix runs in packed single precision (colour8_q20). */
+	if (q >= 20) {
+		const int t8 = tid & 63;
+		const uint8_t *cU = crow, *cV = crow + (FR / 2 + 1) * DH;
+		for (int it = 0; it < FR / 4; it++) {
+			const int lr = 4 * it + (tid >> 6), r = r0 + lr, ci = lr >> 1, j = 4 * t8;
+			const uint2 y8 = *reinterpret_cast<const uint2 *>(ybuf + lr * DW + 8 * t8);
+			const bool mean = r < 2 * DH - 2 && (r & 1);            /* odd rows: the mean of the two chroma rows (rows 510, 511: chroma row 255) */
+			uint2 c8[2];
+#pragma unroll
+			for (int pl = 0; pl < 2; pl++) {
+				const uint8_t *pc = (pl ? cV : cU) + ci * DH + j;
+				uint32_t a0 = *reinterpret_cast<const uint32_t *>(pc), a1 = j + 4 < DH ? *reinterpret_cast<const uint32_t *>(pc + 4) : a0 >> 24;   /* behind the row: its last sample again */
+				if (mean) {
+					const uint32_t b0 = *reinterpret_cast<const uint32_t *>(pc + DH), b1 = j + 4 < DH ? *reinterpret_cast<const uint32_t *>(pc + DH + 4) : b0 >> 24;
+					a0 = avg_up4(a0, b0); a1 = avg_up4(a1, b1);
+				}
+				c8[pl] = chroma_x2(a0, a1);
+			}
+			uint32_t w[6];
+			colour8_q20(y8, c8[0], c8[1], w);
+			uint2 *o = reinterpret_cast<uint2 *>(out + (size_t)img * NHW_IMG_BYTES + (size_t)r * DW * 3 + 24 * t8);   /* consecutive lanes, consecutive 24-byte pieces */
+			o[0] = make_uint2(w[0], w[1]); o[1] = make_uint2(w[2], w[3]); o[2] = make_uint2(w[4], w[5]);
+		}
+	} else {
 		const int t = tid & 127;
 		const uint8_t *cU = crow, *cV = crow + (FR / 2 + 1) * DH;
 		for (int it = 0; it < FR / 2; it++) {
@@ -2166,6 +2256,12 @@ extern "C" void nhw_dec_destroy(nhw_dec *d)
 extern "C" void nhw_dec_debug_stop_after(nhw_dec *d, int stage) { if (d) d->stop_after = stage; }
 
 /* debug: copy a workspace buffer of one image to the host (what = D_* index) */
+extern "C" int nhw_dec_debug_colour(int quality, const void *d_yuv, void *d_rgb, int n)
+{
+	if (!d_yuv || !d_rgb || n < 8 || (n & 7) || quality < 1 || quality > 23) return NHW_E_ARG;
+	k_dec_colour_probe<<<(n / 8 + 255) / 256, 256>>>((const uint8_t *)d_yuv, (uint8_t *)d_rgb, n / 8, quality);
+	return hipGetLastError() == hipSuccess ? NHW_OK : NHW_E_HIP;
+}
 extern "C" int nhw_dec_debug_read(nhw_dec *d, int what, int img, void *dst, size_t bytes)
 {
 	if (!d || what < 0 || what >= D_COUNT || img < 0 || img >= d->max_batch || bytes > k_dec_bytes[what]) { g_derr = "bad argument"; return NHW_E_ARG; }
