@@ -17,7 +17,8 @@
 /* launchers (nhw_front.hip, nhw_tail.hip) */
 void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_stride, uint8_t *u, uint8_t *v, size_t c_stride, hipStream_t s);
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, int16_t *keep, size_t keep_stride, hipStream_t s,
-                         int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0, const uint8_t *src8 = nullptr, size_t src8_plane = 0, int drop_t = 0);
+                         int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0, const uint8_t *src8 = nullptr, size_t src8_plane = 0, int drop_t = 0,
+                         const int16_t *alt = nullptr, size_t alt_plane = 0, int alt_stride = 0);
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s, int drop_nat = 0);
 void nhw_launch_l2_recon(int16_t *jpeg, const int16_t *proc, size_t plane_stride, int16_t *ll1, size_t ll1_stride, int n, hipStream_t s);
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
@@ -253,7 +254,9 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		CHROMA(chroma_head(0));
 	}
 	/* Y4: level-2 analysis (:139) */
-	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
+	/* the LL rows come from ll1 (the front's copy of them in natural orientation, res256): the front does not write them into the work plane as well
+	 * outside the stage checks, and this analysis fills that quadrant of the work plane itself (its transposed first-direction plane) */
+	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s, nullptr, 0, 0, 0, nullptr, 0, 0, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, H);
 	STAGE_DONE();
 	if (q > 6) {                                                     /* first closed loop (:141-283) */
 	nhw_launch_phase(PH_L1, ws, 0, out, d_sizes, d_status, s);

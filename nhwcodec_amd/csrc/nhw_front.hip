@@ -302,7 +302,8 @@ template <int S>
 __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int final_level,
                                                    int16_t *__restrict__ saveb, size_t save_plane, int save_row, int save_kind /* 1: copy of the S x S coefficient block, 2: of the LL quadrant copied back */, int n,
                                                    const uint8_t *__restrict__ src8b, size_t src8_plane /* the block as S x S bytes (a 4:2:0 chroma plane: nhw_encoder.c:2257-2263 widens it first), or null */,
-                                                   int drop_t /* the transposed first-direction plane is not stored: nothing reads it behind a chroma analysis (the dequantiser simulation rewrites every cell) */)
+                                                   int drop_t /* the transposed first-direction plane is not stored: nothing reads it behind a chroma analysis (the dequantiser simulation rewrites every cell) */,
+                                                   const int16_t *__restrict__ altb, size_t alt_plane, int alt_stride /* the block is read from another int16 plane (the first level-2 analysis of the luma takes the LL rows from ll1: the front no longer copies them into the work plane), or null */)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4, NPRE = S * (S / 8) / NT_;
@@ -312,10 +313,11 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 	 * the memory system idle in between.  A workgroup therefore works through several images and has the next block on its way, in registers,
 	 * while it filters the present one.  The barriers order LDS traffic only (no thread reads global memory another one wrote). */
 	uint4 pre[NPRE];
+	const int sstride = altb ? alt_stride : stride;
 	if ((int)blockIdx.x < n) {
-		const int16_t *src = jpegb + (size_t)blockIdx.x * plane_stride;
+		const int16_t *src = altb ? altb + (size_t)blockIdx.x * alt_plane : jpegb + (size_t)blockIdx.x * plane_stride;
 #pragma unroll
-		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = ana_piece(src, src8b ? src8b + (size_t)blockIdx.x * src8_plane : nullptr, v / (S / 8), v % (S / 8), stride, S); }
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = ana_piece(src, src8b ? src8b + (size_t)blockIdx.x * src8_plane : nullptr, v / (S / 8), v % (S / 8), sstride, S); }
 	}
 	for (int img = blockIdx.x; img < n; img += gridDim.x) {
 	int16_t *jpeg = jpegb + (size_t)img * plane_stride, *proc = procb + (size_t)img * plane_stride;
@@ -328,9 +330,9 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 	}
 	lds_barrier();
 	if (img + (int)gridDim.x < n) {
-		const int16_t *src = jpegb + (size_t)(img + gridDim.x) * plane_stride;
+		const int16_t *src = altb ? altb + (size_t)(img + gridDim.x) * alt_plane : jpegb + (size_t)(img + gridDim.x) * plane_stride;
 #pragma unroll
-		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = ana_piece(src, src8b ? src8b + (size_t)(img + gridDim.x) * src8_plane : nullptr, v / (S / 8), v % (S / 8), stride, S); }
+		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = ana_piece(src, src8b ? src8b + (size_t)(img + gridDim.x) * src8_plane : nullptr, v / (S / 8), v % (S / 8), sstride, S); }
 	}
 	for (int i = 0; i < 16; i++) {                                 /* first direction (filters.c:40-86): un-normalised taps */
 		int16_t *x = A + (wv * 16 + i) * LS;
@@ -474,12 +476,13 @@ void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, in
 /* save (optional): a second destination for the block the reference copies right after the transform -- the S x S coefficient block
  * (save_kind 1) or the LL quadrant in natural orientation (save_kind 2) -- written by the fused kernels, by a block copy otherwise */
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level,
-                         int16_t *keep, size_t keep_stride, hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind, const uint8_t *src8, size_t src8_plane, int drop_t)
+                         int16_t *keep, size_t keep_stride, hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind, const uint8_t *src8, size_t src8_plane, int drop_t,
+                         const int16_t *alt, size_t alt_plane, int alt_stride)
 {
 	if (!save) save_kind = 0;
-	if (size == 256 && !keep) { k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane, drop_t); return; }
-	if (size == 128 && !keep) { k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0, drop_t); return; }
-	(void)keep; (void)keep_stride;       /* size 512 is the band kernel's (nhw_launch_front_fused); nothing else is called with another size */
+	if (size == 256 && !keep) { k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane, drop_t, alt, alt_plane, alt_stride); return; }
+	if (size == 128 && !keep) { k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0, drop_t, nullptr, 0, 0); return; }
+	(void)keep; (void)keep_stride;       /* size 512 is the front kernels' (nhw_launch_front_fused); nothing else is called with another size */
 }
 
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s, int drop_nat)

@@ -655,7 +655,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				if (LEFT) {                                            /* LL in natural orientation: jpeg[ky][kx] and ll1[ky][kx], kx < 256 (wavelet_filterbank.c:172-184, nhw_encoder.c:127-135) */
 					uint32_t *jp = reinterpret_cast<uint32_t *>(jpeg + (size_t)(16 * b + kb) * W) + cp, *lp = reinterpret_cast<uint32_t *>(ll1 + (size_t)(16 * b + kb) * H) + cp;
 #pragma unroll
-					for (int kk = 0; kk < 8; kk++) { jp[kk * (W / 2)] = lo[kk]; lp[kk * (H / 2)] = lo[kk]; }
+					for (int kk = 0; kk < 8; kk++) { if (flags & 0x100000) jp[kk * (W / 2)] = lo[kk]; lp[kk * (H / 2)] = lo[kk]; }   /* (the copy in the work plane: stage checks only -- the level-2 analysis reads ll1) */
 				}
 			};
 			if (__builtin_amdgcn_readfirstlane(cp) < H / 2) vertical(std::true_type{}); else vertical(std::false_type{});
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 					st16(op + W + H, pack_hi(hi[0], hi[1]), pack_hi(hi[2], hi[3]), pack_hi(hi[4], hi[5]), pack_hi(hi[6], hi[7]));
 					if (LEFT) {
 #pragma unroll
-						for (int kk = 0; kk < 8; kk++) { jp[(8 * part + kk) * (W / 2)] = lo[kk]; lp[(8 * part + kk) * (H / 2)] = lo[kk]; }
+						for (int kk = 0; kk < 8; kk++) { if (flags & 0x100000) jp[(8 * part + kk) * (W / 2)] = lo[kk]; lp[(8 * part + kk) * (H / 2)] = lo[kk]; }
 					}
 				}
 			};
