@@ -283,6 +283,7 @@ void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_str
 }
 
 /* keep != nullptr: copy of the first 256 rows x 512 of the transposed pass-1 plane (q>=22, level 0) */
+__device__ __forceinline__ uint32_t pk_max_u16x(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 /* ------------------------------------------------------------------------------------------------
  * Whole-block filterbank kernels for the 256- and 128-sized levels: one workgroup keeps the S x S block in
  * LDS (row stride S + 2 shorts: column walks hit 64 different banks), runs both directions there and writes
@@ -334,14 +335,27 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 #pragma unroll
 		for (int u = 0; u < NPRE; u++) { const int v = t + u * NT_; pre[u] = ana_piece(src, src8b ? src8b + (size_t)(img + gridDim.x) * src8_plane : nullptr, v / (S / 8), v % (S / 8), sstride, S); }
 	}
+	/* Both directions read a line two cells to a dword, a lane its own pair (cells 2k, 2k+1); the pair on the left and the first cell on the right
+	 * come over the lanes (DPP shifts by one lane, the seam between the two halves of a 256-cell line through a readlane): one LDS read per lane
+	 * and output pair where there were five 16-bit ones -- the kernel was bound by its LDS instructions. */
 	for (int i = 0; i < 16; i++) {                                 /* first direction (filters.c:40-86): un-normalised taps */
 		int16_t *x = A + (wv * 16 + i) * LS;
+		uint32_t Dw[PPL];
 		int lo[PPL], hi[PPL];
 #pragma unroll
+		for (int u = 0; u < PPL; u++) Dw[u] = reinterpret_cast<const uint32_t *>(x)[lane + 64 * u];
+#pragma unroll
 		for (int u = 0; u < PPL; u++) {
-			const int k = lane + 64 * u;
-			lo[u] = tap5s<S>(x, 1, k);
-			hi[u] = k < HLF - 1 ? (x[2 * k + 1] << 1) - (x[2 * k] + x[2 * k + 2]) : ((x[S - 1] - x[S - 2]) << 1);
+			uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Dw[u], 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+			uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Dw[u], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+			if (u > 0) { const uint32_t seam = (uint32_t)__builtin_amdgcn_readlane((int)Dw[u > 0 ? u - 1 : 0], 63); if (lane == 0) pv = seam; }
+			if (u + 1 < PPL) { const uint32_t seam = (uint32_t)__builtin_amdgcn_readlane((int)Dw[u + 1 < PPL ? u + 1 : u], 0); if (lane == 63) nx = seam; }
+			else if (lane == 63) nx = Dw[u];                           /* x[S] = x[S - 2] */
+			const int e0 = (int16_t)(Dw[u] & 0xFFFF), o0 = (int)Dw[u] >> 16, e1 = (int16_t)(nx & 0xFFFF);
+			int em1 = (int16_t)(pv & 0xFFFF), om1 = (int)pv >> 16;
+			if (u == 0 && lane == 0) { em1 = e1; om1 = o0; }           /* x[-2] = x[2], x[-1] = x[1] */
+			lo[u] = 6 * e0 + 2 * (om1 + o0) - (em1 + e1);
+			hi[u] = (o0 << 1) - (e0 + e1);                             /* the last one: (x[S-1] - x[S-2]) << 1, which is what e1 = e0 gives */
 		}
 #pragma unroll
 		for (int u = 0; u < PPL; u++) { x[lane + 64 * u] = (int16_t)lo[u]; x[HLF + lane + 64 * u] = (int16_t)hi[u]; }
@@ -354,31 +368,108 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 		*reinterpret_cast<uint32_t *>(jpeg + (size_t)i * stride + j) = (uint16_t)A[j * LS + i] | ((uint32_t)(uint16_t)A[(j + 1) * LS + i] << 16);
 	}
 	lds_barrier();
-	for (int i = 0; i < 16; i++) {                                 /* second direction along the columns (filters.c:88-287) */
-		const int c = wv * 16 + i;
-		int16_t *x = A + c;
-		int lo[PPL], hi[PPL];
+	for (int i = 0; i < 8; i++) {                                  /* second direction along the columns (filters.c:88-287), two columns (one dword) at a time */
+		const int c = wv * 16 + 2 * i;
+		const bool left = c < HLF;                                 /* the same for both columns and for the whole wavefront */
+		uint32_t Ew[PPL], Ow[PPL];
+		int lo[PPL][2], hi[PPL][2];
 #pragma unroll
 		for (int u = 0; u < PPL; u++) {
 			const int k = lane + 64 * u;
-			if (c < HLF) {
-				const int r = tap5s<S>(x, LS, k);
-				const int carry = k > 0 ? diffuse(tap5s<S>(x, LS, k - 1)) : 0;
-				lo[u] = rnd_half_away((int16_t)(r + carry), 6);
-				hi[u] = k < HLF - 1 ? rnd_half_away(pair_predict_s(x, LS, k), 3) : ((x[(S - 1) * LS] - x[(S - 2) * LS]) >> 3);
-			} else {
-				lo[u] = rnd_half_away(tap5s<S>(x, LS, k), 4);
-				if (k < HLF - 1) { const int r = pair_predict_s(x, LS, k); hi[u] = r > 0 ? (r + 1) >> 1 : r >> 1; }
-				else hi[u] = ((x[(S - 1) * LS] - x[(S - 2) * LS]) + 1) >> 1;
+			Ew[u] = *reinterpret_cast<const uint32_t *>(A + (2 * k) * LS + c); Ow[u] = *reinterpret_cast<const uint32_t *>(A + (2 * k + 1) * LS + c);
+		}
+		/* Two columns side by side in packed 16-bit arithmetic wherever nothing can leave 16 bits: with every cell of the wavefront's two columns in
+		 * -1300 .. 3000 the un-normalised sums stay inside (10 x 3000 + 2 x 1300 < 32768) -- which is every block of a real picture (the level-2
+		 * input is LL1, the level-1 chroma input a byte plane).  A block outside that range takes the 32-bit form below, which follows the
+		 * reference's int arithmetic where it wraps. */
+		bool wide = false;
+#pragma unroll
+		for (int u = 0; u < PPL; u++) {
+			const uint32_t mx = pk_max_u16x(pk_add16(Ew[u], 0x05140514u), pk_add16(Ow[u], 0x05140514u));   /* + 1300: in range = at most 4300 as unsigned */
+			wide |= (mx & 0xFFFFu) > 4300u || (mx >> 16) > 4300u;
+		}
+		if (!__any(wide)) {
+			uint32_t rlast = 0;
+#pragma unroll
+			for (int u = 0; u < PPL; u++) {
+				const int k = lane + 64 * u;
+				uint32_t em = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x138, 0xF, 0xF, false), om = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ow[u], 0x138, 0xF, 0xF, false);
+				uint32_t en = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x130, 0xF, 0xF, false);
+				if (u > 0) {
+					const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u > 0 ? u - 1 : 0], 63), so_ = (uint32_t)__builtin_amdgcn_readlane((int)Ow[u > 0 ? u - 1 : 0], 63);
+					if (lane == 0) { em = se; om = so_; }
+				}
+				if (u + 1 < PPL) { const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u + 1 < PPL ? u + 1 : u], 0); if (lane == 63) en = se; }
+				else if (lane == 63) en = Ew[u];
+				if (u == 0 && lane == 0) { em = en; om = Ow[u]; }
+				const s16x2 e0 = as_s(Ew[u]), o0 = as_s(Ow[u]), em1 = as_s(em), om1 = as_s(om), e1 = as_s(en);
+				const s16x2 r = e0 * (s16x2)(short)6 + ((om1 + o0) << 1) - (em1 + e1);
+				s16x2 a = e0 + e1;
+				a = a + (a & (em1 + e0) & as_s((k & 1) ? 0x00010001u : 0u));
+				const s16x2 pp = o0 - (a >> 1), tail = o0 - e0;
+				s16x2 l, h;
+				if (left) {
+					uint32_t rp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)as_w(r), 0x138, 0xF, 0xF, false);
+					if (lane == 0) rp = rlast;
+					const s16x2 carry = k > 0 ? pk_diffuse(as_s(rp)) : (s16x2)(short)0;
+					rlast = (uint32_t)__builtin_amdgcn_readlane((int)as_w(r), 63);
+					l = pk_rnd_half_away(r + carry, 6);
+					h = k < HLF - 1 ? pk_rnd_half_away(pp, 3) : (tail >> 3);
+				} else {
+					l = pk_rnd_half_away(r, 4);
+					h = k < HLF - 1 ? pk_rnd_half_away(pp, 1) : ((tail + (s16x2)(short)1) >> 1);   /* pp > 0 ? (pp + 1) >> 1 : pp >> 1 is rounding half away at shift 1 */
+				}
+				lo[u][0] = l.x; lo[u][1] = l.y; hi[u][0] = h.x; hi[u][1] = h.y;
+			}
+		} else {
+		int rlast[2] = { 0, 0 };                                    /* r of cell 63 of the half before (the seam of the carry) */
+#pragma unroll
+			for (int u = 0; u < PPL; u++) {
+				const int k = lane + 64 * u;
+				uint32_t em = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x138, 0xF, 0xF, false), om = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ow[u], 0x138, 0xF, 0xF, false);
+				uint32_t en = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x130, 0xF, 0xF, false);
+				if (u > 0) {
+					const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u > 0 ? u - 1 : 0], 63), so_ = (uint32_t)__builtin_amdgcn_readlane((int)Ow[u > 0 ? u - 1 : 0], 63);
+					if (lane == 0) { em = se; om = so_; }
+				}
+				if (u + 1 < PPL) { const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u + 1 < PPL ? u + 1 : u], 0); if (lane == 63) en = se; }
+				else if (lane == 63) en = Ew[u];                           /* x[S] = x[S - 2] */
+				if (u == 0 && lane == 0) { em = en; om = Ow[u]; }           /* x[-2] = x[2], x[-1] = x[1] */
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const int e0 = h ? (int)Ew[u] >> 16 : (int16_t)(Ew[u] & 0xFFFF), o0 = h ? (int)Ow[u] >> 16 : (int16_t)(Ow[u] & 0xFFFF);
+					const int em1 = h ? (int)em >> 16 : (int16_t)(em & 0xFFFF), om1 = h ? (int)om >> 16 : (int16_t)(om & 0xFFFF), e1 = h ? (int)en >> 16 : (int16_t)(en & 0xFFFF);
+					const int r = 6 * e0 + 2 * (om1 + o0) - (em1 + e1);
+					int a = e0 + e1;
+					if ((k & 1) && (a & 1) && ((em1 + e0) & 1)) a++;
+					const int pp = o0 - (a >> 1), tail = o0 - e0;          /* the predicted odd sample; the last one: x[S-1] - x[S-2] */
+					if (left) {
+						int rp = __builtin_amdgcn_update_dpp(0, r, 0x138, 0xF, 0xF, false);   /* the cell before: its carry comes in (filters.c:203-287) */
+						if (lane == 0) rp = rlast[h];
+						const int carry = k > 0 ? diffuse(rp) : 0;
+						rlast[h] = __builtin_amdgcn_readlane(r, 63);
+						lo[u][h] = rnd_half_away((int16_t)(r + carry), 6);
+						hi[u][h] = k < HLF - 1 ? rnd_half_away(pp, 3) : (tail >> 3);
+					} else {
+						lo[u][h] = rnd_half_away(r, 4);
+						hi[u][h] = k < HLF - 1 ? (pp > 0 ? (pp + 1) >> 1 : pp >> 1) : ((tail + 1) >> 1);
+					}
+				}
 			}
 		}
-		int16_t *o = proc + (size_t)c * stride;
 #pragma unroll
-		for (int u = 0; u < PPL; u++) {
-			const int k = lane + 64 * u;
-			o[k] = (int16_t)lo[u]; o[HLF + k] = (int16_t)hi[u];
-			if (save_kind == 1) { save[(size_t)c * save_row + k] = (int16_t)lo[u]; save[(size_t)c * save_row + HLF + k] = (int16_t)hi[u]; }
-			if (!final_level && c < HLF) x[k * LS] = (int16_t)lo[u];  /* LL, parked in the column's own cells */
+		for (int h = 0; h < 2; h++) {
+			int16_t *o = proc + (size_t)(c + h) * stride;
+#pragma unroll
+			for (int u = 0; u < PPL; u++) {
+				const int k = lane + 64 * u;
+				o[k] = (int16_t)lo[u][h]; o[HLF + k] = (int16_t)hi[u][h];
+				if (save_kind == 1) { save[(size_t)(c + h) * save_row + k] = (int16_t)lo[u][h]; save[(size_t)(c + h) * save_row + HLF + k] = (int16_t)hi[u][h]; }
+			}
+		}
+		if (!final_level && left) {                                  /* LL, parked in the columns' own cells (every lane has read its taps by now) */
+#pragma unroll
+			for (int u = 0; u < PPL; u++) *reinterpret_cast<uint32_t *>(A + (lane + 64 * u) * LS + c) = (uint32_t)(uint16_t)lo[u][0] | ((uint32_t)(uint16_t)lo[u][1] << 16);
 		}
 	}
 	if (!final_level) {
