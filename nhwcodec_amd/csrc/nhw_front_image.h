@@ -151,10 +151,24 @@ __device__ __forceinline__ void convert4(uint32_t w0, uint32_t w1, uint32_t w2, 
 			uw = __builtin_amdgcn_cvt_pk_u8_f32(t.x, e, uw);
 			vw = __builtin_amdgcn_cvt_pk_u8_f32(t.y, e, vw);
 		} else {
-			const uint8_t px[3] = { (uint8_t)(wv[(3 * e) >> 2] >> (8 * ((3 * e) & 3))), (uint8_t)(wv[(3 * e + 1) >> 2] >> (8 * ((3 * e + 1) & 3))), (uint8_t)(wv[(3 * e + 2) >> 2] >> (8 * ((3 * e + 2) & 3))) };
-			int U, V;
-			convert_uv<2>(px, yq, U, V);
-			uw |= (uint32_t)U << (8 * e); vw |= (uint32_t)V << (8 * e);
+			/* q17: 0.94 x the same sums through a float (colorspace.c:196-214).  Exactly, the value is N / 10^6, N = 94 s + 128.5e6 (128.4e6 below zero), and
+			 * the reference's float form can only differ from floor(N / 10^6) within 1e-4 of an integer (convert_uv<2>).  x = s x 9.4e-5f + bias is off by
+			 * less than 2e-5: further than 1.3e-4 from an integer its floor is the answer; the 2.6e-4 of the values that are closer take the reference's
+			 * arithmetic.  (All 2^24 triples: the colour test at q17.) */
+			const f32x2 suv = pk_fma(pk2(b2, b2), pk2(5000.f, -813.f), pk_fma(pk2(b1, b1), pk2(-3313.f, -4187.f), pk2(b0, b0) * pk2(-1687.f, 5000.f)));
+			f32x2 step;
+			asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(step) : "v"(suv), "v"(pk2(1.f, 1.f)));
+			const f32x2 x = pk_fma(suv, pk2(9.4e-5f, 9.4e-5f), pk_fma(step, pk2(0.1f, 0.1f), pk2(128.4f, 128.4f)));
+			const f32x2 fl = x - pk2(0.5f, 0.5f);
+			if (__builtin_fabsf(x.x - __builtin_rintf(x.x)) < 1.3e-4f || __builtin_fabsf(x.y - __builtin_rintf(x.y)) < 1.3e-4f) {
+				const uint8_t px[3] = { (uint8_t)(wv[(3 * e) >> 2] >> (8 * ((3 * e) & 3))), (uint8_t)(wv[(3 * e + 1) >> 2] >> (8 * ((3 * e + 1) & 3))), (uint8_t)(wv[(3 * e + 2) >> 2] >> (8 * ((3 * e + 2) & 3))) };
+				int U, V;
+				convert_uv<2>(px, yq, U, V);
+				uw = (uw & ~(0xFFu << (8 * e))) | ((uint32_t)U << (8 * e)); vw = (vw & ~(0xFFu << (8 * e))) | ((uint32_t)V << (8 * e));
+			} else {
+				uw = __builtin_amdgcn_cvt_pk_u8_f32(fl.x, e, uw);
+				vw = __builtin_amdgcn_cvt_pk_u8_f32(fl.y, e, vw);
+			}
 		}
 	}
 }
