@@ -470,27 +470,41 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				const int t = opaque(t0);
 				const int rr = 1 + (t & 31), sp = t >> 5;
 				if (r0 + rr <= W - 2) {
-					int16_t *ka = kbuf + (rr + 4) * FI_RS + 1 + FI_SEG * sp, *kb = ka + 256;
-					const int nb = sp == FI_NSEG / 2 - 1 ? FI_SEG - 2 : FI_SEG;   /* the last segment ends at column 510 */
+					/* a segment's 32 cells are the high half of dword 16 sg of the row, fifteen whole dwords and the low half of dword 16 sg + 16: the
+					 * cells come in as dwords (a tenth of the LDS instructions of 16-bit accesses), a step's two cells -- one of either segment -- are
+					 * put side by side with one v_perm, and the results go back as dwords, the two half dwords at the ends as 16-bit stores (their other
+					 * halves belong to the neighbouring segments' lanes).  The last segment of a row runs two cells over its end: cell 511 is 0 and
+					 * stays 0, the cell behind it is padding. */
+					uint32_t *da = reinterpret_cast<uint32_t *>(kbuf + (rr + 4) * FI_RS) + (FI_SEG / 2) * sp, *db = da + 128;
 					u16x2 carry = { entry[(rr - 1) * FI_NSEG + sp], entry[(rr - 1) * FI_NSEG + sp + FI_NSEG / 2] }, c29 = carry;
+					uint32_t la = da[0], lb = db[0];                      /* the dword the chunk starts in */
+					uint32_t pend = 0;                                   /* the last step's pair of results: the low halves of the dwords the next chunk starts in */
 #pragma unroll 1
 					for (int ch = 0; ch < FI_SEG / 8; ch++) {
-						s16x2 v[8];
+						uint32_t A[5], B[5];
+						A[0] = la; B[0] = lb;
 #pragma unroll
-						for (int e = 0; e < 8; e++) { v[e].x = ka[8 * ch + e]; v[e].y = kb[8 * ch + e]; }
+						for (int e = 1; e < 5; e++) { A[e] = da[4 * ch + e]; B[e] = db[4 * ch + e]; }
+						la = A[4]; lb = B[4];
+						uint32_t o[8];
 #pragma unroll
 						for (int e = 0; e < 8; e++) {                      /* v == 0: |v| + f(carry) <= 4 gives output 0 by itself; only the carry needs the reset */
-							const s16x2 sgn = v[e] >> 15;
-							const u16x2 a = __builtin_bit_cast(u16x2, (s16x2)((v[e] ^ sgn) - sgn));
+							const s16x2 v = as_s((e & 1) ? pack_lo(A[(e + 1) >> 1], B[(e + 1) >> 1]) : pack_hi(A[e >> 1], B[e >> 1]));
+							const s16x2 sgn = v >> 15;
+							const u16x2 a = __builtin_bit_cast(u16x2, (s16x2)((v ^ sgn) - sgn));
 							const u16x2 acc = a + ((carry + (u16x2)(2)) >> 2);
-							const s16x2 o = __builtin_bit_cast(s16x2, (u16x2)(acc >> 4));
-							v[e] = (o ^ sgn) - sgn;
+							const s16x2 ov = __builtin_bit_cast(s16x2, (u16x2)(acc >> 4));
+							o[e] = as_w((s16x2)((ov ^ sgn) - sgn));
 							carry = as_us(pk_mul_u16(as_w((u16x2)(acc & (u16x2)(15))), pk_min_u16(as_w(a), 0x00010001u)));
 							if (e == 5) c29 = carry;                        /* in the last chunk: the state behind column 510 */
 						}
+						if (ch == 0) { reinterpret_cast<int16_t *>(da)[1] = (int16_t)(o[0] & 0xFFFF); reinterpret_cast<int16_t *>(db)[1] = (int16_t)(o[0] >> 16); }
+						else { da[4 * ch] = pack_lo(pend, o[0]); db[4 * ch] = pack_hi(pend, o[0]); }
 #pragma unroll
-						for (int e = 0; e < 8; e++) { ka[8 * ch + e] = v[e].x; if (8 * ch + e < nb) kb[8 * ch + e] = v[e].y; }
+						for (int e = 1; e < 4; e++) { da[4 * ch + e] = pack_lo(o[2 * e - 1], o[2 * e]); db[4 * ch + e] = pack_hi(o[2 * e - 1], o[2 * e]); }
+						pend = o[7];
 					}
+					reinterpret_cast<int16_t *>(da + 16)[0] = (int16_t)(pend & 0xFFFF); reinterpret_cast<int16_t *>(db + 16)[0] = (int16_t)(pend >> 16);
 					if (sp == FI_NSEG / 2 - 1 && r0 + rr == last_row) misc[0] = (uint8_t)c29.y;
 				}
 				__builtin_amdgcn_s_setprio(0);
