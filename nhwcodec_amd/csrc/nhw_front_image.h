@@ -256,21 +256,30 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 	uint4 pf[NPF];
 	auto issue = [&](int b) {
 		const int t = opaque(t0);
+		/* Rows outside the image are asked for as the nearest row inside and not used: no branches here, so that every address is computed before
+		 * the first load goes out (with a branch per item the compiler put a wait for the first item's loads in front of the second item's --
+		 * a memory round trip in the open, every band). */
 		if (SRC) {
+			const uint4 *rp[2];
 #pragma unroll
 			for (int it = 0; it < 2; it++) {                         /* 16 pixels = 48 bytes an item, two items a thread */
-				const int row = FI_BR * b + 2 + (t >> 5) + 16 * it, g = t & 31;
-				if (row >= 0 && row < W) {
-					const uint4 *rp = reinterpret_cast<const uint4 *>(src + (size_t)row * (W * 3) + 48 * g);
-					pf[3 * it] = rp[0]; pf[3 * it + 1] = rp[1]; pf[3 * it + 2] = rp[2];
-				}
+				int row = FI_BR * b + 2 + (t >> 5) + 16 * it;
+				row = row < 0 ? 0 : row > W - 1 ? W - 1 : row;
+				rp[it] = reinterpret_cast<const uint4 *>(src + (size_t)row * (W * 3) + 48 * (t & 31));
 			}
+#pragma unroll
+			for (int it = 0; it < 2; it++) { pf[3 * it] = rp[it][0]; pf[3 * it + 1] = rp[it][1]; pf[3 * it + 2] = rp[it][2]; }
 		} else {
+			const uint4 *rp[4];
 #pragma unroll
 			for (int it = 0; it < 4; it++) {                         /* 8 pixels = 16 bytes an item, four items a thread */
-				const int k = t + FI_NT * it, row = FI_BR * b + 2 + (k >> 6);
-				if (row >= 0 && row < W) pf[it] = reinterpret_cast<const uint4 *>(reinterpret_cast<const int16_t *>(src) + (size_t)row * W)[k & 63];
+				const int k = t + FI_NT * it;
+				int row = FI_BR * b + 2 + (k >> 6);
+				row = row < 0 ? 0 : row > W - 1 ? W - 1 : row;
+				rp[it] = reinterpret_cast<const uint4 *>(reinterpret_cast<const int16_t *>(src) + (size_t)row * W) + (k & 63);
 			}
+#pragma unroll
+			for (int it = 0; it < 4; it++) pf[it] = *rp[it];
 		}
 	};
 	issue(-1);
@@ -750,17 +759,17 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 	uint4 pf[NPF];
 	auto issue = [&](int s) {                                       /* image rows 32s+1+2j, 32s+2+2j of the thread's group of 16 pixels */
 		const int t = opaque(t0), g = t & 31, j = t >> 5;
+		const uint4 *rp[2];                                            /* (rows outside the image: the nearest row inside, not used -- see k_front_image) */
 #pragma unroll
 		for (int h = 0; h < 2; h++) {
-			const int row = 32 * s + 1 + 2 * j + h;
-			if (row < 0 || row >= W) continue;
-			if (SRC) {
-				const uint4 *rp = reinterpret_cast<const uint4 *>(src + (size_t)row * (W * 3) + 48 * g);
-				pf[3 * h] = rp[0]; pf[3 * h + 1] = rp[1]; pf[3 * h + 2] = rp[2];
-			} else {
-				const uint4 *rp = reinterpret_cast<const uint4 *>(reinterpret_cast<const int16_t *>(src) + (size_t)row * W + 16 * g);
-				pf[2 * h] = rp[0]; pf[2 * h + 1] = rp[1];
-			}
+			int row = 32 * s + 1 + 2 * j + h;
+			row = row < 0 ? 0 : row > W - 1 ? W - 1 : row;
+			rp[h] = SRC ? reinterpret_cast<const uint4 *>(src + (size_t)row * (W * 3) + 48 * g) : reinterpret_cast<const uint4 *>(reinterpret_cast<const int16_t *>(src) + (size_t)row * W + 16 * g);
+		}
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			if (SRC) { pf[3 * h] = rp[h][0]; pf[3 * h + 1] = rp[h][1]; pf[3 * h + 2] = rp[h][2]; }
+			else { pf[2 * h] = rp[h][0]; pf[2 * h + 1] = rp[h][1]; }
 		}
 	};
 	issue(-1);
