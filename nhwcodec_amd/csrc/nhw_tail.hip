@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane);
 	else if (PH == WV_QUANT) {
 		__shared__ __attribute__((aligned(16))) uint8_t park[4][16 * QROW];
-		PROF_BEGIN(); wave_quantise_luma(&c, lane, park[threadIdx.x >> 6], ws.q > 21 || ws.dbg); if (!lane) PROF(&c, 15);
+		__shared__ uint32_t lut[4][QLUT + 3];
+		PROF_BEGIN(); wave_quantise_luma(&c, lane, park[threadIdx.x >> 6], lut[threadIdx.x >> 6], ws.q > 21 || ws.dbg); if (!lane) PROF(&c, 15);
 	}
 	else if (PH == WV_EMIT) { PROF_BEGIN(); wave_emit_ll2(&c, lane); if (!lane) PROF(&c, 4); }
 }

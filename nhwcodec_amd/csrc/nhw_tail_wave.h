@@ -572,8 +572,39 @@ DEV void quant_load_row(const int16_t *p, int r, int lane, int *v)
  * within a strip row after row, odd rows right to left): 16 rows are parked as bytes in a wave-private LDS block and
  * leave as one 64-byte run per strip.  The int16 plane is only written when Y29 needs it (q > 21). */
 #define QROW 516
-DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes of this wavefront */, bool write_plane)
+/* Loop 4 above quality 16 (image_processing.c:314-519, the q > 16 branches), per value of a cell clamped to -128 .. 128: the symbol it
+ * takes when its neighbours do nothing (low byte), and what it is to its neighbours and they to it.  Three rules look sideways, and each
+ * moves the symbol by one step of 8:
+ *   a -7 behind a loud negative x6 (:375), behind an 8 (:389) or in front of one (:378) becomes -9 / -8: symbol 120 instead of 128;
+ *   a 7 behind a loud positive x6 / x7 becomes 9 (:390): 136 instead of 128;
+ *   a negative 15, 23, .. (kept whole by :396) in front of a 1 .. 7 loses 2 first (:381) and is floored after all: one step up.
+ * A wavefront keeps the 257 words in LDS and a cell's step is a lookup, two lane shifts and a dozen bit operations (it was fifty
+ * compare-and-selects for five of six words of a row: nearly every 64 cells hold a +-7). */
+enum : unsigned { QE_AC = 1u << 8, QE_EQ8 = 1u << 9, QE_DC = 1u << 10, QE_R17 = 1u << 11, QE_M7 = 1u << 12, QE_P7 = 1u << 13, QE_N157 = 1u << 14, QE_BIG = 1u << 15, QE_LOUD = 1u << 16 };
+#define QLUT 257
+DEV int clamp128(int x) { return x < -128 ? -128 : x > 128 ? 128 : x; }   /* (one v_med3_i32) */
+DEV unsigned quant_entry(int x)
 {
+	const bool neg = x < 0;
+	const int m = neg ? -x : x;
+	const int mf = (neg && (m & 7) < 7) ? (m & 504) : m;            /* :396: negative values are floored to a multiple of 8 unless they end in 7 */
+	const int v = neg ? -mf : mf;
+	unsigned e = (unsigned)(v + 7) < 15u ? 128u : (unsigned)((v + 128) & 248);
+	if (x <= -13 && x >= -127 && (m & 7) == 6) e |= QE_AC;
+	if (x == 8) e |= QE_EQ8;
+	if (x >= 13 && x <= 127 && (x & 7) >= 6) e |= QE_DC;
+	if (x >= 1 && x <= 7) e |= QE_R17;
+	if (x == -7) e |= QE_M7;
+	if (x == 7) e |= QE_P7;
+	if (x <= -15 && x >= -127 && (m & 7) == 7) e |= QE_N157;
+	if (m > 127) e |= QE_BIG;
+	if (m >= 7) e |= QE_LOUD;
+	return e;
+}
+DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes of this wavefront */, uint32_t *lut /* QLUT words of this wavefront */, bool write_plane)
+{
+	for (int i = lane; i < QLUT; i += 64) lut[i] = quant_entry(i - 128);
+	__threadfence_block();
 	int16_t *p = c->proc;
 	uint8_t *stream = c->scan;
 	int prev[8], cur[8], nxt[8];
@@ -761,33 +792,23 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				park[(rr & 15) * QROW + lane + 64 * k] = (uint8_t)sym;
 			}
 		}
-		if (r >= 1 && !low) {                                      /* loop 4 on row r - 1: a stencil on (left, cell, right) */
-			const int first_next = __builtin_amdgcn_readlane(cur[0], 0);   /* the row below, already through loops 1-3 */
+		if (r >= 1 && !low) {                                      /* loop 4 on row r - 1: a stencil on (left, cell, right), through the class table (quant_entry) */
+			unsigned e[8];
+			for (int k = 0; k < 8; k++) e[k] = lut[clamp128(prev[k]) + 128];
+			const unsigned e_next = lut[clamp128(__builtin_amdgcn_readlane(cur[0], 0)) + 128];   /* the row below, already through loops 1-3 */
 			for (int k = 0; k < 8; k++) {
-				const int raw = prev[k];
-				if (!__ballot(iabs(raw) >= 7)) {                        /* 64 quiet cells: every one is inside the dead zone whatever its neighbours do (the fix-ups only touch +-7) */
+				if (!__ballot(e[k] & QE_LOUD)) {                        /* 64 quiet cells: every one is inside the dead zone whatever its neighbours do (the fix-ups only touch +-7) */
 					if (write_plane) p[(r - 1) * W + lane + 64 * k] = 128;
 					park[((r - 1) & 15) * QROW + lane + 64 * k] = 128;
 					continue;
 				}
-				const int lf = left_of_dpp(prev, k, lane, 0), rt = right_of_dpp(prev, k, 8, lane, first_next);
-				const bool last = k == 7 && lane == 63;             /* column 511: the fix-ups do not reach across the row end, the look at the next cell does */
-				/* straight-line selects (a divergent branch costs scalar exec-mask work in every wavefront of the CU) */
-				const bool m7 = raw == -7;
-				const bool ac = (unsigned)(-lf - 13) < 115u && ((-lf) & 7) == 6;     /* -127 <= lf < -12, residue 6: rewrites a -7 behind it to -9 (:375) */
-				const bool to8 = lf == 8 || (rt == 8 && !last);                      /* :389, :378 */
-				const bool dc = (unsigned)(lf - 13) < 115u && (lf & 7) >= 6;         /* 12 < lf <= 127, residue 6/7: raises a 7 behind it to 9 (:390) */
-				int a = raw;
-				a = (m7 && ac) ? -9 : a;
-				a = (m7 && !ac && to8) ? -8 : a;
-				a = (raw == 7 && dc) ? 9 : a;
-				const bool neg = a < 0;
-				int m = neg ? -a : a;
-				m = (neg && m > 14 && (m & 7) == 7 && (unsigned)(rt - 1) < 7u) ? m - 2 : m;     /* :381 */
-				m = (neg && (m & 7) < 7) ? (m & 504) : m;
-				const int v = neg ? -m : m;
-				int sym = (unsigned)(v + 7) < 15u ? 128 : ((v + 128) & 248);
-				if (__ballot(raw > 127 || raw < -127)) {                /* marks of loops 2-3 and values beyond +-127: rare, whole words skip this */
+				const unsigned el = (unsigned)left_of_dpp(reinterpret_cast<const int *>(e), k, lane, 0), er = (unsigned)right_of_dpp(reinterpret_cast<const int *>(e), k, 8, lane, (int)e_next);
+				const unsigned er8 = (k == 7 && lane == 63) ? 0u : er;   /* column 511: the fix-ups do not reach across the row end (:378), the look at the next cell (:381) does */
+				const unsigned up = e[k] & (((er << 3) & QE_N157) | ((el << 3) & QE_P7));            /* a 15, 23, .. below zero in front of 1..7 is floored after all (:381); a 7 behind a loud x6 / x7 is raised to 9 (:390) */
+				const unsigned dn = e[k] & QE_M7 & ((el << 4) | ((el | er8) << 3));                    /* a -7 behind a loud negative x6 (:375) or beside an 8 (:378, :389) leaves the dead zone */
+				int sym = (int)(e[k] & 255u) + (up ? 8 : 0) - (dn ? 8 : 0);
+				if (__ballot(e[k] & QE_BIG)) {                          /* marks of loops 2-3 and values beyond +-127: rare, whole words skip this */
+					const int raw = prev[k];
 					if (raw > 10000 && (raw == 10100 || raw == 12700 || raw == 12900 || raw == 10204 || raw == 10300 || raw == 12100 || raw == 12200))
 						sym = raw == 10100 ? 128 : raw == 12700 ? 127 : raw == 12900 ? 129 : raw == 10204 ? 125 : raw == 10300 ? 126 : raw == 12100 ? 121 : 122;
 					else if (raw > 127) sym = big_code(raw, k_big_pos);
