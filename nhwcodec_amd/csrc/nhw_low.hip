@@ -849,25 +849,28 @@ __global__ __launch_bounds__(MK_R) void k_low_marks(int16_t *__restrict__ yb, si
 	MarkState no_marks = { 0, 0, 0, 0, 0, 0 };
 	int p = 1;                                                         /* pass D: first pixel of the pair */
 
-	for (int wb = 0; wb < W - 16; wb += MK_A) {                        /* windows of columns wb .. wb + 63: 0, 48, .., 480 */
-		const bool last = wb + MK_A >= W - 16;
-		/* the flags of my row as passes B and C have left them so far (2 bits a cell: two masks) */
-		uint64_t f_lo = 0, f_hi = 0;
-		if (own_row)
-			for (int d = 0; d < 16; d++) {
-				const int col = wb + 4 * d;
-				const uint32_t w = col < W ? *reinterpret_cast<const uint32_t *>(so + (size_t)r * W + col) : 0u;
-				for (int e = 0; e < 4; e++) { f_lo |= (uint64_t)((w >> (8 * e)) & 1) << (4 * d + e); f_hi |= (uint64_t)((w >> (8 * e + 1)) & 1) << (4 * d + e); }
+	/* The windows advance by 48 columns = 96 bytes: read window by window, three in four straddle two 128-byte lines of the contrast map and
+	 * of the flag plane, and with a lane per row nothing holds a line from one window to the next (2.4 - 2.7 fetches a line).  So
+	 * the row is read and sorted in line-aligned blocks of 64 cells, every block once, and a window's masks are shifted out of the two
+	 * blocks it lies in. */
+	const int16_t *kr = km + (size_t)r * W, *ku = km + (size_t)(r - 1) * W;            /* indexed by column: the few cells a fired rule looks at come from the plane */
+	auto sort_block = [&](int bi, MkMasks &mk, uint64_t &f_lo, uint64_t &f_hi) {
+		mk = MkMasks{ 0, 0, 0, 0, 0, 0, 0, 0 };
+		f_lo = 0; f_hi = 0;
+		if (bi >= W / 64) return;
+		const int cb = 64 * bi;
+		if (own_row)                                                   /* the flags of my row as passes B and C have left them so far (2 bits a cell: two masks) */
+			for (int d = 0; d < 4; d++) {
+				const uint4 w4 = *reinterpret_cast<const uint4 *>(so + (size_t)r * W + cb + 16 * d);
+				const uint32_t w[4] = { w4.x, w4.y, w4.z, w4.w };
+				for (int e = 0; e < 16; e++) { f_lo |= (uint64_t)((w[e >> 2] >> (8 * (e & 3))) & 1) << (16 * d + e); f_hi |= (uint64_t)((w[e >> 2] >> (8 * (e & 3) + 1)) & 1) << (16 * d + e); }
 			}
-		const int16_t *kr = km + (size_t)r * W, *ku = km + (size_t)(r - 1) * W;        /* indexed by column: the few cells a fired rule looks at come from the plane */
-		int8_t *ow = own + tid * MK_BP - wb, *uw = upd + tid * MK_BP - wb;
-		MkMasks mk = { 0, 0, 0, 0, 0, 0, 0, 0 };
 		if (in_pic) {
-			uint4 nx = *reinterpret_cast<const uint4 *>(kr + wb);                       /* the next eight cells are on their way while these are sorted */
+			uint4 nx = *reinterpret_cast<const uint4 *>(kr + cb);                       /* the next eight cells are on their way while these are sorted */
 #pragma unroll 1
 			for (int g = 0; g < 8; g++) {
 				const uint4 q4 = nx;
-				if (g < 7) nx = wb + 8 * (g + 1) < W ? *reinterpret_cast<const uint4 *>(kr + wb + 8 * (g + 1)) : make_uint4(0, 0, 0, 0);
+				if (g < 7) nx = *reinterpret_cast<const uint4 *>(kr + cb + 8 * (g + 1));
 				const uint32_t w4[4] = { q4.x, q4.y, q4.z, q4.w };
 #pragma unroll
 				for (int e = 0; e < 8; e++) {
@@ -884,6 +887,20 @@ __global__ __launch_bounds__(MK_R) void k_low_marks(int16_t *__restrict__ yb, si
 				}
 			}
 		}
+	};
+	MkMasks bA, bB;
+	uint64_t fA_lo, fA_hi, fB_lo, fB_hi;
+	int blockA = 0;
+	sort_block(0, bA, fA_lo, fA_hi);
+	sort_block(1, bB, fB_lo, fB_hi);
+	for (int wb = 0; wb < W - 16; wb += MK_A) {                        /* windows of columns wb .. wb + 63: 0, 48, .., 480 */
+		const bool last = wb + MK_A >= W - 16;
+		if ((wb >> 6) != blockA) { blockA = wb >> 6; bA = bB; fA_lo = fB_lo; fA_hi = fB_hi; sort_block(blockA + 1, bB, fB_lo, fB_hi); }
+		const int sh = wb & 63;
+		auto win = [&](uint64_t a, uint64_t b) { return sh ? (a >> sh) | (b << (64 - sh)) : a; };
+		const uint64_t f_lo = win(fA_lo, fB_lo), f_hi = win(fA_hi, fB_hi);
+		int8_t *ow = own + tid * MK_BP - wb, *uw = upd + tid * MK_BP - wb;
+		const MkMasks mk = { win(bA.strong, bB.strong), win(bA.weak, bB.weak), win(bA.small, bB.small), win(bA.ja, bB.ja), win(bA.g56, bB.g56), win(bA.g160, bB.g160), win(bA.jas, bB.jas), win(bA.big, bB.big) };
 		MkFx fx = { kr, ku, ow, uw, wb, 0, 0, 0, 0 };
 		if (walk_c) {
 			CMasks cm = { mk.strong, mk.weak, mk.small, 0 };
@@ -933,6 +950,9 @@ __global__ __launch_bounds__(MK_R) void k_low_marks(int16_t *__restrict__ yb, si
 			}
 			uint64_t rs = raised;
 			while (rs) { const int b = __builtin_ctzll(rs); rs &= rs - 1; so[(size_t)r * W + wb + b] = 1; }
+			/* ... and into the blocks' copies of the flags, which were read before this window wrote (a raised flag reads as 1) */
+			fA_lo |= raised << sh; fA_hi &= ~(raised << sh);
+			if (sh) { fB_lo |= raised >> (64 - sh); fB_hi &= ~(raised >> (64 - sh)); }
 		}
 		__syncthreads();
 		{ uint64_t ud = up_dirty; while (ud) { const int b = __builtin_ctzll(ud); ud &= ud - 1; uw[wb + b] = 0; } }   /* my additions to the row above have been taken */
