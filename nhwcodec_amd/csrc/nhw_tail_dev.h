@@ -104,6 +104,20 @@ DEV int dequant_value(int a)
 	return a > 128 ? a - 125 : a - 131;
 }
 
+/* Byte tests on whole words.  nzb: 0x80 in every byte of y that is not zero (exact per byte: no carry crosses a byte).  nz8x128: the
+ * flags of two words gathered into 8 bits (bit k: byte k of the first word, bit 4 + k: byte k of the second) -- times 128, because the
+ * gather is two v_dot4_u32_u8 with the bit weights as the second operand (a flag byte is 0 or 128); shifts and ORs did that in a dozen
+ * instructions a word, and the byte-mask builders were a third of the packetiser's and of Y31's vector work. */
+DEV uint32_t nzb(uint32_t y) { return (((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u; }
+DEV uint32_t nz8x128(uint32_t fa, uint32_t fb) { return __builtin_amdgcn_udot4(fb, 0x80402010u, __builtin_amdgcn_udot4(fa, 0x08040201u, 0u, false), false); }
+/* bit 4 i + k: byte k of w[i] is NOT `pat`'s byte, i < 8 */
+DEV uint32_t ne_mask32(const uint32_t *w, uint32_t pat)
+{
+	const uint32_t r0 = nz8x128(nzb(w[0] ^ pat), nzb(w[1] ^ pat)), r1 = nz8x128(nzb(w[2] ^ pat), nzb(w[3] ^ pat));
+	const uint32_t r2 = nz8x128(nzb(w[4] ^ pat), nzb(w[5] ^ pat)), r3 = nz8x128(nzb(w[6] ^ pat), nzb(w[7] ^ pat));
+	return (r0 >> 7) | (r1 << 1) | (r2 << 9) | (r3 << 17);
+}
+
 DEV int big_code(int a, const uint8_t *tab)
 {
 	int k = ((a & 0xFFF8) - 128) >> 3;

@@ -992,9 +992,7 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 #define WB(w, k) ((int)(((w)[((k) + 16) >> 2] >> (8 * (((k) + 16) & 3))) & 0xFF))      /* byte at base + k, -16 <= k < 32 */
 #define PM8(v) ((v) == 136 || (v) == 120)
 	/* one bit per window byte 8 .. 39 (bit j = byte base - 16 + j) that equals the byte replicated in `pat`: all a test on an own byte looks at */
-#define EQ4(x, pat) ((((~(((((x) ^ (pat)) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | ((x) ^ (pat)) | 0x7F7F7F7Fu)) >> 7) * 0x00204081u) >> 21 & 15u)
-#define WIN_MASK(w, pat) ((unsigned long long)(EQ4((w)[2], pat) | EQ4((w)[3], pat) << 4 | EQ4((w)[4], pat) << 8 | EQ4((w)[5], pat) << 12 | \
-                                               EQ4((w)[6], pat) << 16 | EQ4((w)[7], pat) << 20 | EQ4((w)[8], pat) << 24 | EQ4((w)[9], pat) << 28) << 8)
+#define WIN_MASK(w, pat) ((unsigned long long)(~ne_mask32((w) + 2, pat)) << 8)
 	/* 4-bit mask of the bytes of a word that are the zero symbol 128 (exact per byte, then the four flags gathered by a multiply) */
 #define Z4(x) ((((~((((x) ^ 0x80808080u) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu | ((x) ^ 0x80808080u) | 0x7F7F7F7Fu)) >> 7) * 0x00204081u) >> 21 & 15u)
 	/* any +-8 symbol (136 / 120) among the 16 own bytes of a window?  (zero-byte test on the words xor-ed with the symbol) */
@@ -1151,7 +1149,6 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 #undef WB
 #undef PM8
 #undef Z4
-#undef EQ4
 #undef WIN_MASK
 #undef HASZ
 #undef ANY_PM8
@@ -2447,14 +2444,10 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 		else { fill += len_; if (fill <= 32) cur |= code_ << (32 - fill); \
 			else { const int sp_ = fill - 32; atomicOr(&words[w], cur | (code_ >> sp_)); w++; cur = (code_ & ((1u << sp_) - 1)) << (32 - sp_); fill = sp_; } } } while (0)
 	const int send = (slice + 1) * PK_SLICE < N ? (slice + 1) * PK_SLICE : N;
-	uint64_t nz = 0;                                 /* bit k: symbol lo + k is not 128 (symbols behind the stream read as 128) */
+	uint64_t nz;                                     /* bit k: symbol lo + k is not 128 (symbols behind the stream read as 128) */
 	{
 		const uint32_t *sw = reinterpret_cast<const uint32_t *>(d + lo);
-		for (int k = 0; k < 16; k++) {
-			uint32_t x = sw[k] ^ 0x80808080u;
-			x = (x | (x >> 4)) & 0x0F0F0F0Fu; x = (x | (x >> 2)) & 0x03030303u; x = (x | (x >> 1)) & 0x01010101u;
-			nz |= (uint64_t)((x | (x >> 7) | (x >> 14) | (x >> 21)) & 15) << (4 * k);
-		}
+		nz = (uint64_t)ne_mask32(sw, 0x80808080u) | (uint64_t)ne_mask32(sw + 8, 0x80808080u) << 32;
 	}
 	int i = lo;
 	if (MODE != 0)                                   /* am I inside the 4 symbols that follow a 132..135 code? */
@@ -2564,17 +2557,11 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	for (int ch = 0; ch < nchunks; ch++) {                       /* per slice: last / first symbol that is not 128 */
 		const int g = ch * NT + tid, lo = g * PK_SLICE;
 		uint64_t nz = 0;                                         /* bit k: symbol lo + k is not 128 */
-		if (lo < N)
-			for (int k = 0; k < 4; k++) {
-				const uint4 v = reinterpret_cast<const uint4 *>(d + lo)[k];
-				const uint32_t w[4] = { v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u };
-				for (int u = 0; u < 4; u++) {
-					uint32_t x = w[u];
-					x = (x | (x >> 4)) & 0x0F0F0F0Fu; x = (x | (x >> 2)) & 0x03030303u; x = (x | (x >> 1)) & 0x01010101u;   /* one bit per non-zero byte */
-					const uint32_t m4 = (x | (x >> 7) | (x >> 14) | (x >> 21)) & 15;
-					nz |= (uint64_t)m4 << (16 * k + 4 * u);
-				}
-			}
+		if (lo < N) {
+			uint32_t w[16];
+			for (int k = 0; k < 4; k++) { const uint4 v = reinterpret_cast<const uint4 *>(d + lo)[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+			nz = (uint64_t)ne_mask32(w, 0x80808080u) | (uint64_t)ne_mask32(w + 8, 0x80808080u) << 32;
+		}
 		prevnz[g] = nz ? lo + 63 - __builtin_clzll(nz) : -1;
 		nextnz[g] = nz ? lo + __builtin_ctzll(nz) : N;
 	}
