@@ -56,14 +56,14 @@ DEV M4 col_range(int lo, int hi)                                /* columns lo..h
 template <int N> DEV unsigned bs_up(unsigned b, int lane, unsigned in0 = 0)          /* cell j takes the bit of cell j - 1 (in0: the bit left of column 0) */
 {
 	const unsigned seam = (((unsigned)__builtin_amdgcn_readlane((int)b, 63) << 1) | in0) & ((1u << N) - 1);
-	const unsigned x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-	return lane ? x : seam;
+	(void)lane;
+	return (unsigned)__builtin_amdgcn_update_dpp((int)seam, (int)b, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);   /* lane 0 has no source and keeps the seam */
 }
 DEV unsigned bs_dn(unsigned b, int lane)                                             /* cell j takes the bit of cell j + 1 (0 behind the last column) */
 {
 	const unsigned seam = (unsigned)__builtin_amdgcn_readlane((int)b, 0) >> 1;
-	const unsigned x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-	return lane < 63 ? x : seam;
+	(void)lane;
+	return (unsigned)__builtin_amdgcn_update_dpp((int)seam, (int)b, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);   /* lane 63 has no source and keeps the seam */
 }
 #define BS_PREDK(b, arr, k0, expr) do { (b) = 0; for (int k_ = (k0); k_ < 4; k_++) { const int x = (arr)[k_]; (b) |= ((expr) ? 1u : 0u) << k_; } } while (0)
 #define BS_PRED(b, arr, n, expr) do { (b) = 0; for (int k_ = 0; k_ < (n); k_++) { const int x = (arr)[k_]; (b) |= ((expr) ? 1u : 0u) << k_; } } while (0)
@@ -552,14 +552,14 @@ DEV bool mult8_from(int x, int from) { return ((unsigned)(x - from) & 0x80000007
 DEV int left_of_dpp(const int *v, int k, int lane, int edge)
 {
 	const int seam = k ? __builtin_amdgcn_readlane(v[k - 1], 63) : edge;
-	const int x = __builtin_amdgcn_update_dpp(0, v[k], 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-	return lane ? x : seam;
+	(void)lane;
+	return __builtin_amdgcn_update_dpp(seam, v[k], 0x138 /* wave_shr:1 */, 0xF, 0xF, false);   /* lane 0 has no source and keeps the seam */
 }
 DEV int right_of_dpp(const int *v, int k, int nk, int lane, int edge)
 {
 	const int seam = k + 1 < nk ? __builtin_amdgcn_readlane(v[k + 1], 0) : edge;
-	const int x = __builtin_amdgcn_update_dpp(0, v[k], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-	return lane < 63 ? x : seam;
+	(void)lane;
+	return __builtin_amdgcn_update_dpp(seam, v[k], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);   /* lane 63 has no source and keeps the seam */
 }
 
 DEV void quant_load_row(const int16_t *p, int r, int lane, int *v)
