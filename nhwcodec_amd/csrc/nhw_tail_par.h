@@ -2429,7 +2429,7 @@ DEV bool book_ok(int v) { return v < 109 ? !(v & 1) : (v == 112 || (v >= 120 && 
 struct SliceBits { uint32_t b[4]; uint64_t s1m, s2m; };
 template <int MODE>
 DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint32_t *words, unsigned bit0, uint8_t *s1, unsigned i1, uint8_t *s2, unsigned i2,
-                   unsigned *out_bits, unsigned *out_n1, unsigned *out_n2, const int *prevnz, const int *nextnz, int slice, SliceBits *rec = nullptr)
+                   unsigned *out_bits, unsigned *out_n1, unsigned *out_n2, int prev_nz /* last symbol before the slice that is not 128 */, int next_nz /* first one behind it */, SliceBits *rec = nullptr)
 {
 	unsigned bits = 0, n1 = 0, n2 = 0;
 	uint32_t cur = 0; int w = (int)(bit0 >> 5), fill = (int)(bit0 & 31);
@@ -2443,7 +2443,7 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 		} \
 		else { fill += len_; if (fill <= 32) cur |= code_ << (32 - fill); \
 			else { const int sp_ = fill - 32; atomicOr(&words[w], cur | (code_ >> sp_)); w++; cur = (code_ & ((1u << sp_) - 1)) << (32 - sp_); fill = sp_; } } } while (0)
-	const int send = (slice + 1) * PK_SLICE < N ? (slice + 1) * PK_SLICE : N;
+	const int send = lo + PK_SLICE < N ? lo + PK_SLICE : N;
 	uint64_t nz;                                     /* bit k: symbol lo + k is not 128 (symbols behind the stream read as 128) */
 	{
 		const uint32_t *sw = reinterpret_cast<const uint32_t *>(d + lo);
@@ -2464,9 +2464,9 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
 			continue;
 		}
 		int a = i, b;                                /* maximal zero run [a, b] around i: inside the slice from the mask, outside from the tables */
-		if (i == lo && i > 0 && d[i - 1] == 128) a = prevnz[slice] + 1;
+		if (i == lo && i > 0 && d[i - 1] == 128) a = prev_nz + 1;
 		if (rest) b = i + __builtin_ctzll(rest) - 1;
-		else b = send < N ? nextnz[slice + 1] - 1 : send - 1;
+		else b = send < N ? next_nz - 1 : send - 1;
 		const int L = b - a + 1;
 		if (L == 1) {
 			if (MODE == 0) atomicAdd(&sh->hist[128], 1); else EMIT(sh->code_sym[128]);
@@ -2509,9 +2509,10 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
  * the 4 symbols before the slice (the walk looks back that far), so that the slices of a wavefront start in 64
  * different banks.  Returns the thread's view: dl[x] is stream symbol x for x in [lo - 4, lo + 64). */
 #define PK_LDS_BYTES ((17 * NT + 1) * 4)
-struct PackPre { uint4 v[PK_CHUNK / 16 / NT]; uint32_t before; };   /* a chunk on its way from memory: the thread's 16-byte pieces, and (thread 0) the four symbols in front of it */
-DEV void pack_fetch(const uint8_t *d, int N, int ch, int tid, PackPre *pre)
+struct PackPre { uint4 v[PK_CHUNK / 16 / NT]; uint32_t before; int prev_nz, next_nz; };   /* a chunk on its way from memory: the thread's 16-byte pieces, (thread 0) the four symbols in front of it, and what the walk of the thread's slice asks the tables (two loads that sat on every slice's chain of dependent steps) */
+DEV void pack_fetch(const uint8_t *d, int N, int ch, int tid, PackPre *pre, const int *prevnz, const int *nextnz)
 {
+	pre->prev_nz = prevnz[ch * NT + tid]; pre->next_nz = nextnz[ch * NT + tid + 1];
 	const int clo = ch * PK_CHUNK;
 #pragma unroll
 	for (int u = 0; u < PK_CHUNK / 16 / NT; u++) {
@@ -2587,12 +2588,13 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	}
 	BARRIER();
 	PackPre pre;
-	pack_fetch(d, N, 0, tid, &pre);
+	pack_fetch(d, N, 0, tid, &pre, prevnz, nextnz);
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
+		const int my_prev = pre.prev_nz, my_next = pre.next_nz;
 		const uint8_t *dl = pack_stage(&pre, ch, tid, lw);
-		if (ch + 1 < nchunks) pack_fetch(d, N, ch + 1, tid, &pre);
-		if (lo < S) pack_walk<0>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
+		if (ch + 1 < nchunks) pack_fetch(d, N, ch + 1, tid, &pre, prevnz, nextnz);
+		if (lo < S) pack_walk<0>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, my_prev, my_next);
 	}
 	BARRIER();
 	if (!tid) PROF(c, 23);
@@ -2655,14 +2657,15 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	uint32_t *words = c->packet + word0;
 	unsigned base_bits = 0, base_n1 = 0, base_n2 = 0;
 	int zeroed = 0;                                              /* words [0, zeroed) are cleared or already carry bits */
-	pack_fetch(d, N, 0, tid, &pre);
+	pack_fetch(d, N, 0, tid, &pre, prevnz, nextnz);
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
 		unsigned bb = 0, x1 = 0, x2 = 0, tb, tn;
+		const int my_prev = pre.prev_nz, my_next = pre.next_nz;
 		const uint8_t *dl = pack_stage(&pre, ch, tid, lw);
-		if (ch + 1 < nchunks) pack_fetch(d, N, ch + 1, tid, &pre);
+		if (ch + 1 < nchunks) pack_fetch(d, N, ch + 1, tid, &pre, prevnz, nextnz);
 		SliceBits rec;
-		if (lo < S) pack_walk<1>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, prevnz, nextnz, ch * NT + tid, &rec);
+		if (lo < S) pack_walk<1>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, my_prev, my_next, &rec);
 		const unsigned ob = block_exscan(bb, tid, sh->bits, &tb);
 		const unsigned on = block_exscan(x1 | (x2 << 16), tid, sh->bits, &tn);
 		const int last = tb ? (int)((base_bits + tb - 1) >> 5) : zeroed - 1;
@@ -2683,7 +2686,7 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 				for (unsigned z = 0; z < x1; z++) if (a1 + z < S_CAP) c->s1[a1 + z] = (uint8_t)((rec.s1m >> z) & 1);
 				for (unsigned z = 0; z < x2; z++) if (a2 + z < S_CAP) c->s2[a2 + z] = (uint8_t)((rec.s2m >> z) & 1);
 			}
-			else pack_walk<2>(dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, prevnz, nextnz, ch * NT + tid);
+			else pack_walk<2>(dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, my_prev, my_next);
 		}
 		base_bits += tb; base_n1 += tn & 0xFFFF; base_n2 += tn >> 16;
 		if (last + 1 > zeroed) zeroed = last + 1;
