@@ -1213,9 +1213,11 @@ DEV unsigned block_exscan_max(unsigned v, int tid, unsigned *shm);
  *   bits   -- the low bits of the non-marker entries, 8 per byte: a compaction;
  *   words  -- the payload symbols, 8 (or 4) per byte.
  * Each thread owns a contiguous chunk of the list; counts go through workgroup prefix sums. */
-DEV void poslist_finish_par(Ctx *c, PosList *pl, const uint8_t *raw, int n, const uint8_t *payload, int payload_len, int word_mode, int tid, unsigned *shm)
+DEV void poslist_finish_par(Ctx *c, PosList *pl, const uint8_t *__restrict__ raw, int n, const uint8_t *__restrict__ payload, int payload_len, int word_mode, int tid, unsigned *shm)
 {
-	uint8_t *P = c->cc, *F = c->half;                            /* pruned list; per-entry flags / compacted low bits */
+	/* (distinct buffers, and told so: a compaction loop "P[at++] = raw[i]" is otherwise a memory round trip a turn, the store may alias the next load) */
+	uint8_t *__restrict__ P = c->cc, *__restrict__ F = c->half;   /* pruned list; per-entry flags / compacted low bits */
+	uint8_t *__restrict__ out_list = pl->list, *__restrict__ out_bits = pl->bits, *__restrict__ out_word = pl->word;
 	unsigned total;
 	{                                                            /* prune (:1546-1561) */
 		const int L = (n + NT - 1) / NT, i0 = tid * L, i1 = i0 + L < n ? i0 + L : n;
@@ -1252,9 +1254,9 @@ DEV void poslist_finish_par(Ctx *c, PosList *pl, const uint8_t *raw, int n, cons
 		for (int i = i0; i < i1; i++) {
 			if (!(i >= 1 && i <= m - 2 && !F[i - 1])) continue;
 			const int h = P[i] >> 1;
-			pl->list[at++] = (uint8_t)(F[i] ? 128 + ((h - (P[i - 1] >> 1)) << 4) + ((P[i + 1] >> 1) - h) : h);
+			out_list[at++] = (uint8_t)(F[i] ? 128 + ((h - (P[i - 1] >> 1)) << 4) + ((P[i + 1] >> 1) - h) : h);
 		}
-		if (tid == 0) { pl->list[0] = P[0] >> 1; pl->len->list_len = 1 + (int)total; }
+		if (tid == 0) { out_list[0] = P[0] >> 1; pl->len->list_len = 1 + (int)total; }
 	}
 #undef PL_FIRE
 	BARRIER();
@@ -1268,7 +1270,7 @@ DEV void poslist_finish_par(Ctx *c, PosList *pl, const uint8_t *raw, int n, cons
 		for (int g = tid; g < groups; g += NT) {
 			int v = 0;
 			for (int b = 0; b < 8; b++) v = (v << 1) | (8 * g + b < nb ? F[8 * g + b] : 0);
-			pl->bits[g] = (uint8_t)v;
+			out_bits[g] = (uint8_t)v;
 		}
 		if (tid == 0) pl->len->bits_len = groups;
 	}
@@ -1278,12 +1280,12 @@ DEV void poslist_finish_par(Ctx *c, PosList *pl, const uint8_t *raw, int n, cons
 			int sym[8];
 			for (int b = 0; b < 8; b++) sym[b] = (8 * g + b < payload_len) ? payload[8 * g + b] : 0;
 			if (word_mode == 2) {
-				pl->word[2 * g] = (uint8_t)(((sym[0] & 3) << 6) | ((sym[1] & 3) << 4) | ((sym[2] & 3) << 2) | (sym[3] & 3));
-				pl->word[2 * g + 1] = (uint8_t)(((sym[4] & 3) << 6) | ((sym[5] & 3) << 4) | ((sym[6] & 3) << 2) | (sym[7] & 3));
+				out_word[2 * g] = (uint8_t)(((sym[0] & 3) << 6) | ((sym[1] & 3) << 4) | ((sym[2] & 3) << 2) | (sym[3] & 3));
+				out_word[2 * g + 1] = (uint8_t)(((sym[4] & 3) << 6) | ((sym[5] & 3) << 4) | ((sym[6] & 3) << 2) | (sym[7] & 3));
 			} else {
 				int v = 0;
 				for (int b = 0; b < 8; b++) v = (v << 1) | (sym[b] & 1);
-				pl->word[g] = (uint8_t)v;
+				out_word[g] = (uint8_t)v;
 			}
 		}
 		if (tid == 0) pl->len->word_len = word_mode == 2 ? 2 * groups : groups;
