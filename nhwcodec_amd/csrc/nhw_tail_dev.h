@@ -118,10 +118,13 @@ DEV uint32_t ne_mask32(const uint32_t *w, uint32_t pat)
 	return (r0 >> 7) | (r1 << 1) | (r2 << 9) | (r3 << 17);
 }
 
+/* the codes of values beyond +-127 (the tables above: steps of 2 with a gap after every third entry).  Worked out, not looked up: the tables
+ * live in global memory and the look-up sat on the quantisers' row chains as a dependent load. */
 DEV int big_code(int a, const uint8_t *tab)
 {
 	int k = ((a & 0xFFF8) - 128) >> 3;
-	return tab[k > 18 ? 18 : k];
+	k = k > 18 ? 18 : k;
+	return tab == k_big_pos ? 10 + 2 * k + 2 * ((k * 11) >> 5) : 60 + 2 * k + 2 * (((k + 1) * 11) >> 5);   /* (k * 11) >> 5 = k / 3 for k < 20 */
 }
 
 DEV int mult8_or_7(int m) { return !(m & 7) || (m & 7) == 7; } /* on a magnitude */
