@@ -638,17 +638,21 @@ DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 {
 	int16_t *p = c->proc, *o = c->ll1;
 	const int q = c->q, j = tid;
-	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *lt = lds + 3 * (CR + 3) * H;
+	/* eight rows a turn (Y22 takes four: it carries three more in three tiles): the two tiles fit in front of the LH1 piece as Y22 leaves it, and
+	 * a turn is three barriers and one wait for the rows whatever its size */
+	constexpr int CR2 = 8;
+	static_assert(2 * CR2 <= 3 * (CR + 3) && LW % CR2 == 0, "Y23's tiles lie in front of the LH1 piece");
+	int16_t *pt = lds, *ot = lds + CR2 * H, *lt = lds + 3 * (CR + 3) * H;
 	int vm1 = p[j * W + H - 1];
-	for (int r0 = 0; r0 < H; r0 += CR) {
-		for (int v = tid; v < CR * (H / 8); v += NT) {
+	for (int r0 = 0; r0 < H; r0 += CR2) {
+		for (int v = tid; v < CR2 * (H / 8); v += NT) {
 			const int i = v / (H / 8), c8 = 8 * (v % (H / 8));
 			*reinterpret_cast<uint4 *>(pt + i * H + c8) = *reinterpret_cast<const uint4 *>(p + (r0 + i) * W + c8);
 			*reinterpret_cast<uint4 *>(ot + i * H + c8) = *reinterpret_cast<const uint4 *>(o + (r0 + i) * H + c8);
 		}
 		if (r0 % LW == 0) lh_tile_load(lt, p, r0, tid);
 		BARRIER();
-		for (int i = 0; i < CR; i++) {
+		for (int i = 0; i < CR2; i++) {
 			int16_t *cell = ot + i * H + j;
 			int16_t *v = lt + j * LP + r0 % LW + i;
 			if (*cell < 12000) {
@@ -687,11 +691,11 @@ DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 			vm1 = v[0];
 		}
 		BARRIER();
-		for (int v = tid; v < CR * (H / 8); v += NT) {
+		for (int v = tid; v < CR2 * (H / 8); v += NT) {
 			const int i = v / (H / 8), c8 = 8 * (v % (H / 8));
 			*reinterpret_cast<uint4 *>(o + (r0 + i) * H + c8) = *reinterpret_cast<const uint4 *>(ot + i * H + c8);
 		}
-		if ((r0 + CR) % LW == 0) lh_tile_store(lt, p, r0 + CR - LW, tid);
+		if ((r0 + CR2) % LW == 0) lh_tile_store(lt, p, r0 + CR2 - LW, tid);
 		BARRIER();
 	}
 }
