@@ -45,11 +45,16 @@ template <int PH>
 __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 {
 	const int img = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	__shared__ uint32_t dq_lut[(PH == WV_DQ1 || PH == WV_DQ0) ? DQ_WORDS : 1];
+	if (PH == WV_DQ1 || PH == WV_DQ0) {                            /* the one workgroup barrier of these kernels: the table of the dequantiser walk */
+		for (int i = threadIdx.x; i < DQ_WORDS; i += 256) dq_lut[i] = dq_entry(i);
+		__syncthreads();
+	}
 	if (img >= ws.n) return;
 	Ctx c;
 	ctx_load(&c, ws, img);
-	if (PH == WV_DQ1) wave_dequant_sim_luma(&c, 1, lane);
-	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane);
+	if (PH == WV_DQ1) wave_dequant_sim_luma(&c, 1, lane, dq_lut);
+	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane, dq_lut);
 	else if (PH == WV_QUANT) {
 		__shared__ __attribute__((aligned(16))) uint8_t park[4][16 * QROW];
 		__shared__ uint32_t lut[4][QLUT + 3];

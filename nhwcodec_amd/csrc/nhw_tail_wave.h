@@ -301,7 +301,42 @@ DEV unsigned bs_range(int lo, int hi, int lane)
 	return b;
 }
 
-DEV void wave_dequant_details(Ctx *c, int part, int lane)
+/* Above quality 16 the walk's questions about a cell -- is it 8, 7, -7, a loud x6 / x7, one of the six marks of the passes before -- and the
+ * value the walk leaves for it come out of one table word per value: -DQ_LIM .. DQ_LIM, then the marks 15300 .. 15800 (every fourth
+ * value from 15300: the six marks and BIG between them).  Low half: dequant_value(floored cell), or what a visited mark stands for; then a
+ * bit a question.  A larger value or an unknown code sends its 64 cells down the comparisons (DQ_BIG). */
+#define DQ_LIM 512
+#define DQ_MARK0 (2 * DQ_LIM + 1)
+#define DQ_WORDS (DQ_MARK0 + 126)
+enum : unsigned { DQ_E8 = 1u << 16, DQ_E7 = 1u << 17, DQ_EM7 = 1u << 18, DQ_DC = 1u << 19, DQ_AC = 1u << 20, DQ_BIG = 1u << 21, DQ_CODE = 1u << 22, DQ_K2 = 1u << 23, DQ_K1 = 1u << 24, DQ_PRP = 1u << 25, DQ_PRN = 1u << 26 };
+DEV int dq_index(int x)
+{
+	const int d = x - 15300;
+	const int cl = x < -DQ_LIM ? -DQ_LIM : x > DQ_LIM ? DQ_LIM : x;
+	return ((unsigned)d <= 500u && !(d & 3)) ? DQ_MARK0 + (d >> 2) : cl + DQ_LIM;
+}
+DEV unsigned dq_entry(int i)
+{
+	if (i >= DQ_MARK0) {
+		const int d = 4 * (i - DQ_MARK0);
+		if (d % 100) return DQ_BIG;
+		const int x = 15300 + d;                                   /* 15300 / 15500 -> 5, 15400 / 15600 -> -5, 15700 -> 6, 15800 -> -6 (:2909-3124) */
+		const int v = (x == 15300 || x == 15500) ? 5 : (x == 15400 || x == 15600) ? -5 : x == 15700 ? 6 : -6;
+		return (unsigned)(uint16_t)(int16_t)v | DQ_CODE | (x <= 15400 ? DQ_K2 : DQ_K1) | (x == 15700 ? DQ_PRP : 0u) | (x == 15800 ? DQ_PRN : 0u);
+	}
+	const int x = i - DQ_LIM;
+	if (x >= DQ_LIM || x <= -DQ_LIM) return DQ_BIG;
+	int a = x;
+	if (a < 0) { a = -a; if ((a & 7) < 7) a &= 0xFFF8; a = -a; }
+	unsigned e = (unsigned)(uint16_t)(int16_t)dequant_value(a);
+	if (x == 8) e |= DQ_E8;
+	if (x == 7) e |= DQ_E7;
+	if (x == -7) e |= DQ_EM7;
+	if (x > 12 && (x & 7) >= 6) e |= DQ_DC;
+	if (x < -12 && ((-x) & 7) == 6) e |= DQ_AC;
+	return e;
+}
+DEV void wave_dequant_details(Ctx *c, int part, int lane, const uint32_t *lut /* DQ_WORDS, filled by the workgroup */)
 {
 	int16_t *p = c->proc, *jp = c->jpeg;
 	const bool hq = c->q > 16;                                     /* quality 1..16: no triple / pair marking, and negative magnitudes keep their low bits on a ration (:2938-2989) */
@@ -368,13 +403,34 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 			}
 		}
 		{                                                          /* :2909-3124 */
-			unsigned code, k1 = 0, k2 = 0;
-			BS_PREDK(code, cur, K0, x > 15000);
-			const bool any_code = __any(code != 0);                 /* most rows carry no mark at all: the tests that tell the marks apart are skipped then */
-			if (any_code) {
-				BS_PREDK(k2, cur, K0, x == 15300 || x == 15400);
-				BS_PREDK(k1, cur, K0, x == 15500 || x == 15600 || x == 15700 || x == 15800);
-			}
+			unsigned code = 0, k1 = 0, k2 = 0, pr_p = 0, pr_n = 0, wr = 0;
+			unsigned e8 = 0, e7 = 0, em7 = 0, dc = 0, ac = 0;
+			unsigned direct = hq ? 0u : 0xFu;                       /* words whose cells are sorted and dequantised by comparisons: all of them at quality 1..16 (no marks there, rationed low bits), above it those with a value beyond the table */
+			int jq[4] = { 0, 0, 0, 0 };                             /* from the table: what the walk leaves for the cell */
+			if (hq)
+				for (int k = K0; k < 4; k++) {
+					const unsigned e = lut[dq_index(cur[k])];
+					if (__ballot(e & DQ_BIG)) { direct |= 1u << k; continue; }
+#define DQB(dst, bit) (dst) |= (((e) & (bit)) ? 1u : 0u) << k
+					DQB(code, DQ_CODE); DQB(k2, DQ_K2); DQB(k1, DQ_K1); DQB(pr_p, DQ_PRP); DQB(pr_n, DQ_PRN);
+					DQB(e8, DQ_E8); DQB(e7, DQ_E7); DQB(em7, DQ_EM7); DQB(dc, DQ_DC); DQB(ac, DQ_AC);
+#undef DQB
+					jq[k] = (int)(int16_t)(e & 0xFFFFu);
+				}
+			if (direct)
+				for (int k = K0; k < 4; k++) {
+					if (!((direct >> k) & 1u)) continue;
+					const int x = cur[k];
+					e8 |= (x == 8 ? 1u : 0u) << k; e7 |= (x == 7 ? 1u : 0u) << k; em7 |= (x == -7 ? 1u : 0u) << k;
+					dc |= (x > 12 && x < 15000 && (x & 7) >= 6 ? 1u : 0u) << k; ac |= (x < -12 && ((-x) & 7) == 6 ? 1u : 0u) << k;
+					if (hq) {                                           /* (no marks below quality 17) */
+						code |= (x > 15000 ? 1u : 0u) << k;
+						k2 |= (x == 15300 || x == 15400 ? 1u : 0u) << k; k1 |= (x == 15500 || x == 15600 || x == 15700 || x == 15800 ? 1u : 0u) << k;
+						pr_p |= (x == 15700 ? 1u : 0u) << k; pr_n |= (x == 15800 ? 1u : 0u) << k;
+						wr |= (x > 15000 && !(x == 15300 || x == 15400 || x == 15500 || x == 15600 || x == 15700 || x == 15800) ? 1u : 0u) << k;   /* code cells with another value (none are produced) write nothing */
+					}
+				}
+			const bool any_code = __any(code != 0);                 /* most rows of a calm picture carry no mark at all */
 			const unsigned rd = bs_range(col0, H - 1, lane);
 			unsigned skipped = 0;
 			if (__any(((k1 | k2) & rd) != 0)) {                    /* which cells the walk steps over: a visited code cell hides the next one (two for a triple) */
@@ -399,9 +455,6 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 			}
 			const unsigned vis = rd & ~skipped, vc = vis & code, vnc = vis & ~code;
 			const unsigned ml = bs_range(0, H - 2, lane);
-			unsigned e8, e7, em7, dc, ac;
-			BS_PREDK(e8, cur, K0, x == 8); BS_PREDK(e7, cur, K0, x == 7); BS_PREDK(em7, cur, K0, x == -7);
-			BS_PREDK(dc, cur, K0, x > 12 && x < 15000 && (x & 7) >= 6); BS_PREDK(ac, cur, K0, x < -12 && ((-x) & 7) == 6);
 			const unsigned dm = part ? 0u : (vnc & ml & dc);
 			const unsigned udm = UP(dm);
 			const unsigned is8 = vnc & (e8 | (e7 & udm));           /* the walk sees an 8 here (a 7 the cell before has raised counts) */
@@ -409,8 +462,7 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 			const unsigned to_8 = e7 & udm;
 			const unsigned self_m8 = vnc & ml & em7 & ~to_m8 & DN(e8);
 			const unsigned m8 = to_m8 | self_m8;
-			unsigned pr_p = 0, pr_n = 0;                            /* visited 15700 / 15800: the partner takes the same +-6 */
-			if (any_code) { BS_PREDK(pr_p, cur, K0, x == 15700); BS_PREDK(pr_n, cur, K0, x == 15800); }
+			/* pr_p / pr_n: visited 15700 / 15800: the partner takes the same +-6 */
 			const unsigned part_p = UP(pr_p & vc), part_n = UP(pr_n & vc);
 			for (int k = K0; k < 4; k++) {
 				if (BIT(m8, k)) cur[k] = -8;
@@ -439,6 +491,10 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 			for (int k = K0; k < 4; k++) {
 				if (BIT(part_p, k)) jv[k] = 6;
 				if (BIT(part_n, k)) jv[k] = -6;
+				if (!((direct >> k) & 1u)) {                            /* from the table; a -7 / 7 a neighbour has turned into -8 / 8 is the one thing it does not know */
+					if (BIT(vis, k)) jv[k] = BIT(m8, k) ? dequant_value(-8) : BIT(to_8, k) ? dequant_value(8) : jq[k];
+					continue;
+				}
 				if (BIT(vc, k)) {
 					const int a = cur[k];
 					if (a == 15300 || a == 15500) jv[k] = 5;
@@ -452,8 +508,6 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane)
 					jv[k] = dequant_value(a);
 				}
 			}
-			unsigned wr = 0;                                        /* code cells with another value (none are produced) write nothing */
-			if (any_code) BS_PREDK(wr, cur, K0, x > 15000 && !(x == 15300 || x == 15400 || x == 15500 || x == 15600 || x == 15700 || x == 15800));
 			je |= part_p | part_n | (vis & ~wr);
 		}
 		for (int k = K0; k < 4; k++) {
@@ -840,11 +894,11 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 }
 
 /* offsetY_recons256 (image_processing.c:2600-3190), one wavefront per image */
-DEV void wave_dequant_sim_luma(Ctx *c, int part, int lane)
+DEV void wave_dequant_sim_luma(Ctx *c, int part, int lane, const uint32_t *lut)
 {
 	PROF_BEGIN();
 	wave_ll2(c, part, lane);
-	wave_dequant_details(c, part, lane);
+	wave_dequant_details(c, part, lane, lut);
 	if (!part) wave_shrink(c, lane);
 	if (!lane) PROF(c, part ? 1 : 7);
 }
