@@ -377,7 +377,9 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane, const uint32_t *lut /*
 				const unsigned ft = ftp | ftn, fv = fvp | fvn;
 				const unsigned ftp_l = DN(ftp), ftn_l = DN(ftn), fvp_l = DN(fvp), fvn_l = DN(fvn);   /* the cell left of a firing cell */
 				const unsigned ftp_r = UP(ftp), ftn_r = UP(ftn);
+				const unsigned touched = fired | ftp_l | ftn_l | fvp_l | fvn_l | ftp_r | ftn_r;   /* a firing cell, the cell on its left, the cell on the right of a triple: few cells of a row, and the nine assignments below are skipped for a word that holds none */
 				for (int k = K0; k < 4; k++) {
+					if (!__ballot(BIT(touched, k))) continue;
 					if (BIT(ft, k)) cur[k] = 0;
 					if (BIT(ftp_l, k)) cur[k] = 15300; if (BIT(ftn_l, k)) cur[k] = 15400;
 					if (BIT(fvp_l, k)) { cur[k] = 15500; nxt[k] = 15500; }
@@ -722,8 +724,10 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 					const unsigned fired = __any(cand2 != 0) ? bs_from4(alt_runs(bs_ballot4(cand2))) : 0u;
 					const unsigned ftp = fired & tp, ftn = fired & tn, fvp = fired & vp, fvn = fired & vn, fv = fvp | fvn;
 					const unsigned ft_l = bs_dn(ftp | ftn, lane), fvp_l = bs_dn(fvp, lane), fvn_l = bs_dn(fvn, lane), fv_l = fvp_l | fvn_l;
+					const unsigned touched = fired | ft_l | fv_l;       /* a firing cell or the cell on its left: a word without one skips the assignments */
 					if (__any(fired != 0))
 					for (int k = 0; k < 4; k++) {
+						if (!__ballot((touched >> k) & 1u)) continue;
 						if ((ftp >> k) & 1) cur[k] = 12700; if ((ftn >> k) & 1) cur[k] = 12900;
 						if ((ft_l >> k) & 1) cur[k] = 10100;
 						if ((fv >> k) & 1) { cur[k] = 10100; nxt[k] = 10100; }
