@@ -2070,20 +2070,34 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 	};
 	/* (a wavefront per row, a lane the row's eight cells from 8 l on -- the layout of the list passes below, whose counts are taken here, where
 	 * the values are made: sh[row] = the row's 32000 / 32500 cells, sh[H + row] = its 30000 / 31000 cells | those of columns 254, 255 << 16) */
+	/* (an item's seven loads are asked for an item ahead: behind the store of the item before they may alias it for all the compiler knows,
+	 * and every turn waited for its own) */
+	struct HqIn { uint2 lw, hw; int l4, h0, h5; uint4 kw; };
+	auto hq_fetch = [&](int idx) {
+		const int rr = idx >> 6, k0 = (idx & 63) * 4;
+		const int16_t *lo = c->first_order + rr * H, *hi = b + rr * H;
+		HqIn in;
+		in.lw = *reinterpret_cast<const uint2 *>(lo + k0); in.hw = *reinterpret_cast<const uint2 *>(hi + k0);
+		in.l4 = k0 + 4 < H ? (int)lo[k0 + 4] : 0x7fffffff; in.h0 = k0 > 0 ? (int)hi[k0 - 1] : 0x7fffffff; in.h5 = k0 + 4 < H ? (int)hi[k0 + 4] : 0x7fffffff;
+		in.kw = *reinterpret_cast<const uint4 *>(c->keep + rr * W + 2 * k0);
+		return in;
+	};
+	HqIn nin = hq_fetch(tid);
 	for (int idx = tid; idx < Q / 4; idx += NT) {                               /* four cells (eight outputs) per item: 8- and 16-byte accesses */
 		const int rr = idx >> 6, k0 = (idx & 63) * 4;
 		int n_q3 = 0, n_e = 0, n_c = 0;
-		const int16_t *lo = c->first_order + rr * H, *hi = b + rr * H;
+		const HqIn in = nin;
+		if (idx + NT < Q / 4) nin = hq_fetch(idx + NT);
 		int l[5], h[6];                                                          /* lo[k0 .. k0 + 4], hi[k0 - 1 .. k0 + 4] */
 		{
-			const uint2 lw = *reinterpret_cast<const uint2 *>(lo + k0), hw = *reinterpret_cast<const uint2 *>(hi + k0);
+			const uint2 lw = in.lw, hw = in.hw;
 			l[0] = (int16_t)(lw.x & 0xFFFF); l[1] = (int16_t)(lw.x >> 16); l[2] = (int16_t)(lw.y & 0xFFFF); l[3] = (int16_t)(lw.y >> 16);
 			h[1] = (int16_t)(hw.x & 0xFFFF); h[2] = (int16_t)(hw.x >> 16); h[3] = (int16_t)(hw.y & 0xFFFF); h[4] = (int16_t)(hw.y >> 16);
-			l[4] = k0 + 4 < H ? lo[k0 + 4] : l[3];
-			h[0] = k0 > 0 ? hi[k0 - 1] : h[1];
-			h[5] = k0 + 4 < H ? hi[k0 + 4] : h[4];
+			l[4] = in.l4 != 0x7fffffff ? in.l4 : l[3];
+			h[0] = in.h0 != 0x7fffffff ? in.h0 : h[1];
+			h[5] = in.h5 != 0x7fffffff ? in.h5 : h[4];
 		}
-		const uint4 kw = *reinterpret_cast<const uint4 *>(c->keep + rr * W + 2 * k0);
+		const uint4 kw = in.kw;
 		const uint32_t kk[4] = { kw.x, kw.y, kw.z, kw.w };
 		uint32_t out[4];
 #pragma unroll
@@ -2103,9 +2117,10 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 			}
 		}
 		*reinterpret_cast<uint4 *>(hs + rr * W + 2 * k0) = make_uint4(out[0], out[1], out[2], out[3]);
-		int t_q3, t_e;
-		(void)wave_exscan(n_q3, t_q3); (void)wave_exscan(n_e, t_e);
-		const int t_c = __shfl(n_c, 31);
+		/* the row's totals (a lane counts 0 .. 8): a ballot and a population count a bit, no trip through the LDS crossbar */
+		int t_q3 = 0, t_e = 0;
+		for (int bit = 0; bit < 4; bit++) { t_q3 += __popcll(__ballot((n_q3 >> bit) & 1)) << bit; t_e += __popcll(__ballot((n_e >> bit) & 1)) << bit; }
+		const int t_c = __builtin_amdgcn_readlane(n_c, 31);
 		if (!lane) { sh[rr] = t_q3; sh[H + rr] = t_e | (t_c << 16); }
 	}
 	BARRIER();
