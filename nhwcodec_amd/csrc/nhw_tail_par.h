@@ -128,12 +128,17 @@ DEV void apply_tags_par(Ctx *c, int tid, int16_t *lds)
 }
 
 /* rows x cols block copy between two planes */
-DEV void copy_block_par(const int16_t *src, int src_row, int16_t *dst, int dst_row, int rows, int cols, int tid)
+/* (16-byte pieces, four in flight per thread: with one 8-byte piece a turn -- load, then a store that may alias the next load -- the copy of a
+ * 128 KB block was 64 memory round trips one after the other; every block copied here is a multiple of 8 columns wide on 16-byte rows) */
+DEV void copy_block_par(const int16_t *__restrict__ src, int src_row, int16_t *__restrict__ dst, int dst_row, int rows, int cols, int tid)
 {
-	const int per = cols >> 2;                       /* 8-byte pieces */
-	for (int idx = tid; idx < rows * per; idx += NT) {
-		const int r = idx / per, k = idx % per;
-		reinterpret_cast<uint2 *>(dst + r * dst_row)[k] = reinterpret_cast<const uint2 *>(src + r * src_row)[k];
+	const int per = cols >> 3, n = rows * per;       /* 16-byte pieces */
+	for (int i0 = tid; i0 < n; i0 += 4 * NT) {
+		uint4 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) { const int idx = i0 + u * NT; if (idx < n) v[u] = reinterpret_cast<const uint4 *>(src + (idx / per) * src_row)[idx % per]; }
+#pragma unroll
+		for (int u = 0; u < 4; u++) { const int idx = i0 + u * NT; if (idx < n) reinterpret_cast<uint4 *>(dst + (idx / per) * dst_row)[idx % per] = v[u]; }
 	}
 }
 
