@@ -865,12 +865,19 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 				const unsigned up = e[k] & (((er << 3) & QE_N157) | ((el << 3) & QE_P7));            /* a 15, 23, .. below zero in front of 1..7 is floored after all (:381); a 7 behind a loud x6 / x7 is raised to 9 (:390) */
 				const unsigned dn = e[k] & QE_M7 & ((el << 4) | ((el | er8) << 3));                    /* a -7 behind a loud negative x6 (:375) or beside an 8 (:378, :389) leaves the dead zone */
 				int sym = (int)(e[k] & 255u) + (up ? 8 : 0) - (dn ? 8 : 0);
-				if (__ballot(e[k] & QE_BIG)) {                          /* marks of loops 2-3 and values beyond +-127: rare, whole words skip this */
+				if (__ballot(e[k] & QE_BIG)) {                          /* marks of loops 2-3 and values beyond +-127: one word in six on busy pictures, and mostly for a large value, so the marks' seven comparisons wait behind a ballot of their own */
 					const int raw = prev[k];
-					if (raw > 10000 && (raw == 10100 || raw == 12700 || raw == 12900 || raw == 10204 || raw == 10300 || raw == 12100 || raw == 12200))
-						sym = raw == 10100 ? 128 : raw == 12700 ? 127 : raw == 12900 ? 129 : raw == 10204 ? 125 : raw == 10300 ? 126 : raw == 12100 ? 121 : 122;
-					else if (raw > 127) sym = big_code(raw, k_big_pos);
-					else if (raw < -127) sym = big_code(-raw, k_big_neg);
+					bool mark = false;
+					if (__ballot(raw > 10000)) {
+						mark = raw > 10000 && (raw == 10100 || raw == 12700 || raw == 12900 || raw == 10204 || raw == 10300 || raw == 12100 || raw == 12200);
+						if (mark) sym = raw == 10100 ? 128 : raw == 12700 ? 127 : raw == 12900 ? 129 : raw == 10204 ? 125 : raw == 10300 ? 126 : raw == 12100 ? 121 : 122;
+					}
+					if (!mark && (raw > 127 || raw < -127)) {                 /* big_code of either sign in one go */
+						const int a = raw < 0 ? -raw : raw;
+						int kk = ((a & 0xFFF8) - 128) >> 3;
+						kk = kk > 18 ? 18 : kk;
+						sym = raw > 0 ? 10 + 2 * kk + 2 * ((kk * 11) >> 5) : 60 + 2 * kk + 2 * (((kk + 1) * 11) >> 5);
+					}
 				}
 				if (write_plane) p[(r - 1) * W + lane + 64 * k] = (int16_t)sym;
 				park[((r - 1) & 15) * QROW + lane + 64 * k] = (uint8_t)sym;
