@@ -1326,20 +1326,29 @@ DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 	const int npass = q >= 21 ? 3 : (q >= 19 ? 2 : 1);
 	uint8_t *raw[3] = { c->raw, c->raw + Q + 512, reinterpret_cast<uint8_t *>(c->hs) };
 	uint8_t *pay[3] = { c->pay, c->pay + Q, reinterpret_cast<uint8_t *>(c->hs) + Q + 512 };
-	int *cnt = reinterpret_cast<int *>(lds);                      /* [3][H] matches per row, then their exclusive prefix */
+	/* One sweep.  A wavefront takes 64 consecutive rows and writes their entries, row after row, where its rows' entries would start if every
+	 * row above were full (64 x 255 raw bytes, 64 x 254 payload bytes a wavefront: the lists' buffers hold four such segments); then the
+	 * three later segments move left to where they belong.  (Until round 4: a sweep to count the rows' matches, prefix sums over the rows,
+	 * a second sweep -- every row loaded and matched twice -- to write.) */
+	const int RSEG = 64 * (H - 1), PSEG = 64 * (H - 2);
+	int *segn = reinterpret_cast<int *>(lds);                     /* [3][4][2]: a wavefront's raw bytes / payload bytes of a pass */
 	unsigned *shm = reinterpret_cast<unsigned *>(lds) + 3 * H;
 	unsigned total[3] = { 0, 0, 0 };
-	for (int sweep = 0; sweep < 2; sweep++) {
-		int nv[4];                                                  /* the next row of this wavefront, requested while the row is worked on (a row only rewrites itself) */
+	{
+		int rl[3] = { 0, 0, 0 }, pln[3] = { 0, 0, 0 };
+		uint8_t *rseg[3], *pseg[3];
+		for (int pass = 0; pass < 3; pass++) { rseg[pass] = raw[pass] + wv * RSEG; pseg[pass] = pay[pass] + wv * PSEG; }
+		const int rbeg = 64 * wv;
+		int nv[4];                                                  /* the next row, requested while the row is worked on (a row only rewrites itself) */
 #pragma unroll
-		for (int k = 0; k < 4; k++) nv[k] = o[wv * H + lane + 64 * k];
-		for (int r = wv; r < H; r += 4) {
+		for (int k = 0; k < 4; k++) nv[k] = o[rbeg * H + lane + 64 * k];
+		for (int r = rbeg; r < rbeg + 64; r++) {
 			int v[4];
 #pragma unroll
 			for (int k = 0; k < 4; k++) v[k] = nv[k];
-			if (r + 4 < H) {
+			if (r + 1 < rbeg + 64) {
 #pragma unroll
-				for (int k = 0; k < 4; k++) nv[k] = o[(r + 4) * H + lane + 64 * k];
+				for (int k = 0; k < 4; k++) nv[k] = o[(r + 1) * H + lane + 64 * k];
 			}
 			if (lane >= 62) v[3] = 0;                               /* columns 254, 255 take no part and are cleared */
 			for (int pass = 0; pass < npass; pass++) {
@@ -1355,32 +1364,45 @@ DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 					if (hit) poslist_match(pass, v[k], &pl[k], &kp[k]);
 				}
 				const int n = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
-				if (!sweep) { if (lane == 0) cnt[pass * H + r] = n; }
-				else {
-					const int base = cnt[pass * H + r];               /* matches in the rows above */
-					int before = 0;
-					for (int k = 0; k < 4; k++) {
-						if ((m[k] >> lane) & 1) {
-							const int at = base + before + __popcll(m[k] & low_bits(lane));
-							raw[pass][at + r] = (uint8_t)(lane + 64 * k); pay[pass][at] = (uint8_t)pl[k];     /* r markers precede this row's entries */
-						}
-						before += __popcll(m[k]);
+				int before = 0;
+				for (int k = 0; k < 4; k++) {
+					if ((m[k] >> lane) & 1) {
+						const int at = before + __popcll(m[k] & low_bits(lane));
+						rseg[pass][rl[pass] + at] = (uint8_t)(lane + 64 * k); pseg[pass][pln[pass] + at] = (uint8_t)pl[k];
 					}
-					if (lane == 0) raw[pass][base + n + r] = H - 2;
+					before += __popcll(m[k]);
 				}
+				if (lane == 0) rseg[pass][rl[pass] + n] = H - 2;      /* the row's marker behind its entries */
+				rl[pass] += n + 1; pln[pass] += n;
 				for (int k = 0; k < 4; k++) if ((m[k] >> lane) & 1) v[k] = kp[k];
 			}
-			if (sweep) for (int k = 0; k < 4; k++) o[r * H + lane + 64 * k] = (int16_t)v[k];
+			for (int k = 0; k < 4; k++) o[r * H + lane + 64 * k] = (int16_t)v[k];
 		}
-		BARRIER();
-		if (!sweep) {
-			for (int pass = 0; pass < npass; pass++) {
-				const unsigned ex = block_exscan((unsigned)cnt[pass * H + tid], tid, shm, &total[pass]);
-				BARRIER();
-				cnt[pass * H + tid] = (int)ex;
+		if (lane == 0) for (int pass = 0; pass < 3; pass++) { segn[(pass * 4 + wv) * 2] = rl[pass]; segn[(pass * 4 + wv) * 2 + 1] = pln[pass]; }
+	}
+	BARRIER();
+	for (int pass = 0; pass < npass; pass++) {
+		int dr = segn[(pass * 4) * 2], dp = segn[(pass * 4) * 2 + 1];   /* where the next segment belongs */
+		for (int w = 1; w < 4; w++) {
+			const int lr = segn[(pass * 4 + w) * 2], lp = segn[(pass * 4 + w) * 2 + 1];
+			for (int which = 0; which < 2; which++) {
+				uint8_t *buf = which ? pay[pass] : raw[pass];
+				const int src = w * (which ? PSEG : RSEG), dst = which ? dp : dr, len = which ? lp : lr;
+				if (src == dst) continue;
+				/* left moves in pieces of 1 KB, a piece read by everybody before anybody writes it: a piece's place ends in front of the next piece's source */
+				for (int c0 = 0; c0 < len; c0 += 4 * NT) {
+					uint8_t b4[4];
+#pragma unroll
+					for (int u = 0; u < 4; u++) { const int i = c0 + tid + u * NT; b4[u] = i < len ? buf[src + i] : (uint8_t)0; }
+					BARRIER();
+#pragma unroll
+					for (int u = 0; u < 4; u++) { const int i = c0 + tid + u * NT; if (i < len) buf[dst + i] = b4[u]; }
+				}
 			}
-			BARRIER();
+			dr += lr; dp += lp;
 		}
+		total[pass] = (unsigned)dp;
+		BARRIER();
 	}
 	if (!tid) PROF(c, 45);
 	for (int pass = 0; pass < npass; pass++) {
