@@ -1304,8 +1304,8 @@ DEV void poslist_finish_par(Ctx *c, PosList *pl, const uint8_t *__restrict__ raw
 
 /* Y25 (nhw_encoder.c:1498-1763): three filters over the LL1 tag plane, each collecting (column, payload) of its
  * codes row by row behind a row marker, and leaving a follow-up code for the next filter in some cells.  A cell's
- * fate through the three filters depends on the cell alone, so one sweep evaluates all three: one wavefront per
- * row (lane l owns columns l + 64k), match masks by ballot, a count sweep, prefix sums over the rows, a write sweep. */
+ * fate through the three filters depends on the cell alone, so one sweep evaluates all three: a wavefront per
+ * row (lane l owns columns l + 64k), match masks by ballot, the entries written in the same sweep (see below). */
 DEV int poslist_match(int pass, int v, int *payload, int *keep)
 {
 	*keep = 0;
