@@ -57,7 +57,9 @@ typedef struct {
 	float prefilter_ms;   /* quality 1..16: the rationed luma pre-filter (k_low_machine + k_low_marks), second of the front group; 0 for 17..23 */
 } nhw_timing;
 
-/* lifecycle: replaces `im.setup=malloc(..)` + per-image mallocs of encode_image (nhw_encoder.c:108-...) */
+/* lifecycle: replaces `im.setup=malloc(..)` + per-image mallocs of encode_image (nhw_encoder.c:108-...).  Everything a batch of up to
+ * max_batch images needs on the device is allocated here and nowhere else: the workspace (5.6 MB per image) and the staging buffers of the
+ * host path nhw_enc_batch / nhw_enc_synth_batch (1.8 MB per image) -- no call behind it allocates, so the first batch costs what the others do */
 int  nhw_enc_create(int device, int max_batch, nhw_enc **out);
 void nhw_enc_destroy(nhw_enc *e);
 const char *nhw_last_error(void);
@@ -101,13 +103,24 @@ int nhw_stage_color(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_y
  * for 17..21 it is a step inside the fused front kernel (NHW_E_QUALITY here).  In place on d_y */
 int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, void *stream);
 /* one analysis level (wavelet_filterbank.c:52-302) on planes of `stride` shorts per row, n_img images
- * spaced plane_stride shorts apart; size = transform size; final_level as in the oracle */
+ * spaced plane_stride shorts apart; size = transform size; final_level as in the oracle.
+ * Size 256 / 128: any `short` input (blocks whose second pass would leave 16 bits take a 32-bit path that follows the reference's `int`
+ * accumulators).  Size 512 is the encoder's level-1 kernel, built for luma, and has a DOMAIN: with U = the largest sample of the planes
+ * (0 if none is positive) and L = minus the smallest (0 if none is negative),
+ *       104 U + 40 L <= NHW_ANA512_BOUND   and   104 L + 40 U <= NHW_ANA512_BOUND
+ * (the 2-D low-pass is the outer product of [-1 2 6 2 -1]: positive weights 104, negative 40; 47 below 32767 for the error-diffusion
+ * carry and the rounding offset of filters.c:246-276; proof: nhwcodec_amd/csrc/nhw_front_image.h).  E.g. L = 4 allows U <= 313, L = 0
+ * U <= 314; the encoder's luma is 0..255 plus at most +-4 of its pre-filters.  Planes outside the domain are refused with NHW_E_ARG
+ * (a synchronising check on the stream): the entry point never returns a plane that differs from the reference's wavelet_analysis(). */
+#define NHW_ANA512_BOUND 32720
 int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size,
                        int final_level, void *stream);
 int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size,
                         void *stream);
 /* the two chroma level-1 analyses (nhw_encoder.c:2265, 2576) as the encoder launches them for quality >= 15, on the 4:2:0 planes of the handle's
- * last batch (a measurement hook: bench.py adds their time to the fused front kernel's) */
+ * last batch (a measurement hook: bench.py adds their time to the fused front kernel's).  The launches are ordered behind that batch; NHW_E_ARG
+ * when the handle's last whole batch had fewer than n images or a quality below 15 (nothing it could work on); it overwrites the chroma
+ * work planes, so it belongs between batches */
 int nhw_stage_chroma_l1(nhw_enc *e, int n, void *stream);
 
 /* ---- decoder (BASELINE config 5): replaces decode_image + write_image_bmp (decoder/codec.h:184-186,

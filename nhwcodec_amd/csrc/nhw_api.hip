@@ -16,7 +16,7 @@
 
 /* launchers (nhw_front.hip, nhw_tail.hip) */
 void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_stride, uint8_t *u, uint8_t *v, size_t c_stride, hipStream_t s);
-void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, int16_t *keep, size_t keep_stride, hipStream_t s,
+void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, hipStream_t s,
                          int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0, const uint8_t *src8 = nullptr, size_t src8_plane = 0, int drop_t = 0,
                          const int16_t *alt = nullptr, size_t alt_plane = 0, int alt_stride = 0);
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s, int drop_nat = 0);
@@ -64,6 +64,7 @@ struct nhw_enc {
 	int lists_fork;   /* the position lists (Y24/Y25) on a third stream (NHW_LISTS_FORK=0 turns it off: +0.75 ms per q20 batch) */
 	int front_fallback; /* debug: every row / segment of the pre-filter carry takes its exact fallback path (tests) */
 	int stop_after;   /* debug: leave the batch driver after this many stages (0 = run everything) */
+	int last_n, last_q; /* images and quality of the last whole batch (nhw_stage_chroma_l1 works on what it left in the 4:2:0 planes) */
 };
 
 static const size_t k_buf_bytes[B_COUNT] = {
@@ -96,6 +97,9 @@ extern "C" int nhw_enc_set_compat(nhw_enc *e, int mode)
 }
 
 extern "C" void nhw_enc_destroy(nhw_enc *e);
+static int host_buffers(nhw_enc *e, int n);
+/* device bytes per image of the host path's staging (nhw_enc_batch / nhw_enc_synth_batch): input slot, output slot, compacted output */
+#define HOST_PATH_BYTES ((size_t)NHW_IMG_BYTES + 2 * (size_t)NHW_OUT_STRIDE + 24)
 extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 {
 	if (!out || max_batch < 1 || max_batch > 65535) { g_err = "bad argument"; return NHW_E_ARG; }
@@ -113,9 +117,10 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 	const int rc = [&]() -> int {                                  /* a failure half-way leaves nothing behind: the handle is destroyed below */
 		size_t free_b = 0, total_b = 0;
 		HIPCHK(hipMemGetInfo(&free_b, &total_b));
-		if (total > free_b) {                                      /* 5.6 MB of workspace per image: say so instead of failing inside hipMalloc */
+		const size_t need = total + HOST_PATH_BYTES * (size_t)max_batch;
+		if (need > free_b) {                                       /* 5.6 MB of workspace + 1.8 MB of host-path staging per image: say so instead of failing inside hipMalloc */
 			char b[200];
-			snprintf(b, sizeof b, "encoder workspace for max_batch %d needs %zu MiB (%.1f MiB per image), %zu MiB of HBM are free", max_batch, total >> 20, (double)total / max_batch / 1048576.0, free_b >> 20);
+			snprintf(b, sizeof b, "encoder workspace for max_batch %d needs %zu MiB (%.1f MiB per image), %zu MiB of HBM are free", max_batch, need >> 20, (double)need / max_batch / 1048576.0, free_b >> 20);
 			g_err = b;
 			return NHW_E_ARG;
 		}
@@ -127,7 +132,9 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 		for (int i = 0; i < 7; i++) HIPCHK(hipEventCreate(&e->ev[i]));
 		for (int i = 0; i < 4; i++) HIPCHK(hipStreamCreateWithFlags(&e->part_stream[i], hipStreamNonBlocking));
 		for (int i = 0; i < 5; i++) HIPCHK(hipEventCreateWithFlags(&e->part_ev[i], hipEventDisableTiming));
-		return NHW_OK;
+		/* the host path's staging buffers, for the whole of max_batch, now: allocated on the first nhw_enc_batch they made that call twice as
+		 * slow as the ones behind it (gigabytes of hipMalloc inside the timed region of whoever measured it) */
+		return host_buffers(e, max_batch);
 	}();
 	if (rc != NHW_OK) { nhw_enc_destroy(e); return rc; }
 	e->parts = 1;   /* sub-batches on streams of their own (NHW_PARTS=2..4) bought 4 % while the tail kernels were latency-bound; they no longer do */
@@ -221,12 +228,12 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		if (q <= 14) nhw_launch_low_prefilter_chroma(comp ? plane8(ws, B_PV) : plane8(ws, B_PU), ws.stride[B_PU], cjpeg, cps, q, n, cs);   /* :2263 / :2579 */
 		else if (!widen_in_analysis) nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, nullptr, 0, cs, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2,   /* + the copy of LL1 */
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, cs, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2,   /* + the copy of LL1 */
 		                    widen_in_analysis ? (comp ? plane8(ws, B_PV) : plane8(ws, B_PU)) : nullptr, ws.stride[B_PU], !ws.dbg);
 		if (low) nhw_launch_low_chroma_thin(cproc, cps, n, cs);      /* :2277-2308 / :2590-2621 */
 		STAGE_DONE();
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, cs, nullptr, 0, 0, 0, nullptr, 0, !ws.dbg);
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, cs, nullptr, 0, 0, 0, nullptr, 0, !ws.dbg);
 		STAGE_DONE();
 		nhw_launch_phase(PH_C2, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
@@ -234,7 +241,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 		STAGE_DONE();
 		nhw_launch_phase(PH_C3, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, nullptr, 0, cs, plane16(ws, B_CL2SAVE), ws.stride[B_CL2SAVE] / 2, H / 2, 1, nullptr, 0, !ws.dbg);   /* + the copy of the level-2 block */
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, cs, plane16(ws, B_CL2SAVE), ws.stride[B_CL2SAVE] / 2, H / 2, 1, nullptr, 0, !ws.dbg);   /* + the copy of the level-2 block */
 		STAGE_DONE();
 		STAGE_DONE();
 		nhw_launch_phase(PH_C4, ws, comp, out, d_sizes, d_status, cs);
@@ -256,7 +263,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	/* Y4: level-2 analysis (:139) */
 	/* the LL rows come from ll1 (the front's copy of them in natural orientation, res256): the front does not write them into the work plane as well
 	 * outside the stage checks, and this analysis fills that quadrant of the work plane itself (its transposed first-direction plane) */
-	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s, nullptr, 0, 0, 0, nullptr, 0, 0, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, H);
+	nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, s, nullptr, 0, 0, 0, nullptr, 0, 0, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, H);
 	STAGE_DONE();
 	if (q > 6) {                                                     /* first closed loop (:141-283) */
 	nhw_launch_phase(PH_L1, ws, 0, out, d_sizes, d_status, s);
@@ -268,8 +275,8 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	nhw_launch_phase(PH_L2, ws, 0, out, d_sizes, d_status, s);
 	STAGE_DONE();
 	} else nhw_launch_l2_recon(jpeg, proc, ps, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, n, s);   /* synthesis + Y8 + Y9 on one residency of the block; the stage checks take the three kernels */
-	if (q > 12) nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s, plane16(ws, B_L2SAVE), ws.stride[B_L2SAVE] / 2, H, 1);   /* + Y13 (:623-631): copy of the coefficient block */
-	else nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, nullptr, 0, s);
+	if (q > 12) nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, s, plane16(ws, B_L2SAVE), ws.stride[B_L2SAVE] / 2, H, 1);   /* + Y13 (:623-631): copy of the coefficient block */
+	else nhw_launch_analysis(jpeg, proc, n, ps, W, H, 1, s);
 	STAGE_DONE();
 	}
 	if (q <= 12) {                                                   /* Y11 (q <= 11), Y12, then Y13 */
@@ -346,7 +353,7 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 	const int parts = (e->stop_after || n < 512) ? 1 : e->parts;
 	if (parts == 1) {
 		const int rc = run_batch(e, ws, d_bgr, n, quality, d_out, d_sizes, d_status, s, 1);
-		if (rc == NHW_OK && !e->stop_after) { e->timed = true; e->timed_parts = 1; e->timed_front_images = n; }
+		if (rc == NHW_OK && !e->stop_after) { e->timed = true; e->timed_parts = 1; e->timed_front_images = n; e->last_n = n; e->last_q = quality; }
 		return rc;
 	}
 	/* the front launch group is the part that is bound by the memory system and the ALUs: it runs once for the whole batch */
@@ -369,7 +376,7 @@ extern "C" int nhw_enc_batch_device(nhw_enc *e, const void *d_bgr, int n, int qu
 		HIPCHK(hipStreamWaitEvent(s, e->part_ev[k], 0));
 	}
 	HIPCHK(hipEventRecord(e->ev[4], s));
-	e->timed = true; e->timed_parts = parts;
+	e->timed = true; e->timed_parts = parts; e->last_n = n; e->last_q = quality;
 	return NHW_OK;
 }
 
@@ -515,8 +522,28 @@ extern "C" int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, vo
 	return NHW_OK;
 }
 
+/* smallest and largest sample of n planes of W x W shorts (the domain check of the size-512 analysis stage) */
+__global__ __launch_bounds__(256) void k_plane_range(const int16_t *__restrict__ base, size_t plane_stride, int *__restrict__ mnmx)
+{
+	const uint4 *p = reinterpret_cast<const uint4 *>(base + (size_t)blockIdx.y * plane_stride);
+	int mn = 32767, mx = -32768;
+	for (int i = blockIdx.x * 256 + threadIdx.x; i < W * W / 8; i += gridDim.x * 256) {
+		const uint4 v = p[i];
+		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+		for (int k = 0; k < 4; k++) {
+			const int a = (int16_t)(w[k] & 0xFFFF), b = (int16_t)(w[k] >> 16);
+			mn = a < mn ? a : mn; mn = b < mn ? b : mn; mx = a > mx ? a : mx; mx = b > mx ? b : mx;
+		}
+	}
+	for (int o = 32; o; o >>= 1) { const int a = __shfl_xor(mn, o), b = __shfl_xor(mx, o); mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
+	if ((threadIdx.x & 63) == 0) { atomicMin(&mnmx[0], mn); atomicMax(&mnmx[1], mx); }
+}
+
 /* one analysis level with the kernels the encoder runs: size 512 = the band kernel on a luma plane (its LL copy goes to the jpeg plane,
- * the second copy it makes to the workspace's ll1), 256 / 128 = the whole-block kernels */
+ * the second copy it makes to the workspace's ll1), 256 / 128 = the whole-block kernels.
+ * Size 512 has a DOMAIN (include/nhw_hip.h, proof in nhw_front_image.h): the level-1 kernel runs both filter passes in packed 16-bit
+ * arithmetic, which equals the reference's `int` accumulators (filters.c:203-287, 346-386) only while the second pass stays inside 16 bits.
+ * Planes outside it are refused (NHW_E_ARG) -- never answered with a plane that differs from wavelet_analysis(). */
 extern "C" int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size,
                                   int final_level, void *stream)
 {
@@ -526,12 +553,24 @@ extern "C" int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_
 	if (size == 512) {
 		if (stride != W || final_level || n_img > e->max_batch) { g_err = "size 512: stride 512, not the final level, n <= max_batch"; return NHW_E_ARG; }
 		const NhwWs &ws = e->ws;
+		{                                                          /* the domain check: U = largest sample (or 0), L = -smallest (or 0); 104 U + 40 L and 104 L + 40 U at most NHW_ANA512_BOUND */
+			int *d_mm = reinterpret_cast<int *>(plane8(ws, B_ROWSTATE)), mm[2] = { 32767, -32768 };   /* (the front kernel's row-state bytes: free until it runs) */
+			HIPCHK(hipMemcpyAsync(d_mm, mm, sizeof mm, hipMemcpyHostToDevice, s));
+			k_plane_range<<<dim3(32, n_img), 256, 0, s>>>((const int16_t *)d_jpeg, plane_stride, d_mm);
+			HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof mm, hipMemcpyDeviceToHost, s));
+			HIPCHK(hipStreamSynchronize(s));
+			const long U = mm[1] > 0 ? mm[1] : 0, L = mm[0] < 0 ? -(long)mm[0] : 0;
+			if (104 * U + 40 * L > NHW_ANA512_BOUND || 104 * L + 40 * U > NHW_ANA512_BOUND) {
+				g_err = "size 512: samples outside the level-1 kernel's 16-bit domain (104 U + 40 L <= 32720, see nhw_hip.h)";
+				return NHW_E_ARG;
+			}
+		}
 		/* the level-1 kernel's input is a plane of its own (the caller's jpeg plane receives the LL rows) */
 		HIPCHK(hipMemcpy2DAsync(plane16(ws, B_KMAP), ws.stride[B_KMAP], d_jpeg, plane_stride * 2, 8 * Q, (size_t)n_img, hipMemcpyDeviceToDevice, s));
 		nhw_launch_front_fused(nullptr, 20, nullptr, nullptr, 0, plane16(ws, B_KMAP), ws.stride[B_KMAP], 0, plane8(ws, B_ROWSTATE), ws.stride[B_ROWSTATE],
 		                       (int16_t *)d_proc, (int16_t *)d_jpeg, plane_stride, plane16(ws, B_LL1), ws.stride[B_LL1] / 2, nullptr, 0, n_img, s, 2);
 	} else if (size == 256 || size == 128)
-		nhw_launch_analysis((int16_t *)d_jpeg, (int16_t *)d_proc, n_img, plane_stride, stride, size, final_level, nullptr, 0, s);
+		nhw_launch_analysis((int16_t *)d_jpeg, (int16_t *)d_proc, n_img, plane_stride, stride, size, final_level, s);
 	else { g_err = "transform size must be 512, 256 or 128"; return NHW_E_ARG; }
 	HIPCHK(hipGetLastError());
 	return NHW_OK;
@@ -543,11 +582,16 @@ extern "C" int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_
 extern "C" int nhw_stage_chroma_l1(nhw_enc *e, int n, void *stream)
 {
 	if (!e || n < 1 || n > e->max_batch) { g_err = "bad argument"; return NHW_E_ARG; }
+	if (!e->timed || n > e->last_n || e->last_q < 15) {             /* the byte planes must be those of a whole batch at a quality that launches this form (q >= 15: the analysis widens the bytes itself) */
+		g_err = "nhw_stage_chroma_l1: the handle's last batch does not cover the request (needs a completed batch of >= n images at quality >= 15)";
+		return NHW_E_ARG;
+	}
 	HIPCHK(hipSetDevice(e->device));
 	const NhwWs &ws = e->ws;
 	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+	HIPCHK(hipStreamWaitEvent(s, e->ev[4], 0));                     /* behind that batch, whatever stream it ran on: its chroma sequence (a stream of the handle) works in the planes written here */
 	for (int comp = 0; comp < 2; comp++)
-		nhw_launch_analysis(plane16(ws, B_CJPEG), plane16(ws, B_CPROC), n, ws.stride[B_CJPEG] / 2, H, H, 0, nullptr, 0, s, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2,
+		nhw_launch_analysis(plane16(ws, B_CJPEG), plane16(ws, B_CPROC), n, ws.stride[B_CJPEG] / 2, H, H, 0, s, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2,
 		                    comp ? plane8(ws, B_PV) : plane8(ws, B_PU), ws.stride[B_PU], 1);
 	HIPCHK(hipGetLastError());
 	return NHW_OK;
@@ -556,6 +600,7 @@ extern "C" int nhw_stage_chroma_l1(nhw_enc *e, int n, void *stream)
 extern "C" int nhw_stage_synthesis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_img, size_t plane_stride, int stride, int size, void *stream)
 {
 	if (!e || n_img < 1) return NHW_E_ARG;
+	if (size != 256 && size != 128) { g_err = "synthesis: transform size must be 256 or 128 (the encoder has no synthesis of size 512)"; return NHW_E_ARG; }
 	HIPCHK(hipSetDevice(e->device));
 	nhw_launch_synthesis((int16_t *)d_jpeg, (int16_t *)d_proc, n_img, plane_stride, stride, size, stream ? (hipStream_t)stream : e->own_stream);
 	HIPCHK(hipGetLastError());

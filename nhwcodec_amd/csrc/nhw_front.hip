@@ -567,19 +567,26 @@ void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, in
 /* save (optional): a second destination for the block the reference copies right after the transform -- the S x S coefficient block
  * (save_kind 1) or the LL quadrant in natural orientation (save_kind 2) -- written by the fused kernels, by a block copy otherwise */
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level,
-                         int16_t *keep, size_t keep_stride, hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind, const uint8_t *src8, size_t src8_plane, int drop_t,
+                         hipStream_t s, int16_t *save, size_t save_plane, int save_row, int save_kind, const uint8_t *src8, size_t src8_plane, int drop_t,
                          const int16_t *alt, size_t alt_plane, int alt_stride)
 {
 	if (!save) save_kind = 0;
-	if (size == 256 && !keep) { k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane, drop_t, alt, alt_plane, alt_stride); return; }
-	if (size == 128 && !keep) { k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0, drop_t, nullptr, 0, 0); return; }
-	(void)keep; (void)keep_stride;       /* size 512 is the front kernels' (nhw_launch_front_fused); nothing else is called with another size */
+	if (size == 256) k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane, drop_t, alt, alt_plane, alt_stride);
+	else if (size == 128) k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0, drop_t, nullptr, 0, 0);
+	else {   /* size 512 is the front kernels' (nhw_launch_front_fused); a caller with any other size would get stale planes: stop loudly */
+		fprintf(stderr, "nhw_launch_analysis: no kernel for transform size %d (256 and 128 only; 512 is nhw_launch_front_fused)\n", size);
+		abort();
+	}
 }
 
 void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s, int drop_nat)
 {
-	if (size == 256) { k_dwt_syn<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat); return; }
-	if (size == 128) { k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat); return; }
+	if (size == 256) k_dwt_syn<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat);
+	else if (size == 128) k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat);
+	else {
+		fprintf(stderr, "nhw_launch_synthesis: no kernel for transform size %d (256 and 128 only)\n", size);
+		abort();
+	}
 }
 
 /* the front launch group = ONE kernel.

@@ -192,7 +192,23 @@ __device__ __forceinline__ uint2 chroma_h8(const uint32_t c[4], uint32_t left)
 	return make_uint2(tri121(p01, e01, o01), tri121(p23, e23, o23));
 }
 
-/* packed 16-bit helpers of the two filter passes (filters.c:88-287: the values stay inside 16 bits, so two columns share a dword) */
+/* packed 16-bit helpers of the two filter passes (filters.c:88-287, 346-386), two columns to a dword.
+ *
+ * INPUT DOMAIN of the level-1 analysis in this file, and why packed 16-bit arithmetic equals the reference's on it.  Let every input
+ * sample lie in [-L, U] (L, U >= 0).  Additions, subtractions and multiplications by constants are exact modulo 2^16 whatever the
+ * intermediate sums do, and the reference stores the first pass in `short` cells too (filters.c:346-386 writes its `int` sums into the
+ * short plane, i.e. modulo 2^16 as well) -- so only the operations that are NOT modular need their operand to be the true integer:
+ * the sign tests and right shifts of the second pass (round-half-away, the error diffusion of :246-276, the predict's halving).
+ *   * second pass, low-pass rows (downfilter53VI, :203-287): r = 6 x0 + 2 (x-1 + x1) - (x-2 + x2) on first-pass low-pass values, which are
+ *     themselves that tap on the input: the 2-D kernel is the outer product of [-1 2 6 2 -1], positive weights (6+2+2)^2 + (1+1)^2 = 104,
+ *     negative ones 2 * 10 * 2 = 40, so  -(104 L + 40 U) <= r <= 104 U + 40 L.  pk_diffuse() reads r's sign and r mod 64: r must be
+ *     the true value.  Then acc = r + carry, |carry| <= 15 (the reference holds acc in a short: modular, fine), and pk_rnd_half_away(acc, 6)
+ *     adds 32 (31 below zero) before the shift: |r| + 15 + 32 <= 32767.  Hence the bound  104 U + 40 L <= 32720,  104 L + 40 U <= 32720
+ *     (NHW_ANA512_BOUND in include/nhw_hip.h; nhw_stage_analysis(size 512) checks it and refuses planes outside).
+ *   * the other sums are smaller for the same L, U and fit a fortiori: the predict's pair sum x0 + x2 (+1) on first-pass low values is at
+ *     most 2 (10 U + 2 L) + 1; the high-pass rows' taps see first-pass differences, |2 x1 - x0 - x2| <= 2 (U + L), so their tap is at most
+ *     24 (U + L) + 8 with the rounding offset.
+ * The encoder's own luma is 0 .. 255 plus what the pre-filters add (at most +-4 a pixel): 104 * 259 + 40 * 4 = 27 096. */
 __device__ __forceinline__ s16x2 pk_rnd_half_away(s16x2 v, int shift) { return (v + (s16x2)(short)(1 << (shift - 1)) + (v >> 15)) >> shift; }
 __device__ __forceinline__ s16x2 pk_diffuse(s16x2 r)
 {

@@ -5,7 +5,7 @@ set -u
 TAG=${1:-r2}; COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-host-path --no-chroma-l1 --sweep="
+CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-host-path --no-chroma-l1 --no-config4-shape --sweep="
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- $CMD > $OUT/stats.log 2>&1
 NHW_CHROMA_FORK=0 rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o s -- $CMD > $OUT/stats1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- $CMD > $OUT/pmc_fetch.log 2>&1

@@ -4,7 +4,7 @@ set -u
 TAG=${1:-qdec}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --sweep="
+CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-config4-shape --sweep="
 NHW_CHROMA_FORK=0 rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o s -- $CMD > $OUT/stats1.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- $CMD > $OUT/stats.log 2>&1
 python profiles/summarise_rocpd.py $(ls $OUT/stats1/*.db | head -1) > $OUT/kernel_stats_1stream.txt 2>&1

@@ -117,6 +117,16 @@ def test_cli_rejects_unimplemented_quality_loudly(cli):
     assert rc == 3 and "not implemented" in err
 
 
+@pytest.mark.parametrize("args,msg", [(["--devices", "foo"], "--devices wants"), (["--devices", "0,"], "--devices wants"), (["--devices", ","], "--devices wants"),
+                                      (["--devices", "0,x"], "--devices wants"), (["--devices", ",".join(["0"] * 17)], "at most 16"),
+                                      (["--chunk", "x"], "--chunk wants"), (["--chunk", "0"], "--chunk wants"), (["--chunk", "99999"], "--chunk wants")])
+def test_cli_rejects_malformed_device_lists_and_chunks(cli, tmp_path, args, msg):
+    """A malformed --devices / --chunk is an error with a message and exit code 1 (before any GPU work), not a silent `device 0` / clamp."""
+    rc, out, err = _run(cli, *args, "--synthetic", "1", "--outdir", str(tmp_path))
+    assert rc == 1 and msg in err, (rc, err)
+    assert not list(tmp_path.iterdir())
+
+
 def test_cli_bad_bmp_exit_codes_match_reference(cli, tmp_path):
     if not os.path.exists(REF_CLI):
         pytest.skip("reference binary not built")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool (GPU box): the encode step with two builds of the library on the same box, alternating.  usage: bash tools/dev/ab.sh <old.so> [q ...]
 OLD=$1; shift; QS=${@:-20}
-B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decode --no-host-path --no-chroma-l1 --sweep="
+B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decode --no-host-path --no-chroma-l1 --no-config4-shape --sweep="
 cp nhwcodec_amd/libnhwhip.so /tmp/new.so
 for i in 1 2 3; do
   for v in new old; do

@@ -384,10 +384,24 @@ int main(int argc, char **argv)
 		if (!strcmp(argv[1], "--seed") && argc > 2) { seed = (uint32_t)strtoul(argv[2], NULL, 10); argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--outdir") && argc > 2) { outdir = argv[2]; argc -= 2; argv += 2; continue; }
 		if (!strcmp(argv[1], "--gpus") && argc > 2) { gpus = atoi(argv[2]); argc -= 2; argv += 2; continue; }
-		if (!strcmp(argv[1], "--chunk") && argc > 2) { g_chunk = atoi(argv[2]); if (g_chunk < 1) g_chunk = 1; if (g_chunk > CHUNK) g_chunk = CHUNK; argc -= 2; argv += 2; continue; }
+		if (!strcmp(argv[1], "--chunk") && argc > 2) {
+			char *end;
+			const long v = strtol(argv[2], &end, 10);
+			if (end == argv[2] || *end || v < 1 || v > CHUNK) { fprintf(stderr, "%s: --chunk wants a number 1..%d, got '%s'\n", PROGRAM, CHUNK, argv[2]); return 1; }
+			g_chunk = (int)v; argc -= 2; argv += 2; continue;
+		}
 		if (!strcmp(argv[1], "--devices") && argc > 2) {            /* one worker per entry; a device may be named more than once (two handles, two workers on one GPU) */
 			const char *p = argv[2];
-			while (*p && ndevlist < 16) { devlist[ndevlist++] = (int)strtol(p, (char **)&p, 10); if (*p == ',') p++; else break; }
+			for (;;) {                                                /* digits, comma, digits, ..: anything else (empty list, trailing comma, garbage, more than 16 entries) is an error, not device 0 */
+				char *end;
+				const long v = strtol(p, &end, 10);
+				if (end == p || v < 0 || v > 1023) { fprintf(stderr, "%s: --devices wants a comma-separated list of device numbers, got '%s'\n", PROGRAM, argv[2]); return 1; }
+				if (ndevlist >= 16) { fprintf(stderr, "%s: --devices: at most 16 entries\n", PROGRAM); return 1; }
+				devlist[ndevlist++] = (int)v;
+				if (*end == '\0') break;
+				if (*end != ',' || end[1] == '\0') { fprintf(stderr, "%s: --devices wants a comma-separated list of device numbers, got '%s'\n", PROGRAM, argv[2]); return 1; }
+				p = end + 1;
+			}
 			argc -= 2; argv += 2; continue;
 		}
 		if (!strcmp(argv[1], "--stock-compat")) { stock_compat = 1; argc -= 1; argv += 1; continue; }
