@@ -26,6 +26,14 @@ namespace nhw {
 #define FI_NT    512                 /* threads of a workgroup: two workgroups share a CU (78 KB of LDS each) */
 #define FI_RS    514                 /* LDS row stride in shorts (257 dwords: a lane per row walks over consecutive banks) */
 #define FI_RD    (FI_RS / 2)         /* the same in dwords */
+/* The LUMA rows have a layout of their own: one unused dword behind every 32 (dword d of a row sits at d + (d >> 5)), 265 dwords a row.
+ * Phase 0 writes a row 32 lanes side by side, eight dwords a lane: unskewed, lane g's dwords 8g + e fall on banks (8g + e) mod 32 -- four
+ * banks for the 32 lanes of a store instruction, an 8-way conflict on every one of the band's luma stores (SQ_LDS_BANK_CONFLICT: half of the
+ * kernel's 267 M conflict cycles a launch in round 4).  With the skew lane g starts at bank 8g + (g >> 2): 32 different banks.  265 = 9 mod 32
+ * is odd, so the phases that put a lane on every row still walk over 32 different banks. */
+#define FI_YRD   265
+#define FI_YRS   (2 * FI_YRD)
+#define FI_YP(d) ((d) + ((d) >> 5))  /* place of dword d (>= 0) of a luma row */
 #define FI_BR    32                  /* new image rows per band = 16 output rows of every sub-band */
 #define FI_YROWS 35                  /* luma rows 32b .. 32b+33 (index = row - 32b) + one spare row (index 34: row 32b+32 as it was before the pair rules) */
 #define FI_KROWS 37                  /* horizontal-pass rows 32b-4 .. 32b+32 (index = row - 32b + 4); rows 5.. hold the contrast / kernel map before that */
@@ -34,12 +42,12 @@ namespace nhw {
 #define FI_LOOK  12                  /* pixels of look-back for a segment's entry state */
 /* byte offsets into the dynamic LDS block */
 #define FI_YB_OFF   16
-#define FI_KB_OFF   (FI_YB_OFF + FI_YROWS * FI_RS * 2)
+#define FI_KB_OFF   (FI_YB_OFF + FI_YROWS * FI_YRS * 2)
 #define FI_STG_OFF  (FI_KB_OFF + 5 * FI_RS * 2)             /* chroma staging: 32 rows x (256 U + 256 V) bytes, over rows 5..20: the rows the SECOND half of the contrast pass fills */
 #define FI_TAB_OFF  (FI_KB_OFF + FI_KROWS * FI_RS * 2)
-#define FI_PT_OFF   FI_TAB_OFF                              /* 225 x 16 B: pair-rule entries */
-#define FI_CA_OFF   (FI_PT_OFF + 3600)                      /* 405 B (+3): class of a kernel value, clamped to -202 .. 202 */
-#define FI_CB_OFF   (FI_CA_OFF + 408)                       /* the same x 16 */
+#define FI_PT_OFF   FI_TAB_OFF                              /* 225 x 12 B: pair-rule entries (three dwords: a stride of 3 spreads the entries over all 32 banks; at 16 B they shared eight) */
+#define FI_CA_OFF   (FI_PT_OFF + 2704)                      /* 405 B (+3): class of a kernel value, clamped to -202 .. 202 */
+#define FI_CB_OFF   (FI_CA_OFF + 408)                       /* the same x 12 */
 #define FI_EN_OFF   (FI_CB_OFF + 408)                       /* 512 B: entry state of every carry segment of the band */
 #define FI_CR_OFF   (FI_EN_OFF + 512)                       /* 2 x 512 B: the last row of filtered chroma, kept for the next band (written by one band while the row of the band before is read) */
 #define FI_MISC_OFF (FI_CR_OFF + 1024)
@@ -224,12 +232,12 @@ __device__ __forceinline__ s16x2 pk_diffuse(s16x2 r)
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
 #ifdef NHW_DEV   /* developer builds: 32 rows of a plane in LDS (from row index 1 / 5 on) into a plane in memory, for tests/gpu_front_debug.py */
-#define FI_DUMP(kind, base) do { if ((flags & 2) && ((flags >> 4) & 15) == (kind) && keepb) { \
+#define FI_DUMP(kind, base, yl) do { if ((flags & 2) && ((flags >> 4) & 15) == (kind) && keepb) { \
 	for (int k_ = t0; k_ < 32 * 256; k_ += FI_NT) { const int rr_ = 1 + (k_ >> 8), o_ = k_ & 255; \
-		if (r0 + rr_ < W - ((kind) == 2 || (kind) == 3)) reinterpret_cast<uint32_t *>(keepb + (size_t)img * keep_stride + (size_t)(r0 + rr_) * W)[o_] = reinterpret_cast<const uint32_t *>((base) + (rr_ - 1) * FI_RS)[o_]; } \
+		if (r0 + rr_ < W - ((kind) == 2 || (kind) == 3)) reinterpret_cast<uint32_t *>(keepb + (size_t)img * keep_stride + (size_t)(r0 + rr_) * W)[o_] = reinterpret_cast<const uint32_t *>((base) + (rr_ - 1) * ((yl) ? FI_YRS : FI_RS))[(yl) ? FI_YP(o_) : o_]; } \
 	__syncthreads(); } } while (0)
 #else
-#define FI_DUMP(kind, base) do { } while (0)
+#define FI_DUMP(kind, base, yl) do { } while (0)
 #endif
 #ifdef NHW_DEV   /* developer builds: clock ticks of thread 0 between the phase boundaries, summed over all workgroups (NHW_FRONT_PROF=1 prints them) */
 __device__ unsigned long long g_fi_prof[16];
@@ -308,10 +316,10 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 		if (t < PCLS * PCLS) {
 			const int c0 = t / PCLS, c1 = t % PCLS;
 			const int r0 = pair_class_rep(c0 - 7), r1 = pair_class_rep(c1 - 7);
-			ptab[4 * t] = prefilter_pair_delta(r0, r1, 0); ptab[4 * t + 1] = prefilter_pair_delta(r0, r1, 1);
-			ptab[4 * t + 2] = (uint32_t)pair_big_flag_fwd(r0, r1); ptab[4 * t + 3] = 0;
+			ptab[3 * t] = prefilter_pair_delta(r0, r1, 0); ptab[3 * t + 1] = prefilter_pair_delta(r0, r1, 1);
+			ptab[3 * t + 2] = (uint32_t)pair_big_flag_fwd(r0, r1);
 		}
-		if (t < 405) { const int k = t - 202, m = pair_mag_class(iabs(k)), c = k < 0 ? 7 - m : 7 + m; tca[t] = (uint8_t)c; tcb[t] = (uint8_t)(16 * c); }
+		if (t < 405) { const int k = t - 202, m = pair_mag_class(iabs(k)), c = k < 0 ? 7 - m : 7 + m; tca[t] = (uint8_t)c; tcb[t] = (uint8_t)(12 * c); }
 		if (t == 0) { misc[0] = 0; misc[2] = 0; misc[3] = 0; misc[8] = 0; }
 	}
 
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
 					for (int e = 0; e < 4; e++) { uw[e] = 0; vw[e] = 0; }
 				}
-				uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + (i + 2) * FI_RS + 16 * g);
+				uint32_t *d = reinterpret_cast<uint32_t *>(ybuf) + (i + 2) * FI_YRD + 8 * g + (g >> 2);   /* FI_YP(8g): eight dwords never straddle a pad */
 #pragma unroll
 				for (int e = 0; e < 8; e++) d[e] = yw[e];
 				/* the pixel on the left of the group comes from the lane on the left (every lane takes part in the shuffle) */
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			for (int it = 0; it < 4; it++) {
 				const int k = t + FI_NT * it, i = k >> 6, row = r0 + 2 + i;
 				const uint4 v = (row >= 0 && row < W) ? pf[it] : make_uint4(0, 0, 0, 0);
-				uint32_t *d = reinterpret_cast<uint32_t *>(ybuf + (i + 2) * FI_RS + 8 * (k & 63));
+				uint32_t *d = reinterpret_cast<uint32_t *>(ybuf) + (i + 2) * FI_YRD + FI_YP(4 * (k & 63));
 				d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 			}
 		}
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 		if (b < 0) {
 			/* rows 0 and 1 sit at luma index 32 and 33: move them to 0 and 1, ask for the first band's rows */
 			const int t = opaque(t0);
-			for (int k = t; k < 2 * FI_RD; k += FI_NT) { uint32_t *y = reinterpret_cast<uint32_t *>(ybuf); y[k] = y[32 * FI_RD + k]; }
+			for (int k = t; k < 2 * FI_YRD; k += FI_NT) { uint32_t *y = reinterpret_cast<uint32_t *>(ybuf); y[k] = y[32 * FI_YRD + k]; }
 			issue(0);
 			__syncthreads();
 			continue;
@@ -404,10 +412,15 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				const int k = t + FI_NT * (it & 1), gh = k >> 4;
 				const int rr = (it < 2 ? 17 : 1) + (k & 15), g = (gh & ~7) | ((gh & 1) << 2) | ((gh >> 1) & 3);   /* 16 lanes a group; the two groups of a half-wavefront 16 banks apart */
 				if (r0 + rr > W - 2) continue;
-				const uint32_t *ru = reinterpret_cast<const uint32_t *>(ybuf + (rr - 1) * FI_RS) + 4 * g - 1, *rm = ru + FI_RD, *rd = rm + FI_RD;
+				/* dwords 4g-1 .. 4g+4 of three rows: the first / last of them lies behind a pad where the group starts / ends a block of 32 dwords */
+				const uint32_t *ru = reinterpret_cast<const uint32_t *>(ybuf) + (rr - 1) * FI_YRD + 4 * g + (g >> 3), *rm = ru + FI_YRD, *rd = rm + FI_YRD;
+				const int om = (g & 7) == 0 ? -2 : -1, op = (g & 7) == 7 ? 5 : 4;
 				uint32_t U[6], M[6], D[6], S[6];
+				U[0] = ru[om]; M[0] = rm[om]; D[0] = rd[om]; U[5] = ru[op]; M[5] = rm[op]; D[5] = rd[op];
 #pragma unroll
-				for (int j = 0; j < 6; j++) { U[j] = ru[j]; M[j] = rm[j]; D[j] = rd[j]; S[j] = pk_add16(pk_add16(U[j], M[j]), D[j]); }
+				for (int j = 1; j < 5; j++) { U[j] = ru[j - 1]; M[j] = rm[j - 1]; D[j] = rd[j - 1]; }
+#pragma unroll
+				for (int j = 0; j < 6; j++) S[j] = pk_add16(pk_add16(U[j], M[j]), D[j]);
 				uint32_t out[4];
 #pragma unroll
 				for (int K = 1; K < 5; K++) {
@@ -435,14 +448,14 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				uint32_t *d = reinterpret_cast<uint32_t *>(kbuf + (rr + 4) * FI_RS + 8 * g);
 				d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3];
 			}
-			if (t < FI_RD) reinterpret_cast<uint32_t *>(ybuf + 34 * FI_RS)[t] = reinterpret_cast<const uint32_t *>(ybuf + 32 * FI_RS)[t];   /* the next band's contrast wants row 32b+32 as it is now */
+			if (t < FI_YRD) reinterpret_cast<uint32_t *>(ybuf + 34 * FI_YRS)[t] = reinterpret_cast<const uint32_t *>(ybuf + 32 * FI_YRS)[t];   /* the next band's contrast wants row 32b+32 as it is now */
 			}
 			__syncthreads();
 			FI_TICK(3); FI_STAMP(2); FI_STAMP(3);
-			FI_DUMP(3, kbuf + 5 * FI_RS);
-			FI_DUMP(4, ybuf + FI_RS);
-			FI_DUMP(5, ybuf);
-			FI_DUMP(6, ybuf + 3 * FI_RS);
+			FI_DUMP(3, kbuf + 5 * FI_RS, 0);
+			FI_DUMP(4, ybuf + FI_YRS, 1);
+			FI_DUMP(5, ybuf, 1);
+			FI_DUMP(6, ybuf + 3 * FI_YRS, 1);
 			/* ------------------------------------------------------------ carry state at the start of every 32-pixel segment (image_processing.c:641-700).
 			 * The carry is a 16-state machine that runs in raster order over the interior of the whole image.  A step maps the 16 states onto at
 			 * most five neighbouring ones and a zero sum resets it: run five candidates (5-bit fields of one dword) through the 12 pixels in
@@ -536,7 +549,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			}
 			__syncthreads();
 			FI_TICK(5); FI_STAMP(5);
-			FI_DUMP(2, kbuf + 5 * FI_RS);
+			FI_DUMP(2, kbuf + 5 * FI_RS, 0);
 			/* ------------------------------------------------------------ pair rules (image_processing.c:810-837, 1927-1990): pixel pairs (1,2), (3,4) .. (509,510) of a row,
 			 * four pairs an item; a pair's deltas depend on its two kernel values and on a flag the pair before hands over -- which depends on
 			 * that pair's values only, so nothing is serial.  Class of a value, entry of a pair: table look-ups (see the fill above). */
@@ -560,15 +573,15 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				for (int j = 0; j < 5; j++) KQ[j] = clampw(KQ[j]);
 				auto lo = [](uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); };
 				auto hi = [](uint32_t w) { return (int)w >> 16; };
-				/* byte offset of a pair's entry: 240 x class of the first + 16 x class of the second */
-				int prev = tcb[202 + lo(P[1])] + 240 * tca[202 + hi(P[0])];
+				/* byte offset of a pair's entry: 180 x class of the first + 12 x class of the second */
+				int prev = tcb[202 + lo(P[1])] + 180 * tca[202 + hi(P[0])];
 				int flag = (int)*reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(ptab) + prev + 8);
 				if (g == 0 && rr == 1) flag = misc[2 + ((b + 1) & 1)];     /* the band before left it (0 at the top of the image) */
 				uint32_t dl[4];
 				int flag2 = 0;
 #pragma unroll
 				for (int e = 0; e < 4; e++) {
-					const int off = tcb[202 + lo(KQ[e + 1])] + 240 * tca[202 + hi(KQ[e])];
+					const int off = tcb[202 + lo(KQ[e + 1])] + 180 * tca[202 + hi(KQ[e])];
 					const uint8_t *en = reinterpret_cast<const uint8_t *>(ptab) + off;
 					dl[e] = *reinterpret_cast<const uint32_t *>(en + 4 * flag);
 					flag = (int)*reinterpret_cast<const uint32_t *>(en + 8);
@@ -580,17 +593,17 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 					if (r0 + rr == last_row) misc[2 + (b & 1)] = (uint8_t)flag2;
 				}
 				/* luma columns 8g+1 .. 8g+8: the high half of dword 4g, dwords 4g+1 .. 4g+3, the low half of dword 4g+4 */
-				uint32_t *yo = reinterpret_cast<uint32_t *>(ybuf + rr * FI_RS) + 4 * g;
-				int16_t *ys = reinterpret_cast<int16_t *>(yo);
+				uint32_t *yo = reinterpret_cast<uint32_t *>(ybuf) + rr * FI_YRD + 4 * g + (g >> 3);
+				int16_t *ys = reinterpret_cast<int16_t *>(yo), *ye = reinterpret_cast<int16_t *>(yo + ((g & 7) == 7 ? 5 : 4));   /* dword 4g+4: behind a pad for the last group of a block */
 				ys[1] = (int16_t)(ys[1] + (int16_t)(dl[0] & 0xFFFFu));
 #pragma unroll
 				for (int j = 1; j < 4; j++) yo[j] = pk_add16(yo[j], pack_hl(dl[j - 1], dl[j]));
-				ys[8] = (int16_t)(ys[8] + (int16_t)(dl[3] >> 16));
+				ye[0] = (int16_t)(ye[0] + (int16_t)(dl[3] >> 16));
 			}
 			}
 			__syncthreads();
 			FI_TICK(6); FI_STAMP(6);
-			FI_DUMP(1, ybuf + FI_RS);
+			FI_DUMP(1, ybuf + FI_YRS, 1);
 		}
 		if (!PRE && SRC) __syncthreads();                              /* the staging rows become rows of the horizontal pass */
 		/* ---------------------------------------------------------------- horizontal pass (filters.c:346-386) of image rows 32b+1 .. 32b+32 (and row 0), four kx an item,
@@ -602,10 +615,11 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			for (int k = t; k < (b == 0 ? 33 : 32) * 64; k += FI_NT) {
 				int rr, g;
 				if (b == 0) { rr = k % 33; g = k / 33; } else { rr = 1 + (k & 31); g = k >> 5; if (rr > top) continue; }
-				const uint32_t *yr = reinterpret_cast<const uint32_t *>(ybuf + rr * FI_RS) + 4 * g - 1;
-				uint32_t X[6];                                           /* X[j] = (x[8g - 2 + 2j], x[8g - 1 + 2j]) */
+				const uint32_t *yr = reinterpret_cast<const uint32_t *>(ybuf) + rr * FI_YRD + 4 * g + (g >> 3);
+				uint32_t X[6];                                           /* X[j] = (x[8g - 2 + 2j], x[8g - 1 + 2j]): dwords 4g-1 .. 4g+4 of the row */
+				X[0] = yr[(g & 7) == 0 ? -2 : -1]; X[5] = yr[(g & 7) == 7 ? 5 : 4];
 #pragma unroll
-				for (int j = 0; j < 6; j++) X[j] = yr[j];
+				for (int j = 1; j < 5; j++) X[j] = yr[j - 1];
 				if (g == 0) X[0] = __builtin_amdgcn_perm(X[1], X[2], 0x07060100u);   /* x[-2] = x[2], x[-1] = x[1] */
 				if (g == 63) X[5] = X[4];                               /* x[512] = x[510] */
 				uint32_t E[5], O[4];
@@ -646,9 +660,9 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
 		for (int e = 0; e < 3; e++) { const int k = t + FI_NT * e; if (k < 5 * FI_RD) hold[e] = reinterpret_cast<const uint32_t *>(kbuf + 32 * FI_RS)[k]; }
 		/* luma rows 32b+32 (before the pair rules) and 32b+33 become the next band's rows 0 and 1 */
-		for (int k = t; k < 2 * FI_RD; k += FI_NT) {
+		for (int k = t; k < 2 * FI_YRD; k += FI_NT) {
 			uint32_t *y = reinterpret_cast<uint32_t *>(ybuf);
-			y[k] = k < FI_RD ? y[(PRE ? 34 : 32) * FI_RD + k] : y[32 * FI_RD + k];   /* k >= FI_RD: row 33, dword k - FI_RD */
+			y[k] = k < FI_YRD ? y[(PRE ? 34 : 32) * FI_YRD + k] : y[32 * FI_YRD + k];   /* k >= FI_YRD: row 33, dword k - FI_YRD */
 		}
 		{
 			/* a thread takes a PAIR of columns (2cp, 2cp+1) -- the halves of one dword -- and eight of the band's output rows.  Columns below 256
