@@ -7,6 +7,9 @@
 
 using namespace nhw;
 
+#ifndef NHW_DENSE_STREAM
+#define NHW_DENSE_STREAM 0          /* 1: the luma byte stream is written (and rewritten by the dense Y31) next to the list -- a developer switch for comparing the two forms */
+#endif
 enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2 };
 
 template <int PH>
@@ -26,7 +29,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_L4A) luma_p4a_par(&c, tid, dyn_lds);
 	else if (PH == PH_L4B) luma_p4b_par(&c, tid, sh_pos, dyn_lds);
 	else if (PH == PH_L4C) luma_p4c_par(&c, tid, sh_pos, dyn_lds);
-	else if (PH == PH_L4D) luma_p4d_par(&c, tid, sh_counts, sh_z, dyn_lds);
+	else if (PH == PH_L4D) luma_p4d_par(&c, tid, sh_counts, sh_z, dyn_lds, NHW_DENSE_STREAM || ws.dbg);
 	else if (PH == PH_L4C2) luma_p4c2_par(&c, tid, reinterpret_cast<unsigned *>(sh_z), sh_pos);
 	else if (PH == PH_LLC) { PROF_BEGIN(); ll_code_chroma_par(&c, tid, reinterpret_cast<uint8_t *>(dyn_lds)); if (!tid) PROF(&c, 18); }
 	else if (PH == PH_C0) chroma_p0_par(&c, comp, tid);
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 	else if (PH == WV_QUANT) {
 		__shared__ __attribute__((aligned(16))) uint8_t park[4][16 * QROW];
 		__shared__ uint32_t lut[4][QLUT + 3];
-		PROF_BEGIN(); wave_quantise_luma(&c, lane, park[threadIdx.x >> 6], lut[threadIdx.x >> 6], ws.q > 21 || ws.dbg); if (!lane) PROF(&c, 15);
+		PROF_BEGIN(); wave_quantise_luma(&c, lane, park[threadIdx.x >> 6], lut[threadIdx.x >> 6], ws.q > 21 || ws.dbg, NHW_DENSE_STREAM || ws.dbg); if (!lane) PROF(&c, 15);
 	}
 	else if (PH == WV_EMIT) { PROF_BEGIN(); wave_emit_ll2(&c, lane); if (!lane) PROF(&c, 4); }
 }
@@ -232,7 +235,7 @@ static size_t phase_lds(int ph)
 	case PH_L4A: return CR_LDS_BYTES > (NT + 2) * TLS * sizeof(int16_t) ? CR_LDS_BYTES : (size_t)(NT + 2) * TLS * sizeof(int16_t);
 	case PH_L4B: return (size_t)(NT + 2) * TLS * sizeof(int16_t);
 	case PH_L4C: return 0;                                         /* Y26 is pointwise, Y27 a wavefront per row straight on the plane */
-	case PH_L4D: return 4608;                                      /* the list of run starts (at most one per 15 groups of the stream); the stream itself is written by the quantiser kernel */
+	case PH_L4D: return SL_LDS_BYTES;                              /* Y31 on the symbol list: the non-zero map and the slices' value offsets in stream order (the dense form of the stage checks: 4608 bytes of them for its list of run starts) */
 	case PH_C5: return CQ_LDS_BYTES > 32 * 130 * 2 + (32 * 128 + 258) * 2 ? CQ_LDS_BYTES : 32 * 130 * 2 + (32 * 128 + 258) * 2;   /* the quantiser's parked rows; the marks' and the emission's tables */
 	default: return 0;
 	}

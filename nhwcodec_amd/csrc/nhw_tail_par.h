@@ -1164,6 +1164,172 @@ DEV void scan_and_rewrite_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z /*
 }
 
 
+/* ---------------------------------------------------------------- Y31 on the symbol LIST (round 5)
+ * The same three rewrites (:2134-2252) on what the luma quantiser leaves since round 5 (wave_quantise_luma): a 64-bit non-zero map per
+ * slice of 64 stream symbols and the non-zero symbols themselves.  Every rule of Y31 asks two things of a symbol -- is it the zero symbol,
+ * is it a +-8 (136 / 120) -- and only ever rewrites symbols that are not zero into others that are not zero, so the map is its "is zero"
+ * plane (whole-word shifts answer the (+-8, 0, 0, 0, +-8) and the "four zeros before / three behind" questions for 64 positions at once), the
+ * +-8 masks of a slice are built from its handful of values, and a rewrite is a byte store into the value list.  The map and the slices'
+ * value offsets sit in LDS in stream order (the quantiser writes them flush-major); the few questions that cross a slice edge go through
+ * sl_sym().  What leaves: the map and the offsets in stream order (c->nzs, c->voff) for the packetiser, the values rewritten in place.
+ * The two symbols the reference zeroes at either end of the stream (:2169-2176) are cleared bits: the values stay where they are, dead. */
+#define SL_SLICES (4 * Q / 64)
+#define SL_LDS_BYTES (SL_SLICES * 12 + 64)   /* with the kernel's own 2 KB: three workgroups to a CU */
+#define SL_OFF(x) ((x) & 0x1FFFFFFFu)          /* a slice's offset word: bits 29..31 say how many symbols at its head a 132..135 code of the slice before covers */
+struct SymList { uint64_t *nz; uint32_t *vo; uint8_t *vals; };      /* nz, vo: LDS, stream order */
+DEV int sl_sym(const SymList &L, int pos)                            /* the symbol at stream position 0 <= pos < 4 Q */
+{
+	const uint64_t M = L.nz[pos >> 6];
+	const int bit = pos & 63;
+	if (!((M >> bit) & 1)) return 128;
+	return L.vals[SL_OFF(L.vo[pos >> 6]) + (unsigned)__builtin_popcountll(M & ((1ull << bit) - 1))];
+}
+DEV void sl_set(const SymList &L, int pos, int v)                    /* pos holds a symbol that is not zero */
+{
+	const uint64_t M = L.nz[pos >> 6];
+	L.vals[SL_OFF(L.vo[pos >> 6]) + (unsigned)__builtin_popcountll(M & ((1ull << (pos & 63)) - 1))] = (uint8_t)v;
+}
+/* slice gi's map; what lies outside the stream is "not zero" (the reference finds a 0 byte there, which is not the zero symbol 128) */
+DEV uint64_t sl_word(const SymList &L, int gi) { return (gi < 0 || gi >= SL_SLICES) ? ~0ull : L.nz[gi]; }
+DEV bool sl_zero(const SymList &L, int pos) { return pos >= 0 && pos < 4 * Q && !((L.nz[pos >> 6] >> (pos & 63)) & 1); }
+DEV bool sl_cand(const SymList &L, int c)                            /* (+-8, 0, 0, 0, +-8) starting at c */
+{
+	if (c < 0 || c > 4 * Q - 5) return false;
+	if (!(sl_zero(L, c + 1) && sl_zero(L, c + 2) && sl_zero(L, c + 3))) return false;
+	return is_pm8(sl_sym(L, c)) && is_pm8(sl_sym(L, c + 4));
+}
+/* the +-8 masks of slice g from its values (bit k: symbol k is 136 / is 120) */
+DEV void sl_pm8(const SymList &L, int g, uint64_t M, uint64_t *p6, uint64_t *p0)
+{
+	uint64_t a = 0, b = 0;
+	const uint8_t *v = L.vals + SL_OFF(L.vo[g]);
+	for (uint64_t m = M; m; m &= m - 1) {
+		const int x = *v++;
+		const uint64_t bit = m & (0 - m);
+		if (x == 136) a |= bit; else if (x == 120) b |= bit;
+	}
+	*p6 = a; *p0 = b;
+}
+DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */, int *sh_counts)
+{
+	const int n = 4 * Q;
+	SymList L;
+	L.nz = reinterpret_cast<uint64_t *>(lds); L.vo = reinterpret_cast<uint32_t *>(lds + SL_SLICES * 8); L.vals = c->vals;
+
+	uint32_t *sel = reinterpret_cast<uint32_t *>(c->half);          /* the selected pairs of rewrite 1 (at most n / 8 of them) */
+	PROF_BEGIN();
+	if (tid == 0) sh_counts[0] = 0;
+	{                                                               /* the map into stream order, every slice's first value: thread = (flush, sixteen strips) */
+		const int f = tid >> 3, s0 = (tid & 7) * 16;
+		uint64_t m[16];
+		unsigned tot = 0;
+		for (int k = 0; k < 16; k++) { m[k] = c->nzq[f * 128 + s0 + k]; tot += (unsigned)__builtin_popcountll(m[k]); }
+		unsigned incl = tot;
+		for (int o = 1; o < 8; o <<= 1) { const unsigned t_ = (unsigned)__shfl_up((int)incl, o, 8); if ((tid & 7) >= o) incl += t_; }
+		unsigned at = c->fbase[f] + incl - tot;
+		for (int k = 0; k < 16; k++) { L.nz[(s0 + k) * 32 + f] = m[k]; L.vo[(s0 + k) * 32 + f] = at; at += (unsigned)__builtin_popcountll(m[k]); }
+	}
+	BARRIER();
+	if (!tid) PROF(c, 40);
+	for (int g = tid; g < SL_SLICES; g += NT) {                     /* rewrite 1, selection (:2134-2167): of a chain of candidates four apart every other one, from the chain's head */
+		const uint64_t M = L.nz[g];
+		if (!M) continue;
+		uint64_t p6, p0;
+		sl_pm8(L, g, M, &p6, &p0);
+		const uint64_t P = p6 | p0;
+		if (!P) continue;
+		const uint64_t Z = ~M, Zn = ~sl_word(L, g + 1);
+		uint64_t own = P & ((Z >> 1) | (Zn << 63)) & ((Z >> 2) | (Zn << 62)) & ((Z >> 3) | (Zn << 61));
+		uint64_t cand = own & (P >> 4);
+		for (uint64_t h = own >> 60 << 60; h; h &= h - 1) {           /* the second +-8 lies in the next slice */
+			const int j = __builtin_ctzll(h), c4 = 64 * g + j + 4;
+			if (c4 < n && is_pm8(sl_sym(L, c4))) cand |= 1ull << j;
+		}
+		for (uint64_t h = cand; h; h &= h - 1) {
+			const int j = __builtin_ctzll(h), cpos = 64 * g + j;
+			int m = 1, back = cpos - 4;
+			while (back >= 64 * g ? (int)((cand >> (back & 63)) & 1) : (int)sl_cand(L, back)) { m++; back -= 4; }
+			if (m & 1) sel[atomicAdd(&sh_counts[0], 1)] = (uint32_t)cpos;
+		}
+	}
+	BARRIER();
+	if (!tid) PROF(c, 41);
+	for (int e = tid; e < sh_counts[0]; e += NT) {                  /* rewrite 1, application */
+		const int cpos = (int)sel[e];
+		const int x = sl_sym(L, cpos), y = sl_sym(L, cpos + 4);
+		sl_set(L, cpos, x == 136 ? (y == 136 ? 132 : 133) : (y == 136 ? 134 : 135));
+		sl_set(L, cpos + 4, 201);
+		if ((cpos & 63) >= 60) L.vo[(cpos >> 6) + 1] |= (uint32_t)((cpos & 63) - 59) << 29;   /* the packetiser's walk of the next slice starts behind the code's five symbols (selected pairs lie eight apart: nobody else writes this word now) */
+	}
+	BARRIER();
+	if (tid == 0) {                                                 /* the first and the last four symbols become zero symbols (:2169-2176): bits off; the first slice's values start behind the dead ones */
+		const uint64_t m0 = L.nz[0];
+		L.vo[0] += (unsigned)__builtin_popcountll(m0 & 0xFull);
+		L.nz[0] = m0 & ~0xFull;
+		L.nz[SL_SLICES - 1] &= ~(0xFull << 60);
+	}
+	BARRIER();
+	if (!tid) PROF(c, 42);
+	for (int g = tid; g < SL_SLICES; g += NT) {                     /* rewrite 2 (:2178-2220): every decision reads what no decision writes (scan_and_rewrite_par has the argument) */
+		const uint64_t M = L.nz[g];
+		if (!M) continue;
+		uint64_t p6, p0;
+		sl_pm8(L, g, M, &p6, &p0);
+		const uint64_t P = p6 | p0;
+		uint64_t act = P;
+		if (g == 0) act &= ~0xFull;                                /* 4 <= i < n - 4 */
+		if (g == SL_SLICES - 1) act &= ~(0xFull << 60);
+		if (!act) continue;
+		const int base = 64 * g;
+		const uint64_t Z = ~M, Zp = ~sl_word(L, g - 1), Zn = ~sl_word(L, g + 1);
+#define ZL(k) ((Z << (k)) | (Zp >> (64 - (k))))                     /* bit j: position base + j - k is the zero symbol */
+#define ZR(k) ((Z >> (k)) | (Zn << (64 - (k))))
+		int v_next = 0;                                             /* the symbol behind the slice, where a pair rule asks for it */
+		uint64_t Pl = P << 1, Pr = P >> 1;                          /* the left / right neighbour is a +-8 */
+		if ((act & 1) && g > 0 && !((Zp >> 63) & 1)) Pl |= is_pm8(sl_sym(L, base - 1)) ? 1ull : 0ull;
+		if ((act >> 63) && g < SL_SLICES - 1 && !(Zn & 1)) { v_next = sl_sym(L, base + 64); if (is_pm8(v_next)) Pr |= 1ull << 63; }
+		if (g == 0) Pl &= ~0x1Full;                                /* the left neighbour is asked only for i > 4 */
+		const uint64_t before4 = ZL(1) & ZL(2) & ZL(3) & ZL(4), after3 = ZR(2) & ZR(3) & ZR(4);
+		const uint64_t taken = Pl & ZR(1) & ((ZL(2) & ZL(3) & ZL(4) & ZL(5)) | (ZL(2) & after3));   /* the left neighbour took me as the second of a pair */
+		act &= ~taken;
+		const uint64_t pairA = act & Pr & ZR(2) & (before4 | (ZL(1) & ZR(3) & ZR(4) & ZR(5)));
+		const uint64_t lone = act & ~pairA & ZR(1) & (before4 | (ZL(1) & after3));
+#undef ZL
+#undef ZR
+		for (uint64_t h = pairA; h; h &= h - 1) {
+			const int j = __builtin_ctzll(h);
+			const bool neg = j < 63 ? (bool)((p0 >> (j + 1)) & 1) : v_next == 120;
+			sl_set(L, base + j + 1, neg ? 157 : 159);
+		}
+		for (uint64_t h = lone; h; h &= h - 1) {
+			const int j = __builtin_ctzll(h);
+			sl_set(L, base + j, ((p6 >> j) & 1) ? 153 : 155);
+		}
+	}
+	BARRIER();
+	if (!tid) PROF(c, 43);
+	for (int g = tid; g < SL_SLICES; g += NT) {                     /* rewrite 3 (:2222-2252): the sign codes behind a zero run of 252 or more; a run belongs to the slice its successor is in */
+		const uint64_t M = L.nz[g];
+		if (!M) continue;
+		const int p = 64 * g + __builtin_ctzll(M);
+		int gp = g - 1, zeros = __builtin_ctzll(M);
+		while (gp >= 0 && L.nz[gp] == 0) { zeros += 64; gp--; }
+		if (gp >= 0) zeros += __builtin_clzll(L.nz[gp]);
+		if (zeros < 252) continue;
+		const int i = p - zeros, b = p - 1;                         /* the run [i, b] */
+		auto fix = [&](int at) { const int v = sl_sym(L, at); if (v == 153) sl_set(L, at, 124); else if (v == 155) sl_set(L, at, 123); };
+		const int fired = b - i >= 256 ? (b - i - 256) / 254 + 1 : 0;
+		const int kk = i + 255 + 254 * (fired - 1);
+		if (fired) for (int at = b + 1; at <= kk + 3; at++) if (at < n) fix(at);
+		const int tail_run = fired ? b - kk + 1 : b - i;
+		if (tail_run >= 252 && b + 1 < n) fix(b + 1);
+	}
+	BARRIER();
+	for (int g = tid; g < SL_SLICES; g += NT) { c->nzs[g] = L.nz[g]; c->voff[g] = L.vo[g]; }
+	if (!tid) PROF(c, 44);
+}
+
+
 /* offsetUV_recons256 (image_processing.c:3192-3353): p is only read, every row writes its own jp cells */
 DEV void dequant_sim_chroma_par(Ctx *c, int comp, int tid)
 {
@@ -2211,10 +2377,14 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 	BARRIER();
 	if (!tid) PROF(c, 16);
 }
-DEV void luma_p4d_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z, int16_t *lds)
+DEV void luma_p4d_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z, int16_t *lds, bool dense)
 {
 	PROF_BEGIN();
-	scan_and_rewrite_par(c, tid, sh_counts, sh_z, lds);                     /* Y31 (Y30: the quantiser wrote the stream) */
+	scan_rewrite_list_par(c, tid, reinterpret_cast<uint8_t *>(lds), sh_counts);   /* Y31 on the list (Y30: the quantiser wrote the symbols in stream order) */
+	if (dense) {                                                            /* ... and on the byte stream, where a stage check reads it */
+		BARRIER();
+		scan_and_rewrite_par(c, tid, sh_counts, sh_z, lds);
+	}
 	if (!tid) PROF(c, 17);
 }
 
@@ -2558,6 +2728,103 @@ DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint
  * different banks.  Returns the thread's view: dl[x] is stream symbol x for x in [lo - 4, lo + 64). */
 #define PK_LDS_BYTES ((17 * NT + 1) * 4)
 struct PackPre { uint4 v[PK_CHUNK / 16 / NT]; uint32_t before; int prev_nz, next_nz; };   /* a chunk on its way from memory: the thread's 16-byte pieces, (thread 0) the four symbols in front of it, and what the walk of the thread's slice asks the tables (two loads that sat on every slice's chain of dependent steps) */
+/* The luma part comes as a list (round 5): a slice's non-zero map and where its values start (c->nzs, c->voff: stream order, left by Y31;
+ * the top three bits of the offset word say how many symbols at the head of the slice belong to a 132..135 code of the slice before).
+ * The walk of a slice needs nothing else: zero runs are the gaps between set bits (prev_nz / next_nz where a run crosses the slice's edge),
+ * the symbols are the slice's values in order.  They travel with the prefetch, sixteen bytes at a time for as many as the slice holds, and
+ * wait in the thread's own LDS slot (nobody else reads it: no barrier), from where the walk takes them byte by byte.  No chunk of the
+ * stream is staged, rebuilt or looked at: a slice without a value costs its zero-run arithmetic and nothing else. */
+struct PackPreL { uint64_t M; uint32_t off; uint4 v[4]; int prev_nz, next_nz; };
+DEV void pack_fetch_list(const Ctx *c, int ch, int tid, PackPreL *pre, const int *prevnz, const int *nextnz)
+{
+	const int g = ch * NT + tid;
+	pre->prev_nz = prevnz[g]; pre->next_nz = nextnz[g + 1];
+	pre->M = c->nzs[g]; pre->off = c->voff[g];
+	const int cnt = __builtin_popcountll(pre->M);
+	const uint8_t *v = c->vals + (pre->off & 0x1FFFFFFFu);         /* (a piece may run past the slice's values: behind `vals` lie the guard's zeros) */
+#pragma unroll
+	for (int k = 0; k < 4; k++) if (cnt > 16 * k) __builtin_memcpy(&pre->v[k], v + 16 * k, 16);
+}
+/* ... into the thread's LDS slot (17-word pitch: the slots of a wavefront start in different banks); returns the slot */
+DEV const uint8_t *pack_stage_list(const PackPreL *pre, int tid, uint32_t *lw)
+{
+	uint32_t *w = lw + 17 * tid;
+	const int cnt = __builtin_popcountll(pre->M);
+#pragma unroll
+	for (int k = 0; k < 4; k++) if (cnt > 16 * k) { w[4 * k] = pre->v[k].x; w[4 * k + 1] = pre->v[k].y; w[4 * k + 2] = pre->v[k].z; w[4 * k + 3] = pre->v[k].w; }
+	return reinterpret_cast<const uint8_t *>(w);
+}
+/* pack_walk for a slice of the list: nz = its map, skip = symbols at its head that a 132..135 code of the slice before covers, vb = its values */
+template <int MODE>
+DEV void pack_walk_list(uint64_t nz, int skip, const uint8_t *vb, int N, int lo, int hi, PackShared *sh, uint32_t *words, unsigned bit0, uint8_t *s1, unsigned i1, uint8_t *s2, unsigned i2,
+                        unsigned *out_bits, unsigned *out_n1, unsigned *out_n2, int prev_nz, int next_nz, SliceBits *rec = nullptr)
+{
+	unsigned bits = 0, n1 = 0, n2 = 0;
+	uint32_t cur = 0; int w = (int)(bit0 >> 5), fill = (int)(bit0 & 31);
+	uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0; uint64_t s1m = 0, s2m = 0;   /* MODE 1 */
+	const int select = sh->select;
+#define EMIT(entry) do { const uint32_t e_ = (entry), code_ = e_ & 0xFFFFFF; const int len_ = (int)(e_ >> 24); \
+		if (MODE == 1) { \
+			r0 = (r0 << len_) | (r1 >> (32 - len_)); r1 = (r1 << len_) | (r2 >> (32 - len_)); r2 = (r2 << len_) | (r3 >> (32 - len_)); r3 = (r3 << len_) | code_; \
+			bits += (unsigned)len_; \
+		} \
+		else { fill += len_; if (fill <= 32) cur |= code_ << (32 - fill); \
+			else { const int sp_ = fill - 32; atomicOr(&words[w], cur | (code_ >> sp_)); w++; cur = (code_ & ((1u << sp_) - 1)) << (32 - sp_); fill = sp_; } } } while (0)
+	const int send = lo + PK_SLICE < N ? lo + PK_SLICE : N;
+	int i = lo, vi = 0;
+	if (MODE != 0 && skip) { i = lo + skip; vi = __builtin_popcountll(nz & ((1ull << skip) - 1)); }   /* inside the 4 symbols that follow a 132..135 code */
+	uint64_t rest = nz >> (i - lo);
+	while (i < hi) {
+		if (rest & 1) {
+			const int px = vb[vi++];
+			if (MODE == 0) { atomicAdd(&sh->hist[px], 1); i++; rest >>= 1; continue; }
+			if (px == 153 || px == 155) { if (MODE == 2 && i1 + n1 < S_CAP) s1[i1 + n1] = (uint8_t)(px == 155); if (MODE == 1 && px == 155) s1m |= 1ull << n1; n1++; i++; rest >>= 1; continue; }
+			if (px == 157 || px == 159) { if (MODE == 2 && i2 + n2 < S_CAP) s2[i2 + n2] = (uint8_t)(px == 159); if (MODE == 1 && px == 159) s2m |= 1ull << n2; n2++; i++; rest >>= 1; continue; }
+			EMIT(sh->code_sym[px]);
+			if (px > 131 && px < 136) { vi += __builtin_popcount((unsigned)rest & 0x1Eu); i += 5; rest >>= 5; } else { i++; rest >>= 1; }
+			continue;
+		}
+		int a = i, b;                                /* maximal zero run [a, b] around i: inside the slice from the map, outside from the tables */
+		if (i == lo && i > 0 && prev_nz != lo - 1) a = prev_nz + 1;
+		if (rest) b = i + __builtin_ctzll(rest) - 1;
+		else b = send < N ? next_nz - 1 : send - 1;
+		const int L = b - a + 1;
+		if (L == 1) {
+			if (MODE == 0) atomicAdd(&sh->hist[128], 1); else EMIT(sh->code_sym[128]);
+		} else if (a == i && L < 255) {              /* the usual run: one piece, begun here */
+			if (MODE == 0) atomicAdd(&sh->runs[L], 1);
+			else if (L < select) { for (int z = 0; z < L; z++) EMIT(sh->code_sym[128]); }
+			else EMIT(sh->code_run[L]);
+		} else {
+			const int m = L > 255 ? (L - 255 + 253) / 254 : 0;       /* pieces of exactly 254, then the rest; mine are those that start in [i, hi) */
+			int k1 = (hi - 1 - a) / 254;
+			if (k1 > m) k1 = m;
+			for (int k = (i - a + 253) / 254; k <= k1; k++) {
+				const int len = k < m ? 254 : L - 254 * m;
+				if (MODE == 0) atomicAdd(&sh->runs[len], 1);
+				else if (len < select) { for (int z = 0; z < len; z++) EMIT(sh->code_sym[128]); }
+				else EMIT(sh->code_run[len]);
+			}
+		}
+		rest = (b + 1 - i) < 64 ? rest >> (b + 1 - i) : 0;
+		i = b + 1;
+	}
+	if (MODE == 2 && fill > 0) atomicOr(&words[w], cur);
+	if (MODE == 1) {
+		*out_bits = bits; *out_n1 = n1; *out_n2 = n2;
+		if (bits <= 128u) {
+			const unsigned sh_ = 128u - bits, ws_ = sh_ >> 5, bs_ = sh_ & 31;
+			const uint32_t w_[7] = { r0, r1, r2, r3, 0u, 0u, 0u };
+			uint32_t x_[5];
+#pragma unroll
+			for (int k_ = 0; k_ < 5; k_++) x_[k_] = ws_ == 0 ? w_[k_] : ws_ == 1 ? w_[k_ + 1] : ws_ == 2 ? w_[k_ + 2] : ws_ == 3 ? w_[(k_ + 3) < 7 ? k_ + 3 : 6] : 0u;
+#pragma unroll
+			for (int k_ = 0; k_ < 4; k_++) rec->b[k_] = bs_ ? (x_[k_] << bs_) | (x_[k_ + 1] >> (32 - bs_)) : x_[k_];
+		}
+		rec->s1m = s1m; rec->s2m = s2m;
+	}
+#undef EMIT
+}
 DEV void pack_fetch(const uint8_t *d, int N, int ch, int tid, PackPre *pre, const int *prevnz, const int *nextnz)
 {
 	pre->prev_nz = prevnz[ch * NT + tid]; pre->next_nz = nextnz[ch * NT + tid + 1];
@@ -2591,7 +2858,7 @@ DEV const uint8_t *pack_stage(const PackPre *pre, int ch, int tid, uint32_t *lw)
 /* Slices are 64 consecutive symbols and a workgroup sweeps the stream in chunks of 256 slices (16 KiB), so the
  * lanes of a wavefront read adjacent cache lines (a thread-per-kilobyte split makes every lane stream its own
  * line and thrashes L1: measured 5 us per symbol). */
-DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uint32_t *lw /* PK_LDS_BYTES */)
+DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uint32_t *lw /* PK_LDS_BYTES */, bool list /* part 0 from the symbol list of Y31 */)
 {
 	const uint8_t *d = c->scan + (part ? 4 * Q : 0);
 	const int N = part ? 2 * Q : 4 * Q;
@@ -2606,7 +2873,8 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	for (int ch = 0; ch < nchunks; ch++) {                       /* per slice: last / first symbol that is not 128 */
 		const int g = ch * NT + tid, lo = g * PK_SLICE;
 		uint64_t nz = 0;                                         /* bit k: symbol lo + k is not 128 */
-		if (lo < N) {
+		if (list) nz = c->nzs[g];
+		else if (lo < N) {
 			uint32_t w[16];
 			for (int k = 0; k < 4; k++) { const uint4 v = reinterpret_cast<const uint4 *>(d + lo)[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
 			nz = (uint64_t)ne_mask32(w, 0x80808080u) | (uint64_t)ne_mask32(w + 8, 0x80808080u) << 32;
@@ -2636,13 +2904,19 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	}
 	BARRIER();
 	PackPre pre;
-	pack_fetch(d, N, 0, tid, &pre, prevnz, nextnz);
+	PackPreL prel;
+	if (list) pack_fetch_list(c, 0, tid, &prel, prevnz, nextnz); else pack_fetch(d, N, 0, tid, &pre, prevnz, nextnz);
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
-		const int my_prev = pre.prev_nz, my_next = pre.next_nz;
-		const uint8_t *dl = pack_stage(&pre, ch, tid, lw);
-		if (ch + 1 < nchunks) pack_fetch(d, N, ch + 1, tid, &pre, prevnz, nextnz);
-		if (lo < S) pack_walk<0>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, my_prev, my_next);
+		const int my_prev = list ? prel.prev_nz : pre.prev_nz, my_next = list ? prel.next_nz : pre.next_nz;
+		const uint64_t my_nz = prel.M;
+		const int my_skip = (int)(prel.off >> 29);
+		const uint8_t *dl = list ? pack_stage_list(&prel, tid, lw) : pack_stage(&pre, ch, tid, lw);
+		if (ch + 1 < nchunks) { if (list) pack_fetch_list(c, ch + 1, tid, &prel, prevnz, nextnz); else pack_fetch(d, N, ch + 1, tid, &pre, prevnz, nextnz); }
+		if (lo < S) {
+			if (list) pack_walk_list<0>(my_nz, my_skip, dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, my_prev, my_next);
+			else pack_walk<0>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, my_prev, my_next);
+		}
 	}
 	BARRIER();
 	if (!tid) PROF(c, 23);
@@ -2705,15 +2979,20 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	uint32_t *words = c->packet + word0;
 	unsigned base_bits = 0, base_n1 = 0, base_n2 = 0;
 	int zeroed = 0;                                              /* words [0, zeroed) are cleared or already carry bits */
-	pack_fetch(d, N, 0, tid, &pre, prevnz, nextnz);
+	if (list) pack_fetch_list(c, 0, tid, &prel, prevnz, nextnz); else pack_fetch(d, N, 0, tid, &pre, prevnz, nextnz);
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
 		unsigned bb = 0, x1 = 0, x2 = 0, tb, tn;
-		const int my_prev = pre.prev_nz, my_next = pre.next_nz;
-		const uint8_t *dl = pack_stage(&pre, ch, tid, lw);
-		if (ch + 1 < nchunks) pack_fetch(d, N, ch + 1, tid, &pre, prevnz, nextnz);
+		const int my_prev = list ? prel.prev_nz : pre.prev_nz, my_next = list ? prel.next_nz : pre.next_nz;
+		const uint64_t my_nz = prel.M;
+		const int my_skip = (int)(prel.off >> 29);
+		const uint8_t *dl = list ? pack_stage_list(&prel, tid, lw) : pack_stage(&pre, ch, tid, lw);
+		if (ch + 1 < nchunks) { if (list) pack_fetch_list(c, ch + 1, tid, &prel, prevnz, nextnz); else pack_fetch(d, N, ch + 1, tid, &pre, prevnz, nextnz); }
 		SliceBits rec;
-		if (lo < S) pack_walk<1>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, my_prev, my_next, &rec);
+		if (lo < S) {
+			if (list) pack_walk_list<1>(my_nz, my_skip, dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, my_prev, my_next, &rec);
+			else pack_walk<1>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, my_prev, my_next, &rec);
+		}
 		const unsigned ob = block_exscan(bb, tid, sh->bits, &tb);
 		const unsigned on = block_exscan(x1 | (x2 << 16), tid, sh->bits, &tn);
 		const int last = tb ? (int)((base_bits + tb - 1) >> 5) : zeroed - 1;
@@ -2734,6 +3013,7 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 				for (unsigned z = 0; z < x1; z++) if (a1 + z < S_CAP) c->s1[a1 + z] = (uint8_t)((rec.s1m >> z) & 1);
 				for (unsigned z = 0; z < x2; z++) if (a2 + z < S_CAP) c->s2[a2 + z] = (uint8_t)((rec.s2m >> z) & 1);
 			}
+			else if (list) pack_walk_list<2>(my_nz, my_skip, dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, my_prev, my_next);
 			else pack_walk<2>(dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, my_prev, my_next);
 		}
 		base_bits += tb; base_n1 += tn & 0xFFFF; base_n2 += tn >> 16;
@@ -2871,11 +3151,11 @@ DEV void final_phase_par(Ctx *c, uint8_t *out, size_t cap, uint32_t *size, int32
 	BARRIER();
 	if (tid == 0) c->scan[4 * Q] = 3;                            /* sentinel behind the luma part (compress_pixel.c:66) */
 	BARRIER();
-	pack_part_par(c, 0, sh, tid, 0, lw);
+	pack_part_par(c, 0, sh, tid, 0, lw, true);
 	if (sh->rc) { if (tid == 0) { *size = 0; *status = sh->rc; } return; }
 	if (tid == 0) { c->scan[4 * Q] = saved; c->scan[6 * Q - 1] = c->scan[6 * Q - 2]; }   /* :464-465 */
 	BARRIER();
-	pack_part_par(c, 1, sh, tid, c->m->size_data1, lw);
+	pack_part_par(c, 1, sh, tid, c->m->size_data1, lw, false);
 	if (sh->rc) { if (tid == 0) { *size = 0; *status = sh->rc; } return; }
 	if (!tid) PROF(c, 19);
 	const size_t n = container_par(c, out, cap, tid);

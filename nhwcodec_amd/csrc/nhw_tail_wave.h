@@ -657,8 +657,18 @@ DEV unsigned quant_entry(int x)
 	if (m >= 7) e |= QE_LOUD;
 	return e;
 }
-DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes of this wavefront */, uint32_t *lut /* QLUT words of this wavefront */, bool write_plane)
+/* The stream leaves as a LIST (round 5): a q20 image holds some 6 000 symbols that are not the zero symbol 128 among its 262 144, and the
+ * dense 256 KB went out here, came back three times in Y31 and three times in the packetiser.  Per flush of 16 rows and strip -- a slice of
+ * 64 consecutive stream symbols -- the lane that owns the strip leaves one 64-bit word (bit k: symbol k of the slice is not 128; nzq[flush][strip],
+ * 1 KB a flush in two coalesced stores) and appends the symbols themselves to `vals`: flush after flush, inside a flush strip after
+ * strip (a wave prefix sum of the popcounts), inside a slice in stream order.  fbase[f] is where flush f starts in `vals`.  Zero-run lengths
+ * are gaps between set bits; Y31 (scan_rewrite_list_par) turns the map into stream order for the packetiser.  `dense`: the byte stream as
+ * well (stage checks). */
+DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes of this wavefront */, uint32_t *lut /* QLUT words of this wavefront */, bool write_plane, bool dense)
 {
+	uint64_t *const nzq = c->nzq;
+	uint8_t *const vals = c->vals;
+	unsigned vtotal = 0;                                            /* values written so far (wave-uniform) */
 	for (int i = lane; i < QLUT; i += 64) lut[i] = quant_entry(i - 128);
 	__threadfence_block();
 	int16_t *p = c->proc;
@@ -886,7 +896,8 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 		if (r >= 1) {
 			if (((r - 1) & 15) == 15) {                                /* 16 rows complete: strips lane and lane + 64 */
 				__threadfence_block();
-				const int rb = r - 16;
+				const int rb = r - 16, f = rb >> 4;
+				if (lane == 0) c->fbase[f] = vtotal;
 				for (int h = 0; h < 2; h++) {
 					const int strip = lane + 64 * h;
 					uint32_t w[16];
@@ -894,14 +905,28 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 						const uint32_t x = *reinterpret_cast<const uint32_t *>(park + i * QROW + 4 * strip);
 						w[i] = ((rb + i) & 1) ? __builtin_bswap32(x) : x;
 					}
-					uint4 *dst = reinterpret_cast<uint4 *>(stream + strip * (4 * W) + 4 * rb);
-					for (int i = 0; i < 4; i++) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+					if (dense) {
+						uint4 *dst = reinterpret_cast<uint4 *>(stream + strip * (4 * W) + 4 * rb);
+						for (int i = 0; i < 4; i++) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+					}
+					const uint64_t M = (uint64_t)ne_mask32(w, 0x80808080u) | (uint64_t)ne_mask32(w + 8, 0x80808080u) << 32;
+					nzq[f * 128 + strip] = M;
+					const unsigned cnt = (unsigned)__builtin_popcountll(M);
+					unsigned incl = cnt;
+					for (int o = 1; o < 64; o <<= 1) { const unsigned t_ = (unsigned)__shfl_up((int)incl, o); if (lane >= o) incl += t_; }
+					unsigned at = vtotal + incl - cnt;
+					vtotal += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+					for (uint64_t m = M; m; m &= m - 1) {                  /* the slice's symbols in stream order, back out of the parked rows (symbol 4 i + k is byte k of row i, odd rows mirrored) */
+						const int bit = __builtin_ctzll(m), i = bit >> 2, k = bit & 3;
+						vals[at++] = park[i * QROW + 4 * strip + (((rb + i) & 1) ? 3 - k : k)];
+					}
 				}
 				__threadfence_block();
 			}
 		}
 		for (int k = 0; k < 8; k++) { prev[k] = cur[k]; cur[k] = nxt[k]; nxt[k] = q0[k]; q0[k] = far[k]; }
 	}
+	if (lane == 0) c->fbase[32] = vtotal;
 }
 
 /* offsetY_recons256 (image_processing.c:2600-3190), one wavefront per image */
