@@ -1198,18 +1198,25 @@ DEV bool sl_cand(const SymList &L, int c)                            /* (+-8, 0,
 	if (!(sl_zero(L, c + 1) && sl_zero(L, c + 2) && sl_zero(L, c + 3))) return false;
 	return is_pm8(sl_sym(L, c)) && is_pm8(sl_sym(L, c + 4));
 }
-/* the +-8 masks of slice g from its values (bit k: symbol k is 136 / is 120) */
-DEV void sl_pm8(const SymList &L, int g, uint64_t M, uint64_t *p6, uint64_t *p0)
+/* the +-8 masks of slice g from its values (bit k: symbol k is 136 / is 120); `first`: the slice's first sixteen values, asked for a few
+ * slices ahead (a dependent byte load per value was most of this pass's time: a slice holds one or two) */
+DEV void sl_pm8(const SymList &L, int g, uint64_t M, uint4 first, uint64_t *p6, uint64_t *p0)
 {
 	uint64_t a = 0, b = 0;
-	const uint8_t *v = L.vals + SL_OFF(L.vo[g]);
-	for (uint64_t m = M; m; m &= m - 1) {
-		const int x = *v++;
+	uint64_t lo = (uint64_t)first.x | (uint64_t)first.y << 32, hi = (uint64_t)first.z | (uint64_t)first.w << 32;
+	const uint8_t *v = L.vals + SL_OFF(L.vo[g]) + 16;
+	int r = 0;
+	for (uint64_t m = M; m; m &= m - 1, r++) {
+		int x;
+		if (r < 16) { x = (int)(lo & 0xFF); lo = (lo >> 8) | (hi << 56); hi >>= 8; } else x = *v++;
 		const uint64_t bit = m & (0 - m);
 		if (x == 136) a |= bit; else if (x == 120) b |= bit;
 	}
 	*p6 = a; *p0 = b;
 }
+#define SL_AHEAD 4                                                 /* slices a thread has in flight */
+#define SL_FETCH(Mk, vk, g0) do { for (int k_ = 0; k_ < SL_AHEAD; k_++) { const int g_ = (g0) + NT * k_; Mk[k_] = L.nz[g_]; \
+		if (Mk[k_]) __builtin_memcpy(&vk[k_], L.vals + SL_OFF(L.vo[g_]), 16); } } while (0)
 DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */, int *sh_counts)
 {
 	const int n = 4 * Q;
@@ -1231,11 +1238,16 @@ DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */,
 	}
 	BARRIER();
 	if (!tid) PROF(c, 40);
-	for (int g = tid; g < SL_SLICES; g += NT) {                     /* rewrite 1, selection (:2134-2167): of a chain of candidates four apart every other one, from the chain's head */
-		const uint64_t M = L.nz[g];
+	for (int g0 = tid; g0 < SL_SLICES; g0 += NT * SL_AHEAD) {        /* rewrite 1, selection (:2134-2167): of a chain of candidates four apart every other one, from the chain's head */
+		uint64_t Mk[SL_AHEAD]; uint4 vk[SL_AHEAD];
+		SL_FETCH(Mk, vk, g0);
+#pragma unroll
+		for (int k = 0; k < SL_AHEAD; k++) {
+		const int g = g0 + NT * k;
+		const uint64_t M = Mk[k];
 		if (!M) continue;
 		uint64_t p6, p0;
-		sl_pm8(L, g, M, &p6, &p0);
+		sl_pm8(L, g, M, vk[k], &p6, &p0);
 		const uint64_t P = p6 | p0;
 		if (!P) continue;
 		const uint64_t Z = ~M, Zn = ~sl_word(L, g + 1);
@@ -1250,6 +1262,7 @@ DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */,
 			int m = 1, back = cpos - 4;
 			while (back >= 64 * g ? (int)((cand >> (back & 63)) & 1) : (int)sl_cand(L, back)) { m++; back -= 4; }
 			if (m & 1) sel[atomicAdd(&sh_counts[0], 1)] = (uint32_t)cpos;
+		}
 		}
 	}
 	BARRIER();
@@ -1270,11 +1283,16 @@ DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */,
 	}
 	BARRIER();
 	if (!tid) PROF(c, 42);
-	for (int g = tid; g < SL_SLICES; g += NT) {                     /* rewrite 2 (:2178-2220): every decision reads what no decision writes (scan_and_rewrite_par has the argument) */
-		const uint64_t M = L.nz[g];
+	for (int g0 = tid; g0 < SL_SLICES; g0 += NT * SL_AHEAD) {        /* rewrite 2 (:2178-2220): every decision reads what no decision writes (scan_and_rewrite_par has the argument) */
+		uint64_t Mk[SL_AHEAD]; uint4 vk[SL_AHEAD];
+		SL_FETCH(Mk, vk, g0);
+#pragma unroll
+		for (int k = 0; k < SL_AHEAD; k++) {
+		const int g = g0 + NT * k;
+		const uint64_t M = Mk[k];
 		if (!M) continue;
 		uint64_t p6, p0;
-		sl_pm8(L, g, M, &p6, &p0);
+		sl_pm8(L, g, M, vk[k], &p6, &p0);
 		const uint64_t P = p6 | p0;
 		uint64_t act = P;
 		if (g == 0) act &= ~0xFull;                                /* 4 <= i < n - 4 */
@@ -1304,6 +1322,7 @@ DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */,
 		for (uint64_t h = lone; h; h &= h - 1) {
 			const int j = __builtin_ctzll(h);
 			sl_set(L, base + j, ((p6 >> j) & 1) ? 153 : 155);
+		}
 		}
 	}
 	BARRIER();
