@@ -39,13 +39,13 @@ namespace {
 /* ---------------------------------------------------------------------------------------------- workspace
  * structure of arrays over the batch: buffer b of image i at base + off[b] + i * size[b] */
 enum {
-	D_META, D_LL, D_SPARE, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_CU, D_SEG, D_COUNT
+	D_META, D_LL, D_SPARE, D_P1, D_P3, D_P5, D_P6, D_MARKS, D_A, D_B, D_CA, D_CB, D_CU, D_SEG, D_NZG, D_COUNT
 };
 enum { P16_CAP = 65536 + 64, P6_CAP = 131072 + 64, PK_WORDS = 98304 /* sanity bound on the packet words of a file (the encoder's buffer holds 80000) */ };
 const size_t k_dec_bytes[D_COUNT] = {
 	/* META */ 512, /* LL */ 24832, /* SPARE */ 1024, /* P1 */ P16_CAP * 2, /* P3 */ P16_CAP * 2, /* P5 */ P16_CAP * 2, /* P6 */ (size_t)P6_CAP * 4,
 	/* MARKS */ 2 * DQ, /* A */ 8 * DQ + 8192, /* B: luma value list */ 16 * DQ + 8192, /* CA */ 2 * (2 * DQ + 4096), /* CB: chroma value list */ 8 * DQ + 8192, /* CU */ 2 * DQ,
-	/* SEG */ 5120
+	/* SEG */ 5120, /* NZG: which 16-byte groups of plane A's rows are in memory (k_dec_expand), a 64-bit word a row */ 4096
 };
 
 struct DecMeta {
@@ -68,6 +68,7 @@ struct DecWs {
 	const uint8_t *blob;       /* device arena holding the .nhw files */
 	const uint64_t *blob_off;  /* n offsets into it */
 	const uint32_t *blob_len;  /* n lengths */
+	int dense;                 /* a stage check is going to read plane A: every group of it is written (production leaves out the all-zero groups of the level-1 detail bands) */
 	template <typename T> __host__ __device__ T *buf(int b, int img) const { return (T *)(base + off[b] + (size_t)img * k_dec_bytes_dev(b)); }
 	__host__ __device__ static size_t k_dec_bytes_dev(int b)
 	{
@@ -75,7 +76,7 @@ struct DecWs {
 		case D_META: return 512; case D_LL: return 24832; case D_SPARE: return 1024;
 		case D_P1: case D_P3: case D_P5: return P16_CAP * 2; case D_P6: return (size_t)P6_CAP * 4;
 		case D_MARKS: return 2 * DQ; case D_A: return 8 * DQ + 8192; case D_B: return 16 * DQ + 8192;
-		case D_CA: return 2 * (2 * DQ + 4096); case D_CB: return 8 * DQ + 8192; case D_SEG: return 5120; default: return 2 * DQ;
+		case D_CA: return 2 * (2 * DQ + 4096); case D_CB: return 8 * DQ + 8192; case D_SEG: return 5120; case D_NZG: return 4096; default: return 2 * DQ;
 		}
 	}
 };
@@ -1030,6 +1031,29 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 	int16_t *a = plane_a(ws, img);
 	int16_t *st = stage[threadIdx.x >> 6];
 	const uint8_t *f = ws.blob + ws.blob_off[img];
+	/* The level-1 detail bands -- three quarters of the plane -- are mostly zeros, and the only reader of those cells is k_dec_final: a
+	 * 16-byte group of a row that holds nothing is NOT stored (2.1 GB of zeros per 4096 files went out here and came back there); nzg[row]
+	 * says which of the row's 64 groups are in memory (the level-1 LL quadrant, rows and columns below 256, always is: the level-2 kernel
+	 * and the passes at the end of this one work in it).  What a later symbol patches into a row that has left goes through put_late. */
+	uint64_t *nzg = ws.buf<uint64_t>(D_NZG, img);
+	uint64_t last_mask = 0;                                       /* the groups of the row stored last */
+	auto store_row = [&](int row, const int16_t *src, bool upper) {
+		const uint4 v = *(const uint4 *)(src + 8 * lane);
+		const bool keep = (upper && lane < 32) || (v.x | v.y | v.z | v.w) != 0 || ws.dense;
+		if (keep) *(uint4 *)(a + (size_t)row * DW + 8 * lane) = v;
+		last_mask = __ballot(keep);
+		if (!lane) nzg[row] = last_mask;
+	};
+	/* cells of the row stored last (flag: this lane has one, at column col) behind its stores: groups that were left out come into being as zeros first */
+	auto put_late = [&](int row, bool flag, int col, int val) {
+		uint64_t need = __ballot(flag), groups = 0;
+		while (need) { const int l = __builtin_ctzll(need); need &= need - 1; groups |= 1ull << (__builtin_amdgcn_readlane(col, l) >> 3); }
+		const uint64_t missing = groups & ~last_mask;
+		wave_sync();
+		if ((missing >> lane) & 1ull) *(uint4 *)(a + (size_t)row * DW + 8 * lane) = make_uint4(0, 0, 0, 0);
+		if (missing) { last_mask |= missing; if (!lane) nzg[row] = last_mask; wave_sync(); }
+		if (flag) a[(size_t)row * DW + col] = (int16_t)val;
+	};
 
 	/* Where the rows come from: the prefix-code walk left the file's values as a list in stream order -- 128 strips of 4 columns, a strip row
 	 * after row -- so the values of any range of rows are, for every strip, the next few entries of the strip's part of the list.  A lane
@@ -1126,11 +1150,14 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 				}
 				__builtin_amdgcn_wave_barrier();
 				const int up = buf[-1];
-				if (up != X_NONE) { wave_sync(); if (!lane) a[(size_t)i0 * DW - 1] = (int16_t)up; }   /* behind the rows the last chunk stored */
+				if (up != X_NONE) {                                     /* the last cell of the row above, behind the rows the last chunk stored (in front of row 0: the pad) */
+					if (i0) put_late(i0 - 1, lane == 0, DW - 1, up);
+					else { wave_sync(); if (!lane) a[-1] = (int16_t)up; }
+				}
 			}
 			pend = buf[(XC + 1) * DW];
 #pragma unroll
-			for (int s = 0; s < XC; s++) *(uint4 *)(a + (size_t)(i0 + s) * DW + 8 * lane) = *(const uint4 *)(buf + s * DW + 8 * lane);
+			for (int s = 0; s < XC; s++) store_row(i0 + s, buf + s * DW, true);
 			{
 				const uint4 h = *(const uint4 *)(buf + XC * DW + 8 * lane);
 				const uint8_t hs = sm[XC * 64 + lane];
@@ -1154,8 +1181,7 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 		int16_t *buf = st + 8;
 		{                                                           /* row 256 is in slot 0: a 1008/1009 in its column 0 writes the last cell of row 255, which has left */
 			const int s256 = buf[0];
-			wave_sync();
-			if ((s256 == 1008 || s256 == 1009) && !lane) a[(size_t)DH * DW - 1] = (int16_t)(s256 == 1008 ? 5 : -5);
+			if (s256 == 1008 || s256 == 1009) put_late(DH - 1, lane == 0, DW - 1, s256 == 1008 ? 5 : -5);
 			wave_sync();
 		}
 		int carry = m->carry;
@@ -1258,15 +1284,13 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 				}
 				if (any) {                                           /* what the symbols write outside the HH half of this row */
 					const bool up67 = (live67.w[0] | live67.w[1] | live67.w[2] | live67.w[3]) != 0;
-					if (up67 && s == 0) wave_sync();                   /* the row above went to memory with the chunk before: patch it there, behind those stores */
 #pragma unroll
 					for (int k = 0; k < 4; k++) {
 						const int c = DH + lane + 64 * k;
-						if (m4_bit(live67, k, lane)) {
-							const int16_t val = (int16_t)(cur[k] == 1006 ? -7 : 7);
-							row[c - DH] = val;
-							if (s) row[c - 3 * DH] = val; else a[(size_t)i * DW + c - 3 * DH] = val;
-						}
+						const bool l67 = m4_bit(live67, k, lane);
+						const int16_t val = (int16_t)(cur[k] == 1006 ? -7 : 7);
+						if (l67) { row[c - DH] = val; if (s) row[c - 3 * DH] = val; }
+						if (up67 && s == 0 && live67.w[k]) put_late(i - 1, l67, c - DH, val);   /* the row above went to memory with the chunk before: patched there, behind those stores */
 						if (m4_bit(liveK, k, lane)) {
 							const int16_t val = (int16_t)(cur[k] == 1008 ? 5 : -5);
 							if (c == DH) row[DH - 1] = val;
@@ -1277,7 +1301,7 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 			}
 			__builtin_amdgcn_wave_barrier();
 #pragma unroll
-			for (int s = 0; s < XD; s++) *(uint4 *)(a + (size_t)(i0 + s) * DW + 8 * lane) = *(const uint4 *)(buf + s * DW + 8 * lane);
+			for (int s = 0; s < XD; s++) store_row(i0 + s, buf + s * DW, false);
 			{
 				const uint4 h = *(const uint4 *)(buf + XD * DW + 8 * lane);
 				__builtin_amdgcn_wave_barrier();
@@ -1994,23 +2018,31 @@ __global__ __launch_bounds__(256) void k_dec_final(DecWs ws, uint8_t *out, int d
 	 * r0/2 - 2 .. r0/2 + 9 -- one 16-byte load at r0/2 (16-byte aligned) and a dword on either side; the low half of line k < 256 is column
 	 * k of rows r0/2 - 1 .. of the level-1 LL, consecutive lanes on consecutive columns.  The few coefficients outside a line's half that
 	 * this touches at the first and the last band are never used (row -1 lies in the pad in front of the plane). */
+	const uint64_t *nzg = ws.buf<uint64_t>(D_NZG, img);
+	/* a line's three groups around column c0 (a multiple of 8): the dword in front, the 16 bytes at c0, the dword behind -- each only if
+	 * k_dec_expand stored its group (gm: the line's groups in memory); a group it left out is zeros, and most of the detail bands' are */
+	auto piece = [&](const int16_t *line, uint64_t gm, int c0, uint32_t w[6]) {
+		const int g = c0 >> 3;
+		const int16_t *src = line + c0;
+		const bool b0 = g > 0 && ((gm >> (g - 1)) & 1), b1 = (gm >> g) & 1, b2 = g < 63 && ((gm >> (g + 1)) & 1);   /* (what lies outside the line is never used) */
+		const uint32_t w0 = b0 ? *reinterpret_cast<const uint32_t *>(src - 2) : 0u, w5 = b2 ? *reinterpret_cast<const uint32_t *>(src + 8) : 0u;
+		const uint4 wm = b1 ? *reinterpret_cast<const uint4 *>(src) : make_uint4(0, 0, 0, 0);
+		w[0] = w0; w[1] = wm.x; w[2] = wm.y; w[3] = wm.z; w[4] = wm.w; w[5] = w5;
+	};
 #pragma unroll
 	for (int half = 0; half < 2; half++) {
 		const int k = tid + DH * half;
+		const uint64_t gm = nzg[k];
 		int hi[12], lo[12];                                                     /* hi[e], lo[e]: coefficient m0 - 1 + e */
 		{
-			const int16_t *src = A + (size_t)k * DW + DH + r0 / 2;
-			const uint32_t w0 = *reinterpret_cast<const uint32_t *>(src - 2), w5 = *reinterpret_cast<const uint32_t *>(src + 8);
-			const uint4 wm = *reinterpret_cast<const uint4 *>(src);
-			const uint32_t w[6] = { w0, wm.x, wm.y, wm.z, wm.w, w5 };
+			uint32_t w[6];
+			piece(A + (size_t)k * DW, gm, DH + r0 / 2, w);
 #pragma unroll
 			for (int e = 0; e < 6; e++) { hi[2 * e] = (int16_t)(w[e] & 0xFFFF); hi[2 * e + 1] = (int16_t)(w[e] >> 16); }
 		}
 		if (half) {
-			const int16_t *src = A + (size_t)k * DW + r0 / 2;
-			const uint32_t w0 = *reinterpret_cast<const uint32_t *>(src - 2), w5 = *reinterpret_cast<const uint32_t *>(src + 8);
-			const uint4 wm = *reinterpret_cast<const uint4 *>(src);
-			const uint32_t w[6] = { w0, wm.x, wm.y, wm.z, wm.w, w5 };
+			uint32_t w[6];
+			piece(A + (size_t)k * DW, gm, r0 / 2, w);
 #pragma unroll
 			for (int e = 0; e < 6; e++) { lo[2 * e] = (int16_t)(w[e] & 0xFFFF); lo[2 * e + 1] = (int16_t)(w[e] >> 16); }
 		} else {
@@ -2278,7 +2310,7 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	HIPCHK(hipSetDevice(d->device));                              /* the handle's device, whatever the calling thread had current */
 	hipStream_t s = stream ? (hipStream_t)stream : d->own_stream;
 	DecWs ws = d->ws;
-	ws.n = n; ws.blob = (const uint8_t *)d_nhw; ws.blob_off = d_off; ws.blob_len = d_len;
+	ws.n = n; ws.blob = (const uint8_t *)d_nhw; ws.blob_off = d_off; ws.blob_len = d_len; ws.dense = d->stop_after != 0;
 	int stage = 0;
 	d->timed = false;
 	const bool fork = (d->chroma_fork & 2) && !d->stop_after;          /* the chroma sequence beside the luma one */
