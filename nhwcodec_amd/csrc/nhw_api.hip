@@ -77,7 +77,8 @@ static const size_t k_buf_bytes[B_COUNT] = {
 	/* R6     */ 2 * Q + 1024, 16384 + 64, 16384 + 64, /* CHARRES */ 2048 + 64, /* QSET3 */ 8 * Q + 64,
 	/* RESU64 */ 512, /* RESV64 */ 512, /* PACKET */ 320000, /* BOOK1 */ 768, /* BOOK2 */ 768, /* SEL1 */ 16384 + 64, /* SEL2 */ 16384 + 64,
 	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512, /* ROWFLAG (unused) */ 16, /* SEGMAP (unused) */ 16, /* STALE */ (8 + 9 * 512) * 2,
-	/* NZQ (32 x 128 words of 64 bits + 33 flush bases) */ Q / 2 + 256, /* NZS */ Q / 2, /* VOFF */ Q / 4, /* VALS (every symbol non-zero: 4 Q) */ 4 * Q
+	/* NZQ (32 x 128 words of 64 bits + 33 flush bases) */ Q / 2 + 256, /* NZS */ Q / 2, /* VOFF */ Q / 4, /* VALS (every symbol non-zero: 4 Q) */ 4 * Q,
+	/* CNZQ (16 flushes x 64 lanes x 2 words of 64 bits + 17 flush bases) */ Q / 4 + 256, /* CVALS */ 2 * Q
 };
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -19,7 +19,6 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	__shared__ int sh_pos[2 * NT + 2];
 	__shared__ uint32_t sh_z[4 * Q / 16 / 32 + 4];
 	extern __shared__ __attribute__((aligned(16))) int16_t dyn_lds[];   /* LDS tiles of the row-serial passes (size chosen per phase at launch) */
-	__shared__ PackShared sh_pack;
 	const int img = blockIdx.x, tid = threadIdx.x;
 	Ctx c;
 	ctx_load(&c, ws, img);
@@ -37,9 +36,19 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_C3) chroma_p3_par(&c, comp, tid);
 	else if (PH == PH_C4) dequant_sim_chroma_par(&c, 0, tid);
 	else if (PH == PH_C5) chroma_p5_par(&c, comp, tid, dyn_lds, sh_counts, ws.dbg != 0);
-	else if (PH == PH_FINAL) {
-		final_phase_par(&c, out + (size_t)img * (512u << 10), 512u << 10, &sizes[img], &status[img], &sh_pack, tid, reinterpret_cast<uint32_t *>(dyn_lds));
-	}
+}
+
+/* Z2 + the container as a kernel of its own: exactly four wavefronts a SIMD.  Its two parts are two inlined copies of the same walks since the
+ * chroma part became a list too, and left alone the register allocator took 158 registers for them (three wavefronts a SIMD: +0.35 ms); held
+ * to 128 it spills 21 dwords in the code-book construction, off the walks. */
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_final(NhwWs ws, uint8_t *out, uint32_t *sizes, int32_t *status)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t dyn_lds[];
+	__shared__ PackShared sh_pack;
+	const int img = blockIdx.x, tid = threadIdx.x;
+	Ctx c;
+	ctx_load(&c, ws, img);
+	final_phase_par(&c, out + (size_t)img * (512u << 10), 512u << 10, &sizes[img], &status[img], &sh_pack, tid, reinterpret_cast<uint32_t *>(dyn_lds));
 }
 
 /* passes that run one wavefront per image (nhw_tail_wave.h): four images per workgroup, no workgroup barriers */
@@ -272,7 +281,7 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 	case PH_C3: k_phase<PH_C3><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C4: k_phase<PH_C4><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C5: k_phase<PH_C5><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
-	case PH_FINAL: k_phase<PH_FINAL><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_FINAL: k_final<<<g, b, lds, s>>>(ws, out, sizes, status); break;
 	}
 }
 

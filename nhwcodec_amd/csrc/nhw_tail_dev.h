@@ -47,6 +47,7 @@ struct Ctx {
 	uint64_t *nzq, *nzs;           /* luma symbol list: non-zero map [flush][strip] (quantiser), [strip][flush] = stream order (Y31) */
 	uint32_t *fbase, *voff;        /* first value of every flush (33 entries: the last is the total); first value of every 64-symbol slice, stream order */
 	uint8_t *vals;                 /* the non-zero symbols, flush after flush, strip after strip, stream order inside a slice */
+	uint64_t *cnzq; uint32_t *cfbase; uint8_t *cvals;   /* the same of the chroma part of the stream (U and V byte-interleaved): [flush = 4 wavefront + turn][lane][2 slices]; a wavefront's values from 32768 x wavefront on */
 	void *prof;
 	NhwMeta *m;
 	PosList res1, res3, res5, res6;
@@ -82,6 +83,7 @@ DEV void ctx_load(Ctx *c, const NhwWs &ws, int img)
 	c->hist = ws.buf<int>(B_HIST, img);
 	c->nzq = ws.buf<uint64_t>(B_NZQ, img); c->fbase = reinterpret_cast<uint32_t *>(c->nzq + 4096); c->nzs = ws.buf<uint64_t>(B_NZS, img);
 	c->voff = ws.buf<uint32_t>(B_VOFF, img); c->vals = ws.buf<uint8_t>(B_VALS, img);
+	c->cnzq = ws.buf<uint64_t>(B_CNZQ, img); c->cfbase = reinterpret_cast<uint32_t *>(c->cnzq + 2048); c->cvals = ws.buf<uint8_t>(B_CVALS, img);
 	c->prof = ws.buf<uint8_t>(B_PROF, img);
 	c->res1.list = ws.buf<uint8_t>(B_R1LIST, img); c->res1.bits = ws.buf<uint8_t>(B_R1BITS, img); c->res1.word = ws.buf<uint8_t>(B_R1WORD, img); c->res1.len = &m->r1;
 	c->res3.list = ws.buf<uint8_t>(B_R3LIST, img); c->res3.bits = ws.buf<uint8_t>(B_R3BITS, img); c->res3.word = ws.buf<uint8_t>(B_R3WORD, img); c->res3.len = &m->r3;

@@ -896,8 +896,9 @@ DEV void clean_details_par(Ctx *c, int tid, int16_t *lds)
  * for 128 KB of coefficients and 64 KB of symbols.) */
 #define CQROW 264
 #define CQ_LDS_BYTES (4 * 16 * CQROW + 2 * (H + 2))
-DEV void quantise_chroma_par(Ctx *c, int comp, int tid, int16_t *lds, bool write_plane)
+DEV void quantise_chroma_par(Ctx *c, int comp, int tid, int16_t *lds, bool write_plane, bool dense /* the merged byte stream as well (stage checks) */)
 {
+	unsigned vtotal = 0;                                            /* V: values this wavefront has appended to the list (wave-uniform) */
 	int16_t *p = c->cproc;
 	uint8_t *ubytes = reinterpret_cast<uint8_t *>(c->band);       /* Q bytes, free during the chroma phases */
 	uint8_t *scan = c->scan + 4 * Q;
@@ -959,7 +960,37 @@ DEV void quantise_chroma_par(Ctx *c, int comp, int tid, int16_t *lds, bool write
 						o[8 * j + 2 * e + 1] = ((u >> 16) & 0xFF) | (((v >> 16) & 0xFF) << 8) | ((u >> 24) << 16) | ((v >> 24) << 24);
 					}
 				}
-				for (int j = 0; j < 8; j++) reinterpret_cast<uint4 *>(scan + 2 * pos)[j] = make_uint4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+				if (dense) for (int j = 0; j < 8; j++) reinterpret_cast<uint4 *>(scan + 2 * pos)[j] = make_uint4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+				/* the merged stream leaves as a list, like the luma part (wave_quantise_luma): the lane's 128 symbols are two slices of 64 -- a
+				 * non-zero map each, [flush][lane][2] -- and their symbols that are not 128 go behind those of the lanes before it (the wavefronts
+				 * of the workgroup run side by side: each appends to a region of its own, 32768 x wavefront, the size of all its symbols).  The
+				 * packetiser's chroma part puts the maps into stream order (pack_chroma_order). */
+				const int F = 4 * wv + (i >> 4);
+				const uint64_t M0 = (uint64_t)ne_mask32(o, 0x80808080u) | (uint64_t)ne_mask32(o + 8, 0x80808080u) << 32;
+				const uint64_t M1 = (uint64_t)ne_mask32(o + 16, 0x80808080u) | (uint64_t)ne_mask32(o + 24, 0x80808080u) << 32;
+				*reinterpret_cast<uint4 *>(c->cnzq + (F * 64 + lane) * 2) = make_uint4((uint32_t)M0, (uint32_t)(M0 >> 32), (uint32_t)M1, (uint32_t)(M1 >> 32));
+				const unsigned cnt = (unsigned)(__builtin_popcountll(M0) + __builtin_popcountll(M1));
+				unsigned incl = cnt;
+				for (int o_ = 1; o_ < 64; o_ <<= 1) { const unsigned t_ = (unsigned)__shfl_up((int)incl, o_); if (lane >= o_) incl += t_; }
+				if (lane == 0) c->cfbase[F] = 32768u * wv + vtotal;
+				uint8_t *vp = c->cvals + 32768u * wv + vtotal + incl - cnt;
+				vtotal += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+				/* the symbols by position: a slice's sixteen dwords wait in the wavefront's parked rows -- every lane has read its own above, the
+				 * next sixteen rows have not begun -- word k of lane l at dword 64 k + l (no bank conflicts), and leave byte by byte for the set bits */
+				uint32_t *sw = reinterpret_cast<uint32_t *>(park);
+				static_assert(16 * CQROW >= 16 * 64 * 4, "a slice of every lane fits the parked rows");
+#pragma unroll
+				for (int hs = 0; hs < 2; hs++) {
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+					for (int k = 0; k < 16; k++) sw[64 * k + lane] = o[16 * hs + k];
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+					const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw) + 4 * lane;
+					for (uint64_t m = hs ? M1 : M0; m; m &= m - 1) {
+						const int bit = __builtin_ctzll(m);
+						*vp++ = sb[256 * (bit >> 2) + (bit & 3)];
+					}
+				}
 			}
 			__threadfence_block();
 		}
@@ -2626,7 +2657,7 @@ DEV void chroma_p5_par(Ctx *c, int comp, int tid, int16_t *lds, int *sh_misc, bo
 	}
 	if (!tid) PROF(c, 21);
 	BARRIER();
-	quantise_chroma_par(c, comp, tid, lds, write_plane);
+	quantise_chroma_par(c, comp, tid, lds, write_plane, write_plane);
 	if (!tid) PROF(c, 22);
 }
 
@@ -2664,89 +2695,8 @@ DEV bool book_ok(int v) { return v < 109 ? !(v & 1) : (v == 112 || (v >= 120 && 
 /* what a slice's walk leaves for the placement behind the prefix sums: its code bits, MSB first, if they fit 128 (they nearly always do: a
  * slice holds a handful of tokens), and its sign symbols as bit masks -- so that a slice is walked once per sweep, not twice */
 struct SliceBits { uint32_t b[4]; uint64_t s1m, s2m; };
-template <int MODE>
-DEV void pack_walk(const uint8_t *d, int N, int lo, int hi, PackShared *sh, uint32_t *words, unsigned bit0, uint8_t *s1, unsigned i1, uint8_t *s2, unsigned i2,
-                   unsigned *out_bits, unsigned *out_n1, unsigned *out_n2, int prev_nz /* last symbol before the slice that is not 128 */, int next_nz /* first one behind it */, SliceBits *rec = nullptr)
-{
-	unsigned bits = 0, n1 = 0, n2 = 0;
-	uint32_t cur = 0; int w = (int)(bit0 >> 5), fill = (int)(bit0 & 31);
-	uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0; uint64_t s1m = 0, s2m = 0;   /* MODE 1 */
-	const int select = sh->select;
-	/* code tables built after the ranking: (length << 24) | code word of a symbol / of a zero run of a given length */
-#define EMIT(entry) do { const uint32_t e_ = (entry), code_ = e_ & 0xFFFFFF; const int len_ = (int)(e_ >> 24); \
-		if (MODE == 1) {   /* the slice's bits in a 128-bit register, the newest at the bottom (left-justified once, at the end: a code is 1 .. 24 bits) */ \
-			r0 = (r0 << len_) | (r1 >> (32 - len_)); r1 = (r1 << len_) | (r2 >> (32 - len_)); r2 = (r2 << len_) | (r3 >> (32 - len_)); r3 = (r3 << len_) | code_; \
-			bits += (unsigned)len_; \
-		} \
-		else { fill += len_; if (fill <= 32) cur |= code_ << (32 - fill); \
-			else { const int sp_ = fill - 32; atomicOr(&words[w], cur | (code_ >> sp_)); w++; cur = (code_ & ((1u << sp_) - 1)) << (32 - sp_); fill = sp_; } } } while (0)
-	const int send = lo + PK_SLICE < N ? lo + PK_SLICE : N;
-	uint64_t nz;                                     /* bit k: symbol lo + k is not 128 (symbols behind the stream read as 128) */
-	{
-		const uint32_t *sw = reinterpret_cast<const uint32_t *>(d + lo);
-		nz = (uint64_t)ne_mask32(sw, 0x80808080u) | (uint64_t)ne_mask32(sw + 8, 0x80808080u) << 32;
-	}
-	int i = lo;
-	if (MODE != 0)                                   /* am I inside the 4 symbols that follow a 132..135 code? */
-		for (int k = 1; k <= 4; k++) if (lo - k >= 0 && d[lo - k] >= 132 && d[lo - k] <= 135) { i = lo - k + 5; break; }
-	uint64_t rest = (i - lo) < 64 ? nz >> (i - lo) : 0;             /* the mask from the walk's position on (bit 0: symbol i) */
-	while (i < hi) {
-		if (rest & 1) {
-			const int px = d[i];
-			if (MODE == 0) { atomicAdd(&sh->hist[px], 1); i++; rest >>= 1; continue; }
-			if (px == 153 || px == 155) { if (MODE == 2 && i1 + n1 < S_CAP) s1[i1 + n1] = (uint8_t)(px == 155); if (MODE == 1 && px == 155) s1m |= 1ull << n1; n1++; i++; rest >>= 1; continue; }
-			if (px == 157 || px == 159) { if (MODE == 2 && i2 + n2 < S_CAP) s2[i2 + n2] = (uint8_t)(px == 159); if (MODE == 1 && px == 159) s2m |= 1ull << n2; n2++; i++; rest >>= 1; continue; }
-			EMIT(sh->code_sym[px]);
-			if (px > 131 && px < 136) { i += 5; rest >>= 5; } else { i++; rest >>= 1; }
-			continue;
-		}
-		int a = i, b;                                /* maximal zero run [a, b] around i: inside the slice from the mask, outside from the tables */
-		if (i == lo && i > 0 && d[i - 1] == 128) a = prev_nz + 1;
-		if (rest) b = i + __builtin_ctzll(rest) - 1;
-		else b = send < N ? next_nz - 1 : send - 1;
-		const int L = b - a + 1;
-		if (L == 1) {
-			if (MODE == 0) atomicAdd(&sh->hist[128], 1); else EMIT(sh->code_sym[128]);
-		} else if (a == i && L < 255) {              /* the usual run: one piece, begun here */
-			if (MODE == 0) atomicAdd(&sh->runs[L], 1);
-			else if (L < select) { for (int z = 0; z < L; z++) EMIT(sh->code_sym[128]); }
-			else EMIT(sh->code_run[L]);
-		} else {
-			const int m = L > 255 ? (L - 255 + 253) / 254 : 0;       /* pieces of exactly 254, then the rest; mine are those that start in [i, hi) */
-			int k1 = (hi - 1 - a) / 254;
-			if (k1 > m) k1 = m;
-			for (int k = (i - a + 253) / 254; k <= k1; k++) {
-				const int len = k < m ? 254 : L - 254 * m;
-				if (MODE == 0) atomicAdd(&sh->runs[len], 1);
-				else if (len < select) { for (int z = 0; z < len; z++) EMIT(sh->code_sym[128]); }
-				else EMIT(sh->code_run[len]);
-			}
-		}
-		rest = (b + 1 - i) < 64 ? rest >> (b + 1 - i) : 0;
-		i = b + 1;
-	}
-	if (MODE == 2 && fill > 0) atomicOr(&words[w], cur);
-	if (MODE == 1) {
-		*out_bits = bits; *out_n1 = n1; *out_n2 = n2;
-		if (bits <= 128u) {                                        /* (more than 128: the slice is walked again to place its bits, MODE 2) */
-			const unsigned sh_ = 128u - bits, ws_ = sh_ >> 5, bs_ = sh_ & 31;
-			const uint32_t w_[7] = { r0, r1, r2, r3, 0u, 0u, 0u };
-			uint32_t x_[5];
-#pragma unroll
-			for (int k_ = 0; k_ < 5; k_++) x_[k_] = ws_ == 0 ? w_[k_] : ws_ == 1 ? w_[k_ + 1] : ws_ == 2 ? w_[k_ + 2] : ws_ == 3 ? w_[(k_ + 3) < 7 ? k_ + 3 : 6] : 0u;
-#pragma unroll
-			for (int k_ = 0; k_ < 4; k_++) rec->b[k_] = bs_ ? (x_[k_] << bs_) | (x_[k_ + 1] >> (32 - bs_)) : x_[k_];
-		}
-		rec->s1m = s1m; rec->s2m = s2m;
-	}
-#undef EMIT
-}
 
-/* One 16 KiB chunk of the symbol stream in LDS, one 64-symbol slice per thread: 17 words per slice, the first holds
- * the 4 symbols before the slice (the walk looks back that far), so that the slices of a wavefront start in 64
- * different banks.  Returns the thread's view: dl[x] is stream symbol x for x in [lo - 4, lo + 64). */
-#define PK_LDS_BYTES ((17 * NT + 1) * 4)
-struct PackPre { uint4 v[PK_CHUNK / 16 / NT]; uint32_t before; int prev_nz, next_nz; };   /* a chunk on its way from memory: the thread's 16-byte pieces, (thread 0) the four symbols in front of it, and what the walk of the thread's slice asks the tables (two loads that sat on every slice's chain of dependent steps) */
+#define PK_LDS_BYTES ((17 * NT + 1) * 4)                         /* a slot of 17 words per thread (its slice's values: up to 64 bytes; the 17-word pitch keeps the slots of a wavefront in different banks); the ranks and the code books between the sweeps */
 /* The luma part comes as a list (round 5): a slice's non-zero map and where its values start (c->nzs, c->voff: stream order, left by Y31;
  * the top three bits of the offset word say how many symbols at the head of the slice belong to a 132..135 code of the slice before).
  * The walk of a slice needs nothing else: zero runs are the gaps between set bits (prev_nz / next_nz where a run crosses the slice's edge),
@@ -2754,13 +2704,13 @@ struct PackPre { uint4 v[PK_CHUNK / 16 / NT]; uint32_t before; int prev_nz, next
  * wait in the thread's own LDS slot (nobody else reads it: no barrier), from where the walk takes them byte by byte.  No chunk of the
  * stream is staged, rebuilt or looked at: a slice without a value costs its zero-run arithmetic and nothing else. */
 struct PackPreL { uint64_t M; uint32_t off; uint4 v[4]; int prev_nz, next_nz; };
-DEV void pack_fetch_list(const Ctx *c, int ch, int tid, PackPreL *pre, const int *prevnz, const int *nextnz)
+DEV void pack_fetch_list(const Ctx *c, const uint8_t *vals, int ch, int tid, PackPreL *pre, const int *prevnz, const int *nextnz)
 {
 	const int g = ch * NT + tid;
 	pre->prev_nz = prevnz[g]; pre->next_nz = nextnz[g + 1];
 	pre->M = c->nzs[g]; pre->off = c->voff[g];
 	const int cnt = __builtin_popcountll(pre->M);
-	const uint8_t *v = c->vals + (pre->off & 0x1FFFFFFFu);         /* (a piece may run past the slice's values: behind `vals` lie the guard's zeros) */
+	const uint8_t *v = vals + (pre->off & 0x1FFFFFFFu);         /* (a piece may run past the slice's values: behind `vals` lie the guard's zeros) */
 #pragma unroll
 	for (int k = 0; k < 4; k++) if (cnt > 16 * k) __builtin_memcpy(&pre->v[k], v + 16 * k, 16);
 }
@@ -2844,43 +2794,42 @@ DEV void pack_walk_list(uint64_t nz, int skip, const uint8_t *vb, int N, int lo,
 	}
 #undef EMIT
 }
-DEV void pack_fetch(const uint8_t *d, int N, int ch, int tid, PackPre *pre, const int *prevnz, const int *nextnz)
-{
-	pre->prev_nz = prevnz[ch * NT + tid]; pre->next_nz = nextnz[ch * NT + tid + 1];
-	const int clo = ch * PK_CHUNK;
-#pragma unroll
-	for (int u = 0; u < PK_CHUNK / 16 / NT; u++) {
-		const int at = clo + 16 * (tid + u * NT);
-		pre->v[u] = at < N ? *reinterpret_cast<const uint4 *>(d + at) : make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
-	}
-	pre->before = (tid == 0 && clo) ? *reinterpret_cast<const uint32_t *>(d + clo - 4) : 0x80808080u;
-}
-/* ... and into LDS once the chunk before is done with (the loads were issued a chunk's work ago) */
-DEV const uint8_t *pack_stage(const PackPre *pre, int ch, int tid, uint32_t *lw)
-{
-	const int clo = ch * PK_CHUNK;
-	BARRIER();
-#pragma unroll
-	for (int u = 0; u < PK_CHUNK / 16 / NT; u++) {
-		const int g = tid + u * NT;
-		const uint4 v = pre->v[u];
-		const int t = g >> 2, j = (g & 3) * 4;
-		uint32_t *w = lw + 17 * t + 1 + j;
-		w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-		if (j == 12) lw[17 * (t + 1)] = v.w;
-	}
-	if (tid == 0) lw[0] = pre->before;
-	BARRIER();
-	return reinterpret_cast<const uint8_t *>(lw + 17 * tid + 1) - (clo + tid * PK_SLICE);
-}
-
 /* Slices are 64 consecutive symbols and a workgroup sweeps the stream in chunks of 256 slices (16 KiB), so the
  * lanes of a wavefront read adjacent cache lines (a thread-per-kilobyte split makes every lane stream its own
  * line and thrashes L1: measured 5 us per symbol). */
-DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uint32_t *lw /* PK_LDS_BYTES */, bool list /* part 0 from the symbol list of Y31 */)
+/* The chroma part's list as the chroma quantiser leaves it (quantise_chroma_par: [flush][lane][2 slices], a wavefront's values in a region of
+ * its own) -> the form the walks read: map and value offset per slice in STREAM order, in the luma part's arrays (c->nzs, c->voff: the luma
+ * part is through with them).  A thread takes eight consecutive slices of a flush (sixteen threads a flush): popcounts, a 16-lane prefix
+ * sum on top of the flush's base.  Slice (flush F = 4 wavefront + turn, lane, half) holds rows 64 wv + 16 turn + 8 (lane & 1) + 4 half .. + 3 of
+ * strip lane >> 1, U and V interleaved: stream slice 64 strip + rows / 4.  The last symbol of the stream is a copy of the one before it
+ * (compress_pixel.c:464-465): only whether it is the zero symbol can matter (it is never walked, a run can end in it). */
+DEV void pack_chroma_order(Ctx *c, int tid)
 {
-	const uint8_t *d = c->scan + (part ? 4 * Q : 0);
+	const int F = tid >> 4, e0 = 8 * (tid & 15);                    /* entries e0 .. e0 + 7 of the flush's 128 */
+	uint64_t m[8];
+	unsigned tot = 0;
+	for (int k = 0; k < 8; k++) { m[k] = c->cnzq[F * 128 + e0 + k]; tot += (unsigned)__builtin_popcountll(m[k]); }
+	unsigned incl = tot;
+	for (int o = 1; o < 16; o <<= 1) { const unsigned t_ = (unsigned)__shfl_up((int)incl, o, 16); if ((tid & 15) >= o) incl += t_; }
+	unsigned at = c->cfbase[F] + incl - tot;
+	const int wv = F >> 2, turn = F & 3;
+	for (int k = 0; k < 8; k++) {
+		const int e = e0 + k, lane = e >> 1, half = e & 1;
+		const int S = 64 * (lane >> 1) + 16 * wv + 4 * turn + 2 * (lane & 1) + half;
+		uint64_t M = m[k];
+		if (S == 2 * Q / 64 - 1) M = (M & ~(1ull << 63)) | ((M >> 62) & 1ull) << 63;
+		c->nzs[S] = M; c->voff[S] = at;
+		at += (unsigned)__builtin_popcountll(m[k]);
+	}
+}
+
+/* A part of the stream comes as a symbol list: the luma part from Y31 (c->nzs, c->voff, c->vals), the chroma part from the chroma quantiser
+ * (c->cnzq / c->cvals, put into stream order here) -- the dense byte stream is only ever written for the stage checks. */
+DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uint32_t *lw /* PK_LDS_BYTES */)
+{
+	const uint8_t *vals = part ? c->cvals : c->vals;
 	const int N = part ? 2 * Q : 4 * Q;
+	if (part) { pack_chroma_order(c, tid); __threadfence_block(); BARRIER(); }
 	const int S = N - 1, nchunks = (S + PK_CHUNK - 1) / PK_CHUNK;
 	const int nsl = nchunks * NT;
 
@@ -2891,13 +2840,7 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	if (tid == 0) { sh->select = part ? 3 : 4; sh->zone = 0; sh->rc = NHW_OK; }
 	for (int ch = 0; ch < nchunks; ch++) {                       /* per slice: last / first symbol that is not 128 */
 		const int g = ch * NT + tid, lo = g * PK_SLICE;
-		uint64_t nz = 0;                                         /* bit k: symbol lo + k is not 128 */
-		if (list) nz = c->nzs[g];
-		else if (lo < N) {
-			uint32_t w[16];
-			for (int k = 0; k < 4; k++) { const uint4 v = reinterpret_cast<const uint4 *>(d + lo)[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
-			nz = (uint64_t)ne_mask32(w, 0x80808080u) | (uint64_t)ne_mask32(w + 8, 0x80808080u) << 32;
-		}
+		const uint64_t nz = c->nzs[g];                           /* bit k: symbol lo + k is not 128 */
 		prevnz[g] = nz ? lo + 63 - __builtin_clzll(nz) : -1;
 		nextnz[g] = nz ? lo + __builtin_ctzll(nz) : N;
 	}
@@ -2922,20 +2865,16 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 		if (tid == 0) nextnz[nsl] = N;
 	}
 	BARRIER();
-	PackPre pre;
 	PackPreL prel;
-	if (list) pack_fetch_list(c, 0, tid, &prel, prevnz, nextnz); else pack_fetch(d, N, 0, tid, &pre, prevnz, nextnz);
+	pack_fetch_list(c, vals, 0, tid, &prel, prevnz, nextnz);
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
-		const int my_prev = list ? prel.prev_nz : pre.prev_nz, my_next = list ? prel.next_nz : pre.next_nz;
+		const int my_prev = prel.prev_nz, my_next = prel.next_nz;
 		const uint64_t my_nz = prel.M;
 		const int my_skip = (int)(prel.off >> 29);
-		const uint8_t *dl = list ? pack_stage_list(&prel, tid, lw) : pack_stage(&pre, ch, tid, lw);
-		if (ch + 1 < nchunks) { if (list) pack_fetch_list(c, ch + 1, tid, &prel, prevnz, nextnz); else pack_fetch(d, N, ch + 1, tid, &pre, prevnz, nextnz); }
-		if (lo < S) {
-			if (list) pack_walk_list<0>(my_nz, my_skip, dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, my_prev, my_next);
-			else pack_walk<0>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, my_prev, my_next);
-		}
+		const uint8_t *dl = pack_stage_list(&prel, tid, lw);
+		if (ch + 1 < nchunks) pack_fetch_list(c, vals, ch + 1, tid, &prel, prevnz, nextnz);
+		if (lo < S) pack_walk_list<0>(my_nz, my_skip, dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, my_prev, my_next);
 	}
 	BARRIER();
 	if (!tid) PROF(c, 23);
@@ -2998,20 +2937,17 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	uint32_t *words = c->packet + word0;
 	unsigned base_bits = 0, base_n1 = 0, base_n2 = 0;
 	int zeroed = 0;                                              /* words [0, zeroed) are cleared or already carry bits */
-	if (list) pack_fetch_list(c, 0, tid, &prel, prevnz, nextnz); else pack_fetch(d, N, 0, tid, &pre, prevnz, nextnz);
+	pack_fetch_list(c, vals, 0, tid, &prel, prevnz, nextnz);
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
 		unsigned bb = 0, x1 = 0, x2 = 0, tb, tn;
-		const int my_prev = list ? prel.prev_nz : pre.prev_nz, my_next = list ? prel.next_nz : pre.next_nz;
+		const int my_prev = prel.prev_nz, my_next = prel.next_nz;
 		const uint64_t my_nz = prel.M;
 		const int my_skip = (int)(prel.off >> 29);
-		const uint8_t *dl = list ? pack_stage_list(&prel, tid, lw) : pack_stage(&pre, ch, tid, lw);
-		if (ch + 1 < nchunks) { if (list) pack_fetch_list(c, ch + 1, tid, &prel, prevnz, nextnz); else pack_fetch(d, N, ch + 1, tid, &pre, prevnz, nextnz); }
+		const uint8_t *dl = pack_stage_list(&prel, tid, lw);
+		if (ch + 1 < nchunks) pack_fetch_list(c, vals, ch + 1, tid, &prel, prevnz, nextnz);
 		SliceBits rec;
-		if (lo < S) {
-			if (list) pack_walk_list<1>(my_nz, my_skip, dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, my_prev, my_next, &rec);
-			else pack_walk<1>(dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, my_prev, my_next, &rec);
-		}
+		if (lo < S) pack_walk_list<1>(my_nz, my_skip, dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, &bb, &x1, &x2, my_prev, my_next, &rec);
 		const unsigned ob = block_exscan(bb, tid, sh->bits, &tb);
 		const unsigned on = block_exscan(x1 | (x2 << 16), tid, sh->bits, &tn);
 		const int last = tb ? (int)((base_bits + tb - 1) >> 5) : zeroed - 1;
@@ -3032,8 +2968,7 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 				for (unsigned z = 0; z < x1; z++) if (a1 + z < S_CAP) c->s1[a1 + z] = (uint8_t)((rec.s1m >> z) & 1);
 				for (unsigned z = 0; z < x2; z++) if (a2 + z < S_CAP) c->s2[a2 + z] = (uint8_t)((rec.s2m >> z) & 1);
 			}
-			else if (list) pack_walk_list<2>(my_nz, my_skip, dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, my_prev, my_next);
-			else pack_walk<2>(dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, my_prev, my_next);
+			else pack_walk_list<2>(my_nz, my_skip, dl, N, lo, hi, sh, words, base_bits + ob, c->s1, base_n1 + (on & 0xFFFF), c->s2, base_n2 + (on >> 16), nullptr, nullptr, nullptr, my_prev, my_next);
 		}
 		base_bits += tb; base_n1 += tn & 0xFFFF; base_n2 += tn >> 16;
 		if (last + 1 > zeroed) zeroed = last + 1;
@@ -3166,15 +3101,12 @@ DEV size_t container_par(Ctx *c, uint8_t *out, size_t cap, int tid)
 DEV void final_phase_par(Ctx *c, uint8_t *out, size_t cap, uint32_t *size, int32_t *status, PackShared *sh, int tid, uint32_t *lw)
 {
 	PROF_BEGIN();
-	uint8_t saved = c->scan[4 * Q];
-	BARRIER();
-	if (tid == 0) c->scan[4 * Q] = 3;                            /* sentinel behind the luma part (compress_pixel.c:66) */
-	BARRIER();
-	pack_part_par(c, 0, sh, tid, 0, lw, true);
+	/* (the reference's sentinel behind the luma part, compress_pixel.c:66, and its copy of the last chroma symbol, :464-465, were writes into the
+	 * byte stream; both parts come as lists now: the walks never reach the sentinel, the copy is made on the chroma part's map) */
+	pack_part_par(c, 0, sh, tid, 0, lw);
 	if (sh->rc) { if (tid == 0) { *size = 0; *status = sh->rc; } return; }
-	if (tid == 0) { c->scan[4 * Q] = saved; c->scan[6 * Q - 1] = c->scan[6 * Q - 2]; }   /* :464-465 */
 	BARRIER();
-	pack_part_par(c, 1, sh, tid, c->m->size_data1, lw, false);
+	pack_part_par(c, 1, sh, tid, c->m->size_data1, lw);
 	if (sh->rc) { if (tid == 0) { *size = 0; *status = sh->rc; } return; }
 	if (!tid) PROF(c, 19);
 	const size_t n = container_par(c, out, cap, tid);

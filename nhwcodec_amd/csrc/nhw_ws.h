@@ -22,7 +22,7 @@ enum {
 	B_R1LIST, B_R1BITS, B_R1WORD, B_R3LIST, B_R3BITS, B_R3WORD, B_R5LIST, B_R5BITS, B_R5WORD,
 	B_R6LIST, B_R6BITS, B_R6WORD, B_CHARRES, B_QSET3,
 	B_RESU64, B_RESV64, B_PACKET, B_BOOK1, B_BOOK2, B_SEL1, B_SEL2, B_S1, B_S2, B_HIST, B_META, B_PROF, B_ROWFLAG, B_SEGMAP, B_STALE,
-	B_NZQ, B_NZS, B_VOFF, B_VALS,   /* the luma symbol stream as a list (nhw_tail_wave.h, wave_quantise_luma): non-zero map as the quantiser writes it, the map and the value offsets in stream order (Y31), the values */
+	B_NZQ, B_NZS, B_VOFF, B_VALS, B_CNZQ, B_CVALS,   /* the luma symbol stream as a list (nhw_tail_wave.h, wave_quantise_luma): non-zero map as the quantiser writes it, the map and the value offsets in stream order (Y31), the values; CNZQ / CVALS: the chroma part's map and values as the chroma quantiser leaves them */
 	B_COUNT
 };
 
