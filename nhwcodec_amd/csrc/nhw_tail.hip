@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	else if (PH == PH_L3) luma_p3_par(&c, tid, sh_pos, sh_counts, dyn_lds);
 	else if (PH == PH_L4A) luma_p4a_par(&c, tid, dyn_lds);
 	else if (PH == PH_L4B) luma_p4b_par(&c, tid, sh_pos, dyn_lds);
-	else if (PH == PH_L4C) luma_p4c_par(&c, tid, sh_pos, dyn_lds);
+	else if (PH == PH_L4C) luma_p4c_par(&c, tid, sh_pos, dyn_lds, ws.q > 21 || ws.dbg);
 	else if (PH == PH_L4D) luma_p4d_par(&c, tid, sh_counts, sh_z, dyn_lds, NHW_DENSE_STREAM || ws.dbg);
 	else if (PH == PH_L4C2) luma_p4c2_par(&c, tid, reinterpret_cast<unsigned *>(sh_z), sh_pos);
 	else if (PH == PH_LLC) { PROF_BEGIN(); ll_code_chroma_par(&c, tid, reinterpret_cast<uint8_t *>(dyn_lds)); if (!tid) PROF(&c, 18); }
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 	else if (PH == WV_QUANT) {
 		__shared__ __attribute__((aligned(16))) uint8_t park[4][16 * QROW];
 		__shared__ uint32_t lut[4][QLUT + 3];
-		PROF_BEGIN(); wave_quantise_luma(&c, lane, park[threadIdx.x >> 6], lut[threadIdx.x >> 6], ws.q > 21 || ws.dbg, NHW_DENSE_STREAM || ws.dbg); if (!lane) PROF(&c, 15);
+		PROF_BEGIN(); wave_quantise_luma(&c, lane, park[threadIdx.x >> 6], lut[threadIdx.x >> 6], ws.q > 21 || ws.dbg, NHW_DENSE_STREAM || ws.dbg, !(ws.q > 21 || ws.dbg)); if (!lane) PROF(&c, 15);
 	}
 	else if (PH == WV_EMIT) { PROF_BEGIN(); wave_emit_ll2(&c, lane); if (!lane) PROF(&c, 4); }
 }

@@ -856,6 +856,102 @@ DEV void clean_rows_wave(int16_t *p, const CleanP f, int r_first, int r_last, in
 	}
 #undef CLEAN_LOAD
 }
+/* One row of Y27 for the lanes' four cells each: o = the row as it is, u / d = the rows above and below, far = the cell behind the span
+ * (HL1: column 256, lane 63 only).  Returns what the last lane's ripple hands to that cell.  (The body of clean_rows_wave's row step.) */
+template <int MODE>
+DEV int clean_row(const CleanP &f, const int o[4], const int u[4], const int d[4], int my_far, int upt, int c0, int jb, int je, int lane, int e[4])
+{
+	const int left = __shfl_up(o[3], 1), sd0 = __shfl_down(o[0], 1), r2 = __shfl_down(o[1], 1);
+	const int r1 = lane < 63 ? sd0 : my_far;
+	int n[4]; bool proc[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const int j = c0 + k;
+		proc[k] = j >= jb && j < je;
+		const int lv = k ? o[k - 1] : left, rv = k < 3 ? o[k + 1] : r1;
+		const int lt = (MODE == 2 && j - 1 >= jb) ? 7 : 6;
+		n[k] = (iabs(lv) >= lt) + (iabs(rv) >= 6) + (iabs(u[k]) >= upt) + (iabs(d[k]) >= 6);
+	}
+	int din = 0, dout;
+	for (;;) {
+		int dd = din;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int j = c0 + k, x = o[k] + dd;
+			if (proc[k]) {
+				const int v1 = k < 3 ? o[k + 1] : r1, v2 = k < 2 ? o[k + 2] : (k == 2 ? r1 : r2);
+				e[k] = clean_cell<MODE>(f, x, n[k], v1, v2, j < f.last_look, dd);
+			} else { e[k] = x; dd = 0; }
+		}
+		dout = dd;
+		int nd = __shfl_up(dout, 1);
+		if (!lane) nd = 0;
+		if (!__any(nd != din)) break;
+		din = nd;
+	}
+	return dout;
+}
+/* Y27 with every row read once (round 5).  clean_details_par below gave the rows of a band to the wavefronts in turn (row r to wavefront
+ * r mod 4), so a row's two neighbours came from memory again with it -- three reads a row -- and HH1, whose test of the row below wants that
+ * row as it was BEFORE the pass, worked against a snapshot of the whole band (a copy out and a read back): 1.25 MB per image for bands that
+ * weigh 0.77 MB read + written.  Here a wavefront takes 64 consecutive rows and keeps the row above, the row itself and the row below AS
+ * THEY WERE in registers, the next row on its way: a row is read once and written once, there is no snapshot.  LH1 and HL1 do not care
+ * which version of a neighbour row they see (the pass never moves a value across 6); HH1's look up asks ">= 7", which is the same before
+ * and after a row's visit, and its look down needs the raw row -- which the rolling registers hold, except for the first row of the next
+ * wavefront's range: that one is read before anybody starts (one barrier).  A row of the lower half is its HL1 half, then its HH1 half (the
+ * ripple HL1 may hand to column 256 goes to HH1's first lane over a readlane instead of through memory). */
+DEV void clean_details_seq(Ctx *c, int tid, bool ll_in_plane /* Y26 has put the level-2 block back into the work plane (else HL1's first row looks up into its copy l2save) */)
+{
+	int16_t *p = c->proc;
+	const int q = c->q, lane = tid & 63, wv = tid >> 6;
+	const CleanP fa = { DEADZONE - 2, q > 22 ? 8 : 9, q > 22 ? 4 : 9, W - 2 };
+	const CleanP fb = { DEADZONE - 2, q > 17 ? 8 : 9, q > 22 ? 4 : 9, H - 2 };
+	const int lim = q > 22 ? 8 : 11;
+	const CleanP fc = { DEADZONE - 1, lim, lim, W - 2 };
+	auto ld = [&](int r, int c0) { return *reinterpret_cast<const uint2 *>(p + (size_t)r * W + c0); };
+	auto st = [&](int r, int c0, const int e[4]) {
+		uint2 w;
+		w.x = (uint32_t)(uint16_t)e[0] | ((uint32_t)(uint16_t)e[1] << 16); w.y = (uint32_t)(uint16_t)e[2] | ((uint32_t)(uint16_t)e[3] << 16);
+		*reinterpret_cast<uint2 *>(p + (size_t)r * W + c0) = w;
+	};
+	const int cl = 4 * lane, ch = H + 4 * lane;                     /* my four cells of a row's left / right half */
+	const int lo0 = H + 64 * wv, lo1 = lo0 + 63 < W - 2 ? lo0 + 63 : W - 2;   /* my rows of the lower half */
+	const uint2 hh_below = ld(lo1 + 1, ch);                         /* the HH1 row below my range, before the wavefront that owns it rewrites it */
+	BARRIER();
+	{                                                               /* LH1: rows 1 .. 254, columns 257 .. 510 */
+		const int r0 = 1 + 64 * wv, r1 = r0 + 63 < H - 2 ? r0 + 63 : H - 2;
+		uint2 up = ld(r0 - 1, ch), cur = ld(r0, ch), dn = ld(r0 + 1, ch);
+		for (int r = r0; r <= r1; r++) {
+			const uint2 nx = ld(r + 2 < W ? r + 2 : r + 1, ch);      /* (row r1 + 2 is never used) */
+			int o[4], u[4], d[4], e[4];
+			unpack4(cur, o); unpack4(up, u); unpack4(dn, d);
+			clean_row<0>(fa, o, u, d, 0, 6, ch, H + 1, W - 1, lane, e);
+			st(r, ch, e);
+			up = cur; cur = dn; dn = nx;
+		}
+	}
+	{                                                               /* rows 256 .. 510: HL1 (columns 1 .. 255), then HH1 (columns 257 .. 510) */
+		uint2 upl = (wv == 0 && !ll_in_plane) ? *reinterpret_cast<const uint2 *>(c->l2save + (size_t)(H - 1) * H + cl) : ld(lo0 - 1, cl), curl = ld(lo0, cl), dnl = ld(lo0 + 1, cl);   /* row 255 under HL1's first row is the last row of the level-2 block */
+		uint2 uph = ld(lo0 - 1, ch), curh = ld(lo0, ch), dnh = lo0 + 1 > lo1 ? hh_below : ld(lo0 + 1, ch);
+		for (int r = lo0; r <= lo1; r++) {
+			const int rn = r + 2 < W ? r + 2 : W - 1;
+			const uint2 nxl = ld(rn, cl);
+			const uint2 nxh = r + 2 > lo1 ? (r + 2 == lo1 + 1 ? hh_below : make_uint2(0, 0)) : ld(rn, ch);
+			int o[4], u[4], d[4], e[4];
+			unpack4(curl, o); unpack4(upl, u); unpack4(dnl, d);
+			const int my_far = (int16_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)curh.x) & 0xFFFFu);   /* column 256 of the row: HL1's last cell looks at it, and its ripple may move it */
+			const int dout = clean_row<1>(fb, o, u, d, my_far, 6, cl, 1, H, lane, e);
+			st(r, cl, e);
+			const int moved = __builtin_amdgcn_readlane(dout, 63);    /* HL1's ripple out of column 255 lands in column 256: HH1's first cell (not processed itself, but its neighbour's left) */
+			unpack4(curh, o); unpack4(uph, u); unpack4(dnh, d);
+			if (lane == 0) o[0] += moved;
+			clean_row<2>(fc, o, u, d, 0, r > H ? 7 : 6, ch, H + 1, W - 1, lane, e);
+			st(r, ch, e);
+			upl = curl; curl = dnl; dnl = nxl;
+			uph = curh; curh = dnh; dnh = nxh;
+		}
+	}
+}
 DEV void clean_details_par(Ctx *c, int tid, int16_t *lds)
 {
 	int16_t *p = c->proc;
@@ -2197,9 +2293,10 @@ DEV void luma_p4b_par(Ctx *c, int tid, int *pos, int16_t *lds)
 	build_poslists_par(c, tid, pos, lds);                                   /* Y25 */
 	if (!tid) PROF(c, 12);
 }
-DEV void luma_p4c_par(Ctx *c, int tid, int *pos, int16_t *lds)
+DEV void luma_p4c_par(Ctx *c, int tid, int *pos, int16_t *lds, bool copy_ll /* quality > 21 and the stage checks: the level-2 block goes back into the work plane (Y26); otherwise the quantiser, its only reader, takes it from l2save itself (quant_load_row) */)
 {
 	PROF_BEGIN();
+	if (copy_ll)
 	for (int g = tid; g < Q / 8; g += NT) {                                  /* Y26 :1893-1910, 8 cells per item */
 		const int r = g >> 5, j0 = (g & 31) * 8;
 		uint4 v = *reinterpret_cast<const uint4 *>(c->l2save + r * H + j0);
@@ -2215,7 +2312,8 @@ DEV void luma_p4c_par(Ctx *c, int tid, int *pos, int16_t *lds)
 	}
 	BARRIER();
 	if (!tid) PROF(c, 13);
-	clean_details_par(c, tid, lds);                                         /* Y27 */
+	(void)lds;
+	clean_details_seq(c, tid, copy_ll);                                     /* Y27 */
 	if (!tid) PROF(c, 14);
 }
 /* Y29 (q > 21): im_recons_wavelet_band (image_processing.c:523-556) + wavelet_synthesis_high_quality_settings

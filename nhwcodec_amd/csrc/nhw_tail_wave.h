@@ -618,8 +618,16 @@ DEV int right_of_dpp(const int *v, int k, int nk, int lane, int edge)
 	return __builtin_amdgcn_update_dpp(seam, v[k], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);   /* lane 63 has no source and keeps the seam */
 }
 
-DEV void quant_load_row(const int16_t *p, int r, int lane, int *v)
+/* ll: the level-2 block (rows and columns below 256) comes from its copy l2save instead of the work plane -- Y26 (nhw_encoder.c:1893-1910) put
+ * it back there with the tags of its LL2 quarter cleared (everything up to 8000 in rows and columns below 128 becomes 0), for this reader
+ * alone: 256 KB of copy per image that this load does itself */
+DEV void quant_load_row(const int16_t *p, int r, int lane, int *v, const int16_t *ll = nullptr)
 {
+	if (ll && r < H) {
+		for (int k = 0; k < 4; k++) { const int x = ll[r * H + lane + 64 * k]; v[k] = (r < H / 2 && k < 2 && x <= 8000) ? 0 : x; }
+		for (int k = 4; k < 8; k++) v[k] = p[r * W + lane + 64 * k];
+		return;
+	}
 	for (int k = 0; k < 8; k++) v[k] = r < W ? p[r * W + lane + 64 * k] : 0;       /* the cell behind the plane reads as 0 (zero guard) */
 }
 
@@ -664,8 +672,9 @@ DEV unsigned quant_entry(int x)
  * strip (a wave prefix sum of the popcounts), inside a slice in stream order.  fbase[f] is where flush f starts in `vals`.  Zero-run lengths
  * are gaps between set bits; Y31 (scan_rewrite_list_par) turns the map into stream order for the packetiser.  `dense`: the byte stream as
  * well (stage checks). */
-DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes of this wavefront */, uint32_t *lut /* QLUT words of this wavefront */, bool write_plane, bool dense)
+DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes of this wavefront */, uint32_t *lut /* QLUT words of this wavefront */, bool write_plane, bool dense, bool ll_from_save)
 {
+	const int16_t *const llsrc = ll_from_save ? c->l2save : nullptr;
 	uint64_t *const nzq = c->nzq;
 	uint8_t *const vals = c->vals;
 	unsigned vtotal = 0;                                            /* values written so far (wave-uniform) */
@@ -675,16 +684,16 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 	uint8_t *stream = c->scan;
 	int prev[8], cur[8], nxt[8];
 	int q0[8];                                                     /* row r+2 in flight (and r+3: `far`; a row's step is 3.5 us, a memory round trip shorter) */
-	quant_load_row(p, 0, lane, cur);
-	quant_load_row(p, 1, lane, nxt);
-	quant_load_row(p, 2, lane, q0);
+	quant_load_row(p, 0, lane, cur, llsrc);
+	quant_load_row(p, 1, lane, nxt, llsrc);
+	quant_load_row(p, 2, lane, q0, llsrc);
 	for (int k = 0; k < 8; k++) prev[k] = 0;
 	const bool low = c->q <= 16;                                   /* quality 1..16 (image_processing.c:357-410, :427-510): no loops 2 and 3; rationed low bits; the `quant4` pushes */
 	int q4_turn = 0, q4_carry = 0;                                 /* quant4: its every-third-pair counter runs through the whole plane; a push out of column 511 lands in the next row's first cell */
 	unsigned last_le0 = 0;                                         /* the last cell of the row above is <= 0 (loop 1 looks at it from column 0) */
 	for (int r = 0; r <= W; r++) {                                 /* step r: loops 1-3 on row r, loop 4 on row r - 1 */
 		int far[8];
-		quant_load_row(p, r + 3, lane, far);
+		quant_load_row(p, r + 3, lane, far, llsrc);
 		if (r < W) {
 			if (r < H) {                                           /* loop 1, upper half: only columns 256..511 (words 4..7) take part */
 				/* both rules start from two neighbours on multiples of 8 (from 8 up): a row without such a pair -- most rows -- is done after that test */
