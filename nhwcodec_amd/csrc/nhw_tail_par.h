@@ -1068,7 +1068,7 @@ DEV void quantise_chroma_par(Ctx *c, int comp, int tid, int16_t *lds, bool write
 				const unsigned cnt = (unsigned)(__builtin_popcountll(M0) + __builtin_popcountll(M1));
 				unsigned incl = cnt;
 				for (int o_ = 1; o_ < 64; o_ <<= 1) { const unsigned t_ = (unsigned)__shfl_up((int)incl, o_); if (lane >= o_) incl += t_; }
-				if (lane == 0) c->cfbase[F] = 32768u * wv + vtotal;
+				if (lane == 0) { c->cfbase[F] = 32768u * wv + vtotal; c->cfbase[16 + wv] = vtotal + (unsigned)__builtin_amdgcn_readlane((int)incl, 63); }   /* [16 + wv]: the wavefront's values so far (its total behind the last flush) */
 				uint8_t *vp = c->cvals + 32768u * wv + vtotal + incl - cnt;
 				vtotal += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
 				/* the symbols by position: a slice's sixteen dwords wait in the wavefront's parked rows -- every lane has read its own above, the
@@ -2963,16 +2963,61 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 		if (tid == 0) nextnz[nsl] = N;
 	}
 	BARRIER();
-	PackPreL prel;
-	pack_fetch_list(c, vals, 0, tid, &prel, prevnz, nextnz);
+	/* The histogram (:81-127) needs no walk of the symbols: every symbol that is not the zero symbol counts once, whatever surrounds it -- a flat
+	 * histogram over the value list, sixteen bytes a thread and turn, every thread equally loaded (as a walk, a slice of the level-2 quadrant
+	 * kept its lane busy for 64 tokens while the other lanes of the wavefront waited) -- and the zero runs are the gaps of the map: a slice's
+	 * gaps, with what prev_nz / next_nz say about the ones that cross its edges.  The values in the list that no symbol owns any more are
+	 * left out: the first and the last four luma symbols that Y31 cleared (the head of the first flush, the tail of the last one), the
+	 * chroma part's last symbol (never walked: compress_pixel.c:81's loop ends one short). */
+	{
+		auto count16 = [&](const uint8_t *base, unsigned at, unsigned lo_, unsigned hi_) {   /* the bytes of [at, at + 16) that lie in [lo_, hi_) */
+			const uint4 v = *reinterpret_cast<const uint4 *>(base + at);
+			const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+			for (int k = 0; k < 16; k++) { const unsigned pos = at + k; if (pos >= lo_ && pos < hi_) atomicAdd(&sh->hist[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1); }
+		};
+		if (!part) {
+			const unsigned lo_ = c->voff[0] & 0x1FFFFFFFu, hi_ = (c->voff[SL_SLICES - 1] & 0x1FFFFFFFu) + (unsigned)__builtin_popcountll(c->nzs[SL_SLICES - 1]);
+			for (unsigned at = (lo_ & ~15u) + 16u * tid; at < hi_; at += 16u * NT) count16(vals, at, lo_, hi_);
+		} else {
+			for (int w4 = 0; w4 < 4; w4++) {
+				const unsigned hi_ = 32768u * w4 + c->cfbase[16 + w4];
+				for (unsigned at = 32768u * w4 + 16u * tid; at < hi_; at += 16u * NT) count16(vals, at, 32768u * w4, hi_);
+			}
+		}
+	}
 	for (int ch = 0; ch < nchunks; ch++) {
-		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
-		const int my_prev = prel.prev_nz, my_next = prel.next_nz;
-		const uint64_t my_nz = prel.M;
-		const int my_skip = (int)(prel.off >> 29);
-		const uint8_t *dl = pack_stage_list(&prel, tid, lw);
-		if (ch + 1 < nchunks) pack_fetch_list(c, vals, ch + 1, tid, &prel, prevnz, nextnz);
-		if (lo < S) pack_walk_list<0>(my_nz, my_skip, dl, N, lo, hi, sh, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, my_prev, my_next);
+		const int g = ch * NT + tid, lo = g * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
+		if (lo >= S) continue;
+		const uint64_t nz = c->nzs[g];
+		const int prev_nz = prevnz[g], next_nz = nextnz[g + 1];
+		const int send = lo + PK_SLICE < N ? lo + PK_SLICE : N;
+		if (part && g == nsl - 1 && (c->cnzq[(15 * 64 + 63) * 2 + 1] >> 63))       /* the chroma part's last symbol as the quantiser left it (slice 2047 = the last entry of the last flush): not walked, not counted */
+			atomicSub(&sh->hist[vals[(c->voff[g] & 0x1FFFFFFFu) + (unsigned)__builtin_popcountll(c->cnzq[(15 * 64 + 63) * 2 + 1]) - 1u]], 1);
+		int i = lo;
+		uint64_t rest = nz;
+		while (i < hi) {
+			if (rest & 1) {                                          /* a run of symbols: counted above */
+				const int n1 = ~rest ? __builtin_ctzll(~rest) : 64;
+				i += n1; rest = n1 < 64 ? rest >> n1 : 0;
+				continue;
+			}
+			int a = i, b;                                            /* maximal zero run [a, b] around i (pack_walk_list) */
+			if (i == lo && i > 0 && prev_nz != lo - 1) a = prev_nz + 1;
+			if (rest) b = i + __builtin_ctzll(rest) - 1;
+			else b = send < N ? next_nz - 1 : send - 1;
+			const int L = b - a + 1;
+			if (L == 1) atomicAdd(&sh->hist[128], 1);
+			else if (a == i && L < 255) atomicAdd(&sh->runs[L], 1);
+			else {
+				const int m = L > 255 ? (L - 255 + 253) / 254 : 0;
+				int k1 = (hi - 1 - a) / 254;
+				if (k1 > m) k1 = m;
+				for (int k = (i - a + 253) / 254; k <= k1; k++) atomicAdd(&sh->runs[k < m ? 254 : L - 254 * m], 1);
+			}
+			rest = (b + 1 - i) < 64 ? rest >> (b + 1 - i) : 0;
+			i = b + 1;
+		}
 	}
 	BARRIER();
 	if (!tid) PROF(c, 23);
@@ -3035,6 +3080,7 @@ DEV void pack_part_par(Ctx *c, int part, PackShared *sh, int tid, int word0, uin
 	uint32_t *words = c->packet + word0;
 	unsigned base_bits = 0, base_n1 = 0, base_n2 = 0;
 	int zeroed = 0;                                              /* words [0, zeroed) are cleared or already carry bits */
+	PackPreL prel;
 	pack_fetch_list(c, vals, 0, tid, &prel, prevnz, nextnz);
 	for (int ch = 0; ch < nchunks; ch++) {
 		const int lo = ch * PK_CHUNK + tid * PK_SLICE, hi = lo + PK_SLICE < S ? lo + PK_SLICE : S;
