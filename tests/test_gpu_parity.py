@@ -596,6 +596,81 @@ def test_tail_stages_match_the_oracle_trace(oracle, q):
     e.close()
 
 
+def _read_ws(e, buf, img, nbytes):
+    out = np.empty(nbytes, np.uint8)
+    assert e.lib.nhw_debug_read(e.h, buf, img, ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(nbytes)) == 0
+    return out
+
+
+def _ws_index(name):
+    """index of a workspace buffer (nhwcodec_amd/csrc/nhw_ws.h, the B_* list) for nhw_debug_read"""
+    import re
+    txt = open(os.path.join(ROOT, "nhwcodec_amd", "csrc", "nhw_ws.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", txt[txt.index("enum {"):txt.index("B_COUNT")], flags=re.S)
+    names = re.findall(r"B_[A-Z0-9_]+", body)
+    return names.index("B_" + name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [1, 10, 16, 17, 20, 23])
+def test_symbol_list_equals_the_byte_stream(oracle, q):
+    """Since round 5 the symbol stream travels as a LIST -- a non-zero map per 64-symbol slice and the symbols that are not 128 (the luma
+    quantiser, Y31 on map + values, the chroma quantiser, the packetiser) -- and the byte stream of the reference (nhw_encoder.c:2108-2252,
+    2553-2570) is only written for the stage checks.  Here both forms are made (the batch driver stopped behind Y31, and behind the second
+    chroma sequence) and compared symbol for symbol: the luma part after all three rewrites of Y31 (chains of (+-8, 0, 0, 0, +-8) across slice
+    edges, the long zero runs of the low qualities, the cleared first and last four symbols), the chroma part as the packetiser will order it.
+    Images: the generator's, noise (every symbol non-zero: the worst case of the list), blocks, flat, gradient, tiles."""
+    import torch
+    import nhwcodec_amd
+    Q = 65536
+    imgs = np.stack([oracle.synth(7000 + 31 * q + i) for i in range(6)] + [class_image(k, q) for k in ("noise", "blocks", "flat", "gradient", "tiles")])
+    e = nhwcodec_amd.Encoder(0, max_batch=len(imgs))
+    d_in = torch.from_numpy(imgs).cuda()
+    rd = lambda name, i, nbytes, dt: np.frombuffer(bytes(_read_ws(e, _ws_index(name), i, nbytes)), dt)
+    luma_stage = 12 if q >= 22 else 13 if q > 12 else 11 if q > 6 else 7       # the stage count behind Y31 (fewer stages where a closed loop is missing)
+    try:
+        e.lib.nhw_debug_stop_after(e.h, luma_stage)
+        e.encode_device(d_in, q)
+        torch.cuda.synchronize()
+        for i in range(len(imgs)):
+            dense = rd("SCAN", i, 4 * Q, np.uint8)
+            nzs, voff, vals = rd("NZS", i, 4 * Q // 8, np.uint64), rd("VOFF", i, 4 * Q // 16, np.uint32), rd("VALS", i, 4 * Q, np.uint8)
+            bits = np.unpackbits(nzs.view(np.uint8), bitorder="little").astype(bool)          # bit k of slice g = symbol 64 g + k
+            got = np.full(4 * Q, 128, np.uint8)
+            cnt = bits.reshape(-1, 64).sum(1)
+            off = (voff & 0x1FFFFFFF).astype(np.int64)
+            idx = np.concatenate([np.arange(o, o + c) for o, c in zip(off, cnt)]) if cnt.sum() else np.zeros(0, np.int64)
+            got[bits] = vals[idx]
+            bad = np.flatnonzero(got != dense)
+            assert bad.size == 0, f"q{q} image {i}: luma list and byte stream differ at {bad[:8].tolist()} ({bad.size} symbols)"
+            assert not (vals[idx] == 128).any(), "a listed symbol is the zero symbol"
+        if q >= 17:
+            e.lib.nhw_debug_stop_after(e.h, luma_stage + 24)                                   # behind V's quantiser (12 stages a chroma sequence)
+            e.encode_device(d_in, q)
+            torch.cuda.synchronize()
+            for i in range(len(imgs)):
+                dense = rd("SCAN", i, 6 * Q, np.uint8)[4 * Q:]
+                cnzq, cvals = rd("CNZQ", i, Q // 4 + 256, np.uint8), rd("CVALS", i, 2 * Q, np.uint8)
+                maps, fbase = cnzq[:Q // 4].view(np.uint64).reshape(16, 64, 2), cnzq[Q // 4:Q // 4 + 64].view(np.uint32)
+                got = np.full(2 * Q, 128, np.uint8)
+                for F in range(16):
+                    at = int(fbase[F])
+                    for lane in range(64):
+                        for half in range(2):
+                            S = 64 * (lane >> 1) + 16 * (F >> 2) + 4 * (F & 3) + 2 * (lane & 1) + half    # the stream slice of (flush, lane, half): pack_chroma_order
+                            b = np.unpackbits(maps[F, lane, half:half + 1].view(np.uint8), bitorder="little").astype(bool)
+                            n = int(b.sum())
+                            got[64 * S:64 * S + 64][b] = cvals[at:at + n]
+                            at += n
+                bad = np.flatnonzero(got != dense)
+                assert bad.size == 0, f"q{q} image {i}: chroma list and byte stream differ at {bad[:8].tolist()} ({bad.size} symbols)"
+    finally:
+        e.lib.nhw_debug_stop_after(e.h, 0)
+    files = e.encode(imgs, q)
+    assert all(f == oracle.encode(imgs[i], q) for i, f in enumerate(files) if i < 3)
+    e.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("q", [1, 10, 13, 16])
 def test_low_quality_stages_match_the_oracle_trace(oracle, q):
