@@ -9,6 +9,8 @@ SOURCES = ["nhw_front.hip", "nhw_tail.hip", "nhw_low.hip", "nhw_api.hip", "nhw_d
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
 if os.environ.get("NHW_DEV"):
     FLAGS.append("-DNHW_DEV")       # phase stamps and pass switches of the front kernels (developer builds only)
+if os.environ.get("NHW_EXTRA_FLAGS"):
+    FLAGS += os.environ["NHW_EXTRA_FLAGS"].split()   # developer experiments (e.g. -DLW=64: tools/dev/build_variant.sh)
 if os.environ.get("NHW_PROFILE"):
     FLAGS.append("-DNHW_PROFILE")   # in-kernel per-pass timers (developer builds only)
 

@@ -51,6 +51,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	final_phase_par(&c, out + (size_t)img * (512u << 10), 512u << 10, &sizes[img], &status[img], &sh_pack, tid, reinterpret_cast<uint32_t *>(dyn_lds));
 }
 
+#ifdef NHW_L4A_WAVES   /* developer experiment: Y19-Y23 as a kernel of its own held to NHW_L4A_WAVES wavefronts a SIMD */
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NHW_L4A_WAVES, NHW_L4A_WAVES))) void k_l4a(NhwWs ws)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t dyn_lds[];
+	Ctx c;
+	ctx_load(&c, ws, blockIdx.x);
+	luma_p4a_par(&c, threadIdx.x, dyn_lds);
+}
+#endif
+
 /* passes that run one wavefront per image (nhw_tail_wave.h): four images per workgroup, no workgroup barriers */
 enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
 template <int PH>
@@ -270,7 +280,11 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 	case PH_L1: k_phase<PH_L1><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L2: k_phase<PH_L2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L3: k_phase<PH_L3><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+#ifdef NHW_L4A_WAVES
+	case PH_L4A: k_l4a<<<g, b, lds, s>>>(ws); break;
+#else
 	case PH_L4A: k_phase<PH_L4A><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+#endif
 	case PH_L4B: k_phase<PH_L4B><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4C: k_phase<PH_L4C><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4D: k_phase<PH_L4D><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;

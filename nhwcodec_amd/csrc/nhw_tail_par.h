@@ -549,11 +549,15 @@ DEV int classify_step(const uint8_t *tab, int q, int r, int j, int16_t *pr, int 
  * from the third on are still untouched; the first three are carried over from the chunk before).  Column 255
  * runs afterwards on a packed LDS copy of its column: its "column 256" is the LH1 column written by the other
  * columns, its ll1 neighbour is column 0, both read live. */
+#ifndef CR
 #define CR 4      /* rows per chunk: 22 KB of LDS, seven workgroups per CU (measured, ms per 4096-image batch: CR 2: 3.78, 4: 3.40, 8: 3.71, 16: 4.00) */
+#endif
 /* The LH1 coefficients of column j are row j of the plane, LW of them at a time for all 256 rows: whole 64-byte pieces of every row
  * (a piece per chunk of rows is a few bytes of a line that has left the L2 again when the next chunk asks for its neighbour -- measured
  * 4x the band's bytes in either direction with 16-byte pieces).  LP: LDS pitch of a column's piece, an odd number of dwords. */
-#define LW 16
+#ifndef LW
+#define LW 16     /* shorts of an LH1 line a tile holds (32 bytes; measured again in round 5 with 64 and 128 bytes: DESIGN 4.3) */
+#endif
 #define LP (LW + 2)
 #define CR_LDS_BYTES (((CR + 3) * 3 * H + H * LP) * 2 + CK_TABLE_BYTES)
 DEV void lh_tile_load(int16_t *lt, const int16_t *p, int r0, int tid)
