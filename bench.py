@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s me
 FRONT_BYTES_PER_IMAGE = 786432 + 786432   # 3 B/px read + 3 B/px written (Y coeffs + 2 x chroma)
 FRONT_KERNEL_NAME = ("front = k_front_image, ONE fused kernel and the whole launch group: BGR24 -> Y + 4:2:0 chroma planes, luma pre-filter (its carry chained inside the kernel), "
                      "both directions of the level-1 analysis; a workgroup walks an image top to bottom with a rolling window of rows in LDS (the luma plane never travels)")
-VALU_PMC_FILE = os.path.join(ROOT, "profiles", "round4_pmc_valu.json")   # profiles/collect_valu.sh: SQ_INSTS_VALU, GRBM_GUI_ACTIVE ... of the same bench command
+VALU_PMC_FILE = os.path.join(ROOT, "profiles", "round5_pmc_valu.json")   # profiles/collect_valu.sh: SQ_INSTS_VALU, GRBM_GUI_ACTIVE ... of the same bench command
 PMC_FILE = os.path.join(ROOT, "profiles", "front_pmc.json")     # written by profiles/pmc_summarise.py from separate rocprofv3 --pmc passes
 
 
@@ -140,7 +140,7 @@ def cpu_decode_baseline(files, budget_s=6.0):
 
 
 def valu_evidence():
-    """VALU issue statistics of the front kernel from the committed PMC pass (profiles/round4_pmc_valu.json, batch 4096, -q20):
+    """VALU issue statistics of the front kernel from the committed PMC pass (profiles/round5_pmc_valu.json, batch 4096, -q20):
     wave-instructions issued / (CUs x kernel cycles) -- the kernel's limiter is vector-instruction issue, not HBM; this is its fraction of
     that roofline (one wave64 instruction per CU and cycle: four 16-lane SIMDs)."""
     try:

@@ -1345,7 +1345,9 @@ DEV void sl_pm8(const SymList &L, int g, uint64_t M, uint4 first, uint64_t *p6, 
 	}
 	*p6 = a; *p0 = b;
 }
+#ifndef SL_AHEAD
 #define SL_AHEAD 4                                                 /* slices a thread has in flight */
+#endif
 #define SL_FETCH(Mk, vk, g0) do { for (int k_ = 0; k_ < SL_AHEAD; k_++) { const int g_ = (g0) + NT * k_; Mk[k_] = L.nz[g_]; \
 		if (Mk[k_]) __builtin_memcpy(&vk[k_], L.vals + SL_OFF(L.vo[g_]), 16); } } while (0)
 DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */, int *sh_counts)

@@ -1,11 +1,11 @@
 """Regenerates the kernel table of DESIGN.md (between the KERNEL_TABLE markers) from the committed profile summaries, so that the numbers
 cannot drift from the files they cite.   usage: python profiles/make_design_table.py [--check]
-inputs: profiles/round4_kernel_stats_1stream.txt (rocprofv3 --kernel-trace --stats, one stream), profiles/round4_pmc.json (FETCH_SIZE and
+inputs: profiles/round5_kernel_stats_1stream.txt (rocprofv3 --kernel-trace --stats, one stream), profiles/round5_pmc.json (FETCH_SIZE and
 WRITE_SIZE per kernel from separate --pmc passes; KiB; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STATS = os.path.join(ROOT, "profiles", "round4_kernel_stats_1stream.txt")
-PMC = os.path.join(ROOT, "profiles", "round4_pmc.json")
+STATS = os.path.join(ROOT, "profiles", "round5_kernel_stats_1stream.txt")
+PMC = os.path.join(ROOT, "profiles", "round5_pmc.json")
 BATCHES = 7.0            # bench.py --steps 5 --warmup 2 in profiles/collect.sh
 PH = ["L1", "L2", "L3", "L4A", "C0", "C2", "C3", "C4", "C5", "FINAL", "L4B", "L4C", "L4D", "LLC", "L4C2"]
 WV = ["DQ1", "DQ0", "EMIT", "QUANT"]
@@ -19,12 +19,13 @@ WHAT = {
     "k_l2_recon": "first closed loop: level-2 synthesis + Y8 (tags -> reconstruction) + Y9 (LL1 pre-compensation) on one LDS residency of the block",
     "L1": "Y5 tag level-2 details", "L2": "Y8, Y9 as a kernel of their own (only the tests' stage checks run it)", "L3": "Y16 LL2 coder (parse), Y17",
     "L4A": "Y19-Y23: small runs (wavefront per row), residual classification (one table-driven step for every kind) and coding (column walks on LDS tiles)",
-    "L4B": "Y24, Y25 position lists + list packing", "L4C": "Y26, Y27 detail clean-up (wavefront per row)", "L4D": "Y31 rewrites of the symbol stream",
+    "L4B": "Y24, Y25 position lists + list packing", "L4C": "Y27 detail clean-up (a wavefront takes 64 consecutive rows, neighbours in registers; Y26 only for q >= 22)", "L4D": "Y31 rewrites, on the symbol LIST (non-zero map + values); leaves map and offsets in stream order",
     "L4C2": "Y29 (q >= 22): band reconstruction, half synthesis, res6 / char_res1 / qsetting3 lists",
     "C0": "chroma: copy", "C2": "chroma: dequantiser simulation 1", "C3": "chroma: tags", "C4": "chroma: dequantiser simulation 2",
-    "C5": "chroma: marks (running-index fixed point), LL2 emission, quantiser (wavefront per row) + stream bytes", "LLC": "Z1 chroma LL2 coder", "FINAL": "Z2 packetiser + container",
+    "C5": "chroma: marks (running-index fixed point), LL2 emission, quantiser (wavefront per row); V leaves the merged chroma stream as a list", "LLC": "Z1 chroma LL2 coder", "FINAL": "Z2 packetiser + container",
+    "k_final": "Z2 packetiser (both parts from the symbol lists) + container; a kernel of its own at four wavefronts a SIMD",
     "DQ1": "a8 dequantiser simulation, first closed loop (wavefront per image)", "DQ0": "a8 dequantiser simulation, second closed loop",
-    "EMIT": "Y14/Y15 LL2 emission", "QUANT": "Y28 luma quantiser + Y30 stream order (wavefront per image)",
+    "EMIT": "Y14/Y15 LL2 emission", "QUANT": "Y28 luma quantiser + Y30: the symbols leave as a list in stream order (wavefront per image); reads the level-2 block from l2save (Y26)",
 }
 
 
