@@ -51,6 +51,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	final_phase_par(&c, out + (size_t)img * (512u << 10), 512u << 10, &sizes[img], &status[img], &sh_pack, tid, reinterpret_cast<uint32_t *>(dyn_lds));
 }
 
+/* Y31 on the symbol list as a kernel of 512 threads (production; the stage checks run k_phase<L4D>, which has the dense form behind it) */
+__global__ __launch_bounds__(512) void k_y31(NhwWs ws)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t dyn_lds[];
+	__shared__ int sh_counts[2];
+	Ctx c;
+	ctx_load(&c, ws, blockIdx.x);
+	PROF_BEGIN();
+	scan_rewrite_list_par<512>(&c, threadIdx.x, reinterpret_cast<uint8_t *>(dyn_lds), sh_counts);
+	if (!threadIdx.x) PROF(&c, 17);
+}
+
 #ifdef NHW_L4A_WAVES   /* developer experiment: Y19-Y23 as a kernel of its own held to NHW_L4A_WAVES wavefronts a SIMD */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NHW_L4A_WAVES, NHW_L4A_WAVES))) void k_l4a(NhwWs ws)
 {
@@ -287,7 +299,7 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 #endif
 	case PH_L4B: k_phase<PH_L4B><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4C: k_phase<PH_L4C><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
-	case PH_L4D: k_phase<PH_L4D><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
+	case PH_L4D: if (NHW_DENSE_STREAM || ws.dbg) k_phase<PH_L4D><<<g, b, lds, s>>>(ws, comp, out, sizes, status); else k_y31<<<g, 512, lds, s>>>(ws); break;
 	case PH_LLC: k_phase<PH_LLC><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4C2: k_phase<PH_L4C2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_C0: k_phase<PH_C0><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;

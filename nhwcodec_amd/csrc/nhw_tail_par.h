@@ -1348,8 +1348,12 @@ DEV void sl_pm8(const SymList &L, int g, uint64_t M, uint4 first, uint64_t *p6, 
 #ifndef SL_AHEAD
 #define SL_AHEAD 4                                                 /* slices a thread has in flight */
 #endif
-#define SL_FETCH(Mk, vk, g0) do { for (int k_ = 0; k_ < SL_AHEAD; k_++) { const int g_ = (g0) + NT * k_; Mk[k_] = L.nz[g_]; \
+#define SL_FETCH(Mk, vk, g0) do { for (int k_ = 0; k_ < SL_AHEAD; k_++) { const int g_ = (g0) + TN * k_; Mk[k_] = L.nz[g_]; \
 		if (Mk[k_]) __builtin_memcpy(&vk[k_], L.vals + SL_OFF(L.vo[g_]), 16); } } while (0)
+/* TN: threads of the workgroup, 256 (inside k_phase<L4D>, with the stage checks' dense form behind it) or 512 (k_y31: the kernel's 49 KB of LDS
+ * hold a CU to three workgroups whatever their size, so twice the threads are twice the wavefronts a CU for a pass that is bound by its
+ * threads' dependent loads) */
+template <int TN>
 DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */, int *sh_counts)
 {
 	const int n = 4 * Q;
@@ -1360,23 +1364,24 @@ DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */,
 	PROF_BEGIN();
 	if (tid == 0) sh_counts[0] = 0;
 	{                                                               /* the map into stream order, every slice's first value: thread = (flush, sixteen strips) */
-		const int f = tid >> 3, s0 = (tid & 7) * 16;
-		uint64_t m[16];
+		constexpr int SPT = SL_SLICES / TN, TPF = 128 / SPT;          /* strips a thread takes of its flush, threads a flush */
+		const int f = tid / TPF, s0 = (tid % TPF) * SPT;
+		uint64_t m[SPT];
 		unsigned tot = 0;
-		for (int k = 0; k < 16; k++) { m[k] = c->nzq[f * 128 + s0 + k]; tot += (unsigned)__builtin_popcountll(m[k]); }
+		for (int k = 0; k < SPT; k++) { m[k] = c->nzq[f * 128 + s0 + k]; tot += (unsigned)__builtin_popcountll(m[k]); }
 		unsigned incl = tot;
-		for (int o = 1; o < 8; o <<= 1) { const unsigned t_ = (unsigned)__shfl_up((int)incl, o, 8); if ((tid & 7) >= o) incl += t_; }
+		for (int o = 1; o < TPF; o <<= 1) { const unsigned t_ = (unsigned)__shfl_up((int)incl, o, TPF); if ((tid % TPF) >= o) incl += t_; }
 		unsigned at = c->fbase[f] + incl - tot;
-		for (int k = 0; k < 16; k++) { L.nz[(s0 + k) * 32 + f] = m[k]; L.vo[(s0 + k) * 32 + f] = at; at += (unsigned)__builtin_popcountll(m[k]); }
+		for (int k = 0; k < SPT; k++) { L.nz[(s0 + k) * 32 + f] = m[k]; L.vo[(s0 + k) * 32 + f] = at; at += (unsigned)__builtin_popcountll(m[k]); }
 	}
 	BARRIER();
 	if (!tid) PROF(c, 40);
-	for (int g0 = tid; g0 < SL_SLICES; g0 += NT * SL_AHEAD) {        /* rewrite 1, selection (:2134-2167): of a chain of candidates four apart every other one, from the chain's head */
+	for (int g0 = tid; g0 < SL_SLICES; g0 += TN * SL_AHEAD) {        /* rewrite 1, selection (:2134-2167): of a chain of candidates four apart every other one, from the chain's head */
 		uint64_t Mk[SL_AHEAD]; uint4 vk[SL_AHEAD];
 		SL_FETCH(Mk, vk, g0);
 #pragma unroll
 		for (int k = 0; k < SL_AHEAD; k++) {
-		const int g = g0 + NT * k;
+		const int g = g0 + TN * k;
 		const uint64_t M = Mk[k];
 		if (!M) continue;
 		uint64_t p6, p0;
@@ -1400,7 +1405,7 @@ DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */,
 	}
 	BARRIER();
 	if (!tid) PROF(c, 41);
-	for (int e = tid; e < sh_counts[0]; e += NT) {                  /* rewrite 1, application */
+	for (int e = tid; e < sh_counts[0]; e += TN) {                  /* rewrite 1, application */
 		const int cpos = (int)sel[e];
 		const int x = sl_sym(L, cpos), y = sl_sym(L, cpos + 4);
 		sl_set(L, cpos, x == 136 ? (y == 136 ? 132 : 133) : (y == 136 ? 134 : 135));
@@ -1416,12 +1421,12 @@ DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */,
 	}
 	BARRIER();
 	if (!tid) PROF(c, 42);
-	for (int g0 = tid; g0 < SL_SLICES; g0 += NT * SL_AHEAD) {        /* rewrite 2 (:2178-2220): every decision reads what no decision writes (scan_and_rewrite_par has the argument) */
+	for (int g0 = tid; g0 < SL_SLICES; g0 += TN * SL_AHEAD) {        /* rewrite 2 (:2178-2220): every decision reads what no decision writes (scan_and_rewrite_par has the argument) */
 		uint64_t Mk[SL_AHEAD]; uint4 vk[SL_AHEAD];
 		SL_FETCH(Mk, vk, g0);
 #pragma unroll
 		for (int k = 0; k < SL_AHEAD; k++) {
-		const int g = g0 + NT * k;
+		const int g = g0 + TN * k;
 		const uint64_t M = Mk[k];
 		if (!M) continue;
 		uint64_t p6, p0;
@@ -1460,7 +1465,7 @@ DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */,
 	}
 	BARRIER();
 	if (!tid) PROF(c, 43);
-	for (int g = tid; g < SL_SLICES; g += NT) {                     /* rewrite 3 (:2222-2252): the sign codes behind a zero run of 252 or more; a run belongs to the slice its successor is in */
+	for (int g = tid; g < SL_SLICES; g += TN) {                     /* rewrite 3 (:2222-2252): the sign codes behind a zero run of 252 or more; a run belongs to the slice its successor is in */
 		const uint64_t M = L.nz[g];
 		if (!M) continue;
 		const int p = 64 * g + __builtin_ctzll(M);
@@ -1477,7 +1482,7 @@ DEV void scan_rewrite_list_par(Ctx *c, int tid, uint8_t *lds /* SL_LDS_BYTES */,
 		if (tail_run >= 252 && b + 1 < n) fix(b + 1);
 	}
 	BARRIER();
-	for (int g = tid; g < SL_SLICES; g += NT) { c->nzs[g] = L.nz[g]; c->voff[g] = L.vo[g]; }
+	for (int g = tid; g < SL_SLICES; g += TN) { c->nzs[g] = L.nz[g]; c->voff[g] = L.vo[g]; }
 	if (!tid) PROF(c, 44);
 }
 
@@ -2534,7 +2539,7 @@ DEV void luma_p4c2_par(Ctx *c, int tid, unsigned *shm /* [NT / 64 + 1] */, int *
 DEV void luma_p4d_par(Ctx *c, int tid, int *sh_counts, uint32_t *sh_z, int16_t *lds, bool dense)
 {
 	PROF_BEGIN();
-	scan_rewrite_list_par(c, tid, reinterpret_cast<uint8_t *>(lds), sh_counts);   /* Y31 on the list (Y30: the quantiser wrote the symbols in stream order) */
+	scan_rewrite_list_par<NT>(c, tid, reinterpret_cast<uint8_t *>(lds), sh_counts);   /* Y31 on the list (Y30: the quantiser wrote the symbols in stream order) */
 	if (dense) {                                                            /* ... and on the byte stream, where a stage check reads it */
 		BARRIER();
 		scan_and_rewrite_par(c, tid, sh_counts, sh_z, lds);
