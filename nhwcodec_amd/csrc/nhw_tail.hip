@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	ctx_load(&c, ws, img);
 	if (PH == PH_L1) luma_p1_par(&c, tid, sh_pos);
 	else if (PH == PH_L2) luma_p2_par(&c, tid, dyn_lds);
-	else if (PH == PH_L3) luma_p3_par(&c, tid, sh_pos, sh_counts, dyn_lds);
+	else if (PH == PH_L3) luma_p3_par(&c, tid, sh_pos, sh_counts, dyn_lds, ws.q <= 12 || ws.dbg != 0);
 	else if (PH == PH_L4A) luma_p4a_par(&c, tid, dyn_lds);
 	else if (PH == PH_L4B) luma_p4b_par(&c, tid, sh_pos, dyn_lds);
 	else if (PH == PH_L4C) luma_p4c_par(&c, tid, sh_pos, dyn_lds, ws.q > 21 || ws.dbg);
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 	if (img >= ws.n) return;
 	Ctx c;
 	ctx_load(&c, ws, img);
-	if (PH == WV_DQ1) wave_dequant_sim_luma(&c, 1, lane, dq_lut);
-	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane, dq_lut);
+	if (PH == WV_DQ1) wave_dequant_sim_luma(&c, 1, lane, dq_lut, false);
+	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane, dq_lut, !ws.dbg);   /* production: the level-2 block straight from l2save (Y17's restore of the work plane is not made: luma_p3_par) */
 	else if (PH == WV_QUANT) {
 		__shared__ __attribute__((aligned(16))) uint8_t park[4][16 * QROW];
 		__shared__ uint32_t lut[4][QLUT + 3];

@@ -2024,7 +2024,7 @@ DEV void luma_p2_par(Ctx *c, int tid, int16_t *lds)
 	precompensate_ll1_par(c, tid, lds);
 	if (!tid) PROF(c, 3);
 }
-DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc, int16_t *lds)
+DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc, int16_t *lds, bool restore /* Y17: the level-2 block back into the work plane -- only where somebody reads it there: quality <= 12 (no second closed loop, whose dequantiser simulation is the one reader and takes the block from l2save itself) and the stage checks */)
 {
 	PROF_BEGIN();
 	if (c->compat) {
@@ -2058,7 +2058,7 @@ DEV void luma_p3_par(Ctx *c, int tid, int *pos, int *sh_misc, int16_t *lds)
 		c->l2save[Q + k] = (int16_t)(k < 4 ? c->stale[4 + 9 * W + k] : k == 4 ? 0x6011 : k < 8 ? 0 : (c->ll_bytes[2 * (k - 8)] | c->ll_bytes[2 * (k - 8) + 1] << 8));
 	}
 	BARRIER();
-	copy_block_par(c->l2save, H, c->proc, W, H, H, tid);          /* Y17 :749-755 */
+	if (restore) copy_block_par(c->l2save, H, c->proc, W, H, H, tid);          /* Y17 :749-755 */
 	BARRIER();
 	if (!tid) PROF(c, 6);
 }

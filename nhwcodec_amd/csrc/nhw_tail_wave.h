@@ -114,11 +114,11 @@ DEV int ll2_round(int v) { return (v > 0 && v < 256) ? (v & 0xFFFE) : v; }
  * ends (the row above has bumped it, its own walk has bumped it), so the untagging / rounding pass (:2697-2735)
  * is folded into the step: p = value, jp = tagged ? value : rounded value, in both loops.
  * ------------------------------------------------------------------------------------------------------------ */
-DEV void ll2_load_row(const int16_t *p, int r, int lane, int *v, M4 *tag, int q, int part, M4 *starts = nullptr)
+DEV void ll2_load_row(const int16_t *p, int r, int lane, int *v, M4 *tag, int q, int part, M4 *starts = nullptr, int ps = W /* row pitch of the plane the rows come from */)
 {
 	if (starts) *starts = m4_zero();
 	if (r >= H / 2) { v[0] = v[1] = v[2] = 0; *tag = m4_zero(); return; }
-	for (int k = 0; k < 3; k++) v[k] = p[r * W + lane + 64 * k];
+	for (int k = 0; k < 3; k++) v[k] = p[r * ps + lane + 64 * k];
 	M4 t = m4_zero();
 	if (q > 17) {                                                  /* :2609-2640 */
 		int v4[4] = { v[0], v[1], v[2], 0 };
@@ -143,20 +143,20 @@ DEV void ll2_load_row(const int16_t *p, int r, int lane, int *v, M4 *tag, int q,
 	*tag = t;
 }
 
-DEV void wave_ll2(Ctx *c, int part, int lane)
+DEV void wave_ll2(Ctx *c, int part, int lane, const int16_t *src, int ss /* where the rows are read: the work plane (pitch W), or -- second closed loop, production -- the level-2 block's copy l2save (pitch H): Y17 (nhw_encoder.c:749-755) restored the block into the work plane for this reader alone */)
 {
 	int16_t *p = c->proc, *jp = c->jpeg;
 	const int q = c->q;
 	int v0[3], v1[3], v2[3], v3[3];
 	M4 t0, t1, t2, t3;
-	ll2_load_row(p, 0, lane, v0, &t0, q, part);
-	ll2_load_row(p, 1, lane, v1, &t1, q, part);
-	ll2_load_row(p, 2, lane, v2, &t2, q, part);
-	ll2_load_row(p, 3, lane, v3, &t3, q, part);
+	ll2_load_row(src, 0, lane, v0, &t0, q, part, nullptr, ss);
+	ll2_load_row(src, 1, lane, v1, &t1, q, part, nullptr, ss);
+	ll2_load_row(src, 2, lane, v2, &t2, q, part, nullptr, ss);
+	ll2_load_row(src, 3, lane, v3, &t3, q, part, nullptr, ss);
 	const M4 ll = col_range(0, H / 2 - 1);
 	for (int r = 0; r < H / 2; r++) {
 		int vn[3]; M4 tn;
-		ll2_load_row(p, r + 4, lane, vn, &tn, q, part);
+		ll2_load_row(src, r + 4, lane, vn, &tn, q, part, nullptr, ss);
 		if (q > 17) {
 			int a0[4] = { v0[0], v0[1], v0[2], 0 }, a1[4] = { v1[0], v1[1], v1[2], 0 }, a2[4] = { v2[0], v2[1], 0, 0 }, a3[4] = { v3[0], v3[1], 0, 0 };
 			M4 o, o1, o2, o3, d2;
@@ -283,14 +283,14 @@ DEV void wave_emit_ll2(Ctx *c, int lane)
  * detail bands of offsetY_recons256 (image_processing.c:2759-3124): triple / vertical-pair marking (writes into
  * the next row), equal-sign 5..7 pairs, and the per-row dequantiser with its next-cell fix-ups.
  * ------------------------------------------------------------------------------------------------------------ */
-DEV void det_load_row(const int16_t *p, int r, int lane, int *v)
+DEV void det_load_row(const int16_t *p, int r, int lane, int *v, int ps = W)
 {
 	if (r >= H) { v[0] = v[1] = v[2] = v[3] = 0; return; }
 	const bool top = r < H / 2;                                    /* rows of the LL2 | HL2 half: only HL2 (columns >= 128) belongs to this pass */
-	v[0] = top ? 0 : p[r * W + lane];
-	v[1] = top ? 0 : p[r * W + lane + 64];
-	v[2] = p[r * W + lane + 128];
-	v[3] = p[r * W + lane + 192];
+	v[0] = top ? 0 : p[r * ps + lane];
+	v[1] = top ? 0 : p[r * ps + lane + 64];
+	v[2] = p[r * ps + lane + 128];
+	v[3] = p[r * ps + lane + 192];
 }
 
 /* columns lo..hi of a 256-column row as a lane's bit field (bit k = column lane + 64k) */
@@ -336,16 +336,16 @@ DEV unsigned dq_entry(int i)
 	if (x < -12 && ((-x) & 7) == 6) e |= DQ_AC;
 	return e;
 }
-DEV void wave_dequant_details(Ctx *c, int part, int lane, const uint32_t *lut /* DQ_WORDS, filled by the workgroup */)
+DEV void wave_dequant_details(Ctx *c, int part, int lane, const uint32_t *lut /* DQ_WORDS, filled by the workgroup */, const int16_t *src, int ss /* see wave_ll2 */)
 {
 	int16_t *p = c->proc, *jp = c->jpeg;
 	const bool hq = c->q > 16;                                     /* quality 1..16: no triple / pair marking, and negative magnitudes keep their low bits on a ration (:2938-2989) */
 	int cur[4], nxt[4], pend_v[4] = { 0, 0, 0, 0 };
 	unsigned pend = 0;                                             /* jp cells of the current row the row above has set (bit-sliced, like every row mask in here) */
 	int q0[4], q1[4], q2[4];                                       /* rows r+2 .. r+4, already on their way (a row step is shorter than a memory round trip) */
-	det_load_row(p, 0, lane, cur);
-	det_load_row(p, 1, lane, nxt);
-	det_load_row(p, 2, lane, q0); det_load_row(p, 3, lane, q1); det_load_row(p, 4, lane, q2);
+	det_load_row(src, 0, lane, cur, ss);
+	det_load_row(src, 1, lane, nxt, ss);
+	det_load_row(src, 2, lane, q0, ss); det_load_row(src, 3, lane, q1, ss); det_load_row(src, 4, lane, q2, ss);
 #define UP(b) bs_up<4>((b), lane)
 #define DN(b) bs_dn((b), lane)
 #define BIT(b, k) (((b) >> (k)) & 1u)
@@ -354,7 +354,7 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane, const uint32_t *lut /*
 	auto row_step = [&](auto k0c, const int r) {
 		constexpr int K0 = decltype(k0c)::value;
 		int far[4];
-		det_load_row(p, r + 5, lane, far);
+		det_load_row(src, r + 5, lane, far, ss);
 		const bool top = r < H / 2;
 		const int col0 = top ? H / 2 : 0;
 		int jv[4] = { pend_v[0], pend_v[1], pend_v[2], pend_v[3] };
@@ -939,11 +939,13 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 }
 
 /* offsetY_recons256 (image_processing.c:2600-3190), one wavefront per image */
-DEV void wave_dequant_sim_luma(Ctx *c, int part, int lane, const uint32_t *lut)
+DEV void wave_dequant_sim_luma(Ctx *c, int part, int lane, const uint32_t *lut, bool from_save)
 {
 	PROF_BEGIN();
-	wave_ll2(c, part, lane);
-	wave_dequant_details(c, part, lane, lut);
+	const int16_t *src = from_save ? c->l2save : c->proc;
+	const int ss = from_save ? H : W;
+	wave_ll2(c, part, lane, src, ss);
+	wave_dequant_details(c, part, lane, lut, src, ss);
 	if (!part) wave_shrink(c, lane);
 	if (!lane) PROF(c, part ? 1 : 7);
 }
