@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void k_wave(NhwWs ws)
 	if (img >= ws.n) return;
 	Ctx c;
 	ctx_load(&c, ws, img);
-	if (PH == WV_DQ1) wave_dequant_sim_luma(&c, 1, lane, dq_lut, false);
-	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane, dq_lut, !ws.dbg);   /* production: the level-2 block straight from l2save (Y17's restore of the work plane is not made: luma_p3_par) */
+	if (PH == WV_DQ1) wave_dequant_sim_luma(&c, 1, lane, dq_lut, false, ws.dbg != 0);
+	else if (PH == WV_DQ0) wave_dequant_sim_luma(&c, 0, lane, dq_lut, !ws.dbg, ws.dbg != 0);   /* production: the level-2 block straight from l2save (Y17's restore of the work plane is not made: luma_p3_par) */
 	else if (PH == WV_QUANT) {
 		__shared__ __attribute__((aligned(16))) uint8_t park[4][16 * QROW];
 		__shared__ uint32_t lut[4][QLUT + 3];

@@ -143,7 +143,7 @@ DEV void ll2_load_row(const int16_t *p, int r, int lane, int *v, M4 *tag, int q,
 	*tag = t;
 }
 
-DEV void wave_ll2(Ctx *c, int part, int lane, const int16_t *src, int ss /* where the rows are read: the work plane (pitch W), or -- second closed loop, production -- the level-2 block's copy l2save (pitch H): Y17 (nhw_encoder.c:749-755) restored the block into the work plane for this reader alone */)
+DEV void wave_ll2(Ctx *c, int part, int lane, bool keep_p, const int16_t *src, int ss /* where the rows are read: the work plane (pitch W), or -- second closed loop, production -- the level-2 block's copy l2save (pitch H): Y17 (nhw_encoder.c:749-755) restored the block into the work plane for this reader alone */)
 {
 	int16_t *p = c->proc, *jp = c->jpeg;
 	const int q = c->q;
@@ -178,7 +178,7 @@ DEV void wave_ll2(Ctx *c, int part, int lane, const int16_t *src, int ss /* wher
 		}
 		for (int k = 0; k < 2; k++) {
 			const int at = r * W + lane + 64 * k;
-			p[at] = (int16_t)v0[k];
+			if (keep_p || !part) p[at] = (int16_t)v0[k];              /* (second loop: the verbatim samples below read them back) */
 			jp[at] = (int16_t)(TB(t0, k) ? v0[k] : ll2_round(v0[k]));
 		}
 		for (int k = 0; k < 3; k++) { v0[k] = v1[k]; v1[k] = v2[k]; v2[k] = v3[k]; v3[k] = vn[k]; }
@@ -336,7 +336,7 @@ DEV unsigned dq_entry(int i)
 	if (x < -12 && ((-x) & 7) == 6) e |= DQ_AC;
 	return e;
 }
-DEV void wave_dequant_details(Ctx *c, int part, int lane, const uint32_t *lut /* DQ_WORDS, filled by the workgroup */, const int16_t *src, int ss /* see wave_ll2 */)
+DEV void wave_dequant_details(Ctx *c, int part, int lane, const uint32_t *lut /* DQ_WORDS, filled by the workgroup */, bool keep_p, const int16_t *src, int ss /* see wave_ll2 */)
 {
 	int16_t *p = c->proc, *jp = c->jpeg;
 	const bool hq = c->q > 16;                                     /* quality 1..16: no triple / pair marking, and negative magnitudes keep their low bits on a ration (:2938-2989) */
@@ -514,7 +514,7 @@ DEV void wave_dequant_details(Ctx *c, int part, int lane, const uint32_t *lut /*
 		}
 		for (int k = K0; k < 4; k++) {
 			const int at = r * W + lane + 64 * k;
-			p[at] = (int16_t)cur[k];
+			if (keep_p) p[at] = (int16_t)cur[k];
 			if (BIT(je, k)) jp[at] = (int16_t)jv[k];
 		}
 		for (int k = 0; k < 4; k++) { cur[k] = nxt[k]; nxt[k] = q0[k]; q0[k] = q1[k]; q1[k] = q2[k]; q2[k] = far[k]; }
@@ -939,13 +939,16 @@ DEV void wave_quantise_luma(Ctx *c, int lane, uint8_t *park /* 16 x QROW bytes o
 }
 
 /* offsetY_recons256 (image_processing.c:2600-3190), one wavefront per image */
-DEV void wave_dequant_sim_luma(Ctx *c, int part, int lane, const uint32_t *lut, bool from_save)
+/* keep_p: the marked coefficients go back into the work plane as the reference's in-place pass leaves them.  Nothing reads them there -- the
+ * synthesis that follows reads the dequantised plane, and the next analysis (first loop) or that synthesis (second loop) rewrites the whole
+ * block -- so production leaves these 128 KB per image and loop out; the stage checks compare the plane and keep them. */
+DEV void wave_dequant_sim_luma(Ctx *c, int part, int lane, const uint32_t *lut, bool from_save, bool keep_p)
 {
 	PROF_BEGIN();
 	const int16_t *src = from_save ? c->l2save : c->proc;
 	const int ss = from_save ? H : W;
-	wave_ll2(c, part, lane, src, ss);
-	wave_dequant_details(c, part, lane, lut, src, ss);
+	wave_ll2(c, part, lane, keep_p, src, ss);
+	wave_dequant_details(c, part, lane, lut, keep_p, src, ss);
 	if (!part) wave_shrink(c, lane);
 	if (!lane) PROF(c, part ? 1 : 7);
 }
