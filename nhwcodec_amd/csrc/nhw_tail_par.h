@@ -800,68 +800,8 @@ DEV int clean_cell(const CleanP &f, int x, int n, int v1, int v2, bool look2, in
 	}
 	return e;
 }
-/* rows r_first .. r_last of the plane, columns jb .. je-1 processed; the lanes span the 256 columns from c_base (the band's half of the row).
- * snap (mode 2): the band as it was before the pass, H wide, its row 0 = plane row H, its column 0 = plane column H. */
-template <int MODE>
-DEV void clean_rows_wave(int16_t *p, const CleanP f, int r_first, int r_last, int c_base, int jb, int je, const int16_t *snap, int tid)
-{
-	const int lane = tid & 63, wv = tid >> 6, c0 = c_base + 4 * lane;
-	const bool outer = je > c_base + H - 1;                        /* HL1: the cell behind the last processed one (column 256) is outside the span */
-	uint2 cur = make_uint2(0, 0), up = cur, dn = cur; int far = 0;
-#define CLEAN_LOAD(r) do { \
-		cur = *reinterpret_cast<const uint2 *>(p + (size_t)(r) * W + c0); \
-		if (MODE == 2 && (r) > H) up = *reinterpret_cast<const uint2 *>(snap + (size_t)((r) - H - 1) * H + c0 - H); \
-		else up = *reinterpret_cast<const uint2 *>(p + (size_t)((r) - 1) * W + c0); \
-		if (MODE == 2) dn = *reinterpret_cast<const uint2 *>(snap + (size_t)((r) - H + 1) * H + c0 - H); \
-		else dn = *reinterpret_cast<const uint2 *>(p + (size_t)((r) + 1) * W + c0); \
-		if (outer && lane == 63) far = p[(size_t)(r) * W + c_base + H]; } while (0)
-	int r = r_first + wv;
-	if (r <= r_last) CLEAN_LOAD(r);
-	for (; r <= r_last; r += NT / 64) {
-		int o[4], u[4], d[4];
-		unpack4(cur, o); unpack4(up, u); unpack4(dn, d);
-		const int my_far = far, upt = (MODE == 2 && r > H) ? 7 : 6;
-		const int row = r;
-		if (r + NT / 64 <= r_last) CLEAN_LOAD(r + NT / 64);
-		/* neighbours across the lanes: the cell on the left of my first one, the two on the right of my last one */
-		const int left = __shfl_up(o[3], 1), sd0 = __shfl_down(o[0], 1), r2 = __shfl_down(o[1], 1);   /* every lane takes part in a shuffle: lane 62 reads lane 63 */
-		const int r1 = lane < 63 ? sd0 : my_far;
-		int n[4]; bool proc[4];
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const int j = c0 + k;
-			proc[k] = j >= jb && j < je;
-			const int lv = k ? o[k - 1] : left, rv = k < 3 ? o[k + 1] : r1;
-			/* the left neighbour has been visited (HH1 zeroes below 7 there) unless it is the cell in front of the range */
-			const int lt = (MODE == 2 && j - 1 >= jb) ? 7 : 6;
-			n[k] = (iabs(lv) >= lt) + (iabs(rv) >= 6) + (iabs(u[k]) >= upt) + (iabs(d[k]) >= 6);
-		}
-		int din = 0, e[4], dout;
-		for (;;) {
-			int dd = din;
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const int j = c0 + k, x = o[k] + dd;
-				if (proc[k]) {
-					const int v1 = k < 3 ? o[k + 1] : r1, v2 = k < 2 ? o[k + 2] : (k == 2 ? r1 : r2);
-					e[k] = clean_cell<MODE>(f, x, n[k], v1, v2, j < f.last_look, dd);
-				} else { e[k] = x; dd = 0; }
-			}
-			dout = dd;
-			int nd = __shfl_up(dout, 1);
-			if (!lane) nd = 0;
-			if (!__any(nd != din)) break;
-			din = nd;
-		}
-		uint2 w;
-		w.x = (uint32_t)(uint16_t)e[0] | ((uint32_t)(uint16_t)e[1] << 16); w.y = (uint32_t)(uint16_t)e[2] | ((uint32_t)(uint16_t)e[3] << 16);
-		*reinterpret_cast<uint2 *>(p + (size_t)row * W + c0) = w;
-		if (outer && lane == 63 && dout) p[(size_t)row * W + c_base + H] = (int16_t)(my_far + dout);
-	}
-#undef CLEAN_LOAD
-}
 /* One row of Y27 for the lanes' four cells each: o = the row as it is, u / d = the rows above and below, far = the cell behind the span
- * (HL1: column 256, lane 63 only).  Returns what the last lane's ripple hands to that cell.  (The body of clean_rows_wave's row step.) */
+ * (HL1: column 256, lane 63 only).  Returns what the last lane's ripple hands to that cell.   */
 template <int MODE>
 DEV int clean_row(const CleanP &f, const int o[4], const int u[4], const int d[4], int my_far, int upt, int c0, int jb, int je, int lane, int e[4])
 {
@@ -895,7 +835,7 @@ DEV int clean_row(const CleanP &f, const int o[4], const int u[4], const int d[4
 	}
 	return dout;
 }
-/* Y27 with every row read once (round 5).  clean_details_par below gave the rows of a band to the wavefronts in turn (row r to wavefront
+/* Y27 with every row read once (round 5).  Until round 4 the rows of a band went to the wavefronts in turn (row r to wavefront
  * r mod 4), so a row's two neighbours came from memory again with it -- three reads a row -- and HH1, whose test of the row below wants that
  * row as it was BEFORE the pass, worked against a snapshot of the whole band (a copy out and a read back): 1.25 MB per image for bands that
  * weigh 0.77 MB read + written.  Here a wavefront takes 64 consecutive rows and keeps the row above, the row itself and the row below AS
@@ -956,28 +896,6 @@ DEV void clean_details_seq(Ctx *c, int tid, bool ll_in_plane /* Y26 has put the 
 		}
 	}
 }
-DEV void clean_details_par(Ctx *c, int tid, int16_t *lds)
-{
-	int16_t *p = c->proc;
-	const int q = c->q;
-	(void)lds;
-	/* (:1912-2098).  LH1 and HL1 zero everything below 6 and never move a value across 6, so "loud" (|v| >= 6) of any cell is the same
-	 * before, during and after these two passes: the vertical neighbour test does not care which row went first.  HH1 zeroes below 7, so
-	 * a 6 above (already visited in raster order) reads as quiet while a 6 below (not yet visited) reads as loud: the vertical neighbours
-	 * are taken from a snapshot of the band, ">= 7" for the row above, ">= 6" for the row below (a cell is >= 7 after its visit exactly
-	 * when it was >= 7 before).  HH1 also reads column 256, which HL1's ripple may have written, hence the barrier between them. */
-	const CleanP fa = { DEADZONE - 2, q > 22 ? 8 : 9, q > 22 ? 4 : 9, W - 2 };
-	clean_rows_wave<0>(p, fa, 1, H - 2, H, H + 1, W - 1, nullptr, tid);             /* LH1: rows 1..254, columns 257..510 */
-	const CleanP fb = { DEADZONE - 2, q > 17 ? 8 : 9, q > 22 ? 4 : 9, H - 2 };
-	clean_rows_wave<1>(p, fb, H, W - 2, 0, 1, H, nullptr, tid);                     /* HL1: rows 256..510, columns 1..255 */
-	BARRIER();
-	copy_block_par(p + H * W + H, W, c->hs, H, H, H, tid);           /* HH1 band (rows 256..511, cols 256..511) before its pass */
-	BARRIER();
-	const int lim = q > 22 ? 8 : 11;
-	const CleanP fc = { DEADZONE - 1, lim, lim, W - 2 };
-	clean_rows_wave<2>(p, fc, H, W - 2, H, H + 1, W - 1, c->hs, tid);               /* HH1: rows 256..510, columns 257..510 */
-}
-
 /* ---------------------------------------------------------------- a10 quantiser */
 /* (the luma quantiser is a wavefront-per-image kernel for every quality: wave_quantise_luma, nhw_tail_wave.h) */
 
