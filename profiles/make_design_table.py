@@ -23,6 +23,7 @@ WHAT = {
     "L4C2": "Y29 (q >= 22): band reconstruction, half synthesis, res6 / char_res1 / qsetting3 lists",
     "C0": "chroma: copy", "C2": "chroma: dequantiser simulation 1", "C3": "chroma: tags", "C4": "chroma: dequantiser simulation 2",
     "C5": "chroma: marks (running-index fixed point), LL2 emission, quantiser (wavefront per row); V leaves the merged chroma stream as a list", "LLC": "Z1 chroma LL2 coder", "FINAL": "Z2 packetiser + container",
+    "k_y31": "Y31 rewrites on the symbol LIST (non-zero map + values), 512 threads an image; leaves map and offsets in stream order",
     "k_final": "Z2 packetiser (both parts from the symbol lists) + container; a kernel of its own at four wavefronts a SIMD",
     "DQ1": "a8 dequantiser simulation, first closed loop (wavefront per image)", "DQ0": "a8 dequantiser simulation, second closed loop",
     "EMIT": "Y14/Y15 LL2 emission", "QUANT": "Y28 luma quantiser + Y30: the symbols leave as a list in stream order (wavefront per image); reads the level-2 block from l2save (Y26)",
@@ -50,7 +51,7 @@ def table():
             continue
         name = m.group(1).strip().split("(")[0]
         calls, total = int(m.group(2)), float(m.group(3))
-        key = max((k for k in pmc if len(k.strip()) > 5 and name.startswith(k.strip())), key=len, default=None)
+        key = max((k for k in pmc if len(k.strip()) >= 5 and name.startswith(k.strip())), key=len, default=None)
         rd = wr = None
         if key and "FETCH_SIZE" in pmc[key] and "WRITE_SIZE" in pmc[key]:
             rd = 2 * pmc[key]["FETCH_SIZE"]["per_launch"] * 1024 / 1e9 * calls / BATCHES

@@ -9,7 +9,7 @@ for ln in open(stats):
         continue
     name = m.group(1).strip().split("(")[0]
     calls, total = int(m.group(2)), float(m.group(3))
-    key = max((k for k in pmc if len(k.strip()) > 5 and name.startswith(k.strip())), key=len, default=None)
+    key = max((k for k in pmc if len(k.strip()) >= 5 and name.startswith(k.strip())), key=len, default=None)
     gb = None
     if key and "FETCH_SIZE" in pmc[key] and "WRITE_SIZE" in pmc[key]:
         gb = (2 * pmc[key]["FETCH_SIZE"]["per_launch"] + pmc[key]["WRITE_SIZE"]["per_launch"]) * 1024 / 1e9 * calls / nb
