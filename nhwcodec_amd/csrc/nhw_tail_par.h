@@ -709,6 +709,213 @@ DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 	}
 }
 
+
+/* ---------------------------------------------------------------- Y22 + Y23 as ONE sweep (round 5)
+ * Y23's step at (r, j) reads what Y22's step at (r, j) has just left -- the recon sample of row r (final since step r - 1), the LL1 cell of row
+ * r (the step's code, or the cell as the step before left it) and the LH1 coefficient (j, 256 + r) -- and nothing that a LATER Y22 step of any
+ * column reads: Y22 looks at its own column's rows r .. r + 2 (in registers here: ColState), at the row above only through the sign of its
+ * difference (ColState::dm1, as Y22 left it), at the coefficient before (lhm1: as Y22 left it, a register; Y23 keeps its own, vm1) and at the
+ * ORIGINAL differences of the column on its right (the tile dt, never written).  So a column thread does both steps of a row one after the
+ * other and the planes are read once: the recon plane's LL quadrant and the LL1 plane as rows (coalesced, a chunk of CR rows ahead in registers),
+ * the LH1 band through the transposing piece tile; the LL1 plane (now the code plane) and the band go back once.  The recon plane's LL
+ * quadrant is NOT written back: nothing reads it behind Y23 (Y26 or the quantiser take the level-2 block from l2save) -- except row 256, the
+ * first row of HL1, which Y22's last step reaches.
+ *
+ * What the reference's column order adds: column 255 is visited last by Y22, and (a) every column's Y22 starts from the recon sample
+ * (j, 255) as it was BEFORE that visit, every column's Y23 from the sample AFTER it; (b) column 255's "column on the right" is the LH1
+ * coefficient (x, 256) as the Y22 step 0 of column x left it minus the LL1 cell (x + 1, 0) as column 0's whole Y22 walk left it.  Hence a
+ * prologue on packed LDS copies: step 0 of every column (only the coefficient is kept), then one thread walks column 0 and column 255
+ * (2 x 255 steps); column 255's results stay in LDS (oc, rc: its cells and residuals as Y22 left them) for thread 255, which only does Y23. */
+struct ColState { int v0, o0, v1, o1, dm1; };                     /* recon sample and LL1 cell of rows r, r + 1 as the walk left them; (sample - cell) of row r - 1 */
+template <class NBF>
+__device__ __forceinline__ void classify_step_reg(const uint8_t *tab, int q, int r, ColState &cs, int v2, int o2, int &lv, int lhm1, NBF nb, int &o_fin)
+{
+	const int res = cs.v0 - cs.o0, a = cs.v1 - cs.o1, d2 = v2 - o2;
+	const int v0 = cs.v0, v1 = cs.v1;
+	int n1 = v1, below = cs.o1, n2 = v2;
+	o_fin = cs.o0;
+	int kind = classify_lookup(tab, res, a, d2);
+	if (kind >= CK_NBP && kind <= CK_PREVLE0) {                    /* the four kinds that look further: two cells of the column on the right and their sign, or the row above */
+		const int sg = (kind == CK_NBP || kind == CK_PREVGE0) ? 1 : -1;
+		bool ok;
+		if (kind <= CK_NBN) { const int x0 = sg * nb(0), x1 = sg * nb(1), x2 = sg * nb(2); ok = (x0 & ~1) == 2 && (x1 & ~1) == 2 && x2 > 0; }
+		else ok = r > 0 && sg * cs.dm1 >= 0;
+		kind = ok ? (sg > 0 ? CK_MARKP : CK_MARKN) : CK_NONE;
+	}
+	if (kind != CK_NONE) {
+		const uint32_t aw = reinterpret_cast<const uint32_t *>(tab + CK_ACT_OFF)[kind];
+		const int code = (int)(aw & 0xFFFF);
+		if (code) o_fin = code;
+		if (q == 18) { const int nx = (int)(aw >> 23) & 3; if (nx) below = nx == 1 ? 14100 : 14000; }
+		n1 = (int16_t)(((aw >> 22) & 1) ? below : v1 + (int)((aw >> 16) & 7) - 2); n2 = (int16_t)(v2 + (int)((aw >> 19) & 7) - 2);
+		const int rule = (int)(aw >> 25);
+		if (rule) {
+			const int bc = (lhm1 < -9 ? -9 : lhm1 > 8 ? 8 : lhm1) + 9;
+			lv = (int16_t)(lv + reinterpret_cast<const int8_t *>(tab + CK_LHT_OFF)[__mul24(__mul24(rule - 1, 9) + lh_class(lv), 18) + bc]);
+		}
+	}
+	cs = ColState{ n1, below, n2, o2, v0 - o_fin };
+}
+/* Y23's step (:1329-1420): pv the recon sample, cell the LL1 cell as Y22 left it, lv the LH1 coefficient (j, 256 + r), vm1 the one before as
+ * THIS walk left it; returns what the cell becomes */
+__device__ __forceinline__ int code_step_reg(int q, int res_setting, int pv, int cell, int &lv, int vm1)
+{
+	if (cell < 12000) {
+		const int res = pv - cell;
+		int out = 0;
+		if (!res || res == 1) { if (lv == -7 || lv == -8) { if (vm1 < 2 && vm1 > -8) lv = -9; } }
+		else if (res == 2) {
+			if (lv > 15 && !(lv & 7)) lv--;
+			else if (lv == -7 || lv == -8) { if (vm1 <= 1) lv = -9; }
+			else if (lv == -6) { if (vm1 <= -1 && vm1 > -8) lv = -9; }
+		}
+		else if (res == 3) {
+			if (q >= 21) out = 144;
+			else if (lv > 15 && !(lv & 7)) lv--;
+			else if (lv <= 0 && (((-lv) + 2) & 0xFFFC) == 8) { if (vm1 <= 2) lv = -10; }
+		}
+		else if (res > res_setting) {
+			out = 141;
+			if (res == 4) { if (lv == 7 || (lv & 0xFFFE) == 8) { if (vm1 >= 0 && vm1 < 8) lv += 2; } }
+			else if (res > 6) {
+				if (res > 7 && q >= 21) out = 148;
+				else if (lv > 15 && !(lv & 7)) lv--;
+				else if (lv == -6 || lv == -7 || lv == -8) { if (vm1 < 0 && vm1 > -8) lv = -9; }
+			}
+		}
+		return out;
+	}
+	switch (cell) {
+	case 14000: return 140; case 14500: return 145; case 12200: return 122; case 12100: return 121; case 12300: return 123;
+	case 12400: return 124; case 14100: return 141; case 12500: return 125; case 12600: return 126; case 14900: return 149;
+	default: return cell;
+	}
+}
+/* LDS: the row tiles ot (LL1 cells) and dt (recon - LL1, as loaded) of rows r0 .. r0 + CR + 1, the cells a chunk's steps leave (two buffers: a
+ * chunk's go out while the next one's are made), the LH1 piece tile, the tables, column 255 as Y22 left it.  Seven workgroups a CU. */
+#define RF_LDS_BYTES ((2 * (CR + 2) * H + 2 * CR * H + H * LP) * 2 + CK_TABLE_BYTES + 3 * H)
+DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
+{
+	PROF_BEGIN();
+	static_assert(NT == H && CR == 4 && LW % CR == 0, "a thread a column; a chunk's four new rows are one 8-byte item a thread");
+	int16_t *p = c->proc, *o = c->ll1;
+	const int q = c->q, j = tid;
+	int16_t *ot = lds, *dt = lds + (CR + 2) * H, *cb = lds + 2 * (CR + 2) * H, *lt = cb + 2 * CR * H;
+	uint8_t *ktab = reinterpret_cast<uint8_t *>(lt + H * LP);
+	int16_t *oc = reinterpret_cast<int16_t *>(ktab + CK_TABLE_BYTES);   /* [H]: column 255's LL1 cells as Y22 left them */
+	int8_t *rc = reinterpret_cast<int8_t *>(oc + H);                    /* [H]: its residuals (recon - cell) as Y22 left them, held to -128 .. 127 (Y23 compares with 0 .. 8) */
+	classify_table_fill(ktab, q, res_setting, tid);
+	int lhm1, vm1, hl0_255 = 0;
+	{                                                              /* ---- prologue, on packed copies in the tiles' space (4376 of its 5120 shorts) */
+		int16_t *pc0 = lds, *oc0 = lds + 260, *d1 = lds + 520, *lc0 = lds + 780, *pc = lds + 1036, *ocs = lds + 1296, *lc = lds + 1556, *l0 = lds + 1812;
+		int16_t *pt3 = lds + 2072, *ot3 = pt3 + 3 * H, *dt3 = ot3 + 3 * H;
+		for (int t = tid; t < H + 2; t += NT) {                     /* columns 0, 1 and 255 of both planes, rows 0 .. 257 (256, 257 of ll1: its zero guard) */
+			const int a0 = p[t * W], b0 = o[t * H];
+			pc0[t] = (int16_t)a0; oc0[t] = (int16_t)b0; d1[t] = (int16_t)(p[t * W + 1] - o[t * H + 1]);
+			pc[t] = p[t * W + H - 1]; ocs[t] = o[t * H + H - 1];
+		}
+		lc0[tid] = p[H + tid]; lc[tid] = p[(H - 1) * W + H + tid];  /* the LH1 coefficients of columns 0 and 255: rows 0 and 255 of the band */
+		l0[tid] = p[tid * W + H];                                   /* (x, 256): the coefficient of column x's row 0 */
+		if (tid == 0) l0[H] = p[H * W + H];
+		if (tid < 3 * (H / 8)) {
+			const int i = tid / (H / 8), c8 = 8 * (tid % (H / 8));
+			const uint4 pv = *reinterpret_cast<const uint4 *>(p + i * W + c8), ov = *reinterpret_cast<const uint4 *>(o + i * H + c8);
+			*reinterpret_cast<uint4 *>(pt3 + i * H + c8) = pv; *reinterpret_cast<uint4 *>(ot3 + i * H + c8) = ov;
+			const uint32_t a[4] = { pv.x, pv.y, pv.z, pv.w }, b[4] = { ov.x, ov.y, ov.z, ov.w };
+			uint32_t d[4];
+			for (int e = 0; e < 4; e++) d[e] = ((a[e] - b[e]) & 0xFFFF) | (((a[e] >> 16) - (b[e] >> 16)) << 16);
+			*reinterpret_cast<uint4 *>(dt3 + i * H + c8) = make_uint4(d[0], d[1], d[2], d[3]);
+		}
+		lhm1 = p[j * W + H - 1];                                    /* (j, 255): column 255 has not been visited */
+		BARRIER();
+		if (j < H - 1) {                                            /* step 0 of every column: column 255 reads the coefficient it leaves */
+			ColState cs{ pt3[j], ot3[j], pt3[H + j], ot3[H + j], 0 };
+			int lv = l0[j], of;
+			classify_step_reg(ktab, q, 0, cs, pt3[2 * H + j], ot3[2 * H + j], lv, lhm1, [&](int dr) { return (int)dt3[dr * H + j + 1]; }, of);
+			l0[j] = (int16_t)lv;
+		}
+		BARRIER();
+		if (tid == 0) {
+			{                                                       /* column 0, whole: column 255 reads its LL1 cells */
+				ColState cs{ pc0[0], oc0[0], pc0[1], oc0[1], 0 };
+				int prev = pc[0];
+				for (int r = 0; r < H - 1; r++) {
+					int lv = lc0[r], of;
+					classify_step_reg(ktab, q, r, cs, pc0[r + 2], oc0[r + 2], lv, prev, [&](int dr) { return (int)d1[r + dr]; }, of);
+					oc0[r] = (int16_t)of; prev = lv;
+				}
+				oc0[H - 1] = (int16_t)cs.o0;
+			}
+			{                                                       /* column 255: its neighbour is (x, 256) - (x + 1, 0), both as left above */
+				ColState cs{ pc[0], ocs[0], pc[1], ocs[1], 0 };
+				int prev = pc[H - 1];
+				for (int r = 0; r < H - 1; r++) {
+					int lv = lc[r], of;
+					const int v0 = cs.v0;
+					classify_step_reg(ktab, q, r, cs, pc[r + 2], ocs[r + 2], lv, prev, [&](int dr) { return (int)l0[r + dr] - (int)oc0[r + dr + 1]; }, of);
+					lc[r] = (int16_t)lv; prev = lv;
+					if (r == 0) l0[H - 1] = (int16_t)lv;              /* (255, 256) is also this column's neighbour of row 255 */
+					pc[r] = (int16_t)v0; oc[r] = (int16_t)of;
+					rc[r] = (int8_t)(cs.dm1 < -128 ? -128 : cs.dm1 > 127 ? 127 : cs.dm1);
+				}
+				const int dl = cs.v0 - cs.o0;
+				pc[H - 1] = (int16_t)cs.v0; oc[H - 1] = (int16_t)cs.o0; rc[H - 1] = (int8_t)(dl < -128 ? -128 : dl > 127 ? 127 : dl);
+				hl0_255 = cs.v1;
+			}
+		}
+		BARRIER();
+		vm1 = pc[j];                                                /* (j, 255) as column 255's walk left it: where Y23 starts */
+		p[(H - 1) * W + H + tid] = lc[tid];                         /* column 255's coefficients, for the piece tile */
+		BARRIER();
+	}
+	if (!tid) PROF(c, 10);
+	/* ---- the sweep */
+	const int pi = tid >> 6, pc4 = 4 * (tid & 63);                  /* my 8-byte item of a chunk's four new rows */
+	auto fetch = [&](int row, uint2 &pv, uint2 &ov) { pv = *reinterpret_cast<const uint2 *>(p + row * W + pc4); ov = *reinterpret_cast<const uint2 *>(o + row * H + pc4); };
+	auto put = [&](int slot, uint2 pv, uint2 ov) {
+		*reinterpret_cast<uint2 *>(ot + slot * H + pc4) = ov;
+		*reinterpret_cast<uint2 *>(dt + slot * H + pc4) = make_uint2(((pv.x - ov.x) & 0xFFFF) | (((pv.x >> 16) - (ov.x >> 16)) << 16), ((pv.y - ov.y) & 0xFFFF) | (((pv.y >> 16) - (ov.y >> 16)) << 16));
+	};
+	uint2 kp = make_uint2(0, 0), ko = kp, np, no;
+	if (pi >= 2) fetch(pi - 2, kp, ko);                             /* rows 0, 1 */
+	fetch(2 + pi, np, no);                                          /* rows 2 .. 5 */
+	ColState cs{ 0, 0, 0, 0, 0 };
+	for (int r0 = 0, buf = 0; r0 < H; r0 += CR, buf ^= 1) {
+		if (pi >= 2) put(pi - 2, kp, ko);                           /* the chunk's first two rows: the last two the chunk before brought */
+		put(2 + pi, np, no);
+		kp = np; ko = no;
+		if (r0 + CR < H) fetch(r0 + CR + 2 + pi, np, no);           /* the next chunk's rows are on their way while this one's columns step (up to row 257: see classify_residuals_par) */
+		if (r0 % LW == 0) lh_tile_load(lt, p, r0, tid);
+		BARRIER();
+		if (r0 == 0) cs = ColState{ (int16_t)(dt[j] + ot[j]), ot[j], (int16_t)(dt[H + j] + ot[H + j]), ot[H + j], 0 };
+		int16_t *cbb = cb + buf * CR * H;
+#pragma unroll
+		for (int i = 0; i < CR; i++) {
+			const int r = r0 + i;
+			int16_t *lh = lt + j * LP + r0 % LW + i;
+			int lv = *lh, cell, pv;
+			if (j < H - 1) {
+				pv = cs.v0;
+				if (r < H - 1) {
+					const int o2 = ot[(i + 2) * H + j], v2 = (int16_t)(dt[(i + 2) * H + j] + o2);
+					classify_step_reg(ktab, q, r, cs, v2, o2, lv, lhm1, [&](int dr) { return (int)dt[(i + dr) * H + j + 1]; }, cell);
+					lhm1 = lv;
+					if (r == H - 2) p[H * W + j] = (int16_t)cs.v1;        /* the last step's second sample is row 256: the first row of HL1 (the reference's walk leaves its quadrant there) */
+				} else cell = cs.o0;
+			} else { cell = oc[r]; pv = cell + rc[r]; }
+			const int out = code_step_reg(q, res_setting, pv, cell, lv, vm1);
+			vm1 = lv;
+			cbb[i * H + j] = (int16_t)out; *lh = (int16_t)lv;
+		}
+		BARRIER();
+		*reinterpret_cast<uint2 *>(o + (r0 + pi) * H + pc4) = *reinterpret_cast<const uint2 *>(cbb + pi * H + pc4);
+		if ((r0 + CR) % LW == 0) lh_tile_store(lt, p, r0 + CR - LW, tid);
+	}
+	if (tid == 0) p[H * W + H - 1] = (int16_t)hl0_255;             /* (column 255's, kept until here: row 256 is column 254's neighbour as it was) */
+	BARRIER();
+	if (!tid) PROF(c, 11);
+}
+
 /* Y24 (nhw_encoder.c:1426-1496): every code of the code plane adds a constant to one, two or three consecutive cells of the first-order
  * plane, linearly indexed, transposed: code (r, j) to cells j * 256 + r .. */
 /* The adds commute, so the pass is a gather: cell x = j * 256 + c of the first-order plane takes A0(code(c, j)) + A1(code(c - 1, j)) +
@@ -2209,11 +2416,15 @@ DEV void luma_p4a_par(Ctx *c, int tid, int16_t *lds)
 	if (!tid) PROF(c, 9);
 	if (q <= 12) return;                                                    /* no second closed loop, no residual lists (:1081, :1498) */
 	const int res_setting = q >= 20 ? 3 : q >= 18 ? 4 : q >= 15 ? 6 : 8;    /* :1075-1079 */
+#ifdef NHW_Y22_Y23_SPLIT
 	classify_residuals_par(c, res_setting, tid, lds);                       /* Y22 */
 	if (!tid) PROF(c, 10);
 	code_residuals_par(c, res_setting, tid, lds);                           /* Y23 */
 	BARRIER();
 	if (!tid) PROF(c, 11);
+#else
+	residuals_fused_par(c, res_setting, tid, lds);                          /* Y22 + Y23 */
+#endif
 }
 DEV void luma_p4b_par(Ctx *c, int tid, int *pos, int16_t *lds)
 {
