@@ -263,11 +263,7 @@ static size_t phase_lds(int ph)
 	case PH_L3: return LL_LDS_BYTES;
 	case PH_LLC: return LLC_LDS_BYTES;
 	case PH_FINAL: return PK_LDS_BYTES;
-#ifdef NHW_Y22_Y23_SPLIT
-	case PH_L4A: return CR_LDS_BYTES > (NT + 2) * TLS * sizeof(int16_t) ? CR_LDS_BYTES : (size_t)(NT + 2) * TLS * sizeof(int16_t);
-#else
 	case PH_L4A: return RF_LDS_BYTES > (NT + 2) * TLS * sizeof(int16_t) ? RF_LDS_BYTES : (size_t)(NT + 2) * TLS * sizeof(int16_t);
-#endif
 	case PH_L4B: return (size_t)(NT + 2) * TLS * sizeof(int16_t);
 	case PH_L4C: return 0;                                         /* Y26 is pointwise, Y27 a wavefront per row straight on the plane */
 	case PH_L4D: return SL_LDS_BYTES;                              /* Y31 on the symbol list: the non-zero map and the slices' value offsets in stream order (the dense form of the stage checks: 4608 bytes of them for its list of run starts) */

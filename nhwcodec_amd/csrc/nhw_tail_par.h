@@ -361,7 +361,7 @@ enum { CK_NONE, CK_MARKP, CK_MARKN, CK_S12100, CK_S12500, CK_S12200, CK_S12600, 
 #define CK_ACT_OFF CK_CLASS_BYTES
 #define CK_LHT_OFF (CK_ACT_OFF + 4 * CK_KINDS)
 #define CK_LH_RULES 5
-#define CK_TABLE_BYTES ((CK_LHT_OFF + CK_LH_RULES * 9 * 18 + 3) & ~3)
+#define CK_TABLE_BYTES ((CK_LHT_OFF + (CK_LH_RULES + 1) * 9 * 18 + 3) & ~3)   /* (rule 0: a row of zeros, so that the step needs no branch) */
 DEV int classify_kind(int q, int res_setting, int res, int a, int d2)
 {
 	if (res == 2 && a == 2 && d2 >= 2) return (d2 < 5 || d2 > 6) ? CK_MARKP : CK_NONE;
@@ -479,8 +479,8 @@ DEV void classify_table_fill(uint8_t *tab, int q, int res_setting, int tid)
 		tab[idx] = (uint8_t)classify_kind(q, res_setting, rc - 9, a, dc - 4);
 	}
 	if (tid < CK_KINDS) reinterpret_cast<uint32_t *>(tab + CK_ACT_OFF)[tid] = classify_action(tid, q);
-	for (int idx = tid; idx < CK_LH_RULES * 9 * 18; idx += NT) {
-		const int rule = idx / (9 * 18) + 1, lc = (idx / 18) % 9, before = idx % 18 - 9;
+	for (int idx = tid; idx < (CK_LH_RULES + 1) * 9 * 18; idx += NT) {
+		const int rule = idx / (9 * 18), lc = (idx / 18) % 9, before = idx % 18 - 9;
 		const int v = lc == 0 ? 0 : lc == 1 ? -16 : lc == 8 ? 15 : lc < 4 ? lc - 10 : lc + 2;   /* one coefficient of the class */
 		reinterpret_cast<int8_t *>(tab + CK_LHT_OFF)[idx] = (int8_t)(lh_rule(rule, v, before) - v);
 	}
@@ -492,65 +492,13 @@ DEV int classify_lookup(const uint8_t *tab, int res, int a, int d2)
 	return tab[__mul24(__mul24(rc, 9) + ac, 12) + dc];
 }
 
-/* the step itself.  pr / orow point at the column's recon sample / LL1 cell of row r (row strides ps / os: the planes
- * themselves, an LDS tile, or a packed copy of the column), lh at the LH1 coefficient the step may nudge, lhm1 is the
- * one before it (as this walk left it).  sp / so: where the right-hand neighbour column is read (the values from
- * before the pass). */
-/* the column's three cells the step looks at travel in registers from step to step (what a step writes is what the next one would read
- * back): recon sample and LL1 cell of rows r, r+1 (the step loads those of row r+2) */
-struct ColCells { int v0, o0, v1, o1; };
-DEV ColCells col_cells(const int16_t *pr, int ps, const int16_t *orow, int os) { return ColCells{ pr[0], orow[0], pr[ps], orow[os] }; }
-template <bool NB_TILE>
-DEV int classify_step(const uint8_t *tab, int q, int r, int j, int16_t *pr, int ps, int16_t *orow, int os, int16_t *lh, int lhm1,
-                      const int16_t *sp, int sp_row, const int16_t *so, int so_rows, ColCells &cc)
-{
-	const int v2 = pr[2 * ps], o2 = orow[2 * os];
-	int lv = lh[0];                                                /* returned: the coefficient as the step leaves it */
-	const int res = cc.v0 - cc.o0, a = cc.v1 - cc.o1, d2 = v2 - o2;
-	const int v1 = cc.v1, o1 = cc.o1;
-	cc = ColCells{ v1, o1, v2, o2 };                               /* a step that does nothing */
-	/* NB_TILE: sp points at the neighbour's (recon - ll1) difference of row r, as it was before the pass, row stride sp_row */
-#define NB(dr) (NB_TILE ? (int)sp[(dr) * sp_row] : (sp[(r + (dr)) * sp_row + j + 1] - ((r + (dr)) < so_rows ? so[(r + (dr)) * H + j + 1] : 0)))
-	int kind = classify_lookup(tab, res, a, d2);
-	if (kind == CK_NONE) return lv;
-	if (kind >= CK_NBP && kind <= CK_PREVLE0) {                    /* the four kinds that look further: two cells of the column on the right and their sign, or the row above */
-		const int sg = (kind == CK_NBP || kind == CK_PREVGE0) ? 1 : -1;
-		bool ok;
-		if (kind <= CK_NBN) { const int x0 = sg * NB(0), x1 = sg * NB(1), x2 = sg * NB(2); ok = (x0 & ~1) == 2 && (x1 & ~1) == 2 && x2 > 0; }
-		else ok = r > 0 && sg * (pr[-ps] - orow[-os]) >= 0;
-		if (!ok) return lv;
-		kind = sg > 0 ? CK_MARKP : CK_MARKN;
-	}
-	const uint32_t aw = reinterpret_cast<const uint32_t *>(tab + CK_ACT_OFF)[kind];
-	const int code = (int)(aw & 0xFFFF);
-	if (code) orow[0] = (int16_t)code;
-	int below = o1;                                                /* the LL1 cell one row down */
-	if (q == 18) { const int nx = (int)(aw >> 23) & 3; if (nx) { below = nx == 1 ? 14100 : 14000; orow[os] = (int16_t)below; } }
-	const int n1 = (int16_t)(((aw >> 22) & 1) ? below : v1 + (int)((aw >> 16) & 7) - 2), n2 = (int16_t)(v2 + (int)((aw >> 19) & 7) - 2);
-	pr[ps] = (int16_t)n1; pr[2 * ps] = (int16_t)n2;
-	cc = ColCells{ n1, below, n2, o2 };
-	const int rule = (int)(aw >> 25);
-	if (rule) {
-		const int bc = (lhm1 < -9 ? -9 : lhm1 > 8 ? 8 : lhm1) + 9;
-		lv = (int16_t)(lv + reinterpret_cast<const int8_t *>(tab + CK_LHT_OFF)[__mul24(__mul24(rule - 1, 9) + lh_class(lv), 18) + bc]);
-		lh[0] = (int16_t)lv;
-	}
-	return lv;
-#undef NB
-}
-
-/* Y22.  The reference walks column after column; column j only reads column j+1 (not yet visited, i.e. its
- * original values) and the recon sample (j,255) of the last column.  Columns 0..254 therefore run in parallel,
- * one thread each.  A column's walk is a chain (a step rewrites the two samples below it and reads what the
- * step before left), so it runs on LDS: per chunk of CR rows every thread copies its own column's samples and
- * LL1 cells into a tile (coalesced, no barrier needed for those), the LH1 coefficients -- row j of the plane for
- * column j -- come through a transposing tile.  What a column reads of its right-hand neighbour is the
- * difference recon - ll1 from before the pass: a third tile, filled from the values as loaded (a chunk's rows
- * from the third on are still untouched; the first three are carried over from the chunk before).  Column 255
- * runs afterwards on a packed LDS copy of its column: its "column 256" is the LH1 column written by the other
- * columns, its ll1 neighbour is column 0, both read live. */
+/* Y22 (:1077-1325).  The reference walks column after column; column j only reads column j+1 (not yet visited, i.e. its original values)
+ * and the recon sample (j, 255) of the last column.  Columns 0..254 therefore run in parallel, one thread each; a column's walk is a chain
+ * (a step rewrites the two samples below it and reads what the step before left).  The planes come as rows through LDS tiles, a chunk of
+ * CR rows at a time; the LH1 coefficients -- row j of the plane for column j -- through a transposing piece tile.  Until round 5 Y22 and
+ * Y23 were two sweeps (column 255 in between, on a packed copy); now one: residuals_fused_par. */
 #ifndef CR
-#define CR 4      /* rows per chunk: 22 KB of LDS, seven workgroups per CU (measured, ms per 4096-image batch: CR 2: 3.78, 4: 3.40, 8: 3.71, 16: 4.00) */
+#define CR 4      /* rows per chunk (measured on the two-sweep form, ms per 4096-image batch: CR 2: 3.78, 4: 3.40, 8: 3.71, 16: 4.00) */
 #endif
 /* The LH1 coefficients of column j are row j of the plane, LW of them at a time for all 256 rows: whole 64-byte pieces of every row
  * (a piece per chunk of rows is a few bytes of a line that has left the L2 again when the next chunk asks for its neighbour -- measured
@@ -559,7 +507,6 @@ DEV int classify_step(const uint8_t *tab, int q, int r, int j, int16_t *pr, int 
 #define LW 16     /* shorts of an LH1 line a tile holds (32 bytes; measured again in round 5 with 64 and 128 bytes: DESIGN 4.3) */
 #endif
 #define LP (LW + 2)
-#define CR_LDS_BYTES (((CR + 3) * 3 * H + H * LP) * 2 + CK_TABLE_BYTES)
 DEV void lh_tile_load(int16_t *lt, const int16_t *p, int r0, int tid)
 {
 	for (int v = tid; v < H * (LW / 8); v += NT) {
@@ -577,139 +524,6 @@ DEV void lh_tile_store(const int16_t *lt, int16_t *p, int r0, int tid)
 		*reinterpret_cast<uint4 *>(p + jj * W + H + r0 + 8 * h) = make_uint4(d[0], d[1], d[2], d[3]);
 	}
 }
-DEV void classify_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
-{
-	int16_t *p = c->proc, *o = c->ll1;
-	const int q = c->q;
-	int16_t *pt = lds, *ot = lds + (CR + 3) * H, *dt = lds + 2 * (CR + 3) * H, *lt = lds + 3 * (CR + 3) * H;   /* pt/ot/dt: rows r0-1 .. r0+CR+1; lt: [column][LP] */
-	uint8_t *ktab = reinterpret_cast<uint8_t *>(lds + 3 * (CR + 3) * H + H * LP);
-	classify_table_fill(ktab, q, res_setting, tid);
-	const int j = tid;
-	int lhm1 = p[j * W + H - 1];                                    /* (j, 255): nothing has touched it yet */
-	for (int r0 = 0; r0 < H - 1; r0 += CR) {
-		if (r0) {                                                   /* the first three rows are the last three of the chunk before: samples and cells as its steps left them, differences as loaded */
-			uint4 kd = make_uint4(0, 0, 0, 0), kp = kd, ko = kd;
-			if (tid < 3 * (H / 8)) { kd = reinterpret_cast<const uint4 *>(dt + CR * H)[tid]; kp = reinterpret_cast<const uint4 *>(pt + CR * H)[tid]; ko = reinterpret_cast<const uint4 *>(ot + CR * H)[tid]; }
-			BARRIER();
-			if (tid < 3 * (H / 8)) { reinterpret_cast<uint4 *>(dt)[tid] = kd; reinterpret_cast<uint4 *>(pt)[tid] = kp; reinterpret_cast<uint4 *>(ot)[tid] = ko; }
-		}
-		for (int v = tid + (r0 ? 3 * (H / 8) : 0); v < (CR + 3) * (H / 8); v += NT) {   /* 8 columns of one row per access */
-			const int i = v / (H / 8), c8 = 8 * (v % (H / 8)), row = r0 - 1 + i;
-			uint4 pv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
-			if (row >= 0) { pv = *reinterpret_cast<const uint4 *>(p + row * W + c8); ov = *reinterpret_cast<const uint4 *>(o + row * H + c8); }   /* rows 256, 257 of ll1 lie in its zero guard */
-			*reinterpret_cast<uint4 *>(pt + i * H + c8) = pv;
-			*reinterpret_cast<uint4 *>(ot + i * H + c8) = ov;
-			const uint32_t a[4] = { pv.x, pv.y, pv.z, pv.w }, b[4] = { ov.x, ov.y, ov.z, ov.w };
-			uint32_t d[4];
-			for (int e = 0; e < 4; e++) d[e] = ((a[e] - b[e]) & 0xFFFF) | (((a[e] >> 16) - (b[e] >> 16)) << 16);
-			*reinterpret_cast<uint4 *>(dt + i * H + c8) = make_uint4(d[0], d[1], d[2], d[3]);
-		}
-		if (r0 % LW == 0) lh_tile_load(lt, p, r0, tid);
-		BARRIER();
-		if (j < H - 1) {
-			ColCells cc = col_cells(pt + H + j, H, ot + H + j, H);
-			for (int i = 0; i < CR && r0 + i < H - 1; i++)
-				lhm1 = classify_step<true>(ktab, q, r0 + i, j, pt + (i + 1) * H + j, H, ot + (i + 1) * H + j, H, lt + j * LP + r0 % LW + i, lhm1, dt + (i + 1) * H + j + 1, H, nullptr, 0, cc);
-		}
-		BARRIER();
-		for (int v = tid; v < (r0 + CR < H - 1 ? CR : CR + 2) * (H / 8); v += NT) {   /* the rows this chunk is through with (the last two go on to the next one in LDS); column 255 travels too, unchanged */
-			const int i = 1 + v / (H / 8), c8 = 8 * (v % (H / 8)), row = r0 - 1 + i;
-			*reinterpret_cast<uint4 *>(p + row * W + c8) = *reinterpret_cast<const uint4 *>(pt + i * H + c8);
-			if (row < H) *reinterpret_cast<uint4 *>(o + row * H + c8) = *reinterpret_cast<const uint4 *>(ot + i * H + c8);
-		}
-		if ((r0 + CR) % LW == 0) lh_tile_store(lt, p, r0 + CR - LW, tid);
-		BARRIER();
-	}
-	{                                                              /* column 255 */
-		int16_t *pc = lds, *oc = lds + H + 8, *lc = lds + 2 * (H + 8);
-		for (int t = tid; t < H + 2; t += NT) { pc[t] = p[t * W + H - 1]; oc[t] = o[t * H + H - 1];   /* rows 256, 257: the guard behind ll1 */ }
-		lc[tid] = p[(H - 1) * W + H + tid];
-		BARRIER();
-		if (tid == 0) {
-			int prev = p[(H - 1) * W + H - 1];
-			ColCells cc = col_cells(pc, 1, oc, 1);
-			for (int r = 0; r < H - 1; r++) {
-				prev = classify_step<false>(ktab, q, r, H - 1, pc + r, 1, oc + r, 1, lc + r, prev, p, W, o, 1 << 30, cc);
-				if (r == 0) p[(H - 1) * W + H] = lc[0];                /* (255, 256) is also this column's "column 256" neighbour of row 255 */
-			}
-		}
-		BARRIER();
-		for (int t = tid; t < H + 2; t += NT) { p[t * W + H - 1] = pc[t]; if (t < H) o[t * H + H - 1] = oc[t]; }
-		p[(H - 1) * W + H + tid] = lc[tid];
-	}
-	BARRIER();
-}
-
-/* Y23 (:1329-1420): cell (r,j) touches its own ll1 cell and the LH1 coefficient (j, 256+r), and reads
- * (j, 256+r-1), which the same column wrote one step earlier: one thread per column, serial in r, on the same
- * LDS tiles as Y22. */
-DEV void code_residuals_par(Ctx *c, int res_setting, int tid, int16_t *lds)
-{
-	int16_t *p = c->proc, *o = c->ll1;
-	const int q = c->q, j = tid;
-	/* eight rows a turn (Y22 takes four: it carries three more in three tiles): the two tiles fit in front of the LH1 piece as Y22 leaves it, and
-	 * a turn is three barriers and one wait for the rows whatever its size */
-	constexpr int CR2 = 8;
-	static_assert(2 * CR2 <= 3 * (CR + 3) && LW % CR2 == 0, "Y23's tiles lie in front of the LH1 piece");
-	int16_t *pt = lds, *ot = lds + CR2 * H, *lt = lds + 3 * (CR + 3) * H;
-	int vm1 = p[j * W + H - 1];
-	for (int r0 = 0; r0 < H; r0 += CR2) {
-		for (int v = tid; v < CR2 * (H / 8); v += NT) {
-			const int i = v / (H / 8), c8 = 8 * (v % (H / 8));
-			*reinterpret_cast<uint4 *>(pt + i * H + c8) = *reinterpret_cast<const uint4 *>(p + (r0 + i) * W + c8);
-			*reinterpret_cast<uint4 *>(ot + i * H + c8) = *reinterpret_cast<const uint4 *>(o + (r0 + i) * H + c8);
-		}
-		if (r0 % LW == 0) lh_tile_load(lt, p, r0, tid);
-		BARRIER();
-		for (int i = 0; i < CR2; i++) {
-			int16_t *cell = ot + i * H + j;
-			int16_t *v = lt + j * LP + r0 % LW + i;
-			if (*cell < 12000) {
-				const int res = pt[i * H + j] - *cell;
-				*cell = 0;
-				if (!res || res == 1) { if (v[0] == -7 || v[0] == -8) { if (vm1 < 2 && vm1 > -8) v[0] = -9; } }
-				else if (res == 2) {
-					if (v[0] > 15 && !(v[0] & 7)) v[0]--;
-					else if (v[0] == -7 || v[0] == -8) { if (vm1 <= 1) v[0] = -9; }
-					else if (v[0] == -6) { if (vm1 <= -1 && vm1 > -8) v[0] = -9; }
-				}
-				else if (res == 3) {
-					if (q >= 21) *cell = 144;
-					else if (v[0] > 15 && !(v[0] & 7)) v[0]--;
-					else if (v[0] <= 0 && (((-v[0]) + 2) & 0xFFFC) == 8) { if (vm1 <= 2) v[0] = -10; }
-				}
-				else if (res > res_setting) {
-					*cell = 141;
-					if (res == 4) { if (v[0] == 7 || (v[0] & 0xFFFE) == 8) { if (vm1 >= 0 && vm1 < 8) v[0] += 2; } }
-					else if (res > 6) {
-						if (res > 7 && q >= 21) *cell = 148;
-						else if (v[0] > 15 && !(v[0] & 7)) v[0]--;
-						else if (v[0] == -6 || v[0] == -7 || v[0] == -8) { if (vm1 < 0 && vm1 > -8) v[0] = -9; }
-					}
-				}
-			} else {
-				switch (*cell) {
-				case 14000: *cell = 140; break; case 14500: *cell = 145; break;
-				case 12200: *cell = 122; break; case 12100: *cell = 121; break;
-				case 12300: *cell = 123; break; case 12400: *cell = 124; break;
-				case 14100: *cell = 141; break; case 12500: *cell = 125; break;
-				case 12600: *cell = 126; break; case 14900: *cell = 149; break;
-				default: break;
-				}
-			}
-			vm1 = v[0];
-		}
-		BARRIER();
-		for (int v = tid; v < CR2 * (H / 8); v += NT) {
-			const int i = v / (H / 8), c8 = 8 * (v % (H / 8));
-			*reinterpret_cast<uint4 *>(o + (r0 + i) * H + c8) = *reinterpret_cast<const uint4 *>(ot + i * H + c8);
-		}
-		if ((r0 + CR2) % LW == 0) lh_tile_store(lt, p, r0 + CR2 - LW, tid);
-		BARRIER();
-	}
-}
-
-
 /* ---------------------------------------------------------------- Y22 + Y23 as ONE sweep (round 5)
  * Y23's step at (r, j) reads what Y22's step at (r, j) has just left -- the recon sample of row r (final since step r - 1), the LL1 cell of row
  * r (the step's code, or the cell as the step before left it) and the LH1 coefficient (j, 256 + r) -- and nothing that a LATER Y22 step of any
@@ -732,7 +546,7 @@ __device__ __forceinline__ void classify_step_reg(const uint8_t *tab, int q, int
 {
 	const int res = cs.v0 - cs.o0, a = cs.v1 - cs.o1, d2 = v2 - o2;
 	const int v0 = cs.v0, v1 = cs.v1;
-	int n1 = v1, below = cs.o1, n2 = v2;
+	int n1, below = cs.o1, n2;
 	o_fin = cs.o0;
 	int kind = classify_lookup(tab, res, a, d2);
 	if (kind >= CK_NBP && kind <= CK_PREVLE0) {                    /* the four kinds that look further: two cells of the column on the right and their sign, or the row above */
@@ -742,17 +556,15 @@ __device__ __forceinline__ void classify_step_reg(const uint8_t *tab, int q, int
 		else ok = r > 0 && sg * cs.dm1 >= 0;
 		kind = ok ? (sg > 0 ? CK_MARKP : CK_MARKN) : CK_NONE;
 	}
-	if (kind != CK_NONE) {
+	{                                                              /* (CK_NONE's word does nothing: no branch around this) */
 		const uint32_t aw = reinterpret_cast<const uint32_t *>(tab + CK_ACT_OFF)[kind];
 		const int code = (int)(aw & 0xFFFF);
-		if (code) o_fin = code;
-		if (q == 18) { const int nx = (int)(aw >> 23) & 3; if (nx) below = nx == 1 ? 14100 : 14000; }
+		o_fin = code ? code : o_fin;
+		if (q == 18) { const int nx = (int)(aw >> 23) & 3; below = nx ? (nx == 1 ? 14100 : 14000) : below; }
 		n1 = (int16_t)(((aw >> 22) & 1) ? below : v1 + (int)((aw >> 16) & 7) - 2); n2 = (int16_t)(v2 + (int)((aw >> 19) & 7) - 2);
 		const int rule = (int)(aw >> 25);
-		if (rule) {
-			const int bc = (lhm1 < -9 ? -9 : lhm1 > 8 ? 8 : lhm1) + 9;
-			lv = (int16_t)(lv + reinterpret_cast<const int8_t *>(tab + CK_LHT_OFF)[__mul24(__mul24(rule - 1, 9) + lh_class(lv), 18) + bc]);
-		}
+		const int bc = (lhm1 < -9 ? -9 : lhm1 > 8 ? 8 : lhm1) + 9;
+		lv = (int16_t)(lv + reinterpret_cast<const int8_t *>(tab + CK_LHT_OFF)[__mul24(__mul24(rule, 9) + lh_class(lv), 18) + bc]);
 	}
 	cs = ColState{ n1, below, n2, o2, v0 - o_fin };
 }
@@ -791,22 +603,63 @@ __device__ __forceinline__ int code_step_reg(int q, int res_setting, int pv, int
 	default: return cell;
 	}
 }
-/* LDS: the row tiles ot (LL1 cells) and dt (recon - LL1, as loaded) of rows r0 .. r0 + CR + 1, the cells a chunk's steps leave (two buffers: a
- * chunk's go out while the next one's are made), the LH1 piece tile, the tables, column 255 as Y22 left it.  Seven workgroups a CU. */
-#define RF_LDS_BYTES ((2 * (CR + 2) * H + 2 * CR * H + H * LP) * 2 + CK_TABLE_BYTES + 3 * H)
+/* The same step from a table: what it does to the coefficient depends on the residual (below 0: nothing; 0 .. 8; above), on which of six
+ * classes the coefficient is in (-9; -8, -7; -6; 7 .. 9; above 15 and a multiple of 8; anything else) and on where the coefficient before
+ * lies (up to -8; -7 .. -1; 0, 1; 2; 3 .. 7; from 8) -- every comparison of code_step_reg is constant on these classes -- and is one of
+ * five things (nothing, = -9, = -10, - 1, + 2); what the cell becomes depends on the residual alone.  The table is filled by running
+ * code_step_reg on a representative of every class (the branches of the chain were most of the step's instructions: 64 columns
+ * find most of them). */
+#define Y23_OPS (11 * 6 * 6)
+#define Y23_TAB_BYTES ((Y23_OPS + 11 + 3) & ~3)
+DEV void code_table_fill(uint8_t *yt, int q, int res_setting, int tid)
+{
+	for (int idx = tid; idx < Y23_OPS + 11; idx += NT) {
+		if (idx < Y23_OPS) {
+			const int res = idx / 36 - 1, lcl = (idx / 6) % 6, vcl = idx % 6;
+			const int lv0 = lcl == 0 ? 100 : lcl == 1 ? -9 : lcl == 2 ? -8 : lcl == 3 ? -6 : lcl == 4 ? 8 : 16;
+			const int vm1 = vcl == 0 ? -8 : vcl == 1 ? -7 : vcl == 2 ? 0 : vcl == 3 ? 2 : vcl == 4 ? 3 : 8;
+			int lv = lv0;
+			code_step_reg(q, res_setting, res, 0, lv, vm1);
+			yt[idx] = (uint8_t)(lv == lv0 ? 0 : lv == -9 ? 1 : lv == -10 ? 2 : lv == lv0 - 1 ? 3 : 4);
+		} else {
+			int lv = 100;
+			yt[idx] = (uint8_t)code_step_reg(q, res_setting, idx - Y23_OPS - 1, 0, lv, 0);
+		}
+	}
+}
+__device__ __forceinline__ int code_step_tab(const uint8_t *yt, int pv, int cell, int &lv, int vm1)
+{
+	const int res = pv - cell, rcl = (res < -1 ? -1 : res > 9 ? 9 : res) + 1;
+	int lcl = (unsigned)(lv + 9) <= 3u ? (int)((0x3221u >> (4 * (lv + 9))) & 15u) : 0;
+	lcl = (unsigned)(lv - 7) <= 2u ? 4 : lcl;
+	lcl = (lv > 15 && !(lv & 7)) ? 5 : lcl;
+	const int vcl = vm1 <= -8 ? 0 : vm1 <= -1 ? 1 : vm1 <= 1 ? 2 : vm1 == 2 ? 3 : vm1 <= 7 ? 4 : 5;
+	const int op = yt[__mul24(__mul24(rcl, 6) + lcl, 6) + vcl];
+	const int nl = op == 0 ? lv : op == 1 ? -9 : op == 2 ? -10 : op == 3 ? lv - 1 : lv + 2;
+	const bool plain = cell < 12000;
+	/* a code of Y22 (12100 .. 14900) becomes its hundredth; anything else from 12000 on stays (the switch of :1398-1416) */
+	const int k = (cell * 5243) >> 19;
+	const bool is_code = k * 100 == cell && (unsigned)(k - 120) < 32u && ((0x2230007Eu >> (k - 120)) & 1u);
+	lv = plain ? nl : lv;
+	return plain ? (int)yt[Y23_OPS + rcl] : is_code ? k : cell;
+}
+/* LDS: the row tiles ot (LL1 cells) and dt (recon - LL1, as loaded) of rows r0 .. r0 + CR + 1, the cells a chunk's steps leave, the LH1 piece
+ * tile, the tables, column 255 as Y22 left it.  Seven workgroups a CU. */
+#define RF_LDS_BYTES ((2 * (CR + 2) * H + CR * H + H * LP) * 2 + CK_TABLE_BYTES + Y23_TAB_BYTES + 3 * H)
 DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 {
 	PROF_BEGIN();
 	static_assert(NT == H && CR == 4 && LW % CR == 0, "a thread a column; a chunk's four new rows are one 8-byte item a thread");
 	int16_t *p = c->proc, *o = c->ll1;
 	const int q = c->q, j = tid;
-	int16_t *ot = lds, *dt = lds + (CR + 2) * H, *cb = lds + 2 * (CR + 2) * H, *lt = cb + 2 * CR * H;
-	uint8_t *ktab = reinterpret_cast<uint8_t *>(lt + H * LP);
-	int16_t *oc = reinterpret_cast<int16_t *>(ktab + CK_TABLE_BYTES);   /* [H]: column 255's LL1 cells as Y22 left them */
+	int16_t *ot = lds, *dt = lds + (CR + 2) * H, *cb = lds + 2 * (CR + 2) * H, *lt = cb + CR * H;
+	uint8_t *ktab = reinterpret_cast<uint8_t *>(lt + H * LP), *ytab = ktab + CK_TABLE_BYTES;
+	int16_t *oc = reinterpret_cast<int16_t *>(ytab + Y23_TAB_BYTES);   /* [H]: column 255's LL1 cells as Y22 left them */
 	int8_t *rc = reinterpret_cast<int8_t *>(oc + H);                    /* [H]: its residuals (recon - cell) as Y22 left them, held to -128 .. 127 (Y23 compares with 0 .. 8) */
 	classify_table_fill(ktab, q, res_setting, tid);
+	code_table_fill(ytab, q, res_setting, tid);
 	int lhm1, vm1, hl0_255 = 0;
-	{                                                              /* ---- prologue, on packed copies in the tiles' space (4376 of its 5120 shorts) */
+	{                                                              /* ---- prologue, on packed copies in the tiles' space (4408 of its 4096 + 4608 shorts: it reaches into the piece tile) */
 		int16_t *pc0 = lds, *oc0 = lds + 260, *d1 = lds + 520, *lc0 = lds + 780, *pc = lds + 1036, *ocs = lds + 1296, *lc = lds + 1556, *l0 = lds + 1812;
 		int16_t *pt3 = lds + 2072, *ot3 = pt3 + 3 * H, *dt3 = ot3 + 3 * H;
 		for (int t = tid; t < H + 2; t += NT) {                     /* columns 0, 1 and 255 of both planes, rows 0 .. 257 (256, 257 of ll1: its zero guard) */
@@ -827,42 +680,107 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 			*reinterpret_cast<uint4 *>(dt3 + i * H + c8) = make_uint4(d[0], d[1], d[2], d[3]);
 		}
 		lhm1 = p[j * W + H - 1];                                    /* (j, 255): column 255 has not been visited */
+		/* The two walks are serial, but most of their steps change nothing, and a step that starts from untouched values (its three rows, the row
+		 * above, the coefficient before) can be evaluated by anybody: a thread a row does that first (em: the rows whose step would change
+		 * something), and the walk goes from such a row on until three steps in a row have changed nothing -- then every value a step looks at is
+		 * untouched again and it jumps to the next row of em.  (One thread doing all 2 x 255 steps was a fifth of the kernel's time.) */
+		uint64_t *em = reinterpret_cast<uint64_t *>(lds + 4376);    /* [2][4] */
+		auto next_set = [&](const uint64_t *m, int r) {
+			for (int w = r >> 6; w < 4; w++) { uint64_t x = m[w]; if (w == (r >> 6)) x &= ~0ull << (r & 63); if (x) return 64 * w + (int)__builtin_ctzll(x); }
+			return H;
+		};
+		auto held = [](int d) { return (int8_t)(d < -128 ? -128 : d > 127 ? 127 : d); };
 		BARRIER();
+		if (!tid) PROF(c, 52);
 		if (j < H - 1) {                                            /* step 0 of every column: column 255 reads the coefficient it leaves */
 			ColState cs{ pt3[j], ot3[j], pt3[H + j], ot3[H + j], 0 };
 			int lv = l0[j], of;
 			classify_step_reg(ktab, q, 0, cs, pt3[2 * H + j], ot3[2 * H + j], lv, lhm1, [&](int dr) { return (int)dt3[dr * H + j + 1]; }, of);
 			l0[j] = (int16_t)lv;
 		}
-		BARRIER();
-		if (tid == 0) {
-			{                                                       /* column 0, whole: column 255 reads its LL1 cells */
-				ColState cs{ pc0[0], oc0[0], pc0[1], oc0[1], 0 };
-				int prev = pc[0];
-				for (int r = 0; r < H - 1; r++) {
-					int lv = lc0[r], of;
-					classify_step_reg(ktab, q, r, cs, pc0[r + 2], oc0[r + 2], lv, prev, [&](int dr) { return (int)d1[r + dr]; }, of);
-					oc0[r] = (int16_t)of; prev = lv;
-				}
-				oc0[H - 1] = (int16_t)cs.o0;
+		{                                                           /* column 0: the rows whose step changes something */
+			bool eff = false;
+			if (tid < H - 1) {
+				const int t = tid, u = t ? t - 1 : 0;
+				ColState cs{ pc0[t], oc0[t], pc0[t + 1], oc0[t + 1], t ? pc0[u] - oc0[u] : 0 };
+				const int lv0 = lc0[t];
+				int lv = lv0, of;
+				classify_step_reg(ktab, q, t, cs, pc0[t + 2], oc0[t + 2], lv, t ? (int)lc0[u] : (int)pc[0], [&](int dr) { return (int)d1[t + dr]; }, of);
+				eff = of != oc0[t] || cs.v0 != pc0[t + 1] || cs.o0 != oc0[t + 1] || cs.v1 != pc0[t + 2] || lv != lv0;
 			}
-			{                                                       /* column 255: its neighbour is (x, 256) - (x + 1, 0), both as left above */
-				ColState cs{ pc[0], ocs[0], pc[1], ocs[1], 0 };
-				int prev = pc[H - 1];
-				for (int r = 0; r < H - 1; r++) {
-					int lv = lc[r], of;
-					const int v0 = cs.v0;
-					classify_step_reg(ktab, q, r, cs, pc[r + 2], ocs[r + 2], lv, prev, [&](int dr) { return (int)l0[r + dr] - (int)oc0[r + dr + 1]; }, of);
-					lc[r] = (int16_t)lv; prev = lv;
-					if (r == 0) l0[H - 1] = (int16_t)lv;              /* (255, 256) is also this column's neighbour of row 255 */
-					pc[r] = (int16_t)v0; oc[r] = (int16_t)of;
-					rc[r] = (int8_t)(cs.dm1 < -128 ? -128 : cs.dm1 > 127 ? 127 : cs.dm1);
+			const uint64_t m = __ballot(eff);
+			if ((tid & 63) == 0) em[tid >> 6] = m;
+		}
+		oc[tid] = ocs[tid]; rc[tid] = held(pc[tid] - ocs[tid]);    /* column 255 where its walk changes nothing */
+		BARRIER();
+		if (!tid) PROF(c, 53);
+		if (tid == 0) {                                             /* column 0: column 255 reads its LL1 cells */
+			ColState cs{ 0, 0, 0, 0, 0 };
+			int prev = 0, quiet = 3, r = 0;
+			while (r < H - 1) {
+				if (quiet >= 3) {
+					r = next_set(em, r);
+					if (r >= H - 1) break;
+					const int u = r ? r - 1 : 0;
+					cs = ColState{ pc0[r], oc0[r], pc0[r + 1], oc0[r + 1], r ? pc0[u] - oc0[u] : 0 };
+					prev = r ? (int)lc0[u] : (int)pc[0];
 				}
-				const int dl = cs.v0 - cs.o0;
-				pc[H - 1] = (int16_t)cs.v0; oc[H - 1] = (int16_t)cs.o0; rc[H - 1] = (int8_t)(dl < -128 ? -128 : dl > 127 ? 127 : dl);
-				hl0_255 = cs.v1;
+				const int o0 = cs.o0, v1 = cs.v1, o1 = cs.o1, v2 = pc0[r + 2], lv0 = lc0[r];
+				int lv = lv0, of;
+				classify_step_reg(ktab, q, r, cs, v2, oc0[r + 2], lv, prev, [&](int dr) { return (int)d1[r + dr]; }, of);
+				if (of != o0 || cs.v0 != v1 || cs.o0 != o1 || cs.v1 != v2 || lv != lv0) { quiet = 0; oc0[r] = (int16_t)of; oc0[r + 1] = (int16_t)cs.o0; } else quiet++;
+				prev = lv; r++;
+#ifdef NHW_PROFILE
+				reinterpret_cast<unsigned long long *>(c->prof)[57] += 1000; if (!quiet) reinterpret_cast<unsigned long long *>(c->prof)[59] += 1000;
+#endif
 			}
 		}
+		if (!tid) PROF(c, 54);
+		BARRIER();
+		{                                                           /* column 255: its neighbour is (x, 256) - (x + 1, 0), both as left above */
+			bool eff = false;
+			if (tid < H - 1) {
+				const int t = tid, u = t ? t - 1 : 0;
+				ColState cs{ pc[t], ocs[t], pc[t + 1], ocs[t + 1], t ? pc[u] - ocs[u] : 0 };
+				const int lv0 = lc[t];
+				int lv = lv0, of;
+				classify_step_reg(ktab, q, t, cs, pc[t + 2], ocs[t + 2], lv, t ? (int)lc[u] : (int)pc[H - 1], [&](int dr) { return (int)l0[t + dr] - (int)oc0[t + dr + 1]; }, of);
+				eff = of != ocs[t] || cs.v0 != pc[t + 1] || cs.o0 != ocs[t + 1] || cs.v1 != pc[t + 2] || lv != lv0;
+				eff |= t >= H - 3;                                    /* rows 253, 254 look at (255, 256), which step 0 may change: always walked */
+			}
+			const uint64_t m = __ballot(eff);
+			if ((tid & 63) == 0) em[4 + (tid >> 6)] = m;
+		}
+		BARRIER();
+		if (tid == 0) {
+			ColState cs{ 0, 0, 0, 0, 0 };
+			int prev = 0, quiet = 3, r = 0;
+			hl0_255 = pc[H];
+			while (r < H - 1) {
+				if (quiet >= 3) {
+					r = next_set(em + 4, r);
+					if (r >= H - 1) break;
+					const int u = r ? r - 1 : 0;
+					cs = ColState{ pc[r], ocs[r], pc[r + 1], ocs[r + 1], r ? pc[u] - ocs[u] : 0 };
+					prev = r ? (int)lc[u] : (int)pc[H - 1];
+				}
+				const int v0 = cs.v0, o0 = cs.o0, v1 = cs.v1, o1 = cs.o1, v2 = pc[r + 2], lv0 = lc[r];
+				int lv = lv0, of;
+				classify_step_reg(ktab, q, r, cs, v2, ocs[r + 2], lv, prev, [&](int dr) { return (int)l0[r + dr] - (int)oc0[r + dr + 1]; }, of);
+				if (of != o0 || cs.v0 != v1 || cs.o0 != o1 || cs.v1 != v2 || lv != lv0) quiet = 0; else quiet++;
+				lc[r] = (int16_t)lv; prev = lv;
+				if (r == 0) l0[H - 1] = (int16_t)lv;                  /* (255, 256) is also this column's neighbour of row 255 */
+				pc[r] = (int16_t)v0; oc[r] = (int16_t)of; rc[r] = held(cs.dm1);
+				pc[r + 1] = (int16_t)cs.v0; pc[r + 2] = (int16_t)cs.v1; ocs[r + 1] = (int16_t)cs.o0;   /* what the step leaves below it (the next step, if the walk goes on from here, carries them in registers) */
+				if (r + 1 < H) { oc[r + 1] = (int16_t)cs.o0; rc[r + 1] = held(cs.v0 - cs.o0); }
+				r++;
+#ifdef NHW_PROFILE
+				reinterpret_cast<unsigned long long *>(c->prof)[58] += 1000; if (!quiet) reinterpret_cast<unsigned long long *>(c->prof)[60] += 1000;
+#endif
+			}
+			hl0_255 = pc[H];
+		}
+		if (!tid) PROF(c, 56);
 		BARRIER();
 		vm1 = pc[j];                                                /* (j, 255) as column 255's walk left it: where Y23 starts */
 		p[(H - 1) * W + H + tid] = lc[tid];                         /* column 255's coefficients, for the piece tile */
@@ -880,7 +798,7 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 	if (pi >= 2) fetch(pi - 2, kp, ko);                             /* rows 0, 1 */
 	fetch(2 + pi, np, no);                                          /* rows 2 .. 5 */
 	ColState cs{ 0, 0, 0, 0, 0 };
-	for (int r0 = 0, buf = 0; r0 < H; r0 += CR, buf ^= 1) {
+	for (int r0 = 0; r0 < H; r0 += CR) {
 		if (pi >= 2) put(pi - 2, kp, ko);                           /* the chunk's first two rows: the last two the chunk before brought */
 		put(2 + pi, np, no);
 		kp = np; ko = no;
@@ -888,7 +806,6 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 		if (r0 % LW == 0) lh_tile_load(lt, p, r0, tid);
 		BARRIER();
 		if (r0 == 0) cs = ColState{ (int16_t)(dt[j] + ot[j]), ot[j], (int16_t)(dt[H + j] + ot[H + j]), ot[H + j], 0 };
-		int16_t *cbb = cb + buf * CR * H;
 #pragma unroll
 		for (int i = 0; i < CR; i++) {
 			const int r = r0 + i;
@@ -903,12 +820,12 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 					if (r == H - 2) p[H * W + j] = (int16_t)cs.v1;        /* the last step's second sample is row 256: the first row of HL1 (the reference's walk leaves its quadrant there) */
 				} else cell = cs.o0;
 			} else { cell = oc[r]; pv = cell + rc[r]; }
-			const int out = code_step_reg(q, res_setting, pv, cell, lv, vm1);
+			const int out = code_step_tab(ytab, pv, cell, lv, vm1);
 			vm1 = lv;
-			cbb[i * H + j] = (int16_t)out; *lh = (int16_t)lv;
+			cb[i * H + j] = (int16_t)out; *lh = (int16_t)lv;
 		}
 		BARRIER();
-		*reinterpret_cast<uint2 *>(o + (r0 + pi) * H + pc4) = *reinterpret_cast<const uint2 *>(cbb + pi * H + pc4);
+		*reinterpret_cast<uint2 *>(o + (r0 + pi) * H + pc4) = *reinterpret_cast<const uint2 *>(cb + pi * H + pc4);   /* (nobody writes cb again before the next barrier) */
 		if ((r0 + CR) % LW == 0) lh_tile_store(lt, p, r0 + CR - LW, tid);
 	}
 	if (tid == 0) p[H * W + H - 1] = (int16_t)hl0_255;             /* (column 255's, kept until here: row 256 is column 254's neighbour as it was) */
@@ -2416,15 +2333,7 @@ DEV void luma_p4a_par(Ctx *c, int tid, int16_t *lds)
 	if (!tid) PROF(c, 9);
 	if (q <= 12) return;                                                    /* no second closed loop, no residual lists (:1081, :1498) */
 	const int res_setting = q >= 20 ? 3 : q >= 18 ? 4 : q >= 15 ? 6 : 8;    /* :1075-1079 */
-#ifdef NHW_Y22_Y23_SPLIT
-	classify_residuals_par(c, res_setting, tid, lds);                       /* Y22 */
-	if (!tid) PROF(c, 10);
-	code_residuals_par(c, res_setting, tid, lds);                           /* Y23 */
-	BARRIER();
-	if (!tid) PROF(c, 11);
-#else
 	residuals_fused_par(c, res_setting, tid, lds);                          /* Y22 + Y23 */
-#endif
 }
 DEV void luma_p4b_par(Ctx *c, int tid, int *pos, int16_t *lds)
 {
