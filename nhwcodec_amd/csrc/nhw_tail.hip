@@ -63,7 +63,12 @@ __global__ __launch_bounds__(512) void k_y31(NhwWs ws)
 	if (!threadIdx.x) PROF(&c, 17);
 }
 
-#ifdef NHW_L4A_WAVES   /* developer experiment: Y19-Y23 as a kernel of its own held to NHW_L4A_WAVES wavefronts a SIMD */
+/* Y19-Y23 of quality 17 .. 23 as a kernel of its own, held to eight wavefronts a SIMD (64 registers): with its 20 KB of LDS that is eight
+ * workgroups a CU -- the 16 images a CU gets of a 4096-image batch in two rounds (k_phase<PH_L4A> takes 67 registers: seven, 7 + 7 + 2).
+ * The low qualities' Y20 (thin_l1_low_par) would spill at 64 and stays on k_phase. */
+#ifndef NHW_L4A_WAVES
+#define NHW_L4A_WAVES 8
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NHW_L4A_WAVES, NHW_L4A_WAVES))) void k_l4a(NhwWs ws)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t dyn_lds[];
@@ -71,7 +76,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NHW_L4A_WAV
 	ctx_load(&c, ws, blockIdx.x);
 	luma_p4a_par(&c, threadIdx.x, dyn_lds);
 }
-#endif
 
 /* passes that run one wavefront per image (nhw_tail_wave.h): four images per workgroup, no workgroup barriers */
 enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
@@ -292,11 +296,7 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 	case PH_L1: k_phase<PH_L1><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L2: k_phase<PH_L2><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L3: k_phase<PH_L3><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
-#ifdef NHW_L4A_WAVES
-	case PH_L4A: k_l4a<<<g, b, lds, s>>>(ws); break;
-#else
-	case PH_L4A: k_phase<PH_L4A><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
-#endif
+	case PH_L4A: if (ws.q >= 17) k_l4a<<<g, b, lds, s>>>(ws); else k_phase<PH_L4A><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4B: k_phase<PH_L4B><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4C: k_phase<PH_L4C><<<g, b, lds, s>>>(ws, comp, out, sizes, status); break;
 	case PH_L4D: if (NHW_DENSE_STREAM || ws.dbg) k_phase<PH_L4D><<<g, b, lds, s>>>(ws, comp, out, sizes, status); else k_y31<<<g, 512, lds, s>>>(ws); break;

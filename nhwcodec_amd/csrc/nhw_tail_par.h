@@ -643,23 +643,28 @@ __device__ __forceinline__ int code_step_tab(const uint8_t *yt, int pv, int cell
 	lv = plain ? nl : lv;
 	return plain ? (int)yt[Y23_OPS + rcl] : is_code ? k : cell;
 }
-/* LDS: the row tiles ot (LL1 cells) and dt (recon - LL1, as loaded) of rows r0 .. r0 + CR + 1, the cells a chunk's steps leave, the LH1 piece
- * tile, the tables, column 255 as Y22 left it.  Seven workgroups a CU. */
-#define RF_LDS_BYTES ((2 * (CR + 2) * H + CR * H + H * LP) * 2 + CK_TABLE_BYTES + Y23_TAB_BYTES + 3 * H)
+/* LDS: the row tiles ot (LL1 cells) and dt (recon - LL1, as loaded) of rows r0 .. r0 + CR + 1, the cells a chunk's steps leave (bytes), the LH1
+ * piece tile, the tables, column 255 as Y22 left it: 20 220 bytes -- EIGHT workgroups a CU, i.e. the 16 images a CU gets of a 4096-image batch
+ * in two rounds (seven were 7 + 7 + 2).
+ * Cells as bytes: an LL1 cell is either a code of Y22 (12100 .. 14900, a multiple of 100) or a sample of the level-1 LL band of an 8-bit
+ * picture, which is far below 12000 in magnitude (|LL1| <= (10 x (10 x 255 + 2 x 255) + ...) / 64 < 500: nhw_front_image.h) -- so what Y23
+ * leaves in a cell is 0 or a code's hundredth, and "from 12000 on" means "a code". */
+#define RF_LDS_BYTES (2 * (CR + 2) * H * 2 + CR * H + H * LP * 2 + CK_TABLE_BYTES + Y23_TAB_BYTES + 2 * H)
 DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 {
 	PROF_BEGIN();
 	static_assert(NT == H && CR == 4 && LW % CR == 0, "a thread a column; a chunk's four new rows are one 8-byte item a thread");
 	int16_t *p = c->proc, *o = c->ll1;
 	const int q = c->q, j = tid;
-	int16_t *ot = lds, *dt = lds + (CR + 2) * H, *cb = lds + 2 * (CR + 2) * H, *lt = cb + CR * H;
+	int16_t *ot = lds, *dt = lds + (CR + 2) * H, *lt = lds + 2 * (CR + 2) * H + CR * H / 2;
+	uint8_t *cb = reinterpret_cast<uint8_t *>(lds + 2 * (CR + 2) * H);   /* [CR][H]: what the chunk's steps leave in the cells */
 	uint8_t *ktab = reinterpret_cast<uint8_t *>(lt + H * LP), *ytab = ktab + CK_TABLE_BYTES;
-	int16_t *oc = reinterpret_cast<int16_t *>(ytab + Y23_TAB_BYTES);   /* [H]: column 255's LL1 cells as Y22 left them */
+	uint8_t *oc = ytab + Y23_TAB_BYTES;                                 /* [H]: column 255's LL1 cells as Y22 left them: a code's hundredth, or 0 */
 	int8_t *rc = reinterpret_cast<int8_t *>(oc + H);                    /* [H]: its residuals (recon - cell) as Y22 left them, held to -128 .. 127 (Y23 compares with 0 .. 8) */
 	classify_table_fill(ktab, q, res_setting, tid);
 	code_table_fill(ytab, q, res_setting, tid);
 	int lhm1, vm1, hl0_255 = 0;
-	{                                                              /* ---- prologue, on packed copies in the tiles' space (4408 of its 4096 + 4608 shorts: it reaches into the piece tile) */
+	{                                                              /* ---- prologue, on packed copies in the tiles' space (4408 of its 3584 + 4608 shorts: it reaches into the piece tile) */
 		int16_t *pc0 = lds, *oc0 = lds + 260, *d1 = lds + 520, *lc0 = lds + 780, *pc = lds + 1036, *ocs = lds + 1296, *lc = lds + 1556, *l0 = lds + 1812;
 		int16_t *pt3 = lds + 2072, *ot3 = pt3 + 3 * H, *dt3 = ot3 + 3 * H;
 		for (int t = tid; t < H + 2; t += NT) {                     /* columns 0, 1 and 255 of both planes, rows 0 .. 257 (256, 257 of ll1: its zero guard) */
@@ -690,6 +695,7 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 			return H;
 		};
 		auto held = [](int d) { return (int8_t)(d < -128 ? -128 : d > 127 ? 127 : d); };
+		auto hundredth = [](int cell) { return (uint8_t)(cell >= 12000 ? cell / 100 : 0); };
 		BARRIER();
 		if (!tid) PROF(c, 52);
 		if (j < H - 1) {                                            /* step 0 of every column: column 255 reads the coefficient it leaves */
@@ -711,7 +717,7 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 			const uint64_t m = __ballot(eff);
 			if ((tid & 63) == 0) em[tid >> 6] = m;
 		}
-		oc[tid] = ocs[tid]; rc[tid] = held(pc[tid] - ocs[tid]);    /* column 255 where its walk changes nothing */
+		oc[tid] = 0; rc[tid] = held(pc[tid] - ocs[tid]);           /* column 255 where its walk changes nothing */
 		BARRIER();
 		if (!tid) PROF(c, 53);
 		if (tid == 0) {                                             /* column 0: column 255 reads its LL1 cells */
@@ -770,9 +776,9 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 				if (of != o0 || cs.v0 != v1 || cs.o0 != o1 || cs.v1 != v2 || lv != lv0) quiet = 0; else quiet++;
 				lc[r] = (int16_t)lv; prev = lv;
 				if (r == 0) l0[H - 1] = (int16_t)lv;                  /* (255, 256) is also this column's neighbour of row 255 */
-				pc[r] = (int16_t)v0; oc[r] = (int16_t)of; rc[r] = held(cs.dm1);
+				pc[r] = (int16_t)v0; oc[r] = hundredth(of); rc[r] = held(cs.dm1);
 				pc[r + 1] = (int16_t)cs.v0; pc[r + 2] = (int16_t)cs.v1; ocs[r + 1] = (int16_t)cs.o0;   /* what the step leaves below it (the next step, if the walk goes on from here, carries them in registers) */
-				if (r + 1 < H) { oc[r + 1] = (int16_t)cs.o0; rc[r + 1] = held(cs.v0 - cs.o0); }
+				oc[r + 1] = hundredth(cs.o0); rc[r + 1] = held(cs.v0 - cs.o0);
 				r++;
 #ifdef NHW_PROFILE
 				reinterpret_cast<unsigned long long *>(c->prof)[58] += 1000; if (!quiet) reinterpret_cast<unsigned long long *>(c->prof)[60] += 1000;
@@ -819,13 +825,16 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 					lhm1 = lv;
 					if (r == H - 2) p[H * W + j] = (int16_t)cs.v1;        /* the last step's second sample is row 256: the first row of HL1 (the reference's walk leaves its quadrant there) */
 				} else cell = cs.o0;
-			} else { cell = oc[r]; pv = cell + rc[r]; }
+			} else { cell = 100 * oc[r]; pv = rc[r]; }              /* (a cell that is no code: 0, and its residual in its place) */
 			const int out = code_step_tab(ytab, pv, cell, lv, vm1);
 			vm1 = lv;
-			cb[i * H + j] = (int16_t)out; *lh = (int16_t)lv;
+			cb[i * H + j] = (uint8_t)out; *lh = (int16_t)lv;
 		}
 		BARRIER();
-		*reinterpret_cast<uint2 *>(o + (r0 + pi) * H + pc4) = *reinterpret_cast<const uint2 *>(cb + pi * H + pc4);   /* (nobody writes cb again before the next barrier) */
+		{                                                           /* (nobody writes cb again before the next barrier) */
+			const uint32_t w = *reinterpret_cast<const uint32_t *>(cb + pi * H + pc4);
+			*reinterpret_cast<uint2 *>(o + (r0 + pi) * H + pc4) = make_uint2((w & 0xFF) | ((w >> 8 & 0xFF) << 16), (w >> 16 & 0xFF) | ((w >> 24) << 16));
+		}
 		if ((r0 + CR) % LW == 0) lh_tile_store(lt, p, r0 + CR - LW, tid);
 	}
 	if (tid == 0) p[H * W + H - 1] = (int16_t)hl0_255;             /* (column 255's, kept until here: row 256 is column 254's neighbour as it was) */
