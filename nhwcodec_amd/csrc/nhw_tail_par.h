@@ -327,7 +327,7 @@ DEV void tag_rows_wave(int16_t *p, int r_first, int r_last, int c_base, int jb, 
 		for (int k = 0; k < 4; k++) fin[k] = (k < 3 ? trip[k + 1] : (lane < 63 ? tnext : 0)) ? 10100 : own[k];
 		uint2 w;
 		w.x = (uint32_t)(uint16_t)fin[0] | ((uint32_t)(uint16_t)fin[1] << 16); w.y = (uint32_t)(uint16_t)fin[2] | ((uint32_t)(uint16_t)fin[3] << 16);
-		*reinterpret_cast<uint2 *>(p + (size_t)row * W + c0) = w;
+		if (fin[0] != o[0] || fin[1] != o[1] || fin[2] != o[2] || fin[3] != o[3]) *reinterpret_cast<uint2 *>(p + (size_t)row * W + c0) = w;   /* (most pieces stay as they are: 1 GB a batch went back unchanged) */
 	}
 }
 DEV void tag_small_runs_par(Ctx *c, int tid, int16_t *lds)
@@ -1750,7 +1750,7 @@ DEV void build_poslists_par(Ctx *c, int tid, int *pos, int16_t *lds)
 				rl[pass] += n + 1; pln[pass] += n;
 				for (int k = 0; k < 4; k++) if ((m[k] >> lane) & 1) v[k] = kp[k];
 			}
-			for (int k = 0; k < 4; k++) o[r * H + lane + 64 * k] = (int16_t)v[k];
+			/* (the reference leaves the follow-up codes and the cleared columns 254, 255 in the plane: nothing reads it behind this pass, so it is not written back) */
 		}
 		if (lane == 0) for (int pass = 0; pass < 3; pass++) { segn[(pass * 4 + wv) * 2] = rl[pass]; segn[(pass * 4 + wv) * 2 + 1] = pln[pass]; }
 	}
