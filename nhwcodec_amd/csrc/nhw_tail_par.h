@@ -276,58 +276,96 @@ DEV void precompensate_ll1_par(Ctx *c, int tid, int16_t *lds)
  * the one on the right has not, so what travels along the row is (value of the cell as its visit left it, value forced on the next cell).
  * A wavefront takes a row, a lane four cells; the lanes start from "nothing forced, left neighbour as it was" and hand their results to
  * the right until nothing moves.  (Every value a cell can be set to fails all of the tests, so the chain dies out after a cell or two.) */
-template <int PASS>
-DEV void tag_cell(int x, int lv, int rv, int &own, int &force_next, int &triple)
+/* The cell rule (:970-1073) only asks where a value lies: 4 .. 7 (bit 0: a neighbour of a triple), 5 .. 7 (bit 1: its centre), 6, 7 (bit 2:
+ * what turns an 8 into a 10), 8 (bit 3), with its sign (bit 4) -- one code a value, from a table in a constant:
+ *   x in +-5..7 between two neighbours in +-4..7 of its sign: x = 12700 / 12900, the next cell is forced to 10100, a triple;
+ *   x = +-8 next to a +-6, 7 of its sign: 10 / -9; else (LH1 only) with a +-8 of its sign on its right: 9 / -9, and the next cell forced to the same.
+ * Written without branches: 64 lanes x 4 cells found every branch of the chain in every row. */
+DEV int tag_code(int v)
 {
-	own = x; force_next = 0; triple = 0;
-	if (x > 4 && x < 8) { if (in_4_7(lv) && in_4_7(rv)) { own = 12700; force_next = 10100; triple = 1; } }
-	else if (x < -4 && x > -8) { if (in_m7_m4(lv) && in_m7_m4(rv)) { own = 12900; force_next = 10100; triple = 1; } }
-	else if (x == 8) {
-		if ((lv & 0xFFFE) == 6 || (rv & 0xFFFE) == 6) own = 10;
-		else if (!PASS && rv == 8) { own = 9; force_next = 9; }
-	}
-	else if (x == -8) {
-		if (((-lv) & 0xFFFE) == 6 || ((-rv) & 0xFFFE) == 6) own = -9;
-		else if (!PASS && rv == -8) { own = -9; force_next = -9; }
-	}
+	int a = v < 0 ? -v : v;
+	a = a > 9 ? 9 : a;
+	return (int)((0x877310000ull >> (4 * a)) & 15u) | (v < 0 ? 16 : 0);
 }
 template <int PASS>
 DEV void tag_rows_wave(int16_t *p, int r_first, int r_last, int c_base, int jb, int je, int tid)
 {
 	const int lane = tid & 63, wv = tid >> 6, c0 = c_base + 4 * lane;
-	int r = r_first + wv;
-	uint2 cur = make_uint2(0, 0);
-	if (r <= r_last) cur = *reinterpret_cast<const uint2 *>(p + (size_t)r * W + c0);
-	for (; r <= r_last; r += NT / 64) {
-		int o[4];
-		unpack4(cur, o);
+	/* four rows of the wavefront's in flight while it works on the four before: a row is 512 bytes, and with one row ahead a CU's 32 wavefronts
+	 * had 16 KB on their way -- the pass waited for memory latency (2.5 us a row) */
+	constexpr int TD = 4, RS = NT / 64;
+	uint2 nxt[TD];
+#pragma unroll
+	for (int u = 0; u < TD; u++) { const int rr = r_first + wv + u * RS; nxt[u] = rr <= r_last ? *reinterpret_cast<const uint2 *>(p + (size_t)rr * W + c0) : make_uint2(0, 0); }
+	bool act[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) act[k] = c0 + k >= jb && c0 + k < je;
+	const uint32_t act_bytes = (act[0] ? 1u : 0u) | (act[1] ? 1u << 8 : 0u) | (act[2] ? 1u << 16 : 0u) | (act[3] ? 1u << 24 : 0u);
+	for (int rb = r_first + wv; rb <= r_last; rb += TD * RS) {
+	uint2 curs[TD];
+#pragma unroll
+	for (int u = 0; u < TD; u++) curs[u] = nxt[u];
+#pragma unroll
+	for (int u = 0; u < TD; u++) { const int rr = rb + (TD + u) * RS; if (rr <= r_last) nxt[u] = *reinterpret_cast<const uint2 *>(p + (size_t)rr * W + c0); }
+#pragma unroll
+	for (int u = 0; u < TD; u++) {
+		const int r = rb + u * RS;
+		if (r > r_last) continue;
+		int o[4], e[4];
+		unpack4(curs[u], o);
 		const int row = r;
-		if (r + NT / 64 <= r_last) cur = *reinterpret_cast<const uint2 *>(p + (size_t)(r + NT / 64) * W + c0);
+#pragma unroll
+		for (int k = 0; k < 4; k++) e[k] = tag_code(o[k]);
+		const int e_right = __shfl_down(e[0], 1), e_left = __shfl_up(e[3], 1);   /* (lane 63's right and lane 0's left neighbour only meet cells outside the pass) */
+		/* Does any cell of the row fire with its neighbours as they are?  All four cells of a lane at once, a code a byte: if none does, the
+		 * walk changes nothing (a cell only sees another left neighbour behind a cell that fired) -- nearly every row: the walk itself
+		 * was most of the pass's instructions. */
+		{
+			const uint32_t E = (uint32_t)e[0] | (uint32_t)e[1] << 8 | (uint32_t)e[2] << 16 | (uint32_t)e[3] << 24;
+			const uint32_t L = E << 8 | (uint32_t)e_left, R = E >> 8 | (uint32_t)e_right << 24;
+			const uint32_t sl = ~((E ^ L) >> 4), sr = ~((E ^ R) >> 4);           /* bit 0 of a byte: the same sign */
+			const uint32_t t3 = (E >> 1) & L & R & sl & sr, near = (E >> 3) & (((L >> 2) & sl) | ((R >> 2) & sr)), pair = PASS ? 0u : (E >> 3) & (R >> 3) & sr;
+			if (!__any(((t3 | near | pair) & act_bytes) != 0)) continue;
+		}
 		const int sd0 = __shfl_down(o[0], 1);                      /* the cell on the right of my last one, as it was */
 		const int left0 = __shfl_up(o[3], 1);
-		int lv_in = left0, force_in = 0, own[4], trip[4], lv_out, force_out;
+		int lv_in = left0, force_in = 0, own[4], lv_out, force_out;
+		bool trip[4];
 		for (;;) {
-			int lv = lv_in, force = force_in;
+			int el = tag_code(lv_in), force = force_in;
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
-				const int j = c0 + k, x = force ? force : o[k];
-				if (j >= jb && j < je) tag_cell<PASS>(x, lv, k < 3 ? o[k + 1] : sd0, own[k], force, trip[k]);
-				else { own[k] = x; force = 0; trip[k] = 0; }
-				lv = own[k];
+				const bool forced = force != 0;
+				const int x = forced ? force : o[k], ex = forced ? 0 : e[k], er = k < 3 ? e[k < 3 ? k + 1 : k] : e_right;
+				const bool sl = !((ex ^ el) & 16), sr = !((ex ^ er) & 16), neg = (ex & 16) != 0;
+				const bool t3 = act[k] && (ex & 2) && (el & 1) && sl && (er & 1) && sr;
+				const bool is8 = act[k] && (ex & 8);
+				const bool near = is8 && (((el & 4) && sl) || ((er & 4) && sr));
+				const bool pair = !PASS && is8 && !near && (er & 8) && sr;
+				int ow = x;
+				ow = t3 ? (neg ? 12900 : 12700) : ow;
+				ow = near ? (neg ? -9 : 10) : ow;
+				ow = pair ? (neg ? -9 : 9) : ow;
+				force = t3 ? 10100 : pair ? ow : 0;
+				trip[k] = t3; own[k] = ow;
+				el = ow != x ? 0 : ex;                              /* (every value a cell can be set or forced to has code 0) */
 			}
-			lv_out = lv; force_out = force;
+			lv_out = own[3]; force_out = force;
 			int nl = __shfl_up(lv_out, 1), nf = __shfl_up(force_out, 1);
 			if (!lane) { nl = left0; nf = 0; }
-			if (!__any(nl != lv_in || nf != force_in)) break;
+			/* what arrives matters to a lane only through its first cell: a forced value, or another left neighbour for a cell that looks at it
+			 * (+-5..7 or +-8, not forced, inside the pass) -- anything else would repeat the evaluation to the same result (half the rows did) */
+			if (!__any(nf != force_in || (nl != lv_in && act[0] && !force_in && (e[0] & 10)))) break;
 			lv_in = nl; force_in = nf;
 		}
-		const int tnext = __shfl_down(trip[0], 1);                 /* a triple marks the cell before it as well */
+		const int tnext = __shfl_down((int)trip[0], 1);            /* a triple marks the cell before it as well */
 		int fin[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) fin[k] = (k < 3 ? trip[k + 1] : (lane < 63 ? tnext : 0)) ? 10100 : own[k];
+		for (int k = 0; k < 4; k++) fin[k] = (k < 3 ? trip[k < 3 ? k + 1 : k] : (lane < 63 && tnext)) ? 10100 : own[k];
 		uint2 w;
 		w.x = (uint32_t)(uint16_t)fin[0] | ((uint32_t)(uint16_t)fin[1] << 16); w.y = (uint32_t)(uint16_t)fin[2] | ((uint32_t)(uint16_t)fin[3] << 16);
 		if (fin[0] != o[0] || fin[1] != o[1] || fin[2] != o[2] || fin[3] != o[3]) *reinterpret_cast<uint2 *>(p + (size_t)row * W + c0) = w;   /* (most pieces stay as they are: 1 GB a batch went back unchanged) */
+	}
 	}
 }
 DEV void tag_small_runs_par(Ctx *c, int tid, int16_t *lds)
@@ -637,11 +675,9 @@ __device__ __forceinline__ int code_step_tab(const uint8_t *yt, int pv, int cell
 	const int op = yt[__mul24(__mul24(rcl, 6) + lcl, 6) + vcl];
 	const int nl = op == 0 ? lv : op == 1 ? -9 : op == 2 ? -10 : op == 3 ? lv - 1 : lv + 2;
 	const bool plain = cell < 12000;
-	/* a code of Y22 (12100 .. 14900) becomes its hundredth; anything else from 12000 on stays (the switch of :1398-1416) */
-	const int k = (cell * 5243) >> 19;
-	const bool is_code = k * 100 == cell && (unsigned)(k - 120) < 32u && ((0x2230007Eu >> (k - 120)) & 1u);
+	/* a code of Y22 (12100 .. 14900) becomes its hundredth (the switch of :1398-1416; from 12000 on a cell IS a code: see RF_LDS_BYTES) */
 	lv = plain ? nl : lv;
-	return plain ? (int)yt[Y23_OPS + rcl] : is_code ? k : cell;
+	return plain ? (int)yt[Y23_OPS + rcl] : (cell * 5243) >> 19;
 }
 /* LDS: the row tiles ot (LL1 cells) and dt (recon - LL1, as loaded) of rows r0 .. r0 + CR + 1, the cells a chunk's steps leave (bytes), the LH1
  * piece tile, the tables, column 255 as Y22 left it: 20 220 bytes -- EIGHT workgroups a CU, i.e. the 16 images a CU gets of a 4096-image batch
@@ -664,7 +700,7 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 	classify_table_fill(ktab, q, res_setting, tid);
 	code_table_fill(ytab, q, res_setting, tid);
 	int lhm1, vm1, hl0_255 = 0;
-	{                                                              /* ---- prologue, on packed copies in the tiles' space (4408 of its 3584 + 4608 shorts: it reaches into the piece tile) */
+	{                                                              /* ---- prologue, on packed copies in the tiles' space (5184 of its 3584 + 4608 shorts: it reaches into the piece tile) */
 		int16_t *pc0 = lds, *oc0 = lds + 260, *d1 = lds + 520, *lc0 = lds + 780, *pc = lds + 1036, *ocs = lds + 1296, *lc = lds + 1556, *l0 = lds + 1812;
 		int16_t *pt3 = lds + 2072, *ot3 = pt3 + 3 * H, *dt3 = ot3 + 3 * H;
 		for (int t = tid; t < H + 2; t += NT) {                     /* columns 0, 1 and 255 of both planes, rows 0 .. 257 (256, 257 of ll1: its zero guard) */
@@ -687,9 +723,10 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 		lhm1 = p[j * W + H - 1];                                    /* (j, 255): column 255 has not been visited */
 		/* The two walks are serial, but most of their steps change nothing, and a step that starts from untouched values (its three rows, the row
 		 * above, the coefficient before) can be evaluated by anybody: a thread a row does that first (em: the rows whose step would change
-		 * something), and the walk goes from such a row on until three steps in a row have changed nothing -- then every value a step looks at is
-		 * untouched again and it jumps to the next row of em.  (One thread doing all 2 x 255 steps was a fifth of the kernel's time.) */
+		 * something), and the walk goes from such a row on until every value the next step looks at is as it was -- then it jumps to the next row
+		 * of em.  (One thread doing all 2 x 255 steps was a fifth of the kernel's time.) */
 		uint64_t *em = reinterpret_cast<uint64_t *>(lds + 4376);    /* [2][4] */
+		int16_t *oc0f = lds + 4408, *pcf = lds + 4668, *lcf = lds + 4928;   /* what the walks leave: column 0's cells, column 255's samples and coefficients (the packed copies stay as they were: a walk compares with them) */
 		auto next_set = [&](const uint64_t *m, int r) {
 			for (int w = r >> 6; w < 4; w++) { uint64_t x = m[w]; if (w == (r >> 6)) x &= ~0ull << (r & 63); if (x) return 64 * w + (int)__builtin_ctzll(x); }
 			return H;
@@ -718,26 +755,29 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 			if ((tid & 63) == 0) em[tid >> 6] = m;
 		}
 		oc[tid] = 0; rc[tid] = held(pc[tid] - ocs[tid]);           /* column 255 where its walk changes nothing */
+		for (int t = tid; t < H + 2; t += NT) { oc0f[t] = oc0[t]; pcf[t] = pc[t]; }
+		lcf[tid] = lc[tid];
 		BARRIER();
 		if (!tid) PROF(c, 53);
-		if (tid == 0) {                                             /* column 0: column 255 reads its LL1 cells */
+		if (tid == 0) {                                             /* column 0: column 255 reads its LL1 cells (oc0f) */
 			ColState cs{ 0, 0, 0, 0, 0 };
-			int prev = 0, quiet = 3, r = 0;
+			int prev = 0, r = 0;
+			bool untouched = true;
 			while (r < H - 1) {
-				if (quiet >= 3) {
+				if (untouched) {
 					r = next_set(em, r);
 					if (r >= H - 1) break;
 					const int u = r ? r - 1 : 0;
 					cs = ColState{ pc0[r], oc0[r], pc0[r + 1], oc0[r + 1], r ? pc0[u] - oc0[u] : 0 };
 					prev = r ? (int)lc0[u] : (int)pc[0];
 				}
-				const int o0 = cs.o0, v1 = cs.v1, o1 = cs.o1, v2 = pc0[r + 2], lv0 = lc0[r];
-				int lv = lv0, of;
-				classify_step_reg(ktab, q, r, cs, v2, oc0[r + 2], lv, prev, [&](int dr) { return (int)d1[r + dr]; }, of);
-				if (of != o0 || cs.v0 != v1 || cs.o0 != o1 || cs.v1 != v2 || lv != lv0) { quiet = 0; oc0[r] = (int16_t)of; oc0[r + 1] = (int16_t)cs.o0; } else quiet++;
+				int lv = lc0[r], of;
+				classify_step_reg(ktab, q, r, cs, pc0[r + 2], oc0[r + 2], lv, prev, [&](int dr) { return (int)d1[r + dr]; }, of);
+				oc0f[r] = (int16_t)of; oc0f[r + 1] = (int16_t)cs.o0;
+				untouched = cs.v0 == pc0[r + 1] && cs.o0 == oc0[r + 1] && cs.v1 == pc0[r + 2] && cs.dm1 == pc0[r] - oc0[r] && lv == lc0[r];   /* everything the next step looks at */
 				prev = lv; r++;
 #ifdef NHW_PROFILE
-				reinterpret_cast<unsigned long long *>(c->prof)[57] += 1000; if (!quiet) reinterpret_cast<unsigned long long *>(c->prof)[59] += 1000;
+				reinterpret_cast<unsigned long long *>(c->prof)[57] += 1000;
 #endif
 			}
 		}
@@ -750,7 +790,7 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 				ColState cs{ pc[t], ocs[t], pc[t + 1], ocs[t + 1], t ? pc[u] - ocs[u] : 0 };
 				const int lv0 = lc[t];
 				int lv = lv0, of;
-				classify_step_reg(ktab, q, t, cs, pc[t + 2], ocs[t + 2], lv, t ? (int)lc[u] : (int)pc[H - 1], [&](int dr) { return (int)l0[t + dr] - (int)oc0[t + dr + 1]; }, of);
+				classify_step_reg(ktab, q, t, cs, pc[t + 2], ocs[t + 2], lv, t ? (int)lc[u] : (int)pc[H - 1], [&](int dr) { return (int)l0[t + dr] - (int)oc0f[t + dr + 1]; }, of);
 				eff = of != ocs[t] || cs.v0 != pc[t + 1] || cs.o0 != ocs[t + 1] || cs.v1 != pc[t + 2] || lv != lv0;
 				eff |= t >= H - 3;                                    /* rows 253, 254 look at (255, 256), which step 0 may change: always walked */
 			}
@@ -760,36 +800,34 @@ DEV void residuals_fused_par(Ctx *c, int res_setting, int tid, int16_t *lds)
 		BARRIER();
 		if (tid == 0) {
 			ColState cs{ 0, 0, 0, 0, 0 };
-			int prev = 0, quiet = 3, r = 0;
-			hl0_255 = pc[H];
+			int prev = 0, r = 0;
+			bool untouched = true;
 			while (r < H - 1) {
-				if (quiet >= 3) {
+				if (untouched) {
 					r = next_set(em + 4, r);
 					if (r >= H - 1) break;
 					const int u = r ? r - 1 : 0;
 					cs = ColState{ pc[r], ocs[r], pc[r + 1], ocs[r + 1], r ? pc[u] - ocs[u] : 0 };
 					prev = r ? (int)lc[u] : (int)pc[H - 1];
 				}
-				const int v0 = cs.v0, o0 = cs.o0, v1 = cs.v1, o1 = cs.o1, v2 = pc[r + 2], lv0 = lc[r];
-				int lv = lv0, of;
-				classify_step_reg(ktab, q, r, cs, v2, ocs[r + 2], lv, prev, [&](int dr) { return (int)l0[r + dr] - (int)oc0[r + dr + 1]; }, of);
-				if (of != o0 || cs.v0 != v1 || cs.o0 != o1 || cs.v1 != v2 || lv != lv0) quiet = 0; else quiet++;
-				lc[r] = (int16_t)lv; prev = lv;
+				int lv = lc[r], of;
+				classify_step_reg(ktab, q, r, cs, pc[r + 2], ocs[r + 2], lv, prev, [&](int dr) { return (int)l0[r + dr] - (int)oc0f[r + dr + 1]; }, of);
+				lcf[r] = (int16_t)lv;
 				if (r == 0) l0[H - 1] = (int16_t)lv;                  /* (255, 256) is also this column's neighbour of row 255 */
-				pc[r] = (int16_t)v0; oc[r] = hundredth(of); rc[r] = held(cs.dm1);
-				pc[r + 1] = (int16_t)cs.v0; pc[r + 2] = (int16_t)cs.v1; ocs[r + 1] = (int16_t)cs.o0;   /* what the step leaves below it (the next step, if the walk goes on from here, carries them in registers) */
-				oc[r + 1] = hundredth(cs.o0); rc[r + 1] = held(cs.v0 - cs.o0);
-				r++;
+				oc[r] = hundredth(of); rc[r] = held(cs.dm1);
+				pcf[r + 1] = (int16_t)cs.v0; pcf[r + 2] = (int16_t)cs.v1; oc[r + 1] = hundredth(cs.o0); rc[r + 1] = held(cs.v0 - cs.o0);   /* what the step leaves below it */
+				untouched = cs.v0 == pc[r + 1] && cs.o0 == ocs[r + 1] && cs.v1 == pc[r + 2] && cs.dm1 == pc[r] - ocs[r] && lv == lc[r];
+				prev = lv; r++;
 #ifdef NHW_PROFILE
-				reinterpret_cast<unsigned long long *>(c->prof)[58] += 1000; if (!quiet) reinterpret_cast<unsigned long long *>(c->prof)[60] += 1000;
+				reinterpret_cast<unsigned long long *>(c->prof)[58] += 1000;
 #endif
 			}
-			hl0_255 = pc[H];
+			hl0_255 = pcf[H];
 		}
 		if (!tid) PROF(c, 56);
 		BARRIER();
-		vm1 = pc[j];                                                /* (j, 255) as column 255's walk left it: where Y23 starts */
-		p[(H - 1) * W + H + tid] = lc[tid];                         /* column 255's coefficients, for the piece tile */
+		vm1 = pcf[j];                                               /* (j, 255) as column 255's walk left it: where Y23 starts */
+		p[(H - 1) * W + H + tid] = lcf[tid];                         /* column 255's coefficients, for the piece tile */
 		BARRIER();
 	}
 	if (!tid) PROF(c, 10);
