@@ -19,7 +19,8 @@ void nhw_launch_color(const uint8_t *bgr, int n, int q, int16_t *y, size_t y_str
 void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, int final_level, hipStream_t s,
                          int16_t *save = nullptr, size_t save_plane = 0, int save_row = 0, int save_kind = 0, const uint8_t *src8 = nullptr, size_t src8_plane = 0, int drop_t = 0,
                          const int16_t *alt = nullptr, size_t alt_plane = 0, int alt_stride = 0);
-void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s, int drop_nat = 0);
+void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s, int drop_nat = 0,
+                          const uint16_t *verb_list = nullptr, size_t verb_list_stride = 0, const int *verb_len = nullptr, size_t verb_len_stride = 0);
 void nhw_launch_l2_recon(int16_t *jpeg, const int16_t *proc, size_t plane_stride, int16_t *ll1, size_t ll1_stride, int n, hipStream_t s);
 void nhw_launch_synth(uint8_t *bgr, int n, uint32_t seed_base, hipStream_t s);
 void nhw_launch_front_fused(const uint8_t *bgr, int q, uint8_t *pu, uint8_t *pv, size_t c_stride, const int16_t *y, size_t y_stride, int with_prefilter,
@@ -52,6 +53,9 @@ struct nhw_enc {
 	hipStream_t own_stream;
 	hipStream_t part_stream[4];   /* a large batch runs as up to four sub-batches on streams of their own (see nhw_enc_batch_device) */
 	hipEvent_t part_ev[5];
+	hipStream_t ll_stream;        /* the LL2 coder (Y16) beside the second dequantiser simulation */
+	hipEvent_t ll_ev[2];
+	int ll_fork;
 	int parts;
 	hipEvent_t ev[7];
 	bool timed;
@@ -134,6 +138,8 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 		for (int i = 0; i < 7; i++) HIPCHK(hipEventCreate(&e->ev[i]));
 		for (int i = 0; i < 4; i++) HIPCHK(hipStreamCreateWithFlags(&e->part_stream[i], hipStreamNonBlocking));
 		for (int i = 0; i < 5; i++) HIPCHK(hipEventCreateWithFlags(&e->part_ev[i], hipEventDisableTiming));
+		HIPCHK(hipStreamCreateWithFlags(&e->ll_stream, hipStreamNonBlocking));
+		for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&e->ll_ev[i], hipEventDisableTiming));
 		/* the host path's staging buffers, for the whole of max_batch, now: allocated on the first nhw_enc_batch they made that call twice as
 		 * slow as the ones behind it (gigabytes of hipMalloc inside the timed region of whoever measured it) */
 		return host_buffers(e, max_batch);
@@ -143,6 +149,8 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 	e->chroma_fork = 1;
 	if (const char *p = getenv("NHW_CHROMA_FORK")) e->chroma_fork = atoi(p) != 0;
 	e->lists_fork = 1;
+	e->ll_fork = 1;
+	if (const char *p = getenv("NHW_LL_FORK")) e->ll_fork = atoi(p) != 0;
 	if (const char *p = getenv("NHW_LISTS_FORK")) e->lists_fork = atoi(p) != 0;
 	if (const char *p = getenv("NHW_PARTS")) { const int k = atoi(p); if (k >= 1 && k <= 4) e->parts = k; }
 	*out = e;
@@ -165,6 +173,8 @@ extern "C" void nhw_enc_destroy(nhw_enc *e)
 	if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
 	for (int i = 0; i < 4; i++) if (e->part_stream[i]) (void)hipStreamDestroy(e->part_stream[i]);
 	for (int i = 0; i < 5; i++) if (e->part_ev[i]) (void)hipEventDestroy(e->part_ev[i]);
+	if (e->ll_stream) (void)hipStreamDestroy(e->ll_stream);
+	for (int i = 0; i < 2; i++) if (e->ll_ev[i]) (void)hipEventDestroy(e->ll_ev[i]);
 	delete e;
 }
 
@@ -172,10 +182,11 @@ static inline int16_t *plane16(const NhwWs &ws, int b) { return (int16_t *)(ws.b
 static inline uint8_t *plane8(const NhwWs &ws, int b) { return ws.base + ws.off[b]; }
 
 /* the whole launch sequence for the images of one workspace view on one stream; `timed`: record the stage events of nhw_timing */
-static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int quality, void *d_out, uint32_t *d_sizes, int32_t *d_status, hipStream_t s,
+static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, int quality, void *d_out, uint32_t *d_sizes, int32_t *d_status, hipStream_t s,
                      int timed /* 0: no events, 1: ev[0..4] (whole batch), 2: ev[2], ev[3] (tail of the first sub-batch; the caller closes with ev[4]) */,
                      int what = 3 /* bit 0: the front launch group (colour, pre-filter, level-1 analysis), bit 1: everything behind it */)
 {
+	NhwWs ws = ws_in;
 	const int q = quality;
 	const bool low = q <= 16;      /* integer colour, the rationed pre-filter of image_processing.c:838-2423 and the other quality 1..16 forms (nhw_low.hip) */
 	int16_t *jpeg = plane16(ws, B_JPEG), *proc = plane16(ws, B_PROC);
@@ -224,6 +235,8 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	 * luma ones, Y15) and, for q > 21, the band plane that Y29 is done with: it runs on a stream of its own next to the luma tail
 	 * and fills the issue slots the latency-bound luma kernels leave.  U and V share their planes, so they stay in sequence. */
 	const bool fork = timed == 1 && what == 3 && !e->stop_after && e->chroma_fork;
+	const bool fork_ll = fork && q > 13 && !ws.compat && e->ll_fork;
+	ws.defer_verbatim = fork_ll;
 	hipStream_t cs = fork ? e->part_stream[0] : s;
 	auto chroma_head = [&](int comp) -> int {                        /* everything up to the second dequantiser simulation */
 		const bool widen_in_analysis = q > 14 && !ws.dbg;              /* the analysis reads the byte plane itself (the stage checks keep the copy as a stage of its own) */
@@ -287,11 +300,27 @@ static int run_batch(nhw_enc *e, const NhwWs &ws, const void *d_bgr, int n, int 
 	}
 	STAGE_DONE();
 	nhw_launch_wave(WV_EMIT, ws, s);                                 /* Y14, Y15 */
+	/* Y16, the LL2 coder, is a latency-bound parse (0.6 ms at 0.3 TB/s) in front of the vector-bound dequantiser simulation, which only wants its
+	 * list of verbatim samples -- at its very end, to put them back into the block.  Production: the coder runs beside the simulation on a
+	 * stream of its own and the synthesis behind both does the putting back (ws.defer_verbatim).  Not in the compatibility mode and not
+	 * below q14, where the coder's launch also lays out heap neighbours that the passes behind it read (luma_p3_par). */
+	if (fork_ll) {
+		HIPCHK(hipEventRecord(e->ll_ev[0], s));
+		HIPCHK(hipStreamWaitEvent(e->ll_stream, e->ll_ev[0], 0));
+		nhw_launch_phase(PH_L3, ws, 0, out, d_sizes, d_status, e->ll_stream);
+		HIPCHK(hipEventRecord(e->ll_ev[1], e->ll_stream));
+		if (q <= 21) HIPCHK(hipEventRecord(e->part_ev[0], e->ll_stream));   /* exception list of the luma plane complete, and the coder through with the bytes behind the luma samples: the chroma emission writes its own there */
+	} else {
 	nhw_launch_phase(PH_L3, ws, 0, out, d_sizes, d_status, s);
 	if (fork && q <= 21) HIPCHK(hipEventRecord(e->part_ev[0], s));   /* exception list of the luma plane complete */
+	}
 	if (q > 12) {                                                    /* second closed loop (:759-779) */
 	nhw_launch_wave(WV_DQ0, ws, s);
 	STAGE_DONE();
+	if (fork_ll) {
+		HIPCHK(hipStreamWaitEvent(s, e->ll_ev[1], 0));               /* (the coder is long done: the simulation takes twice its time) */
+		nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s, q <= 21 && !ws.dbg, ws.buf<uint16_t>(B_LLMEM, 0), ws.stride[B_LLMEM], &ws.buf<NhwMeta>(B_META, 0)->ll_mem_len, ws.stride[B_META]);
+	} else
 	nhw_launch_synthesis(jpeg, proc, n, ps, W, H, s, q <= 21 && !ws.dbg);   /* its copy in natural orientation is only read by Y19 (q > 21, :766-777) */
 	STAGE_DONE();
 	}

@@ -487,7 +487,10 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 
 template <int S>
 __global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int n,
-                                                   int drop_nat /* the reconstruction in natural orientation is not stored (nothing reads it: the chroma loops, the second luma loop below q22) */)
+                                                   int drop_nat /* the reconstruction in natural orientation is not stored (nothing reads it: the chroma loops, the second luma loop below q22) */,
+                                                   const uint16_t *__restrict__ verb_list, size_t verb_list_stride /* bytes */, const int *__restrict__ verb_len, size_t verb_len_stride /* bytes */
+                                                   /* second luma loop, production: the LL2 samples the LL coder sent verbatim keep their exact value (nhw_encoder.c:2728-2735) -- the work plane's
+                                                    * sample goes over the block's before the block is filtered (the dequantiser simulation did this while the coder ran in front of it) */)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	constexpr int LS = S + 2, HLF = S / 2, PPL = HLF / 64, NT_ = S * 4, NPRE = S * (S / 8) / NT_;
@@ -508,6 +511,12 @@ __global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, 
 		d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
 	}
 	lds_barrier();
+	if (verb_list) {
+		const int nm = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(verb_len) + (size_t)img * verb_len_stride);
+		const uint16_t *vl = reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(verb_list) + (size_t)img * verb_list_stride);
+		for (int i = t; i < nm; i += NT_) { const int idx = vl[i], r = idx >> 7, cc = idx & 127; A[r * LS + cc] = proc[(size_t)r * stride + cc]; }
+		if (nm) lds_barrier();
+	}
 	if (img + (int)gridDim.x < n) {
 		const int16_t *src = jpegb + (size_t)(img + gridDim.x) * plane_stride;
 #pragma unroll
@@ -579,10 +588,11 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
 	}
 }
 
-void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s, int drop_nat)
+void nhw_launch_synthesis(int16_t *jpeg, int16_t *proc, int n, size_t plane_stride, int stride, int size, hipStream_t s, int drop_nat,
+                          const uint16_t *verb_list, size_t verb_list_stride, const int *verb_len, size_t verb_len_stride)
 {
-	if (size == 256) k_dwt_syn<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat);
-	else if (size == 128) k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat);
+	if (size == 256) k_dwt_syn<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat, verb_list, verb_list_stride, verb_len, verb_len_stride);
+	else if (size == 128) k_dwt_syn<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, n, drop_nat, nullptr, 0, nullptr, 0);
 	else {
 		fprintf(stderr, "nhw_launch_synthesis: no kernel for transform size %d (256 and 128 only)\n", size);
 		abort();

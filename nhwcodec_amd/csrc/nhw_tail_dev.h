@@ -37,6 +37,7 @@ struct PosList { uint8_t *list, *bits, *word; NhwPosLens *len; };
 struct Ctx {
 	int q;
 	int compat;                    /* NhwWs::compat */
+	int defer_verbatim;            /* NhwWs::defer_verbatim */
 	const int16_t *stale;          /* compat mode: kernel-map cells (k_front_stale) */
 	int16_t *jpeg, *proc, *cjpeg, *cproc, *ll1, *l2save, *cll1, *cl2save, *keep, *first_order, *band, *hs, *tmp16;
 	uint8_t *pu, *pv, *scan, *ll_bytes, *ll_full, *exw, *res4, *ll_comp, *ll_word, *ch_res, *res_u64, *res_v64;
@@ -60,7 +61,7 @@ DEV void ctx_load(Ctx *c, const NhwWs &ws, int img)
 	NhwMeta *m = ws.buf<NhwMeta>(B_META, img);
 	c->m = m;
 	c->q = ws.q;
-	c->compat = ws.compat; c->stale = ws.buf<int16_t>(B_STALE, img);
+	c->compat = ws.compat; c->defer_verbatim = ws.defer_verbatim; c->stale = ws.buf<int16_t>(B_STALE, img);
 	c->jpeg = ws.buf<int16_t>(B_JPEG, img); c->proc = ws.buf<int16_t>(B_PROC, img);
 	c->cjpeg = ws.buf<int16_t>(B_CJPEG, img); c->cproc = ws.buf<int16_t>(B_CPROC, img);
 	c->ll1 = ws.buf<int16_t>(B_LL1, img); c->l2save = ws.buf<int16_t>(B_L2SAVE, img);

@@ -184,7 +184,7 @@ DEV void wave_ll2(Ctx *c, int part, int lane, bool keep_p, const int16_t *src, i
 		for (int k = 0; k < 3; k++) { v0[k] = v1[k]; v1[k] = v2[k]; v2[k] = v3[k]; v3[k] = vn[k]; }
 		t0 = t1; t1 = t2; t2 = t3; t3 = tn;
 	}
-	if (!part) {                                                   /* samples the LL coder sent verbatim keep their exact value (:2728-2735) */
+	if (!part && !c->defer_verbatim) {                             /* samples the LL coder sent verbatim keep their exact value (:2728-2735); production: the synthesis behind this pass does it (k_dwt_syn), the coder runs beside this kernel */
 		__threadfence_block();
 		const int nm = c->m->ll_mem_len;
 		for (int i = lane; i < nm; i += 64) {

@@ -47,6 +47,7 @@ struct NhwWs {
 	int n;
 	int q;
 	int dbg;      /* the batch driver is stopped after a stage (tests): kernels also write the planes that nothing but a test reads */
+	int defer_verbatim;   /* the LL2 coder (Y16) runs beside the second dequantiser simulation: the samples it sent verbatim are put back by the synthesis behind both (k_dwt_syn) */
 	int compat;   /* 0: canonical (out-of-bounds reads see zeros); 1: the heap neighbours of the stock one-image-per-process binary (nhw_hip.h) */
 	template <typename T> __host__ __device__ T *buf(int b, int img) const { return (T *)(base + off[b] + (size_t)img * stride[b]); }
 };
