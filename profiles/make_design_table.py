@@ -17,12 +17,13 @@ WHAT = {
     "k_dwt_syn<256>": "level-2 luma synthesis of the second closed loop",
     "k_dwt_syn<128>": "level-2 chroma synthesis",
     "k_l2_recon": "first closed loop: level-2 synthesis + Y8 (tags -> reconstruction) + Y9 (LL1 pre-compensation) on one LDS residency of the block",
-    "L1": "Y5 tag level-2 details", "L2": "Y8, Y9 as a kernel of their own (only the tests' stage checks run it)", "L3": "Y16 LL2 coder (parse), Y17",
+    "L1": "Y5 tag level-2 details", "L2": "Y8, Y9 as a kernel of their own (only the tests' stage checks run it)", "L3": "Y16 LL2 coder (parse), on a stream of its own beside the second dequantiser simulation",
     "L4A": "Y19-Y23: small runs (wavefront per row), residual classification (one table-driven step for every kind) and coding (column walks on LDS tiles)",
     "L4B": "Y24, Y25 position lists + list packing", "L4C": "Y27 detail clean-up (a wavefront takes 64 consecutive rows, neighbours in registers; Y26 only for q >= 22)", "L4D": "Y31 rewrites, on the symbol LIST (non-zero map + values); leaves map and offsets in stream order",
     "L4C2": "Y29 (q >= 22): band reconstruction, half synthesis, res6 / char_res1 / qsetting3 lists",
     "C0": "chroma: copy", "C2": "chroma: dequantiser simulation 1", "C3": "chroma: tags", "C4": "chroma: dequantiser simulation 2",
     "C5": "chroma: marks (running-index fixed point), LL2 emission, quantiser (wavefront per row); V leaves the merged chroma stream as a list", "LLC": "Z1 chroma LL2 coder", "FINAL": "Z2 packetiser + container",
+    "k_l4a": "Y19-Y23 of q >= 17: Y21 small runs (wavefront per row, rows in which nothing fires skipped), Y22 + Y23 as ONE column sweep on registers and class tables (eight workgroups a CU)",
     "k_y31": "Y31 rewrites on the symbol LIST (non-zero map + values), 512 threads an image; leaves map and offsets in stream order",
     "k_final": "Z2 packetiser (both parts from the symbol lists) + container; a kernel of its own at four wavefronts a SIMD",
     "DQ1": "a8 dequantiser simulation, first closed loop (wavefront per image)", "DQ0": "a8 dequantiser simulation, second closed loop",
