@@ -422,6 +422,38 @@ def test_robustness_classes_more_seeds(enc, oracle, q):
     assert not bad, f"q{q}: images {bad} differ from the oracle"
 
 
+def _residual_range_image(kind, seed):
+    """Pictures whose level-1 LL residuals (reconstruction - LL1) sit in the +-2 .. +-9 range where the rules of Y22 / Y23 fire, everywhere and
+    in particular in the first and the last column and in the last rows: a smooth field + low-amplitude noise / stripes / a textured frame."""
+    rng = np.random.RandomState(4000 + seed)
+    yy, xx = np.mgrid[0:512, 0:512]
+    base = 96 + 48 * np.sin(xx / (17.0 + seed)) * np.cos(yy / (23.0 + 2 * seed)) + 0.08 * xx
+    amp = (3, 6, 12, 24, 40)[seed % 5]
+    if kind == "grain":
+        img = base[..., None] + rng.uniform(-amp, amp, (512, 512, 3))
+    elif kind == "stripes":                                       # columns of alternating offsets: the column walks see a chain in every column
+        img = base[..., None] + amp * (((xx // (1 + seed % 3)) & 1) * 2 - 1)[..., None] + rng.uniform(-2, 2, (512, 512, 3))
+    else:                                                         # frame: the texture only in a border of 24 pixels (columns 0, 255 of the LL band; rows 254, 255)
+        img = np.repeat(base[..., None], 3, 2)
+        m = (xx < 24) | (xx >= 488) | (yy < 24) | (yy >= 488)
+        img[m] += rng.uniform(-amp, amp, (int(m.sum()), 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [13, 15, 16, 17, 18, 19, 20, 21, 22, 23])
+def test_residual_rules_under_load(enc, oracle, q):
+    """Y22 and Y23 are one column sweep since round 5 (residuals_fused_par): a prologue settles what the reference's column order couples
+    (step 0 of every column, column 0's and column 255's whole walks, sparsely), Y23 runs from a class table, and Y21 skips the rows in which no
+    cell fires.  The generator's pictures fire these rules in a few per cent of the cells; these fire them everywhere -- grain of five amplitudes,
+    column stripes, a textured frame that loads exactly the coupled columns and the last rows (the write to row 256) -- at every quality that
+    runs the passes, q18 with its rule that also rewrites the cell below."""
+    imgs = [_residual_range_image(k, s) for k in ("grain", "stripes", "frame") for s in range(5)]
+    got = enc.encode(np.stack(imgs), q)
+    bad = [i for i, im in enumerate(imgs) if got[i] != oracle.encode(im, q)]
+    assert not bad, f"q{q}: images {bad} differ from the oracle"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("q", [1, 8, 10, 20, 23])
 def test_full_batch_4096_every_image_bit_exact(q):
@@ -740,10 +772,11 @@ def test_odd_batch_sizes(oracle, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"NHW_CHROMA_FORK": "0"}, {"NHW_LISTS_FORK": "0"}])
+@pytest.mark.parametrize("env", [{"NHW_CHROMA_FORK": "0"}, {"NHW_LISTS_FORK": "0"}, {"NHW_LL_FORK": "0"}])
 def test_encoder_stream_modes_give_the_same_files(oracle, env):
-    """The chroma sequence and the position lists run on streams of their own beside the luma tail; NHW_CHROMA_FORK=0 /
-    NHW_LISTS_FORK=0 put them back in line.  Same arithmetic under another schedule: 512 images at q20 and q23, every file equal to the
+    """The chroma sequence, the position lists and the LL2 coder run on streams of their own beside the luma tail; NHW_CHROMA_FORK=0 /
+    NHW_LISTS_FORK=0 / NHW_LL_FORK=0 put them back in line (the last one also moves the putting back of the verbatim LL2 samples from the
+    synthesis kernel to the dequantiser simulation again).  Same arithmetic under another schedule: 512 images at q20 and q23, every file equal to the
     default schedule's, a sample of them to the oracle's."""
     import torch
     import nhwcodec_amd
