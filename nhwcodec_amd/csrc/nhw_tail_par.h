@@ -948,61 +948,89 @@ DEV void adjust_first_order_par(Ctx *c, int tid, int16_t *lds /* 64 * FO_TP + 96
  * incoming step (none), hand the step they produce to the lane on their right and repeat until no lane's input moves (one extra round as
  * a rule).  Rows are independent, the next one is on its way while this one is evaluated. */
 struct CleanP { int thresh, lim, lim2, last_look; };
+/* one cell, without branches (every lane of a row took most of the chain's branches anyway): e = the cell as the pass leaves it, dout = what
+ * its ripple hands to the cell on its right */
 template <int MODE>
 DEV int clean_cell(const CleanP &f, int x, int n, int v1, int v2, bool look2, int &dout)
 {
-	int e = 0;
 	const int ax = iabs(x);
-	if (ax >= f.thresh) {
-		e = x;
-		if (ax < f.lim2) {
-			if (MODE == 0) { if (n < 3 && x < f.lim && x > -f.lim) { if (x < -6) e = -7; else if (x > 6) e = 7; } }
-			else if (MODE == 1) { if ((n < 3 && x < f.lim && x > -f.lim) || !n) e = x < 0 ? -7 : 7; }
-			else { if (n < 3) e = x < 0 ? -7 : 7; }
-		}
-	}
-	dout = 0;                                                      /* the ripple (:1957-1976 etc.) */
-	if (iabs(e) > 6) {
-		if (e >= 8 && (e & 7) < 2) { if (v1 > 7 && v1 < 10000) dout = -1; }
-		else if (e == -7 && v1 == 8) e = -8;
-		else if (e < -7 && ((-e) & 7) < 2) {
-			if (v1 < -14) { if (((-v1) & 7) == 7) dout = 1; else if (((-v1) & 7) < 2 && look2 && v2 <= 0) dout = 1; }
-		}
-	}
+	const bool keep = ax >= f.thresh, small = keep && ax < f.lim2, in_lim = x < f.lim && x > -f.lim;
+	bool to7;
+	if (MODE == 0) to7 = small && n < 3 && in_lim && ax > 6;
+	else if (MODE == 1) to7 = small && ((n < 3 && in_lim) || !n);
+	else to7 = small && n < 3;
+	int e = keep ? x : 0;
+	e = to7 ? (x < 0 ? -7 : 7) : e;
+	/* the ripple (:1957-1976 etc.): three cases that exclude one another (e >= 8 on 0 / 1 modulo 8; e == -7 beside an 8; e < -7 on 0 / 1 modulo 8) */
+	const int nv1 = -v1;
+	const bool big_p = e >= 8 && (e & 7) < 2, big_n = e < -7 && ((-e) & 7) < 2;
+	const bool up1 = big_n && v1 < -14 && ((nv1 & 7) == 7 || ((nv1 & 7) < 2 && look2 && v2 <= 0));
+	dout = (big_p && v1 > 7 && v1 < 10000) ? -1 : up1 ? 1 : 0;
+	e = (e == -7 && v1 == 8) ? -8 : e;
 	return e;
 }
-/* One row of Y27 for the lanes' four cells each: o = the row as it is, u / d = the rows above and below, far = the cell behind the span
- * (HL1: column 256, lane 63 only).  Returns what the last lane's ripple hands to that cell.   */
+/* One row of Y27 for the lanes' four cells each: o = the row as it is, up / dn = the rows above and below (two cells a dword: only their
+ * loudness is asked for, two cells an instruction), far = the cell behind the span (HL1: column 256, lane 63 only).  Returns what the last
+ * lane's ripple hands to that cell.  The lanes evaluate their cells for "nothing arrives"; where a ripple does arrive, its lane evaluates
+ * its first cell again, and only if that cell now hands on something else than before do the other three follow (they never did in
+ * 99 % of the rows: the second round of the whole row was a third of the pass's instructions). */
 template <int MODE>
-DEV int clean_row(const CleanP &f, const int o[4], const int u[4], const int d[4], int my_far, int upt, int c0, int jb, int je, int lane, int e[4])
+DEV int clean_row(const CleanP &f, const int o[4], uint2 up, uint2 dn, int my_far, int upt, int c0, int jb, int je, int lane, int e[4])
 {
+	typedef short s16x2_ __attribute__((ext_vector_type(2)));
+	typedef unsigned short u16x2_ __attribute__((ext_vector_type(2)));
 	const int left = __shfl_up(o[3], 1), sd0 = __shfl_down(o[0], 1), r2 = __shfl_down(o[1], 1);
 	const int r1 = lane < 63 ? sd0 : my_far;
+	auto loud2 = [](uint32_t w, uint32_t bias) {                  /* per half: |v| >= 0x8000 - bias */
+		const s16x2_ v = __builtin_bit_cast(s16x2_, w);
+		const u16x2_ a = __builtin_bit_cast(u16x2_, __builtin_elementwise_max(v, -v));
+		return __builtin_bit_cast(uint32_t, (u16x2_)((a + __builtin_bit_cast(u16x2_, bias)) >> (u16x2_)(15)));
+	};
+	const uint32_t bu = 0x80008000u - 0x00010001u * (uint32_t)upt, b6 = 0x7FFA7FFAu;
+	const uint32_t s01 = loud2(up.x, bu) + loud2(dn.x, b6), s23 = loud2(up.y, bu) + loud2(dn.y, b6);
 	int n[4]; bool proc[4];
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
 		const int j = c0 + k;
 		proc[k] = j >= jb && j < je;
-		const int lv = k ? o[k - 1] : left, rv = k < 3 ? o[k + 1] : r1;
+		const int lv = k ? o[k ? k - 1 : 0] : left, rv = k < 3 ? o[k < 3 ? k + 1 : k] : r1;
 		const int lt = (MODE == 2 && j - 1 >= jb) ? 7 : 6;
-		n[k] = (iabs(lv) >= lt) + (iabs(rv) >= 6) + (iabs(u[k]) >= upt) + (iabs(d[k]) >= 6);
+		n[k] = (iabs(lv) >= lt) + (iabs(rv) >= 6) + (int)(((k < 2 ? s01 : s23) >> (16 * (k & 1))) & 3u);
 	}
-	int din = 0, dout;
-	for (;;) {
-		int dd = din;
+	int din = 0, dd = 0, d0out = 0;
 #pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const int j = c0 + k, x = o[k] + dd;
-			if (proc[k]) {
-				const int v1 = k < 3 ? o[k + 1] : r1, v2 = k < 2 ? o[k + 2] : (k == 2 ? r1 : r2);
-				e[k] = clean_cell<MODE>(f, x, n[k], v1, v2, j < f.last_look, dd);
-			} else { e[k] = x; dd = 0; }
-		}
-		dout = dd;
+	for (int k = 0; k < 4; k++) {
+		const int x = o[k] + dd;
+		if (proc[k]) {
+			const int v1 = k < 3 ? o[k < 3 ? k + 1 : k] : r1, v2 = k < 2 ? o[k < 2 ? k + 2 : k] : (k == 2 ? r1 : r2);
+			e[k] = clean_cell<MODE>(f, x, n[k], v1, v2, c0 + k < f.last_look, dd);
+		} else { e[k] = x; dd = 0; }
+		if (k == 0) d0out = dd;
+	}
+	int dout = dd;
+	for (;;) {
 		int nd = __shfl_up(dout, 1);
 		if (!lane) nd = 0;
 		if (!__any(nd != din)) break;
 		din = nd;
+		int d0 = 0;
+		{
+			const int x = o[0] + din;
+			if (proc[0]) e[0] = clean_cell<MODE>(f, x, n[0], o[1], o[2], c0 < f.last_look, d0);
+			else e[0] = x;
+		}
+		if (__any(d0 != d0out)) {                                  /* the first cell hands on something else: the rest of the lane's cells again */
+			d0out = d0; dd = d0;
+#pragma unroll
+			for (int k = 1; k < 4; k++) {
+				const int x = o[k] + dd;
+				if (proc[k]) {
+					const int v1 = k < 3 ? o[k < 3 ? k + 1 : k] : r1, v2 = k < 2 ? o[k < 2 ? k + 2 : k] : (k == 2 ? r1 : r2);
+					e[k] = clean_cell<MODE>(f, x, n[k], v1, v2, c0 + k < f.last_look, dd);
+				} else { e[k] = x; dd = 0; }
+			}
+			dout = dd;
+		}
 	}
 	return dout;
 }
@@ -1038,9 +1066,9 @@ DEV void clean_details_seq(Ctx *c, int tid, bool ll_in_plane /* Y26 has put the 
 		uint2 up = ld(r0 - 1, ch), cur = ld(r0, ch), dn = ld(r0 + 1, ch);
 		for (int r = r0; r <= r1; r++) {
 			const uint2 nx = ld(r + 2 < W ? r + 2 : r + 1, ch);      /* (row r1 + 2 is never used) */
-			int o[4], u[4], d[4], e[4];
-			unpack4(cur, o); unpack4(up, u); unpack4(dn, d);
-			clean_row<0>(fa, o, u, d, 0, 6, ch, H + 1, W - 1, lane, e);
+			int o[4], e[4];
+			unpack4(cur, o);
+			clean_row<0>(fa, o, up, dn, 0, 6, ch, H + 1, W - 1, lane, e);
 			st(r, ch, e);
 			up = cur; cur = dn; dn = nx;
 		}
@@ -1052,15 +1080,15 @@ DEV void clean_details_seq(Ctx *c, int tid, bool ll_in_plane /* Y26 has put the 
 			const int rn = r + 2 < W ? r + 2 : W - 1;
 			const uint2 nxl = ld(rn, cl);
 			const uint2 nxh = r + 2 > lo1 ? (r + 2 == lo1 + 1 ? hh_below : make_uint2(0, 0)) : ld(rn, ch);
-			int o[4], u[4], d[4], e[4];
-			unpack4(curl, o); unpack4(upl, u); unpack4(dnl, d);
+			int o[4], e[4];
+			unpack4(curl, o);
 			const int my_far = (int16_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)curh.x) & 0xFFFFu);   /* column 256 of the row: HL1's last cell looks at it, and its ripple may move it */
-			const int dout = clean_row<1>(fb, o, u, d, my_far, 6, cl, 1, H, lane, e);
+			const int dout = clean_row<1>(fb, o, upl, dnl, my_far, 6, cl, 1, H, lane, e);
 			st(r, cl, e);
 			const int moved = __builtin_amdgcn_readlane(dout, 63);    /* HL1's ripple out of column 255 lands in column 256: HH1's first cell (not processed itself, but its neighbour's left) */
-			unpack4(curh, o); unpack4(uph, u); unpack4(dnh, d);
+			unpack4(curh, o);
 			if (lane == 0) o[0] += moved;
-			clean_row<2>(fc, o, u, d, 0, r > H ? 7 : 6, ch, H + 1, W - 1, lane, e);
+			clean_row<2>(fc, o, uph, dnh, 0, r > H ? 7 : 6, ch, H + 1, W - 1, lane, e);
 			st(r, ch, e);
 			upl = curl; curl = dnl; dnl = nxl;
 			uph = curh; curh = dnh; dnh = nxh;

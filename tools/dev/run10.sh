@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5q
-(timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "whole_encoder or robustness or compat_mode or residual_rules or symbol_list" > gpurun_out/r5q/pytest.log 2>&1); tail -5 gpurun_out/r5q/pytest.log
-bash tools/dev/ab.sh tools/dev/old.so 20 23 10 > gpurun_out/r5q/ab.log 2>&1; cat gpurun_out/r5q/ab.log
-(timeout 300 bash profiles/quick.sh r5q_t 20 > gpurun_out/r5q/quick.log 2>&1); grep -i "k_final\|total" gpurun_out/r5q_t/table.txt
+(timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "whole_encoder or robustness or compat_mode or residual_rules or many_seeds" > gpurun_out/r5q/pytest.log 2>&1); tail -5 gpurun_out/r5q/pytest.log
+bash tools/dev/ab.sh tools/dev/old.so 20 23 > gpurun_out/r5q/ab.log 2>&1; cat gpurun_out/r5q/ab.log
+(timeout 300 bash profiles/quick.sh r5q_t 20 > gpurun_out/r5q/quick.log 2>&1); grep -i "k_phase<11>\|total" gpurun_out/r5q_t/table.txt
