@@ -56,6 +56,7 @@ struct nhw_enc {
 	hipStream_t ll_stream;        /* the LL2 coder (Y16) beside the second dequantiser simulation */
 	hipEvent_t ll_ev[2];
 	int ll_fork;
+	int quant_join;               /* the side streams join in front of the luma quantiser (q <= 21) */
 	int parts;
 	hipEvent_t ev[7];
 	bool timed;
@@ -82,7 +83,8 @@ static const size_t k_buf_bytes[B_COUNT] = {
 	/* RESU64 */ 512, /* RESV64 */ 512, /* PACKET */ 320000, /* BOOK1 */ 768, /* BOOK2 */ 768, /* SEL1 */ 16384 + 64, /* SEL2 */ 16384 + 64,
 	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512, /* ROWFLAG (unused) */ 16, /* SEGMAP (unused) */ 16, /* STALE */ (8 + 9 * 512) * 2,
 	/* NZQ (32 x 128 words of 64 bits + 33 flush bases) */ Q / 2 + 256, /* NZS */ Q / 2, /* VOFF */ Q / 4, /* VALS (every symbol non-zero: 4 Q) */ 4 * Q,
-	/* CNZQ (16 flushes x 64 lanes x 2 words of 64 bits + 17 flush bases) */ Q / 4 + 256, /* CVALS */ 2 * Q
+	/* CNZQ (16 flushes x 64 lanes x 2 words of 64 bits + 17 flush bases) */ Q / 4 + 256, /* CVALS */ 2 * Q,
+	/* CJPEG_V */ 2 * Q, /* CPROC_V */ 2 * Q, /* CLL1_V */ Q / 2, /* CL2SAVE_V */ Q / 2, /* UBYTES */ Q
 };
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -150,6 +152,8 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 	if (const char *p = getenv("NHW_CHROMA_FORK")) e->chroma_fork = atoi(p) != 0;
 	e->lists_fork = 1;
 	e->ll_fork = 1;
+	e->quant_join = 1;
+	if (const char *p = getenv("NHW_QUANT_JOIN")) e->quant_join = atoi(p) != 0;
 	if (const char *p = getenv("NHW_LL_FORK")) e->ll_fork = atoi(p) != 0;
 	if (const char *p = getenv("NHW_LISTS_FORK")) e->lists_fork = atoi(p) != 0;
 	if (const char *p = getenv("NHW_PARTS")) { const int k = atoi(p); if (k >= 1 && k <= 4) e->parts = k; }
@@ -238,12 +242,16 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 	const bool fork_ll = fork && q > 13 && !ws.compat && e->ll_fork;
 	ws.defer_verbatim = fork_ll;
 	hipStream_t cs = fork ? e->part_stream[0] : s;
+	ws.split_chroma = fork;                                          /* (the stage checks and the in-line order keep the reference's one set of planes) */
 	auto chroma_head = [&](int comp) -> int {                        /* everything up to the second dequantiser simulation */
+		const bool vp = comp && ws.split_chroma;
+		int16_t *cjpeg = plane16(ws, vp ? B_CJPEG_V : B_CJPEG), *cproc = plane16(ws, vp ? B_CPROC_V : B_CPROC);
+		int16_t *cll1 = plane16(ws, vp ? B_CLL1_V : B_CLL1), *cl2save = plane16(ws, vp ? B_CL2SAVE_V : B_CL2SAVE);
 		const bool widen_in_analysis = q > 14 && !ws.dbg;              /* the analysis reads the byte plane itself (the stage checks keep the copy as a stage of its own) */
 		if (q <= 14) nhw_launch_low_prefilter_chroma(comp ? plane8(ws, B_PV) : plane8(ws, B_PU), ws.stride[B_PU], cjpeg, cps, q, n, cs);   /* :2263 / :2579 */
 		else if (!widen_in_analysis) nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, cs, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2,   /* + the copy of LL1 */
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, cs, cll1, ws.stride[B_CLL1] / 2, H / 2, 2,   /* + the copy of LL1 */
 		                    widen_in_analysis ? (comp ? plane8(ws, B_PV) : plane8(ws, B_PU)) : nullptr, ws.stride[B_PU], !ws.dbg);
 		if (low) nhw_launch_low_chroma_thin(cproc, cps, n, cs);      /* :2277-2308 / :2590-2621 */
 		STAGE_DONE();
@@ -256,7 +264,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 		STAGE_DONE();
 		nhw_launch_phase(PH_C3, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, cs, plane16(ws, B_CL2SAVE), ws.stride[B_CL2SAVE] / 2, H / 2, 1, nullptr, 0, !ws.dbg);   /* + the copy of the level-2 block */
+		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, cs, cl2save, ws.stride[B_CL2SAVE] / 2, H / 2, 1, nullptr, 0, !ws.dbg);   /* + the copy of the level-2 block */
 		STAGE_DONE();
 		STAGE_DONE();
 		nhw_launch_phase(PH_C4, ws, comp, out, d_sizes, d_status, cs);
@@ -274,6 +282,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 	if (fork) {
 		HIPCHK(hipStreamWaitEvent(cs, e->ev[1], 0));                 /* behind the front launch group: that one is bound by vector issue and has nothing to give (and its time is the roofline figure) */
 		CHROMA(chroma_head(0));
+		CHROMA(chroma_head(1));                                      /* V's head in planes of its own, right behind U's: U's quantiser waits for the luma tail, and this stream stood idle until then (2 ms of a q20 step).  (Measured and not taken: V's head on a stream of its own beside U's, +0.3 ms; V's head held back until the second dequantiser simulation is through, +0.4 ms.) */
 	}
 	/* Y4: level-2 analysis (:139) */
 	/* the LL rows come from ll1 (the front's copy of them in natural orientation, res256): the front does not write them into the work plane as well
@@ -309,10 +318,10 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 		HIPCHK(hipStreamWaitEvent(e->ll_stream, e->ll_ev[0], 0));
 		nhw_launch_phase(PH_L3, ws, 0, out, d_sizes, d_status, e->ll_stream);
 		HIPCHK(hipEventRecord(e->ll_ev[1], e->ll_stream));
-		if (q <= 21) HIPCHK(hipEventRecord(e->part_ev[0], e->ll_stream));   /* exception list of the luma plane complete, and the coder through with the bytes behind the luma samples: the chroma emission writes its own there */
+		HIPCHK(hipEventRecord(e->part_ev[0], e->ll_stream));   /* exception list of the luma plane complete, and the coder through with the bytes behind the luma samples: the chroma emission writes its own there */
 	} else {
 	nhw_launch_phase(PH_L3, ws, 0, out, d_sizes, d_status, s);
-	if (fork && q <= 21) HIPCHK(hipEventRecord(e->part_ev[0], s));   /* exception list of the luma plane complete */
+	if (fork) HIPCHK(hipEventRecord(e->part_ev[0], s));              /* exception list of the luma plane complete */
 	}
 	if (q > 12) {                                                    /* second closed loop (:759-779) */
 	nhw_launch_wave(WV_DQ0, ws, s);
@@ -337,23 +346,33 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 	} else if (q > 12)
 		nhw_launch_phase(PH_L4B, ws, 0, out, d_sizes, d_status, s);  /* Y24, Y25 (:1498) */
 	nhw_launch_phase(PH_L4C, ws, 0, out, d_sizes, d_status, s);      /* Y26, Y27 */
-	nhw_launch_wave(WV_QUANT, ws, s);                                /* Y28 (+ Y30: the symbols leave in stream order), every quality */
-	if (q > 21) nhw_launch_phase(PH_L4C2, ws, 0, out, d_sizes, d_status, s);   /* Y29 */
-	if (fork && q > 21) HIPCHK(hipEventRecord(e->part_ev[0], s));    /* ... and the band plane free */
-	if (fork) {                                                      /* queued here so that the wait finds its event recorded */
+	const bool early_join = fork && e->quant_join;
+	auto chroma_rest = [&]() -> int {
 		HIPCHK(hipStreamWaitEvent(cs, e->part_ev[0], 0));
 		CHROMA(chroma_tail(0));
-		CHROMA(chroma_head(1));
 		CHROMA(chroma_tail(1));
 		nhw_launch_phase(PH_LLC, ws, 0, out, d_sizes, d_status, cs);   /* Z1: the chroma LL2 coder appends to the luma one's output (Y16, long done) */
 		HIPCHK(hipEventRecord(e->part_ev[1], cs));
+		return 1;
+	};
+	/* The quantiser is a wavefront an image at 115 registers: four wavefronts fill a SIMD's register file, and it is as fast as its slowest
+	 * wavefront is late.  A side stream's workgroup that sits on a CU when it starts keeps four of its images waiting for a second round (the
+	 * kernel took 3.0 ms beside the chroma sequence, 1.9 alone).  So the side streams are let finish first (they have had the
+	 * multi-round kernels Y19-Y27 to hide behind), and Y31 and the packetiser then run alone as well. */
+	if (early_join) {
+		CHROMA(chroma_rest());
+		if (fork_lists) HIPCHK(hipStreamWaitEvent(s, e->part_ev[3], 0));
+		HIPCHK(hipStreamWaitEvent(s, e->part_ev[1], 0));
 	}
+	nhw_launch_wave(WV_QUANT, ws, s);                                /* Y28 (+ Y30: the symbols leave in stream order), every quality */
+	if (q > 21) nhw_launch_phase(PH_L4C2, ws, 0, out, d_sizes, d_status, s);   /* Y29 */
+	if (fork && !early_join) CHROMA(chroma_rest());                  /* queued here so that the wait finds its event recorded */
 	nhw_launch_phase(PH_L4D, ws, 0, out, d_sizes, d_status, s);      /* Y31 (Y30, the stream order, is the quantisers' output order) */
 	STAGE_DONE();
 	if (timed) HIPCHK(hipEventRecord(e->ev[2], s));
 
-	if (fork_lists) HIPCHK(hipStreamWaitEvent(s, e->part_ev[3], 0));
-	if (fork) HIPCHK(hipStreamWaitEvent(s, e->part_ev[1], 0));
+	if (fork_lists && !early_join) HIPCHK(hipStreamWaitEvent(s, e->part_ev[3], 0));
+	if (fork) { if (!early_join) HIPCHK(hipStreamWaitEvent(s, e->part_ev[1], 0)); }
 	else
 		for (int comp = 0; comp < 2; comp++) {       /* U then V (:2255-2570, :2572-2868) */
 			CHROMA(chroma_head(comp));

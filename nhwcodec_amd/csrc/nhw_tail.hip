@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_phase(NhwWs ws, int comp, uint8_t *out,
 	extern __shared__ __attribute__((aligned(16))) int16_t dyn_lds[];   /* LDS tiles of the row-serial passes (size chosen per phase at launch) */
 	const int img = blockIdx.x, tid = threadIdx.x;
 	Ctx c;
-	ctx_load(&c, ws, img);
+	ctx_load(&c, ws, img, comp);
 	if (PH == PH_L1) luma_p1_par(&c, tid, sh_pos);
 	else if (PH == PH_L2) luma_p2_par(&c, tid, dyn_lds);
 	else if (PH == PH_L3) luma_p3_par(&c, tid, sh_pos, sh_counts, dyn_lds, ws.q <= 12 || ws.dbg != 0);

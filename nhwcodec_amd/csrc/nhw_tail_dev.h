@@ -40,6 +40,7 @@ struct Ctx {
 	int defer_verbatim;            /* NhwWs::defer_verbatim */
 	const int16_t *stale;          /* compat mode: kernel-map cells (k_front_stale) */
 	int16_t *jpeg, *proc, *cjpeg, *cproc, *ll1, *l2save, *cll1, *cl2save, *keep, *first_order, *band, *hs, *tmp16;
+	uint8_t *ubytes;               /* U's symbols, parked until V's quantiser merges them (quantise_chroma_par) */
 	uint8_t *pu, *pv, *scan, *ll_bytes, *ll_full, *exw, *res4, *ll_comp, *ll_word, *ch_res, *res_u64, *res_v64;
 	uint8_t *sel_word1, *sel_word2, *book1, *book2, *raw, *pay, *cc, *half, *s1, *s2;
 	uint16_t *ll_mem, *char_res1;
@@ -56,16 +57,17 @@ struct Ctx {
 
 DEV void poslist_finish(Ctx *c, PosList *pl, uint8_t *raw, int raw_len, const uint8_t *payload, int payload_len, int word_mode);
 
-DEV void ctx_load(Ctx *c, const NhwWs &ws, int img)
+DEV void ctx_load(Ctx *c, const NhwWs &ws, int img, int comp = 0)
 {
+	const bool vp = comp && ws.split_chroma;                       /* the V sequence's own planes */
 	NhwMeta *m = ws.buf<NhwMeta>(B_META, img);
 	c->m = m;
 	c->q = ws.q;
 	c->compat = ws.compat; c->defer_verbatim = ws.defer_verbatim; c->stale = ws.buf<int16_t>(B_STALE, img);
 	c->jpeg = ws.buf<int16_t>(B_JPEG, img); c->proc = ws.buf<int16_t>(B_PROC, img);
-	c->cjpeg = ws.buf<int16_t>(B_CJPEG, img); c->cproc = ws.buf<int16_t>(B_CPROC, img);
+	c->cjpeg = ws.buf<int16_t>(vp ? B_CJPEG_V : B_CJPEG, img); c->cproc = ws.buf<int16_t>(vp ? B_CPROC_V : B_CPROC, img);
 	c->ll1 = ws.buf<int16_t>(B_LL1, img); c->l2save = ws.buf<int16_t>(B_L2SAVE, img);
-	c->cll1 = ws.buf<int16_t>(B_CLL1, img); c->cl2save = ws.buf<int16_t>(B_CL2SAVE, img);
+	c->cll1 = ws.buf<int16_t>(vp ? B_CLL1_V : B_CLL1, img); c->cl2save = ws.buf<int16_t>(vp ? B_CL2SAVE_V : B_CL2SAVE, img);
 	c->keep = ws.buf<int16_t>(B_KEEP, img); c->first_order = ws.buf<int16_t>(B_FIRST, img);
 	c->band = ws.buf<int16_t>(B_BAND, img); c->hs = ws.buf<int16_t>(B_HS, img); c->tmp16 = ws.buf<int16_t>(B_TMP16, img);
 	c->pu = ws.buf<uint8_t>(B_PU, img); c->pv = ws.buf<uint8_t>(B_PV, img); c->scan = ws.buf<uint8_t>(B_SCAN, img);
@@ -84,6 +86,7 @@ DEV void ctx_load(Ctx *c, const NhwWs &ws, int img)
 	c->hist = ws.buf<int>(B_HIST, img);
 	c->nzq = ws.buf<uint64_t>(B_NZQ, img); c->fbase = reinterpret_cast<uint32_t *>(c->nzq + 4096); c->nzs = ws.buf<uint64_t>(B_NZS, img);
 	c->voff = ws.buf<uint32_t>(B_VOFF, img); c->vals = ws.buf<uint8_t>(B_VALS, img);
+	c->ubytes = ws.buf<uint8_t>(B_UBYTES, img);
 	c->cnzq = ws.buf<uint64_t>(B_CNZQ, img); c->cfbase = reinterpret_cast<uint32_t *>(c->cnzq + 2048); c->cvals = ws.buf<uint8_t>(B_CVALS, img);
 	c->prof = ws.buf<uint8_t>(B_PROF, img);
 	c->res1.list = ws.buf<uint8_t>(B_R1LIST, img); c->res1.bits = ws.buf<uint8_t>(B_R1BITS, img); c->res1.word = ws.buf<uint8_t>(B_R1WORD, img); c->res1.len = &m->r1;

@@ -1117,7 +1117,7 @@ DEV void quantise_chroma_par(Ctx *c, int comp, int tid, int16_t *lds, bool write
 {
 	unsigned vtotal = 0;                                            /* V: values this wavefront has appended to the list (wave-uniform) */
 	int16_t *p = c->cproc;
-	uint8_t *ubytes = reinterpret_cast<uint8_t *>(c->band);       /* Q bytes, free during the chroma phases */
+	uint8_t *ubytes = c->ubytes;                                    /* Q bytes of its own (until round 5: the band plane, which Y29 holds above q21) */
 	uint8_t *scan = c->scan + 4 * Q;
 	const int lane = tid & 63, wv = tid >> 6;
 	uint8_t *park = reinterpret_cast<uint8_t *>(lds) + wv * 16 * CQROW;

@@ -23,6 +23,7 @@ enum {
 	B_R6LIST, B_R6BITS, B_R6WORD, B_CHARRES, B_QSET3,
 	B_RESU64, B_RESV64, B_PACKET, B_BOOK1, B_BOOK2, B_SEL1, B_SEL2, B_S1, B_S2, B_HIST, B_META, B_PROF, B_ROWFLAG, B_SEGMAP, B_STALE,
 	B_NZQ, B_NZS, B_VOFF, B_VALS, B_CNZQ, B_CVALS,   /* the luma symbol stream as a list (nhw_tail_wave.h, wave_quantise_luma): non-zero map as the quantiser writes it, the map and the value offsets in stream order (Y31), the values; CNZQ / CVALS: the chroma part's map and values as the chroma quantiser leaves them */
+	B_CJPEG_V, B_CPROC_V, B_CLL1_V, B_CL2SAVE_V, B_UBYTES,   /* the V plane's own copies of the four chroma work planes (production: NhwWs::split_chroma); UBYTES: where the chroma quantiser parks U's symbols until V's come (it used the band plane, and above q21 waited for Y29 to be through with it) */
 	B_COUNT
 };
 
@@ -47,6 +48,7 @@ struct NhwWs {
 	int n;
 	int q;
 	int dbg;      /* the batch driver is stopped after a stage (tests): kernels also write the planes that nothing but a test reads */
+	int split_chroma;     /* the V sequence works in planes of its own (B_*_V), so that its head -- everything up to the second dequantiser simulation -- runs right behind U's instead of behind U's quantiser, which waits for the luma tail's exception list; the stage checks keep the reference's one set of planes */
 	int defer_verbatim;   /* the LL2 coder (Y16) runs beside the second dequantiser simulation: the samples it sent verbatim are put back by the synthesis behind both (k_dwt_syn) */
 	int compat;   /* 0: canonical (out-of-bounds reads see zeros); 1: the heap neighbours of the stock one-image-per-process binary (nhw_hip.h) */
 	template <typename T> __host__ __device__ T *buf(int b, int img) const { return (T *)(base + off[b] + (size_t)img * stride[b]); }

@@ -772,7 +772,7 @@ def test_odd_batch_sizes(oracle, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"NHW_CHROMA_FORK": "0"}, {"NHW_LISTS_FORK": "0"}, {"NHW_LL_FORK": "0"}])
+@pytest.mark.parametrize("env", [{"NHW_CHROMA_FORK": "0"}, {"NHW_LISTS_FORK": "0"}, {"NHW_LL_FORK": "0"}, {"NHW_QUANT_JOIN": "0"}])
 def test_encoder_stream_modes_give_the_same_files(oracle, env):
     """The chroma sequence, the position lists and the LL2 coder run on streams of their own beside the luma tail; NHW_CHROMA_FORK=0 /
     NHW_LISTS_FORK=0 / NHW_LL_FORK=0 put them back in line (the last one also moves the putting back of the verbatim LL2 samples from the
