@@ -250,12 +250,22 @@ void nhw_launch_l2_recon(int16_t *jpeg, const int16_t *proc, size_t plane_stride
 	k_l2_recon<<<n < 256 ? n : 256, 1024, H * (H + 2) * sizeof(int16_t) + 288, s>>>(jpeg, proc, plane_stride, ll1, ll1_stride, n);
 }
 
-/* rows x cols block of shorts between two strided planes, every image of the batch */
+/* rows x cols block of shorts between two strided planes, every image of the batch: a workgroup an image, 16 bytes a thread and turn, four
+ * turns in flight (cols and both pitches are multiples of 8, every row 16-byte aligned: asserted by the launcher).  Until round 5 a thread
+ * moved ONE short and a workgroup one row: 1.6 ms for the 128 KB block of 4096 images (q <= 12), 0.7 TB/s. */
 __global__ __launch_bounds__(256) void k_copy_block(const int16_t *__restrict__ src, size_t src_plane, int src_row,
                                                     int16_t *__restrict__ dst, size_t dst_plane, int dst_row, int rows, int cols)
 {
-	const int img = blockIdx.z, r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-	if (c < cols) dst[(size_t)img * dst_plane + (size_t)r * dst_row + c] = src[(size_t)img * src_plane + (size_t)r * src_row + c];
+	const int16_t *sp = src + (size_t)blockIdx.x * src_plane;
+	int16_t *dp = dst + (size_t)blockIdx.x * dst_plane;
+	const int per = cols >> 3, n = rows * per;
+	for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
+		uint4 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) { const int i = i0 + u * 256; if (i < n) v[u] = reinterpret_cast<const uint4 *>(sp + (size_t)(i / per) * src_row)[i % per]; }
+#pragma unroll
+		for (int u = 0; u < 4; u++) { const int i = i0 + u * 256; if (i < n) reinterpret_cast<uint4 *>(dp + (size_t)(i / per) * dst_row)[i % per] = v[u]; }
+	}
 }
 
 /* dynamic LDS per phase: number of 256-row column tiles (TLS shorts per row) the phase stages at once */
@@ -314,5 +324,6 @@ void nhw_launch_phase(int ph, const NhwWs &ws, int comp, uint8_t *out, uint32_t 
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row,
                            int rows, int cols, int n, hipStream_t s)
 {
-	k_copy_block<<<dim3((cols + 255) / 256, rows, n), 256, 0, s>>>(src, src_plane, src_row, dst, dst_plane, dst_row, rows, cols);
+	if ((cols | src_row | dst_row) & 7 || (src_plane | dst_plane) & 7 || ((uintptr_t)src | (uintptr_t)dst) & 15) { fprintf(stderr, "nhw_launch_copy_block: block not 16-byte aligned\n"); abort(); }
+	k_copy_block<<<n, 256, 0, s>>>(src, src_plane, src_row, dst, dst_plane, dst_row, rows, cols);
 }
