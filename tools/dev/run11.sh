@@ -2,6 +2,6 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5q
 cp nhwcodec_amd/libnhwhip.so /tmp/base.so
 cp tools/dev/prof.so nhwcodec_amd/libnhwhip.so
-python tests/gpu_pass_profile.py 4096 20 > gpurun_out/r5q/prof20.log 2>&1
+python tests/gpu_pass_profile.py 4096 ${1:-20} > gpurun_out/r5q/prof.log 2>&1
 cp /tmp/base.so nhwcodec_amd/libnhwhip.so
-cat gpurun_out/r5q/prof20.log
+cat gpurun_out/r5q/prof.log
