@@ -1001,7 +1001,7 @@ __device__ static const uint8_t k_ll2_thr[13][7] = {          /* wvlt_thrx1..7 b
 DEVI void zero_below(int16_t *v, int lim) { if (iabs_(*v) < lim) *v = 0; }
 }
 #define LS (H / 2)          /* LL2 is 128 x 128 */
-#define LP (LS + 2)         /* LDS row pitch in shorts: a lane per row then walks 64 different banks */
+#define LP (LS + 4)         /* LDS row pitch in shorts.  66 dwords: the skewed walks' lanes (row r0 + l at column t - 2 l: 65 dwords apart) each have a bank of their own, the lane-per-row walks share one between two.  At LS + 2 (65 dwords) it was the other way round, and every read of the skewed walks -- 60 % of the kernel -- was a 32-way conflict */
 /* Hits are kept as four bitmaps over the LL2 cells: the level-1 children under HH1 get the largest of the limits 32 / 34 / 36 that hit the
  * cell (thrx5 is 34 or 36; the other two bands always get thrx6 and thrx6 + 6), and -- q <= 11 -- its level-2 siblings go too.  Zeroing
  * below a limit is idempotent and monotone, and the walks never read what they zero, so the walks only record hits and all lanes clear
@@ -1010,11 +1010,27 @@ DEVI void zero_below(int16_t *v, int lim) { if (iabs_(*v) < lim) *v = 0; }
  * between (:488-583) write the cell diagonally below and read it back in the next row: one raster walk each, on the scalar unit, every
  * cell's eight samples fetched in one go. */
 #define HITBIT(map, cell) atomicOr(&(map)[(cell) >> 5], 1u << ((cell) & 31))
+namespace {
+/* The walks' hits of ONE row of the 128-cell band, kept in the registers of the lane that makes them (every walk's lane hits cells of one
+ * row only) and OR-ed into the row's four map words when the lane is through: an LDS atomic a hit bit was most of a walk step's time. */
+struct RowBits { uint64_t lo, hi; };
+DEVI void row_set(RowBits &m, int pos, int n)                    /* cells pos .. pos + n - 1 (n <= 3, inside the row) */
+{
+	const uint64_t f = (1ull << n) - 1;
+	if (pos < 64) { m.lo |= f << pos; if (pos + n > 64) m.hi |= f >> (64 - pos); } else m.hi |= f << (pos - 64);
+}
+DEVI void row_flush(uint32_t *map, int row, const RowBits &m)   /* the row's words belong to this lane until the next barrier */
+{
+	uint32_t *w = map + row * 4;
+	if (m.lo) { w[0] |= (uint32_t)m.lo; w[1] |= (uint32_t)(m.lo >> 32); }
+	if (m.hi) { w[2] |= (uint32_t)m.hi; w[3] |= (uint32_t)(m.hi >> 32); }
+}
+}
 #define LL2_NT 256
 __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb, size_t plane_stride, int q)
 {
 	/* LDS sized at launch: the buffer and the hit maps -- three of them where thrx5 is 34 (quality 8 .. 12: the first walk's hits and the last
-	 * walk's share a limit and a map), four where it is 36: 39.4 KB, four workgroups to a CU, instead of 41.5 KB and three */
+	 * walk's share a limit and a map), four where it is 36: 39.9 KB, four workgroups to a CU, instead of 42 KB and three */
 	extern __shared__ __attribute__((aligned(16))) int16_t ll2_lds[];
 	int16_t *ll = ll2_lds;
 	uint32_t *h32 = reinterpret_cast<uint32_t *>(ll2_lds + LS * LP + 8), *h34 = h32 + LS * LS / 32, *hsib = h34 + LS * LS / 32;
@@ -1080,6 +1096,7 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 	for (int r = tid; r < LS; r += LL2_NT) {                       /* five cells in a row (:383-486), in place along the row */
 		int16_t *row = ll + r * LP;
 		int v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+		RowBits hits = { 0, 0 };
 		for (int j = 0; j < LS - 4; j++) {
 			const int v4 = row[j + 4];
 			bool h = false;
@@ -1101,12 +1118,11 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 					if ((a >= 0 && bq >= 0) || (a <= 0 && bq <= 0)) h = true;
 				}
 			}
-			if (h) {
-				for (int k = 1; k < 4; k++) { HITBIT(h5, r * LS + j + k); if (deep) HITBIT(hsib, r * LS + j + k); }
-				any1 = 1;
-			}
+			if (h) { row_set(hits, j + 1, 3); any1 = 1; }
 			v0 = v1; v1 = v2; v2 = v3; v3 = v4;
 		}
+		row_flush(h5, r, hits);
+		if (deep) row_flush(hsib, r, hits);
 	}
 	int last = __syncthreads_or(any1) ? 4 : -1;                   /* the inner loop counter's exit value: row 0, column 4 */
 	/* plus shape (+2, :488-533), then flat corner (+1, :535-583): two raster walks in which a hit at (r, j) rewrites cell (r+1, j+1).
@@ -1125,11 +1141,17 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 			const int r = r0 + lane;
 			const bool row_ok = r < LS - 2;
 			const int nrows = LS - 2 - r0 < 64 ? LS - 2 - r0 : 64;
+			/* the window's cells travel in registers: of rows r and r + 1 only the cell two columns ahead is new at a step (the row above
+			 * wrote it one step ago, and writes nothing behind it), of row r + 2 the one cell looked at; what this lane's own hit writes into
+			 * row r + 1 it keeps (three LDS reads a step where there were seven) */
+			int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+			RowBits t32 = { 0, 0 }, tsib = { 0, 0 };                    /* hits on the cells of row r + 1 */
 			for (int t = 0; t < (LS - 2) + 2 * (nrows - 1); t++) {
 				const int j = t - 2 * lane;
 				if (row_ok && j >= 0 && j < LS - 2) {
 					const int16_t *v = ll + r * LP + j;
-					const int a0 = v[0], a1 = v[1], a2 = v[2], b0 = v[LP], b1 = v[LP + 1], b2 = v[LP + 2], c1 = v[2 * LP + 1];
+					if (j == 0) { a0 = v[0]; a1 = v[1]; b0 = v[LP]; b1 = v[LP + 1]; }
+					const int a2 = v[2], b2 = v[LP + 2], c1 = v[2 * LP + 1];
 					bool outer, hit;
 					if (!pass) { outer = false; hit = iabs_(a1 - c1) < t3 && iabs_(b0 - b2) < t3 && iabs_(b1 - b0) < t4 - 1 && iabs_(a1 - b1) < t4; }
 					else {
@@ -1141,14 +1163,17 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 					if (hit) {
 						const int target = (r + 1) * LS + j + 1;
 						const int e = (a1 + c1 + b0 + b2 + (pass ? 1 : 2)) >> 2;
-						if (iabs_(e - b0) < 5 || iabs_(e - b2) < 5) ll[(r + 1) * LP + j + 1] = (int16_t)e;
-						HITBIT(h32, target);
-						if (deep) for (int k = -1; k < 2; k++) HITBIT(hsib, target + k);
+						if (iabs_(e - b0) < 5 || iabs_(e - b2) < 5) { ll[(r + 1) * LP + j + 1] = (int16_t)e; b1 = (int16_t)e; }
+						(void)target;
+						row_set(t32, j + 1, 1);
+						if (deep) row_set(tsib, j, 3);
 						if (pos > hit_max) hit_max = pos;
 						if (pos < hit_min) hit_min = pos;
 					}
+					a0 = a1; a1 = a2; b0 = b1; b1 = b2;
 				}
 			}
+			if (row_ok) { row_flush(h32, r + 1, t32); if (deep) row_flush(hsib, r + 1, tsib); }
 		}
 		for (int d = 32; d; d >>= 1) {                               /* over the rows */
 			const int a = __shfl_xor(hit_max, d), bq = __shfl_xor(hit_min, d), cq = __shfl_xor(outer_min, d);
@@ -1164,8 +1189,14 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 	if (deep)
 		for (int r = tid; r < LS; r += LL2_NT) {                   /* three flat cells in a row (:585-620): reads only */
 			const int16_t *row = ll + r * LP;
-			for (int j = 0; j < LS - 2; j++)
-				if (iabs_(row[j + 2] - row[j + 1]) < t7 && iabs_(row[j + 2] - row[j]) < t7 && iabs_(row[j + 1] - row[j]) < t7) { HITBIT(h34, r * LS + j + 1); HITBIT(hsib, r * LS + j + 1); }
+			RowBits hits = { 0, 0 };
+			int x0 = row[0], x1 = row[1];
+			for (int j = 0; j < LS - 2; j++) {
+				const int x2 = row[j + 2];
+				if (iabs_(x2 - x1) < t7 && iabs_(x2 - x0) < t7 && iabs_(x1 - x0) < t7) row_set(hits, j + 1, 1);
+				x0 = x1; x1 = x2;
+			}
+			row_flush(h34, r, hits); row_flush(hsib, r, hits);
 		}
 	__syncthreads();
 	for (int k = tid; k < LS * LS / 2; k += LL2_NT) {             /* the smoothed LL2 band goes back */
@@ -1238,7 +1269,7 @@ void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipS
 void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s)
 {
 	const int maps = (q <= 7) ? 4 : 3;                               /* k_ll2_thr[q][4] == 36 up to quality 7 */
-	k_low_ll2<<<n, LL2_NT, (size_t)(128 * 130 + 8) * 2 + (size_t)maps * (128 * 128 / 32) * 4, s>>>(proc, plane_stride, q);
+	k_low_ll2<<<n, LL2_NT, (size_t)(128 * 132 + 8) * 2 + (size_t)maps * (128 * 128 / 32) * 4, s>>>(proc, plane_stride, q);   /* 128 rows at the kernel's pitch LP + the hit maps */
 }
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
                               int q, int n, hipStream_t s)
