@@ -58,7 +58,7 @@ typedef struct {
 } nhw_timing;
 
 /* lifecycle: replaces `im.setup=malloc(..)` + per-image mallocs of encode_image (nhw_encoder.c:108-...).  Everything a batch of up to
- * max_batch images needs on the device is allocated here and nowhere else: the workspace (5.6 MB per image) and the staging buffers of the
+ * max_batch images needs on the device is allocated here and nowhere else: the workspace (7.0 MB per image) and the staging buffers of the
  * host path nhw_enc_batch / nhw_enc_synth_batch (1.8 MB per image) -- no call behind it allocates, so the first batch costs what the others do */
 int  nhw_enc_create(int device, int max_batch, nhw_enc **out);
 void nhw_enc_destroy(nhw_enc *e);

@@ -126,7 +126,7 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 		size_t free_b = 0, total_b = 0;
 		HIPCHK(hipMemGetInfo(&free_b, &total_b));
 		const size_t need = total + HOST_PATH_BYTES * (size_t)max_batch;
-		if (need > free_b) {                                       /* 5.6 MB of workspace + 1.8 MB of host-path staging per image: say so instead of failing inside hipMalloc */
+		if (need > free_b) {                                       /* 7.0 MB of workspace + 1.8 MB of host-path staging per image: say so instead of failing inside hipMalloc */
 			char b[200];
 			snprintf(b, sizeof b, "encoder workspace for max_batch %d needs %zu MiB (%.1f MiB per image), %zu MiB of HBM are free", max_batch, need >> 20, (double)need / max_batch / 1048576.0, free_b >> 20);
 			g_err = b;
