@@ -39,28 +39,23 @@ DEV void tag_l2_details_par(Ctx *c, int tid)
 		if (r > 0) { uv = *reinterpret_cast<const uint4 *>(p + at0 - W); u0 = p[at0 - W - 1]; }
 		dv = *reinterpret_cast<const uint4 *>(p + at0 + W); d7 = p[at0 + W + 8];
 		const uint32_t uw[4] = { uv.x, uv.y, uv.z, uv.w }, dw[4] = { dv.x, dv.y, dv.z, dv.w };
-		uint32_t pw[4] = { pv.x, pv.y, pv.z, pv.w }, cw[4] = { cv.x, cv.y, cv.z, cv.w };
+		uint32_t pw[4] = { pv.x, pv.y, pv.z, pv.w }, cw[4] = { cv.x, cv.y, cv.z, cv.w }, aw[4] = { 0, 0, 0, 0 };
 #pragma unroll
 		for (int e = 0; e < 8; e++) {
 			const int s = (int16_t)(pw[e >> 1] >> (16 * (e & 1))), at = at0 + e;
 			const int up = e ? (int)(int16_t)(uw[(e - 1) >> 1] >> (16 * ((e - 1) & 1))) : u0;
 			const int dn = e < 7 ? (int)(int16_t)(dw[(e + 1) >> 1] >> (16 * ((e + 1) & 1))) : d7;
-			int add = 0;
-			if (s < -7) { if (mult8_or_7(-s)) add = 16000; }
-			else if (s < -4) add = 12000;
-			else if (s >= 0) {
-				if (s >= 2 && s < 5) {
-					if (at >= W + 1 && at < 2 * Q - W - 1 && (up != 0 || dn != 0)) add = 12000;
-				}
-				else if (!(s & 7)) add = 12000;
-				else if ((s & 7) == 1) add = 12000;
-				else if (s > 4 && s <= 7) add = 16000;
-			}
-			if (add) {
-				const int cell = (int16_t)(cw[e >> 1] >> (16 * (e & 1))) + add;
-				cw[e >> 1] = (cw[e >> 1] & ~(0xFFFFu << (16 * (e & 1)))) | ((uint32_t)(uint16_t)cell << (16 * (e & 1)));
-			}
+			/* (no branches: eight cells a thread took every arm of the chain in every item, and the pass was bound by the scalar unit's mask
+			 * bookkeeping -- 2 scalar instructions for every vector one) */
+			const bool neg_big = s < -7 && mult8_or_7(-s), neg_mid = s < -4 && s >= -7;
+			const bool p24 = s >= 2 && s < 5, p24_hit = p24 && at >= W + 1 && at < 2 * Q - W - 1 && (up != 0 || dn != 0);
+			const bool pos = s >= 0 && !p24, p01 = pos && (s & 7) < 2, p57 = pos && !p01 && s > 4 && s <= 7;
+			const int add = (neg_big || p57) ? 16000 : (neg_mid || p24_hit || p01) ? 12000 : 0;
+			aw[e >> 1] |= (uint32_t)add << (16 * (e & 1));
 		}
+		typedef unsigned short u16x2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+		for (int i = 0; i < 4; i++) cw[i] = __builtin_bit_cast(uint32_t, (u16x2_)(__builtin_bit_cast(u16x2_, cw[i]) + __builtin_bit_cast(u16x2_, aw[i])));   /* each cell in its own half (v_pk_add_u16) */
 		*reinterpret_cast<uint4 *>(c->ll1 + r * H + j0) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
 	}
 }
