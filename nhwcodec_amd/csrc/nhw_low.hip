@@ -1036,6 +1036,7 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 	uint32_t *h32 = reinterpret_cast<uint32_t *>(ll2_lds + LS * LP + 8), *h34 = h32 + LS * LS / 32, *hsib = h34 + LS * LS / 32;
 	uint32_t *h36 = k_ll2_thr[q <= 12 ? q : 12][4] == 36 ? hsib + LS * LS / 32 : h34;
 	__shared__ int stale_hits;
+	__shared__ int walk_red[4][3];
 	int16_t *p = procb + (size_t)blockIdx.x * plane_stride;
 	const int tid = threadIdx.x, lane = tid & 63;                  /* four wavefronts: the row walks take a thread per row (128 rows), the clearing of children all 256; the two skewed raster walks stay one wavefront */
 
@@ -1134,55 +1135,66 @@ __global__ __launch_bounds__(LL2_NT) void k_low_ll2(int16_t *__restrict__ procb,
 	 * a cell that passes only the outer test marks the target of the hit before it -- marked already -- or, before the first hit of the
 	 * second walk, what the first walk left: its last hit's target, else the 4 / IM_SIZE of the row pass above. */
 	int last0 = last;                                              /* `count` as the second walk finds it */
-	if (tid < 64)
-	for (int pass = 0; pass < 2; pass++) {
+	{
+		/* Both walks at once, on all four wavefronts (until round 5: one wavefront, the walks and their two blocks of rows one after the other --
+		 * 1000 steps of a lone wavefront at some 1 300 cycles each, 60 % of the kernel): wavefront w takes walk w >> 1 and rows 64 (w & 1) + lane;
+		 * the row of absolute index r of walk p is at column T - 2 r - LAG p in step T, a workgroup barrier a step.  The first walk's skew
+		 * carries over the block seam unchanged.  The second walk may follow the first LAG = 4 steps behind: at (r, j) it reads rows r .. r + 2
+		 * up to column j + 2, whose last write by the first walk -- cell (r + 2, j + 1), from (r + 1, j) -- lies two steps back; and what it
+		 * writes, (r + 1, j + 1), the first walk has read for the last time -- as (r + 1, j)'s upper middle cell -- two steps before. */
+		constexpr int LAG = 4;
+		const int wv = tid >> 6, pass = wv >> 1, r = 64 * (wv & 1) + lane;
+		const bool row_ok = r < LS - 2;
 		int hit_max = -1, hit_min = 1 << 30, outer_min = 1 << 30;    /* visiting positions r * LS + j */
-		for (int r0 = 0; r0 < LS - 2; r0 += 64) {
-			const int r = r0 + lane;
-			const bool row_ok = r < LS - 2;
-			const int nrows = LS - 2 - r0 < 64 ? LS - 2 - r0 : 64;
-			/* the window's cells travel in registers: of rows r and r + 1 only the cell two columns ahead is new at a step (the row above
-			 * wrote it one step ago, and writes nothing behind it), of row r + 2 the one cell looked at; what this lane's own hit writes into
-			 * row r + 1 it keeps (three LDS reads a step where there were seven) */
-			int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-			RowBits t32 = { 0, 0 }, tsib = { 0, 0 };                    /* hits on the cells of row r + 1 */
-			for (int t = 0; t < (LS - 2) + 2 * (nrows - 1); t++) {
-				const int j = t - 2 * lane;
-				if (row_ok && j >= 0 && j < LS - 2) {
-					const int16_t *v = ll + r * LP + j;
-					if (j == 0) { a0 = v[0]; a1 = v[1]; b0 = v[LP]; b1 = v[LP + 1]; }
-					const int a2 = v[2], b2 = v[LP + 2], c1 = v[2 * LP + 1];
-					bool outer, hit;
-					if (!pass) { outer = false; hit = iabs_(a1 - c1) < t3 && iabs_(b0 - b2) < t3 && iabs_(b1 - b0) < t4 - 1 && iabs_(a1 - b1) < t4; }
-					else {
-						outer = iabs_(a2 - a1) < t3 && iabs_(a1 - a0) < t3 && iabs_(a0 - b0) < t3 && iabs_(a2 - b2) < t3;
-						hit = outer && iabs_(c1 - b0) < t3 && iabs_(b0 - b1) < t4;
-					}
-					const int pos = r * LS + j;
-					if (outer && pos < outer_min) outer_min = pos;
-					if (hit) {
-						const int target = (r + 1) * LS + j + 1;
-						const int e = (a1 + c1 + b0 + b2 + (pass ? 1 : 2)) >> 2;
-						if (iabs_(e - b0) < 5 || iabs_(e - b2) < 5) { ll[(r + 1) * LP + j + 1] = (int16_t)e; b1 = (int16_t)e; }
-						(void)target;
-						row_set(t32, j + 1, 1);
-						if (deep) row_set(tsib, j, 3);
-						if (pos > hit_max) hit_max = pos;
-						if (pos < hit_min) hit_min = pos;
-					}
-					a0 = a1; a1 = a2; b0 = b1; b1 = b2;
+		/* the window's cells travel in registers: of rows r and r + 1 only the cell two columns ahead is new at a step (the row above wrote
+		 * it one step ago, and writes nothing behind it), of row r + 2 the one cell looked at; what this lane's own hit writes into row r + 1 it
+		 * keeps (three LDS reads a step where there were seven) */
+		int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+		RowBits t32 = { 0, 0 }, tsib = { 0, 0 };                      /* hits on the cells of row r + 1 */
+		for (int T = 0; T < (LS - 2) + 2 * (LS - 3) + LAG; T++) {
+			const int j = T - 2 * r - LAG * pass;
+			if (row_ok && j >= 0 && j < LS - 2) {
+				const int16_t *v = ll + r * LP + j;
+				if (j == 0) { a0 = v[0]; a1 = v[1]; b0 = v[LP]; b1 = v[LP + 1]; }
+				const int a2 = v[2], b2 = v[LP + 2], c1 = v[2 * LP + 1];
+				bool outer, hit;
+				if (!pass) { outer = false; hit = iabs_(a1 - c1) < t3 && iabs_(b0 - b2) < t3 && iabs_(b1 - b0) < t4 - 1 && iabs_(a1 - b1) < t4; }
+				else {
+					outer = iabs_(a2 - a1) < t3 && iabs_(a1 - a0) < t3 && iabs_(a0 - b0) < t3 && iabs_(a2 - b2) < t3;
+					hit = outer && iabs_(c1 - b0) < t3 && iabs_(b0 - b1) < t4;
 				}
+				const int pos = r * LS + j;
+				if (outer && pos < outer_min) outer_min = pos;
+				if (hit) {
+					const int e = (a1 + c1 + b0 + b2 + (pass ? 1 : 2)) >> 2;
+					if (iabs_(e - b0) < 5 || iabs_(e - b2) < 5) { ll[(r + 1) * LP + j + 1] = (int16_t)e; b1 = (int16_t)e; }
+					row_set(t32, j + 1, 1);                              /* the target (r + 1, j + 1) */
+					if (deep) row_set(tsib, j, 3);
+					if (pos > hit_max) hit_max = pos;
+					if (pos < hit_min) hit_min = pos;
+				}
+				a0 = a1; a1 = a2; b0 = b1; b1 = b2;
 			}
-			if (row_ok) { row_flush(h32, r + 1, t32); if (deep) row_flush(hsib, r + 1, tsib); }
+			__syncthreads();
 		}
-		for (int d = 32; d; d >>= 1) {                               /* over the rows */
+		if (row_ok) {                                              /* (both walks hit row r + 1: atomics here, one a word and lane) */
+			uint32_t *w32 = h32 + (r + 1) * 4, *wsb = hsib + (r + 1) * 4;
+			const uint32_t m32[4] = { (uint32_t)t32.lo, (uint32_t)(t32.lo >> 32), (uint32_t)t32.hi, (uint32_t)(t32.hi >> 32) };
+			const uint32_t msb[4] = { (uint32_t)tsib.lo, (uint32_t)(tsib.lo >> 32), (uint32_t)tsib.hi, (uint32_t)(tsib.hi >> 32) };
+			for (int k = 0; k < 4; k++) { if (m32[k]) atomicOr(&w32[k], m32[k]); if (deep && msb[k]) atomicOr(&wsb[k], msb[k]); }
+		}
+		for (int d = 32; d; d >>= 1) {                               /* over a wavefront's rows */
 			const int a = __shfl_xor(hit_max, d), bq = __shfl_xor(hit_min, d), cq = __shfl_xor(outer_min, d);
 			hit_max = a > hit_max ? a : hit_max; hit_min = bq < hit_min ? bq : hit_min; outer_min = cq < outer_min ? cq : outer_min;
 		}
-		if (!pass) { if (hit_max >= 0) last0 = hit_max + LS + 1; }    /* target of the walk's last hit: (r+1) * LS + j + 1 */
-		else if (deep && outer_min < hit_min) {                      /* cells that pass the outer test before any hit of this walk */
-			if (last0 < 0) { if (lane == 0) stale_hits = 1; }
-			else if (lane < 3) HITBIT(hsib, last0 - 1 + lane);
+		if (lane == 0) { walk_red[wv][0] = hit_max; walk_red[wv][1] = hit_min; walk_red[wv][2] = outer_min; }
+		__syncthreads();
+		const int hm0 = walk_red[0][0] > walk_red[1][0] ? walk_red[0][0] : walk_red[1][0];
+		const int hmin1 = walk_red[2][1] < walk_red[3][1] ? walk_red[2][1] : walk_red[3][1], omin1 = walk_red[2][2] < walk_red[3][2] ? walk_red[2][2] : walk_red[3][2];
+		if (hm0 >= 0) last0 = hm0 + LS + 1;                           /* target of the first walk's last hit: (r + 1) * LS + j + 1 */
+		if (deep && omin1 < hmin1) {                                 /* cells that pass the outer test before any hit of the second walk */
+			if (last0 < 0) { if (tid == 0) stale_hits = 1; }
+			else if (tid < 3) HITBIT(hsib, last0 - 1 + tid);
 		}
 	}
 	__syncthreads();
