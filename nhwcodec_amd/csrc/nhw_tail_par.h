@@ -2014,12 +2014,28 @@ DEV void thin_l1_low_par(Ctx *c, int tid, int *sh /* shared, >= 2 * NT + 2 ints 
 	const int q = c->q;
 	if (q >= 14) {                                               /* :804-832, pointwise */
 		const int t2 = q == 15 ? 19 : 20;
-		for (int idx = tid; idx < 2 * Q; idx += NT) {
-			int16_t *v = p + 2 * Q + idx;
-			const int col = idx & (W - 1), m = iabs(*v);
-			if (m < DEADZONE) continue;
-			if (col < H) { if (m < 11) *v = 0; }
-			else if (m < t2) *v = (int16_t)(*v >= 14 ? 7 : *v <= -14 ? -7 : 0);
+		int16_t *lo = p + 2 * Q;
+		for (int i0 = tid; i0 < 2 * Q / 8; i0 += 4 * NT) {         /* eight cells an item, four items in flight */
+			uint4 w[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) w[u] = reinterpret_cast<const uint4 *>(lo)[i0 + u * NT];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int idx = 8 * (i0 + u * NT);
+				const bool left = (idx & (W - 1)) < H;
+				uint32_t x[4] = { w[u].x, w[u].y, w[u].z, w[u].w };
+				bool ch = false;
+#pragma unroll
+				for (int e = 0; e < 8; e++) {
+					const int v = (int16_t)(x[e >> 1] >> (16 * (e & 1))), m = iabs(v);
+					if (m < DEADZONE) continue;
+					int nv = v;
+					if (left) { if (m < 11) nv = 0; }
+					else if (m < t2) nv = v >= 14 ? 7 : v <= -14 ? -7 : 0;
+					if (nv != v) { x[e >> 1] = (x[e >> 1] & ~(0xFFFFu << (16 * (e & 1)))) | ((uint32_t)(uint16_t)nv << (16 * (e & 1))); ch = true; }
+				}
+				if (ch) reinterpret_cast<uint4 *>(lo)[i0 + u * NT] = make_uint4(x[0], x[1], x[2], x[3]);
+			}
 		}
 		BARRIER();
 		return;
@@ -2153,11 +2169,26 @@ DEV void luma_p4a_par(Ctx *c, int tid, int16_t *lds)
 	if (q > 21) copy_block_par(c->jpeg, W, c->first_order, H, H, H, tid);   /* Y19 :766-777 */
 	if (q <= 15) thin_l1_low_par(c, tid, reinterpret_cast<int *>(lds));     /* Y20 (:804-968) */
 	else if (q < 20) {                                                      /* Y20 (:783-801) */
-		int16_t *p = c->proc;
-		for (int idx = tid; idx < 2 * Q; idx += NT) {
-			int16_t *v = p + 2 * Q + idx;
-			const int col = idx & (W - 1), m = iabs(*v);
-			if (m >= DEADZONE && (col < H ? m < 9 : m <= 14)) *v = (int16_t)(*v > 0 ? 7 : -7);
+		/* (eight cells an item, four items in flight, an item stored only if it changed: a cell a thread and turn was 512 dependent 2-byte
+		 * round trips a thread) */
+		int16_t *p = c->proc + 2 * Q;
+		for (int i0 = tid; i0 < 2 * Q / 8; i0 += 4 * NT) {
+			uint4 w[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) w[u] = reinterpret_cast<const uint4 *>(p)[i0 + u * NT];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int idx = 8 * (i0 + u * NT);
+				const bool left = (idx & (W - 1)) < H;                       /* (an item lies in one half of its row) */
+				uint32_t x[4] = { w[u].x, w[u].y, w[u].z, w[u].w };
+				bool ch = false;
+#pragma unroll
+				for (int e = 0; e < 8; e++) {
+					const int v = (int16_t)(x[e >> 1] >> (16 * (e & 1))), m = iabs(v);
+					if (m >= DEADZONE && (left ? m < 9 : m <= 14)) { x[e >> 1] = (x[e >> 1] & ~(0xFFFFu << (16 * (e & 1)))) | ((uint32_t)(uint16_t)(v > 0 ? 7 : -7) << (16 * (e & 1))); ch = true; }
+				}
+				if (ch) reinterpret_cast<uint4 *>(p)[i0 + u * NT] = make_uint4(x[0], x[1], x[2], x[3]);
+			}
 		}
 	}
 	BARRIER();
