@@ -1,3 +1,5 @@
+#!/bin/bash
+# Developer tool (GPU box): issue counters of the largest kernels, one line each (profiles/collect_valu.sh).
 cd $GRAFT_REPO_ROOT
 bash profiles/collect_valu.sh r5q_v > /dev/null 2>&1
 python - <<'PY'

@@ -1,3 +1,5 @@
+#!/bin/bash
+# Developer tool (GPU box): per-pass clocks inside the tail kernels (tools/dev/prof.so from build_prof.sh; tests/gpu_pass_profile.py).  usage: bash tools/dev/pass_profile.sh [quality]
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5q
 cp nhwcodec_amd/libnhwhip.so /tmp/base.so

@@ -1,3 +1,5 @@
+#!/bin/bash
+# Developer tool (GPU box): start and end of every kernel of one encode step in the default multi-stream run (profiles/timeline_rocpd.py).  usage: bash tools/dev/timeline.sh [quality]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 Q=${1:-20}
 OUT=gpurun_out/r5tl; mkdir -p $OUT; rm -rf $OUT/st
