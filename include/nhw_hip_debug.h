@@ -15,7 +15,7 @@ extern "C" {
 #endif
 
 /* encoder: the next batches stop after launch stage `stage` of the batch driver (0: run to the end).  Stage numbers follow the order of
- * the reference's cross-TU calls in encode_image (nhw_encoder.c:103-2878); tests/gpu_low_debug.py lists them per quality. */
+ * the reference's cross-TU calls in encode_image (nhw_encoder.c:103-2878); tools/dev/gpu_low_debug.py lists them per quality. */
 int nhw_debug_stop_after(nhw_enc *e, int stage);
 /* encoder: every carry segment of the fused front kernel takes its exact replay (the path the look-back falls back to) */
 int nhw_debug_front_fallback(nhw_enc *e, int on);

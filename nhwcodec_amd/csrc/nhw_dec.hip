@@ -1188,7 +1188,8 @@ __global__ __launch_bounds__(256) void k_dec_expand(DecWs ws)
 		int pend0 = X_NONE;                                       /* value a column-511 symbol of the previous row writes to column 0 of this one */
 		int upf[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) upf[k] = a[(size_t)(DH - 1) * DW + DH + lane + 64 * k];
+		for (int k = 0; k < 4; k++)                                   /* row 255's HH half: a group that was not stored is zeros, whatever an earlier batch left in the plane (last_mask is row 255's: loop 1's last store and the put_late above) */
+			upf[k] = ((last_mask >> (32 + 8 * k + (lane >> 3))) & 1ull) ? (int)a[(size_t)(DH - 1) * DW + DH + lane + 64 * k] : 0;
 		for (int i0 = DH; i0 < DW; i0 += XD) {
 			if (i0 + 1 < DW) feed(i0 + 1, i0 + XD < DW ? i0 + XD : DW - 1, i0);
 			__builtin_amdgcn_wave_barrier();

@@ -231,7 +231,7 @@ __device__ __forceinline__ s16x2 pk_diffuse(s16x2 r)
  * a phase is opaque to it: the few adds and shifts are redone every band, and nothing of one phase is alive in another. */
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
-#ifdef NHW_DEV   /* developer builds: 32 rows of a plane in LDS (from row index 1 / 5 on) into a plane in memory, for tests/gpu_front_debug.py */
+#ifdef NHW_DEV   /* developer builds: 32 rows of a plane in LDS (from row index 1 / 5 on) into a plane in memory, for tools/dev/gpu_front_debug.py */
 #define FI_DUMP(kind, base, yl) do { if ((flags & 2) && ((flags >> 4) & 15) == (kind) && keepb) { \
 	for (int k_ = t0; k_ < 32 * 256; k_ += FI_NT) { const int rr_ = 1 + (k_ >> 8), o_ = k_ & 255; \
 		if (r0 + rr_ < W - ((kind) == 2 || (kind) == 3)) reinterpret_cast<uint32_t *>(keepb + (size_t)img * keep_stride + (size_t)(r0 + rr_) * W)[o_] = reinterpret_cast<const uint32_t *>((base) + (rr_ - 1) * ((yl) ? FI_YRS : FI_RS))[(yl) ? FI_YP(o_) : o_]; } \
@@ -245,7 +245,7 @@ __device__ unsigned long long g_fi_prof[16];
 #else
 #define FI_TICK(i) do { } while (0)
 #endif
-#ifdef NHW_DEV   /* developer builds: a switch that ends every band after phase i (tests/gpu_band_ablate.py: the cost of the phases under real contention) */
+#ifdef NHW_DEV   /* developer builds: a switch that ends every band after phase i (tools/dev/gpu_band_ablate.py: the cost of the phases under real contention) */
 #define FI_STAMP(i) do { if (((flags >> 8) & 255) == (i)) { __syncthreads(); continue; } } while (0)
 #else
 #define FI_STAMP(i) do { } while (0)

@@ -23,7 +23,7 @@
 
 static inline int iabs(int v) { return v < 0 ? -v : v; }
 
-/* checkpoint probe (tests/gpu_dec_debug.py): copy one intermediate buffer out of the next decode */
+/* checkpoint probe (tools/dev/gpu_dec_debug.py): copy one intermediate buffer out of the next decode */
 static struct { int id; void *dst; size_t cap, got; } g_probe;
 void nhwo_dec_probe(int id, void *dst, size_t cap) { g_probe.id = id; g_probe.dst = dst; g_probe.cap = cap; g_probe.got = 0; }
 size_t nhwo_dec_probe_len(void) { return g_probe.got; }

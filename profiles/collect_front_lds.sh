@@ -5,7 +5,7 @@ set -u
 TAG=${1:-flds}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-CMD="python tests/gpu_q_timing.py 20"
+CMD="python tools/dev/gpu_q_timing.py 20"
 cp nhwcodec_amd/libnhwhip.so /tmp/new.so
 for v in old new; do
 	if [ $v = old ]; then cp tools/dev/old.so nhwcodec_amd/libnhwhip.so; else cp /tmp/new.so nhwcodec_amd/libnhwhip.so; fi

@@ -7,6 +7,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+DEVTOOLS = os.path.join(ROOT, "tools", "dev")      # the developer scripts (gpu_*.py); four of them hold helpers the tests share
+if DEVTOOLS not in sys.path:
+    sys.path.insert(0, DEVTOOLS)
 
 
 def pytest_configure(config):

@@ -1,7 +1,7 @@
 """Bounded slices of the developer fuzzers in the driver's GPU run (the classes of bug they found in earlier rounds -- chroma pair-mark
 rows whose running index shifts, a cross-XCD race between bands of one image, the rationed pre-filter's rare schedules -- stay guarded):
-  * tests/gpu_fuzz_classes.py: images of mixed classes through the encoder and back through the decoder at q 1, 10, 20, 23 against the oracle;
-  * tests/gpu_hazard_check.py: the images of a synthetic batch whose chroma mark walk ends a row in a pair mark, against the oracle;
+  * tools/dev/gpu_fuzz_classes.py: images of mixed classes through the encoder and back through the decoder at q 1, 10, 20, 23 against the oracle;
+  * tools/dev/gpu_hazard_check.py: the images of a synthetic batch whose chroma mark walk ends a row in a pair mark, against the oracle;
   * bench.py's strong-scaling split at config 4's per-GPU shape (8192 images on one GPU) through the real launcher path.
 Seeded and time-boxed: about a minute of GPU + host time in all."""
 import ctypes
@@ -17,7 +17,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tests.gpu_fuzz_classes import dec_chunk, make, want_chunk  # noqa: E402
+from gpu_fuzz_classes import dec_chunk, make, want_chunk  # noqa: E402
 
 
 @pytest.mark.gpu
@@ -48,12 +48,12 @@ def test_mixed_class_images_encode_and_decode_like_the_oracle(q):
 @pytest.mark.parametrize("q", [5, 8, 11, 14])
 def test_noise_and_hard_edges_at_the_rationed_qualities(q):
     """White noise and hard-edge rectangles at quality 1..16: the images on which the quantisers' rare rules fire (values beyond +-127, the
-    `quant4` pushes out of and into such values, rationed low bits) -- a slice of tests/gpu_fuzz_noise.py, whose full run found a pusher
+    `quant4` pushes out of and into such values, rationed low bits) -- a slice of tools/dev/gpu_fuzz_noise.py, whose full run found a pusher
     that crossed 127 in round 3."""
     from concurrent.futures import ProcessPoolExecutor
     import nhwcodec_amd as na
     from oracle.harness import class_image
-    from tests.gpu_fuzz_noise import want_chunk as noise_want
+    from gpu_fuzz_noise import want_chunk as noise_want
     items = [(k, s) for k in ("noise", "blocks") for s in range(50 + q, 58 + q)]
     imgs = np.stack([class_image(k, s) for k, s in items])
     enc = na.Encoder(0, len(items))
@@ -118,11 +118,11 @@ def test_bench_strong_split_at_config_4_shape():
 @pytest.mark.parametrize("q", [16, 17, 20, 23])
 def test_code_book_overflow_status_matches_the_oracle(q):
     """The reference exits with -1 when the packetiser's code book overflows (compress_pixel.c:234,270,271); the C ABI reports
-    NHW_E_CODEBOOK for THAT image and encodes its neighbours in the batch.  Image: tests/gpu_fuzz_classes.py seed 50431 (overflows from
+    NHW_E_CODEBOOK for THAT image and encodes its neighbours in the batch.  Image: tools/dev/gpu_fuzz_classes.py seed 50431 (overflows from
     quality 17 on, not at 16); oracle side: test_code_book_overflow_is_the_reference_exit."""
     import nhwcodec_amd
     from oracle.oraclepy import Oracle
-    from tests.gpu_fuzz_classes import make, encode_with_status
+    from gpu_fuzz_classes import make, encode_with_status
     o = Oracle()
     imgs = np.stack([o.synth(3), make(50431), o.synth(4), make(50430)])
     enc = nhwcodec_amd.Encoder(0, len(imgs))

@@ -365,7 +365,7 @@ def test_repeated_batches_are_identical():
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,q", [(2429, 20), (2928, 20), (3254, 20), (9205, 23), (9787, 23), (5862, 18)])
 def test_chroma_rows_that_end_in_a_pair_mark(enc, oracle, seed, q):
-    """Images (found with tests/gpu_hazard_check.py) whose chroma mark walk takes a pair mark in the last column of a
+    """Images (found with tools/dev/gpu_hazard_check.py) whose chroma mark walk takes a pair mark in the last column of a
     row: from there on the reference compares against cll1 one cell further on (nhw_encoder.c:2372-2427)."""
     im = oracle.synth(seed)
     assert enc.encode(im[None], q)[0] == oracle.encode(im, q)
@@ -459,7 +459,7 @@ def test_residual_rules_under_load(enc, oracle, q):
 def test_full_batch_4096_every_image_bit_exact(q):
     """BASELINE configs 2 and 3 (-q20; -q1 / -q10 / -q23) at their full size, every one of the 4096 outputs against the oracle (oracle
     side spread over the host cores); -q8 for the band of qualities whose bursts end through t17 (the cut bursts of the chain)"""
-    from tests.gpu_enc_fullcheck import full_encode_check
+    from gpu_enc_fullcheck import full_encode_check
     bad = full_encode_check(4096, q, 900000 + q)
     assert not bad, f"q{q}: images {bad[:16]} differ from the oracle"
 
@@ -711,10 +711,10 @@ def test_low_quality_stages_match_the_oracle_trace(oracle, q):
     """The same walk for the quality 1..16 forms: colour, the rationed pre-filter, both filter banks of both closed loops (where the quality
     has them), both dequantiser simulations (offsetY_recons256 with the rationed low bits), Y11/Y12 (through the analysis that follows
     them), the quantiser's plane, and both chroma sequences with pre_processing_UV -- stage by stage against the oracle's checkpoints
-    (the stage plan is the developer tool's, tests/gpu_low_debug.py)."""
+    (the stage plan is the developer tool's, tools/dev/gpu_low_debug.py)."""
     import torch
     import nhwcodec_amd
-    from tests.gpu_low_debug import B, plan_for, read
+    from gpu_low_debug import B, plan_for, read
     seeds = (0, 1)
     e = nhwcodec_amd.Encoder(0, max_batch=len(seeds))
     imgs = np.stack([oracle.synth(s) for s in seeds])

@@ -163,9 +163,9 @@ def test_low_quality_hard_classes_against_real_reference(oracle, ref, kind):
 
 def test_code_book_overflow_is_the_reference_exit(oracle, ref):
     """compress_pixel.c:234,270,271: the reference calls exit(-1) when the packetiser's code book does not fit.  A busy synthetic class image
-    (found by tests/gpu_fuzz_classes.py, seed 50431) does that from quality 17 on and encodes at 16: the oracle reports NHWO_E_CODEBOOK (-2)
+    (found by tools/dev/gpu_fuzz_classes.py, seed 50431) does that from quality 17 on and encodes at 16: the oracle reports NHWO_E_CODEBOOK (-2)
     exactly where the reference exits."""
-    from tests.gpu_fuzz_classes import make
+    from gpu_fuzz_classes import make
     img = make(50431)
     for q in (16, 17, 20, 23):
         try:

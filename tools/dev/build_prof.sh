@@ -1,5 +1,5 @@
 #!/bin/bash
-# Developer tool (container): the working tree's library with the in-kernel per-pass clocks (NHW_PROFILE) -> tools/dev/prof.so, for tests/gpu_pass_profile.py on the GPU box
+# Developer tool (container): the working tree's library with the in-kernel per-pass clocks (NHW_PROFILE) -> tools/dev/prof.so, for tools/dev/gpu_pass_profile.py on the GPU box
 # (there: cp tools/dev/prof.so nhwcodec_amd/libnhwhip.so before, and the tree's own library back after).
 set -e
 D=$(mktemp -d)

@@ -1,7 +1,7 @@
 """Developer tool (GPU box): the compact band plane of Y29 (q >= 22) against a plain walk over the oracle's quantised plane."""
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import nhwcodec_amd
 from oracle.oraclepy import Oracle

@@ -1,8 +1,8 @@
 """Developer tool (GPU box): run the HIP decoder stage by stage against the oracle's checkpoints.
-usage: python tests/gpu_dec_debug.py [golden|q,seed ...]"""
+usage: python tools/dev/gpu_dec_debug.py [golden|q,seed ...]"""
 import ctypes, glob, os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import nhwcodec_amd as na
 from oracle.oraclepy import Oracle
 
@@ -13,7 +13,7 @@ def files(args):
     out = []
     for a in args:
         if a == "golden":
-            for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dec", "*.nhw"))):
+            for p in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", "dec", "*.nhw"))):
                 out.append((os.path.basename(p), open(p, "rb").read()))
         else:
             q, s = a.split(",")

@@ -1,7 +1,7 @@
 """Developer tool (GPU box): decode throughput at batch N (files produced by the GPU encoder), hipEvent-timed."""
 import sys, os, time
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import nhwcodec_amd as na
 
 def main():

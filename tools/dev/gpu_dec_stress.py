@@ -1,8 +1,8 @@
 """Developer tool (GPU box): decode one resident batch many times, report files whose pixels ever change.
-usage: python tests/gpu_dec_stress.py [n] [q] [repeats]"""
+usage: python tools/dev/gpu_dec_stress.py [n] [q] [repeats]"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import nhwcodec_amd as na
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -1,9 +1,9 @@
 """Developer tool (GPU box): every image of a full batch against the oracle's encoder, spread over processes.
-usage: python tests/gpu_enc_fullcheck.py [n] [q] [seed_base]"""
+usage: python tools/dev/gpu_enc_fullcheck.py [n] [q] [seed_base]"""
 import hashlib, os, sys
 import numpy as np, torch
 from concurrent.futures import ProcessPoolExecutor
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 
 def enc_chunk(args):
     from oracle.oraclepy import Oracle

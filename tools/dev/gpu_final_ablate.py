@@ -1,7 +1,7 @@
 """Developer tool (GPU box, NHW_DEV build): time of the decoder's final kernel with every band ended after phase i."""
 import os, subprocess, sys
 if len(sys.argv) > 1:
-    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
     import torch, nhwcodec_amd as na
     n = 4096
     enc = na.Encoder(0, n); img = enc.synth_device(n, 7); out, sizes, status = enc.encode_device(img, 20); torch.cuda.synchronize(); enc.close(); del img

@@ -1,5 +1,5 @@
 """Developer tool: the front launch group of chosen (image, quality) pairs against the oracle's stage functions, with the positions that differ.
-usage: python tests/gpu_front_debug.py q seed [seed ...]   (seed: int = synthetic seed, or class:seed)"""
+usage: python tools/dev/gpu_front_debug.py q seed [seed ...]   (seed: int = synthetic seed, or class:seed)"""
 import ctypes, sys
 import numpy as np
 import torch

@@ -1,9 +1,9 @@
 """Developer tool (GPU box): images of many classes (flat / gradient / lattice / sinusoid backgrounds with dots, lines, noise, blocks; grey and
-colour) through the GPU encoder at every quality against the oracle.  usage: python tests/gpu_fuzz_classes.py [n_images] [first_seed]"""
+colour) through the GPU encoder at every quality against the oracle.  usage: python tools/dev/gpu_fuzz_classes.py [n_images] [first_seed]"""
 import hashlib, os, sys
 import numpy as np
 from concurrent.futures import ProcessPoolExecutor
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 
 
 def make(seed):

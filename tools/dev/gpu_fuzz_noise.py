@@ -1,10 +1,10 @@
 """Developer tool (GPU box): white-noise and hard-edge images (the classes where the quantisers' rare rules fire: values beyond +-127, the
 `quant4` pushes, rationed low bits) through the GPU encoder at a range of qualities against the oracle.
-usage: python tests/gpu_fuzz_noise.py [first_seed] [n_per_class] [q_first] [q_last]"""
+usage: python tools/dev/gpu_fuzz_noise.py [first_seed] [n_per_class] [q_first] [q_last]"""
 import hashlib, os, sys
 import numpy as np
 from concurrent.futures import ProcessPoolExecutor
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle.harness import class_image
 
 

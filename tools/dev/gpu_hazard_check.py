@@ -1,7 +1,7 @@
 """Developer tool (GPU box): find images of a synthetic batch whose chroma mark walk ends a row in a pair mark (the
 running-index case of nhw_encoder.c:2372-2427) and compare exactly those against the oracle."""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

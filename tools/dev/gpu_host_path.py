@@ -1,6 +1,6 @@
 """Developer tool (GPU box): throughput of the host-buffer entry point nhw_enc_batch (H2D + encode + compaction + D2H included)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import nhwcodec_amd

@@ -1,12 +1,12 @@
 """Developer tool (GPU box): quality 1..16 -- whole encoder against the oracle, and on a mismatch the batch driver stage by stage against
-the oracle's checkpoint trace.  usage: python tests/gpu_low_debug.py [q ...]"""
+the oracle's checkpoint trace.  usage: python tools/dev/gpu_low_debug.py [q ...]"""
 import ctypes
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import nhwcodec_amd  # noqa: E402
 from oracle.oraclepy import Oracle  # noqa: E402

@@ -2,7 +2,7 @@
 Needs a library built with NHW_PROFILE=1 (python -c 'from nhwcodec_amd.build import build; build(True)')."""
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import nhwcodec_amd
 import torch

@@ -1,9 +1,9 @@
 """Developer tool (GPU box): the q <= 16 luma pre-filter as a stage on a full batch -- ms per batch and a check of some images against the oracle.
-usage: python tests/gpu_prefilter_time.py [q ...]   (NHW_N=<images>; NHW_LOW_DBG acts on developer builds)"""
+usage: python tools/dev/gpu_prefilter_time.py [q ...]   (NHW_N=<images>; NHW_LOW_DBG acts on developer builds)"""
 import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import nhwcodec_amd as na
 from oracle.oraclepy import Oracle
 

@@ -1,8 +1,8 @@
 """Developer tool (GPU box): ms per 4096-image batch for a list of quality settings (inputs and outputs resident in HBM).
-usage: python tests/gpu_q_timing.py [q ...]"""
+usage: python tools/dev/gpu_q_timing.py [q ...]"""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import nhwcodec_amd as na
 
 def main(qs, n=4096):

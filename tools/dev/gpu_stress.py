@@ -1,7 +1,7 @@
 """Developer tool (GPU box): encode the same resident batch many times and report images whose output changes
 between runs (races), with the workspace buffers that differ.  usage: gpu_stress.py [runs] [batch] [quality]"""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -1,7 +1,7 @@
 """Developer tool (GPU box): run the pipeline up to each debug stage many times over one resident batch and report
 the first stage whose workspace planes are not reproducible.  usage: gpu_stress_stage.py [runs] [batch] [quality] [first] [last]"""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import nhwcodec_amd
