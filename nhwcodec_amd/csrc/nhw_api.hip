@@ -34,7 +34,7 @@ enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
 enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2 };
 /* quality 1..16 only (nhw_low.hip) */
-void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
+void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride, uint8_t *chain, size_t chain_stride,
                               int q, int n, hipStream_t s);
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s);
 void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipStream_t s);
@@ -212,7 +212,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 		nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
 		HIPCHK(hipEventRecord(e->ev[5], s));                      /* with the front group, whoever brackets it: nhw_timing.color_dwt_ms / prefilter_ms */
 		STAGE_DONE();
-		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], q, n, s);   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser */
+		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], q, n, s);   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser; pair codes and answers -> the q >= 22 plane */
 		HIPCHK(hipEventRecord(e->ev[6], s));
 		STAGE_DONE();
 		if (ws.compat) nhw_launch_low_stale(proc, ps, plane16(ws, B_STALE), ws.stride[B_STALE], n, s);   /* compatibility mode only: the map cells the stock binary's heap re-uses */
@@ -566,7 +566,7 @@ extern "C" int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, vo
 	const NhwWs &ws = e->ws;
 	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
 	/* in place for the caller: filter into the workspace plane the encoder uses, copy back */
-	nhw_launch_low_prefilter((const int16_t *)d_y, 4 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP] / 2, plane16(ws, B_PROC), ws.stride[B_PROC] / 2, plane8(ws, B_SCAN), ws.stride[B_SCAN], quality, n, s);
+	nhw_launch_low_prefilter((const int16_t *)d_y, 4 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP] / 2, plane16(ws, B_PROC), ws.stride[B_PROC] / 2, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], quality, n, s);
 	HIPCHK(hipMemcpy2DAsync(d_y, 8 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP], 8 * Q, (size_t)n, hipMemcpyDeviceToDevice, s));
 	HIPCHK(hipGetLastError());
 	return NHW_OK;

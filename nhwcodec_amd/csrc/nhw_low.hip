@@ -391,67 +391,43 @@ DEVI int final_pair(const PfP &pp, const int16_t *km, int f0, int f1, int p, int
 
 } // namespace
 
-/* src: the luma plane as the colour kernel wrote it (read only); y: the filtered plane (every row is written).
+/* Passes A..C of the quality 1..16 luma pre-filter as THREE kernels (round 6; until round 5 one kernel, k_low_machine, did all of it a row at
+ * a time on one wavefront: its vector stages -- pass A, codes, apply -- and its scalar chain took turns, and each waited for the other).
  *
- * One wavefront per image, 16 wavefronts per CU.  The counters of pass B tie every pixel pair of an image to the one before it, but what
- * that chain really costs is small once it is taken apart (nhw_low_machine.h):
- *   * the machine never looks at the picture, only at four threshold tests per pair (the pair's code); all 64 lanes compute a row's codes
- *     and the prefix sums of its hits;
- *   * inside a burst the counters move by closed forms, so the pairs of a burst are evaluated one per lane and a whole burst is one step of
- *     the chain (burst_lane / burst_commit: ballots and mask arithmetic on the scalar unit);
- *   * what is left -- a burst's first pair, bursts that wake one of the slow schedules, bursts cut by the end of the row -- goes pair by
- *     pair through machine_step_fast / machine_step on wave-uniform values, i.e. in scalar registers with scalar branches;
- *   * the machine's answers (3 bits per pair) are applied to the row by all lanes (pair_apply, tail rules).
- * Pass A's few order-dependent cells and pass C of the rows that hold a marker (its counters only move at markers: k_low_marks takes all
- * other rows a lane per row) are walked on the scalar unit too; those rows are listed in a 512-bit mask (flag plane, row 0).
- * Passes A..C run as ONE sweep over the rows with two rows of every plane in LDS (9.7 KB); the contrast map, the flags and the picture
- * are written once.
+ *   k_low_pre     pass A (contrast map, :601-764) with its few order-dependent cells, the picture copy with the q <= 14 smoothing (:780-807),
+ *                 and the CODE of every pixel pair (four threshold tests of its two map cells: all the pair machine ever asks about the
+ *                 picture) as ONE stream of 510 x 255 bytes in pass B's order -- the reference's pass B (:770-1992) walks the rows one after
+ *                 the other with its counters running on, so a row's end means nothing to the machine;
+ *   k_low_chain   the pair machine and nothing else: codes in, three answer bits a pair out.  Bursts run across row ends;
+ *   k_low_apply   the answers applied to the picture and the map (pass B's picture side, :840-917 / :996-1001 / :1912-1990), the marker
+ *                 classes, and pass C (:1994-2310) of the rows that hold a marker, in row order (its counters run on from marker to marker).
  *
- * History (front of q10 / q1, ms per 4096-image batch): round 2, two images per wavefront with the machines in lanes 0 and 1: 271 / 176;
- * codes + answers, row-parallel pass C, four images per wavefront, machine_step_fast per pair: 118 / 84; whole bursts: see DESIGN 4.7. */
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_low_machine(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
-                                                    int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q, int dbg)
+ * What makes the split legal: a row's codes are made from the map as pass A left it (source plane + pass A's own state only) and the
+ * machine's answers touch the map only behind the chain, so row r + 1's codes never depend on row r's answers.
+ * src: the luma plane as the colour kernel wrote it (read only); y: the filtered plane (every row is written); km: the contrast map.
+ * Codes and answers: B_KEEP (the q >= 22 plane, free below): CH_BYTES of codes, then CH_BYTES of answers. */
+#define CH_N ((W - 2) * 255)                                           /* pixel pairs of a picture in pass B's order: rows 1 .. 510, pairs 0 .. 254 (cells 1 + 2 p, 2 + 2 p) */
+#define CH_CHUNKS ((CH_N + 255) / 256)
+#define CH_BYTES (CH_CHUNKS * 256)
+
+__global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
+                                                int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ codeb, size_t code_stride, int q, int dbg)
 {
 	__shared__ __attribute__((aligned(16))) int16_t s_src[3][W];
-	__shared__ __attribute__((aligned(16))) int16_t s_km[2][W + 8];
-	__shared__ __attribute__((aligned(16))) int16_t s_y[2][W];
-	__shared__ __attribute__((aligned(16))) uint8_t s_so[2][W];
-	__shared__ __attribute__((aligned(16))) int16_t s_sum[W];             /* pass A: the 8-neighbour sums; behind it: the prefix sums of the pairs' hits (s_hits) */
+	__shared__ __attribute__((aligned(16))) int16_t s_km[W + 8];
+	__shared__ __attribute__((aligned(16))) int16_t s_vb[W];              /* pass A's base values */
+	__shared__ __attribute__((aligned(16))) int16_t s_sum[W];             /* pass A: the 8-neighbour sums */
 	__shared__ __attribute__((aligned(8))) uint8_t s_cand[64];            /* per 8-pixel group: the pixels that need the serial visit of pass A */
-	__shared__ __attribute__((aligned(8))) uint8_t s_cmask[4][64];          /* a marker row's cells by class (c_classify), a bit a cell */
-	__shared__ uint32_t s_rowmask[16];                                     /* rows whose pass C ran here */
 	__shared__ int s_misc[4];
-	int16_t *s_hits = s_sum;
 	const int lane = threadIdx.x, img = blockIdx.x;
 	const PfP pp = pf_params(q);
-
-	if (lane < 16) s_rowmask[lane] = 0;
-	/* wave-uniform: pass A's entry carry, its marker state, the machine of pass B with its cache, the state of pass C, the tail rules' flag */
-	int row_carry = 0, prev_big = 0;
+	int row_carry = 0;                                                 /* wave-uniform: pass A's entry carry and its marker state */
 	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-	MarkState ks = { 0, 0, 0, 0, 0, 0 };
-	PfM mach;
-	PfC mcache;
-	machine_reset(mach);
-	machine_cache(mach, mcache);
-
-#ifdef NHW_DEV
-	long long pclk[14] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, pt0 = 0, st0 = 0;   /* 6..13: the chain's steps by kind, cycles and count */
-#define PCLK_BEGIN() (pt0 = (long long)__builtin_readcyclecounter())
-#define PCLK_END(i) (pclk[i] += (long long)__builtin_readcyclecounter() - pt0)
-#define SCLK_BEGIN() (st0 = (long long)__builtin_readcyclecounter())
-#define SCLK_END(i) (pclk[i] += (long long)__builtin_readcyclecounter() - st0, pclk[(i) + 1]++)
-#else
-#define SCLK_BEGIN() ((void)0)
-#define SCLK_END(i) ((void)0)
-#define PCLK_BEGIN() ((void)0)
-#define PCLK_END(i) ((void)0)
-#endif
 	const int c0 = lane * 8;
 	const int16_t *src = srcb + (size_t)img * src_stride;
 	int16_t *yo = yb + (size_t)img * y_stride;
-	int16_t *kmo = kmb + (size_t)img * km_stride;                      /* contrast map and flags as passes A..C leave them */
-	uint8_t *soo = sob + (size_t)img * so_stride;
+	int16_t *kmo = kmb + (size_t)img * km_stride;                      /* the contrast map as pass A leaves it */
+	uint8_t *code = codeb + (size_t)img * code_stride;
 	auto load_row = [&](int r) { *reinterpret_cast<uint4 *>(&s_src[r % 3][c0]) = *reinterpret_cast<const uint4 *>(src + (size_t)r * W + c0); };
 	/* cells c0 - 1 .. c0 + 8 of a row in LDS (0 outside the row) */
 	auto load10 = [&](const int16_t *row, int *out) {
@@ -468,21 +444,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		out[0] = (uint32_t)(uint16_t)row[lane ? c0 - 1 : 0] ^ 0x8000u; out[9] = (uint32_t)(uint16_t)row[lane < 63 ? c0 + 8 : W - 1] ^ 0x8000u;
 	};
 	load_row(0); load_row(1);
-	for (int k = lane; k < 2 * (W + 8); k += 64) (&s_km[0][0])[k] = 0;
+	for (int k = lane; k < W + 8; k += 64) s_km[k] = 0;
 	__syncthreads();
 	*reinterpret_cast<uint4 *>(yo + c0) = *reinterpret_cast<const uint4 *>(&s_src[0][c0]);      /* row 0 is not touched by any pass */
+	int16_t *km = s_km;
 
 	for (int r = 1; r < W - 1; r++) {
-		PCLK_BEGIN();
 		load_row(r + 1);
 		__syncthreads();
-		PCLK_END(0);
-		PCLK_BEGIN();
 		const int16_t *up = s_src[(r - 1) % 3], *mid = s_src[r % 3], *dn = s_src[(r + 1) % 3];
-		int16_t *km = s_km[r & 1];
-		int16_t *y = s_y[r & 1];
-		uint8_t *so = s_so[r & 1];
-		int16_t *s_vb = y;                                           /* pass A's base values: the row's picture copy is made behind it */
 		/* every lane: 8-neighbour sum and magnitude sum of its 8 pixels (:605-618), as the signed base value 15 |sum| + mag of the carry.
 		 * The three rows' cells c0 - 1 .. c0 + 8 come in as one 16-byte read and two cells a row (a read a neighbour was 72 of them) */
 		int smv[8], vbv[8];
@@ -510,7 +480,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		  for (int e = 0; e < 4; e++) { w4[e] = (uint32_t)(uint16_t)vbv[2 * e] | ((uint32_t)(uint16_t)vbv[2 * e + 1] << 16); z4[e] = (uint32_t)(uint16_t)smv[2 * e] | ((uint32_t)(uint16_t)smv[2 * e + 1] << 16); }
 		  *reinterpret_cast<uint4 *>(&s_vb[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
 		  *reinterpret_cast<uint4 *>(&s_sum[c0]) = make_uint4(z4[0], z4[1], z4[2], z4[3]); }
-		*reinterpret_cast<uint2 *>(&so[c0]) = make_uint2(0, 0);
 		__syncthreads();
 		unsigned cand = 0;
 		if (!(dbg & 1)) {
@@ -570,11 +539,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)valv[2 * e] | ((uint32_t)(uint16_t)valv[2 * e + 1] << 16);
 			  *reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
 			for (int e = 0; e < 8; e++) if (smv[e] != 0 && map_candidate(pp, smv[e], valv[e], ms.bump_count < 3, ms.exact_count == 0)) cand |= 1u << e;
+		} else {
+			*reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(0, 0, 0, 0);
 		}
 		s_cand[lane] = (uint8_t)cand;
-		__syncthreads();                                           /* s_vb is dead from here */
-		PCLK_END(1);
-		PCLK_BEGIN();
+		__syncthreads();
 		/* the few order-dependent pixels of pass A, in raster order, on the scalar unit */
 		if (!(dbg & 1)) {
 			for (int l8 = 0; l8 < 8; l8++) {
@@ -589,15 +558,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			}
 		}
 		__syncthreads();
-		PCLK_END(2);
-		PCLK_BEGIN();
-		uint32_t cw = 0;                                             /* the codes of my four pairs */
-		/* all lanes: the row's picture copy (:566) with the q <= 14 smoothing (:780-807, reads the source copy only), the pair codes of the
-		 * row (lane l has pairs 4 l .. 4 l + 3 = cells 8 l + 1 .. 8 l + 8) and the prefix sums of their hits */
+		/* all lanes: the row's picture copy (:566) with the q <= 14 smoothing (:780-807, reads the source copy only) and the pair codes of the
+		 * row (lane l has pairs 4 l .. 4 l + 3 = cells 8 l + 1 .. 8 l + 8) */
 		{
 			int k9[9];                                                 /* map cells c0 .. c0 + 8 */
-			{ const uint4 kq = *reinterpret_cast<const uint4 *>(&km[c0]);
-			  const uint32_t w4[4] = { kq.x, kq.y, kq.z, kq.w };
+			const uint4 kq = *reinterpret_cast<const uint4 *>(&km[c0]);
+			{ const uint32_t w4[4] = { kq.x, kq.y, kq.z, kq.w };
 			  for (int e = 0; e < 4; e++) { k9[2 * e] = (int16_t)(w4[e] & 0xFFFF); k9[2 * e + 1] = (int16_t)(w4[e] >> 16); }
 			  k9[8] = km[c0 + 8]; }
 			uint32_t yw[4];
@@ -623,49 +589,85 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				const uint4 mq = *reinterpret_cast<const uint4 *>(&mid[c0]);
 				yw[0] = mq.x; yw[1] = mq.y; yw[2] = mq.z; yw[3] = mq.w;
 			}
-			*reinterpret_cast<uint4 *>(&y[c0]) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
-			int hp[4], h = 0;
+			*reinterpret_cast<uint4 *>(yo + (size_t)r * W + c0) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+			*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = kq;
+			uint32_t cw = 0;                                             /* the codes of my four pairs */
 			for (int j = 0; j < 4; j++) {
 				const int k0 = k9[2 * j + 1], k1 = k9[2 * j + 2];
 				const int f0 = iabs_(k0) > pp.sharp, f1 = iabs_(k1) > pp.sharp;
-				const uint32_t code = (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (iabs_(k1) > pp.s2 ? 4u : 0u) | (iabs_(k0) > pp.sharp + 96 ? 8u : 0u);
-				cw |= code << (8 * j);
-				h += f0 + f1; hp[j] = h;
+				const uint32_t cd = (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (iabs_(k1) > pp.s2 ? 4u : 0u) | (iabs_(k0) > pp.sharp + 96 ? 8u : 0u);
+				cw |= cd << (8 * j);
 			}
-			int incl = h;                                              /* inclusive scan of the lanes' totals */
-			for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-			const int excl = incl - h;
-			*reinterpret_cast<uint2 *>(&s_hits[4 * lane]) = make_uint2((uint32_t)(uint16_t)(excl + hp[0]) | ((uint32_t)(uint16_t)(excl + hp[1]) << 16),
-			                                                           (uint32_t)(uint16_t)(excl + hp[2]) | ((uint32_t)(uint16_t)(excl + hp[3]) << 16));
+			uint8_t *cp = code + (size_t)(r - 1) * 255 + 4 * lane;      /* the row's 255 codes go behind the row above's: a lane's four bytes sit at any alignment */
+			cp[0] = (uint8_t)cw; cp[1] = (uint8_t)(cw >> 8); cp[2] = (uint8_t)(cw >> 16);
+			if (lane < 63) cp[3] = (uint8_t)(cw >> 24);                 /* pair 255 does not exist */
 		}
 		__syncthreads();
-		PCLK_END(3);
-		PCLK_BEGIN();
+	}
+	*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
+}
+
+/* The pair machine over a picture's code stream: one wavefront a picture, everything wave-uniform on the scalar unit, the lanes only where a
+ * whole burst is evaluated at once (nhw_low_machine.h).  The stream is taken in chunks of 256 pairs: a lane holds four codes of the chunk,
+ * the inclusive prefix sums of the pairs' hits of this chunk and of the next one (a burst looks up to 63 pairs ahead) stand in a ring of 512
+ * in LDS as 16-bit values (only differences are asked for), the answers collect in the lanes and leave 256 bytes a chunk. */
+__global__ __launch_bounds__(64) void k_low_chain(const uint8_t *__restrict__ codeb, size_t code_stride, uint8_t *__restrict__ actb, size_t act_stride, int dbg)
+{
+	__shared__ __attribute__((aligned(16))) uint16_t s_h[512];
+	const int lane = threadIdx.x, img = blockIdx.x;
+	const uint32_t *cp = reinterpret_cast<const uint32_t *>(codeb + (size_t)img * code_stride);
+	uint32_t *ap = reinterpret_cast<uint32_t *>(actb + (size_t)img * act_stride);
+	PfM mach;
+	PfC mcache;
+	machine_reset(mach);
+	machine_cache(mach, mcache);
+	auto load_codes = [&](int k) -> uint32_t {                         /* the four codes of my pairs of chunk k (0 behind the stream's end) */
+		if (k >= CH_CHUNKS) return 0u;
+		uint32_t w = cp[64 * k + lane];
+		const int rem = CH_N - (256 * k + 4 * lane);
+		if (rem < 4) w = rem <= 0 ? 0u : (w & ((1u << (8 * rem)) - 1u));
+		return w & 0x0F0F0F0Fu;
+	};
+	int tot = 0;                                                       /* hits of all pairs before the chunk that is scanned next */
+	auto scan_chunk = [&](int k, uint32_t w) {
+		const uint32_t hw = (w & 0x01010101u) + ((w >> 1) & 0x01010101u);   /* hits of my four pairs, a byte each */
+		const uint32_t pre = hw * 0x01010101u;                              /* their inclusive sums (at most 8) */
+		const int h = (int)(pre >> 24);
+		int incl = h;
+		for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+		const uint32_t base = (uint32_t)(tot + incl - h);
+		const uint32_t a0 = (base + (pre & 255u)) & 0xFFFFu, a1 = (base + ((pre >> 8) & 255u)) & 0xFFFFu, a2 = (base + ((pre >> 16) & 255u)) & 0xFFFFu, a3 = (base + (pre >> 24)) & 0xFFFFu;
+		*reinterpret_cast<uint2 *>(&s_h[((256 * k) & 511) + 4 * lane]) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+		tot += __builtin_amdgcn_readlane(incl, 63);
+	};
+	int pos = 0, hbase = 0;                                            /* hbase: hits of the pairs before pos */
+	bool give_up = false;                                              /* a burst that was declined is walked pair by pair: to its end, or to the next pair machine_step takes */
+	int cut_at = CH_N;                                                 /* where a burst's pairs end: the stream's end, or the pair that ends the burst through t17 (machine_step's) */
+	uint32_t cw = load_codes(0), cw1 = load_codes(1);
+	scan_chunk(0, cw);
+	for (int k = 0; k < CH_CHUNKS; k++) {
+		const uint32_t cw2 = load_codes(k + 2);
+		scan_chunk(k + 1, cw1);
+		__syncthreads();
+		const int cend = 256 * (k + 1) < CH_N ? 256 * (k + 1) : CH_N;
+		uint32_t aw = 0;                                               /* the answers of my four pairs of this chunk */
 		/* the chain: whole bursts where the counters allow it, single pairs otherwise; everything below is wave-uniform.  The chain's one
-		 * scarce resource is the CU's scalar unit (16 wavefronts share it), so nothing on it goes through LDS: a pair's code comes out of
-		 * the lane that made it (readlane), the hits before the present pair are a running sum, the answers go into the lanes' registers. */
-		uint32_t aw = 0;                                             /* the answers of my four pairs */
+		 * scarce resource is the CU's scalar unit (16 wavefronts share it), so nothing on it goes through LDS but a burst's hits: a pair's
+		 * code comes out of the lane that holds it (readlane), the hits before the present pair are a running sum, the answers go into the
+		 * lanes' registers. */
 		if (!(dbg & 2)) {
-			int pos = 0, hbase = 0;                                  /* hbase: hits of the pairs before pos */
-			bool give_up = false;                                    /* a burst that was declined is walked pair by pair: to its end, or to the next pair machine_step takes */
-			int cut_at = 255;                                        /* where a burst's pairs end: the row's end, or the pair that ends the burst through t17 (machine_step's) */
 			auto single_pair = [&]() {
-				const int code = (int)(((uint32_t)__builtin_amdgcn_readlane((int)cw, pos >> 2) >> (8 * (pos & 3))) & 15u);
-				SCLK_BEGIN();
+				const int code = (int)(((uint32_t)__builtin_amdgcn_readlane((int)cw, (pos >> 2) & 63) >> (8 * (pos & 3))) & 15u);
 				int a = pos == cut_at ? -1 : machine_step_fast(mach, mcache, code);
-				const bool slow = a < 0;
-				if (slow) { a = machine_step(mach, code, r); machine_cache(mach, mcache); give_up = false; cut_at = 255; }
-				if (a && lane == (pos >> 2)) aw |= (uint32_t)a << (8 * (pos & 3));
+				if (a < 0) { a = machine_step(mach, code, 1 + pos / 255); machine_cache(mach, mcache); give_up = false; cut_at = CH_N; }
+				if (a && lane == ((pos >> 2) & 63)) aw |= (uint32_t)a << (8 * (pos & 3));
 				hbase += (code & 1) + ((code >> 1) & 1);
 				pos++;
-				if (slow) SCLK_END(8); else SCLK_END(6);
 			};
-			while (pos < 255) {
+			while (pos < cend) {
 				if (mach.t[1] == 0) give_up = false;                  /* a burst's first pair comes next */
 				else if (!give_up && pos != cut_at && burst_entry_ok(mach, mcache)) {
-					SCLK_BEGIN();
-					const int i = pos + lane < 255 ? pos + lane : 255;
-					const int hj = (int)s_hits[i] - hbase;
+					const int hj = (int)(uint16_t)((uint32_t)s_h[(pos + lane) & 511] - (uint32_t)hbase);    /* hits of pairs pos .. pos + lane */
 					const PfBurstLane b = burst_lane(lane, mach.t[1], mach.t[4], mach.t[44], hj, mach.t[10], mach.t[11], mcache.exT);
 					auto hits_to = [&](int e) { return __builtin_amdgcn_readlane(hj, e); };
 					int n;
@@ -674,29 +676,69 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 					if (burst_quiet(mach, mcache))
 						n = burst_commit_quiet(mach, mcache, (unsigned)m_cap, (unsigned)m_wrap, (unsigned)m_win, (unsigned)m_cyc, mcache.w8z ? (unsigned)m_i6 : 0u, cut_at - pos, hits_to);
 					else {
-						PfBurstMasks k;
-						k.cap = m_cap; k.wrap = m_wrap; k.win = m_win; k.cyc = m_cyc; k.i6 = m_i6;
-						k.iS = __ballot(b.iS); k.cnt = __ballot(b.cnt); k.g13 = __ballot(b.g13); k.e15 = __ballot(b.e15); k.eT = __ballot(b.eT);
-						n = burst_commit(mach, mcache, k, cut_at - pos, hits_to);
+						PfBurstMasks km_;
+						km_.cap = m_cap; km_.wrap = m_wrap; km_.win = m_win; km_.cyc = m_cyc; km_.i6 = m_i6;
+						km_.iS = __ballot(b.iS); km_.cnt = __ballot(b.cnt); km_.g13 = __ballot(b.g13); km_.e15 = __ballot(b.e15); km_.eT = __ballot(b.eT);
+						n = burst_commit(mach, mcache, km_, cut_at - pos, hits_to);
 					}
-					if (n > 0) { hbase += __builtin_amdgcn_readlane(hj, n - 1); pos += n; SCLK_END(10); continue; }
-					/* declined.  If that is because one of its pairs ends it through t17, the burst is taken up to that pair as a burst the row cuts
+					if (n > 0) { hbase += __builtin_amdgcn_readlane(hj, n - 1); pos += n; continue; }
+					/* declined.  If that is because one of its pairs ends it through t17, the burst is taken up to that pair as a burst that is cut
 					 * (the next turn of the loop, with the masks made again: this path must not cost the bursts that are taken anything); the
 					 * pair itself goes through machine_step, and what follows it is a burst again */
-					if (cut_at == 255) {
-						const int w = burst_t17_pair(mach, m_cap, m_wrap, m_win, m_cyc, 255 - pos);
-						if (w >= 1 && w < 255 - pos) { cut_at = pos + w; SCLK_END(12); continue; }
+					if (cut_at == CH_N) {
+						const int w = burst_t17_pair(mach, m_cap, m_wrap, m_win, m_cyc, CH_N - pos);
+						if (w >= 1 && w < CH_N - pos) { cut_at = pos + w; continue; }
 					}
-					cut_at = 255;
+					cut_at = CH_N;
 					give_up = true;
-					SCLK_END(12);
 				}
 				single_pair();                                        /* a first pair, or a pair inside a burst that was declined */
 			}
 		}
+		ap[64 * k + lane] = aw;
+		cw = cw1; cw1 = cw2;
+		__syncthreads();                                            /* the next scan writes where chunk k's sums stand */
+	}
+}
+
+/* act: the chain's answers (a byte a pair, stream order); y / km in: as k_low_pre left them; out: as passes A..C leave them (the rows pass C
+ * walks here are listed in the flag plane's row 0 for k_low_marks). */
+__global__ __launch_bounds__(64) void k_low_apply(int16_t *__restrict__ yb, size_t y_stride, int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride,
+                                                  const uint8_t *__restrict__ actb, size_t act_stride, int q, int dbg)
+{
+	__shared__ __attribute__((aligned(16))) int16_t s_km[2][W + 8];
+	__shared__ __attribute__((aligned(16))) int16_t s_y[2][W];
+	__shared__ __attribute__((aligned(16))) uint8_t s_so[2][W];
+	__shared__ __attribute__((aligned(8))) uint8_t s_cmask[4][64];          /* a marker row's cells by class (c_classify), a bit a cell */
+	__shared__ uint32_t s_rowmask[16];                                     /* rows whose pass C ran here */
+	const int lane = threadIdx.x, img = blockIdx.x;
+	const PfP pp = pf_params(q);
+	if (lane < 16) s_rowmask[lane] = 0;
+	int prev_big = 0;                                                  /* wave-uniform: the tail rules' flag, the state of pass C */
+	MarkState ks = { 0, 0, 0, 0, 0, 0 };
+	const int c0 = lane * 8;
+	int16_t *yo = yb + (size_t)img * y_stride;
+	int16_t *kmo = kmb + (size_t)img * km_stride;                      /* contrast map and flags as passes A..C leave them */
+	uint8_t *soo = sob + (size_t)img * so_stride;
+	const uint8_t *act = actb + (size_t)img * act_stride;
+	for (int k = lane; k < 2 * (W + 8); k += 64) (&s_km[0][0])[k] = 0;
+	auto load_act = [&](int r) -> uint32_t { const uint8_t *p = act + (size_t)(r - 1) * 255 + 4 * lane; return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | (lane < 63 ? (uint32_t)p[3] << 24 : 0u); };
+	uint4 nk = *reinterpret_cast<const uint4 *>(kmo + (size_t)W + c0), ny = *reinterpret_cast<const uint4 *>(yo + (size_t)W + c0);   /* row 1 on its way */
+	uint32_t na = load_act(1);
+	__syncthreads();
+
+	for (int r = 1; r < W - 1; r++) {
+		int16_t *km = s_km[r & 1];
+		int16_t *y = s_y[r & 1];
+		uint8_t *so = s_so[r & 1];
+		*reinterpret_cast<uint4 *>(&km[c0]) = nk;
+		*reinterpret_cast<uint4 *>(&y[c0]) = ny;
+		const uint32_t aw = na;
+		if (r + 1 < W - 1) {
+			nk = *reinterpret_cast<const uint4 *>(kmo + (size_t)(r + 1) * W + c0); ny = *reinterpret_cast<const uint4 *>(yo + (size_t)(r + 1) * W + c0);
+			na = load_act(r + 1);
+		}
 		__syncthreads();
-		PCLK_END(4);
-		PCLK_BEGIN();
 		/* all lanes: the answers applied to the row (pass B's picture side), the tail rules, and the test for markers */
 		bool any_mark;
 		{
@@ -727,6 +769,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			  if (lane) { kc[0] = pk; dd[0] = pd; sv[0] = ps; } }
 			bool mark = false;
 			for (int e = 0; e < 8; e++) mark |= iabs_(kc[e]) > 6000;
+			__syncthreads();                                           /* every lane has read its neighbour's cell 8 l + 8 as pass A left it */
 			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)kc[2 * e] | ((uint32_t)(uint16_t)kc[2 * e + 1] << 16);
 			  *reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
 			{ const uint4 yw = *reinterpret_cast<const uint4 *>(&y[c0]);
@@ -766,24 +809,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			}
 			__syncthreads();
 		}
-		PCLK_END(5);
 		if (r > 1) {                                              /* row r-1 is through passes A..C as far as they run here */
 			*reinterpret_cast<uint4 *>(yo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[(r - 1) & 1][c0]);
 			*reinterpret_cast<uint4 *>(kmo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[(r - 1) & 1][c0]);
 			*reinterpret_cast<uint2 *>(soo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[(r - 1) & 1][c0]);
 		}
+		__syncthreads();
 	}
-	__syncthreads();
 	{
 		const int r = W - 2;
 		*reinterpret_cast<uint4 *>(yo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[r & 1][c0]);
 		*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[r & 1][c0]);
 		*reinterpret_cast<uint2 *>(soo + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[r & 1][c0]);
-		*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
 		if (lane < 16) reinterpret_cast<uint32_t *>(soo)[lane] = s_rowmask[lane];      /* flag plane, row 0: the rows k_low_marks must leave alone */
-#ifdef NHW_DEV
-		if (lane < 14) reinterpret_cast<long long *>(soo + (size_t)(W - 1) * W)[lane] = pclk[lane];   /* developer builds: cycles per phase, in the flag plane's unused last row */
-#endif
 	}
 }
 
@@ -1284,13 +1322,15 @@ void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStr
 	k_low_ll2<<<n, LL2_NT, (size_t)(128 * 132 + 8) * 2 + (size_t)maps * (128 * 128 / 32) * 4, s>>>(proc, plane_stride, q);   /* 128 rows at the kernel's pitch LP + the hit maps */
 }
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
-                              int q, int n, hipStream_t s)
+                              uint8_t *chain /* 2 * CH_BYTES an image: the pair codes, the machine's answers */, size_t chain_stride, int q, int n, hipStream_t s)
 {
 	static int dbg = 0;
 #ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing */
 	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
-	k_low_machine<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, q, dbg);
+	k_low_pre<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, chain, chain_stride, q, dbg);
+	k_low_chain<<<n, 64, 0, s>>>(chain, chain_stride, chain + CH_BYTES, chain_stride, dbg);
+	k_low_apply<<<n, 64, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, chain + CH_BYTES, chain_stride, q, dbg);
 	k_low_marks<<<dim3((W - 2 + MK_R - 2) / (MK_R - 1), n), MK_R, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
 }
 /* Compatibility mode (NHW_COMPAT_GLIBC_ONESHOT) only, quality <= 16: the contrast-map cells whose memory the stock binary's malloc hands
