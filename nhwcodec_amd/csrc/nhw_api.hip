@@ -35,7 +35,7 @@ void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, in
 enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2 };
 /* quality 1..16 only (nhw_low.hip) */
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride, uint8_t *chain, size_t chain_stride,
-                              int q, int n, hipStream_t s);
+                              uint16_t *tab, size_t tab_stride, int q, int n, hipStream_t s);
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s);
 void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipStream_t s);
 void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s);
@@ -84,7 +84,8 @@ static const size_t k_buf_bytes[B_COUNT] = {
 	/* S1     */ 131072, /* S2 */ 131072, /* HIST */ 5632, /* META */ 256, /* PROF */ 512, /* ROWFLAG (unused) */ 16, /* SEGMAP (unused) */ 16, /* STALE */ (8 + 9 * 512) * 2,
 	/* NZQ (32 x 128 words of 64 bits + 33 flush bases) */ Q / 2 + 256, /* NZS */ Q / 2, /* VOFF */ Q / 4, /* VALS (every symbol non-zero: 4 Q) */ 4 * Q,
 	/* CNZQ (16 flushes x 64 lanes x 2 words of 64 bits + 17 flush bases) */ Q / 4 + 256, /* CVALS */ 2 * Q,
-	/* CJPEG_V */ 2 * Q, /* CPROC_V */ 2 * Q, /* CLL1_V */ Q / 2, /* CL2SAVE_V */ Q / 2, /* UBYTES */ Q
+	/* CJPEG_V */ 2 * Q, /* CPROC_V */ 2 * Q, /* CLL1_V */ Q / 2, /* CL2SAVE_V */ Q / 2, /* UBYTES */ Q,
+	/* LOWTAB (8 bytes a pair of the 510 x 255, in whole chunks of 256 pairs) */ 8 * ((510 * 255 + 255) / 256) * 256
 };
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -212,7 +213,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 		nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
 		HIPCHK(hipEventRecord(e->ev[5], s));                      /* with the front group, whoever brackets it: nhw_timing.color_dwt_ms / prefilter_ms */
 		STAGE_DONE();
-		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], q, n, s);   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser; pair codes and answers -> the q >= 22 plane */
+		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], (uint16_t *)plane8(ws, B_LOWTAB), ws.stride[B_LOWTAB], q, n, s);   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser; pair codes and answers -> the q >= 22 plane */
 		HIPCHK(hipEventRecord(e->ev[6], s));
 		STAGE_DONE();
 		if (ws.compat) nhw_launch_low_stale(proc, ps, plane16(ws, B_STALE), ws.stride[B_STALE], n, s);   /* compatibility mode only: the map cells the stock binary's heap re-uses */
@@ -566,7 +567,7 @@ extern "C" int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, vo
 	const NhwWs &ws = e->ws;
 	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
 	/* in place for the caller: filter into the workspace plane the encoder uses, copy back */
-	nhw_launch_low_prefilter((const int16_t *)d_y, 4 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP] / 2, plane16(ws, B_PROC), ws.stride[B_PROC] / 2, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], quality, n, s);
+	nhw_launch_low_prefilter((const int16_t *)d_y, 4 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP] / 2, plane16(ws, B_PROC), ws.stride[B_PROC] / 2, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], (uint16_t *)plane8(ws, B_LOWTAB), ws.stride[B_LOWTAB], quality, n, s);
 	HIPCHK(hipMemcpy2DAsync(d_y, 8 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP], 8 * Q, (size_t)n, hipMemcpyDeviceToDevice, s));
 	HIPCHK(hipGetLastError());
 	return NHW_OK;

@@ -124,6 +124,10 @@ DEVI bool map_candidate(const PfP &pp, int sm, int val, bool bumps_left, bool ex
 	return sm > 0 && ((sm <= s2 && val > s2 && val <= s2 + 20) || (exact_left && val == s2 + 21));
 }
 
+/* a test as 0 / 1 pinned in a vector register: the lanes' flags are combined with vector instructions (as lane masks in scalar register pairs every
+ * AND / OR would be an instruction of the scalar unit, the one thing a CU's sixteen chains share) */
+__device__ static __forceinline__ int pf_bit_(int v) { asm volatile("" : "+v"(v)); return v; }
+#define PF_BIT(x) pf_bit_((int)(x))
 #include "nhw_low_machine.h"
 
 
@@ -607,15 +611,86 @@ __global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb
 	*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
 }
 
-/* The pair machine over a picture's code stream: one wavefront a picture, everything wave-uniform on the scalar unit, the lanes only where a
- * whole burst is evaluated at once (nhw_low_machine.h).  The stream is taken in chunks of 256 pairs: a lane holds four codes of the chunk,
- * the inclusive prefix sums of the pairs' hits of this chunk and of the next one (a burst looks up to 63 pairs ahead) stand in a ring of 512
- * in LDS as 16-bit values (only differences are asked for), the answers collect in the lanes and leave 256 bytes a chunk. */
-__global__ __launch_bounds__(64) void k_low_chain(const uint8_t *__restrict__ codeb, size_t code_stride, uint8_t *__restrict__ actb, size_t act_stride, int dbg)
+/* The burst table of a batch's code streams (nhw_low_machine.h: table_entries): a wavefront takes 256 positions of a picture's stream, a
+ * lane four of them (lane, lane + 64, ..: neighbours read neighbouring cells).  In LDS: the inclusive prefix sums of the hits of the 320
+ * pairs from the chunk's first one on (a burst is over within 21 pairs of the position behind which it starts), and their inverse -- the first
+ * pair at which the sum reaches a value -- which answers "where does the burst's hit count reach K" with one read.  8 bytes a position out. */
+__global__ __launch_bounds__(64) void k_low_table(const uint8_t *__restrict__ codeb, size_t code_stride, uint16_t *__restrict__ tabb, size_t tab_stride)
 {
-	__shared__ __attribute__((aligned(16))) uint16_t s_h[512];
+	__shared__ __attribute__((aligned(16))) uint16_t s_hw[8 + 320];          /* s_hw[8 + w]: hits of the window's pairs 0 .. w; s_hw[7] = 0 */
+	__shared__ __attribute__((aligned(16))) uint16_t s_inv[704];             /* s_inv[val]: the first w with s_hw[8 + w] >= val (999: none) */
+	__shared__ __attribute__((aligned(16))) uint8_t s_code[320];
+	const int lane = threadIdx.x, chunk = blockIdx.x, img = blockIdx.y;
+	const uint8_t *code = codeb + (size_t)img * code_stride;
+	uint16_t *tab = tabb + (size_t)img * tab_stride;
+	const int base = 256 * chunk;
+	auto load4 = [&](int w0) -> uint32_t {                               /* the codes of the window's pairs w0 .. w0 + 3 (0 behind the stream's end) */
+		const int at = base + w0;
+		if (at >= CH_N) return 0u;
+		uint32_t w = *reinterpret_cast<const uint32_t *>(code + at);
+		const int rem = CH_N - at;
+		if (rem < 4) w &= (1u << (8 * rem)) - 1u;
+		return w & 0x0F0F0F0Fu;
+	};
+	const uint32_t c_lo = load4(4 * lane), c_hi = lane < 16 ? load4(256 + 4 * lane) : 0u;
+	for (int i = lane; i < 704 / 2; i += 64) reinterpret_cast<uint32_t *>(s_inv)[i] = 999u | (999u << 16);
+	auto scan = [&](uint32_t w, int &excl, uint32_t &pre) {              /* my four pairs' inclusive sums (bytes of pre), the sum of the lanes below me */
+		const uint32_t hw = (w & 0x01010101u) + ((w >> 1) & 0x01010101u);
+		pre = hw * 0x01010101u;
+		const int h = (int)(pre >> 24);
+		int incl = h;
+		for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+		excl = incl - h;
+	};
+	int ex_lo, ex_hi; uint32_t pre_lo, pre_hi;
+	scan(c_lo, ex_lo, pre_lo);
+	const int tot_lo = __builtin_amdgcn_readlane(ex_lo + (int)(pre_lo >> 24), 63);
+	scan(c_hi, ex_hi, pre_hi);
+	ex_hi += tot_lo;
+	*reinterpret_cast<uint32_t *>(&s_code[4 * lane]) = c_lo;
+	if (lane < 16) *reinterpret_cast<uint32_t *>(&s_code[256 + 4 * lane]) = c_hi;
+	if (lane == 0) s_hw[7] = 0;
+	__syncthreads();
+	auto put = [&](int w0, int excl, uint32_t pre) {
+		int before = excl;
+		for (int e = 0; e < 4; e++) {
+			const int now = excl + (int)((pre >> (8 * e)) & 255u);
+			s_hw[8 + w0 + e] = (uint16_t)now;
+			if (now > before) s_inv[before + 1] = (uint16_t)(w0 + e);      /* a pair adds one or two: the values it is the first to reach */
+			if (now > before + 1) s_inv[before + 2] = (uint16_t)(w0 + e);
+			before = now;
+		}
+	};
+	put(4 * lane, ex_lo, pre_lo);
+	if (lane < 16) put(256 + 4 * lane, ex_hi, pre_hi);
+	__syncthreads();
+	for (int k = 0; k < 4; k++) {
+		const int r = lane + 64 * k, p = base + r;
+		const int hb = (int)s_hw[8 + r];                                 /* hits of the window's pairs 0 .. r: the burst's pairs start behind pair r */
+		auto g = [&](int j) { return (int)s_hw[8 + r + 1 + j] - hb; };
+		auto first_ge = [&](int K) { const int w = (int)s_inv[hb + K] - (r + 1); return w < 32 ? w : 32; };
+		unsigned out[4];
+		table_entries(g, first_ge, CH_N - (p + 1), (int)s_code[r], out);
+		if (p < CH_N) *reinterpret_cast<uint2 *>(tab + 4 * (size_t)p) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+	}
+}
+
+/* The pair machine over a picture's code stream: one wavefront a picture, everything wave-uniform on the scalar unit (nhw_low_machine.h).
+ * The stream is taken in chunks of 256 pairs.  A first pair and the burst behind it are ONE look-up in the burst table (table_take: the
+ * chunk's 2 KB of entries stand in LDS, the next chunk's are on their way); what the table does not describe goes through the older forms:
+ * a whole burst evaluated by the lanes at once (burst_lane / burst_commit: the inclusive prefix sums of the pairs' hits of four chunks stand
+ * in a ring of 1024 in LDS as 16-bit values -- only differences are asked for), a pair through machine_step_fast / machine_step.  A lane
+ * holds four codes of the chunk; the answers collect in the lanes and leave 256 bytes a chunk. */
+__global__ __launch_bounds__(64) void k_low_chain(const uint8_t *__restrict__ codeb, size_t code_stride, const uint16_t *__restrict__ tabb, size_t tab_stride,
+                                                  uint8_t *__restrict__ actb, size_t act_stride, int dbg)
+{
+	__shared__ __attribute__((aligned(16))) uint16_t s_h[1024];
+	__shared__ __attribute__((aligned(16))) uint16_t s_tab[2 * 1024 + 4];    /* the table's entries of two chunks (a position's four side by side); behind them four entries that say "not here" */
+	__shared__ __attribute__((aligned(16))) uint8_t s_lut[512];              /* first_lut: the first pair's rules */
+	__shared__ __attribute__((aligned(16))) uint8_t s_act[512];              /* the answers of this chunk's pairs (the other half: zeros for the next) */
 	const int lane = threadIdx.x, img = blockIdx.x;
 	const uint32_t *cp = reinterpret_cast<const uint32_t *>(codeb + (size_t)img * code_stride);
+	const uint4 *tp = reinterpret_cast<const uint4 *>(tabb + (size_t)img * tab_stride);
 	uint32_t *ap = reinterpret_cast<uint32_t *>(actb + (size_t)img * act_stride);
 	PfM mach;
 	PfC mcache;
@@ -637,67 +712,103 @@ __global__ __launch_bounds__(64) void k_low_chain(const uint8_t *__restrict__ co
 		for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
 		const uint32_t base = (uint32_t)(tot + incl - h);
 		const uint32_t a0 = (base + (pre & 255u)) & 0xFFFFu, a1 = (base + ((pre >> 8) & 255u)) & 0xFFFFu, a2 = (base + ((pre >> 16) & 255u)) & 0xFFFFu, a3 = (base + (pre >> 24)) & 0xFFFFu;
-		*reinterpret_cast<uint2 *>(&s_h[((256 * k) & 511) + 4 * lane]) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+		*reinterpret_cast<uint2 *>(&s_h[((256 * k) & 1023) + 4 * lane]) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
 		tot += __builtin_amdgcn_readlane(incl, 63);
 	};
-	int pos = 0, hbase = 0;                                            /* hbase: hits of the pairs before pos */
-	bool give_up = false;                                              /* a burst that was declined is walked pair by pair: to its end, or to the next pair machine_step takes */
-	int cut_at = CH_N;                                                 /* where a burst's pairs end: the stream's end, or the pair that ends the burst through t17 (machine_step's) */
+	auto load_tab = [&](int k, uint4 &a, uint4 &b) {                    /* my 32 bytes of chunk k's 2 KB of entries */
+		if (k >= CH_CHUNKS) { a = make_uint4(0, 0, 0, 0); b = a; return; }
+		a = tp[128 * k + 2 * lane]; b = tp[128 * k + 2 * lane + 1];
+	};
+	auto put_tab = [&](int k, const uint4 &a, const uint4 &b) { uint4 *d = reinterpret_cast<uint4 *>(&s_tab[1024 * (k & 1) + 16 * lane]); d[0] = a; d[1] = b; };
+	for (int i = lane; i < 512; i += 64) s_lut[i] = (uint8_t)first_lut(i);
+	reinterpret_cast<uint2 *>(s_act)[lane] = make_uint2(0, 0);
+	if (lane < 4) s_tab[2048 + lane] = (uint16_t)TAB_NONE;
+	int pos = 0;
 	uint32_t cw = load_codes(0), cw1 = load_codes(1);
+	uint4 ta, tb;
+	load_tab(0, ta, tb);
+	put_tab(0, ta, tb);
+	load_tab(1, ta, tb);
 	scan_chunk(0, cw);
 	for (int k = 0; k < CH_CHUNKS; k++) {
 		const uint32_t cw2 = load_codes(k + 2);
 		scan_chunk(k + 1, cw1);
 		__syncthreads();
 		const int cend = 256 * (k + 1) < CH_N ? 256 * (k + 1) : CH_N;
-		uint32_t aw = 0;                                               /* the answers of my four pairs of this chunk */
-		/* the chain: whole bursts where the counters allow it, single pairs otherwise; everything below is wave-uniform.  The chain's one
-		 * scarce resource is the CU's scalar unit (16 wavefronts share it), so nothing on it goes through LDS but a burst's hits: a pair's
-		 * code comes out of the lane that holds it (readlane), the hits before the present pair are a running sum, the answers go into the
-		 * lanes' registers. */
 		if (!(dbg & 2)) {
-			auto single_pair = [&]() {
-				const int code = (int)(((uint32_t)__builtin_amdgcn_readlane((int)cw, (pos >> 2) & 63) >> (8 * (pos & 3))) & 15u);
-				int a = pos == cut_at ? -1 : machine_step_fast(mach, mcache, code);
-				if (a < 0) { a = machine_step(mach, code, 1 + pos / 255); machine_cache(mach, mcache); give_up = false; cut_at = CH_N; }
-				if (a && lane == ((pos >> 2) & 63)) aw |= (uint32_t)a << (8 * (pos & 3));
-				hbase += (code & 1) + ((code >> 1) & 1);
-				pos++;
-			};
 			while (pos < cend) {
-				if (mach.t[1] == 0) give_up = false;                  /* a burst's first pair comes next */
-				else if (!give_up && pos != cut_at && burst_entry_ok(mach, mcache)) {
-					const int hj = (int)(uint16_t)((uint32_t)s_h[(pos + lane) & 511] - (uint32_t)hbase);    /* hits of pairs pos .. pos + lane */
-					const PfBurstLane b = burst_lane(lane, mach.t[1], mach.t[4], mach.t[44], hj, mach.t[10], mach.t[11], mcache.exT);
-					auto hits_to = [&](int e) { return __builtin_amdgcn_readlane(hj, e); };
-					int n;
-					/* the five masks both tiers ask for, taken where the lanes' tests are made (behind a branch each costs a select and a compare more) */
-					const unsigned long long m_cap = __ballot(b.cap), m_wrap = __ballot(b.wrap), m_win = __ballot(b.win), m_cyc = __ballot(b.cyc), m_i6 = __ballot(b.i6);
-					if (burst_quiet(mach, mcache))
-						n = burst_commit_quiet(mach, mcache, (unsigned)m_cap, (unsigned)m_wrap, (unsigned)m_win, (unsigned)m_cyc, mcache.w8z ? (unsigned)m_i6 : 0u, cut_at - pos, hits_to);
-					else {
-						PfBurstMasks km_;
-						km_.cap = m_cap; km_.wrap = m_wrap; km_.win = m_win; km_.cyc = m_cyc; km_.i6 = m_i6;
-						km_.iS = __ballot(b.iS); km_.cnt = __ballot(b.cnt); km_.g13 = __ballot(b.g13); km_.e15 = __ballot(b.e15); km_.eT = __ballot(b.eT);
-						n = burst_commit(mach, mcache, km_, cut_at - pos, hits_to);
+				if (mach.t[1] == 0) {
+					/* First pairs with their bursts through the table, as many as go: the counters such a step moves stand in scalars of
+					 * their own while it lasts (t18 as (t18 - 1) & 15: the rotation passes 0 where that sum passes 15; t44 doubled: it
+					 * indexes 2-byte entries; t3 and the two "is 1" bits where the first pair's table wants them), the bits that stop an
+					 * entry in one word, and where no entry may be taken at all the look-up is pointed at four entries that say so. */
+					const unsigned flags = (dbg & 16) ? TAB_ALL : tab_flags(mach, mcache);
+					const int tsel = flags == TAB_ALL ? 4096 : 2048 * (k & 1), tmask = flags == TAB_ALL ? 0 : 0x7F8;
+					int v2 = (mach.t[44] & 3) << 1, x18 = (mach.t[18] - 1) & 15, t29 = mach.t[29];
+					int t8125 = mach.t[8] | (mach.t[12] << 8) | (mach.t[5] << 16);   /* the three counters a burst's cap clears (t8 <= 7, t12 <= 1, t5 < 35) */
+					int fs = (mach.t[3] << 4) | ((mach.t[8] == 1) << 6) | ((mach.t[12] == 1) << 7) | (mcache.t14_045 << 8);
+					unsigned seen = 0;                                   /* the codes of the first pairs taken, or-ed */
+					const int pos0 = pos;
+					for (;;) {
+						if (pos >= cend) break;
+						const unsigned entry = (unsigned)LDK(reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(s_tab) + (tsel + (((pos << 3) & tmask) | v2))));
+						if (entry & flags) break;
+						const int x = x18 + (int)((entry >> 7) & 7u);
+						if (x > 15) break;
+						x18 = x & 15;
+						const unsigned lv = (unsigned)LDK(&s_lut[fs | (int)(entry >> 12)]);
+						s_act[pos & 511] = (uint8_t)(lv & 7u);              /* (every lane the same byte) */
+						fs = (fs & ~0x30) | (int)(lv & 0x30u);
+						seen |= entry;
+						t29++;
+						const int e = (int)(entry & 31u);
+						const int capm = ((int)(entry << 26)) >> 31;        /* all ones if the burst ends by its cap */
+						v2 = (v2 + 2 * e) & 6 & capm;
+						t8125 &= ~capm;
+						fs &= ~(0xC0 & capm);
+						pos += e + 2;
 					}
-					if (n > 0) { hbase += __builtin_amdgcn_readlane(hj, n - 1); pos += n; continue; }
-					/* declined.  If that is because one of its pairs ends it through t17, the burst is taken up to that pair as a burst that is cut
-					 * (the next turn of the loop, with the masks made again: this path must not cost the bursts that are taken anything); the
-					 * pair itself goes through machine_step, and what follows it is a burst again */
-					if (cut_at == CH_N) {
-						const int w = burst_t17_pair(mach, m_cap, m_wrap, m_win, m_cyc, CH_N - pos);
-						if (w >= 1 && w < CH_N - pos) { cut_at = pos + w; continue; }
+					if (pos != pos0) {
+						mach.t[44] = v2 >> 1; mach.t[18] = (x18 + 1) & 15; mach.t[8] = t8125 & 255; mach.t[12] = (t8125 >> 8) & 255; mach.t[5] = t8125 >> 16;
+						if (seen & 0x3000u) mach.t[13] = 1;
+						mach.t[29] = t29; mach.t[3] = (fs >> 4) & 3; mach.t[27] = 0;
+						continue;
 					}
-					cut_at = CH_N;
-					give_up = true;
 				}
-				single_pair();                                        /* a first pair, or a pair inside a burst that was declined */
+				bool step_now = false;                                  /* the pair at pos is machine_step's */
+				if (mach.t[1] != 0 && burst_entry_ok(mach, mcache)) {
+					/* inside a burst: its longest clean run, decided in the lanes (gen_lane1 / gen_lane2 / gen_word); the pair that stops it,
+					 * if it is machine_step's, right behind */
+					const int hbase = pos ? LDK(&s_h[(pos - 1) & 1023]) : 0;    /* hits of the pairs before pos */
+					const int hj = (int)(uint16_t)((uint32_t)s_h[(pos + lane) & 1023] - (uint32_t)hbase);    /* hits of pairs pos .. pos + lane */
+					const int hp = lane ? (int)(uint16_t)((uint32_t)s_h[(pos + lane - 1) & 1023] - (uint32_t)hbase) : 0;
+					const PfGenU g = { mach.t[1], mach.t[4], mach.t[44], mach.t[10], mach.t[11], mach.t[18], mach.t[29] > 0, mach.t[30], mach.t[33], CH_N - pos };
+					const PfGen1 d = gen_lane1(lane, g, mcache, hj, hj - hp);
+					auto below = [&](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+					const PfGen2 r = gen_lane2(lane, g, mcache, d, below(__ballot(d.cyc != 0)), below(__ballot(d.counting != 0)));
+					const unsigned wd = gen_word(g, d, r);
+					const int sl = __builtin_ctzll(__ballot(r.stop != 0));   /* lane 63 always stops */
+					const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wd, sl);
+					pos += gen_take(mach, sl, w);
+					if (!(w & 1u)) continue;                              /* a clean run: the burst is over, or goes on behind the lanes' reach */
+					step_now = true;
+				}
+				{                                                     /* the pair that stopped a run; a first pair the table does not take; a pair the counters do not let into a burst */
+					const int code = (int)(((uint32_t)__builtin_amdgcn_readlane((int)(pos < cend ? cw : cw1), (pos >> 2) & 63) >> (8 * (pos & 3))) & 15u);
+					int a = step_now ? -1 : machine_step_fast(mach, mcache, code);
+					if (a < 0) { a = machine_step(mach, code, 1 + pos / 255); machine_cache(mach, mcache); }
+					if (a) STK(&s_act[pos & 511], (uint8_t)a);
+					pos++;
+				}
 			}
 		}
-		ap[64 * k + lane] = aw;
+		__syncthreads();
+		ap[64 * k + lane] = reinterpret_cast<const uint32_t *>(s_act)[64 * (k & 1) + lane];
+		reinterpret_cast<uint32_t *>(s_act)[64 * (k & 1) + lane] = 0;
 		cw = cw1; cw1 = cw2;
-		__syncthreads();                                            /* the next scan writes where chunk k's sums stand */
+		__syncthreads();                                            /* the next chunk's entries go where chunk k - 1's stood, the next scan where chunk k - 2's sums stood */
+		put_tab(k + 1, ta, tb);
+		load_tab(k + 2, ta, tb);
 	}
 }
 
@@ -1322,14 +1433,16 @@ void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStr
 	k_low_ll2<<<n, LL2_NT, (size_t)(128 * 132 + 8) * 2 + (size_t)maps * (128 * 128 / 32) * 4, s>>>(proc, plane_stride, q);   /* 128 rows at the kernel's pitch LP + the hit maps */
 }
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
-                              uint8_t *chain /* 2 * CH_BYTES an image: the pair codes, the machine's answers */, size_t chain_stride, int q, int n, hipStream_t s)
+                              uint8_t *chain /* 2 * CH_BYTES an image: the pair codes, the machine's answers */, size_t chain_stride,
+                              uint16_t *tab /* 8 * CH_BYTES an image: the burst table */, size_t tab_stride, int q, int n, hipStream_t s)
 {
 	static int dbg = 0;
 #ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing */
 	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
 	k_low_pre<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, chain, chain_stride, q, dbg);
-	k_low_chain<<<n, 64, 0, s>>>(chain, chain_stride, chain + CH_BYTES, chain_stride, dbg);
+	k_low_table<<<dim3(CH_CHUNKS, n), 64, 0, s>>>(chain, chain_stride, tab, tab_stride / 2);
+	k_low_chain<<<n, 64, 0, s>>>(chain, chain_stride, tab, tab_stride / 2, chain + CH_BYTES, chain_stride, dbg);
 	k_low_apply<<<n, 64, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, chain + CH_BYTES, chain_stride, q, dbg);
 	k_low_marks<<<dim3((W - 2 + MK_R - 2) / (MK_R - 1), n), MK_R, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
 }

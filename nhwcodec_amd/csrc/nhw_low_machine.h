@@ -312,6 +312,7 @@ struct PfC {
 	int lim;       /* how far behind t33 the schedule's present stage waits */
 	int exA, exB, exT;     /* what else it waits for: exA | (exB & t1 == exT) */
 	int w8z;       /* w8 == 0 (:1506) */
+	int wk;        /* the window (t10, t11): 1 = (8, 12), 2 = (10, 15) or (6, 9), 0 = anything else (the burst table knows the first three) */
 };
 
 DEVI void machine_cache(const PfM &m, PfC &c)
@@ -335,6 +336,7 @@ DEVI void machine_cache(const PfM &m, PfC &c)
 	  c.exB = (s1 & is4) | (s5 & t31);
 	  c.exT = s1 ? 11 : 12; }
 	c.w8z = Wv(8) == 0;
+	c.wk = ((T(10) == 8) & (T(11) == 12)) | ((((T(10) == 10) & (T(11) == 15)) | ((T(10) == 6) & (T(11) == 9))) << 1);
 }
 
 /* The pairs machine_step spends its time on, in short forms: each returns the answer, or -1 (counters untouched) where the pair needs
@@ -542,6 +544,201 @@ DEVI int burst_commit_quiet(PfM &m, const PfC &c, unsigned cap, unsigned wrap, u
 	T(1) = done ? 0 : T(1) + dh + 3 * ((v + e + 1) >> 2);
 	T(4) = done ? 0 : t4e;
 	return e + 1;
+}
+
+/* one pair of a burst in closed form, as the burst table sees it (table_entries below is checked against a walk with this, pair by pair):
+ * lane j = pair j behind the burst's first one, hits = of pairs 0 .. j */
+struct PfLaneD { int end, cap, wrap, cyc, win, i6; };
+DEVI PfLaneD burst_lane_d(int j, int t1_0, int t4_0, int v, int hits, int t10, int t11)
+{
+	PfLaneD d;
+	const int u = v + j;
+	const int t4 = t4_0 + hits;
+	const int t1 = t1_0 + hits + 3 * (u >> 2);                          /* behind the hits of pair j, before its idle step */
+	const int t1i = t1 + (((u & 3) == 3) ? 3 : 0);                      /* behind its idle step */
+	d.cap = t1 >= 15;
+	d.wrap = t1i > 15;
+	d.end = d.cap | d.wrap;
+	d.cyc = (t4 >= 10) & ((t4 > 10) | (t1 != 15));
+	d.win = (t4 == t10) & (t1 == t11) & !d.cyc;
+	d.i6 = t1 == 6;
+	return d;
+}
+
+/* ---- a burst's longest clean prefix, decided in the lanes (round 6) ---------------------------------------------------------------------
+ * burst_commit above takes a whole burst or nothing: a burst with one pair that moves a slow schedule was walked pair by pair
+ * (machine_step_fast, some sixty scalar instructions a pair), and with the gate of the slow schedules open that is most bursts -- the
+ * pictures for which it stays open for long set the kernel's time.  Here every lane decides ITS pair exactly as machine_burst_fast would
+ * find it (the counters in closed form, the counts of the lanes before it by v_mbcnt): does it end the burst, would it be declined; the
+ * first lane that stops -- the burst's end, a pair that needs machine_step, the last pair before the stream's end -- packs the counters'
+ * values into a word (before its pair if that pair is machine_step's, behind it otherwise), and the scalar unit reads that one word.
+ * Every pair of a burst is then taken in a clean run or is a pair machine_step must see: nothing is walked pair by pair any more.
+ *   gen_lane1    the pair's own tests (lane j = pair j behind the present one; hits: of pairs 0 .. j, own: of pair j alone)
+ *   gen_lane2    with the counts of the lanes before it: is it declined, does it stop
+ *   gen_word     bit 0 the pair is machine_step's (the word holds the counters BEFORE it), 1 the burst is over, 2 by its cap, 3 with a hit;
+ *                4..8 t1, 9..13 t4, 14..15 t44, 16..19 t18, 20..26 what t30 has counted
+ *   gen_take     the word into the counters; returns the number of pairs taken (0: the first pair already is machine_step's) */
+#ifndef PF_BIT
+#define PF_BIT(x) ((int)(x))           /* a test as 0 / 1 (the device pins it in a vector register: flags are combined on the vector unit, not as lane masks on the scalar unit) */
+#endif
+struct PfGenU { int t1_0, t4_0, v, t10, t11, t18, t29pos, t30, t33, avail; };   /* the counters' side (wave-uniform) */
+struct PfGen1 { int t1, t1i, t4, u, own, cap, wrap, cyc, win, counting; };
+DEVI PfGen1 gen_lane1(int j, const PfGenU &g, const PfC &c, int hits, int own)
+{
+	PfGen1 d;
+	d.u = g.v + j;
+	d.own = own;
+	d.t4 = g.t4_0 + hits;
+	d.t1 = g.t1_0 + hits + 3 * (d.u >> 2);                              /* behind the hits of pair j, before its idle step */
+	d.t1i = g.t1_0 + hits + 3 * ((d.u + 1) >> 2);                       /* behind its idle step */
+	d.cap = PF_BIT(d.t1 >= 15);
+	d.wrap = PF_BIT(d.t1i > 15);
+	d.cyc = PF_BIT(d.t4 > 10) | (PF_BIT(d.t4 == 10) & PF_BIT(d.t1 != 15));
+	d.win = PF_BIT(d.t4 == g.t10) & PF_BIT(d.t1 == g.t11);
+	const int gate = g.t29pos & c.gate14;
+	d.counting = gate & c.st_lt14 & PF_BIT(d.t1i > 7) & (d.cap ^ 1);    /* an idle pair the t28 schedule counts (:1711) */
+	return d;
+}
+struct PfGen2 { int bad, stop, t18j, cnt_before; };
+DEVI PfGen2 gen_lane2(int j, const PfGenU &g, const PfC &c, const PfGen1 &d, int cyc_before, int cnt_before)
+{
+	PfGen2 r;
+	r.t18j = (g.t18 + cyc_before) & 15;                                 /* t18 as the pair finds it, if no pair before it was stopped */
+	r.cnt_before = cnt_before;
+	const int t17 = d.cyc ? PF_BIT(r.t18j == 0) : d.win;                /* :1004-1039 */
+	const int small4 = PF_BIT(d.t4 < 2);
+	const int gate = g.t29pos & c.gate14;
+	const int bad_cap = (small4 & g.t29pos & c.capA) | c.capB;          /* the cap's two schedule steps (:1466-1500) */
+	const int e15 = PF_BIT(d.t1i == 15);
+	const int sched = (small4 & e15 & c.schedA) | c.schedB;             /* the t32 schedules (:1534-1709) */
+	const int dist = g.t30 + cnt_before + 1 - g.t33;
+	const int stage = (c.arm0 & PF_BIT(d.t1i > 13)) | (PF_BIT(dist > c.lim) & (c.exA | (c.exB & PF_BIT(d.t1i == c.exT)))) | PF_BIT(dist == 9) | e15;   /* :1711-1871 */
+	const int bad_idle = (PF_BIT(d.t1 == 6) & c.w8z) | (gate & sched) | (d.counting & stage);
+	r.bad = t17 | (d.cap ? bad_cap : bad_idle);
+	r.stop = r.bad | d.cap | d.wrap | PF_BIT(j == g.avail - 1) | PF_BIT(j == 63);
+	return r;
+}
+DEVI unsigned gen_word(const PfGenU &g, const PfGen1 &d, const PfGen2 &r)
+{
+	const int end = (d.cap | d.wrap) & (r.bad ^ 1);
+	/* the counters before the pair (it is machine_step's), or behind it (the burst's end: t1 = t4 = 0; a burst the stream cuts: as they stand) */
+	const int t1 = r.bad ? d.t1 - d.own : end ? 0 : d.t1i;
+	const int t4 = r.bad ? d.t4 - d.own : end ? 0 : d.t4;
+	const int t44 = r.bad ? (d.u & 3) : d.cap ? (d.u & 3) : d.wrap ? 0 : ((d.u + 1) & 3);
+	const int t18 = r.bad ? r.t18j : ((r.t18j + d.cyc) & 15);
+	const int cnt = r.bad ? r.cnt_before : r.cnt_before + d.counting;
+	return (unsigned)r.bad | ((unsigned)end << 1) | ((unsigned)(d.cap & end) << 2) | ((unsigned)PF_BIT(d.t4 != 0) << 3)
+	     | ((unsigned)(t1 & 31) << 4) | ((unsigned)(t4 & 31) << 9) | ((unsigned)t44 << 14) | ((unsigned)t18 << 16) | ((unsigned)(cnt & 127) << 20);
+}
+/* can a burst go through the lanes as the counters are?  (burst_entry_ok: inside a burst, nothing pending that only machine_step knows) */
+DEVI int gen_take(PfM &m, int lane_s, unsigned w)
+{
+	const int bad = (int)(w & 1u);
+	const int n = lane_s + 1 - bad;
+	if (n == 0) return 0;
+	T(1) = (int)((w >> 4) & 31u); T(4) = (int)((w >> 9) & 31u); T(44) = (int)((w >> 14) & 3u); T(18) = (int)((w >> 16) & 15u); T(30) += (int)((w >> 20) & 127u);
+	T(17) = 0;
+	if (w & 2u) {
+		if (w & 4u) { if (w & 8u) { T(8) = 0; T(5) = 0; T(12) = 0; } else T(8)++; }
+		T(29)++;
+	}
+	return n;
+}
+
+/* ---- the burst table (round 6) -----------------------------------------------------------------------------------------------------
+ * Nearly every burst starts the same way: behind a first pair, with t1 = 1, t4 = 0 and t44 = v in 0..3 -- and from there its course is a
+ * function of the picture's codes alone: where it ends, whether by its cap, how often it rotates t18, whether a pair sits at the (8, 12)
+ * window or at the one-time step of :1506.  So that function is TABULATED for every pair of the stream and all four v, in parallel, by a
+ * kernel of its own on the vector units (k_low_table), and the chain (one wavefront a picture; what it pays for is scalar instructions,
+ * 17 cycles each with sixteen chains to a CU's scalar unit, while a dependent LDS look-up costs 72) takes a first pair and its burst with
+ * two look-ups and some forty scalar instructions.  Everything the table does not describe -- the gate of the slow schedules open, counters
+ * elsewhere, an entry that says "not here" -- goes through the forms above.
+ * Entry (16 bits) of first-pair position p and v; the burst's pairs are s = p + 1, s + 1, ..:
+ *   bits 0..4  e: the burst's last pair is s + e
+ *   bit 5 cap: it ends by its cap (t1 reaches 15 before the idle step; such a burst has a hit: t8, t5, t12 are cleared)
+ *   bit 6 TAB_NONE: not described -- no end within the window, or behind the stream's end, or ncyc > 7, or the first pair itself has
+ *         bookkeeping to do (its first cell above both thresholds, :850-873)
+ *   bits 7..9 ncyc: how many of its pairs rotate t18 (:1006-1037);  bit 10: one of its pairs sits at the window (8, 12) (:1004 / :1039: it
+ *   ends the burst through t17 if that is the window);  bit 11: one of its idle pairs has t1 == 6 (:1506)
+ *   bits 12..15: the code of pair p itself (the first pair's)
+ * The counters' side of the bargain is one word, tab_flags(): the bits of an entry that stop it as the counters are (TAB_NONE always; the
+ * window bit if the window is (8, 12), the :1506 bit while w8 is 0, the cap bit while the cap's schedule step is due), or TAB_ALL if no
+ * entry may be taken at all. */
+#define TAB_NONE 64u
+#define TAB_ALL 0xFFFFFFFFu
+/* the four entries of one position.  g(j): hits of pairs s .. s + j (j in 0..31; whatever lies behind the stream's end counts as no hit);
+ * first_ge(K): the first j in 0..31 with g(j) >= K, 32 if there is none;  navail: how many of the pairs s, s + 1, .. exist;  code: pair p's */
+template <class G, class J>
+DEVI void table_entries(G g, J first_ge, int navail, int code, unsigned out[4])
+{
+	auto ends = [&](int j, int v, int gj) { return ((1 + gj + 3 * ((v + j) >> 2)) >= 15) | ((1 + gj + 3 * ((v + j + 1) >> 2)) >= 16); };
+	const int j2 = first_ge(2), j3 = first_ge(3), j5 = first_ge(5), j6 = first_ge(6), j8 = first_ge(8), j9 = first_ge(9), j10 = first_ge(10);
+	const int first_slow = (code & 1) & ((code >> 3) & 1);
+	int e = 0;
+	{ int lo = 0, hi = 32;                                              /* v = 0: a binary search (ends() is monotone in j) */
+	  for (int it = 0; it < 5; it++) { const int mid = (lo + hi) >> 1; const int p_ = ends(mid, 0, g(mid)); hi = p_ ? mid : hi; lo = p_ ? lo : mid + 1; }
+	  e = lo; }
+	for (int v = 0; v < 4; v++) {
+		if (v) {                                                        /* the end with v is the end with v - 1 or the pair before it */
+			const int jm = e > 0 ? e - 1 : 0;
+			const int pm = (e > 0) & ends(jm, v, g(jm));
+			e = pm ? e - 1 : e;
+		}
+		const int je = e < 31 ? e : 31;
+		const int ge = g(je);
+		const int t1e = 1 + ge + 3 * ((v + je) >> 2);
+		const int cap = t1e >= 15;
+		int ncyc = je >= j10 ? je - j10 + 1 : 0;
+		ncyc -= (ge == 10) & (t1e == 15);
+		const int min3a = (j9 - 1) < (7 - v) ? (j9 - 1) : (7 - v);
+		const int win = (j8 > 4 - v ? j8 : 4 - v) <= (min3a < je ? min3a : je);
+		const int idle_hi = je - cap;
+		const int a_hi = (j6 - 1) < (3 - v) ? (j6 - 1) : (3 - v);
+		const int b_hi = (j3 - 1) < (7 - v) ? (j3 - 1) : (7 - v);
+		const int i6 = (j5 <= (a_hi < idle_hi ? a_hi : idle_hi)) | ((j2 > 4 - v ? j2 : 4 - v) <= (b_hi < idle_hi ? b_hi : idle_hi));
+		const int none = (e >= 31) | (e >= navail) | (ncyc > 7) | first_slow;
+		out[v] = (unsigned)je | ((unsigned)cap << 5) | (none ? TAB_NONE : 0u) | ((unsigned)(ncyc & 7) << 7) | ((unsigned)win << 10) | ((unsigned)i6 << 11) | ((unsigned)code << 12);
+	}
+}
+/* which bits of an entry stop it as the counters are (t1 == 0: a first pair comes next) */
+DEVI unsigned tab_flags(const PfM &m, const PfC &c)
+{
+	if (c.fb14 | c.t6bad | (T(8) > 6) | c.gate14 | !c.wk | (T(4) != 0) | ((unsigned)T(44) > 3u)) return TAB_ALL;   /* (the gate: whatever t29 is -- it is 0 only before the picture's first burst) */
+	return TAB_NONE | (c.wk == 1 ? 1u << 10 : 0u) | (c.w8z ? 1u << 11 : 0u) | (c.capB ? 1u << 5 : 0u);
+}
+/* the first pair's rules (machine_first_fast without its decline: tab_flags and TAB_NONE cover that) as a table of 512 bytes:
+ * index = the pair's code | t3 << 4 | (t8 == 1) << 6 | (t12 == 1) << 7 | t14_045 << 8;  value = the answer | t3 behind the pair << 4 */
+DEVI unsigned first_lut(int idx)
+{
+	const int f0 = idx & 1, f1 = (idx >> 1) & 1, g1 = (idx >> 2) & 1, t3 = (idx >> 4) & 3, t8is1 = (idx >> 6) & 1, t12is1 = (idx >> 7) & 1, t14_045 = (idx >> 8) & 1;
+	int act = ACT_FIRST | ((f0 & (g1 | t8is1)) ? ACT_ZERO0 : 0);
+	const int rot = f1 & (f0 | t12is1) & t14_045;                        /* the second pixel goes through the weak-first rule or its rotation (:884-930) */
+	const int subst = rot & (t3 == 0) & f0;
+	const int n3 = !rot ? t3 : subst ? 1 : (((t3 == 1) << 1) | ((t3 == 2) * 3));
+	act |= subst ? ACT_SUBST : 0;
+	return (unsigned)act | ((unsigned)n3 << 4);
+}
+/* The chain's step at a first pair (t1 == 0) with the table: entry = the table's for this position and v = t44 (any entry if flags is
+ * TAB_ALL), flags = tab_flags().  Returns -1 (counters untouched: the pair and its burst go through the other forms), or the first pair's
+ * answer with the counters moved over the first pair and its whole burst; pairs: how many pairs that was. */
+DEVI int table_take(PfM &m, unsigned flags, unsigned entry, int &pairs)
+{
+	if (entry & flags) return -1;
+	const int ncyc = (int)((entry >> 7) & 7u), e = (int)(entry & 31u), code = (int)(entry >> 12);
+	const int x = ((T(18) - 1) & 15) + ncyc;                            /* the t18 rotation would pass 0 (:1006-1037: that pair ends the burst through t17) */
+	if (x > 15) return -1;
+	const unsigned lv = first_lut(code | (T(3) << 4) | ((T(8) == 1) << 6) | ((T(12) == 1) << 7) | (((T(14) == 0) | (T(14) == 4) | (T(14) == 5)) << 8));
+	T(3) = (int)((lv >> 4) & 3u);
+	T(2) = code & 1;
+	if (code & 3) T(13) = 1;
+	T(27) = 0;
+	T(18) = (x + 1) & 15;
+	T(17) = 0;
+	if (entry & 32u) { T(8) = 0; T(5) = 0; T(12) = 0; T(44) = (T(44) + e) & 3; }
+	else T(44) = 0;
+	T(29)++;
+	pairs = 2 + e;
+	return (int)(lv & 7u);
 }
 
 #undef T

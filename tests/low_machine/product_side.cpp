@@ -87,17 +87,120 @@ static int row_hop(PfM &m, PfC &c, const uint8_t *codes, uint8_t *acts, int row)
 	return bursted;
 }
 
+/* the burst table of a picture's code stream (k_low_table on the host): table_entries with the hits' prefix sums behind its two accessors */
+static void table_build(const uint8_t *codes, int np, uint16_t *tab)
+{
+	int *hp = (int *)malloc(sizeof(int) * (np + 80));                   /* hp[i + 1]: hits of pairs 0 .. i */
+	hp[0] = 0;
+	for (int i = 0; i < np + 79; i++) hp[i + 1] = hp[i] + (i < np ? (codes[i] & 1) + ((codes[i] >> 1) & 1) : 0);
+	for (int p = 0; p < np; p++) {
+		const int s = p + 1;
+		auto g = [&](int j) { return hp[s + j + 1] - hp[s]; };
+		auto first_ge = [&](int K) { int j = 0; while (j < 32 && g(j) < K) j++; return j; };
+		unsigned out[4];
+		table_entries(g, first_ge, np - s, codes[p], out);
+		for (int v = 0; v < 4; v++) tab[4 * p + v] = (uint16_t)out[v];
+	}
+	free(hp);
+}
+/* every entry against the burst walked pair by pair with burst_lane_d; returns the number of entries that differ */
+static long table_check(const uint8_t *codes, int np, const uint16_t *tab)
+{
+	long bad = 0;
+	int *hp = (int *)malloc(sizeof(int) * (np + 80));
+	hp[0] = 0;
+	for (int i = 0; i < np + 79; i++) hp[i + 1] = hp[i] + (i < np ? (codes[i] & 1) + ((codes[i] >> 1) & 1) : 0);
+	for (int p = 0; p < np; p++) for (int v = 0; v < 4; v++) {
+		const int s = p + 1;
+		int e = -1, ncyc = 0, win = 0, i6 = 0, cap = 0, ge = 0;
+		for (int j = 0; j < 31; j++) {
+			const int hits = hp[s + j + 1] - hp[s];
+			const PfLaneD d = burst_lane_d(j, 1, 0, v, hits, 8, 12);
+			ncyc += d.cyc; win |= d.win;
+			if (d.end) { e = j; cap = d.cap; ge = hits; if (!d.cap) i6 |= d.i6; break; }
+			i6 |= d.i6;
+		}
+		unsigned want;
+		if (e < 0 || e >= np - s || ncyc > 7 || ((codes[p] & 9) == 9)) want = TAB_NONE;
+		else want = (unsigned)e | ((unsigned)cap << 5) | ((unsigned)ncyc << 7) | ((unsigned)win << 10) | ((unsigned)i6 << 11);
+		if (cap && !ge) want = 0xFFFFu;                                 /* (a cap without a hit cannot be: the burst would have wrapped at the pair before) */
+		const unsigned got = tab[4 * p + v] & 0xFFFu;
+		const bool same = want == TAB_NONE ? (got & TAB_NONE) != 0 : got == want;
+		if (!same || (tab[4 * p + v] >> 12) != codes[p]) { if (bad++ < 5) fprintf(stderr, "table entry of pair %d, v %d: %03x, the burst walked pair by pair says %03x\n", p, v, got, want); }
+	}
+	free(hp);
+	return bad;
+}
+/* the chain's walk with the table (k_low_chain on the host): a first pair and its burst through table_take, the rest as in stream_hop */
+static long table_hop(PfM &m, PfC &c, const uint8_t *codes, const uint16_t *tab, uint8_t *acts, int np)
+{
+	long fast = 0;
+	int pos = 0;
+	int *hp = (int *)malloc(sizeof(int) * (np + 64));
+	{ int h = 0; for (int i = 0; i < np + 64; i++) { if (i < np) h += (codes[i] & 1) + ((codes[i] >> 1) & 1); hp[i] = h; } }
+	memset(acts, 0, np);
+	long gen_pairs = 0;
+	while (pos < np) {
+		if (m.t[1] == 0) {
+			{
+				int pairs = 0;
+				const unsigned flags = tab_flags(m, c);
+				const int a = table_take(m, flags, tab[4 * pos + (m.t[44] & 3)], pairs);
+				if (a >= 0) { acts[pos] = (uint8_t)a; pos += pairs; fast += pairs; continue; }
+			}
+		}
+		else if (burst_entry_ok(m, c)) {
+			/* the burst's longest clean prefix, decided "in the lanes" (a loop over j stands in for them, running counts for v_mbcnt) */
+			const int base = pos ? hp[pos - 1] : 0;
+			PfGenU g = { m.t[1], m.t[4], m.t[44], m.t[10], m.t[11], m.t[18], m.t[29] > 0, m.t[30], m.t[33], np - pos };
+			int cyc_before = 0, cnt_before = 0, s = -1; unsigned w = 0;
+			for (int j = 0; j < 64 && s < 0; j++) {
+				const int hits = hp[pos + j] - base, prev = j ? hp[pos + j - 1] - base : 0;
+				const PfGen1 d = gen_lane1(j, g, c, hits, hits - prev);
+				const PfGen2 r = gen_lane2(j, g, c, d, cyc_before, cnt_before);
+				if (r.stop) { s = j; w = gen_word(g, d, r); }
+				cyc_before += d.cyc; cnt_before += d.counting;
+			}
+			const int n = gen_take(m, s, w);
+			pos += n; gen_pairs += n;
+			if (!(w & 1u)) continue;                                        /* a clean run: the burst is over, or goes on behind the lanes' reach */
+			const int a = machine_step(m, codes[pos], 1 + pos / 255);       /* the pair that stopped it */
+			machine_cache(m, c);
+			acts[pos++] = (uint8_t)a;
+			continue;
+		}
+		int a = machine_step_fast(m, c, codes[pos]);
+		if (a < 0) { a = machine_step(m, codes[pos], 1 + pos / 255); machine_cache(m, c); }
+		acts[pos++] = (uint8_t)a;
+	}
+	free(hp);
+	return fast;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc < 5) { fprintf(stderr, "usage: %s q_first q_last images class\n", argv[0]); return 2; }
 	const int q0 = atoi(argv[1]), q1 = atoi(argv[2]), n = atoi(argv[3]), cls = atoi(argv[4]);
 	if (lm_machine_size() != (int)sizeof(PfM)) { fprintf(stderr, "machine layouts differ\n"); return 2; }
+	for (int idx = 0; idx < 512; idx++) for (int t14 = 0; t14 < 6; t14++) {  /* first_lut against machine_first_fast: every index, every t14 it stands for */
+		PfM m; PfC c;
+		machine_reset(m);
+		m.t[3] = (idx >> 4) & 3; m.t[8] = ((idx >> 6) & 1) ? 1 : 2; m.t[12] = (idx >> 7) & 1; m.t[14] = t14; m.t[13] = 0; m.t[27] = 5;
+		machine_cache(m, c);
+		if (c.t14_045 != ((idx >> 8) & 1) || c.fb14) continue;
+		const int a = machine_first_fast(m, c, idx & 15);
+		const unsigned lv = first_lut(idx);
+		if ((idx & 9) == 9) { if (a != -1) { fprintf(stderr, "first_lut: index %d should decline\n", idx); return 1; } continue; }
+		if (a != (int)(lv & 7u) || m.t[3] != (int)((lv >> 4) & 3u)) { fprintf(stderr, "first_lut differs from machine_first_fast at index %d (t14 %d)\n", idx, t14); return 1; }
+	}
 	const int S = 512;
 	uint8_t *bgr = (uint8_t *)malloc(NHWO_IMG_BYTES), *u = (uint8_t *)malloc(65536), *v = (uint8_t *)malloc(65536), *so = (uint8_t *)malloc(S * S);
 	int16_t *y = (int16_t *)malloc(2 * S * S), *src = (int16_t *)malloc(2 * S * S), *km = (int16_t *)malloc(2 * S * S);
 	long bad = 0;
 	for (int q = q0; q <= q1; q++) {
-		long steps = 0, fast = 0, bad_fast = 0, bad_step = 0, bad_hop = 0, bursted = 0;
+		long steps = 0, fast = 0, bad_fast = 0, bad_step = 0, bad_hop = 0, bursted = 0, tabled = 0;
+		static uint16_t s_tab[4 * 510 * 255];
+		static uint8_t s_codes[510 * 255], s_acts_ref[510 * 255], s_acts[510 * 255];
 		int sharp, s2;
 		lm_params(q, &sharp, &s2);
 		for (int s = 0; s < n; s++) {
@@ -130,6 +233,7 @@ int main(int argc, char **argv)
 					machine_cache(mach, cache);
 				}
 			}
+			memcpy(s_codes + (r - 1) * 255, codes, 255); memcpy(s_acts_ref + (r - 1) * 255, acts_ref, 255);
 			bursted += row_hop(hop, hcache, codes, acts_hop, r);
 			if (memcmp(acts_ref, acts_hop, 255) || memcmp(&hop, &mach, sizeof mach)) {
 				if (bad_hop++ < 3) { fprintf(stderr, "q%d image %d row %d: the burst walk differs from the pair-by-pair walk (answers %s)\n", q, s, r, memcmp(acts_ref, acts_hop, 255) ? "differ" : "equal");
@@ -137,8 +241,19 @@ int main(int argc, char **argv)
 				hop = mach; machine_cache(hop, hcache);
 			}
 			}
+			{                                                               /* the whole picture again as one stream with the burst table, the way k_low_chain walks it */
+				PfM sm; PfC sc;
+				machine_reset(sm); machine_cache(sm, sc);
+				table_build(s_codes, 510 * 255, s_tab);
+				bad_hop += table_check(s_codes, 510 * 255, s_tab);
+				tabled += table_hop(sm, sc, s_codes, s_tab, s_acts, 510 * 255);
+				if (memcmp(s_acts, s_acts_ref, 510 * 255) || memcmp(&sm, &mach, sizeof mach)) {
+					if (bad_hop++ < 3) { int i = 0; while (i < 510 * 255 && s_acts[i] == s_acts_ref[i]) i++;
+						fprintf(stderr, "q%d image %d: the table walk differs from the pair-by-pair walk (first answer that differs: pair %d of %d)\n", q, s, i, 510 * 255); }
+				}
+			}
 		}
-		printf("q%d class %d: %ld pairs, fast form %.1f %%, in whole bursts %.1f %%, fast mismatches %ld, step mismatches %ld, burst-walk mismatches %ld\n", q, cls, steps, 100.0 * fast / steps, 100.0 * bursted / steps, bad_fast, bad_step, bad_hop);
+		printf("q%d class %d: %ld pairs, fast form %.1f %%, in whole bursts %.1f %%, through the burst table %.1f %%, fast mismatches %ld, step mismatches %ld, burst-walk mismatches %ld\n", q, cls, steps, 100.0 * fast / steps, 100.0 * bursted / steps, 100.0 * tabled / steps, bad_fast, bad_step, bad_hop);
 		bad += bad_fast + bad_step + bad_hop;
 	}
 	return bad ? 1 : 0;

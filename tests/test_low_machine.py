@@ -28,7 +28,7 @@ def test_machine_forms_follow_the_oracle(machine_check, cls, images):
     r = subprocess.run([machine_check, "1", "16", str(images), str(cls)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("q")]
-    assert len(lines) == 16 and all("fast mismatches 0, step mismatches 0" in l for l in lines), r.stdout
+    assert len(lines) == 16 and all("fast mismatches 0, step mismatches 0, burst-walk mismatches 0" in l for l in lines), r.stdout
     if cls == 0:    # the fast form is what the benchmark images run on
         pct = {int(l.split()[0][1:]): float(l.split("fast form")[1].split("%")[0]) for l in lines}
         assert pct[1] > 99.0 and pct[10] > 99.0, pct
