@@ -281,7 +281,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 	};
 #define CHROMA(call) do { const int rc_ = (call); if (rc_ != 1) return rc_; } while (0)   /* 1 = carry on; NHW_OK (debug stop) or an error leaves */
 	if (fork) {
-		HIPCHK(hipStreamWaitEvent(cs, e->ev[1], 0));                 /* behind the front launch group: that one is bound by vector issue and has nothing to give (and its time is the roofline figure) */
+		HIPCHK(hipStreamWaitEvent(cs, low ? e->ev[5] : e->ev[1], 0));   /* behind the front launch group: that one is bound by vector issue and has nothing to give (and its time is the roofline figure).  Quality 1..16: behind the colour kernel already -- the rationed pre-filter's chain (k_low_chain) is one wavefront a picture on the scalar unit and leaves the vector units and the memory system idle for milliseconds */
 		CHROMA(chroma_head(0));
 		CHROMA(chroma_head(1));                                      /* V's head in planes of its own, right behind U's: U's quantiser waits for the luma tail, and this stream stood idle until then (2 ms of a q20 step).  (Measured and not taken: V's head on a stream of its own beside U's, +0.3 ms; V's head held back until the second dequantiser simulation is through, +0.4 ms.) */
 	}

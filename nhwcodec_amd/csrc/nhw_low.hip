@@ -611,91 +611,34 @@ __global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb
 	*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
 }
 
-/* The burst table of a batch's code streams (nhw_low_machine.h: table_entries): a wavefront takes 256 positions of a picture's stream, a
- * lane four of them (lane, lane + 64, ..: neighbours read neighbouring cells).  In LDS: the inclusive prefix sums of the hits of the 320
- * pairs from the chunk's first one on (a burst is over within 21 pairs of the position behind which it starts), and their inverse -- the first
- * pair at which the sum reaches a value -- which answers "where does the burst's hit count reach K" with one read.  8 bytes a position out. */
-__global__ __launch_bounds__(64) void k_low_table(const uint8_t *__restrict__ codeb, size_t code_stride, uint16_t *__restrict__ tabb, size_t tab_stride)
-{
-	__shared__ __attribute__((aligned(16))) uint16_t s_hw[8 + 320];          /* s_hw[8 + w]: hits of the window's pairs 0 .. w; s_hw[7] = 0 */
-	__shared__ __attribute__((aligned(16))) uint16_t s_inv[704];             /* s_inv[val]: the first w with s_hw[8 + w] >= val (999: none) */
-	__shared__ __attribute__((aligned(16))) uint8_t s_code[320];
-	const int lane = threadIdx.x, chunk = blockIdx.x, img = blockIdx.y;
-	const uint8_t *code = codeb + (size_t)img * code_stride;
-	uint16_t *tab = tabb + (size_t)img * tab_stride;
-	const int base = 256 * chunk;
-	auto load4 = [&](int w0) -> uint32_t {                               /* the codes of the window's pairs w0 .. w0 + 3 (0 behind the stream's end) */
-		const int at = base + w0;
-		if (at >= CH_N) return 0u;
-		uint32_t w = *reinterpret_cast<const uint32_t *>(code + at);
-		const int rem = CH_N - at;
-		if (rem < 4) w &= (1u << (8 * rem)) - 1u;
-		return w & 0x0F0F0F0Fu;
-	};
-	const uint32_t c_lo = load4(4 * lane), c_hi = lane < 16 ? load4(256 + 4 * lane) : 0u;
-	for (int i = lane; i < 704 / 2; i += 64) reinterpret_cast<uint32_t *>(s_inv)[i] = 999u | (999u << 16);
-	auto scan = [&](uint32_t w, int &excl, uint32_t &pre) {              /* my four pairs' inclusive sums (bytes of pre), the sum of the lanes below me */
-		const uint32_t hw = (w & 0x01010101u) + ((w >> 1) & 0x01010101u);
-		pre = hw * 0x01010101u;
-		const int h = (int)(pre >> 24);
-		int incl = h;
-		for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-		excl = incl - h;
-	};
-	int ex_lo, ex_hi; uint32_t pre_lo, pre_hi;
-	scan(c_lo, ex_lo, pre_lo);
-	const int tot_lo = __builtin_amdgcn_readlane(ex_lo + (int)(pre_lo >> 24), 63);
-	scan(c_hi, ex_hi, pre_hi);
-	ex_hi += tot_lo;
-	*reinterpret_cast<uint32_t *>(&s_code[4 * lane]) = c_lo;
-	if (lane < 16) *reinterpret_cast<uint32_t *>(&s_code[256 + 4 * lane]) = c_hi;
-	if (lane == 0) s_hw[7] = 0;
-	__syncthreads();
-	auto put = [&](int w0, int excl, uint32_t pre) {
-		int before = excl;
-		for (int e = 0; e < 4; e++) {
-			const int now = excl + (int)((pre >> (8 * e)) & 255u);
-			s_hw[8 + w0 + e] = (uint16_t)now;
-			if (now > before) s_inv[before + 1] = (uint16_t)(w0 + e);      /* a pair adds one or two: the values it is the first to reach */
-			if (now > before + 1) s_inv[before + 2] = (uint16_t)(w0 + e);
-			before = now;
-		}
-	};
-	put(4 * lane, ex_lo, pre_lo);
-	if (lane < 16) put(256 + 4 * lane, ex_hi, pre_hi);
-	__syncthreads();
-	for (int k = 0; k < 4; k++) {
-		const int r = lane + 64 * k, p = base + r;
-		const int hb = (int)s_hw[8 + r];                                 /* hits of the window's pairs 0 .. r: the burst's pairs start behind pair r */
-		auto g = [&](int j) { return (int)s_hw[8 + r + 1 + j] - hb; };
-		auto first_ge = [&](int K) { const int w = (int)s_inv[hb + K] - (r + 1); return w < 32 ? w : 32; };
-		unsigned out[4];
-		table_entries(g, first_ge, CH_N - (p + 1), (int)s_code[r], out);
-		if (p < CH_N) *reinterpret_cast<uint2 *>(tab + 4 * (size_t)p) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
-	}
-}
-
-/* The pair machine over a picture's code stream: one wavefront a picture, everything wave-uniform on the scalar unit (nhw_low_machine.h).
- * The stream is taken in chunks of 256 pairs.  A first pair and the burst behind it are ONE look-up in the burst table (table_take: the
- * chunk's 2 KB of entries stand in LDS, the next chunk's are on their way); what the table does not describe goes through the older forms:
- * a whole burst evaluated by the lanes at once (burst_lane / burst_commit: the inclusive prefix sums of the pairs' hits of four chunks stand
- * in a ring of 1024 in LDS as 16-bit values -- only differences are asked for), a pair through machine_step_fast / machine_step.  A lane
- * holds four codes of the chunk; the answers collect in the lanes and leave 256 bytes a chunk. */
-__global__ __launch_bounds__(64) void k_low_chain(const uint8_t *__restrict__ codeb, size_t code_stride, const uint16_t *__restrict__ tabb, size_t tab_stride,
-                                                  uint8_t *__restrict__ actb, size_t act_stride, int dbg)
+/* The pair machine over a picture's code stream: TWO wavefronts a picture.
+ *
+ * The chain (wavefront 0): everything wave-uniform on the scalar unit (nhw_low_machine.h).  The stream is taken in chunks of 256 pairs.  A
+ * first pair and the burst behind it are two look-ups (the burst table's entry, the first pair's rules: table_take in nhw_low_machine.h is
+ * the step, written out below on scalars of its own); a burst that starts elsewhere is decided by the lanes -- its longest clean run in one
+ * step (gen_lane1 / gen_lane2 / gen_word) --, and only a pair that moves a slow schedule or ends a burst through t17 goes through
+ * machine_step.  What such a step costs with sixteen chains to a CU (tools/dev/issue_probe.hip): a scalar instruction 17 cycles, a vector
+ * instruction 10, a dependent LDS look-up 72 -- so the step is look-ups and vector work wherever it can be.
+ *
+ * The table's wavefront (wavefront 1) runs one chunk ahead on the vector unit, which the chain leaves idle: the inclusive prefix sums of
+ * the pairs' hits into a ring of four chunks in LDS (16-bit: only differences are asked for; the chain's lanes read them too), their
+ * inverse for the chunk's window -- the first pair at which the sum reaches a value, which answers "where does a burst's hit count reach
+ * K" with one read --, and from those the four entries of each of the chunk's 256 positions (table_entries: a lane takes positions lane,
+ * lane + 64, ..).  One barrier a chunk between the two.  (Until the two were one kernel the table was a kernel of its own over the whole
+ * batch, 4.2 ms and 8.6 GB of traffic per 4096 pictures, in front of a chain of 3 ms at quality 1.)
+ * The answers collect in LDS and leave 256 bytes a chunk. */
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_low_chain(const uint8_t *__restrict__ codeb, size_t code_stride,
+                                                                                             uint8_t *__restrict__ actb, size_t act_stride, int dbg)
 {
 	__shared__ __attribute__((aligned(16))) uint16_t s_h[1024];
 	__shared__ __attribute__((aligned(16))) uint16_t s_tab[2 * 1024 + 4];    /* the table's entries of two chunks (a position's four side by side); behind them four entries that say "not here" */
 	__shared__ __attribute__((aligned(16))) uint8_t s_lut[512];              /* first_lut: the first pair's rules */
 	__shared__ __attribute__((aligned(16))) uint8_t s_act[512];              /* the answers of this chunk's pairs (the other half: zeros for the next) */
-	const int lane = threadIdx.x, img = blockIdx.x;
+	__shared__ __attribute__((aligned(16))) uint16_t s_inv[704];             /* the table's wavefront: s_inv[val] = the first pair of the window at which the hits' sum reaches val (999: none) */
+	__shared__ __attribute__((aligned(16))) uint8_t s_code[256];             /* the table's wavefront: the codes of the chunk it works on */
+	const int lane = threadIdx.x & 63, img = blockIdx.x;
 	const uint32_t *cp = reinterpret_cast<const uint32_t *>(codeb + (size_t)img * code_stride);
-	const uint4 *tp = reinterpret_cast<const uint4 *>(tabb + (size_t)img * tab_stride);
 	uint32_t *ap = reinterpret_cast<uint32_t *>(actb + (size_t)img * act_stride);
-	PfM mach;
-	PfC mcache;
-	machine_reset(mach);
-	machine_cache(mach, mcache);
 	auto load_codes = [&](int k) -> uint32_t {                         /* the four codes of my pairs of chunk k (0 behind the stream's end) */
 		if (k >= CH_CHUNKS) return 0u;
 		uint32_t w = cp[64 * k + lane];
@@ -703,37 +646,79 @@ __global__ __launch_bounds__(64) void k_low_chain(const uint8_t *__restrict__ co
 		if (rem < 4) w = rem <= 0 ? 0u : (w & ((1u << (8 * rem)) - 1u));
 		return w & 0x0F0F0F0Fu;
 	};
-	int tot = 0;                                                       /* hits of all pairs before the chunk that is scanned next */
-	auto scan_chunk = [&](int k, uint32_t w) {
-		const uint32_t hw = (w & 0x01010101u) + ((w >> 1) & 0x01010101u);   /* hits of my four pairs, a byte each */
-		const uint32_t pre = hw * 0x01010101u;                              /* their inclusive sums (at most 8) */
-		const int h = (int)(pre >> 24);
-		int incl = h;
-		for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-		const uint32_t base = (uint32_t)(tot + incl - h);
-		const uint32_t a0 = (base + (pre & 255u)) & 0xFFFFu, a1 = (base + ((pre >> 8) & 255u)) & 0xFFFFu, a2 = (base + ((pre >> 16) & 255u)) & 0xFFFFu, a3 = (base + (pre >> 24)) & 0xFFFFu;
-		*reinterpret_cast<uint2 *>(&s_h[((256 * k) & 1023) + 4 * lane]) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
-		tot += __builtin_amdgcn_readlane(incl, 63);
-	};
-	auto load_tab = [&](int k, uint4 &a, uint4 &b) {                    /* my 32 bytes of chunk k's 2 KB of entries */
-		if (k >= CH_CHUNKS) { a = make_uint4(0, 0, 0, 0); b = a; return; }
-		a = tp[128 * k + 2 * lane]; b = tp[128 * k + 2 * lane + 1];
-	};
-	auto put_tab = [&](int k, const uint4 &a, const uint4 &b) { uint4 *d = reinterpret_cast<uint4 *>(&s_tab[1024 * (k & 1) + 16 * lane]); d[0] = a; d[1] = b; };
+	if (threadIdx.x >= 64) {
+		/* ---- the table's wavefront ---- */
+		auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+		int tot = 0;                                                   /* hits of all pairs before the chunk that is scanned next */
+		auto scan_chunk = [&](int k, uint32_t w) {
+			const uint32_t hw = (w & 0x01010101u) + ((w >> 1) & 0x01010101u);   /* hits of my four pairs, a byte each */
+			const uint32_t pre = hw * 0x01010101u;                              /* their inclusive sums (at most 8) */
+			const int h = (int)(pre >> 24);
+			int incl = h;
+			for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+			const uint32_t base = (uint32_t)(tot + incl - h);
+			const uint32_t a0 = (base + (pre & 255u)) & 0xFFFFu, a1 = (base + ((pre >> 8) & 255u)) & 0xFFFFu, a2 = (base + ((pre >> 16) & 255u)) & 0xFFFFu, a3 = (base + (pre >> 24)) & 0xFFFFu;
+			*reinterpret_cast<uint2 *>(&s_h[((256 * k) & 1023) + 4 * lane]) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+			tot += __builtin_amdgcn_readlane(incl, 63);
+		};
+		/* the entries of chunk k (its codes: w; the sums of chunks k and k + 1 stand in the ring) */
+		auto build = [&](int k, uint32_t w) {
+			const int base = 256 * k;
+			*reinterpret_cast<uint32_t *>(&s_code[4 * lane]) = w;
+			for (int i = lane; i < 704 / 4; i += 64) reinterpret_cast<uint2 *>(s_inv)[i] = make_uint2(999u | (999u << 16), 999u | (999u << 16));
+			wave_sync();
+			const uint32_t hbase = k ? (uint32_t)s_h[(base - 1) & 1023] : 0u;   /* hits of all pairs before the window */
+			auto rel = [&](int wdx) { return (int)(uint16_t)((uint32_t)s_h[(base + wdx) & 1023] - hbase); };   /* hits of the window's pairs 0 .. wdx */
+			auto put = [&](int w0) {
+				int before = w0 ? rel(w0 - 1) : 0;
+				for (int e = 0; e < 4; e++) {
+					const int now = rel(w0 + e);
+					if (now > before) s_inv[before + 1] = (uint16_t)(w0 + e);      /* a pair adds one or two: the values it is the first to reach */
+					if (now > before + 1) s_inv[before + 2] = (uint16_t)(w0 + e);
+					before = now;
+				}
+			};
+			put(4 * lane);
+			if (lane < 16) put(256 + 4 * lane);
+			wave_sync();
+			for (int kk = 0; kk < 4; kk++) {
+				const int r = lane + 64 * kk, p = base + r;
+				const int hb = rel(r);                                      /* hits of the window's pairs 0 .. r: the burst's pairs start behind pair r */
+				auto g = [&](int j) { return rel(r + 1 + j) - hb; };
+				auto first_ge = [&](int K) { const int wv = (int)s_inv[hb + K] - (r + 1); return wv < 32 ? wv : 32; };
+				unsigned out[4];
+				table_entries(g, first_ge, CH_N - (p + 1), (int)s_code[r], out);
+				reinterpret_cast<uint2 *>(&s_tab[1024 * (k & 1)])[r] = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+			}
+		};
+		uint32_t ca = load_codes(0), cb = load_codes(1);
+		scan_chunk(0, ca); scan_chunk(1, cb);
+		wave_sync();
+		build(0, ca);
+		__syncthreads();
+		for (int k = 0; k < CH_CHUNKS; k++) {                            /* the chain is in chunk k: chunk k + 1's entries, chunk k + 2's sums */
+			const uint32_t cc = load_codes(k + 2);
+			scan_chunk(k + 2, cc);
+			wave_sync();
+			build(k + 1, cb);
+			cb = cc;
+			__syncthreads();
+		}
+		return;
+	}
+	/* ---- the chain ---- */
+	PfM mach;
+	PfC mcache;
+	machine_reset(mach);
+	machine_cache(mach, mcache);
 	for (int i = lane; i < 512; i += 64) s_lut[i] = (uint8_t)first_lut(i);
 	reinterpret_cast<uint2 *>(s_act)[lane] = make_uint2(0, 0);
 	if (lane < 4) s_tab[2048 + lane] = (uint16_t)TAB_NONE;
 	int pos = 0;
 	uint32_t cw = load_codes(0), cw1 = load_codes(1);
-	uint4 ta, tb;
-	load_tab(0, ta, tb);
-	put_tab(0, ta, tb);
-	load_tab(1, ta, tb);
-	scan_chunk(0, cw);
+	__syncthreads();
 	for (int k = 0; k < CH_CHUNKS; k++) {
 		const uint32_t cw2 = load_codes(k + 2);
-		scan_chunk(k + 1, cw1);
-		__syncthreads();
 		const int cend = 256 * (k + 1) < CH_N ? 256 * (k + 1) : CH_N;
 		if (!(dbg & 2)) {
 			while (pos < cend) {
@@ -802,13 +787,12 @@ __global__ __launch_bounds__(64) void k_low_chain(const uint8_t *__restrict__ co
 				}
 			}
 		}
-		__syncthreads();
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_wave_barrier();
 		ap[64 * k + lane] = reinterpret_cast<const uint32_t *>(s_act)[64 * (k & 1) + lane];
 		reinterpret_cast<uint32_t *>(s_act)[64 * (k & 1) + lane] = 0;
 		cw = cw1; cw1 = cw2;
-		__syncthreads();                                            /* the next chunk's entries go where chunk k - 1's stood, the next scan where chunk k - 2's sums stood */
-		put_tab(k + 1, ta, tb);
-		load_tab(k + 2, ta, tb);
+		__syncthreads();                                            /* the table's wavefront has chunk k + 1's entries and chunk k + 2's sums standing */
 	}
 }
 
@@ -1441,8 +1425,8 @@ void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y,
 	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
 	k_low_pre<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, chain, chain_stride, q, dbg);
-	k_low_table<<<dim3(CH_CHUNKS, n), 64, 0, s>>>(chain, chain_stride, tab, tab_stride / 2);
-	k_low_chain<<<n, 64, 0, s>>>(chain, chain_stride, tab, tab_stride / 2, chain + CH_BYTES, chain_stride, dbg);
+	(void)tab; (void)tab_stride;
+	k_low_chain<<<n, 128, 0, s>>>(chain, chain_stride, chain + CH_BYTES, chain_stride, dbg);
 	k_low_apply<<<n, 64, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, chain + CH_BYTES, chain_stride, q, dbg);
 	k_low_marks<<<dim3((W - 2 + MK_R - 2) / (MK_R - 1), n), MK_R, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
 }

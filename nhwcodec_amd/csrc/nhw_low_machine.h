@@ -671,33 +671,43 @@ DEVI int gen_take(PfM &m, int lane_s, unsigned w)
 template <class G, class J>
 DEVI void table_entries(G g, J first_ge, int navail, int code, unsigned out[4])
 {
-	auto ends = [&](int j, int v, int gj) { return ((1 + gj + 3 * ((v + j) >> 2)) >= 15) | ((1 + gj + 3 * ((v + j + 1) >> 2)) >= 16); };
+	/* Where the burst ends, without a walk: with f = (v + j) >> 2 the pair j caps if g(j) >= 14 - 3 f, and it wraps if g(j) >= 15 - 3 f' with
+	 * f' = (v + j + 1) >> 2.  Inside one quarter (f fixed: four consecutive j) the first such pair is max(first_ge(14 - 3 f), the quarter's
+	 * first j); the burst's end is the least of those over the quarters -- eleven look-ups that do not depend on v or on each other.  For v > 0
+	 * the end is the end of v - 1 or the pair before it (the counters of (v, j) are those of (v - 1, j + 1) but for the hits of one pair). */
 	const int j2 = first_ge(2), j3 = first_ge(3), j5 = first_ge(5), j6 = first_ge(6), j8 = first_ge(8), j9 = first_ge(9), j10 = first_ge(10);
+	const int j11 = first_ge(11), j12 = first_ge(12), j14 = first_ge(14), j15 = first_ge(15);
 	const int first_slow = (code & 1) & ((code >> 3) & 1);
-	int e = 0;
-	{ int lo = 0, hi = 32;                                              /* v = 0: a binary search (ends() is monotone in j) */
-	  for (int it = 0; it < 5; it++) { const int mid = (lo + hi) >> 1; const int p_ = ends(mid, 0, g(mid)); hi = p_ ? mid : hi; lo = p_ ? lo : mid + 1; }
-	  e = lo; }
+	int e0 = 20;                                                        /* v = 0: pair 20 caps whatever the hits (f = 5) */
+	{
+		const int capk[5] = { j14, j11, j8, j5, j2 }, wrapk[6] = { j15, j12, j9, j6, j3, 0 };
+		for (int f = 0; f < 5; f++) { const int lo = 4 * f, j = capk[f] > lo ? capk[f] : lo; e0 = (j <= lo + 3 && j < e0) ? j : e0; }
+		for (int f = 0; f < 6; f++) { const int lo = 4 * f - 1 > 0 ? 4 * f - 1 : 0, j = wrapk[f] > lo ? wrapk[f] : lo; e0 = (j <= 4 * f + 2 && j < e0) ? j : e0; }
+	}
+	const int ga[4] = { g(e0), g(e0 > 0 ? e0 - 1 : 0), g(e0 > 1 ? e0 - 2 : 0), g(e0 > 2 ? e0 - 3 : 0) };   /* the hits up to the pairs the four ends can be */
+	int e = e0;
 	for (int v = 0; v < 4; v++) {
-		if (v) {                                                        /* the end with v is the end with v - 1 or the pair before it */
-			const int jm = e > 0 ? e - 1 : 0;
-			const int pm = (e > 0) & ends(jm, v, g(jm));
+		if (v) {
+			const int d = e0 - e + 1;                                   /* the pair before the end of v - 1 is e0 - d */
+			const int gm = d == 1 ? ga[1] : d == 2 ? ga[2] : ga[3];
+			const int jm = e - 1;
+			const int pm = (e > 0) & (((1 + gm + 3 * ((v + jm) >> 2)) >= 15) | ((1 + gm + 3 * ((v + jm + 1) >> 2)) >= 16));
 			e = pm ? e - 1 : e;
 		}
-		const int je = e < 31 ? e : 31;
-		const int ge = g(je);
-		const int t1e = 1 + ge + 3 * ((v + je) >> 2);
+		const int dd = e0 - e;
+		const int ge = dd == 0 ? ga[0] : dd == 1 ? ga[1] : dd == 2 ? ga[2] : ga[3];
+		const int t1e = 1 + ge + 3 * ((v + e) >> 2);
 		const int cap = t1e >= 15;
-		int ncyc = je >= j10 ? je - j10 + 1 : 0;
+		int ncyc = e >= j10 ? e - j10 + 1 : 0;
 		ncyc -= (ge == 10) & (t1e == 15);
 		const int min3a = (j9 - 1) < (7 - v) ? (j9 - 1) : (7 - v);
-		const int win = (j8 > 4 - v ? j8 : 4 - v) <= (min3a < je ? min3a : je);
-		const int idle_hi = je - cap;
+		const int win = (j8 > 4 - v ? j8 : 4 - v) <= (min3a < e ? min3a : e);
+		const int idle_hi = e - cap;
 		const int a_hi = (j6 - 1) < (3 - v) ? (j6 - 1) : (3 - v);
 		const int b_hi = (j3 - 1) < (7 - v) ? (j3 - 1) : (7 - v);
 		const int i6 = (j5 <= (a_hi < idle_hi ? a_hi : idle_hi)) | ((j2 > 4 - v ? j2 : 4 - v) <= (b_hi < idle_hi ? b_hi : idle_hi));
-		const int none = (e >= 31) | (e >= navail) | (ncyc > 7) | first_slow;
-		out[v] = (unsigned)je | ((unsigned)cap << 5) | (none ? TAB_NONE : 0u) | ((unsigned)(ncyc & 7) << 7) | ((unsigned)win << 10) | ((unsigned)i6 << 11) | ((unsigned)code << 12);
+		const int none = (e >= navail) | (ncyc > 7) | first_slow;
+		out[v] = (unsigned)e | ((unsigned)cap << 5) | (none ? TAB_NONE : 0u) | ((unsigned)(ncyc & 7) << 7) | ((unsigned)win << 10) | ((unsigned)i6 << 11) | ((unsigned)code << 12);
 	}
 }
 /* which bits of an entry stop it as the counters are (t1 == 0: a first pair comes next) */
