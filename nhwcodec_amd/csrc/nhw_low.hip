@@ -414,8 +414,7 @@ DEVI int final_pair(const PfP &pp, const int16_t *km, int f0, int f1, int p, int
 #define CH_CHUNKS ((CH_N + 255) / 256)
 #define CH_BYTES (CH_CHUNKS * 256)
 
-__global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride,
-                                                int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ codeb, size_t code_stride, int q, int dbg)
+__global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ kmb, size_t km_stride, int q, int dbg)
 {
 	__shared__ __attribute__((aligned(16))) int16_t s_src[3][W];
 	__shared__ __attribute__((aligned(16))) int16_t s_km[W + 8];
@@ -429,18 +428,8 @@ __global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb
 	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	const int c0 = lane * 8;
 	const int16_t *src = srcb + (size_t)img * src_stride;
-	int16_t *yo = yb + (size_t)img * y_stride;
 	int16_t *kmo = kmb + (size_t)img * km_stride;                      /* the contrast map as pass A leaves it */
-	uint8_t *code = codeb + (size_t)img * code_stride;
 	auto load_row = [&](int r) { *reinterpret_cast<uint4 *>(&s_src[r % 3][c0]) = *reinterpret_cast<const uint4 *>(src + (size_t)r * W + c0); };
-	/* cells c0 - 1 .. c0 + 8 of a row in LDS (0 outside the row) */
-	auto load10 = [&](const int16_t *row, int *out) {
-		const uint4 q4 = *reinterpret_cast<const uint4 *>(row + c0);
-		const uint32_t w4[4] = { q4.x, q4.y, q4.z, q4.w };
-		for (int e = 0; e < 4; e++) { out[1 + 2 * e] = (int16_t)(w4[e] & 0xFFFF); out[2 + 2 * e] = (int16_t)(w4[e] >> 16); }
-		const int lo = row[lane ? c0 - 1 : 0], hi = row[lane < 63 ? c0 + 8 : W - 1];
-		out[0] = lane ? lo : 0; out[9] = lane < 63 ? hi : 0;
-	};
 	auto load10u = [&](const int16_t *row, uint32_t *out) {           /* the same as 16-bit unsigned values, sign bit flipped */
 		const uint4 q4 = *reinterpret_cast<const uint4 *>(row + c0);
 		const uint32_t w4[4] = { q4.x ^ 0x80008000u, q4.y ^ 0x80008000u, q4.z ^ 0x80008000u, q4.w ^ 0x80008000u };
@@ -450,7 +439,6 @@ __global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb
 	load_row(0); load_row(1);
 	for (int k = lane; k < W + 8; k += 64) s_km[k] = 0;
 	__syncthreads();
-	*reinterpret_cast<uint4 *>(yo + c0) = *reinterpret_cast<const uint4 *>(&s_src[0][c0]);      /* row 0 is not touched by any pass */
 	int16_t *km = s_km;
 
 	for (int r = 1; r < W - 1; r++) {
@@ -562,53 +550,9 @@ __global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb
 			}
 		}
 		__syncthreads();
-		/* all lanes: the row's picture copy (:566) with the q <= 14 smoothing (:780-807, reads the source copy only) and the pair codes of the
-		 * row (lane l has pairs 4 l .. 4 l + 3 = cells 8 l + 1 .. 8 l + 8) */
-		{
-			int k9[9];                                                 /* map cells c0 .. c0 + 8 */
-			const uint4 kq = *reinterpret_cast<const uint4 *>(&km[c0]);
-			{ const uint32_t w4[4] = { kq.x, kq.y, kq.z, kq.w };
-			  for (int e = 0; e < 4; e++) { k9[2 * e] = (int16_t)(w4[e] & 0xFFFF); k9[2 * e + 1] = (int16_t)(w4[e] >> 16); }
-			  k9[8] = km[c0 + 8]; }
-			uint32_t yw[4];
-			if (pp.smooth) {
-				int u10[10], m10[10], d10[10];
-				load10(up, u10); load10(mid, m10); load10(dn, d10);
-				for (int e2 = 0; e2 < 4; e2++) {
-					int v2[2];
-					for (int h = 0; h < 2; h++) {
-						const int e = 2 * e2 + h, c = c0 + e;
-						const int ctr = m10[e + 1], lf = m10[e], rt = m10[e + 2], ab = u10[e + 1], bl = d10[e + 1];
-						int v = ctr;
-						if (c >= 1 && c <= W - 2) {
-							const int k = k9[e];
-							if (iabs_(k) > 4 && iabs_(k) < pp.smooth_hi && iabs_(ab - lf) < 4 && iabs_(lf - bl) < 4 && iabs_(bl - rt) < 4 && iabs_(rt - ab) < 4)
-								v = ((ctr << 2) + lf + rt + ab + bl + 4) >> 3;
-						}
-						v2[h] = v;
-					}
-					yw[e2] = (uint32_t)(uint16_t)v2[0] | ((uint32_t)(uint16_t)v2[1] << 16);
-				}
-			} else {
-				const uint4 mq = *reinterpret_cast<const uint4 *>(&mid[c0]);
-				yw[0] = mq.x; yw[1] = mq.y; yw[2] = mq.z; yw[3] = mq.w;
-			}
-			*reinterpret_cast<uint4 *>(yo + (size_t)r * W + c0) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
-			*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = kq;
-			uint32_t cw = 0;                                             /* the codes of my four pairs */
-			for (int j = 0; j < 4; j++) {
-				const int k0 = k9[2 * j + 1], k1 = k9[2 * j + 2];
-				const int f0 = iabs_(k0) > pp.sharp, f1 = iabs_(k1) > pp.sharp;
-				const uint32_t cd = (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (iabs_(k1) > pp.s2 ? 4u : 0u) | (iabs_(k0) > pp.sharp + 96 ? 8u : 0u);
-				cw |= cd << (8 * j);
-			}
-			uint8_t *cp = code + (size_t)(r - 1) * 255 + 4 * lane;      /* the row's 255 codes go behind the row above's: a lane's four bytes sit at any alignment */
-			cp[0] = (uint8_t)cw; cp[1] = (uint8_t)(cw >> 8); cp[2] = (uint8_t)(cw >> 16);
-			if (lane < 63) cp[3] = (uint8_t)(cw >> 24);                 /* pair 255 does not exist */
-		}
+		*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&km[c0]);
 		__syncthreads();
 	}
-	*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_src[(W - 1) % 3][c0]);
 }
 
 /* The pair machine over a picture's code stream: TWO wavefronts a picture.
@@ -627,24 +571,32 @@ __global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb
  * lane + 64, ..).  One barrier a chunk between the two.  (Until the two were one kernel the table was a kernel of its own over the whole
  * batch, 4.2 ms and 8.6 GB of traffic per 4096 pictures, in front of a chain of 3 ms at quality 1.)
  * The answers collect in LDS and leave 256 bytes a chunk. */
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_low_chain(const uint8_t *__restrict__ codeb, size_t code_stride,
-                                                                                             uint8_t *__restrict__ actb, size_t act_stride, int dbg)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_low_chain(const int16_t *__restrict__ kmb, size_t km_stride,
+                                                                                             uint8_t *__restrict__ actb, size_t act_stride, int q, int dbg)
 {
 	__shared__ __attribute__((aligned(16))) uint16_t s_h[1024];
 	__shared__ __attribute__((aligned(16))) uint16_t s_tab[2 * 1024 + 4];    /* the table's entries of two chunks (a position's four side by side); behind them four entries that say "not here" */
 	__shared__ __attribute__((aligned(16))) uint8_t s_lut[512];              /* first_lut: the first pair's rules */
 	__shared__ __attribute__((aligned(16))) uint8_t s_act[512];              /* the answers of this chunk's pairs (the other half: zeros for the next) */
 	__shared__ __attribute__((aligned(16))) uint16_t s_inv[704];             /* the table's wavefront: s_inv[val] = the first pair of the window at which the hits' sum reaches val (999: none) */
-	__shared__ __attribute__((aligned(16))) uint8_t s_code[256];             /* the table's wavefront: the codes of the chunk it works on */
+	__shared__ __attribute__((aligned(16))) uint8_t s_code[1024];            /* the pairs' codes, a ring of four chunks: the table's wavefront makes them two chunks ahead of the chain */
 	const int lane = threadIdx.x & 63, img = blockIdx.x;
-	const uint32_t *cp = reinterpret_cast<const uint32_t *>(codeb + (size_t)img * code_stride);
+	const int16_t *km = kmb + (size_t)img * km_stride;                  /* the contrast map as pass A left it */
 	uint32_t *ap = reinterpret_cast<uint32_t *>(actb + (size_t)img * act_stride);
-	auto load_codes = [&](int k) -> uint32_t {                         /* the four codes of my pairs of chunk k (0 behind the stream's end) */
-		if (k >= CH_CHUNKS) return 0u;
-		uint32_t w = cp[64 * k + lane];
-		const int rem = CH_N - (256 * k + 4 * lane);
-		if (rem < 4) w = rem <= 0 ? 0u : (w & ((1u << (8 * rem)) - 1u));
-		return w & 0x0F0F0F0Fu;
+	/* the codes of my four pairs of chunk k, made from their map cells (pair n of the stream: row 1 + n / 255, cells 1 + 2 (n % 255) and the next;
+	 * 0 behind the stream's end): all the machine ever asks about the picture (nhw_low_machine.h) */
+	const PfP pp = pf_params(q);
+	auto load_codes = [&](int k) -> uint32_t {
+		uint32_t w = 0;
+		for (int j = 0; j < 4; j++) {
+			const int n = 256 * k + 4 * lane + j;
+			if (n >= CH_N) break;
+			const int row = n / 255, pr = n - row * 255;
+			const int16_t *c = km + (size_t)(row + 1) * W + 1 + 2 * pr;
+			const int k0 = c[0], k1 = c[1];
+			w |= ((iabs_(k0) > pp.sharp ? 1u : 0u) | (iabs_(k1) > pp.sharp ? 2u : 0u) | (iabs_(k1) > pp.s2 ? 4u : 0u) | (iabs_(k0) > pp.sharp + 96 ? 8u : 0u)) << (8 * j);
+		}
+		return w;
 	};
 	if (threadIdx.x >= 64) {
 		/* ---- the table's wavefront ---- */
@@ -662,9 +614,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 			tot += __builtin_amdgcn_readlane(incl, 63);
 		};
 		/* the entries of chunk k (its codes: w; the sums of chunks k and k + 1 stand in the ring) */
-		auto build = [&](int k, uint32_t w) {
+		auto build = [&](int k) {
 			const int base = 256 * k;
-			*reinterpret_cast<uint32_t *>(&s_code[4 * lane]) = w;
+			const uint8_t *codes = &s_code[base & 1023];
 			for (int i = lane; i < 704 / 4; i += 64) reinterpret_cast<uint2 *>(s_inv)[i] = make_uint2(999u | (999u << 16), 999u | (999u << 16));
 			wave_sync();
 			const uint32_t hbase = k ? (uint32_t)s_h[(base - 1) & 1023] : 0u;   /* hits of all pairs before the window */
@@ -687,21 +639,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 				auto g = [&](int j) { return rel(r + 1 + j) - hb; };
 				auto first_ge = [&](int K) { const int wv = (int)s_inv[hb + K] - (r + 1); return wv < 32 ? wv : 32; };
 				unsigned out[4];
-				table_entries(g, first_ge, CH_N - (p + 1), (int)s_code[r], out);
+				table_entries(g, first_ge, CH_N - (p + 1), (int)codes[r], out);
 				reinterpret_cast<uint2 *>(&s_tab[1024 * (k & 1)])[r] = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
 			}
 		};
-		uint32_t ca = load_codes(0), cb = load_codes(1);
-		scan_chunk(0, ca); scan_chunk(1, cb);
+		auto codes_chunk = [&](int k) { const uint32_t w = load_codes(k); *reinterpret_cast<uint32_t *>(&s_code[((256 * k) & 1023) + 4 * lane]) = w; scan_chunk(k, w); };
+		codes_chunk(0); codes_chunk(1);
 		wave_sync();
-		build(0, ca);
+		build(0);
 		__syncthreads();
-		for (int k = 0; k < CH_CHUNKS; k++) {                            /* the chain is in chunk k: chunk k + 1's entries, chunk k + 2's sums */
-			const uint32_t cc = load_codes(k + 2);
-			scan_chunk(k + 2, cc);
+		for (int k = 0; k < CH_CHUNKS; k++) {                            /* the chain is in chunk k: chunk k + 1's entries, chunk k + 2's codes and sums */
+			codes_chunk(k + 2);
 			wave_sync();
-			build(k + 1, cb);
-			cb = cc;
+			build(k + 1);
 			__syncthreads();
 		}
 		return;
@@ -715,10 +665,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	reinterpret_cast<uint2 *>(s_act)[lane] = make_uint2(0, 0);
 	if (lane < 4) s_tab[2048 + lane] = (uint16_t)TAB_NONE;
 	int pos = 0;
-	uint32_t cw = load_codes(0), cw1 = load_codes(1);
 	__syncthreads();
 	for (int k = 0; k < CH_CHUNKS; k++) {
-		const uint32_t cw2 = load_codes(k + 2);
 		const int cend = 256 * (k + 1) < CH_N ? 256 * (k + 1) : CH_N;
 		if (!(dbg & 2)) {
 			while (pos < cend) {
@@ -779,7 +727,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 					step_now = true;
 				}
 				{                                                     /* the pair that stopped a run; a first pair the table does not take; a pair the counters do not let into a burst */
-					const int code = (int)(((uint32_t)__builtin_amdgcn_readlane((int)(pos < cend ? cw : cw1), (pos >> 2) & 63) >> (8 * (pos & 3))) & 15u);
+					const int code = LDK(&s_code[pos & 1023]);
 					int a = step_now ? -1 : machine_step_fast(mach, mcache, code);
 					if (a < 0) { a = machine_step(mach, code, 1 + pos / 255); machine_cache(mach, mcache); }
 					if (a) STK(&s_act[pos & 511], (uint8_t)a);
@@ -791,16 +739,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 		__builtin_amdgcn_wave_barrier();
 		ap[64 * k + lane] = reinterpret_cast<const uint32_t *>(s_act)[64 * (k & 1) + lane];
 		reinterpret_cast<uint32_t *>(s_act)[64 * (k & 1) + lane] = 0;
-		cw = cw1; cw1 = cw2;
 		__syncthreads();                                            /* the table's wavefront has chunk k + 1's entries and chunk k + 2's sums standing */
 	}
 }
 
 /* act: the chain's answers (a byte a pair, stream order); y / km in: as k_low_pre left them; out: as passes A..C leave them (the rows pass C
  * walks here are listed in the flag plane's row 0 for k_low_marks). */
-__global__ __launch_bounds__(64) void k_low_apply(int16_t *__restrict__ yb, size_t y_stride, int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride,
-                                                  const uint8_t *__restrict__ actb, size_t act_stride, int q, int dbg)
+__global__ __launch_bounds__(64) void k_low_apply(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride, int16_t *__restrict__ kmb, size_t km_stride,
+                                                  uint8_t *__restrict__ sob, size_t so_stride, const uint8_t *__restrict__ actb, size_t act_stride, int q, int dbg)
 {
+	__shared__ __attribute__((aligned(16))) int16_t s_src[3][W];
 	__shared__ __attribute__((aligned(16))) int16_t s_km[2][W + 8];
 	__shared__ __attribute__((aligned(16))) int16_t s_y[2][W];
 	__shared__ __attribute__((aligned(16))) uint8_t s_so[2][W];
@@ -816,10 +764,22 @@ __global__ __launch_bounds__(64) void k_low_apply(int16_t *__restrict__ yb, size
 	int16_t *kmo = kmb + (size_t)img * km_stride;                      /* contrast map and flags as passes A..C leave them */
 	uint8_t *soo = sob + (size_t)img * so_stride;
 	const uint8_t *act = actb + (size_t)img * act_stride;
+	const int16_t *src = srcb + (size_t)img * src_stride;
 	for (int k = lane; k < 2 * (W + 8); k += 64) (&s_km[0][0])[k] = 0;
+	/* cells c0 - 1 .. c0 + 8 of a row in LDS (0 outside the row) */
+	auto load10 = [&](const int16_t *row, int *out) {
+		const uint4 q4 = *reinterpret_cast<const uint4 *>(row + c0);
+		const uint32_t w4[4] = { q4.x, q4.y, q4.z, q4.w };
+		for (int e = 0; e < 4; e++) { out[1 + 2 * e] = (int16_t)(w4[e] & 0xFFFF); out[2 + 2 * e] = (int16_t)(w4[e] >> 16); }
+		const int lo = row[lane ? c0 - 1 : 0], hi = row[lane < 63 ? c0 + 8 : W - 1];
+		out[0] = lane ? lo : 0; out[9] = lane < 63 ? hi : 0;
+	};
 	auto load_act = [&](int r) -> uint32_t { const uint8_t *p = act + (size_t)(r - 1) * 255 + 4 * lane; return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | (lane < 63 ? (uint32_t)p[3] << 24 : 0u); };
-	uint4 nk = *reinterpret_cast<const uint4 *>(kmo + (size_t)W + c0), ny = *reinterpret_cast<const uint4 *>(yo + (size_t)W + c0);   /* row 1 on its way */
+	uint4 nk = *reinterpret_cast<const uint4 *>(kmo + (size_t)W + c0), ns = *reinterpret_cast<const uint4 *>(src + (size_t)2 * W + c0);   /* row 1 of the map, row 2 of the source on their way */
 	uint32_t na = load_act(1);
+	{ const uint4 r0 = *reinterpret_cast<const uint4 *>(src + c0), r1 = *reinterpret_cast<const uint4 *>(src + (size_t)W + c0);
+	  *reinterpret_cast<uint4 *>(&s_src[0][c0]) = r0; *reinterpret_cast<uint4 *>(&s_src[1][c0]) = r1;
+	  *reinterpret_cast<uint4 *>(yo + c0) = r0; }                                                /* row 0 is not touched by any pass */
 	__syncthreads();
 
 	for (int r = 1; r < W - 1; r++) {
@@ -827,13 +787,45 @@ __global__ __launch_bounds__(64) void k_low_apply(int16_t *__restrict__ yb, size
 		int16_t *y = s_y[r & 1];
 		uint8_t *so = s_so[r & 1];
 		*reinterpret_cast<uint4 *>(&km[c0]) = nk;
-		*reinterpret_cast<uint4 *>(&y[c0]) = ny;
+		*reinterpret_cast<uint4 *>(&s_src[(r + 1) % 3][c0]) = ns;
 		const uint32_t aw = na;
 		if (r + 1 < W - 1) {
-			nk = *reinterpret_cast<const uint4 *>(kmo + (size_t)(r + 1) * W + c0); ny = *reinterpret_cast<const uint4 *>(yo + (size_t)(r + 1) * W + c0);
+			nk = *reinterpret_cast<const uint4 *>(kmo + (size_t)(r + 1) * W + c0); ns = *reinterpret_cast<const uint4 *>(src + (size_t)(r + 2) * W + c0);
 			na = load_act(r + 1);
 		}
 		__syncthreads();
+		{
+			/* the row's picture copy (:566) with the q <= 14 smoothing (:780-807: reads the source copy and the map as pass A left it) */
+			const int16_t *up = s_src[(r - 1) % 3], *mid = s_src[r % 3], *dn = s_src[(r + 1) % 3];
+			uint32_t yw[4];
+			if (pp.smooth) {
+				int k9[8];
+				{ const uint4 kq = *reinterpret_cast<const uint4 *>(&km[c0]);
+				  const uint32_t w4[4] = { kq.x, kq.y, kq.z, kq.w };
+				  for (int e = 0; e < 4; e++) { k9[2 * e] = (int16_t)(w4[e] & 0xFFFF); k9[2 * e + 1] = (int16_t)(w4[e] >> 16); } }
+				int u10[10], m10[10], d10[10];
+				load10(up, u10); load10(mid, m10); load10(dn, d10);
+				for (int e2 = 0; e2 < 4; e2++) {
+					int v2[2];
+					for (int h = 0; h < 2; h++) {
+						const int e = 2 * e2 + h, c = c0 + e;
+						const int ctr = m10[e + 1], lf = m10[e], rt = m10[e + 2], ab = u10[e + 1], bl = d10[e + 1];
+						int v = ctr;
+						if (c >= 1 && c <= W - 2) {
+							const int kk = k9[e];
+							if (iabs_(kk) > 4 && iabs_(kk) < pp.smooth_hi && iabs_(ab - lf) < 4 && iabs_(lf - bl) < 4 && iabs_(bl - rt) < 4 && iabs_(rt - ab) < 4)
+								v = ((ctr << 2) + lf + rt + ab + bl + 4) >> 3;
+						}
+						v2[h] = v;
+					}
+					yw[e2] = (uint32_t)(uint16_t)v2[0] | ((uint32_t)(uint16_t)v2[1] << 16);
+				}
+			} else {
+				const uint4 mq = *reinterpret_cast<const uint4 *>(&mid[c0]);
+				yw[0] = mq.x; yw[1] = mq.y; yw[2] = mq.z; yw[3] = mq.w;
+			}
+			*reinterpret_cast<uint4 *>(&y[c0]) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+		}
 		/* all lanes: the answers applied to the row (pass B's picture side), the tail rules, and the test for markers */
 		bool any_mark;
 		{
@@ -917,6 +909,7 @@ __global__ __launch_bounds__(64) void k_low_apply(int16_t *__restrict__ yb, size
 		*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[r & 1][c0]);
 		*reinterpret_cast<uint2 *>(soo + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[r & 1][c0]);
 		if (lane < 16) reinterpret_cast<uint32_t *>(soo)[lane] = s_rowmask[lane];      /* flag plane, row 0: the rows k_low_marks must leave alone */
+		*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(src + (size_t)(W - 1) * W + c0);   /* the last row is not touched either */
 	}
 }
 
@@ -1424,10 +1417,10 @@ void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y,
 #ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing */
 	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
-	k_low_pre<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, chain, chain_stride, q, dbg);
+	k_low_pre<<<n, 64, 0, s>>>(src, src_stride, km, km_stride, q, dbg);
 	(void)tab; (void)tab_stride;
-	k_low_chain<<<n, 128, 0, s>>>(chain, chain_stride, chain + CH_BYTES, chain_stride, dbg);
-	k_low_apply<<<n, 64, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, chain + CH_BYTES, chain_stride, q, dbg);
+	k_low_chain<<<n, 128, 0, s>>>(km, km_stride, chain, chain_stride, q, dbg);
+	k_low_apply<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, chain, chain_stride, q, dbg);
 	k_low_marks<<<dim3((W - 2 + MK_R - 2) / (MK_R - 1), n), MK_R, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
 }
 /* Compatibility mode (NHW_COMPAT_GLIBC_ONESHOT) only, quality <= 16: the contrast-map cells whose memory the stock binary's malloc hands

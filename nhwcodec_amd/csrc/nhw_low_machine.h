@@ -8,6 +8,9 @@
  */
 #ifndef NHW_LOW_MACHINE_H
 #define NHW_LOW_MACHINE_H
+#ifndef PF_COV
+#define PF_COV(n) ((void)0)      /* a developer tool (tools/dev/prelow_fuzz.cpp) counts which of the rare schedule branches a picture reaches */
+#endif
 
 /* ------------------------------------------------------------------------------------------------ pass B: the pair machine (:770-1992) */
 /* The counters are numbered as the reference numbers its variables (t1..t44, w1..w8): they have no documented meaning, and a reader
@@ -126,34 +129,41 @@ DEVN void burst_idle(PfM &m)
 	if (!(T(29) > 0 && (T(14) == 4 || T(14) == 5 || T(39) == 2 || T(41) > 0))) return;
 
 	if (T(4) < 2 && T(1) == 15 && (T(14) == 4 || (T(14) == 5 && T(32) > 2))) {
+		PF_COV(0);
 		if (T(32) == 0 || T(32) == 2 || T(32) == 3 || (T(32) > 7 && T(32) < 500000)) {
-			if (T(32) > 7 && T(14) == 5) { T(14) = 1; T(32) = 1000000; }
-			else if (!T(34)) T(34) = 1;
-			else { T(14) = 5; T(34) = 0; }
+			if (T(32) > 7 && T(14) == 5) { PF_COV(1); T(14) = 1; T(32) = 1000000; }
+			else if (!T(34)) { PF_COV(2); T(34) = 1; }
+			else { PF_COV(3); T(14) = 5; T(34) = 0; }
 		}
 		if (!T(32)) T(14) = 5;
 		T(32)++;
 	}
 	else if (T(32) == 4 || T(32) == 5 || T(32) == 7) {
-		if (T(37) == 4) T(14) = 3;
-		else if (T(37) == 15) { T(14) = 3; T(32)++; }
+		PF_COV(4);
+		if (T(37) == 4) { PF_COV(5); T(14) = 3; }
+		else if (T(37) == 15) { PF_COV(6); T(14) = 3; T(32)++; }
 		else if (T(32) == 7 && T(37) > -345000) {
+			PF_COV(7);
 			if (T(14) == 4) {
+				PF_COV(8);
 				if (!T(42)) T(37) -= 10000;
 				if (T(38) > 0) {
+					PF_COV(9);
 					T(42)++;
 					if (T(42) > 0 || (!T(42) && T(43) > 3)) {
-						if (!T(42)) T(14) = T(43) == 14 ? 3 : T(43) == 24 ? 4 : 1;
+						PF_COV(10);
+						if (!T(42)) { PF_COV(11); T(14) = T(43) == 14 ? 3 : T(43) == 24 ? 4 : 1; }
 						else T(14) = 1;
 						T(39) = 0;
-						if (T(42) > 5) { T(42) = -1; T(43)++; }
+						if (T(42) > 5) { PF_COV(12); T(42) = -1; T(43)++; }
 					}
-					else if (T(42) == -1) { T(14) = 3; T(39) = 2; T(40) = -2; T(42) = 0; }
-					else T(39) = 0;
+					else if (T(42) == -1) { PF_COV(13); T(14) = 3; T(39) = 2; T(40) = -2; T(42) = 0; }
+					else { PF_COV(14); T(39) = 0; }
 				}
-				else { T(14) = 5; T(39) = 1; T(42) = 0; }
+				else { PF_COV(15); T(14) = 5; T(39) = 1; T(42) = 0; }
 			}
 			else if (T(39) >= 1) {
+				PF_COV(16);
 				T(38)++;
 				if (T(39) < 2) T(39) = (T(38) == 2 || T(38) == 4 || T(38) == 6 || T(38) == 9) ? 2 : 0;
 				else {
@@ -163,11 +173,12 @@ DEVN void burst_idle(PfM &m)
 				}
 				if (T(38) >= 1 && T(38) <= 10) T(14) = 4;
 			}
-			else { T(40) = 1; if (T(38) == 1) T(39) = 2; }
+			else { PF_COV(17); T(40) = 1; if (T(38) == 1) T(39) = 2; }
 		}
 		if (T(37) >= 0) T(37)++;
 	}
 	else if (T(32) == 6 && T(36) < 118) {
+		PF_COV(18);
 		if (T(14) == 4 || T(14) == 5 || T(41) == 0 || T(41) > 3) T(36)++;
 		if (T(41) > 3 && T(36) < 8) T(41) = 0;
 		switch (T(36)) {                 /* t36 -> t14; t41 is reset, counted up or set to 4 */
@@ -193,16 +204,16 @@ DEVN void burst_idle(PfM &m)
 		case 11: late_d = 185; l14 = 0; l15 = 4; l1 = -17; break; case 12: late_d = 187; l14 = 3; l15 = 3; l1 = -19; break;
 		default: break;
 		}
-		if (!st && ahead > 10 && T(33) > 0 && T(14) == 4) { T(14) = 3; T(15) += 6; T(28)++; }
-		else if (st == 1 && ahead > 70 && T(14) == 4 && T(1) == 11) { T(15) = 1; T(1) = 13; T(28)++; }
-		else if (st == 2 && T(31) > 2 && T(1) == 15 && T(15) > 1) { T(15) = 15; T(33) = T(30); T(1) = 6; T(28)++; }
-		else if (st == 3 && ahead > 3 && T(31) > 2) { T(15) = 0; T(28)++; }
-		else if (st == 5 && ahead > 22 && T(31) > 2 && T(1) == 12) { T(15) = 3; T(1) = 9; T(28)++; }
-		else if (st == 4 && ahead > 6 && T(1) == 15) { T(14) = 1; T(15) += 6; T(1)++; T(28)++; }
-		else if (st >= 6 && st <= 12 && ahead > late_d) { T(14) = l14; T(15) = l15; T(1) = l1; if (l4) T(4) = l4; T(28)++; }
+		if (!st && ahead > 10 && T(33) > 0 && T(14) == 4) { PF_COV(20); T(14) = 3; T(15) += 6; T(28)++; }
+		else if (st == 1 && ahead > 70 && T(14) == 4 && T(1) == 11) { PF_COV(21); T(15) = 1; T(1) = 13; T(28)++; }
+		else if (st == 2 && T(31) > 2 && T(1) == 15 && T(15) > 1) { PF_COV(22); T(15) = 15; T(33) = T(30); T(1) = 6; T(28)++; }
+		else if (st == 3 && ahead > 3 && T(31) > 2) { PF_COV(23); T(15) = 0; T(28)++; }
+		else if (st == 5 && ahead > 22 && T(31) > 2 && T(1) == 12) { PF_COV(25); T(15) = 3; T(1) = 9; T(28)++; }
+		else if (st == 4 && ahead > 6 && T(1) == 15) { PF_COV(24); T(14) = 1; T(15) += 6; T(1)++; T(28)++; }
+		else if (st >= 6 && st <= 12 && ahead > late_d) { PF_COV(20 + st); T(14) = l14; T(15) = l15; T(1) = l1; if (l4) T(4) = l4; T(28)++; }
 		else if (ahead == 9) { T(1) += (12 - T(4)) >> 2; T(4) = 10; }
 		else if (st > 0 && T(1) == 15 && Wv(1) < 11) { if (T(4) != 10) { if (Wv(1) == 4 || Wv(1) == 10) T(4) = 10; Wv(1)++; } }
-		else if (st == 13 && ahead > 188) { T(14) = 0; T(15) = 3; T(1) = -30; T(28)++; }
+		else if (st == 13 && ahead > 188) { PF_COV(33); T(14) = 0; T(15) = 3; T(1) = -30; T(28)++; }
 	}
 }
 
@@ -285,13 +296,14 @@ DEVI int machine_step(PfM &m, int code, int row)
 		else burst_idle(m);
 
 		if (T(8) > 6 && !T(4) && T(1) > 1 && T(1) < 15) {  /* :1875-1900 */
+			PF_COV(34);
 			T(5)++;
 			if (T(5) < 35) {
 				T(1) = 0;
-				if (!T(13)) { T(12) = 1; T(13) = 1; }
-				else { T(12) = 0; T(13)++; if (T(13) > 3) T(13) = 0; }
+				if (!T(13)) { PF_COV(35); T(12) = 1; T(13) = 1; }
+				else { PF_COV(36); T(12) = 0; T(13)++; if (T(13) > 3) T(13) = 0; }
 			}
-			else T(12) = 0;
+			else { PF_COV(37); T(12) = 0; }
 		}
 		if (T(1) > 15 && T(1) < 1000000) { T(1) = 0; T(4) = 0; T(29)++; }
 	}
