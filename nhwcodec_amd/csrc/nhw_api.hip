@@ -35,7 +35,7 @@ void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, in
 enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2 };
 /* quality 1..16 only (nhw_low.hip) */
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride, uint8_t *chain, size_t chain_stride,
-                              uint16_t *tab, size_t tab_stride, int q, int n, hipStream_t s);
+                              uint16_t *tab, size_t tab_stride, int q, int n, hipStream_t s, int force = 0);
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s);
 void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipStream_t s);
 void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s);
@@ -213,7 +213,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 		nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
 		HIPCHK(hipEventRecord(e->ev[5], s));                      /* with the front group, whoever brackets it: nhw_timing.color_dwt_ms / prefilter_ms */
 		STAGE_DONE();
-		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], (uint16_t *)plane8(ws, B_LOWTAB), ws.stride[B_LOWTAB], q, n, s);   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser; pair codes and answers -> the q >= 22 plane */
+		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], (uint16_t *)plane8(ws, B_LOWTAB), ws.stride[B_LOWTAB], q, n, s, (e->front_fallback & 1) ? 32 : 0);   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser; pair codes and answers -> the q >= 22 plane */
 		HIPCHK(hipEventRecord(e->ev[6], s));
 		STAGE_DONE();
 		if (ws.compat) nhw_launch_low_stale(proc, ps, plane16(ws, B_STALE), ws.stride[B_STALE], n, s);   /* compatibility mode only: the map cells the stock binary's heap re-uses */

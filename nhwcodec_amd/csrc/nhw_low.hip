@@ -414,34 +414,43 @@ DEVI int final_pair(const PfP &pp, const int16_t *km, int f0, int f1, int p, int
 #define CH_CHUNKS ((CH_N + 255) / 256)
 #define CH_BYTES (CH_CHUNKS * 256)
 
-__global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ kmb, size_t km_stride, int q, int dbg)
+#define PRE_RB 32                                                      /* rows of a band of k_low_pre / k_low_apply */
+#define PRE_NB ((W - 2 + PRE_RB - 1) / PRE_RB)
+#define MASK_ROW 320                                                   /* a row's five candidate masks (64 bytes each: border, bump, exact, negative sum, small sum) */
+/* Pass A but for its order-dependent cells, a wavefront a band of 32 rows (until round 6: a wavefront a picture, 510 rows in turn -- 3.4 ms of
+ * latency whatever the batch).  What ties the rows of pass A together is the 4-bit carry that runs on from row to row -- and forgets: the
+ * band's first row takes its entry state from a look-back over the row above (that row is worked through without output; where the last
+ * lane's sixteen candidate states have not merged, the band goes further back, row by row, and comes forward again with the exact state) --
+ * and the marker counters (MapState), which only the few candidate cells move: those are left to k_low_mapfix, with the cells marked here
+ * for every state the counters can be in (five bit masks a row). */
+__global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ kmb, size_t km_stride,
+                                                uint8_t *__restrict__ maskb, size_t mask_stride, int q, int dbg)
 {
 	__shared__ __attribute__((aligned(16))) int16_t s_src[3][W];
 	__shared__ __attribute__((aligned(16))) int16_t s_km[W + 8];
 	__shared__ __attribute__((aligned(16))) int16_t s_vb[W];              /* pass A's base values */
-	__shared__ __attribute__((aligned(16))) int16_t s_sum[W];             /* pass A: the 8-neighbour sums */
-	__shared__ __attribute__((aligned(8))) uint8_t s_cand[64];            /* per 8-pixel group: the pixels that need the serial visit of pass A */
 	__shared__ int s_misc[4];
-	const int lane = threadIdx.x, img = blockIdx.x;
+	const int lane = threadIdx.x, band = blockIdx.x, img = blockIdx.y;
 	const PfP pp = pf_params(q);
-	int row_carry = 0;                                                 /* wave-uniform: pass A's entry carry and its marker state */
-	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	const int c0 = lane * 8;
 	const int16_t *src = srcb + (size_t)img * src_stride;
-	int16_t *kmo = kmb + (size_t)img * km_stride;                      /* the contrast map as pass A leaves it */
+	int16_t *kmo = kmb + (size_t)img * km_stride;                      /* the contrast map as pass A leaves it (but for the cells k_low_mapfix visits) */
+	uint8_t *mask = maskb + (size_t)img * mask_stride;
+	const int r0 = 1 + PRE_RB * band, r1 = r0 + PRE_RB - 1 < W - 2 ? r0 + PRE_RB - 1 : W - 2;
 	auto load_row = [&](int r) { *reinterpret_cast<uint4 *>(&s_src[r % 3][c0]) = *reinterpret_cast<const uint4 *>(src + (size_t)r * W + c0); };
-	auto load10u = [&](const int16_t *row, uint32_t *out) {           /* the same as 16-bit unsigned values, sign bit flipped */
+	auto ring_init = [&](int r) { __syncthreads(); load_row(r - 1); load_row(r); };   /* rows r - 1 and r stand in the ring: row r can be worked on */
+	auto load10u = [&](const int16_t *row, uint32_t *out) {           /* cells c0 - 1 .. c0 + 8 of a row in LDS as 16-bit unsigned values, sign bit flipped */
 		const uint4 q4 = *reinterpret_cast<const uint4 *>(row + c0);
 		const uint32_t w4[4] = { q4.x ^ 0x80008000u, q4.y ^ 0x80008000u, q4.z ^ 0x80008000u, q4.w ^ 0x80008000u };
 		for (int e = 0; e < 4; e++) { out[1 + 2 * e] = w4[e] & 0xFFFFu; out[2 + 2 * e] = w4[e] >> 16; }
 		out[0] = (uint32_t)(uint16_t)row[lane ? c0 - 1 : 0] ^ 0x8000u; out[9] = (uint32_t)(uint16_t)row[lane < 63 ? c0 + 8 : W - 1] ^ 0x8000u;
 	};
-	load_row(0); load_row(1);
 	for (int k = lane; k < W + 8; k += 64) s_km[k] = 0;
-	__syncthreads();
 	int16_t *km = s_km;
-
-	for (int r = 1; r < W - 1; r++) {
+	/* One row of pass A.  known: the carry the row starts from is `carry_in`; otherwise nobody knows it, every lane looks back, and only
+	 * the row's last lanes can be right.  Returns the carry behind the row in carry_out, and whether it is exact; emit: the row's map cells
+	 * and candidate masks go out. */
+	auto do_row = [&](int r, bool known, int carry_in, bool emit, int &carry_out) -> bool {
 		load_row(r + 1);
 		__syncthreads();
 		const int16_t *up = s_src[(r - 1) % 3], *mid = s_src[r % 3], *dn = s_src[(r + 1) % 3];
@@ -468,90 +477,150 @@ __global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb
 				vbv[e] = sm == 0 ? 0 : (sm < 0 ? -(15 * -sm + (int)mg) : 15 * sm + (int)mg);
 			}
 		}
-		{ uint32_t w4[4], z4[4];
-		  for (int e = 0; e < 4; e++) { w4[e] = (uint32_t)(uint16_t)vbv[2 * e] | ((uint32_t)(uint16_t)vbv[2 * e + 1] << 16); z4[e] = (uint32_t)(uint16_t)smv[2 * e] | ((uint32_t)(uint16_t)smv[2 * e + 1] << 16); }
-		  *reinterpret_cast<uint4 *>(&s_vb[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-		  *reinterpret_cast<uint4 *>(&s_sum[c0]) = make_uint4(z4[0], z4[1], z4[2], z4[3]); }
+		{ uint32_t w4[4];
+		  for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)vbv[2 * e] | ((uint32_t)(uint16_t)vbv[2 * e + 1] << 16);
+		  *reinterpret_cast<uint4 *>(&s_vb[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
 		__syncthreads();
-		unsigned cand = 0;
-		if (!(dbg & 1)) {
-			/* entry state of my 8 pixels */
-			/* one step maps all 16 states onto the five (|v| + 0..4) & 15, so five candidates are all there is to follow: 5-bit fields of
-			 * one dword (a field's c + 2 and |v| + 4 stay below 32), every step a handful of whole-dword operations.  The 16 cells before
-			 * mine come in as two 16-byte reads; the lanes the row's own entry state reaches (cells 1 .. c0 - 1 are fewer than 16) start
-			 * from it in all five fields and skip the cells that do not exist */
-			int carry;
-			bool merged;
-			{
-				const uint32_t R = 0x108421u;                           /* 1 in each field */
-				int lb[16];
-				{ const uint4 a4 = *reinterpret_cast<const uint4 *>(&s_vb[c0 >= 16 ? c0 - 16 : 0]), b4 = *reinterpret_cast<const uint4 *>(&s_vb[c0 >= 8 ? c0 - 8 : 0]);
-				  const uint32_t w8[8] = { a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w };
-				  for (int e = 0; e < 8; e++) { lb[2 * e] = (int16_t)(w8[e] & 0xFFFF); lb[2 * e + 1] = (int16_t)(w8[e] >> 16); } }
-				const bool far = c0 > PF_LOOK;
-				uint32_t x = far ? (lb[0] == 0 ? 0u : ((((uint32_t)iabs_(lb[0]) & 15u) * R + 0x418820u) & (15u * R))) : (uint32_t)row_carry * R;
-				for (int i = 1; i < 16; i++) {
-					const int vb = lb[i];
-					const uint32_t nx = vb == 0 ? 0u : ((((uint32_t)iabs_(vb) & 15u) * R + (((x + 2u * R) >> 2) & (7u * R))) & (15u * R));
-					x = (far || c0 - 16 + i >= 1) ? nx : x;
-				}
-				merged = x == (x & 31u) * R;
-				carry = (int)(x & 15u);
+		/* entry state of my 8 pixels: one step maps all 16 states onto the five (|v| + 0..4) & 15, so five candidates are all there is to
+		 * follow: 5-bit fields of one dword (a field's c + 2 and |v| + 4 stay below 32), every step a handful of whole-dword operations.  The 16
+		 * cells before mine come in as two 16-byte reads; the lanes the row's own entry state reaches (cells 1 .. c0 - 1 are fewer than 16)
+		 * start from it in all five fields and skip the cells that do not exist */
+		int carry;
+		bool merged;
+		{
+			const uint32_t R = 0x108421u;                               /* 1 in each field */
+			int lb[16];
+			{ const uint4 a4 = *reinterpret_cast<const uint4 *>(&s_vb[c0 >= 16 ? c0 - 16 : 0]), b4 = *reinterpret_cast<const uint4 *>(&s_vb[c0 >= 8 ? c0 - 8 : 0]);
+			  const uint32_t w8[8] = { a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w };
+			  for (int e = 0; e < 8; e++) { lb[2 * e] = (int16_t)(w8[e] & 0xFFFF); lb[2 * e + 1] = (int16_t)(w8[e] >> 16); } }
+			const bool far = c0 > PF_LOOK;
+			uint32_t x = far ? (lb[0] == 0 ? 0u : ((((uint32_t)iabs_(lb[0]) & 15u) * R + 0x418820u) & (15u * R))) : (uint32_t)carry_in * R;
+			for (int i = 1; i < 16; i++) {
+				const int vb = lb[i];
+				const uint32_t nx = vb == 0 ? 0u : ((((uint32_t)iabs_(vb) & 15u) * R + (((x + 2u * R) >> 2) & (7u * R))) & (15u * R));
+				x = (far || c0 - 16 + i >= 1) ? nx : x;
 			}
-			int valv[8];
-			for (int e = 0; e < 8; e++) {
-				const int vb = vbv[e];
-				valv[e] = 0;
-				if (c0 + e < 1 || c0 + e > W - 2) continue;
-				if (vb == 0) carry = 0;
-				else {
-					const int acc = iabs_(vb) + ((carry + 2) >> 2);
-					valv[e] = vb < 0 ? -(acc >> 4) : (acc >> 4);
-					carry = acc & 15;
-				}
+			merged = x == (x & 31u) * R;
+			if (!known && !far) merged = false;                         /* (these lanes started from a state nobody knows) */
+			carry = (int)(x & 15u);
+		}
+		int valv[8];
+		for (int e = 0; e < 8; e++) {
+			const int vb = vbv[e];
+			valv[e] = 0;
+			if (c0 + e < 1 || c0 + e > W - 2) continue;
+			if (vb == 0) carry = 0;
+			else {
+				const int acc = iabs_(vb) + ((carry + 2) >> 2);
+				valv[e] = vb < 0 ? -(acc >> 4) : (acc >> 4);
+				carry = acc & 15;
 			}
-			if (__any(!merged)) {
-				/* rare: some lane's 16 states had not merged within the look-back -- the row is replayed by one lane */
-				if (lane == 0) {
-					int cr = row_carry;
-					for (int c = 1; c < W - 1; c++) {
-						const int vb = s_vb[c];
-						int val = 0;
-						if (vb == 0) cr = 0; else { const int acc = iabs_(vb) + ((cr + 2) >> 2); val = vb < 0 ? -(acc >> 4) : (acc >> 4); cr = acc & 15; }
-						km[c] = (int16_t)val;
-					}
-					s_misc[0] = cr;
+		}
+		if (!known) {                                                   /* a row worked through for its exit state only: the last lane's, if its candidates merged */
+			carry_out = __builtin_amdgcn_readlane(carry, 63);
+			return __builtin_amdgcn_readlane((int)merged, 63) != 0;
+		}
+		if (__any(!merged)) {
+			/* rare: some lane's 16 states had not merged within the look-back -- the row is replayed by one lane */
+			if (lane == 0) {
+				int cr = carry_in;
+				for (int c = 1; c < W - 1; c++) {
+					const int vb = s_vb[c];
+					int val = 0;
+					if (vb == 0) cr = 0; else { const int acc = iabs_(vb) + ((cr + 2) >> 2); val = vb < 0 ? -(acc >> 4) : (acc >> 4); cr = acc & 15; }
+					km[c] = (int16_t)val;
 				}
-				__syncthreads();
-				for (int e = 0; e < 8; e++) valv[e] = (c0 + e >= 1 && c0 + e <= W - 2) ? (int)km[c0 + e] : 0;
-				row_carry = LDK(&s_misc[0]);
-			} else {
-				row_carry = __builtin_amdgcn_readlane(carry, 63);
+				s_misc[0] = cr;
 			}
+			__syncthreads();
+			for (int e = 0; e < 8; e++) valv[e] = (c0 + e >= 1 && c0 + e <= W - 2) ? (int)km[c0 + e] : 0;
+			carry_out = LDK(&s_misc[0]);
+		} else carry_out = __builtin_amdgcn_readlane(carry, 63);
+		if (emit) {
 			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)valv[2 * e] | ((uint32_t)(uint16_t)valv[2 * e + 1] << 16);
-			  *reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
-			for (int e = 0; e < 8; e++) if (smv[e] != 0 && map_candidate(pp, smv[e], valv[e], ms.bump_count < 3, ms.exact_count == 0)) cand |= 1u << e;
-		} else {
-			*reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(0, 0, 0, 0);
+			  *reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
+			/* the cells the marker rule may want to see (map_candidate, for every state of its two counters), by kind, and what map_cell asks of their sums */
+			unsigned mb = 0, mu = 0, me = 0, mn = 0, msm = 0;
+			const int s2 = pp.s2;
+			for (int e = 0; e < 8; e++) {
+				const int sm = smv[e], val = valv[e];
+				if (sm == 0) continue;
+				if (sm < 0) { mn |= 1u << e; if (-sm <= s2) msm |= 1u << e; if (val == -s2) mu |= 1u << e; if (-sm <= s2 && -val > s2 && -val <= s2 + 20) mb |= 1u << e; }
+				else { if (sm <= s2) msm |= 1u << e; if (sm <= s2 && val > s2 && val <= s2 + 20) mb |= 1u << e; else if (val == s2 + 21) me |= 1u << e; }
+			}
+			uint8_t *mr = mask + (size_t)r * MASK_ROW + lane;
+			mr[0] = (uint8_t)mb; mr[64] = (uint8_t)mu; mr[128] = (uint8_t)me; mr[192] = (uint8_t)mn; mr[256] = (uint8_t)msm;
 		}
-		s_cand[lane] = (uint8_t)cand;
+		return true;
+	};
+	/* the state the band's first row starts from */
+	int carry = 0;
+	if (r0 > 1) {
+		int rr = r0 - 1;
+		bool known = false;
+		for (;;) {                                                      /* back, row by row, to a row whose exit state the look-back gives (nearly always the first) */
+			if (rr == 0) { known = true; carry = 0; break; }                /* (the picture's first row starts from 0) */
+			ring_init(rr);
+			known = do_row(rr, false, 0, false, carry);
+			if ((dbg & 32) && rr > r0 - 4 && rr > 1) known = false;        /* tests: the band goes three rows back */
+			if (known) break;
+			rr--;
+		}
+		for (int f = rr + 1; f < r0; f++) { ring_init(f); do_row(f, true, carry, false, carry); }   /* and forward again with the exact state */
+	}
+	ring_init(r0);
+	for (int r = r0; r <= r1; r++) { do_row(r, true, carry, true, carry); __syncthreads(); }
+}
+
+/* Pass A's order-dependent cells (:620-756, map_cell): the marker rule fires only on borderline pixels, on the first three values that hit the
+ * threshold from below and on the first value of threshold + 21, and its counters run on through the picture -- a few dozen cells a picture,
+ * walked in raster order by one wavefront on the masks k_low_pre left (a row without a candidate costs a look at 64 bytes).  Also clears the
+ * list of rows k_low_apply is about to fill (flag plane, row 0). */
+__global__ __launch_bounds__(64) void k_low_mapfix(int16_t *__restrict__ kmb, size_t km_stride, const uint8_t *__restrict__ maskb, size_t mask_stride,
+                                                   uint8_t *__restrict__ sob, size_t so_stride, int q, int dbg)
+{
+	__shared__ __attribute__((aligned(16))) int16_t s_km[W + 8];
+	const int lane = threadIdx.x, img = blockIdx.x;
+	const PfP pp = pf_params(q);
+	int16_t *kmo = kmb + (size_t)img * km_stride;
+	const uint32_t *mask = reinterpret_cast<const uint32_t *>(maskb + (size_t)img * mask_stride);
+	if (lane < 16) reinterpret_cast<uint32_t *>(sob + (size_t)img * so_stride)[lane] = 0;
+	if (dbg & 1) return;
+	MapState ms = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	for (int k = lane; k < W + 8; k += 64) s_km[k] = 0;
+	/* lane l < 16 holds dword l of each mask of the row (pixels 32 l .. 32 l + 31) */
+	auto load_masks = [&](int r, uint32_t &b, uint32_t &u, uint32_t &e, uint32_t &n, uint32_t &sm) {
+		const uint32_t *m = mask + (size_t)r * (MASK_ROW / 4) + (lane & 15);
+		b = m[0]; u = m[16]; e = m[32]; n = m[48]; sm = m[64];
+	};
+	uint32_t nb, nu, ne, nn, nsm;
+	load_masks(1, nb, nu, ne, nn, nsm);
+	for (int r = 1; r < W - 1; r++) {
+		const uint32_t b = nb, u = nu, e = ne, n = nn, sm = nsm;
+		if (r + 1 < W - 1) load_masks(r + 1, nb, nu, ne, nn, nsm);
+		const uint32_t cand = b | (ms.bump_count < 3 ? u : 0u) | (ms.exact_count == 0 ? e : 0u);
+		const unsigned long long any = __ballot(cand != 0 && lane < 16);
+		if (!any) continue;
 		__syncthreads();
-		/* the few order-dependent pixels of pass A, in raster order, on the scalar unit */
-		if (!(dbg & 1)) {
-			for (int l8 = 0; l8 < 8; l8++) {
-				const uint32_t lo = (uint32_t)LDK(reinterpret_cast<const int *>(s_cand) + 2 * l8), hi = (uint32_t)LDK(reinterpret_cast<const int *>(s_cand) + 2 * l8 + 1);
-				uint64_t m8 = (uint64_t)lo | ((uint64_t)hi << 32);
-				while (m8) {
-					const int bit = __builtin_ctzll(m8);
-					m8 &= m8 - 1;
-					const int c = 64 * l8 + bit;                        /* byte l of the word = group 8 l8 + l, bit e of it = pixel 8 (8 l8 + l) + e */
-					map_cell(ms, pp, c, LDK(&s_sum[c]), LDK(&km[c]), km);
-				}
+		*reinterpret_cast<uint4 *>(&s_km[8 * lane]) = *reinterpret_cast<const uint4 *>(kmo + (size_t)r * W + 8 * lane);
+		__syncthreads();
+		unsigned long long words = any;
+		while (words) {
+			const int w = __builtin_ctzll(words);
+			words &= words - 1;
+			uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)cand, w);
+			const uint32_t nw = (uint32_t)__builtin_amdgcn_readlane((int)n, w), sw = (uint32_t)__builtin_amdgcn_readlane((int)sm, w);
+			while (cw) {
+				const int bit = __builtin_ctz(cw);
+				cw &= cw - 1;
+				const int c = 32 * w + bit;
+				const int neg = (nw >> bit) & 1, small = (sw >> bit) & 1;
+				const int smx = neg ? (small ? -1 : -(pp.s2 + 1)) : (small ? 1 : pp.s2 + 1);   /* map_cell asks for the sum's sign and whether it is above the threshold */
+				map_cell(ms, pp, c, smx, LDK(&s_km[c]), s_km);
 			}
 		}
 		__syncthreads();
-		*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&km[c0]);
-		__syncthreads();
+		*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + 8 * lane) = *reinterpret_cast<const uint4 *>(&s_km[8 * lane]);
 	}
 }
 
@@ -743,29 +812,26 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	}
 }
 
-/* act: the chain's answers (a byte a pair, stream order); y / km in: as k_low_pre left them; out: as passes A..C leave them (the rows pass C
- * walks here are listed in the flag plane's row 0 for k_low_marks). */
+/* Pass B's picture side, a wavefront a band of 32 rows: the picture copy with the q <= 14 smoothing (:566, :780-807), the machine's answers
+ * applied to the picture, the map and the flags (pair_apply: :840-917 / :996-1001 / :1912-1924), the tail rules (:1927-1990), and the list
+ * of rows that hold a marker (pass C walks those in row order: k_low_markrows).  What ties the rows together here is one bit, the tail
+ * rules' flag: it is a function of the pair before alone, so a band takes it from the last pair of the row above (one pair_apply).
+ * act: the chain's answers (a byte a pair, stream order); km in: as passes A left it; out: y, km, flags as pass B leaves them. */
 __global__ __launch_bounds__(64) void k_low_apply(const int16_t *__restrict__ srcb, size_t src_stride, int16_t *__restrict__ yb, size_t y_stride, int16_t *__restrict__ kmb, size_t km_stride,
                                                   uint8_t *__restrict__ sob, size_t so_stride, const uint8_t *__restrict__ actb, size_t act_stride, int q, int dbg)
 {
 	__shared__ __attribute__((aligned(16))) int16_t s_src[3][W];
-	__shared__ __attribute__((aligned(16))) int16_t s_km[2][W + 8];
-	__shared__ __attribute__((aligned(16))) int16_t s_y[2][W];
-	__shared__ __attribute__((aligned(16))) uint8_t s_so[2][W];
-	__shared__ __attribute__((aligned(8))) uint8_t s_cmask[4][64];          /* a marker row's cells by class (c_classify), a bit a cell */
-	__shared__ uint32_t s_rowmask[16];                                     /* rows whose pass C ran here */
-	const int lane = threadIdx.x, img = blockIdx.x;
+	__shared__ __attribute__((aligned(16))) int16_t s_km[W + 8];
+	const int lane = threadIdx.x, band = blockIdx.x, img = blockIdx.y;
 	const PfP pp = pf_params(q);
-	if (lane < 16) s_rowmask[lane] = 0;
-	int prev_big = 0;                                                  /* wave-uniform: the tail rules' flag, the state of pass C */
-	MarkState ks = { 0, 0, 0, 0, 0, 0 };
 	const int c0 = lane * 8;
 	int16_t *yo = yb + (size_t)img * y_stride;
-	int16_t *kmo = kmb + (size_t)img * km_stride;                      /* contrast map and flags as passes A..C leave them */
+	int16_t *kmo = kmb + (size_t)img * km_stride;
 	uint8_t *soo = sob + (size_t)img * so_stride;
 	const uint8_t *act = actb + (size_t)img * act_stride;
 	const int16_t *src = srcb + (size_t)img * src_stride;
-	for (int k = lane; k < 2 * (W + 8); k += 64) (&s_km[0][0])[k] = 0;
+	const int r0 = 1 + PRE_RB * band, r1 = r0 + PRE_RB - 1 < W - 2 ? r0 + PRE_RB - 1 : W - 2;
+	for (int k = lane; k < W + 8; k += 64) s_km[k] = 0;
 	/* cells c0 - 1 .. c0 + 8 of a row in LDS (0 outside the row) */
 	auto load10 = [&](const int16_t *row, int *out) {
 		const uint4 q4 = *reinterpret_cast<const uint4 *>(row + c0);
@@ -775,34 +841,47 @@ __global__ __launch_bounds__(64) void k_low_apply(const int16_t *__restrict__ sr
 		out[0] = lane ? lo : 0; out[9] = lane < 63 ? hi : 0;
 	};
 	auto load_act = [&](int r) -> uint32_t { const uint8_t *p = act + (size_t)(r - 1) * 255 + 4 * lane; return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | (lane < 63 ? (uint32_t)p[3] << 24 : 0u); };
-	uint4 nk = *reinterpret_cast<const uint4 *>(kmo + (size_t)W + c0), ns = *reinterpret_cast<const uint4 *>(src + (size_t)2 * W + c0);   /* row 1 of the map, row 2 of the source on their way */
-	uint32_t na = load_act(1);
-	{ const uint4 r0 = *reinterpret_cast<const uint4 *>(src + c0), r1 = *reinterpret_cast<const uint4 *>(src + (size_t)W + c0);
-	  *reinterpret_cast<uint4 *>(&s_src[0][c0]) = r0; *reinterpret_cast<uint4 *>(&s_src[1][c0]) = r1;
-	  *reinterpret_cast<uint4 *>(yo + c0) = r0; }                                                /* row 0 is not touched by any pass */
-	__syncthreads();
-
-	for (int r = 1; r < W - 1; r++) {
-		int16_t *km = s_km[r & 1];
-		int16_t *y = s_y[r & 1];
-		uint8_t *so = s_so[r & 1];
-		*reinterpret_cast<uint4 *>(&km[c0]) = nk;
+	if (band == 0) *reinterpret_cast<uint4 *>(yo + c0) = *reinterpret_cast<const uint4 *>(src + c0);                                    /* rows 0 and 511 are not touched by any pass */
+	if (band == PRE_NB - 1) *reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(src + (size_t)(W - 1) * W + c0);
+	/* the map cells c0 .. c0 + 8 of a row as pass A left them, out of LDS */
+	auto cells9 = [&](int *kc) {
+		const uint4 kw = *reinterpret_cast<const uint4 *>(&s_km[c0]);
+		const uint32_t w4[4] = { kw.x, kw.y, kw.z, kw.w };
+		for (int e = 0; e < 4; e++) { kc[2 * e] = (int16_t)(w4[e] & 0xFFFF); kc[2 * e + 1] = (int16_t)(w4[e] >> 16); }
+		kc[8] = s_km[c0 + 8];
+	};
+	int prev_big = 0;                                                  /* wave-uniform: the tail rules' flag behind the last pair of the row above */
+	if (r0 > 1 && pp.tail_rules && !(dbg & 2)) {
+		*reinterpret_cast<uint4 *>(&s_km[c0]) = *reinterpret_cast<const uint4 *>(kmo + (size_t)(r0 - 1) * W + c0);
+		const uint32_t aw = load_act(r0 - 1);
+		__syncthreads();
+		int kc[9], e0 = 0, e1 = 0, d0 = 0, d1 = 0, f0 = 0, f1 = 0;
+		cells9(kc);
+		pair_apply(pp, (int)((aw >> 16) & 7), kc[5], kc[6], e0, e1, d0, d1, f0, f1);      /* lane 63's third pair is pair 254 */
+		prev_big = __builtin_amdgcn_readlane(tail_flag(e0, e1), 63);
+		__syncthreads();
+	}
+	uint4 nk = *reinterpret_cast<const uint4 *>(kmo + (size_t)r0 * W + c0), ns = *reinterpret_cast<const uint4 *>(src + (size_t)(r0 + 1) * W + c0);
+	uint32_t na = load_act(r0);
+	*reinterpret_cast<uint4 *>(&s_src[(r0 - 1) % 3][c0]) = *reinterpret_cast<const uint4 *>(src + (size_t)(r0 - 1) * W + c0);
+	*reinterpret_cast<uint4 *>(&s_src[r0 % 3][c0]) = *reinterpret_cast<const uint4 *>(src + (size_t)r0 * W + c0);
+	uint32_t marks = 0;                                                /* lane 0: the band's rows that hold a marker, bit r - r0 */
+	for (int r = r0; r <= r1; r++) {
+		*reinterpret_cast<uint4 *>(&s_km[c0]) = nk;
 		*reinterpret_cast<uint4 *>(&s_src[(r + 1) % 3][c0]) = ns;
 		const uint32_t aw = na;
-		if (r + 1 < W - 1) {
+		if (r < r1) {
 			nk = *reinterpret_cast<const uint4 *>(kmo + (size_t)(r + 1) * W + c0); ns = *reinterpret_cast<const uint4 *>(src + (size_t)(r + 2) * W + c0);
 			na = load_act(r + 1);
 		}
 		__syncthreads();
+		int kc[9];
+		cells9(kc);
+		uint32_t yw[4];
 		{
 			/* the row's picture copy (:566) with the q <= 14 smoothing (:780-807: reads the source copy and the map as pass A left it) */
 			const int16_t *up = s_src[(r - 1) % 3], *mid = s_src[r % 3], *dn = s_src[(r + 1) % 3];
-			uint32_t yw[4];
 			if (pp.smooth) {
-				int k9[8];
-				{ const uint4 kq = *reinterpret_cast<const uint4 *>(&km[c0]);
-				  const uint32_t w4[4] = { kq.x, kq.y, kq.z, kq.w };
-				  for (int e = 0; e < 4; e++) { k9[2 * e] = (int16_t)(w4[e] & 0xFFFF); k9[2 * e + 1] = (int16_t)(w4[e] >> 16); } }
 				int u10[10], m10[10], d10[10];
 				load10(up, u10); load10(mid, m10); load10(dn, d10);
 				for (int e2 = 0; e2 < 4; e2++) {
@@ -812,7 +891,7 @@ __global__ __launch_bounds__(64) void k_low_apply(const int16_t *__restrict__ sr
 						const int ctr = m10[e + 1], lf = m10[e], rt = m10[e + 2], ab = u10[e + 1], bl = d10[e + 1];
 						int v = ctr;
 						if (c >= 1 && c <= W - 2) {
-							const int kk = k9[e];
+							const int kk = kc[e];
 							if (iabs_(kk) > 4 && iabs_(kk) < pp.smooth_hi && iabs_(ab - lf) < 4 && iabs_(lf - bl) < 4 && iabs_(bl - rt) < 4 && iabs_(rt - ab) < 4)
 								v = ((ctr << 2) + lf + rt + ab + bl + 4) >> 3;
 						}
@@ -824,16 +903,10 @@ __global__ __launch_bounds__(64) void k_low_apply(const int16_t *__restrict__ sr
 				const uint4 mq = *reinterpret_cast<const uint4 *>(&mid[c0]);
 				yw[0] = mq.x; yw[1] = mq.y; yw[2] = mq.z; yw[3] = mq.w;
 			}
-			*reinterpret_cast<uint4 *>(&y[c0]) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
 		}
-		/* all lanes: the answers applied to the row (pass B's picture side), the tail rules, and the test for markers */
-		bool any_mark;
+		/* the answers applied to the row (pass B's picture side), the tail rules, and the test for markers */
 		{
-			int kc[9], dd[9], sv[9], e0[4], e1[4];
-			{ const uint4 kw = *reinterpret_cast<const uint4 *>(&km[c0]);
-			  const uint32_t w4[4] = { kw.x, kw.y, kw.z, kw.w };
-			  for (int e = 0; e < 4; e++) { kc[2 * e] = (int16_t)(w4[e] & 0xFFFF); kc[2 * e + 1] = (int16_t)(w4[e] >> 16); }
-			  kc[8] = km[c0 + 8]; }
+			int dd[9], sv[9], e0[4], e1[4];
 			for (int e = 0; e < 9; e++) { dd[e] = 0; sv[e] = 0; }
 			const int npair = lane == 63 ? 3 : 4;                      /* pair 255 does not exist */
 			for (int j = 0; j < 4; j++) {
@@ -856,33 +929,81 @@ __global__ __launch_bounds__(64) void k_low_apply(const int16_t *__restrict__ sr
 			  if (lane) { kc[0] = pk; dd[0] = pd; sv[0] = ps; } }
 			bool mark = false;
 			for (int e = 0; e < 8; e++) mark |= iabs_(kc[e]) > 6000;
-			__syncthreads();                                           /* every lane has read its neighbour's cell 8 l + 8 as pass A left it */
 			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)kc[2 * e] | ((uint32_t)(uint16_t)kc[2 * e + 1] << 16);
-			  *reinterpret_cast<uint4 *>(&km[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
-			{ const uint4 yw = *reinterpret_cast<const uint4 *>(&y[c0]);
-			  uint32_t w4[4] = { yw.x, yw.y, yw.z, yw.w };
-			  for (int e = 0; e < 4; e++) {
-				const int lo = (int16_t)(w4[e] & 0xFFFF) + dd[2 * e], hi = (int16_t)(w4[e] >> 16) + dd[2 * e + 1];
-				w4[e] = (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16);
+			  *reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
+			{ for (int e = 0; e < 4; e++) {
+				const int lo = (int16_t)(yw[e] & 0xFFFF) + dd[2 * e], hi = (int16_t)(yw[e] >> 16) + dd[2 * e + 1];
+				yw[e] = (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16);
 			  }
-			  *reinterpret_cast<uint4 *>(&y[c0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
+			  *reinterpret_cast<uint4 *>(yo + (size_t)r * W + c0) = make_uint4(yw[0], yw[1], yw[2], yw[3]); }
 			{ uint32_t lo = 0, hi = 0;
 			  for (int e = 0; e < 4; e++) { lo |= (uint32_t)sv[e] << (8 * e); hi |= (uint32_t)sv[4 + e] << (8 * e); }
-			  *reinterpret_cast<uint2 *>(&so[c0]) = make_uint2(lo, hi); }
-			any_mark = __any(mark);
-			if (any_mark) {                                           /* the classes pass C asks for, a bit a cell, in cell order */
+			  *reinterpret_cast<uint2 *>(soo + (size_t)r * W + c0) = make_uint2(lo, hi); }
+			if (__any(mark) && !(dbg & 4)) marks |= 1u << (r - r0);
+		}
+		__syncthreads();
+	}
+	if (lane == 0 && marks) {                                         /* flag plane, row 0 (k_low_mapfix cleared it): bit r of its first 512 = row r holds a marker */
+		uint32_t *rm = reinterpret_cast<uint32_t *>(soo);
+		atomicOr(&rm[r0 >> 5], marks << (r0 & 31));
+		if ((r0 & 31) && (marks >> (32 - (r0 & 31)))) atomicOr(&rm[(r0 >> 5) + 1], marks >> (32 - (r0 & 31)));
+	}
+}
+
+/* Pass C (:1994-2310) of the rows that hold a marker, in row order (its counters only move at markers and run on from marker to marker;
+ * every other row is k_low_marks', a lane a row): one wavefront a picture takes the listed rows one after the other -- the row and the row
+ * above in LDS, the row's cells by class as bit masks, lane 0 walks (c_walk_window), both rows go back. */
+__global__ __launch_bounds__(64) void k_low_markrows(int16_t *__restrict__ yb, size_t y_stride, int16_t *__restrict__ kmb, size_t km_stride, uint8_t *__restrict__ sob, size_t so_stride, int q)
+{
+	__shared__ __attribute__((aligned(16))) int16_t s_km[2][W + 8];
+	__shared__ __attribute__((aligned(16))) int16_t s_y[2][W];
+	__shared__ __attribute__((aligned(16))) uint8_t s_so[2][W];
+	__shared__ __attribute__((aligned(8))) uint8_t s_cmask[4][64];          /* the row's cells by class (c_classify), a bit a cell */
+	const int lane = threadIdx.x, img = blockIdx.x;
+	const PfP pp = pf_params(q);
+	const int c0 = lane * 8;
+	int16_t *yo = yb + (size_t)img * y_stride;
+	int16_t *kmo = kmb + (size_t)img * km_stride;
+	uint8_t *soo = sob + (size_t)img * so_stride;
+	uint32_t mw = lane < 16 ? reinterpret_cast<const uint32_t *>(soo)[lane] : 0u;
+	unsigned long long words = __ballot(mw != 0);
+	if (!words) return;
+	for (int k = lane; k < 2 * (W + 8); k += 64) (&s_km[0][0])[k] = 0;
+	MarkState ks = { 0, 0, 0, 0, 0, 0 };
+	auto load = [&](int r) {
+		*reinterpret_cast<uint4 *>(&s_km[r & 1][c0]) = *reinterpret_cast<const uint4 *>(kmo + (size_t)r * W + c0);
+		*reinterpret_cast<uint4 *>(&s_y[r & 1][c0]) = *reinterpret_cast<const uint4 *>(yo + (size_t)r * W + c0);
+		*reinterpret_cast<uint2 *>(&s_so[r & 1][c0]) = *reinterpret_cast<const uint2 *>(soo + (size_t)r * W + c0);
+	};
+	auto store = [&](int r) {
+		*reinterpret_cast<uint4 *>(yo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[r & 1][c0]);
+		*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[r & 1][c0]);
+		*reinterpret_cast<uint2 *>(soo + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[r & 1][c0]);
+	};
+	int prev = -1;                                                     /* the row in the other slot */
+	while (words) {
+		const int w = __builtin_ctzll(words);
+		words &= words - 1;
+		uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)mw, w);
+		while (bits) {
+			const int r = 32 * w + __builtin_ctz(bits);
+			bits &= bits - 1;
+			__syncthreads();
+			if (r >= 2 && prev != r - 1) load(r - 1);
+			load(r);
+			__syncthreads();
+			{
 				uint32_t cs = 0, cwk = 0, cl = 0, cm = 0;
+				const uint4 kw = *reinterpret_cast<const uint4 *>(&s_km[r & 1][c0]);
+				const uint32_t w4[4] = { kw.x, kw.y, kw.z, kw.w };
 				for (int e = 0; e < 8; e++) {
 					bool a, b2, c2, d2;
-					c_classify(pp, kc[e], a, b2, c2, d2);
+					c_classify(pp, (int16_t)((e & 1) ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xFFFF), a, b2, c2, d2);
 					cs |= (uint32_t)a << e; cwk |= (uint32_t)b2 << e; cl |= (uint32_t)c2 << e; cm |= (uint32_t)d2 << e;
 				}
 				s_cmask[0][lane] = (uint8_t)cs; s_cmask[1][lane] = (uint8_t)cwk; s_cmask[2][lane] = (uint8_t)cl; s_cmask[3][lane] = (uint8_t)cm;
 			}
-		}
-		__syncthreads();
-		/* pass C of this row where it holds a marker, in row order: lane 0 walks it on windows of the row's class masks */
-		if (any_mark && !(dbg & 4)) {
+			__syncthreads();
 			if (lane == 0) {
 				MachFx fx = { s_km[r & 1], s_km[(r - 1) & 1], s_y[r & 1], s_y[(r - 1) & 1], s_so[r & 1], s_so[(r - 1) & 1], &s_cmask[0][0], pp };
 				CWalk cw = { 2, 0, 0, 0 };
@@ -892,24 +1013,12 @@ __global__ __launch_bounds__(64) void k_low_apply(const int16_t *__restrict__ sr
 					cm.strong = window64(s_cmask[0], wb); cm.weak = window64(s_cmask[1], wb); cm.small = window64(s_cmask[2], wb); cm.marker = window64(s_cmask[3], wb);
 					c_walk_window<true>(cw, ks, pp, cm, wb, wb + 57 < W - 3 ? wb + 57 : W - 3, r >= 2, fx);
 				}
-				s_rowmask[r >> 5] |= 1u << (r & 31);
 			}
 			__syncthreads();
+			if (r >= 2) store(r - 1);
+			store(r);
+			prev = r;
 		}
-		if (r > 1) {                                              /* row r-1 is through passes A..C as far as they run here */
-			*reinterpret_cast<uint4 *>(yo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[(r - 1) & 1][c0]);
-			*reinterpret_cast<uint4 *>(kmo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[(r - 1) & 1][c0]);
-			*reinterpret_cast<uint2 *>(soo + (size_t)(r - 1) * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[(r - 1) & 1][c0]);
-		}
-		__syncthreads();
-	}
-	{
-		const int r = W - 2;
-		*reinterpret_cast<uint4 *>(yo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_y[r & 1][c0]);
-		*reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = *reinterpret_cast<const uint4 *>(&s_km[r & 1][c0]);
-		*reinterpret_cast<uint2 *>(soo + (size_t)r * W + c0) = *reinterpret_cast<const uint2 *>(&s_so[r & 1][c0]);
-		if (lane < 16) reinterpret_cast<uint32_t *>(soo)[lane] = s_rowmask[lane];      /* flag plane, row 0: the rows k_low_marks must leave alone */
-		*reinterpret_cast<uint4 *>(yo + (size_t)(W - 1) * W + c0) = *reinterpret_cast<const uint4 *>(src + (size_t)(W - 1) * W + c0);   /* the last row is not touched either */
 	}
 }
 
@@ -1411,16 +1520,17 @@ void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStr
 }
 void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
                               uint8_t *chain /* 2 * CH_BYTES an image: the pair codes, the machine's answers */, size_t chain_stride,
-                              uint16_t *tab /* 8 * CH_BYTES an image: the burst table */, size_t tab_stride, int q, int n, hipStream_t s)
+                              uint16_t *tab /* MASK_ROW * W bytes an image: pass A's candidate masks */, size_t tab_stride, int q, int n, hipStream_t s, int force /* 32: the bands of pass A go back three rows for their entry state (tests) */)
 {
 	static int dbg = 0;
 #ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing */
 	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
-	k_low_pre<<<n, 64, 0, s>>>(src, src_stride, km, km_stride, q, dbg);
-	(void)tab; (void)tab_stride;
+	k_low_pre<<<dim3(PRE_NB, n), 64, 0, s>>>(src, src_stride, km, km_stride, reinterpret_cast<uint8_t *>(tab), tab_stride, q, dbg | force);
+	k_low_mapfix<<<n, 64, 0, s>>>(km, km_stride, reinterpret_cast<const uint8_t *>(tab), tab_stride, so, so_stride, q, dbg);
 	k_low_chain<<<n, 128, 0, s>>>(km, km_stride, chain, chain_stride, q, dbg);
-	k_low_apply<<<n, 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, chain, chain_stride, q, dbg);
+	k_low_apply<<<dim3(PRE_NB, n), 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, chain, chain_stride, q, dbg);
+	k_low_markrows<<<n, 64, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q);
 	k_low_marks<<<dim3((W - 2 + MK_R - 2) / (MK_R - 1), n), MK_R, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
 }
 /* Compatibility mode (NHW_COMPAT_GLIBC_ONESHOT) only, quality <= 16: the contrast-map cells whose memory the stock binary's malloc hands

@@ -498,11 +498,12 @@ def test_compat_mode_matches_oracle_and_stock_binary(oracle, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q", [17, 20, 21])
+@pytest.mark.parametrize("q", [1, 8, 10, 16, 17, 20, 21])
 def test_front_fallback_paths_are_exact(oracle, q):
     """The pre-filter's carry normally comes from a short look-back (its 16 states merge within a dozen pixels); where they have not merged, a
     segment is replayed from the one before it, in raster order across the rows of a band (k_front_image).  That path is rare on real
-    content, so a debug switch sends every segment down it: the output must not change."""
+    content, so a debug switch sends every segment down it: the output must not change.  Quality 1..16: the same switch makes every band of
+    pass A (k_low_pre) go three rows back for the state its first row starts from and come forward again with the exact state."""
     import nhwcodec_amd
     enc = nhwcodec_amd.Encoder(0, 32)
     imgs = np.stack([oracle.synth(40 + i) for i in range(20)] + [class_image(k, s) for k in ("noise", "blocks", "tiles", "gradient") for s in (1, 2)])
