@@ -34,8 +34,8 @@ enum { WV_DQ1, WV_DQ0, WV_EMIT, WV_QUANT };
 void nhw_launch_copy_block(const int16_t *src, size_t src_plane, int src_row, int16_t *dst, size_t dst_plane, int dst_row, int rows, int cols, int n, hipStream_t s);
 enum { PH_L1, PH_L2, PH_L3, PH_L4A, PH_C0, PH_C2, PH_C3, PH_C4, PH_C5, PH_FINAL, PH_L4B, PH_L4C, PH_L4D, PH_LLC, PH_L4C2 };
 /* quality 1..16 only (nhw_low.hip) */
-void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride, uint8_t *chain, size_t chain_stride,
-                              uint16_t *tab, size_t tab_stride, int q, int n, hipStream_t s, int force = 0);
+int nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride, uint8_t *chain, size_t chain_stride,
+                             uint16_t *tab, size_t tab_stride, int q, int n, hipStream_t s, int force = 0, int parts = 1, hipStream_t *aux = nullptr, hipEvent_t *ev = nullptr);
 void nhw_launch_low_prefilter_chroma(const uint8_t *src, size_t src_stride, int16_t *dst, size_t dst_stride, int q, int n, hipStream_t s);
 void nhw_launch_low_chroma_thin(int16_t *plane, size_t plane_stride, int n, hipStream_t s);
 void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStream_t s);
@@ -53,6 +53,11 @@ struct nhw_enc {
 	hipStream_t own_stream;
 	hipStream_t part_stream[4];   /* a large batch runs as up to four sub-batches on streams of their own (see nhw_enc_batch_device) */
 	hipEvent_t part_ev[5];
+	hipStream_t low_stream[4];    /* quality 1..16: the pre-filter's sub-batches (nhw_launch_low_prefilter) */
+	hipEvent_t low_ev[13];
+	int low_parts;                /* how many (NHW_LOW_PARTS; 1 = the whole batch in line) */
+	int low_parts_used;           /* ... in the batch that is being queued */
+	int low_chroma;               /* quality 1..16: where the chroma sequence starts (NHW_LOW_CHROMA: 0 behind the front group, 1 behind the colour kernel, 2 behind the last sub-batch's pass A) */
 	hipStream_t ll_stream;        /* the LL2 coder (Y16) beside the second dequantiser simulation */
 	hipEvent_t ll_ev[2];
 	int ll_fork;
@@ -85,7 +90,7 @@ static const size_t k_buf_bytes[B_COUNT] = {
 	/* NZQ (32 x 128 words of 64 bits + 33 flush bases) */ Q / 2 + 256, /* NZS */ Q / 2, /* VOFF */ Q / 4, /* VALS (every symbol non-zero: 4 Q) */ 4 * Q,
 	/* CNZQ (16 flushes x 64 lanes x 2 words of 64 bits + 17 flush bases) */ Q / 4 + 256, /* CVALS */ 2 * Q,
 	/* CJPEG_V */ 2 * Q, /* CPROC_V */ 2 * Q, /* CLL1_V */ Q / 2, /* CL2SAVE_V */ Q / 2, /* UBYTES */ Q,
-	/* LOWTAB (8 bytes a pair of the 510 x 255, in whole chunks of 256 pairs) */ 8 * ((510 * 255 + 255) / 256) * 256
+	/* LOWTAB (quality 1..16: pass A's five candidate masks, 64 bytes each, for every row) */ 320 * 512
 };
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -141,6 +146,10 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 		for (int i = 0; i < 7; i++) HIPCHK(hipEventCreate(&e->ev[i]));
 		for (int i = 0; i < 4; i++) HIPCHK(hipStreamCreateWithFlags(&e->part_stream[i], hipStreamNonBlocking));
 		for (int i = 0; i < 5; i++) HIPCHK(hipEventCreateWithFlags(&e->part_ev[i], hipEventDisableTiming));
+		for (int i = 0; i < 4; i++) HIPCHK(hipStreamCreateWithFlags(&e->low_stream[i], hipStreamNonBlocking));
+		for (int i = 0; i < 13; i++) HIPCHK(hipEventCreateWithFlags(&e->low_ev[i], hipEventDisableTiming));
+		{ const char *lp = getenv("NHW_LOW_PARTS"); e->low_parts = lp ? atoi(lp) : 2; if (e->low_parts < 1 || e->low_parts > 4) e->low_parts = 1; }
+		{ const char *lc = getenv("NHW_LOW_CHROMA"); e->low_chroma = lc ? atoi(lc) : 2; }
 		HIPCHK(hipStreamCreateWithFlags(&e->ll_stream, hipStreamNonBlocking));
 		for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&e->ll_ev[i], hipEventDisableTiming));
 		/* the host path's staging buffers, for the whole of max_batch, now: allocated on the first nhw_enc_batch they made that call twice as
@@ -178,6 +187,8 @@ extern "C" void nhw_enc_destroy(nhw_enc *e)
 	if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
 	for (int i = 0; i < 4; i++) if (e->part_stream[i]) (void)hipStreamDestroy(e->part_stream[i]);
 	for (int i = 0; i < 5; i++) if (e->part_ev[i]) (void)hipEventDestroy(e->part_ev[i]);
+	for (int i = 0; i < 4; i++) if (e->low_stream[i]) (void)hipStreamDestroy(e->low_stream[i]);
+	for (int i = 0; i < 13; i++) if (e->low_ev[i]) (void)hipEventDestroy(e->low_ev[i]);
 	if (e->ll_stream) (void)hipStreamDestroy(e->ll_stream);
 	for (int i = 0; i < 2; i++) if (e->ll_ev[i]) (void)hipEventDestroy(e->ll_ev[i]);
 	delete e;
@@ -213,7 +224,10 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 		nhw_launch_color((const uint8_t *)d_bgr, n, q, jpeg, ws.stride[B_JPEG], plane8(ws, B_PU), plane8(ws, B_PV), ws.stride[B_PU], s);
 		HIPCHK(hipEventRecord(e->ev[5], s));                      /* with the front group, whoever brackets it: nhw_timing.color_dwt_ms / prefilter_ms */
 		STAGE_DONE();
-		nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], (uint16_t *)plane8(ws, B_LOWTAB), ws.stride[B_LOWTAB], q, n, s, (e->front_fallback & 1) ? 32 : 0);   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser; pair codes and answers -> the q >= 22 plane */
+		{ const int lparts = (timed == 1 && what == 3 && !e->stop_after && n >= 1024) ? e->low_parts : 1;   /* (the stage checks and small batches: in line) */
+		  e->low_parts_used = lparts;
+		  HIPCHK((hipError_t)nhw_launch_low_prefilter(jpeg, ws.stride[B_JPEG] / 2, yin, yin_stride / 2, proc, ps, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], (uint16_t *)plane8(ws, B_LOWTAB), ws.stride[B_LOWTAB], q, n, s, (e->front_fallback & 1) ? 32 : 0,
+		                                              lparts, e->low_stream, e->low_ev)); }   /* contrast map -> proc plane, flags -> scan buffer: both free until the band kernel / the quantiser; the pair machine's answers -> the q >= 22 plane */
 		HIPCHK(hipEventRecord(e->ev[6], s));
 		STAGE_DONE();
 		if (ws.compat) nhw_launch_low_stale(proc, ps, plane16(ws, B_STALE), ws.stride[B_STALE], n, s);   /* compatibility mode only: the map cells the stock binary's heap re-uses */
@@ -281,7 +295,7 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 	};
 #define CHROMA(call) do { const int rc_ = (call); if (rc_ != 1) return rc_; } while (0)   /* 1 = carry on; NHW_OK (debug stop) or an error leaves */
 	if (fork) {
-		HIPCHK(hipStreamWaitEvent(cs, low ? e->ev[5] : e->ev[1], 0));   /* behind the front launch group: that one is bound by vector issue and has nothing to give (and its time is the roofline figure).  Quality 1..16: behind the colour kernel already -- the rationed pre-filter's chain (k_low_chain) is one wavefront a picture on the scalar unit and leaves the vector units and the memory system idle for milliseconds */
+		HIPCHK(hipStreamWaitEvent(cs, !low || e->low_chroma == 0 ? e->ev[1] : (e->low_chroma == 2 && e->low_parts_used > 1) ? e->low_ev[e->low_parts_used] : e->ev[5], 0));   /* behind the front launch group: that one is bound by vector issue and has nothing to give (and its time is the roofline figure).  Quality 1..16: behind the colour kernel already -- the rationed pre-filter's chain (k_low_chain) is one wavefront a picture on the scalar unit and leaves the vector units and the memory system idle for milliseconds */
 		CHROMA(chroma_head(0));
 		CHROMA(chroma_head(1));                                      /* V's head in planes of its own, right behind U's: U's quantiser waits for the luma tail, and this stream stood idle until then (2 ms of a q20 step).  (Measured and not taken: V's head on a stream of its own beside U's, +0.3 ms; V's head held back until the second dequantiser simulation is through, +0.4 ms.) */
 	}
@@ -567,7 +581,7 @@ extern "C" int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, vo
 	const NhwWs &ws = e->ws;
 	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
 	/* in place for the caller: filter into the workspace plane the encoder uses, copy back */
-	nhw_launch_low_prefilter((const int16_t *)d_y, 4 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP] / 2, plane16(ws, B_PROC), ws.stride[B_PROC] / 2, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], (uint16_t *)plane8(ws, B_LOWTAB), ws.stride[B_LOWTAB], quality, n, s);
+	HIPCHK((hipError_t)nhw_launch_low_prefilter((const int16_t *)d_y, 4 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP] / 2, plane16(ws, B_PROC), ws.stride[B_PROC] / 2, plane8(ws, B_SCAN), ws.stride[B_SCAN], plane8(ws, B_KEEP), ws.stride[B_KEEP], (uint16_t *)plane8(ws, B_LOWTAB), ws.stride[B_LOWTAB], quality, n, s));
 	HIPCHK(hipMemcpy2DAsync(d_y, 8 * Q, plane16(ws, B_KMAP), ws.stride[B_KMAP], 8 * Q, (size_t)n, hipMemcpyDeviceToDevice, s));
 	HIPCHK(hipGetLastError());
 	return NHW_OK;

@@ -686,10 +686,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 		auto build = [&](int k) {
 			const int base = 256 * k;
 			const uint8_t *codes = &s_code[base & 1023];
-			for (int i = lane; i < 704 / 4; i += 64) reinterpret_cast<uint2 *>(s_inv)[i] = make_uint2(999u | (999u << 16), 999u | (999u << 16));
-			wave_sync();
 			const uint32_t hbase = k ? (uint32_t)s_h[(base - 1) & 1023] : 0u;   /* hits of all pairs before the window */
 			auto rel = [&](int wdx) { return (int)(uint16_t)((uint32_t)s_h[(base + wdx) & 1023] - hbase); };   /* hits of the window's pairs 0 .. wdx */
+			if (base + 320 < CH_N && __builtin_amdgcn_readfirstlane(rel(319)) == 0) {
+				/* not a hit in the window (flat stretches; most of a picture where the threshold is high): every burst that starts here runs its
+				 * 20 - v pairs to the wrap -- t1 goes 1, 4, .. 16 with every fourth idle pair -- and every code is 0 */
+				const uint32_t lo = 19u | (18u << 16), hi = 17u | (16u << 16);
+				for (int kk = 0; kk < 4; kk++) reinterpret_cast<uint2 *>(&s_tab[1024 * (k & 1)])[lane + 64 * kk] = make_uint2(lo, hi);
+				return;
+			}
+			for (int i = lane; i < 704 / 4; i += 64) reinterpret_cast<uint2 *>(s_inv)[i] = make_uint2(999u | (999u << 16), 999u | (999u << 16));
+			wave_sync();
 			auto put = [&](int w0) {
 				int before = w0 ? rel(w0 - 1) : 0;
 				for (int e = 0; e < 4; e++) {
@@ -1518,20 +1525,48 @@ void nhw_launch_low_ll2(int16_t *proc, size_t plane_stride, int q, int n, hipStr
 	const int maps = (q <= 7) ? 4 : 3;                               /* k_ll2_thr[q][4] == 36 up to quality 7 */
 	k_low_ll2<<<n, LL2_NT, (size_t)(128 * 132 + 8) * 2 + (size_t)maps * (128 * 128 / 32) * 4, s>>>(proc, plane_stride, q);   /* 128 rows at the kernel's pitch LP + the hit maps */
 }
-void nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
-                              uint8_t *chain /* 2 * CH_BYTES an image: the pair codes, the machine's answers */, size_t chain_stride,
-                              uint16_t *tab /* MASK_ROW * W bytes an image: pass A's candidate masks */, size_t tab_stride, int q, int n, hipStream_t s, int force /* 32: the bands of pass A go back three rows for their entry state (tests) */)
+/* The pre-filter of a batch.  parts > 1: the batch is cut into sub-batches whose sequences run on streams of their own (aux), the next one's
+ * pass A starting when the one before has finished its own -- the chain (k_low_chain) is two wavefronts a picture that live on the scalar
+ * unit and on look-ups, and leaves the vector units and the memory system to the streaming kernels of the sub-batches before and behind it
+ * (pass A, the answers' application, passes C and D).  ev: 1 + 2 * parts events.  Returns a hipError_t. */
+int nhw_launch_low_prefilter(const int16_t *src, size_t src_stride, int16_t *y, size_t y_stride, int16_t *km, size_t km_stride, uint8_t *so, size_t so_stride,
+                             uint8_t *chain /* CH_BYTES an image: the machine's answers */, size_t chain_stride,
+                             uint16_t *tab /* MASK_ROW * W bytes an image: pass A's candidate masks */, size_t tab_stride, int q, int n, hipStream_t s, int force /* 32: the bands of pass A go back three rows for their entry state (tests) */,
+                             int parts, hipStream_t *aux, hipEvent_t *ev)
 {
 	static int dbg = 0;
 #ifdef NHW_DEV   /* developer builds: bits that switch passes of the pre-filter off for timing */
 	{ const char *e = getenv("NHW_LOW_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
-	k_low_pre<<<dim3(PRE_NB, n), 64, 0, s>>>(src, src_stride, km, km_stride, reinterpret_cast<uint8_t *>(tab), tab_stride, q, dbg | force);
-	k_low_mapfix<<<n, 64, 0, s>>>(km, km_stride, reinterpret_cast<const uint8_t *>(tab), tab_stride, so, so_stride, q, dbg);
-	k_low_chain<<<n, 128, 0, s>>>(km, km_stride, chain, chain_stride, q, dbg);
-	k_low_apply<<<dim3(PRE_NB, n), 64, 0, s>>>(src, src_stride, y, y_stride, km, km_stride, so, so_stride, chain, chain_stride, q, dbg);
-	k_low_markrows<<<n, 64, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q);
-	k_low_marks<<<dim3((W - 2 + MK_R - 2) / (MK_R - 1), n), MK_R, 0, s>>>(y, y_stride, km, km_stride, so, so_stride, q, dbg);
+	auto head = [&](int i0, int m, hipStream_t st) {                    /* pass A of images i0 .. i0 + m - 1 */
+		k_low_pre<<<dim3(PRE_NB, m), 64, 0, st>>>(src + (size_t)i0 * src_stride, src_stride, km + (size_t)i0 * km_stride, km_stride, reinterpret_cast<uint8_t *>(tab) + (size_t)i0 * tab_stride, tab_stride, q, dbg | force);
+		k_low_mapfix<<<m, 64, 0, st>>>(km + (size_t)i0 * km_stride, km_stride, reinterpret_cast<const uint8_t *>(tab) + (size_t)i0 * tab_stride, tab_stride, so + (size_t)i0 * so_stride, so_stride, q, dbg);
+	};
+	auto machine = [&](int i0, int m, hipStream_t st) {                 /* pass B's machine */
+		k_low_chain<<<m, 128, 0, st>>>(km + (size_t)i0 * km_stride, km_stride, chain + (size_t)i0 * chain_stride, chain_stride, q, dbg);
+	};
+	auto rest = [&](int i0, int m, hipStream_t st) {                    /* pass B's picture side, passes C and D */
+		k_low_apply<<<dim3(PRE_NB, m), 64, 0, st>>>(src + (size_t)i0 * src_stride, src_stride, y + (size_t)i0 * y_stride, y_stride, km + (size_t)i0 * km_stride, km_stride, so + (size_t)i0 * so_stride, so_stride,
+		                                           chain + (size_t)i0 * chain_stride, chain_stride, q, dbg);
+		k_low_markrows<<<m, 64, 0, st>>>(y + (size_t)i0 * y_stride, y_stride, km + (size_t)i0 * km_stride, km_stride, so + (size_t)i0 * so_stride, so_stride, q);
+		k_low_marks<<<dim3((W - 2 + MK_R - 2) / (MK_R - 1), m), MK_R, 0, st>>>(y + (size_t)i0 * y_stride, y_stride, km + (size_t)i0 * km_stride, km_stride, so + (size_t)i0 * so_stride, so_stride, q, dbg);
+	};
+	if (parts <= 1 || !aux || !ev) { head(0, n, s); machine(0, n, s); rest(0, n, s); return (int)hipGetLastError(); }
+#define LOWCHK(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+	LOWCHK(hipEventRecord(ev[0], s));
+	for (int p = 0; p < parts; p++) {
+		const int i0 = (int)((long long)n * p / parts), i1 = (int)((long long)n * (p + 1) / parts);
+		LOWCHK(hipStreamWaitEvent(aux[p], ev[0], 0));
+		if (p) LOWCHK(hipStreamWaitEvent(aux[p], ev[p], 0));              /* the sub-batch before is through its pass A */
+		head(i0, i1 - i0, aux[p]);
+		LOWCHK(hipEventRecord(ev[1 + p], aux[p]));
+		machine(i0, i1 - i0, aux[p]);
+		rest(i0, i1 - i0, aux[p]);
+		LOWCHK(hipEventRecord(ev[1 + parts + p], aux[p]));
+	}
+	for (int p = 0; p < parts; p++) LOWCHK(hipStreamWaitEvent(s, ev[1 + parts + p], 0));
+#undef LOWCHK
+	return (int)hipGetLastError();
 }
 /* Compatibility mode (NHW_COMPAT_GLIBC_ONESHOT) only, quality <= 16: the contrast-map cells whose memory the stock binary's malloc hands
  * out again -- res256's slack (row 128, columns 0..3), tree1 (map bytes from 262176 on: rows 272..280 hold what is read before it is

@@ -24,7 +24,7 @@ enum {
 	B_RESU64, B_RESV64, B_PACKET, B_BOOK1, B_BOOK2, B_SEL1, B_SEL2, B_S1, B_S2, B_HIST, B_META, B_PROF, B_ROWFLAG, B_SEGMAP, B_STALE,
 	B_NZQ, B_NZS, B_VOFF, B_VALS, B_CNZQ, B_CVALS,   /* the luma symbol stream as a list (nhw_tail_wave.h, wave_quantise_luma): non-zero map as the quantiser writes it, the map and the value offsets in stream order (Y31), the values; CNZQ / CVALS: the chroma part's map and values as the chroma quantiser leaves them */
 	B_CJPEG_V, B_CPROC_V, B_CLL1_V, B_CL2SAVE_V, B_UBYTES,   /* the V plane's own copies of the four chroma work planes (production: NhwWs::split_chroma); UBYTES: where the chroma quantiser parks U's symbols until V's come (it used the band plane, and above q21 waited for Y29 to be through with it) */
-	B_LOWTAB,   /* quality 1..16: the burst table of the pre-filter's pair machine (nhw_low.hip, k_low_table): 8 bytes a pixel pair of the code stream */
+	B_LOWTAB,   /* quality 1..16: the candidate masks pass A of the pre-filter leaves for its order-dependent cells (nhw_low.hip, k_low_pre -> k_low_mapfix): 320 bytes a row */
 	B_COUNT
 };
 
