@@ -329,6 +329,23 @@ struct PfC {
 
 DEVI void machine_cache(const PfM &m, PfC &c)
 {
+	if ((T(32) | T(28) | T(33) | T(35) | T(36) | T(39) | T(41)) == 0) {
+		/* the slow schedules at rest (no picture has been seen to move them: DESIGN 2) -- what is left of the general form below */
+		const int t14 = T(14), is4 = t14 == 4, is5 = t14 == 5;
+		c.fb14 = (t14 == 1) | (t14 == 2);
+		c.t14_045 = (t14 == 0) | is4 | is5;
+		c.gate14 = is4 | is5;
+		c.t6bad = T(6) > 4000000;
+		c.capA = is4; c.capB = 0;
+		c.schedA = is4; c.schedB = 0;
+		c.st_lt14 = 1;
+		c.arm0 = is5 & (T(31) > 0);
+		c.lim = 10;
+		c.exA = 0; c.exB = 0; c.exT = 12;
+		c.w8z = Wv(8) == 0;
+		c.wk = ((T(10) == 8) & (T(11) == 12)) | ((((T(10) == 10) & (T(11) == 15)) | ((T(10) == 6) & (T(11) == 9))) << 1);
+		return;
+	}
 	const int t14 = T(14), t32 = T(32), st = T(28), t33 = T(33), t31 = T(31) > 2;
 	const int is4 = t14 == 4, is5 = t14 == 5;
 	c.fb14 = (t14 == 1) | (t14 == 2);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box: instruction-fetch, scalar-unit and LDS-wait counters of the q <= 16 pre-filter kernels (k_low_machine, k_low_marks), one
+# Run on the GPU box: instruction-fetch, scalar-unit and LDS-wait counters of the q <= 16 pre-filter kernels (k_low_pre, k_low_mapfix, k_low_chain, k_low_apply, k_low_markrows, k_low_marks), one
 # --pmc pass per group over `python tools/dev/gpu_prefilter_time.py <q>`.  usage: bash profiles/collect_low.sh <tag> [q ...]
 set -u
 TAG=${1:-low}; shift; QS=${@:-10 8}

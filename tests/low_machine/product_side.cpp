@@ -9,6 +9,8 @@
 #define DEVI static inline
 #define DEVN static
 #define Q 65536
+static long g_cov[64];                 /* the probes in the schedule branches no picture has been seen to reach (PF_COV in the header) */
+#define PF_COV(n) (g_cov[n]++)
 #include "../../nhwcodec_amd/csrc/nhw_low_machine.h"
 
 extern "C" {
@@ -256,5 +258,7 @@ int main(int argc, char **argv)
 		printf("q%d class %d: %ld pairs, fast form %.1f %%, in whole bursts %.1f %%, through the burst table %.1f %%, fast mismatches %ld, step mismatches %ld, burst-walk mismatches %ld\n", q, cls, steps, 100.0 * fast / steps, 100.0 * bursted / steps, 100.0 * tabled / steps, bad_fast, bad_step, bad_hop);
 		bad += bad_fast + bad_step + bad_hop;
 	}
+	{ long hit = 0; for (int i = 0; i < 64; i++) hit += g_cov[i] != 0;
+	  printf("schedule probes reached: %ld%s\n", hit, hit ? "  (a picture that reaches the late schedules: pin it against oracle/_ref and add it to the goldens)" : ""); }
 	return bad ? 1 : 0;
 }

@@ -151,18 +151,18 @@ int main(int argc, char **argv)
 		lm_contrast_map(y.data(), km.data(), q);
 		memset(g_cov, 0, sizeof g_cov);
 		PfM m; machine_reset(m);
-		int mx32 = 0, mx36 = 0, mx28 = 0, mx8 = 0, mx5 = 0, mx37 = 0, mx38 = 0, mx43 = 0;
+		int mx32 = 0, mx36 = 0, mx28 = 0, mx8 = 0, mx5 = 0, mx37 = 0, mx38 = 0, mx43 = 0, mx31 = 0, mx33 = 0, any5 = 0;
 		for (int r = 1; r < S - 1; r++) for (int pp = 0; pp < 255; pp++) {
 			const int k0 = km[r * S + 1 + 2 * pp], k1 = km[r * S + 2 + 2 * pp];
 			const int code = (iabs(k0) > sharp) | ((iabs(k1) > sharp) << 1) | ((iabs(k1) > s2) << 2) | ((iabs(k0) > sharp + 96) << 3);
 			machine_step(m, code, r);
 			const int t32 = m.t[32] > 100 ? 9 : m.t[32];
 			mx32 = std::max(mx32, t32); mx36 = std::max(mx36, m.t[36]); mx28 = std::max(mx28, m.t[28]); mx8 = std::max(mx8, m.t[8]); mx5 = std::max(mx5, m.t[5]);
-			mx37 = std::max(mx37, m.t[37] < 0 ? 20 : m.t[37]); mx38 = std::max(mx38, m.t[38]); mx43 = std::max(mx43, m.t[43]);
+			mx37 = std::max(mx37, m.t[37] < 0 ? 20 : m.t[37]); mx31 = std::max(mx31, m.t[31]); mx33 = std::max(mx33, m.t[33] > 0 ? 1 : 0); any5 |= m.t[14] == 5; mx38 = std::max(mx38, m.t[38]); mx43 = std::max(mx43, m.t[43]);
 		}
 		sc.probes = 0;
 		for (int i = 0; i < 64; i++) { cov[i] = g_cov[i]; if (g_cov[i]) sc.probes++; }
-		sc.progress = 1000L * mx32 + 20L * std::min(mx36, 120) + 300L * mx28 + 200L * std::min(mx8, 8) + 50L * std::min(mx5, 40) + 30L * std::min(mx37, 20) + 100L * std::min(mx38, 11) + 100L * std::min(mx43, 25);
+		sc.progress = 5000L * mx31 + 20000L * mx33 + 20000L * any5 + 1000L * mx32 + 20L * std::min(mx36, 120) + 300L * mx28 + 2000L * std::min(mx8, 8) + 50L * std::min(mx5, 40) + 30L * std::min(mx37, 20) + 100L * std::min(mx38, 11) + 100L * std::min(mx43, 25);
 	};
 	struct Ent { Pic p; Score s; };
 	std::vector<Ent> pool;
