@@ -1914,24 +1914,33 @@ DEV void colour8_q20(uint2 y8, uint2 u8, uint2 v8, uint32_t w[6])
 {
 #pragma unroll
 	for (int e = 0; e < 6; e++) w[e] = 0;
+	float worst = 0.f;                                                  /* how close a G of the eight comes to an integer boundary */
 #pragma unroll
 	for (int px = 0; px < 8; px++) {
 		const uint32_t yw = px < 4 ? y8.x : y8.y, uw = px < 4 ? u8.x : u8.y, vw = px < 4 ? v8.x : v8.y;
 		const float yf = ubf_(yw, px & 3), uf = ubf_(uw, px & 3), vf = ubf_(vw, px & 3);
-		const float t = yf * 1000.f;
-		const f32x2_ nrb = __builtin_elementwise_fma((f32x2_){ vf, uf }, (f32x2_){ 1402.f, 1772.f }, (f32x2_){ t, t });
-		const f32x2_ xrb = __builtin_elementwise_fma(nrb, (f32x2_){ 0.001f, 0.001f }, (f32x2_){ (500.f - 1402.f * 128.f) / 1000.f - 0.4995f, (500.f - 1772.f * 128.f) / 1000.f - 0.4995f });
+		/* R, B: Y + 1.402 V' + 0.5 with everything constant in the addend: the product's error (1.3e-5), the fma's rounding below 512 (3e-5) and the
+		 * addend's (2.3e-5) stay a factor of seven inside the 5e-4 between the values' fractions (multiples of 1e-3) and the rounding boundary */
+		const f32x2_ add = (f32x2_){ yf, yf } + (f32x2_){ (500.f - 1402.f * 128.f) / 1000.f - 0.4995f, (500.f - 1772.f * 128.f) / 1000.f - 0.4995f };
+		const f32x2_ xrb = __builtin_elementwise_fma((f32x2_){ vf, uf }, (f32x2_){ 1.402f, 1.772f }, add);
 		const f32x2_ uvc = (f32x2_){ uf, vf } - (f32x2_){ 128.f, 128.f };
 		const float wg = __builtin_fmaf(uvc.y, 71414.f, uvc.x * 34414.f);
 		const float xg = __builtin_fmaf(wg, -1e-5f, yf);                    /* the value the floor is taken of, minus 0.5 */
 		const int b0 = 3 * px;
 		w[b0 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(xrb.x, b0 & 3, w[b0 >> 2]);
 		w[(b0 + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(xrb.y, (b0 + 2) & 3, w[(b0 + 2) >> 2]);
-		if (__builtin_fabsf(xg - __builtin_rintf(xg)) > 0.5f - 1e-4f) {     /* too close to a boundary for single precision */
+		w[(b0 + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(xg, (b0 + 1) & 3, w[(b0 + 1) >> 2]);
+		worst = __builtin_fmaxf(worst, __builtin_fabsf(xg - __builtin_rintf(xg)));
+	}
+	if (worst > 0.5f - 1e-4f) {                                         /* one of the eight is too close to a boundary for single precision (7 triples in 100 000): all eight G again, in the integer / double form */
+#pragma unroll
+		for (int px = 0; px < 8; px++) {
+			const uint32_t yw = px < 4 ? y8.x : y8.y, uw = px < 4 ? u8.x : u8.y, vw = px < 4 ? v8.x : v8.y;
 			int R, G, B;
-			yuv_to_bytes(20, (int)yf, (int)uf, (int)vf, R, G, B);
-			w[(b0 + 1) >> 2] |= (uint32_t)G << (8 * ((b0 + 1) & 3));
-		} else w[(b0 + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(xg, (b0 + 1) & 3, w[(b0 + 1) >> 2]);
+			yuv_to_bytes(20, (int)((yw >> (8 * (px & 3))) & 255u), (int)((uw >> (8 * (px & 3))) & 255u), (int)((vw >> (8 * (px & 3))) & 255u), R, G, B);
+			const int b1 = 3 * px + 1;
+			w[b1 >> 2] = (w[b1 >> 2] & ~(0xFFu << (8 * (b1 & 3)))) | ((uint32_t)G << (8 * (b1 & 3)));
+		}
 	}
 }
 /* byte-wise (a + b + 1) >> 1 on four bytes (v_lerp_u8) */
