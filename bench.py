@@ -28,8 +28,10 @@ sys.path.insert(0, ROOT)
 MPIX_PER_IMAGE = 0.262144
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 FRONT_BYTES_PER_IMAGE = 786432 + 786432   # 3 B/px read + 3 B/px written (Y coeffs + 2 x chroma)
-FRONT_KERNEL_NAME = ("front = k_front_image, ONE fused kernel and the whole launch group: BGR24 -> Y + 4:2:0 chroma planes, luma pre-filter (its carry chained inside the kernel), "
-                     "both directions of the level-1 analysis; a workgroup walks an image top to bottom with a rolling window of rows in LDS (the luma plane never travels)")
+FRONT_KERNEL_NAME = ("THREE launches priced together: k_front_image (one fused kernel = the whole front launch group: BGR24 -> Y + 4:2:0 chroma planes, luma pre-filter with its carry "
+                     "chained inside the kernel, both directions of the luma level-1 analysis; a workgroup walks an image top to bottom with a rolling window of rows in LDS, the luma "
+                     "plane never travels) + the two k_dwt_ana<256> launches of the chroma level-1 analysis (U, V), whose coefficients are part of the 6 B/pixel; "
+                     "frac_front_kernel_alone prices the same bytes over k_front_image only")
 VALU_PMC_FILE = os.path.join(ROOT, "profiles", "round5_pmc_valu.json")   # profiles/collect_valu.sh: SQ_INSTS_VALU, GRBM_GUI_ACTIVE ... of the same bench command
 PMC_FILE = os.path.join(ROOT, "profiles", "front_pmc.json")     # written by profiles/pmc_summarise.py from separate rocprofv3 --pmc passes
 
@@ -436,7 +438,7 @@ def main():
             sok = int((out[2] == 0).sum().item())
             split = timed_steps.last
             sweep.append({"quality": sq, "steps": k, "warmup": 1, "ms_per_step": round(sdt / k * 1e3, 3), "value": round(batch * k * MPIX_PER_IMAGE / sdt, 2), "unit": "Mpixels/s",
-                          **({"front_kernels_ms": {"colour + 4:2:0 (k_color)": round(split["color_ms"] / k, 3), "rationed pre-filter (k_low_machine + k_low_marks)": round(split["prefilter_ms"] / k, 3),
+                          **({"front_kernels_ms": {"colour + 4:2:0 (k_color)": round(split["color_ms"] / k, 3), "rationed pre-filter (k_low_pre, k_low_mapfix, k_low_chain, k_low_apply, k_low_markrows, k_low_marks)": round(split["prefilter_ms"] / k, 3),
                                                    "level-1 analysis (k_front_plain)": round((sfront - split["color_ms"] - split["prefilter_ms"]) / k, 3)}} if sq <= 16 else
                              {"front_kernels_ms": {("k_front_plain (colour + 4:2:0 + level-1 analysis, no pre-filter)" if sq >= 22 else "k_front_image (colour + 4:2:0 + pre-filter + level-1 analysis)"): round(sfront / k, 3)},
                               "front_achieved_GBs": round(batch * FRONT_BYTES_PER_IMAGE / (sfront / k / 1e3) / 1e9, 1)}),
@@ -464,7 +466,7 @@ def main():
             split = timed_steps.last
             legs.append({"quality": sq, "steps": k, "warmup": 1, "ms_per_step": round(sdt / k * 1e3, 3), "value": round(n8 * k * MPIX_PER_IMAGE / sdt, 2), "unit": "Mpixels/s",
                          "images_ok": int((out8[2] == 0).sum().item()), "front_ms": round(sfront / k, 3),
-                         **({"prefilter_ms (k_low_machine + k_low_marks)": round(split["prefilter_ms"] / k, 3)} if sq <= 16 else {})})
+                         **({"prefilter_ms (k_low_pre .. k_low_marks)": round(split["prefilter_ms"] / k, 3)} if sq <= 16 else {})})
         c4_line = {"workload": f"{n8} synthetic images on ONE GPU = the per-rank share of BASELINE config 4 (65536 over 8), whole encoder, inputs and outputs in HBM", "legs": legs}
         enc8.close()
         del bgr8, out8

@@ -54,7 +54,7 @@ typedef struct {
 	float entropy_ms;
 	int parts;            /* sub-batches the stages behind the front ran as (each on a stream of its own); with more than one, luma/chroma/entropy_ms are those of the first */
 	int front_images;     /* images covered by front_ms */
-	float prefilter_ms;   /* quality 1..16: the rationed luma pre-filter (k_low_machine + k_low_marks), second of the front group; 0 for 17..23 */
+	float prefilter_ms;   /* quality 1..16: the rationed luma pre-filter (k_low_pre, k_low_mapfix, k_low_chain, k_low_apply, k_low_markrows, k_low_marks), second of the front group; 0 for 17..23 */
 } nhw_timing;
 
 /* lifecycle: replaces `im.setup=malloc(..)` + per-image mallocs of encode_image (nhw_encoder.c:108-...).  Everything a batch of up to
@@ -99,7 +99,7 @@ int nhw_enc_last_timing(nhw_enc *e, nhw_timing *t);
 /* ---- stage-level entry points (kernel parity tests; same stream rules) ----
  * colour + 4:2:0 (colorspace.c:55-260), any quality 1..23: d_y n*262144 int16, d_u/d_v n*65536 uint8 */
 int nhw_stage_color(nhw_enc *e, const void *d_bgr, int n, int quality, void *d_y, void *d_u, void *d_v, void *stream);
-/* luma pre-filter (image_processing.c:558-2426) as a stage of its own: quality 1..16 (k_low_machine + k_low_marks, the kernels the encoder runs);
+/* luma pre-filter (image_processing.c:558-2426) as a stage of its own: quality 1..16 (k_low_pre .. k_low_marks, the kernels the encoder runs, the whole batch in line);
  * for 17..21 it is a step inside the fused front kernel (NHW_E_QUALITY here).  In place on d_y */
 int nhw_stage_prefilter(nhw_enc *e, void *d_y, int n, int quality, void *stream);
 /* one analysis level (wavelet_filterbank.c:52-302) on planes of `stride` shorts per row, n_img images
