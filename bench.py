@@ -32,7 +32,7 @@ FRONT_KERNEL_NAME = ("THREE launches priced together: k_front_image (one fused k
                      "chained inside the kernel, both directions of the luma level-1 analysis; a workgroup walks an image top to bottom with a rolling window of rows in LDS, the luma "
                      "plane never travels) + the two k_dwt_ana<256> launches of the chroma level-1 analysis (U, V), whose coefficients are part of the 6 B/pixel; "
                      "frac_front_kernel_alone prices the same bytes over k_front_image only")
-VALU_PMC_FILE = os.path.join(ROOT, "profiles", "round5_pmc_valu.json")   # profiles/collect_valu.sh: SQ_INSTS_VALU, GRBM_GUI_ACTIVE ... of the same bench command
+VALU_PMC_FILE = os.path.join(ROOT, "profiles", "round6_pmc_valu.json")   # profiles/collect_valu.sh: SQ_INSTS_VALU, GRBM_GUI_ACTIVE ... of the same bench command
 PMC_FILE = os.path.join(ROOT, "profiles", "front_pmc.json")     # written by profiles/pmc_summarise.py from separate rocprofv3 --pmc passes
 
 
@@ -142,7 +142,7 @@ def cpu_decode_baseline(files, budget_s=6.0):
 
 
 def valu_evidence():
-    """VALU issue statistics of the front kernel from the committed PMC pass (profiles/round5_pmc_valu.json, batch 4096, -q20):
+    """VALU issue statistics of the front kernel from the committed PMC pass (profiles/round6_pmc_valu.json, batch 4096, -q20):
     wave-instructions issued / (CUs x kernel cycles) -- the kernel's limiter is vector-instruction issue, not HBM; this is its fraction of
     that roofline (one wave64 instruction per CU and cycle: four 16-lane SIMDs)."""
     try:
@@ -576,7 +576,7 @@ def main():
                          # the same bytes over the front group PLUS the two chroma level-1 launches whose output the 6 B/pixel include (measured apart, see chroma_l1_ms)
                          "chroma_l1_in_frac": bool(cl1),
                          **({"frac_incl_chroma_l1": round(front_images * FRONT_BYTES_PER_IMAGE / ((front_s + cl1 / 1e3)) / 1e9 / HBM_PEAK_GBS, 4), "chroma_l1_ms": round(cl1, 3)} if cl1 else {}), "sub_batches": tim.parts, "algorithmic_bytes_per_image": FRONT_BYTES_PER_IMAGE, "ms_per_launch_group": round(front_s * 1e3, 3)},
-            "stage_ms": {"front": round(tim.front_ms, 3), "luma_tail (chroma sequence alongside, on its own stream)": round(tim.luma_ms, 3), "chroma left over": round(tim.chroma_ms, 3),
+            "stage_ms": {"front": round(tim.front_ms, 3), "luma_tail incl. the join with the chroma stream in front of the luma quantiser": round(tim.luma_ms, 3), "chroma left over behind it (0 with that join)": round(tim.chroma_ms, 3),
                          "entropy+container": round(tim.entropy_ms, 3), "total": round(tim.total_ms, 3)},
             "images_ok": [int(g[2]) for g in gathered], "bytes_out": [int(g[0]) for g in gathered],
             "ms_per_step_per_rank": [round(v, 3) for v in rank_ms],      # each rank's own clock over its K steps; ms_per_step is the max-over-ranks figure with the barriers

@@ -49,8 +49,8 @@ typedef struct {
 	float total_ms;
 	float front_ms;       /* colour + pre-filter + level-1 analysis (the HBM-roofline kernels) */
 	float color_dwt_ms;   /* quality 1..16: the colour + 4:2:0 kernel, the first of the front group; 0 for 17..23 (the conversion is inside the fused front kernel) */
-	float luma_ms;        /* luma tail; the chroma sequence runs next to it on a stream of its own (NHW_CHROMA_FORK=0: behind it) */
-	float chroma_ms;      /* what is left of the chroma sequence once the luma tail is done (about 0 when it is hidden; its full time with NHW_CHROMA_FORK=0) */
+	float luma_ms;        /* luma tail up to and including the luma quantiser and Y31; the chroma sequence runs next to it on a stream of its own and -- the default since round 5 -- is joined IN FRONT of the luma quantiser, so this figure includes any wait for it (NHW_CHROMA_FORK=0: the chroma sequence follows behind) */
+	float chroma_ms;      /* what is left of the chroma sequence once the luma tail is done: about 0 with the default join in front of the quantiser (NHW_QUANT_JOIN=0: the join in front of the packetiser, where this is the exposed rest; NHW_CHROMA_FORK=0: its full time) */
 	float entropy_ms;
 	int parts;            /* sub-batches the stages behind the front ran as (each on a stream of its own); with more than one, luma/chroma/entropy_ms are those of the first */
 	int front_images;     /* images covered by front_ms */

@@ -251,8 +251,9 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 	if (!(what & 2)) { HIPCHK(hipGetLastError()); return NHW_OK; }
 	}
 	/* The chroma sequence needs nothing of the luma tail except the length of the exception list (its own entries go behind the
-	 * luma ones, Y15) and, for q > 21, the band plane that Y29 is done with: it runs on a stream of its own next to the luma tail
-	 * and fills the issue slots the latency-bound luma kernels leave.  U and V share their planes, so they stay in sequence. */
+	 * luma ones, Y15): it runs on a stream of its own next to the luma tail and fills the issue slots the latency-bound luma kernels
+	 * leave.  (Since round 5 V works in planes of its own and U's symbols are parked in B_UBYTES until V's quantiser merges them: the
+	 * sequence no longer waits for the band plane Y29 is done with, nor V's head for U's quantiser.) */
 	const bool fork = timed == 1 && what == 3 && !e->stop_after && e->chroma_fork;
 	const bool fork_ll = fork && q > 13 && !ws.compat && e->ll_fork;
 	ws.defer_verbatim = fork_ll;
@@ -617,6 +618,9 @@ extern "C" int nhw_stage_analysis(nhw_enc *e, void *d_jpeg, void *d_proc, int n_
 	hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
 	if (size == 512) {
 		if (stride != W || final_level || n_img > e->max_batch) { g_err = "size 512: stride 512, not the final level, n <= max_batch"; return NHW_E_ARG; }
+		if (((uintptr_t)d_jpeg & 15) || ((uintptr_t)d_proc & 15) || (plane_stride & 7) || plane_stride < (size_t)W * W) {   /* the range check and the kernel read 16 bytes at a time */
+			g_err = "size 512: planes must be 16-byte aligned and plane_stride (in samples) a multiple of 8, at least 512 x 512"; return NHW_E_ARG;
+		}
 		const NhwWs &ws = e->ws;
 		{                                                          /* the domain check: U = largest sample (or 0), L = -smallest (or 0); 104 U + 40 L and 104 L + 40 U at most NHW_ANA512_BOUND */
 			int *d_mm = reinterpret_cast<int *>(plane8(ws, B_ROWSTATE)), mm[2] = { 32767, -32768 };   /* (the front kernel's row-state bytes: free until it runs) */

@@ -1,11 +1,11 @@
 """Regenerates the kernel table of DESIGN.md (between the KERNEL_TABLE markers) from the committed profile summaries, so that the numbers
 cannot drift from the files they cite.   usage: python profiles/make_design_table.py [--check]
-inputs: profiles/round5_kernel_stats_1stream.txt (rocprofv3 --kernel-trace --stats, one stream), profiles/round5_pmc.json (FETCH_SIZE and
+inputs: profiles/round6_kernel_stats_1stream.txt (rocprofv3 --kernel-trace --stats, one stream), profiles/round6_pmc.json (FETCH_SIZE and
 WRITE_SIZE per kernel from separate --pmc passes; KiB; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STATS = os.path.join(ROOT, "profiles", "round5_kernel_stats_1stream.txt")
-PMC = os.path.join(ROOT, "profiles", "round5_pmc.json")
+STATS = os.path.join(ROOT, "profiles", "round6_kernel_stats_1stream.txt")
+PMC = os.path.join(ROOT, "profiles", "round6_pmc.json")
 BATCHES = 7.0            # bench.py --steps 5 --warmup 2 in profiles/collect.sh
 PH = ["L1", "L2", "L3", "L4A", "C0", "C2", "C3", "C4", "C5", "FINAL", "L4B", "L4C", "L4D", "LLC", "L4C2"]
 WV = ["DQ1", "DQ0", "EMIT", "QUANT"]

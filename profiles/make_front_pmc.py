@@ -14,5 +14,5 @@ for k, v in d.items():
     if any(n in k for n in ("k_front_image", "k_front_plain", "k_front_stale")) or k.endswith("k_color"):
         front[k] = {"fetch_x2_bytes": 2 * v["FETCH_SIZE"]["per_launch"] * 1024, "write_bytes": v["WRITE_SIZE"]["per_launch"] * 1024}
         total += b
-print(json.dumps({"source_hash": kernel_source_hash(), "commit": commit, "quality": q, "batch": batch, "file": "profiles/round5_pmc.json",
+print(json.dumps({"source_hash": kernel_source_hash(), "commit": commit, "quality": q, "batch": batch, "file": "profiles/round6_pmc.json",
                   "front_bytes_per_image": total / batch, "kernels": front}, indent=1))
