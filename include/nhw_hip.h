@@ -61,6 +61,11 @@ typedef struct {
  * max_batch images needs on the device is allocated here and nowhere else: the workspace (7.0 MB per image) and the staging buffers of the
  * host path nhw_enc_batch / nhw_enc_synth_batch (1.8 MB per image) -- no call behind it allocates, so the first batch costs what the others do */
 int  nhw_enc_create(int device, int max_batch, nhw_enc **out);
+/* The same with flags.  NHW_CREATE_DEVICE_ONLY: for callers of nhw_enc_batch_device only -- the host path's staging buffers (1.8 MB per image:
+ * 7.3 GB at max_batch 4096) are not allocated; a later nhw_enc_batch / nhw_enc_synth_batch on such a handle still works and allocates them
+ * then (that one call pays for it).  Unknown flag bits are NHW_E_ARG. */
+#define NHW_CREATE_DEVICE_ONLY 1u
+int  nhw_enc_create_ex(int device, int max_batch, unsigned flags, nhw_enc **out);
 void nhw_enc_destroy(nhw_enc *e);
 const char *nhw_last_error(void);
 int  nhw_quality_supported(int quality);

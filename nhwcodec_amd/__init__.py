@@ -36,6 +36,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L = ctypes.CDLL(path)
     L.nhw_last_error.restype = ctypes.c_char_p
     L.nhw_enc_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)]
+    L.nhw_enc_create_ex.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.POINTER(P)]
     L.nhw_enc_destroy.argtypes = [P]
     L.nhw_quality_supported.argtypes = [ctypes.c_int]
     L.nhw_enc_set_compat.argtypes = [P, ctypes.c_int]
@@ -59,7 +60,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
 class Encoder:
     """One encoder handle on one GPU.  encode_device() works on torch CUDA tensors already in HBM."""
 
-    def __init__(self, device: int = 0, max_batch: int = 64):
+    def __init__(self, device: int = 0, max_batch: int = 64, device_only: bool = False):
+        """device_only: the handle is for encode_device() -- no staging buffers of the host path (nhw_enc_create_ex, NHW_CREATE_DEVICE_ONLY)"""
         import torch
         if not torch.cuda.is_available():
             raise NhwError("no GPU visible: nhwcodec_amd has no CPU path")
@@ -68,7 +70,7 @@ class Encoder:
         self.device = device
         self.max_batch = max_batch
         h = P()
-        self._chk(self.lib.nhw_enc_create(device, max_batch, ctypes.byref(h)))
+        self._chk(self.lib.nhw_enc_create_ex(device, max_batch, 1 if device_only else 0, ctypes.byref(h)))
         self.h = h
 
     def _chk(self, rc):
@@ -232,7 +234,8 @@ class Decoder:
     """One decoder handle on one GPU: mirror of the reference's decode_image + write_image_bmp
     (decoder/nhw_decoder.c:54, decoder/nhw_decoder_cli.c:108) for batches of .nhw files."""
 
-    def __init__(self, device: int = 0, max_batch: int = 64):
+    def __init__(self, device: int = 0, max_batch: int = 64, device_only: bool = False):
+        """device_only: the handle is for encode_device() -- no staging buffers of the host path (nhw_enc_create_ex, NHW_CREATE_DEVICE_ONLY)"""
         import torch
         if not torch.cuda.is_available():
             raise NhwError("no GPU visible: nhwcodec_amd has no CPU path")

@@ -114,9 +114,10 @@ extern "C" void nhw_enc_destroy(nhw_enc *e);
 static int host_buffers(nhw_enc *e, int n);
 /* device bytes per image of the host path's staging (nhw_enc_batch / nhw_enc_synth_batch): input slot, output slot, compacted output */
 #define HOST_PATH_BYTES ((size_t)NHW_IMG_BYTES + 2 * (size_t)NHW_OUT_STRIDE + 24)
-extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
+extern "C" int nhw_enc_create_ex(int device, int max_batch, unsigned flags, nhw_enc **out)
 {
-	if (!out || max_batch < 1 || max_batch > 65535) { g_err = "bad argument"; return NHW_E_ARG; }
+	if (!out || max_batch < 1 || max_batch > 65535 || (flags & ~(unsigned)NHW_CREATE_DEVICE_ONLY)) { g_err = "bad argument"; return NHW_E_ARG; }
+	const bool host_staging = !(flags & NHW_CREATE_DEVICE_ONLY);
 	HIPCHK(hipSetDevice(device));
 	nhw_enc *e = new nhw_enc();
 	memset(e, 0, sizeof *e);
@@ -131,8 +132,8 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 	const int rc = [&]() -> int {                                  /* a failure half-way leaves nothing behind: the handle is destroyed below */
 		size_t free_b = 0, total_b = 0;
 		HIPCHK(hipMemGetInfo(&free_b, &total_b));
-		const size_t need = total + HOST_PATH_BYTES * (size_t)max_batch;
-		if (need > free_b) {                                       /* 7.0 MB of workspace + 1.8 MB of host-path staging per image: say so instead of failing inside hipMalloc */
+		const size_t need = total + (host_staging ? HOST_PATH_BYTES * (size_t)max_batch : 0);
+		if (need > free_b) {                                       /* 7.0 MB of workspace (+ 1.8 MB of host-path staging) per image: say so instead of failing inside hipMalloc */
 			char b[200];
 			snprintf(b, sizeof b, "encoder workspace for max_batch %d needs %zu MiB (%.1f MiB per image), %zu MiB of HBM are free", max_batch, need >> 20, (double)need / max_batch / 1048576.0, free_b >> 20);
 			g_err = b;
@@ -153,8 +154,9 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 		HIPCHK(hipStreamCreateWithFlags(&e->ll_stream, hipStreamNonBlocking));
 		for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&e->ll_ev[i], hipEventDisableTiming));
 		/* the host path's staging buffers, for the whole of max_batch, now: allocated on the first nhw_enc_batch they made that call twice as
-		 * slow as the ones behind it (gigabytes of hipMalloc inside the timed region of whoever measured it) */
-		return host_buffers(e, max_batch);
+		 * slow as the ones behind it (gigabytes of hipMalloc inside the timed region of whoever measured it).  A caller that only ever hands over
+		 * device buffers says NHW_CREATE_DEVICE_ONLY and does not pay for them; should it call the host path after all, that call allocates. */
+		return host_staging ? host_buffers(e, max_batch) : NHW_OK;
 	}();
 	if (rc != NHW_OK) { nhw_enc_destroy(e); return rc; }
 	e->parts = 1;   /* sub-batches on streams of their own (NHW_PARTS=2..4) bought 4 % while the tail kernels were latency-bound; they no longer do */
@@ -170,6 +172,8 @@ extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out)
 	*out = e;
 	return NHW_OK;
 }
+
+extern "C" int nhw_enc_create(int device, int max_batch, nhw_enc **out) { return nhw_enc_create_ex(device, max_batch, 0u, out); }
 
 extern "C" void nhw_enc_destroy(nhw_enc *e)
 {

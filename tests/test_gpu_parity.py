@@ -811,3 +811,35 @@ def test_build_then_smoke_in_one_process():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "smoke OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_device_only_handle_skips_the_host_staging(oracle):
+    """nhw_enc_create_ex(NHW_CREATE_DEVICE_ONLY): a handle for nhw_enc_batch_device does not hold the host path's 1.8 MB of staging per image;
+    the resident path gives the oracle's bytes, and a host-path call on such a handle still works (it allocates then).  Unknown flags are refused."""
+    import ctypes
+    import torch
+    import nhwcodec_amd
+    n = 512
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    e_full = nhwcodec_amd.Encoder(0, max_batch=n)
+    free1 = torch.cuda.mem_get_info()[0]
+    e_full.close()
+    e = nhwcodec_amd.Encoder(0, max_batch=n, device_only=True)
+    free2 = torch.cuda.mem_get_info()[0]
+    held_full, held_dev = free0 - free1, free0 - free2
+    assert held_full - held_dev > n * 1_700_000, (held_full, held_dev)      # 3 x 512 x 512 in + 2 x the output slot a picture
+    img = e.synth_device(8, seed_base=40)
+    o, sizes, status = e.encode_device(img, 20)
+    torch.cuda.synchronize()
+    assert int((status != 0).sum()) == 0
+    sz = sizes.cpu().numpy()
+    host = img.cpu().numpy()
+    for i in (0, 7):
+        assert o[i, : sz[i]].cpu().numpy().tobytes() == oracle.encode(host[i], 20)
+    got = e.encode(host[:4], 10)                                            # the host path after all: allocates on this call
+    assert got[3] == oracle.encode(host[3], 10)
+    e.close()
+    h = ctypes.c_void_p()
+    assert nhwcodec_amd.load_library().nhw_enc_create_ex(0, 4, 2, ctypes.byref(h)) != 0
