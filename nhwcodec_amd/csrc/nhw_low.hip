@@ -652,6 +652,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	const int lane = threadIdx.x & 63, img = blockIdx.x;
 	const int16_t *km = kmb + (size_t)img * km_stride;                  /* the contrast map as pass A left it */
 	uint32_t *ap = reinterpret_cast<uint32_t *>(actb + (size_t)img * act_stride);
+#ifdef NHW_DEV   /* developer builds: the picture's time in this kernel, in units of 64 clock ticks, in the last (unused) dword of its answers (tools/dev/gpu_chain_spread.py) */
+	const long long dev_t0 = clock64();
+#endif
 	/* the codes of my four pairs of chunk k, made from their map cells (pair n of the stream: row 1 + n / 255, cells 1 + 2 (n % 255) and the next;
 	 * 0 behind the stream's end): all the machine ever asks about the picture (nhw_low_machine.h) */
 	const PfP pp = pf_params(q);
@@ -817,6 +820,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 		reinterpret_cast<uint32_t *>(s_act)[64 * (k & 1) + lane] = 0;
 		__syncthreads();                                            /* the table's wavefront has chunk k + 1's entries and chunk k + 2's sums standing */
 	}
+#ifdef NHW_DEV
+	if (threadIdx.x == 0) ap[CH_BYTES / 4 - 1] = (uint32_t)((clock64() - dev_t0) >> 6);
+#endif
 }
 
 /* Pass B's picture side, a wavefront a band of 32 rows: the picture copy with the q <= 14 smoothing (:566, :780-807), the machine's answers
