@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s me
 FRONT_BYTES_PER_IMAGE = 786432 + 786432   # 3 B/px read + 3 B/px written (Y coeffs + 2 x chroma)
 FRONT_KERNEL_NAME = ("THREE launches priced together: k_front_image (one fused kernel = the whole front launch group: BGR24 -> Y + 4:2:0 chroma planes, luma pre-filter with its carry "
                      "chained inside the kernel, both directions of the luma level-1 analysis; a workgroup walks an image top to bottom with a rolling window of rows in LDS, the luma "
-                     "plane never travels) + the two k_dwt_ana<256> launches of the chroma level-1 analysis (U, V), whose coefficients are part of the 6 B/pixel; "
+                     "plane never travels) + the two k_chroma_l1q launches of the chroma level-1 analysis (U, V; a quarter of a 256 x 256 block to a workgroup), whose coefficients are part of the 6 B/pixel; "
                      "frac_front_kernel_alone prices the same bytes over k_front_image only")
 VALU_PMC_FILE = os.path.join(ROOT, "profiles", "round6_pmc_valu.json")   # profiles/collect_valu.sh: SQ_INSTS_VALU, GRBM_GUI_ACTIVE ... of the same bench command
 PMC_FILE = os.path.join(ROOT, "profiles", "front_pmc.json")     # written by profiles/pmc_summarise.py from separate rocprofv3 --pmc passes

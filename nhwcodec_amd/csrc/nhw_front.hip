@@ -299,6 +299,92 @@ __device__ __forceinline__ uint4 ana_piece(const int16_t *src, const uint8_t *sr
 	const uint2 b = *reinterpret_cast<const uint2 *>(src8 + (size_t)row * S + 8 * o);
 	return make_uint4((b.x & 0xFF) | ((b.x >> 8 & 0xFF) << 16), (b.x >> 16 & 0xFF) | ((b.x >> 24) << 16), (b.y & 0xFF) | ((b.y >> 8 & 0xFF) << 16), (b.y >> 16 & 0xFF) | ((b.y >> 24) << 16));
 }
+/* The second direction (filters.c:88-287) of two columns at once: Ew / Ow hold the even / odd rows' cells of the two columns, a lane its own row pair
+ * k = lane + 64 u; lo / hi: what the pair leaves for its two columns.  left: the columns lie in the first direction's low-pass half. */
+template <int PPL, int HLF>
+__device__ __forceinline__ void ana_col_pair(const uint32_t (&Ew)[PPL], const uint32_t (&Ow)[PPL], bool left, int lane, int (&lo)[PPL][2], int (&hi)[PPL][2])
+{
+	/* Two columns side by side in packed 16-bit arithmetic wherever nothing can leave 16 bits: with every cell of the wavefront's two columns in
+	 * -1300 .. 3000 the un-normalised sums stay inside (10 x 3000 + 2 x 1300 < 32768) -- which is every block of a real picture (the level-2
+	 * input is LL1, the level-1 chroma input a byte plane).  A block outside that range takes the 32-bit form below, which follows the
+	 * reference's int arithmetic where it wraps. */
+	bool wide = false;
+#pragma unroll
+	for (int u = 0; u < PPL; u++) {
+		const uint32_t mx = pk_max_u16x(pk_add16(Ew[u], 0x05140514u), pk_add16(Ow[u], 0x05140514u));   /* + 1300: in range = at most 4300 as unsigned */
+		wide |= (mx & 0xFFFFu) > 4300u || (mx >> 16) > 4300u;
+	}
+	if (!__any(wide)) {
+		uint32_t rlast = 0;
+#pragma unroll
+		for (int u = 0; u < PPL; u++) {
+			const int k = lane + 64 * u;
+			uint32_t em = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x138, 0xF, 0xF, false), om = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ow[u], 0x138, 0xF, 0xF, false);
+			uint32_t en = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x130, 0xF, 0xF, false);
+			if (u > 0) {
+				const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u > 0 ? u - 1 : 0], 63), so_ = (uint32_t)__builtin_amdgcn_readlane((int)Ow[u > 0 ? u - 1 : 0], 63);
+				if (lane == 0) { em = se; om = so_; }
+			}
+			if (u + 1 < PPL) { const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u + 1 < PPL ? u + 1 : u], 0); if (lane == 63) en = se; }
+			else if (lane == 63) en = Ew[u];
+			if (u == 0 && lane == 0) { em = en; om = Ow[u]; }
+			const s16x2 e0 = as_s(Ew[u]), o0 = as_s(Ow[u]), em1 = as_s(em), om1 = as_s(om), e1 = as_s(en);
+			const s16x2 r = e0 * (s16x2)(short)6 + ((om1 + o0) << 1) - (em1 + e1);
+			s16x2 a = e0 + e1;
+			a = a + (a & (em1 + e0) & as_s((k & 1) ? 0x00010001u : 0u));
+			const s16x2 pp = o0 - (a >> 1), tail = o0 - e0;
+			s16x2 l, h;
+			if (left) {
+				uint32_t rp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)as_w(r), 0x138, 0xF, 0xF, false);
+				if (lane == 0) rp = rlast;
+				const s16x2 carry = k > 0 ? pk_diffuse(as_s(rp)) : (s16x2)(short)0;
+				rlast = (uint32_t)__builtin_amdgcn_readlane((int)as_w(r), 63);
+				l = pk_rnd_half_away(r + carry, 6);
+				h = k < HLF - 1 ? pk_rnd_half_away(pp, 3) : (tail >> 3);
+			} else {
+				l = pk_rnd_half_away(r, 4);
+				h = k < HLF - 1 ? pk_rnd_half_away(pp, 1) : ((tail + (s16x2)(short)1) >> 1);   /* pp > 0 ? (pp + 1) >> 1 : pp >> 1 is rounding half away at shift 1 */
+			}
+			lo[u][0] = l.x; lo[u][1] = l.y; hi[u][0] = h.x; hi[u][1] = h.y;
+		}
+	} else {
+	int rlast[2] = { 0, 0 };                                    /* r of cell 63 of the half before (the seam of the carry) */
+#pragma unroll
+		for (int u = 0; u < PPL; u++) {
+			const int k = lane + 64 * u;
+			uint32_t em = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x138, 0xF, 0xF, false), om = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ow[u], 0x138, 0xF, 0xF, false);
+			uint32_t en = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x130, 0xF, 0xF, false);
+			if (u > 0) {
+				const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u > 0 ? u - 1 : 0], 63), so_ = (uint32_t)__builtin_amdgcn_readlane((int)Ow[u > 0 ? u - 1 : 0], 63);
+				if (lane == 0) { em = se; om = so_; }
+			}
+			if (u + 1 < PPL) { const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u + 1 < PPL ? u + 1 : u], 0); if (lane == 63) en = se; }
+			else if (lane == 63) en = Ew[u];                           /* x[S] = x[S - 2] */
+			if (u == 0 && lane == 0) { em = en; om = Ow[u]; }           /* x[-2] = x[2], x[-1] = x[1] */
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const int e0 = h ? (int)Ew[u] >> 16 : (int16_t)(Ew[u] & 0xFFFF), o0 = h ? (int)Ow[u] >> 16 : (int16_t)(Ow[u] & 0xFFFF);
+				const int em1 = h ? (int)em >> 16 : (int16_t)(em & 0xFFFF), om1 = h ? (int)om >> 16 : (int16_t)(om & 0xFFFF), e1 = h ? (int)en >> 16 : (int16_t)(en & 0xFFFF);
+				const int r = 6 * e0 + 2 * (om1 + o0) - (em1 + e1);
+				int a = e0 + e1;
+				if ((k & 1) && (a & 1) && ((em1 + e0) & 1)) a++;
+				const int pp = o0 - (a >> 1), tail = o0 - e0;          /* the predicted odd sample; the last one: x[S-1] - x[S-2] */
+				if (left) {
+					int rp = __builtin_amdgcn_update_dpp(0, r, 0x138, 0xF, 0xF, false);   /* the cell before: its carry comes in (filters.c:203-287) */
+					if (lane == 0) rp = rlast[h];
+					const int carry = k > 0 ? diffuse(rp) : 0;
+					rlast[h] = __builtin_amdgcn_readlane(r, 63);
+					lo[u][h] = rnd_half_away((int16_t)(r + carry), 6);
+					hi[u][h] = k < HLF - 1 ? rnd_half_away(pp, 3) : (tail >> 3);
+				} else {
+					lo[u][h] = rnd_half_away(r, 4);
+					hi[u][h] = k < HLF - 1 ? (pp > 0 ? (pp + 1) >> 1 : pp >> 1) : ((tail + 1) >> 1);
+				}
+			}
+		}
+	}
+}
+
 template <int S>
 __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int final_level,
                                                    int16_t *__restrict__ saveb, size_t save_plane, int save_row, int save_kind /* 1: copy of the S x S coefficient block, 2: of the LL quadrant copied back */, int n,
@@ -378,85 +464,7 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 			const int k = lane + 64 * u;
 			Ew[u] = *reinterpret_cast<const uint32_t *>(A + (2 * k) * LS + c); Ow[u] = *reinterpret_cast<const uint32_t *>(A + (2 * k + 1) * LS + c);
 		}
-		/* Two columns side by side in packed 16-bit arithmetic wherever nothing can leave 16 bits: with every cell of the wavefront's two columns in
-		 * -1300 .. 3000 the un-normalised sums stay inside (10 x 3000 + 2 x 1300 < 32768) -- which is every block of a real picture (the level-2
-		 * input is LL1, the level-1 chroma input a byte plane).  A block outside that range takes the 32-bit form below, which follows the
-		 * reference's int arithmetic where it wraps. */
-		bool wide = false;
-#pragma unroll
-		for (int u = 0; u < PPL; u++) {
-			const uint32_t mx = pk_max_u16x(pk_add16(Ew[u], 0x05140514u), pk_add16(Ow[u], 0x05140514u));   /* + 1300: in range = at most 4300 as unsigned */
-			wide |= (mx & 0xFFFFu) > 4300u || (mx >> 16) > 4300u;
-		}
-		if (!__any(wide)) {
-			uint32_t rlast = 0;
-#pragma unroll
-			for (int u = 0; u < PPL; u++) {
-				const int k = lane + 64 * u;
-				uint32_t em = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x138, 0xF, 0xF, false), om = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ow[u], 0x138, 0xF, 0xF, false);
-				uint32_t en = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x130, 0xF, 0xF, false);
-				if (u > 0) {
-					const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u > 0 ? u - 1 : 0], 63), so_ = (uint32_t)__builtin_amdgcn_readlane((int)Ow[u > 0 ? u - 1 : 0], 63);
-					if (lane == 0) { em = se; om = so_; }
-				}
-				if (u + 1 < PPL) { const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u + 1 < PPL ? u + 1 : u], 0); if (lane == 63) en = se; }
-				else if (lane == 63) en = Ew[u];
-				if (u == 0 && lane == 0) { em = en; om = Ow[u]; }
-				const s16x2 e0 = as_s(Ew[u]), o0 = as_s(Ow[u]), em1 = as_s(em), om1 = as_s(om), e1 = as_s(en);
-				const s16x2 r = e0 * (s16x2)(short)6 + ((om1 + o0) << 1) - (em1 + e1);
-				s16x2 a = e0 + e1;
-				a = a + (a & (em1 + e0) & as_s((k & 1) ? 0x00010001u : 0u));
-				const s16x2 pp = o0 - (a >> 1), tail = o0 - e0;
-				s16x2 l, h;
-				if (left) {
-					uint32_t rp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)as_w(r), 0x138, 0xF, 0xF, false);
-					if (lane == 0) rp = rlast;
-					const s16x2 carry = k > 0 ? pk_diffuse(as_s(rp)) : (s16x2)(short)0;
-					rlast = (uint32_t)__builtin_amdgcn_readlane((int)as_w(r), 63);
-					l = pk_rnd_half_away(r + carry, 6);
-					h = k < HLF - 1 ? pk_rnd_half_away(pp, 3) : (tail >> 3);
-				} else {
-					l = pk_rnd_half_away(r, 4);
-					h = k < HLF - 1 ? pk_rnd_half_away(pp, 1) : ((tail + (s16x2)(short)1) >> 1);   /* pp > 0 ? (pp + 1) >> 1 : pp >> 1 is rounding half away at shift 1 */
-				}
-				lo[u][0] = l.x; lo[u][1] = l.y; hi[u][0] = h.x; hi[u][1] = h.y;
-			}
-		} else {
-		int rlast[2] = { 0, 0 };                                    /* r of cell 63 of the half before (the seam of the carry) */
-#pragma unroll
-			for (int u = 0; u < PPL; u++) {
-				const int k = lane + 64 * u;
-				uint32_t em = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x138, 0xF, 0xF, false), om = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ow[u], 0x138, 0xF, 0xF, false);
-				uint32_t en = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Ew[u], 0x130, 0xF, 0xF, false);
-				if (u > 0) {
-					const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u > 0 ? u - 1 : 0], 63), so_ = (uint32_t)__builtin_amdgcn_readlane((int)Ow[u > 0 ? u - 1 : 0], 63);
-					if (lane == 0) { em = se; om = so_; }
-				}
-				if (u + 1 < PPL) { const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)Ew[u + 1 < PPL ? u + 1 : u], 0); if (lane == 63) en = se; }
-				else if (lane == 63) en = Ew[u];                           /* x[S] = x[S - 2] */
-				if (u == 0 && lane == 0) { em = en; om = Ow[u]; }           /* x[-2] = x[2], x[-1] = x[1] */
-#pragma unroll
-				for (int h = 0; h < 2; h++) {
-					const int e0 = h ? (int)Ew[u] >> 16 : (int16_t)(Ew[u] & 0xFFFF), o0 = h ? (int)Ow[u] >> 16 : (int16_t)(Ow[u] & 0xFFFF);
-					const int em1 = h ? (int)em >> 16 : (int16_t)(em & 0xFFFF), om1 = h ? (int)om >> 16 : (int16_t)(om & 0xFFFF), e1 = h ? (int)en >> 16 : (int16_t)(en & 0xFFFF);
-					const int r = 6 * e0 + 2 * (om1 + o0) - (em1 + e1);
-					int a = e0 + e1;
-					if ((k & 1) && (a & 1) && ((em1 + e0) & 1)) a++;
-					const int pp = o0 - (a >> 1), tail = o0 - e0;          /* the predicted odd sample; the last one: x[S-1] - x[S-2] */
-					if (left) {
-						int rp = __builtin_amdgcn_update_dpp(0, r, 0x138, 0xF, 0xF, false);   /* the cell before: its carry comes in (filters.c:203-287) */
-						if (lane == 0) rp = rlast[h];
-						const int carry = k > 0 ? diffuse(rp) : 0;
-						rlast[h] = __builtin_amdgcn_readlane(r, 63);
-						lo[u][h] = rnd_half_away((int16_t)(r + carry), 6);
-						hi[u][h] = k < HLF - 1 ? rnd_half_away(pp, 3) : (tail >> 3);
-					} else {
-						lo[u][h] = rnd_half_away(r, 4);
-						hi[u][h] = k < HLF - 1 ? (pp > 0 ? (pp + 1) >> 1 : pp >> 1) : ((tail + 1) >> 1);
-					}
-				}
-			}
-		}
+		ana_col_pair<PPL, HLF>(Ew, Ow, left, lane, lo, hi);
 #pragma unroll
 		for (int h = 0; h < 2; h++) {
 			int16_t *o = proc + (size_t)(c + h) * stride;
@@ -482,6 +490,92 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 	}
 	}
 	lds_barrier();                                                 /* the block is done with before the next one moves in */
+	}
+}
+
+/* The level-1 analysis of a 4:2:0 chroma plane (256 x 256 bytes -> the coefficient plane, the LL quadrant in natural orientation and its copy), a
+ * QUARTER of the block to a workgroup: quarter (xh, part) owns the 64 first-direction outputs 64 part .. 64 part + 63 of the low-pass (xh = 0) or
+ * high-pass (xh = 1) half of every row -- it reads its 132 bytes of each row straight from the byte plane, filters them on the way into LDS
+ * (256 rows x 64 cells, 33 KB: four workgroups a CU), runs the second direction down its 64 columns and writes 64 whole rows of the coefficient
+ * plane.  k_dwt_ana<256> holds the block in one 1024-thread workgroup a CU, whose load, filter and store phases follow one another: 0.36 ms a
+ * launch for 1.07 GB; four independent workgroups a CU keep the memory system busy through each other's filter phases.
+ * Block b -> picture ((b >> 5) << 3) | (b & 7), quarter (b >> 3) & 3: the four quarters of a picture sit on one XCD (b mod 8) and read the
+ * picture's bytes through one L2. */
+#define CQ_LS 66
+#define CQ_ROW(r) ((((r) & 1) * 128 + ((r) >> 1)) * CQ_LS)   /* even rows first, then the odd ones: the column pass reads a lane's even row and odd row at a pitch of 33 dwords each -- no bank conflicts (k_dwt_ana's 129-dword pitch puts rows 2k on 16 banks) */
+__global__ __launch_bounds__(256) void k_chroma_l1q(const uint8_t *__restrict__ src8b, size_t src8_plane, int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
+                                                    int16_t *__restrict__ saveb, size_t save_plane, int save_row, int n)
+{
+	constexpr int S = 256, HLF = 128, PPL = 2, stride = 256;
+	__shared__ __attribute__((aligned(16))) int16_t A[S * CQ_LS];
+	__shared__ uint16_t s_halo[S];
+	const int b = blockIdx.x, img = ((b >> 5) << 3) | (b & 7), qd = (b >> 3) & 3;
+	if (img >= n) return;
+	const int xh = qd >> 1, part = qd & 1;
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const uint8_t *src = src8b + (size_t)img * src8_plane;
+	int16_t *proc = procb + (size_t)img * plane_stride, *jpeg = jpegb + (size_t)img * plane_stride;
+	/* what lies beside the quarter's 128 bytes of a row: bytes 126, 127 on the left of the second quarter, byte 128 on the right of the first (the
+	 * row's own ends mirror: x[-2] = x[2], x[-1] = x[1], x[256] = x[254]) */
+	s_halo[t] = part ? *reinterpret_cast<const uint16_t *>(src + (size_t)t * S + 126) : (uint16_t)src[(size_t)t * S + 128];
+	/* first direction (filters.c:40-86): a lane four bytes = two outputs of a row, half a wavefront a row; un-normalised taps */
+	const int rsub = lane >> 5, kk = lane & 31;
+	uint32_t w[8];
+#pragma unroll 1
+	for (int it0 = 0; it0 < 32; it0 += 8) {
+#pragma unroll
+		for (int j = 0; j < 8; j++) w[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)((it0 + j) * 8 + wv * 2 + rsub) * S + 128 * part + 4 * kk);
+		if (it0 == 0) __syncthreads();                              /* the halo is in place */
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const int row = (it0 + j) * 8 + wv * 2 + rsub;
+			const uint32_t x = w[j];
+			uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+			uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+			const uint32_t hl = s_halo[row];
+			const int b0 = x & 255, b1 = (x >> 8) & 255, b2 = (x >> 16) & 255, b3 = x >> 24;
+			int p2 = (pv >> 16) & 255, p3 = pv >> 24, n0 = nx & 255;
+			if (kk == 0) { p2 = part ? (int)(hl & 255) : b2; p3 = part ? (int)(hl >> 8) : b1; }
+			if (kk == 31) n0 = part ? b2 : (int)(hl & 255);
+			int o0, o1;
+			if (xh == 0) { o0 = 6 * b0 + 2 * (p3 + b1) - (p2 + b2); o1 = 6 * b2 + 2 * (b1 + b3) - (b0 + n0); }
+			else { o0 = 2 * b1 - (b0 + b2); o1 = 2 * b3 - (b2 + n0); }
+			*reinterpret_cast<uint32_t *>(A + CQ_ROW(row) + 2 * kk) = (uint32_t)(uint16_t)o0 | ((uint32_t)(uint16_t)o1 << 16);
+		}
+	}
+	__syncthreads();
+	/* second direction down the quarter's columns, two at a time; a wavefront 16 columns */
+	const bool left = xh == 0;
+	const int cbase = HLF * xh + 64 * part;                            /* the quarter's first row of the coefficient plane */
+	for (int i = 0; i < 8; i++) {
+		const int c = wv * 16 + 2 * i;
+		uint32_t Ew[PPL], Ow[PPL];
+		int lo[PPL][2], hi[PPL][2];
+#pragma unroll
+		for (int u = 0; u < PPL; u++) {
+			const int k = lane + 64 * u;
+			Ew[u] = *reinterpret_cast<const uint32_t *>(A + CQ_ROW(2 * k) + c); Ow[u] = *reinterpret_cast<const uint32_t *>(A + CQ_ROW(2 * k + 1) + c);
+		}
+		ana_col_pair<PPL, HLF>(Ew, Ow, left, lane, lo, hi);
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			int16_t *o = proc + (size_t)(cbase + c + h) * stride;
+#pragma unroll
+			for (int u = 0; u < PPL; u++) { const int k = lane + 64 * u; o[k] = (int16_t)lo[u][h]; o[HLF + k] = (int16_t)hi[u][h]; }
+		}
+		if (left) {                                                  /* LL, parked in the columns' own cells (every lane has read its taps by now) */
+#pragma unroll
+			for (int u = 0; u < PPL; u++) *reinterpret_cast<uint32_t *>(A + CQ_ROW(lane + 64 * u) + c) = (uint32_t)(uint16_t)lo[u][0] | ((uint32_t)(uint16_t)lo[u][1] << 16);
+		}
+	}
+	if (!left) return;
+	__syncthreads();
+	int16_t *save = saveb ? saveb + (size_t)img * save_plane : nullptr;
+	for (int v = t; v < HLF * 32; v += 256) {                          /* LL copied back in natural orientation (wavelet_filterbank.c:172-184), and its copy */
+		const int k = v >> 5, c = 2 * (v & 31);
+		const uint32_t wd = *reinterpret_cast<const uint32_t *>(A + CQ_ROW(k) + c);
+		*reinterpret_cast<uint32_t *>(jpeg + (size_t)k * stride + 64 * part + c) = wd;
+		if (save) *reinterpret_cast<uint32_t *>(save + (size_t)k * save_row + 64 * part + c) = wd;
 	}
 }
 
@@ -580,7 +674,10 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
                          const int16_t *alt, size_t alt_plane, int alt_stride)
 {
 	if (!save) save_kind = 0;
-	if (size == 256) k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane, drop_t, alt, alt_plane, alt_stride);
+	static const int quarters = getenv("NHW_CHROMA_L1Q") ? atoi(getenv("NHW_CHROMA_L1Q")) : 1;
+	if (size == 256 && src8 && !final_level && drop_t && save_kind != 1 && !alt && stride == 256 && quarters)   /* the encoder's chroma level 1 from the byte plane */
+		k_chroma_l1q<<<4 * ((n + 7) & ~7), 256, 0, s>>>(src8, src8_plane, proc, jpeg, plane_stride, save_kind == 2 ? save : nullptr, save_plane, save_row, n);
+	else if (size == 256) k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane, drop_t, alt, alt_plane, alt_stride);
 	else if (size == 128) k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0, drop_t, nullptr, 0, 0);
 	else {   /* size 512 is the front kernels' (nhw_launch_front_fused); a caller with any other size would get stale planes: stop loudly */
 		fprintf(stderr, "nhw_launch_analysis: no kernel for transform size %d (256 and 128 only; 512 is nhw_launch_front_fused)\n", size);
