@@ -12,7 +12,8 @@ WV = ["DQ1", "DQ0", "EMIT", "QUANT"]
 WHAT = {
     "k_front_image": "a1 + a2 + Y2 + Y3 fused: BGR24 -> Y, 4:2:0 chroma planes out, pre-filter (carry chained in the kernel), both directions of the level-1 analysis, LL copy; a workgroup walks an image (32 rows a band, 512 threads, 78 KB LDS)",
     "k_front_plain": "the same without the pre-filter (q >= 22; q <= 16 and the analysis stage from a luma plane): horizontal pass from registers, 64 rows a band",
-    "k_dwt_ana<256>": "level-1 chroma analysis, level-2 luma analysis of both closed loops (whole block in LDS, persistent workgroups)",
+    "k_dwt_ana<256>": "level-2 luma analysis of both closed loops (whole block in LDS, persistent workgroups); level-1 chroma analysis only for q <= 14 and the stage checks",
+    "k_chroma_l1q": "level-1 chroma analysis from the 4:2:0 byte plane, a quarter of the 256 x 256 block to a workgroup (four a CU); its coefficients are part of SURVEY's 6 B/pixel",
     "k_dwt_ana<128>": "level-2 chroma analysis",
     "k_dwt_syn<256>": "level-2 luma synthesis of the second closed loop",
     "k_dwt_syn<128>": "level-2 chroma synthesis",
