@@ -39,7 +39,12 @@ namespace nhw {
 #define FI_KROWS 37                  /* horizontal-pass rows 32b-4 .. 32b+32 (index = row - 32b + 4); rows 5.. hold the contrast / kernel map before that */
 #define FI_SEG   32                  /* pixels per carry segment */
 #define FI_NSEG  16
-#define FI_LOOK  12                  /* pixels of look-back for a segment's entry state */
+#ifndef FI_LOOK
+#define FI_LOOK  12                  /* pixels of look-back for a segment's entry state ... */
+#define FI_LOOK2 32                  /* ... and of the second look of the lanes whose candidates have not merged by then (round 6): what is still open after it goes
+                                      * to the serial replay, which cost 0.17 ms a batch with the first look alone (tools/dev/look_ab.sh, q20 front kernel: one look
+                                      * of 8 / 10 / 12 / 16 / 20 pixels 5.7 / 3.5 / 3.01 / 2.88 / 2.89 ms; 12 + 32: 2.84, 16 + 32: 2.86, 10 + 32: 2.85, 12 + 24: 2.85) */
+#endif
 /* byte offsets into the dynamic LDS block */
 #define FI_YB_OFF   16
 #define FI_KB_OFF   (FI_YB_OFF + FI_YROWS * FI_YRS * 2)
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 			FI_DUMP(6, ybuf + 3 * FI_YRS, 1);
 			/* ------------------------------------------------------------ carry state at the start of every 32-pixel segment (image_processing.c:641-700).
 			 * The carry is a 16-state machine that runs in raster order over the interior of the whole image.  A step maps the 16 states onto at
-			 * most five neighbouring ones and a zero sum resets it: run five candidates (5-bit fields of one dword) through the 12 pixels in
+			 * most five neighbouring ones and a zero sum resets it: run five candidates (5-bit fields of one dword) through the 12 pixels (where they have not merged by then: the 32 pixels) in
 			 * front of the segment -- for a row's first segment the end of the row above --; if they end in one state, that is the entry state
 			 * whatever came before.  Where they do not (rare), the segments are replayed in order from the one before.  The band's first
 			 * segment continues from where the band before stopped. */
@@ -469,15 +474,22 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 				if (r0 + rr <= W - 2) {
 					if (sg == 0 && rr == 1) e = misc[0];
 					else {
-						const int16_t *km = sg ? kbuf + (rr + 4) * FI_RS + 1 + FI_SEG * sg - FI_LOOK : kbuf + (rr + 3) * FI_RS + (W - 1 - FI_LOOK);
+						const int16_t *kend = sg ? kbuf + (rr + 4) * FI_RS + 1 + FI_SEG * sg : kbuf + (rr + 3) * FI_RS + (W - 1);   /* the first cell behind the look-back */
 						const uint32_t R = 0x108421u;                    /* 1 in each field */
-						uint32_t x = km[0] == 0 ? 0u : ((((uint32_t)iabs(km[0]) & 15u) * R + 0x418820u) & (15u * R));
-						for (int i = 1; i < FI_LOOK; i++) {
-							const int vb = km[i];
-							const uint32_t nx = (((uint32_t)iabs(vb) & 15u) * R + (((x + 2u * R) >> 2) & (7u * R))) & (15u * R);
-							x = vb == 0 ? 0u : nx;
-						}
-						e = (x == (x & 31u) * R && !(flags & 1)) ? (int)(x & 15u) : 0xFF;
+						auto look = [&](const int len) -> int {
+							const int16_t *km = kend - len;
+							uint32_t x = km[0] == 0 ? 0u : ((((uint32_t)iabs(km[0]) & 15u) * R + 0x418820u) & (15u * R));
+							for (int i = 1; i < len; i++) {
+								const int vb = km[i];
+								const uint32_t nx = (((uint32_t)iabs(vb) & 15u) * R + (((x + 2u * R) >> 2) & (7u * R))) & (15u * R);
+								x = vb == 0 ? 0u : nx;
+							}
+							return (x == (x & 31u) * R && !(flags & 1)) ? (int)(x & 15u) : 0xFF;
+						};
+						e = look(FI_LOOK);
+#ifdef FI_LOOK2
+						if (e == 0xFF && !(flags & 1)) e = look(FI_LOOK2);   /* a second, longer look where the first has not merged: only the wavefronts with such a lane pay for it */
+#endif
 					}
 					entry[(rr - 1) * FI_NSEG + sg] = (uint8_t)e;
 				}
