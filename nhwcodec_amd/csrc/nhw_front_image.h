@@ -493,7 +493,9 @@ __global__ __launch_bounds__(FI_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 					}
 					entry[(rr - 1) * FI_NSEG + sg] = (uint8_t)e;
 				}
+#ifndef FI_TIMING_NO_SERIAL   /* (developer timing experiment: what the serial replay still costs -- results are wrong without it) */
 				if (e == 0xFF) misc[8] = 1;                              /* (cleared again in the pair-rule phase) */
+#endif
 				__syncthreads();
 				if (misc[8]) {
 					if (t == 0) {

@@ -1,4 +1,5 @@
-# Developer tool (GPU box): front kernel time (hipEvents, mean of 30 batches) for builds with different look-back lengths (tools/dev/look<N>.so), interleaved twice.
+# Developer tool (GPU box): front kernel time (hipEvents, mean of 30 batches) for builds with different look-back lengths, interleaved twice.  The builds:
+# bash tools/dev/build_variant.sh look16b -DFI_LOOK2=32 ; ... look12b "-DFI_LOOK=12 -DFI_LOOK2=32" ; -DFI_TIMING_NO_SERIAL: what the serial replay still costs (nothing measurable).
 cd $GRAFT_REPO_ROOT; cp nhwcodec_amd/libnhwhip.so /tmp/orig.so
 cat > /tmp/ft.py <<'P'
 import sys, torch
@@ -13,7 +14,7 @@ for q in (20, 17, 19):
     print(f"q{q} front {acc / 30:.3f}", end="  ")
 print()
 P
-for rep in 1 2; do for v in look12b lookA lookB lookC lookD; do
+for rep in 1 2; do for v in orig look16b look12b; do
   if [ $v = orig ]; then cp /tmp/orig.so nhwcodec_amd/libnhwhip.so; else cp tools/dev/$v.so nhwcodec_amd/libnhwhip.so; fi
   echo "$v: $(timeout 200 python /tmp/ft.py 2>&1 | tail -1)"
 done; done
