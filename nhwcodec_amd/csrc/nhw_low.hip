@@ -520,8 +520,12 @@ __global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb
 			carry_out = __builtin_amdgcn_readlane(carry, 63);
 			return __builtin_amdgcn_readlane((int)merged, 63) != 0;
 		}
+#ifdef PRE_TIMING_NO_SERIAL   /* (developer timing experiment, tools/dev/pre_ab.sh: what the row replays cost -- results are wrong without them) */
+		if (false) {
+#else
 		if (__any(!merged)) {
-			/* rare: some lane's 16 states had not merged within the look-back -- the row is replayed by one lane */
+#endif
+			/* some lane's 16 states had not merged within the look-back -- the row is replayed by one lane (9 % of this kernel's time) */
 			if (lane == 0) {
 				int cr = carry_in;
 				for (int c = 1; c < W - 1; c++) {
