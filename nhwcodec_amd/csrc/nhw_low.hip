@@ -505,41 +505,35 @@ __global__ __launch_bounds__(64) void k_low_pre(const int16_t *__restrict__ srcb
 			carry = (int)(x & 15u);
 		}
 		int valv[8];
-		for (int e = 0; e < 8; e++) {
-			const int vb = vbv[e];
-			valv[e] = 0;
-			if (c0 + e < 1 || c0 + e > W - 2) continue;
-			if (vb == 0) carry = 0;
-			else {
-				const int acc = iabs_(vb) + ((carry + 2) >> 2);
-				valv[e] = vb < 0 ? -(acc >> 4) : (acc >> 4);
-				carry = acc & 15;
+		auto run8 = [&](int cr) -> int {                                /* my eight cells from the entry state cr: their map values, the state behind them */
+			for (int e = 0; e < 8; e++) {
+				const int vb = vbv[e];
+				valv[e] = 0;
+				if (c0 + e < 1 || c0 + e > W - 2) continue;
+				if (vb == 0) cr = 0;
+				else {
+					const int acc = iabs_(vb) + ((cr + 2) >> 2);
+					valv[e] = vb < 0 ? -(acc >> 4) : (acc >> 4);
+					cr = acc & 15;
+				}
 			}
-		}
+			return cr;
+		};
+		int exit_c = run8(carry);
 		if (!known) {                                                   /* a row worked through for its exit state only: the last lane's, if its candidates merged */
-			carry_out = __builtin_amdgcn_readlane(carry, 63);
+			carry_out = __builtin_amdgcn_readlane(exit_c, 63);
 			return __builtin_amdgcn_readlane((int)merged, 63) != 0;
 		}
-#ifdef PRE_TIMING_NO_SERIAL   /* (developer timing experiment, tools/dev/pre_ab.sh: what the row replays cost -- results are wrong without them) */
-		if (false) {
-#else
-		if (__any(!merged)) {
+#ifndef PRE_TIMING_NO_SERIAL   /* (developer timing experiment, tools/dev/pre_ab.sh: what the open lanes cost -- results are wrong without this) */
+		/* Lanes whose sixteen states had not merged within the look-back (stretches of constant contrast: the carry is periodic there and never
+		 * forgets) take their entry state from the lane on their left as soon as that one has its own -- lane 0 always has: it starts from the
+		 * row's entry state --, a lane of every open run a round.  (Until round 6 one lane replayed the whole row, at the same cost: the runs are long.  9 % of this kernel's time) */
+		while (__any(!merged)) {
+			const int up_c = __shfl_up(exit_c, 1), up_ok = __shfl_up((int)merged, 1);
+			if (!merged && up_ok) { merged = true; exit_c = run8(up_c); }
+		}
 #endif
-			/* some lane's 16 states had not merged within the look-back -- the row is replayed by one lane (9 % of this kernel's time) */
-			if (lane == 0) {
-				int cr = carry_in;
-				for (int c = 1; c < W - 1; c++) {
-					const int vb = s_vb[c];
-					int val = 0;
-					if (vb == 0) cr = 0; else { const int acc = iabs_(vb) + ((cr + 2) >> 2); val = vb < 0 ? -(acc >> 4) : (acc >> 4); cr = acc & 15; }
-					km[c] = (int16_t)val;
-				}
-				s_misc[0] = cr;
-			}
-			__syncthreads();
-			for (int e = 0; e < 8; e++) valv[e] = (c0 + e >= 1 && c0 + e <= W - 2) ? (int)km[c0 + e] : 0;
-			carry_out = LDK(&s_misc[0]);
-		} else carry_out = __builtin_amdgcn_readlane(carry, 63);
+		carry_out = __builtin_amdgcn_readlane(exit_c, 63);
 		if (emit) {
 			{ uint32_t w4[4]; for (int e = 0; e < 4; e++) w4[e] = (uint32_t)(uint16_t)valv[2 * e] | ((uint32_t)(uint16_t)valv[2 * e + 1] << 16);
 			  *reinterpret_cast<uint4 *>(kmo + (size_t)r * W + c0) = make_uint4(w4[0], w4[1], w4[2], w4[3]); }
