@@ -518,31 +518,43 @@ __global__ __launch_bounds__(256) void k_chroma_l1q(const uint8_t *__restrict__ 
 	/* what lies beside the quarter's 128 bytes of a row: bytes 126, 127 on the left of the second quarter, byte 128 on the right of the first (the
 	 * row's own ends mirror: x[-2] = x[2], x[-1] = x[1], x[256] = x[254]) */
 	s_halo[t] = part ? *reinterpret_cast<const uint16_t *>(src + (size_t)t * S + 126) : (uint16_t)src[(size_t)t * S + 128];
-	/* first direction (filters.c:40-86): a lane four bytes = two outputs of a row, half a wavefront a row; un-normalised taps */
+	/* first direction (filters.c:40-86): a lane four bytes = two outputs of a row, half a wavefront a row; un-normalised taps as byte dot products
+	 * (v_dot4_u32_u8: the positive and the negative taps apart).  The bytes on either side of the lane's four come over DPP; the quarter's first and
+	 * last lane of a row take them from the halo or the row's mirror. */
 	const int rsub = lane >> 5, kk = lane & 31;
 	uint32_t w[8];
+	auto first_dir = [&](auto xh_tag) {
+		constexpr int XH = decltype(xh_tag)::value;
 #pragma unroll 1
-	for (int it0 = 0; it0 < 32; it0 += 8) {
+		for (int it0 = 0; it0 < 32; it0 += 8) {
 #pragma unroll
-		for (int j = 0; j < 8; j++) w[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)((it0 + j) * 8 + wv * 2 + rsub) * S + 128 * part + 4 * kk);
-		if (it0 == 0) __syncthreads();                              /* the halo is in place */
+			for (int j = 0; j < 8; j++) w[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)((it0 + j) * 8 + wv * 2 + rsub) * S + 128 * part + 4 * kk);
+			if (it0 == 0) __syncthreads();                              /* the halo is in place */
 #pragma unroll
-		for (int j = 0; j < 8; j++) {
-			const int row = (it0 + j) * 8 + wv * 2 + rsub;
-			const uint32_t x = w[j];
-			uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-			uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-			const uint32_t hl = s_halo[row];
-			const int b0 = x & 255, b1 = (x >> 8) & 255, b2 = (x >> 16) & 255, b3 = x >> 24;
-			int p2 = (pv >> 16) & 255, p3 = pv >> 24, n0 = nx & 255;
-			if (kk == 0) { p2 = part ? (int)(hl & 255) : b2; p3 = part ? (int)(hl >> 8) : b1; }
-			if (kk == 31) n0 = part ? b2 : (int)(hl & 255);
-			int o0, o1;
-			if (xh == 0) { o0 = 6 * b0 + 2 * (p3 + b1) - (p2 + b2); o1 = 6 * b2 + 2 * (b1 + b3) - (b0 + n0); }
-			else { o0 = 2 * b1 - (b0 + b2); o1 = 2 * b3 - (b2 + n0); }
-			*reinterpret_cast<uint32_t *>(A + CQ_ROW(row) + 2 * kk) = (uint32_t)(uint16_t)o0 | ((uint32_t)(uint16_t)o1 << 16);
+			for (int j = 0; j < 8; j++) {
+				const int row = (it0 + j) * 8 + wv * 2 + rsub;
+				const uint32_t x = w[j];
+				uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+				uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+				const uint32_t hl = s_halo[row];
+				/* bytes 2, 3 of pv = the two cells on my left, byte 0 of nx = the cell on my right */
+				const uint32_t pv_edge = part ? hl << 16 : __builtin_amdgcn_perm(x, x, 0x01020000u);   /* mirror: x[-2] = x[2] (my byte 2), x[-1] = x[1] (my byte 1) */
+				const uint32_t nx_edge = part ? (x >> 16) & 255u : hl & 255u;                              /* mirror: x[256] = x[254] (my byte 2) */
+				pv = kk == 0 ? pv_edge : pv;
+				nx = kk == 31 ? nx_edge : nx;
+				uint32_t o0, o1;
+				if (XH == 0) {
+					o0 = __builtin_amdgcn_udot4(x, 0x00000206u, __builtin_amdgcn_udot4(pv, 0x02000000u, 0u, false), false) - __builtin_amdgcn_udot4(x, 0x00010000u, __builtin_amdgcn_udot4(pv, 0x00010000u, 0u, false), false);
+					o1 = __builtin_amdgcn_udot4(x, 0x02060200u, 0u, false) - __builtin_amdgcn_udot4(x, 0x00000001u, __builtin_amdgcn_udot4(nx, 0x00000001u, 0u, false), false);
+				} else {
+					o0 = __builtin_amdgcn_udot4(x, 0x00000200u, 0u, false) - __builtin_amdgcn_udot4(x, 0x00010001u, 0u, false);
+					o1 = __builtin_amdgcn_udot4(x, 0x02000000u, 0u, false) - __builtin_amdgcn_udot4(x, 0x00010000u, __builtin_amdgcn_udot4(nx, 0x00000001u, 0u, false), false);
+				}
+				*reinterpret_cast<uint32_t *>(A + CQ_ROW(row) + 2 * kk) = (o0 & 0xFFFFu) | (o1 << 16);
+			}
 		}
-	}
+	};
+	if (xh == 0) first_dir(std::integral_constant<int, 0>()); else first_dir(std::integral_constant<int, 1>());
 	__syncthreads();
 	/* second direction down the quarter's columns, two at a time; a wavefront 16 columns */
 	const bool left = xh == 0;
