@@ -301,7 +301,7 @@ __device__ __forceinline__ uint4 ana_piece(const int16_t *src, const uint8_t *sr
 }
 /* The second direction (filters.c:88-287) of two columns at once: Ew / Ow hold the even / odd rows' cells of the two columns, a lane its own row pair
  * k = lane + 64 u; lo / hi: what the pair leaves for its two columns.  left: the columns lie in the first direction's low-pass half. */
-template <int PPL, int HLF>
+template <int PPL, int HLF, bool IN_RANGE = false /* the caller vouches for the 16-bit range (cells made from bytes): no test, no 32-bit form */>
 __device__ __forceinline__ void ana_col_pair(const uint32_t (&Ew)[PPL], const uint32_t (&Ow)[PPL], bool left, int lane, int (&lo)[PPL][2], int (&hi)[PPL][2])
 {
 	/* Two columns side by side in packed 16-bit arithmetic wherever nothing can leave 16 bits: with every cell of the wavefront's two columns in
@@ -309,12 +309,13 @@ __device__ __forceinline__ void ana_col_pair(const uint32_t (&Ew)[PPL], const ui
 	 * input is LL1, the level-1 chroma input a byte plane).  A block outside that range takes the 32-bit form below, which follows the
 	 * reference's int arithmetic where it wraps. */
 	bool wide = false;
+	if (!IN_RANGE)
 #pragma unroll
 	for (int u = 0; u < PPL; u++) {
 		const uint32_t mx = pk_max_u16x(pk_add16(Ew[u], 0x05140514u), pk_add16(Ow[u], 0x05140514u));   /* + 1300: in range = at most 4300 as unsigned */
 		wide |= (mx & 0xFFFFu) > 4300u || (mx >> 16) > 4300u;
 	}
-	if (!__any(wide)) {
+	if (IN_RANGE || !__any(wide)) {
 		uint32_t rlast = 0;
 #pragma unroll
 		for (int u = 0; u < PPL; u++) {
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(256) void k_chroma_l1q(const uint8_t *__restrict__ 
 			const int k = lane + 64 * u;
 			Ew[u] = *reinterpret_cast<const uint32_t *>(A + CQ_ROW(2 * k) + c); Ow[u] = *reinterpret_cast<const uint32_t *>(A + CQ_ROW(2 * k + 1) + c);
 		}
-		ana_col_pair<PPL, HLF>(Ew, Ow, left, lane, lo, hi);
+		ana_col_pair<PPL, HLF, true>(Ew, Ow, left, lane, lo, hi);   /* first-pass cells of a byte plane: -510 .. 2550 */
 #pragma unroll
 		for (int h = 0; h < 2; h++) {
 			int16_t *o = proc + (size_t)(cbase + c + h) * stride;
