@@ -523,16 +523,17 @@ __global__ __launch_bounds__(256) void k_chroma_l1q(const uint8_t *__restrict__ 
 	 * (v_dot4_u32_u8: the positive and the negative taps apart).  The bytes on either side of the lane's four come over DPP; the quarter's first and
 	 * last lane of a row take them from the halo or the row's mirror. */
 	const int rsub = lane >> 5, kk = lane & 31;
-	uint32_t w[8];
+	constexpr int CQ_B = 32;                                       /* rows' loads in flight a lane: all of them (8 at a time the workgroup waited for memory four times over: 0.59 ms for the two launches, 16 or 32: 0.51) */
+	uint32_t w[CQ_B];
 	auto first_dir = [&](auto xh_tag) {
 		constexpr int XH = decltype(xh_tag)::value;
 #pragma unroll 1
-		for (int it0 = 0; it0 < 32; it0 += 8) {
+		for (int it0 = 0; it0 < 32; it0 += CQ_B) {
 #pragma unroll
-			for (int j = 0; j < 8; j++) w[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)((it0 + j) * 8 + wv * 2 + rsub) * S + 128 * part + 4 * kk);
+			for (int j = 0; j < CQ_B; j++) w[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)((it0 + j) * 8 + wv * 2 + rsub) * S + 128 * part + 4 * kk);
 			if (it0 == 0) __syncthreads();                              /* the halo is in place */
 #pragma unroll
-			for (int j = 0; j < 8; j++) {
+			for (int j = 0; j < CQ_B; j++) {
 				const int row = (it0 + j) * 8 + wv * 2 + rsub;
 				const uint32_t x = w[j];
 				uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
