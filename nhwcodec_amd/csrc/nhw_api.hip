@@ -272,11 +272,12 @@ static int run_batch(nhw_enc *e, const NhwWs &ws_in, const void *d_bgr, int n, i
 		else if (!widen_in_analysis) nhw_launch_phase(PH_C0, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
 		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H, 0, cs, cll1, ws.stride[B_CLL1] / 2, H / 2, 2,   /* + the copy of LL1 */
-		                    widen_in_analysis ? (comp ? plane8(ws, B_PV) : plane8(ws, B_PU)) : nullptr, ws.stride[B_PU], !ws.dbg);
+		                    widen_in_analysis ? (comp ? plane8(ws, B_PV) : plane8(ws, B_PU)) : nullptr, ws.stride[B_PU], ws.dbg ? 0 : 2);   /* 2: nor the LL quadrant back into the work plane -- the level-2 analysis below reads its copy */
 		if (low) nhw_launch_low_chroma_thin(cproc, cps, n, cs);      /* :2277-2308 / :2590-2621 */
 		STAGE_DONE();
 		STAGE_DONE();
-		nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, cs, nullptr, 0, 0, 0, nullptr, 0, !ws.dbg);
+		if (ws.dbg) nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, cs, nullptr, 0, 0, 0, nullptr, 0, 0);
+		else nhw_launch_analysis(cjpeg, cproc, n, cps, H, H / 2, 1, cs, nullptr, 0, 0, 0, nullptr, 0, 1, cll1, ws.stride[B_CLL1] / 2, H / 2);   /* from the copy of LL1 */
 		STAGE_DONE();
 		nhw_launch_phase(PH_C2, ws, comp, out, d_sizes, d_status, cs);
 		STAGE_DONE();
@@ -665,7 +666,7 @@ extern "C" int nhw_stage_chroma_l1(nhw_enc *e, int n, void *stream)
 	HIPCHK(hipStreamWaitEvent(s, e->ev[4], 0));                     /* behind that batch, whatever stream it ran on: its chroma sequence (a stream of the handle) works in the planes written here */
 	for (int comp = 0; comp < 2; comp++)
 		nhw_launch_analysis(plane16(ws, B_CJPEG), plane16(ws, B_CPROC), n, ws.stride[B_CJPEG] / 2, H, H, 0, s, plane16(ws, B_CLL1), ws.stride[B_CLL1] / 2, H / 2, 2,
-		                    comp ? plane8(ws, B_PV) : plane8(ws, B_PU), ws.stride[B_PU], 1);
+		                    comp ? plane8(ws, B_PV) : plane8(ws, B_PU), ws.stride[B_PU], 2);
 	HIPCHK(hipGetLastError());
 	return NHW_OK;
 }

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
 #define CQ_LS 66
 #define CQ_ROW(r) ((((r) & 1) * 128 + ((r) >> 1)) * CQ_LS)   /* even rows first, then the odd ones: the column pass reads a lane's even row and odd row at a pitch of 33 dwords each -- no bank conflicts (k_dwt_ana's 129-dword pitch puts rows 2k on 16 banks) */
 __global__ __launch_bounds__(256) void k_chroma_l1q(const uint8_t *__restrict__ src8b, size_t src8_plane, int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
-                                                    int16_t *__restrict__ saveb, size_t save_plane, int save_row, int n)
+                                                    int16_t *__restrict__ saveb, size_t save_plane, int save_row, int n, int ll_to_jpeg /* 0: the LL quadrant only goes to its copy (the level-2 analysis reads it there) */)
 {
 	constexpr int S = 256, HLF = 128, PPL = 2, stride = 256;
 	__shared__ __attribute__((aligned(16))) int16_t A[S * CQ_LS];
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void k_chroma_l1q(const uint8_t *__restrict__ 
 	for (int v = t; v < HLF * 32; v += 256) {                          /* LL copied back in natural orientation (wavelet_filterbank.c:172-184), and its copy */
 		const int k = v >> 5, c = 2 * (v & 31);
 		const uint32_t wd = *reinterpret_cast<const uint32_t *>(A + CQ_ROW(k) + c);
-		*reinterpret_cast<uint32_t *>(jpeg + (size_t)k * stride + 64 * part + c) = wd;
+		if (ll_to_jpeg) *reinterpret_cast<uint32_t *>(jpeg + (size_t)k * stride + 64 * part + c) = wd;
 		if (save) *reinterpret_cast<uint32_t *>(save + (size_t)k * save_row + 64 * part + c) = wd;
 	}
 }
@@ -690,9 +690,9 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
 	if (!save) save_kind = 0;
 	static const int quarters = getenv("NHW_CHROMA_L1Q") ? atoi(getenv("NHW_CHROMA_L1Q")) : 1;
 	if (size == 256 && src8 && !final_level && drop_t && save_kind != 1 && !alt && stride == 256 && quarters)   /* the encoder's chroma level 1 from the byte plane */
-		k_chroma_l1q<<<4 * ((n + 7) & ~7), 256, 0, s>>>(src8, src8_plane, proc, jpeg, plane_stride, save_kind == 2 ? save : nullptr, save_plane, save_row, n);
+		k_chroma_l1q<<<4 * ((n + 7) & ~7), 256, 0, s>>>(src8, src8_plane, proc, jpeg, plane_stride, save_kind == 2 ? save : nullptr, save_plane, save_row, n, !(drop_t == 2 && save_kind == 2));
 	else if (size == 256) k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane, drop_t, alt, alt_plane, alt_stride);
-	else if (size == 128) k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0, drop_t, nullptr, 0, 0);
+	else if (size == 128) k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0, drop_t, alt, alt_plane, alt_stride);
 	else {   /* size 512 is the front kernels' (nhw_launch_front_fused); a caller with any other size would get stale planes: stop loudly */
 		fprintf(stderr, "nhw_launch_analysis: no kernel for transform size %d (256 and 128 only; 512 is nhw_launch_front_fused)\n", size);
 		abort();
