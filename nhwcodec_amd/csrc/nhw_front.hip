@@ -502,72 +502,67 @@ __global__ __launch_bounds__(S * 4) void k_dwt_ana(int16_t *__restrict__ jpegb, 
  * launch for 1.07 GB; four independent workgroups a CU keep the memory system busy through each other's filter phases.
  * Block b -> picture ((b >> 5) << 3) | (b & 7), quarter (b >> 3) & 3: the four quarters of a picture sit on one XCD (b mod 8) and read the
  * picture's bytes through one L2. */
-template <int NQ> struct CqGeom {                                     /* NQ first-direction outputs of a row to a workgroup: 64 (a quarter of the block) or 32 (an eighth) */
-	static constexpr int LS = NQ + 2;                               /* pitch of a row of the tile in shorts: 33 / 17 dwords */
-	static constexpr int NP = 128 / NQ;                             /* parts of a half row */
-	static constexpr int LPR = NQ / 2, RPP = 64 / LPR, NB = 256 / (4 * RPP);   /* lanes a row, rows a wavefront pass, passes */
-};
-/* even rows first, then the odd ones: the column pass reads a lane's even row and odd row at an odd dword pitch each -- no bank conflicts
- * (k_dwt_ana's 129-dword pitch puts rows 2k on 16 banks) */
-#define CQ_ROW(r) ((((r) & 1) * 128 + ((r) >> 1)) * G::LS)
-template <int NQ>
+#define CQ_LS 66
+#define CQ_ROW(r) ((((r) & 1) * 128 + ((r) >> 1)) * CQ_LS)   /* even rows first, then the odd ones: the column pass reads a lane's even row and odd row at a pitch of 33 dwords each -- no bank conflicts (k_dwt_ana's 129-dword pitch puts rows 2k on 16 banks) */
 __global__ __launch_bounds__(256) void k_chroma_l1q(const uint8_t *__restrict__ src8b, size_t src8_plane, int16_t *__restrict__ procb, int16_t *__restrict__ jpegb, size_t plane_stride,
                                                     int16_t *__restrict__ saveb, size_t save_plane, int save_row, int n, int ll_to_jpeg /* 0: the LL quadrant only goes to its copy (the level-2 analysis reads it there) */)
 {
-	using G = CqGeom<NQ>;
 	constexpr int S = 256, HLF = 128, PPL = 2, stride = 256;
-	__shared__ __attribute__((aligned(16))) int16_t A[S * G::LS];
-	__shared__ uint32_t s_halo[S];
-	const int b = blockIdx.x, sub = (b >> 3) % (2 * G::NP), img = (((b >> 3) / (2 * G::NP)) << 3) | (b & 7);
+	__shared__ __attribute__((aligned(16))) int16_t A[S * CQ_LS];
+	__shared__ uint16_t s_halo[S];
+	const int b = blockIdx.x, img = ((b >> 5) << 3) | (b & 7), qd = (b >> 3) & 3;
 	if (img >= n) return;
-	const int xh = sub / G::NP, part = sub % G::NP;
+	const int xh = qd >> 1, part = qd & 1;
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const uint8_t *src = src8b + (size_t)img * src8_plane;
 	int16_t *proc = procb + (size_t)img * plane_stride, *jpeg = jpegb + (size_t)img * plane_stride;
-	const int x0 = 2 * NQ * part;                                   /* the part's first byte of a row */
-	/* what lies beside the part's bytes of a row: the two bytes on its left (low half) and the byte on its right (bits 16 ..); the row's own ends
-	 * mirror: x[-2] = x[2], x[-1] = x[1], x[256] = x[254] */
-	s_halo[t] = (part ? (uint32_t)*reinterpret_cast<const uint16_t *>(src + (size_t)t * S + x0 - 2) : 0u) | (part < G::NP - 1 ? (uint32_t)src[(size_t)t * S + x0 + 2 * NQ] << 16 : 0u);
-	/* first direction (filters.c:40-86): a lane four bytes = two outputs of a row; un-normalised taps as byte dot products (v_dot4_u32_u8: the
-	 * positive and the negative taps apart).  The bytes on either side of the lane's four come over DPP; the part's first and last lane of a row
-	 * take them from the halo or the row's mirror.  All of a lane's row loads are in flight at once. */
-	const int rsub = lane / G::LPR, kk = lane % G::LPR;
-	uint32_t w[G::NB];
+	/* what lies beside the quarter's 128 bytes of a row: bytes 126, 127 on the left of the second quarter, byte 128 on the right of the first (the
+	 * row's own ends mirror: x[-2] = x[2], x[-1] = x[1], x[256] = x[254]) */
+	s_halo[t] = part ? *reinterpret_cast<const uint16_t *>(src + (size_t)t * S + 126) : (uint16_t)src[(size_t)t * S + 128];
+	/* first direction (filters.c:40-86): a lane four bytes = two outputs of a row, half a wavefront a row; un-normalised taps as byte dot products
+	 * (v_dot4_u32_u8: the positive and the negative taps apart).  The bytes on either side of the lane's four come over DPP; the quarter's first and
+	 * last lane of a row take them from the halo or the row's mirror. */
+	const int rsub = lane >> 5, kk = lane & 31;
+	constexpr int CQ_B = 32;                                       /* rows' loads in flight a lane: all of them (8 at a time the workgroup waited for memory four times over: 0.59 ms for the two launches, 16 or 32: 0.51) */
+	uint32_t w[CQ_B];
 	auto first_dir = [&](auto xh_tag) {
 		constexpr int XH = decltype(xh_tag)::value;
+#pragma unroll 1
+		for (int it0 = 0; it0 < 32; it0 += CQ_B) {
 #pragma unroll
-		for (int j = 0; j < G::NB; j++) w[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)(j * 4 * G::RPP + wv * G::RPP + rsub) * S + x0 + 4 * kk);
-		__syncthreads();                                             /* the halo is in place */
+			for (int j = 0; j < CQ_B; j++) w[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)((it0 + j) * 8 + wv * 2 + rsub) * S + 128 * part + 4 * kk);
+			if (it0 == 0) __syncthreads();                              /* the halo is in place */
 #pragma unroll
-		for (int j = 0; j < G::NB; j++) {
-			const int row = j * 4 * G::RPP + wv * G::RPP + rsub;
-			const uint32_t x = w[j];
-			uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-			uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-			const uint32_t hl = s_halo[row];
-			/* bytes 2, 3 of pv = the two cells on my left, byte 0 of nx = the cell on my right */
-			const uint32_t pv_edge = part ? hl << 16 : __builtin_amdgcn_perm(x, x, 0x01020000u);
-			const uint32_t nx_edge = part < G::NP - 1 ? (hl >> 16) & 255u : (x >> 16) & 255u;
-			pv = kk == 0 ? pv_edge : pv;
-			nx = kk == G::LPR - 1 ? nx_edge : nx;
-			uint32_t o0, o1;
-			if (XH == 0) {
-				o0 = __builtin_amdgcn_udot4(x, 0x00000206u, __builtin_amdgcn_udot4(pv, 0x02000000u, 0u, false), false) - __builtin_amdgcn_udot4(x, 0x00010000u, __builtin_amdgcn_udot4(pv, 0x00010000u, 0u, false), false);
-				o1 = __builtin_amdgcn_udot4(x, 0x02060200u, 0u, false) - __builtin_amdgcn_udot4(x, 0x00000001u, __builtin_amdgcn_udot4(nx, 0x00000001u, 0u, false), false);
-			} else {
-				o0 = __builtin_amdgcn_udot4(x, 0x00000200u, 0u, false) - __builtin_amdgcn_udot4(x, 0x00010001u, 0u, false);
-				o1 = __builtin_amdgcn_udot4(x, 0x02000000u, 0u, false) - __builtin_amdgcn_udot4(x, 0x00010000u, __builtin_amdgcn_udot4(nx, 0x00000001u, 0u, false), false);
+			for (int j = 0; j < CQ_B; j++) {
+				const int row = (it0 + j) * 8 + wv * 2 + rsub;
+				const uint32_t x = w[j];
+				uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+				uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+				const uint32_t hl = s_halo[row];
+				/* bytes 2, 3 of pv = the two cells on my left, byte 0 of nx = the cell on my right */
+				const uint32_t pv_edge = part ? hl << 16 : __builtin_amdgcn_perm(x, x, 0x01020000u);   /* mirror: x[-2] = x[2] (my byte 2), x[-1] = x[1] (my byte 1) */
+				const uint32_t nx_edge = part ? (x >> 16) & 255u : hl & 255u;                              /* mirror: x[256] = x[254] (my byte 2) */
+				pv = kk == 0 ? pv_edge : pv;
+				nx = kk == 31 ? nx_edge : nx;
+				uint32_t o0, o1;
+				if (XH == 0) {
+					o0 = __builtin_amdgcn_udot4(x, 0x00000206u, __builtin_amdgcn_udot4(pv, 0x02000000u, 0u, false), false) - __builtin_amdgcn_udot4(x, 0x00010000u, __builtin_amdgcn_udot4(pv, 0x00010000u, 0u, false), false);
+					o1 = __builtin_amdgcn_udot4(x, 0x02060200u, 0u, false) - __builtin_amdgcn_udot4(x, 0x00000001u, __builtin_amdgcn_udot4(nx, 0x00000001u, 0u, false), false);
+				} else {
+					o0 = __builtin_amdgcn_udot4(x, 0x00000200u, 0u, false) - __builtin_amdgcn_udot4(x, 0x00010001u, 0u, false);
+					o1 = __builtin_amdgcn_udot4(x, 0x02000000u, 0u, false) - __builtin_amdgcn_udot4(x, 0x00010000u, __builtin_amdgcn_udot4(nx, 0x00000001u, 0u, false), false);
+				}
+				*reinterpret_cast<uint32_t *>(A + CQ_ROW(row) + 2 * kk) = (o0 & 0xFFFFu) | (o1 << 16);
 			}
-			*reinterpret_cast<uint32_t *>(A + CQ_ROW(row) + 2 * kk) = (o0 & 0xFFFFu) | (o1 << 16);
 		}
 	};
 	if (xh == 0) first_dir(std::integral_constant<int, 0>()); else first_dir(std::integral_constant<int, 1>());
 	__syncthreads();
-	/* second direction down the part's columns, two at a time */
+	/* second direction down the quarter's columns, two at a time; a wavefront 16 columns */
 	const bool left = xh == 0;
-	const int cbase = HLF * xh + NQ * part;                            /* the part's first row of the coefficient plane */
-	for (int i = 0; i < NQ / 8; i++) {
-		const int c = wv * (NQ / 4) + 2 * i;
+	const int cbase = HLF * xh + 64 * part;                            /* the quarter's first row of the coefficient plane */
+	for (int i = 0; i < 8; i++) {
+		const int c = wv * 16 + 2 * i;
 		uint32_t Ew[PPL], Ow[PPL];
 		int lo[PPL][2], hi[PPL][2];
 #pragma unroll
@@ -590,14 +585,13 @@ __global__ __launch_bounds__(256) void k_chroma_l1q(const uint8_t *__restrict__ 
 	if (!left) return;
 	__syncthreads();
 	int16_t *save = saveb ? saveb + (size_t)img * save_plane : nullptr;
-	for (int v = t; v < HLF * (NQ / 2); v += 256) {                    /* LL copied back in natural orientation (wavelet_filterbank.c:172-184), and its copy */
-		const int k = v / (NQ / 2), c = 2 * (v % (NQ / 2));
+	for (int v = t; v < HLF * 32; v += 256) {                          /* LL copied back in natural orientation (wavelet_filterbank.c:172-184), and its copy */
+		const int k = v >> 5, c = 2 * (v & 31);
 		const uint32_t wd = *reinterpret_cast<const uint32_t *>(A + CQ_ROW(k) + c);
-		if (ll_to_jpeg) *reinterpret_cast<uint32_t *>(jpeg + (size_t)k * stride + NQ * part + c) = wd;
-		if (save) *reinterpret_cast<uint32_t *>(save + (size_t)k * save_row + NQ * part + c) = wd;
+		if (ll_to_jpeg) *reinterpret_cast<uint32_t *>(jpeg + (size_t)k * stride + 64 * part + c) = wd;
+		if (save) *reinterpret_cast<uint32_t *>(save + (size_t)k * save_row + 64 * part + c) = wd;
 	}
 }
-#undef CQ_ROW
 
 template <int S>
 __global__ __launch_bounds__(S * 4) void k_dwt_syn(int16_t *__restrict__ jpegb, int16_t *__restrict__ procb, size_t plane_stride, int stride, int n,
@@ -695,11 +689,8 @@ void nhw_launch_analysis(int16_t *jpeg, int16_t *proc, int n, size_t plane_strid
 {
 	if (!save) save_kind = 0;
 	static const int quarters = getenv("NHW_CHROMA_L1Q") ? atoi(getenv("NHW_CHROMA_L1Q")) : 1;
-	if (size == 256 && src8 && !final_level && drop_t && save_kind != 1 && !alt && stride == 256 && quarters) {   /* the encoder's chroma level 1 from the byte plane */
-		const int ll_jpeg = !(drop_t == 2 && save_kind == 2);
-		if (quarters == 2) k_chroma_l1q<32><<<8 * ((n + 7) & ~7), 256, 0, s>>>(src8, src8_plane, proc, jpeg, plane_stride, save_kind == 2 ? save : nullptr, save_plane, save_row, n, ll_jpeg);
-		else k_chroma_l1q<64><<<4 * ((n + 7) & ~7), 256, 0, s>>>(src8, src8_plane, proc, jpeg, plane_stride, save_kind == 2 ? save : nullptr, save_plane, save_row, n, ll_jpeg);
-	}
+	if (size == 256 && src8 && !final_level && drop_t && save_kind != 1 && !alt && stride == 256 && quarters)   /* the encoder's chroma level 1 from the byte plane */
+		k_chroma_l1q<<<4 * ((n + 7) & ~7), 256, 0, s>>>(src8, src8_plane, proc, jpeg, plane_stride, save_kind == 2 ? save : nullptr, save_plane, save_row, n, !(drop_t == 2 && save_kind == 2));
 	else if (size == 256) k_dwt_ana<256><<<n < DWT_WGS ? n : DWT_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, src8, src8_plane, drop_t, alt, alt_plane, alt_stride);
 	else if (size == 128) k_dwt_ana<128><<<n, 512, 128 * 130 * sizeof(int16_t), s>>>(jpeg, proc, plane_stride, stride, final_level, save, save_plane, save_row, save_kind, n, nullptr, 0, drop_t, alt, alt_plane, alt_stride);
 	else {   /* size 512 is the front kernels' (nhw_launch_front_fused); a caller with any other size would get stale planes: stop loudly */
