@@ -1555,6 +1555,168 @@ __global__ __launch_bounds__(1024) void k_dec_luma_l2(DecWs ws, int items, int u
 	}
 }
 
+/* The same three passes, a QUARTER of the block to a 256-thread workgroup (production; the debug stops keep k_dec_luma_l2): quarter p owns the
+ * 64 columns 64 p .. 64 p + 63 of the row pass's result = rows 64 p .. of the plane.  Its row pass reads, of every row, the low-band cells
+ * 32 p .. 32 p + 32 and the high-band cells 32 p - 1 .. 32 p + 32; the shrink before it looks one cell further: two windows of 36 cells a row
+ * (dword-aligned: block columns 32 p - 2 .. and 126 + 32 p ..), 38 KB of LDS, four workgroups a CU -- whose load, filter and store phases
+ * overlap where the 1024-thread block kernel's follow one another (0.71 ms for 1.3 GB).  Each quarter takes the shrink's decisions for the cells
+ * it reads (from the values as they were, all before any is applied), filters in place, adds the residuals whose plane row is its own and
+ * writes 64 whole rows of the plane.  Block b -> file ((b >> 5) << 3) | (b & 7), quarter (b >> 3) & 3 (a file's quarters on one XCD). */
+#define LQ_LS 74                      /* pitch of a row of the tile in shorts (37 dwords: column walks on 32 banks) */
+__global__ __launch_bounds__(256) void k_dec_luma_l2q(DecWs ws, int items)
+{
+	__shared__ __attribute__((aligned(16))) int16_t T[DH * LQ_LS];
+	constexpr int S = DH, HLF = S / 2;
+	const int b = blockIdx.x, img = ((b >> 5) << 3) | (b & 7), p = (b >> 3) & 3;
+	if (img >= items) return;
+	const DecMeta *m = ws.buf<DecMeta>(D_META, img);
+	if (m->status) return;
+	const int q = m->q;
+	int16_t *pl = plane_a(ws, img);
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const int a_lo = 32 * p - 2, a_hi = 126 + 32 * p;             /* the windows' first block columns */
+	{                                                                /* all of a thread's 36 loads in flight at once (a clamped address where the window leaves the block: no branch in front of a load) */
+		uint32_t v[36];
+#pragma unroll
+		for (int j = 0; j < 36; j++) {
+			const int idx = t + 256 * j, row = idx / 36, d = idx - row * 36;
+			const int col = d < 18 ? a_lo + 2 * d : a_hi + 2 * (d - 18);
+			const int cc = col < 0 ? 0 : col > S - 2 ? S - 2 : col;
+			v[j] = *reinterpret_cast<const uint32_t *>(pl + (size_t)row * DW + cc);
+		}
+#pragma unroll
+		for (int j = 0; j < 36; j++) {
+			const int idx = t + 256 * j, row = idx / 36, d = idx - row * 36;
+			const int col = d < 18 ? a_lo + 2 * d : a_hi + 2 * (d - 18);
+			reinterpret_cast<uint32_t *>(T)[row * (LQ_LS / 2) + d] = (col >= 0 && col < S) ? v[j] : 0u;
+		}
+	}
+	lds_barrier();
+	{
+		/* shrink (:670-721): a lane a ROW (row 64 wv + lane; the tile's pitch of 37 dwords puts 64 rows on different banks): it sorts its row's 72 cells
+		 * into "loud" masks (|v| > 8, > diag; a bit a cell of either window), takes the masks of the rows above and below from its neighbour lanes
+		 * (the wavefront's first and last row: from the next wavefront, through LDS), and the 3 x 3 rule is mask algebra in registers.  All masks are
+		 * made from the values as they were: nothing is applied before every wavefront has read its rows. */
+		__shared__ uint64_t s_edge[4][2][4];                           /* a wavefront's first / last row: m8[0], m8[1], md[0], md[1] */
+		const int diag = q <= 16 ? 16 : 8, r = 64 * wv + lane;
+		uint64_t ok[2], ll[2];                                       /* per window: cells with both neighbours in it and a block column 1 .. 254; cells of the LL2 quadrant's columns */
+		for (int w = 0; w < 2; w++) {
+			ok[w] = 0; ll[w] = 0;
+			for (int x = 1; x < 35; x++) { const int c = (w ? a_hi : a_lo) + x; if (c >= 1 && c <= S - 2) ok[w] |= 1ull << x; if (c < HLF) ll[w] |= 1ull << x; }
+		}
+		uint64_t m8[2] = { 0, 0 }, md[2] = { 0, 0 };
+		{
+			const uint32_t *rw = reinterpret_cast<const uint32_t *>(T) + r * (LQ_LS / 2);
+#pragma unroll
+			for (int d = 0; d < 36; d++) {
+				const uint32_t v = rw[d];
+				const int a0 = iabs((int)(int16_t)(v & 0xFFFFu)), a1 = iabs((int)(int16_t)(v >> 16));
+				const int w = d >= 18, x = 2 * (d - 18 * w);
+				m8[w] |= (uint64_t)(a0 > 8) << x | (uint64_t)(a1 > 8) << (x + 1);
+				md[w] |= (uint64_t)(a0 > diag) << x | (uint64_t)(a1 > diag) << (x + 1);
+			}
+		}
+		if (lane == 0 || lane == 63) { uint64_t *e = s_edge[wv][lane ? 1 : 0]; e[0] = m8[0]; e[1] = m8[1]; e[2] = md[0]; e[3] = md[1]; }
+		lds_barrier();
+		uint64_t h[2];
+		for (int w = 0; w < 2; w++) {
+			auto from = [&](uint64_t v, int dpp_up) -> uint64_t {       /* the value of the lane above (dpp_up) or below */
+				const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+				const uint32_t l2 = dpp_up ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x138, 0xF, 0xF, false) : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xF, 0xF, false);
+				const uint32_t h2 = dpp_up ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x138, 0xF, 0xF, false) : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x130, 0xF, 0xF, false);
+				return (uint64_t)l2 | ((uint64_t)h2 << 32);
+			};
+			uint64_t p8 = from(m8[w], 1), pd = from(md[w], 1), n8 = from(m8[w], 0), nd = from(md[w], 0);
+			if (lane == 0) { p8 = wv ? s_edge[wv - 1][1][w] : 0; pd = wv ? s_edge[wv - 1][1][2 + w] : 0; }
+			if (lane == 63) { n8 = wv < 3 ? s_edge[wv + 1][0][w] : 0; nd = wv < 3 ? s_edge[wv + 1][0][2 + w] : 0; }
+			const uint64_t c8 = m8[w];
+			uint64_t hh = c8 & ~((c8 << 1) | (c8 >> 1) | p8 | n8 | (pd << 1) | (pd >> 1) | (nd << 1) | (nd >> 1)) & ok[w];
+			if (r < HLF) hh &= ~ll[w];                               /* not the LL2 quadrant */
+			if (r < 1 || r > S - 2) hh = 0;
+			h[w] = hh;
+		}
+		for (int w = 0; w < 2; w++) {
+			uint64_t hb = h[w];
+			while (hb) {
+				const int bt = __builtin_ctzll(hb);
+				hb &= hb - 1;
+				int16_t *cell = T + r * LQ_LS + 36 * w + bt;
+				*cell = (int16_t)(*cell > 0 ? *cell - 1 : *cell + 1);
+			}
+		}
+		lds_barrier();
+	}
+	{                                                                /* along the rows, un-normalised: half a wavefront a row, a lane the outputs 2 k, 2 k + 1 of k = 32 p + (lane & 31) */
+		const int rsub = lane >> 5, kk = lane & 31, k = 32 * p + kk;
+#pragma unroll 2
+		for (int it = 0; it < 32; it++) {
+			int16_t *x = T + (it * 8 + wv * 2 + rsub) * LQ_LS;
+			const int l0 = x[kk + 2], ln = k + 1 < HLF ? x[kk + 3] : l0;
+			const int h0 = x[36 + kk + 2], hp = k > 0 ? x[36 + kk + 1] : h0, hn = k + 1 < HLF ? x[36 + kk + 3] : h0;
+			const int ev = (int16_t)((int16_t)(l0 << 3) - ((h0 + hp) << 1));
+			const int od = (int16_t)((int16_t)((l0 + ln) << 2) + (6 * h0 - hp - hn));
+			__builtin_amdgcn_wave_barrier();                          /* every lane of the row has read its taps */
+			reinterpret_cast<uint32_t *>(x)[kk] = (uint32_t)(uint16_t)ev | ((uint32_t)(uint16_t)od << 16);
+		}
+	}
+	lds_barrier();
+	for (int i = 0; i < 16; i++) {                                   /* along the columns, normalised, in place: sample 2k, 2k+1 of column j */
+		int16_t *x = T + wv * 16 + i;
+		int e[2], o[2];
+#pragma unroll
+		for (int u = 0; u < 2; u++) synth_pair<S>(x, LQ_LS, lane + 64 * u, true, e[u], o[u]);
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int u = 0; u < 2; u++) { const int k = lane + 64 * u; x[(2 * k) * LQ_LS] = (int16_t)e[u]; x[(2 * k + 1) * LQ_LS] = (int16_t)o[u]; }
+	}
+	lds_barrier();
+	{                                                                /* residual lists (:731-787): plane cell (row, col) sits at [col][row - 64 p]; a quarter takes the cells of its own plane rows */
+		const uint8_t *f = ws.blob + ws.blob_off[img];
+#define ACC(row, col, d) do { const int r_ = (row); if ((r_ >> 6) == p) add_i16_at(T, (col) * LQ_LS + (r_ & 63), (d)); } while (0)
+		/* a thread's entries of a list eight at a time: their loads (the entry, the byte its sign bits sit in) go out together, then the adds */
+		auto scan = [&](const uint16_t *pp, int cnt, const uint8_t *bits, int nbytes, int per_byte_shift, auto &&apply) {
+			for (int k0 = t; k0 < cnt; k0 += 256 * 8) {
+				int e[8], by[8];
+#pragma unroll
+				for (int j = 0; j < 8; j++) {
+					const int k = k0 + 256 * j, kc = k < cnt ? k : cnt - 1, bi = kc >> per_byte_shift;
+					e[j] = pp[kc]; by[j] = bi < nbytes ? bits[bi] : 0;
+				}
+#pragma unroll
+				for (int j = 0; j < 8; j++) { const int k = k0 + 256 * j; if (k < cnt) apply(k, e[j], by[j]); }
+			}
+		};
+		if (q >= 21) scan(ws.buf<uint16_t>(D_P5, img), (m->res5_bits - 1) * 8, f + m->o_res5_word, m->res5_bits, 3,
+		                  [&](int k, int ps, int byte) { ACC(ps >> 8, ps & 255, ((byte >> (7 - (k & 7))) & 1) ? -3 : 3); });
+		if (q > 12) {
+			const int amp = q >= 18 ? 5 : q >= 15 ? 7 : 9;
+			scan(ws.buf<uint16_t>(D_P1, img), (m->res1_bits - 1) * 8, f + m->o_res1_word, m->res1_bits, 3,
+			     [&](int k, int ps, int byte) { ACC(ps >> 8, ps & 255, ((byte >> (7 - (k & 7))) & 1) ? -amp : amp); });
+		}
+		if (q >= 19)
+			scan(ws.buf<uint16_t>(D_P3, img), (m->res3_bits * 2 - 2) * 4, f + m->o_res3_word, 1 << 30, 2,
+			     [&](int k, int ps, int byte) {
+				const int row = ps >> 8, col = ps & 255;
+				const int sel = (byte >> (6 - 2 * (k & 3))) & 3;
+				const int d0 = sel == 1 ? -4 : sel == 0 ? 4 : sel == 2 ? 2 : -2, d1 = sel == 1 ? -3 : sel == 0 ? 3 : sel == 2 ? 2 : -2, d2 = sel == 2 ? 2 : sel == 3 ? -2 : 0;
+				ACC(row, col, d0);
+				if (row + 1 < DH) ACC(row + 1, col, d1);                /* (rows 254 / 255 reach below the level-1 LL: dropped, see k_dec_luma_l2) */
+				if (d2 && row + 2 < DH) ACC(row + 2, col, d2);
+			     });
+#undef ACC
+	}
+	lds_barrier();
+	for (int i = 0; i < 16; i++) {                                   /* column j of the tile is row 64 p + j of the plane */
+		const int j = wv * 16 + i;
+		uint32_t *dst = reinterpret_cast<uint32_t *>(pl + (size_t)(64 * p + j) * DW);
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			const int k = lane + 64 * u;
+			dst[k] = (uint32_t)(uint16_t)T[(2 * k) * LQ_LS + j] | ((uint32_t)(uint16_t)T[(2 * k + 1) * LQ_LS + j] << 16);
+		}
+	}
+}
+
 /* ---------------------------------------------------------------------------------------------- a chroma plane up to its level-1 synthesis
  * One launch, one LDS residency of the 256 x 256 block per (file, component): the block is BUILT in LDS -- zeros, the component's entries of
  * the walk's value list (stream order -> cells: strips of 8 columns, serpentine, U on even and V on odd positions, nhw_decoder.c:904-932 /
@@ -2356,7 +2518,9 @@ extern "C" int nhw_dec_batch_device(nhw_dec *d, const void *d_nhw, const uint64_
 	{
 		/* level 2 of the luma: shrink, synthesis, residual lists on A's top-left 256 x 256 -> the level-1 LL in the same place */
 		const int upto = d->stop_after == 4 ? 1 : d->stop_after == 5 ? 2 : 3;
-		k_dec_luma_l2<<<n < SYNTH_WGS ? n : SYNTH_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(ws, n, upto);
+		static const int quarters = getenv("NHW_DEC_L2Q") ? atoi(getenv("NHW_DEC_L2Q")) : 1;
+		if (upto == 3 && quarters) k_dec_luma_l2q<<<4 * ((n + 7) & ~7), 256, 0, s>>>(ws, n);
+		else k_dec_luma_l2<<<n < SYNTH_WGS ? n : SYNTH_WGS, 1024, 256 * 258 * sizeof(int16_t), s>>>(ws, n, upto);
 	}
 	STAGE_END();                                                                  /* 4 (the block as the shrink leaves it) */
 	STAGE_END();                                                                  /* 5 (after the synthesis) */
