@@ -1112,11 +1112,12 @@ __global__ __launch_bounds__(MK_R) void k_low_marks(int16_t *__restrict__ yb, si
 				for (int e = 0; e < 16; e++) { f_lo |= (uint64_t)((w[e >> 2] >> (8 * (e & 3))) & 1) << (16 * d + e); f_hi |= (uint64_t)((w[e >> 2] >> (8 * (e & 3) + 1)) & 1) << (16 * d + e); }
 			}
 		if (in_pic) {
-			uint4 nx = *reinterpret_cast<const uint4 *>(kr + cb);                       /* the next eight cells are on their way while these are sorted */
-#pragma unroll 1
+			uint4 blk[8];                                                              /* the block's 64 cells: all eight loads go out together */
+#pragma unroll
+			for (int g = 0; g < 8; g++) blk[g] = *reinterpret_cast<const uint4 *>(kr + cb + 8 * g);
+#pragma unroll
 			for (int g = 0; g < 8; g++) {
-				const uint4 q4 = nx;
-				if (g < 7) nx = *reinterpret_cast<const uint4 *>(kr + cb + 8 * (g + 1));
+				const uint4 q4 = blk[g];
 				const uint32_t w4[4] = { q4.x, q4.y, q4.z, q4.w };
 #pragma unroll
 				for (int e = 0; e < 8; e++) {
