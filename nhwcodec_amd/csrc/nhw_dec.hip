@@ -1891,9 +1891,7 @@ __global__ __launch_bounds__(256) void k_dec_marks(DecWs ws)
 #pragma unroll
 		for (int e = 0; e < 3; e++) { v[2 * e] = (int16_t)(r.w[e] & 0xFFFFu); v[2 * e + 1] = (int16_t)(r.w[e] >> 16); }
 	};
-#ifndef MK_AHEAD
 #define MK_AHEAD 4
-#endif
 	int up[6], mid[6], dn[6];
 	{ const Row8 r0 = ld(0), r1 = ld(1); cells(r0, up); cells(r1, mid); }
 	Row8 fly[MK_AHEAD];
@@ -1975,9 +1973,7 @@ __global__ __launch_bounds__(256) void k_dec_sharpen(DecWs ws)
 	auto put = [&](int r, const int *v /* [4] */) {
 		*reinterpret_cast<uint32_t *>(out + (size_t)r * DH + 4 * lane) = (uint32_t)clip8(v[0]) | ((uint32_t)clip8(v[1]) << 8) | ((uint32_t)clip8(v[2]) << 16) | ((uint32_t)clip8(v[3]) << 24);
 	};
-#ifndef SH_AHEAD
 #define SH_AHEAD 4
-#endif
 	{ const uint2 r0 = ld(0), r1 = ld(1); spread(r0, up); spread(r1, cur); }
 	uint2 fly[SH_AHEAD];
 #pragma unroll

@@ -1,4 +1,4 @@
-# Developer tool (GPU box): the decode leg for variant builds (tools/dev/<name>.so), interleaved.  usage: VARIANTS="a b" bash tools/dev/dec_ab.sh
+# Developer tool (GPU box): the decode leg for variant builds (e.g. the row walks' prefetch depths: MK_AHEAD / SH_AHEAD in nhw_dec.hip, 2 / 4 / 8 measured: 4 stays) (tools/dev/<name>.so), interleaved.  usage: VARIANTS="a b" bash tools/dev/dec_ab.sh
 cd $GRAFT_REPO_ROOT; cp nhwcodec_amd/libnhwhip.so /tmp/orig.so
 for rep in 1 2; do for v in orig $VARIANTS; do
   if [ $v = orig ]; then cp /tmp/orig.so nhwcodec_amd/libnhwhip.so; else cp tools/dev/$v.so nhwcodec_amd/libnhwhip.so; fi
